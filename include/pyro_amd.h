@@ -1,0 +1,215 @@
+/*
+ * pyro_amd.h -- C-ABI of the MI355X (gfx950) numerics backend for Pyro's two
+ * data-parallel hot paths (SVI ELBO gradient under pyro.plate; HMC/NUTS leapfrog).
+ *
+ * Everything here is `extern "C"`, takes plain device pointers + sizes + a HIP
+ * stream handle (as void*), and has no torch / C++ types in any signature.
+ * All pointers are DEVICE pointers unless a parameter says "host".
+ * Every entry point returns PA_OK (0) or a negative error code; the message for
+ * the last error on the calling thread is available from pa_last_error().
+ * Argument errors are detected BEFORE any launch (reference convention: shape
+ * errors are Python exceptions raised before numerics run, trace_struct.py:228-235);
+ * numerical problems are NOT errors: NaN/inf propagate to the outputs
+ * (pyro/util.py:107-146 warn_if_nan; hmc.py:406-414 NaN -> divergence).
+ *
+ * Citations `path:line` are relative to the reference checkout of pyro-ppl/pyro 1.9.1;
+ * "torch:" citations point into the third-party PyTorch that implements the
+ * arithmetic of the reference's distributions.
+ */
+#ifndef PYRO_AMD_H
+#define PYRO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+
+enum { PA_OK = 0, PA_ERR_INVALID = -1, PA_ERR_UNSUPPORTED = -2, PA_ERR_LAUNCH = -3 };
+
+/* element types of floating-point buffers */
+enum { PA_F32 = 0, PA_F64 = 1 };
+
+/* distribution families of the element-wise site kernels.
+ * NORMAL(p0=loc,p1=scale)        torch: torch/distributions/normal.py:88-103
+ * BERNOULLI_LOGITS(p0=logits)    torch: torch/distributions/bernoulli.py:121-125
+ * HALF_CAUCHY(p0=scale)          torch: torch/distributions/half_cauchy.py:74-83
+ * LOG_NORMAL(p0=loc,p1=scale)    torch: torch/distributions/log_normal.py + transforms.ExpTransform
+ * EXPONENTIAL(p0=rate)           torch: torch/distributions/exponential.py
+ * HALF_NORMAL(p0=scale)          torch: torch/distributions/half_normal.py
+ */
+enum {
+  PA_DIST_NORMAL = 0,
+  PA_DIST_BERNOULLI_LOGITS = 1,
+  PA_DIST_HALF_CAUCHY = 2,
+  PA_DIST_LOG_NORMAL = 3,
+  PA_DIST_EXPONENTIAL = 4,
+  PA_DIST_HALF_NORMAL = 5,
+  PA_DIST_COUNT = 6
+};
+
+typedef void* pa_stream_t; /* hipStream_t; NULL = the null stream */
+
+/* A 2-D strided view [rows, cols]; strides in ELEMENTS, 0 = broadcast.
+ * This is how ExpandedDistribution's stride-0 views (torch_distribution.py:483-488)
+ * are handed over without materialising them. ptr may be NULL when unused. */
+typedef struct {
+  const void* ptr;
+  int64_t stride_row;
+  int64_t stride_col;
+} pa_view2d;
+
+int pa_abi_version(void);
+const char* pa_last_error(void);
+/* number of compute units of the current device (host-side query used for grid sizing) */
+int pa_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * RNG: counter-based Philox4x32-10. out[i] depends only on (seed, offset, i) so a draw
+ * is reproducible for any launch geometry and shardable across ranks by offset.
+ * Replaces the torch.normal()/_standard_normal draw inside rsample
+ * (torch: torch/distributions/normal.py:83-86; called from
+ * pyro/distributions/torch_distribution.py:48-52, pyro/poutine/runtime.py:345) and the
+ * momentum draw of HMC (pyro/infer/mcmc/hmc.py:231-248).
+ * f32: one Philox block -> 4 normals (2 Box-Muller pairs); f64: one block -> 2 normals.
+ * If offset_dev != NULL the 64-bit offset is read from device memory (graph-replay safe)
+ * and `offset` is added to it.
+ * ---------------------------------------------------------------------------------- */
+int pa_philox_normal(void* out, int64_t n, int dtype, uint64_t seed, uint64_t offset,
+                     const uint64_t* offset_dev, pa_stream_t stream);
+int pa_philox_uniform(void* out, int64_t n, int dtype, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_dev, pa_stream_t stream);
+/* *counter += inc, executed on the stream (keeps a device-resident Philox offset moving
+ * under hipGraph replay). */
+int pa_counter_add(uint64_t* counter, uint64_t inc, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Element-wise site kernels (SURVEY 8a rows a1,a3,a4,a5).
+ * ---------------------------------------------------------------------------------- */
+
+/* out[r,c] = log_prob(value[r,c]; p0[r,c], p1[r,c]); out is contiguous [rows, cols].
+ * == site["fn"].log_prob(site["value"]) (pyro/poutine/trace_struct.py:264). */
+int pa_dist_log_prob(int dist, int dtype, void* out, pa_view2d value, pa_view2d p0, pa_view2d p1,
+                     int64_t rows, int64_t cols, pa_stream_t stream);
+
+/* Fused log_prob -> scale_and_mask -> plate-dim sum (trace_struct.py:264-278,
+ * pyro/distributions/util.py:311-328):
+ *   out_rowsum[r] = sum_c  mask[r,c] ? scale * log_prob(...)[r,c] : 0
+ * mask.ptr == NULL means "no mask"; mask elements are uint8 (torch.bool).
+ * The reduction is deterministic (fixed two-stage tree, fp64 across threads).
+ * workspace: at least pa_dist_log_prob_sum_workspace(rows, cols) bytes. */
+size_t pa_dist_log_prob_sum_workspace(int64_t rows, int64_t cols);
+int pa_dist_log_prob_sum(int dist, int dtype, void* out_rowsum, pa_view2d value, pa_view2d p0,
+                         pa_view2d p1, pa_view2d mask, double scale, int64_t rows, int64_t cols,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream);
+
+/* Backward of both entry points above: given the upstream gradient g[r,c] (a strided view,
+ * so a per-row gradient is stride_col = 0) writes, for every non-NULL output,
+ *   d_x[r,c] = (mask ? scale : 0) * g[r,c] * d log_prob / d x   (x in value, p0, p1)
+ * as contiguous [rows, cols]. The autograd dual of trace_struct.py:264-278. */
+int pa_dist_log_prob_grad(int dist, int dtype, void* d_value, void* d_p0, void* d_p1, pa_view2d g,
+                          pa_view2d value, pa_view2d p0, pa_view2d p1, pa_view2d mask, double scale,
+                          int64_t rows, int64_t cols, pa_stream_t stream);
+
+/* Reparameterised Normal draw fused with the affine map (torch: normal.py:83-86):
+ *   eps[r,c] = Philox normal (as pa_philox_normal with i = r*cols + c),
+ *   out[r,c] = loc[r,c] + scale[r,c] * eps[r,c].
+ * eps_out (contiguous, may be NULL) receives eps for the backward pass. */
+int pa_normal_rsample(int dtype, void* out, void* eps_out, pa_view2d loc, pa_view2d scale,
+                      int64_t rows, int64_t cols, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_dev, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused plated Bernoulli-logits GLM likelihood: forward AND gradient in ONE pass over X.
+ * Replaces, for an observed site  obs ~ Bernoulli(logits = w @ X^T + b)  under
+ * pyro.plate("data", N) with P vectorised particles (pyro/infer/elbo.py:186-216):
+ *   matmul -> Bernoulli.log_prob (= -BCE-with-logits, torch: bernoulli.py:121-125)
+ *   -> scale_and_mask (pyro/distributions/util.py:311-328) -> .sum() (trace_struct.py:278)
+ *   and the autograd duals of all of them (pyro/infer/trace_elbo.py:153-157).
+ * Inputs : X[N,D] row-major f32, y[N] f32 (0/1), w[P,D] f32, b[P] f32 (NULL = 0),
+ *          mask[N] uint8 (NULL = all true), scale (plate size / subsample size).
+ * Outputs: ll[P]   = scale * sum_n mask_n (y_n l_pn - softplus(l_pn)),  l_pn = w_p.x_n + b_p
+ *          gw[P,D] = scale * sum_n mask_n (y_n - sigmoid(l_pn)) x_n     (= d ll / d w)
+ *          gb[P]   = scale * sum_n mask_n (y_n - sigmoid(l_pn))         (= d ll / d b)
+ * Deterministic reduction (per-block partials in workspace, fp64 finalize).
+ * Supported: f32, 1 <= D <= 128. Otherwise PA_ERR_UNSUPPORTED and the
+ * caller uses the unfused path (matmul + pa_dist_log_prob_sum).
+ * ---------------------------------------------------------------------------------- */
+size_t pa_glm_bernoulli_workspace(int64_t N, int64_t D, int64_t P);
+int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, const float* b,
+                             const uint8_t* mask, double scale, int64_t N, int64_t D, int64_t P,
+                             float* ll, float* gw, float* gb, void* workspace,
+                             size_t workspace_bytes, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * HMC / NUTS.
+ * ---------------------------------------------------------------------------------- */
+
+/* The two momentum/position updates of _single_step_verlet (pyro/ops/integrator.py:45-65)
+ * for C chains of dimension D, row-major [C,D]; step[c] is per-chain (step_stride 0/1):
+ *   pa_leapfrog_kick_drift : r <- r - 0.5*eps*grad ; z <- z + eps * (inv_mass (.) r)
+ *   pa_leapfrog_kick       : r <- r - 0.5*eps*grad
+ * inv_mass is diagonal, [D] (im_stride_row = 0) or per chain [C,D]
+ * (BlockMassMatrix.kinetic_grad, pyro/infer/mcmc/adaptation.py:328-347). */
+int pa_leapfrog_kick_drift(int dtype, void* z, void* r, const void* grad, const void* inv_mass,
+                           int64_t im_stride_row, const void* step, int64_t step_stride, int64_t C,
+                           int64_t D, pa_stream_t stream);
+int pa_leapfrog_kick(int dtype, void* r, const void* grad, const void* step, int64_t step_stride,
+                     int64_t C, int64_t D, pa_stream_t stream);
+
+/* One full NUTS transition (pyro/infer/mcmc/nuts.py:367-522, _build_tree :250-365,
+ * _build_basetree :197-248, _is_turning :184-195) for C independent chains on the
+ * closed-form potential U(z) = 0.5 z^T Lambda z (BASELINE config 3), one wavefront per
+ * chain, iterative tree doubling with wave-uniform control flow, all randomness from
+ * Philox keyed by (seed, chain, transition t, draw kind, tree position).
+ * State (in/out): z[C,D], pe[C] (potential energy at z), grad[C,D] (Lambda z).
+ * Params: Lambda[D,D] symmetric row-major; inv_mass[C,D] diagonal per chain;
+ *         step[C]; max_tree_depth <= 10; use_multinomial (1) or slice sampling (0).
+ * Outputs per chain: accept_prob[C] (= sum_accept_probs/num_proposals, nuts.py:510),
+ *         n_leapfrog[C] int32, depth[C] int32, diverging[C] int32, accepted[C] int32.
+ * Supported: D <= 128. */
+int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const void* Lambda,
+                                const void* inv_mass, const void* step, int64_t C, int64_t D,
+                                int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t,
+                                void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
+                                int32_t* diverging, int32_t* accepted, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under
+ * TraceEnum_ELBO:
+ *   out = sum_{d < B} sum_{w < Wd} logsumexp_t( log_theta[d,t] + log_phi[t, words[w,d]] )
+ * plus its gradient (the adjoint of pyro/ops/einsum/torch_log.py:14-55 and the plate
+ * products of pyro/ops/contract.py:79-160):
+ *   post[t | w,d] = softmax_t(...),  g_theta[d,t] = sum_w post,  g_phi[t,v] = sum_{w,d: words=v} post
+ * words: int64 [Wd,B] (layout of examples/lda.py: words plate dim -2, documents dim -1),
+ * log_theta: [B,T], log_phi: [T,V]. T <= 64.
+ * out_doc[B] receives the per-document sums (deterministic); g_phi is accumulated in
+ * per-workgroup LDS histograms (LDS float atomics: summation order within a workgroup is
+ * not fixed, so g_phi is reproducible to rounding, not bitwise) and reduced over workgroups
+ * by a finalize kernel through `workspace` (>= pa_lda_factor_workspace bytes).
+ * A word id outside [0,V) is a support violation: the result is unspecified but memory safe.
+ * ---------------------------------------------------------------------------------- */
+size_t pa_lda_factor_workspace(int dtype, int64_t B, int64_t T, int64_t V);
+int pa_lda_factor_fwd_bwd(int dtype, const int64_t* words, const void* log_theta,
+                          const void* log_phi, int64_t Wd, int64_t B, int64_t T, int64_t V,
+                          void* out_doc, void* g_theta, void* g_phi, void* workspace,
+                          size_t workspace_bytes, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Flat multi-tensor Adam / ClippedAdam step (pyro/optim/optim.py:117-155,
+ * pyro/optim/clipped_adam.py:52-100). One launch over the flat parameter buffer;
+ * `step_dev` is a device-resident step counter incremented by the kernel (graph safe).
+ * clipped = 0: torch.optim.Adam update; clipped = 1: ClippedAdam (element-wise gradient clamp
+ * to [-clip_norm, clip_norm], lr *= lrd every step, its own denominator form). */
+int pa_adam_step(int dtype, void* param, void* grad, void* exp_avg, void* exp_avg_sq, int64_t n,
+                 double lr, double beta1, double beta2, double eps, double weight_decay,
+                 double clip_norm, double lrd, int clipped, int64_t* step_dev, int zero_grad,
+                 pa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYRO_AMD_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libpyro_amd.so (C-ABI declared in include/pyro_amd.h).
+
+The library is loaded lazily on first use.  There is NO fallback: if the shared library
+is missing, or a tensor handed to a kernel wrapper does not live on a HIP device, a
+RuntimeError is raised -- the product path never silently runs on the CPU.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpyro_amd.so")
+
+PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_LAUNCH = 0, -1, -2, -3
+PA_F32, PA_F64 = 0, 1
+
+DIST_NORMAL = 0
+DIST_BERNOULLI_LOGITS = 1
+DIST_HALF_CAUCHY = 2
+DIST_LOG_NORMAL = 3
+DIST_EXPONENTIAL = 4
+DIST_HALF_NORMAL = 5
+
+
+class View2D(Structure):
+    _fields_ = [("ptr", c_void_p), ("stride_row", c_int64), ("stride_col", c_int64)]
+
+
+NULL_VIEW = View2D(None, 0, 0)
+
+
+class Unsupported(RuntimeError):
+    """Raised when a fused kernel does not cover the requested shape (PA_ERR_UNSUPPORTED)."""
+
+
+_SIGNATURES = {
+    "pa_abi_version": (c_int, []),
+    "pa_last_error": (c_char_p, []),
+    "pa_device_cu_count": (c_int, []),
+    "pa_philox_normal": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "pa_philox_uniform": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "pa_counter_add": (c_int, [c_void_p, c_uint64, c_void_p]),
+    "pa_dist_log_prob": (c_int, [c_int, c_int, c_void_p, View2D, View2D, View2D, c_int64, c_int64,
+                                 c_void_p]),
+    "pa_dist_log_prob_sum_workspace": (c_size_t, [c_int64, c_int64]),
+    "pa_dist_log_prob_sum": (c_int, [c_int, c_int, c_void_p, View2D, View2D, View2D, View2D,
+                                     c_double, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "pa_dist_log_prob_grad": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, View2D, View2D,
+                                      View2D, View2D, View2D, c_double, c_int64, c_int64,
+                                      c_void_p]),
+    "pa_normal_rsample": (c_int, [c_int, c_void_p, c_void_p, View2D, View2D, c_int64, c_int64,
+                                  c_uint64, c_uint64, c_void_p, c_void_p]),
+    "pa_glm_bernoulli_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_glm_bernoulli_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pa_leapfrog_kick_drift": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "pa_leapfrog_kick": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                 c_void_p]),
+    "pa_nuts_gaussian_transition": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                            c_uint64, c_uint64, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p]),
+    "pa_lda_factor_workspace": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
+    "pa_lda_factor_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                      c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    "pa_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
+                             c_double, c_double, c_double, c_double, c_double, c_double, c_int,
+                             c_void_p, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names of every entry point the binding expects (mirrors include/pyro_amd.h)."""
+    return sorted(_SIGNATURES)
+
+
+def load(path=None):
+    """Load the shared library (idempotent). Raises RuntimeError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("PYRO_AMD_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "pyro_amd: HIP extension %s not found. Build it with "
+            "`python -m pyro_amd.csrc.build` (hipcc --offload-arch=gfx950). There is no CPU "
+            "fallback." % path)
+    import torch  # noqa: F401  (loads libamdhip64.so.7 first so we share torch's HIP runtime)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> missing symbol, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pa_abi_version() != 1:
+        raise RuntimeError("pyro_amd: ABI version mismatch: %d" % lib.pa_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == PA_OK:
+        return
+    msg = load().pa_last_error().decode("utf-8", "replace")
+    if rc == PA_ERR_INVALID:
+        raise ValueError("pyro_amd: " + msg)
+    if rc == PA_ERR_UNSUPPORTED:
+        raise Unsupported("pyro_amd: " + msg)
+    raise RuntimeError("pyro_amd: kernel launch failed: " + msg)

@@ -1,0 +1,69 @@
+"""Build libpyro_amd.so (the C-ABI shared library declared in include/pyro_amd.h) in-tree.
+
+    python -m pyro_amd.csrc.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU present. The .so is written to
+pyro_amd/lib/libpyro_amd.so (git-ignored, but shipped to the GPU box by gpurun).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpyro_amd.so")
+OBJ_DIR = os.path.join(HERE, "build")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    hdrs.append(os.path.join(ROOT, "include", "pyro_amd.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force, hdr_mtime):
+    obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+    spath = os.path.join(HERE, src)
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) >= max(os.path.getmtime(spath), hdr_mtime)):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", spath, "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))
+    return obj, True
+
+
+def build_library(force=False, verbose=False):
+    if not os.path.exists(HIPCC):
+        if os.path.exists(LIB_PATH):
+            return LIB_PATH  # GPU box without a toolchain: use the shipped binary
+        raise RuntimeError("hipcc not found at %s and no prebuilt %s" % (HIPCC, LIB_PATH))
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdr_mtime = _deps_mtime()
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, hdr_mtime), sources()))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or force or not os.path.exists(LIB_PATH):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))
+        if verbose:
+            print("linked", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

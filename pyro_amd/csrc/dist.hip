@@ -1,0 +1,392 @@
+// dist.hip -- element-wise sample-site kernels: log_prob, fused log_prob+scale_and_mask+plate
+// sum, their gradient, and the reparameterised Normal draw.  
+//
+// All operands are 2-D strided views [rows, cols] (stride 0 = broadcast), so the stride-0
+// expanded parameters Pyro hands over (torch_distribution.py:483-488) are never materialised.
+// These kernels are HBM-bound: one read of each operand, one write (or none, for the fused
+// sum).  cols is the fast (coalesced) axis; every thread handles ITEMS columns 256 apart.
+#include "common.h"
+
+namespace pa {
+
+constexpr int DIST_THREADS = 256;
+constexpr int DIST_ITEMS = 4;
+
+template <typename T> struct Consts;
+template <> struct Consts<float> {
+  static constexpr float half_log_2pi = 0.91893853320467274178f;
+  static constexpr float log_2_over_pi = -0.45158270528945486473f;  // log(2) - log(pi)
+  static constexpr float log2 = 0.69314718055994530942f;
+};
+template <> struct Consts<double> {
+  static constexpr double half_log_2pi = 0.91893853320467274178;
+  static constexpr double log_2_over_pi = -0.45158270528945486473;
+  static constexpr double log2 = 0.69314718055994530942;
+};
+
+template <typename T> __device__ __forceinline__ T t_log(T x);
+template <> __device__ __forceinline__ float t_log(float x) { return logf(x); }
+template <> __device__ __forceinline__ double t_log(double x) { return log(x); }
+template <typename T> __device__ __forceinline__ T t_log1p(T x);
+template <> __device__ __forceinline__ float t_log1p(float x) { return log1pf(x); }
+template <> __device__ __forceinline__ double t_log1p(double x) { return log1p(x); }
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float t_exp(float x) { return expf(x); }
+template <> __device__ __forceinline__ double t_exp(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_abs(T x) { return x < T(0) ? -x : x; }
+template <typename T> __device__ __forceinline__ T t_inf();
+template <> __device__ __forceinline__ float t_inf() { return __builtin_huge_valf(); }
+template <> __device__ __forceinline__ double t_inf() { return __builtin_huge_val(); }
+
+// ---- per-family arithmetic ------------------------------------------------------------------
+// lp(v,a,b) and grad(v,a,b,&dv,&da,&db) = partial derivatives of lp.
+template <int DIST, typename T> struct Fam;
+
+template <typename T> struct Fam<PA_DIST_NORMAL, T> {  // a=loc b=scale; torch normal.py:88-103
+  static __device__ __forceinline__ T lp(T v, T a, T b) {
+    T d = v - a;
+    return -(d * d) / (T(2) * b * b) - t_log(b) - Consts<T>::half_log_2pi;
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T b, T& dv, T& da, T& db) {
+    T d = v - a, iv = T(1) / (b * b);
+    da = d * iv;
+    dv = -da;
+    db = d * d * iv / b - T(1) / b;
+  }
+};
+template <typename T> struct Fam<PA_DIST_BERNOULLI_LOGITS, T> {  // a=logits; bernoulli.py:121-125
+  static __device__ __forceinline__ T lp(T v, T a, T) {
+    // -BCEWithLogits(a, v) = v*a - softplus(a), softplus(a) = max(a,0) + log1p(exp(-|a|))
+    return v * a - ((a > T(0) ? a : T(0)) + t_log1p(t_exp(-t_abs(a))));
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T, T& dv, T& da, T& db) {
+    T e = t_exp(-t_abs(a));
+    T sig = a >= T(0) ? T(1) / (T(1) + e) : e / (T(1) + e);
+    da = v - sig;
+    dv = a;
+    db = T(0);
+  }
+};
+template <typename T> struct Fam<PA_DIST_HALF_CAUCHY, T> {  // a=scale; half_cauchy.py:74-83
+  static __device__ __forceinline__ T lp(T v, T a, T) {
+    T q = v / a;
+    T r = Consts<T>::log_2_over_pi - t_log(a) - t_log1p(q * q);
+    return v >= T(0) ? r : -t_inf<T>();
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T, T& dv, T& da, T& db) {
+    T den = a * a + v * v;
+    dv = -T(2) * v / den;
+    da = (v * v - a * a) / (a * den);
+    db = T(0);
+  }
+};
+template <typename T> struct Fam<PA_DIST_LOG_NORMAL, T> {  // Normal(a,b) pushed through exp
+  static __device__ __forceinline__ T lp(T v, T a, T b) {
+    T lv = t_log(v);
+    return Fam<PA_DIST_NORMAL, T>::lp(lv, a, b) - lv;
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T b, T& dv, T& da, T& db) {
+    T lv = t_log(v), dn;
+    Fam<PA_DIST_NORMAL, T>::grad(lv, a, b, dn, da, db);
+    dv = (dn - T(1)) / v;
+  }
+};
+template <typename T> struct Fam<PA_DIST_EXPONENTIAL, T> {  // a=rate
+  static __device__ __forceinline__ T lp(T v, T a, T) { return t_log(a) - a * v; }
+  static __device__ __forceinline__ void grad(T v, T a, T, T& dv, T& da, T& db) {
+    dv = -a;
+    da = T(1) / a - v;
+    db = T(0);
+  }
+};
+template <typename T> struct Fam<PA_DIST_HALF_NORMAL, T> {  // a=scale; half_normal.py
+  static __device__ __forceinline__ T lp(T v, T a, T) {
+    T r = Fam<PA_DIST_NORMAL, T>::lp(v, T(0), a) + Consts<T>::log2;
+    return v >= T(0) ? r : -t_inf<T>();
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T, T& dv, T& da, T& db) {
+    T d0;
+    Fam<PA_DIST_NORMAL, T>::grad(v, T(0), a, dv, d0, da);
+    db = T(0);
+  }
+};
+
+template <int DIST> struct NParams { static constexpr int n = 1; };
+template <> struct NParams<PA_DIST_NORMAL> { static constexpr int n = 2; };
+template <> struct NParams<PA_DIST_LOG_NORMAL> { static constexpr int n = 2; };
+
+// ---- kernels ----------------------------------------------------------------------------------
+template <int DIST, typename T>
+__global__ __launch_bounds__(DIST_THREADS) void log_prob_kernel(T* __restrict__ out, ViewT<T> v,
+                                                                ViewT<T> a, ViewT<T> b,
+                                                                int64_t rows, int64_t cols,
+                                                                int64_t bx) {
+  const int64_t row = blockIdx.x / bx, chunk = blockIdx.x % bx;
+  const int64_t c0 = chunk * (DIST_THREADS * DIST_ITEMS) + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < DIST_ITEMS; ++k) {
+    const int64_t c = c0 + k * DIST_THREADS;
+    if (c < cols) {
+      T bb = NParams<DIST>::n > 1 ? b.at(row, c) : T(0);
+      out[row * cols + c] = Fam<DIST, T>::lp(v.at(row, c), a.at(row, c), bb);
+    }
+  }
+}
+
+template <int DIST, typename T>
+__global__ __launch_bounds__(DIST_THREADS) void log_prob_sum_kernel(
+    double* __restrict__ partial, ViewT<T> v, ViewT<T> a, ViewT<T> b, ViewT<uint8_t> m, T scale,
+    int64_t rows, int64_t cols, int64_t bx, int64_t iters) {
+  __shared__ double smem[16];
+  const int64_t row = blockIdx.x / bx, chunk = blockIdx.x % bx;
+  T acc = T(0);
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t c0 = (it * bx + chunk) * (DIST_THREADS * DIST_ITEMS) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < DIST_ITEMS; ++k) {
+      const int64_t c = c0 + k * DIST_THREADS;
+      if (c < cols) {
+        T bb = NParams<DIST>::n > 1 ? b.at(row, c) : T(0);
+        T lp = Fam<DIST, T>::lp(v.at(row, c), a.at(row, c), bb) * scale;
+        // scale_and_mask (distributions/util.py:311-328): where(mask, tensor*scale, 0)
+        if (m.p != nullptr && m.at(row, c) == 0) lp = T(0);
+        acc += lp;
+      }
+    }
+  }
+  double t = block_sum_f64((double)acc, smem);
+  if (threadIdx.x == 0) partial[row * bx + chunk] = t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_finalize_kernel(T* __restrict__ out,
+                                                              const double* __restrict__ partial,
+                                                              int64_t rows, int64_t bx) {
+  // one wave per row; fixed lane->chunk assignment and butterfly order => deterministic
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  double t = 0.0;
+  for (int64_t i = lane; i < bx; i += 64) t += partial[row * bx + i];
+  t = wave_sum(t);
+  if (lane == 0) out[row] = (T)t;
+}
+
+template <int DIST, typename T>
+__global__ __launch_bounds__(DIST_THREADS) void log_prob_grad_kernel(
+    T* __restrict__ dv, T* __restrict__ da, T* __restrict__ db, ViewT<T> g, ViewT<T> v, ViewT<T> a,
+    ViewT<T> b, ViewT<uint8_t> m, T scale, int64_t rows, int64_t cols, int64_t bx) {
+  const int64_t row = blockIdx.x / bx, chunk = blockIdx.x % bx;
+  const int64_t c0 = chunk * (DIST_THREADS * DIST_ITEMS) + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < DIST_ITEMS; ++k) {
+    const int64_t c = c0 + k * DIST_THREADS;
+    if (c < cols) {
+      T bb = NParams<DIST>::n > 1 ? b.at(row, c) : T(0);
+      T gv, ga, gb;
+      Fam<DIST, T>::grad(v.at(row, c), a.at(row, c), bb, gv, ga, gb);
+      T w = g.at(row, c) * scale;
+      const bool keep = (m.p == nullptr) || (m.at(row, c) != 0);
+      const int64_t o = row * cols + c;
+      // masked-out elements get an exact 0 gradient (torch.where backward), even if the
+      // partial derivative itself is inf/NaN there.
+      if (dv) dv[o] = keep ? w * gv : T(0);
+      if (da) da[o] = keep ? w * ga : T(0);
+      if (db) db[o] = keep ? w * gb : T(0);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(DIST_THREADS) void normal_rsample_kernel(
+    T* __restrict__ out, T* __restrict__ eps_out, ViewT<T> loc, ViewT<T> scale, int64_t rows,
+    int64_t cols, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  if (offset_dev) offset += *offset_dev;
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i - r * cols;
+    T e;
+    if constexpr (sizeof(T) == 4)
+      e = philox_normal_f32(seed, offset, (uint64_t)i);
+    else
+      e = philox_normal_f64(seed, offset, (uint64_t)i);
+    if (eps_out) eps_out[i] = e;
+    out[i] = loc.at(r, c) + scale.at(r, c) * e;
+  }
+}
+
+// ---- host dispatch ----------------------------------------------------------------------------
+static int check_common(const char* who, int dist, int dtype, int64_t rows, int64_t cols) {
+  PA_REQUIRE(dist >= 0 && dist < PA_DIST_COUNT, "%s: unknown distribution id %d", who, dist);
+  PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "%s: bad dtype %d", who, dtype);
+  PA_REQUIRE(rows >= 0 && cols >= 0, "%s: negative shape [%lld,%lld]", who, (long long)rows,
+             (long long)cols);
+  PA_REQUIRE(rows < (int64_t(1) << 31) && cols < (int64_t(1) << 40), "%s: shape too large", who);
+  return PA_OK;
+}
+
+static inline int64_t chunks_of(int64_t cols) {
+  return (cols + DIST_THREADS * DIST_ITEMS - 1) / (DIST_THREADS * DIST_ITEMS);
+}
+
+// number of column-chunk blocks per row used by the fused sum (deterministic function of shape)
+static inline int64_t sum_bx(int64_t rows, int64_t cols) {
+  int64_t bx = chunks_of(cols);
+  int64_t cap = (int64_t)2048 / (rows > 0 ? rows : 1);
+  if (cap < 1) cap = 1;
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  return bx;
+}
+
+#define PA_DISPATCH_DIST(DIST_ID, T, CALL)                                              \
+  switch (DIST_ID) {                                                                    \
+    case PA_DIST_NORMAL: { constexpr int D_ = PA_DIST_NORMAL; CALL; } break;              \
+    case PA_DIST_BERNOULLI_LOGITS: { constexpr int D_ = PA_DIST_BERNOULLI_LOGITS; CALL; } break; \
+    case PA_DIST_HALF_CAUCHY: { constexpr int D_ = PA_DIST_HALF_CAUCHY; CALL; } break;    \
+    case PA_DIST_LOG_NORMAL: { constexpr int D_ = PA_DIST_LOG_NORMAL; CALL; } break;      \
+    case PA_DIST_EXPONENTIAL: { constexpr int D_ = PA_DIST_EXPONENTIAL; CALL; } break;    \
+    case PA_DIST_HALF_NORMAL: { constexpr int D_ = PA_DIST_HALF_NORMAL; CALL; } break;    \
+    default: return fail(PA_ERR_UNSUPPORTED, "distribution id %d not implemented", DIST_ID); \
+  }
+
+template <typename T>
+static int log_prob_t(int dist, T* out, pa_view2d value, pa_view2d p0, pa_view2d p1, int64_t rows,
+                      int64_t cols, hipStream_t s) {
+  const int64_t bx = chunks_of(cols);
+  PA_REQUIRE(rows * bx < (int64_t(1) << 31), "log_prob: grid too large");
+  auto v = as_view<T>(value), a = as_view<T>(p0), b = as_view<T>(p1);
+  PA_DISPATCH_DIST(dist, T,
+                   hipLaunchKernelGGL((log_prob_kernel<D_, T>), dim3((unsigned)(rows * bx)),
+                                      dim3(DIST_THREADS), 0, s, out, v, a, b, rows, cols, bx));
+  return check_launch("log_prob_kernel");
+}
+
+template <typename T>
+static int log_prob_sum_t(int dist, T* out, pa_view2d value, pa_view2d p0, pa_view2d p1,
+                          pa_view2d mask, double scale, int64_t rows, int64_t cols, double* ws,
+                          hipStream_t s) {
+  const int64_t bx = sum_bx(rows, cols);
+  const int64_t iters = (chunks_of(cols) + bx - 1) / bx;
+  PA_REQUIRE(rows * bx < (int64_t(1) << 31), "log_prob_sum: grid too large");
+  auto v = as_view<T>(value), a = as_view<T>(p0), b = as_view<T>(p1);
+  auto m = as_view<uint8_t>(mask);
+  PA_DISPATCH_DIST(dist, T,
+                   hipLaunchKernelGGL((log_prob_sum_kernel<D_, T>), dim3((unsigned)(rows * bx)),
+                                      dim3(DIST_THREADS), 0, s, ws, v, a, b, m, (T)scale, rows,
+                                      cols, bx, iters));
+  int rc = check_launch("log_prob_sum_kernel");
+  if (rc != PA_OK) return rc;
+  hipLaunchKernelGGL((rowsum_finalize_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     s, out, ws, rows, bx);
+  return check_launch("rowsum_finalize_kernel");
+}
+
+template <typename T>
+static int log_prob_grad_t(int dist, T* dv, T* da, T* db, pa_view2d g, pa_view2d value,
+                           pa_view2d p0, pa_view2d p1, pa_view2d mask, double scale, int64_t rows,
+                           int64_t cols, hipStream_t s) {
+  const int64_t bx = chunks_of(cols);
+  PA_REQUIRE(rows * bx < (int64_t(1) << 31), "log_prob_grad: grid too large");
+  auto gg = as_view<T>(g), v = as_view<T>(value), a = as_view<T>(p0), b = as_view<T>(p1);
+  auto m = as_view<uint8_t>(mask);
+  PA_DISPATCH_DIST(dist, T,
+                   hipLaunchKernelGGL((log_prob_grad_kernel<D_, T>), dim3((unsigned)(rows * bx)),
+                                      dim3(DIST_THREADS), 0, s, dv, da, db, gg, v, a, b, m,
+                                      (T)scale, rows, cols, bx));
+  return check_launch("log_prob_grad_kernel");
+}
+
+static int nparams(int dist) {
+  return (dist == PA_DIST_NORMAL || dist == PA_DIST_LOG_NORMAL) ? 2 : 1;
+}
+
+}  // namespace pa
+
+extern "C" {
+
+int pa_dist_log_prob(int dist, int dtype, void* out, pa_view2d value, pa_view2d p0, pa_view2d p1,
+                     int64_t rows, int64_t cols, pa_stream_t stream) {
+  int rc = pa::check_common("pa_dist_log_prob", dist, dtype, rows, cols);
+  if (rc != PA_OK) return rc;
+  if (rows == 0 || cols == 0) return PA_OK;
+  PA_REQUIRE(out && value.ptr && p0.ptr, "pa_dist_log_prob: NULL operand");
+  PA_REQUIRE(pa::nparams(dist) < 2 || p1.ptr, "pa_dist_log_prob: family needs p1");
+  if (dtype == PA_F32)
+    return pa::log_prob_t<float>(dist, (float*)out, value, p0, p1, rows, cols,
+                                 pa::as_stream(stream));
+  return pa::log_prob_t<double>(dist, (double*)out, value, p0, p1, rows, cols,
+                                pa::as_stream(stream));
+}
+
+size_t pa_dist_log_prob_sum_workspace(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return (size_t)(rows * pa::sum_bx(rows, cols)) * sizeof(double);
+}
+
+int pa_dist_log_prob_sum(int dist, int dtype, void* out_rowsum, pa_view2d value, pa_view2d p0,
+                         pa_view2d p1, pa_view2d mask, double scale, int64_t rows, int64_t cols,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  int rc = pa::check_common("pa_dist_log_prob_sum", dist, dtype, rows, cols);
+  if (rc != PA_OK) return rc;
+  if (rows == 0) return PA_OK;
+  PA_REQUIRE(out_rowsum, "pa_dist_log_prob_sum: NULL output");
+  if (cols == 0) {
+    // empty plate: the sum over nothing is 0 (torch: tensor.sum() of an empty tensor)
+    hipError_t e = hipMemsetAsync(out_rowsum, 0, (size_t)rows * (dtype == PA_F32 ? 4 : 8),
+                                  pa::as_stream(stream));
+    return e == hipSuccess ? PA_OK : pa::fail(PA_ERR_LAUNCH, "memset: %s", hipGetErrorString(e));
+  }
+  PA_REQUIRE(value.ptr && p0.ptr, "pa_dist_log_prob_sum: NULL operand");
+  PA_REQUIRE(pa::nparams(dist) < 2 || p1.ptr, "pa_dist_log_prob_sum: family needs p1");
+  PA_REQUIRE(workspace && workspace_bytes >= pa_dist_log_prob_sum_workspace(rows, cols),
+             "pa_dist_log_prob_sum: workspace too small (%zu < %zu)", workspace_bytes,
+             pa_dist_log_prob_sum_workspace(rows, cols));
+  if (dtype == PA_F32)
+    return pa::log_prob_sum_t<float>(dist, (float*)out_rowsum, value, p0, p1, mask, scale, rows,
+                                     cols, (double*)workspace, pa::as_stream(stream));
+  return pa::log_prob_sum_t<double>(dist, (double*)out_rowsum, value, p0, p1, mask, scale, rows,
+                                    cols, (double*)workspace, pa::as_stream(stream));
+}
+
+int pa_dist_log_prob_grad(int dist, int dtype, void* d_value, void* d_p0, void* d_p1, pa_view2d g,
+                          pa_view2d value, pa_view2d p0, pa_view2d p1, pa_view2d mask, double scale,
+                          int64_t rows, int64_t cols, pa_stream_t stream) {
+  int rc = pa::check_common("pa_dist_log_prob_grad", dist, dtype, rows, cols);
+  if (rc != PA_OK) return rc;
+  if (rows == 0 || cols == 0) return PA_OK;
+  PA_REQUIRE(g.ptr && value.ptr && p0.ptr, "pa_dist_log_prob_grad: NULL operand");
+  PA_REQUIRE(pa::nparams(dist) < 2 || p1.ptr, "pa_dist_log_prob_grad: family needs p1");
+  if (dtype == PA_F32)
+    return pa::log_prob_grad_t<float>(dist, (float*)d_value, (float*)d_p0, (float*)d_p1, g, value,
+                                      p0, p1, mask, scale, rows, cols, pa::as_stream(stream));
+  return pa::log_prob_grad_t<double>(dist, (double*)d_value, (double*)d_p0, (double*)d_p1, g, value,
+                                     p0, p1, mask, scale, rows, cols, pa::as_stream(stream));
+}
+
+int pa_normal_rsample(int dtype, void* out, void* eps_out, pa_view2d loc, pa_view2d scale,
+                      int64_t rows, int64_t cols, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_dev, pa_stream_t stream) {
+  PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "pa_normal_rsample: bad dtype %d", dtype);
+  PA_REQUIRE(rows >= 0 && cols >= 0, "pa_normal_rsample: negative shape");
+  const int64_t n = rows * cols;
+  if (n == 0) return PA_OK;
+  PA_REQUIRE(out && loc.ptr && scale.ptr, "pa_normal_rsample: NULL operand");
+  int64_t grid = (n + 255) / 256;
+  const int64_t cap = (int64_t)pa::cu_count() * 8;
+  if (grid > cap) grid = cap;
+  if (dtype == PA_F32)
+    hipLaunchKernelGGL((pa::normal_rsample_kernel<float>), dim3((unsigned)grid), dim3(256), 0,
+                       pa::as_stream(stream), (float*)out, (float*)eps_out,
+                       pa::as_view<float>(loc), pa::as_view<float>(scale), rows, cols, seed, offset,
+                       offset_dev);
+  else
+    hipLaunchKernelGGL((pa::normal_rsample_kernel<double>), dim3((unsigned)grid), dim3(256), 0,
+                       pa::as_stream(stream), (double*)out, (double*)eps_out,
+                       pa::as_view<double>(loc), pa::as_view<double>(scale), rows, cols, seed,
+                       offset, offset_dev);
+  return pa::check_launch("normal_rsample_kernel");
+}
+
+}  // extern "C"

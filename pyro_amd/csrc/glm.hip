@@ -1,0 +1,372 @@
+// glm.hip -- fused plated Bernoulli-logits GLM likelihood, forward + gradient in one pass.
+//
+// Reference path replaced (per ELBO-gradient step, P vectorised particles, plate size N):
+//   logits = w @ X^T + b                                  (user model, torch matmul)
+//   Bernoulli(logits).log_prob(y) = -BCEWithLogits        (torch: bernoulli.py:121-125)
+//   scale_and_mask, .sum()                                (pyro/poutine/trace_struct.py:264-278)
+//   backward of all three                                 (pyro/infer/trace_elbo.py:153-157)
+// which materialises [P,N] logits / log-probs / grads several times.  Here X and y are read
+// ONCE; nothing of size P*N ever reaches HBM.
+//
+// gfx950 mapping
+//   * one wavefront owns a 32-row tile of X staged (padded, stride odd => conflict-free
+//     ds_read_b32 in both access directions) in its private slice of LDS;
+//   * GEMM1  L[n,p] = sum_d X[n,d] W[p,d]   : v_mfma_f32_32x32x2_f32, A = X tile (LDS),
+//     B = W fragments held in VGPRs for the whole kernel;
+//   * the C/D register layout of that MFMA (col = lane&31 = p, row = n) is *already* the
+//     A-operand layout of GEMM2  gw[p,d] += sum_n G[p,n] X[n,d]  (k-pair {n, n+4} per
+//     accumulator register), so G = mask*(y - sigmoid(L)) never leaves registers;
+//   * exact f32 MFMA (no xf32/bf16 down-conversion: results are an fmaf chain, see
+//     MI355X guide "FP32-input MFMA"), softplus/sigmoid on the VALU overlap the MFMA pipe
+//     of the co-resident wave;
+//   * deterministic reduction: per-block partials -> fp64 finalize kernel (no float atomics).
+#include "common.h"
+
+namespace pa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GLM_WAVES = 4;  // waves per workgroup
+
+template <int DT>
+struct GlmCfg {
+  static constexpr int DP = 32 * DT;      // padded feature count
+  static constexpr int S = DP + 3;        // LDS row stride in floats (odd)
+  static constexpr int TILE_F = 32 * S;   // floats per wave tile
+};
+
+// floats in one block's partial record: raw MFMA accumulator tiles + ll + gb
+template <int DT, int PT>
+constexpr int glm_record_floats() { return PT * DT * 1024 + 2 * PT * 32; }
+
+template <int DT, int PT, bool VEC4>
+__global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
+    const float* __restrict__ X, const float* __restrict__ y, const float* __restrict__ w,
+    const float* __restrict__ b, const uint8_t* __restrict__ mask, int64_t N, int D, int P,
+    int64_t iters, float* __restrict__ part) {
+  using C = GlmCfg<DT>;
+  constexpr int DP = C::DP, S = C::S, TILE_F = C::TILE_F;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  float* Xs = lds + wave * TILE_F;
+
+  for (int i = threadIdx.x; i < GLM_WAVES * TILE_F; i += 64 * GLM_WAVES) lds[i] = 0.0f;
+
+  // ---- W fragments (B operand of GEMM1) and bias: registers for the whole kernel ----------
+  const int pbase = blockIdx.y * 32 * PT;
+  float wf[PT][DP / 2];
+  float bias[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int p = pbase + pt * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < DP / 2; ++kk) {
+      const int d = 2 * kk + h;
+      wf[pt][kk] = (p < P && d < D) ? w[(int64_t)p * D + d] : 0.0f;
+    }
+    bias[pt] = (p < P && b != nullptr) ? b[p] : 0.0f;
+  }
+
+  f32x16 gwacc[PT][DT];
+  float ll_acc[PT], gb_acc[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    ll_acc[pt] = 0.0f;
+    gb_acc[pt] = 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gwacc[pt][dt][r] = 0.0f;
+  }
+
+  // ---- staging registers: the next tile travels global -> VGPR while this one computes ----
+  constexpr int NLD = VEC4 ? 4 * DT : 16 * DT;  // loads per lane per tile
+  constexpr int EPL = VEC4 ? 4 : 1;             // floats per load
+  float stage[NLD * EPL];
+  float st_y = 0.0f, st_m = 0.0f;
+  const int step_e = 64 * EPL;                   // flat-element stride between a lane's loads
+  const int q0 = step_e / D, r0 = step_e % D;    // (row, col) increment per load
+  const int e0 = lane * EPL;
+  const int n_first = e0 / D, d_first = e0 % D;
+  const int64_t total_e = N * (int64_t)D;
+
+  auto issue_loads = [&](int64_t tile) {
+    const int64_t base = tile * 32 * (int64_t)D;  // flat offset of the tile's first element
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int64_t e = base + e0 + (int64_t)j * step_e;
+      const bool in_tile = (e0 + j * step_e) < 32 * D;
+      if (VEC4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_tile && e < total_e) v = *reinterpret_cast<const float4*>(X + e);
+        stage[4 * j + 0] = v.x; stage[4 * j + 1] = v.y;
+        stage[4 * j + 2] = v.z; stage[4 * j + 3] = v.w;
+      } else {
+        stage[j] = (in_tile && e < total_e) ? X[e] : 0.0f;
+      }
+    }
+    const int64_t n = tile * 32 + l31;
+    if (h == 0 && n < N) {
+      st_m = (mask == nullptr || mask[n] != 0) ? 1.0f : 0.0f;
+      st_y = y[n];
+    } else {
+      st_m = 0.0f;
+      st_y = 0.0f;
+    }
+  };
+  auto write_stage = [&]() {
+    int n = n_first, d = d_first;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      if (e0 + j * step_e < 32 * D) {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) Xs[n * S + d + k] = stage[EPL * j + k];
+      }
+      n += q0;
+      d += r0;
+      if (d >= D) { d -= D; n += 1; }
+    }
+    if (h == 0) {
+      // a masked-out row contributes exactly 0 even if its data are inf/NaN-free garbage:
+      // scale_and_mask is where(mask, x, 0) (pyro/distributions/util.py:326)
+      Xs[l31 * S + DP] = st_m * st_y;
+      Xs[l31 * S + DP + 1] = st_m;
+    }
+  };
+
+  const int64_t ntiles = (N + 31) / 32;
+  int64_t tile = (int64_t)blockIdx.x * GLM_WAVES + wave;
+  const int64_t tile_stride = (int64_t)gridDim.x * GLM_WAVES;
+
+  issue_loads(tile);
+  __syncthreads();  // LDS zero-fill complete
+  write_stage();
+  __syncthreads();
+
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t next = tile + tile_stride;
+    if (it + 1 < iters) issue_loads(next);
+
+    if (tile < ntiles) {
+      // ---- GEMM1: logits tile [32 n, 32 p] per particle tile --------------------------------
+      f32x16 acc[PT];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pt][r] = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < DP / 2; ++kk) {
+        const float a = Xs[l31 * S + 2 * kk + h];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[pt][kk], acc[pt], 0, 0, 0);
+      }
+      // ---- element-wise: log-likelihood and d/dlogit, in the accumulator layout ------------
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float my = Xs[nr * S + DP];
+        const float m = Xs[nr * S + DP + 1];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const float l = acc[pt][r] + bias[pt];
+          const float e = expf(-fabsf(l));
+          const float sp = fmaxf(l, 0.0f) + log1pf(e);   // softplus(l)
+          const float inv = 1.0f / (1.0f + e);
+          const float sig = l >= 0.0f ? inv : e * inv;    // sigmoid(l)
+          ll_acc[pt] += my * l - m * sp;
+          const float g = my - m * sig;
+          gb_acc[pt] += g;
+          acc[pt][r] = g;
+        }
+      }
+      // ---- GEMM2: gw[p,d] += G[p,n] X[n,d]; acc register r IS the A operand for k={nr,nr+4} --
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const float bf = Xs[nr * S + dt * 32 + l31];
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt)
+            gwacc[pt][dt] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(acc[pt][r], bf, gwacc[pt][dt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (it + 1 < iters) write_stage();
+    __syncthreads();
+    tile = next;
+  }
+
+  // ---- block reduction over the 4 waves in a fixed order, then one partial record ---------
+  constexpr int REC = glm_record_floats<DT, PT>();
+  static_assert(PT * DT * 1024 + 2 * PT * 64 <= GLM_WAVES * TILE_F, "LDS too small for epilogue");
+  float* red = lds;                       // [PT*DT*16][64] accumulator slots
+  float* red2 = lds + PT * DT * 1024;     // [2*PT][64] ll/gb per-lane slots
+  for (int wv = 0; wv < GLM_WAVES; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = ((pt * DT + dt) * 16 + r) * 64 + lane;
+            red[idx] = (wv == 0 ? 0.0f : red[idx]) + gwacc[pt][dt][r];
+          }
+        const int i0 = (2 * pt) * 64 + lane, i1 = (2 * pt + 1) * 64 + lane;
+        red2[i0] = (wv == 0 ? 0.0f : red2[i0]) + ll_acc[pt];
+        red2[i1] = (wv == 0 ? 0.0f : red2[i1]) + gb_acc[pt];
+      }
+    }
+    __syncthreads();
+  }
+  float* rec = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * REC;
+  for (int i = threadIdx.x; i < PT * DT * 1024; i += 64 * GLM_WAVES) rec[i] = red[i];
+  // fold the two lane halves (n and n+4 rows) of ll / gb: 32 values per particle tile
+  for (int i = threadIdx.x; i < 2 * PT * 32; i += 64 * GLM_WAVES) {
+    const int q = i >> 5, j = i & 31;
+    rec[PT * DT * 1024 + i] = red2[q * 64 + j] + red2[q * 64 + 32 + j];
+  }
+}
+
+// out[j] = scale * sum_blocks partial[block][slot(j)], fp64 accumulation, fixed order.
+// Output order: gw[P,D] then ll[P] then gb[P].
+template <int DT, int PT>
+__global__ __launch_bounds__(1024) void glm_finalize_kernel(const float* __restrict__ part,
+                                                            int nblocks, int npass, int D, int P,
+                                                            double scale, float* __restrict__ ll,
+                                                            float* __restrict__ gw,
+                                                            float* __restrict__ gb) {
+  constexpr int REC = glm_record_floats<DT, PT>();
+  __shared__ double sm[16][64];
+  const int jj = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int64_t J = (int64_t)P * D + 2 * P;
+  const int64_t j = (int64_t)blockIdx.x * 64 + jj;
+  double acc = 0.0;
+  if (j < J) {
+    int p, slot;
+    if (j < (int64_t)P * D) {
+      p = (int)(j / D);
+      const int d = (int)(j % D);
+      const int pl = p % (32 * PT), pt = pl >> 5, i = pl & 31, dt = d >> 5, c = d & 31;
+      const int hh = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
+      slot = ((pt * DT + dt) * 16 + reg) * 64 + c + 32 * hh;
+    } else {
+      const int64_t k = j - (int64_t)P * D;
+      const int which = k >= P ? 1 : 0;
+      p = (int)(k - (int64_t)which * P);
+      const int pl = p % (32 * PT), pt = pl >> 5, i = pl & 31;
+      slot = PT * DT * 1024 + (2 * pt + which) * 32 + i;
+    }
+    const int pass = p / (32 * PT);
+    const float* base = part + (int64_t)pass * nblocks * REC + slot;
+    for (int blk = s; blk < nblocks; blk += 16) acc += (double)base[(int64_t)blk * REC];
+  }
+  sm[s][jj] = acc;
+  __syncthreads();
+  if (s == 0 && j < J) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][jj];
+    const float v = (float)(t * scale);
+    if (j < (int64_t)P * D) gw[j] = v;
+    else if (j < (int64_t)P * D + P) ll[j - (int64_t)P * D] = v;
+    else gb[j - (int64_t)P * D - P] = v;
+  }
+}
+
+struct GlmPlan {
+  int DT, PT, npass, nblocks, rec;
+  int64_t iters;
+  size_t lds_bytes;
+};
+
+static GlmPlan glm_plan(int64_t N, int64_t D, int64_t P) {
+  GlmPlan pl;
+  pl.DT = D <= 32 ? 1 : (D <= 64 ? 2 : 4);
+  pl.PT = (pl.DT == 1 && P > 32) ? 2 : 1;
+  pl.npass = (int)((P + 32 * pl.PT - 1) / (32 * pl.PT));
+  const int64_t ntiles = (N + 31) / 32;
+  int64_t want = (ntiles + GLM_WAVES - 1) / GLM_WAVES;
+  int64_t cap = (int64_t)cu_count() * 2 / pl.npass;  // 2 workgroups (8 waves) per CU in flight
+  if (cap < 1) cap = 1;
+  pl.nblocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+  pl.iters = (ntiles + (int64_t)pl.nblocks * GLM_WAVES - 1) / ((int64_t)pl.nblocks * GLM_WAVES);
+  if (pl.iters < 1) pl.iters = 1;
+  pl.rec = pl.PT * pl.DT * 1024 + 2 * pl.PT * 32;
+  pl.lds_bytes = (size_t)GLM_WAVES * 32 * (32 * pl.DT + 3) * sizeof(float);
+  return pl;
+}
+
+template <int DT, int PT>
+static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const float* w,
+                      const float* b, const uint8_t* mask, double scale, int64_t N, int D, int P,
+                      float* ll, float* gw, float* gb, float* part, hipStream_t s) {
+  const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  dim3 grid((unsigned)pl.nblocks, (unsigned)pl.npass), block(64 * GLM_WAVES);
+  if (vec4) {
+    auto k = glm_bernoulli_kernel<DT, PT, true>;
+    if (pl.lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pl.lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, pl.lds_bytes, s, X, y, w, b, mask, N, D, P, pl.iters, part);
+  } else {
+    auto k = glm_bernoulli_kernel<DT, PT, false>;
+    if (pl.lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pl.lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, pl.lds_bytes, s, X, y, w, b, mask, N, D, P, pl.iters, part);
+  }
+  int rc = check_launch("glm_bernoulli_kernel");
+  if (rc != PA_OK) return rc;
+  const int64_t J = (int64_t)P * D + 2 * P;
+  hipLaunchKernelGGL((glm_finalize_kernel<DT, PT>), dim3((unsigned)((J + 63) / 64)), dim3(1024), 0,
+                     s, part, pl.nblocks, pl.npass, D, P, scale, ll, gw, gb);
+  return check_launch("glm_finalize_kernel");
+}
+
+}  // namespace pa
+
+extern "C" {
+
+size_t pa_glm_bernoulli_workspace(int64_t N, int64_t D, int64_t P) {
+  if (N < 0 || D < 1 || D > 128 || P < 1) return 0;
+  pa::GlmPlan pl = pa::glm_plan(N, D, P);
+  return (size_t)pl.nblocks * pl.npass * pl.rec * sizeof(float);
+}
+
+int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, const float* b,
+                             const uint8_t* mask, double scale, int64_t N, int64_t D, int64_t P,
+                             float* ll, float* gw, float* gb, void* workspace,
+                             size_t workspace_bytes, pa_stream_t stream) {
+  PA_REQUIRE(N >= 0 && D >= 1 && P >= 1, "glm_bernoulli: bad shape N=%lld D=%lld P=%lld",
+             (long long)N, (long long)D, (long long)P);
+  if (D > 128)
+    return pa::fail(PA_ERR_UNSUPPORTED, "glm_bernoulli: fused kernel supports D <= 128 (got %lld)",
+                    (long long)D);
+  PA_REQUIRE(N < (int64_t(1) << 40) && P < (1 << 20), "glm_bernoulli: shape too large");
+  PA_REQUIRE(w && ll && gw && gb, "glm_bernoulli: NULL parameter/output pointer");
+  PA_REQUIRE(N == 0 || (X && y), "glm_bernoulli: NULL data pointer");
+  PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_workspace(N, D, P),
+             "glm_bernoulli: workspace too small (%zu < %zu)", workspace_bytes,
+             pa_glm_bernoulli_workspace(N, D, P));
+  pa::GlmPlan pl = pa::glm_plan(N, D, P);
+  hipStream_t s = pa::as_stream(stream);
+  float* part = (float*)workspace;
+#define PA_GLM_CASE(DT_, PT_)                                                                    \
+  if (pl.DT == DT_ && pl.PT == PT_)                                                              \
+    return pa::glm_launch<DT_, PT_>(pl, X, y, w, b, mask, scale, N, (int)D, (int)P, ll, gw, gb,  \
+                                    part, s);
+  PA_GLM_CASE(1, 1)
+  PA_GLM_CASE(1, 2)
+  PA_GLM_CASE(2, 1)
+  PA_GLM_CASE(4, 1)
+#undef PA_GLM_CASE
+  return pa::fail(PA_ERR_UNSUPPORTED, "glm_bernoulli: no kernel for DT=%d PT=%d", pl.DT, pl.PT);
+}
+
+}  // extern "C"

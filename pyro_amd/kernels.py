@@ -1,0 +1,241 @@
+"""Torch-tensor wrappers over the C-ABI of libpyro_amd.so.
+
+Every function here hands raw device pointers of torch tensors to a HIP kernel on torch's
+current stream.  Tensors must live on a HIP device: there is no CPU implementation and no
+fallback (``_require_gpu`` raises).  PyTorch is used for device memory and streams only.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import NULL_VIEW, Unsupported, View2D, check  # noqa: F401
+
+_DTYPES = {torch.float32: _lib.PA_F32, torch.float64: _lib.PA_F64}
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "pyro_amd: kernel called with a tensor on %s; the HIP backend only runs on an "
+                "MI355X device and has no CPU fallback" % t.device)
+
+
+def _dtype(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise ValueError("pyro_amd: unsupported dtype %s (float32/float64 only)" % t.dtype)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _view(t, rows, cols):
+    """Describe tensor ``t`` (already broadcast-compatible with a logical [rows, cols]) as a
+    2-D strided view without materialising broadcasts."""
+    if t is None:
+        return NULL_VIEW
+    assert t.dim() == 2
+    sr = 0 if t.shape[0] == 1 and rows != 1 else t.stride(0)
+    sc = 0 if t.shape[1] == 1 and cols != 1 else t.stride(1)
+    if t.shape[0] == 1:
+        sr = 0
+    if t.shape[1] == 1:
+        sc = 0
+    return View2D(t.data_ptr(), sr, sc)
+
+
+# ------------------------------------------------------------------------------------------
+# RNG
+# ------------------------------------------------------------------------------------------
+
+def philox_normal(shape, dtype, device, seed, offset):
+    out = torch.empty(shape, dtype=dtype, device=device)
+    _require_gpu(out)
+    check(_lib.load().pa_philox_normal(_ptr(out), out.numel(), _dtype(out), seed, offset, None,
+                                       _stream()))
+    return out
+
+
+def philox_uniform(shape, dtype, device, seed, offset):
+    out = torch.empty(shape, dtype=dtype, device=device)
+    _require_gpu(out)
+    check(_lib.load().pa_philox_uniform(_ptr(out), out.numel(), _dtype(out), seed, offset, None,
+                                        _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# element-wise site kernels on a [rows, cols] broadcast frame
+# ------------------------------------------------------------------------------------------
+
+def dist_log_prob(dist_id, value, p0, p1, rows, cols):
+    """value/p0/p1: 2-D tensors broadcastable to [rows, cols]. Returns [rows, cols]."""
+    _require_gpu(value, p0, p1)
+    out = torch.empty((rows, cols), dtype=value.dtype, device=value.device)
+    check(_lib.load().pa_dist_log_prob(dist_id, _dtype(value), _ptr(out), _view(value, rows, cols),
+                                       _view(p0, rows, cols), _view(p1, rows, cols), rows, cols,
+                                       _stream()))
+    return out
+
+
+def dist_log_prob_sum(dist_id, value, p0, p1, mask, scale, rows, cols):
+    """Fused log_prob -> scale_and_mask -> sum over cols. Returns [rows]."""
+    _require_gpu(value, p0, p1, mask)
+    lib = _lib.load()
+    out = torch.empty((rows,), dtype=value.dtype, device=value.device)
+    nbytes = lib.pa_dist_log_prob_sum_workspace(rows, cols)
+    ws = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=value.device)
+    check(lib.pa_dist_log_prob_sum(dist_id, _dtype(value), _ptr(out), _view(value, rows, cols),
+                                   _view(p0, rows, cols), _view(p1, rows, cols),
+                                   _view(mask, rows, cols), float(scale), rows, cols, _ptr(ws),
+                                   ws.numel(), _stream()))
+    return out
+
+
+def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need):
+    """Gradients w.r.t. (value, p0, p1) as contiguous [rows, cols] (None where not needed)."""
+    _require_gpu(g, value, p0, p1, mask)
+    outs = [torch.empty((rows, cols), dtype=value.dtype, device=value.device) if n else None
+            for n in need]
+    check(_lib.load().pa_dist_log_prob_grad(
+        dist_id, _dtype(value), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _view(g, rows, cols),
+        _view(value, rows, cols), _view(p0, rows, cols), _view(p1, rows, cols),
+        _view(mask, rows, cols), float(scale), rows, cols, _stream()))
+    return outs
+
+
+def normal_rsample(loc, scale, rows, cols, seed, offset, want_eps=True):
+    _require_gpu(loc, scale)
+    out = torch.empty((rows, cols), dtype=loc.dtype, device=loc.device)
+    eps = torch.empty_like(out) if want_eps else None
+    check(_lib.load().pa_normal_rsample(_dtype(loc), _ptr(out), _ptr(eps), _view(loc, rows, cols),
+                                        _view(scale, rows, cols), rows, cols, seed, offset, None,
+                                        _stream()))
+    return out, eps
+
+
+# ------------------------------------------------------------------------------------------
+# fused Bernoulli-logits GLM
+# ------------------------------------------------------------------------------------------
+
+def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
+    """X[N,D], y[N], w[P,D], b[P] or None, mask[N] bool or None -> (ll[P], gw[P,D], gb[P])."""
+    _require_gpu(X, y, w, b, mask)
+    if X.dtype != torch.float32:
+        raise Unsupported("pyro_amd: fused GLM kernel is float32 only")
+    N, D = X.shape
+    P = w.shape[0]
+    assert X.is_contiguous() and y.is_contiguous() and w.is_contiguous()
+    assert y.shape == (N,) and w.shape == (P, D)
+    if b is not None:
+        assert b.is_contiguous() and b.shape == (P,)
+    if mask is not None:
+        assert mask.is_contiguous() and mask.shape == (N,) and mask.dtype in (torch.bool,
+                                                                             torch.uint8)
+    lib = _lib.load()
+    nbytes = lib.pa_glm_bernoulli_workspace(N, D, P)
+    if nbytes == 0:
+        raise Unsupported("pyro_amd: fused GLM kernel does not support N=%d D=%d P=%d" % (N, D, P))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
+    ll = torch.empty((P,), dtype=X.dtype, device=X.device)
+    gw = torch.empty((P, D), dtype=X.dtype, device=X.device)
+    gb = torch.empty((P,), dtype=X.dtype, device=X.device)
+    check(lib.pa_glm_bernoulli_fwd_bwd(_ptr(X), _ptr(y), _ptr(w), _ptr(b), _ptr(mask),
+                                       float(scale), N, D, P, _ptr(ll), _ptr(gw), _ptr(gb),
+                                       _ptr(ws), nbytes, _stream()))
+    return ll, gw, gb
+
+
+# ------------------------------------------------------------------------------------------
+# HMC / NUTS
+# ------------------------------------------------------------------------------------------
+
+def leapfrog_kick_drift(z, r, grad, inv_mass, step):
+    """In place: r -= 0.5*eps*grad; z += eps*inv_mass*r. z,r,grad: [C,D]; inv_mass [D] or [C,D];
+    step: [C] or 0-dim tensor."""
+    _require_gpu(z, r, grad, inv_mass, step)
+    C, D = z.shape
+    assert z.is_contiguous() and r.is_contiguous() and grad.is_contiguous()
+    assert inv_mass.is_contiguous() and step.is_contiguous()
+    im_stride = D if inv_mass.dim() == 2 else 0
+    st_stride = 1 if step.numel() == C and step.dim() == 1 and C > 1 else (1 if step.dim() == 1 and step.numel() == C else 0)
+    check(_lib.load().pa_leapfrog_kick_drift(_dtype(z), _ptr(z), _ptr(r), _ptr(grad),
+                                             _ptr(inv_mass), im_stride, _ptr(step), st_stride, C,
+                                             D, _stream()))
+
+
+def leapfrog_kick(r, grad, step):
+    _require_gpu(r, grad, step)
+    C, D = r.shape
+    assert r.is_contiguous() and grad.is_contiguous() and step.is_contiguous()
+    st_stride = 1 if step.dim() == 1 and step.numel() == C else 0
+    check(_lib.load().pa_leapfrog_kick(_dtype(r), _ptr(r), _ptr(grad), _ptr(step), st_stride, C,
+                                       D, _stream()))
+
+
+def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth, use_multinomial,
+                             seed, t):
+    """One NUTS transition for all chains, in place on (z, pe, grad).
+    Returns dict(accept_prob[C], n_leapfrog, depth, diverging, accepted: int32[C])."""
+    _require_gpu(z, pe, grad, Lambda, inv_mass, step)
+    C, D = z.shape
+    for x in (z, pe, grad, Lambda, inv_mass, step):
+        assert x.is_contiguous() and x.dtype == z.dtype
+    assert Lambda.shape == (D, D) and inv_mass.shape == (C, D) and step.shape == (C,)
+    ap = torch.empty((C,), dtype=z.dtype, device=z.device)
+    ints = torch.empty((4, C), dtype=torch.int32, device=z.device)
+    check(_lib.load().pa_nuts_gaussian_transition(
+        _dtype(z), _ptr(z), _ptr(pe), _ptr(grad), _ptr(Lambda), _ptr(inv_mass), _ptr(step), C, D,
+        int(max_tree_depth), int(bool(use_multinomial)), int(seed), int(t), _ptr(ap),
+        _ptr(ints[0]), _ptr(ints[1]), _ptr(ints[2]), _ptr(ints[3]), _stream()))
+    return {"accept_prob": ap, "n_leapfrog": ints[0], "depth": ints[1], "diverging": ints[2],
+            "accepted": ints[3]}
+
+
+# ------------------------------------------------------------------------------------------
+# enumerated LDA factor
+# ------------------------------------------------------------------------------------------
+
+def lda_factor_fwd_bwd(words, log_theta, log_phi):
+    """words int64 [Wd,B]; log_theta [B,T]; log_phi [T,V] -> (out_doc[B], g_theta[B,T], g_phi[T,V])"""
+    _require_gpu(words, log_theta, log_phi)
+    Wd, B = words.shape
+    T, V = log_phi.shape
+    assert words.dtype == torch.int64 and words.is_contiguous()
+    assert log_theta.shape == (B, T) and log_theta.is_contiguous() and log_phi.is_contiguous()
+    lib = _lib.load()
+    dt = _dtype(log_theta)
+    nbytes = lib.pa_lda_factor_workspace(dt, B, T, V)
+    ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=words.device)
+    out = torch.empty((B,), dtype=log_theta.dtype, device=words.device)
+    g_theta = torch.empty_like(log_theta)
+    g_phi = torch.empty_like(log_phi)
+    check(lib.pa_lda_factor_fwd_bwd(dt, _ptr(words), _ptr(log_theta), _ptr(log_phi), Wd, B, T, V,
+                                    _ptr(out), _ptr(g_theta), _ptr(g_phi), _ptr(ws), ws.numel(),
+                                    _stream()))
+    return out, g_theta, g_phi
+
+
+# ------------------------------------------------------------------------------------------
+# flat Adam
+# ------------------------------------------------------------------------------------------
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
+              weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True):
+    _require_gpu(param, grad, exp_avg, exp_avg_sq, step_dev)
+    assert step_dev.dtype == torch.int64 and step_dev.numel() == 1
+    for x in (param, grad, exp_avg, exp_avg_sq):
+        assert x.is_contiguous() and x.dtype == param.dtype and x.numel() == param.numel()
+    check(_lib.load().pa_adam_step(_dtype(param), _ptr(param), _ptr(grad), _ptr(exp_avg),
+                                   _ptr(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
+                                   float(betas[1]), float(eps), float(weight_decay),
+                                   float(clip_norm), float(lrd), int(bool(clipped)),
+                                   _ptr(step_dev), int(bool(zero_grad)), _stream()))

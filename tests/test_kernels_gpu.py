@@ -1,0 +1,385 @@
+"""Parity of every HIP kernel (called through the C-ABI) against the numpy oracle.
+
+Tolerances: integer work (Philox bits, enumerated indices) bit-exact; float32 kernels vs the
+float64 oracle rtol 2e-5 on reduced sums / 1e-5 element-wise; float64 kernels rtol 1e-11.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import adam as o_adam
+from oracle import dists as o_dists
+from oracle import glm as o_glm
+from oracle import integrator as o_int
+from oracle import lda as o_lda
+from oracle import nuts as o_nuts
+from oracle import philox as o_philox
+
+
+def _k():
+    from pyro_amd import kernels
+    return kernels
+
+
+def tt(a, dev, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    return t.to(dtype) if dtype is not None else t
+
+
+# ---------------------------------------------------------------------------------------------
+# RNG
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1000, 100003])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_philox_uniform_bit_exact(gpu, n, dtype):
+    k = _k()
+    out = k.philox_uniform((n,), dtype, gpu, seed=0x1234567890ABCDEF, offset=77).cpu().numpy()
+    ref = o_philox.uniform(n, out.dtype, 0x1234567890ABCDEF, 77)
+    assert np.array_equal(out, ref)  # uniforms are exact functions of the integer stream
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float64, 1e-13)])
+def test_philox_normal(gpu, dtype, tol):
+    k = _k()
+    n = 200001
+    out = k.philox_normal((n,), dtype, gpu, seed=42, offset=5).cpu().numpy()
+    ref = o_philox.normal(n, out.dtype, 42, 5)
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * 10)
+    assert abs(out.mean()) < 0.01 and abs(out.std() - 1) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------
+# element-wise site kernels
+# ---------------------------------------------------------------------------------------------
+def _dist_inputs(dist_id, rows, cols, rng, bcast):
+    shape_v = (rows, cols)
+    shape_a = (1, cols) if bcast == "row" else ((rows, 1) if bcast == "col" else (rows, cols))
+    if dist_id == 0:
+        return rng.standard_normal(shape_v), rng.standard_normal(shape_a), rng.uniform(0.5, 2, shape_a)
+    if dist_id == 1:
+        return (rng.uniform(size=shape_v) < 0.4).astype(float), 4 * rng.standard_normal(shape_a), None
+    if dist_id == 2:
+        return np.abs(rng.standard_cauchy(shape_v)), rng.uniform(0.5, 30, shape_a), None
+    if dist_id == 3:
+        return np.exp(rng.standard_normal(shape_v)), rng.standard_normal(shape_a), rng.uniform(0.5, 2, shape_a)
+    if dist_id == 4:
+        return rng.exponential(size=shape_v), rng.uniform(0.5, 2, shape_a), None
+    if dist_id == 5:
+        return np.abs(rng.standard_normal(shape_v)), rng.uniform(0.5, 2, shape_a), None
+
+
+@pytest.mark.parametrize("dist_id", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("rows,cols,bcast", [(1, 1, "none"), (3, 7, "none"), (5, 1031, "row"),
+                                             (7, 2500, "col"), (64, 4099, "none")])
+def test_dist_log_prob_sum_grad(gpu, dist_id, dtype, rows, cols, bcast):
+    k = _k()
+    rng = np.random.default_rng(dist_id * 100 + rows)
+    v, a, b = _dist_inputs(dist_id, rows, cols, rng, bcast)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    v, a = v.astype(np_dt), a.astype(np_dt)
+    b = b.astype(np_dt) if b is not None else None
+    tv, ta = tt(v, gpu), tt(a, gpu)
+    tb = tt(b, gpu) if b is not None else None
+    rtol = 3e-5 if dtype == torch.float32 else 1e-11
+    v64, a64 = v.astype(np.float64), a.astype(np.float64)
+    b64 = b.astype(np.float64) if b is not None else None
+
+    lp = k.dist_log_prob(dist_id, tv, ta, tb, rows, cols).cpu().numpy()
+    ref = np.broadcast_to(o_dists.LOG_PROB[dist_id](v64, a64, b64), (rows, cols))
+    np.testing.assert_allclose(lp, ref, rtol=rtol, atol=rtol)
+
+    mask = rng.uniform(size=(rows, cols)) < 0.7
+    for m, scale in [(None, 1.0), (mask, 2.5)]:
+        tm = tt(m, gpu) if m is not None else None
+        s = k.dist_log_prob_sum(dist_id, tv, ta, tb, tm, scale, rows, cols).cpu().numpy()
+        ref_s = o_dists.log_prob_sum(dist_id, v64, a64, b64, m, scale)
+        np.testing.assert_allclose(s, ref_s, rtol=rtol, atol=rtol * max(1.0, np.abs(ref_s).max()))
+        g_row = rng.standard_normal(rows).astype(np_dt)
+        tg = tt(g_row.reshape(rows, 1), gpu)
+        outs = k.dist_log_prob_grad(dist_id, tg, tv, ta, tb, tm, scale, rows, cols,
+                                    (True, True, b is not None))
+        refs = o_dists.log_prob_sum_grad(dist_id, g_row.astype(np.float64), v64, a64, b64, m, scale)
+        for o, r in zip(outs, refs):
+            if o is not None:
+                r = np.broadcast_to(r, (rows, cols))
+                np.testing.assert_allclose(o.cpu().numpy(), r, rtol=rtol * 3,
+                                           atol=rtol * 3 * max(1.0, np.abs(r).max()))
+
+
+def test_dist_empty_and_errors(gpu):
+    k = _k()
+    v = torch.zeros((4, 0), device=gpu)
+    s = k.dist_log_prob_sum(0, v, v, v, None, 1.0, 4, 0)
+    assert s.shape == (4,) and float(s.abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        k.dist_log_prob(99, torch.zeros((1, 1), device=gpu), torch.zeros((1, 1), device=gpu), None, 1, 1)
+    with pytest.raises(RuntimeError):
+        k.dist_log_prob(0, torch.zeros((1, 1)), torch.zeros((1, 1)), torch.ones((1, 1)), 1, 1)
+
+
+def test_half_cauchy_negative_support(gpu):
+    k = _k()
+    v = torch.tensor([[-1.0, 0.0, 2.0]], device=gpu)
+    a = torch.tensor([[3.0]], device=gpu)
+    lp = k.dist_log_prob(2, v, a, None, 1, 3).cpu().numpy()[0]
+    assert lp[0] == -np.inf and np.isfinite(lp[1:]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_normal_rsample(gpu, dtype):
+    k = _k()
+    rows, cols = 17, 33
+    rng = np.random.default_rng(1)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    loc = rng.standard_normal((1, cols)).astype(np_dt)
+    scale = rng.uniform(0.1, 2, (1, cols)).astype(np_dt)
+    out, eps = k.normal_rsample(tt(loc, gpu), tt(scale, gpu), rows, cols, seed=9, offset=1000)
+    ref_eps = o_philox.normal(rows * cols, np_dt, 9, 1000).reshape(rows, cols)
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    np.testing.assert_allclose(eps.cpu().numpy(), ref_eps, rtol=tol, atol=10 * tol)
+    np.testing.assert_allclose(out.cpu().numpy(), loc + scale * ref_eps, rtol=10 * tol, atol=10 * tol)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused Bernoulli GLM
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,D,P", [(1, 1, 1), (31, 3, 2), (32, 32, 64), (33, 32, 64), (1000, 32, 64),
+                                   (4099, 8, 5), (2048, 32, 33), (5000, 20, 100), (3000, 64, 40),
+                                   (1500, 48, 7), (1200, 128, 12), (700, 100, 3), (0, 4, 2)])
+@pytest.mark.parametrize("use_mask,use_bias", [(False, True), (True, False)])
+def test_glm_bernoulli(gpu, N, D, P, use_mask, use_bias):
+    k = _k()
+    rng = np.random.default_rng(N + D + P)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (rng.standard_normal((P, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32) if use_bias else None
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    mask = (rng.uniform(size=N) < 0.8) if use_mask else None
+    scale = 3.0
+    ll, gw, gb = k.glm_bernoulli_fwd_bwd(tt(X, gpu), tt(y, gpu), tt(w, gpu),
+                                         tt(b, gpu) if b is not None else None,
+                                         tt(mask, gpu) if mask is not None else None, scale)
+    rll, rgw, rgb = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale)
+    sc = max(1.0, float(np.abs(rll).max()) if N else 1.0)
+    np.testing.assert_allclose(ll.cpu().numpy(), rll, rtol=2e-5, atol=2e-5 * sc)
+    np.testing.assert_allclose(gb.cpu().numpy(), rgb, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
+    np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
+
+
+def test_glm_bernoulli_transpose_detecting(gpu):
+    """Asymmetric inputs: a swapped (p,d) or (n,p) mapping cannot pass."""
+    k = _k()
+    N, D, P = 96, 32, 64
+    X = np.zeros((N, D), np.float32)
+    for n in range(N):
+        X[n, (7 * n) % D] = 1.0 + n / N
+    w = np.arange(P * D, dtype=np.float32).reshape(P, D) / (P * D) - 0.3
+    y = (np.arange(N) % 3 == 0).astype(np.float32)
+    ll, gw, gb = k.glm_bernoulli_fwd_bwd(tt(X, gpu), tt(y, gpu), tt(w, gpu), None, None, 1.0)
+    rll, rgw, rgb = o_glm.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
+    np.testing.assert_allclose(ll.cpu().numpy(), rll, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gb.cpu().numpy(), rgb, rtol=1e-5, atol=1e-5)
+
+
+def test_glm_bernoulli_deterministic_and_linear(gpu):
+    """Full-size properties (BASELINE N=1e6, D=32, P=64): bitwise run-to-run determinism, and
+    additivity over a split of the plate (sum of two half-plates == whole plate)."""
+    k = _k()
+    N, D, P = 1_000_000, 32, 64
+    g = torch.Generator(device=gpu).manual_seed(0)
+    X = torch.randn((N, D), device=gpu, generator=g)
+    w = torch.randn((P, D), device=gpu, generator=g) * 0.2
+    b = torch.randn((P,), device=gpu, generator=g)
+    y = (torch.rand((N,), device=gpu, generator=g) < 0.5).float()
+    a1 = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    a2 = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    for u, v in zip(a1, a2):
+        assert torch.equal(u, v)
+    h = N // 2 + 13
+    p1 = k.glm_bernoulli_fwd_bwd(X[:h].contiguous(), y[:h].contiguous(), w, b, None, 1.0)
+    p2 = k.glm_bernoulli_fwd_bwd(X[h:].contiguous(), y[h:].contiguous(), w, b, None, 1.0)
+    for whole, u, v in zip(a1, p1, p2):
+        torch.testing.assert_close(whole, u + v, rtol=2e-5, atol=2e-2)
+    # against torch fp64 on the same device (independent arithmetic) at full size
+    logits = (w.double() @ X.double().T) + b.double()[:, None]
+    ll_ref = (y.double() * logits - torch.nn.functional.softplus(logits)).sum(1)
+    torch.testing.assert_close(a1[0].double(), ll_ref, rtol=2e-5, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# leapfrog
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_leapfrog_matches_oracle(gpu, dtype):
+    k = _k()
+    C, D = 37, 100
+    rng = np.random.default_rng(3)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    A = rng.standard_normal((D, D))
+    Lam = np.linalg.inv(A @ A.T / D + 0.1 * np.eye(D))
+    z = rng.standard_normal((C, D)).astype(np_dt)
+    r = rng.standard_normal((C, D)).astype(np_dt)
+    im = rng.uniform(0.5, 2, (C, D)).astype(np_dt)
+    step = rng.uniform(0.01, 0.2, C).astype(np_dt)
+    tz, tr, tim, tstep = tt(z, gpu), tt(r, gpu), tt(im, gpu), tt(step, gpu)
+    tL = tt(Lam.astype(np_dt), gpu)
+    tg = tz @ tL
+    nsteps = 5
+    for _ in range(nsteps):
+        k.leapfrog_kick_drift(tz, tr, tg, tim, tstep)
+        tg = tz @ tL
+        k.leapfrog_kick(tr, tg, tstep)
+    pg = o_int.gaussian_potential(Lam)
+    tol = 2e-4 if dtype == torch.float32 else 1e-10
+    for c in range(0, C, 9):
+        zz, rr, _, _ = o_int.velocity_verlet(z[c].astype(np.float64), r[c].astype(np.float64), pg,
+                                             im[c].astype(np.float64), float(step[c]), nsteps)
+        np.testing.assert_allclose(tz[c].cpu().numpy(), zz, rtol=tol, atol=tol)
+        np.testing.assert_allclose(tr[c].cpu().numpy(), rr, rtol=tol, atol=tol)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused NUTS transition on the Gaussian potential
+# ---------------------------------------------------------------------------------------------
+def _gauss_problem(D, seed=0):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((D, D))
+    Sigma = A @ A.T / D + 0.1 * np.eye(D)
+    Lam = np.linalg.inv(Sigma)
+    return Sigma, 0.5 * (Lam + Lam.T)
+
+
+@pytest.mark.parametrize("D,multinomial", [(5, True), (100, True), (70, False), (128, True)])
+def test_nuts_gaussian_f64_matches_recursive_oracle(gpu, D, multinomial):
+    """float64: the iterative one-wave-per-chain kernel must reproduce the recursive reference
+    formulation chain by chain (identical tree sizes / accept decisions, positions to 1e-9)."""
+    k = _k()
+    C, T_ = 24, 4
+    _, Lam = _gauss_problem(D)
+    rng = np.random.default_rng(5)
+    z0 = rng.standard_normal((C, D)) * 0.5
+    im = rng.uniform(0.5, 1.5, (C, D))
+    step = rng.uniform(0.05, 0.4, C)
+    seed = 2024
+    tz = tt(z0, gpu)
+    tL = tt(Lam, gpu)
+    tg = (tz @ tL).contiguous()
+    tpe = (0.5 * (tz * tg).sum(1)).contiguous()
+    tim, tstep = tt(im, gpu), tt(step, gpu)
+    pg = o_int.gaussian_potential(Lam)
+    zs = [z0[c].copy() for c in range(C)]
+    st = [pg(zs[c]) for c in range(C)]
+    for t in range(T_):
+        out = k.nuts_gaussian_transition(tz, tpe, tg, tL, tim, tstep, 8, multinomial, seed, t)
+        nl = out["n_leapfrog"].cpu().numpy()
+        dp = out["depth"].cpu().numpy()
+        ac = out["accepted"].cpu().numpy()
+        dv = out["diverging"].cpu().numpy()
+        ap = out["accept_prob"].cpu().numpy()
+        for c in range(C):
+            ref = o_nuts.nuts_transition(zs[c], st[c][0], st[c][1], pg, im[c], step[c],
+                                         o_nuts.KeyedDraws(seed, c, t, np.float64), 8, multinomial)
+            assert nl[c] == ref["n_leapfrog"], (t, c)
+            assert dp[c] == ref["depth"] and bool(ac[c]) == ref["accepted"]
+            assert bool(dv[c]) == ref["diverging"]
+            np.testing.assert_allclose(ap[c], ref["accept_prob"], rtol=1e-9)
+            np.testing.assert_allclose(tz[c].cpu().numpy(), ref["z"], rtol=1e-9, atol=1e-9)
+            zs[c] = ref["z"]
+            st[c] = (ref["pe"], ref["grad"])
+        np.testing.assert_allclose(tpe.cpu().numpy(), [s[0] for s in st], rtol=1e-9, atol=1e-9)
+
+
+def test_nuts_gaussian_f32_statistics(gpu):
+    """float32, config-3 size (1024 chains x 100 dims): after a short run from N(0,I) starts with a
+    fixed step size the pooled sample covariance matches Sigma (statistical parity)."""
+    k = _k()
+    C, D = 1024, 100
+    Sigma, Lam = _gauss_problem(D)
+    tz = torch.zeros((C, D), device=gpu)
+    tL = tt(Lam.astype(np.float32), gpu)
+    tg = (tz @ tL).contiguous()
+    tpe = torch.zeros((C,), device=gpu)
+    tim = torch.ones((C, D), device=gpu)
+    tstep = torch.full((C,), 0.12, device=gpu)
+    acc, tot = [], 0
+    for t in range(60):
+        out = k.nuts_gaussian_transition(tz, tpe, tg, tL, tim, tstep, 10, True, 11, t)
+        tot += int(out["n_leapfrog"].sum())
+        if t >= 30:
+            acc.append(tz.cpu().numpy().copy())
+    samples = np.concatenate(acc, 0)
+    cov = np.cov(samples.T)
+    assert float(out["accept_prob"].mean()) > 0.6
+    assert np.abs(samples.mean(0)).max() < 0.1 * np.sqrt(np.diag(Sigma)).max() + 0.05
+    rel = np.abs(np.diag(cov) - np.diag(Sigma)) / np.diag(Sigma)
+    assert rel.max() < 0.15, rel.max()
+    assert tot > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# LDA enumerated factor
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("Wd,B,T,V", [(8, 100, 8, 100), (64, 1000, 8, 1024), (3, 1, 5, 7),
+                                      (16, 300, 20, 50), (0, 10, 4, 6)])
+def test_lda_factor(gpu, dtype, Wd, B, T, V):
+    k = _k()
+    rng = np.random.default_rng(Wd + B)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    words = rng.integers(0, V, (Wd, B))
+    theta = rng.dirichlet(np.ones(T) * 0.5, B)
+    phi = rng.dirichlet(np.ones(V) * 0.1, T)
+    lt = np.log(theta).astype(np_dt)
+    lp = np.log(np.maximum(phi, 1e-30)).astype(np_dt)
+    out, gt, gp = k.lda_factor_fwd_bwd(tt(words, gpu), tt(lt, gpu), tt(lp, gpu))
+    r_out, r_gt, r_gp = o_lda.lda_factor(words, lt, lp)
+    rtol = 3e-5 if dtype == torch.float32 else 1e-11
+    np.testing.assert_allclose(out.cpu().numpy(), r_out, rtol=rtol, atol=rtol * 10)
+    np.testing.assert_allclose(gt.cpu().numpy(), r_gt, rtol=rtol, atol=rtol * max(Wd, 1))
+    np.testing.assert_allclose(gp.cpu().numpy(), r_gp, rtol=rtol * 4, atol=rtol * max(Wd * B / V, 1) * 4)
+    # posterior responsibilities sum to one per word: sum of g_theta rows == Wd (size-free property)
+    np.testing.assert_allclose(gt.sum(1).cpu().numpy(), np.full(B, Wd), rtol=1e-5)
+
+
+def test_lda_factor_minus_inf_column(gpu):
+    k = _k()
+    lt = torch.log(torch.tensor([[1.0, 0.0], [0.5, 0.5]], device=gpu, dtype=torch.float64))
+    lp = torch.log(torch.tensor([[0.5, 0.5, 0.0], [0.2, 0.3, 0.5]], device=gpu, dtype=torch.float64))
+    words = torch.tensor([[0, 2], [2, 1]], device=gpu)
+    out, gt, gp = k.lda_factor_fwd_bwd(words, lt, lp)
+    r_out, r_gt, r_gp = o_lda.lda_factor(words.cpu().numpy(), lt.cpu().numpy(), lp.cpu().numpy())
+    np.testing.assert_allclose(out.cpu().numpy(), r_out)   # includes a -inf document
+    assert not torch.isnan(gt).any() and not torch.isnan(gp).any()
+
+
+# ---------------------------------------------------------------------------------------------
+# Adam
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("clipped", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_adam_step(gpu, clipped, dtype):
+    k = _k()
+    n = 1000
+    rng = np.random.default_rng(0)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    p = rng.standard_normal(n).astype(np_dt)
+    m = np.zeros(n)
+    v = np.zeros(n)
+    tp, tm, tv = tt(p, gpu), torch.zeros(n, device=gpu, dtype=dtype), torch.zeros(n, device=gpu, dtype=dtype)
+    step_dev = torch.zeros(1, dtype=torch.int64, device=gpu)
+    pr = p.astype(np.float64)
+    for step in range(1, 6):
+        g = (rng.standard_normal(n) * 20).astype(np_dt)
+        tg = tt(g, gpu)
+        k.adam_step(tp, tg, tm, tv, step_dev, lr=0.01, weight_decay=0.01 if clipped else 0.0,
+                    clip_norm=10.0, lrd=0.999, clipped=clipped, zero_grad=True)
+        pr, m, v = o_adam.adam_step(pr, g, m, v, step, 0.01, weight_decay=0.01 if clipped else 0.0,
+                                    clip_norm=10.0, lrd=0.999, clipped=clipped)
+        assert float(tg.abs().sum()) == 0.0
+    assert int(step_dev.item()) == 5
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    np.testing.assert_allclose(tp.cpu().numpy(), pr, rtol=tol, atol=tol)
