@@ -1,0 +1,13 @@
+"""pyro_amd -- MI355X-native backend for Pyro's SVI (Trace_ELBO / TraceEnum_ELBO under
+pyro.plate) and HMC/NUTS hot paths.  The module layout and names mirror ``pyro`` for these
+paths (``pyro_amd.sample``, ``pyro_amd.plate``, ``pyro_amd.infer.SVI`` ...) so a model written
+for the reference runs after ``import pyro_amd as pyro``; the numerics are hand-written HIP
+kernels for gfx950 behind the C-ABI in include/pyro_amd.h.  GPU tensors only: there is no CPU
+fallback.
+"""
+from . import distributions, infer, optim, poutine  # noqa: F401
+from .primitives import (clear_param_store, deterministic, enable_validation, factor,  # noqa: F401
+                         get_param_store, module, param, plate, plate_stack, sample,
+                         set_rng_seed, validation_enabled)
+
+__version__ = "0.1.0"

@@ -328,7 +328,8 @@ static int nuts_launch(T* z, T* pe, T* grad, const T* Lambda, const T* inv_mass,
                        T* ap, int32_t* nl, int32_t* dp, int32_t* dv, int32_t* ac, hipStream_t s) {
   const size_t lds = ((size_t)D * D + 128 + (size_t)WPB * NUTS_MAX_DEPTH * (3 * 128 + 2)) *
                      sizeof(T);
-  PA_REQUIRE(lds <= 160 * 1024, "nuts_gaussian: needs %zu B of LDS (> 160 KiB)", lds);
+  if (lds > 160 * 1024)
+    return fail(PA_ERR_UNSUPPORTED, "nuts_gaussian: needs %zu B of LDS (> 160 KiB)", lds);
   auto k = nuts_gaussian_kernel<T, WPB>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -369,7 +370,14 @@ int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const 
                                      (const float*)inv_mass, (const float*)step, (int)C, (int)D,
                                      max_tree_depth, use_multinomial, seed, t, (float*)accept_prob,
                                      n_leapfrog, depth, diverging, accepted, s);
-  return pa::nuts_launch<double, 2>((double*)z, (double*)pe, (double*)grad, (const double*)Lambda,
+  const size_t lds2 = ((size_t)D * D + 128 + 2 * (size_t)pa::NUTS_MAX_DEPTH * (3 * 128 + 2)) * 8;
+  if (lds2 <= 160 * 1024)
+    return pa::nuts_launch<double, 2>((double*)z, (double*)pe, (double*)grad,
+                                      (const double*)Lambda, (const double*)inv_mass,
+                                      (const double*)step, (int)C, (int)D, max_tree_depth,
+                                      use_multinomial, seed, t, (double*)accept_prob, n_leapfrog,
+                                      depth, diverging, accepted, s);
+  return pa::nuts_launch<double, 1>((double*)z, (double*)pe, (double*)grad, (const double*)Lambda,
                                     (const double*)inv_mass, (const double*)step, (int)C, (int)D,
                                     max_tree_depth, use_multinomial, seed, t, (double*)accept_prob,
                                     n_leapfrog, depth, diverging, accepted, s);

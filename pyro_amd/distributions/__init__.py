@@ -1,0 +1,81 @@
+"""Distribution layer: torch.distributions classes with the Pyro mixin interface
+(reference: pyro/distributions/torch.py:395-419 wraps every torch.distributions class the
+same way), plus HIP-fused overrides for the hot exponential-family sites.
+"""
+import torch
+from torch.distributions import constraints, transforms  # noqa: F401
+from torch.distributions import biject_to, transform_to, kl_divergence  # noqa: F401
+
+from .base import (Delta, MaskedDistribution, ScoreParts, TorchDistribution,  # noqa: F401
+                   TorchDistributionMixin, Unit)
+from .families import (Bernoulli, Exponential, HalfCauchy, HalfNormal, LinearLogits,  # noqa: F401
+                       LogNormal, Normal, linear_logits)
+from .util import enable_validation, is_validation_enabled  # noqa: F401
+
+# ---- everything else: torch.distributions + mixin, arithmetic by ATen on the GPU ----------------
+_FUSED = {"Normal", "Bernoulli", "HalfCauchy", "HalfNormal", "LogNormal", "Exponential"}
+__all__ = ["Delta", "Unit", "MaskedDistribution", "TorchDistribution", "ScoreParts",
+           "LinearLogits", "linear_logits"] + sorted(_FUSED)
+
+
+def _wrap_all():
+    import torch.distributions as td
+    g = globals()
+    for name in td.__all__:
+        cls = getattr(td, name, None)
+        if not isinstance(cls, type) or not issubclass(cls, td.Distribution):
+            continue
+        if cls is td.Distribution or name in g:
+            continue
+        g[name] = type(name, (cls, TorchDistributionMixin), {
+            "__doc__": "torch.distributions.%s with the Pyro mixin interface." % name,
+            "__module__": __name__})
+        __all__.append(name)
+
+
+_wrap_all()
+
+
+# pyro-style overrides that matter for the enumeration path (reference: torch.py:124-149)
+class Categorical(torch.distributions.Categorical, TorchDistributionMixin):
+    def enumerate_support(self, expand=True):
+        result = super().enumerate_support(expand=expand)
+        if not expand:
+            result._pyro_categorical_support = id(self)
+        return result
+
+    def log_prob(self, value):
+        if getattr(value, "_pyro_categorical_support", None) == id(self):
+            # value is the un-expanded support arange(T) on a fresh leftmost dim: reshape, no gather
+            if not torch._C._get_tracing_state():
+                if self._validate_args:
+                    self._validate_sample(value)
+                assert value.size(0) == self.logits.size(-1)
+            logits = self.logits
+            if logits.dim() <= value.dim():
+                logits = logits.reshape((1,) * (1 + value.dim() - logits.dim()) + logits.shape)
+            if not torch._C._get_tracing_state():
+                assert logits.size(-1 - value.dim()) == 1
+            return logits.transpose(-1 - value.dim(), -1).squeeze(-1)
+        return super().log_prob(value)
+
+
+class Independent(torch.distributions.Independent, TorchDistributionMixin):
+    @property
+    def _validate_args(self):
+        return self.base_dist._validate_args
+
+    @_validate_args.setter
+    def _validate_args(self, value):
+        self.base_dist._validate_args = value
+
+    @property
+    def has_enumerate_support(self):
+        return False
+
+    def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        # the plate/event sum of an Independent is the plain sum of its base log_prob
+        if isinstance(mask, torch.Tensor):
+            mask = mask.reshape(mask.shape + (1,) * self.reinterpreted_batch_ndims)
+        f = getattr(self.base_dist, "fused_log_prob_sum", None)
+        return None if f is None else f(value, scale, mask)

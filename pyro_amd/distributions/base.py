@@ -1,0 +1,243 @@
+"""Mixin that gives torch.distributions classes the interface Pyro's handlers call
+(reference seam 1: pyro/distributions/torch_distribution.py:31-299, distribution.py:98-125,
+score_parts.py:21-38), plus Delta / Unit / MaskedDistribution.
+
+Fused protocol (new in this backend): a distribution may define
+
+    fused_log_prob_sum(value, scale, mask) -> 0-dim tensor
+
+returning ``scale_and_mask(log_prob(value), scale, mask).sum()`` from ONE HIP kernel;
+``Trace.compute_log_prob`` uses it when nobody needs the un-reduced log_prob tensor.
+"""
+from collections import namedtuple
+
+import torch
+from torch.distributions import constraints
+
+from .util import broadcast_shape, is_identically_zero, scale_and_mask, sum_rightmost
+
+
+class ScoreParts(namedtuple("ScoreParts", ["log_prob", "score_function", "entropy_term"])):
+    """(log_prob, score_function, entropy_term) used by the ELBO surrogate."""
+
+    def scale_and_mask(self, scale=1.0, mask=None):
+        # score_function is a multiplier, it is masked but never scaled
+        log_prob = scale_and_mask(self.log_prob, scale, mask)
+        score_function = self.score_function
+        if mask is not None and not is_identically_zero(score_function):
+            score_function = scale_and_mask(score_function, 1.0, mask)
+        entropy_term = scale_and_mask(self.entropy_term, scale, mask)
+        return ScoreParts(log_prob, score_function, entropy_term)
+
+
+class TorchDistributionMixin:
+    has_rsample = False
+    has_enumerate_support = False
+
+    def __call__(self, sample_shape=torch.Size()):
+        # rsample when reparameterised, else sample (torch_distribution.py:31-52)
+        return self.rsample(sample_shape) if self.has_rsample else self.sample(sample_shape)
+
+    @property
+    def event_dim(self):
+        return len(self.event_shape)
+
+    def shape(self, sample_shape=torch.Size()):
+        return torch.Size(sample_shape) + self.batch_shape + self.event_shape
+
+    def score_parts(self, x, *args, **kwargs):
+        log_prob = self.log_prob(x, *args, **kwargs)
+        if self.has_rsample:
+            return ScoreParts(log_prob=log_prob, score_function=0, entropy_term=log_prob)
+        return ScoreParts(log_prob=log_prob, score_function=log_prob, entropy_term=0)
+
+    def expand_by(self, sample_shape):
+        return self.expand(torch.Size(sample_shape) + self.batch_shape)
+
+    def reshape(self, sample_shape=None, extra_event_dims=None):
+        raise Exception(".reshape(sample_shape=s, extra_event_dims=n) was renamed: "
+                        "use .expand_by(s).to_event(n)")
+
+    def to_event(self, reinterpreted_batch_ndims=None):
+        if reinterpreted_batch_ndims is None:
+            reinterpreted_batch_ndims = len(self.batch_shape)
+        if reinterpreted_batch_ndims == 0:
+            return self
+        from . import Independent
+        base, n = self, reinterpreted_batch_ndims
+        while isinstance(base, torch.distributions.Independent):
+            n += base.reinterpreted_batch_ndims
+            base = base.base_dist
+        if n < 0:
+            raise ValueError("cannot remove event dims that were never added")
+        return Independent(base, n) if n else base
+
+    def independent(self, reinterpreted_batch_ndims=None):
+        return self.to_event(reinterpreted_batch_ndims)
+
+    def mask(self, mask):
+        return MaskedDistribution(self, mask)
+
+    # ---- fused protocol default: peel wrappers, delegate to the base family -----------------
+    def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        return None
+
+
+def _unwrap_independent(fn):
+    while isinstance(fn, torch.distributions.Independent):
+        fn = fn.base_dist
+    return fn
+
+
+class TorchDistribution(torch.distributions.Distribution, TorchDistributionMixin):
+    """Base class for distributions implemented directly in this package."""
+
+
+class MaskedDistribution(TorchDistribution):
+    """Masks log_prob (and the score parts) of a base distribution
+    (reference: pyro/distributions/torch_distribution.py:302-396)."""
+
+    arg_constraints = {}
+
+    def __init__(self, base_dist, mask):
+        if isinstance(mask, bool):
+            self._mask = mask
+        else:
+            batch_shape = broadcast_shape(mask.shape, base_dist.batch_shape)
+            if mask.shape != batch_shape:
+                mask = mask.expand(batch_shape)
+            if base_dist.batch_shape != batch_shape:
+                base_dist = base_dist.expand(batch_shape)
+            self._mask = mask.bool()
+        self.base_dist = base_dist
+        super().__init__(base_dist.batch_shape, base_dist.event_shape, validate_args=False)
+
+    def expand(self, batch_shape, _instance=None):
+        batch_shape = torch.Size(batch_shape)
+        mask = self._mask if isinstance(self._mask, bool) else self._mask.expand(batch_shape)
+        return MaskedDistribution(self.base_dist.expand(batch_shape), mask)
+
+    @property
+    def has_rsample(self):
+        return self.base_dist.has_rsample
+
+    @property
+    def has_enumerate_support(self):
+        return self.base_dist.has_enumerate_support
+
+    @property
+    def support(self):
+        return self.base_dist.support
+
+    def sample(self, sample_shape=torch.Size()):
+        return self.base_dist.sample(sample_shape)
+
+    def rsample(self, sample_shape=torch.Size()):
+        return self.base_dist.rsample(sample_shape)
+
+    def log_prob(self, value):
+        if self._mask is False:
+            shape = broadcast_shape(self.base_dist.batch_shape,
+                                    value.shape[: value.dim() - self.event_dim])
+            return torch.zeros((), device=value.device).expand(shape)
+        if self._mask is True:
+            return self.base_dist.log_prob(value)
+        return scale_and_mask(self.base_dist.log_prob(value), mask=self._mask)
+
+    def score_parts(self, value):
+        if isinstance(self._mask, bool):
+            return super().score_parts(value)
+        return self.base_dist.score_parts(value).scale_and_mask(mask=self._mask)
+
+    def enumerate_support(self, expand=True):
+        return self.base_dist.enumerate_support(expand=expand)
+
+    def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        if isinstance(self._mask, bool):
+            if self._mask is False:
+                return torch.zeros((), device=value.device, dtype=value.dtype)
+            return self.base_dist.fused_log_prob_sum(value, scale, mask)
+        if self.event_dim != 0:
+            return None
+        m = self._mask if mask is None else (self._mask & mask)
+        return self.base_dist.fused_log_prob_sum(value, scale, m)
+
+
+class Delta(TorchDistribution):
+    """Point mass at ``v`` with log-density ``log_density`` (reference: delta.py:73-77)."""
+
+    has_rsample = True
+    arg_constraints = {"v": constraints.dependent, "log_density": constraints.real}
+
+    def __init__(self, v, log_density=0.0, event_dim=0, validate_args=None):
+        if event_dim > v.dim():
+            raise ValueError("Expected event_dim <= v.dim(), actual {} vs {}".format(
+                event_dim, v.dim()))
+        batch_dim = v.dim() - event_dim
+        batch_shape, event_shape = v.shape[:batch_dim], v.shape[batch_dim:]
+        if isinstance(log_density, (int, float)):
+            log_density = torch.full(batch_shape, float(log_density), dtype=v.dtype,
+                                     device=v.device)
+        elif log_density.shape != batch_shape:
+            raise ValueError("Expected log_density.shape = {}, actual {}".format(
+                log_density.shape, batch_shape))
+        self.v, self.log_density = v, log_density
+        super().__init__(batch_shape, event_shape, validate_args=validate_args)
+
+    @constraints.dependent_property
+    def support(self):
+        return constraints.independent(constraints.real, len(self.event_shape))
+
+    def expand(self, batch_shape, _instance=None):
+        batch_shape = torch.Size(batch_shape)
+        v = self.v.expand(batch_shape + self.event_shape)
+        return Delta(v, self.log_density.expand(batch_shape), len(self.event_shape),
+                     validate_args=False)
+
+    def rsample(self, sample_shape=torch.Size()):
+        shape = torch.Size(sample_shape) + self.v.shape
+        return self.v.expand(shape)
+
+    def log_prob(self, x):
+        v = self.v.expand(self.batch_shape + self.event_shape)
+        log_prob = (x == v).type(x.dtype).log()
+        log_prob = sum_rightmost(log_prob, len(self.event_shape))
+        return log_prob + self.log_density
+
+    @property
+    def mean(self):
+        return self.v
+
+    @property
+    def variance(self):
+        return torch.zeros_like(self.v)
+
+
+class Unit(TorchDistribution):
+    """Trivial distribution over the empty event, carrying a log_factor (pyro.factor)."""
+
+    arg_constraints = {"log_factor": constraints.real}
+    support = constraints.real
+
+    def __init__(self, log_factor, *, has_rsample=None, validate_args=None):
+        log_factor = torch.as_tensor(log_factor)
+        self.log_factor = log_factor
+        self._has_rsample = has_rsample
+        super().__init__(log_factor.shape, torch.Size((0,)), validate_args=validate_args)
+
+    @property
+    def has_rsample(self):
+        return bool(self._has_rsample)
+
+    def expand(self, batch_shape, _instance=None):
+        return Unit(self.log_factor.expand(torch.Size(batch_shape)), has_rsample=self._has_rsample)
+
+    def sample(self, sample_shape=torch.Size()):
+        return self.log_factor.new_empty(torch.Size(sample_shape) + self.shape())
+
+    rsample = sample
+
+    def log_prob(self, value):
+        shape = broadcast_shape(self.batch_shape, value.shape[:-1])
+        return self.log_factor.expand(shape)
+

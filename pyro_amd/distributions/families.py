@@ -1,0 +1,233 @@
+"""HIP-fused distribution families (the hot exponential-family sites of SURVEY 8a).
+
+Each class IS the corresponding torch.distributions class (same constructor, attributes,
+support, ``expand``) with ``log_prob`` routed to the fused element-wise kernel, ``rsample``
+drawing from the Philox stream, and ``fused_log_prob_sum`` providing the one-kernel
+log_prob -> scale_and_mask -> plate-sum reduction.  They require HIP tensors: CPU tensors raise.
+"""
+import torch
+from torch.distributions import constraints
+
+from .. import _lib, rng
+from . import fused
+from .base import TorchDistribution, TorchDistributionMixin
+
+
+def _maskable(mask):
+    return mask is None or isinstance(mask, torch.Tensor)
+
+
+class _FusedElementwise(TorchDistributionMixin):
+    _dist_id = None
+
+    def _params(self):
+        raise NotImplementedError
+
+    def log_prob(self, value):
+        if self._validate_args:
+            self._validate_sample(value)
+        p0, p1 = self._params()
+        return fused.log_prob(self._dist_id, value, p0, p1)
+
+    def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        if not _maskable(mask) or isinstance(scale, torch.Tensor):
+            return None
+        if self._validate_args:
+            self._validate_sample(value)
+        p0, p1 = self._params()
+        return fused.log_prob_sum(self._dist_id, value, p0, p1, mask, scale)
+
+
+class Normal(torch.distributions.Normal, _FusedElementwise):
+    _dist_id = _lib.DIST_NORMAL
+
+    def _params(self):
+        return self.loc, self.scale
+
+    def rsample(self, sample_shape=torch.Size()):
+        shape = self._extended_shape(sample_shape)
+        eps = rng.normal(shape, self.loc.dtype, self.loc.device)
+        return self.loc + eps * self.scale
+
+    def sample(self, sample_shape=torch.Size()):
+        with torch.no_grad():
+            return self.rsample(sample_shape)
+
+
+class LogNormal(torch.distributions.LogNormal, _FusedElementwise):
+    _dist_id = _lib.DIST_LOG_NORMAL
+
+    def _params(self):
+        return self.loc, self.scale
+
+    def rsample(self, sample_shape=torch.Size()):
+        shape = self._extended_shape(sample_shape)
+        eps = rng.normal(shape, self.loc.dtype, self.loc.device)
+        return (self.loc + eps * self.scale).exp()
+
+    def sample(self, sample_shape=torch.Size()):
+        with torch.no_grad():
+            return self.rsample(sample_shape)
+
+
+class HalfCauchy(torch.distributions.HalfCauchy, _FusedElementwise):
+    _dist_id = _lib.DIST_HALF_CAUCHY
+
+    def _params(self):
+        return self.scale, None
+
+    def log_prob(self, value):
+        if self._validate_args:
+            self._validate_sample(value)
+        return fused.log_prob(self._dist_id, value, self.scale, None)
+
+
+class HalfNormal(torch.distributions.HalfNormal, _FusedElementwise):
+    _dist_id = _lib.DIST_HALF_NORMAL
+
+    def _params(self):
+        return self.scale, None
+
+    def rsample(self, sample_shape=torch.Size()):
+        shape = self._extended_shape(sample_shape)
+        eps = rng.normal(shape, self.scale.dtype, self.scale.device)
+        return (eps * self.scale).abs()
+
+
+class Exponential(torch.distributions.Exponential, _FusedElementwise):
+    _dist_id = _lib.DIST_EXPONENTIAL
+
+    def _params(self):
+        return self.rate, None
+
+
+class LinearLogits:
+    """Lazy ``logits = (w @ X^T).squeeze(-2) + b`` of a plated GLM (never materialised).
+
+    X: [N, D] data.  w: [D] or [..., 1, D] (the singleton is the data-plate dim of a
+    vectorised-particle latent, pyro/infer/elbo.py:186-203).  b: scalar / [..., 1] / None.
+    ``Bernoulli(logits=LinearLogits(X, w, b))`` evaluates log-likelihood AND gradient with the
+    fused one-pass kernel instead of materialising the [P, N] logits.
+    """
+
+    def __init__(self, X, w, b=None):
+        if X.dim() != 2:
+            raise ValueError("LinearLogits: X must be [N, D], got {}".format(tuple(X.shape)))
+        if w.shape[-1] != X.shape[-1]:
+            raise ValueError("LinearLogits: w[..., D] does not match X[N, D]: {} vs {}".format(
+                tuple(w.shape), tuple(X.shape)))
+        if w.dim() > 1 and w.shape[-2] != 1:
+            raise ValueError("LinearLogits: expected w of shape [..., 1, D] (data-plate dim must "
+                             "be a singleton), got {}".format(tuple(w.shape)))
+        self.X, self.w, self.b = X, w, b
+        lead = w.shape[:-2] if w.dim() > 1 else torch.Size()
+        if b is not None and b.dim() > 0:
+            if b.shape[-1] != 1:
+                raise ValueError("LinearLogits: expected b of shape [..., 1], got {}".format(
+                    tuple(b.shape)))
+            lead = torch.broadcast_shapes(lead, b.shape[:-1])
+        self.shape = torch.Size(lead) + (X.shape[0],)
+        self.dtype, self.device = X.dtype, X.device
+
+    def dim(self):
+        return len(self.shape)
+
+    def materialize(self):
+        w = self.w
+        out = (w @ self.X.t())
+        if w.dim() > 1:
+            out = out.squeeze(-2)
+        if self.b is not None:
+            out = out + self.b
+        return out
+
+    def flat_params(self):
+        """(w2 [P, D], b1 [P] or None) with the particle dims flattened."""
+        lead = self.shape[:-1]
+        P = 1
+        for s in lead:
+            P *= s
+        D = self.X.shape[1]
+        w2 = self.w.expand(lead + (1, D)).reshape(P, D) if self.w.dim() > 1 else \
+            self.w.expand(lead + (D,)).reshape(P, D)
+        b1 = None
+        if self.b is not None:
+            b = self.b if self.b.dim() > 0 else self.b.reshape(1)
+            b1 = b.expand(lead + (1,)).reshape(P)
+        return w2.contiguous(), (b1.contiguous() if b1 is not None else None)
+
+
+def linear_logits(X, w, b=None):
+    return LinearLogits(X, w, b)
+
+
+class _BernoulliLinear(TorchDistribution):
+    """Bernoulli whose logits are a lazy LinearLogits: the plated GLM observed site."""
+
+    arg_constraints = {}
+    support = constraints.boolean
+    has_enumerate_support = False
+    _allow_f64 = False  # the HIP GLM kernel is float32; other dtypes take the unfused route
+
+    def __init__(self, lazy, validate_args=None):
+        self.lazy = lazy
+        super().__init__(lazy.shape, torch.Size(), validate_args=False)
+
+    @property
+    def logits(self):
+        return self.lazy.materialize()
+
+    def expand(self, batch_shape, _instance=None):
+        batch_shape = torch.Size(batch_shape)
+        if batch_shape == self.batch_shape:
+            return self
+        # a wider batch than the lazy form can express: materialise (unfused path)
+        return Bernoulli(logits=self.lazy.materialize()).expand(batch_shape)
+
+    def sample(self, sample_shape=torch.Size()):
+        with torch.no_grad():
+            return Bernoulli(logits=self.lazy.materialize()).sample(sample_shape)
+
+    def log_prob(self, value):
+        return fused.log_prob(_lib.DIST_BERNOULLI_LOGITS, value, self.lazy.materialize(), None)
+
+    def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        lz = self.lazy
+        N = lz.X.shape[0]
+        if isinstance(scale, torch.Tensor) or not _maskable(mask):
+            return None
+        if value.dim() != 1 or value.shape[0] != N:
+            return None
+        if lz.X.dtype != torch.float32 and not self._allow_f64:
+            return None
+        if mask is not None:
+            if mask.dim() != 1 or mask.shape[0] != N:
+                return None
+            mask = mask.contiguous()
+        if lz.X.shape[1] > 128 or not lz.X.is_contiguous():
+            return None
+        w2, b1 = lz.flat_params()
+        ll = fused.glm_bernoulli_ll(lz.X, value.contiguous(), w2, b1, mask, scale)
+        return ll.sum()
+
+
+class Bernoulli(torch.distributions.Bernoulli, _FusedElementwise):
+    """Bernoulli; with ``logits=`` given, log_prob runs the fused -BCE-with-logits kernel
+    (torch: torch/distributions/bernoulli.py:121-125)."""
+
+    _dist_id = _lib.DIST_BERNOULLI_LOGITS
+
+    def __new__(cls, probs=None, logits=None, validate_args=None):
+        if isinstance(logits, LinearLogits):
+            return _BernoulliLinear(logits, validate_args)
+        return super().__new__(cls)
+
+    def _params(self):
+        return self.logits, None
+
+    def enumerate_support(self, expand=True):
+        return super().enumerate_support(expand)
+
+    @property
+    def has_enumerate_support(self):
+        return True

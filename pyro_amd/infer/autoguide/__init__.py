@@ -1,0 +1,3 @@
+from .guides import AutoDelta, AutoDiagonalNormal, AutoGuide, AutoNormal  # noqa: F401
+from .initialization import (InitMessenger, init_to_feasible, init_to_mean,  # noqa: F401
+                             init_to_median, init_to_sample, init_to_uniform, init_to_value)

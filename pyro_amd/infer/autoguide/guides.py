@@ -1,0 +1,207 @@
+"""Automatic guides (reference: pyro/infer/autoguide/guides.py: AutoGuide :60-200,
+AutoDelta :330-412, AutoNormal :415-603, AutoDiagonalNormal :968-1029).
+
+AutoNormal generates exactly the guide sites the fused kernels see: one
+``Normal(loc, scale).to_event(k)`` auxiliary site per latent plus a ``Delta`` carrying the
+transform's log-abs-det-Jacobian.
+"""
+from contextlib import ExitStack
+
+import torch
+from torch.distributions import biject_to, constraints
+
+from ... import distributions as dist
+from ... import poutine
+from ...distributions.util import sum_rightmost
+from ...primitives import param, plate, sample
+from .initialization import InitMessenger, init_to_feasible, init_to_median
+
+
+def _softplus_inv(y):
+    return y + torch.log(-torch.expm1(-y))
+
+
+class _SoftplusPositive(constraints.Constraint):
+    """scale constraint of AutoNormal: positive, parameterised through softplus."""
+
+    is_discrete = False
+    event_dim = 0
+
+    def check(self, value):
+        return value > 0
+
+
+softplus_positive = _SoftplusPositive()
+
+
+@dist.transform_to.register(_SoftplusPositive)
+def _transform_to_softplus_positive(constraint):
+    return torch.distributions.transforms.SoftplusTransform()
+
+
+class AutoGuide:
+    def __init__(self, model, *, create_plates=None):
+        self.model = model
+        self.create_plates = create_plates
+        self.prototype_trace = None
+        self._prototype_frames = {}
+        self.prefix = type(self).__name__
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def _create_plates(self, *args, **kwargs):
+        if self.create_plates is None:
+            plates = {}
+        else:
+            plates = self.create_plates(*args, **kwargs)
+            if isinstance(plates, plate):
+                plates = [plates]
+            plates = {p.name: p for p in plates}
+        for name, frame in sorted(self._prototype_frames.items()):
+            if name not in plates:
+                full_size = getattr(frame, "full_size", frame.size)
+                plates[name] = plate(name, full_size, dim=frame.dim,
+                                     subsample_size=frame.size if frame.size != full_size else None)
+        return plates
+
+    def _setup_prototype(self, *args, **kwargs):
+        model = poutine.block(InitMessenger(self.init_loc_fn)(self.model))
+        # prototype: run the (blocked) model once, unwrapped from any enumeration
+        with poutine.block():
+            self.prototype_trace = poutine.trace(
+                InitMessenger(self.init_loc_fn)(self.model)).get_trace(*args, **kwargs)
+        del model
+        self.prototype_trace = poutine.util.prune_subsample_sites(self.prototype_trace)
+        self._prototype_frames = {}
+        for name, site in self.prototype_trace.iter_stochastic_nodes():
+            for frame in site["cond_indep_stack"]:
+                if frame.vectorized:
+                    self._prototype_frames[frame.name] = frame
+                else:
+                    raise NotImplementedError("AutoGuide does not support sequential pyro.plate")
+
+    def median(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+class AutoNormal(AutoGuide):
+    scale_constraint = softplus_positive
+
+    def __init__(self, model, *, init_loc_fn=init_to_feasible, init_scale=0.1, create_plates=None):
+        self.init_loc_fn = init_loc_fn
+        if not isinstance(init_scale, float) or not (init_scale > 0):
+            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
+        self._init_scale = init_scale
+        super().__init__(model, create_plates=create_plates)
+        self._event_dims = {}
+        self._inits = {}
+
+    def _setup_prototype(self, *args, **kwargs):
+        super()._setup_prototype(*args, **kwargs)
+        for name, site in self.prototype_trace.iter_stochastic_nodes():
+            if site["infer"].get("enumerate") == "parallel":
+                continue
+            with torch.no_grad():
+                init_loc = biject_to(site["fn"].support).inv(site["value"].detach()).detach()
+            event_dim = site["fn"].event_dim + init_loc.dim() - site["value"].dim()
+            self._event_dims[name] = event_dim
+            for frame in site["cond_indep_stack"]:
+                full_size = getattr(frame, "full_size", None) or frame.size
+                if full_size != frame.size:
+                    dim = frame.dim - event_dim
+                    reps = -(-full_size // init_loc.shape[dim])
+                    init_loc = torch.cat([init_loc] * reps, dim=dim).narrow(dim, 0, full_size)
+            self._inits[name] = (init_loc.contiguous().clone(),
+                                 torch.full_like(init_loc, self._init_scale))
+
+    def _latent_sites(self):
+        for name, site in self.prototype_trace.iter_stochastic_nodes():
+            if name in self._inits:
+                yield name, site
+
+    def _get_loc_and_scale(self, name):
+        init_loc, init_scale = self._inits[name]
+        event_dim = self._event_dims[name]
+        loc = param("{}.locs.{}".format(self.prefix, name), init_loc, constraints.real,
+                    event_dim=event_dim)
+        scale = param("{}.scales.{}".format(self.prefix, name), init_scale, self.scale_constraint,
+                      event_dim=event_dim)
+        return loc, scale
+
+    def forward(self, *args, **kwargs):
+        if self.prototype_trace is None:
+            self._setup_prototype(*args, **kwargs)
+        plates = self._create_plates(*args, **kwargs)
+        result = {}
+        for name, site in self._latent_sites():
+            transform = biject_to(site["fn"].support)
+            with ExitStack() as stack:
+                for frame in site["cond_indep_stack"]:
+                    if frame.vectorized:
+                        stack.enter_context(plates[frame.name])
+                site_loc, site_scale = self._get_loc_and_scale(name)
+                unconstrained_latent = sample(
+                    name + "_unconstrained",
+                    dist.Normal(site_loc, site_scale).to_event(self._event_dims[name]),
+                    infer={"is_auxiliary": True})
+                value = transform(unconstrained_latent)
+                if poutine.get_mask() is False:
+                    log_density = 0.0
+                else:
+                    log_density = transform.inv.log_abs_det_jacobian(value, unconstrained_latent)
+                    log_density = sum_rightmost(
+                        log_density, log_density.dim() - value.dim() + site["fn"].event_dim)
+                delta_dist = dist.Delta(value, log_density=log_density,
+                                        event_dim=site["fn"].event_dim)
+                result[name] = sample(name, delta_dist)
+        return result
+
+    @torch.no_grad()
+    def median(self, *args, **kwargs):
+        out = {}
+        for name, site in self._latent_sites():
+            loc, _ = self._get_loc_and_scale(name)
+            out[name] = biject_to(site["fn"].support)(loc).clone()
+        return out
+
+    @torch.no_grad()
+    def quantiles(self, quantiles, *args, **kwargs):
+        out = {}
+        for name, site in self._latent_sites():
+            loc, scale = self._get_loc_and_scale(name)
+            q = torch.tensor(quantiles, dtype=loc.dtype, device=loc.device)
+            q = q.reshape((-1,) + (1,) * loc.dim())
+            vals = torch.distributions.Normal(loc, scale).icdf(q)
+            out[name] = biject_to(site["fn"].support)(vals)
+        return out
+
+
+AutoDiagonalNormal = AutoNormal  # same variational family; per-site parameters instead of one flat vector
+
+
+class AutoDelta(AutoGuide):
+    """MAP guide: a learnable point estimate per latent site."""
+
+    def __init__(self, model, init_loc_fn=init_to_median, *, create_plates=None):
+        self.init_loc_fn = init_loc_fn
+        super().__init__(model, create_plates=create_plates)
+
+    def forward(self, *args, **kwargs):
+        if self.prototype_trace is None:
+            self._setup_prototype(*args, **kwargs)
+        plates = self._create_plates(*args, **kwargs)
+        result = {}
+        for name, site in self.prototype_trace.iter_stochastic_nodes():
+            with ExitStack() as stack:
+                for frame in site["cond_indep_stack"]:
+                    if frame.vectorized:
+                        stack.enter_context(plates[frame.name])
+                value = param("{}.{}".format(self.prefix, name), site["value"].detach().clone(),
+                              site["fn"].support, event_dim=site["fn"].event_dim)
+                result[name] = sample(name, dist.Delta(value, event_dim=site["fn"].event_dim))
+        return result
+
+    @torch.no_grad()
+    def median(self, *args, **kwargs):
+        return {k: v.clone() for k, v in self(*args, **kwargs).items()}

@@ -1,0 +1,73 @@
+"""Distributed optimizer wrapper: the MI355X-native counterpart of the reference's only
+distributed hook, HorovodOptimizer (pyro/optim/horovod.py:12-55).
+
+The reference all-reduces once PER PARAMETER tensor per step (six 4-byte all-reduces on its
+example).  Here the gradients of all parameters are reduced with ONE collective per step over
+the flat gradient buffer: ``torch.distributed.all_reduce`` on the ``nccl`` backend (= RCCL over
+xGMI on ROCm; ``gloo`` in the CPU tests), followed by a division by the world size -- the
+particle-sharded ELBO estimator is a mean over ranks (SURVEY 8e variant 1).  Parameters must be
+identical on all ranks at the start: ``broadcast_parameters`` mirrors
+hvd.broadcast_parameters(..., root_rank=0) (examples/svi_horovod.py:87-88).
+"""
+import torch
+import torch.distributed as dist
+
+from ..params import _PARAM_STORE
+
+
+def _sorted(params):
+    # deterministic order on every rank, as HorovodOptimizer does (horovod.py:52-55)
+    return sorted(params, key=lambda p: _PARAM_STORE.param_name(p) or "")
+
+
+class RcclOptimizer:
+    def __init__(self, pyro_optim, group=None, average=True):
+        self.optim = pyro_optim
+        self.group = group
+        self.average = average
+        self._broadcast_done = set()
+        if hasattr(pyro_optim, "grad_hook"):
+            pyro_optim.grad_hook = self._allreduce_flat
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _allreduce_flat(self, flat_grad):
+        if self.world_size == 1:
+            return
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average:
+            flat_grad.div_(self.world_size)
+
+    def broadcast_parameters(self, params, root_rank=0):
+        if self.world_size == 1:
+            return
+        for p in _sorted(params):
+            dist.broadcast(p.data, src=root_rank, group=self.group)
+
+    def __call__(self, params, *args, **kwargs):
+        params = _sorted(params)
+        fresh = [p for p in params if p not in self._broadcast_done]
+        if fresh:
+            # newly created parameters start identical on every rank
+            self.broadcast_parameters(fresh)
+            self._broadcast_done.update(fresh)
+        if not hasattr(self.optim, "grad_hook") and self.world_size > 1:
+            # generic per-parameter optimizer: pack -> one all-reduce -> unpack
+            grads = [p.grad for p in params if p.grad is not None]
+            if grads:
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                self._allreduce_flat(flat)
+                off = 0
+                for g in grads:
+                    n = g.numel()
+                    g.copy_(flat[off:off + n].view_as(g))
+                    off += n
+        self.optim(params, *args, **kwargs)
+
+    def get_state(self):
+        return self.optim.get_state()
+
+    def set_state(self, state):
+        self.optim.set_state(state)

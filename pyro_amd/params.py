@@ -1,0 +1,124 @@
+"""Global parameter store (reference: pyro/params/param_store.py:138-336): named, optionally
+constrained parameters backed by unconstrained leaf tensors that the optimizers update."""
+import re
+import weakref
+
+import torch
+from torch.distributions import constraints, transform_to
+
+
+class ParamStoreDict:
+    def __init__(self):
+        self._params = {}        # name -> unconstrained leaf tensor
+        self._param_to_name = {}  # unconstrained leaf -> name
+        self._constraints = {}
+
+    def clear(self):
+        self._params, self._param_to_name, self._constraints = {}, {}, {}
+
+    def items(self):
+        for name in self._params:
+            yield name, self[name]
+
+    def keys(self):
+        return self._params.keys()
+
+    def values(self):
+        for name in self._params:
+            yield self[name]
+
+    def __bool__(self):
+        return bool(self._params)
+
+    def __len__(self):
+        return len(self._params)
+
+    def __contains__(self, name):
+        return name in self._params
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __delitem__(self, name):
+        unconstrained = self._params.pop(name)
+        self._param_to_name.pop(unconstrained)
+        self._constraints.pop(name)
+
+    def __getitem__(self, name):
+        unconstrained = self._params[name]
+        constraint = self._constraints[name]
+        constrained = transform_to(constraint)(unconstrained)
+        if constrained is unconstrained:
+            constrained = unconstrained.view_as(unconstrained) if False else unconstrained
+        try:
+            constrained.unconstrained = weakref.ref(unconstrained)
+        except AttributeError:
+            pass
+        return constrained
+
+    def __setitem__(self, name, new_constrained_value):
+        constraint = self._constraints.get(name, constraints.real)
+        self.setdefault_or_replace(name, new_constrained_value, constraint)
+
+    def setdefault_or_replace(self, name, value, constraint):
+        if constraint is constraints.real and isinstance(value, torch.nn.Parameter):
+            unconstrained = value  # nn.Module parameters are stored by identity (pyro.module)
+        else:
+            with torch.no_grad():
+                unconstrained = transform_to(constraint).inv(value.detach()).clone().contiguous()
+            unconstrained.requires_grad_(True)
+        if name in self._params:
+            self._param_to_name.pop(self._params[name])
+        self._params[name] = unconstrained
+        self._param_to_name[unconstrained] = name
+        self._constraints[name] = constraint
+
+    def setdefault(self, name, init_constrained_value, constraint=constraints.real):
+        if name not in self._params:
+            if callable(init_constrained_value):
+                init_constrained_value = init_constrained_value()
+            self.setdefault_or_replace(name, init_constrained_value, constraint)
+        return self[name]
+
+    def get_param(self, name, init_tensor=None, constraint=constraints.real, event_dim=None):
+        if init_tensor is None:
+            if name not in self._params:
+                raise KeyError("param '{}' is not in the param store and no init was given".format(
+                    name))
+            return self[name]
+        return self.setdefault(name, init_tensor, constraint)
+
+    def param_name(self, p):
+        return self._param_to_name.get(p)
+
+    def named_parameters(self):
+        return self._params.items()
+
+    def get_all_param_names(self):
+        return set(self._params.keys())
+
+    def match(self, name):
+        pattern = re.compile(name)
+        return {n: self[n] for n in self._params if pattern.match(n)}
+
+    def get_state(self):
+        return {"params": {n: p.detach().clone() for n, p in self._params.items()},
+                "constraints": dict(self._constraints)}
+
+    def set_state(self, state):
+        self.clear()
+        for name, unconstrained in state["params"].items():
+            constraint = state["constraints"][name]
+            u = unconstrained.detach().clone().requires_grad_(True)
+            self._params[name] = u
+            self._param_to_name[u] = name
+            self._constraints[name] = constraint
+
+    def save(self, filename):
+        torch.save(self.get_state(), filename)
+
+    def load(self, filename, map_location=None):
+        self.set_state(torch.load(filename, map_location=map_location, weights_only=False))
+
+
+_PARAM_STORE = ParamStoreDict()

@@ -1,0 +1,453 @@
+"""The effect handlers the two hot paths need (reference: pyro/poutine/*_messenger.py).
+
+trace / replay / block / condition / scale / mask / plate (independence + subsampling +
+broadcasting) / enum (parallel enumeration) / seed.  Same names, arguments and message
+semantics as the reference so existing models run unchanged; implementation is independent.
+"""
+import numbers
+from collections import namedtuple
+
+import torch
+
+from .. import rng as _rng
+from . import settings
+from .runtime import (_DIM_ALLOCATOR, _ENUM_ALLOCATOR, Messenger, _BlockLike, apply_stack,
+                      new_message)
+from .trace import Trace
+
+
+# ---------------------------------------------------------------------------------------------
+class TraceMessenger(Messenger):
+    """Record every message into a Trace (reference: trace_messenger.py:142-215)."""
+
+    _wrapper_attrs = ("get_trace",)
+
+    def __init__(self, graph_type=None, param_only=None):
+        super().__init__()
+        self.graph_type = "flat" if graph_type is None else graph_type
+        self.param_only = bool(param_only)
+        self.trace = Trace(self.graph_type)
+
+    def __enter__(self):
+        self.trace = Trace(self.graph_type)
+        return super().__enter__()
+
+    def __call__(self, fn):
+        return super().__call__(fn)
+
+    def get_trace(self):
+        return self.trace.copy()
+
+    def _wrapped_get_trace(self, bound, *args, **kwargs):
+        bound(*args, **kwargs)
+        return self.get_trace()
+
+    def _reset(self):
+        self.trace = Trace(self.graph_type)
+
+    def _pyro_post_sample(self, msg):
+        if self.param_only:
+            return
+        if msg["infer"].get("_do_not_trace"):
+            return
+        self.trace.add_node(msg["name"], **msg.copy())
+
+    def _pyro_post_param(self, msg):
+        self.trace.add_node(msg["name"], **msg.copy())
+
+
+# ---------------------------------------------------------------------------------------------
+class ReplayMessenger(Messenger):
+    """Replay sample sites from a guide trace (reference: replay_messenger.py:60-90)."""
+
+    def __init__(self, trace=None, params=None):
+        super().__init__()
+        if trace is None and params is None:
+            raise ValueError("must provide trace or params to replay against")
+        self.trace, self.params = trace, params
+
+    def _pyro_sample(self, msg):
+        name = msg["name"]
+        if self.trace is not None and name in self.trace:
+            guide_msg = self.trace.nodes[name]
+            if msg["is_observed"]:
+                return
+            if guide_msg["type"] != "sample" or guide_msg["is_observed"]:
+                raise RuntimeError("site {} must be sampled in trace".format(name))
+            msg["done"] = True
+            msg["value"] = guide_msg["value"]
+            msg["infer"] = guide_msg["infer"]
+
+    def _pyro_param(self, msg):
+        if self.params is not None and msg["name"] in self.params:
+            p = self.params[msg["name"]]
+            msg["done"] = True
+            msg["value"] = p["value"] if isinstance(p, dict) else p
+
+
+# ---------------------------------------------------------------------------------------------
+class BlockMessenger(Messenger, _BlockLike):
+    """Hide sites from handlers outside (reference: block_messenger.py)."""
+
+    def __init__(self, hide_fn=None, expose_fn=None, hide_all=True, expose_all=False, hide=None,
+                 expose=None, hide_types=None, expose_types=None):
+        super().__init__()
+        if hide_fn is not None:
+            self.hide_fn = hide_fn
+        elif expose_fn is not None:
+            self.hide_fn = lambda msg: not expose_fn(msg)
+        else:
+            hide = hide or []
+            expose = expose or []
+            hide_types = hide_types or []
+            expose_types = expose_types or []
+            if hide or hide_types:
+                self.hide_fn = lambda msg: msg["name"] in hide or msg["type"] in hide_types
+            elif expose or expose_types:
+                self.hide_fn = lambda msg: not (msg["name"] in expose
+                                                or msg["type"] in expose_types)
+            else:
+                self.hide_fn = lambda msg: not expose_all
+
+    def _process_message(self, msg):
+        msg["stop"] = bool(self.hide_fn(msg))
+
+
+# ---------------------------------------------------------------------------------------------
+class ConditionMessenger(Messenger):
+    """Fix sample sites to observed values (reference: condition_messenger.py)."""
+
+    def __init__(self, data):
+        super().__init__()
+        self.data = data
+
+    def _pyro_sample(self, msg):
+        name = msg["name"]
+        if isinstance(self.data, Trace):
+            if name in self.data.nodes:
+                msg["value"] = self.data.nodes[name]["value"]
+                msg["is_observed"] = msg["value"] is not None
+        elif name in self.data:
+            msg["value"] = self.data[name]
+            msg["is_observed"] = msg["value"] is not None
+
+
+class UnconditionMessenger(Messenger):
+    def _pyro_sample(self, msg):
+        if msg["is_observed"]:
+            msg["is_observed"] = False
+            msg["infer"]["was_observed"] = True
+            msg["infer"]["obs"] = msg["value"]
+            msg["value"] = None
+            msg["done"] = False
+
+
+# ---------------------------------------------------------------------------------------------
+class ScaleMessenger(Messenger):
+    """Multiply the log-probability of enclosed sites (reference: scale_messenger.py:52)."""
+
+    def __init__(self, scale):
+        super().__init__()
+        if isinstance(scale, torch.Tensor):
+            if settings.validation_enabled() and not bool((scale > 0).all()):
+                raise ValueError("Expected scale > 0 but got {}".format(scale))
+        elif not (scale > 0):
+            raise ValueError("Expected scale > 0 but got {}".format(scale))
+        self.scale = scale
+
+    def _process_message(self, msg):
+        msg["scale"] = self.scale * msg["scale"]
+
+
+class MaskMessenger(Messenger):
+    """Mask the log-probability of enclosed sites (reference: mask_messenger.py:39)."""
+
+    def __init__(self, mask):
+        super().__init__()
+        if isinstance(mask, torch.Tensor):
+            if mask.dtype != torch.bool:
+                raise ValueError("Expected mask to be a BoolTensor but got {}".format(type(mask)))
+        elif mask not in (True, False):
+            raise ValueError("Expected mask to be a boolean but got {}".format(type(mask)))
+        self.mask = mask
+
+    def _process_message(self, msg):
+        msg["mask"] = self.mask if msg["mask"] is None else msg["mask"] & self.mask
+
+
+def get_mask():
+    """Current mask of the handler stack (used by autoguides)."""
+    msg = new_message("get_mask", "get_mask", None)
+    msg["done"] = True
+    msg["value"] = None
+    apply_stack(msg)
+    return msg["mask"]
+
+
+# ---------------------------------------------------------------------------------------------
+class CondIndepStackFrame(namedtuple("CondIndepStackFrame",
+                                     ["name", "dim", "size", "counter", "full_size"])):
+    @property
+    def vectorized(self):
+        return self.dim is not None
+
+    def __eq__(self, other):
+        return (type(self) is type(other) and self[:-1] == other[:-1]
+                and (self.full_size == other.full_size if not isinstance(self.full_size, torch.Tensor)
+                     else True))
+
+    def __hash__(self):
+        return hash((self.name, self.dim, self.size, self.counter))
+
+    def __str__(self):
+        return self.name
+
+
+class _Subsample:
+    """The distribution-like object behind a plate's subsample site."""
+
+    def __init__(self, size, subsample_size, device):
+        self.size, self.subsample_size, self.device = size, subsample_size, device
+        self.has_rsample = False
+        self.batch_shape = torch.Size()
+        self.event_shape = torch.Size()
+
+    def __call__(self, sample_shape=torch.Size()):
+        ss = self.subsample_size
+        if ss is None or ss >= self.size:
+            return torch.arange(self.size, device=self.device)
+        return torch.randperm(self.size, device=self.device)[:ss].clone()
+
+    def log_prob(self, x):
+        return torch.tensor(0.0, device=self.device)
+
+
+class PlateMessenger(Messenger):
+    """pyro.plate: conditional independence + subsampling scale + automatic broadcasting
+    (reference: indep_messenger.py:47-147, subsample_messenger.py:74-217,
+    broadcast_messenger.py:46-93, plate_messenger.py:17)."""
+
+    def __init__(self, name, size=None, subsample_size=None, subsample=None, dim=None,
+                 use_cuda=None, device=None):
+        super().__init__()
+        if size is None:
+            assert subsample_size is None and subsample is None
+            size = -1
+            subsample_size = -1
+        else:
+            if not isinstance(size, numbers.Number) or size <= 0:
+                if not isinstance(size, torch.Tensor):
+                    raise ValueError("size must be a positive number, got {}".format(size))
+            if use_cuda is not None:
+                device = "cuda" if use_cuda else "cpu"
+            msg = new_message("sample", name, _Subsample(size, subsample_size, device),
+                              value=subsample)
+            apply_stack(msg)
+            subsample = msg["value"]
+            if subsample_size is None:
+                subsample_size = len(subsample)
+            elif subsample is not None and subsample_size != len(subsample):
+                raise ValueError("subsample_size does not match len(subsample), {} vs {}. Did you "
+                                 "accidentally use different subsample_size in the model and "
+                                 "guide?".format(subsample_size, len(subsample)))
+        if size == 0:
+            raise ZeroDivisionError("size cannot be zero")
+        self.name, self.size, self.subsample_size = name, size, subsample_size
+        self.dim, self.device = dim, device
+        self._indices = subsample
+        self._vectorized = None
+        self.counter = 0
+        self._installed = False
+
+    @property
+    def indices(self):
+        if self._indices is None:
+            self._indices = torch.arange(self.size, device=self.device)
+        return self._indices
+
+    def __enter__(self):
+        if self._vectorized is not False:
+            self._vectorized = True
+        if self._vectorized is True:
+            self.dim = _DIM_ALLOCATOR.allocate(self.name, self.dim)
+        if settings.validation_enabled():
+            self._check_no_conflict()
+        super().__enter__()
+        return self.indices
+
+    def __exit__(self, *args):
+        if self._vectorized is True:
+            _DIM_ALLOCATOR.free(self.name, self.dim)
+        return super().__exit__(*args)
+
+    def _check_no_conflict(self):
+        pass
+
+    def __iter__(self):
+        # sequential plate
+        if self._vectorized is True or self.dim is not None:
+            raise ValueError("cannot use plate {} as both vectorized and non-vectorized "
+                             "independence context".format(self.name))
+        self._vectorized = False
+        self.dim = None
+        with_ = self
+        for i in self.indices:
+            self.counter += 1
+            with with_:
+                yield i if isinstance(i, numbers.Number) else i.item()
+
+    def _reset(self):
+        if self._vectorized:
+            try:
+                _DIM_ALLOCATOR.free(self.name, self.dim)
+            except Exception:
+                pass
+        self._vectorized = None
+        self.counter = 0
+
+    def _process_message(self, msg):
+        frame = CondIndepStackFrame(self.name, self.dim if self._vectorized else None,
+                                    self.subsample_size, self.counter, self.size)
+        msg["cond_indep_stack"] = (frame,) + msg["cond_indep_stack"]
+        if self.size != self.subsample_size:
+            msg["scale"] = msg["scale"] * self.size / self.subsample_size
+        # broadcasting: expand the distribution's batch shape to the plate sizes
+        if msg["type"] == "sample" and self._vectorized and not msg["done"] \
+                and not isinstance(msg["fn"], _Subsample):
+            self._broadcast(msg, frame)
+
+    @staticmethod
+    def _broadcast(msg, frame):
+        dist = msg["fn"]
+        if not hasattr(dist, "batch_shape") or msg["infer"].get("_enumerate_dim") is not None \
+                and False:
+            return
+        actual = list(dist.batch_shape)
+        target = list(actual)
+        if frame.dim is None:
+            return
+        k = -frame.dim
+        if len(target) < k:
+            target = [1] * (k - len(target)) + target
+        if target[-k] == 1 and frame.size != 1 and frame.size != -1:
+            target[-k] = frame.size
+        elif target[-k] != frame.size and frame.size != -1:
+            raise ValueError(
+                "Shape mismatch inside plate('{}') at site {} dim {}, {} vs {}".format(
+                    frame.name, msg["name"], frame.dim, frame.size, target[-k]))
+        if target != actual:
+            msg["fn"] = dist.expand(torch.Size(target))
+
+    def _postprocess_message(self, msg):
+        if msg["type"] in ("param", "subsample") and self.dim is not None \
+                and self.subsample_size != self.size and self.subsample_size != -1:
+            event_dim = msg["kwargs"].get("event_dim")
+            if event_dim is not None:
+                dim = self.dim - event_dim
+                shape = msg["value"].shape
+                if len(shape) >= -dim and shape[dim] != 1:
+                    if settings.validation_enabled() and shape[dim] != self.size:
+                        raise ValueError("Inside pyro.plate({}, {}, dim={}) invalid shape of {}: {}"
+                                         .format(self.name, self.size, self.dim, msg["name"],
+                                                 tuple(shape)))
+                    value = msg["value"]
+                    new_value = value.index_select(dim, self._indices.to(value.device))
+                    if msg["type"] == "param":
+                        param = getattr(value, "_pyro_unconstrained_param", None)
+                        if param is None and hasattr(value, "unconstrained"):
+                            param = value.unconstrained()
+                        new_value._pyro_unconstrained_param = param
+                    msg["value"] = new_value
+
+
+# ---------------------------------------------------------------------------------------------
+class EnumMessenger(Messenger):
+    """Parallel enumeration of discrete sample sites marked infer={"enumerate": "parallel"}
+    (reference: enum_messenger.py:114-254): the site's value becomes its support on a fresh tensor
+    dim to the left of every plate; the support indices are int64 and exact."""
+
+    def __init__(self, first_available_dim=None):
+        super().__init__()
+        assert first_available_dim is None or first_available_dim < 0
+        self.first_available_dim = first_available_dim
+
+    def __enter__(self):
+        if self.first_available_dim is not None:
+            _ENUM_ALLOCATOR.set_first_available_dim(self.first_available_dim)
+        self._dims = {}
+        return super().__enter__()
+
+    def _pyro_sample(self, msg):
+        if msg["done"] or not isinstance(msg["fn"], torch.distributions.Distribution):
+            return
+        if msg["is_observed"]:
+            return
+        strategy = msg["infer"].get("enumerate")
+        if strategy != "parallel":
+            if strategy == "sequential":
+                raise NotImplementedError("sequential enumeration is not supported by this "
+                                          "backend; use infer={'enumerate': 'parallel'}")
+            return
+        dist = msg["fn"]
+        if not getattr(dist, "has_enumerate_support", False):
+            raise NotImplementedError("{} does not support enumeration".format(type(dist)))
+        value = dist.enumerate_support(expand=False)
+        dim, id_ = _ENUM_ALLOCATOR.allocate()
+        event_dim = len(dist.event_shape)
+        # move the support axis (currently leftmost of value) to tensor dim `dim`
+        target_len = -dim + event_dim
+        shape = value.shape
+        extra = target_len - len(shape)
+        tag = getattr(value, "_pyro_categorical_support", None)
+        if extra > 0:
+            value = value.reshape(shape[:1] + (1,) * extra + shape[1:])
+        if tag is not None:
+            value._pyro_categorical_support = tag
+        msg["infer"]["_enumerate_dim"] = dim
+        msg["infer"]["_dim_to_id"] = {dim: id_}
+        msg["value"] = value
+        msg["done"] = True
+
+
+# ---------------------------------------------------------------------------------------------
+class SeedMessenger(Messenger):
+    """Run the wrapped program under a fixed RNG seed, restoring the state afterwards."""
+
+    def __init__(self, rng_seed):
+        super().__init__()
+        assert isinstance(rng_seed, int)
+        self.rng_seed = rng_seed
+
+    def __enter__(self):
+        self.old_state = _rng.get_rng_state()
+        _rng.set_rng_seed(self.rng_seed)
+        return super().__enter__()
+
+    def __exit__(self, *args):
+        _rng.set_rng_state(self.old_state)
+        return super().__exit__(*args)
+
+
+# ---------------------------------------------------------------------------------------------
+def _make_handler(cls):
+    def handler(fn=None, *args, **kwargs):
+        if fn is not None and not (callable(fn) or isinstance(fn, (list, tuple))):
+            raise ValueError("{} is not callable, did you mean to pass it as a keyword arg?"
+                             .format(fn))
+        m = cls(*args, **kwargs)
+        return m(fn) if fn is not None else m
+
+    handler.__name__ = cls.__name__.replace("Messenger", "").lower()
+    handler.__doc__ = cls.__doc__
+    return handler
+
+
+trace = _make_handler(TraceMessenger)
+replay = _make_handler(ReplayMessenger)
+block = _make_handler(BlockMessenger)
+condition = _make_handler(ConditionMessenger)
+uncondition = _make_handler(UnconditionMessenger)
+scale = _make_handler(ScaleMessenger)
+mask = _make_handler(MaskMessenger)
+enum = _make_handler(EnumMessenger)
+seed = _make_handler(SeedMessenger)

@@ -1,0 +1,107 @@
+"""User-facing primitives: sample / param / plate / factor / deterministic
+(reference: pyro/primitives.py:57-91,125-192,283-389)."""
+import warnings
+
+import torch
+
+from . import distributions as dist
+from . import rng
+from .params import _PARAM_STORE
+from .poutine import settings as _poutine_settings
+from .poutine.handlers import PlateMessenger
+from .poutine.runtime import am_i_wrapped, apply_stack, new_message
+
+
+def get_param_store():
+    return _PARAM_STORE
+
+
+def clear_param_store():
+    _PARAM_STORE.clear()
+
+
+def set_rng_seed(seed):
+    rng.set_rng_seed(seed)
+
+
+def enable_validation(is_validate=True):
+    dist.enable_validation(is_validate)
+    _poutine_settings.enable_validation(is_validate)
+
+
+class validation_enabled:
+    def __init__(self, is_validate=True):
+        self.is_validate = is_validate
+
+    def __enter__(self):
+        self.prev = (dist.is_validation_enabled(), _poutine_settings.validation_enabled())
+        enable_validation(self.is_validate)
+
+    def __exit__(self, *a):
+        dist.enable_validation(self.prev[0])
+        _poutine_settings.enable_validation(self.prev[1])
+
+
+def sample(name, fn, *args, obs=None, obs_mask=None, infer=None, **kwargs):
+    """Sample (or observe) a value at a named site."""
+    infer = {} if infer is None else infer.copy()
+    is_observed = infer.pop("is_observed", obs is not None)
+    if obs_mask is not None:
+        raise NotImplementedError("obs_mask is not supported; use poutine.mask")
+    if not am_i_wrapped():
+        if obs is not None and not infer.get("_deterministic"):
+            warnings.warn("trying to observe a value outside of inference at " + name,
+                          RuntimeWarning)
+            return obs
+        return fn(*args, **kwargs)
+    msg = new_message("sample", name, fn, args, kwargs, obs, is_observed, infer)
+    apply_stack(msg)
+    return msg["value"]
+
+
+def factor(name, log_factor, *, has_rsample=None):
+    unit = dist.Unit(log_factor, has_rsample=has_rsample)
+    unit_value = unit.sample()
+    sample(name, unit, obs=unit_value, infer={"is_auxiliary": True})
+
+
+def deterministic(name, value, event_dim=None):
+    event_dim = value.dim() if event_dim is None else event_dim
+    return sample(name, dist.Delta(value, event_dim=event_dim).mask(False), obs=value,
+                  infer={"_deterministic": True})
+
+
+def param(name, init_tensor=None, constraint=dist.constraints.real, event_dim=None):
+    """Fetch (creating on first use) a named learnable parameter."""
+    def fn(*a, **kw):
+        return _PARAM_STORE.get_param(name, init_tensor, constraint, event_dim)
+
+    if not am_i_wrapped():
+        return fn()
+    msg = new_message("param", name, fn, (), {"event_dim": event_dim})
+    apply_stack(msg)
+    return msg["value"]
+
+
+class plate(PlateMessenger):
+    """Conditional-independence context, vectorised (``with``) or sequential (``for``)."""
+
+
+def plate_stack(prefix, sizes, rightmost_dim=-1):
+    from contextlib import ExitStack
+
+    class _Stack(ExitStack):
+        def __enter__(self_):
+            super().__enter__()
+            for i, size in enumerate(reversed(sizes)):
+                self_.enter_context(plate("{}_{}".format(prefix, i), size, dim=rightmost_dim - i))
+            return self_
+
+    return _Stack()
+
+
+def module(name, nn_module, update_module_params=False):
+    """Register every parameter of a torch.nn.Module in the param store (by identity)."""
+    for pname, p in nn_module.named_parameters():
+        param("{}$$${}".format(name, pname), p)
+    return nn_module

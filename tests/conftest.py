@@ -19,3 +19,16 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch):
+    """Route pyro_amd.kernels to the numpy oracle (TEST-ONLY; see tests/oracle_backend.py)."""
+    import pyro_amd
+    from tests import oracle_backend as ob
+
+    ob.install(monkeypatch)
+    pyro_amd.clear_param_store()
+    pyro_amd.set_rng_seed(0)
+    yield
+    pyro_amd.clear_param_store()

@@ -1,0 +1,424 @@
+"""Generate the golden vectors under tests/golden/ by running the UNMODIFIED reference
+(pyro-ppl/pyro 1.9.1 at /root/reference) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is pure Python, so it cannot travel to the GPU box; the vectors it produces do.
+`opt_einsum` (absent third-party dependency) is replaced by the stand-in in oracle/refshim.
+Randomness of the reference is pinned by intercepting its normal draws
+(torch.distributions.utils._standard_normal) / its pyro.sample calls inside NUTS, so that the
+same numbers can be injected into the oracle and into the HIP path.
+All reference computations run in float64 on CPU unless a case says float32.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, "oracle", "refshim"))  # after `import torch` on purpose
+sys.path.insert(0, "/root/reference")
+
+import pyro  # noqa: E402
+import pyro.distributions as dist  # noqa: E402
+import pyro.poutine as poutine  # noqa: E402
+from pyro.infer import SVI, Trace_ELBO  # noqa: E402
+from pyro.infer.autoguide import AutoNormal  # noqa: E402
+from pyro.distributions import constraints  # noqa: E402
+
+assert pyro.__version__ == "1.9.1"
+
+
+class EpsBank:
+    """Replaces torch's standard-normal draw by a pre-generated bank, recording what was used."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.used = []
+
+    def __call__(self, shape, dtype, device):
+        e = self.rng.standard_normal(tuple(shape))
+        self.used.append(e)
+        return torch.as_tensor(e, dtype=dtype, device=device)
+
+    def __enter__(self):
+        import torch.distributions.normal as tn
+        self._old = tn._standard_normal
+        tn._standard_normal = self
+        return self
+
+    def __exit__(self, *a):
+        import torch.distributions.normal as tn
+        tn._standard_normal = self._old
+
+
+def grads_of_store():
+    out = {}
+    for name, p in pyro.get_param_store().named_parameters():
+        out[name] = None if p.grad is None else p.grad.detach().clone().numpy()
+    return out
+
+
+def save(name, **arrays):
+    flat = {}
+    for k, v in arrays.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[k + "/" + kk] = np.asarray(vv)
+        elif isinstance(v, (list, tuple)) and len(v) and isinstance(v[0], np.ndarray):
+            for i, vv in enumerate(v):
+                flat["%s/%03d" % (k, i)] = vv
+        else:
+            flat[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print("wrote", path, {k: np.asarray(v).shape for k, v in flat.items()})
+
+
+# ---------------------------------------------------------------------------------------------
+# G9: log_prob known answers for every fused family (reference distributions, float64)
+# ---------------------------------------------------------------------------------------------
+def g_dists():
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(0)
+    out = {}
+    v = rng.standard_normal((4, 7)); a = rng.standard_normal((1, 7)); b = rng.uniform(0.5, 2, (4, 1))
+    out["normal"] = dict(v=v, a=a, b=b, lp=dist.Normal(torch.tensor(a), torch.tensor(b)).log_prob(torch.tensor(v)).numpy())
+    y = (rng.uniform(size=(4, 7)) < 0.5).astype(float); l = 5 * rng.standard_normal((4, 7))
+    out["bernoulli_logits"] = dict(v=y, a=l, lp=dist.Bernoulli(logits=torch.tensor(l)).log_prob(torch.tensor(y)).numpy())
+    v = np.abs(rng.standard_cauchy((4, 7))); s = rng.uniform(0.5, 30, (1, 7))
+    out["half_cauchy"] = dict(v=v, a=s, lp=dist.HalfCauchy(torch.tensor(s)).log_prob(torch.tensor(v)).numpy())
+    v = np.exp(rng.standard_normal((4, 7)))
+    out["log_normal"] = dict(v=v, a=a, b=b, lp=dist.LogNormal(torch.tensor(a), torch.tensor(b)).log_prob(torch.tensor(v)).numpy())
+    v = rng.exponential(size=(4, 7)); r = rng.uniform(0.5, 2, (4, 1))
+    out["exponential"] = dict(v=v, a=r, lp=dist.Exponential(torch.tensor(r)).log_prob(torch.tensor(v)).numpy())
+    v = np.abs(rng.standard_normal((4, 7)))
+    out["half_normal"] = dict(v=v, a=b, lp=dist.HalfNormal(torch.tensor(b)).log_prob(torch.tensor(v)).numpy())
+    flat = {}
+    for fam, d in out.items():
+        for k, x in d.items():
+            flat[fam + "/" + k] = x
+    # scale_and_mask (pyro/distributions/util.py:311-328)
+    from pyro.distributions.util import scale_and_mask
+    x = rng.standard_normal((4, 7)); m = rng.uniform(size=(4, 7)) < 0.6
+    flat["scale_and_mask/x"] = x
+    flat["scale_and_mask/mask"] = m
+    flat["scale_and_mask/out"] = scale_and_mask(torch.tensor(x), 2.5, torch.tensor(m)).numpy()
+    save("dists", **flat)
+
+
+# ---------------------------------------------------------------------------------------------
+# G1: eight schools (examples/eight_schools/svi.py:20-64 verbatim model/guide; guide inits fixed)
+# ---------------------------------------------------------------------------------------------
+J = 8
+Y = torch.tensor([28.0, 8, -3, 7, -1, 1, 18, 12])
+SIGMA = torch.tensor([15.0, 10, 16, 11, 9, 11, 10, 18])
+
+
+def es_model(data):
+    y = data[:, 0]
+    sigma = data[:, 1]
+    with pyro.plate("data", J):
+        eta = pyro.sample("eta", dist.Normal(torch.zeros(J), torch.ones(J)))
+        mu = pyro.sample("mu", dist.Normal(torch.zeros(1), 10 * torch.ones(1)))
+        tau = pyro.sample("tau", dist.HalfCauchy(scale=25 * torch.ones(1)))
+        theta = mu + tau * eta
+        pyro.sample("obs", dist.Normal(theta, sigma), obs=y)
+
+
+def es_guide_factory(inits):
+    def guide(data):
+        m_eta = pyro.param("loc_eta", inits["loc_eta"].clone())
+        s_eta = pyro.param("scale_eta", inits["scale_eta"].clone(), constraint=constraints.positive)
+        m_mu = pyro.param("loc_mu", inits["loc_mu"].clone())
+        s_mu = pyro.param("scale_mu", inits["scale_mu"].clone(), constraint=constraints.positive)
+        m_lt = pyro.param("loc_logtau", inits["loc_logtau"].clone())
+        s_lt = pyro.param("scale_logtau", inits["scale_logtau"].clone(), constraint=constraints.positive)
+        dist_tau = dist.TransformedDistribution(dist.Normal(m_lt, s_lt),
+                                                transforms=dist.transforms.ExpTransform())
+        with pyro.plate("data", J):
+            pyro.sample("eta", dist.Normal(m_eta, s_eta))
+            pyro.sample("mu", dist.Normal(m_mu, s_mu))
+            pyro.sample("tau", dist_tau)
+    return guide
+
+
+def g_eight_schools():
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(1)
+    inits = {"loc_eta": torch.tensor(rng.standard_normal(J)),
+             "scale_eta": torch.tensor(0.1 * rng.uniform(0.2, 1, J)),
+             "loc_mu": torch.tensor(rng.standard_normal(1)),
+             "scale_mu": torch.tensor(0.1 * rng.uniform(0.2, 1, 1)),
+             "loc_logtau": torch.tensor(rng.standard_normal(1)),
+             "scale_logtau": torch.tensor(0.1 * rng.uniform(0.2, 1, 1))}
+    data = torch.stack([Y.double(), SIGMA.double()], dim=1)
+    pyro.clear_param_store()
+    guide = es_guide_factory(inits)
+    svi = SVI(es_model, guide, pyro.optim.Adam({"lr": 0.01}), loss=Trace_ELBO())
+    losses = []
+    with EpsBank(11) as bank:
+        # step 0: loss and grads at the initial parameters
+        loss0 = Trace_ELBO().loss_and_grads(es_model, guide, data)
+        g0 = grads_of_store()
+        for p in pyro.get_param_store()._params.values():
+            p.grad = None
+        n_first = len(bank.used)
+        for _ in range(30):
+            losses.append(svi.step(data))
+    final = {k: v.detach().numpy() for k, v in pyro.get_param_store().items()}
+    save("eight_schools", inits={k: v.numpy() for k, v in inits.items()}, loss0=loss0, grads0=g0,
+         eps=[e for e in bank.used], n_eps_first=n_first, losses=np.array(losses), final=final)
+
+
+# ---------------------------------------------------------------------------------------------
+# G2: Bayesian logistic regression with AutoNormal, vectorised particles
+# ---------------------------------------------------------------------------------------------
+def logreg_model(X, y):
+    N, D = X.shape
+    w = pyro.sample("w", dist.Normal(torch.zeros(D, dtype=X.dtype), 1.0).to_event(1))
+    b = pyro.sample("b", dist.Normal(torch.zeros((), dtype=X.dtype), 1.0))
+    with pyro.plate("data", N):
+        logits = w @ X.t()
+        logits = logits.squeeze(-2) if logits.dim() > 1 else logits
+        pyro.sample("obs", dist.Bernoulli(logits=logits + b), obs=y)
+
+
+def g_logreg():
+    for tag, dtype, N, D, P in [("f64", torch.float64, 1000, 32, 64), ("f32", torch.float32, 4096, 32, 64),
+                                ("p1", torch.float64, 257, 5, 1)]:
+        torch.set_default_dtype(dtype)
+        rng = np.random.default_rng(5)
+        X = rng.standard_normal((N, D))
+        w_true = rng.standard_normal(D)
+        y = (rng.uniform(size=N) < 1 / (1 + np.exp(-X @ w_true))).astype(float)
+        Xt, yt = torch.tensor(X, dtype=dtype), torch.tensor(y, dtype=dtype)
+        pyro.clear_param_store()
+        guide = AutoNormal(logreg_model, init_scale=0.1)
+        elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+        with EpsBank(3) as bank:
+            loss = elbo.loss_and_grads(logreg_model, guide, Xt, yt)
+        grads = grads_of_store()
+        params = {k: v.detach().clone().numpy() for k, v in pyro.get_param_store().items()}
+        # second evaluation after moving the parameters (non-trivial locs)
+        with torch.no_grad():
+            for name, p in pyro.get_param_store().named_parameters():
+                p.add_(torch.tensor(np.random.default_rng(9).standard_normal(p.shape) * 0.3, dtype=dtype))
+                p.grad = None
+        params2 = {k: v.detach().clone().numpy() for k, v in pyro.get_param_store().items()}
+        with EpsBank(4) as bank2:
+            loss2 = elbo.loss_and_grads(logreg_model, guide, Xt, yt)
+        grads2 = grads_of_store()
+        save("logreg_" + tag, X=X, y=y, P=P, loss=loss, grads=grads, params=params,
+             eps=list(bank.used), loss2=loss2, grads2=grads2, params2=params2, eps2=list(bank2.used))
+
+
+# ---------------------------------------------------------------------------------------------
+# G3: subsampling scale + mask + poutine.scale semantics (trace_struct.py:264-278,
+#     subsample_messenger.py:159-174) on a small plated model; G4: score-function guide site
+# ---------------------------------------------------------------------------------------------
+def g_scale_mask():
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(7)
+    N, B = 50, 20
+    data = torch.tensor(rng.standard_normal(N) + 1.0)
+    mask = torch.tensor(rng.uniform(size=N) < 0.7)
+    idx = torch.tensor(rng.permutation(N)[:B])
+
+    def model(data, mask, idx):
+        loc = pyro.sample("loc", dist.Normal(0.0, 2.0))
+        with poutine.scale(scale=0.5):
+            s = pyro.sample("s", dist.LogNormal(0.0, 0.3))
+        with pyro.plate("data", N, subsample=idx) as ind:
+            with poutine.mask(mask=mask[ind]):
+                pyro.sample("obs", dist.Normal(loc, s), obs=data[ind])
+
+    def guide(data, mask, idx):
+        ql = pyro.param("ql", torch.tensor(0.3))
+        qs = pyro.param("qs", torch.tensor(0.2), constraint=constraints.positive)
+        sl = pyro.param("sl", torch.tensor(-0.1))
+        ss = pyro.param("ss", torch.tensor(0.15), constraint=constraints.positive)
+        pyro.sample("loc", dist.Normal(ql, qs))
+        with poutine.scale(scale=0.5):
+            pyro.sample("s", dist.LogNormal(sl, ss))
+        with pyro.plate("data", N, subsample=idx):
+            pass
+
+    pyro.clear_param_store()
+    with EpsBank(21) as bank:
+        loss = Trace_ELBO().loss_and_grads(model, guide, data, mask, idx)
+    save("scale_mask", data=data.numpy(), mask=mask.numpy(), idx=idx.numpy(), loss=loss,
+         grads=grads_of_store(), eps=list(bank.used))
+
+    # score-function (non-reparameterised) guide site with a plate: test_gradient.py:38-127 style
+    from pyro.distributions.testing import fakes
+
+    def model2(data):
+        with pyro.plate("p", 3):
+            z = pyro.sample("z", dist.Normal(torch.zeros(3), 1.0))
+            with pyro.plate("d", 4):
+                pyro.sample("x", dist.Normal(z, 0.7), obs=data)
+
+    def guide2(data):
+        loc = pyro.param("loc", torch.tensor([0.1, -0.2, 0.4]))
+        sc = pyro.param("sc", torch.tensor([0.9, 1.1, 0.8]), constraint=constraints.positive)
+        with pyro.plate("p", 3):
+            pyro.sample("z", fakes.NonreparameterizedNormal(loc, sc))
+
+    data2 = torch.tensor(rng.standard_normal((4, 3)))
+    zval = torch.tensor(rng.standard_normal(3))
+    pyro.clear_param_store()
+    fixed = poutine.trace(poutine.condition(guide2, data={"z": zval})).get_trace(data2)
+    # make the conditioned site a latent again so replay accepts it
+    fixed.nodes["z"]["is_observed"] = False
+    loss_sf = Trace_ELBO().loss_and_grads(model2, poutine.replay(guide2, trace=fixed), data2)
+    save("score_function", data=data2.numpy(), z=zval.numpy(), loss=loss_sf, grads=grads_of_store())
+
+
+# ---------------------------------------------------------------------------------------------
+# G5: integrator known answers (tests/ops/test_integrator.py:40-180 systems) through the
+#     reference's velocity_verlet
+# ---------------------------------------------------------------------------------------------
+def g_integrator():
+    torch.set_default_dtype(torch.float64)
+    from pyro.ops.integrator import velocity_verlet
+    out = {}
+    # harmonic oscillator: U = 0.5 q^2, unit mass
+    cases = {"harmonic": (lambda q: 0.5 * q["x"] ** 2, 0.0, 1.0, 0.01, 628),
+             "quartic": (lambda q: 0.25 * q["x"].pow(4), 0.02, 0.0, 0.1, 810)}
+    for name, (pot, q0, p0, eps, n) in cases.items():
+        z = {"x": torch.tensor(q0)}
+        r = {"x": torch.tensor(p0)}
+        zf, rf, gf, pe = velocity_verlet(z, r, lambda q: pot(q).sum(), lambda p: {"x": p["x"]}, eps, n)
+        out[name] = dict(q0=q0, p0=p0, eps=eps, n=n, qf=zf["x"].item(), pf=rf["x"].item(), pe=pe.item())
+    # 100-dim correlated Gaussian, diagonal inverse mass, a few steps
+    rng = np.random.default_rng(2)
+    D = 100
+    A = rng.standard_normal((D, D))
+    Lam = np.linalg.inv(A @ A.T / D + 0.1 * np.eye(D))
+    Lam = 0.5 * (Lam + Lam.T)
+    Lt = torch.tensor(Lam)
+    im = torch.tensor(rng.uniform(0.5, 2.0, D))
+    z = {"x": torch.tensor(rng.standard_normal(D))}
+    r = {"x": torch.tensor(rng.standard_normal(D))}
+    zf, rf, gf, pe = velocity_verlet({k: v.clone() for k, v in z.items()}, {k: v.clone() for k, v in r.items()},
+                                     lambda q: 0.5 * q["x"] @ Lt @ q["x"],
+                                     lambda p: {"x": im * p["x"]}, 0.05, 7)
+    flat = {}
+    for k, d in out.items():
+        for kk, vv in d.items():
+            flat[k + "/" + kk] = vv
+    flat.update({"gauss/Lambda": Lam, "gauss/inv_mass": im.numpy(), "gauss/z0": z["x"].numpy(),
+                 "gauss/r0": r["x"].numpy(), "gauss/zf": zf["x"].numpy(), "gauss/rf": rf["x"].numpy(),
+                 "gauss/gf": gf["x"].numpy(), "gauss/pe": pe.item(), "gauss/eps": 0.05, "gauss/n": 7})
+    save("integrator", **flat)
+
+
+# ---------------------------------------------------------------------------------------------
+# G6: reference NUTS transitions on the Gaussian potential with intercepted pyro.sample calls
+# ---------------------------------------------------------------------------------------------
+def g_nuts():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer.mcmc import NUTS
+    rng = np.random.default_rng(3)
+    flat = {}
+    for case, (D, multinomial, step, n_trans) in {"d10_multi": (10, True, 0.35, 6),
+                                                  "d100_multi": (100, True, 0.12, 4),
+                                                  "d10_slice": (10, False, 0.3, 6)}.items():
+        A = rng.standard_normal((D, D))
+        Lam = np.linalg.inv(A @ A.T / D + 0.1 * np.eye(D))
+        Lam = 0.5 * (Lam + Lam.T)
+        Lt = torch.tensor(Lam)
+        inv_mass = rng.uniform(0.5, 1.5, D)
+
+        def potential_fn(z):
+            return 0.5 * z["x"] @ Lt @ z["x"]
+
+        kernel = NUTS(potential_fn=potential_fn, step_size=step, adapt_step_size=False,
+                      adapt_mass_matrix=False, use_multinomial_sampling=multinomial, max_tree_depth=6)
+        z0 = torch.tensor(rng.standard_normal(D) * 0.5)
+        kernel.initial_params = {"x": z0}
+        kernel.setup(0)
+        kernel.mass_matrix_adapter.inverse_mass_matrix = {("x",): torch.tensor(inv_mass)}
+        drawn = {"u": [], "slice": [], "mom": []}
+        real_sample = pyro.sample
+
+        def fake_sample(name, fn, *a, **k):
+            if name.startswith("r_"):
+                e = rng.standard_normal(D)
+                drawn["mom"].append(e)
+                return torch.tensor(e)
+            if name.startswith("slicevar"):
+                e = float(rng.exponential())
+                drawn["slice"].append(e)
+                return torch.tensor(e)
+            u = float(rng.uniform())
+            drawn["u"].append(u)
+            if name.startswith("rand"):
+                return torch.tensor(u)
+            # Bernoulli sites: direction / is_other_half_tree; sample() == (rand < probs)
+            p = fn.probs
+            return (torch.tensor(u) < p).to(p.dtype)
+
+        pyro.sample = fake_sample
+        try:
+            params = {"x": z0}
+            zs, marks = [], []
+            for t in range(n_trans):
+                params = kernel.sample(params)
+                zs.append(params["x"].numpy().copy())
+                marks.append((len(drawn["u"]), len(drawn["slice"])))
+        finally:
+            pyro.sample = real_sample
+        flat.update({case + "/Lambda": Lam, case + "/inv_mass": inv_mass, case + "/z0": z0.numpy(),
+                     case + "/step": step, case + "/multinomial": multinomial,
+                     case + "/zs": np.array(zs), case + "/mom": np.array(drawn["mom"]),
+                     case + "/u": np.array(drawn["u"]), case + "/slice": np.array(drawn["slice"]),
+                     case + "/marks": np.array(marks), case + "/max_tree_depth": 6})
+    save("nuts_reference", **flat)
+
+
+# ---------------------------------------------------------------------------------------------
+# G8: warm-up adaptation: schedule, dual averaging, Welford (adaptation.py:65-202,
+#     ops/dual_averaging.py:55-78, ops/welford.py:27-52)
+# ---------------------------------------------------------------------------------------------
+def g_adaptation():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer.mcmc.adaptation import WarmupAdapter
+    from pyro.ops.dual_averaging import DualAveraging
+    from pyro.ops.welford import WelfordCovariance
+    flat = {}
+    for w in (10, 19, 20, 100, 150, 200, 1000):
+        ad = WarmupAdapter(adapt_step_size=True, adapt_mass_matrix=True)
+        ad._warmup_steps = w
+        sched = ad._build_adaptation_schedule()
+        flat["schedule/%d" % w] = np.array([[s.start, s.end] for s in sched])
+    rng = np.random.default_rng(4)
+    da = DualAveraging(prox_center=math.log(10 * 0.3))
+    gs = rng.uniform(-0.5, 0.5, 50)
+    xs = []
+    for g in gs:
+        da.step(float(g))
+        xs.append(da.get_state())
+    flat["dual/g"] = gs
+    flat["dual/x"] = np.array(xs)
+    flat["dual/prox_center"] = math.log(10 * 0.3)
+    wc = WelfordCovariance(diagonal=True)
+    samples = rng.standard_normal((40, 6)) * np.arange(1, 7)
+    for s in samples:
+        wc.update(torch.tensor(s))
+    flat["welford/samples"] = samples
+    flat["welford/cov_reg"] = wc.get_covariance(regularize=True).numpy()
+    flat["welford/cov"] = wc.get_covariance(regularize=False).numpy()
+    save("adaptation", **flat)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
+                             "adaptation"]
+    for w in which:
+        globals()["g_" + w]()

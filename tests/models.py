@@ -1,0 +1,215 @@
+"""Model/guide definitions and golden-comparison drivers shared by the CPU (oracle-backed) and
+GPU (HIP-backed) test suites.  Models are the reference's, written against the drop-in API."""
+import numpy as np
+import torch
+
+import pyro_amd as pyro
+import pyro_amd.distributions as dist
+import pyro_amd.poutine as poutine
+from pyro_amd.distributions import constraints
+from pyro_amd.infer import SVI, Trace_ELBO
+from pyro_amd.infer.autoguide import AutoNormal
+
+
+class EpsReplay:
+    """Feeds the reference's recorded normal draws to pyro_amd.rng.normal, in order."""
+
+    def __init__(self, eps_list, device):
+        self.eps = list(eps_list)
+        self.device = device
+        self.i = 0
+
+    def __call__(self, shape, dtype, device):
+        e = self.eps[self.i]
+        self.i += 1
+        assert tuple(e.shape) == tuple(shape), (e.shape, tuple(shape))
+        return torch.as_tensor(e, dtype=dtype, device=self.device)
+
+
+def store_grads():
+    return {name: (None if p.grad is None else p.grad.detach().cpu().numpy().copy())
+            for name, p in pyro.get_param_store().named_parameters()}
+
+
+def _eps_of(g, prefix):
+    return [g[k] for k in sorted(k for k in g.files if k.startswith(prefix + "/"))]
+
+
+def assert_grads(got, g, prefix, rtol):
+    for name, val in got.items():
+        ref = g[prefix + "/" + name]
+        sc = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(val, ref, rtol=rtol, atol=rtol * sc, err_msg=name)
+
+
+# ---- eight schools (examples/eight_schools/svi.py:20-64) ----------------------------------------
+J = 8
+
+
+def es_model(data):
+    y = data[:, 0]
+    sigma = data[:, 1]
+    with pyro.plate("data", J):
+        eta = pyro.sample("eta", dist.Normal(torch.zeros(J, device=data.device), torch.ones(J, device=data.device)))
+        mu = pyro.sample("mu", dist.Normal(torch.zeros(1, device=data.device), 10 * torch.ones(1, device=data.device)))
+        tau = pyro.sample("tau", dist.HalfCauchy(scale=25 * torch.ones(1, device=data.device)))
+        theta = mu + tau * eta
+        pyro.sample("obs", dist.Normal(theta, sigma), obs=y)
+
+
+def es_guide_factory(inits):
+    def guide(data):
+        m_eta = pyro.param("loc_eta", inits["loc_eta"].clone())
+        s_eta = pyro.param("scale_eta", inits["scale_eta"].clone(), constraint=constraints.positive)
+        m_mu = pyro.param("loc_mu", inits["loc_mu"].clone())
+        s_mu = pyro.param("scale_mu", inits["scale_mu"].clone(), constraint=constraints.positive)
+        m_lt = pyro.param("loc_logtau", inits["loc_logtau"].clone())
+        s_lt = pyro.param("scale_logtau", inits["scale_logtau"].clone(), constraint=constraints.positive)
+        dist_tau = dist.LogNormal(m_lt, s_lt)  # == TransformedDistribution(Normal, ExpTransform)
+        with pyro.plate("data", J):
+            pyro.sample("eta", dist.Normal(m_eta, s_eta))
+            pyro.sample("mu", dist.Normal(m_mu, s_mu))
+            pyro.sample("tau", dist_tau)
+    return guide
+
+
+def run_eight_schools(g, device, monkeypatch, rtol, optim_factory=None):
+    from pyro_amd import rng
+    dtype = torch.get_default_dtype()
+    y = torch.tensor([28.0, 8, -3, 7, -1, 1, 18, 12], dtype=dtype, device=device)
+    sigma = torch.tensor([15.0, 10, 16, 11, 9, 11, 10, 18], dtype=dtype, device=device)
+    data = torch.stack([y, sigma], dim=1)
+    inits = {k.split("/")[1]: torch.as_tensor(g[k], dtype=dtype, device=device)
+             for k in g.files if k.startswith("inits/")}
+    pyro.clear_param_store()
+    guide = es_guide_factory(inits)
+    replay = EpsReplay(_eps_of(g, "eps"), device)
+    monkeypatch.setattr(rng, "normal", replay)
+    loss0 = Trace_ELBO().loss_and_grads(es_model, guide, data)
+    np.testing.assert_allclose(loss0, float(g["loss0"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads0", rtol * 10)
+    assert replay.i == int(g["n_eps_first"])
+    for p in pyro.get_param_store()._params.values():
+        p.grad = None
+    optim = optim_factory() if optim_factory else pyro.optim.Adam({"lr": 0.01})
+    svi = SVI(es_model, guide, optim, loss=Trace_ELBO())
+    losses = [svi.step(data) for _ in range(len(g["losses"]))]
+    np.testing.assert_allclose(losses, g["losses"], rtol=rtol * 100)
+    for name, value in pyro.get_param_store().items():
+        np.testing.assert_allclose(value.detach().cpu().numpy(), g["final/" + name], rtol=rtol * 1000,
+                                   atol=rtol * 1000)
+
+
+# ---- Bayesian logistic regression ------------------------------------------
+def logreg_model(X, y):
+    """The reference formulation: materialised logits through torch ops."""
+    N, D = X.shape
+    w = pyro.sample("w", dist.Normal(torch.zeros(D, dtype=X.dtype, device=X.device), 1.0).to_event(1))
+    b = pyro.sample("b", dist.Normal(torch.zeros((), dtype=X.dtype, device=X.device), 1.0))
+    with pyro.plate("data", N):
+        logits = w @ X.t()
+        logits = logits.squeeze(-2) if logits.dim() > 1 else logits
+        pyro.sample("obs", dist.Bernoulli(logits=logits + b), obs=y)
+
+
+def logreg_model_fused(X, y):
+    """Same model; the logits stay lazy so the observed site runs the fused one-pass GLM kernel."""
+    N, D = X.shape
+    w = pyro.sample("w", dist.Normal(torch.zeros(D, dtype=X.dtype, device=X.device), 1.0).to_event(1))
+    b = pyro.sample("b", dist.Normal(torch.zeros((), dtype=X.dtype, device=X.device), 1.0))
+    with pyro.plate("data", N):
+        pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
+
+
+def run_logreg(g, device, monkeypatch, fused, dtype, rtol):
+    from pyro_amd import rng
+    from pyro_amd.distributions import families
+    if fused and dtype == torch.float64:
+        # the HIP GLM kernel is f32-only; in f64 host-logic tests the oracle GLM answers instead
+        monkeypatch.setattr(families._BernoulliLinear, "_allow_f64", True, raising=False)
+    X = torch.as_tensor(g["X"], dtype=dtype, device=device)
+    y = torch.as_tensor(g["y"], dtype=dtype, device=device)
+    P = int(g["P"])
+    model = logreg_model_fused if fused else logreg_model
+    pyro.clear_param_store()
+    guide = AutoNormal(model, init_scale=0.1)
+    elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+    guide._setup_prototype(X, y)  # initialisation draws happen before the recorded ones
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps"), device))
+    loss = elbo.loss_and_grads(model, guide, X, y)
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads", rtol * 10)
+    # second evaluation at the moved parameters of the golden run
+    store = pyro.get_param_store()
+    with torch.no_grad():
+        for name in list(store.keys()):
+            store[name] = torch.as_tensor(g["params2/" + name], dtype=dtype, device=device)
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps2"), device))
+    loss2 = elbo.loss_and_grads(model, guide, X, y)
+    np.testing.assert_allclose(loss2, float(g["loss2"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads2", rtol * 10)
+
+
+# ---- scale / mask / subsample ---------------------------------------------------------------------
+def run_scale_mask(g, device, monkeypatch, rtol):
+    from pyro_amd import rng
+    dtype = torch.get_default_dtype()
+    data = torch.as_tensor(g["data"], dtype=dtype, device=device)
+    mask = torch.as_tensor(g["mask"], device=device)
+    idx = torch.as_tensor(g["idx"], device=device)
+    N = data.shape[0]
+
+    def model(data, mask, idx):
+        loc = pyro.sample("loc", dist.Normal(torch.tensor(0.0, device=device), 2.0))
+        with poutine.scale(scale=0.5):
+            s = pyro.sample("s", dist.LogNormal(torch.tensor(0.0, device=device), 0.3))
+        with pyro.plate("data", N, subsample=idx) as ind:
+            with poutine.mask(mask=mask[ind]):
+                pyro.sample("obs", dist.Normal(loc, s), obs=data[ind])
+
+    def guide(data, mask, idx):
+        ql = pyro.param("ql", torch.tensor(0.3, device=device))
+        qs = pyro.param("qs", torch.tensor(0.2, device=device), constraint=constraints.positive)
+        sl = pyro.param("sl", torch.tensor(-0.1, device=device))
+        ss = pyro.param("ss", torch.tensor(0.15, device=device), constraint=constraints.positive)
+        pyro.sample("loc", dist.Normal(ql, qs))
+        with poutine.scale(scale=0.5):
+            pyro.sample("s", dist.LogNormal(sl, ss))
+        with pyro.plate("data", N, subsample=idx):
+            pass
+
+    pyro.clear_param_store()
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps"), device))
+    loss = Trace_ELBO().loss_and_grads(model, guide, data, mask, idx)
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads", rtol * 10)
+
+
+# ---- score-function guide site (non-reparameterised) ----------------------------------------------
+class NonreparameterizedNormal(dist.Normal):
+    has_rsample = False
+
+
+def run_score_function(g, device, rtol):
+    dtype = torch.get_default_dtype()
+    data = torch.as_tensor(g["data"], dtype=dtype, device=device)
+    zval = torch.as_tensor(g["z"], dtype=dtype, device=device)
+
+    def model2(data):
+        with pyro.plate("p", 3):
+            z = pyro.sample("z", dist.Normal(torch.zeros(3, device=device), 1.0))
+            with pyro.plate("d", 4):
+                pyro.sample("x", dist.Normal(z, 0.7), obs=data)
+
+    def guide2(data):
+        loc = pyro.param("loc", torch.tensor([0.1, -0.2, 0.4], device=device))
+        sc = pyro.param("sc", torch.tensor([0.9, 1.1, 0.8], device=device), constraint=constraints.positive)
+        with pyro.plate("p", 3):
+            pyro.sample("z", NonreparameterizedNormal(loc, sc))
+
+    pyro.clear_param_store()
+    fixed = poutine.trace(poutine.condition(guide2, data={"z": zval})).get_trace(data)
+    fixed.nodes["z"]["is_observed"] = False
+    loss = Trace_ELBO().loss_and_grads(model2, poutine.replay(guide2, trace=fixed), data)
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads", rtol * 10)

@@ -1,0 +1,141 @@
+"""TEST-ONLY seam: replaces the functions of pyro_amd.kernels by numpy-oracle implementations so
+the HOST logic (handlers, ELBO assembly, optimizers, MCMC drivers) can be exercised on a machine
+without a GPU.  Installed by the ``oracle_backend`` fixture through monkeypatch; the product
+package never imports this module and has no CPU path of its own.
+"""
+import numpy as np
+import torch
+
+from oracle import adam as o_adam
+from oracle import dists as o_dists
+from oracle import glm as o_glm
+from oracle import integrator as o_int
+from oracle import lda as o_lda
+from oracle import nuts as o_nuts
+from oracle import philox as o_philox
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def _bc(t, rows, cols):
+    return None if t is None else np.broadcast_to(_np(t), (rows, cols))
+
+
+def philox_normal(shape, dtype, device, seed, offset):
+    n = int(np.prod(shape)) if len(shape) else 1
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    return torch.as_tensor(o_philox.normal(n, np_dt, seed, offset).reshape(shape), device=device)
+
+
+def philox_uniform(shape, dtype, device, seed, offset):
+    n = int(np.prod(shape)) if len(shape) else 1
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    return torch.as_tensor(o_philox.uniform(n, np_dt, seed, offset).reshape(shape), device=device)
+
+
+def dist_log_prob(dist_id, value, p0, p1, rows, cols):
+    out = o_dists.LOG_PROB[dist_id](_bc(value, rows, cols).astype(np.float64),
+                                    _bc(p0, rows, cols).astype(np.float64),
+                                    None if p1 is None else _bc(p1, rows, cols).astype(np.float64))
+    return torch.as_tensor(np.ascontiguousarray(out), dtype=value.dtype)
+
+
+def dist_log_prob_sum(dist_id, value, p0, p1, mask, scale, rows, cols):
+    out = o_dists.log_prob_sum(dist_id, _bc(value, rows, cols).astype(np.float64),
+                               _bc(p0, rows, cols).astype(np.float64),
+                               None if p1 is None else _bc(p1, rows, cols).astype(np.float64),
+                               _bc(mask, rows, cols), scale)
+    return torch.as_tensor(np.ascontiguousarray(out), dtype=value.dtype)
+
+
+def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need):
+    v = _bc(value, rows, cols).astype(np.float64)
+    a = _bc(p0, rows, cols).astype(np.float64)
+    b = None if p1 is None else _bc(p1, rows, cols).astype(np.float64)
+    dv, da, db = o_dists.log_prob_grad(dist_id, v, a, b)
+    w = _bc(g, rows, cols).astype(np.float64) * scale
+    m = _bc(mask, rows, cols)
+    outs = []
+    for d, n in zip((dv, da, db), need):
+        if not n:
+            outs.append(None)
+            continue
+        x = w * np.broadcast_to(d, (rows, cols))
+        if m is not None:
+            x = np.where(m, x, 0.0)
+        outs.append(torch.as_tensor(np.ascontiguousarray(x), dtype=value.dtype))
+    return outs
+
+
+def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
+    ll, gw, gb = o_glm.glm_bernoulli_fwd_bwd(_np(X), _np(y), _np(w), _np(b), _np(mask), scale)
+    return (torch.as_tensor(ll, dtype=X.dtype), torch.as_tensor(gw, dtype=X.dtype),
+            torch.as_tensor(gb, dtype=X.dtype))
+
+
+def leapfrog_kick_drift(z, r, grad, inv_mass, step):
+    st = _np(step).reshape(-1, 1) if step.dim() == 1 else _np(step)
+    rn = _np(r) + 0.5 * st * (-_np(grad))
+    r.copy_(torch.as_tensor(rn))
+    z.copy_(torch.as_tensor(_np(z) + st * (_np(inv_mass) * rn)))
+
+
+def leapfrog_kick(r, grad, step):
+    st = _np(step).reshape(-1, 1) if step.dim() == 1 else _np(step)
+    r.copy_(torch.as_tensor(_np(r) + 0.5 * st * (-_np(grad))))
+
+
+def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth, use_multinomial,
+                             seed, t):
+    C, D = z.shape
+    np_dt = np.float32 if z.dtype == torch.float32 else np.float64
+    pg = o_int.gaussian_potential(_np(Lambda).astype(np.float64))
+    ap = np.zeros(C)
+    ints = np.zeros((4, C), np.int32)
+    zn, pen, gn = _np(z).copy(), _np(pe).copy(), _np(grad).copy()
+    for c in range(C):
+        out = o_nuts.nuts_transition(zn[c].astype(np.float64), float(pen[c]), gn[c].astype(np.float64),
+                                     pg, _np(inv_mass)[c].astype(np.float64), float(_np(step)[c]),
+                                     o_nuts.KeyedDraws(seed, c, t, np_dt), max_tree_depth,
+                                     bool(use_multinomial))
+        zn[c], pen[c], gn[c] = out["z"], out["pe"], out["grad"]
+        ap[c] = out["accept_prob"]
+        ints[:, c] = (out["n_leapfrog"], out["depth"], out["diverging"], out["accepted"])
+    z.copy_(torch.as_tensor(zn)); pe.copy_(torch.as_tensor(pen)); grad.copy_(torch.as_tensor(gn))
+    ti = torch.as_tensor(ints)
+    return {"accept_prob": torch.as_tensor(ap, dtype=z.dtype), "n_leapfrog": ti[0], "depth": ti[1],
+            "diverging": ti[2], "accepted": ti[3]}
+
+
+def lda_factor_fwd_bwd(words, log_theta, log_phi):
+    out, gt, gp = o_lda.lda_factor(_np(words), _np(log_theta), _np(log_phi))
+    dt = log_theta.dtype
+    return torch.as_tensor(out, dtype=dt), torch.as_tensor(gt, dtype=dt), torch.as_tensor(gp, dtype=dt)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
+              weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True):
+    step = int(step_dev.item()) + 1
+    p, m, v = o_adam.adam_step(_np(param), _np(grad), _np(exp_avg), _np(exp_avg_sq), step, lr, betas,
+                               eps, weight_decay, clip_norm, lrd, clipped)
+    param.data.copy_(torch.as_tensor(p)); exp_avg.copy_(torch.as_tensor(m))
+    exp_avg_sq.copy_(torch.as_tensor(v))
+    step_dev += 1
+    if zero_grad:
+        grad.zero_()
+
+
+FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
+             "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
+             "nuts_gaussian_transition", "lda_factor_fwd_bwd", "adam_step"]
+
+
+def install(monkeypatch):
+    import pyro_amd.kernels as k
+    g = globals()
+    for name in FUNCTIONS:
+        monkeypatch.setattr(k, name, g[name])
+    # the product refuses CPU tensors; lift that check for host-logic tests only
+    monkeypatch.setattr(k, "_require_gpu", lambda *a: None)

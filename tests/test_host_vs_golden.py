@@ -1,0 +1,43 @@
+"""Host logic (handlers, Trace_ELBO assembly, autoguide, SVI, flat Adam) against the golden
+vectors of the unmodified reference, with the kernels answered by the numpy oracle
+(tests/oracle_backend.py).  The same test bodies run on the GPU through the real HIP kernels in
+tests/test_svi_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import models
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(autouse=True)
+def _cpu_backend(oracle_backend):
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def test_eight_schools_loss_grads_and_trajectory(monkeypatch):
+    models.run_eight_schools(load("eight_schools"), torch.device("cpu"), monkeypatch, rtol=1e-9)
+
+
+@pytest.mark.parametrize("tag,fused", [("f64", False), ("p1", False), ("f64", True), ("p1", True)])
+def test_logreg_loss_and_grads(monkeypatch, tag, fused):
+    # fused=True exercises the LinearLogits -> glm kernel route (oracle GLM here, f64 arithmetic)
+    models.run_logreg(load("logreg_" + tag), torch.device("cpu"), monkeypatch, fused=fused,
+                      dtype=torch.float64, rtol=1e-9)
+
+
+def test_scale_mask_subsample(monkeypatch):
+    models.run_scale_mask(load("scale_mask"), torch.device("cpu"), monkeypatch, rtol=1e-9)
+
+
+def test_score_function_guide(monkeypatch):
+    models.run_score_function(load("score_function"), torch.device("cpu"), rtol=1e-9)

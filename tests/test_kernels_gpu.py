@@ -253,7 +253,7 @@ def _gauss_problem(D, seed=0):
     return Sigma, 0.5 * (Lam + Lam.T)
 
 
-@pytest.mark.parametrize("D,multinomial", [(5, True), (100, True), (70, False), (128, True)])
+@pytest.mark.parametrize("D,multinomial", [(5, True), (100, True), (70, False), (120, True)])
 def test_nuts_gaussian_f64_matches_recursive_oracle(gpu, D, multinomial):
     """float64: the iterative one-wave-per-chain kernel must reproduce the recursive reference
     formulation chain by chain (identical tree sizes / accept decisions, positions to 1e-9)."""
