@@ -67,6 +67,14 @@ const char* pa_last_error(void);
 /* number of compute units of the current device (host-side query used for grid sizing) */
 int pa_device_cu_count(void);
 
+/* Measurement hook: the NEXT launch (on the calling thread) of the dominant kernel named by
+ * `kernel_tag` is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on the
+ * stream it is launched on (only that kernel, not its finalize / helper launches).
+ * ev_start / ev_stop are hipEvent_t handles owned by the caller. Used by bench.py to
+ * measure kernel time inside the timed region without a profiler. */
+enum { PA_KERNEL_GLM = 1, PA_KERNEL_NUTS = 2, PA_KERNEL_LDA = 3, PA_KERNEL_SITE_SUM = 4 };
+int pa_profile_bracket_next(int kernel_tag, void* ev_start, void* ev_stop);
+
 /* ------------------------------------------------------------------------------------
  * RNG: counter-based Philox4x32-10. out[i] depends only on (seed, offset, i) so a draw
  * is reproducible for any launch geometry and shardable across ranks by offset.

@@ -22,6 +22,8 @@ DIST_LOG_NORMAL = 3
 DIST_EXPONENTIAL = 4
 DIST_HALF_NORMAL = 5
 
+KERNEL_GLM, KERNEL_NUTS, KERNEL_LDA, KERNEL_SITE_SUM = 1, 2, 3, 4
+
 
 class View2D(Structure):
     _fields_ = [("ptr", c_void_p), ("stride_row", c_int64), ("stride_col", c_int64)]
@@ -38,6 +40,7 @@ _SIGNATURES = {
     "pa_abi_version": (c_int, []),
     "pa_last_error": (c_char_p, []),
     "pa_device_cu_count": (c_int, []),
+    "pa_profile_bracket_next": (c_int, [c_int, c_void_p, c_void_p]),
     "pa_philox_normal": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "pa_philox_uniform": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "pa_counter_add": (c_int, [c_void_p, c_uint64, c_void_p]),

@@ -18,6 +18,8 @@ int fail(int code, const char* fmt, ...);
 // hipGetLastError() after a launch -> PA_ERR_LAUNCH
 int check_launch(const char* what);
 int cu_count();
+// true (and the two events) if pa_profile_bracket_next(tag, ...) is pending on this thread
+bool take_bracket(int tag, hipEvent_t* start, hipEvent_t* stop);
 
 #define PA_REQUIRE(cond, ...)                                  \
   do {                                                         \

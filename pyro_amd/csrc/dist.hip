@@ -272,10 +272,14 @@ static int log_prob_sum_t(int dist, T* out, pa_view2d value, pa_view2d p0, pa_vi
   PA_REQUIRE(rows * bx < (int64_t(1) << 31), "log_prob_sum: grid too large");
   auto v = as_view<T>(value), a = as_view<T>(p0), b = as_view<T>(p1);
   auto m = as_view<uint8_t>(mask);
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_SITE_SUM, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
   PA_DISPATCH_DIST(dist, T,
                    hipLaunchKernelGGL((log_prob_sum_kernel<D_, T>), dim3((unsigned)(rows * bx)),
                                       dim3(DIST_THREADS), 0, s, ws, v, a, b, m, (T)scale, rows,
                                       cols, bx, iters));
+  if (br) (void)hipEventRecord(ev1, s);
   int rc = check_launch("log_prob_sum_kernel");
   if (rc != PA_OK) return rc;
   hipLaunchKernelGGL((rowsum_finalize_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,

@@ -308,6 +308,9 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
                       float* ll, float* gw, float* gb, float* part, hipStream_t s) {
   const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   dim3 grid((unsigned)pl.nblocks, (unsigned)pl.npass), block(64 * GLM_WAVES);
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
   if (vec4) {
     auto k = glm_bernoulli_kernel<DT, PT, true>;
     if (pl.lds_bytes > 48 * 1024)
@@ -321,6 +324,7 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
                                 (int)pl.lds_bytes);
     hipLaunchKernelGGL(k, grid, block, pl.lds_bytes, s, X, y, w, b, mask, N, D, P, pl.iters, part);
   }
+  if (br) (void)hipEventRecord(ev1, s);
   int rc = check_launch("glm_bernoulli_kernel");
   if (rc != PA_OK) return rc;
   const int64_t J = (int64_t)P * D + 2 * P;

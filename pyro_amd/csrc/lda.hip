@@ -138,8 +138,12 @@ static int lda_launch(const int64_t* words, const T* log_theta, const T* log_phi
   T* part = (T*)((char*)ws + 256);
   hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), s);
   if (e != hipSuccess) return fail(PA_ERR_LAUNCH, "lda_factor: memset: %s", hipGetErrorString(e));
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_LDA, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
   hipLaunchKernelGGL(k, dim3(nb), dim3(LDA_THREADS), lds, s, words, log_theta, log_phi, Wd, B, Tn,
                      V, out_doc, g_theta, part, bad);
+  if (br) (void)hipEventRecord(ev1, s);
   int rc = check_launch("lda_factor_kernel");
   if (rc != PA_OK) return rc;
   const int64_t n = (int64_t)Tn * V;

@@ -338,8 +338,12 @@ static int nuts_launch(T* z, T* pe, T* grad, const T* Lambda, const T* inv_mass,
       return fail(PA_ERR_LAUNCH, "nuts_gaussian: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int grid = (C + WPB - 1) / WPB;
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), lds, s, z, pe, grad, Lambda, inv_mass, step, C,
                      D, max_depth, multinomial, seed, t, ap, nl, dp, dv, ac);
+  if (br) (void)hipEventRecord(ev1, s);
   return check_launch("nuts_gaussian_kernel");
 }
 

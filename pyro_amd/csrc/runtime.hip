@@ -40,9 +40,32 @@ int cu_count() {
   return n;
 }
 
+// one-shot event bracket requested through pa_profile_bracket_next()
+static thread_local int g_br_tag = 0;
+static thread_local hipEvent_t g_br_start = nullptr, g_br_stop = nullptr;
+
+bool take_bracket(int tag, hipEvent_t* start, hipEvent_t* stop) {
+  if (g_br_tag != tag || g_br_start == nullptr) return false;
+  *start = g_br_start;
+  *stop = g_br_stop;
+  g_br_tag = 0;
+  g_br_start = g_br_stop = nullptr;
+  return true;
+}
+
 }  // namespace pa
 
 extern "C" {
+
+int pa_profile_bracket_next(int kernel_tag, void* ev_start, void* ev_stop) {
+  PA_REQUIRE(kernel_tag >= 1 && kernel_tag <= 4, "profile_bracket_next: unknown kernel tag %d",
+             kernel_tag);
+  PA_REQUIRE(ev_start && ev_stop, "profile_bracket_next: NULL event");
+  pa::g_br_tag = kernel_tag;
+  pa::g_br_start = (hipEvent_t)ev_start;
+  pa::g_br_stop = (hipEvent_t)ev_stop;
+  return PA_OK;
+}
 
 int pa_abi_version(void) { return PA_ABI_VERSION; }
 const char* pa_last_error(void) { return pa::g_err; }

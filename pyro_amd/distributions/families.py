@@ -17,7 +17,9 @@ def _maskable(mask):
     return mask is None or isinstance(mask, torch.Tensor)
 
 
-class _FusedElementwise(TorchDistributionMixin):
+class _FusedElementwise:
+    """Overrides that must precede the torch class in the MRO (torch defines log_prob too)."""
+
     _dist_id = None
 
     def _params(self):
@@ -38,7 +40,7 @@ class _FusedElementwise(TorchDistributionMixin):
         return fused.log_prob_sum(self._dist_id, value, p0, p1, mask, scale)
 
 
-class Normal(torch.distributions.Normal, _FusedElementwise):
+class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMixin):
     _dist_id = _lib.DIST_NORMAL
 
     def _params(self):
@@ -54,7 +56,7 @@ class Normal(torch.distributions.Normal, _FusedElementwise):
             return self.rsample(sample_shape)
 
 
-class LogNormal(torch.distributions.LogNormal, _FusedElementwise):
+class LogNormal(_FusedElementwise, torch.distributions.LogNormal, TorchDistributionMixin):
     _dist_id = _lib.DIST_LOG_NORMAL
 
     def _params(self):
@@ -70,7 +72,7 @@ class LogNormal(torch.distributions.LogNormal, _FusedElementwise):
             return self.rsample(sample_shape)
 
 
-class HalfCauchy(torch.distributions.HalfCauchy, _FusedElementwise):
+class HalfCauchy(_FusedElementwise, torch.distributions.HalfCauchy, TorchDistributionMixin):
     _dist_id = _lib.DIST_HALF_CAUCHY
 
     def _params(self):
@@ -82,7 +84,7 @@ class HalfCauchy(torch.distributions.HalfCauchy, _FusedElementwise):
         return fused.log_prob(self._dist_id, value, self.scale, None)
 
 
-class HalfNormal(torch.distributions.HalfNormal, _FusedElementwise):
+class HalfNormal(_FusedElementwise, torch.distributions.HalfNormal, TorchDistributionMixin):
     _dist_id = _lib.DIST_HALF_NORMAL
 
     def _params(self):
@@ -94,7 +96,7 @@ class HalfNormal(torch.distributions.HalfNormal, _FusedElementwise):
         return (eps * self.scale).abs()
 
 
-class Exponential(torch.distributions.Exponential, _FusedElementwise):
+class Exponential(_FusedElementwise, torch.distributions.Exponential, TorchDistributionMixin):
     _dist_id = _lib.DIST_EXPONENTIAL
 
     def _params(self):
@@ -211,7 +213,7 @@ class _BernoulliLinear(TorchDistribution):
         return ll.sum()
 
 
-class Bernoulli(torch.distributions.Bernoulli, _FusedElementwise):
+class Bernoulli(_FusedElementwise, torch.distributions.Bernoulli, TorchDistributionMixin):
     """Bernoulli; with ``logits=`` given, log_prob runs the fused -BCE-with-logits kernel
     (torch: torch/distributions/bernoulli.py:121-125)."""
 

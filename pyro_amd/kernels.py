@@ -53,6 +53,36 @@ def _view(t, rows, cols):
 
 
 # ------------------------------------------------------------------------------------------
+# measurement hook
+# ------------------------------------------------------------------------------------------
+
+class KernelTimer:
+    """Collects HIP-event brackets around launches of one dominant kernel (bench.py).
+    ``arm()`` before the launching call; ``mean_ms()`` after a device synchronise."""
+
+    def __init__(self, kernel_tag):
+        self.tag = kernel_tag
+        self.pairs = []
+
+    def arm(self):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        # torch creates the underlying hipEvent lazily on first record; force creation
+        s.record()
+        e.record()
+        check(_lib.load().pa_profile_bracket_next(self.tag, ctypes.c_void_p(s.cuda_event),
+                                                  ctypes.c_void_p(e.cuda_event)))
+        self.pairs.append((s, e))
+
+    def times_ms(self):
+        return [s.elapsed_time(e) for s, e in self.pairs]
+
+    def mean_ms(self):
+        t = self.times_ms()
+        return sum(t) / len(t) if t else float("nan")
+
+
+# ------------------------------------------------------------------------------------------
 # RNG
 # ------------------------------------------------------------------------------------------
 

@@ -1,0 +1,67 @@
+"""The C-ABI shared library loads (no GPU needed) and exports exactly what include/pyro_amd.h
+declares; the ctypes binding covers every declared entry point; the product fails loudly
+without a GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "pyro_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_vs_binding_vs_library():
+    from pyro_amd import _lib
+    from pyro_amd.csrc.build import build_library
+
+    build_library()
+    declared = header_functions()
+    assert declared, "no declarations parsed"
+    assert declared == _lib.exported_symbols()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True,
+                         check=True).stdout
+    exported = sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\b", out)))
+    assert exported == declared
+    lib = _lib.load()
+    assert lib.pa_abi_version() == 1
+
+
+def test_no_torch_types_in_abi():
+    src = open(os.path.join(ROOT, "include", "pyro_amd.h")).read()
+    assert "at::" not in src and "torch" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    assert 'extern "C"' in src
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_on_cpu_tensors():
+    import pyro_amd.distributions as dist
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dist.Normal(torch.zeros(3), torch.ones(3)).log_prob(torch.zeros(3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dist.Normal(torch.zeros(3), torch.ones(3)).rsample()
+
+
+def test_argument_errors_before_launch():
+    """Error convention: invalid arguments -> ValueError (PA_ERR_INVALID) without touching a device."""
+    import ctypes
+
+    from pyro_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.pa_philox_normal(None, -1, 0, 0, 0, None, None)
+    assert rc == _lib.PA_ERR_INVALID and b"n=" in lib.pa_last_error()
+    rc = lib.pa_glm_bernoulli_fwd_bwd(None, None, None, None, None, 1.0, 10, 200, 4, None, None, None,
+                                      None, 0, None)
+    assert rc == _lib.PA_ERR_UNSUPPORTED
+    with pytest.raises(_lib.Unsupported):
+        _lib.check(rc)
+    assert lib.pa_glm_bernoulli_workspace(10, 200, 4) == 0
+    assert lib.pa_dist_log_prob_sum_workspace(4, 100) > 0
