@@ -203,6 +203,22 @@ class CondIndepStackFrame(namedtuple("CondIndepStackFrame",
         return self.name
 
 
+_ARANGE_CACHE = {}
+
+
+def _cached_arange(size, device):
+    """Index vector of a full (not subsampled) plate.  The reference re-creates
+    torch.arange(size) at every plate entry (subsample_messenger.py:60); for a 1e6..1e7 plate
+    that alone costs milliseconds per step, so it is built once per (size, device)."""
+    key = (int(size), str(device))
+    t = _ARANGE_CACHE.get(key)
+    if t is None:
+        if len(_ARANGE_CACHE) > 64:
+            _ARANGE_CACHE.clear()
+        t = _ARANGE_CACHE[key] = torch.arange(size, device=device)
+    return t
+
+
 class _Subsample:
     """The distribution-like object behind a plate's subsample site."""
 
@@ -215,7 +231,7 @@ class _Subsample:
     def __call__(self, sample_shape=torch.Size()):
         ss = self.subsample_size
         if ss is None or ss >= self.size:
-            return torch.arange(self.size, device=self.device)
+            return _cached_arange(self.size, self.device)
         return torch.randperm(self.size, device=self.device)[:ss].clone()
 
     def log_prob(self, x):
@@ -262,7 +278,7 @@ class PlateMessenger(Messenger):
     @property
     def indices(self):
         if self._indices is None:
-            self._indices = torch.arange(self.size, device=self.device)
+            self._indices = _cached_arange(self.size, self.device)
         return self._indices
 
     def __enter__(self):
