@@ -1,0 +1,37 @@
+#!/bin/bash
+# rocprofv3 recipe used for profiles/: kernel trace + stats, then separate PMC passes.
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd "$R"
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+ARGS="--steps 30 --warmup 5 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python bench.py $ARGS > $OUT/bench_kt.log 2>&1
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE"; do
+  N=$(echo $C | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -o bench -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline $* > $OUT/pmc_$N.log 2>&1
+done
+# keep only what is small: stats + per-kernel aggregates of the counter CSVs
+python - "$OUT" <<'PY'
+import csv, glob, os, sys, collections, json
+out = sys.argv[1]
+summ = {}
+for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            agg[row["Kernel_Name"][:80]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, d in agg.items():
+        for c, v in d.items():
+            summ.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
+    os.remove(f)
+json.dump(summ, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
+for f in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
+    os.remove(f)
+for f in glob.glob(out + "/**/*.db", recursive=True):
+    os.remove(f)
+PY
+du -sh $OUT
