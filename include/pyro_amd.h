@@ -172,7 +172,7 @@ int pa_leapfrog_kick(int dtype, void* r, const void* grad, const void* step, int
  * _build_basetree :197-248, _is_turning :184-195) for C independent chains on the
  * closed-form potential U(z) = 0.5 z^T Lambda z (BASELINE config 3), one wavefront per
  * chain, iterative tree doubling with wave-uniform control flow, all randomness from
- * Philox keyed by (seed, chain, transition t, draw kind, tree position).
+ * Philox keyed by (seed, chain_offset + chain, transition t, draw kind, tree position).
  * State (in/out): z[C,D], pe[C] (potential energy at z), grad[C,D] (Lambda z).
  * Params: Lambda[D,D] symmetric row-major; inv_mass[C,D] diagonal per chain;
  *         step[C]; max_tree_depth <= 10; use_multinomial (1) or slice sampling (0).
@@ -182,8 +182,39 @@ int pa_leapfrog_kick(int dtype, void* r, const void* grad, const void* step, int
 int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const void* Lambda,
                                 const void* inv_mass, const void* step, int64_t C, int64_t D,
                                 int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t,
-                                void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
+                                uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
                                 int32_t* diverging, int32_t* accepted, pa_stream_t stream);
+
+/* NUTS for ARBITRARY potentials, vectorised over chains: the
+ * tree logic of pyro/infer/mcmc/nuts.py:184-522 as a device-resident per-chain state machine.
+ * The caller evaluates the potential energy and its gradient for all chains at the cursor
+ * positions zq[C,D] (a fused likelihood kernel or torch autograd of a chain-batched model,
+ * replacing potential_grad, pyro/ops/integrator.py:68-94); between two evaluations ONE
+ * pa_nuts_tree_advance launch performs, per chain: second half-kick, leaf energies, merges
+ * with parked sibling subtrees (U-turn / divergence / proposal draws), doubling bookkeeping and
+ * the first half-kick + drift of the chain's next leapfrog.  Protocol per transition t:
+ *     pa_nuts_tree_begin(...)                      -> zq, rq hold the first cursor
+ *     do { (peq, gq) = U(zq), dU/dz(zq);  pa_nuts_tree_advance(...); } while (*n_active > 0)
+ * Chains that finished are inactive (cursor frozen); on exit (z, pe, grad) hold each chain's
+ * next state and accept_prob / n_leapfrog / depth / diverging / accepted its statistics.
+ * inv_mass: diagonal, [D] (im_stride_row = 0) or per chain [C,D] (im_stride_row = D).
+ * Randomness: the keyed Philox contract of pa_nuts_gaussian_transition with the chain id
+ * chain_offset + c (so a rank of a chain-sharded job passes its first global chain index).
+ * Supported: D <= 2048. workspace >= pa_nuts_tree_workspace bytes, preserved between calls
+ * of one transition. n_active: device int32, overwritten by every advance call. */
+size_t pa_nuts_tree_workspace(int dtype, int64_t C, int64_t D, int max_tree_depth);
+int pa_nuts_tree_begin(int dtype, const void* z, const void* pe, const void* grad, void* zq,
+                       void* rq, const void* inv_mass, int64_t im_stride_row, const void* step,
+                       int64_t C, int64_t D, int max_tree_depth, int use_multinomial,
+                       uint64_t seed, uint64_t t, uint64_t chain_offset, void* workspace,
+                       size_t workspace_bytes, pa_stream_t stream);
+int pa_nuts_tree_advance(int dtype, void* z, void* pe, void* grad, void* zq, void* rq,
+                         const void* gq, const void* peq, const void* inv_mass,
+                         int64_t im_stride_row, const void* step, int64_t C, int64_t D,
+                         int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t,
+                         uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog,
+                         int32_t* depth, int32_t* diverging, int32_t* accepted, int32_t* n_active,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under

@@ -26,28 +26,11 @@
 //   slot 1025 + j       .x(.y): direction draw of doubling j;  .z(.w): accept draw
 //   slot 2048 + 2^j + id  merge draw of doubling j, id = 2^(j-k) + (i >> k) for the merge
 //                        producing the level-k subtree that ends at leaf i.
-#include "common.h"
+#include "nuts_common.h"
 
 namespace pa {
 
-constexpr int NUTS_MAX_DEPTH = 10;
 constexpr int NUTS_DMAX = 128;
-
-template <typename T> struct Num;
-template <> struct Num<float> {
-  static __device__ __forceinline__ float exp_(float x) { return expf(x); }
-  static __device__ __forceinline__ float log_(float x) { return logf(x); }
-  static __device__ __forceinline__ float log1p_(float x) { return log1pf(x); }
-  static __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
-  static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
-};
-template <> struct Num<double> {
-  static __device__ __forceinline__ double exp_(double x) { return exp(x); }
-  static __device__ __forceinline__ double log_(double x) { return log(x); }
-  static __device__ __forceinline__ double log1p_(double x) { return log1p(x); }
-  static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
-  static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
-};
 
 __device__ __forceinline__ float bcast_lane(float v, int j) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
@@ -58,15 +41,6 @@ __device__ __forceinline__ double bcast_lane(double v, int j) {
   hi = __builtin_amdgcn_readlane(hi, j);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float uni(float v) {
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-}
-__device__ __forceinline__ double uni(double v) {
-  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
 template <typename T> struct P2 {  // a lane's two coordinates (i, i+64)
   T a, b;
 };
@@ -75,20 +49,6 @@ template <typename T> __device__ __forceinline__ P2<T> operator+(P2<T> x, P2<T> 
 }
 template <typename T> __device__ __forceinline__ T dot(P2<T> x, P2<T> y) {
   return uni(wave_sum(x.a * y.a + x.b * y.b));
-}
-
-template <typename T>
-__device__ __forceinline__ T uniform_from(const u32x4& b, int second) {
-  if constexpr (sizeof(T) == 4)
-    return u32_to_unit_f32(second ? b.z : b.x);
-  else
-    return second ? u32x2_to_unit_f64(b.z, b.w) : u32x2_to_unit_f64(b.x, b.y);
-}
-
-template <typename T>
-__device__ __forceinline__ T logaddexp_ref(T x, T y) {  // nuts.py:15-17
-  const T mn = x < y ? x : y, mx = x < y ? y : x;
-  return Num<T>::log1p_(Num<T>::exp_(mn - mx)) + mx;
 }
 
 // g = Lambda z (Lambda symmetric, read as columns), pe = 0.5 z.g
@@ -132,7 +92,7 @@ __global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
     T* __restrict__ z_io, T* __restrict__ pe_io, T* __restrict__ grad_io,
     const T* __restrict__ Lambda, const T* __restrict__ inv_mass, const T* __restrict__ step,
     int C, int D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
-    T* __restrict__ accept_prob_out, int32_t* __restrict__ nleap_out,
+    uint64_t chain_offset, T* __restrict__ accept_prob_out, int32_t* __restrict__ nleap_out,
     int32_t* __restrict__ depth_out, int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ls = reinterpret_cast<T*>(smem_raw);  // [D*D + 128]
@@ -164,7 +124,7 @@ __global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
   const T eps = step[chain];
 
   const uint64_t ctr_base = t << 20;
-  const uint64_t cid = (uint64_t)chain;
+  const uint64_t cid = chain_offset + (uint64_t)chain;
 
   // ---- momentum: r_unscaled ~ N(0, I), r = M^{1/2} r_unscaled (hmc.py:231-248) -----------
   P2<T> ru0;
@@ -325,7 +285,7 @@ __global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
 template <typename T, int WPB>
 static int nuts_launch(T* z, T* pe, T* grad, const T* Lambda, const T* inv_mass, const T* step,
                        int C, int D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
-                       T* ap, int32_t* nl, int32_t* dp, int32_t* dv, int32_t* ac, hipStream_t s) {
+                       uint64_t chain_offset, T* ap, int32_t* nl, int32_t* dp, int32_t* dv, int32_t* ac, hipStream_t s) {
   const size_t lds = ((size_t)D * D + 128 + (size_t)WPB * NUTS_MAX_DEPTH * (3 * 128 + 2)) *
                      sizeof(T);
   if (lds > 160 * 1024)
@@ -342,7 +302,7 @@ static int nuts_launch(T* z, T* pe, T* grad, const T* Lambda, const T* inv_mass,
   const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), lds, s, z, pe, grad, Lambda, inv_mass, step, C,
-                     D, max_depth, multinomial, seed, t, ap, nl, dp, dv, ac);
+                     D, max_depth, multinomial, seed, t, chain_offset, ap, nl, dp, dv, ac);
   if (br) (void)hipEventRecord(ev1, s);
   return check_launch("nuts_gaussian_kernel");
 }
@@ -354,7 +314,7 @@ extern "C" {
 int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const void* Lambda,
                                 const void* inv_mass, const void* step, int64_t C, int64_t D,
                                 int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t,
-                                void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
+                                uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
                                 int32_t* diverging, int32_t* accepted, pa_stream_t stream) {
   PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "nuts_gaussian: bad dtype %d", dtype);
   PA_REQUIRE(C >= 0 && D >= 1, "nuts_gaussian: bad shape C=%lld D=%lld", (long long)C,
@@ -372,18 +332,21 @@ int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const 
   if (dtype == PA_F32)
     return pa::nuts_launch<float, 4>((float*)z, (float*)pe, (float*)grad, (const float*)Lambda,
                                      (const float*)inv_mass, (const float*)step, (int)C, (int)D,
-                                     max_tree_depth, use_multinomial, seed, t, (float*)accept_prob,
+                                     max_tree_depth, use_multinomial, seed, t, chain_offset,
+                                     (float*)accept_prob,
                                      n_leapfrog, depth, diverging, accepted, s);
   const size_t lds2 = ((size_t)D * D + 128 + 2 * (size_t)pa::NUTS_MAX_DEPTH * (3 * 128 + 2)) * 8;
   if (lds2 <= 160 * 1024)
     return pa::nuts_launch<double, 2>((double*)z, (double*)pe, (double*)grad,
                                       (const double*)Lambda, (const double*)inv_mass,
                                       (const double*)step, (int)C, (int)D, max_tree_depth,
-                                      use_multinomial, seed, t, (double*)accept_prob, n_leapfrog,
+                                      use_multinomial, seed, t, chain_offset, (double*)accept_prob,
+                                      n_leapfrog,
                                       depth, diverging, accepted, s);
   return pa::nuts_launch<double, 1>((double*)z, (double*)pe, (double*)grad, (const double*)Lambda,
                                     (const double*)inv_mass, (const double*)step, (int)C, (int)D,
-                                    max_tree_depth, use_multinomial, seed, t, (double*)accept_prob,
+                                    max_tree_depth, use_multinomial, seed, t, chain_offset,
+                                    (double*)accept_prob,
                                     n_leapfrog, depth, diverging, accepted, s);
 }
 

@@ -1,0 +1,515 @@
+// nuts_tree.hip -- NUTS for ARBITRARY potentials, vectorised over chains: the tree logic of
+// pyro/infer/mcmc/nuts.py as a device-resident per-chain state machine.
+//
+// Reference semantics restated (per chain), same citations as nuts.hip:
+//   sample() :367-522, _build_tree() :250-365 (here iterative: the bits of the leaf index are
+//   the merge schedule), _build_basetree() :197-248, _is_turning() :184-195, _logaddexp :15-17,
+//   leapfrog pyro/ops/integrator.py:45-65, momentum hmc.py:231-248 with a diagonal mass matrix
+//   (BlockMassMatrix.scale/unscale/kinetic_grad, adaptation.py:328-392).
+//
+// Division of labour.  The potential energy and its gradient are whatever the caller computes
+// for ALL chains at once at the cursor positions zq[C,D] (a fused likelihood kernel such as
+// pa_glm_bernoulli_fwd_bwd with P = C, or torch autograd of a chain-batched model); between two
+// such evaluations ONE launch of nuts_tree_advance_kernel does, for every chain independently,
+//   second half-kick -> leaf energies / divergence / accept prob -> merges with the parked
+//   sibling subtrees (U-turn checks, multinomial or slice proposal choice) -> doubling
+//   bookkeeping (accept draw, U-turn of the whole tree, next direction) -> first half-kick and
+//   drift of the chain's NEXT leapfrog,
+// so the host loop per leapfrog is {potential(zq) ; advance} with no host decision inside.
+// A chain that has finished its transition is inactive: its cursor no longer moves and its
+// (z, pe, grad) hold the accepted state; the host polls n_active.
+//
+// One workgroup (NW waves) per chain; thread t owns coordinates t, t+NT, ... (NPL of them, in
+// VGPRs), every [C,D] array is read/written fully coalesced, reductions are wave butterflies
+// (+ LDS across waves when NW > 1) in a fixed order => deterministic.  The pending-subtree
+// stack lives in HBM/L2 (4 vectors + 2 scalars per level per chain).
+//
+// Randomness: the SAME keyed Philox contract as nuts.hip (so both kernels, and the recursive
+// oracle, draw identical numbers): counter_lo = t*2^20 + slot, counter_hi = global chain id.
+#include "nuts_common.h"
+
+namespace pa {
+
+template <typename T, int NPL> struct Vec { T x[NPL]; };
+
+enum { FS_ENERGY = 0, FS_LOGSLICE = 1, FS_TREEW = 2, FS_SUMACC = 3, FS_COUNT = 4 };
+enum { IS_ACTIVE = 0, IS_DIR = 1, IS_DEPTH = 2, IS_LEAF = 3, IS_NPROP = 4, IS_ACCEPTED = 5,
+       IS_DIVERGED = 6, IS_COUNT = 8 };
+
+// workspace layout (element counts of T unless noted)
+template <typename T>
+struct TreeWs {
+  T* edges;     // [2][3][C*D]  left{z,r,g}, right{z,r,g}
+  T* r_sum;     // [C*D]
+  T* stack;     // [max_depth][4][C*D]  first_ru, sum_ru, prop_z, prop_g
+  T* stack_s;   // [max_depth][2][C]    weight, prop_pe
+  T* fscal;     // [FS_COUNT][C]
+  int32_t* iscal;  // [IS_COUNT][C]
+};
+static size_t tree_ws_elems(int64_t C, int64_t D, int max_depth) {
+  return (size_t)(6 * C * D + C * D + (int64_t)max_depth * 4 * C * D + (int64_t)max_depth * 2 * C +
+                  FS_COUNT * C);
+}
+template <typename T>
+static TreeWs<T> tree_ws(void* base, int64_t C, int64_t D, int max_depth) {
+  TreeWs<T> w;
+  T* p = (T*)base;
+  w.edges = p; p += 6 * C * D;
+  w.r_sum = p; p += C * D;
+  w.stack = p; p += (int64_t)max_depth * 4 * C * D;
+  w.stack_s = p; p += (int64_t)max_depth * 2 * C;
+  w.fscal = p; p += FS_COUNT * C;
+  w.iscal = (int32_t*)p;
+  return w;
+}
+
+template <typename T, int NW, int NPL>
+struct Chain {
+  static constexpr int NT = 64 * NW;
+  int tid, D;
+  int64_t row;  // chain * D
+  T* red;       // LDS [2*NW]
+  __device__ __forceinline__ bool ok(int m) const { return tid + m * NT < D; }
+  __device__ __forceinline__ Vec<T, NPL> ld(const T* p) const {
+    Vec<T, NPL> v;
+#pragma unroll
+    for (int m = 0; m < NPL; ++m) v.x[m] = ok(m) ? p[row + tid + m * NT] : T(0);
+    return v;
+  }
+  __device__ __forceinline__ void st(T* p, const Vec<T, NPL>& v) const {
+#pragma unroll
+    for (int m = 0; m < NPL; ++m)
+      if (ok(m)) p[row + tid + m * NT] = v.x[m];
+  }
+  // block-wide sums of two per-thread values, identical in every thread, fixed order
+  __device__ __forceinline__ void sum2(T& a, T& b) const {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if constexpr (NW == 1) {
+      a = uni(a);
+      b = uni(b);
+    } else {
+      const int lane = tid & 63, w = tid >> 6;
+      __syncthreads();
+      if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+      __syncthreads();
+      T ta = T(0), tb = T(0);
+#pragma unroll
+      for (int i = 0; i < NW; ++i) { ta += red[2 * i]; tb += red[2 * i + 1]; }
+      a = ta;
+      b = tb;
+    }
+  }
+  __device__ __forceinline__ T dot(const Vec<T, NPL>& a, const Vec<T, NPL>& b) const {
+    T s = T(0), z = T(0);
+#pragma unroll
+    for (int m = 0; m < NPL; ++m) s += a.x[m] * b.x[m];
+    sum2(s, z);
+    return s;
+  }
+  // nuts.py:184-195 (symmetric in first/last)
+  __device__ __forceinline__ bool is_turning(const Vec<T, NPL>& r_first, const Vec<T, NPL>& r_last,
+                                             const Vec<T, NPL>& r_sum) const {
+    T a1 = T(0), a2 = T(0);
+#pragma unroll
+    for (int m = 0; m < NPL; ++m) {
+      const T rho = r_sum.x[m] - (r_first.x[m] + r_last.x[m]) / T(2);
+      a1 += r_first.x[m] * rho;
+      a2 += r_last.x[m] * rho;
+    }
+    sum2(a1, a2);
+    return (a1 <= T(0)) || (a2 <= T(0));
+  }
+};
+
+template <typename T, int NPL>
+__device__ __forceinline__ Vec<T, NPL> vmul(const Vec<T, NPL>& a, const Vec<T, NPL>& b) {
+  Vec<T, NPL> c;
+#pragma unroll
+  for (int m = 0; m < NPL; ++m) c.x[m] = a.x[m] * b.x[m];
+  return c;
+}
+template <typename T, int NPL>
+__device__ __forceinline__ Vec<T, NPL> vadd(const Vec<T, NPL>& a, const Vec<T, NPL>& b) {
+  Vec<T, NPL> c;
+#pragma unroll
+  for (int m = 0; m < NPL; ++m) c.x[m] = a.x[m] + b.x[m];
+  return c;
+}
+
+// first half of a leapfrog on the cursor: r <- r - 0.5 eps g ; z <- z + eps (v . r)
+template <typename T, int NPL>
+__device__ __forceinline__ void kick_drift(Vec<T, NPL>& z, Vec<T, NPL>& r, const Vec<T, NPL>& g,
+                                           const Vec<T, NPL>& v, T eps_d) {
+  const T hk = T(0.5) * eps_d;
+#pragma unroll
+  for (int m = 0; m < NPL; ++m) {
+    r.x[m] = r.x[m] + hk * (-g.x[m]);
+    z.x[m] = z.x[m] + eps_d * (v.x[m] * r.x[m]);
+  }
+}
+
+template <typename T, int NW, int NPL>
+__global__ __launch_bounds__(64 * NW) void nuts_tree_begin_kernel(
+    const T* __restrict__ z, const T* __restrict__ pe, const T* __restrict__ grad,
+    T* __restrict__ zq, T* __restrict__ rq, const T* __restrict__ inv_mass, int64_t im_stride,
+    const T* __restrict__ step, int64_t C, int D, int multinomial, uint64_t seed, uint64_t t,
+    uint64_t chain_offset, TreeWs<T> ws) {
+  __shared__ T red[2 * NW];
+  const int chain = blockIdx.x;
+  Chain<T, NW, NPL> c{(int)threadIdx.x, D, (int64_t)chain * D, red};
+  const int64_t CD = C * D;
+  const uint64_t ctr_base = t << 20, cid = chain_offset + (uint64_t)chain;
+
+  Vec<T, NPL> zc = c.ld(z), gc = c.ld(grad), v, isq, ru0;
+#pragma unroll
+  for (int m = 0; m < NPL; ++m) {
+    const int d = c.tid + m * c.NT;
+    v.x[m] = c.ok(m) ? inv_mass[(int64_t)chain * im_stride + d] : T(1);
+    isq.x[m] = T(1) / Num<T>::sqrt_(v.x[m]);  // mass_matrix_sqrt (adaptation.py:270-282)
+    ru0.x[m] = c.ok(m) ? philox_normal_t<T>(seed, ctr_base, (uint64_t)d, cid) : T(0);
+  }
+  Vec<T, NPL> r0 = vmul(ru0, isq);                              // scale(), adaptation.py:349-373
+  const T energy_current = T(0.5) * c.dot(ru0, ru0) + pe[chain];  // nuts.py:380
+  T log_slice;
+  if (multinomial) {
+    log_slice = -energy_current;
+  } else {
+    const u32x4 b = philox4x32_10(seed, ctr_base + 1024, cid);
+    log_slice = -energy_current - (-Num<T>::log_(uniform_from<T>(b, 0)));  // nuts.py:403-410
+  }
+  // both edges start at the current state
+  for (int e = 0; e < 2; ++e) {
+    c.st(ws.edges + (e * 3 + 0) * CD, zc);
+    c.st(ws.edges + (e * 3 + 1) * CD, r0);
+    c.st(ws.edges + (e * 3 + 2) * CD, gc);
+  }
+  c.st(ws.r_sum, ru0);
+  // first doubling: direction draw, cursor = edge, first half leapfrog
+  const u32x4 bj = philox4x32_10(seed, ctr_base + 1025, cid);
+  const int dir = uniform_from<T>(bj, 0) < T(0.5) ? 1 : -1;
+  const T eps = step[chain];
+  Vec<T, NPL> zn = zc, rn = r0;
+  kick_drift(zn, rn, gc, v, dir == 1 ? eps : -eps);
+  c.st(zq, zn);
+  c.st(rq, rn);
+  if (threadIdx.x == 0) {
+    ws.fscal[FS_ENERGY * C + chain] = energy_current;
+    ws.fscal[FS_LOGSLICE * C + chain] = log_slice;
+    ws.fscal[FS_TREEW * C + chain] = multinomial ? T(0) : T(1);
+    ws.fscal[FS_SUMACC * C + chain] = T(0);
+    ws.iscal[IS_ACTIVE * C + chain] = 1;
+    ws.iscal[IS_DIR * C + chain] = dir;
+    ws.iscal[IS_DEPTH * C + chain] = 0;
+    ws.iscal[IS_LEAF * C + chain] = 0;
+    ws.iscal[IS_NPROP * C + chain] = 0;
+    ws.iscal[IS_ACCEPTED * C + chain] = 0;
+    ws.iscal[IS_DIVERGED * C + chain] = 0;
+  }
+}
+
+template <typename T, int NW, int NPL>
+__global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
+    T* __restrict__ z_io, T* __restrict__ pe_io, T* __restrict__ grad_io, T* __restrict__ zq_io,
+    T* __restrict__ rq_io, const T* __restrict__ gq_in, const T* __restrict__ peq_in,
+    const T* __restrict__ inv_mass, int64_t im_stride, const T* __restrict__ step, int64_t C,
+    int D, int max_depth, int multinomial, uint64_t seed, uint64_t t, uint64_t chain_offset,
+    TreeWs<T> ws, T* __restrict__ accept_prob_out, int32_t* __restrict__ nleap_out,
+    int32_t* __restrict__ depth_out, int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out,
+    int32_t* __restrict__ n_active) {
+  __shared__ T red[2 * NW];
+  const int chain = blockIdx.x;
+  if (ws.iscal[IS_ACTIVE * C + chain] == 0) return;  // block-uniform
+  Chain<T, NW, NPL> c{(int)threadIdx.x, D, (int64_t)chain * D, red};
+  const int64_t CD = C * D;
+  const uint64_t ctr_base = t << 20, cid = chain_offset + (uint64_t)chain;
+
+  const int dir = ws.iscal[IS_DIR * C + chain];
+  int tree_depth = ws.iscal[IS_DEPTH * C + chain];
+  const int i = ws.iscal[IS_LEAF * C + chain];
+  int num_prop = ws.iscal[IS_NPROP * C + chain];
+  const T energy_current = ws.fscal[FS_ENERGY * C + chain];
+  const T log_slice = ws.fscal[FS_LOGSLICE * C + chain];
+  T tree_weight = ws.fscal[FS_TREEW * C + chain];
+  T sum_accept = ws.fscal[FS_SUMACC * C + chain];
+  const T eps = step[chain];
+  const T eps_d = dir == 1 ? eps : -eps;
+  const int j = tree_depth;
+
+  Vec<T, NPL> v, sq;
+#pragma unroll
+  for (int m = 0; m < NPL; ++m) {
+    v.x[m] = c.ok(m) ? inv_mass[(int64_t)chain * im_stride + c.tid + m * c.NT] : T(1);
+    sq.x[m] = Num<T>::sqrt_(v.x[m]);  // mass_matrix_sqrt_inverse
+  }
+  Vec<T, NPL> zq = c.ld(zq_io), rq = c.ld(rq_io), gq = c.ld(gq_in);
+  const T pe_q = peq_in[chain];
+
+  // ---- second half-kick (integrator.py:62-63) and the base tree (nuts.py:197-248) ----------
+  {
+    const T hk = T(0.5) * eps_d;
+#pragma unroll
+    for (int m = 0; m < NPL; ++m) rq.x[m] = rq.x[m] + hk * (-gq.x[m]);
+  }
+  const Vec<T, NPL> ruq = vmul(rq, sq);
+  T energy_new = pe_q + T(0.5) * c.dot(ruq, ruq);
+  if (energy_new != energy_new) energy_new = Num<T>::inf();
+  const T sliced = energy_new + log_slice;
+  const bool leaf_div = sliced > T(1000);
+  T ap = Num<T>::exp_(-(energy_new - energy_current));
+  ap = ap > T(1) ? T(1) : ap;
+  sum_accept += ap;
+  num_prop += 1;
+
+  Vec<T, NPL> b_first = ruq, b_sum = ruq, b_prop = zq, b_propg = gq;
+  T b_w = multinomial ? -sliced : (sliced <= T(0) ? T(1) : T(0));
+  T b_pe = pe_q;
+  bool turning = false;
+  bool finished = false;
+  int diverged = 0;
+  int accepted = ws.iscal[IS_ACCEPTED * C + chain];
+
+  if (leaf_div) {
+    diverged = 1;
+    finished = true;
+  } else {
+    // ---- merge with the parked left siblings (nuts.py:285-342) -----------------------------
+    int k = 0;
+    while ((i >> k) & 1) {
+      const T* e = ws.stack + (int64_t)k * 4 * CD;
+      const Vec<T, NPL> h_first = c.ld(e), h_sum = c.ld(e + CD);
+      const T h_w = ws.stack_s[(2 * k) * C + chain], h_pe = ws.stack_s[(2 * k + 1) * C + chain];
+      T w, prob_other;
+      if (multinomial) {
+        w = logaddexp_ref(h_w, b_w);
+        prob_other = Num<T>::exp_(b_w - w);
+      } else {
+        w = h_w + b_w;
+        prob_other = w > T(0) ? b_w / w : T(0);
+      }
+      const uint64_t id = ((uint64_t)1 << (j - (k + 1))) + (uint64_t)(i >> (k + 1));
+      const u32x4 bm = philox4x32_10(seed, ctr_base + 2048 + ((uint64_t)1 << j) + id, cid);
+      const bool is_other = uniform_from<T>(bm, 0) < prob_other;
+      if (!is_other) {
+        b_prop = c.ld(e + 2 * CD);
+        b_propg = c.ld(e + 3 * CD);
+        b_pe = h_pe;
+      }
+      b_first = h_first;
+      b_sum = vadd(h_sum, b_sum);
+      b_w = w;
+      ++k;
+      if (c.is_turning(b_first, ruq, b_sum)) { turning = true; break; }
+    }
+    if (turning) {
+      finished = true;
+    } else if (i + 1 < (1 << j)) {
+      // park the finished level-k subtree until its right sibling is built; go on leaping
+      T* e = ws.stack + (int64_t)k * 4 * CD;
+      c.st(e, b_first);
+      c.st(e + CD, b_sum);
+      c.st(e + 2 * CD, b_prop);
+      c.st(e + 3 * CD, b_propg);
+      if (threadIdx.x == 0) {
+        ws.stack_s[(2 * k) * C + chain] = b_w;
+        ws.stack_s[(2 * k + 1) * C + chain] = b_pe;
+        ws.iscal[IS_LEAF * C + chain] = i + 1;
+      }
+      kick_drift(zq, rq, gq, v, eps_d);
+      c.st(zq_io, zq);
+      c.st(rq_io, rq);
+    } else {
+      // ---- the doubling is complete (nuts.py:436-503) ---------------------------------------
+      const int e_dir = dir == 1 ? 1 : 0;
+      c.st(ws.edges + (e_dir * 3 + 0) * CD, zq);
+      c.st(ws.edges + (e_dir * 3 + 1) * CD, rq);
+      c.st(ws.edges + (e_dir * 3 + 2) * CD, gq);
+      tree_depth += 1;
+      const T new_tree_prob = multinomial ? Num<T>::exp_(b_w - tree_weight) : b_w / tree_weight;
+      const u32x4 bj = philox4x32_10(seed, ctr_base + 1025 + (uint64_t)j, cid);
+      if (uniform_from<T>(bj, 1) < new_tree_prob) {  // nuts.py:482-492
+        accepted = 1;
+        c.st(z_io, b_prop);
+        c.st(grad_io, b_propg);
+        if (threadIdx.x == 0) pe_io[chain] = b_pe;
+      }
+      Vec<T, NPL> r_sum = vadd(c.ld(ws.r_sum), b_sum);
+      const Vec<T, NPL> ru_other = vmul(c.ld(ws.edges + ((1 - e_dir) * 3 + 1) * CD), sq);
+      if (c.is_turning(ru_other, ruq, r_sum)) {
+        finished = true;
+      } else {
+        tree_weight = multinomial ? logaddexp_ref(tree_weight, b_w) : tree_weight + b_w;
+        if (tree_depth >= max_depth) {
+          finished = true;
+        } else {
+          // next doubling: direction draw, cursor = the edge in that direction
+          c.st(ws.r_sum, r_sum);
+          const u32x4 bn = philox4x32_10(seed, ctr_base + 1025 + (uint64_t)tree_depth, cid);
+          const int ndir = uniform_from<T>(bn, 0) < T(0.5) ? 1 : -1;
+          const int ne = ndir == 1 ? 1 : 0;
+          Vec<T, NPL> zn, rn, gn;
+          if (ne == e_dir) { zn = zq; rn = rq; gn = gq; }
+          else {
+            zn = c.ld(ws.edges + (ne * 3 + 0) * CD);
+            rn = c.ld(ws.edges + (ne * 3 + 1) * CD);
+            gn = c.ld(ws.edges + (ne * 3 + 2) * CD);
+          }
+          kick_drift(zn, rn, gn, v, ndir == 1 ? eps : -eps);
+          c.st(zq_io, zn);
+          c.st(rq_io, rn);
+          if (threadIdx.x == 0) {
+            ws.iscal[IS_DIR * C + chain] = ndir;
+            ws.iscal[IS_LEAF * C + chain] = 0;
+          }
+        }
+      }
+    }
+  }
+
+  if (threadIdx.x == 0) {
+    ws.iscal[IS_DEPTH * C + chain] = tree_depth;
+    ws.iscal[IS_NPROP * C + chain] = num_prop;
+    ws.iscal[IS_ACCEPTED * C + chain] = accepted;
+    ws.fscal[FS_TREEW * C + chain] = tree_weight;
+    ws.fscal[FS_SUMACC * C + chain] = sum_accept;
+    if (finished) {
+      ws.iscal[IS_ACTIVE * C + chain] = 0;
+      ws.iscal[IS_DIVERGED * C + chain] = diverged;
+      accept_prob_out[chain] = sum_accept / (T)num_prop;  // nuts.py:510
+      nleap_out[chain] = num_prop;
+      depth_out[chain] = tree_depth;
+      div_out[chain] = diverged;
+      acc_out[chain] = accepted;
+    } else {
+      atomicAdd(n_active, 1);
+    }
+  }
+}
+
+struct TreePlan { int nw, npl; };
+static bool tree_plan(int64_t D, TreePlan* p) {
+  if (D <= 128) { *p = {1, 2}; return true; }
+  if (D <= 512) { *p = {1, 8}; return true; }
+  if (D <= 2048) { *p = {4, 8}; return true; }
+  return false;
+}
+
+#define PA_TREE_DISPATCH(T, CALL)                                   \
+  do {                                                              \
+    if (pl.nw == 1 && pl.npl == 2) { CALL(T, 1, 2); }               \
+    else if (pl.nw == 1 && pl.npl == 8) { CALL(T, 1, 8); }          \
+    else { CALL(T, 4, 8); }                                         \
+  } while (0)
+
+template <typename T>
+static int tree_begin(const void* z, const void* pe, const void* grad, void* zq, void* rq,
+                      const void* inv_mass, int64_t im_stride, const void* step, int64_t C,
+                      int64_t D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
+                      uint64_t chain_offset, void* workspace, hipStream_t s) {
+  TreePlan pl;
+  tree_plan(D, &pl);
+  TreeWs<T> ws = tree_ws<T>(workspace, C, D, max_depth);
+#define PA_CALL(TT, NW, NPL)                                                                     \
+  hipLaunchKernelGGL((nuts_tree_begin_kernel<TT, NW, NPL>), dim3((unsigned)C), dim3(64 * NW), 0, \
+                     s, (const TT*)z, (const TT*)pe, (const TT*)grad, (TT*)zq, (TT*)rq,          \
+                     (const TT*)inv_mass, im_stride, (const TT*)step, C, (int)D, multinomial,    \
+                     seed, t, chain_offset, ws)
+  PA_TREE_DISPATCH(T, PA_CALL);
+#undef PA_CALL
+  return check_launch("nuts_tree_begin_kernel");
+}
+
+template <typename T>
+static int tree_advance(void* z, void* pe, void* grad, void* zq, void* rq, const void* gq,
+                        const void* peq, const void* inv_mass, int64_t im_stride, const void* step,
+                        int64_t C, int64_t D, int max_depth, int multinomial, uint64_t seed,
+                        uint64_t t, uint64_t chain_offset, void* accept_prob, int32_t* nl,
+                        int32_t* dp, int32_t* dv, int32_t* ac, int32_t* n_active, void* workspace,
+                        hipStream_t s) {
+  TreePlan pl;
+  tree_plan(D, &pl);
+  TreeWs<T> ws = tree_ws<T>(workspace, C, D, max_depth);
+  if (hipMemsetAsync(n_active, 0, sizeof(int32_t), s) != hipSuccess)
+    return fail(PA_ERR_LAUNCH, "nuts_tree_advance: memset failed");
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
+#define PA_CALL(TT, NW, NPL)                                                                      \
+  hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL>), dim3((unsigned)C), dim3(64 * NW), 0, \
+                     s, (TT*)z, (TT*)pe, (TT*)grad, (TT*)zq, (TT*)rq, (const TT*)gq,              \
+                     (const TT*)peq, (const TT*)inv_mass, im_stride, (const TT*)step, C, (int)D,  \
+                     max_depth, multinomial, seed, t, chain_offset, ws, (TT*)accept_prob, nl, dp, \
+                     dv, ac, n_active)
+  PA_TREE_DISPATCH(T, PA_CALL);
+#undef PA_CALL
+  if (br) (void)hipEventRecord(ev1, s);
+  return check_launch("nuts_tree_advance_kernel");
+}
+
+}  // namespace pa
+
+extern "C" {
+
+size_t pa_nuts_tree_workspace(int dtype, int64_t C, int64_t D, int max_tree_depth) {
+  if (C < 0 || D < 1 || D > 2048 || max_tree_depth < 1 || max_tree_depth > pa::NUTS_MAX_DEPTH)
+    return 0;
+  const size_t esz = dtype == PA_F64 ? 8 : 4;
+  size_t bytes = pa::tree_ws_elems(C, D, max_tree_depth) * esz;
+  bytes = (bytes + 15) & ~(size_t)15;
+  return bytes + (size_t)pa::IS_COUNT * C * sizeof(int32_t) + 16;
+}
+
+#define PA_TREE_COMMON_CHECKS(who)                                                                \
+  PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, who ": bad dtype %d", dtype);                    \
+  PA_REQUIRE(C >= 0 && D >= 1, who ": bad shape C=%lld D=%lld", (long long)C, (long long)D);      \
+  if (D > 2048)                                                                                   \
+    return pa::fail(PA_ERR_UNSUPPORTED, who ": D=%lld > 2048", (long long)D);                     \
+  PA_REQUIRE(max_tree_depth >= 1 && max_tree_depth <= pa::NUTS_MAX_DEPTH,                         \
+             who ": max_tree_depth must be in [1,%d]", pa::NUTS_MAX_DEPTH);                       \
+  PA_REQUIRE(C < (1 << 30) && t < ((uint64_t)1 << 43), who ": C or t too large");                 \
+  PA_REQUIRE(im_stride_row == 0 || im_stride_row == D, who ": inv_mass must be [D] or [C,D]");    \
+  if (C == 0) return PA_OK;                                                                       \
+  PA_REQUIRE(workspace && workspace_bytes >= pa_nuts_tree_workspace(dtype, C, D, max_tree_depth), \
+             who ": workspace too small");
+
+int pa_nuts_tree_begin(int dtype, const void* z, const void* pe, const void* grad, void* zq,
+                       void* rq, const void* inv_mass, int64_t im_stride_row, const void* step,
+                       int64_t C, int64_t D, int max_tree_depth, int use_multinomial,
+                       uint64_t seed, uint64_t t, uint64_t chain_offset, void* workspace,
+                       size_t workspace_bytes, pa_stream_t stream) {
+  PA_TREE_COMMON_CHECKS("nuts_tree_begin")
+  PA_REQUIRE(z && pe && grad && zq && rq && inv_mass && step, "nuts_tree_begin: NULL pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    return pa::tree_begin<float>(z, pe, grad, zq, rq, inv_mass, im_stride_row, step, C, D,
+                                 max_tree_depth, use_multinomial, seed, t, chain_offset, workspace,
+                                 s);
+  return pa::tree_begin<double>(z, pe, grad, zq, rq, inv_mass, im_stride_row, step, C, D,
+                                max_tree_depth, use_multinomial, seed, t, chain_offset, workspace,
+                                s);
+}
+
+int pa_nuts_tree_advance(int dtype, void* z, void* pe, void* grad, void* zq, void* rq,
+                         const void* gq, const void* peq, const void* inv_mass,
+                         int64_t im_stride_row, const void* step, int64_t C, int64_t D,
+                         int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t,
+                         uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog,
+                         int32_t* depth, int32_t* diverging, int32_t* accepted, int32_t* n_active,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  PA_TREE_COMMON_CHECKS("nuts_tree_advance")
+  PA_REQUIRE(z && pe && grad && zq && rq && gq && peq && inv_mass && step && accept_prob &&
+                 n_leapfrog && depth && diverging && accepted && n_active,
+             "nuts_tree_advance: NULL pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    return pa::tree_advance<float>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, step, C,
+                                   D, max_tree_depth, use_multinomial, seed, t, chain_offset,
+                                   accept_prob, n_leapfrog, depth, diverging, accepted, n_active,
+                                   workspace, s);
+  return pa::tree_advance<double>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, step, C,
+                                  D, max_tree_depth, use_multinomial, seed, t, chain_offset,
+                                  accept_prob, n_leapfrog, depth, diverging, accepted, n_active,
+                                  workspace, s);
+}
+
+}  // extern "C"

@@ -194,6 +194,12 @@ class _BernoulliLinear(TorchDistribution):
         return fused.log_prob(_lib.DIST_BERNOULLI_LOGITS, value, self.lazy.materialize(), None)
 
     def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        ll = self.fused_log_prob_batch(value, scale, mask)
+        return None if ll is None else ll.sum()
+
+    def fused_log_prob_batch(self, value, scale=1.0, mask=None):
+        """Per-particle / per-chain sums over the data plate: a tensor of the lazy logits'
+        leading shape (one fused GLM pass for all of them)."""
         lz = self.lazy
         N = lz.X.shape[0]
         if isinstance(scale, torch.Tensor) or not _maskable(mask):
@@ -210,7 +216,7 @@ class _BernoulliLinear(TorchDistribution):
             return None
         w2, b1 = lz.flat_params()
         ll = fused.glm_bernoulli_ll(lz.X, value.contiguous(), w2, b1, mask, scale)
-        return ll.sum()
+        return ll.reshape(lz.shape[:-1])
 
 
 class Bernoulli(_FusedElementwise, torch.distributions.Bernoulli, TorchDistributionMixin):

@@ -1,0 +1,184 @@
+"""Warm-up adaptation of step size and mass matrix, vectorised over chains
+(reference: pyro/infer/mcmc/adaptation.py:23-202 WarmupAdapter, :238-392 BlockMassMatrix).
+
+Every chain runs ITS OWN Stan-style scheme exactly as a single reference chain would -- its own
+dual-averaging state, its own Welford estimator, its own step size and diagonal inverse mass --
+held as tensors with a leading chain dim and updated on the device without host round trips
+(the reference keeps python floats and synchronises once per transition, adaptation.py:176).
+Statistics are NOT pooled across chains (that would be a deviation from the reference).
+"""
+import math
+from collections import namedtuple
+
+import torch
+
+from ...ops.dual_averaging import DualAveraging
+from ...ops.welford import WelfordCovariance
+
+adapt_window = namedtuple("adapt_window", ["start", "end"])
+
+
+def build_adaptation_schedule(warmup_steps, start_buffer=75, end_buffer=50, initial_window=25):
+    """Stan's windowed schedule (reference: adaptation.py:65-103)."""
+    schedule = []
+    if warmup_steps < 20:
+        schedule.append(adapt_window(0, warmup_steps - 1))
+        return schedule
+    start_buffer_size, end_buffer_size, init_window_size = start_buffer, end_buffer, initial_window
+    if start_buffer + end_buffer + initial_window > warmup_steps:
+        start_buffer_size = int(0.15 * warmup_steps)
+        end_buffer_size = int(0.1 * warmup_steps)
+        init_window_size = warmup_steps - start_buffer_size - end_buffer_size
+    schedule.append(adapt_window(start=0, end=start_buffer_size - 1))
+    end_window_start = warmup_steps - end_buffer_size
+    next_window_size = init_window_size
+    next_window_start = start_buffer_size
+    while next_window_start < end_window_start:
+        cur_window_start, cur_window_size = next_window_start, next_window_size
+        if 3 * cur_window_size <= end_window_start - cur_window_start:
+            next_window_size = 2 * cur_window_size
+        else:
+            cur_window_size = end_window_start - cur_window_start
+        next_window_start = cur_window_start + cur_window_size
+        schedule.append(adapt_window(cur_window_start, next_window_start - 1))
+    schedule.append(adapt_window(end_window_start, warmup_steps - 1))
+    return schedule
+
+
+class DiagMassMatrix:
+    """Per-chain diagonal mass matrix: inverse mass v[C, D] and the derived square roots
+    (reference: BlockMassMatrix with one diagonal block, adaptation.py:270-392)."""
+
+    def __init__(self, C, D, dtype, device, init_scale=1.0, adapt=True):
+        self.C, self.D = C, D
+        self._scheme = WelfordCovariance(diagonal=True) if adapt else None
+        self.inverse_mass_matrix = torch.full((C, D), float(init_scale), dtype=dtype,
+                                              device=device)
+
+    @property
+    def inverse_mass_matrix(self):
+        return self._v
+
+    @inverse_mass_matrix.setter
+    def inverse_mass_matrix(self, v):
+        if self._scheme is not None:
+            self._scheme.reset()
+        self._v = v.contiguous()
+        self._sqrt_inv = self._v.sqrt()             # mass_matrix_sqrt_inverse
+        self._sqrt = self._sqrt_inv.reciprocal()    # mass_matrix_sqrt
+
+    def update(self, z):
+        self._scheme.update(z.detach())
+
+    def end_adaptation(self):
+        self.inverse_mass_matrix = self._scheme.get_covariance(regularize=True)
+
+    def kinetic_grad(self, r):          # adaptation.py:328-347
+        return self._v * r
+
+    def scale(self, r_unscaled):        # adaptation.py:349-373
+        return self._sqrt * r_unscaled
+
+    def unscale(self, r):               # adaptation.py:375-392
+        return self._sqrt_inv * r
+
+
+class WarmupAdapter:
+    def __init__(self, step_size=1, adapt_step_size=False, target_accept_prob=0.8,
+                 adapt_mass_matrix=False, dense_mass=False):
+        if dense_mass:
+            raise NotImplementedError(
+                "pyro_amd: the vectorised HMC/NUTS kernels adapt a diagonal mass matrix per "
+                "chain (the reference default, full_mass=False); dense mass is not built yet")
+        self.adapt_step_size = adapt_step_size
+        self.adapt_mass_matrix = adapt_mass_matrix
+        self.target_accept_prob = target_accept_prob
+        self.dense_mass = dense_mass
+        self._init_step_size = 1 if step_size is None else step_size
+        self.step_size = None           # tensor [C] after configure
+        self._adaptation_disabled = not (adapt_step_size or adapt_mass_matrix)
+        if adapt_step_size:
+            self._step_size_adapt_scheme = DualAveraging()
+        self._adapt_start_buffer = 75
+        self._adapt_end_buffer = 50
+        self._adapt_initial_window = 25
+        self._warmup_steps = None
+        self._adaptation_schedule = []
+        self._find_reasonable_step_size = None
+        self.mass_matrix_adapter = None
+
+    def _build_adaptation_schedule(self):
+        return build_adaptation_schedule(self._warmup_steps, self._adapt_start_buffer,
+                                         self._adapt_end_buffer, self._adapt_initial_window)
+
+    def configure(self, warmup_steps, C, D, dtype, device, initial_step_size=None,
+                  find_reasonable_step_size_fn=None):
+        self._warmup_steps = warmup_steps
+        s = self._init_step_size if initial_step_size is None else initial_step_size
+        if isinstance(s, torch.Tensor):
+            self.step_size = s.to(dtype=dtype, device=device).expand(C).contiguous().clone()
+        else:
+            self.step_size = torch.full((C,), float(s), dtype=dtype, device=device)
+        self._find_reasonable_step_size = find_reasonable_step_size_fn
+        self.mass_matrix_adapter = DiagMassMatrix(C, D, dtype, device,
+                                                  adapt=self.adapt_mass_matrix)
+        if not self._adaptation_disabled:
+            self._adaptation_schedule = self._build_adaptation_schedule()
+        self._current_window = 0
+        if self.adapt_step_size:
+            self._step_size_adapt_scheme.reset()
+
+    def reset_step_size_adaptation(self, z):
+        """New reasonable step size per chain + restart of dual averaging
+        (reference: adaptation.py:105-113)."""
+        if self._find_reasonable_step_size is not None:
+            self.step_size = self._find_reasonable_step_size(z)
+        self._step_size_adapt_scheme.prox_center = torch.log(10 * self.step_size)
+        self._step_size_adapt_scheme.reset()
+
+    def _update_step_size(self, accept_prob):
+        H = self.target_accept_prob - accept_prob
+        self._step_size_adapt_scheme.step(H)
+        log_step_size, _ = self._step_size_adapt_scheme.get_state()
+        self.step_size = torch.exp(log_step_size).contiguous()
+
+    def _end_adaptation(self):
+        if self.adapt_step_size:
+            _, log_step_size_avg = self._step_size_adapt_scheme.get_state()
+            self.step_size = torch.exp(log_step_size_avg).contiguous()
+
+    def step(self, t, z, accept_prob, z_grad=None):
+        """Called once per warm-up transition with t = 1, 2, ... (the reference passes the
+        already-incremented counter, hmc.py:424-431); z [C, D], accept_prob [C]."""
+        if t >= self._warmup_steps or self._adaptation_disabled:
+            return
+        window = self._adaptation_schedule[self._current_window]
+        num_windows = len(self._adaptation_schedule)
+        mass_matrix_adaptation_phase = self.adapt_mass_matrix and \
+            (0 < self._current_window < num_windows - 1)
+        if self.adapt_step_size:
+            # NaN acceptance probabilities (diverged chains) count as 0, as exp(-inf) does
+            self._update_step_size(torch.nan_to_num(accept_prob, nan=0.0))
+        if mass_matrix_adaptation_phase:
+            self.mass_matrix_adapter.update(z)
+        if t == window.end:
+            if self._current_window == num_windows - 1:
+                self._current_window += 1
+                self._end_adaptation()
+                return
+            if self._current_window == 0:
+                self._current_window += 1
+                return
+            if mass_matrix_adaptation_phase:
+                self.mass_matrix_adapter.end_adaptation()
+                if self.adapt_step_size:
+                    self.reset_step_size_adaptation(z)
+            self._current_window += 1
+
+    @property
+    def adaptation_schedule(self):
+        return self._adaptation_schedule
+
+
+__all__ = ["WarmupAdapter", "DiagMassMatrix", "adapt_window", "build_adaptation_schedule",
+           "math"]

@@ -1,0 +1,248 @@
+"""Hamiltonian Monte Carlo, vectorised over chains on one GPU
+(reference: pyro/infer/mcmc/hmc.py:31-452; same constructor, same MCMCKernel interface).
+
+The reference runs one chain per process; here ``num_chains`` chains are rows of a flat state
+``z[C, D]`` and every leapfrog step is two HIP launches (pa_leapfrog_kick_drift,
+pa_leapfrog_kick) around ONE chain-batched potential evaluation.  Each chain keeps its own step
+size, mass matrix and adaptation state (see adaptation.py).  Randomness comes from the Philox
+stream (pyro_amd.rng) instead of pyro.sample sites.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from ... import kernels, rng
+from ..autoguide.initialization import init_to_uniform
+from .adaptation import WarmupAdapter
+from .mcmc_kernel import MCMCKernel
+from .util import FlatPotential, Layout, initialize_model
+
+
+class HMC(MCMCKernel):
+    def __init__(self, model=None, potential_fn=None, step_size=1, trajectory_length=None,
+                 num_steps=None, adapt_step_size=True, adapt_mass_matrix=True, full_mass=False,
+                 transforms=None, max_plate_nesting=None, jit_compile=False, jit_options=None,
+                 ignore_jit_warnings=False, target_accept_prob=0.8,
+                 init_strategy=init_to_uniform, *, min_stepsize=1e-10, max_stepsize=1e10):
+        if not ((model is None) ^ (potential_fn is None)):
+            raise ValueError("Only one of `model` or `potential_fn` must be specified.")
+        self.model = model
+        self.transforms = transforms
+        self._max_plate_nesting = max_plate_nesting
+        self._jit_compile = jit_compile
+        self._init_strategy = init_strategy
+        self._min_stepsize = min_stepsize
+        self._max_stepsize = max_stepsize
+        self.potential_fn = potential_fn
+        if trajectory_length is not None:
+            self.trajectory_length = trajectory_length
+        elif num_steps is not None:
+            self.trajectory_length = step_size * num_steps
+        else:
+            self.trajectory_length = 2 * math.pi  # from Stan
+        self._direction_threshold = math.log(0.8)  # from Stan
+        self._max_sliced_energy = 1000
+        self.num_chains = 1
+        self.chain_offset = 0      # first global chain index of this rank (chain-sharded runs)
+        self._reset()
+        self._adapter = WarmupAdapter(step_size, adapt_step_size=adapt_step_size,
+                                      adapt_mass_matrix=adapt_mass_matrix,
+                                      target_accept_prob=target_accept_prob,
+                                      dense_mass=full_mass)
+        super().__init__()
+
+    # ---- bookkeeping -------------------------------------------------------------------------
+    def _reset(self):
+        self._t = 0
+        self._accept_cnt = None
+        self._mean_accept_prob = None
+        self._divergences = []
+        self._prototype_trace = None
+        self._initial_params = None
+        self._z = self._pe = self._grad = None
+        self._warmup_steps = None
+        self._layout = None
+        self._n_leapfrog_total = None
+
+    @property
+    def mass_matrix_adapter(self):
+        return self._adapter.mass_matrix_adapter
+
+    @property
+    def inverse_mass_matrix(self):
+        return self.mass_matrix_adapter.inverse_mass_matrix
+
+    @property
+    def step_size(self):
+        return self._adapter.step_size
+
+    @property
+    def initial_params(self):
+        return self._initial_params
+
+    @initial_params.setter
+    def initial_params(self, params):
+        self._initial_params = params
+
+    # ---- setup -------------------------------------------------------------------------------
+    def _initialize_model_properties(self, model_args, model_kwargs):
+        init_params, potential_fn, transforms, trace = initialize_model(
+            self.model, model_args, model_kwargs, transforms=self.transforms,
+            max_plate_nesting=self._max_plate_nesting, num_chains=self.num_chains,
+            init_strategy=self._init_strategy, initial_params=self._initial_params)
+        self.potential_fn = potential_fn
+        self.transforms = transforms
+        self._initial_params = init_params
+        self._prototype_trace = trace
+
+    def setup(self, warmup_steps, *args, **kwargs):
+        self._warmup_steps = warmup_steps
+        if self.model is not None:
+            self._initialize_model_properties(args, kwargs)
+        if not self._initial_params:
+            raise ValueError("HMC/NUTS needs at least one continuous latent site "
+                             "(initial_params is empty)")
+        params = self._initial_params
+        C = self.num_chains
+        first = next(iter(params.values()))
+        # chain-batched parameters carry a leading dim of size num_chains; a single chain may
+        # pass un-batched tensors exactly as with the reference
+        self._batched = C > 1 or bool(getattr(self, "_force_batched", False))
+        if C > 1:
+            for k, v in params.items():
+                if v.dim() == 0 or v.shape[0] != C:
+                    raise ValueError("initial_params['{}'] must have a leading dim of size "
+                                     "num_chains={} (got shape {})".format(k, C, tuple(v.shape)))
+        shapes = {k: (v.shape[1:] if self._batched else v.shape) for k, v in params.items()}
+        self._layout = Layout(shapes)
+        self._potential = FlatPotential(self.potential_fn, self._layout, self._batched)
+        z = self._layout.flatten({k: v.detach() for k, v in params.items()}, C, self._batched)
+        kernels._require_gpu(z)
+        self._z = z.clone()
+        pe, grad = self._potential(self._z)
+        self._pe, self._grad = pe.detach().contiguous(), grad.detach().contiguous()
+        self._accept_cnt = torch.zeros((C,), dtype=torch.int64, device=z.device)
+        self._mean_accept_prob = torch.zeros((C,), dtype=z.dtype, device=z.device)
+        self._n_leapfrog_total = torch.zeros((), dtype=torch.int64, device=z.device)
+        self._adapter.configure(warmup_steps, C, self._layout.D, z.dtype, z.device,
+                                find_reasonable_step_size_fn=self._find_reasonable_step_size)
+        if self._adapter.adapt_step_size:
+            self._adapter.reset_step_size_adaptation(self._z)
+        self._seed = rng._STATE["seed"]
+
+    def cleanup(self):
+        self._reset()
+
+    # ---- pieces of a transition --------------------------------------------------------------
+    def _kinetic_energy(self, r_unscaled):
+        return 0.5 * (r_unscaled * r_unscaled).sum(-1)       # hmc.py:152-156
+
+    def _sample_r(self):
+        r_unscaled = rng.normal(self._z.shape, self._z.dtype, self._z.device)
+        return self.mass_matrix_adapter.scale(r_unscaled), r_unscaled   # hmc.py:231-248
+
+    def _leapfrog(self, z, r, grad, step):
+        """One velocity-Verlet step for all chains, in place on (z, r); returns (pe, grad)."""
+        step = step.contiguous()
+        kernels.leapfrog_kick_drift(z, r, grad, self.inverse_mass_matrix, step)
+        pe, grad = self._potential(z)
+        grad = grad.contiguous()
+        kernels.leapfrog_kick(r, grad, step)
+        return pe, grad
+
+    def _find_reasonable_step_size(self, z):
+        """Per chain: double / halve the step size until the one-step acceptance probability
+        crosses the target (reference: hmc.py:170-229), all chains in lock step under masks."""
+        step = self.step_size.clone()
+        pe, grad = self._potential(z)
+        grad = grad.contiguous()
+        mm = self.mass_matrix_adapter
+
+        def trial(step):
+            r, r_u = self._sample_r()
+            e0 = self._kinetic_energy(r_u) + pe
+            z1, r1 = z.clone(), r.contiguous().clone()
+            pe1, _ = self._leapfrog(z1, r1, grad, step)
+            e1 = self._kinetic_energy(mm.unscale(r1)) + pe1
+            delta = e1 - e0
+            # NaN (diverged trial) compares False -> direction -1, as in the reference
+            return torch.where(self._direction_threshold < -delta, 1, -1)
+
+        direction = trial(step)
+        scale = torch.pow(torch.full_like(step, 2.0), direction.to(step.dtype))
+        active = torch.ones_like(direction, dtype=torch.bool)
+        for _ in range(200):
+            active = active & (step > self._min_stepsize) & (step < self._max_stepsize)
+            if not bool(active.any()):
+                break
+            step = torch.where(active, step * scale, step)
+            active = active & (trial(step) == direction)
+        return step.clamp(min=self._min_stepsize, max=self._max_stepsize).contiguous()
+
+    def _after_transition(self, accept_prob, accepted, diverging):
+        self._t += 1
+        if self._t > self._warmup_steps:
+            n = self._t - self._warmup_steps
+            self._accept_cnt += accepted.to(torch.int64)
+            self._divergences.append(diverging)
+        else:
+            n = self._t
+            self._adapter.step(self._t, self._z, accept_prob, self._grad)
+        self._mean_accept_prob += (torch.nan_to_num(accept_prob, nan=0.0)
+                                   - self._mean_accept_prob) / n
+
+    # ---- one transition for all chains -------------------------------------------------------
+    def _transition(self):
+        z, pe, grad = self._z, self._pe, self._grad
+        mm = self.mass_matrix_adapter
+        r, r_u = self._sample_r()
+        energy_current = self._kinetic_energy(r_u) + pe
+        step = self.step_size
+        num_steps = torch.clamp((self.trajectory_length / step).floor(), min=1)
+        L = int(num_steps.max().item())
+        z_new, r_new, g_new, pe_new = z.clone(), r.contiguous().clone(), grad, pe
+        zero = torch.zeros_like(step)
+        for i in range(L):
+            st = torch.where(num_steps > i, step, zero)   # a chain that is done stands still
+            pe_new, g_new = self._leapfrog(z_new, r_new, g_new, st)
+        self._n_leapfrog_total += num_steps.sum().to(torch.int64)
+        energy_proposal = self._kinetic_energy(mm.unscale(r_new)) + pe_new
+        delta = energy_proposal - energy_current
+        delta = torch.where(torch.isnan(delta), torch.full_like(delta, float("inf")), delta)
+        diverging = delta > self._max_sliced_energy
+        accept_prob = (-delta).exp().clamp(max=1.0)
+        rand = rng.uniform(accept_prob.shape, accept_prob.dtype, accept_prob.device)
+        accepted = rand < accept_prob
+        m = accepted.unsqueeze(-1)
+        self._z = torch.where(m, z_new, z).contiguous()
+        self._grad = torch.where(m, g_new, grad).contiguous()
+        self._pe = torch.where(accepted, pe_new, pe).contiguous()
+        self._after_transition(accept_prob, accepted, diverging)
+
+    def sample(self, params):
+        """One transition; ``params`` is ignored in favour of the cached state when it is the
+        state returned by the previous call (the reference caches the same way, hmc.py:371-379)."""
+        self._transition()
+        return self._layout.unflatten(self._z.clone(), self._batched)
+
+    # ---- reporting ---------------------------------------------------------------------------
+    def logging(self):
+        return OrderedDict([("step size", "{:.2e}".format(float(self.step_size.mean()))),
+                            ("acc. prob", "{:.3f}".format(float(self._mean_accept_prob.mean())))])
+
+    def diagnostics(self):
+        n = max(self._t - self._warmup_steps, 1)
+        out = {"acceptance rate": (self._accept_cnt.to(torch.float64) / n).cpu()}
+        if self._divergences:
+            div = torch.stack(self._divergences).to(torch.bool).cpu()    # [S, C]
+            out["divergences"] = {"chain {}".format(c): torch.nonzero(div[:, c]).reshape(-1).tolist()
+                                  for c in range(div.shape[1])}
+        else:
+            out["divergences"] = {}
+        return out
+
+    @property
+    def num_leapfrog_steps(self):
+        """Total leapfrog steps taken by all chains so far (device counter, host read)."""
+        return int(self._n_leapfrog_total.item())

@@ -1,0 +1,104 @@
+"""No-U-Turn Sampler, vectorised over chains (reference: pyro/infer/mcmc/nuts.py:67-522; same
+constructor and MCMCKernel interface).
+
+Two device paths, both restating the reference's tree doubling chain by chain:
+
+* closed-form Gaussian potential (``GaussianPotential``, D <= 128): ONE fused launch per
+  transition, one wavefront per chain (pa_nuts_gaussian_transition);
+* any other potential: the per-chain tree state machine pa_nuts_tree_begin/advance with one
+  chain-batched potential evaluation per leapfrog step; chains whose tree is finished idle.
+
+Both use the same keyed Philox draws, so they produce the same chains (and the same chains as
+oracle/nuts.py) up to floating-point rounding of the potential.
+"""
+from collections import OrderedDict
+
+import torch
+
+from ... import kernels
+from ..autoguide.initialization import init_to_uniform
+from .hmc import HMC
+from .potentials import GaussianPotential
+
+
+class NUTS(HMC):
+    def __init__(self, model=None, potential_fn=None, step_size=1, adapt_step_size=True,
+                 adapt_mass_matrix=True, full_mass=False, use_multinomial_sampling=True,
+                 transforms=None, max_plate_nesting=None, jit_compile=False, jit_options=None,
+                 ignore_jit_warnings=False, target_accept_prob=0.8, max_tree_depth=10,
+                 init_strategy=init_to_uniform):
+        super().__init__(model, potential_fn, step_size, adapt_step_size=adapt_step_size,
+                         adapt_mass_matrix=adapt_mass_matrix, full_mass=full_mass,
+                         transforms=transforms, max_plate_nesting=max_plate_nesting,
+                         jit_compile=jit_compile, jit_options=jit_options,
+                         ignore_jit_warnings=ignore_jit_warnings,
+                         target_accept_prob=target_accept_prob, init_strategy=init_strategy)
+        self.use_multinomial_sampling = use_multinomial_sampling
+        self._max_tree_depth = max_tree_depth
+        self._max_sliced_energy = 1000
+        self._tree = None
+        self.sync_every = 4      # host polls of n_active in the generic tree loop
+        self.use_fused_gaussian = True
+
+    def setup(self, warmup_steps, *args, **kwargs):
+        super().setup(warmup_steps, *args, **kwargs)
+        self._tree = None
+        self._tree_depth_sum = torch.zeros((), dtype=torch.int64, device=self._z.device)
+        self._fused = (self.use_fused_gaussian and isinstance(self.potential_fn, GaussianPotential)
+                       and self._layout.D <= 128 and len(self._layout.names) == 1)
+        if self._fused:
+            self._Lambda = self.potential_fn.precision.to(self._z.dtype).contiguous()
+
+    def _transition(self):
+        t = self._t
+        step = self.step_size.contiguous()
+        inv_mass = self.inverse_mass_matrix
+        if self._fused:
+            out = kernels.nuts_gaussian_transition(
+                self._z, self._pe, self._grad, self._Lambda, inv_mass, step,
+                self._max_tree_depth, self.use_multinomial_sampling,
+                self._seed, t, self.chain_offset)
+        else:
+            out = self._tree_transition(t, step, inv_mass)
+        self._n_leapfrog_total += out["n_leapfrog"].sum()
+        self._tree_depth_sum += out["depth"].sum()
+        self._last_stats = out
+        self._after_transition(out["accept_prob"], out["accepted"] != 0, out["diverging"] != 0)
+
+    def _tree_transition(self, t, step, inv_mass):
+        tree = self._tree
+        if tree is None or tree.inv_mass is not inv_mass or tree.step is not step:
+            if tree is None:
+                tree = kernels.NutsTree(self._z, self._pe, self._grad, inv_mass, step,
+                                        self._max_tree_depth, self.use_multinomial_sampling,
+                                        self._seed, self.chain_offset)
+                self._tree = tree
+            else:   # adaptation replaced the step-size / mass tensors: re-point, keep workspace
+                tree.inv_mass, tree.step = inv_mass, step
+                tree.im_stride = tree.D if inv_mass.dim() == 2 else 0
+        tree.begin(t)
+        it = 0
+        max_iter = (1 << self._max_tree_depth) + 1
+        while True:
+            pe, grad = self._potential(tree.zq)
+            tree.advance(pe.contiguous(), grad.contiguous())
+            it += 1
+            if it >= max_iter:
+                break
+            # chains can only finish at leaf counts 2^j - 1 or by a U-turn/divergence inside a
+            # doubling; polling every few leaves keeps the host out of the loop
+            if (it & (it + 1)) == 0 or it % self.sync_every == 0:
+                if tree.n_active() == 0:
+                    break
+        return tree.stats()
+
+    def logging(self):
+        out = super().logging()
+        return OrderedDict(list(out.items()))
+
+    def diagnostics(self):
+        out = super().diagnostics()
+        if self._t:
+            out["mean tree depth"] = float(self._tree_depth_sum.item()) / (self._t *
+                                                                          self.num_chains)
+        return out

@@ -1,0 +1,214 @@
+"""Model -> (initial params, potential function, transforms) for HMC/NUTS
+(reference: pyro/infer/mcmc/util.py:264-286 _PEMaker._potential_fn, :370-482 initialize_model),
+plus the flat chain-batched view of the unconstrained state the HIP kernels work on.
+
+Chain batching.  The reference runs one Python process per chain (api.py:239-351); here all C
+chains are one tensor batch.  For a model, the conditioned model is executed ONCE per leapfrog
+step for all chains under an extra outermost ``plate("_num_chains", C, dim=-1-max_plate_nesting)``
+(the same device the ELBO uses for vectorised particles, pyro/infer/elbo.py:186-216) and the
+log-joint is reduced per chain; U(z)[c] = -log p(T^-1(z_c), data) + sum log|det J|.
+"""
+from collections import OrderedDict
+
+import torch
+from torch.distributions import biject_to
+
+from ... import poutine
+from ...distributions.util import scale_and_mask
+from ...ops.integrator import potential_grad
+from ...primitives import plate
+from ..autoguide.initialization import InitMessenger, init_to_uniform
+
+
+class Layout:
+    """Flat layout of the unconstrained latent sites: sorted by name (the reference sorts the
+    site names of a mass-matrix block the same way, hmc.py:307-313), each site flattened."""
+
+    def __init__(self, shapes):
+        self.names = sorted(shapes)
+        self.shapes = OrderedDict((n, torch.Size(shapes[n])) for n in self.names)
+        self.slices = OrderedDict()
+        off = 0
+        for n in self.names:
+            k = self.shapes[n].numel()
+            self.slices[n] = (off, off + k)
+            off += k
+        self.D = off
+
+    def flatten(self, z, C, batched):
+        parts = []
+        for n in self.names:
+            v = z[n]
+            parts.append(v.reshape(C, -1) if batched else v.reshape(1, -1))
+        return torch.cat(parts, dim=1).contiguous() if parts else None
+
+    def unflatten(self, z_flat, batched):
+        out = {}
+        C = z_flat.shape[0]
+        for n in self.names:
+            a, b = self.slices[n]
+            v = z_flat[:, a:b]
+            out[n] = v.reshape((C,) + tuple(self.shapes[n])) if batched else \
+                v.reshape(self.shapes[n])
+        return out
+
+
+class FlatPotential:
+    """(pe[C], grad[C, D]) of a dict-style potential at a flat state z[C, D]."""
+
+    def __init__(self, potential_fn, layout, batched):
+        self.fn, self.layout, self.batched = potential_fn, layout, batched
+        self._direct = getattr(potential_fn, "potential_and_grad", None) \
+            if len(layout.names) == 1 else None
+
+    def __call__(self, z_flat):
+        if self._direct is not None:
+            return self._direct(z_flat)
+        z = {k: v.detach().clone() for k, v in self.layout.unflatten(z_flat, self.batched).items()}
+        grads, pe = potential_grad(self.fn, z)
+        C = z_flat.shape[0]
+        g = torch.cat([grads[n].reshape(C, -1) for n in self.layout.names], dim=1)
+        pe = pe.reshape(-1)
+        if pe.numel() != C:
+            raise ValueError(
+                "potential_fn must return one energy per chain (shape [{}]) when the parameters "
+                "carry a leading chain dim; got shape {}".format(C, tuple(pe.shape)))
+        return pe, g.contiguous()
+
+
+def _guess_max_plate_nesting(model, args, kwargs):
+    with poutine.block():
+        trace = poutine.trace(model).get_trace(*args, **kwargs)
+    dims = [f.dim for site in trace.nodes.values() if site["type"] == "sample"
+            for f in site["cond_indep_stack"] if f.vectorized]
+    return -min(dims) if dims else 0
+
+
+class _PEMaker:
+    def __init__(self, model, model_args, model_kwargs, transforms, max_plate_nesting, num_chains,
+                 batch_ndims):
+        self.model, self.args, self.kwargs = model, model_args, model_kwargs
+        self.transforms = transforms
+        self.mpn = max_plate_nesting
+        self.C = num_chains
+        self.batch_ndims = batch_ndims   # site -> number of batch dims of its distribution
+
+    def _chain_value(self, name, v):
+        """[C, *site_shape] -> [C, 1 ... 1, *site_shape] so the chain dim sits at
+        -1 - max_plate_nesting relative to the site's batch dims."""
+        pad = self.mpn - self.batch_ndims[name]
+        return v.reshape((v.shape[0],) + (1,) * pad + tuple(v.shape[1:]))
+
+    def _chain_sum(self, site):
+        fn, value, scale, mask = site["fn"], site["value"], site["scale"], site["mask"]
+        C = self.C
+        if mask is False:
+            return 0.0
+        if mask is True:
+            mask = None
+        batch = getattr(fn, "fused_log_prob_batch", None)
+        if batch is not None and not isinstance(scale, torch.Tensor):
+            out = batch(value, scale, mask)
+            if out is not None and out.numel() == C:
+                return out.reshape(C)
+        lp = scale_and_mask(fn.log_prob(value, *site["args"], **site["kwargs"]), scale, mask)
+        if lp.dim() > self.mpn + 1:
+            raise NotImplementedError("enumerated sites are not supported by the vectorised "
+                                      "HMC/NUTS potential")
+        if lp.dim() == self.mpn + 1 and lp.shape[0] == C:
+            return lp.reshape(C, -1).sum(-1)
+        return lp.sum()   # does not depend on the chain: a constant shared by all chains
+
+    def potential_fn(self, params):
+        if self.C == 1 and not self._batched(params):
+            constrained = {k: self.transforms[k].inv(v) for k, v in params.items()}
+            trace = poutine.trace(poutine.condition(self.model, constrained)).get_trace(
+                *self.args, **self.kwargs)
+            log_joint = trace.log_prob_sum()
+            for name, t in self.transforms.items():
+                log_joint = log_joint - torch.sum(
+                    t.log_abs_det_jacobian(constrained[name], params[name]))
+            return -log_joint
+        C = self.C
+        constrained = {k: self.transforms[k].inv(v) for k, v in params.items()}
+        cond = {k: self._chain_value(k, v) for k, v in constrained.items()}
+
+        def chained(*a, **kw):
+            with plate("_num_chains", C, dim=-1 - self.mpn):
+                return self.model(*a, **kw)
+
+        trace = poutine.trace(poutine.condition(chained, cond)).get_trace(*self.args,
+                                                                         **self.kwargs)
+        log_joint = 0.0
+        for name, site in trace.nodes.items():
+            if site["type"] == "sample" and type(site["fn"]).__name__ != "_Subsample":
+                log_joint = log_joint + self._chain_sum(site)
+        for name, t in self.transforms.items():
+            ladj = t.log_abs_det_jacobian(constrained[name], params[name])
+            log_joint = log_joint - ladj.reshape(C, -1).sum(-1)
+        if not isinstance(log_joint, torch.Tensor) or log_joint.dim() == 0:
+            log_joint = torch.as_tensor(log_joint).expand(C)
+        return -log_joint
+
+    def _batched(self, params):
+        for k, v in params.items():
+            return v.dim() == len(self._site_shape[k]) + 1
+        return False
+
+
+def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
+                     max_plate_nesting=None, jit_compile=False, jit_options=None,
+                     skip_jit_warnings=False, num_chains=1, init_strategy=init_to_uniform,
+                     initial_params=None):
+    """Returns (initial_params, potential_fn, transforms, prototype_trace).
+
+    With ``num_chains > 1`` the initial parameters carry a leading chain dim and the potential
+    maps them to one energy per chain."""
+    model_kwargs = {} if model_kwargs is None else model_kwargs
+    if jit_compile:
+        import warnings
+        warnings.warn("jit_compile is ignored: the leapfrog loop runs HIP kernels directly")
+    automatic = transforms is None
+    transforms = {} if transforms is None else dict(transforms)
+    if max_plate_nesting is None:
+        max_plate_nesting = _guess_max_plate_nesting(model, model_args, model_kwargs)
+
+    def draw():
+        return poutine.trace(InitMessenger(init_strategy)(model)).get_trace(*model_args,
+                                                                            **model_kwargs)
+
+    trace = draw()
+    batch_ndims, site_shape = {}, {}
+
+    def collect(tr):
+        out = {}
+        for name, node in tr.iter_stochastic_nodes():
+            fn = node["fn"]
+            if type(fn).__name__ == "_Subsample":
+                if fn.subsample_size is not None and fn.subsample_size < fn.size:
+                    raise NotImplementedError("HMC/NUTS does not support models with subsample "
+                                              "sites")
+                continue
+            if getattr(fn, "has_enumerate_support", False):
+                raise NotImplementedError(
+                    "pyro_amd: discrete latent site '{}': enumeration inside HMC/NUTS is not "
+                    "part of this backend".format(name))
+            out[name] = node["value"].detach()
+            batch_ndims[name] = len(fn.batch_shape)
+            if automatic:
+                transforms[name] = biject_to(fn.support).inv
+        return out
+
+    samples = collect(trace)
+    pe_maker = _PEMaker(model, model_args, model_kwargs, transforms, max_plate_nesting,
+                        num_chains, batch_ndims)
+    if initial_params is None:
+        draws = [samples] + [collect(draw()) for _ in range(num_chains - 1)]
+        initial_params = {}
+        for k in samples:
+            vals = [transforms[k](d[k]) for d in draws]
+            initial_params[k] = torch.stack(vals) if num_chains > 1 else vals[0]
+    for k, v in initial_params.items():
+        site_shape[k] = tuple(v.shape[1:]) if num_chains > 1 else tuple(v.shape)
+    pe_maker._site_shape = site_shape
+    return initial_params, pe_maker.potential_fn, transforms, trace

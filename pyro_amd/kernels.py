@@ -212,7 +212,7 @@ def leapfrog_kick(r, grad, step):
 
 
 def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth, use_multinomial,
-                             seed, t):
+                             seed, t, chain_offset=0):
     """One NUTS transition for all chains, in place on (z, pe, grad).
     Returns dict(accept_prob[C], n_leapfrog, depth, diverging, accepted: int32[C])."""
     _require_gpu(z, pe, grad, Lambda, inv_mass, step)
@@ -224,10 +224,77 @@ def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth
     ints = torch.empty((4, C), dtype=torch.int32, device=z.device)
     check(_lib.load().pa_nuts_gaussian_transition(
         _dtype(z), _ptr(z), _ptr(pe), _ptr(grad), _ptr(Lambda), _ptr(inv_mass), _ptr(step), C, D,
-        int(max_tree_depth), int(bool(use_multinomial)), int(seed), int(t), _ptr(ap),
+        int(max_tree_depth), int(bool(use_multinomial)), int(seed), int(t), int(chain_offset),
+        _ptr(ap),
         _ptr(ints[0]), _ptr(ints[1]), _ptr(ints[2]), _ptr(ints[3]), _stream()))
     return {"accept_prob": ap, "n_leapfrog": ints[0], "depth": ints[1], "diverging": ints[2],
             "accepted": ints[3]}
+
+
+class NutsTree:
+    """Device-resident NUTS tree state for C chains of dimension D (pa_nuts_tree_*).
+
+    Protocol per transition:  ``begin(t)``; then until ``n_active() == 0``: the caller writes
+    the potential energy / gradient at ``zq`` into ``peq`` / ``gq`` and calls ``advance()``.
+    ``z, pe, grad`` are the chains' current state (updated in place when a proposal is accepted).
+    """
+
+    def __init__(self, z, pe, grad, inv_mass, step, max_tree_depth=10, use_multinomial=True,
+                 seed=0, chain_offset=0):
+        _require_gpu(z, pe, grad, inv_mass, step)
+        C, D = z.shape
+        for x in (z, pe, grad, inv_mass, step):
+            assert x.is_contiguous() and x.dtype == z.dtype
+        assert pe.shape == (C,) and grad.shape == (C, D) and step.shape == (C,)
+        assert inv_mass.shape in ((D,), (C, D))
+        self.z, self.pe, self.grad, self.inv_mass, self.step = z, pe, grad, inv_mass, step
+        self.C, self.D = C, D
+        self.im_stride = D if inv_mass.dim() == 2 else 0
+        self.max_tree_depth, self.multinomial = int(max_tree_depth), int(bool(use_multinomial))
+        self.seed, self.chain_offset = int(seed), int(chain_offset)
+        self.dt = _dtype(z)
+        lib = _lib.load()
+        nbytes = lib.pa_nuts_tree_workspace(self.dt, C, D, self.max_tree_depth)
+        if nbytes == 0 and C > 0:
+            raise Unsupported("pyro_amd: NUTS tree kernel does not support C=%d D=%d depth=%d"
+                              % (C, D, max_tree_depth))
+        self.nbytes = nbytes
+        self.ws = torch.zeros((max(nbytes, 16),), dtype=torch.uint8, device=z.device)
+        self.zq = torch.empty_like(z)
+        self.rq = torch.empty_like(z)
+        self.accept_prob = torch.zeros((C,), dtype=z.dtype, device=z.device)
+        self.ints = torch.zeros((4, C), dtype=torch.int32, device=z.device)
+        self._n_active = torch.zeros((1,), dtype=torch.int32, device=z.device)
+        self.t = 0
+
+    def begin(self, t):
+        self.t = int(t)
+        check(_lib.load().pa_nuts_tree_begin(
+            self.dt, _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq),
+            _ptr(self.inv_mass), self.im_stride, _ptr(self.step), self.C, self.D,
+            self.max_tree_depth, self.multinomial, self.seed, self.t, self.chain_offset,
+            _ptr(self.ws), self.nbytes, _stream()))
+
+    def advance(self, peq, gq):
+        """peq[C], gq[C,D]: potential energy and gradient at the cursor ``zq``."""
+        _require_gpu(peq, gq)
+        assert peq.is_contiguous() and gq.is_contiguous() and gq.dtype == self.z.dtype
+        assert peq.dtype == self.z.dtype and gq.shape == self.z.shape and peq.numel() == self.C
+        check(_lib.load().pa_nuts_tree_advance(
+            self.dt, _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq),
+            _ptr(gq), _ptr(peq), _ptr(self.inv_mass), self.im_stride, _ptr(self.step),
+            self.C, self.D, self.max_tree_depth, self.multinomial, self.seed, self.t,
+            self.chain_offset, _ptr(self.accept_prob), _ptr(self.ints[0]), _ptr(self.ints[1]),
+            _ptr(self.ints[2]), _ptr(self.ints[3]), _ptr(self._n_active), _ptr(self.ws),
+            self.nbytes, _stream()))
+
+    def n_active(self):
+        """Number of chains still building their tree (host synchronisation)."""
+        return int(self._n_active.item())
+
+    def stats(self):
+        return {"accept_prob": self.accept_prob, "n_leapfrog": self.ints[0], "depth": self.ints[1],
+                "diverging": self.ints[2], "accepted": self.ints[3]}
 
 
 # ------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ from oracle import glm as o_glm
 from oracle import integrator as o_int
 from oracle import lda as o_lda
 from oracle import nuts as o_nuts
+from oracle import nuts_tree as o_tree
 from oracle import philox as o_philox
 
 
@@ -88,7 +89,7 @@ def leapfrog_kick(r, grad, step):
 
 
 def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth, use_multinomial,
-                             seed, t):
+                             seed, t, chain_offset=0):
     C, D = z.shape
     np_dt = np.float32 if z.dtype == torch.float32 else np.float64
     pg = o_int.gaussian_potential(_np(Lambda).astype(np.float64))
@@ -98,7 +99,7 @@ def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth
     for c in range(C):
         out = o_nuts.nuts_transition(zn[c].astype(np.float64), float(pen[c]), gn[c].astype(np.float64),
                                      pg, _np(inv_mass)[c].astype(np.float64), float(_np(step)[c]),
-                                     o_nuts.KeyedDraws(seed, c, t, np_dt), max_tree_depth,
+                                     o_nuts.KeyedDraws(seed, chain_offset + c, t, np_dt), max_tree_depth,
                                      bool(use_multinomial))
         zn[c], pen[c], gn[c] = out["z"], out["pe"], out["grad"]
         ap[c] = out["accept_prob"]
@@ -107,6 +108,46 @@ def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth
     ti = torch.as_tensor(ints)
     return {"accept_prob": torch.as_tensor(ap, dtype=z.dtype), "n_leapfrog": ti[0], "depth": ti[1],
             "diverging": ti[2], "accepted": ti[3]}
+
+
+class NutsTree:
+    """Stand-in for kernels.NutsTree backed by oracle/nuts_tree.py (numpy, host)."""
+
+    def __init__(self, z, pe, grad, inv_mass, step, max_tree_depth=10, use_multinomial=True,
+                 seed=0, chain_offset=0):
+        self.z, self.pe, self.grad, self.inv_mass, self.step = z, pe, grad, inv_mass, step
+        self.C, self.D = z.shape
+        self.im_stride = self.D if inv_mass.dim() == 2 else 0
+        self._args = (max_tree_depth, bool(use_multinomial), seed, chain_offset)
+        self.zq = torch.zeros_like(z)
+        self.rq = torch.zeros_like(z)
+        self._o = None
+
+    def begin(self, t):
+        np_dt = np.float32 if self.z.dtype == torch.float32 else np.float64
+        self._zn, self._pn, self._gn = _np(self.z).copy(), _np(self.pe).copy(), _np(self.grad).copy()
+        self._o = o_tree.NutsTreeOracle(self._zn, self._pn, self._gn, _np(self.inv_mass),
+                                        _np(self.step), *self._args, dtype=np_dt)
+        self._o.begin(t)
+        self._sync()
+
+    def _sync(self):
+        self.zq.copy_(torch.as_tensor(self._o.zq))
+        self.rq.copy_(torch.as_tensor(self._o.rq))
+        self.z.copy_(torch.as_tensor(self._zn)); self.pe.copy_(torch.as_tensor(self._pn))
+        self.grad.copy_(torch.as_tensor(self._gn))
+
+    def advance(self, peq, gq):
+        self._o.advance(_np(peq), _np(gq))
+        self._sync()
+
+    def n_active(self):
+        return self._o.n_active()
+
+    def stats(self):
+        ti = torch.as_tensor(self._o.ints)
+        return {"accept_prob": torch.as_tensor(self._o.accept_prob, dtype=self.z.dtype),
+                "n_leapfrog": ti[0], "depth": ti[1], "diverging": ti[2], "accepted": ti[3]}
 
 
 def lda_factor_fwd_bwd(words, log_theta, log_phi):
@@ -129,7 +170,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999)
 
 FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
-             "nuts_gaussian_transition", "lda_factor_fwd_bwd", "adam_step"]
+             "nuts_gaussian_transition", "lda_factor_fwd_bwd", "adam_step", "NutsTree"]
 
 
 def install(monkeypatch):

@@ -1,0 +1,145 @@
+"""HMC/NUTS on the MI355X: the HIP tree state machine and the fused Gaussian kernel against the
+recursive restatement of the reference (chain-for-chain, float64), plus statistical checks with
+warm-up adaptation mirroring the reference's sampler tests (tests/infer/mcmc/test_nuts.py:111-171,
+test_hmc.py:79-124)."""
+import numpy as np
+import pytest
+import torch
+
+import pyro_amd as pyro
+import pyro_amd.distributions as dist
+from pyro_amd import kernels
+from pyro_amd.infer.mcmc import HMC, MCMC, NUTS, GaussianPotential
+from tests import mcmc_cases as mc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_velocity_verlet_matches_reference(gpu):
+    mc.run_integrator_golden(gpu, 1e-10)
+
+
+@pytest.mark.parametrize("D,C,kind,multinomial,fused", [
+    (5, 4, "gaussian", True, True), (100, 6, "gaussian", True, True),
+    (100, 6, "gaussian", True, False), (70, 4, "gaussian", False, False),
+    (33, 5, "logcosh", True, False), (130, 3, "logcosh", True, False),
+    (600, 2, "gaussian", True, False)])
+def test_nuts_chain_for_chain_f64(gpu, D, C, kind, multinomial, fused):
+    mc.run_nuts_chains_vs_oracle(gpu, D, C, kind, multinomial, 3, fused=fused, rtol=1e-8)
+
+
+def test_tree_kernel_equals_fused_kernel_f32(gpu):
+    """Same keyed draws => the generic tree kernel (torch matmul potential) and the fused
+    Gaussian kernel walk the same trees in float32 for the first transition."""
+    D, C = 100, 64
+    Lam = torch.tensor(mc.make_precision(D, 3), dtype=torch.float32, device=gpu)
+    z0 = torch.randn((C, D), device=gpu) * 0.3
+    res = []
+    for fused in (True, False):
+        pyro.set_rng_seed(9)
+        k = NUTS(potential_fn=GaussianPotential(Lam), step_size=0.15, adapt_step_size=False,
+                 adapt_mass_matrix=False, max_tree_depth=8)
+        k.use_fused_gaussian = fused
+        m = MCMC(k, num_samples=1, warmup_steps=0, num_chains=C, initial_params={"x": z0.clone()})
+        m.run()
+        res.append((m.get_samples(group_by_chain=True)["x"][:, 0], k._last_stats["n_leapfrog"].clone()))
+    same = (res[0][1] == res[1][1])
+    assert same.float().mean() > 0.9          # f32 rounding may flip a rare U-turn decision
+    idx = same.nonzero().reshape(-1)
+    torch.testing.assert_close(res[0][0][idx], res[1][0][idx], rtol=2e-3, atol=2e-3)
+
+
+def test_nuts_gaussian_config3_statistics(gpu):
+    """BASELINE config 3 at reduced size: correlated Gaussian, vectorised chains, step-size and
+    diagonal mass adaptation per chain; posterior moments against the analytic ones."""
+    D, C = 30, 256
+    Lam_np = mc.make_precision(D, 0)
+    Sigma = np.linalg.inv(Lam_np)
+    Lam = torch.tensor(Lam_np, dtype=torch.float32, device=gpu)
+    pyro.set_rng_seed(0)
+    kernel = NUTS(potential_fn=GaussianPotential(Lam), max_tree_depth=8)
+    mcmc = MCMC(kernel, num_samples=150, warmup_steps=150, num_chains=C,
+                initial_params={"x": torch.zeros((C, D), device=gpu)})
+    mcmc.run()
+    x = mcmc.get_samples(group_by_chain=True)["x"].double()        # [C, S, D]
+    sd = np.sqrt(np.diag(Sigma))
+    mean = x.mean((0, 1)).cpu().numpy()
+    var = x.reshape(-1, D).var(0).cpu().numpy()
+    diag = mcmc.diagnostics()
+    n_eff = diag["x"]["n_eff"].cpu().numpy()
+    assert np.all(np.abs(mean) / sd < 5.0 / np.sqrt(n_eff)), (np.abs(mean) / sd * np.sqrt(n_eff)).max()
+    np.testing.assert_allclose(var, np.diag(Sigma), rtol=0.1)
+    assert float(diag["x"]["r_hat"].max()) < 1.05
+    acc = kernel._mean_accept_prob.mean().item()
+    assert 0.6 < acc < 0.95, acc
+    assert sum(len(v) for v in diag["divergences"].values()) == 0
+
+
+@pytest.mark.parametrize("fused_glm", [True, False])
+def test_nuts_logistic_regression(gpu, fused_glm):
+    """tests/infer/mcmc/test_nuts.py:150-171 (logistic regression, rmse(coefs) < 0.1) with
+    vectorised chains; the potential of every leapfrog step is ONE pass of the fused GLM kernel
+    over the data for all chains (fused_glm) or the element-wise site kernels (unfused)."""
+    dim, N, C = 3, 2000, 32
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn((N, dim), generator=g)
+    true = torch.arange(1.0, dim + 1)
+    y = (torch.rand((N,), generator=g) < torch.sigmoid(X @ true)).float()
+    X, y = X.to(gpu), y.to(gpu)
+    model = mc.logreg_mcmc_model if fused_glm else mc.logreg_mcmc_model_unfused
+    pyro.set_rng_seed(1)
+    kernel = NUTS(model, max_tree_depth=6)
+    mcmc = MCMC(kernel, num_samples=60, warmup_steps=100, num_chains=C)
+    mcmc.run(X, y)
+    w = mcmc.get_samples()["w"]
+    assert w.shape == (C * 60, dim)
+    rmse = (w.mean(0).cpu() - true).pow(2).mean().sqrt().item()
+    assert rmse < 0.25, rmse     # posterior mean of a N(0,1)-prior model on 2000 points
+    # both formulations target the same posterior: compare with the MAP from Newton iterations
+    wm = torch.zeros(dim, dtype=torch.float64)
+    Xd, yd = X.double().cpu(), y.double().cpu()
+    for _ in range(30):
+        p = torch.sigmoid(Xd @ wm)
+        H = Xd.t() @ (Xd * (p * (1 - p))[:, None]) + torch.eye(dim, dtype=torch.float64)
+        wm = wm - torch.linalg.solve(H, Xd.t() @ (p - yd) + wm)
+    assert (w.mean(0).double().cpu() - wm).abs().max().item() < 0.05
+    assert float(mcmc.diagnostics()["w"]["r_hat"].max()) < 1.1
+
+
+def test_hmc_conjugate_normal(gpu):
+    """Normal-Normal conjugate posterior through HMC(model) with adaptation
+    (reference test_hmc.py conjugate fixtures)."""
+    data = torch.tensor([1.2, 0.7, 1.9, 1.4, 0.9, 1.6], device=gpu)
+
+    def model(data):
+        mu = pyro.sample("mu", dist.Normal(torch.zeros((), device=data.device), 2.0))
+        with pyro.plate("d", data.shape[0]):
+            pyro.sample("x", dist.Normal(mu, 0.5), obs=data)
+
+    pyro.set_rng_seed(2)
+    mcmc = MCMC(HMC(model, trajectory_length=1.0), num_samples=200, warmup_steps=100,
+                num_chains=64)
+    mcmc.run(data)
+    mu = mcmc.get_samples()["mu"]
+    prec = 1 / 4.0 + 6 / 0.25
+    post_mean = (data.sum().item() / 0.25) / prec
+    assert abs(mu.mean().item() - post_mean) < 0.02
+    assert abs(mu.std().item() - prec ** -0.5) < 0.02
+
+
+def test_chain_offset_shifts_streams(gpu):
+    """Chain c of a run with chain_offset=k equals chain c+k of a run without offset (what makes
+    chain-sharded multi-GPU runs reproduce the single-GPU chains)."""
+    D, C = 20, 8
+    Lam = torch.tensor(mc.make_precision(D, 3), dtype=torch.float64, device=gpu)
+    z0 = torch.randn((C, D), dtype=torch.float64, device=gpu) * 0.3
+    outs = []
+    for off, sl in ((0, slice(0, C)), (3, slice(3, C))):
+        z = z0[sl].clone().contiguous()
+        g = (z @ Lam).contiguous()
+        pe = (0.5 * (z * g).sum(1)).contiguous()
+        n = z.shape[0]
+        kernels.nuts_gaussian_transition(z, pe, g, Lam, torch.ones((n, D), dtype=torch.float64, device=gpu),
+                                         torch.full((n,), 0.2, dtype=torch.float64, device=gpu), 6, True, 5, 0, off)
+        outs.append(z)
+    torch.testing.assert_close(outs[0][3:], outs[1], rtol=0, atol=0)

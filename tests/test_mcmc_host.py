@@ -1,0 +1,149 @@
+"""Host side of the HMC/NUTS path on CPU: adaptation pieces against the reference's golden
+vectors, the recursion->iteration transformation of the NUTS tree (oracle vs oracle), and the
+MCMC driver with kernels answered by the numpy oracle (tests/oracle_backend.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import integrator as o_int
+from oracle import nuts as o_nuts
+from oracle import nuts_tree as o_tree
+from tests import mcmc_cases as mc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def test_adaptation_schedule_matches_reference():
+    from pyro_amd.infer.mcmc.adaptation import build_adaptation_schedule
+    g = load("adaptation")
+    for w in (10, 19, 20, 100, 150, 200, 1000):
+        got = np.array([[s.start, s.end] for s in build_adaptation_schedule(w)])
+        np.testing.assert_array_equal(got, g["schedule/%d" % w])
+
+
+def test_dual_averaging_matches_reference_scalar_and_batched():
+    from pyro_amd.ops.dual_averaging import DualAveraging
+    g = load("adaptation")
+    da = DualAveraging(prox_center=float(g["dual/prox_center"]))
+    # batched: three chains fed the same statistic must reproduce the scalar scheme per chain
+    db = DualAveraging(prox_center=torch.full((3,), float(g["dual/prox_center"]),
+                                              dtype=torch.float64))
+    for i, gi in enumerate(g["dual/g"]):
+        da.step(float(gi))
+        db.step(torch.full((3,), float(gi), dtype=torch.float64))
+        np.testing.assert_allclose(da.get_state(), g["dual/x"][i], rtol=1e-12)
+        np.testing.assert_allclose(db.get_state()[0].numpy(), g["dual/x"][i][0], rtol=1e-12)
+        np.testing.assert_allclose(db.get_state()[1].numpy(), g["dual/x"][i][1], rtol=1e-12)
+
+
+def test_welford_matches_reference_single_and_batched():
+    from pyro_amd.ops.welford import WelfordCovariance
+    g = load("adaptation")
+    w1, wb = WelfordCovariance(diagonal=True), WelfordCovariance(diagonal=True)
+    for s in g["welford/samples"]:
+        w1.update(torch.tensor(s))
+        wb.update(torch.tensor(np.stack([s, 2 * s])))
+    np.testing.assert_allclose(w1.get_covariance(True).numpy(), g["welford/cov_reg"], rtol=1e-12)
+    np.testing.assert_allclose(w1.get_covariance(False).numpy(), g["welford/cov"], rtol=1e-12)
+    np.testing.assert_allclose(wb.get_covariance(False)[0].numpy(), g["welford/cov"], rtol=1e-12)
+    np.testing.assert_allclose(wb.get_covariance(False)[1].numpy(), 4 * g["welford/cov"], rtol=1e-12)
+    wd = WelfordCovariance(diagonal=False)
+    for s in g["welford/samples"]:
+        wd.update(torch.tensor(s))
+    np.testing.assert_allclose(np.diag(wd.get_covariance(False).numpy()), g["welford/cov"],
+                               rtol=1e-10)
+
+
+@pytest.mark.parametrize("D,multinomial", [(5, True), (30, True), (12, False)])
+def test_iterative_tree_equals_recursive_reference_formulation(D, multinomial):
+    """oracle/nuts_tree.py (iterative state machine = the HIP kernel's formulation) against
+    oracle/nuts.py (recursive, pinned against unmodified pyro in test_oracle_vs_golden.py)."""
+    rng = np.random.default_rng(0)
+    Lam = mc.make_precision(D, 1)
+    pg = o_int.gaussian_potential(Lam)
+    C = 5
+    z = rng.standard_normal((C, D)) * 0.5
+    im = rng.uniform(0.5, 1.5, (C, D))
+    step = rng.uniform(0.1, 0.4, C)
+    pe = np.array([pg(z[c])[0] for c in range(C)])
+    g = np.array([pg(z[c])[1] for c in range(C)])
+    z2, pe2, g2 = z.copy(), pe.copy(), g.copy()
+    tree = o_tree.NutsTreeOracle(z2, pe2, g2, im, step, 8, multinomial, seed=7, chain_offset=3)
+    for t in range(3):
+        refs = [o_nuts.nuts_transition(z[c], pe[c], g[c], pg, im[c], step[c],
+                                       o_nuts.KeyedDraws(7, 3 + c, t, np.float64), 8, multinomial)
+                for c in range(C)]
+        tree.begin(t)
+        while tree.n_active():
+            pq = np.array([pg(tree.zq[c])[0] for c in range(C)])
+            gq = np.array([pg(tree.zq[c])[1] for c in range(C)])
+            tree.advance(pq, gq)
+        for c in range(C):
+            r = refs[c]
+            assert tuple(tree.ints[:, c]) == (r["n_leapfrog"], r["depth"], int(r["diverging"]),
+                                              int(r["accepted"]))
+            np.testing.assert_allclose(z2[c], r["z"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(tree.accept_prob[c], r["accept_prob"], rtol=1e-10)
+            z[c], pe[c], g[c] = r["z"], r["pe"], r["grad"]
+
+
+@pytest.fixture
+def _cpu_backend(oracle_backend):
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def test_velocity_verlet_matches_reference(_cpu_backend):
+    mc.run_integrator_golden(torch.device("cpu"), 1e-10)
+
+
+@pytest.mark.parametrize("kind,multinomial,fused", [("gaussian", True, True),
+                                                     ("gaussian", True, False),
+                                                     ("logcosh", False, False)])
+def test_mcmc_driver_chain_for_chain(_cpu_backend, kind, multinomial, fused):
+    mc.run_nuts_chains_vs_oracle(torch.device("cpu"), 6, 3, kind, multinomial, 3, fused=fused)
+
+
+def test_mcmc_model_potential_and_diagnostics(_cpu_backend):
+    """NUTS(model) on a tiny conjugate model through initialize_model (chain-batched potential
+    under the _num_chains plate): potential equals the hand-written one, sampler runs with
+    adaptation, diagnostics have the reference's keys."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer.mcmc import MCMC, NUTS, initialize_model
+
+    data = torch.tensor([0.3, -0.2, 1.1, 0.7])
+
+    def model(data):
+        mu = pyro.sample("mu", dist.Normal(torch.zeros(2), 1.0).to_event(1))
+        s = pyro.sample("s", dist.LogNormal(torch.tensor(0.0), 0.5))
+        with pyro.plate("d", 4):
+            pyro.sample("x", dist.Normal(mu.sum(-1), s), obs=data)
+
+    pyro.set_rng_seed(0)
+    init, pot, transforms, _ = initialize_model(model, (data,), num_chains=3)
+    assert init["mu"].shape == (3, 2) and init["s"].shape == (3,)
+    pe = pot(init)
+    assert pe.shape == (3,)
+    for c in range(3):
+        mu, ls = init["mu"][c], init["s"][c]
+        s = ls.exp()
+        lp = torch.distributions.Normal(0.0, 1.0).log_prob(mu).sum() \
+            + torch.distributions.LogNormal(0.0, 0.5).log_prob(s) \
+            + torch.distributions.Normal(mu.sum(), s).log_prob(data).sum() + ls  # + log|dJ|
+        np.testing.assert_allclose(pe[c].item(), -lp.item(), rtol=1e-10)
+    mcmc = MCMC(NUTS(model, max_tree_depth=4), num_samples=8, warmup_steps=25, num_chains=3)
+    mcmc.run(data)
+    s = mcmc.get_samples(group_by_chain=True)
+    assert s["mu"].shape == (3, 8, 2) and s["s"].shape == (3, 8) and bool((s["s"] > 0).all())
+    d = mcmc.diagnostics()
+    assert set(d["mu"]) == {"n_eff", "r_hat"} and "divergences" in d and "acceptance rate" in d
+    assert mcmc.get_samples()["mu"].shape == (24, 2)
