@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_F32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak (FMA = 2 flop)
 
 
 def parse():
@@ -41,6 +42,11 @@ def parse():
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nuts", action="store_true", help="skip the secondary NUTS measurement")
+    ap.add_argument("--chains", type=int, default=1024, help="NUTS chains per GPU")
+    ap.add_argument("--nuts-dim", type=int, default=100)
+    ap.add_argument("--nuts-warmup", type=int, default=200)
+    ap.add_argument("--nuts-samples", type=int, default=200)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
 
@@ -68,6 +74,114 @@ def cpu_baseline(N, D, P, budget_s):
             "kind": "port",
             "sample": "%d full SVI steps (N=%d, D=%d, P=%d, fp32) of oracle/ref_port_torch.py "
                       "(the reference's torch-CPU operators without its handler overhead)" % (n, N, D, P)}
+
+
+def nuts_cpu_baseline(D, budget_s):
+    """Reference-style single-chain NUTS on the host: the recursive tree of
+    pyro/infer/mcmc/nuts.py (oracle/nuts.py) with the potential gradient taken by torch autograd
+    on CPU tensors on every leapfrog step, as pyro/ops/integrator.py:68-94 does."""
+    import numpy as np
+    from oracle import nuts as o_nuts
+    from pyro_amd import examples
+
+    _, Lam = examples.correlated_gaussian_precision(D, dtype=torch.float64)
+
+    def pot_and_grad(z):
+        zt = torch.tensor(z, requires_grad=True)
+        pe = 0.5 * zt @ Lam @ zt
+        (g,) = torch.autograd.grad(pe, zt)
+        return float(pe), g.numpy()
+
+    z = np.zeros(D)
+    pe, g = pot_and_grad(z)
+    n, t0, t = 0, time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        out = o_nuts.nuts_transition(z, pe, g, pot_and_grad, np.ones(D), 0.15,
+                                     o_nuts.KeyedDraws(1, 0, t, np.float64), 10, True)
+        z, pe, g = out["z"], out["pe"], out["grad"]
+        n += out["n_leapfrog"]
+        t += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "leapfrog steps/s", "cores": 1, "kind": "port",
+            "sample": "%d NUTS transitions (%d leapfrogs) of ONE chain, D=%d, f64, step 0.15, unit "
+                      "mass: oracle/nuts.py recursion + torch-CPU autograd gradient per leapfrog "
+                      "(the reference's per-chain execution model)" % (t, n, D)}
+
+
+def bench_nuts(dev, rank, world, args):
+    """BASELINE config 3: NUTS on a 100-dim correlated Gaussian, 1024 vectorised chains per GPU,
+    200 warm-up (step size + diagonal mass adapted per chain) + 200 sampling transitions.
+    Leapfrog steps/s = all leapfrogs of all chains (warm-up included) / wall time."""
+    import torch.distributed as dist
+
+    import pyro_amd as pyro
+    from pyro_amd import _lib, examples, kernels
+    from pyro_amd.infer.mcmc import MCMC, NUTS, GaussianPotential
+
+    C, D = args.chains, args.nuts_dim
+    _, Lam = examples.correlated_gaussian_precision(D, dtype=torch.float64)
+    Lam = Lam.float().to(dev)
+    pyro.set_rng_seed(1 + rank)
+
+    def run(warmup, samples):
+        kernel = NUTS(potential_fn=GaussianPotential(Lam), max_tree_depth=10,
+                      target_accept_prob=0.8)
+        mcmc = MCMC(kernel, num_samples=samples, warmup_steps=warmup, num_chains=C,
+                    initial_params={"x": torch.zeros((C, D), device=dev)}, shard_chains=False)
+        timer = kernels.KernelTimer(_lib.KERNEL_NUTS)
+        mcmc.hook_fn = lambda *a: timer.arm()
+        timer.arm()
+        mcmc.run()
+        return kernel, mcmc, timer
+
+    run(20, 5)                                   # warm the allocator / code objects
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel, mcmc, timer = run(args.nuts_warmup, args.nuts_samples)
+    nleap = kernel.num_leapfrog_steps
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(nleap), elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        nleap_all, elapsed = float(tot[0]), float(mx[1])
+    else:
+        nleap_all = float(nleap)
+    if rank != 0:
+        return None
+    x = mcmc.get_samples(group_by_chain=True)["x"]
+    diag = mcmc.diagnostics()
+    kern_ms = timer.times_ms()
+    kern_total_ms = sum(kern_ms[:-1]) if len(kern_ms) > 1 else float("nan")
+    n_t = args.nuts_warmup + args.nuts_samples
+    flops = nleap * (2.0 * D * D + 6.0 * D)
+    stream_bytes = nleap * 6.0 * D * 4
+    out = {"metric": "leapfrog steps/sec (NUTS)", "value": nleap_all / elapsed,
+           "unit": "leapfrog steps/s summed over chains", "n_gpus": world,
+           "wall_s": elapsed, "leapfrogs": nleap_all, "scaling": "weak", "dtype": "f32",
+           "config": {"workload": "BASELINE configs[2]: NUTS, %d-dim correlated Gaussian, %d "
+                                  "vectorised chains per GPU, %d warm-up + %d samples, per-chain "
+                                  "step-size and diagonal-mass adaptation, max_tree_depth=10"
+                                  % (D, C, args.nuts_warmup, args.nuts_samples)},
+           "mean_tree_leaves": nleap / (n_t * C),
+           "posterior_check": {"max_r_hat": float(diag["x"]["r_hat"].max()),
+                               "min_n_eff": float(diag["x"]["n_eff"].min()),
+                               "mean_accept_prob": float(kernel._mean_accept_prob.mean())},
+           "roofline": {"bound": "on-chip (state in VGPRs, Lambda in LDS): latency/VALU; the "
+                                 "streaming-model HBM figure is reported for reference",
+                        "kernel": "nuts_gaussian_kernel", "kernel_ms_total": kern_total_ms,
+                        "achieved": flops / (kern_total_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                        "peak": PEAK_F32_VALU_TFLOPS,
+                        "frac": flops / (kern_total_ms * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS,
+                        "streaming_model_TBps": stream_bytes / (kern_total_ms * 1e-3) / 1e12,
+                        "traffic": None}}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = nuts_cpu_baseline(D, min(args.cpu_budget_s, 8.0))
+    return out
 
 
 def main():
@@ -123,6 +237,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    nuts = None if args.no_nuts else bench_nuts(dev, rank, world, args)
     if rank == 0:
         kern_ms = timer.mean_ms()
         gemm_flops = 4.0 * P * N * D                      # two [P,D]x[D,N]-shaped contractions
@@ -155,6 +270,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, P, args.cpu_budget_s)
+        if nuts is not None:
+            out["secondary"] = nuts
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
