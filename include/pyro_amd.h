@@ -107,12 +107,17 @@ int pa_dist_log_prob(int dist, int dtype, void* out, pa_view2d value, pa_view2d 
  * pyro/distributions/util.py:311-328):
  *   out_rowsum[r] = sum_c  mask[r,c] ? scale * log_prob(...)[r,c] : 0
  * mask.ptr == NULL means "no mask"; mask elements are uint8 (torch.bool).
- * The reduction is deterministic (fixed two-stage tree, fp64 across threads).
- * workspace: at least pa_dist_log_prob_sum_workspace(rows, cols) bytes. */
+ *   out_total     = sum_r out_rowsum[r]           (optional, NULL to skip) -- the site's
+ *                   log_prob_sum (trace_struct.py:278) without a separate reduction launch.
+ * The reduction is deterministic (fixed tree, fp64 across threads).  Sites of up to 32768
+ * elements (global latents) take ONE launch and need no workspace
+ * (pa_dist_log_prob_sum_workspace returns 0); larger ones a two-stage reduction through
+ * `workspace` (at least pa_dist_log_prob_sum_workspace(rows, cols) bytes). */
 size_t pa_dist_log_prob_sum_workspace(int64_t rows, int64_t cols);
-int pa_dist_log_prob_sum(int dist, int dtype, void* out_rowsum, pa_view2d value, pa_view2d p0,
-                         pa_view2d p1, pa_view2d mask, double scale, int64_t rows, int64_t cols,
-                         void* workspace, size_t workspace_bytes, pa_stream_t stream);
+int pa_dist_log_prob_sum(int dist, int dtype, void* out_rowsum, void* out_total, pa_view2d value,
+                         pa_view2d p0, pa_view2d p1, pa_view2d mask, double scale, int64_t rows,
+                         int64_t cols, void* workspace, size_t workspace_bytes,
+                         pa_stream_t stream);
 
 /* Backward of both entry points above: given the upstream gradient g[r,c] (a strided view,
  * so a per-row gradient is stride_col = 0) writes, for every non-NULL output,

@@ -47,7 +47,7 @@ _SIGNATURES = {
     "pa_dist_log_prob": (c_int, [c_int, c_int, c_void_p, View2D, View2D, View2D, c_int64, c_int64,
                                  c_void_p]),
     "pa_dist_log_prob_sum_workspace": (c_size_t, [c_int64, c_int64]),
-    "pa_dist_log_prob_sum": (c_int, [c_int, c_int, c_void_p, View2D, View2D, View2D, View2D,
+    "pa_dist_log_prob_sum": (c_int, [c_int, c_int, c_void_p, c_void_p, View2D, View2D, View2D, View2D,
                                      c_double, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "pa_dist_log_prob_grad": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, View2D, View2D,
                                       View2D, View2D, View2D, c_double, c_int64, c_int64,

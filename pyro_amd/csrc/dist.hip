@@ -158,6 +158,47 @@ __global__ __launch_bounds__(DIST_THREADS) void log_prob_sum_kernel(
   if (threadIdx.x == 0) partial[row * bx + chunk] = t;
 }
 
+// Small sites (rows*cols <= SMALL_ELEMS: global latents, a few thousand elements) in ONE launch:
+// wave w of the single workgroup reduces rows w, w+4, ... (lane-strided columns, butterfly), and
+// the four per-wave totals are combined in a fixed order => deterministic, no workspace.
+constexpr int64_t SMALL_ELEMS = 32768;
+template <int DIST, typename T>
+__global__ __launch_bounds__(256) void log_prob_sum_small_kernel(
+    T* __restrict__ out_rowsum, T* __restrict__ out_total, ViewT<T> v, ViewT<T> a, ViewT<T> b,
+    ViewT<uint8_t> m, T scale, int64_t rows, int64_t cols) {
+  __shared__ double wtot[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double tot = 0.0;
+  for (int64_t row = wave; row < rows; row += 4) {
+    T acc = T(0);
+    for (int64_t c = lane; c < cols; c += 64) {
+      T bb = NParams<DIST>::n > 1 ? b.at(row, c) : T(0);
+      T lp = Fam<DIST, T>::lp(v.at(row, c), a.at(row, c), bb) * scale;
+      if (m.p != nullptr && m.at(row, c) == 0) lp = T(0);
+      acc += lp;
+    }
+    const double t = wave_sum((double)acc);
+    if (lane == 0) out_rowsum[row] = (T)t;
+    tot += t;
+  }
+  if (lane == 0) wtot[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0 && out_total != nullptr)
+    *out_total = (T)(((wtot[0] + wtot[1]) + wtot[2]) + wtot[3]);
+}
+
+// out_total = sum_r out_rowsum[r] (large path only), one workgroup, fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_total_kernel(T* __restrict__ out_total,
+                                                           const T* __restrict__ rowsum,
+                                                           int64_t rows) {
+  __shared__ double smem[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < rows; i += 256) acc += (double)rowsum[i];
+  const double t = block_sum_f64(acc, smem);
+  if (threadIdx.x == 0) *out_total = (T)t;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rowsum_finalize_kernel(T* __restrict__ out,
                                                               const double* __restrict__ partial,
@@ -264,9 +305,17 @@ static int log_prob_t(int dist, T* out, pa_view2d value, pa_view2d p0, pa_view2d
 }
 
 template <typename T>
-static int log_prob_sum_t(int dist, T* out, pa_view2d value, pa_view2d p0, pa_view2d p1,
-                          pa_view2d mask, double scale, int64_t rows, int64_t cols, double* ws,
-                          hipStream_t s) {
+static int log_prob_sum_t(int dist, T* out, T* out_total, pa_view2d value, pa_view2d p0,
+                          pa_view2d p1, pa_view2d mask, double scale, int64_t rows, int64_t cols,
+                          double* ws, hipStream_t s) {
+  if (rows * cols <= SMALL_ELEMS) {
+    auto v = as_view<T>(value), a = as_view<T>(p0), b = as_view<T>(p1);
+    auto m = as_view<uint8_t>(mask);
+    PA_DISPATCH_DIST(dist, T,
+                     hipLaunchKernelGGL((log_prob_sum_small_kernel<D_, T>), dim3(1), dim3(256), 0,
+                                        s, out, out_total, v, a, b, m, (T)scale, rows, cols));
+    return check_launch("log_prob_sum_small_kernel");
+  }
   const int64_t bx = sum_bx(rows, cols);
   const int64_t iters = (chunks_of(cols) + bx - 1) / bx;
   PA_REQUIRE(rows * bx < (int64_t(1) << 31), "log_prob_sum: grid too large");
@@ -284,7 +333,10 @@ static int log_prob_sum_t(int dist, T* out, pa_view2d value, pa_view2d p0, pa_vi
   if (rc != PA_OK) return rc;
   hipLaunchKernelGGL((rowsum_finalize_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                      s, out, ws, rows, bx);
-  return check_launch("rowsum_finalize_kernel");
+  rc = check_launch("rowsum_finalize_kernel");
+  if (rc != PA_OK || out_total == nullptr) return rc;
+  hipLaunchKernelGGL((rowsum_total_kernel<T>), dim3(1), dim3(256), 0, s, out_total, out, rows);
+  return check_launch("rowsum_total_kernel");
 }
 
 template <typename T>
@@ -325,33 +377,40 @@ int pa_dist_log_prob(int dist, int dtype, void* out, pa_view2d value, pa_view2d 
 }
 
 size_t pa_dist_log_prob_sum_workspace(int64_t rows, int64_t cols) {
-  if (rows <= 0 || cols <= 0) return 0;
+  if (rows <= 0 || cols <= 0 || rows * cols <= pa::SMALL_ELEMS) return 0;
   return (size_t)(rows * pa::sum_bx(rows, cols)) * sizeof(double);
 }
 
-int pa_dist_log_prob_sum(int dist, int dtype, void* out_rowsum, pa_view2d value, pa_view2d p0,
-                         pa_view2d p1, pa_view2d mask, double scale, int64_t rows, int64_t cols,
-                         void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+int pa_dist_log_prob_sum(int dist, int dtype, void* out_rowsum, void* out_total, pa_view2d value,
+                         pa_view2d p0, pa_view2d p1, pa_view2d mask, double scale, int64_t rows,
+                         int64_t cols, void* workspace, size_t workspace_bytes,
+                         pa_stream_t stream) {
   int rc = pa::check_common("pa_dist_log_prob_sum", dist, dtype, rows, cols);
   if (rc != PA_OK) return rc;
-  if (rows == 0) return PA_OK;
-  PA_REQUIRE(out_rowsum, "pa_dist_log_prob_sum: NULL output");
-  if (cols == 0) {
+  const size_t esz = dtype == PA_F32 ? 4 : 8;
+  if (rows == 0 || cols == 0) {
     // empty plate: the sum over nothing is 0 (torch: tensor.sum() of an empty tensor)
-    hipError_t e = hipMemsetAsync(out_rowsum, 0, (size_t)rows * (dtype == PA_F32 ? 4 : 8),
-                                  pa::as_stream(stream));
+    hipError_t e = hipSuccess;
+    if (rows > 0) {
+      PA_REQUIRE(out_rowsum, "pa_dist_log_prob_sum: NULL output");
+      e = hipMemsetAsync(out_rowsum, 0, (size_t)rows * esz, pa::as_stream(stream));
+    }
+    if (e == hipSuccess && out_total) e = hipMemsetAsync(out_total, 0, esz, pa::as_stream(stream));
     return e == hipSuccess ? PA_OK : pa::fail(PA_ERR_LAUNCH, "memset: %s", hipGetErrorString(e));
   }
+  PA_REQUIRE(out_rowsum, "pa_dist_log_prob_sum: NULL output");
   PA_REQUIRE(value.ptr && p0.ptr, "pa_dist_log_prob_sum: NULL operand");
   PA_REQUIRE(pa::nparams(dist) < 2 || p1.ptr, "pa_dist_log_prob_sum: family needs p1");
-  PA_REQUIRE(workspace && workspace_bytes >= pa_dist_log_prob_sum_workspace(rows, cols),
-             "pa_dist_log_prob_sum: workspace too small (%zu < %zu)", workspace_bytes,
-             pa_dist_log_prob_sum_workspace(rows, cols));
+  const size_t need = pa_dist_log_prob_sum_workspace(rows, cols);
+  PA_REQUIRE(need == 0 || (workspace && workspace_bytes >= need),
+             "pa_dist_log_prob_sum: workspace too small (%zu < %zu)", workspace_bytes, need);
   if (dtype == PA_F32)
-    return pa::log_prob_sum_t<float>(dist, (float*)out_rowsum, value, p0, p1, mask, scale, rows,
-                                     cols, (double*)workspace, pa::as_stream(stream));
-  return pa::log_prob_sum_t<double>(dist, (double*)out_rowsum, value, p0, p1, mask, scale, rows,
-                                    cols, (double*)workspace, pa::as_stream(stream));
+    return pa::log_prob_sum_t<float>(dist, (float*)out_rowsum, (float*)out_total, value, p0, p1,
+                                     mask, scale, rows, cols, (double*)workspace,
+                                     pa::as_stream(stream));
+  return pa::log_prob_sum_t<double>(dist, (double*)out_rowsum, (double*)out_total, value, p0, p1,
+                                    mask, scale, rows, cols, (double*)workspace,
+                                    pa::as_stream(stream));
 }
 
 int pa_dist_log_prob_grad(int dist, int dtype, void* d_value, void* d_p0, void* d_p1, pa_view2d g,

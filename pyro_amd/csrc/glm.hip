@@ -218,11 +218,13 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
         }
       }
     }
-    __syncthreads();
+    // The LDS slice is private to this wave and a wave's DS operations execute in program order,
+    // so re-staging needs no workgroup barrier (waves of a block are free to drift out of phase:
+    // one wave's MFMA burst then overlaps the other waves' VALU phase on the shared CU).
     if (it + 1 < iters) write_stage();
-    __syncthreads();
     tile = next;
   }
+  __syncthreads();
 
   // ---- block reduction over the 4 waves in a fixed order, then one partial record ---------
   constexpr int REC = glm_record_floats<DT, PT>();

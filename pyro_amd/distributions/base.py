@@ -175,6 +175,9 @@ class Delta(TorchDistribution):
                 event_dim, v.dim()))
         batch_dim = v.dim() - event_dim
         batch_shape, event_shape = v.shape[:batch_dim], v.shape[batch_dim:]
+        # a python-number log-density of 0 (identity transforms of the autoguides) is remembered so
+        # that scoring the site costs no kernel at all
+        self._zero_density = isinstance(log_density, (int, float)) and log_density == 0
         if isinstance(log_density, (int, float)):
             log_density = torch.full(batch_shape, float(log_density), dtype=v.dtype,
                                      device=v.device)
@@ -191,18 +194,29 @@ class Delta(TorchDistribution):
     def expand(self, batch_shape, _instance=None):
         batch_shape = torch.Size(batch_shape)
         v = self.v.expand(batch_shape + self.event_shape)
-        return Delta(v, self.log_density.expand(batch_shape), len(self.event_shape),
-                     validate_args=False)
+        new = Delta(v, self.log_density.expand(batch_shape), len(self.event_shape),
+                    validate_args=False)
+        new._zero_density = self._zero_density
+        return new
 
     def rsample(self, sample_shape=torch.Size()):
         shape = torch.Size(sample_shape) + self.v.shape
-        return self.v.expand(shape)
+        return self.v if shape == self.v.shape else self.v.expand(shape)
 
     def log_prob(self, x):
+        if x is self.v:
+            # the site's own draw: (x == v).log() is 0 (it is -inf only where v is NaN, and then the
+            # model site scoring the same NaN value already makes the estimate NaN)
+            return self.log_density
         v = self.v.expand(self.batch_shape + self.event_shape)
         log_prob = (x == v).type(x.dtype).log()
         log_prob = sum_rightmost(log_prob, len(self.event_shape))
         return log_prob + self.log_density
+
+    def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        if value is self.v and self._zero_density:
+            return 0.0      # exactly zero whatever the scale / mask: no kernel, no tensor
+        return None
 
     @property
     def mean(self):

@@ -17,6 +17,20 @@ def _maskable(mask):
     return mask is None or isinstance(mask, torch.Tensor)
 
 
+def _on_device(*values):
+    """Python-number parameters -> 0-dim tensors created ON the device of the tensor parameters by a
+    fill kernel.  torch.distributions would build them with torch.tensor(number, device=...), a
+    host-to-device copy from pageable memory: a synchronisation per distribution object, and an
+    operation that is not permitted while a hipGraph is being captured."""
+    proto = next((v for v in values if isinstance(v, torch.Tensor)), None)
+    if proto is None:
+        return values
+    return tuple(v if isinstance(v, torch.Tensor) or v is None
+                 else torch.full((), float(v), dtype=proto.dtype if proto.is_floating_point()
+                                 else torch.get_default_dtype(), device=proto.device)
+                 for v in values)
+
+
 class _FusedElementwise:
     """Overrides that must precede the torch class in the MRO (torch defines log_prob too)."""
 
@@ -43,13 +57,22 @@ class _FusedElementwise:
 class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMixin):
     _dist_id = _lib.DIST_NORMAL
 
+    def __init__(self, loc, scale, validate_args=None):
+        loc, scale = _on_device(loc, scale)
+        super().__init__(loc, scale, validate_args=validate_args)
+
+    def expand(self, batch_shape, _instance=None):
+        batch_shape = torch.Size(batch_shape)
+        new = type(self)(self.loc.expand(batch_shape), self.scale.expand(batch_shape),
+                         validate_args=False)
+        new._validate_args = self._validate_args
+        return new
+
     def _params(self):
         return self.loc, self.scale
 
     def rsample(self, sample_shape=torch.Size()):
-        shape = self._extended_shape(sample_shape)
-        eps = rng.normal(shape, self.loc.dtype, self.loc.device)
-        return self.loc + eps * self.scale
+        return fused.normal_rsample(self.loc, self.scale, self._extended_shape(sample_shape))
 
     def sample(self, sample_shape=torch.Size()):
         with torch.no_grad():
@@ -59,13 +82,22 @@ class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMix
 class LogNormal(_FusedElementwise, torch.distributions.LogNormal, TorchDistributionMixin):
     _dist_id = _lib.DIST_LOG_NORMAL
 
+    def __init__(self, loc, scale, validate_args=None):
+        loc, scale = _on_device(loc, scale)
+        super().__init__(loc, scale, validate_args=validate_args)
+
+    def expand(self, batch_shape, _instance=None):
+        batch_shape = torch.Size(batch_shape)
+        new = type(self)(self.loc.expand(batch_shape), self.scale.expand(batch_shape),
+                         validate_args=False)
+        new._validate_args = self._validate_args
+        return new
+
     def _params(self):
         return self.loc, self.scale
 
     def rsample(self, sample_shape=torch.Size()):
-        shape = self._extended_shape(sample_shape)
-        eps = rng.normal(shape, self.loc.dtype, self.loc.device)
-        return (self.loc + eps * self.scale).exp()
+        return fused.normal_rsample(self.loc, self.scale, self._extended_shape(sample_shape)).exp()
 
     def sample(self, sample_shape=torch.Size()):
         with torch.no_grad():

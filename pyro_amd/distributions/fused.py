@@ -120,10 +120,11 @@ class _LogProbSum(torch.autograd.Function):
             shapes.append(mask.shape)
         shape = torch.broadcast_shapes(*shapes)
         rows, cols, (v2, a2, b2, m2) = frame([value, p0, p1, mask], shape)
-        rowsum = kernels.dist_log_prob_sum(dist_id, v2, a2, b2, m2, scale, rows, cols)
+        _, total = kernels.dist_log_prob_sum(dist_id, v2, a2, b2, m2, scale, rows, cols,
+                                             want_total=True)
         ctx.dist_id, ctx.shape, ctx.scale = dist_id, shape, scale
         ctx.save_for_backward(value, p0, p1, mask)
-        return rowsum.sum() if rows > 1 else rowsum.reshape(())
+        return total
 
     @staticmethod
     def backward(ctx, g):
@@ -138,6 +139,42 @@ class _LogProbSum(torch.autograd.Function):
         outs = [None if d is None else _sum_to(d.reshape(shape), like)
                 for d, like in ((dv, value), (da, p0), (db, p1))]
         return (None,) + tuple(outs) + (None, None)
+
+
+class _NormalRsample(torch.autograd.Function):
+    """value = loc + scale * eps with eps from the Philox stream, ONE launch (pa_normal_rsample);
+    backward: d loc = g, d scale = g * eps (torch: normal.py:83-86)."""
+
+    @staticmethod
+    def forward(ctx, loc, scale, shape, seed, offset, offset_dev):
+        rows, cols, (l2, s2) = frame([loc, scale], shape)
+        out, eps = kernels.normal_rsample(l2, s2, rows, cols, seed, offset, True, offset_dev)
+        ctx.save_for_backward(eps.reshape(shape))
+        ctx.like = (loc.shape, scale.shape)
+        return out.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (eps,) = ctx.saved_tensors
+        ls, ss = ctx.like
+        d_loc = g.sum_to_size(ls) if ctx.needs_input_grad[0] else None
+        d_scale = (g * eps).sum_to_size(ss) if ctx.needs_input_grad[1] else None
+        return d_loc, d_scale, None, None, None, None
+
+
+def normal_rsample(loc, scale, shape):
+    """Reparameterised Normal draw of ``shape`` (>= broadcast of loc/scale shapes) from the
+    process-wide Philox stream."""
+    from .. import rng
+    shape = torch.Size(shape)
+    if rng.normal is not rng._default_normal or not loc.is_cuda:
+        # someone replaced the eps source (the golden tests replay the reference's draws) or the
+        # tensors are on the host (host-logic tests): keep the draw and the affine map separate
+        eps = rng.normal(shape, loc.dtype, loc.device)
+        return loc + eps * scale
+    n = shape.numel()
+    seed, off, off_dev = rng.reserve(n, loc.dtype)
+    return _NormalRsample.apply(loc, scale, shape, seed, off, off_dev)
 
 
 def log_prob(dist_id, value, p0, p1=None):

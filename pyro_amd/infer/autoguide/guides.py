@@ -39,6 +39,15 @@ def _transform_to_softplus_positive(constraint):
     return torch.distributions.transforms.SoftplusTransform()
 
 
+_IDENTITY = biject_to(constraints.real)
+
+
+def _is_identity(transform):
+    while isinstance(transform, torch.distributions.transforms.IndependentTransform):
+        transform = transform.base_transform
+    return transform is _IDENTITY
+
+
 class AutoGuide:
     def __init__(self, model, *, create_plates=None):
         self.model = model
@@ -146,8 +155,8 @@ class AutoNormal(AutoGuide):
                     dist.Normal(site_loc, site_scale).to_event(self._event_dims[name]),
                     infer={"is_auxiliary": True})
                 value = transform(unconstrained_latent)
-                if poutine.get_mask() is False:
-                    log_density = 0.0
+                if poutine.get_mask() is False or _is_identity(transform):
+                    log_density = 0.0      # real support: the Jacobian term is identically zero
                 else:
                     log_density = transform.inv.log_abs_det_jacobian(value, unconstrained_latent)
                     log_density = sum_rightmost(

@@ -1,4 +1,14 @@
-"""SVI: the drop-in training-step API (reference: pyro/infer/svi.py:38-162)."""
+"""SVI: the drop-in training-step API (reference: pyro/infer/svi.py:38-162).
+
+``SVI(..., hip_graph=True)`` is the MI355X-native fast path: after a few eager steps (which create
+the parameters, the flat optimizer state and run all validation) the WHOLE step -- guide sampling
+from the Philox stream, model replay, fused ELBO-gradient kernels, autograd backward, the flat
+Adam update and the gradient zeroing -- is captured once into a hipGraph and every later
+``step()`` with the same argument tensors is a single graph launch plus the one host read of
+the loss.  No Python handler code and no per-kernel launch latency remain in the step; the random
+stream advances on the device, so a graph-replayed run draws exactly the numbers the eager run
+would (tests/test_svi_gpu.py checks the trajectories are identical).
+"""
 import warnings
 
 import torch
@@ -9,16 +19,35 @@ from ..util import torch_isnan, zero_grads
 from .elbo import ELBO
 
 
+def _arg_key(x):
+    if isinstance(x, torch.Tensor):
+        return ("t", x.data_ptr(), tuple(x.shape), x.dtype, x.device)
+    if isinstance(x, (list, tuple)):
+        return tuple(_arg_key(v) for v in x)
+    try:
+        hash(x)
+        return ("p", x)
+    except TypeError:
+        return ("id", id(x))
+
+
+class _CapturedStep:
+    def __init__(self, graph, cap, loss):
+        self.graph, self.cap, self.loss = graph, cap, loss
+
+
 class SVI:
     def __init__(self, model, guide, optim, loss, loss_and_grads=None, num_samples=0, num_steps=0,
-                 **kwargs):
+                 hip_graph=False, graph_warmup=3, **kwargs):
         if num_steps or num_samples:
             warnings.warn("num_steps / num_samples are ignored (TracePosterior is not part of "
                           "this backend)")
         self.model, self.guide, self.optim = model, guide, optim
+        self._loss_device = None
         if isinstance(loss, ELBO):
             self.loss = loss.loss
             self.loss_and_grads = loss.loss_and_grads
+            self._loss_device = getattr(loss, "loss_and_grads_device", None)
         else:
             if loss_and_grads is None:
                 def _loss_and_grads(model, guide, *args, **kwargs):
@@ -29,22 +58,87 @@ class SVI:
 
                 loss_and_grads = _loss_and_grads
             self.loss, self.loss_and_grads = loss, loss_and_grads
+        self.hip_graph = bool(hip_graph)
+        if self.hip_graph and self._loss_device is None:
+            raise ValueError("hip_graph=True needs an ELBO that provides loss_and_grads_device")
+        self.graph_warmup = int(graph_warmup)
+        self._graphs = {}
+        self._eager_seen = {}
 
     def evaluate_loss(self, *args, **kwargs):
         with torch.no_grad():
             loss = self.loss(self.model, self.guide, *args, **kwargs)
             return loss.item() if isinstance(loss, torch.Tensor) else loss
 
-    def step(self, *args, **kwargs):
-        """One gradient step: loss_and_grads, optimizer update on every touched param, zero grads."""
+    def _params_of(self, param_capture):
+        return set(site["value"].unconstrained() if hasattr(site["value"], "unconstrained")
+                   else getattr(site["value"], "_pyro_unconstrained_param", site["value"])
+                   for site in param_capture.trace.nodes.values())
+
+    def _eager_step(self, *args, **kwargs):
         with poutine.trace(param_only=True) as param_capture:
             loss = self.loss_and_grads(self.model, self.guide, *args, **kwargs)
-        params = set(site["value"].unconstrained() if hasattr(site["value"], "unconstrained")
-                     else getattr(site["value"], "_pyro_unconstrained_param", site["value"])
-                     for site in param_capture.trace.nodes.values())
+        params = self._params_of(param_capture)
         self.optim(params)
         if not getattr(self.optim, "zeroes_grads", False):
             zero_grads(params)
         if isinstance(loss, tuple):
             return type(loss)(map(lambda x: x.item() if isinstance(x, torch.Tensor) else x, loss))
         return loss.item() if isinstance(loss, torch.Tensor) else loss
+
+    def step(self, *args, **kwargs):
+        """One gradient step: loss_and_grads, optimizer update on every touched param, zero grads."""
+        if not self.hip_graph:
+            return self._eager_step(*args, **kwargs)
+        key = (_arg_key(args), _arg_key(tuple(sorted(kwargs.items()))))
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._eager_seen.get(key, 0)
+            if n < self.graph_warmup:
+                self._eager_seen[key] = n + 1
+                return self._eager_step(*args, **kwargs)
+            entry = self._capture(key, args, kwargs)
+            if entry is None:                      # capture failed: stay eager
+                return self._eager_step(*args, **kwargs)
+        entry.cap.before_replay()
+        entry.graph.replay()
+        entry.cap.after_replay()
+        return entry.loss.item()
+
+    def _capture(self, key, args, kwargs):
+        from .. import rng
+        from ..primitives import validation_enabled
+
+        device = None
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                device = a.device
+                break
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        cap = rng.GraphCapture(device)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with validation_enabled(False):   # validation ran in the eager warm-up steps
+                with torch.cuda.graph(graph):
+                    with cap:
+                        with poutine.trace(param_only=True) as param_capture:
+                            loss = self._loss_device(self.model, self.guide, *args, **kwargs)
+                        params = self._params_of(param_capture)
+                        self.optim(params)
+                        if not getattr(self.optim, "zeroes_grads", False):
+                            zero_grads(params)
+                        cap.finish()
+                        loss = loss.detach().clone() if isinstance(loss, torch.Tensor) else \
+                            torch.tensor(float(loss), device=device)
+        except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
+            import os
+            if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
+                raise
+            warnings.warn("pyro_amd: hipGraph capture of SVI.step failed ({}: {}); continuing "
+                          "with eager steps".format(type(e).__name__, e))
+            self.hip_graph = False
+            return None
+        entry = _CapturedStep(graph, cap, loss)
+        self._graphs[key] = entry
+        return entry

@@ -33,6 +33,21 @@ def _compute_log_r(model_trace, guide_trace):
     return log_r
 
 
+_SIGN_CACHE = {}
+
+
+def _signed_sum(terms, signs):
+    """sum_i signs[i] * terms[i] for 0-dim tensors: one stack + one dot (the sign vector is cached
+    on the device per pattern)."""
+    t0 = terms[0]
+    key = (tuple(signs), t0.dtype, t0.device)
+    sv = _SIGN_CACHE.get(key)
+    if sv is None:
+        sv = torch.tensor(signs, dtype=t0.dtype, device=t0.device)
+        _SIGN_CACHE[key] = sv
+    return torch.dot(torch.stack(terms), sv)
+
+
 class Trace_ELBO(ELBO):
     def _guide_is_reparameterized(self, guide_trace):
         for site in guide_trace.nodes.values():
@@ -57,25 +72,40 @@ class Trace_ELBO(ELBO):
     # ---- per-particle (or per vectorised batch of particles) terms ---------------------------
     def _surrogate_and_elbo(self, model_trace, guide_trace):
         """Returns (elbo tensor, surrogate elbo tensor), both 0-dim on the device."""
+        if getattr(guide_trace, "_fully_reparam", False):
+            # every term enters elbo and surrogate alike (entropy_term == log_prob for
+            # reparameterised sites, distribution.py:98-125): sum_model - sum_guide assembled with
+            # ONE stack + ONE signed reduction instead of two accumulations per site
+            terms, signs, const = [], [], 0.0
+            for trace, sign in ((model_trace, 1.0), (guide_trace, -1.0)):
+                for site in trace.nodes.values():
+                    if site["type"] == "sample":
+                        x = site["log_prob_sum"]
+                        if isinstance(x, torch.Tensor):
+                            terms.append(x)
+                            signs.append(sign)
+                        else:
+                            const += sign * x
+            if not terms:
+                return const, const
+            total = _signed_sum(terms, signs)
+            if const != 0.0:
+                total = total + const
+            return total.detach(), total
         elbo = 0.0
         surrogate = 0.0
         for site in model_trace.nodes.values():
             if site["type"] == "sample":
-                elbo = elbo + site["log_prob_sum"].detach()
-                surrogate = surrogate + site["log_prob_sum"]
-        if getattr(guide_trace, "_fully_reparam", False):
-            for site in guide_trace.nodes.values():
-                if site["type"] == "sample":
-                    # entropy_term == log_prob for reparameterised sites (distribution.py:98-125)
-                    elbo = elbo - site["log_prob_sum"].detach()
-                    surrogate = surrogate - site["log_prob_sum"]
-            return elbo, surrogate
+                x = site["log_prob_sum"]
+                elbo = elbo + (x.detach() if isinstance(x, torch.Tensor) else x)
+                surrogate = surrogate + x
         log_r = None
         for name, site in guide_trace.nodes.items():
             if site["type"] != "sample":
                 continue
             log_prob, score_function_term, entropy_term = site["score_parts"]
-            elbo = elbo - site["log_prob_sum"].detach()
+            lps = site["log_prob_sum"]
+            elbo = elbo - (lps.detach() if isinstance(lps, torch.Tensor) else lps)
             if not is_identically_zero(entropy_term):
                 surrogate = surrogate - entropy_term.sum()
             if not is_identically_zero(score_function_term):
@@ -107,14 +137,26 @@ class Trace_ELBO(ELBO):
 
     def loss_and_grads(self, model, guide, *args, **kwargs):
         """Backward on the surrogate; returns the ELBO estimate as a float (one host sync)."""
-        loss = 0.0
-        for model_trace, guide_trace in self._get_traces(model, guide, args, kwargs):
-            e, s = self._surrogate_and_elbo(model_trace, guide_trace)
-            loss = loss - e / self.num_particles
-            trainable = any(site["type"] == "param" for trace in (model_trace, guide_trace)
-                            for site in trace.nodes.values())
-            if trainable and getattr(s, "requires_grad", False):
-                (-s / self.num_particles).backward(retain_graph=self.retain_graph)
-        loss = torch_item(loss)
+        loss = torch_item(self.loss_and_grads_device(model, guide, *args, **kwargs))
         warn_if_nan(loss, "loss")
         return loss
+
+    def loss_and_grads_device(self, model, guide, *args, **kwargs):
+        """Same, but the loss stays a 0-dim device tensor and nothing synchronises with the host
+        (what a captured hipGraph step needs, see SVI(hip_graph=True))."""
+        loss = None
+        c = -1.0 / self.num_particles
+        for model_trace, guide_trace in self._get_traces(model, guide, args, kwargs):
+            e, s = self._surrogate_and_elbo(model_trace, guide_trace)
+            trainable = any(site["type"] == "param" for trace in (model_trace, guide_trace)
+                            for site in trace.nodes.values())
+            if isinstance(s, torch.Tensor) and getattr(guide_trace, "_fully_reparam", False):
+                sl = s * c                      # surrogate loss == loss value in this case
+                term = sl.detach()
+            else:
+                sl = s * c if isinstance(s, torch.Tensor) else None
+                term = e * c
+            loss = term if loss is None else loss + term
+            if trainable and sl is not None and sl.requires_grad:
+                sl.backward(retain_graph=self.retain_graph)
+        return 0.0 if loss is None else loss

@@ -74,6 +74,13 @@ class KernelTimer:
                                                   ctypes.c_void_p(e.cuda_event)))
         self.pairs.append((s, e))
 
+    def read_last(self):
+        """Elapsed ms of the most recently armed bracket (after a device synchronise).  When the
+        bracket was armed for a launch that got captured into a hipGraph, the two event records
+        are graph nodes and every replay re-records them: this is the last replay's kernel time."""
+        s, e = self.pairs[-1]
+        return s.elapsed_time(e)
+
     def times_ms(self):
         return [s.elapsed_time(e) for s, e in self.pairs]
 
@@ -86,20 +93,28 @@ class KernelTimer:
 # RNG
 # ------------------------------------------------------------------------------------------
 
-def philox_normal(shape, dtype, device, seed, offset):
+def philox_normal(shape, dtype, device, seed, offset, offset_dev=None):
+    """offset_dev: optional int64[1] device tensor added to ``offset`` by the kernel."""
     out = torch.empty(shape, dtype=dtype, device=device)
-    _require_gpu(out)
-    check(_lib.load().pa_philox_normal(_ptr(out), out.numel(), _dtype(out), seed, offset, None,
-                                       _stream()))
+    _require_gpu(out, offset_dev)
+    check(_lib.load().pa_philox_normal(_ptr(out), out.numel(), _dtype(out), seed, offset,
+                                       _ptr(offset_dev), _stream()))
     return out
 
 
-def philox_uniform(shape, dtype, device, seed, offset):
+def philox_uniform(shape, dtype, device, seed, offset, offset_dev=None):
     out = torch.empty(shape, dtype=dtype, device=device)
-    _require_gpu(out)
-    check(_lib.load().pa_philox_uniform(_ptr(out), out.numel(), _dtype(out), seed, offset, None,
-                                        _stream()))
+    _require_gpu(out, offset_dev)
+    check(_lib.load().pa_philox_uniform(_ptr(out), out.numel(), _dtype(out), seed, offset,
+                                        _ptr(offset_dev), _stream()))
     return out
+
+
+def counter_add(counter, inc):
+    """*counter += inc on the stream (device-resident Philox base offset; graph-replay safe)."""
+    _require_gpu(counter)
+    assert counter.dtype == torch.int64 and counter.numel() == 1
+    check(_lib.load().pa_counter_add(_ptr(counter), int(inc), _stream()))
 
 
 # ------------------------------------------------------------------------------------------
@@ -116,18 +131,21 @@ def dist_log_prob(dist_id, value, p0, p1, rows, cols):
     return out
 
 
-def dist_log_prob_sum(dist_id, value, p0, p1, mask, scale, rows, cols):
-    """Fused log_prob -> scale_and_mask -> sum over cols. Returns [rows]."""
+def dist_log_prob_sum(dist_id, value, p0, p1, mask, scale, rows, cols, want_total=False):
+    """Fused log_prob -> scale_and_mask -> sum over cols. Returns rowsum[rows], or
+    (rowsum[rows], total 0-dim) with ``want_total`` (the total comes from the same launch)."""
     _require_gpu(value, p0, p1, mask)
     lib = _lib.load()
-    out = torch.empty((rows,), dtype=value.dtype, device=value.device)
+    buf = torch.empty((rows + 1,), dtype=value.dtype, device=value.device)
+    out, total = buf[:rows], buf[rows]
     nbytes = lib.pa_dist_log_prob_sum_workspace(rows, cols)
-    ws = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=value.device)
-    check(lib.pa_dist_log_prob_sum(dist_id, _dtype(value), _ptr(out), _view(value, rows, cols),
-                                   _view(p0, rows, cols), _view(p1, rows, cols),
-                                   _view(mask, rows, cols), float(scale), rows, cols, _ptr(ws),
-                                   ws.numel(), _stream()))
-    return out
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=value.device) if nbytes else None
+    check(lib.pa_dist_log_prob_sum(dist_id, _dtype(value), _ptr(out),
+                                   _ptr(total) if want_total else None,
+                                   _view(value, rows, cols), _view(p0, rows, cols),
+                                   _view(p1, rows, cols), _view(mask, rows, cols), float(scale),
+                                   rows, cols, _ptr(ws), nbytes, _stream()))
+    return (out, total) if want_total else out
 
 
 def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need):
@@ -142,13 +160,13 @@ def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need)
     return outs
 
 
-def normal_rsample(loc, scale, rows, cols, seed, offset, want_eps=True):
-    _require_gpu(loc, scale)
+def normal_rsample(loc, scale, rows, cols, seed, offset, want_eps=True, offset_dev=None):
+    _require_gpu(loc, scale, offset_dev)
     out = torch.empty((rows, cols), dtype=loc.dtype, device=loc.device)
     eps = torch.empty_like(out) if want_eps else None
     check(_lib.load().pa_normal_rsample(_dtype(loc), _ptr(out), _ptr(eps), _view(loc, rows, cols),
-                                        _view(scale, rows, cols), rows, cols, seed, offset, None,
-                                        _stream()))
+                                        _view(scale, rows, cols), rows, cols, seed, offset,
+                                        _ptr(offset_dev), _stream()))
     return out, eps
 
 

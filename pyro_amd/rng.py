@@ -14,6 +14,10 @@ import torch
 from . import kernels
 
 _STATE = {"seed": 0, "offset": 0}
+# While a hipGraph is being captured the block offset of a draw cannot be a launch constant (every
+# replay would repeat the same numbers): draws are addressed relative to a device-resident base
+# counter that the graph itself advances (pa_counter_add) -- see GraphCapture below.
+_CAPTURE = {"active": None}
 
 
 def set_rng_seed(seed):
@@ -37,11 +41,15 @@ def set_rng_state(state):
 
 
 def reserve(n_elements, dtype):
-    """Reserve Philox blocks for ``n_elements`` draws; returns (seed, offset)."""
+    """Reserve Philox blocks for ``n_elements`` draws; returns (seed, offset, offset_dev) where
+    ``offset_dev`` is None (eager) or the device base counter of the active graph capture."""
     per = 4 if dtype == torch.float32 else 2
     off = _STATE["offset"]
     _STATE["offset"] = off + (int(n_elements) + per - 1) // per
-    return _STATE["seed"], off
+    cap = _CAPTURE["active"]
+    if cap is not None:
+        return _STATE["seed"], off - cap.start, cap.base
+    return _STATE["seed"], off, None
 
 
 def normal(shape, dtype, device):
@@ -49,13 +57,54 @@ def normal(shape, dtype, device):
     n = 1
     for s in shape:
         n *= int(s)
-    seed, off = reserve(n, dtype)
-    return kernels.philox_normal(tuple(shape), dtype, device, seed, off)
+    seed, off, off_dev = reserve(n, dtype)
+    return kernels.philox_normal(tuple(shape), dtype, device, seed, off, off_dev)
+
+
+_default_normal = normal
 
 
 def uniform(shape, dtype, device):
     n = 1
     for s in shape:
         n *= int(s)
-    seed, off = reserve(n, dtype)
-    return kernels.philox_uniform(tuple(shape), dtype, device, seed, off)
+    seed, off, off_dev = reserve(n, dtype)
+    return kernels.philox_uniform(tuple(shape), dtype, device, seed, off, off_dev)
+
+
+class GraphCapture:
+    """Makes the Philox stream replay-safe: inside ``with GraphCapture(device) as cap`` every draw
+    reads its block offset as ``*base + relative offset``; ``cap.finish()`` (still inside the
+    capture) appends the node that advances ``*base`` by the blocks one replay consumes.  A replay
+    therefore draws exactly the numbers the same step would draw eagerly: call
+    ``cap.before_replay()`` to (re)synchronise the base with the host-side offset and
+    ``cap.after_replay()`` to advance the host mirror."""
+
+    def __init__(self, device):
+        self.base = torch.zeros((1,), dtype=torch.int64, device=device)
+        self.start = None
+        self.used = None
+        self._base_value = None      # what *base holds on the device, if known
+
+    def __enter__(self):
+        assert _CAPTURE["active"] is None, "nested RNG graph captures are not supported"
+        self.start = _STATE["offset"]
+        _CAPTURE["active"] = self
+        return self
+
+    def finish(self):
+        self.used = _STATE["offset"] - self.start
+        kernels.counter_add(self.base, self.used)
+
+    def __exit__(self, *exc):
+        _CAPTURE["active"] = None
+        _STATE["offset"] = self.start      # capturing executes nothing: no draws were consumed
+
+    def before_replay(self):
+        if self._base_value != _STATE["offset"]:
+            self.base.fill_(_STATE["offset"])
+            self._base_value = _STATE["offset"]
+
+    def after_replay(self):
+        _STATE["offset"] += self.used
+        self._base_value += self.used

@@ -24,13 +24,13 @@ def _bc(t, rows, cols):
     return None if t is None else np.broadcast_to(_np(t), (rows, cols))
 
 
-def philox_normal(shape, dtype, device, seed, offset):
+def philox_normal(shape, dtype, device, seed, offset, offset_dev=None):
     n = int(np.prod(shape)) if len(shape) else 1
     np_dt = np.float32 if dtype == torch.float32 else np.float64
     return torch.as_tensor(o_philox.normal(n, np_dt, seed, offset).reshape(shape), device=device)
 
 
-def philox_uniform(shape, dtype, device, seed, offset):
+def philox_uniform(shape, dtype, device, seed, offset, offset_dev=None):
     n = int(np.prod(shape)) if len(shape) else 1
     np_dt = np.float32 if dtype == torch.float32 else np.float64
     return torch.as_tensor(o_philox.uniform(n, np_dt, seed, offset).reshape(shape), device=device)
@@ -43,12 +43,13 @@ def dist_log_prob(dist_id, value, p0, p1, rows, cols):
     return torch.as_tensor(np.ascontiguousarray(out), dtype=value.dtype)
 
 
-def dist_log_prob_sum(dist_id, value, p0, p1, mask, scale, rows, cols):
+def dist_log_prob_sum(dist_id, value, p0, p1, mask, scale, rows, cols, want_total=False):
     out = o_dists.log_prob_sum(dist_id, _bc(value, rows, cols).astype(np.float64),
                                _bc(p0, rows, cols).astype(np.float64),
                                None if p1 is None else _bc(p1, rows, cols).astype(np.float64),
                                _bc(mask, rows, cols), scale)
-    return torch.as_tensor(np.ascontiguousarray(out), dtype=value.dtype)
+    rs = torch.as_tensor(np.ascontiguousarray(out), dtype=value.dtype)
+    return (rs, rs.sum()) if want_total else rs
 
 
 def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need):

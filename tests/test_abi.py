@@ -64,4 +64,5 @@ def test_argument_errors_before_launch():
     with pytest.raises(_lib.Unsupported):
         _lib.check(rc)
     assert lib.pa_glm_bernoulli_workspace(10, 200, 4) == 0
-    assert lib.pa_dist_log_prob_sum_workspace(4, 100) > 0
+    assert lib.pa_dist_log_prob_sum_workspace(4, 100) == 0       # single-launch small-site path
+    assert lib.pa_dist_log_prob_sum_workspace(4, 100000) > 0

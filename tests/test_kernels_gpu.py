@@ -73,7 +73,8 @@ def _dist_inputs(dist_id, rows, cols, rng, bcast):
 @pytest.mark.parametrize("dist_id", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("rows,cols,bcast", [(1, 1, "none"), (3, 7, "none"), (5, 1031, "row"),
-                                             (7, 2500, "col"), (64, 4099, "none")])
+                                             (7, 2500, "col"), (64, 4099, "none"),
+                                             (300, 100, "none"), (2, 70001, "row")])
 def test_dist_log_prob_sum_grad(gpu, dist_id, dtype, rows, cols, bcast):
     k = _k()
     rng = np.random.default_rng(dist_id * 100 + rows)
@@ -94,9 +95,12 @@ def test_dist_log_prob_sum_grad(gpu, dist_id, dtype, rows, cols, bcast):
     mask = rng.uniform(size=(rows, cols)) < 0.7
     for m, scale in [(None, 1.0), (mask, 2.5)]:
         tm = tt(m, gpu) if m is not None else None
-        s = k.dist_log_prob_sum(dist_id, tv, ta, tb, tm, scale, rows, cols).cpu().numpy()
+        s, tot = k.dist_log_prob_sum(dist_id, tv, ta, tb, tm, scale, rows, cols, want_total=True)
+        s = s.cpu().numpy()
         ref_s = o_dists.log_prob_sum(dist_id, v64, a64, b64, m, scale)
         np.testing.assert_allclose(s, ref_s, rtol=rtol, atol=rtol * max(1.0, np.abs(ref_s).max()))
+        np.testing.assert_allclose(tot.item(), ref_s.sum(), rtol=rtol,
+                                   atol=rtol * max(1.0, np.abs(ref_s).sum()))
         g_row = rng.standard_normal(rows).astype(np_dt)
         tg = tt(g_row.reshape(rows, 1), gpu)
         outs = k.dist_log_prob_grad(dist_id, tg, tv, ta, tb, tm, scale, rows, cols,

@@ -107,3 +107,36 @@ def test_svi_converges_to_reference_posterior(gpu):
     ref = port.loc_w.detach().numpy()
     rel = np.abs(mean - ref).max() / np.abs(ref).max()
     assert rel < 1e-4, rel
+
+
+def test_hip_graph_step_equals_eager_step(gpu):
+    """SVI(hip_graph=True): after the eager warm-up steps the captured step is replayed; the
+    Philox stream advances on the device, so losses and parameters follow EXACTLY the eager
+    trajectory (deterministic kernels => bit-identical)."""
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=3)
+    runs = []
+    for use_graph in (False, True):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(7)
+        pyro.enable_validation(False)
+        try:
+            guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+            svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+                      Trace_ELBO(num_particles=16, vectorize_particles=True, max_plate_nesting=1),
+                      hip_graph=use_graph, graph_warmup=3)
+            losses = [svi.step(X, y) for _ in range(12)]
+            if use_graph:
+                assert svi.hip_graph and len(svi._graphs) == 1   # captured, not fallen back
+            params = {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
+        finally:
+            pyro.enable_validation(True)
+        runs.append((losses, params))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    assert runs[0][0][-1] < runs[0][0][0]
