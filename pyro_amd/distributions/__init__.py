@@ -38,6 +38,22 @@ _wrap_all()
 
 # pyro-style overrides that matter for the enumeration path (reference: torch.py:124-149)
 class Categorical(torch.distributions.Categorical, TorchDistributionMixin):
+    def expand(self, batch_shape, _instance=None):
+        """Expansion keeps the log-probability table a stride-0 VIEW of the un-expanded one.
+        (torch expands ``probs`` first and materialises ``logits`` [batch.., V] from the expanded
+        tensor on first use: for examples/lda.py that is T x words x docs x V elements.)"""
+        new = self._get_checked_instance(Categorical, _instance)
+        batch_shape = torch.Size(batch_shape)
+        param_shape = batch_shape + torch.Size((self._num_events,))
+        new.logits = self.logits.expand(param_shape)       # computed once on the small table
+        if "probs" in self.__dict__:
+            new.probs = self.probs.expand(param_shape)
+        new._param = new.logits
+        new._num_events = self._num_events
+        super(torch.distributions.Categorical, new).__init__(batch_shape, validate_args=False)
+        new._validate_args = self._validate_args
+        return new
+
     def enumerate_support(self, expand=True):
         result = super().enumerate_support(expand=expand)
         if not expand:

@@ -41,3 +41,83 @@ def correlated_gaussian_precision(D, seed=0, dtype=torch.float64):
     Sigma = A @ A.T / D + 0.1 * torch.eye(D, dtype=torch.float64)
     Lam = torch.linalg.inv(Sigma)
     return Sigma.to(dtype), (0.5 * (Lam + Lam.T)).to(dtype)
+
+
+# ---- BASELINE config 4: examples/lda.py:42-122 restated against the drop-in API ----------------
+class LdaArgs:
+    def __init__(self, num_topics=8, num_words=1024, num_docs=1000, num_words_per_doc=64,
+                 layer_sizes="100-100"):
+        self.num_topics, self.num_words, self.num_docs = num_topics, num_words, num_docs
+        self.num_words_per_doc, self.layer_sizes = num_words_per_doc, layer_sizes
+
+
+def lda_model(data=None, args=None, batch_size=None, device=None):
+    """examples/lda.py:42-70: word_topics is enumerated in parallel and summed out exactly."""
+    dev = data.device if data is not None else device
+    with plate("topics", args.num_topics):
+        topic_weights = sample("topic_weights", dist.Gamma(
+            torch.full((), 1.0 / args.num_topics, device=dev), torch.ones((), device=dev)))
+        topic_words = sample("topic_words", dist.Dirichlet(
+            torch.ones(args.num_words, device=dev) / args.num_words))
+    with plate("documents", args.num_docs, device=dev) as ind:
+        if data is not None:
+            assert data.shape == (args.num_words_per_doc, args.num_docs)
+            if ind.shape[0] != args.num_docs:
+                data = data[:, ind]
+        doc_topics = sample("doc_topics", dist.Dirichlet(topic_weights))
+        with plate("words", args.num_words_per_doc):
+            word_topics = sample("word_topics", dist.Categorical(doc_topics),
+                                 infer={"enumerate": "parallel"})
+            data = sample("doc_words", dist.Categorical(topic_words[word_topics]), obs=data)
+    return topic_weights, topic_words, data
+
+
+def lda_make_predictor(args, device):
+    """examples/lda.py:75-90: MLP from word histograms to topic proportions."""
+    import torch.nn as nn
+    sizes = [args.num_words] + [int(s) for s in args.layer_sizes.split("-")] + [args.num_topics]
+    layers = []
+    for a, b in zip(sizes, sizes[1:]):
+        layer = nn.Linear(a, b)
+        layer.weight.data.normal_(0, 0.001)
+        layer.bias.data.normal_(0, 0.001)
+        layers += [layer, nn.Sigmoid()]
+    layers.append(nn.Softmax(dim=-1))
+    return nn.Sequential(*layers).to(device)
+
+
+def lda_guide(predictor, data, args, batch_size=None):
+    """examples/lda.py:93-122: conjugate global factors + amortised Delta for doc_topics."""
+    from .distributions import constraints
+    from .primitives import module, param
+    dev = data.device
+    topic_weights_posterior = param("topic_weights_posterior",
+                                    lambda: torch.ones(args.num_topics, device=dev),
+                                    constraint=constraints.positive)
+    topic_words_posterior = param("topic_words_posterior",
+                                  lambda: torch.ones(args.num_topics, args.num_words, device=dev),
+                                  constraint=constraints.greater_than(0.5))
+    with plate("topics", args.num_topics):
+        sample("topic_weights", dist.Gamma(topic_weights_posterior, torch.ones((), device=dev)))
+        sample("topic_words", dist.Dirichlet(topic_words_posterior))
+    module("predictor", predictor)
+    with plate("documents", args.num_docs, batch_size, device=dev) as ind:
+        if ind.shape[0] != args.num_docs:
+            data = data[:, ind]
+        counts = torch.zeros(args.num_words, data.shape[1], device=dev).scatter_add(
+            0, data, torch.ones(data.shape, device=dev))
+        doc_topics = predictor(counts.transpose(0, 1))
+        sample("doc_topics", dist.Delta(doc_topics, event_dim=1))
+
+
+def synthetic_lda_data(args, device, seed=0):
+    """Documents drawn from a random topic model (int64 word ids [words_per_doc, num_docs])."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    T, V, D, W = args.num_topics, args.num_words, args.num_docs, args.num_words_per_doc
+    phi = torch.softmax(3.0 * torch.randn((T, V), device=device, generator=g), -1)
+    theta = torch.softmax(2.0 * torch.randn((D, T), device=device, generator=g), -1)
+    z = torch.multinomial(theta, W, replacement=True, generator=g)          # [D, W]
+    cdf = phi.cumsum(-1)
+    u = torch.rand((D, W), device=device, generator=g)
+    words = (u.unsqueeze(-1) > cdf[z]).sum(-1).clamp(max=V - 1)            # inverse-CDF draw
+    return words.t().contiguous()

@@ -1,0 +1,204 @@
+"""TraceEnum_ELBO: ELBO with exact marginalisation of discrete model variables enumerated in
+parallel (reference: pyro/infer/traceenum_elbo.py:112-214 _compute_model_factors /
+_compute_dice_elbo, :334-394 _get_trace/_get_traces, :415-470 loss_and_grads).
+
+Scope of this plugin (what BASELINE config 4, examples/lda.py, needs):
+  * discrete sites enumerated in the MODEL (``infer={"enumerate": "parallel"}`` or
+    ``config_enumerate``) and absent from the guide are summed out exactly by plated
+    sum-product message passing (pyro_amd/ops/contract.py);
+  * the guide is fully reparameterised and has no enumerated sites, so every DiCE weight is 1
+    and the surrogate equals the ELBO estimate (pyro/infer/util.py:264-326 reduces to a plain sum).
+Guide-side enumeration and score-function (non-reparameterised) guide sites raise
+NotImplementedError instead of silently producing a biased gradient.
+"""
+from collections import OrderedDict
+
+import torch
+
+from .. import poutine
+from ..distributions.util import scale_and_mask
+from ..ops.contract import LazyGather, Term, contract_tensor_tree
+from ..poutine.util import prune_subsample_sites
+from ..util import torch_item, warn_if_nan
+from .elbo import ELBO
+from .enum import check_model_guide_match, config_enumerate  # noqa: F401
+from .trace_elbo import _signed_sum
+
+
+def _ordinal(site):
+    return frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
+
+
+def _enum_dims_of(tensor, first_enum_dim):
+    """Tensor dims strictly left of the plate block with size > 1 (negative indices)."""
+    n = tensor.dim()
+    return {d - n for d in range(n) if d - n <= first_enum_dim and tensor.shape[d] > 1}
+
+
+def _lazy_gather(site, first_enum_dim):
+    """Observed Categorical whose logits are [T, 1.., V] expanded over two plates and whose value
+    is int64 [W, D]: keep the factor as (table, index) for the fused kernel."""
+    fn, value = site["fn"], site["value"]
+    if not isinstance(fn, torch.distributions.Categorical) or value.dtype != torch.int64:
+        return None
+    if value.dim() != 2 or site["mask"] is not None:
+        return None
+    logits = fn.logits
+    if logits.dim() < 4 or logits.shape[-3:-1] != value.shape:
+        return None
+    lead = logits.shape[:-3]
+    nz = [i for i, s in enumerate(lead) if s > 1]
+    if len(nz) != 1 or logits.stride(-2) != 0 or logits.stride(-3) != 0:
+        return None
+    edim = nz[0] - len(lead) - 2          # tensor dim of the enumerated variable in the factor
+    if edim > first_enum_dim:
+        return None
+    T, V = lead[nz[0]], logits.shape[-1]
+    idx = (0,) * nz[0] + (slice(None),) + (0,) * (len(lead) - nz[0] - 1) + (0, 0, slice(None))
+    table = logits[idx]                   # [T, V] view of the un-expanded log-probabilities
+    return LazyGather(table.reshape(T, V), value, edim)
+
+
+class TraceEnum_ELBO(ELBO):
+    def _get_trace(self, model, guide, args, kwargs):
+        if self.max_plate_nesting == float("inf"):
+            self._guess_max_plate_nesting(model, guide, args, kwargs)
+        first_enum_dim = -1 - self.max_plate_nesting
+        guide_trace = poutine.trace(guide).get_trace(*args, **kwargs)
+        model_enum = poutine.enum(model, first_available_dim=first_enum_dim)
+        model_trace = poutine.trace(poutine.replay(model_enum, trace=guide_trace)).get_trace(
+            *args, **kwargs)
+        if poutine.settings.validation_enabled():
+            check_model_guide_match(model_trace, guide_trace, self.max_plate_nesting)
+        guide_trace = prune_subsample_sites(guide_trace)
+        model_trace = prune_subsample_sites(model_trace)
+        for name, site in guide_trace.nodes.items():
+            if site["type"] != "sample":
+                continue
+            if site["infer"].get("enumerate") or site["infer"].get("_enumerate_dim") is not None:
+                raise NotImplementedError("pyro_amd.TraceEnum_ELBO: guide-side enumeration "
+                                          "(site '{}') is not built".format(name))
+            if not getattr(site["fn"], "has_rsample", False):
+                raise NotImplementedError(
+                    "pyro_amd.TraceEnum_ELBO: non-reparameterised guide site '{}' needs DiCE "
+                    "weights, which this plugin does not build".format(name))
+        model_trace._first_enum_dim = first_enum_dim
+        return model_trace, guide_trace
+
+    # ---- reference: _compute_model_factors + contract + sum (all DiCE weights are 1) ----------
+    def _elbo_tensor(self, model_trace, guide_trace):
+        first_enum_dim = model_trace._first_enum_dim
+        enum_names = [n for n, s in model_trace.nodes.items()
+                      if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None
+                      and n not in guide_trace.nodes]
+        enum_dims = {model_trace.nodes[n]["infer"]["_enumerate_dim"] for n in enum_names}
+        plain, signs, const = [], [], 0.0
+        factors = OrderedDict()
+        scales = []
+        for name, site in model_trace.nodes.items():
+            if site["type"] != "sample":
+                continue
+            if name in enum_names:
+                lp = site["fn"].log_prob(site["value"])
+                lp = scale_and_mask(lp, mask=site["mask"])
+                factors.setdefault(_ordinal(site), []).append(
+                    Term(lp, _enum_dims_of(lp, first_enum_dim) & enum_dims, _ordinal(site)))
+                scales.append(site["scale"])
+                continue
+            lazy = _lazy_gather(site, first_enum_dim) if enum_dims else None
+            if lazy is not None and lazy.enum_dim in enum_dims:
+                factors.setdefault(_ordinal(site), []).append(
+                    Term(None, {lazy.enum_dim}, _ordinal(site), lazy=lazy))
+                scales.append(site["scale"])
+                continue
+            if not enum_dims or not self._depends_on_enum(site, first_enum_dim):
+                fused = model_trace._site_sum(name, site)     # one-kernel plate sum
+                if isinstance(fused, torch.Tensor):
+                    plain.append(fused)
+                    signs.append(1.0)
+                else:
+                    const += fused
+                continue
+            lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
+            dims = _enum_dims_of(lp, first_enum_dim) & enum_dims
+            if dims:
+                lp = scale_and_mask(lp, mask=site["mask"])      # mask inside, scale outside
+                factors.setdefault(_ordinal(site), []).append(Term(lp, dims, _ordinal(site)))
+                scales.append(site["scale"])
+            else:
+                plain.append(scale_and_mask(lp, site["scale"], site["mask"]).sum())
+                signs.append(1.0)
+        if factors:
+            scale = scales[0]
+            for s in scales[1:]:
+                if s != scale:
+                    raise ValueError("Expected all enumerated sample sites to share a common "
+                                     "poutine.scale, but found different scales")
+            for ordinal, terms in contract_tensor_tree(factors, enum_dims, reduce_all=True).items():
+                for term in terms:
+                    t = term.tensor.sum()
+                    plain.append(t * scale if not isinstance(scale, float) or scale != 1.0 else t)
+                    signs.append(1.0)
+        guide_trace.compute_log_prob_sums()
+        for site in guide_trace.nodes.values():
+            if site["type"] == "sample":
+                x = site["log_prob_sum"]
+                if isinstance(x, torch.Tensor):
+                    plain.append(x)
+                    signs.append(-1.0)
+                else:
+                    const -= x
+        if not plain:
+            return const
+        total = _signed_sum(plain, signs)
+        return total + const if const != 0.0 else total
+
+    @staticmethod
+    def _depends_on_enum(site, first_enum_dim):
+        """A site whose distribution batch shape or value reaches into the enumerated dims."""
+        fn = site["fn"]
+        bs = getattr(fn, "batch_shape", ())
+        n = len(bs)
+        if any(bs[i] > 1 for i in range(n) if i - n <= first_enum_dim):
+            return True
+        v = site["value"]
+        ev = len(getattr(fn, "event_shape", ()))
+        n = v.dim() - ev
+        return any(v.shape[i] > 1 for i in range(n) if i - n <= first_enum_dim)
+
+    def loss(self, model, guide, *args, **kwargs):
+        elbo = 0.0
+        with torch.no_grad():
+            for model_trace, guide_trace in self._get_traces(model, guide, args, kwargs):
+                elbo = elbo + self._elbo_tensor(model_trace, guide_trace) / self.num_particles
+        loss = -torch_item(elbo)
+        warn_if_nan(loss, "loss")
+        return loss
+
+    def differentiable_loss(self, model, guide, *args, **kwargs):
+        elbo = 0.0
+        for model_trace, guide_trace in self._get_traces(model, guide, args, kwargs):
+            elbo = elbo + self._elbo_tensor(model_trace, guide_trace) / self.num_particles
+        loss = -elbo
+        warn_if_nan(loss, "loss")
+        return loss
+
+    def loss_and_grads_device(self, model, guide, *args, **kwargs):
+        loss = None
+        c = -1.0 / self.num_particles
+        for model_trace, guide_trace in self._get_traces(model, guide, args, kwargs):
+            e = self._elbo_tensor(model_trace, guide_trace)
+            if not isinstance(e, torch.Tensor):
+                term = e * c
+            else:
+                sl = e * c
+                term = sl.detach()
+                if sl.requires_grad:
+                    sl.backward(retain_graph=self.retain_graph)
+            loss = term if loss is None else loss + term
+        return 0.0 if loss is None else loss
+
+    def loss_and_grads(self, model, guide, *args, **kwargs):
+        loss = torch_item(self.loss_and_grads_device(model, guide, *args, **kwargs))
+        warn_if_nan(loss, "loss")
+        return loss

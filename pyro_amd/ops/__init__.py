@@ -1,3 +1,3 @@
 """Numerical building blocks of the HMC/NUTS path (reference: pyro/ops/integrator.py,
 dual_averaging.py, welford.py, stats.py)."""
-from . import dual_averaging, integrator, stats, welford  # noqa: F401
+from . import contract, dual_averaging, integrator, stats, welford  # noqa: F401

@@ -1,0 +1,119 @@
+"""TraceEnum_ELBO test bodies shared by the CPU (oracle-backed kernels) and GPU suites; the
+expected values come from the unmodified reference (tests/golden/enum.npz, make_golden.py G10)."""
+import numpy as np
+import torch
+
+import pyro_amd as pyro
+import pyro_amd.distributions as dist
+from pyro_amd.distributions import constraints
+from pyro_amd.infer import TraceEnum_ELBO
+from tests.models import EpsReplay, assert_grads, store_grads
+
+
+def _t(x, device, dtype=torch.float64):
+    return torch.tensor(np.asarray(x), dtype=dtype, device=device)
+
+
+def run_lda(g, device, monkeypatch=None, rtol=1e-9, dtype=torch.float64, expect_fused=None):
+    T, V = g["lda/twd0"].shape
+    W, D = g["lda/data"].shape
+    data = torch.tensor(g["lda/data"], device=device)
+
+    def model(data):
+        with pyro.plate("topics", T):
+            topic_weights = pyro.sample("topic_weights", dist.Gamma(
+                torch.full((), 1.0 / T, dtype=dtype, device=device), 1.0))
+            topic_words = pyro.sample("topic_words", dist.Dirichlet(
+                torch.ones(V, dtype=dtype, device=device) / V))
+        with pyro.plate("documents", D):
+            doc_topics = pyro.sample("doc_topics", dist.Dirichlet(topic_weights))
+            with pyro.plate("words", W):
+                word_topics = pyro.sample("word_topics", dist.Categorical(doc_topics),
+                                          infer={"enumerate": "parallel"})
+                pyro.sample("doc_words", dist.Categorical(topic_words[word_topics]), obs=data)
+
+    def guide(data):
+        a = pyro.param("tw", _t(g["lda/tw0"], device, dtype), constraint=constraints.positive)
+        b = pyro.param("twd", _t(g["lda/twd0"], device, dtype), constraint=constraints.positive)
+        c = pyro.param("dt", _t(g["lda/dt0"], device, dtype), constraint=constraints.simplex)
+        with pyro.plate("topics", T):
+            pyro.sample("topic_weights", dist.Delta(a))
+            pyro.sample("topic_words", dist.Delta(b / b.sum(-1, keepdim=True), event_dim=1))
+        with pyro.plate("documents", D):
+            pyro.sample("doc_topics", dist.Delta(c, event_dim=1))
+
+    pyro.clear_param_store()
+    calls = []
+    if expect_fused is not None:
+        import pyro_amd.kernels as k
+        orig = k.lda_factor_fwd_bwd
+
+        def spy(*a, **kw):
+            calls.append(1)
+            return orig(*a, **kw)
+        monkeypatch.setattr(k, "lda_factor_fwd_bwd", spy)
+    loss = TraceEnum_ELBO(max_plate_nesting=2).loss_and_grads(model, guide, data)
+    np.testing.assert_allclose(loss, float(g["lda/loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, "lda/grad", rtol)
+    if expect_fused is not None:
+        assert bool(calls) == expect_fused
+    # differentiable_loss and loss agree with loss_and_grads
+    elbo = TraceEnum_ELBO(max_plate_nesting=2)
+    np.testing.assert_allclose(elbo.loss(model, guide, data), float(g["lda/loss"]), rtol=rtol)
+    np.testing.assert_allclose(elbo.differentiable_loss(model, guide, data).item(),
+                               float(g["lda/loss"]), rtol=rtol)
+
+
+def run_gmm(g, device, monkeypatch, sub, rtol=1e-9, dtype=torch.float64):
+    from pyro_amd import rng
+    K = g["gmm/locs0"].shape[0]
+    x = _t(g["gmm/x"], device, dtype)
+    N = x.shape[0]
+    tag = "gmmsub" if sub else "gmm"
+    idx = torch.tensor(g["gmmsub/idx"], device=device) if sub else None
+
+    def model(x, idx=None):
+        w = pyro.sample("w", dist.Dirichlet(torch.ones(K, dtype=dtype, device=device)))
+        with pyro.plate("comp", K):
+            locs = pyro.sample("locs", dist.Normal(torch.zeros((), dtype=dtype, device=device), 3.0))
+        with pyro.plate("data", N, subsample=idx):
+            z = pyro.sample("z", dist.Categorical(w), infer={"enumerate": "parallel"})
+            pyro.sample("x", dist.Normal(locs[z], 0.7), obs=x if idx is None else x[idx])
+
+    def guide(x, idx=None):
+        ql = pyro.param("ql", _t(g["gmm/locs0"], device, dtype))
+        qs = pyro.param("qs", torch.tensor(0.3, dtype=dtype, device=device),
+                        constraint=constraints.positive)
+        qw = pyro.param("qw", _t(g["gmm/w0"], device, dtype), constraint=constraints.simplex)
+        pyro.sample("w", dist.Delta(qw, event_dim=1))
+        with pyro.plate("comp", K):
+            pyro.sample("locs", dist.Normal(ql, qs))
+        if idx is not None:
+            with pyro.plate("data", N, subsample=idx):
+                pass
+
+    pyro.clear_param_store()
+    eps = [g[k] for k in sorted(k for k in g.files if k.startswith(tag + "/eps/"))]
+    monkeypatch.setattr(rng, "normal", EpsReplay(eps, device))
+    args = (x, idx) if sub else (x,)
+    loss = TraceEnum_ELBO(max_plate_nesting=1).loss_and_grads(model, guide, *args)
+    np.testing.assert_allclose(loss, float(g[tag + "/loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, tag + "/grad", rtol)
+
+
+def lda_brute_force_loss(g):
+    """Independent check of the golden LDA loss: exact marginal by explicit summation over the
+    topic of every word (torch CPU, float64)."""
+    import torch.distributions as td
+    tw, twd, dt = torch.tensor(g["lda/tw0"]), torch.tensor(g["lda/twd0"]), torch.tensor(g["lda/dt0"])
+    T, V = twd.shape
+    data = torch.tensor(g["lda/data"])
+    phi = twd / twd.sum(-1, keepdim=True)
+    lp = td.Gamma(1.0 / T, 1.0).log_prob(tw).sum()
+    lp = lp + td.Dirichlet(torch.ones(V, dtype=torch.float64) / V).log_prob(phi).sum()
+    lp = lp + td.Dirichlet(tw).log_prob(dt).sum()
+    W, D = data.shape
+    for w in range(W):
+        for d in range(D):
+            lp = lp + torch.log((dt[d] * phi[:, data[w, d]]).sum())
+    return -lp.item()

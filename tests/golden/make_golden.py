@@ -417,8 +417,111 @@ def g_adaptation():
     save("adaptation", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# G10: TraceEnum_ELBO (model-side parallel enumeration, reparameterised guide): LDA of
+#      examples/lda.py:42-70 at toy size and a plated Gaussian mixture; values of the continuous
+#      latents are pinned through the eps bank / Delta guides, loss and grads from the reference.
+#      NOTE: the reference's contraction goes through the opt_einsum stand-in (oracle/refshim),
+#      whose pairwise log-space steps are the reference's own pyro/ops/einsum/torch_log.py.
+# ---------------------------------------------------------------------------------------------
+def g_enum():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer import TraceEnum_ELBO
+    rng = np.random.default_rng(12)
+    T, V, W, D = 3, 7, 4, 5
+    data = torch.tensor(rng.integers(0, V, (W, D)))
+    tw0 = rng.uniform(0.5, 2.0, T)
+    twd0 = rng.uniform(0.6, 2.0, (T, V))
+    dt0 = rng.dirichlet(np.ones(T), D)
+
+    def lda_model(data):
+        with pyro.plate("topics", T):
+            topic_weights = pyro.sample("topic_weights", dist.Gamma(1.0 / T, 1.0))
+            topic_words = pyro.sample("topic_words", dist.Dirichlet(torch.ones(V) / V))
+        with pyro.plate("documents", D):
+            doc_topics = pyro.sample("doc_topics", dist.Dirichlet(topic_weights))
+            with pyro.plate("words", W):
+                word_topics = pyro.sample("word_topics", dist.Categorical(doc_topics),
+                                          infer={"enumerate": "parallel"})
+                pyro.sample("doc_words", dist.Categorical(topic_words[word_topics]), obs=data)
+
+    def lda_guide(data):
+        a = pyro.param("tw", torch.tensor(tw0), constraint=constraints.positive)
+        b = pyro.param("twd", torch.tensor(twd0), constraint=constraints.positive)
+        c = pyro.param("dt", torch.tensor(dt0), constraint=constraints.simplex)
+        with pyro.plate("topics", T):
+            pyro.sample("topic_weights", dist.Delta(a))
+            pyro.sample("topic_words", dist.Delta(b / b.sum(-1, keepdim=True), event_dim=1))
+        with pyro.plate("documents", D):
+            pyro.sample("doc_topics", dist.Delta(c, event_dim=1))
+
+    pyro.clear_param_store()
+    loss = TraceEnum_ELBO(max_plate_nesting=2).loss_and_grads(lda_model, lda_guide, data)
+    flat = {"lda/data": data.numpy(), "lda/tw0": tw0, "lda/twd0": twd0, "lda/dt0": dt0,
+            "lda/loss": loss}
+    for k, v in grads_of_store().items():
+        flat["lda/grad/" + k] = v
+
+    # plated Gaussian mixture: global component weights/locs, one assignment per datum
+    K, N = 3, 11
+    x = torch.tensor(rng.standard_normal(N) * 2)
+    locs0 = rng.standard_normal(K)
+    w0 = rng.dirichlet(np.ones(K))
+
+    def gmm_model(x):
+        w = pyro.sample("w", dist.Dirichlet(torch.ones(K)))
+        with pyro.plate("comp", K):
+            locs = pyro.sample("locs", dist.Normal(0.0, 3.0))
+        with pyro.plate("data", N):
+            z = pyro.sample("z", dist.Categorical(w), infer={"enumerate": "parallel"})
+            pyro.sample("x", dist.Normal(locs[z], 0.7), obs=x)
+
+    def gmm_guide(x):
+        ql = pyro.param("ql", torch.tensor(locs0))
+        qs = pyro.param("qs", torch.tensor(0.3), constraint=constraints.positive)
+        qw = pyro.param("qw", torch.tensor(w0), constraint=constraints.simplex)
+        pyro.sample("w", dist.Delta(qw, event_dim=1))
+        with pyro.plate("comp", K):
+            pyro.sample("locs", dist.Normal(ql, qs))
+
+    pyro.clear_param_store()
+    with EpsBank(31) as bank:
+        loss2 = TraceEnum_ELBO(max_plate_nesting=1).loss_and_grads(gmm_model, gmm_guide, x)
+    flat.update({"gmm/x": x.numpy(), "gmm/locs0": locs0, "gmm/w0": w0, "gmm/loss": loss2})
+    for i, e in enumerate(bank.used):
+        flat["gmm/eps/%03d" % i] = e
+    for k, v in grads_of_store().items():
+        flat["gmm/grad/" + k] = v
+    # vectorised particles + subsample scale on the data plate
+    idx = torch.tensor(rng.permutation(N)[:6])
+
+    def gmm_model_sub(x, idx):
+        w = pyro.sample("w", dist.Dirichlet(torch.ones(K)))
+        with pyro.plate("comp", K):
+            locs = pyro.sample("locs", dist.Normal(0.0, 3.0))
+        with pyro.plate("data", N, subsample=idx):
+            z = pyro.sample("z", dist.Categorical(w), infer={"enumerate": "parallel"})
+            pyro.sample("x", dist.Normal(locs[z], 0.7), obs=x[idx])
+
+    def gmm_guide_sub(x, idx):
+        gmm_guide(x)
+        with pyro.plate("data", N, subsample=idx):
+            pass
+
+    pyro.clear_param_store()
+    with EpsBank(32) as bank:
+        loss3 = TraceEnum_ELBO(max_plate_nesting=1).loss_and_grads(gmm_model_sub, gmm_guide_sub, x, idx)
+    flat.update({"gmmsub/idx": idx.numpy(), "gmmsub/loss": loss3})
+    for i, e in enumerate(bank.used):
+        flat["gmmsub/eps/%03d" % i] = e
+    for k, v in grads_of_store().items():
+        flat["gmmsub/grad/" + k] = v
+    save("enum", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation"]
+                             "adaptation", "enum"]
     for w in which:
         globals()["g_" + w]()
+

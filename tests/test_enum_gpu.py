@@ -1,0 +1,78 @@
+"""TraceEnum_ELBO on the MI355X: reference golden (f64) through the fused LDA kernel and the
+generic device contraction, fused == generic at a larger size, and SVI on examples/lda.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pyro_amd as pyro
+from pyro_amd import examples
+from pyro_amd.infer import SVI, TraceEnum_ELBO
+from tests import enum_cases as ec
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_lda_matches_reference(gpu, monkeypatch, fused):
+    if not fused:
+        import pyro_amd.ops.contract as c
+        monkeypatch.setattr(c, "_try_fused_lda", lambda *a: None)
+    ec.run_lda(load("enum"), gpu, monkeypatch, rtol=1e-9, expect_fused=fused)
+
+
+@pytest.mark.parametrize("sub", [False, True])
+def test_gmm_matches_reference(gpu, monkeypatch, sub):
+    ec.run_gmm(load("enum"), gpu, monkeypatch, sub, rtol=1e-9)
+
+
+def _lda_loss_and_grads(args, data, fused, monkeypatch, seed=0):
+    import pyro_amd.ops.contract as c
+    if not fused:
+        monkeypatch.setattr(c, "_try_fused_lda", lambda *a: None)
+    pyro.clear_param_store()
+    pyro.set_rng_seed(seed)
+    torch.manual_seed(seed)
+    predictor = examples.lda_make_predictor(args, data.device)
+    guide = lambda data, args: examples.lda_guide(predictor, data, args)  # noqa: E731
+    elbo = TraceEnum_ELBO(max_plate_nesting=2)
+    loss = elbo.loss_and_grads(examples.lda_model, guide, data, args)
+    grads = {n: p.grad.detach().clone() for n, p in pyro.get_param_store().named_parameters()
+             if p.grad is not None}
+    monkeypatch.undo()
+    return loss, grads
+
+
+def test_lda_fused_equals_generic_f32(gpu, monkeypatch):
+    """examples/lda.py at 2000 docs x 64 words, T=8, V=1024 (f32): the fused kernel against the
+    generic log-space contraction on the same draws (torch RNG for Gamma/Dirichlet)."""
+    args = examples.LdaArgs(num_docs=2000)
+    data = examples.synthetic_lda_data(args, gpu)
+    assert data.dtype == torch.int64 and int(data.min()) >= 0 and int(data.max()) < args.num_words
+    l1, g1 = _lda_loss_and_grads(args, data, True, monkeypatch)
+    l2, g2 = _lda_loss_and_grads(args, data, False, monkeypatch)
+    assert abs(l1 - l2) <= 2e-5 * abs(l2), (l1, l2)
+    assert set(g1) == set(g2) and len(g1) >= 4
+    for k in g1:
+        scale = float(g2[k].abs().max()) + 1e-12
+        assert float((g1[k] - g2[k]).abs().max()) <= 2e-4 * scale, k
+
+
+def test_lda_svi_improves(gpu):
+    args = examples.LdaArgs(num_docs=1000)
+    data = examples.synthetic_lda_data(args, gpu)
+    pyro.clear_param_store()
+    pyro.set_rng_seed(0)
+    predictor = examples.lda_make_predictor(args, gpu)
+    guide = lambda data, args: examples.lda_guide(predictor, data, args)  # noqa: E731
+    svi = SVI(examples.lda_model, guide, pyro.optim.TorchAdam({"lr": 0.01}),
+              TraceEnum_ELBO(max_plate_nesting=2))
+    losses = [svi.step(data, args) for _ in range(30)]
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])

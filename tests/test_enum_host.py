@@ -1,0 +1,61 @@
+"""TraceEnum_ELBO host logic + plated sum-product on CPU (kernels answered by the oracle), against
+loss/gradients of the unmodified reference (tests/golden/enum.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import enum_cases as ec
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def test_golden_lda_loss_is_the_exact_marginal():
+    g = load("enum")
+    np.testing.assert_allclose(ec.lda_brute_force_loss(g), float(g["lda/loss"]), rtol=1e-7)
+
+
+@pytest.fixture
+def _cpu_backend(oracle_backend):
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def test_lda_generic_contraction(_cpu_backend, monkeypatch):
+    # CPU tensors never take the fused-kernel route (it requires device tensors): this exercises
+    # the generic message passing (broadcast add + logsumexp + plate sums)
+    ec.run_lda(load("enum"), torch.device("cpu"), monkeypatch, expect_fused=False)
+
+
+@pytest.mark.parametrize("sub", [False, True])
+def test_gmm(_cpu_backend, monkeypatch, sub):
+    ec.run_gmm(load("enum"), torch.device("cpu"), monkeypatch, sub)
+
+
+def test_lda_fused_route_with_oracle_kernel(_cpu_backend, monkeypatch):
+    """Force the fused route on CPU tensors (oracle LDA kernel): checks the pattern matcher, the
+    (table, index) extraction and the autograd wiring of _LdaFactor."""
+    import pyro_amd.ops.contract as c
+    monkeypatch.setattr(c, "_FUSED_NEEDS_DEVICE", False)
+    ec.run_lda(load("enum"), torch.device("cpu"), monkeypatch, expect_fused=True)
+
+
+def test_unsupported_guides_raise(_cpu_backend):
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer import TraceEnum_ELBO
+
+    def model():
+        pyro.sample("z", dist.Categorical(torch.ones(3) / 3), infer={"enumerate": "parallel"})
+
+    def guide():
+        pyro.sample("z", dist.Categorical(torch.ones(3) / 3))
+
+    with pytest.raises(NotImplementedError):
+        TraceEnum_ELBO(max_plate_nesting=0).loss_and_grads(model, guide)
