@@ -32,8 +32,9 @@ def _arg_key(x):
 
 
 class _CapturedStep:
-    def __init__(self, graph, cap, loss):
+    def __init__(self, graph, cap, loss, graph2=None, between=None):
         self.graph, self.cap, self.loss = graph, cap, loss
+        self.graph2, self.between = graph2, between     # split capture around a collective
 
 
 class SVI:
@@ -102,6 +103,9 @@ class SVI:
                 return self._eager_step(*args, **kwargs)
         entry.cap.before_replay()
         entry.graph.replay()
+        if entry.graph2 is not None:
+            entry.between()            # eager RCCL all-reduce of the flat gradient
+            entry.graph2.replay()
         entry.cap.after_replay()
         return entry.loss.item()
 
@@ -118,6 +122,9 @@ class SVI:
             device = torch.device("cuda", torch.cuda.current_device())
         cap = rng.GraphCapture(device)
         graph = torch.cuda.CUDAGraph()
+        graph2 = between = None
+        split = hasattr(self.optim, "reduce_gradients") and \
+            (getattr(self.optim, "world_size", 1) > 1 or getattr(self, "_force_split", False))
         try:
             with validation_enabled(False):   # validation ran in the eager warm-up steps
                 with torch.cuda.graph(graph):
@@ -125,12 +132,24 @@ class SVI:
                         with poutine.trace(param_only=True) as param_capture:
                             loss = self._loss_device(self.model, self.guide, *args, **kwargs)
                         params = self._params_of(param_capture)
-                        self.optim(params)
-                        if not getattr(self.optim, "zeroes_grads", False):
-                            zero_grads(params)
+                        if not split:
+                            self.optim(params)
+                            if not getattr(self.optim, "zeroes_grads", False):
+                                zero_grads(params)
                         cap.finish()
                         loss = loss.detach().clone() if isinstance(loss, torch.Tensor) else \
                             torch.tensor(float(loss), device=device)
+                if split:
+                    # the gradient all-reduce is NOT captured: graph 1 = loss + backward, then an
+                    # eager collective, then graph 2 = optimizer update + gradient zeroing
+                    optim = self.optim
+                    optim.reduce_gradients(params)
+                    graph2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph2, pool=graph.pool()):
+                        optim.apply(params)
+                        if not getattr(optim, "zeroes_grads", False):
+                            zero_grads(params)
+                    between = lambda: optim.reduce_gradients(params)  # noqa: E731
         except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
             import os
             if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
@@ -139,6 +158,6 @@ class SVI:
                           "with eager steps".format(type(e).__name__, e))
             self.hip_graph = False
             return None
-        entry = _CapturedStep(graph, cap, loss)
+        entry = _CapturedStep(graph, cap, loss, graph2, between)
         self._graphs[key] = entry
         return entry

@@ -131,7 +131,7 @@ class _FlatAdam:
         if self.step_dev is None:
             self.step_dev = torch.zeros(1, dtype=torch.int64, device=proto.device)
 
-    def __call__(self, params, *args, **kwargs):
+    def __call__(self, params, *args, skip_grad_hook=False, **kwargs):
         new = [p for p in params if p not in self._index]
         if new:
             # deterministic order (same on every rank): by param-store name
@@ -145,7 +145,7 @@ class _FlatAdam:
                 elif p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
                     self.grad[o:o + n].add_(p.grad.reshape(-1))
                     p.grad = self.grad[o:o + n].view(p.shape)
-        if self.grad_hook is not None:
+        if self.grad_hook is not None and not skip_grad_hook:
             self.grad_hook(self.grad)
         kernels.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev,
                           lr=self.lr, betas=self.betas, eps=self.eps,

@@ -30,6 +30,11 @@ class RcclOptimizer:
             pyro_optim.grad_hook = self._allreduce_flat
 
     @property
+    def zeroes_grads(self):
+        # the flat fused Adam zeroes the gradient buffer in its own launch
+        return getattr(self.optim, "zeroes_grads", False)
+
+    @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
@@ -45,6 +50,19 @@ class RcclOptimizer:
             return
         for p in _sorted(params):
             dist.broadcast(p.data, src=root_rank, group=self.group)
+
+    # ---- two-phase interface used by the hipGraph step (SVI(hip_graph=True)): the collective
+    # stays an ordinary eager RCCL launch between two captured graphs
+    # [loss + backward] -> reduce_gradients -> [optimizer update + gradient zeroing]
+    def reduce_gradients(self, params):
+        flat = getattr(self.optim, "grad", None)
+        if flat is None:
+            raise RuntimeError("reduce_gradients needs the flat-buffer optimizer "
+                               "(pyro_amd.optim.Adam / ClippedAdam)")
+        self._allreduce_flat(flat)
+
+    def apply(self, params, *args, **kwargs):
+        self.optim(_sorted(params), *args, skip_grad_hook=True, **kwargs)
 
     def __call__(self, params, *args, **kwargs):
         params = _sorted(params)

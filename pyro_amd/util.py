@@ -48,10 +48,12 @@ def warn_if_inf(value, msg="", allow_posinf=False, allow_neginf=False, *, filena
 def zero_grads(tensors):
     """Zero the .grad of each tensor in place (the reference re-allocates zeros_like every step,
     pyro/infer/util.py:85-91; in-place keeps the allocator out of the step)."""
-    for p in tensors:
-        if p.grad is not None:
-            p.grad.detach_()
-            p.grad.zero_()
+    with torch.no_grad():
+        for p in tensors:
+            if p.grad is not None:
+                if p.grad.grad_fn is not None:
+                    p.grad = p.grad.detach()
+                p.grad.zero_()     # works for gradients that are views of a flat buffer too
 
 
 def scalar_like(prototype, fill_value):

@@ -1,0 +1,74 @@
+"""Multi-process (world size 2, gloo, 127.0.0.1) tests of the N>1 paths: the
+particle-sharded SVI step with ONE flat gradient all-reduce, and chain-sharded MCMC."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from tests import dist_worker as dw
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(target, world, args, tmp_path, tag):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    out = str(tmp_path / (tag + "_%d.pt"))
+    procs = [ctx.Process(target=target, args=(r, world, port, out) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
+    return [torch.load(out % r, weights_only=False) for r in range(world)]
+
+
+@pytest.mark.timeout(600)
+def test_particle_sharded_svi_equals_single_process(tmp_path):
+    """2 ranks x P particles with a flat gradient all-reduce (mean) == 1 process with the 2P
+    particles: identical parameters after every step, on every rank."""
+    g = np.random.default_rng(0)
+    N, D, P, steps = 200, 5, 4, 3
+    X = g.standard_normal((N, D))
+    y = (g.uniform(size=N) < 0.5).astype(np.float64)
+
+    def bank(seed):
+        r = np.random.default_rng(seed)
+        out = []
+        for _ in range(steps):
+            out += [r.standard_normal((P, 1, D)), r.standard_normal((P, 1))]   # sites w, b
+        return out
+
+    b0, b1 = bank(1), bank(2)
+    both = [np.concatenate([a, b], axis=0) for a, b in zip(b0, b1)]
+    two = _run(dw.svi_worker, 2, ([b0, b1], X, y, steps), tmp_path, "svi2")
+    one = _run(dw.svi_worker, 1, ([both], X, y, steps), tmp_path, "svi1")
+    for k in two[0]["params"]:
+        torch.testing.assert_close(two[0]["params"][k], two[1]["params"][k], rtol=0, atol=0)
+        torch.testing.assert_close(two[0]["params"][k], one[0]["params"][k], rtol=1e-10, atol=1e-12)
+    # each rank reports the loss of ITS particles; their mean is the 2P-particle loss
+    np.testing.assert_allclose((np.array(two[0]["losses"]) + np.array(two[1]["losses"])) / 2,
+                               one[0]["losses"], rtol=1e-10)
+
+
+@pytest.mark.timeout(600)
+def test_chain_sharded_mcmc_reproduces_single_process_chains(tmp_path):
+    from tests import mcmc_cases as mc
+    D, C, S = 6, 4, 3
+    Lam = mc.make_precision(D, 2)
+    z0 = np.random.default_rng(3).standard_normal((C, D)) * 0.3
+    two = _run(dw.mcmc_worker, 2, (Lam, z0, C, S), tmp_path, "mcmc2")
+    one = _run(dw.mcmc_worker, 1, (Lam, z0, C, S), tmp_path, "mcmc1")
+    assert [r["local_chains"] for r in two] == [2, 2] and [r["offset"] for r in two] == [0, 2]
+    assert two[0]["x"].shape == (C, S, D)
+    torch.testing.assert_close(two[0]["x"], two[1]["x"], rtol=0, atol=0)      # all_gather
+    torch.testing.assert_close(two[0]["x"], one[0]["x"], rtol=1e-12, atol=1e-12)

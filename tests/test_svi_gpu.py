@@ -120,23 +120,32 @@ def test_hip_graph_step_equals_eager_step(gpu):
 
     X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=3)
     runs = []
-    for use_graph in (False, True):
+    for use_graph in (False, True, "split"):
         pyro.clear_param_store()
         pyro.set_rng_seed(7)
         pyro.enable_validation(False)
         try:
             guide = AutoNormal(examples.logreg_model, init_scale=0.1)
-            svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+            optim = pyro.optim.Adam({"lr": 0.02})
+            if use_graph == "split":
+                # the multi-GPU shape of the step on one GPU: [loss+backward] graph, eager
+                # (here: no-op) gradient all-reduce, [optimizer] graph
+                optim = pyro.optim.RcclOptimizer(optim)
+            svi = SVI(examples.logreg_model, guide, optim,
                       Trace_ELBO(num_particles=16, vectorize_particles=True, max_plate_nesting=1),
-                      hip_graph=use_graph, graph_warmup=3)
+                      hip_graph=bool(use_graph), graph_warmup=3)
+            svi._force_split = use_graph == "split"
             losses = [svi.step(X, y) for _ in range(12)]
             if use_graph:
                 assert svi.hip_graph and len(svi._graphs) == 1   # captured, not fallen back
+                entry = next(iter(svi._graphs.values()))
+                assert (entry.graph2 is not None) == (use_graph == "split")
             params = {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
         finally:
             pyro.enable_validation(True)
         runs.append((losses, params))
-    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
-    for k in runs[0][1]:
-        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    for other in runs[1:]:
+        assert runs[0][0] == other[0], (runs[0][0], other[0])
+        for k in runs[0][1]:
+            assert torch.equal(runs[0][1][k], other[1][k]), k
     assert runs[0][0][-1] < runs[0][0][0]
