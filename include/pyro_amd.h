@@ -157,6 +157,21 @@ int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, con
                              float* ll, float* gw, float* gb, void* workspace,
                              size_t workspace_bytes, pa_stream_t stream);
 
+/* Hierarchical variant (BASELINE config 5: logit_n = x_n . w_{g(n)} + b with per-group weights
+ * w[P,G,D] under pyro.plate("groups", G)): rows of X are SORTED BY GROUP; the caller describes
+ * the work as segments seg[nseg][3] = {row_begin, row_end, group} (device int64; each segment
+ * lies inside one group, <= max_seg_rows rows, segments of a group are contiguous) and
+ * group_seg_off[G+1] (device int64: first segment of every group).  One workgroup per segment
+ * runs the same MFMA pipeline as pa_glm_bernoulli_fwd_bwd with that group's weights.
+ * Outputs: ll[P], gb[P] as above, gw[P,G,D] = d ll / d w (groups without rows get 0). */
+size_t pa_glm_bernoulli_grouped_workspace(int64_t nseg, int64_t D, int64_t P);
+int pa_glm_bernoulli_grouped_fwd_bwd(const float* X, const float* y, const float* w,
+                                     const float* b, const uint8_t* mask, double scale, int64_t N,
+                                     int64_t D, int64_t P, int64_t G, const int64_t* seg,
+                                     int64_t nseg, const int64_t* group_seg_off,
+                                     int64_t max_seg_rows, float* ll, float* gw, float* gb,
+                                     void* workspace, size_t workspace_bytes, pa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * HMC / NUTS.
  * ---------------------------------------------------------------------------------- */

@@ -28,3 +28,26 @@ def glm_bernoulli_fwd_bwd(X, y, w, b=None, mask=None, scale=1.0):
         lp = np.where(m, lp, 0.0)
         g = np.where(m, g, 0.0)
     return scale * lp.sum(1), scale * (g @ X), scale * g.sum(1)
+
+
+def glm_bernoulli_grouped_fwd_bwd(X, y, w, group_of_row, b=None, mask=None, scale=1.0):
+    """Hierarchical variant: logit[p, n] = w[p, g(n), :] . x_n + b[p].
+    w: [P, G, D].  Returns ll[P], gw[P, G, D], gb[P] in float64."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    g_of = np.asarray(group_of_row)
+    logits = np.einsum("pnd,nd->pn", w[:, g_of, :], X)
+    if b is not None:
+        logits = logits + np.asarray(b, dtype=np.float64)[:, None]
+    lp = y[None, :] * logits - _softplus(logits)
+    g = y[None, :] - _sigmoid(logits)
+    if mask is not None:
+        m = np.asarray(mask, dtype=bool)[None, :]
+        lp = np.where(m, lp, 0.0)
+        g = np.where(m, g, 0.0)
+    gw = np.zeros_like(w)
+    for grp in range(w.shape[1]):
+        sel = g_of == grp
+        gw[:, grp, :] = g[:, sel] @ X[sel]
+    return scale * lp.sum(1), scale * gw, scale * g.sum(1)

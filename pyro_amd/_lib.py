@@ -58,6 +58,11 @@ _SIGNATURES = {
     "pa_glm_bernoulli_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pa_glm_bernoulli_grouped_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_glm_bernoulli_grouped_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_double, c_int64, c_int64, c_int64, c_int64,
+                                                 c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pa_leapfrog_kick_drift": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "pa_leapfrog_kick": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,

@@ -39,11 +39,15 @@ struct GlmCfg {
 template <int DT, int PT>
 constexpr int glm_record_floats() { return PT * DT * 1024 + 2 * PT * 32; }
 
-template <int DT, int PT, bool VEC4>
+// GROUPED: the hierarchical variant (BASELINE config 5): rows are sorted by group, logits use the
+// group's own weights w[p, g, :]; blockIdx.x is a SEGMENT {row_begin, row_end, group} of one
+// group's rows (seg[3*blockIdx.x ..]), its four waves take that segment's tiles round-robin, and
+// the block's partial record belongs to that group.
+template <int DT, int PT, bool VEC4, bool GROUPED>
 __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
     const float* __restrict__ X, const float* __restrict__ y, const float* __restrict__ w,
     const float* __restrict__ b, const uint8_t* __restrict__ mask, int64_t N, int D, int P,
-    int64_t iters, float* __restrict__ part) {
+    int64_t iters, float* __restrict__ part, const int64_t* __restrict__ seg, int G) {
   using C = GlmCfg<DT>;
   constexpr int DP = C::DP, S = C::S, TILE_F = C::TILE_F;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -52,6 +56,14 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
   float* Xs = lds + wave * TILE_F;
 
   for (int i = threadIdx.x; i < GLM_WAVES * TILE_F; i += 64 * GLM_WAVES) lds[i] = 0.0f;
+
+  int64_t row_begin = 0, row_end = N;
+  int group = 0;
+  if constexpr (GROUPED) {
+    row_begin = seg[3 * (int64_t)blockIdx.x];
+    row_end = seg[3 * (int64_t)blockIdx.x + 1];
+    group = (int)seg[3 * (int64_t)blockIdx.x + 2];
+  }
 
   // ---- W fragments (B operand of GEMM1) and bias: registers for the whole kernel ----------
   const int pbase = blockIdx.y * 32 * PT;
@@ -63,7 +75,9 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
 #pragma unroll
     for (int kk = 0; kk < DP / 2; ++kk) {
       const int d = 2 * kk + h;
-      wf[pt][kk] = (p < P && d < D) ? w[(int64_t)p * D + d] : 0.0f;
+      wf[pt][kk] = (p < P && d < D)
+                       ? w[(GROUPED ? ((int64_t)p * G + group) : (int64_t)p) * D + d]
+                       : 0.0f;
     }
     bias[pt] = (p < P && b != nullptr) ? b[p] : 0.0f;
   }
@@ -89,10 +103,10 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
   const int q0 = step_e / D, r0 = step_e % D;    // (row, col) increment per load
   const int e0 = lane * EPL;
   const int n_first = e0 / D, d_first = e0 % D;
-  const int64_t total_e = N * (int64_t)D;
+  const int64_t total_e = row_end * (int64_t)D;
 
   auto issue_loads = [&](int64_t tile) {
-    const int64_t base = tile * 32 * (int64_t)D;  // flat offset of the tile's first element
+    const int64_t base = (row_begin + tile * 32) * (int64_t)D;  // flat offset of the tile's first element
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int64_t e = base + e0 + (int64_t)j * step_e;
@@ -108,8 +122,8 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
         stage[j] = ok ? v : 0.0f;
       }
     }
-    const int64_t n = tile * 32 + l31;
-    const bool okn = n < N;
+    const int64_t n = row_begin + tile * 32 + l31;
+    const bool okn = n < row_end;
     const int64_t nc = okn ? n : 0;
     const float yv = y[nc];
     const float mv = mask == nullptr ? 1.0f : (mask[nc] != 0 ? 1.0f : 0.0f);
@@ -136,9 +150,9 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
     }
   };
 
-  const int64_t ntiles = (N + 31) / 32;
-  int64_t tile = (int64_t)blockIdx.x * GLM_WAVES + wave;
-  const int64_t tile_stride = (int64_t)gridDim.x * GLM_WAVES;
+  const int64_t ntiles = (row_end - row_begin + 31) / 32;
+  int64_t tile = GROUPED ? (int64_t)wave : (int64_t)blockIdx.x * GLM_WAVES + wave;
+  const int64_t tile_stride = GROUPED ? (int64_t)GLM_WAVES : (int64_t)gridDim.x * GLM_WAVES;
 
   issue_loads(tile);
   __syncthreads();  // LDS zero-fill complete
@@ -337,17 +351,19 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
   if (vec4) {
-    auto k = glm_bernoulli_kernel<DT, PT, true>;
+    auto k = glm_bernoulli_kernel<DT, PT, true, false>;
     if (pl.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)pl.lds_bytes);
-    hipLaunchKernelGGL(k, grid, block, pl.lds_bytes, s, X, y, w, b, mask, N, D, P, pl.iters, part);
+    hipLaunchKernelGGL(k, grid, block, pl.lds_bytes, s, X, y, w, b, mask, N, D, P, pl.iters, part,
+                       (const int64_t*)nullptr, 1);
   } else {
-    auto k = glm_bernoulli_kernel<DT, PT, false>;
+    auto k = glm_bernoulli_kernel<DT, PT, false, false>;
     if (pl.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)pl.lds_bytes);
-    hipLaunchKernelGGL(k, grid, block, pl.lds_bytes, s, X, y, w, b, mask, N, D, P, pl.iters, part);
+    hipLaunchKernelGGL(k, grid, block, pl.lds_bytes, s, X, y, w, b, mask, N, D, P, pl.iters, part,
+                       (const int64_t*)nullptr, 1);
   }
   if (br) (void)hipEventRecord(ev1, s);
   int rc = check_launch("glm_bernoulli_kernel");
@@ -356,6 +372,94 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   hipLaunchKernelGGL((glm_finalize_kernel<DT, PT>), dim3((unsigned)((J + 63) / 64)), dim3(1024), 0,
                      s, part, pl.nblocks, pl.npass, D, P, scale, ll, gw, gb);
   return check_launch("glm_finalize_kernel");
+}
+
+
+// ---- grouped (hierarchical) variant ------------------------------------------------------------
+// gw[p, g, d] = scale * sum over the segments of group g; ll[p], gb[p] = scale * sum over ALL
+// segments.  fp64 accumulation in a fixed order.
+template <int DT, int PT>
+__global__ __launch_bounds__(256) void glm_grouped_finalize_gw_kernel(
+    const float* __restrict__ part, const int64_t* __restrict__ group_seg_off, int nseg, int D,
+    int P, int G, double scale, float* __restrict__ gw) {
+  constexpr int REC = glm_record_floats<DT, PT>();
+  const int64_t J = (int64_t)P * G * D;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  const int d = (int)(j % D);
+  const int g = (int)((j / D) % G);
+  const int p = (int)(j / ((int64_t)D * G));
+  const int pl = p % (32 * PT), pt = pl >> 5, i = pl & 31, dt = d >> 5, c = d & 31;
+  const int hh = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
+  const int slot = ((pt * DT + dt) * 16 + reg) * 64 + c + 32 * hh;
+  const int pass = p / (32 * PT);
+  const float* base = part + (int64_t)pass * nseg * REC + slot;
+  double acc = 0.0;
+  for (int64_t sgi = group_seg_off[g]; sgi < group_seg_off[g + 1]; ++sgi)
+    acc += (double)base[sgi * REC];
+  gw[j] = (float)(acc * scale);
+}
+
+template <int DT, int PT>
+__global__ __launch_bounds__(256) void glm_grouped_finalize_scalar_kernel(
+    const float* __restrict__ part, int nseg, int P, double scale, float* __restrict__ ll,
+    float* __restrict__ gb) {
+  constexpr int REC = glm_record_floats<DT, PT>();
+  __shared__ double smem[16];
+  const int which = blockIdx.x >= (unsigned)P ? 1 : 0;       // 0: ll, 1: gb
+  const int p = blockIdx.x - which * P;
+  const int pl = p % (32 * PT), pt = pl >> 5, i = pl & 31;
+  const int slot = PT * DT * 1024 + (2 * pt + which) * 32 + i;
+  const int pass = p / (32 * PT);
+  const float* base = part + (int64_t)pass * nseg * REC + slot;
+  double acc = 0.0;
+  for (int sgi = threadIdx.x; sgi < nseg; sgi += 256) acc += (double)base[(int64_t)sgi * REC];
+  const double t = block_sum_f64(acc, smem);
+  if (threadIdx.x == 0) (which ? gb : ll)[p] = (float)(t * scale);
+}
+
+template <int DT, int PT>
+static int glm_grouped_launch(const float* X, const float* y, const float* w, const float* b,
+                              const uint8_t* mask, double scale, int64_t N, int D, int P, int G,
+                              const int64_t* seg, int nseg, const int64_t* group_seg_off,
+                              int64_t max_seg_rows, float* ll, float* gw, float* gb, float* part,
+                              hipStream_t s) {
+  const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const int npass = (P + 32 * PT - 1) / (32 * PT);
+  const int64_t seg_tiles = (max_seg_rows + 31) / 32;
+  const int64_t iters = (seg_tiles + GLM_WAVES - 1) / GLM_WAVES;
+  const size_t lds_bytes = (size_t)GLM_WAVES * 32 * (32 * DT + 3) * sizeof(float);
+  dim3 grid((unsigned)nseg, (unsigned)npass), block(64 * GLM_WAVES);
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
+  if (vec4) {
+    auto k = glm_bernoulli_kernel<DT, PT, true, true>;
+    if (lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, s, X, y, w, b, mask, N, D, P, iters, part, seg, G);
+  } else {
+    auto k = glm_bernoulli_kernel<DT, PT, false, true>;
+    if (lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, s, X, y, w, b, mask, N, D, P, iters, part, seg, G);
+  }
+  if (br) (void)hipEventRecord(ev1, s);
+  int rc = check_launch("glm_bernoulli_kernel<grouped>");
+  if (rc != PA_OK) return rc;
+  const int64_t J = (int64_t)P * G * D;
+  hipLaunchKernelGGL((glm_grouped_finalize_gw_kernel<DT, PT>), dim3((unsigned)((J + 255) / 256)),
+                     dim3(256), 0, s, part, group_seg_off, nseg, D, P, G, scale, gw);
+  hipLaunchKernelGGL((glm_grouped_finalize_scalar_kernel<DT, PT>), dim3((unsigned)(2 * P)),
+                     dim3(256), 0, s, part, nseg, P, scale, ll, gb);
+  return check_launch("glm_grouped_finalize");
+}
+
+static void glm_tiles_of(int64_t D, int64_t P, int* DT, int* PT) {
+  *DT = D <= 32 ? 1 : (D <= 64 ? 2 : 4);
+  *PT = (*DT == 1 && P > 32) ? 2 : 1;
 }
 
 }  // namespace pa
@@ -404,6 +508,57 @@ int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, con
   PA_GLM_CASE(4, 1)
 #undef PA_GLM_CASE
   return pa::fail(PA_ERR_UNSUPPORTED, "glm_bernoulli: no kernel for DT=%d PT=%d", pl.DT, pl.PT);
+}
+
+size_t pa_glm_bernoulli_grouped_workspace(int64_t nseg, int64_t D, int64_t P) {
+  if (nseg < 0 || D < 1 || D > 128 || P < 1) return 0;
+  int DT, PT;
+  pa::glm_tiles_of(D, P, &DT, &PT);
+  const int64_t npass = (P + 32 * PT - 1) / (32 * PT);
+  const int64_t rec = (int64_t)PT * DT * 1024 + 2 * PT * 32;
+  return (size_t)(nseg * npass * rec) * sizeof(float);
+}
+
+int pa_glm_bernoulli_grouped_fwd_bwd(const float* X, const float* y, const float* w,
+                                     const float* b, const uint8_t* mask, double scale, int64_t N,
+                                     int64_t D, int64_t P, int64_t G, const int64_t* seg,
+                                     int64_t nseg, const int64_t* group_seg_off,
+                                     int64_t max_seg_rows, float* ll, float* gw, float* gb,
+                                     void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  PA_REQUIRE(N >= 0 && D >= 1 && P >= 1 && G >= 1 && nseg >= 0 && max_seg_rows >= 0,
+             "glm_grouped: bad shape N=%lld D=%lld P=%lld G=%lld nseg=%lld", (long long)N,
+             (long long)D, (long long)P, (long long)G, (long long)nseg);
+  if (D > 128)
+    return pa::fail(PA_ERR_UNSUPPORTED, "glm_grouped: fused kernel supports D <= 128 (got %lld)",
+                    (long long)D);
+  PA_REQUIRE(nseg < (1 << 30) && P < (1 << 20) && G < (1 << 24), "glm_grouped: shape too large");
+  PA_REQUIRE(w && ll && gw && gb, "glm_grouped: NULL parameter/output pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (N == 0 || nseg == 0) {
+    hipError_t e1 = hipMemsetAsync(ll, 0, (size_t)P * 4, s);
+    hipError_t e2 = hipMemsetAsync(gw, 0, (size_t)P * G * D * 4, s);
+    hipError_t e3 = hipMemsetAsync(gb, 0, (size_t)P * 4, s);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+      return pa::fail(PA_ERR_LAUNCH, "glm_grouped: memset failed");
+    return PA_OK;
+  }
+  PA_REQUIRE(X && y && seg && group_seg_off, "glm_grouped: NULL data pointer");
+  PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_grouped_workspace(nseg, D, P),
+             "glm_grouped: workspace too small");
+  int DT, PT;
+  pa::glm_tiles_of(D, P, &DT, &PT);
+  float* part = (float*)workspace;
+#define PA_GLMG_CASE(DT_, PT_)                                                                   \
+  if (DT == DT_ && PT == PT_)                                                                    \
+    return pa::glm_grouped_launch<DT_, PT_>(X, y, w, b, mask, scale, N, (int)D, (int)P, (int)G,  \
+                                            seg, (int)nseg, group_seg_off, max_seg_rows, ll, gw, \
+                                            gb, part, s);
+  PA_GLMG_CASE(1, 1)
+  PA_GLMG_CASE(1, 2)
+  PA_GLMG_CASE(2, 1)
+  PA_GLMG_CASE(4, 1)
+#undef PA_GLMG_CASE
+  return pa::fail(PA_ERR_UNSUPPORTED, "glm_grouped: no kernel for DT=%d PT=%d", DT, PT);
 }
 
 }  // extern "C"

@@ -8,14 +8,15 @@ from torch.distributions import biject_to, transform_to, kl_divergence  # noqa: 
 
 from .base import (Delta, MaskedDistribution, ScoreParts, TorchDistribution,  # noqa: F401
                    TorchDistributionMixin, Unit)
-from .families import (Bernoulli, Exponential, HalfCauchy, HalfNormal, LinearLogits,  # noqa: F401
-                       LogNormal, Normal, linear_logits)
+from .families import (Bernoulli, Exponential, GroupedLinearLogits, HalfCauchy,  # noqa: F401
+                       HalfNormal, LinearLogits, LogNormal, Normal, grouped_linear_logits,
+                       linear_logits)
 from .util import enable_validation, is_validation_enabled  # noqa: F401
 
 # ---- everything else: torch.distributions + mixin, arithmetic by ATen on the GPU ----------------
 _FUSED = {"Normal", "Bernoulli", "HalfCauchy", "HalfNormal", "LogNormal", "Exponential"}
 __all__ = ["Delta", "Unit", "MaskedDistribution", "TorchDistribution", "ScoreParts",
-           "LinearLogits", "linear_logits"] + sorted(_FUSED)
+           "LinearLogits", "linear_logits", "GroupedLinearLogits", "grouped_linear_logits"] + sorted(_FUSED)
 
 
 def _wrap_all():

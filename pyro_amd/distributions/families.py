@@ -195,6 +195,61 @@ def linear_logits(X, w, b=None):
     return LinearLogits(X, w, b)
 
 
+class GroupedLinearLogits:
+    """Lazy ``logits[..., n] = w[..., g(n), :] . X[n] + b`` of a hierarchical GLM whose rows are
+    SORTED BY GROUP (BASELINE config 5).  X: [N, D]; w: [..., G, D] (the plate dim of the
+    ``groups`` plate is the G axis, particle dims lead); b: scalar / [..., 1] / None;
+    ``segments``: kernels.GroupSegments built once from the group offsets."""
+
+    def __init__(self, X, w, b, segments):
+        if X.dim() != 2 or w.dim() < 2 or w.shape[-1] != X.shape[-1] or w.shape[-2] != segments.G:
+            raise ValueError("GroupedLinearLogits: expected X [N, D], w [..., G={}, D], got {} and {}"
+                             .format(segments.G, tuple(X.shape), tuple(w.shape)))
+        if segments.N != X.shape[0]:
+            raise ValueError("GroupedLinearLogits: group offsets cover {} rows, X has {}".format(
+                segments.N, X.shape[0]))
+        self.X, self.w, self.b, self.segments = X, w, b, segments
+        lead = w.shape[:-2]
+        if b is not None and b.dim() > 0:
+            if b.shape[-1] != 1:
+                raise ValueError("GroupedLinearLogits: expected b of shape [..., 1]")
+            lead = torch.broadcast_shapes(lead, b.shape[:-1])
+        self.shape = torch.Size(lead) + (X.shape[0],)
+        self.dtype, self.device = X.dtype, X.device
+
+    def dim(self):
+        return len(self.shape)
+
+    def group_of_row(self):
+        import numpy as np
+        off = self.segments.group_offsets
+        return torch.as_tensor(np.repeat(np.arange(len(off) - 1), np.diff(off)), device=self.X.device)
+
+    def materialize(self):
+        wg = self.w[..., self.group_of_row(), :]                   # [..., N, D]
+        out = (wg * self.X).sum(-1)
+        if self.b is not None:
+            out = out + self.b
+        return out
+
+    def flat_params(self):
+        lead = self.shape[:-1]
+        P = 1
+        for s in lead:
+            P *= s
+        G, D = self.w.shape[-2:]
+        w3 = self.w.expand(lead + (G, D)).reshape(P, G, D).contiguous()
+        b1 = None
+        if self.b is not None:
+            b = self.b if self.b.dim() > 0 else self.b.reshape(1)
+            b1 = b.expand(lead + (1,)).reshape(P).contiguous()
+        return w3, b1
+
+
+def grouped_linear_logits(X, w, b, segments):
+    return GroupedLinearLogits(X, w, b, segments)
+
+
 class _BernoulliLinear(TorchDistribution):
     """Bernoulli whose logits are a lazy LinearLogits: the plated GLM observed site."""
 
@@ -247,7 +302,11 @@ class _BernoulliLinear(TorchDistribution):
         if lz.X.shape[1] > 128 or not lz.X.is_contiguous():
             return None
         w2, b1 = lz.flat_params()
-        ll = fused.glm_bernoulli_ll(lz.X, value.contiguous(), w2, b1, mask, scale)
+        if isinstance(lz, GroupedLinearLogits):
+            ll = fused.glm_bernoulli_grouped_ll(lz.X, value.contiguous(), w2, b1, mask, scale,
+                                                lz.segments)
+        else:
+            ll = fused.glm_bernoulli_ll(lz.X, value.contiguous(), w2, b1, mask, scale)
         return ll.reshape(lz.shape[:-1])
 
 
@@ -258,7 +317,7 @@ class Bernoulli(_FusedElementwise, torch.distributions.Bernoulli, TorchDistribut
     _dist_id = _lib.DIST_BERNOULLI_LOGITS
 
     def __new__(cls, probs=None, logits=None, validate_args=None):
-        if isinstance(logits, LinearLogits):
+        if isinstance(logits, (LinearLogits, GroupedLinearLogits)):
             return _BernoulliLinear(logits, validate_args)
         return super().__new__(cls)
 

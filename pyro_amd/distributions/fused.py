@@ -209,3 +209,26 @@ class _GlmBernoulliSum(torch.autograd.Function):
 def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
     """Per-particle log-likelihood ll[P] (differentiable w.r.t. w[P,D], b[P])."""
     return _GlmBernoulliSum.apply(X, y, w, b, mask, float(scale))
+
+
+class _GlmBernoulliGroupedSum(torch.autograd.Function):
+    """Hierarchical GLM site: ll[P] and d ll / d (w[P,G,D], b[P]) from one pass over the
+    group-sorted rows (pa_glm_bernoulli_grouped_fwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, X, y, w, b, mask, scale, segs):
+        ll, gw, gb = kernels.glm_bernoulli_grouped_fwd_bwd(X, y, w, b, mask, scale, segs)
+        ctx.save_for_backward(gw, gb)
+        ctx.has_b = b is not None
+        return ll
+
+    @staticmethod
+    def backward(ctx, g):
+        gw, gb = ctx.saved_tensors
+        dw = g[:, None, None] * gw if ctx.needs_input_grad[2] else None
+        db = g * gb if (ctx.has_b and ctx.needs_input_grad[3]) else None
+        return None, None, dw, db, None, None, None
+
+
+def glm_bernoulli_grouped_ll(X, y, w, b, mask, scale, segs):
+    return _GlmBernoulliGroupedSum.apply(X, y, w, b, mask, float(scale), segs)

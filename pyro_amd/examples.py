@@ -121,3 +121,52 @@ def synthetic_lda_data(args, device, seed=0):
     u = torch.rand((D, W), device=device, generator=g)
     words = (u.unsqueeze(-1) > cdf[z]).sum(-1).clamp(max=V - 1)            # inverse-CDF draw
     return words.t().contiguous()
+
+
+# ---- BASELINE config 5: hierarchical logistic regression ---------------------------
+def hier_logreg_model(X, y, segments):
+    """mu ~ N(0,1)^D, tau ~ HalfNormal(1)^D, w_g ~ N(mu, tau) for g in plate(groups),
+    obs_n ~ Bernoulli(logits = x_n . w_{g(n)} + b); rows of X sorted by group."""
+    N, D = X.shape
+    G = segments.G
+    z = torch.zeros(D, dtype=X.dtype, device=X.device)
+    mu = sample("mu", dist.Normal(z, 1.0).to_event(1))
+    tau = sample("tau", dist.HalfNormal(torch.ones(D, dtype=X.dtype, device=X.device)).to_event(1))
+    b = sample("b", dist.Normal(torch.zeros((), dtype=X.dtype, device=X.device), 1.0))
+    with plate("groups", G):
+        w = sample("w", dist.Normal(mu, tau).to_event(1))
+    with plate("data", N):
+        sample("obs", dist.Bernoulli(logits=dist.grouped_linear_logits(X, w, b, segments)), obs=y)
+
+
+def hier_logreg_model_unfused(X, y, segments):
+    """Same model in the reference's formulation: gather the per-row weights and reduce."""
+    N, D = X.shape
+    G = segments.G
+    z = torch.zeros(D, dtype=X.dtype, device=X.device)
+    mu = sample("mu", dist.Normal(z, 1.0).to_event(1))
+    tau = sample("tau", dist.HalfNormal(torch.ones(D, dtype=X.dtype, device=X.device)).to_event(1))
+    b = sample("b", dist.Normal(torch.zeros((), dtype=X.dtype, device=X.device), 1.0))
+    with plate("groups", G):
+        w = sample("w", dist.Normal(mu, tau).to_event(1))
+    import numpy as np
+    off = segments.group_offsets
+    g_of = torch.as_tensor(np.repeat(np.arange(G), np.diff(off)), device=X.device)
+    with plate("data", N):
+        logits = (w[..., g_of, :] * X).sum(-1) + b
+        sample("obs", dist.Bernoulli(logits=logits), obs=y)
+
+
+def synthetic_hier_logreg_data(N, D, G, device, seed=0, dtype=torch.float32):
+    """Rows sorted by group; returns X, y, group offsets (host int64 [G+1])."""
+    import numpy as np
+    g = torch.Generator(device=device).manual_seed(seed)
+    X = torch.randn((N, D), device=device, dtype=dtype, generator=g)
+    grp = torch.randint(0, G, (N,), device=device, generator=g).sort()[0]
+    mu = torch.randn((D,), device=device, dtype=dtype, generator=g)
+    wg = mu + 0.5 * torch.randn((G, D), device=device, dtype=dtype, generator=g)
+    logits = (wg[grp] * X).sum(-1)
+    y = (torch.rand((N,), device=device, dtype=dtype, generator=g) < torch.sigmoid(logits)).to(dtype)
+    counts = torch.bincount(grp, minlength=G).cpu().numpy().astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    return X, y, offsets

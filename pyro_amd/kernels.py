@@ -202,6 +202,63 @@ def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
     return ll, gw, gb
 
 
+class GroupSegments:
+    """Work description of the grouped GLM kernel for rows sorted by group: built once per data
+    set from ``group_offsets`` (host int64 [G+1], rows of group g are offsets[g]:offsets[g+1])."""
+
+    def __init__(self, group_offsets, device, target_segments=4096):
+        import numpy as np
+        off = np.asarray(group_offsets, dtype=np.int64)
+        assert off.ndim == 1 and off.size >= 2 and (np.diff(off) >= 0).all() and off[0] == 0
+        self.G = off.size - 1
+        self.N = int(off[-1])
+        # rows per segment: a multiple of 128 (= 4 waves x 32-row tiles) giving ~target_segments
+        rows = max(128, -(-self.N // max(target_segments, 1)))
+        rows = -(-rows // 128) * 128
+        seg, gso = [], [0]
+        for g in range(self.G):
+            a, b = int(off[g]), int(off[g + 1])
+            while a < b:
+                e = min(a + rows, b)
+                seg.append((a, e, g))
+                a = e
+            gso.append(len(seg))
+        self.nseg = len(seg)
+        self.max_seg_rows = rows if seg else 0
+        self.seg = torch.tensor(seg if seg else [(0, 0, 0)], dtype=torch.int64, device=device)
+        self.group_seg_off = torch.tensor(gso, dtype=torch.int64, device=device)
+        self.group_offsets = off
+
+
+def glm_bernoulli_grouped_fwd_bwd(X, y, w, b, mask, scale, segs):
+    """X[N,D] (rows sorted by group), y[N], w[P,G,D], b[P] or None, mask[N] or None, segs:
+    GroupSegments -> (ll[P], gw[P,G,D], gb[P])."""
+    _require_gpu(X, y, w, b, mask)
+    if X.dtype != torch.float32:
+        raise Unsupported("pyro_amd: fused GLM kernel is float32 only")
+    N, D = X.shape
+    P, G = w.shape[0], w.shape[1]
+    assert X.is_contiguous() and y.is_contiguous() and w.is_contiguous()
+    assert w.shape == (P, G, D) and G == segs.G and N == segs.N and y.shape == (N,)
+    if b is not None:
+        assert b.is_contiguous() and b.shape == (P,)
+    if mask is not None:
+        assert mask.is_contiguous() and mask.shape == (N,)
+    lib = _lib.load()
+    nbytes = lib.pa_glm_bernoulli_grouped_workspace(segs.nseg, D, P)
+    if nbytes == 0 and segs.nseg > 0:
+        raise Unsupported("pyro_amd: grouped GLM kernel does not support D=%d P=%d" % (D, P))
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=X.device)
+    ll = torch.empty((P,), dtype=X.dtype, device=X.device)
+    gw = torch.empty((P, G, D), dtype=X.dtype, device=X.device)
+    gb = torch.empty((P,), dtype=X.dtype, device=X.device)
+    check(lib.pa_glm_bernoulli_grouped_fwd_bwd(
+        _ptr(X), _ptr(y), _ptr(w), _ptr(b), _ptr(mask), float(scale), N, D, P, G, _ptr(segs.seg),
+        segs.nseg, _ptr(segs.group_seg_off), segs.max_seg_rows, _ptr(ll), _ptr(gw), _ptr(gb),
+        _ptr(ws), nbytes, _stream()))
+    return ll, gw, gb
+
+
 # ------------------------------------------------------------------------------------------
 # HMC / NUTS
 # ------------------------------------------------------------------------------------------

@@ -519,9 +519,49 @@ def g_enum():
     save("enum", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# G11: hierarchical logistic regression at toy size, AutoNormal, vectorised
+#      particles: loss and gradients of the unmodified reference with banked eps.
+# ---------------------------------------------------------------------------------------------
+def g_hier():
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(21)
+    N, D, G, P = 300, 6, 5, 8
+    sizes = np.array([80, 0, 120, 37, 63])
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    g_of = torch.tensor(np.repeat(np.arange(G), sizes))
+    X = rng.standard_normal((N, D))
+    y = (rng.uniform(size=N) < 0.5).astype(float)
+    Xt, yt = torch.tensor(X), torch.tensor(y)
+
+    def model(X, y):
+        z = torch.zeros(D)
+        mu = pyro.sample("mu", dist.Normal(z, 1.0).to_event(1))
+        tau = pyro.sample("tau", dist.HalfNormal(torch.ones(D)).to_event(1))
+        b = pyro.sample("b", dist.Normal(torch.zeros(()), 1.0))
+        with pyro.plate("groups", G):
+            w = pyro.sample("w", dist.Normal(mu, tau).to_event(1))
+        with pyro.plate("data", N):
+            logits = (w[..., g_of, :] * X).sum(-1) + b
+            pyro.sample("obs", dist.Bernoulli(logits=logits), obs=y)
+
+    pyro.clear_param_store()
+    guide = AutoNormal(model, init_scale=0.1)
+    elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+    guide(Xt, yt)   # prototype + params
+    with torch.no_grad():
+        for name, p in pyro.get_param_store().named_parameters():
+            p.add_(torch.tensor(np.random.default_rng(5).standard_normal(p.shape) * 0.2))
+    params = {k: v.detach().clone().numpy() for k, v in pyro.get_param_store().items()}
+    with EpsBank(6) as bank:
+        loss = elbo.loss_and_grads(model, guide, Xt, yt)
+    save("hier", X=X, y=y, offsets=off, P=P, loss=loss, grads=grads_of_store(), params=params,
+         eps=list(bank.used))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum"]
+                             "adaptation", "enum", "hier"]
     for w in which:
         globals()["g_" + w]()
 

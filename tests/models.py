@@ -213,3 +213,33 @@ def run_score_function(g, device, rtol):
     loss = Trace_ELBO().loss_and_grads(model2, poutine.replay(guide2, trace=fixed), data)
     np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
     assert_grads(store_grads(), g, "grads", rtol * 10)
+
+
+# ---- hierarchical logistic regression (config 5) -------------------------------------------------
+def run_hier(g, device, monkeypatch, fused, dtype=torch.float64, rtol=1e-9):
+    """Loss and gradients of the unmodified reference (tests/golden/hier.npz) through the grouped
+    GLM route (fused) or the gather formulation (unfused)."""
+    from pyro_amd import examples, kernels, rng
+    X = torch.tensor(g["X"], dtype=dtype, device=device)
+    y = torch.tensor(g["y"], dtype=dtype, device=device)
+    segs = kernels.GroupSegments(g["offsets"], device, target_segments=7)
+    model = examples.hier_logreg_model if fused else examples.hier_logreg_model_unfused
+    P = int(g["P"])
+    pyro.clear_param_store()
+    guide = AutoNormal(model, init_scale=0.1)
+    guide._setup_prototype(X, y, segs)
+    guide(X, y, segs)      # creates the parameters
+    store = pyro.get_param_store()
+    with torch.no_grad():
+        for name in list(store.keys()):
+            target = torch.tensor(g["params/" + name], dtype=dtype, device=device)
+            unconstrained = store._params[name]
+            from torch.distributions import transform_to
+            unconstrained.copy_(transform_to(store._constraints[name]).inv(target))
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps"), device))
+    elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+    if fused and dtype == torch.float64:
+        monkeypatch.setattr(dist.families._BernoulliLinear, "_allow_f64", True)
+    loss = elbo.loss_and_grads(model, guide, X, y, segs)
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads", rtol * 10)

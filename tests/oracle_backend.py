@@ -77,6 +77,20 @@ def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
             torch.as_tensor(gb, dtype=X.dtype))
 
 
+class GroupSegments:
+    def __init__(self, group_offsets, device, target_segments=4096):
+        off = np.asarray(group_offsets, dtype=np.int64)
+        self.G, self.N, self.group_offsets = off.size - 1, int(off[-1]), off
+
+
+def glm_bernoulli_grouped_fwd_bwd(X, y, w, b, mask, scale, segs):
+    g_of = np.repeat(np.arange(segs.G), np.diff(segs.group_offsets))
+    ll, gw, gb = o_glm.glm_bernoulli_grouped_fwd_bwd(_np(X), _np(y), _np(w), g_of, _np(b), _np(mask),
+                                                     scale)
+    return (torch.as_tensor(ll, dtype=X.dtype), torch.as_tensor(gw, dtype=X.dtype),
+            torch.as_tensor(gb, dtype=X.dtype))
+
+
 def leapfrog_kick_drift(z, r, grad, inv_mass, step):
     st = _np(step).reshape(-1, 1) if step.dim() == 1 else _np(step)
     rn = _np(r) + 0.5 * st * (-_np(grad))
@@ -171,7 +185,8 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999)
 
 FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
-             "nuts_gaussian_transition", "lda_factor_fwd_bwd", "adam_step", "NutsTree"]
+             "nuts_gaussian_transition", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
+             "glm_bernoulli_grouped_fwd_bwd"]
 
 
 def install(monkeypatch):

@@ -41,3 +41,9 @@ def test_scale_mask_subsample(monkeypatch):
 
 def test_score_function_guide(monkeypatch):
     models.run_score_function(load("score_function"), torch.device("cpu"), rtol=1e-9)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_hierarchical_logreg_loss_and_grads(monkeypatch, fused):
+    # config 5 at toy size: per-group weights under plate("groups"), ragged groups (one empty)
+    models.run_hier(load("hier"), torch.device("cpu"), monkeypatch, fused=fused, rtol=1e-9)

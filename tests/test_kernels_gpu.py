@@ -173,6 +173,44 @@ def test_glm_bernoulli(gpu, N, D, P, use_mask, use_bias):
     np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
 
 
+@pytest.mark.parametrize("N,D,P,G", [(1000, 32, 64, 7), (5000, 32, 64, 50), (777, 8, 5, 3),
+                                     (3000, 64, 20, 11), (400, 32, 33, 40), (2000, 100, 3, 4)])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_glm_bernoulli_grouped(gpu, N, D, P, G, use_mask):
+    """Hierarchical GLM (config 5): per-group weights, rows sorted by group, ragged groups
+    (some empty), against the numpy restatement."""
+    k = _k()
+    rng = np.random.default_rng(N + D + P + G)
+    sizes = rng.multinomial(N, rng.dirichlet(np.ones(G) * 0.7))
+    sizes[rng.integers(0, G)] = 0                      # an empty group
+    sizes[-1] += N - sizes.sum()
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    g_of = np.repeat(np.arange(G), sizes)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (rng.standard_normal((P, G, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32)
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    mask = (rng.uniform(size=N) < 0.8) if use_mask else None
+    segs = k.GroupSegments(off, gpu, target_segments=37)
+    assert segs.nseg >= int((sizes > 0).sum()) and int(segs.group_seg_off[-1]) == segs.nseg
+    ll, gw, gb = k.glm_bernoulli_grouped_fwd_bwd(tt(X, gpu), tt(y, gpu), tt(w, gpu), tt(b, gpu),
+                                                 tt(mask, gpu) if mask is not None else None, 2.0,
+                                                 segs)
+    rll, rgw, rgb = o_glm.glm_bernoulli_grouped_fwd_bwd(X, y, w, g_of, b, mask, 2.0)
+    sc = max(1.0, float(np.abs(rll).max()))
+    np.testing.assert_allclose(ll.cpu().numpy(), rll, rtol=2e-5, atol=2e-5 * sc)
+    np.testing.assert_allclose(gb.cpu().numpy(), rgb, rtol=2e-5, atol=2e-5 * N ** 0.5)
+    np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=2e-5, atol=2e-5 * N ** 0.5)
+    # one group == the flat kernel, bit for bit in ll/gb ordering-independent tolerance
+    segs1 = k.GroupSegments(np.array([0, N]), gpu)
+    l1, g1, b1 = k.glm_bernoulli_grouped_fwd_bwd(tt(X, gpu), tt(y, gpu), tt(w[:, :1].copy(), gpu),
+                                                 tt(b, gpu), None, 1.0, segs1)
+    l0, g0, b0 = k.glm_bernoulli_fwd_bwd(tt(X, gpu), tt(y, gpu), tt(w[:, 0].copy(), gpu), tt(b, gpu),
+                                         None, 1.0)
+    torch.testing.assert_close(l1, l0, rtol=1e-5, atol=1e-4 * sc)
+    torch.testing.assert_close(g1[:, 0], g0, rtol=1e-5, atol=1e-4 * N ** 0.5)
+
+
 def test_glm_bernoulli_transpose_detecting(gpu):
     """Asymmetric inputs: a swapped (p,d) or (n,p) mapping cannot pass."""
     k = _k()
