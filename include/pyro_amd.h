@@ -205,6 +205,33 @@ int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const 
                                 uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
                                 int32_t* diverging, int32_t* accepted, pa_stream_t stream);
 
+/* Persistent form of the same kernel: num_transitions consecutive transitions t0, t0+1, ... per
+ * launch, each wavefront staying with its chain (the data-dependent tree sizes of the individual
+ * transitions average out over the launch instead of making every launch as long as its longest
+ * tree), with the per-transition part of the warm-up adaptation done in-kernel, per chain:
+ *   da_state[C][5] = {x_avg, g_avg, t, prox_center, x_t}: DualAveraging.step on
+ *       H = target_accept - accept_prob, step[c] <- exp(x_t)  (pyro/ops/dual_averaging.py:55-78,
+ *       pyro/infer/mcmc/adaptation.py:115-121); NULL = fixed step size;
+ *   welford[C][2][D] = {mean, m2}: WelfordCovariance.update of z, diagonal, the sample count is
+ *       welford_n0 + k (pyro/ops/welford.py:27-38); NULL = off;
+ * (window-end events -- new mass matrix, step-size search -- stay on the host between launches.)
+ * samples[num_transitions][C][D] (NULL = not recorded) receives z after every transition;
+ * mean_accept[C] is the running mean of accept_prob with mean_n0 transitions already in it;
+ * counters[3][C] (int64, accumulated): leapfrog steps, tree depths, accepted proposals (the last
+ * only with count_accepts); div_flags[num_transitions][C] (int8, with count_accepts, NULL = off).
+ * accept_prob ... accepted report the LAST transition.  f32, D <= 128: Lambda's columns are held
+ * in VGPRs (one workgroup = one wave = one chain); otherwise Lambda is staged in LDS. */
+int pa_nuts_gaussian_run(int dtype, void* z, void* pe, void* grad, const void* Lambda,
+                         const void* inv_mass, void* step, int64_t C, int64_t D,
+                         int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t0,
+                         int64_t num_transitions, uint64_t chain_offset, void* da_state,
+                         double target_accept, void* welford, int64_t welford_n0, void* samples,
+                         void* mean_accept, int64_t mean_n0, int64_t* counters, int count_accepts,
+                         int8_t* div_flags, void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
+                         int32_t* diverging, int32_t* accepted, pa_stream_t stream);
+/* Test hook: force_lds != 0 makes the f32 path use the LDS-resident Lambda variant too. */
+int pa_nuts_gaussian_set_variant(int force_lds);
+
 /* NUTS for ARBITRARY potentials, vectorised over chains: the
  * tree logic of pyro/infer/mcmc/nuts.py:184-522 as a device-resident per-chain state machine.
  * The caller evaluates the potential energy and its gradient for all chains at the cursor

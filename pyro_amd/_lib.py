@@ -71,6 +71,12 @@ _SIGNATURES = {
                                             c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                             c_uint64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
+    "pa_nuts_gaussian_run": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_int64, c_int64, c_int, c_int, c_uint64, c_uint64,
+                                     c_int64, c_uint64, c_void_p, c_double, c_void_p, c_int64,
+                                     c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pa_nuts_gaussian_set_variant": (c_int, [c_int]),
     "pa_nuts_tree_workspace": (c_size_t, [c_int, c_int64, c_int64, c_int]),
     "pa_nuts_tree_begin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,

@@ -48,31 +48,73 @@ template <typename T> __device__ __forceinline__ P2<T> operator+(P2<T> x, P2<T> 
   return P2<T>{x.a + y.a, x.b + y.b};
 }
 template <typename T> __device__ __forceinline__ T dot(P2<T> x, P2<T> y) {
-  return uni(wave_sum(x.a * y.a + x.b * y.b));
+  // fixed contraction (round the .b product, then one fma) so every kernel variant that inlines
+  // this computes bit-identical energies whatever the surrounding code looks like
+  T p;
+  {
+#pragma clang fp contract(off)
+    p = x.b * y.b;
+  }
+  return uni(wave_sum(__builtin_fma(x.a, y.a, p)));
 }
 
-// g = Lambda z (Lambda symmetric, read as columns), pe = 0.5 z.g
+// ---- potentials: g = Lambda z (Lambda symmetric, read as columns), pe = 0.5 z.g ---------------
+// PotLds: Lambda staged once per workgroup in LDS (any dtype, D <= 128).
 template <typename T>
-__device__ __forceinline__ void potential(const T* __restrict__ Ls, int D, int lane, P2<T> z,
-                                          P2<T>& g, T& pe) {
-  T g0 = T(0), g1 = T(0);
-  const int d0 = D < 64 ? D : 64;
+struct PotLds {
+  const T* Ls;
+  int D, lane;
+  __device__ __forceinline__ void operator()(P2<T> z, P2<T>& g, T& pe) const {
+    T g0 = T(0), g1 = T(0);
+    const int d0 = D < 64 ? D : 64;
 #pragma unroll 4
-  for (int j = 0; j < d0; ++j) {
-    const T zj = bcast_lane(z.a, j);
-    g0 += Ls[j * D + lane] * zj;
-    g1 += Ls[j * D + lane + 64] * zj;
-  }
+    for (int j = 0; j < d0; ++j) {
+      const T zj = bcast_lane(z.a, j);
+      g0 += Ls[j * D + lane] * zj;
+      g1 += Ls[j * D + lane + 64] * zj;
+    }
 #pragma unroll 4
-  for (int j = 64; j < D; ++j) {
-    const T zj = bcast_lane(z.b, j - 64);
-    g0 += Ls[j * D + lane] * zj;
-    g1 += Ls[j * D + lane + 64] * zj;
+    for (int j = 64; j < D; ++j) {
+      const T zj = bcast_lane(z.b, j - 64);
+      g0 += Ls[j * D + lane] * zj;
+      g1 += Ls[j * D + lane + 64] * zj;
+    }
+    g.a = lane < D ? g0 : T(0);
+    g.b = lane + 64 < D ? g1 : T(0);
+    pe = T(0.5) * dot(z, g);
   }
-  g.a = lane < D ? g0 : T(0);
-  g.b = lane + 64 < D ? g1 : T(0);
-  pe = T(0.5) * dot(z, g);
-}
+};
+
+// PotReg: f32, the lane's two columns of Lambda live in VGPRs for the whole launch (2*DPAD
+// registers): the mat-vec is DPAD x {v_readlane -> SGPR, 2 v_fmac with register operands}, no LDS
+// traffic and no load latency on the critical path of the leapfrog.  Same summation order as
+// PotLds (j ascending), so both give bit-identical f32 results.
+template <int DPAD>
+struct PotReg {
+  float La[DPAD], Lb[DPAD];
+  int D, lane;
+  __device__ __forceinline__ void load(const float* __restrict__ Lambda, int D_, int lane_) {
+    D = D_;
+    lane = lane_;
+#pragma unroll
+    for (int j = 0; j < DPAD; ++j) {
+      La[j] = (j < D && lane < D) ? Lambda[j * D + lane] : 0.0f;
+      Lb[j] = (j < D && lane + 64 < D) ? Lambda[j * D + lane + 64] : 0.0f;
+    }
+  }
+  __device__ __forceinline__ void operator()(P2<float> z, P2<float>& g, float& pe) const {
+    float g0 = 0.0f, g1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DPAD; ++j) {
+      const float zj = j < 64 ? bcast_lane(z.a, j) : bcast_lane(z.b, j - 64);
+      g0 = __builtin_fmaf(La[j], zj, g0);
+      g1 = __builtin_fmaf(Lb[j], zj, g1);
+    }
+    g.a = g0;
+    g.b = g1;
+    pe = 0.5f * dot(z, g);
+  }
+};
 
 template <typename T>
 __device__ __forceinline__ bool is_turning(P2<T> r_first, P2<T> r_last, P2<T> r_sum) {
@@ -87,54 +129,24 @@ struct Edge {
   P2<T> z, r, ru, g;
 };
 
-template <typename T, int WPB>
-__global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
-    T* __restrict__ z_io, T* __restrict__ pe_io, T* __restrict__ grad_io,
-    const T* __restrict__ Lambda, const T* __restrict__ inv_mass, const T* __restrict__ step,
-    int C, int D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
-    uint64_t chain_offset, T* __restrict__ accept_prob_out, int32_t* __restrict__ nleap_out,
-    int32_t* __restrict__ depth_out, int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ls = reinterpret_cast<T*>(smem_raw);  // [D*D + 128]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ls_elems = D * D + 128;
-  // wave-private stack: [NUTS_MAX_DEPTH][3][128] vectors then [NUTS_MAX_DEPTH][2] scalars
-  T* stk = Ls + ls_elems + wave * (NUTS_MAX_DEPTH * (3 * 128 + 2));
-  T* stk_s = stk + NUTS_MAX_DEPTH * 3 * 128;
+template <typename T>
+struct TransitionStats {
+  T accept_prob;
+  int n_leapfrog, depth, diverged, accepted;
+};
 
-  for (int i = threadIdx.x; i < ls_elems; i += 64 * WPB) Ls[i] = i < D * D ? Lambda[i] : T(0);
-  __syncthreads();
-
-  const int chain = blockIdx.x * WPB + wave;
-  if (chain >= C) return;  // wave-uniform; no block-level sync after this point
-
-  const bool va = lane < D, vb = lane + 64 < D;
-  auto ld = [&](const T* p) {
-    return P2<T>{va ? p[(int64_t)chain * D + lane] : T(0),
-                 vb ? p[(int64_t)chain * D + lane + 64] : T(0)};
-  };
-  P2<T> zc = ld(z_io);
-  P2<T> gc = ld(grad_io);
-  T pe_c = pe_io[chain];
-  // diagonal inverse mass v; mass_matrix_sqrt_inverse = sqrt(v); mass_matrix_sqrt = 1/sqrt(v)
-  P2<T> v{va ? inv_mass[(int64_t)chain * D + lane] : T(1),
-          vb ? inv_mass[(int64_t)chain * D + lane + 64] : T(1)};
-  const P2<T> sq{Num<T>::sqrt_(v.a), Num<T>::sqrt_(v.b)};
-  const P2<T> isq{T(1) / sq.a, T(1) / sq.b};
-  const T eps = step[chain];
-
+// One NUTS transition of one chain (nuts.py:367-522), state (zc, pe_c, gc) updated in place.
+template <typename T, typename Pot>
+__device__ __forceinline__ void nuts_transition(const Pot& potential, P2<T>& zc, T& pe_c, P2<T>& gc,
+                                                P2<T> v, P2<T> sq, P2<T> isq, T eps, bool va,
+                                                bool vb, int lane, int max_depth, int multinomial,
+                                                uint64_t seed, uint64_t t, uint64_t cid, T* stk,
+                                                T* stk_s, TransitionStats<T>& out) {
   const uint64_t ctr_base = t << 20;
-  const uint64_t cid = chain_offset + (uint64_t)chain;
-
   // ---- momentum: r_unscaled ~ N(0, I), r = M^{1/2} r_unscaled (hmc.py:231-248) -----------
   P2<T> ru0;
-  if constexpr (sizeof(T) == 4) {
-    ru0.a = va ? philox_normal_f32(seed, ctr_base, (uint64_t)lane, cid) : 0.f;
-    ru0.b = vb ? philox_normal_f32(seed, ctr_base, (uint64_t)(lane + 64), cid) : 0.f;
-  } else {
-    ru0.a = va ? philox_normal_f64(seed, ctr_base, (uint64_t)lane, cid) : 0.0;
-    ru0.b = vb ? philox_normal_f64(seed, ctr_base, (uint64_t)(lane + 64), cid) : 0.0;
-  }
+  ru0.a = va ? philox_normal_t<T>(seed, ctr_base, (uint64_t)lane, cid) : T(0);
+  ru0.b = vb ? philox_normal_t<T>(seed, ctr_base, (uint64_t)(lane + 64), cid) : T(0);
   P2<T> r0{ru0.a * isq.a, ru0.b * isq.b};
   const T energy_current = T(0.5) * dot(ru0, ru0) + pe_c;  // nuts.py:380
 
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
   T tree_weight = multinomial ? T(0) : T(1);
   int accepted = 0, diverged = 0;
   int tree_depth = 0;
+  bool moved = false;
 
   while (tree_depth < max_depth) {
     const int j = tree_depth;
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
       zq.a = zq.a + eps_d * (v.a * rq.a);
       zq.b = zq.b + eps_d * (v.b * rq.b);
       T pe_q;
-      potential(Ls, D, lane, zq, gq, pe_q);
+      potential(zq, gq, pe_q);
       rq.a = rq.a + hk * (-gq.a);
       rq.b = rq.b + hk * (-gq.b);
       // ---- base tree (nuts.py:197-248) ----------------------------------------------------
@@ -256,6 +269,7 @@ __global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
     const T rnd = uni(uniform_from<T>(bj, 1));
     if (rnd < new_tree_prob) {  // nuts.py:482-492
       accepted = 1;
+      moved = true;
       zc = c_prop;
       pe_c = c_pe;
     }
@@ -267,25 +281,196 @@ __global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(
 
   // gradient at the returned position (the reference caches it with the proposal; it is a
   // deterministic function of z, recomputed here instead of carrying D more words per subtree)
-  T pe_chk;
-  potential(Ls, D, lane, zc, gc, pe_chk);
-  if (va) { z_io[(int64_t)chain * D + lane] = zc.a; grad_io[(int64_t)chain * D + lane] = gc.a; }
-  if (vb) { z_io[(int64_t)chain * D + lane + 64] = zc.b;
-            grad_io[(int64_t)chain * D + lane + 64] = gc.b; }
+  if (moved) {
+    T pe_chk;
+    potential(zc, gc, pe_chk);
+  }
+  out.accept_prob = sum_accept / (T)num_prop;  // nuts.py:510
+  out.n_leapfrog = num_prop;
+  out.depth = tree_depth;
+  out.diverged = diverged;
+  out.accepted = accepted;
+}
+
+// Optional per-chain adaptation executed between the transitions of one launch
+// (WarmupAdapter.step without its window-end branch, adaptation.py:166-185):
+//   da[chain*5 + {0: x_avg, 1: g_avg, 2: t, 3: prox_center, 4: x_t}]  dual averaging of log step
+//   wf[chain*2*D + {0..D-1: mean, D..2D-1: m2}]                        Welford of z, count wf_n0 + k
+struct RunArgs {
+  int64_t num_transitions;
+  double target_accept;      // dual averaging statistic H = target - accept_prob
+  double da_t0, da_kappa, da_gamma;
+  int64_t wf_n0;             // Welford samples seen before this launch
+  int64_t mean_n0;           // transitions already averaged into mean_accept
+  int count_accepts;         // sampling phase: accumulate accepted / record divergences
+};
+
+template <typename T, int WPB, typename Pot, bool LDS_LAMBDA>
+__device__ __forceinline__ void nuts_run_body(
+    Pot& potential, T* stk, T* stk_s, int chain, int lane, T* __restrict__ z_io,
+    T* __restrict__ pe_io, T* __restrict__ grad_io, const T* __restrict__ inv_mass,
+    T* __restrict__ step, int C, int D, int max_depth, int multinomial, uint64_t seed, uint64_t t0,
+    uint64_t chain_offset, RunArgs ra, T* __restrict__ da, T* __restrict__ wf,
+    T* __restrict__ samples, T* __restrict__ mean_accept, int64_t* __restrict__ counters,
+    int8_t* __restrict__ div_flags, T* __restrict__ accept_prob_out,
+    int32_t* __restrict__ nleap_out, int32_t* __restrict__ depth_out,
+    int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out) {
+  const bool va = lane < D, vb = lane + 64 < D;
+  const int64_t row = (int64_t)chain * D;
+  P2<T> zc{va ? z_io[row + lane] : T(0), vb ? z_io[row + lane + 64] : T(0)};
+  P2<T> gc{va ? grad_io[row + lane] : T(0), vb ? grad_io[row + lane + 64] : T(0)};
+  T pe_c = pe_io[chain];
+  // diagonal inverse mass v; mass_matrix_sqrt_inverse = sqrt(v); mass_matrix_sqrt = 1/sqrt(v)
+  const P2<T> v{va ? inv_mass[row + lane] : T(1), vb ? inv_mass[row + lane + 64] : T(1)};
+  const P2<T> sq{Num<T>::sqrt_(v.a), Num<T>::sqrt_(v.b)};
+  const P2<T> isq{T(1) / sq.a, T(1) / sq.b};
+  T eps = step[chain];
+  const uint64_t cid = chain_offset + (uint64_t)chain;
+
+  // adaptation state in registers for the whole launch
+  T x_avg = T(0), g_avg = T(0), da_t = T(0), prox = T(0), x_t = T(0);
+  if (da) { x_avg = da[chain * 5]; g_avg = da[chain * 5 + 1]; da_t = da[chain * 5 + 2];
+            prox = da[chain * 5 + 3]; x_t = da[chain * 5 + 4]; }
+  P2<T> w_mean{T(0), T(0)}, w_m2{T(0), T(0)};
+  if (wf) {
+    const int64_t wrow = (int64_t)chain * 2 * D;
+    w_mean = P2<T>{va ? wf[wrow + lane] : T(0), vb ? wf[wrow + lane + 64] : T(0)};
+    w_m2 = P2<T>{va ? wf[wrow + D + lane] : T(0), vb ? wf[wrow + D + lane + 64] : T(0)};
+  }
+  T mean_ap = mean_accept ? mean_accept[chain] : T(0);
+  int64_t nleap_tot = 0, depth_tot = 0, acc_tot = 0;
+  TransitionStats<T> st{T(0), 0, 0, 0, 0};
+
+  for (int64_t k = 0; k < ra.num_transitions; ++k) {
+    nuts_transition<T>(potential, zc, pe_c, gc, v, sq, isq, eps, va, vb, lane, max_depth,
+                       multinomial, seed, t0 + (uint64_t)k, cid, stk, stk_s, st);
+    nleap_tot += st.n_leapfrog;
+    depth_tot += st.depth;
+    T ap = st.accept_prob;
+    if (ap != ap) ap = T(0);   // NaN acceptance counts as 0 (as exp(-inf) would)
+    mean_ap += (ap - mean_ap) / (T)(ra.mean_n0 + k + 1);
+    if (ra.count_accepts) {
+      acc_tot += st.accepted;
+      if (div_flags && lane == 0) div_flags[k * (int64_t)C + chain] = (int8_t)st.diverged;
+    }
+    if (da) {  // DualAveraging.step (pyro/ops/dual_averaging.py:55-78) on H = target - ap
+      const T g = (T)ra.target_accept - ap;
+      da_t += T(1);
+      g_avg = (T(1) - T(1) / (da_t + (T)ra.da_t0)) * g_avg + g / (da_t + (T)ra.da_t0);
+      x_t = prox - Num<T>::sqrt_(da_t) / (T)ra.da_gamma * g_avg;
+      const T weight = Num<T>::exp_(-(T)ra.da_kappa * Num<T>::log_(da_t));
+      x_avg = (T(1) - weight) * x_avg + weight * x_t;
+      eps = Num<T>::exp_(x_t);
+    }
+    if (wf) {  // WelfordCovariance.update, diagonal (pyro/ops/welford.py:27-38)
+      const T n = (T)(ra.wf_n0 + k + 1);
+      const P2<T> pre{zc.a - w_mean.a, zc.b - w_mean.b};
+      w_mean = P2<T>{w_mean.a + pre.a / n, w_mean.b + pre.b / n};
+      w_m2 = P2<T>{w_m2.a + pre.a * (zc.a - w_mean.a), w_m2.b + pre.b * (zc.b - w_mean.b)};
+    }
+    if (samples) {
+      T* srow = samples + (k * (int64_t)C + chain) * D;
+      if (va) srow[lane] = zc.a;
+      if (vb) srow[lane + 64] = zc.b;
+    }
+  }
+
+  if (va) { z_io[row + lane] = zc.a; grad_io[row + lane] = gc.a; }
+  if (vb) { z_io[row + lane + 64] = zc.b; grad_io[row + lane + 64] = gc.b; }
+  if (wf) {
+    const int64_t wrow = (int64_t)chain * 2 * D;
+    if (va) { wf[wrow + lane] = w_mean.a; wf[wrow + D + lane] = w_m2.a; }
+    if (vb) { wf[wrow + lane + 64] = w_mean.b; wf[wrow + D + lane + 64] = w_m2.b; }
+  }
   if (lane == 0) {
     pe_io[chain] = pe_c;
-    accept_prob_out[chain] = sum_accept / (T)num_prop;  // nuts.py:510
-    nleap_out[chain] = num_prop;
-    depth_out[chain] = tree_depth;
-    div_out[chain] = diverged;
-    acc_out[chain] = accepted;
+    if (da) { da[chain * 5] = x_avg; da[chain * 5 + 1] = g_avg; da[chain * 5 + 2] = da_t;
+              da[chain * 5 + 4] = x_t; step[chain] = eps; }
+    if (mean_accept) mean_accept[chain] = mean_ap;
+    if (counters) {
+      counters[chain] += nleap_tot;
+      counters[(int64_t)C + chain] += depth_tot;
+      counters[2 * (int64_t)C + chain] += acc_tot;
+    }
+    accept_prob_out[chain] = st.accept_prob;
+    nleap_out[chain] = st.n_leapfrog;
+    depth_out[chain] = st.depth;
+    div_out[chain] = st.diverged;
+    acc_out[chain] = st.accepted;
   }
 }
 
+#define PA_NUTS_RUN_PARAMS                                                                        \
+  T *__restrict__ z_io, T *__restrict__ pe_io, T *__restrict__ grad_io,                           \
+      const T *__restrict__ Lambda, const T *__restrict__ inv_mass, T *__restrict__ step, int C,  \
+      int D, int max_depth, int multinomial, uint64_t seed, uint64_t t0, uint64_t chain_offset,   \
+      RunArgs ra, T *__restrict__ da, T *__restrict__ wf, T *__restrict__ samples,                \
+      T *__restrict__ mean_accept, int64_t *__restrict__ counters, int8_t *__restrict__ div_flags, \
+      T *__restrict__ accept_prob_out, int32_t *__restrict__ nleap_out,                           \
+      int32_t *__restrict__ depth_out, int32_t *__restrict__ div_out, int32_t *__restrict__ acc_out
+#define PA_NUTS_RUN_ARGS                                                                           \
+  z_io, pe_io, grad_io, inv_mass, step, C, D, max_depth, multinomial, seed, t0, chain_offset, ra,  \
+      da, wf, samples, mean_accept, counters, div_flags, accept_prob_out, nleap_out, depth_out,    \
+      div_out, acc_out
+
+// Lambda in LDS: WPB waves (= chains) per workgroup share one copy.
 template <typename T, int WPB>
-static int nuts_launch(T* z, T* pe, T* grad, const T* Lambda, const T* inv_mass, const T* step,
-                       int C, int D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
-                       uint64_t chain_offset, T* ap, int32_t* nl, int32_t* dp, int32_t* dv, int32_t* ac, hipStream_t s) {
+__global__ __launch_bounds__(64 * WPB) void nuts_gaussian_kernel(PA_NUTS_RUN_PARAMS) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Ls = reinterpret_cast<T*>(smem_raw);  // [D*D + 128]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ls_elems = D * D + 128;
+  // wave-private stack: [NUTS_MAX_DEPTH][3][128] vectors then [NUTS_MAX_DEPTH][2] scalars
+  T* stk = Ls + ls_elems + wave * (NUTS_MAX_DEPTH * (3 * 128 + 2));
+  T* stk_s = stk + NUTS_MAX_DEPTH * 3 * 128;
+  for (int i = threadIdx.x; i < ls_elems; i += 64 * WPB) Ls[i] = i < D * D ? Lambda[i] : T(0);
+  __syncthreads();
+  const int chain = blockIdx.x * WPB + wave;
+  if (chain >= C) return;  // wave-uniform; no block-level sync after this point
+  PotLds<T> pot{Ls, D, lane};
+  nuts_run_body<T, WPB, PotLds<T>, true>(pot, stk, stk_s, chain, lane, PA_NUTS_RUN_ARGS);
+}
+
+// Lambda columns in VGPRs (f32): one wave = one chain = one workgroup, up to 512 VGPRs per lane.
+template <int DPAD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void nuts_gaussian_reg_kernel(float* __restrict__ z_io, float* __restrict__ pe_io,
+                              float* __restrict__ grad_io, const float* __restrict__ Lambda,
+                              const float* __restrict__ inv_mass, float* __restrict__ step, int C,
+                              int D, int max_depth, int multinomial, uint64_t seed, uint64_t t0,
+                              uint64_t chain_offset, RunArgs ra, float* __restrict__ da,
+                              float* __restrict__ wf, float* __restrict__ samples,
+                              float* __restrict__ mean_accept, int64_t* __restrict__ counters,
+                              int8_t* __restrict__ div_flags, float* __restrict__ accept_prob_out,
+                              int32_t* __restrict__ nleap_out, int32_t* __restrict__ depth_out,
+                              int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out) {
+  using T = float;
+  __shared__ float stack_s[NUTS_MAX_DEPTH * (3 * 128 + 2)];
+  const int lane = threadIdx.x;
+  const int chain = blockIdx.x;
+  PotReg<DPAD> pot;
+  pot.load(Lambda, D, lane);
+  nuts_run_body<float, 1, PotReg<DPAD>, false>(pot, stack_s, stack_s + NUTS_MAX_DEPTH * 3 * 128,
+                                               chain, lane, PA_NUTS_RUN_ARGS);
+}
+
+template <typename T>
+struct RunPtrs {
+  T *z, *pe, *grad;
+  const T* Lambda;
+  const T* inv_mass;
+  T* step;
+  T *da, *wf, *samples, *mean_accept;
+  int64_t* counters;
+  int8_t* div_flags;
+  T* ap;
+  int32_t *nl, *dp, *dv, *ac;
+};
+
+template <typename T, int WPB>
+static int nuts_launch_lds(const RunPtrs<T>& p, int C, int D, int max_depth, int multinomial,
+                           uint64_t seed, uint64_t t0, uint64_t chain_offset, const RunArgs& ra,
+                           hipStream_t s) {
   const size_t lds = ((size_t)D * D + 128 + (size_t)WPB * NUTS_MAX_DEPTH * (3 * 128 + 2)) *
                      sizeof(T);
   if (lds > 160 * 1024)
@@ -298,12 +483,52 @@ static int nuts_launch(T* z, T* pe, T* grad, const T* Lambda, const T* inv_mass,
       return fail(PA_ERR_LAUNCH, "nuts_gaussian: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int grid = (C + WPB - 1) / WPB;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), lds, s, p.z, p.pe, p.grad, p.Lambda,
+                     p.inv_mass, p.step, C, D, max_depth, multinomial, seed, t0, chain_offset, ra,
+                     p.da, p.wf, p.samples, p.mean_accept, p.counters, p.div_flags, p.ap, p.nl,
+                     p.dp, p.dv, p.ac);
+  return PA_OK;
+}
+
+template <int DPAD>
+static void nuts_launch_reg(const RunPtrs<float>& p, int C, int D, int max_depth, int multinomial,
+                            uint64_t seed, uint64_t t0, uint64_t chain_offset, const RunArgs& ra,
+                            hipStream_t s) {
+  hipLaunchKernelGGL((nuts_gaussian_reg_kernel<DPAD>), dim3(C), dim3(64), 0, s, p.z, p.pe, p.grad,
+                     p.Lambda, p.inv_mass, p.step, C, D, max_depth, multinomial, seed, t0,
+                     chain_offset, ra, p.da, p.wf, p.samples, p.mean_accept, p.counters,
+                     p.div_flags, p.ap, p.nl, p.dp, p.dv, p.ac);
+}
+
+static int g_nuts_force_lds = 0;  // test hook: pa_nuts_gaussian_set_variant
+
+template <typename T>
+static int nuts_dispatch(const RunPtrs<T>& p, int C, int D, int max_depth, int multinomial,
+                         uint64_t seed, uint64_t t0, uint64_t chain_offset, const RunArgs& ra,
+                         hipStream_t s) {
   hipEvent_t ev0, ev1;
   const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WPB), lds, s, z, pe, grad, Lambda, inv_mass, step, C,
-                     D, max_depth, multinomial, seed, t, chain_offset, ap, nl, dp, dv, ac);
+  int rc = PA_OK;
+  if constexpr (sizeof(T) == 4) {
+    if (!g_nuts_force_lds) {
+      if (D <= 32) nuts_launch_reg<32>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+      else if (D <= 64) nuts_launch_reg<64>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+      else if (D <= 96) nuts_launch_reg<96>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+      else if (D <= 104) nuts_launch_reg<104>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+      else nuts_launch_reg<128>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+    } else {
+      rc = nuts_launch_lds<T, 4>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+    }
+  } else {
+    const size_t lds2 = ((size_t)D * D + 128 + 2 * (size_t)NUTS_MAX_DEPTH * (3 * 128 + 2)) * 8;
+    if (lds2 <= 160 * 1024)
+      rc = nuts_launch_lds<T, 2>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+    else
+      rc = nuts_launch_lds<T, 1>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+  }
   if (br) (void)hipEventRecord(ev1, s);
+  if (rc != PA_OK) return rc;
   return check_launch("nuts_gaussian_kernel");
 }
 
@@ -311,11 +536,12 @@ static int nuts_launch(T* z, T* pe, T* grad, const T* Lambda, const T* inv_mass,
 
 extern "C" {
 
-int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const void* Lambda,
-                                const void* inv_mass, const void* step, int64_t C, int64_t D,
-                                int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t,
-                                uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
-                                int32_t* diverging, int32_t* accepted, pa_stream_t stream) {
+int pa_nuts_gaussian_set_variant(int force_lds) {
+  pa::g_nuts_force_lds = force_lds ? 1 : 0;
+  return PA_OK;
+}
+
+static int nuts_common_checks(int dtype, int64_t C, int64_t D, int max_tree_depth, uint64_t t) {
   PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "nuts_gaussian: bad dtype %d", dtype);
   PA_REQUIRE(C >= 0 && D >= 1, "nuts_gaussian: bad shape C=%lld D=%lld", (long long)C,
              (long long)D);
@@ -324,30 +550,59 @@ int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const 
   PA_REQUIRE(max_tree_depth >= 1 && max_tree_depth <= pa::NUTS_MAX_DEPTH,
              "nuts_gaussian: max_tree_depth must be in [1,%d]", pa::NUTS_MAX_DEPTH);
   PA_REQUIRE(C < (1 << 30) && t < ((uint64_t)1 << 43), "nuts_gaussian: C or t too large");
-  if (C == 0) return PA_OK;
+  return PA_OK;
+}
+
+int pa_nuts_gaussian_run(int dtype, void* z, void* pe, void* grad, const void* Lambda,
+                         const void* inv_mass, void* step, int64_t C, int64_t D,
+                         int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t0,
+                         int64_t num_transitions, uint64_t chain_offset, void* da_state,
+                         double target_accept, void* welford, int64_t welford_n0, void* samples,
+                         void* mean_accept, int64_t mean_n0, int64_t* counters, int count_accepts,
+                         int8_t* div_flags, void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
+                         int32_t* diverging, int32_t* accepted, pa_stream_t stream) {
+  int rc = nuts_common_checks(dtype, C, D, max_tree_depth, t0 + (uint64_t)num_transitions);
+  if (rc != PA_OK) return rc;
+  PA_REQUIRE(num_transitions >= 0, "nuts_gaussian_run: negative num_transitions");
+  if (C == 0 || num_transitions == 0) return PA_OK;
   PA_REQUIRE(z && pe && grad && Lambda && inv_mass && step && accept_prob && n_leapfrog && depth &&
                  diverging && accepted,
              "nuts_gaussian: NULL pointer");
+  pa::RunArgs ra;
+  ra.num_transitions = num_transitions;
+  ra.target_accept = target_accept;
+  ra.da_t0 = 10.0; ra.da_kappa = 0.75; ra.da_gamma = 0.05;   // DualAveraging defaults
+  ra.wf_n0 = welford_n0;
+  ra.mean_n0 = mean_n0;
+  ra.count_accepts = count_accepts;
   hipStream_t s = pa::as_stream(stream);
-  if (dtype == PA_F32)
-    return pa::nuts_launch<float, 4>((float*)z, (float*)pe, (float*)grad, (const float*)Lambda,
-                                     (const float*)inv_mass, (const float*)step, (int)C, (int)D,
-                                     max_tree_depth, use_multinomial, seed, t, chain_offset,
-                                     (float*)accept_prob,
-                                     n_leapfrog, depth, diverging, accepted, s);
-  const size_t lds2 = ((size_t)D * D + 128 + 2 * (size_t)pa::NUTS_MAX_DEPTH * (3 * 128 + 2)) * 8;
-  if (lds2 <= 160 * 1024)
-    return pa::nuts_launch<double, 2>((double*)z, (double*)pe, (double*)grad,
-                                      (const double*)Lambda, (const double*)inv_mass,
-                                      (const double*)step, (int)C, (int)D, max_tree_depth,
-                                      use_multinomial, seed, t, chain_offset, (double*)accept_prob,
-                                      n_leapfrog,
-                                      depth, diverging, accepted, s);
-  return pa::nuts_launch<double, 1>((double*)z, (double*)pe, (double*)grad, (const double*)Lambda,
-                                    (const double*)inv_mass, (const double*)step, (int)C, (int)D,
-                                    max_tree_depth, use_multinomial, seed, t, chain_offset,
-                                    (double*)accept_prob,
-                                    n_leapfrog, depth, diverging, accepted, s);
+  if (dtype == PA_F32) {
+    pa::RunPtrs<float> p{(float*)z, (float*)pe, (float*)grad, (const float*)Lambda,
+                         (const float*)inv_mass, (float*)step, (float*)da_state, (float*)welford,
+                         (float*)samples, (float*)mean_accept, counters, div_flags,
+                         (float*)accept_prob, n_leapfrog, depth, diverging, accepted};
+    return pa::nuts_dispatch<float>(p, (int)C, (int)D, max_tree_depth, use_multinomial, seed, t0,
+                                    chain_offset, ra, s);
+  }
+  pa::RunPtrs<double> p{(double*)z, (double*)pe, (double*)grad, (const double*)Lambda,
+                        (const double*)inv_mass, (double*)step, (double*)da_state, (double*)welford,
+                        (double*)samples, (double*)mean_accept, counters, div_flags,
+                        (double*)accept_prob, n_leapfrog, depth, diverging, accepted};
+  return pa::nuts_dispatch<double>(p, (int)C, (int)D, max_tree_depth, use_multinomial, seed, t0,
+                                   chain_offset, ra, s);
+}
+
+int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const void* Lambda,
+                                const void* inv_mass, const void* step, int64_t C, int64_t D,
+                                int max_tree_depth, int use_multinomial, uint64_t seed, uint64_t t,
+                                uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog,
+                                int32_t* depth, int32_t* diverging, int32_t* accepted,
+                                pa_stream_t stream) {
+  // one transition, no adaptation, no sample buffer: `step` is only read
+  return pa_nuts_gaussian_run(dtype, z, pe, grad, Lambda, inv_mass, const_cast<void*>(step), C, D,
+                              max_tree_depth, use_multinomial, seed, t, 1, chain_offset, nullptr,
+                              0.8, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr,
+                              accept_prob, n_leapfrog, depth, diverging, accepted, stream);
 }
 
 }  // extern "C"

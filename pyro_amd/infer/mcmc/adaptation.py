@@ -175,6 +175,75 @@ class WarmupAdapter:
                     self.reset_step_size_adaptation(z)
             self._current_window += 1
 
+    # ---- bulk interface: the per-transition part of step() runs inside the persistent NUTS kernel
+    # (pa_nuts_gaussian_run); the host only handles the window-end events -------------------------
+    def bulk_span(self, t_done):
+        """(k, adapting): the transitions t_done+1 .. t_done+k can share one launch -- no window
+        end strictly inside -- and whether step() would adapt during them."""
+        remaining = self._warmup_steps - t_done
+        if self._adaptation_disabled or t_done + 1 >= self._warmup_steps:
+            return remaining, False
+        window = self._adaptation_schedule[self._current_window]
+        k = max(1, min(window.end - t_done, self._warmup_steps - 1 - t_done))
+        return k, True
+
+    def in_mass_phase(self):
+        num_windows = len(self._adaptation_schedule)
+        return self.adapt_mass_matrix and (0 < self._current_window < num_windows - 1)
+
+    def da_state(self):
+        """Dual-averaging state as one [C, 5] tensor {x_avg, g_avg, t, prox_center, x_t}."""
+        s = self._step_size_adapt_scheme
+        st = torch.zeros((self.step_size.shape[0], 5), dtype=self.step_size.dtype,
+                         device=self.step_size.device)
+        st[:, 0] = s._x_avg
+        st[:, 1] = s._g_avg
+        st[:, 2] = float(s._t)
+        st[:, 3] = s.prox_center
+        st[:, 4] = getattr(s, "_x_t", 0.0)
+        return st
+
+    def load_da_state(self, st, k):
+        s = self._step_size_adapt_scheme
+        s._x_avg, s._g_avg, s._x_t = st[:, 0].clone(), st[:, 1].clone(), st[:, 4].clone()
+        s._t += k
+
+    def welford_state(self):
+        """([C, 2, D] {mean, m2}, samples seen) of the mass-matrix estimator."""
+        w = self.mass_matrix_adapter._scheme
+        v = self.mass_matrix_adapter.inverse_mass_matrix
+        st = torch.zeros((v.shape[0], 2, v.shape[1]), dtype=v.dtype, device=v.device)
+        st[:, 0] = w._mean
+        st[:, 1] = w._m2
+        return st, w.n_samples
+
+    def load_welford_state(self, st, k):
+        w = self.mass_matrix_adapter._scheme
+        w._mean, w._m2 = st[:, 0].clone(), st[:, 1].clone()
+        w.n_samples += k
+
+    def finish_span(self, t, z):
+        """The window-end branch of step() (adaptation.py:186-202) for a span that ended at t."""
+        if t >= self._warmup_steps or self._adaptation_disabled:
+            return
+        window = self._adaptation_schedule[self._current_window]
+        if t != window.end:
+            return
+        num_windows = len(self._adaptation_schedule)
+        mass_phase = self.in_mass_phase()
+        if self._current_window == num_windows - 1:
+            self._current_window += 1
+            self._end_adaptation()
+            return
+        if self._current_window == 0:
+            self._current_window += 1
+            return
+        if mass_phase:
+            self.mass_matrix_adapter.end_adaptation()
+            if self.adapt_step_size:
+                self.reset_step_size_adaptation(z)
+        self._current_window += 1
+
     @property
     def adaptation_schedule(self):
         return self._adaptation_schedule

@@ -144,7 +144,24 @@ class MCMC:
             fast = isinstance(k, HMC)
             S, C = self.num_samples, self._local_chains
             params = k.initial_params
-            if fast:
+            bulk = fast and getattr(k, "_fused", False) and getattr(k, "use_persistent", False) \
+                and self.hook_fn is None
+            if bulk:
+                # persistent launches: many transitions per kernel, samples written by the kernel
+                buf = torch.empty((S, C, k._layout.D), dtype=k._z.dtype, device=k._z.device)
+                done = 0
+                while done < self.warmup_steps:
+                    done += k._transition_many(self.warmup_steps - done)
+                k.end_warmup()
+                done = 0
+                while done < S:
+                    done += k._transition_many(S - done, samples=buf[done:])
+                flat = buf.transpose(0, 1)    # [C, S, D]
+                z_acc = {}
+                for name in k._layout.names:
+                    a, b = k._layout.slices[name]
+                    z_acc[name] = flat[:, :, a:b].reshape((C, S) + tuple(k._layout.shapes[name]))
+            elif fast:
                 buf = torch.empty((S, C, k._layout.D), dtype=k._z.dtype, device=k._z.device)
                 for i in range(self.warmup_steps):
                     k._transition()

@@ -39,6 +39,8 @@ class NUTS(HMC):
         self._tree = None
         self.sync_every = 4      # host polls of n_active in the generic tree loop
         self.use_fused_gaussian = True
+        self.use_persistent = True   # many transitions per launch on the fused Gaussian path
+        self._launch_hook = None     # called before every fused launch (bench: event brackets)
 
     def setup(self, warmup_steps, *args, **kwargs):
         super().setup(warmup_steps, *args, **kwargs)
@@ -48,6 +50,8 @@ class NUTS(HMC):
                        and self._layout.D <= 128 and len(self._layout.names) == 1)
         if self._fused:
             self._Lambda = self.potential_fn.precision.to(self._z.dtype).contiguous()
+        self._counters = torch.zeros((3, self.num_chains), dtype=torch.int64,
+                                     device=self._z.device)
 
     def _transition(self):
         t = self._t
@@ -64,6 +68,58 @@ class NUTS(HMC):
         self._tree_depth_sum += out["depth"].sum()
         self._last_stats = out
         self._after_transition(out["accept_prob"], out["accepted"] != 0, out["diverging"] != 0)
+
+    def _transition_many(self, k, samples=None):
+        """Up to ``k`` transitions in ONE persistent launch (fused Gaussian path): returns how many
+        were done -- a launch never crosses a warm-up window end or the warm-up/sampling border.
+        The per-transition half of the adaptation (dual averaging, Welford) runs in the kernel."""
+        assert self._fused
+        ad = self._adapter
+        warm = self._t < self._warmup_steps
+        da = wf = None
+        wf_n0 = 0
+        if warm:
+            span, adapting = ad.bulk_span(self._t)
+            k = min(k, span)
+            if adapting and ad.adapt_step_size:
+                da = ad.da_state()
+            if adapting and ad.in_mass_phase():
+                wf, wf_n0 = ad.welford_state()
+            mean_n0 = self._t
+        else:
+            mean_n0 = self._t - self._warmup_steps
+        step = ad.step_size
+        if not step.is_contiguous():
+            step = step.contiguous()
+            ad.step_size = step
+        div = None
+        if not warm:
+            div = torch.zeros((k, self.num_chains), dtype=torch.int8, device=self._z.device)
+        if samples is not None:
+            samples = samples[:k]
+        if self._launch_hook is not None:
+            self._launch_hook()
+        out = kernels.nuts_gaussian_run(
+            self._z, self._pe, self._grad, self._Lambda, self.inverse_mass_matrix, step,
+            self._max_tree_depth, self.use_multinomial_sampling, self._seed, self._t, k,
+            self.chain_offset, da_state=da, target_accept=ad.target_accept_prob, welford=wf,
+            welford_n0=wf_n0, samples=samples, mean_accept=self._mean_accept_prob,
+            mean_n0=mean_n0, counters=self._counters, count_accepts=not warm, div_flags=div)
+        self._last_stats = out
+        self._t += k
+        if warm:
+            if da is not None:
+                ad.load_da_state(da, k)
+            if wf is not None:
+                ad.load_welford_state(wf, k)
+            ad.finish_span(self._t, self._z)
+        else:
+            self._divergences.extend(div[i] for i in range(k))
+        return k
+
+    @property
+    def num_leapfrog_steps(self):
+        return int(self._n_leapfrog_total.item()) + int(self._counters[0].sum().item())
 
     def _tree_transition(self, t, step, inv_mass):
         tree = self._tree
@@ -97,8 +153,10 @@ class NUTS(HMC):
         return OrderedDict(list(out.items()))
 
     def diagnostics(self):
+        self._accept_cnt = self._accept_cnt + self._counters[2]
+        self._counters[2].zero_()
         out = super().diagnostics()
         if self._t:
-            out["mean tree depth"] = float(self._tree_depth_sum.item()) / (self._t *
-                                                                          self.num_chains)
+            depth = float(self._tree_depth_sum.item()) + float(self._counters[1].sum().item())
+            out["mean tree depth"] = depth / (self._t * self.num_chains)
         return out

@@ -306,6 +306,39 @@ def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth
             "accepted": ints[3]}
 
 
+def nuts_gaussian_run(z, pe, grad, Lambda, inv_mass, step, max_tree_depth, use_multinomial, seed,
+                      t0, num_transitions, chain_offset=0, da_state=None, target_accept=0.8,
+                      welford=None, welford_n0=0, samples=None, mean_accept=None, mean_n0=0,
+                      counters=None, count_accepts=False, div_flags=None):
+    """``num_transitions`` NUTS transitions per chain in ONE launch, in place on (z, pe, grad) and,
+    when adapting, on (step, da_state [C,5], welford [C,2,D]).  Returns the statistics of the last
+    transition like nuts_gaussian_transition."""
+    _require_gpu(z, pe, grad, Lambda, inv_mass, step, da_state, welford, samples, mean_accept,
+                 counters, div_flags)
+    C, D = z.shape
+    K = int(num_transitions)
+    for x in (z, pe, grad, Lambda, inv_mass, step, da_state, welford, samples, mean_accept):
+        assert x is None or (x.is_contiguous() and x.dtype == z.dtype)
+    assert Lambda.shape == (D, D) and inv_mass.shape == (C, D) and step.shape == (C,)
+    assert da_state is None or da_state.shape == (C, 5)
+    assert welford is None or welford.shape == (C, 2, D)
+    assert samples is None or samples.shape == (K, C, D)
+    assert counters is None or (counters.shape == (3, C) and counters.dtype == torch.int64
+                                and counters.is_contiguous())
+    assert div_flags is None or (div_flags.shape == (K, C) and div_flags.dtype == torch.int8
+                                 and div_flags.is_contiguous())
+    ap = torch.empty((C,), dtype=z.dtype, device=z.device)
+    ints = torch.empty((4, C), dtype=torch.int32, device=z.device)
+    check(_lib.load().pa_nuts_gaussian_run(
+        _dtype(z), _ptr(z), _ptr(pe), _ptr(grad), _ptr(Lambda), _ptr(inv_mass), _ptr(step), C, D,
+        int(max_tree_depth), int(bool(use_multinomial)), int(seed), int(t0), K, int(chain_offset),
+        _ptr(da_state), float(target_accept), _ptr(welford), int(welford_n0), _ptr(samples),
+        _ptr(mean_accept), int(mean_n0), _ptr(counters), int(bool(count_accepts)), _ptr(div_flags),
+        _ptr(ap), _ptr(ints[0]), _ptr(ints[1]), _ptr(ints[2]), _ptr(ints[3]), _stream()))
+    return {"accept_prob": ap, "n_leapfrog": ints[0], "depth": ints[1], "diverging": ints[2],
+            "accepted": ints[3]}
+
+
 class NutsTree:
     """Device-resident NUTS tree state for C chains of dimension D (pa_nuts_tree_*).
 

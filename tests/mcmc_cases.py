@@ -154,3 +154,31 @@ def logreg_mcmc_model_unfused(X, y):
         logits = w @ X.t()
         logits = logits.squeeze(-2) if logits.dim() > 1 else logits
         pyro.sample("obs", dist.Bernoulli(logits=logits), obs=y)
+
+
+def run_persistent_equals_stepwise(device, dtype, rtol, C=6, D=9, warmup=40, S=6):
+    """MCMC(NUTS(GaussianPotential)) with step-size + mass adaptation: the persistent multi-transition
+    launches (in-kernel dual averaging / Welford, host window ends) against the per-transition
+    host-adapted path.  Same Philox keys => the same chains up to rounding of the adaptation math."""
+    Lam = torch.tensor(make_precision(D, 4), dtype=dtype, device=device)
+    z0 = torch.tensor(np.random.default_rng(1).standard_normal((C, D)) * 0.3, dtype=dtype,
+                      device=device)
+    outs = []
+    for persistent in (False, True):
+        pyro.set_rng_seed(77)
+        kernel = NUTS(potential_fn=GaussianPotential(Lam), max_tree_depth=5)
+        kernel.use_persistent = persistent
+        mcmc = MCMC(kernel, num_samples=S, warmup_steps=warmup, num_chains=C,
+                    initial_params={"x": z0.clone()})
+        mcmc.run()
+        outs.append((mcmc.get_samples(group_by_chain=True)["x"].clone(),
+                     kernel.step_size.clone(), kernel.inverse_mass_matrix.clone(),
+                     kernel.num_leapfrog_steps, mcmc.diagnostics()))
+    a, b = outs
+    assert a[3] == b[3], (a[3], b[3])                       # identical trees
+    torch.testing.assert_close(a[1], b[1], rtol=rtol, atol=0)
+    torch.testing.assert_close(a[2], b[2], rtol=rtol, atol=0)
+    torch.testing.assert_close(a[0], b[0], rtol=rtol, atol=rtol)
+    torch.testing.assert_close(a[4]["acceptance rate"], b[4]["acceptance rate"])
+    assert a[4]["divergences"] == b[4]["divergences"]
+    assert abs(a[4]["mean tree depth"] - b[4]["mean tree depth"]) < 1e-12

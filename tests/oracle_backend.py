@@ -125,6 +125,45 @@ def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth
             "diverging": ti[2], "accepted": ti[3]}
 
 
+def nuts_gaussian_run(z, pe, grad, Lambda, inv_mass, step, max_tree_depth, use_multinomial, seed,
+                      t0, num_transitions, chain_offset=0, da_state=None, target_accept=0.8,
+                      welford=None, welford_n0=0, samples=None, mean_accept=None, mean_n0=0,
+                      counters=None, count_accepts=False, div_flags=None):
+    """Stand-in of the persistent kernel: the single-transition stand-in in a loop plus the
+    per-transition adaptation recurrences (DualAveraging.step / WelfordCovariance.update)."""
+    out = None
+    for k in range(int(num_transitions)):
+        out = nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth,
+                                       use_multinomial, seed, t0 + k, chain_offset)
+        ap = torch.nan_to_num(out["accept_prob"], nan=0.0)
+        if counters is not None:
+            counters[0] += out["n_leapfrog"].to(torch.int64)
+            counters[1] += out["depth"].to(torch.int64)
+            if count_accepts:
+                counters[2] += out["accepted"].to(torch.int64)
+        if mean_accept is not None:
+            mean_accept += (ap - mean_accept) / (mean_n0 + k + 1)
+        if count_accepts and div_flags is not None:
+            div_flags[k] = out["diverging"].to(torch.int8)
+        if da_state is not None:
+            g = target_accept - ap
+            da_state[:, 2] += 1
+            t = da_state[:, 2]
+            da_state[:, 1] = (1 - 1 / (t + 10.0)) * da_state[:, 1] + g / (t + 10.0)
+            da_state[:, 4] = da_state[:, 3] - t.sqrt() / 0.05 * da_state[:, 1]
+            w = t ** (-0.75)
+            da_state[:, 0] = (1 - w) * da_state[:, 0] + w * da_state[:, 4]
+            step.copy_(da_state[:, 4].exp())
+        if welford is not None:
+            n = welford_n0 + k + 1
+            pre = z - welford[:, 0]
+            welford[:, 0] += pre / n
+            welford[:, 1] += pre * (z - welford[:, 0])
+        if samples is not None:
+            samples[k] = z
+    return out
+
+
 class NutsTree:
     """Stand-in for kernels.NutsTree backed by oracle/nuts_tree.py (numpy, host)."""
 
@@ -185,7 +224,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999)
 
 FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
-             "nuts_gaussian_transition", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
+             "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd"]
 
 

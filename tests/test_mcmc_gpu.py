@@ -143,3 +143,50 @@ def test_chain_offset_shifts_streams(gpu):
                                          torch.full((n,), 0.2, dtype=torch.float64, device=gpu), 6, True, 5, 0, off)
         outs.append(z)
     torch.testing.assert_close(outs[0][3:], outs[1], rtol=0, atol=0)
+
+
+def test_persistent_launch_path_equals_per_transition_path_f64(gpu):
+    # in-kernel dual averaging uses device exp/log/sqrt: equal to the host recurrences to rounding
+    mc.run_persistent_equals_stepwise(gpu, torch.float64, 1e-6)
+
+
+@pytest.mark.parametrize("D", [5, 64, 100, 128])
+def test_multi_transition_launch_is_bitwise_sequence_of_single_launches(gpu, D):
+    """K transitions in one launch == K launches of one transition (no adaptation), bit for bit,
+    for f64 (Lambda in LDS) and f32 (Lambda columns in VGPRs); and the two f32 variants
+    (registers / LDS) agree bit for bit with each other."""
+    from pyro_amd import _lib
+    C, K = 16, 5
+    res = {}
+    for dtype, variants in ((torch.float64, [0]), (torch.float32, [0, 1])):
+        Lam = torch.tensor(mc.make_precision(D, 6), dtype=dtype, device=gpu)
+        z0 = torch.tensor(np.random.default_rng(2).standard_normal((C, D)) * 0.3, dtype=dtype, device=gpu)
+        im = torch.tensor(np.random.default_rng(3).uniform(0.5, 1.5, (C, D)), dtype=dtype, device=gpu)
+        st = torch.full((C,), 0.2, dtype=dtype, device=gpu)
+        for force_lds in variants:
+            _lib.load().pa_nuts_gaussian_set_variant(force_lds)
+            try:
+                outs = []
+                for mode in ("bulk", "single"):
+                    z = z0.clone()
+                    g = (z @ Lam).contiguous()
+                    pe = (0.5 * (z * g).sum(1)).contiguous()
+                    samples = torch.zeros((K, C, D), dtype=dtype, device=gpu)
+                    cnt = torch.zeros((3, C), dtype=torch.int64, device=gpu)
+                    if mode == "bulk":
+                        kernels.nuts_gaussian_run(z, pe, g, Lam, im, st, 6, True, 11, 3, K, 5,
+                                                  samples=samples, counters=cnt)
+                    else:
+                        for k in range(K):
+                            kernels.nuts_gaussian_run(z, pe, g, Lam, im, st, 6, True, 11, 3 + k, 1, 5,
+                                                      samples=samples[k:k + 1], counters=cnt)
+                    outs.append((z, pe, g, samples, cnt))
+                for u, v in zip(*outs):
+                    assert torch.equal(u, v)
+                res[(dtype, force_lds)] = outs[0]
+            finally:
+                _lib.load().pa_nuts_gaussian_set_variant(0)
+    for u, v in zip(res[(torch.float32, 0)], res[(torch.float32, 1)]):
+        assert torch.equal(u, v)
+    # and f32 follows the f64 trees for the first transition
+    assert (res[(torch.float32, 0)][4][0] > 0).all()

@@ -147,3 +147,8 @@ def test_mcmc_model_potential_and_diagnostics(_cpu_backend):
     d = mcmc.diagnostics()
     assert set(d["mu"]) == {"n_eff", "r_hat"} and "divergences" in d and "acceptance rate" in d
     assert mcmc.get_samples()["mu"].shape == (24, 2)
+
+
+def test_persistent_launch_path_equals_per_transition_path(_cpu_backend):
+    mc.run_persistent_equals_stepwise(torch.device("cpu"), torch.float64, 1e-10, C=3, D=5,
+                                      warmup=30, S=4)
