@@ -150,7 +150,15 @@ int pa_normal_rsample(int dtype, void* out, void* eps_out, pa_view2d loc, pa_vie
  * Deterministic reduction (per-block partials in workspace, fp64 finalize).
  * Supported: f32, 1 <= D <= 128. Otherwise PA_ERR_UNSUPPORTED and the
  * caller uses the unfused path (matmul + pa_dist_log_prob_sum).
+ *
+ * Two arithmetic variants, selected process-wide by pa_glm_set_variant:
+ *   0 (default) the contractions run on the bf16 matrix cores with every f32 operand split
+ *     exactly into three bf16 pieces and the six piece products of order >= 2^-16 accumulated
+ *     in f32 (error O(2^-23) per product: f32-roundoff class, not bit-identical to an fmaf
+ *     chain).  Needs D % 4 == 0 and a 16-byte aligned X; other layouts take variant 1.
+ *   1 exact f32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 fmaf chain per product sum.
  * ---------------------------------------------------------------------------------- */
+int pa_glm_set_variant(int variant);
 size_t pa_glm_bernoulli_workspace(int64_t N, int64_t D, int64_t P);
 int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, const float* b,
                              const uint8_t* mask, double scale, int64_t N, int64_t D, int64_t P,

@@ -54,6 +54,7 @@ _SIGNATURES = {
                                       c_void_p]),
     "pa_normal_rsample": (c_int, [c_int, c_void_p, c_void_p, View2D, View2D, c_int64, c_int64,
                                   c_uint64, c_uint64, c_void_p, c_void_p]),
+    "pa_glm_set_variant": (c_int, [c_int]),
     "pa_glm_bernoulli_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_glm_bernoulli_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,

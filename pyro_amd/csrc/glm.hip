@@ -21,8 +21,13 @@
 //     of the co-resident wave;
 //   * deterministic reduction: per-block partials -> fp64 finalize kernel (no float atomics).
 #include "common.h"
+#include "glm_bf16.h"
 
 namespace pa {
+
+// 0 = bf16x3 split-precision matrix-core kernel (glm_bf16.h) when the layout allows it, 1 = always
+// the exact-f32 MFMA kernel below.  Process-wide; see pa_glm_set_variant.
+static int g_glm_variant = 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -105,38 +110,38 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
   const int n_first = e0 / D, d_first = e0 % D;
   const int64_t total_e = row_end * (int64_t)D;
 
+  // Loads use CLAMPED addresses and are consumed raw; validity is applied in write_stage(), one
+  // tile of compute later (a select next to the load makes the compiler wait for it right there
+  // and exposes the full HBM latency on every tile).
   auto issue_loads = [&](int64_t tile) {
     const int64_t base = (row_begin + tile * 32) * (int64_t)D;  // flat offset of the tile's first element
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int64_t e = base + e0 + (int64_t)j * step_e;
       const bool ok = ((e0 + j * step_e) < 32 * D) && (e < total_e);
-      // branch-free: always load from a clamped in-range address, select afterwards
       const int64_t ec = ok ? e : 0;
       if (VEC4) {
         const float4 v = *reinterpret_cast<const float4*>(X + ec);
-        stage[4 * j + 0] = ok ? v.x : 0.0f; stage[4 * j + 1] = ok ? v.y : 0.0f;
-        stage[4 * j + 2] = ok ? v.z : 0.0f; stage[4 * j + 3] = ok ? v.w : 0.0f;
+        stage[4 * j + 0] = v.x; stage[4 * j + 1] = v.y;
+        stage[4 * j + 2] = v.z; stage[4 * j + 3] = v.w;
       } else {
-        const float v = X[ec];
-        stage[j] = ok ? v : 0.0f;
+        stage[j] = X[ec];
       }
     }
     const int64_t n = row_begin + tile * 32 + l31;
-    const bool okn = n < row_end;
-    const int64_t nc = okn ? n : 0;
-    const float yv = y[nc];
-    const float mv = mask == nullptr ? 1.0f : (mask[nc] != 0 ? 1.0f : 0.0f);
-    st_m = okn ? mv : 0.0f;
-    st_y = okn ? yv : 0.0f;
+    const int64_t nc = n < row_end ? n : 0;
+    st_y = y[nc];
+    st_m = mask == nullptr ? 1.0f : (mask[nc] != 0 ? 1.0f : 0.0f);
   };
-  auto write_stage = [&]() {
+  auto write_stage = [&](int64_t tile) {
+    const int64_t base = (row_begin + tile * 32) * (int64_t)D;
     int n = n_first, d = d_first;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       if (e0 + j * step_e < 32 * D) {
+        const bool ok = base + e0 + (int64_t)j * step_e < total_e;
 #pragma unroll
-        for (int k = 0; k < EPL; ++k) Xs[n * S + d + k] = stage[EPL * j + k];
+        for (int k = 0; k < EPL; ++k) Xs[n * S + d + k] = ok ? stage[EPL * j + k] : 0.0f;
       }
       n += q0;
       d += r0;
@@ -145,8 +150,10 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
     if (h == 0) {
       // a masked-out row contributes exactly 0 even if its data are inf/NaN-free garbage:
       // scale_and_mask is where(mask, x, 0) (pyro/distributions/util.py:326)
-      Xs[l31 * S + DP] = st_m * st_y;
-      Xs[l31 * S + DP + 1] = st_m;
+      const bool okn = row_begin + tile * 32 + l31 < row_end;
+      const float m = okn ? st_m : 0.0f;
+      Xs[l31 * S + DP] = okn ? m * st_y : 0.0f;
+      Xs[l31 * S + DP + 1] = m;
     }
   };
 
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
 
   issue_loads(tile);
   __syncthreads();  // LDS zero-fill complete
-  write_stage();
+  write_stage(tile);
   __syncthreads();
 
   for (int64_t it = 0; it < iters; ++it) {
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
     // The LDS slice is private to this wave and a wave's DS operations execute in program order,
     // so re-staging needs no workgroup barrier (waves of a block are free to drift out of phase:
     // one wave's MFMA burst then overlaps the other waves' VALU phase on the shared CU).
-    if (it + 1 < iters) write_stage();
+    if (it + 1 < iters) write_stage(next);
     tile = next;
   }
   __syncthreads();
@@ -350,7 +357,14 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   hipEvent_t ev0, ev1;
   const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  if (vec4) {
+  if (vec4 && g_glm_variant == 0) {
+    auto k = glm_bernoulli_bf16_kernel<DT, PT, false>;
+    constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k, grid, block, lds, s, X, y, w, b, mask, N, D, P, pl.iters, part,
+                       (const int64_t*)nullptr, 1);
+  } else if (vec4) {
     auto k = glm_bernoulli_kernel<DT, PT, true, false>;
     if (pl.lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -433,7 +447,13 @@ static int glm_grouped_launch(const float* X, const float* y, const float* w, co
   hipEvent_t ev0, ev1;
   const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  if (vec4) {
+  if (vec4 && g_glm_variant == 0) {
+    auto k = glm_bernoulli_bf16_kernel<DT, PT, true>;
+    constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k, grid, block, lds, s, X, y, w, b, mask, N, D, P, iters, part, seg, G);
+  } else if (vec4) {
     auto k = glm_bernoulli_kernel<DT, PT, true, true>;
     if (lds_bytes > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -465,6 +485,12 @@ static void glm_tiles_of(int64_t D, int64_t P, int* DT, int* PT) {
 }  // namespace pa
 
 extern "C" {
+
+int pa_glm_set_variant(int variant) {
+  PA_REQUIRE(variant == 0 || variant == 1, "glm_set_variant: expected 0 (bf16x3) or 1 (exact f32)");
+  pa::g_glm_variant = variant;
+  return PA_OK;
+}
 
 size_t pa_glm_bernoulli_workspace(int64_t N, int64_t D, int64_t P) {
   if (N < 0 || D < 1 || D > 128 || P < 1) return 0;

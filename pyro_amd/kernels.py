@@ -174,6 +174,16 @@ def normal_rsample(loc, scale, rows, cols, seed, offset, want_eps=True, offset_d
 # fused Bernoulli-logits GLM
 # ------------------------------------------------------------------------------------------
 
+GLM_BF16X3, GLM_EXACT_F32 = 0, 1
+
+
+def glm_set_variant(variant):
+    """Process-wide arithmetic of the fused GLM kernels: GLM_BF16X3 (default; bf16 matrix cores
+    with 3-way split operands, f32-roundoff-class error) or GLM_EXACT_F32 (f32 MFMA, bit-for-bit an
+    fmaf chain)."""
+    check(_lib.load().pa_glm_set_variant(int(variant)))
+
+
 def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
     """X[N,D], y[N], w[P,D], b[P] or None, mask[N] bool or None -> (ll[P], gw[P,D], gb[P])."""
     _require_gpu(X, y, w, b, mask)

@@ -148,13 +148,22 @@ def test_normal_rsample(gpu, dtype):
 
 
 # ---------------------------------------------------------------------------------------------
-# fused Bernoulli GLM
+# fused Bernoulli GLM -- both arithmetic variants (bf16x3 split on the bf16 matrix cores = the
+# default, exact-f32 MFMA) are held to the SAME tolerances against the float64 oracle
 # ---------------------------------------------------------------------------------------------
+@pytest.fixture(params=[0, 1], ids=["bf16x3", "exact_f32"])
+def glm_variant(request):
+    k = _k()
+    k.glm_set_variant(request.param)
+    yield request.param
+    k.glm_set_variant(k.GLM_BF16X3)
+
+
 @pytest.mark.parametrize("N,D,P", [(1, 1, 1), (31, 3, 2), (32, 32, 64), (33, 32, 64), (1000, 32, 64),
                                    (4099, 8, 5), (2048, 32, 33), (5000, 20, 100), (3000, 64, 40),
                                    (1500, 48, 7), (1200, 128, 12), (700, 100, 3), (0, 4, 2)])
 @pytest.mark.parametrize("use_mask,use_bias", [(False, True), (True, False)])
-def test_glm_bernoulli(gpu, N, D, P, use_mask, use_bias):
+def test_glm_bernoulli(gpu, glm_variant, N, D, P, use_mask, use_bias):
     k = _k()
     rng = np.random.default_rng(N + D + P)
     X = rng.standard_normal((N, D)).astype(np.float32)
@@ -176,7 +185,7 @@ def test_glm_bernoulli(gpu, N, D, P, use_mask, use_bias):
 @pytest.mark.parametrize("N,D,P,G", [(1000, 32, 64, 7), (5000, 32, 64, 50), (777, 8, 5, 3),
                                      (3000, 64, 20, 11), (400, 32, 33, 40), (2000, 100, 3, 4)])
 @pytest.mark.parametrize("use_mask", [False, True])
-def test_glm_bernoulli_grouped(gpu, N, D, P, G, use_mask):
+def test_glm_bernoulli_grouped(gpu, glm_variant, N, D, P, G, use_mask):
     """Hierarchical GLM (config 5): per-group weights, rows sorted by group, ragged groups
     (some empty), against the numpy restatement."""
     k = _k()
@@ -211,7 +220,7 @@ def test_glm_bernoulli_grouped(gpu, N, D, P, G, use_mask):
     torch.testing.assert_close(g1[:, 0], g0, rtol=1e-5, atol=1e-4 * N ** 0.5)
 
 
-def test_glm_bernoulli_transpose_detecting(gpu):
+def test_glm_bernoulli_transpose_detecting(gpu, glm_variant):
     """Asymmetric inputs: a swapped (p,d) or (n,p) mapping cannot pass."""
     k = _k()
     N, D, P = 96, 32, 64
@@ -227,7 +236,7 @@ def test_glm_bernoulli_transpose_detecting(gpu):
     np.testing.assert_allclose(gb.cpu().numpy(), rgb, rtol=1e-5, atol=1e-5)
 
 
-def test_glm_bernoulli_deterministic_and_linear(gpu):
+def test_glm_bernoulli_deterministic_and_linear(gpu, glm_variant):
     """Full-size properties (BASELINE N=1e6, D=32, P=64): bitwise run-to-run determinism, and
     additivity over a split of the plate (sum of two half-plates == whole plate)."""
     k = _k()
@@ -250,6 +259,32 @@ def test_glm_bernoulli_deterministic_and_linear(gpu):
     logits = (w.double() @ X.double().T) + b.double()[:, None]
     ll_ref = (y.double() * logits - torch.nn.functional.softplus(logits)).sum(1)
     torch.testing.assert_close(a1[0].double(), ll_ref, rtol=2e-5, atol=1e-3)
+
+
+def test_glm_bf16x3_is_f32_class(gpu):
+    """The split-precision variant is an f32-equivalent: its error against the float64 oracle on
+    per-row logit-sensitive outputs is of the size of the exact-f32 kernel's own rounding error
+    (a plain bf16 GEMM would be ~1e-2 relative here)."""
+    k = _k()
+    N, D, P = 4096, 32, 64
+    rng = np.random.default_rng(5)
+    X = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-3, 3, (N, 1)))).astype(np.float32)
+    w = rng.standard_normal((P, D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32)
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    errs = {}
+    try:
+        for v in (k.GLM_BF16X3, k.GLM_EXACT_F32):
+            k.glm_set_variant(v)
+            out = k.glm_bernoulli_fwd_bwd(tt(X, gpu), tt(y, gpu), tt(w, gpu), tt(b, gpu), None, 1.0)
+            errs[v] = [float(np.abs(o.cpu().numpy() - r).max() / np.abs(r).max())
+                       for o, r in zip(out, ref)]
+    finally:
+        k.glm_set_variant(k.GLM_BF16X3)
+    for e_split, e_exact in zip(errs[k.GLM_BF16X3], errs[k.GLM_EXACT_F32]):
+        assert e_split < 3e-6, errs                     # f32-class absolute bound
+        assert e_split < 8 * e_exact + 5e-7, errs       # and comparable to the exact kernel's
 
 
 # ---------------------------------------------------------------------------------------------
