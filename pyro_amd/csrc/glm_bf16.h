@@ -48,7 +48,7 @@ struct GlmBfCfg {
   static constexpr int WROWS = 32 * PT;
   static constexpr int W_BYTES = 3 * WROWS * RS;
   static constexpr int WAUX_BYTES = WROWS * 8;
-  static constexpr int WAVE_BYTES = 3 * PLANE + 256;   // + yh[32] f32 + aux[32] u32
+  static constexpr int WAVE_BYTES = 3 * PLANE + 384;   // + yh[32] f32 + aux[64] u32 (upper half 0)
   static constexpr int LDS_BYTES = W_BYTES + WAUX_BYTES + GLMB_WAVES * WAVE_BYTES;
 };
 
@@ -110,18 +110,24 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
   }
   const int pbase = blockIdx.y * WROWS;
 
-  // ---- staging registers: the next tile travels global -> VGPR while this one computes ------
+  // ---- staging: tile k+2 travels global -> VGPR (raw) while tile k computes; tile k+1 is split
+  //      into its bf16 planes in registers under the MFMAs of GEMM1 and written to LDS at the end
+  //      of tile k (after the last LDS read of tile k's planes) --------------------------------
   constexpr int NLD = 4 * DT;                 // float4 loads per lane per tile
+  constexpr bool EARLY_SPLIT = (DT == 1);     // larger D: no registers for the split planes
   float4 stage[NLD];
   float st_y = 0.0f;
   uint8_t st_m = 0;
+  uint32_t xs1[2 * NLD], xs2[2 * NLD], xs3[2 * NLD];
+  float xs_yh = -0.5f;
+  uint32_t xs_aux = 0u;
   const int D4 = D >> 2;                      // float4 per row
   const int64_t total_e = row_end * (int64_t)D;
 
-  // The loads are issued with CLAMPED addresses and consumed raw: validity is applied only in
-  // write_stage(), one whole tile of compute later.  (Selecting `ok ? v : 0` next to the load
-  // makes the compiler wait for the load right there -- s_waitcnt vmcnt(0) in front of the
-  // compute block -- which exposes the full HBM latency on every tile.)
+  // Loads use CLAMPED addresses and are consumed raw; validity is applied when the tile is split,
+  // a whole tile of compute later (a select next to the load would make the compiler wait for the
+  // load right there and expose the HBM latency on every tile).  A tile index past the end simply
+  // loads in-range garbage that is masked out: the loop body has no branches.
   auto issue_loads = [&](int64_t tile) {
     const int64_t base = (row_begin + tile * 32) * (int64_t)D;
 #pragma unroll
@@ -134,41 +140,49 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     const int64_t n = row_begin + tile * 32 + l31;
     const int64_t nc = n < row_end ? n : 0;
     st_y = y[nc];
-    st_m = mask == nullptr ? (uint8_t)1 : mask[nc];
+    // always a load (no branch in the loop body): without a mask the byte read is ignored
+    st_m = *(mask != nullptr ? mask + nc : reinterpret_cast<const uint8_t*>(y + nc));
   };
-  // (row, col) of this lane's j-th float4 and the increments between consecutive j
-  const int n_first = lane / D4, d_first = (lane % D4) * 4;
-  const int qn = 64 / D4, qd = (64 % D4) * 4;
-  auto write_stage = [&](int64_t tile) {
+  auto split_unit = [&](int j, int64_t tile) {          // stage[j] -> xs*[2j], xs*[2j+1]
     const int64_t base = (row_begin + tile * 32) * (int64_t)D;
-    int n = n_first, d = d_first;
+    const bool ok = base + 4 * (int64_t)(j * 64 + lane) < total_e;
+    split_pair(ok ? stage[j].x : 0.0f, ok ? stage[j].y : 0.0f, xs1[2 * j], xs2[2 * j], xs3[2 * j]);
+    split_pair(ok ? stage[j].z : 0.0f, ok ? stage[j].w : 0.0f, xs1[2 * j + 1], xs2[2 * j + 1],
+               xs3[2 * j + 1]);
+  };
+  auto split_row = [&](int64_t tile) {
+    const bool okr = (row_begin + tile * 32 + l31 < row_end) && (mask == nullptr || st_m != 0);
+    // scale_and_mask is where(mask, x, 0) (pyro/distributions/util.py:326): a row that does not
+    // count gets y = 0 and the -1e30 logit offset
+    xs_yh = (okr ? st_y : 0.0f) - 0.5f;
+    xs_aux = (BF16_ONE << 16) | (okr ? 0u : BF16_NEG_HUGE);     // k slots {offset, 1.0}
+  };
+  // (row, col) of this lane's j-th float4; lanes past the end of a narrow tile (D < DP) write into
+  // the 16-byte pad of row 0, which nobody reads
+  int wofs[NLD];
+  {
+    int n = lane / D4, d = (lane % D4) * 4;
+    const int qn = 64 / D4, qd = (64 % D4) * 4;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int f = j * 64 + lane;
-      if (f < 8 * D) {
-        const bool ok = base + 4 * (int64_t)f < total_e;
-        uint32_t a1, a2, a3, b1, b2, b3;
-        split_pair(ok ? stage[j].x : 0.0f, ok ? stage[j].y : 0.0f, a1, a2, a3);
-        split_pair(ok ? stage[j].z : 0.0f, ok ? stage[j].w : 0.0f, b1, b2, b3);
-        unsigned char* q = Xp + n * RS + d * 2;
-        *reinterpret_cast<uint2*>(q) = make_uint2(a1, b1);
-        *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(a2, b2);
-        *reinterpret_cast<uint2*>(q + 2 * PLANE) = make_uint2(a3, b3);
-      }
+      wofs[j] = (j * 64 + lane < 8 * D) ? n * RS + d * 2 : DP * 2;
       n += qn;
       d += qd;
       if (d >= D) { d -= D; n += 1; }
     }
-    if (h == 0) {
-      const bool okr = (row_begin + tile * 32 + l31 < row_end) && st_m != 0;
-      // scale_and_mask is where(mask, x, 0) (pyro/distributions/util.py:326): a row that does not
-      // count gets y = 0 and the -1e30 logit offset
-      yh_s[l31] = (okr ? st_y : 0.0f) - 0.5f;
-      aux_s[l31] = (BF16_ONE << 16) | (okr ? 0u : BF16_NEG_HUGE);   // {offset, 1.0}
+  }
+  auto write_xs = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      unsigned char* q = Xp + wofs[j];
+      *reinterpret_cast<uint2*>(q) = make_uint2(xs1[2 * j], xs1[2 * j + 1]);
+      *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(xs2[2 * j], xs2[2 * j + 1]);
+      *reinterpret_cast<uint2*>(q + 2 * PLANE) = make_uint2(xs3[2 * j], xs3[2 * j + 1]);
     }
+    yh_s[l31] = xs_yh;          // both lane halves hold the same row values
+    aux_s[l31] = xs_aux;
   };
 
-  const int64_t ntiles = (row_end - row_begin + 31) / 32;
   int64_t tile = GROUPED ? (int64_t)wave : (int64_t)blockIdx.x * GLMB_WAVES + wave;
   const int64_t tile_stride = GROUPED ? (int64_t)GLMB_WAVES : (int64_t)gridDim.x * GLMB_WAVES;
 
@@ -197,7 +211,11 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     waux[2 * pl] = BF16_ONE | (p1 << 16);                    // k slots {0: 1.0, 1: b1}
     waux[2 * pl + 1] = (p2 & 0xffffu) | (p3 << 16);          // k slots {2: b2, 3: b3}
   }
-  write_stage(tile);
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) split_unit(j, tile);
+  split_row(tile);
+  write_xs();
+  issue_loads(tile + tile_stride);
   __syncthreads();
 
   bf16x8 b_aux[PT];
@@ -207,11 +225,11 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
                           h == 0 ? waux[2 * (pt * 32 + l31) + 1] : 0u, 0u, 0u);
 
   f32x16v gwacc[PT][DT];
-  float ll_acc[PT], gb_acc[PT];
+  f32x2v ll2[PT], gb2[PT];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    ll_acc[pt] = 0.0f;
-    gb_acc[pt] = 0.0f;
+    ll2[pt] = f32x2v{0.0f, 0.0f};
+    gb2[pt] = f32x2v{0.0f, 0.0f};
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -221,118 +239,159 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
   const unsigned char* a_row = Xp + l31 * RS + 16 * h;            // A operand of GEMM1
   const unsigned char* w_row = Wp + l31 * RS + 16 * h;            // B operand of GEMM1
   const unsigned char* x_col = Xp + (4 * h) * RS + l31 * 2;       // B operand of GEMM2
+  const uint32_t aux_ones = h == 0 ? (BF16_ONE | (BF16_ONE << 16)) : 0u;
+
+  // piece products in increasing order of magnitude: (x3,w1) (x2,w2) (x1,w3) (x2,w1) (x1,w2) (x1,w1)
+  constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+  constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+  constexpr int NM1 = 1 + 6 * KC;             // MFMAs of GEMM1 per particle tile
 
   for (int64_t it = 0; it < iters; ++it) {
-    const int64_t next = tile + tile_stride;
-    if (it + 1 < iters) issue_loads(next);
+    const int64_t nxt = tile + tile_stride;
+    f32x16v acc[PT];
+    bf16x8 xa[3], wa[3], xb[3];
+    uint32_t g1[PT][8], g2[PT][8], g3[PT][8];
 
-    if (tile < ntiles) {
-      // ---- GEMM1 (+ bias / row-offset MFMA) ------------------------------------------------
-      f32x16v acc[PT];
-      {
-        const bf16x8 a_aux = as_bf16x8(h == 0 ? aux_s[l31] : 0u,
-                                       h == 0 ? (BF16_ONE | (BF16_ONE << 16)) : 0u, 0u, 0u);
+    // i-th MFMA of GEMM1 for particle tile pt (0: bias / row-offset, then chunk-major pieces)
+    auto gemm1 = [&](int pt, int i) {
+      if (i == 0) {
+        // aux_s[32..63] stay 0: the upper lane half (k slots 8..15) contributes nothing
+        const bf16x8 a_aux = as_bf16x8(aux_s[lane], aux_ones, 0u, 0u);
         const f32x16v zero = {};
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_aux, b_aux[pt], zero, 0, 0, 0);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_aux, b_aux[pt], zero, 0, 0, 0);
+        return;
       }
+      const int c = (i - 1) / 6, t = (i - 1) % 6;
+      if (t == 0) {
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(a_row + 32 * c);
-        const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(a_row + 32 * c + PLANE);
-        const bf16x8 x3 = *reinterpret_cast<const bf16x8*>(a_row + 32 * c + 2 * PLANE);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          const unsigned char* wq = w_row + pt * 32 * RS + 32 * c;
-          const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wq);
-          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wq + WROWS * RS);
-          const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wq + 2 * WROWS * RS);
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1, acc[pt], 0, 0, 0);
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w2, acc[pt], 0, 0, 0);
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w3, acc[pt], 0, 0, 0);
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w1, acc[pt], 0, 0, 0);
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w2, acc[pt], 0, 0, 0);
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1, acc[pt], 0, 0, 0);
+        for (int pl = 0; pl < 3; ++pl) {
+          xa[pl] = *reinterpret_cast<const bf16x8*>(a_row + 32 * c + pl * PLANE);
+          wa[pl] = *reinterpret_cast<const bf16x8*>(w_row + pt * 32 * RS + 32 * c + pl * WROWS * RS);
         }
       }
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[TA[t]], wa[TB[t]], acc[pt], 0, 0, 0);
+    };
+    // element-wise on accumulator registers 2i, 2i+1 of particle tile pt (rows n = (r&3) + 8(r>>2)
+    // + 4h), two at a time so that the plain f32 arithmetic packs into v_pk_*_f32:
+    //   y*l - softplus(l) = (y - 1/2) l - |l|/2 - ln2*log2(1 + e),  e = exp(-|l|)
+    //   (a row with the -1e30 offset gives (-1/2)(-1e30) - 1e30/2 - 0 = 0 exactly)
+    //   g = y - sigmoid(l) = (y - 1/2) - copysign(1/(1+e) - 1/2, l)
+    // then g -> three bf16 pieces, packed as the A operand of GEMM2
+    auto elem = [&](int pt, int i) {
+      const int r = 2 * i;
+      const float* yp = yh_s + 8 * (r >> 2) + 4 * h + (r & 3);
+      const f32x2v yh = *reinterpret_cast<const f32x2v*>(yp);
+      const f32x2v l = {acc[pt][r], acc[pt][r + 1]};
+      const f32x2v a = {__builtin_fabsf(l.x), __builtin_fabsf(l.y)};
+      const f32x2v na = a * -1.44269504088896340736f;
+      const f32x2v e = {__builtin_amdgcn_exp2f(na.x), __builtin_amdgcn_exp2f(na.y)};
+      const f32x2v t = e + 1.0f;
+      const f32x2v lg = {__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
+      const f32x2v inv = {__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
+      f32x2v u = yh * l;
+      u = a * -0.5f + u;
+      u = lg * -0.69314718055994530942f + u;
+      ll2[pt] += u;
+      const f32x2v dd = inv - 0.5f;
+      const f32x2v ds = {__builtin_copysignf(dd.x, l.x), __builtin_copysignf(dd.y, l.y)};
+      const f32x2v g = yh - ds;
+      gb2[pt] += g;
+      split_pair(g.x, g.y, g1[pt][i], g2[pt][i], g3[pt][i]);
+    };
+    // B operand of GEMM2 for K half kh, feature tile dt: 8 rows n(8kh+j, h) of column d = 32dt+l31
+    // from each plane (16-bit LDS reads; gfx950 runs with SRAM ECC, where a d16 load does not
+    // preserve the other register half, so the pairs are packed on the VALU)
+    auto load_xb = [&](int kh, int dt) {
+      u16x8v c[3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * kh + j;
+        const unsigned char* q = x_col + ((r & 3) + 8 * (r >> 2)) * RS + dt * 64;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          c[pl][j] = *reinterpret_cast<const unsigned short*>(q + pl * PLANE);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) xb[pl] = __builtin_bit_cast(bf16x8, c[pl]);
+    };
+    // i-th MFMA of GEMM2 for (pt, kh): feature tile dt = i / 6, piece product i % 6
+    auto gemm2 = [&](int pt, int kh, int i) {
+      const int dt = i / 6, t = i % 6;
+      if (t == 0) load_xb(kh, dt);
+      const uint32_t* gp = TA[t] == 0 ? g1[pt] : (TA[t] == 1 ? g2[pt] : g3[pt]);
+      const bf16x8 ga = as_bf16x8(gp[4 * kh], gp[4 * kh + 1], gp[4 * kh + 2], gp[4 * kh + 3]);
+      gwacc[pt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, xb[TB[t]], gwacc[pt][dt], 0, 0, 0);
+    };
+    // NM matrix instructions fm(0..NM-1) with NV units of vector work fv(0..NV-1) spread between
+    // them in program order (the two pipes run concurrently; a wave issues in order)
+#define PA_INTERLEAVE(NM, NV, FM, FV)                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < ((NM) > 0 ? (NM) : 1); ++i_) {  \
+    if (i_ < (NM)) { FM(i_); }                                             \
+    const int nm_ = (NM) > 0 ? (NM) : 1;                                   \
+    _Pragma("unroll") for (int j_ = i_ * (NV) / nm_; j_ < (i_ + 1) * (NV) / nm_; ++j_) { FV(j_); } \
+  }
 
-      // ---- element-wise on the accumulator registers; g -> three bf16 planes in registers ----
-      // register r of a lane (p = l31, h) is row n = (r&3) + 8*(r>>2) + 4*h: yh for r = 4q..4q+3
-      // is the float4 at yh_s[8q + 4h]
-      float yh[16];
+    // P0: GEMM1(pt 0)  ||  split of the next tile (registers only)
+#define FM_(i) gemm1(0, i)
+#define FV_(j) { if (EARLY_SPLIT) { if (j < NLD) split_unit(j, nxt); else split_row(nxt); } }
+    PA_INTERLEAVE(NM1, NLD + 1, FM_, FV_)
+#undef FM_
+#undef FV_
+    if (EARLY_SPLIT) issue_loads(nxt + tile_stride);
+    if constexpr (PT == 2) {
+      // P1: GEMM1(pt 1)  ||  element-wise(pt 0, registers 0..7)
+#define FM_(i) gemm1(1, i)
+#define FV_(j) elem(0, j)
+      PA_INTERLEAVE(NM1, 4, FM_, FV_)
+#undef FM_
+#undef FV_
+    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(yh_s + 8 * q + 4 * h);
-        yh[4 * q + 0] = v.x; yh[4 * q + 1] = v.y; yh[4 * q + 2] = v.z; yh[4 * q + 3] = v.w;
-      }
-      uint32_t g1[PT][8], g2[PT][8], g3[PT][8];
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        float gv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float l = acc[pt][r];
-          const float a = fabsf(l);
-          // e = exp(-|l|) via v_exp_f32 (2^x); t = 1 + e in (1, 2]
-          const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * a);
-          const float t = 1.0f + e;
-          const float lg = __builtin_amdgcn_logf(t);       // log2(1 + e)
-          const float inv = __builtin_amdgcn_rcpf(t);      // sigmoid(|l|) in [0.5, 1)
-          // y*l - softplus(l) = (y - 1/2) l - |l|/2 - ln2*log2(1 + e); a row with the -1e30
-          // offset gives (-1/2)(-1e30) - 1e30/2 - 0 = 0 exactly
-          float u = yh[r] * l;
-          u = __builtin_fmaf(-0.5f, a, u);
-          u = __builtin_fmaf(-0.69314718055994530942f, lg, u);
-          ll_acc[pt] += u;
-          // sigmoid(l) - 1/2 = copysign(inv - 1/2, l): g = y - sigmoid(l) = yh - that
-          const float gg = yh[r] - __builtin_copysignf(inv - 0.5f, l);
-          gb_acc[pt] += gg;
-          gv[r] = gg;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) split_pair(gv[2 * i], gv[2 * i + 1], g1[pt][i], g2[pt][i], g3[pt][i]);
-      }
-
-      // ---- GEMM2: K half kh = accumulator registers 8kh..8kh+7 (rows n(r, h)) -----------------
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          u16x8v c1, c2, c3;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int r = 8 * kh + j;
-            const int nrow = (r & 3) + 8 * (r >> 2);           // + 4h is folded into x_col
-            const unsigned char* q = x_col + nrow * RS + dt * 64;
-            c1[j] = *reinterpret_cast<const unsigned short*>(q);
-            c2[j] = *reinterpret_cast<const unsigned short*>(q + PLANE);
-            c3[j] = *reinterpret_cast<const unsigned short*>(q + 2 * PLANE);
-          }
-          const bf16x8 x1 = __builtin_bit_cast(bf16x8, c1);
-          const bf16x8 x2 = __builtin_bit_cast(bf16x8, c2);
-          const bf16x8 x3 = __builtin_bit_cast(bf16x8, c3);
-#pragma unroll
-          for (int pt = 0; pt < PT; ++pt) {
-            const bf16x8 a1 = as_bf16x8(g1[pt][4 * kh], g1[pt][4 * kh + 1], g1[pt][4 * kh + 2], g1[pt][4 * kh + 3]);
-            const bf16x8 a2 = as_bf16x8(g2[pt][4 * kh], g2[pt][4 * kh + 1], g2[pt][4 * kh + 2], g2[pt][4 * kh + 3]);
-            const bf16x8 a3 = as_bf16x8(g3[pt][4 * kh], g3[pt][4 * kh + 1], g3[pt][4 * kh + 2], g3[pt][4 * kh + 3]);
-            f32x16v t = gwacc[pt][dt];
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, x1, t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x2, t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x3, t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x1, t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x2, t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, t, 0, 0, 0);
-            gwacc[pt][dt] = t;
-          }
-        }
-      }
+      for (int j = 0; j < 4; ++j) elem(0, j);
     }
-    // the LDS slice is private to this wave and a wave's DS operations execute in program order:
-    // re-staging needs no workgroup barrier
-    if (it + 1 < iters) write_stage(next);
-    tile = next;
+    // P2: GEMM2(pt 0, K half 0)  ||  element-wise(pt 0, registers 8..15)
+#define FM_(i) gemm2(0, 0, i)
+#define FV_(j) elem(0, 4 + j)
+    PA_INTERLEAVE(6 * DT, 4, FM_, FV_)
+#undef FM_
+#undef FV_
+    if constexpr (PT == 2) {
+      // P3: GEMM2(pt 0, K half 1)  ||  element-wise(pt 1, registers 0..7)
+#define FM_(i) gemm2(0, 1, i)
+#define FV_(j) elem(1, j)
+      PA_INTERLEAVE(6 * DT, 4, FM_, FV_)
+#undef FM_
+#undef FV_
+      // P4: GEMM2(pt 1, K half 0)  ||  element-wise(pt 1, registers 8..15)
+#define FM_(i) gemm2(1, 0, i)
+#define FV_(j) elem(1, 4 + j)
+      PA_INTERLEAVE(6 * DT, 4, FM_, FV_)
+#undef FM_
+#undef FV_
+      // P5: GEMM2(pt 1, K half 1)
+#pragma unroll
+      for (int i = 0; i < 6 * DT; ++i) gemm2(1, 1, i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6 * DT; ++i) gemm2(0, 1, i);
+    }
+#undef PA_INTERLEAVE
+    // every LDS read of this tile's planes has been issued (a wave's DS operations execute in
+    // program order, the slice is private to the wave): overwrite them with the next tile
+    if (!EARLY_SPLIT) {
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) split_unit(j, nxt);
+      split_row(nxt);
+    }
+    write_xs();
+    if (!EARLY_SPLIT) issue_loads(nxt + tile_stride);
+    tile = nxt;
+  }
+  float ll_acc[PT], gb_acc[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    ll_acc[pt] = ll2[pt].x + ll2[pt].y;
+    gb_acc[pt] = gb2[pt].x + gb2[pt].y;
   }
   __syncthreads();
 
