@@ -144,6 +144,12 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     st_m = *(mask != nullptr ? mask + nc : reinterpret_cast<const uint8_t*>(y + nc));
   };
   auto split_unit = [&](int j, int64_t tile) {          // stage[j] -> xs*[2j], xs*[2j+1]
+#ifdef PA_GLM_PROBE_NOSPLITX
+    xs1[2 * j] = cvt_pk_bf16(stage[j].x, stage[j].y); xs1[2 * j + 1] = cvt_pk_bf16(stage[j].z, stage[j].w);
+    xs2[2 * j] = xs1[2 * j]; xs2[2 * j + 1] = xs1[2 * j + 1];
+    xs3[2 * j] = xs1[2 * j]; xs3[2 * j + 1] = xs1[2 * j + 1];
+    return;
+#endif
     const int64_t base = (row_begin + tile * 32) * (int64_t)D;
     const bool ok = base + 4 * (int64_t)(j * 64 + lane) < total_e;
     split_pair(ok ? stage[j].x : 0.0f, ok ? stage[j].y : 0.0f, xs1[2 * j], xs2[2 * j], xs3[2 * j]);
@@ -262,6 +268,10 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
         return;
       }
       const int c = (i - 1) / 6, t = (i - 1) % 6;
+#ifdef PA_GLM_PROBE_NOGEMM1
+      if (t == 0) acc[pt][c] += yh_s[lane & 31];
+      return;
+#endif
       if (t == 0) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -282,6 +292,12 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
       const float* yp = yh_s + 8 * (r >> 2) + 4 * h + (r & 3);
       const f32x2v yh = *reinterpret_cast<const f32x2v*>(yp);
       const f32x2v l = {acc[pt][r], acc[pt][r + 1]};
+#ifdef PA_GLM_PROBE_NOELEM   // tools/probes/glm_variants: marginal cost of the element-wise math
+      ll2[pt] += l;
+      gb2[pt] += yh;
+      split_pair(l.x, l.y, g1[pt][i], g2[pt][i], g3[pt][i]);
+      return;
+#endif
       const f32x2v a = {__builtin_fabsf(l.x), __builtin_fabsf(l.y)};
       const f32x2v na = a * -1.44269504088896340736f;
       const f32x2v e = {__builtin_amdgcn_exp2f(na.x), __builtin_amdgcn_exp2f(na.y)};
@@ -296,6 +312,12 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
       const f32x2v ds = {__builtin_copysignf(dd.x, l.x), __builtin_copysignf(dd.y, l.y)};
       const f32x2v g = yh - ds;
       gb2[pt] += g;
+#ifdef PA_GLM_PROBE_NOSPLITG
+      g1[pt][i] = cvt_pk_bf16(g.x, g.y);
+      g2[pt][i] = g1[pt][i];
+      g3[pt][i] = g1[pt][i];
+      return;
+#endif
       split_pair(g.x, g.y, g1[pt][i], g2[pt][i], g3[pt][i]);
     };
     // B operand of GEMM2 for K half kh, feature tile dt: 8 rows n(8kh+j, h) of column d = 32dt+l31
@@ -317,7 +339,15 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     // i-th MFMA of GEMM2 for (pt, kh): feature tile dt = i / 6, piece product i % 6
     auto gemm2 = [&](int pt, int kh, int i) {
       const int dt = i / 6, t = i % 6;
+#ifdef PA_GLM_PROBE_NOGEMM2
+      if (t == 0) gwacc[pt][dt][kh] += __builtin_bit_cast(float, g1[pt][4 * kh] ^ g2[pt][4 * kh + 1] ^ g3[pt][4 * kh + 2]);
+      return;
+#endif
+#ifdef PA_GLM_PROBE_NOXB
+      if (t == 0 && kh == 0 && pt == 0) load_xb(kh, dt);
+#else
       if (t == 0) load_xb(kh, dt);
+#endif
       const uint32_t* gp = TA[t] == 0 ? g1[pt] : (TA[t] == 1 ? g2[pt] : g3[pt]);
       const bf16x8 ga = as_bf16x8(gp[4 * kh], gp[4 * kh + 1], gp[4 * kh + 2], gp[4 * kh + 3]);
       gwacc[pt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, xb[TB[t]], gwacc[pt][dt], 0, 0, 0);
