@@ -136,6 +136,77 @@ int pa_normal_rsample(int dtype, void* out, void* eps_out, pa_view2d loc, pa_vie
                       const uint64_t* offset_dev, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * ELBO assembly over many SMALL sites in one launch.
+ *
+ * The reference scores every sample site separately (Trace.compute_log_prob,
+ * trace_struct.py:248-288: log_prob, scale_and_mask, .sum() per site) and adds the sums up on the
+ * host side of autograd (trace_elbo.py:82-112).  For global latents these are tiny tensors: the
+ * cost is one launch per operation.  Here every small element-wise site of the model and guide
+ * traces (priors, guide densities) plus the already-reduced terms of the big sites (entries of
+ * kind PA_SITE_IDENTITY: log_prob(value) = value) are summed by ONE workgroup:
+ *     out_total = coef_all * sum_e coef_e * sum_{r,c} mask_e ? log_prob_e(value; p0, p1)[r,c] : 0
+ * (coef_e = sign in the ELBO times the site's scale), fp64 accumulation in a fixed order.
+ * The backward entry point produces, for every requested operand of every entry, the gradient
+ * ALREADY REDUCED to the operand's own broadcast shape: contiguous [rows or 1, cols or 1], a
+ * stride of 0 over a dimension of size > 1 meaning "summed over it" -- the autograd duals of
+ * expand + log_prob + scale_and_mask + sum in one launch (one workgroup per entry).
+ * Limits: n <= PA_MULTI_MAX_ENTRIES per call (chain calls with accumulate = 1), rows*cols <=
+ * PA_MULTI_MAX_ELEMS per entry; entries are host structs, copied into the kernel arguments.
+ * ---------------------------------------------------------------------------------- */
+#define PA_SITE_IDENTITY 100
+#define PA_MULTI_MAX_ENTRIES 16
+#define PA_MULTI_MAX_ELEMS 65536
+typedef struct {
+  int32_t dist;          /* PA_DIST_* or PA_SITE_IDENTITY */
+  int32_t need;          /* backward: bit0 = d_value, bit1 = d_p0, bit2 = d_p1 wanted */
+  int64_t rows, cols;
+  pa_view2d value, p0, p1, mask; /* mask: uint8, ptr NULL = none; p1.ptr NULL when unused */
+  double coef;
+  void* d_value;         /* backward outputs (NULL when not wanted) */
+  void* d_p0;
+  void* d_p1;
+} pa_site_entry;
+int pa_multi_log_prob_sum(int dtype, void* out_total, const pa_site_entry* entries, int n,
+                          double coef_all, int accumulate, pa_stream_t stream);
+/* g: device pointer to the upstream gradient of out_total (one element of `dtype`). */
+int pa_multi_log_prob_grad(int dtype, const void* g, const pa_site_entry* entries, int n,
+                           double coef_all, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mean-field Normal guide: all latent sites drawn in one launch (AutoNormal,
+ * pyro/infer/autoguide/guides.py:415-603: per site  scale = softplus(rho) (the
+ * softplus_positive constraint), z = Normal(loc, scale).rsample() under P vectorised particles).
+ *   eps_s[p,i] = Philox normal number p*n_s + i of the stream (seed, offset_s)   -- exactly the
+ *                draws of pa_normal_rsample called site by site with the same offsets
+ *   scale_s[i] = softplus(rho_s[i]),  z_s[p,i] = loc_s[i] + scale_s[i] * eps_s[p,i]
+ * Backward (one launch, one workgroup per site), given d_z_s[P,n_s] and d_scale_s[n_s] (the
+ * gradient w.r.t. the scale output used by the guide's own density; may be NULL) and d_loc_out_s:
+ *   d_loc_s[i] = sum_p d_z[p,i] + d_loc_out[i]
+ *   d_rho_s[i] = (sum_p d_z[p,i] eps[p,i] + d_scale[i]) * sigmoid(rho[i])
+ * ---------------------------------------------------------------------------------- */
+#define PA_MF_MAX_SITES 16
+typedef struct {
+  const void* loc;       /* [n] */
+  const void* rho;       /* [n] unconstrained scale */
+  void* z;               /* [P, n] out */
+  void* scale;           /* [n] out */
+  void* loc_out;         /* [n] out: copy of loc (the guide's density takes its loc from here, so
+                            that every gradient of loc arrives through ONE backward) */
+  void* eps;             /* [P, n] out (kept for the backward) */
+  int64_t n;
+  uint64_t offset;       /* Philox block offset of this site's draws */
+  const void* d_z;       /* backward inputs (each may be NULL = zero) / outputs */
+  const void* d_scale;
+  const void* d_loc_out;
+  void* d_loc;
+  void* d_rho;
+} pa_mf_site;
+int pa_meanfield_normal_sample(int dtype, const pa_mf_site* sites, int nsites, int64_t P,
+                               uint64_t seed, const uint64_t* offset_dev, pa_stream_t stream);
+int pa_meanfield_normal_sample_bwd(int dtype, const pa_mf_site* sites, int nsites, int64_t P,
+                                   pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused plated Bernoulli-logits GLM likelihood: forward AND gradient in ONE pass over X.
  * Replaces, for an observed site  obs ~ Bernoulli(logits = w @ X^T + b)  under
  * pyro.plate("data", N) with P vectorised particles (pyro/infer/elbo.py:186-216):
@@ -159,6 +230,11 @@ int pa_normal_rsample(int dtype, void* out, void* eps_out, pa_view2d loc, pa_vie
  *   1 exact f32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 fmaf chain per product sum.
  * ---------------------------------------------------------------------------------- */
 int pa_glm_set_variant(int variant);
+/* Chain rule of the two gradient outputs with the upstream gradient g[P] of ll[P] (the autograd
+ * dual of the fused site), one launch: dw[p, :] = g[p] * gw[p, :] (W floats per particle: D, or
+ * G*D for the grouped variant), db[p] = g[p] * gb[p].  dw / db may be NULL. */
+int pa_glm_chain(const float* g, const float* gw, const float* gb, int64_t P, int64_t W, float* dw,
+                 float* db, pa_stream_t stream);
 size_t pa_glm_bernoulli_workspace(int64_t N, int64_t D, int64_t P);
 int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, const float* b,
                              const uint8_t* mask, double scale, int64_t N, int64_t D, int64_t P,
@@ -295,7 +371,9 @@ int pa_lda_factor_fwd_bwd(int dtype, const int64_t* words, const void* log_theta
 /* ------------------------------------------------------------------------------------
  * Flat multi-tensor Adam / ClippedAdam step (pyro/optim/optim.py:117-155,
  * pyro/optim/clipped_adam.py:52-100). One launch over the flat parameter buffer;
- * `step_dev` is a device-resident step counter incremented by the kernel (graph safe).
+ * `step_dev` points to TWO device-resident int64: [0] the step counter, advanced by the kernel
+ * itself (the last workgroup to finish does it: one launch per step, graph safe), [1] the ticket
+ * counter of that hand-off, which must be 0 on entry and is 0 again on exit.
  * clipped = 0: torch.optim.Adam update; clipped = 1: ClippedAdam (element-wise gradient clamp
  * to [-clip_norm, clip_norm], lr *= lrd every step, its own denominator form). */
 int pa_adam_step(int dtype, void* param, void* grad, void* exp_avg, void* exp_avg_sq, int64_t n,

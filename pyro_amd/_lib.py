@@ -31,6 +31,26 @@ class View2D(Structure):
 
 NULL_VIEW = View2D(None, 0, 0)
 
+SITE_IDENTITY = 100
+MULTI_MAX_ENTRIES = 16
+MULTI_MAX_ELEMS = 65536
+MF_MAX_SITES = 16
+
+
+class SiteEntry(Structure):
+    """pa_site_entry (include/pyro_amd.h)."""
+    _fields_ = [("dist", c_int32), ("need", c_int32), ("rows", c_int64), ("cols", c_int64),
+                ("value", View2D), ("p0", View2D), ("p1", View2D), ("mask", View2D),
+                ("coef", c_double), ("d_value", c_void_p), ("d_p0", c_void_p), ("d_p1", c_void_p)]
+
+
+class MfSite(Structure):
+    """pa_mf_site (include/pyro_amd.h)."""
+    _fields_ = [("loc", c_void_p), ("rho", c_void_p), ("z", c_void_p), ("scale", c_void_p),
+                ("loc_out", c_void_p), ("eps", c_void_p), ("n", c_int64), ("offset", c_uint64),
+                ("d_z", c_void_p), ("d_scale", c_void_p), ("d_loc_out", c_void_p),
+                ("d_loc", c_void_p), ("d_rho", c_void_p)]
+
 
 class Unsupported(RuntimeError):
     """Raised when a fused kernel does not cover the requested shape (PA_ERR_UNSUPPORTED)."""
@@ -54,7 +74,16 @@ _SIGNATURES = {
                                       c_void_p]),
     "pa_normal_rsample": (c_int, [c_int, c_void_p, c_void_p, View2D, View2D, c_int64, c_int64,
                                   c_uint64, c_uint64, c_void_p, c_void_p]),
+    "pa_multi_log_prob_sum": (c_int, [c_int, c_void_p, POINTER(SiteEntry), c_int, c_double, c_int,
+                                      c_void_p]),
+    "pa_multi_log_prob_grad": (c_int, [c_int, c_void_p, POINTER(SiteEntry), c_int, c_double,
+                                       c_void_p]),
+    "pa_meanfield_normal_sample": (c_int, [c_int, POINTER(MfSite), c_int, c_int64, c_uint64,
+                                           c_void_p, c_void_p]),
+    "pa_meanfield_normal_sample_bwd": (c_int, [c_int, POINTER(MfSite), c_int, c_int64, c_void_p]),
     "pa_glm_set_variant": (c_int, [c_int]),
+    "pa_glm_chain": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                             c_void_p]),
     "pa_glm_bernoulli_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_glm_bernoulli_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,

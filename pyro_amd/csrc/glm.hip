@@ -280,18 +280,20 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
 }
 
 // out[j] = scale * sum_blocks partial[block][slot(j)], fp64 accumulation, fixed order.
-// Output order: gw[P,D] then ll[P] then gb[P].
+// Output order: gw[P,D] then ll[P] then gb[P].  One workgroup = FIN_OUT outputs x FIN_GROUPS
+// record groups (thread (j, s) sums records s, s + FIN_GROUPS, ...; the groups are then combined
+// through LDS in a fixed order): many small workgroups so that the ~4 MB of partial records are
+// pulled by the whole chip rather than by a few dozen CUs.
+constexpr int FIN_OUT = 8, FIN_GROUPS = 32;
 template <int DT, int PT>
-__global__ __launch_bounds__(1024) void glm_finalize_kernel(const float* __restrict__ part,
-                                                            int nblocks, int npass, int D, int P,
-                                                            double scale, float* __restrict__ ll,
-                                                            float* __restrict__ gw,
-                                                            float* __restrict__ gb) {
+__global__ __launch_bounds__(FIN_OUT * FIN_GROUPS) void glm_finalize_kernel(
+    const float* __restrict__ part, int nblocks, int npass, int D, int P, double scale,
+    float* __restrict__ ll, float* __restrict__ gw, float* __restrict__ gb) {
   constexpr int REC = glm_record_floats<DT, PT>();
-  __shared__ double sm[16][64];
-  const int jj = threadIdx.x & 63, s = threadIdx.x >> 6;
+  __shared__ double sm[FIN_GROUPS][FIN_OUT];
+  const int jj = threadIdx.x % FIN_OUT, s = threadIdx.x / FIN_OUT;
   const int64_t J = (int64_t)P * D + 2 * P;
-  const int64_t j = (int64_t)blockIdx.x * 64 + jj;
+  const int64_t j = (int64_t)blockIdx.x * FIN_OUT + jj;
   double acc = 0.0;
   if (j < J) {
     int p, slot;
@@ -310,18 +312,44 @@ __global__ __launch_bounds__(1024) void glm_finalize_kernel(const float* __restr
     }
     const int pass = p / (32 * PT);
     const float* base = part + (int64_t)pass * nblocks * REC + slot;
-    for (int blk = s; blk < nblocks; blk += 16) acc += (double)base[(int64_t)blk * REC];
+    float v[8];
+    int blk = s;
+    for (; blk + 7 * FIN_GROUPS < nblocks; blk += 8 * FIN_GROUPS) {   // 8 loads in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(blk + u * FIN_GROUPS) * REC];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; blk < nblocks; blk += FIN_GROUPS) acc += (double)base[(int64_t)blk * REC];
   }
   sm[s][jj] = acc;
   __syncthreads();
   if (s == 0 && j < J) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += sm[k][jj];
+    for (int k = 0; k < FIN_GROUPS; ++k) t += sm[k][jj];
     const float v = (float)(t * scale);
     if (j < (int64_t)P * D) gw[j] = v;
     else if (j < (int64_t)P * D + P) ll[j - (int64_t)P * D] = v;
     else gb[j - (int64_t)P * D - P] = v;
+  }
+}
+
+// Chain rule of the site's two gradient outputs with the upstream gradient g[P] of ll[P]:
+//   dw[p, :] = g[p] * gw[p, :],  db[p] = g[p] * gb[p]      (one launch instead of two products)
+__global__ __launch_bounds__(256) void glm_chain_kernel(const float* __restrict__ g,
+                                                        const float* __restrict__ gw,
+                                                        const float* __restrict__ gb, int64_t P,
+                                                        int64_t W, float* __restrict__ dw,
+                                                        float* __restrict__ db) {
+  const int64_t n = P * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + P;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n) {
+      if (dw) dw[i] = g[i / W] * gw[i];
+    } else if (db) {
+      db[i - n] = g[i - n] * gb[i - n];
+    }
   }
 }
 
@@ -383,8 +411,9 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   int rc = check_launch("glm_bernoulli_kernel");
   if (rc != PA_OK) return rc;
   const int64_t J = (int64_t)P * D + 2 * P;
-  hipLaunchKernelGGL((glm_finalize_kernel<DT, PT>), dim3((unsigned)((J + 63) / 64)), dim3(1024), 0,
-                     s, part, pl.nblocks, pl.npass, D, P, scale, ll, gw, gb);
+  hipLaunchKernelGGL((glm_finalize_kernel<DT, PT>), dim3((unsigned)((J + FIN_OUT - 1) / FIN_OUT)),
+                     dim3(FIN_OUT * FIN_GROUPS), 0, s, part, pl.nblocks, pl.npass, D, P, scale, ll,
+                     gw, gb);
   return check_launch("glm_finalize_kernel");
 }
 
@@ -485,6 +514,19 @@ static void glm_tiles_of(int64_t D, int64_t P, int* DT, int* PT) {
 }  // namespace pa
 
 extern "C" {
+
+int pa_glm_chain(const float* g, const float* gw, const float* gb, int64_t P, int64_t W, float* dw,
+                 float* db, pa_stream_t stream) {
+  PA_REQUIRE(P >= 0 && W >= 0, "glm_chain: bad shape P=%lld W=%lld", (long long)P, (long long)W);
+  if (P == 0) return PA_OK;
+  PA_REQUIRE(g && (!dw || gw) && (!db || gb), "glm_chain: NULL input");
+  int64_t grid = (P * W + P + 255) / 256;
+  const int64_t cap = (int64_t)pa::cu_count() * 8;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(pa::glm_chain_kernel, dim3((unsigned)grid), dim3(256), 0, pa::as_stream(stream),
+                     g, gw, gb, P, W, dw, db);
+  return pa::check_launch("glm_chain_kernel");
+}
 
 int pa_glm_set_variant(int variant) {
   PA_REQUIRE(variant == 0 || variant == 1, "glm_set_variant: expected 0 (bf16x3) or 1 (exact f32)");

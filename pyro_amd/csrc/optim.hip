@@ -13,9 +13,12 @@ __global__ __launch_bounds__(256) void adam_kernel(T* __restrict__ p, T* __restr
                                                    T* __restrict__ m, T* __restrict__ v, int64_t n,
                                                    double lr, double b1, double b2, double eps,
                                                    double wd, double clip, double lrd, int clipped,
-                                                   const int64_t* __restrict__ step_dev,
+                                                   int64_t* __restrict__ step_dev,
                                                    int zero_grad) {
-  const int64_t step = *step_dev + 1;  // the counter is bumped by adam_bump_kernel afterwards
+  // step_dev[0] = steps taken so far, step_dev[1] = workgroups of THIS launch that have finished.
+  // Every workgroup reads the step count when it starts; the last one to finish (all others have
+  // read it by then) advances it and resets the ticket: no separate "bump" launch.
+  const int64_t step = step_dev[0] + 1;
   const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   // ClippedAdam multiplies lr by lrd before every step (clipped_adam.py:63)
   const double lr_t = clipped ? lr * pow(lrd, (double)step) : lr;
@@ -41,9 +44,18 @@ __global__ __launch_bounds__(256) void adam_kernel(T* __restrict__ p, T* __restr
     p[i] = p[i] - upd;
     if (zero_grad) g[i] = T(0);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long ticket =
+        atomicAdd(reinterpret_cast<unsigned long long*>(step_dev + 1), 1ull);
+    if (ticket == (unsigned long long)gridDim.x - 1) {
+      step_dev[1] = 0;
+      step_dev[0] = step;
+    }
+  }
 }
 
-__global__ void adam_bump_kernel(int64_t* step_dev) { *step_dev += 1; }
+__global__ void adam_bump_kernel(int64_t* step_dev) { step_dev[0] += 1; }
 
 }  // namespace pa
 
@@ -72,10 +84,9 @@ int pa_adam_step(int dtype, void* param, void* grad, void* exp_avg, void* exp_av
                          (double*)param, (double*)grad, (double*)exp_avg, (double*)exp_avg_sq, n,
                          lr, beta1, beta2, eps, weight_decay, clip_norm, lrd, clipped, step_dev,
                          zero_grad);
-    int rc = pa::check_launch("adam_kernel");
-    if (rc != PA_OK) return rc;
+    return pa::check_launch("adam_kernel");
   }
-  hipLaunchKernelGGL(pa::adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  hipLaunchKernelGGL(pa::adam_bump_kernel, dim3(1), dim3(1), 0, s, step_dev);   // n == 0
   return pa::check_launch("adam_bump_kernel");
 }
 

@@ -96,3 +96,9 @@ class Independent(torch.distributions.Independent, TorchDistributionMixin):
             mask = mask.reshape(mask.shape + (1,) * self.reinterpreted_batch_ndims)
         f = getattr(self.base_dist, "fused_log_prob_sum", None)
         return None if f is None else f(value, scale, mask)
+
+    def fused_site_entry(self, value, scale=1.0, mask=None):
+        if isinstance(mask, torch.Tensor):
+            mask = mask.reshape(mask.shape + (1,) * self.reinterpreted_batch_ndims)
+        f = getattr(self.base_dist, "fused_site_entry", None)
+        return None if f is None else f(value, scale, mask)

@@ -162,6 +162,16 @@ class MaskedDistribution(TorchDistribution):
         m = self._mask if mask is None else (self._mask & mask)
         return self.base_dist.fused_log_prob_sum(value, scale, m)
 
+    def fused_site_entry(self, value, scale=1.0, mask=None):
+        f = getattr(self.base_dist, "fused_site_entry", None)
+        if f is None or self._mask is False:
+            return None
+        if self._mask is True:
+            return f(value, scale, mask)
+        if self.event_dim != 0:
+            return None
+        return f(value, scale, self._mask if mask is None else (self._mask & mask))
+
 
 class Delta(TorchDistribution):
     """Point mass at ``v`` with log-density ``log_density`` (reference: delta.py:73-77)."""
@@ -179,8 +189,8 @@ class Delta(TorchDistribution):
         # that scoring the site costs no kernel at all
         self._zero_density = isinstance(log_density, (int, float)) and log_density == 0
         if isinstance(log_density, (int, float)):
-            log_density = torch.full(batch_shape, float(log_density), dtype=v.dtype,
-                                     device=v.device)
+            from .families import device_constant   # cached 0-dim constant, expanded: no kernel
+            log_density = device_constant(log_density, v.dtype, v.device).expand(batch_shape)
         elif log_density.shape != batch_shape:
             raise ValueError("Expected log_density.shape = {}, actual {}".format(
                 log_density.shape, batch_shape))

@@ -17,17 +17,30 @@ def _maskable(mask):
     return mask is None or isinstance(mask, torch.Tensor)
 
 
+_CONSTANTS = {}
+
+
+def device_constant(value, dtype, device):
+    """A cached read-only 0-dim tensor holding ``value`` on ``device``: created once by a fill
+    kernel, then reused by every distribution object that is built from a Python number (one fill
+    launch per constant per step otherwise; and a host-to-device copy -- a synchronisation that is
+    not permitted while a hipGraph is being captured -- if built with torch.tensor)."""
+    key = (float(value), dtype, device)
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = torch.full((), float(value), dtype=dtype, device=device)
+        _CONSTANTS[key] = t
+    return t
+
+
 def _on_device(*values):
-    """Python-number parameters -> 0-dim tensors created ON the device of the tensor parameters by a
-    fill kernel.  torch.distributions would build them with torch.tensor(number, device=...), a
-    host-to-device copy from pageable memory: a synchronisation per distribution object, and an
-    operation that is not permitted while a hipGraph is being captured."""
+    """Python-number parameters -> cached 0-dim tensors ON the device of the tensor parameters."""
     proto = next((v for v in values if isinstance(v, torch.Tensor)), None)
     if proto is None:
         return values
+    dtype = proto.dtype if proto.is_floating_point() else torch.get_default_dtype()
     return tuple(v if isinstance(v, torch.Tensor) or v is None
-                 else torch.full((), float(v), dtype=proto.dtype if proto.is_floating_point()
-                                 else torch.get_default_dtype(), device=proto.device)
+                 else device_constant(v, dtype, proto.device)
                  for v in values)
 
 
@@ -53,9 +66,29 @@ class _FusedElementwise:
         p0, p1 = self._params()
         return fused.log_prob_sum(self._dist_id, value, p0, p1, mask, scale)
 
+    def fused_site_entry(self, value, scale=1.0, mask=None):
+        """(dist_id, value, p0, p1, mask, scale) for fused.SiteBatch, which sums many small sites
+        in one launch; None if the site cannot be described that way."""
+        if not _maskable(mask) or isinstance(scale, torch.Tensor):
+            return None
+        if self._validate_args:
+            self._validate_sample(value)
+        # the parameters as given BEFORE any .expand(): stride-0 expanded views would make the
+        # gradient land on the expanded shape and be reduced by a separate autograd node
+        p0, p1 = getattr(self, "_base_params", None) or self._params()
+        return self._dist_id, value, p0, p1, mask, scale
+
+    def expand(self, batch_shape, _instance=None):
+        new = super().expand(batch_shape, _instance)
+        new._base_params = getattr(self, "_base_params", None) or self._params()
+        return new
+
 
 class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMixin):
     _dist_id = _lib.DIST_NORMAL
+    # a draw made ahead of time for this very distribution object (fused.meanfield_sample draws all
+    # sites of a mean-field guide in one launch); handed out by rsample() when the shape matches
+    _presampled = None
 
     def __init__(self, loc, scale, validate_args=None):
         loc, scale = _on_device(loc, scale)
@@ -66,13 +99,22 @@ class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMix
         new = type(self)(self.loc.expand(batch_shape), self.scale.expand(batch_shape),
                          validate_args=False)
         new._validate_args = self._validate_args
+        new._base_params = getattr(self, "_base_params", None) or (self.loc, self.scale)
+        new._presampled = self._presampled
         return new
 
     def _params(self):
         return self.loc, self.scale
 
     def rsample(self, sample_shape=torch.Size()):
-        return fused.normal_rsample(self.loc, self.scale, self._extended_shape(sample_shape))
+        shape = self._extended_shape(sample_shape)
+        pre = self._presampled
+        if pre is not None:
+            if pre.shape != shape:
+                raise ValueError("pre-drawn value of shape {} does not fit the requested {}".format(
+                    tuple(pre.shape), tuple(shape)))
+            return pre
+        return fused.normal_rsample(self.loc, self.scale, shape)
 
     def sample(self, sample_shape=torch.Size()):
         with torch.no_grad():
@@ -91,6 +133,7 @@ class LogNormal(_FusedElementwise, torch.distributions.LogNormal, TorchDistribut
         new = type(self)(self.loc.expand(batch_shape), self.scale.expand(batch_shape),
                          validate_args=False)
         new._validate_args = self._validate_args
+        new._base_params = getattr(self, "_base_params", None) or (self.loc, self.scale)
         return new
 
     def _params(self):

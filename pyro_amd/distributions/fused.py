@@ -162,6 +162,57 @@ class _NormalRsample(torch.autograd.Function):
         return d_loc, d_scale, None, None, None, None
 
 
+class _MeanFieldSample(torch.autograd.Function):
+    """All mean-field Normal sites of a guide: per site  scale = softplus(rho),
+    z = loc + scale * eps  for P vectorised particles, ONE launch forward
+    (pa_meanfield_normal_sample) and ONE backward (pa_meanfield_normal_sample_bwd).  Inputs are the
+    unconstrained parameter leaves (loc_0, rho_0, loc_1, rho_1, ...); outputs per site
+    (z [P, n], scale [n], loc_out [n])."""
+
+    @staticmethod
+    def forward(ctx, P, seed, offsets, offset_dev, *params):
+        locs = [p.detach().reshape(-1) for p in params[0::2]]
+        rhos = [p.detach().reshape(-1) for p in params[1::2]]
+        zs, scales, louts, epss = kernels.meanfield_normal_sample(locs, rhos, P, seed, offsets,
+                                                                  offset_dev)
+        ctx.P, ctx.nsites = P, len(locs)
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(*rhos, *epss)
+        out = []
+        for z, sc, lo in zip(zs, scales, louts):
+            out += [z, sc, lo]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        k = ctx.nsites
+        saved = ctx.saved_tensors
+        rhos, epss = saved[:k], saved[k:]
+        d_locs, d_rhos = kernels.meanfield_normal_sample_bwd(
+            rhos, epss, grads[0::3], grads[1::3], grads[2::3], ctx.P)
+        out = []
+        for i in range(k):
+            out += [d_locs[i].reshape(ctx.shapes[2 * i]), d_rhos[i].reshape(ctx.shapes[2 * i + 1])]
+        return (None, None, None, None) + tuple(out)
+
+
+def meanfield_sample(locs, rhos, P):
+    """Draw every site of a mean-field Normal guide at once.  locs / rhos: the unconstrained
+    parameter leaves per site (rho -> scale through softplus).  The Philox blocks are reserved
+    site by site, exactly as a sequence of normal_rsample calls would, so the draws are the ones
+    the unfused path produces.  Returns per site (z [P, n], scale [n], loc_out [n])."""
+    from .. import rng
+    seed, offsets, off_dev = None, [], None
+    for loc in locs:
+        seed, off, off_dev = rng.reserve(P * loc.numel(), loc.dtype)
+        offsets.append(off)
+    params = []
+    for loc, rho in zip(locs, rhos):
+        params += [loc, rho]
+    out = _MeanFieldSample.apply(P, seed, tuple(offsets), off_dev, *params)
+    return [tuple(out[3 * i:3 * i + 3]) for i in range(len(locs))]
+
+
 def normal_rsample(loc, scale, shape):
     """Reparameterised Normal draw of ``shape`` (>= broadcast of loc/scale shapes) from the
     process-wide Philox stream."""
@@ -175,6 +226,129 @@ def normal_rsample(loc, scale, shape):
     n = shape.numel()
     seed, off, off_dev = rng.reserve(n, loc.dtype)
     return _NormalRsample.apply(loc, scale, shape, seed, off, off_dev)
+
+
+# ---- many small sites in one launch ---------------------------------------------------------------
+def _entry_frame(dist_id, value, p0, p1, mask):
+    """2-D strided views of one entry's operands over their broadcast frame, or None when the entry
+    cannot go through the multi-site kernel (too large, operands not expressible as strided views,
+    mixed dtypes)."""
+    from .. import _lib
+    ops = [t for t in (value, p0, p1) if t is not None]
+    if any(not t.is_floating_point() or t.dtype != value.dtype for t in ops):
+        return None
+    shapes = [t.shape for t in ops]
+    if mask is not None:
+        shapes.append(mask.shape)
+    shape = torch.broadcast_shapes(*shapes)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if n > _lib.MULTI_MAX_ELEMS:
+        return None
+    rows, cols, (v2, a2, b2, m2) = frame([value, p0, p1, mask], shape)
+    for t, t2 in ((value, v2), (p0, a2), (p1, b2)):
+        if t is None or not t.requires_grad:
+            continue
+        # the reduced gradient [rows or 1, cols or 1] must be reshapeable to the operand itself
+        rr = 1 if (t2.shape[0] == 1 or t2.stride(0) == 0) and rows > 1 else rows
+        cc = 1 if (t2.shape[1] == 1 or t2.stride(1) == 0) and cols > 1 else cols
+        if rr * cc != t.numel() or t2.untyped_storage().data_ptr() != t.untyped_storage().data_ptr():
+            return None
+    return rows, cols, v2, a2, b2, m2
+
+
+class _MultiLogProbSum(torch.autograd.Function):
+    """total = coef_all * sum_e coef_e * sum(mask_e ? log_prob_e(value_e; p0_e, p1_e) : 0) over a
+    table of small entries: ONE launch forward (pa_multi_log_prob_sum), ONE launch backward that
+    writes every operand gradient already reduced to the operand's shape
+    (pa_multi_log_prob_grad)."""
+
+    @staticmethod
+    def forward(ctx, meta, coef_all, *tensors):
+        entries = _MultiLogProbSum._entries(meta, tensors, None)
+        proto = tensors[0]
+        ctx.meta, ctx.coef_all = meta, coef_all
+        ctx.save_for_backward(*tensors)
+        return kernels.multi_log_prob_sum(entries, coef_all, proto.dtype, proto.device)
+
+    @staticmethod
+    def _entries(meta, tensors, needs):
+        entries, i = [], 0
+        for dist_id, nops, mask, coef in meta:
+            ops = list(tensors[i:i + nops]) + [None] * (3 - nops)
+            fr = _entry_frame(dist_id, ops[0], ops[1], ops[2], mask)
+            assert fr is not None
+            rows, cols, v2, a2, b2, m2 = fr
+            e = dict(dist=dist_id, rows=rows, cols=cols, value=v2, p0=a2, p1=b2, mask=m2, coef=coef)
+            if needs is not None:
+                e["need"] = tuple(list(needs[i:i + nops]) + [False] * (3 - nops))
+            entries.append(e)
+            i += nops
+        return entries
+
+    @staticmethod
+    def backward(ctx, g):
+        tensors = ctx.saved_tensors
+        needs = ctx.needs_input_grad[2:]
+        entries = _MultiLogProbSum._entries(ctx.meta, tensors, needs)
+        proto = tensors[0]
+        grads = kernels.multi_log_prob_grad(g, entries, ctx.coef_all, proto.dtype, proto.device)
+        out, i = [], 0
+        for (dist_id, nops, mask, coef), gs in zip(ctx.meta, grads):
+            for j in range(nops):
+                t = tensors[i + j]
+                out.append(None if gs[j] is None else gs[j].reshape(t.shape))
+            i += nops
+        return (None, None) + tuple(out)
+
+
+class SiteBatch:
+    """Collects the small element-wise sites (and already-reduced terms) of an ELBO estimate and
+    evaluates their signed sum with one fused launch."""
+
+    def __init__(self):
+        self.meta, self.tensors, self.const = [], [], 0.0
+
+    def add_site(self, dist_id, value, p0, p1, mask, scale, sign):
+        """True if the site was taken into the batch."""
+        if isinstance(scale, torch.Tensor) or not (mask is None or isinstance(mask, torch.Tensor)):
+            return False
+        if mask is not None and mask.dtype != torch.bool:
+            mask = mask.bool()
+        if self.tensors and (value.dtype != self.tensors[0].dtype
+                             or value.device != self.tensors[0].device):
+            return False
+        if _entry_frame(dist_id, value, p0, p1, mask) is None:
+            return False
+        ops = [t for t in (value, p0, p1) if t is not None]
+        self.meta.append((dist_id, len(ops), mask, float(sign) * float(scale)))
+        self.tensors.extend(ops)
+        return True
+
+    def add_term(self, x, sign):
+        """An already computed term (tensor of any small shape, or a Python number): sign * x.sum()."""
+        from .. import _lib
+        if not isinstance(x, torch.Tensor):
+            self.const += float(sign) * float(x)
+            return True
+        if self.tensors and (x.dtype != self.tensors[0].dtype or x.device != self.tensors[0].device):
+            return False
+        if not x.is_floating_point() or _entry_frame(_lib.SITE_IDENTITY, x, None, None, None) is None:
+            return False
+        self.meta.append((_lib.SITE_IDENTITY, 1, None, float(sign)))
+        self.tensors.append(x)
+        return True
+
+    def total(self, coef_all=1.0):
+        """coef_all * (sum of everything added); a 0-dim tensor (or a float if nothing but
+        constants was added)."""
+        if not self.tensors:
+            return coef_all * self.const
+        out = _MultiLogProbSum.apply(tuple(self.meta), float(coef_all), *self.tensors)
+        if self.const != 0.0:
+            out = out + coef_all * self.const
+        return out
 
 
 def log_prob(dist_id, value, p0, p1=None):
@@ -201,8 +375,8 @@ class _GlmBernoulliSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         gw, gb = ctx.saved_tensors
-        dw = g[:, None] * gw if ctx.needs_input_grad[2] else None
-        db = g * gb if (ctx.has_b and ctx.needs_input_grad[3]) else None
+        dw, db = kernels.glm_chain(g, gw, gb, ctx.needs_input_grad[2],
+                                   ctx.has_b and ctx.needs_input_grad[3])
         return None, None, dw, db, None, None
 
 
@@ -225,8 +399,8 @@ class _GlmBernoulliGroupedSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         gw, gb = ctx.saved_tensors
-        dw = g[:, None, None] * gw if ctx.needs_input_grad[2] else None
-        db = g * gb if (ctx.has_b and ctx.needs_input_grad[3]) else None
+        dw, db = kernels.glm_chain(g, gw, gb, ctx.needs_input_grad[2],
+                                   ctx.has_b and ctx.needs_input_grad[3])
         return None, None, dw, db, None, None, None
 
 

@@ -138,10 +138,74 @@ class AutoNormal(AutoGuide):
                       event_dim=event_dim)
         return loc, scale
 
+    def _fused_draw(self):
+        """All latent sites drawn by ONE launch (distributions.fused.meanfield_sample) instead of a
+        softplus + rsample chain per site; returns {name: Normal with the draw attached} or None
+        when the fused form does not apply (parameters not on the device, a replaced eps source,
+        subsampled plates, outer plates interleaved with a site's own dims, a guide prefix whose
+        scale constraint is not the softplus one)."""
+        from ... import kernels, rng
+        from ...distributions import fused
+        from ...poutine.runtime import _PYRO_STACK
+        from ...primitives import param_unconstrained
+
+        if self.scale_constraint is not softplus_positive or rng.normal is not rng._default_normal:
+            return None
+        names = [name for name, _ in self._latent_sites()]
+        if not names:
+            return None
+        own = set()
+        for name, site in self._latent_sites():
+            for frame in site["cond_indep_stack"]:
+                if getattr(frame, "full_size", frame.size) != frame.size:
+                    return None                       # subsampled plate: per-site path
+                own.add(frame.name)
+        outer = [(m.dim, m.size) for m in _PYRO_STACK
+                 if isinstance(m, plate) and m._vectorized is True and m.name not in own]
+        if any(m.size != m.subsample_size for m in _PYRO_STACK
+               if isinstance(m, plate) and m._vectorized is True and m.name not in own):
+            return None
+        locs, rhos = [], []
+        for name in names:
+            init_loc, init_scale = self._inits[name]
+            ed = self._event_dims[name]
+            loc = param_unconstrained("{}.locs.{}".format(self.prefix, name), init_loc,
+                                      constraints.real, event_dim=ed)
+            rho = param_unconstrained("{}.scales.{}".format(self.prefix, name), init_scale,
+                                      self.scale_constraint, event_dim=ed)
+            if not (loc.is_cuda or kernels.HOST_TEST_BACKEND) or loc.dtype != rho.dtype \
+                    or loc.dtype not in (torch.float32, torch.float64) \
+                    or not loc.is_contiguous() or not rho.is_contiguous():
+                return None
+            # every outer (particle) plate must sit to the left of the site's own batch dims
+            batch_rank = loc.dim() - ed
+            if any(-d <= batch_rank for d, _ in outer):
+                return None
+            locs.append(loc)
+            rhos.append(rho)
+        if any(l.dtype != locs[0].dtype or l.device != locs[0].device for l in locs):
+            return None
+        P = 1
+        for _, size in outer:
+            P *= size
+        drawn = fused.meanfield_sample(locs, rhos, P)
+        out = {}
+        for name, loc, (z, scale, loc_out) in zip(names, locs, drawn):
+            ed = self._event_dims[name]
+            batch_rank = loc.dim() - ed
+            lead = [1] * (max([-d for d, _ in outer], default=batch_rank) - batch_rank)
+            for d, size in outer:
+                lead[len(lead) + batch_rank + d] = size
+            fn = dist.Normal(loc_out.reshape(loc.shape), scale.reshape(loc.shape))
+            fn._presampled = z.reshape(tuple(lead) + tuple(loc.shape))
+            out[name] = fn
+        return out
+
     def forward(self, *args, **kwargs):
         if self.prototype_trace is None:
             self._setup_prototype(*args, **kwargs)
         plates = self._create_plates(*args, **kwargs)
+        fused_fns = self._fused_draw()
         result = {}
         for name, site in self._latent_sites():
             transform = biject_to(site["fn"].support)
@@ -149,10 +213,13 @@ class AutoNormal(AutoGuide):
                 for frame in site["cond_indep_stack"]:
                     if frame.vectorized:
                         stack.enter_context(plates[frame.name])
-                site_loc, site_scale = self._get_loc_and_scale(name)
+                if fused_fns is not None:
+                    base_fn = fused_fns[name]
+                else:
+                    site_loc, site_scale = self._get_loc_and_scale(name)
+                    base_fn = dist.Normal(site_loc, site_scale)
                 unconstrained_latent = sample(
-                    name + "_unconstrained",
-                    dist.Normal(site_loc, site_scale).to_event(self._event_dims[name]),
+                    name + "_unconstrained", base_fn.to_event(self._event_dims[name]),
                     infer={"is_auxiliary": True})
                 value = transform(unconstrained_latent)
                 if poutine.get_mask() is False or _is_identity(transform):

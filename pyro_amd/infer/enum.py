@@ -19,7 +19,9 @@ def get_importance_trace(graph_type, max_plate_nesting, model, guide, args, kwar
         check_model_guide_match(model_trace, guide_trace, max_plate_nesting)
     guide_trace = prune_subsample_sites(guide_trace)
     model_trace = prune_subsample_sites(model_trace)
-    if fused_sums:
+    if fused_sums == "defer":
+        pass        # the caller batches the per-site sums (Trace.collect_log_prob_sums)
+    elif fused_sums:
         model_trace.compute_log_prob_sums()
     else:
         model_trace.compute_log_prob()

@@ -137,7 +137,7 @@ class SVI:
                             if not getattr(self.optim, "zeroes_grads", False):
                                 zero_grads(params)
                         cap.finish()
-                        loss = loss.detach().clone() if isinstance(loss, torch.Tensor) else \
+                        loss = loss.detach() if isinstance(loss, torch.Tensor) else \
                             torch.tensor(float(loss), device=device)
                 if split:
                     # the gradient all-reduce is NOT captured: graph 1 = loss + backward, then an

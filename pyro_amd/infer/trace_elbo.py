@@ -34,6 +34,18 @@ def _compute_log_r(model_trace, guide_trace):
 
 
 _SIGN_CACHE = {}
+_UNIT_GRADS = {}
+
+
+def _unit_grad(x):
+    """Cached 0-dim one used as the root gradient of backward() (autograd would launch a fill
+    kernel for it on every step)."""
+    key = (x.dtype, x.device)
+    g = _UNIT_GRADS.get(key)
+    if g is None:
+        g = torch.ones((), dtype=x.dtype, device=x.device)
+        _UNIT_GRADS[key] = g
+    return g
 
 
 def _signed_sum(terms, signs):
@@ -57,11 +69,11 @@ class Trace_ELBO(ELBO):
         return True
 
     def _get_trace(self, model, guide, args, kwargs):
-        # fused sums for the model always; guide handled after inspecting reparameterisation
+        # nothing is scored yet: the fully-reparameterised case batches all per-site sums into one
+        # launch (see _batched_total), the general case takes the un-reduced path of the reference
         model_trace, guide_trace = get_importance_trace("flat", self.max_plate_nesting, model,
-                                                        guide, args, kwargs, fused_sums=True)
+                                                        guide, args, kwargs, fused_sums="defer")
         if self._guide_is_reparameterized(guide_trace):
-            guide_trace.compute_log_prob_sums()
             guide_trace._fully_reparam = True
         else:
             model_trace.compute_log_prob()
@@ -69,29 +81,39 @@ class Trace_ELBO(ELBO):
             guide_trace._fully_reparam = False
         return model_trace, guide_trace
 
+    @staticmethod
+    def _batched_total(model_trace, guide_trace, coef=1.0):
+        """coef * (sum of model log_prob_sums - sum of guide log_prob_sums) as a 0-dim device
+        tensor (or a float if no site produced a tensor): every small site and the reduced terms of
+        the large ones in ONE fused launch, forward and backward (distributions.fused.SiteBatch)."""
+        from ..distributions.fused import SiteBatch
+        from ..poutine import settings
+
+        batch = SiteBatch()
+        left = model_trace.collect_log_prob_sums(batch, 1.0)
+        left += guide_trace.collect_log_prob_sums(batch, -1.0)
+        total = batch.total(coef)
+        for sign, term in left:
+            total = total + (coef * sign) * term
+        if settings.validation_enabled() and isinstance(total, torch.Tensor) \
+                and not bool(torch.isfinite(total.detach())):
+            # name the offending site(s) the way the reference does (trace_struct.py:279-286)
+            with torch.no_grad():
+                model_trace.compute_log_prob_sums()
+                guide_trace.compute_log_prob_sums()
+        return total
+
     # ---- per-particle (or per vectorised batch of particles) terms ---------------------------
     def _surrogate_and_elbo(self, model_trace, guide_trace):
         """Returns (elbo tensor, surrogate elbo tensor), both 0-dim on the device."""
         if getattr(guide_trace, "_fully_reparam", False):
             # every term enters elbo and surrogate alike (entropy_term == log_prob for
-            # reparameterised sites, distribution.py:98-125): sum_model - sum_guide assembled with
-            # ONE stack + ONE signed reduction instead of two accumulations per site
-            terms, signs, const = [], [], 0.0
-            for trace, sign in ((model_trace, 1.0), (guide_trace, -1.0)):
-                for site in trace.nodes.values():
-                    if site["type"] == "sample":
-                        x = site["log_prob_sum"]
-                        if isinstance(x, torch.Tensor):
-                            terms.append(x)
-                            signs.append(sign)
-                        else:
-                            const += sign * x
-            if not terms:
-                return const, const
-            total = _signed_sum(terms, signs)
-            if const != 0.0:
-                total = total + const
+            # reparameterised sites, distribution.py:98-125)
+            total = self._batched_total(model_trace, guide_trace)
+            if not isinstance(total, torch.Tensor):
+                return total, total
             return total.detach(), total
+        model_trace.compute_log_prob_sums()
         elbo = 0.0
         surrogate = 0.0
         for site in model_trace.nodes.values():
@@ -147,16 +169,20 @@ class Trace_ELBO(ELBO):
         loss = None
         c = -1.0 / self.num_particles
         for model_trace, guide_trace in self._get_traces(model, guide, args, kwargs):
-            e, s = self._surrogate_and_elbo(model_trace, guide_trace)
             trainable = any(site["type"] == "param" for trace in (model_trace, guide_trace)
                             for site in trace.nodes.values())
-            if isinstance(s, torch.Tensor) and getattr(guide_trace, "_fully_reparam", False):
-                sl = s * c                      # surrogate loss == loss value in this case
-                term = sl.detach()
+            if getattr(guide_trace, "_fully_reparam", False):
+                # surrogate loss == loss value; the -1/num_particles factor rides in the kernel
+                sl = self._batched_total(model_trace, guide_trace, coef=c)
+                if not isinstance(sl, torch.Tensor):
+                    term, sl = sl, None
+                else:
+                    term = sl.detach()
             else:
+                e, s = self._surrogate_and_elbo(model_trace, guide_trace)
                 sl = s * c if isinstance(s, torch.Tensor) else None
                 term = e * c
             loss = term if loss is None else loss + term
             if trainable and sl is not None and sl.requires_grad:
-                sl.backward(retain_graph=self.retain_graph)
+                sl.backward(_unit_grad(sl), retain_graph=self.retain_graph)
         return 0.0 if loss is None else loss

@@ -14,6 +14,10 @@ from ._lib import NULL_VIEW, Unsupported, View2D, check  # noqa: F401
 _DTYPES = {torch.float32: _lib.PA_F32, torch.float64: _lib.PA_F64}
 
 
+# True only while tests/oracle_backend.py is installed (host-logic tests on a machine without a GPU)
+HOST_TEST_BACKEND = False
+
+
 def _require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -171,6 +175,121 @@ def normal_rsample(loc, scale, rows, cols, seed, offset, want_eps=True, offset_d
 
 
 # ------------------------------------------------------------------------------------------
+# many small sites in one launch (ELBO assembly, mean-field Normal guide)
+# ------------------------------------------------------------------------------------------
+
+def _reduced_shape(view, rows, cols):
+    """Shape [rows or 1, cols or 1] of the gradient of an operand described by ``view``."""
+    return (1 if (view.stride_row == 0 and rows > 1) else rows,
+            1 if (view.stride_col == 0 and cols > 1) else cols)
+
+
+def multi_log_prob_sum(entries, coef_all, dtype, device):
+    """entries: list of dicts {dist, rows, cols, value, p0, p1, mask (2-D strided tensors or
+    None), coef}.  Returns the 0-dim total  coef_all * sum_e coef_e * sum(masked log_prob_e)."""
+    lib = _lib.load()
+    out = torch.empty((), dtype=dtype, device=device)
+    n = len(entries)
+    for lo in range(0, max(n, 1), _lib.MULTI_MAX_ENTRIES):
+        chunk = entries[lo:lo + _lib.MULTI_MAX_ENTRIES]
+        arr = (_lib.SiteEntry * max(len(chunk), 1))()
+        for k, e in enumerate(chunk):
+            rows, cols = e["rows"], e["cols"]
+            _require_gpu(e["value"], e["p0"], e["p1"], e["mask"])
+            arr[k] = _lib.SiteEntry(e["dist"], 0, rows, cols, _view(e["value"], rows, cols),
+                                    _view(e["p0"], rows, cols), _view(e["p1"], rows, cols),
+                                    _view(e["mask"], rows, cols), float(e["coef"]), None, None, None)
+        check(lib.pa_multi_log_prob_sum(_DTYPES[dtype], _ptr(out), arr, len(chunk), float(coef_all),
+                                        1 if lo > 0 else 0, _stream()))
+    return out
+
+
+def multi_log_prob_grad(g, entries, coef_all, dtype, device):
+    """Backward of multi_log_prob_sum: ``entries`` as above plus ``need`` = (bool, bool, bool).
+    Returns per entry a tuple (d_value, d_p0, d_p1) of tensors already reduced to the operand's
+    own 2-D broadcast shape [rows or 1, cols or 1] (None where not needed)."""
+    lib = _lib.load()
+    _require_gpu(g)
+    assert g.numel() == 1
+    g = g.reshape(()).contiguous()
+    outs = []
+    for lo in range(0, len(entries), _lib.MULTI_MAX_ENTRIES):
+        chunk = entries[lo:lo + _lib.MULTI_MAX_ENTRIES]
+        arr = (_lib.SiteEntry * len(chunk))()
+        for k, e in enumerate(chunk):
+            rows, cols = e["rows"], e["cols"]
+            views = [_view(e["value"], rows, cols), _view(e["p0"], rows, cols),
+                     _view(e["p1"], rows, cols)]
+            grads, need_bits = [], 0
+            for j, (need, src) in enumerate(zip(e["need"], (e["value"], e["p0"], e["p1"]))):
+                if need and src is not None:
+                    grads.append(torch.empty(_reduced_shape(views[j], rows, cols), dtype=dtype,
+                                             device=device))
+                    need_bits |= 1 << j
+                else:
+                    grads.append(None)
+            arr[k] = _lib.SiteEntry(e["dist"], need_bits, rows, cols, views[0], views[1], views[2],
+                                    _view(e["mask"], rows, cols), float(e["coef"]),
+                                    _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]))
+            outs.append(tuple(grads))
+        check(lib.pa_multi_log_prob_grad(_DTYPES[dtype], _ptr(g), arr, len(chunk), float(coef_all),
+                                         _stream()))
+    return outs
+
+
+def meanfield_normal_sample(locs, rhos, P, seed, offsets, offset_dev=None):
+    """All mean-field Normal sites of a guide in one launch.  locs/rhos: lists of contiguous 1-D
+    (flattened) parameter tensors; offsets: Philox block offset per site.  Returns lists
+    (z [P, n], scale [n], loc_out [n], eps [P, n])."""
+    lib = _lib.load()
+    _require_gpu(*locs, *rhos, offset_dev)
+    dtype, device = locs[0].dtype, locs[0].device
+    zs, scales, louts, epss = [], [], [], []
+    for lo in range(0, len(locs), _lib.MF_MAX_SITES):
+        hi = min(lo + _lib.MF_MAX_SITES, len(locs))
+        arr = (_lib.MfSite * (hi - lo))()
+        for k in range(lo, hi):
+            n = locs[k].numel()
+            assert locs[k].is_contiguous() and rhos[k].is_contiguous() and rhos[k].numel() == n
+            z = torch.empty((P, n), dtype=dtype, device=device)
+            eps = torch.empty((P, n), dtype=dtype, device=device)
+            sc = torch.empty((n,), dtype=dtype, device=device)
+            lout = torch.empty((n,), dtype=dtype, device=device)
+            zs.append(z); scales.append(sc); louts.append(lout); epss.append(eps)
+            arr[k - lo] = _lib.MfSite(_ptr(locs[k]), _ptr(rhos[k]), _ptr(z), _ptr(sc), _ptr(lout),
+                                      _ptr(eps), n, int(offsets[k]), None, None, None, None, None)
+        check(lib.pa_meanfield_normal_sample(_DTYPES[dtype], arr, hi - lo, int(P), int(seed),
+                                             _ptr(offset_dev), _stream()))
+    return zs, scales, louts, epss
+
+
+def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P):
+    """Backward of meanfield_normal_sample: d_zs[k] [P, n], d_scales[k] [n], d_louts[k] [n] (each
+    may be None = zero) -> lists (d_loc [n], d_rho [n])."""
+    lib = _lib.load()
+    dtype, device = rhos[0].dtype, rhos[0].device
+    d_locs, d_rhos = [], []
+    for lo in range(0, len(rhos), _lib.MF_MAX_SITES):
+        hi = min(lo + _lib.MF_MAX_SITES, len(rhos))
+        arr = (_lib.MfSite * (hi - lo))()
+        keep = []
+        for k in range(lo, hi):
+            n = rhos[k].numel()
+            dz, ds, dl_in = (None if t is None else t.contiguous()
+                             for t in (d_zs[k], d_scales[k], d_louts[k]))
+            _require_gpu(rhos[k], epss[k], dz, ds, dl_in)
+            dl = torch.empty((n,), dtype=dtype, device=device)
+            dr = torch.empty((n,), dtype=dtype, device=device)
+            d_locs.append(dl); d_rhos.append(dr)
+            keep += [dz, ds, dl_in]
+            arr[k - lo] = _lib.MfSite(None, _ptr(rhos[k]), None, None, None, _ptr(epss[k]), n, 0,
+                                      _ptr(dz), _ptr(ds), _ptr(dl_in), _ptr(dl), _ptr(dr))
+        check(lib.pa_meanfield_normal_sample_bwd(_DTYPES[dtype], arr, hi - lo, int(P), _stream()))
+        del keep
+    return d_locs, d_rhos
+
+
+# ------------------------------------------------------------------------------------------
 # fused Bernoulli-logits GLM
 # ------------------------------------------------------------------------------------------
 
@@ -210,6 +329,19 @@ def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
                                        float(scale), N, D, P, _ptr(ll), _ptr(gw), _ptr(gb),
                                        _ptr(ws), nbytes, _stream()))
     return ll, gw, gb
+
+
+def glm_chain(g, gw, gb, need_w=True, need_b=True):
+    """(g[:, None...] * gw, g * gb) in one launch: the backward of the fused GLM site."""
+    _require_gpu(g, gw, gb)
+    P = g.numel()
+    g = g.reshape(P).contiguous()
+    assert gw.is_contiguous() and gw.shape[0] == P and gw.dtype == torch.float32
+    W = gw.numel() // max(P, 1)
+    dw = torch.empty_like(gw) if need_w else None
+    db = torch.empty_like(gb) if (need_b and gb is not None) else None
+    check(_lib.load().pa_glm_chain(_ptr(g), _ptr(gw), _ptr(gb), P, W, _ptr(dw), _ptr(db), _stream()))
+    return dw, db
 
 
 class GroupSegments:
@@ -446,7 +578,7 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
               weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True):
     _require_gpu(param, grad, exp_avg, exp_avg_sq, step_dev)
-    assert step_dev.dtype == torch.int64 and step_dev.numel() == 1
+    assert step_dev.dtype == torch.int64 and step_dev.numel() == 2   # [step, ticket]
     for x in (param, grad, exp_avg, exp_avg_sq):
         assert x.is_contiguous() and x.dtype == param.dtype and x.numel() == param.numel()
     check(_lib.load().pa_adam_step(_dtype(param), _ptr(param), _ptr(grad), _ptr(exp_avg),

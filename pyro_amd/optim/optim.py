@@ -129,7 +129,7 @@ class _FlatAdam:
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
         if self.step_dev is None:
-            self.step_dev = torch.zeros(1, dtype=torch.int64, device=proto.device)
+            self.step_dev = torch.zeros(2, dtype=torch.int64, device=proto.device)  # [step, ticket]
 
     def __call__(self, params, *args, skip_grad_hook=False, **kwargs):
         new = [p for p in params if p not in self._index]
@@ -156,7 +156,7 @@ class _FlatAdam:
         return {"names": [_PARAM_STORE.param_name(p) for p in self._params],
                 "exp_avg": None if self.exp_avg is None else self.exp_avg.clone(),
                 "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.clone(),
-                "step": None if self.step_dev is None else int(self.step_dev.item())}
+                "step": None if self.step_dev is None else int(self.step_dev[0].item())}
 
     def set_state(self, state):
         self._pending_state = state

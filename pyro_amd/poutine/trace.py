@@ -124,6 +124,44 @@ class Trace:
                 warn_if_inf(site["log_prob_sum"], "log_prob_sum at site '{}'".format(name),
                             allow_neginf=True)
 
+    def collect_log_prob_sums(self, batch, sign, site_filter=lambda name, site: True):
+        """Batched fused path: instead of one reduction launch per site, every small element-wise
+        site is described to ``batch`` (distributions.fused.SiteBatch) and the whole signed sum is
+        produced by one launch in ``batch.total()``.  Sites that cannot be described that way are
+        reduced on their own and handed over as already-computed terms.  Returns the list of
+        (sign, tensor) terms the batch could not take (other dtype / device)."""
+        leftovers = []
+        for name, site in self.nodes.items():
+            if site["type"] != "sample" or not site_filter(name, site):
+                continue
+            term = site.get("log_prob_sum")
+            if term is None:
+                fn, value, scale, mask = site["fn"], site["value"], site["scale"], site["mask"]
+                if mask is False:
+                    continue
+                if mask is True:
+                    mask = None
+                plain = not site["args"] and not site["kwargs"]
+                entry_fn = getattr(fn, "fused_site_entry", None) if plain else None
+                if entry_fn is not None and isinstance(value, torch.Tensor):
+                    try:
+                        entry = entry_fn(value, scale, mask)
+                    except ValueError as e:
+                        raise self._site_error(name, site, e) from e
+                    if entry is not None and batch.add_site(*entry, sign):
+                        continue
+                batch_fn = getattr(fn, "fused_log_prob_batch", None) if plain else None
+                if batch_fn is not None:
+                    try:
+                        term = batch_fn(value, scale, mask)      # e.g. per-particle sums ll[P]
+                    except ValueError as e:
+                        raise self._site_error(name, site, e) from e
+                if term is None:
+                    term = self._site_sum(name, site)
+            if not batch.add_term(term, sign):
+                leftovers.append((sign, term.sum() if term.dim() else term))
+        return leftovers
+
     def _site_sum(self, name, site):
         fn, value, scale, mask = site["fn"], site["value"], site["scale"], site["mask"]
         if mask is False:

@@ -83,6 +83,32 @@ def param(name, init_tensor=None, constraint=dist.constraints.real, event_dim=No
     return msg["value"]
 
 
+def param_unconstrained(name, init_tensor=None, constraint=dist.constraints.real, event_dim=None):
+    """Like ``param`` (same site name, same "param" message, created on first use) but the site's
+    value is the UNCONSTRAINED leaf tensor: for callers that apply the constraint's transform inside
+    a fused kernel (AutoNormal: scale = softplus(rho) in pa_meanfield_normal_sample) and would
+    otherwise pay a transform launch per parameter per step.  ``value.unconstrained()`` returns the
+    leaf itself, which is what SVI collects."""
+    import weakref
+
+    def fn(*a, **kw):
+        if name not in _PARAM_STORE:
+            _PARAM_STORE.get_param(name, init_tensor, constraint, event_dim)
+        leaf = _PARAM_STORE._params[name]
+        try:
+            leaf.unconstrained = weakref.ref(leaf)
+        except AttributeError:
+            pass
+        return leaf
+
+    if not am_i_wrapped():
+        return fn()
+    msg = new_message("param", name, fn, (), {"event_dim": event_dim},
+                      infer={"_unconstrained_value": True})
+    apply_stack(msg)
+    return msg["value"]
+
+
 class plate(PlateMessenger):
     """Conditional-independence context, vectorised (``with``) or sequential (``for``)."""
 

@@ -71,10 +71,97 @@ def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need)
     return outs
 
 
+def _entry_np(e):
+    rows, cols = e["rows"], e["cols"]
+    v = _bc(e["value"], rows, cols).astype(np.float64)
+    a = None if e["p0"] is None else _bc(e["p0"], rows, cols).astype(np.float64)
+    b = None if e["p1"] is None else _bc(e["p1"], rows, cols).astype(np.float64)
+    return v, a, b, _bc(e["mask"], rows, cols)
+
+
+def multi_log_prob_sum(entries, coef_all, dtype, device):
+    """Numpy restatement of pa_multi_log_prob_sum (SITE_IDENTITY = 100: log_prob(value) = value)."""
+    tot = 0.0
+    for e in entries:
+        v, a, b, m = _entry_np(e)
+        lp = v if e["dist"] == 100 else o_dists.LOG_PROB[e["dist"]](v, a, b)
+        if m is not None:
+            lp = np.where(m, lp, 0.0)
+        tot += e["coef"] * lp.sum()
+    return torch.as_tensor(coef_all * tot, dtype=dtype)
+
+
+def multi_log_prob_grad(g, entries, coef_all, dtype, device):
+    outs = []
+    for e in entries:
+        rows, cols = e["rows"], e["cols"]
+        v, a, b, m = _entry_np(e)
+        if e["dist"] == 100:
+            grads = (np.ones_like(v), None, None)
+        else:
+            grads = o_dists.log_prob_grad(e["dist"], v, a, b)
+        w = float(g) * coef_all * e["coef"]
+        res = []
+        for need, src, d in zip(e["need"], (e["value"], e["p0"], e["p1"]), grads):
+            if not need or src is None:
+                res.append(None)
+                continue
+            x = w * np.broadcast_to(d, (rows, cols))
+            if m is not None:
+                x = np.where(m, x, 0.0)
+            if (src.shape[0] == 1 or src.stride(0) == 0) and rows > 1:
+                x = x.sum(0, keepdims=True)
+            if (src.shape[1] == 1 or src.stride(1) == 0) and cols > 1:
+                x = x.sum(1, keepdims=True)
+            res.append(torch.as_tensor(np.ascontiguousarray(x), dtype=dtype))
+        outs.append(tuple(res))
+    return outs
+
+
+def meanfield_normal_sample(locs, rhos, P, seed, offsets, offset_dev=None):
+    zs, scales, louts, epss = [], [], [], []
+    base = 0 if offset_dev is None else int(offset_dev.item())
+    for loc, rho, off in zip(locs, rhos, offsets):
+        n = loc.numel()
+        np_dt = np.float32 if loc.dtype == torch.float32 else np.float64
+        eps = o_philox.normal(P * n, np_dt, seed, base + int(off)).reshape(P, n)
+        r = _np(rho).astype(np.float64)
+        sc = np.where(r > 20, r, np.log1p(np.exp(np.minimum(r, 20))))
+        z = _np(loc).astype(np.float64)[None, :] + sc[None, :] * eps
+        zs.append(torch.as_tensor(z, dtype=loc.dtype))
+        scales.append(torch.as_tensor(sc, dtype=loc.dtype))
+        louts.append(loc.detach().clone())
+        epss.append(torch.as_tensor(eps, dtype=loc.dtype))
+    return zs, scales, louts, epss
+
+
+def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P):
+    d_locs, d_rhos = [], []
+    for rho, eps, dz, ds, dlo in zip(rhos, epss, d_zs, d_scales, d_louts):
+        r = _np(rho).astype(np.float64)
+        sl = np.zeros_like(r) if dz is None else _np(dz).astype(np.float64).sum(0)
+        ss = np.zeros_like(r) if dz is None else (_np(dz).astype(np.float64) * _np(eps)).sum(0)
+        if ds is not None:
+            ss = ss + _np(ds).astype(np.float64)
+        if dlo is not None:
+            sl = sl + _np(dlo).astype(np.float64)
+        sig = np.where(r > 20, 1.0, 1.0 / (1.0 + np.exp(-r)))
+        d_locs.append(torch.as_tensor(sl, dtype=rho.dtype))
+        d_rhos.append(torch.as_tensor(ss * sig, dtype=rho.dtype))
+    return d_locs, d_rhos
+
+
 def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
     ll, gw, gb = o_glm.glm_bernoulli_fwd_bwd(_np(X), _np(y), _np(w), _np(b), _np(mask), scale)
     return (torch.as_tensor(ll, dtype=X.dtype), torch.as_tensor(gw, dtype=X.dtype),
             torch.as_tensor(gb, dtype=X.dtype))
+
+
+def glm_chain(g, gw, gb, need_w=True, need_b=True):
+    gg = g.reshape(-1)
+    dw = gg.reshape((-1,) + (1,) * (gw.dim() - 1)) * gw if need_w else None
+    db = gg * gb if (need_b and gb is not None) else None
+    return dw, db
 
 
 class GroupSegments:
@@ -212,12 +299,12 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
               weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True):
-    step = int(step_dev.item()) + 1
+    step = int(step_dev[0].item()) + 1
     p, m, v = o_adam.adam_step(_np(param), _np(grad), _np(exp_avg), _np(exp_avg_sq), step, lr, betas,
                                eps, weight_decay, clip_norm, lrd, clipped)
     param.data.copy_(torch.as_tensor(p)); exp_avg.copy_(torch.as_tensor(m))
     exp_avg_sq.copy_(torch.as_tensor(v))
-    step_dev += 1
+    step_dev[0] += 1
     if zero_grad:
         grad.zero_()
 
@@ -225,7 +312,8 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999)
 FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
-             "glm_bernoulli_grouped_fwd_bwd"]
+             "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad",
+             "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain"]
 
 
 def install(monkeypatch):
@@ -235,3 +323,4 @@ def install(monkeypatch):
         monkeypatch.setattr(k, name, g[name])
     # the product refuses CPU tensors; lift that check for host-logic tests only
     monkeypatch.setattr(k, "_require_gpu", lambda *a: None)
+    monkeypatch.setattr(k, "HOST_TEST_BACKEND", True)

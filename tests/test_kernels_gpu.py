@@ -440,14 +440,14 @@ def test_lda_factor_minus_inf_column(gpu):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_adam_step(gpu, clipped, dtype):
     k = _k()
-    n = 1000
+    n = 100_003      # several workgroups: the last one to finish advances the step counter
     rng = np.random.default_rng(0)
     np_dt = np.float32 if dtype == torch.float32 else np.float64
     p = rng.standard_normal(n).astype(np_dt)
     m = np.zeros(n)
     v = np.zeros(n)
     tp, tm, tv = tt(p, gpu), torch.zeros(n, device=gpu, dtype=dtype), torch.zeros(n, device=gpu, dtype=dtype)
-    step_dev = torch.zeros(1, dtype=torch.int64, device=gpu)
+    step_dev = torch.zeros(2, dtype=torch.int64, device=gpu)      # [step, ticket]
     pr = p.astype(np.float64)
     for step in range(1, 6):
         g = (rng.standard_normal(n) * 20).astype(np_dt)
@@ -457,6 +457,6 @@ def test_adam_step(gpu, clipped, dtype):
         pr, m, v = o_adam.adam_step(pr, g, m, v, step, 0.01, weight_decay=0.01 if clipped else 0.0,
                                     clip_norm=10.0, lrd=0.999, clipped=clipped)
         assert float(tg.abs().sum()) == 0.0
-    assert int(step_dev.item()) == 5
+    assert step_dev.tolist() == [5, 0]
     tol = 1e-5 if dtype == torch.float32 else 1e-12
     np.testing.assert_allclose(tp.cpu().numpy(), pr, rtol=tol, atol=tol)

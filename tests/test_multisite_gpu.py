@@ -1,0 +1,187 @@
+"""The many-small-sites kernels (pa_multi_log_prob_sum / _grad, pa_meanfield_normal_sample / _bwd)
+through the C-ABI against the numpy restatements in tests/oracle_backend.py, and the fused
+ELBO-assembly / mean-field guide host paths against the per-site paths they replace.
+
+Tolerances: float64 rtol 1e-11 (same arithmetic, different summation order); float32 vs the float64
+restatement rtol 2e-5; Philox draws as in test_kernels_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import philox as o_philox
+from tests import oracle_backend as ob
+
+
+def _entries(rng, dtype, dev):
+    """A table mixing every family, every broadcast pattern, masks and an identity term."""
+    def t(a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=dev)
+
+    R, C = 48, 20
+    ents = []
+    # Normal: value full, loc row-broadcast ([1,C] -> summed over rows), scale scalar
+    ents.append(dict(dist=0, rows=R, cols=C, value=t(rng.standard_normal((R, C))),
+                     p0=t(rng.standard_normal((1, C))), p1=t(rng.uniform(0.5, 2, (1, 1))), mask=None,
+                     coef=-1.0, need=(True, True, True)))
+    # Normal: value full, loc col-broadcast ([R,1]), scale full, with a mask
+    ents.append(dict(dist=0, rows=R, cols=C, value=t(rng.standard_normal((R, C))),
+                     p0=t(rng.standard_normal((R, 1))), p1=t(rng.uniform(0.5, 2, (R, C))),
+                     mask=torch.as_tensor(rng.uniform(size=(R, C)) < 0.7, device=dev), coef=2.5,
+                     need=(True, True, True)))
+    # Bernoulli-logits
+    ents.append(dict(dist=1, rows=7, cols=300, value=t((rng.uniform(size=(7, 300)) < 0.4) * 1.0),
+                     p0=t(rng.standard_normal((7, 300))), p1=None, mask=None, coef=1.0,
+                     need=(False, True, False)))
+    # HalfCauchy, LogNormal, Exponential, HalfNormal on positive values; scalar / row params
+    pos = rng.uniform(0.1, 3, (5, 33))
+    ents.append(dict(dist=2, rows=5, cols=33, value=t(pos), p0=t(rng.uniform(0.5, 2, (1, 1))), p1=None,
+                     mask=None, coef=1.0, need=(True, True, False)))
+    ents.append(dict(dist=3, rows=5, cols=33, value=t(pos), p0=t(rng.standard_normal((1, 33))),
+                     p1=t(rng.uniform(0.5, 2, (5, 1))), mask=None, coef=-0.5, need=(True, True, True)))
+    ents.append(dict(dist=4, rows=5, cols=33, value=t(pos), p0=t(rng.uniform(0.5, 2, (5, 33))), p1=None,
+                     mask=None, coef=1.0, need=(True, True, False)))
+    ents.append(dict(dist=5, rows=1, cols=33, value=t(pos[:1]), p0=t(rng.uniform(0.5, 2, (1, 33))),
+                     p1=None, mask=None, coef=3.0, need=(True, True, False)))
+    # identity: an already-reduced per-particle term
+    ents.append(dict(dist=100, rows=1, cols=64, value=t(rng.standard_normal((1, 64))), p0=None, p1=None,
+                     mask=None, coef=1.0, need=(True, False, False)))
+    # an empty site
+    ents.append(dict(dist=0, rows=0, cols=4, value=t(np.zeros((0, 4))), p0=t(np.zeros((1, 4))),
+                     p1=t(np.ones((1, 1))), mask=None, coef=1.0, need=(False, False, False)))
+    return ents
+
+
+def _cpu(e):
+    out = dict(e)
+    for k in ("value", "p0", "p1", "mask"):
+        if out[k] is not None:
+            # keep the broadcast pattern visible to the restatement: size-1 dims stay size 1
+            out[k] = out[k].cpu()
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_multi_log_prob_sum_and_grad_vs_restatement(gpu, dtype):
+    from pyro_amd import kernels as k
+
+    rng = np.random.default_rng(3)
+    ents = _entries(rng, dtype, gpu)
+    rtol = 2e-5 if dtype == torch.float32 else 1e-11
+    tot = k.multi_log_prob_sum(ents, -0.25, dtype, gpu)
+    cpu_ents = [_cpu(e) for e in ents]
+    ref = ob.multi_log_prob_sum([dict(e, value=e["value"].double(),
+                                      p0=None if e["p0"] is None else e["p0"].double(),
+                                      p1=None if e["p1"] is None else e["p1"].double())
+                                 for e in cpu_ents], -0.25, torch.float64, None)
+    np.testing.assert_allclose(float(tot), float(ref), rtol=rtol)
+    g = torch.tensor(1.7, dtype=dtype, device=gpu)
+    grads = k.multi_log_prob_grad(g, ents, -0.25, dtype, gpu)
+    ref_g = ob.multi_log_prob_grad(torch.tensor(1.7, dtype=torch.float64), cpu_ents, -0.25,
+                                   torch.float64, None)
+    for e, gs, rs in zip(ents, grads, ref_g):
+        for a, b in zip(gs, rs):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert tuple(a.shape) == tuple(b.shape)
+                sc = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+                np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=rtol * 5, atol=rtol * 5 * sc)
+
+
+def test_multi_more_entries_than_one_launch(gpu):
+    """> PA_MULTI_MAX_ENTRIES entries: chained launches accumulate into the same total."""
+    from pyro_amd import kernels as k
+
+    rng = np.random.default_rng(4)
+    ents = []
+    for i in range(37):
+        v = torch.as_tensor(rng.standard_normal((3, 5)), device=gpu)
+        ents.append(dict(dist=0, rows=3, cols=5, value=v, p0=torch.zeros((1, 1), dtype=v.dtype, device=gpu),
+                         p1=torch.ones((1, 1), dtype=v.dtype, device=gpu), mask=None, coef=(-1.0) ** i,
+                         need=(True, False, False)))
+    tot = k.multi_log_prob_sum(ents, 1.0, torch.float64, gpu)
+    ref = ob.multi_log_prob_sum([_cpu(e) for e in ents], 1.0, torch.float64, None)
+    np.testing.assert_allclose(float(tot), float(ref), rtol=1e-11)
+    grads = k.multi_log_prob_grad(torch.ones((), dtype=torch.float64, device=gpu), ents, 1.0,
+                                  torch.float64, gpu)
+    assert len(grads) == 37
+    for i, (e, gs) in enumerate(zip(ents, grads)):
+        np.testing.assert_allclose(gs[0].cpu().numpy(), (-1.0) ** i * -e["value"].cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_meanfield_sample_and_backward(gpu, dtype):
+    from pyro_amd import kernels as k
+
+    rng = np.random.default_rng(5)
+    P, sizes = 64, [32, 1, 1000]
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    locs = [torch.as_tensor(rng.standard_normal(n), dtype=dtype, device=gpu) for n in sizes]
+    rhos = [torch.as_tensor(rng.uniform(-3, 25, n), dtype=dtype, device=gpu) for n in sizes]
+    offsets = [10, 700, 900]
+    zs, scales, louts, epss = k.meanfield_normal_sample(locs, rhos, P, 11, offsets)
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    for n, loc, rho, off, z, sc, lo, eps in zip(sizes, locs, rhos, offsets, zs, scales, louts, epss):
+        ref_eps = o_philox.normal(P * n, np_dt, 11, off).reshape(P, n)
+        np.testing.assert_allclose(eps.cpu().numpy(), ref_eps, rtol=tol, atol=10 * tol)
+        r = rho.double().cpu().numpy()
+        ref_sc = np.where(r > 20, r, np.log1p(np.exp(np.minimum(r, 20))))
+        np.testing.assert_allclose(sc.cpu().numpy(), ref_sc, rtol=20 * tol)
+        assert torch.equal(lo, loc)
+        np.testing.assert_allclose(z.cpu().numpy(), loc.cpu().numpy()[None] + ref_sc[None] * ref_eps,
+                                   rtol=50 * tol, atol=50 * tol)
+    d_zs = [torch.as_tensor(rng.standard_normal((P, n)), dtype=dtype, device=gpu) for n in sizes]
+    d_zs[1] = None
+    d_scs = [torch.as_tensor(rng.standard_normal(n), dtype=dtype, device=gpu) for n in sizes]
+    d_scs[2] = None
+    d_los = [None, torch.as_tensor(rng.standard_normal(1), dtype=dtype, device=gpu), None]
+    d_locs, d_rhos = k.meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scs, d_los, P)
+    cpu = lambda xs: [None if x is None else x.double().cpu() for x in xs]   # noqa: E731
+    r_locs, r_rhos = ob.meanfield_normal_sample_bwd(cpu(rhos), cpu(epss), cpu(d_zs), cpu(d_scs),
+                                                    cpu(d_los), P)
+    rt = 3e-5 if dtype == torch.float32 else 1e-11
+    for a, b in zip(d_locs + d_rhos, r_locs + r_rhos):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=rt, atol=rt * 10)
+
+
+def _logreg_loss_and_grads(gpu, batched, fused_guide, monkeypatch):
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    from pyro_amd.distributions import fused
+
+    N, D, P = 3000, 32, 64
+    X, y = examples.synthetic_logreg_data(N, D, gpu, seed=0)
+    pyro.clear_param_store()
+    pyro.set_rng_seed(7)
+    if not batched:
+        monkeypatch.setattr(fused.SiteBatch, "add_site", lambda self, *a, **k: False)
+    if not fused_guide:
+        monkeypatch.setattr(AutoNormal, "_fused_draw", lambda self: None)
+    guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+    elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+    loss = elbo.loss_and_grads(examples.logreg_model, guide, X, y)
+    grads = {n: p.grad.detach().clone() for n, p in pyro.get_param_store().named_parameters()}
+    monkeypatch.undo()
+    return loss, grads
+
+
+def test_batched_elbo_and_fused_guide_equal_per_site_paths(gpu, monkeypatch):
+    """One ELBO-gradient evaluation of the config-2 model with (a) every site reduced on its own
+    and the guide drawn site by site, (b) the batched ELBO assembly, (c) batched assembly + fused
+    mean-field draw: same Philox draws, same loss and gradients up to float32 summation order."""
+    import pyro_amd as pyro
+    pyro.enable_validation(False)
+    try:
+        ref = _logreg_loss_and_grads(gpu, False, False, monkeypatch)
+        for batched, fused_guide in ((True, False), (True, True)):
+            out = _logreg_loss_and_grads(gpu, batched, fused_guide, monkeypatch)
+            assert abs(out[0] - ref[0]) <= 2e-6 * abs(ref[0]), (out[0], ref[0])
+            assert set(out[1]) == set(ref[1])
+            for name in ref[1]:
+                torch.testing.assert_close(out[1][name], ref[1][name], rtol=2e-4, atol=2e-4)
+    finally:
+        pyro.enable_validation(True)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# kernel-by-kernel sequence of ONE eager SVI.step of the bench workload (developer tool)
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
+OUT=gpurun_out/trace_step; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python bench.py --steps 2 --warmup 2 --no-graph --no-nuts --no-cpu-baseline --plate ${1:-1000000} > $OUT/log.txt 2>&1
+python - "$OUT" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# last step = after the last but one adam kernel
+idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+lo, hi = idx[-2] + 1, idx[-1] + 3
+t0 = int(rows[lo]["Start_Timestamp"])
+with open(sys.argv[1] + "/last_step.txt", "w") as out:
+    for r in rows[lo:hi]:
+        line = "%9.1f us  %7.1f us  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"][:110])
+        out.write(line + "\n")
+print(open(sys.argv[1] + "/last_step.txt").read())
+import os; os.remove(f)
+PY
