@@ -153,18 +153,37 @@ int pa_normal_rsample(int dtype, void* out, void* eps_out, pa_view2d loc, pa_vie
  * Limits: n <= PA_MULTI_MAX_ENTRIES per call (chain calls with accumulate = 1), rows*cols <=
  * PA_MULTI_MAX_ELEMS per entry; entries are host structs, copied into the kernel arguments.
  * ---------------------------------------------------------------------------------- */
-#define PA_SITE_IDENTITY 100
+#define PA_SITE_IDENTITY 100   /* log_prob(value) = value       (d/dvalue = 1) */
+#define PA_SITE_NONE 101       /* log_prob(value) = 0: only a carrier of `extra_grad` */
 #define PA_MULTI_MAX_ENTRIES 16
 #define PA_MULTI_MAX_ELEMS 65536
+/* `need` bits of pa_site_entry (backward) */
+#define PA_NEED_VALUE 1
+#define PA_NEED_P0 2
+#define PA_NEED_P1 4
+#define PA_VALUE_BY_CHAIN 16   /* this entry's value gradient is produced by another entry's chain */
 typedef struct {
-  int32_t dist;          /* PA_DIST_* or PA_SITE_IDENTITY */
-  int32_t need;          /* backward: bit0 = d_value, bit1 = d_p0, bit2 = d_p1 wanted */
+  int32_t dist;          /* PA_DIST_*, PA_SITE_IDENTITY or PA_SITE_NONE */
+  int32_t need;          /* backward: PA_NEED_* | PA_VALUE_BY_CHAIN */
   int64_t rows, cols;
   pa_view2d value, p0, p1, mask; /* mask: uint8, ptr NULL = none; p1.ptr NULL when unused */
   double coef;
   void* d_value;         /* backward outputs (NULL when not wanted) */
   void* d_p0;
   void* d_p1;
+  /* Several entries may score the SAME value tensor (a latent's prior in the model and its density
+   * in the guide).  chain_next links them (index of the next entry, -1 = end): the workgroup of
+   * the chain head writes the SUM of their value gradients into the head's d_value; the linked
+   * entries carry PA_VALUE_BY_CHAIN.  All members must have the head's rows/cols and an un-reduced
+   * value operand. */
+  int32_t chain_next;
+  int32_t reserved;
+  /* A term of the total whose gradient w.r.t. this entry's value tensor is already known (the
+   * fused GLM site returns its log-likelihood together with d ll / d w): added as
+   * d_value[i] += g * coef_all * extra_coef * extra_grad[i]  (contiguous [rows, cols]; the value
+   * operand must be un-reduced).  NULL = none. */
+  const void* extra_grad;
+  double extra_coef;
 } pa_site_entry;
 int pa_multi_log_prob_sum(int dtype, void* out_total, const pa_site_entry* entries, int n,
                           double coef_all, int accumulate, pa_stream_t stream);
@@ -195,6 +214,9 @@ typedef struct {
   void* eps;             /* [P, n] out (kept for the backward) */
   int64_t n;
   uint64_t offset;       /* Philox block offset of this site's draws */
+  int32_t accumulate;    /* backward: 1 = d_loc / d_rho are ADDED to (they point into the
+                            optimizer's flat gradient buffer), 0 = overwritten */
+  int32_t reserved;
   const void* d_z;       /* backward inputs (each may be NULL = zero) / outputs */
   const void* d_scale;
   const void* d_loc_out;

@@ -32,6 +32,8 @@ class View2D(Structure):
 NULL_VIEW = View2D(None, 0, 0)
 
 SITE_IDENTITY = 100
+SITE_NONE = 101
+NEED_VALUE, NEED_P0, NEED_P1, VALUE_BY_CHAIN = 1, 2, 4, 16
 MULTI_MAX_ENTRIES = 16
 MULTI_MAX_ELEMS = 65536
 MF_MAX_SITES = 16
@@ -41,14 +43,16 @@ class SiteEntry(Structure):
     """pa_site_entry (include/pyro_amd.h)."""
     _fields_ = [("dist", c_int32), ("need", c_int32), ("rows", c_int64), ("cols", c_int64),
                 ("value", View2D), ("p0", View2D), ("p1", View2D), ("mask", View2D),
-                ("coef", c_double), ("d_value", c_void_p), ("d_p0", c_void_p), ("d_p1", c_void_p)]
+                ("coef", c_double), ("d_value", c_void_p), ("d_p0", c_void_p), ("d_p1", c_void_p),
+                ("chain_next", c_int32), ("reserved", c_int32), ("extra_grad", c_void_p),
+                ("extra_coef", c_double)]
 
 
 class MfSite(Structure):
     """pa_mf_site (include/pyro_amd.h)."""
     _fields_ = [("loc", c_void_p), ("rho", c_void_p), ("z", c_void_p), ("scale", c_void_p),
                 ("loc_out", c_void_p), ("eps", c_void_p), ("n", c_int64), ("offset", c_uint64),
-                ("d_z", c_void_p), ("d_scale", c_void_p), ("d_loc_out", c_void_p),
+                ("accumulate", c_int32), ("reserved", c_int32), ("d_z", c_void_p), ("d_scale", c_void_p), ("d_loc_out", c_void_p),
                 ("d_loc", c_void_p), ("d_rho", c_void_p)]
 
 

@@ -25,6 +25,9 @@ struct EntryDev {
   int64_t vsr, vsc, asr, asc, bsr, bsc, msr, msc;
   double coef;
   void *dv, *da, *db;
+  int chain_next;
+  const void* xg;
+  double xcoef;
 };
 struct MultiArgs {
   int n;
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(MULTI_THREADS) void multi_sum_kernel(const MultiArg
       case PA_DIST_LOG_NORMAL: s = entry_sum<PA_DIST_LOG_NORMAL, T>(e); break;
       case PA_DIST_EXPONENTIAL: s = entry_sum<PA_DIST_EXPONENTIAL, T>(e); break;
       case PA_DIST_HALF_NORMAL: s = entry_sum<PA_DIST_HALF_NORMAL, T>(e); break;
+      case PA_SITE_NONE: s = 0.0; break;
       default: s = entry_sum<PA_SITE_IDENTITY, T>(e); break;
     }
     acc += e.coef * s;
@@ -121,13 +125,16 @@ constexpr int GRAD_THREADS = 256;
 // a dimension are spread over thread groups and combined through LDS in a fixed order.
 template <int DIST, typename T>
 __device__ void entry_grad_operand(const EntryDev& e, int which, int64_t sr, int64_t sc, T* out,
-                                   double w, double* red /* [GRAD_THREADS] */) {
+                                   double w, double* red /* [GRAD_THREADS] */,
+                                   bool accumulate = false) {
   const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols, t = threadIdx.x;
   const bool red_r = (sr == 0 && R > 1), red_c = (sc == 0 && C > 1);
   if (!red_r && !red_c) {
+#pragma unroll 4
     for (uint32_t i = t; i < R * C; i += GRAD_THREADS) {
       const uint32_t r = i / C, c = i - r * C;
-      out[i] = (T)(w * (double)entry_grad_at<DIST, T>(e, which, r, c));
+      const T x = (T)(w * (double)entry_grad_at<DIST, T>(e, which, r, c));
+      out[i] = accumulate ? out[i] + x : x;
     }
   } else if (red_r != red_c) {
     // K = kept dimension (its index is the output index), L = summed dimension
@@ -138,16 +145,18 @@ __device__ void entry_grad_operand(const EntryDev& e, int which, int64_t sr, int
     for (uint32_t kb = 0; kb < K; kb += tk) {
       const uint32_t k = kb + k0;
       T acc = T(0);
-      if (g < ng && k < K)
+      if (g < ng && k < K) {
+#pragma unroll 4
         for (uint32_t l = g; l < L; l += ng)
           acc += red_r ? entry_grad_at<DIST, T>(e, which, l, k) : entry_grad_at<DIST, T>(e, which, k, l);
+      }
       __syncthreads();
       red[t] = (double)acc;
       __syncthreads();
       if (g == 0 && k < K) {
         double s = 0.0;
         for (uint32_t j = 0; j < ng; ++j) s += red[j * tk + k0];
-        out[k] = (T)(w * s);
+        out[k] = (T)(w * s) + (accumulate ? out[k] : T(0));
       }
     }
     __syncthreads();
@@ -158,17 +167,35 @@ __device__ void entry_grad_operand(const EntryDev& e, int which, int64_t sr, int
       acc += entry_grad_at<DIST, T>(e, which, r, c);
     }
     const double tot = block_sum_f64((double)acc, red);
-    if (t == 0) out[0] = (T)(w * tot);
+    if (t == 0) out[0] = (T)(w * tot) + (accumulate ? out[0] : T(0));
     __syncthreads();
   }
 }
 
+// value gradient of entry e into out (run-time family dispatch: chain members differ in family)
+template <typename T>
+__device__ void value_grad_pass(const EntryDev& e, T* out, double w, double* smem, bool accumulate) {
+  switch (e.dist) {
+#define PA_VG(D_) case D_: entry_grad_operand<D_, T>(e, 0, e.vsr, e.vsc, out, w, smem, accumulate); break;
+    PA_VG(PA_DIST_NORMAL) PA_VG(PA_DIST_BERNOULLI_LOGITS) PA_VG(PA_DIST_HALF_CAUCHY)
+    PA_VG(PA_DIST_LOG_NORMAL) PA_VG(PA_DIST_EXPONENTIAL) PA_VG(PA_DIST_HALF_NORMAL)
+    PA_VG(PA_SITE_IDENTITY)
+#undef PA_VG
+    default:   // PA_SITE_NONE: zero gradient
+      if (!accumulate) {
+        const bool red_r = (e.vsr == 0 && e.rows > 1), red_c = (e.vsc == 0 && e.cols > 1);
+        const uint32_t n = (uint32_t)((red_r ? 1 : e.rows) * (red_c ? 1 : e.cols));
+        for (uint32_t i = threadIdx.x; i < n; i += GRAD_THREADS) out[i] = T(0);
+      }
+      break;
+  }
+}
+
 template <int DIST, typename T>
-__device__ void entry_grad_all(const EntryDev& e, double w, double* smem) {
-  if ((e.need & 1) && e.dv) entry_grad_operand<DIST, T>(e, 0, e.vsr, e.vsc, (T*)e.dv, w, smem);
-  if constexpr (DIST != PA_SITE_IDENTITY) {
-    if ((e.need & 2) && e.da) entry_grad_operand<DIST, T>(e, 1, e.asr, e.asc, (T*)e.da, w, smem);
-    if (NParams<DIST>::n > 1 && (e.need & 4) && e.db)
+__device__ void param_grads(const EntryDev& e, double w, double* smem) {
+  if constexpr (DIST < PA_DIST_COUNT) {
+    if ((e.need & PA_NEED_P0) && e.da) entry_grad_operand<DIST, T>(e, 1, e.asr, e.asc, (T*)e.da, w, smem);
+    if (NParams<DIST>::n > 1 && (e.need & PA_NEED_P1) && e.db)
       entry_grad_operand<DIST, T>(e, 2, e.bsr, e.bsc, (T*)e.db, w, smem);
   }
 }
@@ -178,16 +205,34 @@ __global__ __launch_bounds__(GRAD_THREADS) void multi_grad_kernel(const MultiArg
                                                                   const T* __restrict__ g,
                                                                   double coef_all) {
   __shared__ double smem[GRAD_THREADS];
-  const EntryDev& e = kernarg_table<MultiArgs>()->e[blockIdx.x];
-  const double w = (double)g[0] * coef_all * e.coef;
+  const MultiArgs& args = *kernarg_table<MultiArgs>();
+  const EntryDev& e = args.e[blockIdx.x];
+  const double gw = (double)g[0] * coef_all;
+  if ((e.need & PA_NEED_VALUE) && e.dv && !(e.need & PA_VALUE_BY_CHAIN)) {
+    T* out = (T*)e.dv;
+    value_grad_pass<T>(e, out, gw * e.coef, smem, false);
+    for (int k = e.chain_next; k >= 0; k = args.e[k].chain_next) {   // same value tensor, same frame
+      __syncthreads();
+      value_grad_pass<T>(args.e[k], out, gw * args.e[k].coef, smem, true);
+    }
+    if (e.xg != nullptr) {
+      __syncthreads();
+      const T* xg = (const T*)e.xg;
+      const T xw = (T)(gw * e.xcoef);
+      const uint32_t n = (uint32_t)(e.rows * e.cols);
+      for (uint32_t i = threadIdx.x; i < n; i += GRAD_THREADS) out[i] += xw * xg[i];
+    }
+    __syncthreads();
+  }
+  const double w = gw * e.coef;
   switch (e.dist) {
-    case PA_DIST_NORMAL: entry_grad_all<PA_DIST_NORMAL, T>(e, w, smem); break;
-    case PA_DIST_BERNOULLI_LOGITS: entry_grad_all<PA_DIST_BERNOULLI_LOGITS, T>(e, w, smem); break;
-    case PA_DIST_HALF_CAUCHY: entry_grad_all<PA_DIST_HALF_CAUCHY, T>(e, w, smem); break;
-    case PA_DIST_LOG_NORMAL: entry_grad_all<PA_DIST_LOG_NORMAL, T>(e, w, smem); break;
-    case PA_DIST_EXPONENTIAL: entry_grad_all<PA_DIST_EXPONENTIAL, T>(e, w, smem); break;
-    case PA_DIST_HALF_NORMAL: entry_grad_all<PA_DIST_HALF_NORMAL, T>(e, w, smem); break;
-    default: entry_grad_all<PA_SITE_IDENTITY, T>(e, w, smem); break;
+    case PA_DIST_NORMAL: param_grads<PA_DIST_NORMAL, T>(e, w, smem); break;
+    case PA_DIST_BERNOULLI_LOGITS: param_grads<PA_DIST_BERNOULLI_LOGITS, T>(e, w, smem); break;
+    case PA_DIST_HALF_CAUCHY: param_grads<PA_DIST_HALF_CAUCHY, T>(e, w, smem); break;
+    case PA_DIST_LOG_NORMAL: param_grads<PA_DIST_LOG_NORMAL, T>(e, w, smem); break;
+    case PA_DIST_EXPONENTIAL: param_grads<PA_DIST_EXPONENTIAL, T>(e, w, smem); break;
+    case PA_DIST_HALF_NORMAL: param_grads<PA_DIST_HALF_NORMAL, T>(e, w, smem); break;
+    default: break;
   }
 }
 
@@ -198,13 +243,14 @@ static int to_dev(const pa_site_entry* in, int n, MultiArgs* out, const char* wh
   out->n = n;
   for (int k = 0; k < n; ++k) {
     const pa_site_entry& s = in[k];
-    PA_REQUIRE((s.dist >= 0 && s.dist < PA_DIST_COUNT) || s.dist == PA_SITE_IDENTITY,
+    PA_REQUIRE((s.dist >= 0 && s.dist < PA_DIST_COUNT) || s.dist == PA_SITE_IDENTITY ||
+                   s.dist == PA_SITE_NONE,
                "%s: entry %d: unknown distribution id %d", who, k, s.dist);
     PA_REQUIRE(s.rows >= 0 && s.cols >= 0 && s.rows * s.cols <= PA_MULTI_MAX_ELEMS,
                "%s: entry %d: shape [%lld,%lld] out of range", who, k, (long long)s.rows,
                (long long)s.cols);
     PA_REQUIRE(s.rows * s.cols == 0 || s.value.ptr, "%s: entry %d: NULL value", who, k);
-    if (s.dist != PA_SITE_IDENTITY) {
+    if (s.dist < PA_DIST_COUNT) {
       PA_REQUIRE(s.rows * s.cols == 0 || s.p0.ptr, "%s: entry %d: NULL p0", who, k);
       PA_REQUIRE(s.rows * s.cols == 0 ||
                      !(s.dist == PA_DIST_NORMAL || s.dist == PA_DIST_LOG_NORMAL) || s.p1.ptr,
@@ -218,6 +264,16 @@ static int to_dev(const pa_site_entry* in, int n, MultiArgs* out, const char* wh
     d.bsr = s.p1.stride_row; d.bsc = s.p1.stride_col;
     d.msr = s.mask.stride_row; d.msc = s.mask.stride_col;
     d.coef = s.coef; d.dv = s.d_value; d.da = s.d_p0; d.db = s.d_p1;
+    PA_REQUIRE(s.chain_next >= -1 && s.chain_next < n && s.chain_next != k,
+               "%s: entry %d: bad chain_next %d", who, k, s.chain_next);
+    const bool red_v = (s.value.stride_row == 0 && s.rows > 1) ||
+                       (s.value.stride_col == 0 && s.cols > 1);
+    PA_REQUIRE(!(red_v && (s.chain_next >= 0 || s.extra_grad || (s.need & PA_VALUE_BY_CHAIN))),
+               "%s: entry %d: chained / extra value gradients need an un-reduced value operand", who,
+               k);
+    PA_REQUIRE(s.chain_next < 0 || (in[s.chain_next].rows == s.rows && in[s.chain_next].cols == s.cols),
+               "%s: entry %d: chain members must share the frame", who, k);
+    d.chain_next = s.chain_next; d.xg = s.extra_grad; d.xcoef = s.extra_coef;
   }
   return PA_OK;
 }
@@ -228,6 +284,7 @@ struct MfSiteDev {
   void *z, *scale, *loc_out, *eps;
   int64_t n;
   uint64_t offset;
+  int accumulate;
   const void *d_z, *d_scale, *d_loc_out;
   void *d_loc, *d_rho;
 };
@@ -287,12 +344,14 @@ __global__ __launch_bounds__(256) void meanfield_sample_bwd_kernel(const MfArgs 
   for (uint32_t cb = 0; cb < n; cb += tk) {
     const uint32_t c = cb + c0;
     T al = T(0), as = T(0);
-    if (dz != nullptr && g < ng && c < n)
+    if (dz != nullptr && g < ng && c < n) {
+#pragma unroll 8
       for (uint32_t p = g; p < PP; p += ng) {
         const T gz = dz[p * n + c];
         al += gz;
         as += gz * eps[p * n + c];
       }
+    }
     __syncthreads();
     red_l[t] = (double)al;
     red_s[t] = (double)as;
@@ -307,8 +366,8 @@ __global__ __launch_bounds__(256) void meanfield_sample_bwd_kernel(const MfArgs 
       if (dlo != nullptr) sl += (double)dlo[c];
       const double x = (double)rho[c];
       const double sig = x > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-x));   // d softplus / d x
-      if (dloc) dloc[c] = (T)sl;
-      if (drho) drho[c] = (T)(ss * sig);
+      if (dloc) dloc[c] = (T)sl + (s.accumulate ? dloc[c] : T(0));
+      if (drho) drho[c] = (T)(ss * sig) + (s.accumulate ? drho[c] : T(0));
     }
   }
 }
@@ -323,7 +382,8 @@ static int mf_to_dev(const pa_mf_site* in, int n, MfArgs* out, const char* who) 
     PA_REQUIRE(s.n >= 0 && s.n < (int64_t(1) << 31), "%s: site %d: bad size", who, k);
     MfSiteDev& d = out->s[k];
     d.loc = s.loc; d.rho = s.rho; d.z = s.z; d.scale = s.scale; d.loc_out = s.loc_out;
-    d.eps = s.eps; d.n = s.n; d.offset = s.offset; d.d_z = s.d_z; d.d_scale = s.d_scale;
+    d.eps = s.eps; d.n = s.n; d.offset = s.offset; d.accumulate = s.accumulate;
+    d.d_z = s.d_z; d.d_scale = s.d_scale;
     d.d_loc_out = s.d_loc_out; d.d_loc = s.d_loc; d.d_rho = s.d_rho;
   }
   return PA_OK;

@@ -327,6 +327,53 @@ class _BernoulliLinear(TorchDistribution):
         ll = self.fused_log_prob_batch(value, scale, mask)
         return None if ll is None else ll.sum()
 
+    def fused_linear_term(self, value, scale=1.0, mask=None):
+        """(ll[lead shape], [(w, d ll.sum()/d w), (b, d ll.sum()/d b)]) from ONE pass over X, with
+        no autograd node: fused.SiteBatch carries the two gradients in its own backward launch."""
+        lz = self.lazy
+        args = self._glm_args(value, scale, mask)
+        if args is None or not isinstance(lz.w, torch.Tensor):
+            return None
+        w2, b1, mask = args
+        with torch.no_grad():
+            if isinstance(lz, GroupedLinearLogits):
+                from .. import kernels
+                ll, gw, gb = kernels.glm_bernoulli_grouped_fwd_bwd(lz.X, value.contiguous(), w2, b1,
+                                                                   mask, float(scale), lz.segments)
+            else:
+                from .. import kernels
+                ll, gw, gb = kernels.glm_bernoulli_fwd_bwd(lz.X, value.contiguous(), w2, b1, mask,
+                                                           float(scale))
+        targets = []
+        if lz.w.numel() == gw.numel():
+            targets.append((lz.w, gw.reshape(lz.w.shape)))
+        elif lz.w.requires_grad:
+            return None            # w was broadcast over particles: take the autograd route
+        if lz.b is not None and isinstance(lz.b, torch.Tensor):
+            if lz.b.numel() == gb.numel():
+                targets.append((lz.b, gb.reshape(lz.b.shape)))
+            elif lz.b.requires_grad:
+                return None
+        return ll.reshape(lz.shape[:-1]), targets
+
+    def _glm_args(self, value, scale, mask):
+        lz = self.lazy
+        N = lz.X.shape[0]
+        if isinstance(scale, torch.Tensor) or not _maskable(mask):
+            return None
+        if value.dim() != 1 or value.shape[0] != N:
+            return None
+        if lz.X.dtype != torch.float32 and not self._allow_f64:
+            return None
+        if mask is not None:
+            if mask.dim() != 1 or mask.shape[0] != N:
+                return None
+            mask = mask.contiguous()
+        if lz.X.shape[1] > 128 or not lz.X.is_contiguous():
+            return None
+        w2, b1 = lz.flat_params()
+        return w2, b1, mask
+
     def fused_log_prob_batch(self, value, scale=1.0, mask=None):
         """Per-particle / per-chain sums over the data plate: a tensor of the lazy logits'
         leading shape (one fused GLM pass for all of them)."""

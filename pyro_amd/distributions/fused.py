@@ -177,6 +177,7 @@ class _MeanFieldSample(torch.autograd.Function):
                                                                   offset_dev)
         ctx.P, ctx.nsites = P, len(locs)
         ctx.shapes = [p.shape for p in params]
+        ctx.params = params if GRAD_SINK else None
         ctx.save_for_backward(*rhos, *epss)
         out = []
         for z, sc, lo in zip(zs, scales, louts):
@@ -188,12 +189,29 @@ class _MeanFieldSample(torch.autograd.Function):
         k = ctx.nsites
         saved = ctx.saved_tensors
         rhos, epss = saved[:k], saved[k:]
+        # gradient sink: when both leaves of a site already own a dense .grad (the views into the
+        # optimizer's flat gradient buffer), the kernel adds into it directly and autograd is told
+        # "no gradient" -- one AccumulateGrad add launch per parameter less
+        sinks = None
+        if ctx.params is not None:
+            sinks = []
+            for i in range(k):
+                pl, pr = ctx.params[2 * i], ctx.params[2 * i + 1]
+                ok = all(p.is_leaf and p.grad is not None and p.grad.is_contiguous()
+                         and p.grad.dtype == p.dtype and p.grad.device == p.device
+                         and p.grad.grad_fn is None and not p._backward_hooks for p in (pl, pr))
+                sinks.append((pl.grad.reshape(-1), pr.grad.reshape(-1)) if ok else None)
         d_locs, d_rhos = kernels.meanfield_normal_sample_bwd(
-            rhos, epss, grads[0::3], grads[1::3], grads[2::3], ctx.P)
+            rhos, epss, grads[0::3], grads[1::3], grads[2::3], ctx.P, sinks)
         out = []
         for i in range(k):
-            out += [d_locs[i].reshape(ctx.shapes[2 * i]), d_rhos[i].reshape(ctx.shapes[2 * i + 1])]
+            out += [None if d_locs[i] is None else d_locs[i].reshape(ctx.shapes[2 * i]),
+                    None if d_rhos[i] is None else d_rhos[i].reshape(ctx.shapes[2 * i + 1])]
         return (None, None, None, None) + tuple(out)
+
+
+# _MeanFieldSample.backward adds straight into existing parameter .grad buffers (see there)
+GRAD_SINK = True
 
 
 def meanfield_sample(locs, rhos, P):
@@ -262,13 +280,15 @@ class _MultiLogProbSum(torch.autograd.Function):
     """total = coef_all * sum_e coef_e * sum(mask_e ? log_prob_e(value_e; p0_e, p1_e) : 0) over a
     table of small entries: ONE launch forward (pa_multi_log_prob_sum), ONE launch backward that
     writes every operand gradient already reduced to the operand's shape
-    (pa_multi_log_prob_grad)."""
+    (pa_multi_log_prob_grad).  Entries that score the same value tensor (a latent's prior and its
+    guide density) are chained: their value gradients arrive summed, in one buffer.  ``extras`` are
+    terms whose gradient w.r.t. one of the value tensors is already known (the fused GLM site)."""
 
     @staticmethod
-    def forward(ctx, meta, coef_all, *tensors):
+    def forward(ctx, meta, extras, coef_all, *tensors):
         entries = _MultiLogProbSum._entries(meta, tensors, None)
         proto = tensors[0]
-        ctx.meta, ctx.coef_all = meta, coef_all
+        ctx.meta, ctx.extras, ctx.coef_all = meta, extras, coef_all
         ctx.save_for_backward(*tensors)
         return kernels.multi_log_prob_sum(entries, coef_all, proto.dtype, proto.device)
 
@@ -289,9 +309,42 @@ class _MultiLogProbSum(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        from .. import _lib
         tensors = ctx.saved_tensors
-        needs = ctx.needs_input_grad[2:]
+        needs = ctx.needs_input_grad[3:]
         entries = _MultiLogProbSum._entries(ctx.meta, tensors, needs)
+        # position of every entry's value among the inputs
+        pos, i = [], 0
+        for dist_id, nops, mask, coef in ctx.meta:
+            pos.append(i)
+            i += nops
+
+        def unreduced(e):
+            v = e["value"]
+            return not ((v.shape[0] == 1 or v.stride(0) == 0) and e["rows"] > 1) and \
+                not ((v.shape[1] == 1 or v.stride(1) == 0) and e["cols"] > 1)
+
+        # chain entries scoring the same tensor (within one launch of PA_MULTI_MAX_ENTRIES entries)
+        heads = {}
+        for k, e in enumerate(entries):
+            if not e["need"][0] or not unreduced(e):
+                continue
+            key = (id(tensors[pos[k]]), k // _lib.MULTI_MAX_ENTRIES, e["rows"], e["cols"])
+            if key in heads:
+                tail = heads[key]
+                while entries[tail].get("chain_next", -1) >= 0:
+                    tail = entries[tail]["chain_next"]
+                entries[tail]["chain_next"] = k
+                e["by_chain"] = True
+            else:
+                heads[key] = k
+        for target_pos, xg, xcoef in ctx.extras:
+            for (tid, _, _, _), k in heads.items():
+                if tid == id(tensors[target_pos]) and "extra_grad" not in entries[k]:
+                    entries[k]["extra_grad"], entries[k]["extra_coef"] = xg, xcoef
+                    break
+            else:
+                raise RuntimeError("pyro_amd: no value-gradient carrier for an extra term")
         proto = tensors[0]
         grads = kernels.multi_log_prob_grad(g, entries, ctx.coef_all, proto.dtype, proto.device)
         out, i = [], 0
@@ -300,7 +353,7 @@ class _MultiLogProbSum(torch.autograd.Function):
                 t = tensors[i + j]
                 out.append(None if gs[j] is None else gs[j].reshape(t.shape))
             i += nops
-        return (None, None) + tuple(out)
+        return (None, None, None) + tuple(out)
 
 
 class SiteBatch:
@@ -309,6 +362,11 @@ class SiteBatch:
 
     def __init__(self):
         self.meta, self.tensors, self.const = [], [], 0.0
+        self.extras = []          # (target tensor, known gradient, coef)
+
+    def _compatible(self, x):
+        return not self.tensors or (x.dtype == self.tensors[0].dtype
+                                    and x.device == self.tensors[0].device)
 
     def add_site(self, dist_id, value, p0, p1, mask, scale, sign):
         """True if the site was taken into the batch."""
@@ -316,8 +374,7 @@ class SiteBatch:
             return False
         if mask is not None and mask.dtype != torch.bool:
             mask = mask.bool()
-        if self.tensors and (value.dtype != self.tensors[0].dtype
-                             or value.device != self.tensors[0].device):
+        if not self._compatible(value):
             return False
         if _entry_frame(dist_id, value, p0, p1, mask) is None:
             return False
@@ -332,7 +389,7 @@ class SiteBatch:
         if not isinstance(x, torch.Tensor):
             self.const += float(sign) * float(x)
             return True
-        if self.tensors and (x.dtype != self.tensors[0].dtype or x.device != self.tensors[0].device):
+        if not self._compatible(x):
             return False
         if not x.is_floating_point() or _entry_frame(_lib.SITE_IDENTITY, x, None, None, None) is None:
             return False
@@ -340,12 +397,46 @@ class SiteBatch:
         self.tensors.append(x)
         return True
 
+    def add_linear_term(self, x, targets, sign):
+        """sign * x.sum() where ``x`` carries no autograd history but its gradient w.r.t. each
+        tensor of ``targets`` = [(tensor, d x.sum() / d tensor), ...] is known: the gradients ride
+        in the batch's backward launch (added to the value gradient of the entries that score the
+        same tensor) instead of an autograd node of their own."""
+        from .. import _lib
+        assert not x.requires_grad
+        targets = [(t, gt) for t, gt in targets if t is not None and t.requires_grad]
+        for t, gt in targets:
+            if not self._compatible(t) or gt.dtype != t.dtype or gt.numel() != t.numel() \
+                    or t.numel() > _lib.MULTI_MAX_ELEMS:
+                return False
+        if not self.add_term(x, sign):
+            return False
+        for t, gt in targets:
+            self.extras.append((t, gt.contiguous(), float(sign)))
+        return True
+
     def total(self, coef_all=1.0):
         """coef_all * (sum of everything added); a 0-dim tensor (or a float if nothing but
         constants was added)."""
+        from .. import _lib
         if not self.tensors:
             return coef_all * self.const
-        out = _MultiLogProbSum.apply(tuple(self.meta), float(coef_all), *self.tensors)
+        meta, tensors, extras = list(self.meta), list(self.tensors), []
+        for t, gt, coef in self.extras:
+            # the known gradient needs an entry that produces d/dt un-reduced: one scoring t itself
+            # (found by identity among the value operands) or a carrier entry added for it
+            pos, i = None, 0
+            for dist_id, nops, mask, c in meta:
+                if tensors[i] is t:
+                    pos = i
+                    break
+                i += nops
+            if pos is None:
+                pos = len(tensors)
+                meta.append((_lib.SITE_NONE, 1, None, 0.0))
+                tensors.append(t)
+            extras.append((pos, gt, coef))
+        out = _MultiLogProbSum.apply(tuple(meta), tuple(extras), float(coef_all), *tensors)
         if self.const != 0.0:
             out = out + coef_all * self.const
         return out

@@ -198,16 +198,20 @@ def multi_log_prob_sum(entries, coef_all, dtype, device):
             _require_gpu(e["value"], e["p0"], e["p1"], e["mask"])
             arr[k] = _lib.SiteEntry(e["dist"], 0, rows, cols, _view(e["value"], rows, cols),
                                     _view(e["p0"], rows, cols), _view(e["p1"], rows, cols),
-                                    _view(e["mask"], rows, cols), float(e["coef"]), None, None, None)
+                                    _view(e["mask"], rows, cols), float(e["coef"]), None, None, None,
+                                    -1, 0, None, 0.0)
         check(lib.pa_multi_log_prob_sum(_DTYPES[dtype], _ptr(out), arr, len(chunk), float(coef_all),
                                         1 if lo > 0 else 0, _stream()))
     return out
 
 
 def multi_log_prob_grad(g, entries, coef_all, dtype, device):
-    """Backward of multi_log_prob_sum: ``entries`` as above plus ``need`` = (bool, bool, bool).
-    Returns per entry a tuple (d_value, d_p0, d_p1) of tensors already reduced to the operand's
-    own 2-D broadcast shape [rows or 1, cols or 1] (None where not needed)."""
+    """Backward of multi_log_prob_sum: ``entries`` as above plus ``need`` = (bool, bool, bool) and
+    optionally ``chain_next`` (index of the next entry scoring the SAME value tensor: the head's
+    d_value receives the sum), ``by_chain`` (this entry's value gradient comes from a chain head),
+    ``extra_grad`` / ``extra_coef`` (a known gradient added to d_value).  Chains must not straddle
+    a PA_MULTI_MAX_ENTRIES boundary.  Returns per entry a tuple (d_value, d_p0, d_p1) of tensors
+    already reduced to the operand's own 2-D broadcast shape (None where not produced)."""
     lib = _lib.load()
     _require_gpu(g)
     assert g.numel() == 1
@@ -221,16 +225,28 @@ def multi_log_prob_grad(g, entries, coef_all, dtype, device):
             views = [_view(e["value"], rows, cols), _view(e["p0"], rows, cols),
                      _view(e["p1"], rows, cols)]
             grads, need_bits = [], 0
+            by_chain = bool(e.get("by_chain", False))
             for j, (need, src) in enumerate(zip(e["need"], (e["value"], e["p0"], e["p1"]))):
-                if need and src is not None:
+                if need and src is not None and not (j == 0 and by_chain):
                     grads.append(torch.empty(_reduced_shape(views[j], rows, cols), dtype=dtype,
                                              device=device))
                     need_bits |= 1 << j
                 else:
                     grads.append(None)
+            if by_chain:
+                need_bits |= _lib.NEED_VALUE | _lib.VALUE_BY_CHAIN
+            nxt = e.get("chain_next", -1)
+            if nxt >= 0:
+                assert lo <= nxt < lo + len(chunk), "a gradient chain straddles two launches"
+                nxt -= lo
+            xg = e.get("extra_grad")
+            if xg is not None:
+                _require_gpu(xg)
+                assert xg.is_contiguous() and xg.numel() == rows * cols and xg.dtype == dtype
             arr[k] = _lib.SiteEntry(e["dist"], need_bits, rows, cols, views[0], views[1], views[2],
                                     _view(e["mask"], rows, cols), float(e["coef"]),
-                                    _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]))
+                                    _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), nxt, 0,
+                                    _ptr(xg), float(e.get("extra_coef", 0.0)))
             outs.append(tuple(grads))
         check(lib.pa_multi_log_prob_grad(_DTYPES[dtype], _ptr(g), arr, len(chunk), float(coef_all),
                                          _stream()))
@@ -257,15 +273,18 @@ def meanfield_normal_sample(locs, rhos, P, seed, offsets, offset_dev=None):
             lout = torch.empty((n,), dtype=dtype, device=device)
             zs.append(z); scales.append(sc); louts.append(lout); epss.append(eps)
             arr[k - lo] = _lib.MfSite(_ptr(locs[k]), _ptr(rhos[k]), _ptr(z), _ptr(sc), _ptr(lout),
-                                      _ptr(eps), n, int(offsets[k]), None, None, None, None, None)
+                                      _ptr(eps), n, int(offsets[k]), 0, 0, None, None, None, None,
+                                      None)
         check(lib.pa_meanfield_normal_sample(_DTYPES[dtype], arr, hi - lo, int(P), int(seed),
                                              _ptr(offset_dev), _stream()))
     return zs, scales, louts, epss
 
 
-def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P):
+def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P, sinks=None):
     """Backward of meanfield_normal_sample: d_zs[k] [P, n], d_scales[k] [n], d_louts[k] [n] (each
-    may be None = zero) -> lists (d_loc [n], d_rho [n])."""
+    may be None = zero) -> lists (d_loc [n], d_rho [n]).  ``sinks[k]`` = (grad_loc, grad_rho)
+    contiguous tensors the results are ADDED to instead (the optimizer's flat gradient views);
+    the returned entries are None for those sites."""
     lib = _lib.load()
     dtype, device = rhos[0].dtype, rhos[0].device
     d_locs, d_rhos = [], []
@@ -278,12 +297,20 @@ def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P):
             dz, ds, dl_in = (None if t is None else t.contiguous()
                              for t in (d_zs[k], d_scales[k], d_louts[k]))
             _require_gpu(rhos[k], epss[k], dz, ds, dl_in)
-            dl = torch.empty((n,), dtype=dtype, device=device)
-            dr = torch.empty((n,), dtype=dtype, device=device)
-            d_locs.append(dl); d_rhos.append(dr)
+            sink = None if sinks is None else sinks[k]
+            if sink is not None:
+                dl, dr = sink
+                _require_gpu(dl, dr)
+                assert dl.is_contiguous() and dr.is_contiguous() and dl.numel() == n == dr.numel()
+                d_locs.append(None); d_rhos.append(None)
+            else:
+                dl = torch.empty((n,), dtype=dtype, device=device)
+                dr = torch.empty((n,), dtype=dtype, device=device)
+                d_locs.append(dl); d_rhos.append(dr)
             keep += [dz, ds, dl_in]
             arr[k - lo] = _lib.MfSite(None, _ptr(rhos[k]), None, None, None, _ptr(epss[k]), n, 0,
-                                      _ptr(dz), _ptr(ds), _ptr(dl_in), _ptr(dl), _ptr(dr))
+                                      1 if sink is not None else 0, 0, _ptr(dz), _ptr(ds),
+                                      _ptr(dl_in), _ptr(dl), _ptr(dr))
         check(lib.pa_meanfield_normal_sample_bwd(_DTYPES[dtype], arr, hi - lo, int(P), _stream()))
         del keep
     return d_locs, d_rhos

@@ -150,6 +150,14 @@ class Trace:
                         raise self._site_error(name, site, e) from e
                     if entry is not None and batch.add_site(*entry, sign):
                         continue
+                lin_fn = getattr(fn, "fused_linear_term", None) if plain else None
+                if lin_fn is not None and torch.is_grad_enabled():
+                    try:
+                        lin = lin_fn(value, scale, mask)   # (ll, [(tensor, known gradient), ...])
+                    except ValueError as e:
+                        raise self._site_error(name, site, e) from e
+                    if lin is not None and batch.add_linear_term(lin[0], lin[1], sign):
+                        continue
                 batch_fn = getattr(fn, "fused_log_prob_batch", None) if plain else None
                 if batch_fn is not None:
                     try:

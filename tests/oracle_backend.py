@@ -84,6 +84,8 @@ def multi_log_prob_sum(entries, coef_all, dtype, device):
     tot = 0.0
     for e in entries:
         v, a, b, m = _entry_np(e)
+        if e["dist"] == 101:
+            continue
         lp = v if e["dist"] == 100 else o_dists.LOG_PROB[e["dist"]](v, a, b)
         if m is not None:
             lp = np.where(m, lp, 0.0)
@@ -92,27 +94,40 @@ def multi_log_prob_sum(entries, coef_all, dtype, device):
 
 
 def multi_log_prob_grad(g, entries, coef_all, dtype, device):
-    outs = []
-    for e in entries:
+    def operand_grad(e, j):
         rows, cols = e["rows"], e["cols"]
         v, a, b, m = _entry_np(e)
         if e["dist"] == 100:
-            grads = (np.ones_like(v), None, None)
+            d = np.ones_like(v) if j == 0 else None
+        elif e["dist"] == 101:
+            d = np.zeros_like(v) if j == 0 else None
         else:
-            grads = o_dists.log_prob_grad(e["dist"], v, a, b)
-        w = float(g) * coef_all * e["coef"]
+            d = o_dists.log_prob_grad(e["dist"], v, a, b)[j]
+        x = float(g) * coef_all * e["coef"] * np.broadcast_to(d, (rows, cols))
+        if m is not None:
+            x = np.where(m, x, 0.0)
+        src = (e["value"], e["p0"], e["p1"])[j]
+        if (src.shape[0] == 1 or src.stride(0) == 0) and rows > 1:
+            x = x.sum(0, keepdims=True)
+        if (src.shape[1] == 1 or src.stride(1) == 0) and cols > 1:
+            x = x.sum(1, keepdims=True)
+        return x
+
+    outs = []
+    for e in entries:
         res = []
-        for need, src, d in zip(e["need"], (e["value"], e["p0"], e["p1"]), grads):
-            if not need or src is None:
+        for j, (need, src) in enumerate(zip(e["need"], (e["value"], e["p0"], e["p1"]))):
+            if not need or src is None or (j == 0 and e.get("by_chain")):
                 res.append(None)
                 continue
-            x = w * np.broadcast_to(d, (rows, cols))
-            if m is not None:
-                x = np.where(m, x, 0.0)
-            if (src.shape[0] == 1 or src.stride(0) == 0) and rows > 1:
-                x = x.sum(0, keepdims=True)
-            if (src.shape[1] == 1 or src.stride(1) == 0) and cols > 1:
-                x = x.sum(1, keepdims=True)
+            x = operand_grad(e, j)
+            if j == 0:
+                k = e.get("chain_next", -1)
+                while k >= 0:
+                    x = x + operand_grad(entries[k], 0)
+                    k = entries[k].get("chain_next", -1)
+                if e.get("extra_grad") is not None:
+                    x = x + float(g) * coef_all * e["extra_coef"] * _np(e["extra_grad"]).reshape(x.shape)
             res.append(torch.as_tensor(np.ascontiguousarray(x), dtype=dtype))
         outs.append(tuple(res))
     return outs
@@ -135,9 +150,9 @@ def meanfield_normal_sample(locs, rhos, P, seed, offsets, offset_dev=None):
     return zs, scales, louts, epss
 
 
-def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P):
+def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P, sinks=None):
     d_locs, d_rhos = [], []
-    for rho, eps, dz, ds, dlo in zip(rhos, epss, d_zs, d_scales, d_louts):
+    for k, (rho, eps, dz, ds, dlo) in enumerate(zip(rhos, epss, d_zs, d_scales, d_louts)):
         r = _np(rho).astype(np.float64)
         sl = np.zeros_like(r) if dz is None else _np(dz).astype(np.float64).sum(0)
         ss = np.zeros_like(r) if dz is None else (_np(dz).astype(np.float64) * _np(eps)).sum(0)
@@ -146,6 +161,11 @@ def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P):
         if dlo is not None:
             sl = sl + _np(dlo).astype(np.float64)
         sig = np.where(r > 20, 1.0, 1.0 / (1.0 + np.exp(-r)))
+        if sinks is not None and sinks[k] is not None:
+            sinks[k][0].add_(torch.as_tensor(sl, dtype=rho.dtype))
+            sinks[k][1].add_(torch.as_tensor(ss * sig, dtype=rho.dtype))
+            d_locs.append(None); d_rhos.append(None)
+            continue
         d_locs.append(torch.as_tensor(sl, dtype=rho.dtype))
         d_rhos.append(torch.as_tensor(ss * sig, dtype=rho.dtype))
     return d_locs, d_rhos
