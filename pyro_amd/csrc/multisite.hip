@@ -35,64 +35,119 @@ struct MultiArgs {
 };
 
 // The entry tables are kernel arguments passed BY VALUE and indexed with a run-time (uniform)
-// index.  Indexing the parameter object itself would make the compiler spill the whole table to
-// scratch memory in every thread; reading it through the kernarg segment pointer keeps the accesses
-// scalar loads from constant memory.  The table must be the FIRST kernel parameter (offset 0).
-template <typename A>
-__device__ __forceinline__ const A* kernarg_table() {
-  return (const A*)__builtin_amdgcn_kernarg_segment_ptr();   // address-space cast (constant -> generic)
+// index.  Indexing the parameter object itself makes the compiler spill the whole table to scratch
+// memory in every thread, and reading it through a generic pointer makes every field access a
+// separate (re-issued) vector load.  Instead ONE table element is copied out of the kernarg segment
+// through a constant-address-space pointer: scalar loads into SGPRs, done once.  The table must be
+// the FIRST kernel parameter (offset 0 of the kernarg segment).
+template <typename S>
+__device__ __forceinline__ S kernarg_load(uint32_t byte_offset) {
+  static_assert(sizeof(S) % 4 == 0, "kernarg element must be a multiple of 4 bytes");
+  typedef __attribute__((address_space(4))) const uint32_t* cptr;
+  typedef __attribute__((address_space(4))) const char* cbytes;
+  cptr p = (cptr)((cbytes)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset);
+  union { S s; uint32_t w[sizeof(S) / 4]; } u;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(S) / 4); ++i) u.w[i] = p[i];
+  return u.s;
 }
 
 constexpr int MULTI_THREADS = 1024;
+constexpr int UN = 8;   // independent iterations per batch: their loads are in flight together
 template <> struct NParams<PA_SITE_IDENTITY> { static constexpr int n = 1; };
 
-// entries are small (rows*cols <= PA_MULTI_MAX_ELEMS): 32-bit index arithmetic throughout
+// These kernels touch a few thousand elements: what they cost is dependent memory round trips
+// (~1 us each), not bandwidth.  Every loop therefore runs in batches of UN branch-free iterations
+// (out-of-range iterations read element 0 and are discarded), so that the loads of a batch are
+// issued back to back, and entries / operands are processed side by side wherever possible.
+// Entries are small (rows*cols <= PA_MULTI_MAX_ELEMS): 32-bit index arithmetic throughout.
+template <typename T>
+struct Elem {
+  T v, a, b;
+  bool keep;
+};
 template <int DIST, typename T>
-__device__ __forceinline__ double entry_sum(const EntryDev& e) {
-  const T* v = (const T*)e.v;
-  const T* a = (const T*)e.a;
-  const T* b = (const T*)e.b;
-  const uint32_t C = (uint32_t)e.cols, n = (uint32_t)(e.rows * e.cols);
-  const int32_t vsr = (int32_t)e.vsr, vsc = (int32_t)e.vsc, asr = (int32_t)e.asr,
-                asc = (int32_t)e.asc, bsr = (int32_t)e.bsr, bsc = (int32_t)e.bsc,
-                msr = (int32_t)e.msr, msc = (int32_t)e.msc;
-  T acc = T(0);
-  for (uint32_t i = threadIdx.x; i < n; i += MULTI_THREADS) {
-    const uint32_t r = i / C, c = i - r * C;
-    if (e.m != nullptr && e.m[r * msr + c * msc] == 0) continue;
-    T x;
-    if constexpr (DIST == PA_SITE_IDENTITY) {
-      x = v[r * vsr + c * vsc];
-    } else {
-      const T bb = NParams<DIST>::n > 1 ? b[r * bsr + c * bsc] : T(0);
-      x = Fam<DIST, T>::lp(v[r * vsr + c * vsc], a[r * asr + c * asc], bb);
-    }
-    acc += x;      // at most PA_MULTI_MAX_ELEMS / 1024 = 64 terms per thread; fp64 across threads
+__device__ __forceinline__ Elem<T> load_elem(const EntryDev& e, uint32_t r, uint32_t c, bool ok) {
+  r = ok ? r : 0u;
+  c = ok ? c : 0u;
+  Elem<T> x;
+  x.v = ((const T*)e.v)[r * (int32_t)e.vsr + c * (int32_t)e.vsc];
+  x.a = T(0);
+  x.b = T(0);
+  if constexpr (DIST < PA_DIST_COUNT) {
+    x.a = ((const T*)e.a)[r * (int32_t)e.asr + c * (int32_t)e.asc];
+    if (NParams<DIST>::n > 1) x.b = ((const T*)e.b)[r * (int32_t)e.bsr + c * (int32_t)e.bsc];
   }
-  return (double)acc;
+  x.keep = ok && (e.m == nullptr || e.m[r * (int32_t)e.msr + c * (int32_t)e.msc] != 0);
+  return x;
+}
+template <int DIST, typename T>
+__device__ __forceinline__ T elem_lp(const Elem<T>& x) {
+  if constexpr (DIST == PA_SITE_IDENTITY) return x.v;
+  else if constexpr (DIST == PA_SITE_NONE) return T(0);
+  else return Fam<DIST, T>::lp(x.v, x.a, x.b);
+}
+template <int DIST, typename T>
+__device__ __forceinline__ void elem_grad(const Elem<T>& x, T& gv, T& ga, T& gb) {
+  if constexpr (DIST == PA_SITE_IDENTITY) { gv = T(1); ga = T(0); gb = T(0); }
+  else if constexpr (DIST == PA_SITE_NONE) { gv = T(0); ga = T(0); gb = T(0); }
+  else Fam<DIST, T>::grad(x.v, x.a, x.b, gv, ga, gb);
 }
 
+#define PA_DISPATCH_ENTRY(DIST_ID, CALL)                                                         \
+  switch (DIST_ID) {                                                                             \
+    case PA_DIST_NORMAL: { constexpr int D_ = PA_DIST_NORMAL; CALL; } break;                     \
+    case PA_DIST_BERNOULLI_LOGITS: { constexpr int D_ = PA_DIST_BERNOULLI_LOGITS; CALL; } break; \
+    case PA_DIST_HALF_CAUCHY: { constexpr int D_ = PA_DIST_HALF_CAUCHY; CALL; } break;           \
+    case PA_DIST_LOG_NORMAL: { constexpr int D_ = PA_DIST_LOG_NORMAL; CALL; } break;             \
+    case PA_DIST_EXPONENTIAL: { constexpr int D_ = PA_DIST_EXPONENTIAL; CALL; } break;           \
+    case PA_DIST_HALF_NORMAL: { constexpr int D_ = PA_DIST_HALF_NORMAL; CALL; } break;           \
+    case PA_SITE_IDENTITY: { constexpr int D_ = PA_SITE_IDENTITY; CALL; } break;                 \
+    default: { constexpr int D_ = PA_SITE_NONE; CALL; } break;                                   \
+  }
+
+// sum of the masked log-densities of elements start, start + step, ... of entry e
+template <int DIST, typename T>
+__device__ __forceinline__ double entry_sum(const EntryDev& e, uint32_t start, uint32_t step) {
+  const uint32_t C = (uint32_t)e.cols, n = (uint32_t)(e.rows * e.cols);
+  T acc = T(0);
+  if constexpr (DIST == PA_SITE_NONE) return 0.0;
+  for (uint32_t base = start; base < n; base += UN * step) {
+    Elem<T> x[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const uint32_t i = base + u * step;
+      const uint32_t r = i / C;
+      x[u] = load_elem<DIST, T>(e, r, i - r * C, i < n);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc += x[u].keep ? elem_lp<DIST, T>(x[u]) : T(0);
+  }
+  return (double)acc;   // <= PA_MULTI_MAX_ELEMS / 64 terms per lane; fp64 across lanes
+}
+
+// ONE workgroup of 16 waves: the entries are spread over the waves (several waves per entry when
+// there are fewer than 16), so that all of them are read concurrently.
 template <typename T>
 __global__ __launch_bounds__(MULTI_THREADS) void multi_sum_kernel(const MultiArgs args_by_value,
                                                                   T* __restrict__ out,
                                                                   double coef_all, int accumulate) {
   __shared__ double smem[16];
-  const MultiArgs& args = *kernarg_table<MultiArgs>();
+  const int n_entries = kernarg_load<int>(offsetof(MultiArgs, n));
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  constexpr int NW = MULTI_THREADS / 64;
+  const int wpe = n_entries >= NW ? 1 : NW / (n_entries > 0 ? n_entries : 1);   // waves per entry
+  const int epr = NW / wpe;                                                     // entries per round
   double acc = 0.0;
-  for (int k = 0; k < args.n; ++k) {
-    const EntryDev& e = args.e[k];
-    double s = 0.0;
-    switch (e.dist) {
-      case PA_DIST_NORMAL: s = entry_sum<PA_DIST_NORMAL, T>(e); break;
-      case PA_DIST_BERNOULLI_LOGITS: s = entry_sum<PA_DIST_BERNOULLI_LOGITS, T>(e); break;
-      case PA_DIST_HALF_CAUCHY: s = entry_sum<PA_DIST_HALF_CAUCHY, T>(e); break;
-      case PA_DIST_LOG_NORMAL: s = entry_sum<PA_DIST_LOG_NORMAL, T>(e); break;
-      case PA_DIST_EXPONENTIAL: s = entry_sum<PA_DIST_EXPONENTIAL, T>(e); break;
-      case PA_DIST_HALF_NORMAL: s = entry_sum<PA_DIST_HALF_NORMAL, T>(e); break;
-      case PA_SITE_NONE: s = 0.0; break;
-      default: s = entry_sum<PA_SITE_IDENTITY, T>(e); break;
+  for (int k0 = 0; k0 < n_entries; k0 += epr) {
+    const int k = k0 + wave / wpe;
+    if (k < n_entries && wave / wpe < epr) {
+      const EntryDev e = kernarg_load<EntryDev>(offsetof(MultiArgs, e) + k * sizeof(EntryDev));
+      const uint32_t start = (uint32_t)((wave % wpe) * 64 + lane), step = (uint32_t)(wpe * 64);
+      double s = 0.0;
+      PA_DISPATCH_ENTRY(e.dist, s = (entry_sum<D_, T>(e, start, step)));
+      acc += e.coef * s;
     }
-    acc += e.coef * s;
   }
   const double t = block_sum_f64(acc, smem);
   if (threadIdx.x == 0) {
@@ -101,138 +156,197 @@ __global__ __launch_bounds__(MULTI_THREADS) void multi_sum_kernel(const MultiArg
   }
 }
 
-// gradient of one entry w.r.t. operand WHICH (0 value, 1 p0, 2 p1) at element (r, c)
+constexpr int GRAD_THREADS = 256;
+// thread groups along the summed dimension for tk threads along the kept one.  Capped: the groups'
+// partial sums are combined by ONE thread per kept index reading them back from LDS one after the
+// other (fixed order), and 256 dependent LDS reads cost more than the whole rest of the kernel.
+__device__ __forceinline__ uint32_t row_groups(uint32_t tk) {
+  const uint32_t ng = GRAD_THREADS / tk;
+  return ng > 8u ? 8u : ng;
+}
+enum { PAT_SKIP = 0, PAT_FULL = 1, PAT_ROWRED = 2, PAT_SCALAR = 3, PAT_COLRED = 4 };
+__device__ __forceinline__ int pattern_of(bool wanted, int64_t sr, int64_t sc, int64_t R, int64_t C) {
+  if (!wanted) return PAT_SKIP;
+  const bool red_r = (sr == 0 && R > 1), red_c = (sc == 0 && C > 1);
+  return red_r ? (red_c ? PAT_SCALAR : PAT_ROWRED) : (red_c ? PAT_COLRED : PAT_FULL);
+}
+
+// One pass over entry e that produces, side by side,
+//   the value gradient (un-reduced: written, or added when `accumulate`; plus the known extra term),
+//   the p0 and p1 gradients for the patterns FULL / ROWRED (summed over rows) / SCALAR.
+// Thread t owns column c = t % tk and the rows g, g + ng, ... (g = t / tk): a fixed element ->
+// thread map, so that chained passes over the same value buffer need no synchronisation.
 template <int DIST, typename T>
-__device__ __forceinline__ T entry_grad_at(const EntryDev& e, int which, uint32_t r, uint32_t c) {
-  if (e.m != nullptr && e.m[r * (int32_t)e.msr + c * (int32_t)e.msc] == 0) return T(0);
-  if constexpr (DIST == PA_SITE_IDENTITY) {
-    return T(1);
-  } else {
-    const T* v = (const T*)e.v;
-    const T* a = (const T*)e.a;
-    const T* b = (const T*)e.b;
-    const T bb = NParams<DIST>::n > 1 ? b[r * (int32_t)e.bsr + c * (int32_t)e.bsc] : T(0);
-    T gv, ga, gb;
-    Fam<DIST, T>::grad(v[r * (int32_t)e.vsr + c * (int32_t)e.vsc],
-                       a[r * (int32_t)e.asr + c * (int32_t)e.asc], bb, gv, ga, gb);
-    return which == 0 ? gv : (which == 1 ? ga : gb);
+__device__ __forceinline__ void combined_pass(const EntryDev& e, double w, int pv, bool accumulate,
+                                              const T* xg, T xw, int pa_, int pb_, double* red) {
+  const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols, t = threadIdx.x;
+  const uint32_t tk = C < GRAD_THREADS ? C : GRAD_THREADS, ng = row_groups(tk);
+  const uint32_t c0 = t % tk, g = t / tk;
+  T* dv = (T*)e.dv;
+  T* da = (T*)e.da;
+  T* db = (T*)e.db;
+  const T wT = (T)w;
+  T tot_a = T(0), tot_b = T(0);                 // SCALAR patterns: everything this thread saw
+  for (uint32_t cb = 0; cb < C; cb += tk) {
+    const uint32_t c = cb + c0;
+    const bool okc = g < ng && c < C;
+    T col_a = T(0), col_b = T(0);               // ROWRED patterns: this thread's column
+    for (uint32_t rb = g; rb < R; rb += UN * ng) {
+      Elem<T> x[UN];
+      T old[UN], ex[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const uint32_t r = rb + u * ng;
+        const bool ok = okc && r < R;
+        x[u] = load_elem<DIST, T>(e, r, c, ok);
+        const uint32_t o = ok ? r * C + c : 0u;
+        old[u] = (pv == PAT_FULL && accumulate) ? dv[o] : T(0);
+        ex[u] = (pv == PAT_FULL && xg != nullptr) ? xg[o] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const uint32_t r = rb + u * ng;
+        const bool ok = okc && r < R;
+        T gv, ga, gb;
+        elem_grad<DIST, T>(x[u], gv, ga, gb);
+        gv = x[u].keep ? gv : T(0);
+        ga = x[u].keep ? ga : T(0);
+        gb = x[u].keep ? gb : T(0);
+        if (ok) {
+          const uint32_t o = r * C + c;
+          if (pv == PAT_FULL) dv[o] = old[u] + wT * gv + xw * ex[u];
+          if (pa_ == PAT_FULL) da[o] = wT * ga;
+          if (pb_ == PAT_FULL) db[o] = wT * gb;
+        }
+        col_a += ga;
+        col_b += gb;
+      }
+    }
+    tot_a += col_a;
+    tot_b += col_b;
+    if (pa_ == PAT_ROWRED || pb_ == PAT_ROWRED) {
+      __syncthreads();
+      red[t] = (double)col_a;
+      red[GRAD_THREADS + t] = (double)col_b;
+      __syncthreads();
+      if (g == 0 && c < C) {
+        double sa = 0.0, sb = 0.0;
+        for (uint32_t j = 0; j < ng; ++j) {
+          sa += red[j * tk + c0];
+          sb += red[GRAD_THREADS + j * tk + c0];
+        }
+        if (pa_ == PAT_ROWRED) da[c] = (T)(w * sa);
+        if (pb_ == PAT_ROWRED) db[c] = (T)(w * sb);
+      }
+    }
+  }
+  if (pa_ == PAT_SCALAR || pb_ == PAT_SCALAR) {
+    __syncthreads();
+    red[t] = (double)tot_a;
+    red[GRAD_THREADS + t] = (double)tot_b;
+    __syncthreads();
+    if (t < 64) {
+      double sa = 0.0, sb = 0.0;
+      for (uint32_t j = t; j < GRAD_THREADS; j += 64) {
+        sa += red[j];
+        sb += red[GRAD_THREADS + j];
+      }
+      sa = wave_sum(sa);
+      sb = wave_sum(sb);
+      if (t == 0) {
+        if (pa_ == PAT_SCALAR) da[0] = (T)(w * sa);
+        if (pb_ == PAT_SCALAR) db[0] = (T)(w * sb);
+      }
+    }
   }
 }
 
-constexpr int GRAD_THREADS = 256;
-
-// out (contiguous [rows or 1, cols or 1]) = w * reduce(grad) for operand `which`.  Reductions over
-// a dimension are spread over thread groups and combined through LDS in a fixed order.
+// generic single-operand pass (any pattern, incl. reductions over columns): the rarely needed
+// fallback for operands the combined pass does not cover
 template <int DIST, typename T>
-__device__ void entry_grad_operand(const EntryDev& e, int which, int64_t sr, int64_t sc, T* out,
-                                   double w, double* red /* [GRAD_THREADS] */,
-                                   bool accumulate = false) {
+__device__ __forceinline__ void operand_pass(const EntryDev& e, int which, int pat, T* out, double w,
+                                             double* red) {
   const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols, t = threadIdx.x;
-  const bool red_r = (sr == 0 && R > 1), red_c = (sc == 0 && C > 1);
-  if (!red_r && !red_c) {
-#pragma unroll 4
-    for (uint32_t i = t; i < R * C; i += GRAD_THREADS) {
-      const uint32_t r = i / C, c = i - r * C;
-      const T x = (T)(w * (double)entry_grad_at<DIST, T>(e, which, r, c));
-      out[i] = accumulate ? out[i] + x : x;
-    }
-  } else if (red_r != red_c) {
-    // K = kept dimension (its index is the output index), L = summed dimension
-    const uint32_t K = red_r ? C : R, L = red_r ? R : C;
-    const uint32_t tk = K < GRAD_THREADS ? K : GRAD_THREADS;   // threads along the kept dim
-    const uint32_t ng = GRAD_THREADS / tk;                     // groups along the summed dim
+  auto at = [&](uint32_t r, uint32_t c) -> T {
+    const Elem<T> x = load_elem<DIST, T>(e, r, c, true);
+    T gv, ga, gb;
+    elem_grad<DIST, T>(x, gv, ga, gb);
+    const T gsel = which == 0 ? gv : (which == 1 ? ga : gb);
+    return x.keep ? gsel : T(0);
+  };
+  if (pat == PAT_FULL) {
+    for (uint32_t i = t; i < R * C; i += GRAD_THREADS) out[i] = (T)(w * (double)at(i / C, i % C));
+  } else if (pat == PAT_ROWRED || pat == PAT_COLRED) {
+    const bool rr = pat == PAT_ROWRED;
+    const uint32_t K = rr ? C : R, L = rr ? R : C;
+    const uint32_t tk = K < GRAD_THREADS ? K : GRAD_THREADS, ng = row_groups(tk);
     const uint32_t k0 = t % tk, g = t / tk;
     for (uint32_t kb = 0; kb < K; kb += tk) {
       const uint32_t k = kb + k0;
       T acc = T(0);
-      if (g < ng && k < K) {
-#pragma unroll 4
-        for (uint32_t l = g; l < L; l += ng)
-          acc += red_r ? entry_grad_at<DIST, T>(e, which, l, k) : entry_grad_at<DIST, T>(e, which, k, l);
-      }
+      if (g < ng && k < K)
+        for (uint32_t l = g; l < L; l += ng) acc += rr ? at(l, k) : at(k, l);
       __syncthreads();
       red[t] = (double)acc;
       __syncthreads();
       if (g == 0 && k < K) {
-        double s = 0.0;
-        for (uint32_t j = 0; j < ng; ++j) s += red[j * tk + k0];
-        out[k] = (T)(w * s) + (accumulate ? out[k] : T(0));
+        double sacc = 0.0;
+        for (uint32_t j = 0; j < ng; ++j) sacc += red[j * tk + k0];
+        out[k] = (T)(w * sacc);
       }
     }
-    __syncthreads();
-  } else {                                // scalar operand
+  } else if (pat == PAT_SCALAR) {
     T acc = T(0);
-    for (uint32_t i = t; i < R * C; i += GRAD_THREADS) {
-      const uint32_t r = i / C, c = i - r * C;
-      acc += entry_grad_at<DIST, T>(e, which, r, c);
-    }
-    const double tot = block_sum_f64((double)acc, red);
-    if (t == 0) out[0] = (T)(w * tot) + (accumulate ? out[0] : T(0));
+    for (uint32_t i = t; i < R * C; i += GRAD_THREADS) acc += at(i / C, i % C);
     __syncthreads();
+    const double tot = block_sum_f64((double)acc, red);
+    if (t == 0) out[0] = (T)(w * tot);
   }
+  __syncthreads();
 }
 
-// value gradient of entry e into out (run-time family dispatch: chain members differ in family)
-template <typename T>
-__device__ void value_grad_pass(const EntryDev& e, T* out, double w, double* smem, bool accumulate) {
-  switch (e.dist) {
-#define PA_VG(D_) case D_: entry_grad_operand<D_, T>(e, 0, e.vsr, e.vsc, out, w, smem, accumulate); break;
-    PA_VG(PA_DIST_NORMAL) PA_VG(PA_DIST_BERNOULLI_LOGITS) PA_VG(PA_DIST_HALF_CAUCHY)
-    PA_VG(PA_DIST_LOG_NORMAL) PA_VG(PA_DIST_EXPONENTIAL) PA_VG(PA_DIST_HALF_NORMAL)
-    PA_VG(PA_SITE_IDENTITY)
-#undef PA_VG
-    default:   // PA_SITE_NONE: zero gradient
-      if (!accumulate) {
-        const bool red_r = (e.vsr == 0 && e.rows > 1), red_c = (e.vsc == 0 && e.cols > 1);
-        const uint32_t n = (uint32_t)((red_r ? 1 : e.rows) * (red_c ? 1 : e.cols));
-        for (uint32_t i = threadIdx.x; i < n; i += GRAD_THREADS) out[i] = T(0);
-      }
-      break;
-  }
-}
-
-template <int DIST, typename T>
-__device__ void param_grads(const EntryDev& e, double w, double* smem) {
-  if constexpr (DIST < PA_DIST_COUNT) {
-    if ((e.need & PA_NEED_P0) && e.da) entry_grad_operand<DIST, T>(e, 1, e.asr, e.asc, (T*)e.da, w, smem);
-    if (NParams<DIST>::n > 1 && (e.need & PA_NEED_P1) && e.db)
-      entry_grad_operand<DIST, T>(e, 2, e.bsr, e.bsc, (T*)e.db, w, smem);
-  }
-}
-
+// everything workgroup `blockIdx.x` owes for entry e: its own value gradient (unless a chain head
+// produces it) followed by the chained entries' contributions to the same buffer, and its p0 / p1
+// gradients -- the common patterns in one pass each
 template <typename T>
 __global__ __launch_bounds__(GRAD_THREADS) void multi_grad_kernel(const MultiArgs args_by_value,
                                                                   const T* __restrict__ g,
                                                                   double coef_all) {
-  __shared__ double smem[GRAD_THREADS];
-  const MultiArgs& args = *kernarg_table<MultiArgs>();
-  const EntryDev& e = args.e[blockIdx.x];
+  __shared__ double red[2 * GRAD_THREADS];
+  const EntryDev e =
+      kernarg_load<EntryDev>(offsetof(MultiArgs, e) + blockIdx.x * sizeof(EntryDev));
+  if (e.rows * e.cols == 0) return;
   const double gw = (double)g[0] * coef_all;
-  if ((e.need & PA_NEED_VALUE) && e.dv && !(e.need & PA_VALUE_BY_CHAIN)) {
-    T* out = (T*)e.dv;
-    value_grad_pass<T>(e, out, gw * e.coef, smem, false);
-    for (int k = e.chain_next; k >= 0; k = args.e[k].chain_next) {   // same value tensor, same frame
-      __syncthreads();
-      value_grad_pass<T>(args.e[k], out, gw * args.e[k].coef, smem, true);
-    }
-    if (e.xg != nullptr) {
-      __syncthreads();
-      const T* xg = (const T*)e.xg;
-      const T xw = (T)(gw * e.xcoef);
-      const uint32_t n = (uint32_t)(e.rows * e.cols);
-      for (uint32_t i = threadIdx.x; i < n; i += GRAD_THREADS) out[i] += xw * xg[i];
-    }
-    __syncthreads();
-  }
+  const bool own_value = (e.need & PA_NEED_VALUE) && e.dv && !(e.need & PA_VALUE_BY_CHAIN);
+  const bool param_family = e.dist >= 0 && e.dist < PA_DIST_COUNT;
+  int pv = pattern_of(own_value, e.vsr, e.vsc, e.rows, e.cols);
+  int pa_ = pattern_of(param_family && (e.need & PA_NEED_P0) && e.da, e.asr, e.asc, e.rows, e.cols);
+  int pb_ = pattern_of(param_family && (e.need & PA_NEED_P1) && e.db &&
+                           (e.dist == PA_DIST_NORMAL || e.dist == PA_DIST_LOG_NORMAL),
+                       e.bsr, e.bsc, e.rows, e.cols);
+  // what the combined pass cannot do goes through the generic per-operand passes first
+  const int pv_c = pv == PAT_FULL ? pv : PAT_SKIP;
+  const int pa_c = pa_ == PAT_COLRED ? PAT_SKIP : pa_;
+  const int pb_c = pb_ == PAT_COLRED ? PAT_SKIP : pb_;
   const double w = gw * e.coef;
-  switch (e.dist) {
-    case PA_DIST_NORMAL: param_grads<PA_DIST_NORMAL, T>(e, w, smem); break;
-    case PA_DIST_BERNOULLI_LOGITS: param_grads<PA_DIST_BERNOULLI_LOGITS, T>(e, w, smem); break;
-    case PA_DIST_HALF_CAUCHY: param_grads<PA_DIST_HALF_CAUCHY, T>(e, w, smem); break;
-    case PA_DIST_LOG_NORMAL: param_grads<PA_DIST_LOG_NORMAL, T>(e, w, smem); break;
-    case PA_DIST_EXPONENTIAL: param_grads<PA_DIST_EXPONENTIAL, T>(e, w, smem); break;
-    case PA_DIST_HALF_NORMAL: param_grads<PA_DIST_HALF_NORMAL, T>(e, w, smem); break;
-    default: break;
+  if (pv != PAT_SKIP && pv != PAT_FULL) {
+    PA_DISPATCH_ENTRY(e.dist, (operand_pass<D_, T>(e, 0, pv, (T*)e.dv, w, red)));
+  }
+  if (pa_ == PAT_COLRED) { PA_DISPATCH_ENTRY(e.dist, (operand_pass<D_, T>(e, 1, pa_, (T*)e.da, w, red))); }
+  if (pb_ == PAT_COLRED) { PA_DISPATCH_ENTRY(e.dist, (operand_pass<D_, T>(e, 2, pb_, (T*)e.db, w, red))); }
+  if (pv_c != PAT_SKIP || pa_c != PAT_SKIP || pb_c != PAT_SKIP) {
+    const T xw = (T)(gw * e.xcoef);
+    PA_DISPATCH_ENTRY(e.dist, (combined_pass<D_, T>(e, w, pv_c, false, (const T*)e.xg, xw, pa_c, pb_c, red)));
+  }
+  if (own_value && pv == PAT_FULL) {
+    for (int k = e.chain_next; k >= 0;) {   // same value tensor, same frame, same element->thread map
+      const EntryDev m = kernarg_load<EntryDev>(offsetof(MultiArgs, e) + k * sizeof(EntryDev));
+      EntryDev mm = m;
+      mm.dv = e.dv;
+      PA_DISPATCH_ENTRY(m.dist, (combined_pass<D_, T>(mm, gw * m.coef, PAT_FULL, true, (const T*)nullptr, T(0),
+                                                      PAT_SKIP, PAT_SKIP, red)));
+      k = m.chain_next;
+    }
   }
 }
 
@@ -302,7 +416,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void meanfield_sample_kernel(const MfArgs args_by_value,
                                                                int64_t P, uint64_t seed,
                                                                const uint64_t* __restrict__ offset_dev) {
-  const MfSiteDev& s = kernarg_table<MfArgs>()->s[blockIdx.y];
+  const MfSiteDev s = kernarg_load<MfSiteDev>(offsetof(MfArgs, s) + blockIdx.y * sizeof(MfSiteDev));
   const uint64_t off = s.offset + (offset_dev ? *offset_dev : 0);
   const T* loc = (const T*)s.loc;
   const T* rho = (const T*)s.rho;
@@ -331,7 +445,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void meanfield_sample_bwd_kernel(const MfArgs args_by_value,
                                                                    int64_t P) {
   __shared__ double red_l[256], red_s[256];
-  const MfSiteDev& s = kernarg_table<MfArgs>()->s[blockIdx.x];
+  const MfSiteDev s = kernarg_load<MfSiteDev>(offsetof(MfArgs, s) + blockIdx.x * sizeof(MfSiteDev));
   const T* dz = (const T*)s.d_z;
   const T* eps = (const T*)s.eps;
   const T* dsc = (const T*)s.d_scale;
@@ -340,18 +454,34 @@ __global__ __launch_bounds__(256) void meanfield_sample_bwd_kernel(const MfArgs 
   T* dloc = (T*)s.d_loc;
   T* drho = (T*)s.d_rho;
   const uint32_t n = (uint32_t)s.n, t = threadIdx.x, PP = (uint32_t)P;
-  const uint32_t tk = n < 256 ? n : 256, ng = 256 / tk, c0 = t % tk, g = t / tk;
+  if (n == 0) return;
+  const uint32_t tk = n < 256 ? n : 256, ng = row_groups(tk), c0 = t % tk, g = t / tk;
   for (uint32_t cb = 0; cb < n; cb += tk) {
     const uint32_t c = cb + c0;
+    const bool okc = g < ng && c < n;
+    // the per-column inputs of the epilogue are requested up front, next to the first batch
+    const uint32_t cc = c < n ? c : 0u;
+    const T v_dsc = dsc != nullptr ? dsc[cc] : T(0), v_dlo = dlo != nullptr ? dlo[cc] : T(0);
+    const T v_rho = rho[cc];
+    const T v_ol = (s.accumulate && dloc) ? dloc[cc] : T(0), v_or = (s.accumulate && drho) ? drho[cc] : T(0);
     T al = T(0), as = T(0);
-    if (dz != nullptr && g < ng && c < n) {
-#pragma unroll 8
-      for (uint32_t p = g; p < PP; p += ng) {
-        const T gz = dz[p * n + c];
-        al += gz;
-        as += gz * eps[p * n + c];
+    if (dz != nullptr)
+      for (uint32_t pb = g; pb < PP; pb += UN * ng) {
+        T gz[UN], ev[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const uint32_t p = pb + u * ng;
+          const uint32_t o = (okc && p < PP) ? p * n + c : 0u;
+          gz[u] = dz[o];
+          ev[u] = eps[o];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const bool ok = okc && (pb + u * ng) < PP;
+          al += ok ? gz[u] : T(0);
+          as += ok ? gz[u] * ev[u] : T(0);
+        }
       }
-    }
     __syncthreads();
     red_l[t] = (double)al;
     red_s[t] = (double)as;
@@ -362,12 +492,18 @@ __global__ __launch_bounds__(256) void meanfield_sample_bwd_kernel(const MfArgs 
         sl += red_l[j * tk + c0];
         ss += red_s[j * tk + c0];
       }
-      if (dsc != nullptr) ss += (double)dsc[c];
-      if (dlo != nullptr) sl += (double)dlo[c];
-      const double x = (double)rho[c];
-      const double sig = x > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-x));   // d softplus / d x
-      if (dloc) dloc[c] = (T)sl + (s.accumulate ? dloc[c] : T(0));
-      if (drho) drho[c] = (T)(ss * sig) + (s.accumulate ? drho[c] : T(0));
+      ss += (double)v_dsc;
+      sl += (double)v_dlo;
+      double sig;                                   // d softplus / d x (1 beyond the threshold)
+      if constexpr (sizeof(T) == 8) {
+        const double x = (double)v_rho;
+        sig = x > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-x));
+      } else {
+        const float x = (float)v_rho;
+        sig = x > 20.0f ? 1.0 : (double)(1.0f / (1.0f + expf(-x)));
+      }
+      if (dloc) dloc[c] = (T)sl + v_ol;
+      if (drho) drho[c] = (T)(ss * sig) + v_or;
     }
   }
 }
