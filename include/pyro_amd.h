@@ -93,6 +93,13 @@ int pa_philox_uniform(void* out, int64_t n, int dtype, uint64_t seed, uint64_t o
 /* *counter += inc, executed on the stream (keeps a device-resident Philox offset moving
  * under hipGraph replay). */
 int pa_counter_add(uint64_t* counter, uint64_t inc, pa_stream_t stream);
+/* End-of-step node of a captured SVI step (pyro/infer/svi.py:134-162 returns the loss as a Python
+ * float, i.e. synchronises every step): *counter += inc (counter may be NULL), then the scalar at
+ * `src` (device, `dtype`) is stored as a double to `host_value` and `*host_seq` is incremented
+ * behind a system-scope release fence.  host_value / host_seq are PINNED host memory (device
+ * mapped): the host polls host_seq instead of calling a stream synchronisation or a D2H copy. */
+int pa_publish_scalar(int dtype, const void* src, double* host_value, uint64_t* host_seq,
+                      uint64_t* counter, uint64_t inc, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Element-wise site kernels (SURVEY 8a rows a1,a3,a4,a5).

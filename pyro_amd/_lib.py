@@ -68,6 +68,7 @@ _SIGNATURES = {
     "pa_philox_normal": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "pa_philox_uniform": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "pa_counter_add": (c_int, [c_void_p, c_uint64, c_void_p]),
+    "pa_publish_scalar": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "pa_dist_log_prob": (c_int, [c_int, c_int, c_void_p, View2D, View2D, View2D, c_int64, c_int64,
                                  c_void_p]),
     "pa_dist_log_prob_sum_workspace": (c_size_t, [c_int64, c_int64]),

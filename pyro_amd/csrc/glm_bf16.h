@@ -36,6 +36,8 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8v __attribute__((ext_vector_type(8)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16* lds_v4i16_ptr;
 
 constexpr int GLMB_WAVES = 4;
 
@@ -62,14 +64,18 @@ __device__ __forceinline__ float bf16_hi(uint32_t p) {
 }
 
 // (a, b) -> three packed bf16 pairs with a = a1+a2+a3, b = b1+b2+b3 (exact for finite inputs whose
-// leading piece does not overflow bf16)
+// leading piece does not overflow bf16).  Written on 2-vectors so that the residuals are one
+// v_pk_add_f32 each.
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& p1, uint32_t& p2,
                                            uint32_t& p3) {
-  p1 = cvt_pk_bf16(a, b);
-  const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
-  p2 = cvt_pk_bf16(ra, rb);
-  const float sa = ra - bf16_lo(p2), sb = rb - bf16_hi(p2);
-  p3 = cvt_pk_bf16(sa, sb);
+  const f32x2v v = {a, b};
+  p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32
+  const f32x2v f1 = {bf16_lo(p1), bf16_hi(p1)};
+  const f32x2v r = v - f1;
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+  const f32x2v f2 = {bf16_lo(p2), bf16_hi(p2)};
+  const f32x2v q = r - f2;
+  p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, bf16x2));
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
@@ -90,7 +96,8 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
   using C = GlmBfCfg<DT, PT>;
   constexpr int DP = C::DP, KC = C::KC, RS = C::RS, PLANE = C::PLANE, WROWS = C::WROWS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar
   const int l31 = lane & 31, h = lane >> 5;
   unsigned char* Wp = smem;
   uint32_t* waux = reinterpret_cast<uint32_t*>(smem + C::W_BYTES);
@@ -124,24 +131,36 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
   const int D4 = D >> 2;                      // float4 per row
   const int64_t total_e = row_end * (int64_t)D;
 
-  // Loads use CLAMPED addresses and are consumed raw; validity is applied when the tile is split,
-  // a whole tile of compute later (a select next to the load would make the compiler wait for the
-  // load right there and expose the HBM latency on every tile).  A tile index past the end simply
-  // loads in-range garbage that is masked out: the loop body has no branches.
+  // Loads use CLAMPED addresses and are consumed raw, a whole tile of compute later (a select next
+  // to the load would make the compiler wait for the load right there and expose the HBM latency
+  // on every tile).  All per-tile address arithmetic is scalar (the tile index is wave-uniform):
+  // per load one v_min_u32 of the lane's constant offset against the tile's last valid offset.
+  // Rows past the end of the plate / segment (and whole tiles past it) read in-range data of other
+  // rows and are switched off through the -1e30 row offset: their X values never matter (a
+  // non-finite X entry anywhere makes the result non-finite either way).  No branches in the loop.
+  uint32_t lofs[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) lofs[j] = (j * 64 + lane < 8 * D) ? 4u * (uint32_t)(j * 64 + lane) : 0u;
+  const int64_t all_e = N * (int64_t)D;
   auto issue_loads = [&](int64_t tile) {
     const int64_t base = (row_begin + tile * 32) * (int64_t)D;
+    const bool tv = base < total_e;
+    const int64_t sb = tv ? base : 0;
+    const int64_t rem = (tv ? total_e : all_e) - sb;                 // >= D >= 4
+    const uint32_t lim = (uint32_t)(rem < 32 * (int64_t)D ? rem : 32 * (int64_t)D) - 4u;
+    const float* Xb = X + sb;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int f = j * 64 + lane;            // float4 index inside the tile
-      const int64_t e = base + 4 * (int64_t)f;
-      const bool ok = (f < 8 * D) && (e < total_e);
-      stage[j] = *reinterpret_cast<const float4*>(X + (ok ? e : 0));
+      const uint32_t off = lofs[j] < lim ? lofs[j] : lim;
+      stage[j] = *reinterpret_cast<const float4*>(Xb + off);
     }
-    const int64_t n = row_begin + tile * 32 + l31;
-    const int64_t nc = n < row_end ? n : 0;
-    st_y = y[nc];
+    const int64_t rb = tv ? row_begin + tile * 32 : 0;
+    const int64_t rrem = (tv ? row_end : N) - rb;                    // >= 1
+    const uint32_t rlim = (uint32_t)(rrem < 32 ? rrem : 32) - 1u;
+    const uint32_t ro = (uint32_t)l31 < rlim ? (uint32_t)l31 : rlim;
+    st_y = y[rb + ro];
     // always a load (no branch in the loop body): without a mask the byte read is ignored
-    st_m = *(mask != nullptr ? mask + nc : reinterpret_cast<const uint8_t*>(y + nc));
+    st_m = *(mask != nullptr ? mask + rb + ro : reinterpret_cast<const uint8_t*>(y + rb + ro));
   };
   auto split_unit = [&](int j, int64_t tile) {          // stage[j] -> xs*[2j], xs*[2j+1]
 #ifdef PA_GLM_PROBE_NOSPLITX
@@ -150,14 +169,12 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     xs3[2 * j] = xs1[2 * j]; xs3[2 * j + 1] = xs1[2 * j + 1];
     return;
 #endif
-    const int64_t base = (row_begin + tile * 32) * (int64_t)D;
-    const bool ok = base + 4 * (int64_t)(j * 64 + lane) < total_e;
-    split_pair(ok ? stage[j].x : 0.0f, ok ? stage[j].y : 0.0f, xs1[2 * j], xs2[2 * j], xs3[2 * j]);
-    split_pair(ok ? stage[j].z : 0.0f, ok ? stage[j].w : 0.0f, xs1[2 * j + 1], xs2[2 * j + 1],
-               xs3[2 * j + 1]);
+    split_pair(stage[j].x, stage[j].y, xs1[2 * j], xs2[2 * j], xs3[2 * j]);
+    split_pair(stage[j].z, stage[j].w, xs1[2 * j + 1], xs2[2 * j + 1], xs3[2 * j + 1]);
   };
   auto split_row = [&](int64_t tile) {
-    const bool okr = (row_begin + tile * 32 + l31 < row_end) && (mask == nullptr || st_m != 0);
+    const int64_t rows_left = row_end - (row_begin + tile * 32);     // scalar; <= 0: tile past the end
+    const bool okr = (int64_t)l31 < rows_left && (mask == nullptr || st_m != 0);
     // scale_and_mask is where(mask, x, 0) (pyro/distributions/util.py:326): a row that does not
     // count gets y = 0 and the -1e30 logit offset
     xs_yh = (okr ? st_y : 0.0f) - 0.5f;
@@ -244,7 +261,10 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
 
   const unsigned char* a_row = Xp + l31 * RS + 16 * h;            // A operand of GEMM1
   const unsigned char* w_row = Wp + l31 * RS + 16 * h;            // B operand of GEMM1
-  const unsigned char* x_col = Xp + (4 * h) * RS + l31 * 2;       // B operand of GEMM2
+  // B operand of GEMM2 (transpose read): this lane's row (4h + (q>>2)) and column group of the
+  // 16-lane group it belongs to, q = lane & 15
+  const uint32_t x_tr_lds = (uint32_t)(uintptr_t)(Xp + (4 * h + ((lane & 15) >> 2)) * RS +
+                                                  (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
   const uint32_t aux_ones = h == 0 ? (BF16_ONE | (BF16_ONE << 16)) : 0u;
 
   // piece products in increasing order of magnitude: (x3,w1) (x2,w2) (x1,w3) (x2,w1) (x1,w2) (x1,w1)
@@ -320,21 +340,23 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
 #endif
       split_pair(g.x, g.y, g1[pt][i], g2[pt][i], g3[pt][i]);
     };
-    // B operand of GEMM2 for K half kh, feature tile dt: 8 rows n(8kh+j, h) of column d = 32dt+l31
-    // from each plane (16-bit LDS reads; gfx950 runs with SRAM ECC, where a d16 load does not
-    // preserve the other register half, so the pairs are packed on the VALU)
+    // B operand of GEMM2 for K half kh, feature tile dt: rows n(8kh+j, h), j = 0..7, of column
+    // d = 32dt + l31 from each plane -- a column access into the row-major planes, done by the LDS
+    // transpose read ds_read_b64_tr_b16: within a 16-lane group lane q passes the address of 4
+    // consecutive bf16 of row (q>>2) (columns 4(q&3)..+3 of the group's 16) and lane i receives
+    // column i of that 4x16 block (mapping measured by tools/probes/tr16_probe.hip).  Two reads
+    // (rows 16kh+4h+{0..3} and +8) make the 8 K-slots of one operand.
     auto load_xb = [&](int kh, int dt) {
-      u16x8v c[3];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = 8 * kh + j;
-        const unsigned char* q = x_col + ((r & 3) + 8 * (r >> 2)) * RS + dt * 64;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          c[pl][j] = *reinterpret_cast<const unsigned short*>(q + pl * PLANE);
+      for (int pl = 0; pl < 3; ++pl) {
+        const uint32_t a0 = x_tr_lds + (uint32_t)((16 * kh) * RS + dt * 64 + pl * PLANE);
+        const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)a0);
+        const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)(a0 + 8 * RS));
+        u16x8v c = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2],
+                    (unsigned short)lo[3], (unsigned short)hi[0], (unsigned short)hi[1],
+                    (unsigned short)hi[2], (unsigned short)hi[3]};
+        xb[pl] = __builtin_bit_cast(bf16x8, c);
       }
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) xb[pl] = __builtin_bit_cast(bf16x8, c[pl]);
     };
     // i-th MFMA of GEMM2 for (pt, kh): feature tile dt = i / 6, piece product i % 6
     auto gemm2 = [&](int pt, int kh, int i) {

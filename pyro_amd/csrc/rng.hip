@@ -58,6 +58,22 @@ __global__ __launch_bounds__(256) void philox_fill_f64(double* __restrict__ out,
 
 __global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
 
+// End-of-step node of a captured training step: advances the Philox base counter of the graph
+// and hands the step's scalar result to the host through pinned (device-mapped) memory: the value
+// first, then -- behind a system-scope fence -- a sequence number the host polls.  The host reads
+// the result a few microseconds after the kernel ran, without a stream synchronisation or a
+// device-to-host copy call.
+template <typename T>
+__global__ void publish_scalar_kernel(const T* __restrict__ src, double* host_value,
+                                      uint64_t* host_seq, uint64_t* counter, uint64_t inc) {
+  if (counter != nullptr) *counter += inc;
+  const double v = (double)*src;
+  __hip_atomic_store(host_value, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();                       // the value is visible to the host before the flag
+  const uint64_t seq = __hip_atomic_load(host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool NORMAL>
 static int fill(void* out, int64_t n, int dtype, uint64_t seed, uint64_t offset,
                 const uint64_t* offset_dev, pa_stream_t stream) {
@@ -91,6 +107,19 @@ int pa_philox_uniform(void* out, int64_t n, int dtype, uint64_t seed, uint64_t o
                       const uint64_t* offset_dev, pa_stream_t stream) {
   return pa::fill<false>(out, n, dtype, seed, offset, offset_dev, stream);
 }
+int pa_publish_scalar(int dtype, const void* src, double* host_value, uint64_t* host_seq,
+                      uint64_t* counter, uint64_t inc, pa_stream_t stream) {
+  PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "publish_scalar: bad dtype %d", dtype);
+  PA_REQUIRE(src && host_value && host_seq, "publish_scalar: NULL pointer");
+  if (dtype == PA_F32)
+    hipLaunchKernelGGL((pa::publish_scalar_kernel<float>), dim3(1), dim3(1), 0, pa::as_stream(stream),
+                       (const float*)src, host_value, host_seq, counter, inc);
+  else
+    hipLaunchKernelGGL((pa::publish_scalar_kernel<double>), dim3(1), dim3(1), 0,
+                       pa::as_stream(stream), (const double*)src, host_value, host_seq, counter, inc);
+  return pa::check_launch("publish_scalar");
+}
+
 int pa_counter_add(uint64_t* counter, uint64_t inc, pa_stream_t stream) {
   PA_REQUIRE(counter != nullptr, "counter_add: NULL counter");
   hipLaunchKernelGGL(pa::counter_add_kernel, dim3(1), dim3(1), 0, pa::as_stream(stream), counter,

@@ -5,13 +5,26 @@ from . import distributions as dist
 from .primitives import plate, sample
 
 
+_ZEROS = {}
+
+
+def _zeros(shape, like):
+    """Prior-location constants hoisted out of the model body (what a user does with
+    ``loc = X.new_zeros(D)`` above the model): allocated and filled once, not once per step."""
+    key = (tuple(shape), like.dtype, like.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(shape, dtype=like.dtype, device=like.device)
+    return z
+
+
 def logreg_model(X, y):
     """BASELINE config 2: Bayesian logistic regression, plate over N data points.
     The logits stay lazy (dist.linear_logits) so the observed site runs the fused one-pass
     GLM kernel; replace it by ``(w @ X.T).squeeze(-2) + b`` for the reference formulation."""
     N, D = X.shape
-    w = sample("w", dist.Normal(torch.zeros(D, dtype=X.dtype, device=X.device), 1.0).to_event(1))
-    b = sample("b", dist.Normal(torch.zeros((), dtype=X.dtype, device=X.device), 1.0))
+    w = sample("w", dist.Normal(_zeros((D,), X), 1.0).to_event(1))
+    b = sample("b", dist.Normal(_zeros((), X), 1.0))
     with plate("data", N):
         sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
 

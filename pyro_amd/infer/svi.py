@@ -32,9 +32,29 @@ def _arg_key(x):
 
 
 class _CapturedStep:
-    def __init__(self, graph, cap, loss, graph2=None, between=None):
+    def __init__(self, graph, cap, loss, graph2=None, between=None, mailbox=None):
         self.graph, self.cap, self.loss = graph, cap, loss
         self.graph2, self.between = graph2, between     # split capture around a collective
+        # pinned host memory the graph's last node writes the loss into (value, sequence number):
+        # polled by the host instead of a stream synchronisation + device-to-host copy
+        self.mailbox = mailbox
+        if mailbox is not None:
+            self._value_np, self._seq_np = mailbox[0].numpy(), mailbox[1].numpy()
+            self._seq = int(self._seq_np[0])
+
+    def read_loss(self):
+        if self.mailbox is None:
+            return self.loss.item()
+        want = self._seq + 1
+        seq, spins = self._seq_np, 0
+        while int(seq[0]) != want:
+            spins += 1
+            if spins > 5_000_000:           # ~seconds: something is wrong, fall back to a real sync
+                torch.cuda.current_stream().synchronize()
+                if int(seq[0]) != want:
+                    raise RuntimeError("pyro_amd: the captured step did not publish its loss")
+        self._seq = want
+        return float(self._value_np[0])
 
 
 class SVI:
@@ -107,7 +127,7 @@ class SVI:
             entry.between()            # eager RCCL all-reduce of the flat gradient
             entry.graph2.replay()
         entry.cap.after_replay()
-        return entry.loss.item()
+        return entry.read_loss()
 
     def _capture(self, key, args, kwargs):
         from .. import rng
@@ -121,6 +141,8 @@ class SVI:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         cap = rng.GraphCapture(device)
+        mailbox = (torch.zeros(1, dtype=torch.float64).pin_memory(),
+                   torch.zeros(1, dtype=torch.int64).pin_memory())
         graph = torch.cuda.CUDAGraph()
         graph2 = between = None
         split = hasattr(self.optim, "reduce_gradients") and \
@@ -136,9 +158,9 @@ class SVI:
                             self.optim(params)
                             if not getattr(self.optim, "zeroes_grads", False):
                                 zero_grads(params)
-                        cap.finish()
                         loss = loss.detach() if isinstance(loss, torch.Tensor) else \
-                            torch.tensor(float(loss), device=device)
+                            torch.full((), float(loss), device=device)
+                        cap.finish(publish=(loss,) + mailbox)
                 if split:
                     # the gradient all-reduce is NOT captured: graph 1 = loss + backward, then an
                     # eager collective, then graph 2 = optimizer update + gradient zeroing
@@ -158,6 +180,6 @@ class SVI:
                           "with eager steps".format(type(e).__name__, e))
             self.hip_graph = False
             return None
-        entry = _CapturedStep(graph, cap, loss, graph2, between)
+        entry = _CapturedStep(graph, cap, loss, graph2, between, mailbox)
         self._graphs[key] = entry
         return entry

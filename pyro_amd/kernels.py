@@ -114,6 +114,16 @@ def philox_uniform(shape, dtype, device, seed, offset, offset_dev=None):
     return out
 
 
+def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
+    """Graph epilogue: counter += inc (optional), then the device scalar ``src`` is written to the
+    pinned host tensors ``host_value`` (float64[1]) / ``host_seq`` (int64[1], incremented)."""
+    _require_gpu(src, counter)
+    assert host_value.is_pinned() and host_seq.is_pinned()
+    assert host_value.dtype == torch.float64 and host_seq.dtype == torch.int64
+    check(_lib.load().pa_publish_scalar(_dtype(src), _ptr(src), _ptr(host_value), _ptr(host_seq),
+                                        _ptr(counter), int(inc), _stream()))
+
+
 def counter_add(counter, inc):
     """*counter += inc on the stream (device-resident Philox base offset; graph-replay safe)."""
     _require_gpu(counter)

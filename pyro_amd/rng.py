@@ -92,9 +92,15 @@ class GraphCapture:
         _CAPTURE["active"] = self
         return self
 
-    def finish(self):
+    def finish(self, publish=None):
+        """Append the node that advances ``*base`` by the blocks one replay consumes.  With
+        ``publish`` = (device scalar, pinned float64[1], pinned int64[1]) the same node also hands
+        that scalar (the step's loss) to the host (kernels.publish_scalar)."""
         self.used = _STATE["offset"] - self.start
-        kernels.counter_add(self.base, self.used)
+        if publish is not None:
+            kernels.publish_scalar(publish[0], publish[1], publish[2], self.base, self.used)
+        else:
+            kernels.counter_add(self.base, self.used)
 
     def __exit__(self, *exc):
         _CAPTURE["active"] = None
