@@ -106,24 +106,29 @@ __device__ __forceinline__ void elem_grad(const Elem<T>& x, T& gv, T& ga, T& gb)
     default: { constexpr int D_ = PA_SITE_NONE; CALL; } break;                                   \
   }
 
-// sum of the masked log-densities of elements start, start + step, ... of entry e
+// sum of the masked log-densities of entry e over the `nth` threads (tid = 0..nth-1) of the waves
+// that share it.  Thread -> (column c0, row group g): no per-element index division, rows in
+// batches of UNS branch-free iterations (these loops are as much VALU-issue-bound -- logf, a
+// division per element -- as latency-bound, so the batches are kept small: an out-of-range
+// iteration still costs its arithmetic).
+constexpr int UNS = 4;
 template <int DIST, typename T>
-__device__ __forceinline__ double entry_sum(const EntryDev& e, uint32_t start, uint32_t step) {
-  const uint32_t C = (uint32_t)e.cols, n = (uint32_t)(e.rows * e.cols);
+__device__ __forceinline__ double entry_sum(const EntryDev& e, uint32_t tid, uint32_t nth) {
+  const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols;
   T acc = T(0);
   if constexpr (DIST == PA_SITE_NONE) return 0.0;
-  for (uint32_t base = start; base < n; base += UN * step) {
-    Elem<T> x[UN];
+  const uint32_t tk = C < nth ? C : nth, ng = nth / tk;
+  const uint32_t c0 = tid % tk, g = tid / tk;
+  if (g >= ng) return 0.0;
+  for (uint32_t c = c0; c < C; c += tk)
+    for (uint32_t rb = g; rb < R; rb += UNS * ng) {
+      Elem<T> x[UNS];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const uint32_t i = base + u * step;
-      const uint32_t r = i / C;
-      x[u] = load_elem<DIST, T>(e, r, i - r * C, i < n);
+      for (int u = 0; u < UNS; ++u) x[u] = load_elem<DIST, T>(e, rb + u * ng, c, rb + u * ng < R);
+#pragma unroll
+      for (int u = 0; u < UNS; ++u) acc += x[u].keep ? elem_lp<DIST, T>(x[u]) : T(0);
     }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) acc += x[u].keep ? elem_lp<DIST, T>(x[u]) : T(0);
-  }
-  return (double)acc;   // <= PA_MULTI_MAX_ELEMS / 64 terms per lane; fp64 across lanes
+  return (double)acc;   // few terms per lane; fp64 across lanes
 }
 
 // ONE workgroup of 16 waves: the entries are spread over the waves (several waves per entry when
@@ -143,9 +148,9 @@ __global__ __launch_bounds__(MULTI_THREADS) void multi_sum_kernel(const MultiArg
     const int k = k0 + wave / wpe;
     if (k < n_entries && wave / wpe < epr) {
       const EntryDev e = kernarg_load<EntryDev>(offsetof(MultiArgs, e) + k * sizeof(EntryDev));
-      const uint32_t start = (uint32_t)((wave % wpe) * 64 + lane), step = (uint32_t)(wpe * 64);
+      const uint32_t tid = (uint32_t)((wave % wpe) * 64 + lane), nth = (uint32_t)(wpe * 64);
       double s = 0.0;
-      PA_DISPATCH_ENTRY(e.dist, s = (entry_sum<D_, T>(e, start, step)));
+      PA_DISPATCH_ENTRY(e.dist, s = (entry_sum<D_, T>(e, tid, nth)));
       acc += e.coef * s;
     }
   }
