@@ -272,7 +272,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("glm_bernoulli_kernel_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("glm_bernoulli_bf16_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -288,7 +288,11 @@ def main():
                        "parallelism": "particles sharded x%d, flat RCCL grad all-reduce" % world},
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "kernel": "glm_bernoulli_kernel",
+                         "traffic": traffic, "kernel": "glm_bernoulli_bf16_kernel",
+                         "arithmetic": "f32-equivalent: f32 operands split exactly into 3 bf16 "
+                                       "pieces, 6 piece products on the bf16 matrix cores, f32 "
+                                       "accumulation (peak quoted = f32-input MFMA, the rate of the "
+                                       "exact-f32 alternative)",
                          "kernel_ms": kern_ms, "flops_per_launch": gemm_flops,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_achieved_TBps": alg_bytes / (kern_ms * 1e-3) / 1e12,
