@@ -446,6 +446,8 @@ __global__ __launch_bounds__(256) void meanfield_sample_kernel(const MfArgs args
   }
 }
 
+// grid = (sites, column tiles): a column's sum over the P particles is independent of every other
+// column, so a large (plated) site spreads over many workgroups; small sites use tile 0 only
 template <typename T>
 __global__ __launch_bounds__(256) void meanfield_sample_bwd_kernel(const MfArgs args_by_value,
                                                                    int64_t P) {
@@ -459,9 +461,10 @@ __global__ __launch_bounds__(256) void meanfield_sample_bwd_kernel(const MfArgs 
   T* dloc = (T*)s.d_loc;
   T* drho = (T*)s.d_rho;
   const uint32_t n = (uint32_t)s.n, t = threadIdx.x, PP = (uint32_t)P;
-  if (n == 0) return;
-  const uint32_t tk = n < 256 ? n : 256, ng = row_groups(tk), c0 = t % tk, g = t / tk;
-  for (uint32_t cb = 0; cb < n; cb += tk) {
+  const uint32_t tk = n < 256 ? n : 256;
+  if (n == 0 || blockIdx.y * tk >= n) return;
+  const uint32_t ng = row_groups(tk), c0 = t % tk, g = t / tk;
+  for (uint32_t cb = blockIdx.y * tk; cb < n; cb += gridDim.y * tk) {
     const uint32_t c = cb + c0;
     const bool okc = g < ng && c < n;
     // the per-column inputs of the epilogue are requested up front, next to the first batch
@@ -607,16 +610,22 @@ int pa_meanfield_normal_sample_bwd(int dtype, const pa_mf_site* sites, int nsite
   int rc = pa::mf_to_dev(sites, nsites, &args, "pa_meanfield_normal_sample_bwd");
   if (rc != PA_OK) return rc;
   if (nsites == 0) return PA_OK;
-  for (int k = 0; k < nsites; ++k)
+  int64_t maxn = 0;
+  for (int k = 0; k < nsites; ++k) {
     PA_REQUIRE(sites[k].n == 0 || (sites[k].rho && sites[k].eps),
                "pa_meanfield_normal_sample_bwd: site %d: NULL pointer", k);
+    if (sites[k].n > maxn) maxn = sites[k].n;
+  }
+  int64_t gy = (maxn + 255) / 256;
+  if (gy < 1) gy = 1;
+  if (gy > 4096) gy = 4096;
   hipStream_t s = pa::as_stream(stream);
   if (dtype == PA_F32)
-    hipLaunchKernelGGL((pa::meanfield_sample_bwd_kernel<float>), dim3((unsigned)nsites), dim3(256),
-                       0, s, args, P);
-  else
-    hipLaunchKernelGGL((pa::meanfield_sample_bwd_kernel<double>), dim3((unsigned)nsites),
+    hipLaunchKernelGGL((pa::meanfield_sample_bwd_kernel<float>), dim3((unsigned)nsites, (unsigned)gy),
                        dim3(256), 0, s, args, P);
+  else
+    hipLaunchKernelGGL((pa::meanfield_sample_bwd_kernel<double>),
+                       dim3((unsigned)nsites, (unsigned)gy), dim3(256), 0, s, args, P);
   return pa::check_launch("meanfield_sample_bwd_kernel");
 }
 

@@ -47,6 +47,10 @@ class Categorical(torch.distributions.Categorical, TorchDistributionMixin):
         batch_shape = torch.Size(batch_shape)
         param_shape = batch_shape + torch.Size((self._num_events,))
         new.logits = self.logits.expand(param_shape)       # computed once on the small table
+        # the un-expanded table: consumers that only need the table itself (the fused enumeration
+        # kernels) must not index the expanded view -- the autograd dual of select/expand
+        # materialises a zero tensor of the EXPANDED shape (T x words x docs x V elements)
+        new._base_logits = getattr(self, "_base_logits", self.logits)
         if "probs" in self.__dict__:
             new.probs = self.probs.expand(param_shape)
         new._param = new.logits

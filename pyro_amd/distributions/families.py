@@ -147,8 +147,30 @@ class LogNormal(_FusedElementwise, torch.distributions.LogNormal, TorchDistribut
             return self.rsample(sample_shape)
 
 
+def _zero_loc_base(base_cls, scale):
+    """base_cls(0, scale) with the zero location as a cached device constant: torch builds it with
+    torch.tensor(0, device=...), a host-to-device copy (a synchronisation, and not permitted while
+    a hipGraph is being captured)."""
+    if isinstance(scale, torch.Tensor):
+        zero = device_constant(0.0, scale.dtype if scale.is_floating_point()
+                               else torch.get_default_dtype(), scale.device)
+        return base_cls(zero, scale, validate_args=False)
+    return base_cls(0, scale, validate_args=False)
+
+
 class HalfCauchy(_FusedElementwise, torch.distributions.HalfCauchy, TorchDistributionMixin):
     _dist_id = _lib.DIST_HALF_CAUCHY
+
+    def __init__(self, scale, validate_args=None):
+        base = _zero_loc_base(torch.distributions.Cauchy, scale)
+        torch.distributions.TransformedDistribution.__init__(
+            self, base, torch.distributions.transforms.AbsTransform(), validate_args=validate_args)
+
+    def expand(self, batch_shape, _instance=None):
+        new = type(self)(self.scale.expand(torch.Size(batch_shape)), validate_args=False)
+        new._validate_args = self._validate_args
+        new._base_params = getattr(self, "_base_params", None) or self._params()
+        return new
 
     def _params(self):
         return self.scale, None
@@ -161,6 +183,17 @@ class HalfCauchy(_FusedElementwise, torch.distributions.HalfCauchy, TorchDistrib
 
 class HalfNormal(_FusedElementwise, torch.distributions.HalfNormal, TorchDistributionMixin):
     _dist_id = _lib.DIST_HALF_NORMAL
+
+    def __init__(self, scale, validate_args=None):
+        base = _zero_loc_base(torch.distributions.Normal, scale)
+        torch.distributions.TransformedDistribution.__init__(
+            self, base, torch.distributions.transforms.AbsTransform(), validate_args=validate_args)
+
+    def expand(self, batch_shape, _instance=None):
+        new = type(self)(self.scale.expand(torch.Size(batch_shape)), validate_args=False)
+        new._validate_args = self._validate_args
+        new._base_params = getattr(self, "_base_params", None) or self._params()
+        return new
 
     def _params(self):
         return self.scale, None
@@ -333,6 +366,9 @@ class _BernoulliLinear(TorchDistribution):
         lz = self.lazy
         args = self._glm_args(value, scale, mask)
         if args is None or not isinstance(lz.w, torch.Tensor):
+            return None
+        # the batch carries gradients of small tensors only; decide BEFORE running the kernel
+        if lz.w.requires_grad and lz.w.numel() > _lib.MULTI_MAX_ELEMS:
             return None
         w2, b1, mask = args
         with torch.no_grad():

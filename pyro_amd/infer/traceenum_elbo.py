@@ -54,9 +54,13 @@ def _lazy_gather(site, first_enum_dim):
     if edim > first_enum_dim:
         return None
     T, V = lead[nz[0]], logits.shape[-1]
-    idx = (0,) * nz[0] + (slice(None),) + (0,) * (len(lead) - nz[0] - 1) + (0, 0, slice(None))
-    table = logits[idx]                   # [T, V] view of the un-expanded log-probabilities
-    return LazyGather(table.reshape(T, V), value, edim)
+    base = getattr(fn, "_base_logits", None)
+    if base is not None and base.numel() == T * V and base.shape[-1] == V:
+        table = base.reshape(T, V)        # the table before Categorical.expand (no huge backward)
+    else:
+        idx = (0,) * nz[0] + (slice(None),) + (0,) * (len(lead) - nz[0] - 1) + (0, 0, slice(None))
+        table = logits[idx].reshape(T, V)  # [T, V] view of the un-expanded log-probabilities
+    return LazyGather(table, value, edim)
 
 
 class TraceEnum_ELBO(ELBO):

@@ -1,0 +1,56 @@
+"""BASELINE configs 4 (LDA, TraceEnum_ELBO) and 5 (hierarchical logistic regression, one GPU's share)
+on one MI355X (developer tool; bench.py reports the same numbers under `other_configs`)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import pyro_amd as pyro
+from pyro_amd import examples, kernels
+from pyro_amd.infer import SVI, Trace_ELBO, TraceEnum_ELBO
+from pyro_amd.infer.autoguide import AutoNormal
+
+
+def timed(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True):
+    X, y, off = examples.synthetic_hier_logreg_data(N, D, G, dev, seed=0)
+    segs = kernels.GroupSegments(off, dev)
+    pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
+    guide = AutoNormal(examples.hier_logreg_model, init_scale=0.1)
+    svi = SVI(examples.hier_logreg_model, guide, pyro.optim.Adam({"lr": 0.01}),
+              Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
+              hip_graph=graph, graph_warmup=2)
+    dt = timed(lambda: svi.step(X, y, segs), steps, 5)
+    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1),
+            "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
+
+
+def config4(dev, docs=100_000, steps=10):
+    args = examples.LdaArgs(num_docs=docs)
+    data = examples.synthetic_lda_data(args, dev)
+    pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
+    predictor = examples.lda_make_predictor(args, dev)
+    guide = lambda data, args: examples.lda_guide(predictor, data, args)  # noqa: E731
+    svi = SVI(examples.lda_model, guide, pyro.optim.TorchAdam({"lr": 0.01}), TraceEnum_ELBO(max_plate_nesting=2))
+    dt = timed(lambda: svi.step(data, args), steps, 3)
+    pairs = docs * args.num_words_per_doc
+    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
+            "algorithmic_TBps": pairs * 8.5 / dt / 1e12}
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    print("config 5 (N=1e7, P=64, G=1000):", config5(dev))
+    print("config 5 eager:", config5(dev, steps=5, graph=False))
+    print("config 4 (1e5 docs):", config4(dev))
