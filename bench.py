@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--particles", type=int, default=64, help="particles per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nuts", action="store_true", help="skip the secondary NUTS measurement")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the one-GPU measurements of BASELINE configs 4 (LDA) and 5 (hierarchical)")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager SVI.step (Python handlers + one launch per kernel) instead of the "
                          "captured hipGraph step")
@@ -263,6 +265,25 @@ def main():
         elapsed = float(t.item())
 
     nuts = None if args.no_nuts else bench_nuts(dev, rank, world, args)
+    others = None
+    if world == 1 and not args.no_others:
+        # BASELINE configs[3] and configs[4] (one GPU's share) -- reported, not the headline value
+        from tools import bench_configs
+        others = {}
+        try:
+            r5 = bench_configs.config5(dev, steps=20)
+            r5["workload"] = ("BASELINE configs[4], one GPU's share: hierarchical logistic regression, "
+                              "plate=1e7, D=32, 1000 groups, 64 of the 512 particles, AutoNormal, Adam, "
+                              "graphed SVI.step; grouped bf16x3 GLM kernel")
+            others["config5_hierarchical_logreg"] = r5
+            r4 = bench_configs.config4(dev, steps=10)
+            r4["workload"] = ("BASELINE configs[3]: examples/lda.py, TraceEnum_ELBO, 1e5 documents (all "
+                              "in the plate), 8 topics, 1024 words, 64 words per document, amortised "
+                              "guide; word_topics enumerated and summed out by the fused LDA kernel")
+            others["config4_lda"] = r4
+        except Exception as e:  # noqa: BLE001  (secondary measurements must not kill the headline)
+            others["error"] = "%s: %s" % (type(e).__name__, e)
+        pyro.clear_param_store()
     if rank == 0:
         kern_ms = sum(kern_ms_list) / len(kern_ms_list) if kern_ms_list else timer.mean_ms()
         gemm_flops = 4.0 * P * N * D                      # two [P,D]x[D,N]-shaped contractions
@@ -302,6 +323,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, D, P, args.cpu_budget_s)
         if nuts is not None:
             out["secondary"] = nuts
+        if others:
+            out["other_configs"] = others
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -559,9 +559,75 @@ def g_hier():
          eps=list(bank.used))
 
 
+# ---------------------------------------------------------------------------------------------
+# G10: TraceMeanField_ELBO (analytic KL where registered, sampled fall-back otherwise) and
+#      Predictive (vectorised posterior-predictive draws) through the reference
+# ---------------------------------------------------------------------------------------------
+def g_meanfield():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer import Predictive, TraceMeanField_ELBO
+    rng = np.random.default_rng(11)
+    N = 7
+    data = torch.tensor(rng.standard_normal(N) + 1.0)
+
+    def model(data):
+        loc = pyro.sample("loc", dist.Normal(torch.zeros(3), 2.0).to_event(1))      # analytic KL
+        sc = pyro.sample("sc", dist.LogNormal(0.0, 0.5))                            # analytic KL
+        g = pyro.sample("g", dist.Gamma(2.0, 3.0))                                  # no KL vs LogNormal
+        with pyro.plate("d", N):
+            pyro.sample("x", dist.Normal(loc.sum(-1) * g, sc), obs=data)
+
+    def guide(data):
+        ql = pyro.param("ql", torch.tensor([0.3, -0.2, 0.1]))
+        qs = pyro.param("qs", torch.tensor([0.5, 0.7, 0.9]), constraint=constraints.positive)
+        sl = pyro.param("sl", torch.tensor(-0.1))
+        ss = pyro.param("ss", torch.tensor(0.3), constraint=constraints.positive)
+        gl = pyro.param("gl", torch.tensor(-0.4))
+        gs = pyro.param("gs", torch.tensor(0.2), constraint=constraints.positive)
+        pyro.sample("loc", dist.Normal(ql, qs).to_event(1))
+        pyro.sample("sc", dist.LogNormal(sl, ss))
+        pyro.sample("g", dist.LogNormal(gl, gs))
+
+    out = {}
+    for tag, P in (("p1", 1), ("p5", 5)):
+        pyro.clear_param_store()
+        elbo = TraceMeanField_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=1)
+        with EpsBank(31) as bank:
+            loss = elbo.loss_and_grads(model, guide, data)
+        out[tag] = dict(loss=loss, grads=grads_of_store(), eps=list(bank.used))
+    save("meanfield", data=data.numpy(), loss_p1=out["p1"]["loss"], grads_p1=out["p1"]["grads"],
+         eps_p1=out["p1"]["eps"], loss_p5=out["p5"]["loss"], grads_p5=out["p5"]["grads"],
+         eps_p5=out["p5"]["eps"])
+
+    # Predictive: posterior draws of the latents given, x sampled afresh, vectorised
+    def model_p(data):
+        m = pyro.sample("m", dist.Normal(0.0, 2.0))
+        s = pyro.sample("s", dist.LogNormal(0.0, 0.5))
+        with pyro.plate("d", N):
+            pyro.sample("x", dist.Normal(m, s), obs=data)
+
+    S = 6
+    post = {"m": torch.tensor(rng.standard_normal(S)),
+            "s": torch.tensor(np.exp(0.3 * rng.standard_normal(S)))}
+    with EpsBank(32) as bank:
+        pred = Predictive(model_p, posterior_samples=post, parallel=True)(None)      # x sampled
+    with EpsBank(33) as bank2:
+        pred_all = Predictive(model_p, posterior_samples=post, parallel=True,
+                              return_sites=["x", "m"])(None)
+    with EpsBank(34) as bank3:
+        pred_seq = Predictive(model_p, posterior_samples=post, parallel=False)(None)
+    save("predictive", post=post_np(post), x=pred["x"].numpy(), eps=list(bank.used),
+         x2=pred_all["x"].numpy(), m2=pred_all["m"].numpy(), eps2=list(bank2.used),
+         x3=pred_seq["x"].numpy(), eps3=list(bank3.used))
+
+
+def post_np(d):
+    return {k: v.numpy() for k, v in d.items()}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier"]
+                             "adaptation", "enum", "hier", "meanfield"]
     for w in which:
         globals()["g_" + w]()
 

@@ -14,12 +14,18 @@ from pyro_amd.infer.autoguide import AutoNormal
 class EpsReplay:
     """Feeds the reference's recorded normal draws to pyro_amd.rng.normal, in order."""
 
-    def __init__(self, eps_list, device):
+    def __init__(self, eps_list, device, lenient=False):
         self.eps = list(eps_list)
         self.device = device
         self.i = 0
+        # lenient: draws whose shape is not the next recorded one are "don't care" draws (prototype
+        # runs, which the reference makes through torch.normal, outside the recorded stream)
+        self.lenient = lenient
 
     def __call__(self, shape, dtype, device):
+        if self.lenient and (self.i >= len(self.eps)
+                             or tuple(self.eps[self.i].shape) != tuple(shape)):
+            return torch.zeros(tuple(shape), dtype=dtype, device=self.device)
         e = self.eps[self.i]
         self.i += 1
         assert tuple(e.shape) == tuple(shape), (e.shape, tuple(shape))
@@ -144,7 +150,7 @@ def run_logreg(g, device, monkeypatch, fused, dtype, rtol):
     with torch.no_grad():
         for name in list(store.keys()):
             store[name] = torch.as_tensor(g["params2/" + name], dtype=dtype, device=device)
-    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps2"), device))
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps2"), device, lenient=True))
     loss2 = elbo.loss_and_grads(model, guide, X, y)
     np.testing.assert_allclose(loss2, float(g["loss2"]), rtol=rtol)
     assert_grads(store_grads(), g, "grads2", rtol * 10)
@@ -243,3 +249,80 @@ def run_hier(g, device, monkeypatch, fused, dtype=torch.float64, rtol=1e-9):
     loss = elbo.loss_and_grads(model, guide, X, y, segs)
     np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
     assert_grads(store_grads(), g, "grads", rtol * 10)
+
+
+# ---- TraceMeanField_ELBO and Predictive (golden: tests/golden/make_golden.py g_meanfield) ---------
+def run_meanfield(g, device, monkeypatch, tag, rtol):
+    """Loss and gradients of the reference's TraceMeanField_ELBO: analytic KL for the Normal and
+    LogNormal pairs, sampled fall-back for the Gamma prior / LogNormal guide pair."""
+    from pyro_amd import rng
+    from pyro_amd.infer import TraceMeanField_ELBO
+    dtype = torch.get_default_dtype()
+    data = torch.as_tensor(g["data"], dtype=dtype, device=device)
+    N = data.shape[0]
+
+    def t(x):
+        return torch.tensor(x, dtype=dtype, device=device)
+
+    def model(data):
+        loc = pyro.sample("loc", dist.Normal(torch.zeros(3, dtype=dtype, device=device), 2.0).to_event(1))
+        sc = pyro.sample("sc", dist.LogNormal(t(0.0), 0.5))
+        gg = pyro.sample("g", dist.Gamma(t(2.0), t(3.0)))
+        with pyro.plate("d", N):
+            pyro.sample("x", dist.Normal(loc.sum(-1) * gg, sc), obs=data)
+
+    def guide(data):
+        ql = pyro.param("ql", t([0.3, -0.2, 0.1]))
+        qs = pyro.param("qs", t([0.5, 0.7, 0.9]), constraint=constraints.positive)
+        sl = pyro.param("sl", t(-0.1))
+        ss = pyro.param("ss", t(0.3), constraint=constraints.positive)
+        gl = pyro.param("gl", t(-0.4))
+        gs = pyro.param("gs", t(0.2), constraint=constraints.positive)
+        pyro.sample("loc", dist.Normal(ql, qs).to_event(1))
+        pyro.sample("sc", dist.LogNormal(sl, ss))
+        pyro.sample("g", dist.LogNormal(gl, gs))
+
+    P = 1 if tag == "p1" else 5
+    pyro.clear_param_store()
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps_" + tag), device))
+    elbo = TraceMeanField_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=1)
+    loss = elbo.loss_and_grads(model, guide, data)
+    np.testing.assert_allclose(loss, float(g["loss_" + tag]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads_" + tag, rtol * 10)
+
+
+def run_predictive(g, device, monkeypatch, rtol):
+    from pyro_amd import rng
+    from pyro_amd.infer import Predictive
+    dtype = torch.get_default_dtype()
+    N = g["x"].shape[1]
+
+    def model_p(data):
+        m = pyro.sample("m", dist.Normal(torch.zeros((), dtype=dtype, device=device), 2.0))
+        s = pyro.sample("s", dist.LogNormal(torch.zeros((), dtype=dtype, device=device), 0.5))
+        with pyro.plate("d", N):
+            pyro.sample("x", dist.Normal(m, s), obs=data)
+
+    post = {k: torch.as_tensor(g["post/" + k], dtype=dtype, device=device) for k in ("m", "s")}
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps"), device, lenient=True))
+    pred = Predictive(model_p, posterior_samples=post, parallel=True)(None)
+    assert set(pred) == {"x"}
+    np.testing.assert_allclose(pred["x"].cpu().numpy(), g["x"], rtol=rtol)
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps2"), device, lenient=True))
+    pred = Predictive(model_p, posterior_samples=post, parallel=True, return_sites=["x", "m"])(None)
+    np.testing.assert_allclose(pred["x"].cpu().numpy(), g["x2"], rtol=rtol)
+    assert tuple(pred["m"].shape) == g["m2"].shape
+    np.testing.assert_allclose(pred["m"].cpu().numpy(), g["m2"], rtol=rtol)
+    # sequential: the recorded draws are the six [N] vectors of x; the two prototype runs come first
+    replay = EpsReplay(_eps_of(g, "eps3"), device, lenient=True)
+    skip = {"n": 2}
+
+    def seq_normal(shape, dtype, dev):
+        if tuple(shape) == (N,) and skip["n"] > 0:
+            skip["n"] -= 1
+            return torch.zeros(tuple(shape), dtype=dtype, device=device)
+        return replay(shape, dtype, dev)
+
+    monkeypatch.setattr(rng, "normal", seq_normal)
+    pred = Predictive(model_p, posterior_samples=post, parallel=False)(None)
+    np.testing.assert_allclose(pred["x"].cpu().numpy(), g["x3"], rtol=rtol)

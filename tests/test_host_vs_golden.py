@@ -47,3 +47,12 @@ def test_score_function_guide(monkeypatch):
 def test_hierarchical_logreg_loss_and_grads(monkeypatch, fused):
     # config 5 at toy size: per-group weights under plate("groups"), ragged groups (one empty)
     models.run_hier(load("hier"), torch.device("cpu"), monkeypatch, fused=fused, rtol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["p1", "p5"])
+def test_trace_mean_field_elbo(monkeypatch, tag):
+    models.run_meanfield(load("meanfield"), torch.device("cpu"), monkeypatch, tag, rtol=1e-9)
+
+
+def test_predictive(monkeypatch):
+    models.run_predictive(load("predictive"), torch.device("cpu"), monkeypatch, rtol=1e-10)

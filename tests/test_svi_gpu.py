@@ -66,6 +66,19 @@ def test_score_function_guide(gpu):
     models.run_score_function(load("score_function"), gpu, rtol=1e-9)
 
 
+@pytest.mark.parametrize("tag", ["p1", "p5"])
+def test_trace_mean_field_elbo(gpu, monkeypatch, tag):
+    """TraceMeanField_ELBO (analytic KL + sampled fall-back) against the reference's loss / grads."""
+    torch.set_default_dtype(torch.float64)
+    models.run_meanfield(load("meanfield"), gpu, monkeypatch, tag, rtol=1e-9)
+
+
+def test_predictive(gpu, monkeypatch):
+    """Predictive (vectorised and sequential) against the reference's draws (recorded normals)."""
+    torch.set_default_dtype(torch.float64)
+    models.run_predictive(load("predictive"), gpu, monkeypatch, rtol=1e-10)
+
+
 def test_svi_converges_to_reference_posterior(gpu):
     """Posterior means after optimisation match the reference's (north-star criterion): the
     deterministic analytic optimum of the Gaussian family is the comparison point -- both

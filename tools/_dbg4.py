@@ -18,9 +18,10 @@ class M(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, a=(), kw=None):
         out = func(*a, **(kw or {}))
         n = max([t.numel() for t in list(a) + [out] if isinstance(t, torch.Tensor)] + [0])
-        if n >= 50_000:
+        isl = any(isinstance(t, torch.Tensor) and t.dtype in (torch.int64, torch.bool) for t in list(a) + [out])
+        if n >= 1_000_000 and isl:
             st = [f for f in traceback.extract_stack() if "pyro_amd" in f.filename or "tools/" in f.filename]
-            where = "; ".join("%s:%d" % (f.filename.split("/")[-1], f.lineno) for f in st[-3:]) if st else "autograd"
+            where = "; ".join("%s:%d" % (f.filename.split("/")[-1], f.lineno) for f in st[-5:]) if st else "autograd"
             big[(str(func), where, n)] += 1
         return out
 with M():
