@@ -437,6 +437,16 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     }
     write_xs();
     if (!EARLY_SPLIT) issue_loads(nxt + tile_stride);
+#ifdef PA_GLM_SCHED_PIPELINE
+    // ask the machine scheduler for an even MFMA : VALU interleave over the whole (branch-free) body
+    if constexpr (DT == 1 && PT == 2) {
+#pragma unroll
+      for (int i = 0; i < 50; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, PA_GLM_SCHED_PIPELINE, 0);  // VALU
+      }
+    }
+#endif
     tile = nxt;
   }
   float ll_acc[PT], gb_acc[PT];

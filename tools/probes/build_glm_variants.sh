@@ -15,6 +15,11 @@ $H $F -DPROBE_NAME=nogemm1 -DPA_GLM_PROBE_NOGEMM1 -c glm_variants_unit.hip -o /t
 $H $F -DPROBE_NAME=minimal -DPA_GLM_PROBE_NOELEM -DPA_GLM_PROBE_NOSPLITG -DPA_GLM_PROBE_NOSPLITX -DPA_GLM_PROBE_NOGEMM1 -DPA_GLM_PROBE_NOGEMM2 -c glm_variants_unit.hip -o /tmp/gv_minimal.o &
 $H $F -DPROBE_NAME=nomfma -DPA_GLM_PROBE_NOGEMM1 -DPA_GLM_PROBE_NOGEMM2 -c glm_variants_unit.hip -o /tmp/gv_nomfma.o &
 $H $F -DPROBE_NAME=novalu -DPA_GLM_PROBE_NOELEM -DPA_GLM_PROBE_NOSPLITG -DPA_GLM_PROBE_NOSPLITX -c glm_variants_unit.hip -o /tmp/gv_novalu.o &
+$H $F -DPROBE_NAME=sched6 -DPA_GLM_SCHED_PIPELINE=6 -c glm_variants_unit.hip -o /tmp/gv_sched6.o &
+$H $F -DPROBE_NAME=sched8 -DPA_GLM_SCHED_PIPELINE=8 -c glm_variants_unit.hip -o /tmp/gv_sched8.o &
+$H $F -DPROBE_NAME=sched10 -DPA_GLM_SCHED_PIPELINE=10 -c glm_variants_unit.hip -o /tmp/gv_sched10.o &
+$H $F -DPROBE_NAME=sched11 -DPA_GLM_SCHED_PIPELINE=11 -c glm_variants_unit.hip -o /tmp/gv_sched11.o &
+$H $F -DPROBE_NAME=sched13 -DPA_GLM_SCHED_PIPELINE=13 -c glm_variants_unit.hip -o /tmp/gv_sched13.o &
 wait
 $H $F -c glm_variants_main.cpp -o /tmp/gvmain.o
 $H --offload-arch=gfx950 /tmp/gvmain.o /tmp/gv_*.o -o glm_variants

@@ -4,7 +4,7 @@
 #include <stdlib.h>
 #include <vector>
 #define DECL(n) extern "C" float run_##n(const float*, const float*, const float*, const float*, int64_t, int, int, float*, int, int);
-DECL(base) DECL(noelem) DECL(nosplitg) DECL(nogemm2) DECL(noxb) DECL(nogemm1) DECL(nosplitx) DECL(nosplit) DECL(minimal) DECL(nomfma) DECL(novalu)
+DECL(base) DECL(noelem) DECL(nosplitg) DECL(nogemm2) DECL(noxb) DECL(nogemm1) DECL(nosplitx) DECL(nosplit) DECL(sched6) DECL(sched8) DECL(sched10) DECL(sched11) DECL(sched13) DECL(minimal) DECL(nomfma) DECL(novalu)
 namespace pa { int cu_count() { return 256; } }
 int main(int argc, char** argv) {
   const int64_t N = 1000000; const int D = 32, P = 64;
@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
   for (int nb : {512}) {
     printf("nblocks=%d\n", nb);
 #define RUN(n) printf("  %-10s %8.1f us\n", #n, run_##n(X, y, w, b, N, D, P, part, nb, 20));
-    RUN(base) RUN(noelem) RUN(nosplitg) RUN(nosplitx) RUN(nosplit) RUN(nogemm2) RUN(noxb) RUN(nogemm1) RUN(nomfma) RUN(novalu) RUN(minimal)
+    RUN(base) RUN(sched6) RUN(sched8) RUN(sched10) RUN(sched11) RUN(sched13) RUN(base) RUN(noelem) RUN(nosplitg) RUN(nosplitx) RUN(nosplit) RUN(nogemm2) RUN(noxb) RUN(nogemm1) RUN(nomfma) RUN(novalu) RUN(minimal)
   }
   return 0;
 }
