@@ -26,12 +26,47 @@ bool take_bracket(int tag, hipEvent_t* start, hipEvent_t* stop);
     if (!(cond)) return ::pa::fail(PA_ERR_INVALID, __VA_ARGS__); \
   } while (0)
 
-// ---- wave-level reductions (64 lanes, butterfly over ds_swizzle/dpp via __shfl_xor) -------
+// ---- wave-level reductions (64 lanes) ------------------------------------------------------------
+// Sum over the wave in a FIXED order, result uniform in every lane.  Within a row of 16 lanes the
+// butterfly runs on DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: ~8 cycles a step);
+// the four row sums are then read with v_readlane and added as scalars.  (__shfl_xor lowers to
+// ds_bpermute: six dependent LDS round trips, ~500 cycles per reduction -- the NUTS transition
+// kernel does half a dozen dot products per leapfrog step.)
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(dpp_mov<CTRL>(__float_as_int(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+  const int lo = dpp_mov<CTRL>(__double2loint(v)), hi = dpp_mov<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_get(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_get(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
+  if constexpr (sizeof(T) == 4 || sizeof(T) == 8) {
+    v += dpp_get<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_get<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_get<0x141>(v);   // row_half_mirror: the other quad of the 8
+    v += dpp_get<0x140>(v);   // row_mirror: the other half of the row of 16
+    const T s0 = lane_get(v, 0), s1 = lane_get(v, 16), s2 = lane_get(v, 32), s3 = lane_get(v, 48);
+    return (s0 + s1) + (s2 + s3);
+  } else {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
 }
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
