@@ -9,9 +9,18 @@ constexpr int NUTS_MAX_DEPTH = 10;
 
 template <typename T> struct Num;
 template <> struct Num<float> {
-  static __device__ __forceinline__ float exp_(float x) { return expf(x); }
-  static __device__ __forceinline__ float log_(float x) { return logf(x); }
-  static __device__ __forceinline__ float log1p_(float x) { return log1pf(x); }
+  // f32 chains: the hardware transcendentals (v_exp_f32 / v_log_f32, ~1 ulp) instead of the
+  // ~60-instruction library routines -- these feed acceptance probabilities and log-weights that
+  // are compared with uniform draws, every lane of the wave computes them redundantly, and a tree
+  // merge needs three of them.  The float64 kernels (the ones held to the oracle chain for chain)
+  // keep the exact library functions.
+  static __device__ __forceinline__ float exp_(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+  }
+  static __device__ __forceinline__ float log_(float x) {
+    return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+  }
+  static __device__ __forceinline__ float log1p_(float x) { return log_(1.0f + x); }
   static __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
   static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
 };
