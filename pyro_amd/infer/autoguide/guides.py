@@ -253,7 +253,236 @@ class AutoNormal(AutoGuide):
         return out
 
 
-AutoDiagonalNormal = AutoNormal  # same variational family; per-site parameters instead of one flat vector
+# ---- AutoContinuous family (reference: guides.py:605-1029) -----------------------------------------
+class _UnitLowerCholesky(constraints.Constraint):
+    """Lower-triangular square matrices with a unit diagonal (pyro constraints.unit_lower_cholesky)."""
+
+    event_dim = 2
+    is_discrete = False
+
+    def check(self, value):
+        tril = value.tril()
+        lower = (tril == value).reshape(value.shape[:-2] + (-1,)).min(-1)[0]
+        ones = (value.diagonal(dim1=-2, dim2=-1) == 1).min(-1)[0]
+        return lower & ones
+
+
+unit_lower_cholesky = _UnitLowerCholesky()
+
+
+class _UnitLowerCholeskyTransform(torch.distributions.transforms.Transform):
+    """x -> tril(x, -1) + I (pyro/distributions/transforms/cholesky.py UnitLowerCholeskyTransform)."""
+
+    domain = constraints.independent(constraints.real, 2)
+    codomain = unit_lower_cholesky
+    bijective = True
+
+    def __eq__(self, other):
+        return isinstance(other, _UnitLowerCholeskyTransform)
+
+    def _call(self, x):
+        return x.tril(-1) + torch.eye(x.size(-1), device=x.device, dtype=x.dtype)
+
+    def _inverse(self, y):
+        return y.tril(-1)
+
+    def log_abs_det_jacobian(self, x, y):
+        return x.new_zeros(x.shape[:-2])
+
+
+@dist.transform_to.register(_UnitLowerCholesky)
+def _transform_to_unit_lower_cholesky(constraint):
+    return _UnitLowerCholeskyTransform()
+
+
+class _GuideMVN(torch.distributions.MultivariateNormal, dist.TorchDistributionMixin):
+    """MultivariateNormal whose reparameterised draw takes its standard normals from the backend's
+    Philox stream (pyro_amd.rng.normal) and applies the affine map as ONE dense product over all
+    particles: z = loc + eps @ scale_tril^T -- the genuine dense matvec of this guide family
+    (rocBLAS / MFMA for large latent spaces)."""
+
+    def rsample(self, sample_shape=torch.Size()):
+        from ... import rng
+        shape = self._extended_shape(sample_shape)
+        eps = rng.normal(shape, self.loc.dtype, self.loc.device)
+        return self.loc + torch.matmul(eps, self._unbroadcasted_scale_tril.transpose(-1, -2))
+
+    def expand(self, batch_shape, _instance=None):
+        new = torch.distributions.MultivariateNormal.expand(
+            self, batch_shape, _instance=self._get_checked_instance(_GuideMVN, _instance))
+        return new
+
+
+def _product(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+class AutoContinuous(AutoGuide):
+    """All latent sites transformed to unconstrained space and concatenated into ONE latent vector;
+    subclasses provide the distribution over it (guides.py:605-828)."""
+
+    def __init__(self, model, init_loc_fn=init_to_median):
+        self.init_loc_fn = init_loc_fn
+        super().__init__(model)
+
+    def _setup_prototype(self, *args, **kwargs):
+        super()._setup_prototype(*args, **kwargs)
+        self._unconstrained_shapes = {}
+        self._cond_indep_stacks = {}
+        for name, site in self.prototype_trace.iter_stochastic_nodes():
+            with torch.no_grad():
+                self._unconstrained_shapes[name] = \
+                    biject_to(site["fn"].support).inv(site["value"]).shape
+            self._cond_indep_stacks[name] = site["cond_indep_stack"]
+        self.latent_dim = sum(_product(shape) for shape in self._unconstrained_shapes.values())
+        if self.latent_dim == 0:
+            raise RuntimeError("{} found no latent variables; Use an empty guide instead".format(
+                type(self).__name__))
+
+    def _init_loc(self):
+        parts = []
+        for name, site in self.prototype_trace.iter_stochastic_nodes():
+            with torch.no_grad():
+                parts.append(biject_to(site["fn"].support).inv(site["value"].detach()).reshape(-1))
+        latent = torch.cat(parts)
+        assert latent.size() == (self.latent_dim,)
+        return latent
+
+    def get_posterior(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def sample_latent(self, *args, **kwargs):
+        pos_dist = self.get_posterior(*args, **kwargs)
+        return sample("_{}_latent".format(self.prefix), pos_dist, infer={"is_auxiliary": True})
+
+    def _unpack_latent(self, latent):
+        batch_shape = latent.shape[:-1]   # plates outside of _setup_prototype, e.g. parallel particles
+        pos = 0
+        for name, site in self.prototype_trace.iter_stochastic_nodes():
+            constrained_shape = site["value"].shape
+            unconstrained_shape = self._unconstrained_shapes[name]
+            size = _product(unconstrained_shape)
+            event_dim = site["fn"].event_dim + len(unconstrained_shape) - len(constrained_shape)
+            unconstrained_shape = torch.broadcast_shapes(unconstrained_shape,
+                                                         batch_shape + (1,) * event_dim)
+            yield site, latent[..., pos:pos + size].reshape(unconstrained_shape)
+            pos += size
+        assert pos == latent.size(-1)
+
+    def forward(self, *args, **kwargs):
+        if self.prototype_trace is None:
+            self._setup_prototype(*args, **kwargs)
+        latent = self.sample_latent(*args, **kwargs)
+        plates = self._create_plates(*args, **kwargs)
+        result = {}
+        for site, unconstrained_value in self._unpack_latent(latent):
+            name = site["name"]
+            transform = biject_to(site["fn"].support)
+            value = transform(unconstrained_value)
+            if poutine.get_mask() is False or _is_identity(transform):
+                log_density = 0.0
+            else:
+                log_density = transform.inv.log_abs_det_jacobian(value, unconstrained_value)
+                log_density = sum_rightmost(
+                    log_density, log_density.dim() - value.dim() + site["fn"].event_dim)
+            delta_dist = dist.Delta(value, log_density=log_density, event_dim=site["fn"].event_dim)
+            with ExitStack() as stack:
+                for frame in self._cond_indep_stacks[name]:
+                    if frame.vectorized:
+                        stack.enter_context(plates[frame.name])
+                result[name] = sample(name, delta_dist)
+        return result
+
+    def _loc_scale(self, *args, **kwargs):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def median(self, *args, **kwargs):
+        loc, _ = self._loc_scale(*args, **kwargs)
+        return {site["name"]: biject_to(site["fn"].support)(unconstrained_value).clone()
+                for site, unconstrained_value in self._unpack_latent(loc.detach())}
+
+    @torch.no_grad()
+    def quantiles(self, quantiles, *args, **kwargs):
+        loc, scale = self._loc_scale(*args, **kwargs)
+        q = torch.tensor(quantiles, dtype=loc.dtype, device=loc.device).unsqueeze(-1)
+        latents = torch.distributions.Normal(loc, scale).icdf(q)
+        result = {}
+        for latent in latents:
+            for site, unconstrained_value in self._unpack_latent(latent):
+                result.setdefault(site["name"], []).append(
+                    biject_to(site["fn"].support)(unconstrained_value))
+        return {k: torch.stack(v) for k, v in result.items()}
+
+
+class AutoDiagonalNormal(AutoContinuous):
+    """Diagonal Normal over the concatenated unconstrained latent vector (guides.py:968-1029):
+    parameters ``<prefix>.loc`` and ``<prefix>.scale`` (softplus-positive)."""
+
+    scale_constraint = softplus_positive
+
+    def __init__(self, model, init_loc_fn=init_to_median, init_scale=0.1):
+        if not isinstance(init_scale, float) or not (init_scale > 0):
+            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
+        self._init_scale = init_scale
+        super().__init__(model, init_loc_fn=init_loc_fn)
+
+    def _setup_prototype(self, *args, **kwargs):
+        super()._setup_prototype(*args, **kwargs)
+        self._loc0 = self._init_loc()
+
+    def _params(self):
+        loc = param("{}.loc".format(self.prefix), lambda: self._loc0.clone(), constraints.real)
+        scale = param("{}.scale".format(self.prefix),
+                      lambda: torch.full_like(self._loc0, self._init_scale), self.scale_constraint)
+        return loc, scale
+
+    def get_posterior(self, *args, **kwargs):
+        loc, scale = self._params()
+        return dist.Normal(loc, scale).to_event(1)
+
+    def _loc_scale(self, *args, **kwargs):
+        return self._params()
+
+
+class AutoMultivariateNormal(AutoContinuous):
+    """Full-covariance Normal through its Cholesky factor (guides.py:855-965): parameters
+    ``<prefix>.loc``, ``<prefix>.scale`` (softplus-positive) and ``<prefix>.scale_tril`` (unit lower
+    Cholesky); scale_tril of the posterior = scale[..., None] * scale_tril."""
+
+    scale_constraint = softplus_positive
+    scale_tril_constraint = unit_lower_cholesky
+
+    def __init__(self, model, init_loc_fn=init_to_median, init_scale=0.1):
+        if not isinstance(init_scale, float) or not (init_scale > 0):
+            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
+        self._init_scale = init_scale
+        super().__init__(model, init_loc_fn=init_loc_fn)
+
+    def _setup_prototype(self, *args, **kwargs):
+        super()._setup_prototype(*args, **kwargs)
+        self._loc0 = self._init_loc()
+
+    def _params(self):
+        loc = param("{}.loc".format(self.prefix), lambda: self._loc0.clone(), constraints.real)
+        scale = param("{}.scale".format(self.prefix),
+                      lambda: torch.full_like(self._loc0, self._init_scale), self.scale_constraint)
+        scale_tril = param("{}.scale_tril".format(self.prefix),
+                           lambda: torch.eye(self.latent_dim, dtype=self._loc0.dtype,
+                                             device=self._loc0.device), self.scale_tril_constraint)
+        return loc, scale, scale_tril
+
+    def get_posterior(self, *args, **kwargs):
+        loc, scale, scale_tril = self._params()
+        return _GuideMVN(loc, scale_tril=scale[..., None] * scale_tril)
+
+    def _loc_scale(self, *args, **kwargs):
+        loc, scale, scale_tril = self._params()
+        st = scale[..., None] * scale_tril
+        return loc, st.pow(2).sum(-1).sqrt()
 
 
 class AutoDelta(AutoGuide):

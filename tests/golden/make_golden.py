@@ -46,14 +46,18 @@ class EpsBank:
         return torch.as_tensor(e, dtype=dtype, device=device)
 
     def __enter__(self):
+        import torch.distributions.multivariate_normal as tm
         import torch.distributions.normal as tn
         self._old = tn._standard_normal
         tn._standard_normal = self
+        tm._standard_normal = self
         return self
 
     def __exit__(self, *a):
+        import torch.distributions.multivariate_normal as tm
         import torch.distributions.normal as tn
         tn._standard_normal = self._old
+        tm._standard_normal = self._old
 
 
 def grads_of_store():
@@ -621,13 +625,66 @@ def g_meanfield():
          x3=pred_seq["x"].numpy(), eps3=list(bank3.used))
 
 
+# ---------------------------------------------------------------------------------------------
+# G11: AutoContinuous guides (AutoDiagonalNormal, AutoMultivariateNormal): loss and gradients
+# ---------------------------------------------------------------------------------------------
+def g_autocont():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer.autoguide import AutoDiagonalNormal, AutoMultivariateNormal, init_to_feasible
+    rng = np.random.default_rng(17)
+    N, D = 12, 3
+    X = torch.tensor(rng.standard_normal((N, D)))
+    y = torch.tensor(rng.standard_normal(N))
+
+    def model(X, y):
+        w = pyro.sample("w", dist.Normal(torch.zeros(D), 1.0).to_event(1))
+        s = pyro.sample("s", dist.LogNormal(0.0, 1.0))                    # positive support
+        with pyro.plate("g", 2):
+            u = pyro.sample("u", dist.Normal(0.0, 1.0))                   # plated latent
+        with pyro.plate("data", N):
+            mean = (X * w.unsqueeze(-2)).sum(-1) + u.sum(-1, keepdim=True)
+            pyro.sample("obs", dist.Normal(mean, s.unsqueeze(-1)), obs=y)
+
+    out = {}
+    for gname, cls in (("diag", AutoDiagonalNormal), ("mvn", AutoMultivariateNormal)):
+        for tag, P in (("p1", 1), ("p4", 4)):
+            pyro.clear_param_store()
+            guide = cls(model, init_loc_fn=init_to_feasible, init_scale=0.1)
+            guide(X, y)       # create parameters
+            store = pyro.get_param_store()
+            g2 = np.random.default_rng(23)
+            from torch.distributions import transform_to
+            with torch.no_grad():
+                for name in sorted(store.keys()):
+                    p_ = store[name]
+                    if name.endswith("scale_tril"):
+                        target = torch.tensor(np.tril(0.1 * g2.standard_normal(tuple(p_.shape)), -1)
+                                              + np.eye(p_.shape[0]))
+                    elif name.endswith("scale"):
+                        target = torch.tensor(np.exp(0.2 * g2.standard_normal(tuple(p_.shape)) - 1.5))
+                    else:
+                        target = torch.tensor(0.3 * g2.standard_normal(tuple(p_.shape)))
+                    # in place on the unconstrained leaf (the guide module holds the same tensor)
+                    store._params[name].data.copy_(transform_to(store._constraints[name]).inv(target))
+            params = {k: v.detach().clone().numpy() for k, v in store.items()}
+            elbo = Trace_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=1)
+            with EpsBank(41) as bank:
+                loss = elbo.loss_and_grads(model, guide, X, y)
+            key = gname + "_" + tag
+            out["loss_" + key] = loss
+            out["grads_" + key] = grads_of_store()
+            out["params_" + key] = params
+            out["eps_" + key] = list(bank.used)
+    save("autocont", X=X.numpy(), y=y.numpy(), **out)
+
+
 def post_np(d):
     return {k: v.numpy() for k, v in d.items()}
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont"]
     for w in which:
         globals()["g_" + w]()
 

@@ -326,3 +326,46 @@ def run_predictive(g, device, monkeypatch, rtol):
     monkeypatch.setattr(rng, "normal", seq_normal)
     pred = Predictive(model_p, posterior_samples=post, parallel=False)(None)
     np.testing.assert_allclose(pred["x"].cpu().numpy(), g["x3"], rtol=rtol)
+
+
+# ---- AutoContinuous guides (golden: tests/golden/make_golden.py g_autocont) -----------------------
+def run_autocont(g, device, monkeypatch, which, tag, rtol):
+    """AutoDiagonalNormal / AutoMultivariateNormal: loss and gradients of the reference for a model
+    with a vector site, a positive site (exp transform, Jacobian term) and a plated site."""
+    from torch.distributions import transform_to
+    from pyro_amd import rng
+    from pyro_amd.infer.autoguide import (AutoDiagonalNormal, AutoMultivariateNormal,
+                                          init_to_feasible)
+    dtype = torch.get_default_dtype()
+    X = torch.as_tensor(g["X"], dtype=dtype, device=device)
+    y = torch.as_tensor(g["y"], dtype=dtype, device=device)
+    N, D = X.shape
+
+    def t(x):
+        return torch.tensor(x, dtype=dtype, device=device)
+
+    def model(X, y):
+        w = pyro.sample("w", dist.Normal(torch.zeros(D, dtype=dtype, device=device), 1.0).to_event(1))
+        s = pyro.sample("s", dist.LogNormal(t(0.0), 1.0))
+        with pyro.plate("g", 2):
+            u = pyro.sample("u", dist.Normal(t(0.0), 1.0))
+        with pyro.plate("data", N):
+            mean = (X * w.unsqueeze(-2)).sum(-1) + u.sum(-1, keepdim=True)
+            pyro.sample("obs", dist.Normal(mean, s.unsqueeze(-1)), obs=y)
+
+    cls = AutoDiagonalNormal if which == "diag" else AutoMultivariateNormal
+    key = which + "_" + tag
+    P = 1 if tag == "p1" else 4
+    pyro.clear_param_store()
+    guide = cls(model, init_loc_fn=init_to_feasible, init_scale=0.1)
+    guide(X, y)       # creates the parameters
+    store = pyro.get_param_store()
+    with torch.no_grad():
+        for name in list(store.keys()):
+            target = torch.tensor(g["params_" + key + "/" + name], dtype=dtype, device=device)
+            store._params[name].copy_(transform_to(store._constraints[name]).inv(target))
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps_" + key), device))
+    elbo = Trace_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=1)
+    loss = elbo.loss_and_grads(model, guide, X, y)
+    np.testing.assert_allclose(loss, float(g["loss_" + key]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads_" + key, rtol * 10)

@@ -56,3 +56,9 @@ def test_trace_mean_field_elbo(monkeypatch, tag):
 
 def test_predictive(monkeypatch):
     models.run_predictive(load("predictive"), torch.device("cpu"), monkeypatch, rtol=1e-10)
+
+
+@pytest.mark.parametrize("which", ["diag", "mvn"])
+@pytest.mark.parametrize("tag", ["p1", "p4"])
+def test_autocontinuous_guides(monkeypatch, which, tag):
+    models.run_autocont(load("autocont"), torch.device("cpu"), monkeypatch, which, tag, rtol=1e-9)

@@ -73,6 +73,14 @@ def test_trace_mean_field_elbo(gpu, monkeypatch, tag):
     models.run_meanfield(load("meanfield"), gpu, monkeypatch, tag, rtol=1e-9)
 
 
+@pytest.mark.parametrize("which", ["diag", "mvn"])
+@pytest.mark.parametrize("tag", ["p1", "p4"])
+def test_autocontinuous_guides(gpu, monkeypatch, which, tag):
+    """AutoDiagonalNormal / AutoMultivariateNormal against the reference's loss and gradients."""
+    torch.set_default_dtype(torch.float64)
+    models.run_autocont(load("autocont"), gpu, monkeypatch, which, tag, rtol=1e-9)
+
+
 def test_predictive(gpu, monkeypatch):
     """Predictive (vectorised and sequential) against the reference's draws (recorded normals)."""
     torch.set_default_dtype(torch.float64)
