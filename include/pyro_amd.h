@@ -410,6 +410,17 @@ int pa_adam_step(int dtype, void* param, void* grad, void* exp_avg, void* exp_av
                  double clip_norm, double lrd, int clipped, int64_t* step_dev, int zero_grad,
                  pa_stream_t stream);
 
+/* pa_adam_step (n > 0) whose last workgroup also does what pa_publish_scalar does: advance the
+ * Philox block counter (may be NULL) and hand the scalar `src` (the step's loss) to the host
+ * through the pinned (host_value, host_seq) mailbox.  A captured SVI step (pyro/infer/svi.py:
+ * 133-159: loss_and_grads, optimizer, zero_grads, return loss) then ends in this one launch. */
+int pa_adam_step_publish(int dtype, void* param, void* grad, void* exp_avg, void* exp_avg_sq,
+                         int64_t n, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, double clip_norm, double lrd, int clipped,
+                         int64_t* step_dev, int zero_grad, int src_dtype, const void* src,
+                         double* host_value, uint64_t* host_seq, uint64_t* counter, uint64_t inc,
+                         pa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,10 @@ _SIGNATURES = {
     "pa_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                              c_double, c_double, c_double, c_double, c_double, c_double, c_int,
                              c_void_p, c_int, c_void_p]),
+    "pa_adam_step_publish": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_double, c_double, c_double, c_double, c_double, c_double,
+                                     c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_uint64, c_void_p]),
 }
 
 _lib = None

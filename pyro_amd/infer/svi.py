@@ -154,13 +154,18 @@ class SVI:
                         with poutine.trace(param_only=True) as param_capture:
                             loss = self._loss_device(self.model, self.guide, *args, **kwargs)
                         params = self._params_of(param_capture)
-                        if not split:
-                            self.optim(params)
-                            if not getattr(self.optim, "zeroes_grads", False):
-                                zero_grads(params)
                         loss = loss.detach() if isinstance(loss, torch.Tensor) else \
                             torch.full((), float(loss), device=device)
-                        cap.finish(publish=(loss,) + mailbox)
+                        if not split and getattr(self.optim, "fused_publish", False):
+                            # the update launch also advances the Philox counter and hands the
+                            # loss to the host: the step ends in it
+                            self.optim(params, publish=cap.finish_args((loss,) + mailbox))
+                        else:
+                            if not split:
+                                self.optim(params)
+                                if not getattr(self.optim, "zeroes_grads", False):
+                                    zero_grads(params)
+                            cap.finish(publish=(loss,) + mailbox)
                 if split:
                     # the gradient all-reduce is NOT captured: graph 1 = loss + backward, then an
                     # eager collective, then graph 2 = optimizer update + gradient zeroing

@@ -613,11 +613,26 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
 # ------------------------------------------------------------------------------------------
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
-              weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True):
+              weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True,
+              publish=None):
+    """``publish`` = (device scalar, pinned float64[1], pinned int64[1], counter or None, inc):
+    the launch's last workgroup also does what publish_scalar does (pa_adam_step_publish)."""
     _require_gpu(param, grad, exp_avg, exp_avg_sq, step_dev)
     assert step_dev.dtype == torch.int64 and step_dev.numel() == 2   # [step, ticket]
     for x in (param, grad, exp_avg, exp_avg_sq):
         assert x.is_contiguous() and x.dtype == param.dtype and x.numel() == param.numel()
+    if publish is not None:
+        src, host_value, host_seq, counter, inc = publish
+        _require_gpu(src)
+        assert src.numel() == 1 and host_value.dtype == torch.float64 and host_value.is_pinned()
+        assert host_seq.dtype == torch.int64 and host_seq.is_pinned()
+        check(_lib.load().pa_adam_step_publish(
+            _dtype(param), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+            float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+            float(clip_norm), float(lrd), int(bool(clipped)), _ptr(step_dev), int(bool(zero_grad)),
+            _dtype(src), _ptr(src), _ptr(host_value), _ptr(host_seq),
+            _ptr(counter) if counter is not None else None, int(inc), _stream()))
+        return
     check(_lib.load().pa_adam_step(_dtype(param), _ptr(param), _ptr(grad), _ptr(exp_avg),
                                    _ptr(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
                                    float(betas[1]), float(eps), float(weight_decay),

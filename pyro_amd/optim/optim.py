@@ -131,7 +131,9 @@ class _FlatAdam:
         if self.step_dev is None:
             self.step_dev = torch.zeros(2, dtype=torch.int64, device=proto.device)  # [step, ticket]
 
-    def __call__(self, params, *args, skip_grad_hook=False, **kwargs):
+    fused_publish = True     # __call__(publish=...) folds the loss hand-over into the update launch
+
+    def __call__(self, params, *args, skip_grad_hook=False, publish=None, **kwargs):
         new = [p for p in params if p not in self._index]
         if new:
             # deterministic order (same on every rank): by param-store name
@@ -150,7 +152,10 @@ class _FlatAdam:
         kernels.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev,
                           lr=self.lr, betas=self.betas, eps=self.eps,
                           weight_decay=self.weight_decay, clip_norm=self.clip_norm, lrd=self.lrd,
-                          clipped=self._clipped, zero_grad=True)
+                          clipped=self._clipped, zero_grad=True,
+                          publish=publish if self.flat.numel() else None)
+        if publish is not None and not self.flat.numel():
+            kernels.publish_scalar(*publish)
 
     def get_state(self):
         return {"names": [_PARAM_STORE.param_name(p) for p in self._params],

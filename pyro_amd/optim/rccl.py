@@ -35,6 +35,10 @@ class RcclOptimizer:
         return getattr(self.optim, "zeroes_grads", False)
 
     @property
+    def fused_publish(self):
+        return getattr(self.optim, "fused_publish", False)
+
+    @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 

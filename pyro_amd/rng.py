@@ -102,6 +102,12 @@ class GraphCapture:
         else:
             kernels.counter_add(self.base, self.used)
 
+    def finish_args(self, publish):
+        """The arguments ``finish(publish)`` would launch with, for a caller that folds the node
+        into its own last launch (the optimizer update: kernels.adam_step(publish=...))."""
+        self.used = _STATE["offset"] - self.start
+        return (publish[0], publish[1], publish[2], self.base, self.used)
+
     def __exit__(self, *exc):
         _CAPTURE["active"] = None
         _STATE["offset"] = self.start      # capturing executes nothing: no draws were consumed

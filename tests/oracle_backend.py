@@ -318,7 +318,9 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
-              weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True):
+              weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True,
+              publish=None):
+    assert publish is None          # only a captured (GPU) step folds the hand-over in
     step = int(step_dev[0].item()) + 1
     p, m, v = o_adam.adam_step(_np(param), _np(grad), _np(exp_avg), _np(exp_avg_sq), step, lr, betas,
                                eps, weight_decay, clip_norm, lrd, clipped)

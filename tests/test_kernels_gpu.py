@@ -460,3 +460,29 @@ def test_adam_step(gpu, clipped, dtype):
     assert step_dev.tolist() == [5, 0]
     tol = 1e-5 if dtype == torch.float32 else 1e-12
     np.testing.assert_allclose(tp.cpu().numpy(), pr, rtol=tol, atol=tol)
+
+
+def test_adam_step_publish_hands_over_the_scalar(gpu):
+    """pa_adam_step_publish == pa_adam_step + pa_publish_scalar: same update, and the pinned
+    mailbox / device counter advance exactly once per launch."""
+    k = _k()
+    n = 70_001
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    bufs = []
+    for _ in range(2):
+        bufs.append((tt(p0, gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu),
+                     torch.zeros(2, dtype=torch.int64, device=gpu)))
+    hv = torch.zeros(1, dtype=torch.float64).pin_memory()
+    hs = torch.zeros(1, dtype=torch.int64).pin_memory()
+    counter = torch.full((1,), 40, dtype=torch.int64, device=gpu)
+    for step in range(1, 4):
+        g = (rng.standard_normal(n) * 3).astype(np.float32)
+        loss = torch.full((), 1.5 * step, device=gpu, dtype=torch.float32)
+        (pa, ma, va, sa), (pb, mb, vb, sb) = bufs
+        k.adam_step(pa, tt(g, gpu), ma, va, sa, lr=0.01)
+        k.adam_step(pb, tt(g, gpu), mb, vb, sb, lr=0.01, publish=(loss, hv, hs, counter, 7))
+        torch.cuda.synchronize()
+        assert hs.item() == step and hv.item() == 1.5 * step
+        assert counter.item() == 40 + 7 * step
+    assert torch.equal(bufs[0][0], bufs[1][0]) and bufs[1][3].tolist() == [3, 0]
