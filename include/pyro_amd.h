@@ -410,6 +410,14 @@ int pa_adam_step(int dtype, void* param, void* grad, void* exp_avg, void* exp_av
                  double clip_norm, double lrd, int clipped, int64_t* step_dev, int zero_grad,
                  pa_stream_t stream);
 
+/* Per-chain dense matrix x vector: y[c] = M[c] x[c] (transpose = 0) or M[c]^T x[c]
+ * (transpose = 1); M[C, D, D] row-major with chain stride m_stride_chain elements (0 = one matrix
+ * shared by all chains), x, y [C, D] contiguous, x != y.  Replaces the dense-block products of
+ * BlockMassMatrix.kinetic_grad / scale / unscale (pyro/infer/mcmc/adaptation.py:328-392), which
+ * the reference runs one chain per process; here every chain carries its own adapted matrix. */
+int pa_chain_matvec(int dtype, const void* M, int64_t m_stride_chain, const void* x, void* y,
+                    int64_t C, int64_t D, int transpose, pa_stream_t stream);
+
 /* pa_adam_step (n > 0) whose last workgroup also does what pa_publish_scalar does: advance the
  * Philox block counter (may be NULL) and hand the scalar `src` (the step's loss) to the host
  * through the pinned (host_value, host_seq) mailbox.  A captured SVI step (pyro/infer/svi.py:

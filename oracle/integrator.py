@@ -10,7 +10,8 @@ def single_step_verlet(z, r, potential_and_grad, inv_mass, step_size, z_grads=No
     if z_grads is None:
         _, z_grads = potential_and_grad(z)
     r = r + 0.5 * step_size * (-z_grads)          # r(n+1/2)
-    z = z + step_size * (inv_mass * r)            # z(n+1)
+    v = inv_mass * r if np.ndim(inv_mass) < 2 else inv_mass @ r   # kinetic_grad (adaptation.py:328-347)
+    z = z + step_size * v                         # z(n+1)
     pe, z_grads = potential_and_grad(z)
     r = r + 0.5 * step_size * (-z_grads)          # r(n+1)
     return z, r, z_grads, pe

@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE -- NUTS transition restated from pyro/infer/mcmc/nuts.py (recursive
 formulation, exactly as the reference: _build_basetree :197-248, _build_tree :250-365,
 _is_turning :184-195, sample :367-522, _logaddexp :15-17) for a flat position vector with a
-diagonal mass matrix (pyro/infer/mcmc/adaptation.py:238-392; hmc.py:152-156 kinetic energy,
-:231-248 momentum draw).
+diagonal (inv_mass[D]) or dense (inv_mass[D, D], full_mass=True) mass matrix
+(pyro/infer/mcmc/adaptation.py:238-392; hmc.py:152-156 kinetic energy, :231-248 momentum draw).
 
 Randomness is abstracted behind a ``draws`` object so the same code can be
  * pinned against the unmodified reference (SequenceDraws: the reference's own pyro.sample
@@ -89,13 +89,26 @@ class _Nuts:
         self.pg = potential_and_grad
         self.dtype = np.dtype(dtype).type
         self.v = np.asarray(inv_mass, dtype=self.dtype)
-        # BlockMassMatrix.inverse_mass_matrix.setter, diagonal case (adaptation.py:270-282)
-        self.sqrt_inv = np.sqrt(self.v)                       # mass_matrix_sqrt_inverse
-        self.sqrt = (self.dtype(1) / self.sqrt_inv)           # mass_matrix_sqrt
+        # BlockMassMatrix.inverse_mass_matrix.setter (adaptation.py:270-282)
+        if self.v.ndim == 1:
+            self.sqrt_inv = np.sqrt(self.v)                   # mass_matrix_sqrt_inverse
+            self.sqrt = (self.dtype(1) / self.sqrt_inv)       # mass_matrix_sqrt
+        else:
+            # dense: sqrt_inverse = cholesky(inverse mass)^T (upper), sqrt = its triangular inverse
+            self.sqrt_inv = np.linalg.cholesky(self.v).T.astype(self.dtype)
+            self.sqrt = np.linalg.inv(self.sqrt_inv).astype(self.dtype)
         self.eps = self.dtype(step_size)
         self.draws = draws
         self.multinomial = multinomial
         self.n_grad_evals = 0
+
+    def scale(self, r_unscaled):
+        """adaptation.py:349-373."""
+        return self.sqrt * r_unscaled if self.v.ndim == 1 else self.sqrt @ r_unscaled
+
+    def unscale(self, r):
+        """adaptation.py:375-392."""
+        return self.sqrt_inv * r if self.v.ndim == 1 else self.sqrt_inv @ r
 
     def kinetic(self, r_unscaled):
         return self.dtype(0.5) * self.dtype(r_unscaled.dot(r_unscaled))   # hmc.py:152-156
@@ -110,7 +123,7 @@ class _Nuts:
         step = self.eps if direction == 1 else -self.eps
         z_new, r_new, z_grads, pe = single_step_verlet(z, r, self.pg, self.v, step, z_grads)
         self.n_grad_evals += 1
-        r_new_unscaled = r_new * self.sqrt_inv
+        r_new_unscaled = self.unscale(r_new)
         energy_new = self.dtype(pe) + self.kinetic(r_new_unscaled)
         if math.isnan(energy_new):
             energy_new = self.dtype(math.inf)
@@ -177,7 +190,7 @@ def nuts_transition(z, pe, z_grads, potential_and_grad, inv_mass, step_size, dra
     z = np.asarray(z, dtype=dt)
     z_grads = np.asarray(z_grads, dtype=dt)
     r_unscaled = np.asarray(draws.momentum(z.shape[0]), dtype=dt)
-    r = r_unscaled * n.sqrt                                   # adaptation.py:349-373 scale()
+    r = n.scale(r_unscaled)                                   # adaptation.py:349-373 scale()
     energy_current = n.kinetic(r_unscaled) + dt(pe)
     if multinomial:
         log_slice = -energy_current

@@ -12,6 +12,7 @@ from collections import namedtuple
 
 import torch
 
+from ... import kernels
 from ...ops.dual_averaging import DualAveraging
 from ...ops.welford import WelfordCovariance
 
@@ -83,13 +84,109 @@ class DiagMassMatrix:
         return self._sqrt_inv * r
 
 
+class DenseMassMatrix:
+    """Per-chain dense (or block-structured) mass matrix: inverse mass V[C, D, D] and its
+    Cholesky factor L (V = L L^T) (reference: BlockMassMatrix with dense blocks,
+    adaptation.py:238-392; ``full_mass=True`` or a list of site-name tuples, hmc.py:296-333).
+
+    ``mask`` [D, D] (0/1) encodes the block structure over the flat layout: entries outside the
+    dense blocks (and off the diagonal of the remaining sites) are held at zero, which is what
+    adapting every block with its own Welford estimator amounts to.
+
+    The reference's three products are provided (kinetic_grad = V r, scale = L^-T eps,
+    unscale = L^T r), but the samplers do not call them per leapfrog step: they run in the
+    WHITENED coordinates z' = L^-1 z, r' = L^T r, where the same Hamiltonian has unit mass
+        U'(z') = U(L z'),  grad' = L^T grad,  K = r'.r'/2,
+    so the leapfrog / tree kernels written for a diagonal mass are reused unchanged, and the
+    per-step cost of the dense mass is the two per-chain products ``color`` and ``pull``
+    (kernels.chain_matvec, one launch each for all chains).  ``r'`` is exactly the reference's
+    "unscaled" momentum (unscale(r) = L^T r), so the U-turn test, the kinetic energy and the
+    momentum draw r' ~ N(0, I) are the reference's own, term for term."""
+
+    def __init__(self, C, D, dtype, device, mask=None, init_scale=1.0, adapt=True):
+        self.C, self.D = C, D
+        self._scheme = WelfordCovariance(diagonal=False) if adapt else None
+        self._mask = None if mask is None else mask.to(dtype=dtype, device=device)
+        self.version = 0
+        self.unit_diag = torch.ones((C, D), dtype=dtype, device=device)
+        eye = torch.eye(D, dtype=dtype, device=device) * float(init_scale)
+        self.inverse_mass_matrix = eye.expand(C, D, D)
+
+    @property
+    def inverse_mass_matrix(self):
+        return self._v
+
+    @inverse_mass_matrix.setter
+    def inverse_mass_matrix(self, v):
+        if self._scheme is not None:
+            self._scheme.reset()
+        if v.dim() == 2:
+            v = v.expand(self.C, self.D, self.D)
+        self._v = v.contiguous()
+        # adaptation.py:270-282: sqrt_inverse = cholesky(V)^T = L^T, sqrt = triu_inverse = L^-T
+        self._L = torch.linalg.cholesky(self._v).contiguous()
+        eye = torch.eye(self.D, dtype=v.dtype, device=v.device).expand_as(self._L)
+        self._Linv = torch.linalg.solve_triangular(self._L, eye, upper=False).contiguous()
+        self.version += 1
+
+    def update(self, z):
+        self._scheme.update(z.detach())
+
+    def end_adaptation(self):
+        cov = self._scheme.get_covariance(regularize=True)
+        if self._mask is not None:
+            cov = cov * self._mask
+        self.inverse_mass_matrix = cov
+
+    # ---- the reference's products (adaptation.py:328-392) --------------------------------------
+    def kinetic_grad(self, r):
+        return kernels.chain_matvec(self._v, r.contiguous())
+
+    def scale(self, r_unscaled):
+        return kernels.chain_matvec(self._Linv, r_unscaled.contiguous(), transpose=True)
+
+    def unscale(self, r):
+        return kernels.chain_matvec(self._L, r.contiguous(), transpose=True)
+
+    # ---- whitened coordinates --------------------------------------------------------------------
+    def whiten(self, z):            # z' = L^-1 z
+        return kernels.chain_matvec(self._Linv, z.contiguous())
+
+    def color(self, zw):            # z = L z'
+        return kernels.chain_matvec(self._L, zw.contiguous())
+
+    def pull(self, grad):           # grad' = L^T grad
+        return kernels.chain_matvec(self._L, grad.contiguous(), transpose=True)
+
+
+def block_mask(layout, dense_mass):
+    """0/1 matrix [D, D] of the mass-matrix structure over a flat Layout: ``dense_mass`` True =
+    one dense block over all sites; a list of site-name tuples = one dense block per tuple, the
+    remaining sites diagonal (hmc.py:296-326)."""
+    D = layout.D
+    if dense_mass is True:
+        return None
+    msg = "full_mass should be a list of tuples of site names."
+    assert isinstance(dense_mass, list), msg
+    mask = torch.eye(D)
+    seen = set()
+    for block in dense_mass:
+        assert block and isinstance(block, tuple), msg
+        idx = []
+        for name in block:
+            assert isinstance(name, str) and name in layout.slices, msg
+            assert name not in seen, "Site names specified in full_mass are duplicated."
+            seen.add(name)
+            a, b = layout.slices[name]
+            idx.extend(range(a, b))
+        idx = torch.tensor(idx)
+        mask[idx.unsqueeze(-1), idx.unsqueeze(0)] = 1.0
+    return mask
+
+
 class WarmupAdapter:
     def __init__(self, step_size=1, adapt_step_size=False, target_accept_prob=0.8,
                  adapt_mass_matrix=False, dense_mass=False):
-        if dense_mass:
-            raise NotImplementedError(
-                "pyro_amd: the vectorised HMC/NUTS kernels adapt a diagonal mass matrix per "
-                "chain (the reference default, full_mass=False); dense mass is not built yet")
         self.adapt_step_size = adapt_step_size
         self.adapt_mass_matrix = adapt_mass_matrix
         self.target_accept_prob = target_accept_prob
@@ -112,7 +209,7 @@ class WarmupAdapter:
                                          self._adapt_end_buffer, self._adapt_initial_window)
 
     def configure(self, warmup_steps, C, D, dtype, device, initial_step_size=None,
-                  find_reasonable_step_size_fn=None):
+                  find_reasonable_step_size_fn=None, layout=None):
         self._warmup_steps = warmup_steps
         s = self._init_step_size if initial_step_size is None else initial_step_size
         if isinstance(s, torch.Tensor):
@@ -120,8 +217,13 @@ class WarmupAdapter:
         else:
             self.step_size = torch.full((C,), float(s), dtype=dtype, device=device)
         self._find_reasonable_step_size = find_reasonable_step_size_fn
-        self.mass_matrix_adapter = DiagMassMatrix(C, D, dtype, device,
-                                                  adapt=self.adapt_mass_matrix)
+        if self.dense_mass:
+            mask = block_mask(layout, self.dense_mass) if layout is not None else None
+            self.mass_matrix_adapter = DenseMassMatrix(C, D, dtype, device, mask=mask,
+                                                       adapt=self.adapt_mass_matrix)
+        else:
+            self.mass_matrix_adapter = DiagMassMatrix(C, D, dtype, device,
+                                                      adapt=self.adapt_mass_matrix)
         if not self._adaptation_disabled:
             self._adaptation_schedule = self._build_adaptation_schedule()
         self._current_window = 0
@@ -249,5 +351,5 @@ class WarmupAdapter:
         return self._adaptation_schedule
 
 
-__all__ = ["WarmupAdapter", "DiagMassMatrix", "adapt_window", "build_adaptation_schedule",
+__all__ = ["WarmupAdapter", "DiagMassMatrix", "DenseMassMatrix", "block_mask", "adapt_window", "build_adaptation_schedule",
            "math"]

@@ -170,7 +170,7 @@ class MCMC:
                 k.end_warmup()
                 for i in range(S):
                     k._transition()
-                    buf[i].copy_(k._z)
+                    buf[i].copy_(k._position())
                     if self.hook_fn is not None:
                         self.hook_fn(k, None, "Sample", i)
                 flat = buf.transpose(0, 1)    # [C, S, D]

@@ -19,6 +19,35 @@ from .mcmc_kernel import MCMCKernel
 from .util import FlatPotential, Layout, initialize_model
 
 
+class _UnitMassView:
+    """What the kernels see when the sampler runs in the whitened coordinates of a dense mass
+    matrix (adaptation.DenseMassMatrix): unit diagonal inverse mass, scale/unscale = identity."""
+
+    def __init__(self, dense):
+        self.inverse_mass_matrix = dense.unit_diag
+
+    @staticmethod
+    def scale(r_unscaled):
+        return r_unscaled
+
+    @staticmethod
+    def unscale(r):
+        return r
+
+
+class _WhitenedPotential:
+    """U'(z') = U(L z'), grad' = L^T grad for the CURRENT Cholesky factor of the adapter's dense
+    inverse mass (two kernels.chain_matvec launches around the potential itself)."""
+
+    def __init__(self, base, adapter):
+        self.base, self.adapter = base, adapter
+
+    def __call__(self, zw):
+        mm = self.adapter.mass_matrix_adapter
+        pe, grad = self.base(mm.color(zw))
+        return pe, mm.pull(grad)
+
+
 class HMC(MCMCKernel):
     def __init__(self, model=None, potential_fn=None, step_size=1, trajectory_length=None,
                  num_steps=None, adapt_step_size=True, adapt_mass_matrix=True, full_mass=False,
@@ -45,6 +74,7 @@ class HMC(MCMCKernel):
         self._max_sliced_energy = 1000
         self.num_chains = 1
         self.chain_offset = 0      # first global chain index of this rank (chain-sharded runs)
+        self._dense = bool(full_mass)
         self._reset()
         self._adapter = WarmupAdapter(step_size, adapt_step_size=adapt_step_size,
                                       adapt_mass_matrix=adapt_mass_matrix,
@@ -61,6 +91,7 @@ class HMC(MCMCKernel):
         self._prototype_trace = None
         self._initial_params = None
         self._z = self._pe = self._grad = None
+        self._zr, self._white_version = None, -1
         self._warmup_steps = None
         self._layout = None
         self._n_leapfrog_total = None
@@ -72,6 +103,42 @@ class HMC(MCMCKernel):
     @property
     def inverse_mass_matrix(self):
         return self.mass_matrix_adapter.inverse_mass_matrix
+
+    @property
+    def _mm_eff(self):
+        """Mass-matrix object of the coordinates the kernels run in: the adapter itself (diagonal
+        mass) or the unit mass of the whitened problem (dense mass)."""
+        mm = self.mass_matrix_adapter
+        if not self._dense:
+            return mm
+        view = getattr(self, "_unit_view", None)
+        if view is None or view.inverse_mass_matrix is not mm.unit_diag:
+            view = self._unit_view = _UnitMassView(mm)
+        return view
+
+    def _position(self):
+        """The chains' positions in the model's (unconstrained) coordinates; ``self._z`` holds
+        the whitened coordinates when the mass matrix is dense."""
+        return self._zr if self._dense else self._z
+
+    def _sync_coordinates(self):
+        """Dense mass only: if the mass matrix was replaced since the state was whitened (a
+        warm-up window ended, or the user assigned ``inverse_mass_matrix``), re-express it."""
+        if self._dense and self.mass_matrix_adapter.version != self._white_version:
+            self._rewhiten(self._zr)
+
+    def _rewhiten(self, z_real):
+        """(Re)express the state in the whitened coordinates of the current dense mass matrix."""
+        self._zr = z_real.clone()
+        self._white_version = self.mass_matrix_adapter.version
+        zw = self.mass_matrix_adapter.whiten(z_real)
+        pe, grad = self._potential(zw)
+        if self._z is None or self._pe is None:
+            self._z, self._pe, self._grad = zw, pe.detach().contiguous(), grad.detach().contiguous()
+        else:       # in place: the NUTS tree workspace keeps references to these buffers
+            self._z.copy_(zw)
+            self._pe.copy_(pe.detach())
+            self._grad.copy_(grad.detach())
 
     @property
     def step_size(self):
@@ -119,16 +186,22 @@ class HMC(MCMCKernel):
         self._potential = FlatPotential(self.potential_fn, self._layout, self._batched)
         z = self._layout.flatten({k: v.detach() for k, v in params.items()}, C, self._batched)
         kernels._require_gpu(z)
-        self._z = z.clone()
-        pe, grad = self._potential(self._z)
-        self._pe, self._grad = pe.detach().contiguous(), grad.detach().contiguous()
+        self._adapter.configure(warmup_steps, C, self._layout.D, z.dtype, z.device,
+                                find_reasonable_step_size_fn=self._find_reasonable_step_size,
+                                layout=self._layout)
+        if self._dense:
+            self._potential = _WhitenedPotential(self._potential, self._adapter)
+            self._z = self._pe = None
+            self._rewhiten(z)
+        else:
+            self._z = z.clone()
+            pe, grad = self._potential(self._z)
+            self._pe, self._grad = pe.detach().contiguous(), grad.detach().contiguous()
         self._accept_cnt = torch.zeros((C,), dtype=torch.int64, device=z.device)
         self._mean_accept_prob = torch.zeros((C,), dtype=z.dtype, device=z.device)
         self._n_leapfrog_total = torch.zeros((), dtype=torch.int64, device=z.device)
-        self._adapter.configure(warmup_steps, C, self._layout.D, z.dtype, z.device,
-                                find_reasonable_step_size_fn=self._find_reasonable_step_size)
         if self._adapter.adapt_step_size:
-            self._adapter.reset_step_size_adaptation(self._z)
+            self._adapter.reset_step_size_adaptation(z)
         self._seed = rng._STATE["seed"]
 
     def cleanup(self):
@@ -140,12 +213,12 @@ class HMC(MCMCKernel):
 
     def _sample_r(self):
         r_unscaled = rng.normal(self._z.shape, self._z.dtype, self._z.device)
-        return self.mass_matrix_adapter.scale(r_unscaled), r_unscaled   # hmc.py:231-248
+        return self._mm_eff.scale(r_unscaled), r_unscaled   # hmc.py:231-248
 
     def _leapfrog(self, z, r, grad, step):
         """One velocity-Verlet step for all chains, in place on (z, r); returns (pe, grad)."""
         step = step.contiguous()
-        kernels.leapfrog_kick_drift(z, r, grad, self.inverse_mass_matrix, step)
+        kernels.leapfrog_kick_drift(z, r, grad, self._mm_eff.inverse_mass_matrix, step)
         pe, grad = self._potential(z)
         grad = grad.contiguous()
         kernels.leapfrog_kick(r, grad, step)
@@ -155,9 +228,11 @@ class HMC(MCMCKernel):
         """Per chain: double / halve the step size until the one-step acceptance probability
         crosses the target (reference: hmc.py:170-229), all chains in lock step under masks."""
         step = self.step_size.clone()
+        if self._dense:
+            z = self.mass_matrix_adapter.whiten(z)    # ``z`` arrives in model coordinates
         pe, grad = self._potential(z)
         grad = grad.contiguous()
-        mm = self.mass_matrix_adapter
+        mm = self._mm_eff
 
         def trial(step):
             r, r_u = self._sample_r()
@@ -182,20 +257,24 @@ class HMC(MCMCKernel):
 
     def _after_transition(self, accept_prob, accepted, diverging):
         self._t += 1
+        if self._dense:
+            self._zr = self.mass_matrix_adapter.color(self._z)
         if self._t > self._warmup_steps:
             n = self._t - self._warmup_steps
             self._accept_cnt += accepted.to(torch.int64)
             self._divergences.append(diverging)
         else:
             n = self._t
-            self._adapter.step(self._t, self._z, accept_prob, self._grad)
+            self._adapter.step(self._t, self._position(), accept_prob, None)
+            self._sync_coordinates()      # a window may have ended: new mass, new coordinates
         self._mean_accept_prob += (torch.nan_to_num(accept_prob, nan=0.0)
                                    - self._mean_accept_prob) / n
 
     # ---- one transition for all chains -------------------------------------------------------
     def _transition(self):
+        self._sync_coordinates()
         z, pe, grad = self._z, self._pe, self._grad
-        mm = self.mass_matrix_adapter
+        mm = self._mm_eff
         r, r_u = self._sample_r()
         energy_current = self._kinetic_energy(r_u) + pe
         step = self.step_size
@@ -224,7 +303,7 @@ class HMC(MCMCKernel):
         """One transition; ``params`` is ignored in favour of the cached state when it is the
         state returned by the previous call (the reference caches the same way, hmc.py:371-379)."""
         self._transition()
-        return self._layout.unflatten(self._z.clone(), self._batched)
+        return self._layout.unflatten(self._position().clone(), self._batched)
 
     # ---- reporting ---------------------------------------------------------------------------
     def logging(self):

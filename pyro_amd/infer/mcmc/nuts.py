@@ -47,16 +47,18 @@ class NUTS(HMC):
         self._tree = None
         self._tree_depth_sum = torch.zeros((), dtype=torch.int64, device=self._z.device)
         self._fused = (self.use_fused_gaussian and isinstance(self.potential_fn, GaussianPotential)
-                       and self._layout.D <= 128 and len(self._layout.names) == 1)
+                       and self._layout.D <= 128 and len(self._layout.names) == 1
+                       and not self._dense)   # dense mass: per-chain whitened potential, tree path
         if self._fused:
             self._Lambda = self.potential_fn.precision.to(self._z.dtype).contiguous()
         self._counters = torch.zeros((3, self.num_chains), dtype=torch.int64,
                                      device=self._z.device)
 
     def _transition(self):
+        self._sync_coordinates()
         t = self._t
         step = self.step_size.contiguous()
-        inv_mass = self.inverse_mass_matrix
+        inv_mass = self._mm_eff.inverse_mass_matrix
         if self._fused:
             out = kernels.nuts_gaussian_transition(
                 self._z, self._pe, self._grad, self._Lambda, inv_mass, step,

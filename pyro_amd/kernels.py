@@ -456,6 +456,20 @@ def leapfrog_kick_drift(z, r, grad, inv_mass, step):
                                              D, _stream()))
 
 
+def chain_matvec(M, x, transpose=False):
+    """y[c] = M[c] @ x[c] (or M[c]^T @ x[c]): M [C, D, D] (or [D, D] shared by all chains),
+    x [C, D]; one launch for all chains (pa_chain_matvec)."""
+    _require_gpu(M, x)
+    C, D = x.shape
+    assert M.shape[-2:] == (D, D) and M.dim() in (2, 3) and M.dtype == x.dtype
+    assert M.is_contiguous() and x.is_contiguous()
+    assert M.dim() == 2 or M.shape[0] == C
+    y = torch.empty_like(x)
+    check(_lib.load().pa_chain_matvec(_dtype(x), _ptr(M), D * D if M.dim() == 3 else 0, _ptr(x),
+                                      _ptr(y), C, D, int(bool(transpose)), _stream()))
+    return y
+
+
 def leapfrog_kick(r, grad, step):
     _require_gpu(r, grad, step)
     C, D = r.shape

@@ -332,18 +332,27 @@ def g_nuts():
     flat = {}
     for case, (D, multinomial, step, n_trans) in {"d10_multi": (10, True, 0.35, 6),
                                                   "d100_multi": (100, True, 0.12, 4),
-                                                  "d10_slice": (10, False, 0.3, 6)}.items():
+                                                  "d10_slice": (10, False, 0.3, 6),
+                                                  "d10_dense": (10, True, 0.5, 6),
+                                                  "d12_dense_slice": (12, False, 0.45, 5)}.items():
         A = rng.standard_normal((D, D))
         Lam = np.linalg.inv(A @ A.T / D + 0.1 * np.eye(D))
         Lam = 0.5 * (Lam + Lam.T)
         Lt = torch.tensor(Lam)
-        inv_mass = rng.uniform(0.5, 1.5, D)
+        dense = "dense" in case
+        if dense:      # full_mass=True: a dense SPD inverse mass matrix (not the exact covariance)
+            B = rng.standard_normal((D, D))
+            inv_mass = 0.6 * np.linalg.inv(Lam) + 0.2 * (B @ B.T / D) + 0.1 * np.eye(D)
+            inv_mass = 0.5 * (inv_mass + inv_mass.T)
+        else:
+            inv_mass = rng.uniform(0.5, 1.5, D)
 
         def potential_fn(z):
             return 0.5 * z["x"] @ Lt @ z["x"]
 
         kernel = NUTS(potential_fn=potential_fn, step_size=step, adapt_step_size=False,
-                      adapt_mass_matrix=False, use_multinomial_sampling=multinomial, max_tree_depth=6)
+                      adapt_mass_matrix=False, use_multinomial_sampling=multinomial, max_tree_depth=6,
+                      full_mass=dense)
         z0 = torch.tensor(rng.standard_normal(D) * 0.5)
         kernel.initial_params = {"x": z0}
         kernel.setup(0)
@@ -418,6 +427,38 @@ def g_adaptation():
     flat["welford/samples"] = samples
     flat["welford/cov_reg"] = wc.get_covariance(regularize=True).numpy()
     flat["welford/cov"] = wc.get_covariance(regularize=False).numpy()
+    # dense estimator + the derived matrices of BlockMassMatrix (adaptation.py:270-392), one dense
+    # block over two sites and one diagonal block
+    wd = WelfordCovariance(diagonal=False)
+    mix = rng.standard_normal((6, 6))
+    dsamples = rng.standard_normal((40, 6)) @ mix
+    for s_ in dsamples:
+        wd.update(torch.tensor(s_))
+    flat["welford_dense/samples"] = dsamples
+    flat["welford_dense/cov_reg"] = wd.get_covariance(regularize=True).numpy()
+    flat["welford_dense/cov"] = wd.get_covariance(regularize=False).numpy()
+    from pyro.infer.mcmc.adaptation import BlockMassMatrix
+    bm = BlockMassMatrix()
+    bm.configure({("a", "b"): (4, 4), ("c",): (2,)}, adapt_mass_matrix=True,
+                 options={"dtype": torch.float64})
+    zs = rng.standard_normal((30, 6)) @ mix
+    for z_ in zs:
+        zt = torch.tensor(z_)
+        bm.update({"a": zt[:3], "b": zt[3:4], "c": zt[4:]}, None)
+    bm.end_adaptation()
+    r = torch.tensor(rng.standard_normal(6))
+    rd = {"a": r[:3], "b": r[3:4], "c": r[4:]}
+    kg = bm.kinetic_grad(rd)
+    flat["block/zs"] = zs
+    flat["block/r"] = r.numpy()
+    flat["block/inv_ab"] = bm.inverse_mass_matrix[("a", "b")].numpy()
+    flat["block/inv_c"] = bm.inverse_mass_matrix[("c",)].numpy()
+    flat["block/kinetic_grad"] = torch.cat([kg["a"], kg["b"], kg["c"]]).numpy()
+    ru = {("a", "b"): r[:4], ("c",): r[4:]}
+    sc = bm.scale(ru, rd)
+    flat["block/scale"] = torch.cat([sc["a"], sc["b"], sc["c"]]).numpy()
+    us = bm.unscale(rd)
+    flat["block/unscale"] = torch.cat([us[("a", "b")], us[("c",)]]).numpy()
     save("adaptation", **flat)
 
 

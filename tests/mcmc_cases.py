@@ -138,6 +138,130 @@ def run_nuts_chains_vs_oracle(device, D, C, kind, multinomial, n_trans, fused, r
     return samples
 
 
+def make_dense_inverse_mass(C, D, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for _ in range(C):
+        B = g.standard_normal((D, D))
+        out.append(B @ B.T / D + 0.3 * np.eye(D))
+    return np.stack(out)
+
+
+def run_nuts_dense_mass_vs_oracle(device, D, C, kind, multinomial, n_trans, rtol=1e-8,
+                                  max_tree_depth=5, dtype=torch.float64):
+    """NUTS(full_mass=True) with a different dense inverse mass per chain, chain-for-chain against
+    the restatement of the reference (which is pinned on reference runs with full_mass=True,
+    tests/golden/nuts_reference.npz d10_dense / d12_dense_slice).  The product runs in whitened
+    coordinates; the oracle runs the reference's formulation."""
+    Lam = make_precision(D, 21)
+    g = np.random.default_rng(6)
+    z0 = g.standard_normal((C, D)) * 0.4
+    inv_mass = make_dense_inverse_mass(C, D, 7)
+    steps = g.uniform(0.1, 0.35, C)
+    Lt = torch.tensor(Lam, dtype=dtype, device=device)
+    pot = GaussianPotential(Lt) if kind == "gaussian" else LogCoshPotential(Lt)
+    pyro.set_rng_seed(321)
+    kernel = NUTS(potential_fn=pot, step_size=1.0, adapt_step_size=False, adapt_mass_matrix=False,
+                  use_multinomial_sampling=multinomial, max_tree_depth=max_tree_depth,
+                  full_mass=True)
+    mcmc = MCMC(kernel, num_samples=n_trans, warmup_steps=0, num_chains=C,
+                initial_params={"x": torch.tensor(z0, dtype=dtype, device=device)})
+    orig_setup = kernel.setup
+
+    def setup(warmup_steps, *a, **k):
+        orig_setup(warmup_steps, *a, **k)
+        kernel._adapter.step_size = torch.tensor(steps, dtype=dtype, device=device)
+        kernel.mass_matrix_adapter.inverse_mass_matrix = torch.tensor(inv_mass, dtype=dtype,
+                                                                     device=device)
+    kernel.setup = setup
+    mcmc.run()
+    assert not kernel._fused
+    samples = mcmc.get_samples(group_by_chain=True)["x"].cpu().numpy()
+    pg = _np_potentials(kind, Lam)
+    np_dt = np.float64 if dtype == torch.float64 else np.float32
+    nleap = 0
+    for c in range(C):
+        z = z0[c].copy()
+        pe, gr = pg(z)
+        for t in range(n_trans):
+            out = o_nuts.nuts_transition(z, pe, gr, pg, inv_mass[c], steps[c],
+                                         o_nuts.KeyedDraws(321, c, t, np_dt), max_tree_depth,
+                                         multinomial, dtype=np_dt)
+            z, pe, gr = out["z"], out["pe"], out["grad"]
+            nleap += out["n_leapfrog"]
+            np.testing.assert_allclose(samples[c, t], z, rtol=rtol, atol=rtol,
+                                       err_msg="chain %d transition %d" % (c, t))
+    assert kernel.num_leapfrog_steps == nleap
+
+
+def run_dense_mass_products_vs_reference(device):
+    """DenseMassMatrix against BlockMassMatrix of the reference (tests/golden/adaptation.npz
+    block/*): one dense block over sites (a, b), site c diagonal; Welford adaptation, then the
+    three products."""
+    from pyro_amd.infer.mcmc.adaptation import DenseMassMatrix, block_mask
+    from pyro_amd.infer.mcmc.util import Layout
+    g = load("adaptation")
+    layout = Layout({"a": (3,), "b": (), "c": (2,)})
+    mask = block_mask(layout, [("a", "b")])
+    C = 2                                    # second chain sees the samples scaled by 2
+    mm = DenseMassMatrix(C, 6, torch.float64, device, mask=mask)
+    for z in g["block/zs"]:
+        mm.update(torch.tensor(np.stack([z, 2 * z]), device=device))
+    mm.end_adaptation()
+    V = mm.inverse_mass_matrix.cpu().numpy()
+    np.testing.assert_allclose(V[0][:4, :4], g["block/inv_ab"], rtol=1e-10)
+    np.testing.assert_allclose(np.diag(V[0])[4:], g["block/inv_c"], rtol=1e-10)
+    assert np.all(V[0][:4, 4:] == 0) and V[0][4, 5] == 0
+    # chain 1 differs only through the regulariser's additive shrinkage term
+    n = len(g["block/zs"])
+    shrink = 1e-3 * (5.0 / (n + 5.0))
+    np.testing.assert_allclose(V[1][:4, :4] - shrink * np.eye(4),
+                               4 * (g["block/inv_ab"] - shrink * np.eye(4)), rtol=1e-9, atol=1e-12)
+    r = torch.tensor(np.stack([g["block/r"], g["block/r"]]), device=device)
+    np.testing.assert_allclose(mm.kinetic_grad(r)[0].cpu().numpy(), g["block/kinetic_grad"], rtol=1e-10)
+    np.testing.assert_allclose(mm.scale(r)[0].cpu().numpy(), g["block/scale"], rtol=1e-10)
+    np.testing.assert_allclose(mm.unscale(r)[0].cpu().numpy(), g["block/unscale"], rtol=1e-10)
+    # whitened coordinates: color(whiten(z)) = z, and unit kinetic energy of r' = L^T r
+    z = torch.tensor(g["block/zs"][:2].copy(), device=device)
+    np.testing.assert_allclose(mm.color(mm.whiten(z)).cpu().numpy(), z.cpu().numpy(), rtol=1e-10)
+    ru = mm.unscale(r)
+    np.testing.assert_allclose((ru * ru).sum(-1).cpu().numpy(),
+                               (r * mm.kinetic_grad(r)).sum(-1).cpu().numpy(), rtol=1e-10)
+
+
+def run_dense_mass_adaptation(device, dtype, C=4, D=5, warmup=150, S=150, check=True):
+    """Warm-up with dense mass adaptation on a correlated Gaussian, NUTS and HMC: the adapted
+    inverse mass approaches the target covariance and the draws have the right moments."""
+    Lam = make_precision(D, 31)
+    Sigma = np.linalg.inv(Lam)
+    Lt = torch.tensor(Lam, dtype=dtype, device=device)
+    out = {}
+    for name, kernel in (("nuts", NUTS(potential_fn=GaussianPotential(Lt), full_mass=True,
+                                        max_tree_depth=5)),
+                         ("hmc", HMC(potential_fn=GaussianPotential(Lt), full_mass=True,
+                                     trajectory_length=1.5))):
+        pyro.set_rng_seed(7)
+        g = np.random.default_rng(8)
+        init = {"x": torch.tensor(g.standard_normal((C, D)), dtype=dtype, device=device)}
+        mcmc = MCMC(kernel, num_samples=S, warmup_steps=warmup, num_chains=C, initial_params=init)
+        mcmc.run()
+        V = kernel.inverse_mass_matrix.cpu().numpy()
+        x = mcmc.get_samples()["x"].cpu().numpy().astype(np.float64)
+        out[name] = (V, x)
+        if check:
+            assert V.shape == (C, D, D)
+            off = np.abs(V - np.transpose(V, (0, 2, 1))).max()
+            assert off < 1e-6
+            # dense adaptation picked up the correlations: closer to Sigma than its own diagonal
+            err_dense = np.abs(V.mean(0) - Sigma).max()
+            err_diag = np.abs(np.diag(np.diag(Sigma)) - Sigma).max()
+            assert err_dense < 0.6 * err_diag, (name, err_dense, err_diag)
+            emp = np.cov(x.T)
+            assert np.abs(x.mean(0)).max() < 0.5 * np.sqrt(np.diag(Sigma)).max()
+            assert np.abs(emp - Sigma).max() < 0.5 * np.abs(Sigma).max(), name
+    return out
+
+
 def logreg_mcmc_model(X, y):
     D = X.shape[1]
     w = pyro.sample("w", dist.Normal(torch.zeros(D, dtype=X.dtype, device=X.device),

@@ -331,11 +331,19 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999)
         grad.zero_()
 
 
+def chain_matvec(M, x, transpose=False):
+    Mn, xn = _np(M), _np(x)
+    if Mn.ndim == 2:
+        Mn = np.broadcast_to(Mn, (xn.shape[0],) + Mn.shape)
+    y = np.einsum("cij,ci->cj" if transpose else "cij,cj->ci", Mn, xn)
+    return torch.as_tensor(np.ascontiguousarray(y), dtype=x.dtype)
+
+
 FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad",
-             "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain"]
+             "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec"]
 
 
 def install(monkeypatch):

@@ -190,3 +190,37 @@ def test_multi_transition_launch_is_bitwise_sequence_of_single_launches(gpu, D):
         assert torch.equal(u, v)
     # and f32 follows the f64 trees for the first transition
     assert (res[(torch.float32, 0)][4][0] > 0).all()
+
+
+# ---- dense ("full_mass") mass matrix ---------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("C,D", [(1, 1), (3, 7), (5, 64), (4, 100), (2, 333)])
+def test_chain_matvec_kernel(gpu, dtype, C, D):
+    g = np.random.default_rng(C * 1000 + D)
+    M = g.standard_normal((C, D, D))
+    x = g.standard_normal((C, D))
+    tM = torch.tensor(M, dtype=dtype, device=gpu)
+    tx = torch.tensor(x, dtype=dtype, device=gpu)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    scale = np.sqrt(D)
+    for tr, eq in ((False, "cij,cj->ci"), (True, "cij,ci->cj")):
+        y = kernels.chain_matvec(tM, tx, transpose=tr).cpu().numpy()
+        np.testing.assert_allclose(y, np.einsum(eq, M, x), rtol=tol, atol=tol * scale)
+        # one matrix shared by all chains
+        ys = kernels.chain_matvec(tM[0].contiguous(), tx, transpose=tr).cpu().numpy()
+        np.testing.assert_allclose(ys, np.einsum(eq, np.broadcast_to(M[0], M.shape), x), rtol=tol,
+                                   atol=tol * scale)
+
+
+def test_dense_mass_matrix_products_match_reference(gpu):
+    mc.run_dense_mass_products_vs_reference(gpu)
+
+
+@pytest.mark.parametrize("D,C,kind,multinomial", [(6, 4, "gaussian", True), (40, 5, "logcosh", True),
+                                                  (100, 3, "gaussian", False)])
+def test_nuts_dense_mass_chain_for_chain_f64(gpu, D, C, kind, multinomial):
+    mc.run_nuts_dense_mass_vs_oracle(gpu, D, C, kind, multinomial, 3, rtol=1e-8)
+
+
+def test_dense_mass_adaptation_recovers_covariance(gpu):
+    mc.run_dense_mass_adaptation(gpu, torch.float32, C=16, D=8, warmup=300, S=300)

@@ -149,6 +149,39 @@ def test_mcmc_model_potential_and_diagnostics(_cpu_backend):
     assert mcmc.get_samples()["mu"].shape == (24, 2)
 
 
+def test_welford_dense_matches_reference():
+    from pyro_amd.ops.welford import WelfordCovariance
+    g = load("adaptation")
+    w1, wb = WelfordCovariance(diagonal=False), WelfordCovariance(diagonal=False)
+    for s in g["welford_dense/samples"]:
+        w1.update(torch.tensor(s))
+        wb.update(torch.tensor(np.stack([s, -s])))
+    np.testing.assert_allclose(w1.get_covariance(True).numpy(), g["welford_dense/cov_reg"], rtol=1e-11)
+    np.testing.assert_allclose(w1.get_covariance(False).numpy(), g["welford_dense/cov"], rtol=1e-11)
+    for c in range(2):
+        np.testing.assert_allclose(wb.get_covariance(True)[c].numpy(), g["welford_dense/cov_reg"],
+                                   rtol=1e-11)
+
+
+def test_dense_mass_matrix_products_match_reference(_cpu_backend):
+    mc.run_dense_mass_products_vs_reference(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("kind,multinomial", [("gaussian", True), ("logcosh", False)])
+def test_nuts_dense_mass_chain_for_chain(_cpu_backend, kind, multinomial):
+    mc.run_nuts_dense_mass_vs_oracle(torch.device("cpu"), 6, 3, kind, multinomial, 3)
+
+
+def test_dense_mass_adaptation_runs_on_host(_cpu_backend):
+    """Host logic of the dense warm-up (window ends re-whiten the state, step-size search in the
+    new coordinates): small run through the oracle kernels, structural checks only."""
+    out = mc.run_dense_mass_adaptation(torch.device("cpu"), torch.float64, C=2, D=3, warmup=40,
+                                       S=5, check=False)
+    for V, x in out.values():
+        assert V.shape == (2, 3, 3) and np.isfinite(V).all() and np.isfinite(x).all()
+        assert np.abs(V - np.eye(3)).max() > 1e-3          # adaptation replaced the identity
+
+
 def test_persistent_launch_path_equals_per_transition_path(_cpu_backend):
     mc.run_persistent_equals_stepwise(torch.device("cpu"), torch.float64, 1e-10, C=3, D=5,
                                       warmup=30, S=4)
