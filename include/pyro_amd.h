@@ -251,12 +251,18 @@ int pa_meanfield_normal_sample_bwd(int dtype, const pa_mf_site* sites, int nsite
  * Supported: f32, 1 <= D <= 128. Otherwise PA_ERR_UNSUPPORTED and the
  * caller uses the unfused path (matmul + pa_dist_log_prob_sum).
  *
- * Two arithmetic variants, selected process-wide by pa_glm_set_variant:
- *   0 (default) the contractions run on the bf16 matrix cores with every f32 operand split
- *     exactly into three bf16 pieces and the six piece products of order >= 2^-16 accumulated
- *     in f32 (error O(2^-23) per product: f32-roundoff class, not bit-identical to an fmaf
- *     chain).  Needs D % 4 == 0 and a 16-byte aligned X; other layouts take variant 1.
+ * Arithmetic variants, selected process-wide by pa_glm_set_variant:
+ *   0 (default, automatic)
+ *     - P <= 4 (incl. the reference's default num_particles = 1), D % 4 == 0, 8 <= D, aligned X, w:
+ *       a vector-ALU streaming kernel (plain f32 fmaf chains; the pass is HBM-bound there and
+ *       the matrix-core tiling only adds latency);
+ *     - otherwise, D <= 64, D % 4 == 0 and a 16-byte aligned X: the contractions run on the bf16
+ *       matrix cores with every f32 operand split exactly into three bf16 pieces and the six
+ *       piece products of order >= 2^-16 accumulated in f32 (error O(2^-23) per product:
+ *       f32-roundoff class, not bit-identical to an fmaf chain);
+ *     - other layouts take variant 1.
  *   1 exact f32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an f32 fmaf chain per product sum.
+ *   2 as 0 but never the few-particle kernel (the matrix-core kernels at every P).
  * ---------------------------------------------------------------------------------- */
 int pa_glm_set_variant(int variant);
 /* Chain rule of the two gradient outputs with the upstream gradient g[P] of ll[P] (the autograd

@@ -25,8 +25,10 @@
 
 namespace pa {
 
-// 0 = bf16x3 split-precision matrix-core kernel (glm_bf16.h) when the layout allows it, 1 = always
-// the exact-f32 MFMA kernel below.  Process-wide; see pa_glm_set_variant.
+// 0 = automatic: the few-particle vector-ALU kernel (glm_rows.h) for P <= 4, the bf16x3
+// split-precision matrix-core kernel (glm_bf16.h) when the layout allows it, else exact f32;
+// 1 = always the exact-f32 MFMA kernel below; 2 = as 0 without the few-particle kernel.
+// Process-wide; see pa_glm_set_variant.
 static int g_glm_variant = 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -353,6 +355,10 @@ __global__ __launch_bounds__(256) void glm_chain_kernel(const float* __restrict_
   }
 }
 
+}  // namespace pa
+#include "glm_rows.h"
+namespace pa {
+
 struct GlmPlan {
   int DT, PT, npass, nblocks, rec;
   int64_t iters;
@@ -385,13 +391,18 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   hipEvent_t ev0, ev1;
   const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  if (vec4 && g_glm_variant == 0) {
-    auto k = glm_bernoulli_bf16_kernel<DT, PT, false>;
-    constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, grid, block, lds, s, X, y, w, b, mask, N, D, P, pl.iters, part,
-                       (const int64_t*)nullptr, 1);
+  // D > 64 (DT = 4): the split-precision kernel would need 64 gradient-accumulator registers per
+  // lane on top of its three operand planes and spills (measured 2.1x SLOWER than the exact-f32
+  // kernel at D = 128); that shape stays on the exact kernel.
+  if (vec4 && g_glm_variant != 1 && DT < 4) {
+    if constexpr (DT < 4) {
+      auto k = glm_bernoulli_bf16_kernel<DT, PT, false>;
+      constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(k, grid, block, lds, s, X, y, w, b, mask, N, D, P, pl.iters, part,
+                         (const int64_t*)nullptr, 1);
+    }
   } else if (vec4) {
     auto k = glm_bernoulli_kernel<DT, PT, true, false>;
     if (pl.lds_bytes > 48 * 1024)
@@ -476,12 +487,14 @@ static int glm_grouped_launch(const float* X, const float* y, const float* w, co
   hipEvent_t ev0, ev1;
   const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  if (vec4 && g_glm_variant == 0) {
-    auto k = glm_bernoulli_bf16_kernel<DT, PT, true>;
-    constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, grid, block, lds, s, X, y, w, b, mask, N, D, P, iters, part, seg, G);
+  if (vec4 && g_glm_variant != 1 && DT < 4) {
+    if constexpr (DT < 4) {
+      auto k = glm_bernoulli_bf16_kernel<DT, PT, true>;
+      constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(k, grid, block, lds, s, X, y, w, b, mask, N, D, P, iters, part, seg, G);
+    }
   } else if (vec4) {
     auto k = glm_bernoulli_kernel<DT, PT, true, true>;
     if (lds_bytes > 48 * 1024)
@@ -529,7 +542,8 @@ int pa_glm_chain(const float* g, const float* gw, const float* gb, int64_t P, in
 }
 
 int pa_glm_set_variant(int variant) {
-  PA_REQUIRE(variant == 0 || variant == 1, "glm_set_variant: expected 0 (bf16x3) or 1 (exact f32)");
+  PA_REQUIRE(variant >= 0 && variant <= 2,
+             "glm_set_variant: expected 0 (automatic), 1 (exact f32) or 2 (bf16x3 matrix cores)");
   pa::g_glm_variant = variant;
   return PA_OK;
 }
@@ -537,7 +551,12 @@ int pa_glm_set_variant(int variant) {
 size_t pa_glm_bernoulli_workspace(int64_t N, int64_t D, int64_t P) {
   if (N < 0 || D < 1 || D > 128 || P < 1) return 0;
   pa::GlmPlan pl = pa::glm_plan(N, D, P);
-  return (size_t)pl.nblocks * pl.npass * pl.rec * sizeof(float);
+  size_t floats = (size_t)pl.nblocks * pl.npass * pl.rec;
+  if (P <= 4) {   // the few-particle kernel's records (glm_rows.h) share the workspace
+    const size_t rows = pa::glm_rows_workspace_floats(N, D, P);
+    if (rows > floats) floats = rows;
+  }
+  return floats * sizeof(float);
 }
 
 int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, const float* b,
@@ -566,6 +585,8 @@ int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, con
     return PA_OK;
   }
   float* part = (float*)workspace;
+  if (pa::g_glm_variant == 0 && pa::glm_rows_applicable(X, w, D, P))
+    return pa::glm_rows_launch(X, y, w, b, mask, scale, N, (int)D, (int)P, ll, gw, gb, part, s);
 #define PA_GLM_CASE(DT_, PT_)                                                                    \
   if (pl.DT == DT_ && pl.PT == PT_)                                                              \
     return pa::glm_launch<DT_, PT_>(pl, X, y, w, b, mask, scale, N, (int)D, (int)P, ll, gw, gb,  \

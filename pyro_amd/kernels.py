@@ -330,13 +330,14 @@ def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P, sinks=No
 # fused Bernoulli-logits GLM
 # ------------------------------------------------------------------------------------------
 
-GLM_BF16X3, GLM_EXACT_F32 = 0, 1
+GLM_AUTO, GLM_EXACT_F32, GLM_BF16X3 = 0, 1, 2
 
 
 def glm_set_variant(variant):
-    """Process-wide arithmetic of the fused GLM kernels: GLM_BF16X3 (default; bf16 matrix cores
-    with 3-way split operands, f32-roundoff-class error) or GLM_EXACT_F32 (f32 MFMA, bit-for-bit an
-    fmaf chain)."""
+    """Process-wide kernel choice of the fused GLM site: GLM_AUTO (default: vector-ALU streaming
+    kernel for P <= 4, otherwise the bf16 matrix cores with 3-way split operands --
+    f32-roundoff-class error), GLM_EXACT_F32 (f32 MFMA, bit-for-bit an fmaf chain) or GLM_BF16X3
+    (the split-precision matrix-core kernel at every P)."""
     check(_lib.load().pa_glm_set_variant(int(variant)))
 
 

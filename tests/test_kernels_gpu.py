@@ -148,20 +148,26 @@ def test_normal_rsample(gpu, dtype):
 
 
 # ---------------------------------------------------------------------------------------------
-# fused Bernoulli GLM -- both arithmetic variants (bf16x3 split on the bf16 matrix cores = the
-# default, exact-f32 MFMA) are held to the SAME tolerances against the float64 oracle
+# fused Bernoulli GLM -- all kernel choices (automatic = few-particle VALU kernel / bf16x3 split
+# on the bf16 matrix cores, exact-f32 MFMA, bf16x3 at every P) are held to the SAME tolerances
+# against the float64 oracle
 # ---------------------------------------------------------------------------------------------
-@pytest.fixture(params=[0, 1], ids=["bf16x3", "exact_f32"])
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "exact_f32", "bf16x3"])
 def glm_variant(request):
     k = _k()
     k.glm_set_variant(request.param)
     yield request.param
-    k.glm_set_variant(k.GLM_BF16X3)
+    k.glm_set_variant(k.GLM_AUTO)
 
 
 @pytest.mark.parametrize("N,D,P", [(1, 1, 1), (31, 3, 2), (32, 32, 64), (33, 32, 64), (1000, 32, 64),
                                    (4099, 8, 5), (2048, 32, 33), (5000, 20, 100), (3000, 64, 40),
-                                   (1500, 48, 7), (1200, 128, 12), (700, 100, 3), (0, 4, 2)])
+                                   (1500, 48, 7), (1200, 128, 12), (700, 100, 3), (0, 4, 2),
+                                   # few particles: the vector-ALU streaming kernel (every lanes-
+                                   # per-row width, ragged tails, P = 1..4)
+                                   (5000, 32, 1), (4097, 8, 2), (3001, 12, 3), (2500, 16, 4),
+                                   (7777, 20, 1), (999, 64, 2), (1234, 128, 4), (65, 36, 3),
+                                   (100000, 32, 4)])
 @pytest.mark.parametrize("use_mask,use_bias", [(False, True), (True, False)])
 def test_glm_bernoulli(gpu, glm_variant, N, D, P, use_mask, use_bias):
     k = _k()
@@ -261,6 +267,45 @@ def test_glm_bernoulli_deterministic_and_linear(gpu, glm_variant):
     torch.testing.assert_close(a1[0].double(), ll_ref, rtol=2e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("P", [1, 4])
+def test_glm_few_particles_full_size(gpu, P):
+    """N = 1e6 with the reference's default num_particles = 1 (and 4): the streaming kernel against
+    the exact-f32 matrix-core kernel and torch fp64, bitwise run-to-run determinism, masked rows
+    holding huge (finite) garbage contribute exactly nothing (where(mask, x, 0) semantics; NaN
+    data under the mask poison the gradient in the reference too: 0 * NaN in the matmul backward)."""
+    k = _k()
+    N, D = 1_000_000, 32
+    g = torch.Generator(device=gpu).manual_seed(1)
+    X = torch.randn((N, D), device=gpu, generator=g)
+    w = torch.randn((P, D), device=gpu, generator=g) * 0.2
+    b = torch.randn((P,), device=gpu, generator=g)
+    y = (torch.rand((N,), device=gpu, generator=g) < 0.5).float()
+    a1 = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    a2 = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    for u, v in zip(a1, a2):
+        assert torch.equal(u, v)
+    try:
+        k.glm_set_variant(k.GLM_EXACT_F32)
+        e = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    finally:
+        k.glm_set_variant(k.GLM_AUTO)
+    for u, v in zip(a1, e):
+        torch.testing.assert_close(u, v, rtol=2e-5, atol=2e-2)
+    logits = (w.double() @ X.double().T) + b.double()[:, None]
+    ll_ref = (y.double() * logits - torch.nn.functional.softplus(logits)).sum(1)
+    torch.testing.assert_close(a1[0].double(), ll_ref, rtol=2e-5, atol=1e-3)
+    gw_ref = (y.double() - torch.sigmoid(logits)) @ X.double()
+    torch.testing.assert_close(a1[1].double(), gw_ref, rtol=1e-4, atol=2e-2)
+    mask = torch.rand((N,), device=gpu, generator=g) < 0.7
+    Xn = X.clone()
+    Xn[~mask] = 1e30
+    m1 = k.glm_bernoulli_fwd_bwd(Xn, y, w, b, mask, 1.0)
+    m0 = k.glm_bernoulli_fwd_bwd(X[mask].contiguous(), y[mask].contiguous(), w, b, None, 1.0)
+    for u, v in zip(m1, m0):
+        assert bool(torch.isfinite(u).all())
+        torch.testing.assert_close(u, v, rtol=2e-5, atol=2e-2)
+
+
 def test_glm_bf16x3_is_f32_class(gpu):
     """The split-precision variant is an f32-equivalent: its error against the float64 oracle on
     per-row logit-sensitive outputs is of the size of the exact-f32 kernel's own rounding error
@@ -281,7 +326,7 @@ def test_glm_bf16x3_is_f32_class(gpu):
             errs[v] = [float(np.abs(o.cpu().numpy() - r).max() / np.abs(r).max())
                        for o, r in zip(out, ref)]
     finally:
-        k.glm_set_variant(k.GLM_BF16X3)
+        k.glm_set_variant(k.GLM_AUTO)
     for e_split, e_exact in zip(errs[k.GLM_BF16X3], errs[k.GLM_EXACT_F32]):
         assert e_split < 3e-6, errs                     # f32-class absolute bound
         assert e_split < 8 * e_exact + 5e-7, errs       # and comparable to the exact kernel's

@@ -9,12 +9,14 @@ from tools.bench_kernels import timeit
 
 dev = torch.device("cuda:0")
 QUICK = "--quick" in sys.argv
-CONFIGS = [(1_000_000, 32, 64), (1_000_000, 32, 32), (1_000_000, 64, 32), (10_000_000, 32, 64)]
+CONFIGS = [(1_000_000, 32, 64), (1_000_000, 32, 32), (1_000_000, 64, 32), (10_000_000, 32, 64),
+           (1_000_000, 8, 64), (1_000_000, 128, 64), (1_000_000, 64, 64), (1_000_000, 32, 128),
+           (1_000_000, 32, 8), (1_000_000, 32, 1), (1_000_000, 20, 64)]   # sweep D in {8, 128}
 if QUICK:
     CONFIGS = CONFIGS[:1]
-for variant in (k.GLM_BF16X3, k.GLM_EXACT_F32):
+for variant in (k.GLM_AUTO, k.GLM_EXACT_F32):
   k.glm_set_variant(variant)
-  print("variant", "bf16x3" if variant == k.GLM_BF16X3 else "exact f32")
+  print("variant", "auto (rows / bf16x3)" if variant == k.GLM_AUTO else "exact f32")
   for (N, D, P) in CONFIGS:
       X = torch.randn((N, D), device=dev)
       y = (torch.rand((N,), device=dev) < 0.5).float()
