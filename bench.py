@@ -281,6 +281,14 @@ def main():
                               "in the plate), 8 topics, 1024 words, 64 words per document, amortised "
                               "guide; word_topics enumerated and summed out by the fused LDA kernel")
             others["config4_lda"] = r4
+            r2m = bench_configs.config2_variant(dev, "mvn")
+            r2m["workload"] = ("BASELINE configs[1] with AutoMultivariateNormal (the second guide "
+                               "SURVEY 8d names), 64 particles, graphed SVI.step")
+            others["config2_automultivariatenormal"] = r2m
+            r2p = bench_configs.config2_variant(dev, "normal", P=1)
+            r2p["workload"] = ("BASELINE configs[1] at the reference's default num_particles=1: "
+                               "few-particle vector-ALU GLM kernel (HBM-bound), graphed SVI.step")
+            others["config2_one_particle"] = r2p
         except Exception as e:  # noqa: BLE001  (secondary measurements must not kill the headline)
             others["error"] = "%s: %s" % (type(e).__name__, e)
         pyro.clear_param_store()

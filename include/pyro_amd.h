@@ -416,6 +416,24 @@ int pa_adam_step(int dtype, void* param, void* grad, void* exp_avg, void* exp_av
                  double clip_norm, double lrd, int clipped, int64_t* step_dev, int zero_grad,
                  pa_stream_t stream);
 
+/* Full-covariance Normal guide (AutoMultivariateNormal, pyro/infer/autoguide/guides.py:855-965:
+ * MultivariateNormal(loc, scale_tril = softplus(rho)[:, None] * (tril(A, -1) + I)); rsample and
+ * log_prob of torch/distributions/multivariate_normal.py) for P vectorised particles in one launch:
+ *   eps[P, n] ~ N(0, 1) (Philox stream (seed, offset [+ *offset_dev]); eps_given != 0: read instead),
+ *   z[p] = loc + S * (L eps[p]),  logq[p] = -|eps[p]|^2/2 - sum_i log S_i - n/2 log(2 pi),
+ * with S = softplus(rho) [n], L = tril(A, -1) + I, A [n, n] row-major (unconstrained values).
+ * 1 <= n <= 4096. */
+int pa_mvn_tril_sample(int dtype, const void* loc, const void* rho, const void* A, int64_t n,
+                       int64_t P, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                       int eps_given, void* eps, void* z, void* logq, pa_stream_t stream);
+/* Its backward: (d_z [P, n] or NULL, d_logq [P] or NULL) -> gradients of the unconstrained
+ * parameters d_loc [n], d_rho [n], d_A [n, n] (zero on and above the diagonal); each may be NULL;
+ * accumulate != 0 adds into the buffers (the optimizer's flat gradient views). */
+int pa_mvn_tril_sample_bwd(int dtype, const void* loc, const void* rho, const void* eps,
+                           const void* z, const void* d_z, const void* d_logq, int64_t n,
+                           int64_t P, void* d_loc, void* d_rho, void* d_A, int accumulate,
+                           pa_stream_t stream);
+
 /* Per-chain dense matrix x vector: y[c] = M[c] x[c] (transpose = 0) or M[c]^T x[c]
  * (transpose = 1); M[C, D, D] row-major with chain stride m_stride_chain elements (0 = one matrix
  * shared by all chains), x, y [C, D] contiguous, x != y.  Replaces the dense-block products of

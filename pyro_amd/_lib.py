@@ -128,6 +128,11 @@ _SIGNATURES = {
     "pa_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                              c_double, c_double, c_double, c_double, c_double, c_double, c_int,
                              c_void_p, c_int, c_void_p]),
+    "pa_mvn_tril_sample": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
+                                   c_uint64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pa_mvn_tril_sample_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_void_p]),
     "pa_chain_matvec": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                 c_void_p]),
     "pa_adam_step_publish": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

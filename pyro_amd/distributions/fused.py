@@ -231,6 +231,51 @@ def meanfield_sample(locs, rhos, P):
     return [tuple(out[3 * i:3 * i + 3]) for i in range(len(locs))]
 
 
+class _MvnTrilSample(torch.autograd.Function):
+    """Full-covariance Normal guide draw: z [P, n] and log q(z) [P] from the unconstrained leaves
+    (loc, rho, A) in ONE launch (pa_mvn_tril_sample), their gradients in ONE (.._bwd), added
+    straight into the parameters' dense .grad buffers when those exist (see _MeanFieldSample)."""
+
+    @staticmethod
+    def forward(ctx, P, seed, offset, offset_dev, eps, loc, rho, A):
+        l, r, a = loc.detach().reshape(-1), rho.detach().reshape(-1), A.detach()
+        z, logq, eps = kernels.mvn_tril_sample(l, r, a, P, seed, offset, offset_dev, eps)
+        ctx.params = (loc, rho, A) if GRAD_SINK else None
+        ctx.shapes = (loc.shape, rho.shape, A.shape)
+        ctx.save_for_backward(l, r, eps, z)
+        return z, logq
+
+    @staticmethod
+    def backward(ctx, d_z, d_logq):
+        l, r, eps, z = ctx.saved_tensors
+        sinks = None
+        if ctx.params is not None and all(
+                p.is_leaf and p.grad is not None and p.grad.is_contiguous()
+                and p.grad.dtype == p.dtype and p.grad.device == p.device
+                and p.grad.grad_fn is None and not p._backward_hooks for p in ctx.params):
+            sinks = tuple(p.grad.reshape(-1) for p in ctx.params[:2]) + (ctx.params[2].grad,)
+        d_loc, d_rho, d_A = kernels.mvn_tril_sample_bwd(l, r, eps, z, d_z, d_logq, sinks)
+        if sinks is not None:
+            return (None,) * 8
+        return (None, None, None, None, None, d_loc.reshape(ctx.shapes[0]),
+                d_rho.reshape(ctx.shapes[1]), d_A.reshape(ctx.shapes[2]))
+
+
+def mvn_tril_sample(loc, rho, A, shape):
+    """(z [P, n], log q(z) [P]) of Normal(loc, scale_tril = softplus(rho)[:, None] * (tril(A, -1)
+    + I)) for the P = prod(shape[:-1]) particles of a draw of ``shape``; the standard normals are
+    the ones ``rng.normal(shape)`` would return at this point of the stream (or whatever a replaced
+    ``rng.normal`` returns)."""
+    from .. import rng
+    n = loc.numel()
+    P = torch.Size(shape).numel() // n
+    if rng.normal is not rng._default_normal:
+        eps = rng.normal(tuple(shape), loc.dtype, loc.device).reshape(P, n).contiguous()
+        return _MvnTrilSample.apply(P, 0, 0, None, eps, loc, rho, A)
+    seed, off, off_dev = rng.reserve(P * n, loc.dtype)
+    return _MvnTrilSample.apply(P, seed, off, off_dev, None, loc, rho, A)
+
+
 def normal_rsample(loc, scale, shape):
     """Reparameterised Normal draw of ``shape`` (>= broadcast of loc/scale shapes) from the
     process-wide Philox stream."""

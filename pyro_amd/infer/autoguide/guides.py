@@ -313,6 +313,50 @@ class _GuideMVN(torch.distributions.MultivariateNormal, dist.TorchDistributionMi
         return new
 
 
+class _FusedGuideMVN(dist.TorchDistribution):
+    """The posterior of AutoMultivariateNormal as ONE fused draw: rsample() produces the value
+    and its log-density together (distributions.fused.mvn_tril_sample: the draw knows its own
+    standard normals, so log q needs no triangular solve), log_prob(that value) hands the density
+    back.  Any other use (log_prob of a foreign value, mean, ...) goes through the ordinary
+    MultivariateNormal built on demand."""
+
+    arg_constraints = {}
+    support = constraints.real_vector
+    has_rsample = True
+
+    def __init__(self, loc, rho, A, build, batch_shape=torch.Size()):
+        self._leaves, self._build = (loc, rho, A), build
+        self._value = self._logq = None
+        super().__init__(torch.Size(batch_shape), torch.Size((loc.numel(),)), validate_args=False)
+
+    def expand(self, batch_shape, _instance=None):
+        return _FusedGuideMVN(*self._leaves, self._build, batch_shape=batch_shape)
+
+    def rsample(self, sample_shape=torch.Size()):
+        from ...distributions import fused
+        shape = self._extended_shape(sample_shape)
+        z, logq = fused.mvn_tril_sample(*self._leaves, shape)
+        self._value, self._logq = z.reshape(shape), logq.reshape(shape[:-1])
+        return self._value
+
+    def sample(self, sample_shape=torch.Size()):
+        with torch.no_grad():
+            return self.rsample(sample_shape)
+
+    def log_prob(self, value):
+        if value is self._value:
+            return self._logq
+        return self._build().expand(self.batch_shape).log_prob(value)
+
+    @property
+    def mean(self):
+        return self._build().mean
+
+    @property
+    def variance(self):
+        return self._build().variance
+
+
 def _product(shape):
     n = 1
     for s in shape:
@@ -475,9 +519,30 @@ class AutoMultivariateNormal(AutoContinuous):
                                              device=self._loc0.device), self.scale_tril_constraint)
         return loc, scale, scale_tril
 
-    def get_posterior(self, *args, **kwargs):
+    def _plain_posterior(self):
         loc, scale, scale_tril = self._params()
         return _GuideMVN(loc, scale_tril=scale[..., None] * scale_tril)
+
+    def get_posterior(self, *args, **kwargs):
+        from ... import kernels
+        from ...primitives import param_unconstrained
+        if self.scale_constraint is softplus_positive and \
+                self.scale_tril_constraint is unit_lower_cholesky and self.latent_dim <= 4096:
+            d = self.latent_dim
+            loc = param_unconstrained("{}.loc".format(self.prefix),
+                                      lambda: self._loc0.clone(), constraints.real)
+            rho = param_unconstrained("{}.scale".format(self.prefix),
+                                      lambda: torch.full_like(self._loc0, self._init_scale),
+                                      self.scale_constraint)
+            A = param_unconstrained("{}.scale_tril".format(self.prefix),
+                                    lambda: torch.eye(d, dtype=self._loc0.dtype,
+                                                      device=self._loc0.device),
+                                    self.scale_tril_constraint)
+            if (loc.is_cuda or kernels.HOST_TEST_BACKEND) and A.is_contiguous() \
+                    and loc.dtype in (torch.float32, torch.float64) \
+                    and loc.dtype == rho.dtype == A.dtype:
+                return _FusedGuideMVN(loc, rho, A, self._plain_posterior)
+        return self._plain_posterior()
 
     def _loc_scale(self, *args, **kwargs):
         loc, scale, scale_tril = self._params()

@@ -326,6 +326,50 @@ def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P, sinks=No
     return d_locs, d_rhos
 
 
+def mvn_tril_sample(loc, rho, A, P, seed=0, offset=0, offset_dev=None, eps=None):
+    """Full-covariance Normal guide draw for P particles (pa_mvn_tril_sample): loc, rho [n],
+    A [n, n] unconstrained; ``eps`` [P, n] given = use it instead of the Philox stream.
+    Returns (z [P, n], logq [P], eps [P, n])."""
+    _require_gpu(loc, rho, A, eps, offset_dev)
+    n = loc.numel()
+    assert loc.is_contiguous() and rho.is_contiguous() and A.is_contiguous()
+    assert rho.numel() == n and A.shape == (n, n) and rho.dtype == loc.dtype == A.dtype
+    given = eps is not None
+    if given:
+        assert eps.shape == (P, n) and eps.is_contiguous() and eps.dtype == loc.dtype
+    else:
+        eps = torch.empty((P, n), dtype=loc.dtype, device=loc.device)
+    z = torch.empty((P, n), dtype=loc.dtype, device=loc.device)
+    logq = torch.empty((P,), dtype=loc.dtype, device=loc.device)
+    check(_lib.load().pa_mvn_tril_sample(_dtype(loc), _ptr(loc), _ptr(rho), _ptr(A), n, int(P),
+                                         int(seed), int(offset), _ptr(offset_dev), int(given),
+                                         _ptr(eps), _ptr(z), _ptr(logq), _stream()))
+    return z, logq, eps
+
+
+def mvn_tril_sample_bwd(loc, rho, eps, z, d_z, d_logq, sinks=None):
+    """Backward of mvn_tril_sample -> (d_loc [n], d_rho [n], d_A [n, n]); ``sinks`` = three
+    contiguous tensors the gradients are ADDED to instead (then None is returned for each)."""
+    P, n = eps.shape
+    d_z = None if d_z is None else d_z.contiguous()
+    d_logq = None if d_logq is None else d_logq.contiguous()
+    _require_gpu(loc, rho, eps, z, d_z, d_logq)
+    if sinks is not None:
+        d_loc, d_rho, d_A = sinks
+        _require_gpu(d_loc, d_rho, d_A)
+        assert all(t.is_contiguous() and t.dtype == loc.dtype for t in sinks)
+        assert d_loc.numel() == n and d_rho.numel() == n and d_A.numel() == n * n
+    else:
+        d_loc = torch.empty((n,), dtype=loc.dtype, device=loc.device)
+        d_rho = torch.empty((n,), dtype=loc.dtype, device=loc.device)
+        d_A = torch.empty((n, n), dtype=loc.dtype, device=loc.device)
+    check(_lib.load().pa_mvn_tril_sample_bwd(_dtype(loc), _ptr(loc), _ptr(rho), _ptr(eps), _ptr(z),
+                                             _ptr(d_z), _ptr(d_logq), n, int(P), _ptr(d_loc),
+                                             _ptr(d_rho), _ptr(d_A), int(sinks is not None),
+                                             _stream()))
+    return (None, None, None) if sinks is not None else (d_loc, d_rho, d_A)
+
+
 # ------------------------------------------------------------------------------------------
 # fused Bernoulli-logits GLM
 # ------------------------------------------------------------------------------------------

@@ -331,6 +331,44 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999)
         grad.zero_()
 
 
+def _softplus_np(x):
+    return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+
+
+def mvn_tril_sample(loc, rho, A, P, seed=0, offset=0, offset_dev=None, eps=None):
+    """torch/distributions/multivariate_normal.py rsample + log_prob for scale_tril =
+    softplus(rho)[:, None] * (tril(A, -1) + I), written out in numpy."""
+    n = loc.numel()
+    if eps is None:
+        eps = philox_normal((P, n), loc.dtype, loc.device, seed, offset, offset_dev)
+    e, lo, S, An = _np(eps), _np(loc), _softplus_np(_np(rho)), _np(A)
+    L = np.tril(An, -1) + np.eye(n)
+    T = S[:, None] * L
+    z = lo + e @ T.T
+    # log_prob through the triangular solve, as the reference computes it
+    y = np.linalg.solve(T, (z - lo).T).T
+    logq = -0.5 * (y * y).sum(-1) - np.log(np.diag(T)).sum() - 0.5 * n * np.log(2 * np.pi)
+    return (torch.as_tensor(z, dtype=loc.dtype), torch.as_tensor(logq, dtype=loc.dtype), eps)
+
+
+def mvn_tril_sample_bwd(loc, rho, eps, z, d_z, d_logq, sinks=None):
+    P, n = eps.shape
+    e, S, r = _np(eps), _softplus_np(_np(rho)), _np(rho)
+    dz = np.zeros((P, n)) if d_z is None else _np(d_z)
+    dq = np.zeros(P) if d_logq is None else _np(d_logq)
+    u = (_np(z) - _np(loc)) / S
+    d_loc = dz.sum(0)
+    dS = (dz * u).sum(0) - dq.sum() / S
+    d_rho = dS * np.where(r > 20, 1.0, 1.0 / (1.0 + np.exp(-r)))
+    d_A = np.tril(S[:, None] * (dz.T @ e), -1)
+    outs = [torch.as_tensor(np.ascontiguousarray(v), dtype=loc.dtype) for v in (d_loc, d_rho, d_A)]
+    if sinks is not None:
+        for sk, v in zip(sinks, outs):
+            sk.add_(v.reshape(sk.shape))
+        return None, None, None
+    return tuple(outs)
+
+
 def chain_matvec(M, x, transpose=False):
     Mn, xn = _np(M), _np(x)
     if Mn.ndim == 2:
@@ -343,7 +381,8 @@ FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad",
-             "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec"]
+             "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
+             "mvn_tril_sample_bwd"]
 
 
 def install(monkeypatch):

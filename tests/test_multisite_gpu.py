@@ -185,3 +185,88 @@ def test_batched_elbo_and_fused_guide_equal_per_site_paths(gpu, monkeypatch):
                 torch.testing.assert_close(out[1][name], ref[1][name], rtol=2e-4, atol=2e-4)
     finally:
         pyro.enable_validation(True)
+
+
+# ---- full-covariance Normal guide (pa_mvn_tril_sample / _bwd) -------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n,P", [(1, 1), (6, 4), (33, 64), (200, 7), (700, 3)])
+def test_mvn_tril_sample_kernels(gpu, dtype, n, P):
+    """Forward against torch's own MultivariateNormal (rsample formula + log_prob through the
+    triangular solve) in float64, backward against autograd of that formulation; the in-kernel
+    Philox draws are the ones the stream's fill kernel produces."""
+    from pyro_amd import kernels as k
+    g = np.random.default_rng(n * 100 + P)
+    loc = torch.tensor(g.standard_normal(n), dtype=dtype, device=gpu)
+    rho = torch.tensor(g.uniform(-2.0, 1.5, n), dtype=dtype, device=gpu)
+    if n > 3:
+        rho[0] = 25.0                         # beyond the softplus threshold
+    A = torch.tensor(g.standard_normal((n, n)) / np.sqrt(n), dtype=dtype, device=gpu)
+    z, logq, eps = k.mvn_tril_sample(loc, rho, A, P, seed=11, offset=5)
+    want_eps = k.philox_normal((P, n), dtype, gpu, 11, 5)
+    assert torch.equal(eps, want_eps)
+    z2, logq2, _ = k.mvn_tril_sample(loc, rho, A, P, eps=eps.clone())
+    assert torch.equal(z, z2) and torch.equal(logq, logq2)
+
+    l64, r64, A64 = (t.double().clone().requires_grad_(True) for t in (loc, rho, A))
+    S = torch.nn.functional.softplus(r64)
+    T = S[:, None] * (A64.tril(-1) + torch.eye(n, dtype=torch.float64, device=gpu))
+    mvn = torch.distributions.MultivariateNormal(l64, scale_tril=T)
+    z_ref = l64 + eps.double() @ T.T
+    lq_ref = mvn.log_prob(z_ref)
+    tol = 1e-11 if dtype == torch.float64 else 3e-5
+    sc = float(z_ref.detach().abs().max())
+    torch.testing.assert_close(z.double(), z_ref.detach(), rtol=tol, atol=tol * sc)
+    torch.testing.assert_close(logq.double(), lq_ref.detach(), rtol=tol, atol=tol * n)
+
+    d_z = torch.tensor(g.standard_normal((P, n)), dtype=dtype, device=gpu)
+    d_q = torch.tensor(g.standard_normal(P), dtype=dtype, device=gpu)
+    ((z_ref * d_z.double()).sum() + (lq_ref * d_q.double()).sum()).backward()
+    d_loc, d_rho, d_A = k.mvn_tril_sample_bwd(loc, rho, eps, z, d_z, d_q)
+    for got, ref in ((d_loc, l64.grad), (d_rho, r64.grad), (d_A, A64.grad)):
+        torch.testing.assert_close(got.double(), ref, rtol=tol * 10, atol=tol * 10 * float(ref.abs().max() + 1))
+    assert float(d_A.triu().abs().max()) == 0.0
+    # accumulating form (the optimizer's flat gradient views)
+    sinks = (torch.ones(n, dtype=dtype, device=gpu), torch.ones(n, dtype=dtype, device=gpu),
+             torch.ones((n, n), dtype=dtype, device=gpu))
+    k.mvn_tril_sample_bwd(loc, rho, eps, z, d_z, d_q, sinks=sinks)
+    torch.testing.assert_close(sinks[0], d_loc + 1)
+    torch.testing.assert_close(sinks[2], d_A + 1)
+
+
+def test_fused_mvn_guide_equals_plain_posterior(gpu):
+    """AutoMultivariateNormal through the fused draw == through MultivariateNormal (same Philox
+    stream position, so the same standard normals): loss and every parameter gradient."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer import Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoMultivariateNormal, guides
+
+    data = torch.tensor([0.3, -1.2, 2.0, 0.7, 0.1], dtype=torch.float64, device=gpu)
+
+    def model(data):
+        mu = pyro.sample("mu", dist.Normal(torch.zeros(3, dtype=torch.float64, device=gpu), 2.0).to_event(1))
+        s = pyro.sample("s", dist.LogNormal(torch.zeros((), dtype=torch.float64, device=gpu), 0.5))
+        with pyro.plate("d", 5):
+            pyro.sample("x", dist.Normal(mu.sum(-1, keepdim=True), s.unsqueeze(-1)), obs=data)
+
+    out = {}
+    for fused in (True, False):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(3)
+        guide = AutoMultivariateNormal(model, init_scale=0.3)
+        if not fused:
+            guide.get_posterior = lambda *a, **k: guide._plain_posterior()
+        elbo = Trace_ELBO(num_particles=8, vectorize_particles=True, max_plate_nesting=1)
+        guide(data)                                       # create the parameters
+        st = pyro.get_param_store()
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(0)
+            st._params["AutoMultivariateNormal.scale_tril"].copy_(
+                (torch.randn(4, 4, generator=g, dtype=torch.float64) * 0.3).tril(-1).to(gpu))
+        pyro.set_rng_seed(5)
+        loss = elbo.loss_and_grads(model, guide, data)
+        out[fused] = (loss, {n: p.grad.clone() for n, p in st._params.items()})
+    assert isinstance(guide.get_posterior(), guides._GuideMVN)
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-10)
+    for name, gr in out[False][1].items():
+        torch.testing.assert_close(out[True][1][name], gr, rtol=1e-8, atol=1e-10)

@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 import pyro_amd as pyro
 from pyro_amd import examples, kernels
 from pyro_amd.infer import SVI, Trace_ELBO, TraceEnum_ELBO
-from pyro_amd.infer.autoguide import AutoNormal
+from pyro_amd.infer.autoguide import AutoMultivariateNormal, AutoNormal
 
 
 def timed(fn, n, warm):
@@ -36,6 +36,22 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True):
             "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
 
 
+def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=True):
+    """BASELINE configs[1] with the other guide SURVEY 8(d) names (AutoMultivariateNormal) or with
+    the reference's default num_particles = 1 (few-particle GLM kernel)."""
+    X, y = examples.synthetic_logreg_data(N, D, dev, seed=0)
+    pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
+    g = AutoMultivariateNormal(examples.logreg_model, init_scale=0.1) if guide == "mvn" else \
+        AutoNormal(examples.logreg_model, init_scale=0.1)
+    svi = SVI(examples.logreg_model, g, pyro.optim.Adam({"lr": 0.01}),
+              Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
+              hip_graph=graph, graph_warmup=2)
+    dt = timed(lambda: svi.step(X, y), steps, 8)
+    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "num_particles": P,
+            "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1),
+            "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
+
+
 def config4(dev, docs=100_000, steps=10):
     args = examples.LdaArgs(num_docs=docs)
     data = examples.synthetic_lda_data(args, dev)
@@ -54,3 +70,6 @@ if __name__ == "__main__":
     print("config 5 (N=1e7, P=64, G=1000):", config5(dev))
     print("config 5 eager:", config5(dev, steps=5, graph=False))
     print("config 4 (1e5 docs):", config4(dev))
+    print("config 2, AutoMultivariateNormal:", config2_variant(dev, "mvn"))
+    print("config 2, AutoNormal, num_particles=1:", config2_variant(dev, "normal", P=1))
+    print("config 2, AutoNormal, num_particles=4:", config2_variant(dev, "normal", P=4))
