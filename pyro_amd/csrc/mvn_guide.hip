@@ -46,13 +46,31 @@ __global__ __launch_bounds__(256) void mvn_tril_sample_kernel(
     part -= 0.5 * (double)e * (double)e + (double)t_log(mvn_softplus<T>(rho[j]));
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int i = wave; i < n; i += nw) {                    // wave-uniform rows
-    const T* row = A + (int64_t)i * n;
-    T acc = T(0);
-    for (int j = lane; j < i; j += 64) acc += row[j] * es[j];   // strictly lower part
-    acc = wave_sum(acc);
-    if (lane == 0) z[p * n + i] = loc[i] + mvn_softplus<T>(rho[i]) * (acc + es[i]);
+  if (n <= 128) {
+    // small latent space: one thread per row, the row's loads independent of each other (the
+    // factor stays in L2 / the vector cache: P workgroups read the same n*n values)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const T* row = A + (int64_t)i * n;
+      T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+      int j = 0;
+      for (; j + 3 < i; j += 4) {
+        a0 += row[j] * es[j];
+        a1 += row[j + 1] * es[j + 1];
+        a2 += row[j + 2] * es[j + 2];
+        a3 += row[j + 3] * es[j + 3];
+      }
+      for (; j < i; ++j) a0 += row[j] * es[j];
+      z[p * n + i] = loc[i] + mvn_softplus<T>(rho[i]) * (((a0 + a1) + (a2 + a3)) + es[i]);
+    }
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = wave; i < n; i += nw) {                    // wave-uniform rows, coalesced
+      const T* row = A + (int64_t)i * n;
+      T acc = T(0);
+      for (int j = lane; j < i; j += 64) acc += row[j] * es[j];   // strictly lower part
+      acc = wave_sum(acc);
+      if (lane == 0) z[p * n + i] = loc[i] + mvn_softplus<T>(rho[i]) * (acc + es[i]);
+    }
   }
   const double tot = block_sum_f64(part, red);
   if (threadIdx.x == 0) logq[p] = (T)(tot - 0.5 * (double)n * 1.8378770664093453);  // log(2 pi)
@@ -64,18 +82,34 @@ __global__ __launch_bounds__(256) void mvn_tril_sample_bwd_kernel(
     const T* __restrict__ loc, const T* __restrict__ rho, const T* __restrict__ eps,
     const T* __restrict__ z, const T* __restrict__ d_z, const T* __restrict__ d_logq, int n,
     int P, T* __restrict__ d_loc, T* __restrict__ d_rho, T* __restrict__ d_A, int accumulate) {
-  __shared__ double red[16];
+  __shared__ double red[3][4];
+  __shared__ T part[4][64];
   const int i = blockIdx.x;
   const T rho_i = rho[i], loc_i = loc[i];
   const T S = mvn_softplus<T>(rho_i);
-  // d A[i, j] = S_i * sum_p d_z[p, i] * eps[p, j] for j < i, 0 elsewhere (unit diagonal, zero upper)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // d A[i, j] = S_i * sum_p d_z[p, i] * eps[p, j] for j < i, 0 elsewhere (unit diagonal, zero
+  // upper).  Wave w takes the particles p = w (mod 4); 64 columns per pass.
   if (d_A != nullptr)
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-      T acc = T(0);
-      if (j < i && d_z != nullptr)
-        for (int p = 0; p < P; ++p) acc += d_z[(int64_t)p * n + i] * eps[(int64_t)p * n + j];
-      const int64_t o = (int64_t)i * n + j;
-      d_A[o] = (accumulate ? d_A[o] : T(0)) + S * acc;
+    for (int jb = 0; jb < n; jb += 64) {
+      const int j = jb + lane;
+      T a0 = T(0), a1 = T(0);
+      if (j < i && d_z != nullptr) {
+        int p = wave;
+        for (; p + 4 < P; p += 8) {
+          a0 += d_z[(int64_t)p * n + i] * eps[(int64_t)p * n + j];
+          a1 += d_z[(int64_t)(p + 4) * n + i] * eps[(int64_t)(p + 4) * n + j];
+        }
+        for (; p < P; p += 4) a0 += d_z[(int64_t)p * n + i] * eps[(int64_t)p * n + j];
+      }
+      part[wave][lane] = a0 + a1;
+      __syncthreads();
+      if (wave == 0 && j < n) {
+        const int64_t o = (int64_t)i * n + j;
+        const T acc = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        d_A[o] = (accumulate ? d_A[o] : T(0)) + S * acc;
+      }
+      __syncthreads();
     }
   // d loc_i = sum_p d_z[p, i];  d S_i = sum_p d_z[p, i] * u[p, i] - (sum_p d_logq[p]) / S_i,
   // u = L eps = (z - loc) / S
@@ -86,10 +120,15 @@ __global__ __launch_bounds__(256) void mvn_tril_sample_bwd_kernel(
     ss += (double)g * (double)((z[(int64_t)p * n + i] - loc_i) / S);
     sg += d_logq != nullptr ? (double)d_logq[p] : 0.0;
   }
-  sl = block_sum_f64(sl, red);
-  ss = block_sum_f64(ss, red);
-  sg = block_sum_f64(sg, red);
+  sl = wave_sum(sl);
+  ss = wave_sum(ss);
+  sg = wave_sum(sg);
+  if (lane == 0) { red[0][wave] = sl; red[1][wave] = ss; red[2][wave] = sg; }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    sl = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    sg = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
     const double dS = ss - sg / (double)S;
     const double x = (double)rho_i;
     const double sig = x > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-x));   // d softplus / d x

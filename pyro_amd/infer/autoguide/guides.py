@@ -357,6 +357,28 @@ class _FusedGuideMVN(dist.TorchDistribution):
         return self._build().variance
 
 
+class _SplitLatent(torch.autograd.Function):
+    """latent[..., sum(sizes)] -> one CONTIGUOUS tensor per site; the backward is one concatenation
+    (slicing views would cost a zero-fill + strided copy per site and an add per extra site in
+    autograd, and a .contiguous() copy wherever a kernel consumes the slice)."""
+
+    @staticmethod
+    def forward(ctx, latent, sizes):
+        ctx.sizes, ctx.meta = sizes, (latent.shape, latent.dtype, latent.device)
+        out, pos = [], 0
+        for size in sizes:
+            out.append(latent[..., pos:pos + size].contiguous())
+            pos += size
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, dtype, device = ctx.meta
+        parts = [g if g is not None else torch.zeros(shape[:-1] + (size,), dtype=dtype, device=device)
+                 for g, size in zip(grads, ctx.sizes)]
+        return torch.cat(parts, dim=-1), None
+
+
 def _product(shape):
     n = 1
     for s in shape:
@@ -404,17 +426,18 @@ class AutoContinuous(AutoGuide):
 
     def _unpack_latent(self, latent):
         batch_shape = latent.shape[:-1]   # plates outside of _setup_prototype, e.g. parallel particles
-        pos = 0
-        for name, site in self.prototype_trace.iter_stochastic_nodes():
+        sites = list(self.prototype_trace.iter_stochastic_nodes())
+        sizes = tuple(_product(self._unconstrained_shapes[name]) for name, _ in sites)
+        assert sum(sizes) == latent.size(-1)
+        parts = _SplitLatent.apply(latent, sizes) if latent.requires_grad else \
+            torch.split(latent, sizes, dim=-1)
+        for (name, site), part in zip(sites, parts):
             constrained_shape = site["value"].shape
             unconstrained_shape = self._unconstrained_shapes[name]
-            size = _product(unconstrained_shape)
             event_dim = site["fn"].event_dim + len(unconstrained_shape) - len(constrained_shape)
             unconstrained_shape = torch.broadcast_shapes(unconstrained_shape,
                                                          batch_shape + (1,) * event_dim)
-            yield site, latent[..., pos:pos + size].reshape(unconstrained_shape)
-            pos += size
-        assert pos == latent.size(-1)
+            yield site, part.reshape(unconstrained_shape)
 
     def forward(self, *args, **kwargs):
         if self.prototype_trace is None:
