@@ -134,6 +134,33 @@ int pa_dist_log_prob_grad(int dist, int dtype, void* d_value, void* d_p0, void* 
                           pa_view2d value, pa_view2d p0, pa_view2d p1, pa_view2d mask, double scale,
                           int64_t rows, int64_t cols, pa_stream_t stream);
 
+/* The same site sum and gradient for operands that broadcast along a MIDDLE dimension of the
+ * site's frame (a plated latent under the particle plate: w[P, G, D] scored against mu[P, 1, D]),
+ * which are not 2-D strided views: a frame of ndim <= 4 dims `sizes`, every operand with its own
+ * element strides (0 = broadcast; NULL strides for an absent operand), fewer than 2^31 elements.
+ *   out_total      = sum over the frame of (mask ? scale : 0) * log_prob
+ *   d_x[flat i]    = (mask ? scale : 0) * g[0] * d log_prob / d x, contiguous over the frame
+ * (trace_struct.py:248-288 with the expanded parameters of torch_distribution.py:483-488). */
+size_t pa_dist_log_prob_sum_nd_workspace(void);
+int pa_dist_log_prob_sum_nd(int dist, int dtype, void* out_total, int ndim, const int64_t* sizes,
+                            const void* value, const int64_t* value_strides, const void* p0,
+                            const int64_t* p0_strides, const void* p1, const int64_t* p1_strides,
+                            const uint8_t* mask, const int64_t* mask_strides, double scale,
+                            void* workspace, size_t workspace_bytes, pa_stream_t stream);
+int pa_dist_log_prob_grad_nd(int dist, int dtype, void* d_value, void* d_p0, void* d_p1,
+                             const void* g, int ndim, const int64_t* sizes, const void* value,
+                             const int64_t* value_strides, const void* p0,
+                             const int64_t* p0_strides, const void* p1, const int64_t* p1_strides,
+                             const uint8_t* mask, const int64_t* mask_strides, double scale,
+                             pa_stream_t stream);
+/* out[A, B] = sum over R of in[A, R, B] (contiguous): brings an un-reduced gradient back to the
+ * shape of an operand that was broadcast along leading (A = 1), middle or trailing (B = 1) dims --
+ * the autograd dual of an expand (torch sum_to_size).  fp64 accumulation, fixed order.
+ * A < 65536; workspace of pa_sum_to_nd_workspace(A, R, B) bytes (0 for small R). */
+size_t pa_sum_to_nd_workspace(int64_t A, int64_t R, int64_t B);
+int pa_sum_to_nd(int dtype, const void* in, void* out, int64_t A, int64_t R, int64_t B,
+                 void* workspace, size_t workspace_bytes, pa_stream_t stream);
+
 /* Reparameterised Normal draw fused with the affine map (torch: normal.py:83-86):
  *   eps[r,c] = Philox normal (as pa_philox_normal with i = r*cols + c),
  *   out[r,c] = loc[r,c] + scale[r,c] * eps[r,c].

@@ -128,6 +128,16 @@ _SIGNATURES = {
     "pa_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                              c_double, c_double, c_double, c_double, c_double, c_double, c_int,
                              c_void_p, c_int, c_void_p]),
+    "pa_dist_log_prob_sum_nd_workspace": (c_size_t, []),
+    "pa_dist_log_prob_sum_nd": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_double, c_void_p, c_size_t, c_void_p]),
+    "pa_dist_log_prob_grad_nd": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
+    "pa_sum_to_nd_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_sum_to_nd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                             c_size_t, c_void_p]),
     "pa_mvn_tril_sample": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
                                    c_uint64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pa_mvn_tril_sample_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -63,7 +63,9 @@ class _FusedElementwise:
             return None
         if self._validate_args:
             self._validate_sample(value)
-        p0, p1 = self._params()
+        # un-expanded parameters (see fused_site_entry): the kernels broadcast by stride and
+        # reduce the gradient to the operand's own shape themselves
+        p0, p1 = getattr(self, "_base_params", None) or self._params()
         return fused.log_prob_sum(self._dist_id, value, p0, p1, mask, scale)
 
     def fused_site_entry(self, value, scale=1.0, mask=None):

@@ -76,12 +76,104 @@ def frame(operands, shape):
                         for o in operands]
 
 
+_ND_MIN_ELEMS = 65536      # below this the 2-D / torch paths are launch-bound anyway
+
+
+def _frame_lazy(operands, shape):
+    """frame(), except that a site the N-D kernels should take (see _use_nd) is reported as
+    (rows, cols, [None, ...]) BEFORE any broadcast is materialised."""
+    shape = tuple(int(s) for s in shape)
+    n = 1
+    for s_ in shape:
+        n *= s_
+    if _ND_MIN_ELEMS <= n < 2 ** 31 and (operands[0].is_cuda or kernels.HOST_TEST_BACKEND) \
+            and operands[0].dtype in (torch.float32, torch.float64) and len(shape) > 0:
+        infos = [None if o is None else _collapse(o, shape) for o in operands]
+        best = None
+        for k in range(0, len(shape) + 1):
+            if all(i is None or i[1][k] is not None for i in infos):
+                best = k
+                break
+        cols = 1
+        if best is not None:
+            for s_ in shape[best:]:
+                cols *= s_
+        if (best is None or cols < 128) and _nd_frame(operands, shape) is not None:
+            return 0, 0, [None] * len(operands)
+    return frame(operands, shape)
+
+
 def _sum_to(g, like):
+    """``g`` (the frame's shape) summed down to the shape of the broadcast operand ``like``: large
+    device tensors go through pa_sum_to_nd, one pass per run of adjacent broadcast dims."""
     if g is None:
         return None
     if g.shape == like.shape:
         return g
-    return g.sum_to_size(like.shape) if like.dim() > 0 or g.dim() > 0 else g
+    if g.numel() < _ND_MIN_ELEMS or not (g.is_cuda or kernels.HOST_TEST_BACKEND) \
+            or g.dtype not in (torch.float32, torch.float64):
+        return g.sum_to_size(like.shape) if like.dim() > 0 or g.dim() > 0 else g
+    shape = list(g.shape)
+    lead = len(shape) - like.dim()
+    keep = [False] * lead + [ls == s for ls, s in zip(like.shape, shape[lead:])]   # False = reduce
+    x = g.contiguous()
+    d = len(shape) - 1
+    while d >= 0:
+        if keep[d] or shape[d] == 1:
+            d -= 1
+            continue
+        hi = d
+        while d - 1 >= 0 and (not keep[d - 1] or shape[d - 1] == 1):
+            d -= 1
+        A = 1
+        for s_ in shape[:d]:
+            A *= s_
+        R = 1
+        for s_ in shape[d:hi + 1]:
+            R *= s_
+        B = 1
+        for s_ in shape[hi + 1:]:
+            B *= s_
+        if A >= 65536:                      # outside the kernel's grid: let torch do this one
+            return g.sum_to_size(like.shape)
+        x = kernels.sum_to_nd(x, A, R, B)
+        for j in range(d, hi + 1):
+            shape[j] = 1
+        d -= 1
+    return x.reshape(like.shape)
+
+
+def _nd_frame(operands, shape):
+    """(merged shape, operands viewed on it) with at most 4 dims for the N-D site kernels, or None:
+    size-1 dims are dropped and adjacent dims merged wherever every operand is laid out as one."""
+    shape = tuple(int(s) for s in shape)
+    exp = [None if o is None else o.expand(shape) for o in operands]
+    dims = [i for i, n in enumerate(shape) if n != 1]
+    if not dims:
+        return None
+    groups = [[dims[0]]]
+    for i in dims[1:]:
+        j = groups[-1][-1]
+        if all(e is None or e.stride(j) == e.stride(i) * shape[i] for e in exp):
+            groups[-1].append(i)
+        else:
+            groups.append([i])
+    if len(groups) > 4:
+        return None
+    mshape = []
+    for grp in groups:
+        n = 1
+        for i in grp:
+            n *= shape[i]
+        mshape.append(n)
+    views = []
+    for e in exp:
+        if e is None:
+            views.append(None)
+            continue
+        views.append(torch.as_strided(e, tuple(mshape), tuple(e.stride(grp[-1]) for grp in groups),
+                                      e.storage_offset()))
+    return tuple(mshape), views
 
 
 class _LogProb(torch.autograd.Function):
@@ -119,23 +211,32 @@ class _LogProbSum(torch.autograd.Function):
         if mask is not None:
             shapes.append(mask.shape)
         shape = torch.broadcast_shapes(*shapes)
-        rows, cols, (v2, a2, b2, m2) = frame([value, p0, p1, mask], shape)
-        _, total = kernels.dist_log_prob_sum(dist_id, v2, a2, b2, m2, scale, rows, cols,
-                                             want_total=True)
         ctx.dist_id, ctx.shape, ctx.scale = dist_id, shape, scale
         ctx.save_for_backward(value, p0, p1, mask)
+        ctx.nd = None
+        rows, cols, (v2, a2, b2, m2) = _frame_lazy([value, p0, p1, mask], shape)
+        if v2 is None:                       # N-D route chosen before anything was materialised
+            ctx.nd = True
+            mshape, (vn, an, bn, mn) = _nd_frame([value, p0, p1, mask], shape)
+            return kernels.dist_log_prob_sum_nd(dist_id, mshape, vn, an, bn, mn, scale)
+        _, total = kernels.dist_log_prob_sum(dist_id, v2, a2, b2, m2, scale, rows, cols,
+                                             want_total=True)
         return total
 
     @staticmethod
     def backward(ctx, g):
         value, p0, p1, mask = ctx.saved_tensors
         shape = ctx.shape
-        rows, cols, (v2, a2, b2, m2) = frame([value, p0, p1, mask], shape)
-        g2 = g.reshape(1, 1)
         need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2],
                 p1 is not None and ctx.needs_input_grad[3])
-        dv, da, db = kernels.dist_log_prob_grad(ctx.dist_id, g2, v2, a2, b2, m2, ctx.scale, rows,
-                                                cols, need)
+        if ctx.nd:
+            mshape, (vn, an, bn, mn) = _nd_frame([value, p0, p1, mask], shape)
+            dv, da, db = kernels.dist_log_prob_grad_nd(ctx.dist_id, mshape, g, vn, an, bn, mn,
+                                                       ctx.scale, need)
+        else:
+            rows, cols, (v2, a2, b2, m2) = frame([value, p0, p1, mask], shape)
+            dv, da, db = kernels.dist_log_prob_grad(ctx.dist_id, g.reshape(1, 1), v2, a2, b2, m2,
+                                                    ctx.scale, rows, cols, need)
         outs = [None if d is None else _sum_to(d.reshape(shape), like)
                 for d, like in ((dv, value), (da, p0), (db, p1))]
         return (None,) + tuple(outs) + (None, None)

@@ -174,6 +174,69 @@ def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need)
     return outs
 
 
+def _nd_args(shape, t):
+    """(pointer, int64[ndim] element strides of ``t`` expanded to ``shape``) for the N-D kernels."""
+    import ctypes
+    if t is None:
+        return None, None, None
+    e = t.expand(shape)
+    arr = (ctypes.c_int64 * len(shape))(*[0 if n == 1 else int(st)
+                                          for n, st in zip(shape, e.stride())])
+    return _ptr(e), arr, e
+
+
+def dist_log_prob_sum_nd(dist_id, shape, value, p0, p1, mask, scale):
+    """sum(scale_and_mask(log_prob)) over the broadcast frame ``shape`` (<= 4 dims) of operands
+    that need not be 2-D collapsible (pa_dist_log_prob_sum_nd).  Returns a 0-dim tensor."""
+    import ctypes
+    _require_gpu(value, p0, p1, mask)
+    lib = _lib.load()
+    shape = tuple(int(s) for s in shape)
+    sizes = (ctypes.c_int64 * len(shape))(*shape)
+    total = torch.empty((), dtype=value.dtype, device=value.device)
+    nbytes = lib.pa_dist_log_prob_sum_nd_workspace()
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=value.device)
+    pv, sv, kv = _nd_args(shape, value)
+    pa_, sa, ka = _nd_args(shape, p0)
+    pb, sb, kb = _nd_args(shape, p1)
+    pm, sm, km = _nd_args(shape, mask)
+    check(lib.pa_dist_log_prob_sum_nd(dist_id, _dtype(value), _ptr(total), len(shape), sizes, pv,
+                                      sv, pa_, sa, pb, sb, pm, sm, float(scale), _ptr(ws), nbytes,
+                                      _stream()))
+    return total
+
+
+def dist_log_prob_grad_nd(dist_id, shape, g, value, p0, p1, mask, scale, need):
+    """Un-reduced gradients w.r.t. (value, p0, p1), each contiguous of ``shape`` (None where not
+    needed); ``g`` = upstream gradient of the site sum (one element)."""
+    import ctypes
+    _require_gpu(g, value, p0, p1, mask)
+    shape = tuple(int(s) for s in shape)
+    sizes = (ctypes.c_int64 * len(shape))(*shape)
+    outs = [torch.empty(shape, dtype=value.dtype, device=value.device) if n else None for n in need]
+    pv, sv, kv = _nd_args(shape, value)
+    pa_, sa, ka = _nd_args(shape, p0)
+    pb, sb, kb = _nd_args(shape, p1)
+    pm, sm, km = _nd_args(shape, mask)
+    g = g.reshape(1).contiguous()
+    check(_lib.load().pa_dist_log_prob_grad_nd(
+        dist_id, _dtype(value), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(g), len(shape),
+        sizes, pv, sv, pa_, sa, pb, sb, pm, sm, float(scale), _stream()))
+    return outs
+
+
+def sum_to_nd(x, A, R, B):
+    """x contiguous, viewed as [A, R, B] -> [A, B] summed over R (pa_sum_to_nd)."""
+    _require_gpu(x)
+    assert x.is_contiguous() and x.numel() == A * R * B
+    lib = _lib.load()
+    out = torch.empty((A, B), dtype=x.dtype, device=x.device)
+    nbytes = lib.pa_sum_to_nd_workspace(A, R, B)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device) if nbytes else None
+    check(lib.pa_sum_to_nd(_dtype(x), _ptr(x), _ptr(out), A, R, B, _ptr(ws), nbytes, _stream()))
+    return out
+
+
 def normal_rsample(loc, scale, rows, cols, seed, offset, want_eps=True, offset_dev=None):
     _require_gpu(loc, scale, offset_dev)
     out = torch.empty((rows, cols), dtype=loc.dtype, device=loc.device)

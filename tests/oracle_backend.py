@@ -71,6 +71,43 @@ def dist_log_prob_grad(dist_id, g, value, p0, p1, mask, scale, rows, cols, need)
     return outs
 
 
+def _bcn(t, shape):
+    return None if t is None else np.broadcast_to(_np(t), shape)
+
+
+def dist_log_prob_sum_nd(dist_id, shape, value, p0, p1, mask, scale):
+    lp = o_dists.LOG_PROB[dist_id](_bcn(value, shape).astype(np.float64),
+                                   _bcn(p0, shape).astype(np.float64),
+                                   None if p1 is None else _bcn(p1, shape).astype(np.float64)) * scale
+    m = _bcn(mask, shape)
+    if m is not None:
+        lp = np.where(m, lp, 0.0)
+    return torch.as_tensor(lp.sum(), dtype=value.dtype)
+
+
+def dist_log_prob_grad_nd(dist_id, shape, g, value, p0, p1, mask, scale, need):
+    v = _bcn(value, shape).astype(np.float64)
+    a = _bcn(p0, shape).astype(np.float64)
+    b = None if p1 is None else _bcn(p1, shape).astype(np.float64)
+    dv, da, db = o_dists.log_prob_grad(dist_id, v, a, b)
+    w = float(_np(g).reshape(-1)[0]) * scale
+    m = _bcn(mask, shape)
+    outs = []
+    for d, n in zip((dv, da, db), need):
+        if not n:
+            outs.append(None)
+            continue
+        x = w * np.broadcast_to(d, shape)
+        if m is not None:
+            x = np.where(m, x, 0.0)
+        outs.append(torch.as_tensor(np.ascontiguousarray(x), dtype=value.dtype))
+    return outs
+
+
+def sum_to_nd(x, A, R, B):
+    return torch.as_tensor(np.ascontiguousarray(_np(x).reshape(A, R, B).sum(1)), dtype=x.dtype)
+
+
 def _entry_np(e):
     rows, cols = e["rows"], e["cols"]
     v = _bc(e["value"], rows, cols).astype(np.float64)
@@ -382,7 +419,7 @@ FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
-             "mvn_tril_sample_bwd"]
+             "mvn_tril_sample_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd"]
 
 
 def install(monkeypatch):

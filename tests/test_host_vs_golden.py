@@ -62,3 +62,46 @@ def test_predictive(monkeypatch):
 @pytest.mark.parametrize("tag", ["p1", "p4"])
 def test_autocontinuous_guides(monkeypatch, which, tag):
     models.run_autocont(load("autocont"), torch.device("cpu"), monkeypatch, which, tag, rtol=1e-9)
+
+
+def test_large_plated_site_takes_the_nd_route(monkeypatch):
+    """A latent under a plate AND the particle plate scored against parameters that broadcast along
+    the middle dim (config 5's w[P, G, D] ~ Normal(mu[P, 1, D], tau[P, 1, D])): the N-D site
+    kernels + sum_to reduction against torch autograd of the reference formulation."""
+    import numpy as np
+    from pyro_amd.distributions import fused
+    from tests import oracle_backend
+    oracle_backend.install(monkeypatch)
+    monkeypatch.setattr(fused, "_ND_MIN_ELEMS", 64)
+    torch.manual_seed(0)
+    P, G, D = 3, 7, 5
+    w = torch.randn(P, G, D, dtype=torch.float64, requires_grad=True)
+    mu = torch.randn(P, 1, D, dtype=torch.float64, requires_grad=True)
+    tau = (torch.rand(P, 1, D, dtype=torch.float64) + 0.5).requires_grad_(True)
+    mask = torch.rand(G, 1) < 0.8
+    calls = []
+    import pyro_amd.kernels as k
+    real = k.dist_log_prob_sum_nd
+    monkeypatch.setattr(k, "dist_log_prob_sum_nd", lambda *a: (calls.append(a[1]), real(*a))[1])
+    out = fused.log_prob_sum(0, w, mu, tau, mask=mask, scale=2.5)
+    assert calls == [(P, G, D)]
+    (out * 0.7).backward()
+    got = [t.grad.clone() for t in (w, mu, tau)]
+    for t in (w, mu, tau):
+        t.grad = None
+    ref = (torch.distributions.Normal(mu, tau).log_prob(w) * 2.5 * mask).sum()
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-12)
+    (ref * 0.7).backward()
+    for g, t in zip(got, (w, mu, tau)):
+        assert g.shape == t.shape
+        torch.testing.assert_close(g, t.grad, rtol=1e-10, atol=1e-12)
+    # leading broadcast (the guide's [G, D] parameters under the particle plate): merged to 2 dims
+    loc = torch.randn(G, D, dtype=torch.float64, requires_grad=True)
+    calls.clear()
+    out2 = fused.log_prob_sum(0, w.detach(), loc, torch.ones((), dtype=torch.float64))
+    out2.backward()
+    ref2 = torch.distributions.Normal(loc.detach().requires_grad_(True), 1.0)
+    l2 = ref2.log_prob(w.detach()).sum()
+    l2.backward()
+    np.testing.assert_allclose(out2.item(), l2.item(), rtol=1e-12)
+    torch.testing.assert_close(loc.grad, ref2.loc.grad, rtol=1e-10, atol=1e-12)

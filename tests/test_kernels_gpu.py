@@ -531,3 +531,73 @@ def test_adam_step_publish_hands_over_the_scalar(gpu):
         assert hs.item() == step and hv.item() == 1.5 * step
         assert counter.item() == 40 + 7 * step
     assert torch.equal(bufs[0][0], bufs[1][0]) and bufs[1][3].tolist() == [3, 0]
+
+
+# ---------------------------------------------------------------------------------------------
+# N-D site kernels (operands that broadcast along a middle dim) and the sum_to reduction
+# ---------------------------------------------------------------------------------------------
+def _nd_cases(rng):
+    # (dist id, frame, value shape, p0 shape, p1 shape or None, positive value?)
+    return [(0, (7, 50, 33), (7, 50, 33), (7, 1, 33), (7, 1, 33), False),      # mu[P,1,D] vs w[P,G,D]
+            (0, (5, 40, 16), (5, 40, 16), (40, 16), (1,), False),               # leading broadcast
+            (0, (3, 4, 30, 8), (3, 4, 30, 8), (3, 1, 30, 1), (4, 1, 8), False), # 4 dims, mixed
+            (1, (6, 70, 9), (70, 9), (6, 70, 9), None, False),                  # Bernoulli logits
+            (2, (4, 33, 5), (4, 33, 5), (4, 1, 5), None, True),                 # HalfCauchy
+            (3, (4, 33, 5), (4, 33, 5), (1, 33, 1), (4, 1, 5), True),           # LogNormal
+            (5, (2, 300, 3), (2, 300, 3), (2, 1, 3), None, True)]               # HalfNormal
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_dist_log_prob_nd(gpu, dtype, use_mask):
+    from tests import oracle_backend as ob
+    k = _k()
+    rng = np.random.default_rng(17)
+    for dist_id, shape, vs, as_, bs, positive in _nd_cases(rng):
+        if dist_id == 1:
+            v = (rng.uniform(size=vs) < 0.4).astype(np.float64)
+            a = rng.standard_normal(as_)
+        else:
+            v = rng.uniform(0.2, 3.0, vs) if positive else rng.standard_normal(vs)
+            a = rng.uniform(0.5, 2.0, as_) if dist_id in (2, 5) else rng.standard_normal(as_)
+        b = None if bs is None else rng.uniform(0.5, 2.0, bs)
+        m = (rng.uniform(size=shape[-2:]) < 0.7) if use_mask else None
+        tv, ta = (torch.tensor(x, dtype=dtype, device=gpu) for x in (v, a))
+        tb = None if b is None else torch.tensor(b, dtype=dtype, device=gpu)
+        tm = None if m is None else torch.tensor(m, device=gpu)
+        cv, ca = tv.cpu(), ta.cpu()
+        cb, cm = (None if t is None else t.cpu() for t in (tb, tm))
+        tol = 1e-11 if dtype == torch.float64 else 3e-5
+        got = k.dist_log_prob_sum_nd(dist_id, shape, tv, ta, tb, tm, 1.7)
+        ref = ob.dist_log_prob_sum_nd(dist_id, shape, cv.double(), ca.double(),
+                                      None if cb is None else cb.double(), cm, 1.7)
+        np.testing.assert_allclose(got.item(), ref.item(), rtol=tol, atol=tol * abs(ref.item()))
+        g = torch.tensor([0.6], dtype=dtype, device=gpu)
+        need = (True, True, b is not None)
+        outs = k.dist_log_prob_grad_nd(dist_id, shape, g, tv, ta, tb, tm, 1.7, need)
+        refs = ob.dist_log_prob_grad_nd(dist_id, shape, g.cpu().double(), cv.double(), ca.double(),
+                                        None if cb is None else cb.double(), cm, 1.7, need)
+        for o, r in zip(outs, refs):
+            if r is None:
+                assert o is None
+                continue
+            assert o.shape == tuple(shape) and o.is_contiguous()
+            np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), rtol=tol * 5,
+                                       atol=tol * 5 * float(r.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("A,R,B", [(1, 64, 32000), (64, 1000, 32), (6400, 32, 1), (3, 5, 7),
+                                   (1, 1, 1), (2, 100003, 1), (5, 1, 9), (1, 300000, 3),
+                                   (17, 129, 257)])
+def test_sum_to_nd(gpu, dtype, A, R, B):
+    k = _k()
+    rng = np.random.default_rng(A + R + B)
+    x = rng.standard_normal((A, R, B))
+    tx = torch.tensor(x, dtype=dtype, device=gpu)
+    got = k.sum_to_nd(tx, A, R, B)
+    again = k.sum_to_nd(tx, A, R, B)
+    assert torch.equal(got, again)                       # deterministic
+    ref = tx.double().sum(1)
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    torch.testing.assert_close(got.double(), ref, rtol=tol, atol=tol * np.sqrt(R) * 4)
