@@ -224,6 +224,13 @@ int pa_multi_log_prob_sum(int dtype, void* out_total, const pa_site_entry* entri
 /* g: device pointer to the upstream gradient of out_total (one element of `dtype`). */
 int pa_multi_log_prob_grad(int dtype, const void* g, const pa_site_entry* entries, int n,
                            double coef_all, pa_stream_t stream);
+/* Both of the above in ONE launch, for a caller that differentiates the total immediately
+ * (Trace_ELBO.loss_and_grads: surrogate_loss.backward() right after the forward,
+ * pyro/infer/trace_elbo.py:153-157): out_total as pa_multi_log_prob_sum, the operand gradients as
+ * pa_multi_log_prob_grad with the upstream gradient g (NULL = 1). */
+int pa_multi_log_prob_sum_grad(int dtype, void* out_total, const void* g,
+                               const pa_site_entry* entries, int n, double coef_all,
+                               int accumulate, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Mean-field Normal guide: all latent sites drawn in one launch (AutoNormal,

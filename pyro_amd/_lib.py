@@ -83,6 +83,8 @@ _SIGNATURES = {
                                       c_void_p]),
     "pa_multi_log_prob_grad": (c_int, [c_int, c_void_p, POINTER(SiteEntry), c_int, c_double,
                                        c_void_p]),
+    "pa_multi_log_prob_sum_grad": (c_int, [c_int, c_void_p, c_void_p, POINTER(SiteEntry), c_int,
+                                           c_double, c_int, c_void_p]),
     "pa_meanfield_normal_sample": (c_int, [c_int, POINTER(MfSite), c_int, c_int64, c_uint64,
                                            c_void_p, c_void_p]),
     "pa_meanfield_normal_sample_bwd": (c_int, [c_int, POINTER(MfSite), c_int, c_int64, c_void_p]),

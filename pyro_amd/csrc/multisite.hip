@@ -133,14 +133,13 @@ __device__ __forceinline__ double entry_sum(const EntryDev& e, uint32_t tid, uin
 
 // ONE workgroup of 16 waves: the entries are spread over the waves (several waves per entry when
 // there are fewer than 16), so that all of them are read concurrently.
-template <typename T>
-__global__ __launch_bounds__(MULTI_THREADS) void multi_sum_kernel(const MultiArgs args_by_value,
-                                                                  T* __restrict__ out,
-                                                                  double coef_all, int accumulate) {
+template <typename T, int NTHREADS>
+__device__ __forceinline__ void multi_sum_body(T* __restrict__ out, double coef_all,
+                                               int accumulate) {
   __shared__ double smem[16];
   const int n_entries = kernarg_load<int>(offsetof(MultiArgs, n));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  constexpr int NW = MULTI_THREADS / 64;
+  constexpr int NW = NTHREADS / 64;
   const int wpe = n_entries >= NW ? 1 : NW / (n_entries > 0 ? n_entries : 1);   // waves per entry
   const int epr = NW / wpe;                                                     // entries per round
   double acc = 0.0;
@@ -159,6 +158,13 @@ __global__ __launch_bounds__(MULTI_THREADS) void multi_sum_kernel(const MultiArg
     const double base = accumulate ? (double)*out : 0.0;
     *out = (T)(base + coef_all * t);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(MULTI_THREADS) void multi_sum_kernel(const MultiArgs args_by_value,
+                                                                  T* __restrict__ out,
+                                                                  double coef_all, int accumulate) {
+  multi_sum_body<T, MULTI_THREADS>(out, coef_all, accumulate);
 }
 
 constexpr int GRAD_THREADS = 256;
@@ -314,14 +320,12 @@ __device__ __forceinline__ void operand_pass(const EntryDev& e, int which, int p
 // produces it) followed by the chained entries' contributions to the same buffer, and its p0 / p1
 // gradients -- the common patterns in one pass each
 template <typename T>
-__global__ __launch_bounds__(GRAD_THREADS) void multi_grad_kernel(const MultiArgs args_by_value,
-                                                                  const T* __restrict__ g,
-                                                                  double coef_all) {
+__device__ __forceinline__ void multi_grad_body(int entry, const T* __restrict__ g,
+                                                double coef_all) {
   __shared__ double red[2 * GRAD_THREADS];
-  const EntryDev e =
-      kernarg_load<EntryDev>(offsetof(MultiArgs, e) + blockIdx.x * sizeof(EntryDev));
+  const EntryDev e = kernarg_load<EntryDev>(offsetof(MultiArgs, e) + entry * sizeof(EntryDev));
   if (e.rows * e.cols == 0) return;
-  const double gw = (double)g[0] * coef_all;
+  const double gw = (g != nullptr ? (double)g[0] : 1.0) * coef_all;
   const bool own_value = (e.need & PA_NEED_VALUE) && e.dv && !(e.need & PA_VALUE_BY_CHAIN);
   const bool param_family = e.dist >= 0 && e.dist < PA_DIST_COUNT;
   int pv = pattern_of(own_value, e.vsr, e.vsc, e.rows, e.cols);
@@ -353,6 +357,26 @@ __global__ __launch_bounds__(GRAD_THREADS) void multi_grad_kernel(const MultiArg
       k = m.chain_next;
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GRAD_THREADS) void multi_grad_kernel(const MultiArgs args_by_value,
+                                                                  const T* __restrict__ g,
+                                                                  double coef_all) {
+  multi_grad_body<T>((int)blockIdx.x, g, coef_all);
+}
+
+// Forward AND backward of the table in one launch, for a caller that knows it will differentiate
+// the total right away (Trace_ELBO.loss_and_grads: surrogate.backward() follows the forward
+// immediately, pyro/infer/trace_elbo.py:153-157): workgroups 0..n-1 write the operand gradients
+// for an upstream gradient g (NULL = 1), workgroup n the total.
+template <typename T>
+__global__ __launch_bounds__(GRAD_THREADS) void multi_sum_grad_kernel(
+    const MultiArgs args_by_value, T* __restrict__ out, const T* __restrict__ g, double coef_all,
+    int accumulate) {
+  const int n_entries = kernarg_load<int>(offsetof(MultiArgs, n));
+  if ((int)blockIdx.x == n_entries) multi_sum_body<T, GRAD_THREADS>(out, coef_all, accumulate);
+  else multi_grad_body<T>((int)blockIdx.x, g, coef_all);
 }
 
 static int to_dev(const pa_site_entry* in, int n, MultiArgs* out, const char* who) {
@@ -570,6 +594,26 @@ int pa_multi_log_prob_grad(int dtype, const void* g, const pa_site_entry* entrie
     hipLaunchKernelGGL((pa::multi_grad_kernel<double>), dim3((unsigned)n), dim3(pa::GRAD_THREADS), 0, s,
                        args, (const double*)g, coef_all);
   return pa::check_launch("multi_grad_kernel");
+}
+
+int pa_multi_log_prob_sum_grad(int dtype, void* out_total, const void* g,
+                               const pa_site_entry* entries, int n, double coef_all,
+                               int accumulate, pa_stream_t stream) {
+  PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "pa_multi_log_prob_sum_grad: bad dtype %d", dtype);
+  PA_REQUIRE(out_total != nullptr, "pa_multi_log_prob_sum_grad: NULL output");
+  pa::MultiArgs args;
+  int rc = pa::to_dev(entries, n, &args, "pa_multi_log_prob_sum_grad");
+  if (rc != PA_OK) return rc;
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    hipLaunchKernelGGL((pa::multi_sum_grad_kernel<float>), dim3((unsigned)n + 1),
+                       dim3(pa::GRAD_THREADS), 0, s, args, (float*)out_total, (const float*)g,
+                       coef_all, accumulate);
+  else
+    hipLaunchKernelGGL((pa::multi_sum_grad_kernel<double>), dim3((unsigned)n + 1),
+                       dim3(pa::GRAD_THREADS), 0, s, args, (double*)out_total, (const double*)g,
+                       coef_all, accumulate);
+  return pa::check_launch("multi_sum_grad_kernel");
 }
 
 int pa_meanfield_normal_sample(int dtype, const pa_mf_site* sites, int nsites, int64_t P,

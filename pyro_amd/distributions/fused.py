@@ -432,10 +432,20 @@ class _MultiLogProbSum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, extras, coef_all, *tensors):
-        entries = _MultiLogProbSum._entries(meta, tensors, None)
         proto = tensors[0]
         ctx.meta, ctx.extras, ctx.coef_all = meta, extras, coef_all
         ctx.save_for_backward(*tensors)
+        ctx.eager = None
+        needs = ctx.needs_input_grad[3:]
+        if EAGER_GRAD["on"] and any(needs) and len(meta) <= _lib_const("MULTI_MAX_ENTRIES"):
+            # the caller differentiates the total right away with a unit upstream gradient
+            # (Trace_ELBO.loss_and_grads): gradients come out of the forward launch
+            entries = _MultiLogProbSum._grad_entries(meta, extras, tensors, needs)
+            total, grads = kernels.multi_log_prob_sum_grad(entries, coef_all, proto.dtype,
+                                                           proto.device)
+            ctx.eager = grads
+            return total
+        entries = _MultiLogProbSum._entries(meta, tensors, None)
         return kernels.multi_log_prob_sum(entries, coef_all, proto.dtype, proto.device)
 
     @staticmethod
@@ -454,14 +464,12 @@ class _MultiLogProbSum(torch.autograd.Function):
         return entries
 
     @staticmethod
-    def backward(ctx, g):
+    def _grad_entries(meta, extras, tensors, needs):
         from .. import _lib
-        tensors = ctx.saved_tensors
-        needs = ctx.needs_input_grad[3:]
-        entries = _MultiLogProbSum._entries(ctx.meta, tensors, needs)
+        entries = _MultiLogProbSum._entries(meta, tensors, needs)
         # position of every entry's value among the inputs
         pos, i = [], 0
-        for dist_id, nops, mask, coef in ctx.meta:
+        for dist_id, nops, mask, coef in meta:
             pos.append(i)
             i += nops
 
@@ -484,22 +492,45 @@ class _MultiLogProbSum(torch.autograd.Function):
                 e["by_chain"] = True
             else:
                 heads[key] = k
-        for target_pos, xg, xcoef in ctx.extras:
+        for target_pos, xg, xcoef in extras:
             for (tid, _, _, _), k in heads.items():
                 if tid == id(tensors[target_pos]) and "extra_grad" not in entries[k]:
                     entries[k]["extra_grad"], entries[k]["extra_coef"] = xg, xcoef
                     break
             else:
                 raise RuntimeError("pyro_amd: no value-gradient carrier for an extra term")
+        return entries
+
+    @staticmethod
+    def backward(ctx, g):
+        tensors = ctx.saved_tensors
+        needs = ctx.needs_input_grad[3:]
         proto = tensors[0]
-        grads = kernels.multi_log_prob_grad(g, entries, ctx.coef_all, proto.dtype, proto.device)
+        if ctx.eager is not None:
+            # the forward assumed an upstream gradient of 1: true when g IS the cached unit tensor
+            grads, unit = ctx.eager, g.data_ptr() == EAGER_GRAD.get("unit_ptr")
+        else:
+            entries = _MultiLogProbSum._grad_entries(ctx.meta, ctx.extras, tensors, needs)
+            grads, unit = kernels.multi_log_prob_grad(g, entries, ctx.coef_all, proto.dtype,
+                                                      proto.device), True
         out, i = [], 0
         for (dist_id, nops, mask, coef), gs in zip(ctx.meta, grads):
             for j in range(nops):
                 t = tensors[i + j]
-                out.append(None if gs[j] is None else gs[j].reshape(t.shape))
+                d = None if gs[j] is None else gs[j].reshape(t.shape)
+                out.append(d if d is None or unit else d * g)
             i += nops
         return (None, None, None) + tuple(out)
+
+
+# Set by Trace_ELBO.loss_and_grads around the ELBO assembly: the total is differentiated at once
+# with a unit upstream gradient, so _MultiLogProbSum may produce the gradients in its forward launch
+EAGER_GRAD = {"on": False}
+
+
+def _lib_const(name):
+    from .. import _lib
+    return getattr(_lib, name)
 
 
 class SiteBatch:

@@ -172,8 +172,18 @@ class Trace_ELBO(ELBO):
             trainable = any(site["type"] == "param" for trace in (model_trace, guide_trace)
                             for site in trace.nodes.values())
             if getattr(guide_trace, "_fully_reparam", False):
-                # surrogate loss == loss value; the -1/num_particles factor rides in the kernel
-                sl = self._batched_total(model_trace, guide_trace, coef=c)
+                # surrogate loss == loss value; the -1/num_particles factor rides in the kernel.
+                # backward() follows immediately with a unit root gradient, so the assembly may
+                # produce its gradients in the forward launch (fused.EAGER_GRAD)
+                from ..distributions import fused
+                eager = fused.EAGER_GRAD
+                eager["on"] = bool(trainable) and torch.is_grad_enabled()
+                try:
+                    sl = self._batched_total(model_trace, guide_trace, coef=c)
+                finally:
+                    eager["on"] = False
+                if isinstance(sl, torch.Tensor):
+                    eager["unit_ptr"] = _unit_grad(sl).data_ptr()
                 if not isinstance(sl, torch.Tensor):
                     term, sl = sl, None
                 else:

@@ -292,38 +292,58 @@ def multi_log_prob_grad(g, entries, coef_all, dtype, device):
     outs = []
     for lo in range(0, len(entries), _lib.MULTI_MAX_ENTRIES):
         chunk = entries[lo:lo + _lib.MULTI_MAX_ENTRIES]
-        arr = (_lib.SiteEntry * len(chunk))()
-        for k, e in enumerate(chunk):
-            rows, cols = e["rows"], e["cols"]
-            views = [_view(e["value"], rows, cols), _view(e["p0"], rows, cols),
-                     _view(e["p1"], rows, cols)]
-            grads, need_bits = [], 0
-            by_chain = bool(e.get("by_chain", False))
-            for j, (need, src) in enumerate(zip(e["need"], (e["value"], e["p0"], e["p1"]))):
-                if need and src is not None and not (j == 0 and by_chain):
-                    grads.append(torch.empty(_reduced_shape(views[j], rows, cols), dtype=dtype,
-                                             device=device))
-                    need_bits |= 1 << j
-                else:
-                    grads.append(None)
-            if by_chain:
-                need_bits |= _lib.NEED_VALUE | _lib.VALUE_BY_CHAIN
-            nxt = e.get("chain_next", -1)
-            if nxt >= 0:
-                assert lo <= nxt < lo + len(chunk), "a gradient chain straddles two launches"
-                nxt -= lo
-            xg = e.get("extra_grad")
-            if xg is not None:
-                _require_gpu(xg)
-                assert xg.is_contiguous() and xg.numel() == rows * cols and xg.dtype == dtype
-            arr[k] = _lib.SiteEntry(e["dist"], need_bits, rows, cols, views[0], views[1], views[2],
-                                    _view(e["mask"], rows, cols), float(e["coef"]),
-                                    _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), nxt, 0,
-                                    _ptr(xg), float(e.get("extra_coef", 0.0)))
-            outs.append(tuple(grads))
+        arr, grads = _grad_table(chunk, lo, dtype, device)
+        outs += grads
         check(lib.pa_multi_log_prob_grad(_DTYPES[dtype], _ptr(g), arr, len(chunk), float(coef_all),
                                          _stream()))
     return outs
+
+
+def _grad_table(chunk, lo, dtype, device):
+    """ctypes entry table (with freshly allocated gradient outputs) of one launch's entries."""
+    arr = (_lib.SiteEntry * len(chunk))()
+    outs = []
+    for k, e in enumerate(chunk):
+        rows, cols = e["rows"], e["cols"]
+        _require_gpu(e["value"], e["p0"], e["p1"], e["mask"])
+        views = [_view(e["value"], rows, cols), _view(e["p0"], rows, cols),
+                 _view(e["p1"], rows, cols)]
+        grads, need_bits = [], 0
+        by_chain = bool(e.get("by_chain", False))
+        for j, (need, src) in enumerate(zip(e["need"], (e["value"], e["p0"], e["p1"]))):
+            if need and src is not None and not (j == 0 and by_chain):
+                grads.append(torch.empty(_reduced_shape(views[j], rows, cols), dtype=dtype,
+                                         device=device))
+                need_bits |= 1 << j
+            else:
+                grads.append(None)
+        if by_chain:
+            need_bits |= _lib.NEED_VALUE | _lib.VALUE_BY_CHAIN
+        nxt = e.get("chain_next", -1)
+        if nxt >= 0:
+            assert lo <= nxt < lo + len(chunk), "a gradient chain straddles two launches"
+            nxt -= lo
+        xg = e.get("extra_grad")
+        if xg is not None:
+            _require_gpu(xg)
+            assert xg.is_contiguous() and xg.numel() == rows * cols and xg.dtype == dtype
+        arr[k] = _lib.SiteEntry(e["dist"], need_bits, rows, cols, views[0], views[1], views[2],
+                                _view(e["mask"], rows, cols), float(e["coef"]),
+                                _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), nxt, 0,
+                                _ptr(xg), float(e.get("extra_coef", 0.0)))
+        outs.append(tuple(grads))
+    return arr, outs
+
+
+def multi_log_prob_sum_grad(entries, coef_all, dtype, device):
+    """multi_log_prob_sum AND multi_log_prob_grad (upstream gradient 1) of one table of at most
+    PA_MULTI_MAX_ENTRIES entries in ONE launch: returns (total 0-dim, per-entry gradient tuples)."""
+    assert 0 < len(entries) <= _lib.MULTI_MAX_ENTRIES
+    out = torch.empty((), dtype=dtype, device=device)
+    arr, grads = _grad_table(entries, 0, dtype, device)
+    check(_lib.load().pa_multi_log_prob_sum_grad(_DTYPES[dtype], _ptr(out), None, arr, len(entries),
+                                                 float(coef_all), 0, _stream()))
+    return out, grads
 
 
 def meanfield_normal_sample(locs, rhos, P, seed, offsets, offset_dev=None):

@@ -170,6 +170,11 @@ def multi_log_prob_grad(g, entries, coef_all, dtype, device):
     return outs
 
 
+def multi_log_prob_sum_grad(entries, coef_all, dtype, device):
+    return (multi_log_prob_sum(entries, coef_all, dtype, device),
+            multi_log_prob_grad(1.0, entries, coef_all, dtype, device))
+
+
 def meanfield_normal_sample(locs, rhos, P, seed, offsets, offset_dev=None):
     zs, scales, louts, epss = [], [], [], []
     base = 0 if offset_dev is None else int(offset_dev.item())
@@ -417,7 +422,7 @@ def chain_matvec(M, x, transpose=False):
 FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
-             "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad",
+             "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
              "mvn_tril_sample_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd"]
 

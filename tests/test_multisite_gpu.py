@@ -90,6 +90,26 @@ def test_multi_log_prob_sum_and_grad_vs_restatement(gpu, dtype):
                 np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=rtol * 5, atol=rtol * 5 * sc)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_multi_sum_grad_in_one_launch_equals_the_two_launches(gpu, dtype):
+    """pa_multi_log_prob_sum_grad (unit upstream gradient) == pa_multi_log_prob_sum followed by
+    pa_multi_log_prob_grad(g = 1): the gradients bit for bit (same code, same launch geometry per
+    entry), the total to summation-order tolerance (4 waves instead of 16)."""
+    from pyro_amd import kernels as k
+
+    rng = np.random.default_rng(8)
+    ents = _entries(rng, dtype, gpu)
+    tot2, grads2 = k.multi_log_prob_sum_grad(ents, -0.25, dtype, gpu)
+    tot = k.multi_log_prob_sum(ents, -0.25, dtype, gpu)
+    grads = k.multi_log_prob_grad(torch.ones((), dtype=dtype, device=gpu), ents, -0.25, dtype, gpu)
+    np.testing.assert_allclose(float(tot2), float(tot), rtol=2e-6 if dtype == torch.float32 else 1e-13)
+    for gs, hs in zip(grads, grads2):
+        for a, b in zip(gs, hs):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
+
+
 def test_multi_more_entries_than_one_launch(gpu):
     """> PA_MULTI_MAX_ENTRIES entries: chained launches accumulate into the same total."""
     from pyro_amd import kernels as k
