@@ -281,6 +281,10 @@ def main():
                               "in the plate), 8 topics, 1024 words, 64 words per document, amortised "
                               "guide; word_topics enumerated and summed out by the fused LDA kernel")
             others["config4_lda"] = r4
+            r1 = bench_configs.config1(dev)
+            r1["workload"] = ("BASELINE configs[0]: eight schools, Trace_ELBO, 1 particle, Adam; graphed "
+                              "SVI.step (the reference's own CPU-runnable case: ~58 steps/s there)")
+            others["config1_eight_schools"] = r1
             r2m = bench_configs.config2_variant(dev, "mvn")
             r2m["workload"] = ("BASELINE configs[1] with AutoMultivariateNormal (the second guide "
                                "SURVEY 8d names), 64 particles, graphed SVI.step")

@@ -52,6 +52,43 @@ def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=T
             "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
 
 
+def config1(dev, steps=300, graph=True):
+    """BASELINE configs[0]: eight schools (examples/eight_schools/svi.py:20-76), Trace_ELBO with one
+    particle, Adam lr 0.01 -- every site is a handful of elements: pure launch / host overhead."""
+    from pyro_amd import distributions as dist
+    from pyro_amd.distributions import constraints
+    J = 8
+    y = torch.tensor([28.0, 8, -3, 7, -1, 1, 18, 12], device=dev)
+    sigma = torch.tensor([15.0, 10, 16, 11, 9, 11, 10, 18], device=dev)
+    zJ, oJ = torch.zeros(J, device=dev), torch.ones(J, device=dev)
+    z1, o10, o25 = torch.zeros(1, device=dev), 10 * torch.ones(1, device=dev), 25 * torch.ones(1, device=dev)
+
+    def model(y, sigma):
+        with pyro.plate("data", J):
+            eta = pyro.sample("eta", dist.Normal(zJ, oJ))
+            mu = pyro.sample("mu", dist.Normal(z1, o10))
+            tau = pyro.sample("tau", dist.HalfCauchy(scale=o25))
+            pyro.sample("obs", dist.Normal(mu + tau * eta, sigma), obs=y)
+
+    def guide(y, sigma):
+        m_eta = pyro.param("loc_eta", lambda: torch.zeros(J, device=dev))
+        s_eta = pyro.param("scale_eta", lambda: 0.1 * torch.ones(J, device=dev), constraint=constraints.positive)
+        m_mu = pyro.param("loc_mu", lambda: torch.zeros(1, device=dev))
+        s_mu = pyro.param("scale_mu", lambda: 0.1 * torch.ones(1, device=dev), constraint=constraints.positive)
+        m_lt = pyro.param("loc_logtau", lambda: torch.zeros(1, device=dev))
+        s_lt = pyro.param("scale_logtau", lambda: 0.1 * torch.ones(1, device=dev), constraint=constraints.positive)
+        with pyro.plate("data", J):
+            pyro.sample("eta", dist.Normal(m_eta, s_eta))
+            pyro.sample("mu", dist.Normal(m_mu, s_mu))
+            pyro.sample("tau", dist.LogNormal(m_lt, s_lt))
+
+    pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
+    svi = SVI(model, guide, pyro.optim.Adam({"lr": 0.01}), Trace_ELBO(), hip_graph=graph, graph_warmup=2)
+    dt = timed(lambda: svi.step(y, sigma), steps, 10)
+    return {"steps_per_s": 1 / dt, "us_per_step": dt * 1e6,
+            "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1)}
+
+
 def config4(dev, docs=100_000, steps=10):
     args = examples.LdaArgs(num_docs=docs)
     data = examples.synthetic_lda_data(args, dev)
@@ -70,6 +107,8 @@ if __name__ == "__main__":
     print("config 5 (N=1e7, P=64, G=1000):", config5(dev))
     print("config 5 eager:", config5(dev, steps=5, graph=False))
     print("config 4 (1e5 docs):", config4(dev))
+    print("config 1 (eight schools):", config1(dev))
+    print("config 1 eager:", config1(dev, steps=100, graph=False))
     print("config 2, AutoMultivariateNormal:", config2_variant(dev, "mvn"))
     print("config 2, AutoNormal, num_particles=1:", config2_variant(dev, "normal", P=1))
     print("config 2, AutoNormal, num_particles=4:", config2_variant(dev, "normal", P=4))
