@@ -54,6 +54,13 @@ class TorchDistributionMixin:
     def expand_by(self, sample_shape):
         return self.expand(torch.Size(sample_shape) + self.batch_shape)
 
+    def has_rsample_(self, value):
+        """Force reparameterised or detached sampling on this instance (distribution.py:180-199)."""
+        if not (value is True or value is False):
+            raise ValueError("Expected value in [False,True], actual {}".format(value))
+        self.has_rsample = value
+        return self
+
     def reshape(self, sample_shape=None, extra_event_dims=None):
         raise Exception(".reshape(sample_shape=s, extra_event_dims=n) was renamed: "
                         "use .expand_by(s).to_event(n)")

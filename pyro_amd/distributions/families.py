@@ -103,6 +103,8 @@ class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMix
         new._validate_args = self._validate_args
         new._base_params = getattr(self, "_base_params", None) or (self.loc, self.scale)
         new._presampled = self._presampled
+        if "has_rsample" in self.__dict__:      # has_rsample_() set on this instance
+            new.has_rsample = self.__dict__["has_rsample"]
         return new
 
     def _params(self):

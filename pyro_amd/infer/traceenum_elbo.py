@@ -6,10 +6,13 @@ Scope of this plugin (what BASELINE config 4, examples/lda.py, needs):
   * discrete sites enumerated in the MODEL (``infer={"enumerate": "parallel"}`` or
     ``config_enumerate``) and absent from the guide are summed out exactly by plated
     sum-product message passing (pyro_amd/ops/contract.py);
-  * the guide is fully reparameterised and has no enumerated sites, so every DiCE weight is 1
-    and the surrogate equals the ELBO estimate (pyro/infer/util.py:264-326 reduces to a plain sum).
-Guide-side enumeration and score-function (non-reparameterised) guide sites raise
-NotImplementedError instead of silently producing a biased gradient.
+  * with a fully reparameterised guide every DiCE weight is 1 and the surrogate equals the ELBO
+    estimate (pyro/infer/util.py:264-326 reduces to a plain sum);
+  * score-function (non-reparameterised, non-enumerated) guide sites get their DiCE weights
+    exp(log q - stop_gradient(log q)) on every cost whose plate context contains the site's
+    (Dice.compute_expectation, pyro/infer/util.py:196-326, for sampled sites) -- as long as the
+    model has no enumerated factors in the same trace.
+Guide-side enumeration raises NotImplementedError instead of silently producing a biased gradient.
 """
 from collections import OrderedDict
 
@@ -82,19 +85,53 @@ class TraceEnum_ELBO(ELBO):
             if site["infer"].get("enumerate") or site["infer"].get("_enumerate_dim") is not None:
                 raise NotImplementedError("pyro_amd.TraceEnum_ELBO: guide-side enumeration "
                                           "(site '{}') is not built".format(name))
-            if not getattr(site["fn"], "has_rsample", False):
-                raise NotImplementedError(
-                    "pyro_amd.TraceEnum_ELBO: non-reparameterised guide site '{}' needs DiCE "
-                    "weights, which this plugin does not build".format(name))
         model_trace._first_enum_dim = first_enum_dim
         return model_trace, guide_trace
 
     # ---- reference: _compute_model_factors + contract + sum (all DiCE weights are 1) ----------
+    def _dice_elbo(self, model_trace, guide_trace, dice):
+        """sum over cost terms of cost * exp(sum of the DiCE log-factors of the score-function
+        guide sites whose plate context is contained in the cost's) -- value: the ELBO estimate,
+        gradient: pathwise + score-function terms (pyro/infer/util.py:264-326)."""
+        def weight(ordinal):
+            fs = [f for t, f in dice if t <= ordinal]
+            if not fs:
+                return None
+            total = fs[0]
+            for f in fs[1:]:
+                total = total + f
+            return total.exp()
+
+        elbo = 0.0
+        for trace, sign in ((model_trace, 1.0), (guide_trace, -1.0)):
+            for name, site in trace.nodes.items():
+                if site["type"] != "sample":
+                    continue
+                lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
+                cost = scale_and_mask(lp, site["scale"], site["mask"])
+                w = weight(_ordinal(site))
+                term = (cost * w).sum() if w is not None else cost.sum()
+                elbo = elbo + sign * term
+        return elbo
+
     def _elbo_tensor(self, model_trace, guide_trace):
         first_enum_dim = model_trace._first_enum_dim
         enum_names = [n for n, s in model_trace.nodes.items()
                       if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None
                       and n not in guide_trace.nodes]
+        dice = []
+        for name, site in guide_trace.nodes.items():
+            if site["type"] == "sample" and not getattr(site["fn"], "has_rsample", False):
+                lq = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
+                lq = scale_and_mask(lq, 1.0, site["mask"])     # masked, never scaled
+                if lq.requires_grad:
+                    dice.append((_ordinal(site), lq - lq.detach()))
+        if dice:
+            if enum_names:
+                raise NotImplementedError(
+                    "pyro_amd.TraceEnum_ELBO: score-function guide sites together with enumerated "
+                    "model sites need DiCE weights inside the contraction, which is not built")
+            return self._dice_elbo(model_trace, guide_trace, dice)
         enum_dims = {model_trace.nodes[n]["infer"]["_enumerate_dim"] for n in enum_names}
         plain, signs, const = [], [], 0.0
         factors = OrderedDict()

@@ -1,0 +1,42 @@
+"""The reference's own ELBO-gradient known-answer tests (tests/kat_cases.py) on the host logic:
+kernels answered by the numpy oracle (tests/oracle_backend.py)."""
+import pytest
+import torch
+
+from tests import kat_cases as kc
+
+CPU = torch.device("cpu")
+RSAMPLE = [(True, None), (True, False), (True, True), (False, None)]
+IDS = ["reparam", "reparam-False", "reparam-True", "nonreparam"]
+
+
+@pytest.fixture(autouse=True)
+def _backend(oracle_backend):
+    yield
+
+
+@pytest.mark.parametrize("reparameterized,has_rsample", RSAMPLE, ids=IDS)
+@pytest.mark.parametrize("elbo", ["Trace_ELBO", "TraceEnum_ELBO"])
+def test_particle_gradient(elbo, reparameterized, has_rsample):
+    kc.run_particle_gradient(CPU, elbo, reparameterized, has_rsample)
+
+
+@pytest.mark.parametrize("scale", [1.0, 2.0], ids=["unscaled", "scaled"])
+@pytest.mark.parametrize("reparameterized,has_rsample", [(True, None), (False, None)],
+                         ids=["reparam", "nonreparam"])
+@pytest.mark.parametrize("subsample", [False, True], ids=["full", "subsample"])
+@pytest.mark.parametrize("elbo", ["Trace_ELBO", "TraceMeanField_ELBO"])
+def test_subsample_gradient(elbo, reparameterized, has_rsample, subsample, scale):
+    try:
+        kc.run_subsample_gradient(CPU, elbo, reparameterized, has_rsample, subsample, scale)
+    except NotImplementedError as e:       # the reference test: `with xfail_if_not_implemented()`
+        pytest.xfail(str(e))
+
+
+@pytest.mark.parametrize("reparameterized", [True, False], ids=["reparam", "nonreparam"])
+def test_plate(reparameterized):
+    kc.run_plate(CPU, "Trace_ELBO", reparameterized, num_particles=100000)
+
+
+def test_plating_sums():
+    kc.run_plating_sums(CPU)
