@@ -8,11 +8,17 @@ Scope of this plugin (what BASELINE config 4, examples/lda.py, needs):
     sum-product message passing (pyro_amd/ops/contract.py);
   * with a fully reparameterised guide every DiCE weight is 1 and the surrogate equals the ELBO
     estimate (pyro/infer/util.py:264-326 reduces to a plain sum);
-  * score-function (non-reparameterised, non-enumerated) guide sites get their DiCE weights
-    exp(log q - stop_gradient(log q)) on every cost whose plate context contains the site's
-    (Dice.compute_expectation, pyro/infer/util.py:196-326, for sampled sites) -- as long as the
-    model has no enumerated factors in the same trace.
-Guide-side enumeration raises NotImplementedError instead of silently producing a biased gradient.
+  * guide sites enumerated in parallel (``config_enumerate(guide)``) and score-function
+    (non-reparameterised) sampled guide sites enter through their DiCE factors: every cost at
+    plate context o is weighted by exp(sum of the factors of the guide sites whose context is
+    contained in o) -- q itself for an enumerated site, exp(log q - stop_gradient(log q)) for a
+    sampled one -- and summed over plates and enumeration dims (Dice.compute_expectation,
+    pyro/infer/util.py:196-326; the reference contracts the same products with an einsum and
+    reads marginals back, here the broadcast product is formed directly: same value and gradient,
+    exponential in the number of jointly enumerated guide variables per cost);
+  * model enumeration must be no more global than guide enumeration (the reference's
+    _check_model_guide_enumeration_constraint, traceenum_elbo.py:50-65).
+Sequential enumeration raises NotImplementedError.
 """
 from collections import OrderedDict
 
@@ -71,47 +77,89 @@ class TraceEnum_ELBO(ELBO):
         if self.max_plate_nesting == float("inf"):
             self._guess_max_plate_nesting(model, guide, args, kwargs)
         first_enum_dim = -1 - self.max_plate_nesting
-        guide_trace = poutine.trace(guide).get_trace(*args, **kwargs)
-        model_enum = poutine.enum(model, first_available_dim=first_enum_dim)
+        # guide sites enumerate first; the model continues on the dims after them
+        # (traceenum_elbo.py:352-360: the two EnumMessengers share the global allocator)
+        guide_enum = poutine.enum(guide, first_available_dim=first_enum_dim)
+        guide_trace = poutine.trace(guide_enum).get_trace(*args, **kwargs)
+        model_enum = poutine.enum(model)
         model_trace = poutine.trace(poutine.replay(model_enum, trace=guide_trace)).get_trace(
             *args, **kwargs)
         if poutine.settings.validation_enabled():
             check_model_guide_match(model_trace, guide_trace, self.max_plate_nesting)
         guide_trace = prune_subsample_sites(guide_trace)
         model_trace = prune_subsample_sites(model_trace)
-        for name, site in guide_trace.nodes.items():
-            if site["type"] != "sample":
-                continue
-            if site["infer"].get("enumerate") or site["infer"].get("_enumerate_dim") is not None:
-                raise NotImplementedError("pyro_amd.TraceEnum_ELBO: guide-side enumeration "
-                                          "(site '{}') is not built".format(name))
         model_trace._first_enum_dim = first_enum_dim
         return model_trace, guide_trace
 
     # ---- reference: _compute_model_factors + contract + sum (all DiCE weights are 1) ----------
-    def _dice_elbo(self, model_trace, guide_trace, dice):
-        """sum over cost terms of cost * exp(sum of the DiCE log-factors of the score-function
-        guide sites whose plate context is contained in the cost's) -- value: the ELBO estimate,
-        gradient: pathwise + score-function terms (pyro/infer/util.py:264-326)."""
-        def weight(ordinal):
+    def _dice_elbo(self, model_trace, guide_trace, dice, enum_names, enum_dims):
+        """sum over cost terms of cost * exp(sum of the DiCE log-factors of the guide sites whose
+        plate context is contained in the cost's), summed over plates and enumeration dims --
+        value: the ELBO estimate, gradient: pathwise + score-function + exact-expectation terms
+        (pyro/infer/util.py:264-326, traceenum_elbo.py:112-214)."""
+        first_enum_dim = model_trace._first_enum_dim
+
+        def expectation(ordinal, cost):
             fs = [f for t, f in dice if t <= ordinal]
             if not fs:
-                return None
+                return cost.sum()
             total = fs[0]
             for f in fs[1:]:
                 total = total + f
-            return total.exp()
+            prob = total.exp()
+            # zero-probability branches contribute nothing even where the cost is infinite
+            cost = torch.where(prob > 0, cost, torch.zeros((), dtype=cost.dtype, device=cost.device))
+            return (prob * cost).sum()
 
+        costs = []
+        factors = OrderedDict()
+        scales = []
+        for name, site in model_trace.nodes.items():
+            if site["type"] != "sample":
+                continue
+            lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
+            o = _ordinal(site)
+            dims = (_enum_dims_of(lp, first_enum_dim) & enum_dims) if enum_dims else set()
+            if name in enum_names:
+                # the enumerated site's own factor is its UNmasked, unscaled log-probability
+                # (traceenum_elbo.py:168-174): summed over its support it is exactly 0
+                factors.setdefault(o, []).append(Term(lp, dims, o))
+                scales.append(site["scale"])
+            elif dims:
+                # mask inside, scale outside the log-expectation (traceenum_elbo.py:158-167)
+                factors.setdefault(o, []).append(Term(scale_and_mask(lp, mask=site["mask"]), dims, o))
+                scales.append(site["scale"])
+            else:
+                costs.append((o, scale_and_mask(lp, site["scale"], site["mask"])))
+        if factors:
+            min_ordinal = frozenset.intersection(*factors.keys())
+            for name, site in guide_trace.nodes.items():
+                if site["type"] == "sample" and site["infer"].get("_enumerate_dim") is not None:
+                    for f in site["cond_indep_stack"]:
+                        if f.vectorized and f not in min_ordinal:
+                            raise ValueError(
+                                "Expected model enumeration to be no more global than guide "
+                                "enumeration, but found model enumeration sites upstream of guide "
+                                "site '{}' in plate('{}'). Try converting some model enumeration "
+                                "sites to guide enumeration sites.".format(name, f.name))
+            scale = scales[0]
+            for sc in scales[1:]:
+                if sc != scale:
+                    raise ValueError("Expected all enumerated sample sites to share a common "
+                                     "poutine.scale, but found different scales")
+            for ordinal, terms in contract_tensor_tree(factors, enum_dims).items():
+                for term in terms:
+                    t = term.tensor
+                    costs.append((ordinal, t * scale if not isinstance(scale, float) or scale != 1.0
+                                  else t))
+        for name, site in guide_trace.nodes.items():
+            if site["type"] != "sample":
+                continue
+            lq = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
+            costs.append((_ordinal(site), -scale_and_mask(lq, site["scale"], site["mask"])))
         elbo = 0.0
-        for trace, sign in ((model_trace, 1.0), (guide_trace, -1.0)):
-            for name, site in trace.nodes.items():
-                if site["type"] != "sample":
-                    continue
-                lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
-                cost = scale_and_mask(lp, site["scale"], site["mask"])
-                w = weight(_ordinal(site))
-                term = (cost * w).sum() if w is not None else cost.sum()
-                elbo = elbo + sign * term
+        for o, c in costs:
+            elbo = elbo + expectation(o, c)
         return elbo
 
     def _elbo_tensor(self, model_trace, guide_trace):
@@ -119,20 +167,21 @@ class TraceEnum_ELBO(ELBO):
         enum_names = [n for n, s in model_trace.nodes.items()
                       if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None
                       and n not in guide_trace.nodes]
+        enum_dims = {model_trace.nodes[n]["infer"]["_enumerate_dim"] for n in enum_names}
         dice = []
         for name, site in guide_trace.nodes.items():
-            if site["type"] == "sample" and not getattr(site["fn"], "has_rsample", False):
+            if site["type"] != "sample":
+                continue
+            enumerated = site["infer"].get("_enumerate_dim") is not None
+            if enumerated or not getattr(site["fn"], "has_rsample", False):
                 lq = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
                 lq = scale_and_mask(lq, 1.0, site["mask"])     # masked, never scaled
-                if lq.requires_grad:
+                if enumerated:
+                    dice.append((_ordinal(site), lq))
+                elif lq.requires_grad:
                     dice.append((_ordinal(site), lq - lq.detach()))
         if dice:
-            if enum_names:
-                raise NotImplementedError(
-                    "pyro_amd.TraceEnum_ELBO: score-function guide sites together with enumerated "
-                    "model sites need DiCE weights inside the contraction, which is not built")
-            return self._dice_elbo(model_trace, guide_trace, dice)
-        enum_dims = {model_trace.nodes[n]["infer"]["_enumerate_dim"] for n in enum_names}
+            return self._dice_elbo(model_trace, guide_trace, dice, enum_names, enum_dims)
         plain, signs, const = [], [], 0.0
         factors = OrderedDict()
         scales = []
@@ -140,8 +189,9 @@ class TraceEnum_ELBO(ELBO):
             if site["type"] != "sample":
                 continue
             if name in enum_names:
+                # unmasked, unscaled (traceenum_elbo.py:168-174): a masked-out plate slice of an
+                # enumerated variable must still sum to probability one
                 lp = site["fn"].log_prob(site["value"])
-                lp = scale_and_mask(lp, mask=site["mask"])
                 factors.setdefault(_ordinal(site), []).append(
                     Term(lp, _enum_dims_of(lp, first_enum_dim) & enum_dims, _ordinal(site)))
                 scales.append(site["scale"])

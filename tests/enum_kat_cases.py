@@ -1,0 +1,245 @@
+"""TraceEnum_ELBO known-answer tests of the reference (tests/infer/test_enum.py:1795-2632:
+test_elbo_enumerate_1..3, _plate_1..3, _plates_1..2), restated compactly against the drop-in API.
+Each case builds an "auto" model that relies on plated parallel enumeration and a "hand" model
+in which the same quantity is written out (closed-form marginal, or sequential plates), and
+requires equal loss and equal gradients w.r.t. every parameter -- _check_loss_and_grads of the
+reference.  The guide enumerates its discrete site (config_enumerate), so the DiCE expectation
+over guide enumeration is part of every case that has a guide."""
+import torch
+from torch.autograd import grad
+
+import pyro_amd as pyro
+import pyro_amd.distributions as dist
+import pyro_amd.poutine as poutine
+from pyro_amd.distributions import constraints
+from pyro_amd.infer import TraceEnum_ELBO, config_enumerate
+
+
+def _check_loss_and_grads(expected_loss, actual_loss):
+    torch.testing.assert_close(actual_loss, expected_loss, rtol=1e-5, atol=1e-6)
+    names = sorted(pyro.get_param_store().keys())
+    params = [pyro.param(name).unconstrained() for name in names]
+    actual = grad(actual_loss, params, allow_unused=True, retain_graph=True)
+    expected = grad(expected_loss, params, allow_unused=True, retain_graph=True)
+    for name, a, e in zip(names, actual, expected):
+        if a is None or e is None:
+            continue
+        torch.testing.assert_close(a, e, rtol=1e-4, atol=1e-6, msg=lambda m, n=name: n + ": " + m)
+
+
+def _xyz_params(device, z_depends_on_y=True):
+    def t(v):
+        return torch.tensor(v, device=device)
+    pyro.clear_param_store()
+    pyro.param("guide_probs_x", t([0.1, 0.9]), constraint=constraints.simplex)
+    pyro.param("model_probs_x", t([0.4, 0.6]), constraint=constraints.simplex)
+    pyro.param("model_probs_y", t([[0.75, 0.25], [0.55, 0.45]]), constraint=constraints.simplex)
+    pyro.param("model_probs_z", t([[0.3, 0.7], [0.2, 0.8]]) if z_depends_on_y else t([0.3, 0.7]),
+               constraint=constraints.simplex)
+
+
+PAR = {"enumerate": "parallel"}
+
+
+def run_enumerate_chain(device, variant, scale):
+    """x -> y -> z without plates (test_elbo_enumerate_1..3): y enumerated in the model and summed
+    out; the hand model carries the closed-form marginal probs_y @ probs_z."""
+    _xyz_params(device, z_depends_on_y=variant != 1)
+    zero = torch.tensor(0, device=device)
+
+    def auto_model():
+        px, py, pz = (pyro.param("model_probs_" + k) for k in "xyz")
+        x = pyro.sample("x", dist.Categorical(px))
+        with poutine.scale(scale=scale if variant == 3 else 1.0):
+            y = pyro.sample("y", dist.Categorical(py[x]), infer=PAR)
+            pyro.sample("z", dist.Categorical(pz[y] if variant != 1 else pz), obs=zero)
+
+    def hand_model():
+        px, py, pz = (pyro.param("model_probs_" + k) for k in "xyz")
+        x = pyro.sample("x", dist.Categorical(px))
+        with poutine.scale(scale=scale if variant == 3 else 1.0):
+            pyro.sample("z", dist.Categorical(py.mm(pz)[x] if variant != 1 else pz), obs=zero)
+
+    def guide():
+        pyro.sample("x", dist.Categorical(pyro.param("guide_probs_x")))
+
+    guide = config_enumerate(guide)
+    if variant != 3:           # the whole program scaled (models and guide alike)
+        auto_model, hand_model, guide = (poutine.scale(f, scale=scale)
+                                         for f in (auto_model, hand_model, guide))
+    elbo = TraceEnum_ELBO(max_plate_nesting=0, strict_enumeration_warning=False)
+    _check_loss_and_grads(elbo.differentiable_loss(hand_model, guide),
+                          elbo.differentiable_loss(auto_model, guide))
+
+
+def run_enumerate_plate(device, variant, num_samples, num_masked, scale):
+    """x -> y -> z with a data plate around z only (1), around y and z (2), around everything (3)
+    (test_elbo_enumerate_plate_1..3), optionally masked; hand model: a sequential plate over the
+    unmasked indices."""
+    _xyz_params(device)
+    g = torch.Generator().manual_seed(num_samples)
+    data = torch.multinomial(torch.tensor([0.3, 0.7]), num_samples, replacement=True,
+                             generator=g).to(device)
+    masked = num_masked != num_samples
+    mask = torch.arange(num_samples, device=device) < num_masked
+
+    def maybe_mask():
+        return poutine.mask(mask=mask) if masked else poutine.scale(scale=1.0)
+
+    def auto_model(data):
+        px, py, pz = (pyro.param("model_probs_" + k) for k in "xyz")
+        if variant == 3:
+            with pyro.plate("data", len(data)), maybe_mask():
+                x = pyro.sample("x", dist.Categorical(px))
+                y = pyro.sample("y", dist.Categorical(py[x]), infer=PAR)
+                pyro.sample("z", dist.Categorical(pz[y]), obs=data)
+            return
+        x = pyro.sample("x", dist.Categorical(px))
+        with poutine.scale(scale=scale):
+            if variant == 1:
+                y = pyro.sample("y", dist.Categorical(py[x]), infer=PAR)
+                with pyro.plate("data", len(data)), maybe_mask():
+                    pyro.sample("z", dist.Categorical(pz[y]), obs=data)
+            else:
+                with pyro.plate("data", len(data)), maybe_mask():
+                    y = pyro.sample("y", dist.Categorical(py[x]), infer=PAR)
+                    pyro.sample("z", dist.Categorical(pz[y]), obs=data)
+
+    def hand_model(data):
+        px, py, pz = (pyro.param("model_probs_" + k) for k in "xyz")
+        if variant == 3:
+            for i in pyro.plate("data", num_masked):
+                x = pyro.sample("x_{}".format(i), dist.Categorical(px))
+                y = pyro.sample("y_{}".format(i), dist.Categorical(py[x]), infer=PAR)
+                pyro.sample("z_{}".format(i), dist.Categorical(pz[y]), obs=data[i])
+            return
+        x = pyro.sample("x", dist.Categorical(px))
+        with poutine.scale(scale=scale):
+            if variant == 1:
+                y = pyro.sample("y", dist.Categorical(py[x]), infer=PAR)
+            for i in pyro.plate("data", num_masked):
+                if variant == 2:
+                    y = pyro.sample("y_{}".format(i), dist.Categorical(py[x]), infer=PAR)
+                pyro.sample("z_{}".format(i), dist.Categorical(pz[y]), obs=data[i])
+
+    def auto_guide(data):
+        pq = pyro.param("guide_probs_x")
+        if variant == 3:
+            with pyro.plate("data", len(data)), maybe_mask():
+                pyro.sample("x", dist.Categorical(pq))
+        else:
+            pyro.sample("x", dist.Categorical(pq))
+
+    def hand_guide(data):
+        pq = pyro.param("guide_probs_x")
+        if variant == 3:
+            for i in pyro.plate("data", num_masked):
+                pyro.sample("x_{}".format(i), dist.Categorical(pq))
+        else:
+            pyro.sample("x", dist.Categorical(pq))
+
+    auto_guide, hand_guide = config_enumerate(auto_guide), config_enumerate(hand_guide)
+    if variant == 3:
+        auto_model, hand_model, auto_guide, hand_guide = (
+            poutine.scale(f, scale=scale) for f in (auto_model, hand_model, auto_guide, hand_guide))
+    auto = TraceEnum_ELBO(max_plate_nesting=1, strict_enumeration_warning=False)
+    hand = TraceEnum_ELBO(max_plate_nesting=1 if variant != 1 else 0,
+                          strict_enumeration_warning=False)
+    _check_loss_and_grads(hand.differentiable_loss(hand_model, hand_guide, data),
+                          auto.differentiable_loss(auto_model, auto_guide, data))
+
+
+def run_enumerate_plates(device, variant, scale):
+    """Two plates: unrelated (1: a->b in M, c->d in N) or sharing an enumerated parent
+    (2: b <- a -> c), everything enumerated in the model, empty guide
+    (test_elbo_enumerate_plates_1..2)."""
+    def t(v):
+        return torch.tensor(v, device=device)
+    pyro.clear_param_store()
+    pyro.param("probs_a", t([0.45, 0.55]), constraint=constraints.simplex)
+    pyro.param("probs_b", t([[0.6, 0.4], [0.4, 0.6]]), constraint=constraints.simplex)
+    if variant == 1:
+        pyro.param("probs_c", t([0.75, 0.25]), constraint=constraints.simplex)
+        pyro.param("probs_d", t([[0.4, 0.6], [0.3, 0.7]]), constraint=constraints.simplex)
+    else:
+        pyro.param("probs_c", t([[0.75, 0.25], [0.55, 0.45]]), constraint=constraints.simplex)
+    b_data, cd_data = t([0, 1]), t([0, 0, 1])
+
+    def auto_model():
+        pa, pb, pc = (pyro.param("probs_" + k) for k in "abc")
+        if variant == 1:
+            pd = pyro.param("probs_d")
+            with pyro.plate("a_axis", 2):
+                a = pyro.sample("a", dist.Categorical(pa))
+                pyro.sample("b", dist.Categorical(pb[a]), obs=b_data)
+            with pyro.plate("c_axis", 3):
+                c = pyro.sample("c", dist.Categorical(pc))
+                pyro.sample("d", dist.Categorical(pd[c]), obs=cd_data)
+        else:
+            a = pyro.sample("a", dist.Categorical(pa))
+            with pyro.plate("b_axis", 2):
+                pyro.sample("b", dist.Categorical(pb[a]), obs=b_data)
+            with pyro.plate("c_axis", 3):
+                pyro.sample("c", dist.Categorical(pc[a]), obs=cd_data)
+
+    def hand_model():
+        pa, pb, pc = (pyro.param("probs_" + k) for k in "abc")
+        if variant == 1:
+            pd = pyro.param("probs_d")
+            for i in pyro.plate("a_axis", 2):
+                a = pyro.sample("a_{}".format(i), dist.Categorical(pa))
+                pyro.sample("b_{}".format(i), dist.Categorical(pb[a]), obs=b_data[i])
+            for j in pyro.plate("c_axis", 3):
+                c = pyro.sample("c_{}".format(j), dist.Categorical(pc))
+                pyro.sample("d_{}".format(j), dist.Categorical(pd[c]), obs=cd_data[j])
+        else:
+            a = pyro.sample("a", dist.Categorical(pa))
+            for i in pyro.plate("b_axis", 2):
+                pyro.sample("b_{}".format(i), dist.Categorical(pb[a]), obs=b_data[i])
+            for j in pyro.plate("c_axis", 3):
+                pyro.sample("c_{}".format(j), dist.Categorical(pc[a]), obs=cd_data[j])
+
+    def guide():
+        pass
+
+    auto_model = config_enumerate(poutine.scale(auto_model, scale=scale))
+    hand_model = config_enumerate(poutine.scale(hand_model, scale=scale))
+    auto_loss = TraceEnum_ELBO(max_plate_nesting=1).differentiable_loss(auto_model, guide)
+    hand_loss = TraceEnum_ELBO(max_plate_nesting=0).differentiable_loss(hand_model, guide)
+    _check_loss_and_grads(hand_loss, auto_loss)
+
+
+def run_guide_enumeration_closed_form(device):
+    """Guide-side enumeration gives the EXACT expectation: for a discrete latent with an observed
+    child the ELBO equals sum_x q(x) [log p(x) + log p(obs | x) - log q(x)] (the KL-type closed
+    forms of tests/infer/test_enum.py:341-395), with zero variance across seeds."""
+    def t(v):
+        return torch.tensor(v, device=device)
+    pyro.clear_param_store()
+    q = pyro.param("q", t([0.2, 0.5, 0.3]), constraint=constraints.simplex)
+    p = t([0.5, 0.25, 0.25])
+    lik = t([[0.9, 0.1], [0.4, 0.6], [0.2, 0.8]])
+
+    def model():
+        x = pyro.sample("x", dist.Categorical(p))
+        with pyro.plate("d", 3):
+            pyro.sample("obs", dist.Categorical(lik[x]), obs=t([1, 0, 1]))
+
+    @config_enumerate
+    def guide():
+        pyro.sample("x", dist.Categorical(pyro.param("q")))
+
+    elbo = TraceEnum_ELBO(max_plate_nesting=1)
+    losses = []
+    for seed in (0, 1):
+        pyro.set_rng_seed(seed)
+        losses.append(elbo.differentiable_loss(model, guide))
+    assert torch.equal(losses[0].detach(), losses[1].detach())
+    qq = pyro.param("q")
+    ll = lik[:, 1].log() * 2 + lik[:, 0].log()
+    expected = -(qq * (p.log() + ll - qq.log())).sum()
+    torch.testing.assert_close(losses[0], expected, rtol=1e-5, atol=1e-6)
+    u = pyro.param("q").unconstrained()
+    ga, = grad(losses[0], [u], retain_graph=True)
+    ge, = grad(expected, [u])
+    torch.testing.assert_close(ga, ge, rtol=1e-4, atol=1e-6)

@@ -76,3 +76,31 @@ def test_lda_svi_improves(gpu):
     losses = [svi.step(data, args) for _ in range(30)]
     assert np.isfinite(losses).all()
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+# ---- the reference's hand-vs-auto enumeration KATs (tests/enum_kat_cases.py) on the device -------
+from tests import enum_kat_cases as ekc   # noqa: E402
+
+
+@pytest.mark.parametrize("scale", [1, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_elbo_enumerate_chain(gpu, variant, scale):
+    ekc.run_enumerate_chain(gpu, variant, scale)
+
+
+@pytest.mark.parametrize("scale", [1, 10])
+@pytest.mark.parametrize("num_samples,num_masked", [(1, 1), (2, 2), (3, 2)],
+                         ids=["single", "batch", "masked"])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_elbo_enumerate_plate(gpu, variant, num_samples, num_masked, scale):
+    ekc.run_enumerate_plate(gpu, variant, num_samples, num_masked, scale)
+
+
+@pytest.mark.parametrize("scale", [1, 10])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_elbo_enumerate_plates(gpu, variant, scale):
+    ekc.run_enumerate_plates(gpu, variant, scale)
+
+
+def test_guide_enumeration_is_the_exact_expectation(gpu):
+    ekc.run_guide_enumeration_closed_form(gpu)

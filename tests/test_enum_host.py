@@ -46,16 +46,46 @@ def test_lda_fused_route_with_oracle_kernel(_cpu_backend, monkeypatch):
     ec.run_lda(load("enum"), torch.device("cpu"), monkeypatch, expect_fused=True)
 
 
-def test_unsupported_guides_raise(_cpu_backend):
+def test_sequential_enumeration_raises(_cpu_backend):
     import pyro_amd as pyro
     import pyro_amd.distributions as dist
     from pyro_amd.infer import TraceEnum_ELBO
 
     def model():
-        pyro.sample("z", dist.Categorical(torch.ones(3) / 3), infer={"enumerate": "parallel"})
+        pyro.sample("z", dist.Categorical(torch.ones(3) / 3))
 
     def guide():
-        pyro.sample("z", dist.Categorical(torch.ones(3) / 3))
+        pyro.sample("z", dist.Categorical(torch.ones(3) / 3), infer={"enumerate": "sequential"})
 
     with pytest.raises(NotImplementedError):
         TraceEnum_ELBO(max_plate_nesting=0).loss_and_grads(model, guide)
+
+
+# ---- the reference's hand-vs-auto enumeration KATs (tests/enum_kat_cases.py) ---------------------
+from tests import enum_kat_cases as ekc   # noqa: E402
+
+CPU = torch.device("cpu")
+
+
+@pytest.mark.parametrize("scale", [1, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_elbo_enumerate_chain(_cpu_backend, variant, scale):
+    ekc.run_enumerate_chain(CPU, variant, scale)
+
+
+@pytest.mark.parametrize("scale", [1, 10])
+@pytest.mark.parametrize("num_samples,num_masked", [(1, 1), (2, 2), (3, 2)],
+                         ids=["single", "batch", "masked"])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_elbo_enumerate_plate(_cpu_backend, variant, num_samples, num_masked, scale):
+    ekc.run_enumerate_plate(CPU, variant, num_samples, num_masked, scale)
+
+
+@pytest.mark.parametrize("scale", [1, 10])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_elbo_enumerate_plates(_cpu_backend, variant, scale):
+    ekc.run_enumerate_plates(CPU, variant, scale)
+
+
+def test_guide_enumeration_is_the_exact_expectation(_cpu_backend):
+    ekc.run_guide_enumeration_closed_form(CPU)
