@@ -262,6 +262,56 @@ def run_dense_mass_adaptation(device, dtype, C=4, D=5, warmup=150, S=150, check=
     return out
 
 
+def run_structured_mass(device, dtype=torch.float32, warmup=1000, C=4):
+    """tests/infer/mcmc/test_nuts.py:465-503 test_structured_mass: full_mass False / True give a
+    diagonal / dense inverse mass over all sites; full_mass=[("w",), ("x", "y")] adapts two dense
+    blocks and a diagonal rest, each approaching the corresponding block of the target covariance
+    (atol = rtol = 0.5 as in the reference).  Chains are vectorised here, so the sites are
+    concatenated along the last dim."""
+    def t(v):
+        return torch.tensor(v, dtype=dtype, device=device)
+
+    def model(cov):
+        def wide(n):
+            return dist.Normal(torch.zeros(n, dtype=dtype, device=device), 1000.0).to_event(1)
+        w = pyro.sample("w", wide(2))
+        x = pyro.sample("x", wide(1))
+        y = pyro.sample("y", wide(1))
+        z = pyro.sample("z", wide(1))
+        wxyz = torch.cat([w, x, y, z], dim=-1)
+        pyro.sample("obs", dist.MultivariateNormal(torch.zeros(5, dtype=dtype, device=device), cov),
+                    obs=wxyz)
+
+    w_cov, xy_cov, z_var = t([[1.5, 0.5], [0.5, 1.5]]), t([[2.0, 1.0], [1.0, 3.0]]), t([2.5])
+    cov = torch.zeros(5, 5, dtype=dtype, device=device)
+    cov[:2, :2], cov[2:4, 2:4], cov[4, 4] = w_cov, xy_cov, z_var[0]
+    for dense_mass in (True, False):                                      # smoke tests
+        pyro.set_rng_seed(0)
+        kernel = NUTS(model, full_mass=dense_mass, max_tree_depth=4)
+        MCMC(kernel, num_samples=1, warmup_steps=1, num_chains=2).run(cov)
+        assert kernel.inverse_mass_matrix.dim() == 2 + int(dense_mass)    # leading chain dim
+    pyro.set_rng_seed(1)
+    kernel = NUTS(model, full_mass=[("w",), ("x", "y")], max_tree_depth=6)
+    mcmc = MCMC(kernel, num_samples=1, warmup_steps=warmup, num_chains=C)
+    mcmc.run(cov)
+    V = kernel.inverse_mass_matrix                                         # [C, 5, 5]
+    sl = kernel._layout.slices
+    assert list(kernel._layout.names) == ["w", "x", "y", "z"]
+    w0, w1 = sl["w"]
+    x0, y1 = sl["x"][0], sl["y"][1]
+    z0 = sl["z"][0]
+    for c in range(C):
+        torch.testing.assert_close(V[c, w0:w1, w0:w1], w_cov, atol=0.5, rtol=0.5)
+        torch.testing.assert_close(V[c, x0:y1, x0:y1], xy_cov, atol=0.5, rtol=0.5)
+        torch.testing.assert_close(V[c, z0, z0].reshape(1), z_var, atol=0.5, rtol=0.5)
+        # the structure: nothing outside the two dense blocks and the diagonal
+        off = V[c].clone()
+        off[w0:w1, w0:w1] = 0
+        off[x0:y1, x0:y1] = 0
+        off[z0, z0] = 0
+        assert float(off.abs().max()) == 0.0
+
+
 def logreg_mcmc_model(X, y):
     D = X.shape[1]
     w = pyro.sample("w", dist.Normal(torch.zeros(D, dtype=X.dtype, device=X.device),

