@@ -26,7 +26,7 @@ import torch
 
 from .. import poutine
 from ..distributions.util import scale_and_mask
-from ..ops.contract import LazyGather, Term, contract_tensor_tree
+from ..ops.contract import LazyGather, Term, align, contract_tensor_tree, pack
 from ..poutine.util import prune_subsample_sites
 from ..util import torch_item, warn_if_nan
 from .elbo import ELBO
@@ -42,6 +42,11 @@ def _enum_dims_of(tensor, first_enum_dim):
     """Tensor dims strictly left of the plate block with size > 1 (negative indices)."""
     n = tensor.dim()
     return {d - n for d in range(n) if d - n <= first_enum_dim and tensor.shape[d] > 1}
+
+
+def _packed(site, lp, first_enum_dim):
+    """The site's log-probability tensor as a packed, id-named Term."""
+    return pack(lp, site["infer"].get("_dim_to_id", {}), -1 - first_enum_dim, _ordinal(site))
 
 
 def _lazy_gather(site, first_enum_dim):
@@ -60,7 +65,7 @@ def _lazy_gather(site, first_enum_dim):
     if len(nz) != 1 or logits.stride(-2) != 0 or logits.stride(-3) != 0:
         return None
     edim = nz[0] - len(lead) - 2          # tensor dim of the enumerated variable in the factor
-    if edim > first_enum_dim:
+    if edim > first_enum_dim or edim not in site["infer"].get("_dim_to_id", {}):
         return None
     T, V = lead[nz[0]], logits.shape[-1]
     base = getattr(fn, "_base_logits", None)
@@ -69,7 +74,7 @@ def _lazy_gather(site, first_enum_dim):
     else:
         idx = (0,) * nz[0] + (slice(None),) + (0,) * (len(lead) - nz[0] - 1) + (0, 0, slice(None))
         table = logits[idx].reshape(T, V)  # [T, V] view of the un-expanded log-probabilities
-    return LazyGather(table, value, edim)
+    return site["infer"]["_dim_to_id"][edim], LazyGather(table, value)
 
 
 class TraceEnum_ELBO(ELBO):
@@ -92,24 +97,27 @@ class TraceEnum_ELBO(ELBO):
         return model_trace, guide_trace
 
     # ---- reference: _compute_model_factors + contract + sum (all DiCE weights are 1) ----------
-    def _dice_elbo(self, model_trace, guide_trace, dice, enum_names, enum_dims):
+    def _dice_elbo(self, model_trace, guide_trace, dice, enum_names, enum_ids):
         """sum over cost terms of cost * exp(sum of the DiCE log-factors of the guide sites whose
-        plate context is contained in the cost's), summed over plates and enumeration dims --
+        plate context is contained in the cost's), summed over plates and enumerated names --
         value: the ELBO estimate, gradient: pathwise + score-function + exact-expectation terms
-        (pyro/infer/util.py:264-326, traceenum_elbo.py:112-214)."""
+        (pyro/infer/util.py:264-326, traceenum_elbo.py:112-214).  All tensors are packed Terms."""
         first_enum_dim = model_trace._first_enum_dim
 
-        def expectation(ordinal, cost):
-            fs = [f for t, f in dice if t <= ordinal]
+        def expectation(cost):
+            fs = [f for f in dice if f.ordinal <= cost.ordinal]
             if not fs:
-                return cost.sum()
-            total = fs[0]
-            for f in fs[1:]:
-                total = total + f
+                return cost.tensor.sum()
+            ids = sorted(set(cost.ids).union(*(f.ids for f in fs)))
+            total = None
+            for f in fs:
+                x = align(f, ids)
+                total = x if total is None else total + x
             prob = total.exp()
+            c = align(cost, ids)
             # zero-probability branches contribute nothing even where the cost is infinite
-            cost = torch.where(prob > 0, cost, torch.zeros((), dtype=cost.dtype, device=cost.device))
-            return (prob * cost).sum()
+            c = torch.where(prob > 0, c, torch.zeros((), dtype=c.dtype, device=c.device))
+            return (prob * c).sum()
 
         costs = []
         factors = OrderedDict()
@@ -118,19 +126,21 @@ class TraceEnum_ELBO(ELBO):
             if site["type"] != "sample":
                 continue
             lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
-            o = _ordinal(site)
-            dims = (_enum_dims_of(lp, first_enum_dim) & enum_dims) if enum_dims else set()
             if name in enum_names:
                 # the enumerated site's own factor is its UNmasked, unscaled log-probability
                 # (traceenum_elbo.py:168-174): summed over its support it is exactly 0
-                factors.setdefault(o, []).append(Term(lp, dims, o))
+                term = _packed(site, lp, first_enum_dim)
+                factors.setdefault(term.ordinal, []).append(term)
                 scales.append(site["scale"])
-            elif dims:
+                continue
+            term = _packed(site, scale_and_mask(lp, mask=site["mask"]), first_enum_dim)
+            if term.dims & enum_ids:
                 # mask inside, scale outside the log-expectation (traceenum_elbo.py:158-167)
-                factors.setdefault(o, []).append(Term(scale_and_mask(lp, mask=site["mask"]), dims, o))
+                factors.setdefault(term.ordinal, []).append(term)
                 scales.append(site["scale"])
             else:
-                costs.append((o, scale_and_mask(lp, site["scale"], site["mask"])))
+                term.tensor = scale_and_mask(term.tensor, site["scale"], None)
+                costs.append(term)
         if factors:
             min_ordinal = frozenset.intersection(*factors.keys())
             for name, site in guide_trace.nodes.items():
@@ -147,19 +157,20 @@ class TraceEnum_ELBO(ELBO):
                 if sc != scale:
                     raise ValueError("Expected all enumerated sample sites to share a common "
                                      "poutine.scale, but found different scales")
-            for ordinal, terms in contract_tensor_tree(factors, enum_dims).items():
+            for ordinal, terms in contract_tensor_tree(factors, enum_ids).items():
                 for term in terms:
-                    t = term.tensor
-                    costs.append((ordinal, t * scale if not isinstance(scale, float) or scale != 1.0
-                                  else t))
+                    if not isinstance(scale, float) or scale != 1.0:
+                        term.tensor = term.tensor * scale
+                    costs.append(term)
         for name, site in guide_trace.nodes.items():
             if site["type"] != "sample":
                 continue
             lq = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
-            costs.append((_ordinal(site), -scale_and_mask(lq, site["scale"], site["mask"])))
+            costs.append(_packed(site, -scale_and_mask(lq, site["scale"], site["mask"]),
+                                 first_enum_dim))
         elbo = 0.0
-        for o, c in costs:
-            elbo = elbo + expectation(o, c)
+        for c in costs:
+            elbo = elbo + expectation(c)
         return elbo
 
     def _elbo_tensor(self, model_trace, guide_trace):
@@ -167,7 +178,8 @@ class TraceEnum_ELBO(ELBO):
         enum_names = [n for n, s in model_trace.nodes.items()
                       if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None
                       and n not in guide_trace.nodes]
-        enum_dims = {model_trace.nodes[n]["infer"]["_enumerate_dim"] for n in enum_names}
+        enum_ids = {model_trace.nodes[n]["infer"]["_dim_to_id"][
+            model_trace.nodes[n]["infer"]["_enumerate_dim"]] for n in enum_names}
         dice = []
         for name, site in guide_trace.nodes.items():
             if site["type"] != "sample":
@@ -177,11 +189,11 @@ class TraceEnum_ELBO(ELBO):
                 lq = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
                 lq = scale_and_mask(lq, 1.0, site["mask"])     # masked, never scaled
                 if enumerated:
-                    dice.append((_ordinal(site), lq))
+                    dice.append(_packed(site, lq, first_enum_dim))
                 elif lq.requires_grad:
-                    dice.append((_ordinal(site), lq - lq.detach()))
+                    dice.append(_packed(site, lq - lq.detach(), first_enum_dim))
         if dice:
-            return self._dice_elbo(model_trace, guide_trace, dice, enum_names, enum_dims)
+            return self._dice_elbo(model_trace, guide_trace, dice, enum_names, enum_ids)
         plain, signs, const = [], [], 0.0
         factors = OrderedDict()
         scales = []
@@ -192,17 +204,17 @@ class TraceEnum_ELBO(ELBO):
                 # unmasked, unscaled (traceenum_elbo.py:168-174): a masked-out plate slice of an
                 # enumerated variable must still sum to probability one
                 lp = site["fn"].log_prob(site["value"])
-                factors.setdefault(_ordinal(site), []).append(
-                    Term(lp, _enum_dims_of(lp, first_enum_dim) & enum_dims, _ordinal(site)))
+                term = _packed(site, lp, first_enum_dim)
+                factors.setdefault(term.ordinal, []).append(term)
                 scales.append(site["scale"])
                 continue
-            lazy = _lazy_gather(site, first_enum_dim) if enum_dims else None
-            if lazy is not None and lazy.enum_dim in enum_dims:
+            lazy = _lazy_gather(site, first_enum_dim) if enum_ids else None
+            if lazy is not None and lazy[0] in enum_ids:
                 factors.setdefault(_ordinal(site), []).append(
-                    Term(None, {lazy.enum_dim}, _ordinal(site), lazy=lazy))
+                    Term(None, (lazy[0],), _ordinal(site), lazy=lazy[1]))
                 scales.append(site["scale"])
                 continue
-            if not enum_dims or not self._depends_on_enum(site, first_enum_dim):
+            if not enum_ids or not self._depends_on_enum(site, first_enum_dim):
                 fused = model_trace._site_sum(name, site)     # one-kernel plate sum
                 if isinstance(fused, torch.Tensor):
                     plain.append(fused)
@@ -211,10 +223,9 @@ class TraceEnum_ELBO(ELBO):
                     const += fused
                 continue
             lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
-            dims = _enum_dims_of(lp, first_enum_dim) & enum_dims
-            if dims:
-                lp = scale_and_mask(lp, mask=site["mask"])      # mask inside, scale outside
-                factors.setdefault(_ordinal(site), []).append(Term(lp, dims, _ordinal(site)))
+            term = _packed(site, scale_and_mask(lp, mask=site["mask"]), first_enum_dim)
+            if term.dims & enum_ids:          # mask inside, scale outside the log-expectation
+                factors.setdefault(term.ordinal, []).append(term)
                 scales.append(site["scale"])
             else:
                 plain.append(scale_and_mask(lp, site["scale"], site["mask"]).sum())
@@ -225,7 +236,7 @@ class TraceEnum_ELBO(ELBO):
                 if s != scale:
                     raise ValueError("Expected all enumerated sample sites to share a common "
                                      "poutine.scale, but found different scales")
-            for ordinal, terms in contract_tensor_tree(factors, enum_dims, reduce_all=True).items():
+            for ordinal, terms in contract_tensor_tree(factors, enum_ids, reduce_all=True).items():
                 for term in terms:
                     t = term.tensor.sum()
                     plain.append(t * scale if not isinstance(scale, float) or scale != 1.0 else t)

@@ -1,16 +1,21 @@
 """Plated sum-product in log space: marginalise enumerated discrete variables out of a set of
 log-factors that live in (tree-structured) plate contexts
 (reference: pyro/ops/contract.py:44-202 _partition_terms / _contract_component /
-contract_tensor_tree, with LogRing of pyro/ops/rings.py:178-216 and the log-space pairwise
-einsum of pyro/ops/einsum/torch_log.py:14-55).
+contract_tensor_tree, with LogRing of pyro/ops/rings.py:178-216, the log-space pairwise einsum of
+pyro/ops/einsum/torch_log.py:14-55, and the packed, symbol-named tensors of
+pyro/poutine/trace_struct.py:398-473 + pyro/ops/packed.py).
 
-Differences in representation, not in algebra: factors stay UNPACKED (right-aligned tensor dims:
-plates at -1..-max_plate_nesting, one fresh dim per enumerated variable to their left), so no
-opt_einsum-style symbol table or contraction-path search is needed: a sum-contraction is a
-broadcast add + logsumexp over the enumerated dims, a plate product is a sum over the plate dims.
-The LDA-shaped leaf (a factor constant along the inner plate + an observed Categorical whose
-logits are gathered by the enumerated value) is contracted by ONE fused HIP kernel
-(pa_lda_factor_fwd_bwd) that never materialises the [T, words, docs] tensor.
+Representation: a factor is PACKED -- its leading dims are exactly the enumerated variables it
+depends on, named by the variables' unique ids (``Term.ids``), followed by a right-aligned block of
+``nplates`` plate dims (size 1 where the factor does not vary).  Naming by id rather than by tensor
+position is what lets pyro.markov recycle enumeration dims: x_{t-2} and x_t may have occupied the
+same tensor dim in the program, here they are different names.  No einsum symbol strings and no
+contraction-path search are needed: variables are eliminated one at a time in a greedy min-size
+order (a chain of T variables costs T small logsumexps, never a K^T tensor); a sum-contraction is
+an aligned broadcast add + logsumexp over the eliminated names, a plate product is a sum over the
+plate dims.  The LDA-shaped leaf (a factor constant along the inner plate + an observed
+Categorical whose logits are gathered by the enumerated value) is contracted by ONE fused HIP
+kernel (pa_lda_factor_fwd_bwd) that never materialises the [T, words, docs] tensor.
 """
 from collections import OrderedDict
 
@@ -23,13 +28,18 @@ _FUSED_NEEDS_DEVICE = True    # tests lift this to drive the fused route with th
 
 
 class Term:
-    """A log-factor: dense ``tensor`` (or a lazy gather), the enumerated dims it depends on and
-    the plate context (``ordinal``: frozenset of vectorised CondIndepStackFrames) it lives in."""
+    """A packed log-factor: ``tensor`` [k_1..k_m, *plate block] (or a lazy gather), ``ids`` = the m
+    enumerated variables of the leading dims, ``ordinal`` = the plate context (frozenset of
+    vectorised CondIndepStackFrames) it lives in."""
 
-    __slots__ = ("tensor", "dims", "ordinal", "lazy")
+    __slots__ = ("tensor", "ids", "ordinal", "lazy")
 
-    def __init__(self, tensor, dims, ordinal, lazy=None):
-        self.tensor, self.dims, self.ordinal, self.lazy = tensor, frozenset(dims), ordinal, lazy
+    def __init__(self, tensor, ids, ordinal, lazy=None):
+        self.tensor, self.ids, self.ordinal, self.lazy = tensor, tuple(ids), ordinal, lazy
+
+    @property
+    def dims(self):
+        return frozenset(self.ids)
 
     def dense(self):
         if self.tensor is None:
@@ -37,18 +47,53 @@ class Term:
         return self.tensor
 
 
+def pack(tensor, dim_to_id, nplates, ordinal):
+    """Right-aligned program tensor (plates at -1..-nplates, enumeration dims to their left at the
+    positions ``dim_to_id`` names) -> packed Term (trace_struct.py:428-473 pack_tensors)."""
+    t = tensor
+    if t.dim() < nplates:
+        t = t.reshape((1,) * (nplates - t.dim()) + tuple(t.shape))
+    n_enum = t.dim() - nplates
+    ids, sizes = [], []
+    for i in range(n_enum):
+        if t.shape[i] > 1:
+            d = i - t.dim()
+            if d not in dim_to_id:
+                raise ValueError("enumeration dim {} of a log-factor of shape {} is not known to the "
+                                 "enumeration bookkeeping (is max_plate_nesting too small?)"
+                                 .format(d, tuple(tensor.shape)))
+            ids.append(dim_to_id[d])
+            sizes.append(t.shape[i])
+    if len(ids) != n_enum:
+        t = t.reshape(tuple(sizes) + tuple(t.shape[n_enum:]))
+    return Term(t, ids, ordinal)
+
+
+def align(term, ids):
+    """The term's tensor laid out over the names ``ids`` (a superset of its own): size-1 dims for
+    the names it does not depend on, its own dims permuted into that order."""
+    x = term.dense()
+    m = len(term.ids)
+    if tuple(term.ids) == tuple(ids):
+        return x
+    pos = {v: i for i, v in enumerate(ids)}
+    order = sorted(range(m), key=lambda i: pos[term.ids[i]])
+    if order != list(range(m)):
+        x = x.permute(order + list(range(m, x.dim())))
+    present = set(term.ids)
+    index = tuple(slice(None) if v in present else None for v in ids)
+    return x[index] if len(ids) != m else x
+
+
 class LazyGather:
     """log-factor b[t, w, d] = table[t, index[w, d]] kept un-materialised (observed Categorical
     whose logits were gathered by an enumerated value: examples/lda.py:68-70)."""
 
-    def __init__(self, table, index, enum_dim):
-        self.table, self.index, self.enum_dim = table, index, enum_dim   # [T,V], int64 [W,D]
+    def __init__(self, table, index):
+        self.table, self.index = table, index   # [T,V], int64 [W,D]
 
     def materialize(self):
-        T = self.table.shape[0]
-        out = self.table[:, self.index]                    # [T, W, D]
-        extra = -self.enum_dim - out.dim()
-        return out.reshape((T,) + (1,) * extra + tuple(self.index.shape))
+        return self.table[:, self.index]                   # [T, W, D]: packed, two plates
 
 
 class _LdaFactor(torch.autograd.Function):
@@ -67,20 +112,48 @@ class _LdaFactor(torch.autograd.Function):
         return None, g * g_theta, g * g_phi
 
 
-def _sumproduct(terms, dims):
-    """logsumexp over ``dims`` of the broadcast sum of the terms (dims kept as size 1 so the
-    right-aligned layout survives)."""
+def _sumproduct(terms, sum_ids):
+    """logsumexp over the names ``sum_ids`` of the aligned sum of the terms -> (tensor, ids)."""
+    ids = sorted(set().union(*(t.ids for t in terms))) if terms else []
     total = None
     for t in terms:
-        x = t.dense()
+        x = align(t, ids)
         total = x if total is None else total + x
-    if dims:
-        total = torch.logsumexp(total, dim=sorted(dims), keepdim=True)
-    return total
+    drop = [i for i, v in enumerate(ids) if v in sum_ids]
+    if drop:
+        total = torch.logsumexp(total, dim=drop)
+    return total, [v for v in ids if v not in sum_ids]
+
+
+def _eliminate(terms, sum_ids):
+    """Variable elimination: sum out ``sum_ids`` one name at a time, always the one whose
+    neighbourhood (union of names over the terms that mention it) is smallest.  Returns the
+    remaining terms (those that never mentioned an eliminated name + the messages)."""
+    terms = list(terms)
+    pending = set(sum_ids)
+    while pending:
+        best, best_cost = None, None
+        for v in sorted(pending):
+            nb = set()
+            for t in terms:
+                if v in t.ids:
+                    nb.update(t.ids)
+            if not nb:
+                continue
+            if best is None or len(nb) < best_cost:
+                best, best_cost = v, len(nb)
+        if best is None:
+            break
+        group = [t for t in terms if best in t.ids]
+        terms = [t for t in terms if best not in t.ids]
+        tensor, ids = _sumproduct(group, {best})
+        terms.append(Term(tensor, ids, group[0].ordinal))
+        pending.discard(best)
+    return terms
 
 
 def _product(tensor, frames):
-    """Plate product in log space = sum over the plates' tensor dims."""
+    """Plate product in log space = sum over the plates' tensor dims (kept as size 1)."""
     for f in sorted(frames, key=lambda f: f.dim):
         if tensor.dim() >= -f.dim and tensor.shape[f.dim] > 1:
             tensor = tensor.sum(f.dim, keepdim=True)
@@ -89,88 +162,86 @@ def _product(tensor, frames):
     return tensor
 
 
-def _try_fused_lda(terms, dims, contract_frames):
-    """The LDA leaf: dims == {t}, one dense term a[t, (w), d] constant along the inner plate w,
-    one lazy gather over (w, d), and both plates are contracted here.  Returns a 0-dim tensor or
-    None when the pattern does not match."""
-    if len(dims) != 1 or len(terms) != 2:
+def _try_fused_lda(terms, sum_ids, contract_frames):
+    """The LDA leaf: one enumerated name t, one dense term a[t, (w), d] constant along the inner
+    plate w, one lazy gather over (w, d), and both plates are contracted here.  Returns a 0-dim
+    tensor or None when the pattern does not match."""
+    if len(sum_ids) != 1 or len(terms) != 2:
         return None
     lazy = [t for t in terms if t.tensor is None and isinstance(t.lazy, LazyGather)]
     dense = [t for t in terms if t.tensor is not None]
     if len(lazy) != 1 or len(dense) != 1:
         return None
-    (edim,) = dims
+    (tid,) = sum_ids
     lz, a = lazy[0].lazy, dense[0].tensor
-    if lz.enum_dim != edim or lz.index.dim() != 2 or (_FUSED_NEEDS_DEVICE and not a.is_cuda):
+    if lazy[0].ids != (tid,) or dense[0].ids != (tid,) or lz.index.dim() != 2 \
+            or (_FUSED_NEEDS_DEVICE and not a.is_cuda):
         return None
     plate_dims = {f.dim for f in contract_frames}
     if plate_dims != {-1, -2} or {f.dim for f in lazy[0].ordinal} != {-1, -2}:
         return None
     W, D = lz.index.shape
     T = lz.table.shape[0]
-    if T > 64 or a.dim() != -edim or a.shape[edim] != T or a.shape[-1] != D:
-        return None
-    if any(s != 1 for i, s in enumerate(a.shape) if i not in (a.dim() + edim, a.dim() - 1, a.dim() - 2)):
+    if T > 64 or a.dim() != 3 or a.shape[0] != T or a.shape[-1] != D:
         return None
     if a.shape[-2] != 1 and a.stride(-2) != 0:
         return None           # genuinely word-dependent prior over topics: generic path
-    a2 = a.select(-2, 0)                                   # [T, 1.., D]
-    log_theta = a2.reshape(T, D).t().contiguous()          # [D, T]
+    log_theta = a.select(-2, 0).t().contiguous()           # [D, T]
     if lz.table.dtype != log_theta.dtype:
         return None
     return _LdaFactor.apply(lz.index.contiguous(), log_theta, lz.table.contiguous())
 
 
-def _partition(terms, dims):
-    """Connected components of the bipartite graph terms <-> enumerated dims
+def _partition(terms, sum_ids):
+    """Connected components of the bipartite graph terms <-> enumerated names
     (reference: contract.py:44-84)."""
     remaining = list(terms)
     components = []
-    seen_dims = set()
-    for d in sorted(dims, reverse=True):
-        if d in seen_dims:
+    seen = set()
+    for d in sorted(sum_ids):
+        if d in seen:
             continue
-        comp_dims, comp_terms, frontier = {d}, [], [d]
+        comp_ids, comp_terms, frontier = {d}, [], [d]
         while frontier:
             x = frontier.pop()
             for t in list(remaining):
                 if x in t.dims:
                     remaining.remove(t)
                     comp_terms.append(t)
-                    for d2 in t.dims & dims:
-                        if d2 not in comp_dims:
-                            comp_dims.add(d2)
+                    for d2 in t.dims & sum_ids:
+                        if d2 not in comp_ids:
+                            comp_ids.add(d2)
                             frontier.append(d2)
-        seen_dims |= comp_dims
+        seen |= comp_ids
         if comp_terms:
-            components.append((comp_terms, comp_dims))
-    for t in remaining:       # terms without any contraction dim: components of their own
+            components.append((comp_terms, comp_ids))
+    for t in remaining:       # terms without any contraction name: components of their own
         components.append(([t], set()))
     return components
 
 
-def _contract_component(tensor_tree, sum_dims, reduce_all=False):
-    """Contract all ``sum_dims`` out of one connected component by message passing from the
+def _contract_component(tensor_tree, sum_ids, reduce_all=False):
+    """Contract all ``sum_ids`` out of one connected component by message passing from the
     deepest plate context to the root (reference: contract.py:87-165 with target_dims = {})."""
-    dim_to_ordinal = {}
+    id_to_ordinal = {}
     for ordinal, terms in tensor_tree.items():
         for term in terms:
-            for d in sum_dims & term.dims:
-                dim_to_ordinal[d] = dim_to_ordinal.get(d, ordinal) & ordinal
-    dims_tree = {}
-    for d, ordinal in dim_to_ordinal.items():
-        dims_tree.setdefault(ordinal, set()).add(d)
+            for d in sum_ids & term.dims:
+                id_to_ordinal[d] = id_to_ordinal.get(d, ordinal) & ordinal
+    ids_tree = {}
+    for d, ordinal in id_to_ordinal.items():
+        ids_tree.setdefault(ordinal, set()).add(d)
     min_ordinal = frozenset.intersection(*tensor_tree)
-    while any(dims_tree.values()):
+    while any(ids_tree.values()):
         leaf = max(tensor_tree, key=len)
         leaf_terms = tensor_tree.pop(leaf)
-        leaf_dims = dims_tree.pop(leaf, set())
-        for terms, dims in _partition(leaf_terms, leaf_dims):
+        leaf_ids = ids_tree.pop(leaf, set())
+        for terms, ids in _partition(leaf_terms, leaf_ids):
             if leaf == min_ordinal:
                 parent = leaf
             else:
-                pending = set().union(*(t.dims for t in terms)) & sum_dims - dims
-                parents = [o for o, d in dims_tree.items() if d & pending]
+                pending = set().union(*(t.dims for t in terms)) & sum_ids - ids
+                parents = [o for o, d in ids_tree.items() if d & pending]
                 parent = frozenset.union(*parents) if parents else min_ordinal
                 if parent == leaf:
                     raise NotImplementedError(
@@ -181,30 +252,30 @@ def _contract_component(tensor_tree, sum_dims, reduce_all=False):
             # (the ELBO sums every contracted factor completely): lets the fused kernel cover
             # logsumexp AND both plate sums
             fuse_frames = leaf if (reduce_all and parent == leaf) else contract_frames
-            fused = _try_fused_lda(terms, dims, fuse_frames)
+            fused = _try_fused_lda(terms, ids, fuse_frames)
             if fused is not None:
-                tensor = fused
+                tensor, new_ids = fused, []
             else:
-                tensor = _product(_sumproduct(terms, dims), contract_frames)
-            new_dims = (set().union(*(t.dims for t in terms)) - dims) if terms else set()
-            tensor_tree.setdefault(parent, []).append(Term(tensor, new_dims, parent))
+                tensor, new_ids = _sumproduct(_eliminate(terms, ids), set())
+                tensor = _product(tensor, contract_frames)
+            tensor_tree.setdefault(parent, []).append(Term(tensor, new_ids, parent))
     assert len(tensor_tree) == 1
     ordinal, terms = tensor_tree.popitem()
-    tensor = _sumproduct(terms, set())
-    return ordinal, Term(tensor, (), ordinal)
+    tensor, ids = _sumproduct(terms, set())
+    return ordinal, Term(tensor, ids, ordinal)
 
 
-def contract_tensor_tree(tensor_tree, sum_dims, reduce_all=False):
-    """{ordinal: [Term]} -> {ordinal: [Term]} with every enumerated dim summed out; plate dims are
-    contracted only as far as the message passing requires (reference: contract.py:168-210).
+def contract_tensor_tree(tensor_tree, sum_ids, reduce_all=False):
+    """{ordinal: [Term]} -> {ordinal: [Term]} with every name of ``sum_ids`` summed out; plate dims
+    are contracted only as far as the message passing requires (reference: contract.py:168-210).
     With ``reduce_all`` a factor may come back already summed over its remaining plates."""
     assert isinstance(tensor_tree, OrderedDict)
     all_terms = [t for terms in tensor_tree.values() for t in terms]
     contracted = OrderedDict()
-    for terms, dims in _partition(all_terms, set(sum_dims)):
+    for terms, ids in _partition(all_terms, set(sum_ids)):
         component = OrderedDict()
         for t in terms:
             component.setdefault(t.ordinal, []).append(t)
-        ordinal, term = _contract_component(component, dims, reduce_all)
+        ordinal, term = _contract_component(component, ids, reduce_all)
         contracted.setdefault(ordinal, []).append(term)
     return contracted

@@ -379,8 +379,13 @@ class PlateMessenger(Messenger):
 # ---------------------------------------------------------------------------------------------
 class EnumMessenger(Messenger):
     """Parallel enumeration of discrete sample sites marked infer={"enumerate": "parallel"}
-    (reference: enum_messenger.py:114-254): the site's value becomes its support on a fresh tensor
-    dim to the left of every plate; the support indices are int64 and exact."""
+    (reference: enum_messenger.py:114-254): the site's value becomes its support on a tensor dim
+    to the left of every plate; the support indices are int64 and exact.
+
+    Every sample site that passes through also gets ``infer["_dim_to_id"]``: which enumerated
+    VARIABLE (unique id) each enumeration dim of its tensors refers to at this point of the
+    program.  Outside pyro.markov a dim belongs to one variable for good; inside, dims are recycled
+    once their variable has left the Markov scope, and the id is what tells x_{t-2} from x_t."""
 
     def __init__(self, first_available_dim=None):
         super().__init__()
@@ -390,12 +395,23 @@ class EnumMessenger(Messenger):
     def __enter__(self):
         if self.first_available_dim is not None:
             _ENUM_ALLOCATOR.set_first_available_dim(self.first_available_dim)
-        self._dims = {}
+        self._markov_depths = {}      # site name -> markov depth at which it was sampled
+        self._param_dims = {}         # site name -> {enum dim: id} visible to its parameters
+        self._value_dims = {}         # site name -> {enum dim: id} its value really depends on
         return super().__enter__()
 
     def _pyro_sample(self, msg):
         if msg["done"] or not isinstance(msg["fn"], torch.distributions.Distribution):
             return
+        scope = msg["infer"].get("_markov_scope")          # site name -> depth (MarkovMessenger)
+        param_dims = dict(_ENUM_ALLOCATOR.dim_to_id)
+        if scope is not None:
+            for name, depth in scope.items():
+                # a site whose markov context has exited since is no longer visible
+                if self._markov_depths.get(name) == depth:
+                    param_dims.update(self._value_dims.get(name, {}))
+            self._markov_depths[msg["name"]] = msg["infer"]["_markov_depth"]
+        self._param_dims[msg["name"]] = param_dims
         if msg["is_observed"]:
             return
         strategy = msg["infer"].get("enumerate")
@@ -408,21 +424,96 @@ class EnumMessenger(Messenger):
         if not getattr(dist, "has_enumerate_support", False):
             raise NotImplementedError("{} does not support enumeration".format(type(dist)))
         value = dist.enumerate_support(expand=False)
-        dim, id_ = _ENUM_ALLOCATOR.allocate()
+        dim, id_ = _ENUM_ALLOCATOR.allocate(None if scope is None else set(param_dims))
         event_dim = len(dist.event_shape)
-        # move the support axis (currently leftmost of value) to tensor dim `dim`
-        target_len = -dim + event_dim
+        # enumerate_support(expand=False) is [K, 1, ..., 1, *event_shape]: put the support axis at
+        # tensor dim `dim` (counted left of the event dims), whatever rank the batch shape has
         shape = value.shape
-        extra = target_len - len(shape)
+        ev = tuple(shape[len(shape) - event_dim:]) if event_dim else ()
+        assert all(n == 1 for n in shape[1:len(shape) - event_dim]), \
+            "enumerate_support(expand=False) must not expand batch dims"
         tag = getattr(value, "_pyro_categorical_support", None)
-        if extra > 0:
-            value = value.reshape(shape[:1] + (1,) * extra + shape[1:])
+        value = value.reshape(shape[:1] + (1,) * (-1 - dim) + ev)
         if tag is not None:
             value._pyro_categorical_support = tag
+        value_dims = {d: param_dims[d] for d in range(event_dim - value.dim(), 0)
+                      if d in param_dims and value.size(d - event_dim) > 1}
+        value_dims[dim] = id_
         msg["infer"]["_enumerate_dim"] = dim
-        msg["infer"]["_dim_to_id"] = {dim: id_}
+        msg["infer"]["_dim_to_id"] = value_dims
         msg["value"] = value
         msg["done"] = True
+
+    def _pyro_post_sample(self, msg):
+        if not isinstance(msg["fn"], torch.distributions.Distribution) or msg["value"] is None:
+            return
+        value = msg["value"]
+        event_dim = len(msg["fn"].event_shape)
+        shape = value.shape[:value.dim() - event_dim]
+        dim_to_id = msg["infer"].setdefault("_dim_to_id", {})
+        for d, i in self._param_dims.get(msg["name"], {}).items():
+            dim_to_id.setdefault(d, i)
+        self._value_dims[msg["name"]] = {d: i for d, i in dim_to_id.items()
+                                         if len(shape) >= -d and shape[d] > 1}
+
+
+class MarkovMessenger(Messenger):
+    """Markov dependency declaration (reference: markov_messenger.py:17-130): sample sites in the
+    body of ``for t in pyro.markov(range(T), history=h)`` may depend only on sites of the current
+    and the previous ``h`` iterations, so enumeration dims are recycled after h + 1 steps.  Marks
+    every sample site with its Markov scope (names of the sites visible from it and their depth)
+    for EnumMessenger.  Re-entrant: the same instance is entered once per iteration."""
+
+    def __init__(self, history=1, keep=False, dim=None, name=None):
+        super().__init__()
+        assert history >= 0
+        if dim is not None or name is not None:
+            raise NotImplementedError("vectorized markov is not implemented (neither in the "
+                                      "reference): leave dim and name unset")
+        self.history, self.keep = history, keep
+        self._iterable = None
+        self._pos = -1
+        self._stack = []
+        self._ref_count = 0
+
+    def generator(self, iterable):
+        self._iterable = iterable
+        return self
+
+    def __iter__(self):
+        from contextlib import ExitStack
+        with ExitStack() as stack:
+            for value in self._iterable:
+                stack.enter_context(self)
+                yield value
+
+    def __enter__(self):
+        self._pos += 1
+        if len(self._stack) <= self._pos:
+            self._stack.append(set())
+        self._ref_count += 1                      # re-entrant: on the handler stack only once
+        if self._ref_count == 1:
+            super().__enter__()
+        return self
+
+    def __exit__(self, *args):
+        if not self.keep:
+            self._stack.pop()
+        self._pos -= 1
+        self._ref_count -= 1
+        if self._ref_count == 0:
+            return super().__exit__(*args)
+
+    def _pyro_sample(self, msg):
+        from collections import Counter
+        if msg["done"] or type(msg["fn"]).__name__ == "_Subsample":
+            return
+        infer = msg["infer"]
+        scope = infer.setdefault("_markov_scope", Counter())     # site name -> markov depth
+        for pos in range(max(0, self._pos - self.history), self._pos + 1):
+            scope.update(self._stack[pos])
+        infer["_markov_depth"] = 1 + infer.get("_markov_depth", 0)
+        self._stack[self._pos].add(msg["name"])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -467,3 +558,14 @@ scale = _make_handler(ScaleMessenger)
 mask = _make_handler(MaskMessenger)
 enum = _make_handler(EnumMessenger)
 seed = _make_handler(SeedMessenger)
+
+
+def markov(fn=None, history=1, keep=False, dim=None, name=None):
+    """Markov dependency declaration: as a context manager, a decorator, or around an iterable
+    (``for t in markov(range(T))``) (reference: pyro/poutine/handlers.py markov)."""
+    if fn is None:
+        return MarkovMessenger(history=history, keep=keep, dim=dim, name=name)
+    if not callable(fn):
+        # an iterable
+        return MarkovMessenger(history=history, keep=keep, dim=dim, name=name).generator(iterable=fn)
+    return MarkovMessenger(history=history, keep=keep, dim=dim, name=name)(fn)

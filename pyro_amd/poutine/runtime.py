@@ -66,8 +66,10 @@ _DIM_ALLOCATOR = _DimAllocator()
 
 
 class _EnumAllocator:
-    """Allocates tensor dims (left of all plates) and integer ids to enumerated sample sites
-    (reference: runtime.py:246-303).  Only global (non-markov) allocation is supported."""
+    """Allocates tensor dims (left of all plates) and unique integer ids to enumerated sample
+    sites (reference: runtime.py:246-303).  A site outside any pyro.markov context gets a global
+    dim that is never reused; inside one it gets the first dim not occupied by a variable that is
+    still visible from it (``scope_dims``), so a chain of T variables needs history + 1 dims."""
 
     def __init__(self):
         self.set_first_available_dim(-1)
@@ -76,7 +78,7 @@ class _EnumAllocator:
         assert first_available_dim < 0
         self.next_available_dim = first_available_dim
         self.next_available_id = 0
-        self.dim_to_id = {}
+        self.dim_to_id = {}                     # global dims only
 
     def allocate(self, scope_dims=None):
         id_ = self.next_available_id
@@ -85,8 +87,12 @@ class _EnumAllocator:
         if dim == -float("inf"):
             raise ValueError("max_plate_nesting must be set to a finite value for parallel "
                              "enumeration")
-        self.next_available_dim -= 1
-        self.dim_to_id[dim] = id_
+        if scope_dims is None:
+            self.next_available_dim -= 1
+            self.dim_to_id[dim] = id_
+        else:
+            while dim in scope_dims:
+                dim -= 1
         return dim, id_
 
 

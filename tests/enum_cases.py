@@ -5,6 +5,7 @@ import torch
 
 import pyro_amd as pyro
 import pyro_amd.distributions as dist
+import pyro_amd.poutine as poutine
 from pyro_amd.distributions import constraints
 from pyro_amd.infer import TraceEnum_ELBO
 from tests.models import EpsReplay, assert_grads, store_grads
@@ -117,3 +118,67 @@ def lda_brute_force_loss(g):
         for d in range(D):
             lp = lp + torch.log((dt[d] * phi[:, data[w, d]]).sum())
     return -lp.item()
+
+
+# ---- hidden Markov models under pyro.markov (tests/golden/hmm.npz from the reference) -------------
+def run_hmm(g, device, which, rtol=1e-9, dtype=torch.float64):
+    """examples/hmm.py model_1 (one hidden chain, emissions in a nested plate, ragged masked
+    sequences) and model_3 (two hidden chains, factorial emission) with pyro.params: the loss is
+    the exact negative log marginal likelihood; value and gradients against the reference."""
+    from pyro_amd.distributions import constraints
+    seqs, lengths = _t(g["sequences"], device, dtype), torch.tensor(g["lengths"], device=device)
+    S, L, D = seqs.shape
+
+    def model_1(sequences, lengths):
+        probs_x = pyro.param("probs_x", _t(g["probs_x"], device, dtype), constraint=constraints.simplex)
+        probs_y = pyro.param("probs_y", _t(g["probs_y"], device, dtype),
+                             constraint=constraints.unit_interval)
+        tones_plate = pyro.plate("tones", D, dim=-1)
+        with pyro.plate("sequences", S, dim=-2):
+            x = 0
+            for t in pyro.markov(range(int(lengths.max()))):
+                with poutine.mask(mask=(t < lengths).unsqueeze(-1)):
+                    x = pyro.sample("x_{}".format(t), dist.Categorical(probs_x[x]),
+                                    infer={"enumerate": "parallel"})
+                    with tones_plate:
+                        pyro.sample("y_{}".format(t), dist.Bernoulli(probs_y[x.squeeze(-1)]),
+                                    obs=sequences[:, t])
+
+    def model_3(sequences, lengths):
+        probs_w = pyro.param("probs_w", _t(g["probs_w"], device, dtype), constraint=constraints.simplex)
+        probs_x = pyro.param("probs_x", _t(g["probs_x"], device, dtype), constraint=constraints.simplex)
+        probs_y = pyro.param("probs_yw", _t(g["probs_yw"], device, dtype),
+                             constraint=constraints.unit_interval)
+        tones_plate = pyro.plate("tones", D, dim=-1)
+        with pyro.plate("sequences", S, dim=-2):
+            w, x = 0, 0
+            for t in pyro.markov(range(int(lengths.max()))):
+                with poutine.mask(mask=(t < lengths).unsqueeze(-1)):
+                    w = pyro.sample("w_{}".format(t), dist.Categorical(probs_w[w]),
+                                    infer={"enumerate": "parallel"})
+                    x = pyro.sample("x_{}".format(t), dist.Categorical(probs_x[x]),
+                                    infer={"enumerate": "parallel"})
+                    with tones_plate as tones:
+                        pyro.sample("y_{}".format(t), dist.Bernoulli(probs_y[w, x, tones]),
+                                    obs=sequences[:, t])
+
+    def guide(sequences, lengths):
+        pass
+
+    model, tag = (model_1, "m1") if which == 1 else (model_3, "m3")
+    pyro.clear_param_store()
+    elbo = TraceEnum_ELBO(max_plate_nesting=2)
+    loss = elbo.differentiable_loss(model, guide, seqs, lengths)
+    np.testing.assert_allclose(loss.item(), float(g[tag + "/loss"]), rtol=rtol)
+    names = sorted(pyro.get_param_store().keys())
+    params = [pyro.param(n).unconstrained() for n in names]
+    grads = torch.autograd.grad(loss, params)
+    for n, gr in zip(names, grads):
+        ref = g[tag + "/grad/" + n]
+        np.testing.assert_allclose(gr.cpu().numpy(), ref, rtol=rtol * 100,
+                                   atol=rtol * 100 * float(np.abs(ref).max()), err_msg=n)
+    # the trace needs only history + 1 enumeration dims per chain, however long the sequence
+    tr = poutine.trace(poutine.enum(model, first_available_dim=-3)).get_trace(seqs, lengths)
+    dims = {s["infer"]["_enumerate_dim"] for s in tr.nodes.values()
+            if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None}
+    assert len(dims) <= (2 if which == 1 else 4), dims

@@ -723,9 +723,90 @@ def post_np(d):
     return {k: v.numpy() for k, v in d.items()}
 
 
+# ---------------------------------------------------------------------------------------------
+# G11: hidden Markov models (examples/hmm.py:97-137 model_1, :192-222 model_3 shapes at toy size):
+#      pyro.markov recycles the enumeration dims, sequences of ragged lengths are masked, the
+#      emissions sit in a nested plate.  Parameters are pyro.params so that the loss is the exact
+#      negative log marginal likelihood and its gradient is deterministic.
+# ---------------------------------------------------------------------------------------------
+def g_hmm():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer import TraceEnum_ELBO
+    rng = np.random.default_rng(21)
+    S, L, K, D = 4, 6, 3, 5
+    lengths = np.array([6, 3, 5, 1])
+    seqs = (rng.uniform(size=(S, L, D)) < 0.4).astype(np.float64)
+    px0 = rng.dirichlet(np.ones(K), K)
+    py0 = rng.uniform(0.1, 0.9, (K, D))
+    pw0 = rng.dirichlet(np.ones(K), K)
+    pyw0 = rng.uniform(0.1, 0.9, (K, K, D))
+    sequences, lens = torch.tensor(seqs), torch.tensor(lengths)
+
+    def model_1(sequences, lengths):
+        probs_x = pyro.param("probs_x", torch.tensor(px0), constraint=constraints.simplex)
+        probs_y = pyro.param("probs_y", torch.tensor(py0), constraint=constraints.unit_interval)
+        tones_plate = pyro.plate("tones", D, dim=-1)
+        with pyro.plate("sequences", S, dim=-2):
+            x = 0
+            for t in pyro.markov(range(int(lengths.max()))):
+                with poutine.mask(mask=(t < lengths).unsqueeze(-1)):
+                    x = pyro.sample("x_{}".format(t), dist.Categorical(probs_x[x]),
+                                    infer={"enumerate": "parallel"})
+                    with tones_plate:
+                        pyro.sample("y_{}".format(t), dist.Bernoulli(probs_y[x.squeeze(-1)]),
+                                    obs=sequences[:, t])
+
+    def model_3(sequences, lengths):
+        # two hidden chains w, x; the emission depends on both (factorial HMM)
+        probs_w = pyro.param("probs_w", torch.tensor(pw0), constraint=constraints.simplex)
+        probs_x = pyro.param("probs_x", torch.tensor(px0), constraint=constraints.simplex)
+        probs_y = pyro.param("probs_yw", torch.tensor(pyw0), constraint=constraints.unit_interval)
+        tones_plate = pyro.plate("tones", D, dim=-1)
+        with pyro.plate("sequences", S, dim=-2):
+            w, x = 0, 0
+            for t in pyro.markov(range(int(lengths.max()))):
+                with poutine.mask(mask=(t < lengths).unsqueeze(-1)):
+                    w = pyro.sample("w_{}".format(t), dist.Categorical(probs_w[w]),
+                                    infer={"enumerate": "parallel"})
+                    x = pyro.sample("x_{}".format(t), dist.Categorical(probs_x[x]),
+                                    infer={"enumerate": "parallel"})
+                    with tones_plate as tones:
+                        pyro.sample("y_{}".format(t), dist.Bernoulli(probs_y[w, x, tones]),
+                                    obs=sequences[:, t])
+
+    def guide(sequences, lengths):
+        pass
+
+    flat = {"sequences": seqs, "lengths": lengths, "probs_x": px0, "probs_y": py0, "probs_w": pw0,
+            "probs_yw": pyw0}
+    for tag, model in (("m1", model_1), ("m3", model_3)):
+        pyro.clear_param_store()
+        elbo = TraceEnum_ELBO(max_plate_nesting=2)
+        loss = elbo.differentiable_loss(model, guide, sequences, lens)
+        names = sorted(pyro.get_param_store().keys())
+        params = [pyro.param(n).unconstrained() for n in names]
+        grads = torch.autograd.grad(loss, params)
+        flat[tag + "/loss"] = loss.item()
+        for n, g in zip(names, grads):
+            flat[tag + "/grad/" + n] = g.numpy()
+    # brute-force check of model_1's loss for the shortest sequences (forward algorithm in numpy)
+    def fwd(seq, T):
+        alpha = px0[0].copy()
+        for t in range(T):
+            if t > 0:
+                alpha = alpha @ px0
+            em = np.prod(np.where(seq[t] > 0, py0, 1 - py0), axis=1)
+            alpha = alpha * em
+        return np.log(alpha.sum())
+    flat["m1/loss_forward_algorithm"] = -sum(fwd(seqs[i], lengths[i]) for i in range(S))
+    assert abs(flat["m1/loss_forward_algorithm"] - flat["m1/loss"]) < 1e-9, (flat["m1/loss"],
+                                                                           flat["m1/loss_forward_algorithm"])
+    save("hmm", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm"]
     for w in which:
         globals()["g_" + w]()
 

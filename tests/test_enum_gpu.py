@@ -78,6 +78,11 @@ def test_lda_svi_improves(gpu):
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
 
 
+@pytest.mark.parametrize("which", [1, 3])
+def test_hmm_under_markov_matches_reference(gpu, which):
+    ec.run_hmm(load("hmm"), gpu, which)
+
+
 # ---- the reference's hand-vs-auto enumeration KATs (tests/enum_kat_cases.py) on the device -------
 from tests import enum_kat_cases as ekc   # noqa: E402
 

@@ -46,6 +46,11 @@ def test_lda_fused_route_with_oracle_kernel(_cpu_backend, monkeypatch):
     ec.run_lda(load("enum"), torch.device("cpu"), monkeypatch, expect_fused=True)
 
 
+@pytest.mark.parametrize("which", [1, 3])
+def test_hmm_under_markov_matches_reference(_cpu_backend, which):
+    ec.run_hmm(load("hmm"), torch.device("cpu"), which)
+
+
 def test_sequential_enumeration_raises(_cpu_backend):
     import pyro_amd as pyro
     import pyro_amd.distributions as dist
