@@ -468,6 +468,22 @@ int pa_mvn_tril_sample_bwd(int dtype, const void* loc, const void* rho, const vo
                            int64_t P, void* d_loc, void* d_rho, void* d_A, int accumulate,
                            pa_stream_t stream);
 
+/* A chain of T enumerated discrete variables (K <= 64 states each) summed out for B independent
+ * batch elements -- the forward algorithm and its forward-backward gradient in one launch:
+ *   log_z[b]              = log sum_{v_0..v_{T-1}} exp(sum_t unary[b,t,v_t] + sum_t pair[b,t,v_t,v_{t+1}])
+ *   grad_unary[b,t,j]     = d log_z[b] / d unary[b,t,j]       (posterior marginal of v_t)
+ *   grad_pairwise[b,t,i,j]= d log_z[b] / d pair[b,t,i,j]      (posterior of the pair), [B,T-1,K,K]
+ * unary [B,T,K] contiguous; pair[b,t] = pairwise + b*pair_stride_batch + t*pair_stride_step
+ * (elements; 0 = shared), row-major [K,K].  Replaces the pairwise log-space contractions of
+ * pyro/ops/contract.py:79-202 + pyro/ops/einsum/torch_log.py:14-55 and their autograd duals for
+ * models written with pyro.markov (examples/hmm.py).  K > 64: PA_ERR_UNSUPPORTED.
+ * workspace: pa_logchain_workspace(dtype, B, T, K) bytes. */
+size_t pa_logchain_workspace(int dtype, int64_t B, int64_t T, int64_t K);
+int pa_logchain_fwd_bwd(int dtype, const void* unary, const void* pairwise,
+                        int64_t pair_stride_batch, int64_t pair_stride_step, int64_t B,
+                        int64_t T, int64_t K, void* log_z, void* grad_unary, void* grad_pairwise,
+                        void* workspace, size_t workspace_bytes, pa_stream_t stream);
+
 /* Per-chain dense matrix x vector: y[c] = M[c] x[c] (transpose = 0) or M[c]^T x[c]
  * (transpose = 1); M[C, D, D] row-major with chain stride m_stride_chain elements (0 = one matrix
  * shared by all chains), x, y [C, D] contiguous, x != y.  Replaces the dense-block products of

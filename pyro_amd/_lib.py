@@ -145,6 +145,10 @@ _SIGNATURES = {
     "pa_mvn_tril_sample_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                        c_int, c_void_p]),
+    "pa_logchain_workspace": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
+    "pa_logchain_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                    c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
     "pa_chain_matvec": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                 c_void_p]),
     "pa_adam_step_publish": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -183,3 +183,37 @@ def synthetic_hier_logreg_data(N, D, G, device, seed=0, dtype=torch.float32):
     counts = torch.bincount(grp, minlength=G).cpu().numpy().astype(np.int64)
     offsets = np.concatenate([[0], np.cumsum(counts)])
     return X, y, offsets
+
+
+# ---- examples/hmm.py:97-137 (model_1) restated against the drop-in API ---------------------------
+def hmm_model_1(sequences, lengths, hidden_dim=16):
+    """One hidden chain per sequence under pyro.markov, emissions in a nested plate, ragged
+    sequences masked; transition / emission probabilities are learnable parameters (maximum
+    likelihood; the example's priors + AutoDelta guide add two small sites)."""
+    from . import markov, poutine
+    from .distributions import constraints
+    from .primitives import param
+    S, L, D = sequences.shape
+    dev = sequences.device
+    probs_x = param("probs_x", lambda: torch.softmax(torch.randn(hidden_dim, hidden_dim, device=dev), -1),
+                    constraint=constraints.simplex)
+    probs_y = param("probs_y", lambda: torch.rand(hidden_dim, D, device=dev) * 0.8 + 0.1,
+                    constraint=constraints.unit_interval)
+    tones_plate = plate("tones", D, dim=-1)
+    with plate("sequences", S, dim=-2):
+        x = 0
+        for t in markov(range(L)):
+            with poutine.mask(mask=(t < lengths).unsqueeze(-1)):
+                x = sample("x_{}".format(t), dist.Categorical(probs_x[x]),
+                           infer={"enumerate": "parallel"})
+                with tones_plate:
+                    sample("y_{}".format(t), dist.Bernoulli(probs_y[x.squeeze(-1)]),
+                           obs=sequences[:, t])
+
+
+def synthetic_hmm_data(S, L, D, device, seed=0):
+    g = torch.Generator(device=device).manual_seed(seed)
+    seqs = (torch.rand((S, L, D), device=device, generator=g) < 0.3).float()
+    lengths = torch.randint(L // 2, L + 1, (S,), device=device, generator=g)
+    lengths[0] = L
+    return seqs, lengths

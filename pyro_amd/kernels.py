@@ -409,6 +409,36 @@ def meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scales, d_louts, P, sinks=No
     return d_locs, d_rhos
 
 
+def logchain_fwd_bwd(unary, pairwise):
+    """Chain of enumerated variables summed out (pa_logchain_fwd_bwd): unary [B, T, K], pairwise
+    [B, T-1, K, K] (contiguous; or [T-1, K, K] / [K, K] shared) ->
+    (log_z [B], grad_unary [B, T, K], grad_pairwise [B, T-1, K, K])."""
+    _require_gpu(unary, pairwise)
+    B, T, K = unary.shape
+    assert unary.is_contiguous() and (T == 1 or pairwise.is_contiguous())
+    lib = _lib.load()
+    spb = spt = 0
+    if T > 1:
+        assert pairwise.dtype == unary.dtype and pairwise.shape[-2:] == (K, K)
+        if pairwise.dim() == 4:
+            assert pairwise.shape[:2] == (B, T - 1)
+            spb, spt = (T - 1) * K * K, K * K
+        elif pairwise.dim() == 3:
+            assert pairwise.shape[0] == T - 1
+            spt = K * K
+        else:
+            assert pairwise.dim() == 2
+    log_z = torch.empty((B,), dtype=unary.dtype, device=unary.device)
+    g_u = torch.empty_like(unary)
+    g_p = torch.empty((B, max(T - 1, 0), K, K), dtype=unary.dtype, device=unary.device)
+    nbytes = lib.pa_logchain_workspace(_dtype(unary), B, T, K)
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=unary.device)
+    check(lib.pa_logchain_fwd_bwd(_dtype(unary), _ptr(unary), _ptr(pairwise) if T > 1 else None,
+                                  spb, spt, B, T, K, _ptr(log_z), _ptr(g_u), _ptr(g_p), _ptr(ws),
+                                  nbytes, _stream()))
+    return log_z, g_u, g_p
+
+
 def mvn_tril_sample(loc, rho, A, P, seed=0, offset=0, offset_dev=None, eps=None):
     """Full-covariance Normal guide draw for P particles (pa_mvn_tril_sample): loc, rho [n],
     A [n, n] unconstrained; ``eps`` [P, n] given = use it instead of the Philox stream.

@@ -25,6 +25,7 @@ from .. import kernels
 
 
 _FUSED_NEEDS_DEVICE = True    # tests lift this to drive the fused route with the oracle kernel
+FUSED_CHAIN = True            # HMM-shaped components go through pa_logchain_fwd_bwd
 
 
 class Term:
@@ -110,6 +111,97 @@ class _LdaFactor(torch.autograd.Function):
     def backward(ctx, g):
         g_theta, g_phi = ctx.saved_tensors
         return None, g * g_theta, g * g_phi
+
+
+class _LogChain(torch.autograd.Function):
+    """log Z of a chain of enumerated variables for every batch element (forward algorithm) with
+    the forward-backward posteriors as gradient, ONE launch (pa_logchain_fwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, unary, pairwise):
+        log_z, g_u, g_p = kernels.logchain_fwd_bwd(unary, pairwise)
+        ctx.save_for_backward(g_u, g_p)
+        return log_z
+
+    @staticmethod
+    def backward(ctx, g):
+        g_u, g_p = ctx.saved_tensors
+        return g.reshape(-1, 1, 1) * g_u, g.reshape(-1, 1, 1, 1) * g_p
+
+
+def _try_fused_chain(terms, sum_ids):
+    """A component whose names form a simple path (every term mentions one or two of them, the
+    two-name terms link consecutive variables: an HMM written with pyro.markov) is summed out by
+    the fused forward-backward kernel.  Returns the packed tensor [*plate block] or None."""
+    T = len(sum_ids)
+    if T < 3 or not terms:
+        return None
+    proto = None
+    for t in terms:
+        if t.tensor is None or not (1 <= len(t.ids) <= 2) or not set(t.ids) <= sum_ids:
+            return None
+        proto = t.tensor if proto is None else proto
+    if proto.dtype not in (torch.float32, torch.float64) or \
+            not (proto.is_cuda or kernels.HOST_TEST_BACKEND):
+        return None
+    adj = {v: set() for v in sum_ids}
+    for t in terms:
+        if len(t.ids) == 2:
+            a, b = t.ids
+            adj[a].add(b)
+            adj[b].add(a)
+    ends = sorted(v for v, n in adj.items() if len(n) == 1)
+    if len(ends) != 2 or any(len(n) > 2 or len(n) == 0 for n in adj.values()):
+        return None
+    order, prev = [ends[0]], None
+    while len(order) < T:
+        nxt = [v for v in adj[order[-1]] if v != prev]
+        if len(nxt) != 1:
+            return None
+        prev = order[-1]
+        order.append(nxt[0])
+    if len(set(order)) != T:
+        return None
+    pos = {v: i for i, v in enumerate(order)}
+    nplates = None
+    K = None
+    batch = ()
+    for t in terms:
+        m = len(t.ids)
+        x = t.tensor
+        nplates = x.dim() - m if nplates is None else nplates
+        if x.dim() - m != nplates or any(k != x.shape[0] for k in x.shape[:m]):
+            return None
+        K = x.shape[0] if K is None else K
+        if x.shape[0] != K:
+            return None
+        batch = torch.broadcast_shapes(batch, tuple(x.shape[m:]))
+    if K > 64:
+        return None
+    B = 1
+    for n in batch:
+        B *= int(n)
+    unary = [None] * T
+    pair = [None] * (T - 1)
+    for t in terms:
+        if len(t.ids) == 1:
+            i = pos[t.ids[0]]
+            unary[i] = t.tensor if unary[i] is None else unary[i] + t.tensor
+        else:
+            a, b = t.ids
+            if abs(pos[a] - pos[b]) != 1:
+                return None
+            first = a if pos[a] < pos[b] else b
+            x = align(t, (first, b if first == a else a))
+            i = pos[first]
+            pair[i] = x if pair[i] is None else pair[i] + x
+    zeros_u = proto.new_zeros((K,) + (1,) * nplates)
+    U = torch.stack([(zeros_u if u is None else u).expand((K,) + tuple(batch)) for u in unary])
+    P = torch.stack([p.expand((K, K) + tuple(batch)) for p in pair])
+    nb = len(batch)
+    U = U.permute(tuple(range(2, 2 + nb)) + (0, 1)).reshape(B, T, K).contiguous()
+    P = P.permute(tuple(range(3, 3 + nb)) + (0, 1, 2)).reshape(B, T - 1, K, K).contiguous()
+    return _LogChain.apply(U, P).reshape(tuple(batch))
 
 
 def _sumproduct(terms, sum_ids):
@@ -253,8 +345,11 @@ def _contract_component(tensor_tree, sum_ids, reduce_all=False):
             # logsumexp AND both plate sums
             fuse_frames = leaf if (reduce_all and parent == leaf) else contract_frames
             fused = _try_fused_lda(terms, ids, fuse_frames)
+            chain = _try_fused_chain(terms, ids) if fused is None and FUSED_CHAIN else None
             if fused is not None:
                 tensor, new_ids = fused, []
+            elif chain is not None:
+                tensor, new_ids = _product(chain, contract_frames), []
             else:
                 tensor, new_ids = _sumproduct(_eliminate(terms, ids), set())
                 tensor = _product(tensor, contract_frames)

@@ -121,7 +121,7 @@ def lda_brute_force_loss(g):
 
 
 # ---- hidden Markov models under pyro.markov (tests/golden/hmm.npz from the reference) -------------
-def run_hmm(g, device, which, rtol=1e-9, dtype=torch.float64):
+def run_hmm(g, device, which, rtol=1e-9, dtype=torch.float64, fused_chain=True):
     """examples/hmm.py model_1 (one hidden chain, emissions in a nested plate, ragged masked
     sequences) and model_3 (two hidden chains, factorial emission) with pyro.params: the loss is
     the exact negative log marginal likelihood; value and gradients against the reference."""
@@ -168,7 +168,20 @@ def run_hmm(g, device, which, rtol=1e-9, dtype=torch.float64):
     model, tag = (model_1, "m1") if which == 1 else (model_3, "m3")
     pyro.clear_param_store()
     elbo = TraceEnum_ELBO(max_plate_nesting=2)
-    loss = elbo.differentiable_loss(model, guide, seqs, lengths)
+    import pyro_amd.kernels as k
+    import pyro_amd.ops.contract as contract
+    calls = []
+    real = k.logchain_fwd_bwd
+    k.logchain_fwd_bwd = lambda u, p: (calls.append(tuple(u.shape)), real(u, p))[1]
+    try:
+        contract.FUSED_CHAIN = fused_chain
+        loss = elbo.differentiable_loss(model, guide, seqs, lengths)
+    finally:
+        k.logchain_fwd_bwd = real
+        contract.FUSED_CHAIN = True
+    # model_1 is one chain per sequence: the whole elimination is ONE fused launch over [S, T, K]
+    assert calls == ([(S, int(lengths.max()), g["probs_x"].shape[0])] if which == 1 and fused_chain
+                     else []), calls
     np.testing.assert_allclose(loss.item(), float(g[tag + "/loss"]), rtol=rtol)
     names = sorted(pyro.get_param_store().keys())
     params = [pyro.param(n).unconstrained() for n in names]

@@ -411,6 +411,29 @@ def mvn_tril_sample_bwd(loc, rho, eps, z, d_z, d_logq, sinks=None):
     return tuple(outs)
 
 
+def logchain_fwd_bwd(unary, pairwise):
+    """Forward algorithm + forward-backward posteriors in numpy (float64)."""
+    from scipy.special import logsumexp
+    U = _np(unary).astype(np.float64)
+    B, T, K = U.shape
+    Pn = _np(pairwise).astype(np.float64) if T > 1 else np.zeros((B, 0, K, K))
+    Pn = np.broadcast_to(Pn, (B, max(T - 1, 0), K, K))
+    alpha = np.zeros((B, T, K))
+    alpha[:, 0] = U[:, 0]
+    for t in range(1, T):
+        alpha[:, t] = U[:, t] + logsumexp(alpha[:, t - 1, :, None] + Pn[:, t - 1], axis=1)
+    lz = logsumexp(alpha[:, -1], axis=1)
+    beta = np.zeros((B, T, K))
+    xi = np.zeros((B, max(T - 1, 0), K, K))
+    for t in range(T - 2, -1, -1):
+        w = U[:, t + 1] + beta[:, t + 1]
+        beta[:, t] = logsumexp(Pn[:, t] + w[:, None, :], axis=2)
+        xi[:, t] = np.exp(alpha[:, t, :, None] + Pn[:, t] + w[:, None, :] - lz[:, None, None])
+    gamma = np.exp(alpha + beta - lz[:, None, None])
+    mk = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=unary.dtype)   # noqa: E731
+    return mk(lz), mk(gamma), mk(xi)
+
+
 def chain_matvec(M, x, transpose=False):
     Mn, xn = _np(M), _np(x)
     if Mn.ndim == 2:
@@ -424,7 +447,7 @@ FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
-             "mvn_tril_sample_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd"]
+             "mvn_tril_sample_bwd", "logchain_fwd_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd"]
 
 
 def install(monkeypatch):

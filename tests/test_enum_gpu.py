@@ -78,9 +78,46 @@ def test_lda_svi_improves(gpu):
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("fused_chain", [True, False], ids=["fused_chain", "generic"])
 @pytest.mark.parametrize("which", [1, 3])
-def test_hmm_under_markov_matches_reference(gpu, which):
-    ec.run_hmm(load("hmm"), gpu, which)
+def test_hmm_under_markov_matches_reference(gpu, which, fused_chain, dtype, rtol):
+    ec.run_hmm(load("hmm"), gpu, which, fused_chain=fused_chain, dtype=dtype, rtol=rtol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,T,K,shared", [(1, 1, 1, False), (5, 2, 3, False), (7, 9, 16, True),
+                                          (3, 130, 64, False), (229, 129, 16, True)])
+def test_logchain_kernel(gpu, dtype, B, T, K, shared):
+    """pa_logchain_fwd_bwd against the numpy forward-backward restatement and torch autograd of a
+    plain log-space forward recursion; -inf potentials (forbidden transitions) included."""
+    from pyro_amd import kernels as k
+    from tests import oracle_backend as ob
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + K)
+    U = torch.randn(B, T, K, generator=g, dtype=torch.float64)
+    P = torch.randn((T - 1, K, K) if shared else (B, max(T - 1, 0), K, K), generator=g,
+                    dtype=torch.float64)
+    if K > 2 and T > 1:
+        P[..., 0, 1] = float("-inf")
+    Ud, Pd = U.to(gpu, dtype).contiguous(), P.to(gpu, dtype).contiguous()
+    lz, gu, gp = k.logchain_fwd_bwd(Ud, Pd)
+    rlz, rgu, rgp = ob.logchain_fwd_bwd(U, P)
+    tol = 1e-10 if dtype == torch.float64 else 3e-5
+    torch.testing.assert_close(lz.double().cpu(), rlz, rtol=tol, atol=tol * T)
+    torch.testing.assert_close(gu.double().cpu(), rgu, rtol=tol * 10, atol=tol * 10)
+    torch.testing.assert_close(gp.double().cpu(), rgp, rtol=tol * 10, atol=tol * 10)
+    # posteriors are distributions
+    torch.testing.assert_close(gu.sum(-1), torch.ones_like(gu.sum(-1)), rtol=tol * 100, atol=tol * 100)
+    if T <= 9:                                   # autograd of the plain recursion
+        Ua = U.clone().requires_grad_(True)
+        Pa = (P if not shared else P.expand(B, T - 1, K, K)).clone().requires_grad_(True)
+        a = Ua[:, 0]
+        for t in range(1, T):
+            a = Ua[:, t] + torch.logsumexp(a[:, :, None] + Pa[:, t - 1], dim=1)
+        torch.logsumexp(a, dim=1).sum().backward()
+        torch.testing.assert_close(gu.double().cpu(), Ua.grad, rtol=tol * 10, atol=tol * 10)
+        if T > 1:
+            torch.testing.assert_close(gp.double().cpu(), Pa.grad, rtol=tol * 10, atol=tol * 10)
 
 
 # ---- the reference's hand-vs-auto enumeration KATs (tests/enum_kat_cases.py) on the device -------

@@ -46,9 +46,10 @@ def test_lda_fused_route_with_oracle_kernel(_cpu_backend, monkeypatch):
     ec.run_lda(load("enum"), torch.device("cpu"), monkeypatch, expect_fused=True)
 
 
+@pytest.mark.parametrize("fused_chain", [True, False], ids=["fused_chain", "generic"])
 @pytest.mark.parametrize("which", [1, 3])
-def test_hmm_under_markov_matches_reference(_cpu_backend, which):
-    ec.run_hmm(load("hmm"), torch.device("cpu"), which)
+def test_hmm_under_markov_matches_reference(_cpu_backend, which, fused_chain):
+    ec.run_hmm(load("hmm"), torch.device("cpu"), which, fused_chain=fused_chain)
 
 
 def test_sequential_enumeration_raises(_cpu_backend):
