@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel durations of configs 4 / 5 (developer tool): bash tools/kstats_cfg.sh 5|4|mvn|p1
+# per-kernel durations of configs 4 / 5 (developer tool): bash tools/kstats_cfg.sh 5|4|mvn|p1|hmm
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 C=${1:-5}; OUT=gpurun_out/kstats_cfg$C; rm -rf $OUT; mkdir -p $OUT
@@ -9,7 +9,8 @@ import torch
 from tools import bench_configs as b
 dev=torch.device('cuda:0')
 print({'5': lambda: b.config5(dev, steps=10), '4': lambda: b.config4(dev, steps=5),
-       'mvn': lambda: b.config2_variant(dev, 'mvn', steps=20), 'p1': lambda: b.config2_variant(dev, 'normal', P=1, steps=20)}['$C']())
+       'mvn': lambda: b.config2_variant(dev, 'mvn', steps=20), 'p1': lambda: b.config2_variant(dev, 'normal', P=1, steps=20),
+       'hmm': lambda: b.config_hmm(dev, steps=5, graph=True)}['$C']())
 " > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys, os
