@@ -255,3 +255,42 @@ def run_plating_sums(device):
         pyro.clear_param_store()
         loss = Trace_ELBO(max_plate_nesting=2).loss(model, guide, data)
         np.testing.assert_allclose(loss, -expected.item(), rtol=1e-5)
+
+
+def run_normal_normal(device, elbo_name, reparameterized, n_steps, hip_graph=True):
+    """tests/infer/test_inference.py:55-173 NormalNormalTests.do_elbo_test: conjugate
+    Normal-Normal with known precisions; SVI (Adam lr 0.001) from a perturbed start must reach the
+    analytic posterior (MSE of loc and log sigma < 0.05).  The step runs as a hipGraph replay."""
+    Elbo = ELBOS[elbo_name]
+    lam0, loc0 = _t([0.1, 0.1], device), _t([0.0, 0.5], device)
+    lam = _t([6.0, 4.0], device)
+    data = _t([[-0.1, 0.3], [0.00, 0.4], [0.20, 0.5], [0.10, 0.7]], device)
+    n_data = float(len(data))
+    analytic_lam_n = lam0 + n_data * lam
+    analytic_log_sig_n = -0.5 * torch.log(analytic_lam_n)
+    analytic_loc_n = data.sum(0) * (lam / analytic_lam_n) + loc0 * (lam0 / analytic_lam_n)
+    prior_scale, obs_scale = torch.pow(lam0, -0.5), torch.pow(lam, -0.5)
+    Normal = dist.Normal if reparameterized else NonreparameterizedNormal
+    pyro.clear_param_store()
+
+    def model():
+        loc_latent = pyro.sample("loc_latent", dist.Normal(loc0, prior_scale).to_event(1))
+        with pyro.plate("data", 4):
+            pyro.sample("obs", dist.Normal(loc_latent, obs_scale).to_event(1), obs=data)
+        return loc_latent
+
+    def guide():
+        loc_q = pyro.param("loc_q", lambda: analytic_loc_n.detach() + 0.134)
+        log_sig_q = pyro.param("log_sig_q", lambda: analytic_log_sig_n.detach() - 0.14)
+        pyro.sample("loc_latent", Normal(loc_q, torch.exp(log_sig_q)).to_event(1))
+
+    pyro.set_rng_seed(0)
+    svi = SVI(model, guide, Adam({"lr": 0.001}), loss=Elbo(), hip_graph=hip_graph)
+    for _ in range(n_steps):
+        svi.step()
+    if hip_graph:
+        assert svi.hip_graph and len(svi._graphs) == 1
+    loc_error = float(((pyro.param("loc_q").detach() - analytic_loc_n) ** 2).mean())
+    log_sig_error = float(((pyro.param("log_sig_q").detach() - analytic_log_sig_n) ** 2).mean())
+    assert loc_error < 0.05 and log_sig_error < 0.05, (loc_error, log_sig_error)
+    return loc_error, log_sig_error

@@ -42,3 +42,11 @@ def test_plate_elbo_vectorized_particles(gpu, elbo, reparameterized):
 
 def test_plating_sums(gpu):
     kc.run_plating_sums(gpu)
+
+
+@pytest.mark.parametrize("elbo,reparameterized,n_steps", [("Trace_ELBO", True, 5000),
+                                                          ("TraceMeanField_ELBO", True, 3000),
+                                                          ("Trace_ELBO", False, 15000)],
+                         ids=["reparameterized", "analytic_kl", "nonreparameterized"])
+def test_normal_normal_convergence(gpu, elbo, reparameterized, n_steps):
+    kc.run_normal_normal(gpu, elbo, reparameterized, n_steps)
