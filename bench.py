@@ -285,6 +285,11 @@ def main():
             r1["workload"] = ("BASELINE configs[0]: eight schools, Trace_ELBO, 1 particle, Adam; graphed "
                               "SVI.step (the reference's own CPU-runnable case: ~58 steps/s there)")
             others["config1_eight_schools"] = r1
+            rh = bench_configs.config_hmm(dev, steps=10, graph=True)
+            rh["workload"] = ("examples/hmm.py model_1 at its JSB-chorales size (229 sequences x 129 "
+                              "steps, 16 hidden states, 88 tones), TraceEnum_ELBO under pyro.markov, "
+                              "chain summed out by pa_logchain_fwd_bwd, graphed SVI.step")
+            others["hmm_example"] = rh
             r2m = bench_configs.config2_variant(dev, "mvn")
             r2m["workload"] = ("BASELINE configs[1] with AutoMultivariateNormal (the second guide "
                                "SURVEY 8d names), 64 particles, graphed SVI.step")

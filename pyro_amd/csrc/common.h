@@ -78,6 +78,21 @@ __device__ __forceinline__ T wave_max(T v) {
   return v;
 }
 
+// Sum of doubles over the first ``nw`` waves of the block (all of them take part; any further
+// waves must have left the kernel); result valid in thread 0.
+__device__ __forceinline__ double block_sum_f64_waves(double v, double* smem /* >= nw doubles */,
+                                                      int nw) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) t += smem[i];  // fixed order -> deterministic
+  return t;
+}
+
 // Block-wide sum of doubles for blocks of up to 1024 threads; result valid in thread 0.
 __device__ __forceinline__ double block_sum_f64(double v, double* smem /* >= 16 doubles */) {
   v = wave_sum(v);

@@ -310,7 +310,7 @@ __device__ __forceinline__ void operand_pass(const EntryDev& e, int which, int p
     T acc = T(0);
     for (uint32_t i = t; i < R * C; i += GRAD_THREADS) acc += at(i / C, i % C);
     __syncthreads();
-    const double tot = block_sum_f64((double)acc, red);
+    const double tot = block_sum_f64_waves((double)acc, red, GRAD_THREADS / 64);
     if (t == 0) out[0] = (T)(w * tot);
   }
   __syncthreads();
@@ -370,13 +370,19 @@ __global__ __launch_bounds__(GRAD_THREADS) void multi_grad_kernel(const MultiArg
 // the total right away (Trace_ELBO.loss_and_grads: surrogate.backward() follows the forward
 // immediately, pyro/infer/trace_elbo.py:153-157): workgroups 0..n-1 write the operand gradients
 // for an upstream gradient g (NULL = 1), workgroup n the total.
-template <typename T>
-__global__ __launch_bounds__(GRAD_THREADS) void multi_sum_grad_kernel(
+template <typename T, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void multi_sum_grad_kernel(
     const MultiArgs args_by_value, T* __restrict__ out, const T* __restrict__ g, double coef_all,
     int accumulate) {
   const int n_entries = kernarg_load<int>(offsetof(MultiArgs, n));
-  if ((int)blockIdx.x == n_entries) multi_sum_body<T, GRAD_THREADS>(out, coef_all, accumulate);
-  else multi_grad_body<T>((int)blockIdx.x, g, coef_all);
+  if ((int)blockIdx.x == n_entries) {
+    multi_sum_body<T, NTHREADS>(out, coef_all, accumulate);
+  } else {
+    // the gradient code is written for GRAD_THREADS threads; surplus waves of a wider launch (the
+    // width the total's workgroup wants) leave at once -- they take no part in its barriers
+    if (NTHREADS > GRAD_THREADS && threadIdx.x >= GRAD_THREADS) return;
+    multi_grad_body<T>((int)blockIdx.x, g, coef_all);
+  }
 }
 
 static int to_dev(const pa_site_entry* in, int n, MultiArgs* out, const char* who) {
@@ -606,13 +612,15 @@ int pa_multi_log_prob_sum_grad(int dtype, void* out_total, const void* g,
   if (rc != PA_OK) return rc;
   hipStream_t s = pa::as_stream(stream);
   if (dtype == PA_F32)
-    hipLaunchKernelGGL((pa::multi_sum_grad_kernel<float>), dim3((unsigned)n + 1),
-                       dim3(pa::GRAD_THREADS), 0, s, args, (float*)out_total, (const float*)g,
+    // f32: 16 waves for the total's workgroup (the gradient code fits the 128-VGPR budget of a
+    // 1024-thread launch); f64 gradient code needs more registers: 256-thread launch
+    hipLaunchKernelGGL((pa::multi_sum_grad_kernel<float, pa::MULTI_THREADS>), dim3((unsigned)n + 1),
+                       dim3(pa::MULTI_THREADS), 0, s, args, (float*)out_total, (const float*)g,
                        coef_all, accumulate);
   else
-    hipLaunchKernelGGL((pa::multi_sum_grad_kernel<double>), dim3((unsigned)n + 1),
-                       dim3(pa::GRAD_THREADS), 0, s, args, (double*)out_total, (const double*)g,
-                       coef_all, accumulate);
+    hipLaunchKernelGGL((pa::multi_sum_grad_kernel<double, pa::GRAD_THREADS>),
+                       dim3((unsigned)n + 1), dim3(pa::GRAD_THREADS), 0, s, args,
+                       (double*)out_total, (const double*)g, coef_all, accumulate);
   return pa::check_launch("multi_sum_grad_kernel");
 }
 

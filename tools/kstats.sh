@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 TAG=${1:-k}; OUT=gpurun_out/kstats_$TAG; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o b -- python bench.py --steps 40 --warmup 5 --no-nuts --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o b -- python bench.py --steps 40 --warmup 5 --no-nuts --no-others --no-cpu-baseline > $OUT/bench.log 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/kt/**/*kernel_stats.csv", recursive=True)[0]
