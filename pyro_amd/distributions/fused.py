@@ -393,10 +393,41 @@ def normal_rsample(loc, scale, shape):
 
 
 # ---- many small sites in one launch ---------------------------------------------------------------
+# layout signature of an entry -> its 2-D factorisation: (rows, cols, per-operand (stride_row,
+# stride_col) or None) -- or False for "not an entry".  The factorisation is a pure function of the
+# operands' shapes, strides, dtypes and requires_grad flags, and a model presents the same layouts
+# every step, so the stride analysis (a few dozen microseconds of Python per entry) runs once.
+_FRAME_CACHE = {}
+
+
 def _entry_frame(dist_id, value, p0, p1, mask):
     """2-D strided views of one entry's operands over their broadcast frame, or None when the entry
     cannot go through the multi-site kernel (too large, operands not expressible as strided views,
     mixed dtypes)."""
+    key = tuple(None if t is None else (t.shape, t.stride(), t.dtype, t.requires_grad)
+                for t in (value, p0, p1, mask))
+    hit = _FRAME_CACHE.get(key)
+    if hit is not None:
+        if hit is False:
+            return None
+        rows, cols, strides = hit
+        views = [None if t is None else torch.as_strided(t, (rows, cols), st, t.storage_offset())
+                 for t, st in zip((value, p0, p1, mask), strides)]
+        return (rows, cols) + tuple(views)
+    out = _entry_frame_uncached(dist_id, value, p0, p1, mask)
+    if len(_FRAME_CACHE) < 4096:
+        if out is None:
+            _FRAME_CACHE[key] = False
+        else:
+            rows, cols = out[0], out[1]
+            ok = all(v is None or v.untyped_storage().data_ptr() == t.untyped_storage().data_ptr()
+                     for t, v in zip((value, p0, p1, mask), out[2:]))
+            if ok:       # (a materialised broadcast is a fresh tensor: not a layout property)
+                _FRAME_CACHE[key] = (rows, cols, [None if v is None else v.stride() for v in out[2:]])
+    return out
+
+
+def _entry_frame_uncached(dist_id, value, p0, p1, mask):
     from .. import _lib
     ops = [t for t in (value, p0, p1) if t is not None]
     if any(not t.is_floating_point() or t.dtype != value.dtype for t in ops):
@@ -451,9 +482,10 @@ class _MultiLogProbSum(torch.autograd.Function):
     @staticmethod
     def _entries(meta, tensors, needs):
         entries, i = [], 0
-        for dist_id, nops, mask, coef in meta:
+        for dist_id, nops, mask, coef, fr in meta:
             ops = list(tensors[i:i + nops]) + [None] * (3 - nops)
-            fr = _entry_frame(dist_id, ops[0], ops[1], ops[2], mask)
+            if fr is None:       # not framed when the entry was added (a carrier entry)
+                fr = _entry_frame(dist_id, ops[0], ops[1], ops[2], mask)
             assert fr is not None
             rows, cols, v2, a2, b2, m2 = fr
             e = dict(dist=dist_id, rows=rows, cols=cols, value=v2, p0=a2, p1=b2, mask=m2, coef=coef)
@@ -469,7 +501,7 @@ class _MultiLogProbSum(torch.autograd.Function):
         entries = _MultiLogProbSum._entries(meta, tensors, needs)
         # position of every entry's value among the inputs
         pos, i = [], 0
-        for dist_id, nops, mask, coef in meta:
+        for dist_id, nops, mask, coef, _ in meta:
             pos.append(i)
             i += nops
 
@@ -514,7 +546,7 @@ class _MultiLogProbSum(torch.autograd.Function):
             grads, unit = kernels.multi_log_prob_grad(g, entries, ctx.coef_all, proto.dtype,
                                                       proto.device), True
         out, i = [], 0
-        for (dist_id, nops, mask, coef), gs in zip(ctx.meta, grads):
+        for (dist_id, nops, mask, coef, _), gs in zip(ctx.meta, grads):
             for j in range(nops):
                 t = tensors[i + j]
                 d = None if gs[j] is None else gs[j].reshape(t.shape)
@@ -553,10 +585,14 @@ class SiteBatch:
             mask = mask.bool()
         if not self._compatible(value):
             return False
-        if _entry_frame(dist_id, value, p0, p1, mask) is None:
+        with torch.no_grad():        # the 2-D views are only read for their pointers / strides
+            fr = _entry_frame(dist_id, value, p0, p1, mask)
+        if fr is None:
             return False
         ops = [t for t in (value, p0, p1) if t is not None]
-        self.meta.append((dist_id, len(ops), mask, float(sign) * float(scale)))
+        # the frame travels with the entry: forward and backward reuse it instead of re-deriving
+        # it (three derivations per entry were a third of the eager step's host time)
+        self.meta.append((dist_id, len(ops), mask, float(sign) * float(scale), fr))
         self.tensors.extend(ops)
         return True
 
@@ -568,9 +604,13 @@ class SiteBatch:
             return True
         if not self._compatible(x):
             return False
-        if not x.is_floating_point() or _entry_frame(_lib.SITE_IDENTITY, x, None, None, None) is None:
+        if not x.is_floating_point():
             return False
-        self.meta.append((_lib.SITE_IDENTITY, 1, None, float(sign)))
+        with torch.no_grad():
+            fr = _entry_frame(_lib.SITE_IDENTITY, x, None, None, None)
+        if fr is None:
+            return False
+        self.meta.append((_lib.SITE_IDENTITY, 1, None, float(sign), fr))
         self.tensors.append(x)
         return True
 
@@ -603,14 +643,14 @@ class SiteBatch:
             # the known gradient needs an entry that produces d/dt un-reduced: one scoring t itself
             # (found by identity among the value operands) or a carrier entry added for it
             pos, i = None, 0
-            for dist_id, nops, mask, c in meta:
+            for dist_id, nops, mask, c, _ in meta:
                 if tensors[i] is t:
                     pos = i
                     break
                 i += nops
             if pos is None:
                 pos = len(tensors)
-                meta.append((_lib.SITE_NONE, 1, None, 0.0))
+                meta.append((_lib.SITE_NONE, 1, None, 0.0, None))
                 tensors.append(t)
             extras.append((pos, gt, coef))
         out = _MultiLogProbSum.apply(tuple(meta), tuple(extras), float(coef_all), *tensors)
