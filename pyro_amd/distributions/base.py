@@ -90,12 +90,6 @@ class TorchDistributionMixin:
         return None
 
 
-def _unwrap_independent(fn):
-    while isinstance(fn, torch.distributions.Independent):
-        fn = fn.base_dist
-    return fn
-
-
 class TorchDistribution(torch.distributions.Distribution, TorchDistributionMixin):
     """Base class for distributions implemented directly in this package."""
 

@@ -8,10 +8,6 @@ from torch.distributions import biject_to
 from ...poutine.runtime import Messenger
 
 
-def _is_multivariate(d):
-    return len(d.event_shape) > 0
-
-
 def init_to_feasible(site=None):
     """Initialise to an arbitrary feasible point (0 in unconstrained space), ignoring the
     distribution's parameters."""

@@ -38,12 +38,6 @@ def _ordinal(site):
     return frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
 
 
-def _enum_dims_of(tensor, first_enum_dim):
-    """Tensor dims strictly left of the plate block with size > 1 (negative indices)."""
-    n = tensor.dim()
-    return {d - n for d in range(n) if d - n <= first_enum_dim and tensor.shape[d] > 1}
-
-
 def _packed(site, lp, first_enum_dim):
     """The site's log-probability tensor as a packed, id-named Term."""
     return pack(lp, site["infer"].get("_dim_to_id", {}), -1 - first_enum_dim, _ordinal(site))
