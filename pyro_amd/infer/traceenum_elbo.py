@@ -18,7 +18,7 @@ Scope of this plugin (what BASELINE config 4, examples/lda.py, needs):
     exponential in the number of jointly enumerated guide variables per cost);
   * model enumeration must be no more global than guide enumeration (the reference's
     _check_model_guide_enumeration_constraint, traceenum_elbo.py:50-65).
-Sequential enumeration raises NotImplementedError.
+Sequential enumeration is supported for guide sites (one trace per joint assignment).
 """
 from collections import OrderedDict
 
@@ -72,13 +72,36 @@ def _lazy_gather(site, first_enum_dim):
 
 
 class TraceEnum_ELBO(ELBO):
+    def _get_traces(self, model, guide, args, kwargs):
+        """As ELBO._get_traces; guide sites marked for SEQUENTIAL enumeration multiply the traces:
+        one (model, guide) pair per joint assignment of those sites (pyro/infer/enum.py:88-135),
+        each weighted through the sites' DiCE factors, the estimate is their sum."""
+        self._seq_queue, self._seq_assignment = [], None
+        for pair in super()._get_traces(model, guide, args, kwargs):
+            yield pair
+            queue = self._seq_queue
+            while queue:
+                assignment = queue.pop(0)
+                self._seq_assignment = assignment
+                try:
+                    if self.vectorize_particles:
+                        yield self._get_vectorized_trace(model, guide, args, kwargs)
+                    else:
+                        yield self._get_trace(model, guide, args, kwargs)
+                finally:
+                    self._seq_assignment = None
+
     def _get_trace(self, model, guide, args, kwargs):
         if self.max_plate_nesting == float("inf"):
             self._guess_max_plate_nesting(model, guide, args, kwargs)
         first_enum_dim = -1 - self.max_plate_nesting
         # guide sites enumerate first; the model continues on the dims after them
         # (traceenum_elbo.py:352-360: the two EnumMessengers share the global allocator)
-        guide_enum = poutine.enum(guide, first_available_dim=first_enum_dim)
+        from ..poutine.handlers import SequentialEnumMessenger
+        if getattr(self, "_seq_queue", None) is None:
+            self._seq_queue = []
+        seq = SequentialEnumMessenger(getattr(self, "_seq_assignment", None) or {}, self._seq_queue)
+        guide_enum = poutine.enum(seq(guide), first_available_dim=first_enum_dim)
         guide_trace = poutine.trace(guide_enum).get_trace(*args, **kwargs)
         model_enum = poutine.enum(model)
         model_trace = poutine.trace(poutine.replay(model_enum, trace=guide_trace)).get_trace(
@@ -178,7 +201,10 @@ class TraceEnum_ELBO(ELBO):
         for name, site in guide_trace.nodes.items():
             if site["type"] != "sample":
                 continue
-            enumerated = site["infer"].get("_enumerate_dim") is not None
+            # enumerated in parallel (own tensor dim) or sequentially (one value per trace): the
+            # site's probability itself weights the downstream costs
+            enumerated = site["infer"].get("_enumerate_dim") is not None or \
+                site["infer"].get("_enum_total") is not None
             if enumerated or not getattr(site["fn"], "has_rsample", False):
                 lq = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
                 lq = scale_and_mask(lq, 1.0, site["mask"])     # masked, never scaled

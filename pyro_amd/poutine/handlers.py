@@ -416,9 +416,10 @@ class EnumMessenger(Messenger):
             return
         strategy = msg["infer"].get("enumerate")
         if strategy != "parallel":
-            if strategy == "sequential":
-                raise NotImplementedError("sequential enumeration is not supported by this "
-                                          "backend; use infer={'enumerate': 'parallel'}")
+            if strategy == "sequential" and msg["infer"].get("_enum_total") is None:
+                raise NotImplementedError(
+                    "sequential enumeration is handled by TraceEnum_ELBO for GUIDE sites only "
+                    "(site '{}'); use infer={{'enumerate': 'parallel'}} here".format(msg["name"]))
             return
         dist = msg["fn"]
         if not getattr(dist, "has_enumerate_support", False):
@@ -455,6 +456,37 @@ class EnumMessenger(Messenger):
             dim_to_id.setdefault(d, i)
         self._value_dims[msg["name"]] = {d: i for d, i in dim_to_id.items()
                                          if len(shape) >= -d and shape[d] > 1}
+
+
+class SequentialEnumMessenger(Messenger):
+    """One branch of the sequential enumeration of a program's discrete sites marked
+    infer={"enumerate": "sequential"} (reference: pyro/infer/enum.py:88-135 iter_discrete_traces
+    with poutine.queue / iter_discrete_escape / iter_discrete_extend).  ``assignment`` fixes the
+    support index of the sites already branched on; the first time a further sequential site is
+    met the run continues with its first value and the alternatives are pushed on ``queue`` --
+    every element of the queue is one complete assignment prefix, every run one trace."""
+
+    def __init__(self, assignment, queue):
+        super().__init__()
+        self.assignment, self.queue = dict(assignment), queue
+
+    def _pyro_sample(self, msg):
+        if msg["done"] or msg["is_observed"] or msg["infer"].get("enumerate") != "sequential":
+            return
+        dist = msg["fn"]
+        if not getattr(dist, "has_enumerate_support", False):
+            raise NotImplementedError("{} does not support enumeration".format(type(dist)))
+        support = dist.enumerate_support(expand=True)
+        name = msg["name"]
+        if name not in self.assignment:
+            for k in range(1, support.shape[0]):
+                alt = dict(self.assignment)
+                alt[name] = k
+                self.queue.append(alt)
+            self.assignment[name] = 0
+        msg["infer"]["_enum_total"] = support.shape[0]
+        msg["value"] = support[self.assignment[name]]
+        msg["done"] = True
 
 
 class MarkovMessenger(Messenger):

@@ -146,3 +146,7 @@ def test_elbo_enumerate_plates(gpu, variant, scale):
 
 def test_guide_enumeration_is_the_exact_expectation(gpu):
     ekc.run_guide_enumeration_closed_form(gpu)
+
+
+def test_sequential_guide_enumeration_equals_parallel(gpu):
+    ekc.run_sequential_equals_parallel(gpu)

@@ -52,19 +52,24 @@ def test_hmm_under_markov_matches_reference(_cpu_backend, which, fused_chain):
     ec.run_hmm(load("hmm"), torch.device("cpu"), which, fused_chain=fused_chain)
 
 
-def test_sequential_enumeration_raises(_cpu_backend):
+def test_sequential_enumeration_in_the_model_raises(_cpu_backend):
     import pyro_amd as pyro
     import pyro_amd.distributions as dist
     from pyro_amd.infer import TraceEnum_ELBO
 
     def model():
-        pyro.sample("z", dist.Categorical(torch.ones(3) / 3))
+        pyro.sample("z", dist.Categorical(torch.ones(3) / 3), infer={"enumerate": "sequential"})
 
     def guide():
-        pyro.sample("z", dist.Categorical(torch.ones(3) / 3), infer={"enumerate": "sequential"})
+        pass
 
     with pytest.raises(NotImplementedError):
         TraceEnum_ELBO(max_plate_nesting=0).loss_and_grads(model, guide)
+
+
+def test_sequential_guide_enumeration_equals_parallel(_cpu_backend):
+    from tests import enum_kat_cases
+    enum_kat_cases.run_sequential_equals_parallel(torch.device("cpu"))
 
 
 # ---- the reference's hand-vs-auto enumeration KATs (tests/enum_kat_cases.py) ---------------------
