@@ -26,6 +26,7 @@ class RcclOptimizer:
         self.group = group
         self.average = average
         self._broadcast_done = set()
+        self._avg_op = None            # None: untried, True / False: ReduceOp.AVG (un)available
         if hasattr(pyro_optim, "grad_hook"):
             pyro_optim.grad_hook = self._allreduce_flat
 
@@ -45,6 +46,17 @@ class RcclOptimizer:
     def _allreduce_flat(self, flat_grad):
         if self.world_size == 1:
             return
+        if self.average and self._avg_op is not False:
+            # RCCL averages inside the collective (one launch less on the step's critical path);
+            # backends without ReduceOp.AVG (gloo) refuse synchronously, before anything is queued
+            try:
+                dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.group)
+                self._avg_op = True
+                return
+            except (RuntimeError, ValueError, NotImplementedError):
+                if self._avg_op is True:
+                    raise
+                self._avg_op = False
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
             flat_grad.div_(self.world_size)
