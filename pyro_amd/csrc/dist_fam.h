@@ -35,25 +35,49 @@ template <> __device__ __forceinline__ double t_inf() { return __builtin_huge_va
 // lp(v,a,b) and grad(v,a,b,&dv,&da,&db) = partial derivatives of lp.
 template <int DIST, typename T> struct Fam;
 
+// log and reciprocal of a positive, normal-range parameter (a scale).  f32: v_log_f32 / v_rcp_f32
+// (1 ulp) instead of the library log and the IEEE division sequence -- a large Normal site is
+// VALU-bound with those (2.9 TB/s on [64, 1e6]), HBM-bound without.  f64: library / true division.
+template <typename T> __device__ __forceinline__ T pos_log(T x) { return t_log(x); }
+template <> __device__ __forceinline__ float pos_log(float x) {
+  return 0.69314718055994530942f * __builtin_amdgcn_logf(x);
+}
+template <typename T> __device__ __forceinline__ T pos_rcp(T x) { return T(1) / x; }
+template <> __device__ __forceinline__ float pos_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 template <typename T> struct Fam<PA_DIST_NORMAL, T> {  // a=loc b=scale; torch normal.py:88-103
   static __device__ __forceinline__ T lp(T v, T a, T b) {
-    T d = v - a;
-    return -(d * d) / (T(2) * b * b) - t_log(b) - Consts<T>::half_log_2pi;
+    const T d = (v - a) * pos_rcp(b);
+    return T(-0.5) * d * d - pos_log(b) - Consts<T>::half_log_2pi;
   }
   static __device__ __forceinline__ void grad(T v, T a, T b, T& dv, T& da, T& db) {
-    T d = v - a, iv = T(1) / (b * b);
-    da = d * iv;
+    const T ib = pos_rcp(b), d = (v - a) * ib;
+    da = d * ib;
     dv = -da;
-    db = d * d * iv / b - T(1) / b;
+    db = (d * d - T(1)) * ib;
   }
 };
+// exp(-|a|) and log1p of it.  f32: the hardware exp2 / log2 (v_exp_f32, v_log_f32) -- e in (0, 1]
+// so 1 + e is exact to 6e-8 ABSOLUTE and log2(1 + e) * ln 2 carries that absolute error into a term
+// of size O(1): the same arithmetic as the fused GLM kernels (glm.hip), 3x fewer instructions than
+// the library expf / log1pf on a site of 6.4e7 elements (which is VALU-bound, not HBM-bound, with
+// the library calls).  f64 keeps the library functions.
+template <typename T> __device__ __forceinline__ T exp_neg_abs(T a) { return t_exp(-t_abs(a)); }
+template <> __device__ __forceinline__ float exp_neg_abs(float a) {
+  return __builtin_amdgcn_exp2f(-1.44269504088896340736f * fabsf(a));
+}
+template <typename T> __device__ __forceinline__ T log1p_unit(T e) { return t_log1p(e); }
+template <> __device__ __forceinline__ float log1p_unit(float e) {
+  return 0.69314718055994530942f * __builtin_amdgcn_logf(1.0f + e);
+}
+
 template <typename T> struct Fam<PA_DIST_BERNOULLI_LOGITS, T> {  // a=logits; bernoulli.py:121-125
   static __device__ __forceinline__ T lp(T v, T a, T) {
     // -BCEWithLogits(a, v) = v*a - softplus(a), softplus(a) = max(a,0) + log1p(exp(-|a|))
-    return v * a - ((a > T(0) ? a : T(0)) + t_log1p(t_exp(-t_abs(a))));
+    return v * a - ((a > T(0) ? a : T(0)) + log1p_unit(exp_neg_abs(a)));
   }
   static __device__ __forceinline__ void grad(T v, T a, T, T& dv, T& da, T& db) {
-    T e = t_exp(-t_abs(a));
+    T e = exp_neg_abs(a);
     T sig = a >= T(0) ? T(1) / (T(1) + e) : e / (T(1) + e);
     da = v - sig;
     dv = a;
