@@ -290,6 +290,11 @@ def main():
                               "steps, 16 hidden states, 88 tones), TraceEnum_ELBO under pyro.markov, "
                               "chain summed out by pa_logchain_fwd_bwd, graphed SVI.step")
             others["hmm_example"] = rh
+            rv = bench_configs.config_hmm_vectorised(dev)
+            rv["workload"] = ("the same HMM likelihood with time vectorised in one DiscreteHMM site "
+                              "(examples/hmm.py model_7's construction): one pa_logchain_fwd_bwd launch "
+                              "for all sequences, graphed SVI.step")
+            others["hmm_example_vectorised"] = rv
             r2m = bench_configs.config2_variant(dev, "mvn")
             r2m["workload"] = ("BASELINE configs[1] with AutoMultivariateNormal (the second guide "
                                "SURVEY 8d names), 64 particles, graphed SVI.step")

@@ -106,3 +106,4 @@ class Independent(torch.distributions.Independent, TorchDistributionMixin):
             mask = mask.reshape(mask.shape + (1,) * self.reinterpreted_batch_ndims)
         f = getattr(self.base_dist, "fused_site_entry", None)
         return None if f is None else f(value, scale, mask)
+from .hmm import DiscreteHMM  # noqa: E402,F401

@@ -211,6 +211,30 @@ def hmm_model_1(sequences, lengths, hidden_dim=16):
                            obs=sequences[:, t])
 
 
+def hmm_model_vectorised(sequences, lengths, hidden_dim=16):
+    """The same likelihood with time vectorised (examples/hmm.py:580-611 model_7's construction):
+    one DiscreteHMM site per sequence batch, ragged lengths through a masked observation
+    distribution -- the whole marginal likelihood is one forward-backward launch."""
+    from .distributions import constraints
+    from .primitives import param
+    S, L, D = sequences.shape
+    dev = sequences.device
+    probs_x = param("probs_x", lambda: torch.softmax(torch.randn(hidden_dim, hidden_dim, device=dev), -1),
+                    constraint=constraints.simplex)
+    probs_y = param("probs_y", lambda: torch.rand(hidden_dim, D, device=dev) * 0.8 + 0.1,
+                    constraint=constraints.unit_interval)
+    with plate("sequences", S, dim=-1):
+        t = torch.arange(L, device=dev)
+        # the chain starts in state 0 (built on the device: a host-side element assignment would
+        # be a host-to-device copy, which a captured step cannot contain)
+        init_logits = torch.zeros(hidden_dim, device=dev, dtype=probs_x.dtype).masked_fill(
+            torch.arange(hidden_dim, device=dev) > 0, -float("inf"))
+        obs_dist = dist.Bernoulli(probs_y).to_event(1)                    # batch [K]
+        obs_dist = obs_dist.mask((t < lengths.unsqueeze(-1)).unsqueeze(-1))   # batch [S, L, K]
+        hmm = dist.DiscreteHMM(init_logits, probs_x.log(), obs_dist)
+        sample("y", hmm, obs=sequences)
+
+
 def synthetic_hmm_data(S, L, D, device, seed=0):
     g = torch.Generator(device=device).manual_seed(seed)
     seqs = (torch.rand((S, L, D), device=device, generator=g) < 0.3).float()

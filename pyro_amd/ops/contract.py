@@ -121,12 +121,17 @@ class _LogChain(torch.autograd.Function):
     def forward(ctx, unary, pairwise):
         log_z, g_u, g_p = kernels.logchain_fwd_bwd(unary, pairwise)
         ctx.save_for_backward(g_u, g_p)
+        ctx.pair_shape = pairwise.shape
         return log_z
 
     @staticmethod
     def backward(ctx, g):
+        from ..distributions.fused import _sum_to
         g_u, g_p = ctx.saved_tensors
-        return g.reshape(-1, 1, 1) * g_u, g.reshape(-1, 1, 1, 1) * g_p
+        d_pair = g.reshape(-1, 1, 1, 1) * g_p
+        if len(ctx.pair_shape) < 4:       # potentials shared by the batch (and by the steps)
+            d_pair = _sum_to(d_pair, d_pair.new_empty(ctx.pair_shape))
+        return g.reshape(-1, 1, 1) * g_u, d_pair
 
 
 def _try_fused_chain(terms, sum_ids):

@@ -804,9 +804,52 @@ def g_hmm():
     save("hmm", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# G12: pyro.distributions.DiscreteHMM.log_prob (pyro/distributions/hmm.py:243-369) and its
+#      gradients: heterogeneous (per-step, per-batch) and homogeneous (shared) parameters,
+#      Normal and multi-dimensional Bernoulli observations, data longer than the parameters' time
+#      axis in the homogeneous case.
+# ---------------------------------------------------------------------------------------------
+def g_discrete_hmm():
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(31)
+    flat = {}
+    K, T, B, D = 4, 7, 3, 5
+    cases = {
+        "hetero": dict(init=rng.standard_normal((B, K)), trans=rng.standard_normal((B, T, K, K)),
+                       loc=rng.standard_normal((B, T, K)), value=rng.standard_normal((B, T))),
+        "homog": dict(init=rng.standard_normal((K,)), trans=rng.standard_normal((1, K, K)),
+                      loc=rng.standard_normal((1, K)), value=rng.standard_normal((B, T))),
+        "steps": dict(init=rng.standard_normal((K,)), trans=rng.standard_normal((T, K, K)),
+                      loc=rng.standard_normal((T, K)), value=rng.standard_normal((B, T))),
+    }
+    for tag, c in cases.items():
+        init, trans, loc = (torch.tensor(c[k], requires_grad=True) for k in ("init", "trans", "loc"))
+        d = dist.DiscreteHMM(init, trans, dist.Normal(loc, 0.7))
+        lp = d.log_prob(torch.tensor(c["value"]))
+        lp.sum().backward()
+        flat.update({tag + "/" + k: v for k, v in c.items()})
+        flat[tag + "/log_prob"] = lp.detach().numpy()
+        flat[tag + "/g_init"], flat[tag + "/g_trans"], flat[tag + "/g_loc"] = (
+            init.grad.numpy(), trans.grad.numpy(), loc.grad.numpy())
+    # Bernoulli emissions with an event dim (the hmm.py example: tones)
+    init = torch.tensor(rng.standard_normal((K,)), requires_grad=True)
+    trans = torch.tensor(rng.standard_normal((1, K, K)), requires_grad=True)
+    py = torch.tensor(rng.uniform(0.1, 0.9, (K, D)), requires_grad=True)
+    value = torch.tensor((rng.uniform(size=(B, T, D)) < 0.4).astype(np.float64))
+    d = dist.DiscreteHMM(init, trans, dist.Bernoulli(py).to_event(1))
+    lp = d.log_prob(value)
+    lp.sum().backward()
+    flat.update({"bern/init": init.detach().numpy(), "bern/trans": trans.detach().numpy(),
+                 "bern/probs": py.detach().numpy(), "bern/value": value.numpy(),
+                 "bern/log_prob": lp.detach().numpy(), "bern/g_init": init.grad.numpy(),
+                 "bern/g_trans": trans.grad.numpy(), "bern/g_probs": py.grad.numpy()})
+    save("discrete_hmm", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm"]
     for w in which:
         globals()["g_" + w]()
 

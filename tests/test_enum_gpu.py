@@ -150,3 +150,12 @@ def test_guide_enumeration_is_the_exact_expectation(gpu):
 
 def test_sequential_guide_enumeration_equals_parallel(gpu):
     ekc.run_sequential_equals_parallel(gpu)
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-5)])
+def test_discrete_hmm_matches_reference(gpu, dtype, rtol):
+    ec.run_discrete_hmm(load("discrete_hmm"), gpu, dtype=dtype, rtol=rtol)
+
+
+def test_hmm_vectorised_over_time_equals_markov_model(gpu):
+    ec.run_hmm_vectorised_equals_markov(gpu)

@@ -52,6 +52,14 @@ def test_hmm_under_markov_matches_reference(_cpu_backend, which, fused_chain):
     ec.run_hmm(load("hmm"), torch.device("cpu"), which, fused_chain=fused_chain)
 
 
+def test_discrete_hmm_matches_reference(_cpu_backend):
+    ec.run_discrete_hmm(load("discrete_hmm"), torch.device("cpu"))
+
+
+def test_hmm_vectorised_over_time_equals_markov_model(_cpu_backend):
+    ec.run_hmm_vectorised_equals_markov(torch.device("cpu"))
+
+
 def test_sequential_enumeration_in_the_model_raises(_cpu_backend):
     import pyro_amd as pyro
     import pyro_amd.distributions as dist

@@ -89,6 +89,22 @@ def config1(dev, steps=300, graph=True):
             "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1)}
 
 
+def config_hmm_vectorised(dev, S=229, L=129, K=16, D=88, steps=50, graph=True):
+    """The same HMM likelihood with time vectorised in one DiscreteHMM site (examples/hmm.py
+    model_7's construction): observation log-probabilities for all steps at once, the chain summed
+    out by one pa_logchain_fwd_bwd launch."""
+    seqs, lengths = examples.synthetic_hmm_data(S, L, D, dev)
+    pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
+    model = lambda s, l: examples.hmm_model_vectorised(s, l, K)      # noqa: E731
+    svi = SVI(model, lambda s, l: None, pyro.optim.Adam({"lr": 0.05}),
+              TraceEnum_ELBO(max_plate_nesting=1), hip_graph=graph, graph_warmup=2)
+    l0 = svi.step(seqs, lengths)
+    dt = timed(lambda: svi.step(seqs, lengths), steps, 3)
+    l1 = svi.step(seqs, lengths)
+    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "loss_first": l0, "loss_last": l1,
+            "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1)}
+
+
 def config_hmm(dev, S=229, L=129, K=16, D=88, steps=5, fused=True, graph=False):
     """examples/hmm.py model_1 at the size of its JSB-chorales default (229 sequences, up to 129
     steps, 16 hidden states, 88 tones), TraceEnum_ELBO, Adam: the chain elimination is one
@@ -131,6 +147,8 @@ if __name__ == "__main__":
     print("hmm (229 x 129 x 16 states), fused chain:", config_hmm(dev))
     print("hmm, generic elimination:", config_hmm(dev, steps=2, fused=False))
     print("hmm, fused chain, graphed step:", config_hmm(dev, steps=10, graph=True))
+    print("hmm, time vectorised (DiscreteHMM), graphed:", config_hmm_vectorised(dev))
+    print("hmm, time vectorised (DiscreteHMM), eager:", config_hmm_vectorised(dev, steps=20, graph=False))
     print("config 1 (eight schools):", config1(dev))
     print("config 1 eager:", config1(dev, steps=100, graph=False))
     print("config 2, AutoMultivariateNormal:", config2_variant(dev, "mvn"))
