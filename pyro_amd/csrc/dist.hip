@@ -14,16 +14,39 @@ constexpr int DIST_THREADS = 256;
 constexpr int DIST_ITEMS = 4;
 
 // ---- kernels ----------------------------------------------------------------------------------
+// Element-wise kernels: a workgroup covers RPB = 256 / TC rows x (TC * ITEMS) columns, TC = the
+// power of two >= cols / ITEMS (capped at 256): long rows get one row per workgroup and 1024 columns
+// per chunk, short rows (a [S*T*K, 88] emission table) share a workgroup instead of leaving most of
+// its threads idle behind a one-row-per-workgroup grid.
+struct ElemGeom {
+  int tc;            // threads along the columns (power of two)
+  int64_t bx;        // column chunks per row block
+  int64_t grid;
+};
+static inline ElemGeom elem_geom(int64_t rows, int64_t cols) {
+  int64_t want = (cols + DIST_ITEMS - 1) / DIST_ITEMS;
+  int tc = 1;
+  while (tc < DIST_THREADS && tc < want) tc *= 2;
+  ElemGeom g;
+  g.tc = tc;
+  g.bx = (cols + (int64_t)tc * DIST_ITEMS - 1) / ((int64_t)tc * DIST_ITEMS);
+  const int64_t rpb = DIST_THREADS / tc;
+  g.grid = ((rows + rpb - 1) / rpb) * g.bx;
+  return g;
+}
+
 template <int DIST, typename T>
 __global__ __launch_bounds__(DIST_THREADS) void log_prob_kernel(T* __restrict__ out, ViewT<T> v,
                                                                 ViewT<T> a, ViewT<T> b,
                                                                 int64_t rows, int64_t cols,
-                                                                int64_t bx) {
-  const int64_t row = blockIdx.x / bx, chunk = blockIdx.x % bx;
-  const int64_t c0 = chunk * (DIST_THREADS * DIST_ITEMS) + threadIdx.x;
+                                                                int64_t bx, int tc) {
+  const int rpb = DIST_THREADS / tc;
+  const int64_t row = (blockIdx.x / bx) * rpb + threadIdx.x / tc, chunk = blockIdx.x % bx;
+  if (row >= rows) return;
+  const int64_t c0 = chunk * ((int64_t)tc * DIST_ITEMS) + threadIdx.x % tc;
 #pragma unroll
   for (int k = 0; k < DIST_ITEMS; ++k) {
-    const int64_t c = c0 + k * DIST_THREADS;
+    const int64_t c = c0 + (int64_t)k * tc;
     if (c < cols) {
       T bb = NParams<DIST>::n > 1 ? b.at(row, c) : T(0);
       out[row * cols + c] = Fam<DIST, T>::lp(v.at(row, c), a.at(row, c), bb);
@@ -114,12 +137,14 @@ __global__ __launch_bounds__(256) void rowsum_finalize_kernel(T* __restrict__ ou
 template <int DIST, typename T>
 __global__ __launch_bounds__(DIST_THREADS) void log_prob_grad_kernel(
     T* __restrict__ dv, T* __restrict__ da, T* __restrict__ db, ViewT<T> g, ViewT<T> v, ViewT<T> a,
-    ViewT<T> b, ViewT<uint8_t> m, T scale, int64_t rows, int64_t cols, int64_t bx) {
-  const int64_t row = blockIdx.x / bx, chunk = blockIdx.x % bx;
-  const int64_t c0 = chunk * (DIST_THREADS * DIST_ITEMS) + threadIdx.x;
+    ViewT<T> b, ViewT<uint8_t> m, T scale, int64_t rows, int64_t cols, int64_t bx, int tc) {
+  const int rpb = DIST_THREADS / tc;
+  const int64_t row = (blockIdx.x / bx) * rpb + threadIdx.x / tc, chunk = blockIdx.x % bx;
+  if (row >= rows) return;
+  const int64_t c0 = chunk * ((int64_t)tc * DIST_ITEMS) + threadIdx.x % tc;
 #pragma unroll
   for (int k = 0; k < DIST_ITEMS; ++k) {
-    const int64_t c = c0 + k * DIST_THREADS;
+    const int64_t c = c0 + (int64_t)k * tc;
     if (c < cols) {
       T bb = NParams<DIST>::n > 1 ? b.at(row, c) : T(0);
       T gv, ga, gb;
@@ -182,12 +207,13 @@ static inline int64_t sum_bx(int64_t rows, int64_t cols) {
 template <typename T>
 static int log_prob_t(int dist, T* out, pa_view2d value, pa_view2d p0, pa_view2d p1, int64_t rows,
                       int64_t cols, hipStream_t s) {
-  const int64_t bx = chunks_of(cols);
-  PA_REQUIRE(rows * bx < (int64_t(1) << 31), "log_prob: grid too large");
+  const ElemGeom gm = elem_geom(rows, cols);
+  PA_REQUIRE(gm.grid < (int64_t(1) << 31), "log_prob: grid too large");
   auto v = as_view<T>(value), a = as_view<T>(p0), b = as_view<T>(p1);
   PA_DISPATCH_DIST(dist, T,
-                   hipLaunchKernelGGL((log_prob_kernel<D_, T>), dim3((unsigned)(rows * bx)),
-                                      dim3(DIST_THREADS), 0, s, out, v, a, b, rows, cols, bx));
+                   hipLaunchKernelGGL((log_prob_kernel<D_, T>), dim3((unsigned)gm.grid),
+                                      dim3(DIST_THREADS), 0, s, out, v, a, b, rows, cols, gm.bx,
+                                      gm.tc));
   return check_launch("log_prob_kernel");
 }
 
@@ -230,14 +256,14 @@ template <typename T>
 static int log_prob_grad_t(int dist, T* dv, T* da, T* db, pa_view2d g, pa_view2d value,
                            pa_view2d p0, pa_view2d p1, pa_view2d mask, double scale, int64_t rows,
                            int64_t cols, hipStream_t s) {
-  const int64_t bx = chunks_of(cols);
-  PA_REQUIRE(rows * bx < (int64_t(1) << 31), "log_prob_grad: grid too large");
+  const ElemGeom gm = elem_geom(rows, cols);
+  PA_REQUIRE(gm.grid < (int64_t(1) << 31), "log_prob_grad: grid too large");
   auto gg = as_view<T>(g), v = as_view<T>(value), a = as_view<T>(p0), b = as_view<T>(p1);
   auto m = as_view<uint8_t>(mask);
   PA_DISPATCH_DIST(dist, T,
-                   hipLaunchKernelGGL((log_prob_grad_kernel<D_, T>), dim3((unsigned)(rows * bx)),
+                   hipLaunchKernelGGL((log_prob_grad_kernel<D_, T>), dim3((unsigned)gm.grid),
                                       dim3(DIST_THREADS), 0, s, dv, da, db, gg, v, a, b, m,
-                                      (T)scale, rows, cols, bx));
+                                      (T)scale, rows, cols, gm.bx, gm.tc));
   return check_launch("log_prob_grad_kernel");
 }
 

@@ -10,7 +10,8 @@ from tools import bench_configs as b
 dev=torch.device('cuda:0')
 print({'5': lambda: b.config5(dev, steps=10), '4': lambda: b.config4(dev, steps=5),
        'mvn': lambda: b.config2_variant(dev, 'mvn', steps=20), 'p1': lambda: b.config2_variant(dev, 'normal', P=1, steps=20),
-       'hmm': lambda: b.config_hmm(dev, steps=5, graph=True)}['$C']())
+       'hmm': lambda: b.config_hmm(dev, steps=5, graph=True),
+       'hmmv': lambda: b.config_hmm_vectorised(dev, steps=10)}['$C']())
 " > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys, os
