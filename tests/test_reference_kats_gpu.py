@@ -20,8 +20,6 @@ def test_particle_gradient(gpu, elbo, reparameterized, has_rsample):
 @pytest.mark.parametrize("subsample", [False, True], ids=["full", "subsample"])
 @pytest.mark.parametrize("elbo", ["Trace_ELBO", "DiffTrace_ELBO", "TraceMeanField_ELBO", "TraceEnum_ELBO"])
 def test_subsample_gradient(gpu, elbo, reparameterized, has_rsample, subsample, scale):
-    if elbo == "DiffTrace_ELBO":
-        pytest.skip("SVI(loss=callable) without loss_and_grads: covered by Trace_ELBO here")
     try:
         kc.run_subsample_gradient(gpu, elbo, reparameterized, has_rsample, subsample, scale)
     except NotImplementedError as e:       # the reference test: `with xfail_if_not_implemented()`

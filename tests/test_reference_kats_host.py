@@ -25,7 +25,7 @@ def test_particle_gradient(elbo, reparameterized, has_rsample):
 @pytest.mark.parametrize("reparameterized,has_rsample", [(True, None), (False, None)],
                          ids=["reparam", "nonreparam"])
 @pytest.mark.parametrize("subsample", [False, True], ids=["full", "subsample"])
-@pytest.mark.parametrize("elbo", ["Trace_ELBO", "TraceMeanField_ELBO"])
+@pytest.mark.parametrize("elbo", ["Trace_ELBO", "DiffTrace_ELBO", "TraceMeanField_ELBO"])
 def test_subsample_gradient(elbo, reparameterized, has_rsample, subsample, scale):
     try:
         kc.run_subsample_gradient(CPU, elbo, reparameterized, has_rsample, subsample, scale)
