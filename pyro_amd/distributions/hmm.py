@@ -76,10 +76,13 @@ class DiscreteHMM(TorchDistribution):
         if trans.shape[-3] not in (1, T):
             raise ValueError("transition_logits has {} time steps, the data {}".format(
                 trans.shape[-3], T))
-        fused = K <= 64 and obs_logits.dtype in (torch.float32, torch.float64) and \
-            (obs_logits.is_cuda or kernels.HOST_TEST_BACKEND)
+        if not (obs_logits.is_cuda or kernels.HOST_TEST_BACKEND):
+            raise RuntimeError("pyro_amd: DiscreteHMM.log_prob needs device tensors (there is no "
+                               "CPU implementation in this package)")
+        fused = K <= 64 and obs_logits.dtype in (torch.float32, torch.float64)
         if not fused:
-            # plain forward recursion (more than 64 states, or tensors the kernels do not take)
+            # more than 64 states (or a dtype the kernel does not take): the forward recursion
+            # step by step with device tensor ops
             a = init
             for t in range(T):
                 tr = trans[..., t if trans.shape[-3] > 1 else 0, :, :]
