@@ -286,3 +286,44 @@ def run_sequential_equals_parallel(device):
             continue
         loss = elbo.differentiable_loss(model, make_guide(how_a, how_b))
         _check_loss_and_grads(ref, loss)
+
+
+def run_markov_history(device, history, T=5, K=2):
+    """pyro.markov(history=h): x_t depends on the previous h states; the loss of the enumerated
+    model equals the brute-force sum over all K^T joint assignments (the reference's
+    tests/infer/test_enum.py markov tests compare against hand-unrolled models the same way), and
+    no more than h + 1 enumeration dims are ever in use."""
+    import itertools
+    torch.manual_seed(history)
+    init = torch.softmax(torch.randn(K), -1).to(device)
+    # transition table indexed by the previous `history` states
+    trans = torch.softmax(torch.randn((K,) * history + (K,)), -1).to(device)
+    emit = torch.softmax(torch.randn(K, 3), -1).to(device)
+    data = torch.randint(0, 3, (T,)).to(device)
+
+    def model():
+        xs = []
+        for t in pyro.markov(range(T), history=history):
+            if t < history:
+                probs = init
+            else:
+                probs = trans[tuple(xs[t - history:t])]
+            x = pyro.sample("x_{}".format(t), dist.Categorical(probs), infer=PAR)
+            pyro.sample("y_{}".format(t), dist.Categorical(emit[x]), obs=data[t])
+            xs.append(x)
+
+    pyro.clear_param_store()
+    elbo = TraceEnum_ELBO(max_plate_nesting=0)
+    loss = elbo.differentiable_loss(model, lambda: None)
+    total = torch.zeros((), dtype=init.dtype, device=device)
+    for assign in itertools.product(range(K), repeat=T):
+        p = torch.ones((), dtype=init.dtype, device=device)
+        for t, x in enumerate(assign):
+            p = p * (init[x] if t < history else trans[tuple(assign[t - history:t]) + (x,)])
+            p = p * emit[x, data[t]]
+        total = total + p
+    torch.testing.assert_close(loss, -total.log(), rtol=1e-5, atol=1e-6)
+    tr = poutine.trace(poutine.enum(model, first_available_dim=-1)).get_trace()
+    dims = {s["infer"]["_enumerate_dim"] for s in tr.nodes.values()
+            if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None}
+    assert len(dims) == history + 1, dims

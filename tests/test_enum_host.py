@@ -106,5 +106,10 @@ def test_elbo_enumerate_plates(_cpu_backend, variant, scale):
     ekc.run_enumerate_plates(CPU, variant, scale)
 
 
+@pytest.mark.parametrize("history", [1, 2, 3])
+def test_markov_history_equals_brute_force(_cpu_backend, history):
+    ekc.run_markov_history(CPU, history)
+
+
 def test_guide_enumeration_is_the_exact_expectation(_cpu_backend):
     ekc.run_guide_enumeration_closed_form(CPU)
