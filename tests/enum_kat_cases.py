@@ -327,3 +327,45 @@ def run_markov_history(device, history, T=5, K=2):
     dims = {s["infer"]["_enumerate_dim"] for s in tr.nodes.values()
             if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None}
     assert len(dims) == history + 1, dims
+
+
+def run_guide_side_markov(device, T=4, K=2):
+    """A Markov chain enumerated in the GUIDE (config_enumerate) under pyro.markov: the ELBO is the
+    exact expectation sum_x q(x) [log p(x, y) - log q(x)] over all K^T paths, although the program
+    only ever used two enumeration dims."""
+    import itertools
+    torch.manual_seed(11)
+    trans = torch.softmax(torch.randn(K, K), -1).to(device)
+    emit = torch.softmax(torch.randn(K, 3), -1).to(device)
+    data = torch.randint(0, 3, (T,)).to(device)
+    q0 = torch.softmax(torch.randn(K, K), -1).to(device)
+
+    def model():
+        x = 0
+        for t in pyro.markov(range(T)):
+            x = pyro.sample("x_{}".format(t), dist.Categorical(trans[x]))
+            pyro.sample("y_{}".format(t), dist.Categorical(emit[x]), obs=data[t])
+
+    @config_enumerate
+    def guide():
+        q = pyro.param("q", q0, constraint=constraints.simplex)
+        x = 0
+        for t in pyro.markov(range(T)):
+            x = pyro.sample("x_{}".format(t), dist.Categorical(q[x]))
+
+    pyro.clear_param_store()
+    loss = TraceEnum_ELBO(max_plate_nesting=0).differentiable_loss(model, guide)
+    q = pyro.param("q")
+    total = 0.0
+    for path in itertools.product(range(K), repeat=T):
+        lq, lp, prev = 0.0, 0.0, 0
+        for t, x in enumerate(path):
+            lq = lq + q[prev, x].log()
+            lp = lp + trans[prev, x].log() + emit[x, data[t]].log()
+            prev = x
+        total = total + lq.exp() * (lp - lq)
+    torch.testing.assert_close(loss, -total, rtol=1e-5, atol=1e-6)
+    u = q.unconstrained()
+    ga, = grad(loss, [u], retain_graph=True)
+    ge, = grad(-total, [u])
+    torch.testing.assert_close(ga, ge, rtol=1e-4, atol=1e-6)

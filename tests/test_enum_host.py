@@ -111,5 +111,9 @@ def test_markov_history_equals_brute_force(_cpu_backend, history):
     ekc.run_markov_history(CPU, history)
 
 
+def test_guide_side_markov_enumeration_is_exact(_cpu_backend):
+    ekc.run_guide_side_markov(CPU)
+
+
 def test_guide_enumeration_is_the_exact_expectation(_cpu_backend):
     ekc.run_guide_enumeration_closed_form(CPU)
