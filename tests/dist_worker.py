@@ -74,3 +74,45 @@ def mcmc_worker(rank, world, port, out_path, Lam, z0, num_chains, n_samples):
                out_path % rank)
     if world > 1:
         dist.destroy_process_group()
+
+
+def data_sharded_worker(rank, world, port, out_path, bank, X, y, steps):
+    """Data-sharded SVI (SURVEY 8e variant 2): every rank scores ITS rows of the plate, scaled to
+    the full plate (plate(N, subsample=rows of this rank)), with the same particles everywhere;
+    the mean of the per-rank gradients is the full-data gradient.  The optimizer is a generic
+    per-parameter one (TorchAdam), so RcclOptimizer takes its pack -> all-reduce -> unpack route."""
+    _setup(rank, world, port)
+    import pyro_amd as pyro
+    import pyro_amd.distributions as pdist
+    from pyro_amd import rng
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    from tests import models
+
+    Xt, yt = torch.tensor(X), torch.tensor(y)
+    N, D = Xt.shape
+    rows = torch.arange(N)[rank::world]
+
+    def model(Xs, ys, idx):
+        w = pyro.sample("w", pdist.Normal(torch.zeros(D), 1.0).to_event(1))
+        b = pyro.sample("b", pdist.Normal(torch.zeros(()), 1.0))
+        with pyro.plate("data", N, subsample=idx):
+            logits = (w @ Xs.t()).squeeze(-2) if w.dim() > 1 else w @ Xs.t()
+            pyro.sample("obs", pdist.Bernoulli(logits=logits + b), obs=ys)
+
+    P = bank[0].shape[0]
+    pyro.clear_param_store()
+    pyro.set_rng_seed(7)
+    guide = AutoNormal(model, init_scale=0.1)
+    guide._setup_prototype(Xt[rows], yt[rows], rows)
+    rng.normal = models.EpsReplay(bank, torch.device("cpu"))
+    optim = pyro.optim.TorchAdam({"lr": 0.05})
+    if world > 1:
+        optim = pyro.optim.RcclOptimizer(optim)
+    svi = SVI(model, guide, optim, Trace_ELBO(num_particles=P, vectorize_particles=True,
+                                              max_plate_nesting=1))
+    losses = [svi.step(Xt[rows], yt[rows], rows) for _ in range(steps)]
+    params = {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
+    torch.save({"losses": losses, "params": params}, out_path % rank)
+    if world > 1:
+        dist.destroy_process_group()

@@ -72,3 +72,21 @@ def test_chain_sharded_mcmc_reproduces_single_process_chains(tmp_path):
     assert two[0]["x"].shape == (C, S, D)
     torch.testing.assert_close(two[0]["x"], two[1]["x"], rtol=0, atol=0)      # all_gather
     torch.testing.assert_close(two[0]["x"], one[0]["x"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.timeout(600)
+def test_data_sharded_svi_equals_single_process(tmp_path):
+    """2 ranks x half of the plate's rows (scaled to the full plate), same particles, generic
+    per-parameter optimizer behind RcclOptimizer == 1 process with all rows."""
+    g = np.random.default_rng(3)
+    N, D, P, steps = 120, 4, 3, 3
+    X = g.standard_normal((N, D))
+    y = (g.uniform(size=N) < 0.5).astype(np.float64)
+    bank = []
+    for _ in range(steps):
+        bank += [g.standard_normal((P, 1, D)), g.standard_normal((P, 1))]
+    two = _run(dw.data_sharded_worker, 2, (bank, X, y, steps), tmp_path, "ds2")
+    one = _run(dw.data_sharded_worker, 1, (bank, X, y, steps), tmp_path, "ds1")
+    for k in two[0]["params"]:
+        torch.testing.assert_close(two[0]["params"][k], two[1]["params"][k], rtol=0, atol=0)
+        torch.testing.assert_close(two[0]["params"][k], one[0]["params"][k], rtol=1e-9, atol=1e-11)
