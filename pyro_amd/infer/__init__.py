@@ -3,6 +3,7 @@ from .enum import config_enumerate  # noqa: F401
 from .svi import SVI  # noqa: F401
 from .trace_elbo import Trace_ELBO  # noqa: F401
 from .traceenum_elbo import TraceEnum_ELBO  # noqa: F401
+from .tracegraph_elbo import TraceGraph_ELBO  # noqa: F401
 from .trace_mean_field_elbo import TraceMeanField_ELBO  # noqa: F401
 from .predictive import Predictive  # noqa: F401
 from .mcmc import HMC, MCMC, NUTS  # noqa: F401

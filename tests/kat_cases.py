@@ -11,7 +11,7 @@ import torch
 import pyro_amd as pyro
 import pyro_amd.distributions as dist
 import pyro_amd.poutine as poutine
-from pyro_amd.infer import SVI, Trace_ELBO, TraceEnum_ELBO, TraceMeanField_ELBO
+from pyro_amd.infer import SVI, Trace_ELBO, TraceEnum_ELBO, TraceGraph_ELBO, TraceMeanField_ELBO
 from pyro_amd.optim import Adam
 
 
@@ -23,7 +23,7 @@ def DiffTrace_ELBO(*args, **kwargs):
     return Trace_ELBO(*args, **kwargs).differentiable_loss
 
 
-ELBOS = {"Trace_ELBO": Trace_ELBO, "TraceEnum_ELBO": TraceEnum_ELBO,
+ELBOS = {"Trace_ELBO": Trace_ELBO, "TraceEnum_ELBO": TraceEnum_ELBO, "TraceGraph_ELBO": TraceGraph_ELBO,
          "TraceMeanField_ELBO": TraceMeanField_ELBO, "DiffTrace_ELBO": DiffTrace_ELBO}
 
 
@@ -294,3 +294,47 @@ def run_normal_normal(device, elbo_name, reparameterized, n_steps, hip_graph=Tru
     log_sig_error = float(((pyro.param("log_sig_q").detach() - analytic_log_sig_n) ** 2).mean())
     assert loc_error < 0.05 and log_sig_error < 0.05, (loc_error, log_sig_error)
     return loc_error, log_sig_error
+
+
+def run_tracegraph_normal_normal(device, reparameterized, n_steps, prec, baseline=None, lr=0.0015):
+    """tests/integration_tests/test_tracegraph_elbo.py:25-105 NormalNormalTests.do_elbo_test:
+    TraceGraph_ELBO on the conjugate Normal-Normal model with the latent inside a plate and the
+    observations in a Python loop; Adam(lr 0.0015, betas (0.97, 0.999)); the guide must reach the
+    analytic posterior.  ``baseline``: infer["baseline"] options for the guide site (the reference
+    exercises them on NormalNormalNormalTests, :107-260)."""
+    lam0, loc0 = _t([0.1, 0.1], device), _t([0.0, 0.5], device)
+    lam = _t([6.0, 4.0], device)
+    data = [_t(v, device) for v in ([-0.1, 0.3], [0.00, 0.4], [0.20, 0.5], [0.10, 0.7])]
+    n_data = float(len(data))
+    sum_data = data[0] + data[1] + data[2] + data[3]
+    analytic_lam_n = lam0 + n_data * lam
+    analytic_log_sig_n = -0.5 * torch.log(analytic_lam_n)
+    analytic_loc_n = sum_data * (lam / analytic_lam_n) + loc0 * (lam0 / analytic_lam_n)
+    prior_scale, obs_scale = torch.pow(lam0, -0.5), torch.pow(lam, -0.5)
+    Normal = dist.Normal if reparameterized else NonreparameterizedNormal
+    pyro.clear_param_store()
+
+    def model():
+        with pyro.plate("plate", 2):
+            loc_latent = pyro.sample("loc_latent", Normal(loc0, prior_scale))
+            for i, x in enumerate(data):
+                pyro.sample("obs_%d" % i, dist.Normal(loc_latent, obs_scale), obs=x)
+        return loc_latent
+
+    def guide():
+        loc_q = pyro.param("loc_q", lambda: analytic_loc_n.detach() + 0.334)
+        log_sig_q = pyro.param("log_sig_q", lambda: analytic_log_sig_n.detach() - 0.29)
+        with pyro.plate("plate", 2):
+            pyro.sample("loc_latent", Normal(loc_q, torch.exp(log_sig_q)),
+                        infer={} if baseline is None else {"baseline": dict(baseline)})
+
+    pyro.set_rng_seed(0)
+    svi = SVI(model, guide, Adam({"lr": lr, "betas": (0.97, 0.999)}), loss=TraceGraph_ELBO())
+    for _ in range(n_steps):
+        svi.step()
+    loc_error = float(((pyro.param("loc_q").detach() - analytic_loc_n) ** 2).mean())
+    log_sig_error = float(((pyro.param("log_sig_q").detach() - analytic_log_sig_n) ** 2).mean())
+    assert loc_error < prec and log_sig_error < prec, (loc_error, log_sig_error)
+    if baseline is not None and baseline.get("use_decaying_avg_baseline"):
+        avg = pyro.get_param_store()["__baseline_avg_downstream_cost_loc_latent"].detach()
+        assert avg.shape == (2,) and bool(torch.isfinite(avg).all()) and float(avg.abs().sum()) > 0

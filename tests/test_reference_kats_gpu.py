@@ -18,7 +18,8 @@ def test_particle_gradient(gpu, elbo, reparameterized, has_rsample):
 @pytest.mark.parametrize("scale", [1.0, 2.0], ids=["unscaled", "scaled"])
 @pytest.mark.parametrize("reparameterized,has_rsample", RSAMPLE, ids=IDS)
 @pytest.mark.parametrize("subsample", [False, True], ids=["full", "subsample"])
-@pytest.mark.parametrize("elbo", ["Trace_ELBO", "DiffTrace_ELBO", "TraceMeanField_ELBO", "TraceEnum_ELBO"])
+@pytest.mark.parametrize("elbo", ["Trace_ELBO", "DiffTrace_ELBO", "TraceGraph_ELBO", "TraceMeanField_ELBO",
+                                  "TraceEnum_ELBO"])
 def test_subsample_gradient(gpu, elbo, reparameterized, has_rsample, subsample, scale):
     try:
         kc.run_subsample_gradient(gpu, elbo, reparameterized, has_rsample, subsample, scale)
@@ -27,7 +28,7 @@ def test_subsample_gradient(gpu, elbo, reparameterized, has_rsample, subsample, 
 
 
 @pytest.mark.parametrize("reparameterized", [True, False], ids=["reparam", "nonreparam"])
-@pytest.mark.parametrize("elbo", ["Trace_ELBO", "TraceEnum_ELBO"])
+@pytest.mark.parametrize("elbo", ["Trace_ELBO", "TraceGraph_ELBO", "TraceEnum_ELBO"])
 def test_plate(gpu, elbo, reparameterized):
     kc.run_plate(gpu, elbo, reparameterized)
 
@@ -48,3 +49,11 @@ def test_plating_sums(gpu):
                          ids=["reparameterized", "analytic_kl", "nonreparameterized"])
 def test_normal_normal_convergence(gpu, elbo, reparameterized, n_steps):
     kc.run_normal_normal(gpu, elbo, reparameterized, n_steps)
+
+
+@pytest.mark.parametrize("reparameterized,n_steps,prec,baseline", [
+    (True, 1500, 0.02, None), (False, 5000, 0.05, None),
+    (False, 5000, 0.05, {"use_decaying_avg_baseline": True, "baseline_beta": 0.9})],
+    ids=["reparameterized", "nonreparameterized", "decaying_avg_baseline"])
+def test_tracegraph_normal_normal(gpu, reparameterized, n_steps, prec, baseline):
+    kc.run_tracegraph_normal_normal(gpu, reparameterized, n_steps, prec, baseline)

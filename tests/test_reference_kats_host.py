@@ -25,7 +25,7 @@ def test_particle_gradient(elbo, reparameterized, has_rsample):
 @pytest.mark.parametrize("reparameterized,has_rsample", [(True, None), (False, None)],
                          ids=["reparam", "nonreparam"])
 @pytest.mark.parametrize("subsample", [False, True], ids=["full", "subsample"])
-@pytest.mark.parametrize("elbo", ["Trace_ELBO", "DiffTrace_ELBO", "TraceMeanField_ELBO"])
+@pytest.mark.parametrize("elbo", ["Trace_ELBO", "DiffTrace_ELBO", "TraceGraph_ELBO", "TraceMeanField_ELBO"])
 def test_subsample_gradient(elbo, reparameterized, has_rsample, subsample, scale):
     try:
         kc.run_subsample_gradient(CPU, elbo, reparameterized, has_rsample, subsample, scale)
@@ -40,3 +40,14 @@ def test_plate(reparameterized):
 
 def test_plating_sums():
     kc.run_plating_sums(CPU)
+
+
+@pytest.mark.parametrize("baseline", [None, {"use_decaying_avg_baseline": True, "baseline_beta": 0.9},
+                                      {"baseline_value": 0.0}],
+                         ids=["no_baseline", "decaying_avg", "baseline_value"])
+def test_tracegraph_baselines_host_logic(baseline):
+    """A few steps through the host logic (baseline bookkeeping in the param store, shapes, the
+    regression loss of a trainable baseline); the convergence runs of the reference are GPU tests."""
+    if baseline is not None and "baseline_value" in baseline:
+        baseline = {"baseline_value": torch.zeros(2, requires_grad=True)}
+    kc.run_tracegraph_normal_normal(CPU, False, 30, prec=1e9, baseline=baseline)
