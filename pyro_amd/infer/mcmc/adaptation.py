@@ -122,11 +122,18 @@ class DenseMassMatrix:
             self._scheme.reset()
         if v.dim() == 2:
             v = v.expand(self.C, self.D, self.D)
-        self._v = v.contiguous()
         # adaptation.py:270-282: sqrt_inverse = cholesky(V)^T = L^T, sqrt = triu_inverse = L^-T
-        self._L = torch.linalg.cholesky(self._v).contiguous()
-        eye = torch.eye(self.D, dtype=v.dtype, device=v.device).expand_as(self._L)
-        self._Linv = torch.linalg.solve_triangular(self._L, eye, upper=False).contiguous()
+        L = torch.linalg.cholesky(v)
+        eye = torch.eye(self.D, dtype=v.dtype, device=v.device).expand_as(L)
+        Linv = torch.linalg.solve_triangular(L, eye, upper=False)
+        if getattr(self, "_L", None) is not None and self._L.shape == L.shape \
+                and self._L.dtype == L.dtype and self._L.device == L.device:
+            # same buffers, new contents: a captured potential (jit_compile) keeps pointing at them
+            self._v.copy_(v)
+            self._L.copy_(L)
+            self._Linv.copy_(Linv)
+        else:
+            self._v, self._L, self._Linv = v.contiguous().clone(), L.contiguous(), Linv.contiguous()
         self.version += 1
 
     def update(self, z):

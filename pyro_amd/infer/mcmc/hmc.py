@@ -16,7 +16,7 @@ from ... import kernels, rng
 from ..autoguide.initialization import init_to_uniform
 from .adaptation import WarmupAdapter
 from .mcmc_kernel import MCMCKernel
-from .util import FlatPotential, Layout, initialize_model
+from .util import FlatPotential, GraphedPotential, Layout, initialize_model
 
 
 class _UnitMassView:
@@ -191,6 +191,11 @@ class HMC(MCMCKernel):
                                 layout=self._layout)
         if self._dense:
             self._potential = _WhitenedPotential(self._potential, self._adapter)
+        if self._jit_compile:
+            # the reference's jit_compile traces the potential with torch.jit; here the whole
+            # evaluation (model + backward + mass-matrix products) becomes a hipGraph replay
+            self._potential = GraphedPotential(self._potential)
+        if self._dense:
             self._z = self._pe = None
             self._rewhiten(z)
         else:

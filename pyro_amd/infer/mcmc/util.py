@@ -76,6 +76,55 @@ class FlatPotential:
         return pe, g.contiguous()
 
 
+class GraphedPotential:
+    """``jit_compile=True`` of HMC / NUTS on this backend: after a few eager evaluations the whole
+    potential evaluation -- the model executed for all chains under the handlers, its autograd
+    backward, the mass-matrix products of a dense mass -- is captured into a hipGraph and every
+    later leapfrog step replays it (the reference traces the same computation with torch.jit,
+    pyro/infer/mcmc/util.py:300-338 + pyro/ops/jit.py).  One model execution is ~1 ms of Python
+    and a few dozen launches; a replay is two stream operations.
+
+    The captured kernels read ``z`` from a buffer owned by this object and write (pe, grad) into
+    buffers owned by it; callers get copies.  A potential that cannot be captured (it synchronises
+    with the host, allocates pinned memory, ...) falls back to eager evaluation with a warning."""
+
+    def __init__(self, base, warmup=3):
+        self.base, self.warmup = base, warmup
+        self.calls, self.graph, self.failed = 0, None, False
+        self.z_static = self.pe_static = self.grad_static = None
+
+    def __call__(self, z_flat):
+        if self.failed or not z_flat.is_cuda:
+            return self.base(z_flat)
+        if self.graph is None or z_flat.shape != self.z_static.shape:
+            self.calls += 1
+            if self.calls <= self.warmup or self.graph is not None:
+                return self.base(z_flat)
+            try:
+                self._capture(z_flat)
+            except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
+                import os
+                import warnings
+                if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
+                    raise
+                warnings.warn("pyro_amd: hipGraph capture of the potential failed ({}: {}); "
+                              "continuing with eager evaluations".format(type(e).__name__, e))
+                self.failed = True
+                return self.base(z_flat)
+        self.z_static.copy_(z_flat)
+        self.graph.replay()
+        return self.pe_static.clone(), self.grad_static.clone()
+
+    def _capture(self, z_flat):
+        self.z_static = z_flat.detach().clone()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            pe, grad = self.base(self.z_static)
+            pe, grad = pe.detach().contiguous(), grad.detach().contiguous()
+        self.graph, self.pe_static, self.grad_static = graph, pe, grad
+
+
 def _guess_max_plate_nesting(model, args, kwargs):
     with poutine.block():
         trace = poutine.trace(model).get_trace(*args, **kwargs)

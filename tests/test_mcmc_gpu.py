@@ -235,3 +235,27 @@ def test_dense_mass_adaptation_recovers_covariance(gpu):
 
 def test_structured_mass(gpu):
     mc.run_structured_mass(gpu)
+
+
+@pytest.mark.parametrize("full_mass", [False, True], ids=["diag_mass", "dense_mass"])
+def test_jit_compile_replays_the_potential_as_a_graph(gpu, full_mass):
+    """NUTS(model, jit_compile=True): the potential (model under the chains plate + backward, with
+    the dense-mass products when full_mass) is captured into a hipGraph after a few eager calls;
+    the chains are the ones of the eager run, bit for bit, through warm-up adaptation (which
+    replaces the dense mass matrix under the captured graph) and sampling."""
+    dim, N, C = 3, 500, 8
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn((N, dim), generator=g).to(gpu)
+    y = (torch.rand((N,), generator=g) < 0.5).float().to(gpu)
+    out = []
+    for jit in (False, True):
+        pyro.set_rng_seed(3)
+        kernel = NUTS(mc.logreg_mcmc_model, max_tree_depth=5, jit_compile=jit, full_mass=full_mass)
+        mcmc = MCMC(kernel, num_samples=20, warmup_steps=60, num_chains=C)
+        mcmc.run(X, y)
+        out.append(mcmc.get_samples(group_by_chain=True)["w"].clone())
+        if jit:
+            pot = kernel._potential
+            assert type(pot).__name__ == "GraphedPotential" and pot.graph is not None \
+                and not pot.failed
+    assert torch.equal(out[0], out[1])
