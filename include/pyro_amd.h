@@ -415,6 +415,17 @@ int pa_nuts_tree_advance(int dtype, void* z, void* pe, void* grad, void* zq, voi
                          uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog,
                          int32_t* depth, int32_t* diverging, int32_t* accepted, int32_t* n_active,
                          void* workspace, size_t workspace_bytes, pa_stream_t stream);
+/* pa_nuts_tree_advance with the transition index read from device memory (*t_dev): the launch
+ * can sit in a hipGraph that is replayed for every leapfrog step of every transition (a captured
+ * scalar argument would freeze t, i.e. the Philox keys). */
+int pa_nuts_tree_advance_tdev(int dtype, void* z, void* pe, void* grad, void* zq, void* rq,
+                              const void* gq, const void* peq, const void* inv_mass,
+                              int64_t im_stride_row, const void* step, int64_t C, int64_t D,
+                              int max_tree_depth, int use_multinomial, uint64_t seed,
+                              const uint64_t* t_dev, uint64_t chain_offset, void* accept_prob,
+                              int32_t* n_leapfrog, int32_t* depth, int32_t* diverging,
+                              int32_t* accepted, int32_t* n_active, void* workspace,
+                              size_t workspace_bytes, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under

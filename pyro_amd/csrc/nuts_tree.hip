@@ -213,7 +213,8 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     T* __restrict__ z_io, T* __restrict__ pe_io, T* __restrict__ grad_io, T* __restrict__ zq_io,
     T* __restrict__ rq_io, const T* __restrict__ gq_in, const T* __restrict__ peq_in,
     const T* __restrict__ inv_mass, int64_t im_stride, const T* __restrict__ step, int64_t C,
-    int D, int max_depth, int multinomial, uint64_t seed, uint64_t t, uint64_t chain_offset,
+    int D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
+    const uint64_t* __restrict__ t_dev, uint64_t chain_offset,
     TreeWs<T> ws, T* __restrict__ accept_prob_out, int32_t* __restrict__ nleap_out,
     int32_t* __restrict__ depth_out, int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out,
     int32_t* __restrict__ n_active) {
@@ -222,7 +223,10 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
   if (ws.iscal[IS_ACTIVE * C + chain] == 0) return;  // block-uniform
   Chain<T, NW, NPL> c{(int)threadIdx.x, D, (int64_t)chain * D, red};
   const int64_t CD = C * D;
-  const uint64_t ctr_base = t << 20, cid = chain_offset + (uint64_t)chain;
+  // the transition index keys the Philox draws; a launch that is replayed from a hipGraph reads it
+  // from device memory (pa_nuts_tree_advance_tdev) instead of its (captured) argument
+  const uint64_t tt = t_dev != nullptr ? *t_dev : t;
+  const uint64_t ctr_base = tt << 20, cid = chain_offset + (uint64_t)chain;
 
   const int dir = ws.iscal[IS_DIR * C + chain];
   int tree_depth = ws.iscal[IS_DEPTH * C + chain];
@@ -423,9 +427,9 @@ template <typename T>
 static int tree_advance(void* z, void* pe, void* grad, void* zq, void* rq, const void* gq,
                         const void* peq, const void* inv_mass, int64_t im_stride, const void* step,
                         int64_t C, int64_t D, int max_depth, int multinomial, uint64_t seed,
-                        uint64_t t, uint64_t chain_offset, void* accept_prob, int32_t* nl,
-                        int32_t* dp, int32_t* dv, int32_t* ac, int32_t* n_active, void* workspace,
-                        hipStream_t s) {
+                        uint64_t t, const uint64_t* t_dev, uint64_t chain_offset, void* accept_prob,
+                        int32_t* nl, int32_t* dp, int32_t* dv, int32_t* ac, int32_t* n_active,
+                        void* workspace, hipStream_t s) {
   TreePlan pl;
   tree_plan(D, &pl);
   TreeWs<T> ws = tree_ws<T>(workspace, C, D, max_depth);
@@ -438,8 +442,8 @@ static int tree_advance(void* z, void* pe, void* grad, void* zq, void* rq, const
   hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL>), dim3((unsigned)C), dim3(64 * NW), 0, \
                      s, (TT*)z, (TT*)pe, (TT*)grad, (TT*)zq, (TT*)rq, (const TT*)gq,              \
                      (const TT*)peq, (const TT*)inv_mass, im_stride, (const TT*)step, C, (int)D,  \
-                     max_depth, multinomial, seed, t, chain_offset, ws, (TT*)accept_prob, nl, dp, \
-                     dv, ac, n_active)
+                     max_depth, multinomial, seed, t, t_dev, chain_offset, ws, (TT*)accept_prob, nl, \
+                     dp, dv, ac, n_active)
   PA_TREE_DISPATCH(T, PA_CALL);
 #undef PA_CALL
   if (br) (void)hipEventRecord(ev1, s);
@@ -503,13 +507,38 @@ int pa_nuts_tree_advance(int dtype, void* z, void* pe, void* grad, void* zq, voi
   hipStream_t s = pa::as_stream(stream);
   if (dtype == PA_F32)
     return pa::tree_advance<float>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, step, C,
-                                   D, max_tree_depth, use_multinomial, seed, t, chain_offset,
-                                   accept_prob, n_leapfrog, depth, diverging, accepted, n_active,
-                                   workspace, s);
+                                   D, max_tree_depth, use_multinomial, seed, t, nullptr,
+                                   chain_offset, accept_prob, n_leapfrog, depth, diverging,
+                                   accepted, n_active, workspace, s);
   return pa::tree_advance<double>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, step, C,
-                                  D, max_tree_depth, use_multinomial, seed, t, chain_offset,
-                                  accept_prob, n_leapfrog, depth, diverging, accepted, n_active,
-                                  workspace, s);
+                                  D, max_tree_depth, use_multinomial, seed, t, nullptr,
+                                  chain_offset, accept_prob, n_leapfrog, depth, diverging,
+                                  accepted, n_active, workspace, s);
+}
+
+int pa_nuts_tree_advance_tdev(int dtype, void* z, void* pe, void* grad, void* zq, void* rq,
+                              const void* gq, const void* peq, const void* inv_mass,
+                              int64_t im_stride_row, const void* step, int64_t C, int64_t D,
+                              int max_tree_depth, int use_multinomial, uint64_t seed,
+                              const uint64_t* t_dev, uint64_t chain_offset, void* accept_prob,
+                              int32_t* n_leapfrog, int32_t* depth, int32_t* diverging,
+                              int32_t* accepted, int32_t* n_active, void* workspace,
+                              size_t workspace_bytes, pa_stream_t stream) {
+  const uint64_t t = 0;                 // (the checks below also bound the scalar index)
+  PA_TREE_COMMON_CHECKS("nuts_tree_advance_tdev")
+  PA_REQUIRE(z && pe && grad && zq && rq && gq && peq && inv_mass && step && accept_prob &&
+                 n_leapfrog && depth && diverging && accepted && n_active && t_dev,
+             "nuts_tree_advance_tdev: NULL pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    return pa::tree_advance<float>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, step, C,
+                                   D, max_tree_depth, use_multinomial, seed, 0, t_dev,
+                                   chain_offset, accept_prob, n_leapfrog, depth, diverging,
+                                   accepted, n_active, workspace, s);
+  return pa::tree_advance<double>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, step, C,
+                                  D, max_tree_depth, use_multinomial, seed, 0, t_dev,
+                                  chain_offset, accept_prob, n_leapfrog, depth, diverging,
+                                  accepted, n_active, workspace, s);
 }
 
 }  // extern "C"

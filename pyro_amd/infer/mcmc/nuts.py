@@ -45,6 +45,8 @@ class NUTS(HMC):
     def setup(self, warmup_steps, *args, **kwargs):
         super().setup(warmup_steps, *args, **kwargs)
         self._tree = None
+        self._step_buf = self._mass_buf = self._round_graph = None     # jit_compile round graph
+        self._round_calls, self._round_failed = 0, False
         self._tree_depth_sum = torch.zeros((), dtype=torch.int64, device=self._z.device)
         self._fused = (self.use_fused_gaussian and isinstance(self.potential_fn, GaussianPotential)
                        and self._layout.D <= 128 and len(self._layout.names) == 1
@@ -125,6 +127,19 @@ class NUTS(HMC):
 
     def _tree_transition(self, t, step, inv_mass):
         tree = self._tree
+        replayable = bool(self._jit_compile)
+        if replayable:
+            # the tree kernels of a captured round read step / inverse mass through pointers:
+            # persistent buffers, refreshed in place when adaptation hands over new tensors
+            if getattr(self, "_step_buf", None) is None or self._step_buf.shape != step.shape \
+                    or self._mass_buf.shape != inv_mass.shape:
+                self._step_buf, self._mass_buf = step.clone(), inv_mass.clone()
+                self._round_graph, self._round_calls = None, 0
+                tree = self._tree = None
+            else:
+                self._step_buf.copy_(step)
+                self._mass_buf.copy_(inv_mass)
+            step, inv_mass = self._step_buf, self._mass_buf
         if tree is None or tree.inv_mass is not inv_mass or tree.step is not step:
             if tree is None:
                 tree = kernels.NutsTree(self._z, self._pe, self._grad, inv_mass, step,
@@ -138,8 +153,11 @@ class NUTS(HMC):
         it = 0
         max_iter = (1 << self._max_tree_depth) + 1
         while True:
-            pe, grad = self._potential(tree.zq)
-            tree.advance(pe.contiguous(), grad.contiguous())
+            if replayable:
+                self._round(tree)
+            else:
+                pe, grad = self._potential(tree.zq)
+                tree.advance(pe.contiguous(), grad.contiguous())
             it += 1
             if it >= max_iter:
                 break
@@ -149,6 +167,38 @@ class NUTS(HMC):
                 if tree.n_active() == 0:
                     break
         return tree.stats()
+
+    def _round(self, tree):
+        """One tree round = potential at the cursor + tree bookkeeping.  With jit_compile the pair
+        is captured into ONE hipGraph (after a few eager rounds) and replayed: the transition index
+        reaches the tree kernel through device memory, step size and mass through persistent
+        buffers, so the same graph serves every leapfrog of every transition."""
+        base = getattr(self._potential, "base", self._potential)
+        graph = getattr(self, "_round_graph", None)
+        if graph is None and not getattr(self, "_round_failed", False):
+            self._round_calls = getattr(self, "_round_calls", 0) + 1
+            if self._round_calls > 8:
+                try:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        pe, grad = base(tree.zq)
+                        tree.advance_replayable(pe.detach().contiguous(), grad.detach().contiguous())
+                    self._round_graph = graph
+                    self._round_keep = (pe, grad)
+                except Exception as e:  # noqa: BLE001
+                    import os
+                    import warnings
+                    if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
+                        raise
+                    warnings.warn("pyro_amd: hipGraph capture of the NUTS round failed ({}: {}); "
+                                  "continuing with eager rounds".format(type(e).__name__, e))
+                    self._round_failed, graph = True, None
+        if graph is not None:
+            graph.replay()
+            return
+        pe, grad = self._potential(tree.zq)
+        tree.advance_replayable(pe.contiguous(), grad.contiguous())
 
     def logging(self):
         out = super().logging()

@@ -725,9 +725,11 @@ class NutsTree:
         self.ints = torch.zeros((4, C), dtype=torch.int32, device=z.device)
         self._n_active = torch.zeros((1,), dtype=torch.int32, device=z.device)
         self.t = 0
+        self.t_dev = torch.zeros((1,), dtype=torch.int64, device=z.device)   # for advance_replayable
 
     def begin(self, t):
         self.t = int(t)
+        self.t_dev.fill_(self.t)
         check(_lib.load().pa_nuts_tree_begin(
             self.dt, _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq),
             _ptr(self.inv_mass), self.im_stride, _ptr(self.step), self.C, self.D,
@@ -743,6 +745,21 @@ class NutsTree:
             self.dt, _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq),
             _ptr(gq), _ptr(peq), _ptr(self.inv_mass), self.im_stride, _ptr(self.step),
             self.C, self.D, self.max_tree_depth, self.multinomial, self.seed, self.t,
+            self.chain_offset, _ptr(self.accept_prob), _ptr(self.ints[0]), _ptr(self.ints[1]),
+            _ptr(self.ints[2]), _ptr(self.ints[3]), _ptr(self._n_active), _ptr(self.ws),
+            self.nbytes, _stream()))
+
+    def advance_replayable(self, peq, gq):
+        """advance() whose transition index comes from device memory (set by begin()): the launch
+        may be captured into a hipGraph once and replayed for every leapfrog of every transition
+        (pa_nuts_tree_advance_tdev).  inv_mass / step must be persistent buffers."""
+        _require_gpu(peq, gq)
+        assert peq.is_contiguous() and gq.is_contiguous() and gq.dtype == self.z.dtype
+        assert peq.dtype == self.z.dtype and gq.shape == self.z.shape and peq.numel() == self.C
+        check(_lib.load().pa_nuts_tree_advance_tdev(
+            self.dt, _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq),
+            _ptr(gq), _ptr(peq), _ptr(self.inv_mass), self.im_stride, _ptr(self.step),
+            self.C, self.D, self.max_tree_depth, self.multinomial, self.seed, _ptr(self.t_dev),
             self.chain_offset, _ptr(self.accept_prob), _ptr(self.ints[0]), _ptr(self.ints[1]),
             _ptr(self.ints[2]), _ptr(self.ints[3]), _ptr(self._n_active), _ptr(self.ws),
             self.nbytes, _stream()))

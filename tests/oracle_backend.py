@@ -344,6 +344,8 @@ class NutsTree:
         self._o.advance(_np(peq), _np(gq))
         self._sync()
 
+    advance_replayable = advance
+
     def n_active(self):
         return self._o.n_active()
 
