@@ -847,9 +847,61 @@ def g_discrete_hmm():
     save("discrete_hmm", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# G13: TraceGraph_ELBO with baselines (pyro/infer/tracegraph_elbo.py:28-236): a score-function
+#      site in a plate with a decaying-average baseline and a trainable baseline_value, the
+#      latent fixed through replay, two consecutive evaluations (the average moves in between).
+# ---------------------------------------------------------------------------------------------
+def g_tracegraph():
+    torch.set_default_dtype(torch.float64)
+    from pyro.distributions.testing import fakes
+    from pyro.infer import TraceGraph_ELBO
+    rng = np.random.default_rng(41)
+    data = torch.tensor(rng.standard_normal((4, 3)))
+    zvals = [torch.tensor(rng.standard_normal(3)) for _ in range(2)]
+    flat = {"data": data.numpy(), "z0": zvals[0].numpy(), "z1": zvals[1].numpy()}
+    for tag, opts in (("avg", {"use_decaying_avg_baseline": True, "baseline_beta": 0.8}),
+                      ("value", "value"), ("both", "both")):
+        pyro.clear_param_store()
+
+        def model(data):
+            with pyro.plate("p", 3):
+                z = pyro.sample("z", dist.Normal(torch.zeros(3), 1.0))
+                with pyro.plate("d", 4):
+                    pyro.sample("x", dist.Normal(z, 0.7), obs=data)
+
+        def guide(data):
+            loc = pyro.param("loc", torch.tensor([0.1, -0.2, 0.4]))
+            sc = pyro.param("sc", torch.tensor([0.9, 1.1, 0.8]), constraint=constraints.positive)
+            if opts == "value":
+                b = {"baseline_value": pyro.param("bv", torch.tensor([-3.0, -6.0, -9.0]))}
+            elif opts == "both":
+                b = {"baseline_value": pyro.param("bv", torch.tensor([-3.0, -6.0, -9.0])),
+                     "use_decaying_avg_baseline": True, "baseline_beta": 0.8}
+            else:
+                b = dict(opts)
+            with pyro.plate("p", 3):
+                pyro.sample("z", fakes.NonreparameterizedNormal(loc, sc), infer={"baseline": b})
+
+        for k, zval in enumerate(zvals):
+            fixed = poutine.trace(poutine.condition(guide, data={"z": zval})).get_trace(data)
+            fixed.nodes["z"]["is_observed"] = False
+            for p_ in pyro.get_param_store()._params.values():
+                p_.grad = None
+            loss = TraceGraph_ELBO().loss_and_grads(model, poutine.replay(guide, trace=fixed), data)
+            flat["%s/loss%d" % (tag, k)] = loss
+            for name, g_ in grads_of_store().items():
+                if not name.startswith("__baseline"):
+                    flat["%s/grads%d/%s" % (tag, k, name)] = g_
+            store = pyro.get_param_store()
+            if "__baseline_avg_downstream_cost_z" in store:
+                flat["%s/avg%d" % (tag, k)] = store["__baseline_avg_downstream_cost_z"].detach().numpy()
+    save("tracegraph", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph"]
     for w in which:
         globals()["g_" + w]()
 

@@ -369,3 +369,50 @@ def run_autocont(g, device, monkeypatch, which, tag, rtol):
     loss = elbo.loss_and_grads(model, guide, X, y)
     np.testing.assert_allclose(loss, float(g["loss_" + key]), rtol=rtol)
     assert_grads(store_grads(), g, "grads_" + key, rtol * 10)
+
+
+# ---- TraceGraph_ELBO baselines against the reference (tests/golden/tracegraph.npz) ----------------
+def run_tracegraph_baselines(g, device, rtol):
+    """Loss, parameter gradients (incl. the trainable baseline_value) and the stored decaying
+    average of two consecutive evaluations with the latent fixed through replay."""
+    from pyro_amd.infer import TraceGraph_ELBO
+    dtype = torch.get_default_dtype()
+    data = torch.as_tensor(g["data"], dtype=dtype, device=device)
+    zvals = [torch.as_tensor(g["z%d" % k], dtype=dtype, device=device) for k in range(2)]
+
+    def t(v):
+        return torch.tensor(v, dtype=dtype, device=device)
+
+    for tag in ("avg", "value", "both"):
+        pyro.clear_param_store()
+
+        def model(data):
+            with pyro.plate("p", 3):
+                z = pyro.sample("z", dist.Normal(torch.zeros(3, dtype=dtype, device=device), 1.0))
+                with pyro.plate("d", 4):
+                    pyro.sample("x", dist.Normal(z, 0.7), obs=data)
+
+        def guide(data):
+            loc = pyro.param("loc", t([0.1, -0.2, 0.4]))
+            sc = pyro.param("sc", t([0.9, 1.1, 0.8]), constraint=constraints.positive)
+            b = {}
+            if tag in ("value", "both"):
+                b["baseline_value"] = pyro.param("bv", t([-3.0, -6.0, -9.0]))
+            if tag in ("avg", "both"):
+                b.update({"use_decaying_avg_baseline": True, "baseline_beta": 0.8})
+            with pyro.plate("p", 3):
+                pyro.sample("z", NonreparameterizedNormal(loc, sc), infer={"baseline": b})
+
+        for k, zval in enumerate(zvals):
+            fixed = poutine.trace(poutine.condition(guide, data={"z": zval})).get_trace(data)
+            fixed.nodes["z"]["is_observed"] = False
+            for p_ in pyro.get_param_store()._params.values():
+                p_.grad = None
+            loss = TraceGraph_ELBO().loss_and_grads(model, poutine.replay(guide, trace=fixed), data)
+            np.testing.assert_allclose(loss, float(g["%s/loss%d" % (tag, k)]), rtol=rtol)
+            grads = {n: v for n, v in store_grads().items() if not n.startswith("__baseline")}
+            assert_grads(grads, g, "%s/grads%d" % (tag, k), rtol * 10)
+            key = "%s/avg%d" % (tag, k)
+            if key in g.files:
+                avg = pyro.get_param_store()["__baseline_avg_downstream_cost_z"].detach().cpu().numpy()
+                np.testing.assert_allclose(avg, g[key], rtol=rtol * 10)

@@ -64,6 +64,16 @@ def test_autocontinuous_guides(monkeypatch, which, tag):
     models.run_autocont(load("autocont"), torch.device("cpu"), monkeypatch, which, tag, rtol=1e-9)
 
 
+def test_tracegraph_baselines_match_reference(monkeypatch):
+    from tests import oracle_backend
+    oracle_backend.install(monkeypatch)
+    torch.set_default_dtype(torch.float64)
+    try:
+        models.run_tracegraph_baselines(load("tracegraph"), torch.device("cpu"), 1e-9)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 def test_large_plated_site_takes_the_nd_route(monkeypatch):
     """A latent under a plate AND the particle plate scored against parameters that broadcast along
     the middle dim (config 5's w[P, G, D] ~ Normal(mu[P, 1, D], tau[P, 1, D])): the N-D site

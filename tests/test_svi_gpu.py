@@ -66,6 +66,11 @@ def test_score_function_guide(gpu):
     models.run_score_function(load("score_function"), gpu, rtol=1e-9)
 
 
+def test_tracegraph_baselines_match_reference(gpu):
+    torch.set_default_dtype(torch.float64)
+    models.run_tracegraph_baselines(load("tracegraph"), gpu, rtol=1e-9)
+
+
 @pytest.mark.parametrize("tag", ["p1", "p5"])
 def test_trace_mean_field_elbo(gpu, monkeypatch, tag):
     """TraceMeanField_ELBO (analytic KL + sampled fall-back) against the reference's loss / grads."""
