@@ -252,3 +252,84 @@ def run_hmm_vectorised_equals_markov(device, dtype=torch.float64, rtol=1e-9):
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=rtol)
     for a, b in zip(out[1][1], out[0][1]):
         np.testing.assert_allclose(a, b, rtol=rtol * 100, atol=rtol * 100 * float(np.abs(b).max()))
+
+
+# ---- guide-side enumeration + DiCE (tests/golden/guide_enum.npz from traceenum_elbo.py) -----------
+class _NonreparameterizedNormal(dist.Normal):
+    has_rsample = False
+
+
+def run_guide_enum_vs_reference(g, device, dtype=torch.float64, rtol=1e-9):
+    """Loss and gradients of the reference for (1) a masked, scaled plate with x enumerated in the
+    guide and y in the model, (2) a score-function Normal upstream of a guide-enumerated site."""
+    from pyro_amd import poutine
+    from pyro_amd.infer import config_enumerate
+
+    def t(v):
+        return torch.tensor(v, dtype=dtype, device=device)
+
+    def params():
+        pyro.clear_param_store()
+        pyro.param("guide_probs_x", t([0.1, 0.9]), constraint=constraints.simplex)
+        pyro.param("model_probs_x", t([0.4, 0.6]), constraint=constraints.simplex)
+        pyro.param("model_probs_y", t([[0.75, 0.25], [0.55, 0.45]]), constraint=constraints.simplex)
+        pyro.param("model_probs_z", t([[0.3, 0.7], [0.2, 0.8]]), constraint=constraints.simplex)
+
+    def check(tag, loss):
+        names = sorted(n for n in pyro.get_param_store().keys() if tag + "/grad/" + n in g.files)
+        ps = [pyro.param(n).unconstrained() for n in names]
+        gs = torch.autograd.grad(loss, ps)
+        np.testing.assert_allclose(loss.item(), float(g[tag + "/loss"]), rtol=rtol)
+        for n, got in zip(names, gs):
+            ref = g[tag + "/grad/" + n]
+            np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=rtol * 100,
+                                       atol=rtol * 100 * float(np.abs(ref).max()), err_msg=tag + n)
+
+    data = torch.tensor([0, 1, 1], device=device)
+    mask = torch.tensor([True, True, False], device=device)
+
+    @poutine.scale(scale=10.0)
+    def model1(data):
+        px, py, pz = (pyro.param("model_probs_" + k) for k in "xyz")
+        with pyro.plate("data", 3), poutine.mask(mask=mask):
+            x = pyro.sample("x", dist.Categorical(px))
+            y = pyro.sample("y", dist.Categorical(py[x]), infer={"enumerate": "parallel"})
+            pyro.sample("z", dist.Categorical(pz[y]), obs=data)
+
+    @poutine.scale(scale=10.0)
+    @config_enumerate
+    def guide1(data):
+        pq = pyro.param("guide_probs_x")
+        with pyro.plate("data", 3), poutine.mask(mask=mask):
+            pyro.sample("x", dist.Categorical(pq))
+
+    params()
+    check("plate", TraceEnum_ELBO(max_plate_nesting=1, strict_enumeration_warning=False)
+          .differentiable_loss(model1, guide1, data))
+
+    zfix = torch.as_tensor(g["score/s"], dtype=dtype, device=device)
+
+    def model2():
+        s = pyro.sample("s", dist.Normal(t(0.0), t(1.0)))
+        x = pyro.sample("x", dist.Categorical(pyro.param("model_probs_x")))
+        pz = pyro.param("model_probs_z")
+        pyro.sample("obs", dist.Normal(s + x.to(dtype), t(0.8)), obs=t(0.9))
+        pyro.sample("z", dist.Categorical(pz[x]), obs=torch.tensor(1, device=device))
+
+    @config_enumerate
+    def guide2():
+        loc = pyro.param("s_loc", t(0.2))
+        pyro.sample("s", _NonreparameterizedNormal(loc, t(0.9)))
+        pyro.sample("x", dist.Categorical(pyro.param("guide_probs_x")))
+
+    params()
+    fixed = poutine.trace(poutine.condition(guide2, data={"s": zfix})).get_trace()
+    fixed.nodes["s"]["is_observed"] = False
+
+    def guide2_fixed():
+        tr = poutine.Trace()
+        tr.add_node("s", **fixed.nodes["s"])
+        return poutine.replay(guide2, trace=tr)()
+
+    check("score", TraceEnum_ELBO(max_plate_nesting=0, strict_enumeration_warning=False)
+          .differentiable_loss(model2, guide2_fixed))

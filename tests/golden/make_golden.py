@@ -899,9 +899,92 @@ def g_tracegraph():
     save("tracegraph", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# G14: guide-side parallel enumeration with DiCE (traceenum_elbo.py:112-214, infer/util.py:196-326):
+#      the "auto" programs of tests/infer/test_enum.py:2121-2208 (everything inside one masked
+#      plate, x enumerated in the guide, y in the model) and :1823-1866 (no plate), plus a
+#      score-function site upstream of an enumerated one; loss and gradients from the reference.
+# ---------------------------------------------------------------------------------------------
+def g_guide_enum():
+    torch.set_default_dtype(torch.float64)
+    from pyro.distributions.testing import fakes
+    from pyro.infer import TraceEnum_ELBO, config_enumerate
+    flat = {}
+    data = torch.tensor([0, 1, 1])
+    mask = torch.tensor([True, True, False])
+
+    def params():
+        pyro.clear_param_store()
+        pyro.param("guide_probs_x", torch.tensor([0.1, 0.9]), constraint=constraints.simplex)
+        pyro.param("model_probs_x", torch.tensor([0.4, 0.6]), constraint=constraints.simplex)
+        pyro.param("model_probs_y", torch.tensor([[0.75, 0.25], [0.55, 0.45]]), constraint=constraints.simplex)
+        pyro.param("model_probs_z", torch.tensor([[0.3, 0.7], [0.2, 0.8]]), constraint=constraints.simplex)
+
+    def record(tag, loss):
+        names = sorted(pyro.get_param_store().keys())
+        ps = [pyro.param(n).unconstrained() for n in names]
+        gs = torch.autograd.grad(loss, ps, allow_unused=True)
+        flat[tag + "/loss"] = loss.item()
+        for n, g_ in zip(names, gs):
+            if g_ is not None:
+                flat[tag + "/grad/" + n] = g_.numpy()
+
+    # (1) one masked plate around x (guide-enumerated), y (model-enumerated), z (observed)
+    @poutine.scale(scale=10.0)
+    def model1(data):
+        px, py, pz = (pyro.param("model_probs_" + k) for k in "xyz")
+        with pyro.plate("data", 3), poutine.mask(mask=mask):
+            x = pyro.sample("x", dist.Categorical(px))
+            y = pyro.sample("y", dist.Categorical(py[x]), infer={"enumerate": "parallel"})
+            pyro.sample("z", dist.Categorical(pz[y]), obs=data)
+
+    @poutine.scale(scale=10.0)
+    @config_enumerate
+    def guide1(data):
+        pq = pyro.param("guide_probs_x")
+        with pyro.plate("data", 3), poutine.mask(mask=mask):
+            pyro.sample("x", dist.Categorical(pq))
+
+    params()
+    record("plate", TraceEnum_ELBO(max_plate_nesting=1, strict_enumeration_warning=False)
+           .differentiable_loss(model1, guide1, data))
+
+    # (2) a score-function Normal site upstream of a guide-enumerated Categorical
+    zfix = torch.tensor(0.37)
+
+    def model2():
+        s = pyro.sample("s", dist.Normal(0.0, 1.0))
+        px = pyro.param("model_probs_x")
+        x = pyro.sample("x", dist.Categorical(px))
+        pz = pyro.param("model_probs_z")
+        pyro.sample("obs", dist.Normal(s + x.to(s.dtype), 0.8), obs=torch.tensor(0.9))
+        pyro.sample("z", dist.Categorical(pz[x]), obs=torch.tensor(1))
+
+    @config_enumerate
+    def guide2():
+        loc = pyro.param("s_loc", torch.tensor(0.2))
+        pyro.sample("s", fakes.NonreparameterizedNormal(loc, 0.9))
+        pyro.sample("x", dist.Categorical(pyro.param("guide_probs_x")))
+
+    params()
+    fixed = poutine.trace(poutine.condition(guide2, data={"s": zfix})).get_trace()
+    fixed.nodes["s"]["is_observed"] = False
+
+    def guide2_fixed():
+        # replay only the continuous draw; the discrete site is enumerated afresh
+        tr = poutine.Trace()
+        tr.add_node("s", **fixed.nodes["s"])
+        return poutine.replay(guide2, trace=tr)()
+
+    record("score", TraceEnum_ELBO(max_plate_nesting=0, strict_enumeration_warning=False)
+           .differentiable_loss(model2, guide2_fixed))
+    flat["score/s"] = zfix.numpy()
+    save("guide_enum", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum"]
     for w in which:
         globals()["g_" + w]()
 

@@ -159,3 +159,7 @@ def test_discrete_hmm_matches_reference(gpu, dtype, rtol):
 
 def test_hmm_vectorised_over_time_equals_markov_model(gpu):
     ec.run_hmm_vectorised_equals_markov(gpu)
+
+
+def test_guide_enumeration_and_dice_match_reference(gpu):
+    ec.run_guide_enum_vs_reference(load("guide_enum"), gpu)

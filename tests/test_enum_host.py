@@ -117,3 +117,7 @@ def test_guide_side_markov_enumeration_is_exact(_cpu_backend):
 
 def test_guide_enumeration_is_the_exact_expectation(_cpu_backend):
     ekc.run_guide_enumeration_closed_form(CPU)
+
+
+def test_guide_enumeration_and_dice_match_reference(_cpu_backend):
+    ec.run_guide_enum_vs_reference(load("guide_enum"), CPU)
