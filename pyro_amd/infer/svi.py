@@ -149,7 +149,10 @@ class SVI:
             (getattr(self.optim, "world_size", 1) > 1 or getattr(self, "_force_split", False))
         try:
             with validation_enabled(False):   # validation ran in the eager warm-up steps
-                with torch.cuda.graph(graph):
+                # with a process group alive its watchdog thread polls events while we capture:
+                # only THIS thread's calls may invalidate the capture
+                mode = {"capture_error_mode": "thread_local"} if split else {}
+                with torch.cuda.graph(graph, **mode):
                     with cap:
                         with poutine.trace(param_only=True) as param_capture:
                             loss = self._loss_device(self.model, self.guide, *args, **kwargs)
@@ -172,7 +175,7 @@ class SVI:
                     optim = self.optim
                     optim.reduce_gradients(params)
                     graph2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph2, pool=graph.pool()):
+                    with torch.cuda.graph(graph2, pool=graph.pool(), **mode):
                         optim.apply(params)
                         if not getattr(optim, "zeroes_grads", False):
                             zero_grads(params)
