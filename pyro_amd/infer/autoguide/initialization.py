@@ -84,6 +84,8 @@ class InitMessenger(Messenger):
     def _pyro_sample(self, msg):
         if msg["done"] or msg["is_observed"] or type(msg["fn"]).__name__ == "_Subsample":
             return
+        if getattr(msg["fn"], "has_enumerate_support", False):
+            return      # discrete: no unconstrained space to initialise in; drawn (or enumerated)
         with torch.no_grad():
             value = self.init_fn(msg)
         if value is not None:

@@ -7,6 +7,11 @@ chains are one tensor batch.  For a model, the conditioned model is executed ONC
 step for all chains under an extra outermost ``plate("_num_chains", C, dim=-1-max_plate_nesting)``
 (the same device the ELBO uses for vectorised particles, pyro/infer/elbo.py:186-216) and the
 log-joint is reduced per chain; U(z)[c] = -log p(T^-1(z_c), data) + sum log|det J|.
+
+Discrete latent sites are summed out of the potential exactly (reference: TraceEinsumEvaluator,
+pyro/infer/mcmc/util.py:162-241): they are enumerated in parallel on the tensor dims to the left of
+the plates (and of the chain dim) and the log-factors contracted by the plated sum-product of
+``ops.contract`` -- per chain, because the chain plate is part of every factor's plate context.
 """
 from collections import OrderedDict
 
@@ -141,6 +146,7 @@ class _PEMaker:
         self.mpn = max_plate_nesting
         self.C = num_chains
         self.batch_ndims = batch_ndims   # site -> number of batch dims of its distribution
+        self.enum = False                # the model has discrete latent sites to sum out
 
     def _chain_value(self, name, v):
         """[C, *site_shape] -> [C, 1 ... 1, *site_shape] so the chain dim sits at
@@ -168,12 +174,59 @@ class _PEMaker:
             return lp.reshape(C, -1).sum(-1)
         return lp.sum()   # does not depend on the chain: a constant shared by all chains
 
+    def _enum_log_joint(self, trace, nplates, C):
+        """log of the joint density with every enumerated site summed out: one value per chain
+        (``C`` given; the chain plate is the outermost of the ``nplates`` plate dims) or a scalar.
+        As in the reference every factor enters scaled and masked (trace_struct.py:248-288)."""
+        from ...ops.contract import contract_tensor_tree, pack
+
+        terms, enum_ids = [], set()
+        for name, site in trace.nodes.items():
+            if site["type"] != "sample" or type(site["fn"]).__name__ == "_Subsample":
+                continue
+            mask = site["mask"]
+            if mask is False:
+                continue
+            lp = scale_and_mask(site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"]),
+                                site["scale"], None if mask is True else mask)
+            ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
+            terms.append(pack(lp, site["infer"].get("_dim_to_id", {}), nplates, ordinal))
+            edim = site["infer"].get("_enumerate_dim")
+            if edim is not None:
+                enum_ids.add(site["infer"]["_dim_to_id"][edim])
+
+        def reduce(t):
+            if C is None:
+                return t.sum()
+            if t.dim() == nplates and t.shape[0] == C:
+                return t.reshape(C, -1).sum(-1)
+            return t.sum()         # the same for every chain
+
+        total = 0.0
+        factors = OrderedDict()
+        for term in terms:
+            if term.dims & enum_ids:
+                factors.setdefault(term.ordinal, []).append(term)
+            else:
+                total = total + reduce(term.tensor)
+        if factors:
+            for out in contract_tensor_tree(factors, enum_ids).values():
+                for term in out:
+                    total = total + reduce(term.tensor)
+        return total
+
+    def _enumerated(self, fn, nplates):
+        from ..enum import config_enumerate
+        return poutine.enum(config_enumerate(fn), first_available_dim=-1 - nplates)
+
     def potential_fn(self, params):
         if self.C == 1 and not self._batched(params):
             constrained = {k: self.transforms[k].inv(v) for k, v in params.items()}
-            trace = poutine.trace(poutine.condition(self.model, constrained)).get_trace(
+            model = self._enumerated(self.model, self.mpn) if self.enum else self.model
+            trace = poutine.trace(poutine.condition(model, constrained)).get_trace(
                 *self.args, **self.kwargs)
-            log_joint = trace.log_prob_sum()
+            log_joint = self._enum_log_joint(trace, self.mpn, None) if self.enum else \
+                trace.log_prob_sum()
             for name, t in self.transforms.items():
                 log_joint = log_joint - torch.sum(
                     t.log_abs_det_jacobian(constrained[name], params[name]))
@@ -186,12 +239,17 @@ class _PEMaker:
             with plate("_num_chains", C, dim=-1 - self.mpn):
                 return self.model(*a, **kw)
 
+        if self.enum:
+            chained = self._enumerated(chained, self.mpn + 1)
         trace = poutine.trace(poutine.condition(chained, cond)).get_trace(*self.args,
                                                                          **self.kwargs)
-        log_joint = 0.0
-        for name, site in trace.nodes.items():
-            if site["type"] == "sample" and type(site["fn"]).__name__ != "_Subsample":
-                log_joint = log_joint + self._chain_sum(site)
+        if self.enum:
+            log_joint = self._enum_log_joint(trace, self.mpn + 1, C)
+        else:
+            log_joint = 0.0
+            for name, site in trace.nodes.items():
+                if site["type"] == "sample" and type(site["fn"]).__name__ != "_Subsample":
+                    log_joint = log_joint + self._chain_sum(site)
         for name, t in self.transforms.items():
             ladj = t.log_abs_det_jacobian(constrained[name], params[name])
             log_joint = log_joint - ladj.reshape(C, -1).sum(-1)
@@ -228,6 +286,7 @@ def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
 
     trace = draw()
     batch_ndims, site_shape = {}, {}
+    enumerated = set()
 
     def collect(tr):
         out = {}
@@ -239,9 +298,8 @@ def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
                                               "sites")
                 continue
             if getattr(fn, "has_enumerate_support", False):
-                raise NotImplementedError(
-                    "pyro_amd: discrete latent site '{}': enumeration inside HMC/NUTS is not "
-                    "part of this backend".format(name))
+                enumerated.add(name)       # summed out of the potential, not a coordinate
+                continue
             out[name] = node["value"].detach()
             batch_ndims[name] = len(fn.batch_shape)
             if automatic:
@@ -260,4 +318,5 @@ def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
     for k, v in initial_params.items():
         site_shape[k] = tuple(v.shape[1:]) if num_chains > 1 else tuple(v.shape)
     pe_maker._site_shape = site_shape
+    pe_maker.enum = bool(enumerated)
     return initial_params, pe_maker.potential_fn, transforms, trace

@@ -982,9 +982,76 @@ def g_guide_enum():
     save("guide_enum", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# G15: discrete latents summed out of the HMC/NUTS potential (pyro/infer/mcmc/util.py:162-286
+#      TraceEinsumEvaluator + _PEMaker): the GMM and Bernoulli-latent models of
+#      tests/infer/mcmc/test_nuts.py:273-328 and a 5-step Gaussian HMM (:331-392) -- potential
+#      energy and its gradient at fixed unconstrained points from the reference's potential_fn.
+# ---------------------------------------------------------------------------------------------
+def g_mcmc_enum():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer.mcmc.util import initialize_model
+    flat = {}
+    K, N = 3, 40
+
+    def gmm(data):
+        phi = pyro.sample("phi", dist.Dirichlet(torch.ones(K)))
+        with pyro.plate("num_clusters", K):
+            means = pyro.sample("cluster_means", dist.Normal(torch.arange(float(K)), 1.0))
+        with pyro.plate("data", data.shape[0]):
+            a = pyro.sample("assignments", dist.Categorical(phi))
+            pyro.sample("obs", dist.Normal(means[a], 1.0), obs=data)
+
+    @poutine.broadcast
+    def bern(data):
+        y_prob = pyro.sample("y_prob", dist.Beta(1.0, 1.0))
+        with pyro.plate("data", data.shape[0]):
+            y = pyro.sample("y", dist.Bernoulli(y_prob))
+            z = pyro.sample("z", dist.Bernoulli(0.65 * y + 0.1))
+            pyro.sample("obs", dist.Normal(2.0 * z, 1.0), obs=data)
+
+    dim = 3
+
+    def hmm(data):
+        initialize = pyro.sample("initialize", dist.Dirichlet(torch.ones(dim)))
+        with pyro.plate("states", dim):
+            transition = pyro.sample("transition", dist.Dirichlet(torch.ones(dim, dim)))
+            loc = pyro.sample("emission_loc", dist.Normal(torch.zeros(dim), torch.ones(dim)))
+            scale = pyro.sample("emission_scale", dist.LogNormal(torch.zeros(dim), torch.ones(dim)))
+        x = None
+        for t, y in pyro.markov(enumerate(data)):
+            x = pyro.sample("x_{}".format(t),
+                            dist.Categorical(initialize if x is None else transition[x]),
+                            infer={"enumerate": "parallel"})
+            pyro.sample("y_{}".format(t), dist.Normal(loc[x], scale[x]), obs=y)
+
+    gen = torch.Generator().manual_seed(11)
+    datasets = {
+        "gmm": torch.tensor([1.0, 5.0, 10.0])[torch.randint(0, 3, (N,), generator=gen)]
+        + torch.randn(N, generator=gen),
+        "bern": 2.0 * (torch.rand(N, generator=gen) < 0.3).double() + torch.randn(N, generator=gen),
+        "hmm": torch.randn(6, generator=gen) + torch.arange(6.0) % 3,
+    }
+    for tag, model in (("gmm", gmm), ("bern", bern), ("hmm", hmm)):
+        data = datasets[tag]
+        pyro.set_rng_seed(0)
+        init, potential_fn, transforms, _ = initialize_model(model, (data,), max_plate_nesting=1)
+        flat[tag + "/data"] = data.numpy()
+        for k in range(3):                          # three points per model
+            z = {n: (torch.randn(v.shape, generator=gen) * 0.7).requires_grad_(True)
+                 for n, v in sorted(init.items())}
+            pe = potential_fn(z)
+            grads = torch.autograd.grad(pe, list(z.values()))
+            flat["%s/pe%d" % (tag, k)] = pe.item()
+            for (n, v), g_ in zip(z.items(), grads):
+                flat["%s/z%d/%s" % (tag, k, n)] = v.detach().numpy()
+                flat["%s/g%d/%s" % (tag, k, n)] = g_.numpy()
+    save("mcmc_enum", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum"]
     for w in which:
         globals()["g_" + w]()
 

@@ -356,3 +356,117 @@ def run_persistent_equals_stepwise(device, dtype, rtol, C=6, D=9, warmup=40, S=6
     torch.testing.assert_close(a[4]["acceptance rate"], b[4]["acceptance rate"])
     assert a[4]["divergences"] == b[4]["divergences"]
     assert abs(a[4]["mean tree depth"] - b[4]["mean tree depth"]) < 1e-12
+
+
+# ---- discrete latents summed out of the potential (tests/golden/mcmc_enum.npz) -------------------
+def _enum_models(device, dtype, batch_safe):
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.ops.indexing import Vindex
+
+    def t(v):
+        return torch.as_tensor(v, dtype=dtype, device=device)
+
+    K, dim = 3, 3
+
+    def gmm(data):
+        phi = pyro.sample("phi", dist.Dirichlet(torch.ones(K, dtype=dtype, device=device)))
+        with pyro.plate("num_clusters", K):
+            means = pyro.sample("cluster_means", dist.Normal(t([0.0, 1.0, 2.0]), t(1.0)))
+        with pyro.plate("data", data.shape[0]):
+            a = pyro.sample("assignments", dist.Categorical(phi))
+            # tests/infer/mcmc/test_nuts.py:286 indexes means[a]; with a leading chain dim the
+            # cluster dim has to move off the data plate's dim first
+            m = Vindex(means.unsqueeze(-2))[..., a] if batch_safe else means[a]
+            pyro.sample("obs", dist.Normal(m, t(1.0)), obs=data)
+
+    def bern(data):
+        y_prob = pyro.sample("y_prob", dist.Beta(t(1.0), t(1.0)))
+        with pyro.plate("data", data.shape[0]):
+            y = pyro.sample("y", dist.Bernoulli(y_prob))
+            z = pyro.sample("z", dist.Bernoulli(0.65 * y + 0.1))
+            pyro.sample("obs", dist.Normal(2.0 * z, t(1.0)), obs=data)
+
+    def hmm(data):
+        initialize = pyro.sample("initialize", dist.Dirichlet(torch.ones(dim, dtype=dtype, device=device)))
+        with pyro.plate("states", dim):
+            transition = pyro.sample("transition",
+                                     dist.Dirichlet(torch.ones(dim, dim, dtype=dtype, device=device)))
+            loc = pyro.sample("emission_loc", dist.Normal(torch.zeros(dim, dtype=dtype, device=device), t(1.0)))
+            scale = pyro.sample("emission_scale",
+                                dist.LogNormal(torch.zeros(dim, dtype=dtype, device=device), t(1.0)))
+        x = None
+        for i, y in pyro.markov(enumerate(data)):
+            x = pyro.sample("x_{}".format(i),
+                            dist.Categorical(initialize if x is None else transition[x]),
+                            infer={"enumerate": "parallel"})
+            pyro.sample("y_{}".format(i), dist.Normal(loc[x], scale[x]), obs=y)
+
+    return {"gmm": gmm, "bern": bern, "hmm": hmm}
+
+
+def run_enum_potential_vs_reference(device, dtype=torch.float64, rtol=1e-9):
+    """U(z) and dU/dz with the discrete sites enumerated and summed out equal the reference's
+    potential_fn (TraceEinsumEvaluator) at three points per model: one chain at a time through the
+    reference-verbatim programs, and all three points as three chains of ONE evaluation."""
+    import pyro_amd as pyro
+    from pyro_amd.infer.mcmc import initialize_model
+
+    g = load("mcmc_enum")
+    for batch_safe, tags in ((False, ("gmm", "bern", "hmm")), (True, ("gmm", "bern"))):
+        models = _enum_models(device, dtype, batch_safe)
+        for tag in tags:
+            data = torch.as_tensor(g[tag + "/data"], dtype=dtype, device=device)
+            names = sorted(k.split("/")[2] for k in g.files if k.startswith(tag + "/z0/"))
+            pyro.set_rng_seed(0)
+            C = 3 if batch_safe else 1
+            init, pot, _, _ = initialize_model(models[tag], (data,), max_plate_nesting=1,
+                                               num_chains=C)
+            assert sorted(init) == names, (sorted(init), names)
+
+            def point(k):
+                return {n: torch.as_tensor(g["%s/z%d/%s" % (tag, k, n)], dtype=dtype, device=device)
+                        for n in names}
+
+            if batch_safe:
+                z = {n: torch.stack([point(k)[n] for k in range(3)]).requires_grad_(True)
+                     for n in names}
+                pe = pot(z)
+                assert pe.shape == (3,)
+                grads = torch.autograd.grad(pe.sum(), [z[n] for n in names])
+                for k in range(3):
+                    np.testing.assert_allclose(pe[k].item(), float(g["%s/pe%d" % (tag, k)]), rtol=rtol)
+                    for n, gr in zip(names, grads):
+                        ref = g["%s/g%d/%s" % (tag, k, n)]
+                        np.testing.assert_allclose(gr[k].cpu().numpy(), ref, rtol=rtol * 100,
+                                                   atol=rtol * 100 * float(np.abs(ref).max() + 1e-300))
+            else:
+                for k in range(3):
+                    z = {n: v.requires_grad_(True) for n, v in point(k).items()}
+                    pe = pot(z)
+                    grads = torch.autograd.grad(pe, [z[n] for n in names])
+                    np.testing.assert_allclose(pe.item(), float(g["%s/pe%d" % (tag, k)]), rtol=rtol)
+                    for n, gr in zip(names, grads):
+                        ref = g["%s/g%d/%s" % (tag, k, n)]
+                        np.testing.assert_allclose(gr.cpu().numpy(), ref, rtol=rtol * 100,
+                                                   atol=rtol * 100 * float(np.abs(ref).max() + 1e-300))
+
+
+def run_bernoulli_latent_kat(device, dtype=torch.float32, C=4):
+    """tests/infer/mcmc/test_nuts.py:306-328 (and test_hmc.py:277-306): posterior mean of y_prob
+    with the two Bernoulli layers summed out, here on C chains of one batch."""
+    import pyro_amd as pyro
+    from pyro_amd.infer.mcmc import MCMC, NUTS
+
+    torch.manual_seed(3)
+    N = 2000
+    y = (torch.rand(N) < 0.3).to(dtype)
+    z = (torch.rand(N) < 0.65 * y + 0.1).to(dtype)
+    data = (2.0 * z + torch.randn(N)).to(dtype).to(device)
+    pyro.set_rng_seed(0)
+    model = _enum_models(device, dtype, True)["bern"]
+    mcmc = MCMC(NUTS(model, max_plate_nesting=1), num_samples=150, warmup_steps=100, num_chains=C)
+    mcmc.run(data)
+    s = mcmc.get_samples()["y_prob"]
+    assert s.shape == (150 * C,)
+    assert abs(s.mean().item() - 0.3) < 0.05, s.mean().item()

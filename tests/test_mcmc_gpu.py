@@ -259,3 +259,12 @@ def test_jit_compile_replays_the_potential_as_a_graph(gpu, full_mass):
             assert type(pot).__name__ == "GraphedPotential" and pot.graph is not None \
                 and not pot.failed
     assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 1e-4)])
+def test_discrete_latents_are_summed_out_of_the_potential(gpu, dtype, rtol):
+    mc.run_enum_potential_vs_reference(gpu, dtype=dtype, rtol=rtol)
+
+
+def test_bernoulli_latent_model_kat(gpu):
+    mc.run_bernoulli_latent_kat(gpu, dtype=torch.float32, C=4)

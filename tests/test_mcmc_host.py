@@ -202,3 +202,11 @@ def test_structured_mass_host_logic(_cpu_backend):
 def test_persistent_launch_path_equals_per_transition_path(_cpu_backend):
     mc.run_persistent_equals_stepwise(torch.device("cpu"), torch.float64, 1e-10, C=3, D=5,
                                       warmup=30, S=4)
+
+
+def test_discrete_latents_are_summed_out_of_the_potential(_cpu_backend):
+    mc.run_enum_potential_vs_reference(torch.device("cpu"))
+
+
+def test_bernoulli_latent_model_kat(_cpu_backend):
+    mc.run_bernoulli_latent_kat(torch.device("cpu"), dtype=torch.float64, C=2)
