@@ -1049,9 +1049,83 @@ def g_mcmc_enum():
     save("mcmc_enum", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# G16: potentials of models with constrained supports (pyro/infer/mcmc/util.py:264-286 _PEMaker,
+#      :370-482 initialize_model: biject_to(support).inv per site, log|det J| correction) -- the
+#      conjugate programs of tests/infer/mcmc/test_nuts.py:184-270,394-462 and test_hmc.py:216-275;
+#      potential energy and gradient at fixed unconstrained points from the reference.
+# ---------------------------------------------------------------------------------------------
+def g_mcmc_potential():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer.mcmc.util import initialize_model
+    flat = {}
+    gen = torch.Generator().manual_seed(5)
+
+    def beta_bernoulli(data):
+        p = pyro.sample("p_latent", dist.Beta(torch.tensor([1.1, 1.1]), torch.tensor([1.1, 1.1])))
+        pyro.sample("obs", dist.Bernoulli(p), obs=data)
+
+    def gamma_normal(data):
+        s = pyro.sample("p_latent", dist.Gamma(torch.tensor([1.0, 1.0]), torch.tensor([1.0, 1.0])))
+        pyro.sample("obs", dist.Normal(3.0, s), obs=data)
+
+    def dirichlet_categorical(data):
+        p = pyro.sample("p_latent", dist.Dirichlet(torch.tensor([1.0, 1.0, 1.0])))
+        pyro.sample("obs", dist.Categorical(p), obs=data)
+
+    def gamma_beta(data):
+        a = pyro.sample("alpha", dist.Gamma(concentration=1.0, rate=1.0))
+        b = pyro.sample("beta", dist.Gamma(concentration=1.0, rate=1.0))
+        pyro.sample("x", dist.Beta(concentration1=a, concentration0=b), obs=data)
+
+    def beta_binomial(data):
+        a = pyro.sample("alpha", dist.HalfCauchy(1.0))
+        b = pyro.sample("beta", dist.HalfCauchy(1.0))
+        with pyro.plate("plate_0", data.shape[-1]):
+            probs = pyro.sample("probs", dist.Beta(a, b))
+            with pyro.plate("data", data.shape[0]):
+                pyro.sample("binomial", dist.Binomial(probs=probs, total_count=1000), obs=data)
+
+    def gamma_poisson(data):
+        a = pyro.sample("alpha", dist.HalfCauchy(1.0))
+        b = pyro.sample("beta", dist.HalfCauchy(1.0))
+        with pyro.plate("plate_0", data.shape[-1]):
+            rate = pyro.sample("rate", dist.Gamma(a, b))
+            with pyro.plate("data", data.shape[0]):
+                pyro.sample("obs", dist.Poisson(rate), obs=data)
+
+    datasets = {
+        "beta_bernoulli": (torch.rand(50, 2, generator=gen) < torch.tensor([0.9, 0.1])).double(),
+        "gamma_normal": 3.0 + torch.randn(40, 2, generator=gen) * torch.tensor([0.5, 2.0]),
+        "dirichlet_categorical": torch.multinomial(torch.tensor([0.1, 0.6, 0.3]), 60, True, generator=gen),
+        "gamma_beta": torch.rand(30, generator=gen) * 0.8 + 0.1,
+        "beta_binomial": torch.round(1000 * (torch.rand(6, 3, generator=gen) * 0.2
+                                             + torch.tensor([0.1, 0.4, 0.7]))),
+        "gamma_poisson": torch.poisson(torch.tensor([3.0, 10.0]).expand(8, 2), generator=gen),
+    }
+    models = dict(beta_bernoulli=beta_bernoulli, gamma_normal=gamma_normal,
+                  dirichlet_categorical=dirichlet_categorical, gamma_beta=gamma_beta,
+                  beta_binomial=beta_binomial, gamma_poisson=gamma_poisson)
+    for tag, model in models.items():
+        data = datasets[tag]
+        pyro.set_rng_seed(0)
+        init, potential_fn, transforms, _ = initialize_model(model, (data,))
+        flat[tag + "/data"] = data.numpy()
+        for k in range(3):
+            z = {n: (torch.randn(v.shape, generator=gen) * 0.7).requires_grad_(True)
+                 for n, v in sorted(init.items())}
+            pe = potential_fn(z)
+            grads = torch.autograd.grad(pe, list(z.values()))
+            flat["%s/pe%d" % (tag, k)] = pe.item()
+            for (n, v), g_ in zip(z.items(), grads):
+                flat["%s/z%d/%s" % (tag, k, n)] = v.detach().numpy()
+                flat["%s/g%d/%s" % (tag, k, n)] = g_.numpy()
+    save("mcmc_potential", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential"]
     for w in which:
         globals()["g_" + w]()
 

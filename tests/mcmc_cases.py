@@ -470,3 +470,103 @@ def run_bernoulli_latent_kat(device, dtype=torch.float32, C=4):
     s = mcmc.get_samples()["y_prob"]
     assert s.shape == (150 * C,)
     assert abs(s.mean().item() - 0.3) < 0.05, s.mean().item()
+
+
+# ---- potentials of models with constrained supports (tests/golden/mcmc_potential.npz) -------------
+def _conjugate_models(device, dtype):
+    """The conjugate programs of tests/infer/mcmc/test_nuts.py:184-270,394-462 with their batch dims
+    declared as plates (same density; needed for the leading chain dim to have a place)."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+
+    def t(v):
+        return torch.as_tensor(v, dtype=dtype, device=device)
+
+    def beta_bernoulli(data):
+        with pyro.plate("c", 2, dim=-1):
+            p = pyro.sample("p_latent", dist.Beta(t([1.1, 1.1]), t([1.1, 1.1])))
+            with pyro.plate("d", data.shape[0], dim=-2):
+                pyro.sample("obs", dist.Bernoulli(p), obs=data)
+
+    def gamma_normal(data):
+        with pyro.plate("c", 2, dim=-1):
+            s = pyro.sample("p_latent", dist.Gamma(t([1.0, 1.0]), t([1.0, 1.0])))
+            with pyro.plate("d", data.shape[0], dim=-2):
+                pyro.sample("obs", dist.Normal(t(3.0), s), obs=data)
+
+    def dirichlet_categorical(data):
+        p = pyro.sample("p_latent", dist.Dirichlet(t([1.0, 1.0, 1.0])))
+        with pyro.plate("d", data.shape[0]):
+            pyro.sample("obs", dist.Categorical(p), obs=data)
+
+    def gamma_beta(data):
+        a = pyro.sample("alpha", dist.Gamma(t(1.0), t(1.0)))
+        b = pyro.sample("beta", dist.Gamma(t(1.0), t(1.0)))
+        with pyro.plate("d", data.shape[0]):
+            pyro.sample("x", dist.Beta(a, b), obs=data)
+
+    def beta_binomial(data):
+        a = pyro.sample("alpha", dist.HalfCauchy(t(1.0)))
+        b = pyro.sample("beta", dist.HalfCauchy(t(1.0)))
+        with pyro.plate("plate_0", data.shape[-1]):
+            probs = pyro.sample("probs", dist.Beta(a, b))
+            with pyro.plate("data", data.shape[0]):
+                pyro.sample("binomial", dist.Binomial(probs=probs, total_count=1000), obs=data)
+
+    def gamma_poisson(data):
+        a = pyro.sample("alpha", dist.HalfCauchy(t(1.0)))
+        b = pyro.sample("beta", dist.HalfCauchy(t(1.0)))
+        with pyro.plate("plate_0", data.shape[-1]):
+            rate = pyro.sample("rate", dist.Gamma(a, b))
+            with pyro.plate("data", data.shape[0]):
+                pyro.sample("obs", dist.Poisson(rate), obs=data)
+
+    return dict(beta_bernoulli=beta_bernoulli, gamma_normal=gamma_normal,
+                dirichlet_categorical=dirichlet_categorical, gamma_beta=gamma_beta,
+                beta_binomial=beta_binomial, gamma_poisson=gamma_poisson)
+
+
+def run_constrained_potentials_vs_reference(device, dtype=torch.float64, rtol=1e-9):
+    """U(z) = -log p(T^-1(z), data) - log|det J| and its gradient equal the reference's
+    potential_fn: per chain (unbatched call) and for three chains in one evaluation."""
+    import pyro_amd as pyro
+    from pyro_amd.infer.mcmc import initialize_model
+
+    g = load("mcmc_potential")
+    models = _conjugate_models(device, dtype)
+    for tag, model in models.items():
+        raw = g[tag + "/data"]
+        data = torch.as_tensor(raw, device=device)
+        data = data.to(dtype) if tag != "dirichlet_categorical" else data.long()
+        names = sorted(k.split("/")[2] for k in g.files if k.startswith(tag + "/z0/"))
+
+        def point(k):
+            return {n: torch.as_tensor(g["%s/z%d/%s" % (tag, k, n)], dtype=dtype, device=device)
+                    for n in names}
+
+        def check(pe, grads, k, sel):
+            np.testing.assert_allclose(sel(pe).item(), float(g["%s/pe%d" % (tag, k)]), rtol=rtol,
+                                       err_msg=tag)
+            for n, gr in zip(names, grads):
+                ref = g["%s/g%d/%s" % (tag, k, n)]
+                np.testing.assert_allclose(sel(gr).cpu().numpy(), ref, rtol=rtol * 100,
+                                           atol=rtol * 100 * float(np.abs(ref).max() + 1e-300),
+                                           err_msg=tag + "/" + n)
+
+        for C in (1, 3):
+            pyro.set_rng_seed(0)
+            init, pot, _, _ = initialize_model(model, (data,), num_chains=C)
+            assert sorted(init) == names, (sorted(init), names)
+            if C == 1:
+                for k in range(3):
+                    z = {n: v.requires_grad_(True) for n, v in point(k).items()}
+                    pe = pot(z)
+                    check(pe, torch.autograd.grad(pe, [z[n] for n in names]), k, lambda x: x)
+            else:
+                z = {n: torch.stack([point(k)[n] for k in range(3)]).requires_grad_(True)
+                     for n in names}
+                pe = pot(z)
+                assert pe.shape == (3,)
+                grads = torch.autograd.grad(pe.sum(), [z[n] for n in names])
+                for k in range(3):
+                    check(pe, grads, k, lambda x, k=k: x[k])

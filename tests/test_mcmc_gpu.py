@@ -268,3 +268,8 @@ def test_discrete_latents_are_summed_out_of_the_potential(gpu, dtype, rtol):
 
 def test_bernoulli_latent_model_kat(gpu):
     mc.run_bernoulli_latent_kat(gpu, dtype=torch.float32, C=4)
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+def test_constrained_support_potentials_match_reference(gpu, dtype, rtol):
+    mc.run_constrained_potentials_vs_reference(gpu, dtype=dtype, rtol=rtol)

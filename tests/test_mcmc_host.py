@@ -210,3 +210,7 @@ def test_discrete_latents_are_summed_out_of_the_potential(_cpu_backend):
 
 def test_bernoulli_latent_model_kat(_cpu_backend):
     mc.run_bernoulli_latent_kat(torch.device("cpu"), dtype=torch.float64, C=2)
+
+
+def test_constrained_support_potentials_match_reference(_cpu_backend):
+    mc.run_constrained_potentials_vs_reference(torch.device("cpu"))
