@@ -5,12 +5,15 @@ tests/infer/test_inference.py:943-1007 plate-sum semantics).  The bodies follow 
 line by line -- same data, seeds where they matter, closed-form expectations and precisions; only
 the import changes.  Shared by the CPU suite (kernels answered by the numpy oracle: host logic) and
 the GPU suite (HIP kernels)."""
+import math
+
 import numpy as np
 import torch
 
 import pyro_amd as pyro
 import pyro_amd.distributions as dist
 import pyro_amd.poutine as poutine
+from pyro_amd.distributions import constraints
 from pyro_amd.infer import SVI, Trace_ELBO, TraceEnum_ELBO, TraceGraph_ELBO, TraceMeanField_ELBO
 from pyro_amd.optim import Adam
 
@@ -338,3 +341,76 @@ def run_tracegraph_normal_normal(device, reparameterized, n_steps, prec, baselin
     if baseline is not None and baseline.get("use_decaying_avg_baseline"):
         avg = pyro.get_param_store()["__baseline_avg_downstream_cost_loc_latent"].detach()
         assert avg.shape == (2,) and bool(torch.isfinite(avg).all()) and float(avg.abs().sum()) > 0
+
+
+class NonreparameterizedGamma(dist.Gamma):
+    has_rsample = False
+
+
+class NonreparameterizedBeta(dist.Beta):
+    has_rsample = False
+
+
+def run_poisson_gamma(device, reparameterized, n_steps, hip_graph=False):
+    """tests/infer/test_inference.py:307-402 PoissonGammaTests.do_elbo_test: Gamma(1,1) prior,
+    Poisson data [1,2,3]; SVI (Adam lr 2e-4, betas (0.97, 0.999)) from a perturbed start reaches the
+    conjugate posterior Gamma(alpha0 + sum, beta0 + n) within 0.2 / 0.15."""
+    alpha0, beta0 = _t(1.0, device), _t(1.0, device)
+    data = _t([1.0, 2.0, 3.0], device)
+    alpha_n, beta_n = alpha0 + data.sum(), beta0 + 3.0
+    Gamma = dist.Gamma if reparameterized else NonreparameterizedGamma
+    pyro.clear_param_store()
+
+    def model():
+        lam = pyro.sample("lambda_latent", Gamma(alpha0, beta0))
+        with pyro.plate("data", 3):
+            pyro.sample("obs", dist.Poisson(lam), obs=data)
+
+    def guide():
+        alpha_q = pyro.param("alpha_q", lambda: alpha_n.detach() + math.exp(0.17),
+                             constraint=constraints.positive)
+        beta_q = pyro.param("beta_q", lambda: beta_n.detach() / math.exp(0.143),
+                            constraint=constraints.positive)
+        pyro.sample("lambda_latent", Gamma(alpha_q, beta_q))
+
+    pyro.set_rng_seed(0)
+    svi = SVI(model, guide, Adam({"lr": 0.0002, "betas": (0.97, 0.999)}), loss=Trace_ELBO(),
+              hip_graph=hip_graph)
+    for _ in range(n_steps):
+        svi.step()
+    a_err = abs(float(pyro.param("alpha_q").detach()) - float(alpha_n))
+    b_err = abs(float(pyro.param("beta_q").detach()) - float(beta_n))
+    assert a_err < 0.2 and b_err < 0.15, (a_err, b_err)
+
+
+def run_bernoulli_beta(device, reparameterized, n_steps, vectorized, hip_graph=False):
+    """tests/infer/test_inference.py:588-716 BernoulliBetaTests.do_elbo_test (incl. the vectorised
+    two-particle variant): Beta(1,1) prior, data [0,1,1,1]; log alpha_q, log beta_q reach the
+    conjugate posterior within 0.08."""
+    alpha0, beta0 = _t(1.0, device), _t(1.0, device)
+    data = _t([0.0, 1.0, 1.0, 1.0], device)
+    log_alpha_n = torch.log(alpha0 + data.sum())
+    log_beta_n = torch.log(beta0 - data.sum() + 4.0)
+    Beta = dist.Beta if reparameterized else NonreparameterizedBeta
+    pyro.clear_param_store()
+
+    def model():
+        p = pyro.sample("p_latent", Beta(alpha0, beta0))
+        with pyro.plate("data", 4):
+            pyro.sample("obs", dist.Bernoulli(p), obs=data)
+
+    def guide():
+        a = pyro.param("alpha_q_log", lambda: log_alpha_n.detach() + 0.17)
+        b = pyro.param("beta_q_log", lambda: log_beta_n.detach() - 0.143)
+        pyro.sample("p_latent", Beta(torch.exp(a), torch.exp(b)))
+
+    loss = Trace_ELBO(num_particles=2, vectorize_particles=True, max_plate_nesting=1) \
+        if vectorized else Trace_ELBO()
+    pyro.set_rng_seed(0)
+    svi = SVI(model, guide, Adam({"lr": 0.001, "betas": (0.97, 0.999)}), loss=loss,
+              hip_graph=hip_graph)
+    for _ in range(n_steps):
+        svi.step()
+    a_err = abs(float(pyro.param("alpha_q_log").detach() - log_alpha_n))
+    b_err = abs(float(pyro.param("beta_q_log").detach() - log_beta_n))
+    assert a_err < 0.08 and b_err < 0.08, (a_err, b_err)

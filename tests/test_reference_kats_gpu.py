@@ -57,3 +57,14 @@ def test_normal_normal_convergence(gpu, elbo, reparameterized, n_steps):
     ids=["reparameterized", "nonreparameterized", "decaying_avg_baseline"])
 def test_tracegraph_normal_normal(gpu, reparameterized, n_steps, prec, baseline):
     kc.run_tracegraph_normal_normal(gpu, reparameterized, n_steps, prec, baseline)
+
+
+@pytest.mark.parametrize("reparameterized,vectorized,n_steps", [(True, False, 10000), (False, False, 10000),
+                                                                (True, True, 5000)],
+                         ids=["reparameterized", "nonreparameterized", "reparameterized_vectorized"])
+def test_bernoulli_beta_convergence(gpu, reparameterized, vectorized, n_steps):
+    kc.run_bernoulli_beta(gpu, reparameterized, n_steps, vectorized, hip_graph=True)
+
+
+def test_poisson_gamma_convergence(gpu):
+    kc.run_poisson_gamma(gpu, True, 10000, hip_graph=True)

@@ -51,3 +51,8 @@ def test_tracegraph_baselines_host_logic(baseline):
     if baseline is not None and "baseline_value" in baseline:
         baseline = {"baseline_value": torch.zeros(2, requires_grad=True)}
     kc.run_tracegraph_normal_normal(CPU, False, 30, prec=1e9, baseline=baseline)
+
+
+def test_bernoulli_beta_convergence_vectorized():
+    # Beta rsample (torch's _standard_gamma gradients) through two vectorised particles
+    kc.run_bernoulli_beta(CPU, True, 5000, vectorized=True)
