@@ -151,19 +151,31 @@ class HMC(MCMCKernel):
     @initial_params.setter
     def initial_params(self, params):
         self._initial_params = params
+        self._drawn_initial_params = False      # given by the caller: kept across runs
 
     # ---- setup -------------------------------------------------------------------------------
     def _initialize_model_properties(self, model_args, model_kwargs):
         init_params, potential_fn, transforms, trace = initialize_model(
             self.model, model_args, model_kwargs, transforms=self.transforms,
             max_plate_nesting=self._max_plate_nesting, num_chains=self.num_chains,
-            init_strategy=self._init_strategy, initial_params=self._initial_params)
+            init_strategy=self._init_strategy,
+            # points drawn by an earlier run are not reused (the reference forgets them in
+            # cleanup(), hmc.py:363-364): every run of a model kernel initialises afresh
+            initial_params=None if getattr(self, "_drawn_initial_params", False)
+            else self._initial_params)
+        self._drawn_initial_params = getattr(self, "_drawn_initial_params", False) or \
+            self._initial_params is None
         self.potential_fn = potential_fn
         self.transforms = transforms
         self._initial_params = init_params
         self._prototype_trace = trace
 
     def setup(self, warmup_steps, *args, **kwargs):
+        # a kernel object that already ran starts over: transition counter (it indexes the
+        # per-transition random streams and the adaptation schedule), statistics, whitened state
+        self._t = 0
+        self._divergences = []
+        self._zr, self._white_version = None, -1
         self._warmup_steps = warmup_steps
         if self.model is not None:
             self._initialize_model_properties(args, kwargs)

@@ -570,3 +570,38 @@ def run_constrained_potentials_vs_reference(device, dtype=torch.float64, rtol=1e
                 grads = torch.autograd.grad(pe.sum(), [z[n] for n in names])
                 for k in range(3):
                     check(pe, grads, k, lambda x, k=k: x[k])
+
+
+def run_sequential_consistent(device, dtype=torch.float64):
+    """tests/infer/mcmc/test_mcmc_api.py:326-368 (nothing left over from a previous run) in this
+    backend's terms: a kernel object that already ran -- adapted step size, mass matrix, tree
+    buffers, graphs -- reproduces its chains from the same seed, and equals a fresh kernel.  (Chain
+    c of a batch equals the chain a run restricted to it produces: test_chain_offset_shifts_streams
+    on the GPU and the chain-sharded gloo test.)"""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer.mcmc import MCMC, NUTS
+
+    data = torch.tensor([1.0], dtype=dtype, device=device)
+
+    def model(data):
+        x = pyro.sample("x", dist.Normal(torch.zeros((), dtype=dtype, device=device), 1.0))
+        y = pyro.sample("y", dist.Normal(x, 1.0))
+        with pyro.plate("d", 1):
+            pyro.sample("obs", dist.Normal(y, 1.0), obs=data)
+
+    def run(kernel):
+        pyro.set_rng_seed(7)
+        z = torch.linspace(-1.0, 1.0, 6, dtype=dtype, device=device).reshape(3, 2)
+        m = MCMC(kernel, num_samples=30, warmup_steps=30, num_chains=3,
+                 initial_params={"x": z[:, 0].clone(), "y": z[:, 1].clone()})
+        m.run(data)
+        s = m.get_samples(group_by_chain=True)
+        return np.stack([s["x"].cpu().numpy(), s["y"].cpu().numpy()])
+
+    kernel = NUTS(model, max_tree_depth=5)
+    first = run(kernel)
+    assert first.shape == (2, 3, 30) and np.isfinite(first).all()
+    assert np.abs(first[:, 0] - first[:, 1]).max() > 0        # chains differ from each other
+    np.testing.assert_array_equal(run(kernel), first)          # the same object, second run
+    np.testing.assert_array_equal(run(NUTS(model, max_tree_depth=5)), first)

@@ -273,3 +273,7 @@ def test_bernoulli_latent_model_kat(gpu):
 @pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
 def test_constrained_support_potentials_match_reference(gpu, dtype, rtol):
     mc.run_constrained_potentials_vs_reference(gpu, dtype=dtype, rtol=rtol)
+
+
+def test_sequential_consistent(gpu):
+    mc.run_sequential_consistent(gpu)

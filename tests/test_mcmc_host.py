@@ -214,3 +214,7 @@ def test_bernoulli_latent_model_kat(_cpu_backend):
 
 def test_constrained_support_potentials_match_reference(_cpu_backend):
     mc.run_constrained_potentials_vs_reference(torch.device("cpu"))
+
+
+def test_sequential_consistent(_cpu_backend):
+    mc.run_sequential_consistent(torch.device("cpu"))
