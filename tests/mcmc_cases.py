@@ -605,3 +605,50 @@ def run_sequential_consistent(device, dtype=torch.float64):
     assert np.abs(first[:, 0] - first[:, 1]).max() > 0        # chains differ from each other
     np.testing.assert_array_equal(run(kernel), first)          # the same object, second run
     np.testing.assert_array_equal(run(NUTS(model, max_tree_depth=5)), first)
+
+
+# ---- conjugate Gaussian chains (tests/infer/mcmc/test_nuts.py:30-146, test_hmc.py:34-170) ----------
+GAUSSIAN_CHAINS = {
+    # id: (dim, chain_len, num_obs, num_samples, expected_means, expected_precs, mean_tol, std_tol)
+    "dim=10_chain-len=3_num_obs=1": (10, 3, 1, 800, [0.25, 0.50, 0.75], [1.33, 1, 1.33], 0.09, 0.09),
+    "dim=10_chain-len=4_num_obs=1": (10, 4, 1, 1600, [0.20, 0.40, 0.60, 0.80],
+                                     [1.25, 0.83, 0.83, 1.25], 0.07, 0.06),
+    "dim=5_chain-len=2_num_obs=10000": (5, 2, 10000, 800, [0.5, 1.0], [2.0, 10000], 0.05, 0.05),
+    "dim=5_chain-len=9_num_obs=1": (5, 9, 1, 1400, [0.10, 0.20, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90],
+                                    [1.11, 0.63, 0.48, 0.42, 0.4, 0.42, 0.48, 0.63, 1.11], 0.08, 0.08),
+}
+
+
+def run_gaussian_chain(device, case, kernel="nuts", dtype=torch.float32, C=8, **kernel_kwargs):
+    """The reference's conjugate Gaussian-chain sampler test: loc_1 ~ N(0,1), loc_i ~ N(loc_{i-1},1),
+    obs ~ N(loc_T, 1); rmse of the posterior means / stds of every loc_i against the closed form.
+    The reference's ``num_samples`` are spread over C chains of one batch (200 warm-up steps each)."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer.mcmc import HMC, MCMC, NUTS
+
+    dim, chain_len, num_obs, num_samples, means, precs, mean_tol, std_tol = GAUSSIAN_CHAINS[case]
+    data = torch.ones(num_obs, dim, dtype=dtype, device=device)
+    one = torch.ones((), dtype=dtype, device=device)
+
+    def model(data):
+        loc = torch.zeros(dim, dtype=dtype, device=device)
+        with pyro.plate("dim", dim, dim=-1):
+            for i in range(1, chain_len + 1):
+                loc = pyro.sample("loc_{}".format(i), dist.Normal(loc, one))
+            with pyro.plate("obs_plate", num_obs, dim=-2):
+                pyro.sample("obs", dist.Normal(loc, one), obs=data)
+
+    pyro.set_rng_seed(0)
+    k = NUTS(model, **kernel_kwargs) if kernel == "nuts" else HMC(model, **kernel_kwargs)
+    mcmc = MCMC(k, num_samples=max(num_samples // C, 50) * 2, warmup_steps=200, num_chains=C)
+    mcmc.run(data)
+    samples = mcmc.get_samples()
+    for i in range(1, chain_len + 1):
+        latent = samples["loc_{}".format(i)].double()
+        exp_mean = torch.full((dim,), means[i - 1], dtype=torch.float64, device=device)
+        exp_std = 1.0 / torch.sqrt(torch.full((dim,), float(precs[i - 1]), dtype=torch.float64,
+                                              device=device))
+        e_mean = (latent.mean(0) - exp_mean).pow(2).mean().sqrt().item()
+        e_std = (latent.std(0) - exp_std).pow(2).mean().sqrt().item()
+        assert e_mean < mean_tol and e_std < std_tol, (case, i, e_mean, e_std)

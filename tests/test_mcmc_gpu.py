@@ -277,3 +277,15 @@ def test_constrained_support_potentials_match_reference(gpu, dtype, rtol):
 
 def test_sequential_consistent(gpu):
     mc.run_sequential_consistent(gpu)
+
+
+@pytest.mark.parametrize("jit", [False, True], ids=["eager", "graphed"])
+@pytest.mark.parametrize("case", sorted(mc.GAUSSIAN_CHAINS))
+def test_nuts_conjugate_gaussian_chain(gpu, case, jit):
+    mc.run_gaussian_chain(gpu, case, "nuts", jit_compile=jit)
+
+
+def test_hmc_conjugate_gaussian_chain(gpu):
+    # test_hmc.py:79-124: fixed trajectory length on the first chain fixture
+    mc.run_gaussian_chain(gpu, "dim=10_chain-len=3_num_obs=1", "hmc", step_size=0.5, num_steps=4,
+                          jit_compile=True)

@@ -218,3 +218,4 @@ def test_constrained_support_potentials_match_reference(_cpu_backend):
 
 def test_sequential_consistent(_cpu_backend):
     mc.run_sequential_consistent(torch.device("cpu"))
+
