@@ -369,3 +369,101 @@ def run_guide_side_markov(device, T=4, K=2):
     ga, = grad(loss, [u], retain_graph=True)
     ge, = grad(-total, [u])
     torch.testing.assert_close(ga, ge, rtol=1e-4, atol=1e-6)
+
+
+# ---- closed-form KL known answers (tests/infer/test_enum.py:338-395, :544-622, :625-714) -----------
+def run_elbo_bern(device, method, enumerate1, scale):
+    """One Bernoulli site enumerated in the guide: loss = scale * KL(q || p) exactly (prec 1e-3),
+    through loss / differentiable_loss / loss_and_grads."""
+    from torch.distributions import kl_divergence
+    pyro.clear_param_store()
+    q = pyro.param("q", torch.tensor(0.5, dtype=torch.float64, device=device, requires_grad=True))
+    p = torch.tensor(0.25, dtype=torch.float64, device=device)
+    kl = kl_divergence(torch.distributions.Bernoulli(q), torch.distributions.Bernoulli(p))
+
+    @poutine.scale(scale=scale)
+    def model():
+        with pyro.plate("particles", 1):
+            pyro.sample("z", dist.Bernoulli(p).expand([1]))
+
+    @config_enumerate(default=enumerate1)
+    @poutine.scale(scale=scale)
+    def guide():
+        qq = pyro.param("q")
+        with pyro.plate("particles", 1):
+            pyro.sample("z", dist.Bernoulli(qq).expand([1]))
+
+    elbo = TraceEnum_ELBO(strict_enumeration_warning=True)
+    if method == "loss":
+        assert abs(elbo.loss(model, guide) - kl.item() * scale) < 1e-3
+        return
+    if method == "differentiable_loss":
+        actual = grad(elbo.differentiable_loss(model, guide), [q])[0]
+    else:
+        elbo.loss_and_grads(model, guide)
+        actual = pyro.param("q").unconstrained().grad
+    expected = grad(kl, [q])[0] * scale
+    assert abs(float(actual) - float(expected)) < 1e-3, (actual, expected)
+
+
+def run_elbo_berns(device, method, enums):
+    """Three Bernoulli sites, each enumerated sequentially or in parallel in the guide: the loss is
+    the sum of the three KLs and its gradient w.r.t. the shared q exact (prec 1e-3)."""
+    from torch.distributions import kl_divergence
+    pyro.clear_param_store()
+    q = pyro.param("q", torch.tensor(0.75, dtype=torch.float64, device=device, requires_grad=True))
+    ps = [torch.tensor(v, dtype=torch.float64, device=device) for v in (0.1, 0.2, 0.3)]
+
+    def model():
+        for i, p in enumerate(ps):
+            pyro.sample("x%d" % (i + 1), dist.Bernoulli(p))
+
+    def guide():
+        qq = pyro.param("q")
+        for i, e in enumerate(enums):
+            pyro.sample("x%d" % (i + 1), dist.Bernoulli(qq), infer={"enumerate": e})
+
+    kl = sum(kl_divergence(torch.distributions.Bernoulli(q), torch.distributions.Bernoulli(p))
+             for p in ps)
+    expected_grad = grad(kl, [q])[0]
+    elbo = TraceEnum_ELBO(num_particles=1, vectorize_particles=True, strict_enumeration_warning=True)
+    if method == "differentiable_loss":
+        loss = elbo.differentiable_loss(model, guide)
+        actual_loss, actual_grad = loss.item(), grad(loss, [q])[0]
+    else:
+        actual_loss = elbo.loss_and_grads(model, guide)
+        actual_grad = pyro.param("q").unconstrained().grad
+    assert abs(actual_loss - kl.item()) < 1e-3, (actual_loss, kl.item())
+    assert abs(float(actual_grad) - float(expected_grad)) < 1e-3, (actual_grad, expected_grad)
+
+
+def run_elbo_categoricals(device, enums, max_plate_nesting):
+    """Three Categorical sites of different support sizes, sequential / parallel in any mix."""
+    from torch.distributions import kl_divergence
+
+    def t(v):
+        return torch.tensor(v, dtype=torch.float64, device=device)
+
+    pyro.clear_param_store()
+    ps = [t([0.6, 0.4]), t([0.3, 0.3, 0.4]), t([0.1, 0.2, 0.3, 0.4])]
+    qs = [pyro.param("q%d" % (i + 1), v.requires_grad_(True)) for i, v in enumerate(
+        [t([0.4, 0.6]), t([0.4, 0.3, 0.3]), t([0.4, 0.3, 0.2, 0.1])])]
+
+    def model():
+        for i, p in enumerate(ps):
+            pyro.sample("x%d" % (i + 1), dist.Categorical(p))
+
+    def guide():
+        for i, e in enumerate(enums):
+            pyro.sample("x%d" % (i + 1), dist.Categorical(pyro.param("q%d" % (i + 1))),
+                        infer={"enumerate": e})
+
+    kl = sum(kl_divergence(torch.distributions.Categorical(q), torch.distributions.Categorical(p))
+             for q, p in zip(qs, ps))
+    expected_grads = grad(kl, qs)
+    elbo = TraceEnum_ELBO(max_plate_nesting=max_plate_nesting, strict_enumeration_warning=True)
+    actual_loss = elbo.loss_and_grads(model, guide)
+    assert abs(actual_loss - kl.item()) < 1e-3, (actual_loss, kl.item())
+    for i, e in enumerate(expected_grads):
+        a = pyro.param("q%d" % (i + 1)).unconstrained().grad
+        assert float((a - e).abs().max()) < 1e-3, (i, a, e)

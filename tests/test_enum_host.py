@@ -121,3 +121,26 @@ def test_guide_enumeration_is_the_exact_expectation(_cpu_backend):
 
 def test_guide_enumeration_and_dice_match_reference(_cpu_backend):
     ec.run_guide_enum_vs_reference(load("guide_enum"), CPU)
+
+
+@pytest.mark.parametrize("scale", [1, 10])
+@pytest.mark.parametrize("method", ["loss", "differentiable_loss", "loss_and_grads"])
+@pytest.mark.parametrize("enumerate1", ["sequential", "parallel"])
+def test_elbo_bern(_cpu_backend, method, enumerate1, scale):
+    ekc.run_elbo_bern(CPU, method, enumerate1, scale)
+
+
+@pytest.mark.parametrize("method", ["differentiable_loss", "loss_and_grads"])
+@pytest.mark.parametrize("enums", [("parallel",) * 3, ("sequential",) * 3,
+                                   ("sequential", "parallel", "sequential"),
+                                   ("parallel", "sequential", "parallel")], ids="-".join)
+def test_elbo_berns(_cpu_backend, method, enums):
+    ekc.run_elbo_berns(CPU, method, enums)
+
+
+@pytest.mark.parametrize("max_plate_nesting", [0, 1])
+@pytest.mark.parametrize("enums", [("parallel",) * 3, ("sequential",) * 3,
+                                   ("sequential", "parallel", "parallel"),
+                                   ("parallel", "parallel", "sequential")], ids="-".join)
+def test_elbo_categoricals(_cpu_backend, enums, max_plate_nesting):
+    ekc.run_elbo_categoricals(CPU, enums, max_plate_nesting)
