@@ -414,3 +414,59 @@ def run_bernoulli_beta(device, reparameterized, n_steps, vectorized, hip_graph=F
     a_err = abs(float(pyro.param("alpha_q_log").detach() - log_alpha_n))
     b_err = abs(float(pyro.param("beta_q_log").detach() - log_beta_n))
     assert a_err < 0.08 and b_err < 0.08, (a_err, b_err)
+
+
+def run_elbo_mapdata(device, map_type, batch_size, n_steps, lr):
+    """tests/infer/test_elbo_mapdata.py:20-139: conjugate Normal-Normal with the data mapped through a
+    sequential plate / a vectorised plate / a plain Python loop, optionally subsampled, the guide
+    holding a dummy plate of the same name so that model and guide share the subsample;
+    TraceGraph_ELBO + Adam reach the analytic posterior (sum of squared errors 0.05 / 0.06)."""
+    lam0, loc0 = _t([0.1, 0.1], device), _t([0.0, 0.5], device)
+    lam = _t([6.0, 4.0], device)
+    data = _t([[0.1, 0.21], [0.16, 0.11], [0.06, 0.31], [-0.01, 0.07], [0.23, 0.25], [0.19, 0.18],
+               [0.09, 0.41], [-0.04, 0.17]], device)
+    n = len(data)
+    analytic_lam_n = lam0 + float(n) * lam
+    analytic_log_sig_n = -0.5 * torch.log(analytic_lam_n)
+    analytic_loc_n = data.sum(0) * (lam / analytic_lam_n) + loc0 * (lam0 / analytic_lam_n)
+    off = _t([-0.18, 0.23], device)
+    pyro.clear_param_store()
+    seen = []
+
+    def model():
+        loc_latent = pyro.sample("loc_latent", dist.Normal(loc0, torch.pow(lam0, -0.5)).to_event(1))
+        obs_scale = torch.pow(lam, -0.5)
+        if map_type == "iplate":
+            for i in pyro.plate("aaa", n, batch_size):
+                pyro.sample("obs_%d" % i, dist.Normal(loc_latent, obs_scale).to_event(1), obs=data[i])
+        elif map_type == "plate":
+            with pyro.plate("aaa", n, batch_size) as ind:
+                seen.append(("model", tuple(int(v) for v in ind)))
+                pyro.sample("obs", dist.Normal(loc_latent, obs_scale).to_event(1), obs=data[ind])
+        else:
+            for i, x in enumerate(data):
+                pyro.sample("obs_%d" % i, dist.Normal(loc_latent, obs_scale).to_event(1), obs=x)
+
+    def guide():
+        loc_q = pyro.param("loc_q", lambda: analytic_loc_n.detach().clone() + off)
+        log_sig_q = pyro.param("log_sig_q", lambda: analytic_log_sig_n.detach().clone() - off)
+        pyro.sample("loc_latent", dist.Normal(loc_q, torch.exp(log_sig_q)).to_event(1))
+        if map_type == "iplate":
+            for i in pyro.plate("aaa", n, batch_size):
+                pass
+        elif map_type == "plate":
+            with pyro.plate("aaa", n, batch_size) as ind:
+                seen.append(("guide", tuple(int(v) for v in ind)))
+
+    pyro.set_rng_seed(161)
+    svi = SVI(model, guide, Adam({"lr": lr}), loss=TraceGraph_ELBO())
+    for _ in range(n_steps):
+        svi.step()
+    if map_type == "plate":          # the model replays the guide's subsample, step by step
+        assert len(seen) == 2 * n_steps
+        assert all(seen[2 * k][1] == seen[2 * k + 1][1] for k in range(n_steps))
+        if batch_size is not None and batch_size < n:
+            assert len({s[1] for s in seen}) > 1
+    loc_error = float(((analytic_loc_n - pyro.param("loc_q").detach()) ** 2).sum())
+    log_sig_error = float(((analytic_log_sig_n - pyro.param("log_sig_q").detach()) ** 2).sum())
+    assert loc_error < 0.05 and log_sig_error < 0.06, (loc_error, log_sig_error)

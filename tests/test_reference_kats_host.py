@@ -56,3 +56,11 @@ def test_tracegraph_baselines_host_logic(baseline):
 def test_bernoulli_beta_convergence_vectorized():
     # Beta rsample (torch's _standard_gamma gradients) through two vectorised particles
     kc.run_bernoulli_beta(CPU, True, 5000, vectorized=True)
+
+
+@pytest.mark.parametrize("map_type,batch_size,n_steps,lr", [
+    ("iplate", 8, 100, 0.018), ("iplate", None, 100, 0.013), ("range", None, 100, 0.011),
+    ("plate", 3, 2500, 0.0024)], ids=["iplate-8", "iplate-all", "range", "plate-3"])
+def test_elbo_mapdata(map_type, batch_size, n_steps, lr):
+    # the reference's 7000-step plate cases (lr 0.0008) are shortened here: 2500 steps at 3x the rate
+    kc.run_elbo_mapdata(CPU, map_type, batch_size, n_steps, lr)
