@@ -80,8 +80,8 @@ def _config_fn(default, expand, num_samples, tmc):
 
 def config_enumerate(guide=None, default="parallel", expand=False, num_samples=None, tmc="diagonal"):
     """Mark every enumerable site of ``guide`` (or model) for enumeration."""
-    if default not in ("sequential", "parallel"):
-        raise ValueError("Invalid default value. Expected 'sequential' or 'parallel'")
+    if default not in ("sequential", "parallel", None):
+        raise ValueError("Invalid default value. Expected 'sequential', 'parallel', or None")
     if guide is None:
         return lambda g: config_enumerate(g, default=default, expand=expand,
                                           num_samples=num_samples, tmc=tmc)

@@ -416,11 +416,7 @@ class EnumMessenger(Messenger):
             return
         strategy = msg["infer"].get("enumerate")
         if strategy != "parallel":
-            if strategy == "sequential" and msg["infer"].get("_enum_total") is None:
-                raise NotImplementedError(
-                    "sequential enumeration is handled by TraceEnum_ELBO for GUIDE sites only "
-                    "(site '{}'); use infer={{'enumerate': 'parallel'}} here".format(msg["name"]))
-            return
+            return          # sequential: branched on by SequentialEnumMessenger (guide sites)
         dist = msg["fn"]
         if not getattr(dist, "has_enumerate_support", False):
             raise NotImplementedError("{} does not support enumeration".format(type(dist)))
@@ -435,6 +431,10 @@ class EnumMessenger(Messenger):
             "enumerate_support(expand=False) must not expand batch dims"
         tag = getattr(value, "_pyro_categorical_support", None)
         value = value.reshape(shape[:1] + (1,) * (-1 - dim) + ev)
+        if msg["infer"].get("expand", False):
+            # enumerate_support(expand=True): the support axis, then the full batch shape
+            batch = tuple(dist.batch_shape)
+            value = value.expand(shape[:1] + (1,) * (-1 - dim - len(batch)) + batch + ev)
         if tag is not None:
             value._pyro_categorical_support = tag
         value_dims = {d: param_dims[d] for d in range(event_dim - value.dim(), 0)
@@ -448,6 +448,12 @@ class EnumMessenger(Messenger):
     def _pyro_post_sample(self, msg):
         if not isinstance(msg["fn"], torch.distributions.Distribution) or msg["value"] is None:
             return
+        if not msg["is_observed"] and msg["infer"].get("enumerate") == "sequential" \
+                and msg["infer"].get("_enum_total") is None:
+            # neither branched on in the guide nor replayed from a guide site that was
+            raise NotImplementedError(
+                "sequential enumeration is handled by TraceEnum_ELBO for GUIDE sites only "
+                "(site '{}'); use infer={{'enumerate': 'parallel'}} here".format(msg["name"]))
         value = msg["value"]
         event_dim = len(msg["fn"].event_shape)
         shape = value.shape[:value.dim() - event_dim]
@@ -476,7 +482,7 @@ class SequentialEnumMessenger(Messenger):
         dist = msg["fn"]
         if not getattr(dist, "has_enumerate_support", False):
             raise NotImplementedError("{} does not support enumeration".format(type(dist)))
-        support = dist.enumerate_support(expand=True)
+        support = dist.enumerate_support(expand=bool(msg["infer"].get("expand", False)))
         name = msg["name"]
         if name not in self.assignment:
             for k in range(1, support.shape[0]):

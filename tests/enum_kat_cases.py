@@ -467,3 +467,71 @@ def run_elbo_categoricals(device, enums, max_plate_nesting):
     for i, e in enumerate(expected_grads):
         a = pyro.param("q%d" % (i + 1)).unconstrained().grad
         assert float((a - e).abs().max()) < 1e-3, (i, a, e)
+
+
+# ---- shapes under vectorised particles + enumeration (tests/infer/test_valid_models.py:1661-1795) ---
+def run_vectorized_num_particles(device, elbo_name):
+    from pyro_amd import infer
+    Elbo = getattr(infer, elbo_name)
+    data = torch.ones(1000, 2, device=device)
+    a = torch.tensor(1.1, device=device)
+
+    def model():
+        with pyro.plate("components", 2):
+            p = pyro.sample("p", dist.Beta(a, a))
+            assert p.shape == (10, 1, 2)
+            with pyro.plate("data", data.shape[0]):
+                pyro.sample("obs", dist.Bernoulli(p), obs=data)
+
+    def guide():
+        with pyro.plate("components", 2):
+            pyro.sample("p", dist.Beta(a, a))
+
+    pyro.clear_param_store()
+    g = config_enumerate(guide) if elbo_name == "TraceEnum_ELBO" else guide
+    kw = {"strict_enumeration_warning": False} if elbo_name == "TraceEnum_ELBO" else {}
+    loss = Elbo(num_particles=10, vectorize_particles=True, max_plate_nesting=2, **kw).loss(model, g)
+    assert loss == loss and abs(loss) != float("inf")
+
+
+def run_enum_discrete_vectorized_num_particles(device, enumerate_, expand, num_particles):
+    a = torch.tensor(1.1, device=device)
+    half = torch.tensor(0.5, device=device)
+    P = num_particles
+
+    @config_enumerate(default=enumerate_, expand=expand)
+    def model():
+        x_plate = pyro.plate("x_plate", 10, 5, dim=-1)
+        y_plate = pyro.plate("y_plate", 11, 6, dim=-2)
+        with x_plate:
+            b = pyro.sample("b", dist.Beta(a, a))
+        with y_plate:
+            c = pyro.sample("c", dist.Bernoulli(half))
+        with x_plate, y_plate:
+            d = pyro.sample("d", dist.Bernoulli(b))
+        lead = (P, 1) if P > 1 else ()
+        assert b.shape == lead + (5,) if P > 1 else b.shape == (5,)
+        if enumerate_ == "parallel":
+            if expand:
+                assert c.shape == ((2, P, 6, 1) if P > 1 else (2, 6, 1))
+                assert d.shape == ((2, 1, P, 6, 5) if P > 1 else (2, 1, 6, 5))
+            else:
+                assert c.shape == ((2, 1, 1, 1) if P > 1 else (2, 1, 1))
+                assert d.shape == ((2, 1, 1, 1, 1) if P > 1 else (2, 1, 1, 1))
+        elif enumerate_ == "sequential":
+            if expand:
+                assert c.shape == ((P, 6, 1) if P > 1 else (6, 1))
+                assert d.shape == ((P, 6, 5) if P > 1 else (6, 5))
+            else:
+                assert c.shape == ((1, 1, 1) if P > 1 else (1, 1))
+                assert d.shape == ((1, 1, 1) if P > 1 else (1, 1))
+        else:
+            assert c.shape == ((P, 6, 1) if P > 1 else (6, 1))
+            assert d.shape == ((P, 6, 5) if P > 1 else (6, 5))
+
+    pyro.clear_param_store()
+    pyro.set_rng_seed(0)
+    elbo = TraceEnum_ELBO(max_plate_nesting=2, num_particles=P, vectorize_particles=True,
+                          strict_enumeration_warning=(enumerate_ == "parallel"))
+    loss = elbo.loss(model, model)
+    assert loss == loss and abs(loss) != float("inf")

@@ -144,3 +144,15 @@ def test_elbo_berns(_cpu_backend, method, enums):
                                    ("parallel", "parallel", "sequential")], ids="-".join)
 def test_elbo_categoricals(_cpu_backend, enums, max_plate_nesting):
     ekc.run_elbo_categoricals(CPU, enums, max_plate_nesting)
+
+
+@pytest.mark.parametrize("elbo", ["Trace_ELBO", "TraceGraph_ELBO", "TraceEnum_ELBO"])
+def test_vectorized_num_particles(_cpu_backend, elbo):
+    ekc.run_vectorized_num_particles(CPU, elbo)
+
+
+@pytest.mark.parametrize("enumerate_,expand", [(None, False), ("sequential", False), ("sequential", True),
+                                               ("parallel", False), ("parallel", True)])
+@pytest.mark.parametrize("num_particles", [1, 50])
+def test_enum_discrete_vectorized_num_particles(_cpu_backend, enumerate_, expand, num_particles):
+    ekc.run_enum_discrete_vectorized_num_particles(CPU, enumerate_, expand, num_particles)
