@@ -82,6 +82,11 @@ def config_enumerate(guide=None, default="parallel", expand=False, num_samples=N
     """Mark every enumerable site of ``guide`` (or model) for enumeration."""
     if default not in ("sequential", "parallel", None):
         raise ValueError("Invalid default value. Expected 'sequential', 'parallel', or None")
+    if num_samples is not None:
+        # (reference: enum.py:138-220 + enumerate_site's Monte-Carlo branch) -- not built; summing
+        # the support exactly instead would silently change shapes and variance
+        raise NotImplementedError("pyro_amd: config_enumerate(num_samples=...) (Monte-Carlo "
+                                  "enumeration) is not implemented; enumerate exactly")
     if guide is None:
         return lambda g: config_enumerate(g, default=default, expand=expand,
                                           num_samples=num_samples, tmc=tmc)

@@ -417,6 +417,9 @@ class EnumMessenger(Messenger):
         strategy = msg["infer"].get("enumerate")
         if strategy != "parallel":
             return          # sequential: branched on by SequentialEnumMessenger (guide sites)
+        if msg["infer"].get("num_samples") is not None:
+            raise NotImplementedError("pyro_amd: infer={'num_samples': ...} (Monte-Carlo enumeration) "
+                                      "is not implemented (site '%s')" % msg["name"])
         dist = msg["fn"]
         if not getattr(dist, "has_enumerate_support", False):
             raise NotImplementedError("{} does not support enumeration".format(type(dist)))

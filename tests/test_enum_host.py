@@ -156,3 +156,18 @@ def test_vectorized_num_particles(_cpu_backend, elbo):
 @pytest.mark.parametrize("num_particles", [1, 50])
 def test_enum_discrete_vectorized_num_particles(_cpu_backend, enumerate_, expand, num_particles):
     ekc.run_enum_discrete_vectorized_num_particles(CPU, enumerate_, expand, num_particles)
+
+
+def test_monte_carlo_enumeration_is_refused(_cpu_backend):
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer import TraceEnum_ELBO, config_enumerate
+    with pytest.raises(NotImplementedError):
+        config_enumerate(lambda: None, num_samples=10)
+
+    def model():
+        pyro.sample("x", dist.Bernoulli(torch.tensor(0.3)),
+                    infer={"enumerate": "parallel", "num_samples": 5})
+
+    with pytest.raises(NotImplementedError):
+        TraceEnum_ELBO(max_plate_nesting=0).loss(model, lambda: None)
