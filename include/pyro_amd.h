@@ -310,6 +310,26 @@ int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, con
                              float* ll, float* gw, float* gb, void* workspace,
                              size_t workspace_bytes, pa_stream_t stream);
 
+/* The same pass with the design matrix kept in HBM as its exact 3-way bf16 decomposition
+ * (x = x1 + x2 + x3, the split the matrix-core kernel of variant 0 performs on the fly), packed ONCE
+ * per data set by pa_glm_pack_planes into a tile image (per 32-row tile three [32][32] bf16 planes,
+ * rows >= N and columns >= D zero, padded to whole 128-row groups) that pa_glm_bernoulli_planes_fwd_bwd
+ * streams HBM -> LDS by DMA.  X never changes between ELBO-gradient steps
+ * (pyro/infer/svi.py:134-162 passes the same data tensor every step), so the split, the staging
+ * registers and the LDS writes of the on-the-fly kernel leave the per-step work; the arithmetic and
+ * the outputs are those of pa_glm_bernoulli_fwd_bwd variant 0 (no mask argument: masked plates take
+ * the entry above).  D <= 32; any P (64 particles per pass over the image).
+ * pa_glm_planes_tune(ring_depth 2..4, workgroups per CU; 0 = default) is a measurement knob. */
+size_t pa_glm_planes_bytes(int64_t N, int64_t D);
+int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_t planes_bytes,
+                       pa_stream_t stream);
+int pa_glm_planes_tune(int ring_depth, int blocks_per_cu);
+size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P);
+int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const float* w,
+                                    const float* b, double scale, int64_t N, int64_t D, int64_t P,
+                                    float* ll, float* gw, float* gb, void* workspace,
+                                    size_t workspace_bytes, pa_stream_t stream);
+
 /* Hierarchical variant (BASELINE config 5: logit_n = x_n . w_{g(n)} + b with per-group weights
  * w[P,G,D] under pyro.plate("groups", G)): rows of X are SORTED BY GROUP; the caller describes
  * the work as segments seg[nseg][3] = {row_begin, row_end, group} (device int64; each segment

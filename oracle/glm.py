@@ -51,3 +51,44 @@ def glm_bernoulli_grouped_fwd_bwd(X, y, w, group_of_row, b=None, mask=None, scal
         sel = g_of == grp
         gw[:, grp, :] = g[:, sel] @ X[sel]
     return scale * lp.sum(1), scale * gw, scale * g.sum(1)
+
+
+# ---- the plane image of pa_glm_pack_planes (include/pyro_amd.h), restated in numpy ---------------
+def _bf16_round(x):
+    """f32 array -> f32 array holding the nearest bf16 (round to nearest even), as
+    v_cvt_pk_bf16_f32 does for finite inputs."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def bf16_split3(x):
+    """x (f32) -> (x1, x2, x3) bf16-valued f32 arrays with x1 + x2 + x3 == x exactly (finite x
+    away from the bf16 overflow / f32 underflow ranges): the residuals are computed in f32,
+    where they are exact."""
+    x = np.asarray(x, dtype=np.float32)
+    x1 = _bf16_round(x)
+    r = (x - x1).astype(np.float32)
+    x2 = _bf16_round(r)
+    x3 = _bf16_round((r - x2).astype(np.float32))
+    return x1, x2, x3
+
+
+def glm_plane_image(X):
+    """uint16 image [tiles, 3 planes, 1024] of an [N, D <= 32] f32 design matrix: per 32-row tile
+    three [32 rows][32 cols] bf16 planes, the four 16-byte slots (8 columns) of row r stored at slot
+    s ^ ((r >> 2) & 3); rows >= N and columns >= D are zero; whole 128-row groups."""
+    X = np.asarray(X, dtype=np.float32)
+    N, D = X.shape
+    assert D <= 32
+    tiles = -(-max(N, 0) // 32)
+    tiles = -(-tiles // 4) * 4
+    Xp = np.zeros((tiles * 32, 32), dtype=np.float32)
+    Xp[:N, :D] = X
+    img = np.zeros((tiles, 3, 32, 4, 8), dtype=np.uint16)
+    r = np.arange(32)
+    for pl, piece in enumerate(bf16_split3(Xp)):
+        bits = (piece.view(np.uint32) >> 16).astype(np.uint16).reshape(tiles, 32, 4, 8)
+        for s in range(4):
+            img[:, pl, r, s ^ ((r >> 2) & 3), :] = bits[:, r, s, :]
+    return img.reshape(tiles, 3, 1024)

@@ -18,6 +18,11 @@ OBJ_DIR = os.path.join(HERE, "build")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file additions.  glm.hip: the matrix-core GLM kernels interleave f32 element-wise math with bf16
+# MFMAs; packed f32 instructions (which the SLP vectoriser forms from adjacent scalar operations) do
+# not overlap the MFMAs on gfx950 and cost 2-4x a plain instruction next to them
+# (tools/probes/issue_probe.hip), so that file is built without SLP vectorisation.
+FILE_FLAGS = {"glm.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -36,7 +41,7 @@ def _compile(src, force, hdr_mtime):
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(spath), hdr_mtime)):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", spath, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", spath, "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, res.stdout, res.stderr))

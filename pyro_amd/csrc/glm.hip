@@ -22,6 +22,7 @@
 //   * deterministic reduction: per-block partials -> fp64 finalize kernel (no float atomics).
 #include "common.h"
 #include "glm_bf16.h"
+#include "glm_planes.h"
 
 namespace pa {
 
@@ -290,7 +291,7 @@ constexpr int FIN_OUT = 8, FIN_GROUPS = 32;
 template <int DT, int PT>
 __global__ __launch_bounds__(FIN_OUT * FIN_GROUPS) void glm_finalize_kernel(
     const float* __restrict__ part, int nblocks, int npass, int D, int P, double scale,
-    float* __restrict__ ll, float* __restrict__ gw, float* __restrict__ gb) {
+    float* __restrict__ ll, float* __restrict__ gw, float* __restrict__ gb, double ll_offset) {
   constexpr int REC = glm_record_floats<DT, PT>();
   __shared__ double sm[FIN_GROUPS][FIN_OUT];
   const int jj = threadIdx.x % FIN_OUT, s = threadIdx.x / FIN_OUT;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(FIN_OUT * FIN_GROUPS) void glm_finalize_kernel(
     for (int k = 0; k < FIN_GROUPS; ++k) t += sm[k][jj];
     const float v = (float)(t * scale);
     if (j < (int64_t)P * D) gw[j] = v;
-    else if (j < (int64_t)P * D + P) ll[j - (int64_t)P * D] = v;
+    else if (j < (int64_t)P * D + P) ll[j - (int64_t)P * D] = (float)((t + ll_offset) * scale);
     else gb[j - (int64_t)P * D - P] = v;
   }
 }
@@ -424,7 +425,7 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   const int64_t J = (int64_t)P * D + 2 * P;
   hipLaunchKernelGGL((glm_finalize_kernel<DT, PT>), dim3((unsigned)((J + FIN_OUT - 1) / FIN_OUT)),
                      dim3(FIN_OUT * FIN_GROUPS), 0, s, part, pl.nblocks, pl.npass, D, P, scale, ll,
-                     gw, gb);
+                     gw, gb, 0.0);
   return check_launch("glm_finalize_kernel");
 }
 
@@ -517,6 +518,45 @@ static int glm_grouped_launch(const float* X, const float* y, const float* w, co
   hipLaunchKernelGGL((glm_grouped_finalize_scalar_kernel<DT, PT>), dim3((unsigned)(2 * P)),
                      dim3(256), 0, s, part, nseg, P, scale, ll, gb);
   return check_launch("glm_grouped_finalize");
+}
+
+// ---- design matrix kept as its bf16 planes (glm_planes.h) -----------------------------------------
+// developer knobs (pa_glm_planes_tune): ring depth and workgroups per CU; 0 = defaults
+static int g_planes_nb = 3;
+static int g_planes_bpc = 0;
+
+static int64_t glm_planes_tiles(int64_t N) {
+  const int64_t t = (N + 31) / 32;
+  return (t + GLMP_PAD_TILES - 1) / GLMP_PAD_TILES * GLMP_PAD_TILES;
+}
+
+struct GlmPlanesPlan {
+  int nb, bpc, npass, nblocks;
+  int64_t nst;
+};
+
+static GlmPlanesPlan glm_planes_plan(int64_t N, int64_t P) {
+  GlmPlanesPlan pl;
+  pl.nb = g_planes_nb;
+  const int bpc_max = pl.nb == 2 ? 4 : (pl.nb == 3 ? 3 : 2);      // what the LDS ring admits
+  pl.bpc = g_planes_bpc > 0 && g_planes_bpc < bpc_max ? g_planes_bpc : bpc_max;
+  pl.npass = (int)((P + 63) / 64);
+  pl.nst = ((N + 31) / 32 + 1) / 2;                               // 64-row super-tiles
+  int64_t cap = (int64_t)cu_count() * pl.bpc / pl.npass;
+  if (cap < 1) cap = 1;
+  pl.nblocks = (int)(pl.nst < cap ? (pl.nst < 1 ? 1 : pl.nst) : cap);
+  return pl;
+}
+
+template <int NB, int OCC>
+static void glm_planes_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
+                                  const float* w, const float* b, int64_t N, int D, int P,
+                                  float* part, hipStream_t s) {
+  auto k = glm_planes_kernel<2, NB, OCC>;
+  constexpr int lds = GlmPlCfg<2, NB>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
+                     b, N, D, P, pl.nst, part, cu_count());
 }
 
 static void glm_tiles_of(int64_t D, int64_t P, int* DT, int* PT) {
@@ -648,6 +688,93 @@ int pa_glm_bernoulli_grouped_fwd_bwd(const float* X, const float* y, const float
   PA_GLMG_CASE(4, 1)
 #undef PA_GLMG_CASE
   return pa::fail(PA_ERR_UNSUPPORTED, "glm_grouped: no kernel for DT=%d PT=%d", DT, PT);
+}
+
+size_t pa_glm_planes_bytes(int64_t N, int64_t D) {
+  if (N < 0 || D < 1 || D > 32) return 0;
+  return (size_t)pa::glm_planes_tiles(N) * pa::GLMP_TILE;
+}
+
+int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_t planes_bytes,
+                       pa_stream_t stream) {
+  PA_REQUIRE(N >= 0 && D >= 1, "glm_pack_planes: bad shape N=%lld D=%lld", (long long)N, (long long)D);
+  if (D > 32)
+    return pa::fail(PA_ERR_UNSUPPORTED, "glm_pack_planes: the plane image holds D <= 32 (got %lld)",
+                    (long long)D);
+  PA_REQUIRE(N < (int64_t(1) << 40), "glm_pack_planes: shape too large");
+  PA_REQUIRE(planes && planes_bytes >= pa_glm_planes_bytes(N, D), "glm_pack_planes: image too small");
+  PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_pack_planes: unaligned image");
+  PA_REQUIRE(N == 0 || X, "glm_pack_planes: NULL data pointer");
+  const int64_t nt = pa::glm_planes_tiles(N);
+  if (nt == 0) return PA_OK;
+  hipLaunchKernelGGL(pa::glm_pack_planes_kernel, dim3((unsigned)((nt * 128 + 255) / 256)), dim3(256),
+                     0, pa::as_stream(stream), X, N, (int)D, nt, (unsigned char*)planes);
+  return pa::check_launch("glm_pack_planes_kernel");
+}
+
+int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
+  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 2 && ring_depth <= 4),
+             "glm_planes_tune: ring depth 2..4 (0 = default)");
+  PA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 4, "glm_planes_tune: 0..4 workgroups per CU");
+  pa::g_planes_nb = ring_depth == 0 ? 3 : ring_depth;
+  pa::g_planes_bpc = blocks_per_cu;
+  return PA_OK;
+}
+
+size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P) {
+  if (N < 0 || D < 1 || D > 32 || P < 1) return 0;
+  const pa::GlmPlanesPlan pl = pa::glm_planes_plan(N, P);
+  // records of the deepest / widest tuning so that the knob never invalidates a workspace
+  const size_t cap = (size_t)pa::cu_count() * 4;
+  const size_t nb = (size_t)pl.nst < cap ? (size_t)(pl.nst < 1 ? 1 : pl.nst) : cap;
+  return nb * pl.npass * (2 * 1024 + 2 * 2 * 32) * sizeof(float);
+}
+
+int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const float* w,
+                                    const float* b, double scale, int64_t N, int64_t D, int64_t P,
+                                    float* ll, float* gw, float* gb, void* workspace,
+                                    size_t workspace_bytes, pa_stream_t stream) {
+  PA_REQUIRE(N >= 0 && D >= 1 && P >= 1, "glm_planes: bad shape N=%lld D=%lld P=%lld", (long long)N,
+             (long long)D, (long long)P);
+  if (D > 32)
+    return pa::fail(PA_ERR_UNSUPPORTED, "glm_planes: the plane image holds D <= 32 (got %lld)",
+                    (long long)D);
+  PA_REQUIRE(N < (int64_t(1) << 40) && P < (1 << 20), "glm_planes: shape too large");
+  PA_REQUIRE(w && ll && gw && gb, "glm_planes: NULL parameter/output pointer");
+  PA_REQUIRE(N == 0 || (planes && y), "glm_planes: NULL data pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (N == 0) {
+    hipError_t e1 = hipMemsetAsync(ll, 0, (size_t)P * 4, s);
+    hipError_t e2 = hipMemsetAsync(gw, 0, (size_t)P * D * 4, s);
+    hipError_t e3 = hipMemsetAsync(gb, 0, (size_t)P * 4, s);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+      return pa::fail(PA_ERR_LAUNCH, "glm_planes: memset failed");
+    return PA_OK;
+  }
+  PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_planes: unaligned image");
+  PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_planes_workspace(N, D, P),
+             "glm_planes: workspace too small");
+  const pa::GlmPlanesPlan pl = pa::glm_planes_plan(N, P);
+  float* part = (float*)workspace;
+  const unsigned char* img = (const unsigned char*)planes;
+  hipEvent_t ev0, ev1;
+  const bool br = pa::take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
+  if (pl.nb == 2) pa::glm_planes_launch_one<2, 4>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
+  else if (pl.nb == 3) pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
+  else pa::glm_planes_launch_one<4, 2>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
+  if (br) (void)hipEventRecord(ev1, s);
+  int rc = pa::check_launch("glm_planes_kernel");
+  if (rc != PA_OK) return rc;
+  const int64_t J = (int64_t)P * D + 2 * P;
+  hipLaunchKernelGGL((pa::glm_finalize_kernel<1, 2>),
+                     dim3((unsigned)((J + pa::FIN_OUT - 1) / pa::FIN_OUT)),
+                     dim3(pa::FIN_OUT * pa::FIN_GROUPS), 0, s, part, pl.nblocks, pl.npass, (int)D,
+                     (int)P, scale, ll, gw, gb,
+                     // every padding row of the processed super-tiles added log2(2) = 1 to the
+                     // log2(1 + e) sum of every particle (glm_planes.h): ln2 per row back in
+                     (double)(pl.nst * 64 - N) * 0.6931471805599453);
+  return pa::check_launch("glm_finalize_kernel");
 }
 
 }  // extern "C"

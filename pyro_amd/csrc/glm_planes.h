@@ -1,0 +1,475 @@
+// glm_planes.h -- the fused Bernoulli-logits GLM pass (forward + gradient) on the bf16 matrix cores
+// with the design matrix kept in HBM as its three bf16 planes (included by glm.hip; same record
+// format and finalize kernel as the other GLM kernels).
+//
+// The reference recomputes everything of size [P, N] every ELBO-gradient step
+// (pyro/poutine/trace_struct.py:264-278 + autograd duals); X itself never changes between steps.
+// pa_glm_pack_planes splits X ONCE into the exact 3-way bf16 decomposition x = x1 + x2 + x3 of
+// glm_bf16.h (same rounding, same bits) and stores it as a TILE IMAGE: per 32-row tile three planes
+// [32 rows][32 cols] bf16 of 2048 B each, the 16-byte slots of a row XOR-swizzled so that the image
+// can be copied verbatim into LDS (buffer/global_load ... lds: 64 lanes x 16 B, lane-linear, no
+// VGPRs, no ds_write) and then read conflict-free both as rows (ds_read_b128: A operand of
+// GEMM1) and as columns (ds_read_b64_tr_b16: B operand of GEMM2).
+//
+// Work decomposition (P <= 64 particles per pass, NPT = 1 or 2 particle tiles of 32):
+//   workgroup = 4 waves = NRT row tiles x NPT particle tiles of one SUPER-TILE of 32*NRT rows;
+//   a wave owns 32 rows x 32 particles: 13 + 12 bf16 MFMAs and 16 accumulator elements per lane and
+//   tile, <= 168 VGPRs => 3 waves per SIMD (the r01 kernel: 64 particles per wave, 2 waves per SIMD).
+//   The super-tile images travel HBM -> LDS through an NB-deep ring, NB-1 tiles ahead, one raw
+//   s_barrier per tile; waits are counted (s_waitcnt vmcnt(N)), never drained in the loop.
+#pragma once
+#include "glm_bf16.h"
+
+namespace pa {
+
+constexpr int GLMP_PLANE = 2048;            // bytes of one plane of a 32-row tile
+constexpr int GLMP_TILE = 3 * GLMP_PLANE;   // bytes of one 32-row tile image
+constexpr int GLMP_PAD_TILES = 4;           // the image is padded to whole 128-row groups
+constexpr float GLMP_LOG2E = 1.44269504088896340736f;
+
+// byte offset of (row r, 16-byte slot s = 8 columns) inside one plane
+__host__ __device__ constexpr int glmp_slot_ofs(int r, int s) {
+  return r * 64 + ((s ^ ((r >> 2) & 3)) << 4);
+}
+
+// one thread per (tile, row, slot): 8 consecutive features of one row -> 3 x 16 B
+__global__ __launch_bounds__(256) void glm_pack_planes_kernel(const float* __restrict__ X, int64_t N,
+                                                              int D, int64_t ntiles,
+                                                              unsigned char* __restrict__ img) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ntiles * 128) return;
+  const int64_t T = idx >> 7;
+  const int r = (int)(idx >> 2) & 31, s = (int)idx & 3;
+  const int64_t row = T * 32 + r;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int d = 8 * s + j;
+    v[j] = (row < N && d < D) ? X[row * D + d] : 0.0f;
+  }
+  uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p1[j], p2[j], p3[j]);
+  unsigned char* q = img + T * GLMP_TILE + glmp_slot_ofs(r, s);
+  *reinterpret_cast<uint4*>(q) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+  *reinterpret_cast<uint4*>(q + GLMP_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+  *reinterpret_cast<uint4*>(q + 2 * GLMP_PLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+}
+
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+
+// split_pair of glm_bf16.h written on scalars (same roundings, same bits): two v_sub_f32 per level
+// instead of one v_pk_add_f32
+__device__ __forceinline__ void split_pair_scalar(float a, float b, uint32_t& p1, uint32_t& p2,
+                                                  uint32_t& p3) {
+  p1 = cvt_pk_bf16(a, b);
+  const float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
+  p2 = cvt_pk_bf16(ra, rb);
+  const float qa = ra - bf16_lo(p2), qb = rb - bf16_hi(p2);
+  p3 = cvt_pk_bf16(qa, qb);
+}
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+template <int NPT, int NB>
+struct GlmPlCfg {
+  static constexpr int NRT = 4 / NPT;                  // row tiles per super-tile
+  static constexpr int ST_BYTES = NRT * GLMP_TILE;     // super-tile image
+  static constexpr int PW = NRT * 6 / 4;               // 1 KiB DMA pieces per wave and super-tile
+  static constexpr int NDMA = PW + 1;                  // + the wave's 32 observations
+  static constexpr int WROWS = 32 * NPT;
+  static constexpr int WPL = WROWS * 64;               // one W plane
+  static constexpr int OFS_WAUX = 3 * WPL;
+  static constexpr int OFS_RING = OFS_WAUX + WROWS * 8;
+  static constexpr int OFS_Y = OFS_RING + NB * ST_BYTES;
+  static constexpr int LDS_BYTES = OFS_Y + NB * 4 * 256;
+};
+
+// LDS-DMA as inline asm: 64 lanes x 16 B (or 4 B) from per-lane global addresses to the wave-uniform
+// LDS byte address `lds_dst` + lane * 16 (4).  Written as asm on purpose: hipcc orders LDS reads
+// behind an LDS-DMA it can see with s_waitcnt vmcnt(0) (it cannot tell which bytes the DMA writes),
+// which would drain the prefetch ring in every iteration; the loop below waits with counted
+// s_waitcnt vmcnt(N) + s_barrier instead.  M0 (the LDS base of the DMA) is compiler-reserved:
+// saved, set and restored inside the one statement.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// Exact 3-way split of a pair by TRUNCATION: piece 1 = the upper 16 bits of the f32 (8 significant
+// bits), the residual (exact in f32, <= 16 significant bits) again, the second residual (<= 8
+// significant bits) is a bf16 itself.  a = a1 + a2 + a3 exactly for every finite a (subnormal
+// residuals included).  Two v_and + two v_sub per level on the fast VALU path and one v_perm_b32 to
+// pack a pair's upper halves; the round-to-nearest split of glm_bf16.h needs v_cvt_pk + a shift
+// (both on the slow path) per level.
+__device__ __forceinline__ uint32_t pack_hi16(float a, float b) {   // {bf16 bits of a, of b}
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a),
+                               0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float a) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) & 0xffff0000u);
+}
+__device__ __forceinline__ void split_pair_trunc(float a, float b, uint32_t& p1, uint32_t& p2,
+                                                 uint32_t& p3) {
+  p1 = pack_hi16(a, b);
+  const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
+  p2 = pack_hi16(ra, rb);
+  const float qa = ra - trunc_bf16(ra), qb = rb - trunc_bf16(rb);
+  p3 = pack_hi16(qa, qb);
+}
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+// tools/probes/glm_planes_probe: per-phase shader-clock stamps of one wave per workgroup
+#ifdef PA_GLMP_STAMP
+#define PA_STAMP(i)                                                              \
+  do {                                                                           \
+    const uint64_t now_ = __builtin_readcyclecounter();                          \
+    stamp_acc[i] += now_ - stamp_last;                                           \
+    stamp_last = now_;                                                           \
+  } while (0)
+#else
+#define PA_STAMP(i) do { } while (0)
+#endif
+
+template <int NPT, int NB, int OCC>
+__global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
+    const unsigned char* __restrict__ img, const float* __restrict__ y,
+    const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
+    int64_t nst, float* __restrict__ part, int prio_cus) {
+  using C = GlmPlCfg<NPT, NB>;
+  constexpr int NRT = C::NRT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS, WPL = C::WPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int rt = wave / NPT, pt = wave % NPT;
+  const int pbase = blockIdx.y * WROWS;
+
+#ifdef PA_GLMP_STAMP
+  const uint64_t stamp_entry = wall_clock64();
+#endif
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  const int64_t grid = gridDim.x;
+  const int64_t first = blockIdx.x;
+  const int64_t my_count = first < nst ? (nst - first + grid - 1) / grid : 0;
+
+  // ---- DMA of super-tile `st` (clamped: prefetches past the end re-read the last one) into ring
+  //      slot `bi`: this wave's PW pieces of the image + its 32 observations --------------------
+  auto issue = [&](int64_t st, int bi) {
+#ifdef PA_GLMP_ABL_NODMA
+    return;
+#endif
+    const int64_t stc = st < nst ? st : nst - 1;
+    const unsigned char* src = img + stc * ST_BYTES + (wave * PW) * 1024 + lane * 16;
+    const uint32_t dst = lds_base + C::OFS_RING + bi * ST_BYTES + (wave * PW) * 1024;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) dma16(src + k * 1024, dst + k * 1024);
+    int64_t row = (stc * NRT + rt) * 32 + l31;
+    row = row < N ? row : N - 1;
+    dma4(y + row, lds_base + C::OFS_Y + (bi * 4 + wave) * 256);
+  };
+
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) issue(first + k * grid, k);
+
+  // ---- W planes (same row image as X: slot swizzle by row) and the bias pieces, once per block --
+  for (int idx = threadIdx.x; idx < WROWS * 4; idx += 256) {
+    const int pl = idx >> 2, s = idx & 3;
+    const int p = pbase + pl;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = 8 * s + j;
+      // log2(e) rides in W and b (one f32 rounding each): the accumulator then holds
+      // l2 = l * log2(e), the argument of the hardware exp2 / the natural scale of log2
+      v[j] = (p < P && d < D) ? w[(int64_t)p * D + d] * GLMP_LOG2E : 0.0f;
+    }
+    uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p1[j], p2[j], p3[j]);
+    unsigned char* q = smem + (pl >> 5) * GLMP_PLANE + glmp_slot_ofs(pl & 31, s);
+    *reinterpret_cast<uint4*>(q) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+    *reinterpret_cast<uint4*>(q + WPL) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    *reinterpret_cast<uint4*>(q + 2 * WPL) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+  }
+  uint32_t* waux = reinterpret_cast<uint32_t*>(smem + C::OFS_WAUX);
+  for (int pl = threadIdx.x; pl < WROWS; pl += 256) {
+    const int p = pbase + pl;
+    const float bv = (p < P && b != nullptr) ? b[p] * GLMP_LOG2E : 0.0f;
+    uint32_t p1, p2, p3;
+    split_pair(bv, 0.0f, p1, p2, p3);
+    waux[2 * pl] = BF16_ONE | (p1 << 16);                    // k slots {0: 1.0, 1: b1}
+    waux[2 * pl + 1] = (p2 & 0xffffu) | (p3 << 16);          // k slots {2: b2, 3: b3}
+  }
+  __syncthreads();
+
+  const bf16x8 b_aux = as_bf16x8(h == 0 ? waux[2 * (pt * 32 + l31)] : 0u,
+                                 h == 0 ? waux[2 * (pt * 32 + l31) + 1] : 0u, 0u, 0u);
+  f32x16v gwacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gwacc[r] = 0.0f;
+  float s_yl[2] = {0.0f, 0.0f}, s_abs[2] = {0.0f, 0.0f}, s_g[2] = {0.0f, 0.0f};
+  // sum_n log2(t_n), t in [1, 2], is kept as an exponent count plus a running product of mantissas:
+  // one multiply per element instead of one v_log_f32 (8 issue cycles) + one add, and two
+  // v_frexp per 8 elements; the logarithm of the two products is taken once, after the loop
+  float p_t[2] = {1.0f, 1.0f};
+  int e_t[2] = {0, 0};
+
+  // lane-constant LDS offsets
+  //   A operand of GEMM1 / B operand (W): row l31, K chunk c, slot 2c + h
+  const int a_ofs0 = glmp_slot_ofs(l31, h), a_ofs1 = glmp_slot_ofs(l31, 2 + h);
+  const unsigned char* w_row = smem + pt * GLMP_PLANE;
+  //   B operand of GEMM2 (transpose read): within a 16-lane group lane q passes the address of 4
+  //   consecutive bf16 of row 4h + (q >> 2), columns 16*(group & 1) + 4*(q & 3) .. +3, and receives
+  //   column q of that 4 x 16 block; the rows of K half kh are 16kh + 4h + {0..3} and + 8, whose
+  //   slot swizzle is h and h + 2
+  const int q = lane & 15, gi1 = (lane >> 4) & 1;
+  const int tr_row = 4 * h + (q >> 2);
+  const int tr_slot = 2 * gi1 + ((q & 3) >> 1), tr_in = (q & 1) * 8;
+  const int tr_ofs_a = tr_row * 64 + ((tr_slot ^ h) << 4) + tr_in;              // rows +0..3
+  const int tr_ofs_b = (tr_row + 8) * 64 + ((tr_slot ^ ((h + 2) & 3)) << 4) + tr_in;   // rows +8..11
+
+  constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
+  constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
+
+#ifdef PA_GLMP_STAMP
+  uint64_t stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t stamp_last = __builtin_readcyclecounter();
+  const uint64_t stamp_t0 = stamp_last, stamp_w0 = wall_clock64();
+#endif
+  int64_t st = first;
+  int bi = 0;
+  const uint32_t prio_slot = (uint32_t)(blockIdx.x / prio_cus);
+  uint64_t prio_clock = wall_clock64();
+  for (int64_t it = 0; it < my_count; ++it) {
+    PA_STAMP(7);
+    // The SIMD arbitrates between its waves by priority, then AGE: left alone, the workgroup that
+    // was dispatched first to a CU runs ahead of its co-residents and finishes ~25 us early, and the
+    // youngest one runs the tail alone at a third of the CU's issue rate (measured:
+    // tools/probes/glm_planes_probe).  Time slices of 2.56 us rotate the priority levels over the
+    // co-resident workgroups (slot = blockIdx.x / #CUs: speed only, no correctness dependence).
+#ifndef PA_GLMP_ABL_NOPRIO
+    if constexpr (OCC > 1) {
+      const uint32_t ph = ((uint32_t)(prio_clock >> 8) + prio_slot) % (uint32_t)OCC;
+      if (ph == 0) __builtin_amdgcn_s_setprio(0);
+      else if (ph == 1) __builtin_amdgcn_s_setprio(1);
+      else if (ph == 2) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(3);
+      prio_clock = wall_clock64();     // read now, used at the next tile: the SMEM latency hides
+    }
+#endif
+    wait_vmcnt<(NB - 2) * C::NDMA>();       // this wave's pieces of super-tile `it` have landed
+    PA_STAMP(0);
+    __builtin_amdgcn_s_barrier();           // ... and everybody else's; slot (it-1) % NB is free
+    PA_STAMP(1);
+    {
+      int bn = bi + (NB - 1);
+      bn = bn >= NB ? bn - NB : bn;
+      issue(st + (NB - 1) * grid, bn);
+    }
+    const unsigned char* Xt = smem + C::OFS_RING + bi * ST_BYTES + rt * GLMP_TILE;
+    float* ys = reinterpret_cast<float*>(smem + C::OFS_Y + (bi * 4 + wave) * 256);
+    // Rows past the end of the plate (the image holds zeros there) must not count: their aux
+    // operand is all zero (no bias), so their logit is exactly 0, and their y - 1/2 is stored as 0:
+    // then g = 0 - copysign(1/2 - 1/2, 0) = 0 and every running sum gets 0 except the log2(1 + e)
+    // sum, which gets log2(2) = 1 per such row and particle -- a known count, taken out again by the
+    // finalize step (ll_pad_rows).  The wave's 32 observations are turned into y - 1/2 in place.
+    const int64_t rows_left = N - (st * NRT + rt) * 32;        // scalar
+    const bool okr = (int64_t)l31 < rows_left;
+    if (lane < 32) ys[lane] = okr ? ys[lane] - 0.5f : 0.0f;
+    const uint32_t tr_a = (uint32_t)(uintptr_t)Xt + (uint32_t)tr_ofs_a;
+    const uint32_t tr_b = (uint32_t)(uintptr_t)Xt + (uint32_t)tr_ofs_b;
+    // ---- GEMM1: L2[n, p] = log2(e) (sum_d X[n, d] W[p, d] + b[p]) -------------------------------
+    f32x16v acc;
+    {
+      const uint32_t a0 = (h == 0 && okr) ? (BF16_ONE << 16) : 0u;              // k slots {-, 1.0}
+      const uint32_t a1 = (h == 0 && okr) ? (BF16_ONE | (BF16_ONE << 16)) : 0u;  // k slots {1.0, 1.0}
+      const f32x16v zero = {};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0, a1, 0u, 0u), b_aux, zero, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 xa[3], wa[3];
+      const int ao = c == 0 ? a_ofs0 : a_ofs1;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        xa[pl] = *reinterpret_cast<const bf16x8*>(Xt + pl * GLMP_PLANE + ao);
+        wa[pl] = *reinterpret_cast<const bf16x8*>(w_row + pl * WPL + ao);
+      }
+#ifdef PA_GLMP_ABL_NOGEMM1
+      acc[c] += __builtin_bit_cast(float, (uint32_t)xa[0][0] ^ (uint32_t)wa[1][1] ^ (uint32_t)xa[2][2] ^ (uint32_t)wa[0][3] ^ (uint32_t)xa[1][0] ^ (uint32_t)wa[2][0]);
+#else
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[TA[t]], wa[TB[t]], acc, 0, 0, 0);
+#endif
+    }
+
+#ifdef PA_GLMP_STAMP
+    asm volatile("" : "+v"(acc));
+    PA_STAMP(2);
+#endif
+    // ---- element-wise on the accumulator (rows n = (r&3) + 8(r>>2) + 4h of this wave's tile), per
+    //      K half of GEMM2.  Plain (unpacked) f32 instructions only: v_pk_*_f32 does not overlap the
+    //      bf16 MFMAs on gfx950 and costs 2-4x a plain VALU instruction next to them
+    //      (tools/probes/issue_probe: up to ~6 plain VALU / 2 transcendentals per MFMA issue for
+    //      free).  With e = exp(-|l|), t = 1 + e:
+    //        y l - softplus(l) = ln2 ((y - 1/2) l2 - |l2|/2 - log2(t))   (three running sums)
+    //        g = y - sigmoid(l) = (y - 1/2) - copysign(1/t - 1/2, l2)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      // B operand of GEMM2 for this K half: ds_read_b64_tr_b16 as inline asm (the builtin makes
+      // hipcc drain vmcnt(0) in front of it -- it cannot tell the read from the LDS-DMA writes in
+      // flight -- which would shorten the prefetch ring to one tile)
+      v2u32 xlo[3], xhi[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        if (kh == 0) {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xlo[pl]) : "v"(tr_a), "n"(pl * GLMP_PLANE));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[pl]) : "v"(tr_b), "n"(pl * GLMP_PLANE));
+        } else {
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xlo[pl]) : "v"(tr_a), "n"(pl * GLMP_PLANE + 1024));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[pl]) : "v"(tr_b), "n"(pl * GLMP_PLANE + 1024));
+        }
+      }
+      const float4 y0 = *reinterpret_cast<const float4*>(ys + 16 * kh + 4 * h);
+      const float4 y1 = *reinterpret_cast<const float4*>(ys + 16 * kh + 8 + 4 * h);
+      const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+      float g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float l2 = acc[8 * kh + i];
+        const float yh = yv[i];
+#if defined(PA_GLMP_ABL_NOTRANS)     // ablation probes (tools/probes/build_glm_planes_probes.sh)
+        const float e = -__builtin_fabsf(l2) * 0.25f;
+        const float t = e + 1.0f;
+        const float inv = t - 0.25f;
+#elif defined(PA_GLMP_ABL_ONETRANS)
+        const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(l2));
+        const float t = e + 1.0f;
+        const float inv = t - 0.25f;
+#else
+        const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(l2));
+        const float t = e + 1.0f;
+        const float inv = __builtin_amdgcn_rcpf(t);
+#endif
+        s_yl[i & 1] = __builtin_fmaf(yh, l2, s_yl[i & 1]);
+        s_abs[i & 1] += __builtin_fabsf(l2);
+        p_t[i & 1] *= t;          // sum of log2(t) = log2 of the running product (renormalised below)
+        g[i] = yh - __builtin_copysignf(inv - 0.5f, l2);
+        s_g[i & 1] += g[i];
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {      // 4 factors <= 2 since the last renormalisation: < 16
+        e_t[c2] += __builtin_amdgcn_frexp_expf(p_t[c2]);
+        p_t[c2] = __builtin_amdgcn_frexp_mantf(p_t[c2]);
+      }
+      uint32_t g1[4], g2[4], g3[4];
+#pragma unroll
+#ifdef PA_GLMP_ABL_NOSPLIT
+      for (int i = 0; i < 4; ++i) { g1[i] = pack_hi16(g[2 * i], g[2 * i + 1]); g2[i] = g1[i] ^ 0x10001u; g3[i] = g1[i] ^ 0x20002u; }
+#else
+      for (int i = 0; i < 4; ++i) split_pair_trunc(g[2 * i], g[2 * i + 1], g1[i], g2[i], g3[i]);
+#endif
+#ifdef PA_GLMP_STAMP
+      asm volatile("" : "+v"(g3[0]), "+v"(g3[1]), "+v"(g3[2]), "+v"(g3[3]));
+      PA_STAMP(3 + 2 * kh);
+#endif
+      // the six transpose reads of this K half were issued in front of the element-wise block;
+      // hipcc does not count inline-asm DS operations, so wait for them here.  The wait statement
+      // names every destination: nothing that consumes them moves above it.
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1]), "+v"(xlo[2]), "+v"(xhi[2])
+                   :
+                   : "memory");
+      bf16x8 xb[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const u32x4v cc = {xlo[pl][0], xlo[pl][1], xhi[pl][0], xhi[pl][1]};
+        xb[pl] = __builtin_bit_cast(bf16x8, cc);
+      }
+      const bf16x8 ga[3] = {as_bf16x8(g1[0], g1[1], g1[2], g1[3]), as_bf16x8(g2[0], g2[1], g2[2], g2[3]),
+                            as_bf16x8(g3[0], g3[1], g3[2], g3[3])};
+#ifdef PA_GLMP_ABL_NOGEMM2
+      gwacc[kh] += __builtin_bit_cast(float, g1[0] ^ g2[1] ^ g3[2] ^ xlo[0][0] ^ xhi[1][1] ^ xlo[2][0]);
+#else
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        gwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[TA[t]], xb[TB[t]], gwacc, 0, 0, 0);
+#endif
+#ifdef PA_GLMP_STAMP
+      asm volatile("" : "+v"(gwacc));
+      PA_STAMP(4 + 2 * kh);
+#endif
+    }
+    st += grid;
+    bi = bi + 1 == NB ? 0 : bi + 1;
+  }
+#ifdef PA_GLMP_STAMP
+  if (lane == 0 && blockIdx.y == 0) {
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(part) + (1 << 20) + ((int64_t)blockIdx.x * 4 + wave) * 16;
+    for (int i = 0; i < 8; ++i) dbg[i] = stamp_acc[i];
+    dbg[8] = __builtin_readcyclecounter() - stamp_t0;
+    dbg[9] = wall_clock64() - stamp_w0;
+    dbg[10] = (uint64_t)my_count;
+    dbg[11] = stamp_entry;
+    dbg[12] = stamp_w0;
+    dbg[13] = wall_clock64();
+  }
+#endif
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_setprio(0);
+  __syncthreads();
+
+  // ---- block reduction over the row tiles in a fixed order, then one partial record in the format
+  //      of glm.hip: [pt][16 regs][64 lanes] accumulator tiles, then ll and gb per particle -------
+  constexpr int REC = NPT * 1024 + 2 * NPT * 32;
+  static_assert((NPT * 1024 + 2 * NPT * 64) * 4 <= C::LDS_BYTES - C::OFS_RING, "LDS too small");
+  float* red = reinterpret_cast<float*>(smem + C::OFS_RING);
+  float* red2 = red + NPT * 1024;
+  const float s_lg = (float)(e_t[0] + e_t[1]) + (__builtin_amdgcn_logf(p_t[0]) + __builtin_amdgcn_logf(p_t[1]));
+  const float ll_acc = 0.69314718055994530942f *
+                       ((s_yl[0] + s_yl[1]) - 0.5f * (s_abs[0] + s_abs[1]) - s_lg);
+  const float gb_acc = s_g[0] + s_g[1];
+  for (int rr = 0; rr < NRT; ++rr) {
+    if (rt == rr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = (pt * 16 + r) * 64 + lane;
+        red[idx] = (rr == 0 ? 0.0f : red[idx]) + gwacc[r];
+      }
+      const int i0 = (2 * pt) * 64 + lane, i1 = (2 * pt + 1) * 64 + lane;
+      red2[i0] = (rr == 0 ? 0.0f : red2[i0]) + ll_acc;
+      red2[i1] = (rr == 0 ? 0.0f : red2[i1]) + gb_acc;
+    }
+    __syncthreads();
+  }
+  float* rec = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * REC;
+  for (int i = threadIdx.x; i < NPT * 1024; i += 256) rec[i] = red[i];
+  for (int i = threadIdx.x; i < 2 * NPT * 32; i += 256) {
+    const int qq = i >> 5, j = i & 31;
+    rec[NPT * 1024 + i] = red2[qq * 64 + j] + red2[qq * 64 + 32 + j];
+  }
+#ifdef PA_GLMP_STAMP
+  if (lane == 0 && blockIdx.y == 0)
+    (reinterpret_cast<uint64_t*>(part) + (1 << 20) + ((int64_t)blockIdx.x * 4 + wave) * 16)[14] = wall_clock64();
+#endif
+}
+
+}  // namespace pa

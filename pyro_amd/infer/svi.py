@@ -13,7 +13,7 @@ import warnings
 
 import torch
 
-from .. import poutine
+from .. import kernels, poutine
 from ..params import _PARAM_STORE
 from ..util import torch_isnan, zero_grads
 from .elbo import ELBO
@@ -21,7 +21,9 @@ from .elbo import ELBO
 
 def _arg_key(x):
     if isinstance(x, torch.Tensor):
-        return ("t", x.data_ptr(), tuple(x.shape), x.dtype, x.device)
+        # the version counter is part of the key: a tensor that was updated in place gets fresh
+        # eager (validated) steps and its own capture instead of a replay that assumes the old data
+        return ("t", x.data_ptr(), tuple(x.shape), x.dtype, x.device, x._version)
     if isinstance(x, (list, tuple)):
         return tuple(_arg_key(v) for v in x)
     try:
@@ -83,8 +85,13 @@ class SVI:
         if self.hip_graph and self._loss_device is None:
             raise ValueError("hip_graph=True needs an ELBO that provides loss_and_grads_device")
         self.graph_warmup = int(graph_warmup)
+        # captured steps by argument signature, least recently used first; bounded: fresh
+        # mini-batch tensors or a python scalar that changes every step would otherwise grow the
+        # table (and the graph memory pool) without ever reaching a replay
         self._graphs = {}
         self._eager_seen = {}
+        self.max_graphs = int(kwargs.pop("max_graphs", 8))
+        self._warned_keys = False
 
     def evaluate_loss(self, *args, **kwargs):
         with torch.no_grad():
@@ -116,11 +123,27 @@ class SVI:
         if entry is None:
             n = self._eager_seen.get(key, 0)
             if n < self.graph_warmup:
+                if n == 0 and len(self._eager_seen) >= 8 * self.max_graphs:
+                    # signatures that never came back: forget the oldest half
+                    for k in list(self._eager_seen)[:len(self._eager_seen) // 2]:
+                        del self._eager_seen[k]
+                    if not self._warned_keys:
+                        self._warned_keys = True
+                        warnings.warn("pyro_amd: SVI(hip_graph=True) keeps seeing new argument "
+                                      "signatures (fresh tensors or changing scalars every step); "
+                                      "such steps run eagerly. Pass the same tensors (update them "
+                                      "in place) to reach the captured step.")
                 self._eager_seen[key] = n + 1
                 return self._eager_step(*args, **kwargs)
             entry = self._capture(key, args, kwargs)
             if entry is None:                      # capture failed: stay eager
                 return self._eager_step(*args, **kwargs)
+            self._eager_seen.pop(key, None)
+            while len(self._graphs) > self.max_graphs:     # evict the least recently used capture
+                del self._graphs[next(iter(self._graphs))]
+        else:
+            self._graphs[key] = self._graphs.pop(key)      # most recently used last
+        kernels.glm_planes_revalidate()     # data the graph reads through a cached image
         entry.cap.before_replay()
         entry.graph.replay()
         if entry.graph2 is not None:

@@ -490,12 +490,122 @@ def mvn_tril_sample_bwd(loc, rho, eps, z, d_z, d_logq, sinks=None):
 GLM_AUTO, GLM_EXACT_F32, GLM_BF16X3 = 0, 1, 2
 
 
+_glm_variant = GLM_AUTO
+
+
 def glm_set_variant(variant):
     """Process-wide kernel choice of the fused GLM site: GLM_AUTO (default: vector-ALU streaming
     kernel for P <= 4, otherwise the bf16 matrix cores with 3-way split operands --
     f32-roundoff-class error), GLM_EXACT_F32 (f32 MFMA, bit-for-bit an fmaf chain) or GLM_BF16X3
     (the split-precision matrix-core kernel at every P)."""
+    global _glm_variant
     check(_lib.load().pa_glm_set_variant(int(variant)))
+    _glm_variant = int(variant)
+
+
+# ---- the design matrix as its bf16 planes (pa_glm_pack_planes), cached per tensor OBJECT ---------
+# X does not change between ELBO-gradient steps, so its exact 3-way bf16 split is computed once and
+# kept beside it (1.5x the bytes of X).  An entry belongs to one tensor object (weak reference: it
+# goes when the tensor goes) and remembers the tensor's version counter: an in-place update of X
+# re-packs INTO THE SAME BUFFER, so a captured hipGraph that reads the image stays valid --
+# glm_planes_revalidate() is called by SVI before every replay.
+GLM_PLANES_OFF, GLM_PLANES_AUTO, GLM_PLANES_ALWAYS = 0, 1, 2
+_planes_mode = GLM_PLANES_AUTO
+_planes_cache = {}          # id(X) -> [weakref, version, planes or None, sightings]
+_PLANES_MAX_D, _PLANES_MIN_P = 32, 33
+
+
+def glm_set_planes_mode(mode):
+    """GLM_PLANES_AUTO (default): a design matrix seen for the second time is packed and the
+    plane-image kernel used from then on; GLM_PLANES_ALWAYS: packed at first sight;
+    GLM_PLANES_OFF: the design matrix is split on the fly every step."""
+    global _planes_mode
+    _planes_mode = int(mode)
+    if _planes_mode == GLM_PLANES_OFF:
+        _planes_cache.clear()
+
+
+def glm_planes_tune(ring_depth=0, blocks_per_cu=0):
+    check(_lib.load().pa_glm_planes_tune(int(ring_depth), int(blocks_per_cu)))
+
+
+def glm_pack_planes(X, out=None):
+    """X[N,D] f32 (D <= 32) -> the uint8 tile image pa_glm_bernoulli_planes_fwd_bwd reads."""
+    _require_gpu(X)
+    N, D = X.shape
+    lib = _lib.load()
+    nbytes = lib.pa_glm_planes_bytes(N, D)
+    if nbytes == 0 and N > 0:
+        raise Unsupported("pyro_amd: no plane image for N=%d D=%d" % (N, D))
+    if out is None:
+        out = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=X.device)
+    check(lib.pa_glm_pack_planes(_ptr(X), N, D, _ptr(out), nbytes, _stream()))
+    return out
+
+
+def _planes_entry_of(X):
+    key = id(X)
+    ent = _planes_cache.get(key)
+    if ent is not None and ent[0]() is not X:        # the id was recycled
+        ent = None
+    if ent is None:
+        import weakref
+        ent = [weakref.ref(X, lambda _r, k=key: _planes_cache.pop(k, None)), X._version, None, 0]
+        _planes_cache[key] = ent
+    return ent
+
+
+def glm_planes_of(X):
+    """The cached plane image of X or None (not yet worth packing / mode off)."""
+    if _planes_mode == GLM_PLANES_OFF:
+        return None
+    ent = _planes_entry_of(X)
+    ent[3] += 1
+    if ent[2] is None:
+        if _planes_mode == GLM_PLANES_AUTO and ent[3] < 2:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None                  # never allocate + pack inside a capture
+        ent[2] = glm_pack_planes(X)
+        ent[1] = X._version
+    elif ent[1] != X._version:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("pyro_amd: a design matrix changed in place during a graph capture")
+        glm_pack_planes(X, out=ent[2])
+        ent[1] = X._version
+    return ent[2]
+
+
+def glm_planes_revalidate():
+    """Re-pack every cached image whose tensor was modified in place (called before a captured
+    step is replayed: the graph reads the image, not X)."""
+    for ent in list(_planes_cache.values()):
+        X = ent[0]()
+        if X is not None and ent[2] is not None and ent[1] != X._version:
+            glm_pack_planes(X, out=ent[2])
+            ent[1] = X._version
+
+
+def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D):
+    """planes = glm_pack_planes(X[N,D]), y[N], w[P,D], b[P] or None -> (ll[P], gw[P,D], gb[P])."""
+    _require_gpu(planes, y, w, b)
+    P = w.shape[0]
+    assert y.is_contiguous() and w.is_contiguous() and y.shape == (N,) and w.shape == (P, D)
+    assert y.dtype == torch.float32 and w.dtype == torch.float32
+    if b is not None:
+        assert b.is_contiguous() and b.shape == (P,)
+    lib = _lib.load()
+    nbytes = lib.pa_glm_bernoulli_planes_workspace(N, D, P)
+    if nbytes == 0:
+        raise Unsupported("pyro_amd: plane-image GLM kernel does not support N=%d D=%d P=%d" % (N, D, P))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=y.device)
+    ll = torch.empty((P,), dtype=w.dtype, device=y.device)
+    gw = torch.empty((P, D), dtype=w.dtype, device=y.device)
+    gb = torch.empty((P,), dtype=w.dtype, device=y.device)
+    check(lib.pa_glm_bernoulli_planes_fwd_bwd(_ptr(planes), _ptr(y), _ptr(w), _ptr(b), float(scale),
+                                              N, D, P, _ptr(ll), _ptr(gw), _ptr(gb), _ptr(ws),
+                                              nbytes, _stream()))
+    return ll, gw, gb
 
 
 def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
@@ -512,6 +622,11 @@ def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
     if mask is not None:
         assert mask.is_contiguous() and mask.shape == (N,) and mask.dtype in (torch.bool,
                                                                              torch.uint8)
+    if (mask is None and D <= _PLANES_MAX_D and P >= _PLANES_MIN_P and N > 0
+            and _glm_variant == GLM_AUTO):
+        planes = glm_planes_of(X)
+        if planes is not None:
+            return glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D)
     lib = _lib.load()
     nbytes = lib.pa_glm_bernoulli_workspace(N, D, P)
     if nbytes == 0:

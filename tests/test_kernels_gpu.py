@@ -333,6 +333,106 @@ def test_glm_bf16x3_is_f32_class(gpu):
 
 
 # ---------------------------------------------------------------------------------------------
+# fused Bernoulli GLM on the cached bf16 plane image of X (pa_glm_pack_planes /
+# pa_glm_bernoulli_planes_fwd_bwd): same tolerances against the float64 oracle as the on-the-fly
+# kernels; the image itself is integer work and must match the numpy restatement bit for bit
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,D", [(1, 1), (31, 3), (32, 32), (33, 32), (127, 20), (128, 32), (129, 7),
+                                 (1000, 32), (4099, 8), (0, 4)])
+def test_glm_plane_image_bit_exact(gpu, N, D):
+    k = _k()
+    rng = np.random.default_rng(7 * N + D)
+    X = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-6, 6, (N, 1)))).astype(np.float32)
+    img = k.glm_pack_planes(tt(X, gpu))
+    ref = o_glm.glm_plane_image(X)
+    got = img.cpu().numpy()[:ref.size * 2].view(np.uint16).reshape(ref.shape)
+    assert np.array_equal(got, ref)
+
+
+@pytest.fixture(params=[2, 3, 4], ids=["ring2", "ring3", "ring4"])
+def planes_ring(request):
+    k = _k()
+    k.glm_planes_tune(request.param, 0)
+    yield request.param
+    k.glm_planes_tune(0, 0)
+
+
+@pytest.mark.parametrize("N,D,P", [(1, 1, 33), (31, 3, 40), (32, 32, 64), (33, 32, 64), (63, 32, 64),
+                                   (64, 32, 64), (65, 32, 64), (1000, 32, 64), (4099, 8, 37),
+                                   (2048, 32, 33), (5000, 20, 100), (70000, 32, 64),
+                                   (3001, 12, 130), (129, 32, 5)])
+@pytest.mark.parametrize("use_bias", [True, False])
+def test_glm_planes(gpu, planes_ring, N, D, P, use_bias):
+    k = _k()
+    rng = np.random.default_rng(N + D + P)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (rng.standard_normal((P, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32) if use_bias else None
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    scale = 3.0
+    planes = k.glm_pack_planes(tt(X, gpu))
+    ll, gw, gb = k.glm_bernoulli_planes_fwd_bwd(planes, tt(y, gpu), tt(w, gpu),
+                                                tt(b, gpu) if b is not None else None, scale, N, D)
+    rll, rgw, rgb = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, scale)
+    sc = max(1.0, float(np.abs(rll).max()))
+    np.testing.assert_allclose(ll.cpu().numpy(), rll, rtol=2e-5, atol=2e-5 * sc)
+    np.testing.assert_allclose(gb.cpu().numpy(), rgb, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
+    np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
+
+
+def test_glm_planes_transpose_detecting_and_f32_class(gpu):
+    """Asymmetric operands with a wide dynamic range (any row/column or K-slot permutation error in
+    the DMA image, the row reads or the transpose reads shows up), and the f32-class error bound
+    of test_glm_bf16x3_is_f32_class on the plane-image kernel."""
+    k = _k()
+    N, D, P = 4096 + 37, 32, 64
+    rng = np.random.default_rng(5)
+    X = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-3, 3, (N, 1)))).astype(np.float32)
+    X *= (1.0 + 0.1 * np.arange(D, dtype=np.float32))[None, :]
+    w = (rng.standard_normal((P, D)) * (1.0 + 0.05 * np.arange(P))[:, None]).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32)
+    y = (rng.uniform(size=N) < 0.3).astype(np.float32)
+    ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    out = k.glm_bernoulli_planes_fwd_bwd(k.glm_pack_planes(tt(X, gpu)), tt(y, gpu), tt(w, gpu),
+                                         tt(b, gpu), 1.0, N, D)
+    for o, r in zip(out, ref):
+        assert float(np.abs(o.cpu().numpy() - r).max() / np.abs(r).max()) < 3e-6
+
+
+def test_glm_planes_cache_follows_the_tensor(gpu):
+    """The image is cached per tensor object: first sight -> on-the-fly kernel, second sight ->
+    packed; an in-place update of X re-packs into the same buffer (the pointer a captured graph
+    holds stays valid); results always equal the on-the-fly kernel's within f32 roundoff."""
+    k = _k()
+    N, D, P = 5000, 32, 64
+    g = torch.Generator(device="cpu").manual_seed(3)
+    X = torch.randn((N, D), generator=g).to(gpu)
+    y = (torch.rand((N,), generator=g) < 0.5).float().to(gpu)
+    w = (torch.randn((P, D), generator=g) * 0.2).to(gpu)
+    try:
+        k.glm_set_planes_mode(k.GLM_PLANES_OFF)
+        base = k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
+        k.glm_set_planes_mode(k.GLM_PLANES_AUTO)
+        assert k.glm_planes_of(X) is None                  # first sight
+        img = k.glm_planes_of(X)                           # second sight: packed
+        assert img is not None and k.glm_planes_of(X) is img
+        out = k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
+        for u, v in zip(out, base):
+            torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-3)
+        X.mul_(-0.5)                                       # in place: version counter moves
+        k.glm_planes_revalidate()
+        assert k.glm_planes_of(X).data_ptr() == img.data_ptr()
+        out2 = k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
+        k.glm_set_planes_mode(k.GLM_PLANES_OFF)
+        base2 = k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
+        for u, v in zip(out2, base2):
+            torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-3)
+        assert not torch.allclose(out2[1], out[1])
+    finally:
+        k.glm_set_planes_mode(k.GLM_PLANES_AUTO)
+
+
+# ---------------------------------------------------------------------------------------------
 # leapfrog
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
