@@ -319,7 +319,7 @@ int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, con
  * registers and the LDS writes of the on-the-fly kernel leave the per-step work; the arithmetic and
  * the outputs are those of pa_glm_bernoulli_fwd_bwd variant 0 (no mask argument: masked plates take
  * the entry above).  D <= 32; any P (64 particles per pass over the image).
- * pa_glm_planes_tune(ring_depth 2..4, workgroups per CU; 0 = default) is a measurement knob. */
+ * pa_glm_planes_tune(ring_depth 3..4, workgroups per CU; 0 = default) is a measurement knob. */
 size_t pa_glm_planes_bytes(int64_t N, int64_t D);
 int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_t planes_bytes,
                        pa_stream_t stream);

@@ -538,7 +538,7 @@ struct GlmPlanesPlan {
 static GlmPlanesPlan glm_planes_plan(int64_t N, int64_t P) {
   GlmPlanesPlan pl;
   pl.nb = g_planes_nb;
-  const int bpc_max = pl.nb == 2 ? 4 : (pl.nb == 3 ? 3 : 2);      // what the LDS ring admits
+  const int bpc_max = pl.nb == 3 ? 3 : 2;                         // what the LDS ring admits
   pl.bpc = g_planes_bpc > 0 && g_planes_bpc < bpc_max ? g_planes_bpc : bpc_max;
   pl.npass = (int)((P + 63) / 64);
   pl.nst = ((N + 31) / 32 + 1) / 2;                               // 64-row super-tiles
@@ -713,8 +713,8 @@ int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_
 }
 
 int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
-  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 2 && ring_depth <= 4),
-             "glm_planes_tune: ring depth 2..4 (0 = default)");
+  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 4),
+             "glm_planes_tune: ring depth 3..4 (0 = default)");
   PA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 4, "glm_planes_tune: 0..4 workgroups per CU");
   pa::g_planes_nb = ring_depth == 0 ? 3 : ring_depth;
   pa::g_planes_bpc = blocks_per_cu;
@@ -760,8 +760,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   hipEvent_t ev0, ev1;
   const bool br = pa::take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  if (pl.nb == 2) pa::glm_planes_launch_one<2, 4>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
-  else if (pl.nb == 3) pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
+  if (pl.nb == 3) pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
   else pa::glm_planes_launch_one<4, 2>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
   if (br) (void)hipEventRecord(ev1, s);
   int rc = pa::check_launch("glm_planes_kernel");

@@ -253,12 +253,117 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
   uint64_t stamp_last = __builtin_readcyclecounter();
   const uint64_t stamp_t0 = stamp_last, stamp_w0 = wall_clock64();
 #endif
+  // ---- pieces of the per-tile work ------------------------------------------------------------
+  // Rows past the end of the plate (the image holds zeros there) must not count: their aux operand
+  // is all zero (no bias), so their logit is exactly 0, and their y - 1/2 is stored as 0: then
+  // g = 0 - copysign(1/2 - 1/2, 0) = 0 and every running sum gets 0 except the log2(1 + e) sum,
+  // which gets log2(2) = 1 per such row and particle -- a known count, taken out again by the
+  // finalize step.  The wave's 32 observations of ring slot b become y - 1/2 in place.
+  auto prep_rows = [&](int b, int64_t st_) -> bool {
+    float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + (b * 4 + wave) * 256);
+    const int64_t rows_left = N - (st_ * NRT + rt) * 32;        // scalar
+    const bool okr = (int64_t)l31 < rows_left;
+    if (lane < 32) ys_[lane] = okr ? ys_[lane] - 0.5f : 0.0f;
+    return okr;
+  };
+  // GEMM1: L2[n, p] = log2(e) (sum_d X[n, d] W[p, d] + b[p]); first the bias through the aux operand
+  auto gemm1_aux = [&](bool okr) -> f32x16v {
+    const uint32_t a0 = (h == 0 && okr) ? (BF16_ONE << 16) : 0u;              // k slots {-, 1.0}
+    const uint32_t a1 = (h == 0 && okr) ? (BF16_ONE | (BF16_ONE << 16)) : 0u;  // k slots {1.0, 1.0}
+    const f32x16v zero = {};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0, a1, 0u, 0u), b_aux, zero, 0, 0, 0);
+  };
+  auto load_ab = [&](const unsigned char* Xt, int c, bf16x8 (&xa)[3], bf16x8 (&wa)[3]) {
+    const int ao = c == 0 ? a_ofs0 : a_ofs1;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      xa[pl] = *reinterpret_cast<const bf16x8*>(Xt + pl * GLMP_PLANE + ao);
+      wa[pl] = *reinterpret_cast<const bf16x8*>(w_row + pl * WPL + ao);
+    }
+  };
+  // element-wise on one accumulator element (row n = (r&3) + 8(r>>2) + 4h of the wave's tile).
+  // Plain (unpacked) f32 instructions only: v_pk_*_f32 does not overlap the bf16 MFMAs on gfx950
+  // and costs 2-4x a plain VALU instruction next to them (tools/probes/issue_probe: ~6 plain VALU or
+  // 2 transcendentals per MFMA issue for free).  With e = exp2(-|l2|), t = 1 + e:
+  //     y l - softplus(l) = ln2 ((y - 1/2) l2 - |l2|/2 - log2(t))       (three running sums)
+  //     g = y - sigmoid(l) = (y - 1/2) - copysign(1/t - 1/2, l2)
+  auto elem1 = [&](float l2, float yh, int par) -> float {
+    const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(l2));
+    const float t = e + 1.0f;
+    const float inv = __builtin_amdgcn_rcpf(t);
+    s_yl[par] = __builtin_fmaf(yh, l2, s_yl[par]);
+    s_abs[par] += __builtin_fabsf(l2);
+    p_t[par] *= t;            // sum of log2(t) = log2 of the running product (renormalised per half)
+    const float g = yh - __builtin_copysignf(inv - 0.5f, l2);
+    s_g[par] += g;
+    return g;
+  };
+  auto renorm = [&]() {       // 4 factors <= 2 per chain since the last call: the product stays < 16
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      e_t[c2] += __builtin_amdgcn_frexp_expf(p_t[c2]);
+      p_t[c2] = __builtin_amdgcn_frexp_mantf(p_t[c2]);
+    }
+  };
+  // B operand of GEMM2: ds_read_b64_tr_b16 as inline asm (the builtin makes hipcc drain vmcnt(0) in
+  // front of it); hipcc does not count inline-asm DS operations, tr_wait() waits for them and names
+  // every destination, so that nothing consuming them moves above the wait
+  auto tr_wait = [&](v2u32 (&xlo)[3], v2u32 (&xhi)[3], bf16x8 (&xb)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1]), "+v"(xlo[2]), "+v"(xhi[2])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const u32x4v cc = {xlo[pl][0], xlo[pl][1], xhi[pl][0], xhi[pl][1]};
+      xb[pl] = __builtin_bit_cast(bf16x8, cc);
+    }
+  };
+  auto tr_issue = [&](uint32_t tr_a, uint32_t tr_b, int kh, v2u32 (&xlo)[3], v2u32 (&xhi)[3]) {
+    const uint32_t a = tr_a + (kh ? 1024u : 0u), b2 = tr_b + (kh ? 1024u : 0u);
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(xlo[0]) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(xhi[0]) : "v"(b2));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xlo[1]) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xhi[1]) : "v"(b2));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(xlo[2]) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(xhi[2]) : "v"(b2));
+  };
+  auto load_y = [&](const float* ys_, int kh, float (&yv)[8]) {
+    const float4 y0 = *reinterpret_cast<const float4*>(ys_ + 16 * kh + 4 * h);
+    const float4 y1 = *reinterpret_cast<const float4*>(ys_ + 16 * kh + 8 + 4 * h);
+    yv[0] = y0.x; yv[1] = y0.y; yv[2] = y0.z; yv[3] = y0.w;
+    yv[4] = y1.x; yv[5] = y1.y; yv[6] = y1.z; yv[7] = y1.w;
+  };
+
   int64_t st = first;
   int bi = 0;
   const uint32_t prio_slot = (uint32_t)(blockIdx.x / prio_cus);
   uint64_t prio_clock = wall_clock64();
+
+  // ---- software pipeline: iteration `it` runs GEMM1 of tile it+1 (matrix pipe) against the
+  //      element-wise work and GEMM2 of tile it, so that every wave always has both MFMA and VALU
+  //      instructions to issue (a wave issues in order: with the phases back to back each wave
+  //      alternates between a pure-MFMA and a pure-VALU stretch and three waves per SIMD do not
+  //      cover that -- measured 1600 cycles per tile and SIMD against ~950 of issue time).
+  //      Ring: slot it % NB holds tile it (GEMM2 reads), slot (it+1) % NB tile it+1 (GEMM1 reads),
+  //      the DMA of tile it+NB-1 goes into the slot tile it-1 left -------------------------------
+  f32x16v acc_cur = {};
+  if (my_count > 0) {
+    wait_vmcnt<(NB - 2) * C::NDMA>();       // this wave's pieces of tile 0 have landed
+    __builtin_amdgcn_s_barrier();           // ... and everybody else's
+    const bool ok0 = prep_rows(0, st);
+    acc_cur = gemm1_aux(ok0);
+    const unsigned char* X0 = smem + C::OFS_RING + rt * GLMP_TILE;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 xa[3], wa[3];
+      load_ab(X0, c, xa, wa);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[TA[t]], wa[TB[t]], acc_cur, 0, 0, 0);
+    }
+  }
   for (int64_t it = 0; it < my_count; ++it) {
-    PA_STAMP(7);
     // The SIMD arbitrates between its waves by priority, then AGE: left alone, the workgroup that
     // was dispatched first to a CU runs ahead of its co-residents and finishes ~25 us early, and the
     // youngest one runs the tail alone at a third of the CU's issue rate (measured:
@@ -274,152 +379,76 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
       prio_clock = wall_clock64();     // read now, used at the next tile: the SMEM latency hides
     }
 #endif
-    wait_vmcnt<(NB - 2) * C::NDMA>();       // this wave's pieces of super-tile `it` have landed
-    PA_STAMP(0);
-    __builtin_amdgcn_s_barrier();           // ... and everybody else's; slot (it-1) % NB is free
-    PA_STAMP(1);
+    int bn = bi + 1 == NB ? 0 : bi + 1;     // slot of tile it+1
+    wait_vmcnt<(NB - 3) * C::NDMA>();       // this wave's pieces of tile it+1 have landed
+    __builtin_amdgcn_s_barrier();           // ... and everybody else's; the slot of tile it-1 is free
     {
-      int bn = bi + (NB - 1);
-      bn = bn >= NB ? bn - NB : bn;
-      issue(st + (NB - 1) * grid, bn);
+      int bf = bi + (NB - 1);
+      bf = bf >= NB ? bf - NB : bf;
+      issue(st + (NB - 1) * grid, bf);
     }
-    const unsigned char* Xt = smem + C::OFS_RING + bi * ST_BYTES + rt * GLMP_TILE;
-    float* ys = reinterpret_cast<float*>(smem + C::OFS_Y + (bi * 4 + wave) * 256);
-    // Rows past the end of the plate (the image holds zeros there) must not count: their aux
-    // operand is all zero (no bias), so their logit is exactly 0, and their y - 1/2 is stored as 0:
-    // then g = 0 - copysign(1/2 - 1/2, 0) = 0 and every running sum gets 0 except the log2(1 + e)
-    // sum, which gets log2(2) = 1 per such row and particle -- a known count, taken out again by the
-    // finalize step (ll_pad_rows).  The wave's 32 observations are turned into y - 1/2 in place.
-    const int64_t rows_left = N - (st * NRT + rt) * 32;        // scalar
-    const bool okr = (int64_t)l31 < rows_left;
-    if (lane < 32) ys[lane] = okr ? ys[lane] - 0.5f : 0.0f;
-    const uint32_t tr_a = (uint32_t)(uintptr_t)Xt + (uint32_t)tr_ofs_a;
-    const uint32_t tr_b = (uint32_t)(uintptr_t)Xt + (uint32_t)tr_ofs_b;
-    // ---- GEMM1: L2[n, p] = log2(e) (sum_d X[n, d] W[p, d] + b[p]) -------------------------------
-    f32x16v acc;
-    {
-      const uint32_t a0 = (h == 0 && okr) ? (BF16_ONE << 16) : 0u;              // k slots {-, 1.0}
-      const uint32_t a1 = (h == 0 && okr) ? (BF16_ONE | (BF16_ONE << 16)) : 0u;  // k slots {1.0, 1.0}
-      const f32x16v zero = {};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0, a1, 0u, 0u), b_aux, zero, 0, 0, 0);
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      bf16x8 xa[3], wa[3];
-      const int ao = c == 0 ? a_ofs0 : a_ofs1;
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        xa[pl] = *reinterpret_cast<const bf16x8*>(Xt + pl * GLMP_PLANE + ao);
-        wa[pl] = *reinterpret_cast<const bf16x8*>(w_row + pl * WPL + ao);
-      }
-#ifdef PA_GLMP_ABL_NOGEMM1
-      acc[c] += __builtin_bit_cast(float, (uint32_t)xa[0][0] ^ (uint32_t)wa[1][1] ^ (uint32_t)xa[2][2] ^ (uint32_t)wa[0][3] ^ (uint32_t)xa[1][0] ^ (uint32_t)wa[2][0]);
-#else
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[TA[t]], wa[TB[t]], acc, 0, 0, 0);
-#endif
-    }
+    const unsigned char* Xc = smem + C::OFS_RING + bi * ST_BYTES + rt * GLMP_TILE;
+    const unsigned char* Xn = smem + C::OFS_RING + bn * ST_BYTES + rt * GLMP_TILE;
+    const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y + (bi * 4 + wave) * 256);
+    const uint32_t tr_a = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_a;
+    const uint32_t tr_b = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_b;
 
-#ifdef PA_GLMP_STAMP
-    asm volatile("" : "+v"(acc));
-    PA_STAMP(2);
-#endif
-    // ---- element-wise on the accumulator (rows n = (r&3) + 8(r>>2) + 4h of this wave's tile), per
-    //      K half of GEMM2.  Plain (unpacked) f32 instructions only: v_pk_*_f32 does not overlap the
-    //      bf16 MFMAs on gfx950 and costs 2-4x a plain VALU instruction next to them
-    //      (tools/probes/issue_probe: up to ~6 plain VALU / 2 transcendentals per MFMA issue for
-    //      free).  With e = exp(-|l|), t = 1 + e:
-    //        y l - softplus(l) = ln2 ((y - 1/2) l2 - |l2|/2 - log2(t))   (three running sums)
-    //        g = y - sigmoid(l) = (y - 1/2) - copysign(1/t - 1/2, l2)
+    const bool okn = prep_rows(bn, st + grid);
+    f32x16v acc_nxt = gemm1_aux(okn);
+    v2u32 xlo[3], xhi[3];
+    bf16x8 xa[3], wa[3], xb[3];
+    float yv[8], g[8];
+    uint32_t g1[4], g2[4], g3[4];
+
+    // -- GEMM1(it+1), K chunk 0 and 1  ||  element-wise(it, K half 0) and its split
+    tr_issue(tr_a, tr_b, 0, xlo, xhi);
+    load_y(ysc, 0, yv);
+    load_ab(Xn, 0, xa, wa);
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      // B operand of GEMM2 for this K half: ds_read_b64_tr_b16 as inline asm (the builtin makes
-      // hipcc drain vmcnt(0) in front of it -- it cannot tell the read from the LDS-DMA writes in
-      // flight -- which would shorten the prefetch ring to one tile)
-      v2u32 xlo[3], xhi[3];
+    for (int t = 0; t < 6; ++t) {
+      acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[TA[t]], wa[TB[t]], acc_nxt, 0, 0, 0);
+      g[t] = elem1(acc_cur[t], yv[t], t & 1);
+    }
+    load_ab(Xn, 1, xa, wa);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        if (kh == 0) {
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xlo[pl]) : "v"(tr_a), "n"(pl * GLMP_PLANE));
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[pl]) : "v"(tr_b), "n"(pl * GLMP_PLANE));
-        } else {
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xlo[pl]) : "v"(tr_a), "n"(pl * GLMP_PLANE + 1024));
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xhi[pl]) : "v"(tr_b), "n"(pl * GLMP_PLANE + 1024));
-        }
-      }
-      const float4 y0 = *reinterpret_cast<const float4*>(ys + 16 * kh + 4 * h);
-      const float4 y1 = *reinterpret_cast<const float4*>(ys + 16 * kh + 8 + 4 * h);
-      const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-      float g[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float l2 = acc[8 * kh + i];
-        const float yh = yv[i];
-#if defined(PA_GLMP_ABL_NOTRANS)     // ablation probes (tools/probes/build_glm_planes_probes.sh)
-        const float e = -__builtin_fabsf(l2) * 0.25f;
-        const float t = e + 1.0f;
-        const float inv = t - 0.25f;
-#elif defined(PA_GLMP_ABL_ONETRANS)
-        const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(l2));
-        const float t = e + 1.0f;
-        const float inv = t - 0.25f;
-#else
-        const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(l2));
-        const float t = e + 1.0f;
-        const float inv = __builtin_amdgcn_rcpf(t);
-#endif
-        s_yl[i & 1] = __builtin_fmaf(yh, l2, s_yl[i & 1]);
-        s_abs[i & 1] += __builtin_fabsf(l2);
-        p_t[i & 1] *= t;          // sum of log2(t) = log2 of the running product (renormalised below)
-        g[i] = yh - __builtin_copysignf(inv - 0.5f, l2);
-        s_g[i & 1] += g[i];
-      }
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {      // 4 factors <= 2 since the last renormalisation: < 16
-        e_t[c2] += __builtin_amdgcn_frexp_expf(p_t[c2]);
-        p_t[c2] = __builtin_amdgcn_frexp_mantf(p_t[c2]);
-      }
-      uint32_t g1[4], g2[4], g3[4];
-#pragma unroll
-#ifdef PA_GLMP_ABL_NOSPLIT
-      for (int i = 0; i < 4; ++i) { g1[i] = pack_hi16(g[2 * i], g[2 * i + 1]); g2[i] = g1[i] ^ 0x10001u; g3[i] = g1[i] ^ 0x20002u; }
-#else
-      for (int i = 0; i < 4; ++i) split_pair_trunc(g[2 * i], g[2 * i + 1], g1[i], g2[i], g3[i]);
-#endif
-#ifdef PA_GLMP_STAMP
-      asm volatile("" : "+v"(g3[0]), "+v"(g3[1]), "+v"(g3[2]), "+v"(g3[3]));
-      PA_STAMP(3 + 2 * kh);
-#endif
-      // the six transpose reads of this K half were issued in front of the element-wise block;
-      // hipcc does not count inline-asm DS operations, so wait for them here.  The wait statement
-      // names every destination: nothing that consumes them moves above it.
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1]), "+v"(xlo[2]), "+v"(xhi[2])
-                   :
-                   : "memory");
-      bf16x8 xb[3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        const u32x4v cc = {xlo[pl][0], xlo[pl][1], xhi[pl][0], xhi[pl][1]};
-        xb[pl] = __builtin_bit_cast(bf16x8, cc);
-      }
+    for (int t = 0; t < 6; ++t) {
+      acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[TA[t]], wa[TB[t]], acc_nxt, 0, 0, 0);
+      if (t < 2) g[6 + t] = elem1(acc_cur[6 + t], yv[6 + t], t & 1);
+      else split_pair_trunc(g[2 * (t - 2)], g[2 * (t - 2) + 1], g1[t - 2], g2[t - 2], g3[t - 2]);
+    }
+    renorm();
+    tr_wait(xlo, xhi, xb);
+    // -- GEMM2(it, K half 0)  ||  element-wise(it, K half 1) and its split
+    {
       const bf16x8 ga[3] = {as_bf16x8(g1[0], g1[1], g1[2], g1[3]), as_bf16x8(g2[0], g2[1], g2[2], g2[3]),
                             as_bf16x8(g3[0], g3[1], g3[2], g3[3])};
-#ifdef PA_GLMP_ABL_NOGEMM2
-      gwacc[kh] += __builtin_bit_cast(float, g1[0] ^ g2[1] ^ g3[2] ^ xlo[0][0] ^ xhi[1][1] ^ xlo[2][0]);
-#else
+      tr_issue(tr_a, tr_b, 1, xlo, xhi);
+      load_y(ysc, 1, yv);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        gwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[TA[t]], xb[TB[t]], gwacc, 0, 0, 0);
+        if (t < 4) {
+          g[2 * t] = elem1(acc_cur[8 + 2 * t], yv[2 * t], 0);
+          g[2 * t + 1] = elem1(acc_cur[8 + 2 * t + 1], yv[2 * t + 1], 1);
+        }
+      }
+    }
+    renorm();
+    uint32_t h1[4], h2[4], h3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair_trunc(g[2 * j], g[2 * j + 1], h1[j], h2[j], h3[j]);
+    tr_wait(xlo, xhi, xb);
+    // -- GEMM2(it, K half 1)
+    {
+      const bf16x8 ga[3] = {as_bf16x8(h1[0], h1[1], h1[2], h1[3]), as_bf16x8(h2[0], h2[1], h2[2], h2[3]),
+                            as_bf16x8(h3[0], h3[1], h3[2], h3[3])};
 #pragma unroll
       for (int t = 0; t < 6; ++t)
         gwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[TA[t]], xb[TB[t]], gwacc, 0, 0, 0);
-#endif
-#ifdef PA_GLMP_STAMP
-      asm volatile("" : "+v"(gwacc));
-      PA_STAMP(4 + 2 * kh);
-#endif
     }
+    acc_cur = acc_nxt;
     st += grid;
-    bi = bi + 1 == NB ? 0 : bi + 1;
+    bi = bn;
   }
 #ifdef PA_GLMP_STAMP
   if (lane == 0 && blockIdx.y == 0) {

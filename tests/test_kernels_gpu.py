@@ -252,10 +252,18 @@ def test_glm_bernoulli_deterministic_and_linear(gpu, glm_variant):
     w = torch.randn((P, D), device=gpu, generator=g) * 0.2
     b = torch.randn((P,), device=gpu, generator=g)
     y = (torch.rand((N,), device=gpu, generator=g) < 0.5).float()
+    a0 = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    # automatic mode: the first call sees X for the first time and splits it on the fly; from the
+    # second sight on X is kept as its bf16 plane image and the plane-image kernel runs (same
+    # arithmetic class, different summation order): deterministic from there on
     a1 = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
     a2 = k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
     for u, v in zip(a1, a2):
         assert torch.equal(u, v)
+    for u, v in zip(a0, a1):
+        torch.testing.assert_close(u, v, rtol=2e-5, atol=2e-2)
+    if glm_variant == 0:
+        assert k.glm_planes_of(X) is not None
     h = N // 2 + 13
     p1 = k.glm_bernoulli_fwd_bwd(X[:h].contiguous(), y[:h].contiguous(), w, b, None, 1.0)
     p2 = k.glm_bernoulli_fwd_bwd(X[h:].contiguous(), y[h:].contiguous(), w, b, None, 1.0)
@@ -349,7 +357,7 @@ def test_glm_plane_image_bit_exact(gpu, N, D):
     assert np.array_equal(got, ref)
 
 
-@pytest.fixture(params=[2, 3, 4], ids=["ring2", "ring3", "ring4"])
+@pytest.fixture(params=[3, 4], ids=["ring3", "ring4"])
 def planes_ring(request):
     k = _k()
     k.glm_planes_tune(request.param, 0)

@@ -82,8 +82,8 @@ def main():
         e.record()
         torch.cuda.synchronize()
         print(f"  pack planes (once per X)    {s.elapsed_time(e) * 1e3:8.1f} us")
-        for nb in (2, 3, 4):
-            for bpc in range(1, {2: 4, 3: 3, 4: 2}[nb] + 1):
+        for nb in (3, 4):
+            for bpc in range(1, {3: 3, 4: 2}[nb] + 1):
                 k.glm_planes_tune(nb, bpc)
                 us, out = graph_time(lambda: k.glm_bernoulli_planes_fwd_bwd(planes, y, w, b, 1.0, N, D))
                 print(f"  planes ring={nb} wg/CU={bpc}      {us:8.1f} us   {N*(4*D+4)/us/1e6:6.3f} TB/s(alg)"

@@ -87,7 +87,7 @@ int main() {
   (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(pa::glm_pack_planes_kernel, dim3((unsigned)((nt * 128 + 255) / 256)), dim3(256), 0, 0, X, N, D, nt, img);
   run<3, 3>(img, y, w, b, N, D, P, part, 3);
-  run<2, 4>(img, y, w, b, N, D, P, part, 2);
+  run<4, 2>(img, y, w, b, N, D, P, part, 2);
   run<3, 3>(img, y, w, b, N, D, P, part, 1);
   return 0;
 }
