@@ -278,7 +278,7 @@ class _MeanFieldSample(torch.autograd.Function):
                                                                   offset_dev)
         ctx.P, ctx.nsites = P, len(locs)
         ctx.shapes = [p.shape for p in params]
-        ctx.params = params if GRAD_SINK else None
+        ctx.params = params if GRAD_SINK["on"] else None
         ctx.save_for_backward(*rhos, *epss)
         out = []
         for z, sc, lo in zip(zs, scales, louts):
@@ -311,8 +311,36 @@ class _MeanFieldSample(torch.autograd.Function):
         return (None, None, None, None) + tuple(out)
 
 
-# _MeanFieldSample.backward adds straight into existing parameter .grad buffers (see there)
-GRAD_SINK = True
+# _MeanFieldSample.backward / _MvnTrilSample.backward may add straight into existing parameter
+# .grad buffers and tell autograd "no gradient" (see there).  That is only sound when the caller IS
+# the accumulation into .grad: ELBO.loss_and_grads_device switches it on around its own
+# guide run + backward (grad_sink() below).  Everywhere else -- differentiable_loss, ELBOModule,
+# torch.autograd.grad, backward(inputs=...), create_graph -- it stays off and the Functions hand
+# ordinary gradients to autograd.
+GRAD_SINK = {"on": False}
+
+
+class grad_sink:
+    """Context manager / decorator: guide draws made inside may sink their parameter gradients
+    directly into ``.grad`` when their backward runs (the draw remembers the setting)."""
+
+    def __enter__(self):
+        self._prev = GRAD_SINK["on"]
+        GRAD_SINK["on"] = True
+        return self
+
+    def __exit__(self, *exc):
+        GRAD_SINK["on"] = self._prev
+        return False
+
+    def __call__(self, fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapped(*args, **kwargs):
+            with grad_sink():
+                return fn(*args, **kwargs)
+        return wrapped
 
 
 def meanfield_sample(locs, rhos, P):
@@ -341,7 +369,7 @@ class _MvnTrilSample(torch.autograd.Function):
     def forward(ctx, P, seed, offset, offset_dev, eps, loc, rho, A):
         l, r, a = loc.detach().reshape(-1), rho.detach().reshape(-1), A.detach()
         z, logq, eps = kernels.mvn_tril_sample(l, r, a, P, seed, offset, offset_dev, eps)
-        ctx.params = (loc, rho, A) if GRAD_SINK else None
+        ctx.params = (loc, rho, A) if GRAD_SINK["on"] else None
         ctx.shapes = (loc.shape, rho.shape, A.shape)
         ctx.save_for_backward(l, r, eps, z)
         return z, logq

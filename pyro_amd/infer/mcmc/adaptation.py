@@ -301,35 +301,21 @@ class WarmupAdapter:
         return self.adapt_mass_matrix and (0 < self._current_window < num_windows - 1)
 
     def da_state(self):
-        """Dual-averaging state as one [C, 5] tensor {x_avg, g_avg, t, prox_center, x_t}."""
-        s = self._step_size_adapt_scheme
-        st = torch.zeros((self.step_size.shape[0], 5), dtype=self.step_size.dtype,
-                         device=self.step_size.device)
-        st[:, 0] = s._x_avg
-        st[:, 1] = s._g_avg
-        st[:, 2] = float(s._t)
-        st[:, 3] = s.prox_center
-        st[:, 4] = getattr(s, "_x_t", 0.0)
-        return st
+        """Dual-averaging record [C, 5] of the persistent kernel (ops/dual_averaging.py)."""
+        return self._step_size_adapt_scheme.to_record(self.step_size.shape[0], self.step_size.dtype,
+                                                      self.step_size.device)
 
     def load_da_state(self, st, k):
-        s = self._step_size_adapt_scheme
-        s._x_avg, s._g_avg, s._x_t = st[:, 0].clone(), st[:, 1].clone(), st[:, 4].clone()
-        s._t += k
+        self._step_size_adapt_scheme.from_record(st, k)
 
     def welford_state(self):
-        """([C, 2, D] {mean, m2}, samples seen) of the mass-matrix estimator."""
+        """([C, 2, D] {mean, scatter}, draws seen) of the mass-matrix estimator."""
         w = self.mass_matrix_adapter._scheme
         v = self.mass_matrix_adapter.inverse_mass_matrix
-        st = torch.zeros((v.shape[0], 2, v.shape[1]), dtype=v.dtype, device=v.device)
-        st[:, 0] = w._mean
-        st[:, 1] = w._m2
-        return st, w.n_samples
+        return w.to_record(v.shape[0], v.shape[1], v.dtype, v.device), w.n_samples
 
     def load_welford_state(self, st, k):
-        w = self.mass_matrix_adapter._scheme
-        w._mean, w._m2 = st[:, 0].clone(), st[:, 1].clone()
-        w.n_samples += k
+        self.mass_matrix_adapter._scheme.from_record(st, k)
 
     def finish_span(self, t, z):
         """The window-end branch of step() (adaptation.py:186-202) for a span that ended at t."""

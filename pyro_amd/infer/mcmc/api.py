@@ -200,6 +200,12 @@ class MCMC:
             self._local_samples = z_acc
             self._samples = self._gather(z_acc)
             self._diagnostics = k.diagnostics()
+        # the reference's driver ends a run with kernel.cleanup() (api.py:170), which there drops the
+        # jit-compiled potential; here the run's statistics stay readable on the kernel object
+        # (leapfrog counts, adapted step sizes) and only the captured graphs are released
+        release = getattr(k, "release_graphs", None)
+        if release is not None:
+            release()
         return self
 
     def _gather(self, z_acc):

@@ -224,6 +224,14 @@ class HMC(MCMCKernel):
     def cleanup(self):
         self._reset()
 
+    def release_graphs(self):
+        """Drop captured hipGraphs (jit_compile) and their static buffers; the sampler state and
+        its statistics stay.  The next setup() / transition re-captures."""
+        pot = getattr(self, "_potential", None)
+        if isinstance(pot, GraphedPotential):
+            pot.graph, pot.calls = None, 0
+            pot.z_static = pot.pe_static = pot.grad_static = None
+
     # ---- pieces of a transition --------------------------------------------------------------
     def _kinetic_energy(self, r_unscaled):
         return 0.5 * (r_unscaled * r_unscaled).sum(-1)       # hmc.py:152-156

@@ -42,6 +42,11 @@ class NUTS(HMC):
         self.use_persistent = True   # many transitions per launch on the fused Gaussian path
         self._launch_hook = None     # called before every fused launch (bench: event brackets)
 
+    def release_graphs(self):
+        super().release_graphs()
+        self._round_graph = self._step_buf = self._mass_buf = None
+        self._round_calls = 0
+
     def setup(self, warmup_steps, *args, **kwargs):
         super().setup(warmup_steps, *args, **kwargs)
         self._tree = None

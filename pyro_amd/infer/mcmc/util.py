@@ -309,14 +309,53 @@ def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
     samples = collect(trace)
     pe_maker = _PEMaker(model, model_args, model_kwargs, transforms, max_plate_nesting,
                         num_chains, batch_ndims)
+    draws_made = initial_params is None
     if initial_params is None:
         draws = [samples] + [collect(draw()) for _ in range(num_chains - 1)]
         initial_params = {}
         for k in samples:
             vals = [transforms[k](d[k]) for d in draws]
             initial_params[k] = torch.stack(vals) if num_chains > 1 else vals[0]
+    drawn = draws_made
     for k, v in initial_params.items():
         site_shape[k] = tuple(v.shape[1:]) if num_chains > 1 else tuple(v.shape)
     pe_maker._site_shape = site_shape
     pe_maker.enum = bool(enumerated)
+    if drawn:
+        # A chain that starts where the potential or its gradient is not finite rejects every
+        # proposal (and drives the step-size search to its floor): such starting points are drawn
+        # again, as the reference does (pyro/infer/mcmc/util.py:430-470, up to 100 attempts).
+        for attempt in range(100):
+            bad = ~_finite_start(pe_maker.potential_fn, initial_params, num_chains)
+            if not bool(bad.any()):
+                break
+            for c in torch.nonzero(bad).reshape(-1).tolist():
+                d = collect(draw())
+                for k in initial_params:
+                    z = transforms[k](d[k])
+                    if num_chains > 1:
+                        initial_params[k][c] = z
+                    else:
+                        initial_params[k] = z
+        else:
+            raise ValueError("Model specification seems incorrect - cannot find valid initial "
+                             "params (the potential energy or its gradient is not finite after "
+                             "100 draws).")
     return initial_params, pe_maker.potential_fn, transforms, trace
+
+
+def _finite_start(potential_fn, params, num_chains):
+    """bool [num_chains]: potential and gradient finite at the given unconstrained point(s)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    with torch.enable_grad():
+        pe = potential_fn(leaves)
+        pe = pe if isinstance(pe, torch.Tensor) else torch.as_tensor(pe)
+        grads = torch.autograd.grad(pe.sum(), list(leaves.values()), allow_unused=True) \
+            if pe.requires_grad else [None] * len(leaves)
+    ok = torch.isfinite(pe.detach()).reshape(-1)
+    if ok.numel() != num_chains:
+        ok = ok.all().expand(num_chains).clone()
+    for g in grads:
+        if g is not None:
+            ok = ok & torch.isfinite(g.reshape(num_chains, -1)).all(1)
+    return ok

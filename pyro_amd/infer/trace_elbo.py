@@ -14,6 +14,8 @@ through MultiFrameTensor); the difference is how the per-site terms are produced
 """
 import torch
 
+from ..distributions.fused import grad_sink as _grad_sink
+
 from ..distributions.util import is_identically_zero
 from ..util import torch_item, warn_if_nan
 from .elbo import ELBO
@@ -163,6 +165,7 @@ class Trace_ELBO(ELBO):
         warn_if_nan(loss, "loss")
         return loss
 
+    @_grad_sink()
     def loss_and_grads_device(self, model, guide, *args, **kwargs):
         """Same, but the loss stays a 0-dim device tensor and nothing synchronises with the host
         (what a captured hipGraph step needs, see SVI(hip_graph=True))."""

@@ -11,6 +11,8 @@ terms (small tensors, torch arithmetic) ride in the same launch as already-compu
 import warnings
 
 import torch
+
+from ..distributions.fused import grad_sink as _grad_sink
 from torch.distributions import kl_divergence
 
 from .. import poutine
@@ -95,6 +97,7 @@ class TraceMeanField_ELBO(Trace_ELBO):
         warn_if_nan(loss, "loss")
         return loss
 
+    @_grad_sink()
     def loss_and_grads_device(self, model, guide, *args, **kwargs):
         loss = None
         for model_trace, guide_trace in self._get_traces(model, guide, args, kwargs):

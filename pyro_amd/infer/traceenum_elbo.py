@@ -24,6 +24,8 @@ from collections import OrderedDict
 
 import torch
 
+from ..distributions.fused import grad_sink as _grad_sink
+
 from .. import poutine
 from ..distributions.util import scale_and_mask
 from ..ops.contract import LazyGather, Term, align, contract_tensor_tree, pack
@@ -305,6 +307,7 @@ class TraceEnum_ELBO(ELBO):
         warn_if_nan(loss, "loss")
         return loss
 
+    @_grad_sink()
     def loss_and_grads_device(self, model, guide, *args, **kwargs):
         loss = None
         c = -1.0 / self.num_particles

@@ -4,30 +4,50 @@ import torch
 from ..distributions.util import is_identically_zero
 
 
-class MultiFrameTensor(dict):
-    """Maps plate-stacks (tuples of frames) to tensors and sums them down to a target stack."""
+class MultiFrameTensor:
+    """Per-site terms of an ELBO estimator filed by the set of vectorised plates they live in
+    (the role of pyro/infer/util.py:122-171 in Trace_ELBO._compute_log_r, trace_elbo.py:20-29).
+
+    ``add((stack, tensor), ...)`` files a tensor under the vectorised frames of its plate stack
+    (terms of the same plate set are summed at once); ``sum_to(stack)`` returns the total of all
+    filed terms with every plate that is NOT in ``stack`` summed out -- the downstream-cost a
+    score-function site inside ``stack`` sees.  Plate dims are negative (counted from the right),
+    so a filed tensor can be reduced with one keepdim sum over the foreign plates and its leading
+    singleton dims dropped afterwards.
+    """
 
     def __init__(self, *items):
-        super().__init__()
+        self._by_plates = {}
         self.add(*items)
 
+    def __len__(self):
+        return len(self._by_plates)
+
+    def items(self):
+        return self._by_plates.items()
+
     def add(self, *items):
-        for cond_indep_stack, value in items:
-            frames = frozenset(f for f in cond_indep_stack if f.vectorized)
-            assert all(f.dim < 0 and -value.dim() <= f.dim for f in frames)
-            if frames in self:
-                self[frames] = self[frames] + value
-            else:
-                self[frames] = value
+        for stack, value in items:
+            plates = frozenset(f for f in stack if f.vectorized)
+            for f in plates:
+                if not (-value.dim() <= f.dim < 0):
+                    raise ValueError("term of shape {} does not reach plate {!r} (dim {})".format(
+                        tuple(value.shape), f.name, f.dim))
+            held = self._by_plates.get(plates)
+            self._by_plates[plates] = value if held is None else held + value
 
     def sum_to(self, target_frames):
+        keep = set(target_frames)
         total = None
-        for frames, value in self.items():
-            for f in frames:
-                if f not in target_frames and value.shape[f.dim] != 1:
-                    value = value.sum(f.dim, True)
-            while value.shape and value.shape[0] == 1:
-                value = value.squeeze(0)
+        for plates, value in self._by_plates.items():
+            foreign = [f.dim for f in plates if f not in keep and value.shape[f.dim] != 1]
+            if foreign:
+                value = value.sum(foreign, keepdim=True)
+            lead = 0
+            while lead < value.dim() and value.shape[lead] == 1:
+                lead += 1
+            if lead:
+                value = value.reshape(value.shape[lead:])
             total = value if total is None else total + value
         return 0.0 if total is None else total
 

@@ -1,8 +1,17 @@
-"""Welford online (co)variance (reference: pyro/ops/welford.py:7-52).
+"""Streaming mean / scatter statistics of the warm-up draws, from which HMC / NUTS build their
+inverse mass matrix (Welford's update; reference: pyro/ops/welford.py:7-52, regularisation as in
+Stan's ``welford_*_estimator``).
 
-``sample`` may be [D] (one chain) or [C, D] (one independent estimator per vectorised chain;
-diagonal only -- the dense estimator is per chain [D, D] as in the reference)."""
+Written around the record the persistent NUTS kernel keeps per chain (``[C, 2, D] = {mean,
+scatter}`` for the diagonal estimator): ``to_record`` / ``from_record`` move it to and from the
+device path.  A draw is ``[D]`` (one chain) or ``[C, D]`` (one independent estimator per
+vectorised chain); the dense estimator keeps a ``[..., D, D]`` scatter matrix per chain.
+"""
 import torch
+
+# the estimate is shrunk towards SHRINK_TARGET * I as if SHRINK_COUNT extra draws had been seen
+SHRINK_COUNT = 5.0
+SHRINK_TARGET = 1e-3
 
 
 class WelfordCovariance:
@@ -11,34 +20,43 @@ class WelfordCovariance:
         self.reset()
 
     def reset(self):
-        self._mean = 0.0
-        self._m2 = 0.0
         self.n_samples = 0
+        self.mean = 0.0
+        self.scatter = 0.0          # sum of (x - mean_before)(x - mean_after): [.., D] or [.., D, D]
 
     def update(self, sample):
         self.n_samples += 1
-        delta_pre = sample - self._mean
-        self._mean = self._mean + delta_pre / self.n_samples
-        delta_post = sample - self._mean
+        before = sample - self.mean
+        self.mean = self.mean + before / self.n_samples
+        after = sample - self.mean
         if self.diagonal:
-            self._m2 = self._m2 + delta_pre * delta_post
-        elif sample.dim() == 1:
-            self._m2 = self._m2 + torch.outer(delta_post, delta_pre)
+            self.scatter = self.scatter + before * after
         else:
-            self._m2 = self._m2 + delta_post.unsqueeze(-1) * delta_pre.unsqueeze(-2)
+            # outer product per chain; `after` indexes rows so that the sum stays symmetric up to
+            # rounding exactly as the one-chain torch.outer(after, before) form does
+            self.scatter = self.scatter + after.unsqueeze(-1) * before.unsqueeze(-2)
 
     def get_covariance(self, regularize=True):
-        if self.n_samples < 2:
+        n = self.n_samples
+        if n < 2:
             raise RuntimeError("Insufficient samples to estimate covariance")
-        cov = self._m2 / (self.n_samples - 1)
-        if regularize:
-            # regularisation from Stan
-            scaled_cov = (self.n_samples / (self.n_samples + 5.0)) * cov
-            shrinkage = 1e-3 * (5.0 / (self.n_samples + 5.0))
-            if self.diagonal:
-                cov = scaled_cov + shrinkage
-            else:
-                eye = torch.eye(scaled_cov.size(-1), dtype=scaled_cov.dtype,
-                                device=scaled_cov.device)
-                cov = scaled_cov + shrinkage * eye
-        return cov
+        cov = self.scatter / (n - 1)
+        if not regularize:
+            return cov
+        keep = n / (n + SHRINK_COUNT)
+        floor = SHRINK_TARGET * (SHRINK_COUNT / (n + SHRINK_COUNT))
+        if self.diagonal:
+            return keep * cov + floor
+        d = cov.size(-1)
+        return keep * cov + floor * torch.eye(d, dtype=cov.dtype, device=cov.device)
+
+    # ---- the kernel's record (diagonal estimator) ----------------------------------------------
+    def to_record(self, chains, dim, dtype, device):
+        rec = torch.zeros((chains, 2, dim), dtype=dtype, device=device)
+        rec[:, 0] = self.mean
+        rec[:, 1] = self.scatter
+        return rec
+
+    def from_record(self, rec, draws_taken):
+        self.mean, self.scatter = rec[:, 0].clone(), rec[:, 1].clone()
+        self.n_samples += draws_taken

@@ -77,8 +77,53 @@ def RMSprop(optim_args, clip_args=None):
     return PyroOptim(torch.optim.RMSprop, optim_args, clip_args)
 
 
+class _FlatGroup:
+    """One generation of parameters: every tensor created in the same optimizer call.  Their
+    values, gradients and Adam moments are views into four flat buffers that are never
+    re-allocated (a captured hipGraph keeps pointing at live memory), and they share one device
+    step counter for as long as every step touches all of them."""
+
+    def __init__(self, params):
+        proto = params[0]
+        kernels._require_gpu(proto)  # HIP-only flat fused kernel (TorchAdam is the generic one)
+        self.params = list(params)
+        self.index = {}
+        total = sum(p.numel() for p in params)
+        self.flat, self.grad, self.exp_avg, self.exp_avg_sq = (
+            torch.zeros(total, dtype=proto.dtype, device=proto.device) for _ in range(4))
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.detach().reshape(-1))
+            if p.grad is not None:
+                self.grad[off:off + n].copy_(p.grad.reshape(-1))
+            self.index[p] = (off, n)
+            # the parameter (and its .grad) becomes a view into the flat buffers
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+        self.step_dev = torch.zeros(2, dtype=torch.int64, device=proto.device)   # [step, ticket]
+        self.own_steps = None      # param -> own [step, ticket] once the group is stepped raggedly
+
+    def adopt_grads(self, params):
+        """autograd may have re-created .grad for a parameter whose grad was None: fold it back."""
+        for p in params:
+            o, n = self.index[p]
+            if p.grad is None:
+                p.grad = self.grad[o:o + n].view(p.shape)
+            elif p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
+                self.grad[o:o + n].add_(p.grad.reshape(-1))
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+
 class _FlatAdam:
-    """Adam over one flat buffer holding every parameter seen so far."""
+    """Adam over flat buffers.  Semantics of the reference's per-parameter optimizers
+    (pyro/optim/optim.py:117-155) are kept: a step moves exactly the parameters passed to it, and a
+    parameter's bias correction / learning-rate decay count ITS OWN steps.  Parameters created in
+    one call form a group that is updated by ONE launch while every step touches the whole group
+    (the normal case: all parameters exist after the first step and are used by every step);
+    parameters created later form a new group with its own step counter, and a group that is ever
+    stepped partially falls back to one launch and one counter per parameter."""
 
     _clipped = False
     zeroes_grads = True  # the kernel zeroes the flat gradient in the same pass
@@ -96,75 +141,128 @@ class _FlatAdam:
         self.lrd = float(a.pop("lrd", 1.0))
         if a:
             raise ValueError("unsupported optimizer arguments: {}".format(sorted(a)))
-        self._params = []          # list of leaf tensors, in flat order
-        self._index = {}           # leaf -> (offset, numel)
-        self.flat = self.grad = self.exp_avg = self.exp_avg_sq = self.step_dev = None
-        self.grad_hook = None      # e.g. the RCCL all-reduce of the flat gradient
+        self._groups = []
+        self._group_of = {}        # leaf -> its _FlatGroup
+        self._pending_state = None
+        self.grad_hook = None      # e.g. the RCCL all-reduce of a flat gradient buffer
 
-    # -- flat buffer management ----------------------------------------------------------------
-    def _rebuild(self, new_params):
-        olds = (self.flat, self.grad, self.exp_avg, self.exp_avg_sq)
-        old_n = 0 if self.flat is None else self.flat.numel()
-        params = self._params + new_params
-        proto = params[0]
-        kernels._require_gpu(proto)  # HIP-only flat fused kernel (TorchAdam is the generic one)
-        total = sum(p.numel() for p in params)
-        bufs = [torch.zeros(total, dtype=proto.dtype, device=proto.device) for _ in range(4)]
-        if old_n:
-            for b, o in zip(bufs, olds):
-                b[:old_n].copy_(o)
-        off = old_n
-        for p in new_params:
-            n = p.numel()
-            bufs[0][off:off + n].copy_(p.detach().reshape(-1))
-            if p.grad is not None:
-                bufs[1][off:off + n].copy_(p.grad.reshape(-1))
-            self._index[p] = (off, n)
-            off += n
-        self._params = params
-        self.flat, self.grad, self.exp_avg, self.exp_avg_sq = bufs
-        # every parameter (and its .grad) becomes a view into the flat buffers
-        for p in params:
-            o, n = self._index[p]
-            p.data = self.flat[o:o + n].view(p.shape)
-            p.grad = self.grad[o:o + n].view(p.shape)
-        if self.step_dev is None:
-            self.step_dev = torch.zeros(2, dtype=torch.int64, device=proto.device)  # [step, ticket]
+    # ---- views used by the distributed wrapper and the tests ------------------------------------
+    def grad_buffers(self):
+        return [g.grad for g in self._groups]
+
+    @property
+    def grad(self):
+        """The flat gradient buffer (the RCCL message) when all parameters live in one group."""
+        if not self._groups:
+            return None
+        if len(self._groups) > 1:
+            raise RuntimeError("parameters were created in several optimizer calls: use "
+                               "grad_buffers()")
+        return self._groups[0].grad
+
+    @property
+    def flat(self):
+        return self._groups[0].flat if len(self._groups) == 1 else None
+
+    @property
+    def step_dev(self):
+        return self._groups[0].step_dev if len(self._groups) == 1 else None
 
     fused_publish = True     # __call__(publish=...) folds the loss hand-over into the update launch
 
+    def _launch(self, flat, grad, m, v, step_dev, publish):
+        kernels.adam_step(flat, grad, m, v, step_dev, lr=self.lr, betas=self.betas, eps=self.eps,
+                          weight_decay=self.weight_decay, clip_norm=self.clip_norm, lrd=self.lrd,
+                          clipped=self._clipped, zero_grad=True, publish=publish)
+
     def __call__(self, params, *args, skip_grad_hook=False, publish=None, **kwargs):
-        new = [p for p in params if p not in self._index]
+        params = list(params)
+        new = [p for p in params if p not in self._group_of]
         if new:
             # deterministic order (same on every rank): by param-store name
             new.sort(key=lambda p: _PARAM_STORE.param_name(p) or "")
-            self._rebuild(new)
-        else:
-            for p in params:  # autograd may have re-created .grad for a param whose grad was None
-                o, n = self._index[p]
-                if p.grad is None:
-                    p.grad = self.grad[o:o + n].view(p.shape)
-                elif p.grad.data_ptr() != self.grad.data_ptr() + o * self.grad.element_size():
-                    self.grad[o:o + n].add_(p.grad.reshape(-1))
-                    p.grad = self.grad[o:o + n].view(p.shape)
+            group = _FlatGroup(new)
+            self._groups.append(group)
+            for p in new:
+                self._group_of[p] = group
+            self._restore_into(group)
+        wanted, fresh = set(params), set(new)
+        work = []
+        for g in self._groups:
+            touched = [p for p in g.params if p in wanted]
+            if not touched:
+                continue            # the reference only steps parameters seen in this step
+            g.adopt_grads([p for p in touched if p not in fresh])
+            work.append((g, touched))
         if self.grad_hook is not None and not skip_grad_hook:
-            self.grad_hook(self.grad)
-        kernels.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev,
-                          lr=self.lr, betas=self.betas, eps=self.eps,
-                          weight_decay=self.weight_decay, clip_norm=self.clip_norm, lrd=self.lrd,
-                          clipped=self._clipped, zero_grad=True,
-                          publish=publish if self.flat.numel() else None)
-        if publish is not None and not self.flat.numel():
+            for g, _ in work:
+                self.grad_hook(g.grad)
+        launches = []
+        for g, touched in work:
+            if g.own_steps is None and len(touched) == len(g.params):
+                launches.append((g.flat, g.grad, g.exp_avg, g.exp_avg_sq, g.step_dev))
+                continue
+            if g.own_steps is None:          # first partial step: every parameter gets its own
+                g.own_steps = {p: g.step_dev.clone() for p in g.params}     # counter from here on
+            for p in touched:
+                o, n = g.index[p]
+                launches.append((g.flat[o:o + n], g.grad[o:o + n], g.exp_avg[o:o + n],
+                                 g.exp_avg_sq[o:o + n], g.own_steps[p]))
+        launches = [l for l in launches if l[0].numel()]
+        for i, l in enumerate(launches):
+            self._launch(*l, publish=publish if i == len(launches) - 1 else None)
+        if publish is not None and not launches:
             kernels.publish_scalar(*publish)
 
+    # ---- checkpointing (reference: PyroOptim.get_state / set_state, optim.py:157-200) -----------
     def get_state(self):
-        return {"names": [_PARAM_STORE.param_name(p) for p in self._params],
-                "exp_avg": None if self.exp_avg is None else self.exp_avg.clone(),
-                "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.clone(),
-                "step": None if self.step_dev is None else int(self.step_dev[0].item())}
+        """{parameter name: {"exp_avg", "exp_avg_sq", "step"}} -- per parameter, as the reference's
+        state dict is, so that a checkpoint does not depend on how parameters were grouped."""
+        state = {}
+        for g in self._groups:
+            shared = None if g.own_steps is not None else int(g.step_dev[0].item())
+            for p in g.params:
+                o, n = g.index[p]
+                step = shared if shared is not None else int(g.own_steps[p][0].item())
+                state[_PARAM_STORE.param_name(p)] = {
+                    "exp_avg": g.exp_avg[o:o + n].clone().view(p.shape),
+                    "exp_avg_sq": g.exp_avg_sq[o:o + n].clone().view(p.shape),
+                    "step": step}
+        return state
 
     def set_state(self, state):
-        self._pending_state = state
+        """Restores moments and step counts; parameters that do not exist yet pick their entry up
+        when they are first seen (as the reference's _state_waiting_to_be_consumed does)."""
+        self._pending_state = dict(state)
+        for g in self._groups:
+            self._restore_into(g)
+
+    def _restore_into(self, g):
+        if not self._pending_state:
+            return
+        steps = {}
+        for p in g.params:
+            name = _PARAM_STORE.param_name(p)
+            entry = self._pending_state.pop(name, None)
+            if entry is None:
+                continue
+            o, n = g.index[p]
+            for key, buf in (("exp_avg", g.exp_avg), ("exp_avg_sq", g.exp_avg_sq)):
+                t = entry[key]
+                if t.numel() != n:
+                    raise ValueError("optimizer state of {!r}: {} has {} elements, the parameter {}"
+                                     .format(name, key, t.numel(), n))
+                buf[o:o + n].copy_(t.reshape(-1).to(buf.device, buf.dtype))
+            steps[p] = int(entry["step"])
+        if not steps:
+            return
+        if len(steps) == len(g.params) and len(set(steps.values())) == 1 and g.own_steps is None:
+            g.step_dev[0] = next(iter(steps.values()))
+        else:
+            if g.own_steps is None:
+                g.own_steps = {p: g.step_dev.clone() for p in g.params}
+            for p, st in steps.items():
+                g.own_steps[p][0] = st
 
     def save(self, filename):
         torch.save(self.get_state(), filename)

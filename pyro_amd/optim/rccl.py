@@ -71,11 +71,11 @@ class RcclOptimizer:
     # stays an ordinary eager RCCL launch between two captured graphs
     # [loss + backward] -> reduce_gradients -> [optimizer update + gradient zeroing]
     def reduce_gradients(self, params):
-        flat = getattr(self.optim, "grad", None)
-        if flat is None:
+        if not hasattr(self.optim, "grad_buffers"):
             raise RuntimeError("reduce_gradients needs the flat-buffer optimizer "
                                "(pyro_amd.optim.Adam / ClippedAdam)")
-        self._allreduce_flat(flat)
+        for flat in self.optim.grad_buffers():     # one buffer unless parameters appeared late
+            self._allreduce_flat(flat)
 
     def apply(self, params, *args, **kwargs):
         self.optim(_sorted(params), *args, skip_grad_hook=True, **kwargs)

@@ -115,3 +115,44 @@ def test_large_plated_site_takes_the_nd_route(monkeypatch):
     l2.backward()
     np.testing.assert_allclose(out2.item(), l2.item(), rtol=1e-12)
     torch.testing.assert_close(loc.grad, ref2.loc.grad, rtol=1e-10, atol=1e-12)
+
+
+def test_flat_adam_steps_only_what_it_is_given_and_resumes_from_a_checkpoint():
+    """Partial steps, a parameter created at step 4 (own bias correction), get_state / set_state
+    round trip into a fresh optimizer: equal to one torch.optim.Adam per parameter
+    (pyro/optim/optim.py:117-155,157-200)."""
+    from tests import optim_cases
+    optim_cases.run_semantics(torch.device("cpu"))
+
+
+def test_guide_gradients_reach_autograd_outside_loss_and_grads(monkeypatch):
+    """The fused guide draws sink their gradients straight into .grad only inside
+    ELBO.loss_and_grads; differentiable_loss + torch.autograd.grad (the torch-optimizer /
+    ELBOModule route of pyro/infer/elbo.py:137-142) must see ordinary gradients, also after the
+    flat optimizer has made every .grad a permanent view."""
+    import pyro_amd as pyro
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    pyro.clear_param_store()
+    pyro.set_rng_seed(1)
+    dev = torch.device("cpu")
+    g = np.random.default_rng(0)
+    X = torch.as_tensor(g.standard_normal((50, 4)))
+    y = torch.as_tensor((g.uniform(size=50) < 0.5).astype(np.float64))
+    guide = AutoNormal(models.logreg_model_fused, init_scale=0.1)
+    elbo = Trace_ELBO(num_particles=3, vectorize_particles=True, max_plate_nesting=1)
+    svi = SVI(models.logreg_model_fused, guide, pyro.optim.Adam({"lr": 0.01}), elbo)
+    svi.step(X, y)                                     # .grad is now a view into the flat buffer
+    params = [p for _, p in sorted(pyro.get_param_store()._params.items())]
+    assert all(p.grad is not None for p in params)
+    pyro.set_rng_seed(5)
+    loss = elbo.differentiable_loss(models.logreg_model_fused, guide, X, y)
+    grads = torch.autograd.grad(loss, params, allow_unused=False)
+    assert all(gr is not None and bool(torch.isfinite(gr).all()) for gr in grads)
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in params)     # nothing leaked into .grad
+    pyro.set_rng_seed(5)
+    ref = elbo.loss_and_grads(models.logreg_model_fused, guide, X, y)  # same draws, sink path
+    for p, gr in zip(params, grads):
+        np.testing.assert_allclose(p.grad.numpy(), gr.numpy(), rtol=1e-10, atol=1e-12)
+    assert abs(ref - float(loss)) < 1e-9 * abs(ref)
+    pyro.clear_param_store()

@@ -219,3 +219,27 @@ def test_constrained_support_potentials_match_reference(_cpu_backend):
 def test_sequential_consistent(_cpu_backend):
     mc.run_sequential_consistent(torch.device("cpu"))
 
+
+
+def test_initialize_model_redraws_non_finite_starting_points(_cpu_backend):
+    """Half of the uniform(-2, 2) initial draws put sqrt(x) at NaN: those chains are drawn again
+    until potential and gradient are finite; a model that is never finite raises the reference's
+    error (pyro/infer/mcmc/util.py:430-470)."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer.mcmc.util import initialize_model
+
+    def model(bad=False):
+        x = pyro.sample("x", dist.Normal(0.0, 3.0))
+        loc = torch.sqrt(x) if not bad else torch.log(-x * x - 1.0)
+        pyro.sample("obs", dist.Normal(loc, 1.0), obs=torch.tensor(0.5))
+
+    from pyro_amd.primitives import validation_enabled
+    pyro.set_rng_seed(0)
+    with validation_enabled(False):       # Normal(loc=nan) is what the bad starts produce
+        init, potential, _, _ = initialize_model(model, num_chains=16)
+        assert bool((init["x"] > 0).all())
+        pe = potential({k: v.clone() for k, v in init.items()})
+        assert bool(torch.isfinite(pe).all())
+        with pytest.raises(ValueError, match="cannot find valid initial params"):
+            initialize_model(model, model_args=(True,), num_chains=4)

@@ -221,3 +221,11 @@ def test_hierarchical_logreg_full_size_properties(gpu):
                                                   w[:, g0:g0 + step].contiguous(), b, None, 1.0, s2)
         lo_all += l.double()
     torch.testing.assert_close(a1[0].double(), lo_all, rtol=2e-5, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-6)])
+def test_flat_adam_semantics_and_checkpoint(gpu, dtype, tol):
+    """tests/optim_cases.py on the HIP update kernel: parameters not passed do not move, a late
+    parameter counts its own steps, get_state / set_state resumes exactly."""
+    from tests import optim_cases
+    optim_cases.run_semantics(gpu, dtype, tol)
