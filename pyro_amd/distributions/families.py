@@ -6,6 +6,8 @@ drawing from the Philox stream, and ``fused_log_prob_sum`` providing the one-ker
 log_prob -> scale_and_mask -> plate-sum reduction.  They require HIP tensors: CPU tensors raise.
 """
 import torch
+
+from ..ops import lazy as _lazy
 from torch.distributions import constraints
 
 from .. import _lib, rng
@@ -447,6 +449,10 @@ class Bernoulli(_FusedElementwise, torch.distributions.Bernoulli, TorchDistribut
     _dist_id = _lib.DIST_BERNOULLI_LOGITS
 
     def __new__(cls, probs=None, logits=None, validate_args=None):
+        if isinstance(logits, _lazy.DeferredMatmul):
+            # unmodified model text (w @ X.t() ... + b): the plated GLM if its shape says so;
+            # otherwise torch's constructor evaluates the product (broadcast_all is a torch function)
+            logits = logits.as_linear_logits() or logits
         if isinstance(logits, (LinearLogits, GroupedLinearLogits)):
             return _BernoulliLinear(logits, validate_args)
         return super().__new__(cls)

@@ -96,6 +96,7 @@ class GraphedPotential:
     def __init__(self, base, warmup=3):
         self.base, self.warmup = base, warmup
         self.calls, self.graph, self.failed = 0, None, False
+        self.replays = 0           # graph launches so far (survives release of the graph)
         self.z_static = self.pe_static = self.grad_static = None
 
     def __call__(self, z_flat):
@@ -118,6 +119,7 @@ class GraphedPotential:
                 return self.base(z_flat)
         self.z_static.copy_(z_flat)
         self.graph.replay()
+        self.replays += 1
         return self.pe_static.clone(), self.grad_static.clone()
 
     def _capture(self, z_flat):

@@ -544,13 +544,18 @@ def glm_pack_planes(X, out=None):
 
 
 def _planes_entry_of(X):
-    key = id(X)
+    # X may be a fresh view object every step (``w @ X.t()`` hands over ``X.t().t()``): the entry
+    # belongs to the view's BASE tensor (the user's long-lived object; all views share its
+    # version counter) and the view's geometry
+    base = X._base if X._base is not None else X
+    key = (id(base), X.storage_offset(), tuple(X.shape), tuple(X.stride()))
     ent = _planes_cache.get(key)
-    if ent is not None and ent[0]() is not X:        # the id was recycled
+    if ent is not None and ent[0]() is not base:     # the id was recycled
         ent = None
     if ent is None:
         import weakref
-        ent = [weakref.ref(X, lambda _r, k=key: _planes_cache.pop(k, None)), X._version, None, 0]
+        ent = [weakref.ref(base, lambda _r, k=key: _planes_cache.pop(k, None)), X._version, None, 0,
+               (X.storage_offset(), tuple(X.shape), tuple(X.stride()))]
         _planes_cache[key] = ent
     return ent
 
@@ -580,10 +585,11 @@ def glm_planes_revalidate():
     """Re-pack every cached image whose tensor was modified in place (called before a captured
     step is replayed: the graph reads the image, not X)."""
     for ent in list(_planes_cache.values()):
-        X = ent[0]()
-        if X is not None and ent[2] is not None and ent[1] != X._version:
-            glm_pack_planes(X, out=ent[2])
-            ent[1] = X._version
+        base = ent[0]()
+        if base is not None and ent[2] is not None and ent[1] != base._version:
+            off, shape, stride = ent[4]
+            glm_pack_planes(base.as_strided(shape, stride, off), out=ent[2])
+            ent[1] = base._version
 
 
 def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D):

@@ -6,6 +6,7 @@ import torch
 
 from . import distributions as dist
 from . import rng
+from .ops import lazy as _lazy
 from .params import _PARAM_STORE
 from .poutine import settings as _poutine_settings
 from .poutine.handlers import PlateMessenger
@@ -56,7 +57,12 @@ def sample(name, fn, *args, obs=None, obs_mask=None, infer=None, **kwargs):
         return fn(*args, **kwargs)
     msg = new_message("sample", name, fn, args, kwargs, obs, is_observed, infer)
     apply_stack(msg)
-    return msg["value"]
+    value = msg["value"]
+    if not is_observed and isinstance(value, torch.Tensor):
+        # latents travel on as a transparent tensor subclass that lets unmodified GLM model text
+        # (w @ X.t()) reach the fused kernel (ops/lazy.py); the trace keeps the plain tensor
+        value = _lazy.as_latent(value)
+    return value
 
 
 def factor(name, log_factor, *, has_rsample=None):

@@ -137,6 +137,11 @@ def run_logreg(g, device, monkeypatch, fused, dtype, rtol):
     y = torch.as_tensor(g["y"], dtype=dtype, device=device)
     P = int(g["P"])
     model = logreg_model_fused if fused else logreg_model
+    if not fused:
+        # "unfused" means the logits are materialised: switch the lazy recognition of
+        # w @ X.t() (pyro_amd/ops/lazy.py) off for this run
+        from pyro_amd.ops import lazy
+        monkeypatch.setitem(lazy.ENABLED, "on", False)
     pyro.clear_param_store()
     guide = AutoNormal(model, init_scale=0.1)
     elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)

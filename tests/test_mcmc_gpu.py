@@ -256,8 +256,9 @@ def test_jit_compile_replays_the_potential_as_a_graph(gpu, full_mass):
         out.append(mcmc.get_samples(group_by_chain=True)["w"].clone())
         if jit:
             pot = kernel._potential
-            assert type(pot).__name__ == "GraphedPotential" and pot.graph is not None \
-                and not pot.failed
+            # MCMC.run releases the captured graph at the end; the replay count stays
+            assert type(pot).__name__ == "GraphedPotential" and pot.replays > 100 \
+                and pot.graph is None and not pot.failed
     assert torch.equal(out[0], out[1])
 
 

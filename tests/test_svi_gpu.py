@@ -229,3 +229,70 @@ def test_flat_adam_semantics_and_checkpoint(gpu, dtype, tol):
     parameter counts its own steps, get_state / set_state resumes exactly."""
     from tests import optim_cases
     optim_cases.run_semantics(gpu, dtype, tol)
+
+
+def test_reference_model_text_reaches_the_fused_kernel(gpu, monkeypatch):
+    """SURVEY 8(d)'s model verbatim (``logits = w @ X.t(); logits.squeeze(-2); Bernoulli(logits=logits
+    + b)``): the latent's matmul with the constant design matrix is deferred (ops/lazy.py) and the
+    observed site runs pa_glm_bernoulli*_fwd_bwd; loss and gradients equal the materialised route."""
+    import pyro_amd as pyro
+    from pyro_amd import kernels
+    from pyro_amd.infer import Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    from pyro_amd.ops import lazy
+
+    g = np.random.default_rng(0)
+    N, D, P = 6000, 32, 40
+    X = torch.as_tensor(g.standard_normal((N, D)).astype(np.float32), device=gpu)
+    y = torch.as_tensor((g.uniform(size=N) < 0.5).astype(np.float32), device=gpu)
+    calls = []
+    real = kernels.glm_bernoulli_fwd_bwd
+    monkeypatch.setattr(kernels, "glm_bernoulli_fwd_bwd",
+                        lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    out = {}
+    for mode in (True, False):
+        monkeypatch.setitem(lazy.ENABLED, "on", mode)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(11)
+        guide = AutoNormal(models.logreg_model, init_scale=0.1)
+        elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+        n0 = len(calls)
+        loss = elbo.loss_and_grads(models.logreg_model, guide, X, y)
+        out[mode] = (loss, models.store_grads(), len(calls) - n0)
+    assert out[True][2] == 1 and out[False][2] == 0          # fused kernel only on the lazy route
+    assert abs(out[True][0] - out[False][0]) < 2e-5 * abs(out[False][0])
+    for k in out[False][1]:
+        np.testing.assert_allclose(out[True][1][k], out[False][1][k], rtol=2e-3, atol=2e-3)
+    pyro.clear_param_store()
+
+
+def test_deferred_matmul_behaves_as_the_product_everywhere_else(gpu):
+    """Anything but squeeze / + bias / Bernoulli(logits=...) evaluates the deferred product: model
+    text that uses the logits differently runs exactly as written."""
+    from pyro_amd.ops import lazy
+    g = torch.Generator(device="cpu").manual_seed(0)
+    X = torch.randn((500, 8), generator=g).to(gpu)
+    w = torch.randn((3, 1, 8), generator=g).to(gpu)
+    b = torch.randn((3, 1), generator=g).to(gpu)
+    wl = lazy.as_latent(w)
+    assert isinstance(wl, lazy.LatentTensor) and type(wl * 2.0) is torch.Tensor
+    d = wl @ X.t()
+    ref = w @ X.t()
+    assert isinstance(d, lazy.DeferredMatmul) and d.shape == ref.shape and d.dim() == 3
+    torch.testing.assert_close(torch.sigmoid(d), torch.sigmoid(ref))
+    torch.testing.assert_close(d * 2.0, ref * 2.0)
+    torch.testing.assert_close(d - 1.0, ref - 1.0)
+    torch.testing.assert_close(d[1], ref[1])
+    torch.testing.assert_close(d.sum(-1), ref.sum(-1))
+    torch.testing.assert_close(d.squeeze(0), ref.squeeze(0))            # not the plate dim: evaluated
+    s = d.squeeze(-2)
+    assert isinstance(s, lazy.DeferredMatmul) and s.shape == (3, 500)
+    sb = s + lazy.as_latent(b)
+    assert isinstance(sb, lazy.DeferredMatmul) and sb.as_linear_logits() is not None
+    torch.testing.assert_close(sb.materialize(), ref.squeeze(-2) + b)
+    torch.testing.assert_close(s + torch.ones((500,), device=gpu), ref.squeeze(-2) + 1.0)   # not a bias
+    assert type(wl @ torch.randn((8, 8), device=gpu)) is torch.Tensor    # small matrix: not deferred
+    x1 = lazy.as_latent(torch.randn((8,), generator=g).to(gpu))
+    d1 = X @ x1
+    assert isinstance(d1, lazy.DeferredMatmul) and d1.shape == (500,)
+    torch.testing.assert_close(d1.materialize(), X @ x1.as_subclass(torch.Tensor))

@@ -36,17 +36,27 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True):
             "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
 
 
-def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=True):
-    """BASELINE configs[1] with the other guide SURVEY 8(d) names (AutoMultivariateNormal) or with
-    the reference's default num_particles = 1 (few-particle GLM kernel)."""
+def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=True, model=None,
+                    lazy_matmul=True):
+    """BASELINE configs[1] with the other guide SURVEY 8(d) names (AutoMultivariateNormal), with
+    the reference's default num_particles = 1 (few-particle GLM kernel), with the explicit
+    dist.linear_logits model, or with the lazy recognition of w @ X.t() switched off (materialised
+    logits: rocBLAS products around the fused site kernels)."""
+    from pyro_amd.ops import lazy
     X, y = examples.synthetic_logreg_data(N, D, dev, seed=0)
     pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
-    g = AutoMultivariateNormal(examples.logreg_model, init_scale=0.1) if guide == "mvn" else \
-        AutoNormal(examples.logreg_model, init_scale=0.1)
-    svi = SVI(examples.logreg_model, g, pyro.optim.Adam({"lr": 0.01}),
+    model = examples.logreg_model if model is None else model
+    g = AutoMultivariateNormal(model, init_scale=0.1) if guide == "mvn" else \
+        AutoNormal(model, init_scale=0.1)
+    svi = SVI(model, g, pyro.optim.Adam({"lr": 0.01}),
               Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
               hip_graph=graph, graph_warmup=2)
-    dt = timed(lambda: svi.step(X, y), steps, 8)
+    prev = lazy.ENABLED["on"]
+    lazy.ENABLED["on"] = bool(lazy_matmul)
+    try:
+        dt = timed(lambda: svi.step(X, y), steps, 8)
+    finally:
+        lazy.ENABLED["on"] = prev
     return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "num_particles": P,
             "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1),
             "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
