@@ -106,12 +106,24 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
   constexpr int NLD = VEC4 ? 4 * DT : 16 * DT;  // loads per lane per tile
   constexpr int EPL = VEC4 ? 4 : 1;             // floats per load
   float stage[NLD * EPL];
+  uint8_t stage_m[NLD];        // mask byte of the row each staged load belongs to (1 without a mask)
   float st_y = 0.0f, st_m = 0.0f;
   const int step_e = 64 * EPL;                   // flat-element stride between a lane's loads
   const int q0 = step_e / D, r0 = step_e % D;    // (row, col) increment per load
   const int e0 = lane * EPL;
   const int n_first = e0 / D, d_first = e0 % D;
   const int64_t total_e = row_end * (int64_t)D;
+  int nrow[NLD];               // tile-local row of this lane's j-th load
+  {
+    int n = n_first, d = d_first;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      nrow[j] = n;
+      n += q0;
+      d += r0;
+      if (d >= D) { d -= D; n += 1; }
+    }
+  }
 
   // Loads use CLAMPED addresses and are consumed raw; validity is applied in write_stage(), one
   // tile of compute later (a select next to the load makes the compiler wait for it right there
@@ -130,6 +142,10 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
       } else {
         stage[j] = X[ec];
       }
+      // a masked row must contribute nothing whatever it holds (where(mask, x, 0),
+      // pyro/distributions/util.py:326): its X values are dropped at staging, so that inf-sized
+      // garbage cannot turn 0 * l into NaN
+      stage_m[j] = (mask != nullptr && ok) ? mask[row_begin + tile * 32 + nrow[j]] : (uint8_t)1;
     }
     const int64_t n = row_begin + tile * 32 + l31;
     const int64_t nc = n < row_end ? n : 0;
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       if (e0 + j * step_e < 32 * D) {
-        const bool ok = base + e0 + (int64_t)j * step_e < total_e;
+        const bool ok = (base + e0 + (int64_t)j * step_e < total_e) && stage_m[j] != 0;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) Xs[n * S + d + k] = ok ? stage[EPL * j + k] : 0.0f;
       }
@@ -397,7 +413,8 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   // kernel at D = 128); that shape stays on the exact kernel.
   if (vec4 && g_glm_variant != 1 && DT < 4) {
     if constexpr (DT < 4) {
-      auto k = glm_bernoulli_bf16_kernel<DT, PT, false>;
+      auto k = mask != nullptr ? glm_bernoulli_bf16_kernel<DT, PT, false, true>
+                               : glm_bernoulli_bf16_kernel<DT, PT, false, false>;
       constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -490,7 +507,8 @@ static int glm_grouped_launch(const float* X, const float* y, const float* w, co
   if (br) (void)hipEventRecord(ev0, s);
   if (vec4 && g_glm_variant != 1 && DT < 4) {
     if constexpr (DT < 4) {
-      auto k = glm_bernoulli_bf16_kernel<DT, PT, true>;
+      auto k = mask != nullptr ? glm_bernoulli_bf16_kernel<DT, PT, true, true>
+                               : glm_bernoulli_bf16_kernel<DT, PT, true, false>;
       constexpr int lds = GlmBfCfg<DT, PT>::LDS_BYTES;
       if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -88,7 +88,12 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint32_t a, uint32_t b, uint32_t c, 
 constexpr uint32_t BF16_NEG_HUGE = 0xF149u;
 constexpr uint32_t BF16_ONE = 0x3F80u;
 
-template <int DT, int PT, bool GROUPED>
+// MASKED: a row mask is given.  A masked row must contribute exactly nothing whatever it holds
+// (scale_and_mask is where(mask, x, 0), pyro/distributions/util.py:326): besides the -1e30 logit
+// offset (which silences ll and g only while |x . w| stays far below 1e30) its X values are
+// replaced by 0 before the split, so that huge finite garbage under the mask cannot reach the
+// logits or the gradient products.  Separate instantiation: the unmasked loop carries no selects.
+template <int DT, int PT, bool GROUPED, bool MASKED>
 __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     const float* __restrict__ X, const float* __restrict__ y, const float* __restrict__ w,
     const float* __restrict__ b, const uint8_t* __restrict__ mask, int64_t N, int D, int P,
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
   constexpr int NLD = 4 * DT;                 // float4 loads per lane per tile
   constexpr bool EARLY_SPLIT = (DT == 1);     // larger D: no registers for the split planes
   float4 stage[NLD];
+  uint8_t stage_m[NLD];                       // MASKED: the mask byte of each staged float4's row
   float st_y = 0.0f;
   uint8_t st_m = 0;
   uint32_t xs1[2 * NLD], xs2[2 * NLD], xs3[2 * NLD];
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     for (int j = 0; j < NLD; ++j) {
       const uint32_t off = lofs[j] < lim ? lofs[j] : lim;
       stage[j] = *reinterpret_cast<const float4*>(Xb + off);
+      if constexpr (MASKED) stage_m[j] = mask[sb / D + off / (uint32_t)D];   // row of this float4
     }
     const int64_t rb = tv ? row_begin + tile * 32 : 0;
     const int64_t rrem = (tv ? row_end : N) - rb;                    // >= 1
@@ -169,6 +176,9 @@ __global__ __launch_bounds__(64 * GLMB_WAVES, 2) void glm_bernoulli_bf16_kernel(
     xs3[2 * j] = xs1[2 * j]; xs3[2 * j + 1] = xs1[2 * j + 1];
     return;
 #endif
+    if constexpr (MASKED) {
+      if (stage_m[j] == 0) stage[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     split_pair(stage[j].x, stage[j].y, xs1[2 * j], xs2[2 * j], xs3[2 * j]);
     split_pair(stage[j].z, stage[j].w, xs1[2 * j + 1], xs2[2 * j + 1], xs3[2 * j + 1]);
   };

@@ -273,6 +273,38 @@ def test_glm_bernoulli_deterministic_and_linear(gpu, glm_variant):
     logits = (w.double() @ X.double().T) + b.double()[:, None]
     ll_ref = (y.double() * logits - torch.nn.functional.softplus(logits)).sum(1)
     torch.testing.assert_close(a1[0].double(), ll_ref, rtol=2e-5, atol=1e-3)
+    # the gradients at full size, all 64 particles, against torch fp64
+    gfac = y.double() - torch.sigmoid(logits)
+    for out in (a0, a1):
+        torch.testing.assert_close(out[1].double(), gfac @ X.double(), rtol=1e-4, atol=2e-2)
+        torch.testing.assert_close(out[2].double(), gfac.sum(1), rtol=1e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["auto", "exact_f32", "bf16x3"])
+def test_glm_masked_rows_with_huge_garbage_contribute_nothing(gpu, variant):
+    """where(mask, x, 0) semantics on the matrix-core kernels (P = 64): masked rows holding 1e30
+    (|x . w| far beyond the -1e30 logit offset that silences ordinary masked rows) and 3e38 leave
+    every output equal to the run on the unmasked rows alone."""
+    k = _k()
+    N, D, P = 20000, 32, 64
+    g = torch.Generator(device=gpu).manual_seed(4)
+    X = torch.randn((N, D), device=gpu, generator=g)
+    w = torch.randn((P, D), device=gpu, generator=g)
+    b = torch.randn((P,), device=gpu, generator=g)
+    y = (torch.rand((N,), device=gpu, generator=g) < 0.5).float()
+    mask = torch.rand((N,), device=gpu, generator=g) < 0.7
+    try:
+        k.glm_set_variant(variant)
+        m0 = k.glm_bernoulli_fwd_bwd(X[mask].contiguous(), y[mask].contiguous(), w, b, None, 1.0)
+        for junk in (1e30, -3e38):
+            Xn = X.clone()
+            Xn[~mask] = junk
+            m1 = k.glm_bernoulli_fwd_bwd(Xn, y, w, b, mask, 1.0)
+            for u, v in zip(m1, m0):
+                assert bool(torch.isfinite(u).all())
+                torch.testing.assert_close(u, v, rtol=2e-5, atol=2e-2)
+    finally:
+        k.glm_set_variant(k.GLM_AUTO)
 
 
 @pytest.mark.parametrize("P", [1, 4])

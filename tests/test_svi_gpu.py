@@ -296,3 +296,64 @@ def test_deferred_matmul_behaves_as_the_product_everywhere_else(gpu):
     d1 = X @ x1
     assert isinstance(d1, lazy.DeferredMatmul) and d1.shape == (500,)
     torch.testing.assert_close(d1.materialize(), X @ x1.as_subclass(torch.Tensor))
+
+
+def test_north_star_acceptance_at_the_north_star_config(gpu):
+    """BASELINE.json's acceptance criterion at ITS config: Bayesian logistic regression, plate
+    N = 1e6, D = 32, 64 vectorised particles -- 100 Adam steps of the HIP path (SURVEY 8d's model
+    text verbatim, lazy matmul -> plane-image GLM kernel from the second step on) against the
+    torch-CPU port of the reference step (oracle/ref_port_torch.py, pinned on the reference's
+    golden vectors) fed the SAME standard-normal bank: posterior means within 1e-4 relative."""
+    import pyro_amd as pyro
+    from pyro_amd import examples, rng
+    from oracle.ref_port_torch import LogRegAutoNormalPort
+    N, D, P, steps, lr = 1_000_000, 32, 64, 100, 0.05
+    g = np.random.default_rng(0)
+    X = g.standard_normal((N, D), dtype=np.float32)
+    w_true = g.standard_normal(D)
+    y = (g.uniform(size=N) < 1 / (1 + np.exp(-X @ w_true))).astype(np.float32)
+    bank = [(g.standard_normal((P, 1, D)), g.standard_normal((P, 1))) for _ in range(steps)]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # the port's best count (bench.py sweep)
+    try:
+        port = LogRegAutoNormalPort(torch.tensor(X), torch.tensor(y), P, lr=lr)
+        for ew, eb in bank:
+            port.loss_and_grads(torch.tensor(ew, dtype=torch.float32), torch.tensor(eb, dtype=torch.float32))
+            for o in port.optims:
+                o.step()
+            for p in port.params:
+                p.grad = None
+    finally:
+        torch.set_num_threads(threads)
+    Xt, yt = torch.as_tensor(X, device=gpu), torch.as_tensor(y, device=gpu)
+    pyro.clear_param_store()
+    pyro.enable_validation(False)
+    try:
+        guide = pyro.infer.autoguide.AutoNormal(examples.logreg_model, init_scale=0.1)
+        svi = pyro.infer.SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": lr}),
+                             pyro.infer.Trace_ELBO(num_particles=P, vectorize_particles=True,
+                                                   max_plate_nesting=1))
+        guide._setup_prototype(Xt, yt)
+        flat = [e for pair in bank for e in pair]
+        orig = rng.normal
+        rng.normal = models.EpsReplay(flat, gpu)
+        try:
+            for _ in range(steps):
+                svi.step(Xt, yt)
+        finally:
+            rng.normal = orig
+    finally:
+        pyro.enable_validation(True)
+    from pyro_amd import kernels
+    assert kernels.glm_planes_of(Xt.t().t()) is not None          # the plane-image kernel ran
+    store = pyro.get_param_store()
+    for name, ref in (("AutoNormal.locs.w", port.loc_w), ("AutoNormal.locs.b", port.loc_b)):
+        mean = store[name].detach().cpu().numpy().reshape(-1)
+        ref = ref.detach().numpy().reshape(-1)
+        rel = np.abs(mean - ref).max() / np.abs(ref).max()
+        assert rel < 1e-4, (name, rel)
+    # posterior scales too (same criterion)
+    sw = store["AutoNormal.scales.w"].detach().cpu().numpy()
+    ref_sw = torch.nn.functional.softplus(port.rho_w).detach().numpy()
+    assert np.abs(sw - ref_sw).max() / np.abs(ref_sw).max() < 1e-3
+    pyro.clear_param_store()

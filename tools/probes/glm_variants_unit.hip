@@ -7,7 +7,7 @@
 extern "C" float CAT(run_, PROBE_NAME)(const float* X, const float* y, const float* w, const float* b,
                                        int64_t N, int D, int P, float* part, int nblocks, int reps) {
   using namespace pa;
-  auto k = glm_bernoulli_bf16_kernel<1, 2, false>;
+  auto k = glm_bernoulli_bf16_kernel<1, 2, false, false>;
   constexpr int lds = GlmBfCfg<1, 2>::LDS_BYTES;
   const int64_t ntiles = (N + 31) / 32;
   const int64_t iters = (ntiles + (int64_t)nblocks * GLMB_WAVES - 1) / ((int64_t)nblocks * GLMB_WAVES);
