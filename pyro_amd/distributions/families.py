@@ -227,6 +227,10 @@ class LinearLogits:
     """
 
     def __init__(self, X, w, b=None):
+        # the site values themselves, not the latent-tensor aliases model code holds (ops/lazy.py):
+        # the ELBO assembly chains gradients by tensor identity
+        w = _lazy._plain(w)
+        b = _lazy._plain(b) if isinstance(b, torch.Tensor) else b
         if X.dim() != 2:
             raise ValueError("LinearLogits: X must be [N, D], got {}".format(tuple(X.shape)))
         if w.shape[-1] != X.shape[-1]:
@@ -284,6 +288,8 @@ class GroupedLinearLogits:
     ``segments``: kernels.GroupSegments built once from the group offsets."""
 
     def __init__(self, X, w, b, segments):
+        w = _lazy._plain(w)
+        b = _lazy._plain(b) if isinstance(b, torch.Tensor) else b
         if X.dim() != 2 or w.dim() < 2 or w.shape[-1] != X.shape[-1] or w.shape[-2] != segments.G:
             raise ValueError("GroupedLinearLogits: expected X [N, D], w [..., G={}, D], got {} and {}"
                              .format(segments.G, tuple(X.shape), tuple(w.shape)))

@@ -25,7 +25,13 @@ ENABLED = {"on": True}
 
 
 def _plain(t):
-    return t.as_subclass(torch.Tensor) if type(t) is not torch.Tensor and isinstance(t, torch.Tensor) else t
+    """The plain tensor behind a latent: the very object the trace holds (so that downstream code
+    that keys on tensor identity -- e.g. the gradient chaining of the ELBO assembly -- sees the
+    site's value, not a view of it)."""
+    if type(t) is torch.Tensor or not isinstance(t, torch.Tensor):
+        return t
+    origin = getattr(t, "_pa_origin", None)
+    return origin if origin is not None else t.as_subclass(torch.Tensor)
 
 
 def _is_design_transpose(m):
@@ -63,7 +69,9 @@ class LatentTensor(torch.Tensor):
 def as_latent(value):
     if (ENABLED["on"] and type(value) is torch.Tensor and value.is_cuda
             and value.dtype == torch.float32 and 1 <= value.dim() and value.shape[-1] <= 128):
-        return value.as_subclass(LatentTensor)
+        lat = value.as_subclass(LatentTensor)
+        lat._pa_origin = value
+        return lat
     return value
 
 

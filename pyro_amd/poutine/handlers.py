@@ -77,6 +77,7 @@ class ReplayMessenger(Messenger):
             msg["done"] = True
             msg["value"] = guide_msg["value"]
             msg["infer"] = guide_msg["infer"]
+            msg["_replayed"] = True       # primitives.sample: the value reaches MODEL code
 
     def _pyro_param(self, msg):
         if self.params is not None and msg["name"] in self.params:

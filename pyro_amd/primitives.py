@@ -58,9 +58,13 @@ def sample(name, fn, *args, obs=None, obs_mask=None, infer=None, **kwargs):
     msg = new_message("sample", name, fn, args, kwargs, obs, is_observed, infer)
     apply_stack(msg)
     value = msg["value"]
-    if not is_observed and isinstance(value, torch.Tensor):
-        # latents travel on as a transparent tensor subclass that lets unmodified GLM model text
-        # (w @ X.t()) reach the fused kernel (ops/lazy.py); the trace keeps the plain tensor
+    if not is_observed and isinstance(value, torch.Tensor) and \
+            (msg.get("_replayed") or msg["is_observed"]):
+        # a latent whose value was fixed from outside (replayed from a guide trace, or conditioned
+        # as the HMC/NUTS potential does) reaches MODEL code as a transparent tensor subclass that
+        # lets unmodified GLM model text (w @ X.t()) reach the fused kernel (ops/lazy.py); the
+        # trace keeps the plain tensor, and guide code keeps getting plain tensors (an alias there
+        # would split the latent's gradient over two autograd edges)
         value = _lazy.as_latent(value)
     return value
 
