@@ -277,6 +277,161 @@ class TraceEnum_ELBO(ELBO):
         total = _signed_sum(plain, signs)
         return total + const if const != 0.0 else total
 
+    # ---- posterior of the enumerated model sites (reference: traceenum_elbo.py:224-313, 473-520;
+    #      MarginalRing / SampleRing of pyro/ops/rings.py:274-329 through the adjoint of the
+    #      sum-product).  Here the adjoint IS autograd: the marginal of an enumerated site is the
+    #      gradient of the log-partition function with respect to a probe added to that site's
+    #      log-factor (for a chain written with pyro.markov the fused kernel pa_logchain_fwd_bwd
+    #      returns exactly these posteriors as its gradient), and sampling conditions on the sites
+    #      already drawn by adding their indicator as evidence. -----------------------------------
+    def _enum_sites(self, model_trace, guide_trace):
+        names = [n for n, s in model_trace.nodes.items()
+                 if s["type"] == "sample" and s["infer"].get("_enumerate_dim") is not None
+                 and n not in guide_trace.nodes]
+        ids = {model_trace.nodes[n]["infer"]["_dim_to_id"][
+            model_trace.nodes[n]["infer"]["_enumerate_dim"]] for n in names}
+        return names, ids
+
+    def _log_partition(self, model_trace, enum_names, enum_ids, extra):
+        """log Z of the enumerated part of the model: every factor that carries an enumerated name,
+        summed out over names and plates.  ``extra[name]`` is added to site ``name``'s factor."""
+        first_enum_dim = model_trace._first_enum_dim
+        factors = OrderedDict()
+        for name, site in model_trace.nodes.items():
+            if site["type"] != "sample":
+                continue
+            if name in enum_names:
+                lp = site["fn"].log_prob(site["value"])
+                if name in extra:
+                    lp = lp + extra[name]
+                term = _packed(site, lp, first_enum_dim)
+                factors.setdefault(term.ordinal, []).append(term)
+                continue
+            if not self._depends_on_enum(site, first_enum_dim):
+                continue
+            lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
+            term = _packed(site, scale_and_mask(lp, mask=site["mask"]), first_enum_dim)
+            if term.dims & enum_ids:
+                factors.setdefault(term.ordinal, []).append(term)
+        total = 0.0
+        for ordinal, terms in contract_tensor_tree(factors, enum_ids, reduce_all=True).items():
+            for term in terms:
+                total = total + term.tensor.sum()
+        return total
+
+    def _posterior_of(self, model_trace, enum_names, enum_ids, name, evidence):
+        """Normalised posterior of enumerated site ``name`` given the evidence tensors of the
+        sites already fixed: [.., K] with the plate dims of the site in front."""
+        site = model_trace.nodes[name]
+        with torch.enable_grad():
+            lp0 = site["fn"].log_prob(site["value"])
+            edim0 = site["infer"]["_enumerate_dim"]
+            fed = model_trace._first_enum_dim
+            # the probe lives on the site's own enumeration dim and its plate dims only: other
+            # variables' enumeration dims in the factor (a Markov parent) broadcast
+            shape = [s_ if (i - lp0.dim() > fed or i - lp0.dim() == edim0) else 1
+                     for i, s_ in enumerate(lp0.shape)]
+            probe = torch.zeros(shape, dtype=lp0.dtype, device=lp0.device, requires_grad=True)
+            extra = dict(evidence)
+            extra[name] = probe if name not in evidence else evidence[name] + probe
+            log_z = self._log_partition(model_trace, enum_names, enum_ids, extra)
+            (g,) = torch.autograd.grad(log_z, [probe])
+        edim = site["infer"]["_enumerate_dim"]
+        g = g.clamp(min=0.0)
+        p = g / g.sum(edim, keepdim=True)
+        p = p.unsqueeze(-1).transpose(-1, edim - 1)
+        while p.dim() > 1 and p.shape[0] == 1:
+            p = p.squeeze(0)
+        return p
+
+    @staticmethod
+    def _make_dist(fn, probs):
+        """The site's distribution family with the given probabilities over its support."""
+        from .. import distributions as dist
+        import torch.distributions as td
+        base = fn
+        while hasattr(base, "base_dist"):
+            base = base.base_dist
+        if isinstance(base, td.Bernoulli):
+            return dist.Bernoulli(probs=probs[..., 1])
+        if isinstance(base, td.OneHotCategorical):
+            return dist.OneHotCategorical(probs=probs)
+        if isinstance(base, td.Categorical):
+            return dist.Categorical(probs=probs)
+        raise NotImplementedError("marginals of an enumerated {} site".format(type(base).__name__))
+
+    def _posterior_traces(self, what, model, guide, args, kwargs):
+        if self.num_particles != 1:
+            raise NotImplementedError("TraceEnum_ELBO.{}() is not compatible with multiple "
+                                      "particles.".format(what))
+        model_trace, guide_trace = next(iter(self._get_traces(model, guide, args, kwargs)))
+        for site in guide_trace.nodes.values():
+            if site["type"] == "sample" and ("_enumerate_dim" in site["infer"]
+                                             or "_enum_total" in site["infer"]):
+                raise NotImplementedError("TraceEnum_ELBO.{}() is not compatible with guide "
+                                          "enumeration.".format(what))
+        return model_trace, guide_trace
+
+    def compute_marginals(self, model, guide, *args, **kwargs):
+        """Marginal distribution of every model-enumerated sample site given all observations:
+        an OrderedDict site name -> distribution of the site's family."""
+        model_trace, guide_trace = self._posterior_traces("compute_marginals", model, guide, args,
+                                                          kwargs)
+        enum_names, enum_ids = self._enum_sites(model_trace, guide_trace)
+        out = OrderedDict()
+        for name in enum_names:
+            probs = self._posterior_of(model_trace, enum_names, enum_ids, name, {})
+            out[name] = self._make_dist(model_trace.nodes[name]["fn"], probs.detach())
+        return out
+
+    def sample_posterior(self, model, guide, *args, **kwargs):
+        """One joint draw of all model-enumerated sites from their posterior given the
+        observations (forward filtering / backward sampling in the order the model visits the
+        sites); returns what the model returns with those sites at their drawn values."""
+        import warnings
+        from ..poutine.runtime import Messenger
+        with poutine.block(), warnings.catch_warnings():
+            warnings.filterwarnings("ignore", "Found vars in model but not guide")
+            model_trace, guide_trace = self._posterior_traces("sample_posterior", model, guide,
+                                                              args, kwargs)
+        enum_names, enum_ids = self._enum_sites(model_trace, guide_trace)
+        elbo = self
+
+        class _BackwardSample(Messenger):
+            def __init__(self):
+                super().__init__()
+                self.evidence = {}
+
+            def _pyro_sample(self, msg):
+                name = msg["name"]
+                if name not in enum_names or msg["is_observed"]:
+                    return
+                probs = elbo._posterior_of(model_trace, enum_names, enum_ids, name, self.evidence)
+                msg["fn"] = elbo._make_dist(msg["fn"], probs.detach())
+                msg["infer"] = dict(msg["infer"])
+                msg["infer"].pop("enumerate", None)        # an ordinary draw from the posterior
+
+            def _pyro_post_sample(self, msg):
+                name = msg["name"]
+                if name not in enum_names or msg["is_observed"]:
+                    return
+                site = model_trace.nodes[name]
+                support, value = site["value"], msg["value"]
+                ev = len(site["fn"].event_shape)
+                # indicator of the drawn value on the site's enumerated support, shaped like the
+                # site's log-factor: 0 where the support equals the draw, -inf elsewhere
+                v = value.to(support.dtype)
+                hit = (support == v)
+                for _ in range(ev):
+                    hit = hit.all(-1)
+                neg = torch.full((), -float("inf"), dtype=torch.get_default_dtype(), device=hit.device)
+                zero = torch.zeros((), dtype=neg.dtype, device=hit.device)
+                lp_dtype = site["fn"].log_prob(support).dtype
+                self.evidence[name] = torch.where(hit, zero, neg).to(lp_dtype)
+
+        with _BackwardSample():
+            return poutine.replay(model, trace=guide_trace)(*args, **kwargs)
+
     @staticmethod
     def _depends_on_enum(site, first_enum_dim):
         """A site whose distribution batch shape or value reaches into the enumerated dims."""

@@ -1123,9 +1123,39 @@ def g_mcmc_potential():
     save("mcmc_potential", **flat)
 
 
+# ---------------------------------------------------------------------------------------------
+# posterior marginals of model-enumerated sites (traceenum_elbo.py:224-251, 473-493): a global
+# Bernoulli and a plated Categorical sharing a Normal likelihood
+# ---------------------------------------------------------------------------------------------
+def g_marginals():
+    from pyro.infer import TraceEnum_ELBO, config_enumerate
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(21)
+    data = rng.standard_normal(7) * 1.5
+    pi = rng.dirichlet(np.ones(3))
+    locs = np.array([-1.0, 0.5, 2.0])
+    shift = 0.8
+    td, tpi, tl = torch.tensor(data), torch.tensor(pi), torch.tensor(locs)
+
+    @config_enumerate
+    def model():
+        s = pyro.sample("s", dist.Bernoulli(torch.tensor(0.3)))
+        with pyro.plate("data", len(td)):
+            z = pyro.sample("z", dist.Categorical(tpi))
+            pyro.sample("obs", dist.Normal(tl[z] + shift * s, 1.0), obs=td)
+
+    def guide():
+        pass
+
+    pyro.clear_param_store()
+    m = TraceEnum_ELBO(max_plate_nesting=1).compute_marginals(model, guide)
+    save("marginals", data=data, pi=pi, locs=locs, shift=np.array(shift),
+         s_probs=m["s"].probs.detach().numpy(), z_probs=m["z"].probs.detach().numpy())
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals"]
     for w in which:
         globals()["g_" + w]()
 

@@ -163,3 +163,34 @@ def test_hmm_vectorised_over_time_equals_markov_model(gpu):
 
 def test_guide_enumeration_and_dice_match_reference(gpu):
     ec.run_guide_enum_vs_reference(load("guide_enum"), gpu)
+
+
+# ---- posterior of the enumerated sites (compute_marginals / sample_posterior) on the MI355X -------
+from tests import posterior_kat_cases as pkc   # noqa: E402
+
+
+@pytest.mark.parametrize("which,prior", [("bernoulli", 0.2), ("categorical", [0.2, 0.3, 0.5]),
+                                         ("onehot", [0.2, 0.3, 0.3, 0.2])])
+def test_compute_marginals_single(gpu, which, prior):
+    pkc.run_marginals_single(gpu, which, prior)
+
+
+@pytest.mark.parametrize("size", [3, 10, 20])
+def test_compute_marginals_hmm(gpu, size):
+    pkc.run_marginals_hmm(gpu, size)
+
+
+def test_compute_marginals_matches_reference_on_a_plated_mixture(gpu):
+    torch.set_default_dtype(torch.float64)
+    try:
+        pkc.run_marginals_plated_golden(gpu, np.load(os.path.join(os.path.dirname(__file__), "golden",
+                                                                  "marginals.npz")), 1e-9)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_backwardsample_posterior(gpu):
+    pkc.run_backwardsample_smoke(gpu, [0.0, None])
+    pkc.run_backwardsample_2(gpu)
+    pkc.run_backwardsample_3(gpu)
+    pkc.run_backwardsample_hmm_joint(gpu)

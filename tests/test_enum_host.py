@@ -171,3 +171,52 @@ def test_monte_carlo_enumeration_is_refused(_cpu_backend):
 
     with pytest.raises(NotImplementedError):
         TraceEnum_ELBO(max_plate_nesting=0).loss(model, lambda: None)
+
+
+# ---- posterior of the enumerated sites: the reference's compute_marginals / sample_posterior tests
+#      (tests/infer/test_enum.py:3725-4010) on the host logic -----------------------------------
+from tests import posterior_kat_cases as pkc   # noqa: E402
+
+_PRIORS = [("bernoulli", 0.2), ("categorical", [0.2, 0.8]), ("categorical", [0.2, 0.3, 0.5]),
+           ("categorical", [0.2, 0.3, 0.3, 0.2]), ("onehot", [0.2, 0.8]), ("onehot", [0.2, 0.3, 0.5]),
+           ("onehot", [0.2, 0.3, 0.3, 0.2])]
+_RESTRICT = [(True, None, 1, False), (False, "sequential", 1, False), (False, "parallel", 1, False),
+             (False, None, 2, False), (False, None, 2, True)]
+
+
+@pytest.mark.parametrize("which,prior", _PRIORS)
+def test_compute_marginals_single(_cpu_backend, which, prior):
+    pkc.run_marginals_single(CPU, which, prior)
+
+
+@pytest.mark.parametrize("ok,enumerate_guide,num_particles,vectorize_particles", _RESTRICT)
+@pytest.mark.parametrize("what", ["marginals", "posterior"])
+def test_posterior_restrictions(_cpu_backend, ok, enumerate_guide, num_particles, vectorize_particles,
+                                what):
+    pkc.run_marginals_restrictions(CPU, ok, enumerate_guide, num_particles, vectorize_particles, what)
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 4, 10, 20])
+def test_compute_marginals_hmm(_cpu_backend, size):
+    pkc.run_marginals_hmm(CPU, size)
+
+
+@pytest.mark.parametrize("observed", ["", "a", "b", "ab"])
+def test_marginals_2678(_cpu_backend, observed):
+    pkc.run_marginals_2678(CPU, observed)
+
+
+def test_compute_marginals_matches_reference_on_a_plated_mixture(_cpu_backend):
+    pkc.run_marginals_plated_golden(CPU, np.load(os.path.join(os.path.dirname(__file__), "golden",
+                                                              "marginals.npz")), 1e-9)
+
+
+@pytest.mark.parametrize("data", [[None, None], [0.0, None], [None, 0], [0.0, 0]])
+def test_backwardsample_posterior_smoke(_cpu_backend, data):
+    pkc.run_backwardsample_smoke(CPU, data)
+
+
+def test_backwardsample_posterior_statistics(_cpu_backend):
+    pkc.run_backwardsample_2(CPU, 4000)
+    pkc.run_backwardsample_3(CPU, 4000)
+    pkc.run_backwardsample_hmm_joint(CPU, 4, 3000)
