@@ -170,11 +170,21 @@ class SVI:
         graph2 = between = None
         split = hasattr(self.optim, "reduce_gradients") and \
             (getattr(self.optim, "world_size", 1) > 1 or getattr(self, "_force_split", False))
+        # Opt-in (PYRO_AMD_GRAPH_COLLECTIVE=1): capture the RCCL all-reduce of the flat gradient
+        # INSIDE the step's graph -- one replay per step at any world size, no eager collective and
+        # no stream hand-over between two graphs.  RCCL collectives are capturable like NCCL's; the
+        # default stays the split form below because a failed capture with a live process group
+        # cannot be tested in a single-GPU container.
+        import os as _os
+        if split and _os.environ.get("PYRO_AMD_GRAPH_COLLECTIVE") == "1" and \
+                not getattr(self, "_force_split", False):
+            split = False
         try:
             with validation_enabled(False):   # validation ran in the eager warm-up steps
                 # with a process group alive its watchdog thread polls events while we capture:
                 # only THIS thread's calls may invalidate the capture
-                mode = {"capture_error_mode": "thread_local"} if split else {}
+                multi = getattr(self.optim, "world_size", 1) > 1
+                mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
                 with torch.cuda.graph(graph, **mode):
                     with cap:
                         with poutine.trace(param_only=True) as param_capture:
