@@ -48,7 +48,11 @@ enum {
   PA_DIST_LOG_NORMAL = 3,
   PA_DIST_EXPONENTIAL = 4,
   PA_DIST_HALF_NORMAL = 5,
-  PA_DIST_COUNT = 6
+  PA_DIST_GAMMA = 6,           /* p0 = concentration, p1 = rate          (torch gamma.py log_prob) */
+  PA_DIST_BETA = 7,            /* p0 = concentration1, p1 = concentration0 (torch beta.py/dirichlet.py) */
+  PA_DIST_POISSON = 8,         /* p0 = rate                               (torch poisson.py) */
+  PA_DIST_BINOMIAL_LOGITS = 9, /* p0 = logits, p1 = total_count (pyro/distributions/torch.py:83-101) */
+  PA_DIST_COUNT = 10
 };
 
 typedef void* pa_stream_t; /* hipStream_t; NULL = the null stream */

@@ -57,6 +57,41 @@ def half_normal_log_prob(v, scale):
     return np.where(v >= 0, lp, -np.inf)
 
 
+def _xlogy(x, y):
+    """torch.xlogy: 0 where x == 0 whatever y is."""
+    x, y = np.broadcast_arrays(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(x == 0, 0.0, x * np.log(y))
+
+
+def gamma_log_prob(v, concentration, rate):
+    """torch: torch/distributions/gamma.py log_prob
+    (xlogy(concentration, rate) + xlogy(concentration - 1, value) - rate * value - lgamma)."""
+    from scipy.special import gammaln
+    return _xlogy(concentration, rate) + _xlogy(concentration - 1, v) - rate * v - gammaln(concentration)
+
+
+def beta_log_prob(v, c1, c0):
+    """torch: torch/distributions/beta.py log_prob = Dirichlet([c1, c0]).log_prob([v, 1 - v])
+    (torch/distributions/dirichlet.py log_prob: sum xlogy(c - 1, x) + lgamma(sum c) - sum lgamma(c))."""
+    from scipy.special import gammaln
+    return _xlogy(c1 - 1, v) + _xlogy(c0 - 1, 1 - v) + gammaln(c1 + c0) - gammaln(c1) - gammaln(c0)
+
+
+def poisson_log_prob(v, rate):
+    """torch: torch/distributions/poisson.py log_prob (value.xlogy(rate) - rate - lgamma(value + 1))."""
+    from scipy.special import gammaln
+    return _xlogy(v, rate) - rate - gammaln(v + 1)
+
+
+def binomial_logits_log_prob(v, logits, total_count):
+    """pyro/distributions/torch.py:83-101 with approx_log_prob_tol = 0:
+    k * logits - n * softplus(logits) + log C(n, k)   (pyro/ops/special.py log_binomial)."""
+    from scipy.special import gammaln
+    n = total_count
+    return v * logits - n * _softplus(logits) + gammaln(n + 1) - gammaln(v + 1) - gammaln(n - v + 1)
+
+
 LOG_PROB = {
     0: lambda v, a, b: normal_log_prob(v, a, b),
     1: lambda v, a, b: bernoulli_logits_log_prob(v, a),
@@ -64,6 +99,10 @@ LOG_PROB = {
     3: lambda v, a, b: log_normal_log_prob(v, a, b),
     4: lambda v, a, b: exponential_log_prob(v, a),
     5: lambda v, a, b: half_normal_log_prob(v, a),
+    6: lambda v, a, b: gamma_log_prob(v, a, b),
+    7: lambda v, a, b: beta_log_prob(v, a, b),
+    8: lambda v, a, b: poisson_log_prob(v, a),
+    9: lambda v, a, b: binomial_logits_log_prob(v, a, b),
 }
 
 
@@ -94,6 +133,19 @@ def log_prob_grad(dist_id, v, a, b):
     if dist_id == 5:
         dv, _, db = normal_grad(v, 0.0, a)
         return dv, db, z
+    if dist_id in (6, 7, 8, 9):
+        from scipy.special import digamma
+        if dist_id == 6:
+            return (a - 1) / v - b, np.log(b) + np.log(v) - digamma(a) + z, a / b - v
+        if dist_id == 7:
+            pab = digamma(a + b)
+            return ((a - 1) / v - (b - 1) / (1 - v), np.log(v) + pab - digamma(a),
+                    np.log(1 - v) + pab - digamma(b))
+        if dist_id == 8:
+            return np.log(a) - digamma(v + 1), v / a - 1, z
+        pnk = digamma(b - v + 1)
+        return (a - digamma(v + 1) + pnk, v - b * _sigmoid(a),
+                digamma(b + 1) - pnk - _softplus(a))
     raise ValueError(dist_id)
 
 

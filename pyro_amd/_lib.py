@@ -21,6 +21,10 @@ DIST_HALF_CAUCHY = 2
 DIST_LOG_NORMAL = 3
 DIST_EXPONENTIAL = 4
 DIST_HALF_NORMAL = 5
+DIST_GAMMA = 6
+DIST_BETA = 7
+DIST_POISSON = 8
+DIST_BINOMIAL_LOGITS = 9
 
 KERNEL_GLM, KERNEL_NUTS, KERNEL_LDA, KERNEL_SITE_SUM = 1, 2, 3, 4
 

@@ -267,9 +267,7 @@ static int log_prob_grad_t(int dist, T* dv, T* da, T* db, pa_view2d g, pa_view2d
   return check_launch("log_prob_grad_kernel");
 }
 
-static int nparams(int dist) {
-  return (dist == PA_DIST_NORMAL || dist == PA_DIST_LOG_NORMAL) ? 2 : 1;
-}
+static int nparams(int dist) { return dist_nparams(dist); }
 
 }  // namespace pa
 

@@ -128,9 +128,100 @@ template <typename T> struct Fam<PA_DIST_HALF_NORMAL, T> {  // a=scale; half_nor
   }
 };
 
+// ---- families with Gamma-function normalisers ---------------------------------------------------
+template <typename T> __device__ __forceinline__ T t_lgamma(T x);
+template <> __device__ __forceinline__ float t_lgamma(float x) { return lgammaf(x); }
+// f64: an out-of-line call -- the library lgamma inlined into the one-workgroup site kernels
+// (1024 threads, 128 VGPRs) spills every family's path, not just the Gamma-function ones
+template <> inline __device__ __noinline__ double t_lgamma(double x) { return lgamma(x); }
+// x * log(y) with the convention 0 * log(0) = 0 (torch.xlogy)
+template <typename T> __device__ __forceinline__ T t_xlogy(T x, T y) {
+  return x == T(0) ? T(0) : x * t_log(y);
+}
+// psi(x), x > 0: upward recurrence psi(x) = psi(x+1) - 1/x into the asymptotic range, then
+//   psi(x) ~ ln x - 1/(2x) - sum_k B_2k / (2k x^2k)
+// (the series is cut where its first dropped term is below the type's rounding: x >= 6 with four
+// terms for f32 (1e-8), x >= 10 with seven terms for f64 (1e-15)).
+template <typename T> __device__ __forceinline__ T t_digamma(T x) {
+  constexpr bool f32 = sizeof(T) == 4;
+  const T lim = f32 ? T(6) : T(10);
+  T r = T(0);
+  while (x < lim) {
+    r -= T(1) / x;
+    x += T(1);
+  }
+  const T ix = T(1) / x, f = ix * ix;
+  T t;
+  if constexpr (f32) {
+    t = f * (T(-1.0 / 12) + f * (T(1.0 / 120) + f * (T(-1.0 / 252) + f * T(1.0 / 240))));
+  } else {
+    t = f * (T(-1.0 / 12) + f * (T(1.0 / 120) + f * (T(-1.0 / 252) + f * (T(1.0 / 240) +
+        f * (T(-1.0 / 132) + f * (T(691.0 / 32760) + f * T(-1.0 / 12)))))));
+  }
+  return r + t_log(x) - T(0.5) * ix + t;
+}
+
+template <typename T> struct Fam<PA_DIST_GAMMA, T> {  // a=concentration b=rate; torch gamma.py
+  static __device__ __forceinline__ T lp(T v, T a, T b) {
+    return t_xlogy(a, b) + t_xlogy(a - T(1), v) - b * v - t_lgamma(a);
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T b, T& dv, T& da, T& db) {
+    dv = (a - T(1)) / v - b;
+    da = t_log(b) + t_log(v) - t_digamma(a);
+    db = a / b - v;
+  }
+};
+template <typename T> struct Fam<PA_DIST_BETA, T> {  // a=concentration1 b=concentration0
+  // torch beta.py scores Dirichlet([a, b]) at [v, 1 - v] (dirichlet.py log_prob)
+  static __device__ __forceinline__ T lp(T v, T a, T b) {
+    return t_xlogy(a - T(1), v) + t_xlogy(b - T(1), T(1) - v) + t_lgamma(a + b) - t_lgamma(a) -
+           t_lgamma(b);
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T b, T& dv, T& da, T& db) {
+    const T u = T(1) - v, pab = t_digamma(a + b);
+    dv = (a - T(1)) / v - (b - T(1)) / u;
+    da = t_log(v) + pab - t_digamma(a);
+    db = t_log(u) + pab - t_digamma(b);
+  }
+};
+template <typename T> struct Fam<PA_DIST_POISSON, T> {  // a=rate; torch poisson.py
+  static __device__ __forceinline__ T lp(T v, T a, T) {
+    return t_xlogy(v, a) - a - t_lgamma(v + T(1));
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T, T& dv, T& da, T& db) {
+    dv = t_log(a) - t_digamma(v + T(1));
+    da = v / a - T(1);
+    db = T(0);
+  }
+};
+template <typename T> struct Fam<PA_DIST_BINOMIAL_LOGITS, T> {  // a=logits b=total_count
+  // k*a - n*softplus(a) + log C(n, k)   (pyro/distributions/torch.py:83-101, tol = 0)
+  static __device__ __forceinline__ T lp(T v, T a, T n) {
+    const T sp = (a > T(0) ? a : T(0)) + t_log1p(t_exp(-t_abs(a)));
+    return v * a - n * sp + t_lgamma(n + T(1)) - t_lgamma(v + T(1)) - t_lgamma(n - v + T(1));
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T n, T& dv, T& da, T& db) {
+    const T e = t_exp(-t_abs(a));
+    const T sig = a >= T(0) ? T(1) / (T(1) + e) : e / (T(1) + e);
+    const T sp = (a > T(0) ? a : T(0)) + t_log1p(e);
+    const T pnk = t_digamma(n - v + T(1));
+    da = v - n * sig;
+    dv = a - t_digamma(v + T(1)) + pnk;
+    db = t_digamma(n + T(1)) - pnk - sp;
+  }
+};
+
 template <int DIST> struct NParams { static constexpr int n = 1; };
 template <> struct NParams<PA_DIST_NORMAL> { static constexpr int n = 2; };
 template <> struct NParams<PA_DIST_LOG_NORMAL> { static constexpr int n = 2; };
+template <> struct NParams<PA_DIST_GAMMA> { static constexpr int n = 2; };
+template <> struct NParams<PA_DIST_BETA> { static constexpr int n = 2; };
+template <> struct NParams<PA_DIST_BINOMIAL_LOGITS> { static constexpr int n = 2; };
+// host-side twin of NParams<>
+__host__ __device__ static inline int dist_nparams(int dist) {
+  return (dist == PA_DIST_NORMAL || dist == PA_DIST_LOG_NORMAL || dist == PA_DIST_GAMMA ||
+          dist == PA_DIST_BETA || dist == PA_DIST_BINOMIAL_LOGITS) ? 2 : 1;
+}
 
 
 #define PA_DISPATCH_DIST(DIST_ID, T, CALL)                                              \
@@ -141,6 +232,10 @@ template <> struct NParams<PA_DIST_LOG_NORMAL> { static constexpr int n = 2; };
     case PA_DIST_LOG_NORMAL: { constexpr int D_ = PA_DIST_LOG_NORMAL; CALL; } break;      \
     case PA_DIST_EXPONENTIAL: { constexpr int D_ = PA_DIST_EXPONENTIAL; CALL; } break;    \
     case PA_DIST_HALF_NORMAL: { constexpr int D_ = PA_DIST_HALF_NORMAL; CALL; } break;    \
+    case PA_DIST_GAMMA: { constexpr int D_ = PA_DIST_GAMMA; CALL; } break;                \
+    case PA_DIST_BETA: { constexpr int D_ = PA_DIST_BETA; CALL; } break;                  \
+    case PA_DIST_POISSON: { constexpr int D_ = PA_DIST_POISSON; CALL; } break;            \
+    case PA_DIST_BINOMIAL_LOGITS: { constexpr int D_ = PA_DIST_BINOMIAL_LOGITS; CALL; } break; \
     default: return fail(PA_ERR_UNSUPPORTED, "distribution id %d not implemented", DIST_ID); \
   }
 

@@ -228,7 +228,7 @@ int pa_dist_log_prob_sum_nd(int dist, int dtype, void* out_total, int ndim, cons
       return pa::fail(PA_ERR_LAUNCH, "log_prob_sum_nd: memset failed");
     return PA_OK;
   }
-  const int np = (dist == PA_DIST_NORMAL || dist == PA_DIST_LOG_NORMAL) ? 2 : 1;
+  const int np = pa::dist_nparams(dist);
   PA_REQUIRE(value && p0 && (np < 2 || p1), "log_prob_sum_nd: NULL operand");
   PA_REQUIRE(workspace && workspace_bytes >= pa_dist_log_prob_sum_nd_workspace(),
              "log_prob_sum_nd: workspace too small");
@@ -273,7 +273,7 @@ int pa_dist_log_prob_grad_nd(int dist, int dtype, void* d_value, void* d_p0, voi
   int rc = pa::nd_setup("log_prob_grad_nd", ndim, sizes, &f);
   if (rc != PA_OK) return rc;
   if (f.total == 0 || (!d_value && !d_p0 && !d_p1)) return PA_OK;
-  const int np = (dist == PA_DIST_NORMAL || dist == PA_DIST_LOG_NORMAL) ? 2 : 1;
+  const int np = pa::dist_nparams(dist);
   PA_REQUIRE(value && p0 && (np < 2 || p1), "log_prob_grad_nd: NULL operand");
   pa::NdStrides sv, sa, sb, sm;
   if ((rc = pa::nd_strides("log_prob_grad_nd", ndim, sizes, value_strides, &sv)) != PA_OK) return rc;

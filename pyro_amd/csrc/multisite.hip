@@ -102,6 +102,10 @@ __device__ __forceinline__ void elem_grad(const Elem<T>& x, T& gv, T& ga, T& gb)
     case PA_DIST_LOG_NORMAL: { constexpr int D_ = PA_DIST_LOG_NORMAL; CALL; } break;             \
     case PA_DIST_EXPONENTIAL: { constexpr int D_ = PA_DIST_EXPONENTIAL; CALL; } break;           \
     case PA_DIST_HALF_NORMAL: { constexpr int D_ = PA_DIST_HALF_NORMAL; CALL; } break;           \
+    case PA_DIST_GAMMA: { constexpr int D_ = PA_DIST_GAMMA; CALL; } break;                       \
+    case PA_DIST_BETA: { constexpr int D_ = PA_DIST_BETA; CALL; } break;                         \
+    case PA_DIST_POISSON: { constexpr int D_ = PA_DIST_POISSON; CALL; } break;                   \
+    case PA_DIST_BINOMIAL_LOGITS: { constexpr int D_ = PA_DIST_BINOMIAL_LOGITS; CALL; } break;   \
     case PA_SITE_IDENTITY: { constexpr int D_ = PA_SITE_IDENTITY; CALL; } break;                 \
     default: { constexpr int D_ = PA_SITE_NONE; CALL; } break;                                   \
   }
@@ -331,7 +335,7 @@ __device__ __forceinline__ void multi_grad_body(int entry, const T* __restrict__
   int pv = pattern_of(own_value, e.vsr, e.vsc, e.rows, e.cols);
   int pa_ = pattern_of(param_family && (e.need & PA_NEED_P0) && e.da, e.asr, e.asc, e.rows, e.cols);
   int pb_ = pattern_of(param_family && (e.need & PA_NEED_P1) && e.db &&
-                           (e.dist == PA_DIST_NORMAL || e.dist == PA_DIST_LOG_NORMAL),
+                           dist_nparams(e.dist) > 1,
                        e.bsr, e.bsc, e.rows, e.cols);
   // what the combined pass cannot do goes through the generic per-operand passes first
   const int pv_c = pv == PAT_FULL ? pv : PAT_SKIP;
@@ -402,7 +406,7 @@ static int to_dev(const pa_site_entry* in, int n, MultiArgs* out, const char* wh
     if (s.dist < PA_DIST_COUNT) {
       PA_REQUIRE(s.rows * s.cols == 0 || s.p0.ptr, "%s: entry %d: NULL p0", who, k);
       PA_REQUIRE(s.rows * s.cols == 0 ||
-                     !(s.dist == PA_DIST_NORMAL || s.dist == PA_DIST_LOG_NORMAL) || s.p1.ptr,
+                     dist_nparams(s.dist) < 2 || s.p1.ptr,
                  "%s: entry %d: family needs p1", who, k);
     }
     EntryDev& d = out->e[k];

@@ -217,6 +217,92 @@ class Exponential(_FusedElementwise, torch.distributions.Exponential, TorchDistr
         return self.rate, None
 
 
+class _GammaFunctionFamily(_FusedElementwise):
+    """Families whose normaliser needs lgamma / digamma (dist_fam.h t_lgamma, t_digamma): same
+    fused log_prob / log_prob_sum / site-entry routes as the others; ``rsample`` stays torch's
+    (``_standard_gamma`` rejection sampler with its implicit reparameterisation gradient)."""
+
+    def _value(self, value):
+        return value
+
+    def log_prob(self, value):
+        if self._validate_args:
+            self._validate_sample(value)
+        p0, p1 = self._params()
+        return fused.log_prob(self._dist_id, self._value(value), p0, p1)
+
+    def fused_log_prob_sum(self, value, scale=1.0, mask=None):
+        return super().fused_log_prob_sum(self._value(value), scale, mask)
+
+    def fused_site_entry(self, value, scale=1.0, mask=None):
+        return super().fused_site_entry(self._value(value), scale, mask)
+
+
+class Gamma(_GammaFunctionFamily, torch.distributions.Gamma, TorchDistributionMixin):
+    _dist_id = _lib.DIST_GAMMA
+
+    def __init__(self, concentration, rate, validate_args=None):
+        concentration, rate = _on_device(concentration, rate)
+        super().__init__(concentration, rate, validate_args=validate_args)
+
+    def expand(self, batch_shape, _instance=None):
+        batch_shape = torch.Size(batch_shape)
+        new = type(self)(self.concentration.expand(batch_shape), self.rate.expand(batch_shape),
+                         validate_args=False)
+        new._validate_args = self._validate_args
+        new._base_params = getattr(self, "_base_params", None) or self._params()
+        return new
+
+    def _params(self):
+        return self.concentration, self.rate
+
+
+class Beta(_GammaFunctionFamily, torch.distributions.Beta, TorchDistributionMixin):
+    _dist_id = _lib.DIST_BETA
+
+    def __init__(self, concentration1, concentration0, validate_args=None):
+        concentration1, concentration0 = _on_device(concentration1, concentration0)
+        super().__init__(concentration1, concentration0, validate_args=validate_args)
+        # the operands as given: torch keeps only their stack (the Dirichlet it samples from), and
+        # reading them back out of it would put a select + stack-backward pair on every gradient
+        self._given = (concentration1, concentration0)
+
+    def expand(self, batch_shape, _instance=None):
+        batch_shape = torch.Size(batch_shape)
+        new = type(self)(self._given[0].expand(batch_shape), self._given[1].expand(batch_shape),
+                         validate_args=False)
+        new._validate_args = self._validate_args
+        new._base_params = getattr(self, "_base_params", None) or self._given
+        return new
+
+    def _params(self):
+        # stride-0 views of the given operands on the batch shape (log_prob has the batch shape)
+        return tuple(p.expand(self.batch_shape) for p in self._given)
+
+
+class _CountFamily(_GammaFunctionFamily):
+    def _value(self, value):
+        p0 = self._params()[0]
+        return value if value.dtype == p0.dtype else value.to(p0.dtype)
+
+
+class Poisson(_CountFamily, torch.distributions.Poisson, TorchDistributionMixin):
+    _dist_id = _lib.DIST_POISSON
+
+    def _params(self):
+        return self.rate, None
+
+
+class Binomial(_CountFamily, torch.distributions.Binomial, TorchDistributionMixin):
+    """log_prob restates the reference's override (pyro/distributions/torch.py:83-101) with
+    ``approx_log_prob_tol = 0``, its default."""
+    _dist_id = _lib.DIST_BINOMIAL_LOGITS
+
+    def _params(self):
+        logits, n = self.logits, self.total_count
+        return logits, (n if n.dtype == logits.dtype else n.to(logits.dtype))
+
+
 class LinearLogits:
     """Lazy ``logits = (w @ X^T).squeeze(-2) + b`` of a plated GLM (never materialised).
 

@@ -112,7 +112,79 @@ def g_dists():
     flat["scale_and_mask/x"] = x
     flat["scale_and_mask/mask"] = m
     flat["scale_and_mask/out"] = scale_and_mask(torch.tensor(x), 2.5, torch.tensor(m)).numpy()
+    # Gamma-function families (drawn AFTER everything above so the older arrays keep their values);
+    # autograd gradients of the reference's log_prob are stored with them
+    def with_grads(fam, make, v, a, b=None, value_grad=True):
+        tv = torch.tensor(v, requires_grad=value_grad)
+        ta = torch.tensor(a, requires_grad=True)
+        tb = torch.tensor(b, requires_grad=True) if b is not None else None
+        lp = make(ta, tb).log_prob(tv)
+        ins = [t for t in (tv if value_grad else None, ta, tb) if t is not None]
+        gs = list(torch.autograd.grad(lp.sum(), ins))
+        flat[fam + "/v"], flat[fam + "/a"], flat[fam + "/lp"] = v, a, lp.detach().numpy()
+        if b is not None:
+            flat[fam + "/b"] = b
+        if value_grad:
+            flat[fam + "/dv"] = gs.pop(0).numpy()
+        flat[fam + "/da"] = gs.pop(0).numpy()
+        if b is not None:
+            flat[fam + "/db"] = gs.pop(0).numpy()
+
+    c = rng.uniform(0.2, 12, (1, 7)); r = rng.uniform(0.3, 4, (4, 1))
+    with_grads("gamma", lambda a, b: dist.Gamma(a, b), rng.gamma(np.broadcast_to(c, (4, 7))) / r, c, r)
+    c1 = rng.uniform(0.3, 9, (4, 7)); c0 = rng.uniform(0.3, 9, (1, 7))
+    with_grads("beta", lambda a, b: dist.Beta(a, b), rng.beta(c1, np.broadcast_to(c0, (4, 7))), c1, c0)
+    lam = rng.uniform(0.2, 40, (4, 1))
+    with_grads("poisson", lambda a, b: dist.Poisson(a), rng.poisson(np.broadcast_to(lam, (4, 7))).astype(float),
+               lam, value_grad=False)
+    n = rng.integers(1, 60, (1, 7)).astype(float); lg = 3 * rng.standard_normal((4, 7))
+    k = rng.binomial(np.broadcast_to(n, (4, 7)).astype(int), 1 / (1 + np.exp(-lg))).astype(float)
+    tk, tl = torch.tensor(k), torch.tensor(lg, requires_grad=True)
+    lp = dist.Binomial(torch.tensor(n), logits=tl).log_prob(tk)
+    flat["binomial_logits/v"], flat["binomial_logits/a"], flat["binomial_logits/b"] = k, lg, n
+    flat["binomial_logits/lp"] = lp.detach().numpy()
+    flat["binomial_logits/da"] = torch.autograd.grad(lp.sum(), tl)[0].numpy()
     save("dists", **flat)
+
+
+# ---------------------------------------------------------------------------------------------
+# Gamma-function families inside an ELBO: Gamma / Beta latents (model AND guide sites), Poisson /
+# Binomial likelihoods under a plate; the guide is replayed at fixed values so the estimate is a
+# deterministic function of the parameters
+# ---------------------------------------------------------------------------------------------
+def g_expfam():
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(23)
+    N = 37
+    counts = torch.tensor(rng.poisson(3.0, N).astype(float))
+    trials = torch.tensor(rng.integers(1, 30, N).astype(float))
+    succ = torch.tensor(rng.binomial(trials.numpy().astype(int), 0.3).astype(float))
+    expo = torch.tensor(rng.uniform(0.5, 2.0, N))
+
+    def model(counts, trials, succ, expo):
+        rate = pyro.sample("rate", dist.Gamma(2.0, 0.5))
+        p = pyro.sample("p", dist.Beta(1.5, 2.5))
+        with pyro.plate("data", N):
+            pyro.sample("c", dist.Poisson(rate * expo), obs=counts)
+            pyro.sample("k", dist.Binomial(trials, probs=p), obs=succ)
+
+    def guide(counts, trials, succ, expo):
+        qc = pyro.param("qc", torch.tensor(4.0), constraint=constraints.positive)
+        qr = pyro.param("qr", torch.tensor(1.3), constraint=constraints.positive)
+        qa = pyro.param("qa", torch.tensor(2.2), constraint=constraints.positive)
+        qb = pyro.param("qb", torch.tensor(5.1), constraint=constraints.positive)
+        pyro.sample("rate", dist.Gamma(qc, qr))
+        pyro.sample("p", dist.Beta(qa, qb))
+
+    pyro.clear_param_store()
+    z = {"rate": torch.tensor(2.7), "p": torch.tensor(0.31)}
+    args = (counts, trials, succ, expo)
+    fixed = poutine.trace(poutine.condition(guide, data=z)).get_trace(*args)
+    for name in z:
+        fixed.nodes[name]["is_observed"] = False
+    loss = Trace_ELBO().loss_and_grads(model, poutine.replay(guide, trace=fixed), *args)
+    save("expfam", counts=counts.numpy(), trials=trials.numpy(), succ=succ.numpy(), expo=expo.numpy(),
+         rate=2.7, p=0.31, loss=loss, grads=grads_of_store())
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1155,7 +1227,7 @@ def g_marginals():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam"]
     for w in which:
         globals()["g_" + w]()
 

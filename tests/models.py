@@ -196,6 +196,40 @@ def run_scale_mask(g, device, monkeypatch, rtol):
     assert_grads(store_grads(), g, "grads", rtol * 10)
 
 
+# ---- Gamma-function families (Gamma / Beta latents, Poisson / Binomial likelihoods) ---------------
+def run_expfam(g, device, rtol, dtype=None):
+    dtype = dtype or torch.get_default_dtype()
+    t = lambda k: torch.as_tensor(g[k], dtype=dtype, device=device)   # noqa: E731
+    c = lambda x: torch.tensor(float(x), dtype=dtype, device=device)  # noqa: E731
+    counts, trials, succ, expo = t("counts"), t("trials"), t("succ"), t("expo")
+    N = counts.shape[0]
+
+    def model(counts, trials, succ, expo):
+        rate = pyro.sample("rate", dist.Gamma(c(2.0), 0.5))
+        p = pyro.sample("p", dist.Beta(c(1.5), 2.5))
+        with pyro.plate("data", N):
+            pyro.sample("c", dist.Poisson(rate * expo), obs=counts)
+            pyro.sample("k", dist.Binomial(trials, probs=p), obs=succ)
+
+    def guide(counts, trials, succ, expo):
+        qc = pyro.param("qc", c(4.0), constraint=constraints.positive)
+        qr = pyro.param("qr", c(1.3), constraint=constraints.positive)
+        qa = pyro.param("qa", c(2.2), constraint=constraints.positive)
+        qb = pyro.param("qb", c(5.1), constraint=constraints.positive)
+        pyro.sample("rate", dist.Gamma(qc, qr))
+        pyro.sample("p", dist.Beta(qa, qb))
+
+    pyro.clear_param_store()
+    z = {"rate": c(g["rate"]), "p": c(g["p"])}
+    args = (counts, trials, succ, expo)
+    fixed = poutine.trace(poutine.condition(guide, data=z)).get_trace(*args)
+    for name in z:
+        fixed.nodes[name]["is_observed"] = False
+    loss = Trace_ELBO().loss_and_grads(model, poutine.replay(guide, trace=fixed), *args)
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads", rtol * 10)
+
+
 # ---- score-function guide site (non-reparameterised) ----------------------------------------------
 class NonreparameterizedNormal(dist.Normal):
     has_rsample = False

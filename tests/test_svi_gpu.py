@@ -61,6 +61,14 @@ def test_scale_mask_subsample(gpu, monkeypatch):
     models.run_scale_mask(load("scale_mask"), gpu, monkeypatch, rtol=1e-9)
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 3e-5)])
+def test_gamma_function_families_in_an_elbo(gpu, dtype, rtol):
+    """Gamma / Beta model and guide sites, Poisson / Binomial likelihoods: estimate and gradients
+    of the reference (fixture expfam) through the fused site kernels."""
+    torch.set_default_dtype(dtype)
+    models.run_expfam(load("expfam"), gpu, rtol, dtype=dtype)
+
+
 def test_score_function_guide(gpu):
     torch.set_default_dtype(torch.float64)
     models.run_score_function(load("score_function"), gpu, rtol=1e-9)
