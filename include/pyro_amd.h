@@ -52,7 +52,14 @@ enum {
   PA_DIST_BETA = 7,            /* p0 = concentration1, p1 = concentration0 (torch beta.py/dirichlet.py) */
   PA_DIST_POISSON = 8,         /* p0 = rate                               (torch poisson.py) */
   PA_DIST_BINOMIAL_LOGITS = 9, /* p0 = logits, p1 = total_count (pyro/distributions/torch.py:83-101) */
-  PA_DIST_COUNT = 10
+  /* the two halves of -KL(Normal(lq, sq) || Normal(lp, sp)) (torch/distributions/kl.py
+   * _kl_normal_normal; pyro/infer/trace_mean_field_elbo.py:121-137 replaces log p - log q by it):
+   *   KL_NORMAL_LOC  (value = lq, p0 = lp, p1 = sp):  -(lq - lp)^2 / (2 sp^2) - log sp
+   *   KL_NORMAL_SCALE(value = sq, p0 = sp):            log sq + 1/2 - sq^2 / (2 sp^2)
+   * so that an analytic-KL site is two ordinary entries of the multi-site launch. */
+  PA_DIST_KL_NORMAL_LOC = 10,
+  PA_DIST_KL_NORMAL_SCALE = 11,
+  PA_DIST_COUNT = 12
 };
 
 typedef void* pa_stream_t; /* hipStream_t; NULL = the null stream */

@@ -92,6 +92,22 @@ def binomial_logits_log_prob(v, logits, total_count):
     return v * logits - n * _softplus(logits) + gammaln(n + 1) - gammaln(v + 1) - gammaln(n - v + 1)
 
 
+def kl_normal_normal(lq, sq, lp, sp):
+    """torch: torch/distributions/kl.py _kl_normal_normal."""
+    var_ratio = (sq / sp) ** 2
+    t1 = ((lq - lp) / sp) ** 2
+    return 0.5 * (var_ratio + t1 - 1 - np.log(var_ratio))
+
+
+def kl_normal_loc_half(lq, lp, sp):
+    """-KL(N(lq,sq) || N(lp,sp)) = this + kl_normal_scale_half(sq, sp)   (include/pyro_amd.h)."""
+    return -((lq - lp) ** 2) / (2 * sp ** 2) - np.log(sp)
+
+
+def kl_normal_scale_half(sq, sp):
+    return np.log(sq) + 0.5 - sq ** 2 / (2 * sp ** 2)
+
+
 LOG_PROB = {
     0: lambda v, a, b: normal_log_prob(v, a, b),
     1: lambda v, a, b: bernoulli_logits_log_prob(v, a),
@@ -103,6 +119,8 @@ LOG_PROB = {
     7: lambda v, a, b: beta_log_prob(v, a, b),
     8: lambda v, a, b: poisson_log_prob(v, a),
     9: lambda v, a, b: binomial_logits_log_prob(v, a, b),
+    10: lambda v, a, b: kl_normal_loc_half(v, a, b),
+    11: lambda v, a, b: kl_normal_scale_half(v, a),
 }
 
 
@@ -133,6 +151,10 @@ def log_prob_grad(dist_id, v, a, b):
     if dist_id == 5:
         dv, _, db = normal_grad(v, 0.0, a)
         return dv, db, z
+    if dist_id == 10:
+        return normal_grad(v, a, b)
+    if dist_id == 11:
+        return 1 / v - v / a ** 2, v ** 2 / a ** 3, z
     if dist_id in (6, 7, 8, 9):
         from scipy.special import digamma
         if dist_id == 6:

@@ -25,6 +25,8 @@ DIST_GAMMA = 6
 DIST_BETA = 7
 DIST_POISSON = 8
 DIST_BINOMIAL_LOGITS = 9
+DIST_KL_NORMAL_LOC = 10
+DIST_KL_NORMAL_SCALE = 11
 
 KERNEL_GLM, KERNEL_NUTS, KERNEL_LDA, KERNEL_SITE_SUM = 1, 2, 3, 4
 

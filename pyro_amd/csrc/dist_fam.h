@@ -211,16 +211,42 @@ template <typename T> struct Fam<PA_DIST_BINOMIAL_LOGITS, T> {  // a=logits b=to
   }
 };
 
+// -KL(Normal(lq, sq) || Normal(lp, sp)) = KL_NORMAL_LOC(lq; lp, sp) + KL_NORMAL_SCALE(sq; sp)
+// (torch kl.py _kl_normal_normal: 0.5 * (sq^2/sp^2 + (lq - lp)^2/sp^2 - 1 - log(sq^2/sp^2)))
+template <typename T> struct Fam<PA_DIST_KL_NORMAL_LOC, T> {   // v=lq a=lp b=sp
+  static __device__ __forceinline__ T lp(T v, T a, T b) {
+    const T d = (v - a) * pos_rcp(b);
+    return T(-0.5) * d * d - pos_log(b);
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T b, T& dv, T& da, T& db) {
+    Fam<PA_DIST_NORMAL, T>::grad(v, a, b, dv, da, db);
+  }
+};
+template <typename T> struct Fam<PA_DIST_KL_NORMAL_SCALE, T> {   // v=sq a=sp
+  static __device__ __forceinline__ T lp(T v, T a, T) {
+    const T q = v * pos_rcp(a);
+    return pos_log(v) + T(0.5) - T(0.5) * q * q;
+  }
+  static __device__ __forceinline__ void grad(T v, T a, T, T& dv, T& da, T& db) {
+    const T ia = pos_rcp(a), q = v * ia;
+    dv = pos_rcp(v) - q * ia;
+    da = q * q * ia;
+    db = T(0);
+  }
+};
+
 template <int DIST> struct NParams { static constexpr int n = 1; };
 template <> struct NParams<PA_DIST_NORMAL> { static constexpr int n = 2; };
 template <> struct NParams<PA_DIST_LOG_NORMAL> { static constexpr int n = 2; };
 template <> struct NParams<PA_DIST_GAMMA> { static constexpr int n = 2; };
 template <> struct NParams<PA_DIST_BETA> { static constexpr int n = 2; };
 template <> struct NParams<PA_DIST_BINOMIAL_LOGITS> { static constexpr int n = 2; };
+template <> struct NParams<PA_DIST_KL_NORMAL_LOC> { static constexpr int n = 2; };
 // host-side twin of NParams<>
 __host__ __device__ static inline int dist_nparams(int dist) {
   return (dist == PA_DIST_NORMAL || dist == PA_DIST_LOG_NORMAL || dist == PA_DIST_GAMMA ||
-          dist == PA_DIST_BETA || dist == PA_DIST_BINOMIAL_LOGITS) ? 2 : 1;
+          dist == PA_DIST_BETA || dist == PA_DIST_BINOMIAL_LOGITS ||
+          dist == PA_DIST_KL_NORMAL_LOC) ? 2 : 1;
 }
 
 
@@ -236,6 +262,8 @@ __host__ __device__ static inline int dist_nparams(int dist) {
     case PA_DIST_BETA: { constexpr int D_ = PA_DIST_BETA; CALL; } break;                  \
     case PA_DIST_POISSON: { constexpr int D_ = PA_DIST_POISSON; CALL; } break;            \
     case PA_DIST_BINOMIAL_LOGITS: { constexpr int D_ = PA_DIST_BINOMIAL_LOGITS; CALL; } break; \
+    case PA_DIST_KL_NORMAL_LOC: { constexpr int D_ = PA_DIST_KL_NORMAL_LOC; CALL; } break; \
+    case PA_DIST_KL_NORMAL_SCALE: { constexpr int D_ = PA_DIST_KL_NORMAL_SCALE; CALL; } break; \
     default: return fail(PA_ERR_UNSUPPORTED, "distribution id %d not implemented", DIST_ID); \
   }
 

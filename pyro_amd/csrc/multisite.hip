@@ -106,6 +106,8 @@ __device__ __forceinline__ void elem_grad(const Elem<T>& x, T& gv, T& ga, T& gb)
     case PA_DIST_BETA: { constexpr int D_ = PA_DIST_BETA; CALL; } break;                         \
     case PA_DIST_POISSON: { constexpr int D_ = PA_DIST_POISSON; CALL; } break;                   \
     case PA_DIST_BINOMIAL_LOGITS: { constexpr int D_ = PA_DIST_BINOMIAL_LOGITS; CALL; } break;   \
+    case PA_DIST_KL_NORMAL_LOC: { constexpr int D_ = PA_DIST_KL_NORMAL_LOC; CALL; } break;       \
+    case PA_DIST_KL_NORMAL_SCALE: { constexpr int D_ = PA_DIST_KL_NORMAL_SCALE; CALL; } break;   \
     case PA_SITE_IDENTITY: { constexpr int D_ = PA_SITE_IDENTITY; CALL; } break;                 \
     default: { constexpr int D_ = PA_SITE_NONE; CALL; } break;                                   \
   }

@@ -624,6 +624,39 @@ class SiteBatch:
         self.tensors.extend(ops)
         return True
 
+    def add_kl_normal(self, q_loc, q_scale, p_loc, p_scale, shape, mask, scale, sign):
+        """sign * scale * sum over ``shape`` of mask ? KL(Normal(q_loc, q_scale) || Normal(p_loc,
+        p_scale)) : 0 as TWO entries of the launch (the KL_NORMAL_LOC / KL_NORMAL_SCALE halves,
+        include/pyro_amd.h).  The operands are the distributions' un-expanded parameters: dims of
+        ``shape`` that no operand (nor the mask) spans contribute a constant factor, folded into
+        the entry's coefficient.  True if taken."""
+        from .. import _lib
+        if isinstance(scale, torch.Tensor):
+            return False
+        total = 1
+        for d in shape:
+            total *= int(d)
+        n_meta, n_tensors = len(self.meta), len(self.tensors)
+        for dist_id, ops in ((_lib.DIST_KL_NORMAL_LOC, (q_loc, p_loc, p_scale)),
+                             (_lib.DIST_KL_NORMAL_SCALE, (q_scale, p_scale, None))):
+            shapes = [t.shape for t in ops if t is not None]
+            if mask is not None and isinstance(mask, torch.Tensor):
+                shapes.append(mask.shape)
+            try:
+                spanned = torch.broadcast_shapes(*shapes)
+                ok = torch.broadcast_shapes(spanned, shape) == torch.Size(shape)
+            except RuntimeError:
+                ok = False
+            n = 1
+            for d in (spanned if ok else ()):
+                n *= int(d)
+            ok = ok and n > 0 and self.add_site(dist_id, ops[0], ops[1], ops[2], mask,
+                                                float(scale) * (total // n), -sign)
+            if not ok:
+                del self.meta[n_meta:], self.tensors[n_tensors:]
+                return False
+        return True
+
     def add_term(self, x, sign):
         """An already computed term (tensor of any small shape, or a Python number): sign * x.sum()."""
         from .. import _lib

@@ -36,6 +36,42 @@ def _check_mean_field_requirement(model_trace, guide_trace):
                       "Guide sites:\n  " + "\n  ".join(guide_sites))
 
 
+def _normal_operands(fn):
+    """(loc, scale, (event dims, family), shape) of a Normal / LogNormal, possibly under ``to_event`` -- the parameters as
+    given before any expand (the site kernels broadcast by stride) -- or None."""
+    from ..distributions import families
+    event = 0
+    while isinstance(fn, torch.distributions.Independent):
+        event += fn.reinterpreted_batch_ndims
+        fn = fn.base_dist
+    if type(fn) not in (families.Normal, families.LogNormal):
+        return None
+    loc, scale = getattr(fn, "_base_params", None) or (fn.loc, fn.scale)
+    # (a LogNormal pair has the KL of its base Normals: torch kl.py _kl_transformed_transformed)
+    return loc, scale, (event, type(fn)), fn.batch_shape
+
+
+def _add_normal_kl(batch, gsite, msite):
+    """KL(q || p) of a Normal / Normal pair (same event dims) as two entries of the batch's launch
+    instead of ~8 element-wise torch kernels and their autograd duals; False = not applicable."""
+    q, p = _normal_operands(gsite["fn"]), _normal_operands(msite["fn"])
+    if q is None or p is None or q[2] != p[2]:
+        return False
+    shape = q[3]
+    try:
+        if torch.broadcast_shapes(shape, p[3]) != shape:
+            return False
+    except RuntimeError:
+        return False
+    mask = gsite["mask"]
+    if mask is not None:
+        if not isinstance(mask, torch.Tensor):
+            return False
+        if q[2][0]:                       # the mask spans batch dims only
+            mask = mask.reshape(mask.shape + (1,) * q[2][0])
+    return batch.add_kl_normal(q[0], q[1], p[0], p[1], shape, mask, gsite["scale"], -1.0)
+
+
 class TraceMeanField_ELBO(Trace_ELBO):
     def _get_trace(self, model, guide, args, kwargs):
         model_trace, guide_trace = super()._get_trace(model, guide, args, kwargs)
@@ -57,6 +93,9 @@ class TraceMeanField_ELBO(Trace_ELBO):
             if msite["type"] != "sample" or msite["is_observed"] or name not in guide_trace.nodes:
                 continue
             gsite = guide_trace.nodes[name]
+            if _add_normal_kl(batch, gsite, msite):
+                analytic.add(name)
+                continue
             try:
                 kl_qp = kl_divergence(gsite["fn"], msite["fn"])
             except NotImplementedError:

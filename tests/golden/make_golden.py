@@ -144,6 +144,17 @@ def g_dists():
     flat["binomial_logits/v"], flat["binomial_logits/a"], flat["binomial_logits/b"] = k, lg, n
     flat["binomial_logits/lp"] = lp.detach().numpy()
     flat["binomial_logits/da"] = torch.autograd.grad(lp.sum(), tl)[0].numpy()
+    # analytic KL of the Normal / Normal pair (trace_mean_field_elbo.py:121-137 uses kl_divergence)
+    lq, sq = rng.standard_normal((4, 7)), rng.uniform(0.2, 2, (4, 7))
+    lp_, sp = rng.standard_normal((1, 7)), rng.uniform(0.5, 3, (4, 1))
+    ts = [torch.tensor(x, requires_grad=True) for x in (lq, sq, lp_, sp)]
+    kl = torch.distributions.kl_divergence(dist.Normal(ts[0], ts[1]), dist.Normal(ts[2], ts[3]))
+    gs = torch.autograd.grad(kl.sum(), ts)
+    for k, x in zip(("lq", "sq", "lp", "sp"), (lq, sq, lp_, sp)):
+        flat["kl_normal/" + k] = x
+    flat["kl_normal/kl"] = kl.detach().numpy()
+    for k, x in zip(("dlq", "dsq", "dlp", "dsp"), gs):
+        flat["kl_normal/" + k] = x.numpy()
     save("dists", **flat)
 
 

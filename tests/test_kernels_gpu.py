@@ -80,9 +80,13 @@ def _dist_inputs(dist_id, rows, cols, rng, bcast):
         n = rng.integers(1, 80, shape_a).astype(float)
         k = np.floor(rng.uniform(size=shape_v) * (np.broadcast_to(n, shape_v) + 1))
         return np.minimum(k, np.broadcast_to(n, shape_v)), 3 * rng.standard_normal(shape_a), n
+    if dist_id == 10:     # KL_NORMAL_LOC(lq; lp, sp)
+        return rng.standard_normal(shape_v), rng.standard_normal(shape_a), rng.uniform(0.5, 2, shape_a)
+    if dist_id == 11:     # KL_NORMAL_SCALE(sq; sp)
+        return rng.uniform(0.2, 2, shape_v), rng.uniform(0.5, 2, shape_a), None
 
 
-@pytest.mark.parametrize("dist_id", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("dist_id", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("rows,cols,bcast", [(1, 1, "none"), (3, 7, "none"), (5, 1031, "row"),
                                              (7, 2500, "col"), (64, 4099, "none"),

@@ -86,6 +86,70 @@ def test_trace_mean_field_elbo(gpu, monkeypatch, tag):
     models.run_meanfield(load("meanfield"), gpu, monkeypatch, tag, rtol=1e-9)
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("P", [1, 6])
+def test_fused_normal_kl_equals_kl_divergence(gpu, monkeypatch, dtype, rtol, P):
+    """The Normal/Normal (and LogNormal/LogNormal) KL terms of TraceMeanField_ELBO ride in the
+    multi-site launch as two entries each; with the route switched off the same terms come from
+    torch.distributions.kl_divergence.  Same loss, same gradients -- on sites with event dims,
+    under a masked + subsample-scaled plate, with broadcast prior parameters and particles."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd import poutine, rng
+    from pyro_amd.infer import TraceMeanField_ELBO, trace_mean_field_elbo as tmf
+    from torch.distributions import constraints
+    torch.set_default_dtype(dtype)
+    G, N = 5, 9
+    gen = torch.Generator().manual_seed(3)
+    data = torch.randn(N, G, generator=gen).to(gpu)
+    mask = (torch.rand(G, generator=gen) < 0.7).to(gpu)
+    c = lambda *x: torch.tensor(x if len(x) > 1 else x[0], device=gpu)    # noqa: E731
+
+    def model(data):
+        w = pyro.sample("w", dist.Normal(torch.zeros(3, device=gpu), c(1.0, 2.0, 0.5)).to_event(1))
+        s = pyro.sample("s", dist.LogNormal(c(0.0), 0.4))
+        with pyro.plate("g", 2 * G, subsample_size=G, dim=-1), poutine.mask(mask=mask):
+            m = pyro.sample("m", dist.Normal(w.sum(-1), 1.5))
+            with pyro.plate("n", N, dim=-2):
+                pyro.sample("x", dist.Normal(m, s), obs=data)
+
+    def guide(data):
+        wl = pyro.param("wl", c(0.2, -0.1, 0.3))
+        ws = pyro.param("ws", c(0.4, 0.6, 0.8), constraint=constraints.positive)
+        sl = pyro.param("sl", c(-0.2))
+        ss = pyro.param("ss", c(0.3), constraint=constraints.positive)
+        ml = pyro.param("ml", torch.linspace(-1, 1, 2 * G, device=gpu))
+        ms = pyro.param("ms", torch.linspace(0.3, 0.9, 2 * G, device=gpu), constraint=constraints.positive)
+        pyro.sample("w", dist.Normal(wl, ws).to_event(1))
+        pyro.sample("s", dist.LogNormal(sl, ss))
+        with pyro.plate("g", 2 * G, subsample_size=G, dim=-1) as idx, poutine.mask(mask=mask):
+            pyro.sample("m", dist.Normal(ml[idx], ms[idx]))
+
+    def run(fused_route):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(11)
+        if not fused_route:
+            monkeypatch.setattr(tmf, "_add_normal_kl", lambda *a: False)
+        taken = []
+        real = tmf._add_normal_kl
+        monkeypatch.setattr(tmf, "_add_normal_kl", lambda *a: taken.append(real(*a)) or taken[-1])
+        elbo = TraceMeanField_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=2)
+        loss = elbo.loss_and_grads(model, guide, data)
+        grads = {k: v.grad.clone() for k, v in pyro.get_param_store().named_parameters()}
+        monkeypatch.undo()
+        return loss, grads, taken
+
+    loss_f, grads_f, taken = run(True)
+    assert taken == [True, True, True]
+    loss_t, grads_t, taken = run(False)
+    assert taken == [False, False, False]
+    np.testing.assert_allclose(loss_f, loss_t, rtol=rtol)
+    assert set(grads_f) == set(grads_t) == {"wl", "ws", "sl", "ss", "ml", "ms"}
+    for k in grads_f:
+        np.testing.assert_allclose(grads_f[k].cpu().numpy(), grads_t[k].cpu().numpy(), rtol=rtol * 10,
+                                   atol=rtol * 10 * float(grads_t[k].abs().max()))
+
+
 @pytest.mark.parametrize("which", ["diag", "mvn"])
 @pytest.mark.parametrize("tag", ["p1", "p4"])
 def test_autocontinuous_guides(gpu, monkeypatch, which, tag):

@@ -37,7 +37,7 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True):
 
 
 def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=True, model=None,
-                    lazy_matmul=True):
+                    lazy_matmul=True, elbo=Trace_ELBO):
     """BASELINE configs[1] with the other guide SURVEY 8(d) names (AutoMultivariateNormal), with
     the reference's default num_particles = 1 (few-particle GLM kernel), with the explicit
     dist.linear_logits model, or with the lazy recognition of w @ X.t() switched off (materialised
@@ -49,7 +49,7 @@ def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=T
     g = AutoMultivariateNormal(model, init_scale=0.1) if guide == "mvn" else \
         AutoNormal(model, init_scale=0.1)
     svi = SVI(model, g, pyro.optim.Adam({"lr": 0.01}),
-              Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
+              elbo(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
               hip_graph=graph, graph_warmup=2)
     prev = lazy.ENABLED["on"]
     lazy.ENABLED["on"] = bool(lazy_matmul)
