@@ -479,6 +479,29 @@ int pa_lda_factor_fwd_bwd(int dtype, const int64_t* words, const void* log_theta
                           void* out_doc, void* g_theta, void* g_phi, void* workspace,
                           size_t workspace_bytes, pa_stream_t stream);
 
+/* The same factor through an INVERTED INDEX of the corpus, built once (the data of
+ * examples/lda.py:133-141 does not change between steps): the scatter into g_phi becomes a gather
+ * over each word's document list -- no atomics, every sum in a fixed order (g_phi bitwise
+ * reproducible), ~8x less time per step at 1e5 documents x 64 words.
+ * Index image (int32): header {magic, Wd, B, V, ntasks, task capacity, Wd*B, 0}, off[V+1],
+ * first_task[V+1], task_v/task_start/task_len[capacity], docs[Wd*B]:
+ *   docs[off[v] .. off[v+1]) = the document d of every pair (w, d) with words[w,d] == v, in
+ *   ascending order of w*B + d (a stable counting sort; ids outside [0,V) are filed under 0 and
+ *   flagged by the step); tasks cut every word's list into segments of <= 2048 pairs.
+ * pa_lda_index_bytes returns 0 when no index exists for the shape (Wd*B >= 2^31, V > 15360):
+ * callers keep the atomic entry point above for those. */
+size_t pa_lda_index_bytes(int64_t Wd, int64_t B, int64_t V);
+size_t pa_lda_index_workspace(int64_t Wd, int64_t B, int64_t V);
+int pa_lda_build_index(const int64_t* words, int64_t Wd, int64_t B, int64_t V, void* index,
+                       size_t index_bytes, void* workspace, size_t workspace_bytes,
+                       pa_stream_t stream);
+size_t pa_lda_factor_indexed_workspace(int dtype, int64_t Wd, int64_t B, int64_t T, int64_t V);
+int pa_lda_factor_indexed_fwd_bwd(int dtype, const int64_t* words, const void* index,
+                                  size_t index_bytes, const void* log_theta, const void* log_phi,
+                                  int64_t Wd, int64_t B, int64_t T, int64_t V, void* out_doc,
+                                  void* g_theta, void* g_phi, void* workspace,
+                                  size_t workspace_bytes, pa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Flat multi-tensor Adam / ClippedAdam step (pyro/optim/optim.py:117-155,
  * pyro/optim/clipped_adam.py:52-100). One launch over the flat parameter buffer;

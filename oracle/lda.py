@@ -35,3 +35,31 @@ def lda_factor(words, log_theta, log_phi):
     for t in range(T):
         np.add.at(g_phi[t], words.reshape(-1), post[t].reshape(-1))
     return out_doc, g_theta, g_phi
+
+
+LDA_SEG = 2048      # pairs per word-major task (pyro_amd/csrc/lda.hip)
+
+
+def lda_word_index(words, V):
+    """The inverted index of a corpus (include/pyro_amd.h, pa_lda_build_index): for every word v the
+    documents of the pairs (w, d) that hold it, in ascending order of w * B + d, and the cut of the
+    lists into tasks of <= LDA_SEG pairs.  Returns (off[V+1], first_task[V+1], task_v, task_start,
+    task_len, docs) as int32 arrays.  Ids outside [0, V) are filed under 0."""
+    words = np.asarray(words)
+    Wd, B = words.shape
+    flat = words.reshape(-1).astype(np.int64)
+    flat = np.where((flat < 0) | (flat >= V), 0, flat)
+    order = np.argsort(flat, kind="stable")
+    docs = (order % max(B, 1)).astype(np.int32)
+    counts = np.bincount(flat, minlength=V)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    ntask = (counts + LDA_SEG - 1) // LDA_SEG
+    first_task = np.concatenate([[0], np.cumsum(ntask)]).astype(np.int32)
+    task_v, task_start, task_len = [], [], []
+    for v in range(V):
+        for st in range(off[v], off[v + 1], LDA_SEG):
+            task_v.append(v)
+            task_start.append(st)
+            task_len.append(min(LDA_SEG, off[v + 1] - st))
+    i32 = lambda x: np.asarray(x, dtype=np.int32)   # noqa: E731
+    return off, first_task, i32(task_v), i32(task_start), i32(task_len), docs

@@ -145,6 +145,15 @@ _SIGNATURES = {
     "pa_lda_factor_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "pa_lda_index_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_lda_index_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_lda_build_index": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_size_t,
+                                   c_void_p, c_size_t, c_void_p]),
+    "pa_lda_factor_indexed_workspace": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "pa_lda_factor_indexed_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                              c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                              c_void_p]),
     "pa_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                              c_double, c_double, c_double, c_double, c_double, c_double, c_int,
                              c_void_p, c_int, c_void_p]),

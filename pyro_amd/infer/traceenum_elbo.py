@@ -45,6 +45,26 @@ def _packed(site, lp, first_enum_dim):
     return pack(lp, site["infer"].get("_dim_to_id", {}), -1 - first_enum_dim, _ordinal(site))
 
 
+def _enum_log_prob(site):
+    """log_prob of an enumerated site at its own enumerated support.  For a Categorical that was
+    expanded over plates (``Categorical(doc_topics)`` inside the words plate of examples/lda.py) the
+    answer is the log-probability table itself with the support axis moved to the enumeration dim --
+    a VIEW of the un-expanded table, [T, 1.., batch] -- instead of a gather out of the expanded
+    table, whose result ([T, words, docs]) and whose autograd dual (zeros of that shape, a scatter,
+    a sum back over the words) are 200 MB tensors at 1e5 documents."""
+    fn, value = site["fn"], site["value"]
+    base = getattr(fn, "_base_logits", None)
+    from ..distributions import Categorical
+    if base is not None and type(fn).log_prob is Categorical.log_prob \
+            and site["infer"].get("_enumerate_dim") is not None and value.dim() >= 1:
+        T, n = base.shape[-1], value.dim()
+        batch = base.shape[:-1]
+        if value.shape == (T,) + (1,) * (n - 1) and len(batch) <= n - 1 \
+                and site["infer"]["_enumerate_dim"] == -n:
+            return base.movedim(-1, 0).reshape((T,) + (1,) * (n - 1 - len(batch)) + tuple(batch))
+    return fn.log_prob(value)
+
+
 def _lazy_gather(site, first_enum_dim):
     """Observed Categorical whose logits are [T, 1.., V] expanded over two plates and whose value
     is int64 [W, D]: keep the factor as (table, index) for the fused kernel."""
@@ -144,7 +164,8 @@ class TraceEnum_ELBO(ELBO):
         for name, site in model_trace.nodes.items():
             if site["type"] != "sample":
                 continue
-            lp = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
+            lp = _enum_log_prob(site) if name in enum_names else \
+                site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
             if name in enum_names:
                 # the enumerated site's own factor is its UNmasked, unscaled log-probability
                 # (traceenum_elbo.py:168-174): summed over its support it is exactly 0
@@ -225,7 +246,7 @@ class TraceEnum_ELBO(ELBO):
             if name in enum_names:
                 # unmasked, unscaled (traceenum_elbo.py:168-174): a masked-out plate slice of an
                 # enumerated variable must still sum to probability one
-                lp = site["fn"].log_prob(site["value"])
+                lp = _enum_log_prob(site)
                 term = _packed(site, lp, first_enum_dim)
                 factors.setdefault(term.ordinal, []).append(term)
                 scales.append(site["scale"])
@@ -301,7 +322,7 @@ class TraceEnum_ELBO(ELBO):
             if site["type"] != "sample":
                 continue
             if name in enum_names:
-                lp = site["fn"].log_prob(site["value"])
+                lp = _enum_log_prob(site)
                 if name in extra:
                     lp = lp + extra[name]
                 term = _packed(site, lp, first_enum_dim)

@@ -898,8 +898,90 @@ class NutsTree:
 # enumerated LDA factor
 # ------------------------------------------------------------------------------------------
 
-def lda_factor_fwd_bwd(words, log_theta, log_phi):
-    """words int64 [Wd,B]; log_theta [B,T]; log_phi [T,V] -> (out_doc[B], g_theta[B,T], g_phi[T,V])"""
+# The corpus does not change between ELBO-gradient steps: its inverted index (pa_lda_build_index) is
+# built once per tensor object and kept beside it, under the same policy as the GLM plane image
+# above (second sighting; never inside a capture; re-built into the same buffer when the tensor was
+# modified in place, so a captured graph that reads the index stays valid).
+LDA_INDEX_OFF, LDA_INDEX_AUTO, LDA_INDEX_ALWAYS = 0, 1, 2
+_lda_index_mode = LDA_INDEX_AUTO
+_lda_index_cache = {}       # (id(base), offset, shape, stride) -> [weakref, version, index, sightings, geometry, V]
+
+
+def lda_set_index_mode(mode):
+    """LDA_INDEX_AUTO (default): a word-id tensor seen for the second time is indexed and the
+    atomic-free kernels used from then on; LDA_INDEX_ALWAYS: at first sight; LDA_INDEX_OFF: the
+    LDS-atomic kernel every step (a mini-batch ``data[:, ind]`` is a fresh tensor every step and
+    takes that route under every mode but ALWAYS)."""
+    global _lda_index_mode
+    _lda_index_mode = int(mode)
+    if _lda_index_mode == LDA_INDEX_OFF:
+        _lda_index_cache.clear()
+
+
+def lda_build_index(words, V, out=None):
+    """words int64 [Wd,B] -> the int32 index image pa_lda_factor_indexed_fwd_bwd reads (or None
+    when the shape has none)."""
+    _require_gpu(words)
+    Wd, B = words.shape
+    lib = _lib.load()
+    nbytes = lib.pa_lda_index_bytes(Wd, B, V)
+    if nbytes == 0:
+        return None
+    assert words.dtype == torch.int64 and words.is_contiguous()
+    if out is None:
+        out = torch.empty((nbytes // 4,), dtype=torch.int32, device=words.device)
+    wbytes = lib.pa_lda_index_workspace(Wd, B, V)
+    ws = torch.empty((max(wbytes, 256),), dtype=torch.uint8, device=words.device)
+    check(lib.pa_lda_build_index(_ptr(words), Wd, B, V, _ptr(out), out.numel() * 4, _ptr(ws),
+                                 ws.numel(), _stream()))
+    return out
+
+
+def _lda_index_of(words, V):
+    if _lda_index_mode == LDA_INDEX_OFF:
+        return None
+    base = words._base if words._base is not None else words
+    geom = (words.storage_offset(), tuple(words.shape), tuple(words.stride()))
+    key = (id(base),) + geom + (int(V),)
+    ent = _lda_index_cache.get(key)
+    if ent is not None and ent[0]() is not base:
+        ent = None
+    if ent is None:
+        import weakref
+        ent = [weakref.ref(base, lambda _r, k=key: _lda_index_cache.pop(k, None)), words._version,
+               None, 0, geom, int(V)]
+        _lda_index_cache[key] = ent
+    ent[3] += 1
+    if ent[2] is None:
+        if _lda_index_mode == LDA_INDEX_AUTO and ent[3] < 2:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ent[2] = lda_build_index(words, V)
+        if ent[2] is None:
+            ent[2] = False               # no index for this shape: do not ask again
+        ent[1] = words._version
+    elif ent[2] is not False and ent[1] != words._version:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("pyro_amd: a corpus changed in place during a graph capture")
+        lda_build_index(words, V, out=ent[2])
+        ent[1] = words._version
+    return ent[2] if ent[2] is not False else None
+
+
+def lda_index_revalidate():
+    """Re-build every cached index whose tensor was modified in place (before a graph replay)."""
+    for ent in list(_lda_index_cache.values()):
+        base = ent[0]()
+        if base is not None and isinstance(ent[2], torch.Tensor) and ent[1] != base._version:
+            off, shape, stride = ent[4]
+            lda_build_index(base.as_strided(shape, stride, off), ent[5], out=ent[2])
+            ent[1] = base._version
+
+
+def lda_factor_fwd_bwd(words, log_theta, log_phi, index=None):
+    """words int64 [Wd,B]; log_theta [B,T]; log_phi [T,V] -> (out_doc[B], g_theta[B,T], g_phi[T,V]).
+    ``index``: an image from lda_build_index (default: the cached one of ``words``, if any)."""
     _require_gpu(words, log_theta, log_phi)
     Wd, B = words.shape
     T, V = log_phi.shape
@@ -907,11 +989,21 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
     assert log_theta.shape == (B, T) and log_theta.is_contiguous() and log_phi.is_contiguous()
     lib = _lib.load()
     dt = _dtype(log_theta)
-    nbytes = lib.pa_lda_factor_workspace(dt, B, T, V)
-    ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=words.device)
+    if index is None:
+        index = _lda_index_of(words, V)
     out = torch.empty((B,), dtype=log_theta.dtype, device=words.device)
     g_theta = torch.empty_like(log_theta)
     g_phi = torch.empty_like(log_phi)
+    if index is not None:
+        nbytes = lib.pa_lda_factor_indexed_workspace(dt, Wd, B, T, V)
+        ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=words.device)
+        check(lib.pa_lda_factor_indexed_fwd_bwd(dt, _ptr(words), _ptr(index), index.numel() * 4,
+                                                _ptr(log_theta), _ptr(log_phi), Wd, B, T, V,
+                                                _ptr(out), _ptr(g_theta), _ptr(g_phi), _ptr(ws),
+                                                ws.numel(), _stream()))
+        return out, g_theta, g_phi
+    nbytes = lib.pa_lda_factor_workspace(dt, B, T, V)
+    ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=words.device)
     check(lib.pa_lda_factor_fwd_bwd(dt, _ptr(words), _ptr(log_theta), _ptr(log_phi), Wd, B, T, V,
                                     _ptr(out), _ptr(g_theta), _ptr(g_phi), _ptr(ws), ws.numel(),
                                     _stream()))

@@ -672,6 +672,130 @@ def test_lda_factor(gpu, dtype, Wd, B, T, V):
     np.testing.assert_allclose(gt.sum(1).cpu().numpy(), np.full(B, Wd), rtol=1e-5)
 
 
+def _lda_words(rng, Wd, B, V, zipf):
+    if not zipf:
+        return rng.integers(0, V, (Wd, B))
+    p = 1.0 / np.arange(1, V + 1) ** 1.3          # a few words hold most of the corpus
+    return rng.choice(V, size=(Wd, B), p=p / p.sum())
+
+
+@pytest.mark.parametrize("Wd,B,V,zipf", [(8, 100, 100, False), (64, 3000, 1024, False),
+                                         (64, 3000, 1024, True), (3, 1, 7, False), (0, 10, 6, False),
+                                         (5, 70001, 33, True)])
+def test_lda_word_index_bit_exact(gpu, Wd, B, V, zipf):
+    """pa_lda_build_index against the oracle's stable sort: integer work, bit for bit."""
+    k = _k()
+    rng = np.random.default_rng(Wd * 7 + B)
+    words = _lda_words(rng, Wd, B, V, zipf)
+    if Wd * B > 10:
+        words.reshape(-1)[3] = V + 5          # a support violation is filed under word 0
+        words.reshape(-1)[7] = -2
+    img = k.lda_build_index(tt(words, gpu), V).cpu().numpy()
+    off, first_task, task_v, task_start, task_len, docs = o_lda.lda_word_index(words, V)
+    n, nt = Wd * B, len(task_v)
+    cap = n // o_lda.LDA_SEG + V + 1
+    assert tuple(img[1:7]) == (Wd, B, V, nt, cap, n)
+    p = 8
+    assert np.array_equal(img[p:p + V + 1], off); p += V + 1
+    assert np.array_equal(img[p:p + V + 1], first_task); p += V + 1
+    assert np.array_equal(img[p:p + nt], task_v); p += cap
+    assert np.array_equal(img[p:p + nt], task_start); p += cap
+    assert np.array_equal(img[p:p + nt], task_len); p += cap
+    assert np.array_equal(img[p:p + n], docs) and p + n == img.size
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("Wd,B,T,V,zipf", [(8, 100, 8, 100, False), (64, 1000, 8, 1024, False),
+                                           (64, 4000, 8, 1024, True), (3, 1, 5, 7, False),
+                                           (16, 300, 20, 50, True), (0, 10, 4, 6, False)])
+def test_lda_factor_indexed(gpu, dtype, Wd, B, T, V, zipf):
+    """The atomic-free (inverted index) route: oracle parity, bitwise reproducible results, and
+    agreement with the atomic route."""
+    k = _k()
+    rng = np.random.default_rng(Wd + B)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    words = _lda_words(rng, Wd, B, V, zipf)
+    theta = rng.dirichlet(np.ones(T) * 0.5, B)
+    phi = rng.dirichlet(np.ones(V) * 0.1, T)
+    lt = np.log(theta).astype(np_dt)
+    lp = np.log(np.maximum(phi, 1e-30)).astype(np_dt)
+    tw, tlt, tlp = tt(words, gpu), tt(lt, gpu), tt(lp, gpu)
+    index = k.lda_build_index(tw, V)
+    out, gt, gp = k.lda_factor_fwd_bwd(tw, tlt, tlp, index=index)
+    r_out, r_gt, r_gp = o_lda.lda_factor(words, lt, lp)
+    rtol = 3e-5 if dtype == torch.float32 else 1e-11
+    np.testing.assert_allclose(out.cpu().numpy(), r_out, rtol=rtol, atol=rtol * 10)
+    np.testing.assert_allclose(gt.cpu().numpy(), r_gt, rtol=rtol, atol=rtol * max(Wd, 1))
+    np.testing.assert_allclose(gp.cpu().numpy(), r_gp, rtol=rtol * 4, atol=rtol * max(Wd * B / V, 1) * 4)
+    out2, gt2, gp2 = k.lda_factor_fwd_bwd(tw, tlt, tlp, index=k.lda_build_index(tw, V))
+    assert torch.equal(gp, gp2) and torch.equal(out, out2) and torch.equal(gt, gt2)
+    k.lda_set_index_mode(k.LDA_INDEX_OFF)
+    try:
+        out3, gt3, gp3 = k.lda_factor_fwd_bwd(tw, tlt, tlp)
+    finally:
+        k.lda_set_index_mode(k.LDA_INDEX_AUTO)
+    # (the two routes split a document's words over a different number of waves: same sums, other order)
+    np.testing.assert_allclose(out.cpu().numpy(), out3.cpu().numpy(), rtol=rtol, atol=rtol * 10)
+    np.testing.assert_allclose(gt.cpu().numpy(), gt3.cpu().numpy(), rtol=rtol, atol=rtol * max(Wd, 1))
+    np.testing.assert_allclose(gp.cpu().numpy(), gp3.cpu().numpy(), rtol=rtol * 4,
+                               atol=rtol * max(Wd * B / V, 1) * 4)
+
+
+def test_lda_index_cache_policy(gpu):
+    """AUTO: the first call on a tensor takes the atomic route, the second builds the index; an
+    in-place change of the corpus re-builds it into the same buffer."""
+    k = _k()
+    rng = np.random.default_rng(5)
+    Wd, B, T, V = 16, 500, 8, 64
+    words = tt(rng.integers(0, V, (Wd, B)), gpu)
+    lt = torch.log_softmax(torch.randn(B, T, device=gpu), -1)
+    lp = torch.log_softmax(torch.randn(T, V, device=gpu), -1)
+    k._lda_index_cache.clear()
+    a = k.lda_factor_fwd_bwd(words, lt, lp)
+    ent = next(iter(k._lda_index_cache.values()))
+    assert ent[2] is None and ent[3] == 1
+    b = k.lda_factor_fwd_bwd(words, lt, lp)
+    assert ent[2] is not None and ent[3] == 2
+    buf = ent[2].data_ptr()
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    words[0, :10] = (words[0, :10] + 1) % V
+    c = k.lda_factor_fwd_bwd(words, lt, lp)
+    assert ent[2].data_ptr() == buf and ent[1] == words._version
+    r = o_lda.lda_factor(words.cpu().numpy(), lt.cpu().numpy(), lp.cpu().numpy())
+    np.testing.assert_allclose(c[2].cpu().numpy(), r[2], rtol=2e-4, atol=2e-3)
+    # a mini-batch is a fresh tensor every step: first sighting, atomic route, no index built
+    sub = words[:, :100].contiguous()
+    k.lda_factor_fwd_bwd(sub, lt[:100].contiguous(), lp)
+    fresh = [e for e in k._lda_index_cache.values() if e[0]() is sub]
+    assert len(fresh) == 1 and fresh[0][2] is None
+
+
+def test_lda_factor_indexed_full_size_properties(gpu):
+    """BASELINE config 4 size (1e5 documents x 64 words, T=8, V=1024), f32: responsibilities sum
+    to one per pair on both sides of the factor, both routes agree, g_phi is reproducible."""
+    k = _k()
+    g = torch.Generator(device=gpu).manual_seed(0)
+    Wd, B, T, V = 64, 100_000, 8, 1024
+    words = torch.randint(0, V, (Wd, B), device=gpu, generator=g)
+    lt = torch.log_softmax(torch.randn(B, T, device=gpu, generator=g), -1)
+    lp = torch.log_softmax(2 * torch.randn(T, V, device=gpu, generator=g), -1)
+    index = k.lda_build_index(words, V)
+    out, gt, gp = k.lda_factor_fwd_bwd(words, lt, lp, index=index)
+    assert torch.allclose(gt.sum(1), torch.full((B,), float(Wd), device=gpu), rtol=1e-5)
+    counts = torch.bincount(words.reshape(-1), minlength=V).double()
+    np.testing.assert_allclose(gp.double().sum(0).cpu().numpy(), counts.cpu().numpy(), rtol=2e-5)
+    k.lda_set_index_mode(k.LDA_INDEX_OFF)
+    try:
+        out_a, gt_a, gp_a = k.lda_factor_fwd_bwd(words, lt, lp)
+    finally:
+        k.lda_set_index_mode(k.LDA_INDEX_AUTO)
+    np.testing.assert_allclose(out.cpu().numpy(), out_a.cpu().numpy(), rtol=3e-5)
+    np.testing.assert_allclose(gt.cpu().numpy(), gt_a.cpu().numpy(), rtol=3e-5, atol=2e-3)
+    np.testing.assert_allclose(gp.cpu().numpy(), gp_a.cpu().numpy(), rtol=2e-4, atol=1e-2)
+    assert torch.equal(gp, k.lda_factor_fwd_bwd(words, lt, lp, index=index)[2])
+
+
 def test_lda_factor_minus_inf_column(gpu):
     k = _k()
     lt = torch.log(torch.tensor([[1.0, 0.0], [0.5, 0.5]], device=gpu, dtype=torch.float64))
