@@ -64,21 +64,26 @@ template <typename T>
 struct PotLds {
   const T* Ls;
   int D, lane;
+  // Four partial sums per column (rows j = k mod 4), combined as (s0 + s1) + (s2 + s3): four
+  // independent FMA chains instead of one of length D -- with one wave per SIMD nothing else hides
+  // the FMA latency.  PotReg below uses the same partition and order: bit-identical results.
   __device__ __forceinline__ void operator()(P2<T> z, P2<T>& g, T& pe) const {
-    T g0 = T(0), g1 = T(0);
+    T s0[4] = {T(0), T(0), T(0), T(0)}, s1[4] = {T(0), T(0), T(0), T(0)};
     const int d0 = D < 64 ? D : 64;
 #pragma unroll 4
     for (int j = 0; j < d0; ++j) {
       const T zj = bcast_lane(z.a, j);
-      g0 += Ls[j * D + lane] * zj;
-      g1 += Ls[j * D + lane + 64] * zj;
+      s0[j & 3] = __builtin_fma(Ls[j * D + lane], zj, s0[j & 3]);
+      s1[j & 3] = __builtin_fma(Ls[j * D + lane + 64], zj, s1[j & 3]);
     }
 #pragma unroll 4
     for (int j = 64; j < D; ++j) {
       const T zj = bcast_lane(z.b, j - 64);
-      g0 += Ls[j * D + lane] * zj;
-      g1 += Ls[j * D + lane + 64] * zj;
+      s0[j & 3] = __builtin_fma(Ls[j * D + lane], zj, s0[j & 3]);
+      s1[j & 3] = __builtin_fma(Ls[j * D + lane + 64], zj, s1[j & 3]);
     }
+    const T g0 = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+    const T g1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
     g.a = lane < D ? g0 : T(0);
     g.b = lane + 64 < D ? g1 : T(0);
     pe = T(0.5) * dot(z, g);
@@ -91,27 +96,45 @@ struct PotLds {
 // PotLds (j ascending), so both give bit-identical f32 results.
 template <int DPAD>
 struct PotReg {
-  float La[DPAD], Lb[DPAD];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f L[DPAD];          // {Lambda[j][lane], Lambda[j][lane + 64]}: one register pair per row j
+  float* zs;            // 128 floats of LDS owned by this wave: z broadcast to every lane
   int D, lane;
-  __device__ __forceinline__ void load(const float* __restrict__ Lambda, int D_, int lane_) {
+  __device__ __forceinline__ void load(const float* __restrict__ Lambda, int D_, int lane_,
+                                       float* zs_) {
     D = D_;
     lane = lane_;
+    zs = zs_;
 #pragma unroll
     for (int j = 0; j < DPAD; ++j) {
-      La[j] = (j < D && lane < D) ? Lambda[j * D + lane] : 0.0f;
-      Lb[j] = (j < D && lane + 64 < D) ? Lambda[j * D + lane + 64] : 0.0f;
+      L[j][0] = (j < D && lane < D) ? Lambda[j * D + lane] : 0.0f;
+      L[j][1] = (j < D && lane + 64 < D) ? Lambda[j * D + lane + 64] : 0.0f;
     }
   }
+  // z goes through LDS once (2 ds_write_b32 per lane) and comes back as wave-uniform 16-byte
+  // reads (4 coordinates per ds_read_b128, every lane the same address: a broadcast), and the two
+  // columns of a lane advance together in ONE v_pk_fma_f32 per row: DPAD/4 LDS reads + DPAD packed
+  // FMAs per mat-vec instead of DPAD x {v_readlane, 2 v_fmac}.  Each component is an ordinary fma,
+  // partial sums and their order as in PotLds: bit-identical results.
   __device__ __forceinline__ void operator()(P2<float> z, P2<float>& g, float& pe) const {
-    float g0 = 0.0f, g1 = 0.0f;
+    zs[lane] = z.a;
+    zs[lane + 64] = z.b;
+    // (plain v_fmac: v_pk_fma_f32 issues in two passes on gfx950 -- measured, no gain over two FMAs)
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // rows j mod 4 (as PotLds)
+    const float4* z4 = reinterpret_cast<const float4*>(zs);
 #pragma unroll
-    for (int j = 0; j < DPAD; ++j) {
-      const float zj = j < 64 ? bcast_lane(z.a, j) : bcast_lane(z.b, j - 64);
-      g0 = __builtin_fmaf(La[j], zj, g0);
-      g1 = __builtin_fmaf(Lb[j], zj, g1);
+    for (int j4 = 0; j4 < DPAD / 4; ++j4) {
+      const float4 q = z4[j4];
+      const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k] = __builtin_fmaf(L[4 * j4 + k][0], qq[k], a[k]);
+        b[k] = __builtin_fmaf(L[4 * j4 + k][1], qq[k], b[k]);
+      }
     }
-    g.a = g0;
-    g.b = g1;
+    const float acc[2] = {(a[0] + a[1]) + (a[2] + a[3]), (b[0] + b[1]) + (b[2] + b[3])};
+    g.a = acc[0];
+    g.b = acc[1];
     pe = 0.5f * dot(z, g);
   }
 };
@@ -448,8 +471,9 @@ void nuts_gaussian_reg_kernel(float* __restrict__ z_io, float* __restrict__ pe_i
   __shared__ float stack_s[NUTS_MAX_DEPTH * (3 * 128 + 2)];
   const int lane = threadIdx.x;
   const int chain = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) float zb_s[128];
   PotReg<DPAD> pot;
-  pot.load(Lambda, D, lane);
+  pot.load(Lambda, D, lane, zb_s);
   nuts_run_body<float, 1, PotReg<DPAD>, false>(pot, stack_s, stack_s + NUTS_MAX_DEPTH * 3 * 128,
                                                chain, lane, PA_NUTS_RUN_ARGS);
 }

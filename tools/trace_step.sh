@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 OUT=gpurun_out/trace_step; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python bench.py --steps 2 --warmup 2 --no-graph --no-nuts --no-others --no-cpu-baseline --plate ${1:-1000000} > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python bench.py --steps 3 --warmup 8 ${GRAPHFLAG:---no-graph} --no-nuts --no-others --no-cpu-baseline --plate ${1:-1000000} > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
@@ -11,7 +11,13 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last step = after the last but one adam kernel
 idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-lo, hi = idx[-2] + 1, idx[-1] + 3
+# the tightest step (a graph replay when the bench captured one)
+best = None
+for a, b in zip(idx, idx[1:]):
+    span = int(rows[b]["End_Timestamp"]) - int(rows[a + 1]["Start_Timestamp"])
+    if best is None or span < best[0]:
+        best = (span, a + 1, b + 1)
+lo, hi = best[1], best[2]
 t0 = int(rows[lo]["Start_Timestamp"])
 with open(sys.argv[1] + "/last_step.txt", "w") as out:
     for r in rows[lo:hi]:
