@@ -416,10 +416,12 @@ def main():
                          "bf16_mfma_TFLOPs": 6 * gemm_flops / (kern_ms * 1e-3) / 1e12,
                          "frac_bf16_mfma": 6 * gemm_flops / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                          "f32_equivalent_TFLOPs": achieved_tflops,
-                         "binding_resource": "VALU issue (element-wise sigmoid/softplus + the 3-way "
-                                             "split of g: ~18 VALU + 2 transcendental instructions "
-                                             "per (row, particle); PMC: VALU busy ~100 % of the "
-                                             "loop, profiles/r02_*)"},
+                         "binding_resource": "VALU issue next to the MFMA pipe: 332 VALU instructions "
+                                             "per wave and 32x32 (row, particle) tile (sigmoid / "
+                                             "softplus sums + the exact 3-way bf16 split of g) "
+                                             "against 25 MFMAs; PMC per launch: VALU issue 47 us "
+                                             "of SIMD time, matrix pipe busy 26 us, kernel 65 us "
+                                             "(profiles/r02_pmc_summary.json, DESIGN.md section 3)"},
             "rccl_ranks": world,
         }
         if world == 1 and not args.no_cpu_baseline:

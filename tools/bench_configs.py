@@ -144,10 +144,12 @@ def config4(dev, docs=100_000, steps=10):
     guide = lambda data, args: examples.lda_guide(predictor, data, args)  # noqa: E731
     # examples/lda.py:131 uses ClippedAdam: here the flat fused one (one launch for all parameters,
     # the predictor's weights included)
-    svi = SVI(examples.lda_model, guide, pyro.optim.ClippedAdam({"lr": 0.01}), TraceEnum_ELBO(max_plate_nesting=2))
-    dt = timed(lambda: svi.step(data, args), steps, 3)
+    svi = SVI(examples.lda_model, guide, pyro.optim.ClippedAdam({"lr": 0.01}), TraceEnum_ELBO(max_plate_nesting=2),
+              hip_graph=True, graph_warmup=3)
+    dt = timed(lambda: svi.step(data, args), steps, 6)
     pairs = docs * args.num_words_per_doc
     return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
+            "graphed": bool(svi.hip_graph and len(svi._graphs) == 1),
             "algorithmic_TBps": pairs * 8.5 / dt / 1e12}
 
 
