@@ -8,19 +8,35 @@ configured per site exactly as in the reference, through
 ``infer={"baseline": {"use_decaying_avg_baseline": True, "baseline_beta": 0.9, "baseline_value":
 tensor, "nn_baseline": module, "nn_baseline_input": tensor}}``.
 
-Dependency structure.  The downstream cost here is Rao-Blackwellised by the PLATE structure -- the
-sum of every log p - log q term, reduced to the plates of z (what Trace_ELBO uses,
-trace_elbo.py:20-29 + MultiFrameTensor.sum_to) -- whereas the reference additionally drops terms
-that data-flow provenance (pyro/ops/provenance.py) shows to be independent of z.  Both are unbiased
-estimators of the same gradient; the reference's has the lower variance on models with long chains
-of dependent non-reparameterised sites.  With a fully reparameterised guide this class is
-Trace_ELBO, fused paths included.
+Dependency structure (tracegraph_elbo.py:178-236).  The downstream cost of z is the sum of the
+log p / -log q terms that DEPEND on z -- found by data-flow provenance: values drawn at
+non-reparameterised sites are wrapped by ``TrackNonReparam`` in ``ops.provenance.ProvenanceTensor``,
+every torch function propagates the set of site names, and a term belongs to z's downstream cost
+when z is in the provenance of the term's site (its value, its distribution's parameters) --
+reduced to the plates of z (MultiFrameTensor.sum_to).  With a fully reparameterised guide this class
+is Trace_ELBO, fused paths included.
 """
 import torch
 
+from collections import defaultdict
+
 from ..distributions.util import is_identically_zero
+from ..ops.provenance import detach_provenance, site_provenance, track_provenance
 from ..params import _PARAM_STORE
-from .trace_elbo import Trace_ELBO, _compute_log_r
+from ..poutine.runtime import Messenger
+from ..poutine.util import site_is_subsample
+from .trace_elbo import Trace_ELBO
+from .util import MultiFrameTensor
+
+
+class TrackNonReparam(Messenger):
+    """Tags the value of every non-reparameterised latent sample site with the site's name
+    (tracegraph_elbo.py:239-287); whatever is computed from it carries the tag on."""
+
+    def _pyro_post_sample(self, msg):
+        if msg["type"] == "sample" and not site_is_subsample(msg) and not msg["is_observed"] \
+                and not getattr(msg["fn"], "has_rsample", False):
+            msg["value"] = track_provenance(msg["value"], frozenset({msg["name"]}))
 
 
 def _get_baseline_options(site):
@@ -63,34 +79,45 @@ def _construct_baseline(name, guide_site, downstream_cost):
 
 
 class TraceGraph_ELBO(Trace_ELBO):
+    def _get_trace(self, model, guide, args, kwargs):
+        with TrackNonReparam():
+            return super()._get_trace(model, guide, args, kwargs)
+
     def _surrogate_and_elbo(self, model_trace, guide_trace):
         if getattr(guide_trace, "_fully_reparam", False):
             return super()._surrogate_and_elbo(model_trace, guide_trace)
-        model_trace.compute_log_prob_sums()
+        model_trace.compute_log_prob()
         elbo, surrogate = 0.0, 0.0
+        downstream = defaultdict(MultiFrameTensor)       # non-reparam site -> the costs it influences
         for site in model_trace.nodes.values():
-            if site["type"] == "sample":
-                x = site["log_prob_sum"]
-                elbo = elbo + (x.detach() if isinstance(x, torch.Tensor) else x)
-                surrogate = surrogate + x
-        log_r = None
+            if site["type"] != "sample":
+                continue
+            x = detach_provenance(site["log_prob_sum"])
+            elbo = elbo + (x.detach() if isinstance(x, torch.Tensor) else x)
+            surrogate = surrogate + x
+            for key in site_provenance(site):
+                downstream[key].add((site["cond_indep_stack"],
+                                     detach_provenance(site["log_prob"]).detach()))
         for name, site in guide_trace.nodes.items():
             if site["type"] != "sample":
                 continue
-            log_prob, score_function_term, entropy_term = site["score_parts"]
-            lps = site["log_prob_sum"]
+            entropy_term = site["score_parts"].entropy_term
+            lps = detach_provenance(site["log_prob_sum"])
             elbo = elbo - (lps.detach() if isinstance(lps, torch.Tensor) else lps)
             if not is_identically_zero(entropy_term):
-                surrogate = surrogate - entropy_term.sum()
-            if not is_identically_zero(score_function_term):
-                if log_r is None:
-                    log_r = _compute_log_r(model_trace, guide_trace)
-                downstream_cost = log_r.sum_to(site["cond_indep_stack"])
-                use, baseline_loss, baseline = _construct_baseline(name, site, downstream_cost)
-                if use:
-                    downstream_cost = downstream_cost - (
-                        baseline.detach() if isinstance(baseline, torch.Tensor) else baseline)
-                surrogate = surrogate + (downstream_cost * score_function_term).sum()
-                # the surrogate is MAXIMISED: the baseline regression loss enters with a minus
-                surrogate = surrogate - baseline_loss
+                surrogate = surrogate - detach_provenance(entropy_term).sum()
+            for key in site_provenance(site):
+                downstream[key].add((site["cond_indep_stack"],
+                                     -detach_provenance(site["log_prob"]).detach()))
+        for name, cost in downstream.items():
+            site = guide_trace.nodes[name]
+            downstream_cost = cost.sum_to(site["cond_indep_stack"])
+            score_function_term = detach_provenance(site["score_parts"].score_function)
+            use, baseline_loss, baseline = _construct_baseline(name, site, downstream_cost)
+            if use:
+                downstream_cost = downstream_cost - (
+                    baseline.detach() if isinstance(baseline, torch.Tensor) else baseline)
+            surrogate = surrogate + (score_function_term * downstream_cost).sum()
+            # the surrogate is MAXIMISED: the baseline regression loss enters with a minus
+            surrogate = surrogate - baseline_loss
         return elbo, surrogate

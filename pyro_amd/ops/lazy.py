@@ -53,6 +53,9 @@ class LatentTensor(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        if any(t is not LatentTensor and t is not torch.Tensor and t.__name__ == "ProvenanceTensor"
+               for t in types):
+            return NotImplemented          # ops.provenance handles the call (and keeps its tags)
         if ENABLED["on"] and getattr(func, "__name__", "") in _MATMUL_NAMES and len(args) == 2 \
                 and not kwargs:
             a, b = args

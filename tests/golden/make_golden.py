@@ -983,6 +983,64 @@ def g_tracegraph():
 
 
 # ---------------------------------------------------------------------------------------------
+# TraceGraph_ELBO with data-flow provenance (tracegraph_elbo.py:178-236): independent and chained
+# non-reparameterised sites, a local one inside a plate, a discrete one used as an index; the
+# downstream cost of a site holds only the terms that depend on it.  Latents fixed through replay.
+# ---------------------------------------------------------------------------------------------
+def g_tracegraph_prov():
+    torch.set_default_dtype(torch.float64)
+    from pyro.distributions.testing import fakes
+    from pyro.infer import TraceGraph_ELBO
+    rng = np.random.default_rng(43)
+    x = torch.tensor(rng.standard_normal(4))
+    y = torch.tensor(0.7)
+    w = torch.tensor(1.0)
+    table = torch.tensor([0.2, 0.5, 0.9])
+    fixed_vals = {"a": torch.tensor(0.4), "b": torch.tensor(-0.8), "k": torch.tensor(2),
+                  "c": torch.tensor(rng.standard_normal(4))}
+
+    def model(x, y, w):
+        a = pyro.sample("a", dist.Normal(0.0, 1.0))
+        b = pyro.sample("b", dist.Normal(0.0, 1.0))
+        k = pyro.sample("k", dist.Categorical(torch.tensor([0.3, 0.3, 0.4])))
+        with pyro.plate("d", 4):
+            c = pyro.sample("c", dist.Normal(a, 1.0))
+            pyro.sample("x", dist.Normal(c, 0.5), obs=x)
+        pyro.sample("y", dist.Normal(b * b, 0.7), obs=y)
+        pyro.sample("w", dist.Bernoulli(table[k]), obs=w)
+
+    def guide(x, y, w):
+        qa = pyro.param("qa", torch.tensor(0.2))
+        qb = pyro.param("qb", torch.tensor(-0.3))
+        qc = pyro.param("qc", torch.tensor([0.1, -0.1, 0.3, 0.0]))
+        qk = pyro.param("qk", torch.tensor([0.2, 0.3, 0.5]), constraint=constraints.simplex)
+        a = pyro.sample("a", fakes.NonreparameterizedNormal(qa, 0.9),
+                        infer={"baseline": {"use_decaying_avg_baseline": True, "baseline_beta": 0.7}})
+        pyro.sample("b", fakes.NonreparameterizedNormal(qb, 1.1))
+        pyro.sample("k", dist.Categorical(qk))
+        with pyro.plate("d", 4):
+            pyro.sample("c", fakes.NonreparameterizedNormal(qc + 0.5 * a, 0.8))
+
+    pyro.clear_param_store()
+    flat = {"x": x.numpy(), "y": y.numpy(), "w": w.numpy(), "table": table.numpy()}
+    for name, v in fixed_vals.items():
+        flat["fixed/" + name] = v.numpy()
+    for k_ in range(2):
+        fixed = poutine.trace(poutine.condition(guide, data=fixed_vals)).get_trace(x, y, w)
+        for name in fixed_vals:
+            fixed.nodes[name]["is_observed"] = False
+        for p_ in pyro.get_param_store()._params.values():
+            p_.grad = None
+        loss = TraceGraph_ELBO().loss_and_grads(model, poutine.replay(guide, trace=fixed), x, y, w)
+        flat["loss%d" % k_] = loss
+        for name, g_ in grads_of_store().items():
+            if not name.startswith("__baseline"):
+                flat["grads%d/%s" % (k_, name)] = g_
+        flat["avg%d" % k_] = pyro.get_param_store()["__baseline_avg_downstream_cost_a"].detach().numpy()
+    save("tracegraph_prov", **flat)
+
+
+# ---------------------------------------------------------------------------------------------
 # G14: guide-side parallel enumeration with DiCE (traceenum_elbo.py:112-214, infer/util.py:196-326):
 #      the "auto" programs of tests/infer/test_enum.py:2121-2208 (everything inside one masked
 #      plate, x enumerated in the guide, y in the model) and :1823-1866 (no plate), plus a
@@ -1238,7 +1296,7 @@ def g_marginals():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov"]
     for w in which:
         globals()["g_" + w]()
 

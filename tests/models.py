@@ -196,6 +196,57 @@ def run_scale_mask(g, device, monkeypatch, rtol):
     assert_grads(store_grads(), g, "grads", rtol * 10)
 
 
+def run_tracegraph_provenance(g, device, rtol):
+    """TraceGraph_ELBO on a program whose downstream costs differ site by site (independent and
+    chained non-reparameterised sites, a local one in a plate, a discrete index): loss, gradients
+    and the stored average of a's downstream cost against the reference (tracegraph_prov.npz)."""
+    from pyro_amd.infer import TraceGraph_ELBO
+    dtype = torch.get_default_dtype()
+
+    def t(v, dt=dtype):
+        return torch.as_tensor(np.asarray(v), dtype=dt, device=device)
+
+    x, y, w, table = t(g["x"]), t(g["y"]), t(g["w"]), t(g["table"])
+    fixed_vals = {"a": t(g["fixed/a"]), "b": t(g["fixed/b"]), "k": t(g["fixed/k"], torch.int64),
+                  "c": t(g["fixed/c"])}
+
+    def model(x, y, w):
+        a = pyro.sample("a", dist.Normal(t(0.0), 1.0))
+        b = pyro.sample("b", dist.Normal(t(0.0), 1.0))
+        k = pyro.sample("k", dist.Categorical(t([0.3, 0.3, 0.4])))
+        with pyro.plate("d", 4):
+            c = pyro.sample("c", dist.Normal(a, 1.0))
+            pyro.sample("x", dist.Normal(c, 0.5), obs=x)
+        pyro.sample("y", dist.Normal(b * b, 0.7), obs=y)
+        pyro.sample("w", dist.Bernoulli(table[k]), obs=w)
+
+    def guide(x, y, w):
+        qa = pyro.param("qa", t(0.2))
+        qb = pyro.param("qb", t(-0.3))
+        qc = pyro.param("qc", t([0.1, -0.1, 0.3, 0.0]))
+        qk = pyro.param("qk", t([0.2, 0.3, 0.5]), constraint=constraints.simplex)
+        a = pyro.sample("a", NonreparameterizedNormal(qa, 0.9),
+                        infer={"baseline": {"use_decaying_avg_baseline": True, "baseline_beta": 0.7}})
+        pyro.sample("b", NonreparameterizedNormal(qb, 1.1))
+        pyro.sample("k", dist.Categorical(qk))
+        with pyro.plate("d", 4):
+            pyro.sample("c", NonreparameterizedNormal(qc + 0.5 * a, 0.8))
+
+    pyro.clear_param_store()
+    for k_ in range(2):
+        fixed = poutine.trace(poutine.condition(guide, data=fixed_vals)).get_trace(x, y, w)
+        for name in fixed_vals:
+            fixed.nodes[name]["is_observed"] = False
+        for p_ in pyro.get_param_store()._params.values():
+            p_.grad = None
+        loss = TraceGraph_ELBO().loss_and_grads(model, poutine.replay(guide, trace=fixed), x, y, w)
+        np.testing.assert_allclose(loss, float(g["loss%d" % k_]), rtol=rtol)
+        grads = {n: v for n, v in store_grads().items() if not n.startswith("__baseline")}
+        assert_grads(grads, g, "grads%d" % k_, rtol * 10)
+        avg = pyro.get_param_store()["__baseline_avg_downstream_cost_a"].detach().cpu().numpy()
+        np.testing.assert_allclose(avg, g["avg%d" % k_], rtol=rtol * 10)
+
+
 # ---- Gamma-function families (Gamma / Beta latents, Poisson / Binomial likelihoods) ---------------
 def run_expfam(g, device, rtol, dtype=None):
     dtype = dtype or torch.get_default_dtype()

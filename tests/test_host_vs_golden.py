@@ -74,6 +74,41 @@ def test_tracegraph_baselines_match_reference(monkeypatch):
         torch.set_default_dtype(torch.float32)
 
 
+def test_tracegraph_provenance_matches_reference(monkeypatch):
+    """Downstream costs by data-flow provenance (tracegraph_elbo.py:178-236): the reference's
+    gradients on a program where they differ from the plate-only Rao-Blackwellisation."""
+    from tests import oracle_backend
+    oracle_backend.install(monkeypatch)
+    torch.set_default_dtype(torch.float64)
+    try:
+        models.run_tracegraph_provenance(load("tracegraph_prov"), torch.device("cpu"), 1e-9)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_provenance_tensor_propagation():
+    from pyro_amd.ops.provenance import (ProvenanceTensor, detach_provenance, get_provenance,
+                                         site_provenance, track_provenance)
+    a = track_provenance(torch.tensor([1.0, 2.0]), {"a"})
+    b = track_provenance(torch.tensor(3.0), {"b"})
+    k = track_provenance(torch.tensor(1), {"k"})
+    assert isinstance(a, ProvenanceTensor) and get_provenance(a) == {"a"}
+    assert get_provenance(a * 2 + 1) == {"a"} and get_provenance(a + b) == {"a", "b"}
+    assert get_provenance(torch.stack([a, a * b])) == {"a", "b"}
+    assert get_provenance(torch.tensor([0.1, 0.9])[k]) == {"k"}
+    assert get_provenance(torch.ones(2)) == frozenset()
+    assert get_provenance(track_provenance(a, {"c"})) == {"a", "c"}
+    plain = detach_provenance(a + b)
+    assert type(plain) is torch.Tensor and torch.equal(plain, torch.tensor([4.0, 5.0]))
+    d = torch.distributions.Independent(torch.distributions.Normal(a, 1.0), 1)
+    assert site_provenance({"value": torch.zeros(2), "fn": d, "mask": None, "scale": 1.0}) == {"a"}
+    assert site_provenance({"value": b, "fn": torch.distributions.Normal(0.0, 1.0)}) == {"b"}
+    # gradients flow through tagged tensors as through plain ones
+    p = torch.tensor(2.0, requires_grad=True)
+    (track_provenance(p * 1.0, {"z"}) * 3).backward()
+    assert p.grad.item() == 3.0
+
+
 def test_large_plated_site_takes_the_nd_route(monkeypatch):
     """A latent under a plate AND the particle plate scored against parameters that broadcast along
     the middle dim (config 5's w[P, G, D] ~ Normal(mu[P, 1, D], tau[P, 1, D])): the N-D site

@@ -79,6 +79,11 @@ def test_tracegraph_baselines_match_reference(gpu):
     models.run_tracegraph_baselines(load("tracegraph"), gpu, rtol=1e-9)
 
 
+def test_tracegraph_provenance_matches_reference(gpu):
+    torch.set_default_dtype(torch.float64)
+    models.run_tracegraph_provenance(load("tracegraph_prov"), gpu, rtol=1e-9)
+
+
 @pytest.mark.parametrize("tag", ["p1", "p5"])
 def test_trace_mean_field_elbo(gpu, monkeypatch, tag):
     """TraceMeanField_ELBO (analytic KL + sampled fall-back) against the reference's loss / grads."""
