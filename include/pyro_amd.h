@@ -503,6 +503,30 @@ int pa_lda_factor_indexed_fwd_bwd(int dtype, const int64_t* words, const void* i
                                   size_t workspace_bytes, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * One elimination step of the plated sum-product in log space (SURVEY 8a row a16, 8f rank 4;
+ * pyro/ops/contract.py:79-160 _contract_component, pyro/ops/einsum/torch_log.py:14-55):
+ *     out[kept] = logsumexp over frame dim `rdim` of  sum_k term_k[frame]
+ * `sizes[ndim]` is the frame (the union of the terms' dims after alignment), every term a strided
+ * view over it (stride 0 = the term does not depend on that dim: nothing is materialised), `out`
+ * contiguous over the frame without `rdim`.  An all -inf column gives -inf.
+ * The gradient entry point writes the one tensor every term's gradient is a reduction of:
+ *     G[frame] (contiguous) = g_out[kept] * exp( sum_k term_k[frame] - out[kept] )
+ * (the posterior weights of the eliminated variable; d out / d term_k = G summed over the dims the
+ * term does not have: pa_sum_to_nd).
+ * ---------------------------------------------------------------------------------- */
+#define PA_LSE_MAX_TERMS 4
+#define PA_LSE_MAX_DIMS 6
+typedef struct {
+  const void* ptr;
+  int64_t strides[PA_LSE_MAX_DIMS];   /* in elements, over the frame's dims */
+} pa_lse_term;
+int pa_logsumexp_terms(int dtype, void* out, int nterms, const pa_lse_term* terms, int ndim,
+                       const int64_t* sizes, int rdim, pa_stream_t stream);
+int pa_logsumexp_terms_grad(int dtype, void* G, const void* g_out, const void* out, int nterms,
+                            const pa_lse_term* terms, int ndim, const int64_t* sizes, int rdim,
+                            pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Flat multi-tensor Adam / ClippedAdam step (pyro/optim/optim.py:117-155,
  * pyro/optim/clipped_adam.py:52-100). One launch over the flat parameter buffer;
  * `step_dev` points to TWO device-resident int64: [0] the step counter, advanced by the kernel

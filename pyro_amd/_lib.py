@@ -54,6 +54,14 @@ class SiteEntry(Structure):
                 ("extra_coef", c_double)]
 
 
+LSE_MAX_TERMS, LSE_MAX_DIMS = 4, 6
+
+
+class LseTerm(Structure):
+    """pa_lse_term (include/pyro_amd.h)."""
+    _fields_ = [("ptr", c_void_p), ("strides", c_int64 * LSE_MAX_DIMS)]
+
+
 class MfSite(Structure):
     """pa_mf_site (include/pyro_amd.h)."""
     _fields_ = [("loc", c_void_p), ("rho", c_void_p), ("z", c_void_p), ("scale", c_void_p),
@@ -145,6 +153,10 @@ _SIGNATURES = {
     "pa_lda_factor_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "pa_logsumexp_terms": (c_int, [c_int, c_void_p, c_int, POINTER(LseTerm), c_int, POINTER(c_int64),
+                                   c_int, c_void_p]),
+    "pa_logsumexp_terms_grad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, POINTER(LseTerm),
+                                        c_int, POINTER(c_int64), c_int, c_void_p]),
     "pa_lda_index_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_lda_index_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_lda_build_index": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_size_t,

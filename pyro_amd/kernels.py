@@ -898,6 +898,55 @@ class NutsTree:
 # enumerated LDA factor
 # ------------------------------------------------------------------------------------------
 
+# ------------------------------------------------------------------------------------------
+# one elimination step of the plated sum-product (logsumexp of a sum of broadcast terms)
+# ------------------------------------------------------------------------------------------
+
+from ctypes import c_int64 as _c_int64  # noqa: E402
+
+
+def _lse_table(terms, frame):
+    arr = (_lib.LseTerm * len(terms))()
+    for k, t in enumerate(terms):
+        e = t.expand(frame)                       # stride 0 where the term does not depend on a dim
+        st = (_c_int64 * _lib.LSE_MAX_DIMS)(*([int(x) for x in e.stride()] +
+                                              [0] * (_lib.LSE_MAX_DIMS - len(frame))))
+        arr[k] = _lib.LseTerm(_ptr(t), st)
+    sizes = (_c_int64 * len(frame))(*[int(x) for x in frame])
+    return arr, sizes
+
+
+def logsumexp_terms(terms, frame, rdim):
+    """out = logsumexp over dim ``rdim`` of the sum of ``terms`` (tensors broadcastable to the
+    shape ``frame``; nothing of the frame's size is materialised).  Returns a contiguous tensor of
+    the frame's shape without ``rdim``."""
+    _require_gpu(*terms)
+    frame = tuple(int(x) for x in frame)
+    assert 1 <= len(terms) <= _lib.LSE_MAX_TERMS and 1 <= len(frame) <= _lib.LSE_MAX_DIMS
+    dtype = terms[0].dtype
+    assert all(t.dtype == dtype for t in terms)
+    kept = frame[:rdim] + frame[rdim + 1:]
+    out = torch.empty(kept, dtype=dtype, device=terms[0].device)
+    arr, sizes = _lse_table(terms, frame)
+    check(_lib.load().pa_logsumexp_terms(_DTYPES[dtype], _ptr(out), len(terms), arr, len(frame), sizes,
+                                         rdim, _stream()))
+    return out
+
+
+def logsumexp_terms_grad(terms, frame, rdim, out, g_out):
+    """G[frame] = g_out[kept] * exp(sum of terms - out[kept]): every term's gradient is G summed over
+    the dims the term does not have."""
+    _require_gpu(out, g_out, *terms)
+    frame = tuple(int(x) for x in frame)
+    dtype = terms[0].dtype
+    G = torch.empty(frame, dtype=dtype, device=terms[0].device)
+    g_out = g_out.contiguous()
+    arr, sizes = _lse_table(terms, frame)
+    check(_lib.load().pa_logsumexp_terms_grad(_DTYPES[dtype], _ptr(G), _ptr(g_out), _ptr(out),
+                                              len(terms), arr, len(frame), sizes, rdim, _stream()))
+    return G
+
+
 # The corpus does not change between ELBO-gradient steps: its inverted index (pa_lda_build_index) is
 # built once per tensor object and kept beside it, under the same policy as the GLM plane image
 # above (second sighting; never inside a capture; re-built into the same buffer when the tensor was

@@ -209,17 +209,61 @@ def _try_fused_chain(terms, sum_ids):
     return _LogChain.apply(U, P).reshape(tuple(batch))
 
 
+FUSED_SUMPRODUCT = True       # eliminations go through pa_logsumexp_terms (one pass, no frame tensor)
+
+
+class _LogSumExpTerms(torch.autograd.Function):
+    """logsumexp over one dim of the sum of up to four broadcast log-factors: ONE forward launch
+    reading every factor through its own strides (pa_logsumexp_terms), ONE backward launch writing
+    the posterior weights G (pa_logsumexp_terms_grad); a factor's gradient is G summed over the
+    dims the factor does not have (pa_sum_to_nd).  Replaces adds that materialise the frame,
+    torch.logsumexp's three passes, and the autograd duals of all of them."""
+
+    @staticmethod
+    def forward(ctx, frame, rdim, *terms):
+        out = kernels.logsumexp_terms(terms, frame, rdim)
+        ctx.frame, ctx.rdim = frame, rdim
+        ctx.save_for_backward(out, *terms)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..distributions.fused import _sum_to
+        out, terms = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        G = kernels.logsumexp_terms_grad(terms, ctx.frame, ctx.rdim, out, g)
+        grads = [_sum_to(G, t) if need else None
+                 for t, need in zip(terms, ctx.needs_input_grad[2:])]
+        return (None, None) + tuple(grads)
+
+
 def _sumproduct(terms, sum_ids):
     """logsumexp over the names ``sum_ids`` of the aligned sum of the terms -> (tensor, ids)."""
     ids = sorted(set().union(*(t.ids for t in terms))) if terms else []
-    total = None
-    for t in terms:
-        x = align(t, ids)
-        total = x if total is None else total + x
     drop = [i for i, v in enumerate(ids) if v in sum_ids]
+    keep_ids = [v for v in ids if v not in sum_ids]
+    aligned = [align(t, ids) for t in terms]
+    if FUSED_SUMPRODUCT and len(drop) == 1 and 1 <= len(aligned) <= 4:
+        x0 = aligned[0]
+        ok = all(isinstance(x, torch.Tensor) and x.dtype == x0.dtype and x.device == x0.device
+                 for x in aligned) and x0.dtype in (torch.float32, torch.float64) \
+            and (x0.is_cuda or kernels.HOST_TEST_BACKEND)
+        if ok:
+            nd = max(x.dim() for x in aligned)
+            # right-align the plate blocks: every term is [its ids..., *plates]; pad between the
+            # id dims and the plate dims so that all terms have the same rank
+            m = len(ids)
+            padded = [x if x.dim() == nd else x.reshape(tuple(x.shape[:m]) + (1,) * (nd - x.dim())
+                                                        + tuple(x.shape[m:])) for x in aligned]
+            frame = tuple(torch.broadcast_shapes(*(x.shape for x in padded)))
+            if len(frame) <= 6 and all(s > 0 for s in frame):
+                out = _LogSumExpTerms.apply(frame, drop[0], *padded)
+                return out, keep_ids
+    total = None
+    for x in aligned:
+        total = x if total is None else total + x
     if drop:
         total = torch.logsumexp(total, dim=drop)
-    return total, [v for v in ids if v not in sum_ids]
+    return total, keep_ids
 
 
 def _eliminate(terms, sum_ids):

@@ -361,6 +361,18 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
     return torch.as_tensor(out, dtype=dt), torch.as_tensor(gt, dtype=dt), torch.as_tensor(gp, dtype=dt)
 
 
+def logsumexp_terms(terms, frame, rdim):
+    from oracle import logsumexp as o_lse
+    out, _ = o_lse.logsumexp_terms([_np(t) for t in terms], tuple(frame), rdim)
+    return torch.as_tensor(out, dtype=terms[0].dtype)
+
+
+def logsumexp_terms_grad(terms, frame, rdim, out, g_out):
+    from oracle import logsumexp as o_lse
+    G = o_lse.logsumexp_terms_grad([_np(t) for t in terms], tuple(frame), rdim, _np(g_out))
+    return torch.as_tensor(G, dtype=terms[0].dtype)
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
               weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True,
               publish=None):
@@ -449,7 +461,8 @@ FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
-             "mvn_tril_sample_bwd", "logchain_fwd_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd"]
+             "mvn_tril_sample_bwd", "logchain_fwd_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd",
+             "logsumexp_terms", "logsumexp_terms_grad"]
 
 
 def install(monkeypatch):

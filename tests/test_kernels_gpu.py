@@ -808,6 +808,80 @@ def test_lda_factor_minus_inf_column(gpu):
 
 
 # ---------------------------------------------------------------------------------------------
+# one elimination step of the plated sum-product (logsumexp of a sum of broadcast terms)
+# ---------------------------------------------------------------------------------------------
+_LSE_CASES = [
+    # frame, reduced dim, term shapes (broadcastable to the frame)
+    ((16, 5000), 0, [(16, 1), (16, 5000)]),                         # mixture: weights + per-datum terms
+    ((7, 33), 0, [(7, 33)]),
+    ((4, 6, 50), 1, [(4, 6, 1), (1, 6, 50), (4, 1, 50)]),           # middle dim, three factors
+    ((3, 5, 2, 129), 1, [(3, 5, 1, 1), (1, 5, 2, 129), (3, 1, 2, 1), (1, 5, 1, 129)]),
+    ((8, 1, 1000), 0, [(8, 1, 1), (8, 1, 1000)]),
+    ((5,), 0, [(5,), (5,)]),
+    ((2, 3, 4, 5, 6, 7), 3, [(2, 1, 4, 5, 1, 7), (1, 3, 1, 5, 6, 1)]),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", range(len(_LSE_CASES)))
+def test_logsumexp_terms(gpu, dtype, case):
+    from oracle import logsumexp as o_lse
+    k = _k()
+    frame, rdim, shapes = _LSE_CASES[case]
+    rng = np.random.default_rng(case)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    terms = [(3 * rng.standard_normal(sh)).astype(np_dt) for sh in shapes]
+    terms[-1].reshape(-1)[::7] = -np.inf                      # impossible assignments
+    if case == 1:
+        terms[0][:, 3] = -np.inf                              # a whole column: out = -inf, G = 0
+    tts = [tt(t, gpu) for t in terms]
+    out = k.logsumexp_terms(tts, frame, rdim)
+    ref, _ = o_lse.logsumexp_terms(terms, frame, rdim)
+    tol = 2e-6 if dtype == torch.float32 else 1e-12
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=tol, atol=tol * 10)
+    g_out = rng.standard_normal(ref.shape).astype(np_dt)
+    G = k.logsumexp_terms_grad(tts, frame, rdim, out, tt(g_out, gpu))
+    refG = o_lse.logsumexp_terms_grad(terms, frame, rdim, g_out)
+    assert not torch.isnan(G).any()
+    np.testing.assert_allclose(G.cpu().numpy(), refG, rtol=tol * 20, atol=tol * 20)
+    # posterior weights sum to the upstream gradient over the eliminated variable
+    np.testing.assert_allclose(G.sum(rdim).cpu().numpy()[fin], g_out[fin], rtol=tol * 50, atol=tol * 50)
+
+
+def test_fused_sumproduct_equals_torch_route(gpu):
+    """ops.contract._sumproduct through pa_logsumexp_terms against its own torch route (aligned adds
+    + torch.logsumexp), values and the gradients of every term (reduced to the term's shape)."""
+    from pyro_amd.ops import contract as c
+    rng = np.random.default_rng(4)
+    ord_ = frozenset()
+    shapes = {("a", "b"): (3, 4, 1, 50), ("b",): (4, 2, 50), ("a",): (3, 2, 1), ("b", "a"): (4, 3, 1, 1)}
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 3e-6)):
+        res = []
+        for fused in (True, False):
+            c.FUSED_SUMPRODUCT = fused
+            try:
+                ts = [torch.tensor(rng0, dtype=dtype, device=gpu, requires_grad=True)
+                      for rng0 in [np.random.default_rng(7 + i).standard_normal(sh)
+                                   for i, sh in enumerate(shapes.values())]]
+                terms = [c.Term(t, ids, ord_) for t, ids in zip(ts, shapes)]
+                out, ids = c._sumproduct(terms, {"b"})
+                assert ids == ["a"]
+                grads = torch.autograd.grad(out.sum() * 1.5, ts)
+                res.append((out.detach(), grads))
+            finally:
+                c.FUSED_SUMPRODUCT = True
+        (o1, g1), (o2, g2) = res
+        np.testing.assert_allclose(o1.cpu().numpy(), o2.cpu().numpy(), rtol=tol, atol=tol)
+        for x, y in zip(g1, g2):
+            assert x.shape == y.shape
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=tol * 20, atol=tol * 20)
+
+
+# ---------------------------------------------------------------------------------------------
 # Adam
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("clipped", [False, True])
