@@ -503,6 +503,19 @@ int pa_lda_factor_indexed_fwd_bwd(int dtype, const int64_t* words, const void* i
                                   size_t workspace_bytes, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Dirichlet log-density rows (torch/distributions/dirichlet.py log_prob; the simplex-valued sites of
+ * examples/lda.py:45-60):  out[r] = sum_k xlogy(c[r,k]-1, x[r,k]) + lgamma(sum_k c[r,k]) - sum_k lgamma(c[r,k]).
+ * value / concentration: 2-D strided views [rows, K] (row stride 0 = one concentration vector for
+ * all rows).  Gradients (g[rows] upstream, outputs contiguous [rows, K], NULL = not wanted):
+ *   d_value[r,k] = g[r] (c-1)/x,  d_concentration[r,k] = g[r] (log x + psi(sum c) - psi(c_k)).
+ * ---------------------------------------------------------------------------------- */
+int pa_dirichlet_log_prob(int dtype, void* out, pa_view2d value, pa_view2d concentration,
+                          int64_t rows, int64_t K, pa_stream_t stream);
+int pa_dirichlet_log_prob_grad(int dtype, const void* g, pa_view2d value, pa_view2d concentration,
+                               int64_t rows, int64_t K, void* d_value, void* d_concentration,
+                               pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * One elimination step of the plated sum-product in log space (SURVEY 8a row a16, 8f rank 4;
  * pyro/ops/contract.py:79-160 _contract_component, pyro/ops/einsum/torch_log.py:14-55):
  *     out[kept] = logsumexp over frame dim `rdim` of  sum_k term_k[frame]

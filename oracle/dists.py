@@ -92,6 +92,25 @@ def binomial_logits_log_prob(v, logits, total_count):
     return v * logits - n * _softplus(logits) + gammaln(n + 1) - gammaln(v + 1) - gammaln(n - v + 1)
 
 
+def dirichlet_log_prob(x, concentration):
+    """torch: torch/distributions/dirichlet.py log_prob
+    (xlogy(concentration - 1, value).sum(-1) + lgamma(concentration.sum(-1)) - lgamma(concentration).sum(-1))."""
+    from scipy.special import gammaln
+    c = np.asarray(concentration, dtype=np.float64)
+    return _xlogy(c - 1, x).sum(-1) + gammaln(c.sum(-1)) - gammaln(c).sum(-1)
+
+
+def dirichlet_log_prob_grad(g, x, concentration):
+    """(d/dx, d/dconcentration) of sum(g * log_prob), both of the broadcast [..., K] shape."""
+    from scipy.special import digamma
+    x = np.asarray(x, dtype=np.float64)
+    c = np.asarray(concentration, dtype=np.float64)
+    shape = np.broadcast(x, c).shape
+    x, c = np.broadcast_to(x, shape), np.broadcast_to(c, shape)
+    g = np.broadcast_to(np.asarray(g, dtype=np.float64), shape[:-1])[..., None]
+    return g * (c - 1) / x, g * (np.log(x) + digamma(c.sum(-1, keepdims=True)) - digamma(c))
+
+
 def kl_normal_normal(lq, sq, lp, sp):
     """torch: torch/distributions/kl.py _kl_normal_normal."""
     var_ratio = (sq / sp) ** 2

@@ -58,8 +58,25 @@ def _backend(name):
     return importlib.import_module(name)
 
 
+def _check_sizes(ins, operands):
+    """opt_einsum validates label sizes before contracting (its error text is what the reference's
+    tests match on: tests/ops/test_contract.py:727-733)."""
+    sizes = {}
+    for k, (labels, op) in enumerate(zip(ins, operands)):
+        shape = getattr(op, "shape", None)
+        if shape is None or len(shape) != len(labels):
+            continue
+        for c, n in zip(labels, shape):
+            n = int(n)
+            if c in sizes and sizes[c] != n and 1 not in (sizes[c], n):
+                raise ValueError("Size of label '{}' for operand {} ({}) does not match previous "
+                                 "terms ({}).".format(c, k, n, sizes[c]))
+            sizes[c] = max(sizes.get(c, 1), n)
+
+
 def contract(equation, *operands, backend="auto", **kwargs):
     ins, out = _parse(equation, len(operands))
+    _check_sizes(ins, operands)
     be = _backend(backend)
     cache = sharing.current_cache()
     ins = list(ins)

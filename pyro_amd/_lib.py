@@ -153,6 +153,9 @@ _SIGNATURES = {
     "pa_lda_factor_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "pa_dirichlet_log_prob": (c_int, [c_int, c_void_p, View2D, View2D, c_int64, c_int64, c_void_p]),
+    "pa_dirichlet_log_prob_grad": (c_int, [c_int, c_void_p, View2D, View2D, c_int64, c_int64,
+                                           c_void_p, c_void_p, c_void_p]),
     "pa_logsumexp_terms": (c_int, [c_int, c_void_p, c_int, POINTER(LseTerm), c_int, POINTER(c_int64),
                                    c_int, c_void_p]),
     "pa_logsumexp_terms_grad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, POINTER(LseTerm),

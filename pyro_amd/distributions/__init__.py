@@ -8,14 +8,14 @@ from torch.distributions import biject_to, transform_to, kl_divergence  # noqa: 
 
 from .base import (Delta, MaskedDistribution, ScoreParts, TorchDistribution,  # noqa: F401
                    TorchDistributionMixin, Unit)
-from .families import (Bernoulli, Beta, Binomial, Exponential, Gamma,  # noqa: F401
+from .families import (Bernoulli, Beta, Binomial, Dirichlet, Exponential, Gamma,  # noqa: F401
                        GroupedLinearLogits, HalfCauchy, HalfNormal, LinearLogits, LogNormal, Normal,
                        Poisson, grouped_linear_logits, linear_logits)
 from .util import enable_validation, is_validation_enabled  # noqa: F401
 
 # ---- everything else: torch.distributions + mixin, arithmetic by ATen on the GPU ----------------
 _FUSED = {"Normal", "Bernoulli", "HalfCauchy", "HalfNormal", "LogNormal", "Exponential",
-          "Gamma", "Beta", "Poisson", "Binomial"}
+          "Gamma", "Beta", "Poisson", "Binomial", "Dirichlet"}
 __all__ = ["Delta", "Unit", "MaskedDistribution", "TorchDistribution", "ScoreParts",
            "LinearLogits", "linear_logits", "GroupedLinearLogits", "grouped_linear_logits"] + sorted(_FUSED)
 

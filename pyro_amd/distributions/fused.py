@@ -242,6 +242,27 @@ class _LogProbSum(torch.autograd.Function):
         return (None,) + tuple(outs) + (None, None)
 
 
+class _DirichletLogProb(torch.autograd.Function):
+    """Dirichlet.log_prob in one launch each way (pa_dirichlet_log_prob / _grad)."""
+
+    @staticmethod
+    def forward(ctx, value, concentration):
+        ctx.save_for_backward(value, concentration)
+        return kernels.dirichlet_log_prob(value, concentration)
+
+    @staticmethod
+    def backward(ctx, g):
+        value, conc = ctx.saved_tensors
+        dv, dc = kernels.dirichlet_log_prob_grad(g, value, conc, ctx.needs_input_grad[0],
+                                                 ctx.needs_input_grad[1])
+        return (None if dv is None else _sum_to(dv, value),
+                None if dc is None else _sum_to(dc, conc))
+
+
+def dirichlet_log_prob(value, concentration):
+    return _DirichletLogProb.apply(value, concentration)
+
+
 class _NormalRsample(torch.autograd.Function):
     """value = loc + scale * eps with eps from the Philox stream, ONE launch (pa_normal_rsample);
     backward: d loc = g, d scale = g * eps (torch: normal.py:83-86)."""

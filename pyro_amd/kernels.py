@@ -899,6 +899,61 @@ class NutsTree:
 # ------------------------------------------------------------------------------------------
 
 # ------------------------------------------------------------------------------------------
+# Dirichlet log-density rows
+# ------------------------------------------------------------------------------------------
+
+def dirichlet_log_prob(value, concentration):
+    """value [..., K] on the simplex, concentration [..., K] or [K] -> log-density [...]."""
+    _require_gpu(value, concentration)
+    K = value.shape[-1]
+    batch = torch.broadcast_shapes(value.shape[:-1], concentration.shape[:-1])
+    rows = 1
+    for n in batch:
+        rows *= int(n)
+    keep = []
+    views = []
+    for t in (value, concentration):
+        if t.numel() != K:
+            t = t.expand(batch + (K,)).reshape(rows, K)     # (a copy only for a partial broadcast)
+            keep.append(t)
+            views.append(_lib.View2D(_ptr(t), t.stride(0), t.stride(1)))
+        else:
+            t = t.reshape(K)
+            keep.append(t)
+            views.append(_lib.View2D(_ptr(t), 0, t.stride(0)))
+    out = torch.empty(batch, dtype=value.dtype, device=value.device)
+    check(_lib.load().pa_dirichlet_log_prob(_dtype(value), _ptr(out), views[0], views[1], rows, K,
+                                            _stream()))
+    return out
+
+
+def dirichlet_log_prob_grad(g, value, concentration, need_value, need_conc):
+    """Gradients of sum(g * log_prob): (d_value, d_concentration) as [rows..., K] tensors of the
+    BROADCAST batch shape (the caller reduces a broadcast operand's gradient), None where unwanted."""
+    _require_gpu(g, value, concentration)
+    K = value.shape[-1]
+    batch = torch.broadcast_shapes(value.shape[:-1], concentration.shape[:-1])
+    rows = 1
+    for n in batch:
+        rows *= int(n)
+    keep, views = [], []
+    for t in (value, concentration):
+        if t.numel() != K:
+            t = t.expand(batch + (K,)).reshape(rows, K)
+            views.append(_lib.View2D(_ptr(t), t.stride(0), t.stride(1)))
+        else:
+            t = t.reshape(K)
+            views.append(_lib.View2D(_ptr(t), 0, t.stride(0)))
+        keep.append(t)
+    g = g.expand(batch).contiguous()
+    dv = torch.empty(batch + (K,), dtype=value.dtype, device=value.device) if need_value else None
+    dc = torch.empty(batch + (K,), dtype=value.dtype, device=value.device) if need_conc else None
+    check(_lib.load().pa_dirichlet_log_prob_grad(_dtype(value), _ptr(g), views[0], views[1], rows, K,
+                                                 _ptr(dv), _ptr(dc), _stream()))
+    return dv, dc
+
+
+# ------------------------------------------------------------------------------------------
 # one elimination step of the plated sum-product (logsumexp of a sum of broadcast terms)
 # ------------------------------------------------------------------------------------------
 

@@ -155,6 +155,17 @@ def g_dists():
     flat["kl_normal/kl"] = kl.detach().numpy()
     for k, x in zip(("dlq", "dsq", "dlp", "dsp"), gs):
         flat["kl_normal/" + k] = x.numpy()
+    # Dirichlet rows (examples/lda.py:45-60): a shared concentration vector and per-row ones
+    for tag, cshape in (("dirichlet_shared", (5,)), ("dirichlet_rows", (6, 5))):
+        c = rng.uniform(0.2, 6, cshape)
+        xx = rng.dirichlet(np.ones(5), 6)
+        tx = torch.tensor(xx, requires_grad=True)
+        tc = torch.tensor(c, requires_grad=True)
+        lp = dist.Dirichlet(tc).log_prob(tx)
+        w = torch.tensor(rng.standard_normal(6))
+        gx, gc = torch.autograd.grad((lp * w).sum(), [tx, tc])
+        flat[tag + "/x"], flat[tag + "/c"], flat[tag + "/w"] = xx, c, w.numpy()
+        flat[tag + "/lp"], flat[tag + "/dx"], flat[tag + "/dc"] = lp.detach().numpy(), gx.numpy(), gc.numpy()
     save("dists", **flat)
 
 

@@ -178,6 +178,50 @@ def test_gamma_function_family_classes(gpu, fam, dist_id, dtype):
     np.testing.assert_allclose(e.log_prob(tv).detach().cpu().numpy()[1], ref_lp, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("rows,K,shared", [(1000, 8, True), (1000, 8, False), (8, 1024, False),
+                                           (3, 70, True), (1, 2, False), (40000, 5, True)])
+def test_dirichlet_log_prob_and_grad(gpu, dtype, rows, K, shared):
+    """pa_dirichlet_log_prob / _grad (thread-per-row for K <= 32, wave-per-row above) against the
+    oracle, with a concentration vector shared by all rows read through row stride 0."""
+    k = _k()
+    rng = np.random.default_rng(rows + K)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    x = rng.dirichlet(np.ones(K) * 0.7, rows).astype(np_dt)
+    x = np.maximum(x, 1e-30).astype(np_dt)
+    c = rng.uniform(0.1, 8, (K,) if shared else (rows, K)).astype(np_dt)
+    w = rng.standard_normal(rows).astype(np_dt)
+    tx, tc, tw = tt(x, gpu), tt(c, gpu), tt(w, gpu)
+    tol = 1e-4 if dtype == torch.float32 else 1e-11
+    lp = k.dirichlet_log_prob(tx, tc)
+    ref = o_dists.dirichlet_log_prob(x.astype(np.float64), c.astype(np.float64))
+    np.testing.assert_allclose(lp.cpu().numpy(), ref, rtol=tol, atol=tol * max(1.0, np.abs(ref).max()))
+    dx, dc = k.dirichlet_log_prob_grad(tw, tx, tc, True, True)
+    rdx, rdc = o_dists.dirichlet_log_prob_grad(w, x.astype(np.float64), c.astype(np.float64))
+    np.testing.assert_allclose(dx.cpu().numpy(), rdx, rtol=tol * 3, atol=tol * 3 * np.abs(rdx).max())
+    np.testing.assert_allclose(dc.cpu().numpy(), rdc, rtol=tol * 3, atol=tol * 3 * np.abs(rdc).max())
+
+
+@pytest.mark.parametrize("tag", ["dirichlet_shared", "dirichlet_rows"])
+def test_dirichlet_class_vs_reference_fixture(gpu, tag):
+    """pyro_amd.distributions.Dirichlet: the reference's log_prob and autograd gradients (f64),
+    also through expand over a plate."""
+    import os
+    import pyro_amd.distributions as d
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dists.npz"))
+    tx = torch.tensor(g[tag + "/x"], device=gpu, requires_grad=True)
+    tc = torch.tensor(g[tag + "/c"], device=gpu, requires_grad=True)
+    w = torch.tensor(g[tag + "/w"], device=gpu)
+    dd = d.Dirichlet(tc)
+    if tc.dim() == 1:
+        dd = dd.expand((6,))
+    lp = dd.log_prob(tx)
+    np.testing.assert_allclose(lp.detach().cpu().numpy(), g[tag + "/lp"], rtol=1e-11)
+    gx, gc = torch.autograd.grad((lp * w).sum(), [tx, tc])
+    np.testing.assert_allclose(gx.cpu().numpy(), g[tag + "/dx"], rtol=1e-10)
+    np.testing.assert_allclose(gc.cpu().numpy(), g[tag + "/dc"], rtol=1e-10, atol=1e-11)
+
+
 def test_dist_empty_and_errors(gpu):
     k = _k()
     v = torch.zeros((4, 0), device=gpu)
