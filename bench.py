@@ -328,8 +328,16 @@ def main():
             r4 = bench_configs.config4(dev, steps=10)
             r4["workload"] = ("BASELINE configs[3]: examples/lda.py, TraceEnum_ELBO, 1e5 documents (all "
                               "in the plate), 8 topics, 1024 words, 64 words per document, amortised "
-                              "guide; word_topics enumerated and summed out by the fused LDA kernel")
+                              "guide; word_topics enumerated and summed out by the indexed LDA kernels "
+                              "(no atomics); graphed SVI.step; ~2.4 ms of the step are the example "
+                              "guide's own rocBLAS products over the 1e5 x 1024 count matrix")
             others["config4_lda"] = r4
+            for bs in (32, 4096):      # the mini-batch variants SURVEY 8(d) lists
+                rb = bench_configs.config4(dev, steps=30, batch_size=bs)
+                rb["workload"] = ("examples/lda.py with batch_size=%d of 1e5 documents per step (a fresh "
+                                  "sub-sampled word matrix every step: LDS-atomic factor kernel), "
+                                  "graphed SVI.step" % bs)
+                others["config4_lda_batch%d" % bs] = rb
             r1 = bench_configs.config1(dev)
             r1["workload"] = ("BASELINE configs[0]: eight schools, Trace_ELBO, 1 particle, Adam; graphed "
                               "SVI.step (the reference's own CPU-runnable case: ~58 steps/s there)")

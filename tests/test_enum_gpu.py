@@ -194,3 +194,26 @@ def test_backwardsample_posterior(gpu):
     pkc.run_backwardsample_2(gpu)
     pkc.run_backwardsample_3(gpu)
     pkc.run_backwardsample_hmm_joint(gpu)
+
+
+def test_lda_minibatch_graphed_steps_draw_the_eager_subsamples(gpu):
+    """examples/lda.py with batch_size (a fresh sub-sampled word matrix per step) under
+    SVI(hip_graph=True): every replay draws a NEW subsample -- the same one the eager step draws --
+    so the loss sequences agree step for step (learning rate 0: the parameters stay put)."""
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, TraceEnum_ELBO
+    args = examples.LdaArgs(num_docs=3000)
+    data = examples.synthetic_lda_data(args, gpu)
+    seqs = []
+    for graph in (False, True):
+        pyro.clear_param_store(); pyro.set_rng_seed(0); torch.manual_seed(0)
+        predictor = examples.lda_make_predictor(args, gpu)
+        guide = lambda data, args: examples.lda_guide(predictor, data, args, 64)  # noqa: E731
+        svi = SVI(examples.lda_model, guide, pyro.optim.ClippedAdam({"lr": 0.0}),
+                  TraceEnum_ELBO(max_plate_nesting=2), hip_graph=graph, graph_warmup=3)
+        seqs.append([svi.step(data, args) for _ in range(9)])
+        if graph:
+            assert len(svi._graphs) == 1
+    assert len(set(seqs[0])) == 9                       # nine different subsamples
+    np.testing.assert_allclose(seqs[0], seqs[1], rtol=1e-6)

@@ -136,19 +136,22 @@ def config_hmm(dev, S=229, L=129, K=16, D=88, steps=5, fused=True, graph=False):
             "fused_chain": fused, "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1)}
 
 
-def config4(dev, docs=100_000, steps=10):
+def config4(dev, docs=100_000, steps=10, batch_size=None):
+    """batch_size=None: every document in every step (BASELINE configs[3] as quoted); 32 / 4096: the
+    mini-batch variants SURVEY 8(d) lists (examples/lda.py's own default is 32): the sub-sampled
+    word matrix is a fresh tensor every step, so the factor takes the LDS-atomic kernel."""
     args = examples.LdaArgs(num_docs=docs)
     data = examples.synthetic_lda_data(args, dev)
     pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
     predictor = examples.lda_make_predictor(args, dev)
-    guide = lambda data, args: examples.lda_guide(predictor, data, args)  # noqa: E731
+    guide = lambda data, args: examples.lda_guide(predictor, data, args, batch_size)  # noqa: E731
     # examples/lda.py:131 uses ClippedAdam: here the flat fused one (one launch for all parameters,
     # the predictor's weights included)
     svi = SVI(examples.lda_model, guide, pyro.optim.ClippedAdam({"lr": 0.01}), TraceEnum_ELBO(max_plate_nesting=2),
               hip_graph=True, graph_warmup=3)
     dt = timed(lambda: svi.step(data, args), steps, 6)
-    pairs = docs * args.num_words_per_doc
-    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
+    pairs = (docs if batch_size is None else batch_size) * args.num_words_per_doc
+    return {"batch_size": batch_size, "steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
             "graphed": bool(svi.hip_graph and len(svi._graphs) == 1),
             "algorithmic_TBps": pairs * 8.5 / dt / 1e12}
 
