@@ -1,5 +1,5 @@
 """HMC / NUTS, vectorised over chains on the GPU (reference: pyro/infer/mcmc/__init__.py)."""
-from .adaptation import WarmupAdapter  # noqa: F401
+from .adaptation import ArrowheadMassMatrix, WarmupAdapter  # noqa: F401
 from .api import MCMC  # noqa: F401
 from .hmc import HMC  # noqa: F401
 from .mcmc_kernel import MCMCKernel  # noqa: F401

@@ -166,6 +166,103 @@ class DenseMassMatrix:
         return kernels.chain_matvec(self._L, grad.contiguous(), transpose=True)
 
 
+SymmArrowhead = namedtuple("SymmArrowhead", ["top", "bottom_diag"])
+
+
+class ArrowheadMassMatrix:
+    """What the user assigns -- ``kernel.mass_matrix_adapter = ArrowheadMassMatrix()`` before
+    ``MCMC.run`` (reference: adaptation.py:395-580, tests/infer/mcmc/test_nuts.py:506-546): the MASS
+    matrix is adapted, from the potential's GRADIENTS, with arrowhead structure -- the sites named in
+    the kernel's ``full_mass`` form the dense head (their rows / columns are full), every other
+    coordinate keeps only its diagonal entry.  ``WarmupAdapter.configure`` turns it into the
+    per-chain device object below."""
+
+    def __init__(self, init_scale=1.0):
+        self._init_scale = float(init_scale)
+
+
+def head_indices(layout, dense_mass):
+    """Flat indices of the arrowhead's head in the order the sites are named in ``full_mass``
+    (adaptation.py:458-474: dense blocks first, concatenated), then of the tail."""
+    head = []
+    if dense_mass is True:
+        head = list(range(layout.D))
+    elif dense_mass:
+        for block in dense_mass:
+            for name in block:
+                a, b = layout.slices[name]
+                head.extend(range(a, b))
+    taken = set(head)
+    tail = [i for i in range(layout.D) if i not in taken]
+    return head, tail
+
+
+class ArrowheadDenseMassMatrix(DenseMassMatrix):
+    """Per-chain arrowhead mass matrix M[C, D, D] (zero outside the head's rows / columns and the
+    diagonal), adapted as the regularised covariance of the potential's gradients
+    (WelfordArrowheadCovariance, pyro/ops/welford.py:55-101: the entries an arrowhead keeps are the
+    same entries of the full Welford estimate).  The samplers only need V = M^-1 and its Cholesky
+    factor, which the dense machinery above provides (whitened coordinates, pa_chain_matvec): the
+    arrowhead is held as a dense [D, D] per chain -- O(D^2) memory instead of the reference's
+    O(D x head), same transitions.  If the masked estimate is not positive definite the head-tail
+    block is halved and the factorisation retried, up to six times (pyro/ops/arrowhead.py:30-52)."""
+
+    uses_grad = True
+
+    def __init__(self, C, D, dtype, device, head, tail, init_scale=1.0, adapt=True):
+        self._head = torch.tensor(head, dtype=torch.int64, device=device)
+        self._tail = torch.tensor(tail, dtype=torch.int64, device=device)
+        mask = torch.eye(D, dtype=dtype, device=device)
+        if head:
+            mask[self._head, :] = 1.0
+            mask[:, self._head] = 1.0
+        self._arrow_mask = mask
+        cross = torch.zeros((D, D), dtype=dtype, device=device)      # the head-tail block B and B^T
+        if head and tail:
+            cross[self._head.unsqueeze(-1), self._tail.unsqueeze(0)] = 1.0
+            cross[self._tail.unsqueeze(-1), self._head.unsqueeze(0)] = 1.0
+        self._cross = cross
+        self._mass = None
+        super().__init__(C, D, dtype, device, mask=None, init_scale=1.0, adapt=adapt)
+        eye = torch.eye(D, dtype=dtype, device=device) * float(init_scale)
+        self.mass_matrix_dense = eye.expand(C, D, D)
+
+    @property
+    def mass_matrix_dense(self):
+        return self._mass
+
+    @mass_matrix_dense.setter
+    def mass_matrix_dense(self, M):
+        M = (M * self._arrow_mask).contiguous()
+        self._mass = M                 # as assigned (the reference keeps the un-halved matrix too)
+        for attempt in range(6):
+            _, info = torch.linalg.cholesky_ex(M)
+            bad = info != 0
+            if not bool(bad.any()):
+                break
+            # halve the head-tail block of the chains whose matrix is not positive definite
+            M = torch.where(bad.reshape(-1, 1, 1) & (self._cross > 0), M * 0.5, M)
+        else:
+            raise RuntimeError("Singular schur complement in computing Cholesky of the input "
+                               "arrowhead matrix")
+        self.inverse_mass_matrix = torch.cholesky_inverse(torch.linalg.cholesky(M))
+
+    @property
+    def mass_matrix(self):
+        """SymmArrowhead(top [C, head, D], bottom_diag [C, D - head]) with the coordinates in the
+        reference's order: head sites as named in ``full_mass``, then the others."""
+        order = torch.cat([self._head, self._tail])
+        M = self._mass[:, order][:, :, order]
+        h = self._head.numel()
+        return SymmArrowhead(M[:, :h, :], torch.diagonal(M, dim1=-2, dim2=-1)[:, h:])
+
+    def update(self, z_grad):
+        self._scheme.update(z_grad.detach())
+
+    def end_adaptation(self):
+        self.mass_matrix_dense = self._scheme.get_covariance(regularize=True)
+
+
 def block_mask(layout, dense_mass):
     """0/1 matrix [D, D] of the mass-matrix structure over a flat Layout: ``dense_mass`` True =
     one dense block over all sites; a list of site-name tuples = one dense block per tuple, the
@@ -198,6 +295,7 @@ class WarmupAdapter:
         self.adapt_mass_matrix = adapt_mass_matrix
         self.target_accept_prob = target_accept_prob
         self.dense_mass = dense_mass
+        self.arrowhead = None          # an ArrowheadMassMatrix prototype assigned by the user
         self._init_step_size = 1 if step_size is None else step_size
         self.step_size = None           # tensor [C] after configure
         self._adaptation_disabled = not (adapt_step_size or adapt_mass_matrix)
@@ -224,7 +322,12 @@ class WarmupAdapter:
         else:
             self.step_size = torch.full((C,), float(s), dtype=dtype, device=device)
         self._find_reasonable_step_size = find_reasonable_step_size_fn
-        if self.dense_mass:
+        if self.arrowhead is not None:
+            head, tail = head_indices(layout, self.dense_mass)
+            self.mass_matrix_adapter = ArrowheadDenseMassMatrix(
+                C, D, dtype, device, head, tail, init_scale=self.arrowhead._init_scale,
+                adapt=self.adapt_mass_matrix)
+        elif self.dense_mass:
             mask = block_mask(layout, self.dense_mass) if layout is not None else None
             self.mass_matrix_adapter = DenseMassMatrix(C, D, dtype, device, mask=mask,
                                                        adapt=self.adapt_mass_matrix)
@@ -269,7 +372,8 @@ class WarmupAdapter:
             # NaN acceptance probabilities (diverged chains) count as 0, as exp(-inf) does
             self._update_step_size(torch.nan_to_num(accept_prob, nan=0.0))
         if mass_matrix_adaptation_phase:
-            self.mass_matrix_adapter.update(z)
+            mm = self.mass_matrix_adapter
+            self.mass_matrix_adapter.update(z_grad if getattr(mm, "uses_grad", False) else z)
         if t == window.end:
             if self._current_window == num_windows - 1:
                 self._current_window += 1

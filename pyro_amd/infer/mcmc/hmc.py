@@ -100,6 +100,16 @@ class HMC(MCMCKernel):
     def mass_matrix_adapter(self):
         return self._adapter.mass_matrix_adapter
 
+    @mass_matrix_adapter.setter
+    def mass_matrix_adapter(self, value):
+        """``kernel.mass_matrix_adapter = ArrowheadMassMatrix()`` (reference: hmc.py:334-347): the
+        head of the arrowhead is the sites of ``full_mass``; takes effect at the next setup."""
+        from .adaptation import ArrowheadMassMatrix
+        if not isinstance(value, ArrowheadMassMatrix):
+            raise TypeError("mass_matrix_adapter accepts an ArrowheadMassMatrix()")
+        self._adapter.arrowhead = value
+        self._dense = True          # the samplers run in the whitened coordinates of M^-1
+
     @property
     def inverse_mass_matrix(self):
         return self.mass_matrix_adapter.inverse_mass_matrix
@@ -290,7 +300,11 @@ class HMC(MCMCKernel):
             self._divergences.append(diverging)
         else:
             n = self._t
-            self._adapter.step(self._t, self._position(), accept_prob, None)
+            mm = self.mass_matrix_adapter
+            z_grad = None
+            if getattr(mm, "uses_grad", False):     # model-coordinates gradient: L^-T grad'
+                z_grad = mm.scale(self._grad)
+            self._adapter.step(self._t, self._position(), accept_prob, z_grad)
             self._sync_coordinates()      # a window may have ended: new mass, new coordinates
         self._mean_accept_prob += (torch.nan_to_num(accept_prob, nan=0.0)
                                    - self._mean_accept_prob) / n

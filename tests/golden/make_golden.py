@@ -1052,6 +1052,50 @@ def g_tracegraph_prov():
 
 
 # ---------------------------------------------------------------------------------------------
+# ArrowheadMassMatrix (adaptation.py:395-580, ops/arrowhead.py, ops/welford.py:55-101): the mass
+# matrix adapted from gradient samples, its inverse, and the three products, from the reference.
+# ---------------------------------------------------------------------------------------------
+def g_arrowhead():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer.mcmc.adaptation import ArrowheadMassMatrix
+    from pyro.ops.arrowhead import SymmArrowhead
+    rng = np.random.default_rng(47)
+    D, h = 6, 4
+    flat = {}
+    A = rng.standard_normal((D, 2 * D))
+    prec = A @ A.T * 0.1
+    grads = rng.multivariate_normal(np.zeros(D), prec, size=40)
+    for tag in ("adapted", "not_pd"):
+        mm = ArrowheadMassMatrix()
+        shapes = {("a", "b"): (h, h), ("c",): (D - h,)}
+        mm.configure(shapes, adapt_mass_matrix=True, options={"dtype": torch.float64})
+        names = ("a", "b", "c")
+        if tag == "adapted":
+            for g_ in grads:
+                t = torch.tensor(g_)
+                mm.update(None, {"a": t[:2], "b": t[2:4], "c": t[4:]})
+            mm.end_adaptation()
+        else:     # a head-tail block too large for positive definiteness: the sqrt halves it
+            top = torch.eye(h, D)
+            top[:, h:] = 0.9
+            mm.mass_matrix = {names: SymmArrowhead(top, torch.ones(D - h))}
+        M = mm.mass_matrix[names]
+        flat[tag + "/top"], flat[tag + "/bottom_diag"] = M.top.numpy(), M.bottom_diag.numpy()
+        flat[tag + "/inverse_mass"] = mm.inverse_mass_matrix[names].numpy()
+        r = torch.tensor(rng.standard_normal(D))
+        rd = {"a": r[:2], "b": r[2:4], "c": r[4:]}
+        v = mm.kinetic_grad(rd)
+        flat[tag + "/r"] = r.numpy()
+        flat[tag + "/kinetic_grad"] = torch.cat([v[n] for n in names]).numpy()
+        u = mm.unscale(rd)[names]
+        flat[tag + "/unscale"] = u.numpy()
+        sc = mm.scale({names: r}, rd)
+        flat[tag + "/scale"] = torch.cat([sc[n] for n in names]).numpy()
+    flat["grads"] = grads
+    save("arrowhead", **flat)
+
+
+# ---------------------------------------------------------------------------------------------
 # G14: guide-side parallel enumeration with DiCE (traceenum_elbo.py:112-214, infer/util.py:196-326):
 #      the "auto" programs of tests/infer/test_enum.py:2121-2208 (everything inside one masked
 #      plate, x enumerated in the guide, y in the model) and :1823-1866 (no plate), plus a
@@ -1307,7 +1351,7 @@ def g_marginals():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov", "arrowhead"]
     for w in which:
         globals()["g_" + w]()
 

@@ -652,3 +652,42 @@ def run_gaussian_chain(device, case, kernel="nuts", dtype=torch.float32, C=8, **
         e_mean = (latent.mean(0) - exp_mean).pow(2).mean().sqrt().item()
         e_std = (latent.std(0) - exp_std).pow(2).mean().sqrt().item()
         assert e_mean < mean_tol and e_std < std_tol, (case, i, e_mean, e_std)
+
+
+def run_arrowhead_mass(device, dtype=torch.float32, warmup=1000, C=4):
+    """tests/infer/mcmc/test_nuts.py:506-546 test_arrowhead_mass: NUTS with
+    ``kernel.mass_matrix_adapter = ArrowheadMassMatrix()`` and full_mass=[("w",), ("y", "x")] adapts
+    an arrowhead MASS matrix (head = w, y, x; tail = z diagonal) from the potential's gradients; its
+    head rows and tail diagonal approach those of the target precision (atol = rtol = 0.2 as in the
+    reference, per chain)."""
+    from pyro_amd.infer.mcmc import ArrowheadMassMatrix
+
+    def model(prec):
+        def wide(n):
+            return dist.Normal(torch.zeros(n, dtype=dtype, device=device), 1000.0).to_event(1)
+        w = pyro.sample("w", wide(2))
+        x = pyro.sample("x", wide(1))
+        y = pyro.sample("y", wide(1))
+        z = pyro.sample("z", wide(2))
+        wyxz = torch.cat([w, y, x, z], dim=-1)
+        pyro.sample("obs", dist.MultivariateNormal(torch.zeros(6, dtype=dtype, device=device),
+                                                   precision_matrix=prec), obs=wyxz)
+
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(6, 12, generator=g, dtype=torch.float64)
+    prec = (A @ A.t() * 0.1).to(dtype=dtype, device=device)
+    pyro.set_rng_seed(2)
+    kernel = NUTS(model, full_mass=[("w",), ("y", "x")], max_tree_depth=7)
+    kernel.mass_matrix_adapter = ArrowheadMassMatrix()
+    mcmc = MCMC(kernel, num_samples=1, warmup_steps=warmup, num_chains=C)
+    mcmc.run(prec)
+    top, bottom = kernel.mass_matrix_adapter.mass_matrix       # reference order: w, y, x | z
+    assert tuple(top.shape) == (C, 4, 6) and tuple(bottom.shape) == (C, 2)
+    for c in range(C):
+        torch.testing.assert_close(top[c], prec[:4], atol=0.2, rtol=0.2)
+        torch.testing.assert_close(bottom[c], prec.diagonal()[4:], atol=0.2, rtol=0.2)
+    # the structure: the tail block of the mass matrix is diagonal
+    M = kernel.mass_matrix_adapter.mass_matrix_dense
+    sl = kernel._layout.slices
+    z0, z1 = sl["z"]
+    assert float(M[:, z0, z1 - 1].abs().max()) == 0.0

@@ -237,6 +237,10 @@ def test_structured_mass(gpu):
     mc.run_structured_mass(gpu)
 
 
+def test_arrowhead_mass(gpu):
+    mc.run_arrowhead_mass(gpu)
+
+
 @pytest.mark.parametrize("full_mass", [False, True], ids=["diag_mass", "dense_mass"])
 def test_jit_compile_replays_the_potential_as_a_graph(gpu, full_mass):
     """NUTS(model, jit_compile=True): the potential (model under the chains plate + backward, with

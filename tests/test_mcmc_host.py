@@ -243,3 +243,41 @@ def test_initialize_model_redraws_non_finite_starting_points(_cpu_backend):
         assert bool(torch.isfinite(pe).all())
         with pytest.raises(ValueError, match="cannot find valid initial params"):
             initialize_model(model, model_args=(True,), num_chains=4)
+
+
+@pytest.mark.parametrize("tag", ["adapted", "not_pd"])
+def test_arrowhead_mass_matrix_matches_reference(monkeypatch, tag):
+    """ArrowheadMassMatrix (adaptation.py:395-580): the mass matrix adapted from the reference's
+    gradient samples (Welford on gradients, arrowhead mask, regularisation), its inverse -- also when
+    the head-tail block has to be halved for positive definiteness -- and kinetic_grad against the
+    reference's own objects (tests/golden/arrowhead.npz).  scale / unscale use another square root
+    of the same matrix (Cholesky of M^-1 instead of the upper-triangular arrowhead root): they are
+    checked as inverses of each other and through the quadratic form they define."""
+    from tests import oracle_backend
+    from pyro_amd.infer.mcmc.adaptation import ArrowheadDenseMassMatrix
+    oracle_backend.install(monkeypatch)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "arrowhead.npz"))
+    D, h, C = 6, 4, 2
+    dev = torch.device("cpu")
+    mm = ArrowheadDenseMassMatrix(C, D, torch.float64, dev, list(range(h)), list(range(h, D)))
+    if tag == "adapted":
+        for row in g["grads"]:
+            mm.update(torch.tensor(row).expand(C, D))
+        mm.end_adaptation()
+    else:
+        M = torch.eye(D, dtype=torch.float64)
+        M[:h, h:] = 0.9
+        M[h:, :h] = 0.9
+        mm.mass_matrix_dense = M.expand(C, D, D)
+    top, bottom = mm.mass_matrix
+    for c in range(C):
+        np.testing.assert_allclose(top[c].numpy(), g[tag + "/top"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(bottom[c].numpy(), g[tag + "/bottom_diag"], rtol=1e-10)
+        np.testing.assert_allclose(mm.inverse_mass_matrix[c].numpy(), g[tag + "/inverse_mass"],
+                                   rtol=1e-8, atol=1e-10)
+    r = torch.tensor(g[tag + "/r"]).expand(C, D).contiguous()
+    np.testing.assert_allclose(mm.kinetic_grad(r)[0].numpy(), g[tag + "/kinetic_grad"], rtol=1e-8)
+    u = mm.unscale(r)
+    np.testing.assert_allclose((u[0] ** 2).sum().item(), (g[tag + "/unscale"] ** 2).sum(), rtol=1e-8)
+    np.testing.assert_allclose(mm.scale(u)[1].numpy(), r[1].numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(mm.color(mm.whiten(r))[0].numpy(), r[0].numpy(), rtol=1e-8, atol=1e-10)
