@@ -170,7 +170,7 @@ class SVI:
         graph = torch.cuda.CUDAGraph()
         graph2 = between = None
         split = hasattr(self.optim, "reduce_gradients") and \
-            (getattr(self.optim, "world_size", 1) > 1 or getattr(self, "_force_split", False))
+            (getattr(self.optim, "multi_rank", False) or getattr(self, "_force_split", False))
         # Opt-in (PYRO_AMD_GRAPH_COLLECTIVE=1): capture the RCCL all-reduce of the flat gradient
         # INSIDE the step's graph -- one replay per step at any world size, no eager collective and
         # no stream hand-over between two graphs.  RCCL collectives are capturable like NCCL's; the
@@ -184,7 +184,7 @@ class SVI:
             with validation_enabled(False):   # validation ran in the eager warm-up steps
                 # with a process group alive its watchdog thread polls events while we capture:
                 # only THIS thread's calls may invalidate the capture
-                multi = getattr(self.optim, "world_size", 1) > 1
+                multi = getattr(self.optim, "multi_rank", False)
                 mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
                 with torch.cuda.graph(graph, **mode):
                     with cap:

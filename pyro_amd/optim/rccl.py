@@ -27,6 +27,9 @@ class RcclOptimizer:
         self.average = average
         self._broadcast_done = set()
         self._avg_op = None            # None: untried, True / False: ReduceOp.AVG (un)available
+        # test hook: run the collectives (and the multi-rank step structure of SVI) at world size 1
+        # too, so that RCCL and its capture into a hipGraph can be exercised on a one-GPU box
+        self.force_collective = False
         if hasattr(pyro_optim, "grad_hook"):
             pyro_optim.grad_hook = self._allreduce_flat
 
@@ -43,8 +46,12 @@ class RcclOptimizer:
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    @property
+    def multi_rank(self):
+        return self.world_size > 1 or (self.force_collective and dist.is_initialized())
+
     def _allreduce_flat(self, flat_grad):
-        if self.world_size == 1:
+        if not self.multi_rank:
             return
         if self.average and self._avg_op is not False:
             # RCCL averages inside the collective (one launch less on the step's critical path);

@@ -434,3 +434,20 @@ def test_north_star_acceptance_at_the_north_star_config(gpu):
     ref_sw = torch.nn.functional.softplus(port.rho_w).detach().numpy()
     assert np.abs(sw - ref_sw).max() / np.abs(ref_sw).max() < 1e-3
     pyro.clear_param_store()
+
+
+def test_rccl_all_reduce_eager_and_captured_in_the_step_graph(gpu):
+    """RCCL itself, at world size 1 (all a one-GPU box offers): the flat-gradient all-reduce as an
+    eager launch between two graphs (the default multi-rank step) and captured inside ONE hipGraph
+    (PYRO_AMD_GRAPH_COLLECTIVE=1) give the losses of the plain single-process step.  Runs in a
+    subprocess: a process group is global state."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RCCL_ONE_RANK_ROWS="200000", RCCL_ONE_RANK_STEPS="20",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_one_rank.py")], cwd=root,
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "RCCL one-rank OK" in out.stdout
+    assert "two graphs + eager collective" in out.stdout and out.stdout.count("one graph") >= 2
