@@ -548,6 +548,36 @@ def test_glm_planes_transpose_detecting_and_f32_class(gpu):
         assert float(np.abs(o.cpu().numpy() - r).max() / np.abs(r).max()) < 3e-6
 
 
+@pytest.mark.parametrize("variant", ["planes", "bf16", "exact"])
+def test_glm_extreme_logits(gpu, variant):
+    """Saturated logits (|x.w + b| up to ~200): exp2(-|l|) underflows to zero, 1 + e = 1, the
+    sigmoid is exactly 0 or 1; log-likelihood and gradients stay finite and equal the float64 oracle
+    on every kernel variant."""
+    k = _k()
+    N, D, P = 3000, 32, 64
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (6.0 * rng.standard_normal((P, D))).astype(np.float32)          # logits ~ N(0, 34^2)
+    b = (20.0 * rng.standard_normal(P)).astype(np.float32)
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    tX, ty, tw, tb = tt(X, gpu), tt(y, gpu), tt(w, gpu), tt(b, gpu)
+    try:
+        if variant == "planes":
+            out = k.glm_bernoulli_planes_fwd_bwd(k.glm_pack_planes(tX), ty, tw, tb, 1.0, N, D)
+        else:
+            k.glm_set_planes_mode(k.GLM_PLANES_OFF)
+            k.glm_set_variant(k.GLM_EXACT_F32 if variant == "exact" else k.GLM_AUTO)
+            out = k.glm_bernoulli_fwd_bwd(tX, ty, tw, tb, None, 1.0)
+    finally:
+        k.glm_set_planes_mode(k.GLM_PLANES_AUTO)
+        k.glm_set_variant(k.GLM_AUTO)
+    for o, r in zip(out, ref):
+        got = o.cpu().numpy()
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, r, rtol=3e-5, atol=3e-5 * np.abs(r).max())
+
+
 def test_glm_planes_cache_follows_the_tensor(gpu):
     """The image is cached per tensor object: first sight -> on-the-fly kernel, second sight ->
     packed; an in-place update of X re-packs into the same buffer (the pointer a captured graph
