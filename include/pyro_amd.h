@@ -389,6 +389,16 @@ int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const 
                                 uint64_t chain_offset, void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
                                 int32_t* diverging, int32_t* accepted, pa_stream_t stream);
 
+/* Reasonable step size per chain for the closed-form Gaussian potential (pyro/infer/mcmc/hmc.py:
+ * 170-229: double / halve the step until the one-step acceptance probability crosses 0.8), every
+ * chain running its own loop in ONE launch: step[C] is read as the starting point and overwritten.
+ * Momenta are keyed Philox draws (seed, key + trial index, chain_offset + chain). */
+int pa_nuts_gaussian_find_step(int dtype, const void* z, const void* pe, const void* grad,
+                               const void* Lambda, const void* inv_mass, void* step, int64_t C,
+                               int64_t D, uint64_t seed, uint64_t key, uint64_t chain_offset,
+                               double min_step, double max_step, double direction_threshold,
+                               pa_stream_t stream);
+
 /* Persistent form of the same kernel: num_transitions consecutive transitions t0, t0+1, ... per
  * launch, each wavefront staying with its chain (the data-dependent tree sizes of the individual
  * transitions average out over the launch instead of making every launch as long as its longest

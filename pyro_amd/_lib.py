@@ -149,6 +149,9 @@ _SIGNATURES = {
                                           c_int64, c_int, c_int, c_uint64, c_void_p, c_uint64,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_size_t, c_void_p]),
+    "pa_nuts_gaussian_find_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_uint64,
+                                           c_double, c_double, c_double, c_void_p]),
     "pa_lda_factor_workspace": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
     "pa_lda_factor_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

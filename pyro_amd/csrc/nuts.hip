@@ -478,6 +478,62 @@ void nuts_gaussian_reg_kernel(float* __restrict__ z_io, float* __restrict__ pe_i
                                                chain, lane, PA_NUTS_RUN_ARGS);
 }
 
+// ---- reasonable step size per chain (reference: hmc.py:170-229; Stan's heuristic) ----------------
+// One wave = one chain.  A trial = fresh momentum, ONE leapfrog with the candidate step size, the
+// change of the Hamiltonian; the first trial fixes the direction (double while the one-step
+// acceptance stays above 0.8, else halve), then the step is scaled until the direction flips or
+// the step leaves (min, max).  The host version ran the same loop for all chains in lock step with
+// ~15 launches and one host synchronisation per trial; here every chain runs its own loop in one
+// launch.  Lambda is read from global memory (L2): a few dozen mat-vecs per chain, once per window.
+template <typename T>
+__global__ __launch_bounds__(64) void nuts_gaussian_find_step_kernel(
+    const T* __restrict__ z_in, const T* __restrict__ pe_in, const T* __restrict__ grad_in,
+    const T* __restrict__ Lambda, const T* __restrict__ inv_mass, T* __restrict__ step, int C,
+    int D, uint64_t seed, uint64_t key, uint64_t chain_offset, T min_step, T max_step,
+    T direction_threshold) {
+  const int lane = threadIdx.x, chain = blockIdx.x;
+  const bool va = lane < D, vb = lane + 64 < D;
+  const int64_t row = (int64_t)chain * D;
+  const P2<T> z{va ? z_in[row + lane] : T(0), vb ? z_in[row + lane + 64] : T(0)};
+  const P2<T> g{va ? grad_in[row + lane] : T(0), vb ? grad_in[row + lane + 64] : T(0)};
+  const T pe = pe_in[chain];
+  const P2<T> v{va ? inv_mass[row + lane] : T(1), vb ? inv_mass[row + lane + 64] : T(1)};
+  const P2<T> sq{Num<T>::sqrt_(v.a), Num<T>::sqrt_(v.b)};
+  const P2<T> isq{T(1) / sq.a, T(1) / sq.b};
+  const uint64_t cid = chain_offset + (uint64_t)chain;
+  PotLds<T> pot{Lambda, D, lane};
+  T eps = step[chain];
+
+  auto trial = [&](T e, uint64_t it) -> int {
+    const uint64_t ctr = (key + it) << 20;
+    P2<T> ru{va ? philox_normal_t<T>(seed, ctr, (uint64_t)lane, cid) : T(0),
+             vb ? philox_normal_t<T>(seed, ctr, (uint64_t)(lane + 64), cid) : T(0)};
+    P2<T> r{ru.a * isq.a, ru.b * isq.b};
+    const T e0 = T(0.5) * dot(ru, ru) + pe;
+    const T hk = T(0.5) * e;
+    r.a = r.a + hk * (-g.a);
+    r.b = r.b + hk * (-g.b);
+    P2<T> z1{z.a + e * (v.a * r.a), z.b + e * (v.b * r.b)}, g1;
+    T pe1;
+    pot(z1, g1, pe1);
+    r.a = r.a + hk * (-g1.a);
+    r.b = r.b + hk * (-g1.b);
+    const P2<T> ru1{r.a * sq.a, r.b * sq.b};
+    const T delta = (T(0.5) * dot(ru1, ru1) + pe1) - e0;
+    return (direction_threshold < -delta) ? 1 : -1;        // NaN compares false: direction -1
+  };
+
+  const int direction = trial(eps, 0);
+  const T scale = direction > 0 ? T(2) : T(0.5);
+  for (uint64_t it = 1; it <= 200; ++it) {
+    if (!(eps > min_step && eps < max_step)) break;
+    eps = eps * scale;
+    if (trial(eps, it) != direction) break;
+  }
+  eps = eps < min_step ? min_step : (eps > max_step ? max_step : eps);
+  if (lane == 0) step[chain] = eps;
+}
+
 template <typename T>
 struct RunPtrs {
   T *z, *pe, *grad;
@@ -627,6 +683,30 @@ int pa_nuts_gaussian_transition(int dtype, void* z, void* pe, void* grad, const 
                               max_tree_depth, use_multinomial, seed, t, 1, chain_offset, nullptr,
                               0.8, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr,
                               accept_prob, n_leapfrog, depth, diverging, accepted, stream);
+}
+
+int pa_nuts_gaussian_find_step(int dtype, const void* z, const void* pe, const void* grad,
+                               const void* Lambda, const void* inv_mass, void* step, int64_t C,
+                               int64_t D, uint64_t seed, uint64_t key, uint64_t chain_offset,
+                               double min_step, double max_step, double direction_threshold,
+                               pa_stream_t stream) {
+  int rc = nuts_common_checks(dtype, C, D, 1, 0);
+  if (rc != PA_OK) return rc;
+  PA_REQUIRE(key < ((uint64_t)1 << 43), "nuts_gaussian_find_step: key too large");
+  if (C == 0) return PA_OK;
+  PA_REQUIRE(z && pe && grad && Lambda && inv_mass && step, "nuts_gaussian_find_step: NULL pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    hipLaunchKernelGGL((pa::nuts_gaussian_find_step_kernel<float>), dim3((unsigned)C), dim3(64), 0, s,
+                       (const float*)z, (const float*)pe, (const float*)grad, (const float*)Lambda,
+                       (const float*)inv_mass, (float*)step, (int)C, (int)D, seed, key, chain_offset,
+                       (float)min_step, (float)max_step, (float)direction_threshold);
+  else
+    hipLaunchKernelGGL((pa::nuts_gaussian_find_step_kernel<double>), dim3((unsigned)C), dim3(64), 0,
+                       s, (const double*)z, (const double*)pe, (const double*)grad,
+                       (const double*)Lambda, (const double*)inv_mass, (double*)step, (int)C, (int)D,
+                       seed, key, chain_offset, min_step, max_step, direction_threshold);
+  return pa::check_launch("nuts_gaussian_find_step_kernel");
 }
 
 }  // extern "C"

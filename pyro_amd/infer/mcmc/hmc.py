@@ -227,9 +227,14 @@ class HMC(MCMCKernel):
         self._accept_cnt = torch.zeros((C,), dtype=torch.int64, device=z.device)
         self._mean_accept_prob = torch.zeros((C,), dtype=z.dtype, device=z.device)
         self._n_leapfrog_total = torch.zeros((), dtype=torch.int64, device=z.device)
+        self._seed = rng._STATE["seed"]
+        self._prepare_paths()
         if self._adapter.adapt_step_size:
             self._adapter.reset_step_size_adaptation(z)
-        self._seed = rng._STATE["seed"]
+
+    def _prepare_paths(self):
+        """Hook: device fast paths that depend on the state laid out by setup() (NUTS: the fused
+        closed-form Gaussian kernels) are chosen before the first step-size search."""
 
     def cleanup(self):
         self._reset()
@@ -263,6 +268,17 @@ class HMC(MCMCKernel):
         """Per chain: double / halve the step size until the one-step acceptance probability
         crosses the target (reference: hmc.py:170-229), all chains in lock step under masks."""
         step = self.step_size.clone()
+        if getattr(self, "_fused", False) and not self._dense \
+                and getattr(self, "_Lambda", None) is not None and z.is_cuda:
+            # closed-form Gaussian potential: every chain runs the loop on the device, one launch
+            pe, grad = self._potential(z)
+            self._find_step_calls = getattr(self, "_find_step_calls", 0) + 1
+            key = (1 << 42) + 256 * self._find_step_calls       # disjoint from transition indices
+            return kernels.nuts_gaussian_find_step(
+                z, pe.detach(), grad.detach(), self._Lambda, self.inverse_mass_matrix, step,
+                self._seed if getattr(self, "_seed", None) is not None else rng._STATE["seed"],
+                key, self.chain_offset, self._min_stepsize, self._max_stepsize,
+                self._direction_threshold)
         if self._dense:
             z = self.mass_matrix_adapter.whiten(z)    # ``z`` arrives in model coordinates
         pe, grad = self._potential(z)

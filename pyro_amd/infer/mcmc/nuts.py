@@ -47,17 +47,21 @@ class NUTS(HMC):
         self._round_graph = self._step_buf = self._mass_buf = None
         self._round_calls = 0
 
+    def _prepare_paths(self):
+        self._fused = (self.use_fused_gaussian and isinstance(self.potential_fn, GaussianPotential)
+                       and self._layout.D <= 128 and len(self._layout.names) == 1
+                       and not self._dense)   # dense mass: per-chain whitened potential, tree path
+        self._Lambda = None
+        if self._fused:
+            self._Lambda = self.potential_fn.precision.to(self._z.dtype).contiguous()
+
     def setup(self, warmup_steps, *args, **kwargs):
+        self._fused, self._Lambda = False, None
         super().setup(warmup_steps, *args, **kwargs)
         self._tree = None
         self._step_buf = self._mass_buf = self._round_graph = None     # jit_compile round graph
         self._round_calls, self._round_failed = 0, False
         self._tree_depth_sum = torch.zeros((), dtype=torch.int64, device=self._z.device)
-        self._fused = (self.use_fused_gaussian and isinstance(self.potential_fn, GaussianPotential)
-                       and self._layout.D <= 128 and len(self._layout.names) == 1
-                       and not self._dense)   # dense mass: per-chain whitened potential, tree path
-        if self._fused:
-            self._Lambda = self.potential_fn.precision.to(self._z.dtype).contiguous()
         self._counters = torch.zeros((3, self.num_chains), dtype=torch.int64,
                                      device=self._z.device)
 

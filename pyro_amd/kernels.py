@@ -778,6 +778,21 @@ def nuts_gaussian_transition(z, pe, grad, Lambda, inv_mass, step, max_tree_depth
             "accepted": ints[3]}
 
 
+def nuts_gaussian_find_step(z, pe, grad, Lambda, inv_mass, step, seed, key, chain_offset,
+                            min_step, max_step, direction_threshold):
+    """Reasonable step size per chain (hmc.py:170-229) for the Gaussian potential, one launch:
+    returns a new [C] tensor; ``step`` is the starting point."""
+    _require_gpu(z, pe, grad, Lambda, inv_mass, step)
+    C, D = z.shape
+    out = step.contiguous().clone()
+    im = inv_mass if inv_mass.dim() == 2 else inv_mass.expand(C, D)
+    check(_lib.load().pa_nuts_gaussian_find_step(
+        _dtype(z), _ptr(z.contiguous()), _ptr(pe.contiguous()), _ptr(grad.contiguous()),
+        _ptr(Lambda), _ptr(im.contiguous()), _ptr(out), C, D, int(seed), int(key),
+        int(chain_offset), float(min_step), float(max_step), float(direction_threshold), _stream()))
+    return out
+
+
 def nuts_gaussian_run(z, pe, grad, Lambda, inv_mass, step, max_tree_depth, use_multinomial, seed,
                       t0, num_transitions, chain_offset=0, da_state=None, target_accept=0.8,
                       welford=None, welford_n0=0, samples=None, mean_accept=None, mean_n0=0,

@@ -302,3 +302,34 @@ def test_hmc_conjugate_gaussian_chain(gpu):
     # test_hmc.py:79-124: fixed trajectory length on the first chain fixture
     mc.run_gaussian_chain(gpu, "dim=10_chain-len=3_num_obs=1", "hmc", step_size=0.5, num_steps=4,
                           jit_compile=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_device_step_size_search_matches_the_lock_step_search(gpu, dtype):
+    """pa_nuts_gaussian_find_step (every chain its own doubling / halving loop, one launch) against
+    the host search it replaces on the fused Gaussian path (all chains in lock step, hmc.py:170-229):
+    different momentum draws, so the comparison is distributional -- every result is the start value
+    times a power of two, and the two searches agree on the typical step within one doubling."""
+    from pyro_amd import examples
+    from pyro_amd.infer.mcmc import MCMC, NUTS, GaussianPotential
+    C, D = 256, 40
+    _, Lam = examples.correlated_gaussian_precision(D, dtype=torch.float64)
+    Lam = Lam.to(dtype=dtype, device=gpu)
+    res = {}
+    for fused in (True, False):
+        pyro.set_rng_seed(3)
+        kernel = NUTS(potential_fn=GaussianPotential(Lam), max_tree_depth=5, step_size=1.0)
+        kernel.use_fused_gaussian = fused
+        kernel.initial_params = {"x": 0.1 * torch.ones((C, D), dtype=dtype, device=gpu)}
+        kernel.num_chains = C
+        kernel.setup(1)
+        z = kernel._z.clone()
+        kernel._adapter.step_size = torch.ones(C, dtype=dtype, device=gpu)
+        step = kernel._find_reasonable_step_size(z)
+        assert step.shape == (C,) and bool(torch.isfinite(step).all())
+        k = torch.log2(step)
+        assert torch.allclose(k, k.round(), atol=1e-5)          # 1.0 * 2^k
+        res[fused] = k.round()
+    med = {f: float(v.median()) for f, v in res.items()}
+    assert abs(med[True] - med[False]) <= 1.0, med
+    assert float((res[True] - med[True]).abs().max()) <= 3.0
