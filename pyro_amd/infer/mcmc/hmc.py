@@ -369,9 +369,14 @@ class HMC(MCMCKernel):
         n = max(self._t - self._warmup_steps, 1)
         out = {"acceptance rate": (self._accept_cnt.to(torch.float64) / n).cpu()}
         if self._divergences:
-            div = torch.stack(self._divergences).to(torch.bool).cpu()    # [S, C]
-            out["divergences"] = {"chain {}".format(c): torch.nonzero(div[:, c]).reshape(-1).tolist()
-                                  for c in range(div.shape[1])}
+            div = torch.stack(self._divergences).to(torch.bool).cpu().numpy()    # [S, C]
+            # one pass over the (few) divergent transitions instead of a nonzero() per chain
+            per_chain = {c: [] for c in range(div.shape[1])}
+            if div.any():
+                import numpy as np
+                for s_, c in zip(*np.nonzero(div)):
+                    per_chain[int(c)].append(int(s_))
+            out["divergences"] = {"chain {}".format(c): v for c, v in per_chain.items()}
         else:
             out["divergences"] = {}
         return out
