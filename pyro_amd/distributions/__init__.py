@@ -12,6 +12,7 @@ from .families import (Bernoulli, Beta, Binomial, Dirichlet, Exponential, Gamma,
                        GroupedLinearLogits, HalfCauchy, HalfNormal, LinearLogits, LogNormal, Normal,
                        Poisson, grouped_linear_logits, linear_logits)
 from .util import enable_validation, is_validation_enabled  # noqa: F401
+from . import kl as _kl  # noqa: F401,E402  (registers the reference's extra kl_divergence pairs)
 
 # ---- everything else: torch.distributions + mixin, arithmetic by ATen on the GPU ----------------
 _FUSED = {"Normal", "Bernoulli", "HalfCauchy", "HalfNormal", "LogNormal", "Exponential",

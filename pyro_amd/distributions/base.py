@@ -153,6 +153,19 @@ class MaskedDistribution(TorchDistribution):
     def enumerate_support(self, expand=True):
         return self.base_dist.enumerate_support(expand=expand)
 
+    # moments are those of the base distribution (torch_distribution.py:376-382)
+    @property
+    def mean(self):
+        return self.base_dist.mean
+
+    @property
+    def variance(self):
+        return self.base_dist.variance
+
+    def conjugate_update(self, other):
+        updated, log_normalizer = self.base_dist.conjugate_update(other)
+        return updated.mask(self._mask), scale_and_mask(log_normalizer, mask=self._mask)
+
     def fused_log_prob_sum(self, value, scale=1.0, mask=None):
         if isinstance(self._mask, bool):
             if self._mask is False:

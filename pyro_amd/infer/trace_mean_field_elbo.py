@@ -87,14 +87,23 @@ class TraceMeanField_ELBO(Trace_ELBO):
         """coef * ELBO particle of trace_mean_field_elbo.py:104-150 as a 0-dim tensor."""
         from ..distributions.fused import SiteBatch
 
+        from ..distributions.base import Delta
         batch = SiteBatch()
-        analytic, left = set(), []
+        analytic, delta_sites, left = set(), set(), []
         for name, msite in model_trace.nodes.items():
             if msite["type"] != "sample" or msite["is_observed"] or name not in guide_trace.nodes:
                 continue
             gsite = guide_trace.nodes[name]
             if _add_normal_kl(batch, gsite, msite):
                 analytic.add(name)
+                continue
+            if type(gsite["fn"]) is Delta and not isinstance(gsite["scale"], torch.Tensor) \
+                    and gsite["scale"] == msite["scale"] and gsite["mask"] is msite["mask"]:
+                # kl_divergence(Delta(v), p) = -p.log_prob(v) (distributions/kl.py, the Delta's own
+                # log_density does not enter): -KL is the model site's log-probability at the
+                # replayed value -- it rides in the batch as an ordinary model entry, and the
+                # guide's Delta contributes nothing
+                delta_sites.add(name)
                 continue
             try:
                 kl_qp = kl_divergence(gsite["fn"], msite["fn"])
@@ -112,7 +121,7 @@ class TraceMeanField_ELBO(Trace_ELBO):
         left += model_trace.collect_log_prob_sums(
             batch, 1.0, lambda name, site: name not in analytic)
         left += guide_trace.collect_log_prob_sums(
-            batch, -1.0, lambda name, site: name not in analytic)
+            batch, -1.0, lambda name, site: name not in analytic and name not in delta_sites)
         total = batch.total(coef)
         for sign, term in left:
             total = total + (coef * sign) * term

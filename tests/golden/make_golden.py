@@ -810,6 +810,17 @@ def g_autocont():
             out["grads_" + key] = grads_of_store()
             out["params_" + key] = params
             out["eps_" + key] = list(bank.used)
+            # the same guide under TraceMeanField_ELBO: its Delta sites take the analytic route
+            # kl_divergence(Delta, prior) = -prior.log_prob(value) (pyro/distributions/kl.py:19-21)
+            from pyro.infer import TraceMeanField_ELBO
+            for p_ in store._params.values():
+                p_.grad = None
+            mf = TraceMeanField_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=1)
+            with EpsBank(41) as bank2:
+                mf_loss = mf.loss_and_grads(model, guide, X, y)
+            assert len(bank2.used) == len(bank.used) and all(np.array_equal(a, b) for a, b in zip(bank2.used, bank.used))
+            out["mf_loss_" + key] = mf_loss
+            out["mf_grads_" + key] = grads_of_store()
     save("autocont", X=X.numpy(), y=y.numpy(), **out)
 
 

@@ -419,7 +419,7 @@ def run_predictive(g, device, monkeypatch, rtol):
 
 
 # ---- AutoContinuous guides (golden: tests/golden/make_golden.py g_autocont) -----------------------
-def run_autocont(g, device, monkeypatch, which, tag, rtol):
+def run_autocont(g, device, monkeypatch, which, tag, rtol, mean_field=False):
     """AutoDiagonalNormal / AutoMultivariateNormal: loss and gradients of the reference for a model
     with a vector site, a positive site (exp transform, Jacobian term) and a plated site."""
     from torch.distributions import transform_to
@@ -455,6 +455,16 @@ def run_autocont(g, device, monkeypatch, which, tag, rtol):
             target = torch.tensor(g["params_" + key + "/" + name], dtype=dtype, device=device)
             store._params[name].copy_(transform_to(store._constraints[name]).inv(target))
     monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps_" + key), device))
+    if mean_field:
+        # the guide's Delta sites take kl_divergence(Delta, prior) = -prior.log_prob(value): the
+        # reference's loss differs from Trace_ELBO's by the Jacobian term of the positive site
+        from pyro_amd.infer import TraceMeanField_ELBO
+        elbo = TraceMeanField_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=1)
+        loss = elbo.loss_and_grads(model, guide, X, y)
+        np.testing.assert_allclose(loss, float(g["mf_loss_" + key]), rtol=rtol)
+        assert abs(float(g["mf_loss_" + key]) - float(g["loss_" + key])) > 1e-3
+        assert_grads(store_grads(), g, "mf_grads_" + key, rtol * 10)
+        return
     elbo = Trace_ELBO(num_particles=P, vectorize_particles=P > 1, max_plate_nesting=1)
     loss = elbo.loss_and_grads(model, guide, X, y)
     np.testing.assert_allclose(loss, float(g["loss_" + key]), rtol=rtol)

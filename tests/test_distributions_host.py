@@ -1,0 +1,62 @@
+"""Reference distribution KATs on the torch-wrapped classes (CPU): Delta, .mask, Categorical."""
+import pytest
+import torch
+
+import pyro_amd.distributions as dist
+from tests import dist_kat_cases as dk
+
+CPU = torch.device("cpu")
+
+
+def test_delta():
+    dk.run_delta(CPU)
+
+
+@pytest.mark.parametrize("batch_dim,event_dim", [(b, e) for b in range(4) for e in range(1 + b)])
+@pytest.mark.parametrize("has_log_density", [False, True])
+def test_delta_shapes(batch_dim, event_dim, has_log_density):
+    dk.run_delta_shapes(CPU, batch_dim, event_dim, has_log_density)
+
+
+@pytest.mark.parametrize("batch_shape", [(), [], (2,), [2], torch.Size([2]), [2, 3]])
+def test_delta_expand(batch_shape):
+    dk.run_delta_expand(CPU, batch_shape)
+
+
+@pytest.mark.parametrize("batch_dim,mask_dim", [(b, m) for b in range(3) for m in range(1 + b)])
+@pytest.mark.parametrize("event_dim", [0, 1, 2])
+def test_mask(batch_dim, event_dim, mask_dim):
+    # a torch-wrapped (un-fused) discrete family: the fused ones refuse CPU tensors by design
+    dk.run_mask(CPU, lambda shape: dist.Geometric(torch.tensor(0.1)).expand_by(shape),
+                batch_dim, event_dim, mask_dim)
+
+
+@pytest.mark.parametrize("mask", [False, True, torch.tensor(False), torch.tensor(True)])
+def test_mask_type(mask):
+    dk.run_mask_type(CPU, dist.Laplace, mask)
+
+
+@pytest.mark.parametrize("event_shape", [(), (4,)])
+@pytest.mark.parametrize("dist_shape", [(), (3,), (2, 1), (2, 3)])
+@pytest.mark.parametrize("mask_shape", [(), (3,), (2, 1), (2, 3)])
+def test_mask_broadcast(event_shape, dist_shape, mask_shape):
+    dk.run_mask_broadcast(CPU, dist.Laplace, event_shape, dist_shape, mask_shape)
+
+
+def test_mask_kl_divergence():
+    dk.run_mask_kl(CPU, dist.Laplace)
+
+
+@pytest.mark.parametrize("p_mask", [False, True, torch.tensor(False), torch.tensor(True)])
+@pytest.mark.parametrize("q_mask", [False, True, torch.tensor(False), torch.tensor(True)])
+def test_mask_kl_divergence_type(p_mask, q_mask):
+    dk.run_mask_kl_type(CPU, dist.Laplace, p_mask, q_mask)
+
+
+@pytest.mark.parametrize("shape", [None, (), (4,), (3, 2)], ids=str)
+def test_mask_noop(shape):
+    dk.run_mask_noop(CPU, dist.Laplace, shape)
+
+
+def test_categorical():
+    dk.run_categorical(CPU)

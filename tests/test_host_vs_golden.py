@@ -64,6 +64,13 @@ def test_autocontinuous_guides(monkeypatch, which, tag):
     models.run_autocont(load("autocont"), torch.device("cpu"), monkeypatch, which, tag, rtol=1e-9)
 
 
+@pytest.mark.parametrize("which", ["diag", "mvn"])
+@pytest.mark.parametrize("tag", ["p1", "p4"])
+def test_autocontinuous_guides_under_trace_mean_field(monkeypatch, which, tag):
+    models.run_autocont(load("autocont"), torch.device("cpu"), monkeypatch, which, tag, rtol=1e-9,
+                        mean_field=True)
+
+
 def test_tracegraph_baselines_match_reference(monkeypatch):
     from tests import oracle_backend
     oracle_backend.install(monkeypatch)

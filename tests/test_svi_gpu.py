@@ -163,6 +163,15 @@ def test_autocontinuous_guides(gpu, monkeypatch, which, tag):
     models.run_autocont(load("autocont"), gpu, monkeypatch, which, tag, rtol=1e-9)
 
 
+@pytest.mark.parametrize("which", ["diag", "mvn"])
+@pytest.mark.parametrize("tag", ["p1", "p4"])
+def test_autocontinuous_guides_under_trace_mean_field(gpu, monkeypatch, which, tag):
+    """The guides' Delta sites under TraceMeanField_ELBO: kl_divergence(Delta, prior), as the
+    reference registers it -- loss and gradients of the reference."""
+    torch.set_default_dtype(torch.float64)
+    models.run_autocont(load("autocont"), gpu, monkeypatch, which, tag, rtol=1e-9, mean_field=True)
+
+
 def test_predictive(gpu, monkeypatch):
     """Predictive (vectorised and sequential) against the reference's draws (recorded normals)."""
     torch.set_default_dtype(torch.float64)
