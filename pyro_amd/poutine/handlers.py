@@ -39,7 +39,13 @@ class TraceMessenger(Messenger):
         return self.trace.copy()
 
     def _wrapped_get_trace(self, bound, *args, **kwargs):
-        bound(*args, **kwargs)
+        ret = bound(*args, **kwargs)
+        if not self.param_only:
+            # the call's arguments and return value as nodes of their own
+            # (trace_messenger.py:187-215): Predictive(return_sites=["_RETURN"]) reads the latter
+            self.trace.add_node("_INPUT", name="_INPUT", type="args", args=args, kwargs=kwargs)
+            self.trace.nodes.move_to_end("_INPUT", last=False)
+            self.trace.add_node("_RETURN", name="_RETURN", type="return", value=ret)
         return self.get_trace()
 
     def _reset(self):
