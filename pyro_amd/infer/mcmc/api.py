@@ -126,6 +126,7 @@ class MCMC:
                     initial_params = {k: v[lo:lo + self._local_chains]
                                       for k, v in initial_params.items()}
             kernel.initial_params = initial_params
+        self._given_initial_params = initial_params
         if mp_context is not None:
             warnings.warn("mp_context is ignored: chains are vectorised on the GPU, not forked")
 
@@ -141,11 +142,18 @@ class MCMC:
             k.setup(self.warmup_steps, *args, **kwargs)
             if self.transforms is None:
                 self.transforms = getattr(k, "transforms", None) or {}
-            fast = isinstance(k, HMC)
+            fast = isinstance(k, HMC) and not getattr(k, "_empty", False)
             S, C = self.num_samples, self._local_chains
             params = k.initial_params
             bulk = fast and getattr(k, "_fused", False) and getattr(k, "use_persistent", False) \
                 and self.hook_fn is None
+            per_chain_diag = None
+
+            def hook(stage, i):
+                if self.hook_fn is not None:
+                    cur = k._layout.unflatten(k._position(), k._batched) if fast else {}
+                    self.hook_fn(k, cur, stage, i)
+
             if bulk:
                 # persistent launches: many transitions per kernel, samples written by the kernel
                 buf = torch.empty((S, C, k._layout.D), dtype=k._z.dtype, device=k._z.device)
@@ -165,32 +173,54 @@ class MCMC:
                 buf = torch.empty((S, C, k._layout.D), dtype=k._z.dtype, device=k._z.device)
                 for i in range(self.warmup_steps):
                     k._transition()
-                    if self.hook_fn is not None:
-                        self.hook_fn(k, None, "Warmup", i)
+                    hook("Warmup", i)
                 k.end_warmup()
                 for i in range(S):
                     k._transition()
                     buf[i].copy_(k._position())
-                    if self.hook_fn is not None:
-                        self.hook_fn(k, None, "Sample", i)
+                    hook("Sample", i)
                 flat = buf.transpose(0, 1)    # [C, S, D]
                 z_acc = {}
                 for name in k._layout.names:
                     a, b = k._layout.slices[name]
                     z_acc[name] = flat[:, :, a:b].reshape((C, S) + tuple(k._layout.shapes[name]))
-            else:
-                acc = None
+            elif isinstance(k, HMC):
+                # a model without continuous latent sites: nothing moves, the hooks still run
                 for i in range(self.warmup_steps):
-                    params = k.sample(params)
+                    hook("Warmup", i)
                 for i in range(S):
-                    params = k.sample(params)
-                    if acc is None:
-                        acc = {n: [] for n in params}
-                    for n, v in params.items():
-                        acc[n].append(v.detach().clone())
-                z_acc = {n: torch.stack(v, dim=0) for n, v in acc.items()}
-                z_acc = {n: (v.transpose(0, 1) if C > 1 else v.unsqueeze(0))
-                         for n, v in z_acc.items()}
+                    hook("Sample", i)
+                z_acc = {}
+            else:
+                # a user-written MCMCKernel knows nothing of vectorised chains: one chain after the
+                # other through the MCMCKernel interface, as the reference's sequential sampler does
+                # (api.py:212-237); the first chain reuses the setup() above
+                given = self._given_initial_params
+                chains, per_chain_diag = [], []
+                for c in range(C):
+                    if c > 0 or (given is not None and C > 1):
+                        if given is not None:
+                            k.initial_params = {n: (v[c] if C > 1 else v) for n, v in given.items()}
+                        k.setup(self.warmup_steps, *args, **kwargs)
+                    params = k.initial_params
+                    for i in range(self.warmup_steps):
+                        params = k.sample(params)
+                        if self.hook_fn is not None:
+                            self.hook_fn(k, params, "Warmup", i)
+                    acc = None
+                    for i in range(S):
+                        params = k.sample(params)
+                        if self.hook_fn is not None:
+                            self.hook_fn(k, params, "Sample", i)
+                        if acc is None:
+                            acc = {n: [] for n in params}
+                        for n, v in params.items():
+                            acc[n].append(v.detach().clone())
+                    chains.append({n: torch.stack(v, dim=0) for n, v in (acc or {}).items()})
+                    per_chain_diag.append(k.diagnostics())
+                    if c + 1 < C:
+                        k.cleanup()
+                z_acc = {n: torch.stack([ch[n] for ch in chains], dim=0) for n in chains[0]}
             if self.save_params is not None:
                 z_acc = {n: v for n, v in z_acc.items() if n in self.save_params}
             # back to the constrained space of the model (api.py:600-603)
@@ -199,7 +229,15 @@ class MCMC:
                     z_acc[name] = self.transforms[name].inv(z)
             self._local_samples = z_acc
             self._samples = self._gather(z_acc)
-            self._diagnostics = k.diagnostics()
+            if per_chain_diag is not None:
+                # {key: {"chain i": value}} as the reference's driver merges them (api.py:560-575)
+                merged = {}
+                for c, d in enumerate(per_chain_diag):
+                    for key, value in (d or {}).items():
+                        merged.setdefault(key, {})["chain {}".format(c)] = value
+                self._diagnostics = merged
+            else:
+                self._diagnostics = k.diagnostics()
         # the reference's driver ends a run with kernel.cleanup() (api.py:170), which there drops the
         # jit-compiled potential; here the run's statistics stay readable on the kernel object
         # (leapfrog counts, adapted step sizes) and only the captured graphs are released

@@ -189,9 +189,12 @@ class HMC(MCMCKernel):
         self._warmup_steps = warmup_steps
         if self.model is not None:
             self._initialize_model_properties(args, kwargs)
-        if not self._initial_params:
-            raise ValueError("HMC/NUTS needs at least one continuous latent site "
-                             "(initial_params is empty)")
+        self._empty = not self._initial_params
+        if self._empty:
+            # a model without continuous latent sites: nothing to move (the reference's kernels run
+            # such a model too, test_mcmc_api.py:236-286); transitions are no-ops, samples are {}
+            self._warmup_steps = warmup_steps
+            return
         params = self._initial_params
         C = self.num_chains
         first = next(iter(params.values()))
@@ -357,6 +360,8 @@ class HMC(MCMCKernel):
     def sample(self, params):
         """One transition; ``params`` is ignored in favour of the cached state when it is the
         state returned by the previous call (the reference caches the same way, hmc.py:371-379)."""
+        if getattr(self, "_empty", False):
+            return params
         self._transition()
         return self._layout.unflatten(self._position().clone(), self._batched)
 
@@ -366,8 +371,12 @@ class HMC(MCMCKernel):
                             ("acc. prob", "{:.3f}".format(float(self._mean_accept_prob.mean())))])
 
     def diagnostics(self):
+        if getattr(self, "_empty", False):
+            return {}
         n = max(self._t - self._warmup_steps, 1)
-        out = {"acceptance rate": (self._accept_cnt.to(torch.float64) / n).cpu()}
+        rate = (self._accept_cnt.to(torch.float64) / n).cpu().tolist()
+        # one entry per chain, as the reference's driver assembles them (api.py:560-575)
+        out = {"acceptance rate": {"chain {}".format(c): r for c, r in enumerate(rate)}}
         if self._divergences:
             div = torch.stack(self._divergences).to(torch.bool).cpu().numpy()    # [S, C]
             # one pass over the (few) divergent transitions instead of a nonzero() per chain

@@ -58,6 +58,8 @@ class NUTS(HMC):
     def setup(self, warmup_steps, *args, **kwargs):
         self._fused, self._Lambda = False, None
         super().setup(warmup_steps, *args, **kwargs)
+        if getattr(self, "_empty", False):
+            return
         self._tree = None
         self._step_buf = self._mass_buf = self._round_graph = None     # jit_compile round graph
         self._round_calls, self._round_failed = 0, False
@@ -214,6 +216,8 @@ class NUTS(HMC):
         return OrderedDict(list(out.items()))
 
     def diagnostics(self):
+        if getattr(self, "_empty", False):
+            return {}
         self._accept_cnt = self._accept_cnt + self._counters[2]
         self._counters[2].zero_()
         out = super().diagnostics()

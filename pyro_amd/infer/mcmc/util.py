@@ -287,6 +287,11 @@ def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
                                                                             **model_kwargs)
 
     trace = draw()
+    # batch dims that are not declared through a plate count too: the chain plate must sit to the
+    # left of every batch dim of every site
+    for node in trace.nodes.values():
+        if node["type"] == "sample" and type(node["fn"]).__name__ != "_Subsample":
+            max_plate_nesting = max(max_plate_nesting, len(node["fn"].batch_shape))
     batch_ndims, site_shape = {}, {}
     enumerated = set()
 
