@@ -215,19 +215,32 @@ class _FlatAdam:
             kernels.publish_scalar(*publish)
 
     # ---- checkpointing (reference: PyroOptim.get_state / set_state, optim.py:157-200) -----------
+    def _group_args(self):
+        g = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+        if self._clipped:
+            g.update({"clip_norm": self.clip_norm, "lrd": self.lrd})
+        return g
+
     def get_state(self):
-        """{parameter name: {"exp_avg", "exp_avg_sq", "step"}} -- per parameter, as the reference's
-        state dict is, so that a checkpoint does not depend on how parameters were grouped."""
+        """{parameter name: state_dict of a one-parameter torch optimizer} -- the layout of the
+        reference's ``PyroOptim.get_state`` (pyro/optim/optim.py:157-166: ``{"state": {0: {"step",
+        "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}`` per parameter), so that a checkpoint
+        depends neither on how parameters were grouped here nor on which of the two
+        implementations wrote it."""
         state = {}
         for g in self._groups:
             shared = None if g.own_steps is not None else int(g.step_dev[0].item())
             for p in g.params:
                 o, n = g.index[p]
                 step = shared if shared is not None else int(g.own_steps[p][0].item())
+                group = dict(self._group_args(), params=[0])
+                if self._clipped:
+                    group["lr"] = self.lr * self.lrd ** step
                 state[_PARAM_STORE.param_name(p)] = {
-                    "exp_avg": g.exp_avg[o:o + n].clone().view(p.shape),
-                    "exp_avg_sq": g.exp_avg_sq[o:o + n].clone().view(p.shape),
-                    "step": step}
+                    "state": {0: {"step": torch.tensor(float(step)),
+                                  "exp_avg": g.exp_avg[o:o + n].clone().view(p.shape),
+                                  "exp_avg_sq": g.exp_avg_sq[o:o + n].clone().view(p.shape)}},
+                    "param_groups": [group]}
         return state
 
     def set_state(self, state):
@@ -246,6 +259,11 @@ class _FlatAdam:
             entry = self._pending_state.pop(name, None)
             if entry is None:
                 continue
+            if "state" in entry:          # torch optimizer layout (this class's own, the reference's)
+                inner = entry["state"]
+                if not inner:
+                    continue              # the parameter had not been stepped when it was saved
+                entry = next(iter(inner.values()))
             o, n = g.index[p]
             for key, buf in (("exp_avg", g.exp_avg), ("exp_avg_sq", g.exp_avg_sq)):
                 t = entry[key]
@@ -271,11 +289,30 @@ class _FlatAdam:
         self.set_state(torch.load(filename, map_location=map_location, weights_only=False))
 
 
+def _per_parameter_route(optim_args, clip_args):
+    """Arguments the flat buffers cannot express -- a callable giving every parameter its own
+    settings, gradient clipping by ``clip_args`` (pyro/optim/optim.py:96-114, 140-153) -- take the
+    reference's per-parameter route."""
+    return callable(optim_args) or clip_args is not None
+
+
 class Adam(_FlatAdam):
-    """torch.optim.Adam semantics, one fused launch for all parameters."""
+    """torch.optim.Adam semantics, one fused launch for all parameters.  ``Adam(callable)`` or
+    ``Adam(args, clip_args)`` returns the per-parameter ``PyroOptim(torch.optim.Adam, ...)``."""
+
+    def __new__(cls, optim_args, clip_args=None):
+        if _per_parameter_route(optim_args, clip_args):
+            return PyroOptim(torch.optim.Adam, optim_args, clip_args)
+        return super().__new__(cls)
 
 
 class ClippedAdam(_FlatAdam):
     """pyro.optim.ClippedAdam semantics (element-wise gradient clamp + lr decay)."""
 
     _clipped = True
+
+    def __new__(cls, optim_args, clip_args=None):
+        if _per_parameter_route(optim_args, clip_args):
+            from .clipped_adam import ClippedAdam as TorchClippedAdam
+            return PyroOptim(TorchClippedAdam, optim_args, clip_args)
+        return super().__new__(cls)
