@@ -43,12 +43,35 @@ class validation_enabled:
         _poutine_settings.enable_validation(self.prev[1])
 
 
+def _partially_observed(name, fn, obs, obs_mask, *args, **kwargs):
+    """``obs_mask`` (reference: pyro/primitives.py:94-122): the site splits into
+    ``<name>_observed`` (scored where the mask holds) and ``<name>_unobserved`` (a latent, scored
+    where it does not); the model continues with their interleaving, recorded as the deterministic
+    site ``<name>``."""
+    from .poutine import mask as _mask
+    with _mask(mask=obs_mask):
+        observed = sample(name + "_observed", fn, *args, obs=obs, **kwargs)
+    with _mask(mask=~obs_mask):
+        unobserved = sample(name + "_unobserved", fn, *args, **kwargs)
+    batch_mask = obs_mask.reshape(tuple(obs_mask.shape) + (1,) * fn.event_dim)
+    try:
+        value = torch.where(batch_mask, observed, unobserved)
+    except RuntimeError as e:
+        if "must match the size of tensor" in str(e):
+            shape = torch.broadcast_shapes(observed.shape, unobserved.shape)
+            raise ValueError("Invalid obs_mask shape {}; should be broadcastable to batch_shape = {}"
+                             .format(tuple(obs_mask.shape),
+                                     tuple(shape[:len(shape) - fn.event_dim]))) from e
+        raise
+    return deterministic(name, value, event_dim=fn.event_dim)
+
+
 def sample(name, fn, *args, obs=None, obs_mask=None, infer=None, **kwargs):
     """Sample (or observe) a value at a named site."""
     infer = {} if infer is None else infer.copy()
     is_observed = infer.pop("is_observed", obs is not None)
     if obs_mask is not None:
-        raise NotImplementedError("obs_mask is not supported; use poutine.mask")
+        return _partially_observed(name, fn, obs, obs_mask, *args, **kwargs)
     if not am_i_wrapped():
         if obs is not None and not infer.get("_deterministic"):
             warnings.warn("trying to observe a value outside of inference at " + name,
