@@ -114,6 +114,37 @@ class ParamStoreDict:
             self._param_to_name[u] = name
             self._constraints[name] = constraint
 
+    def scope(self, state=None):
+        """Context manager for several parameter stores in one process (param_store.py:337-372):
+        inside, the store holds ``state`` (empty by default); on exit the previous contents come
+        back and the scope's own are written into the yielded state dict, which can be entered
+        again."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _scope():
+            inner = {"params": {}, "constraints": {}} if state is None else state
+            outer = self._snapshot()
+            try:
+                self.clear()
+                self._restore(inner)
+                yield inner
+                inner.update(self._snapshot())
+            finally:
+                self.clear()
+                self._restore(outer)
+        return _scope()
+
+    def _snapshot(self):
+        """The store's tensors themselves (no copies: a scope hands the same leaves back)."""
+        return {"params": dict(self._params), "constraints": dict(self._constraints)}
+
+    def _restore(self, snap):
+        for name, u in snap["params"].items():
+            self._params[name] = u
+            self._param_to_name[u] = name
+            self._constraints[name] = snap["constraints"][name]
+
     def save(self, filename):
         torch.save(self.get_state(), filename)
 

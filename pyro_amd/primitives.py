@@ -160,7 +160,33 @@ def plate_stack(prefix, sizes, rightmost_dim=-1):
 
 
 def module(name, nn_module, update_module_params=False):
-    """Register every parameter of a torch.nn.Module in the param store (by identity)."""
+    """Register every trainable parameter of a torch.nn.Module in the param store under
+    ``<name>$$$<parameter name>`` (reference: pyro/primitives.py:403-503).  A parameter the store
+    already holds under that name (a loaded checkpoint, an earlier module object) wins: with
+    ``update_module_params=True`` the stored tensors are put INTO the module in place of its own."""
+    import inspect
+    import warnings as _warnings
+    from operator import attrgetter
+    if "$$$" in name:
+        raise AssertionError("improper module name, since contains $$$")
+    if inspect.isclass(nn_module):
+        raise NotImplementedError("pyro.module does not support class constructors for the "
+                                  "argument nn_module")
+    stored = {}
     for pname, p in nn_module.named_parameters():
-        param("{}$$${}".format(name, pname), p)
+        if p.requires_grad:
+            returned = param("{}$$${}".format(name, pname), p)
+            if returned.data_ptr() != p.data_ptr() or returned.shape != p.shape:
+                stored[pname] = returned
+        elif nn_module.training:
+            _warnings.warn("{} was not registered in the param store because requires_grad=False. "
+                           "You can silence this warning by calling my_module.train(False)"
+                           .format(pname))
+    if stored and update_module_params:
+        for pname in [n for n, _ in nn_module.named_parameters()]:
+            if pname not in stored:
+                continue
+            head, _, leaf = pname.rpartition(".")
+            owner = attrgetter(head)(nn_module) if head else nn_module
+            owner._parameters[leaf] = stored[pname]
     return nn_module
