@@ -9,6 +9,6 @@ from . import distributions, infer, ops, optim, poutine  # noqa: F401
 from .primitives import (clear_param_store, deterministic, enable_validation, factor,  # noqa: F401
                          get_param_store, module, param, plate, plate_stack, sample,
                          set_rng_seed, validation_enabled)
-from .poutine.handlers import markov  # noqa: F401  (pyro.markov, pyro/primitives.py)
+from .poutine.handlers import condition, do, markov  # noqa: F401  (pyro/__init__.py:7)
 
 __version__ = "0.1.0"

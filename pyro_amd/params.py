@@ -152,4 +152,26 @@ class ParamStoreDict:
         self.set_state(torch.load(filename, map_location=map_location, weights_only=False))
 
 
+_MODULE_NAMESPACE_DIVIDER = "$$$"
+
+
+def param_with_module_name(pyro_name, param_name):
+    return _MODULE_NAMESPACE_DIVIDER.join([pyro_name, param_name])
+
+
+def module_from_param_with_module_name(param_name):
+    return param_name.split(_MODULE_NAMESPACE_DIVIDER)[0]
+
+
+def user_param_name(param_name):
+    """The name the user gave: what follows ``<module>$$$`` (param_store.py:388-391)."""
+    if _MODULE_NAMESPACE_DIVIDER in param_name:
+        return param_name.split(_MODULE_NAMESPACE_DIVIDER)[1]
+    return param_name
+
+
+def normalize_param_name(name):
+    return name.replace(_MODULE_NAMESPACE_DIVIDER, ".")
+
+
 _PARAM_STORE = ParamStoreDict()

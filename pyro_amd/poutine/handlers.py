@@ -5,6 +5,7 @@ broadcasting) / enum (parallel enumeration) / seed.  Same names, arguments and m
 semantics as the reference so existing models run unchanged; implementation is independent.
 """
 import numbers
+import warnings
 from collections import namedtuple
 
 import torch
@@ -94,27 +95,46 @@ class ReplayMessenger(Messenger):
 
 # ---------------------------------------------------------------------------------------------
 class BlockMessenger(Messenger, _BlockLike):
-    """Hide sites from handlers outside (reference: block_messenger.py)."""
+    """Hide sites from handlers outside (reference: block_messenger.py:19-84 decision rule, :101-168).
+
+    With no arguments everything is hidden.  ``hide=`` / ``hide_types=`` hide only what they name;
+    ``expose=`` / ``expose_types=`` hide everything except what they name; an observed sample site has
+    type ``"observe"`` for the two ``*_types`` lists.  ``hide_fn`` / ``expose_fn`` replace the rule."""
 
     def __init__(self, hide_fn=None, expose_fn=None, hide_all=True, expose_all=False, hide=None,
                  expose=None, hide_types=None, expose_types=None):
         super().__init__()
+        if not (hide_fn is None or expose_fn is None):
+            raise ValueError("Only specify one of hide_fn or expose_fn")
         if hide_fn is not None:
             self.hide_fn = hide_fn
         elif expose_fn is not None:
             self.hide_fn = lambda msg: not expose_fn(msg)
         else:
-            hide = hide or []
-            expose = expose or []
-            hide_types = hide_types or []
-            expose_types = expose_types or []
-            if hide or hide_types:
-                self.hide_fn = lambda msg: msg["name"] in hide or msg["type"] in hide_types
-            elif expose or expose_types:
-                self.hide_fn = lambda msg: not (msg["name"] in expose
-                                                or msg["type"] in expose_types)
-            else:
-                self.hide_fn = lambda msg: not expose_all
+            self.hide_fn = self._default_rule(hide_all, expose_all, hide, expose, hide_types,
+                                              expose_types)
+
+    @staticmethod
+    def _default_rule(hide_all, expose_all, hide, expose, hide_types, expose_types):
+        assert (hide_all is False and expose_all is False) or hide_all != expose_all, \
+            "cannot hide and expose a site"
+        # naming things to hide turns "hide all" off, naming things to expose turns it on; in the
+        # order the reference applies them (hide, expose, hide_types, expose_types)
+        for given, turns_on in ((hide, False), (expose, True), (hide_types, False), (expose_types, True)):
+            if given is not None:
+                hide_all = turns_on
+        hide, expose = frozenset(hide or ()), frozenset(expose or ())
+        hide_types, expose_types = frozenset(hide_types or ()), frozenset(expose_types or ())
+        assert hide.isdisjoint(expose), "cannot hide and expose a site"
+        assert hide_types.isdisjoint(expose_types), "cannot hide and expose a site type"
+
+        def rule(msg):
+            kind = "observe" if msg["type"] == "sample" and msg["is_observed"] else msg["type"]
+            if msg["name"] in hide or kind in hide_types:
+                return True
+            return hide_all and msg["name"] not in expose and kind not in expose_types
+
+        return rule
 
     def _process_message(self, msg):
         msg["stop"] = bool(self.hide_fn(msg))
@@ -137,6 +157,92 @@ class ConditionMessenger(Messenger):
         elif name in self.data:
             msg["value"] = self.data[name]
             msg["is_observed"] = msg["value"] is not None
+
+
+class SubstituteMessenger(Messenger):
+    """Fix ``pyro.param`` sites to given values (reference: substitute_messenger.py:18-107): the
+    value of a param whose user-facing name is in ``data`` is replaced; the rest are untouched."""
+
+    def __init__(self, data):
+        super().__init__()
+        self.data = data
+        self._seen = {}
+
+    def __enter__(self):
+        self._seen = {}
+        if settings.validation_enabled() and isinstance(self.data, dict):
+            self._hits, self._misses = set(), set()
+        return super().__enter__()
+
+    def __exit__(self, *args):
+        self._seen = {}
+        if settings.validation_enabled() and isinstance(self.data, dict):
+            extra = set(self.data) - self._hits
+            if extra:
+                warnings.warn("pyro.module data did not find params ['{}']. Did you instead mean one "
+                              "of ['{}']?".format("', '".join(extra), "', '".join(self._misses)))
+        return super().__exit__(*args)
+
+    def _pyro_param(self, msg):
+        from ..params import user_param_name
+        name = msg["name"]
+        key = user_param_name(name)
+        validating = settings.validation_enabled() and isinstance(self.data, dict)
+        if key not in self.data.keys():
+            if validating:
+                self._misses.add(key)
+            return
+        msg["value"] = self.data[key]
+        if validating:
+            self._hits.add(key)
+        if name in self._seen:          # the same param statement again: same value
+            msg["value"] = self._seen[name]["value"]
+        else:
+            self._seen[name] = msg
+
+
+class InferConfigMessenger(Messenger):
+    """``msg["infer"].update(config_fn(msg))`` at every sample and param site
+    (reference: infer_config_messenger.py:14-58)."""
+
+    def __init__(self, config_fn):
+        super().__init__()
+        self.config_fn = config_fn
+
+    def _pyro_sample(self, msg):
+        msg["infer"].update(self.config_fn(msg))
+
+    _pyro_param = _pyro_sample
+
+
+class DoMessenger(Messenger):
+    """Intervention (reference: do_messenger.py:14-97): the original statement still runs as its own,
+    un-intervened site; the site the rest of the program sees carries the given value, is renamed
+    ``name + "__CF"``, marked observed and hidden from the handlers outside."""
+
+    def __init__(self, data):
+        super().__init__()
+        self.data = data
+        self._token = str(id(self))
+
+    def _pyro_sample(self, msg):
+        if msg.get("_intervener_id") == self._token or self.data.get(msg["name"]) is None:
+            return
+        if msg.get("_intervener_id") is not None:
+            warnings.warn("Attempting to intervene on variable {} multiple times,this is almost "
+                          "certainly incorrect behavior".format(msg["name"]), RuntimeWarning)
+        msg["_intervener_id"] = self._token
+        twin = msg.copy()                       # the un-intervened statement, sent down the stack
+        twin["cond_indep_stack"] = ()           # the plates add themselves again on the way
+        apply_stack(twin)
+        intervention = self.data[msg["name"]]
+        msg["name"] = msg["name"] + "__CF"
+        if isinstance(intervention, numbers.Number):
+            intervention = torch.tensor(intervention)
+        elif not isinstance(intervention, torch.Tensor):
+            raise NotImplementedError("Interventions of type {} not implemented (yet)".format(
+                type(intervention)))
+        msg["value"], msg["is_observed"], msg["stop"] = intervention, True, True
 
 
 class UnconditionMessenger(Messenger):
@@ -258,6 +364,8 @@ class PlateMessenger(Messenger):
             size = -1
             subsample_size = -1
         else:
+            if size == 0:
+                raise ZeroDivisionError("size cannot be zero")
             if not isinstance(size, numbers.Number) or size <= 0:
                 if not isinstance(size, torch.Tensor):
                     raise ValueError("size must be a positive number, got {}".format(size))
@@ -602,6 +710,9 @@ replay = _make_handler(ReplayMessenger)
 block = _make_handler(BlockMessenger)
 condition = _make_handler(ConditionMessenger)
 uncondition = _make_handler(UnconditionMessenger)
+substitute = _make_handler(SubstituteMessenger)
+infer_config = _make_handler(InferConfigMessenger)
+do = _make_handler(DoMessenger)
 scale = _make_handler(ScaleMessenger)
 mask = _make_handler(MaskMessenger)
 enum = _make_handler(EnumMessenger)

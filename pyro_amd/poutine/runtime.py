@@ -216,6 +216,13 @@ class _BoundHandler:
         with self.handler:
             return self.fn(*args, **kwargs)
 
+    def __get__(self, instance, owner=None):
+        # a handler applied to a method in a class body: bind like a function would
+        # (the role of _bound_partial, pyro/poutine/messenger.py:35-56)
+        if instance is None:
+            return self
+        return functools.partial(self, instance)
+
     def __getattr__(self, name):
         # expose e.g. .get_trace of a TraceMessenger-wrapped function
         h = object.__getattribute__(self, "handler")

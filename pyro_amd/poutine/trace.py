@@ -85,10 +85,10 @@ class Trace:
                 yield name, node
 
     # ---- log-probabilities ----------------------------------------------------------------
-    def _site_error(self, name, site, exc):
+    def _site_error(self, name, site, exc, what="log_prob"):
         shapes = self.format_shapes(last_site=name)
-        return ValueError("Error while computing log_prob at site '{}':\n{}\n{}".format(
-            name, exc, shapes))
+        return ValueError("Error while computing {} at site '{}':\n{}\n{}".format(
+            what, name, exc, shapes))
 
     def compute_log_prob(self, site_filter=lambda name, site: True):
         """Un-reduced path: site["unscaled_log_prob"], ["log_prob"], ["log_prob_sum"]."""
@@ -147,7 +147,7 @@ class Trace:
                     try:
                         entry = entry_fn(value, scale, mask)
                     except ValueError as e:
-                        raise self._site_error(name, site, e) from e
+                        raise self._site_error(name, site, e, "log_prob_sum") from e
                     if entry is not None and batch.add_site(*entry, sign):
                         continue
                 lin_fn = getattr(fn, "fused_linear_term", None) if plain else None
@@ -155,7 +155,7 @@ class Trace:
                     try:
                         lin = lin_fn(value, scale, mask)   # (ll, [(tensor, known gradient), ...])
                     except ValueError as e:
-                        raise self._site_error(name, site, e) from e
+                        raise self._site_error(name, site, e, "log_prob_sum") from e
                     if lin is not None and batch.add_linear_term(lin[0], lin[1], sign):
                         continue
                 batch_fn = getattr(fn, "fused_log_prob_batch", None) if plain else None
@@ -163,7 +163,7 @@ class Trace:
                     try:
                         term = batch_fn(value, scale, mask)      # e.g. per-particle sums ll[P]
                     except ValueError as e:
-                        raise self._site_error(name, site, e) from e
+                        raise self._site_error(name, site, e, "log_prob_sum") from e
                 if term is None:
                     term = self._site_sum(name, site)
             if not batch.add_term(term, sign):
@@ -182,13 +182,13 @@ class Trace:
             try:
                 out = fused(value, scale, mask)
             except ValueError as e:
-                raise self._site_error(name, site, e) from e
+                raise self._site_error(name, site, e, "log_prob_sum") from e
             if out is not None:
                 return out
         try:
             log_p = fn.log_prob(value, *site["args"], **site["kwargs"])
         except ValueError as e:
-            raise self._site_error(name, site, e) from e
+            raise self._site_error(name, site, e, "log_prob_sum") from e
         return scale_and_mask(log_p, scale, mask).sum()
 
     def log_prob_sum(self, site_filter=lambda name, site: True):
@@ -208,7 +208,7 @@ class Trace:
             try:
                 value = site["fn"].score_parts(site["value"], *site["args"], **site["kwargs"])
             except ValueError as e:
-                raise self._site_error(name, site, e) from e
+                raise self._site_error(name, site, e, "score_parts") from e
             site["unscaled_log_prob"] = value.log_prob
             value = value.scale_and_mask(site["scale"], site["mask"])
             site["score_parts"] = value
