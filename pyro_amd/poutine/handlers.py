@@ -12,20 +12,59 @@ import torch
 
 from .. import rng as _rng
 from . import settings
-from .runtime import (_DIM_ALLOCATOR, _ENUM_ALLOCATOR, Messenger, _BlockLike, apply_stack,
+from .runtime import (_DIM_ALLOCATOR, _ENUM_ALLOCATOR, Messenger, _BlockLike, _BoundHandler, apply_stack,
                       new_message)
 from .trace import Trace
 
 
 # ---------------------------------------------------------------------------------------------
-class TraceMessenger(Messenger):
-    """Record every message into a Trace (reference: trace_messenger.py:142-215)."""
+def _dense_edges(trace):
+    """Edges site -> later site unless the two sit in different iterations of a common sequential
+    plate (the dependency structure "dense" traces carry; trace_messenger.py:20-46)."""
+    from .util import site_is_subsample
+    sites = [(name, node) for name, node in trace.nodes.items()
+             if node["type"] == "sample" and not site_is_subsample(node)]
+    for k, (name, node) in enumerate(sites):
+        for past_name, past in sites[:k]:
+            independent = any(a.name == b.name and a.counter != b.counter
+                              for a, b in zip(node["cond_indep_stack"], past["cond_indep_stack"]))
+            if not independent:
+                trace.add_edge(past_name, name)
 
-    _wrapper_attrs = ("get_trace",)
+
+class _TraceHandler(_BoundHandler):
+    """``poutine.trace(fn)``: calling it runs ``fn`` under the messenger and records the call's
+    arguments and return value as the ``_INPUT`` / ``_RETURN`` nodes; ``.trace`` is the live trace of
+    the last call, ``.get_trace(*args)`` runs and returns a copy (trace_messenger.py:158-217)."""
+
+    def __call__(self, *args, **kwargs):
+        msngr = self.handler
+        with msngr:
+            msngr.trace.add_node("_INPUT", name="_INPUT", type="args", args=args, kwargs=kwargs)
+            try:
+                ret = self.fn(*args, **kwargs)
+            except (ValueError, RuntimeError) as e:
+                shapes = msngr.trace.format_shapes()
+                raise type(e)("{}\n{}".format(e, shapes)).with_traceback(e.__traceback__) from e
+            msngr.trace.add_node("_RETURN", name="_RETURN", type="return", value=ret)
+        return ret
+
+    @property
+    def trace(self):
+        return self.handler.trace
+
+    def get_trace(self, *args, **kwargs):
+        self(*args, **kwargs)
+        return self.handler.get_trace()
+
+
+class TraceMessenger(Messenger):
+    """Record every message into a Trace (reference: trace_messenger.py:49-156)."""
 
     def __init__(self, graph_type=None, param_only=None):
         super().__init__()
         self.graph_type = "flat" if graph_type is None else graph_type
+        assert self.graph_type in ("flat", "dense")
         self.param_only = bool(param_only)
         self.trace = Trace(self.graph_type)
 
@@ -33,21 +72,23 @@ class TraceMessenger(Messenger):
         self.trace = Trace(self.graph_type)
         return super().__enter__()
 
+    def __exit__(self, *args):
+        if self.param_only:
+            for name, node in list(self.trace.nodes.items()):
+                if node["type"] != "param":
+                    self.trace.remove_node(name)
+        if self.graph_type == "dense":
+            _dense_edges(self.trace)
+        return super().__exit__(*args)
+
     def __call__(self, fn):
-        return super().__call__(fn)
+        if not callable(fn):
+            raise ValueError("{} is not callable, did you mean to pass it as a keyword arg?"
+                             .format(fn))
+        return _TraceHandler(self, fn)
 
     def get_trace(self):
         return self.trace.copy()
-
-    def _wrapped_get_trace(self, bound, *args, **kwargs):
-        ret = bound(*args, **kwargs)
-        if not self.param_only:
-            # the call's arguments and return value as nodes of their own
-            # (trace_messenger.py:187-215): Predictive(return_sites=["_RETURN"]) reads the latter
-            self.trace.add_node("_INPUT", name="_INPUT", type="args", args=args, kwargs=kwargs)
-            self.trace.nodes.move_to_end("_INPUT", last=False)
-            self.trace.add_node("_RETURN", name="_RETURN", type="return", value=ret)
-        return self.get_trace()
 
     def _reset(self):
         self.trace = Trace(self.graph_type)
@@ -288,13 +329,7 @@ class MaskMessenger(Messenger):
         msg["mask"] = self.mask if msg["mask"] is None else msg["mask"] & self.mask
 
 
-def get_mask():
-    """Current mask of the handler stack (used by autoguides)."""
-    msg = new_message("get_mask", "get_mask", None)
-    msg["done"] = True
-    msg["value"] = None
-    apply_stack(msg)
-    return msg["mask"]
+from .runtime import get_mask, get_plates  # noqa: E402,F401
 
 
 # ---------------------------------------------------------------------------------------------

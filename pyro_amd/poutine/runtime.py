@@ -224,9 +224,25 @@ class _BoundHandler:
         return functools.partial(self, instance)
 
     def __getattr__(self, name):
-        # expose e.g. .get_trace of a TraceMessenger-wrapped function
-        h = object.__getattribute__(self, "handler")
-        extra = getattr(h, "_wrapper_attrs", ())
-        if name in extra:
-            return functools.partial(getattr(h, "_wrapped_" + name), self)
+        # what the wrapped callable offers (e.g. .get_trace of a traced function further in)
         return getattr(object.__getattribute__(self, "fn"), name)
+
+
+def get_mask():
+    """The mask the enclosing ``poutine.mask`` handlers apply right now: None, a bool, or a tensor
+    (reference: pyro/poutine/runtime.py get_mask)."""
+    return _query("get_mask")["mask"]
+
+
+def get_plates():
+    """The frames of the ``pyro.plate`` contexts the caller is inside of, as a tuple
+    (reference: pyro/poutine/runtime.py get_plates)."""
+    return tuple(_query("get_plates")["cond_indep_stack"])
+
+
+def _query(kind):
+    msg = new_message(kind, kind, None)
+    msg["done"] = True
+    msg["value"] = None
+    apply_stack(msg)
+    return msg

@@ -22,6 +22,8 @@ class Trace:
         assert graph_type in ("flat", "dense")
         self.graph_type = graph_type
         self.nodes = OrderedDict()
+        self._succ = OrderedDict()         # the DAG over site names (dense graphs, trace_struct.py:148-201)
+        self._pred = OrderedDict()
 
     def __contains__(self, name):
         return name in self.nodes
@@ -41,14 +43,57 @@ class Trace:
             elif kwargs["type"] != "param":
                 raise RuntimeError("Multiple {} sites named '{}'".format(kwargs["type"], site_name))
         self.nodes[site_name] = kwargs
+        self._succ.setdefault(site_name, set())
+        self._pred.setdefault(site_name, set())
+
+    def add_edge(self, site1, site2):
+        for site in (site1, site2):
+            if site not in self.nodes:
+                self.add_node(site)
+        self._succ[site1].add(site2)
+        self._pred[site2].add(site1)
 
     def remove_node(self, site_name):
         del self.nodes[site_name]
+        for p in self._pred.pop(site_name, ()):
+            self._succ[p].discard(site_name)
+        for q in self._succ.pop(site_name, ()):
+            self._pred[q].discard(site_name)
+
+    def predecessors(self, site_name):
+        return self._pred[site_name]
+
+    def successors(self, site_name):
+        return self._succ[site_name]
+
+    @property
+    def edges(self):
+        for site, followers in self._succ.items():
+            for follower in followers:
+                yield site, follower
+
+    def _dfs(self, site, visited):
+        """Post-order walk of what is reachable from ``site`` and not yet visited."""
+        if site in visited:
+            return
+        for follower in self._succ[site]:
+            yield from self._dfs(follower, visited)
+        visited.add(site)
+        yield site
+
+    def topological_sort(self, reverse=False):
+        visited, post_order = set(), []
+        for site in self._succ:
+            post_order.extend(self._dfs(site, visited))
+        return post_order if reverse else post_order[::-1]
 
     def copy(self):
         new = Trace(self.graph_type)
         for name, site in self.nodes.items():
             new.nodes[name] = dict(site)
+        for name in self._succ:
+            new._succ[name] = set(self._succ[name])
+            new._pred[name] = set(self._pred[name])
         return new
 
     def detach_(self):
