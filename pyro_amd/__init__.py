@@ -5,9 +5,9 @@ for the reference runs after ``import pyro_amd as pyro``; the numerics are hand-
 kernels for gfx950 behind the C-ABI in include/pyro_amd.h.  GPU tensors only: there is no CPU
 fallback.
 """
-from . import distributions, infer, ops, optim, poutine  # noqa: F401
+from . import distributions, infer, ops, optim, poutine, settings  # noqa: F401
 from .primitives import (clear_param_store, deterministic, enable_validation, factor,  # noqa: F401
-                         get_param_store, module, param, plate, plate_stack, sample,
+                         get_param_store, module, param, plate, plate_stack, random_module, sample, subsample,
                          set_rng_seed, validation_enabled)
 from .poutine.handlers import condition, do, markov  # noqa: F401  (pyro/__init__.py:7)
 

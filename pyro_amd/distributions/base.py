@@ -260,15 +260,15 @@ class Unit(TorchDistribution):
     def __init__(self, log_factor, *, has_rsample=None, validate_args=None):
         log_factor = torch.as_tensor(log_factor)
         self.log_factor = log_factor
-        self._has_rsample = has_rsample
+        if has_rsample is not None:
+            # an instance attribute only when the caller said so: a guide-side pyro.factor has to
+            # (pyro/util.py:447-462 looks into __dict__)
+            self.has_rsample = has_rsample
         super().__init__(log_factor.shape, torch.Size((0,)), validate_args=validate_args)
 
-    @property
-    def has_rsample(self):
-        return bool(self._has_rsample)
-
     def expand(self, batch_shape, _instance=None):
-        return Unit(self.log_factor.expand(torch.Size(batch_shape)), has_rsample=self._has_rsample)
+        return Unit(self.log_factor.expand(torch.Size(batch_shape)),
+                    has_rsample=self.__dict__.get("has_rsample"))
 
     def sample(self, sample_shape=torch.Size()):
         return self.log_factor.new_empty(torch.Size(sample_shape) + self.shape())

@@ -7,3 +7,5 @@ from .tracegraph_elbo import TraceGraph_ELBO  # noqa: F401
 from .trace_mean_field_elbo import TraceMeanField_ELBO  # noqa: F401
 from .predictive import Predictive  # noqa: F401
 from .mcmc import HMC, MCMC, NUTS  # noqa: F401
+
+from .util import enable_validation, is_validation_enabled  # noqa: E402,F401

@@ -52,9 +52,19 @@ class ELBO(metaclass=ABCMeta):
             guide_trace = poutine.trace(guide).get_trace(*args, **kwargs)
             model_trace = poutine.trace(poutine.replay(model, trace=guide_trace)).get_trace(
                 *args, **kwargs)
-        dims = [frame.dim for trace in (model_trace, guide_trace)
-                for site in trace.nodes.values() if site["type"] == "sample"
-                for frame in site["cond_indep_stack"] if frame.vectorized]
+        from ..poutine.util import prune_subsample_sites
+        from ..util import check_site_shape
+        from .util import is_validation_enabled
+        guide_trace = prune_subsample_sites(guide_trace)
+        model_trace = prune_subsample_sites(model_trace)
+        sites = [site for trace in (model_trace, guide_trace) for site in trace.nodes.values()
+                 if site["type"] == "sample"]
+        # shapes are checked now, against the un-enumerated run: once max_plate_nesting is finite,
+        # whatever sits left of it is allowed to broadcast (elbo.py:160-168)
+        if is_validation_enabled():
+            for site in sites:
+                check_site_shape(site, max_plate_nesting=float("inf"))
+        dims = [frame.dim for site in sites for frame in site["cond_indep_stack"] if frame.vectorized]
         self.max_plate_nesting = -min(dims) if dims else 0
         if self.vectorize_particles and self.num_particles > 1:
             self.max_plate_nesting += 1

@@ -1,9 +1,20 @@
 """Importance-trace construction shared by the ELBO estimators
 (reference: pyro/infer/enum.py:45-85 get_importance_trace, :138-220 config_enumerate)."""
+from .util import is_validation_enabled
 import numbers
 
 from .. import poutine
 from ..poutine.util import prune_subsample_sites
+from ..util import check_model_guide_match, check_site_shape  # noqa: F401
+
+
+def check_site_shapes(model_trace, guide_trace, max_plate_nesting):
+    """``check_site_shape`` at every sample site of both traces (enum.py:76-83).  Needs no un-reduced
+    log_prob: on the fused path the shape is derived from the distribution and the value."""
+    for trace in (model_trace, guide_trace):
+        for site in trace.nodes.values():
+            if site["type"] == "sample":
+                check_site_shape(site, max_plate_nesting)
 
 
 def get_importance_trace(graph_type, max_plate_nesting, model, guide, args, kwargs, detach=False,
@@ -15,7 +26,7 @@ def get_importance_trace(graph_type, max_plate_nesting, model, guide, args, kwar
         guide_trace.detach_()
     model_trace = poutine.trace(poutine.replay(model, trace=guide_trace),
                                 graph_type=graph_type).get_trace(*args, **kwargs)
-    if poutine.settings.validation_enabled():
+    if is_validation_enabled():
         check_model_guide_match(model_trace, guide_trace, max_plate_nesting)
     guide_trace = prune_subsample_sites(guide_trace)
     model_trace = prune_subsample_sites(model_trace)
@@ -26,43 +37,9 @@ def get_importance_trace(graph_type, max_plate_nesting, model, guide, args, kwar
     else:
         model_trace.compute_log_prob()
         guide_trace.compute_score_parts()
+    if is_validation_enabled():
+        check_site_shapes(model_trace, guide_trace, max_plate_nesting)
     return model_trace, guide_trace
-
-
-def check_model_guide_match(model_trace, guide_trace, max_plate_nesting=float("inf")):
-    """Site-level sanity checks (reference: pyro/util.py:314-398, condensed)."""
-    import warnings
-
-    guide_vars = {name for name, site in guide_trace.nodes.items()
-                  if site["type"] == "sample" and not poutine.util.site_is_subsample(site)}
-    aux_vars = {name for name, site in guide_trace.nodes.items()
-                if site["type"] == "sample" and site["infer"].get("is_auxiliary")}
-    model_vars = {name for name, site in model_trace.nodes.items()
-                  if site["type"] == "sample" and not site["is_observed"]
-                  and not poutine.util.site_is_subsample(site)}
-    enum_vars = {name for name, site in model_trace.nodes.items()
-                 if site["type"] == "sample" and not site["is_observed"]
-                 and site["infer"].get("_enumerate_dim") is not None
-                 and name not in guide_vars}
-    if aux_vars & model_vars:
-        warnings.warn("Found auxiliary vars in the model: {}".format(aux_vars & model_vars))
-    if not (guide_vars <= model_vars | aux_vars):
-        warnings.warn("Found non-auxiliary vars in guide but not model, consider marking these "
-                      "infer={{'is_auxiliary': True}}:\n{}".format(guide_vars - aux_vars - model_vars))
-    if not (model_vars <= guide_vars | enum_vars):
-        warnings.warn("Found vars in model but not guide: {}".format(
-            model_vars - guide_vars - enum_vars))
-    for name in model_vars & guide_vars:
-        m, g = model_trace.nodes[name], guide_trace.nodes[name]
-        if hasattr(m["fn"], "shape") and hasattr(g["fn"], "shape"):
-            ms, gs = m["fn"].shape(*m["args"], **m["kwargs"]) if False else m["fn"].shape(), \
-                g["fn"].shape()
-            if ms != gs and not (m["infer"].get("_enumerate_dim") is not None):
-                # allow broadcastable differences only
-                for a, b in zip(reversed(ms), reversed(gs)):
-                    if a != b and a != 1 and b != 1:
-                        raise ValueError("Model and guide shapes disagree at site '{}': {} vs {}"
-                                         .format(name, tuple(ms), tuple(gs)))
 
 
 def _config_fn(default, expand, num_samples, tmc):

@@ -12,12 +12,13 @@ through MultiFrameTensor); the difference is how the per-site terms are produced
     trace_elbo.py:90,97);
   * otherwise (non-reparameterised guide sites) the un-reduced path of the reference is taken.
 """
+from .util import is_validation_enabled
 import torch
 
 from ..distributions.fused import grad_sink as _grad_sink
 
 from ..distributions.util import is_identically_zero
-from ..util import torch_item, warn_if_nan
+from ..util import check_if_enumerated, torch_item, warn_if_nan
 from .elbo import ELBO
 from .enum import get_importance_trace
 from .util import MultiFrameTensor, get_plate_stacks
@@ -75,6 +76,8 @@ class Trace_ELBO(ELBO):
         # launch (see _batched_total), the general case takes the un-reduced path of the reference
         model_trace, guide_trace = get_importance_trace("flat", self.max_plate_nesting, model,
                                                         guide, args, kwargs, fused_sums="defer")
+        if is_validation_enabled():
+            check_if_enumerated(guide_trace)
         if self._guide_is_reparameterized(guide_trace):
             guide_trace._fully_reparam = True
         else:
@@ -97,7 +100,7 @@ class Trace_ELBO(ELBO):
         total = batch.total(coef)
         for sign, term in left:
             total = total + (coef * sign) * term
-        if settings.validation_enabled() and isinstance(total, torch.Tensor) \
+        if is_validation_enabled() and isinstance(total, torch.Tensor) \
                 and not bool(torch.isfinite(total.detach())):
             # name the offending site(s) the way the reference does (trace_struct.py:279-286)
             with torch.no_grad():
@@ -157,6 +160,8 @@ class Trace_ELBO(ELBO):
             surrogate_loss = surrogate_loss - s / self.num_particles
             loss = loss - e / self.num_particles
         warn_if_nan(surrogate_loss, "loss")
+        if not isinstance(surrogate_loss, torch.Tensor):       # a pair without sample sites
+            return loss
         return loss + (surrogate_loss - surrogate_loss.detach())
 
     def loss_and_grads(self, model, guide, *args, **kwargs):

@@ -8,6 +8,7 @@ on the sampled terms otherwise (:131-137).  Observed sites, fall-back sites and 
 go through the batched one-launch reduction of Trace_ELBO (distributions.fused.SiteBatch); the KL
 terms (small tensors, torch arithmetic) ride in the same launch as already-computed terms.
 """
+from .util import is_validation_enabled
 import warnings
 
 import torch
@@ -78,7 +79,7 @@ class TraceMeanField_ELBO(Trace_ELBO):
         if not getattr(guide_trace, "_fully_reparam", False):
             raise NotImplementedError("TraceMeanField_ELBO requires every guide site to be "
                                       "reparameterised (check_fully_reparametrized in the reference)")
-        if poutine.settings.validation_enabled():
+        if is_validation_enabled():
             _check_mean_field_requirement(model_trace, guide_trace)
         return model_trace, guide_trace
 

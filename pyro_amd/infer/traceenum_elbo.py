@@ -20,6 +20,8 @@ Scope of this plugin (what BASELINE config 4, examples/lda.py, needs):
     _check_model_guide_enumeration_constraint, traceenum_elbo.py:50-65).
 Sequential enumeration is supported for guide sites (one trace per joint assignment).
 """
+from .util import is_validation_enabled
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -30,9 +32,9 @@ from .. import poutine
 from ..distributions.util import scale_and_mask
 from ..ops.contract import LazyGather, Term, align, contract_tensor_tree, pack
 from ..poutine.util import prune_subsample_sites
-from ..util import torch_item, warn_if_nan
+from ..util import check_traceenum_requirements, torch_item, warn_if_nan
 from .elbo import ELBO
-from .enum import check_model_guide_match, config_enumerate  # noqa: F401
+from .enum import check_model_guide_match, check_site_shapes, config_enumerate  # noqa: F401
 from .trace_elbo import _signed_sum
 
 
@@ -128,10 +130,21 @@ class TraceEnum_ELBO(ELBO):
         model_enum = poutine.enum(model)
         model_trace = poutine.trace(poutine.replay(model_enum, trace=guide_trace)).get_trace(
             *args, **kwargs)
-        if poutine.settings.validation_enabled():
+        if is_validation_enabled():
             check_model_guide_match(model_trace, guide_trace, self.max_plate_nesting)
         guide_trace = prune_subsample_sites(guide_trace)
         model_trace = prune_subsample_sites(model_trace)
+        if is_validation_enabled():
+            check_site_shapes(model_trace, guide_trace, self.max_plate_nesting)
+            check_traceenum_requirements(model_trace, guide_trace)
+            enumerating = any(site["infer"].get("enumerate") for trace in (guide_trace, model_trace)
+                              for site in trace.nodes.values() if site["type"] == "sample")
+            if self.strict_enumeration_warning and not enumerating:
+                warnings.warn(
+                    "TraceEnum_ELBO found no sample sites configured for enumeration. If you want to "
+                    "enumerate sites, you need to @config_enumerate or set "
+                    'infer={"enumerate": "sequential"} or infer={"enumerate": "parallel"}? If you do '
+                    "not want to enumerate, consider using Trace_ELBO instead.")
         model_trace._first_enum_dim = first_enum_dim
         return model_trace, guide_trace
 

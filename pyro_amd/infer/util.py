@@ -2,6 +2,18 @@
 import torch
 
 from ..distributions.util import is_identically_zero
+from ..util import torch_item, zero_grads  # noqa: F401  (their reference home is pyro/infer/util.py)
+
+_VALIDATION_ENABLED = __debug__     # pyro.infer's own switch (pyro/infer/util.py:23-36)
+
+
+def enable_validation(is_validate):
+    global _VALIDATION_ENABLED
+    _VALIDATION_ENABLED = bool(is_validate)
+
+
+def is_validation_enabled():
+    return _VALIDATION_ENABLED
 
 
 class MultiFrameTensor:

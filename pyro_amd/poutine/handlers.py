@@ -12,7 +12,8 @@ import torch
 
 from .. import rng as _rng
 from . import settings
-from .runtime import (_DIM_ALLOCATOR, _ENUM_ALLOCATOR, Messenger, _BlockLike, _BoundHandler, apply_stack,
+from .runtime import (_DIM_ALLOCATOR, _ENUM_ALLOCATOR, Messenger, NonlocalExit, _BlockLike, _BoundHandler,
+                      apply_stack,
                       new_message)
 from .trace import Trace
 
@@ -91,7 +92,10 @@ class TraceMessenger(Messenger):
         return self.trace.copy()
 
     def _reset(self):
-        self.trace = Trace(self.graph_type)
+        fresh = Trace(self.graph_type)
+        if "_INPUT" in self.trace.nodes:        # a restarted run is still the same call
+            fresh.add_node("_INPUT", **self.trace.nodes["_INPUT"])
+        self.trace = fresh
 
     def _pyro_post_sample(self, msg):
         if self.param_only:
@@ -135,6 +139,28 @@ class ReplayMessenger(Messenger):
 
 
 # ---------------------------------------------------------------------------------------------
+class _HideRule:
+    """block's decision rule as a picklable object (wrapped models are torch.save'd by users)."""
+
+    def __init__(self, hide_all, hide, expose, hide_types, expose_types):
+        self.hide_all, self.hide, self.expose = hide_all, hide, expose
+        self.hide_types, self.expose_types = hide_types, expose_types
+
+    def __call__(self, msg):
+        kind = "observe" if msg["type"] == "sample" and msg["is_observed"] else msg["type"]
+        if msg["name"] in self.hide or kind in self.hide_types:
+            return True
+        return self.hide_all and msg["name"] not in self.expose and kind not in self.expose_types
+
+
+class _Negated:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, msg):
+        return not self.fn(msg)
+
+
 class BlockMessenger(Messenger, _BlockLike):
     """Hide sites from handlers outside (reference: block_messenger.py:19-84 decision rule, :101-168).
 
@@ -150,7 +176,7 @@ class BlockMessenger(Messenger, _BlockLike):
         if hide_fn is not None:
             self.hide_fn = hide_fn
         elif expose_fn is not None:
-            self.hide_fn = lambda msg: not expose_fn(msg)
+            self.hide_fn = _Negated(expose_fn)
         else:
             self.hide_fn = self._default_rule(hide_all, expose_all, hide, expose, hide_types,
                                               expose_types)
@@ -168,14 +194,7 @@ class BlockMessenger(Messenger, _BlockLike):
         hide_types, expose_types = frozenset(hide_types or ()), frozenset(expose_types or ())
         assert hide.isdisjoint(expose), "cannot hide and expose a site"
         assert hide_types.isdisjoint(expose_types), "cannot hide and expose a site type"
-
-        def rule(msg):
-            kind = "observe" if msg["type"] == "sample" and msg["is_observed"] else msg["type"]
-            if msg["name"] in hide or kind in hide_types:
-                return True
-            return hide_all and msg["name"] not in expose and kind not in expose_types
-
-        return rule
+        return _HideRule(hide_all, hide, expose, hide_types, expose_types)
 
     def _process_message(self, msg):
         msg["stop"] = bool(self.hide_fn(msg))
@@ -284,6 +303,122 @@ class DoMessenger(Messenger):
             raise NotImplementedError("Interventions of type {} not implemented (yet)".format(
                 type(intervention)))
         msg["value"], msg["is_observed"], msg["stop"] = intervention, True, True
+
+
+class EscapeMessenger(Messenger):
+    """Leave the program at the first sample site ``escape_fn`` accepts, by raising
+    :class:`NonlocalExit` carrying that site once the handlers below have seen it
+    (reference: escape_messenger.py:9-44)."""
+
+    def __init__(self, escape_fn):
+        super().__init__()
+        self.escape_fn = escape_fn
+
+    def _pyro_sample(self, msg):
+        if self.escape_fn(msg):
+            msg["done"] = True
+            msg["stop"] = True
+
+            def leave(m):
+                raise NonlocalExit(m)
+
+            msg["continuation"] = leave
+
+
+class LiftMessenger(Messenger):
+    """Turn ``pyro.param`` statements into ``pyro.sample`` statements drawn from ``prior``: a
+    distribution, a stochastic function of the param's initial tensor, or a dict of those by param
+    name -- unnamed params stay params (reference: lift_messenger.py:21-140)."""
+
+    def __init__(self, prior):
+        super().__init__()
+        self.prior = prior
+        self._drawn = {}
+
+    def __enter__(self):
+        self._drawn = {}
+        if settings.validation_enabled() and isinstance(self.prior, dict):
+            self._hits, self._misses = set(), set()
+        return super().__enter__()
+
+    def __exit__(self, *args):
+        self._drawn = {}
+        if settings.validation_enabled() and isinstance(self.prior, dict):
+            extra = set(self.prior) - self._hits
+            if extra:
+                warnings.warn("pyro.module prior did not find params ['{}']. Did you instead mean one "
+                              "of ['{}']?".format("', '".join(extra), "', '".join(self._misses)))
+        return super().__exit__(*args)
+
+    def _pyro_param(self, msg):
+        from ..params import user_param_name
+        from torch.distributions import Distribution
+        name = msg["name"]
+        key = user_param_name(name)
+        prior = self.prior
+        if isinstance(prior, dict):
+            validating = settings.validation_enabled()
+            if key not in prior:
+                if validating:
+                    self._misses.add(key)
+                return
+            if validating:
+                self._hits.add(key)
+            prior = prior[key]
+        if isinstance(prior, Distribution):
+            msg["fn"], msg["args"], msg["kwargs"], msg["infer"] = prior, (), {}, {}
+        elif callable(prior):
+            # called with what followed the name in the param statement (its initial tensor);
+            # a function-valued prior given directly (not through a dict) also hides the site
+            if not isinstance(self.prior, dict):
+                msg["stop"] = True
+            msg["fn"], msg["args"] = prior, msg["args"][1:]
+        else:
+            raise TypeError("prior must be a distribution, a callable or a dict of those")
+        msg["type"] = "sample"
+        if name in self._drawn:                 # the same param statement again: the same draw
+            msg["value"], msg["is_observed"], msg["stop"] = self._drawn[name]["value"], True, True
+        else:
+            self._drawn[name] = msg
+            msg["is_observed"] = False
+
+
+class EqualizeMessenger(Messenger):
+    """Force the primitive statements whose names match ``sites`` (full-match regular expressions)
+    to take the value of the first of them.  Later matches become observed ``Delta`` sites that
+    score nothing, or -- ``keep_dist=True`` -- keep their distribution, which conditions the model
+    on the values being equal (reference: equalize_messenger.py:14-103)."""
+
+    def __init__(self, sites, type="sample", keep_dist=False):
+        super().__init__()
+        self.sites = [sites] if isinstance(sites, str) else sites
+        self.type, self.keep_dist = type, keep_dist
+        self.value = None
+
+    def __enter__(self):
+        self.value = None
+        return super().__enter__()
+
+    def _matches(self, msg):
+        import re
+        return msg["type"] == self.type and any(re.fullmatch(pattern, msg["name"]) is not None
+                                                for pattern in self.sites)
+
+    def _postprocess_message(self, msg):
+        if self.value is None and self._matches(msg):
+            assert msg["value"] is not None
+            self.value = msg["value"]
+
+    def _process_message(self, msg):
+        if self.value is None or not self._matches(msg):
+            return
+        msg["value"] = self.value
+        if msg["type"] == "sample":
+            msg["is_observed"] = True
+            if not self.keep_dist:
+                from ..distributions import Delta
+                msg["infer"] = {"_deterministic": True}
+                msg["fn"] = Delta(self.value, event_dim=msg["fn"].event_dim).mask(False)
 
 
 class UnconditionMessenger(Messenger):
@@ -439,7 +574,8 @@ class PlateMessenger(Messenger):
         if settings.validation_enabled():
             self._check_no_conflict()
         super().__enter__()
-        return self.indices
+        # a plate of unknown size (``pyro.plate("name")``) has no indices to hand out
+        return self.indices if self._indices is not None or self.size >= 0 else None
 
     def __exit__(self, *args):
         if self._vectorized is True:
@@ -505,25 +641,37 @@ class PlateMessenger(Messenger):
             msg["fn"] = dist.expand(torch.Size(target))
 
     def _postprocess_message(self, msg):
-        if msg["type"] in ("param", "subsample") and self.dim is not None \
-                and self.subsample_size != self.size and self.subsample_size != -1:
-            event_dim = msg["kwargs"].get("event_dim")
-            if event_dim is not None:
-                dim = self.dim - event_dim
-                shape = msg["value"].shape
-                if len(shape) >= -dim and shape[dim] != 1:
-                    if settings.validation_enabled() and shape[dim] != self.size:
-                        raise ValueError("Inside pyro.plate({}, {}, dim={}) invalid shape of {}: {}"
-                                         .format(self.name, self.size, self.dim, msg["name"],
-                                                 tuple(shape)))
-                    value = msg["value"]
-                    new_value = value.index_select(dim, self._indices.to(value.device))
-                    if msg["type"] == "param":
-                        param = getattr(value, "_pyro_unconstrained_param", None)
-                        if param is None and hasattr(value, "unconstrained"):
-                            param = value.unconstrained()
-                        new_value._pyro_unconstrained_param = param
-                    msg["value"] = new_value
+        """``pyro.param(..., event_dim=e)`` and ``pyro.subsample(data, event_dim=e)`` inside a
+        vectorised plate: the tensor's dim at this plate must have the plate's full size (or 1, or be
+        absent) and is cut down to the current subsample (subsample_messenger.py:176-217)."""
+        if msg["type"] not in ("param", "subsample") or self.dim is None:
+            return
+        event_dim = msg["kwargs"].get("event_dim")
+        if event_dim is None:
+            return
+        assert event_dim >= 0
+        dim = self.dim - event_dim
+        value = msg["value"]
+        shape = value.shape
+        if len(shape) < -dim or shape[dim] == 1:
+            return
+        if settings.validation_enabled() and shape[dim] != self.size:
+            statement = "pyro.param({}, ..., event_dim={})".format(msg["name"], event_dim) \
+                if msg["type"] == "param" else "pyro.subsample(..., event_dim={})".format(event_dim)
+            raise ValueError("Inside pyro.plate({}, {}, dim={}) invalid shape of {}: {}".format(
+                self.name, self.size, self.dim, statement, shape))
+        if self.subsample_size < self.size:
+            new_value = value.index_select(dim, self._indices.to(value.device))
+            if msg["type"] == "param":
+                param = getattr(value, "_pyro_unconstrained_param", None)
+                if param is None:
+                    param = value.unconstrained()
+                # which rows of the parameter this step touches, for optimisers that care
+                if not hasattr(param, "_pyro_subsample"):
+                    param._pyro_subsample = {}
+                param._pyro_subsample[dim] = self._indices
+                new_value._pyro_unconstrained_param = param
+            msg["value"] = new_value
 
 
 # ---------------------------------------------------------------------------------------------
@@ -605,8 +753,8 @@ class EnumMessenger(Messenger):
                 and msg["infer"].get("_enum_total") is None:
             # neither branched on in the guide nor replayed from a guide site that was
             raise NotImplementedError(
-                "sequential enumeration is handled by TraceEnum_ELBO for GUIDE sites only "
-                "(site '{}'); use infer={{'enumerate': 'parallel'}} here".format(msg["name"]))
+                "At site {!r}, model-side sequential enumeration is not implemented. Try parallel "
+                "enumeration or guide-side enumeration.".format(msg["name"]))
         value = msg["value"]
         event_dim = len(msg["fn"].event_shape)
         shape = value.shape[:value.dim() - event_dim]
@@ -748,6 +896,41 @@ uncondition = _make_handler(UnconditionMessenger)
 substitute = _make_handler(SubstituteMessenger)
 infer_config = _make_handler(InferConfigMessenger)
 do = _make_handler(DoMessenger)
+escape = _make_handler(EscapeMessenger)
+equalize = _make_handler(EqualizeMessenger)
+lift = _make_handler(LiftMessenger)
+
+
+def queue(fn=None, queue=None, max_tries=None, extend_fn=None, escape_fn=None, num_samples=None):
+    """Sequential search: take a partial trace from ``queue``, replay ``fn`` against it until the
+    first site ``escape_fn(partial_trace, msg)`` accepts, push ``extend_fn``'s extensions of the
+    trace-so-far, repeat; the first complete run's return value is the result
+    (reference: pyro/poutine/handlers.py:542-606)."""
+    import functools
+    from . import util
+    max_tries = int(1e6) if max_tries is None else max_tries
+    extend_fn = util.enum_extend if extend_fn is None else extend_fn
+    escape_fn = util.discrete_escape if escape_fn is None else escape_fn
+    num_samples = -1 if num_samples is None else num_samples
+
+    def wrapper(wrapped):
+        def _fn(*args, **kwargs):
+            for _ in range(max_tries):
+                assert not queue.empty(), "trying to get() from an empty queue will deadlock"
+                partial_trace = queue.get()
+                traced = trace(escape(replay(wrapped, trace=partial_trace),
+                                      escape_fn=functools.partial(escape_fn, partial_trace)))
+                try:
+                    return traced(*args, **kwargs)
+                except NonlocalExit as exit_:
+                    exit_.reset_stack()
+                    for longer in extend_fn(traced.trace.copy(), exit_.site, num_samples=num_samples):
+                        queue.put(longer)
+            raise ValueError("max tries ({}) exceeded".format(max_tries))
+
+        return _fn
+
+    return wrapper(fn) if fn is not None else wrapper
 scale = _make_handler(ScaleMessenger)
 mask = _make_handler(MaskMessenger)
 enum = _make_handler(EnumMessenger)

@@ -6,6 +6,7 @@ handler stack; reference: pyro/poutine/runtime.py:108-181,334-390) so that model
 written for the reference run unchanged.  It is deliberately small: host code is plumbing, the
 numerics live in libpyro_amd.so.
 """
+import contextlib
 import functools
 
 _PYRO_STACK = []
@@ -246,3 +247,20 @@ def _query(kind):
     msg["value"] = None
     apply_stack(msg)
     return msg
+
+
+@contextlib.contextmanager
+def block_messengers(predicate):
+    """EXPERIMENTAL in the reference too (messenger.py:264-287): the handlers on the stack for which
+    ``predicate`` holds are muted (replaced by do-nothing handlers, without exit/enter) for the
+    duration of the context; yields the list of muted handlers."""
+    muted = {}
+    try:
+        for i, handler in enumerate(_PYRO_STACK):
+            if predicate(handler):
+                muted[i] = handler
+                _PYRO_STACK[i] = Messenger()
+        yield list(muted.values())
+    finally:
+        for i, handler in muted.items():
+            _PYRO_STACK[i] = handler

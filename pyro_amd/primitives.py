@@ -26,7 +26,9 @@ def set_rng_seed(seed):
 
 
 def enable_validation(is_validate=True):
+    from .infer import util as _infer_util
     dist.enable_validation(is_validate)
+    _infer_util.enable_validation(is_validate)
     _poutine_settings.enable_validation(is_validate)
 
 
@@ -35,12 +37,16 @@ class validation_enabled:
         self.is_validate = is_validate
 
     def __enter__(self):
-        self.prev = (dist.is_validation_enabled(), _poutine_settings.validation_enabled())
+        from .infer import util as _infer_util
+        self.prev = (dist.is_validation_enabled(), _poutine_settings.validation_enabled(),
+                     _infer_util.is_validation_enabled())
         enable_validation(self.is_validate)
 
     def __exit__(self, *a):
+        from .infer import util as _infer_util
         dist.enable_validation(self.prev[0])
         _poutine_settings.enable_validation(self.prev[1])
+        _infer_util.enable_validation(self.prev[2])
 
 
 def _partially_observed(name, fn, obs, obs_mask, *args, **kwargs):
@@ -106,12 +112,13 @@ def deterministic(name, value, event_dim=None):
 
 def param(name, init_tensor=None, constraint=dist.constraints.real, event_dim=None):
     """Fetch (creating on first use) a named learnable parameter."""
-    def fn(*a, **kw):
-        return _PARAM_STORE.get_param(name, init_tensor, constraint, event_dim)
-
     if not am_i_wrapped():
-        return fn()
-    msg = new_message("param", name, fn, (), {"event_dim": event_dim})
+        return _PARAM_STORE.get_param(name, init_tensor, constraint, event_dim)
+    # the message reads like the reference's (primitives.py:88-89): fn = the store's get_param,
+    # args = (name[, init]), kwargs = constraint / event_dim -- poutine.lift rewrites these
+    args = (name,) if init_tensor is None else (name, init_tensor)
+    msg = new_message("param", name, _PARAM_STORE.get_param, args,
+                      {"constraint": constraint, "event_dim": event_dim})
     apply_stack(msg)
     return msg["value"]
 
@@ -190,3 +197,36 @@ def module(name, nn_module, update_module_params=False):
             owner = attrgetter(head)(nn_module) if head else nn_module
             owner._parameters[leaf] = stored[pname]
     return nn_module
+
+
+def subsample(data, event_dim):
+    """``data`` cut down to the subsamples of the enclosing plates: each plate selects along its own dim,
+    counted from the right of ``data``'s batch part, i.e. left of the ``event_dim`` rightmost dims
+    (reference: pyro/primitives.py:237-280).  Outside of plates: ``data`` itself."""
+    assert isinstance(event_dim, int) and event_dim >= 0
+    if not am_i_wrapped():
+        return data
+    msg = new_message("subsample", None, None, (data, event_dim), {"event_dim": event_dim},
+                      value=data)
+    msg["done"] = True
+    apply_stack(msg)
+    return msg["value"]
+
+
+def random_module(name, nn_module, prior, *args, **kwargs):
+    """DEPRECATED in the reference too (primitives.py:506-543): a callable that returns a copy of
+    ``nn_module`` whose parameters are drawn from ``prior`` (``poutine.lift`` over ``pyro.module``)."""
+    import copy
+    import warnings as _warnings
+    from . import poutine as _poutine
+    _warnings.warn("The `random_module` primitive is deprecated, and will be removed in a future "
+                   "release. Use `pyro.nn.Module` to create Bayesian modules from `torch.nn.Module` "
+                   "instances.", FutureWarning)
+    assert hasattr(nn_module, "parameters"), "Module is not a NN module."
+    lifted = _poutine.lift(module, prior=prior)
+
+    def _fn():
+        # update_module_params=True: the draws have to end up in the returned copy
+        return lifted(name, copy.deepcopy(nn_module), *args, update_module_params=True, **kwargs)
+
+    return _fn

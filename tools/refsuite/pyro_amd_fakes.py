@@ -1,0 +1,61 @@
+"""Stand-ins for pyro.distributions.testing.fakes (test-support classes of the reference: distributions
+that claim NOT to be reparameterised, or whose score function must be used)."""
+import sys
+import types
+
+import pyro_amd.distributions as dist
+
+
+def install():
+    class NonreparameterizedBeta(dist.Beta):
+        has_rsample = False
+
+    class NonreparameterizedAnalyticBeta(dist.Beta):
+        has_rsample = False
+
+    class NonreparameterizedNormal(dist.Normal):
+        has_rsample = False
+
+    class NonreparameterizedGamma(dist.Gamma):
+        has_rsample = False
+
+    class NonreparameterizedDirichlet(dist.Dirichlet):
+        has_rsample = False
+
+    testing = types.ModuleType("pyro.distributions.testing")
+    fakes = types.ModuleType("pyro.distributions.testing.fakes")
+    for cls in (NonreparameterizedBeta, NonreparameterizedAnalyticBeta, NonreparameterizedNormal,
+                NonreparameterizedGamma, NonreparameterizedDirichlet):
+        setattr(fakes, cls.__name__, cls)
+    testing.fakes = fakes
+    testing.__path__ = []
+    sys.modules["pyro.distributions.testing"] = testing
+    sys.modules["pyro.distributions.testing.fakes"] = fakes
+    dist.testing = testing
+
+
+def install_out_of_scope():
+    """Names the reference's test files import that lie outside SURVEY 8 (other estimators, reparam
+    strategies): constructing one skips the test, so that the rest of the file still runs."""
+    import pytest
+    import pyro_amd.infer as infer
+
+    def _skipper(name):
+        def __init__(self, *args, **kwargs):
+            pytest.skip("out of scope for this package: " + name)
+        return type(name, (), {"__init__": __init__})
+
+    for name in ("EnergyDistance", "TraceTailAdaptive_ELBO", "RenyiELBO", "ReweightedWakeSleep",
+                 "TraceTMC_ELBO", "JitTraceTMC_ELBO", "SVGD", "CSIS", "Importance", "SMCFilter"):
+        if not hasattr(infer, name):
+            setattr(infer, name, _skipper(name))
+    tmc = types.ModuleType("pyro.infer.tracetmc_elbo")
+    tmc.TraceTMC_ELBO = infer.TraceTMC_ELBO
+    sys.modules["pyro.infer.tracetmc_elbo"] = tmc
+    if "pyro.infer.reparam" not in sys.modules:
+        reparam = types.ModuleType("pyro.infer.reparam")
+        for name in ("LatentStableReparam", "LocScaleReparam", "TransformReparam", "StableReparam",
+                     "SymmetricStableReparam", "NeuTraReparam", "ConjugateReparam"):
+            setattr(reparam, name, _skipper(name))
+        sys.modules["pyro.infer.reparam"] = reparam
+        infer.reparam = reparam
