@@ -42,36 +42,76 @@ def get_importance_trace(graph_type, max_plate_nesting, model, guide, args, kwar
     return model_trace, guide_trace
 
 
+def iter_discrete_escape(trace, msg):
+    """A latent site marked for sequential enumeration that ``trace`` does not hold yet."""
+    return (msg["type"] == "sample" and not msg["is_observed"]
+            and msg["infer"].get("enumerate") == "sequential" and msg["name"] not in trace)
+
+
+def iter_discrete_extend(trace, site, **ignored):
+    """One extension of ``trace`` per value in the support of ``site`` (each carrying the size of the
+    support as ``infer["_enum_total"]``)."""
+    support = site["fn"].enumerate_support(expand=bool(site["infer"].get("expand", False)))
+    for value in support:
+        chosen = site.copy()
+        chosen["infer"] = dict(site["infer"], _enum_total=support.shape[0])
+        chosen["value"] = value
+        longer = trace.copy()
+        longer.add_node(site["name"], **chosen)
+        yield longer
+
+
+def iter_discrete_traces(graph_type, fn, *args, **kwargs):
+    """All traces of ``fn`` over the joint support of its sequentially enumerated sites, depth first
+    (reference: pyro/infer/enum.py:88-111, on poutine.queue)."""
+    from queue import LifoQueue
+    pending = LifoQueue()
+    pending.put(poutine.Trace())
+    traced = poutine.trace(poutine.queue(fn, pending, escape_fn=iter_discrete_escape,
+                                         extend_fn=iter_discrete_extend), graph_type=graph_type)
+    while not pending.empty():
+        yield traced.get_trace(*args, **kwargs)
+
+
 def _config_fn(default, expand, num_samples, tmc):
     def fn(site):
         if site["type"] != "sample" or site["is_observed"]:
             return {}
-        if not getattr(site["fn"], "has_enumerate_support", False):
+        if type(site["fn"]).__name__ == "_Subsample":
             return {}
-        if site["infer"].get("enumerate") is not None:
-            return {}
-        return {"enumerate": default, "expand": expand}
+        infer = site["infer"]
+        if num_samples is not None:         # local sampling applies to every latent site
+            return {"enumerate": infer.get("enumerate", default),
+                    "num_samples": infer.get("num_samples", num_samples),
+                    "expand": infer.get("expand", expand), "tmc": infer.get("tmc", tmc)}
+        if getattr(site["fn"], "has_enumerate_support", False):
+            return {"enumerate": infer.get("enumerate", default),
+                    "expand": infer.get("expand", expand)}
+        return {}
 
     return fn
 
 
 def config_enumerate(guide=None, default="parallel", expand=False, num_samples=None, tmc="diagonal"):
-    """Mark every enumerable site of ``guide`` (or model) for enumeration."""
-    if default not in ("sequential", "parallel", None):
-        raise ValueError("Invalid default value. Expected 'sequential', 'parallel', or None")
+    """Mark the sites of ``guide`` (or of a model) for enumeration: every site that can enumerate its
+    support -- or, with ``num_samples=n``, every latent site for n local Monte-Carlo draws on an
+    enumeration dim.  A site's own ``infer`` entries win.  Usable as a decorator
+    (reference: pyro/infer/enum.py:138-220)."""
+    if default not in ("sequential", "parallel", "flat", None):
+        raise ValueError("Invalid default value. Expected 'sequential', 'parallel', or None, but got "
+                         "{}".format(repr(default)))
+    if expand not in (True, False):
+        raise ValueError("Invalid expand value. Expected True or False, but got {}".format(repr(expand)))
     if num_samples is not None:
-        # (reference: enum.py:138-220 + enumerate_site's Monte-Carlo branch) -- not built; summing
-        # the support exactly instead would silently change shapes and variance
-        raise NotImplementedError("pyro_amd: config_enumerate(num_samples=...) (Monte-Carlo "
-                                  "enumeration) is not implemented; enumerate exactly")
+        if not (isinstance(num_samples, numbers.Number) and num_samples > 0):
+            raise ValueError("Invalid num_samples, expected None or positive integer, but got "
+                             "{}".format(repr(num_samples)))
+        if default == "sequential":
+            raise ValueError('Local sampling does not support "sequential" sampling; use "parallel" '
+                             "sampling instead.")
+    if tmc == "full" and num_samples is not None and num_samples > 1:
+        expand = True
     if guide is None:
         return lambda g: config_enumerate(g, default=default, expand=expand,
                                           num_samples=num_samples, tmc=tmc)
-
-    cfg = _config_fn(default, expand, num_samples, tmc)
-
-    class _Infer(poutine.Messenger):
-        def _pyro_sample(self, msg):
-            msg["infer"].update(cfg(msg))
-
-    return _Infer()(guide)
+    return poutine.infer_config(guide, config_fn=_config_fn(default, expand, num_samples, tmc))

@@ -21,6 +21,7 @@ Scope of this plugin (what BASELINE config 4, examples/lda.py, needs):
 Sequential enumeration is supported for guide sites (one trace per joint assignment).
 """
 from .util import is_validation_enabled
+import math
 import warnings
 from collections import OrderedDict
 
@@ -30,7 +31,7 @@ from ..distributions.fused import grad_sink as _grad_sink
 
 from .. import poutine
 from ..distributions.util import scale_and_mask
-from ..ops.contract import LazyGather, Term, align, contract_tensor_tree, pack
+from ..ops.contract import LazyGather, Term, _eliminate, align, contract_tensor_tree, pack
 from ..poutine.util import prune_subsample_sites
 from ..util import check_traceenum_requirements, torch_item, warn_if_nan
 from .elbo import ELBO
@@ -47,6 +48,26 @@ def _packed(site, lp, first_enum_dim):
     return pack(lp, site["infer"].get("_dim_to_id", {}), -1 - first_enum_dim, _ordinal(site))
 
 
+def _check_local_sampling(model_trace, guide_trace):
+    """Warnings about ``num_samples`` sites (traceenum_elbo.py:68-108): different draw counts across
+    guide sites may bias the estimate; a site multiply sampled in the MODEL is summed like an
+    enumerated one, which is not an unbiased gradient."""
+    counts = {site["infer"]["num_samples"] for site in guide_trace.nodes.values()
+              if site["type"] == "sample" and site["infer"].get("enumerate") == "parallel"
+              and site["infer"].get("num_samples") is not None}
+    if len(counts) > 1:
+        warnings.warn("\n".join([
+            "Using different numbers of Monte Carlo samples for different guide sites in "
+            "TraceEnum_ELBO.", "This may be biased if the guide is not factorized"]), UserWarning)
+    for name, site in model_trace.nodes.items():
+        if site["type"] == "sample" and site["infer"].get("enumerate") == "parallel" \
+                and site["infer"].get("num_samples") and name not in guide_trace:
+            warnings.warn("\n".join([
+                "Site {} is multiply sampled in model,".format(site["name"]),
+                "expect incorrect gradient estimates from TraceEnum_ELBO.",
+                "Consider using exact enumeration or guide sampling if possible."]), RuntimeWarning)
+
+
 def _enum_log_prob(site):
     """log_prob of an enumerated site at its own enumerated support.  For a Categorical that was
     expanded over plates (``Categorical(doc_topics)`` inside the words plate of examples/lda.py) the
@@ -58,7 +79,8 @@ def _enum_log_prob(site):
     base = getattr(fn, "_base_logits", None)
     from ..distributions import Categorical
     if base is not None and type(fn).log_prob is Categorical.log_prob \
-            and site["infer"].get("_enumerate_dim") is not None and value.dim() >= 1:
+            and site["infer"].get("_enumerate_dim") is not None and value.dim() >= 1 \
+            and site["infer"].get("num_samples") is None:
         T, n = base.shape[-1], value.dim()
         batch = base.shape[:-1]
         if value.shape == (T,) + (1,) * (n - 1) and len(batch) <= n - 1 \
@@ -137,6 +159,7 @@ class TraceEnum_ELBO(ELBO):
         if is_validation_enabled():
             check_site_shapes(model_trace, guide_trace, self.max_plate_nesting)
             check_traceenum_requirements(model_trace, guide_trace)
+            _check_local_sampling(model_trace, guide_trace)
             enumerating = any(site["infer"].get("enumerate") for trace in (guide_trace, model_trace)
                               for site in trace.nodes.values() if site["type"] == "sample")
             if self.strict_enumeration_warning and not enumerating:
@@ -156,20 +179,46 @@ class TraceEnum_ELBO(ELBO):
         (pyro/infer/util.py:264-326, traceenum_elbo.py:112-214).  All tensors are packed Terms."""
         first_enum_dim = model_trace._first_enum_dim
 
+        marginals = {}
+        # a guide site enumerated SEQUENTIALLY splits the run into one trace per value; a cost that is
+        # not downstream of it (its plate context does not contain the site's) shows up unchanged in
+        # every one of those traces and has to be counted once (infer/util.py:238-262)
+        repeats = {}
+        for site in guide_trace.nodes.values():
+            if site["type"] == "sample" and site["infer"].get("enumerate") == "sequential" \
+                    and site["infer"].get("_enum_total") is not None:
+                o = _ordinal(site)
+                repeats[o] = repeats.get(o, 0.0) + math.log(site["infer"]["_enum_total"])
+
+        def once(cost):
+            log_denom = sum(v for o, v in repeats.items() if not o <= cost.ordinal)
+            return math.exp(-log_denom) if log_denom else 1.0
+
         def expectation(cost):
+            """cost . P(names the cost depends on): the weights of the upstream guide sites, with every
+            name the cost does NOT carry summed out first (variable elimination; never the joint
+            table over all enumerated guide sites -- infer/util.py:264-326 asks the marginals of the
+            same sum-product)."""
             fs = [f for f in dice if f.ordinal <= cost.ordinal]
             if not fs:
-                return cost.tensor.sum()
-            ids = sorted(set(cost.ids).union(*(f.ids for f in fs)))
-            total = None
-            for f in fs:
-                x = align(f, ids)
-                total = x if total is None else total + x
-            prob = total.exp()
+                return cost.tensor.sum() * once(cost)
+            key = (cost.ordinal, frozenset(cost.ids))
+            prob = marginals.get(key)
+            ids = sorted(cost.ids)
+            if prob is None:
+                other = set().union(*(f.ids for f in fs)) - set(cost.ids)
+                left = _eliminate(fs, other) if other else fs
+                total = None
+                for f in left:
+                    extra = set(f.ids) - set(ids)
+                    assert not extra, extra
+                    x = align(f, ids)
+                    total = x if total is None else total + x
+                prob = marginals[key] = total.exp()
             c = align(cost, ids)
             # zero-probability branches contribute nothing even where the cost is infinite
             c = torch.where(prob > 0, c, torch.zeros((), dtype=c.dtype, device=c.device))
-            return (prob * c).sum()
+            return (prob * c).sum() * once(cost)
 
         costs = []
         factors = OrderedDict()
@@ -244,7 +293,14 @@ class TraceEnum_ELBO(ELBO):
             if enumerated or not getattr(site["fn"], "has_rsample", False):
                 lq = site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"])
                 lq = scale_and_mask(lq, 1.0, site["mask"])     # masked, never scaled
-                if enumerated:
+                draws = site["infer"].get("num_samples") if site["infer"].get("enumerate") else None
+                if draws is not None:
+                    # n local draws instead of the support: each weighs 1/n, and a draw that is not
+                    # reparameterised carries its score function (infer/util.py:176-186)
+                    score = lq * 0.0 if getattr(site["fn"], "has_rsample", False) \
+                        else lq - lq.detach()
+                    dice.append(_packed(site, score - math.log(draws), first_enum_dim))
+                elif enumerated:
                     dice.append(_packed(site, lq, first_enum_dim))
                 elif lq.requires_grad:
                     dice.append(_packed(site, lq - lq.detach(), first_enum_dim))

@@ -716,8 +716,7 @@ class EnumMessenger(Messenger):
         if strategy != "parallel":
             return          # sequential: branched on by SequentialEnumMessenger (guide sites)
         if msg["infer"].get("num_samples") is not None:
-            raise NotImplementedError("pyro_amd: infer={'num_samples': ...} (Monte-Carlo enumeration) "
-                                      "is not implemented (site '%s')" % msg["name"])
+            return self._sample_locally(msg, scope, param_dims)
         dist = msg["fn"]
         if not getattr(dist, "has_enumerate_support", False):
             raise NotImplementedError("{} does not support enumeration".format(type(dist)))
@@ -738,6 +737,61 @@ class EnumMessenger(Messenger):
             value = value.expand(shape[:1] + (1,) * (-1 - dim - len(batch)) + batch + ev)
         if tag is not None:
             value._pyro_categorical_support = tag
+        value_dims = {d: param_dims[d] for d in range(event_dim - value.dim(), 0)
+                      if d in param_dims and value.size(d - event_dim) > 1}
+        value_dims[dim] = id_
+        msg["infer"]["_enumerate_dim"] = dim
+        msg["infer"]["_dim_to_id"] = value_dims
+        msg["value"] = value
+        msg["done"] = True
+
+    def _sample_locally(self, msg, scope, param_dims):
+        """``infer={"enumerate": "parallel", "num_samples": n}``: n draws on a fresh dim instead of the
+        support (local Monte-Carlo "enumeration"; enum_messenger.py:17-134).  Without ``expand`` the
+        draws keep only the plate dims of the batch shape: along every other batch dim of size > 1 (a
+        population of upstream particles) draw s keeps ONE ancestor -- its own index ("diagonal", the
+        default) or a uniformly chosen one ("mixture")."""
+        dist, n = msg["fn"], msg["infer"]["num_samples"]
+        event_dim = len(dist.event_shape)
+        if n > 1 and msg["infer"].get("expand", False):
+            value = dist(sample_shape=torch.Size([n]))
+        elif n > 1:
+            strategy = msg["infer"].get("tmc", "diagonal")
+            if strategy not in ("diagonal", "mixture"):
+                raise ValueError("{} not a valid TMC strategy".format(strategy))
+            value = dist(sample_shape=torch.Size([n]))
+            keep = [1] * len(dist.batch_shape)
+            for f in msg["cond_indep_stack"]:
+                if f.vectorized:
+                    keep[f.dim] = f.size if f.size > 0 else dist.batch_shape[f.dim]
+            for k, want in enumerate(keep):
+                d = 1 + k                                   # dim of `value` (0 is the draw axis)
+                have = value.shape[d]
+                if have > 1 and want == 1:
+                    if strategy == "diagonal":
+                        ancestor = torch.arange(have, device=value.device)
+                        if have != n:
+                            raise ValueError("diagonal TMC needs as many draws ({}) as upstream "
+                                             "particles ({}) at site '{}'".format(n, have, msg["name"]))
+                    else:
+                        ancestor = torch.randint(have, (n,), device=value.device)
+                    index_shape = list(value.shape)
+                    index_shape[d] = 1
+                    index = ancestor.reshape((n,) + (1,) * (value.dim() - 1)).expand(index_shape)
+                    value = value.gather(d, index)
+            assert tuple(value.shape) == (n,) + tuple(keep) + tuple(dist.event_shape)
+        else:
+            raise ValueError("num_samples must be greater than 1 at site '{}'".format(msg["name"]))
+        dim, id_ = _ENUM_ALLOCATOR.allocate(None if scope is None else set(param_dims))
+        actual_dim = -1 - len(dist.batch_shape)             # where the draw axis sits now
+        if dim < actual_dim:
+            value = value.reshape(value.shape[:1] + (1,) * (actual_dim - dim) + value.shape[1:])
+        elif actual_dim < dim:
+            assert value.size(dim - event_dim) == 1, \
+                "pyro.markov dim conflict at dim {}".format(actual_dim)
+            value = value.transpose(dim - event_dim, actual_dim - event_dim)
+            while value.dim() and value.size(0) == 1:
+                value = value.squeeze(0)
         value_dims = {d: param_dims[d] for d in range(event_dim - value.dim(), 0)
                       if d in param_dims and value.size(d - event_dim) > 1}
         value_dims[dim] = id_

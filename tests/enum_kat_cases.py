@@ -535,3 +535,96 @@ def run_enum_discrete_vectorized_num_particles(device, enumerate_, expand, num_p
                           strict_enumeration_warning=(enumerate_ == "parallel"))
     loss = elbo.loss(model, model)
     assert loss == loss and abs(loss) != float("inf")
+
+
+def run_elbo_plate_plate(device, enums):
+    """tests/infer/test_enum.py:944-1016 with every guide site enumerated: w outside, x in plate
+    "outer", y in plate "inner", z in both.  A sequentially enumerated site splits the run into one
+    trace per value, and the costs that are not downstream of it must still count once: the loss is
+    (1 + outer + inner + outer*inner) KLs exactly."""
+    from torch.distributions import kl_divergence
+    pyro.clear_param_store()
+    outer_dim, inner_dim = 2, 2
+    q = pyro.param("q", torch.tensor(0.75, dtype=torch.float64, device=device, requires_grad=True))
+    p = torch.tensor(0.2693204236205713, dtype=torch.float64, device=device)
+
+    def program(d, infers):
+        context1 = pyro.plate("outer", outer_dim, dim=-1)
+        context2 = pyro.plate("inner", inner_dim, dim=-2)
+        pyro.sample("w", d, infer=infers[0])
+        with context1:
+            pyro.sample("x", d, infer=infers[1])
+        with context2:
+            pyro.sample("y", d, infer=infers[2])
+        with context1, context2:
+            pyro.sample("z", d, infer=infers[3])
+
+    def model():
+        program(dist.Bernoulli(p), [{}] * 4)
+
+    def guide():
+        program(dist.Bernoulli(pyro.param("q")), [{"enumerate": e} for e in enums])
+
+    kl = (1 + outer_dim + inner_dim + outer_dim * inner_dim) * kl_divergence(
+        torch.distributions.Bernoulli(q), torch.distributions.Bernoulli(p))
+    expected_grad = grad(kl, [q])[0]
+    elbo = TraceEnum_ELBO(num_particles=1, vectorize_particles=True, strict_enumeration_warning=True)
+    actual_loss = elbo.loss_and_grads(model, guide)
+    assert abs(actual_loss - kl.item()) < 1e-6, (actual_loss, kl.item())
+    assert abs(float(pyro.param("q").grad) - float(expected_grad)) < 1e-6
+
+
+def run_local_sampling(device, num_samples=20000, tmc="diagonal", expand=False):
+    """``num_samples`` draws on an enumeration dim instead of the support (tests/infer/test_enum.py:
+    454-540, 797-870): two dependent Bernoulli sites in a plate, both multiply sampled in the guide.
+    The estimate is the exact ELBO up to Monte-Carlo error; the gradient is the score-function one."""
+    from torch.distributions import kl_divergence
+    pyro.clear_param_store()
+    pyro.set_rng_seed(0)
+    q = pyro.param("q", torch.tensor(0.75, dtype=torch.float64, device=device, requires_grad=True))
+    p = torch.tensor(0.2693204236205713, dtype=torch.float64, device=device)
+    infer = {"enumerate": "parallel", "num_samples": num_samples, "tmc": tmc, "expand": expand}
+
+    def model():
+        pyro.sample("y", dist.Bernoulli(p))
+        with pyro.plate("plate", 3):
+            pyro.sample("z", dist.Bernoulli(p))
+
+    def guide():
+        qq = pyro.param("q")
+        pyro.sample("y", dist.Bernoulli(qq), infer=infer)
+        with pyro.plate("plate", 3):
+            pyro.sample("z", dist.Bernoulli(qq), infer=infer)
+
+    kl = 4 * kl_divergence(torch.distributions.Bernoulli(q), torch.distributions.Bernoulli(p))
+    expected_grad = grad(kl, [q])[0]
+    elbo = TraceEnum_ELBO(max_plate_nesting=1, strict_enumeration_warning=True)
+    actual_loss = elbo.loss_and_grads(model, guide)
+    assert abs(actual_loss - kl.item()) < 0.05 * kl.item(), (actual_loss, kl.item())
+    assert abs(float(pyro.param("q").grad) - float(expected_grad)) < 0.05 * abs(float(expected_grad)), \
+        (float(pyro.param("q").grad), float(expected_grad))
+    # shapes: the draws sit on their own dim left of the plate
+    tr = poutine.trace(poutine.enum(guide, first_available_dim=-2)).get_trace()
+    assert tr.nodes["y"]["value"].shape == (num_samples, 1)
+    assert tr.nodes["z"]["value"].shape[-1] == 3 and tr.nodes["z"]["value"].shape[0] == num_samples
+
+
+def run_local_sampling_of_a_reparameterised_site(device):
+    """A Normal guide site with num_samples: pathwise gradients, each draw weighing 1/n."""
+    pyro.clear_param_store()
+    pyro.set_rng_seed(1)
+    loc = pyro.param("loc", torch.tensor(0.3, dtype=torch.float64, device=device, requires_grad=True))
+    one = torch.ones((), dtype=torch.float64, device=device)
+
+    def model():
+        pyro.sample("x", dist.Normal(0.0 * one, one))
+
+    def guide():
+        pyro.sample("x", dist.Normal(pyro.param("loc"), one),
+                    infer={"enumerate": "parallel", "num_samples": 50000})
+
+    elbo = TraceEnum_ELBO(max_plate_nesting=0)
+    loss = elbo.loss_and_grads(model, guide)
+    # KL(N(loc,1) || N(0,1)) = loc^2 / 2, gradient loc
+    assert abs(loss - 0.045) < 0.01, loss
+    assert abs(float(pyro.param("loc").grad) - 0.3) < 0.02

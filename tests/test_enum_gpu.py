@@ -152,6 +152,22 @@ def test_sequential_guide_enumeration_equals_parallel(gpu):
     ekc.run_sequential_equals_parallel(gpu)
 
 
+@pytest.mark.parametrize("enums", [("sequential",) * 4, ("parallel",) * 4,
+                                   ("parallel", "sequential", "parallel", "sequential"),
+                                   ("sequential", "sequential", "parallel", "parallel")], ids="-".join)
+def test_elbo_plate_plate(gpu, enums):
+    ekc.run_elbo_plate_plate(gpu, enums)
+
+
+@pytest.mark.parametrize("tmc,expand", [("diagonal", False), ("mixture", False), ("diagonal", True)])
+def test_local_monte_carlo_sampling(gpu, tmc, expand):
+    ekc.run_local_sampling(gpu, tmc=tmc, expand=expand)
+
+
+def test_local_sampling_of_a_reparameterised_site(gpu):
+    ekc.run_local_sampling_of_a_reparameterised_site(gpu)
+
+
 @pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-5)])
 def test_discrete_hmm_matches_reference(gpu, dtype, rtol):
     ec.run_discrete_hmm(load("discrete_hmm"), gpu, dtype=dtype, rtol=rtol)

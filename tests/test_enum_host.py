@@ -158,19 +158,47 @@ def test_enum_discrete_vectorized_num_particles(_cpu_backend, enumerate_, expand
     ekc.run_enum_discrete_vectorized_num_particles(CPU, enumerate_, expand, num_particles)
 
 
-def test_monte_carlo_enumeration_is_refused(_cpu_backend):
+@pytest.mark.parametrize("enums", [("sequential",) * 4, ("parallel",) * 4,
+                                   ("parallel", "sequential", "parallel", "sequential"),
+                                   ("sequential", "parallel", "sequential", "parallel"),
+                                   ("parallel", "parallel", "sequential", "sequential"),
+                                   ("sequential", "sequential", "parallel", "parallel"),
+                                   ("parallel", "sequential", "sequential", "parallel")], ids="-".join)
+def test_elbo_plate_plate(_cpu_backend, enums):
+    ekc.run_elbo_plate_plate(CPU, enums)
+
+
+@pytest.mark.parametrize("tmc,expand", [("diagonal", False), ("mixture", False), ("diagonal", True)])
+def test_local_monte_carlo_sampling(_cpu_backend, tmc, expand):
+    ekc.run_local_sampling(CPU, tmc=tmc, expand=expand)
+
+
+def test_local_sampling_of_a_reparameterised_site(_cpu_backend):
+    ekc.run_local_sampling_of_a_reparameterised_site(CPU)
+
+
+def test_config_enumerate_arguments(_cpu_backend):
     import pyro_amd as pyro
     import pyro_amd.distributions as dist
-    from pyro_amd.infer import TraceEnum_ELBO, config_enumerate
-    with pytest.raises(NotImplementedError):
-        config_enumerate(lambda: None, num_samples=10)
+    from pyro_amd import poutine
+    from pyro_amd.infer import config_enumerate
+    for bad in (dict(default="bogus"), dict(expand=None), dict(num_samples=0),
+                dict(default="sequential", num_samples=3)):
+        with pytest.raises(ValueError):
+            config_enumerate(lambda: None, **bad)
 
-    def model():
-        pyro.sample("x", dist.Bernoulli(torch.tensor(0.3)),
-                    infer={"enumerate": "parallel", "num_samples": 5})
+    def guide():
+        pyro.sample("a", dist.Bernoulli(torch.tensor(0.5)))
+        pyro.sample("b", dist.Normal(torch.tensor(0.0), 1.0))
+        pyro.sample("c", dist.Bernoulli(torch.tensor(0.5)), infer={"enumerate": "sequential"})
 
-    with pytest.raises(NotImplementedError):
-        TraceEnum_ELBO(max_plate_nesting=0).loss(model, lambda: None)
+    tr = poutine.trace(config_enumerate(guide)).get_trace()
+    assert tr.nodes["a"]["infer"] == {"enumerate": "parallel", "expand": False}
+    assert tr.nodes["b"]["infer"] == {}
+    assert tr.nodes["c"]["infer"] == {"enumerate": "sequential", "expand": False}
+    tr = poutine.trace(config_enumerate(guide, num_samples=7, tmc="full")).get_trace()
+    assert tr.nodes["b"]["infer"] == {"enumerate": "parallel", "num_samples": 7, "expand": True,
+                                      "tmc": "full"}
 
 
 # ---- posterior of the enumerated sites: the reference's compute_marginals / sample_posterior tests
