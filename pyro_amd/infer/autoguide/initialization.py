@@ -74,6 +74,28 @@ def init_to_value(site=None, values=None, *, fallback=init_to_uniform):
     return fallback(site)
 
 
+class _InitToGenerated:
+    def __init__(self, generate):
+        self.generate = generate
+        self._init = None
+        self._seen = set()
+
+    def __call__(self, site):
+        # a site name coming round again means a new execution of the model: new strategy
+        if self._init is None or site["name"] in self._seen:
+            self._init = self.generate()
+            self._seen = set()
+        self._seen.add(site["name"])
+        return self._init(site)
+
+
+def init_to_generated(site=None, generate=lambda: init_to_uniform):
+    """Initialise with the strategy ``generate()`` returns, asked for once per execution of the model
+    -- e.g. an ``init_to_value`` over freshly drawn values (initialization.py:183-217)."""
+    init = _InitToGenerated(generate)
+    return init if site is None else init(site)
+
+
 class InitMessenger(Messenger):
     """Set the value of each latent site with an init strategy instead of sampling."""
 

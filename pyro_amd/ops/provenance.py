@@ -16,7 +16,18 @@ _EMPTY = frozenset()
 
 
 class ProvenanceTensor(torch.Tensor):
+    """``ProvenanceTensor(data, provenance)``: ``data`` (same storage) carrying the frozenset."""
     _pa_provenance = _EMPTY
+
+    def __new__(cls, data, provenance=_EMPTY, **kwargs):
+        if not provenance:
+            return data
+        out = data.as_subclass(cls)
+        out._pa_provenance = frozenset(provenance) | get_provenance(data)
+        return out
+
+    def __init__(self, data, provenance=_EMPTY):
+        pass
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -32,7 +43,7 @@ class ProvenanceTensor(torch.Tensor):
 def _collect(x, found, depth=0):
     if isinstance(x, torch.Tensor):
         found.update(getattr(x, "_pa_provenance", _EMPTY))
-    elif isinstance(x, (list, tuple)):
+    elif isinstance(x, (list, tuple, set, frozenset)):
         for v in x:
             _collect(v, found, depth)
     elif isinstance(x, dict):
@@ -58,11 +69,21 @@ def track_provenance(x, provenance):
     """An alias of ``x`` (same storage, same autograd history) carrying ``provenance`` in addition to
     what ``x`` carries; ``x`` itself is left as it is."""
     provenance = frozenset(provenance)
-    if not isinstance(x, torch.Tensor) or not provenance:
+    if not provenance:
         return x
-    tagged = x.as_subclass(ProvenanceTensor)         # a new Python object even for a tagged x
-    tagged._pa_provenance = provenance | get_provenance(x)
-    return tagged
+    if isinstance(x, torch.Tensor):
+        tagged = x.as_subclass(ProvenanceTensor)     # a new Python object even for a tagged x
+        tagged._pa_provenance = provenance | get_provenance(x)
+        return tagged
+    # containers: every tensor inside, the container type kept
+    if isinstance(x, (list, set, frozenset)):
+        return type(x)(track_provenance(v, provenance) for v in x)
+    if isinstance(x, tuple):
+        items = [track_provenance(v, provenance) for v in x]
+        return type(x)(*items) if hasattr(x, "_fields") else tuple(items)
+    if isinstance(x, dict):
+        return type(x)((k, track_provenance(v, provenance)) for k, v in x.items())
+    return x
 
 
 def get_provenance(x):

@@ -46,7 +46,10 @@ def install_out_of_scope():
         return type(name, (), {"__init__": __init__})
 
     for name in ("EnergyDistance", "TraceTailAdaptive_ELBO", "RenyiELBO", "ReweightedWakeSleep",
-                 "TraceTMC_ELBO", "JitTraceTMC_ELBO", "SVGD", "CSIS", "Importance", "SMCFilter"):
+                 "TraceTMC_ELBO", "JitTraceTMC_ELBO", "SVGD", "CSIS", "Importance", "SMCFilter",
+                 "MHResampler", "WeighedPredictive", "Resampler", "RBFSteinKernel", "SMCFailed",
+                 "EmpiricalMarginal", "TracePosterior", "TracePredictive", "DiscreteHMCGibbs",
+                 "EasyGuide", "BetaBinomialPair", "GammaPoissonPair", "UnitJacobianReparam"):
         if not hasattr(infer, name):
             setattr(infer, name, _skipper(name))
     for name in ("Stable", "ProjectedNormal", "ZeroInflatedPoisson", "OrderedLogistic",
@@ -60,6 +63,15 @@ def install_out_of_scope():
     imp = types.ModuleType("pyro.infer.importance")
     imp.vectorized_importance_weights = lambda *a, **k: pytest.skip("out of scope: importance weights")
     imp.Importance = infer.Importance
+    imp.psis_diagnostic = lambda *a, **k: pytest.skip("out of scope: psis_diagnostic")
+    nn = types.ModuleType("pyro.nn")
+    for name in ("PyroModule", "PyroParam", "PyroSample", "AutoRegressiveNN", "DenseNN", "pyro_method"):
+        setattr(nn, name, _skipper(name))
+    sys.modules["pyro.nn"] = nn
+    multi = types.ModuleType("pyro.optim.multi")
+    for name in ("MultiOptimizer", "MixedMultiOptimizer", "Newton", "PyroMultiOptimizer", "TorchMultiOptimizer"):
+        setattr(multi, name, _skipper(name))
+    sys.modules["pyro.optim.multi"] = multi
     sys.modules["pyro.infer.importance"] = imp
     import collections
     import pyro_amd.infer.util as infer_util
