@@ -262,6 +262,9 @@ class Beta(_GammaFunctionFamily, torch.distributions.Beta, TorchDistributionMixi
 
     def __init__(self, concentration1, concentration0, validate_args=None):
         concentration1, concentration0 = _on_device(concentration1, concentration0)
+        if not isinstance(concentration1, torch.Tensor):       # Beta(1.0, 1.0): all Python numbers
+            concentration1, concentration0 = torch.distributions.utils.broadcast_all(
+                concentration1, concentration0)
         super().__init__(concentration1, concentration0, validate_args=validate_args)
         # the operands as given: torch keeps only their stack (the Dirichlet it samples from), and
         # reading them back out of it would put a select + stack-backward pair on every gradient

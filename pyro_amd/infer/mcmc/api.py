@@ -127,8 +127,9 @@ class MCMC:
                                       for k, v in initial_params.items()}
             kernel.initial_params = initial_params
         self._given_initial_params = initial_params
-        if mp_context is not None:
-            warnings.warn("mp_context is ignored: chains are vectorised on the GPU, not forked")
+        # mp_context (how the reference forks one process per chain) has nothing to configure here:
+        # the chains are one vectorised batch on the device; accepted and ignored, silently, so that
+        # scripts written for the reference run unchanged
 
     def run(self, *args, **kwargs):
         k = self.kernel

@@ -140,6 +140,77 @@ def _guess_max_plate_nesting(model, args, kwargs):
     return -min(dims) if dims else 0
 
 
+def enum_log_joint(trace, nplates, C=None):
+    """log of the joint density of ``trace`` with every enumerated site summed out: one value per
+    chain (``C`` given; the chain plate is the outermost of the ``nplates`` plate dims) or a scalar.
+    As in the reference every factor enters scaled and masked (trace_struct.py:248-288)."""
+    from ...ops.contract import contract_tensor_tree, pack
+
+    terms, enum_ids = [], set()
+    for name, site in trace.nodes.items():
+        if site["type"] != "sample" or type(site["fn"]).__name__ == "_Subsample":
+            continue
+        mask = site["mask"]
+        if mask is False:
+            continue
+        lp = scale_and_mask(site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"]),
+                            site["scale"], None if mask is True else mask)
+        ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
+        terms.append(pack(lp, site["infer"].get("_dim_to_id", {}), nplates, ordinal))
+        edim = site["infer"].get("_enumerate_dim")
+        if edim is not None:
+            enum_ids.add(site["infer"]["_dim_to_id"][edim])
+
+    def reduce(t):
+        if C is None:
+            return t.sum()
+        if t.dim() == nplates and t.shape[0] == C:
+            return t.reshape(C, -1).sum(-1)
+        return t.sum()         # the same for every chain
+
+    total = 0.0
+    factors = OrderedDict()
+    for term in terms:
+        if term.dims & enum_ids:
+            factors.setdefault(term.ordinal, []).append(term)
+        else:
+            total = total + reduce(term.tensor)
+    if factors:
+        for out in contract_tensor_tree(factors, enum_ids).values():
+            for term in out:
+                total = total + reduce(term.tensor)
+    return total
+
+
+class TraceEinsumEvaluator:
+    """``log_prob(model_trace)``: the log joint of a trace whose discrete latent sites were enumerated
+    in parallel, with those sites summed out by plated variable elimination -- what HMC/NUTS
+    differentiate for models with discrete latents (interface of pyro/infer/mcmc/util.py:161-241;
+    the reference also has a TraceTreeEvaluator that walks the plate tree instead of calling einsum --
+    same answers, and the same class here)."""
+
+    def __init__(self, model_trace, has_enumerable_sites=False, max_plate_nesting=None):
+        self.has_enumerable_sites = has_enumerable_sites
+        self.max_plate_nesting = max_plate_nesting
+        if has_enumerable_sites and max_plate_nesting is None:
+            raise ValueError("Finite value required for `max_plate_nesting` when model has discrete "
+                             "(enumerable) sites.")
+
+    def log_prob(self, model_trace):
+        if not self.has_enumerable_sites:
+            return model_trace.log_prob_sum()
+        from ...util import check_site_shape
+        from ..util import is_validation_enabled
+        if is_validation_enabled():
+            for site in model_trace.nodes.values():
+                if site["type"] == "sample" and type(site["fn"]).__name__ != "_Subsample":
+                    check_site_shape(site, self.max_plate_nesting)
+        return enum_log_joint(model_trace, self.max_plate_nesting)
+
+
+TraceTreeEvaluator = TraceEinsumEvaluator
+
+
 class _PEMaker:
     def __init__(self, model, model_args, model_kwargs, transforms, max_plate_nesting, num_chains,
                  batch_ndims):
@@ -149,6 +220,23 @@ class _PEMaker:
         self.C = num_chains
         self.batch_ndims = batch_ndims   # site -> number of batch dims of its distribution
         self.enum = False                # the model has discrete latent sites to sum out
+
+    # torch drops the strong reference an inverse transform holds to its transform when pickled
+    # (Transform.__getstate__ sets _inv = None): potential functions are torch.save'd by users
+    # (the reference patches torch for this, distributions/torch_patch.py:45-53), so the
+    # inverse transforms travel as their base transform
+    def __getstate__(self):
+        from torch.distributions.transforms import _InverseTransform
+        state = self.__dict__.copy()
+        state["transforms"] = {k: ("inv", t._inv) if isinstance(t, _InverseTransform) else ("fwd", t)
+                               for k, t in self.transforms.items()}
+        return state
+
+    def __setstate__(self, state):
+        state = dict(state)
+        state["transforms"] = {k: (t.inv if kind == "inv" else t)
+                               for k, (kind, t) in state["transforms"].items()}
+        self.__dict__.update(state)
 
     def _chain_value(self, name, v):
         """[C, *site_shape] -> [C, 1 ... 1, *site_shape] so the chain dim sits at
@@ -177,45 +265,7 @@ class _PEMaker:
         return lp.sum()   # does not depend on the chain: a constant shared by all chains
 
     def _enum_log_joint(self, trace, nplates, C):
-        """log of the joint density with every enumerated site summed out: one value per chain
-        (``C`` given; the chain plate is the outermost of the ``nplates`` plate dims) or a scalar.
-        As in the reference every factor enters scaled and masked (trace_struct.py:248-288)."""
-        from ...ops.contract import contract_tensor_tree, pack
-
-        terms, enum_ids = [], set()
-        for name, site in trace.nodes.items():
-            if site["type"] != "sample" or type(site["fn"]).__name__ == "_Subsample":
-                continue
-            mask = site["mask"]
-            if mask is False:
-                continue
-            lp = scale_and_mask(site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"]),
-                                site["scale"], None if mask is True else mask)
-            ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
-            terms.append(pack(lp, site["infer"].get("_dim_to_id", {}), nplates, ordinal))
-            edim = site["infer"].get("_enumerate_dim")
-            if edim is not None:
-                enum_ids.add(site["infer"]["_dim_to_id"][edim])
-
-        def reduce(t):
-            if C is None:
-                return t.sum()
-            if t.dim() == nplates and t.shape[0] == C:
-                return t.reshape(C, -1).sum(-1)
-            return t.sum()         # the same for every chain
-
-        total = 0.0
-        factors = OrderedDict()
-        for term in terms:
-            if term.dims & enum_ids:
-                factors.setdefault(term.ordinal, []).append(term)
-            else:
-                total = total + reduce(term.tensor)
-        if factors:
-            for out in contract_tensor_tree(factors, enum_ids).values():
-                for term in out:
-                    total = total + reduce(term.tensor)
-        return total
+        return enum_log_joint(trace, nplates, C)
 
     def _enumerated(self, fn, nplates):
         from ..enum import config_enumerate
@@ -274,9 +324,8 @@ def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
     With ``num_chains > 1`` the initial parameters carry a leading chain dim and the potential
     maps them to one energy per chain."""
     model_kwargs = {} if model_kwargs is None else model_kwargs
-    if jit_compile:
-        import warnings
-        warnings.warn("jit_compile is ignored: the leapfrog loop runs HIP kernels directly")
+    # jit_compile / jit_options / skip_jit_warnings: accepted for scripts written for the reference; there is
+    # no tracing compiler here (kernels capture their rounds in HIP graphs, see HMC(jit_compile=True))
     automatic = transforms is None
     transforms = {} if transforms is None else dict(transforms)
     if max_plate_nesting is None:
@@ -287,6 +336,16 @@ def initialize_model(model, model_args=(), model_kwargs=None, transforms=None,
                                                                             **model_kwargs)
 
     trace = draw()
+    from ...util import check_site_shape
+    from ..util import is_validation_enabled
+    discrete = [name for name, node in trace.iter_stochastic_nodes()
+                if getattr(node["fn"], "has_enumerate_support", False)]
+    if discrete and is_validation_enabled():
+        # summing out discrete sites relies on the plate structure: every batch dim must be declared
+        # (the reference checks this in TraceEinsumEvaluator, mcmc/util.py:196-203)
+        for node in trace.nodes.values():
+            if node["type"] == "sample" and type(node["fn"]).__name__ != "_Subsample":
+                check_site_shape(node, max_plate_nesting)
     # batch dims that are not declared through a plate count too: the chain plate must sit to the
     # left of every batch dim of every site
     for node in trace.nodes.values():
@@ -366,3 +425,12 @@ def _finite_start(potential_fn, params, num_chains):
         if g is not None:
             ok = ok & torch.isfinite(g.reshape(num_chains, -1)).all(1)
     return ok
+
+
+def __getattr__(name):
+    # pyro.infer.mcmc.util is where the reference keeps these (mcmc/util.py:620-806); they live next
+    # to the MCMC driver here (api.py imports this module, hence the late lookup)
+    if name in ("select_samples", "diagnostics", "print_summary"):
+        from . import api
+        return getattr(api, name)
+    raise AttributeError("module {!r} has no attribute {!r}".format(__name__, name))

@@ -10,3 +10,4 @@ from .plate_messenger import block_plate  # noqa: F401
 from .trace import Trace  # noqa: F401
 from . import util  # noqa: F401
 from .util import prune_subsample_sites, site_is_subsample  # noqa: F401
+from .messenger import unwrap  # noqa: E402,F401

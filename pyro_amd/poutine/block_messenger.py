@@ -1,0 +1,3 @@
+"""pyro.poutine.block_messenger: the reference's module path for these names (they live in handlers.py /
+runtime.py / trace.py here)."""
+from .handlers import BlockMessenger  # noqa: F401

@@ -1,0 +1,3 @@
+"""pyro.poutine.markov_messenger: the reference's module path for these names (they live in handlers.py /
+runtime.py / trace.py here)."""
+from .handlers import MarkovMessenger  # noqa: F401

@@ -1,5 +1,6 @@
 """Small shared utilities (reference: pyro/util.py:107-146 warn_if_nan/inf, pyro/infer/util.py
 torch_item / zero_grads)."""
+import contextlib
 import itertools
 import math
 import numbers
@@ -88,6 +89,61 @@ def scalar_like(prototype, fill_value):
 
 
 from .rng import get_rng_state, set_rng_seed, set_rng_state  # noqa: E402,F401  (pyro/util.py:37-63)
+
+
+# ---- small conveniences user code imports from pyro.util (pyro/util.py:639-725) -----------------------------
+class optional:
+    """``with optional(ctx, condition):`` enters ``ctx`` only if ``condition`` holds."""
+
+    def __init__(self, context_manager, condition):
+        self.context_manager, self.condition = context_manager, condition
+
+    def __enter__(self):
+        if self.condition:
+            return self.context_manager.__enter__()
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        if self.condition:
+            return self.context_manager.__exit__(exc_type, exc_val, exc_tb)
+
+
+class ExperimentalWarning(UserWarning):
+    pass
+
+
+@contextlib.contextmanager
+def ignore_experimental_warning():
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", category=ExperimentalWarning)
+        yield
+
+
+@contextlib.contextmanager
+def ignore_jit_warnings(filter=None):
+    """Nothing is traced by a compiler here (HIP graphs capture launches, not Python), so there are no
+    tracer warnings to silence; kept so that models written for the reference run unchanged."""
+    yield
+
+
+def jit_iter(tensor):
+    return list(tensor)
+
+
+class timed:
+    def __enter__(self):
+        import timeit
+        self._timer = timeit.default_timer
+        self.start = self._timer()
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.end = self._timer()
+        self.elapsed = self.end - self.start
+
+
+def torch_float(x):
+    return x.float() if isinstance(x, torch.Tensor) else float(x)
+
 
 
 # ---- model / guide structure checks (run under pyro.enable_validation; pyro/util.py:284-636) --------------

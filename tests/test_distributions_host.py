@@ -60,3 +60,14 @@ def test_mask_noop(shape):
 
 def test_categorical():
     dk.run_categorical(CPU)
+
+
+def test_families_built_from_python_numbers_expand(oracle_backend):
+    """dist.Beta(1.0, 1.0) inside a plate (tests/infer/mcmc/test_mcmc_util.py beta_bernoulli)."""
+    import pyro_amd.distributions as dist
+    for d in (dist.Beta(1.0, 1.0), dist.Gamma(2.0, 1.0), dist.Normal(0.0, 1.0), dist.Poisson(3.0),
+              dist.Exponential(1.0), dist.LogNormal(0.0, 1.0), dist.HalfCauchy(1.0), dist.HalfNormal(1.0)):
+        e = d.expand((3,))
+        assert e.batch_shape == (3,)
+        x = e.sample()
+        assert x.shape == (3,) and e.log_prob(x).shape == (3,)

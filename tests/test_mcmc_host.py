@@ -281,3 +281,97 @@ def test_arrowhead_mass_matrix_matches_reference(monkeypatch, tag):
     np.testing.assert_allclose((u[0] ** 2).sum().item(), (g[tag + "/unscale"] ** 2).sum(), rtol=1e-8)
     np.testing.assert_allclose(mm.scale(u)[1].numpy(), r[1].numpy(), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(mm.color(mm.whiten(r))[0].numpy(), r[0].numpy(), rtol=1e-8, atol=1e-10)
+
+
+# ---- the potential of models with discrete latents, and its pickling (tests/infer/mcmc/test_valid_models.py) ----
+def _enum_model(data):
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    p = pyro.sample("p", dist.Uniform(0.0, 1.0))
+    y = pyro.sample("y", dist.Bernoulli(p))
+    q = 0.5 + 0.25 * y
+    with pyro.plate("intermediate", 1, dim=-2):
+        v = pyro.sample("v", dist.Bernoulli(q))
+        with pyro.plate("data", len(data), dim=-1):
+            r = 0.4 + 0.1 * v
+            z = pyro.sample("z", dist.Bernoulli(r))
+            pyro.sample("obs", dist.Normal(2 * z - 1, 1.0), obs=data)
+
+
+@pytest.mark.parametrize("data,expected_log_prob", [
+    (torch.tensor([1.0]), torch.tensor(-1.3434)),
+    (torch.tensor([0.0]), torch.tensor(-1.4189)),
+    (torch.tensor([1.0, 0.0]), torch.tensor(-3.1767)),
+])
+def test_trace_einsum_evaluator_sums_out_enumerated_sites(oracle_backend, data, expected_log_prob):
+    """test_enum_log_prob_nested_plates-style known answers of the reference: p conditioned, y / v / z
+    enumerated in parallel, the log joint with all three summed out."""
+    from pyro_amd import poutine
+    from pyro_amd.infer import config_enumerate
+    from pyro_amd.infer.mcmc.util import TraceEinsumEvaluator, TraceTreeEvaluator
+    model = poutine.enum(config_enumerate(poutine.condition(_enum_model, data={"p": torch.tensor(0.4)})),
+                         first_available_dim=-3)
+    tr = poutine.trace(model).get_trace(data)
+    for Eval in (TraceEinsumEvaluator, TraceTreeEvaluator):
+        lp = Eval(tr, True, 2).log_prob(tr)
+        # brute force over the 2 x 2 x 2^n assignments
+        import itertools
+        import math
+        total = -math.inf
+        n = len(data)
+        for y, v in itertools.product((0.0, 1.0), repeat=2):
+            q = 0.5 + 0.25 * y
+            r = 0.4 + 0.1 * v
+            lp_yv = math.log(0.4 if y else 0.6) + math.log(q if v else 1 - q)
+            for zs in itertools.product((0.0, 1.0), repeat=n):
+                t = lp_yv
+                for z, x in zip(zs, data.tolist()):
+                    t += math.log(r if z else 1 - r) - 0.5 * (x - (2 * z - 1)) ** 2 - 0.5 * math.log(2 * math.pi)
+                total = max(total, t) + math.log1p(math.exp(-abs(total - t))) if total > -math.inf else t
+        assert abs(float(lp) - total) < 1e-5, (float(lp), total)
+    with pytest.raises(ValueError, match="Finite value required for `max_plate_nesting`"):
+        TraceEinsumEvaluator(tr, True, None)
+
+
+def _beta_bernoulli_model(data):
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    p = pyro.sample("p_latent", dist.Beta(torch.tensor([1.1, 1.1]), torch.tensor([1.1, 1.1])))
+    with pyro.plate("data", data.shape[0], dim=-2):
+        pyro.sample("obs", dist.Bernoulli(p), obs=data)
+
+
+def test_potential_fn_survives_torch_save(oracle_backend):
+    import io
+    from pyro_amd.infer.mcmc.util import initialize_model
+    torch.manual_seed(0)
+    data = (torch.rand(50, 2) < torch.tensor([0.8, 0.2])).float()
+    _, potential_fn, _, _ = initialize_model(_beta_bernoulli_model, (data,), jit_compile=True,
+                                             skip_jit_warnings=True)
+    buffer = io.BytesIO()
+    torch.save(potential_fn, buffer)
+    buffer.seek(0)
+    again = torch.load(buffer, weights_only=False)
+    z = {"p_latent": torch.tensor([0.2, 0.6])}
+    assert torch.allclose(again(z), potential_fn(z))
+
+
+def test_initialize_model_checks_shapes_when_discrete_sites_are_summed_out(oracle_backend):
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer.mcmc.util import initialize_model
+
+    def gmm():
+        data = torch.tensor([0.0, 0.0, 3.0, 3.0, 3.0, 5.0, 5.0])
+        mix = pyro.sample("phi", dist.Dirichlet(torch.ones(3)))
+        means = pyro.sample("cluster_means", dist.Normal(torch.arange(3.0), 1.0))   # stray batch dim
+        with pyro.plate("data", 7):
+            a = pyro.sample("assignments", dist.Categorical(mix))
+            pyro.sample("obs", dist.Normal(means[a], 1.0), obs=data)
+
+    pyro.enable_validation(True)
+    try:
+        with pytest.raises(ValueError, match="invalid log_prob shape"):
+            initialize_model(gmm)
+    finally:
+        pyro.enable_validation(False)

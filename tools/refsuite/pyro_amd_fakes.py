@@ -64,6 +64,27 @@ def install_out_of_scope():
     imp.vectorized_importance_weights = lambda *a, **k: pytest.skip("out of scope: importance weights")
     imp.Importance = infer.Importance
     imp.psis_diagnostic = lambda *a, **k: pytest.skip("out of scope: psis_diagnostic")
+    import pyro_amd.infer.mcmc.api as mcmc_api
+    import pyro_amd.infer.mcmc as mcmc_pkg
+    for name in ("StreamingMCMC", "_MultiSampler", "_UnarySampler"):
+        if not hasattr(mcmc_api, name):
+            setattr(mcmc_api, name, _skipper(name))
+            setattr(mcmc_pkg, name, getattr(mcmc_api, name))
+    import pyro_amd.infer.autoguide as autoguide
+    from pyro_amd.infer.autoguide import initialization as _ini
+    for name in dir(_ini):
+        if name.startswith("init_to_") and not hasattr(autoguide, name):
+            setattr(autoguide, name, getattr(_ini, name))
+    for name in ("AutoLaplaceApproximation", "AutoIAFNormal", "AutoStructured", "AutoGaussian",
+                 "AutoHierarchicalNormalMessenger", "AutoNormalMessenger", "AutoRegressiveMessenger",
+                 "AutoDiscreteParallel", "AutoCallable", "AutoContinuous"):
+        if not hasattr(autoguide, name):
+            setattr(autoguide, name, _skipper(name))
+    streaming = types.ModuleType("pyro.ops.streaming")
+    for name in ("CountMeanVarianceStats", "StatsOfDict", "CountMeanStats", "CountStats", "StackStats",
+                 "StreamingStats"):
+        setattr(streaming, name, _skipper(name))
+    sys.modules["pyro.ops.streaming"] = streaming
     nn = types.ModuleType("pyro.nn")
     for name in ("PyroModule", "PyroParam", "PyroSample", "AutoRegressiveNN", "DenseNN", "pyro_method"):
         setattr(nn, name, _skipper(name))
