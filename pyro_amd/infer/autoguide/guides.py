@@ -5,6 +5,7 @@ AutoNormal generates exactly the guide sites the fused kernels see: one
 ``Normal(loc, scale).to_event(k)`` auxiliary site per latent plus a ``Delta`` carrying the
 transform's log-abs-det-Jacobian.
 """
+import contextlib
 from contextlib import ExitStack
 
 import torch
@@ -48,6 +49,50 @@ def _is_identity(transform):
     return transform is _IDENTITY
 
 
+@contextlib.contextmanager
+def helpful_support_errors(site):
+    """A latent site without an unconstrained coordinate system (discrete, on a sphere) fails deep
+    inside ``biject_to``; say what to do instead (reference: autoguide/utils.py:62-86)."""
+    try:
+        yield
+    except NotImplementedError as e:
+        support = site["fn"].support
+        name = site["name"]
+        if getattr(support, "is_discrete", False):
+            raise ValueError(
+                "Continuous inference cannot handle discrete sample site '{0}'. Consider enumerating "
+                "that variable as documented in https://pyro.ai/examples/enumeration.html . If you are "
+                "already enumerating, take care to hide this site when constructing an autoguide, e.g. "
+                "guide = AutoNormal(poutine.block(model, hide=['{0}'])).".format(name)) from None
+        if "sphere" in repr(support).lower():
+            raise ValueError(
+                "Continuous inference cannot handle spherical sample site '{0}'. Consider using "
+                "ProjectedNormal distribution together with a reparameterizer, e.g. "
+                "poutine.reparam(config={{'{0}': ProjectedNormalReparam()}}).".format(name)) from None
+        raise e from None
+
+
+def periodic_repeat(tensor, size, dim):
+    """``tensor`` repeated along ``dim`` (period = its size there) and cut to ``size``: how the value
+    drawn for one subsample initialises the parameter of the FULL plate
+    (reference: pyro/ops/tensor_utils.py periodic_repeat)."""
+    if dim >= 0:
+        dim -= tensor.dim()
+    period = tensor.size(dim)
+    repeats = [1] * tensor.dim()
+    repeats[dim] = -(-size // period)
+    return tensor.repeat(*repeats).narrow(dim, 0, size)
+
+
+def _full_plate_value(value, site, event_dim):
+    """A value observed under subsampled plates, laid out for the full plates."""
+    for frame in site["cond_indep_stack"]:
+        full_size = getattr(frame, "full_size", None) or frame.size
+        if full_size != frame.size:
+            value = periodic_repeat(value, full_size, frame.dim - event_dim).contiguous()
+    return value
+
+
 class AutoGuide:
     def __init__(self, model, *, create_plates=None):
         self.model = model
@@ -58,6 +103,11 @@ class AutoGuide:
 
     def __call__(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
+
+    def call(self, *args, **kwargs):
+        """The draws as a tuple ordered by site name (reference: guides.py:108-115)."""
+        result = self(*args, **kwargs)
+        return tuple(v for _, v in sorted(result.items()))
 
     def _create_plates(self, *args, **kwargs):
         if self.create_plates is None:
@@ -111,16 +161,11 @@ class AutoNormal(AutoGuide):
         for name, site in self.prototype_trace.iter_stochastic_nodes():
             if site["infer"].get("enumerate") == "parallel":
                 continue
-            with torch.no_grad():
+            with torch.no_grad(), helpful_support_errors(site):
                 init_loc = biject_to(site["fn"].support).inv(site["value"].detach()).detach()
             event_dim = site["fn"].event_dim + init_loc.dim() - site["value"].dim()
             self._event_dims[name] = event_dim
-            for frame in site["cond_indep_stack"]:
-                full_size = getattr(frame, "full_size", None) or frame.size
-                if full_size != frame.size:
-                    dim = frame.dim - event_dim
-                    reps = -(-full_size // init_loc.shape[dim])
-                    init_loc = torch.cat([init_loc] * reps, dim=dim).narrow(dim, 0, full_size)
+            init_loc = _full_plate_value(init_loc, site, event_dim)
             self._inits[name] = (init_loc.contiguous().clone(),
                                  torch.full_like(init_loc, self._init_scale))
 
@@ -399,7 +444,7 @@ class AutoContinuous(AutoGuide):
         self._unconstrained_shapes = {}
         self._cond_indep_stacks = {}
         for name, site in self.prototype_trace.iter_stochastic_nodes():
-            with torch.no_grad():
+            with torch.no_grad(), helpful_support_errors(site):
                 self._unconstrained_shapes[name] = \
                     biject_to(site["fn"].support).inv(site["value"]).shape
             self._cond_indep_stacks[name] = site["cond_indep_stack"]
@@ -590,8 +635,13 @@ class AutoDelta(AutoGuide):
                 for frame in site["cond_indep_stack"]:
                     if frame.vectorized:
                         stack.enter_context(plates[frame.name])
-                value = param("{}.{}".format(self.prefix, name), site["value"].detach().clone(),
-                              site["fn"].support, event_dim=site["fn"].event_dim)
+                event_dim = site["fn"].event_dim
+                # the point estimate covers the FULL plates; inside the (subsampling) plates entered
+                # above, pyro.param hands back the rows of the current subsample
+                init = _full_plate_value(site["value"].detach(), site, event_dim).clone()
+                with helpful_support_errors(site):
+                    value = param("{}.{}".format(self.prefix, name), init, site["fn"].support,
+                                  event_dim=event_dim)
                 result[name] = sample(name, dist.Delta(value, event_dim=site["fn"].event_dim))
         return result
 

@@ -362,8 +362,27 @@ class HMC(MCMCKernel):
         state returned by the previous call (the reference caches the same way, hmc.py:371-379)."""
         if getattr(self, "_empty", False):
             return params
+        if getattr(self, "_cache_cleared", False):
+            self._cache_cleared = False
+            self._restart_at(params)
         self._transition()
         return self._layout.unflatten(self._position().clone(), self._batched)
+
+    def clear_cache(self):
+        """Forget the cached state (position, potential, gradient): the next ``sample(params)`` starts
+        from ``params`` and evaluates the potential there (reference: hmc.py:363-379)."""
+        self._cache_cleared = True
+
+    def _restart_at(self, params):
+        z = self._layout.flatten(params, self.num_chains, self._batched)
+        z = z.to(self._z.dtype) if self._z is not None else z
+        if self._dense:
+            self._rewhiten(z)
+        else:                       # in place: device fast paths keep references to these buffers
+            self._z.copy_(z)
+            pe, grad = self._potential(self._z)
+            self._pe.copy_(pe.detach())
+            self._grad.copy_(grad.detach())
 
     # ---- reporting ---------------------------------------------------------------------------
     def logging(self):

@@ -1,0 +1,112 @@
+"""Autoguide behaviour found by running tests/infer/test_autoguide.py of the reference against this package
+(tools/refsuite): subsampled plates (the parameters cover the FULL plate, each step touches the rows of
+its subsample), the error for discrete latent sites, ``guide.call``."""
+import pytest
+import torch
+
+import pyro_amd as pyro
+import pyro_amd.distributions as dist
+from pyro_amd import poutine
+from pyro_amd.infer import SVI, Trace_ELBO
+from pyro_amd.infer.autoguide import (AutoDelta, AutoDiagonalNormal, AutoMultivariateNormal, AutoNormal,
+                                      init_to_feasible, init_to_median)
+from pyro_amd.optim import Adam
+
+
+@pytest.fixture(autouse=True)
+def _host(monkeypatch):
+    from tests import oracle_backend
+    oracle_backend.install(monkeypatch)
+    pyro.clear_param_store()
+
+
+@pytest.mark.parametrize("auto_class", [AutoDelta, AutoNormal])
+def test_subsample_guide(auto_class):
+    """The model of tutorial/source/easyguide.ipynb (tests/infer/test_autoguide.py:1146-1193): local
+    latents in a plate whose subsample is passed in; two epochs over consecutive mini-batches."""
+    def model(batch, subsample, full_size):
+        steps = len(batch)
+        result = [None] * steps
+        drift = pyro.sample("drift", dist.LogNormal(-1.0, 0.5))
+        data_plate = pyro.plate("data", full_size, subsample=subsample)
+        assert data_plate.size == 50
+        with data_plate:
+            z = 0.0
+            for t in range(steps):
+                z = pyro.sample("state_{}".format(t), dist.Normal(z, drift))
+                result[t] = pyro.sample("obs_{}".format(t), dist.Bernoulli(logits=z), obs=batch[t])
+        return torch.stack(result)
+
+    def create_plates(batch, subsample, full_size):
+        return pyro.plate("data", full_size, subsample=subsample)
+
+    guide = auto_class(model, create_plates=create_plates)
+    full_size, batch_size, steps = 50, 20, 4
+    pyro.set_rng_seed(123456789)
+    data = model([None] * steps, torch.arange(full_size), full_size)
+    assert data.shape == (steps, full_size)
+    pyro.clear_param_store()
+    svi = SVI(model, guide, Adam({"lr": 0.02}), Trace_ELBO())
+    for epoch in range(2):
+        for beg in range(0, full_size, batch_size):
+            end = min(full_size, beg + batch_size)
+            svi.step(data[:, beg:end], torch.arange(beg, end), full_size=full_size)
+    store = pyro.get_param_store()
+    local = [name for name in store.keys() if "state_0" in name]
+    assert local and all(store[name].shape == (full_size,) for name in local)
+    assert all(store[name].shape == () for name in store.keys() if "drift" in name)
+
+
+@pytest.mark.parametrize("independent", [True, False], ids=["independent", "dependent"])
+@pytest.mark.parametrize("auto_class", [AutoDelta, AutoNormal])
+def test_subsample_guide_with_create_plates_and_pyro_subsample(auto_class, independent):
+    def model(data):
+        size = data.shape[0]
+        with pyro.plate("origin", size, dim=-2), pyro.plate("destin", size, dim=-1):
+            batch = pyro.subsample(data, event_dim=0)
+            assert batch.size(0) == batch.size(1), batch.shape
+            pyro.sample("obs", dist.Normal(0.0, 1.0), obs=batch)
+
+    def create_plates(data):
+        size = data.shape[0]
+        origin = pyro.plate("origin", size, subsample_size=5, dim=-2)
+        if independent:
+            return origin, pyro.plate("destin", size, subsample_size=5, dim=-1)
+        with origin as subsample:
+            pass
+        return origin, pyro.plate("destin", size, subsample=subsample, dim=-1)
+
+    svi = SVI(model, auto_class(model, create_plates=create_plates), Adam({"lr": 0.01}), Trace_ELBO())
+    data = torch.randn(10, 10)
+    for _ in range(2):
+        svi.step(data)
+
+
+@pytest.mark.parametrize("auto_class", [AutoDelta, AutoDiagonalNormal, AutoMultivariateNormal, AutoNormal])
+@pytest.mark.parametrize("init_loc_fn", [init_to_feasible, init_to_median])
+def test_discrete_site_gets_a_helpful_error(auto_class, init_loc_fn):
+    def model():
+        p = pyro.sample("p", dist.Beta(2.0, 2.0))
+        x = pyro.sample("x", dist.Bernoulli(p))
+        pyro.sample("obs", dist.Bernoulli(p * x + (1 - p) * (1 - x)), obs=torch.tensor([1.0, 0.0]))
+
+    guide = auto_class(model, init_loc_fn=init_loc_fn)
+    with pytest.raises(ValueError, match=".*enumeration.html.*"):
+        guide()
+    # ... and the advice works: hide the discrete site from the guide
+    pyro.clear_param_store()
+    auto_class(poutine.block(model, hide=["x"]), init_loc_fn=init_loc_fn)()
+
+
+def test_call_returns_the_draws_ordered_by_name():
+    def model():
+        pyro.sample("b", dist.Normal(0.0, 1.0))
+        pyro.sample("a", dist.LogNormal(0.0, 1.0))
+
+    guide = AutoNormal(model)
+    guide()                                   # the first call also draws the prototype
+    pyro.set_rng_seed(0)
+    as_dict = guide()
+    pyro.set_rng_seed(0)
+    as_tuple = guide.call()
+    assert torch.equal(as_tuple[0], as_dict["a"]) and torch.equal(as_tuple[1], as_dict["b"])

@@ -375,3 +375,27 @@ def test_initialize_model_checks_shapes_when_discrete_sites_are_summed_out(oracl
             initialize_model(gmm)
     finally:
         pyro.enable_validation(False)
+
+
+def test_clear_cache_restarts_the_kernel_at_the_given_point(oracle_backend):
+    """tests/infer/mcmc/test_hmc.py:309-337 drives a kernel by hand: kernel(params) is one transition from
+    the cached state, and after clear_cache() from ``params``."""
+    import pyro_amd as pyro
+    from pyro_amd.infer import HMC
+    pyro.set_rng_seed(0)
+
+    def potential(params):
+        return 0.5 * torch.sum((params["z"] - 5.0) ** 2)
+
+    kernel = HMC(potential_fn=potential, step_size=1e-3, num_steps=2, adapt_step_size=False,
+                 adapt_mass_matrix=False)
+    kernel.initial_params = {"z": torch.tensor(0.0)}
+    kernel.setup(0)
+    a = kernel({"z": torch.tensor(0.0)})
+    b = kernel({"z": torch.tensor(100.0)})           # ignored: continues from the cached state
+    assert abs(float(b["z"]) - float(a["z"])) < 0.1
+    kernel.clear_cache()
+    c = kernel({"z": torch.tensor(100.0)})           # restarts there
+    assert abs(float(c["z"]) - 100.0) < 1.0
+    d = kernel(c)
+    assert abs(float(d["z"]) - float(c["z"])) < 1.0

@@ -77,7 +77,8 @@ def install_out_of_scope():
             setattr(autoguide, name, getattr(_ini, name))
     for name in ("AutoLaplaceApproximation", "AutoIAFNormal", "AutoStructured", "AutoGaussian",
                  "AutoHierarchicalNormalMessenger", "AutoNormalMessenger", "AutoRegressiveMessenger",
-                 "AutoDiscreteParallel", "AutoCallable", "AutoContinuous"):
+                 "AutoDiscreteParallel", "AutoCallable", "AutoContinuous", "AutoGuideList",
+                 "AutoLowRankMultivariateNormal"):
         if not hasattr(autoguide, name):
             setattr(autoguide, name, _skipper(name))
     streaming = types.ModuleType("pyro.ops.streaming")
@@ -88,7 +89,20 @@ def install_out_of_scope():
     nn = types.ModuleType("pyro.nn")
     for name in ("PyroModule", "PyroParam", "PyroSample", "AutoRegressiveNN", "DenseNN", "pyro_method"):
         setattr(nn, name, _skipper(name))
+    nn.__path__ = []
+    nn_module = types.ModuleType("pyro.nn.module")
+    for name in ("PyroModule", "PyroParam", "PyroSample", "pyro_method", "to_pyro_module_", "clear"):
+        setattr(nn_module, name, getattr(nn, name, _skipper(name)))
+    nn.module = nn_module
+    sys.modules["pyro.nn.module"] = nn_module
     sys.modules["pyro.nn"] = nn
+    gaussian = types.ModuleType("pyro.ops.gaussian")
+    gaussian.Gaussian = _skipper("Gaussian")
+    sys.modules["pyro.ops.gaussian"] = gaussian
+    ag = types.ModuleType("pyro.infer.autoguide.gaussian")
+    ag.AutoGaussianFunsor = _skipper("AutoGaussianFunsor")
+    ag.AutoGaussian = _skipper("AutoGaussian")
+    sys.modules["pyro.infer.autoguide.gaussian"] = ag
     multi = types.ModuleType("pyro.optim.multi")
     for name in ("MultiOptimizer", "MixedMultiOptimizer", "Newton", "PyroMultiOptimizer", "TorchMultiOptimizer"):
         setattr(multi, name, _skipper(name))
@@ -104,7 +118,8 @@ def install_out_of_scope():
     if "pyro.infer.reparam" not in sys.modules:
         reparam = types.ModuleType("pyro.infer.reparam")
         for name in ("LatentStableReparam", "LocScaleReparam", "TransformReparam", "StableReparam",
-                     "SymmetricStableReparam", "NeuTraReparam", "ConjugateReparam"):
+                     "SymmetricStableReparam", "NeuTraReparam", "ConjugateReparam",
+                     "ProjectedNormalReparam", "HaarReparam", "DiscreteCosineReparam", "SplitReparam"):
             setattr(reparam, name, _skipper(name))
         sys.modules["pyro.infer.reparam"] = reparam
         infer.reparam = reparam
