@@ -81,6 +81,18 @@ def install_out_of_scope():
                  "AutoLowRankMultivariateNormal"):
         if not hasattr(autoguide, name):
             setattr(autoguide, name, _skipper(name))
+    contrib = types.ModuleType("pyro.contrib")
+    contrib.__path__ = []
+    cc = types.ModuleType("pyro.contrib.conjugate")
+    cc.__path__ = []
+    cci = types.ModuleType("pyro.contrib.conjugate.infer")
+    for name in ("BetaBinomialPair", "GammaPoissonPair", "collapse_conjugate", "posterior_replay"):
+        setattr(cci, name, _skipper(name))
+    cc.infer = cci
+    contrib.conjugate = cc
+    sys.modules["pyro.contrib"] = contrib
+    sys.modules["pyro.contrib.conjugate"] = cc
+    sys.modules["pyro.contrib.conjugate.infer"] = cci
     streaming = types.ModuleType("pyro.ops.streaming")
     for name in ("CountMeanVarianceStats", "StatsOfDict", "CountMeanStats", "CountStats", "StackStats",
                  "StreamingStats"):
