@@ -127,7 +127,7 @@ class NutsTreeOracle:
                     e_dir = 1 if s.dir == 1 else 0
                     s.edges[e_dir] = (zq, rq, g)
                     s.depth += 1
-                    new_prob = math.exp(b_w - s.tree_weight) if self.multinomial else \
+                    new_prob = math.exp(min(b_w - s.tree_weight, 700.0)) if self.multinomial else \
                         b_w / s.tree_weight
                     if s.draws.accept(j) < new_prob:
                         s.accepted = True

@@ -166,7 +166,20 @@ class DenseMassMatrix:
         return kernels.chain_matvec(self._L, grad.contiguous(), transpose=True)
 
 
-SymmArrowhead = namedtuple("SymmArrowhead", ["top", "bottom_diag"])
+class SymmArrowhead(namedtuple("SymmArrowhead", ["top", "bottom_diag"])):
+    """(top, bottom_diag) of a symmetric arrowhead matrix (pyro/ops/arrowhead.py:10).  Also answers the
+    reference's access through the block key -- ``adapter.mass_matrix[("w", "y", "x", "z")]`` -- with the
+    chain dim dropped when there is one chain."""
+
+    __slots__ = ()
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple) and key and all(isinstance(k, str) for k in key):
+            top, bottom = tuple(self)
+            if top.dim() == 3 and top.shape[0] == 1:
+                return SymmArrowhead(top[0], bottom[0])
+            return self
+        return super().__getitem__(key)
 
 
 class ArrowheadMassMatrix:

@@ -75,6 +75,7 @@ class HMC(MCMCKernel):
         self.num_chains = 1
         self.chain_offset = 0      # first global chain index of this rank (chain-sharded runs)
         self._dense = bool(full_mass)
+        self._full_mass = full_mass
         self._reset()
         self._adapter = WarmupAdapter(step_size, adapt_step_size=adapt_step_size,
                                       adapt_mass_matrix=adapt_mass_matrix,
@@ -112,7 +113,48 @@ class HMC(MCMCKernel):
 
     @property
     def inverse_mass_matrix(self):
-        return self.mass_matrix_adapter.inverse_mass_matrix
+        """The reference's public form (hmc.py:349-351, adaptation.py:196-216): a dict from the tuple of
+        site names of a mass-matrix block to that block of M^-1 -- 1-D (diagonal block) or 2-D (dense
+        block).  ``full_mass=False`` / ``True``: one block over all sites (sorted by name);
+        ``full_mass=[("a",), ("b", "c")]``: those dense blocks plus one diagonal block of the remaining
+        sites; with an ``ArrowheadMassMatrix``: one block, head sites first.  With several chains every
+        value has a leading chain dim (the chains adapt separately, as the reference's processes do).
+        The flat tensor the kernels use is ``kernel.mass_matrix_adapter.inverse_mass_matrix``."""
+        layout = getattr(self, "_layout", None)
+        if layout is None:
+            return {}
+        V = self.mass_matrix_adapter.inverse_mass_matrix              # [C, D] or [C, D, D]
+        dense = V.dim() == 3
+
+        def flat(names):
+            idx = []
+            for name in names:
+                a, b = layout.slices[name]
+                idx.extend(range(a, b))
+            return torch.tensor(idx, dtype=torch.int64, device=V.device)
+
+        def block(names, as_dense):
+            i = flat(names)
+            if dense:
+                sub = V[:, i][:, :, i]
+                out = sub if as_dense else torch.diagonal(sub, dim1=-2, dim2=-1)
+            else:
+                out = V[:, i]
+            return out if self._batched else out[0]
+
+        full_mass = getattr(self, "_full_mass", False)
+        blocks = full_mass if isinstance(full_mass, list) else []
+        named = [name for b in blocks for name in b]
+        rest = tuple(n for n in layout.names if n not in set(named))
+        if getattr(self._adapter, "arrowhead", None) is not None:
+            key = tuple(named) + rest if blocks else tuple(layout.names)
+            return {key: block(key, True)}
+        if not blocks:
+            return {tuple(layout.names): block(layout.names, dense)}
+        out = {tuple(b): block(b, True) for b in blocks}
+        if rest:
+            out[rest] = block(rest, False)
+        return out
 
     @property
     def _mm_eff(self):
@@ -278,7 +320,7 @@ class HMC(MCMCKernel):
             self._find_step_calls = getattr(self, "_find_step_calls", 0) + 1
             key = (1 << 42) + 256 * self._find_step_calls       # disjoint from transition indices
             return kernels.nuts_gaussian_find_step(
-                z, pe.detach(), grad.detach(), self._Lambda, self.inverse_mass_matrix, step,
+                z, pe.detach(), grad.detach(), self._Lambda, self.mass_matrix_adapter.inverse_mass_matrix, step,
                 self._seed if getattr(self, "_seed", None) is not None else rng._STATE["seed"],
                 key, self.chain_offset, self._min_stepsize, self._max_stepsize,
                 self._direction_threshold)

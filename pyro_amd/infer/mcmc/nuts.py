@@ -115,7 +115,7 @@ class NUTS(HMC):
         if self._launch_hook is not None:
             self._launch_hook()
         out = kernels.nuts_gaussian_run(
-            self._z, self._pe, self._grad, self._Lambda, self.inverse_mass_matrix, step,
+            self._z, self._pe, self._grad, self._Lambda, self.mass_matrix_adapter.inverse_mass_matrix, step,
             self._max_tree_depth, self.use_multinomial_sampling, self._seed, self._t, k,
             self.chain_offset, da_state=da, target_accept=ad.target_accept_prob, welford=wf,
             welford_n0=wf_n0, samples=samples, mean_accept=self._mean_accept_prob,

@@ -951,6 +951,13 @@ substitute = _make_handler(SubstituteMessenger)
 infer_config = _make_handler(InferConfigMessenger)
 do = _make_handler(DoMessenger)
 escape = _make_handler(EscapeMessenger)
+
+
+def broadcast(fn=None):
+    """Deprecated in the reference (plates broadcast by themselves since 0.3): the identity."""
+    return Messenger()(fn) if fn is not None else Messenger()
+
+
 equalize = _make_handler(EqualizeMessenger)
 lift = _make_handler(LiftMessenger)
 

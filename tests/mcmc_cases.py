@@ -245,7 +245,7 @@ def run_dense_mass_adaptation(device, dtype, C=4, D=5, warmup=150, S=150, check=
         init = {"x": torch.tensor(g.standard_normal((C, D)), dtype=dtype, device=device)}
         mcmc = MCMC(kernel, num_samples=S, warmup_steps=warmup, num_chains=C, initial_params=init)
         mcmc.run()
-        V = kernel.inverse_mass_matrix.cpu().numpy()
+        V = kernel.mass_matrix_adapter.inverse_mass_matrix.cpu().numpy()
         x = mcmc.get_samples()["x"].cpu().numpy().astype(np.float64)
         out[name] = (V, x)
         if check:
@@ -289,12 +289,23 @@ def run_structured_mass(device, dtype=torch.float32, warmup=1000, C=4):
         pyro.set_rng_seed(0)
         kernel = NUTS(model, full_mass=dense_mass, max_tree_depth=4)
         MCMC(kernel, num_samples=1, warmup_steps=1, num_chains=2).run(cov)
-        assert kernel.inverse_mass_matrix.dim() == 2 + int(dense_mass)    # leading chain dim
+        assert kernel.mass_matrix_adapter.inverse_mass_matrix.dim() == 2 + int(dense_mass)   # chain dim
+        assert kernel.inverse_mass_matrix[("w", "x", "y", "z")].dim() == 1 + 1 + int(dense_mass)
     pyro.set_rng_seed(1)
     kernel = NUTS(model, full_mass=[("w",), ("x", "y")], max_tree_depth=6)
     mcmc = MCMC(kernel, num_samples=1, warmup_steps=warmup, num_chains=C)
     mcmc.run(cov)
-    V = kernel.inverse_mass_matrix                                         # [C, 5, 5]
+    V = kernel.mass_matrix_adapter.inverse_mass_matrix                     # [C, 5, 5]
+    # the reference's public form (tests/infer/mcmc/test_nuts.py:501-503): one entry per block
+    blocks = kernel.inverse_mass_matrix
+    assert set(blocks) == {("w",), ("x", "y"), ("z",)}
+    lead = (C,) if C > 1 else ()
+    assert blocks[("w",)].shape == lead + (2, 2) and blocks[("x", "y")].shape == lead + (2, 2)
+    assert blocks[("z",)].shape == lead + (1,)
+    first = (lambda t: t[0]) if C > 1 else (lambda t: t)
+    torch.testing.assert_close(first(blocks[("w",)]), w_cov, atol=0.5, rtol=0.5)
+    torch.testing.assert_close(first(blocks[("x", "y")]), xy_cov, atol=0.5, rtol=0.5)
+    torch.testing.assert_close(first(blocks[("z",)]), z_var, atol=0.5, rtol=0.5)
     sl = kernel._layout.slices
     assert list(kernel._layout.names) == ["w", "x", "y", "z"]
     w0, w1 = sl["w"]
@@ -346,7 +357,7 @@ def run_persistent_equals_stepwise(device, dtype, rtol, C=6, D=9, warmup=40, S=6
                     initial_params={"x": z0.clone()})
         mcmc.run()
         outs.append((mcmc.get_samples(group_by_chain=True)["x"].clone(),
-                     kernel.step_size.clone(), kernel.inverse_mass_matrix.clone(),
+                     kernel.step_size.clone(), kernel.mass_matrix_adapter.inverse_mass_matrix.clone(),
                      kernel.num_leapfrog_steps, mcmc.diagnostics()))
     a, b = outs
     assert a[3] == b[3], (a[3], b[3])                       # identical trees
@@ -681,6 +692,9 @@ def run_arrowhead_mass(device, dtype=torch.float32, warmup=1000, C=4):
     kernel.mass_matrix_adapter = ArrowheadMassMatrix()
     mcmc = MCMC(kernel, num_samples=1, warmup_steps=warmup, num_chains=C)
     mcmc.run(prec)
+    assert ("w", "y", "x", "z") in kernel.inverse_mass_matrix
+    keyed = kernel.mass_matrix_adapter.mass_matrix[("w", "y", "x", "z")]       # the reference's access
+    assert tuple(keyed.top.shape)[-2:] == (4, 6) and tuple(keyed.bottom_diag.shape)[-1:] == (2,)
     top, bottom = kernel.mass_matrix_adapter.mass_matrix       # reference order: w, y, x | z
     assert tuple(top.shape) == (C, 4, 6) and tuple(bottom.shape) == (C, 2)
     for c in range(C):
