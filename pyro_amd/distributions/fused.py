@@ -176,6 +176,55 @@ def _nd_frame(operands, shape):
     return tuple(mshape), views
 
 
+def _differentiable_log_prob(dist_id, value, p0, p1):
+    """The same densities written with torch operators.  Used ONLY when a gradient of a gradient is
+    asked for (``torch.autograd.grad(..., create_graph=True)``: Newton steps inside a guide, Laplace
+    approximations): the HIP backward kernels return plain tensors, so the first-order gradient is then
+    re-derived by autograd from this expression, on the same device, and stays differentiable."""
+    from .. import _lib as L
+    td = torch.distributions
+    if dist_id == L.DIST_NORMAL:
+        return td.Normal(p0, p1, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_BERNOULLI_LOGITS:
+        return -torch.nn.functional.binary_cross_entropy_with_logits(
+            p0.expand(torch.broadcast_shapes(p0.shape, value.shape)),
+            value.expand(torch.broadcast_shapes(p0.shape, value.shape)), reduction="none")
+    if dist_id == L.DIST_HALF_CAUCHY:
+        return td.HalfCauchy(p0, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_LOG_NORMAL:
+        return td.LogNormal(p0, p1, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_EXPONENTIAL:
+        return td.Exponential(p0, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_HALF_NORMAL:
+        return td.HalfNormal(p0, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_GAMMA:
+        return td.Gamma(p0, p1, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_BETA:
+        return td.Beta(p0, p1, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_POISSON:
+        return td.Poisson(p0, validate_args=False).log_prob(value)
+    if dist_id == L.DIST_BINOMIAL_LOGITS:
+        n, k = p1, value
+        log_comb = torch.lgamma(n + 1) - torch.lgamma(k + 1) - torch.lgamma(n - k + 1)
+        return k * p0 - n * torch.nn.functional.softplus(p0) + log_comb
+    if dist_id == L.DIST_KL_NORMAL_LOC:
+        return -((value - p0) ** 2) / (2 * p1 ** 2) - torch.log(p1)
+    if dist_id == L.DIST_KL_NORMAL_SCALE:
+        return torch.log(value) + 0.5 - value ** 2 / (2 * p0 ** 2)
+    raise NotImplementedError("second-order gradients of distribution id {}".format(dist_id))
+
+
+def _differentiable_grads(dist_id, g, value, p0, p1, mask, scale, needs):
+    """(dv, da, db) as differentiable functions of the inputs and of ``g`` (see above)."""
+    from .util import scale_and_mask
+    with torch.enable_grad():
+        lp = scale_and_mask(_differentiable_log_prob(dist_id, value, p0, p1), scale, mask)
+        inputs = [t for t, need in zip((value, p0, p1), needs) if need]
+        got = iter(torch.autograd.grad(lp, inputs, g.expand_as(lp) if g.dim() else g * torch.ones_like(lp),
+                                       create_graph=True, allow_unused=True)) if inputs else iter(())
+    return tuple(next(got) if need else None for need in needs)
+
+
 class _LogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dist_id, value, p0, p1):
@@ -190,9 +239,11 @@ class _LogProb(torch.autograd.Function):
     def backward(ctx, g):
         value, p0, p1 = ctx.saved_tensors
         shape = ctx.shape
-        rows, cols, (g2, v2, a2, b2) = frame([g, value, p0, p1], shape)
         need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2],
                 p1 is not None and ctx.needs_input_grad[3])
+        if torch.is_grad_enabled():                 # create_graph=True
+            return (None,) + _differentiable_grads(ctx.dist_id, g, value, p0, p1, None, 1.0, need)
+        rows, cols, (g2, v2, a2, b2) = frame([g, value, p0, p1], shape)
         dv, da, db = kernels.dist_log_prob_grad(ctx.dist_id, g2, v2, a2, b2, None, 1.0, rows, cols,
                                                 need)
         outs = [None if d is None else _sum_to(d.reshape(shape), like)
@@ -229,6 +280,9 @@ class _LogProbSum(torch.autograd.Function):
         shape = ctx.shape
         need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2],
                 p1 is not None and ctx.needs_input_grad[3])
+        if torch.is_grad_enabled():                 # create_graph=True
+            return (None,) + _differentiable_grads(ctx.dist_id, g, value, p0, p1, mask, ctx.scale,
+                                                   need) + (None, None)
         if ctx.nd:
             mshape, (vn, an, bn, mn) = _nd_frame([value, p0, p1, mask], shape)
             dv, da, db = kernels.dist_log_prob_grad_nd(ctx.dist_id, mshape, g, vn, an, bn, mn,

@@ -175,3 +175,49 @@ def run_categorical(device):
         assert c.log_prob(support).size() == torch.Size((3,) + c.batch_shape)
     logits = torch.randn((1, 2, 1, 3, 1, 2), device=device)      # test_view_reshape_bug
     dist.Categorical(logits=logits).sample((4,))
+
+
+def run_second_order_gradients(device):
+    """tests/infer/test_enum.py:307-335 takes a Newton step inside a guide: gradients of gradients of
+    log_prob (``create_graph=True``) through the fused families, against torch's own classes."""
+    import torch.distributions as td
+    from torch.autograd import grad
+    import pyro_amd.distributions as dist
+
+    def t(x, rg=False):
+        return torch.tensor(x, dtype=torch.float64, device=device, requires_grad=rg)
+
+    cases = [
+        (dist.Normal, td.Normal, [0.3, 1.3], t([0.0, 1.0, 3.0])),
+        (dist.LogNormal, td.LogNormal, [0.3, 0.8], t([0.5, 1.0, 3.0])),
+        (dist.Gamma, td.Gamma, [2.0, 1.5], t([0.5, 1.0, 3.0])),
+        (dist.Beta, td.Beta, [2.0, 3.0], t([0.2, 0.5, 0.9])),
+        (dist.HalfCauchy, td.HalfCauchy, [1.2], t([0.5, 1.0, 3.0])),
+        (dist.Exponential, td.Exponential, [0.7], t([0.5, 1.0, 3.0])),
+        (dist.Poisson, td.Poisson, [2.5], t([0.0, 1.0, 3.0])),
+    ]
+    for ours, theirs, params, data in cases:
+        out = []
+        for cls in (ours, theirs):
+            ps = [t(p, True) for p in params]
+            lp = cls(*ps).log_prob(data).sum()
+            g = grad(lp, ps[:1], create_graph=True)[0]
+            assert g.requires_grad
+            H = grad(g, ps, allow_unused=True)
+            out.append((g.detach(), [h.detach() for h in H if h is not None]))
+        torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-9, atol=1e-11)
+        for a, b in zip(out[0][1], out[1][1]):
+            torch.testing.assert_close(a, b, rtol=1e-8, atol=1e-10)
+    # the value as the differentiated input, and a first-order backward afterwards (the Newton step)
+    x = t(0.2, True)
+    scale = t(1.3, True)
+    data = t([0.0, 1.0, 3.0])
+    results = []
+    for N in (dist.Normal, td.Normal):
+        loss = -(N(t(0.0), t(10.0)).log_prob(x) + N(x, scale).log_prob(data).sum())
+        g = grad(loss, [x], create_graph=True)[0]
+        H = grad(g, [x], create_graph=True)[0]
+        newton = x.detach() - g / H
+        results.append((newton.detach(), grad(newton, [scale])[0]))
+    torch.testing.assert_close(results[0][0], results[1][0], rtol=1e-9, atol=0)
+    torch.testing.assert_close(results[0][1], results[1][1], rtol=1e-8, atol=1e-12)

@@ -55,3 +55,7 @@ def test_mask_noop(gpu, shape):
 
 def test_categorical(gpu):
     dk.run_categorical(gpu)
+
+
+def test_second_order_gradients_through_the_fused_families(gpu):
+    dk.run_second_order_gradients(gpu)

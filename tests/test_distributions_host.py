@@ -71,3 +71,7 @@ def test_families_built_from_python_numbers_expand(oracle_backend):
         assert e.batch_shape == (3,)
         x = e.sample()
         assert x.shape == (3,) and e.log_prob(x).shape == (3,)
+
+
+def test_second_order_gradients_through_the_fused_families(oracle_backend):
+    dk.run_second_order_gradients(torch.device("cpu"))
