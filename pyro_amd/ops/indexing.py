@@ -64,3 +64,36 @@ class Vindex:
 
     def __getitem__(self, args):
         return vindex(self._tensor, args)
+
+
+def _flatten_index(args, out):
+    # nested index tuples are spliced in; two Ellipsis in a row count as one
+    for arg in args:
+        if isinstance(arg, tuple):
+            _flatten_index(arg, out)
+        elif arg is Ellipsis and out and out[-1] is Ellipsis:
+            continue
+        else:
+            out.append(arg)
+
+
+def index(tensor, args):
+    """``tensor[args]`` where ``args`` may hold nested tuples, e.g. ``(Ellipsis, t)`` with
+    ``t = (Ellipsis, None)`` meaning ``tensor.unsqueeze(-1)`` (reference: pyro/ops/indexing.py:25-59)."""
+    if not isinstance(args, tuple):
+        return tensor[args]
+    if not args:
+        return tensor
+    flat = []
+    _flatten_index(args, flat)
+    return tensor[tuple(flat)]
+
+
+class Index:
+    """``Index(x)[..., i, j, :]`` = ``index(x, (Ellipsis, i, j, slice(None)))``."""
+
+    def __init__(self, tensor):
+        self._tensor = tensor
+
+    def __getitem__(self, args):
+        return index(self._tensor, args)

@@ -135,3 +135,15 @@ def hpdi(input, prob, dim=0):
     lo = intervals_left.gather(dim, index_start)
     hi = intervals_right.gather(dim, index_start)
     return torch.cat([lo, hi], dim)
+
+
+def _cummin(input):
+    """Cumulative minimum along dim 0 (the reference builds an N x N mask for it, stats.py:142-159)."""
+    return torch.cummin(input, dim=0)[0]
+
+
+def resample(input, num_samples, dim=0, replacement=False):
+    """``num_samples`` entries of ``input`` along ``dim``, drawn uniformly (stats.py:222-233)."""
+    weights = torch.ones(input.size(dim), dtype=input.dtype, device=input.device)
+    indices = torch.multinomial(weights, num_samples, replacement)
+    return input.index_select(dim, indices)

@@ -44,3 +44,15 @@ def test_unsupported_forms_raise():
         Vindex(x)[i, ..., 0]
     with pytest.raises(NotImplementedError):
         Vindex(x)[i, 1:3]
+
+
+def test_index_flattens_nested_index_tuples():
+    """pyro.ops.indexing.Index (tests/ops/test_indexing.py): ``t`` may itself be an index tuple."""
+    import torch
+    from pyro_amd.ops.indexing import Index, index
+    x = torch.arange(12.0).reshape(3, 4)
+    assert torch.equal(Index(x)[..., 1], x[..., 1])
+    assert torch.equal(Index(x)[..., slice(None)], x)
+    assert torch.equal(Index(x)[..., (Ellipsis, None)], x.unsqueeze(-1))
+    assert torch.equal(index(x, ((1,), (Ellipsis,))), x[1])
+    assert index(x, ()) is x
