@@ -6,7 +6,7 @@ import torch
 from torch.distributions import constraints, transforms  # noqa: F401
 from torch.distributions import biject_to, transform_to, kl_divergence  # noqa: F401
 
-from .base import (Delta, MaskedDistribution, ScoreParts, TorchDistribution,  # noqa: F401
+from .base import (Delta, ExpandedDistribution, MaskedDistribution, ScoreParts, TorchDistribution,  # noqa: F401
                    TorchDistributionMixin, Unit)
 from .families import (Bernoulli, Beta, Binomial, Dirichlet, Exponential, Gamma,  # noqa: F401
                        GroupedLinearLogits, HalfCauchy, HalfNormal, LinearLogits, LogNormal, Normal,

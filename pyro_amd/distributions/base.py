@@ -91,7 +91,102 @@ class TorchDistributionMixin:
 
 
 class TorchDistribution(torch.distributions.Distribution, TorchDistributionMixin):
-    """Base class for distributions implemented directly in this package."""
+    """Base class for distributions implemented directly in this package -- and for the user's own:
+    a subclass that does not write ``expand`` still works inside plates, through the generic wrapper
+    below (reference: torch_distribution.py:279-299)."""
+
+    def expand(self, batch_shape, _instance=None):
+        return ExpandedDistribution(self, batch_shape)
+
+
+class ExpandedDistribution(TorchDistribution):
+    """``base_dist`` seen with a larger batch shape: independent draws along every dim that was added or
+    stretched from size 1, the base distribution's own log_prob broadcast over them
+    (reference: torch_distribution.py:399-526)."""
+
+    arg_constraints = {}
+
+    def __init__(self, base_dist, batch_shape=torch.Size()):
+        self.base_dist = base_dist
+        super().__init__(base_dist.batch_shape, base_dist.event_shape, validate_args=False)
+        self.expand(batch_shape)
+
+    @staticmethod
+    def _grown(old, new):
+        """``old`` broadcast up to ``new`` (never down): the resulting shape, or ValueError."""
+        old, new = tuple(old), tuple(new)
+        if len(new) < len(old):
+            raise ValueError("Cannot broadcast distribution of shape {} to shape {}".format(old, new))
+        out = list(new[:len(new) - len(old)])
+        for have, want in zip(old, new[len(new) - len(old):]):
+            if have != want and have != 1:
+                raise ValueError("Cannot broadcast distribution of shape {} to shape {}".format(old, new))
+            out.append(want if have == 1 else have)
+        return torch.Size(out)
+
+    def expand(self, batch_shape, _instance=None):
+        # in place, as the reference does: an expanded distribution only ever grows
+        grown = self._grown(self.batch_shape, batch_shape)
+        self._batch_shape = self._grown(self.base_dist.batch_shape, grown)
+        return self
+
+    has_rsample = property(lambda self: self.base_dist.has_rsample)
+    has_enumerate_support = property(lambda self: self.base_dist.has_enumerate_support)
+
+    @constraints.dependent_property
+    def support(self):
+        return self.base_dist.support
+
+    def _draw(self, draw, sample_shape):
+        sample_shape = torch.Size(sample_shape)
+        base, full = tuple(self.base_dist.batch_shape), tuple(self.batch_shape)
+        lead = full[:len(full) - len(base)]
+        stretched = [(j, want) for j, (have, want) in enumerate(zip(base, full[len(lead):]))
+                     if have == 1 and want != 1]
+        x = draw(sample_shape + torch.Size(lead) + torch.Size([size for _, size in stretched]))
+        # x: sample_shape + lead + stretched sizes + base batch + event; each stretched axis swaps
+        # places with the size-1 axis it fills
+        first = len(sample_shape) + len(lead)
+        for i, (j, _) in enumerate(stretched):
+            x = x.transpose(first + i, first + len(stretched) + j)
+        return x.reshape(sample_shape + self.batch_shape + self.event_shape)
+
+    def sample(self, sample_shape=torch.Size()):
+        return self._draw(self.base_dist.sample, sample_shape)
+
+    def rsample(self, sample_shape=torch.Size()):
+        return self._draw(self.base_dist.rsample, sample_shape)
+
+    def _value_batch(self, value):
+        return broadcast_shape(self.batch_shape, value.shape[:value.dim() - self.event_dim])
+
+    def log_prob(self, value):
+        return self.base_dist.log_prob(value).expand(self._value_batch(value))
+
+    def score_parts(self, value):
+        shape = self._value_batch(value)
+        parts = self.base_dist.score_parts(value)
+        if self.batch_shape == self.base_dist.batch_shape:
+            return parts
+        return ScoreParts(*(p.expand(shape) if isinstance(p, torch.Tensor) else p for p in parts))
+
+    def enumerate_support(self, expand=True):
+        values = self.base_dist.enumerate_support(expand=False)
+        values = values.reshape(values.shape[:1] + (1,) * len(self.batch_shape))
+        return values.expand(values.shape[:1] + self.batch_shape) if expand else values
+
+    @property
+    def mean(self):
+        return self.base_dist.mean.expand(self.batch_shape + self.event_shape)
+
+    @property
+    def variance(self):
+        return self.base_dist.variance.expand(self.batch_shape + self.event_shape)
+
+    def conjugate_update(self, other):
+        updated, log_normalizer = self.base_dist.conjugate_update(other)
+        return updated.expand(self.batch_shape), log_normalizer.expand(self.batch_shape)
+
 
 
 class MaskedDistribution(TorchDistribution):

@@ -15,15 +15,17 @@ def torch_item(x):
 
 
 def torch_isnan(x):
+    """Does a number or tensor hold ANY NaN (a 0-dim bool tensor for tensors; pyro/util.py:66-75)."""
     if isinstance(x, numbers.Number):
         return x != x
-    return torch.isnan(x)
+    return torch.isnan(x).any()
 
 
 def torch_isinf(x):
+    """Does a number or tensor hold any +inf or -inf."""
     if isinstance(x, numbers.Number):
         return x in (math.inf, -math.inf)
-    return torch.isinf(x)
+    return torch.isinf(x).any()
 
 
 def _caller(filename, lineno):

@@ -75,3 +75,50 @@ def test_families_built_from_python_numbers_expand(oracle_backend):
 
 def test_second_order_gradients_through_the_fused_families(oracle_backend):
     dk.run_second_order_gradients(torch.device("cpu"))
+
+
+def test_a_user_distribution_without_expand_works_inside_plates(oracle_backend):
+    """tests/distributions/test_distributions.py (test_expand_new_dim & co. with the default expand): a
+    TorchDistribution subclass that does not write ``expand`` gets the generic ExpandedDistribution."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd import poutine
+    from torch.distributions import constraints
+
+    class Shifted(dist.TorchDistribution):
+        arg_constraints = {"loc": constraints.real}
+        support = constraints.real
+        has_rsample = True
+
+        def __init__(self, loc):
+            self.loc = loc
+            super().__init__(loc.shape, validate_args=False)
+
+        def rsample(self, sample_shape=torch.Size()):
+            shape = torch.Size(sample_shape) + self.loc.shape
+            return self.loc + torch.randn(shape)
+
+        def log_prob(self, value):
+            return -0.5 * (value - self.loc) ** 2
+
+    d = Shifted(torch.tensor([[0.0], [10.0]]))              # batch (2, 1)
+    big = d.expand((3, 2, 4))
+    assert isinstance(big, dist.ExpandedDistribution) and big.batch_shape == (3, 2, 4)
+    x = big.rsample((5,))
+    assert x.shape == (5, 3, 2, 4)
+    assert (x[:, :, 0].abs() < 6).all() and ((x[:, :, 1] - 10).abs() < 6).all()
+    assert x[0, 0, 0].unique().numel() == 4                  # independent along the stretched dim
+    assert big.log_prob(x).shape == (5, 3, 2, 4)
+    assert big.expand((7, 3, 2, 4)).batch_shape == (7, 3, 2, 4)
+    for bad in ((2, 4), (3, 3, 4)):
+        with pytest.raises(ValueError, match="Cannot broadcast"):
+            Shifted(torch.zeros(2, 1)).expand((3, 2, 4)).expand(bad)
+
+    def model():
+        with pyro.plate("a", 4, dim=-1), pyro.plate("b", 3, dim=-3):
+            return pyro.sample("x", Shifted(torch.tensor([[0.0], [10.0]])))
+
+    tr = poutine.trace(model).get_trace()
+    assert tr.nodes["x"]["value"].shape == (3, 2, 4)
+    tr.compute_log_prob()
+    assert tr.nodes["x"]["log_prob"].shape == (3, 2, 4)

@@ -46,7 +46,7 @@ def install_out_of_scope():
         return type(name, (), {"__init__": __init__})
 
     for name in ("EnergyDistance", "TraceTailAdaptive_ELBO", "RenyiELBO", "ReweightedWakeSleep",
-                 "TraceTMC_ELBO", "JitTraceTMC_ELBO", "SVGD", "CSIS", "Importance", "SMCFilter",
+                 "TraceTMC_ELBO", "JitTraceTMC_ELBO", "SVGD", "CSIS", "Importance", "SMCFilter", "Trace_MMD",
                  "MHResampler", "WeighedPredictive", "Resampler", "RBFSteinKernel", "SMCFailed",
                  "EmpiricalMarginal", "TracePosterior", "TracePredictive", "DiscreteHMCGibbs",
                  "EasyGuide", "BetaBinomialPair", "GammaPoissonPair", "UnitJacobianReparam"):
@@ -57,8 +57,28 @@ def install_out_of_scope():
                  "GaussianHMM", "BetaBinomial", "SpanningTree", "OneTwoMatching", "Rejector"):
         if not hasattr(dist, name):
             setattr(dist, name, _skipper(name))
+    # any other distribution name of the reference: a stand-in that skips when constructed
+    dist.__getattr__ = lambda name: (_ for _ in ()).throw(AttributeError(name)) \
+        if name.startswith("__") else _skipper(name)
+    for modname, names in (("naive_dirichlet", ("NaiveBeta", "NaiveDirichlet")),
+                           ("rejection_exponential", ("RejectionExponential",)),
+                           ("gof", ("auto_goodness_of_fit",)), ("special", ())):
+        m = types.ModuleType("pyro.distributions.testing." + modname)
+        for n in names:
+            setattr(m, n, _skipper(n))
+        sys.modules["pyro.distributions.testing." + modname] = m
+    # pyro.distributions.torch as a module path -- NOT set as an attribute of the package: inside the
+    # package ``torch`` must keep meaning the library
+    dtorch = types.ModuleType("pyro.distributions.torch")
+    for name in dist.__all__ + ["Categorical", "Independent"]:
+        obj = dist.__dict__.get(name)
+        if isinstance(obj, type):
+            setattr(dtorch, name, obj)
+    sys.modules["pyro.distributions.torch"] = dtorch
     rg = types.ModuleType("pyro.distributions.testing.rejection_gamma")
-    rg.ShapeAugmentedGamma = _skipper("ShapeAugmentedGamma")
+    for n in ("ShapeAugmentedGamma", "ShapeAugmentedBeta", "ShapeAugmentedDirichlet", "RejectionStandardGamma",
+              "RejectionGamma"):
+        setattr(rg, n, _skipper(n))
     sys.modules["pyro.distributions.testing.rejection_gamma"] = rg
     imp = types.ModuleType("pyro.infer.importance")
     imp.vectorized_importance_weights = lambda *a, **k: pytest.skip("out of scope: importance weights")
@@ -98,7 +118,18 @@ def install_out_of_scope():
         setattr(cci, name, _skipper(name))
     cc.infer = cci
     contrib.conjugate = cc
+    gp = types.ModuleType("pyro.contrib.gp")
+    gp.__path__ = []
+    gpk = types.ModuleType("pyro.contrib.gp.kernels")
+    for name in ("RBF", "Matern32", "Exponential", "Kernel"):
+        setattr(gpk, name, _skipper(name))
+    gp.kernels = gpk
+    contrib.gp = gp
+    sys.modules["pyro.contrib.gp"] = gp
+    sys.modules["pyro.contrib.gp.kernels"] = gpk
     sys.modules["pyro.contrib"] = contrib
+    import pyro_amd
+    pyro_amd.contrib = contrib
     sys.modules["pyro.contrib.conjugate"] = cc
     sys.modules["pyro.contrib.conjugate.infer"] = cci
     streaming = types.ModuleType("pyro.ops.streaming")
