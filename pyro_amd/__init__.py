@@ -6,9 +6,15 @@ kernels for gfx950 behind the C-ABI in include/pyro_amd.h.  GPU tensors only: th
 fallback.
 """
 from . import distributions, infer, ops, optim, poutine, settings  # noqa: F401
-from .primitives import (clear_param_store, deterministic, enable_validation, factor,  # noqa: F401
+from .primitives import (barrier, clear_param_store, deterministic, enable_validation, factor,  # noqa: F401
+                         iarange, irange,
                          get_param_store, module, param, plate, plate_stack, random_module, sample, subsample,
                          set_rng_seed, validation_enabled)
 from .poutine.handlers import condition, do, markov  # noqa: F401  (pyro/__init__.py:7)
 
 __version__ = "0.1.0"
+
+import logging as _logging  # noqa: E402
+
+log = _logging.getLogger("pyro_amd")      # pyro.log (pyro/logger.py)
+log.setLevel(_logging.INFO)

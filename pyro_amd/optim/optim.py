@@ -15,6 +15,26 @@ from .. import kernels
 from ..params import _PARAM_STORE
 
 
+def is_scheduler(optimizer):
+    """Is this a torch learning-rate scheduler (it holds its optimizer) rather than an optimizer?"""
+    return hasattr(optimizer, "optimizer")
+
+
+def _state_of(obj):
+    # checkpoint of one parameter's optimizer, or of its scheduler AND optimizer (optim.py:45-68)
+    if is_scheduler(obj):
+        return {"scheduler": obj.state_dict(), "optimizer": obj.optimizer.state_dict()}
+    return obj.state_dict()
+
+
+def _restore(obj, state):
+    if is_scheduler(obj):
+        obj.load_state_dict(state["scheduler"])
+        obj.optimizer.load_state_dict(state["optimizer"])
+    else:
+        obj.load_state_dict(state)
+
+
 class PyroOptim:
     """Wrap a torch optimizer class; one instance per parameter (reference-compatible)."""
 
@@ -32,24 +52,32 @@ class PyroOptim:
             return self.pt_optim_args(name)
         return self.pt_optim_args
 
+    def _get_optim(self, param):
+        return self.pt_optim_constructor([param], **self._args_for(param))
+
+    @staticmethod
+    def _optimizer_of(obj):
+        # a learning-rate scheduler (PyroLRScheduler) holds its optimizer
+        return getattr(obj, "optimizer", obj)
+
     def __call__(self, params, *args, **kwargs):
         for p in params:
             if p not in self.optim_objs:
-                self.optim_objs[p] = self.pt_optim_constructor([p], **self._args_for(p))
+                self.optim_objs[p] = self._get_optim(p)
                 name = _PARAM_STORE.param_name(p)
                 state = self._state_waiting_to_be_consumed.pop(name, None)
                 if state is not None:
-                    self.optim_objs[p].load_state_dict(state)
+                    _restore(self.optim_objs[p], state)
             if self.pt_clip_args is not None:
                 clip = self.pt_clip_args
                 if "clip_norm" in clip:
                     torch.nn.utils.clip_grad_norm_([p], clip["clip_norm"])
                 if "clip_value" in clip:
                     torch.nn.utils.clip_grad_value_([p], clip["clip_value"])
-            self.optim_objs[p].step(*args, **kwargs)
+            self._optimizer_of(self.optim_objs[p]).step(*args, **kwargs)
 
     def get_state(self):
-        return {_PARAM_STORE.param_name(p): o.state_dict() for p, o in self.optim_objs.items()}
+        return {_PARAM_STORE.param_name(p): _state_of(o) for p, o in self.optim_objs.items()}
 
     def set_state(self, state_dict):
         self._state_waiting_to_be_consumed.update(state_dict)
@@ -59,6 +87,49 @@ class PyroOptim:
 
     def load(self, filename, map_location=None):
         self.set_state(torch.load(filename, map_location=map_location, weights_only=False))
+
+
+class PyroLRScheduler(PyroOptim):
+    """A torch learning-rate scheduler per dynamically created parameter (reference: lr_scheduler.py).
+    ``optim_args`` holds ``"optimizer"`` (a torch optimizer class), ``"optim_args"`` (its arguments) and the
+    scheduler's own arguments; ``svi.step`` steps the optimizers, ``scheduler.step()`` the schedules::
+
+        scheduler = pyro.optim.ExponentialLR({"optimizer": torch.optim.SGD, "optim_args": {"lr": 0.01},
+                                              "gamma": 0.1})
+    """
+
+    def __init__(self, scheduler_constructor, optim_args, clip_args=None):
+        optim_args = dict(optim_args)
+        self.pt_scheduler_constructor = scheduler_constructor
+        pt_optim_constructor = optim_args.pop("optimizer")
+        optim_kwargs = optim_args.pop("optim_args")
+        self.kwargs = optim_args
+        super().__init__(pt_optim_constructor, optim_kwargs, clip_args)
+
+    def _get_optim(self, param):
+        return self.pt_scheduler_constructor(super()._get_optim(param), **self.kwargs)
+
+    def step(self, *args, **kwargs):
+        """Advance every parameter's schedule (same arguments as the torch scheduler's ``step``)."""
+        for scheduler in self.optim_objs.values():
+            scheduler.step(*args, **kwargs)
+
+
+def _torch_wrappers():
+    """``pyro.optim.<Name>`` for every optimizer class of torch.optim and every scheduler class of
+    torch.optim.lr_scheduler (reference: pytorch_optimizers.py builds the same names in a loop)."""
+    import functools
+    out = {}
+    for name, cls in vars(torch.optim).items():
+        if isinstance(cls, type) and issubclass(cls, torch.optim.Optimizer) \
+                and cls not in (torch.optim.Optimizer, torch.optim.LBFGS):
+            out[name] = functools.partial(PyroOptim, cls)
+    base = torch.optim.lr_scheduler.LRScheduler
+    for name, cls in vars(torch.optim.lr_scheduler).items():
+        if isinstance(cls, type) and (issubclass(cls, base) or name == "ReduceLROnPlateau") \
+                and cls is not base and not name.startswith("_"):
+            out[name] = functools.partial(PyroLRScheduler, cls)
+    return out
 
 
 def TorchAdam(optim_args, clip_args=None):

@@ -11,3 +11,4 @@ from .trace import Trace  # noqa: F401
 from . import util  # noqa: F401
 from .util import prune_subsample_sites, site_is_subsample  # noqa: F401
 from .messenger import unwrap  # noqa: E402,F401
+from .util import enable_validation, is_validation_enabled  # noqa: E402,F401

@@ -230,3 +230,27 @@ def random_module(name, nn_module, prior, *args, **kwargs):
         return lifted(name, copy.deepcopy(nn_module), *args, update_module_params=True, **kwargs)
 
     return _fn
+
+
+class iarange(plate):
+    """Deprecated spelling of :class:`plate` as a context manager (pyro/primitives.py:392-397)."""
+
+    def __init__(self, *args, **kwargs):
+        import warnings as _warnings
+        _warnings.warn("pyro.iarange is deprecated; use pyro.plate instead", DeprecationWarning)
+        super().__init__(*args, **kwargs)
+
+
+class irange(plate):
+    """Deprecated spelling of :class:`plate` as a loop (pyro/primitives.py:400-405)."""
+
+    def __init__(self, *args, **kwargs):
+        import warnings as _warnings
+        _warnings.warn("pyro.irange is deprecated; use pyro.plate instead", DeprecationWarning)
+        super().__init__(*args, **kwargs)
+
+
+def barrier(data):
+    """EXPERIMENTAL in the reference (a synchronisation point for lazily evaluated funsor values under
+    ``poutine.collapse``): values are always ground here, so this is the identity."""
+    return data

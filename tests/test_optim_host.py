@@ -167,3 +167,34 @@ def test_flat_and_per_parameter_optimizers_agree_and_exchange_checkpoints(monkey
                 np.testing.assert_allclose(got[n].numpy(), ref[n].numpy(), rtol=1e-10, atol=1e-12)
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_lr_scheduler_wrappers_and_their_checkpoints():
+    """pyro.optim.<Scheduler>({"optimizer": ..., "optim_args": ..., **scheduler_args}) (tests/optim/
+    test_optim.py:332-440): svi.step steps the optimizers, scheduler.step() the schedules; the state holds
+    both; every optimizer / scheduler class of torch has a wrapper."""
+    import pyro_amd as pyro
+    from pyro_amd import optim
+    for name in ("Adagrad", "Adamax", "RMSprop", "SGD", "ExponentialLR", "StepLR", "LambdaLR",
+                 "ReduceLROnPlateau", "MultiStepLR", "CosineAnnealingLR"):
+        assert hasattr(optim, name), name
+    pyro.clear_param_store()
+    pyro.param("x", torch.tensor(1.0))
+
+    def run(sched, epochs):
+        for _ in range(epochs):
+            u = pyro.param("x").unconstrained()
+            u.grad = torch.tensor(1.0)
+            sched([u])
+            sched.step()
+        return pyro.param("x").item()
+
+    cfg = {"optimizer": torch.optim.SGD, "optim_args": {"lr": 0.1}, "gamma": 0.5}
+    sched = optim.ExponentialLR(dict(cfg))
+    assert abs(run(sched, 3) - (1.0 - 0.1 - 0.05 - 0.025)) < 1e-6
+    state = sched.get_state()
+    assert set(state["x"]) == {"scheduler", "optimizer"}
+    again = optim.ExponentialLR(dict(cfg))
+    again.set_state(state)
+    assert abs(run(again, 1) - (0.825 - 0.0125)) < 1e-6        # continues at the decayed rate
+    assert not optim.optim.is_scheduler(torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=0.1))

@@ -132,6 +132,10 @@ def install_out_of_scope():
     pyro_amd.contrib = contrib
     sys.modules["pyro.contrib.conjugate"] = cc
     sys.modules["pyro.contrib.conjugate.infer"] = cci
+    import pyro_amd.optim as optim_pkg
+    for name in ("DCTAdam", "AdagradRMSProp", "HorovodOptimizer"):
+        if not hasattr(optim_pkg, name):
+            setattr(optim_pkg, name, _skipper(name))
     streaming = types.ModuleType("pyro.ops.streaming")
     for name in ("CountMeanVarianceStats", "StatsOfDict", "CountMeanStats", "CountStats", "StackStats",
                  "StreamingStats"):
