@@ -100,6 +100,7 @@ class AutoGuide:
         self.prototype_trace = None
         self._prototype_frames = {}
         self.prefix = type(self).__name__
+        self.master = None                  # weakref to the AutoGuideList this guide is a part of
 
     def __call__(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
@@ -110,6 +111,11 @@ class AutoGuide:
         return tuple(v for _, v in sorted(result.items()))
 
     def _create_plates(self, *args, **kwargs):
+        master = getattr(self, "master", None)
+        if master is not None:
+            # a part of an AutoGuideList: the list made the plates of this call (one subsample for all)
+            assert self.create_plates is None, "Cannot pass create_plates() to non-master guide"
+            return master().plates
         if self.create_plates is None:
             plates = {}
         else:
@@ -122,6 +128,7 @@ class AutoGuide:
                 full_size = getattr(frame, "full_size", frame.size)
                 plates[name] = plate(name, full_size, dim=frame.dim,
                                      subsample_size=frame.size if frame.size != full_size else None)
+        self.plates = plates
         return plates
 
     def _setup_prototype(self, *args, **kwargs):
@@ -616,6 +623,123 @@ class AutoMultivariateNormal(AutoContinuous):
         loc, scale, scale_tril = self._params()
         st = scale[..., None] * scale_tril
         return loc, st.pow(2).sum(-1).sqrt()
+
+
+class AutoLowRankMultivariateNormal(AutoContinuous):
+    """Low-rank plus diagonal Normal over the concatenated unconstrained latent vector (reference:
+    guides.py:968-1029): parameters ``<prefix>.loc``, ``<prefix>.scale`` (softplus-positive) and
+    ``<prefix>.cov_factor`` [latent_dim, rank]; covariance = scale (W W^T + I) scale.  ``rank`` defaults to
+    round(sqrt(latent_dim))."""
+
+    scale_constraint = softplus_positive
+
+    def __init__(self, model, init_loc_fn=init_to_median, init_scale=0.1, rank=None):
+        if not isinstance(init_scale, float) or not (init_scale > 0):
+            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
+        if not (rank is None or isinstance(rank, int) and rank > 0):
+            raise ValueError("Expected rank > 0 but got {}".format(rank))
+        self._init_scale = init_scale
+        self.rank = rank
+        super().__init__(model, init_loc_fn=init_loc_fn)
+
+    def _setup_prototype(self, *args, **kwargs):
+        super()._setup_prototype(*args, **kwargs)
+        self._loc0 = self._init_loc()
+        if self.rank is None:
+            self.rank = int(round(self.latent_dim ** 0.5))
+
+    def _params(self):
+        loc0 = self._loc0
+        loc = param("{}.loc".format(self.prefix), lambda: loc0.clone(), constraints.real)
+        scale = param("{}.scale".format(self.prefix),
+                      lambda: torch.full_like(loc0, 0.5 ** 0.5 * self._init_scale), self.scale_constraint)
+        cov_factor = param("{}.cov_factor".format(self.prefix),
+                           lambda: loc0.new_empty(self.latent_dim, self.rank).normal_(
+                               0, 1 / self.rank ** 0.5), constraints.real)
+        return loc, scale, cov_factor
+
+    def get_posterior(self, *args, **kwargs):
+        loc, scale, cov_factor = self._params()
+        return dist.LowRankMultivariateNormal(loc, cov_factor * scale.unsqueeze(-1), scale * scale)
+
+    def _loc_scale(self, *args, **kwargs):
+        loc, scale, cov_factor = self._params()
+        return loc, scale * (cov_factor.pow(2).sum(-1) + 1).sqrt()
+
+
+class AutoCallable(AutoGuide):
+    """A hand-written guide function as a part of an :class:`AutoGuideList` (guides.py:279-316)."""
+
+    def __init__(self, model, guide, median=lambda *args, **kwargs: {}):
+        super().__init__(model)
+        self._guide = guide
+        self.median = median
+
+    def forward(self, *args, **kwargs):
+        result = self._guide(*args, **kwargs)
+        return {} if result is None else result
+
+
+class AutoGuideList(AutoGuide):
+    """Several guides, each for a part of the model (made by ``poutine.block``-ing the model down to some
+    of its sites), run one after the other; the plates are created once per call and shared
+    (reference: guides.py:184-276)::
+
+        guide = AutoGuideList(model)
+        guide.append(AutoDelta(poutine.block(model, expose=["drift"])))
+        guide.append(AutoNormal(poutine.block(model, hide=["drift"])))
+    """
+
+    init_loc_fn = staticmethod(init_to_feasible)
+
+    def __init__(self, model, *, create_plates=None):
+        super().__init__(model, create_plates=create_plates)
+        self._parts = []
+
+    def __len__(self):
+        return len(self._parts)
+
+    def __iter__(self):
+        return iter(self._parts)
+
+    def __getitem__(self, index):
+        return self._parts[index]
+
+    def append(self, part):
+        if not isinstance(part, AutoGuide):
+            part = AutoCallable(self.model, part)
+        if getattr(part, "master", None) is not None:
+            raise RuntimeError("The module `{}` is already added.".format(part.prefix))
+        import weakref
+        part.master = weakref.ref(self)
+        part.prefix = "{}.{}".format(self.prefix, len(self._parts))     # parameter names: <list>.<i>...
+        self._parts.append(part)
+
+    def add(self, part):
+        import warnings
+        warnings.warn("The method `.add` has been deprecated in favor of `.append`.", DeprecationWarning)
+        self.append(part)
+
+    def forward(self, *args, **kwargs):
+        if self.prototype_trace is None:
+            self._setup_prototype(*args, **kwargs)
+        self._create_plates(*args, **kwargs)
+        result = {}
+        for part in self._parts:
+            result.update(part(*args, **kwargs))
+        return result
+
+    def median(self, *args, **kwargs):
+        result = {}
+        for part in self._parts:
+            result.update(part.median(*args, **kwargs))
+        return result
+
+    def quantiles(self, quantiles, *args, **kwargs):
+        result = {}
+        for part in self._parts:
+            result.update(part.quantiles(quantiles, *args, **kwargs))
+        return result
 
 
 class AutoDelta(AutoGuide):

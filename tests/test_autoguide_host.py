@@ -8,7 +8,8 @@ import pyro_amd as pyro
 import pyro_amd.distributions as dist
 from pyro_amd import poutine
 from pyro_amd.infer import SVI, Trace_ELBO
-from pyro_amd.infer.autoguide import (AutoDelta, AutoDiagonalNormal, AutoMultivariateNormal, AutoNormal,
+from pyro_amd.infer.autoguide import (AutoDelta, AutoDiagonalNormal, AutoGuideList,
+                                      AutoLowRankMultivariateNormal, AutoMultivariateNormal, AutoNormal,
                                       init_to_feasible, init_to_median)
 from pyro_amd.optim import Adam
 
@@ -20,7 +21,7 @@ def _host(monkeypatch):
     pyro.clear_param_store()
 
 
-@pytest.mark.parametrize("auto_class", [AutoDelta, AutoNormal])
+@pytest.mark.parametrize("auto_class", [AutoDelta, AutoNormal, AutoGuideList])
 def test_subsample_guide(auto_class):
     """The model of tutorial/source/easyguide.ipynb (tests/infer/test_autoguide.py:1146-1193): local
     latents in a plate whose subsample is passed in; two epochs over consecutive mini-batches."""
@@ -40,7 +41,12 @@ def test_subsample_guide(auto_class):
     def create_plates(batch, subsample, full_size):
         return pyro.plate("data", full_size, subsample=subsample)
 
-    guide = auto_class(model, create_plates=create_plates)
+    if auto_class is AutoGuideList:
+        guide = AutoGuideList(model, create_plates=create_plates)
+        guide.append(AutoDelta(poutine.block(model, expose=["drift"])))
+        guide.append(AutoNormal(poutine.block(model, hide=["drift"])))
+    else:
+        guide = auto_class(model, create_plates=create_plates)
     full_size, batch_size, steps = 50, 20, 4
     pyro.set_rng_seed(123456789)
     data = model([None] * steps, torch.arange(full_size), full_size)
@@ -110,3 +116,35 @@ def test_call_returns_the_draws_ordered_by_name():
     pyro.set_rng_seed(0)
     as_tuple = guide.call()
     assert torch.equal(as_tuple[0], as_dict["a"]) and torch.equal(as_tuple[1], as_dict["b"])
+
+
+@pytest.mark.parametrize("auto_class", [AutoLowRankMultivariateNormal, AutoGuideList])
+def test_median_of_the_fitted_guide(auto_class):
+    """tests/infer/test_autoguide.py:359-417 (test_median): Normal / LogNormal / Beta priors, no data."""
+    def model():
+        pyro.sample("x", dist.Normal(0.0, 1.0))
+        pyro.sample("y", dist.LogNormal(0.0, 1.0))
+        pyro.sample("z", dist.Beta(2.0, 2.0))
+
+    if auto_class is AutoGuideList:
+        guide = AutoGuideList(model)
+        guide.append(AutoNormal(poutine.block(model, expose=["x"])))
+        guide.append(AutoLowRankMultivariateNormal(poutine.block(model, hide=["x"])))
+    else:
+        guide = auto_class(model)
+    pyro.set_rng_seed(0)
+    svi = SVI(model, guide, Adam({"lr": 0.02, "betas": (0.8, 0.99)}),
+              Trace_ELBO(num_particles=200, vectorize_particles=True))
+    for _ in range(150):
+        svi.step()
+    median = guide.median()
+    assert abs(float(median["x"])) < 0.15
+    assert abs(float(median["y"]) - 1.0) < 0.15
+    assert abs(float(median["z"]) - 0.5) < 0.1
+    q = guide.quantiles([0.1, 0.5, 0.9])
+    assert all(float(q[k][0]) < float(q[k][1]) < float(q[k][2]) for k in ("x", "y", "z"))
+    names = set(pyro.get_param_store().keys())
+    if auto_class is AutoGuideList:
+        assert {"AutoGuideList.0.locs.x", "AutoGuideList.1.loc", "AutoGuideList.1.cov_factor"} <= names
+    else:
+        assert pyro.param("AutoLowRankMultivariateNormal.cov_factor").shape == (3, 2)
