@@ -1,7 +1,7 @@
 """pyro_amd.poutine -- effect handlers (same surface as pyro.poutine for the hot paths)."""
 from . import runtime, settings  # noqa: F401
 from .handlers import (BlockMessenger, CondIndepStackFrame, ConditionMessenger,  # noqa: F401
-                       DoMessenger, EqualizeMessenger, EscapeMessenger, broadcast, equalize, InferConfigMessenger, LiftMessenger,
+                       DoMessenger, EqualizeMessenger, EscapeMessenger, ReparamMessenger, broadcast, equalize, reparam, InferConfigMessenger, LiftMessenger,
                        SubstituteMessenger, do, escape, infer_config, lift, queue, substitute, EnumMessenger, MarkovMessenger, MaskMessenger, PlateMessenger, ReplayMessenger,
                        ScaleMessenger, SeedMessenger, TraceMessenger, UnconditionMessenger, block,
                        condition, enum, get_mask, markov, mask, replay, scale, seed, trace, uncondition)

@@ -421,6 +421,50 @@ class EqualizeMessenger(Messenger):
                 msg["fn"] = Delta(self.value, event_dim=msg["fn"].event_dim).mask(False)
 
 
+class ReparamMessenger(Messenger):
+    """Replace the sample sites named by ``config`` (a dict site name -> reparameteriser, or a function of
+    the site returning one or None) by the reparameteriser's auxiliary sites + a deterministic map
+    (reference: reparam_messenger.py:35-122).  As a decorator the reparameterisers also see the call's
+    ``args, kwargs``."""
+
+    def __init__(self, config):
+        super().__init__()
+        assert isinstance(config, dict) or callable(config)
+        self.config = config
+        self._args_kwargs = None
+
+    def __call__(self, fn):
+        if not callable(fn):
+            raise ValueError("{} is not callable, did you mean to pass it as a keyword arg?".format(fn))
+        return _ReparamHandler(self, fn)
+
+    def _pyro_sample(self, msg):
+        if type(msg["fn"]).__name__ == "_Subsample":
+            return
+        reparam = self.config.get(msg["name"]) if isinstance(self.config, dict) else self.config(msg)
+        if reparam is None:
+            return
+        reparam.args_kwargs = self._args_kwargs
+        try:
+            new = reparam.apply({"name": msg["name"], "fn": msg["fn"], "value": msg["value"],
+                                 "is_observed": msg["is_observed"]})
+        finally:
+            reparam.args_kwargs = None
+        if new["value"] is not None and msg["value"] is not None and msg["value"] is not new["value"]:
+            assert new["value"].shape == msg["value"].shape
+        msg["fn"], msg["value"], msg["is_observed"] = new["fn"], new["value"], new["is_observed"]
+
+
+class _ReparamHandler(_BoundHandler):
+    def __call__(self, *args, **kwargs):
+        self.handler._args_kwargs = args, kwargs
+        try:
+            with self.handler:
+                return self.fn(*args, **kwargs)
+        finally:
+            self.handler._args_kwargs = None
+
+
 class UnconditionMessenger(Messenger):
     def _pyro_sample(self, msg):
         if msg["is_observed"]:
@@ -951,6 +995,7 @@ substitute = _make_handler(SubstituteMessenger)
 infer_config = _make_handler(InferConfigMessenger)
 do = _make_handler(DoMessenger)
 escape = _make_handler(EscapeMessenger)
+reparam = _make_handler(ReparamMessenger)
 
 
 def broadcast(fn=None):

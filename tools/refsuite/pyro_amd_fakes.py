@@ -170,11 +170,14 @@ def install_out_of_scope():
     tmc = types.ModuleType("pyro.infer.tracetmc_elbo")
     tmc.TraceTMC_ELBO = infer.TraceTMC_ELBO
     sys.modules["pyro.infer.tracetmc_elbo"] = tmc
-    if "pyro.infer.reparam" not in sys.modules:
+    reparam = sys.modules.get("pyro.infer.reparam")
+    if reparam is None:
         reparam = types.ModuleType("pyro.infer.reparam")
-        for name in ("LatentStableReparam", "LocScaleReparam", "TransformReparam", "StableReparam",
-                     "SymmetricStableReparam", "NeuTraReparam", "ConjugateReparam",
-                     "ProjectedNormalReparam", "HaarReparam", "DiscreteCosineReparam", "SplitReparam"):
-            setattr(reparam, name, _skipper(name))
         sys.modules["pyro.infer.reparam"] = reparam
         infer.reparam = reparam
+    for name in ("LatentStableReparam", "LocScaleReparam", "TransformReparam", "StableReparam",
+                 "SymmetricStableReparam", "NeuTraReparam", "ConjugateReparam", "ProjectedNormalReparam",
+                 "HaarReparam", "DiscreteCosineReparam", "SplitReparam", "StructuredReparam",
+                 "LinearHMMReparam", "StudentTReparam", "GumbelSoftmaxReparam", "UnitJacobianReparam"):
+        if not hasattr(reparam, name):
+            setattr(reparam, name, _skipper(name))
