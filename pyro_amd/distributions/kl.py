@@ -1,67 +1,72 @@
-"""KL divergences the reference registers on top of torch's (pyro/distributions/kl.py:19-56,
-pyro/distributions/torch_distribution.py:529-547) -- ``TraceMeanField_ELBO`` calls
-``kl_divergence(guide_fn, model_fn)`` on whatever the two traces hold, so the set of registered
-pairs decides which sites take the analytic route:
+"""KL pairs registered on top of torch's, the ones the reference adds (pyro/distributions/kl.py,
+pyro/distributions/torch_distribution.py): ``TraceMeanField_ELBO`` asks ``kl_divergence(guide_fn, model_fn)``
+for whatever the two traces hold, so this table decides which sites take the analytic route.
 
-* Delta || anything: ``-q.log_prob(p.v)`` (autoguides emit Delta sites; note that the Delta's own
-  ``log_density`` does not enter, exactly as in the reference);
-* Independent || Independent with DIFFERENT numbers of reinterpreted dims (torch only knows equal
-  ones): the shared dims are summed, the rest stays wrapped;
-* Independent(Delta | Normal, 1) || MultivariateNormal in closed form;
-* MaskedDistribution || MaskedDistribution: the KL of the bases under the conjunction of the masks.
+* ``Delta || anything`` = ``-q.log_prob(point)``: autoguides emit Delta sites; the Delta's own ``log_density``
+  does not enter, as in the reference;
+* ``Independent || Independent`` with different numbers of reinterpreted dims (torch only knows equal ones):
+  the common dims are summed out of the KL of what remains wrapped;
+* ``Independent(Delta or Normal, 1) || MultivariateNormal`` in closed form;
+* ``Masked || Masked``: the KL of the bases where both masks hold.
 """
 import math
 
-from torch.distributions import Independent as _TorchIndependent
-from torch.distributions import MultivariateNormal, Normal, kl_divergence, register_kl
-from torch.distributions.distribution import Distribution as _TorchDistribution
+import torch.distributions as td
+from torch.distributions import kl_divergence, register_kl
 
 from .base import Delta, MaskedDistribution
 from .util import scale_and_mask, sum_rightmost
 
+_HALF_LOG_2PI_E = 0.5 * (1.0 + math.log(2.0 * math.pi))       # entropy of a unit normal coordinate
 
-@register_kl(Delta, _TorchDistribution)
-def _kl_delta(p, q):
+
+def _peel(d, keep):
+    """An Independent with only ``keep`` of its reinterpreted dims left (its base when none are left)."""
+    return type(d)(d.base_dist, keep) if keep else d.base_dist
+
+
+@register_kl(Delta, td.Distribution)
+def _point_mass_against(p, q):
     return -q.log_prob(p.v)
 
 
-@register_kl(_TorchIndependent, _TorchIndependent)
-def _kl_independent_independent(p, q):
-    shared = min(p.reinterpreted_batch_ndims, q.reinterpreted_batch_ndims)
-    p_rest = p.reinterpreted_batch_ndims - shared
-    q_rest = q.reinterpreted_batch_ndims - shared
-    p = type(p)(p.base_dist, p_rest) if p_rest else p.base_dist
-    q = type(q)(q.base_dist, q_rest) if q_rest else q.base_dist
-    kl = kl_divergence(p, q)
-    return sum_rightmost(kl, shared) if shared else kl
+@register_kl(td.Independent, td.Independent)
+def _independent_pair(p, q):
+    common = min(p.reinterpreted_batch_ndims, q.reinterpreted_batch_ndims)
+    inner = kl_divergence(_peel(p, p.reinterpreted_batch_ndims - common),
+                          _peel(q, q.reinterpreted_batch_ndims - common))
+    return sum_rightmost(inner, common) if common else inner
 
 
-@register_kl(_TorchIndependent, MultivariateNormal)
-def _kl_independent_mvn(p, q):
-    if isinstance(p.base_dist, Delta) and p.reinterpreted_batch_ndims == 1:
-        return -q.log_prob(p.base_dist.v)
-    if isinstance(p.base_dist, Normal) and p.reinterpreted_batch_ndims == 1:
-        dim = q.event_shape[0]
-        p_cov = p.base_dist.scale ** 2
-        q_precision = q.precision_matrix.diagonal(dim1=-2, dim2=-1)
-        return (0.5 * (p_cov * q_precision).sum(-1) - 0.5 * dim * (1 + math.log(2 * math.pi))
-                - q.log_prob(p.base_dist.loc) - p.base_dist.scale.log().sum(-1))
-    raise NotImplementedError
+@register_kl(td.Independent, td.MultivariateNormal)
+def _diagonal_against_mvn(p, q):
+    base = p.base_dist
+    if p.reinterpreted_batch_ndims != 1 or not isinstance(base, (Delta, td.Normal)):
+        raise NotImplementedError
+    if isinstance(base, Delta):
+        return -q.log_prob(base.v)
+    # E_p[-log q] - H[p] for p = N(loc, diag(scale^2)): only the diagonal of q's precision meets p's covariance
+    n = q.event_shape[0]
+    trace_term = 0.5 * (base.scale.pow(2) * q.precision_matrix.diagonal(dim1=-2, dim2=-1)).sum(-1)
+    entropy = base.scale.log().sum(-1) + n * _HALF_LOG_2PI_E
+    return trace_term - q.log_prob(base.loc) - entropy
+
+
+def _both(m1, m2):
+    # conjunction of two masks, each a bool or a bool tensor
+    if m1 is False or m2 is False:
+        return False
+    if m1 is True:
+        return m2
+    if m2 is True or m1 is m2:
+        return m1
+    return m1 & m2
 
 
 @register_kl(MaskedDistribution, MaskedDistribution)
-def _kl_masked_masked(p, q):
-    if p._mask is False or q._mask is False:
-        mask = False
-    elif p._mask is True:
-        mask = q._mask
-    elif q._mask is True:
-        mask = p._mask
-    elif p._mask is q._mask:
-        mask = p._mask
-    else:
-        mask = p._mask & q._mask
+def _masked_pair(p, q):
+    mask = _both(p._mask, q._mask)
     if mask is False:
-        return 0.0      # a float: the device cannot be known
+        return 0.0                    # a float: there is no tensor to take a device from
     kl = kl_divergence(p.base_dist, q.base_dist)
     return kl if mask is True else scale_and_mask(kl, mask=mask)

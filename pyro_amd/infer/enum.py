@@ -1,7 +1,9 @@
 """Importance-trace construction shared by the ELBO estimators
 (reference: pyro/infer/enum.py:45-85 get_importance_trace, :138-220 config_enumerate)."""
-from .util import is_validation_enabled
+import functools
 import numbers
+
+from .util import is_validation_enabled
 
 from .. import poutine
 from ..poutine.util import prune_subsample_sites
@@ -42,76 +44,58 @@ def get_importance_trace(graph_type, max_plate_nesting, model, guide, args, kwar
     return model_trace, guide_trace
 
 
-def iter_discrete_escape(trace, msg):
-    """A latent site marked for sequential enumeration that ``trace`` does not hold yet."""
-    return (msg["type"] == "sample" and not msg["is_observed"]
-            and msg["infer"].get("enumerate") == "sequential" and msg["name"] not in trace)
-
-
-def iter_discrete_extend(trace, site, **ignored):
-    """One extension of ``trace`` per value in the support of ``site`` (each carrying the size of the
-    support as ``infer["_enum_total"]``)."""
-    support = site["fn"].enumerate_support(expand=bool(site["infer"].get("expand", False)))
-    for value in support:
-        chosen = site.copy()
-        chosen["infer"] = dict(site["infer"], _enum_total=support.shape[0])
-        chosen["value"] = value
-        longer = trace.copy()
-        longer.add_node(site["name"], **chosen)
-        yield longer
-
-
 def iter_discrete_traces(graph_type, fn, *args, **kwargs):
-    """All traces of ``fn`` over the joint support of its sequentially enumerated sites, depth first
-    (reference: pyro/infer/enum.py:88-111, on poutine.queue)."""
-    from queue import LifoQueue
-    pending = LifoQueue()
-    pending.put(poutine.Trace())
-    traced = poutine.trace(poutine.queue(fn, pending, escape_fn=iter_discrete_escape,
-                                         extend_fn=iter_discrete_extend), graph_type=graph_type)
-    while not pending.empty():
-        yield traced.get_trace(*args, **kwargs)
+    """Every trace of ``fn`` over the joint support of its sites marked
+    ``infer={"enumerate": "sequential"}``, depth first.  Each such site carries the size of its support in
+    ``infer["_enum_total"]``.  (The reference builds this on ``poutine.queue`` with escape / extend callbacks,
+    pyro/infer/enum.py:17-111; here one run = one assignment of support indices handed to
+    ``SequentialEnumMessenger``, which also reports the alternatives of every newly met site.)"""
+    from ..poutine.handlers import SequentialEnumMessenger
+    pending = [{}]                              # assignments (site name -> support index) still to run
+    while pending:
+        assignment = pending.pop()
+        found = []
+        branch = SequentialEnumMessenger(assignment, found)
+        yield poutine.trace(branch(fn), graph_type=graph_type).get_trace(*args, **kwargs)
+        pending.extend(reversed(found))         # the run just made took index 0 of each new site
 
 
-def _config_fn(default, expand, num_samples, tmc):
-    def fn(site):
-        if site["type"] != "sample" or site["is_observed"]:
+class _EnumerationConfig:
+    """The ``infer`` entries ``config_enumerate`` adds to a site; entries the site already has win."""
+
+    def __init__(self, default, expand, num_samples, tmc):
+        self.default, self.expand, self.num_samples, self.tmc = default, expand, num_samples, tmc
+
+    def __call__(self, site):
+        if site["type"] != "sample" or site["is_observed"] or type(site["fn"]).__name__ == "_Subsample":
             return {}
-        if type(site["fn"]).__name__ == "_Subsample":
+        local = self.num_samples is not None              # local sampling applies to every latent site
+        if not local and not getattr(site["fn"], "has_enumerate_support", False):
             return {}
-        infer = site["infer"]
-        if num_samples is not None:         # local sampling applies to every latent site
-            return {"enumerate": infer.get("enumerate", default),
-                    "num_samples": infer.get("num_samples", num_samples),
-                    "expand": infer.get("expand", expand), "tmc": infer.get("tmc", tmc)}
-        if getattr(site["fn"], "has_enumerate_support", False):
-            return {"enumerate": infer.get("enumerate", default),
-                    "expand": infer.get("expand", expand)}
-        return {}
-
-    return fn
+        offered = {"enumerate": self.default, "expand": self.expand}
+        if local:
+            offered.update(num_samples=self.num_samples, tmc=self.tmc)
+        return {key: site["infer"].get(key, value) for key, value in offered.items()}
 
 
 def config_enumerate(guide=None, default="parallel", expand=False, num_samples=None, tmc="diagonal"):
     """Mark the sites of ``guide`` (or of a model) for enumeration: every site that can enumerate its
     support -- or, with ``num_samples=n``, every latent site for n local Monte-Carlo draws on an
-    enumeration dim.  A site's own ``infer`` entries win.  Usable as a decorator
-    (reference: pyro/infer/enum.py:138-220)."""
+    enumeration dim.  Usable as a decorator, with or without arguments (pyro/infer/enum.py:138-220)."""
     if default not in ("sequential", "parallel", "flat", None):
         raise ValueError("Invalid default value. Expected 'sequential', 'parallel', or None, but got "
                          "{}".format(repr(default)))
-    if expand not in (True, False):
+    if expand is not True and expand is not False:
         raise ValueError("Invalid expand value. Expected True or False, but got {}".format(repr(expand)))
     if num_samples is not None:
-        if not (isinstance(num_samples, numbers.Number) and num_samples > 0):
+        if not isinstance(num_samples, numbers.Number) or num_samples <= 0:
             raise ValueError("Invalid num_samples, expected None or positive integer, but got "
                              "{}".format(repr(num_samples)))
         if default == "sequential":
             raise ValueError('Local sampling does not support "sequential" sampling; use "parallel" '
                              "sampling instead.")
-    if tmc == "full" and num_samples is not None and num_samples > 1:
-        expand = True
-    if guide is None:
-        return lambda g: config_enumerate(g, default=default, expand=expand,
-                                          num_samples=num_samples, tmc=tmc)
-    return poutine.infer_config(guide, config_fn=_config_fn(default, expand, num_samples, tmc))
+        if tmc == "full" and num_samples > 1:
+            expand = True
+    configure = functools.partial(poutine.infer_config,
+                                  config_fn=_EnumerationConfig(default, expand, num_samples, tmc))
+    return configure if guide is None else configure(guide)

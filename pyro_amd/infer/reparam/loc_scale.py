@@ -1,52 +1,61 @@
-"""Non-centring of location-scale families (reference: pyro/infer/reparam/loc_scale.py)."""
+"""Non-centring of location-scale families (role of pyro/infer/reparam/loc_scale.py; Gorinova, Moore,
+Hoffman 2019): the funnel geometry of ``x ~ F(loc, scale)`` with random loc / scale is removed by sampling
+in coordinates where the site's law does not depend on them."""
 import torch
 from torch.distributions import constraints
 
-from ... import distributions as dist
 from ...distributions.util import is_identically_one
-from ...primitives import param, sample
+from ...primitives import param
 from ..util import is_validation_enabled
 from .reparam import Reparam
 
 
+def _in_unit_interval(c):
+    c = torch.as_tensor(c)
+    return bool(((c >= 0) & (c <= 1)).all())
+
+
 class LocScaleReparam(Reparam):
-    """Partial non-centring of a location-scale site: with ``c = centered`` in [0, 1] the auxiliary site
-    ``<name>_decentered ~ Family(c loc, scale^c)`` is sampled and
-    ``value = loc + scale^(1-c) (decentered - c loc)``.  ``centered=None`` learns c per element
-    (``<name>_centered``); ``shape_params`` names the other constructor arguments to carry over
-    (default: all of ``arg_constraints`` except loc and scale)."""
+    """With centring ``c`` in [0, 1] (per site or per element) the auxiliary site is
+    ``<name>_decentered ~ F(c * loc, scale ** c)`` and ``x = loc + scale ** (1 - c) * (aux - c * loc)``:
+    c = 1 changes nothing, c = 0 samples the standardised variable.  ``centered=None`` makes c a learnable
+    parameter ``<name>_centered`` (initially 0.5).  ``shape_params``: names of the family's other
+    constructor arguments to carry over (default: everything in ``arg_constraints`` but loc and scale)."""
 
     def __init__(self, centered=None, shape_params=None):
-        assert centered is None or isinstance(centered, (float, torch.Tensor))
+        if centered is not None:
+            assert isinstance(centered, (float, torch.Tensor)), centered
+            if is_validation_enabled():
+                assert _in_unit_interval(centered), "centered must lie in [0, 1]"
         if shape_params is not None:
-            assert isinstance(shape_params, (tuple, list)) and all(isinstance(n, str) for n in shape_params)
-        if is_validation_enabled() and centered is not None:
-            c = torch.as_tensor(centered)
-            assert bool((0 <= c).all()) and bool((c <= 1).all())
-        self.centered, self.shape_params = centered, shape_params
+            assert isinstance(shape_params, (tuple, list))
+            assert all(isinstance(name, str) for name in shape_params)
+        self.centered = centered
+        self.shape_params = shape_params
+
+    def _centering(self, name, family, event_shape):
+        if self.centered is not None:
+            return self.centered
+        return param(name + "_centered", lambda: family.loc.new_full(event_shape, 0.5),
+                     constraint=constraints.unit_interval)
 
     def apply(self, msg):
-        name, fn, value, is_observed = msg["name"], msg["fn"], msg["value"], msg["is_observed"]
-        centered = self.centered
-        if is_identically_one(centered):
+        if is_identically_one(self.centered):
             return msg
-        event_shape = fn.event_shape
-        fn, event_dim = self._unwrap(fn)
+        family, event_dim = self._unwrap(msg["fn"])
+        loc, scale = family.loc, family.scale
+        c = self._centering(msg["name"], family, msg["fn"].event_shape)
         if self.shape_params is None:
-            self.shape_params = tuple(k for k in fn.arg_constraints if k not in ("loc", "scale"))
-        params = {key: getattr(fn, key) for key in self.shape_params}
-        if centered is None:
-            centered = param("{}_centered".format(name), lambda: fn.loc.new_full(event_shape, 0.5),
-                             constraint=constraints.unit_interval)
-        params["loc"] = fn.loc * centered
-        params["scale"] = fn.scale ** centered
-        decentered_fn = type(fn)(**params)
-        decentered_value = None
-        if value is not None:
-            decentered_value = (value - fn.loc) * fn.scale.pow(centered - 1) + centered * fn.loc
-        decentered_value = sample("{}_decentered".format(name), self._wrap(decentered_fn, event_dim),
-                                  obs=decentered_value, infer={"is_observed": is_observed})
-        if value is None:
-            value = fn.loc + fn.scale.pow(1 - centered) * (decentered_value - centered * fn.loc)
-        return {"fn": dist.Delta(value, event_dim=event_dim).mask(False), "value": value,
-                "is_observed": True}
+            self.shape_params = tuple(k for k in family.arg_constraints if k != "loc" and k != "scale")
+        kept = {k: getattr(family, k) for k in self.shape_params}
+        aux_fn = type(family)(loc=c * loc, scale=scale ** c, **kept)
+        spread = scale ** (1 - c)                          # what is left of the scale outside the aux site
+
+        def to_aux(x):
+            return (x - loc) / spread + c * loc
+
+        def from_aux(a):
+            return loc + spread * (a - c * loc)
+
+        return self._through_auxiliary(msg, msg["name"] + "_decentered", self._wrap(aux_fn, event_dim),
+                                       event_dim, to_aux, from_aux)

@@ -1,31 +1,26 @@
-"""Sampling the base of a TransformedDistribution (reference: pyro/infer/reparam/transform.py)."""
+"""A latent ``TransformedDistribution`` sampled in the coordinates of its base distribution (role of
+pyro/infer/reparam/transform.py): useful when the posterior is simple before the transforms."""
+import functools
+
 import torch
 
-from ... import distributions as dist
-from ...primitives import sample
 from .reparam import Reparam
 
 
+def _compose(transforms):
+    return lambda x: functools.reduce(lambda acc, t: t(acc), transforms, x)
+
+
 class TransformReparam(Reparam):
-    """A latent ``TransformedDistribution`` site: sample ``<name>_base`` from the base distribution and push
-    it through the transforms."""
+    """``<name>_base ~ base_dist`` is the auxiliary site; the site itself becomes the image of that draw under
+    the distribution's transforms.  For latent sites only."""
 
     def apply(self, msg):
-        name, fn, value, is_observed = msg["name"], msg["fn"], msg["value"], msg["is_observed"]
-        fn, event_dim = self._unwrap(fn)
-        assert isinstance(fn, torch.distributions.TransformedDistribution)
-        value_base = value
-        if value is not None:
-            for t in reversed(fn.transforms):
-                value_base = t.inv(value_base)
-        base_event_dim = event_dim
-        for t in reversed(fn.transforms):
-            base_event_dim += t.domain.event_dim - t.codomain.event_dim
-        value_base = sample("{}_base".format(name), self._wrap(fn.base_dist, base_event_dim),
-                            obs=value_base, infer={"is_observed": is_observed})
-        if value is None:
-            value = value_base
-            for t in fn.transforms:
-                value = t(value)
-        return {"fn": dist.Delta(value, event_dim=event_dim).mask(False), "value": value,
-                "is_observed": True}
+        td, event_dim = self._unwrap(msg["fn"])
+        assert isinstance(td, torch.distributions.TransformedDistribution), type(td)
+        forward = list(td.transforms)
+        backward = [t.inv for t in reversed(forward)]
+        # every transform may change how many rightmost dims form one event
+        base_event_dim = event_dim + sum(t.domain.event_dim - t.codomain.event_dim for t in forward)
+        return self._through_auxiliary(msg, msg["name"] + "_base", self._wrap(td.base_dist, base_event_dim),
+                                       event_dim, _compose(backward), _compose(forward))

@@ -1,18 +1,29 @@
-"""ClippedAdam as a torch ``Optimizer`` (the semantics of pyro/optim/clipped_adam.py:14-100): Adam
-with every gradient element clamped to [-clip_norm, clip_norm] and the learning rate of each group
-multiplied by ``lrd`` after every step.  Used per parameter (``pyro_amd.optim.ClippedAdam`` with
-callable arguments); the fused flat-buffer form is pa_adam_step with the same arithmetic."""
+"""ClippedAdam as a torch ``Optimizer`` (the semantics of pyro.optim.clipped_adam.ClippedAdam): Adam on
+gradients clamped element-wise to ``[-clip_norm, clip_norm]``, with each group's learning rate multiplied
+by ``lrd`` at every step.  This per-parameter form serves ``pyro_amd.optim.ClippedAdam`` when it is given
+callable arguments or ``clip_args``; the flat-buffer form (all parameters in one ``pa_adam_step`` launch)
+does the same arithmetic.  Written over whole parameter lists with torch's ``_foreach`` operators: one
+fused sequence per group instead of a Python loop per parameter."""
 import math
 
 import torch
 from torch.optim.optimizer import Optimizer
 
+_DEFAULTS = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, clip_norm=10.0, lrd=1.0)
+
 
 class ClippedAdam(Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, clip_norm=10.0,
-                 lrd=1.0):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                                      clip_norm=clip_norm, lrd=lrd))
+    def __init__(self, params, **hyper):
+        unknown = set(hyper) - set(_DEFAULTS)
+        if unknown:
+            raise TypeError("unexpected ClippedAdam arguments: {}".format(sorted(unknown)))
+        super().__init__(params, {**_DEFAULTS, **hyper})
+
+    def _moments(self, p):
+        slot = self.state[p]
+        if not slot:
+            slot.update(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+        return slot
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -21,24 +32,26 @@ class ClippedAdam(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
-            beta1, beta2 = group["betas"]
-            group["lr"] *= group["lrd"]                 # decay first: step k uses lr * lrd^k
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                grad = p.grad.clamp(-group["clip_norm"], group["clip_norm"])
-                state = self.state[p]
-                if not state:
-                    state["step"] = 0
-                    state["exp_avg"] = torch.zeros_like(grad)
-                    state["exp_avg_sq"] = torch.zeros_like(grad)
-                state["step"] += 1
-                if group["weight_decay"] != 0:
-                    grad = grad.add(p, alpha=group["weight_decay"])
-                m, v = state["exp_avg"], state["exp_avg_sq"]
-                m.mul_(beta1).add_(grad, alpha=1 - beta1)
-                v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-                k = state["step"]
-                step_size = group["lr"] * math.sqrt(1 - beta2 ** k) / (1 - beta1 ** k)
-                p.addcdiv_(m, v.sqrt().add_(group["eps"]), value=-step_size)
+            group["lr"] *= group["lrd"]                     # the k-th step runs at lr * lrd ** k
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            b1, b2 = group["betas"]
+            bound = group["clip_norm"]
+            grads = [p.grad.clamp(-bound, bound) for p in live]
+            if group["weight_decay"]:
+                torch._foreach_add_(grads, live, alpha=group["weight_decay"])
+            slots = [self._moments(p) for p in live]
+            first = [s["exp_avg"] for s in slots]
+            second = [s["exp_avg_sq"] for s in slots]
+            torch._foreach_mul_(first, b1)
+            torch._foreach_add_(first, grads, alpha=1 - b1)
+            torch._foreach_mul_(second, b2)
+            torch._foreach_addcmul_(second, grads, grads, value=1 - b2)
+            denominators = torch._foreach_sqrt(second)
+            torch._foreach_add_(denominators, group["eps"])
+            for p, s, m, d in zip(live, slots, first, denominators):
+                s["step"] += 1                              # parameters may have joined at different times
+                k = s["step"]
+                p.addcdiv_(m, d, value=-group["lr"] * math.sqrt(1 - b2 ** k) / (1 - b1 ** k))
         return loss
