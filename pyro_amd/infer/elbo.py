@@ -1,20 +1,28 @@
-"""ELBO base class: the plugin seam SVI consumes (reference: pyro/infer/elbo.py:28-237).
+"""The estimator base class SVI consumes (constructor arguments and entry points of pyro.infer.ELBO, so that
+``Trace_ELBO(num_particles=64, vectorize_particles=True)`` means here what it means there).
 
-Same constructor arguments and the same three entry points (loss, loss_and_grads,
-differentiable_loss); ``vectorize_particles`` wraps model and guide in an outermost
-plate("num_particles_vectorized", P, dim=-max_plate_nesting) exactly like the reference
-(elbo.py:186-216) so the particle batch becomes the leading tensor dim the kernels stream over.
+What the base class owns is the PARTICLE dimension: with ``vectorize_particles`` model and guide run once
+inside an outermost ``plate("num_particles_vectorized", P)`` placed just left of the model's own plates, which
+is what turns the particle batch into the leading tensor dim the kernels stream over; otherwise the pair is
+traced ``num_particles`` times.  Subclasses provide ``_get_trace`` (one traced pair) and the three entry
+points ``loss`` / ``loss_and_grads`` / ``differentiable_loss``.
 """
+import abc
+import math
 import warnings
-from abc import ABCMeta, abstractmethod
 
 import torch
 
 from .. import poutine
+from ..poutine.util import prune_subsample_sites
 from ..primitives import plate
+
+_PARTICLE_PLATE = "num_particles_vectorized"
 
 
 class ELBOModule(torch.nn.Module):
+    """``elbo(model, guide)``: a module whose forward is the differentiable loss (for torch optimisers)."""
+
     def __init__(self, model, guide, elbo):
         super().__init__()
         self.model, self.guide, self.elbo = model, guide, elbo
@@ -23,75 +31,79 @@ class ELBOModule(torch.nn.Module):
         return self.elbo.differentiable_loss(self.model, self.guide, *args, **kwargs)
 
 
-class ELBO(metaclass=ABCMeta):
-    def __init__(self, num_particles=1, max_plate_nesting=float("inf"), max_iarange_nesting=None,
-                 vectorize_particles=False, strict_enumeration_warning=True,
-                 ignore_jit_warnings=False, jit_options=None, retain_graph=None,
-                 tail_adaptive_beta=-1.0):
+def deepest_plate(model, guide, args, kwargs, validate):
+    """How many vectorised plate dims the pair uses, found by one un-enumerated run of guide and model.
+    With ``validate`` the log_prob shapes of that run are checked against the plates now -- later, with a
+    finite ``max_plate_nesting``, whatever lies left of it may broadcast freely."""
+    from ..util import check_site_shape
+    with poutine.block():
+        guide_trace = poutine.trace(guide).get_trace(*args, **kwargs)
+        model_trace = poutine.trace(poutine.replay(model, trace=guide_trace)).get_trace(*args, **kwargs)
+    depth = 0
+    for trace in (prune_subsample_sites(model_trace), prune_subsample_sites(guide_trace)):
+        for site in trace.nodes.values():
+            if site["type"] != "sample":
+                continue
+            if validate:
+                check_site_shape(site, max_plate_nesting=math.inf)
+            depth = max([depth] + [-f.dim for f in site["cond_indep_stack"] if f.vectorized])
+    return depth
+
+
+class ELBO(abc.ABC):
+    def __init__(self, num_particles=1, max_plate_nesting=math.inf, max_iarange_nesting=None,
+                 vectorize_particles=False, strict_enumeration_warning=True, ignore_jit_warnings=False,
+                 jit_options=None, retain_graph=None, tail_adaptive_beta=-1.0):
         if max_iarange_nesting is not None:
-            warnings.warn("max_iarange_nesting is deprecated; use max_plate_nesting",
+            warnings.warn("max_iarange_nesting is deprecated; use max_plate_nesting instead",
                           DeprecationWarning)
             max_plate_nesting = max_iarange_nesting
-        self.max_plate_nesting = max_plate_nesting
-        self.num_particles = num_particles
-        self.vectorize_particles = vectorize_particles
-        self.retain_graph = retain_graph
-        if self.vectorize_particles and self.num_particles > 1:
-            self.max_plate_nesting += 1
+        self.num_particles, self.vectorize_particles = num_particles, vectorize_particles
+        self.max_plate_nesting = max_plate_nesting + self._particle_dims
         self.strict_enumeration_warning = strict_enumeration_warning
-        self.ignore_jit_warnings = ignore_jit_warnings
-        self.jit_options = jit_options
+        self.retain_graph = retain_graph
+        # accepted for signature compatibility; there is no tracing compiler to configure
+        self.ignore_jit_warnings, self.jit_options = ignore_jit_warnings, jit_options
         self.tail_adaptive_beta = tail_adaptive_beta
 
     def __call__(self, model, guide):
         return ELBOModule(model, guide, self)
 
+    # ---- the particle dimension ------------------------------------------------------------------------------
+    @property
+    def _particle_dims(self):
+        return int(bool(self.vectorize_particles) and self.num_particles > 1)
+
     def _guess_max_plate_nesting(self, model, guide, args, kwargs):
-        """Run model and guide once to find the deepest vectorised plate."""
-        with poutine.block():
-            guide_trace = poutine.trace(guide).get_trace(*args, **kwargs)
-            model_trace = poutine.trace(poutine.replay(model, trace=guide_trace)).get_trace(
-                *args, **kwargs)
-        from ..poutine.util import prune_subsample_sites
-        from ..util import check_site_shape
         from .util import is_validation_enabled
-        guide_trace = prune_subsample_sites(guide_trace)
-        model_trace = prune_subsample_sites(model_trace)
-        sites = [site for trace in (model_trace, guide_trace) for site in trace.nodes.values()
-                 if site["type"] == "sample"]
-        # shapes are checked now, against the un-enumerated run: once max_plate_nesting is finite,
-        # whatever sits left of it is allowed to broadcast (elbo.py:160-168)
-        if is_validation_enabled():
-            for site in sites:
-                check_site_shape(site, max_plate_nesting=float("inf"))
-        dims = [frame.dim for site in sites for frame in site["cond_indep_stack"] if frame.vectorized]
-        self.max_plate_nesting = -min(dims) if dims else 0
-        if self.vectorize_particles and self.num_particles > 1:
-            self.max_plate_nesting += 1
+        self.max_plate_nesting = deepest_plate(model, guide, args, kwargs, is_validation_enabled()) \
+            + self._particle_dims
 
     def _vectorized_num_particles(self, fn):
-        def wrapped_fn(*args, **kwargs):
-            if self.num_particles == 1:
-                return fn(*args, **kwargs)
-            with plate("num_particles_vectorized", self.num_particles,
-                       dim=-self.max_plate_nesting):
+        """``fn`` run inside the particle plate (as it is for a single particle)."""
+        if self.num_particles == 1:
+            return fn
+
+        def in_particle_plate(*args, **kwargs):
+            with plate(_PARTICLE_PLATE, self.num_particles, dim=-self.max_plate_nesting):
                 return fn(*args, **kwargs)
 
-        return wrapped_fn
+        return in_particle_plate
 
     def _get_vectorized_trace(self, model, guide, args, kwargs):
-        return self._get_trace(self._vectorized_num_particles(model),
-                               self._vectorized_num_particles(guide), args, kwargs)
-
-    @abstractmethod
-    def _get_trace(self, model, guide, args, kwargs):
-        raise NotImplementedError
+        wrap = self._vectorized_num_particles
+        return self._get_trace(wrap(model), wrap(guide), args, kwargs)
 
     def _get_traces(self, model, guide, args, kwargs):
-        if self.vectorize_particles:
-            if self.max_plate_nesting == float("inf"):
-                self._guess_max_plate_nesting(model, guide, args, kwargs)
-            yield self._get_vectorized_trace(model, guide, args, kwargs)
-        else:
+        """The traced (model, guide) pairs one evaluation averages over."""
+        if not self.vectorize_particles:
             for _ in range(self.num_particles):
                 yield self._get_trace(model, guide, args, kwargs)
+            return
+        if self.max_plate_nesting == math.inf:
+            self._guess_max_plate_nesting(model, guide, args, kwargs)
+        yield self._get_vectorized_trace(model, guide, args, kwargs)
+
+    @abc.abstractmethod
+    def _get_trace(self, model, guide, args, kwargs):
+        """One (model_trace, guide_trace) pair."""

@@ -1,39 +1,54 @@
-"""MCMCKernel: the interface MCMC drives (reference seam 3(iii):
-pyro/infer/mcmc/mcmc_kernel.py:7-80)."""
-from abc import ABCMeta, abstractmethod
+"""What the MCMC driver asks of a transition kernel (the interface of pyro.infer.mcmc.MCMCKernel, so that
+kernels written for the reference plug in unchanged).
+
+Only ``sample`` is mandatory.  HMC and NUTS of this package additionally run all chains as ONE batch on the
+device (``chain_batched = True``); a kernel that does not say so -- every user-written one -- is driven chain
+after chain through exactly the calls below, in this order::
+
+    setup(warmup_steps, *model_args, **model_kwargs)      once per chain
+    params = initial_params                               the starting point (a dict name -> tensor)
+    params = sample(params)  x (warmup_steps + num_samples), with logging() polled for the progress line
+    diagnostics()                                         merged into MCMC.diagnostics()
+    cleanup()
+"""
+import abc
 
 
-class MCMCKernel(object, metaclass=ABCMeta):
-    def setup(self, warmup_steps, *args, **kwargs):
-        """Optional: set up anything needed before the first ``sample`` call."""
-        pass
+class MCMCKernel(abc.ABC):
+    chain_batched = False
 
-    def cleanup(self):
-        pass
-
-    def logging(self):
-        """An OrderedDict of name -> formatted value shown while sampling."""
-        return None
-
-    def diagnostics(self):
-        """A dict of diagnostics available when the run completes."""
-        return {}
-
-    def end_warmup(self):
-        pass
-
-    @property
-    def initial_params(self):
-        raise NotImplementedError
-
-    @initial_params.setter
-    def initial_params(self, params):
-        raise NotImplementedError
-
-    @abstractmethod
+    # ---- the one thing a kernel must provide ------------------------------------------------------------
+    @abc.abstractmethod
     def sample(self, params):
-        """One transition: params (dict of tensors) -> new params."""
-        raise NotImplementedError
+        """One transition from ``params`` (dict of tensors); returns the next state in the same form."""
 
     def __call__(self, params):
         return self.sample(params)
+
+    # ---- the starting point: stored here unless a kernel computes its own ----------------------------------
+    def _get_initial_params(self):
+        raise NotImplementedError("{} does not define initial_params".format(type(self).__name__))
+
+    def _set_initial_params(self, params):
+        raise NotImplementedError("{} does not accept initial_params".format(type(self).__name__))
+
+    initial_params = property(lambda self: self._get_initial_params(),
+                              lambda self, params: self._set_initial_params(params))
+
+    # ---- optional hooks, all no-ops by default ---------------------------------------------------------------
+    def setup(self, warmup_steps, *args, **kwargs):
+        """Before the first transition of a chain; receives the model's arguments."""
+
+    def end_warmup(self):
+        """Between the last warm-up transition and the first kept one."""
+
+    def cleanup(self):
+        """After the last transition of a chain."""
+
+    def logging(self):
+        """Progress information: an ordered mapping name -> already formatted value, or None."""
+        return None
+
+    def diagnostics(self):
+        """Whatever the kernel wants reported once the run is over."""
+        return {}
