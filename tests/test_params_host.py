@@ -1,126 +1,112 @@
-"""tests/params/test_param.py of the reference restated (CPU): the dict interface of the parameter
-store, save / load with pyro.module, scopes."""
-import os
-import tempfile
-
-import numpy as np
+"""The parameter store (CPU): mapping interface, constraints, persistence together with ``pyro.module``,
+nested scopes.  The behaviours are the ones tests/params/test_param.py of the reference pins."""
+import pytest
 import torch
-import torch.nn as nn
 from torch.distributions import constraints
 
 import pyro_amd as pyro
 
 
-def _eq(a, b):
-    np.testing.assert_allclose(torch.as_tensor(a).detach().numpy(), torch.as_tensor(b).detach().numpy(),
-                               rtol=1e-6, atol=1e-6)
+@pytest.fixture
+def store():
+    s = pyro.get_param_store()
+    s.clear()
+    yield s
+    s.clear()
 
 
-def test_save_and_load():
-    pyro.clear_param_store()
-    lin1, lin2, lin3 = nn.Linear(3, 2), nn.Linear(3, 2), nn.Linear(3, 2)
-    lin = pyro.module("mymodule", lin1)
-    pyro.module("mymodule2", lin2)
-    x = torch.randn(1, 3)
-    myparam = pyro.param("myparam", 1.234 * torch.ones(1))
-    cost = torch.sum(torch.pow(lin(x), 2.0)) * torch.pow(myparam, 4.0)
-    cost.backward()
-    leaf = myparam.unconstrained() if hasattr(myparam, "unconstrained") else myparam
-    optim = torch.optim.Adam(list(lin1.parameters()) + [leaf], lr=0.01)
-    stale = pyro.param("myparam").detach().numpy().copy()
-    optim.step()
-    fresh = pyro.param("myparam").detach().numpy().copy()
-    store = pyro.get_param_store()
+def _same(a, b):
+    torch.testing.assert_close(torch.as_tensor(a).detach(), torch.as_tensor(b).detach(), rtol=1e-6, atol=1e-6)
+
+
+# ---- the mapping interface --------------------------------------------------------------------------------
+def test_an_empty_store_is_falsy_and_empty(store):
+    assert not store and len(store) == 0
+    assert [list(view) for view in (store.keys(), store.values(), store.items())] == [[], [], []]
+    assert "anything" not in store
+
+
+def test_assignment_setdefault_and_deletion(store):
+    store["w"] = torch.zeros(1, 2, 3)
+    store.setdefault("s", torch.ones(4, 5), constraint=constraints.positive)
+    assert store and len(store) == 2 and set(store.keys()) == {"w", "s"} == {k for k, _ in store.items()}
+    assert store["w"].shape == (1, 2, 3) and store["s"].shape == (4, 5)
+    # setdefault never overwrites
+    _same(store.setdefault("w", torch.ones(1, 2, 3)), torch.zeros(1, 2, 3))
+    _same(store.setdefault("s", torch.zeros(4, 5)), torch.ones(4, 5))
+    # a real-valued parameter IS its unconstrained leaf; a positive one lives in log space
+    assert store["w"].unconstrained() is store["w"]
+    _same(store["s"].unconstrained(), torch.zeros(4, 5))
+    del store["w"]
+    assert "w" not in store and list(store.keys()) == ["s"]
+    _same(store["s"].unconstrained(), torch.zeros(4, 5))
+    del store["s"]
+    assert not store
+
+
+# ---- persistence and pyro.module ---------------------------------------------------------------------------
+def test_a_saved_store_feeds_a_new_module_object(store, tmp_path):
+    trained, bystander, newcomer = (torch.nn.Linear(3, 2) for _ in range(3))
+    net = pyro.module("net", trained)
+    pyro.module("other", bystander)
+    gain = pyro.param("gain", torch.full((1,), 1.234))
+    (net(torch.randn(1, 3)).pow(2).sum() * gain.pow(4)).backward()
+    before = pyro.param("gain").detach().clone()
+    torch.optim.Adam(list(trained.parameters()) + [gain.unconstrained()], lr=0.01).step()
+    after = pyro.param("gain").detach().clone()
+    assert not torch.equal(before, after)
     names = sorted(store.keys())
-    assert len(names) == 5
-    with tempfile.TemporaryDirectory() as d:
-        f = os.path.join(d, "paramstore.unittest.out")
-        store.save(f)
-        pyro.clear_param_store()
-        assert len(list(store.keys())) == 0
-        store.load(f)
+    assert names == ["gain", "net$$$bias", "net$$$weight", "other$$$bias", "other$$$weight"]
 
-    def modules_are_equal():
-        return bool((lin3.weight == lin1.weight).all() and (lin3.bias == lin1.bias).all())
+    path = str(tmp_path / "store.pt")
+    store.save(path)
+    store.clear()
+    assert len(store) == 0
+    store.load(path)
+    assert sorted(store.keys()) == names and torch.equal(pyro.param("gain").detach(), after)
 
-    assert not modules_are_equal()
-    pyro.module("mymodule", lin3, update_module_params=False)
-    assert id(lin3.weight) != id(pyro.param("mymodule$$$weight"))
-    assert not modules_are_equal()
-    pyro.module("mymodule", lin3, update_module_params=True)
-    assert id(lin3.weight) == id(pyro.param("mymodule$$$weight"))
-    assert modules_are_equal()
-    now = pyro.param("myparam").detach().numpy()
-    assert stale != now and fresh == now
-    assert sorted(store.keys()) == names
+    def adopted():
+        return torch.equal(newcomer.weight, trained.weight) and torch.equal(newcomer.bias, trained.bias)
+
+    # registering a different module object under the same name: the store wins, and only
+    # update_module_params=True puts its tensors INTO the module
+    pyro.module("net", newcomer, update_module_params=False)
+    assert newcomer.weight is not pyro.param("net$$$weight") and not adopted()
+    pyro.module("net", newcomer, update_module_params=True)
+    assert newcomer.weight is pyro.param("net$$$weight") and adopted()
 
 
-def test_dict_interface():
-    ps = pyro.get_param_store()
-    ps.clear()
-    assert not ps and len(ps) == 0 and "x" not in ps
-    assert list(ps.items()) == [] and list(ps.keys()) == [] and list(ps.values()) == []
-    ps["x"] = torch.zeros(1, 2, 3)
-    assert ps and len(ps) == 1 and "x" in ps and "y" not in ps
-    assert list(ps.keys()) == ["x"] and [k for k, v in ps.items()] == ["x"]
-    assert len(list(ps.values())) == 1 and ps["x"].shape == (1, 2, 3)
-    _eq(ps.setdefault("x", torch.ones(1, 2, 3)), torch.zeros(1, 2, 3))
-    assert ps["x"].unconstrained() is ps["x"]
-    ps.setdefault("y", torch.ones(4, 5), constraint=constraints.positive)
-    assert len(ps) == 2 and sorted(ps.keys()) == ["x", "y"]
-    assert ps["y"].shape == (4, 5)
-    _eq(ps.setdefault("y", torch.zeros(4, 5)), torch.ones(4, 5))
-    _eq(ps["y"].unconstrained(), torch.zeros(4, 5))
-    del ps["x"]
-    assert len(ps) == 1 and "x" not in ps and "y" in ps and list(ps.keys()) == ["y"]
-    _eq(ps["y"].unconstrained(), torch.zeros(4, 5))
-    del ps["y"]
-    assert not ps and len(ps) == 0 and list(ps.keys()) == []
+# ---- scopes ---------------------------------------------------------------------------------------------------
+def _declare(spec):
+    for name, (value, constraint) in spec.items():
+        pyro.param(name, value, constraint=constraint)
 
 
-def test_scope():
-    x0, z0 = torch.randn(()), torch.randn(5).exp()
-    x1, y1 = torch.randn(3), torch.randn(2, 1).exp()
-    y2, z2 = torch.randn(2, 1).exp(), torch.randn(1, 4).exp()
-    z2 /= z2.sum()
-    table = {"z0": constraints.positive, "y1": constraints.positive, "y2": constraints.positive,
-             "z2": constraints.simplex}
-    ps = pyro.get_param_store()
-    ps.clear()
+def _holds(store, spec):
+    assert set(store) == set(spec)
+    for name, (value, constraint) in spec.items():
+        _same(pyro.param(name), value)
+        assert store._constraints[name] == constraint
 
-    def check(name):
-        assert ps._constraints[name[:1]] == table.get(name, constraints.real)
 
-    def base():
-        assert set(ps) == {"x", "z"}
-        _eq(pyro.param("x"), x0); _eq(pyro.param("z"), z0)
-        check("x0"); check("z0")
-
-    assert not ps
-    pyro.param("x", x0)
-    pyro.param("z", z0, constraint=constraints.positive)
-    base()
-    with ps.scope() as scope1:
-        assert not ps
-        pyro.param("x", x1)
-        pyro.param("y", y1, constraint=constraints.positive)
-        assert set(ps) == {"x", "y"}
-        _eq(pyro.param("x"), x1); _eq(pyro.param("y"), y1)
-        check("x1"); check("y1")
-    base()
-    with ps.scope() as scope2:
-        assert not ps
-        pyro.param("y", y2, constraint=constraints.positive)
-        pyro.param("z", z2, constraint=constraints.simplex)
-        assert set(ps) == {"y", "z"}
-        _eq(pyro.param("y"), y2); _eq(pyro.param("z"), z2)
-        check("y2"); check("z2")
-    base()
-    with ps.scope(scope1) as s:
-        assert s is scope1 and set(ps) == {"x", "y"}
-        _eq(pyro.param("x"), x1); _eq(pyro.param("y"), y1)
-    base()
-    with ps.scope(scope2) as s:
-        assert s is scope2 and set(ps) == {"y", "z"}
-        _eq(pyro.param("y"), y2); _eq(pyro.param("z"), z2)
-    base()
+def test_scopes_are_separate_stores_that_can_be_reentered(store):
+    simplex_row = torch.randn(1, 4).exp()
+    simplex_row = simplex_row / simplex_row.sum()
+    outer = {"x": (torch.randn(()), constraints.real), "z": (torch.randn(5).exp(), constraints.positive)}
+    first = {"x": (torch.randn(3), constraints.real), "y": (torch.randn(2, 1).exp(), constraints.positive)}
+    second = {"y": (torch.randn(2, 1).exp(), constraints.positive), "z": (simplex_row, constraints.simplex)}
+    _declare(outer)
+    _holds(store, outer)
+    states = []
+    for spec in (first, second):
+        with store.scope() as state:
+            assert not store                       # a new scope starts empty
+            _declare(spec)
+            _holds(store, spec)
+        states.append(state)
+        _holds(store, outer)                       # and leaves the enclosing store as it was
+    for spec, state in zip((first, second), states):
+        with store.scope(state) as again:
+            assert again is state
+            _holds(store, spec)
+        _holds(store, outer)

@@ -36,82 +36,89 @@ def test_nested_sequential_plates_scale():
             assert node["scale"] == 4.0 * 2.0
 
 
-def plate_model(subsample_size):
-    loc, scale = torch.zeros(20), torch.ones(20)
+LOC, SCALE = torch.zeros(20), torch.ones(20)
+
+
+def _vectorised(subsample_size):
     with pyro.plate("plate", 20, subsample_size) as batch:
-        pyro.sample("x", Normal(loc[batch], scale[batch]))
-        return [int(i) for i in batch]
+        pyro.sample("x", Normal(LOC[batch], SCALE[batch]))
+        return batch.tolist()
 
 
-def iplate_model(subsample_size):
-    loc, scale = torch.zeros(20), torch.ones(20)
-    result = []
+def _sequential(subsample_size):
+    picked = []
     for i in pyro.plate("plate", 20, subsample_size):
-        pyro.sample("x_{}".format(i), Normal(loc[i], scale[i]))
-        result.append(int(i))
-    return result
+        pyro.sample("x_{}".format(i), Normal(LOC[i], SCALE[i]))
+        picked.append(int(i))
+    return picked
 
 
-def nested_iplate_model(subsample_size):
-    loc, scale = torch.zeros(20), torch.ones(20)
-    result = []
+def _nested_sequential(subsample_size):
     inner = pyro.plate("inner", 20, 5)
+    picked = []
     for i in pyro.plate("outer", 20, subsample_size):
-        result.append([])
+        row = []
         for j in inner:
-            pyro.sample("x_{}_{}".format(i, j), Normal(loc[i] + loc[j], scale[i] + scale[j]))
-            result[-1].append(int(j))
-    return result
+            pyro.sample("x_{}_{}".format(i, j), Normal(LOC[i] + LOC[j], SCALE[i] + SCALE[j]))
+            row.append(int(j))
+        picked.append(row)
+    return picked
 
 
-MODELS = [plate_model, iplate_model, nested_iplate_model]
-
-
-@pytest.mark.parametrize("subsample_size", [5, 20])
-@pytest.mark.parametrize("model", MODELS)
-def test_cond_indep_stack(model, subsample_size):
-    tr = poutine.trace(model).get_trace(subsample_size)
-    for name, node in tr.nodes.items():
-        if name.startswith("x"):
-            assert node["cond_indep_stack"], name
+PROGRAMS = {"vectorised": _vectorised, "sequential": _sequential, "nested": _nested_sequential}
+plate_model, iplate_model = _vectorised, _sequential
 
 
 @pytest.mark.parametrize("subsample_size", [5, 20])
-@pytest.mark.parametrize("model", MODELS)
-def test_replay_reuses_the_subsample(model, subsample_size):
+@pytest.mark.parametrize("kind", sorted(PROGRAMS))
+def test_every_site_in_a_plate_knows_its_frames(kind, subsample_size):
+    trace = poutine.trace(PROGRAMS[kind]).get_trace(subsample_size)
+    inside = [node for name, node in trace.nodes.items() if name.startswith("x")]
+    assert inside and all(node["cond_indep_stack"] for node in inside)
+
+
+@pytest.mark.parametrize("subsample_size", [5, 20])
+@pytest.mark.parametrize("kind", sorted(PROGRAMS))
+def test_replay_reuses_the_subsample(kind, subsample_size):
+    program = PROGRAMS[kind]
     pyro.set_rng_seed(0)
-    traced = poutine.trace(model)
-    original = traced(subsample_size)
-    assert poutine.replay(model, trace=traced.trace)(subsample_size) == original
-    if subsample_size < 20:
-        assert traced(subsample_size) != original
+    traced = poutine.trace(program)
+    first = traced(subsample_size)
+    assert poutine.replay(program, trace=traced.trace)(subsample_size) == first
+    if subsample_size < 20:                       # a real subsample: a fresh run draws another one
+        assert traced(subsample_size) != first
 
 
 @pytest.mark.parametrize("sequential", [False, True])
-def test_custom_subsample(sequential):
-    def model(subsample):
+def test_a_given_subsample_is_used_as_is(sequential):
+    wanted = [1, 3, 5, 7]
+
+    def program(subsample):
         if sequential:
             return [int(i) for i in pyro.plate("plate", 20, subsample=subsample)]
         with pyro.plate("plate", 20, subsample=subsample) as batch:
             return [int(i) for i in batch]
 
-    subsample = [1, 3, 5, 7]
-    assert model(subsample) == subsample
-    assert poutine.trace(model)(subsample) == subsample
+    assert program(wanted) == wanted == poutine.trace(program)(wanted)
 
 
-@pytest.mark.parametrize("model", [plate_model, iplate_model])
-@pytest.mark.parametrize("behavior,model_size,guide_size", [
-    ("error", 20, 5), ("error", 5, 20), ("error", 5, None), ("ok", 20, 20), ("ok", 20, None),
-    ("ok", 5, 5), ("ok", None, 20), ("ok", None, 5), ("ok", None, None)])
-def test_model_guide_subsample_size_mismatch(behavior, model_size, guide_size, model):
-    traced = poutine.trace(model)
-    expected = traced(guide_size)
-    if behavior == "ok":
-        assert poutine.replay(model, trace=traced.trace)(model_size) == expected
-    else:
+# sizes the guide ran with -> sizes the model may run with when replayed against it
+_COMPATIBLE = [(20, 20), (None, 20), (5, 5), (20, None), (5, None), (None, None)]
+_CLASHING = [(5, 20), (20, 5), (None, 5)]
+
+
+@pytest.mark.parametrize("kind", ["vectorised", "sequential"])
+@pytest.mark.parametrize("guide_size,model_size", _COMPATIBLE + _CLASHING)
+def test_model_guide_subsample_size_mismatch(kind, guide_size, model_size):
+    program = PROGRAMS[kind]
+    traced = poutine.trace(program)
+    drawn = traced(guide_size)
+    replayed = poutine.replay(program, trace=traced.trace)
+    if (guide_size, model_size) in _CLASHING:
         with pytest.raises(ValueError):
-            poutine.replay(model, trace=traced.trace)(model_size)
+            replayed(model_size)
+    else:
+        assert replayed(model_size) == drawn
 
 
 # ---- runtime queries --------------------------------------------------------------------------------------
