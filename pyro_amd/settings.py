@@ -1,72 +1,87 @@
-"""Global settings registry (the interface of pyro/settings.py: get / set / context / register).
+"""Global settings (the interface of pyro.settings: ``get`` / ``set`` / ``context`` / ``register``).
 
-A setting is an alias for a module-level constant or class attribute that lives where it is used;
-the registry only knows where to find it.  ``with settings.context(alias=value): ...`` (also a
-decorator) overrides temporarily.
+A setting is an ALIAS for a module-level constant or a class attribute that lives where it is used; this module
+only keeps the address book.  ``with settings.context(alias=value): ...`` -- also usable as a decorator --
+overrides temporarily; ``register`` doubles as a decorator for the function that validates new values.
 """
-import functools
-from contextlib import contextmanager
-from importlib import import_module
-
-_REGISTRY = {}      # alias -> (module name, dotted attribute path, validator or None)
+import contextlib
+import importlib
+import operator
 
 
-def _owner_and_attr(alias):
-    modulename, deepname, _ = _REGISTRY[alias]
-    owner = import_module(modulename)
-    *path, attr = deepname.split(".")
-    for name in path:
-        owner = getattr(owner, name)
-    return owner, attr
+class _Address:
+    """Where a setting lives: ``module`` + dotted attribute path, and who checks new values."""
+
+    __slots__ = ("module", "path", "validator")
+
+    def __init__(self, module, path, validator):
+        self.module, self.path, self.validator = module, path.split("."), validator
+
+    def _owner(self):
+        holder = importlib.import_module(self.module)
+        return operator.attrgetter(".".join(self.path[:-1]))(holder) if len(self.path) > 1 else holder
+
+    def read(self):
+        return getattr(self._owner(), self.path[-1])
+
+    def write(self, value):
+        if self.validator is not None:
+            self.validator(value)
+        setattr(self._owner(), self.path[-1], value)
+
+
+_BOOK = {}          # alias -> _Address
 
 
 def get(alias=None):
-    """One setting, or all of them as a dict when ``alias`` is omitted."""
-    if alias is None:
-        return {a: get(a) for a in sorted(_REGISTRY)}
-    owner, attr = _owner_and_attr(alias)
-    return getattr(owner, attr)
+    """One setting, or a dict of all of them (sorted by alias) when called without one."""
+    if alias is not None:
+        return _BOOK[alias].read()
+    return {name: _BOOK[name].read() for name in sorted(_BOOK)}
 
 
-def set(**kwargs):
-    """``settings.set(alias=value, ...)``; each value goes through the setting's validator first."""
-    for alias, value in kwargs.items():
-        validator = _REGISTRY[alias][2]
-        if validator is not None:
-            validator(value)
-        owner, attr = _owner_and_attr(alias)
-        setattr(owner, attr, value)
+def set(**values):
+    """``settings.set(alias=value, ...)``; unknown aliases are a KeyError, rejected values whatever the
+    setting's validator raises."""
+    for alias, value in values.items():
+        _BOOK[alias].write(value)
 
 
-@contextmanager
-def context(**kwargs):
-    saved = {alias: get(alias) for alias in kwargs}
+@contextlib.contextmanager
+def context(**values):
+    before = {alias: get(alias) for alias in values}
+    set(**values)
     try:
-        set(**kwargs)
         yield
     finally:
-        set(**saved)
+        set(**before)
 
 
 def register(alias, modulename, deepname, validator=None):
-    """Declare a setting: ``register("my_setting", __name__, "MY_CONSTANT")``, or as a decorator on
-    the function that validates new values."""
-    _REGISTRY[alias] = (modulename, deepname, validator)
-    if validator is not None:
-        return validator
-    return functools.partial(register, alias, modulename, deepname)
+    """``register("my_setting", __name__, "MY_CONSTANT")`` declares a setting; the returned callable accepts
+    the validator, so that the same line works as a decorator::
+
+        @register("my_setting", __name__, "MY_CONSTANT")
+        def _check(value):
+            assert value > 0
+    """
+    entry = _BOOK[alias] = _Address(modulename, deepname, validator)
+
+    def with_validator(fn):
+        entry.validator = fn
+        return fn
+
+    return validator if validator is not None else with_validator
 
 
-def _is_bool(value):
-    assert isinstance(value, bool)
+def _must_be_bool(value):
+    assert isinstance(value, bool), value
 
 
-register("validate_distributions_pyro", "pyro_amd.distributions.util", "_VALIDATION_ENABLED", _is_bool)
-register("validate_poutine", "pyro_amd.poutine.settings", "_VALIDATE", _is_bool)
-register("validate_infer", "pyro_amd.infer.util", "_VALIDATION_ENABLED", _is_bool)
-
-
-@register("validate_distributions_torch", "torch.distributions.distribution",
-          "Distribution._validate_args")
-def _validate_torch_flag(value):
-    assert isinstance(value, bool)
+for _alias, _module, _name in (
+        ("validate_distributions_pyro", "pyro_amd.distributions.util", "_VALIDATION_ENABLED"),
+        ("validate_distributions_torch", "torch.distributions.distribution", "Distribution._validate_args"),
+        ("validate_poutine", "pyro_amd.poutine.settings", "_VALIDATE"),
+        ("validate_infer", "pyro_amd.infer.util", "_VALIDATION_ENABLED")):
+    register(_alias, _module, _name, _must_be_bool)
+del _alias, _module, _name
