@@ -5,14 +5,14 @@ HIP kernels are answered by the numpy/torch oracle backend (no GPU here), and py
 files where they lie under /root/reference -- nothing is copied, nothing is written there:
 
     cd /tmp/refsuite && PYTHONDONTWRITEBYTECODE=1 \
-      PYTHONPATH=/root/repo/tools/refsuite:/root/repo:/root/reference \
+      PYTHONPATH=/root/repo/tests/refsuite:/root/repo:/root/reference \
       python -m pytest -p pyro_alias_plugin -p no:cacheprovider --rootdir=/tmp/refsuite -q \
       /root/reference/tests/infer/test_valid_models.py
 
 A module of the reference that this package does not have makes the importing test file fail at
 collection, which is the information wanted.  What it found and what was restated as committed tests is
-recorded in tools/refsuite/RESULTS.md.  This is development tooling: nothing in the product, in tests/,
-in bench.py or in smoke() imports it, and it cannot run on the GPU box (no /root/reference there).
+recorded in tests/refsuite/RESULTS.md.  This is test infrastructure kept next to the tests (it uses tests/oracle_backend.py): nothing in the
+product, in the collected test files, in bench.py or in smoke() imports it, and it cannot run on the GPU box (no /root/reference there).
 """
 import importlib
 import importlib.util

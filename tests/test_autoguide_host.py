@@ -1,5 +1,5 @@
 """Autoguide behaviour found by running tests/infer/test_autoguide.py of the reference against this package
-(tools/refsuite): subsampled plates (the parameters cover the FULL plate, each step touches the rows of
+(tests/refsuite): subsampled plates (the parameters cover the FULL plate, each step touches the rows of
 its subsample), the error for discrete latent sites, ``guide.call``."""
 import pytest
 import torch

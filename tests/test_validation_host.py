@@ -1,7 +1,7 @@
 """Error / warning behaviour of the estimators under ``pyro.enable_validation`` -- a restatement of the
 parts of tests/infer/test_valid_models.py (and tests/test_settings.py, tests/test_util.py,
 tests/ops/test_provenance.py) where running the reference's own files against this package
-(tools/refsuite) found differences.  CPU host logic; kernels answered by the oracle backend."""
+(tests/refsuite) found differences.  CPU host logic; kernels answered by the oracle backend."""
 import warnings
 
 import pytest
