@@ -365,3 +365,111 @@ def test_do_under_a_plate_does_not_enter_the_plate_twice():
     assert "z1__CF" not in tr.nodes                       # hidden from the handlers outside
     assert torch.equal(tr.nodes["x"]["fn"].base_dist.loc, fix_z1 + tr.nodes["z2"]["value"])
     tr.compute_log_prob()
+
+
+# ---- lift, escape / queue, equalize (tests/poutine/test_poutines.py Lift / Queue / Equalize handler tests) ----------
+def test_lift_turns_params_into_sample_sites():
+    def prior_for(tensor, *args, **kwargs):
+        return Normal(torch.zeros(tensor.shape), 1.0).sample()
+
+    tr = poutine.trace(guide).get_trace()
+    params = {"loc1", "scale1", "loc2", "scale2"}
+    # a function-valued prior given directly hides the lifted sites from the handlers outside
+    lifted = poutine.trace(poutine.lift(guide, prior=prior_for)).get_trace()
+    assert all((name in lifted) == (name not in params) for name in tr.nodes)
+    # a dict names the params to lift; the others stay params
+    pyro.clear_param_store()
+    lifted = poutine.trace(poutine.lift(guide, prior={"loc1": prior_for, "scale1": Normal(1.0, 0.1)})).get_trace()
+    assert lifted.nodes["loc1"]["type"] == "sample" and not lifted.nodes["loc1"]["is_observed"]
+    assert lifted.nodes["loc1"]["fn"] is prior_for
+    assert lifted.nodes["scale1"]["type"] == "sample" and lifted.nodes["loc2"]["type"] == "param"
+
+    def twice():
+        a = pyro.param("loc")
+        b = pyro.param("loc")
+        assert a == b                      # the second statement sees the first draw
+
+    poutine.trace(poutine.lift(twice, prior=Normal(0.0, 1.0)))()
+
+
+def test_random_module_draws_a_copy_of_the_network():
+    net = torch.nn.Linear(2, 1)
+    with pytest.warns(FutureWarning):
+        lifted = pyro.random_module("net", net, prior=Normal(0.0, 1.0))
+    tr = poutine.trace(lifted).get_trace()
+    sites = [n for n, node in tr.nodes.items() if node["type"] == "sample"]
+    assert sorted(sites) == ["net$$$bias", "net$$$weight"]
+    drawn = tr.nodes["_RETURN"]["value"]
+    assert drawn is not net and torch.equal(drawn.weight, tr.nodes["net$$$weight"]["value"])
+
+
+def test_queue_visits_every_assignment_of_the_discrete_sites():
+    from queue import Queue
+
+    def hmm():
+        probs = torch.tensor([[0.8], [0.3]])
+        state = torch.ones(1)
+        path = []
+        for t in range(3):
+            state = pyro.sample("latent_{}".format(t), Bernoulli(probs[state[0].long()]))
+            pyro.sample("observe_{}".format(t), Normal(state, 1.0), obs=torch.ones(1))
+            path.append(int(state.item()))
+        return tuple(path)
+
+    todo = Queue()
+    todo.put(poutine.Trace())
+    runner = poutine.trace(poutine.queue(hmm, queue=todo))
+    seen = []
+    while not todo.empty():
+        tr = runner.get_trace()
+        assert {"_INPUT", "_RETURN", "latent_2", "observe_2"} <= set(tr.nodes)
+        seen.append(tr.nodes["_RETURN"]["value"])
+    assert len(seen) == 8 == len(set(seen))
+    with pytest.raises(poutine.NonlocalExit):
+        poutine.escape(hmm, escape_fn=lambda msg: msg["name"] == "latent_1")()
+
+
+def test_equalize_ties_sites_together():
+    def per_category(category):
+        shift = pyro.param("{}_shift".format(category), torch.randn(1))
+        std = pyro.sample("{}_std".format(category), dist.LogNormal(0.0, 1.0))
+        return pyro.sample("{}_values".format(category), Normal(shift, std))
+
+    def program():
+        return {c: per_category(c) for c in ("dog", "cat")}
+
+    tr = poutine.trace(poutine.equalize(program, ".+_std")).get_trace()
+    assert torch.equal(tr.nodes["dog_std"]["value"], tr.nodes["cat_std"]["value"])
+    assert tr.nodes["cat_std"]["is_observed"] and tr.nodes["cat_std"]["infer"] == {"_deterministic": True}
+    assert not tr.nodes["dog_std"]["is_observed"]
+    tied = poutine.equalize(poutine.equalize(program, ".+_std"), ".+_shift", "param")
+    tr = poutine.trace(tied).get_trace()
+    assert torch.equal(tr.nodes["dog_shift"]["value"], tr.nodes["cat_shift"]["value"])
+    # keep_dist=True: conditioning on equality, the later site keeps scoring under its own prior
+    def two():
+        pyro.sample("x", Normal(0.0, 1.0))
+        pyro.sample("y", Normal(5.0, 3.0))
+
+    tr = poutine.trace(poutine.equalize(two, ["x", "y"], keep_dist=True)).get_trace()
+    x = tr.nodes["x"]["value"]
+    assert torch.equal(tr.nodes["y"]["value"], x) and tr.nodes["y"]["is_observed"]
+    expected = Normal(0.0, 1.0).log_prob(x) + Normal(5.0, 3.0).log_prob(x)
+    assert abs(float(tr.log_prob_sum()) - float(expected)) < 1e-5
+
+
+def test_broadcast_is_the_identity_and_block_messengers_mutes():
+    from pyro_amd.poutine.runtime import block_messengers
+
+    @poutine.broadcast
+    def program():
+        with pyro.plate("p", 3):
+            return pyro.sample("x", Normal(0.0, 1.0))
+
+    assert program().shape == (3,)
+    with poutine.trace() as outer:
+        with poutine.scale(scale=2.0) as scaling:
+            with block_messengers(lambda m: m is scaling) as muted:
+                assert muted == [scaling]
+                pyro.sample("a", Normal(0.0, 1.0))
+            pyro.sample("b", Normal(0.0, 1.0))
+    assert outer.trace.nodes["a"]["scale"] == 1.0 and outer.trace.nodes["b"]["scale"] == 2.0
