@@ -5,7 +5,7 @@ for the reference runs after ``import pyro_amd as pyro``; the numerics are hand-
 kernels for gfx950 behind the C-ABI in include/pyro_amd.h.  GPU tensors only: there is no CPU
 fallback.
 """
-from . import distributions, infer, ops, optim, poutine, settings  # noqa: F401
+from . import distributions, infer, nn, ops, optim, poutine, settings  # noqa: F401
 from .primitives import (barrier, clear_param_store, deterministic, enable_validation, factor,  # noqa: F401
                          iarange, irange,
                          get_param_store, module, param, plate, plate_stack, random_module, sample, subsample,

@@ -82,6 +82,7 @@ for _alias, _module, _name in (
         ("validate_distributions_pyro", "pyro_amd.distributions.util", "_VALIDATION_ENABLED"),
         ("validate_distributions_torch", "torch.distributions.distribution", "Distribution._validate_args"),
         ("validate_poutine", "pyro_amd.poutine.settings", "_VALIDATE"),
-        ("validate_infer", "pyro_amd.infer.util", "_VALIDATION_ENABLED")):
+        ("validate_infer", "pyro_amd.infer.util", "_VALIDATION_ENABLED"),
+        ("module_local_params", "pyro_amd.nn.module", "_MODULE_LOCAL_PARAMS")):
     register(_alias, _module, _name, _must_be_bool)
 del _alias, _module, _name

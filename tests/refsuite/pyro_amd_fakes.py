@@ -141,16 +141,15 @@ def install_out_of_scope():
                  "StreamingStats"):
         setattr(streaming, name, _skipper(name))
     sys.modules["pyro.ops.streaming"] = streaming
-    nn = types.ModuleType("pyro.nn")
-    for name in ("PyroModule", "PyroParam", "PyroSample", "AutoRegressiveNN", "DenseNN", "pyro_method"):
-        setattr(nn, name, _skipper(name))
-    nn.__path__ = []
-    nn_module = types.ModuleType("pyro.nn.module")
-    for name in ("PyroModule", "PyroParam", "PyroSample", "pyro_method", "to_pyro_module_", "clear"):
-        setattr(nn_module, name, getattr(nn, name, _skipper(name)))
-    nn.module = nn_module
-    sys.modules["pyro.nn.module"] = nn_module
-    sys.modules["pyro.nn"] = nn
+    nn = sys.modules.get("pyro.nn")
+    if nn is None:
+        nn = types.ModuleType("pyro.nn")
+        nn.__path__ = []
+        sys.modules["pyro.nn"] = nn
+    for name in ("PyroModule", "PyroParam", "PyroSample", "AutoRegressiveNN", "DenseNN", "pyro_method",
+                 "ConditionalAutoRegressiveNN", "MaskedLinear", "PyroModuleList"):
+        if not hasattr(nn, name):
+            setattr(nn, name, _skipper(name))
     gaussian = types.ModuleType("pyro.ops.gaussian")
     gaussian.Gaussian = _skipper("Gaussian")
     sys.modules["pyro.ops.gaussian"] = gaussian
