@@ -211,6 +211,9 @@ class PyroModule(torch.nn.Module, metaclass=_PyroModuleMeta):
                 prior = prior(self)
             return prior if isinstance(prior, torch.Tensor) else prior()
         value = super().__getattr__(name)
+        if isinstance(value, PyroModule) and scope is not None and \
+                (value._pyro_scope is not scope or (not value._pyro_name and full)):
+            value._pyro_adopt(full, scope)          # converted or attached behind our back: name it now
         if in_call and not _local_params():
             if isinstance(value, torch.nn.Parameter) and not name.endswith("_unconstrained"):
                 return scope.recall(full, lambda: primitives.param(full, value))

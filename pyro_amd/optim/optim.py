@@ -47,10 +47,24 @@ class PyroOptim:
         self._state_waiting_to_be_consumed = {}
 
     def _args_for(self, param):
-        if callable(self.pt_optim_args):
-            name = _PARAM_STORE.param_name(param)
-            return self.pt_optim_args(name)
-        return self.pt_optim_args
+        """The optimizer arguments of one parameter.  A callable receives the parameter's name the way
+        ``nn.Module.named_parameters()`` spells it (``"net.linear.bias"``; a ``pyro.module`` name's ``$$$`` is a
+        dot) -- or, for the deprecated two-argument form, (module name, parameter name)."""
+        if not callable(self.pt_optim_args):
+            return self.pt_optim_args
+        from ..params import (module_from_param_with_module_name, normalize_param_name, user_param_name)
+        import inspect
+        name = _PARAM_STORE.param_name(param)
+        try:
+            two = len(inspect.signature(self.pt_optim_args).parameters) == 2
+        except (TypeError, ValueError):
+            two = False
+        if two and name is not None:
+            chosen = self.pt_optim_args(module_from_param_with_module_name(name), user_param_name(name))
+        else:
+            chosen = self.pt_optim_args(name if name is None else normalize_param_name(name))
+        assert isinstance(chosen, dict), "per-param optim arg must return defaults dictionary"
+        return chosen
 
     def _get_optim(self, param):
         return self.pt_optim_constructor([param], **self._args_for(param))

@@ -198,3 +198,34 @@ def test_lr_scheduler_wrappers_and_their_checkpoints():
     again.set_state(state)
     assert abs(run(again, 1) - (0.825 - 0.0125)) < 1e-6        # continues at the decayed rate
     assert not optim.optim.is_scheduler(torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=0.1))
+
+
+def test_per_parameter_arguments_receive_module_style_names():
+    """tests/optim/test_optim.py (dynamic lr, name_preserved_by_to_pyro_module): a callable gets
+    ``"net.bias"`` for a pyro.module parameter, or (module, parameter) in the deprecated two-argument form."""
+    import pyro_amd as pyro
+    from pyro_amd import optim
+    pyro.clear_param_store()
+    net = torch.nn.Linear(2, 1)
+    pyro.module("net", net)
+    pyro.param("free", torch.zeros(3))
+    leaves = [pyro.param(n).unconstrained() for n in sorted(pyro.get_param_store().keys())]
+    for leaf in leaves:
+        leaf.grad = torch.ones_like(leaf)
+    seen, seen2 = set(), set()
+
+    def one_arg(name):
+        seen.add(name)
+        return {"lr": 0.1 if name == "free" else 0.0}
+
+    def two_args(module_name, param_name):
+        seen2.add((module_name, param_name))
+        return {"lr": 0.0}
+
+    before = net.bias.detach().clone()
+    optim.SGD(one_arg)(leaves)
+    assert seen == {"free", "net.weight", "net.bias"}
+    assert torch.equal(net.bias.detach(), before)                      # lr 0 for the module's parameters
+    assert torch.allclose(pyro.param("free"), torch.full((3,), -0.1))
+    optim.SGD(two_args)(leaves)
+    assert seen2 == {("free", "free"), ("net", "weight"), ("net", "bias")}
