@@ -615,6 +615,40 @@ int pa_adam_step_publish(int dtype, void* param, void* grad, void* exp_avg, void
                          double* host_value, uint64_t* host_seq, uint64_t* counter, uint64_t inc,
                          pa_stream_t stream);
 
+/* ---- the chained tail of an SVI step ------------------------------------------------------------
+ * Replaces the dependent small launches that end the reference's step -- per-site sums and their
+ * autograd duals (pyro/infer/trace_elbo.py:130-159), AccumulateGrad + per-parameter optimizer steps
+ * (pyro/optim/optim.py:117-155), zero_grads (pyro/infer/util.py:85-91) -- which even as four
+ * launches of this library cost ~5 us of graph-node dispatch each.
+ *
+ * Between pa_chain_begin(stream, sync, bytes) and pa_chain_end() on the calling thread, these entry
+ * points called with `stream` and float32 data RECORD their work instead of launching it:
+ *     the finalize step of pa_glm_bernoulli_fwd_bwd / pa_glm_bernoulli_planes_fwd_bwd,
+ *     pa_multi_log_prob_sum_grad, pa_meanfield_normal_sample_bwd (<= 8 sites),
+ *     pa_adam_step / pa_adam_step_publish,
+ * in that order, at most one of each.  The recorded phases run as ONE kernel (device-wide barriers
+ * between phases, bit-identical results) when pa_chain_end / pa_chain_flush is called, when a
+ * recordable call does not continue the order, or when ANY other entry point of this library is
+ * about to launch (it may read what the phases write).  The caller guarantees that nothing outside
+ * this library touches the phases' inputs or outputs on the device between the recording and the
+ * flush (pyro_amd/kernels.py: a TorchDispatchMode flushes before every kernel-launching torch
+ * operator), and keeps every recorded buffer alive until then.
+ * sync: PA_CHAIN_SYNC_BYTES of zero-initialised device memory that stays allocated as long as a
+ * captured graph holding a chain launch may be replayed; launches leave it zero. */
+#define PA_CHAIN_SYNC_BYTES 64
+int pa_chain_begin(pa_stream_t stream, void* sync_words, size_t sync_bytes);
+/* launch what is pending; recording continues */
+int pa_chain_flush(void);
+/* launch what is pending and stop recording; optional out-params: chain launches made since
+ * pa_chain_begin and the number of phases they carried */
+int pa_chain_end(int* launches, int* phases);
+/* phases recorded and not yet launched */
+int pa_chain_pending(void);
+/* developer hook: 32 x uint64 of device memory that later chain launches fill with wall-clock
+ * (100 MHz) stamps at their phase boundaries (workgroup 0: [0..7], the total's workgroup:
+ * [16..23]); NULL switches it off */
+int pa_chain_debug_stamps(void* stamps32);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,7 @@ NEED_VALUE, NEED_P0, NEED_P1, VALUE_BY_CHAIN = 1, 2, 4, 16
 MULTI_MAX_ENTRIES = 16
 MULTI_MAX_ELEMS = 65536
 MF_MAX_SITES = 16
+CHAIN_SYNC_BYTES = 64
 
 
 class SiteEntry(Structure):
@@ -196,6 +197,11 @@ _SIGNATURES = {
                                     c_void_p]),
     "pa_chain_matvec": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                 c_void_p]),
+    "pa_chain_begin": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "pa_chain_flush": (c_int, []),
+    "pa_chain_end": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "pa_chain_pending": (c_int, []),
+    "pa_chain_debug_stamps": (c_int, [c_void_p]),
     "pa_adam_step_publish": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_double, c_double, c_double, c_double, c_double, c_double,
                                      c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,

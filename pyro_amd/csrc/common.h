@@ -186,6 +186,8 @@ inline ViewT<T> as_view(const pa_view2d& v) {
   return ViewT<T>{(const T*)v.ptr, v.stride_row, v.stride_col};
 }
 
-inline hipStream_t as_stream(pa_stream_t s) { return (hipStream_t)s; }
+// The stream a launcher is about to launch on.  Defined in chain.hip: phases recorded for the chained
+// tail of an SVI step (chain.h) are launched first -- whatever follows may read what they write.
+hipStream_t as_stream(pa_stream_t s);
 
 }  // namespace pa

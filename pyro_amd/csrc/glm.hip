@@ -23,6 +23,8 @@
 #include "common.h"
 #include "glm_bf16.h"
 #include "glm_planes.h"
+#include "glm_finalize.h"
+#include "chain.h"
 
 namespace pa {
 
@@ -43,9 +45,6 @@ struct GlmCfg {
   static constexpr int TILE_F = 32 * S;   // floats per wave tile
 };
 
-// floats in one block's partial record: raw MFMA accumulator tiles + ll + gb
-template <int DT, int PT>
-constexpr int glm_record_floats() { return PT * DT * 1024 + 2 * PT * 32; }
 
 // GROUPED: the hierarchical variant (BASELINE config 5): rows are sorted by group, logits use the
 // group's own weights w[p, g, :]; blockIdx.x is a SEGMENT {row_begin, row_end, group} of one
@@ -298,62 +297,6 @@ __global__ __launch_bounds__(64 * GLM_WAVES, 2) void glm_bernoulli_kernel(
   }
 }
 
-// out[j] = scale * sum_blocks partial[block][slot(j)], fp64 accumulation, fixed order.
-// Output order: gw[P,D] then ll[P] then gb[P].  One workgroup = FIN_OUT outputs x FIN_GROUPS
-// record groups (thread (j, s) sums records s, s + FIN_GROUPS, ...; the groups are then combined
-// through LDS in a fixed order): many small workgroups so that the ~4 MB of partial records are
-// pulled by the whole chip rather than by a few dozen CUs.
-constexpr int FIN_OUT = 8, FIN_GROUPS = 32;
-template <int DT, int PT>
-__global__ __launch_bounds__(FIN_OUT * FIN_GROUPS) void glm_finalize_kernel(
-    const float* __restrict__ part, int nblocks, int npass, int D, int P, double scale,
-    float* __restrict__ ll, float* __restrict__ gw, float* __restrict__ gb, double ll_offset) {
-  constexpr int REC = glm_record_floats<DT, PT>();
-  __shared__ double sm[FIN_GROUPS][FIN_OUT];
-  const int jj = threadIdx.x % FIN_OUT, s = threadIdx.x / FIN_OUT;
-  const int64_t J = (int64_t)P * D + 2 * P;
-  const int64_t j = (int64_t)blockIdx.x * FIN_OUT + jj;
-  double acc = 0.0;
-  if (j < J) {
-    int p, slot;
-    if (j < (int64_t)P * D) {
-      p = (int)(j / D);
-      const int d = (int)(j % D);
-      const int pl = p % (32 * PT), pt = pl >> 5, i = pl & 31, dt = d >> 5, c = d & 31;
-      const int hh = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
-      slot = ((pt * DT + dt) * 16 + reg) * 64 + c + 32 * hh;
-    } else {
-      const int64_t k = j - (int64_t)P * D;
-      const int which = k >= P ? 1 : 0;
-      p = (int)(k - (int64_t)which * P);
-      const int pl = p % (32 * PT), pt = pl >> 5, i = pl & 31;
-      slot = PT * DT * 1024 + (2 * pt + which) * 32 + i;
-    }
-    const int pass = p / (32 * PT);
-    const float* base = part + (int64_t)pass * nblocks * REC + slot;
-    float v[8];
-    int blk = s;
-    for (; blk + 7 * FIN_GROUPS < nblocks; blk += 8 * FIN_GROUPS) {   // 8 loads in flight
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(blk + u * FIN_GROUPS) * REC];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; blk < nblocks; blk += FIN_GROUPS) acc += (double)base[(int64_t)blk * REC];
-  }
-  sm[s][jj] = acc;
-  __syncthreads();
-  if (s == 0 && j < J) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < FIN_GROUPS; ++k) t += sm[k][jj];
-    const float v = (float)(t * scale);
-    if (j < (int64_t)P * D) gw[j] = v;
-    else if (j < (int64_t)P * D + P) ll[j - (int64_t)P * D] = (float)((t + ll_offset) * scale);
-    else gb[j - (int64_t)P * D - P] = v;
-  }
-}
-
 // Chain rule of the site's two gradient outputs with the upstream gradient g[P] of ll[P]:
 //   dw[p, :] = g[p] * gw[p, :],  db[p] = g[p] * gb[p]      (one launch instead of two products)
 __global__ __launch_bounds__(256) void glm_chain_kernel(const float* __restrict__ g,
@@ -440,6 +383,9 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
   int rc = check_launch("glm_bernoulli_kernel");
   if (rc != PA_OK) return rc;
   const int64_t J = (int64_t)P * D + 2 * P;
+  rc = chain_record_fin((pa_stream_t)s, DT, PT, part, pl.nblocks, pl.npass, D, P, scale, ll, gw, gb,
+                        0.0);
+  if (rc != 0) return rc < 0 ? rc : PA_OK;       // recorded as a phase of the step's chained tail
   hipLaunchKernelGGL((glm_finalize_kernel<DT, PT>), dim3((unsigned)((J + FIN_OUT - 1) / FIN_OUT)),
                      dim3(FIN_OUT * FIN_GROUPS), 0, s, part, pl.nblocks, pl.npass, D, P, scale, ll,
                      gw, gb, 0.0);
@@ -784,13 +730,16 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   int rc = pa::check_launch("glm_planes_kernel");
   if (rc != PA_OK) return rc;
   const int64_t J = (int64_t)P * D + 2 * P;
+  // every padding row of the processed super-tiles added log2(2) = 1 to the log2(1 + e) sum of
+  // every particle (glm_planes.h): ln2 per row back in
+  const double ll_offset = (double)(pl.nst * 64 - N) * 0.6931471805599453;
+  rc = pa::chain_record_fin(stream, 1, 2, part, pl.nblocks, pl.npass, (int)D, (int)P, scale, ll, gw,
+                            gb, ll_offset);
+  if (rc != 0) return rc < 0 ? rc : PA_OK;       // recorded as a phase of the step's chained tail
   hipLaunchKernelGGL((pa::glm_finalize_kernel<1, 2>),
                      dim3((unsigned)((J + pa::FIN_OUT - 1) / pa::FIN_OUT)),
                      dim3(pa::FIN_OUT * pa::FIN_GROUPS), 0, s, part, pl.nblocks, pl.npass, (int)D,
-                     (int)P, scale, ll, gw, gb,
-                     // every padding row of the processed super-tiles added log2(2) = 1 to the
-                     // log2(1 + e) sum of every particle (glm_planes.h): ln2 per row back in
-                     (double)(pl.nst * 64 - N) * 0.6931471805599453);
+                     (int)P, scale, ll, gw, gb, ll_offset);
   return pa::check_launch("glm_finalize_kernel");
 }
 

@@ -9,6 +9,7 @@ the loss.  No Python handler code and no per-kernel launch latency remain in the
 stream advances on the device, so a graph-replayed run draws exactly the numbers the eager run
 would (tests/test_svi_gpu.py checks the trajectories are identical).
 """
+import os as _os
 import warnings
 
 import torch
@@ -21,9 +22,11 @@ from .elbo import ELBO
 
 def _arg_key(x):
     if isinstance(x, torch.Tensor):
-        # the version counter is part of the key: a tensor that was updated in place gets fresh
-        # eager (validated) steps and its own capture instead of a replay that assumes the old data
-        return ("t", x.data_ptr(), tuple(x.shape), x.dtype, x.device, x._version)
+        # identity and geometry only -- NOT the version counter: a replay reads the live memory, so
+        # a tensor that is updated in place between steps (the way to feed new data to a captured
+        # step) keeps its capture; images derived from it (GLM planes, LDA index) are re-packed by
+        # the revalidate hooks before the replay
+        return ("t", x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, x.device)
     if isinstance(x, (list, tuple)):
         return tuple(_arg_key(v) for v in x)
     try:
@@ -92,6 +95,7 @@ class SVI:
         self._eager_seen = {}
         self.max_graphs = int(kwargs.pop("max_graphs", 8))
         self._warned_keys = False
+        self._const_rec = {}       # signature -> ConstantRecorder of its last eager step
 
     def evaluate_loss(self, *args, **kwargs):
         with torch.no_grad():
@@ -134,6 +138,15 @@ class SVI:
                                       "such steps run eagerly. Pass the same tensors (update them "
                                       "in place) to reach the captured step.")
                 self._eager_seen[key] = n + 1
+                if n == self.graph_warmup - 1 and _os.environ.get("PYRO_AMD_HOIST", "1") != "0":
+                    # the last eager step before the capture: note the constant tensors the model
+                    # and guide create, so that the captured step need not fill them again
+                    from .constants import ConstantRecorder
+                    rec = ConstantRecorder()
+                    with rec:
+                        out = self._eager_step(*args, **kwargs)
+                    self._const_rec[key] = rec
+                    return out
                 return self._eager_step(*args, **kwargs)
             entry = self._capture(key, args, kwargs)
             if entry is None:                      # capture failed: stay eager
@@ -154,6 +167,16 @@ class SVI:
         return entry.read_loss()
 
     def _capture(self, key, args, kwargs):
+        from .constants import HoistedConstantWritten
+        rec = self._const_rec.pop(key, None)
+        try:
+            return self._capture_once(key, args, kwargs, rec)
+        except HoistedConstantWritten:
+            # the step writes into a tensor it created with zeros()/ones()/full(): such a tensor
+            # has to be filled on every replay -- capture again with the fills inside the graph
+            return self._capture_once(key, args, kwargs, None)
+
+    def _capture_once(self, key, args, kwargs, const_rec):
         from .. import rng
         from ..primitives import validation_enabled
 
@@ -180,6 +203,21 @@ class SVI:
         if split and _os.environ.get("PYRO_AMD_GRAPH_COLLECTIVE") == "1" and \
                 not getattr(self, "_force_split", False):
             split = False
+        # the dependent small launches that end the step (GLM finalize, ELBO assembly, guide
+        # backward, Adam + loss hand-over) become phases of ONE kernel (kernels.chain_recording);
+        # PYRO_AMD_CHAIN=0 keeps them as separate graph nodes
+        import contextlib
+        chained = _os.environ.get("PYRO_AMD_CHAIN", "1") != "0"
+        if chained:
+            kernels.chain_sync_buffer(device)          # allocated and zeroed outside the capture
+        chain = lambda: kernels.chain_recording(device) if chained else contextlib.nullcontext()  # noqa: E731
+        self.chain_stats = []
+        if const_rec is not None and const_rec.calls:
+            from .constants import ConstantReplayer
+            consts = ConstantReplayer(const_rec)       # pre-filled copies, made outside the capture
+        else:
+            consts = None
+        hoist = (lambda: consts) if consts is not None else contextlib.nullcontext
         try:
             with validation_enabled(False):   # validation ran in the eager warm-up steps
                 # with a process group alive its watchdog thread polls events while we capture:
@@ -187,7 +225,7 @@ class SVI:
                 multi = getattr(self.optim, "multi_rank", False)
                 mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
                 with torch.cuda.graph(graph, **mode):
-                    with cap:
+                    with cap, chain() as rec, hoist():
                         with poutine.trace(param_only=True) as param_capture:
                             loss = self._loss_device(self.model, self.guide, *args, **kwargs)
                         params = self._params_of(param_capture)
@@ -203,6 +241,7 @@ class SVI:
                                 if not getattr(self.optim, "zeroes_grads", False):
                                     zero_grads(params)
                             cap.finish(publish=(loss,) + mailbox)
+                    self.chain_stats.append(getattr(rec, "stats", None))
                 if split:
                     # the gradient all-reduce is NOT captured: graph 1 = loss + backward, then an
                     # eager collective, then graph 2 = optimizer update + gradient zeroing
@@ -210,12 +249,16 @@ class SVI:
                     optim.reduce_gradients(params)
                     graph2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph2, pool=graph.pool(), **mode):
-                        optim.apply(params)
-                        if not getattr(optim, "zeroes_grads", False):
-                            zero_grads(params)
+                        with chain():
+                            optim.apply(params)
+                            if not getattr(optim, "zeroes_grads", False):
+                                zero_grads(params)
                     between = lambda: optim.reduce_gradients(params)  # noqa: E731
         except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
             import os
+            from .constants import HoistedConstantWritten
+            if isinstance(e, HoistedConstantWritten):
+                raise
             if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
                 raise
             warnings.warn("pyro_amd: hipGraph capture of SVI.step failed ({}: {}); continuing "
@@ -223,5 +266,8 @@ class SVI:
             self.hip_graph = False
             return None
         entry = _CapturedStep(graph, cap, loss, graph2, between, mailbox)
+        # the graph reads the hoisted constants on every replay: they live as long as the entry
+        entry.constants = consts.tensors if consts is not None else []
+        entry.constants_served = consts.served if consts is not None else 0
         self._graphs[key] = entry
         return entry

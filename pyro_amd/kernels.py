@@ -7,6 +7,7 @@ fallback (``_require_gpu`` raises).  PyTorch is used for device memory and strea
 import ctypes
 
 import torch
+import torch.utils._python_dispatch
 
 from . import _lib
 from ._lib import NULL_VIEW, Unsupported, View2D, check  # noqa: F401
@@ -38,7 +39,11 @@ def _stream():
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    if t is None:
+        return None
+    if _CHAIN["keep"] is not None:
+        _CHAIN["keep"].append(t)       # a recorded launch reads / writes it at the flush
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _view(t, rows, cols):
@@ -46,6 +51,8 @@ def _view(t, rows, cols):
     2-D strided view without materialising broadcasts."""
     if t is None:
         return NULL_VIEW
+    if _CHAIN["keep"] is not None:
+        _CHAIN["keep"].append(t)
     assert t.dim() == 2
     sr = 0 if t.shape[0] == 1 and rows != 1 else t.stride(0)
     sc = 0 if t.shape[1] == 1 and cols != 1 else t.stride(1)
@@ -54,6 +61,114 @@ def _view(t, rows, cols):
     if t.shape[1] == 1:
         sc = 0
     return View2D(t.data_ptr(), sr, sc)
+
+
+# ------------------------------------------------------------------------------------------
+# the chained tail of a captured SVI step (include/pyro_amd.h "the chained tail", csrc/chain.hip)
+# ------------------------------------------------------------------------------------------
+# While ``chain_recording`` is active the dependent small launches that end an ELBO-gradient step
+# (GLM finalize, ELBO assembly, guide backward, Adam) are recorded by the library and launched as
+# the phases of ONE kernel.  Everything the library launches itself flushes the pending phases
+# first (csrc: as_stream); what torch launches is watched by a TorchDispatchMode: any operator
+# that is not a pure view / allocation flushes before it runs, so a torch kernel can never read
+# (or overwrite) a buffer a pending phase has yet to write (or read).  Tensors whose pointers were
+# handed to the library while recording are kept alive until the flush.
+_CHAIN = {"keep": None, "sync": {}, "stats": None}
+
+_FREE_OPS = None
+
+
+def _free_ops():
+    global _FREE_OPS
+    if _FREE_OPS is None:
+        a = torch.ops.aten
+        names = ["empty.memory_format", "empty_strided.default", "empty_like.default",
+                 "new_empty.default", "new_empty_strided.default", "detach.default", "alias.default",
+                 "lift_fresh.default", "_unsafe_view.default", "_reshape_alias.default",
+                 "is_same_size.default", "sym_size.int", "sym_stride.int", "sym_numel.default",
+                 "sym_storage_offset.default", "is_pinned.default"]
+        ops = set()
+        for n in names:
+            pkt, ov = n.split(".")
+            try:
+                ops.add(getattr(getattr(a, pkt), ov))
+            except AttributeError:
+                pass
+        _FREE_OPS = ops
+    return _FREE_OPS
+
+
+def _launches_nothing(func):
+    """True for operators that only make views / metadata / uninitialised memory."""
+    if func in _free_ops():
+        return True
+    try:
+        return bool(func.is_view)
+    except AttributeError:
+        return False
+
+
+class _ChainGuard(torch.utils._python_dispatch.TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        if not _launches_nothing(func):
+            chain_flush()
+        return func(*args, **(kwargs or {}))
+
+
+def chain_sync_buffer(device):
+    """The zeroed device words the chain kernel's phase barriers count in (allocate BEFORE a graph
+    capture; persistent: captured chain launches keep using it)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _CHAIN["sync"].get(key)
+    if buf is None:
+        buf = torch.zeros((_lib.CHAIN_SYNC_BYTES // 4,), dtype=torch.int32, device=device)
+        _CHAIN["sync"][key] = buf
+    return buf
+
+
+def chain_debug_stamps(buf):
+    """Developer hook: ``buf`` = int64[32] device tensor that later chain launches fill with
+    wall-clock stamps at their phase boundaries (None: off).  pa_chain_debug_stamps."""
+    check(_lib.load().pa_chain_debug_stamps(None if buf is None else ctypes.c_void_p(buf.data_ptr())))
+    _CHAIN["stamps"] = buf
+
+
+def chain_flush():
+    """Launch the recorded phases now (no-op when nothing is pending)."""
+    if _CHAIN["keep"] is not None:
+        check(_lib.load().pa_chain_flush())
+
+
+class chain_recording:
+    """Context manager: record the chainable launches made inside on torch's current stream and run
+    them as phases of one kernel (see above).  ``stats`` after exit: (chain launches, phases)."""
+
+    def __init__(self, device):
+        self.sync = chain_sync_buffer(device)
+        self.stats = (0, 0)
+        self._guard = None
+
+    def __enter__(self):
+        assert _CHAIN["keep"] is None, "nested chain recordings"
+        check(_lib.load().pa_chain_begin(_stream(), ctypes.c_void_p(self.sync.data_ptr()),
+                                         self.sync.numel() * 4))
+        _CHAIN["keep"] = []
+        self._guard = _ChainGuard()
+        self._guard.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            self._guard.__exit__(*exc)
+        finally:
+            a, b = ctypes.c_int(0), ctypes.c_int(0)
+            rc = _lib.load().pa_chain_end(ctypes.byref(a), ctypes.byref(b))
+            _CHAIN["keep"] = None
+            self.stats = (a.value, b.value)
+        if exc[0] is None:
+            check(rc)
+        return False
 
 
 # ------------------------------------------------------------------------------------------

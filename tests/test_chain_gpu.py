@@ -1,0 +1,173 @@
+"""The chained tail of an SVI step (csrc/chain.hip) and the hoisted constants of a captured step
+(infer/constants.py) on the MI355X.
+
+The chain runs the SAME device code with the same thread geometry as the four stand-alone launches
+it replaces, so every comparison here is BITWISE: loss values and parameters of chained steps
+against unchained steps from the same seed."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _clean():
+    import pyro_amd
+    pyro_amd.clear_param_store()
+    yield
+    pyro_amd.clear_param_store()
+    pyro_amd.enable_validation(True)
+
+
+def _setup(gpu, N=20000, D=32, P=64, seed=11):
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(N, D, gpu, seed=3)
+    pyro.clear_param_store()
+    pyro.set_rng_seed(seed)
+    pyro.enable_validation(False)
+    guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+    svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+              Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1))
+    return pyro, svi, X, y
+
+
+def _params(pyro):
+    return {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
+
+
+def _chained_eager_step(svi, X, y):
+    """One eager step whose tail is recorded and launched as a chain."""
+    from pyro_amd import kernels, poutine
+    with kernels.chain_recording(X.device) as rec:
+        with poutine.trace(param_only=True) as pc:
+            loss = svi._loss_device(svi.model, svi.guide, X, y)
+        params = svi._params_of(pc)
+        svi.optim(params)
+    return float(loss), rec.stats
+
+
+@pytest.mark.parametrize("P", [64, 16])
+def test_chained_tail_is_bitwise_the_separate_launches(gpu, P):
+    """P = 64: plane-image GLM kernel (after the second sighting) ; P = 16: the bf16x3 kernel."""
+    runs = []
+    for chained in (False, True):
+        pyro, svi, X, y = _setup(gpu, P=P)
+        losses, stats = [], None
+        for i in range(6):
+            if chained and i >= 2:        # (the first steps create parameters / optimizer state)
+                loss, stats = _chained_eager_step(svi, X, y)
+            else:
+                loss = svi.step(X, y)
+            losses.append(loss)
+        runs.append((losses, _params(pyro), stats))
+    assert runs[1][2] == (1, 4), runs[1][2]           # ONE launch carrying all four phases
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+def test_captured_step_is_three_nodes_of_ours(gpu):
+    """SVI(hip_graph=True) on the config-2 model text: the capture holds the guide draw, the GLM
+    kernel and ONE chain launch; the two ``X.new_zeros`` of the model are served from hoisted
+    constants; the trajectory is bitwise the eager one."""
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    out = []
+    for graph in (False, True):
+        # fresh tensors per run: the plane image of a design matrix is cached per tensor object and
+        # decides which GLM kernel the FIRST steps run
+        X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=3)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(5)
+        pyro.enable_validation(False)
+        guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+        svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+                  Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1),
+                  hip_graph=graph, graph_warmup=3)
+        losses = [svi.step(X, y) for _ in range(10)]
+        if graph:
+            assert svi.hip_graph and len(svi._graphs) == 1
+            assert svi.chain_stats == [(1, 4)], svi.chain_stats
+            entry = next(iter(svi._graphs.values()))
+            assert entry.constants_served == 2, entry.constants_served
+        out.append((losses, _params(pyro)))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
+def test_torch_operator_between_phases_flushes_the_chain(gpu):
+    """A torch kernel that reads what a pending phase writes must see it written: the dispatch
+    guard launches the pending phases first."""
+    from pyro_amd import kernels
+
+    g = torch.Generator(device=gpu).manual_seed(0)
+    N, D, P = 4096, 32, 8
+    X = torch.randn((N, D), device=gpu, generator=g)
+    y = (torch.rand((N,), device=gpu, generator=g) < 0.5).float()
+    w = torch.randn((P, D), device=gpu, generator=g) * 0.1
+    b = torch.randn((P,), device=gpu, generator=g) * 0.1
+    ll0, gw0, gb0 = kernels.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    with kernels.chain_recording(gpu) as rec:
+        ll, gw, gb = kernels.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)   # finalize is pending
+        from pyro_amd import _lib
+        assert _lib.load().pa_chain_pending() == 1
+        twice = ll * 2.0                                                    # a torch kernel reads ll
+        assert _lib.load().pa_chain_pending() == 0
+    assert rec.stats == (1, 1)
+    assert torch.equal(ll, ll0) and torch.equal(gw, gw0) and torch.equal(gb, gb0)
+    assert torch.equal(twice, ll0 * 2.0)
+
+
+def test_a_step_that_writes_into_a_fresh_constant_is_captured_with_its_fills(gpu):
+    """``z = X.new_zeros(D); z += 1`` must be re-filled on every replay: the capture with hoisted
+    constants is refused and redone with the fill nodes inside the graph."""
+    import pyro_amd as pyro
+    from pyro_amd import distributions as dist
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X = torch.randn((512, 4), device=gpu)
+    yv = (torch.rand((512,), device=gpu) < 0.5).float()
+
+    def model(X, y):
+        loc = X.new_zeros(4)
+        loc += 0.5                                    # in place on the fresh tensor
+        w = pyro.sample("w", dist.Normal(loc, 1.0).to_event(1))
+        with pyro.plate("data", X.shape[0]):
+            pyro.sample("obs", dist.Bernoulli(logits=(X * w.unsqueeze(-2)).sum(-1)), obs=y)
+
+    out = []
+    for graph in (False, True):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(2)
+        pyro.enable_validation(False)
+        svi = SVI(model, AutoNormal(model), pyro.optim.Adam({"lr": 0.05}),
+                  Trace_ELBO(num_particles=8, vectorize_particles=True, max_plate_nesting=1),
+                  hip_graph=graph, graph_warmup=2)
+        losses = [svi.step(X, yv) for _ in range(8)]
+        if graph:
+            assert svi.hip_graph and len(svi._graphs) == 1
+            assert next(iter(svi._graphs.values())).constants_served == 0
+        out.append(losses)
+    assert out[0] == out[1]
+
+
+def test_chain_can_be_switched_off(gpu, monkeypatch):
+    monkeypatch.setenv("PYRO_AMD_CHAIN", "0")
+    monkeypatch.setenv("PYRO_AMD_HOIST", "0")
+    import pyro_amd as pyro
+    pyro, svi, X, y = _setup(gpu)
+    svi.hip_graph, svi.graph_warmup = True, 2
+    losses = [svi.step(X, y) for _ in range(5)]
+    assert svi.hip_graph and svi.chain_stats == [None]
+    assert all(l == l for l in losses)
