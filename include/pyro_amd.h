@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 1
+#define PA_ABI_VERSION 2
 
 enum { PA_OK = 0, PA_ERR_INVALID = -1, PA_ERR_UNSUPPORTED = -2, PA_ERR_LAUNCH = -3 };
 
@@ -105,10 +105,13 @@ int pa_philox_uniform(void* out, int64_t n, int dtype, uint64_t seed, uint64_t o
  * under hipGraph replay). */
 int pa_counter_add(uint64_t* counter, uint64_t inc, pa_stream_t stream);
 /* End-of-step node of a captured SVI step (pyro/infer/svi.py:134-162 returns the loss as a Python
- * float, i.e. synchronises every step): *counter += inc (counter may be NULL), then the scalar at
- * `src` (device, `dtype`) is stored as a double to `host_value` and `*host_seq` is incremented
- * behind a system-scope release fence.  host_value / host_seq are PINNED host memory (device
- * mapped): the host polls host_seq instead of calling a stream synchronisation or a D2H copy. */
+ * float, i.e. synchronises every step): counter[0] += inc, then the scalar at `src` (device,
+ * `dtype`) is stored as a double to `host_value` and a NEW sequence number to `*host_seq` behind a
+ * system-scope release fence.  host_value / host_seq are PINNED host memory (device mapped): the
+ * host polls host_seq for a change instead of calling a stream synchronisation or a D2H copy.
+ * counter: device uint64[2] = {Philox block counter, publish sequence}; the sequence number
+ * written is ++counter[1].  counter may be NULL: the sequence number is then *host_seq + 1, read
+ * back over the bus (ABI 1 behaviour; a PCIe round trip at the end of every step). */
 int pa_publish_scalar(int dtype, const void* src, double* host_value, uint64_t* host_seq,
                       uint64_t* counter, uint64_t inc, pa_stream_t stream);
 
@@ -644,6 +647,13 @@ int pa_chain_flush(void);
 int pa_chain_end(int* launches, int* phases);
 /* phases recorded and not yet launched */
 int pa_chain_pending(void);
+/* fuse_tail = 1 (default): when every gradient of the recorded ELBO assembly feeds the backward
+ * of exactly one mean-field site and the sites' parameters tile the optimizer's flat buffer, the
+ * assembly / guide-backward / Adam phases run per site inside one workgroup each (no device-wide
+ * barrier between them); 0: always the generic phase-by-phase form.  Same results either way. */
+int pa_chain_tune(int fuse_tail);
+/* chain launches since pa_chain_begin that took the fused form */
+int pa_chain_fused_launches(void);
 /* developer hook: 32 x uint64 of device memory that later chain launches fill with wall-clock
  * (100 MHz) stamps at their phase boundaries (workgroup 0: [0..7], the total's workgroup:
  * [16..23]); NULL switches it off */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpyro_amd.so")
 
 PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_LAUNCH = 0, -1, -2, -3
 PA_F32, PA_F64 = 0, 1
+ABI_VERSION = 2      # PA_ABI_VERSION of include/pyro_amd.h
 
 DIST_NORMAL = 0
 DIST_BERNOULLI_LOGITS = 1
@@ -202,6 +203,8 @@ _SIGNATURES = {
     "pa_chain_end": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "pa_chain_pending": (c_int, []),
     "pa_chain_debug_stamps": (c_int, [c_void_p]),
+    "pa_chain_tune": (c_int, [c_int]),
+    "pa_chain_fused_launches": (c_int, []),
     "pa_adam_step_publish": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_double, c_double, c_double, c_double, c_double, c_double,
                                      c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
@@ -233,7 +236,7 @@ def load(path=None):
         fn = getattr(lib, name)  # AttributeError -> missing symbol, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.pa_abi_version() != 1:
+    if lib.pa_abi_version() != ABI_VERSION:
         raise RuntimeError("pyro_amd: ABI version mismatch: %d" % lib.pa_abi_version())
     _lib = lib
     return lib

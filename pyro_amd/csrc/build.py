@@ -23,6 +23,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # not overlap the MFMAs on gfx950 and cost 2-4x a plain instruction next to them
 # (tools/probes/issue_probe.hip), so that file is built without SLP vectorisation.
 FILE_FLAGS = {"glm.hip": ["-fno-slp-vectorize"]}
+if os.environ.get("PA_CHAIN_LATENCY_PROBE"):          # developer probe (tools/chain_stamps.py)
+    FILE_FLAGS["chain.hip"] = ["-DPA_CHAIN_LATENCY_PROBE"]
 
 
 def sources():
@@ -48,6 +50,20 @@ def _compile(src, force, hdr_mtime):
     return obj, True
 
 
+def build_variant(suffix, extra_flags, verbose=False):
+    """A second library next to the shipped one, built with extra compiler flags (developer A/B
+    runs: ``PYRO_AMD_LIB=pyro_amd/lib/libpyro_amd_<suffix>.so python bench.py``)."""
+    global OBJ_DIR, LIB_PATH, FLAGS
+    keep = (OBJ_DIR, LIB_PATH, FLAGS)
+    OBJ_DIR = os.path.join(HERE, "build_" + suffix)
+    LIB_PATH = os.path.join(LIB_DIR, "libpyro_amd_%s.so" % suffix)
+    FLAGS = FLAGS + list(extra_flags)
+    try:
+        return build_library(force=False, verbose=verbose)
+    finally:
+        OBJ_DIR, LIB_PATH, FLAGS = keep
+
+
 def build_library(force=False, verbose=False):
     if not os.path.exists(HIPCC):
         if os.path.exists(LIB_PATH):
@@ -71,4 +87,8 @@ def build_library(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:          # --variant <suffix> <flag> [<flag> ...]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True))

@@ -32,6 +32,14 @@ struct MfArgs8 {          // same prefix layout as MfArgs: the body addresses si
 };
 static_assert(offsetof(MfArgs8, s) == offsetof(MfArgs, s), "layout");
 
+constexpr int CH_TAIL_ENTRIES = 6;
+struct TailSite {
+  int n_entries;
+  int entries[CH_TAIL_ENTRIES];   // indices into the ELBO assembly's table, ascending
+  int extras_mask;                // bit q: entries[q] carries a known extra value gradient
+  int64_t off_loc, off_rho;       // element offsets of the site's loc / rho in the flat buffers
+};
+
 struct ChainArgs {
   MultiArgs multi;        // tables first; read through the kernarg segment (multisite_dev.h)
   MfArgs8 mf;
@@ -61,8 +69,12 @@ struct ChainArgs {
   int grid[CH_PHASES];    // virtual workgroups per phase
   int last;               // the last present phase (its final arrival resets the counters)
   uint64_t* stamps;       // developer hook (pa_chain_debug_stamps): 32 wall-clock stamps, or NULL
+  // --- the fused form (chain_tail_kernel): per mean-field site the entries whose gradients only
+  //     that site's backward consumes, and where the site's parameters live in the flat buffers
+  int tail_nsites;
+  TailSite tail[CH_MF_SITES];
 };
-static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+static_assert(sizeof(ChainArgs) <= 6144, "kernel arguments grew unexpectedly");
 
 // Arrival at the end of phase p (called by the workgroups that had work in it, all threads).  The
 // workgroup barrier orders every wave's stores (acknowledged by the XCD's L2) before thread 0's
@@ -193,6 +205,192 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
   PA_CHAIN_STAMP(7);
 }
 
+// ---- the fused form ------------------------------------------------------------------------------
+// When every gradient the ELBO assembly produces is consumed by the backward of ONE mean-field site,
+// and the sites' parameters tile the optimizer's flat buffer, the three phases after the finalize
+// step have no cross-workgroup dependence at all: workgroup k runs the assembly's gradient code for
+// site k's entries, the site's backward (sum over the particles) and Adam on the site's two slices
+// of the flat buffers, one after the other, separated by workgroup barriers only.  The ELBO total
+// runs beside them in its own workgroup; the last of the nsites + 1 arrivals advances the step
+// counter and hands the loss to the host.  Same device code and thread geometry per element as the
+// separate launches: bit-identical results.
+__global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
+  const bool total_wg = blockIdx.x == gridDim.x - 1;
+  if (!total_wg && threadIdx.x >= 256) return;
+  const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x;
+  uint32_t* sync = a.sync;
+  // roles: workgroups [0, nsites) = one per mean-field site (they start on their own entries at
+  // once), [nsites, nw) = the finalize phase's workers, the last one = the ELBO total
+  const int nfw = nw - a.tail_nsites;                       // finalize workers (>= 1 when needed)
+  const int part_fin = a.grid[CH_FIN] < nfw ? a.grid[CH_FIN] : nfw;
+  PA_CHAIN_STAMP(0);
+  if (a.have[CH_FIN] && !total_wg && me >= a.tail_nsites) {
+    const int fme = me - a.tail_nsites;
+    if (fme < part_fin) {
+      if (a.fin_DT == 1 && a.fin_PT == 2) chain_fin<1, 2>(a, fme, nfw);
+      else if (a.fin_DT == 1 && a.fin_PT == 1) chain_fin<1, 1>(a, fme, nfw);
+      else if (a.fin_DT == 2 && a.fin_PT == 1) chain_fin<2, 1>(a, fme, nfw);
+      else chain_fin<4, 1>(a, fme, nfw);
+      // (the counters are re-armed by the tail's last arrival, below)
+      chain_signal(sync, CH_FIN, (uint32_t)part_fin, false);
+    }
+  }
+  PA_CHAIN_STAMP(1);
+  if (!total_wg && me >= a.tail_nsites) return;
+  constexpr uint32_t KB = (uint32_t)offsetof(ChainArgs, multi);
+  constexpr uint32_t KMF = (uint32_t)offsetof(ChainArgs, mf);
+  // (the site record is read field by field through the kernarg segment: indexing a local copy of
+  //  its entry list with a run-time index would put the copy into scratch memory)
+  const uint32_t KT = (uint32_t)offsetof(ChainArgs, tail) + (uint32_t)me * (uint32_t)sizeof(TailSite);
+  auto tail_entry = [&](int q) -> int {
+    return kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, entries) + 4u * (uint32_t)q);
+  };
+  int ts_n = 0, ts_mask = 0;
+  if (!total_wg) {
+    // everything that does not depend on the finalize phase runs BEFORE the wait: the gradients of
+    // the site's own entries (prior, guide density); what the big kernel contributes (the extra
+    // term of the value gradient) is added afterwards
+    ts_n = kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, n_entries));
+    ts_mask = kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, extras_mask));
+#ifdef PA_CHAIN_LATENCY_PROBE
+    if (a.stamps != nullptr && me == 0 && threadIdx.x == 0) {
+      a.stamps[24] = (uint64_t)ts_n + wall_clock64();                       // after a kernarg table read
+      const EntryDev e0 = kernarg_load<EntryDev>(KB + (uint32_t)offsetof(MultiArgs, e) +
+                                                 (uint32_t)tail_entry(0) * (uint32_t)sizeof(EntryDev));
+      a.stamps[25] = (uint64_t)(e0.rows > 1 << 30) + wall_clock64();        // ... two dependent ones
+      const float z0 = ((const float*)e0.v)[0];
+      a.stamps[26] = (uint64_t)(z0 == 12345.f) + wall_clock64();            // ... and a data read
+      const int64_t st0 = a.ad_step[0];
+      a.stamps[27] = (uint64_t)(st0 < 0) + wall_clock64();                  // another data read
+    }
+#endif
+#ifdef PA_CHAIN_LATENCY_PROBE
+    for (int rep = 0; rep < 2; ++rep)      // second round: the same code with warm caches (idempotent)
+#endif
+    for (int q = 0; q < ts_n; ++q) {
+      multi_grad_body<float>(KB, tail_entry(q), a.multi_g, a.multi_coef_all, GRAD_NO_EXTRAS);
+      __syncthreads();
+    }
+  }
+  PA_CHAIN_STAMP(7);
+  if (a.have[CH_FIN]) chain_wait(sync, CH_FIN, (uint32_t)part_fin);
+  PA_CHAIN_STAMP(2);
+  int64_t step = 0;
+  if (total_wg) {
+    multi_sum_body<float, MULTI_THREADS>(KB, a.multi_out, a.multi_coef_all, a.multi_accumulate);
+    if (threadIdx.x == 0) step = a.ad_step[0] + 1;
+  } else {
+    for (int q = 0; q < ts_n; ++q)
+      if (ts_mask >> q & 1)
+        multi_grad_body<float>(KB, tail_entry(q), a.multi_g, a.multi_coef_all, GRAD_EXTRAS_ONLY);
+    __syncthreads();
+    PA_CHAIN_STAMP(3);
+    // all column tiles of the site in this workgroup (tile 0 of 1: the body strides over them)
+    meanfield_sample_bwd_body<float>(KMF, (uint32_t)me, 0u, 1u, a.mf_P);
+    __syncthreads();
+    PA_CHAIN_STAMP(4);
+    const MfSiteDev ms = kernarg_load<MfSiteDev>(KMF + (uint32_t)offsetof(MfArgs, s) +
+                                                 (uint32_t)me * (uint32_t)sizeof(MfSiteDev));
+    const int64_t off_loc = kernarg_load<int64_t>(KT + (uint32_t)offsetof(TailSite, off_loc));
+    const int64_t off_rho = kernarg_load<int64_t>(KT + (uint32_t)offsetof(TailSite, off_rho));
+    adam_two_ranges<float>(off_loc, off_rho, ms.n, a.ad_p, a.ad_g, a.ad_m, a.ad_v, a.ad_step,
+                           a.ad_lr, a.ad_b1, a.ad_b2, a.ad_eps, a.ad_wd, a.ad_clip, a.ad_lrd,
+                           a.ad_clipped, a.ad_zero, &step);
+    PA_CHAIN_STAMP(5);
+  }
+  // arrival: the workgroup's writes are released, then the ticket; the last of the nsites + 1
+  // arrivals (acquire: it reads the total another workgroup wrote) ends the step
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned long long ticket = __hip_atomic_fetch_add(
+        reinterpret_cast<unsigned long long*>(a.ad_step + 1), 1ull, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (unsigned long long)a.tail_nsites) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      a.ad_step[1] = 0;
+      a.ad_step[0] = step;
+#pragma unroll
+      for (int q = 0; q < CH_PHASES; ++q)
+        __hip_atomic_store(&sync[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      publish_to_host(a.ad_pub);
+    }
+  }
+  PA_CHAIN_STAMP(6);
+}
+
+// Does the recorded chain have the fused form?  Fills a.tail / a.tail_nsites.
+static bool chain_plan_tail(ChainArgs& a) {
+  if (!(a.have[CH_MULTI] && a.have[CH_MF] && a.have[CH_ADAM])) return false;
+  if (a.multi_g != nullptr || a.mf_nsites < 1 || a.mf_nsites > CH_MF_SITES) return false;
+  const float* g0 = a.ad_g;
+  const float* g1 = a.ad_g + a.ad_n;
+  int owner[PA_MULTI_MAX_ENTRIES];
+  for (int e = 0; e < a.multi.n; ++e) owner[e] = -1;
+  int64_t covered = 0;
+  int64_t lo[2 * CH_MF_SITES], hi[2 * CH_MF_SITES];
+  for (int k = 0; k < a.mf_nsites; ++k) {
+    const MfSiteDev& s = a.mf.s[k];
+    TailSite& t = a.tail[k];
+    t.n_entries = 0;
+    t.extras_mask = 0;
+    if (s.n < 1 || s.n > 4096 || !s.accumulate || s.d_loc == nullptr || s.d_rho == nullptr) return false;
+    const float* dl = (const float*)s.d_loc;
+    const float* dr = (const float*)s.d_rho;
+    if (dl < g0 || dl + s.n > g1 || dr < g0 || dr + s.n > g1) return false;
+    t.off_loc = dl - g0;
+    t.off_rho = dr - g0;
+    lo[2 * k] = t.off_loc; hi[2 * k] = t.off_loc + s.n;
+    lo[2 * k + 1] = t.off_rho; hi[2 * k + 1] = t.off_rho + s.n;
+    covered += 2 * s.n;
+    for (int e = 0; e < a.multi.n; ++e) {
+      const EntryDev& en = a.multi.e[e];
+      const bool own_v = (en.need & PA_NEED_VALUE) && en.dv && !(en.need & PA_VALUE_BY_CHAIN);
+      const bool own_a = (en.need & PA_NEED_P0) && en.da, own_b = (en.need & PA_NEED_P1) && en.db;
+      int hits = 0, outs = 0;
+      if (own_v) { ++outs; hits += (en.dv == s.d_z); }
+      if (own_a) { ++outs; hits += (en.da == s.d_loc_out || en.da == s.d_scale); }
+      if (own_b) { ++outs; hits += (en.db == s.d_loc_out || en.db == s.d_scale); }
+      if (hits == 0) continue;
+      if (hits != outs || owner[e] >= 0) return false;     // an output goes somewhere else
+      if (t.n_entries == CH_TAIL_ENTRIES) return false;
+      owner[e] = k;
+      if (t.n_entries == 0) t.extras_mask = 0;
+      if (own_v && en.xg != nullptr) t.extras_mask |= 1 << t.n_entries;
+      t.entries[t.n_entries++] = e;
+    }
+  }
+  // every entry that writes a gradient belongs to a site
+  for (int e = 0; e < a.multi.n; ++e) {
+    const EntryDev& en = a.multi.e[e];
+    const bool writes = ((en.need & PA_NEED_VALUE) && en.dv && !(en.need & PA_VALUE_BY_CHAIN)) ||
+                        ((en.need & PA_NEED_P0) && en.da) || ((en.need & PA_NEED_P1) && en.db);
+    if (writes && owner[e] < 0) return false;
+  }
+  // every gradient a site's backward reads is written by one of its entries
+  for (int k = 0; k < a.mf_nsites; ++k) {
+    const MfSiteDev& s = a.mf.s[k];
+    const void* wants[3] = {s.d_z, s.d_scale, s.d_loc_out};
+    for (const void* w : wants) {
+      if (w == nullptr) continue;
+      bool found = false;
+      for (int q = 0; q < a.tail[k].n_entries && !found; ++q) {
+        const EntryDev& en = a.multi.e[a.tail[k].entries[q]];
+        found = en.dv == w || en.da == w || en.db == w;
+      }
+      if (!found) return false;
+    }
+  }
+  // the sites' slices tile the flat buffer exactly
+  if (covered != a.ad_n) return false;
+  const int m = 2 * a.mf_nsites;
+  for (int i = 0; i < m; ++i)
+    for (int j = i + 1; j < m; ++j)
+      if (lo[i] < hi[j] && lo[j] < hi[i]) return false;
+  a.tail_nsites = a.mf_nsites;
+  return true;
+}
+
 // ---- host side: the recording ------------------------------------------------------------------
 struct ChainState {
   bool on = false;
@@ -200,6 +398,7 @@ struct ChainState {
   int top = -1;            // highest phase kind recorded so far (-1: nothing pending)
   int launches = 0;        // chain launches since pa_chain_begin (diagnostics)
   int phases = 0;          // phases those launches carried
+  int fused = 0;           // launches that took the fused form
   ChainArgs a;
 };
 // One recording per process, NOT per thread: the backward half of a step (the guide's backward,
@@ -207,6 +406,7 @@ struct ChainState {
 // was started on the caller's.  The entry points are serialised by the host language (the GIL).
 static ChainState g_chain;
 static uint64_t* g_chain_stamps = nullptr;
+static int g_chain_fuse = 1;
 
 static int chain_launch() {
   ChainState& c = g_chain;
@@ -225,7 +425,17 @@ static int chain_launch() {
   if (maxgrid < nw) nw = maxgrid;
   const hipStream_t s = c.stream;
   c.top = -1;                                   // (before the launch: as_stream() must not recurse)
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)nw + 1), dim3(1024), 0, s, a);
+  a.tail_nsites = 0;
+  if (g_chain_fuse && cu_count() - 1 > CH_MF_SITES && chain_plan_tail(a)) {
+    // the sites' workgroups + the finalize workers (as many as that phase has virtual workgroups,
+    // within what is co-resident)
+    nw = a.tail_nsites + (a.have[CH_FIN] ? a.grid[CH_FIN] : 0);
+    if (nw > cu_count() - 1) nw = cu_count() - 1;
+    hipLaunchKernelGGL(chain_tail_kernel, dim3((unsigned)nw + 1), dim3(1024), 0, s, a);
+    c.fused += 1;
+  } else {
+    hipLaunchKernelGGL(chain_kernel, dim3((unsigned)nw + 1), dim3(1024), 0, s, a);
+  }
   c.launches += 1;
   c.phases += np;
   for (int p = 0; p < CH_PHASES; ++p) a.have[p] = 0;
@@ -330,7 +540,7 @@ int pa_chain_begin(pa_stream_t stream, void* sync_words, size_t sync_bytes) {
   pa::g_chain.on = true;
   pa::g_chain.stream = (hipStream_t)stream;
   pa::g_chain.top = -1;
-  pa::g_chain.launches = pa::g_chain.phases = 0;
+  pa::g_chain.launches = pa::g_chain.phases = pa::g_chain.fused = 0;
   for (int p = 0; p < pa::CH_PHASES; ++p) pa::g_chain.a.have[p] = 0;
   pa::g_chain.a.sync = (uint32_t*)sync_words;
   return PA_OK;
@@ -350,8 +560,22 @@ int pa_chain_end(int* launches, int* phases) {
   return rc;
 }
 
+int pa_chain_tune(int fuse_tail) {
+  pa::g_chain_fuse = fuse_tail ? 1 : 0;
+  return PA_OK;
+}
+
+int pa_chain_fused_launches(void) { return pa::g_chain.fused; }
+
 int pa_chain_debug_stamps(void* stamps32) {
   pa::g_chain_stamps = (uint64_t*)stamps32;
+#ifdef PA_CHAIN_LATENCY_PROBE
+  // (64 words in this build: [32..61] are stamps taken inside the bodies by workgroup 0)
+  uint64_t* p = (uint64_t*)stamps32;
+  int zero = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(pa::pa_dbg_stamps), &p, sizeof(p));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(pa::pa_dbg_next), &zero, sizeof(zero));
+#endif
   return PA_OK;
 }
 

@@ -42,8 +42,20 @@ __device__ __forceinline__ void glm_finalize_body(
     }
     const int pass = p / (32 * PT);
     const float* base = part + (int64_t)pass * nblocks * REC + slot;
-    float v[8];
+    // the records are summed in increasing order whatever the batching: what a batch buys is that
+    // its loads are in flight together (a thread's 24 records of a 768-workgroup launch: ONE
+    // memory round trip instead of three)
     int blk = s;
+    {
+      float v[24];
+      for (; blk + 23 * FIN_GROUPS < nblocks; blk += 24 * FIN_GROUPS) {
+#pragma unroll
+        for (int u = 0; u < 24; ++u) v[u] = base[(int64_t)(blk + u * FIN_GROUPS) * REC];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) acc += (double)v[u];
+      }
+    }
+    float v[8];
     for (; blk + 7 * FIN_GROUPS < nblocks; blk += 8 * FIN_GROUPS) {   // 8 loads in flight
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(blk + u * FIN_GROUPS) * REC];

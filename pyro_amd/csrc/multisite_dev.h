@@ -53,6 +53,19 @@ __device__ __forceinline__ S kernarg_load(uint32_t byte_offset) {
   return u.s;
 }
 
+// developer probe (chain.hip, PA_CHAIN_LATENCY_PROBE): wall-clock stamps from inside the bodies
+#ifdef PA_CHAIN_LATENCY_PROBE
+static __device__ uint64_t* pa_dbg_stamps = nullptr;
+static __device__ int pa_dbg_next = 0;
+#define PA_DBG_STAMP()                                                                  \
+  do {                                                                                  \
+    if (pa_dbg_stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && pa_dbg_next < 30) \
+      pa_dbg_stamps[32 + pa_dbg_next++] = wall_clock64();                               \
+  } while (0)
+#else
+#define PA_DBG_STAMP() do { } while (0)
+#endif
+
 constexpr int MULTI_THREADS = 1024;
 constexpr int UN = 8;   // independent iterations per batch: their loads are in flight together
 template <> struct NParams<PA_SITE_IDENTITY> { static constexpr int n = 1; };
@@ -279,6 +292,38 @@ __device__ __forceinline__ void combined_pass(const EntryDev& e, double w, int p
   }
 }
 
+// dv += xw * xg (the known extra term of a value gradient), with combined_pass's element -> thread
+// map.  Applied AFTER the entry's own pass and every chained pass: the extra term (the fused GLM
+// site's gradient) is the only operand of an ELBO assembly that depends on the big kernel before
+// it, so everything else can be computed while that kernel's reduction is still running
+// (chain.hip: the fused tail does exactly that).
+template <typename T>
+__device__ __forceinline__ void extras_pass(const EntryDev& e, const T* xg, T xw) {
+  const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols, t = threadIdx.x;
+  const uint32_t tk = C < GRAD_THREADS ? C : GRAD_THREADS, ng = row_groups(tk);
+  const uint32_t c0 = t % tk, g = t / tk;
+  T* dv = (T*)e.dv;
+  for (uint32_t cb = 0; cb < C; cb += tk) {
+    const uint32_t c = cb + c0;
+    const bool okc = g < ng && c < C;
+    for (uint32_t rb = g; rb < R; rb += UN * ng) {
+      T old[UN], ex[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const uint32_t r = rb + u * ng;
+        const uint32_t o = (okc && r < R) ? r * C + c : 0u;
+        old[u] = dv[o];
+        ex[u] = xg[o];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const uint32_t r = rb + u * ng;
+        if (okc && r < R) dv[r * C + c] = old[u] + xw * ex[u];
+      }
+    }
+  }
+}
+
 // generic single-operand pass (any pattern, incl. reductions over columns): the rarely needed
 // fallback for operands the combined pass does not cover
 template <int DIST, typename T>
@@ -326,13 +371,17 @@ __device__ __forceinline__ void operand_pass(const EntryDev& e, int which, int p
 // everything workgroup `blockIdx.x` owes for entry e: its own value gradient (unless a chain head
 // produces it) followed by the chained entries' contributions to the same buffer, and its p0 / p1
 // gradients -- the common patterns in one pass each
+// mode 0: everything; 1: everything but the extra term; 2: the extra term only
+enum { GRAD_ALL = 0, GRAD_NO_EXTRAS = 1, GRAD_EXTRAS_ONLY = 2 };
 template <typename T>
 __device__ __forceinline__ void multi_grad_body(uint32_t kbase, int entry, const T* __restrict__ g,
-                                                double coef_all) {
+                                                double coef_all, int mode = GRAD_ALL) {
   __shared__ double red[2 * GRAD_THREADS];
+  PA_DBG_STAMP();
   const EntryDev e = kernarg_load<EntryDev>(kbase + offsetof(MultiArgs, e) + entry * sizeof(EntryDev));
   if (e.rows * e.cols == 0) return;
   const double gw = (g != nullptr ? (double)g[0] : 1.0) * coef_all;
+  PA_DBG_STAMP();
   const bool own_value = (e.need & PA_NEED_VALUE) && e.dv && !(e.need & PA_VALUE_BY_CHAIN);
   const bool param_family = e.dist >= 0 && e.dist < PA_DIST_COUNT;
   int pv = pattern_of(own_value, e.vsr, e.vsc, e.rows, e.cols);
@@ -345,15 +394,20 @@ __device__ __forceinline__ void multi_grad_body(uint32_t kbase, int entry, const
   const int pa_c = pa_ == PAT_COLRED ? PAT_SKIP : pa_;
   const int pb_c = pb_ == PAT_COLRED ? PAT_SKIP : pb_;
   const double w = gw * e.coef;
+  const bool extras = own_value && pv == PAT_FULL && e.xg != nullptr;
+  if (mode == GRAD_EXTRAS_ONLY) {
+    if (extras) extras_pass<T>(e, (const T*)e.xg, (T)(gw * e.xcoef));
+    return;
+  }
   if (pv != PAT_SKIP && pv != PAT_FULL) {
     PA_DISPATCH_ENTRY(e.dist, (operand_pass<D_, T>(e, 0, pv, (T*)e.dv, w, red)));
   }
   if (pa_ == PAT_COLRED) { PA_DISPATCH_ENTRY(e.dist, (operand_pass<D_, T>(e, 1, pa_, (T*)e.da, w, red))); }
   if (pb_ == PAT_COLRED) { PA_DISPATCH_ENTRY(e.dist, (operand_pass<D_, T>(e, 2, pb_, (T*)e.db, w, red))); }
   if (pv_c != PAT_SKIP || pa_c != PAT_SKIP || pb_c != PAT_SKIP) {
-    const T xw = (T)(gw * e.xcoef);
-    PA_DISPATCH_ENTRY(e.dist, (combined_pass<D_, T>(e, w, pv_c, false, (const T*)e.xg, xw, pa_c, pb_c, red)));
+    PA_DISPATCH_ENTRY(e.dist, (combined_pass<D_, T>(e, w, pv_c, false, (const T*)nullptr, T(0), pa_c, pb_c, red)));
   }
+  PA_DBG_STAMP();
   if (own_value && pv == PAT_FULL) {
     for (int k = e.chain_next; k >= 0;) {   // same value tensor, same frame, same element->thread map
       const EntryDev m = kernarg_load<EntryDev>(kbase + offsetof(MultiArgs, e) + k * sizeof(EntryDev));
@@ -362,8 +416,10 @@ __device__ __forceinline__ void multi_grad_body(uint32_t kbase, int entry, const
       PA_DISPATCH_ENTRY(m.dist, (combined_pass<D_, T>(mm, gw * m.coef, PAT_FULL, true, (const T*)nullptr, T(0),
                                                       PAT_SKIP, PAT_SKIP, red)));
       k = m.chain_next;
+      PA_DBG_STAMP();
     }
   }
+  if (extras && mode == GRAD_ALL) extras_pass<T>(e, (const T*)e.xg, (T)(gw * e.xcoef));
 }
 
 template <typename T>

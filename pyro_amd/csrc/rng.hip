@@ -2,6 +2,7 @@
 // Memory-bound element-wise fill: 16 B stores per lane, grid-stride, one Philox block per
 // 4 (f32) or 2 (f64) outputs so out[i] never depends on the launch geometry.
 #include "common.h"
+#include "optim_dev.h"
 
 namespace pa {
 
@@ -66,12 +67,8 @@ __global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
 template <typename T>
 __global__ void publish_scalar_kernel(const T* __restrict__ src, double* host_value,
                                       uint64_t* host_seq, uint64_t* counter, uint64_t inc) {
-  if (counter != nullptr) *counter += inc;
-  const double v = (double)*src;
-  __hip_atomic_store(host_value, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();                       // the value is visible to the host before the flag
-  const uint64_t seq = __hip_atomic_load(host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(host_seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  publish_to_host(AdamPublish{src, sizeof(T) == 4 ? PA_F32 : PA_F64, host_value, host_seq, counter,
+                              inc});
 }
 
 template <bool NORMAL>

@@ -50,15 +50,17 @@ class _CapturedStep:
     def read_loss(self):
         if self.mailbox is None:
             return self.loss.item()
-        want = self._seq + 1
+        # one publish per replay, each with a new sequence number (a device-side count: it need not
+        # be the previous number of THIS mailbox plus one)
+        last = self._seq
         seq, spins = self._seq_np, 0
-        while int(seq[0]) != want:
+        while int(seq[0]) == last:
             spins += 1
             if spins > 5_000_000:           # ~seconds: something is wrong, fall back to a real sync
                 torch.cuda.current_stream().synchronize()
-                if int(seq[0]) != want:
+                if int(seq[0]) == last:
                     raise RuntimeError("pyro_amd: the captured step did not publish its loss")
-        self._seq = want
+        self._seq = int(seq[0])
         return float(self._value_np[0])
 
 
@@ -242,6 +244,7 @@ class SVI:
                                     zero_grads(params)
                             cap.finish(publish=(loss,) + mailbox)
                     self.chain_stats.append(getattr(rec, "stats", None))
+                    self.chain_fused = getattr(rec, "fused", 0)
                 if split:
                     # the gradient all-reduce is NOT captured: graph 1 = loss + backward, then an
                     # eager collective, then graph 2 = optimizer update + gradient zeroing

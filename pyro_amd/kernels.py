@@ -134,6 +134,11 @@ def chain_debug_stamps(buf):
     _CHAIN["stamps"] = buf
 
 
+def chain_tune(fuse_tail=True):
+    """pa_chain_tune: allow (default) / forbid the per-site fused form of the chained tail."""
+    check(_lib.load().pa_chain_tune(int(bool(fuse_tail))))
+
+
 def chain_flush():
     """Launch the recorded phases now (no-op when nothing is pending)."""
     if _CHAIN["keep"] is not None:
@@ -147,6 +152,7 @@ class chain_recording:
     def __init__(self, device):
         self.sync = chain_sync_buffer(device)
         self.stats = (0, 0)
+        self.fused = 0
         self._guard = None
 
     def __enter__(self):
@@ -166,6 +172,7 @@ class chain_recording:
             rc = _lib.load().pa_chain_end(ctypes.byref(a), ctypes.byref(b))
             _CHAIN["keep"] = None
             self.stats = (a.value, b.value)
+            self.fused = _lib.load().pa_chain_fused_launches()
         if exc[0] is None:
             check(rc)
         return False
@@ -235,6 +242,7 @@ def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
     _require_gpu(src, counter)
     assert host_value.is_pinned() and host_seq.is_pinned()
     assert host_value.dtype == torch.float64 and host_seq.dtype == torch.int64
+    assert counter is None or (counter.dtype == torch.int64 and counter.numel() >= 2)
     check(_lib.load().pa_publish_scalar(_dtype(src), _ptr(src), _ptr(host_value), _ptr(host_seq),
                                         _ptr(counter), int(inc), _stream()))
 
@@ -242,7 +250,7 @@ def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
 def counter_add(counter, inc):
     """*counter += inc on the stream (device-resident Philox base offset; graph-replay safe)."""
     _require_gpu(counter)
-    assert counter.dtype == torch.int64 and counter.numel() == 1
+    assert counter.dtype == torch.int64 and counter.numel() >= 1
     check(_lib.load().pa_counter_add(_ptr(counter), int(inc), _stream()))
 
 
@@ -1262,6 +1270,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999)
         _require_gpu(src)
         assert src.numel() == 1 and host_value.dtype == torch.float64 and host_value.is_pinned()
         assert host_seq.dtype == torch.int64 and host_seq.is_pinned()
+        assert counter is None or (counter.dtype == torch.int64 and counter.numel() >= 2)
         check(_lib.load().pa_adam_step_publish(
             _dtype(param), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),

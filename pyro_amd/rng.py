@@ -81,7 +81,8 @@ class GraphCapture:
     ``cap.after_replay()`` to advance the host mirror."""
 
     def __init__(self, device):
-        self.base = torch.zeros((1,), dtype=torch.int64, device=device)
+        # device words {Philox block base, publish sequence}: pa_publish_scalar's `counter`
+        self.base = torch.zeros((2,), dtype=torch.int64, device=device)
         self.start = None
         self.used = None
         self._base_value = None      # what *base holds on the device, if known
@@ -114,7 +115,7 @@ class GraphCapture:
 
     def before_replay(self):
         if self._base_value != _STATE["offset"]:
-            self.base.fill_(_STATE["offset"])
+            self.base[:1].fill_(_STATE["offset"])
             self._base_value = _STATE["offset"]
 
     def after_replay(self):

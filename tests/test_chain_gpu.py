@@ -49,27 +49,35 @@ def _chained_eager_step(svi, X, y):
             loss = svi._loss_device(svi.model, svi.guide, X, y)
         params = svi._params_of(pc)
         svi.optim(params)
-    return float(loss), rec.stats
+    return float(loss), rec.stats + (rec.fused,)
 
 
 @pytest.mark.parametrize("P", [64, 16])
 def test_chained_tail_is_bitwise_the_separate_launches(gpu, P):
-    """P = 64: plane-image GLM kernel (after the second sighting) ; P = 16: the bf16x3 kernel."""
+    """P = 64: plane-image GLM kernel (after the second sighting) ; P = 16: the bf16x3 kernel.
+    Unchained / chained phase by phase / chained with the per-site fused tail."""
+    from pyro_amd import kernels
     runs = []
-    for chained in (False, True):
-        pyro, svi, X, y = _setup(gpu, P=P)
-        losses, stats = [], None
-        for i in range(6):
-            if chained and i >= 2:        # (the first steps create parameters / optimizer state)
-                loss, stats = _chained_eager_step(svi, X, y)
-            else:
-                loss = svi.step(X, y)
-            losses.append(loss)
-        runs.append((losses, _params(pyro), stats))
-    assert runs[1][2] == (1, 4), runs[1][2]           # ONE launch carrying all four phases
-    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
-    for k in runs[0][1]:
-        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    try:
+        for chained in (False, "phases", "fused"):
+            kernels.chain_tune(fuse_tail=chained == "fused")
+            pyro, svi, X, y = _setup(gpu, P=P)
+            losses, stats = [], None
+            for i in range(6):
+                if chained and i >= 2:        # (the first steps create parameters / optimizer state)
+                    loss, stats = _chained_eager_step(svi, X, y)
+                else:
+                    loss = svi.step(X, y)
+                losses.append(loss)
+            runs.append((losses, _params(pyro), stats))
+    finally:
+        kernels.chain_tune(fuse_tail=True)
+    assert runs[1][2] == (1, 4, 0), runs[1][2]        # ONE launch carrying all four phases
+    assert runs[2][2] == (1, 4, 1), runs[2][2]        # ... in the fused form
+    for other in runs[1:]:
+        assert runs[0][0] == other[0], (runs[0][0], other[0])
+        for k in runs[0][1]:
+            assert torch.equal(runs[0][1][k], other[1][k]), k
 
 
 def test_captured_step_is_three_nodes_of_ours(gpu):
@@ -96,7 +104,7 @@ def test_captured_step_is_three_nodes_of_ours(gpu):
         losses = [svi.step(X, y) for _ in range(10)]
         if graph:
             assert svi.hip_graph and len(svi._graphs) == 1
-            assert svi.chain_stats == [(1, 4)], svi.chain_stats
+            assert svi.chain_stats == [(1, 4)] and svi.chain_fused == 1, svi.chain_stats
             entry = next(iter(svi._graphs.values()))
             assert entry.constants_served == 2, entry.constants_served
         out.append((losses, _params(pyro)))

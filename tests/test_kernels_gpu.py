@@ -997,7 +997,7 @@ def test_adam_step_publish_hands_over_the_scalar(gpu):
                      torch.zeros(2, dtype=torch.int64, device=gpu)))
     hv = torch.zeros(1, dtype=torch.float64).pin_memory()
     hs = torch.zeros(1, dtype=torch.int64).pin_memory()
-    counter = torch.full((1,), 40, dtype=torch.int64, device=gpu)
+    counter = torch.tensor([40, 100], dtype=torch.int64, device=gpu)   # {Philox base, publish sequence}
     for step in range(1, 4):
         g = (rng.standard_normal(n) * 3).astype(np.float32)
         loss = torch.full((), 1.5 * step, device=gpu, dtype=torch.float32)
@@ -1005,8 +1005,8 @@ def test_adam_step_publish_hands_over_the_scalar(gpu):
         k.adam_step(pa, tt(g, gpu), ma, va, sa, lr=0.01)
         k.adam_step(pb, tt(g, gpu), mb, vb, sb, lr=0.01, publish=(loss, hv, hs, counter, 7))
         torch.cuda.synchronize()
-        assert hs.item() == step and hv.item() == 1.5 * step
-        assert counter.item() == 40 + 7 * step
+        assert hs.item() == 100 + step and hv.item() == 1.5 * step      # the device-side sequence
+        assert counter.tolist() == [40 + 7 * step, 100 + step]
     assert torch.equal(bufs[0][0], bufs[1][0]) and bufs[1][3].tolist() == [3, 0]
 
 

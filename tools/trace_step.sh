@@ -10,7 +10,7 @@ f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last step = after the last but one adam kernel
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "chain_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "chain_" in r["Kernel_Name"]]
 # the tightest step (a graph replay when the bench captured one)
 best = None
 for a, b in zip(idx, idx[1:]):
