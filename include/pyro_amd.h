@@ -338,6 +338,12 @@ size_t pa_glm_planes_bytes(int64_t N, int64_t D);
 int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_t planes_bytes,
                        pa_stream_t stream);
 int pa_glm_planes_tune(int ring_depth, int blocks_per_cu);
+/* 0 (default): the separate finalize launch; 1: pa_glm_bernoulli_planes_fwd_bwd reduces its
+ * per-workgroup partial records INSIDE the kernel (two levels of last-arriver sums, bit-identical
+ * results).  Measured slower at large plates (one workgroup per sum has too little memory-level
+ * parallelism): a developer switch.  The workspace holds the fp64 level-1 partials in both modes
+ * (pa_glm_bernoulli_planes_workspace). */
+int pa_glm_planes_finalize_mode(int in_kernel);
 size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P);
 int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const float* w,
                                     const float* b, double scale, int64_t N, int64_t D, int64_t P,
@@ -647,7 +653,9 @@ int pa_chain_flush(void);
 int pa_chain_end(int* launches, int* phases);
 /* phases recorded and not yet launched */
 int pa_chain_pending(void);
-/* fuse_tail = 1 (default): when every gradient of the recorded ELBO assembly feeds the backward
+/* fuse_tail = 3: as 1 below, without the one-pass code for AutoNormal-shaped sites (site_tail.h):
+ * each site runs the generic entry / backward / Adam code in its workgroup.
+ * fuse_tail = 1 (default): when every gradient of the recorded ELBO assembly feeds the backward
  * of exactly one mean-field site and the sites' parameters tile the optimizer's flat buffer, the
  * assembly / guide-backward / Adam phases run per site inside one workgroup each (no device-wide
  * barrier between them); 0: always the generic phase-by-phase form.  Same results either way. */

@@ -114,6 +114,7 @@ _SIGNATURES = {
     "pa_glm_planes_bytes": (c_size_t, [c_int64, c_int64]),
     "pa_glm_pack_planes": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "pa_glm_planes_tune": (c_int, [c_int, c_int]),
+    "pa_glm_planes_finalize_mode": (c_int, [c_int]),
     "pa_glm_bernoulli_planes_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_glm_bernoulli_planes_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                                 c_int64, c_int64, c_int64, c_void_p, c_void_p,
@@ -238,6 +239,8 @@ def load(path=None):
         fn.argtypes = args
     if lib.pa_abi_version() != ABI_VERSION:
         raise RuntimeError("pyro_amd: ABI version mismatch: %d" % lib.pa_abi_version())
+    if os.environ.get("PYRO_AMD_GLM_FINALIZE") == "in_kernel":     # developer A/B switch
+        lib.pa_glm_planes_finalize_mode(1)
     _lib = lib
     return lib
 

@@ -20,6 +20,7 @@
 #include "glm_finalize.h"
 #include "multisite_dev.h"
 #include "optim_dev.h"
+#include "site_tail.h"
 
 namespace pa {
 
@@ -38,6 +39,8 @@ struct TailSite {
   int entries[CH_TAIL_ENTRIES];   // indices into the ELBO assembly's table, ascending
   int extras_mask;                // bit q: entries[q] carries a known extra value gradient
   int64_t off_loc, off_rho;       // element offsets of the site's loc / rho in the flat buffers
+  int fast;                       // 1: the one-pass form of site_tail.h applies (entries[0] = the
+  int layout;                     //    prior entry, entries[1] = the guide entry); its layout
 };
 
 struct ChainArgs {
@@ -245,28 +248,42 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
   auto tail_entry = [&](int q) -> int {
     return kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, entries) + 4u * (uint32_t)q);
   };
-  int ts_n = 0, ts_mask = 0;
+  int ts_n = 0, ts_mask = 0, ts_fast = 0;
+  int64_t step = 0;
+  if (!total_wg) ts_fast = kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, fast));
+  if (!total_wg && ts_fast) {
+    // ---- the one-pass form: everything of this site with each element loaded once --------------
+    __shared__ double fast_red[4 * GRAD_THREADS];
+    __shared__ float fast_xch[4 * 64];
+    const int layout = kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, layout));
+    const EntryDev eh = kernarg_load<EntryDev>(KB + (uint32_t)offsetof(MultiArgs, e) +
+                                               (uint32_t)tail_entry(0) * (uint32_t)sizeof(EntryDev));
+    const EntryDev eg = kernarg_load<EntryDev>(KB + (uint32_t)offsetof(MultiArgs, e) +
+                                               (uint32_t)tail_entry(1) * (uint32_t)sizeof(EntryDev));
+    const MfSiteDev ms = kernarg_load<MfSiteDev>(KMF + (uint32_t)offsetof(MfArgs, s) +
+                                                 (uint32_t)me * (uint32_t)sizeof(MfSiteDev));
+    const int64_t off_loc = kernarg_load<int64_t>(KT + (uint32_t)offsetof(TailSite, off_loc));
+    const int64_t off_rho = kernarg_load<int64_t>(KT + (uint32_t)offsetof(TailSite, off_rho));
+    const SiteAdam ad{a.ad_p, a.ad_g, a.ad_m, a.ad_v, a.ad_step, a.ad_lr, a.ad_b1, a.ad_b2, a.ad_eps,
+                      a.ad_wd, a.ad_clip, a.ad_lrd, a.ad_clipped, a.ad_zero};
+    auto wait = [&]() {
+      PA_CHAIN_STAMP(7);
+      if (a.have[CH_FIN]) chain_wait(sync, CH_FIN, (uint32_t)part_fin);
+      else __syncthreads();
+      PA_CHAIN_STAMP(2);
+    };
+// (Normal priors only: instantiating the other families here makes the kernel spill
+    //  registers; their sites take the generic form -- chain_plan_tail)
+    site_fast<PA_DIST_NORMAL>(eh, eg, ms, layout, a.multi_coef_all, off_loc, off_rho, ad, fast_red,
+                              fast_xch, wait, &step);
+    PA_CHAIN_STAMP(5);
+  } else {
   if (!total_wg) {
     // everything that does not depend on the finalize phase runs BEFORE the wait: the gradients of
     // the site's own entries (prior, guide density); what the big kernel contributes (the extra
     // term of the value gradient) is added afterwards
     ts_n = kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, n_entries));
     ts_mask = kernarg_load<int>(KT + (uint32_t)offsetof(TailSite, extras_mask));
-#ifdef PA_CHAIN_LATENCY_PROBE
-    if (a.stamps != nullptr && me == 0 && threadIdx.x == 0) {
-      a.stamps[24] = (uint64_t)ts_n + wall_clock64();                       // after a kernarg table read
-      const EntryDev e0 = kernarg_load<EntryDev>(KB + (uint32_t)offsetof(MultiArgs, e) +
-                                                 (uint32_t)tail_entry(0) * (uint32_t)sizeof(EntryDev));
-      a.stamps[25] = (uint64_t)(e0.rows > 1 << 30) + wall_clock64();        // ... two dependent ones
-      const float z0 = ((const float*)e0.v)[0];
-      a.stamps[26] = (uint64_t)(z0 == 12345.f) + wall_clock64();            // ... and a data read
-      const int64_t st0 = a.ad_step[0];
-      a.stamps[27] = (uint64_t)(st0 < 0) + wall_clock64();                  // another data read
-    }
-#endif
-#ifdef PA_CHAIN_LATENCY_PROBE
-    for (int rep = 0; rep < 2; ++rep)      // second round: the same code with warm caches (idempotent)
-#endif
     for (int q = 0; q < ts_n; ++q) {
       multi_grad_body<float>(KB, tail_entry(q), a.multi_g, a.multi_coef_all, GRAD_NO_EXTRAS);
       __syncthreads();
@@ -275,7 +292,6 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
   PA_CHAIN_STAMP(7);
   if (a.have[CH_FIN]) chain_wait(sync, CH_FIN, (uint32_t)part_fin);
   PA_CHAIN_STAMP(2);
-  int64_t step = 0;
   if (total_wg) {
     multi_sum_body<float, MULTI_THREADS>(KB, a.multi_out, a.multi_coef_all, a.multi_accumulate);
     if (threadIdx.x == 0) step = a.ad_step[0] + 1;
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
                            a.ad_clipped, a.ad_zero, &step);
     PA_CHAIN_STAMP(5);
   }
+  }   // (generic form)
   // arrival: the workgroup's writes are released, then the ticket; the last of the nsites + 1
   // arrivals (acquire: it reads the total another workgroup wrote) ends the step
   __syncthreads();
@@ -318,6 +335,8 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
   }
   PA_CHAIN_STAMP(6);
 }
+
+static int g_chain_fast_sites = 1;     // pa_chain_tune bit 1
 
 // Does the recorded chain have the fused form?  Fills a.tail / a.tail_nsites.
 static bool chain_plan_tail(ChainArgs& a) {
@@ -387,6 +406,37 @@ static bool chain_plan_tail(ChainArgs& a) {
   for (int i = 0; i < m; ++i)
     for (int j = i + 1; j < m; ++j)
       if (lo[i] < hi[j] && lo[j] < hi[i]) return false;
+  // which sites have the shape site_tail.h does in one pass
+  for (int k = 0; k < a.mf_nsites; ++k) {
+    const MfSiteDev& s = a.mf.s[k];
+    TailSite& t = a.tail[k];
+    t.fast = 0;
+    t.layout = SITE_LAYOUT_COLS;
+    if (!g_chain_fast_sites || t.n_entries != 2) continue;
+    const EntryDev& h = a.multi.e[t.entries[0]];
+    const EntryDev& q = a.multi.e[t.entries[1]];
+    const bool family = h.dist == PA_DIST_NORMAL;
+    const bool shape =
+        family && q.dist == PA_DIST_NORMAL && h.m == nullptr &&
+        q.m == nullptr && h.chain_next == t.entries[1] && q.chain_next < 0 &&
+        (h.need & PA_NEED_VALUE) && !(h.need & PA_VALUE_BY_CHAIN) && h.dv == s.d_z &&
+        !((h.need & PA_NEED_P0) && h.da) && !((h.need & PA_NEED_P1) && h.db) &&
+        (q.need & PA_VALUE_BY_CHAIN) && (q.need & PA_NEED_P0) && (q.need & PA_NEED_P1) &&
+        q.da == s.d_loc_out && q.db == s.d_scale && q.da != nullptr && q.db != nullptr &&
+        q.v == h.v && q.vsr == h.vsr && q.vsc == h.vsc && q.rows == h.rows && q.cols == h.cols &&
+        s.d_z != nullptr && s.eps != nullptr && s.rho != nullptr;
+    if (!shape) continue;
+    const int64_t P = a.mf_P;
+    if (s.n >= 2 && s.n <= GRAD_THREADS && h.rows == P && h.cols == s.n && h.vsr == s.n &&
+        h.vsc == 1 && q.asr == 0 && q.asc == 1 && q.bsr == 0 && q.bsc == 1) {
+      const int64_t ng = GRAD_THREADS / s.n > 8 ? 8 : GRAD_THREADS / s.n;
+      if (P <= UN * ng) { t.fast = 1; t.layout = SITE_LAYOUT_COLS; }
+    } else if (s.n == 1 && h.rows == 1 && h.cols == P && P >= 2 && P <= 64 && h.vsc == 1 &&
+               q.asc == 0 && q.bsc == 0) {
+      t.fast = 1;
+      t.layout = SITE_LAYOUT_SCALAR;
+    }
+  }
   a.tail_nsites = a.mf_nsites;
   return true;
 }
@@ -561,7 +611,9 @@ int pa_chain_end(int* launches, int* phases) {
 }
 
 int pa_chain_tune(int fuse_tail) {
-  pa::g_chain_fuse = fuse_tail ? 1 : 0;
+  // bit 0: the per-site fused form; bit 1 (with bit 0): NOT the one-pass site code of site_tail.h
+  pa::g_chain_fuse = (fuse_tail & 1) ? 1 : 0;
+  pa::g_chain_fast_sites = (fuse_tail & 2) ? 0 : 1;
   return PA_OK;
 }
 

@@ -515,12 +515,42 @@ static GlmPlanesPlan glm_planes_plan(int64_t N, int64_t P) {
 template <int NB, int OCC>
 static void glm_planes_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
                                   const float* w, const float* b, int64_t N, int D, int P,
-                                  float* part, hipStream_t s) {
+                                  float* part, const GlmFinArgs& fin, hipStream_t s) {
   auto k = glm_planes_kernel<2, NB, OCC>;
   constexpr int lds = GlmPlCfg<2, NB>::LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
-                     b, N, D, P, pl.nst, part, cu_count());
+                     b, N, D, P, pl.nst, part, cu_count(), fin);
+}
+
+// ---- in-kernel finalize (glm_planes.h): the arrival counters --------------------------------------
+// One zeroed block per device, allocated the first time a plane image is packed (never inside a
+// stream capture) and kept: launches leave the counters zero.  One plane-image launch per device at
+// a time (stream order), as everywhere in this library.
+// 0 (default) = the stand-alone finalize launch (272 workgroups pull the records in parallel: ~6 us,
+// or a phase of the chained tail); 1 = inside the kernel: measured SLOWER on the MI355X (the GLM
+// kernel 68 -> 105 us at the headline size): the two serial last-arriver sums are made by ONE
+// workgroup each, 9 dependent rounds of loads at ~2 us per round (data fresh from other XCDs), where
+// the separate launch has the whole chip's memory-level parallelism.  Kept as a measured negative
+// result and for small plates (pa_glm_planes_finalize_mode).
+static int g_planes_fin_mode = 0;
+constexpr int GLMF_MAX_PASSES = 32;
+static uint32_t* g_glmf_counters[64] = {nullptr};
+
+static uint32_t* glmf_counters(bool may_allocate) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (g_glmf_counters[dev] == nullptr && may_allocate) {
+    void* p = nullptr;
+    const size_t bytes = (size_t)GLMF_MAX_PASSES * GLMF_CNT_STRIDE * sizeof(uint32_t);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    g_glmf_counters[dev] = (uint32_t*)p;
+  }
+  return g_glmf_counters[dev];
 }
 
 static void glm_tiles_of(int64_t D, int64_t P, int* DT, int* PT) {
@@ -661,6 +691,12 @@ size_t pa_glm_planes_bytes(int64_t N, int64_t D) {
 
 int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_t planes_bytes,
                        pa_stream_t stream) {
+  {
+    // the arrival counters of the in-kernel finalize: packing never happens inside a capture
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)
+      (void)pa::glmf_counters(true);
+  }
   PA_REQUIRE(N >= 0 && D >= 1, "glm_pack_planes: bad shape N=%lld D=%lld", (long long)N, (long long)D);
   if (D > 32)
     return pa::fail(PA_ERR_UNSUPPORTED, "glm_pack_planes: the plane image holds D <= 32 (got %lld)",
@@ -674,6 +710,12 @@ int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_
   hipLaunchKernelGGL(pa::glm_pack_planes_kernel, dim3((unsigned)((nt * 128 + 255) / 256)), dim3(256),
                      0, pa::as_stream(stream), X, N, (int)D, nt, (unsigned char*)planes);
   return pa::check_launch("glm_pack_planes_kernel");
+}
+
+int pa_glm_planes_finalize_mode(int in_kernel) {
+  PA_REQUIRE(in_kernel == 0 || in_kernel == 1, "glm_planes_finalize_mode: 0 or 1");
+  pa::g_planes_fin_mode = in_kernel;
+  return PA_OK;
 }
 
 int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
@@ -691,7 +733,10 @@ size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P) {
   // records of the deepest / widest tuning so that the knob never invalidates a workspace
   const size_t cap = (size_t)pa::cu_count() * 4;
   const size_t nb = (size_t)pl.nst < cap ? (size_t)(pl.nst < 1 ? 1 : pl.nst) : cap;
-  return nb * pl.npass * (2 * 1024 + 2 * 2 * 32) * sizeof(float);
+  const size_t rec = 2 * 1024 + 2 * 2 * 32;
+  // the partial records, then the fp64 level-1 partials of the in-kernel finalize
+  return nb * pl.npass * rec * sizeof(float) +
+         (size_t)pl.npass * pa::GLMF_GROUPS * rec * sizeof(double);
 }
 
 int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const float* w,
@@ -724,15 +769,28 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   hipEvent_t ev0, ev1;
   const bool br = pa::take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  if (pl.nb == 3) pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
-  else pa::glm_planes_launch_one<4, 2>(pl, img, y, w, b, N, (int)D, (int)P, part, s);
-  if (br) (void)hipEventRecord(ev1, s);
-  int rc = pa::check_launch("glm_planes_kernel");
-  if (rc != PA_OK) return rc;
-  const int64_t J = (int64_t)P * D + 2 * P;
   // every padding row of the processed super-tiles added log2(2) = 1 to the log2(1 + e) sum of
   // every particle (glm_planes.h): ln2 per row back in
   const double ll_offset = (double)(pl.nst * 64 - N) * 0.6931471805599453;
+  pa::GlmFinArgs fin;
+  fin.counters = nullptr;
+  if (pa::g_planes_fin_mode == 1 && pl.npass <= pa::GLMF_MAX_PASSES) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    fin.counters = pa::glmf_counters(!capturing);
+  }
+  const size_t rec_bytes = (size_t)pl.nblocks * pl.npass * (2 * 1024 + 2 * 2 * 32) * sizeof(float);
+  fin.part64 = (double*)((char*)workspace + ((rec_bytes + 15) & ~(size_t)15));
+  fin.ll = ll; fin.gw = gw; fin.gb = gb;
+  fin.scale = scale; fin.ll_offset = ll_offset;
+  fin.D = (int)D; fin.P = (int)P;
+  if (pl.nb == 3) pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
+  else pa::glm_planes_launch_one<4, 2>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
+  if (br) (void)hipEventRecord(ev1, s);
+  int rc = pa::check_launch("glm_planes_kernel");
+  if (rc != PA_OK) return rc;
+  if (fin.counters != nullptr) return PA_OK;        // ll / gw / gb were written by the kernel itself
+  const int64_t J = (int64_t)P * D + 2 * P;
   rc = pa::chain_record_fin(stream, 1, 2, part, pl.nblocks, pl.npass, (int)D, (int)P, scale, ll, gw,
                             gb, ll_offset);
   if (rc != 0) return rc < 0 ? rc : PA_OK;       // recorded as a phase of the step's chained tail

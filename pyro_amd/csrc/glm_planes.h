@@ -158,11 +158,117 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define PA_STAMP(i) do { } while (0)
 #endif
 
+// ---- in-kernel finalize -------------------------------------------------------------------------
+// The stand-alone finalize kernel (glm_finalize.h) reads the 768 partial records (6.7 MB at the
+// headline size) after this kernel has ended: ~10 us of a 100 us step, most of it waiting.  Here the
+// same sums are formed by the workgroups themselves as they finish, two levels, never blocking:
+//   level 1: record i belongs to group i % 32; the LAST workgroup of a group to arrive (device-wide
+//            ticket) sums the group's records, in increasing record order, into an fp64 partial;
+//   level 2: the last of those group finishers sums the 32 partials in group order, scales, and
+//            writes ll / gw / gb.
+// That is exactly the arithmetic of glm_finalize_kernel (its thread (j, s) sums the records
+// s, s + 32, ... in fp64 and the 32 sums are then added in order of s): bit-identical outputs.  Most
+// groups complete while other workgroups are still streaming; exposed after the last workgroup's
+// main loop: one group sum (209 KB) + the final sum (557 KB of partials) by one workgroup each.
+struct GlmFinArgs {
+  uint32_t* counters;     // NULL = off.  Per particle pass 40 words: [0..31] groups, [32] level 2;
+                          // zero between launches (the final arrival re-arms them)
+  double* part64;         // [npass][32][REC] level-1 partials
+  float *ll, *gw, *gb;
+  double scale, ll_offset;
+  int D, P;
+};
+constexpr int GLMF_GROUPS = 32, GLMF_CNT_STRIDE = 40;
+
+template <int NPT>
+__device__ __forceinline__ void glmp_finalize_in_kernel(const GlmFinArgs& f, const float* part,
+                                                        unsigned char* smem) {
+  constexpr int REC = NPT * 1024 + 2 * NPT * 32;
+  const int nblocks = (int)gridDim.x, pass = (int)blockIdx.y, me = (int)blockIdx.x;
+  const int ngroups = nblocks < GLMF_GROUPS ? nblocks : GLMF_GROUPS;
+  const int s = me % GLMF_GROUPS;
+  uint32_t* cnt = f.counters + pass * GLMF_CNT_STRIDE;
+  int* flag = reinterpret_cast<int*>(smem);
+  __syncthreads();                                  // every wave's record stores are at the L2
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t gsize = (uint32_t)((nblocks - s + GLMF_GROUPS - 1) / GLMF_GROUPS);
+    const uint32_t t = __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == gsize - 1u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  // ---- level 1: the group's records, increasing order, fp64
+  const float* base = part + (int64_t)pass * nblocks * REC;
+  double* my64 = f.part64 + ((int64_t)pass * GLMF_GROUPS + s) * REC;
+  for (int j = threadIdx.x; j < REC; j += 256) {
+    double acc = 0.0;
+    int blk = s;
+    {
+      float v[24];
+      for (; blk + 23 * GLMF_GROUPS < nblocks; blk += 24 * GLMF_GROUPS) {
+#pragma unroll
+        for (int u = 0; u < 24; ++u) v[u] = base[(int64_t)(blk + u * GLMF_GROUPS) * REC + j];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) acc += (double)v[u];
+      }
+    }
+    for (; blk < nblocks; blk += GLMF_GROUPS) acc += (double)base[(int64_t)blk * REC + j];
+    my64[j] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const uint32_t t = __hip_atomic_fetch_add(&cnt[GLMF_GROUPS], 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == (uint32_t)ngroups - 1u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  // ---- level 2: the partials in group order -> outputs (slot arithmetic of glm_finalize_body)
+  const double* p64 = f.part64 + (int64_t)pass * GLMF_GROUPS * REC;
+  const int D = f.D, WROWS = 32 * NPT;
+  const int nloc = WROWS * D + 2 * WROWS;
+  for (int q = threadIdx.x; q < nloc; q += 256) {
+    int pl, slot, kind;                       // kind 0: gw, 1: ll, 2: gb
+    int d = 0;
+    if (q < WROWS * D) {
+      pl = q / D;
+      d = q - pl * D;
+      kind = 0;
+      const int pt = pl >> 5, i = pl & 31, hh = (i >> 2) & 1, reg = (i & 3) + 4 * (i >> 3);
+      slot = (pt * 16 + reg) * 64 + d + 32 * hh;
+    } else {
+      const int k = q - WROWS * D, which = k >= WROWS ? 1 : 0;
+      pl = k - which * WROWS;
+      kind = 1 + which;
+      slot = NPT * 1024 + (2 * (pl >> 5) + which) * 32 + (pl & 31);
+    }
+    const int p = pass * WROWS + pl;
+    if (p >= f.P) continue;
+    double part_v[GLMF_GROUPS];
+#pragma unroll
+    for (int k = 0; k < GLMF_GROUPS; ++k) part_v[k] = k < ngroups ? p64[(int64_t)k * REC + slot] : 0.0;
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < GLMF_GROUPS; ++k) t += part_v[k];
+    if (kind == 0) f.gw[(int64_t)p * D + d] = (float)(t * f.scale);
+    else if (kind == 1) f.ll[p] = (float)((t + f.ll_offset) * f.scale);
+    else f.gb[p] = (float)(t * f.scale);
+  }
+  if (threadIdx.x <= GLMF_GROUPS)              // re-arm: every arrival of this pass has happened
+    __hip_atomic_store(&cnt[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int NPT, int NB, int OCC>
 __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
     const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
-    int64_t nst, float* __restrict__ part, int prio_cus) {
+    int64_t nst, float* __restrict__ part, int prio_cus, const GlmFinArgs fin) {
   using C = GlmPlCfg<NPT, NB>;
   constexpr int NRT = C::NRT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS, WPL = C::WPL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -510,6 +616,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
   if (lane == 0 && blockIdx.y == 0)
     (reinterpret_cast<uint64_t*>(part) + (1 << 20) + ((int64_t)blockIdx.x * 4 + wave) * 16)[14] = wall_clock64();
 #endif
+  if (fin.counters != nullptr) glmp_finalize_in_kernel<NPT>(fin, part, smem);
 }
 
 }  // namespace pa

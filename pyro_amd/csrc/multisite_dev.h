@@ -210,6 +210,9 @@ __device__ __forceinline__ int pattern_of(bool wanted, int64_t sr, int64_t sc, i
 template <int DIST, typename T>
 __device__ __forceinline__ void combined_pass(const EntryDev& e, double w, int pv, bool accumulate,
                                               const T* xg, T xw, int pa_, int pb_, double* red) {
+  // (no contraction of a * b + c in this function's own expressions: the same sums are formed by
+  //  site_tail.h in one pass, and the two must round alike whatever the surrounding code)
+#pragma clang fp contract(off)
   const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols, t = threadIdx.x;
   const uint32_t tk = C < GRAD_THREADS ? C : GRAD_THREADS, ng = row_groups(tk);
   const uint32_t c0 = t % tk, g = t / tk;
@@ -299,6 +302,7 @@ __device__ __forceinline__ void combined_pass(const EntryDev& e, double w, int p
 // (chain.hip: the fused tail does exactly that).
 template <typename T>
 __device__ __forceinline__ void extras_pass(const EntryDev& e, const T* xg, T xw) {
+#pragma clang fp contract(off)
   const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols, t = threadIdx.x;
   const uint32_t tk = C < GRAD_THREADS ? C : GRAD_THREADS, ng = row_groups(tk);
   const uint32_t c0 = t % tk, g = t / tk;
@@ -329,6 +333,7 @@ __device__ __forceinline__ void extras_pass(const EntryDev& e, const T* xg, T xw
 template <int DIST, typename T>
 __device__ __forceinline__ void operand_pass(const EntryDev& e, int which, int pat, T* out, double w,
                                              double* red) {
+#pragma clang fp contract(off)
   const uint32_t R = (uint32_t)e.rows, C = (uint32_t)e.cols, t = threadIdx.x;
   auto at = [&](uint32_t r, uint32_t c) -> T {
     const Elem<T> x = load_elem<DIST, T>(e, r, c, true);
@@ -505,6 +510,16 @@ struct MfArgs {
   MfSiteDev s[PA_MF_MAX_SITES];
 };
 
+// d softplus / d x (1 beyond torch's threshold of 20)
+template <typename T> __device__ __forceinline__ double softplus_slope(T rho) {
+  if constexpr (sizeof(T) == 8) {
+    const double x = (double)rho;
+    return x > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-x));
+  } else {
+    const float x = (float)rho;
+    return x > 20.0f ? 1.0 : (double)(1.0f / (1.0f + expf(-x)));
+  }
+}
 template <typename T> __device__ __forceinline__ T softplus_t(T x) {
   // torch.nn.functional.softplus (threshold 20): x for large x, log1p(exp(x)) otherwise
   return x > T(20) ? x : t_log1p(t_exp(x));
@@ -544,6 +559,7 @@ __global__ __launch_bounds__(256) void meanfield_sample_kernel(const MfArgs args
 template <typename T>
 __device__ __forceinline__ void meanfield_sample_bwd_body(uint32_t kbase, uint32_t site, uint32_t tile,
                                                           uint32_t ntiles, int64_t P) {
+#pragma clang fp contract(off)
   __shared__ double red_l[256], red_s[256];
   const MfSiteDev s = kernarg_load<MfSiteDev>(kbase + offsetof(MfArgs, s) + site * sizeof(MfSiteDev));
   const T* dz = (const T*)s.d_z;
@@ -595,14 +611,7 @@ __device__ __forceinline__ void meanfield_sample_bwd_body(uint32_t kbase, uint32
       }
       ss += (double)v_dsc;
       sl += (double)v_dlo;
-      double sig;                                   // d softplus / d x (1 beyond the threshold)
-      if constexpr (sizeof(T) == 8) {
-        const double x = (double)v_rho;
-        sig = x > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-x));
-      } else {
-        const float x = (float)v_rho;
-        sig = x > 20.0f ? 1.0 : (double)(1.0f / (1.0f + expf(-x)));
-      }
+      const double sig = softplus_slope<T>(v_rho);
       if (dloc) dloc[c] = (T)sl + v_ol;
       if (drho) drho[c] = (T)(ss * sig) + v_or;
     }

@@ -134,9 +134,10 @@ def chain_debug_stamps(buf):
     _CHAIN["stamps"] = buf
 
 
-def chain_tune(fuse_tail=True):
-    """pa_chain_tune: allow (default) / forbid the per-site fused form of the chained tail."""
-    check(_lib.load().pa_chain_tune(int(bool(fuse_tail))))
+def chain_tune(fuse_tail=True, fast_sites=True):
+    """pa_chain_tune: allow (default) / forbid the per-site fused form of the chained tail, and
+    within it the one-pass code for AutoNormal-shaped sites."""
+    check(_lib.load().pa_chain_tune((1 if fuse_tail else 0) | (0 if fast_sites else 2)))
 
 
 def chain_flush():
@@ -650,6 +651,13 @@ def glm_set_planes_mode(mode):
 
 def glm_planes_tune(ring_depth=0, blocks_per_cu=0):
     check(_lib.load().pa_glm_planes_tune(int(ring_depth), int(blocks_per_cu)))
+
+
+def glm_planes_finalize_mode(in_kernel=False):
+    """pa_glm_planes_finalize_mode: reduce the plane-image kernel's partial records with the separate
+    finalize launch (default; a phase of the chained tail in a captured step) or inside the kernel
+    (bit-identical, measured slower at large plates)."""
+    check(_lib.load().pa_glm_planes_finalize_mode(int(bool(in_kernel))))
 
 
 def glm_pack_planes(X, out=None):

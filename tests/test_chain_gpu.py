@@ -59,8 +59,8 @@ def test_chained_tail_is_bitwise_the_separate_launches(gpu, P):
     from pyro_amd import kernels
     runs = []
     try:
-        for chained in (False, "phases", "fused"):
-            kernels.chain_tune(fuse_tail=chained == "fused")
+        for chained in (False, "phases", "fused", "fast"):
+            kernels.chain_tune(fuse_tail=chained in ("fused", "fast"), fast_sites=chained == "fast")
             pyro, svi, X, y = _setup(gpu, P=P)
             losses, stats = [], None
             for i in range(6):
@@ -74,6 +74,7 @@ def test_chained_tail_is_bitwise_the_separate_launches(gpu, P):
         kernels.chain_tune(fuse_tail=True)
     assert runs[1][2] == (1, 4, 0), runs[1][2]        # ONE launch carrying all four phases
     assert runs[2][2] == (1, 4, 1), runs[2][2]        # ... in the fused form
+    assert runs[3][2] == (1, 4, 1), runs[3][2]        # ... with the one-pass site code
     for other in runs[1:]:
         assert runs[0][0] == other[0], (runs[0][0], other[0])
         for k in runs[0][1]:
@@ -168,6 +169,30 @@ def test_a_step_that_writes_into_a_fresh_constant_is_captured_with_its_fills(gpu
             assert next(iter(svi._graphs.values())).constants_served == 0
         out.append(losses)
     assert out[0] == out[1]
+
+
+def test_in_kernel_finalize_is_bitwise_the_separate_launch(gpu):
+    """pa_glm_bernoulli_planes_fwd_bwd: the two-level last-arriver reduction inside the kernel against
+    the stand-alone finalize kernel, incl. a plate that does not fill the grid and P > 64 (two
+    particle passes)."""
+    from pyro_amd import kernels
+    g = torch.Generator(device=gpu).manual_seed(0)
+    try:
+        for N, D, P in ((200_000, 32, 64), (1000, 17, 40), (70_000, 32, 130), (64, 8, 33)):
+            X = torch.randn((N, D), device=gpu, generator=g)
+            y = (torch.rand((N,), device=gpu, generator=g) < 0.5).float()
+            w = torch.randn((P, D), device=gpu, generator=g) * 0.1
+            b = torch.randn((P,), device=gpu, generator=g) * 0.1
+            planes = kernels.glm_pack_planes(X)
+            outs = []
+            for mode in (False, True, True):
+                kernels.glm_planes_finalize_mode(mode)
+                outs.append(kernels.glm_bernoulli_planes_fwd_bwd(planes, y, w, b, 1.0, N, D))
+            for o in outs[1:]:
+                for a, r in zip(o, outs[0]):
+                    assert torch.equal(a, r), (N, D, P)
+    finally:
+        kernels.glm_planes_finalize_mode(False)
 
 
 def test_chain_can_be_switched_off(gpu, monkeypatch):

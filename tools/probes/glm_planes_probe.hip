@@ -19,9 +19,9 @@ static void run(const unsigned char* img, const float* y, const float* w, const 
   const int nblocks = 256 * bpc;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, nst, part, 256);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, nst, part, 256, pa::GlmFinArgs{});
   (void)hipEventRecord(e0);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, nst, part, 256);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, nst, part, 256, pa::GlmFinArgs{});
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms = 0;
