@@ -75,6 +75,7 @@ struct ChainArgs {
   // --- the fused form (chain_tail_kernel): per mean-field site the entries whose gradients only
   //     that site's backward consumes, and where the site's parameters live in the flat buffers
   int tail_nsites;
+  uint32_t fin_dep_mask;  // entries of the ELBO assembly that read the finalize phase's outputs
   TailSite tail[CH_MF_SITES];
 };
 static_assert(sizeof(ChainArgs) <= 6144, "kernel arguments grew unexpectedly");
@@ -117,13 +118,26 @@ __device__ __forceinline__ void chain_wait(uint32_t* sync, int p, uint32_t expec
   __syncthreads();
 }
 
-template <int DT, int PT>
+// SUB virtual workgroups of 256 threads side by side in one physical workgroup of 256 * SUB threads
+// (workgroup `me` of `nw` takes the virtual workgroups SUB * me + sub, + SUB * nw, ...)
+template <int DT, int PT, int SUB>
 __device__ __forceinline__ void chain_fin(const ChainArgs& a, int me, int nw) {
-  for (int64_t vb = me; vb < a.grid[CH_FIN]; vb += nw) {
-    glm_finalize_body<DT, PT>(vb, a.fin_part, a.fin_nblocks, a.fin_npass, a.fin_D, a.fin_P,
-                              a.fin_scale, a.fin_ll, a.fin_gw, a.fin_gb, a.fin_ll_offset);
+  __shared__ double sm[SUB][FIN_GROUPS][FIN_OUT];
+  const int sub = SUB == 1 ? 0 : (int)(threadIdx.x >> 8), tid = (int)(threadIdx.x & 255);
+  for (int64_t base = (int64_t)me * SUB; base < a.grid[CH_FIN]; base += (int64_t)nw * SUB) {
+    // (a virtual workgroup past the end does nothing but keep the barriers aligned)
+    glm_finalize_body<DT, PT>(base + sub, a.fin_part, a.fin_nblocks, a.fin_npass, a.fin_D, a.fin_P,
+                              a.fin_scale, a.fin_ll, a.fin_gw, a.fin_gb, a.fin_ll_offset, tid,
+                              sm[sub]);
     __syncthreads();      // the body's LDS staging is reused by the next virtual workgroup
   }
+}
+template <int SUB>
+__device__ __forceinline__ void chain_fin_any(const ChainArgs& a, int me, int nw) {
+  if (a.fin_DT == 1 && a.fin_PT == 2) chain_fin<1, 2, SUB>(a, me, nw);
+  else if (a.fin_DT == 1 && a.fin_PT == 1) chain_fin<1, 1, SUB>(a, me, nw);
+  else if (a.fin_DT == 2 && a.fin_PT == 1) chain_fin<2, 1, SUB>(a, me, nw);
+  else chain_fin<4, 1, SUB>(a, me, nw);
 }
 
 #define PA_CHAIN_STAMP(i)                                                     \
@@ -147,10 +161,7 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
 
   if (a.have[CH_FIN]) {
     if (!total_wg && me < part_fin) {
-      if (a.fin_DT == 1 && a.fin_PT == 2) chain_fin<1, 2>(a, me, nw);
-      else if (a.fin_DT == 1 && a.fin_PT == 1) chain_fin<1, 1>(a, me, nw);
-      else if (a.fin_DT == 2 && a.fin_PT == 1) chain_fin<2, 1>(a, me, nw);
-      else chain_fin<4, 1>(a, me, nw);
+      chain_fin_any<1>(a, me, nw);
       chain_signal(sync, CH_FIN, (uint32_t)part_fin, a.last == CH_FIN);
     }
     prev = CH_FIN;
@@ -219,27 +230,28 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
 // separate launches: bit-identical results.
 __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
   const bool total_wg = blockIdx.x == gridDim.x - 1;
-  if (!total_wg && threadIdx.x >= 256) return;
   const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x;
   uint32_t* sync = a.sync;
-  // roles: workgroups [0, nsites) = one per mean-field site (they start on their own entries at
-  // once), [nsites, nw) = the finalize phase's workers, the last one = the ELBO total
+  // roles: workgroups [0, nsites) = one per mean-field site (code written for 256 threads: the
+  // surplus waves leave at once; they start on their own entries at once), [nsites, nw) = the
+  // finalize phase's workers (all 1024 threads: four virtual workgroups side by side, so that the
+  // phase is ONE round on a quarter of the chip and 68 arrivals instead of 272), the last one = the
+  // ELBO total
+  if (me < a.tail_nsites && threadIdx.x >= 256) return;
   const int nfw = nw - a.tail_nsites;                       // finalize workers (>= 1 when needed)
-  const int part_fin = a.grid[CH_FIN] < nfw ? a.grid[CH_FIN] : nfw;
+  const int fin_vwg = (a.grid[CH_FIN] + 3) / 4;
+  const int part_fin = fin_vwg < nfw ? fin_vwg : nfw;
   PA_CHAIN_STAMP(0);
-  if (a.have[CH_FIN] && !total_wg && me >= a.tail_nsites) {
+  if (!total_wg && me >= a.tail_nsites) {
     const int fme = me - a.tail_nsites;
-    if (fme < part_fin) {
-      if (a.fin_DT == 1 && a.fin_PT == 2) chain_fin<1, 2>(a, fme, nfw);
-      else if (a.fin_DT == 1 && a.fin_PT == 1) chain_fin<1, 1>(a, fme, nfw);
-      else if (a.fin_DT == 2 && a.fin_PT == 1) chain_fin<2, 1>(a, fme, nfw);
-      else chain_fin<4, 1>(a, fme, nfw);
+    if (a.have[CH_FIN] && fme < part_fin) {
+      chain_fin_any<4>(a, fme, nfw);
       // (the counters are re-armed by the tail's last arrival, below)
       chain_signal(sync, CH_FIN, (uint32_t)part_fin, false);
     }
+    return;
   }
   PA_CHAIN_STAMP(1);
-  if (!total_wg && me >= a.tail_nsites) return;
   constexpr uint32_t KB = (uint32_t)offsetof(ChainArgs, multi);
   constexpr uint32_t KMF = (uint32_t)offsetof(ChainArgs, mf);
   // (the site record is read field by field through the kernarg segment: indexing a local copy of
@@ -278,6 +290,11 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
                               fast_xch, wait, &step);
     PA_CHAIN_STAMP(5);
   } else {
+  double total_acc = 0.0;
+  if (total_wg) {
+    // the entries that do not read what the finalize phase writes, while that phase is running
+    total_acc = multi_sum_partial<float, MULTI_THREADS>(KB, a.fin_dep_mask, 0u);
+  }
   if (!total_wg) {
     // everything that does not depend on the finalize phase runs BEFORE the wait: the gradients of
     // the site's own entries (prior, guide density); what the big kernel contributes (the extra
@@ -293,7 +310,8 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
   if (a.have[CH_FIN]) chain_wait(sync, CH_FIN, (uint32_t)part_fin);
   PA_CHAIN_STAMP(2);
   if (total_wg) {
-    multi_sum_body<float, MULTI_THREADS>(KB, a.multi_out, a.multi_coef_all, a.multi_accumulate);
+    total_acc += multi_sum_partial<float, MULTI_THREADS>(KB, 0u, a.fin_dep_mask);
+    multi_sum_finish<float>(total_acc, a.multi_out, a.multi_coef_all, a.multi_accumulate);
     if (threadIdx.x == 0) step = a.ad_step[0] + 1;
   } else {
     for (int q = 0; q < ts_n; ++q)
@@ -406,6 +424,22 @@ static bool chain_plan_tail(ChainArgs& a) {
   for (int i = 0; i < m; ++i)
     for (int j = i + 1; j < m; ++j)
       if (lo[i] < hi[j] && lo[j] < hi[i]) return false;
+  // which entries read what the finalize phase writes (all of them when a wave of the total's
+  // workgroup owns several entries: the split sum is then not the same sequence of additions)
+  a.fin_dep_mask = 0u;
+  if (a.have[CH_FIN]) {
+    auto in_fin = [&](const void* p) {
+      const float* f = (const float*)p;
+      return p != nullptr &&
+             ((f >= a.fin_ll && f < a.fin_ll + a.fin_P) || (f >= a.fin_gb && f < a.fin_gb + a.fin_P) ||
+              (f >= a.fin_gw && f < a.fin_gw + (int64_t)a.fin_P * a.fin_D));
+    };
+    for (int e = 0; e < a.multi.n; ++e) {
+      const EntryDev& en = a.multi.e[e];
+      if (in_fin(en.v) || in_fin(en.a) || in_fin(en.b) || in_fin(en.m)) a.fin_dep_mask |= 1u << e;
+    }
+    if (a.multi.n > MULTI_THREADS / 64) a.fin_dep_mask = 0xffffffffu;
+  }
   // which sites have the shape site_tail.h does in one pass
   for (int k = 0; k < a.mf_nsites; ++k) {
     const MfSiteDev& s = a.mf.s[k];
@@ -479,7 +513,7 @@ static int chain_launch() {
   if (g_chain_fuse && cu_count() - 1 > CH_MF_SITES && chain_plan_tail(a)) {
     // the sites' workgroups + the finalize workers (as many as that phase has virtual workgroups,
     // within what is co-resident)
-    nw = a.tail_nsites + (a.have[CH_FIN] ? a.grid[CH_FIN] : 0);
+    nw = a.tail_nsites + (a.have[CH_FIN] ? (a.grid[CH_FIN] + 3) / 4 : 0);
     if (nw > cu_count() - 1) nw = cu_count() - 1;
     hipLaunchKernelGGL(chain_tail_kernel, dim3((unsigned)nw + 1), dim3(1024), 0, s, a);
     c.fused += 1;

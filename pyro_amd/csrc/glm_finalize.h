@@ -15,13 +15,15 @@ constexpr int glm_record_floats() { return PT * DT * 1024 + 2 * PT * 32; }
 // through LDS in a fixed order): many small workgroups so that the ~4 MB of partial records are
 // pulled by the whole chip rather than by a few dozen CUs.
 constexpr int FIN_OUT = 8, FIN_GROUPS = 32;
+// (tid = 0..255 within the virtual workgroup `vb`; sm = its FIN_GROUPS x FIN_OUT doubles of LDS: a
+//  1024-thread workgroup of the chained tail runs four virtual workgroups side by side)
 template <int DT, int PT>
 __device__ __forceinline__ void glm_finalize_body(
     int64_t vb, const float* __restrict__ part, int nblocks, int npass, int D, int P, double scale,
-    float* __restrict__ ll, float* __restrict__ gw, float* __restrict__ gb, double ll_offset) {
+    float* __restrict__ ll, float* __restrict__ gw, float* __restrict__ gb, double ll_offset, int tid,
+    double (*sm)[FIN_OUT]) {
   constexpr int REC = glm_record_floats<DT, PT>();
-  __shared__ double sm[FIN_GROUPS][FIN_OUT];
-  const int jj = threadIdx.x % FIN_OUT, s = threadIdx.x / FIN_OUT;
+  const int jj = tid % FIN_OUT, s = tid / FIN_OUT;
   const int64_t J = (int64_t)P * D + 2 * P;
   const int64_t j = vb * FIN_OUT + jj;
   double acc = 0.0;
@@ -81,8 +83,9 @@ template <int DT, int PT>
 __global__ __launch_bounds__(FIN_OUT * FIN_GROUPS) void glm_finalize_kernel(
     const float* __restrict__ part, int nblocks, int npass, int D, int P, double scale,
     float* __restrict__ ll, float* __restrict__ gw, float* __restrict__ gb, double ll_offset) {
+  __shared__ double sm[FIN_GROUPS][FIN_OUT];
   glm_finalize_body<DT, PT>((int64_t)blockIdx.x, part, nblocks, npass, D, P, scale, ll, gw, gb,
-                            ll_offset);
+                            ll_offset, (int)threadIdx.x, sm);
 }
 
 }  // namespace pa

@@ -153,10 +153,14 @@ __device__ __forceinline__ double entry_sum(const EntryDev& e, uint32_t tid, uin
 
 // ONE workgroup of 16 waves: the entries are spread over the waves (several waves per entry when
 // there are fewer than 16), so that all of them are read concurrently.
+// multi_sum_partial: this wave's share of sum_e coef_e * sum(entry e) over the entries selected by
+// (skip_mask, only_mask): bit e of skip_mask set = leave entry e out; only_mask != 0 = only those.
+// The chained tail sums the entries that do not depend on the finalize phase while that phase is
+// still running and the others afterwards -- the same additions in the same order as one call as
+// long as every wave owns at most one entry (n <= NTHREADS / 64; the caller guarantees it).
 template <typename T, int NTHREADS>
-__device__ __forceinline__ void multi_sum_body(uint32_t kbase, T* __restrict__ out, double coef_all,
-                                               int accumulate) {
-  __shared__ double smem[16];
+__device__ __forceinline__ double multi_sum_partial(uint32_t kbase, uint32_t skip_mask,
+                                                    uint32_t only_mask) {
   const int n_entries = kernarg_load<int>(kbase + offsetof(MultiArgs, n));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   constexpr int NW = NTHREADS / 64;
@@ -166,6 +170,7 @@ __device__ __forceinline__ void multi_sum_body(uint32_t kbase, T* __restrict__ o
   for (int k0 = 0; k0 < n_entries; k0 += epr) {
     const int k = k0 + wave / wpe;
     if (k < n_entries && wave / wpe < epr) {
+      if ((skip_mask >> k & 1u) || (only_mask != 0u && !(only_mask >> k & 1u))) continue;
       const EntryDev e = kernarg_load<EntryDev>(kbase + offsetof(MultiArgs, e) + k * sizeof(EntryDev));
       const uint32_t tid = (uint32_t)((wave % wpe) * 64 + lane), nth = (uint32_t)(wpe * 64);
       double s = 0.0;
@@ -173,11 +178,22 @@ __device__ __forceinline__ void multi_sum_body(uint32_t kbase, T* __restrict__ o
       acc += e.coef * s;
     }
   }
+  return acc;
+}
+template <typename T>
+__device__ __forceinline__ void multi_sum_finish(double acc, T* __restrict__ out, double coef_all,
+                                                 int accumulate) {
+  __shared__ double smem[16];
   const double t = block_sum_f64(acc, smem);
   if (threadIdx.x == 0) {
     const double base = accumulate ? (double)*out : 0.0;
     *out = (T)(base + coef_all * t);
   }
+}
+template <typename T, int NTHREADS>
+__device__ __forceinline__ void multi_sum_body(uint32_t kbase, T* __restrict__ out, double coef_all,
+                                               int accumulate) {
+  multi_sum_finish<T>(multi_sum_partial<T, NTHREADS>(kbase, 0u, 0u), out, coef_all, accumulate);
 }
 
 template <typename T>
