@@ -15,10 +15,12 @@ with ONE flat RCCL all-reduce per step; value = world_size * steps / max-over-ra
 
 Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline`.  The timed region replays one
 hipGraph per step; HIP events recorded inside a captured graph do not time the bracketed node on
-ROCm 7.2, so the dominant kernel's duration (`roofline.kernel_ms`) is taken from HIP-event
-brackets around the same kernel, on its launch stream, in eager steps of the same workload run
-right AFTER the timed region (`kernel_ms_source` says so); the rocprofv3 kernel trace of this same
-command, committed under profiles/, gives the in-graph duration (`kernel_ms_rocprof`).
+ROCm 7.2, so the dominant kernel's duration (`roofline.kernel_ms`) is read from the DEVICE's wall
+clock: the kernel itself records its earliest workgroup entry and latest workgroup exit
+(pa_glm_planes_stamps), in 20 replays of the same graph right after the timed region.  Beside it:
+`kernel_ms_eager` (HIP events around the kernel on its launch stream in eager steps) and
+`kernel_ms_rocprof` (the rocprofv3 kernel trace of this same command, committed under profiles/).
+`validated` repeats the headline with pyro.enable_validation(True) (SURVEY 8d asks for both).
 """
 import argparse
 import json
@@ -268,6 +270,8 @@ def main():
     if world > 1:
         optim = pyro.optim.RcclOptimizer(optim)
     use_graph = not args.no_graph
+    # the dominant kernel's own clock stamps (a launch argument: created before the capture)
+    clock = kernels.GlmDeviceClock(dev)
     svi = SVI(examples.logreg_model, guide, optim,
               Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
               hip_graph=use_graph, graph_warmup=2)
@@ -302,12 +306,44 @@ def main():
             kern_ms_list.append(timer.read_last())
     sync()
     elapsed = time.perf_counter() - t0
+    clock_ms = []
     if graphed and not graphed_events:
-        # fall-back: bracket the same kernel in eager steps right after the timed region
+        # the kernel's duration inside the graph, from its own stamps on the device clock
+        for _ in range(20):
+            clock.arm()
+            svi.step(X, y)
+            torch.cuda.synchronize()
+            clock_ms.append(clock.read_ms())
+        clock_ms = [v for v in clock_ms if v == v]
+        # ... and bracketed with HIP events in eager steps of the same workload
         for _ in range(10):
             timer.arm()
             svi._eager_step(X, y)
         torch.cuda.synchronize()
+    validated = None
+    if world == 1 and graphed:
+        # the same measurement with validation switched on (it runs in the eager steps before the
+        # capture; the captured step is the same graph)
+        pyro.enable_validation(True)
+        try:
+            svi_v = SVI(examples.logreg_model, guide, optim,
+                        Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
+                        hip_graph=True, graph_warmup=2)
+            for _ in range(6):
+                svi_v.step(X, y)
+            nv = min(args.steps, 200)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(nv):
+                svi_v.step(X, y)
+            torch.cuda.synchronize()
+            tv = time.perf_counter() - tv
+            validated = {"value": nv / tv, "ms_per_step": tv / nv * 1e3, "steps": nv,
+                         "graphed": bool(svi_v.hip_graph and len(svi_v._graphs) == 1),
+                         "note": "pyro.enable_validation(True): argument / shape / support checks "
+                                 "run in the eager steps that precede the capture"}
+        finally:
+            pyro.enable_validation(False)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -374,7 +410,8 @@ def main():
             others["error"] = "%s: %s" % (type(e).__name__, e)
         pyro.clear_param_store()
     if rank == 0:
-        kern_ms = sum(kern_ms_list) / len(kern_ms_list) if kern_ms_list else timer.mean_ms()
+        kern_ms_eager = sum(kern_ms_list) / len(kern_ms_list) if kern_ms_list else timer.mean_ms()
+        kern_ms = sum(clock_ms) / len(clock_ms) if clock_ms else kern_ms_eager
         gemm_flops = 4.0 * P * N * D                      # two [P,D]x[D,N]-shaped contractions
         alg_bytes = N * (4 * D + 4)                        # X (f32) + y (f32), read once
         achieved_tflops = gemm_flops / (kern_ms * 1e-3) / 1e12
@@ -383,12 +420,12 @@ def main():
         # profiles/: they cannot be collected from inside the run
         traffic = rocprof_ms = None
         traffic_src = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic, rocprof_ms = tj.get("hbm_bytes_per_launch"), tj.get("kernel_ms_in_graph")
-                traffic_src = "profiles/r02_traffic.json (" + tj.get("how", "") + ")"
+                traffic_src = "profiles/r03_traffic.json (" + tj.get("how", "") + ")"
             except Exception:
                 traffic = None
         planes = kernels.glm_planes_of(X) is not None
@@ -411,11 +448,15 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "glm_planes_kernel" if planes else "glm_bernoulli_bf16_kernel",
                          "kernel_ms": kern_ms,
-                         "kernel_ms_source": "HIP events around the kernel on its launch stream in "
-                                             "10 eager steps of the same workload right after the "
-                                             "timed region (events inside a captured graph do not "
-                                             "time their node on ROCm 7.2)",
+                         "kernel_ms_source": ("the kernel's own stamps on the device wall clock "
+                                              "(earliest workgroup entry -> latest workgroup exit), "
+                                              "mean of %d replays of the captured step right after "
+                                              "the timed region" % len(clock_ms)) if clock_ms else
+                                             "HIP events around the kernel on its launch stream",
+                         "kernel_ms_eager": kern_ms_eager,
                          "kernel_ms_rocprof": rocprof_ms,
+                         "frac_rocprof": (alg_bytes / (rocprof_ms * 1e-3) / 1e12 / PEAK_HBM_TBS)
+                         if rocprof_ms else None,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "arithmetic": "f32-equivalent: every f32 operand split exactly into 3 bf16 "
                                        "pieces, the 6 piece products of order >= 2^-16 on the bf16 "
@@ -434,6 +475,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, P, args.cpu_budget_s)
+        if validated is not None:
+            out["validated"] = validated
+        out["step_anatomy"] = {"graph_nodes": "meanfield_sample, glm_planes, chain_tail (GLM finalize "
+                                              "+ ELBO assembly + guide backward + Adam + loss hand-over)",
+                               "chain": getattr(svi, "chain_stats", None),
+                               "chain_fused": getattr(svi, "chain_fused", None)}
         if nuts is not None:
             out["secondary"] = nuts
         if others:

@@ -344,6 +344,11 @@ int pa_glm_planes_tune(int ring_depth, int blocks_per_cu);
  * parallelism): a developer switch.  The workspace holds the fp64 level-1 partials in both modes
  * (pa_glm_bernoulli_planes_workspace). */
 int pa_glm_planes_finalize_mode(int in_kernel);
+/* Measurement hook: later launches of the plane-image kernel record {earliest workgroup entry,
+ * latest workgroup exit} on the device's 100 MHz wall clock into two_u64[0..1] with min / max
+ * atomics (initialise to {UINT64_MAX, 0}); NULL = off.  The kernel's duration inside a captured
+ * hipGraph, where HIP events do not time their node (bench.py roofline.kernel_ms). */
+int pa_glm_planes_stamps(void* two_u64);
 size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P);
 int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const float* w,
                                     const float* b, double scale, int64_t N, int64_t D, int64_t P,

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "pa_glm_pack_planes": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "pa_glm_planes_tune": (c_int, [c_int, c_int]),
     "pa_glm_planes_finalize_mode": (c_int, [c_int]),
+    "pa_glm_planes_stamps": (c_int, [c_void_p]),
     "pa_glm_bernoulli_planes_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_glm_bernoulli_planes_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                                 c_int64, c_int64, c_int64, c_void_p, c_void_p,

@@ -146,6 +146,10 @@ template <typename T> __device__ __forceinline__ T t_digamma(T x) {
   constexpr bool f32 = sizeof(T) == 4;
   const T lim = f32 ? T(6) : T(10);
   T r = T(0);
+  // the arguments here are concentrations / counts + 1: positive.  Anything else (garbage in a row
+  // that a mask removes afterwards: -inf, -1e30 sentinels) must not reach the recurrence -- x + 1
+  // == x below -2^24 (f32) and the loop would never end
+  if (!(x > T(0))) return (T)__builtin_nan("");
   while (x < lim) {
     r -= T(1) / x;
     x += T(1);

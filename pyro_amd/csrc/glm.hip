@@ -534,6 +534,7 @@ static void glm_planes_launch_one(const GlmPlanesPlan& pl, const unsigned char* 
 // the separate launch has the whole chip's memory-level parallelism.  Kept as a measured negative
 // result and for small plates (pa_glm_planes_finalize_mode).
 static int g_planes_fin_mode = 0;
+static unsigned long long* g_planes_stamps = nullptr;      // pa_glm_planes_stamps
 constexpr int GLMF_MAX_PASSES = 32;
 static uint32_t* g_glmf_counters[64] = {nullptr};
 
@@ -712,6 +713,11 @@ int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_
   return pa::check_launch("glm_pack_planes_kernel");
 }
 
+int pa_glm_planes_stamps(void* two_u64) {
+  pa::g_planes_stamps = (unsigned long long*)two_u64;
+  return PA_OK;
+}
+
 int pa_glm_planes_finalize_mode(int in_kernel) {
   PA_REQUIRE(in_kernel == 0 || in_kernel == 1, "glm_planes_finalize_mode: 0 or 1");
   pa::g_planes_fin_mode = in_kernel;
@@ -784,6 +790,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   fin.ll = ll; fin.gw = gw; fin.gb = gb;
   fin.scale = scale; fin.ll_offset = ll_offset;
   fin.D = (int)D; fin.P = (int)P;
+  fin.tstamps = pa::g_planes_stamps;
   if (pl.nb == 3) pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
   else pa::glm_planes_launch_one<4, 2>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
   if (br) (void)hipEventRecord(ev1, s);

@@ -177,6 +177,10 @@ struct GlmFinArgs {
   float *ll, *gw, *gb;
   double scale, ll_offset;
   int D, P;
+  // measurement hook (pa_glm_planes_stamps): {earliest workgroup entry, latest workgroup exit} of the
+  // launch on the 100 MHz wall clock (min / max atomics), or NULL.  The kernel's duration INSIDE a
+  // captured hipGraph, where HIP events do not time their node on ROCm 7.2.
+  unsigned long long* tstamps;
 };
 constexpr int GLMF_GROUPS = 32, GLMF_CNT_STRIDE = 40;
 
@@ -281,6 +285,9 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
 #ifdef PA_GLMP_STAMP
   const uint64_t stamp_entry = wall_clock64();
 #endif
+  if (fin.tstamps != nullptr && threadIdx.x == 0)
+    __hip_atomic_fetch_min(&fin.tstamps[0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
   const int64_t grid = gridDim.x;
   const int64_t first = blockIdx.x;
@@ -617,6 +624,9 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
     (reinterpret_cast<uint64_t*>(part) + (1 << 20) + ((int64_t)blockIdx.x * 4 + wave) * 16)[14] = wall_clock64();
 #endif
   if (fin.counters != nullptr) glmp_finalize_in_kernel<NPT>(fin, part, smem);
+  if (fin.tstamps != nullptr && threadIdx.x == 0)
+    __hip_atomic_fetch_max(&fin.tstamps[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace pa

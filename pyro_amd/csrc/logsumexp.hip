@@ -52,20 +52,31 @@ __global__ __launch_bounds__(256) void lse_fwd_kernel(const LseArgs a, T* __rest
     if (k < a.nterms) rs[k] = a.t[k].s[a.rdim];
   const int64_t K = a.sizes[a.rdim];
   const T ninf = -__builtin_huge_val();
+  // torch.logsumexp semantics at the edges: a NaN term makes the result NaN (a comparison with NaN
+  // is false: without the flag the term would silently drop out and an enumerated model with a NaN
+  // log-factor would report a finite loss and a zero gradient); a +inf term makes it +inf (the
+  // rescaled sum would form exp(inf - inf))
+  const T pinf = __builtin_huge_val();
   T m = ninf, s = T(0);
+  bool has_nan = false, has_pinf = false;
   for (int64_t r = 0; r < K; ++r) {
     T v = T(0);
 #pragma unroll
     for (int k = 0; k < PA_LSE_MAX_TERMS; ++k)
       if (k < a.nterms) v += ((const T*)a.t[k].p)[base[k] + r * rs[k]];
-    if (v > m) {                       // (never taken for v = -inf or NaN-free -inf terms)
+    if (v != v) {
+      has_nan = true;
+    } else if (v == pinf) {
+      has_pinf = true;
+    } else if (v > m) {                // (never taken for v = -inf)
       s = s * lse_exp(m - v) + T(1);   // m = -inf: exp(-inf) = 0
       m = v;
     } else if (v > ninf) {
       s += lse_exp(v - m);
     }
   }
-  out[i] = s > T(0) ? m + lse_log(s) : ninf;
+  const T fin = s > T(0) ? m + lse_log(s) : ninf;
+  out[i] = has_nan ? (T)__builtin_nan("") : (has_pinf ? pinf : fin);
 }
 
 // thread = one frame element
@@ -94,7 +105,10 @@ __global__ __launch_bounds__(256) void lse_bwd_kernel(const LseArgs a, T* __rest
     if (k < a.nterms) v += ((const T*)a.t[k].p)[off[k]];
   const T o = out[kept];
   const T ninf = -__builtin_huge_val();
-  G[j] = (v > ninf && o > ninf) ? g_out[kept] * lse_exp(v - o) : T(0);
+  // NaN in -> NaN out (as autograd through torch.logsumexp); out = +inf: exp(v - inf) = 0 for the
+  // finite terms and NaN for the +inf ones, torch's values
+  if (v != v || o != o) G[j] = (T)__builtin_nan("");
+  else G[j] = (v > ninf && o > ninf) ? g_out[kept] * lse_exp(v - o) : T(0);
 }
 
 static int lse_fill(LseArgs* a, int nterms, const pa_lse_term* terms, int ndim, const int64_t* sizes,

@@ -86,7 +86,7 @@ def _frame_lazy(operands, shape):
     n = 1
     for s_ in shape:
         n *= s_
-    if _ND_MIN_ELEMS <= n < 2 ** 31 and (operands[0].is_cuda or kernels.HOST_TEST_BACKEND) \
+    if _ND_MIN_ELEMS <= n < 2 ** 31 and kernels.on_device(operands[0]) \
             and operands[0].dtype in (torch.float32, torch.float64) and len(shape) > 0:
         infos = [None if o is None else _collapse(o, shape) for o in operands]
         best = None
@@ -110,7 +110,7 @@ def _sum_to(g, like):
         return None
     if g.shape == like.shape:
         return g
-    if g.numel() < _ND_MIN_ELEMS or not (g.is_cuda or kernels.HOST_TEST_BACKEND) \
+    if g.numel() < _ND_MIN_ELEMS or not kernels.on_device(g) \
             or g.dtype not in (torch.float32, torch.float64):
         return g.sum_to_size(like.shape) if like.dim() > 0 or g.dim() > 0 else g
     shape = list(g.shape)
@@ -307,6 +307,12 @@ class _DirichletLogProb(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         value, conc = ctx.saved_tensors
+        if torch.is_grad_enabled():                 # create_graph=True: see _differentiable_grads
+            with torch.enable_grad():
+                lp = torch.distributions.Dirichlet(conc, validate_args=False).log_prob(value)
+                inputs = [t for t, need in zip((value, conc), ctx.needs_input_grad) if need]
+                got = iter(torch.autograd.grad(lp, inputs, g, create_graph=True, allow_unused=True))
+            return tuple(next(got) if need else None for need in ctx.needs_input_grad)
         dv, dc = kernels.dirichlet_log_prob_grad(g, value, conc, ctx.needs_input_grad[0],
                                                  ctx.needs_input_grad[1])
         return (None if dv is None else _sum_to(dv, value),

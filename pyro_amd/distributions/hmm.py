@@ -76,7 +76,7 @@ class DiscreteHMM(TorchDistribution):
         if trans.shape[-3] not in (1, T):
             raise ValueError("transition_logits has {} time steps, the data {}".format(
                 trans.shape[-3], T))
-        if not (obs_logits.is_cuda or kernels.HOST_TEST_BACKEND):
+        if not kernels.on_device(obs_logits):
             raise RuntimeError("pyro_amd: DiscreteHMM.log_prob needs device tensors (there is no "
                                "CPU implementation in this package)")
         fused = K <= 64 and obs_logits.dtype in (torch.float32, torch.float64)

@@ -225,7 +225,7 @@ class AutoNormal(AutoGuide):
                                       constraints.real, event_dim=ed)
             rho = param_unconstrained("{}.scales.{}".format(self.prefix, name), init_scale,
                                       self.scale_constraint, event_dim=ed)
-            if not (loc.is_cuda or kernels.HOST_TEST_BACKEND) or loc.dtype != rho.dtype \
+            if not kernels.on_device(loc) or loc.dtype != rho.dtype \
                     or loc.dtype not in (torch.float32, torch.float64) \
                     or not loc.is_contiguous() or not rho.is_contiguous():
                 return None
@@ -613,7 +613,7 @@ class AutoMultivariateNormal(AutoContinuous):
                                     lambda: torch.eye(d, dtype=self._loc0.dtype,
                                                       device=self._loc0.device),
                                     self.scale_tril_constraint)
-            if (loc.is_cuda or kernels.HOST_TEST_BACKEND) and A.is_contiguous() \
+            if kernels.on_device(loc) and A.is_contiguous() \
                     and loc.dtype in (torch.float32, torch.float64) \
                     and loc.dtype == rho.dtype == A.dtype:
                 return _FusedGuideMVN(loc, rho, A, self._plain_posterior)

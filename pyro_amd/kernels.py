@@ -15,8 +15,10 @@ from ._lib import NULL_VIEW, Unsupported, View2D, check  # noqa: F401
 _DTYPES = {torch.float32: _lib.PA_F32, torch.float64: _lib.PA_F64}
 
 
-# True only while tests/oracle_backend.py is installed (host-logic tests on a machine without a GPU)
-HOST_TEST_BACKEND = False
+def on_device(t):
+    """Does ``t`` live where the HIP kernels run?  The fused routes are taken for such tensors only;
+    everything else goes through the torch operators."""
+    return t.is_cuda
 
 
 def _require_gpu(*tensors):
@@ -658,6 +660,30 @@ def glm_planes_finalize_mode(in_kernel=False):
     finalize launch (default; a phase of the chained tail in a captured step) or inside the kernel
     (bit-identical, measured slower at large plates)."""
     check(_lib.load().pa_glm_planes_finalize_mode(int(bool(in_kernel))))
+
+
+class GlmDeviceClock:
+    """Duration of the plane-image GLM kernel from the device's own wall clock (pa_glm_planes_stamps):
+    works inside a captured hipGraph.  ``arm()`` before a launch / replay, ``read_ms()`` after a
+    device synchronise.  Must be created BEFORE a step is captured (the pointer is a launch
+    argument)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(2, dtype=torch.int64, device=device)
+        check(_lib.load().pa_glm_planes_stamps(ctypes.c_void_p(self.buf.data_ptr())))
+        self._init = torch.tensor([-1, 0], dtype=torch.int64, device=device)   # {UINT64_MAX, 0}
+
+    def arm(self):
+        self.buf.copy_(self._init)
+
+    def read_ms(self):
+        lo, hi = self.buf.tolist()
+        if lo == -1 or hi == 0:
+            return float("nan")
+        return (hi - lo) / 100e6 * 1e3
+
+    def close(self):
+        check(_lib.load().pa_glm_planes_stamps(None))
 
 
 def glm_pack_planes(X, out=None):

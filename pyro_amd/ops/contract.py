@@ -24,7 +24,6 @@ import torch
 from .. import kernels
 
 
-_FUSED_NEEDS_DEVICE = True    # tests lift this to drive the fused route with the oracle kernel
 FUSED_CHAIN = True            # HMM-shaped components go through pa_logchain_fwd_bwd
 
 
@@ -147,7 +146,7 @@ def _try_fused_chain(terms, sum_ids):
             return None
         proto = t.tensor if proto is None else proto
     if proto.dtype not in (torch.float32, torch.float64) or \
-            not (proto.is_cuda or kernels.HOST_TEST_BACKEND):
+            not kernels.on_device(proto):
         return None
     adj = {v: set() for v in sum_ids}
     for t in terms:
@@ -230,6 +229,19 @@ class _LogSumExpTerms(torch.autograd.Function):
     def backward(ctx, g):
         from ..distributions.fused import _sum_to
         out, terms = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        if torch.is_grad_enabled():
+            # create_graph=True (Hessians, Newton steps through an enumerated model): the kernel's
+            # gradients carry no autograd history, so the first-order gradient is re-derived from
+            # the same expression written with torch operators and stays differentiable
+            with torch.enable_grad():
+                total = terms[0].expand(ctx.frame)
+                for t in terms[1:]:
+                    total = total + t
+                lse = torch.logsumexp(total, ctx.rdim)
+                inputs = [t for t, need in zip(terms, ctx.needs_input_grad[2:]) if need]
+                got = iter(torch.autograd.grad(lse, inputs, g, create_graph=True, allow_unused=True))
+            return (None, None) + tuple(next(got) if need else None
+                                        for need in ctx.needs_input_grad[2:])
         G = kernels.logsumexp_terms_grad(terms, ctx.frame, ctx.rdim, out, g)
         grads = [_sum_to(G, t) if need else None
                  for t, need in zip(terms, ctx.needs_input_grad[2:])]
@@ -246,7 +258,7 @@ def _sumproduct(terms, sum_ids):
         x0 = aligned[0]
         ok = all(isinstance(x, torch.Tensor) and x.dtype == x0.dtype and x.device == x0.device
                  for x in aligned) and x0.dtype in (torch.float32, torch.float64) \
-            and (x0.is_cuda or kernels.HOST_TEST_BACKEND)
+            and kernels.on_device(x0)
         if ok:
             nd = max(x.dim() for x in aligned)
             # right-align the plate blocks: every term is [its ids..., *plates]; pad between the
@@ -316,7 +328,7 @@ def _try_fused_lda(terms, sum_ids, contract_frames):
     (tid,) = sum_ids
     lz, a = lazy[0].lazy, dense[0].tensor
     if lazy[0].ids != (tid,) or dense[0].ids != (tid,) or lz.index.dim() != 2 \
-            or (_FUSED_NEEDS_DEVICE and not a.is_cuda):
+            or not kernels.on_device(a):
         return None
     plate_dims = {f.dim for f in contract_frames}
     if plate_dims != {-1, -2} or {f.dim for f in lazy[0].ordinal} != {-1, -2}:

@@ -46,7 +46,8 @@ def install_out_of_scope():
         return type(name, (), {"__init__": __init__})
 
     for name in ("EnergyDistance", "TraceTailAdaptive_ELBO", "RenyiELBO", "ReweightedWakeSleep",
-                 "TraceTMC_ELBO", "JitTraceTMC_ELBO", "SVGD", "CSIS", "Importance", "SMCFilter", "Trace_MMD",
+                 "TraceTMC_ELBO", "JitTraceTMC_ELBO", "JitTrace_ELBO", "JitTraceGraph_ELBO",
+                 "JitTraceEnum_ELBO", "JitTraceMeanField_ELBO", "SVGD", "CSIS", "Importance", "SMCFilter", "Trace_MMD",
                  "MHResampler", "WeighedPredictive", "Resampler", "RBFSteinKernel", "SMCFailed",
                  "EmpiricalMarginal", "TracePosterior", "TracePredictive", "DiscreteHMCGibbs",
                  "EasyGuide", "BetaBinomialPair", "GammaPoissonPair", "UnitJacobianReparam"):

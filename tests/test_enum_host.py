@@ -28,8 +28,10 @@ def _cpu_backend(oracle_backend):
 
 
 def test_lda_generic_contraction(_cpu_backend, monkeypatch):
-    # CPU tensors never take the fused-kernel route (it requires device tensors): this exercises
-    # the generic message passing (broadcast add + logsumexp + plate sums)
+    # the generic message passing (broadcast add + logsumexp + plate sums) with the LDA-shaped
+    # leaf's fused route switched off, as tests/test_enum_gpu.py does on the device
+    import pyro_amd.ops.contract as c
+    monkeypatch.setattr(c, "_try_fused_lda", lambda *a: None)
     ec.run_lda(load("enum"), torch.device("cpu"), monkeypatch, expect_fused=False)
 
 
@@ -41,8 +43,6 @@ def test_gmm(_cpu_backend, monkeypatch, sub):
 def test_lda_fused_route_with_oracle_kernel(_cpu_backend, monkeypatch):
     """Force the fused route on CPU tensors (oracle LDA kernel): checks the pattern matcher, the
     (table, index) extraction and the autograd wiring of _LdaFactor."""
-    import pyro_amd.ops.contract as c
-    monkeypatch.setattr(c, "_FUSED_NEEDS_DEVICE", False)
     ec.run_lda(load("enum"), torch.device("cpu"), monkeypatch, expect_fused=True)
 
 

@@ -926,6 +926,51 @@ def test_logsumexp_terms(gpu, dtype, case):
     np.testing.assert_allclose(G.sum(rdim).cpu().numpy()[fin], g_out[fin], rtol=tol * 50, atol=tol * 50)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_logsumexp_terms_nan_and_inf_follow_torch(gpu, dtype):
+    """A NaN log-factor must poison the result (not drop out), two +inf terms give +inf (not NaN),
+    forward and backward as autograd through torch.logsumexp does."""
+    k = _k()
+    x = torch.randn((6, 5), dtype=dtype, device=gpu)
+    y = torch.randn((1, 5), dtype=dtype, device=gpu)
+    x[0, 1] = float("nan")
+    x[1, 2] = float("inf")
+    x[2, 2] = float("inf")
+    x[3, 3] = float("inf")
+    x[:, 4] = -float("inf")
+    out = k.logsumexp_terms([x, y], (6, 5), 0)
+    xr, yr = x.clone().requires_grad_(True), y.clone()
+    ref = torch.logsumexp(xr + yr, 0)
+    assert torch.equal(torch.isnan(out), torch.isnan(ref))
+    assert torch.equal(out[~torch.isnan(ref)], ref[~torch.isnan(ref)].detach()) or \
+        torch.allclose(out[~torch.isnan(ref)], ref[~torch.isnan(ref)].detach(), rtol=1e-5)
+    g = torch.ones(5, dtype=dtype, device=gpu)
+    G = k.logsumexp_terms_grad([x, y], (6, 5), 0, out, g)
+    ref.backward(g)
+    rg = xr.grad
+    # column 4 (all -inf): torch's own backward gives NaN there (exp(-inf + inf)); the kernel's 0 is
+    # the convention of the sum-product (an impossible assignment has no posterior weight)
+    cols = [0, 1, 2, 3]
+    assert torch.equal(torch.isnan(G[:, cols]), torch.isnan(rg[:, cols]))
+    ok = ~torch.isnan(rg[:, cols])
+    assert torch.allclose(G[:, cols][ok], rg[:, cols][ok], rtol=1e-5, atol=1e-7)
+    assert (G[:, 4] == 0).all()
+
+
+def test_digamma_of_garbage_terminates_with_nan(gpu):
+    """Gamma / Beta / Poisson gradients are computed before masking: a -inf or -1e30 sentinel in a
+    masked-out row must give NaN, not an endless recurrence."""
+    k = _k()
+    for dtype in (torch.float32, torch.float64):
+        conc = torch.tensor([[2.0, -float("inf"), -1e30, 0.0]], dtype=dtype, device=gpu)
+        rate = torch.ones_like(conc)
+        v = torch.full_like(conc, 0.5)
+        g = torch.ones_like(conc)
+        dv, da, db = k.dist_log_prob_grad(6, g, v, conc, rate, None, 1.0, 1, 4, (True, True, True))
+        torch.cuda.synchronize()
+        assert torch.isfinite(da[0, 0]) and torch.isnan(da[0, 1:]).all()
+
+
 def test_fused_sumproduct_equals_torch_route(gpu):
     """ops.contract._sumproduct through pa_logsumexp_terms against its own torch route (aligned adds
     + torch.logsumexp), values and the gradients of every term (reduced to the term's shape)."""
