@@ -324,6 +324,30 @@ int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, con
                              float* ll, float* gw, float* gb, void* workspace,
                              size_t workspace_bytes, pa_stream_t stream);
 
+/* ---- the hierarchical GLM site on the plane image (BASELINE config 5) -------------------------
+ * Rows sorted by group, cut into segments seg[nseg][3] = {row_begin, row_end, group} (device
+ * int64; as pa_glm_bernoulli_grouped_fwd_bwd).  The image places every segment on a super-tile
+ * (64-row) boundary: segment s owns the super-tiles [st_off[s], st_off[s+1]) (device int64[nseg+1],
+ * st_off[s+1] - st_off[s] = ceil(rows_s / 64), nst_total = st_off[nseg]); the observations y are
+ * stored with it in the same padded row order, so y is part of the image (re-pack when y changes).
+ * pa_glm_bernoulli_grouped_planes_fwd_bwd = pa_glm_bernoulli_grouped_fwd_bwd (same outputs:
+ * ll[P], gw[P,G,D], gb[P]; no mask) streaming the image instead of re-splitting X every step:
+ * one workgroup per segment with w[:, group, :].  Replaces, per ELBO-gradient step, the gather
+ * w[..., g_n, :] + matmul + Bernoulli.log_prob + scale_and_mask + sum and their autograd duals
+ * (pyro/poutine/trace_struct.py:264-278, pyro/poutine/subsample_messenger.py:159-174 for the scale). */
+size_t pa_glm_grouped_planes_bytes(int64_t nst_total, int64_t D);
+int pa_glm_pack_planes_grouped(const float* X, const float* y, int64_t N, int64_t D,
+                               const int64_t* seg, const int64_t* st_off, int64_t nseg,
+                               int64_t nst_total, void* planes, size_t planes_bytes,
+                               pa_stream_t stream);
+size_t pa_glm_bernoulli_grouped_planes_workspace(int64_t nseg, int64_t P);
+int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, const float* b,
+                                            double scale, int64_t N, int64_t D, int64_t P, int64_t G,
+                                            const int64_t* seg, const int64_t* st_off, int64_t nseg,
+                                            const int64_t* group_seg_off, int64_t nst_total,
+                                            float* ll, float* gw, float* gb, void* workspace,
+                                            size_t workspace_bytes, pa_stream_t stream);
+
 /* The same pass with the design matrix kept in HBM as its exact 3-way bf16 decomposition
  * (x = x1 + x2 + x3, the split the matrix-core kernel of variant 0 performs on the fly), packed ONCE
  * per data set by pa_glm_pack_planes into a tile image (per 32-row tile three [32][32] bf16 planes,

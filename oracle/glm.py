@@ -92,3 +92,32 @@ def glm_plane_image(X):
         for s in range(4):
             img[:, pl, r, s ^ ((r >> 2) & 3), :] = bits[:, r, s, :]
     return img.reshape(tiles, 3, 1024)
+
+
+def glm_grouped_plane_image(X, y, seg):
+    """(uint16 tile image, float32 padded observations) of pa_glm_pack_planes_grouped: ``seg`` =
+    rows [a, e) of one group each (kernels.GroupSegments.seg); every segment starts on a 64-row
+    super-tile boundary, its last super-tile is padded with zero rows; the tile format is
+    glm_plane_image's.  Restates the layout rule of the reference-side gather w[..., g_n, :] for
+    rows sorted by group: nothing of the reference is numeric here, the image
+    is a bit-exact re-arrangement of X's exact bf16 split."""
+    X = np.asarray(X, dtype=np.float32)
+    y = np.asarray(y, dtype=np.float32)
+    D = X.shape[1]
+    blocks, yb = [], []
+    for a, e, _ in np.asarray(seg).reshape(-1, 3):
+        a, e = int(a), int(e)
+        rows = e - a
+        pad = -(-rows // 64) * 64
+        blk = np.zeros((pad, D), dtype=np.float32)
+        blk[:rows] = X[a:e]
+        yv = np.zeros(pad, dtype=np.float32)
+        yv[:rows] = y[a:e]
+        blocks.append(blk)
+        yb.append(yv)
+    if not blocks:
+        return np.zeros((0, 3, 1024), dtype=np.uint16), np.zeros(0, dtype=np.float32)
+    Xp = np.concatenate(blocks)
+    img = glm_plane_image(Xp)[: Xp.shape[0] // 32]       # (glm_plane_image pads to 128-row groups)
+    return img, np.concatenate(yb)
+

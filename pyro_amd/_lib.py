@@ -112,6 +112,14 @@ _SIGNATURES = {
                                          c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
     "pa_glm_planes_bytes": (c_size_t, [c_int64, c_int64]),
+    "pa_glm_grouped_planes_bytes": (c_size_t, [c_int64, c_int64]),
+    "pa_glm_pack_planes_grouped": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                           c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "pa_glm_bernoulli_grouped_planes_workspace": (c_size_t, [c_int64, c_int64]),
+    "pa_glm_bernoulli_grouped_planes_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64,
+                                                        c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                                        c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "pa_glm_pack_planes": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "pa_glm_planes_tune": (c_int, [c_int, c_int]),
     "pa_glm_planes_finalize_mode": (c_int, [c_int]),

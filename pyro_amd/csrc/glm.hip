@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void glm_grouped_finalize_gw_kernel(
 template <int DT, int PT>
 __global__ __launch_bounds__(256) void glm_grouped_finalize_scalar_kernel(
     const float* __restrict__ part, int nseg, int P, double scale, float* __restrict__ ll,
-    float* __restrict__ gb) {
+    float* __restrict__ gb, double ll_offset) {
   constexpr int REC = glm_record_floats<DT, PT>();
   __shared__ double smem[16];
   const int which = blockIdx.x >= (unsigned)P ? 1 : 0;       // 0: ll, 1: gb
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void glm_grouped_finalize_scalar_kernel(
   double acc = 0.0;
   for (int sgi = threadIdx.x; sgi < nseg; sgi += 256) acc += (double)base[(int64_t)sgi * REC];
   const double t = block_sum_f64(acc, smem);
-  if (threadIdx.x == 0) (which ? gb : ll)[p] = (float)(t * scale);
+  if (threadIdx.x == 0) (which ? gb : ll)[p] = (float)((t + (which ? 0.0 : ll_offset)) * scale);
 }
 
 template <int DT, int PT>
@@ -480,7 +480,7 @@ static int glm_grouped_launch(const float* X, const float* y, const float* w, co
   hipLaunchKernelGGL((glm_grouped_finalize_gw_kernel<DT, PT>), dim3((unsigned)((J + 255) / 256)),
                      dim3(256), 0, s, part, group_seg_off, nseg, D, P, G, scale, gw);
   hipLaunchKernelGGL((glm_grouped_finalize_scalar_kernel<DT, PT>), dim3((unsigned)(2 * P)),
-                     dim3(256), 0, s, part, nseg, P, scale, ll, gb);
+                     dim3(256), 0, s, part, nseg, P, scale, ll, gb, 0.0);
   return check_launch("glm_grouped_finalize");
 }
 
@@ -512,21 +512,6 @@ static GlmPlanesPlan glm_planes_plan(int64_t N, int64_t P) {
   return pl;
 }
 
-template <int NB, int OCC>
-static void glm_planes_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
-                                  const float* w, const float* b, int64_t N, int D, int P,
-                                  float* part, const GlmFinArgs& fin, hipStream_t s) {
-  auto k = glm_planes_kernel<2, NB, OCC>;
-  constexpr int lds = GlmPlCfg<2, NB>::LDS_BYTES;
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
-                     b, N, D, P, pl.nst, part, cu_count(), fin);
-}
-
-// ---- in-kernel finalize (glm_planes.h): the arrival counters --------------------------------------
-// One zeroed block per device, allocated the first time a plane image is packed (never inside a
-// stream capture) and kept: launches leave the counters zero.  One plane-image launch per device at
-// a time (stream order), as everywhere in this library.
 // 0 (default) = the stand-alone finalize launch (272 workgroups pull the records in parallel: ~6 us,
 // or a phase of the chained tail); 1 = inside the kernel: measured SLOWER on the MI355X (the GLM
 // kernel 68 -> 105 us at the headline size): the two serial last-arriver sums are made by ONE
@@ -535,6 +520,41 @@ static void glm_planes_launch_one(const GlmPlanesPlan& pl, const unsigned char* 
 // result and for small plates (pa_glm_planes_finalize_mode).
 static int g_planes_fin_mode = 0;
 static unsigned long long* g_planes_stamps = nullptr;      // pa_glm_planes_stamps
+
+template <int NB, int OCC>
+static void glm_planes_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
+                                  const float* w, const float* b, int64_t N, int D, int P,
+                                  float* part, const GlmFinArgs& fin, hipStream_t s) {
+  auto k = glm_planes_kernel<2, NB, OCC>;
+  constexpr int lds = GlmPlCfg<2, NB>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
+                     b, N, D, P, pl.nst, part, cu_count(), fin, GlmGroupArgs{nullptr, nullptr, 1});
+}
+
+// the hierarchical variant: one workgroup per segment
+static void glm_planes_launch_grouped(int nseg, int npass, const unsigned char* img,
+                                      const float* y_img, const float* w, const float* b, int64_t N,
+                                      int D, int P, int64_t nst_total, float* part,
+                                      const GlmGroupArgs& grp, hipStream_t s) {
+  auto k = glm_planes_kernel<2, 3, 3, true>;
+  constexpr int lds = GlmPlCfg<2, 3>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  GlmFinArgs fin;
+  fin.counters = nullptr;
+  fin.part64 = nullptr;
+  fin.ll = fin.gw = fin.gb = nullptr;
+  fin.scale = fin.ll_offset = 0.0;
+  fin.D = D; fin.P = P;
+  fin.tstamps = g_planes_stamps;
+  hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)npass), dim3(256), lds, s, img, y_img, w, b, N,
+                     D, P, nst_total, part, cu_count(), fin, grp);
+}
+
+// ---- in-kernel finalize (glm_planes.h): the arrival counters --------------------------------------
+// One zeroed block per device, allocated the first time a plane image is packed (never inside a
+// stream capture) and kept: launches leave the counters zero.  One plane-image launch per device at
+// a time (stream order), as everywhere in this library.
 constexpr int GLMF_MAX_PASSES = 32;
 static uint32_t* g_glmf_counters[64] = {nullptr};
 
@@ -683,6 +703,90 @@ int pa_glm_bernoulli_grouped_fwd_bwd(const float* X, const float* y, const float
   PA_GLMG_CASE(4, 1)
 #undef PA_GLMG_CASE
   return pa::fail(PA_ERR_UNSUPPORTED, "glm_grouped: no kernel for DT=%d PT=%d", DT, PT);
+}
+
+size_t pa_glm_grouped_planes_bytes(int64_t nst_total, int64_t D) {
+  if (nst_total < 0 || D < 1 || D > 32) return 0;
+  // the tile image, then the observations in the image's padded row order
+  return (size_t)nst_total * 2 * pa::GLMP_TILE + (size_t)nst_total * 64 * sizeof(float);
+}
+
+int pa_glm_pack_planes_grouped(const float* X, const float* y, int64_t N, int64_t D,
+                               const int64_t* seg, const int64_t* st_off, int64_t nseg,
+                               int64_t nst_total, void* planes, size_t planes_bytes,
+                               pa_stream_t stream) {
+  PA_REQUIRE(N >= 0 && D >= 1 && D <= 32 && nseg >= 0 && nst_total >= 0,
+             "glm_pack_planes_grouped: bad shape N=%lld D=%lld nseg=%lld", (long long)N, (long long)D,
+             (long long)nseg);
+  PA_REQUIRE(nseg < (1 << 30), "glm_pack_planes_grouped: too many segments");
+  if (nst_total == 0 || nseg == 0) return PA_OK;
+  PA_REQUIRE(X && y && seg && st_off && planes, "glm_pack_planes_grouped: NULL pointer");
+  PA_REQUIRE(planes_bytes >= pa_glm_grouped_planes_bytes(nst_total, D),
+             "glm_pack_planes_grouped: image buffer too small");
+  PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_pack_planes_grouped: unaligned image");
+  unsigned char* img = (unsigned char*)planes;
+  float* y_img = (float*)(img + (size_t)nst_total * 2 * pa::GLMP_TILE);
+  const int64_t ntiles = nst_total * 2;
+  hipLaunchKernelGGL(pa::glm_pack_planes_grouped_kernel, dim3((unsigned)((ntiles * 128 + 255) / 256)),
+                     dim3(256), 0, pa::as_stream(stream), X, y, (int)D, seg, st_off, (int)nseg, ntiles,
+                     img, y_img);
+  return pa::check_launch("glm_pack_planes_grouped_kernel");
+}
+
+size_t pa_glm_bernoulli_grouped_planes_workspace(int64_t nseg, int64_t P) {
+  if (nseg < 0 || P < 1) return 0;
+  const size_t npass = (size_t)((P + 63) / 64);
+  return (size_t)(nseg < 1 ? 1 : nseg) * npass * (2 * 1024 + 2 * 2 * 32) * sizeof(float);
+}
+
+int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, const float* b,
+                                            double scale, int64_t N, int64_t D, int64_t P, int64_t G,
+                                            const int64_t* seg, const int64_t* st_off, int64_t nseg,
+                                            const int64_t* group_seg_off, int64_t nst_total,
+                                            float* ll, float* gw, float* gb, void* workspace,
+                                            size_t workspace_bytes, pa_stream_t stream) {
+  PA_REQUIRE(N >= 0 && D >= 1 && P >= 1 && G >= 1 && nseg >= 0 && nst_total >= 0,
+             "glm_grouped_planes: bad shape N=%lld D=%lld P=%lld G=%lld nseg=%lld", (long long)N,
+             (long long)D, (long long)P, (long long)G, (long long)nseg);
+  if (D > 32)
+    return pa::fail(PA_ERR_UNSUPPORTED, "glm_grouped_planes: the plane image holds D <= 32 (got %lld)",
+                    (long long)D);
+  PA_REQUIRE(nseg < (1 << 30) && P < (1 << 20) && G < (1 << 24), "glm_grouped_planes: shape too large");
+  PA_REQUIRE(w && ll && gw && gb, "glm_grouped_planes: NULL parameter/output pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (N == 0 || nseg == 0 || nst_total == 0) {
+    hipError_t e1 = hipMemsetAsync(ll, 0, (size_t)P * 4, s);
+    hipError_t e2 = hipMemsetAsync(gw, 0, (size_t)P * G * D * 4, s);
+    hipError_t e3 = hipMemsetAsync(gb, 0, (size_t)P * 4, s);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+      return pa::fail(PA_ERR_LAUNCH, "glm_grouped_planes: memset failed");
+    return PA_OK;
+  }
+  PA_REQUIRE(planes && seg && st_off && group_seg_off, "glm_grouped_planes: NULL data pointer");
+  PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_grouped_planes: unaligned image");
+  PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_grouped_planes_workspace(nseg, P),
+             "glm_grouped_planes: workspace too small");
+  const unsigned char* img = (const unsigned char*)planes;
+  const float* y_img = (const float*)(img + (size_t)nst_total * 2 * pa::GLMP_TILE);
+  float* part = (float*)workspace;
+  const int npass = (int)((P + 63) / 64);
+  hipEvent_t ev0, ev1;
+  const bool br = pa::take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
+  pa::glm_planes_launch_grouped((int)nseg, npass, img, y_img, w, b, N, (int)D, (int)P, nst_total, part,
+                                pa::GlmGroupArgs{seg, st_off, (int)G}, s);
+  if (br) (void)hipEventRecord(ev1, s);
+  int rc = pa::check_launch("glm_planes_kernel<grouped>");
+  if (rc != PA_OK) return rc;
+  // the padding rows of every segment's last super-tile added log2(2) = 1 each to the log2(1 + e)
+  // sum of every particle: ln2 per row back in
+  const double ll_offset = (double)(nst_total * 64 - N) * 0.6931471805599453;
+  const int64_t J = (int64_t)P * G * D;
+  hipLaunchKernelGGL((pa::glm_grouped_finalize_gw_kernel<1, 2>), dim3((unsigned)((J + 255) / 256)),
+                     dim3(256), 0, s, part, group_seg_off, (int)nseg, (int)D, (int)P, (int)G, scale, gw);
+  hipLaunchKernelGGL((pa::glm_grouped_finalize_scalar_kernel<1, 2>), dim3((unsigned)(2 * P)),
+                     dim3(256), 0, s, part, (int)nseg, (int)P, scale, ll, gb, ll_offset);
+  return pa::check_launch("glm_grouped_finalize");
 }
 
 size_t pa_glm_planes_bytes(int64_t N, int64_t D) {

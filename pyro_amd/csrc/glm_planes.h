@@ -56,6 +56,45 @@ __global__ __launch_bounds__(256) void glm_pack_planes_kernel(const float* __res
   *reinterpret_cast<uint4*>(q + 2 * GLMP_PLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
 }
 
+// The hierarchical variant (BASELINE config 5): rows are sorted by group and cut into segments
+// {row_begin, row_end, group} (kernels.GroupSegments); in the image every segment starts on a
+// super-tile (64-row) boundary -- segment s owns the super-tiles [st_off[s], st_off[s + 1]), its last
+// one padded with zero rows -- so that a workgroup streams one segment with one group's weights.
+// The observations travel in the same padded row order (y_img: zeros in the padding).
+__global__ __launch_bounds__(256) void glm_pack_planes_grouped_kernel(
+    const float* __restrict__ X, const float* __restrict__ y, int D, const int64_t* __restrict__ seg,
+    const int64_t* __restrict__ st_off, int nseg, int64_t ntiles, unsigned char* __restrict__ img,
+    float* __restrict__ y_img) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ntiles * 128) return;
+  const int64_t T = idx >> 7, st = T >> 1;
+  const int r = (int)(idx >> 2) & 31, sl = (int)idx & 3;
+  // the segment that owns super-tile st: the last s with st_off[s] <= st
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (st_off[mid] <= st) lo = mid;
+    else hi = mid - 1;
+  }
+  const int64_t a = seg[3 * lo], e = seg[3 * lo + 1];
+  const int64_t row = a + (T - 2 * st_off[lo]) * 32 + r;
+  const bool ok = row < e;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int d = 8 * sl + j;
+    v[j] = (ok && d < D) ? X[row * D + d] : 0.0f;
+  }
+  uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p1[j], p2[j], p3[j]);
+  unsigned char* q = img + T * GLMP_TILE + glmp_slot_ofs(r, sl);
+  *reinterpret_cast<uint4*>(q) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+  *reinterpret_cast<uint4*>(q + GLMP_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+  *reinterpret_cast<uint4*>(q + 2 * GLMP_PLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+  if (sl == 0) y_img[T * 32 + r] = ok ? y[row] : 0.0f;
+}
+
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
 
 // split_pair of glm_bf16.h written on scalars (same roundings, same bits): two v_sub_f32 per level
@@ -268,11 +307,21 @@ __device__ __forceinline__ void glmp_finalize_in_kernel(const GlmFinArgs& f, con
     __hip_atomic_store(&cnt[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int NPT, int NB, int OCC>
+// GROUPED: blockIdx.x = a segment of one group's rows (seg / st_off as in the pack kernel, y = the
+// padded observation image): the workgroup walks the segment's own super-tiles with that group's
+// weights w[p, group, :] and its partial record belongs to the group.
+struct GlmGroupArgs {
+  const int64_t* seg;       // [nseg][3] {row_begin, row_end, group}
+  const int64_t* st_off;    // [nseg + 1]
+  int G;
+};
+
+template <int NPT, int NB, int OCC, bool GROUPED = false>
 __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
     const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
-    int64_t nst, float* __restrict__ part, int prio_cus, const GlmFinArgs fin) {
+    int64_t nst, float* __restrict__ part, int prio_cus, const GlmFinArgs fin,
+    const GlmGroupArgs grp) {
   using C = GlmPlCfg<NPT, NB>;
   constexpr int NRT = C::NRT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS, WPL = C::WPL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -289,9 +338,23 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
     __hip_atomic_fetch_min(&fin.tstamps[0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
-  const int64_t grid = gridDim.x;
-  const int64_t first = blockIdx.x;
-  const int64_t my_count = first < nst ? (nst - first + grid - 1) / grid : 0;
+  // the super-tiles this workgroup walks (first, first + grid, ...: my_count of them, prefetches
+  // clamped below st_end), the rows they hold counted from super-tile row_st0 (n_rows of them are
+  // real), and the weights' row stride
+  int64_t grid = gridDim.x, first = blockIdx.x, st_end = nst, row_st0 = 0, n_rows = N;
+  int64_t my_count = first < nst ? (nst - first + grid - 1) / grid : 0;
+  int64_t w_stride = D;
+  if constexpr (GROUPED) {
+    const int64_t sg = blockIdx.x;
+    first = grp.st_off[sg];
+    st_end = grp.st_off[sg + 1];
+    my_count = st_end - first;
+    grid = 1;
+    row_st0 = first;
+    n_rows = grp.seg[3 * sg + 1] - grp.seg[3 * sg];
+    w += grp.seg[3 * sg + 2] * D;                       // w[p, group, :]
+    w_stride = (int64_t)grp.G * D;
+  }
 
   // ---- DMA of super-tile `st` (clamped: prefetches past the end re-read the last one) into ring
   //      slot `bi`: this wave's PW pieces of the image + its 32 observations --------------------
@@ -299,13 +362,14 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
 #ifdef PA_GLMP_ABL_NODMA
     return;
 #endif
-    const int64_t stc = st < nst ? st : nst - 1;
+    const int64_t stc = st < st_end ? st : st_end - 1;
     const unsigned char* src = img + stc * ST_BYTES + (wave * PW) * 1024 + lane * 16;
     const uint32_t dst = lds_base + C::OFS_RING + bi * ST_BYTES + (wave * PW) * 1024;
 #pragma unroll
     for (int k = 0; k < PW; ++k) dma16(src + k * 1024, dst + k * 1024);
     int64_t row = (stc * NRT + rt) * 32 + l31;
-    row = row < N ? row : N - 1;
+    // (GROUPED: y is the padded observation image, every row of every super-tile exists)
+    if constexpr (!GROUPED) row = row < N ? row : N - 1;
     dma4(y + row, lds_base + C::OFS_Y + (bi * 4 + wave) * 256);
   };
 
@@ -322,7 +386,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
       const int d = 8 * s + j;
       // log2(e) rides in W and b (one f32 rounding each): the accumulator then holds
       // l2 = l * log2(e), the argument of the hardware exp2 / the natural scale of log2
-      v[j] = (p < P && d < D) ? w[(int64_t)p * D + d] * GLMP_LOG2E : 0.0f;
+      v[j] = (p < P && d < D) ? w[(int64_t)p * w_stride + d] * GLMP_LOG2E : 0.0f;
     }
     uint32_t p1[4], p2[4], p3[4];
 #pragma unroll
@@ -385,7 +449,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_kernel(
   // finalize step.  The wave's 32 observations of ring slot b become y - 1/2 in place.
   auto prep_rows = [&](int b, int64_t st_) -> bool {
     float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + (b * 4 + wave) * 256);
-    const int64_t rows_left = N - (st_ * NRT + rt) * 32;        // scalar
+    const int64_t rows_left = n_rows - ((st_ - row_st0) * NRT + rt) * 32;        // scalar
     const bool okr = (int64_t)l31 < rows_left;
     if (lane < 32) ys_[lane] = okr ? ys_[lane] - 0.5f : 0.0f;
     return okr;

@@ -747,6 +747,14 @@ def glm_planes_revalidate():
             off, shape, stride = ent[4]
             glm_pack_planes(base.as_strided(shape, stride, off), out=ent[2])
             ent[1] = base._version
+    for segs in list(_grouped_with_image):
+        ent = segs._planes
+        if ent is None or ent[4] is None:
+            continue
+        X, y = ent[0](), ent[2]()
+        if X is not None and y is not None and (ent[1] != X._version or ent[3] != y._version):
+            glm_pack_planes_grouped(X, y, segs, out=ent[4])
+            ent[1], ent[3] = X._version, y._version
 
 
 def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D):
@@ -843,6 +851,86 @@ class GroupSegments:
         self.seg = torch.tensor(seg if seg else [(0, 0, 0)], dtype=torch.int64, device=device)
         self.group_seg_off = torch.tensor(gso, dtype=torch.int64, device=device)
         self.group_offsets = off
+        # the plane image of this row partition (pa_glm_pack_planes_grouped): every segment starts on
+        # a 64-row super-tile boundary
+        st = [0]
+        for a, e, _ in seg:
+            st.append(st[-1] + (e - a + 63) // 64)
+        self.nst_total = st[-1]
+        self.st_off = torch.tensor(st, dtype=torch.int64, device=device)
+        self._planes = None          # [weakref X, X version, weakref y, y version, image, sightings]
+
+
+# ---- the plane image of a grouped design matrix (belongs to the GroupSegments object) ------------
+import weakref as _weakref  # noqa: E402
+
+_grouped_with_image = _weakref.WeakSet()
+
+
+def glm_pack_planes_grouped(X, y, segs, out=None):
+    """X[N,D] f32 (D <= 32), y[N], segs -> the uint8 image pa_glm_bernoulli_grouped_planes_fwd_bwd
+    reads (tile planes, then y in the image's padded row order)."""
+    _require_gpu(X, y)
+    N, D = X.shape
+    lib = _lib.load()
+    nbytes = lib.pa_glm_grouped_planes_bytes(segs.nst_total, D)
+    if nbytes == 0 and N > 0:
+        raise Unsupported("pyro_amd: no grouped plane image for N=%d D=%d" % (N, D))
+    assert X.is_contiguous() and y.is_contiguous() and X.dtype == torch.float32 == y.dtype
+    if out is None:
+        out = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=X.device)
+    check(lib.pa_glm_pack_planes_grouped(_ptr(X), _ptr(y), N, D, _ptr(segs.seg), _ptr(segs.st_off),
+                                         segs.nseg, segs.nst_total, _ptr(out), nbytes, _stream()))
+    return out
+
+
+def glm_grouped_planes_of(X, y, segs):
+    """The cached image of (X, y) under ``segs`` or None; same policy as glm_planes_of (second
+    sighting, never packed inside a capture, re-packed into the same buffer when X or y changed in
+    place)."""
+    if _planes_mode == GLM_PLANES_OFF:
+        return None
+    ent = segs._planes
+    if ent is not None and (ent[0]() is not X or ent[2]() is not y):
+        ent = None                                     # another data set under the same partition
+    if ent is None:
+        ent = [_weakref.ref(X), X._version, _weakref.ref(y), y._version, None, 0]
+        segs._planes = ent
+    ent[5] += 1
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent[4] is None:
+        if (_planes_mode == GLM_PLANES_AUTO and ent[5] < 2) or capturing:
+            return None
+        ent[4] = glm_pack_planes_grouped(X, y, segs)
+        ent[1], ent[3] = X._version, y._version
+        _grouped_with_image.add(segs)
+    elif ent[1] != X._version or ent[3] != y._version:
+        if capturing:
+            raise RuntimeError("pyro_amd: a design matrix changed in place during a graph capture")
+        glm_pack_planes_grouped(X, y, segs, out=ent[4])
+        ent[1], ent[3] = X._version, y._version
+    return ent[4]
+
+
+def glm_bernoulli_grouped_planes_fwd_bwd(planes, w, b, scale, N, D, segs):
+    """planes = glm_pack_planes_grouped(X, y, segs), w[P,G,D], b[P] or None ->
+    (ll[P], gw[P,G,D], gb[P])."""
+    _require_gpu(planes, w, b)
+    P, G = w.shape[0], w.shape[1]
+    assert w.is_contiguous() and w.shape == (P, G, D) and G == segs.G and w.dtype == torch.float32
+    if b is not None:
+        assert b.is_contiguous() and b.shape == (P,)
+    lib = _lib.load()
+    nbytes = lib.pa_glm_bernoulli_grouped_planes_workspace(segs.nseg, P)
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=w.device)
+    ll = torch.empty((P,), dtype=w.dtype, device=w.device)
+    gw = torch.empty((P, G, D), dtype=w.dtype, device=w.device)
+    gb = torch.empty((P,), dtype=w.dtype, device=w.device)
+    check(lib.pa_glm_bernoulli_grouped_planes_fwd_bwd(
+        _ptr(planes), _ptr(w), _ptr(b), float(scale), N, D, P, G, _ptr(segs.seg), _ptr(segs.st_off),
+        segs.nseg, _ptr(segs.group_seg_off), segs.nst_total, _ptr(ll), _ptr(gw), _ptr(gb), _ptr(ws),
+        nbytes, _stream()))
+    return ll, gw, gb
 
 
 def glm_bernoulli_grouped_fwd_bwd(X, y, w, b, mask, scale, segs):
@@ -851,6 +939,13 @@ def glm_bernoulli_grouped_fwd_bwd(X, y, w, b, mask, scale, segs):
     _require_gpu(X, y, w, b, mask)
     if X.dtype != torch.float32:
         raise Unsupported("pyro_amd: fused GLM kernel is float32 only")
+    if (mask is None and X.shape[1] <= _PLANES_MAX_D and w.shape[0] >= _PLANES_MIN_P
+            and X.shape[0] > 0 and _glm_variant == GLM_AUTO and X.is_contiguous()
+            and y.is_contiguous() and y.dtype == torch.float32):
+        planes = glm_grouped_planes_of(X, y, segs)
+        if planes is not None:
+            return glm_bernoulli_grouped_planes_fwd_bwd(planes, w, b, scale, X.shape[0], X.shape[1],
+                                                        segs)
     N, D = X.shape
     P, G = w.shape[0], w.shape[1]
     assert X.is_contiguous() and y.is_contiguous() and w.is_contiguous()

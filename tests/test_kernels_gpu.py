@@ -335,6 +335,57 @@ def test_glm_bernoulli_grouped(gpu, glm_variant, N, D, P, G, use_mask):
     torch.testing.assert_close(g1[:, 0], g0, rtol=1e-5, atol=1e-4 * N ** 0.5)
 
 
+@pytest.mark.parametrize("N,D,P,G", [(5000, 32, 64, 7), (70_000, 17, 40, 50), (300, 8, 130, 3)])
+def test_glm_grouped_plane_image_kernel(gpu, N, D, P, G):
+    """The hierarchical GLM site on the plane image (pa_glm_pack_planes_grouped +
+    pa_glm_bernoulli_grouped_planes_fwd_bwd): the packer bit-exact against the oracle's image, the
+    kernel against the numpy restatement (same tolerances as the kernel that splits X on the fly)
+    and against that kernel itself, ragged groups incl. an empty one, P > 64 (two particle passes)."""
+    k = _k()
+    rng = np.random.default_rng(N + D + P + G)
+    sizes = rng.multinomial(N, rng.dirichlet(np.ones(G) * 0.7))
+    sizes[rng.integers(0, G)] = 0
+    sizes[-1] += N - sizes.sum()
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    g_of = np.repeat(np.arange(G), sizes)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (rng.standard_normal((P, G, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32)
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    segs = k.GroupSegments(off, gpu, target_segments=23)
+    tX, ty = tt(X, gpu), tt(y, gpu)
+    planes = k.glm_pack_planes_grouped(tX, ty, segs)
+    img, ypad = o_glm.glm_grouped_plane_image(X, y, segs.seg.cpu().numpy())
+    nb_img = img.size * 2
+    got = planes.cpu().numpy()
+    assert np.array_equal(got[:nb_img].view(np.uint16).reshape(img.shape), img)      # bit-exact
+    assert np.array_equal(got[nb_img:nb_img + ypad.size * 4].view(np.float32), ypad)
+    ll, gw, gb = k.glm_bernoulli_grouped_planes_fwd_bwd(planes, tt(w, gpu), tt(b, gpu), 2.0, N, D, segs)
+    rll, rgw, rgb = o_glm.glm_bernoulli_grouped_fwd_bwd(X, y, w, g_of, b, None, 2.0)
+    sc = max(1.0, float(np.abs(rll).max()))
+    np.testing.assert_allclose(ll.cpu().numpy(), rll, rtol=2e-5, atol=2e-5 * sc)
+    np.testing.assert_allclose(gb.cpu().numpy(), rgb, rtol=2e-5, atol=2e-5 * N ** 0.5)
+    np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=2e-5, atol=2e-5 * N ** 0.5)
+    k.glm_set_planes_mode(k.GLM_PLANES_OFF)
+    try:
+        l0, g0, b0 = k.glm_bernoulli_grouped_fwd_bwd(tX, ty, tt(w, gpu), tt(b, gpu), None, 2.0, segs)
+    finally:
+        k.glm_set_planes_mode(k.GLM_PLANES_AUTO)
+    torch.testing.assert_close(ll, l0, rtol=1e-5, atol=1e-4 * sc)
+    torch.testing.assert_close(gw, g0, rtol=1e-5, atol=1e-4 * N ** 0.5)
+    # the cached route: second sighting packs, an in-place change of y re-packs into the same buffer
+    segs2 = k.GroupSegments(off, gpu, target_segments=23)
+    for _ in range(2):
+        l1, g1, b1 = k.glm_bernoulli_grouped_fwd_bwd(tX, ty, tt(w, gpu), tt(b, gpu), None, 2.0, segs2)
+    assert segs2._planes[4] is not None and torch.equal(l1, ll) and torch.equal(g1, gw)
+    buf = segs2._planes[4].data_ptr()
+    ty.copy_(1.0 - ty)
+    l2, g2, b2 = k.glm_bernoulli_grouped_fwd_bwd(tX, ty, tt(w, gpu), tt(b, gpu), None, 2.0, segs2)
+    assert segs2._planes[4].data_ptr() == buf
+    rll2, _, _ = o_glm.glm_bernoulli_grouped_fwd_bwd(X, 1.0 - y, w, g_of, b, None, 2.0)
+    np.testing.assert_allclose(l2.cpu().numpy(), rll2, rtol=2e-5, atol=2e-5 * sc)
+
+
 def test_glm_bernoulli_transpose_detecting(gpu, glm_variant):
     """Asymmetric inputs: a swapped (p,d) or (n,p) mapping cannot pass."""
     k = _k()

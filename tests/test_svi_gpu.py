@@ -284,9 +284,22 @@ def test_hierarchical_logreg_full_size_properties(gpu):
     segs = k.GroupSegments(off, gpu)
     w = torch.randn((P, G, D), device=gpu) * 0.2
     b = torch.randn((P,), device=gpu)
+    # first sighting: the kernel that splits X on the fly; from the second on the plane image
+    a0 = k.glm_bernoulli_grouped_fwd_bwd(X, y, w, b, None, 1.0, segs)
     a1 = k.glm_bernoulli_grouped_fwd_bwd(X, y, w, b, None, 1.0, segs)
     a2 = k.glm_bernoulli_grouped_fwd_bwd(X, y, w, b, None, 1.0, segs)
+    assert segs._planes[4] is not None
     for u, v in zip(a1, a2):
+        assert torch.equal(u, v)
+    torch.testing.assert_close(a0[0], a1[0], rtol=2e-5, atol=1e-2)
+    torch.testing.assert_close(a0[1], a1[1], rtol=1e-4, atol=1e-2)
+    k.glm_set_planes_mode(k.GLM_PLANES_OFF)
+    try:
+        b1 = k.glm_bernoulli_grouped_fwd_bwd(X, y, w, b, None, 1.0, segs)
+        b2 = k.glm_bernoulli_grouped_fwd_bwd(X, y, w, b, None, 1.0, segs)
+    finally:
+        k.glm_set_planes_mode(k.GLM_PLANES_AUTO)
+    for u, v in zip(b1, b2):
         assert torch.equal(u, v)
     ll_sum = torch.zeros(P, device=gpu, dtype=torch.float64)
     for grp in (0, 17, 999):

@@ -14,8 +14,8 @@ import csv, glob, sys, os
 f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-lo, hi = idx[-2] + 1, idx[-1] + 1
+idx = [i for i, r in enumerate(rows) if "meanfield_sample_kernel" in r["Kernel_Name"]]
+lo, hi = idx[-2], idx[-1]
 t0 = int(rows[lo]["Start_Timestamp"])
 for r in rows[lo:hi]:
     print("%9.1f us  %7.1f us  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"][:120]))
