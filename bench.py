@@ -60,6 +60,12 @@ def parse():
     ap.add_argument("--nuts-warmup", type=int, default=200)
     ap.add_argument("--nuts-samples", type=int, default=200)
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--config5-sharded", action="store_true",
+                    help="also time BASELINE configs[4] with the PLATE sharded over the ranks (SURVEY "
+                         "8e variant 2): rows / world per GPU, the same particles everywhere, the "
+                         "likelihood scaled to the full plate, one flat RCCL gradient all-reduce")
+    ap.add_argument("--config5-rows", type=int, default=10_000_000)
+    ap.add_argument("--config5-groups", type=int, default=1000)
     return ap.parse_args()
 
 
@@ -248,12 +254,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PYRO_AMD_BENCH_DEVICE=cpu: the multi-process plumbing of this script (rendezvous, barrier,
+    # max-over-ranks timing, the one JSON line) on host tensors over gloo -- used by
+    # tests/test_distributed_cpu.py with the kernels answered by the test oracle; never a measurement
+    on_gpu = os.environ.get("PYRO_AMD_BENCH_DEVICE", "cuda") != "cpu"
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        args.no_nuts = args.no_others = args.no_cpu_baseline = args.no_graph = True
 
     import pyro_amd as pyro
     from pyro_amd import _lib, examples, kernels
@@ -271,12 +286,21 @@ def main():
         optim = pyro.optim.RcclOptimizer(optim)
     use_graph = not args.no_graph
     # the dominant kernel's own clock stamps (a launch argument: created before the capture)
-    clock = kernels.GlmDeviceClock(dev)
+    clock = kernels.GlmDeviceClock(dev) if on_gpu else None
     svi = SVI(examples.logreg_model, guide, optim,
               Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
               hip_graph=use_graph, graph_warmup=2)
 
-    timer = kernels.KernelTimer(_lib.KERNEL_GLM)
+    class _NoTimer:                      # (host run: nothing to bracket)
+        pairs = []
+
+        def arm(self):
+            pass
+
+        def mean_ms(self):
+            return float("nan")
+
+    timer = kernels.KernelTimer(_lib.KERNEL_GLM) if on_gpu else _NoTimer()
     # untimed warm-up; with hip_graph the step is captured here (after 2 eager steps) and the
     # bracket armed for the capturing step becomes two event-record nodes of the graph
     for _ in range(max(args.warmup, 4 if use_graph else 0)):
@@ -294,7 +318,8 @@ def main():
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     sync()
     t0 = time.perf_counter()
@@ -349,6 +374,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    sharded5 = None
+    if args.config5_sharded:
+        # every rank holds rows / world rows (its own synthetic shard), draws the SAME particles (one
+        # seed), scores its rows scaled by `world`, and the flat gradient is averaged over the ranks
+        n_loc = args.config5_rows // world
+        Xs, ys, off = examples.synthetic_hier_logreg_data(n_loc, D, args.config5_groups, dev, seed=100 + rank)
+        segs = kernels.GroupSegments(off, dev)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(4321)
+        model5 = lambda X_, y_, s_: examples.hier_logreg_model(X_, y_, s_, plate_scale=float(world))  # noqa: E731
+        opt5 = pyro.optim.Adam({"lr": 0.01})
+        if world > 1:
+            opt5 = pyro.optim.RcclOptimizer(opt5)
+        svi5 = SVI(model5, AutoNormal(model5, init_scale=0.1), opt5,
+                   Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
+                   hip_graph=use_graph, graph_warmup=2)
+        for _ in range(6):
+            svi5.step(Xs, ys, segs)
+        sync()
+        t5 = time.perf_counter()
+        n5 = max(3, min(args.steps, 20))
+        for _ in range(n5):
+            svi5.step(Xs, ys, segs)
+        sync()
+        t5 = time.perf_counter() - t5
+        if world > 1:
+            tt5 = torch.tensor([t5], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt5, op=dist.ReduceOp.MAX)
+            t5 = float(tt5.item())
+        sharded5 = {"steps_per_s": n5 / t5, "ms_per_step": t5 / n5 * 1e3, "rows_per_rank": n_loc,
+                    "rows_total": n_loc * world, "particles": P, "ranks": world, "scaling": "strong",
+                    "workload": "BASELINE configs[4], plate sharded over the ranks (SURVEY 8e variant 2): "
+                                "hierarchical logistic regression, %d rows in all, %d groups, the same %d "
+                                "particles on every rank, likelihood scaled by the world size, flat "
+                                "gradient all-reduce (mean)" % (n_loc * world, args.config5_groups, P)}
+        pyro.clear_param_store()
     nuts = None if args.no_nuts else bench_nuts(dev, rank, world, args)
     others = None
     if world == 1 and not args.no_others:
@@ -428,7 +489,7 @@ def main():
                 traffic_src = "profiles/r03_traffic.json (" + tj.get("how", "") + ")"
             except Exception:
                 traffic = None
-        planes = kernels.glm_planes_of(X) is not None
+        planes = on_gpu and kernels.glm_planes_of(X) is not None
         out = {
             "metric": "ELBO-grad steps/sec (SVI)", "value": world * args.steps / elapsed,
             "unit": "ELBO-grad steps/s (64 particles x 1e6-row plate per step)",
@@ -483,6 +544,9 @@ def main():
                                "chain_fused": getattr(svi, "chain_fused", None)}
         if nuts is not None:
             out["secondary"] = nuts
+        if sharded5 is not None:
+            others = dict(others or {})
+            others["config5_plate_sharded"] = sharded5
         if others:
             out["other_configs"] = others
         print(json.dumps(out), flush=True)

@@ -144,9 +144,12 @@ def synthetic_lda_data(args, device, seed=0):
 
 
 # ---- BASELINE config 5: hierarchical logistic regression ---------------------------
-def hier_logreg_model(X, y, segments):
+def hier_logreg_model(X, y, segments, plate_scale=1.0):
     """mu ~ N(0,1)^D, tau ~ HalfNormal(1)^D, w_g ~ N(mu, tau) for g in plate(groups),
-    obs_n ~ Bernoulli(logits = x_n . w_{g(n)} + b); rows of X sorted by group."""
+    obs_n ~ Bernoulli(logits = x_n . w_{g(n)} + b); rows of X sorted by group.
+    ``plate_scale``: this process holds 1 / plate_scale of the plate's rows (a data-sharded run,
+    SURVEY 8e variant 2): its likelihood is scaled to the full plate, as plate(size, subsample_size)
+    does in examples/svi_horovod.py:52-59, and the mean of the ranks' gradients is the full-data one."""
     N, D = X.shape
     G = segments.G
     z = torch.zeros(D, dtype=X.dtype, device=X.device)
@@ -155,7 +158,8 @@ def hier_logreg_model(X, y, segments):
     b = sample("b", dist.Normal(torch.zeros((), dtype=X.dtype, device=X.device), 1.0))
     with plate("groups", G):
         w = sample("w", dist.Normal(mu, tau).to_event(1))
-    with plate("data", N):
+    from . import poutine
+    with poutine.scale(scale=float(plate_scale)), plate("data", N):
         sample("obs", dist.Bernoulli(logits=dist.grouped_linear_logits(X, w, b, segments)), obs=y)
 
 

@@ -171,14 +171,31 @@ class SVI:
     def _capture(self, key, args, kwargs):
         from .constants import HoistedConstantWritten
         rec = self._const_rec.pop(key, None)
-        try:
-            return self._capture_once(key, args, kwargs, rec)
-        except HoistedConstantWritten:
-            # the step writes into a tensor it created with zeros()/ones()/full(): such a tensor
-            # has to be filled on every replay -- capture again with the fills inside the graph
-            return self._capture_once(key, args, kwargs, None)
+        multi = hasattr(self.optim, "reduce_gradients") and getattr(self.optim, "multi_rank", False)
+        # with several ranks the step is first captured as ONE graph with the RCCL all-reduce of the
+        # flat gradient inside it (RCCL collectives are capturable like NCCL's); if that capture
+        # fails the step is captured in the split form [loss + backward] -> eager all-reduce ->
+        # [update], which has run on RCCL since round 2
+        forms = [False, True] if multi and not getattr(self, "_force_split", False) \
+            and _os.environ.get("PYRO_AMD_GRAPH_COLLECTIVE", "1") != "0" else [None]
+        for form in forms:
+            try:
+                entry = self._capture_once(key, args, kwargs, rec, force_split=form,
+                                           quiet=form is False)
+            except HoistedConstantWritten:
+                # the step writes into a tensor it created with zeros()/ones()/full(): such a
+                # tensor has to be filled on every replay -- capture again with the fills inside
+                entry = self._capture_once(key, args, kwargs, None, force_split=form,
+                                           quiet=form is False)
+            if entry is not None:
+                return entry
+            if form is False:
+                warnings.warn("pyro_amd: capturing the gradient all-reduce inside the step's graph "
+                              "failed; capturing the step in two graphs around an eager collective")
+                self.hip_graph = True           # (the failed attempt switched it off)
+        return None
 
-    def _capture_once(self, key, args, kwargs, const_rec):
+    def _capture_once(self, key, args, kwargs, const_rec, force_split=None, quiet=False):
         from .. import rng
         from ..primitives import validation_enabled
 
@@ -196,15 +213,12 @@ class SVI:
         graph2 = between = None
         split = hasattr(self.optim, "reduce_gradients") and \
             (getattr(self.optim, "multi_rank", False) or getattr(self, "_force_split", False))
-        # Opt-in (PYRO_AMD_GRAPH_COLLECTIVE=1): capture the RCCL all-reduce of the flat gradient
+        # split = False with several ranks: the RCCL all-reduce of the flat gradient is captured
         # INSIDE the step's graph -- one replay per step at any world size, no eager collective and
-        # no stream hand-over between two graphs.  RCCL collectives are capturable like NCCL's; the
-        # default stays the split form below because a failed capture with a live process group
-        # cannot be tested in a single-GPU container.
-        import os as _os
-        if split and _os.environ.get("PYRO_AMD_GRAPH_COLLECTIVE") == "1" and \
-                not getattr(self, "_force_split", False):
-            split = False
+        # no stream hand-over between two graphs (the default, see _capture; PYRO_AMD_GRAPH_COLLECTIVE=0
+        # keeps the two-graph form)
+        if force_split is not None:
+            split = bool(force_split)
         # the dependent small launches that end the step (GLM finalize, ELBO assembly, guide
         # backward, Adam + loss hand-over) become phases of ONE kernel (kernels.chain_recording);
         # PYRO_AMD_CHAIN=0 keeps them as separate graph nodes
@@ -264,6 +278,9 @@ class SVI:
                 raise
             if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
                 raise
+            if quiet:
+                self.hip_graph = False
+                return None
             warnings.warn("pyro_amd: hipGraph capture of SVI.step failed ({}: {}); continuing "
                           "with eager steps".format(type(e).__name__, e))
             self.hip_graph = False

@@ -69,10 +69,24 @@ class RcclOptimizer:
             flat_grad.div_(self.world_size)
 
     def broadcast_parameters(self, params, root_rank=0):
+        """Every rank starts from rank ``root_rank``'s values: ONE broadcast of the parameters packed
+        into a flat buffer per dtype (the reference's hvd.broadcast_parameters is one collective per
+        tensor, examples/svi_horovod.py:87-88)."""
         if self.world_size == 1:
             return
+        by_dtype = {}
         for p in _sorted(params):
-            dist.broadcast(p.data, src=root_rank, group=self.group)
+            by_dtype.setdefault((p.dtype, p.device), []).append(p)
+        for ps in by_dtype.values():
+            with torch.no_grad():
+                flat = torch.cat([p.data.reshape(-1) for p in ps]) if len(ps) > 1 else \
+                    ps[0].data.reshape(-1).clone()
+                dist.broadcast(flat, src=root_rank, group=self.group)
+                off = 0
+                for p in ps:
+                    n = p.numel()
+                    p.data.copy_(flat[off:off + n].view_as(p.data))
+                    off += n
 
     # ---- two-phase interface used by the hipGraph step (SVI(hip_graph=True)): the collective
     # stays an ordinary eager RCCL launch between two captured graphs

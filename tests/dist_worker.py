@@ -116,3 +116,29 @@ def data_sharded_worker(rank, world, port, out_path, bank, X, y, steps):
     torch.save({"losses": losses, "params": params}, out_path % rank)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_worker(rank, world, port, out_path, steps):
+    """bench.py itself, launched the way the driver launches it for N > 1 (RANK / WORLD_SIZE /
+    MASTER_* in the environment), on host tensors over gloo with the kernels answered by the oracle:
+    the rendezvous, the barrier-bracketed timed region, the max-over-ranks time and the ONE JSON line
+    of rank 0."""
+    import contextlib
+    import io
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                       "PYRO_AMD_BENCH_DEVICE": "cpu"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from tests import oracle_backend as ob
+    ob.install(_MP())
+    import bench
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", str(steps), "--warmup", "1",
+                "--plate", "512", "--features", "8", "--particles", "4", "--config5-sharded",
+                "--config5-rows", "600", "--config5-groups", "5"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    torch.save({"stdout": buf.getvalue()}, out_path % rank)
+

@@ -90,3 +90,23 @@ def test_data_sharded_svi_equals_single_process(tmp_path):
     for k in two[0]["params"]:
         torch.testing.assert_close(two[0]["params"][k], two[1]["params"][k], rtol=0, atol=0)
         torch.testing.assert_close(two[0]["params"][k], one[0]["params"][k], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.timeout(600)
+def test_bench_torchrun_path_prints_one_line_with_two_ranks(tmp_path):
+    """`bench.py --gpus 2 --steps 3` end to end under the driver's launch contract (two processes,
+    RANK / WORLD_SIZE / MASTER_* from the environment), host tensors + gloo + oracle kernels: rank 0
+    prints exactly one JSON line that says two ranks took part in the gradient all-reduce; rank 1
+    prints nothing."""
+    import json
+    outs = _run(dw.bench_worker, 2, (3,), tmp_path, "bench2")
+    lines = [ln for ln in outs[0]["stdout"].splitlines() if ln.strip()]
+    assert len(lines) == 1, outs[0]["stdout"]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 3
+    assert rec["metric"].startswith("ELBO-grad steps/sec") and rec["value"] > 0
+    assert rec["scaling"] == "weak" and rec["higher_is_better"] is True
+    assert outs[1]["stdout"].strip() == ""
+    sh = rec["other_configs"]["config5_plate_sharded"]
+    assert sh["ranks"] == 2 and sh["rows_total"] == 600 and sh["steps_per_s"] > 0
+
