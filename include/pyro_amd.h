@@ -653,6 +653,19 @@ int pa_adam_step_publish(int dtype, void* param, void* grad, void* exp_avg, void
                          double* host_value, uint64_t* host_seq, uint64_t* counter, uint64_t inc,
                          pa_stream_t stream);
 
+/* Reparameterised standard-Gamma draws out[i] ~ Gamma(alpha[i], 1) on the keyed Philox stream and,
+ * when d_alpha != NULL, the implicit reparameterisation gradient d out[i] / d alpha[i].  Replaces
+ * torch._standard_gamma + torch._standard_gamma_grad behind torch.distributions.Gamma.rsample
+ * (gamma.py:80-88), which pyro's Gamma / Beta / Dirichlet draw through (pyro/distributions/torch.py;
+ * examples/lda.py:107-109).  Element i reads the Philox blocks (offset + *offset_dev + i, tag | k),
+ * k = attempt of the Marsaglia-Tsang rejection loop (budget 24): reproducible for any launch
+ * geometry and replay-safe in a hipGraph.  alpha: view on the [rows, cols] frame; out, d_alpha
+ * contiguous.  pa_gamma_implicit_grad: the gradient alone, at given (alpha, value). */
+int pa_gamma_rsample(int dtype, void* out, void* d_alpha, pa_view2d alpha, int64_t rows, int64_t cols,
+                     uint64_t seed, uint64_t offset, const uint64_t* offset_dev, pa_stream_t stream);
+int pa_gamma_implicit_grad(int dtype, void* d_alpha, pa_view2d alpha, pa_view2d value, int64_t rows,
+                           int64_t cols, pa_stream_t stream);
+
 /* ---- the chained tail of an SVI step ------------------------------------------------------------
  * Replaces the dependent small launches that end the reference's step -- per-site sums and their
  * autograd duals (pyro/infer/trace_elbo.py:130-159), AccumulateGrad + per-parameter optimizer steps

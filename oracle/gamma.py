@@ -1,0 +1,125 @@
+"""TEST INFRASTRUCTURE -- reparameterised Gamma draws and their implicit gradient, restated in numpy.
+
+Reference behaviour restated: ``torch.distributions.Gamma.rsample`` (torch/distributions/gamma.py:80-88)
+draws ``torch._standard_gamma(concentration) / rate`` and differentiates through
+``torch._standard_gamma_grad``; pyro's Gamma / Beta / Dirichlet are thin wrappers of the torch classes
+(pyro/distributions/torch.py), and examples/lda.py:107-109 draws its guide's global sites this way.
+The reference's draws come from torch's generator (sample-for-sample parity is impossible by
+construction, see oracle/philox.py); what is pinned is
+  * the DISTRIBUTION of the draws: Kolmogorov-Smirnov against scipy.stats.gamma (tests), and
+  * the GRADIENT at fixed (concentration, value): against torch._standard_gamma_grad itself
+    (tests/golden/gamma_grad.npz, written by tests/golden/make_golden.py) and against a central
+    difference of scipy.special.gammainc.
+The functions below follow pyro_amd/csrc/gamma.hip statement by statement (same Philox blocks, fp64).
+"""
+import numpy as np
+
+from . import philox
+
+GAMMA_TAG = 0x47414D4D00000000
+ATTEMPTS = 24
+
+
+def standard_gamma(alpha, seed, offset):
+    """Draws for the flattened ``alpha`` (element i reads the blocks (offset + i, tag | k))."""
+    a = np.asarray(alpha, dtype=np.float64).reshape(-1)
+    n = a.size
+    a1 = np.where(a < 1.0, a + 1.0, a)
+    d = a1 - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    cand = d.copy()
+    done = np.zeros(n, dtype=bool)
+    blocks = np.uint64(offset) + np.arange(n, dtype=np.uint64)
+    for k in range(ATTEMPTS):
+        if done.all():
+            break
+        rx, ry, rz, rw = philox.philox4x32_10(seed, blocks, np.uint64(GAMMA_TAG | k))
+        u1 = philox.u32x2_to_unit_f64(rx, ry)
+        u2 = (rz.astype(np.float64) + 0.5) / 4294967296.0
+        ua = (rw.astype(np.float64) + 0.5) / 4294967296.0
+        x = np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586 * u2)
+        t = 1.0 + c * x
+        ok = t > 0.0
+        v = np.where(ok, t, 1.0) ** 3
+        live = ~done & ok
+        cand = np.where(live, d * v, cand)
+        with np.errstate(divide="ignore"):
+            acc = np.log(ua) < 0.5 * x * x + d - d * v + d * np.log(v)
+        done |= live & acc
+    rx, ry, _, _ = philox.philox4x32_10(seed, blocks, np.uint64(GAMMA_TAG | 255))
+    ub = philox.u32x2_to_unit_f64(rx, ry)
+    out = np.where(a < 1.0, cand * ub ** (1.0 / np.where(a < 1.0, a, 1.0)), cand)
+    return out.reshape(np.shape(alpha))
+
+
+def _digamma(x):
+    from scipy.special import digamma
+    return digamma(x)
+
+
+def implicit_grad(alpha, x):
+    """d x / d alpha of the reparameterised standard-Gamma draw (implicit differentiation of the CDF):
+    the dual-number power series (x < alpha + 1) / modified-Lentz continued fraction of gamma.hip."""
+    a_all = np.asarray(alpha, dtype=np.float64)
+    x_all = np.asarray(x, dtype=np.float64)
+    a_all, x_all = np.broadcast_arrays(a_all, x_all)
+    out = np.zeros(a_all.shape)
+    for idx in np.ndindex(a_all.shape):
+        a, xv = float(a_all[idx]), float(x_all[idx])
+        if not (xv > 0.0 and a > 0.0):
+            continue
+        lx_psi = np.log(xv) - float(_digamma(a))
+        if xv < a + 1.0:
+            t, dt = 1.0 / a, -1.0 / (a * a)
+            S, dS = t, dt
+            for n in range(1, 500):
+                den = a + n
+                f = xv / den
+                dt = dt * f - t * f / den
+                t *= f
+                S += t
+                dS += dt
+                if abs(t) < 1e-17 * abs(S) and abs(dt) < 1e-17 * abs(dS):
+                    break
+            out[idx] = -xv * (S * lx_psi + dS)
+        else:
+            tiny = 1e-300
+            b, db = xv + 1.0 - a, -1.0
+            c, dc = 1.0 / tiny, 0.0
+            d = 1.0 / b
+            dd = -db / (b * b)
+            h, dh = d, dd
+            for i in range(1, 500):
+                an, dan = -i * (i - a), float(i)
+                b += 2.0
+                dn = an * d + b
+                ddn = dan * d + an * dd + db
+                if abs(dn) < tiny:
+                    dn = tiny
+                cn = b + an / c
+                dcn = db + dan / c - an * dc / (c * c)
+                if abs(cn) < tiny:
+                    cn = tiny
+                d = 1.0 / dn
+                dd = -ddn / (dn * dn)
+                c, dc = cn, dcn
+                de = d * c
+                dde = dd * c + d * dc
+                dh = dh * de + h * dde
+                h *= de
+                if abs(de - 1.0) < 1e-16 and abs(dde) < 1e-16:
+                    break
+            out[idx] = xv * (h * lx_psi + dh)
+    return out
+
+
+def implicit_grad_by_differences(alpha, x, rel=1e-5):
+    """The same quantity from its definition, -(dP/da) / pdf, with a central difference of
+    scipy.special.gammainc: an independent check of the series / continued fraction above."""
+    from scipy.special import gammainc, gammaln
+    a = np.asarray(alpha, dtype=np.float64)
+    xv = np.asarray(x, dtype=np.float64)
+    h = rel * a
+    dP = (gammainc(a + h, xv) - gammainc(a - h, xv)) / (2 * h)
+    pdf = np.exp((a - 1.0) * np.log(xv) - xv - gammaln(a))
+    return -dP / pdf

@@ -208,6 +208,9 @@ _SIGNATURES = {
                                     c_void_p]),
     "pa_chain_matvec": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                 c_void_p]),
+    "pa_gamma_rsample": (c_int, [c_int, c_void_p, c_void_p, View2D, c_int64, c_int64, c_uint64, c_uint64,
+                                 c_void_p, c_void_p]),
+    "pa_gamma_implicit_grad": (c_int, [c_int, c_void_p, View2D, View2D, c_int64, c_int64, c_void_p]),
     "pa_chain_begin": (c_int, [c_void_p, c_void_p, c_size_t]),
     "pa_chain_flush": (c_int, []),
     "pa_chain_end": (c_int, [POINTER(c_int), POINTER(c_int)]),

@@ -238,6 +238,17 @@ class _GammaFunctionFamily(_FusedElementwise):
         return super().fused_site_entry(self._value(value), scale, mask)
 
 
+def _native_draws(t):
+    """Draw through the HIP Philox sampler?  (device tensors of a supported dtype; when a test has
+    replaced the normal source, torch's samplers keep their own generator semantics)"""
+    from .. import kernels, rng
+    return (isinstance(t, torch.Tensor) and kernels.on_device(t) and rng.normal is rng._default_normal
+            and t.dtype in (torch.float32, torch.float64) and NATIVE_GAMMA["on"])
+
+
+NATIVE_GAMMA = {"on": True}
+
+
 class Gamma(_GammaFunctionFamily, torch.distributions.Gamma, TorchDistributionMixin):
     _dist_id = _lib.DIST_GAMMA
 
@@ -255,6 +266,16 @@ class Gamma(_GammaFunctionFamily, torch.distributions.Gamma, TorchDistributionMi
 
     def _params(self):
         return self.concentration, self.rate
+
+    def rsample(self, sample_shape=torch.Size()):
+        # torch: _standard_gamma(concentration.expand(shape)) / rate.expand(shape), clamped away
+        # from zero (gamma.py:80-88); the draw and its implicit gradient come from one HIP launch
+        if not _native_draws(self.concentration):
+            return super().rsample(sample_shape)
+        shape = self._extended_shape(sample_shape)
+        value = fused.standard_gamma(self.concentration, shape) / self.rate.expand(shape)
+        value.detach().clamp_(min=torch.finfo(value.dtype).tiny)
+        return value
 
 
 class Beta(_GammaFunctionFamily, torch.distributions.Beta, TorchDistributionMixin):
@@ -282,6 +303,21 @@ class Beta(_GammaFunctionFamily, torch.distributions.Beta, TorchDistributionMixi
         # stride-0 views of the given operands on the batch shape (log_prob has the batch shape)
         return tuple(p.expand(self.batch_shape) for p in self._given)
 
+    def rsample(self, sample_shape=torch.Size()):
+        # X = Ga / (Ga + Gb) with independent Gamma(concentration1), Gamma(concentration0) draws:
+        # the pathwise gradient flows through the two draws' implicit gradients (an unbiased
+        # reparameterisation gradient; torch's Beta draws through Dirichlet._dirichlet_grad, a
+        # different -- equally unbiased -- estimator of the same derivative)
+        c1, c0 = self._given
+        if not (isinstance(c1, torch.Tensor) and _native_draws(c1)):
+            return super().rsample(sample_shape)
+        shape = self._extended_shape(sample_shape)
+        ga = fused.standard_gamma(c1, shape)
+        gb = fused.standard_gamma(c0 if isinstance(c0, torch.Tensor) else c1.new_tensor(float(c0)), shape)
+        value = ga / (ga + gb)
+        eps = torch.finfo(value.dtype).eps
+        return value.clamp(min=eps, max=1 - eps)
+
 
 class Dirichlet(torch.distributions.Dirichlet, TorchDistributionMixin):
     """torch's Dirichlet (constructor, ``rsample`` through ``_Dirichlet`` with its implicit
@@ -297,6 +333,17 @@ class Dirichlet(torch.distributions.Dirichlet, TorchDistributionMixin):
             base = getattr(self, "_base_concentration", None)
             return fused.dirichlet_log_prob(value, conc if base is None else base)
         return super().log_prob(value)
+
+    def rsample(self, sample_shape=torch.Size()):
+        # x = g / sum(g), g_k ~ Gamma(concentration_k): pathwise gradient through the draws' implicit
+        # gradients (see Beta.rsample)
+        if not _native_draws(self.concentration):
+            return super().rsample(sample_shape)
+        shape = self._extended_shape(sample_shape)
+        g = fused.standard_gamma(self.concentration, shape)
+        value = g / g.sum(-1, keepdim=True)
+        tiny = torch.finfo(value.dtype).tiny
+        return value.clamp(min=tiny)
 
     def expand(self, batch_shape, _instance=None):
         new = super().expand(batch_shape, _instance)

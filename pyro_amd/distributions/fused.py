@@ -344,6 +344,38 @@ class _NormalRsample(torch.autograd.Function):
         return d_loc, d_scale, None, None, None, None
 
 
+class _StandardGamma(torch.autograd.Function):
+    """g ~ Gamma(concentration, 1) of ``shape`` from the keyed Philox stream, ONE launch that also
+    produces d g / d concentration (pa_gamma_rsample: Marsaglia-Tsang + the implicit
+    reparameterisation gradient); backward = one product and the un-broadcast.  torch:
+    _standard_gamma / _standard_gamma_grad behind Gamma.rsample (gamma.py:80-88)."""
+
+    @staticmethod
+    def forward(ctx, concentration, shape, seed, offset, offset_dev):
+        rows, cols, (a2,) = frame([concentration], shape)
+        need = ctx.needs_input_grad[0]
+        out, dal = kernels.gamma_rsample(a2, rows, cols, seed, offset, offset_dev, want_grad=need)
+        ctx.like = concentration
+        if need:
+            ctx.save_for_backward(dal.reshape(shape))
+        return out.reshape(shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (dal,) = ctx.saved_tensors
+        return _sum_to(g * dal, ctx.like), None, None, None, None
+
+
+def standard_gamma(concentration, shape):
+    """Reparameterised Gamma(concentration, 1) draw of ``shape`` from the process-wide Philox stream
+    (one block per element is reserved, whatever the rejection loop consumes)."""
+    from .. import rng
+    shape = torch.Size(shape)
+    seed, off, off_dev = rng.reserve_blocks(shape.numel())
+    return _StandardGamma.apply(concentration, shape, seed, off, off_dev)
+
+
 class _MeanFieldSample(torch.autograd.Function):
     """All mean-field Normal sites of a guide: per site  scale = softplus(rho),
     z = loc + scale * eps  for P vectorised particles, ONE launch forward

@@ -239,6 +239,27 @@ def philox_uniform(shape, dtype, device, seed, offset, offset_dev=None):
     return out
 
 
+def gamma_rsample(alpha, rows, cols, seed, offset, offset_dev=None, want_grad=True):
+    """alpha: 2-D tensor broadcastable to [rows, cols] -> (standard-Gamma draws [rows, cols],
+    d draw / d alpha [rows, cols] or None).  pa_gamma_rsample."""
+    _require_gpu(alpha, offset_dev)
+    out = torch.empty((rows, cols), dtype=alpha.dtype, device=alpha.device)
+    dal = torch.empty_like(out) if want_grad else None
+    check(_lib.load().pa_gamma_rsample(_dtype(alpha), _ptr(out), _ptr(dal), _view(alpha, rows, cols),
+                                       rows, cols, seed, offset, _ptr(offset_dev), _stream()))
+    return out, dal
+
+
+def gamma_implicit_grad(alpha, value):
+    """d value / d alpha of reparameterised standard-Gamma draws at given (alpha, value), same shapes."""
+    _require_gpu(alpha, value)
+    a2, v2 = alpha.reshape(1, -1), value.reshape(1, -1)
+    out = torch.empty_like(v2)
+    check(_lib.load().pa_gamma_implicit_grad(_dtype(alpha), _ptr(out), _view(a2, 1, a2.shape[1]),
+                                             _view(v2, 1, v2.shape[1]), 1, v2.shape[1], _stream()))
+    return out.reshape(value.shape)
+
+
 def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
     """Graph epilogue: counter += inc (optional), then the device scalar ``src`` is written to the
     pinned host tensors ``host_value`` (float64[1]) / ``host_seq`` (int64[1], incremented)."""

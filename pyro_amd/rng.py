@@ -52,6 +52,17 @@ def reserve(n_elements, dtype):
     return _STATE["seed"], off, None
 
 
+def reserve_blocks(n_blocks):
+    """Reserve ``n_blocks`` whole Philox blocks (draws that key one block per element, such as the
+    Gamma sampler's rejection loop); returns (seed, offset, offset_dev) like ``reserve``."""
+    off = _STATE["offset"]
+    _STATE["offset"] = off + int(n_blocks)
+    cap = _CAPTURE["active"]
+    if cap is not None:
+        return _STATE["seed"], off - cap.start, cap.base
+    return _STATE["seed"], off, None
+
+
 def normal(shape, dtype, device):
     """Standard normal draws from the Philox stream (HIP kernel, GPU only)."""
     n = 1

@@ -1360,9 +1360,32 @@ def g_marginals():
          s_probs=m["s"].probs.detach().numpy(), z_probs=m["z"].probs.detach().numpy())
 
 
+# ---------------------------------------------------------------------------------------------
+# Reparameterised Gamma / Beta / Dirichlet draws of the reference (pyro.distributions.Gamma.rsample ->
+# torch._standard_gamma + torch._standard_gamma_grad, torch/distributions/gamma.py:80-88): the implicit
+# gradient d sample / d concentration at fixed (concentration, sample), quantile by quantile, and the
+# pathwise gradients of a Gamma site's draw w.r.t. both parameters through pyro's own class.
+# ---------------------------------------------------------------------------------------------
+def g_gamma_grad():
+    from scipy import stats
+    conc = np.array([0.05, 0.3, 0.9, 1.0, 1.7, 2.5, 7.9, 8.1, 30.0, 200.0, 1500.0])
+    quant = np.array([0.005, 0.05, 0.2, 0.5, 0.8, 0.95, 0.995])
+    a = np.broadcast_to(conc[:, None], (conc.size, quant.size)).copy()
+    x = stats.gamma.ppf(quant[None, :], a)
+    g = torch._standard_gamma_grad(torch.tensor(a), torch.tensor(x)).numpy()
+    # through the reference's class: value = standard_gamma(c) / r with value fixed by the draw
+    c = torch.tensor([0.7, 2.0, 11.0], requires_grad=True)
+    r = torch.tensor([0.5, 3.0, 1.5], requires_grad=True)
+    torch.manual_seed(3)
+    v = dist.Gamma(c, r).rsample()
+    (v * torch.tensor([1.0, 2.0, 3.0])).sum().backward()
+    save("gamma_grad", conc=a, value=x, grad=g, site_conc=c.detach().numpy(), site_rate=r.detach().numpy(),
+         site_value=v.detach().numpy(), site_dconc=c.grad.numpy(), site_drate=r.grad.numpy())
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov", "arrowhead"]
+                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov", "arrowhead", "gamma_grad"]
     for w in which:
         globals()["g_" + w]()
 

@@ -36,6 +36,19 @@ def philox_uniform(shape, dtype, device, seed, offset, offset_dev=None):
     return torch.as_tensor(o_philox.uniform(n, np_dt, seed, offset).reshape(shape), device=device)
 
 
+def gamma_rsample(alpha, rows, cols, seed, offset, offset_dev=None, want_grad=True):
+    from oracle import gamma as o_gamma
+    a = np.ascontiguousarray(_bc(alpha, rows, cols), dtype=np.float64)
+    np_dt = np.float32 if alpha.dtype == torch.float32 else np.float64
+    x = o_gamma.standard_gamma(a, seed, offset)
+    x = np.maximum(x, np.finfo(np_dt).tiny).astype(np_dt)
+    out = torch.as_tensor(x, device=alpha.device)
+    if not want_grad:
+        return out, None
+    g = o_gamma.implicit_grad(a, x.astype(np.float64)).astype(np_dt)
+    return out, torch.as_tensor(g, device=alpha.device)
+
+
 def dist_log_prob(dist_id, value, p0, p1, rows, cols):
     out = o_dists.LOG_PROB[dist_id](_bc(value, rows, cols).astype(np.float64),
                                     _bc(p0, rows, cols).astype(np.float64),
@@ -462,7 +475,7 @@ FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_
              "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
              "mvn_tril_sample_bwd", "logchain_fwd_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd",
-             "logsumexp_terms", "logsumexp_terms_grad"]
+             "logsumexp_terms", "logsumexp_terms_grad", "gamma_rsample"]
 
 
 def install(monkeypatch):
