@@ -653,6 +653,35 @@ int pa_adam_step_publish(int dtype, void* param, void* grad, void* exp_avg, void
                          double* host_value, uint64_t* host_seq, uint64_t* counter, uint64_t inc,
                          pa_stream_t stream);
 
+/* ---- first layer of an amortised guide over word histograms (examples/lda.py:76-92,113-121) -------
+ * The reference builds counts = zeros(V, B).scatter_add(0, data, ones) on every step and runs
+ * nn.Linear(V, H) on its transpose (dense 410 MB at V = 1024, B = 1e5, four f32 GEMMs per step with
+ * the backward).  The histogram is a pure function of the corpus: it is built once (by the caller:
+ * pyro_amd/kernels.py::bow_images, bit-exact integer work) as two bf16 images in MFMA-operand order
+ *   image_a [ceil(B/32)][V/16][64 lanes][8 bf16]: lane l -> document 32 mt + (l & 31), words 16 kt + 8 (l >> 5) + 0..7
+ *   image_b [V/32][Bp/16][64 lanes][8 bf16]    : lane l -> word 32 vt + (l & 31), documents 16 kt + 8 (l >> 5) + 0..7
+ * (Bp = B rounded up to 32, missing documents zero; counts must be <= 256: exact in bf16).
+ * pa_bow_linear_fwd: out[B, H] = bias + C W^T with W[H, V] f32 split exactly into three bf16 planes
+ * per call; pa_bow_linear_bwd: dW[H, V] = d_out^T C with d_out[B, H] split likewise, the sum over the
+ * documents split over workgroups and reduced in a fixed order.  f32-class results (exact piece
+ * products, f32 accumulation).  V % 128 == 0, H <= 128; workspace: pa_bow_workspace bytes. */
+size_t pa_bow_workspace(int64_t B, int64_t V, int64_t H);
+int pa_bow_linear_fwd(const void* image_a, const float* W, const float* bias, int64_t B, int64_t V,
+                      int64_t H, float* out, void* workspace, size_t workspace_bytes,
+                      pa_stream_t stream);
+int pa_bow_linear_bwd(const void* image_b, const float* d_out, int64_t B, int64_t V, int64_t H,
+                      float* dW, void* workspace, size_t workspace_bytes, pa_stream_t stream);
+
+/* out[M, N] = A^T X for tall f32 operands A[B, M], X[B, N] (M, N <= 128, B large): the weight
+ * gradient of a Linear layer over a large batch, dW = d_out^T input (examples/lda.py:76-92 with
+ * B = 1e5 documents; torch: mm backward -> a rocBLAS 100 x 100 x 1e5 product that does not split
+ * the long dimension).  Both operands are split exactly into three bf16 pieces, the six products
+ * of order >= 2^-16 run on the matrix cores with f32 accumulation, the long dimension is split
+ * over workgroups and reduced in a fixed order (f32-class result, bitwise reproducible). */
+size_t pa_tsgemm_tn_workspace(int64_t B, int64_t M, int64_t N);
+int pa_tsgemm_tn(const float* A, const float* X, int64_t B, int64_t M, int64_t N, float* out,
+                 void* workspace, size_t workspace_bytes, pa_stream_t stream);
+
 /* Reparameterised standard-Gamma draws out[i] ~ Gamma(alpha[i], 1) on the keyed Philox stream and,
  * when d_alpha != NULL, the implicit reparameterisation gradient d out[i] / d alpha[i].  Replaces
  * torch._standard_gamma + torch._standard_gamma_grad behind torch.distributions.Gamma.rsample

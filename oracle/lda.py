@@ -63,3 +63,47 @@ def lda_word_index(words, V):
             task_len.append(min(LDA_SEG, off[v + 1] - st))
     i32 = lambda x: np.asarray(x, dtype=np.int32)   # noqa: E731
     return off, first_task, i32(task_v), i32(task_start), i32(task_len), docs
+
+
+def bow_counts(words, V):
+    """The dense histogram counts[v, b] of examples/lda.py:116-119 (zeros(V, B).scatter_add(0, data,
+    ones)), float64."""
+    words = np.asarray(words)
+    Wd, B = words.shape
+    c = np.zeros((V, B))
+    np.add.at(c, (words, np.broadcast_to(np.arange(B), words.shape)), 1.0)
+    return c
+
+
+def bow_images(words, V):
+    """(image_a, image_b) of pyro_amd/kernels.py::bow_images as float arrays [blocks.., 64 lanes, 8]:
+    image_a block (mt, kt), lane l -> document 32 mt + (l & 31), words 16 kt + 8 (l >> 5) + 0..7;
+    image_b block (vt, kt), lane l -> word 32 vt + (l & 31), documents 16 kt + 8 (l >> 5) + 0..7."""
+    c = bow_counts(words, V)
+    B = c.shape[1]
+    Bp = -(-B // 32) * 32
+    cp = np.zeros((V, Bp))
+    cp[:, :B] = c
+    a = np.zeros((Bp // 32, V // 16, 64, 8))
+    b = np.zeros((V // 32, Bp // 16, 64, 8))
+    lane = np.arange(64)
+    for q in range(8):
+        # image_a[mt, kt, l, q] = cp[16 kt + 8 (l >> 5) + q, 32 mt + (l & 31)]
+        a[:, :, :, q] = cp[(16 * np.arange(V // 16)[None, :, None] + 8 * (lane >> 5)[None, None, :] + q),
+                           (32 * np.arange(Bp // 32)[:, None, None] + (lane & 31)[None, None, :])]
+        b[:, :, :, q] = cp[(32 * np.arange(V // 32)[:, None, None] + (lane & 31)[None, None, :]),
+                           (16 * np.arange(Bp // 16)[None, :, None] + 8 * (lane >> 5)[None, None, :] + q)]
+    return a, b
+
+
+def bow_linear(words, V, W, bias):
+    """h = counts^T W^T + bias, float64 (the first nn.Linear of examples/lda.py:76-92 on the
+    transposed histogram)."""
+    return bow_counts(words, V).T @ np.asarray(W, dtype=np.float64).T + (0.0 if bias is None else bias)
+
+
+def bow_linear_grad(words, V, d_out):
+    """(dW, dbias) of bow_linear for the upstream gradient d_out [B, H]."""
+    d = np.asarray(d_out, dtype=np.float64)
+    return d.T @ bow_counts(words, V).T, d.sum(0)
+

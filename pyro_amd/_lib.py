@@ -208,6 +208,14 @@ _SIGNATURES = {
                                     c_void_p]),
     "pa_chain_matvec": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                 c_void_p]),
+    "pa_bow_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_bow_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    "pa_bow_linear_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "pa_tsgemm_tn_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_tsgemm_tn": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
+                             c_void_p]),
     "pa_gamma_rsample": (c_int, [c_int, c_void_p, c_void_p, View2D, c_int64, c_int64, c_uint64, c_uint64,
                                  c_void_p, c_void_p]),
     "pa_gamma_implicit_grad": (c_int, [c_int, c_void_p, View2D, View2D, c_int64, c_int64, c_void_p]),

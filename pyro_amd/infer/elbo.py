@@ -37,7 +37,9 @@ def deepest_plate(model, guide, args, kwargs, validate):
     finite ``max_plate_nesting``, whatever lies left of it may broadcast freely."""
     from ..util import check_site_shape
     with poutine.block():
-        guide_trace = poutine.trace(guide).get_trace(*args, **kwargs)
+        from ..ops import lazy
+        with lazy.watch_histograms():
+            guide_trace = poutine.trace(guide).get_trace(*args, **kwargs)
         model_trace = poutine.trace(poutine.replay(model, trace=guide_trace)).get_trace(*args, **kwargs)
     depth = 0
     for trace in (prune_subsample_sites(model_trace), prune_subsample_sites(guide_trace)):

@@ -23,7 +23,9 @@ def get_importance_trace(graph_type, max_plate_nesting, model, guide, args, kwar
                          fused_sums=False):
     """Guide trace, then the model replayed against it.  With ``fused_sums`` the per-site
     quantities are produced by the fused one-kernel reductions (log_prob_sum only)."""
-    guide_trace = poutine.trace(guide, graph_type=graph_type).get_trace(*args, **kwargs)
+    from ..ops import lazy
+    with lazy.watch_histograms():      # (examples/lda.py's word histogram: see ops/lazy.py)
+        guide_trace = poutine.trace(guide, graph_type=graph_type).get_trace(*args, **kwargs)
     if detach:
         guide_trace.detach_()
     model_trace = poutine.trace(poutine.replay(model, trace=guide_trace),

@@ -160,6 +160,7 @@ class SVI:
             self._graphs[key] = self._graphs.pop(key)      # most recently used last
         kernels.glm_planes_revalidate()     # data the graph reads through a cached image
         kernels.lda_index_revalidate()
+        kernels.bow_revalidate()
         entry.cap.before_replay()
         entry.graph.replay()
         if entry.graph2 is not None:

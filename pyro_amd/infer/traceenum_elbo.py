@@ -148,7 +148,9 @@ class TraceEnum_ELBO(ELBO):
             self._seq_queue = []
         seq = SequentialEnumMessenger(getattr(self, "_seq_assignment", None) or {}, self._seq_queue)
         guide_enum = poutine.enum(seq(guide), first_available_dim=first_enum_dim)
-        guide_trace = poutine.trace(guide_enum).get_trace(*args, **kwargs)
+        from ..ops import lazy
+        with lazy.watch_histograms():      # (examples/lda.py's word histogram: see ops/lazy.py)
+            guide_trace = poutine.trace(guide_enum).get_trace(*args, **kwargs)
         model_enum = poutine.enum(model)
         model_trace = poutine.trace(poutine.replay(model_enum, trace=guide_trace)).get_trace(
             *args, **kwargs)

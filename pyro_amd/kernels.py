@@ -1403,6 +1403,123 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi, index=None):
 
 
 # ------------------------------------------------------------------------------------------
+# bag-of-words first layer (the amortised guide of examples/lda.py)
+# ------------------------------------------------------------------------------------------
+# The word histogram of a corpus as two bf16 operand images (include/pyro_amd.h "first layer of an
+# amortised guide"), built once per corpus tensor and kept beside it under the policy of the GLM
+# plane image / LDA index (second sighting, never inside a capture, re-built into the same buffers
+# when the tensor was modified in place).
+_bow_cache = {}          # (id(base), geometry, V) -> [weakref, version, (image_a, image_b), sightings, geometry, V]
+BOW_MAX_COUNT = 256      # counts are stored in bf16: exact up to 256 words per document
+
+
+def bow_images(words, V):
+    """words int64 [Wd, B] (word ids < V) -> (image_a, image_b) bf16 tensors.  Integer work, exact;
+    one-off per corpus, so it is written with torch operators: the dense histogram, then the two
+    operand orders by reshape / permute."""
+    _require_gpu(words)
+    Wd, B = words.shape
+    assert words.dtype == torch.int64 and V % 128 == 0 and Wd <= BOW_MAX_COUNT
+    Bp = (B + 31) // 32 * 32
+    counts = torch.zeros((V, Bp), dtype=torch.float32, device=words.device)
+    counts[:, :B].scatter_add_(0, words, torch.ones(words.shape, dtype=torch.float32, device=words.device))
+    img_b = counts.reshape(V // 32, 32, Bp // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16)
+    img_a = counts.t().reshape(Bp // 32, 32, V // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16)
+    return img_a, img_b
+
+
+def bow_images_of(words, V):
+    """The cached images of ``words`` or None (not yet worth building / shape not covered)."""
+    if words.dtype != torch.int64 or words.dim() != 2 or V % 128 != 0 or words.shape[0] > BOW_MAX_COUNT \
+            or not words.is_cuda:
+        return None
+    import weakref
+    base = words._base if words._base is not None else words
+    geom = (words.storage_offset(), tuple(words.shape), tuple(words.stride()))
+    key = (id(base),) + geom + (int(V),)
+    ent = _bow_cache.get(key)
+    if ent is not None and ent[0]() is not base:
+        ent = None
+    if ent is None:
+        ent = [weakref.ref(base, lambda _r, k=key: _bow_cache.pop(k, None)), words._version, None, 0, geom,
+               int(V)]
+        _bow_cache[key] = ent
+    ent[3] += 1
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent[2] is None:
+        if ent[3] < 2 or capturing:
+            return None
+        ent[2] = bow_images(words, V)
+        ent[1] = words._version
+    elif ent[1] != words._version:
+        if capturing:
+            raise RuntimeError("pyro_amd: a corpus changed in place during a graph capture")
+        a, b = bow_images(words, V)
+        ent[2][0].copy_(a)
+        ent[2][1].copy_(b)
+        ent[1] = words._version
+    return ent[2]
+
+
+def bow_revalidate():
+    """Re-build the cached images of corpora that were modified in place (before a graph replay)."""
+    for ent in list(_bow_cache.values()):
+        base = ent[0]()
+        if base is not None and ent[2] is not None and ent[1] != base._version:
+            off, shape, stride = ent[4]
+            a, b = bow_images(base.as_strided(shape, stride, off), ent[5])
+            ent[2][0].copy_(a)
+            ent[2][1].copy_(b)
+            ent[1] = base._version
+
+
+def bow_linear_fwd(image_a, W, bias, B):
+    """out[B, H] = bias + counts @ W.T (pa_bow_linear_fwd); W [H, V] f32."""
+    _require_gpu(image_a, W, bias)
+    H, V = W.shape
+    assert W.is_contiguous() and W.dtype == torch.float32 and (bias is None or bias.is_contiguous())
+    lib = _lib.load()
+    nbytes = lib.pa_bow_workspace(B, V, H)
+    if nbytes == 0:
+        raise Unsupported("pyro_amd: bag-of-words layer does not cover B=%d V=%d H=%d" % (B, V, H))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=W.device)
+    out = torch.empty((B, H), dtype=torch.float32, device=W.device)
+    check(lib.pa_bow_linear_fwd(_ptr(image_a), _ptr(W), _ptr(bias), B, V, H, _ptr(out), _ptr(ws), nbytes,
+                                _stream()))
+    return out
+
+
+def bow_linear_bwd(image_b, d_out, V):
+    """dW[H, V] = d_out.T @ counts (pa_bow_linear_bwd); d_out [B, H] f32."""
+    _require_gpu(image_b, d_out)
+    B, H = d_out.shape
+    d_out = d_out.contiguous()
+    lib = _lib.load()
+    nbytes = lib.pa_bow_workspace(B, V, H)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=d_out.device)
+    dW = torch.empty((H, V), dtype=torch.float32, device=d_out.device)
+    check(lib.pa_bow_linear_bwd(_ptr(image_b), _ptr(d_out), B, V, H, _ptr(dW), _ptr(ws), nbytes, _stream()))
+    return dW
+
+
+def tsgemm_tn(a, x):
+    """a[B, M].T @ x[B, N] -> [M, N] for tall f32 operands (M, N <= 128): pa_tsgemm_tn."""
+    _require_gpu(a, x)
+    B, M = a.shape
+    N = x.shape[1]
+    assert x.shape[0] == B and a.dtype == torch.float32 == x.dtype
+    a, x = a.contiguous(), x.contiguous()
+    lib = _lib.load()
+    nbytes = lib.pa_tsgemm_tn_workspace(B, M, N)
+    if nbytes == 0:
+        raise Unsupported("pyro_amd: tsgemm_tn does not cover B=%d M=%d N=%d" % (B, M, N))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(lib.pa_tsgemm_tn(_ptr(a), _ptr(x), B, M, N, _ptr(out), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
 # flat Adam
 # ------------------------------------------------------------------------------------------
 

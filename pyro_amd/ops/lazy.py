@@ -171,3 +171,203 @@ class DeferredMatmul:
                "__le__", "__ge__"):
         locals()[_n] = _binary(_n) if _n != "__neg__" else (lambda self: -self.materialize())
     del _n, _binary
+
+
+# ---- the word histogram of an amortised guide (examples/lda.py:113-121) --------------------------
+# The reference guide writes
+#     counts = torch.zeros(V, B).scatter_add(0, data, torch.ones(data.shape))
+#     doc_topics = predictor(counts.transpose(0, 1))          # nn.Sequential(nn.Linear(V, H), ...)
+# on every step: a dense [V, B] matrix that is a pure function of the (constant) corpus, then four
+# f32 GEMMs over it.  While a guide / model runs under ``watch_histograms()`` (the ELBO estimators
+# switch it on around their traces), a scatter_add of FRESH ones into FRESH zeros along dim 0 with a
+# 2-D int64 index returns a DeferredCounts instead of running; transposing keeps it deferred;
+# ``torch.nn.functional.linear`` on the [B, V] orientation takes the bag-of-words kernels
+# (pa_bow_linear_fwd / _bwd over the corpus's cached histogram images); ANY other use materialises
+# exactly what the user wrote.
+class DeferredCounts:
+    def __init__(self, words, V, dtype, transposed=False):
+        self.words, self.V, self.dtype, self.transposed = words, int(V), dtype, transposed
+        self.device = words.device
+        vb = (self.V, words.shape[1])
+        self.shape = torch.Size(vb[::-1] if transposed else vb)
+
+    def dim(self):
+        return 2
+
+    ndim = 2
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def transpose(self, d0, d1):
+        if {d0 % 2, d1 % 2} == {0, 1}:
+            return DeferredCounts(self.words, self.V, self.dtype, not self.transposed)
+        return self
+
+    def t(self):
+        return DeferredCounts(self.words, self.V, self.dtype, not self.transposed)
+
+    T = property(t)
+    mT = property(t)
+
+    def materialize(self):
+        w = self.words
+        with torch._C.DisableTorchFunction():        # (the watcher must not defer this one again)
+            out = torch.zeros((self.V, w.shape[1]), dtype=self.dtype, device=w.device).scatter_add(
+                0, w, torch.ones(w.shape, dtype=self.dtype, device=w.device))
+        return out.transpose(0, 1) if self.transposed else out
+
+    def _linear(self, weight, bias):
+        """F.linear(self, weight, bias) on the kernels, or None when they do not cover the call."""
+        from .. import kernels
+        if not (ENABLED["on"] and self.transposed and self.dtype == torch.float32
+                and isinstance(weight, torch.Tensor) and weight.dim() == 2 and weight.is_cuda
+                and weight.dtype == torch.float32 and weight.shape[1] == self.V
+                and weight.shape[0] <= 128 and self.V % 128 == 0
+                and (bias is None or (isinstance(bias, torch.Tensor) and bias.dtype == torch.float32))):
+            return None
+        images = kernels.bow_images_of(self.words, self.V)
+        if images is None:
+            return None
+        out = _BowLinear.apply(weight, bias, images[0], images[1], self.words.shape[1])
+        return out.as_subclass(TallActivation) if out.shape[0] >= TALL_MIN_ROWS else out
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.nn.functional.linear and args and isinstance(args[0], DeferredCounts):
+            weight = args[1] if len(args) > 1 else kwargs.get("weight")
+            bias = args[2] if len(args) > 2 else kwargs.get("bias")
+            out = args[0]._linear(weight, bias)
+            if out is not None:
+                return out
+
+        def ev(x):
+            if isinstance(x, DeferredCounts):
+                return x.materialize()
+            if isinstance(x, (list, tuple)):
+                return type(x)(ev(v) for v in x)
+            return x
+        return func(*ev(args), **{k: ev(v) for k, v in kwargs.items()})
+
+    def __getattr__(self, name):        # only reached for attributes not defined above
+        return getattr(self.materialize(), name)
+
+
+# ---- the layers after it: activations of a large batch ---------------------------------------------
+# What the bag-of-words layer returns is a plain tensor in every respect but one: it remembers that it
+# is the activation of a LARGE batch, and so do the results of element-wise functions of it.  A
+# following ``F.linear`` then takes its weight gradient dW = d_out^T input through pa_tsgemm_tn (the
+# long dimension split over the chip) instead of torch's mm backward (one rocBLAS product over 1e5
+# rows: 342 us for a 100 x 100 weight at B = 1e5).  Forward and input gradient stay torch's.
+TALL_MIN_ROWS = 4096
+_ELEMENTWISE = {"sigmoid", "tanh", "relu", "softmax", "log_softmax", "softplus", "gelu", "elu",
+                "leaky_relu", "dropout", "silu", "exp", "log"}
+
+
+class TallActivation(torch.Tensor):
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if func is torch.nn.functional.linear and args and isinstance(args[0], TallActivation) \
+                and ENABLED["on"]:
+            x = args[0]
+            weight = args[1] if len(args) > 1 else kwargs.get("weight")
+            bias = args[2] if len(args) > 2 else kwargs.get("bias")
+            if (x.dim() == 2 and x.shape[0] >= TALL_MIN_ROWS and x.shape[1] <= 128 and x.is_cuda
+                    and x.dtype == torch.float32 and type(weight) in (torch.Tensor, torch.nn.Parameter)
+                    and weight.dim() == 2 and weight.shape[0] <= 128 and weight.dtype == torch.float32):
+                out = _TallLinear.apply(x.as_subclass(torch.Tensor), weight, bias)
+                return out.as_subclass(TallActivation)
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        if name in _ELEMENTWISE and isinstance(out, torch.Tensor) and args \
+                and isinstance(args[0], TallActivation) and out.shape[:1] == args[0].shape[:1] \
+                and out.dim() == 2:
+            return out.as_subclass(TallActivation)
+        return out
+
+
+class _TallLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        with torch._C.DisableTorchFunctionSubclass():
+            return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import kernels
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dW = kernels.tsgemm_tn(g, x) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+class _BowLinear(torch.autograd.Function):
+    """h = bias + counts @ W.T over the corpus's histogram images; d W = d_h.T @ counts, d bias =
+    sum d_h; the histogram itself carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, image_a, image_b, B):
+        from .. import kernels
+        w = weight.detach().contiguous()
+        out = kernels.bow_linear_fwd(image_a, w, None if bias is None else bias.detach().contiguous(), B)
+        ctx.image_b, ctx.V, ctx.has_bias = image_b, w.shape[1], bias is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import kernels
+        dW = kernels.bow_linear_bwd(ctx.image_b, g, ctx.V) if ctx.needs_input_grad[0] else None
+        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return dW, db, None, None, None
+
+
+class _HistogramWatcher(torch.overrides.TorchFunctionMode):
+    def __init__(self):
+        super().__init__()
+        self._fresh = {}                   # id(tensor) -> (weak reference, fill value)
+
+    def _note(self, t, value):
+        import weakref
+        if type(t) is torch.Tensor and t.is_cuda:
+            self._fresh[id(t)] = (weakref.ref(t), value)
+
+    def _is_fresh(self, t, value):
+        ent = self._fresh.get(id(t))
+        return ent is not None and ent[0]() is t and ent[1] == value and t._version == 0
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.zeros or func is torch.ones:
+            out = func(*args, **kwargs)
+            self._note(out, 0.0 if func is torch.zeros else 1.0)
+            return out
+        if func is torch.Tensor.scatter_add or func is torch.scatter_add:
+            full = list(args) + [kwargs[k] for k in ("dim", "index", "src") if k in kwargs]
+            if len(full) == 4:
+                base, dim, index, src = full
+                if (ENABLED["on"] and isinstance(dim, int) and dim == 0 and type(index) is torch.Tensor
+                        and index.dtype == torch.int64 and index.dim() == 2 and index.is_cuda
+                        and type(base) is torch.Tensor and base.dim() == 2
+                        and base.shape[1] == index.shape[1] and base.is_floating_point()
+                        and type(src) is torch.Tensor and src.shape == index.shape
+                        and src.dtype == base.dtype and not base.requires_grad and not src.requires_grad
+                        and self._is_fresh(base, 0.0) and self._is_fresh(src, 1.0)):
+                    return DeferredCounts(index, base.shape[0], base.dtype)
+        return func(*args, **kwargs)
+
+
+def watch_histograms():
+    """Context manager: recognise the histogram construction above in code run inside (a no-op
+    context when the recognition is switched off)."""
+    import contextlib
+    return _HistogramWatcher() if ENABLED["on"] else contextlib.nullcontext()
+

@@ -1174,3 +1174,137 @@ def test_sum_to_nd(gpu, dtype, A, R, B):
     ref = tx.double().sum(1)
     tol = 1e-12 if dtype == torch.float64 else 2e-6
     torch.testing.assert_close(got.double(), ref, rtol=tol, atol=tol * np.sqrt(R) * 4)
+
+
+@pytest.mark.parametrize("Wd,B,V,H", [(64, 3000, 1024, 100), (7, 65, 128, 128), (30, 32, 256, 1)])
+def test_bag_of_words_linear(gpu, Wd, B, V, H):
+    """The first layer of examples/lda.py's amortised guide without the per-step histogram
+    (pa_bow_linear_fwd / _bwd): the histogram images bit-exact (integer work) against the oracle's
+    layout, forward and gradients against the float64 dense restatement at f32-roundoff class, and
+    against torch's own f32 route."""
+    from oracle import lda as o_lda
+    k = _k()
+    rng = np.random.default_rng(Wd + B + V + H)
+    words = rng.integers(0, V, size=(Wd, B))
+    words[:, 0] = 5                                              # a document of ONE word: count Wd
+    W = (rng.standard_normal((H, V)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(H).astype(np.float32)
+    d = rng.standard_normal((B, H)).astype(np.float32)
+    tw = torch.as_tensor(words, device=gpu)
+    ia, ib = k.bow_images(tw, V)
+    ra, rb = o_lda.bow_images(words, V)
+    assert np.array_equal(ia.float().cpu().numpy().reshape(ra.shape), ra)
+    assert np.array_equal(ib.float().cpu().numpy().reshape(rb.shape), rb)
+    out = k.bow_linear_fwd(ia, tt(W, gpu), tt(bias, gpu), B)
+    ref = o_lda.bow_linear(words, V, W, bias)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-6, atol=2e-6 * scale)
+    dW = k.bow_linear_bwd(ib, tt(d, gpu), V)
+    rdW, _ = o_lda.bow_linear_grad(words, V, d)
+    np.testing.assert_allclose(dW.cpu().numpy(), rdW, rtol=2e-6, atol=2e-6 * np.abs(rdW).max())
+    # no bias; the same through torch's f32 operators on the dense histogram
+    out0 = k.bow_linear_fwd(ia, tt(W, gpu), None, B)
+    counts = torch.zeros(V, B, device=gpu).scatter_add(0, tw, torch.ones(tw.shape, device=gpu))
+    torch.testing.assert_close(out0, counts.t() @ tt(W, gpu).t(), rtol=1e-5, atol=1e-5 * float(scale))
+
+
+def test_word_histogram_is_recognised_in_guide_text(gpu):
+    """examples/lda.py's guide text verbatim -- zeros(V, B).scatter_add(0, data, ones) then
+    predictor(counts.transpose(0, 1)) -- under watch_histograms(): from the second sighting of the
+    corpus the first Linear runs on the bag-of-words kernels; values and parameter gradients equal the
+    dense route; every other use of the histogram materialises it."""
+    import torch.nn as nn
+    from pyro_amd import kernels as k
+    from pyro_amd.ops import lazy
+    g = torch.Generator(device=gpu).manual_seed(0)
+    V, B, Wd = 256, 500, 40
+    data = torch.randint(0, V, (Wd, B), device=gpu, generator=g)
+    torch.manual_seed(0)
+    predictor = nn.Sequential(nn.Linear(V, 30), nn.Sigmoid(), nn.Linear(30, 4), nn.Softmax(dim=-1)).to(gpu)
+
+    def guide_body():
+        counts = torch.zeros(V, data.shape[1], device=gpu).scatter_add(0, data, torch.ones(data.shape, device=gpu))
+        return counts, predictor(counts.transpose(0, 1))
+
+    calls = []
+    orig = k.bow_linear_fwd
+    k.bow_linear_fwd = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+    try:
+        outs, grads = [], []
+        for rep in range(3):
+            for p in predictor.parameters():
+                p.grad = None
+            with lazy.watch_histograms():
+                counts, y = guide_body()
+            assert isinstance(counts, lazy.DeferredCounts) and tuple(counts.shape) == (V, B)
+            (y * torch.arange(4, device=gpu)).sum().backward()
+            outs.append(y.detach().clone())
+            grads.append([p.grad.clone() for p in predictor.parameters()])
+        assert len(calls) == 2                    # first sighting: the dense route; then the kernels
+        for o, gr in zip(outs[1:], grads[1:]):
+            torch.testing.assert_close(o, outs[0], rtol=1e-5, atol=1e-6)
+            for a, b in zip(gr, grads[0]):
+                torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6 * float(b.abs().max()) + 1e-9)
+        # another use: behaves as the dense tensor
+        with lazy.watch_histograms():
+            counts, _ = guide_body()
+            assert float(counts.sum()) == Wd * B and torch.equal(counts.t().sum(1), torch.full((B,), float(Wd), device=gpu))
+            # an in-place update before the scatter: not the pattern, runs as written
+            z = torch.zeros(V, B, device=gpu)
+            z += 1
+            assert isinstance(z.scatter_add(0, data, torch.ones(data.shape, device=gpu)), torch.Tensor)
+    finally:
+        k.bow_linear_fwd = orig
+
+
+@pytest.mark.parametrize("B,M,N", [(100_000, 100, 100), (5000, 8, 100), (33, 128, 1), (4097, 37, 128)])
+def test_tall_skinny_weight_gradient_product(gpu, B, M, N):
+    """pa_tsgemm_tn: a[B, M].T @ x[B, N] against float64 (f32-roundoff class: exact bf16x3 splits,
+    f32 accumulation over the chunks, fp64 over the partials) and bitwise reproducible."""
+    k = _k()
+    rng = np.random.default_rng(B + M + N)
+    a = rng.standard_normal((B, M)).astype(np.float32)
+    x = (rng.standard_normal((B, N)) * np.exp(rng.uniform(-3, 3, size=(1, N)))).astype(np.float32)
+    out = k.tsgemm_tn(tt(a, gpu), tt(x, gpu))
+    ref = a.astype(np.float64).T @ x.astype(np.float64)
+    bound = (np.abs(a).astype(np.float64).T @ np.abs(x).astype(np.float64))
+    assert np.all(np.abs(out.cpu().numpy() - ref) <= 4e-7 * bound * max(1.0, np.sqrt(B) / 30) + 1e-30)
+    assert torch.equal(out, k.tsgemm_tn(tt(a, gpu), tt(x, gpu)))
+
+
+def test_layers_after_the_bag_of_words_layer_take_the_tall_weight_gradient(gpu):
+    """nn.Sequential(Linear, Sigmoid, Linear, Sigmoid, Linear, Sigmoid, Softmax) on a large batch of
+    histograms (examples/lda.py:76-92): parameter gradients equal the dense torch route; the second and
+    third Linear take pa_tsgemm_tn for dW."""
+    import torch.nn as nn
+    from pyro_amd import kernels as k
+    from pyro_amd.ops import lazy
+    g = torch.Generator(device=gpu).manual_seed(1)
+    V, B, Wd = 256, 6000, 20
+    data = torch.randint(0, V, (Wd, B), device=gpu, generator=g)
+    torch.manual_seed(1)
+    predictor = nn.Sequential(nn.Linear(V, 100), nn.Sigmoid(), nn.Linear(100, 100), nn.Sigmoid(),
+                              nn.Linear(100, 8), nn.Sigmoid(), nn.Softmax(dim=-1)).to(gpu)
+    wts = torch.randn(B, 8, device=gpu, generator=g)
+    calls = []
+    orig = k.tsgemm_tn
+    k.tsgemm_tn = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+    try:
+        res = []
+        for on in (False, True, True):
+            lazy.ENABLED["on"] = on
+            for p in predictor.parameters():
+                p.grad = None
+            with lazy.watch_histograms():
+                counts = torch.zeros(V, B, device=gpu).scatter_add(0, data, torch.ones(data.shape, device=gpu))
+                y = predictor(counts.transpose(0, 1))
+            (y * wts).sum().backward()
+            res.append((y.detach().clone(), [p.grad.clone() for p in predictor.parameters()]))
+    finally:
+        lazy.ENABLED["on"] = True
+        k.tsgemm_tn = orig
+    assert len(calls) == 2                    # (third run: both later Linear layers)
+    torch.testing.assert_close(res[2][0], res[0][0], rtol=1e-5, atol=1e-7)
+    for a, b in zip(res[2][1], res[0][1]):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max()) + 1e-10)
+

@@ -1,0 +1,32 @@
+#!/bin/bash
+# kernel-by-kernel sequence of ONE graphed SVI.step of configs 4 / 5 (developer tool): bash tools/trace_cfg.sh 4|5
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
+C=${1:-4}; OUT=gpurun_out/trace_cfg$C; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python -c "
+import sys; sys.path.insert(0,'.')
+import torch
+from tools import bench_configs as b
+dev=torch.device('cuda:0')
+print({'4': lambda: b.config4(dev, steps=4), '5': lambda: b.config5(dev, steps=4)}['$C']())
+" > $OUT/log.txt 2>&1
+python - "$OUT" <<'PY'
+import csv, glob, sys, os
+f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# a step ends with the optimizer's launch (adam_kernel or the chained tail)
+idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "chain_" in r["Kernel_Name"]]
+ends = [i for k, i in enumerate(idx) if k + 1 == len(idx) or idx[k + 1] - i > 3]
+lo, hi = ends[-2] + 1, ends[-1] + 1
+t0 = int(rows[lo]["Start_Timestamp"])
+tot = {}
+for r in rows[lo:hi]:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print("%9.1f us  %7.1f us  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, d, r["Kernel_Name"][:110]))
+    key = "pa::" if "pa::" in r["Kernel_Name"] else ("rocBLAS" if r["Kernel_Name"].startswith("Cijk") else "ATen/other")
+    tot[key] = tot.get(key, 0.0) + d
+span = (int(rows[hi - 1]["End_Timestamp"]) - t0) / 1e3
+print("step span %.1f us, %d launches; kernel time by origin: %s" % (span, hi - lo, {k: round(v, 1) for k, v in tot.items()}))
+os.remove(f)
+PY
