@@ -83,17 +83,24 @@ typedef float f32x16b __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ bf16x8 as_op(const uint4& c) { return as_bf16x8(c.x, c.y, c.z, c.w); }
 
-// h[B, H] = bias + C W^T: one wave = 64 documents (two 32-row tiles) x 128 hidden units
+// h[B, H] = bias + C W^T.  Workgroup = 4 waves = 256 documents (a wave: two 32-row tiles x 128 hidden
+// units).  The W planes of a chunk of four k-steps (4 x 12 operand blocks = 48 KiB) are brought into LDS
+// once per workgroup -- each wave copies a quarter, lane-linear, no conflicts -- and all four waves
+// read their B operands from there: the L2 serves 786 KB per 256 documents instead of per 64 (the
+// first version, every wave reading the planes itself, ran at the L2's bandwidth: 250 us for 36 us of
+// MFMA work at B = 1e5).  The histogram operands (A) stream from HBM straight into registers, one
+// chunk ahead.
+constexpr int BOW_KC = 4;                                   // k-steps per LDS chunk
 __global__ __launch_bounds__(256) void bow_linear_fwd_kernel(const uint4* __restrict__ imgA,
                                                              const uint4* __restrict__ wpl,
                                                              const float* __restrict__ bias,
                                                              int64_t B, int V, int H,
                                                              float* __restrict__ out) {
+  __shared__ uint4 wsm[BOW_KC * BOW_HT * 3 * 64];             // [k-step][tile][plane][lane]: 48 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nmt = (B + 31) / 32;                                  // document tiles
   const int64_t mt0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
-  if (mt0 >= nmt) return;
-  const bool two = mt0 + 1 < nmt;
+  const bool live = mt0 < nmt, two = mt0 + 1 < nmt;
   const int nkt = V / 16;
   const int64_t wblk = (int64_t)nkt * BOW_HT * 64;                    // chunks per W plane
   f32x16b acc[2][BOW_HT];
@@ -103,22 +110,51 @@ __global__ __launch_bounds__(256) void bow_linear_fwd_kernel(const uint4* __rest
     for (int n = 0; n < BOW_HT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-  const uint4* a0p = imgA + (mt0 * nkt) * 64 + lane;
-  const uint4* a1p = imgA + ((two ? mt0 + 1 : mt0) * nkt) * 64 + lane;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const bf16x8 a0 = as_op(a0p[(int64_t)kt * 64]);
-    const bf16x8 a1 = as_op(a1p[(int64_t)kt * 64]);
+  const uint4* a0p = imgA + ((live ? mt0 : 0) * nkt) * 64 + lane;
+  const uint4* a1p = imgA + ((two ? mt0 + 1 : (live ? mt0 : 0)) * nkt) * 64 + lane;
+  uint4 ca0[BOW_KC], ca1[BOW_KC];
 #pragma unroll
-    for (int n = 0; n < BOW_HT; ++n) {
-      const uint4* bp = wpl + ((int64_t)kt * BOW_HT + n) * 64 + lane;
+  for (int q = 0; q < BOW_KC; ++q) {
+    ca0[q] = a0p[(int64_t)q * 64];
+    ca1[q] = a1p[(int64_t)q * 64];
+  }
+  for (int kc = 0; kc < nkt; kc += BOW_KC) {
+    // this wave's quarter of the chunk's 48 blocks: (k-step, tile, plane) = block index / lane
+    __syncthreads();                                        // the previous chunk has been consumed
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        const bf16x8 bb = as_op(bp[pl * wblk]);
-        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][n], 0, 0, 0);
-        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][n], 0, 0, 0);
-      }
+    for (int q = 0; q < BOW_KC * BOW_HT * 3 / 4; ++q) {
+      const int blk = wave * (BOW_KC * BOW_HT * 3 / 4) + q;
+      const int ks = blk / (BOW_HT * 3), n = (blk / 3) % BOW_HT, pl = blk % 3;
+      wsm[blk * 64 + lane] = wpl[((int64_t)(kc + ks) * BOW_HT + n) * 64 + lane + pl * wblk];
+    }
+    // the histogram operands of the NEXT chunk (clamped at the end)
+    uint4 na0[BOW_KC], na1[BOW_KC];
+    const int kn = kc + BOW_KC < nkt ? kc + BOW_KC : kc;
+#pragma unroll
+    for (int q = 0; q < BOW_KC; ++q) {
+      na0[q] = a0p[(int64_t)(kn + q) * 64];
+      na1[q] = a1p[(int64_t)(kn + q) * 64];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BOW_KC; ++ks) {
+      const bf16x8 a0 = as_op(ca0[ks]), a1 = as_op(ca1[ks]);
+#pragma unroll
+      for (int n = 0; n < BOW_HT; ++n)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const bf16x8 bb = as_op(wsm[((ks * BOW_HT + n) * 3 + pl) * 64 + lane]);
+          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][n], 0, 0, 0);
+          acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][n], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BOW_KC; ++q) {
+      ca0[q] = na0[q];
+      ca1[q] = na1[q];
     }
   }
+  if (!live) return;
   // C/D layout: lane = column (hidden unit), register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const int jl = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -228,24 +264,41 @@ __global__ __launch_bounds__(256) void tsgemm_tn_kernel(const uint4* __restrict_
     }
 }
 
+// out[m, n] = sum_s partial[s][m][n]: 8 outputs x 32 chunk groups per workgroup (thread (j, g) sums the
+// chunks g, g + 32, ... in fp64, the 32 group sums are added in order): fixed order, whole chip
 __global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restrict__ partial, int ksplit,
                                                             int M, int N, float* __restrict__ out) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= M * N) return;
-  const int m = idx / N, n = idx - m * N;
+  __shared__ double sm[32][8];
+  const int jj = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int idx = blockIdx.x * 8 + jj;
   double acc = 0.0;
-  for (int s = 0; s < ksplit; ++s) acc += (double)partial[(int64_t)s * 128 * 128 + m * 128 + n];
-  out[idx] = (float)acc;
+  if (idx < M * N) {
+    const int m = idx / N, n = idx - m * N;
+    for (int s = g; s < ksplit; s += 32) acc += (double)partial[(int64_t)s * 128 * 128 + m * 128 + n];
+  }
+  sm[g][jj] = acc;
+  __syncthreads();
+  if (g == 0 && idx < M * N) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += sm[k][jj];
+    out[idx] = (float)t;
+  }
 }
 
 // dW[H, V] = sum_s partial[s] in increasing s (fp64), one thread per element
 __global__ __launch_bounds__(256) void bow_reduce_kernel(const float* __restrict__ partial, int ksplit,
                                                          int H, int V, float* __restrict__ dW) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)H * V) return;
+  // 64 consecutive outputs x 4 chunk groups per workgroup (coalesced 256-byte rows of every partial)
+  __shared__ double sm[4][64];
+  const int jj = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + jj;
   double acc = 0.0;
-  for (int s = 0; s < ksplit; ++s) acc += (double)partial[(int64_t)s * 128 * V + idx];
-  dW[idx] = (float)acc;
+  if (idx < (int64_t)H * V)
+    for (int s = g; s < ksplit; s += 4) acc += (double)partial[(int64_t)s * 128 * V + idx];
+  sm[g][jj] = acc;
+  __syncthreads();
+  if (g == 0 && idx < (int64_t)H * V) dW[idx] = (float)(((sm[0][jj] + sm[1][jj]) + sm[2][jj]) + sm[3][jj]);
 }
 
 static int bow_ksplit(int64_t Bp, int V) {
@@ -311,7 +364,7 @@ int pa_tsgemm_tn(const float* A, const float* X, int64_t B, int64_t M, int64_t N
   const int ks = pa_ts_ksplit(Bp);
   hipLaunchKernelGGL(pa::tsgemm_tn_kernel, dim3((unsigned)ks), dim3(256), 0, s, (const uint4*)apl,
                      (const uint4*)xpl, Bp, ks, part);
-  hipLaunchKernelGGL(pa::tsgemm_reduce_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, part,
+  hipLaunchKernelGGL(pa::tsgemm_reduce_kernel, dim3((unsigned)((M * N + 7) / 8)), dim3(256), 0, s, part,
                      ks, (int)M, (int)N, out);
   return pa::check_launch("tsgemm_tn");
 }
@@ -364,7 +417,7 @@ int pa_bow_linear_bwd(const void* image_b, const float* d_out, int64_t B, int64_
   const int ks = pa::bow_ksplit(Bp, (int)V);
   hipLaunchKernelGGL(pa::bow_linear_bwd_kernel, dim3((unsigned)(V / 128), (unsigned)ks), dim3(256), 0, s,
                      (const uint4*)dpl, (const uint4*)image_b, Bp, (int)V, ks, part);
-  hipLaunchKernelGGL(pa::bow_reduce_kernel, dim3((unsigned)((H * V + 255) / 256)), dim3(256), 0, s, part, ks,
+  hipLaunchKernelGGL(pa::bow_reduce_kernel, dim3((unsigned)((H * V + 63) / 64)), dim3(256), 0, s, part, ks,
                      (int)H, (int)V, dW);
   return pa::check_launch("bow_linear_bwd");
 }
