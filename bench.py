@@ -35,6 +35,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+BINDING_F16 = ("instruction issue: ~260 VALU instructions per wave and 32x32 (row, particle) tile "
+               "(sigmoid / softplus sums, the two-level f16 split of g) next to 13 MFMAs; two workgroups "
+               "per CU (more waves only add barrier waits); PMC per launch in "
+               "profiles/r03_pmc_summary.json, DESIGN.md section 3")
+BINDING_BF16 = ("VALU issue next to the MFMA pipe: 332 VALU instructions per wave and 32x32 (row, "
+                "particle) tile (sigmoid / softplus sums + the exact 3-way bf16 split of g) against 25 "
+                "MFMAs; PMC per launch: VALU issue 47 us of SIMD time, matrix pipe busy 26 us, kernel "
+                "65 us (profiles/r02_pmc_summary.json, DESIGN.md section 3)")
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_F32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak (FMA = 2 flop)
@@ -490,6 +498,8 @@ def main():
             except Exception:
                 traffic = None
         planes = on_gpu and kernels.glm_planes_of(X) is not None
+        f16 = planes and kernels.glm_planes_format() == kernels.GLM_PLANES_F16X2
+        n_prod = 3 if f16 else 6                       # piece products per element product
         out = {
             "metric": "ELBO-grad steps/sec (SVI)", "value": world * args.steps / elapsed,
             "unit": "ELBO-grad steps/s (64 particles x 1e6-row plate per step)",
@@ -507,7 +517,8 @@ def main():
                          "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
                          "frac": alg_bytes / (kern_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "glm_planes_kernel" if planes else "glm_bernoulli_bf16_kernel",
+                         "kernel": ("glm_planes_f16_kernel" if f16 else "glm_planes_kernel") if planes
+                         else "glm_bernoulli_bf16_kernel",
                          "kernel_ms": kern_ms,
                          "kernel_ms_source": ("the kernel's own stamps on the device wall clock "
                                               "(earliest workgroup entry -> latest workgroup exit), "
@@ -519,19 +530,21 @@ def main():
                          "frac_rocprof": (alg_bytes / (rocprof_ms * 1e-3) / 1e12 / PEAK_HBM_TBS)
                          if rocprof_ms else None,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "arithmetic": "f32-equivalent: every f32 operand split exactly into 3 bf16 "
+                         "arithmetic": ("f32-class: every f32 operand as two power-of-two-scaled f16 "
+                                        "pieces (2^-22 relative), the 3 piece products of order >= "
+                                        "2^-11 on the f16 matrix cores, f32 accumulation; error "
+                                        "against float64 equal to an f32 evaluation's "
+                                        "(tests/test_kernels_gpu.py::test_glm_planes_f16_is_f32_class; "
+                                        "PYRO_AMD_GLM_PLANES=bf16x3 selects the exact 3-piece image)")
+                         if f16 else
+                                       "f32-equivalent: every f32 operand split exactly into 3 bf16 "
                                        "pieces, the 6 piece products of order >= 2^-16 on the bf16 "
                                        "matrix cores, f32 accumulation",
                          # the other two resources the kernel uses, for the same duration:
-                         "bf16_mfma_TFLOPs": 6 * gemm_flops / (kern_ms * 1e-3) / 1e12,
-                         "frac_bf16_mfma": 6 * gemm_flops / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                         "mfma_piece_TFLOPs": n_prod * gemm_flops / (kern_ms * 1e-3) / 1e12,
+                         "frac_16bit_mfma": n_prod * gemm_flops / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                          "f32_equivalent_TFLOPs": achieved_tflops,
-                         "binding_resource": "VALU issue next to the MFMA pipe: 332 VALU instructions "
-                                             "per wave and 32x32 (row, particle) tile (sigmoid / "
-                                             "softplus sums + the exact 3-way bf16 split of g) "
-                                             "against 25 MFMAs; PMC per launch: VALU issue 47 us "
-                                             "of SIMD time, matrix pipe busy 26 us, kernel 65 us "
-                                             "(profiles/r02_pmc_summary.json, DESIGN.md section 3)"},
+                         "binding_resource": BINDING_F16 if f16 else BINDING_BF16},
             "rccl_ranks": world,
         }
         if world == 1 and not args.no_cpu_baseline:

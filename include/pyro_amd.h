@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 2
+#define PA_ABI_VERSION 3
 
 enum { PA_OK = 0, PA_ERR_INVALID = -1, PA_ERR_UNSUPPORTED = -2, PA_ERR_LAUNCH = -3 };
 
@@ -335,13 +335,14 @@ int pa_glm_bernoulli_fwd_bwd(const float* X, const float* y, const float* w, con
  * one workgroup per segment with w[:, group, :].  Replaces, per ELBO-gradient step, the gather
  * w[..., g_n, :] + matmul + Bernoulli.log_prob + scale_and_mask + sum and their autograd duals
  * (pyro/poutine/trace_struct.py:264-278, pyro/poutine/subsample_messenger.py:159-174 for the scale). */
-size_t pa_glm_grouped_planes_bytes(int64_t nst_total, int64_t D);
-int pa_glm_pack_planes_grouped(const float* X, const float* y, int64_t N, int64_t D,
+size_t pa_glm_grouped_planes_bytes(int format, int64_t nst_total, int64_t D);
+int pa_glm_pack_planes_grouped(int format, const float* X, const float* y, int64_t N, int64_t D,
                                const int64_t* seg, const int64_t* st_off, int64_t nseg,
                                int64_t nst_total, void* planes, size_t planes_bytes,
                                pa_stream_t stream);
 size_t pa_glm_bernoulli_grouped_planes_workspace(int64_t nseg, int64_t P);
-int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, const float* b,
+int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, const float* w,
+                                            const float* b,
                                             double scale, int64_t N, int64_t D, int64_t P, int64_t G,
                                             const int64_t* seg, const int64_t* st_off, int64_t nseg,
                                             const int64_t* group_seg_off, int64_t nst_total,
@@ -357,10 +358,24 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, 
  * registers and the LDS writes of the on-the-fly kernel leave the per-step work; the arithmetic and
  * the outputs are those of pa_glm_bernoulli_fwd_bwd variant 0 (no mask argument: masked plates take
  * the entry above).  D <= 32; any P (64 particles per pass over the image).
- * pa_glm_planes_tune(ring_depth 3..4, workgroups per CU; 0 = default) is a measurement knob. */
-size_t pa_glm_planes_bytes(int64_t N, int64_t D);
-int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_t planes_bytes,
-                       pa_stream_t stream);
+ * pa_glm_planes_tune(ring_depth 3..4, workgroups per CU; 0 = default) is a measurement knob.
+ *
+ * Two image formats (`format`, the same value when an image is sized, packed and used):
+ *   PA_GLM_PLANES_BF16X3  three bf16 planes, x = x1 + x2 + x3 EXACTLY; six piece products per
+ *                         element product (dropped terms O(2^-24)); 6 B per element;
+ *   PA_GLM_PLANES_F16X2   two f16 planes of X scaled by a power of two chosen from max |X| (found on
+ *                         the device at pack time, kept in the image's trailer), x ~= x1 + x2 to
+ *                         2^-22 relative (elements below 2^-13 max |X|: 2^-40 max |X| absolute);
+ *                         three piece products; W and the gradient operand are split the same way
+ *                         inside the kernel with per-particle power-of-two scales.  Error per logit
+ *                         <= 3 * 2^-22 sum_d |x_d w_d| -- inside the 32 * 2^-24 bound of an f32 FMA
+ *                         chain over 32 features; 4 B per element (the f32 matrix's own size), 13
+ *                         instead of 25 matrix instructions per 32x32 tile (csrc/glm_planes16.h). */
+#define PA_GLM_PLANES_BF16X3 0
+#define PA_GLM_PLANES_F16X2 1
+size_t pa_glm_planes_bytes(int format, int64_t N, int64_t D);
+int pa_glm_pack_planes(int format, const float* X, int64_t N, int64_t D, void* planes,
+                       size_t planes_bytes, pa_stream_t stream);
 int pa_glm_planes_tune(int ring_depth, int blocks_per_cu);
 /* 0 (default): the separate finalize launch; 1: pa_glm_bernoulli_planes_fwd_bwd reduces its
  * per-workgroup partial records INSIDE the kernel (two levels of last-arriver sums, bit-identical
@@ -374,7 +389,7 @@ int pa_glm_planes_finalize_mode(int in_kernel);
  * hipGraph, where HIP events do not time their node (bench.py roofline.kernel_ms). */
 int pa_glm_planes_stamps(void* two_u64);
 size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P);
-int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const float* w,
+int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float* y, const float* w,
                                     const float* b, double scale, int64_t N, int64_t D, int64_t P,
                                     float* ll, float* gw, float* gb, void* workspace,
                                     size_t workspace_bytes, pa_stream_t stream);

@@ -94,6 +94,81 @@ def glm_plane_image(X):
     return img.reshape(tiles, 3, 1024)
 
 
+# ---- the two-plane scaled f16 image (format PA_GLM_PLANES_F16X2, csrc/glm_planes16.h) -----------
+GLMH_KMAX = 60
+
+
+def f16_image_exponent(X):
+    """kx of the image: max |X| * 2^kx in [2^14, 2^15); 0 for an all-zero or non-finite matrix
+    (glmh_exponent_of: the unsigned maximum of the magnitudes' bit patterns, NaN above inf)."""
+    X = np.asarray(X, dtype=np.float32)
+    if X.size == 0:
+        return 0
+    bits = int((X.view(np.uint32) & np.uint32(0x7FFFFFFF)).max())
+    e = (bits >> 23) & 0xFF
+    if bits == 0 or e == 0xFF:
+        return 0
+    k = 14 - (-127 if e == 0 else e - 127)
+    return max(-GLMH_KMAX, min(GLMH_KMAX, k))
+
+
+def f16_split2(x):
+    """x (f32) -> (x1, x2) f16-valued f32 arrays, x1 = RN_f16(x), x2 = RN_f16(x - x1) (the residual
+    is exact in f32): x1 + x2 = x to 2^-22 |x| while x2 is a normal f16."""
+    x = np.asarray(x, dtype=np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        x1 = x.astype(np.float16)
+        r = (x - x1.astype(np.float32)).astype(np.float32)
+        x2 = r.astype(np.float16)
+    return x1, x2
+
+
+def glm_plane_image_f16(X, kx=None):
+    """(uint16 image [tiles, 2 planes, 1024], kx) of an [N, D <= 32] f32 design matrix: glm_plane_image's
+    tile geometry with the two f16 pieces of X * 2^kx."""
+    X = np.asarray(X, dtype=np.float32)
+    N, D = X.shape
+    assert D <= 32
+    if kx is None:
+        kx = f16_image_exponent(X)
+    tiles = -(-max(N, 0) // 32)
+    tiles = -(-tiles // 4) * 4
+    Xp = np.zeros((tiles * 32, 32), dtype=np.float32)
+    Xp[:N, :D] = np.ldexp(X, kx).astype(np.float32)
+    img = np.zeros((tiles, 2, 32, 4, 8), dtype=np.uint16)
+    r = np.arange(32)
+    for pl, piece in enumerate(f16_split2(Xp)):
+        bits = piece.view(np.uint16).reshape(tiles, 32, 4, 8)
+        for s in range(4):
+            img[:, pl, r, s ^ ((r >> 2) & 3), :] = bits[:, r, s, :]
+    return img.reshape(tiles, 2, 1024), kx
+
+
+def glm_grouped_plane_image_f16(X, y, seg):
+    """(uint16 tile image, float32 padded observations, kx): glm_grouped_plane_image in the f16 format;
+    the exponent comes from the whole of X."""
+    X = np.asarray(X, dtype=np.float32)
+    y = np.asarray(y, dtype=np.float32)
+    D = X.shape[1]
+    kx = f16_image_exponent(X)
+    blocks, yb = [], []
+    for a, e, _ in np.asarray(seg).reshape(-1, 3):
+        a, e = int(a), int(e)
+        rows = e - a
+        pad = -(-rows // 64) * 64
+        blk = np.zeros((pad, D), dtype=np.float32)
+        blk[:rows] = X[a:e]
+        yv = np.zeros(pad, dtype=np.float32)
+        yv[:rows] = y[a:e]
+        blocks.append(blk)
+        yb.append(yv)
+    if not blocks:
+        return np.zeros((0, 2, 1024), dtype=np.uint16), np.zeros(0, dtype=np.float32), kx
+    Xp = np.concatenate(blocks)
+    img = glm_plane_image_f16(Xp, kx)[0][: Xp.shape[0] // 32]
+    return img, np.concatenate(yb), kx
+
+
 def glm_grouped_plane_image(X, y, seg):
     """(uint16 tile image, float32 padded observations) of pa_glm_pack_planes_grouped: ``seg`` =
     rows [a, e) of one group each (kernels.GroupSegments.seg); every segment starts on a 64-row

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpyro_amd.so")
 
 PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_LAUNCH = 0, -1, -2, -3
 PA_F32, PA_F64 = 0, 1
-ABI_VERSION = 2      # PA_ABI_VERSION of include/pyro_amd.h
+ABI_VERSION = 3      # PA_ABI_VERSION of include/pyro_amd.h
 
 DIST_NORMAL = 0
 DIST_BERNOULLI_LOGITS = 1
@@ -111,21 +111,21 @@ _SIGNATURES = {
     "pa_glm_bernoulli_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
-    "pa_glm_planes_bytes": (c_size_t, [c_int64, c_int64]),
-    "pa_glm_grouped_planes_bytes": (c_size_t, [c_int64, c_int64]),
-    "pa_glm_pack_planes_grouped": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+    "pa_glm_planes_bytes": (c_size_t, [c_int, c_int64, c_int64]),
+    "pa_glm_grouped_planes_bytes": (c_size_t, [c_int, c_int64, c_int64]),
+    "pa_glm_pack_planes_grouped": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                            c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "pa_glm_bernoulli_grouped_planes_workspace": (c_size_t, [c_int64, c_int64]),
-    "pa_glm_bernoulli_grouped_planes_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64,
+    "pa_glm_bernoulli_grouped_planes_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_int64,
                                                         c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                                         c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                                         c_void_p, c_void_p, c_size_t, c_void_p]),
-    "pa_glm_pack_planes": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "pa_glm_pack_planes": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "pa_glm_planes_tune": (c_int, [c_int, c_int]),
     "pa_glm_planes_finalize_mode": (c_int, [c_int]),
     "pa_glm_planes_stamps": (c_int, [c_void_p]),
     "pa_glm_bernoulli_planes_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
-    "pa_glm_bernoulli_planes_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double,
+    "pa_glm_bernoulli_planes_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                                 c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "pa_glm_bernoulli_grouped_workspace": (c_size_t, [c_int64, c_int64, c_int64]),

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "glm_bf16.h"
 #include "glm_planes.h"
+#include "glm_planes16.h"
 #include "glm_finalize.h"
 #include "chain.h"
 
@@ -551,6 +552,59 @@ static void glm_planes_launch_grouped(int nseg, int npass, const unsigned char* 
                      D, P, nst_total, part, cu_count(), fin, grp);
 }
 
+// ---- the two-plane f16 image (glm_planes16.h): 8 KiB super-tiles, four workgroups per CU ----------
+static int64_t glmh_tile_bytes(int64_t ntiles) { return ntiles * (int64_t)GLMH_TILE; }
+
+static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
+  GlmPlanesPlan pl;
+  pl.nb = 3;
+  // measured at the headline size (tools/bench_glm_planes.py, kernel + finalize): 2 workgroups per
+  // CU 57.6 us, 3: 59.5, 4: 62.4 -- the loop is issue-bound, more waves only add barrier waits
+  pl.bpc = g_planes_bpc > 0 && g_planes_bpc <= 4 ? g_planes_bpc : 2;
+  pl.npass = (int)((P + 63) / 64);
+  pl.nst = ((N + 31) / 32 + 1) / 2;
+  int64_t cap = (int64_t)cu_count() * pl.bpc / pl.npass;
+  if (cap < 1) cap = 1;
+  pl.nblocks = (int)(pl.nst < cap ? (pl.nst < 1 ? 1 : pl.nst) : cap);
+  return pl;
+}
+
+template <int OCC>
+static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
+                            const float* w, const float* b, int64_t N, int D, int P, float* part,
+                            const uint32_t* trailer, hipStream_t s) {
+  auto k = glm_planes_f16_kernel<3, OCC, false>;
+  constexpr int lds = GlmHCfg<3>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
+                     b, N, D, P, pl.nst, part, cu_count(), trailer, g_planes_stamps,
+                     GlmGroupArgs{nullptr, nullptr, 1});
+}
+
+template <int OCC>
+static void glmh_launch_grouped(int nseg, int npass, const unsigned char* img, const float* y_img,
+                                const float* w, const float* b, int64_t N, int D, int P,
+                                int64_t nst_total, float* part, const uint32_t* trailer,
+                                const GlmGroupArgs& grp, hipStream_t s) {
+  auto k = glm_planes_f16_kernel<3, OCC, true>;
+  constexpr int lds = GlmHCfg<3>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)npass), dim3(256), lds, s, img, y_img, w, b, N,
+                     D, P, nst_total, part, cu_count(), trailer, g_planes_stamps, grp);
+}
+
+// max |X| -> the image trailer {bits, kx}; the pack kernels derive kx from it
+static int glmh_absmax(const float* X, int64_t n, uint32_t* trailer, hipStream_t s) {
+  if (hipMemsetAsync(trailer, 0, GLMH_TRAILER, s) != hipSuccess)
+    return pa::fail(PA_ERR_LAUNCH, "glm_pack_planes: memset of the image trailer failed");
+  if (n == 0) return PA_OK;
+  int64_t grid = (n + 256 * 8 - 1) / (256 * 8);
+  const int64_t cap = (int64_t)cu_count() * 8;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(glm_absmax_kernel, dim3((unsigned)grid), dim3(256), 0, s, X, n, trailer);
+  return pa::check_launch("glm_absmax_kernel");
+}
+
 // ---- in-kernel finalize (glm_planes.h): the arrival counters --------------------------------------
 // One zeroed block per device, allocated the first time a plane image is packed (never inside a
 // stream capture) and kept: launches leave the counters zero.  One plane-image launch per device at
@@ -705,28 +759,47 @@ int pa_glm_bernoulli_grouped_fwd_bwd(const float* X, const float* y, const float
   return pa::fail(PA_ERR_UNSUPPORTED, "glm_grouped: no kernel for DT=%d PT=%d", DT, PT);
 }
 
-size_t pa_glm_grouped_planes_bytes(int64_t nst_total, int64_t D) {
+#define PA_REQUIRE_FORMAT(f, who)                                                   \
+  PA_REQUIRE((f) == PA_GLM_PLANES_BF16X3 || (f) == PA_GLM_PLANES_F16X2, who ": unknown image format %d", (f))
+
+size_t pa_glm_grouped_planes_bytes(int format, int64_t nst_total, int64_t D) {
   if (nst_total < 0 || D < 1 || D > 32) return 0;
-  // the tile image, then the observations in the image's padded row order
+  // the tile image, then the observations in the image's padded row order (f16: then the trailer)
+  if (format == PA_GLM_PLANES_F16X2)
+    return (size_t)nst_total * 2 * pa::GLMH_TILE + (size_t)nst_total * 64 * sizeof(float) +
+           pa::GLMH_TRAILER;
+  if (format != PA_GLM_PLANES_BF16X3) return 0;
   return (size_t)nst_total * 2 * pa::GLMP_TILE + (size_t)nst_total * 64 * sizeof(float);
 }
 
-int pa_glm_pack_planes_grouped(const float* X, const float* y, int64_t N, int64_t D,
+int pa_glm_pack_planes_grouped(int format, const float* X, const float* y, int64_t N, int64_t D,
                                const int64_t* seg, const int64_t* st_off, int64_t nseg,
                                int64_t nst_total, void* planes, size_t planes_bytes,
                                pa_stream_t stream) {
   PA_REQUIRE(N >= 0 && D >= 1 && D <= 32 && nseg >= 0 && nst_total >= 0,
              "glm_pack_planes_grouped: bad shape N=%lld D=%lld nseg=%lld", (long long)N, (long long)D,
              (long long)nseg);
+  PA_REQUIRE_FORMAT(format, "glm_pack_planes_grouped");
   PA_REQUIRE(nseg < (1 << 30), "glm_pack_planes_grouped: too many segments");
   if (nst_total == 0 || nseg == 0) return PA_OK;
   PA_REQUIRE(X && y && seg && st_off && planes, "glm_pack_planes_grouped: NULL pointer");
-  PA_REQUIRE(planes_bytes >= pa_glm_grouped_planes_bytes(nst_total, D),
+  PA_REQUIRE(planes_bytes >= pa_glm_grouped_planes_bytes(format, nst_total, D),
              "glm_pack_planes_grouped: image buffer too small");
   PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_pack_planes_grouped: unaligned image");
   unsigned char* img = (unsigned char*)planes;
-  float* y_img = (float*)(img + (size_t)nst_total * 2 * pa::GLMP_TILE);
   const int64_t ntiles = nst_total * 2;
+  if (format == PA_GLM_PLANES_F16X2) {
+    float* y16 = (float*)(img + pa::glmh_tile_bytes(ntiles));
+    uint32_t* trailer = (uint32_t*)(y16 + nst_total * 64);
+    hipStream_t s = pa::as_stream(stream);
+    const int rc = pa::glmh_absmax(X, N * D, trailer, s);
+    if (rc != PA_OK) return rc;
+    hipLaunchKernelGGL(pa::glm_pack_planes_f16_grouped_kernel,
+                       dim3((unsigned)((ntiles * 128 + 255) / 256)), dim3(256), 0, s, X, y, (int)D, seg,
+                       st_off, (int)nseg, ntiles, img, y16, trailer);
+    return pa::check_launch("glm_pack_planes_f16_grouped_kernel");
+  }
+  float* y_img = (float*)(img + (size_t)nst_total * 2 * pa::GLMP_TILE);
   hipLaunchKernelGGL(pa::glm_pack_planes_grouped_kernel, dim3((unsigned)((ntiles * 128 + 255) / 256)),
                      dim3(256), 0, pa::as_stream(stream), X, y, (int)D, seg, st_off, (int)nseg, ntiles,
                      img, y_img);
@@ -739,7 +812,7 @@ size_t pa_glm_bernoulli_grouped_planes_workspace(int64_t nseg, int64_t P) {
   return (size_t)(nseg < 1 ? 1 : nseg) * npass * (2 * 1024 + 2 * 2 * 32) * sizeof(float);
 }
 
-int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, const float* b,
+int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, const float* w, const float* b,
                                             double scale, int64_t N, int64_t D, int64_t P, int64_t G,
                                             const int64_t* seg, const int64_t* st_off, int64_t nseg,
                                             const int64_t* group_seg_off, int64_t nst_total,
@@ -751,6 +824,7 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, 
   if (D > 32)
     return pa::fail(PA_ERR_UNSUPPORTED, "glm_grouped_planes: the plane image holds D <= 32 (got %lld)",
                     (long long)D);
+  PA_REQUIRE_FORMAT(format, "glm_grouped_planes");
   PA_REQUIRE(nseg < (1 << 30) && P < (1 << 20) && G < (1 << 24), "glm_grouped_planes: shape too large");
   PA_REQUIRE(w && ll && gw && gb, "glm_grouped_planes: NULL parameter/output pointer");
   hipStream_t s = pa::as_stream(stream);
@@ -767,14 +841,30 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, 
   PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_grouped_planes_workspace(nseg, P),
              "glm_grouped_planes: workspace too small");
   const unsigned char* img = (const unsigned char*)planes;
-  const float* y_img = (const float*)(img + (size_t)nst_total * 2 * pa::GLMP_TILE);
   float* part = (float*)workspace;
   const int npass = (int)((P + 63) / 64);
   hipEvent_t ev0, ev1;
   const bool br = pa::take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  pa::glm_planes_launch_grouped((int)nseg, npass, img, y_img, w, b, N, (int)D, (int)P, nst_total, part,
-                                pa::GlmGroupArgs{seg, st_off, (int)G}, s);
+  if (format == PA_GLM_PLANES_F16X2) {
+    const float* y16 = (const float*)(img + pa::glmh_tile_bytes(nst_total * 2));
+    const uint32_t* trailer = (const uint32_t*)(y16 + nst_total * 64);
+    const pa::GlmGroupArgs ga{seg, st_off, (int)G};
+    const int bpc = pa::g_planes_bpc > 0 ? pa::g_planes_bpc : 3;
+    if (bpc >= 4)
+      pa::glmh_launch_grouped<4>((int)nseg, npass, img, y16, w, b, N, (int)D, (int)P, nst_total, part,
+                                 trailer, ga, s);
+    else if (bpc == 3)
+      pa::glmh_launch_grouped<3>((int)nseg, npass, img, y16, w, b, N, (int)D, (int)P, nst_total, part,
+                                 trailer, ga, s);
+    else
+      pa::glmh_launch_grouped<2>((int)nseg, npass, img, y16, w, b, N, (int)D, (int)P, nst_total, part,
+                                 trailer, ga, s);
+  } else {
+    const float* y_img = (const float*)(img + (size_t)nst_total * 2 * pa::GLMP_TILE);
+    pa::glm_planes_launch_grouped((int)nseg, npass, img, y_img, w, b, N, (int)D, (int)P, nst_total,
+                                  part, pa::GlmGroupArgs{seg, st_off, (int)G}, s);
+  }
   if (br) (void)hipEventRecord(ev1, s);
   int rc = pa::check_launch("glm_planes_kernel<grouped>");
   if (rc != PA_OK) return rc;
@@ -789,28 +879,43 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(const void* planes, const float* w, 
   return pa::check_launch("glm_grouped_finalize");
 }
 
-size_t pa_glm_planes_bytes(int64_t N, int64_t D) {
+size_t pa_glm_planes_bytes(int format, int64_t N, int64_t D) {
   if (N < 0 || D < 1 || D > 32) return 0;
+  if (format == PA_GLM_PLANES_F16X2)
+    return (size_t)pa::glmh_tile_bytes(pa::glm_planes_tiles(N)) + pa::GLMH_TRAILER;
+  if (format != PA_GLM_PLANES_BF16X3) return 0;
   return (size_t)pa::glm_planes_tiles(N) * pa::GLMP_TILE;
 }
 
-int pa_glm_pack_planes(const float* X, int64_t N, int64_t D, void* planes, size_t planes_bytes,
-                       pa_stream_t stream) {
+int pa_glm_pack_planes(int format, const float* X, int64_t N, int64_t D, void* planes,
+                       size_t planes_bytes, pa_stream_t stream) {
   {
     // the arrival counters of the in-kernel finalize: packing never happens inside a capture
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone)
       (void)pa::glmf_counters(true);
   }
+  PA_REQUIRE_FORMAT(format, "glm_pack_planes");
   PA_REQUIRE(N >= 0 && D >= 1, "glm_pack_planes: bad shape N=%lld D=%lld", (long long)N, (long long)D);
   if (D > 32)
     return pa::fail(PA_ERR_UNSUPPORTED, "glm_pack_planes: the plane image holds D <= 32 (got %lld)",
                     (long long)D);
   PA_REQUIRE(N < (int64_t(1) << 40), "glm_pack_planes: shape too large");
-  PA_REQUIRE(planes && planes_bytes >= pa_glm_planes_bytes(N, D), "glm_pack_planes: image too small");
+  PA_REQUIRE(planes && planes_bytes >= pa_glm_planes_bytes(format, N, D),
+             "glm_pack_planes: image too small");
   PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_pack_planes: unaligned image");
   PA_REQUIRE(N == 0 || X, "glm_pack_planes: NULL data pointer");
   const int64_t nt = pa::glm_planes_tiles(N);
+  if (format == PA_GLM_PLANES_F16X2) {
+    hipStream_t s = pa::as_stream(stream);
+    uint32_t* trailer = (uint32_t*)((unsigned char*)planes + pa::glmh_tile_bytes(nt));
+    const int rc = pa::glmh_absmax(X, N * D, trailer, s);
+    if (rc != PA_OK) return rc;
+    // (also with no rows: the kernel's thread 0 writes the exponent into the trailer)
+    hipLaunchKernelGGL(pa::glm_pack_planes_f16_kernel, dim3((unsigned)((nt * 128 + 255) / 256 + (nt == 0))),
+                       dim3(256), 0, s, X, N, (int)D, nt, (unsigned char*)planes, trailer);
+    return pa::check_launch("glm_pack_planes_f16_kernel");
+  }
   if (nt == 0) return PA_OK;
   hipLaunchKernelGGL(pa::glm_pack_planes_kernel, dim3((unsigned)((nt * 128 + 255) / 256)), dim3(256),
                      0, pa::as_stream(stream), X, N, (int)D, nt, (unsigned char*)planes);
@@ -839,6 +944,7 @@ int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
 
 size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P) {
   if (N < 0 || D < 1 || D > 32 || P < 1) return 0;
+  // (the same for both image formats: the record count is capped at four workgroups per CU)
   const pa::GlmPlanesPlan pl = pa::glm_planes_plan(N, P);
   // records of the deepest / widest tuning so that the knob never invalidates a workspace
   const size_t cap = (size_t)pa::cu_count() * 4;
@@ -849,7 +955,7 @@ size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P) {
          (size_t)pl.npass * pa::GLMF_GROUPS * rec * sizeof(double);
 }
 
-int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const float* w,
+int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float* y, const float* w,
                                     const float* b, double scale, int64_t N, int64_t D, int64_t P,
                                     float* ll, float* gw, float* gb, void* workspace,
                                     size_t workspace_bytes, pa_stream_t stream) {
@@ -858,6 +964,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   if (D > 32)
     return pa::fail(PA_ERR_UNSUPPORTED, "glm_planes: the plane image holds D <= 32 (got %lld)",
                     (long long)D);
+  PA_REQUIRE_FORMAT(format, "glm_planes");
   PA_REQUIRE(N < (int64_t(1) << 40) && P < (1 << 20), "glm_planes: shape too large");
   PA_REQUIRE(w && ll && gw && gb, "glm_planes: NULL parameter/output pointer");
   PA_REQUIRE(N == 0 || (planes && y), "glm_planes: NULL data pointer");
@@ -873,7 +980,8 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_planes: unaligned image");
   PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_planes_workspace(N, D, P),
              "glm_planes: workspace too small");
-  const pa::GlmPlanesPlan pl = pa::glm_planes_plan(N, P);
+  const pa::GlmPlanesPlan pl =
+      format == PA_GLM_PLANES_F16X2 ? pa::glmh_plan(N, P) : pa::glm_planes_plan(N, P);
   float* part = (float*)workspace;
   const unsigned char* img = (const unsigned char*)planes;
   hipEvent_t ev0, ev1;
@@ -884,7 +992,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   const double ll_offset = (double)(pl.nst * 64 - N) * 0.6931471805599453;
   pa::GlmFinArgs fin;
   fin.counters = nullptr;
-  if (pa::g_planes_fin_mode == 1 && pl.npass <= pa::GLMF_MAX_PASSES) {
+  if (format == PA_GLM_PLANES_BF16X3 && pa::g_planes_fin_mode == 1 && pl.npass <= pa::GLMF_MAX_PASSES) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     fin.counters = pa::glmf_counters(!capturing);
@@ -895,8 +1003,15 @@ int pa_glm_bernoulli_planes_fwd_bwd(const void* planes, const float* y, const fl
   fin.scale = scale; fin.ll_offset = ll_offset;
   fin.D = (int)D; fin.P = (int)P;
   fin.tstamps = pa::g_planes_stamps;
-  if (pl.nb == 3) pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
-  else pa::glm_planes_launch_one<4, 2>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
+  if (format == PA_GLM_PLANES_F16X2) {
+    const uint32_t* trailer = (const uint32_t*)(img + pa::glmh_tile_bytes(pa::glm_planes_tiles(N)));
+    if (pl.bpc >= 4) pa::glmh_launch_one<4>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    else pa::glmh_launch_one<3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+  } else if (pl.nb == 3) {
+    pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
+  } else {
+    pa::glm_planes_launch_one<4, 2>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
+  }
   if (br) (void)hipEventRecord(ev1, s);
   int rc = pa::check_launch("glm_planes_kernel");
   if (rc != PA_OK) return rc;

@@ -1,0 +1,511 @@
+// glm_planes16.h -- the fused Bernoulli-logits GLM pass of glm_planes.h with the design matrix kept
+// as TWO scaled f16 planes instead of three bf16 planes (included by glm.hip; same partial-record
+// format, same finalize).
+//
+// Why.  glm_planes_kernel is bound by instruction issue, not by HBM: per 32x32 tile 25 bf16 MFMAs
+// (six piece products per GEMM K chunk) next to ~300 VALU instructions, 2100 clocks per tile and SIMD
+// (profiles/r03_pmc_summary.json), and its image is 1.5x the f32 matrix.  An f16 carries 11
+// significant bits: two pieces x ~= x1 + x2 (round-to-nearest at each level, the residual exact in
+// f32) represent an f32 to 2^-22 relative -- the representation error of ONE f32 rounding is 2^-24
+// -- and a product needs the three piece products of order >= 2^-11:
+//     x*w ~= x2*w1 + x1*w2 + x1*w1                       (dropped: x2*w2 = O(2^-22 |x||w|))
+// i.e. 13 MFMAs per tile instead of 25, a two-level split of the gradient operand instead of a
+// three-level one, and an image of exactly the f32 matrix's size (4 B per element: the algorithmic
+// bytes of SURVEY 8d).  Error per logit <= 3 * 2^-22 sum_d |x_d w_d| against the 32 * 2^-24 bound of
+// an f32 FMA chain over D = 32 -- the same class; measured against the f64 oracle next to torch's own
+// f32 result in tests/test_kernels_gpu.py::test_glm_planes_f16_is_f32_class.
+//
+// f16 has 5 exponent bits: the pieces are SCALED by powers of two (exact) so that they sit at the top
+// of the f16 range and the second pieces stay normal over 2^-13 of dynamic range below the largest
+// element (smaller elements keep an ABSOLUTE error <= 2^-40 of the largest: below the f32
+// accumulation's own rounding):
+//   X:  one exponent kx per image, max |X| 2^kx in [2^14, 2^15) (pa_glm_pack_planes finds max |X| on
+//       the device and stores kx in the image's trailer: no host round trip);
+//   W:  one exponent kw[p] per particle row, chosen in the kernel's prologue from max_d |w[p,d]| and
+//       the bias (below); the f32 accumulator then holds 2^(kx + kw[p]) * l2 and the element-wise code
+//       starts with one multiply by the per-lane constant 2^-(kx + kw[p]);
+//   b:  enters the accumulator through the aux MFMA as three f16 pieces of b 2^(kx+kw[p]-15) against
+//       2^15 (rows past the end of the plate: 0, their logit is exactly 0 as in glm_planes.h);
+//       kw[p] is capped so that this stays inside f16 -- when the bias dominates the row, W gives up
+//       low bits that are below the rounding of (x.w + b) anyway;
+//   g:  y - sigmoid(l) is formed as 2^14 g (one fma instead of a subtraction), so that its second
+//       piece is normal down to |g| = 2^-17; the gradient accumulator holds 2^(14 + kx) gw.
+#pragma once
+#include "glm_planes.h"
+
+namespace pa {
+
+constexpr int GLMH_TILE = 2 * GLMP_PLANE;   // bytes of one 32-row tile image: planes x1, x2
+constexpr int GLMH_TRAILER = 256;           // after the tiles (and y_img): u32 max|X| bits, i32 kx
+constexpr int GLMH_KMAX = 60;               // |kx|, |kw| <= 60: every descale factor is a normal f32
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f16x8 as_f16x8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  u32x4v v = {a, b, c, d};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+// the image exponent from max |X| (IEEE bits of a non-negative f32; 0 or non-finite: no scaling)
+__host__ __device__ __forceinline__ int glmh_exponent_of(uint32_t absmax_bits) {
+  const int e = (int)(absmax_bits >> 23) & 0xff;
+  if (absmax_bits == 0u || e == 0xff) return 0;
+  // ilogb of a normal f32 is e - 127; subnormals (e == 0) are treated as 2^-127
+  int k = 14 - (e == 0 ? -127 : e - 127);
+  return k > GLMH_KMAX ? GLMH_KMAX : (k < -GLMH_KMAX ? -GLMH_KMAX : k);
+}
+
+// max |X| as the unsigned maximum of the magnitudes' bit patterns (NaN patterns order above +inf:
+// a non-finite matrix gets kx = 0 and its NaN / inf reach the outputs as they would in f32)
+__global__ __launch_bounds__(256) void glm_absmax_kernel(const float* __restrict__ X, int64_t n,
+                                                         uint32_t* __restrict__ out) {
+  uint32_t m = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t v = __builtin_bit_cast(uint32_t, X[i]) & 0x7fffffffu;
+    m = v > m ? v : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+
+// (a, b) -> hi and lo f16 pairs, a ~= a1 + a2 to 2^-22 |a| (RN at both levels; the residual is one
+// v_fma_mix_f32 per element: f16 piece times -1 plus the f32 value, exact)
+__device__ __forceinline__ void split_pair_f16(float a, float b, uint32_t& p1, uint32_t& p2) {
+  const f32x2v v = {a, b};
+  p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2v));   // v_cvt_pk_f16_f32
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p1), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p1), "v"(b));
+  const f32x2v r = {ra, rb};
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2v));
+}
+__device__ __forceinline__ float f16_lo(uint32_t p) {
+  return (float)__builtin_bit_cast(f16x2v, p)[0];
+}
+__device__ __forceinline__ float f16_hi(uint32_t p) {
+  return (float)__builtin_bit_cast(f16x2v, p)[1];
+}
+
+// 8 consecutive features of one row, already scaled -> 2 x 16 B
+__device__ __forceinline__ void glmh_store_slot(const float (&v)[8], unsigned char* q) {
+  uint32_t p1[4], p2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_pair_f16(v[2 * j], v[2 * j + 1], p1[j], p2[j]);
+  *reinterpret_cast<uint4*>(q) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+  *reinterpret_cast<uint4*>(q + GLMP_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+}
+
+// one thread per (tile, row, slot); `trailer` = {max |X| bits (glm_absmax_kernel), kx (written here)}
+__global__ __launch_bounds__(256) void glm_pack_planes_f16_kernel(const float* __restrict__ X,
+                                                                  int64_t N, int D, int64_t ntiles,
+                                                                  unsigned char* __restrict__ img,
+                                                                  uint32_t* __restrict__ trailer) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kx = glmh_exponent_of(trailer[0]);
+  if (idx == 0) trailer[1] = (uint32_t)kx;
+  if (idx >= ntiles * 128) return;
+  const int64_t T = idx >> 7;
+  const int r = (int)(idx >> 2) & 31, s = (int)idx & 3;
+  const int64_t row = T * 32 + r;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int d = 8 * s + j;
+    v[j] = (row < N && d < D) ? ldexpf(X[row * D + d], kx) : 0.0f;
+  }
+  glmh_store_slot(v, img + T * GLMH_TILE + glmp_slot_ofs(r, s));
+}
+
+// the hierarchical variant: segments on super-tile boundaries, see glm_pack_planes_grouped_kernel
+__global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
+    const float* __restrict__ X, const float* __restrict__ y, int D, const int64_t* __restrict__ seg,
+    const int64_t* __restrict__ st_off, int nseg, int64_t ntiles, unsigned char* __restrict__ img,
+    float* __restrict__ y_img, uint32_t* __restrict__ trailer) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kx = glmh_exponent_of(trailer[0]);
+  if (idx == 0) trailer[1] = (uint32_t)kx;
+  if (idx >= ntiles * 128) return;
+  const int64_t T = idx >> 7, st = T >> 1;
+  const int r = (int)(idx >> 2) & 31, sl = (int)idx & 3;
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (st_off[mid] <= st) lo = mid;
+    else hi = mid - 1;
+  }
+  const int64_t a = seg[3 * lo], e = seg[3 * lo + 1];
+  const int64_t row = a + (T - 2 * st_off[lo]) * 32 + r;
+  const bool ok = row < e;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int d = 8 * sl + j;
+    v[j] = (ok && d < D) ? ldexpf(X[row * D + d], kx) : 0.0f;
+  }
+  glmh_store_slot(v, img + T * GLMH_TILE + glmp_slot_ofs(r, sl));
+  if (sl == 0) y_img[T * 32 + r] = ok ? y[row] : 0.0f;
+}
+
+template <int NB>
+struct GlmHCfg {
+  static constexpr int NRT = 2, NPT = 2;
+  static constexpr int ST_BYTES = NRT * GLMH_TILE;     // 8 KiB super-tile image (64 rows)
+  static constexpr int PW = ST_BYTES / 1024 / 4;       // 1 KiB DMA pieces per wave and super-tile
+  static constexpr int NDMA = PW + 1;                  // + the wave's 32 observations
+  static constexpr int WROWS = 32 * NPT;
+  static constexpr int WPL = WROWS * 64;               // one W plane
+  static constexpr int OFS_WAUX = 2 * WPL;             // per particle 16 B: {b1 | b2, b3, descale, -}
+  static constexpr int OFS_RING = OFS_WAUX + WROWS * 16;
+  static constexpr int OFS_Y = OFS_RING + NB * ST_BYTES;
+  static constexpr int LDS_BYTES = OFS_Y + NB * 4 * 256;
+};
+
+constexpr uint32_t F16_2P15 = 0x7800u;        // 2^15
+constexpr float GLMH_GSCALE = 16384.0f;       // 2^14: the scale of y - 1/2 and of g
+
+template <int NB, int OCC, bool GROUPED = false>
+__global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
+    const unsigned char* __restrict__ img, const float* __restrict__ y,
+    const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
+    int64_t nst, float* __restrict__ part, int prio_cus, const uint32_t* __restrict__ trailer,
+    unsigned long long* __restrict__ tstamps, const GlmGroupArgs grp) {
+  using C = GlmHCfg<NB>;
+  constexpr int NRT = C::NRT, NPT = C::NPT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS,
+                WPL = C::WPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int rt = wave / NPT, pt = wave % NPT;
+  const int pbase = blockIdx.y * WROWS;
+
+  if (tstamps != nullptr && threadIdx.x == 0)
+    __hip_atomic_fetch_min(&tstamps[0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  int64_t grid = gridDim.x, first = blockIdx.x, st_end = nst, row_st0 = 0, n_rows = N;
+  int64_t my_count = first < nst ? (nst - first + grid - 1) / grid : 0;
+  int64_t w_stride = D;
+  if constexpr (GROUPED) {
+    const int64_t sg = blockIdx.x;
+    first = grp.st_off[sg];
+    st_end = grp.st_off[sg + 1];
+    my_count = st_end - first;
+    grid = 1;
+    row_st0 = first;
+    n_rows = grp.seg[3 * sg + 1] - grp.seg[3 * sg];
+    w += grp.seg[3 * sg + 2] * D;                       // w[p, group, :]
+    w_stride = (int64_t)grp.G * D;
+  }
+
+  auto issue = [&](int64_t st, int bi) {
+    const int64_t stc = st < st_end ? st : st_end - 1;
+    const unsigned char* src = img + stc * ST_BYTES + (wave * PW) * 1024 + lane * 16;
+    const uint32_t dst = lds_base + C::OFS_RING + bi * ST_BYTES + (wave * PW) * 1024;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) dma16(src + k * 1024, dst + k * 1024);
+    int64_t row = (stc * NRT + rt) * 32 + l31;
+    if constexpr (!GROUPED) row = row < N ? row : N - 1;
+    dma4(y + row, lds_base + C::OFS_Y + (bi * 4 + wave) * 256);
+  };
+
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) issue(first + k * grid, k);
+
+  // ---- W planes and the per-particle constants, once per block: thread (pl, s) holds 8 features of
+  //      particle row pl; the four threads of a row are neighbours --------------------------------
+  const int kx = (int)trailer[1];
+  {
+    const int pl = threadIdx.x >> 2, s = threadIdx.x & 3;
+    const int p = pbase + pl;
+    float v[8];
+    float mw = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = 8 * s + j;
+      // log2(e) rides in W and b (one f32 rounding each), as in glm_planes.h
+      v[j] = (p < P && d < D) ? w[(int64_t)p * w_stride + d] * GLMP_LOG2E : 0.0f;
+      mw = __builtin_fmaxf(mw, __builtin_fabsf(v[j]));
+    }
+    mw = __builtin_fmaxf(mw, __shfl_xor(mw, 1));
+    mw = __builtin_fmaxf(mw, __shfl_xor(mw, 2));
+    const float b2 = (p < P && b != nullptr) ? b[p] * GLMP_LOG2E : 0.0f;
+    // NaN / inf weights: fmaxf drops a NaN; the scaled pieces below carry it into the accumulator
+    const uint32_t mwb = __builtin_bit_cast(uint32_t, mw), bb = __builtin_bit_cast(uint32_t, b2) & 0x7fffffffu;
+    const int ew = (int)(mwb >> 23), eb = (int)(bb >> 23);
+    int kw = (mwb != 0u && ew != 0xff) ? 14 - (ew - 127) : GLMH_KMAX;
+    const int kb = (bb != 0u && eb != 0xff) ? 29 - kx - (eb - 127) : GLMH_KMAX;
+    kw = kw < kb ? kw : kb;
+    kw = kw > GLMH_KMAX ? GLMH_KMAX : (kw < -GLMH_KMAX ? -GLMH_KMAX : kw);
+    if (mwb == 0u && bb == 0u) kw = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ldexpf(v[j], kw);
+    uint32_t p1[4], p2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair_f16(v[2 * j], v[2 * j + 1], p1[j], p2[j]);
+    unsigned char* q = smem + (pl >> 5) * GLMP_PLANE + glmp_slot_ofs(pl & 31, s);
+    *reinterpret_cast<uint4*>(q) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+    *reinterpret_cast<uint4*>(q + WPL) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    if (s == 0) {
+      // the bias in accumulator units over 2^15, three pieces (24 bits)
+      const float bs = ldexpf(b2, kx + kw - 15);
+      uint32_t q1, q2, q3, dummy;
+      split_pair_f16(bs, 0.0f, q1, q2);
+      const float r2 = (bs - f16_lo(q1)) - f16_lo(q2);
+      split_pair_f16(r2, 0.0f, q3, dummy);
+      uint32_t* wx = reinterpret_cast<uint32_t*>(smem + C::OFS_WAUX) + 4 * pl;
+      wx[0] = (q1 & 0xffffu) | (q2 << 16);              // k slots {0: b1, 1: b2}
+      wx[1] = q3 & 0xffffu;                             // k slots {2: b3, 3: 0}
+      wx[2] = __builtin_bit_cast(uint32_t, ldexpf(1.0f, -(kx + kw)));
+      wx[3] = 0u;
+    }
+  }
+  __syncthreads();
+
+  const uint32_t* wx_l = reinterpret_cast<const uint32_t*>(smem + C::OFS_WAUX) + 4 * (pt * 32 + l31);
+  const f16x8 b_aux = as_f16x8(h == 0 ? wx_l[0] : 0u, h == 0 ? wx_l[1] : 0u, 0u, 0u);
+  const float dsc = __builtin_bit_cast(float, wx_l[2]);       // 2^-(kx + kw[particle of this lane])
+  f32x16v gwacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gwacc[r] = 0.0f;
+  float s_yl[2] = {0.0f, 0.0f}, s_abs[2] = {0.0f, 0.0f}, s_g[2] = {0.0f, 0.0f};
+  float p_t[2] = {1.0f, 1.0f};
+  int e_t[2] = {0, 0};
+
+  const int a_ofs0 = glmp_slot_ofs(l31, h), a_ofs1 = glmp_slot_ofs(l31, 2 + h);
+  const unsigned char* w_row = smem + pt * GLMP_PLANE;
+  const int q = lane & 15, gi1 = (lane >> 4) & 1;
+  const int tr_row = 4 * h + (q >> 2);
+  const int tr_slot = 2 * gi1 + ((q & 3) >> 1), tr_in = (q & 1) * 8;
+  const int tr_ofs_a = tr_row * 64 + ((tr_slot ^ h) << 4) + tr_in;
+  const int tr_ofs_b = (tr_row + 8) * 64 + ((tr_slot ^ ((h + 2) & 3)) << 4) + tr_in;
+
+  // piece products of a K chunk, smallest first: x2 w1, x1 w2, x1 w1
+  constexpr int TA[3] = {1, 0, 0};
+  constexpr int TB[3] = {0, 1, 0};
+
+  // W operands of both K chunks stay in registers for the whole launch (2 x 2 x 4 VGPRs)
+  f16x8 wa0[2], wa1[2];
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    wa0[pl] = *reinterpret_cast<const f16x8*>(w_row + pl * WPL + a_ofs0);
+    wa1[pl] = *reinterpret_cast<const f16x8*>(w_row + pl * WPL + a_ofs1);
+  }
+
+  // the wave's 32 observations of ring slot b become 2^14 (y - 1/2) in place (0 past the end)
+  auto prep_rows = [&](int b_, int64_t st_) -> bool {
+    float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + (b_ * 4 + wave) * 256);
+    const int64_t rows_left = n_rows - ((st_ - row_st0) * NRT + rt) * 32;        // scalar
+    const bool okr = (int64_t)l31 < rows_left;
+    if (lane < 32) ys_[lane] = okr ? __builtin_fmaf(ys_[lane], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
+    return okr;
+  };
+  auto gemm1_aux = [&](bool okr) -> f32x16v {
+    const uint32_t a0 = (h == 0 && okr) ? (F16_2P15 | (F16_2P15 << 16)) : 0u;   // k slots {0, 1}
+    const uint32_t a1 = (h == 0 && okr) ? F16_2P15 : 0u;                        // k slot 2
+    const f32x16v zero = {};
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a0, a1, 0u, 0u), b_aux, zero, 0, 0, 0);
+  };
+  auto load_a = [&](const unsigned char* Xt, int c, f16x8 (&xa)[2]) {
+    const int ao = c == 0 ? a_ofs0 : a_ofs1;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) xa[pl] = *reinterpret_cast<const f16x8*>(Xt + pl * GLMP_PLANE + ao);
+  };
+  // element-wise on one accumulator element, plain f32 instructions only (see glm_planes.h); returns
+  // 2^14 g
+  auto elem1 = [&](float acc, float yh, int par) -> float {
+    const float l2 = acc * dsc;
+    const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(l2));
+    const float t = e + 1.0f;
+    const float inv = __builtin_amdgcn_rcpf(t);
+    s_yl[par] = __builtin_fmaf(yh, l2, s_yl[par]);
+    s_abs[par] += __builtin_fabsf(l2);
+    p_t[par] *= t;
+    const float g = yh - __builtin_copysignf(__builtin_fmaf(inv, GLMH_GSCALE, -0.5f * GLMH_GSCALE), l2);
+    s_g[par] += g;
+    return g;
+  };
+  auto renorm = [&]() {
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      e_t[c2] += __builtin_amdgcn_frexp_expf(p_t[c2]);
+      p_t[c2] = __builtin_amdgcn_frexp_mantf(p_t[c2]);
+    }
+  };
+  auto tr_wait = [&](v2u32 (&xlo)[2], v2u32 (&xhi)[2], f16x8 (&xb)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(xlo[0]), "+v"(xhi[0]), "+v"(xlo[1]), "+v"(xhi[1])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const u32x4v cc = {xlo[pl][0], xlo[pl][1], xhi[pl][0], xhi[pl][1]};
+      xb[pl] = __builtin_bit_cast(f16x8, cc);
+    }
+  };
+  auto tr_issue = [&](uint32_t tr_a, uint32_t tr_b, int kh, v2u32 (&xlo)[2], v2u32 (&xhi)[2]) {
+    const uint32_t a = tr_a + (kh ? 1024u : 0u), b2 = tr_b + (kh ? 1024u : 0u);
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(xlo[0]) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(xhi[0]) : "v"(b2));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xlo[1]) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xhi[1]) : "v"(b2));
+  };
+  auto load_y = [&](const float* ys_, int kh, float (&yv)[8]) {
+    const float4 y0 = *reinterpret_cast<const float4*>(ys_ + 16 * kh + 4 * h);
+    const float4 y1 = *reinterpret_cast<const float4*>(ys_ + 16 * kh + 8 + 4 * h);
+    yv[0] = y0.x; yv[1] = y0.y; yv[2] = y0.z; yv[3] = y0.w;
+    yv[4] = y1.x; yv[5] = y1.y; yv[6] = y1.z; yv[7] = y1.w;
+  };
+
+  int64_t st = first;
+  int bi = 0;
+  const uint32_t prio_slot = (uint32_t)(blockIdx.x / prio_cus);
+  uint64_t prio_clock = wall_clock64();
+
+  // ---- software pipeline as in glm_planes.h: GEMM1 of tile it+1 runs against the element-wise work
+  //      and GEMM2 of tile it ---------------------------------------------------------------------
+  f32x16v acc_cur = {};
+  if (my_count > 0) {
+    wait_vmcnt<(NB - 2) * C::NDMA>();
+    __builtin_amdgcn_s_barrier();
+    const bool ok0 = prep_rows(0, st);
+    acc_cur = gemm1_aux(ok0);
+    const unsigned char* X0 = smem + C::OFS_RING + rt * GLMH_TILE;
+    f16x8 xa[2];
+    load_a(X0, 0, xa);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa0[TB[t]], acc_cur, 0, 0, 0);
+    load_a(X0, 1, xa);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa1[TB[t]], acc_cur, 0, 0, 0);
+  }
+  for (int64_t it = 0; it < my_count; ++it) {
+    if constexpr (OCC > 1) {
+      const uint32_t ph = ((uint32_t)(prio_clock >> 8) + prio_slot) % (uint32_t)OCC;
+      if (ph == 0) __builtin_amdgcn_s_setprio(0);
+      else if (ph == 1) __builtin_amdgcn_s_setprio(1);
+      else if (ph == 2) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(3);
+      prio_clock = wall_clock64();
+    }
+    int bn = bi + 1 == NB ? 0 : bi + 1;
+    wait_vmcnt<(NB - 3) * C::NDMA>();
+    __builtin_amdgcn_s_barrier();
+    {
+      int bf = bi + (NB - 1);
+      bf = bf >= NB ? bf - NB : bf;
+      issue(st + (NB - 1) * grid, bf);
+    }
+    const unsigned char* Xc = smem + C::OFS_RING + bi * ST_BYTES + rt * GLMH_TILE;
+    const unsigned char* Xn = smem + C::OFS_RING + bn * ST_BYTES + rt * GLMH_TILE;
+    const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y + (bi * 4 + wave) * 256);
+    const uint32_t tr_a = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_a;
+    const uint32_t tr_b = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_b;
+
+    const bool okn = prep_rows(bn, st + grid);
+    f32x16v acc_nxt = gemm1_aux(okn);
+    v2u32 xlo[2], xhi[2];
+    f16x8 xa[2], xb[2];
+    float yv[8], g[8];
+    uint32_t g1[4], g2[4];
+
+    // -- GEMM1(it+1)  ||  element-wise(it, K half 0) and its split
+    tr_issue(tr_a, tr_b, 0, xlo, xhi);
+    load_y(ysc, 0, yv);
+    load_a(Xn, 0, xa);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa0[TB[t]], acc_nxt, 0, 0, 0);
+      g[2 * t] = elem1(acc_cur[2 * t], yv[2 * t], 0);
+      g[2 * t + 1] = elem1(acc_cur[2 * t + 1], yv[2 * t + 1], 1);
+    }
+    load_a(Xn, 1, xa);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa1[TB[t]], acc_nxt, 0, 0, 0);
+      if (t == 0) {
+        g[6] = elem1(acc_cur[6], yv[6], 0);
+        g[7] = elem1(acc_cur[7], yv[7], 1);
+      } else {
+        split_pair_f16(g[4 * (t - 1)], g[4 * (t - 1) + 1], g1[2 * (t - 1)], g2[2 * (t - 1)]);
+        split_pair_f16(g[4 * (t - 1) + 2], g[4 * (t - 1) + 3], g1[2 * (t - 1) + 1], g2[2 * (t - 1) + 1]);
+      }
+    }
+    renorm();
+    tr_wait(xlo, xhi, xb);
+    // -- GEMM2(it, K half 0)  ||  element-wise(it, K half 1)
+    {
+      const f16x8 ga[2] = {as_f16x8(g1[0], g1[1], g1[2], g1[3]), as_f16x8(g2[0], g2[1], g2[2], g2[3])};
+      tr_issue(tr_a, tr_b, 1, xlo, xhi);
+      load_y(ysc, 1, yv);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        gwacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[TA[t]], xb[TB[t]], gwacc, 0, 0, 0);
+        const int e0 = t == 0 ? 0 : (t == 1 ? 3 : 6), e1 = t == 2 ? 8 : e0 + 3;
+#pragma unroll
+        for (int j = e0; j < e1; ++j) g[j] = elem1(acc_cur[8 + j], yv[j], j & 1);
+      }
+    }
+    renorm();
+    uint32_t h1[4], h2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair_f16(g[2 * j], g[2 * j + 1], h1[j], h2[j]);
+    tr_wait(xlo, xhi, xb);
+    // -- GEMM2(it, K half 1)
+    {
+      const f16x8 ga[2] = {as_f16x8(h1[0], h1[1], h1[2], h1[3]), as_f16x8(h2[0], h2[1], h2[2], h2[3])};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        gwacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[TA[t]], xb[TB[t]], gwacc, 0, 0, 0);
+    }
+    acc_cur = acc_nxt;
+    st += grid;
+    bi = bn;
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_setprio(0);
+  __syncthreads();
+
+  // ---- block reduction over the row tiles in a fixed order, one partial record in the format of
+  //      glm.hip; the power-of-two scales come out here (exact) --------------------------------------
+  constexpr int REC = NPT * 1024 + 2 * NPT * 32;
+  static_assert((NPT * 1024 + 2 * NPT * 64) * 4 <= C::LDS_BYTES - C::OFS_RING, "LDS too small");
+  float* red = reinterpret_cast<float*>(smem + C::OFS_RING);
+  float* red2 = red + NPT * 1024;
+  const float gw_dsc = ldexpf(1.0f, -(14 + kx)), g_dsc = 1.0f / GLMH_GSCALE;
+  const float s_lg = (float)(e_t[0] + e_t[1]) + (__builtin_amdgcn_logf(p_t[0]) + __builtin_amdgcn_logf(p_t[1]));
+  const float ll_acc = 0.69314718055994530942f *
+                       ((s_yl[0] + s_yl[1]) * g_dsc - 0.5f * (s_abs[0] + s_abs[1]) - s_lg);
+  const float gb_acc = (s_g[0] + s_g[1]) * g_dsc;
+  for (int rr = 0; rr < NRT; ++rr) {
+    if (rt == rr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = (pt * 16 + r) * 64 + lane;
+        red[idx] = (rr == 0 ? 0.0f : red[idx]) + gwacc[r] * gw_dsc;
+      }
+      const int i0 = (2 * pt) * 64 + lane, i1 = (2 * pt + 1) * 64 + lane;
+      red2[i0] = (rr == 0 ? 0.0f : red2[i0]) + ll_acc;
+      red2[i1] = (rr == 0 ? 0.0f : red2[i1]) + gb_acc;
+    }
+    __syncthreads();
+  }
+  float* rec = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * REC;
+  for (int i = threadIdx.x; i < NPT * 1024; i += 256) rec[i] = red[i];
+  for (int i = threadIdx.x; i < 2 * NPT * 32; i += 256) {
+    const int qq = i >> 5, j = i & 31;
+    rec[NPT * 1024 + i] = red2[qq * 64 + j] + red2[qq * 64 + 32 + j];
+  }
+  if (tstamps != nullptr && threadIdx.x == 0)
+    __hip_atomic_fetch_max(&tstamps[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace pa

@@ -5,6 +5,7 @@ current stream.  Tensors must live on a HIP device: there is no CPU implementati
 fallback (``_require_gpu`` raises).  PyTorch is used for device memory and streams only.
 """
 import ctypes
+import os
 
 import torch
 import torch.utils._python_dispatch
@@ -658,6 +659,11 @@ def glm_set_variant(variant):
 # glm_planes_revalidate() is called by SVI before every replay.
 GLM_PLANES_OFF, GLM_PLANES_AUTO, GLM_PLANES_ALWAYS = 0, 1, 2
 _planes_mode = GLM_PLANES_AUTO
+# image formats (include/pyro_amd.h): three exact bf16 planes, or two scaled f16 planes (default:
+# 4 B per element and 13 instead of 25 matrix instructions per tile; f32-class, see glm_planes16.h)
+GLM_PLANES_BF16X3, GLM_PLANES_F16X2 = 0, 1
+_planes_format = {"bf16x3": GLM_PLANES_BF16X3, "f16x2": GLM_PLANES_F16X2}[
+    os.environ.get("PYRO_AMD_GLM_PLANES", "f16x2")]
 _planes_cache = {}          # id(X) -> [weakref, version, planes or None, sightings]
 _PLANES_MAX_D, _PLANES_MIN_P = 32, 33
 
@@ -670,6 +676,32 @@ def glm_set_planes_mode(mode):
     _planes_mode = int(mode)
     if _planes_mode == GLM_PLANES_OFF:
         _planes_cache.clear()
+
+
+def glm_set_planes_format(fmt):
+    """GLM_PLANES_F16X2 (default) or GLM_PLANES_BF16X3 for images packed from now on; cached images
+    of the other format are dropped."""
+    global _planes_format
+    assert fmt in (GLM_PLANES_BF16X3, GLM_PLANES_F16X2)
+    if fmt != _planes_format:
+        _planes_cache.clear()
+        for segs in list(_grouped_with_image):
+            segs._planes = None
+    _planes_format = int(fmt)
+
+
+def glm_planes_format():
+    return _planes_format
+
+
+def _new_image(nbytes, device, fmt):
+    out = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=device)
+    out.pa_format = fmt           # the image buffer remembers its format
+    return out
+
+
+def _format_of(planes):
+    return getattr(planes, "pa_format", GLM_PLANES_BF16X3)
 
 
 def glm_planes_tune(ring_depth=0, blocks_per_cu=0):
@@ -707,17 +739,23 @@ class GlmDeviceClock:
         check(_lib.load().pa_glm_planes_stamps(None))
 
 
-def glm_pack_planes(X, out=None):
-    """X[N,D] f32 (D <= 32) -> the uint8 tile image pa_glm_bernoulli_planes_fwd_bwd reads."""
+def glm_pack_planes(X, out=None, fmt=None):
+    """X[N,D] f32 (D <= 32) -> the uint8 tile image pa_glm_bernoulli_planes_fwd_bwd reads (``fmt``:
+    GLM_PLANES_F16X2 / GLM_PLANES_BF16X3, default the process-wide format; ``out``: re-pack into an
+    existing image, in its format)."""
     _require_gpu(X)
     N, D = X.shape
     lib = _lib.load()
-    nbytes = lib.pa_glm_planes_bytes(N, D)
+    if out is not None:
+        fmt = _format_of(out)
+    elif fmt is None:
+        fmt = _planes_format
+    nbytes = lib.pa_glm_planes_bytes(fmt, N, D)
     if nbytes == 0 and N > 0:
         raise Unsupported("pyro_amd: no plane image for N=%d D=%d" % (N, D))
     if out is None:
-        out = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=X.device)
-    check(lib.pa_glm_pack_planes(_ptr(X), N, D, _ptr(out), nbytes, _stream()))
+        out = _new_image(nbytes, X.device, fmt)
+    check(lib.pa_glm_pack_planes(fmt, _ptr(X), N, D, _ptr(out), nbytes, _stream()))
     return out
 
 
@@ -794,7 +832,7 @@ def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D):
     ll = torch.empty((P,), dtype=w.dtype, device=y.device)
     gw = torch.empty((P, D), dtype=w.dtype, device=y.device)
     gb = torch.empty((P,), dtype=w.dtype, device=y.device)
-    check(lib.pa_glm_bernoulli_planes_fwd_bwd(_ptr(planes), _ptr(y), _ptr(w), _ptr(b), float(scale),
+    check(lib.pa_glm_bernoulli_planes_fwd_bwd(_format_of(planes), _ptr(planes), _ptr(y), _ptr(w), _ptr(b), float(scale),
                                               N, D, P, _ptr(ll), _ptr(gw), _ptr(gb), _ptr(ws),
                                               nbytes, _stream()))
     return ll, gw, gb
@@ -888,19 +926,23 @@ import weakref as _weakref  # noqa: E402
 _grouped_with_image = _weakref.WeakSet()
 
 
-def glm_pack_planes_grouped(X, y, segs, out=None):
+def glm_pack_planes_grouped(X, y, segs, out=None, fmt=None):
     """X[N,D] f32 (D <= 32), y[N], segs -> the uint8 image pa_glm_bernoulli_grouped_planes_fwd_bwd
     reads (tile planes, then y in the image's padded row order)."""
     _require_gpu(X, y)
     N, D = X.shape
     lib = _lib.load()
-    nbytes = lib.pa_glm_grouped_planes_bytes(segs.nst_total, D)
+    if out is not None:
+        fmt = _format_of(out)
+    elif fmt is None:
+        fmt = _planes_format
+    nbytes = lib.pa_glm_grouped_planes_bytes(fmt, segs.nst_total, D)
     if nbytes == 0 and N > 0:
         raise Unsupported("pyro_amd: no grouped plane image for N=%d D=%d" % (N, D))
     assert X.is_contiguous() and y.is_contiguous() and X.dtype == torch.float32 == y.dtype
     if out is None:
-        out = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=X.device)
-    check(lib.pa_glm_pack_planes_grouped(_ptr(X), _ptr(y), N, D, _ptr(segs.seg), _ptr(segs.st_off),
+        out = _new_image(nbytes, X.device, fmt)
+    check(lib.pa_glm_pack_planes_grouped(fmt, _ptr(X), _ptr(y), N, D, _ptr(segs.seg), _ptr(segs.st_off),
                                          segs.nseg, segs.nst_total, _ptr(out), nbytes, _stream()))
     return out
 
@@ -948,7 +990,7 @@ def glm_bernoulli_grouped_planes_fwd_bwd(planes, w, b, scale, N, D, segs):
     gw = torch.empty((P, G, D), dtype=w.dtype, device=w.device)
     gb = torch.empty((P,), dtype=w.dtype, device=w.device)
     check(lib.pa_glm_bernoulli_grouped_planes_fwd_bwd(
-        _ptr(planes), _ptr(w), _ptr(b), float(scale), N, D, P, G, _ptr(segs.seg), _ptr(segs.st_off),
+        _format_of(planes), _ptr(planes), _ptr(w), _ptr(b), float(scale), N, D, P, G, _ptr(segs.seg), _ptr(segs.st_off),
         segs.nseg, _ptr(segs.group_seg_off), segs.nst_total, _ptr(ll), _ptr(gw), _ptr(gb), _ptr(ws),
         nbytes, _stream()))
     return ll, gw, gb

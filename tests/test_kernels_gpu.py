@@ -335,8 +335,18 @@ def test_glm_bernoulli_grouped(gpu, glm_variant, N, D, P, G, use_mask):
     torch.testing.assert_close(g1[:, 0], g0, rtol=1e-5, atol=1e-4 * N ** 0.5)
 
 
+@pytest.fixture(params=["f16x2", "bf16x3"])
+def planes_fmt(request):
+    """Both plane-image formats (include/pyro_amd.h PA_GLM_PLANES_*); the process default is restored."""
+    k = _k()
+    before = k.glm_planes_format()
+    k.glm_set_planes_format(k.GLM_PLANES_F16X2 if request.param == "f16x2" else k.GLM_PLANES_BF16X3)
+    yield request.param
+    k.glm_set_planes_format(before)
+
+
 @pytest.mark.parametrize("N,D,P,G", [(5000, 32, 64, 7), (70_000, 17, 40, 50), (300, 8, 130, 3)])
-def test_glm_grouped_plane_image_kernel(gpu, N, D, P, G):
+def test_glm_grouped_plane_image_kernel(gpu, planes_fmt, N, D, P, G):
     """The hierarchical GLM site on the plane image (pa_glm_pack_planes_grouped +
     pa_glm_bernoulli_grouped_planes_fwd_bwd): the packer bit-exact against the oracle's image, the
     kernel against the numpy restatement (same tolerances as the kernel that splits X on the fly)
@@ -355,9 +365,14 @@ def test_glm_grouped_plane_image_kernel(gpu, N, D, P, G):
     segs = k.GroupSegments(off, gpu, target_segments=23)
     tX, ty = tt(X, gpu), tt(y, gpu)
     planes = k.glm_pack_planes_grouped(tX, ty, segs)
-    img, ypad = o_glm.glm_grouped_plane_image(X, y, segs.seg.cpu().numpy())
-    nb_img = img.size * 2
     got = planes.cpu().numpy()
+    if planes_fmt == "f16x2":
+        img, ypad, kx = o_glm.glm_grouped_plane_image_f16(X, y, segs.seg.cpu().numpy())
+        trailer = got[img.size * 2 + ypad.size * 4:][:8].view(np.int32)
+        assert int(trailer[1]) == kx
+    else:
+        img, ypad = o_glm.glm_grouped_plane_image(X, y, segs.seg.cpu().numpy())
+    nb_img = img.size * 2
     assert np.array_equal(got[:nb_img].view(np.uint16).reshape(img.shape), img)      # bit-exact
     assert np.array_equal(got[nb_img:nb_img + ypad.size * 4].view(np.float32), ypad)
     ll, gw, gb = k.glm_bernoulli_grouped_planes_fwd_bwd(planes, tt(w, gpu), tt(b, gpu), 2.0, N, D, segs)
@@ -539,14 +554,31 @@ def test_glm_bf16x3_is_f32_class(gpu):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,D", [(1, 1), (31, 3), (32, 32), (33, 32), (127, 20), (128, 32), (129, 7),
                                  (1000, 32), (4099, 8), (0, 4)])
-def test_glm_plane_image_bit_exact(gpu, N, D):
+def test_glm_plane_image_bit_exact(gpu, planes_fmt, N, D):
     k = _k()
     rng = np.random.default_rng(7 * N + D)
     X = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-6, 6, (N, 1)))).astype(np.float32)
-    img = k.glm_pack_planes(tt(X, gpu))
-    ref = o_glm.glm_plane_image(X)
-    got = img.cpu().numpy()[:ref.size * 2].view(np.uint16).reshape(ref.shape)
+    img = k.glm_pack_planes(tt(X, gpu)).cpu().numpy()
+    if planes_fmt == "f16x2":
+        ref, kx = o_glm.glm_plane_image_f16(X)
+        assert int(img[ref.size * 2:][:8].view(np.int32)[1]) == kx       # the trailer's exponent
+    else:
+        ref = o_glm.glm_plane_image(X)
+    got = img[:ref.size * 2].view(np.uint16).reshape(ref.shape)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("scale", [1e-30, 3e-5, 1.0, 77.0, 1e20, 0.0])
+def test_glm_plane_image_f16_exponent(gpu, scale):
+    """The f16 image's power-of-two scale follows max |X| over the whole f32 range (and is 0 for an
+    all-zero matrix); pieces bit-exact against the numpy restatement."""
+    k = _k()
+    rng = np.random.default_rng(3)
+    X = (rng.standard_normal((200, 9)) * scale).astype(np.float32)
+    img = k.glm_pack_planes(tt(X, gpu), fmt=k.GLM_PLANES_F16X2).cpu().numpy()
+    ref, kx = o_glm.glm_plane_image_f16(X)
+    assert int(img[ref.size * 2:][:8].view(np.int32)[1]) == kx
+    assert np.array_equal(img[:ref.size * 2].view(np.uint16).reshape(ref.shape), ref)
 
 
 @pytest.fixture(params=[3, 4], ids=["ring3", "ring4"])
@@ -562,7 +594,7 @@ def planes_ring(request):
                                    (2048, 32, 33), (5000, 20, 100), (70000, 32, 64),
                                    (3001, 12, 130), (129, 32, 5)])
 @pytest.mark.parametrize("use_bias", [True, False])
-def test_glm_planes(gpu, planes_ring, N, D, P, use_bias):
+def test_glm_planes(gpu, planes_fmt, planes_ring, N, D, P, use_bias):
     k = _k()
     rng = np.random.default_rng(N + D + P)
     X = rng.standard_normal((N, D)).astype(np.float32)
@@ -580,7 +612,7 @@ def test_glm_planes(gpu, planes_ring, N, D, P, use_bias):
     np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
 
 
-def test_glm_planes_transpose_detecting_and_f32_class(gpu):
+def test_glm_planes_transpose_detecting_and_f32_class(gpu, planes_fmt):
     """Asymmetric operands with a wide dynamic range (any row/column or K-slot permutation error in
     the DMA image, the row reads or the transpose reads shows up), and the f32-class error bound
     of test_glm_bf16x3_is_f32_class on the plane-image kernel."""
@@ -599,7 +631,56 @@ def test_glm_planes_transpose_detecting_and_f32_class(gpu):
         assert float(np.abs(o.cpu().numpy() - r).max() / np.abs(r).max()) < 3e-6
 
 
-@pytest.mark.parametrize("variant", ["planes", "bf16", "exact"])
+@pytest.mark.parametrize("case", ["plain", "bias_dominated", "tiny_w", "huge_w", "zero_w", "wide_x",
+                                  "mixed_particles"])
+def test_glm_planes_f16_is_f32_class(gpu, case):
+    """The two-plane f16 image (csrc/glm_planes16.h): its error against the float64 oracle is of the
+    size of an f32 evaluation's own error -- measured next to torch's f32 matmul + softplus on the
+    same inputs -- whatever the magnitudes of X, w and b (the power-of-two scales are per image and
+    per particle)."""
+    k = _k()
+    N, D, P = 20000, 32, 64
+    rng = np.random.default_rng(17)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (rng.standard_normal((P, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32)
+    if case == "bias_dominated":
+        w *= np.float32(1e-3)
+        b *= np.float32(8.0)
+    elif case == "tiny_w":
+        w *= np.float32(1e-12)
+        b *= np.float32(1e-12)
+    elif case == "huge_w":
+        X *= np.float32(1e-9)
+        w *= np.float32(1e9)
+    elif case == "zero_w":
+        w[:] = 0
+        b[:] = 0
+    elif case == "wide_x":
+        X *= np.exp(rng.uniform(-9, 9, (N, 1))).astype(np.float32)
+        w *= np.float32(0.01)
+    elif case == "mixed_particles":
+        w *= np.exp(rng.uniform(-12, 3, (P, 1))).astype(np.float32)
+    y = (rng.uniform(size=N) < 0.4).astype(np.float32)
+    ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
+    tX, ty, tw, tb = tt(X, gpu), tt(y, gpu), tt(w, gpu), tt(b, gpu)
+    out = k.glm_bernoulli_planes_fwd_bwd(k.glm_pack_planes(tX, fmt=k.GLM_PLANES_F16X2), ty, tw, tb,
+                                         1.0, N, D)
+    # torch's own f32 evaluation of the same quantities (CPU, the reference's arithmetic)
+    cX, cy, cw, cb = (torch.from_numpy(a) for a in (X, y, w, b))
+    lg = cw @ cX.t() + cb[:, None]
+    t_ll = (cy * lg - torch.nn.functional.softplus(lg)).sum(1)
+    g = cy - torch.sigmoid(lg)
+    f32 = (t_ll.numpy(), (g @ cX).numpy(), g.sum(1).numpy())
+    for name, o, r, f in zip(("ll", "gw", "gb"), out, ref, f32):
+        denom = max(float(np.abs(r).max()), 1e-30)
+        e_ours = float(np.abs(o.cpu().numpy() - r).max()) / denom
+        e_f32 = float(np.abs(f - r).max()) / denom
+        assert e_ours < 3e-6, (case, name, e_ours, e_f32)
+        assert e_ours < 4 * e_f32 + 3e-7, (case, name, e_ours, e_f32)
+
+
+@pytest.mark.parametrize("variant", ["planes", "planes_bf16x3", "bf16", "exact"])
 def test_glm_extreme_logits(gpu, variant):
     """Saturated logits (|x.w + b| up to ~200): exp2(-|l|) underflows to zero, 1 + e = 1, the
     sigmoid is exactly 0 or 1; log-likelihood and gradients stay finite and equal the float64 oracle
@@ -614,8 +695,9 @@ def test_glm_extreme_logits(gpu, variant):
     ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
     tX, ty, tw, tb = tt(X, gpu), tt(y, gpu), tt(w, gpu), tt(b, gpu)
     try:
-        if variant == "planes":
-            out = k.glm_bernoulli_planes_fwd_bwd(k.glm_pack_planes(tX), ty, tw, tb, 1.0, N, D)
+        if variant.startswith("planes"):
+            fmt = k.GLM_PLANES_BF16X3 if variant.endswith("bf16x3") else k.GLM_PLANES_F16X2
+            out = k.glm_bernoulli_planes_fwd_bwd(k.glm_pack_planes(tX, fmt=fmt), ty, tw, tb, 1.0, N, D)
         else:
             k.glm_set_planes_mode(k.GLM_PLANES_OFF)
             k.glm_set_variant(k.GLM_EXACT_F32 if variant == "exact" else k.GLM_AUTO)

@@ -75,18 +75,19 @@ def main():
         us, out = graph_time(lambda: k.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0))
         print(f"N={N} D={D} P={P}")
         print(f"  on-the-fly bf16x3           {us:8.1f} us   rel err ll {err(out)[0]:.1e} gw {err(out)[1]:.1e}")
-        planes = k.glm_pack_planes(X)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        k.glm_pack_planes(X, out=planes)
-        e.record()
-        torch.cuda.synchronize()
-        print(f"  pack planes (once per X)    {s.elapsed_time(e) * 1e3:8.1f} us")
-        for nb in (3, 4):
-            for bpc in range(1, {3: 3, 4: 2}[nb] + 1):
+        for fmt, fname, settings in ((k.GLM_PLANES_BF16X3, "bf16x3", [(3, 1), (3, 2), (3, 3), (4, 1), (4, 2)]),
+                                     (k.GLM_PLANES_F16X2, "f16x2", [(3, 2), (3, 3), (3, 4)])):
+            planes = k.glm_pack_planes(X, fmt=fmt)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            k.glm_pack_planes(X, out=planes)
+            e.record()
+            torch.cuda.synchronize()
+            print(f"  pack {fname} (once per X)    {s.elapsed_time(e) * 1e3:8.1f} us")
+            for nb, bpc in settings:
                 k.glm_planes_tune(nb, bpc)
                 us, out = graph_time(lambda: k.glm_bernoulli_planes_fwd_bwd(planes, y, w, b, 1.0, N, D))
-                print(f"  planes ring={nb} wg/CU={bpc}      {us:8.1f} us   {N*(4*D+4)/us/1e6:6.3f} TB/s(alg)"
+                print(f"  {fname} ring={nb} wg/CU={bpc}      {us:8.1f} us   {N*(4*D+4)/us/1e6:6.3f} TB/s(alg)"
                       f"   rel err ll {err(out)[0]:.1e} gw {err(out)[1]:.1e}")
         k.glm_planes_tune(0, 0)
         del X, planes

@@ -35,10 +35,10 @@ json.dump(summ, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 kms = None
 for f in glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "glm_planes_kernel" in row["Name"]:
+        if "glm_planes_" in row["Name"] and "kernel" in row["Name"] and "pack" not in row["Name"]:
             kms = float(row["AverageNs"]) / 1e6
 for k, d in summ.items():
-    if "glm_planes_kernel" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+    if "glm_planes_" in k and "pack" not in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"]["mean"], d["WRITE_SIZE"]["mean"]
         json.dump({"kernel": k, "hbm_bytes_per_launch": (2 * f + w) * 1024, "kernel_ms_in_graph": kms,
                    "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w,
