@@ -95,9 +95,6 @@ def glm_plane_image(X):
 
 
 # ---- the two-plane scaled f16 image (format PA_GLM_PLANES_F16X2, csrc/glm_planes16.h) -----------
-GLMH_KMAX = 60
-
-
 def f16_image_exponent(X):
     """kx of the image: max |X| * 2^kx in [2^14, 2^15); 0 for an all-zero or non-finite matrix
     (glmh_exponent_of: the unsigned maximum of the magnitudes' bit patterns, NaN above inf)."""
@@ -108,8 +105,7 @@ def f16_image_exponent(X):
     e = (bits >> 23) & 0xFF
     if bits == 0 or e == 0xFF:
         return 0
-    k = 14 - (-127 if e == 0 else e - 127)
-    return max(-GLMH_KMAX, min(GLMH_KMAX, k))
+    return 14 - (-127 if e == 0 else e - 127)
 
 
 def f16_split2(x):

@@ -37,7 +37,7 @@ namespace pa {
 
 constexpr int GLMH_TILE = 2 * GLMP_PLANE;   // bytes of one 32-row tile image: planes x1, x2
 constexpr int GLMH_TRAILER = 256;           // after the tiles (and y_img): u32 max|X| bits, i32 kx
-constexpr int GLMH_KMAX = 60;               // |kx|, |kw| <= 60: every descale factor is a normal f32
+constexpr int GLMH_KNONE = 1 << 20;         // "no constraint" in the choice of a row's exponent
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
@@ -52,8 +52,7 @@ __host__ __device__ __forceinline__ int glmh_exponent_of(uint32_t absmax_bits) {
   const int e = (int)(absmax_bits >> 23) & 0xff;
   if (absmax_bits == 0u || e == 0xff) return 0;
   // ilogb of a normal f32 is e - 127; subnormals (e == 0) are treated as 2^-127
-  int k = 14 - (e == 0 ? -127 : e - 127);
-  return k > GLMH_KMAX ? GLMH_KMAX : (k < -GLMH_KMAX ? -GLMH_KMAX : k);
+  return 14 - (e == 0 ? -127 : e - 127);          // -113 .. 141
 }
 
 // max |X| as the unsigned maximum of the magnitudes' bit patterns (NaN patterns order above +inf:
@@ -238,11 +237,10 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     // NaN / inf weights: fmaxf drops a NaN; the scaled pieces below carry it into the accumulator
     const uint32_t mwb = __builtin_bit_cast(uint32_t, mw), bb = __builtin_bit_cast(uint32_t, b2) & 0x7fffffffu;
     const int ew = (int)(mwb >> 23), eb = (int)(bb >> 23);
-    int kw = (mwb != 0u && ew != 0xff) ? 14 - (ew - 127) : GLMH_KMAX;
-    const int kb = (bb != 0u && eb != 0xff) ? 29 - kx - (eb - 127) : GLMH_KMAX;
+    int kw = (mwb != 0u && ew != 0xff) ? 14 - (ew == 0 ? -127 : ew - 127) : GLMH_KNONE;
+    const int kb = (bb != 0u && eb != 0xff) ? 29 - kx - (eb == 0 ? -127 : eb - 127) : GLMH_KNONE;
     kw = kw < kb ? kw : kb;
-    kw = kw > GLMH_KMAX ? GLMH_KMAX : (kw < -GLMH_KMAX ? -GLMH_KMAX : kw);
-    if (mwb == 0u && bb == 0u) kw = 0;
+    if (kw == GLMH_KNONE) kw = 0;                   // an all-zero (or non-finite) row
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = ldexpf(v[j], kw);
     uint32_t p1[4], p2[4];
@@ -261,7 +259,11 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
       uint32_t* wx = reinterpret_cast<uint32_t*>(smem + C::OFS_WAUX) + 4 * pl;
       wx[0] = (q1 & 0xffffu) | (q2 << 16);              // k slots {0: b1, 1: b2}
       wx[1] = q3 & 0xffffu;                             // k slots {2: b3, 3: 0}
-      wx[2] = __builtin_bit_cast(uint32_t, ldexpf(1.0f, -(kx + kw)));
+      // the descale factor stays a normal f32: beyond +-126 the logits are below / above anything
+      // f32 itself could hold
+      int kd = -(kx + kw);
+      kd = kd > 126 ? 126 : (kd < -126 ? -126 : kd);
+      wx[2] = __builtin_bit_cast(uint32_t, ldexpf(1.0f, kd));
       wx[3] = 0u;
     }
   }
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   static_assert((NPT * 1024 + 2 * NPT * 64) * 4 <= C::LDS_BYTES - C::OFS_RING, "LDS too small");
   float* red = reinterpret_cast<float*>(smem + C::OFS_RING);
   float* red2 = red + NPT * 1024;
-  const float gw_dsc = ldexpf(1.0f, -(14 + kx)), g_dsc = 1.0f / GLMH_GSCALE;
+  const float g_dsc = 1.0f / GLMH_GSCALE;
   const float s_lg = (float)(e_t[0] + e_t[1]) + (__builtin_amdgcn_logf(p_t[0]) + __builtin_amdgcn_logf(p_t[1]));
   const float ll_acc = 0.69314718055994530942f *
                        ((s_yl[0] + s_yl[1]) * g_dsc - 0.5f * (s_abs[0] + s_abs[1]) - s_lg);
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int idx = (pt * 16 + r) * 64 + lane;
-        red[idx] = (rr == 0 ? 0.0f : red[idx]) + gwacc[r] * gw_dsc;
+        red[idx] = (rr == 0 ? 0.0f : red[idx]) + ldexpf(gwacc[r], -(14 + kx));
       }
       const int i0 = (2 * pt) * 64 + lane, i1 = (2 * pt + 1) * 64 + lane;
       red2[i0] = (rr == 0 ? 0.0f : red2[i0]) + ll_acc;

@@ -632,7 +632,7 @@ def test_glm_planes_transpose_detecting_and_f32_class(gpu, planes_fmt):
 
 
 @pytest.mark.parametrize("case", ["plain", "bias_dominated", "tiny_w", "huge_w", "zero_w", "wide_x",
-                                  "mixed_particles"])
+                                  "mixed_particles", "x_1e-30"])
 def test_glm_planes_f16_is_f32_class(gpu, case):
     """The two-plane f16 image (csrc/glm_planes16.h): its error against the float64 oracle is of the
     size of an f32 evaluation's own error -- measured next to torch's f32 matmul + softplus on the
@@ -659,6 +659,9 @@ def test_glm_planes_f16_is_f32_class(gpu, case):
     elif case == "wide_x":
         X *= np.exp(rng.uniform(-9, 9, (N, 1))).astype(np.float32)
         w *= np.float32(0.01)
+    elif case == "x_1e-30":
+        X *= np.float32(1e-30)
+        w *= np.float32(1e30)
     elif case == "mixed_particles":
         w *= np.exp(rng.uniform(-12, 3, (P, 1))).astype(np.float32)
     y = (rng.uniform(size=N) < 0.4).astype(np.float32)
