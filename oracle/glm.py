@@ -155,7 +155,8 @@ def glm_grouped_plane_image_f16(X, y, seg):
         blk = np.zeros((pad, D), dtype=np.float32)
         blk[:rows] = X[a:e]
         yv = np.zeros(pad, dtype=np.float32)
-        yv[:rows] = y[a:e]
+        # as the kernel consumes them: 2^14 (y - 1/2) (one rounding, an fma), 0 in the padding
+        yv[:rows] = (y[a:e].astype(np.float64) * 16384.0 - 8192.0).astype(np.float32)
         blocks.append(blk)
         yb.append(yv)
     if not blocks:

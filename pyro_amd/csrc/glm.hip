@@ -557,7 +557,7 @@ static int64_t glmh_tile_bytes(int64_t ntiles) { return ntiles * (int64_t)GLMH_T
 
 static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
   GlmPlanesPlan pl;
-  pl.nb = 3;
+  pl.nb = g_planes_nb;
   // measured at the headline size (tools/bench_glm_planes.py, kernel + finalize): 2 workgroups per
   // CU 57.6 us, 3: 59.5, 4: 62.4 -- the loop is issue-bound, more waves only add barrier waits
   pl.bpc = g_planes_bpc > 0 && g_planes_bpc <= 4 ? g_planes_bpc : 2;
@@ -569,12 +569,12 @@ static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
   return pl;
 }
 
-template <int OCC>
+template <int NB, int OCC>
 static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
                             const float* w, const float* b, int64_t N, int D, int P, float* part,
                             const uint32_t* trailer, hipStream_t s) {
-  auto k = glm_planes_f16_kernel<3, OCC, false>;
-  constexpr int lds = GlmHCfg<3>::LDS_BYTES;
+  auto k = glm_planes_f16_kernel<NB, OCC, false>;
+  constexpr int lds = GlmHCfg<NB>::LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
                      b, N, D, P, pl.nst, part, cu_count(), trailer, g_planes_stamps,
@@ -850,7 +850,8 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, cons
     const float* y16 = (const float*)(img + pa::glmh_tile_bytes(nst_total * 2));
     const uint32_t* trailer = (const uint32_t*)(y16 + nst_total * 64);
     const pa::GlmGroupArgs ga{seg, st_off, (int)G};
-    const int bpc = pa::g_planes_bpc > 0 ? pa::g_planes_bpc : 3;
+    // (config 5, 1e7 rows: 0.667 / 0.668 / 0.657 ms per step at 2 / 3 / 4 workgroups per CU)
+    const int bpc = pa::g_planes_bpc > 0 ? pa::g_planes_bpc : 4;
     if (bpc >= 4)
       pa::glmh_launch_grouped<4>((int)nseg, npass, img, y16, w, b, N, (int)D, (int)P, nst_total, part,
                                  trailer, ga, s);
@@ -1005,8 +1006,9 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   fin.tstamps = pa::g_planes_stamps;
   if (format == PA_GLM_PLANES_F16X2) {
     const uint32_t* trailer = (const uint32_t*)(img + pa::glmh_tile_bytes(pa::glm_planes_tiles(N)));
-    if (pl.bpc >= 4) pa::glmh_launch_one<4>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
-    else pa::glmh_launch_one<3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    if (pl.nb == 4) pa::glmh_launch_one<4, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    else if (pl.bpc >= 4) pa::glmh_launch_one<3, 4>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    else pa::glmh_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
   } else if (pl.nb == 3) {
     pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);
   } else {

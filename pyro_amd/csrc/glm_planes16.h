@@ -39,6 +39,7 @@ constexpr int GLMH_TILE = 2 * GLMP_PLANE;   // bytes of one 32-row tile image: p
 constexpr int GLMH_TRAILER = 256;           // after the tiles (and y_img): u32 max|X| bits, i32 kx
 constexpr int GLMH_KNONE = 1 << 20;         // "no constraint" in the choice of a row's exponent
 
+constexpr float GLMH_GSCALE = 16384.0f;      // 2^14: the scale of y - 1/2 and of g
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
     v[j] = (ok && d < D) ? ldexpf(X[row * D + d], kx) : 0.0f;
   }
   glmh_store_slot(v, img + T * GLMH_TILE + glmp_slot_ofs(r, sl));
-  if (sl == 0) y_img[T * 32 + r] = ok ? y[row] : 0.0f;
+  // the observations as the kernel consumes them: 2^14 (y - 1/2), 0 in the padding
+  if (sl == 0) y_img[T * 32 + r] = ok ? __builtin_fmaf(y[row], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
 }
 
 template <int NB>
@@ -165,7 +167,6 @@ struct GlmHCfg {
 };
 
 constexpr uint32_t F16_2P15 = 0x7800u;        // 2^15
-constexpr float GLMH_GSCALE = 16384.0f;       // 2^14: the scale of y - 1/2 and of g
 
 template <int NB, int OCC, bool GROUPED = false>
 __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
@@ -304,7 +305,9 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + (b_ * 4 + wave) * 256);
     const int64_t rows_left = n_rows - ((st_ - row_st0) * NRT + rt) * 32;        // scalar
     const bool okr = (int64_t)l31 < rows_left;
-    if (lane < 32) ys_[lane] = okr ? __builtin_fmaf(ys_[lane], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
+    // (GROUPED: the image already holds the transformed observations)
+    if constexpr (!GROUPED)
+      if (lane < 32) ys_[lane] = okr ? __builtin_fmaf(ys_[lane], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
     return okr;
   };
   auto gemm1_aux = [&](bool okr) -> f32x16v {

@@ -15,10 +15,11 @@ import csv, glob, sys, os
 f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a step ends with the optimizer's launch (adam_kernel or the chained tail)
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "chain_" in r["Kernel_Name"]]
-ends = [i for k, i in enumerate(idx) if k + 1 == len(idx) or idx[k + 1] - i > 3]
-lo, hi = ends[-2] + 1, ends[-1] + 1
+# steps repeat: the previous step ends where the last 8 kernel names of the trace occurred before
+names = [r["Kernel_Name"] for r in rows]
+m, end = 8, len(rows) - 1
+prev = next(j for j in range(end - 1, m, -1) if names[j - m + 1:j + 1] == names[end - m + 1:end + 1])
+lo, hi = prev + 1, end + 1
 t0 = int(rows[lo]["Start_Timestamp"])
 tot = {}
 for r in rows[lo:hi]:
