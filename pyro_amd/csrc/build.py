@@ -86,9 +86,43 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+TORCH_LIB_PATH = os.path.join(LIB_DIR, "libpyro_amd_torch.so")
+
+
+def build_torch_ops(force=False, verbose=False):
+    """libpyro_amd_torch.so: the TORCH_LIBRARY registration of csrc/torch_ops.cpp (host-only C++ over
+    the C-ABI; g++ against torch's headers, linked to libpyro_amd.so next to it)."""
+    src = os.path.join(HERE, "torch_ops.cpp")
+    cxx = os.environ.get("CXX", "g++")
+    import shutil
+    if shutil.which(cxx) is None:
+        if os.path.exists(TORCH_LIB_PATH):
+            return TORCH_LIB_PATH
+        raise RuntimeError("no C++ compiler (%s) and no prebuilt %s" % (cxx, TORCH_LIB_PATH))
+    deps = max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "pyro_amd.h")))
+    if not force and os.path.exists(TORCH_LIB_PATH) and os.path.getmtime(TORCH_LIB_PATH) >= deps:
+        return TORCH_LIB_PATH
+    import torch
+    from torch.utils import cpp_extension
+    tlib = cpp_extension.library_paths()[0]
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in cpp_extension.include_paths()]
+    cmd += ["-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), src, "-o", TORCH_LIB_PATH,
+            "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-L" + LIB_DIR, "-lpyro_amd",
+            "-Wl,-rpath,$ORIGIN"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("torch_ops.cpp failed to build:\n%s\n%s" % (res.stdout, res.stderr))
+    if verbose:
+        print("linked", TORCH_LIB_PATH)
+    return TORCH_LIB_PATH
+
+
 if __name__ == "__main__":
     if "--variant" in sys.argv:          # --variant <suffix> <flag> [<flag> ...]
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
     else:
         print(build_library(force="--force" in sys.argv, verbose=True))
+        print(build_torch_ops(force="--force" in sys.argv, verbose=True))

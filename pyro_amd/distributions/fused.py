@@ -863,7 +863,14 @@ class _GlmBernoulliSum(torch.autograd.Function):
 
 
 def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
-    """Per-particle log-likelihood ll[P] (differentiable w.r.t. w[P,D], b[P])."""
+    """Per-particle log-likelihood ll[P] (differentiable w.r.t. w[P,D], b[P]).  On the GPU the site
+    goes through the dispatcher ops of ops/torch_library.py (pyro_amd::glm_bernoulli[_planes] and, in
+    the backward, pyro_amd::glm_chain: visible to torch.jit.trace / torch.compile) once
+    libpyro_amd_torch.so is present; the autograd.Function over the ctypes binding otherwise."""
+    if kernels.on_device(X) and X.dtype == torch.float32:
+        from ..ops import torch_library
+        if torch_library.available():
+            return torch_library.glm_bernoulli_ll(X, y, w, b, mask, scale)
     return _GlmBernoulliSum.apply(X, y, w, b, mask, float(scale))
 
 

@@ -66,3 +66,24 @@ def test_argument_errors_before_launch():
     assert lib.pa_glm_bernoulli_workspace(10, 200, 4) == 0
     assert lib.pa_dist_log_prob_sum_workspace(4, 100) == 0       # single-launch small-site path
     assert lib.pa_dist_log_prob_sum_workspace(4, 100000) > 0
+
+
+def test_torch_library_shim_loads_and_registers_the_schemas():
+    """csrc/torch_ops.cpp: the TORCH_LIBRARY registration over the C-ABI loads without a GPU and the
+    dispatcher knows the four ops (no compute here)."""
+    import torch
+
+    from pyro_amd.csrc.build import build_torch_ops
+    from pyro_amd.ops import torch_library
+    build_torch_ops()
+    assert torch_library.available()
+    for name, nret in (("glm_pack_planes", 1), ("glm_bernoulli_planes", 3), ("glm_bernoulli", 3),
+                       ("glm_chain", 2)):
+        schema = getattr(torch.ops.pyro_amd, name).default._schema
+        assert len(schema.returns) == nret, schema
+    # shape functions (register_fake): meta tensors flow through without touching a device
+    w = torch.empty((64, 32), device="meta")
+    ll, gw, gb = torch.ops.pyro_amd.glm_bernoulli_planes(
+        torch.empty((16,), dtype=torch.uint8, device="meta"), torch.empty((100,), device="meta"), w,
+        None, 1.0, 100, 32, 1)
+    assert ll.shape == (64,) and gw.shape == (64, 32) and gb.shape == (64,)
