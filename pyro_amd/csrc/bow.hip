@@ -22,6 +22,7 @@
 //   d planes [3][H/32][B/16] blocks: lane l = hidden unit (l & 31), k group: d[16 kt + 8 kg .. +7 docs][j]
 #include "common.h"
 #include "glm_bf16.h"
+#include "lds_dma.h"
 
 namespace pa {
 
@@ -83,92 +84,134 @@ typedef float f32x16b __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ bf16x8 as_op(const uint4& c) { return as_bf16x8(c.x, c.y, c.z, c.w); }
 
-// h[B, H] = bias + C W^T.  Workgroup = 4 waves = 256 documents (a wave: two 32-row tiles x 128 hidden
-// units).  The W planes of a chunk of four k-steps (4 x 12 operand blocks = 48 KiB) are brought into LDS
-// once per workgroup -- each wave copies a quarter, lane-linear, no conflicts -- and all four waves
-// read their B operands from there: the L2 serves 786 KB per 256 documents instead of per 64 (the
-// first version, every wave reading the planes itself, ran at the L2's bandwidth: 250 us for 36 us of
-// MFMA work at B = 1e5).  The histogram operands (A) stream from HBM straight into registers, one
-// chunk ahead.
-constexpr int BOW_KC = 4;                                   // k-steps per LDS chunk
-__global__ __launch_bounds__(256) void bow_linear_fwd_kernel(const uint4* __restrict__ imgA,
-                                                             const uint4* __restrict__ wpl,
-                                                             const float* __restrict__ bias,
-                                                             int64_t B, int V, int H,
-                                                             float* __restrict__ out) {
-  __shared__ uint4 wsm[BOW_KC * BOW_HT * 3 * 64];             // [k-step][tile][plane][lane]: 48 KiB
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// h[B, H] = bias + C W^T.  Work unit = 256 documents = 4 waves x two 32-row tiles x 128 hidden units,
+// two workgroups per CU.  The W planes travel in chunks of two k-steps (2 x 12 operand blocks = 24
+// KiB) L2 -> LDS by DMA (global_load_lds: no registers, each wave copies a quarter, lane-linear) into
+// a DOUBLE buffer one chunk ahead of the MFMAs, all four waves read their B operands from there; the
+// histogram operands (A) stream from HBM straight into registers one chunk ahead (two register sets:
+// a third one, two chunks ahead, does not fit next to the 128 accumulator registers at two waves per
+// SIMD).  Every VMEM operation of the loop is inline asm with hand-counted s_waitcnt: hipcc counts
+// only the loads it can see, so a compiler-placed wait for an A operand also drained the younger W
+// DMAs of the next chunk (147 us; before that: one LDS buffer filled through registers between two
+// barriers 243 us; every wave reading the planes itself 250 us -- for 26 us of MFMA work and 205 MB
+// of image at B = 1e5).
+constexpr int BOW_KC = 2;                                   // k-steps per LDS chunk
+constexpr int BOW_CHUNK_BLOCKS = BOW_KC * BOW_HT * 3;       // 24 blocks of 1 KiB
+constexpr int BOW_FWD_LDS = 2 * BOW_CHUNK_BLOCKS * 1024;    // 48 KiB
+constexpr int BOW_NA = 2 * BOW_KC;                          // A loads per chunk and lane
+
+struct BowASet { u32x4v t[2][BOW_KC]; };                    // [tile][k-step]
+
+__device__ __forceinline__ void bow_gload(u32x4v& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+// everything but the youngest N VMEM operations has landed; names the registers of the set about to be
+// consumed so that nothing reading them moves above the wait
+template <int N>
+__device__ __forceinline__ void bow_wait(BowASet& a) {
+  static_assert(BOW_KC == 2, "operand list");
+  asm volatile("s_waitcnt vmcnt(%4)"
+               : "+v"(a.t[0][0]), "+v"(a.t[0][1]), "+v"(a.t[1][0]), "+v"(a.t[1][1])
+               : "n"(N)
+               : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void bow_linear_fwd_kernel(const uint4* __restrict__ imgA,
+                                                                const uint4* __restrict__ wpl,
+                                                                const float* __restrict__ bias,
+                                                                int64_t B, int V, int H,
+                                                                float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bow_smem[];
+  const uint4* wsm = reinterpret_cast<const uint4*>(bow_smem);   // [buffer][k-step][tile][plane][lane]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)bow_smem);
   const int64_t nmt = (B + 31) / 32;                                  // document tiles
-  const int64_t mt0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
-  const bool live = mt0 < nmt, two = mt0 + 1 < nmt;
-  const int nkt = V / 16;
-  const int64_t wblk = (int64_t)nkt * BOW_HT * 64;                    // chunks per W plane
-  f32x16b acc[2][BOW_HT];
+  const int64_t nunits = (nmt + 7) / 8;
+  const int nkt = V / 16, nch = nkt / BOW_KC;                         // (nch is a multiple of 4)
+  const int64_t wblk = (int64_t)nkt * BOW_HT * 64;                    // uint4 per W plane
+  // this wave's quarter of chunk c: (k-step, tile, plane) = block index
+  auto issue_w = [&](int c, int buf) {
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < BOW_HT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-  const uint4* a0p = imgA + ((live ? mt0 : 0) * nkt) * 64 + lane;
-  const uint4* a1p = imgA + ((two ? mt0 + 1 : (live ? mt0 : 0)) * nkt) * 64 + lane;
-  uint4 ca0[BOW_KC], ca1[BOW_KC];
-#pragma unroll
-  for (int q = 0; q < BOW_KC; ++q) {
-    ca0[q] = a0p[(int64_t)q * 64];
-    ca1[q] = a1p[(int64_t)q * 64];
-  }
-  for (int kc = 0; kc < nkt; kc += BOW_KC) {
-    // this wave's quarter of the chunk's 48 blocks: (k-step, tile, plane) = block index / lane
-    __syncthreads();                                        // the previous chunk has been consumed
-#pragma unroll
-    for (int q = 0; q < BOW_KC * BOW_HT * 3 / 4; ++q) {
-      const int blk = wave * (BOW_KC * BOW_HT * 3 / 4) + q;
+    for (int q = 0; q < BOW_CHUNK_BLOCKS / 4; ++q) {
+      const int blk = wave * (BOW_CHUNK_BLOCKS / 4) + q;
       const int ks = blk / (BOW_HT * 3), n = (blk / 3) % BOW_HT, pl = blk % 3;
-      wsm[blk * 64 + lane] = wpl[((int64_t)(kc + ks) * BOW_HT + n) * 64 + lane + pl * wblk];
+      dma16_cached(wpl + ((int64_t)(c * BOW_KC + ks) * BOW_HT + n) * 64 + lane + pl * wblk,
+                   lds_base + (uint32_t)((buf * BOW_CHUNK_BLOCKS + blk) * 1024));
     }
-    // the histogram operands of the NEXT chunk (clamped at the end)
-    uint4 na0[BOW_KC], na1[BOW_KC];
-    const int kn = kc + BOW_KC < nkt ? kc + BOW_KC : kc;
+  };
+  for (int64_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int64_t mt0 = (unit * 4 + wave) * 2;
+    const bool live = mt0 < nmt, two = mt0 + 1 < nmt;
+    f32x16b acc[2][BOW_HT];
 #pragma unroll
-    for (int q = 0; q < BOW_KC; ++q) {
-      na0[q] = a0p[(int64_t)(kn + q) * 64];
-      na1[q] = a1p[(int64_t)(kn + q) * 64];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < BOW_KC; ++ks) {
-      const bf16x8 a0 = as_op(ca0[ks]), a1 = as_op(ca1[ks]);
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int n = 0; n < BOW_HT; ++n)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const bf16x8 bb = as_op(wsm[((ks * BOW_HT + n) * 3 + pl) * 64 + lane]);
-          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][n], 0, 0, 0);
-          acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][n], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    const uint4* a0p = imgA + ((live ? mt0 : 0) * nkt) * 64 + lane;
+    const uint4* a1p = imgA + ((two ? mt0 + 1 : (live ? mt0 : 0)) * nkt) * 64 + lane;
+    auto issue_a = [&](int c, BowASet& s) {
+#pragma unroll
+      for (int q = 0; q < BOW_KC; ++q) {
+        bow_gload(s.t[0][q], a0p + (int64_t)(c * BOW_KC + q) * 64);
+        bow_gload(s.t[1][q], a1p + (int64_t)(c * BOW_KC + q) * 64);
+      }
+    };
+    // One chunk: set `cur` holds A(c) (requested one chunk ago together with W(c)), `nxt` receives
+    // A(c + 1).  Nothing of this wave is in flight across the barrier.
+    auto chunk = [&](int c, BowASet& cur, BowASet& nxt) {
+      const int buf = c & 1;
+      bow_wait<0>(cur);
+      __syncthreads();                       // everybody's share of W(c); the other buffer is free
+      if (c + 1 < nch) {
+        issue_w(c + 1, buf ^ 1);
+        // (never past the end: the registers of a load nobody waits for are free for the compiler
+        // to reuse -- data landing later would overwrite whatever lives there, e.g. the epilogue's
+        // store addresses)
+        issue_a(c + 1, nxt);
+      }
+      const uint4* wb = wsm + (int64_t)buf * BOW_CHUNK_BLOCKS * 64;
+#pragma unroll
+      for (int ks = 0; ks < BOW_KC; ++ks) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, cur.t[0][ks]), a1 = __builtin_bit_cast(bf16x8, cur.t[1][ks]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int n = 0; n < BOW_HT; ++n) {
+            const bf16x8 bb = as_op(wb[((ks * BOW_HT + n) * 3 + pl) * 64 + lane]);
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][n], 0, 0, 0);
+            acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][n], 0, 0, 0);
+          }
+      }
+    };
+    // (the previous unit's last chunk sits in buffer 1 -- nch is even -- and this wave is past the
+    // barrier that ended the reads of buffer 0)
+    BowASet s0, s1;
+    issue_w(0, 0);
+    issue_a(0, s0);
+    for (int c = 0; c < nch; c += 2) {         // (nch is even)
+      chunk(c, s0, s1);
+      chunk(c + 1, s1, s0);
+    }
+    wait_vmcnt<0>();                           // nothing asynchronous is left when registers change hands
+    if (!live) continue;
+    // C/D layout: lane = column (hidden unit), register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int jl = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (m == 1 && !two) break;
+#pragma unroll
+      for (int n = 0; n < BOW_HT; ++n) {
+        const int j = n * 32 + jl;
+        if (j >= H) continue;
+        const float bj = bias != nullptr ? bias[j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t doc = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (doc < B) out[doc * H + j] = acc[m][n][r] + bj;
         }
-    }
-#pragma unroll
-    for (int q = 0; q < BOW_KC; ++q) {
-      ca0[q] = na0[q];
-      ca1[q] = na1[q];
-    }
-  }
-  if (!live) return;
-  // C/D layout: lane = column (hidden unit), register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  const int jl = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    if (m == 1 && !two) break;
-#pragma unroll
-    for (int n = 0; n < BOW_HT; ++n) {
-      const int j = n * 32 + jl;
-      if (j >= H) continue;
-      const float bj = bias != nullptr ? bias[j] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t doc = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (doc < B) out[doc * H + j] = acc[m][n][r] + bj;
       }
     }
   }
@@ -181,7 +224,18 @@ __global__ __launch_bounds__(256) void bow_linear_bwd_kernel(const uint4* __rest
                                                              int64_t Bp, int V, int ksplit,
                                                              float* __restrict__ partial) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // wave = hidden tile
-  const int vb = blockIdx.x, s = blockIdx.y;
+  // The V / 128 workgroups of one document chunk s all read the chunk's d planes (77 MB in total at
+  // B = 1e5, H = 128): dispatched to different XCDs -- consecutive workgroup ids go round-robin over
+  // the 8 XCDs -- every L2 fetched its own copy from HBM (820 MB of traffic, 130 us).  The linear id is
+  // decoded so that the workgroups of a chunk share an XCD and run back to back: the planes come from
+  // HBM once and from that L2 afterwards.
+  const int nvb = V / 128;
+  const int64_t L = blockIdx.x;
+  const int xcd = (int)(L & 7);
+  const int64_t slot = L >> 3;
+  const int vb = (int)(slot % nvb);
+  const int s = (int)((slot / nvb) * 8 + xcd);
+  if (s >= ksplit) return;
   const int64_t nkt = Bp / 16;
   const int64_t per = (nkt + ksplit - 1) / ksplit;
   const int64_t k_lo = (int64_t)s * per, k_hi = (k_lo + per < nkt) ? k_lo + per : nkt;
@@ -192,17 +246,41 @@ __global__ __launch_bounds__(256) void bow_linear_bwd_kernel(const uint4* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
   const uint4* ap = dpl + ((int64_t)wave * nkt) * 64 + lane;
-  for (int64_t kt = k_lo; kt < k_hi; ++kt) {
-    bf16x8 a[3];
+  const uint4* bp = imgB + ((int64_t)vb * 4 * nkt) * 64 + lane;
+  // The operands of a k-step are 7 independent 16-byte loads per lane and feed 12 MFMAs (384 pipe
+  // clocks): issued in the iteration that uses them the loop runs at the memory latency (~2000
+  // clocks per k-step and wave; measured 134 us for 40 us of matrix work at B = 1e5).  Three register
+  // sets, loads two k-steps ahead (clamped at the end: a re-read of the last step, never consumed).
+  struct Ops { uint4 a[3], b[4]; };
+  auto load = [&](int64_t kt, Ops& o) {
+    const int64_t k = kt < k_hi ? kt : k_hi - 1;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[pl] = as_op(ap[kt * 64 + pl * dblk]);
+    for (int pl = 0; pl < 3; ++pl) o.a[pl] = ap[k * 64 + pl * dblk];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const bf16x8 bb = as_op(imgB[(((int64_t)vb * 4 + n) * nkt + kt) * 64 + lane]);
+    for (int n = 0; n < 4; ++n) o.b[n] = bp[((int64_t)n * nkt + k) * 64];
+  };
+  auto mma = [&](const Ops& o) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pl], bb, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_op(o.a[pl]), as_op(o.b[n]), acc[n], 0, 0, 0);
+  };
+  if (k_lo < k_hi) {
+    Ops o0, o1, o2;
+    load(k_lo, o0);
+    load(k_lo + 1, o1);
+    int64_t kt = k_lo;
+    for (; kt + 2 < k_hi; kt += 3) {
+      load(kt + 2, o2);
+      mma(o0);
+      load(kt + 3, o0);
+      mma(o1);
+      load(kt + 4, o1);
+      mma(o2);
     }
+    if (kt < k_hi) mma(o0);
+    if (kt + 1 < k_hi) mma(o1);
   }
   float* dst = partial + (int64_t)s * 128 * V;
   const int wl = lane & 31, hh = lane >> 5;
@@ -239,19 +317,36 @@ __global__ __launch_bounds__(256) void tsgemm_tn_kernel(const uint4* __restrict_
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
   constexpr int TA[6] = {2, 1, 0, 1, 0, 0};
   constexpr int TB[6] = {0, 1, 2, 0, 1, 0};
-  for (int64_t kt = k_lo; kt < k_hi; ++kt) {
-    bf16x8 a[3];
+  // 15 independent operand loads per k-step for 24 MFMAs: two register sets, one k-step ahead (see
+  // bow_linear_bwd_kernel)
+  struct Ops { uint4 a[3], b[4][3]; };
+  auto load = [&](int64_t kt, Ops& o) {
+    const int64_t k = kt < k_hi ? kt : k_hi - 1;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[pl] = as_op(a_pl[((int64_t)wave * nkt + kt) * 64 + lane + pl * blk]);
+    for (int pl = 0; pl < 3; ++pl) o.a[pl] = a_pl[((int64_t)wave * nkt + k) * 64 + lane + pl * blk];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      bf16x8 b[3];
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[pl] = as_op(x_pl[((int64_t)n * nkt + kt) * 64 + lane + pl * blk]);
+      for (int pl = 0; pl < 3; ++pl) o.b[n][pl] = x_pl[((int64_t)n * nkt + k) * 64 + lane + pl * blk];
+  };
+  auto mma = [&](const Ops& o) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int t = 0; t < 6; ++t)          // smallest products first
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]], b[TB[t]], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_op(o.a[TA[t]]), as_op(o.b[n][TB[t]]), acc[n], 0, 0, 0);
+  };
+  if (k_lo < k_hi) {
+    Ops o0, o1;
+    load(k_lo, o0);
+    int64_t kt = k_lo;
+    for (; kt + 1 < k_hi; kt += 2) {
+      load(kt + 1, o1);
+      mma(o0);
+      load(kt + 2, o0);
+      mma(o1);
     }
+    if (kt < k_hi) mma(o0);
   }
   float* dst = partial + (int64_t)s * 128 * 128;
   const int cl = lane & 31, hh = lane >> 5;
@@ -386,8 +481,12 @@ int pa_bow_linear_fwd(const void* image_a, const float* W, const float* bias, in
   hipEvent_t ev0, ev1;
   const bool br = pa::take_bracket(PA_KERNEL_LDA, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
-  const int64_t nmt = (B + 31) / 32, nwg = (nmt + 7) / 8;
-  hipLaunchKernelGGL(pa::bow_linear_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, s,
+  const int64_t nmt = (B + 31) / 32, nunits = (nmt + 7) / 8;
+  const int64_t slots = (int64_t)pa::cu_count() * 2;
+  const int64_t nwg = nunits < slots ? nunits : slots;
+  (void)hipFuncSetAttribute((const void*)pa::bow_linear_fwd_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, pa::BOW_FWD_LDS);
+  hipLaunchKernelGGL(pa::bow_linear_fwd_kernel, dim3((unsigned)nwg), dim3(256), pa::BOW_FWD_LDS, s,
                      (const uint4*)image_a, (const uint4*)wpl, bias, B, (int)V, (int)H, out);
   if (br) (void)hipEventRecord(ev1, s);
   return pa::check_launch("bow_linear_fwd_kernel");
@@ -415,7 +514,8 @@ int pa_bow_linear_bwd(const void* image_b, const float* d_out, int64_t B, int64_
   hipLaunchKernelGGL(pa::bow_split_d_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, d_out,
                      B, Bp, (int)H, dpl);
   const int ks = pa::bow_ksplit(Bp, (int)V);
-  hipLaunchKernelGGL(pa::bow_linear_bwd_kernel, dim3((unsigned)(V / 128), (unsigned)ks), dim3(256), 0, s,
+  const int64_t ks8 = (ks + 7) / 8 * 8;           // (workgroups with s >= ks return at once)
+  hipLaunchKernelGGL(pa::bow_linear_bwd_kernel, dim3((unsigned)((V / 128) * ks8)), dim3(256), 0, s,
                      (const uint4*)dpl, (const uint4*)image_b, Bp, (int)V, ks, part);
   hipLaunchKernelGGL(pa::bow_reduce_kernel, dim3((unsigned)((H * V + 63) / 64)), dim3(256), 0, s, part, ks,
                      (int)H, (int)V, dW);

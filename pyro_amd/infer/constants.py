@@ -12,7 +12,7 @@ aborts the capture with ``HoistedConstantWritten`` and SVI captures again withou
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
-_MAX_ELEMS = 1 << 24
+_MAX_ELEMS = 1 << 28        # up to 1 GiB of f32 per constant (config 4: a 410 MB zeros histogram that is never read)
 
 
 class HoistedConstantWritten(RuntimeError):

@@ -31,9 +31,29 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True):
     svi = SVI(examples.hier_logreg_model, guide, pyro.optim.Adam({"lr": 0.01}),
               Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
               hip_graph=graph, graph_warmup=2)
+    clock = kernels.GlmDeviceClock(dev)          # before the capture: the pointer is a launch argument
     dt = timed(lambda: svi.step(X, y, segs), steps, 5)
-    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1),
-            "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
+    kms = []
+    for _ in range(5):                           # the grouped plane-image kernel inside the captured step
+        clock.arm()
+        svi.step(X, y, segs)
+        torch.cuda.synchronize()
+        kms.append(clock.read_ms())
+    clock.close()
+    kms = [v for v in kms if v == v]
+    out = {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1),
+           "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
+    if kms:
+        k_ms = sum(kms) / len(kms)
+        alg = N * (4 * D + 4)
+        f16 = kernels.glm_planes_format() == kernels.GLM_PLANES_F16X2
+        out["roofline"] = {"bound": "hbm", "kernel": "glm_planes_f16_kernel<grouped>" if f16 else "glm_planes_kernel<grouped>",
+                           "kernel_ms": k_ms, "kernel_ms_source": "device wall-clock stamps inside the captured step "
+                                                                  "(pa_glm_planes_stamps), mean of %d replays" % len(kms),
+                           "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9,
+                           "peak": 8000.0, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
+                           "traffic": None, "share_of_step": k_ms / (dt * 1e3)}
+    return out
 
 
 def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=True, model=None,
@@ -151,9 +171,43 @@ def config4(dev, docs=100_000, steps=10, batch_size=None):
               hip_graph=True, graph_warmup=3)
     dt = timed(lambda: svi.step(data, args), steps, 6)
     pairs = (docs if batch_size is None else batch_size) * args.num_words_per_doc
-    return {"batch_size": batch_size, "steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
-            "graphed": bool(svi.hip_graph and len(svi._graphs) == 1),
-            "algorithmic_TBps": pairs * 8.5 / dt / 1e12}
+    out = {"batch_size": batch_size, "steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
+           "graphed": bool(svi.hip_graph and len(svi._graphs) == 1),
+           "algorithmic_TBps": pairs * 8.5 / dt / 1e12}
+    import os
+    if batch_size is None and not os.environ.get("PA_NO_ROOFLINE"):
+        try:
+            out["roofline"] = _config4_roofline(data, args, predictor, dt)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def _config4_roofline(data, args, predictor, dt):
+    """The step's longest kernel: the first layer of the amortised guide on the corpus's cached
+    bag-of-words image (pa_bow_linear_fwd), timed stand-alone on the same operands with HIP events."""
+    V = args.num_words
+    imgs = kernels.bow_images_of(data, V)
+    if imgs is None:
+        return None
+    lin = [m for m in predictor.modules() if isinstance(m, torch.nn.Linear)][0]
+    B = data.shape[1]
+    W, bias = lin.weight.detach().contiguous(), lin.bias.detach().contiguous()
+    for _ in range(3):
+        kernels.bow_linear_fwd(imgs[0], W, bias, B)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        kernels.bow_linear_fwd(imgs[0], W, bias, B)
+    e.record()
+    torch.cuda.synchronize()
+    k_ms = s.elapsed_time(e) / 20
+    alg = imgs[0].numel() * 2 + B * W.shape[0] * 4 + W.numel() * 4     # image once, out once, W once
+    return {"bound": "hbm", "kernel": "bow_linear_fwd_kernel (+ its split / reduce launches)", "kernel_ms": k_ms,
+            "kernel_ms_source": "HIP events around 20 stand-alone calls on the step's operands",
+            "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12, "traffic": None,
+            "share_of_step": k_ms / (dt * 1e3)}
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 C=${1:-4}; OUT=gpurun_out/trace_cfg$C; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python -c "
+PA_NO_ROOFLINE=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python -c "
 import sys; sys.path.insert(0,'.')
 import torch
 from tools import bench_configs as b
