@@ -697,6 +697,23 @@ size_t pa_tsgemm_tn_workspace(int64_t B, int64_t M, int64_t N);
 int pa_tsgemm_tn(const float* A, const float* X, int64_t B, int64_t M, int64_t N, float* out,
                  void* workspace, size_t workspace_bytes, pa_stream_t stream);
 
+/* A Linear layer over a tall batch (B rows >> 128 features; the inner layers of examples/lda.py:76-92's
+ * predictor over 1e5 documents) without rocBLAS and without operand-split passes (csrc/tall.hip).
+ *   pa_tall_linear: Y[B, C] = G[B, R] Wm[R, C] (+ bias[C] when not NULL), R, C <= 128, G / Y contiguous;
+ *     Wm[r][c] = W[r * w_row_stride + c * w_col_stride]: F.linear's forward is Wm = weight^T (strides 1,
+ *     in_features), autograd's dx = g weight is Wm = weight (strides in_features, 1).
+ *   pa_tall_wgrad:  dW[R, K] = G^T X and, when db != NULL, db[R] = sum_b G[b, :] for G[B, R], X[B, K]
+ *     (R, K <= 128): autograd's weight and bias gradients of F.linear in one pass over the batch; the
+ *     long dimension is split over waves and reduced in a fixed order (bitwise reproducible).
+ * Operands are split exactly into three bf16 pieces in registers, six piece products on the matrix
+ * cores, f32 accumulation (f32-class).  Replaces torch.nn.functional.linear and its AddmmBackward /
+ * MmBackward products + the bias reduce. */
+int pa_tall_linear(const float* G, int64_t B, int64_t R, const float* W, int64_t w_row_stride,
+                   int64_t w_col_stride, int64_t C, const float* bias, float* Y, pa_stream_t stream);
+size_t pa_tall_wgrad_workspace(int64_t B, int64_t R, int64_t K);
+int pa_tall_wgrad(const float* G, const float* X, int64_t B, int64_t R, int64_t K, float* dW, float* db,
+                  void* workspace, size_t workspace_bytes, pa_stream_t stream);
+
 /* Reparameterised standard-Gamma draws out[i] ~ Gamma(alpha[i], 1) on the keyed Philox stream and,
  * when d_alpha != NULL, the implicit reparameterisation gradient d out[i] / d alpha[i].  Replaces
  * torch._standard_gamma + torch._standard_gamma_grad behind torch.distributions.Gamma.rsample

@@ -107,3 +107,17 @@ def bow_linear_grad(words, V, d_out):
     d = np.asarray(d_out, dtype=np.float64)
     return d.T @ bow_counts(words, V).T, d.sum(0)
 
+
+
+# ---- csrc/tall.hip: a Linear layer over a tall batch (the inner layers of examples/lda.py:76-92's predictor),
+# restated in float64: torch.nn.functional.linear and autograd's products for it
+def tall_linear(x, weight, bias=None):
+    """F.linear(x, weight, bias) = x weight^T + bias (torch/nn/functional.py linear)."""
+    out = np.asarray(x, np.float64) @ np.asarray(weight, np.float64).T
+    return out if bias is None else out + np.asarray(bias, np.float64)
+
+
+def tall_linear_grads(x, weight, g):
+    """(dx, dW, db) of F.linear for the upstream gradient g: g weight, g^T x, g.sum(0)."""
+    x, weight, g = (np.asarray(a, np.float64) for a in (x, weight, g))
+    return g @ weight, g.T @ x, g.sum(0)

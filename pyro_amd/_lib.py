@@ -111,6 +111,11 @@ _SIGNATURES = {
     "pa_glm_bernoulli_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pa_tall_linear": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                               c_void_p, c_void_p]),
+    "pa_tall_wgrad_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
+    "pa_tall_wgrad": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                              c_size_t, c_void_p]),
     "pa_glm_planes_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "pa_glm_grouped_planes_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "pa_glm_pack_planes_grouped": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,

@@ -1,0 +1,356 @@
+// tall.hip -- a Linear layer over a tall batch (B rows >> 128 features) without rocBLAS and without
+// separate operand-split passes: the inner layers of an amortised guide (examples/lda.py:76-92,
+// nn.Linear(100, 100) and nn.Linear(100, 8) over 1e5 documents per ELBO-gradient step).
+//
+// Reference path replaced per layer and step: F.linear forward (one rocBLAS product), and in the
+// backward  dx = g W  (rocBLAS),  dW = g^T x  (rocBLAS: a 100 x 100 x 1e5 product, long dimension not
+// split),  db = g.sum(0)  (a reduce kernel) -- torch/nn/functional.py linear + autograd's
+// AddmmBackward / MmBackward.  Measured on the MI355X at B = 1e5: 75 us (forward, 100 -> 100), 71 us
+// (dx) -- 27 TFLOP/s on 2 GFLOP -- and, on this library's round-3 route for dW, two split passes of
+// 25 us each in front of a 42-us product plus an 11-23 us reduce for db.
+//
+// Here, two kernels, f32 operands split exactly into three bf16 pieces in registers (the six piece
+// products of order >= 2^-16 on the matrix cores, f32 accumulation: f32-class, as glm_bf16.h):
+//   pa_tall_linear      Y[B, C] = G[B, R] Wm[R, C] (+ bias[C]),  R, C <= 128.  Wm is addressed through two
+//                       strides, so the forward (Wm = weight^T) and dx (Wm = weight) need no transposed
+//                       copy.  A wave owns 32 rows: A operands straight from HBM (two 16-byte loads per
+//                       lane and k-step, split in registers), B operands = the Wm planes, split once per
+//                       workgroup into LDS in operand order.
+//   pa_tall_wgrad       dW[R, K] = G^T X,  db[R] = sum_b G  for G[B, R], X[B, K]: the long dimension is the
+//                       MFMA K index; lane (r, k-group) reads 8 consecutive rows of its column -- for a
+//                       fixed row the 32 lanes of a group read 32 consecutive floats -- and splits them
+//                       in registers; every wave accumulates its own [32, 128] tile over its share of
+//                       the rows, partial tiles are reduced in a fixed order (bitwise reproducible).
+#include "common.h"
+#include "glm_bf16.h"
+
+namespace pa {
+
+constexpr int TALL_MAX = 128;
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void tall_split8(const float (&v)[8], bf16x8& c1, bf16x8& c2, bf16x8& c3) {
+  uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p1[j], p2[j], p3[j]);
+  c1 = as_bf16x8(p1[0], p1[1], p1[2], p1[3]);
+  c2 = as_bf16x8(p2[0], p2[1], p2[2], p2[3]);
+  c3 = as_bf16x8(p3[0], p3[1], p3[2], p3[3]);
+}
+
+constexpr int TALL_TA[6] = {2, 1, 0, 1, 0, 0};      // piece products, smallest first
+constexpr int TALL_TB[6] = {0, 1, 2, 0, 1, 0};
+
+// ---- Y = G Wm + bias ---------------------------------------------------------------------------
+// LDS: Wm planes [k-step][column tile][plane] blocks of 64 lanes x 16 B (lane = column (l & 31) of the
+// tile, k group l >> 5: Wm[16 ks + 8 kg .. + 7][column]); NKS k-steps x NCT column tiles.
+template <int NKS, int NCT>
+__global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restrict__ G, int64_t B, int R,
+                                                          const float* __restrict__ W, int64_t w_rs,
+                                                          int64_t w_cs, int C,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tall_smem[];
+  uint4* wsm = reinterpret_cast<uint4*>(tall_smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, kg = lane >> 5;
+  // the planes, once per workgroup: all of a wave's loads are requested before the first split
+  {
+    constexpr int NBLK = (NKS * NCT + 3) / 4;
+    float wv[NBLK][8];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+      const int blk = wave + 4 * i;
+      const int ks = blk / NCT, ct = blk % NCT;
+      const int c = 32 * ct + l31;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = 16 * ks + 8 * kg + q;
+        wv[i][q] = (blk < NKS * NCT && r < R && c < C) ? W[(int64_t)r * w_rs + (int64_t)c * w_cs] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+      const int blk = wave + 4 * i;
+      if (blk >= NKS * NCT) break;
+      bf16x8 c1, c2, c3;
+      tall_split8(wv[i], c1, c2, c3);
+      wsm[(blk * 3 + 0) * 64 + lane] = __builtin_bit_cast(uint4, c1);
+      wsm[(blk * 3 + 1) * 64 + lane] = __builtin_bit_cast(uint4, c2);
+      wsm[(blk * 3 + 2) * 64 + lane] = __builtin_bit_cast(uint4, c3);
+    }
+  }
+  __syncthreads();
+  const int64_t ntiles = (B + 31) / 32;
+  const bool vec4 = (R & 3) == 0;                       // 16-byte row loads
+  // this lane's 8 floats of every k-step of tile t (rows past the end: zeros)
+  auto load_tile = [&](int64_t t, float (&v)[NKS][8]) {
+    const int64_t row = t * 32 + l31;
+    const bool rok = row < B;
+    const float* gr = G + (rok ? row : 0) * R;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int r0 = 16 * ks + 8 * kg;
+      if (vec4 && rok && r0 + 8 <= R) {
+        const float4 a = *reinterpret_cast<const float4*>(gr + r0);
+        const float4 b = *reinterpret_cast<const float4*>(gr + r0 + 4);
+        v[ks][0] = a.x; v[ks][1] = a.y; v[ks][2] = a.z; v[ks][3] = a.w;
+        v[ks][4] = b.x; v[ks][5] = b.y; v[ks][6] = b.z; v[ks][7] = b.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[ks][q] = (rok && r0 + q < R) ? gr[r0 + q] : 0.0f;
+      }
+    }
+  };
+  const int64_t t_step = (int64_t)gridDim.x * 4;
+  float vn[NKS][8];
+  {
+    const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
+    if (t0 < ntiles) load_tile(t0, vn);
+  }
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += t_step) {
+    float v[NKS][8];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[ks][q] = vn[ks][q];
+    if (t + t_step < ntiles) load_tile(t + t_step, vn);      // the next tile travels under this one's MFMAs
+    f32x16t acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      bf16x8 a[3];
+      tall_split8(v[ks], a[0], a[1], a[2]);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          b[pl] = __builtin_bit_cast(bf16x8, wsm[((ks * NCT + ct) * 3 + pl) * 64 + lane]);
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TALL_TA[p]], b[TALL_TB[p]], acc[ct], 0, 0, 0);
+      }
+      // (keeps the scheduler from hoisting the B-operand reads of every later k-step above this
+      // one's MFMAs: 84 ds_read_b128 in flight = 336 registers, measured as spills)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // C/D layout: lane = column, register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int c = 32 * ct + l31;
+      if (c >= C) continue;
+      const float bc = bias != nullptr ? bias[c] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t orow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (orow < B) Y[orow * C + c] = acc[ct][r] + bc;
+      }
+    }
+  }
+}
+
+// ---- dW = G^T X, db = sum G --------------------------------------------------------------------
+// Wave `gw` (global index) owns row tile gw % nrt of dW and every (nwaves / nrt)-th k-step of 16 batch
+// rows; partial[gw][32][128] and partial_db[gw][32].
+template <int NCT>
+__global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict__ G,
+                                                         const float* __restrict__ X, int64_t B, int R,
+                                                         int K, int nrt, float* __restrict__ partial,
+                                                         float* __restrict__ partial_db) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
+  const int rt = (int)(gw % nrt);
+  const int64_t share = gw / nrt, nshares = nwaves / nrt;            // (nwaves is a multiple of nrt)
+  const int64_t nks = (B + 15) / 16;
+  const int r = 32 * rt + l31;
+  const bool r_ok = r < R;
+  f32x16t acc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
+  float dbs = 0.0f;
+  // The 8 + 8 NCT strided loads of a k-step feed 6 NCT MFMAs: requested in the iteration that uses
+  // them the loop runs at the memory latency.  Three register sets, two k-steps ahead.
+  struct Raw { float ga[8], xv[NCT][8]; };
+  auto load = [&](int64_t ks, Raw& o) {
+    const int64_t b0 = ks * 16 + 8 * kg;                 // (ks past the end: every row fails the test)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o.ga[q] = (r_ok && b0 + q < B) ? G[(b0 + q) * R + r] : 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int k = 32 * ct + l31;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.xv[ct][q] = (k < K && b0 + q < B) ? X[(b0 + q) * K + k] : 0.0f;
+    }
+  };
+  auto mma = [&](const Raw& o) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dbs += o.ga[q];
+    bf16x8 a[3];
+    tall_split8(o.ga, a[0], a[1], a[2]);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      bf16x8 b[3];
+      tall_split8(o.xv[ct], b[0], b[1], b[2]);
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TALL_TA[p]], b[TALL_TB[p]], acc[ct], 0, 0, 0);
+    }
+  };
+  if (share < nks) {
+    Raw o0, o1, o2;
+    load(share, o0);
+    load(share + nshares, o1);
+    int64_t ks = share;
+    for (; ks + 2 * nshares < nks; ks += 3 * nshares) {
+      load(ks + 2 * nshares, o2);
+      mma(o0);
+      load(ks + 3 * nshares, o0);
+      mma(o1);
+      load(ks + 4 * nshares, o1);
+      mma(o2);
+    }
+    if (ks < nks) mma(o0);
+    if (ks + nshares < nks) mma(o1);
+  }
+  float* dst = partial + gw * (32 * TALL_MAX);
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = (i & 3) + 8 * (i >> 2) + 4 * kg;
+      dst[m * TALL_MAX + 32 * ct + l31] = acc[ct][i];
+    }
+  dbs += __shfl_xor(dbs, 32);
+  if (kg == 0) partial_db[gw * 32 + l31] = dbs;
+}
+
+// dW[r][k] = the sum over the waves that own r's tile: 8 outputs x 32 groups per workgroup, thread (j, g)
+// sums the parts g, g + 32, ... in fp64 and the 32 group sums are added in order (fixed order, whole
+// chip); the outputs past R K are db
+__global__ __launch_bounds__(256) void tall_wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                                const float* __restrict__ partial_db,
+                                                                int64_t nwaves, int nrt, int R, int K,
+                                                                float* __restrict__ dW,
+                                                                float* __restrict__ db) {
+  __shared__ double sm[32][8];
+  const int jj = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int idx = blockIdx.x * 8 + jj;
+  const int nout = R * K + (db != nullptr ? R : 0);
+  const int64_t nparts = nwaves / nrt;
+  double acc = 0.0;
+  if (idx < R * K) {
+    const int r = idx / K, k = idx - r * K;
+    const int rt = r >> 5, m = r & 31;
+    for (int64_t p = g; p < nparts; p += 32)
+      acc += (double)partial[(rt + nrt * p) * (32 * TALL_MAX) + m * TALL_MAX + k];
+  } else if (idx < nout) {
+    const int r = idx - R * K;
+    const int rt = r >> 5, m = r & 31;
+    for (int64_t p = g; p < nparts; p += 32) acc += (double)partial_db[(rt + nrt * p) * 32 + m];
+  }
+  sm[g][jj] = acc;
+  __syncthreads();
+  if (g == 0 && idx < nout) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) t += sm[q][jj];
+    if (idx < R * K) dW[idx] = (float)t;
+    else db[idx - R * K] = (float)t;
+  }
+}
+
+static int tall_wgrad_grid(int64_t B) {
+  // one workgroup per CU (a wave per SIMD; each keeps three k-steps in flight); never more waves than k-steps
+  int64_t g = (int64_t)cu_count();
+  const int64_t nks = (B + 15) / 16;
+  if (g * 4 > nks) g = (nks + 3) / 4;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace pa
+
+extern "C" {
+
+int pa_tall_linear(const float* G, int64_t B, int64_t R, const float* W, int64_t w_row_stride,
+                   int64_t w_col_stride, int64_t C, const float* bias, float* Y, pa_stream_t stream) {
+  PA_REQUIRE(B >= 0 && R >= 1 && R <= pa::TALL_MAX && C >= 1 && C <= pa::TALL_MAX,
+             "tall_linear: needs 1 <= R, C <= 128 (B=%lld R=%lld C=%lld)", (long long)B, (long long)R,
+             (long long)C);
+  if (B == 0) return PA_OK;
+  PA_REQUIRE(G && W && Y, "tall_linear: NULL pointer");
+  const int nks = (int)((R + 15) / 16), nct = (int)((C + 31) / 32);
+  const int64_t ntiles = (B + 31) / 32;
+  int64_t grid = (ntiles + 3) / 4;
+  const int64_t cap = (int64_t)pa::cu_count() * (nks * nct > 16 ? 1 : 2);
+  if (grid > cap) grid = cap;
+  const size_t lds = (size_t)nks * nct * 3 * 1024;
+  hipStream_t s = pa::as_stream(stream);
+#define PA_TALL_CASE(NKS_, NCT_)                                                                       \
+  if (nks <= NKS_ && nct <= NCT_) {                                                                    \
+    auto k = pa::tall_linear_kernel<NKS_, NCT_>;                                                       \
+    const size_t l = (size_t)NKS_ * NCT_ * 3 * 1024;                                                   \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);     \
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), l, s, G, B, (int)R, W, w_row_stride,        \
+                       w_col_stride, (int)C, bias, Y);                                                 \
+    return pa::check_launch("tall_linear_kernel");                                                     \
+  }
+  (void)lds;
+  PA_TALL_CASE(1, 4)
+  PA_TALL_CASE(8, 1)
+  PA_TALL_CASE(7, 4)
+  PA_TALL_CASE(8, 4)
+#undef PA_TALL_CASE
+  return pa::fail(PA_ERR_UNSUPPORTED, "tall_linear: no kernel for R=%lld C=%lld", (long long)R, (long long)C);
+}
+
+size_t pa_tall_wgrad_workspace(int64_t B, int64_t R, int64_t K) {
+  if (B < 0 || R < 1 || R > pa::TALL_MAX || K < 1 || K > pa::TALL_MAX) return 0;
+  const size_t nwaves = (size_t)pa::cu_count() * 2 * 4;
+  return nwaves * (32 * pa::TALL_MAX + 32) * sizeof(float);
+}
+
+int pa_tall_wgrad(const float* G, const float* X, int64_t B, int64_t R, int64_t K, float* dW, float* db,
+                  void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  PA_REQUIRE(B >= 0 && R >= 1 && R <= pa::TALL_MAX && K >= 1 && K <= pa::TALL_MAX,
+             "tall_wgrad: needs 1 <= R, K <= 128 (B=%lld R=%lld K=%lld)", (long long)B, (long long)R,
+             (long long)K);
+  PA_REQUIRE(dW != nullptr, "tall_wgrad: NULL output");
+  hipStream_t s = pa::as_stream(stream);
+  if (B == 0) {
+    hipError_t e1 = hipMemsetAsync(dW, 0, (size_t)R * K * sizeof(float), s);
+    hipError_t e2 = db ? hipMemsetAsync(db, 0, (size_t)R * sizeof(float), s) : hipSuccess;
+    if (e1 != hipSuccess || e2 != hipSuccess) return pa::fail(PA_ERR_LAUNCH, "tall_wgrad: memset failed");
+    return PA_OK;
+  }
+  PA_REQUIRE(G && X && workspace, "tall_wgrad: NULL pointer");
+  PA_REQUIRE(workspace_bytes >= pa_tall_wgrad_workspace(B, R, K), "tall_wgrad: workspace too small");
+  int nrt = (int)((R + 31) / 32);
+  if (nrt == 3) nrt = 4;                               // (a wave's tile index is gw % nrt, 4 waves per workgroup)
+  const int grid = pa::tall_wgrad_grid(B);
+  const int64_t nwaves = (int64_t)grid * 4;
+  float* part = (float*)workspace;
+  float* part_db = part + nwaves * (32 * pa::TALL_MAX);
+  const int nct = (int)((K + 31) / 32);
+#define PA_TALLW_CASE(NCT_)                                                                            \
+  if (nct == NCT_)                                                                                     \
+    hipLaunchKernelGGL((pa::tall_wgrad_kernel<NCT_>), dim3((unsigned)grid), dim3(256), 0, s, G, X, B,  \
+                       (int)R, (int)K, nrt, part, part_db);
+  PA_TALLW_CASE(1)
+  PA_TALLW_CASE(2)
+  PA_TALLW_CASE(3)
+  PA_TALLW_CASE(4)
+#undef PA_TALLW_CASE
+  const int64_t n = R * K + R;
+  hipLaunchKernelGGL(pa::tall_wgrad_reduce_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, s, part,
+                     part_db, nwaves, nrt, (int)R, (int)K, dW, db);
+  return pa::check_launch("tall_wgrad");
+}
+
+}  // extern "C"

@@ -1544,6 +1544,36 @@ def bow_linear_bwd(image_b, d_out, V):
     return dW
 
 
+def tall_linear(g, W, w_row_stride, w_col_stride, C, bias=None):
+    """g[B, R] @ Wm[R, C] (+ bias): pa_tall_linear; Wm[r][c] = W.flat[r * w_row_stride + c * w_col_stride]."""
+    _require_gpu(g, W, bias)
+    B, R = g.shape
+    assert g.dtype == torch.float32 == W.dtype and g.is_contiguous() and W.is_contiguous()
+    if R > 128 or C > 128:
+        raise Unsupported("pyro_amd: tall_linear covers at most 128 features (R=%d C=%d)" % (R, C))
+    out = torch.empty((B, C), dtype=torch.float32, device=g.device)
+    check(_lib.load().pa_tall_linear(_ptr(g), B, R, _ptr(W), int(w_row_stride), int(w_col_stride), int(C),
+                                     _ptr(bias), _ptr(out), _stream()))
+    return out
+
+
+def tall_wgrad(g, x, want_bias=True):
+    """(g[B, R].T @ x[B, K], g.sum(0)) in one pass over the batch: pa_tall_wgrad."""
+    _require_gpu(g, x)
+    B, R = g.shape
+    K = x.shape[1]
+    assert x.shape[0] == B and g.dtype == torch.float32 == x.dtype and g.is_contiguous() and x.is_contiguous()
+    lib = _lib.load()
+    nbytes = lib.pa_tall_wgrad_workspace(B, R, K)
+    if nbytes == 0:
+        raise Unsupported("pyro_amd: tall_wgrad covers at most 128 features (R=%d K=%d)" % (R, K))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=g.device)
+    dW = torch.empty((R, K), dtype=torch.float32, device=g.device)
+    db = torch.empty((R,), dtype=torch.float32, device=g.device) if want_bias else None
+    check(lib.pa_tall_wgrad(_ptr(g), _ptr(x), B, R, K, _ptr(dW), _ptr(db), _ptr(ws), nbytes, _stream()))
+    return dW, db
+
+
 def tsgemm_tn(a, x):
     """a[B, M].T @ x[B, N] -> [M, N] for tall f32 operands (M, N <= 128): pa_tsgemm_tn."""
     _require_gpu(a, x)

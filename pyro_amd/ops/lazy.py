@@ -290,22 +290,32 @@ class TallActivation(torch.Tensor):
 
 
 class _TallLinear(torch.autograd.Function):
+    """F.linear over a tall batch on the kernels of csrc/tall.hip: forward and dx are pa_tall_linear
+    with the weight addressed through strides (no transposed copy), dW and db come from ONE pass
+    over the batch (pa_tall_wgrad)."""
+
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+        from .. import kernels
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        with torch._C.DisableTorchFunctionSubclass():
-            return torch.nn.functional.linear(x, weight, bias)
+        n_out, n_in = w.shape
+        # Wm = weight^T: Wm[r][c] = weight[c][r]
+        return kernels.tall_linear(x, w, 1, n_in, n_out, None if bias is None else bias.detach().contiguous())
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         from .. import kernels
-        x, weight = ctx.saved_tensors
+        x, w = ctx.saved_tensors
         g = g.contiguous()
-        dx = g @ weight if ctx.needs_input_grad[0] else None
-        dW = kernels.tsgemm_tn(g, x) if ctx.needs_input_grad[1] else None
-        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        n_out, n_in = w.shape
+        dx = kernels.tall_linear(g, w, n_in, 1, n_in) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = kernels.tall_wgrad(g, x, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dW, db
 
 

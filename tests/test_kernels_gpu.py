@@ -1293,6 +1293,57 @@ def test_bag_of_words_linear(gpu, Wd, B, V, H):
     torch.testing.assert_close(out0, counts.t() @ tt(W, gpu).t(), rtol=1e-5, atol=1e-5 * float(scale))
 
 
+@pytest.mark.parametrize("B,n_in,n_out", [(20000, 100, 100), (5000, 100, 8), (4100, 8, 100), (33, 16, 32),
+                                          (1000, 7, 5), (70000, 128, 128), (31, 1, 1)])
+def test_tall_linear_layer(gpu, B, n_in, n_out):
+    """pa_tall_linear / pa_tall_wgrad (csrc/tall.hip): forward, dx, dW and db of F.linear over a tall
+    batch against the float64 restatement at f32-roundoff class, against torch's own f32 operators, and
+    bitwise reproducible (fixed-order reduction of the batch dimension)."""
+    from oracle import lda as o_lda
+    k = _k()
+    rng = np.random.default_rng(B + n_in + n_out)
+    x = rng.standard_normal((B, n_in)).astype(np.float32)
+    W = (rng.standard_normal((n_out, n_in)) / np.sqrt(n_in)).astype(np.float32)
+    bias = rng.standard_normal(n_out).astype(np.float32)
+    g = rng.standard_normal((B, n_out)).astype(np.float32)
+    tx, tW, tb, tg = tt(x, gpu), tt(W, gpu), tt(bias, gpu), tt(g, gpu)
+    out = k.tall_linear(tx, tW, 1, n_in, n_out, tb)                  # Wm = W^T
+    ref = o_lda.tall_linear(x, W, bias)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-6, atol=2e-6 * np.abs(ref).max())
+    out0 = k.tall_linear(tx, tW, 1, n_in, n_out, None)
+    torch.testing.assert_close(out0, tx @ tW.t(), rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    dx = k.tall_linear(tg, tW, n_in, 1, n_in)                        # Wm = W
+    dW, db = k.tall_wgrad(tg, tx)
+    rdx, rdW, rdb = o_lda.tall_linear_grads(x, W, g)
+    np.testing.assert_allclose(dx.cpu().numpy(), rdx, rtol=2e-6, atol=2e-6 * np.abs(rdx).max())
+    scale = (np.abs(g).astype(np.float64).T @ np.abs(x).astype(np.float64)).max()
+    np.testing.assert_allclose(dW.cpu().numpy(), rdW, rtol=0, atol=1e-6 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), rdb, rtol=0, atol=1e-6 * np.abs(g).sum(0).max())
+    dW2, db2 = k.tall_wgrad(tg, tx)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    assert k.tall_wgrad(tg, tx, want_bias=False)[1] is None
+
+
+def test_tall_linear_autograd_route(gpu):
+    """The lazy route of ops/lazy.py (_TallLinear): an nn.Linear applied to a TallActivation gives the
+    values and the parameter / input gradients of the plain torch route."""
+    from pyro_amd.ops import lazy
+    torch.manual_seed(0)
+    B = 6000
+    x = torch.randn((B, 100), device=gpu, requires_grad=True)
+    lin = torch.nn.Linear(100, 8).to(gpu)
+    ref = torch.sigmoid(lin(x))
+    ref.square().sum().backward()
+    want = [x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    out = torch.sigmoid(lin(x.as_subclass(lazy.TallActivation)))
+    assert isinstance(out, lazy.TallActivation)
+    torch.testing.assert_close(out.as_subclass(torch.Tensor), ref, rtol=1e-5, atol=1e-6)
+    out.square().sum().backward()
+    for got, w in zip([x.grad, lin.weight.grad, lin.bias.grad], want):
+        torch.testing.assert_close(got, w, rtol=1e-4, atol=1e-4 * float(w.abs().max()))
+
+
 def test_word_histogram_is_recognised_in_guide_text(gpu):
     """examples/lda.py's guide text verbatim -- zeros(V, B).scatter_add(0, data, ones) then
     predictor(counts.transpose(0, 1)) -- under watch_histograms(): from the second sighting of the
@@ -1360,7 +1411,7 @@ def test_tall_skinny_weight_gradient_product(gpu, B, M, N):
 def test_layers_after_the_bag_of_words_layer_take_the_tall_weight_gradient(gpu):
     """nn.Sequential(Linear, Sigmoid, Linear, Sigmoid, Linear, Sigmoid, Softmax) on a large batch of
     histograms (examples/lda.py:76-92): parameter gradients equal the dense torch route; the second and
-    third Linear take pa_tsgemm_tn for dW."""
+    third Linear take the tall-batch kernels of csrc/tall.hip (pa_tall_linear / pa_tall_wgrad)."""
     import torch.nn as nn
     from pyro_amd import kernels as k
     from pyro_amd.ops import lazy
@@ -1372,8 +1423,8 @@ def test_layers_after_the_bag_of_words_layer_take_the_tall_weight_gradient(gpu):
                               nn.Linear(100, 8), nn.Sigmoid(), nn.Softmax(dim=-1)).to(gpu)
     wts = torch.randn(B, 8, device=gpu, generator=g)
     calls = []
-    orig = k.tsgemm_tn
-    k.tsgemm_tn = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+    orig = k.tall_wgrad
+    k.tall_wgrad = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
     try:
         res = []
         for on in (False, True, True):
@@ -1387,7 +1438,7 @@ def test_layers_after_the_bag_of_words_layer_take_the_tall_weight_gradient(gpu):
             res.append((y.detach().clone(), [p.grad.clone() for p in predictor.parameters()]))
     finally:
         lazy.ENABLED["on"] = True
-        k.tsgemm_tn = orig
+        k.tall_wgrad = orig
     assert len(calls) == 2                    # (third run: both later Linear layers)
     torch.testing.assert_close(res[2][0], res[0][0], rtol=1e-5, atol=1e-7)
     for a, b in zip(res[2][1], res[0][1]):
