@@ -61,16 +61,21 @@ def _register():
     def setup(ctx, inputs, output):
         _, gw, gb = output
         ctx.save_for_backward(gw, gb)
+        ctx.has_b = inputs[3] is not None            # (.., .., w, b, ...) in both schemas
 
-    def backward_planes(ctx, g_ll, g_gw, g_gb):
+    def _grads(ctx, g_ll):
         gw, gb = ctx.saved_tensors
         dw, db = torch.ops.pyro_amd.glm_chain(g_ll, gw, gb)
+        return (dw if ctx.needs_input_grad[2] else None,
+                db if (ctx.has_b and ctx.needs_input_grad[3]) else None)
+
+    def backward_planes(ctx, g_ll, g_gw, g_gb):
+        dw, db = _grads(ctx, g_ll)
         # (planes, y, w, b, scale, N, D, format)
         return None, None, dw, db, None, None, None, None
 
     def backward_plain(ctx, g_ll, g_gw, g_gb):
-        gw, gb = ctx.saved_tensors
-        dw, db = torch.ops.pyro_amd.glm_chain(g_ll, gw, gb)
+        dw, db = _grads(ctx, g_ll)
         # (X, y, w, b, mask, scale)
         return None, None, dw, db, None, None
 

@@ -77,6 +77,22 @@ def test_autograd_through_the_ops(gpu):
         np.testing.assert_allclose(tb.grad.cpu().numpy(), c * rgb, rtol=2e-4, atol=2e-5 * N ** 0.5)
 
 
+def test_autograd_without_a_bias(gpu):
+    """b = None (a model without an intercept, e.g. the NUTS logistic regression of
+    tests/test_mcmc_gpu.py): the backward returns no gradient for the absent input."""
+    k, tl = _setup()
+    N, D, P = 2000, 3, 32
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = torch.randn((N, D), generator=g).to(gpu)
+    y = (torch.rand((N,), generator=g) < 0.5).float().to(gpu)
+    w = torch.randn((P, D), generator=g).to(gpu).requires_grad_()
+    ll = tl.glm_bernoulli_ll(X, y, w, None)
+    (gw,) = torch.autograd.grad(ll.sum(), [w])
+    lg = w.detach().double() @ X.double().t()
+    ref = ((y.double() - torch.sigmoid(lg)) @ X.double())
+    torch.testing.assert_close(gw.double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
 def _neg_elbo(X, y, eps_w, eps_b):
     """-ELBO of SURVEY 8(d)'s model under a mean-field Normal guide as a function of the guide's four
     unconstrained tensors (AutoNormal: scale = softplus-free 'scales' parameter is constrained positive,
