@@ -797,6 +797,26 @@ def glm_planes_of(X):
     return ent[2]
 
 
+def glm_planes_invalidate(X=None):
+    """Forget the cached plane image of ``X`` (of every tensor when None).  The caches follow a tensor's
+    version counter only: a write that does not bump it (``X.data.copy_()``, a numpy / DLPack alias, a
+    kernel of another library) leaves a stale image behind -- call this after such a write.  A captured
+    step that was reading the image must be captured again (``SVI`` does so when the argument
+    signature changes; otherwise create a new ``SVI``)."""
+    if X is None:
+        _planes_cache.clear()
+        for segs in list(_grouped_with_image):
+            segs._planes = None
+        return
+    base = X._base if X._base is not None else X
+    for key in [k for k, ent in _planes_cache.items() if ent[0]() is base]:
+        _planes_cache.pop(key, None)
+    for segs in list(_grouped_with_image):
+        ent = segs._planes
+        if ent is not None and (ent[0]() is X or ent[2]() is X):
+            segs._planes = None
+
+
 def glm_planes_revalidate():
     """Re-pack every cached image whose tensor was modified in place (called before a captured
     step is replayed: the graph reads the image, not X)."""

@@ -84,6 +84,13 @@ class PyroOptim:
                     _restore(self.optim_objs[p], state)
             if self.pt_clip_args is not None:
                 clip = self.pt_clip_args
+                if callable(clip):
+                    # per-parameter clipping: called with (module name, parameter name) as the
+                    # reference does (optim.py:238-255)
+                    from ..params import module_from_param_with_module_name, user_param_name
+                    pname = _PARAM_STORE.param_name(p)
+                    clip = clip(module_from_param_with_module_name(pname), user_param_name(pname))
+                    assert isinstance(clip, dict), "per-param clip arg must return defaults dictionary"
                 if "clip_norm" in clip:
                     torch.nn.utils.clip_grad_norm_([p], clip["clip_norm"])
                 if "clip_value" in clip:

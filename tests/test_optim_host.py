@@ -83,6 +83,27 @@ def test_clip_args(pyro_optim, clip, value):
         opt.optim_objs[x2].zero_grad()
 
 
+def test_callable_clip_args():
+    """clip_args as a callable of (module name, parameter name) -> dict, per parameter, as
+    pyro/optim/optim.py:238-255: one parameter clipped, the other not."""
+    pyro.clear_param_store()
+    a = pyro.param("mod$$$a", torch.tensor(0.0))
+    b = pyro.param("b", torch.tensor(0.0))
+    seen = []
+
+    def clip(module_name, param_name):
+        seen.append((module_name, param_name))
+        return {"clip_value": 1.0} if param_name == "a" else {}
+
+    opt = optim.SGD({"lr": 1.0}, clip)
+    ua, ub = pyro.get_param_store()._params["mod$$$a"], pyro.get_param_store()._params["b"]
+    ua.grad = torch.tensor(5.0)
+    ub.grad = torch.tensor(5.0)
+    opt([ua, ub])
+    assert ("mod", "a") in seen and ("b", "b") in seen      # (a name without a module: the reference passes it twice)
+    assert float(ua) == -1.0 and float(ub) == -5.0
+
+
 @pytest.mark.parametrize("clip_norm", [1.0, 3.0, 5.0])
 def test_clippedadam_clip(clip_norm):
     x1 = torch.tensor(0.0, requires_grad=True)
