@@ -569,12 +569,12 @@ static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
   return pl;
 }
 
-template <int NB, int OCC>
+template <int NB, int OCC, bool PRIV = false>
 static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
                             const float* w, const float* b, int64_t N, int D, int P, float* part,
                             const uint32_t* trailer, hipStream_t s) {
-  auto k = glm_planes_f16_kernel<NB, OCC, false>;
-  constexpr int lds = GlmHCfg<NB>::LDS_BYTES;
+  auto k = glm_planes_f16_kernel<NB, OCC, false, PRIV>;
+  constexpr int lds = GlmHCfg<NB, PRIV>::LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
                      b, N, D, P, pl.nst, part, cu_count(), trailer, g_planes_stamps,
@@ -935,8 +935,9 @@ int pa_glm_planes_finalize_mode(int in_kernel) {
 }
 
 int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
-  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 4),
-             "glm_planes_tune: ring depth 3..4 (0 = default)");
+  // (5 / 6: the f16 kernel with per-wave private rings of depth 3 / 4 -- a measurement knob)
+  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 6),
+             "glm_planes_tune: ring depth 3..6 (0 = default)");
   PA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 4, "glm_planes_tune: 0..4 workgroups per CU");
   pa::g_planes_nb = ring_depth == 0 ? 3 : ring_depth;
   pa::g_planes_bpc = blocks_per_cu;
@@ -1006,7 +1007,9 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   fin.tstamps = pa::g_planes_stamps;
   if (format == PA_GLM_PLANES_F16X2) {
     const uint32_t* trailer = (const uint32_t*)(img + pa::glmh_tile_bytes(pa::glm_planes_tiles(N)));
-    if (pl.nb == 4) pa::glmh_launch_one<4, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    if (pl.nb == 5) pa::glmh_launch_one<3, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    else if (pl.nb == 6) pa::glmh_launch_one<4, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    else if (pl.nb == 4) pa::glmh_launch_one<4, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.bpc >= 4) pa::glmh_launch_one<3, 4>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else pa::glmh_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
   } else if (pl.nb == 3) {

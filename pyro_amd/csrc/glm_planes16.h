@@ -152,29 +152,34 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
   if (sl == 0) y_img[T * 32 + r] = ok ? __builtin_fmaf(y[row], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
 }
 
-template <int NB>
+// PRIV: every wave keeps a PRIVATE ring of its own 32-row tile (4 KiB: the two waves of a row tile
+// -- particle tiles 0 and 1 -- each fetch it, the second from the cache) instead of the workgroup
+// sharing a ring of super-tiles: the tile loop then needs no workgroup barrier at all, only the wave's
+// own counted s_waitcnt.
+template <int NB, bool PRIV = false>
 struct GlmHCfg {
   static constexpr int NRT = 2, NPT = 2;
   static constexpr int ST_BYTES = NRT * GLMH_TILE;     // 8 KiB super-tile image (64 rows)
-  static constexpr int PW = ST_BYTES / 1024 / 4;       // 1 KiB DMA pieces per wave and super-tile
+  static constexpr int PW = PRIV ? GLMH_TILE / 1024 : ST_BYTES / 1024 / 4;   // 1 KiB DMA pieces per wave and tile
   static constexpr int NDMA = PW + 1;                  // + the wave's 32 observations
+  static constexpr int RING_BYTES = PRIV ? 4 * NB * GLMH_TILE : NB * ST_BYTES;
   static constexpr int WROWS = 32 * NPT;
   static constexpr int WPL = WROWS * 64;               // one W plane
   static constexpr int OFS_WAUX = 2 * WPL;             // per particle 16 B: {b1 | b2, b3, descale, -}
   static constexpr int OFS_RING = OFS_WAUX + WROWS * 16;
-  static constexpr int OFS_Y = OFS_RING + NB * ST_BYTES;
+  static constexpr int OFS_Y = OFS_RING + RING_BYTES;
   static constexpr int LDS_BYTES = OFS_Y + NB * 4 * 256;
 };
 
 constexpr uint32_t F16_2P15 = 0x7800u;        // 2^15
 
-template <int NB, int OCC, bool GROUPED = false>
+template <int NB, int OCC, bool GROUPED = false, bool PRIV = false>
 __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
     const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
     int64_t nst, float* __restrict__ part, int prio_cus, const uint32_t* __restrict__ trailer,
     unsigned long long* __restrict__ tstamps, const GlmGroupArgs grp) {
-  using C = GlmHCfg<NB>;
+  using C = GlmHCfg<NB, PRIV>;
   constexpr int NRT = C::NRT, NPT = C::NPT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS,
                 WPL = C::WPL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -205,8 +210,9 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 
   auto issue = [&](int64_t st, int bi) {
     const int64_t stc = st < st_end ? st : st_end - 1;
-    const unsigned char* src = img + stc * ST_BYTES + (wave * PW) * 1024 + lane * 16;
-    const uint32_t dst = lds_base + C::OFS_RING + bi * ST_BYTES + (wave * PW) * 1024;
+    const unsigned char* src = img + stc * ST_BYTES + (PRIV ? rt * GLMH_TILE : (wave * PW) * 1024) + lane * 16;
+    const uint32_t dst = lds_base + C::OFS_RING +
+                         (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + (wave * PW) * 1024);
 #pragma unroll
     for (int k = 0; k < PW; ++k) dma16(src + k * 1024, dst + k * 1024);
     int64_t row = (stc * NRT + rt) * 32 + l31;
@@ -377,10 +383,10 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   f32x16v acc_cur = {};
   if (my_count > 0) {
     wait_vmcnt<(NB - 2) * C::NDMA>();
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!PRIV) __builtin_amdgcn_s_barrier();
     const bool ok0 = prep_rows(0, st);
     acc_cur = gemm1_aux(ok0);
-    const unsigned char* X0 = smem + C::OFS_RING + rt * GLMH_TILE;
+    const unsigned char* X0 = smem + C::OFS_RING + (PRIV ? wave * NB * GLMH_TILE : rt * GLMH_TILE);
     f16x8 xa[2];
     load_a(X0, 0, xa);
 #pragma unroll
@@ -402,14 +408,14 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     }
     int bn = bi + 1 == NB ? 0 : bi + 1;
     wait_vmcnt<(NB - 3) * C::NDMA>();
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!PRIV) __builtin_amdgcn_s_barrier();
     {
       int bf = bi + (NB - 1);
       bf = bf >= NB ? bf - NB : bf;
       issue(st + (NB - 1) * grid, bf);
     }
-    const unsigned char* Xc = smem + C::OFS_RING + bi * ST_BYTES + rt * GLMH_TILE;
-    const unsigned char* Xn = smem + C::OFS_RING + bn * ST_BYTES + rt * GLMH_TILE;
+    const unsigned char* Xc = smem + C::OFS_RING + (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + rt * GLMH_TILE);
+    const unsigned char* Xn = smem + C::OFS_RING + (PRIV ? (wave * NB + bn) * GLMH_TILE : bn * ST_BYTES + rt * GLMH_TILE);
     const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y + (bi * 4 + wave) * 256);
     const uint32_t tr_a = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_a;
     const uint32_t tr_b = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_b;
