@@ -63,10 +63,12 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
       const int blk = wave + 4 * i;
       const int ks = blk / NCT, ct = blk % NCT;
       const int c = 32 * ct + l31;
+      const float* wp = W + (int64_t)(c < C ? c : C - 1) * w_cs;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int r = 16 * ks + 8 * kg + q;
-        wv[i][q] = (blk < NKS * NCT && r < R && c < C) ? W[(int64_t)r * w_rs + (int64_t)c * w_cs] : 0.0f;
+        const float x = wp[(int64_t)(r < R ? r : R - 1) * w_rs];
+        wv[i][q] = (blk < NKS * NCT && r < R && c < C) ? x : 0.0f;
       }
     }
 #pragma unroll
@@ -85,20 +87,28 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
   const bool vec4 = (R & 3) == 0;                       // 16-byte row loads
   // this lane's 8 floats of every k-step of tile t (rows past the end: zeros)
   auto load_tile = [&](int64_t t, float (&v)[NKS][8]) {
+    // Every load is unconditional, from a clamped address, and a select zeroes what is out of range:
+    // a predicated load compiles to a branch with its own s_waitcnt, and a tile has up to 56 of them
+    // (measured: 110 waits per tile, 62 us for 11 us of MFMA work).
     const int64_t row = t * 32 + l31;
     const bool rok = row < B;
-    const float* gr = G + (rok ? row : 0) * R;
+    const float* gr = G + (rok ? row : B - 1) * R;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int r0 = 16 * ks + 8 * kg;
-      if (vec4 && rok && r0 + 8 <= R) {
-        const float4 a = *reinterpret_cast<const float4*>(gr + r0);
-        const float4 b = *reinterpret_cast<const float4*>(gr + r0 + 4);
-        v[ks][0] = a.x; v[ks][1] = a.y; v[ks][2] = a.z; v[ks][3] = a.w;
-        v[ks][4] = b.x; v[ks][5] = b.y; v[ks][6] = b.z; v[ks][7] = b.w;
+      if (vec4) {                                            // (wave-uniform) R % 4 == 0: two 16-byte granules
+        const bool ok0 = r0 + 4 <= R, ok1 = r0 + 8 <= R;
+        const float4 a = *reinterpret_cast<const float4*>(gr + (ok0 ? r0 : 0));
+        const float4 b = *reinterpret_cast<const float4*>(gr + (ok1 ? r0 + 4 : 0));
+        const bool k0 = rok && ok0, k1 = rok && ok1;
+        v[ks][0] = k0 ? a.x : 0.0f; v[ks][1] = k0 ? a.y : 0.0f; v[ks][2] = k0 ? a.z : 0.0f; v[ks][3] = k0 ? a.w : 0.0f;
+        v[ks][4] = k1 ? b.x : 0.0f; v[ks][5] = k1 ? b.y : 0.0f; v[ks][6] = k1 ? b.z : 0.0f; v[ks][7] = k1 ? b.w : 0.0f;
       } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[ks][q] = (rok && r0 + q < R) ? gr[r0 + q] : 0.0f;
+        for (int q = 0; q < 8; ++q) {
+          const float x = gr[r0 + q < R ? r0 + q : 0];
+          v[ks][q] = (rok && r0 + q < R) ? x : 0.0f;
+        }
       }
     }
   };
@@ -139,15 +149,22 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
       __builtin_amdgcn_sched_barrier(0);
     }
     // C/D layout: lane = column, register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const bool full = t * 32 + 32 <= B;                      // (wave-uniform) no row test per store
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const int c = 32 * ct + l31;
       if (c >= C) continue;
       const float bc = bias != nullptr ? bias[c] : 0.0f;
+      float* yp = Y + (t * 32 + 4 * kg) * C + c;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t orow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-        if (orow < B) Y[orow * C + c] = acc[ct][r] + bc;
+        for (int r = 0; r < 16; ++r) yp[((r & 3) + 8 * (r >> 2)) * C] = acc[ct][r] + bc;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t orow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          if (orow < B) yp[((r & 3) + 8 * (r >> 2)) * C] = acc[ct][r] + bc;
+        }
       }
     }
   }
@@ -178,15 +195,37 @@ __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict
   // The 8 + 8 NCT strided loads of a k-step feed 6 NCT MFMAs: requested in the iteration that uses
   // them the loop runs at the memory latency.  Three register sets, two k-steps ahead.
   struct Raw { float ga[8], xv[NCT][8]; };
+  // Loads are unconditional from clamped columns (a predicated load is a branch with its own wait:
+  // 40 per k-step); only a k-step that crosses the end of the batch takes the tested path.
+  const int rc = r_ok ? r : R - 1;
   auto load = [&](int64_t ks, Raw& o) {
-    const int64_t b0 = ks * 16 + 8 * kg;                 // (ks past the end: every row fails the test)
+    const int64_t b0 = ks * 16 + 8 * kg;
+    if (ks * 16 + 16 <= B) {                              // (wave-uniform)
+      const float* gp = G + b0 * R + rc;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) o.ga[q] = (r_ok && b0 + q < B) ? G[(b0 + q) * R + r] : 0.0f;
+      for (int q = 0; q < 8; ++q) {
+        const float x = gp[(int64_t)q * R];
+        o.ga[q] = r_ok ? x : 0.0f;
+      }
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const int k = 32 * ct + l31;
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int k = 32 * ct + l31;
+        const float* xp = X + b0 * K + (k < K ? k : K - 1);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o.xv[ct][q] = (k < K && b0 + q < B) ? X[(b0 + q) * K + k] : 0.0f;
+        for (int q = 0; q < 8; ++q) {
+          const float x = xp[(int64_t)q * K];
+          o.xv[ct][q] = k < K ? x : 0.0f;
+        }
+      }
+    } else {                                              // the last k-step (or one past the end: all zero)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.ga[q] = (r_ok && b0 + q < B) ? G[(b0 + q) * R + r] : 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int k = 32 * ct + l31;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.xv[ct][q] = (k < K && b0 + q < B) ? X[(b0 + q) * K + k] : 0.0f;
+      }
     }
   };
   auto mma = [&](const Raw& o) {
