@@ -5,6 +5,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 timeout -s KILL 500 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err
 timeout -s KILL 120 python bench.py --steps 20 --warmup 5 --no-others --no-nuts --no-cpu-baseline > gpurun_out/r03_bench_driver_args.json 2>/dev/null
+timeout -s KILL 200 python bench.py --steps 20000 --warmup 10 --no-others --no-nuts --no-cpu-baseline > gpurun_out/r03_bench_soak_20000_steps.json 2>/dev/null
 timeout -s KILL 400 bash tools/prof.sh r03 --no-nuts > gpurun_out/prof_r03.log 2>&1
 GRAPHFLAG=" " timeout -s KILL 120 bash tools/trace_step.sh > gpurun_out/r03_trace_step.txt 2>&1
 for c in 4 5; do
