@@ -77,6 +77,32 @@ def parse():
     return ap.parse_args()
 
 
+def measured_hbm(dev):
+    """What this box's HBM delivers to plain streaming kernels (report the measured peak
+    beside the nominal 8 TB/s): a 1-GiB device-to-device copy (bytes read + bytes written per second)
+    and a read-only reduction over the same buffer, torch's own kernels, best of 5."""
+    import torch
+    n = 1 << 28                                            # 1 GiB of f32
+    a = torch.empty((n,), dtype=torch.float32, device=dev).fill_(1.0)
+    b = torch.empty_like(a)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def best(fn):
+        fn()
+        t = []
+        for _ in range(5):
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            t.append(s.elapsed_time(e) * 1e-3)
+        return min(t)
+    t_copy = best(lambda: b.copy_(a))
+    t_read = best(lambda: a.sum())
+    return {"copy_GBps": 2 * 4 * n / t_copy / 1e9, "read_GBps": 4 * n / t_read / 1e9,
+            "how": "1 GiB f32: torch d2d copy (read + written bytes) and torch.sum (read bytes), best of 5"}
+
+
 def cpu_baseline(N, D, P, budget_s):
     """Time the torch-CPU port of the reference's SVI step (oracle/ref_port_torch.py) on the
     host cores, on the SAME workload shape, bounded to ~budget_s seconds of CPU work.  The thread
@@ -547,6 +573,11 @@ def main():
                          "binding_resource": BINDING_F16 if f16 else BINDING_BF16},
             "rccl_ranks": world,
         }
+        if world == 1 and on_gpu:
+            try:
+                out["roofline"]["measured_hbm"] = measured_hbm(dev)
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["measured_hbm"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, P, args.cpu_budget_s)
         if validated is not None:

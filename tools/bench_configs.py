@@ -12,6 +12,19 @@ from pyro_amd.infer import SVI, Trace_ELBO, TraceEnum_ELBO
 from pyro_amd.infer.autoguide import AutoMultivariateNormal, AutoNormal
 
 
+def _committed_traffic(cfg, kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes (tools/pmc_cfg.sh ->
+    profiles/r03_traffic_cfg<cfg>.json), or None: counters cannot be collected from inside the run."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                        "r03_traffic_cfg%s.json" % cfg)
+    try:
+        return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def timed(fn, n, warm):
     for _ in range(warm):
         fn()
@@ -52,7 +65,9 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True):
                                                                   "(pa_glm_planes_stamps), mean of %d replays" % len(kms),
                            "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9,
                            "peak": 8000.0, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
-                           "traffic": None, "share_of_step": k_ms / (dt * 1e3)}
+                           "traffic": _committed_traffic(5, "glm_planes_f16_kernel" if f16 else "glm_planes_kernel"),
+                           "traffic_source": "profiles/r03_traffic_cfg5.json (rocprofv3 --pmc, tools/pmc_cfg.sh)",
+                           "share_of_step": k_ms / (dt * 1e3)}
     return out
 
 
@@ -206,7 +221,9 @@ def _config4_roofline(data, args, predictor, dt):
     return {"bound": "hbm", "kernel": "bow_linear_fwd_kernel (+ its split / reduce launches)", "kernel_ms": k_ms,
             "kernel_ms_source": "HIP events around 20 stand-alone calls on the step's operands",
             "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
-            "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12, "traffic": None,
+            "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
+            "traffic": _committed_traffic(4, "bow_linear_fwd_kernel"),
+            "traffic_source": "profiles/r03_traffic_cfg4.json (rocprofv3 --pmc, tools/pmc_cfg.sh)",
             "share_of_step": k_ms / (dt * 1e3)}
 
 
