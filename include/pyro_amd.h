@@ -697,40 +697,6 @@ size_t pa_tsgemm_tn_workspace(int64_t B, int64_t M, int64_t N);
 int pa_tsgemm_tn(const float* A, const float* X, int64_t B, int64_t M, int64_t N, float* out,
                  void* workspace, size_t workspace_bytes, pa_stream_t stream);
 
-/* ---- small element-wise operators of a captured step as one kernel (csrc/smallops.hip) -------------
- * Replaces the one-launch-per-operator execution of the small torch operators a model / guide text and
- * their autograd duals consist of (constraint transforms pyro/params/param_store.py:186-206,
- * normalisations, clamps, scalings): between pa_smallops_begin(stream) and pa_smallops_end() the host
- * records instructions instead of launching operators; the pending program (<= PA_SMALLOPS_MAX
- * instructions) runs as ONE workgroup that interprets it in order when pa_smallops_flush() is called,
- * when the program is full, when any other entry point of this library launches, or when a chained-tail
- * phase is recorded.  An instruction: dst[f] = op(src0[f], src1[f] | imm) over a row-major frame of
- * ndim <= 4 dims, every operand addressed through its own element strides (0 = broadcast); float32
- * data, uint8 for the boolean operands / results of WHERE, the comparisons and AND.  `barrier` != 0:
- * the instruction touches memory an earlier instruction of the same program wrote.  torch's
- * arithmetic: IEEE + - * /, libm expf / logf, clamp and where with NaN propagation as in ATen. */
-enum {
-  PA_SO_ADD = 1, PA_SO_SUB, PA_SO_MUL, PA_SO_DIV, PA_SO_ADD_IMM, PA_SO_MUL_IMM, PA_SO_DIV_IMM,
-  PA_SO_RSUB_IMM, PA_SO_RDIV_IMM, PA_SO_NEG, PA_SO_EXP, PA_SO_LOG, PA_SO_RECIP, PA_SO_SQRT, PA_SO_CLAMP,
-  PA_SO_COPY, PA_SO_FILL, PA_SO_WHERE, PA_SO_GE_IMM, PA_SO_LE_IMM, PA_SO_GT_IMM, PA_SO_LT_IMM,
-  PA_SO_AND_U8, PA_SO_COUNT
-};
-#define PA_SMALLOPS_MAX 28
-typedef struct {
-  uint32_t op, ndim, numel, barrier;
-  uint32_t shape[4];
-  int32_t dst_stride[4], src0_stride[4], src1_stride[4], src2_stride[4];
-  float imm, imm2;
-  void* dst;
-  const void* src0;
-  const void* src1;
-  const void* src2;
-} pa_smallop;
-int pa_smallops_begin(pa_stream_t stream);
-int pa_smallops_record(const pa_smallop* op);
-int pa_smallops_flush(void);
-int pa_smallops_end(int* launches, int* recorded);
-
 /* A Linear layer over a tall batch (B rows >> 128 features; the inner layers of examples/lda.py:76-92's
  * predictor over 1e5 documents) without rocBLAS and without operand-split passes (csrc/tall.hip).
  *   pa_tall_linear: Y[B, C] = G[B, R] Wm[R, C] (+ bias[C] when not NULL), R, C <= 128, G / Y contiguous;

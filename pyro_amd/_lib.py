@@ -111,10 +111,6 @@ _SIGNATURES = {
     "pa_glm_bernoulli_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_double, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
-    "pa_smallops_begin": (c_int, [c_void_p]),
-    "pa_smallops_record": (c_int, [c_void_p]),
-    "pa_smallops_flush": (c_int, []),
-    "pa_smallops_end": (c_int, [c_void_p, c_void_p]),
     "pa_tall_linear": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                c_void_p, c_void_p]),
     "pa_tall_wgrad_workspace": (c_size_t, [c_int64, c_int64, c_int64]),

@@ -17,12 +17,6 @@ struct MultiArgs;
 struct MfArgs;
 struct AdamPublish;
 
-// the pending chain phases / the pending small-operator program (smallops.hip), launched now; both are
-// no-ops when nothing is pending.  Invariant: at most one of the two is pending at any time -- recording
-// into one flushes the other -- and anything else the library launches flushes both (as_stream()).
-int chain_flush_pending();
-int smallops_flush_pending();
-
 // Each returns 1 when the call was recorded (the caller must NOT launch), 0 when the caller has to
 // launch itself (not recording, other stream, not eligible), < 0 = error code.
 int chain_record_fin(pa_stream_t stream, int DT, int PT, const float* part, int nblocks, int npass,

@@ -532,9 +532,6 @@ static bool chain_open(pa_stream_t stream, int k, int* rc) {
   ChainState& c = g_chain;
   *rc = PA_OK;
   if (!c.on) return false;
-  // a pending small-operator program may write what this phase reads: it goes first
-  *rc = smallops_flush_pending();
-  if (*rc != PA_OK) return false;
   if ((hipStream_t)stream != c.stream) {
     *rc = chain_launch();
     return false;
@@ -613,11 +610,8 @@ int chain_record_adam(pa_stream_t stream, float* p, float* g, float* m, float* v
 // may read what the pending phases write, so they go first
 hipStream_t as_stream(pa_stream_t s) {
   if (g_chain.on && g_chain.top >= 0) (void)chain_launch();
-  (void)smallops_flush_pending();
   return (hipStream_t)s;
 }
-
-int chain_flush_pending() { return (g_chain.on && g_chain.top >= 0) ? chain_launch() : PA_OK; }
 
 }  // namespace pa
 

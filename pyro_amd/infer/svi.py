@@ -235,14 +235,6 @@ class SVI:
         else:
             consts = None
         hoist = (lambda: consts) if consts is not None else contextlib.nullcontext
-        # opt-in experiment (PYRO_AMD_SMALLOPS=1, measured slower -- see ops/smallops.py): the small
-        # element-wise torch operators of the step recorded and run as one interpreter launch per run
-        from ..ops import smallops
-        if smallops.enabled() and device.type == "cuda":
-            small_mode = smallops.SmallOps(protected=consts._storages if consts is not None else ())
-            small = lambda: small_mode  # noqa: E731
-        else:
-            small_mode, small = None, contextlib.nullcontext
         try:
             with validation_enabled(False):   # validation ran in the eager warm-up steps
                 # with a process group alive its watchdog thread polls events while we capture:
@@ -250,7 +242,7 @@ class SVI:
                 multi = getattr(self.optim, "multi_rank", False)
                 mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
                 with torch.cuda.graph(graph, **mode):
-                    with cap, chain() as rec, hoist(), small():
+                    with cap, chain() as rec, hoist():
                         with poutine.trace(param_only=True) as param_capture:
                             loss = self._loss_device(self.model, self.guide, *args, **kwargs)
                         params = self._params_of(param_capture)
@@ -266,7 +258,6 @@ class SVI:
                                 if not getattr(self.optim, "zeroes_grads", False):
                                     zero_grads(params)
                             cap.finish(publish=(loss,) + mailbox)
-                    self.smallops_stats = (small_mode.launches, small_mode.recorded) if small_mode else None
                     self.chain_stats.append(getattr(rec, "stats", None))
                     self.chain_fused = getattr(rec, "fused", 0)
                 if split:

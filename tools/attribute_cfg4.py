@@ -34,7 +34,6 @@ class Count(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.by = collections.defaultdict(collections.Counter)
-        self.shapes = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.name().rsplit(".", 1)[0] if func.name().count(".") else func.name()
@@ -47,14 +46,7 @@ class Count(TorchDispatchMode):
                     frame = "%s:%d %s" % (fn.split("pyro_amd/")[-1], fr.lineno, fr.name)
                     break
             self.by[frame][name] += 1
-        out = func(*args, **(kwargs or {}))
-        if not name.startswith(SKIP):
-            o = out[0] if isinstance(out, (tuple, list)) and out else out
-            if isinstance(o, torch.Tensor):
-                ins = [a for a in args if isinstance(a, torch.Tensor)]
-                big = max([o.numel()] + [a.numel() for a in ins])
-                self.shapes[(name, str(o.dtype).replace("torch.", ""), "small" if big <= 65536 else "BIG")] += 1
-        return out
+        return func(*args, **(kwargs or {}))
 
 
 with Count() as cnt:
@@ -64,7 +56,3 @@ tot = sum(sum(c.values()) for c in cnt.by.values())
 print("non-view operators dispatched by one eager step:", tot)
 for fr, c in sorted(cnt.by.items(), key=lambda x: -sum(x[1].values()))[:45]:
     print("%4d  %-58s %s" % (sum(c.values()), fr[-58:], dict(c.most_common(5))))
-
-print("operator / dtype / size class (max numel of output and inputs <= 65536 = small):")
-for (name, dt, cls), n in sorted(cnt.shapes.items(), key=lambda x: (x[0][2], -x[1])):
-    print("  %3d  %-5s %-8s %s" % (n, cls, dt, name))

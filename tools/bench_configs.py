@@ -55,7 +55,7 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True):
     clock.close()
     kms = [v for v in kms if v == v]
     out = {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1),
-           "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12, "smallops_launches_recorded": getattr(svi, "smallops_stats", None)}
+           "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
     if kms:
         k_ms = sum(kms) / len(kms)
         alg = N * (4 * D + 4)
@@ -188,7 +188,7 @@ def config4(dev, docs=100_000, steps=10, batch_size=None):
     pairs = (docs if batch_size is None else batch_size) * args.num_words_per_doc
     out = {"batch_size": batch_size, "steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
            "graphed": bool(svi.hip_graph and len(svi._graphs) == 1),
-           "algorithmic_TBps": pairs * 8.5 / dt / 1e12, "smallops_launches_recorded": getattr(svi, "smallops_stats", None)}
+           "algorithmic_TBps": pairs * 8.5 / dt / 1e12}
     import os
     if batch_size is None and not os.environ.get("PA_NO_ROOFLINE"):
         try:
