@@ -340,6 +340,28 @@ int pa_glm_pack_planes_grouped(int format, const float* X, const float* y, int64
                                const int64_t* seg, const int64_t* st_off, int64_t nseg,
                                int64_t nst_total, void* planes, size_t planes_bytes,
                                pa_stream_t stream);
+/* The same image from rows that are NOT sorted by group -- SURVEY 8(d) config 5 as the reference
+ * writes it: g = randint(0, G, (N,)), logits = (w[..., g, :] * X).sum(-1) + b, an advanced-index
+ * gather + product + reduction + Bernoulli.log_prob + sum and their autograd duals
+ * (torch: aten index / index_backward; pyro/poutine/trace_struct.py:264-278).
+ * pa_group_rows_build: a STABLE counting sort of the row indices by group id (integer work,
+ * bit-exact: rows[offsets[k] .. offsets[k+1]) = the n with g[n] == k in ascending n = numpy
+ * argsort(g, kind="stable"); offsets = exclusive cumulative bincount), device int64 outputs
+ * offsets[G+1], rows[N]; *n_out_of_range (device int64) = number of ids outside [0, G) (torch raises
+ * IndexError for those; the caller does too).  G <= 16384, N < 2^31, else PA_ERR_UNSUPPORTED
+ * (pa_group_rows_workspace returns 0).
+ * pa_glm_pack_planes_grouped_rows: pa_glm_pack_planes_grouped reading X[row_of[i]], y[row_of[i]]
+ * for image row i (seg / st_off describe the SORTED order; row_of = rows above; NULL = identity).
+ * No sorted copy of X is made; everything downstream (pa_glm_bernoulli_grouped_planes_fwd_bwd) is
+ * unchanged because the likelihood sum does not depend on the row order. */
+size_t pa_group_rows_workspace(int64_t N, int64_t G);
+int pa_group_rows_build(const int64_t* g, int64_t N, int64_t G, int64_t* offsets, int64_t* rows,
+                        int64_t* n_out_of_range, void* workspace, size_t workspace_bytes,
+                        pa_stream_t stream);
+int pa_glm_pack_planes_grouped_rows(int format, const float* X, const float* y, const int64_t* row_of,
+                                    int64_t N, int64_t D, const int64_t* seg, const int64_t* st_off,
+                                    int64_t nseg, int64_t nst_total, void* planes, size_t planes_bytes,
+                                    pa_stream_t stream);
 size_t pa_glm_bernoulli_grouped_planes_workspace(int64_t nseg, int64_t P);
 int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, const float* w,
                                             const float* b,

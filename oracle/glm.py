@@ -193,3 +193,17 @@ def glm_grouped_plane_image(X, y, seg):
     img = glm_plane_image(Xp)[: Xp.shape[0] // 32]       # (glm_plane_image pads to 128-row groups)
     return img, np.concatenate(yb)
 
+
+
+# ---- rows of a plate ordered by an unsorted group id (pa_group_rows_build) ------------------------
+def group_rows(g, G):
+    """(offsets int64 [G+1], rows int64 [N]): rows[offsets[k]:offsets[k+1]] = the n with g[n] == k in
+    ascending n.  Restates what the reference's advanced index ``w[..., g, :]`` (SURVEY 8d config 5;
+    torch: aten index, scored by pyro/poutine/trace_struct.py:264-278) implies for a kernel that
+    visits rows group by group: integer work, the kernel's output is compared bit for bit."""
+    g = np.asarray(g, dtype=np.int64)
+    if g.size and (g.min() < 0 or g.max() >= G):
+        raise IndexError("group id outside [0, %d)" % G)
+    rows = np.argsort(g, kind="stable").astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(np.bincount(g, minlength=G))]).astype(np.int64)
+    return offsets, rows

@@ -120,6 +120,12 @@ _SIGNATURES = {
     "pa_glm_grouped_planes_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "pa_glm_pack_planes_grouped": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                            c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "pa_group_rows_workspace": (c_size_t, [c_int64, c_int64]),
+    "pa_group_rows_build": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
+    "pa_glm_pack_planes_grouped_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                                c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_size_t,
+                                                c_void_p]),
     "pa_glm_bernoulli_grouped_planes_workspace": (c_size_t, [c_int64, c_int64]),
     "pa_glm_bernoulli_grouped_planes_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_int64,
                                                         c_int64, c_int64, c_int64, c_void_p, c_void_p,

@@ -776,6 +776,14 @@ int pa_glm_pack_planes_grouped(int format, const float* X, const float* y, int64
                                const int64_t* seg, const int64_t* st_off, int64_t nseg,
                                int64_t nst_total, void* planes, size_t planes_bytes,
                                pa_stream_t stream) {
+  return pa_glm_pack_planes_grouped_rows(format, X, y, nullptr, N, D, seg, st_off, nseg, nst_total,
+                                         planes, planes_bytes, stream);
+}
+
+int pa_glm_pack_planes_grouped_rows(int format, const float* X, const float* y, const int64_t* row_of,
+                                    int64_t N, int64_t D, const int64_t* seg, const int64_t* st_off,
+                                    int64_t nseg, int64_t nst_total, void* planes, size_t planes_bytes,
+                                    pa_stream_t stream) {
   PA_REQUIRE(N >= 0 && D >= 1 && D <= 32 && nseg >= 0 && nst_total >= 0,
              "glm_pack_planes_grouped: bad shape N=%lld D=%lld nseg=%lld", (long long)N, (long long)D,
              (long long)nseg);
@@ -795,14 +803,14 @@ int pa_glm_pack_planes_grouped(int format, const float* X, const float* y, int64
     const int rc = pa::glmh_absmax(X, N * D, trailer, s);
     if (rc != PA_OK) return rc;
     hipLaunchKernelGGL(pa::glm_pack_planes_f16_grouped_kernel,
-                       dim3((unsigned)((ntiles * 128 + 255) / 256)), dim3(256), 0, s, X, y, (int)D, seg,
-                       st_off, (int)nseg, ntiles, img, y16, trailer);
+                       dim3((unsigned)((ntiles * 128 + 255) / 256)), dim3(256), 0, s, X, y, row_of, (int)D,
+                       seg, st_off, (int)nseg, ntiles, img, y16, trailer);
     return pa::check_launch("glm_pack_planes_f16_grouped_kernel");
   }
   float* y_img = (float*)(img + (size_t)nst_total * 2 * pa::GLMP_TILE);
   hipLaunchKernelGGL(pa::glm_pack_planes_grouped_kernel, dim3((unsigned)((ntiles * 128 + 255) / 256)),
-                     dim3(256), 0, pa::as_stream(stream), X, y, (int)D, seg, st_off, (int)nseg, ntiles,
-                     img, y_img);
+                     dim3(256), 0, pa::as_stream(stream), X, y, row_of, (int)D, seg, st_off, (int)nseg,
+                     ntiles, img, y_img);
   return pa::check_launch("glm_pack_planes_grouped_kernel");
 }
 

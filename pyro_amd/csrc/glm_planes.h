@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void glm_pack_planes_kernel(const float* __res
 // one padded with zero rows -- so that a workgroup streams one segment with one group's weights.
 // The observations travel in the same padded row order (y_img: zeros in the padding).
 __global__ __launch_bounds__(256) void glm_pack_planes_grouped_kernel(
-    const float* __restrict__ X, const float* __restrict__ y, int D, const int64_t* __restrict__ seg,
-    const int64_t* __restrict__ st_off, int nseg, int64_t ntiles, unsigned char* __restrict__ img,
-    float* __restrict__ y_img) {
+    const float* __restrict__ X, const float* __restrict__ y, const int64_t* __restrict__ row_of, int D,
+    const int64_t* __restrict__ seg, const int64_t* __restrict__ st_off, int nseg, int64_t ntiles,
+    unsigned char* __restrict__ img, float* __restrict__ y_img) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= ntiles * 128) return;
   const int64_t T = idx >> 7, st = T >> 1;
@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void glm_pack_planes_grouped_kernel(
     else hi = mid - 1;
   }
   const int64_t a = seg[3 * lo], e = seg[3 * lo + 1];
-  const int64_t row = a + (T - 2 * st_off[lo]) * 32 + r;
-  const bool ok = row < e;
+  const int64_t pos = a + (T - 2 * st_off[lo]) * 32 + r;
+  const bool ok = pos < e;
+  // row_of (pa_group_rows_build): the image's row `pos` is the data's row row_of[pos] (unsorted ids)
+  const int64_t row = (ok && row_of) ? row_of[pos] : pos;
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {

@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_kernel(const float* _
 
 // the hierarchical variant: segments on super-tile boundaries, see glm_pack_planes_grouped_kernel
 __global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
-    const float* __restrict__ X, const float* __restrict__ y, int D, const int64_t* __restrict__ seg,
-    const int64_t* __restrict__ st_off, int nseg, int64_t ntiles, unsigned char* __restrict__ img,
-    float* __restrict__ y_img, uint32_t* __restrict__ trailer) {
+    const float* __restrict__ X, const float* __restrict__ y, const int64_t* __restrict__ row_of, int D,
+    const int64_t* __restrict__ seg, const int64_t* __restrict__ st_off, int nseg, int64_t ntiles,
+    unsigned char* __restrict__ img, float* __restrict__ y_img, uint32_t* __restrict__ trailer) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int kx = glmh_exponent_of(trailer[0]);
   if (idx == 0) trailer[1] = (uint32_t)kx;
@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
     else hi = mid - 1;
   }
   const int64_t a = seg[3 * lo], e = seg[3 * lo + 1];
-  const int64_t row = a + (T - 2 * st_off[lo]) * 32 + r;
-  const bool ok = row < e;
+  const int64_t pos = a + (T - 2 * st_off[lo]) * 32 + r;
+  const bool ok = pos < e;
+  const int64_t row = (ok && row_of) ? row_of[pos] : pos;
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {

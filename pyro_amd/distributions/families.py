@@ -471,6 +471,8 @@ class GroupedLinearLogits:
 
     def group_of_row(self):
         import numpy as np
+        if self.segments.ids is not None:            # rows in their original order
+            return self.segments.ids
         off = self.segments.group_offsets
         return torch.as_tensor(np.repeat(np.arange(len(off) - 1), np.diff(off)), device=self.X.device)
 
@@ -580,6 +582,10 @@ class _BernoulliLinear(TorchDistribution):
             mask = mask.contiguous()
         if lz.X.shape[1] > 128 or not lz.X.is_contiguous():
             return None
+        if isinstance(lz, GroupedLinearLogits):
+            from .. import kernels
+            if not kernels.glm_grouped_rows_servable(lz.X, value, mask, lz.segments):
+                return None
         w2, b1 = lz.flat_params()
         return w2, b1, mask
 
@@ -600,6 +606,10 @@ class _BernoulliLinear(TorchDistribution):
             mask = mask.contiguous()
         if lz.X.shape[1] > 128 or not lz.X.is_contiguous():
             return None
+        if isinstance(lz, GroupedLinearLogits):
+            from .. import kernels
+            if not kernels.glm_grouped_rows_servable(lz.X, value, mask, lz.segments):
+                return None
         w2, b1 = lz.flat_params()
         if isinstance(lz, GroupedLinearLogits):
             ll = fused.glm_bernoulli_grouped_ll(lz.X, value.contiguous(), w2, b1, mask, scale,
@@ -620,6 +630,9 @@ class Bernoulli(_FusedElementwise, torch.distributions.Bernoulli, TorchDistribut
             # unmodified model text (w @ X.t() ... + b): the plated GLM if its shape says so;
             # otherwise torch's constructor evaluates the product (broadcast_all is a torch function)
             logits = logits.as_linear_logits() or logits
+        elif isinstance(logits, _lazy.DeferredGroupDot):
+            # the hierarchical GLM as the reference writes it: (w[..., g, :] * X).sum(-1) + b
+            logits = logits.as_grouped_linear_logits() or logits.materialize()
         if isinstance(logits, (LinearLogits, GroupedLinearLogits)):
             return _BernoulliLinear(logits, validate_args)
         return super().__new__(cls)

@@ -163,6 +163,25 @@ def hier_logreg_model(X, y, segments, plate_scale=1.0):
         sample("obs", dist.Bernoulli(logits=dist.grouped_linear_logits(X, w, b, segments)), obs=y)
 
 
+def hier_logreg_model_reference(X, y, g, G, plate_scale=1.0):
+    """SURVEY 8(d) config 5 exactly as the reference would write it: g = int64 [N] group ids in ANY
+    order, logit_n = x_n . w_{g_n} + b through an advanced-index gather.  Nothing here names the
+    backend: the gather of a latent is recognised lazily (ops/lazy.py::DeferredGroupDot) and the
+    observed site runs the grouped plane-image kernel; with the recognition switched off the same
+    text runs operator by operator."""
+    N, D = X.shape
+    z = torch.zeros(D, dtype=X.dtype, device=X.device)
+    mu = sample("mu", dist.Normal(z, 1.0).to_event(1))
+    tau = sample("tau", dist.HalfNormal(torch.ones(D, dtype=X.dtype, device=X.device)).to_event(1))
+    b = sample("b", dist.Normal(torch.zeros((), dtype=X.dtype, device=X.device), 1.0))
+    with plate("groups", G):
+        w = sample("w", dist.Normal(mu, tau).to_event(1))
+    from . import poutine
+    with poutine.scale(scale=float(plate_scale)), plate("data", N):
+        logits = (w[..., g, :] * X).sum(-1) + b
+        sample("obs", dist.Bernoulli(logits=logits), obs=y)
+
+
 def hier_logreg_model_unfused(X, y, segments):
     """Same model in the reference's formulation: gather the per-row weights and reduce."""
     N, D = X.shape
@@ -194,6 +213,23 @@ def synthetic_hier_logreg_data(N, D, G, device, seed=0, dtype=torch.float32):
     counts = torch.bincount(grp, minlength=G).cpu().numpy().astype(np.int64)
     offsets = np.concatenate([[0], np.cumsum(counts)])
     return X, y, offsets
+
+
+def synthetic_hier_logreg_data_unsorted(N, D, G, device, seed=0, dtype=torch.float32):
+    """SURVEY 8(d) config 5's data: g = randint(0, G, (N,)) left in its random order; returns X, y, g."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    X = torch.randn((N, D), device=device, dtype=dtype, generator=g)
+    grp = torch.randint(0, G, (N,), device=device, generator=g)
+    mu = torch.randn((D,), device=device, dtype=dtype, generator=g)
+    wg = mu + 0.5 * torch.randn((G, D), device=device, dtype=dtype, generator=g)
+    y = torch.empty((N,), device=device, dtype=dtype)
+    step = 1 << 20                                   # (the gathered weights of 1e7 rows are 1.3 GB)
+    for lo in range(0, N, step):
+        hi = min(N, lo + step)
+        logits = (wg[grp[lo:hi]] * X[lo:hi]).sum(-1)
+        y[lo:hi] = (torch.rand((hi - lo,), device=device, dtype=dtype, generator=g)
+                    < torch.sigmoid(logits)).to(dtype)
+    return X, y, grp
 
 
 # ---- examples/hmm.py:97-137 (model_1) restated against the drop-in API ---------------------------

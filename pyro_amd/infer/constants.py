@@ -55,9 +55,21 @@ def _key_of(func, args, kwargs):
         return None
 
 
+def _fill_of(name, fill, args, kwargs):
+    """The fill value of a factory call (None: not a number we can re-create)."""
+    if fill is not None:
+        return fill
+    v = kwargs.get("fill_value") if kwargs else None
+    if v is None:
+        pos = 2 if name == "new_full" else 1
+        v = args[pos] if len(args) > pos else None
+    return v if isinstance(v, (int, float, bool)) else None
+
+
 class ConstantRecorder(TorchDispatchMode):
     """Notes every constant-filled device tensor created while active: ``calls`` = list of
-    (key, result tensor)."""
+    (key, (shape, strides, dtype, device, fill value)) -- descriptions only: holding the tensors of the
+    eager step themselves would keep up to 1 GiB each alive per argument signature."""
 
     def __init__(self):
         super().__init__()
@@ -71,8 +83,11 @@ class ConstantRecorder(TorchDispatchMode):
         if func in _FACTORIES and isinstance(out, torch.Tensor) and out.is_cuda \
                 and out.numel() <= _MAX_ELEMS and not out.requires_grad:
             key = _key_of(func, args, kwargs)
-            if key is not None:
-                self.calls.append((key, out))
+            name, fill = _FACTORIES[func]
+            value = _fill_of(name, fill, args, kwargs)
+            if key is not None and value is not None:
+                self.calls.append((key, (tuple(out.shape), tuple(out.stride()), out.dtype, out.device,
+                                         value)))
         return out
 
 
@@ -87,8 +102,11 @@ class ConstantReplayer(TorchDispatchMode):
         self.tensors = []         # keep-alive: a captured graph reads them on every replay
         self.served = 0
         with torch.no_grad():
-            for key, t in recorder.calls:
-                c = t.detach().clone()      # same shape / strides / dtype / device, same values
+            for key, (shape, stride, dtype, device, value) in recorder.calls:
+                # re-created from the recorded fill value (not cloned from the eager step's tensor: a
+                # write the dispatcher cannot see -- a raw-pointer kernel, a .data alias -- would
+                # otherwise be frozen into the "constant")
+                c = torch.empty_strided(shape, stride, dtype=dtype, device=device).fill_(value)
                 self._queues.setdefault(key, []).append(c)
                 self._storages.add(c.untyped_storage().data_ptr())
                 self.tensors.append(c)

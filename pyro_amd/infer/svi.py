@@ -133,6 +133,7 @@ class SVI:
                     # signatures that never came back: forget the oldest half
                     for k in list(self._eager_seen)[:len(self._eager_seen) // 2]:
                         del self._eager_seen[k]
+                        self._const_rec.pop(k, None)
                     if not self._warned_keys:
                         self._warned_keys = True
                         warnings.warn("pyro_amd: SVI(hip_graph=True) keeps seeing new argument "

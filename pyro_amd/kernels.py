@@ -831,6 +831,10 @@ def glm_planes_revalidate():
         if ent is None or ent[4] is None:
             continue
         X, y = ent[0](), ent[2]()
+        if segs.ids is not None and segs.ids._version != segs.ids_version:
+            # a captured step reads the segment table of the OLD ids: nothing can be patched in place
+            raise RuntimeError("pyro_amd: the group-id tensor of a hierarchical GLM site was written in "
+                               "place under a captured step; pass a new tensor instead")
         if X is not None and y is not None and (ent[1] != X._version or ent[3] != y._version):
             glm_pack_planes_grouped(X, y, segs, out=ent[4])
             ent[1], ent[3] = X._version, y._version
@@ -938,6 +942,11 @@ class GroupSegments:
         self.nst_total = st[-1]
         self.st_off = torch.tensor(st, dtype=torch.int64, device=device)
         self._planes = None          # [weakref X, X version, weakref y, y version, image, sightings]
+        # rows NOT sorted by group (grouped_rows_of): image row i is the data's row rows[i], and
+        # ``ids`` is the unsorted id vector g itself (what the un-fused formulation gathers with)
+        self.rows = None
+        self.ids = None
+        self.ids_version = 0
 
 
 # ---- the plane image of a grouped design matrix (belongs to the GroupSegments object) ------------
@@ -962,9 +971,78 @@ def glm_pack_planes_grouped(X, y, segs, out=None, fmt=None):
     assert X.is_contiguous() and y.is_contiguous() and X.dtype == torch.float32 == y.dtype
     if out is None:
         out = _new_image(nbytes, X.device, fmt)
-    check(lib.pa_glm_pack_planes_grouped(fmt, _ptr(X), _ptr(y), N, D, _ptr(segs.seg), _ptr(segs.st_off),
-                                         segs.nseg, segs.nst_total, _ptr(out), nbytes, _stream()))
+    check(lib.pa_glm_pack_planes_grouped_rows(fmt, _ptr(X), _ptr(y), _ptr(segs.rows), N, D, _ptr(segs.seg),
+                                              _ptr(segs.st_off), segs.nseg, segs.nst_total, _ptr(out),
+                                              nbytes, _stream()))
     return out
+
+
+def group_rows_build(g, G):
+    """g: int64 [N] device, unsorted group ids -> (offsets int64 [G+1], rows int64 [N]) on the device:
+    rows[offsets[k]:offsets[k+1]] = the n with g[n] == k, ascending (a stable counting sort;
+    bit-exact against oracle/glm.py::group_rows).  Raises IndexError for ids outside [0, G) as
+    torch's advanced indexing does, Unsupported beyond the kernel's limits."""
+    _require_gpu(g)
+    assert g.dtype == torch.int64 and g.dim() == 1 and g.is_contiguous()
+    N, G = g.shape[0], int(G)
+    lib = _lib.load()
+    nbytes = lib.pa_group_rows_workspace(N, G)
+    if nbytes == 0:
+        raise Unsupported("pyro_amd: no group-row index for N=%d G=%d" % (N, G))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=g.device)
+    offsets = torch.empty((G + 1,), dtype=torch.int64, device=g.device)
+    rows = torch.empty((N,), dtype=torch.int64, device=g.device)
+    bad = torch.empty((1,), dtype=torch.int64, device=g.device)
+    check(lib.pa_group_rows_build(_ptr(g), N, G, _ptr(offsets), _ptr(rows), _ptr(bad), _ptr(ws), nbytes,
+                                  _stream()))
+    nbad = int(bad.item())
+    if nbad:
+        raise IndexError("pyro_amd: %d group ids are outside [0, %d)" % (nbad, G))
+    return offsets, rows
+
+
+_group_rows_cache = {}      # id(g) -> [weakref g, version, G, GroupSegments]
+
+
+def glm_grouped_rows_servable(X, y, mask, segs):
+    """Can the fused grouped kernel serve this call?  Always for rows sorted by group; rows in their
+    original order (segs.rows) only through the plane image."""
+    if segs.rows is None:
+        return True
+    if (mask is not None or X.shape[1] > _PLANES_MAX_D or _planes_mode == GLM_PLANES_OFF
+            or X.dtype != torch.float32 or y.dtype != torch.float32 or not X.is_contiguous()
+            or X.shape[0] == 0):
+        return False
+    if segs.ids._version != segs.ids_version:
+        return False            # stale partition (ids written in place): the caller re-derives it
+    ent = segs._planes
+    have = ent is not None and ent[4] is not None and ent[0]() is X and ent[2]() is y
+    return have or not torch.cuda.is_current_stream_capturing()
+
+
+def grouped_rows_of(g, G):
+    """The GroupSegments of an UNSORTED id vector (built once per tensor object and version: the sort
+    permutation, the segment table of the sorted order); None inside a graph capture when it does
+    not exist yet (the sort reads its offsets back to the host)."""
+    ent = _group_rows_cache.get(id(g))
+    if ent is not None and (ent[0]() is not g or ent[2] != G):
+        ent = None
+    if ent is not None and ent[1] == g._version:
+        return ent[3]
+    if torch.cuda.is_current_stream_capturing():
+        if ent is not None:
+            raise RuntimeError("pyro_amd: group ids changed in place during a graph capture")
+        return None
+    offsets, rows = group_rows_build(g, G)
+    if ent is not None:
+        # same tensor, new contents: the partition (and with it every shape downstream) changes
+        _grouped_with_image.discard(ent[3])
+    segs = GroupSegments(offsets.cpu().numpy(), g.device)
+    segs.rows, segs.ids, segs.ids_version = rows, g, g._version
+    for k in [k for k, e in _group_rows_cache.items() if e[0]() is None]:
+        del _group_rows_cache[k]
+    _group_rows_cache[id(g)] = [_weakref.ref(g), g._version, G, segs]
+    return segs
 
 
 def glm_grouped_planes_of(X, y, segs):
@@ -982,7 +1060,8 @@ def glm_grouped_planes_of(X, y, segs):
     ent[5] += 1
     capturing = torch.cuda.is_current_stream_capturing()
     if ent[4] is None:
-        if (_planes_mode == GLM_PLANES_AUTO and ent[5] < 2) or capturing:
+        # (rows in their original order have no other fused kernel: packed at first sight)
+        if (_planes_mode == GLM_PLANES_AUTO and ent[5] < 2 and segs.rows is None) or capturing:
             return None
         ent[4] = glm_pack_planes_grouped(X, y, segs)
         ent[1], ent[3] = X._version, y._version
@@ -1022,13 +1101,17 @@ def glm_bernoulli_grouped_fwd_bwd(X, y, w, b, mask, scale, segs):
     _require_gpu(X, y, w, b, mask)
     if X.dtype != torch.float32:
         raise Unsupported("pyro_amd: fused GLM kernel is float32 only")
-    if (mask is None and X.shape[1] <= _PLANES_MAX_D and w.shape[0] >= _PLANES_MIN_P
-            and X.shape[0] > 0 and _glm_variant == GLM_AUTO and X.is_contiguous()
-            and y.is_contiguous() and y.dtype == torch.float32):
+    if (mask is None and X.shape[1] <= _PLANES_MAX_D
+            and (w.shape[0] >= _PLANES_MIN_P or segs.rows is not None)
+            and X.shape[0] > 0 and (_glm_variant == GLM_AUTO or segs.rows is not None)
+            and X.is_contiguous() and y.is_contiguous() and y.dtype == torch.float32):
         planes = glm_grouped_planes_of(X, y, segs)
         if planes is not None:
             return glm_bernoulli_grouped_planes_fwd_bwd(planes, w, b, scale, X.shape[0], X.shape[1],
                                                         segs)
+    if segs.rows is not None:
+        raise Unsupported("pyro_amd: rows in their original order are only served by the plane image "
+                          "(no mask, D <= 32, float32, image packed outside a capture)")
     N, D = X.shape
     P, G = w.shape[0], w.shape[1]
     assert X.is_contiguous() and y.is_contiguous() and w.is_contiguous()

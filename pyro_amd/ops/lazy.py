@@ -24,6 +24,12 @@ MIN_ROWS = 256              # below this the unfused route is as fast and nothin
 ENABLED = {"on": True}
 
 
+def _on_device(t):
+    """Recognition is for device tensors (the kernels have no CPU form); the host tests of the
+    recognition LOGIC replace this predicate."""
+    return t.is_cuda
+
+
 def _plain(t):
     """The plain tensor behind a latent: the very object the trace holds (so that downstream code
     that keys on tensor identity -- e.g. the gradient chaining of the ELBO assembly -- sees the
@@ -34,16 +40,19 @@ def _plain(t):
     return origin if origin is not None else t.as_subclass(torch.Tensor)
 
 
+_DTYPES = (torch.float32,)    # what the fused kernels compute in (host tests of the logic widen it)
+
+
 def _is_design_transpose(m):
     """m == X.t() for a contiguous, constant [N, D] float32 device matrix X?"""
-    return (type(m) is torch.Tensor and m.dim() == 2 and not m.requires_grad and m.is_cuda
-            and m.dtype == torch.float32 and m.shape[1] >= MIN_ROWS and m.shape[0] <= 128
+    return (type(m) is torch.Tensor and m.dim() == 2 and not m.requires_grad and _on_device(m)
+            and m.dtype in _DTYPES and m.shape[1] >= MIN_ROWS and m.shape[0] <= 128
             and m.stride(0) == 1 and m.stride(1) == m.shape[0])
 
 
 def _is_design(m):
-    return (type(m) is torch.Tensor and m.dim() == 2 and not m.requires_grad and m.is_cuda
-            and m.dtype == torch.float32 and m.shape[0] >= MIN_ROWS and m.shape[1] <= 128
+    return (type(m) is torch.Tensor and m.dim() == 2 and not m.requires_grad and _on_device(m)
+            and m.dtype in _DTYPES and m.shape[0] >= MIN_ROWS and m.shape[1] <= 128
             and m.is_contiguous())
 
 
@@ -65,13 +74,58 @@ class LatentTensor(torch.Tensor):
             if isinstance(b, LatentTensor) and _is_design(a) and b.dim() == 1 \
                     and a.shape[1] == b.shape[0] and a.dtype == b.dtype:
                 return DeferredMatmul(a, _plain(b))                         # X @ w
+        if ENABLED["on"] and len(args) == 2 and not kwargs and isinstance(args[0], LatentTensor) \
+                and getattr(func, "__name__", "") == "__getitem__":
+            ids = _group_gather_index(args[0], args[1])
+            if ids is not None:
+                return DeferredGroupDot(_plain(args[0]), ids)               # w[..., g, :]
+        for a in args:
+            if isinstance(a, _DEFERRED):       # the deferred operand's own handler decides
+                return type(a).__torch_function__(func, types, args, kwargs)
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)       # plain tensors come back: laziness ends here
 
 
+def _group_gather_index(w, index):
+    """``index`` selects rows of the second-to-last dim of ``w`` by ONE 1-D int64 device tensor and
+    keeps every other dim whole (``w[..., g, :]``, ``w[:, g]``, ``w[g]`` for a 2-D w): the id tensor,
+    else None."""
+    if w.dim() < 2 or w.shape[-1] > 128:
+        return None
+    if type(index) is torch.Tensor:
+        index = (index,)
+    if not isinstance(index, tuple):
+        return None
+    ids, pos, n_before, seen_ellipsis = None, None, 0, False
+    for k, it in enumerate(index):
+        if it is Ellipsis:
+            if seen_ellipsis:
+                return None
+            seen_ellipsis = True
+        elif isinstance(it, slice):
+            if it != slice(None):
+                return None
+        elif type(it) is torch.Tensor:
+            if ids is not None:
+                return None
+            ids, pos = it, k
+        else:
+            return None
+    if ids is None or ids.dtype != torch.int64 or ids.dim() != 1 or not _on_device(ids) \
+            or ids.requires_grad or ids.shape[0] < MIN_ROWS or not ids.is_contiguous():
+        return None
+    # the dim the tensor index lands on
+    if seen_ellipsis:
+        e = [k for k, it in enumerate(index) if it is Ellipsis][0]
+        dim = pos if pos < e else w.dim() - (len(index) - pos)
+    else:
+        dim = pos
+    return ids if dim == w.dim() - 2 else None
+
+
 def as_latent(value):
-    if (ENABLED["on"] and type(value) is torch.Tensor and value.is_cuda
-            and value.dtype == torch.float32 and 1 <= value.dim() and value.shape[-1] <= 128):
+    if (ENABLED["on"] and type(value) is torch.Tensor and _on_device(value)
+            and value.dtype in _DTYPES and 1 <= value.dim() and value.shape[-1] <= 128):
         lat = value.as_subclass(LatentTensor)
         lat._pa_origin = value
         return lat
@@ -149,6 +203,11 @@ class DeferredMatmul:
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if len(args) == 2 and not kwargs and getattr(func, "__name__", "") in ("add", "__add__", "__radd__"):
+            d, o = (args[0], args[1]) if isinstance(args[0], DeferredMatmul) else (args[1], args[0])
+            if not isinstance(o, DeferredMatmul):
+                return d._with_bias(o)                                      # b + logits
+
         def ev(x):
             if isinstance(x, DeferredMatmul):
                 return x.materialize()
@@ -171,6 +230,140 @@ class DeferredMatmul:
                "__le__", "__ge__"):
         locals()[_n] = _binary(_n) if _n != "__neg__" else (lambda self: -self.materialize())
     del _n, _binary
+
+
+# ---- the hierarchical GLM in the reference's formulation ---------------------
+#     logits = (w[..., g, :] * X).sum(-1) + b            # g: int64 [N], UNSORTED group ids
+#     pyro.sample("obs", Bernoulli(logits=logits), obs=y)
+# The reference materialises the gathered weights [P, N, D] (82 GB at N=1e7, P=64, D=32), the product,
+# the logits, the log-probs and their autograd duals.  Here the advanced index on a latent returns a
+# DeferredGroupDot in stage "gather"; multiplying by the constant [N, D] design matrix moves it to
+# stage "product", ``.sum(-1)`` to stage "logits", ``+ b`` attaches the bias; ``Bernoulli(logits=...)``
+# turns stage "logits" into the grouped plane-image site (kernels.grouped_rows_of: the sort permutation
+# and segment table, built once per id tensor).  ANY other use evaluates exactly what was written.
+class DeferredGroupDot:
+    def __init__(self, w, ids, stage="gather", X=None, bias=None):
+        self.w, self.ids, self.stage, self.X, self.bias = w, ids, stage, X, bias
+        N = ids.shape[0]
+        lead = tuple(w.shape[:-2])
+        if stage == "logits":
+            shape = lead + (N,)
+            if isinstance(bias, torch.Tensor):
+                shape = tuple(torch.broadcast_shapes(shape, bias.shape))
+        else:
+            shape = lead + (N, w.shape[-1])
+        self.shape = torch.Size(shape)
+        self.dtype, self.device = w.dtype, w.device
+
+    def dim(self):
+        return len(self.shape)
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def _times(self, other):
+        if self.stage == "gather" and _is_design(other) and other.shape[0] == self.ids.shape[0] \
+                and other.shape[1] == self.w.shape[-1] and other.dtype == self.dtype \
+                and other.device == self.device:
+            return DeferredGroupDot(self.w, self.ids, "product", other)
+        return self.materialize() * other
+
+    __mul__ = _times
+    __rmul__ = _times
+
+    def sum(self, *args, **kwargs):
+        dim = args[0] if args else kwargs.get("dim")
+        if self.stage == "product" and isinstance(dim, int) and not isinstance(dim, bool) \
+                and dim % len(self.shape) == len(self.shape) - 1 and len(args) <= 1 \
+                and not kwargs.get("keepdim", False) and kwargs.get("dtype") is None \
+                and set(kwargs) <= {"dim", "keepdim", "dtype"}:
+            return DeferredGroupDot(self.w, self.ids, "logits", self.X)
+        return self.materialize().sum(*args, **kwargs)
+
+    def _with_bias(self, other):
+        other = _plain(other) if isinstance(other, torch.Tensor) else other
+        if self.stage == "logits" and self.bias is None:
+            if isinstance(other, (int, float)):
+                return DeferredGroupDot(self.w, self.ids, "logits", self.X,
+                                        torch.full((), float(other), dtype=self.dtype, device=self.device))
+            if isinstance(other, torch.Tensor) and other.dtype == self.dtype and other.device == self.device \
+                    and (other.dim() == 0 or other.shape[-1] == 1) and other.dim() <= len(self.shape):
+                return DeferredGroupDot(self.w, self.ids, "logits", self.X, other)
+        return self.materialize() + other
+
+    __add__ = _with_bias
+    __radd__ = _with_bias
+
+    def as_grouped_linear_logits(self):
+        """The fused site's lazy operand, or None when this is not (yet) the hierarchical GLM or the
+        grouped kernel cannot serve it."""
+        if self.stage != "logits":
+            return None
+        from .. import kernels
+        from ..distributions.families import GroupedLinearLogits
+        try:
+            segs = kernels.grouped_rows_of(self.ids, self.w.shape[-2])
+            if segs is None:
+                return None
+            return GroupedLinearLogits(self.X, self.w, self.bias, segs)
+        except (ValueError, kernels.Unsupported):
+            return None
+
+    def materialize(self):
+        out = self.w[..., self.ids, :]
+        if self.stage != "gather":
+            out = out * self.X
+        if self.stage == "logits":
+            out = out.sum(-1)
+            if self.bias is not None:
+                out = out + self.bias
+        return out
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if len(args) == 2 and not kwargs:
+            a, b = args
+            if name in ("mul", "__mul__", "__rmul__", "multiply"):
+                d, o = (a, b) if isinstance(a, DeferredGroupDot) else (b, a)
+                if not isinstance(o, DeferredGroupDot):
+                    return d._times(o)
+            if name in ("add", "__add__", "__radd__"):
+                d, o = (a, b) if isinstance(a, DeferredGroupDot) else (b, a)
+                if not isinstance(o, DeferredGroupDot):
+                    return d._with_bias(o)
+        if name == "sum" and args and isinstance(args[0], DeferredGroupDot):
+            return args[0].sum(*args[1:], **kwargs)
+
+        def ev(x):
+            if isinstance(x, DeferredGroupDot):
+                return x.materialize()
+            if isinstance(x, (list, tuple)):
+                return type(x)(ev(v) for v in x)
+            return x
+        return func(*ev(args), **{k: ev(v) for k, v in kwargs.items()})
+
+    def __getattr__(self, name):        # only reached for attributes not defined above
+        return getattr(self.materialize(), name)
+
+    def _binary(name):
+        def op(self, other):
+            return getattr(self.materialize(), name)(other)
+        op.__name__ = name
+        return op
+
+    for _n in ("__sub__", "__rsub__", "__truediv__", "__rtruediv__", "__neg__", "__getitem__",
+               "__matmul__", "__rmatmul__", "__pow__", "__lt__", "__gt__", "__le__", "__ge__"):
+        locals()[_n] = _binary(_n) if _n != "__neg__" else (lambda self: -self.materialize())
+    del _n, _binary
+
+
+_DEFERRED = (DeferredMatmul, DeferredGroupDot)
 
 
 # ---- the word histogram of an amortised guide (examples/lda.py:113-121) --------------------------

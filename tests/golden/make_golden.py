@@ -659,6 +659,46 @@ def g_enum():
 
 
 # ---------------------------------------------------------------------------------------------
+# G11b: the same model with UNSORTED int64 group ids, as SURVEY 8d config 5 writes it
+#       (g = randint(0, G, (N,)); logits = (w[..., g, :] * X).sum(-1) + b): what the lazy recognition
+#       of ops/lazy.py::DeferredGroupDot must reproduce through the grouped plane-image kernel.
+# ---------------------------------------------------------------------------------------------
+def g_hier_unsorted():
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(22)
+    N, D, G, P = 700, 6, 9, 8
+    gid = rng.integers(0, G, size=N)
+    gid[gid == 4] = 5                       # an empty group
+    X = rng.standard_normal((N, D))
+    y = (rng.uniform(size=N) < 0.5).astype(float)
+    Xt, yt, gt = torch.tensor(X), torch.tensor(y), torch.tensor(gid)
+
+    def model(X, y, g):
+        z = torch.zeros(D)
+        mu = pyro.sample("mu", dist.Normal(z, 1.0).to_event(1))
+        tau = pyro.sample("tau", dist.HalfNormal(torch.ones(D)).to_event(1))
+        b = pyro.sample("b", dist.Normal(torch.zeros(()), 1.0))
+        with pyro.plate("groups", G):
+            w = pyro.sample("w", dist.Normal(mu, tau).to_event(1))
+        with pyro.plate("data", N):
+            logits = (w[..., g, :] * X).sum(-1) + b
+            pyro.sample("obs", dist.Bernoulli(logits=logits), obs=y)
+
+    pyro.clear_param_store()
+    guide = AutoNormal(model, init_scale=0.1)
+    elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+    guide(Xt, yt, gt)   # prototype + params
+    with torch.no_grad():
+        for name, p in pyro.get_param_store().named_parameters():
+            p.add_(torch.tensor(np.random.default_rng(5).standard_normal(p.shape) * 0.2))
+    params = {k: v.detach().clone().numpy() for k, v in pyro.get_param_store().items()}
+    with EpsBank(6) as bank:
+        loss = elbo.loss_and_grads(model, guide, Xt, yt, gt)
+    save("hier_unsorted", X=X, y=y, g=gid, G=G, P=P, loss=loss, grads=grads_of_store(), params=params,
+         eps=list(bank.used))
+
+
+# ---------------------------------------------------------------------------------------------
 # G11: hierarchical logistic regression at toy size, AutoNormal, vectorised
 #      particles: loss and gradients of the unmodified reference with banked eps.
 # ---------------------------------------------------------------------------------------------
@@ -1385,7 +1425,7 @@ def g_gamma_grad():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov", "arrowhead", "gamma_grad"]
+                             "adaptation", "enum", "hier", "hier_unsorted", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov", "arrowhead", "gamma_grad"]
     for w in which:
         globals()["g_" + w]()
 

@@ -341,6 +341,33 @@ def run_hier(g, device, monkeypatch, fused, dtype=torch.float64, rtol=1e-9):
     assert_grads(store_grads(), g, "grads", rtol * 10)
 
 
+def run_hier_unsorted(g, device, monkeypatch, dtype=torch.float64, rtol=1e-9):
+    """tests/golden/hier_unsorted.npz: the reference's loss and gradients for the gather formulation
+    with unsorted group ids, through examples.hier_logreg_model_reference (the same text)."""
+    from pyro_amd import examples, rng
+    X = torch.tensor(g["X"], dtype=dtype, device=device)
+    y = torch.tensor(g["y"], dtype=dtype, device=device)
+    ids = torch.tensor(g["g"], dtype=torch.int64, device=device)
+    G, P = int(g["G"]), int(g["P"])
+    model = examples.hier_logreg_model_reference
+    pyro.clear_param_store()
+    guide = AutoNormal(model, init_scale=0.1)
+    guide._setup_prototype(X, y, ids, G)
+    guide(X, y, ids, G)      # creates the parameters
+    store = pyro.get_param_store()
+    with torch.no_grad():
+        for name in list(store.keys()):
+            target = torch.tensor(g["params/" + name], dtype=dtype, device=device)
+            from torch.distributions import transform_to
+            store._params[name].copy_(transform_to(store._constraints[name]).inv(target))
+    monkeypatch.setattr(rng, "normal", EpsReplay(_eps_of(g, "eps"), device))
+    elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+    loss = elbo.loss_and_grads(model, guide, X, y, ids, G)
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads", rtol * 10)
+    pyro.clear_param_store()
+
+
 # ---- TraceMeanField_ELBO and Predictive (golden: tests/golden/make_golden.py g_meanfield) ---------
 def run_meanfield(g, device, monkeypatch, tag, rtol):
     """Loss and gradients of the reference's TraceMeanField_ELBO: analytic KL for the Normal and

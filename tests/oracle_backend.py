@@ -243,10 +243,24 @@ class GroupSegments:
     def __init__(self, group_offsets, device, target_segments=4096):
         off = np.asarray(group_offsets, dtype=np.int64)
         self.G, self.N, self.group_offsets = off.size - 1, int(off[-1]), off
+        self.rows = self.ids = None
+        self.ids_version = 0
+
+
+def grouped_rows_of(g, G):
+    """kernels.grouped_rows_of answered by oracle/glm.py::group_rows (no cache: host-logic tests)."""
+    off, rows = o_glm.group_rows(_np(g), G)
+    segs = GroupSegments(off, g.device)
+    segs.rows, segs.ids, segs.ids_version = torch.as_tensor(rows), g, g._version
+    return segs
+
+
+def glm_grouped_rows_servable(X, y, mask, segs):
+    return segs.rows is None or mask is None
 
 
 def glm_bernoulli_grouped_fwd_bwd(X, y, w, b, mask, scale, segs):
-    g_of = np.repeat(np.arange(segs.G), np.diff(segs.group_offsets))
+    g_of = np.repeat(np.arange(segs.G), np.diff(segs.group_offsets)) if segs.ids is None else _np(segs.ids)
     ll, gw, gb = o_glm.glm_bernoulli_grouped_fwd_bwd(_np(X), _np(y), _np(w), g_of, _np(b), _np(mask),
                                                      scale)
     return (torch.as_tensor(ll, dtype=X.dtype), torch.as_tensor(gw, dtype=X.dtype),
@@ -472,7 +486,7 @@ def chain_matvec(M, x, transpose=False):
 FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
-             "glm_bernoulli_grouped_fwd_bwd", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
+             "glm_bernoulli_grouped_fwd_bwd", "grouped_rows_of", "glm_grouped_rows_servable", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
              "mvn_tril_sample_bwd", "logchain_fwd_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd",
              "logsumexp_terms", "logsumexp_terms_grad", "gamma_rsample"]
@@ -486,3 +500,5 @@ def install(monkeypatch):
     # the product refuses CPU tensors; lift that check for host-logic tests only
     monkeypatch.setattr(k, "_require_gpu", lambda *a: None)
     monkeypatch.setattr(k, "on_device", lambda t: True)     # the oracle stands in for the device
+    from pyro_amd.ops import lazy
+    monkeypatch.setattr(lazy, "_on_device", lambda t: True)  # ... for the lazy recognition too

@@ -49,6 +49,26 @@ def test_hierarchical_logreg_loss_and_grads(monkeypatch, fused):
     models.run_hier(load("hier"), torch.device("cpu"), monkeypatch, fused=fused, rtol=1e-9)
 
 
+@pytest.mark.parametrize("lazy_on", [True, False])
+def test_hierarchical_reference_text_with_unsorted_groups(monkeypatch, lazy_on):
+    """SURVEY 8(d) config 5 as the reference writes it ((w[..., g, :] * X).sum(-1) + b, unsorted int64
+    ids) against the reference's own loss and gradients: recognised lazily (DeferredGroupDot -> the
+    grouped site, the oracle standing in for the kernel) and operator by operator."""
+    from pyro_amd import kernels
+    from pyro_amd.ops import lazy
+    calls = []
+    real = kernels.glm_bernoulli_grouped_fwd_bwd
+    monkeypatch.setattr(kernels, "glm_bernoulli_grouped_fwd_bwd",
+                        lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setitem(lazy.ENABLED, "on", lazy_on)
+    if lazy_on:
+        monkeypatch.setattr(lazy, "_DTYPES", (torch.float32, torch.float64))   # the oracle is float64
+        from pyro_amd import distributions as dist
+        monkeypatch.setattr(dist.families._BernoulliLinear, "_allow_f64", True)
+    models.run_hier_unsorted(load("hier_unsorted"), torch.device("cpu"), monkeypatch, rtol=1e-9)
+    assert len(calls) == (1 if lazy_on else 0)
+
+
 @pytest.mark.parametrize("tag", ["p1", "p5"])
 def test_trace_mean_field_elbo(monkeypatch, tag):
     models.run_meanfield(load("meanfield"), torch.device("cpu"), monkeypatch, tag, rtol=1e-9)

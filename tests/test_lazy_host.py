@@ -1,0 +1,82 @@
+"""Host logic of the lazy recognition (ops/lazy.py) on CPU: the predicates that say "device tensor" are
+answered with yes (tests/oracle_backend.py), so the recognition LOGIC -- which expressions stay
+deferred, what they evaluate to when used any other way -- is tested without a GPU; the kernels behind
+the recognised sites are tested in the -m gpu files."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import glm as o_glm
+
+
+@pytest.fixture(autouse=True)
+def _cpu_backend(oracle_backend):
+    yield
+
+
+def test_oracle_group_rows_is_the_stable_sort():
+    rng = np.random.default_rng(0)
+    for N, G in [(0, 3), (1, 1), (1000, 7), (5000, 1000)]:
+        g = rng.integers(0, G, size=N)
+        off, rows = o_glm.group_rows(g, G)
+        assert off[0] == 0 and off[-1] == N and (np.diff(off) >= 0).all() and off.shape == (G + 1,)
+        assert sorted(rows.tolist()) == list(range(N))
+        for k in range(G):
+            seg = rows[off[k]:off[k + 1]]
+            assert (g[seg] == k).all() and (np.diff(seg) > 0).all()       # ascending inside a group
+    with pytest.raises(IndexError):
+        o_glm.group_rows(np.array([0, 5]), 5)
+
+
+def test_group_gather_recognition_and_fallbacks():
+    from pyro_amd.ops import lazy
+    gen = torch.Generator().manual_seed(0)
+    N, D, G, P = 500, 8, 7, 3
+    X = torch.randn((N, D), generator=gen)
+    ids = torch.randint(0, G, (N,), generator=gen)
+    w = torch.randn((P, G, D), generator=gen)
+    b = torch.randn((P, 1), generator=gen)
+    wl, bl = lazy.as_latent(w), lazy.as_latent(b)
+    ref = w[..., ids, :]
+    d = wl[..., ids, :]
+    assert isinstance(d, lazy.DeferredGroupDot) and d.stage == "gather" and d.shape == ref.shape
+    assert isinstance(wl[:, ids], lazy.DeferredGroupDot) and isinstance(wl[:, ids, :], lazy.DeferredGroupDot)
+    assert type(wl[..., ids]) is torch.Tensor and type(wl[0]) is torch.Tensor
+    assert type(wl[:, ids[:10]]) is torch.Tensor and type(wl[:, ids.to(torch.int32)]) is torch.Tensor
+    w2 = lazy.as_latent(torch.randn((G, D), generator=gen))
+    assert isinstance(w2[ids], lazy.DeferredGroupDot) and w2[ids].shape == (N, D)
+    torch.testing.assert_close(d * 2.0, ref * 2.0)
+    torch.testing.assert_close(d - 1.0, ref - 1.0)
+    torch.testing.assert_close(torch.tanh(d), torch.tanh(ref))
+    p = d * X
+    assert isinstance(p, lazy.DeferredGroupDot) and p.stage == "product"
+    assert isinstance(X * d, lazy.DeferredGroupDot) and isinstance(torch.mul(d, X), lazy.DeferredGroupDot)
+    torch.testing.assert_close(d * X[:, :1], ref * X[:, :1])                 # not the design matrix
+    torch.testing.assert_close(p.sum(), (ref * X).sum())
+    torch.testing.assert_close(p.sum(-1, keepdim=True), (ref * X).sum(-1, keepdim=True))
+    torch.testing.assert_close(p.sum(0), (ref * X).sum(0))
+    for s in (p.sum(-1), torch.sum(p, -1), p.sum(dim=-1), p.sum(2)):
+        assert isinstance(s, lazy.DeferredGroupDot) and s.stage == "logits" and s.shape == (P, N)
+    s = p.sum(-1)
+    torch.testing.assert_close(torch.sigmoid(s), torch.sigmoid((ref * X).sum(-1)))
+    for sb in (s + bl, bl + s, s + 0.5):
+        assert isinstance(sb, lazy.DeferredGroupDot) and sb.stage == "logits"
+    torch.testing.assert_close((bl + s).materialize(), (ref * X).sum(-1) + b)
+    assert (s + bl).bias is b                                               # the site's own tensor
+    torch.testing.assert_close(s + torch.ones(N), (ref * X).sum(-1) + 1.0)   # not a bias: evaluated
+    torch.testing.assert_close((s + bl) + 1.0, (ref * X).sum(-1) + b + 1.0)  # a second addend: evaluated
+    lz = (s + bl).as_grouped_linear_logits()
+    assert lz is not None and lz.shape == (P, N) and lz.segments.ids is ids
+    torch.testing.assert_close(lz.materialize(), (ref * X).sum(-1) + b)
+    assert d.as_grouped_linear_logits() is None and p.as_grouped_linear_logits() is None
+
+
+def test_bias_on_the_left_keeps_the_plated_glm_deferred():
+    from pyro_amd.ops import lazy
+    gen = torch.Generator().manual_seed(1)
+    X = torch.randn((400, 8), generator=gen)
+    w = lazy.as_latent(torch.randn((3, 1, 8), generator=gen))
+    b = lazy.as_latent(torch.randn((3, 1), generator=gen))
+    s = (w @ X.t()).squeeze(-2)
+    for sb in (s + b, b + s):
+        assert isinstance(sb, lazy.DeferredMatmul) and sb.as_linear_logits() is not None

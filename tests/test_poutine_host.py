@@ -370,7 +370,8 @@ def test_do_under_a_plate_does_not_enter_the_plate_twice():
 # ---- lift, escape / queue, equalize (tests/poutine/test_poutines.py Lift / Queue / Equalize handler tests) ----------
 def test_lift_turns_params_into_sample_sites():
     def prior_for(tensor, *args, **kwargs):
-        return Normal(torch.zeros(tensor.shape), 1.0).sample()
+        # (positive: the lifted scale parameters are DRAWN from it and validated by Normal(loc, scale))
+        return Normal(torch.zeros(tensor.shape), 1.0).sample().abs() + 0.1
 
     tr = poutine.trace(guide).get_trace()
     params = {"loc1", "scale1", "loc2", "scale2"}
