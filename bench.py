@@ -38,7 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 BINDING_F16 = ("instruction issue: ~260 VALU instructions per wave and 32x32 (row, particle) tile "
                "(sigmoid / softplus sums, the two-level f16 split of g) next to 13 MFMAs; two workgroups "
                "per CU (more waves only add barrier waits); PMC per launch in "
-               "profiles/r03_pmc_summary.json, DESIGN.md section 3")
+               "profiles/r0N_pmc_summary.json (latest round), DESIGN.md section 3")
 BINDING_BF16 = ("VALU issue next to the MFMA pipe: 332 VALU instructions per wave and 32x32 (row, "
                 "particle) tile (sigmoid / softplus sums + the exact 3-way bf16 split of g) against 25 "
                 "MFMAs; PMC per launch: VALU issue 47 us of SIMD time, matrix pipe busy 26 us, kernel "
@@ -68,13 +68,27 @@ def parse():
     ap.add_argument("--nuts-warmup", type=int, default=200)
     ap.add_argument("--nuts-samples", type=int, default=200)
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--config5-sharded", action="store_true",
+    ap.add_argument("--config5-sharded", action=argparse.BooleanOptionalAction, default=None,
                     help="also time BASELINE configs[4] with the PLATE sharded over the ranks (SURVEY "
                          "8e variant 2): rows / world per GPU, the same particles everywhere, the "
-                         "likelihood scaled to the full plate, one flat RCCL gradient all-reduce")
+                         "likelihood scaled to the full plate, one flat RCCL gradient all-reduce "
+                         "(default: on when launched with more than one rank)")
     ap.add_argument("--config5-rows", type=int, default=10_000_000)
     ap.add_argument("--config5-groups", type=int, default=1000)
     return ap.parse_args()
+
+
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one (counters cannot be collected from
+    inside the run: the rocprofv3 passes of tools/prof.sh write them), or None."""
+    import re
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for f in os.listdir(pdir) if os.path.isdir(pdir) else []:
+        m = re.fullmatch(r"r(\d+)_" + re.escape(suffix), f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), os.path.join(pdir, f))
+    return best[1] if best else None
 
 
 def measured_hbm(dev):
@@ -355,16 +369,23 @@ def main():
         if on_gpu:
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if not graphed:
-            timer.arm()
-        svi.step(X, y)             # returns the loss as a float: one host read per step
-        if graphed_events:
-            kern_ms_list.append(timer.read_last())
-    sync()
-    elapsed = time.perf_counter() - t0
+    # The timed region is EXACTLY args.steps steps between barrier + synchronize on both sides.  At the
+    # driver's --steps 20 that is ~1.7 ms of timing, so the block is repeated (a count fixed by the
+    # arguments alone: every rank runs the same number of barriers) and the MEDIAN block is the
+    # headline; every block's time is in the line (`blocks_ms_per_step`).
+    nblocks = max(1, min(25, -(-2000 // max(args.steps, 1))))
+    block_s = []
+    for _ in range(nblocks):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if not graphed:
+                timer.arm()
+            svi.step(X, y)             # returns the loss as a float: one host read per step
+            if graphed_events:
+                kern_ms_list.append(timer.read_last())
+        sync()
+        block_s.append(time.perf_counter() - t0)
     clock_ms = []
     if graphed and not graphed_events:
         # the kernel's duration inside the graph, from its own stamps on the device clock
@@ -403,21 +424,30 @@ def main():
                                  "run in the eager steps that precede the capture"}
         finally:
             pyro.enable_validation(False)
+    rccl_ranks = 1
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor(block_s, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # max over ranks, block by block
+        block_s = [float(v) for v in t.cpu()]
+        # how many ranks the communicator actually holds: a sum of ones through the same backend the
+        # gradient all-reduce uses (not the WORLD_SIZE environment variable)
+        ones = torch.ones((1,), device=dev, dtype=torch.float32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(round(float(ones.item())))
+    elapsed = sorted(block_s)[len(block_s) // 2]           # the median block
 
     sharded5 = None
+    if args.config5_sharded is None:
+        args.config5_sharded = world > 1                   # (both SURVEY 8e variants on a multi-GPU run)
     if args.config5_sharded:
         # every rank holds rows / world rows (its own synthetic shard), draws the SAME particles (one
         # seed), scores its rows scaled by `world`, and the flat gradient is averaged over the ranks
         n_loc = args.config5_rows // world
-        Xs, ys, off = examples.synthetic_hier_logreg_data(n_loc, D, args.config5_groups, dev, seed=100 + rank)
-        segs = kernels.GroupSegments(off, dev)
+        G5 = args.config5_groups
+        Xs, ys, gs = examples.synthetic_hier_logreg_data_unsorted(n_loc, D, G5, dev, seed=100 + rank)
         pyro.clear_param_store()
         pyro.set_rng_seed(4321)
-        model5 = lambda X_, y_, s_: examples.hier_logreg_model(X_, y_, s_, plate_scale=float(world))  # noqa: E731
+        model5 = lambda X_, y_, g_: examples.hier_logreg_model_reference(X_, y_, g_, G5, plate_scale=float(world))  # noqa: E731
         opt5 = pyro.optim.Adam({"lr": 0.01})
         if world > 1:
             opt5 = pyro.optim.RcclOptimizer(opt5)
@@ -425,12 +455,12 @@ def main():
                    Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
                    hip_graph=use_graph, graph_warmup=2)
         for _ in range(6):
-            svi5.step(Xs, ys, segs)
+            svi5.step(Xs, ys, gs)
         sync()
         t5 = time.perf_counter()
         n5 = max(3, min(args.steps, 20))
         for _ in range(n5):
-            svi5.step(Xs, ys, segs)
+            svi5.step(Xs, ys, gs)
         sync()
         t5 = time.perf_counter() - t5
         if world > 1:
@@ -440,9 +470,10 @@ def main():
         sharded5 = {"steps_per_s": n5 / t5, "ms_per_step": t5 / n5 * 1e3, "rows_per_rank": n_loc,
                     "rows_total": n_loc * world, "particles": P, "ranks": world, "scaling": "strong",
                     "workload": "BASELINE configs[4], plate sharded over the ranks (SURVEY 8e variant 2): "
-                                "hierarchical logistic regression, %d rows in all, %d groups, the same %d "
-                                "particles on every rank, likelihood scaled by the world size, flat "
-                                "gradient all-reduce (mean)" % (n_loc * world, args.config5_groups, P)}
+                                "hierarchical logistic regression in the reference's formulation (unsorted "
+                                "int64 group ids, (w[..., g, :] * X).sum(-1) + b), %d rows in all, %d groups, "
+                                "the same %d particles on every rank, likelihood scaled by the world size, "
+                                "flat gradient all-reduce (mean)" % (n_loc * world, args.config5_groups, P)}
         pyro.clear_param_store()
     nuts = None if args.no_nuts else bench_nuts(dev, rank, world, args)
     others = None
@@ -452,16 +483,18 @@ def main():
         others = {}
         try:
             r5 = bench_configs.config5(dev, steps=20)
-            r5["workload"] = ("BASELINE configs[4], one GPU's share: hierarchical logistic regression, "
-                              "plate=1e7, D=32, 1000 groups, 64 of the 512 particles, AutoNormal, Adam, "
-                              "graphed SVI.step; grouped bf16x3 GLM kernel")
+            r5["workload"] = ("BASELINE configs[4], one GPU's share, SURVEY 8(d)'s model text verbatim: "
+                              "hierarchical logistic regression, plate=1e7, D=32, g = randint(0, 1000, (N,)) "
+                              "UNSORTED, logits = (w[..., g, :] * X).sum(-1) + b, 64 of the 512 particles, "
+                              "AutoNormal, Adam, graphed SVI.step; the gather is recognised lazily and runs "
+                              "the grouped plane-image GLM kernel (%s)" % r5.get("roofline", {}).get("kernel", "?"))
             others["config5_hierarchical_logreg"] = r5
             r4 = bench_configs.config4(dev, steps=10)
             r4["workload"] = ("BASELINE configs[3]: examples/lda.py, TraceEnum_ELBO, 1e5 documents (all "
                               "in the plate), 8 topics, 1024 words, 64 words per document, amortised "
                               "guide; word_topics enumerated and summed out by the indexed LDA kernels "
-                              "(no atomics); graphed SVI.step; ~2.4 ms of the step are the example "
-                              "guide's own rocBLAS products over the 1e5 x 1024 count matrix")
+                              "(no atomics), the guide's first layer on the bag-of-words image, its inner "
+                              "layers on the tall-batch kernels; graphed SVI.step")
             others["config4_lda"] = r4
             for bs in (32, 4096):      # the mini-batch variants SURVEY 8(d) lists
                 rb = bench_configs.config4(dev, steps=30, batch_size=bs)
@@ -496,6 +529,25 @@ def main():
                                "and hoisted prior constants instead of the reference's model text "
                                "(same kernels, two fill launches fewer)")
             others["config2_explicit_linear_logits"] = r2e
+            # "loss_and_grads only" beside the full step, the D sweep, and the
+            # exact three-plane bf16 image beside the default two-plane f16 one on every run
+            r2g = bench_configs.config2_variant(dev, "normal", no_update=True)
+            r2g["workload"] = ("BASELINE configs[1], loss_and_grads only: the captured step without the "
+                               "optimizer update (guide draw, fused ELBO gradient, guide backward, gradient "
+                               "zeroing, host read of the loss)")
+            others["config2_loss_and_grads_only"] = r2g
+            r2x = bench_configs.config2_variant(dev, "normal", planes_format=kernels.GLM_PLANES_BF16X3)
+            r2x["workload"] = ("BASELINE configs[1] on the EXACT three-plane bf16 image (every f32 operand "
+                               "split exactly, 6 piece products): the headline's arithmetic without the "
+                               "2^-22 representation error of the two-plane f16 image")
+            others["config2_bf16x3_exact_split"] = r2x
+            for Dv in (8, 64, 128):
+                rd = bench_configs.config2_variant(dev, "normal", D=Dv, steps=30)
+                rd["workload"] = ("BASELINE configs[1] at D=%d (SURVEY 8d sweep): %s" % (
+                    Dv, "plane-image kernel" if Dv <= 32 else
+                    ("bf16x3 kernel, X split on the fly (no plane image beyond D=32)" if Dv <= 64 else
+                     "exact-f32 MFMA kernel (no split-precision variant beyond D=64)")))
+                others["config2_D%d" % Dv] = rd
             r2u = bench_configs.config2_variant(dev, "normal", lazy_matmul=False, steps=20)
             r2u["workload"] = ("BASELINE configs[1], the reference's model text with the lazy recognition "
                                "of w @ X.t() switched OFF: [P, N] logits materialised by rocBLAS, "
@@ -515,12 +567,12 @@ def main():
         # profiles/: they cannot be collected from inside the run
         traffic = rocprof_ms = None
         traffic_src = None
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if os.path.exists(tpath):
+        tpath = latest_profile("traffic.json")
+        if tpath is not None:
             try:
                 tj = json.load(open(tpath))
                 traffic, rocprof_ms = tj.get("hbm_bytes_per_launch"), tj.get("kernel_ms_in_graph")
-                traffic_src = "profiles/r03_traffic.json (" + tj.get("how", "") + ")"
+                traffic_src = "profiles/%s (%s)" % (os.path.basename(tpath), tj.get("how", ""))
             except Exception:
                 traffic = None
         planes = on_gpu and kernels.glm_planes_of(X) is not None
@@ -531,6 +583,9 @@ def main():
             "unit": "ELBO-grad steps/s (64 particles x 1e6-row plate per step)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "timing": {"blocks": len(block_s), "steps_per_block": args.steps, "statistic": "median block "
+                       "(each block = exactly `steps` steps between barrier + synchronize, max over ranks)",
+                       "blocks_ms_per_step": [round(b / args.steps * 1e3, 5) for b in block_s]},
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: Bayesian logistic regression, plate=%d, "
                                    "D=%d, Trace_ELBO num_particles=%d per GPU (vectorised), AutoNormal, "
@@ -571,7 +626,7 @@ def main():
                          "frac_16bit_mfma": n_prod * gemm_flops / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                          "f32_equivalent_TFLOPs": achieved_tflops,
                          "binding_resource": BINDING_F16 if f16 else BINDING_BF16},
-            "rccl_ranks": world,
+            "rccl_ranks": rccl_ranks,      # measured: all_reduce(SUM) of ones over the process group
         }
         if world == 1 and on_gpu:
             try:

@@ -68,11 +68,15 @@ def implicit_grad(alpha, x):
         a, xv = float(a_all[idx]), float(x_all[idx])
         if not (xv > 0.0 and a > 0.0):
             continue
+        if a > 1e8:             # normal limit, see gamma.hip
+            out[idx] = 1.0 + (xv - a) / (2.0 * a)
+            continue
+        budget = 500 + int(16.0 * np.sqrt(a))      # ~ c sqrt(a) terms are needed near x ~ a
         lx_psi = np.log(xv) - float(_digamma(a))
         if xv < a + 1.0:
             t, dt = 1.0 / a, -1.0 / (a * a)
             S, dS = t, dt
-            for n in range(1, 500):
+            for n in range(1, budget):
                 den = a + n
                 f = xv / den
                 dt = dt * f - t * f / den
@@ -89,7 +93,7 @@ def implicit_grad(alpha, x):
             d = 1.0 / b
             dd = -db / (b * b)
             h, dh = d, dd
-            for i in range(1, 500):
+            for i in range(1, budget):
                 an, dan = -i * (i - a), float(i)
                 b += 2.0
                 dn = an * d + b

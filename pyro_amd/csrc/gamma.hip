@@ -61,11 +61,18 @@ __device__ __forceinline__ double gamma_draw(double a, uint64_t seed, uint64_t b
 // d x / d a at (a, x), see the header
 __device__ __forceinline__ double gamma_implicit_grad(double a, double x) {
   if (!(x > 0.0) || !(a > 0.0)) return 0.0;
+  // Both evaluations below need ~ c sqrt(a) terms near x ~ a (the terms only start to fall once
+  // n > x - a and then fall like exp(-n^2 / 2a)): the budget grows with sqrt(a) -- a fixed 500 was
+  // silently truncated from a ~ 2e4 upwards (1.6 % off at 3e4, 0.117 instead of 1.0 at 1e6).  Beyond
+  // 1e8 the draw is normal to O(1/a): x = a + sqrt(a) z with z held fixed gives
+  // d x / d a = 1 + z / (2 sqrt(a)) = 1 + (x - a) / (2 a), relative error < 2e-8 there.
+  if (a > 1e8) return 1.0 + (x - a) / (2.0 * a);
+  const int budget = 500 + (int)(16.0 * sqrt(a));
   const double lx_psi = log(x) - t_digamma<double>(a);
   if (x < a + 1.0) {
     // S = sum_n x^n / (a (a+1) ... (a+n)) and its derivative in a
     double t = 1.0 / a, dt = -1.0 / (a * a), S = t, dS = dt;
-    for (int n = 1; n < 500; ++n) {
+    for (int n = 1; n < budget; ++n) {
       const double den = a + n, f = x / den;
       dt = dt * f - t * f / den;
       t *= f;
@@ -82,7 +89,7 @@ __device__ __forceinline__ double gamma_implicit_grad(double a, double x) {
   double c = 1.0 / tiny, dc = 0.0;
   double d = 1.0 / b, dd = -db / (b * b);
   double h = d, dh = dd;
-  for (int i = 1; i < 500; ++i) {
+  for (int i = 1; i < budget; ++i) {
     const double an = -(double)i * ((double)i - a), dan = (double)i;
     b += 2.0;                                     // (db stays -1)
     double dn = an * d + b, ddn = dan * d + an * dd + db;

@@ -189,41 +189,51 @@ class ExpandedDistribution(TorchDistribution):
 
 
 
+def _of_base(name):
+    return property(lambda self: getattr(self.base_dist, name))
+
+
 class MaskedDistribution(TorchDistribution):
-    """Masks log_prob (and the score parts) of a base distribution
-    (reference: pyro/distributions/torch_distribution.py:302-396)."""
+    """``base_dist.mask(m)``: the density counts only where ``m`` holds (what the reference's class of
+    the same name provides, pyro/distributions/torch_distribution.py:302-396).  Here the mask is not an
+    extra pass over the log-density: it is the u8 ``mask`` ARGUMENT every site kernel already takes
+    (include/pyro_amd.h pa_dist_log_prob_sum / pa_site_entry), so the class reduces to one rule --
+    ``_gate`` -- that says what reaches the kernel: None (everything counts), False (nothing does) or
+    a bool tensor, combined with the mask a ``poutine.mask`` handler brings."""
 
     arg_constraints = {}
+    # everything that does not involve the density is the base distribution's
+    has_rsample, has_enumerate_support, support = _of_base("has_rsample"), _of_base("has_enumerate_support"), _of_base("support")
+    mean, variance = _of_base("mean"), _of_base("variance")
 
     def __init__(self, base_dist, mask):
-        if isinstance(mask, bool):
-            self._mask = mask
-        else:
-            batch_shape = broadcast_shape(mask.shape, base_dist.batch_shape)
-            if mask.shape != batch_shape:
-                mask = mask.expand(batch_shape)
-            if base_dist.batch_shape != batch_shape:
-                base_dist = base_dist.expand(batch_shape)
-            self._mask = mask.bool()
-        self.base_dist = base_dist
+        if not isinstance(mask, bool):
+            shape = broadcast_shape(mask.shape, base_dist.batch_shape)
+            mask = mask.bool().expand(shape)
+            if base_dist.batch_shape != shape:
+                base_dist = base_dist.expand(shape)
+        self.base_dist, self._mask = base_dist, mask
         super().__init__(base_dist.batch_shape, base_dist.event_shape, validate_args=False)
+
+    def _gate(self, other=None):
+        mine = None if self._mask is True else self._mask
+        if mine is None or other is None:
+            return mine if other is None else other
+        if mine is False or other is False:
+            return False
+        return mine & other
+
+    def _nothing(self, value):
+        """Zeros of the log-density's shape without evaluating the base distribution (a False mask is
+        how models switch a site off on data that may lie outside its support)."""
+        lead = value.shape[:value.dim() - self.event_dim]
+        return value.new_zeros(()).expand(broadcast_shape(self.base_dist.batch_shape, lead))
 
     def expand(self, batch_shape, _instance=None):
         batch_shape = torch.Size(batch_shape)
-        mask = self._mask if isinstance(self._mask, bool) else self._mask.expand(batch_shape)
-        return MaskedDistribution(self.base_dist.expand(batch_shape), mask)
-
-    @property
-    def has_rsample(self):
-        return self.base_dist.has_rsample
-
-    @property
-    def has_enumerate_support(self):
-        return self.base_dist.has_enumerate_support
-
-    @property
-    def support(self):
-        return self.base_dist.support
+        m = self._mask
+        return MaskedDistribution(self.base_dist.expand(batch_shape),
+                                  m if isinstance(m, bool) else m.expand(batch_shape))
 
     def sample(self, sample_shape=torch.Size()):
         return self.base_dist.sample(sample_shape)
@@ -231,55 +241,45 @@ class MaskedDistribution(TorchDistribution):
     def rsample(self, sample_shape=torch.Size()):
         return self.base_dist.rsample(sample_shape)
 
-    def log_prob(self, value):
-        if self._mask is False:
-            shape = broadcast_shape(self.base_dist.batch_shape,
-                                    value.shape[: value.dim() - self.event_dim])
-            return torch.zeros((), device=value.device).expand(shape)
-        if self._mask is True:
-            return self.base_dist.log_prob(value)
-        return scale_and_mask(self.base_dist.log_prob(value), mask=self._mask)
-
-    def score_parts(self, value):
-        if isinstance(self._mask, bool):
-            return super().score_parts(value)
-        return self.base_dist.score_parts(value).scale_and_mask(mask=self._mask)
-
     def enumerate_support(self, expand=True):
         return self.base_dist.enumerate_support(expand=expand)
 
-    # moments are those of the base distribution (torch_distribution.py:376-382)
-    @property
-    def mean(self):
-        return self.base_dist.mean
+    def log_prob(self, value):
+        gate = self._gate()
+        if gate is False:
+            return self._nothing(value)
+        lp = self.base_dist.log_prob(value)
+        return lp if gate is None else scale_and_mask(lp, mask=gate)
 
-    @property
-    def variance(self):
-        return self.base_dist.variance
+    def score_parts(self, value):
+        gate = self._gate()
+        if gate is None or gate is False:
+            return super().score_parts(value)          # built from self.log_prob: masked already
+        return self.base_dist.score_parts(value).scale_and_mask(mask=gate)
 
     def conjugate_update(self, other):
         updated, log_normalizer = self.base_dist.conjugate_update(other)
         return updated.mask(self._mask), scale_and_mask(log_normalizer, mask=self._mask)
 
+    # ---- the fused protocol: the gate goes to the kernel with the handler's mask ---------------------
+    def _fused(self, method, value, scale, mask):
+        f = getattr(self.base_dist, method, None)
+        gate = self._gate(mask)
+        if f is None or (gate is not None and gate is not False and self.event_dim != 0):
+            return None        # a tensor mask over event dims is not a per-element kernel mask
+        return f, gate
+
     def fused_log_prob_sum(self, value, scale=1.0, mask=None):
-        if isinstance(self._mask, bool):
-            if self._mask is False:
-                return torch.zeros((), device=value.device, dtype=value.dtype)
-            return self.base_dist.fused_log_prob_sum(value, scale, mask)
-        if self.event_dim != 0:
-            return None
-        m = self._mask if mask is None else (self._mask & mask)
-        return self.base_dist.fused_log_prob_sum(value, scale, m)
+        if self._mask is False:
+            return value.new_zeros(())
+        hit = self._fused("fused_log_prob_sum", value, scale, mask)
+        return None if hit is None else hit[0](value, scale, hit[1])
 
     def fused_site_entry(self, value, scale=1.0, mask=None):
-        f = getattr(self.base_dist, "fused_site_entry", None)
-        if f is None or self._mask is False:
+        if self._mask is False:
             return None
-        if self._mask is True:
-            return f(value, scale, mask)
-        if self.event_dim != 0:
-            return None
-        return f(value, scale, self._mask if mask is None else (self._mask & mask))
+        hit = self._fused("fused_site_entry", value, scale, mask)
+        return None if hit is None else hit[0](value, scale, hit[1])
 
 
 class Delta(TorchDistribution):

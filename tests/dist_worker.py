@@ -135,8 +135,8 @@ def bench_worker(rank, world, port, out_path, steps):
     ob.install(_MP())
     import bench
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", str(steps), "--warmup", "1",
-                "--plate", "512", "--features", "8", "--particles", "4", "--config5-sharded",
-                "--config5-rows", "600", "--config5-groups", "5"]
+                "--plate", "512", "--features", "8", "--particles", "4",
+                "--config5-rows", "600", "--config5-groups", "5"]     # (--config5-sharded: on by default at N > 1)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main()

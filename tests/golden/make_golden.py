@@ -1419,8 +1419,16 @@ def g_gamma_grad():
     torch.manual_seed(3)
     v = dist.Gamma(c, r).rsample()
     (v * torch.tensor([1.0, 2.0, 3.0])).sum().backward()
+    # large concentrations (a learned guide concentration): values within a +- 3 sqrt(a), where the
+    # series / continued fraction need ~ sqrt(a) terms (round-3 ADVICE: a fixed budget truncated them)
+    conc_l = np.array([1e4, 3e4, 1e5, 1e6, 1e7, 3e8])
+    zs = np.array([-3.0, -2.0, -1.0, -0.3, 0.0, 0.3, 1.0, 2.0, 3.0])
+    a_l = np.broadcast_to(conc_l[:, None], (conc_l.size, zs.size)).copy()
+    x_l = a_l + zs[None, :] * np.sqrt(a_l)
+    g_l = torch._standard_gamma_grad(torch.tensor(a_l), torch.tensor(x_l)).numpy()
     save("gamma_grad", conc=a, value=x, grad=g, site_conc=c.detach().numpy(), site_rate=r.detach().numpy(),
-         site_value=v.detach().numpy(), site_dconc=c.grad.numpy(), site_drate=r.grad.numpy())
+         site_value=v.detach().numpy(), site_dconc=c.grad.numpy(), site_drate=r.grad.numpy(),
+         conc_large=a_l, value_large=x_l, grad_large=g_l)
 
 
 if __name__ == "__main__":

@@ -110,3 +110,52 @@ def test_bench_torchrun_path_prints_one_line_with_two_ranks(tmp_path):
     sh = rec["other_configs"]["config5_plate_sharded"]
     assert sh["ranks"] == 2 and sh["rows_total"] == 600 and sh["steps_per_s"] > 0
 
+
+
+def test_captured_collective_falls_back_to_the_split_form(monkeypatch):
+    """SVI._capture with several ranks: the step is first captured as ONE graph holding the gradient
+    all-reduce; when that capture fails the split form (graph 1 -> eager collective -> graph 2) is
+    captured instead, with a warning, and the captured-step mode stays on.  The capture itself needs a
+    GPU; its CONTROL FLOW does not (the one-graph form has never met a second rank on hardware, so the
+    fall-back is what a first multi-GPU run may take)."""
+    import warnings
+
+    import pyro_amd as pyro
+    from pyro_amd.infer import SVI, Trace_ELBO
+
+    class _TwoRankOptim:                 # what RcclOptimizer looks like to SVI at world size 2
+        multi_rank = True
+        zeroes_grads = True
+
+        def reduce_gradients(self, params):
+            pass
+
+        def __call__(self, params, *a, **k):
+            pass
+
+    svi = SVI(lambda: None, lambda: None, _TwoRankOptim(), Trace_ELBO(), hip_graph=True)
+    forms = []
+
+    def fake_capture_once(key, args, kwargs, rec, force_split=None, quiet=False):
+        forms.append((force_split, quiet))
+        if force_split is False:         # the one-graph form fails (as a capture error would)
+            svi.hip_graph = False
+            return None
+        return "split-entry"
+
+    monkeypatch.setattr(svi, "_capture_once", fake_capture_once)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        entry = svi._capture(("k",), (), {})
+    assert entry == "split-entry" and forms == [(False, True), (True, False)]
+    assert svi.hip_graph is True and any("two graphs" in str(x.message) for x in w)
+    # PYRO_AMD_GRAPH_COLLECTIVE=0 goes straight to the default (split) form
+    forms.clear()
+    monkeypatch.setenv("PYRO_AMD_GRAPH_COLLECTIVE", "0")
+    assert svi._capture(("k",), (), {}) == "split-entry" and forms == [(None, False)]
+    # the one-graph form succeeding is taken as is
+    monkeypatch.delenv("PYRO_AMD_GRAPH_COLLECTIVE")
+    forms.clear()
+    monkeypatch.setattr(svi, "_capture_once", lambda *a, force_split=None, quiet=False: "one-graph")
+    assert svi._capture(("k",), (), {}) == "one-graph"
+    pyro.clear_param_store()

@@ -94,6 +94,12 @@ def test_gamma_rsample_kernel_equals_the_oracle(gpu, dtype):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gamma_grad.npz"))
     got = k.gamma_implicit_grad(torch.as_tensor(g["conc"], device=gpu), torch.as_tensor(g["value"], device=gpu))
     np.testing.assert_allclose(got.cpu().numpy(), g["grad"], rtol=2e-3)
+    # large concentrations (1e4 .. 3e8, values within a +- 3 sqrt(a)): the iteration budget grows with
+    # sqrt(a); against torch's function and, statement for statement, against the oracle
+    al, xl = g["conc_large"], g["value_large"]
+    got = k.gamma_implicit_grad(torch.as_tensor(al, device=gpu), torch.as_tensor(xl, device=gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, g["grad_large"], rtol=2e-5)
+    np.testing.assert_allclose(got, o_gamma.implicit_grad(al, xl), rtol=1e-9)
 
 
 def test_gamma_beta_dirichlet_rsample_distribution_and_pathwise_gradients(gpu):

@@ -1006,6 +1006,34 @@ def test_lda_factor_indexed_full_size_properties(gpu):
     assert torch.equal(gp, k.lda_factor_fwd_bwd(words, lt, lp, index=index)[2])
 
 
+def test_lda_factor_indexed_full_size_against_the_oracle(gpu):
+    """BASELINE config 4 at ITS size (1e5 documents x 64 words, T = 8, V = 1024): the
+    inverted index bit for bit against oracle/lda.py::lda_word_index at 6.4 M pairs (int32 ranks, the
+    task cut of frequent words), and pa_lda_factor_indexed_fwd_bwd against oracle/lda.py::lda_factor
+    (float64 numpy, the reference's max-shift / exp / sum / log chain) at f32 1e-4 -- a Zipf-like
+    corpus, so that word lists span many tasks and the last documents sit in ragged tiles."""
+    k = _k()
+    Wd, B, T, V = 64, 100_000, 8, 1024
+    rng = np.random.default_rng(4)
+    words = _lda_words(rng, Wd, B, V, True)
+    lt = np.log(rng.dirichlet(np.ones(T) * 0.5, size=B)).astype(np.float32)
+    lp = np.log(rng.dirichlet(np.ones(V) * 0.1, size=T) + 1e-30).astype(np.float32)
+    tw, tlt, tlp = tt(words, gpu), tt(lt, gpu), tt(lp, gpu)
+    img = k.lda_build_index(tw, V).cpu().numpy()
+    off, first_task, task_v, task_start, task_len, docs = o_lda.lda_word_index(words, V)
+    n, nt = Wd * B, len(task_v)
+    cap = n // o_lda.LDA_SEG + V + 1
+    assert tuple(img[1:7]) == (Wd, B, V, nt, cap, n)
+    p = 8 + 2 * (V + 1)
+    assert np.array_equal(img[8:8 + V + 1], off) and np.array_equal(img[p:p + nt], task_v)
+    assert np.array_equal(img[p + 3 * cap:p + 3 * cap + n], docs)                     # bit-exact
+    out, gt, gp = k.lda_factor_fwd_bwd(tw, tlt, tlp, index=k.lda_build_index(tw, V))
+    r_out, r_gt, r_gp = o_lda.lda_factor(words, lt, lp)
+    np.testing.assert_allclose(out.cpu().numpy(), r_out, rtol=1e-4)
+    np.testing.assert_allclose(gt.cpu().numpy(), r_gt, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gp.cpu().numpy(), r_gp, rtol=1e-4, atol=1e-4 * float(np.sqrt(r_gp.max())))
+
+
 def test_lda_factor_minus_inf_column(gpu):
     k = _k()
     lt = torch.log(torch.tensor([[1.0, 0.0], [0.5, 0.5]], device=gpu, dtype=torch.float64))

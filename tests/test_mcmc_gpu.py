@@ -82,6 +82,34 @@ def test_nuts_gaussian_config3_statistics(gpu):
     assert sum(len(v) for v in diag["divergences"].values()) == 0
 
 
+def test_nuts_gaussian_config3_at_the_baseline_size(gpu):
+    """BASELINE config 3 as SURVEY 8(d) states it: 100-dim correlated Gaussian, 1024 vectorised chains,
+    200 warm-up + 200 samples, step size and diagonal mass adapted per chain, max_tree_depth = 10 --
+    and ITS acceptance thresholds: |mean| / sigma < 4 / sqrt(ESS) per dimension, variances within
+    10 %, split R-hat < 1.01 across the 1024 chains (pyro/infer/mcmc/util.py:507-528 diagnostics)."""
+    from pyro_amd import examples
+    D, C = 100, 1024
+    Sigma, Lam = examples.correlated_gaussian_precision(D, dtype=torch.float64)
+    Sigma = Sigma.numpy()
+    pyro.set_rng_seed(0)
+    kernel = NUTS(potential_fn=GaussianPotential(Lam.float().to(gpu)), max_tree_depth=10,
+                  target_accept_prob=0.8)
+    mcmc = MCMC(kernel, num_samples=200, warmup_steps=200, num_chains=C,
+                initial_params={"x": torch.zeros((C, D), device=gpu)})
+    mcmc.run()
+    x = mcmc.get_samples(group_by_chain=True)["x"].double()        # [C, S, D]
+    assert tuple(x.shape) == (C, 200, D)
+    sd = np.sqrt(np.diag(Sigma))
+    mean = x.mean((0, 1)).cpu().numpy()
+    var = x.reshape(-1, D).var(0).cpu().numpy()
+    diag = mcmc.diagnostics()
+    n_eff = np.minimum(diag["x"]["n_eff"].cpu().numpy(), C * 200.0)      # (antithetic chains report more)
+    assert np.all(np.abs(mean) / sd < 4.0 / np.sqrt(n_eff)), (np.abs(mean) / sd * np.sqrt(n_eff)).max()
+    np.testing.assert_allclose(var, np.diag(Sigma), rtol=0.1)
+    assert float(diag["x"]["r_hat"].max()) < 1.01
+    assert sum(len(v) for v in diag["divergences"].values()) == 0
+
+
 @pytest.mark.parametrize("fused_glm", [True, False])
 def test_nuts_logistic_regression(gpu, fused_glm):
     """tests/infer/mcmc/test_nuts.py:150-171 (logistic regression, rmse(coefs) < 0.1) with

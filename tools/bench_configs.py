@@ -16,13 +16,24 @@ def _committed_traffic(cfg, kernel):
     """HBM bytes per launch of ``kernel`` from the committed PMC passes (tools/pmc_cfg.sh ->
     profiles/r03_traffic_cfg<cfg>.json), or None: counters cannot be collected from inside the run."""
     import json
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                        "r03_traffic_cfg%s.json" % cfg)
+    path = _traffic_path(cfg)
     try:
         return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:  # noqa: BLE001
         return None
+
+
+def _traffic_path(cfg):
+    """The latest round's profiles/rNN_traffic_cfg<cfg>.json."""
+    import os
+    import re
+    pdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    best = None
+    for f in os.listdir(pdir):
+        m = re.fullmatch(r"r(\d+)_traffic_cfg%s\.json" % cfg, f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), os.path.join(pdir, f))
+    return best[1] if best else os.path.join(pdir, "r03_traffic_cfg%s.json" % cfg)
 
 
 def timed(fn, n, warm):
@@ -75,13 +86,22 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True, referen
                            "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9,
                            "peak": 8000.0, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
                            "traffic": _committed_traffic(5, "glm_planes_f16_kernel" if f16 else "glm_planes_kernel"),
-                           "traffic_source": "profiles/r03_traffic_cfg5.json (rocprofv3 --pmc, tools/pmc_cfg.sh)",
+                           "traffic_source": "profiles/%s (rocprofv3 --pmc, tools/pmc_cfg.sh)" % __import__("os").path.basename(_traffic_path(5)),
                            "share_of_step": k_ms / (dt * 1e3)}
     return out
 
 
+class _NoUpdate:
+    """An 'optimizer' that leaves the parameters alone: SVI.step is then loss_and_grads (+ the gradient
+    zeroing every step needs) -- SURVEY 8(d)'s "loss_and_grads only" figure, captured like the full step."""
+    zeroes_grads = False
+
+    def __call__(self, params, *args, **kwargs):
+        pass
+
+
 def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=True, model=None,
-                    lazy_matmul=True, elbo=Trace_ELBO):
+                    lazy_matmul=True, elbo=Trace_ELBO, planes_format=None, no_update=False):
     """BASELINE configs[1] with the other guide SURVEY 8(d) names (AutoMultivariateNormal), with
     the reference's default num_particles = 1 (few-particle GLM kernel), with the explicit
     dist.linear_logits model, or with the lazy recognition of w @ X.t() switched off (materialised
@@ -92,16 +112,21 @@ def config2_variant(dev, guide="mvn", P=64, N=1_000_000, D=32, steps=50, graph=T
     model = examples.logreg_model if model is None else model
     g = AutoMultivariateNormal(model, init_scale=0.1) if guide == "mvn" else \
         AutoNormal(model, init_scale=0.1)
-    svi = SVI(model, g, pyro.optim.Adam({"lr": 0.01}),
+    svi = SVI(model, g, _NoUpdate() if no_update else pyro.optim.Adam({"lr": 0.01}),
               elbo(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
               hip_graph=graph, graph_warmup=2)
     prev = lazy.ENABLED["on"]
     lazy.ENABLED["on"] = bool(lazy_matmul)
+    prev_fmt = kernels.glm_planes_format()
+    if planes_format is not None:
+        kernels.glm_set_planes_format(planes_format)
     try:
         dt = timed(lambda: svi.step(X, y), steps, 8)
     finally:
         lazy.ENABLED["on"] = prev
-    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "num_particles": P,
+        if planes_format is not None:
+            kernels.glm_set_planes_format(prev_fmt)
+    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "num_particles": P, "D": D,
             "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1),
             "algorithmic_TBps": N * (4 * D + 4) / dt / 1e12}
 
@@ -232,7 +257,7 @@ def _config4_roofline(data, args, predictor, dt):
             "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
             "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
             "traffic": _committed_traffic(4, "bow_linear_fwd_kernel"),
-            "traffic_source": "profiles/r03_traffic_cfg4.json (rocprofv3 --pmc, tools/pmc_cfg.sh)",
+            "traffic_source": "profiles/%s (rocprofv3 --pmc, tools/pmc_cfg.sh)" % __import__("os").path.basename(_traffic_path(4)),
             "share_of_step": k_ms / (dt * 1e3)}
 
 
