@@ -52,7 +52,10 @@ at::Tensor glm_pack_planes(const at::Tensor& X, int64_t format) {
   return out;
 }
 
-std::tuple<at::Tensor, at::Tensor, at::Tensor> glm_bernoulli_planes(
+// (ll, gw, gb, ws): the workspace is an OUTPUT so that the caller can keep it alive -- inside a chained
+// tail (pa_chain_begin) the launcher only RECORDS the finalize phase, which reads the partial records
+// in ws when the chain is flushed, after this function has returned
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> glm_bernoulli_planes(
     const at::Tensor& planes, const at::Tensor& y, const at::Tensor& w,
     const std::optional<at::Tensor>& b, double scale, int64_t N, int64_t D, int64_t format) {
   require_f32_gpu(y, "y");
@@ -75,10 +78,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> glm_bernoulli_planes(
                                         ll.data_ptr<float>(), gw.data_ptr<float>(), gb.data_ptr<float>(),
                                         ws.data_ptr(), ws_bytes, current_stream()),
         "glm_bernoulli_planes");
-  return {ll, gw, gb};
+  return {ll, gw, gb, ws};
 }
 
-std::tuple<at::Tensor, at::Tensor, at::Tensor> glm_bernoulli(
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> glm_bernoulli(
     const at::Tensor& X, const at::Tensor& y, const at::Tensor& w, const std::optional<at::Tensor>& b,
     const std::optional<at::Tensor>& mask, double scale) {
   require_f32_gpu(X, "X");
@@ -104,7 +107,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> glm_bernoulli(
                                  m, scale, N, D, P, ll.data_ptr<float>(), gw.data_ptr<float>(),
                                  gb.data_ptr<float>(), ws.data_ptr(), ws_bytes, current_stream()),
         "glm_bernoulli");
-  return {ll, gw, gb};
+  return {ll, gw, gb, ws};
 }
 
 // (g[P] * gw[P, W], g[P] * gb[P]): the backward of the site
@@ -122,14 +125,39 @@ std::tuple<at::Tensor, at::Tensor> glm_chain(const at::Tensor& g, const at::Tens
   return {dw, db};
 }
 
+// pa_adam_step over the flat parameter buffer (pyro/optim/optim.py:117-155 + clipped_adam.py:52-100 +
+// pyro/infer/util.py:85-91 zero_grads in one launch); every tensor argument is updated in place
+void adam_step(at::Tensor param, at::Tensor grad, at::Tensor exp_avg, at::Tensor exp_avg_sq, at::Tensor step,
+               double lr, double beta1, double beta2, double eps, double weight_decay, double clip_norm,
+               double lrd, bool clipped, bool zero_grad) {
+  TORCH_CHECK(param.is_cuda() && param.is_contiguous() && grad.is_contiguous() && exp_avg.is_contiguous() &&
+                  exp_avg_sq.is_contiguous(), "pyro_amd::adam_step: contiguous GPU buffers");
+  TORCH_CHECK(param.scalar_type() == at::kFloat || param.scalar_type() == at::kDouble,
+              "pyro_amd::adam_step: float32 / float64");
+  TORCH_CHECK(grad.scalar_type() == param.scalar_type() && exp_avg.scalar_type() == param.scalar_type() &&
+                  exp_avg_sq.scalar_type() == param.scalar_type() && grad.numel() == param.numel() &&
+                  exp_avg.numel() == param.numel() && exp_avg_sq.numel() == param.numel(),
+              "pyro_amd::adam_step: param / grad / moments of one dtype and size");
+  TORCH_CHECK(step.is_cuda() && step.scalar_type() == at::kLong && step.numel() == 2,
+              "pyro_amd::adam_step: step = int64[2] {step counter, ticket}");
+  check(pa_adam_step(param.scalar_type() == at::kFloat ? PA_F32 : PA_F64, param.data_ptr(), grad.data_ptr(),
+                     exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), lr, beta1, beta2, eps,
+                     weight_decay, clip_norm, lrd, clipped ? 1 : 0, step.data_ptr<int64_t>(), zero_grad ? 1 : 0,
+                     current_stream()),
+        "adam_step");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(pyro_amd, m) {
   m.def("glm_pack_planes(Tensor X, int format) -> Tensor");
   m.def("glm_bernoulli_planes(Tensor planes, Tensor y, Tensor w, Tensor? b, float scale, int N, int D, "
-        "int format) -> (Tensor, Tensor, Tensor)");
+        "int format) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("glm_bernoulli(Tensor X, Tensor y, Tensor w, Tensor? b, Tensor? mask, float scale) -> "
-        "(Tensor, Tensor, Tensor)");
+        "(Tensor, Tensor, Tensor, Tensor)");
+  m.def("adam_step(Tensor(a!) param, Tensor(b!) grad, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, "
+        "Tensor(e!) step, float lr, float beta1, float beta2, float eps, float weight_decay, float clip_norm, "
+        "float lrd, bool clipped, bool zero_grad) -> ()");
   m.def("glm_chain(Tensor g, Tensor gw, Tensor gb) -> (Tensor, Tensor)");
 }
 
@@ -139,4 +167,5 @@ TORCH_LIBRARY_IMPL(pyro_amd, CUDA, m) {
   m.impl("glm_bernoulli_planes", &glm_bernoulli_planes);
   m.impl("glm_bernoulli", &glm_bernoulli);
   m.impl("glm_chain", &glm_chain);
+  m.impl("adam_step", &adam_step);
 }

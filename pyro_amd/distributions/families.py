@@ -539,6 +539,9 @@ class _BernoulliLinear(TorchDistribution):
         """(ll[lead shape], [(w, d ll.sum()/d w), (b, d ll.sum()/d b)]) from ONE pass over X, with
         no autograd node: fused.SiteBatch carries the two gradients in its own backward launch."""
         lz = self.lazy
+        from ..ops import torch_library
+        if torch_library._routing_now():
+            return None      # a tracer is recording: the site must be a graph node (fused_log_prob_batch)
         args = self._glm_args(value, scale, mask)
         if args is None or not isinstance(lz.w, torch.Tensor):
             return None

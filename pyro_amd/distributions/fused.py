@@ -8,6 +8,7 @@ passed as stride-0 views and never materialised.
 import torch
 
 from .. import kernels
+from ..ops.torch_library import dispatcher_op as _dispatcher_op
 
 
 def _collapse(t, shape):
@@ -225,6 +226,7 @@ def _differentiable_grads(dist_id, g, value, p0, p1, mask, scale, needs):
     return tuple(next(got) if need else None for need in needs)
 
 
+@_dispatcher_op("dist_log_prob")
 class _LogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dist_id, value, p0, p1):
@@ -251,6 +253,7 @@ class _LogProb(torch.autograd.Function):
         return (None,) + tuple(outs)
 
 
+@_dispatcher_op("dist_log_prob_sum")
 class _LogProbSum(torch.autograd.Function):
     """scalar = sum(scale_and_mask(log_prob(value), scale, mask))  -- one fused kernel."""
 
@@ -296,6 +299,7 @@ class _LogProbSum(torch.autograd.Function):
         return (None,) + tuple(outs) + (None, None)
 
 
+@_dispatcher_op("dirichlet_log_prob")
 class _DirichletLogProb(torch.autograd.Function):
     """Dirichlet.log_prob in one launch each way (pa_dirichlet_log_prob / _grad)."""
 
@@ -323,6 +327,7 @@ def dirichlet_log_prob(value, concentration):
     return _DirichletLogProb.apply(value, concentration)
 
 
+@_dispatcher_op("normal_rsample")
 class _NormalRsample(torch.autograd.Function):
     """value = loc + scale * eps with eps from the Philox stream, ONE launch (pa_normal_rsample);
     backward: d loc = g, d scale = g * eps (torch: normal.py:83-86)."""
@@ -344,6 +349,7 @@ class _NormalRsample(torch.autograd.Function):
         return d_loc, d_scale, None, None, None, None
 
 
+@_dispatcher_op("standard_gamma")
 class _StandardGamma(torch.autograd.Function):
     """g ~ Gamma(concentration, 1) of ``shape`` from the keyed Philox stream, ONE launch that also
     produces d g / d concentration (pa_gamma_rsample: Marsaglia-Tsang + the implicit
@@ -376,6 +382,7 @@ def standard_gamma(concentration, shape):
     return _StandardGamma.apply(concentration, shape, seed, off, off_dev)
 
 
+@_dispatcher_op("meanfield_normal_sample")
 class _MeanFieldSample(torch.autograd.Function):
     """All mean-field Normal sites of a guide: per site  scale = softplus(rho),
     z = loc + scale * eps  for P vectorised particles, ONE launch forward
@@ -473,6 +480,7 @@ def meanfield_sample(locs, rhos, P):
     return [tuple(out[3 * i:3 * i + 3]) for i in range(len(locs))]
 
 
+@_dispatcher_op("mvn_tril_sample")
 class _MvnTrilSample(torch.autograd.Function):
     """Full-covariance Normal guide draw: z [P, n] and log q(z) [P] from the unconstrained leaves
     (loc, rho, A) in ONE launch (pa_mvn_tril_sample), their gradients in ONE (.._bwd), added
@@ -594,6 +602,7 @@ def _entry_frame_uncached(dist_id, value, p0, p1, mask):
     return rows, cols, v2, a2, b2, m2
 
 
+@_dispatcher_op("multi_log_prob_sum")
 class _MultiLogProbSum(torch.autograd.Function):
     """total = coef_all * sum_e coef_e * sum(mask_e ? log_prob_e(value_e; p0_e, p1_e) : 0) over a
     table of small entries: ONE launch forward (pa_multi_log_prob_sum), ONE launch backward that
@@ -843,6 +852,7 @@ def log_prob_sum(dist_id, value, p0, p1=None, mask=None, scale=1.0):
     return _LogProbSum.apply(dist_id, value, p0, p1, mask, float(scale))
 
 
+@_dispatcher_op("glm_bernoulli_ll")
 class _GlmBernoulliSum(torch.autograd.Function):
     """sum_p scale * sum_n mask_n log Bernoulli(y_n | logits = w_p.x_n + b_p): forward and
     backward of the whole observed site from ONE pass over X (pa_glm_bernoulli_fwd_bwd)."""
@@ -874,6 +884,7 @@ def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
     return _GlmBernoulliSum.apply(X, y, w, b, mask, float(scale))
 
 
+@_dispatcher_op("glm_bernoulli_grouped_ll")
 class _GlmBernoulliGroupedSum(torch.autograd.Function):
     """Hierarchical GLM site: ll[P] and d ll / d (w[P,G,D], b[P]) from one pass over the
     group-sorted rows (pa_glm_bernoulli_grouped_fwd_bwd)."""

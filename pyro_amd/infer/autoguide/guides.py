@@ -15,6 +15,7 @@ from ... import distributions as dist
 from ... import poutine
 from ...distributions.util import sum_rightmost
 from ...primitives import param, plate, sample
+from ...ops.torch_library import dispatcher_op as _dispatcher_op
 from .initialization import InitMessenger, init_to_feasible, init_to_median
 
 
@@ -409,6 +410,7 @@ class _FusedGuideMVN(dist.TorchDistribution):
         return self._build().variance
 
 
+@_dispatcher_op("split_latent")
 class _SplitLatent(torch.autograd.Function):
     """latent[..., sum(sizes)] -> one CONTIGUOUS tensor per site; the backward is one concatenation
     (slicing views would cost a zero-fill + strided copy per site and an add per extra site in

@@ -204,3 +204,49 @@ class Trace_ELBO(ELBO):
             if trainable and sl is not None and sl.requires_grad:
                 sl.backward(_unit_grad(sl), retain_graph=self.retain_graph)
         return 0.0 if loss is None else loss
+
+
+class JitTrace_ELBO(Trace_ELBO):
+    """Trace_ELBO whose ``differentiable_loss`` is recorded once with ``torch.jit.trace`` and replayed
+    (reference: pyro/infer/trace_elbo.py:162-257, on pyro/ops/jit.py).  The recorded graph consists of
+    ``pyro_amd::*`` dispatcher ops (ops/torch_library.py: guide draw, ELBO assembly, the fused GLM site,
+    ...) and ATen glue; gradients of a replay come from the ops' registered autograd formulas.
+
+    Same limits as the reference: static model structure, tensor inputs as positional arguments,
+    everything else as keyword arguments (one trace per distinct set).  ``SVI(hip_graph=True)`` is the
+    faster way to run a fixed step on this backend (one hipGraph replay, no operator dispatch at all);
+    this class is the drop-in for code written against the reference's JIT estimators."""
+
+    def _traced(self, model, guide):
+        import weakref
+
+        from ..ops import jit
+        key = (id(model), id(guide))
+        cache = self.__dict__.setdefault("_jit_cache", {})
+        if key not in cache:
+            weakself = weakref.ref(self)
+
+            @jit.trace(ignore_warnings=self.ignore_jit_warnings, jit_options=self.jit_options)
+            def differentiable_loss(*args, **kwargs):
+                me = weakself()
+                return Trace_ELBO.differentiable_loss(me, model, guide, *args, **kwargs)
+
+            cache[key] = (differentiable_loss, model, guide)     # (the ids stay valid while cached)
+        return cache[key][0]
+
+    def differentiable_loss(self, model, guide, *args, **kwargs):
+        return self._traced(model, guide)(*args, **kwargs)
+
+    def loss(self, model, guide, *args, **kwargs):
+        with torch.no_grad():
+            return torch_item(self.differentiable_loss(model, guide, *args, **kwargs))
+
+    def loss_and_grads(self, model, guide, *args, **kwargs):
+        loss = self.differentiable_loss(model, guide, *args, **kwargs)
+        if isinstance(loss, torch.Tensor) and loss.requires_grad:
+            loss.backward(retain_graph=self.retain_graph)
+        loss = torch_item(loss)
+        warn_if_nan(loss, "loss")
+        return loss
+
+    loss_and_grads_device = None          # (a traced estimator is not captured into a hipGraph as well)

@@ -22,6 +22,7 @@ from collections import OrderedDict
 import torch
 
 from .. import kernels
+from .torch_library import dispatcher_op as _dispatcher_op
 
 
 FUSED_CHAIN = True            # HMM-shaped components go through pa_logchain_fwd_bwd
@@ -96,6 +97,7 @@ class LazyGather:
         return self.table[:, self.index]                   # [T, W, D]: packed, two plates
 
 
+@_dispatcher_op("lda_factor")
 class _LdaFactor(torch.autograd.Function):
     """sum_{d,w} logsumexp_t(log_theta[d,t] + log_phi[t, words[w,d]]) and its gradient from ONE
     pass over the int64 word ids (pa_lda_factor_fwd_bwd)."""
@@ -112,6 +114,7 @@ class _LdaFactor(torch.autograd.Function):
         return None, g * g_theta, g * g_phi
 
 
+@_dispatcher_op("logchain")
 class _LogChain(torch.autograd.Function):
     """log Z of a chain of enumerated variables for every batch element (forward algorithm) with
     the forward-backward posteriors as gradient, ONE launch (pa_logchain_fwd_bwd)."""
@@ -211,6 +214,7 @@ def _try_fused_chain(terms, sum_ids):
 FUSED_SUMPRODUCT = True       # eliminations go through pa_logsumexp_terms (one pass, no frame tensor)
 
 
+@_dispatcher_op("logsumexp_terms")
 class _LogSumExpTerms(torch.autograd.Function):
     """logsumexp over one dim of the sum of up to four broadcast log-factors: ONE forward launch
     reading every factor through its own strides (pa_logsumexp_terms), ONE backward launch writing

@@ -19,6 +19,8 @@ as written, on the unfused route.  Every other operation on a latent returns pla
 """
 import torch
 
+
+from .torch_library import dispatcher_op as _dispatcher_op
 _MATMUL_NAMES = ("matmul", "__matmul__")
 MIN_ROWS = 256              # below this the unfused route is as fast and nothing is deferred
 ENABLED = {"on": True}
@@ -482,6 +484,7 @@ class TallActivation(torch.Tensor):
         return out
 
 
+@_dispatcher_op("tall_linear")
 class _TallLinear(torch.autograd.Function):
     """F.linear over a tall batch on the kernels of csrc/tall.hip: forward and dx are pa_tall_linear
     with the weight addressed through strides (no transposed copy), dW and db come from ONE pass
@@ -512,6 +515,7 @@ class _TallLinear(torch.autograd.Function):
         return dx, dW, db
 
 
+@_dispatcher_op("bow_linear")
 class _BowLinear(torch.autograd.Function):
     """h = bias + counts @ W.T over the corpus's histogram images; d W = d_h.T @ counts, d bias =
     sum d_h; the histogram itself carries no gradient."""

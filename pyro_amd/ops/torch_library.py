@@ -1,16 +1,31 @@
-"""The fused GLM site as torch dispatcher ops (``torch.ops.pyro_amd.*``).
+"""The kernels as torch dispatcher ops (``torch.ops.pyro_amd.*``).
 
-``csrc/torch_ops.cpp`` registers the schemas and the GPU implementations with ``TORCH_LIBRARY`` over
-the same extern-"C" launchers the ctypes binding calls; this module loads that library and adds what
-is Python-side by nature: the shape functions (``register_fake``: torch.compile / meta tensors) and
-the autograd formula (``register_autograd``): the backward of ``glm_bernoulli[_planes]`` is ONE more
-op, ``pyro_amd::glm_chain``.  With the ops in the dispatcher ``torch.jit.trace`` of a loss function
-records the site as a graph node (pyro/ops/jit.py:104-109 traces the reference's loss the same way;
-its graph is made of ATen nodes) and replays it on new parameter values.
+SURVEY 8(b) asks that the backend's numerics appear to torch as custom ops so that they survive
+``torch.jit.trace`` (what the reference's ``JitTrace_ELBO`` is built on, pyro/ops/jit.py:104-109,
+pyro/infer/trace_elbo.py:162-257) and ``torch.compile``: a ctypes launch is invisible to a tracer, the
+tensors it fills would be frozen into the graph as constants.  Two layers:
 
-Only this site is registered: the other kernels (guide sampling, the multi-site ELBO assembly, the
-optimizer) stay ctypes launches, which a tracer does not see -- a whole ``differentiable_loss`` is
-therefore NOT traceable into a reusable graph yet and no JitTrace_ELBO is offered.
+* ``csrc/torch_ops.cpp`` (``TORCH_LIBRARY``, C++ over the extern-"C" launchers): the observed GLM site
+  ``glm_bernoulli[_planes]`` + its backward ``glm_chain``, ``glm_pack_planes``, and the flat optimizer
+  update ``adam_step``.  This module adds their shape functions (``register_fake``) and autograd
+  formulas (``register_autograd``).
+
+* every other kernel-backed operation of a step is a ``torch.autograd.Function`` of this package
+  (``distributions/fused.py``, ``ops/contract.py``, ``ops/lazy.py``: the mean-field guide draw, the
+  multi-site ELBO assembly, the single-site sums, the Dirichlet / Gamma / Normal draws, the
+  AutoMultivariateNormal draw, the LDA factor, the log-sum-exp elimination step, the chain kernel,
+  the bag-of-words and tall-batch layers).  ``dispatcher_op(name)`` registers each of them as a pair of
+  NAMED dispatcher ops, ``pyro_amd::<name>`` and ``pyro_amd::<name>_bwd``, with the schema
+  ``(Tensor[] tensors, int spec) -> Tensor[]``, a shape function and an autograd formula that
+  connects the two.  ``tensors`` are ALL tensor arguments of the call (whatever their nesting);
+  ``spec`` names the call's non-tensor arguments -- distribution ids, broadcast frames, Philox offsets,
+  scales -- in a table of this process (the reference's traced functions are not serialisable either:
+  they close over the model).  The op bodies run the Function's own ``forward`` / ``backward``, i.e.
+  the very launches the eager path makes, so a traced graph and the eager step cannot drift apart.
+
+Routing: ``Function.apply`` goes through the dispatcher op while a tracer is recording (or inside
+``routing()``); the un-traced hot path keeps calling the launchers directly (its chained tail and
+gradient sinks are wired to them).
 """
 import os
 
@@ -42,24 +57,30 @@ def _register():
         n = _lib.load().pa_glm_planes_bytes(int(format), X.shape[0], X.shape[1])
         return X.new_empty((max(n, 16),), dtype=torch.uint8)
 
-    def _three(w):
+    def _four(w, nbytes):
         P = w.shape[0]
-        return w.new_empty((P,)), w.new_empty(tuple(w.shape)), w.new_empty((P,))
+        return (w.new_empty((P,)), w.new_empty(tuple(w.shape)), w.new_empty((P,)),
+                w.new_empty((max(int(nbytes), 1),), dtype=torch.uint8))
 
     @lib.register_fake("pyro_amd::glm_bernoulli_planes")
     def _(planes, y, w, b, scale, N, D, format):
-        return _three(w)
+        return _four(w, _lib.load().pa_glm_bernoulli_planes_workspace(int(N), int(D), w.shape[0]))
 
     @lib.register_fake("pyro_amd::glm_bernoulli")
     def _(X, y, w, b, mask, scale):
-        return _three(w)
+        return _four(w, _lib.load().pa_glm_bernoulli_workspace(X.shape[0], X.shape[1], w.shape[0]))
 
     @lib.register_fake("pyro_amd::glm_chain")
     def _(g, gw, gb):
         return torch.empty_like(gw), torch.empty_like(gb)
 
+    @lib.register_fake("pyro_amd::adam_step")
+    def _(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, clip_norm, lrd,
+          clipped, zero_grad):
+        return None
+
     def setup(ctx, inputs, output):
-        _, gw, gb = output
+        _, gw, gb, _ws = output
         ctx.save_for_backward(gw, gb)
         ctx.has_b = inputs[3] is not None            # (.., .., w, b, ...) in both schemas
 
@@ -69,12 +90,12 @@ def _register():
         return (dw if ctx.needs_input_grad[2] else None,
                 db if (ctx.has_b and ctx.needs_input_grad[3]) else None)
 
-    def backward_planes(ctx, g_ll, g_gw, g_gb):
+    def backward_planes(ctx, g_ll, g_gw, g_gb, g_ws):
         dw, db = _grads(ctx, g_ll)
         # (planes, y, w, b, scale, N, D, format)
         return None, None, dw, db, None, None, None, None
 
-    def backward_plain(ctx, g_ll, g_gw, g_gb):
+    def backward_plain(ctx, g_ll, g_gw, g_gb, g_ws):
         dw, db = _grads(ctx, g_ll)
         # (X, y, w, b, mask, scale)
         return None, None, dw, db, None, None
@@ -104,8 +125,292 @@ def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
     w = w.contiguous()
     b = b.contiguous() if b is not None else None
     if planes is not None:
-        return torch.ops.pyro_amd.glm_bernoulli_planes(planes, y, w, b, float(scale), N, D,
-                                                       kernels._format_of(planes))[0]
-    if mask is not None:
-        mask = mask.contiguous()
-    return torch.ops.pyro_amd.glm_bernoulli(X.contiguous(), y, w, b, mask, float(scale))[0]
+        out = torch.ops.pyro_amd.glm_bernoulli_planes(planes, y, w, b, float(scale), N, D,
+                                                      kernels._format_of(planes))
+    else:
+        if mask is not None:
+            mask = mask.contiguous()
+        out = torch.ops.pyro_amd.glm_bernoulli(X.contiguous(), y, w, b, mask, float(scale))
+    keep = kernels._CHAIN["keep"]
+    if keep is not None:
+        # inside a chained tail the launcher has only RECORDED the finalize phase: the partial records
+        # (the op's workspace) and the outputs it writes stay alive until the chain is flushed
+        keep.extend(out)
+    return out[0]
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8,
+              weight_decay=0.0, clip_norm=0.0, lrd=1.0, clipped=False, zero_grad=True):
+    """kernels.adam_step through the dispatcher op ``pyro_amd::adam_step`` (in-place on every tensor
+    argument): the optimizer update as a graph node of a traced / compiled step."""
+    if not available():
+        raise RuntimeError("pyro_amd: libpyro_amd_torch.so is not built (python -m pyro_amd.csrc.build)")
+    torch.ops.pyro_amd.adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, float(lr), float(betas[0]),
+                                 float(betas[1]), float(eps), float(weight_decay), float(clip_norm),
+                                 float(lrd), bool(clipped), bool(zero_grad))
+
+
+# ------------------------------------------------------------------------------------------------------
+# autograd Functions as named dispatcher ops
+# ------------------------------------------------------------------------------------------------------
+ROUTE = {"on": False}
+_SPECS = []             # process-local: the non-tensor side of every routed call signature
+_SPEC_INDEX = {}
+_OPS = {}               # op name -> Function class
+_frag = {"lib": None}
+
+
+class routing:
+    """Context manager: ``Function.apply`` of the registered Functions goes through the dispatcher ops
+    inside (a tracer switches this on by itself; the context is for tests and torch.compile)."""
+
+    def __enter__(self):
+        self._prev = ROUTE["on"]
+        ROUTE["on"] = True
+        return self
+
+    def __exit__(self, *exc):
+        ROUTE["on"] = self._prev
+        return False
+
+
+def _routing_now():
+    return ROUTE["on"] or torch._C._get_tracing_state() is not None
+
+
+class _Slot:
+    """Where a tensor argument sat in the call's (nested) argument structure."""
+    __slots__ = ("i",)
+
+    def __init__(self, i):
+        self.i = i
+
+
+def _flatten(obj, tensors):
+    if isinstance(obj, torch.Tensor):
+        tensors.append(obj)
+        return _Slot(len(tensors) - 1)
+    if isinstance(obj, tuple):
+        return tuple(_flatten(o, tensors) for o in obj)
+    if isinstance(obj, list):
+        return [_flatten(o, tensors) for o in obj]
+    if isinstance(obj, dict):
+        return {k: _flatten(v, tensors) for k, v in obj.items()}
+    return obj
+
+
+def _unflatten(obj, tensors):
+    if isinstance(obj, _Slot):
+        return tensors[obj.i]
+    if isinstance(obj, tuple):
+        return tuple(_unflatten(o, tensors) for o in obj)
+    if isinstance(obj, list):
+        return [_unflatten(o, tensors) for o in obj]
+    if isinstance(obj, dict):
+        return {k: _unflatten(v, tensors) for k, v in obj.items()}
+    return obj
+
+
+def _hashable(obj, tensors):
+    if isinstance(obj, _Slot):
+        t = tensors[obj.i]
+        return ("T", tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device), t.requires_grad)
+    if isinstance(obj, (tuple, list)):
+        return (type(obj).__name__,) + tuple(_hashable(o, tensors) for o in obj)
+    if isinstance(obj, dict):
+        return ("dict",) + tuple(sorted((k, _hashable(v, tensors)) for k, v in obj.items()))
+    try:
+        hash(obj)
+        return obj
+    except TypeError:
+        return ("id", id(obj))
+
+
+class _Ctx:
+    """What a Function's forward / backward expect of ``ctx``, without the autograd engine behind it."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+class _CallSpec:
+    def __init__(self, name, fn_cls, structure, top_slots, needs):
+        self.name, self.fn_cls, self.structure = name, fn_cls, structure
+        self.top_slots = top_slots      # per top-level argument: its tensor index or None
+        self.needs = needs              # needs_input_grad as the Function sees it (per argument)
+        self.n_out = None               # outputs of the Function (the op returns these + saved tensors)
+        self.single = False             # the Function returned one tensor, not a tuple
+        self.saved_from = None          # per saved tensor: ("in", j) | ("out", k)
+        self.out_meta = None            # (shape, dtype) per op output: the shape function
+        self.attrs = {}                 # what forward stored on ctx besides tensors
+        self.bwd_none = None            # per tensor input: backward gave no gradient
+        self.n_in = 0
+        self.n_ret = 0
+
+
+def _spec_of(name, fn_cls, args):
+    tensors = []
+    structure = _flatten(tuple(args), tensors)
+    try:
+        key = (name, _hashable(structure, tensors))
+        hash(key)
+    except TypeError:
+        key = None
+    sid = _SPEC_INDEX.get(key) if key is not None else None
+    if sid is None:
+        top = tuple(a.i if isinstance(a, _Slot) else None for a in structure)
+        needs = tuple(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
+        sp = _CallSpec(name, fn_cls, structure, top, needs)
+        sp.n_in = len(tensors)
+        _SPECS.append(sp)
+        sid = len(_SPECS) - 1
+        if key is not None:
+            _SPEC_INDEX[key] = sid
+    return sid, tensors
+
+
+def _fwd_impl(tensors, spec):
+    sp = _SPECS[spec]
+    args = _unflatten(sp.structure, list(tensors))
+    ctx = _Ctx(sp.needs)
+    with torch.no_grad():
+        out = sp.fn_cls.forward(ctx, *args)
+    single = isinstance(out, torch.Tensor)
+    outs = [out] if single else list(out)
+    saved = list(ctx.saved_tensors)
+    saved_from, extra = [], []
+    for s in saved:
+        if s is None:
+            saved_from.append(("none", 0))
+            continue
+        hit = next((j for j, t in enumerate(tensors) if t is s), None)
+        if hit is not None:
+            saved_from.append(("in", hit))          # an input: not returned (an op must not alias its inputs)
+            continue
+        hit = next((k for k, t in enumerate(outs) if t is s), None)
+        if hit is not None:
+            saved_from.append(("out", hit))
+        else:
+            saved_from.append(("out", len(outs) + len(extra)))
+            extra.append(s)
+    sp.n_out, sp.single, sp.saved_from = len(outs), single, saved_from
+    sp.attrs = {k: v for k, v in ctx.__dict__.items() if k not in ("needs_input_grad", "saved_tensors")}
+    ret = outs + extra
+    # an output that IS an input (or a view of one) would break the op contract: copy it
+    ins = {t.untyped_storage().data_ptr() for t in tensors if t.numel() > 0}
+    ret = [r.clone() if (r.numel() > 0 and r.untyped_storage().data_ptr() in ins) else r for r in ret]
+    sp.out_meta = [(tuple(r.shape), r.dtype) for r in ret]
+    sp.n_ret = len(ret)
+    return ret
+
+
+def _fwd_fake(tensors, spec):
+    sp = _SPECS[spec]
+    if sp.out_meta is None:
+        raise RuntimeError("pyro_amd::%s: shapes are known once the call has run for real (trace / "
+                           "compile after one eager step)" % sp.name)
+    proto = tensors[0]
+    return [proto.new_empty(shape, dtype=dtype) for shape, dtype in sp.out_meta]
+
+
+def _bwd_impl(tensors, spec):
+    sp = _SPECS[spec]
+    grads, saved = list(tensors[:sp.n_out]), list(tensors[sp.n_out:])
+    ctx = _Ctx(sp.needs)
+    ctx.__dict__.update(sp.attrs)
+    ctx.saved_tensors = tuple(saved)
+    with torch.no_grad():
+        res = sp.fn_cls.backward(ctx, *grads)
+    if isinstance(res, torch.Tensor) or res is None:
+        res = (res,)
+    out, none = [None] * sp.n_in, [True] * sp.n_in
+    for pos, j in enumerate(sp.top_slots):
+        if j is not None and pos < len(res) and res[pos] is not None:
+            out[j], none[j] = res[pos], False
+    sp.bwd_none = none
+    proto = tensors[0]
+    return [proto.new_empty((0,)) if o is None else o for o in out]
+
+
+def _bwd_fake(tensors, spec):
+    sp = _SPECS[spec]
+    proto = tensors[0]
+    return [proto.new_empty((0,)) for _ in range(sp.n_in)]
+
+
+def _setup_context(ctx, inputs, output):
+    tensors, spec = inputs
+    sp = _SPECS[spec]
+    saved = []
+    for kind, j in sp.saved_from:
+        saved.append(None if kind == "none" else (tensors[j] if kind == "in" else output[j]))
+    ctx.spec = spec
+    ctx.none_saved = [s is None for s in saved]
+    ctx.save_for_backward(*[s for s in saved if s is not None])
+    ctx.protos = [(o.shape, o.dtype, o.device) for o in output[:sp.n_out]]
+
+
+def _make_backward(name):
+    def backward(ctx, grads):
+        sp = _SPECS[ctx.spec]
+        gs = []
+        for g, (shape, dtype, device) in zip(grads[:sp.n_out], ctx.protos):
+            gs.append(torch.zeros(shape, dtype=dtype, device=device) if g is None else g)
+        it = iter(ctx.saved_tensors)
+        # (a saved None cannot travel in a Tensor[]: an empty tensor stands for it)
+        saved = [gs[0].new_empty((0,)) if is_none else next(it) for is_none in ctx.none_saved]
+        res = getattr(torch.ops.pyro_amd, name + "_bwd")(gs + saved, ctx.spec)
+        return [None if sp.bwd_none[j] else res[j] for j in range(sp.n_in)], None
+    return backward
+
+
+def dispatcher_op(name):
+    """Class decorator for a ``torch.autograd.Function``: registers ``pyro_amd::<name>`` and
+    ``pyro_amd::<name>_bwd`` (see the module docstring) and makes ``apply`` go through them while a
+    tracer is recording."""
+    def deco(fn_cls):
+        if _frag["lib"] is None:
+            _frag["lib"] = torch.library.Library("pyro_amd", "FRAGMENT")
+        lib = _frag["lib"]
+        lib.define("%s(Tensor[] tensors, int spec) -> Tensor[]" % name)
+        lib.define("%s_bwd(Tensor[] tensors, int spec) -> Tensor[]" % name)
+        lib.impl(name, _fwd_impl, "CompositeExplicitAutograd")
+        lib.impl(name + "_bwd", _bwd_impl, "CompositeExplicitAutograd")
+        torch.library.register_fake("pyro_amd::" + name, _fwd_fake, lib=lib)
+        torch.library.register_fake("pyro_amd::" + name + "_bwd", _bwd_fake, lib=lib)
+        torch.library.register_autograd("pyro_amd::" + name, _make_backward(name),
+                                        setup_context=_setup_context, lib=lib)
+        _OPS[name] = fn_cls
+        eager_apply = fn_cls.apply
+
+        def apply(*args):
+            if not _routing_now() or not any(isinstance(a, torch.Tensor) for a in args):
+                return eager_apply(*args)
+            sid, tensors = _spec_of(name, fn_cls, args)
+            out = getattr(torch.ops.pyro_amd, name)(tensors, sid)
+            sp = _SPECS[sid]
+            return out[0] if sp.single else tuple(out[:sp.n_out])
+
+        fn_cls.apply = staticmethod(apply)
+        fn_cls.op_name = "pyro_amd::" + name
+        return fn_cls
+    return deco
+
+
+def registered_ops():
+    """Names of the dispatcher ops of this module (C++ ones once the shim is loaded)."""
+    names = ["pyro_amd::" + n for n in _OPS] + ["pyro_amd::" + n + "_bwd" for n in _OPS]
+    if available():
+        names += ["pyro_amd::" + n for n in ("glm_pack_planes", "glm_bernoulli_planes", "glm_bernoulli",
+                                             "glm_chain", "adam_step")]
+    return sorted(names)

@@ -543,3 +543,61 @@ def run_tracegraph_baselines(g, device, rtol):
             if key in g.files:
                 avg = pyro.get_param_store()["__baseline_avg_downstream_cost_z"].detach().cpu().numpy()
                 np.testing.assert_allclose(avg, g[key], rtol=rtol * 10)
+
+
+# ---- JitTrace_ELBO (pyro/infer/trace_elbo.py:162-257 over pyro/ops/jit.py:48-163) -----------------
+def run_logreg_jit(g, device, monkeypatch, fused, dtype, rtol, expect_ops=()):
+    """Trace ``differentiable_loss`` of the config-2 model at the golden file's FIRST parameter set with
+    its SECOND noise, then move the parameters to the second set and replay the recorded graph: loss
+    and gradients must be the reference's second evaluation (params2, eps2) -- a traced graph that had
+    frozen a kernel's output as a constant would reproduce the first parameter set's numbers."""
+    from pyro_amd import rng
+    from pyro_amd.distributions import families
+    from pyro_amd.infer import JitTrace_ELBO
+    if fused and dtype == torch.float64:
+        monkeypatch.setattr(families._BernoulliLinear, "_allow_f64", True, raising=False)
+    X = torch.as_tensor(g["X"], dtype=dtype, device=device)
+    y = torch.as_tensor(g["y"], dtype=dtype, device=device)
+    P = int(g["P"])
+    model = logreg_model_fused if fused else logreg_model
+    pyro.clear_param_store()
+    guide = AutoNormal(model, init_scale=0.1)
+    guide._setup_prototype(X, y)
+    eps2 = _eps_of(g, "eps2")
+    # the first call runs the function once eagerly (parameter discovery) and once under the tracer
+    monkeypatch.setattr(rng, "normal", EpsReplay(eps2 + eps2, device, lenient=True))
+    elbo = JitTrace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1,
+                         ignore_jit_warnings=True)
+    loss1 = elbo.loss_and_grads(model, guide, X, y)
+    grads1 = store_grads()
+    # eager Trace_ELBO at the same parameters and noise
+    for p in pyro.get_param_store()._params.values():
+        p.grad = None
+    monkeypatch.setattr(rng, "normal", EpsReplay(eps2, device, lenient=True))
+    ref1 = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1).loss_and_grads(
+        model, guide, X, y)
+    np.testing.assert_allclose(loss1, ref1, rtol=1e-6 if dtype == torch.float32 else 1e-12)
+    for name, val in store_grads().items():
+        sc = max(1.0, float(np.abs(val).max()))
+        np.testing.assert_allclose(grads1[name], val, rtol=rtol, atol=rtol * sc, err_msg=name)
+    (compiled,) = [c for c, _, _ in elbo._jit_cache.values()]
+    (traced,) = compiled.compiled.values()
+    graph = str(traced.graph)
+    for op in expect_ops:
+        assert op in graph, (op, sorted({ln.split("= ")[1].split("(")[0] for ln in graph.split("\n")
+                                         if "= pyro_amd::" in ln}))
+    # move the parameters; the recorded graph (noise eps2 frozen in it) answers at the new values
+    store = pyro.get_param_store()
+    with torch.no_grad():
+        for name in list(store.keys()):
+            store[name] = torch.as_tensor(g["params2/" + name], dtype=dtype, device=device)
+    for p in store._params.values():
+        p.grad = None
+
+    def no_draws(shape, dtype, device):
+        raise AssertionError("a replay of the traced loss must not re-run the Python model")
+    monkeypatch.setattr(rng, "normal", no_draws)
+    loss2 = elbo.loss_and_grads(model, guide, X, y)
+    np.testing.assert_allclose(loss2, float(g["loss2"]), rtol=rtol)
+    assert_grads(store_grads(), g, "grads2", rtol * 10)
+    return graph

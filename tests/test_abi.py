@@ -77,13 +77,25 @@ def test_torch_library_shim_loads_and_registers_the_schemas():
     from pyro_amd.ops import torch_library
     build_torch_ops()
     assert torch_library.available()
-    for name, nret in (("glm_pack_planes", 1), ("glm_bernoulli_planes", 3), ("glm_bernoulli", 3),
-                       ("glm_chain", 2)):
+    # (ll, gw, gb, workspace): the workspace is an output so that a chained tail can keep it alive
+    for name, nret in (("glm_pack_planes", 1), ("glm_bernoulli_planes", 4), ("glm_bernoulli", 4),
+                       ("glm_chain", 2), ("adam_step", 0)):
         schema = getattr(torch.ops.pyro_amd, name).default._schema
         assert len(schema.returns) == nret, schema
     # shape functions (register_fake): meta tensors flow through without touching a device
     w = torch.empty((64, 32), device="meta")
-    ll, gw, gb = torch.ops.pyro_amd.glm_bernoulli_planes(
+    ll, gw, gb, ws = torch.ops.pyro_amd.glm_bernoulli_planes(
         torch.empty((16,), dtype=torch.uint8, device="meta"), torch.empty((100,), device="meta"), w,
         None, 1.0, 100, 32, 1)
-    assert ll.shape == (64,) and gw.shape == (64, 32) and gb.shape == (64,)
+    assert ll.shape == (64,) and gw.shape == (64, 32) and gb.shape == (64,) and ws.dtype == torch.uint8
+    # every kernel-backed autograd Function of the package is a NAMED dispatcher op pair
+    import pyro_amd  # noqa: F401
+    names = torch_library.registered_ops()
+    for op in ("meanfield_normal_sample", "multi_log_prob_sum", "dist_log_prob_sum", "dist_log_prob",
+               "lda_factor", "logsumexp_terms", "logchain", "normal_rsample", "standard_gamma",
+               "mvn_tril_sample", "glm_bernoulli_ll", "glm_bernoulli_grouped_ll", "adam_step"):
+        assert "pyro_amd::" + op in names, op
+        if op != "adam_step":
+            assert "pyro_amd::" + op + "_bwd" in names, op
+            assert str(getattr(torch.ops.pyro_amd, op).default._schema).endswith(
+                "(Tensor[] tensors, int spec) -> Tensor[]")

@@ -1,0 +1,103 @@
+"""JitTrace_ELBO on the device (reference: pyro/infer/trace_elbo.py:162-257 over pyro/ops/jit.py:48-163):
+the traced ``differentiable_loss`` holds the step's kernels as ``pyro_amd::*`` dispatcher ops
+(pyro_amd/ops/torch_library.py), replays at new parameter values with the reference's numbers
+(tests/golden/logreg_f32.npz, written by the unmodified reference), and its Philox draws continue the
+stream the eager estimator would have consumed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import models
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(autouse=True)
+def _clean():
+    import pyro_amd
+    pyro_amd.clear_param_store()
+    yield
+    torch.set_default_dtype(torch.float32)
+    pyro_amd.clear_param_store()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_traced_config2_loss_replays_with_the_reference_numbers(gpu, monkeypatch, fused):
+    g = np.load(os.path.join(G, "logreg_f32.npz"))
+    ops = ("pyro_amd::meanfield_normal_sample", "pyro_amd::glm_bernoulli", "pyro_amd::multi_log_prob_sum") \
+        if fused else ()
+    graph = models.run_logreg_jit(g, gpu, monkeypatch, fused=fused, dtype=torch.float32, rtol=2e-4,
+                                  expect_ops=ops)
+    recorded = {ln.split("= ")[1].split("(")[0] for ln in graph.split("\n") if "= pyro_amd::" in ln}
+    assert recorded, "no kernel of this package was recorded as a graph node"
+    # (what is not pyro_amd:: is ATen glue; nothing may be a Python call-back)
+    assert "PythonOp" not in graph
+
+
+def test_traced_draws_continue_the_philox_stream(gpu):
+    """Replays draw fresh noise: the k-th traced evaluation equals the eager estimator's evaluation at
+    the same position of the Philox stream (the first call consumes two evaluations' worth: the eager
+    parameter-discovery run and the run under the tracer)."""
+    import pyro_amd as pyro
+    from pyro_amd.infer import JitTrace_ELBO, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    N, D, P = 4096, 16, 64
+    gen = torch.Generator().manual_seed(0)
+    X = torch.randn((N, D), generator=gen).to(gpu)
+    y = (torch.rand((N,), generator=gen) < 0.5).float().to(gpu)
+
+    def run(cls, n):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(7)
+        guide = AutoNormal(models.logreg_model_fused, init_scale=0.1)
+        guide._setup_prototype(X, y)
+        pyro.set_rng_seed(7)
+        kw = dict(ignore_jit_warnings=True) if cls is JitTrace_ELBO else {}
+        elbo = cls(num_particles=P, vectorize_particles=True, max_plate_nesting=1, **kw)
+        return [elbo.loss(models.logreg_model_fused, guide, X, y) for _ in range(n)]
+
+    eager = run(Trace_ELBO, 6)
+    assert len(set(eager)) == 6
+    traced = run(JitTrace_ELBO, 4)
+    np.testing.assert_allclose(traced, eager[2:], rtol=1e-6)
+
+
+def test_svi_with_a_traced_loss_follows_the_eager_trajectory(gpu):
+    """SVI over JitTrace_ELBO (the way the reference's examples use it, examples/svi_horovod.py:101 /
+    --jit flags): same parameters after a few Adam steps as SVI over Trace_ELBO started two draws
+    later in the stream."""
+    import pyro_amd as pyro
+    from pyro_amd import rng
+    from pyro_amd.infer import SVI, JitTrace_ELBO, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    N, D, P = 2048, 8, 64
+    gen = torch.Generator().manual_seed(1)
+    X = torch.randn((N, D), generator=gen).to(gpu)
+    y = (torch.rand((N,), generator=gen) < 0.5).float().to(gpu)
+    model = models.logreg_model_fused
+
+    def run(cls, skip):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(3)
+        guide = AutoNormal(model, init_scale=0.1)
+        guide._setup_prototype(X, y)
+        pyro.set_rng_seed(3)
+        kw = dict(ignore_jit_warnings=True) if cls is JitTrace_ELBO else {}
+        elbo = cls(num_particles=P, vectorize_particles=True, max_plate_nesting=1, **kw)
+        if skip:
+            with torch.no_grad():
+                for _ in range(skip):
+                    Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1).loss(
+                        model, guide, X, y)
+        svi = SVI(model, guide, pyro.optim.Adam({"lr": 0.05}), loss=elbo, hip_graph=False)
+        losses = [svi.step(X, y) for _ in range(5)]
+        return losses, {k: v.detach().cpu().numpy().copy() for k, v in pyro.get_param_store().items()}
+
+    l_eager, p_eager = run(Trace_ELBO, 2)
+    l_jit, p_jit = run(JitTrace_ELBO, 0)
+    np.testing.assert_allclose(l_jit, l_eager, rtol=2e-6)
+    for name in p_eager:
+        np.testing.assert_allclose(p_jit[name], p_eager[name], rtol=1e-5, atol=1e-6, err_msg=name)

@@ -1,0 +1,82 @@
+"""pyro_amd.ops.jit.trace / JitTrace_ELBO on the host (kernels answered by the numpy oracle through
+tests/oracle_backend.py): the reference's contract for traced functions (pyro/ops/jit.py:48-163,
+tests/ops/test_jit.py in the reference) and the traced ELBO against the reference-generated fixture."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pyro_amd as pyro
+from tests import models
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(autouse=True)
+def _cpu_backend(oracle_backend):
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def test_trace_reads_params_as_graph_inputs():
+    """A traced function of pyro.param values follows the parameters (they are inputs of the recorded
+    graph, not constants) and is differentiable w.r.t. them."""
+    from pyro_amd.ops import jit
+
+    calls = []
+
+    @jit.trace
+    def f(x):
+        calls.append(1)
+        a = pyro.param("a", torch.tensor(2.0))
+        b = pyro.param("b", torch.tensor([1.0, 3.0]))
+        return (a * x * b).sum()
+
+    x = torch.tensor([1.0, 2.0])
+    assert float(f(x)) == pytest.approx(2.0 * (1.0 + 6.0))
+    n_python_runs = len(calls)
+    with torch.no_grad():
+        pyro.get_param_store()._params["a"].fill_(5.0)
+    out = f(x)
+    assert float(out) == pytest.approx(5.0 * 7.0)
+    assert len(calls) == n_python_runs                       # replayed, not re-run
+    out.backward()
+    np.testing.assert_allclose(pyro.get_param_store()._params["b"].grad.numpy(), [5.0, 10.0])
+    # keyword arguments are part of the signature: one trace per distinct set
+    assert len(f.compiled) == 1
+
+
+def test_trace_keyword_arguments_select_the_compiled_graph():
+    from pyro_amd.ops import jit
+
+    @jit.trace
+    def f(x, scale=1.0):
+        return pyro.param("s", torch.tensor(3.0)) * x.sum() * scale
+
+    x = torch.ones(4)
+    assert float(f(x, scale=2.0)) == pytest.approx(24.0)
+    assert float(f(x, scale=0.5)) == pytest.approx(6.0)
+    assert float(f(x, scale=2.0)) == pytest.approx(24.0)
+    assert len(f.compiled) == 2
+
+
+def test_trace_accepts_unhashable_keyword_arguments():
+    """(lists / dicts / sets in kwargs are frozen into the signature key, pyro/ops/jit.py:68-77)"""
+    from pyro_amd.ops import jit
+
+    @jit.trace
+    def f(x, dims=None, opts=None):
+        return pyro.param("t", torch.tensor(2.0)) * x.sum(dims) .sum() * opts["k"]
+
+    x = torch.ones(2, 3)
+    assert float(f(x, dims=[0], opts={"k": 2.0})) == pytest.approx(24.0)
+    assert float(f(x, dims=[0], opts={"k": 2.0})) == pytest.approx(24.0)
+    assert len(f.compiled) == 1
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_jit_trace_elbo_replays_at_new_parameter_values(monkeypatch, fused):
+    g = np.load(os.path.join(G, "logreg_f64.npz"))
+    models.run_logreg_jit(g, torch.device("cpu"), monkeypatch, fused=fused, dtype=torch.float64, rtol=1e-9)

@@ -155,3 +155,35 @@ def test_jit_trace_records_the_site_and_replays(gpu):
     loss_b = _neg_elbo(X, y, *eps("eps2"))
     np.testing.assert_allclose(float(torch.jit.trace(loss_b, tuple(p2), check_trace=False)(*p2)),
                                float(g["loss2"]), rtol=2e-4)
+
+
+def test_op_workspace_stays_alive_while_its_finalize_phase_is_pending(gpu):
+    """Inside a chained tail the launcher only RECORDS the finalize phase, which reads the partial
+    records in the op's workspace when the chain is flushed.  The workspace is an op OUTPUT and the
+    Python wrapper parks it (and the outputs the phase writes) in the chain's keep-list: the caching
+    allocator cannot hand the block to anyone else before the flush."""
+    from pyro_amd import _lib
+    k, tl = _setup()
+    N, D, P = 4096, 32, 64                      # workspace well under 1 MB
+    g = torch.Generator(device="cpu").manual_seed(9)
+    X = torch.randn((N, D), generator=g).to(gpu)
+    y = (torch.rand((N,), generator=g) < 0.5).float().to(gpu)
+    w = (0.3 * torch.randn((P, D), generator=g)).to(gpu).requires_grad_()
+    b = torch.randn((P,), generator=g).to(gpu).requires_grad_()
+    for _ in range(2):
+        ref = tl.glm_bernoulli_ll(X, y, w, b)           # (second call: plane image)
+    (rw, rb) = torch.autograd.grad(ref.sum(), [w, b])
+    with k.chain_recording(gpu) as rec:
+        ll = tl.glm_bernoulli_ll(X, y, w, b)
+        assert _lib.load().pa_chain_pending() == 1
+        kept = [t for t in k._CHAIN["keep"] if t.dtype == torch.uint8]
+        assert kept and kept[-1].numel() < (1 << 20), [t.numel() for t in kept]
+        ws_ptr = kept[-1].data_ptr()
+        # blocks of the workspace's size requested now come from elsewhere
+        others = [torch.empty((kept[-1].numel(),), dtype=torch.uint8, device=gpu) for _ in range(8)]
+        assert all(o.data_ptr() != ws_ptr for o in others)
+        assert _lib.load().pa_chain_pending() == 1      # (allocations do not flush)
+    assert rec.stats == (1, 1)
+    assert torch.equal(ll, ref)
+    (gw, gb) = torch.autograd.grad(ll.sum(), [w, b])
+    assert torch.equal(gw, rw) and torch.equal(gb, rb)
