@@ -17,8 +17,7 @@ import weakref
 import torch
 
 from .. import poutine, rng
-from ..params import _PARAM_STORE
-from ..primitives import validation_enabled
+from ..primitives import param_unconstrained, validation_enabled
 
 
 def _freeze(value):
@@ -74,9 +73,12 @@ class CompiledFunction:
         self.jit_options.setdefault("check_trace", False)
         self._param_names = None
         self._draws = {}
+        self._offsets = {}
 
     def _leaves(self):
-        return [_PARAM_STORE._params[name] for name in self._param_names]
+        # through the "param" primitive, OUTSIDE the block below: an enclosing handler (SVI's parameter
+        # capture) sees every parameter on every call, replayed or not (pyro/ops/jit.py:119-121)
+        return [param_unconstrained(name) for name in self._param_names]
 
     def __call__(self, *args, **kwargs):
         key = (len(args), _freeze(kwargs))
@@ -105,7 +107,14 @@ class CompiledFunction:
                                    first=True)
             self.compiled[key] = traced
             self._draws[key] = draws
+            self._offsets[key] = [t.storage_offset() for t in example]
         inputs = tuple(self._leaves()) + tuple(args)
+        # strided views taken inside the function (torch.as_strided in the site kernels' operand
+        # frames) are recorded with the ABSOLUTE storage offset their base had under the tracer.  An
+        # input that has moved inside its storage since -- the flat optimizer turns every parameter
+        # into a view of one buffer at its first step -- is handed over as a (differentiable) copy
+        inputs = tuple(t if t.storage_offset() == off else t.clone()
+                       for t, off in zip(inputs, self._offsets[key]))
         with poutine.block(hide=self._param_names):
             with poutine.trace(param_only=True) as capture:
                 ret = self._draws[key].run(lambda: self.compiled[key](*inputs), first=False)

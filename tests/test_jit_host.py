@@ -80,3 +80,43 @@ def test_trace_accepts_unhashable_keyword_arguments():
 def test_jit_trace_elbo_replays_at_new_parameter_values(monkeypatch, fused):
     g = np.load(os.path.join(G, "logreg_f64.npz"))
     models.run_logreg_jit(g, torch.device("cpu"), monkeypatch, fused=fused, dtype=torch.float64, rtol=1e-9)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_svi_over_a_traced_loss_updates_the_parameters(monkeypatch, fused):
+    """SVI collects the parameters of a step from the "param" messages it sees: a replayed graph runs
+    no Python, so CompiledFunction reads its leaves through the param primitive on every call.  With
+    the same (frozen) noise the traced and the eager estimator give the same Adam trajectory."""
+    from pyro_amd import rng
+    from pyro_amd.distributions import families
+    from pyro_amd.infer import SVI, JitTrace_ELBO, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    if fused:
+        monkeypatch.setattr(families._BernoulliLinear, "_allow_f64", True, raising=False)
+    N, D, P = 300, 6, 5
+    gen = torch.Generator().manual_seed(1)
+    X = torch.randn((N, D), generator=gen)
+    y = (torch.rand((N,), generator=gen) < 0.5).double()
+    model = models.logreg_model_fused if fused else models.logreg_model
+
+    def frozen_noise(shape, dtype, device):
+        n = int(np.prod(shape))
+        return torch.sin(torch.arange(1, n + 1, dtype=dtype) * 0.7).reshape(tuple(shape))
+    monkeypatch.setattr(rng, "normal", frozen_noise)
+
+    def run(cls):
+        pyro.clear_param_store()
+        guide = AutoNormal(model, init_scale=0.1)
+        guide._setup_prototype(X, y)
+        kw = dict(ignore_jit_warnings=True) if cls is JitTrace_ELBO else {}
+        elbo = cls(num_particles=P, vectorize_particles=True, max_plate_nesting=1, **kw)
+        svi = SVI(model, guide, pyro.optim.Adam({"lr": 0.05}), loss=elbo)
+        losses = [svi.step(X, y) for _ in range(6)]
+        return losses, {k: v.detach().numpy().copy() for k, v in pyro.get_param_store().items()}
+
+    l_eager, p_eager = run(Trace_ELBO)
+    l_jit, p_jit = run(JitTrace_ELBO)
+    assert len(set(l_jit)) == 6
+    np.testing.assert_allclose(l_jit, l_eager, rtol=1e-10)
+    for name in p_eager:
+        np.testing.assert_allclose(p_jit[name], p_eager[name], rtol=1e-9, atol=1e-12, err_msg=name)

@@ -164,7 +164,7 @@ def test_op_workspace_stays_alive_while_its_finalize_phase_is_pending(gpu):
     allocator cannot hand the block to anyone else before the flush."""
     from pyro_amd import _lib
     k, tl = _setup()
-    N, D, P = 4096, 32, 64                      # workspace well under 1 MB
+    N, D, P = 4096, 32, 64
     g = torch.Generator(device="cpu").manual_seed(9)
     X = torch.randn((N, D), generator=g).to(gpu)
     y = (torch.rand((N,), generator=g) < 0.5).float().to(gpu)
@@ -177,7 +177,7 @@ def test_op_workspace_stays_alive_while_its_finalize_phase_is_pending(gpu):
         ll = tl.glm_bernoulli_ll(X, y, w, b)
         assert _lib.load().pa_chain_pending() == 1
         kept = [t for t in k._CHAIN["keep"] if t.dtype == torch.uint8]
-        assert kept and kept[-1].numel() < (1 << 20), [t.numel() for t in kept]
+        assert kept, "the op's workspace is not in the chain's keep-list"
         ws_ptr = kept[-1].data_ptr()
         # blocks of the workspace's size requested now come from elsewhere
         others = [torch.empty((kept[-1].numel(),), dtype=torch.uint8, device=gpu) for _ in range(8)]
