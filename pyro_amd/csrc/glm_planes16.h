@@ -73,16 +73,21 @@ __global__ __launch_bounds__(256) void glm_absmax_kernel(const float* __restrict
   if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
 }
 
-// (a, b) -> hi and lo f16 pairs, a ~= a1 + a2 to 2^-22 |a| (RN at both levels; the residual is one
-// v_fma_mix_f32 per element: f16 piece times -1 plus the f32 value, exact)
+// (a, b) -> hi and lo f16 pairs, a ~= a1 + a2 to 2^-22 |a| (RN at both levels).  The residual
+// a - a1 is exact in f32 and goes straight to its f16 half: one v_fma_mixlo_f16 / v_fma_mixhi_f16 per
+// element (f16 piece times -1 plus the f32 value, rounded once to f16), 3 instructions per pair
 __device__ __forceinline__ void split_pair_f16(float a, float b, uint32_t& p1, uint32_t& p2) {
+#ifdef PA_GLMH_ABL_NOSPLIT       // (tools/probes/glm_planes16_probe.hip: timing ablations, wrong numbers)
+  p1 = __builtin_bit_cast(uint32_t, a);
+  p2 = __builtin_bit_cast(uint32_t, b);
+  return;
+#endif
   const f32x2v v = {a, b};
   p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2v));   // v_cvt_pk_f16_f32
-  float ra, rb;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(p1), "v"(a));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(p1), "v"(b));
-  const f32x2v r = {ra, rb};
-  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2v));
+  uint32_t r;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p1), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p1), "v"(b));
+  p2 = r;
 }
 __device__ __forceinline__ float f16_lo(uint32_t p) {
   return (float)__builtin_bit_cast(f16x2v, p)[0];
@@ -174,6 +179,23 @@ struct GlmHCfg {
 
 constexpr uint32_t F16_2P15 = 0x7800u;        // 2^15
 
+// the two GEMMs' MFMAs (timing ablations of tools/probes/glm_planes16_probe.hip keep the operands alive
+// and drop the instruction)
+__device__ __forceinline__ f32x16v glmh_keep(const f16x8& a, const f16x8& b, const f32x16v& c) {
+  asm volatile("" : : "v"(a), "v"(b));
+  return c;
+}
+#ifdef PA_GLMH_ABL_NOGEMM1
+#define GLMH_MFMA1(a, b, c) glmh_keep(a, b, c)
+#else
+#define GLMH_MFMA1(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+#ifdef PA_GLMH_ABL_NOGEMM2
+#define GLMH_MFMA2(a, b, c) glmh_keep(a, b, c)
+#else
+#define GLMH_MFMA2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+
 template <int NB, int OCC, bool GROUPED = false, bool PRIV = false>
 __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
@@ -210,6 +232,9 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   }
 
   auto issue = [&](int64_t st, int bi) {
+#ifdef PA_GLMH_ABL_NODMA
+    return;
+#endif
     const int64_t stc = st < st_end ? st : st_end - 1;
     const unsigned char* src = img + stc * ST_BYTES + (PRIV ? rt * GLMH_TILE : (wave * PW) * 1024) + lane * 16;
     const uint32_t dst = lds_base + C::OFS_RING +
@@ -283,6 +308,8 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   f32x16v gwacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) gwacc[r] = 0.0f;
+  // (sum_n g stays on the vector pipe: measured, an MFMA costs ~22 cycles of SIMD time next to this
+  //  loop's VALU stream -- 4 MFMAs against a ones operand are slower than the 16 v_add they replace)
   float s_yl[2] = {0.0f, 0.0f}, s_abs[2] = {0.0f, 0.0f}, s_g[2] = {0.0f, 0.0f};
   float p_t[2] = {1.0f, 1.0f};
   int e_t[2] = {0, 0};
@@ -321,7 +348,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const uint32_t a0 = (h == 0 && okr) ? (F16_2P15 | (F16_2P15 << 16)) : 0u;   // k slots {0, 1}
     const uint32_t a1 = (h == 0 && okr) ? F16_2P15 : 0u;                        // k slot 2
     const f32x16v zero = {};
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a0, a1, 0u, 0u), b_aux, zero, 0, 0, 0);
+    return GLMH_MFMA1(as_f16x8(a0, a1, 0u, 0u), b_aux, zero);
   };
   auto load_a = [&](const unsigned char* Xt, int c, f16x8 (&xa)[2]) {
     const int ao = c == 0 ? a_ofs0 : a_ofs1;
@@ -331,17 +358,30 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   // element-wise on one accumulator element, plain f32 instructions only (see glm_planes.h); returns
   // 2^14 g
   auto elem1 = [&](float acc, float yh, int par) -> float {
+#ifdef PA_GLMH_ABL_NOELEM
+    return acc + yh;
+#endif
     const float l2 = acc * dsc;
+#ifdef PA_GLMH_ABL_NOTRANS
+    const float e = __builtin_fabsf(l2) * -0.001f;
+    const float t = e + 1.0f;
+    const float inv = t * 0.5f;
+#else
     const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(l2));
     const float t = e + 1.0f;
     const float inv = __builtin_amdgcn_rcpf(t);
+#endif
     s_yl[par] = __builtin_fmaf(yh, l2, s_yl[par]);
-    s_abs[par] += __builtin_fabsf(l2);
+    // (spelled out: left to itself the compiler sometimes materialises |l2| with a v_and first)
+    asm("v_add_f32 %0, |%1|, %0" : "+v"(s_abs[par]) : "v"(l2));
     p_t[par] *= t;
     const float g = yh - __builtin_copysignf(__builtin_fmaf(inv, GLMH_GSCALE, -0.5f * GLMH_GSCALE), l2);
     s_g[par] += g;
     return g;
   };
+  // (1 + e <= 2: the mantissa product of 8 tiles x 8 factors per chain stays below 2^64; its
+  //  exponent is harvested every 8th tile and after the loop -- the rounding of the product is
+  //  relative whatever its magnitude)
   auto renorm = [&]() {
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
@@ -361,6 +401,10 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     }
   };
   auto tr_issue = [&](uint32_t tr_a, uint32_t tr_b, int kh, v2u32 (&xlo)[2], v2u32 (&xhi)[2]) {
+#ifdef PA_GLMH_ABL_NOTR
+    xlo[0] = xhi[0] = xlo[1] = xhi[1] = v2u32{tr_a, tr_b};
+    return;
+#endif
     const uint32_t a = tr_a + (kh ? 1024u : 0u), b2 = tr_b + (kh ? 1024u : 0u);
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(xlo[0]) : "v"(a));
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(xhi[0]) : "v"(b2));
@@ -392,21 +436,36 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     load_a(X0, 0, xa);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
-      acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa0[TB[t]], acc_cur, 0, 0, 0);
+      acc_cur = GLMH_MFMA1(xa[TA[t]], wa0[TB[t]], acc_cur);
     load_a(X0, 1, xa);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
-      acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa1[TB[t]], acc_cur, 0, 0, 0);
+      acc_cur = GLMH_MFMA1(xa[TA[t]], wa1[TB[t]], acc_cur);
   }
-  for (int64_t it = 0; it < my_count; ++it) {
+  // one tile; the accumulator of the tile after it is built in `acc_nxt` while `acc_cur` is consumed
+  // -- the loop below calls it with the two accumulators swapped every other tile, so that the
+  // hand-over costs no register copies
+  int64_t it = 0;
+  auto tile = [&](const f32x16v& acc_cur, f32x16v& acc_nxt) {
+#if defined(PA_GLMH_ABL_NOPRIO)
+    if constexpr (false) {
+      const uint32_t ph = 0;
+#elif defined(PA_GLMH_PRIO_BY_TILE)
+    if constexpr (OCC > 1) {
+      const uint32_t ph = ((uint32_t)(it >> 2) + prio_slot) % (uint32_t)OCC;
+#else
     if constexpr (OCC > 1) {
       const uint32_t ph = ((uint32_t)(prio_clock >> 8) + prio_slot) % (uint32_t)OCC;
+#endif
       if (ph == 0) __builtin_amdgcn_s_setprio(0);
       else if (ph == 1) __builtin_amdgcn_s_setprio(1);
       else if (ph == 2) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(3);
+#if !defined(PA_GLMH_PRIO_BY_TILE)
       prio_clock = wall_clock64();
+#endif
     }
+    if ((it & 7) == 7) renorm();
     int bn = bi + 1 == NB ? 0 : bi + 1;
     wait_vmcnt<(NB - 3) * C::NDMA>();
     if constexpr (!PRIV) __builtin_amdgcn_s_barrier();
@@ -422,7 +481,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const uint32_t tr_b = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_b;
 
     const bool okn = prep_rows(bn, st + grid);
-    f32x16v acc_nxt = gemm1_aux(okn);
+    acc_nxt = gemm1_aux(okn);
     v2u32 xlo[2], xhi[2];
     f16x8 xa[2], xb[2];
     float yv[8], g[8];
@@ -434,14 +493,14 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     load_a(Xn, 0, xa);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa0[TB[t]], acc_nxt, 0, 0, 0);
+      acc_nxt = GLMH_MFMA1(xa[TA[t]], wa0[TB[t]], acc_nxt);
       g[2 * t] = elem1(acc_cur[2 * t], yv[2 * t], 0);
       g[2 * t + 1] = elem1(acc_cur[2 * t + 1], yv[2 * t + 1], 1);
     }
     load_a(Xn, 1, xa);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[TA[t]], wa1[TB[t]], acc_nxt, 0, 0, 0);
+      acc_nxt = GLMH_MFMA1(xa[TA[t]], wa1[TB[t]], acc_nxt);
       if (t == 0) {
         g[6] = elem1(acc_cur[6], yv[6], 0);
         g[7] = elem1(acc_cur[7], yv[7], 1);
@@ -450,7 +509,6 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
         split_pair_f16(g[4 * (t - 1) + 2], g[4 * (t - 1) + 3], g1[2 * (t - 1) + 1], g2[2 * (t - 1) + 1]);
       }
     }
-    renorm();
     tr_wait(xlo, xhi, xb);
     // -- GEMM2(it, K half 0)  ||  element-wise(it, K half 1)
     {
@@ -459,13 +517,12 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
       load_y(ysc, 1, yv);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        gwacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[TA[t]], xb[TB[t]], gwacc, 0, 0, 0);
+        gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
         const int e0 = t == 0 ? 0 : (t == 1 ? 3 : 6), e1 = t == 2 ? 8 : e0 + 3;
 #pragma unroll
         for (int j = e0; j < e1; ++j) g[j] = elem1(acc_cur[8 + j], yv[j], j & 1);
       }
     }
-    renorm();
     uint32_t h1[4], h2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) split_pair_f16(g[2 * j], g[2 * j + 1], h1[j], h2[j]);
@@ -475,14 +532,21 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
       const f16x8 ga[2] = {as_f16x8(h1[0], h1[1], h1[2], h1[3]), as_f16x8(h2[0], h2[1], h2[2], h2[3])};
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        gwacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[TA[t]], xb[TB[t]], gwacc, 0, 0, 0);
+        gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
     }
-    acc_cur = acc_nxt;
     st += grid;
     bi = bn;
+    ++it;
+  };
+  f32x16v acc_alt = {};
+  while (it + 1 < my_count) {
+    tile(acc_cur, acc_alt);
+    tile(acc_alt, acc_cur);
   }
+  if (it < my_count) tile(acc_cur, acc_alt);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_setprio(0);
+  renorm();
   __syncthreads();
 
   // ---- block reduction over the row tiles in a fixed order, one partial record in the format of
