@@ -35,10 +35,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
-BINDING_F16 = ("instruction issue: ~260 VALU instructions per wave and 32x32 (row, particle) tile "
-               "(sigmoid / softplus sums, the two-level f16 split of g) next to 13 MFMAs; two workgroups "
-               "per CU (more waves only add barrier waits); PMC per launch in "
-               "profiles/r0N_pmc_summary.json (latest round), DESIGN.md section 3")
+BINDING_F16 = ("serialised phases of two waves per SIMD: 229 VALU instructions per wave and 32x32 (row, "
+               "particle) tile (sigmoid / softplus sums, the two-level f16 split of g) + 13 MFMAs + the "
+               "tile loop's barrier / operand reads; timing ablations (profiles/r04_glm16_ablation.txt): "
+               "fixed 5 us + loop skeleton 11.5 + element-wise 15 + split 7 + MFMA 8 + LDS-DMA beside the "
+               "compute 7 add up to the kernel's duration; the image stream alone runs at 4.6 TB/s")
 BINDING_BF16 = ("VALU issue next to the MFMA pipe: 332 VALU instructions per wave and 32x32 (row, "
                 "particle) tile (sigmoid / softplus sums + the exact 3-way bf16 split of g) against 25 "
                 "MFMAs; PMC per launch: VALU issue 47 us of SIMD time, matrix pipe busy 26 us, kernel "
@@ -60,6 +61,8 @@ def parse():
     ap.add_argument("--no-nuts", action="store_true", help="skip the secondary NUTS measurement")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the one-GPU measurements of BASELINE configs 4 (LDA) and 5 (hierarchical)")
+    ap.add_argument("--no-prearm", action="store_true",
+                    help="headline without SVI(prearm=True): every replay launched by its own step() call")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager SVI.step (Python handlers + one launch per kernel) instead of the "
                          "captured hipGraph step")
@@ -335,9 +338,12 @@ def main():
     use_graph = not args.no_graph
     # the dominant kernel's own clock stamps (a launch argument: created before the capture)
     clock = kernels.GlmDeviceClock(dev) if on_gpu else None
+    # prearm: step k+1's replay is enqueued (behind a gate node) while step k executes, and released
+    # by the next step() call -- SVI.step per step, loss returned per step (pyro_amd/infer/svi.py)
+    prearm = use_graph and world == 1 and not args.no_prearm
     svi = SVI(examples.logreg_model, guide, optim,
               Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
-              hip_graph=use_graph, graph_warmup=2)
+              hip_graph=use_graph, graph_warmup=2, prearm=prearm)
 
     class _NoTimer:                      # (host run: nothing to bracket)
         pairs = []
@@ -386,6 +392,24 @@ def main():
                 kern_ms_list.append(timer.read_last())
         sync()
         block_s.append(time.perf_counter() - t0)
+    # which kernel the headline ran (the secondary measurements below switch image formats)
+    headline_planes = bool(on_gpu and kernels.glm_planes_of(X) is not None)
+    headline_f16 = headline_planes and kernels.glm_planes_format() == kernels.GLM_PLANES_F16X2
+    prearmed = bool(prearm and graphed and next(iter(svi._graphs.values())).gate is not None)
+    unarmed = None
+    if prearmed:
+        # the same captured step with every replay launched by its own step() call
+        svi.disarm()
+        nu = min(args.steps, 300)
+        sync()
+        tu = time.perf_counter()
+        for _ in range(nu):
+            svi.step(X, y)
+        sync()
+        tu = time.perf_counter() - tu
+        unarmed = {"value": nu / tu, "ms_per_step": tu / nu * 1e3, "steps": nu,
+                   "note": "the same capture after SVI.disarm(): the host launches each replay when "
+                           "step() is called (round 3's way)"}
     clock_ms = []
     if graphed and not graphed_events:
         # the kernel's duration inside the graph, from its own stamps on the device clock
@@ -575,8 +599,7 @@ def main():
                 traffic_src = "profiles/%s (%s)" % (os.path.basename(tpath), tj.get("how", ""))
             except Exception:
                 traffic = None
-        planes = on_gpu and kernels.glm_planes_of(X) is not None
-        f16 = planes and kernels.glm_planes_format() == kernels.GLM_PLANES_F16X2
+        planes, f16 = headline_planes, headline_f16      # (noted right after the timed region)
         n_prod = 3 if f16 else 6                       # piece products per element product
         out = {
             "metric": "ELBO-grad steps/sec (SVI)", "value": world * args.steps / elapsed,
@@ -590,8 +613,10 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Bayesian logistic regression, plate=%d, "
                                    "D=%d, Trace_ELBO num_particles=%d per GPU (vectorised), AutoNormal, "
                                    "Adam; the model text of SURVEY 8(d) verbatim (logits = w @ X.t() ...); "
-                                   "full SVI.step (%s)" % (N, D, P, "one hipGraph replay per step"
-                                                            if graphed else "eager launches"),
+                                   "full SVI.step (%s)" % (N, D, P, ("one hipGraph replay per step" + (
+                                       ", SVI(prearm=True): the replay of step k+1 is enqueued behind a "
+                                       "gate node while step k executes and released by the next step() "
+                                       "call" if prearmed else "")) if graphed else "eager launches"),
                        "parallelism": "particles sharded x%d, flat RCCL grad all-reduce" % world},
             # the plate scan is priced against HBM (algorithmic bytes = X and y once)
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
@@ -637,6 +662,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, D, P, args.cpu_budget_s)
         if validated is not None:
             out["validated"] = validated
+        if unarmed is not None:
+            out["without_prearm"] = unarmed
         out["step_anatomy"] = {"graph_nodes": "meanfield_sample, glm_planes, chain_tail (GLM finalize "
                                               "+ ELBO assembly + guide backward + Adam + loss hand-over)",
                                "chain": getattr(svi, "chain_stats", None),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 3
+#define PA_ABI_VERSION 4
 
 enum { PA_OK = 0, PA_ERR_INVALID = -1, PA_ERR_UNSUPPORTED = -2, PA_ERR_LAUNCH = -3 };
 
@@ -114,6 +114,30 @@ int pa_counter_add(uint64_t* counter, uint64_t inc, pa_stream_t stream);
  * back over the bus (ABI 1 behaviour; a PCIe round trip at the end of every step). */
 int pa_publish_scalar(int dtype, const void* src, double* host_value, uint64_t* host_seq,
                       uint64_t* counter, uint64_t inc, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * The step gate: a captured SVI step enqueued BEFORE the host asks for it.
+ * (pyro/infer/svi.py:134-162: step() returns the loss, so the reference's loop has the host between
+ * every two steps; here the launch latency of step k+1 overlaps the execution of step k.)
+ *
+ * pa_gate launches a one-thread kernel as the first node of a captured step.  `gate` = device
+ * int64[2] {number of the last step that ran, abort flag of the current replay}; `go` / `ack` = PINNED
+ * host int64[1] each.  The kernel numbers its replay n = gate[0] + 1 and spins on *go:
+ *   *go >= n          -> the step runs: gate[0] = n, gate[1] = 0;
+ *   *go == -n         -> cancelled by the host;
+ *   timeout_us passed -> given up (the host did not come back: it may be waiting on this very stream);
+ * in the last two cases gate[1] = 1, *ack = n (system-scope release) and every gate-aware kernel of the
+ * replay returns at once, so the replay changes nothing.  A replay launched the ordinary way finds
+ * *go >= n already and passes through.
+ *
+ * pa_gate_scope(gate) .. pa_gate_scope(NULL): launches of gate-aware kernels made in between read
+ * `gate[1]` at their start (guide draw, the plane-image GLM kernel, the chained tail).
+ * pa_gate_stats: launches this library made since the scope opened / how many of them were
+ * gate-aware -- a captured step may only be pre-enqueued when the two are equal (and torch launched
+ * nothing). */
+int pa_gate(const int64_t* go, int64_t* gate, int64_t* ack, int64_t timeout_us, pa_stream_t stream);
+int pa_gate_scope(int64_t* gate);
+int pa_gate_stats(int64_t* launches, int64_t* aware);
 
 /* ------------------------------------------------------------------------------------
  * Element-wise site kernels (SURVEY 8a rows a1,a3,a4,a5).

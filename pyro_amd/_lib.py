@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpyro_amd.so")
 
 PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_LAUNCH = 0, -1, -2, -3
 PA_F32, PA_F64 = 0, 1
-ABI_VERSION = 3      # PA_ABI_VERSION of include/pyro_amd.h
+ABI_VERSION = 4      # PA_ABI_VERSION of include/pyro_amd.h
 
 DIST_NORMAL = 0
 DIST_BERNOULLI_LOGITS = 1
@@ -85,6 +85,9 @@ _SIGNATURES = {
     "pa_philox_uniform": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "pa_counter_add": (c_int, [c_void_p, c_uint64, c_void_p]),
     "pa_publish_scalar": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "pa_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pa_gate_scope": (c_int, [c_void_p]),
+    "pa_gate_stats": (c_int, [c_void_p, c_void_p]),
     "pa_dist_log_prob": (c_int, [c_int, c_int, c_void_p, View2D, View2D, View2D, c_int64, c_int64,
                                  c_void_p]),
     "pa_dist_log_prob_sum_workspace": (c_size_t, [c_int64, c_int64]),

@@ -72,6 +72,7 @@ struct ChainArgs {
   int grid[CH_PHASES];    // virtual workgroups per phase
   int last;               // the last present phase (its final arrival resets the counters)
   uint64_t* stamps;       // developer hook (pa_chain_debug_stamps): 32 wall-clock stamps, or NULL
+  const int64_t* gate;    // the step gate's abort word (pa_gate_scope), or NULL
   // --- the fused form (chain_tail_kernel): per mean-field site the entries whose gradients only
   //     that site's backward consumes, and where the site's parameters live in the flat buffers
   int tail_nsites;
@@ -147,6 +148,7 @@ __device__ __forceinline__ void chain_fin_any(const ChainArgs& a, int me, int nw
   } while (0)
 
 __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
+  if (a.gate != nullptr && *a.gate != 0) return;    // the step gate gave this replay up (pa_gate)
   const bool total_wg = blockIdx.x == gridDim.x - 1;
   // worker workgroups run code written for 256 threads: the surplus waves leave before any barrier
   if (!total_wg && threadIdx.x >= 256) return;
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
 // counter and hands the loss to the host.  Same device code and thread geometry per element as the
 // separate launches: bit-identical results.
 __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
+  if (a.gate != nullptr && *a.gate != 0) return;    // the step gate gave this replay up (pa_gate)
   const bool total_wg = blockIdx.x == gridDim.x - 1;
   const int nw = (int)gridDim.x - 1, me = (int)blockIdx.x;
   uint32_t* sync = a.sync;
@@ -504,6 +507,8 @@ static int chain_launch() {
       if (a.grid[p] > maxgrid) maxgrid = a.grid[p];
     }
   a.stamps = g_chain_stamps;
+  a.gate = gate_word();
+  gate_aware_launch();
   int nw = cu_count() - 1;
   if (nw < 1) nw = 1;
   if (maxgrid < nw) nw = maxgrid;

@@ -18,6 +18,10 @@ int fail(int code, const char* fmt, ...);
 // hipGetLastError() after a launch -> PA_ERR_LAUNCH
 int check_launch(const char* what);
 int cu_count();
+// the step gate (pa_gate_scope): the word gate-aware kernels poll at their start, or nullptr; a
+// launcher of such a kernel calls gate_aware_launch() once per launch it passes gate_word() to
+const int64_t* gate_word();
+void gate_aware_launch();
 // true (and the two events) if pa_profile_bracket_next(tag, ...) is pending on this thread
 bool take_bracket(int tag, hipEvent_t* start, hipEvent_t* stop);
 

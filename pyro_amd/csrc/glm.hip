@@ -578,7 +578,8 @@ static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, c
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
                      b, N, D, P, pl.nst, part, cu_count(), trailer, g_planes_stamps,
-                     GlmGroupArgs{nullptr, nullptr, 1});
+                     GlmGroupArgs{nullptr, nullptr, 1}, gate_word());
+  gate_aware_launch();
 }
 
 template <int OCC>
@@ -590,7 +591,8 @@ static void glmh_launch_grouped(int nseg, int npass, const unsigned char* img, c
   constexpr int lds = GlmHCfg<3>::LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)npass), dim3(256), lds, s, img, y_img, w, b, N,
-                     D, P, nst_total, part, cu_count(), trailer, g_planes_stamps, grp);
+                     D, P, nst_total, part, cu_count(), trailer, g_planes_stamps, grp, gate_word());
+  gate_aware_launch();
 }
 
 // max |X| -> the image trailer {bits, kx}; the pack kernels derive kx from it

@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
     const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
     int64_t nst, float* __restrict__ part, int prio_cus, const uint32_t* __restrict__ trailer,
-    unsigned long long* __restrict__ tstamps, const GlmGroupArgs grp) {
+    unsigned long long* __restrict__ tstamps, const GlmGroupArgs grp,
+    const int64_t* __restrict__ gate) {
+  if (gate != nullptr && *gate != 0) return;        // the step gate gave this replay up (pa_gate)
   using C = GlmHCfg<NB, PRIV>;
   constexpr int NRT = C::NRT, NPT = C::NPT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS,
                 WPL = C::WPL;

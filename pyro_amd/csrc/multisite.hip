@@ -88,10 +88,11 @@ int pa_meanfield_normal_sample(int dtype, const pa_mf_site* sites, int nsites, i
   hipStream_t s = pa::as_stream(stream);
   if (dtype == PA_F32)
     hipLaunchKernelGGL((pa::meanfield_sample_kernel<float>), dim3((unsigned)gx, (unsigned)nsites),
-                       dim3(256), 0, s, args, P, seed, offset_dev);
+                       dim3(256), 0, s, args, P, seed, offset_dev, pa::gate_word());
   else
     hipLaunchKernelGGL((pa::meanfield_sample_kernel<double>), dim3((unsigned)gx, (unsigned)nsites),
-                       dim3(256), 0, s, args, P, seed, offset_dev);
+                       dim3(256), 0, s, args, P, seed, offset_dev, pa::gate_word());
+  pa::gate_aware_launch();
   return pa::check_launch("meanfield_sample_kernel");
 }
 

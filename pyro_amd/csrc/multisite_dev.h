@@ -544,7 +544,9 @@ template <typename T> __device__ __forceinline__ T softplus_t(T x) {
 template <typename T>
 __global__ __launch_bounds__(256) void meanfield_sample_kernel(const MfArgs args_by_value,
                                                                int64_t P, uint64_t seed,
-                                                               const uint64_t* __restrict__ offset_dev) {
+                                                               const uint64_t* __restrict__ offset_dev,
+                                                               const int64_t* __restrict__ gate) {
+  if (gate != nullptr && *gate != 0) return;        // the step gate gave this replay up (pa_gate)
   const MfSiteDev s = kernarg_load<MfSiteDev>(offsetof(MfArgs, s) + blockIdx.y * sizeof(MfSiteDev));
   const uint64_t off = s.offset + (offset_dev ? *offset_dev : 0);
   const T* loc = (const T*)s.loc;

@@ -22,7 +22,14 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// the step gate: see include/pyro_amd.h.  (entry points are serialised by the host language)
+static int64_t* g_gate = nullptr;
+static int64_t g_gate_launches = 0, g_gate_aware = 0;
+const int64_t* gate_word() { return g_gate == nullptr ? nullptr : g_gate + 1; }
+void gate_aware_launch() { g_gate_aware += 1; }
+
 int check_launch(const char* what) {
+  g_gate_launches += 1;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
   return PA_OK;
@@ -53,9 +60,55 @@ bool take_bracket(int tag, hipEvent_t* start, hipEvent_t* stop) {
   return true;
 }
 
+__global__ void gate_kernel(const int64_t* go, int64_t* gate, int64_t* ack, unsigned long long ticks) {
+  const int64_t n = gate[0] + 1;
+  const unsigned long long t0 = wall_clock64();
+  int aborted = 0;
+  for (unsigned iter = 0;; ++iter) {
+    const int64_t v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v >= n) break;
+    // (the iteration cap bounds the wait even if the clock should ever stand still)
+    if (v == -n || wall_clock64() - t0 > ticks || iter > (1u << 22)) {
+      aborted = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  gate[1] = aborted;
+  if (!aborted) {
+    gate[0] = n;
+  } else {
+    __hip_atomic_store(ack, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 }  // namespace pa
 
 extern "C" {
+
+int pa_gate(const int64_t* go, int64_t* gate, int64_t* ack, int64_t timeout_us, pa_stream_t stream) {
+  PA_REQUIRE(go && gate && ack, "pa_gate: NULL pointer");
+  PA_REQUIRE(timeout_us > 0 && timeout_us <= 100000, "pa_gate: timeout_us=%lld outside (0, 1e5]",
+             (long long)timeout_us);
+  // wall_clock64 counts at 100 MHz
+  hipLaunchKernelGGL(pa::gate_kernel, dim3(1), dim3(1), 0, pa::as_stream(stream), go, gate, ack,
+                     (unsigned long long)timeout_us * 100ull);
+  pa::g_gate_aware += 1;
+  return pa::check_launch("gate_kernel");
+}
+
+int pa_gate_scope(int64_t* gate) {
+  pa::g_gate = gate;
+  pa::g_gate_launches = pa::g_gate_aware = 0;
+  return PA_OK;
+}
+
+int pa_gate_stats(int64_t* launches, int64_t* aware) {
+  if (launches) *launches = pa::g_gate_launches;
+  if (aware) *aware = pa::g_gate_aware;
+  return PA_OK;
+}
 
 int pa_profile_bracket_next(int kernel_tag, void* ev_start, void* ev_stop) {
   PA_REQUIRE(kernel_tag >= 1 && kernel_tag <= 4, "profile_bracket_next: unknown kernel tag %d",

@@ -36,7 +36,24 @@ def _arg_key(x):
         return ("id", id(x))
 
 
+def _versions(args, kwargs):
+    """In-place-write counters of every tensor argument (a pre-armed replay reads their memory)."""
+    out = []
+    for a in list(args) + [v for _, v in sorted(kwargs.items())]:
+        if isinstance(a, torch.Tensor):
+            out.append(a._version)
+        elif isinstance(a, (list, tuple)):
+            out.extend(t._version for t in a if isinstance(t, torch.Tensor))
+    return out
+
+
 class _CapturedStep:
+    gate = None            # kernels.StepGate when the step's first node is a gate (SVI(prearm=True))
+    armed = False          # the NEXT replay is already enqueued behind its gate
+    armed_state = None     # what the host looked like when it was enqueued
+    arm_backoff = 0        # steps to run un-armed after the gate gave an armed replay up
+    arm_penalty = 1
+
     def __init__(self, graph, cap, loss, graph2=None, between=None, mailbox=None):
         self.graph, self.cap, self.loss = graph, cap, loss
         self.graph2, self.between = graph2, between     # split capture around a collective
@@ -47,26 +64,75 @@ class _CapturedStep:
             self._value_np, self._seq_np = mailbox[0].numpy(), mailbox[1].numpy()
             self._seq = int(self._seq_np[0])
 
-    def read_loss(self):
+    # ---- the step gate (kernels.StepGate): replays enqueued ahead of the host ------------------
+    def launch(self):
+        """Run the step now: release the replay waiting in its gate, or enqueue one that passes."""
+        g = self.gate
+        if g is None:
+            self.graph.replay()
+            return False
+        g.go_np[0] = g.next
+        if self.armed:
+            self.armed = False
+            return True                 # (it may have given itself up meanwhile: read_loss checks)
+        self.graph.replay()
+        return False
+
+    def arm(self, state):
+        """Enqueue the NEXT step behind its gate (call right after launch(): the host's launch
+        latency then overlaps the device's execution of the current step)."""
+        self.graph.replay()
+        self.armed, self.armed_state = True, state
+
+    def cancel(self):
+        """The armed replay must not run (the host changed something it would read)."""
+        g = self.gate
+        n = g.next
+        g.go_np[0] = -n
+        spins = 0
+        while int(g.ack_np[0]) != n:
+            spins += 1
+            if spins > 2_000_000:
+                torch.cuda.current_stream().synchronize()
+                break
+        self.armed = False
+
+    def read_loss(self, released_armed=False):
         if self.mailbox is None:
             return self.loss.item()
         # one publish per replay, each with a new sequence number (a device-side count: it need not
         # be the previous number of THIS mailbox plus one)
         last = self._seq
         seq, spins = self._seq_np, 0
+        g = self.gate
+        ack = g.ack_np if (g is not None and released_armed) else None
         while int(seq[0]) == last:
             spins += 1
+            if ack is not None and int(ack[0]) == g.next:
+                # the gate had given the armed replay up before the release arrived (the host was
+                # away longer than the gate's patience): nothing ran.  A replay already enqueued
+                # for the NEXT step numbers itself by what has run, finds its number released and
+                # runs as this step; otherwise the step is launched the ordinary way
+                ack = None
+                if self.armed:
+                    self.armed = False
+                else:
+                    self.graph.replay()
+                self.arm_backoff = self.arm_penalty
+                self.arm_penalty = min(self.arm_penalty * 2, 1024)
             if spins > 5_000_000:           # ~seconds: something is wrong, fall back to a real sync
                 torch.cuda.current_stream().synchronize()
                 if int(seq[0]) == last:
                     raise RuntimeError("pyro_amd: the captured step did not publish its loss")
         self._seq = int(seq[0])
+        if g is not None:
+            g.next += 1
         return float(self._value_np[0])
 
 
 class SVI:
     def __init__(self, model, guide, optim, loss, loss_and_grads=None, num_samples=0, num_steps=0,
-                 hip_graph=False, graph_warmup=3, **kwargs):
+                 hip_graph=False, graph_warmup=3, prearm=False, **kwargs):
         if num_steps or num_samples:
             warnings.warn("num_steps / num_samples are ignored (TracePosterior is not part of "
                           "this backend)")
@@ -87,6 +153,15 @@ class SVI:
                 loss_and_grads = _loss_and_grads
             self.loss, self.loss_and_grads = loss, loss_and_grads
         self.hip_graph = bool(hip_graph)
+        # prearm: right after launching step k the replay of step k+1 is enqueued behind a gate node
+        # and released by the next step() call with one store to pinned memory (the launch latency
+        # of a step overlaps the execution of the one before).  A promise by the caller: between two
+        # step() calls with the same arguments nothing is enqueued on the device that the step must
+        # see or that must see the step -- in-place writes to the step's ARGUMENT tensors and to
+        # parameters are noticed (the armed replay is cancelled), other device work is not; a host that
+        # stays away longer than the gate's patience (100 us) finds the replay given up and the step
+        # runs the ordinary way.  Only steps whose every node can be given up are armed.
+        self.prearm = bool(prearm) and _os.environ.get("PYRO_AMD_PREARM", "1") != "0"
         if self.hip_graph and self._loss_device is None:
             raise ValueError("hip_graph=True needs an ELBO that provides loss_and_grads_device")
         self.graph_warmup = int(graph_warmup)
@@ -159,16 +234,58 @@ class SVI:
                 del self._graphs[next(iter(self._graphs))]
         else:
             self._graphs[key] = self._graphs.pop(key)      # most recently used last
-        kernels.glm_planes_revalidate()     # data the graph reads through a cached image
-        kernels.lda_index_revalidate()
-        kernels.bow_revalidate()
-        entry.cap.before_replay()
-        entry.graph.replay()
-        if entry.graph2 is not None:
-            entry.between()            # eager RCCL all-reduce of the flat gradient
-            entry.graph2.replay()
+        if entry.gate is None:
+            kernels.glm_planes_revalidate()     # data the graph reads through a cached image
+            kernels.lda_index_revalidate()
+            kernels.bow_revalidate()
+            entry.cap.before_replay()
+            entry.graph.replay()
+            if entry.graph2 is not None:
+                entry.between()            # eager RCCL all-reduce of the flat gradient
+                entry.graph2.replay()
+            entry.cap.after_replay()
+            return entry.read_loss()
+        return self._gated_step(entry, args, kwargs)
+
+    def disarm(self):
+        """Stop enqueuing replays ahead of time (prearm=True): cancels a waiting one; later steps of
+        the existing captures run as ordinary replays through their (already released) gates."""
+        self.prearm = False
+        for e in self._graphs.values():
+            if e.armed:
+                e.cancel()
+            e.arm_backoff = 1 << 60
+
+    def _host_state(self, args, kwargs):
+        from .. import rng
+        return (_versions(args, kwargs), [p._version for p in _PARAM_STORE._params.values()],
+                rng._STATE["offset"])
+
+    def _gated_step(self, entry, args, kwargs):
+        """The fast path of a captured step whose first node is a gate (prearm=True)."""
+        if entry.armed:
+            # the armed replay reads the device as the stream will have left it BEFORE anything the
+            # host enqueued since: only sound if the host enqueued nothing it depends on
+            if self._host_state(args, kwargs) != entry.armed_state or kernels.revalidate_pending():
+                entry.cancel()
+        for other in self._graphs.values():          # (a replay armed for another signature)
+            if other is not entry and other.armed:
+                other.cancel()
+        if not entry.armed:
+            kernels.glm_planes_revalidate()
+            kernels.lda_index_revalidate()
+            kernels.bow_revalidate()
+            entry.cap.before_replay()
+        released = entry.launch()
         entry.cap.after_replay()
-        return entry.read_loss()
+        if entry.arm_backoff > 0:
+            entry.arm_backoff -= 1
+        else:
+            entry.arm(self._host_state(args, kwargs))
+        loss = entry.read_loss(released_armed=released)
+        if released and entry.arm_backoff == 0:
+            entry.arm_penalty = 1
+        return loss
 
     def _capture(self, key, args, kwargs):
         from .constants import HoistedConstantWritten
@@ -181,14 +298,22 @@ class SVI:
         forms = [False, True] if multi and not getattr(self, "_force_split", False) \
             and _os.environ.get("PYRO_AMD_GRAPH_COLLECTIVE", "1") != "0" else [None]
         for form in forms:
+            gated = self.prearm and not multi
             try:
                 entry = self._capture_once(key, args, kwargs, rec, force_split=form,
-                                           quiet=form is False)
+                                           quiet=form is False, with_gate=gated)
             except HoistedConstantWritten:
                 # the step writes into a tensor it created with zeros()/ones()/full(): such a
                 # tensor has to be filled on every replay -- capture again with the fills inside
+                rec = None
                 entry = self._capture_once(key, args, kwargs, None, force_split=form,
-                                           quiet=form is False)
+                                           quiet=form is False, with_gate=gated)
+            if entry is not None and entry.gate is not None and not entry.gate.armable:
+                # some node of this step would still run after the gate gave a replay up (a torch
+                # kernel, a launch of ours that does not poll the gate): capture it without one
+                self._graphs.pop(key, None)
+                entry = self._capture_once(key, args, kwargs, rec, force_split=form,
+                                           quiet=form is False, with_gate=False)
             if entry is not None:
                 return entry
             if form is False:
@@ -197,7 +322,8 @@ class SVI:
                 self.hip_graph = True           # (the failed attempt switched it off)
         return None
 
-    def _capture_once(self, key, args, kwargs, const_rec, force_split=None, quiet=False):
+    def _capture_once(self, key, args, kwargs, const_rec, force_split=None, quiet=False,
+                      with_gate=False):
         from .. import rng
         from ..primitives import validation_enabled
 
@@ -236,6 +362,8 @@ class SVI:
         else:
             consts = None
         hoist = (lambda: consts) if consts is not None else contextlib.nullcontext
+        gate = kernels.StepGate(device) if (with_gate and chained and not split) else None
+        gated = (lambda: gate) if gate is not None else contextlib.nullcontext
         try:
             with validation_enabled(False):   # validation ran in the eager warm-up steps
                 # with a process group alive its watchdog thread polls events while we capture:
@@ -243,7 +371,9 @@ class SVI:
                 multi = getattr(self.optim, "multi_rank", False)
                 mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
                 with torch.cuda.graph(graph, **mode):
-                    with cap, chain() as rec, hoist():
+                    with gated(), cap, chain() as rec, hoist():
+                        if gate is not None:
+                            gate.launch()          # first node: holds a replay enqueued ahead of time
                         with poutine.trace(param_only=True) as param_capture:
                             loss = self._loss_device(self.model, self.guide, *args, **kwargs)
                         params = self._params_of(param_capture)
@@ -288,6 +418,7 @@ class SVI:
             self.hip_graph = False
             return None
         entry = _CapturedStep(graph, cap, loss, graph2, between, mailbox)
+        entry.gate = gate
         # the graph reads the hoisted constants on every replay: they live as long as the entry
         entry.constants = consts.tensors if consts is not None else []
         entry.constants_served = consts.served if consts is not None else 0

@@ -114,6 +114,8 @@ def _launches_nothing(func):
 class _ChainGuard(torch.utils._python_dispatch.TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         if not _launches_nothing(func):
+            if "torch_ops" in _CHAIN:          # (a StepGate scope counts what torch launches)
+                _CHAIN["torch_ops"] += 1
             chain_flush()
         return func(*args, **(kwargs or {}))
 
@@ -270,6 +272,46 @@ def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
     assert counter is None or (counter.dtype == torch.int64 and counter.numel() >= 2)
     check(_lib.load().pa_publish_scalar(_dtype(src), _ptr(src), _ptr(host_value), _ptr(host_seq),
                                         _ptr(counter), int(inc), _stream()))
+
+
+class StepGate:
+    """The device / pinned-host words of one captured step's gate (include/pyro_amd.h "the step gate"):
+    a replay enqueued ahead of time waits in its first node until the host writes its number into
+    ``go`` -- or gives itself up after ``timeout_us`` and changes nothing."""
+
+    def __init__(self, device, timeout_us=100):
+        self.gate = torch.zeros((2,), dtype=torch.int64, device=device)     # {last step run, abort}
+        self.go = torch.zeros((1,), dtype=torch.int64).pin_memory()
+        self.ack = torch.zeros((1,), dtype=torch.int64).pin_memory()
+        self.go_np, self.ack_np = self.go.numpy(), self.ack.numpy()
+        self.timeout_us = int(timeout_us)
+        self.next = 1                  # number of the next replay that will RUN
+        self.total = self.aware = -1   # launches of the capture / gate-aware ones among them
+        self.torch_ops = -1            # torch operators that launched something during the capture
+
+    def launch(self):
+        """The gate node (first node of the capture)."""
+        check(_lib.load().pa_gate(_ptr(self.go), _ptr(self.gate), _ptr(self.ack), self.timeout_us,
+                                  _stream()))
+
+    def __enter__(self):
+        check(_lib.load().pa_gate_scope(_ptr(self.gate)))
+        _CHAIN["torch_ops"] = 0
+        return self
+
+    def __exit__(self, *exc):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        lib = _lib.load()
+        lib.pa_gate_stats(ctypes.byref(a), ctypes.byref(b))
+        lib.pa_gate_scope(None)
+        self.total, self.aware = a.value, b.value
+        self.torch_ops = _CHAIN.pop("torch_ops", -1)
+        return False
+
+    @property
+    def armable(self):
+        """Every node of the captured step returns at once when the gate gives a replay up."""
+        return self.total > 0 and self.total == self.aware and self.torch_ops == 0
 
 
 def counter_add(counter, inc):
@@ -838,6 +880,30 @@ def glm_planes_revalidate():
         if X is not None and y is not None and (ent[1] != X._version or ent[3] != y._version):
             glm_pack_planes_grouped(X, y, segs, out=ent[4])
             ent[1], ent[3] = X._version, y._version
+
+
+def revalidate_pending():
+    """True when one of the revalidate hooks (plane images, LDA index, bag-of-words images) would
+    re-pack something: a tensor behind a cached image was written in place since the image was made."""
+    for ent in list(_planes_cache.values()):
+        base = ent[0]()
+        if base is not None and ent[2] is not None and ent[1] != base._version:
+            return True
+    for segs in list(_grouped_with_image):
+        ent = segs._planes
+        if ent is None or ent[4] is None:
+            continue
+        X, y = ent[0](), ent[2]()
+        if segs.ids is not None and segs.ids._version != segs.ids_version:
+            return True
+        if X is not None and y is not None and (ent[1] != X._version or ent[3] != y._version):
+            return True
+    for cache in (_lda_index_cache, _bow_cache):
+        for ent in list(cache.values()):
+            base = ent[0]()
+            if base is not None and ent[2] is not None and ent[1] != base._version:
+                return True
+    return False
 
 
 def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D):

@@ -204,3 +204,119 @@ def test_chain_can_be_switched_off(gpu, monkeypatch):
     losses = [svi.step(X, y) for _ in range(5)]
     assert svi.hip_graph and svi.chain_stats == [None]
     assert all(l == l for l in losses)
+
+
+# ---- the step gate: replays enqueued ahead of the host (SVI(prearm=True), pa_gate) ----------------
+def _gate_run(gpu, prearm, between=None, steps=24, seed=7, N=20000):
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(N, 32, gpu, seed=3)
+    pyro.clear_param_store()
+    pyro.set_rng_seed(seed)
+    pyro.enable_validation(False)
+    guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+    svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+              Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1),
+              hip_graph=True, graph_warmup=3, prearm=prearm)
+    losses = []
+    for i in range(steps):
+        if between is not None:
+            between(i, svi, X, y)
+        losses.append(svi.step(X, y))
+    torch.cuda.synchronize()
+    return losses, _params(pyro), svi
+
+
+def test_prearmed_steps_are_bitwise_the_ordinary_ones(gpu):
+    """Every node of the config-2 step polls the gate: the capture is armable, from the second
+    replay on each step() finds its replay already enqueued, and the trajectory is bit-identical."""
+    l0, p0, _ = _gate_run(gpu, prearm=False)
+    l1, p1, svi = _gate_run(gpu, prearm=True)
+    (entry,) = svi._graphs.values()
+    g = entry.gate
+    assert g is not None and g.armable and (g.total, g.aware, g.torch_ops) == (4, 4, 0), \
+        (g.total, g.aware, g.torch_ops)
+    assert entry.armed and entry.arm_backoff == 0
+    assert g.next == 24 - 3 + 1                     # every replay ran exactly once
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    # the replay left armed at the end gives itself up: the stream drains (synchronize returns) and
+    # nothing has changed
+    torch.cuda.synchronize()
+    import pyro_amd as pyro
+    for k, v in _params(pyro).items():
+        assert torch.equal(v, p1[k]), k
+    assert int(g.ack_np[0]) == g.next
+
+
+def test_gate_gives_a_replay_up_when_the_host_stays_away(gpu):
+    """The host sleeps between steps (longer than the gate's 100 us): the armed replay has given
+    itself up, the step runs the ordinary way, arming backs off -- same trajectory."""
+    import time
+
+    def nap(i, svi, X, y):
+        if i in (8, 9, 15):
+            time.sleep(0.003)
+
+    l0, p0, _ = _gate_run(gpu, prearm=False)
+    l1, p1, svi = _gate_run(gpu, prearm=True, between=nap)
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    (entry,) = svi._graphs.values()
+    assert entry.gate.next == 24 - 3 + 1
+
+
+def test_writes_between_steps_cancel_the_armed_replay(gpu):
+    """In-place writes to an argument tensor or to a parameter between two steps are enqueued BEHIND
+    the armed replay; step() notices the version counters and cancels it, so the step sees them."""
+    import pyro_amd as pyro
+
+    def meddle(i, svi, X, y):
+        if i == 10:
+            X.mul_(0.5)                                   # new data in the same tensor
+        if i == 14:
+            with torch.no_grad():
+                pyro.get_param_store()._params["AutoNormal.locs.w"].mul_(0.9)
+        if i == 18:
+            pyro.set_rng_seed(123)                        # the host-side stream position moved
+
+    l0, p0, _ = _gate_run(gpu, prearm=False, between=meddle)
+    l1, p1, _ = _gate_run(gpu, prearm=True, between=meddle)
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
+def test_a_step_with_a_torch_kernel_in_it_is_captured_without_a_gate(gpu):
+    """prearm=True on a step that launches something which cannot be given up (here: the model's
+    logits are materialised by torch operators): no gate node, ordinary replays."""
+    import pyro_amd as pyro
+    from pyro_amd import distributions as dist
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X = torch.randn((2000, 4), device=gpu)
+    yv = (torch.rand((2000,), device=gpu) < 0.5).float()
+
+    def model(X, y):
+        w = pyro.sample("w", dist.Normal(X.new_zeros(4), 1.0).to_event(1))
+        with pyro.plate("data", X.shape[0]):
+            pyro.sample("obs", dist.Bernoulli(logits=torch.tanh(X * w.unsqueeze(-2)).sum(-1)), obs=y)
+
+    out = []
+    for prearm in (False, True):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(2)
+        pyro.enable_validation(False)
+        svi = SVI(model, AutoNormal(model), pyro.optim.Adam({"lr": 0.05}),
+                  Trace_ELBO(num_particles=8, vectorize_particles=True, max_plate_nesting=1),
+                  hip_graph=True, graph_warmup=2, prearm=prearm)
+        out.append([svi.step(X, yv) for _ in range(8)])
+        (entry,) = svi._graphs.values()
+        assert entry.gate is None
+    assert out[0] == out[1]

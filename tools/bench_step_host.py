@@ -38,3 +38,29 @@ def f():
 print("replay + async D2H to pinned + event sync %.1f us" % t(f))
 from pyro_amd.infer.svi import _arg_key
 print("_arg_key                         %.1f us" % t(lambda: (_arg_key((X, y)), _arg_key(()))))
+
+# ---- anatomy of one step() on the host (perf_counter stamps inside the fast path) -----------------
+import numpy as np
+def anatomy(n=400):
+    rows = []
+    torch.cuda.synchronize()
+    for _ in range(n):
+        t0 = time.perf_counter()
+        key = (_arg_key((X, y)), _arg_key(()))
+        e = svi._graphs[key]
+        from pyro_amd import kernels
+        kernels.glm_planes_revalidate(); kernels.lda_index_revalidate(); kernels.bow_revalidate()
+        e.cap.before_replay()
+        t1 = time.perf_counter()
+        e.graph.replay()
+        t2 = time.perf_counter()
+        e.cap.after_replay()
+        loss = e.read_loss()
+        t3 = time.perf_counter()
+        rows.append((t1 - t0, t2 - t1, t3 - t2))
+    a = np.array(rows[50:]) * 1e6
+    print("host anatomy (median us): before replay %.1f | graph.replay() call %.1f | poll until loss %.1f | total %.1f"
+          % (np.median(a[:, 0]), np.median(a[:, 1]), np.median(a[:, 2]), np.median(a.sum(1))))
+anatomy()
+print("back-to-back replays, 300 per sync: %.1f us per replay (GPU-side cadence without the host in the loop)"
+      % t(lambda: entry.graph.replay(), n=300))

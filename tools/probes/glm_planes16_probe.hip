@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   auto launch = [&]() {
     hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, nst, part, 256, trailer,
-                       (unsigned long long*)nullptr, GlmGroupArgs{nullptr, nullptr, 1});
+                       (unsigned long long*)nullptr, GlmGroupArgs{nullptr, nullptr, 1}, (const int64_t*)nullptr);
   };
   for (int i = 0; i < 5; ++i) launch();
   float best = 1e9f, tot = 0;
