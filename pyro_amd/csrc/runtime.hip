@@ -72,7 +72,7 @@ __global__ void gate_kernel(const int64_t* go, int64_t* gate, int64_t* ack, unsi
       aborted = 1;
       break;
     }
-    __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_s_sleep(2);
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   gate[1] = aborted;

@@ -36,21 +36,11 @@ def _arg_key(x):
         return ("id", id(x))
 
 
-def _versions(args, kwargs):
-    """In-place-write counters of every tensor argument (a pre-armed replay reads their memory)."""
-    out = []
-    for a in list(args) + [v for _, v in sorted(kwargs.items())]:
-        if isinstance(a, torch.Tensor):
-            out.append(a._version)
-        elif isinstance(a, (list, tuple)):
-            out.extend(t._version for t in a if isinstance(t, torch.Tensor))
-    return out
-
-
 class _CapturedStep:
     gate = None            # kernels.StepGate when the step's first node is a gate (SVI(prearm=True))
     armed = False          # the NEXT replay is already enqueued behind its gate
     armed_state = None     # what the host looked like when it was enqueued
+    armed_nargs = 0
     arm_backoff = 0        # steps to run un-armed after the gate gave an armed replay up
     arm_penalty = 1
 
@@ -162,6 +152,7 @@ class SVI:
         # stays away longer than the gate's patience (100 us) finds the replay given up and the step
         # runs the ordinary way.  Only steps whose every node can be given up are armed.
         self.prearm = bool(prearm) and _os.environ.get("PYRO_AMD_PREARM", "1") != "0"
+        self._armed_fast = None     # (entry, argument objects, their key) of the armed replay
         if self.hip_graph and self._loss_device is None:
             raise ValueError("hip_graph=True needs an ELBO that provides loss_and_grads_device")
         self.graph_warmup = int(graph_warmup)
@@ -199,6 +190,16 @@ class SVI:
         """One gradient step: loss_and_grads, optimizer update on every touched param, zero grads."""
         if not self.hip_graph:
             return self._eager_step(*args, **kwargs)
+        fast = self._armed_fast
+        if fast is not None:
+            # the step after an armed one, called with the very same argument objects: release the
+            # waiting replay before anything else (the device idles while the host is in here)
+            entry, fargs, fkey = fast
+            if (not kwargs and len(args) == len(fargs) and all(a is b for a, b in zip(args, fargs))
+                    and entry.armed and _arg_key(args) == fkey
+                    and self._host_state_unchanged(*entry.armed_state)
+                    and not kernels.revalidate_pending()):
+                return self._gated_step(entry, args, kwargs, checked=True)
         key = (_arg_key(args), _arg_key(tuple(sorted(kwargs.items()))))
         entry = self._graphs.get(key)
         if entry is None:
@@ -251,22 +252,49 @@ class SVI:
         """Stop enqueuing replays ahead of time (prearm=True): cancels a waiting one; later steps of
         the existing captures run as ordinary replays through their (already released) gates."""
         self.prearm = False
+        self._armed_fast = None
         for e in self._graphs.values():
             if e.armed:
                 e.cancel()
             e.arm_backoff = 1 << 60
 
     def _host_state(self, args, kwargs):
+        """What an armed replay depends on besides the device's own state: (tensor, version) of every
+        argument tensor and parameter, and the host-side position of the Philox stream."""
         from .. import rng
-        return (_versions(args, kwargs), [p._version for p in _PARAM_STORE._params.values()],
-                rng._STATE["offset"])
+        refs = []
+        for a in list(args) + [v for _, v in sorted(kwargs.items())]:
+            if isinstance(a, torch.Tensor):
+                refs.append((a, a._version))
+            elif isinstance(a, (list, tuple)):
+                refs.extend((t, t._version) for t in a if isinstance(t, torch.Tensor))
+        params = _PARAM_STORE._params
+        refs.extend((p, p._version) for p in params.values())
+        return refs, len(params), rng._STATE
 
-    def _gated_step(self, entry, args, kwargs):
+    @staticmethod
+    def _host_state_unchanged(state, offset):
+        refs, nparams, rng_state = state
+        if rng_state["offset"] != offset or len(_PARAM_STORE._params) != nparams:
+            return False
+        for t, v in refs:
+            if t._version != v:
+                return False
+        return True
+
+    def _gated_step(self, entry, args, kwargs, checked=False):
         """The fast path of a captured step whose first node is a gate (prearm=True)."""
+        if checked:
+            entry.launch()
+            entry.cap.after_replay()
+            from .. import rng
+            entry.arm((self._host_state(args, kwargs), rng._STATE["offset"]))
+            return entry.read_loss(released_armed=True)
         if entry.armed:
             # the armed replay reads the device as the stream will have left it BEFORE anything the
             # host enqueued since: only sound if the host enqueued nothing it depends on
-            if self._host_state(args, kwargs) != entry.armed_state or kernels.revalidate_pending():
+            if not (self._host_state_unchanged(*entry.armed_state)
+                    and len(args) == entry.armed_nargs) or kernels.revalidate_pending():
                 entry.cancel()
         for other in self._graphs.values():          # (a replay armed for another signature)
             if other is not entry and other.armed:
@@ -281,7 +309,10 @@ class SVI:
         if entry.arm_backoff > 0:
             entry.arm_backoff -= 1
         else:
-            entry.arm(self._host_state(args, kwargs))
+            from .. import rng
+            entry.armed_nargs = len(args)
+            entry.arm((self._host_state(args, kwargs), rng._STATE["offset"]))
+            self._armed_fast = (entry, args, _arg_key(args)) if not kwargs else None
         loss = entry.read_loss(released_armed=released)
         if released and entry.arm_backoff == 0:
             entry.arm_penalty = 1
