@@ -24,6 +24,7 @@
 #include "glm_bf16.h"
 #include "glm_planes.h"
 #include "glm_planes16.h"
+#include "glm_planes16w.h"
 #include "glm_finalize.h"
 #include "chain.h"
 
@@ -582,6 +583,25 @@ static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, c
   gate_aware_launch();
 }
 
+// one wave per 32-row tile and 64 particles (glm_planes16w.h): groups of four tiles (128 rows)
+template <int NB>
+static void glmw_launch(int bpc, const unsigned char* img, const float* y, const float* w, const float* b,
+                        int64_t N, int D, int P, float* part, const uint32_t* trailer, int* nblocks_out,
+                        hipStream_t s) {
+  auto k = glm_planes_f16w_kernel<NB>;
+  constexpr int lds = GlmWCfg<NB>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int npass = (int)((P + 63) / 64);
+  const int64_t ngrp = (N + 127) / 128;
+  int64_t cap = (int64_t)cu_count() * bpc / npass;
+  if (cap < 1) cap = 1;
+  const int nblocks = (int)(ngrp < cap ? ngrp : cap);
+  *nblocks_out = nblocks;
+  hipLaunchKernelGGL(k, dim3((unsigned)nblocks, (unsigned)npass), dim3(256), lds, s, img, y, w, b, N, D, P,
+                     ngrp, part, trailer, g_planes_stamps, gate_word());
+  gate_aware_launch();
+}
+
 template <int OCC>
 static void glmh_launch_grouped(int nseg, int npass, const unsigned char* img, const float* y_img,
                                 const float* w, const float* b, int64_t N, int D, int P,
@@ -945,9 +965,10 @@ int pa_glm_planes_finalize_mode(int in_kernel) {
 }
 
 int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
-  // (5 / 6: the f16 kernel with per-wave private rings of depth 3 / 4 -- a measurement knob)
-  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 6),
-             "glm_planes_tune: ring depth 3..6 (0 = default)");
+  // (f16 image: 3 / 4 = ring depth of the 32 x 32-tile kernel; measurement knobs: 5 / 6 the same with
+  //  per-wave private rings of depth 3 / 4, 9 / 10 one wave per tile and 64 particles, ring depth 3 / 4)
+  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 10),
+             "glm_planes_tune: ring depth code 3..10 (0 = default)");
   PA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 4, "glm_planes_tune: 0..4 workgroups per CU");
   pa::g_planes_nb = ring_depth == 0 ? 3 : ring_depth;
   pa::g_planes_bpc = blocks_per_cu;
@@ -992,8 +1013,12 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_planes: unaligned image");
   PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_planes_workspace(N, D, P),
              "glm_planes: workspace too small");
-  const pa::GlmPlanesPlan pl =
+  pa::GlmPlanesPlan pl =
       format == PA_GLM_PLANES_F16X2 ? pa::glmh_plan(N, P) : pa::glm_planes_plan(N, P);
+  // the f16 image: tuning codes 9 / 10 run one wave per 32-row tile and 64 particles (glm_planes16w.h,
+  // ring depth 3 / 4) -- measured equal to the default kernel (profiles/r04_glm16_ablation.txt): both
+  // are bound by the same element-wise VALU stream
+  const bool wide = format == PA_GLM_PLANES_F16X2 && (pl.nb == 9 || pl.nb == 10) && pl.bpc <= 2;
   float* part = (float*)workspace;
   const unsigned char* img = (const unsigned char*)planes;
   hipEvent_t ev0, ev1;
@@ -1001,7 +1026,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   if (br) (void)hipEventRecord(ev0, s);
   // every padding row of the processed super-tiles added log2(2) = 1 to the log2(1 + e) sum of
   // every particle (glm_planes.h): ln2 per row back in
-  const double ll_offset = (double)(pl.nst * 64 - N) * 0.6931471805599453;
+  const double ll_offset = (double)((wide ? (N + 127) / 128 * 128 : pl.nst * 64) - N) * 0.6931471805599453;
   pa::GlmFinArgs fin;
   fin.counters = nullptr;
   if (format == PA_GLM_PLANES_BF16X3 && pa::g_planes_fin_mode == 1 && pl.npass <= pa::GLMF_MAX_PASSES) {
@@ -1017,7 +1042,9 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   fin.tstamps = pa::g_planes_stamps;
   if (format == PA_GLM_PLANES_F16X2) {
     const uint32_t* trailer = (const uint32_t*)(img + pa::glmh_tile_bytes(pa::glm_planes_tiles(N)));
-    if (pl.nb == 5) pa::glmh_launch_one<3, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    if (wide && pl.nb == 9) pa::glmw_launch<3>(pl.bpc, img, y, w, b, N, (int)D, (int)P, part, trailer, &pl.nblocks, s);
+    else if (wide) pa::glmw_launch<4>(pl.bpc, img, y, w, b, N, (int)D, (int)P, part, trailer, &pl.nblocks, s);
+    else if (pl.nb == 5) pa::glmh_launch_one<3, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.nb == 6) pa::glmh_launch_one<4, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.nb == 4) pa::glmh_launch_one<4, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.bpc >= 4) pa::glmh_launch_one<3, 4>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);

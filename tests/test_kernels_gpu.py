@@ -581,7 +581,9 @@ def test_glm_plane_image_f16_exponent(gpu, scale):
     assert np.array_equal(img[:ref.size * 2].view(np.uint16).reshape(ref.shape), ref)
 
 
-@pytest.fixture(params=[3, 4], ids=["ring3", "ring4"])
+# (9: one wave per 32-row tile and 64 particles, csrc/glm_planes16w.h -- f16 image only; the bf16x3
+#  image reads the code as its ring depth 4)
+@pytest.fixture(params=[3, 4, 9], ids=["ring3", "ring4", "wide"])
 def planes_ring(request):
     k = _k()
     k.glm_planes_tune(request.param, 0)

@@ -76,7 +76,7 @@ def main():
         print(f"N={N} D={D} P={P}")
         print(f"  on-the-fly bf16x3           {us:8.1f} us   rel err ll {err(out)[0]:.1e} gw {err(out)[1]:.1e}")
         for fmt, fname, settings in ((k.GLM_PLANES_BF16X3, "bf16x3", [(3, 3)]),
-                                     (k.GLM_PLANES_F16X2, "f16x2", [(3, 2), (5, 1), (5, 2), (6, 1), (6, 2)])):
+                                     (k.GLM_PLANES_F16X2, "f16x2", [(3, 2), (9, 2), (10, 2), (9, 1), (5, 2), (3, 2)])):
             planes = k.glm_pack_planes(X, fmt=fmt)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "../../pyro_amd/csrc/glm_planes16.h"
+#include "../../pyro_amd/csrc/glm_planes16w.h"
 namespace pa { int cu_count() { return 256; } }
 
 int main(int argc, char** argv) {
@@ -38,16 +38,27 @@ int main(int argc, char** argv) {
 #ifndef PROBE_OCC
 #define PROBE_OCC 3
 #endif
+#ifdef PROBE_WIDE
+  auto k = glm_planes_f16w_kernel<PROBE_NB>;
+  constexpr int lds = GlmWCfg<PROBE_NB>::LDS_BYTES;
+#else
   auto k = glm_planes_f16_kernel<PROBE_NB, PROBE_OCC, false, PROBE_PRIV>;
   constexpr int lds = GlmHCfg<PROBE_NB, PROBE_PRIV>::LDS_BYTES;
+#endif
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const int64_t nst = argc > 3 ? atoll(argv[3]) : ((N + 31) / 32 + 1) / 2;   // (0: prologue + epilogue only, NODMA builds)
   const int nblocks = 256 * bpc;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   auto launch = [&]() {
+#ifdef PROBE_WIDE
+    const int64_t ngrp = argc > 3 ? atoll(argv[3]) : (N + 127) / 128;
+    hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, ngrp, part, trailer,
+                       (unsigned long long*)nullptr, (const int64_t*)nullptr);
+#else
     hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, nst, part, 256, trailer,
                        (unsigned long long*)nullptr, GlmGroupArgs{nullptr, nullptr, 1}, (const int64_t*)nullptr);
+#endif
   };
   for (int i = 0; i < 5; ++i) launch();
   float best = 1e9f, tot = 0;
