@@ -807,7 +807,10 @@ int pa_chain_pending(void);
  * fuse_tail = 1 (default): when every gradient of the recorded ELBO assembly feeds the backward
  * of exactly one mean-field site and the sites' parameters tile the optimizer's flat buffer, the
  * assembly / guide-backward / Adam phases run per site inside one workgroup each (no device-wide
- * barrier between them); 0: always the generic phase-by-phase form.  Same results either way. */
+ * barrier between them); 0: always the generic phase-by-phase form.  Same results either way.
+ * Bits 8 and up: race hunting -- a non-zero seed makes every workgroup of the chain kernels sleep a
+ * pseudo-random 0..17 us in front of each phase arrival and after each phase wait, which shuffles the
+ * order of the device-wide arrivals (the kernels must give bit-identical results under any seed). */
 int pa_chain_tune(int fuse_tail);
 /* chain launches since pa_chain_begin that took the fused form */
 int pa_chain_fused_launches(void);

@@ -73,6 +73,8 @@ struct ChainArgs {
   int last;               // the last present phase (its final arrival resets the counters)
   uint64_t* stamps;       // developer hook (pa_chain_debug_stamps): 32 wall-clock stamps, or NULL
   const int64_t* gate;    // the step gate's abort word (pa_gate_scope), or NULL
+  uint32_t jitter;        // race hunting (pa_chain_tune bits 8..): seed of pseudo-random per-workgroup
+                          // delays in front of every arrival and after every wait; 0 = off
   // --- the fused form (chain_tail_kernel): per mean-field site the entries whose gradients only
   //     that site's backward consumes, and where the site's parameters live in the flat buffers
   int tail_nsites;
@@ -88,7 +90,23 @@ static_assert(sizeof(ChainArgs) <= 6144, "kernel arguments grew unexpectedly");
 // took 20 us -- then ONE relaxed add.  The final arrival of the launch's last phase re-arms the
 // counters: by then every wait of the launch has completed (a workgroup only waits in front of a
 // phase it takes part in, and arrives at that phase afterwards).
-__device__ __forceinline__ void chain_signal(uint32_t* sync, int p, uint32_t expected, bool last) {
+// race hunting: workgroup- and phase-dependent delays of 0..17 us shuffle the order in which the
+// workgroups reach their arrivals and leave their waits (tests/test_chain_gpu.py runs the step under
+// many seeds and compares bit for bit with the separate launches)
+__device__ __forceinline__ void chain_jitter(uint32_t seed, int p, uint32_t salt) {
+  if (seed == 0u) return;
+  uint32_t hsh = seed * 2654435761u ^ (blockIdx.x + 1u) * 40503u ^ (uint32_t)(p + 1) * 2246822519u ^ salt;
+  hsh ^= hsh >> 15;
+  hsh *= 2654435761u;
+  hsh ^= hsh >> 13;
+  const uint32_t n = (hsh >> 8) & 63u;
+  if ((hsh & 3u) == 0u) return;                      // a quarter of the workgroups: no delay at all
+  for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+}
+
+__device__ __forceinline__ void chain_signal(uint32_t jitter, uint32_t* sync, int p, uint32_t expected,
+                                             bool last) {
+  chain_jitter(jitter, p, 0x9e3779b9u);
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -107,7 +125,7 @@ __device__ __forceinline__ void chain_signal(uint32_t* sync, int p, uint32_t exp
 // every workgroup that spins); ONE acquire fence by the spinning thread follows the loop (it
 // invalidates the CU's vector L1 and the stale lines of the L2 for every wave of the workgroup),
 // then the workgroup barrier.
-__device__ __forceinline__ void chain_wait(uint32_t* sync, int p, uint32_t expected) {
+__device__ __forceinline__ void chain_wait(uint32_t jitter, uint32_t* sync, int p, uint32_t expected) {
   if (threadIdx.x == 0) {
     const uint64_t t0 = wall_clock64();
     while (__hip_atomic_load(&sync[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
@@ -117,6 +135,7 @@ __device__ __forceinline__ void chain_wait(uint32_t* sync, int p, uint32_t expec
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  chain_jitter(jitter, p, 0x85ebca6bu);
 }
 
 // SUB virtual workgroups of 256 threads side by side in one physical workgroup of 256 * SUB threads
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
   if (a.have[CH_FIN]) {
     if (!total_wg && me < part_fin) {
       chain_fin_any<1>(a, me, nw);
-      chain_signal(sync, CH_FIN, (uint32_t)part_fin, a.last == CH_FIN);
+      chain_signal(a.jitter, sync, CH_FIN, (uint32_t)part_fin, a.last == CH_FIN);
     }
     prev = CH_FIN;
     prev_n = part_fin;
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
   if (a.have[CH_MULTI]) {
     constexpr uint32_t KB = (uint32_t)offsetof(ChainArgs, multi);
     if (total_wg || me < part_multi - 1) {
-      if (prev >= 0) chain_wait(sync, prev, (uint32_t)prev_n);
+      if (prev >= 0) chain_wait(a.jitter, sync, prev, (uint32_t)prev_n);
       PA_CHAIN_STAMP(2);
       if (total_wg) {
         multi_sum_body<float, MULTI_THREADS>(KB, a.multi_out, a.multi_coef_all, a.multi_accumulate);
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
           __syncthreads();
         }
       }
-      chain_signal(sync, CH_MULTI, (uint32_t)part_multi, a.last == CH_MULTI);
+      chain_signal(a.jitter, sync, CH_MULTI, (uint32_t)part_multi, a.last == CH_MULTI);
     }
     prev = CH_MULTI;
     prev_n = part_multi;
@@ -193,14 +212,14 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
   if (a.have[CH_MF]) {
     constexpr uint32_t KB = (uint32_t)offsetof(ChainArgs, mf);
     if (me < part_mf) {
-      if (prev >= 0) chain_wait(sync, prev, (uint32_t)prev_n);
+      if (prev >= 0) chain_wait(a.jitter, sync, prev, (uint32_t)prev_n);
       PA_CHAIN_STAMP(4);
       for (int vb = me; vb < a.grid[CH_MF]; vb += nw) {
         meanfield_sample_bwd_body<float>(KB, (uint32_t)(vb % a.mf_nsites),
                                          (uint32_t)(vb / a.mf_nsites), (uint32_t)a.mf_gy, a.mf_P);
         __syncthreads();
       }
-      chain_signal(sync, CH_MF, (uint32_t)part_mf, a.last == CH_MF);
+      chain_signal(a.jitter, sync, CH_MF, (uint32_t)part_mf, a.last == CH_MF);
     }
     prev = CH_MF;
     prev_n = part_mf;
@@ -209,13 +228,13 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainArgs a) {
   if (a.have[CH_ADAM]) {
     const int part_adam = a.grid[CH_ADAM] < nw ? a.grid[CH_ADAM] : nw;
     if (me < part_adam) {
-      if (prev >= 0) chain_wait(sync, prev, (uint32_t)prev_n);
+      if (prev >= 0) chain_wait(a.jitter, sync, prev, (uint32_t)prev_n);
       PA_CHAIN_STAMP(6);
       for (int64_t vb = me; vb < a.grid[CH_ADAM]; vb += nw)
         adam_body<float>(vb, (int64_t)a.grid[CH_ADAM], a.ad_p, a.ad_g, a.ad_m, a.ad_v, a.ad_n,
                          a.ad_lr, a.ad_b1, a.ad_b2, a.ad_eps, a.ad_wd, a.ad_clip, a.ad_lrd,
                          a.ad_clipped, a.ad_step, a.ad_zero, a.ad_pub);
-      chain_signal(sync, CH_ADAM, (uint32_t)part_adam, a.last == CH_ADAM);
+      chain_signal(a.jitter, sync, CH_ADAM, (uint32_t)part_adam, a.last == CH_ADAM);
     }
   }
   PA_CHAIN_STAMP(7);
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
     if (a.have[CH_FIN] && fme < part_fin) {
       chain_fin_any<4>(a, fme, nfw);
       // (the counters are re-armed by the tail's last arrival, below)
-      chain_signal(sync, CH_FIN, (uint32_t)part_fin, false);
+      chain_signal(a.jitter, sync, CH_FIN, (uint32_t)part_fin, false);
     }
     return;
   }
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
                       a.ad_wd, a.ad_clip, a.ad_lrd, a.ad_clipped, a.ad_zero};
     auto wait = [&]() {
       PA_CHAIN_STAMP(7);
-      if (a.have[CH_FIN]) chain_wait(sync, CH_FIN, (uint32_t)part_fin);
+      if (a.have[CH_FIN]) chain_wait(a.jitter, sync, CH_FIN, (uint32_t)part_fin);
       else __syncthreads();
       PA_CHAIN_STAMP(2);
     };
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(1024) void chain_tail_kernel(const ChainArgs a) {
     }
   }
   PA_CHAIN_STAMP(7);
-  if (a.have[CH_FIN]) chain_wait(sync, CH_FIN, (uint32_t)part_fin);
+  if (a.have[CH_FIN]) chain_wait(a.jitter, sync, CH_FIN, (uint32_t)part_fin);
   PA_CHAIN_STAMP(2);
   if (total_wg) {
     total_acc += multi_sum_partial<float, MULTI_THREADS>(KB, 0u, a.fin_dep_mask);
@@ -494,6 +513,7 @@ struct ChainState {
 static ChainState g_chain;
 static uint64_t* g_chain_stamps = nullptr;
 static int g_chain_fuse = 1;
+static uint32_t g_chain_jitter = 0;
 
 static int chain_launch() {
   ChainState& c = g_chain;
@@ -508,6 +528,7 @@ static int chain_launch() {
     }
   a.stamps = g_chain_stamps;
   a.gate = gate_word();
+  a.jitter = g_chain_jitter;
   gate_aware_launch();
   int nw = cu_count() - 1;
   if (nw < 1) nw = 1;
@@ -653,6 +674,7 @@ int pa_chain_tune(int fuse_tail) {
   // bit 0: the per-site fused form; bit 1 (with bit 0): NOT the one-pass site code of site_tail.h
   pa::g_chain_fuse = (fuse_tail & 1) ? 1 : 0;
   pa::g_chain_fast_sites = (fuse_tail & 2) ? 0 : 1;
+  pa::g_chain_jitter = (uint32_t)fuse_tail >> 8;         // race hunting: see chain_jitter()
   return PA_OK;
 }
 

@@ -139,10 +139,12 @@ def chain_debug_stamps(buf):
     _CHAIN["stamps"] = buf
 
 
-def chain_tune(fuse_tail=True, fast_sites=True):
+def chain_tune(fuse_tail=True, fast_sites=True, jitter_seed=0):
     """pa_chain_tune: allow (default) / forbid the per-site fused form of the chained tail, and
-    within it the one-pass code for AutoNormal-shaped sites."""
-    check(_lib.load().pa_chain_tune((1 if fuse_tail else 0) | (0 if fast_sites else 2)))
+    within it the one-pass code for AutoNormal-shaped sites.  ``jitter_seed`` != 0: race hunting --
+    pseudo-random per-workgroup delays around every device-wide arrival / wait of the chain kernels."""
+    check(_lib.load().pa_chain_tune((1 if fuse_tail else 0) | (0 if fast_sites else 2)
+                                    | ((int(jitter_seed) & 0x7fffff) << 8)))
 
 
 def chain_flush():

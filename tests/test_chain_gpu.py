@@ -320,3 +320,91 @@ def test_a_step_with_a_torch_kernel_in_it_is_captured_without_a_gate(gpu):
         (entry,) = svi._graphs.values()
         assert entry.gate is None
     assert out[0] == out[1]
+
+
+# ---- race hunting: the device-wide arrival counters under shuffled timing --------------------------
+@pytest.mark.parametrize("form", ["fused", "phases"])
+def test_chain_kernels_are_bitwise_stable_under_shuffled_arrivals(gpu, form):
+    """SURVEY section 5 (race detection): the chained tail orders its phases with device-wide arrival
+    counters (one release fence per workgroup, relaxed spin + one acquire) and the captured step hands
+    its loss over through a pinned mailbox.  With ``jitter_seed`` every workgroup sleeps a pseudo-random
+    0..17 us in front of each arrival and after each wait, so that across seeds every workgroup gets to
+    be first and last at every counter.  A missing fence or a wait on the wrong count shows up as a
+    changed bit: 16 seeds x 6 chained steps (eager, chained phase by phase or in the per-site fused
+    form) and 3 seeds x 40 replays of the captured step against the un-chained trajectory."""
+    from pyro_amd import kernels
+    fuse = form == "fused"
+    try:
+        kernels.chain_tune(fuse_tail=fuse)
+        pyro, svi, X, y = _setup(gpu, P=64)
+        ref_losses, ref_params = [], None
+        for i in range(8):
+            ref_losses.append(svi.step(X, y))                     # separate launches
+        ref_params = _params(pyro)
+        for seed in range(1, 17):
+            kernels.chain_tune(fuse_tail=fuse, jitter_seed=seed * 7919)
+            pyro, svi, X, y = _setup(gpu, P=64)
+            losses = []
+            for i in range(8):
+                losses.append(_chained_eager_step(svi, X, y)[0] if i >= 2 else svi.step(X, y))
+            assert losses == ref_losses, (seed, losses, ref_losses)
+            got = _params(pyro)
+            for k in ref_params:
+                assert torch.equal(ref_params[k], got[k]), (seed, k)
+    finally:
+        kernels.chain_tune(fuse_tail=True)
+
+
+def test_captured_step_is_bitwise_stable_under_shuffled_arrivals(gpu):
+    import pyro_amd as pyro
+    from pyro_amd import examples, kernels
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    def run(graph, seed, prearm=False, steps=43):
+        kernels.chain_tune(fuse_tail=True, jitter_seed=seed)
+        X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=3)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(5)
+        pyro.enable_validation(False)
+        guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+        svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+                  Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1),
+                  hip_graph=graph, graph_warmup=3, prearm=prearm)
+        losses = [svi.step(X, y) for _ in range(steps)]
+        torch.cuda.synchronize()
+        return losses, _params(pyro)
+
+    def step_ms(seed):
+        """Mean time of one replay of the captured step (the delays must be real for the test to mean
+        anything; they are launch arguments of the chain kernel, fixed at capture)."""
+        import time
+        kernels.chain_tune(fuse_tail=True, jitter_seed=seed)
+        X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=3)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(5)
+        pyro.enable_validation(False)
+        guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+        svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+                  Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1),
+                  hip_graph=True, graph_warmup=3)
+        for _ in range(10):
+            svi.step(X, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            svi.step(X, y)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 200 * 1e3
+
+    try:
+        plain, shuffled = step_ms(0), step_ms(4242)
+        assert shuffled > plain + 0.004, (plain, shuffled)       # >= 4 us of injected delay per step
+        ref = run(False, 0)
+        for seed, prearm in ((11, False), (977, False), (31337, True)):
+            got = run(True, seed, prearm)
+            assert got[0] == ref[0], seed
+            for k in ref[1]:
+                assert torch.equal(ref[1][k], got[1][k]), (seed, k)
+    finally:
+        kernels.chain_tune(fuse_tail=True)
