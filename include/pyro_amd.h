@@ -404,14 +404,17 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, cons
  * registers and the LDS writes of the on-the-fly kernel leave the per-step work; the arithmetic and
  * the outputs are those of pa_glm_bernoulli_fwd_bwd variant 0 (no mask argument: masked plates take
  * the entry above).  D <= 32; any P (64 particles per pass over the image).
- * pa_glm_planes_tune(ring_depth 3..4, workgroups per CU; 0 = default) is a measurement knob.
+ * pa_glm_planes_tune(ring depth code 3..10, workgroups per CU; 0 = default) is a measurement knob.
  *
  * Two image formats (`format`, the same value when an image is sized, packed and used):
  *   PA_GLM_PLANES_BF16X3  three bf16 planes, x = x1 + x2 + x3 EXACTLY; six piece products per
  *                         element product (dropped terms O(2^-24)); 6 B per element;
- *   PA_GLM_PLANES_F16X2   two f16 planes of X scaled by a power of two chosen from max |X| (found on
- *                         the device at pack time, kept in the image's trailer), x ~= x1 + x2 to
- *                         2^-22 relative (elements below 2^-13 max |X|: 2^-40 max |X| absolute);
+ *   PA_GLM_PLANES_F16X2   two f16 planes of X with every COLUMN scaled by its own power of two,
+ *                         chosen from the column's max |x| (found on the device at pack time, kept in
+ *                         the image's trailer: u32[32] maxima, i32[32] exponents), x ~= x1 + x2 to
+ *                         2^-22 relative (elements below 2^-13 of their column's maximum: 2^-40 of
+ *                         that maximum, absolute) -- columns of very different magnitude keep their
+ *                         precision;
  *                         three piece products; W and the gradient operand are split the same way
  *                         inside the kernel with per-particle power-of-two scales.  Error per logit
  *                         <= 3 * 2^-22 sum_d |x_d w_d| -- inside the 32 * 2^-24 bound of an f32 FMA

@@ -95,17 +95,26 @@ def glm_plane_image(X):
 
 
 # ---- the two-plane scaled f16 image (format PA_GLM_PLANES_F16X2, csrc/glm_planes16.h) -----------
-def f16_image_exponent(X):
-    """kx of the image: max |X| * 2^kx in [2^14, 2^15); 0 for an all-zero or non-finite matrix
-    (glmh_exponent_of: the unsigned maximum of the magnitudes' bit patterns, NaN above inf)."""
-    X = np.asarray(X, dtype=np.float32)
-    if X.size == 0:
-        return 0
-    bits = int((X.view(np.uint32) & np.uint32(0x7FFFFFFF)).max())
+def _f16_exponent_of_bits(bits):
     e = (bits >> 23) & 0xFF
     if bits == 0 or e == 0xFF:
         return 0
     return 14 - (-127 if e == 0 else e - 127)
+
+
+def f16_image_exponent(X):
+    """kx[32] of the image, one exponent per COLUMN: max_n |X[n,d]| * 2^kx[d] in [2^14, 2^15); 0 for
+    an all-zero or non-finite column and for the padding columns d >= D (glmh_exponent_of on
+    glm_absmax_kernel's column maxima: the unsigned maximum of the magnitudes' bit patterns, NaN
+    above inf)."""
+    X = np.asarray(X, dtype=np.float32)
+    kx = np.zeros(32, dtype=np.int32)
+    if X.size == 0:
+        return kx
+    bits = (np.ascontiguousarray(X).view(np.uint32) & np.uint32(0x7FFFFFFF)).max(axis=0)
+    for d, bb in enumerate(bits):
+        kx[d] = _f16_exponent_of_bits(int(bb))
+    return kx
 
 
 def f16_split2(x):
@@ -120,8 +129,8 @@ def f16_split2(x):
 
 
 def glm_plane_image_f16(X, kx=None):
-    """(uint16 image [tiles, 2 planes, 1024], kx) of an [N, D <= 32] f32 design matrix: glm_plane_image's
-    tile geometry with the two f16 pieces of X * 2^kx."""
+    """(uint16 image [tiles, 2 planes, 1024], kx[32]) of an [N, D <= 32] f32 design matrix:
+    glm_plane_image's tile geometry with the two f16 pieces of X[:, d] * 2^kx[d]."""
     X = np.asarray(X, dtype=np.float32)
     N, D = X.shape
     assert D <= 32
@@ -130,7 +139,7 @@ def glm_plane_image_f16(X, kx=None):
     tiles = -(-max(N, 0) // 32)
     tiles = -(-tiles // 4) * 4
     Xp = np.zeros((tiles * 32, 32), dtype=np.float32)
-    Xp[:N, :D] = np.ldexp(X, kx).astype(np.float32)
+    Xp[:N, :D] = np.ldexp(X, np.asarray(kx)[None, :D]).astype(np.float32)
     img = np.zeros((tiles, 2, 32, 4, 8), dtype=np.uint16)
     r = np.arange(32)
     for pl, piece in enumerate(f16_split2(Xp)):
@@ -142,7 +151,7 @@ def glm_plane_image_f16(X, kx=None):
 
 def glm_grouped_plane_image_f16(X, y, seg):
     """(uint16 tile image, float32 padded observations, kx): glm_grouped_plane_image in the f16 format;
-    the exponent comes from the whole of X."""
+    the column exponents come from the whole of X."""
     X = np.asarray(X, dtype=np.float32)
     y = np.asarray(y, dtype=np.float32)
     D = X.shape[1]

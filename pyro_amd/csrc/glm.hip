@@ -616,14 +616,14 @@ static void glmh_launch_grouped(int nseg, int npass, const unsigned char* img, c
 }
 
 // max |X| -> the image trailer {bits, kx}; the pack kernels derive kx from it
-static int glmh_absmax(const float* X, int64_t n, uint32_t* trailer, hipStream_t s) {
+static int glmh_absmax(const float* X, int64_t N, int D, uint32_t* trailer, hipStream_t s) {
   if (hipMemsetAsync(trailer, 0, GLMH_TRAILER, s) != hipSuccess)
     return pa::fail(PA_ERR_LAUNCH, "glm_pack_planes: memset of the image trailer failed");
-  if (n == 0) return PA_OK;
-  int64_t grid = (n + 256 * 8 - 1) / (256 * 8);
+  if (N == 0) return PA_OK;
+  int64_t grid = (N + 8 * 8 - 1) / (8 * 8);               // 8 rows per step and workgroup
   const int64_t cap = (int64_t)cu_count() * 8;
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL(glm_absmax_kernel, dim3((unsigned)grid), dim3(256), 0, s, X, n, trailer);
+  hipLaunchKernelGGL(glm_absmax_kernel, dim3((unsigned)grid), dim3(256), 0, s, X, N, D, trailer);
   return pa::check_launch("glm_absmax_kernel");
 }
 
@@ -822,7 +822,7 @@ int pa_glm_pack_planes_grouped_rows(int format, const float* X, const float* y, 
     float* y16 = (float*)(img + pa::glmh_tile_bytes(ntiles));
     uint32_t* trailer = (uint32_t*)(y16 + nst_total * 64);
     hipStream_t s = pa::as_stream(stream);
-    const int rc = pa::glmh_absmax(X, N * D, trailer, s);
+    const int rc = pa::glmh_absmax(X, N, (int)D, trailer, s);
     if (rc != PA_OK) return rc;
     hipLaunchKernelGGL(pa::glm_pack_planes_f16_grouped_kernel,
                        dim3((unsigned)((ntiles * 128 + 255) / 256)), dim3(256), 0, s, X, y, row_of, (int)D,
@@ -940,7 +940,7 @@ int pa_glm_pack_planes(int format, const float* X, int64_t N, int64_t D, void* p
   if (format == PA_GLM_PLANES_F16X2) {
     hipStream_t s = pa::as_stream(stream);
     uint32_t* trailer = (uint32_t*)((unsigned char*)planes + pa::glmh_tile_bytes(nt));
-    const int rc = pa::glmh_absmax(X, N * D, trailer, s);
+    const int rc = pa::glmh_absmax(X, N, (int)D, trailer, s);
     if (rc != PA_OK) return rc;
     // (also with no rows: the kernel's thread 0 writes the exponent into the trailer)
     hipLaunchKernelGGL(pa::glm_pack_planes_f16_kernel, dim3((unsigned)((nt * 128 + 255) / 256 + (nt == 0))),

@@ -19,24 +19,32 @@
 // of the f16 range and the second pieces stay normal over 2^-13 of dynamic range below the largest
 // element (smaller elements keep an ABSOLUTE error <= 2^-40 of the largest: below the f32
 // accumulation's own rounding):
-//   X:  one exponent kx per image, max |X| 2^kx in [2^14, 2^15) (pa_glm_pack_planes finds max |X| on
-//       the device and stores kx in the image's trailer: no host round trip);
-//   W:  one exponent kw[p] per particle row, chosen in the kernel's prologue from max_d |w[p,d]| and
-//       the bias (below); the f32 accumulator then holds 2^(kx + kw[p]) * l2 and the element-wise code
-//       starts with one multiply by the per-lane constant 2^-(kx + kw[p]);
-//   b:  enters the accumulator through the aux MFMA as three f16 pieces of b 2^(kx+kw[p]-15) against
+//   X:  one exponent kx[d] per COLUMN, max_n |X[n,d]| 2^kx[d] in [2^14, 2^15) (pa_glm_pack_planes finds
+//       the column maxima on the device and stores the exponents in the image's trailer: no host round
+//       trip).  Per column, not per image: a design matrix with raw columns of order 1e6 beside 0/1
+//       indicators keeps 22 bits in every column (round 3 scaled the whole image by one power of two
+//       and lost the second piece of columns 2^13 below the largest one);
+//   W:  the kernel's prologue forms w'[p,d] = w[p,d] 2^-kx[d] (so that x'.w' = x.w) and picks one
+//       exponent kw[p] per particle row from max_d |w'[p,d]| and the bias (below); the f32 accumulator
+//       holds 2^kw[p] * l2 and the element-wise code starts with one multiply by the per-lane constant
+//       2^-kw[p].  Columns whose w' is 2^13 below the row's largest lose w's second piece -- their
+//       products are that far below the row's dominant one;
+//   b:  enters the accumulator through the aux MFMA as three f16 pieces of b 2^(kw[p]-15) against
 //       2^15 (rows past the end of the plate: 0, their logit is exactly 0 as in glm_planes.h);
 //       kw[p] is capped so that this stays inside f16 -- when the bias dominates the row, W gives up
 //       low bits that are below the rounding of (x.w + b) anyway;
 //   g:  y - sigmoid(l) is formed as 2^14 g (one fma instead of a subtraction), so that its second
-//       piece is normal down to |g| = 2^-17; the gradient accumulator holds 2^(14 + kx) gw.
+//       piece is normal down to |g| = 2^-17; the gradient accumulator of column d holds
+//       2^(14 + kx[d]) gw[., d].
 #pragma once
 #include "glm_planes.h"
 
 namespace pa {
 
 constexpr int GLMH_TILE = 2 * GLMP_PLANE;   // bytes of one 32-row tile image: planes x1, x2
-constexpr int GLMH_TRAILER = 256;           // after the tiles (and y_img): u32 max|X| bits, i32 kx
+constexpr int GLMH_TRAILER = 256;           // after the tiles (and y_img): u32[32] column max |X| bits,
+                                            // i32[32] column exponents kx[d]
+constexpr int GLMH_KX = 32;                 // index of kx[0] in the trailer's words
 constexpr int GLMH_KNONE = 1 << 20;         // "no constraint" in the choice of a row's exponent
 
 constexpr float GLMH_GSCALE = 16384.0f;      // 2^14: the scale of y - 1/2 and of g
@@ -56,21 +64,21 @@ __host__ __device__ __forceinline__ int glmh_exponent_of(uint32_t absmax_bits) {
   return 14 - (e == 0 ? -127 : e - 127);          // -113 .. 141
 }
 
-// max |X| as the unsigned maximum of the magnitudes' bit patterns (NaN patterns order above +inf:
-// a non-finite matrix gets kx = 0 and its NaN / inf reach the outputs as they would in f32)
-__global__ __launch_bounds__(256) void glm_absmax_kernel(const float* __restrict__ X, int64_t n,
+// column maxima of |X| as the unsigned maximum of the magnitudes' bit patterns (NaN patterns order
+// above +inf: a non-finite column gets kx = 0 and its NaN / inf reach the outputs as they would in
+// f32).  256 threads = 8 rows x 32 columns per step; out[d], d < D
+__global__ __launch_bounds__(256) void glm_absmax_kernel(const float* __restrict__ X, int64_t N, int D,
                                                          uint32_t* __restrict__ out) {
+  const int d = threadIdx.x & 31, r0 = threadIdx.x >> 5;
   uint32_t m = 0u;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const uint32_t v = __builtin_bit_cast(uint32_t, X[i]) & 0x7fffffffu;
-    m = v > m ? v : m;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
-    m = t > m ? t : m;
-  }
-  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+  if (d < D)
+    for (int64_t r = (int64_t)blockIdx.x * 8 + r0; r < N; r += (int64_t)gridDim.x * 8) {
+      const uint32_t v = __builtin_bit_cast(uint32_t, X[r * D + d]) & 0x7fffffffu;
+      m = v > m ? v : m;
+    }
+  const uint32_t t = (uint32_t)__shfl_xor((int)m, 32);           // the wave's other row of this column
+  m = t > m ? t : m;
+  if ((threadIdx.x & 63) < 32 && d < D && m != 0u) atomicMax(out + d, m);
 }
 
 // (a, b) -> hi and lo f16 pairs, a ~= a1 + a2 to 2^-22 |a| (RN at both levels).  The residual
@@ -111,8 +119,7 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_kernel(const float* _
                                                                   unsigned char* __restrict__ img,
                                                                   uint32_t* __restrict__ trailer) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int kx = glmh_exponent_of(trailer[0]);
-  if (idx == 0) trailer[1] = (uint32_t)kx;
+  if (idx < 32) trailer[GLMH_KX + idx] = (uint32_t)glmh_exponent_of(trailer[idx]);
   if (idx >= ntiles * 128) return;
   const int64_t T = idx >> 7;
   const int r = (int)(idx >> 2) & 31, s = (int)idx & 3;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_kernel(const float* _
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int d = 8 * s + j;
-    v[j] = (row < N && d < D) ? ldexpf(X[row * D + d], kx) : 0.0f;
+    v[j] = (row < N && d < D) ? ldexpf(X[row * D + d], glmh_exponent_of(trailer[d])) : 0.0f;
   }
   glmh_store_slot(v, img + T * GLMH_TILE + glmp_slot_ofs(r, s));
 }
@@ -132,8 +139,7 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
     const int64_t* __restrict__ seg, const int64_t* __restrict__ st_off, int nseg, int64_t ntiles,
     unsigned char* __restrict__ img, float* __restrict__ y_img, uint32_t* __restrict__ trailer) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int kx = glmh_exponent_of(trailer[0]);
-  if (idx == 0) trailer[1] = (uint32_t)kx;
+  if (idx < 32) trailer[GLMH_KX + idx] = (uint32_t)glmh_exponent_of(trailer[idx]);
   if (idx >= ntiles * 128) return;
   const int64_t T = idx >> 7, st = T >> 1;
   const int r = (int)(idx >> 2) & 31, sl = (int)idx & 3;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int d = 8 * sl + j;
-    v[j] = (ok && d < D) ? ldexpf(X[row * D + d], kx) : 0.0f;
+    v[j] = (ok && d < D) ? ldexpf(X[row * D + d], glmh_exponent_of(trailer[d])) : 0.0f;
   }
   glmh_store_slot(v, img + T * GLMH_TILE + glmp_slot_ofs(r, sl));
   // the observations as the kernel consumes them: 2^14 (y - 1/2), 0 in the padding
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 
   // ---- W planes and the per-particle constants, once per block: thread (pl, s) holds 8 features of
   //      particle row pl; the four threads of a row are neighbours --------------------------------
-  const int kx = (int)trailer[1];
+  const int kx_l = (int)trailer[GLMH_KX + l31];        // the exponent of this lane's gradient column
   {
     const int pl = threadIdx.x >> 2, s = threadIdx.x & 3;
     const int p = pbase + pl;
@@ -262,8 +268,10 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int d = 8 * s + j;
-      // log2(e) rides in W and b (one f32 rounding each), as in glm_planes.h
-      v[j] = (p < P && d < D) ? w[(int64_t)p * w_stride + d] * GLMP_LOG2E : 0.0f;
+      // log2(e) rides in W and b (one f32 rounding each), as in glm_planes.h; the column's exponent
+      // comes off here (exact)
+      v[j] = (p < P && d < D)
+                 ? ldexpf(w[(int64_t)p * w_stride + d] * GLMP_LOG2E, -(int)trailer[GLMH_KX + d]) : 0.0f;
       mw = __builtin_fmaxf(mw, __builtin_fabsf(v[j]));
     }
     mw = __builtin_fmaxf(mw, __shfl_xor(mw, 1));
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const uint32_t mwb = __builtin_bit_cast(uint32_t, mw), bb = __builtin_bit_cast(uint32_t, b2) & 0x7fffffffu;
     const int ew = (int)(mwb >> 23), eb = (int)(bb >> 23);
     int kw = (mwb != 0u && ew != 0xff) ? 14 - (ew == 0 ? -127 : ew - 127) : GLMH_KNONE;
-    const int kb = (bb != 0u && eb != 0xff) ? 29 - kx - (eb == 0 ? -127 : eb - 127) : GLMH_KNONE;
+    const int kb = (bb != 0u && eb != 0xff) ? 29 - (eb == 0 ? -127 : eb - 127) : GLMH_KNONE;
     kw = kw < kb ? kw : kb;
     if (kw == GLMH_KNONE) kw = 0;                   // an all-zero (or non-finite) row
 #pragma unroll
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     *reinterpret_cast<uint4*>(q + WPL) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
     if (s == 0) {
       // the bias in accumulator units over 2^15, three pieces (24 bits)
-      const float bs = ldexpf(b2, kx + kw - 15);
+      const float bs = ldexpf(b2, kw - 15);
       uint32_t q1, q2, q3, dummy;
       split_pair_f16(bs, 0.0f, q1, q2);
       const float r2 = (bs - f16_lo(q1)) - f16_lo(q2);
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
       wx[1] = q3 & 0xffffu;                             // k slots {2: b3, 3: 0}
       // the descale factor stays a normal f32: beyond +-126 the logits are below / above anything
       // f32 itself could hold
-      int kd = -(kx + kw);
+      int kd = -kw;
       kd = kd > 126 ? 126 : (kd < -126 ? -126 : kd);
       wx[2] = __builtin_bit_cast(uint32_t, ldexpf(1.0f, kd));
       wx[3] = 0u;
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 
   const uint32_t* wx_l = reinterpret_cast<const uint32_t*>(smem + C::OFS_WAUX) + 4 * (pt * 32 + l31);
   const f16x8 b_aux = as_f16x8(h == 0 ? wx_l[0] : 0u, h == 0 ? wx_l[1] : 0u, 0u, 0u);
-  const float dsc = __builtin_bit_cast(float, wx_l[2]);       // 2^-(kx + kw[particle of this lane])
+  const float dsc = __builtin_bit_cast(float, wx_l[2]);       // 2^-kw[particle of this lane]
   f32x16v gwacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) gwacc[r] = 0.0f;
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int idx = (pt * 16 + r) * 64 + lane;
-        red[idx] = (rr == 0 ? 0.0f : red[idx]) + ldexpf(gwacc[r], -(14 + kx));
+        red[idx] = (rr == 0 ? 0.0f : red[idx]) + ldexpf(gwacc[r], -(14 + kx_l));
       }
       const int i0 = (2 * pt) * 64 + lane, i1 = (2 * pt + 1) * 64 + lane;
       red2[i0] = (rr == 0 ? 0.0f : red2[i0]) + ll_acc;

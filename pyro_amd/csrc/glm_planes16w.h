@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void glm_planes_f16w_kernel(
 
   // ---- W planes and the per-particle constants, once per block (glm_planes16.h: same rules): thread
   //      (pl, s) holds 8 features of particle row pl ------------------------------------------------
-  const int kx = (int)trailer[1];
+  const int kx_l = (int)trailer[GLMH_KX + l31];        // the exponent of this lane's gradient column
   {
     const int pl = threadIdx.x >> 2, s = threadIdx.x & 3;
     const int p = pbase + pl;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void glm_planes_f16w_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int d = 8 * s + j;
-      v[j] = (p < P && d < D) ? w[(int64_t)p * D + d] * GLMP_LOG2E : 0.0f;
+      v[j] = (p < P && d < D) ? ldexpf(w[(int64_t)p * D + d] * GLMP_LOG2E, -(int)trailer[GLMH_KX + d]) : 0.0f;
       mw = __builtin_fmaxf(mw, __builtin_fabsf(v[j]));
     }
     mw = __builtin_fmaxf(mw, __shfl_xor(mw, 1));
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void glm_planes_f16w_kernel(
     const uint32_t mwb = __builtin_bit_cast(uint32_t, mw), bb = __builtin_bit_cast(uint32_t, b2) & 0x7fffffffu;
     const int ew = (int)(mwb >> 23), eb = (int)(bb >> 23);
     int kw = (mwb != 0u && ew != 0xff) ? 14 - (ew == 0 ? -127 : ew - 127) : GLMH_KNONE;
-    const int kb = (bb != 0u && eb != 0xff) ? 29 - kx - (eb == 0 ? -127 : eb - 127) : GLMH_KNONE;
+    const int kb = (bb != 0u && eb != 0xff) ? 29 - (eb == 0 ? -127 : eb - 127) : GLMH_KNONE;
     kw = kw < kb ? kw : kb;
     if (kw == GLMH_KNONE) kw = 0;
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void glm_planes_f16w_kernel(
     *reinterpret_cast<uint4*>(q) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
     *reinterpret_cast<uint4*>(q + WPL) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
     if (s == 0) {
-      const float bs = ldexpf(b2, kx + kw - 15);
+      const float bs = ldexpf(b2, kw - 15);
       uint32_t q1, q2, q3, dummy;
       split_pair_f16(bs, 0.0f, q1, q2);
       const float r2 = (bs - f16_lo(q1)) - f16_lo(q2);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void glm_planes_f16w_kernel(
       uint32_t* wx = reinterpret_cast<uint32_t*>(smem + C::OFS_WAUX) + 4 * pl;
       wx[0] = (q1 & 0xffffu) | (q2 << 16);
       wx[1] = q3 & 0xffffu;
-      int kd = -(kx + kw);
+      int kd = -kw;
       kd = kd > 126 ? 126 : (kd < -126 ? -126 : kd);
       wx[2] = __builtin_bit_cast(uint32_t, ldexpf(1.0f, kd));
       wx[3] = 0u;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void glm_planes_f16w_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int idx = (pt * 16 + r) * 64 + lane;
-          red[idx] = (rr == 0 ? 0.0f : red[idx]) + ldexpf(gwacc[pt][r], -(14 + kx));
+          red[idx] = (rr == 0 ? 0.0f : red[idx]) + ldexpf(gwacc[pt][r], -(14 + kx_l));
         }
         const int i0 = (2 * pt) * 64 + lane, i1 = (2 * pt + 1) * 64 + lane;
         red2[i0] = (rr == 0 ? 0.0f : red2[i0]) + ll_acc;

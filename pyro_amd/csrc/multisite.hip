@@ -81,7 +81,9 @@ int pa_meanfield_normal_sample(int dtype, const pa_mf_site* sites, int nsites, i
                "pa_meanfield_normal_sample: site %d: NULL pointer", k);
     if (sites[k].n > maxn) maxn = sites[k].n;
   }
-  int64_t gx = (P * maxn + 255) / 256;
+  // (a thread draws one Philox block = 4 f32 / 2 f64 elements per trip)
+  const int64_t per = dtype == PA_F32 ? 4 : 2;
+  int64_t gx = ((P * maxn + per - 1) / per + 255) / 256;
   if (gx < 1) gx = 1;
   const int64_t cap = (int64_t)pa::cu_count() * 4;
   if (gx > cap) gx = cap;

@@ -368,8 +368,8 @@ def test_glm_grouped_plane_image_kernel(gpu, planes_fmt, N, D, P, G):
     got = planes.cpu().numpy()
     if planes_fmt == "f16x2":
         img, ypad, kx = o_glm.glm_grouped_plane_image_f16(X, y, segs.seg.cpu().numpy())
-        trailer = got[img.size * 2 + ypad.size * 4:][:8].view(np.int32)
-        assert int(trailer[1]) == kx
+        trailer = got[img.size * 2 + ypad.size * 4:][:256].view(np.int32)
+        assert np.array_equal(trailer[32:64], kx)                  # one exponent per column
     else:
         img, ypad = o_glm.glm_grouped_plane_image(X, y, segs.seg.cpu().numpy())
     nb_img = img.size * 2
@@ -561,7 +561,7 @@ def test_glm_plane_image_bit_exact(gpu, planes_fmt, N, D):
     img = k.glm_pack_planes(tt(X, gpu)).cpu().numpy()
     if planes_fmt == "f16x2":
         ref, kx = o_glm.glm_plane_image_f16(X)
-        assert int(img[ref.size * 2:][:8].view(np.int32)[1]) == kx       # the trailer's exponent
+        assert np.array_equal(img[ref.size * 2:][:256].view(np.int32)[32:64], kx)   # the trailer's exponents
     else:
         ref = o_glm.glm_plane_image(X)
     got = img[:ref.size * 2].view(np.uint16).reshape(ref.shape)
@@ -577,7 +577,7 @@ def test_glm_plane_image_f16_exponent(gpu, scale):
     X = (rng.standard_normal((200, 9)) * scale).astype(np.float32)
     img = k.glm_pack_planes(tt(X, gpu), fmt=k.GLM_PLANES_F16X2).cpu().numpy()
     ref, kx = o_glm.glm_plane_image_f16(X)
-    assert int(img[ref.size * 2:][:8].view(np.int32)[1]) == kx
+    assert np.array_equal(img[ref.size * 2:][:256].view(np.int32)[32:64], kx)
     assert np.array_equal(img[:ref.size * 2].view(np.uint16).reshape(ref.shape), ref)
 
 
@@ -634,12 +634,14 @@ def test_glm_planes_transpose_detecting_and_f32_class(gpu, planes_fmt):
 
 
 @pytest.mark.parametrize("case", ["plain", "bias_dominated", "tiny_w", "huge_w", "zero_w", "wide_x",
-                                  "mixed_particles", "x_1e-30"])
+                                  "mixed_particles", "x_1e-30", "raw_columns", "wide_columns"])
 def test_glm_planes_f16_is_f32_class(gpu, case):
     """The two-plane f16 image (csrc/glm_planes16.h): its error against the float64 oracle is of the
     size of an f32 evaluation's own error -- measured next to torch's f32 matmul + softplus on the
-    same inputs -- whatever the magnitudes of X, w and b (the power-of-two scales are per image and
-    per particle)."""
+    same inputs -- whatever the magnitudes of X, w and b (the power-of-two scales are per COLUMN of X
+    and per particle).  ``raw_columns``: an un-standardised design matrix, columns of order 1e6 beside
+    0/1 indicators, with weights that re-balance them (products of order one in every column);
+    ``wide_columns``: column scales 18 decades apart, weights inverse to them."""
     k = _k()
     N, D, P = 20000, 32, 64
     rng = np.random.default_rng(17)
@@ -666,6 +668,14 @@ def test_glm_planes_f16_is_f32_class(gpu, case):
         w *= np.float32(1e30)
     elif case == "mixed_particles":
         w *= np.exp(rng.uniform(-12, 3, (P, 1))).astype(np.float32)
+    elif case == "raw_columns":
+        X[:, 16:] = (rng.uniform(size=(N, 16)) < 0.3).astype(np.float32)          # indicators
+        X[:, :16] *= np.float32(1e6)                                              # raw measurements
+        w[:, :16] *= np.float32(1e-6)
+    elif case == "wide_columns":
+        cs = np.exp(rng.uniform(-20, 20, (1, D))).astype(np.float32)
+        X *= cs
+        w /= cs
     y = (rng.uniform(size=N) < 0.4).astype(np.float32)
     ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.0)
     tX, ty, tw, tb = tt(X, gpu), tt(y, gpu), tt(w, gpu), tt(b, gpu)

@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
   uint32_t* trailer = reinterpret_cast<uint32_t*>(img + (size_t)nt * GLMH_TILE);
   (void)hipMemset(trailer, 0, GLMH_TRAILER);
-  hipLaunchKernelGGL(glm_absmax_kernel, dim3(1024), dim3(256), 0, 0, X, N * D, trailer);
+  hipLaunchKernelGGL(glm_absmax_kernel, dim3(1024), dim3(256), 0, 0, X, N, D, trailer);
   hipLaunchKernelGGL(glm_pack_planes_f16_kernel, dim3((unsigned)((nt * 128 + 255) / 256)), dim3(256), 0, 0, X, N, D, nt, img, trailer);
 #ifndef PROBE_NB
 #define PROBE_NB 3
