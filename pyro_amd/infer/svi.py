@@ -339,7 +339,7 @@ class SVI:
                 rec = None
                 entry = self._capture_once(key, args, kwargs, None, force_split=form,
                                            quiet=form is False, with_gate=gated)
-            if entry is not None and entry.gate is not None and not entry.gate.armable:
+            if getattr(entry, "gate", None) is not None and not entry.gate.armable:
                 # some node of this step would still run after the gate gave a replay up (a torch
                 # kernel, a launch of ours that does not poll the gate): capture it without one
                 self._graphs.pop(key, None)

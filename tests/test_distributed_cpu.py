@@ -136,7 +136,8 @@ def test_captured_collective_falls_back_to_the_split_form(monkeypatch):
     svi = SVI(lambda: None, lambda: None, _TwoRankOptim(), Trace_ELBO(), hip_graph=True)
     forms = []
 
-    def fake_capture_once(key, args, kwargs, rec, force_split=None, quiet=False):
+    def fake_capture_once(key, args, kwargs, rec, force_split=None, quiet=False, with_gate=False):
+        assert with_gate is False            # (several ranks: a collective cannot be given up)
         forms.append((force_split, quiet))
         if force_split is False:         # the one-graph form fails (as a capture error would)
             svi.hip_graph = False
