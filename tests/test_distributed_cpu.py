@@ -157,6 +157,7 @@ def test_captured_collective_falls_back_to_the_split_form(monkeypatch):
     # the one-graph form succeeding is taken as is
     monkeypatch.delenv("PYRO_AMD_GRAPH_COLLECTIVE")
     forms.clear()
-    monkeypatch.setattr(svi, "_capture_once", lambda *a, force_split=None, quiet=False: "one-graph")
+    monkeypatch.setattr(svi, "_capture_once",
+                        lambda *a, force_split=None, quiet=False, with_gate=False: "one-graph")
     assert svi._capture(("k",), (), {}) == "one-graph"
     pyro.clear_param_store()
