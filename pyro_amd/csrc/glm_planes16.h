@@ -549,11 +549,19 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     ++it;
   };
   f32x16v acc_alt = {};
-  while (it + 1 < my_count) {
-    tile(acc_cur, acc_alt);
-    tile(acc_alt, acc_cur);
+  if constexpr (OCC >= 4) {
+    // (128 registers per wave: the second accumulator set of the unrolled form would spill)
+    while (it < my_count) {
+      tile(acc_cur, acc_alt);
+      acc_cur = acc_alt;
+    }
+  } else {
+    while (it + 1 < my_count) {
+      tile(acc_cur, acc_alt);
+      tile(acc_alt, acc_cur);
+    }
+    if (it < my_count) tile(acc_cur, acc_alt);
   }
-  if (it < my_count) tile(acc_cur, acc_alt);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_setprio(0);
   renorm();
