@@ -55,7 +55,11 @@ template <typename T> __device__ __forceinline__ T dot(P2<T> x, P2<T> y) {
 #pragma clang fp contract(off)
     p = x.b * y.b;
   }
-  return uni(wave_sum(__builtin_fma(x.a, y.a, p)));
+  // (f32 chains reduce in f32: __builtin_fma on floats is the DOUBLE fma -- until round 4 every dot of
+  //  an f32 chain ran a float64 DPP tree: two half-rate adds, two DPP moves, two zero fills and two
+  //  v_readlane per step instead of one v_add_f32_dpp; four dots per leapfrog)
+  if constexpr (sizeof(T) == 4) return uni(wave_sum(__builtin_fmaf(x.a, y.a, p)));
+  else return uni(wave_sum(__builtin_fma(x.a, y.a, p)));
 }
 
 // ---- potentials: g = Lambda z (Lambda symmetric, read as columns), pe = 0.5 z.g ---------------
@@ -119,19 +123,26 @@ struct PotReg {
   __device__ __forceinline__ void operator()(P2<float> z, P2<float>& g, float& pe) const {
     zs[lane] = z.a;
     zs[lane + 64] = z.b;
-    // (plain v_fmac: v_pk_fma_f32 issues in two passes on gfx950 -- measured, no gain over two FMAs)
-    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // rows j mod 4 (as PotLds)
+    // One v_pk_fma_f32 per row advances both columns of the lane: {a[k], b[k]} += L[j] * z_j with z_j
+    // BROADCAST from the low or the high half of the register pair the ds_read_b128 delivered
+    // (op_sel / op_sel_hi on src1) -- written out: left to itself the compiler forms the same packed
+    // FMAs but copies every second z_j into a fresh register first (26 v_mov per mat-vec).  Each
+    // component is an ordinary fma, partial sums and their order as in PotLds: bit-identical results.
+    v2f acc2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};   // rows j mod 4 (as PotLds)
     const float4* z4 = reinterpret_cast<const float4*>(zs);
 #pragma unroll
     for (int j4 = 0; j4 < DPAD / 4; ++j4) {
       const float4 q = z4[j4];
-      const float qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a[k] = __builtin_fmaf(L[4 * j4 + k][0], qq[k], a[k]);
-        b[k] = __builtin_fmaf(L[4 * j4 + k][1], qq[k], b[k]);
-      }
+      const v2f zlo = {q.x, q.y}, zhi = {q.z, q.w};
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[0]) : "v"(L[4 * j4 + 0]), "v"(zlo));
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+          : "+v"(acc2[1]) : "v"(L[4 * j4 + 1]), "v"(zlo));
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[2]) : "v"(L[4 * j4 + 2]), "v"(zhi));
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+          : "+v"(acc2[3]) : "v"(L[4 * j4 + 3]), "v"(zhi));
     }
+    const float a[4] = {acc2[0][0], acc2[1][0], acc2[2][0], acc2[3][0]};
+    const float b[4] = {acc2[0][1], acc2[1][1], acc2[2][1], acc2[3][1]};
     const float acc[2] = {(a[0] + a[1]) + (a[2] + a[3]), (b[0] + b[1]) + (b[2] + b[3])};
     g.a = acc[0];
     g.b = acc[1];
