@@ -81,19 +81,28 @@ int pa_meanfield_normal_sample(int dtype, const pa_mf_site* sites, int nsites, i
                "pa_meanfield_normal_sample: site %d: NULL pointer", k);
     if (sites[k].n > maxn) maxn = sites[k].n;
   }
-  // (a thread draws one Philox block = 4 f32 / 2 f64 elements per trip)
-  const int64_t per = dtype == PA_F32 ? 4 : 2;
+  // small sites: one element per thread (latency); from 64 K elements on: one Philox block = 4 f32 /
+  // 2 f64 elements per thread and trip (a quarter / half of the generator work) -- the same numbers
+  const bool big = P * maxn >= (int64_t(1) << 16);
+  const int64_t per = !big ? 1 : (dtype == PA_F32 ? 4 : 2);
   int64_t gx = ((P * maxn + per - 1) / per + 255) / 256;
   if (gx < 1) gx = 1;
   const int64_t cap = (int64_t)pa::cu_count() * 4;
   if (gx > cap) gx = cap;
   hipStream_t s = pa::as_stream(stream);
-  if (dtype == PA_F32)
-    hipLaunchKernelGGL((pa::meanfield_sample_kernel<float>), dim3((unsigned)gx, (unsigned)nsites),
-                       dim3(256), 0, s, args, P, seed, offset_dev, pa::gate_word());
+  const dim3 grid((unsigned)gx, (unsigned)nsites);
+  if (dtype == PA_F32 && big)
+    hipLaunchKernelGGL((pa::meanfield_sample_block_kernel<float>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, pa::gate_word());
+  else if (dtype == PA_F32)
+    hipLaunchKernelGGL((pa::meanfield_sample_kernel<float>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, pa::gate_word());
+  else if (big)
+    hipLaunchKernelGGL((pa::meanfield_sample_block_kernel<double>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, pa::gate_word());
   else
-    hipLaunchKernelGGL((pa::meanfield_sample_kernel<double>), dim3((unsigned)gx, (unsigned)nsites),
-                       dim3(256), 0, s, args, P, seed, offset_dev, pa::gate_word());
+    hipLaunchKernelGGL((pa::meanfield_sample_kernel<double>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, pa::gate_word());
   pa::gate_aware_launch();
   return pa::check_launch("meanfield_sample_kernel");
 }

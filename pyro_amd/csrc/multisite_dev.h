@@ -555,6 +555,40 @@ __global__ __launch_bounds__(256) void meanfield_sample_kernel(const MfArgs args
   T* eps = (T*)s.eps;
   T* sc = (T*)s.scale;
   T* lo = (T*)s.loc_out;
+  // one element per thread: small sites (a step's latents of a few thousand elements) are a latency
+  // problem -- one short dependent chain per thread, the redundant Philox blocks cost nothing
+  const int64_t total = P * s.n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i % s.n;
+    T e;
+    if constexpr (sizeof(T) == 4) e = philox_normal_f32(seed, off, (uint64_t)i);
+    else e = philox_normal_f64(seed, off, (uint64_t)i);
+    const T sp = softplus_t<T>(rho[c]);
+    eps[i] = e;
+    z[i] = loc[c] + sp * e;
+    if (i < s.n) {
+      sc[c] = sp;
+      lo[c] = loc[c];
+    }
+  }
+}
+
+// the same draws for LARGE sites (a plated latent of millions of elements: throughput)
+template <typename T>
+__global__ __launch_bounds__(256) void meanfield_sample_block_kernel(const MfArgs args_by_value,
+                                                               int64_t P, uint64_t seed,
+                                                               const uint64_t* __restrict__ offset_dev,
+                                                               const int64_t* __restrict__ gate) {
+  if (gate != nullptr && *gate != 0) return;        // the step gate gave this replay up (pa_gate)
+  const MfSiteDev s = kernarg_load<MfSiteDev>(offsetof(MfArgs, s) + blockIdx.y * sizeof(MfSiteDev));
+  const uint64_t off = s.offset + (offset_dev ? *offset_dev : 0);
+  const T* loc = (const T*)s.loc;
+  const T* rho = (const T*)s.rho;
+  T* z = (T*)s.z;
+  T* eps = (T*)s.eps;
+  T* sc = (T*)s.scale;
+  T* lo = (T*)s.loc_out;
   const int64_t total = P * s.n;
   // one Philox block per thread and trip: its 4 (f32) / 2 (f64) normals are the draws of PER
   // consecutive elements (philox_normal_f32 / _f64: element i = lane i % PER of block i / PER) -- the

@@ -166,6 +166,30 @@ def test_meanfield_sample_and_backward(gpu, dtype):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=rt, atol=rt * 10)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_meanfield_sample_block_kernel_draws_the_same_numbers(gpu, dtype):
+    """Launches whose largest site has >= 64 K elements take the kernel that draws one Philox block (4
+    f32 / 2 f64 normals) per thread and trip instead of one element per thread: bit for bit the same
+    outputs for every site, whatever element count / block remainder (sizes not multiples of 4)."""
+    from pyro_amd import kernels as k
+
+    rng = np.random.default_rng(6)
+    P = 64
+    small, big = [33, 1, 1001], [33, 1, 1001, 1027]           # 64 x 1027 = 65 728 elements
+    locs = [torch.as_tensor(rng.standard_normal(n), dtype=dtype, device=gpu) for n in big]
+    rhos = [torch.as_tensor(rng.uniform(-3, 25, n), dtype=dtype, device=gpu) for n in big]
+    offsets = [10, 700, 900, 30000]
+    a = k.meanfield_normal_sample(locs[:3], rhos[:3], P, 11, offsets[:3])
+    b = k.meanfield_normal_sample(locs, rhos, P, 11, offsets)
+    for group_a, group_b in zip(a, b):
+        for ta, tb in zip(group_a, group_b[:3]):
+            assert torch.equal(ta, tb)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    ref_eps = o_philox.normal(P * 1027, np_dt, 11, 30000).reshape(P, 1027)
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    np.testing.assert_allclose(b[3][3].cpu().numpy(), ref_eps, rtol=tol, atol=10 * tol)
+
+
 def _logreg_loss_and_grads(gpu, batched, fused_guide, monkeypatch):
     import pyro_amd as pyro
     from pyro_amd import examples
