@@ -437,11 +437,22 @@ int pa_glm_planes_finalize_mode(int in_kernel);
  * atomics (initialise to {UINT64_MAX, 0}); NULL = off.  The kernel's duration inside a captured
  * hipGraph, where HIP events do not time their node (bench.py roofline.kernel_ms). */
 int pa_glm_planes_stamps(void* two_u64);
+/* The label-linear part of the site's log-likelihood is a dot product with two DATA moments,
+ *   sum_n (y_n - 1/2) (x_n . w_p + b_p) = c . w_p + c0 b_p,   c[d] = sum_n (y_n - 1/2) x[n,d],
+ *                                                             c0   = sum_n (y_n - 1/2):
+ * pa_glm_label_moments computes moments[33] = {c[0..31] (0 beyond D), c0} in float64 with a fixed
+ * summation order, once per (X, y) (the host caches it beside the image).  Handed to
+ * pa_glm_bernoulli_planes_fwd_bwd (format F16X2, default tuning) it replaces one fma per (row, particle)
+ * element of the kernel's loop; NULL = the kernel sums the term itself.  The gradient never takes
+ * this route.  (pyro/distributions/torch.py Bernoulli.log_prob = -BCE-with-logits, restated.) */
+size_t pa_glm_label_moments_workspace(int64_t N);
+int pa_glm_label_moments(const float* X, const float* y, int64_t N, int64_t D, double* moments,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream);
 size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P);
 int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float* y, const float* w,
                                     const float* b, double scale, int64_t N, int64_t D, int64_t P,
                                     float* ll, float* gw, float* gb, void* workspace,
-                                    size_t workspace_bytes, pa_stream_t stream);
+                                    size_t workspace_bytes, const double* moments, pa_stream_t stream);
 
 /* Hierarchical variant (BASELINE config 5: logit_n = x_n . w_{g(n)} + b with per-group weights
  * w[P,G,D] under pyro.plate("groups", G)): rows of X are SORTED BY GROUP; the caller describes

@@ -95,6 +95,18 @@ def glm_plane_image(X):
 
 
 # ---- the two-plane scaled f16 image (format PA_GLM_PLANES_F16X2, csrc/glm_planes16.h) -----------
+def label_moments(X, y):
+    """float64[33] = {sum_n (y_n - 1/2) X[n, d] (0 beyond D), sum_n (y_n - 1/2)}: the data moments of
+    the label-linear part of the Bernoulli-logits log-likelihood, sum_n (y_n - 1/2) (x_n . w + b) =
+    c . w + c0 b (pa_glm_label_moments)."""
+    X = np.asarray(X, dtype=np.float64)
+    yh = np.asarray(y, dtype=np.float64) - 0.5
+    out = np.zeros(33)
+    out[:X.shape[1]] = yh @ X
+    out[32] = yh.sum()
+    return out
+
+
 def _f16_exponent_of_bits(bits):
     e = (bits >> 23) & 0xFF
     if bits == 0 or e == 0xFF:

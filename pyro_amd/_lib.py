@@ -141,7 +141,10 @@ _SIGNATURES = {
     "pa_glm_bernoulli_planes_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_glm_bernoulli_planes_fwd_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                                 c_int64, c_int64, c_int64, c_void_p, c_void_p,
-                                                c_void_p, c_void_p, c_size_t, c_void_p]),
+                                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pa_glm_label_moments_workspace": (c_size_t, [c_int64]),
+    "pa_glm_label_moments": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
     "pa_glm_bernoulli_grouped_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_glm_bernoulli_grouped_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_double, c_int64, c_int64, c_int64, c_int64,

@@ -570,16 +570,16 @@ static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
   return pl;
 }
 
-template <int NB, int OCC, bool PRIV = false>
+template <int NB, int OCC, bool PRIV = false, bool LIN = false>
 static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
                             const float* w, const float* b, int64_t N, int D, int P, float* part,
-                            const uint32_t* trailer, hipStream_t s) {
-  auto k = glm_planes_f16_kernel<NB, OCC, false, PRIV>;
+                            const uint32_t* trailer, hipStream_t s, const double* moments = nullptr) {
+  auto k = glm_planes_f16_kernel<NB, OCC, false, PRIV, LIN>;
   constexpr int lds = GlmHCfg<NB, PRIV>::LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
                      b, N, D, P, pl.nst, part, cu_count(), trailer, g_planes_stamps,
-                     GlmGroupArgs{nullptr, nullptr, 1}, gate_word());
+                     GlmGroupArgs{nullptr, nullptr, 1}, gate_word(), moments);
   gate_aware_launch();
 }
 
@@ -611,7 +611,8 @@ static void glmh_launch_grouped(int nseg, int npass, const unsigned char* img, c
   constexpr int lds = GlmHCfg<3>::LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)npass), dim3(256), lds, s, img, y_img, w, b, N,
-                     D, P, nst_total, part, cu_count(), trailer, g_planes_stamps, grp, gate_word());
+                     D, P, nst_total, part, cu_count(), trailer, g_planes_stamps, grp, gate_word(),
+                     (const double*)nullptr);
   gate_aware_launch();
 }
 
@@ -988,10 +989,38 @@ size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P) {
          (size_t)pl.npass * pa::GLMF_GROUPS * rec * sizeof(double);
 }
 
+size_t pa_glm_label_moments_workspace(int64_t N) {
+  if (N < 0) return 0;
+  int64_t grid = (N + 63) / 64;
+  const int64_t cap = (int64_t)pa::cu_count() * 4;
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  return (size_t)grid * 33 * sizeof(double);
+}
+
+int pa_glm_label_moments(const float* X, const float* y, int64_t N, int64_t D, double* moments,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  PA_REQUIRE(N >= 0 && D >= 1 && D <= 32, "glm_label_moments: bad shape N=%lld D=%lld", (long long)N,
+             (long long)D);
+  PA_REQUIRE(moments != nullptr && (N == 0 || (X && y)), "glm_label_moments: NULL pointer");
+  PA_REQUIRE(workspace && workspace_bytes >= pa_glm_label_moments_workspace(N),
+             "glm_label_moments: workspace too small");
+  const int nblocks = (int)(pa_glm_label_moments_workspace(N) / (33 * sizeof(double)));
+  hipStream_t s = pa::as_stream(stream);
+  hipLaunchKernelGGL(pa::glm_label_moments_partial_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, X, y,
+                     N, (int)D, (double*)workspace);
+  int rc = pa::check_launch("glm_label_moments_partial_kernel");
+  if (rc != PA_OK) return rc;
+  hipLaunchKernelGGL(pa::glm_label_moments_final_kernel, dim3(1), dim3(64), 0, s,
+                     (const double*)workspace, nblocks, moments);
+  return pa::check_launch("glm_label_moments_final_kernel");
+}
+
 int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float* y, const float* w,
                                     const float* b, double scale, int64_t N, int64_t D, int64_t P,
                                     float* ll, float* gw, float* gb, void* workspace,
-                                    size_t workspace_bytes, pa_stream_t stream) {
+                                    size_t workspace_bytes, const double* moments,
+                                    pa_stream_t stream) {
   PA_REQUIRE(N >= 0 && D >= 1 && P >= 1, "glm_planes: bad shape N=%lld D=%lld P=%lld", (long long)N,
              (long long)D, (long long)P);
   if (D > 32)
@@ -1048,6 +1077,8 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
     else if (pl.nb == 6) pa::glmh_launch_one<4, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.nb == 4) pa::glmh_launch_one<4, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.bpc >= 4) pa::glmh_launch_one<3, 4>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    else if (moments != nullptr)
+      pa::glmh_launch_one<3, 3, false, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, moments);
     else pa::glmh_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
   } else if (pl.nb == 3) {
     pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);

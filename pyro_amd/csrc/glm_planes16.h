@@ -81,6 +81,39 @@ __global__ __launch_bounds__(256) void glm_absmax_kernel(const float* __restrict
   if ((threadIdx.x & 63) < 32 && d < D && m != 0u) atomicMax(out + d, m);
 }
 
+// ---- data moments of the label-linear term (LIN above): c[d] = sum_n (y_n - 1/2) x[n,d], c[32] = sum_n
+//      (y_n - 1/2); float64, fixed order: per-workgroup partials [grid][33], then one workgroup adds
+//      them in index order (a pure function of (X, y): bit-reproducible) ---------------------------------
+__global__ __launch_bounds__(256) void glm_label_moments_partial_kernel(const float* __restrict__ X,
+                                                                        const float* __restrict__ y,
+                                                                        int64_t N, int D,
+                                                                        double* __restrict__ part) {
+  __shared__ double sm[8][33];
+  const int d = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  double acc = 0.0, acc0 = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 8 + r0; r < N; r += (int64_t)gridDim.x * 8) {
+    const double yh = (double)y[r] - 0.5;
+    if (d < D) acc = __builtin_fma(yh, (double)X[r * D + d], acc);
+    if (d == 0) acc0 += yh;
+  }
+  sm[r0][d] = acc;
+  if (d == 0) sm[r0][32] = acc0;
+  __syncthreads();
+  if (threadIdx.x < 33) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
+    part[(int64_t)blockIdx.x * 33 + threadIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(64) void glm_label_moments_final_kernel(const double* __restrict__ part,
+                                                                     int nblocks, double* __restrict__ out) {
+  if (threadIdx.x >= 33) return;
+  double t = 0.0;
+  for (int k = 0; k < nblocks; ++k) t += part[(int64_t)k * 33 + threadIdx.x];
+  out[threadIdx.x] = t;
+}
+
 // (a, b) -> hi and lo f16 pairs, a ~= a1 + a2 to 2^-22 |a| (RN at both levels).  The residual
 // a - a1 is exact in f32 and goes straight to its f16 half: one v_fma_mixlo_f16 / v_fma_mixhi_f16 per
 // element (f16 piece times -1 plus the f32 value, rounded once to f16), 3 instructions per pair
@@ -202,13 +235,18 @@ __device__ __forceinline__ f32x16v glmh_keep(const f16x8& a, const f16x8& b, con
 #define GLMH_MFMA2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
 
-template <int NB, int OCC, bool GROUPED = false, bool PRIV = false>
+// LIN: the label-linear part of the log-likelihood, sum_n (y_n - 1/2) l[n,p] = c . w_p + c0 b_p with the
+// data moments c[d] = sum_n (y_n - 1/2) x[n,d], c0 = sum_n (y_n - 1/2) (pa_glm_label_moments: float64,
+// once per (X, y)), is added by workgroup 0 of each pass in the epilogue instead of one fma per (row,
+// particle) element in the loop.  Only the log-likelihood takes this route: the gradient keeps
+// g = y - sigmoid(l) element by element (near the optimum g is small where sigmoid - 1/2 is not).
+template <int NB, int OCC, bool GROUPED = false, bool PRIV = false, bool LIN = false>
 __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
     const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
     int64_t nst, float* __restrict__ part, int prio_cus, const uint32_t* __restrict__ trailer,
     unsigned long long* __restrict__ tstamps, const GlmGroupArgs grp,
-    const int64_t* __restrict__ gate) {
+    const int64_t* __restrict__ gate, const double* __restrict__ moments = nullptr) {
   if (gate != nullptr && *gate != 0) return;        // the step gate gave this replay up (pa_gate)
   using C = GlmHCfg<NB, PRIV>;
   constexpr int NRT = C::NRT, NPT = C::NPT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS,
@@ -381,7 +419,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const float t = e + 1.0f;
     const float inv = __builtin_amdgcn_rcpf(t);
 #endif
-    s_yl[par] = __builtin_fmaf(yh, l2, s_yl[par]);
+    if constexpr (!LIN) s_yl[par] = __builtin_fmaf(yh, l2, s_yl[par]);
     // (spelled out: left to itself the compiler sometimes materialises |l2| with a v_and first)
     asm("v_add_f32 %0, |%1|, %0" : "+v"(s_abs[par]) : "v"(l2));
     p_t[par] *= t;
@@ -595,7 +633,17 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   for (int i = threadIdx.x; i < NPT * 1024; i += 256) rec[i] = red[i];
   for (int i = threadIdx.x; i < 2 * NPT * 32; i += 256) {
     const int qq = i >> 5, j = i & 31;
-    rec[NPT * 1024 + i] = red2[qq * 64 + j] + red2[qq * 64 + 32 + j];
+    float v = red2[qq * 64 + j] + red2[qq * 64 + 32 + j];
+    if constexpr (LIN) {
+      // workgroup 0 of the pass: + c . w_p + c0 b_p (natural-log units, float64) on the ll slots
+      const int p = pbase + (qq >> 1) * 32 + j;
+      if (blockIdx.x == 0 && (qq & 1) == 0 && p < P) {
+        double lin = b != nullptr ? moments[32] * (double)b[p] : 0.0;
+        for (int d = 0; d < D; ++d) lin = __builtin_fma(moments[d], (double)w[(int64_t)p * w_stride + d], lin);
+        v += (float)lin;
+      }
+    }
+    rec[NPT * 1024 + i] = v;
   }
   if (tstamps != nullptr && threadIdx.x == 0)
     __hip_atomic_fetch_max(&tstamps[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED,

@@ -606,6 +606,7 @@ static int nuts_dispatch(const RunPtrs<T>& p, int C, int D, int max_depth, int m
       if (D <= 32) nuts_launch_reg<32>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
       else if (D <= 64) nuts_launch_reg<64>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
       else if (D <= 96) nuts_launch_reg<96>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
+      else if (D <= 100) nuts_launch_reg<100>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
       else if (D <= 104) nuts_launch_reg<104>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
       else nuts_launch_reg<128>(p, C, D, max_depth, multinomial, seed, t0, chain_offset, ra, s);
     } else {

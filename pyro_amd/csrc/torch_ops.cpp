@@ -57,7 +57,8 @@ at::Tensor glm_pack_planes(const at::Tensor& X, int64_t format) {
 // in ws when the chain is flushed, after this function has returned
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> glm_bernoulli_planes(
     const at::Tensor& planes, const at::Tensor& y, const at::Tensor& w,
-    const std::optional<at::Tensor>& b, double scale, int64_t N, int64_t D, int64_t format) {
+    const std::optional<at::Tensor>& b, double scale, int64_t N, int64_t D, int64_t format,
+    const std::optional<at::Tensor>& moments) {
   require_f32_gpu(y, "y");
   require_f32_gpu(w, "w");
   TORCH_CHECK(planes.is_cuda() && planes.scalar_type() == at::kByte, "pyro_amd: planes must be a uint8 image");
@@ -73,10 +74,16 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> glm_bernoulli_planes(
   at::Tensor ws = at::empty({(int64_t)ws_bytes}, w.options().dtype(at::kByte));
   at::Tensor ll = at::empty({P}, w.options()), gw = at::empty({P, D}, w.options()),
              gb = at::empty({P}, w.options());
+  const double* mom = nullptr;          // pa_glm_label_moments of (X, y), float64[33] (or none)
+  if (moments.has_value() && moments->defined()) {
+    TORCH_CHECK(moments->is_cuda() && moments->scalar_type() == at::kDouble && moments->numel() == 33 &&
+                    moments->is_contiguous(), "pyro_amd::glm_bernoulli_planes: moments = float64[33]");
+    mom = moments->data_ptr<double>();
+  }
   check(pa_glm_bernoulli_planes_fwd_bwd((int)format, planes.data_ptr(), y.data_ptr<float>(),
                                         w.data_ptr<float>(), f32_ptr(b), scale, N, D, P,
                                         ll.data_ptr<float>(), gw.data_ptr<float>(), gb.data_ptr<float>(),
-                                        ws.data_ptr(), ws_bytes, current_stream()),
+                                        ws.data_ptr(), ws_bytes, mom, current_stream()),
         "glm_bernoulli_planes");
   return {ll, gw, gb, ws};
 }
@@ -152,7 +159,7 @@ void adam_step(at::Tensor param, at::Tensor grad, at::Tensor exp_avg, at::Tensor
 TORCH_LIBRARY(pyro_amd, m) {
   m.def("glm_pack_planes(Tensor X, int format) -> Tensor");
   m.def("glm_bernoulli_planes(Tensor planes, Tensor y, Tensor w, Tensor? b, float scale, int N, int D, "
-        "int format) -> (Tensor, Tensor, Tensor, Tensor)");
+        "int format, Tensor? moments=None) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("glm_bernoulli(Tensor X, Tensor y, Tensor w, Tensor? b, Tensor? mask, float scale) -> "
         "(Tensor, Tensor, Tensor, Tensor)");
   m.def("adam_step(Tensor(a!) param, Tensor(b!) grad, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, "

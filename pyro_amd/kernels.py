@@ -815,9 +815,89 @@ def _planes_entry_of(X):
     if ent is None:
         import weakref
         ent = [weakref.ref(base, lambda _r, k=key: _planes_cache.pop(k, None)), X._version, None, 0,
-               (X.storage_offset(), tuple(X.shape), tuple(X.stride()))]
+               (X.storage_offset(), tuple(X.shape), tuple(X.stride())), {}]
         _planes_cache[key] = ent
     return ent
+
+
+# ---- label moments (include/pyro_amd.h pa_glm_label_moments): cached per (image of X, y) -------------
+LABEL_MOMENTS = {"on": os.environ.get("PYRO_AMD_GLM_LABEL_MOMENTS", "1") != "0"}
+
+
+def glm_label_moments(X, y, out=None):
+    """float64[33] = {sum_n (y_n - 1/2) X[n, d] for d < 32 (0 beyond D), sum_n (y_n - 1/2)}."""
+    _require_gpu(X, y)
+    N, D = X.shape
+    assert X.is_contiguous() and y.is_contiguous() and X.dtype == torch.float32 and y.dtype == torch.float32
+    lib = _lib.load()
+    nbytes = lib.pa_glm_label_moments_workspace(N)
+    ws = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=X.device)
+    if out is None:
+        out = torch.empty((33,), dtype=torch.float64, device=X.device)
+    check(lib.pa_glm_label_moments(_ptr(X), _ptr(y), N, D, _ptr(out), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+def glm_label_moments_of(X, y):
+    """The cached moments of (X, y) for the plane-image kernel, or None (no f16 image of X yet, inside
+    a capture without a cached entry, labels that change from call to call, switched off)."""
+    if not LABEL_MOMENTS["on"] or _planes_format != GLM_PLANES_F16X2 or _planes_mode == GLM_PLANES_OFF:
+        return None
+    if not (X.is_contiguous() and y.is_contiguous() and y.dtype == torch.float32):
+        return None
+    ent = _planes_entry_of(X)
+    if ent[2] is None or _format_of(ent[2]) != GLM_PLANES_F16X2:
+        return None
+    cache = ent[5]
+    ybase = y._base if y._base is not None else y
+    key = (id(ybase), y.storage_offset(), tuple(y.shape), tuple(y.stride()))
+    m = cache.get(key)
+    if m is not None and m[0]() is not ybase:
+        m = None
+    capturing = torch.cuda.is_current_stream_capturing()
+    if m is None:
+        if capturing or cache.get("misses", 0) > 8:
+            return None                       # (labels that keep changing: the kernel sums the term itself)
+        import weakref
+        cache["misses"] = cache.get("misses", 0) + 1
+        for k in [k for k in cache if k != "misses"][:-3]:
+            cache.pop(k, None)
+        m = [weakref.ref(ybase), y._version, X._version, glm_label_moments(X, y),
+             (y.storage_offset(), tuple(y.shape), tuple(y.stride()))]
+        cache[key] = m
+        return m[3]
+    if m[1] != y._version or m[2] != X._version:
+        if capturing:
+            raise RuntimeError("pyro_amd: the observations of a GLM site changed in place during a graph capture")
+        glm_label_moments(X, y, out=m[3])
+        m[1], m[2] = y._version, X._version
+    return m[3]
+
+
+def _label_moments_stale(ent):
+    base = ent[0]()
+    for k, m in ent[5].items():
+        if k == "misses":
+            continue
+        yb = m[0]()
+        if base is not None and yb is not None and (m[1] != yb._version or m[2] != base._version):
+            return True
+    return False
+
+
+def _label_moments_refresh(ent):
+    base = ent[0]()
+    if base is None:
+        return
+    off, shape, stride = ent[4]
+    for k, m in list(ent[5].items()):
+        if k == "misses":
+            continue
+        yb = m[0]()
+        if yb is not None and (m[1] != yb._version or m[2] != base._version):
+            yo, ys, yst = m[4]
+            glm_label_moments(base.as_strided(shape, stride, off), yb.as_strided(ys, yst, yo), out=m[3])
+            m[1], m[2] = yb._version, base._version
 
 
 def glm_planes_of(X):
@@ -870,6 +950,8 @@ def glm_planes_revalidate():
             off, shape, stride = ent[4]
             glm_pack_planes(base.as_strided(shape, stride, off), out=ent[2])
             ent[1] = base._version
+        if len(ent[5]) > 0 and _label_moments_stale(ent):
+            _label_moments_refresh(ent)           # (the captured step reads the moments, not y)
     for segs in list(_grouped_with_image):
         ent = segs._planes
         if ent is None or ent[4] is None:
@@ -891,6 +973,8 @@ def revalidate_pending():
         base = ent[0]()
         if base is not None and ent[2] is not None and ent[1] != base._version:
             return True
+        if len(ent[5]) > 0 and _label_moments_stale(ent):
+            return True
     for segs in list(_grouped_with_image):
         ent = segs._planes
         if ent is None or ent[4] is None:
@@ -908,9 +992,10 @@ def revalidate_pending():
     return False
 
 
-def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D):
-    """planes = glm_pack_planes(X[N,D]), y[N], w[P,D], b[P] or None -> (ll[P], gw[P,D], gb[P])."""
-    _require_gpu(planes, y, w, b)
+def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D, moments=None):
+    """planes = glm_pack_planes(X[N,D]), y[N], w[P,D], b[P] or None -> (ll[P], gw[P,D], gb[P]).
+    ``moments``: glm_label_moments(X, y) (f16 image, default tuning) or None."""
+    _require_gpu(planes, y, w, b, moments)
     P = w.shape[0]
     assert y.is_contiguous() and w.is_contiguous() and y.shape == (N,) and w.shape == (P, D)
     assert y.dtype == torch.float32 and w.dtype == torch.float32
@@ -926,7 +1011,7 @@ def glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D):
     gb = torch.empty((P,), dtype=w.dtype, device=y.device)
     check(lib.pa_glm_bernoulli_planes_fwd_bwd(_format_of(planes), _ptr(planes), _ptr(y), _ptr(w), _ptr(b), float(scale),
                                               N, D, P, _ptr(ll), _ptr(gw), _ptr(gb), _ptr(ws),
-                                              nbytes, _stream()))
+                                              nbytes, _ptr(moments), _stream()))
     return ll, gw, gb
 
 
@@ -948,7 +1033,8 @@ def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
             and _glm_variant == GLM_AUTO):
         planes = glm_planes_of(X)
         if planes is not None:
-            return glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D)
+            return glm_bernoulli_planes_fwd_bwd(planes, y, w, b, scale, N, D,
+                                                moments=glm_label_moments_of(X, y))
     lib = _lib.load()
     nbytes = lib.pa_glm_bernoulli_workspace(N, D, P)
     if nbytes == 0:

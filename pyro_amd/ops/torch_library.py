@@ -63,7 +63,7 @@ def _register():
                 w.new_empty((max(int(nbytes), 1),), dtype=torch.uint8))
 
     @lib.register_fake("pyro_amd::glm_bernoulli_planes")
-    def _(planes, y, w, b, scale, N, D, format):
+    def _(planes, y, w, b, scale, N, D, format, moments=None):
         return _four(w, _lib.load().pa_glm_bernoulli_planes_workspace(int(N), int(D), w.shape[0]))
 
     @lib.register_fake("pyro_amd::glm_bernoulli")
@@ -92,8 +92,8 @@ def _register():
 
     def backward_planes(ctx, g_ll, g_gw, g_gb, g_ws):
         dw, db = _grads(ctx, g_ll)
-        # (planes, y, w, b, scale, N, D, format)
-        return None, None, dw, db, None, None, None, None
+        # (planes, y, w, b, scale, N, D, format, moments)
+        return None, None, dw, db, None, None, None, None, None
 
     def backward_plain(ctx, g_ll, g_gw, g_gb, g_ws):
         dw, db = _grads(ctx, g_ll)
@@ -115,10 +115,12 @@ def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
     try:
         N, D = int(X.shape[0]), int(X.shape[1])
         P = int(w.shape[0])
-        planes = None
+        planes = moments = None
         if (mask is None and D <= kernels._PLANES_MAX_D and P >= kernels._PLANES_MIN_P and N > 0
                 and kernels._glm_variant == kernels.GLM_AUTO):
             planes = kernels.glm_planes_of(X)
+            if planes is not None:
+                moments = kernels.glm_label_moments_of(X, y)
     finally:
         torch._C._set_tracing_state(state)
     y = y.contiguous()
@@ -126,7 +128,7 @@ def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
     b = b.contiguous() if b is not None else None
     if planes is not None:
         out = torch.ops.pyro_amd.glm_bernoulli_planes(planes, y, w, b, float(scale), N, D,
-                                                      kernels._format_of(planes))
+                                                      kernels._format_of(planes), moments)
     else:
         if mask is not None:
             mask = mask.contiguous()

@@ -1484,3 +1484,72 @@ def test_layers_after_the_bag_of_words_layer_take_the_tall_weight_gradient(gpu):
     for a, b in zip(res[2][1], res[0][1]):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max()) + 1e-10)
 
+
+
+# ---- label moments: the (y - 1/2) . l part of the log-likelihood as a dot product with data moments ----
+@pytest.mark.parametrize("N,D", [(1, 1), (63, 7), (5000, 32), (100_003, 20)])
+def test_glm_label_moments_equal_the_oracle(gpu, N, D):
+    k = _k()
+    rng = np.random.default_rng(N + D)
+    X = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-3, 3, (1, D)))).astype(np.float32)
+    y = (rng.uniform(size=N) < 0.3).astype(np.float32)
+    got = k.glm_label_moments(tt(X, gpu), tt(y, gpu)).cpu().numpy()
+    ref = o_glm.label_moments(X, y)
+    scale = np.abs(np.asarray(X, np.float64)).sum(0).max() + 1.0
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13 * scale)
+    again = k.glm_label_moments(tt(X, gpu), tt(y, gpu)).cpu().numpy()
+    assert np.array_equal(got, again)                        # fixed summation order
+
+
+@pytest.mark.parametrize("N,D,P,use_bias", [(4099, 32, 64, True), (70000, 17, 100, True), (2048, 32, 33, False)])
+def test_glm_planes_with_label_moments(gpu, N, D, P, use_bias):
+    """pa_glm_bernoulli_planes_fwd_bwd with the moments of (X, y): the gradient outputs are bit for bit
+    those of the kernel that sums the label-linear term itself (the gradient never takes the moments
+    route), the log-likelihood agrees with it and with the float64 oracle."""
+    k = _k()
+    rng = np.random.default_rng(N + P)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (rng.standard_normal((P, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32) if use_bias else None
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    tX, ty, tw = tt(X, gpu), tt(y, gpu), tt(w, gpu)
+    tb = tt(b, gpu) if use_bias else None
+    planes = k.glm_pack_planes(tX, fmt=k.GLM_PLANES_F16X2)
+    plain = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 1.5, N, D)
+    mom = k.glm_label_moments(tX, ty)
+    lin = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 1.5, N, D, moments=mom)
+    assert torch.equal(plain[1], lin[1]) and torch.equal(plain[2], lin[2])
+    ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 1.5)
+    sc = max(1.0, float(np.abs(ref[0]).max()))
+    np.testing.assert_allclose(lin[0].cpu().numpy(), ref[0], rtol=2e-5, atol=2e-5 * sc)
+    np.testing.assert_allclose(lin[0].cpu().numpy(), plain[0].cpu().numpy(), rtol=2e-6, atol=2e-6 * sc)
+    e_lin = float(np.abs(lin[0].cpu().numpy() - ref[0]).max())
+    e_plain = float(np.abs(plain[0].cpu().numpy() - ref[0]).max())
+    assert e_lin <= 2 * e_plain + 1e-6 * sc, (e_lin, e_plain)
+
+
+def test_glm_label_moments_follow_the_tensors(gpu):
+    """kernels.glm_label_moments_of: cached per (image of X, y); labels written in place are picked up
+    by the revalidate hook (the buffer a captured step reads is refreshed, not replaced)."""
+    k = _k()
+    rng = np.random.default_rng(3)
+    N, D, P = 5000, 32, 64
+    X = tt(rng.standard_normal((N, D)).astype(np.float32), gpu)
+    y = tt((rng.uniform(size=N) < 0.5).astype(np.float32), gpu)
+    w = tt((rng.standard_normal((P, D)) * 0.2).astype(np.float32), gpu)
+    assert k.glm_label_moments_of(X, y) is None                    # no image yet
+    k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
+    k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)              # second sighting: image + moments
+    m = k.glm_label_moments_of(X, y)
+    assert m is not None and m is k.glm_label_moments_of(X, y)
+    ref = o_glm.label_moments(X.cpu().numpy(), y.cpu().numpy())
+    np.testing.assert_allclose(m.cpu().numpy(), ref, rtol=1e-12, atol=1e-9)
+    y.copy_(1.0 - y)                                               # new labels in the same tensor
+    assert k.revalidate_pending()
+    k.glm_planes_revalidate()
+    assert not k.revalidate_pending()
+    assert k.glm_label_moments_of(X, y) is m                       # same buffer, new content
+    np.testing.assert_allclose(m.cpu().numpy(), -ref, rtol=1e-12, atol=1e-9)
+    got = k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
+    want = o_glm.glm_bernoulli_fwd_bwd(X.cpu().numpy(), y.cpu().numpy(), w.cpu().numpy(), None, None, 1.0)
+    np.testing.assert_allclose(got[0].cpu().numpy(), want[0], rtol=2e-5)
