@@ -427,6 +427,34 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     s_g[par] += g;
     return g;
   };
+  // two elements at once: ONE reciprocal serves both -- r = 1 / (t0 t1), 1 / t0 = r t1, 1 / t1 = r t0 --
+  // and the product t0 t1 is also what the log-sum chain multiplies in: per pair one transcendental
+  // and the two chain multiplies become four plain multiplies (transcendentals issue at a quarter
+  // of the plain rate).  t in [1, 2]: no range issue; two more roundings per sigmoid (~2.5 ulp).
+  auto elem2 = [&](float acc0, float acc1, float yh0, float yh1, int chain, float& g0, float& g1) {
+#if defined(PA_GLMH_ABL_NOELEM) || defined(PA_GLMH_ABL_NOTRANS)
+    g0 = elem1(acc0, yh0, 0);
+    g1 = elem1(acc1, yh1, 1);
+    return;
+#endif
+    const float l0 = acc0 * dsc, l1 = acc1 * dsc;
+    const float t0 = __builtin_amdgcn_exp2f(-__builtin_fabsf(l0)) + 1.0f;
+    const float t1 = __builtin_amdgcn_exp2f(-__builtin_fabsf(l1)) + 1.0f;
+    const float tt = t0 * t1;
+    const float r = __builtin_amdgcn_rcpf(tt);
+    const float inv0 = r * t1, inv1 = r * t0;
+    if constexpr (!LIN) {
+      s_yl[0] = __builtin_fmaf(yh0, l0, s_yl[0]);
+      s_yl[1] = __builtin_fmaf(yh1, l1, s_yl[1]);
+    }
+    asm("v_add_f32 %0, |%1|, %0" : "+v"(s_abs[0]) : "v"(l0));
+    asm("v_add_f32 %0, |%1|, %0" : "+v"(s_abs[1]) : "v"(l1));
+    p_t[chain] *= tt;
+    g0 = yh0 - __builtin_copysignf(__builtin_fmaf(inv0, GLMH_GSCALE, -0.5f * GLMH_GSCALE), l0);
+    g1 = yh1 - __builtin_copysignf(__builtin_fmaf(inv1, GLMH_GSCALE, -0.5f * GLMH_GSCALE), l1);
+    s_g[0] += g0;
+    s_g[1] += g1;
+  };
   // (1 + e <= 2: the mantissa product of 8 tiles x 8 factors per chain stays below 2^64; its
   //  exponent is harvested every 8th tile and after the loop -- the rounding of the product is
   //  relative whatever its magnitude)
@@ -542,16 +570,14 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       acc_nxt = GLMH_MFMA1(xa[TA[t]], wa0[TB[t]], acc_nxt);
-      g[2 * t] = elem1(acc_cur[2 * t], yv[2 * t], 0);
-      g[2 * t + 1] = elem1(acc_cur[2 * t + 1], yv[2 * t + 1], 1);
+      elem2(acc_cur[2 * t], acc_cur[2 * t + 1], yv[2 * t], yv[2 * t + 1], t & 1, g[2 * t], g[2 * t + 1]);
     }
     load_a(Xn, 1, xa);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       acc_nxt = GLMH_MFMA1(xa[TA[t]], wa1[TB[t]], acc_nxt);
       if (t == 0) {
-        g[6] = elem1(acc_cur[6], yv[6], 0);
-        g[7] = elem1(acc_cur[7], yv[7], 1);
+        elem2(acc_cur[6], acc_cur[7], yv[6], yv[7], 1, g[6], g[7]);
       } else {
         split_pair_f16(g[4 * (t - 1)], g[4 * (t - 1) + 1], g1[2 * (t - 1)], g2[2 * (t - 1)]);
         split_pair_f16(g[4 * (t - 1) + 2], g[4 * (t - 1) + 3], g1[2 * (t - 1) + 1], g2[2 * (t - 1) + 1]);
@@ -566,9 +592,12 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
-        const int e0 = t == 0 ? 0 : (t == 1 ? 3 : 6), e1 = t == 2 ? 8 : e0 + 3;
+        // (pairs 0, 1 | 2 | 3 of the K half beside the three MFMAs)
+        const int q0 = t == 0 ? 0 : t + 1, q1 = t == 0 ? 2 : t + 2;
 #pragma unroll
-        for (int j = e0; j < e1; ++j) g[j] = elem1(acc_cur[8 + j], yv[j], j & 1);
+        for (int qp = q0; qp < q1; ++qp)
+          elem2(acc_cur[8 + 2 * qp], acc_cur[9 + 2 * qp], yv[2 * qp], yv[2 * qp + 1], qp & 1, g[2 * qp],
+                g[2 * qp + 1]);
       }
     }
     uint32_t h1[4], h2[4];
