@@ -340,7 +340,9 @@ def main():
     clock = kernels.GlmDeviceClock(dev) if on_gpu else None
     # prearm: step k+1's replay is enqueued (behind a gate node) while step k executes, and released
     # by the next step() call -- SVI.step per step, loss returned per step (pyro_amd/infer/svi.py)
-    prearm = use_graph and world == 1 and not args.no_prearm
+    # (blocks shorter than 100 steps: every block ends in a synchronisation that has to sit out the
+    #  armed replay's patience, which costs what the overlap buys -- plain replays there)
+    prearm = use_graph and world == 1 and not args.no_prearm and args.steps >= 100
     svi = SVI(examples.logreg_model, guide, optim,
               Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
               hip_graph=use_graph, graph_warmup=2, prearm=prearm)

@@ -149,7 +149,7 @@ class SVI:
         # step() calls with the same arguments nothing is enqueued on the device that the step must
         # see or that must see the step -- in-place writes to the step's ARGUMENT tensors and to
         # parameters are noticed (the armed replay is cancelled), other device work is not; a host that
-        # stays away longer than the gate's patience (100 us) finds the replay given up and the step
+        # stays away longer than the gate's patience (40 us) finds the replay given up and the step
         # runs the ordinary way.  Only steps whose every node can be given up are armed.
         self.prearm = bool(prearm) and _os.environ.get("PYRO_AMD_PREARM", "1") != "0"
         self._armed_fast = None     # (entry, argument objects, their key) of the armed replay

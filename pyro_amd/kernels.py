@@ -279,9 +279,11 @@ def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
 class StepGate:
     """The device / pinned-host words of one captured step's gate (include/pyro_amd.h "the step gate"):
     a replay enqueued ahead of time waits in its first node until the host writes its number into
-    ``go`` -- or gives itself up after ``timeout_us`` and changes nothing."""
+    ``go`` -- or gives itself up after ``timeout_us`` and changes nothing.  40 us: several times what a
+    host loop needs to come back (3-8 us), short enough that a stream synchronisation right after a
+    step -- which has to sit out the armed replay's patience -- costs little."""
 
-    def __init__(self, device, timeout_us=100):
+    def __init__(self, device, timeout_us=40):
         self.gate = torch.zeros((2,), dtype=torch.int64, device=device)     # {last step run, abort}
         self.go = torch.zeros((1,), dtype=torch.int64).pin_memory()
         self.ack = torch.zeros((1,), dtype=torch.int64).pin_memory()

@@ -254,7 +254,7 @@ def test_prearmed_steps_are_bitwise_the_ordinary_ones(gpu):
 
 
 def test_gate_gives_a_replay_up_when_the_host_stays_away(gpu):
-    """The host sleeps between steps (longer than the gate's 100 us): the armed replay has given
+    """The host sleeps between steps (longer than the gate's 40 us): the armed replay has given
     itself up, the step runs the ordinary way, arming backs off -- same trajectory."""
     import time
 
