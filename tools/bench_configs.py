@@ -232,9 +232,41 @@ def config4(dev, docs=100_000, steps=10, batch_size=None):
     return out
 
 
+def _step_composition(cfg):
+    """Launch count and the largest kernels of one step from the latest committed one-step trace
+    (profiles/rNN_cfg<cfg>_step_trace.txt, tools/trace_cfg.sh): what the step is made of when no single
+    kernel dominates it."""
+    import glob
+    import os
+    import re
+    from collections import defaultdict
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                          "r*_cfg%d_step_trace.txt" % cfg)))
+    if not paths:
+        return None
+    agg, n, tot, span = defaultdict(lambda: [0, 0.0]), 0, 0.0, None
+    for ln in open(paths[-1]):
+        m = re.match(r"\s*([\d.]+) us\s+([\d.]+) us\s+(.*)", ln)
+        if m:
+            name = re.sub(r"^void ", "", m.group(3).strip()).split("(")[0].split("<")[0]
+            agg[name][0] += 1
+            agg[name][1] += float(m.group(2))
+            n += 1
+            tot += float(m.group(2))
+        m = re.match(r"step span ([\d.]+) us", ln)
+        if m:
+            span = float(m.group(1))
+    top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]
+    return {"source": "profiles/" + os.path.basename(paths[-1]) + " (rocprofv3 --kernel-trace of one captured step)",
+            "launches": n, "kernel_time_us": round(tot, 1), "step_span_us_under_the_tracer": span,
+            "largest": [{"kernel": k, "launches": c, "us": round(t, 1), "share_of_kernel_time": round(t / tot, 3)}
+                        for k, (c, t) in top]}
+
+
 def _config4_roofline(data, args, predictor, dt):
-    """The step's longest kernel: the first layer of the amortised guide on the corpus's cached
-    bag-of-words image (pa_bow_linear_fwd), timed stand-alone on the same operands with HIP events."""
+    """No kernel dominates this step (the largest is 7 % of it: ``step_composition``); the block prices
+    the first layer of the amortised guide on the corpus's cached bag-of-words image (pa_bow_linear_fwd),
+    timed stand-alone on the same operands with HIP events."""
     V = args.num_words
     imgs = kernels.bow_images_of(data, V)
     if imgs is None:
@@ -258,7 +290,9 @@ def _config4_roofline(data, args, predictor, dt):
             "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
             "traffic": _committed_traffic(4, "bow_linear_fwd_kernel"),
             "traffic_source": "profiles/%s (rocprofv3 --pmc, tools/pmc_cfg.sh)" % __import__("os").path.basename(_traffic_path(4)),
-            "share_of_step": k_ms / (dt * 1e3)}
+            "share_of_step": k_ms / (dt * 1e3),
+            "note": "a flat step: 153 launches, the largest kernel 7 % of it -- see step_composition",
+            "step_composition": _step_composition(4)}
 
 
 if __name__ == "__main__":
