@@ -822,6 +822,9 @@ int pa_chain_pending(void);
  * of exactly one mean-field site and the sites' parameters tile the optimizer's flat buffer, the
  * assembly / guide-backward / Adam phases run per site inside one workgroup each (no device-wide
  * barrier between them); 0: always the generic phase-by-phase form.  Same results either way.
+ * Bit 2 (value 4): the guide draw in front of a plane-image GLM launch stays its own launch (default: inside a
+ * recording pa_meanfield_normal_sample parks its launch and the GLM kernel whose weights / bias are two of its
+ * sites' draws makes them in its own prologue -- the same numbers, one graph node less).
  * Bits 8 and up: race hunting -- a non-zero seed makes every workgroup of the chain kernels sleep a
  * pseudo-random 0..17 us in front of each phase arrival and after each phase wait, which shuffles the
  * order of the device-wide arrivals (the kernels must give bit-identical results under any seed). */

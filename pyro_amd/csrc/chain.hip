@@ -634,7 +634,83 @@ int chain_record_adam(pa_stream_t stream, float* p, float* g, float* m, float* v
 
 // every launcher of the library converts its stream argument here: whatever it is about to launch
 // may read what the pending phases write, so they go first
+// ---- the parked guide draw (chain.h) -------------------------------------------------------------------
+struct PendingDraw {
+  bool have = false;
+  MfArgs args;
+  int nsites = 0;
+  int64_t P = 0;
+  uint64_t seed = 0;
+  const uint64_t* offset_dev = nullptr;
+};
+static PendingDraw g_draw;
+static int g_draw_enabled = 1;            // pa_chain_tune bit 2 switches the fusion off
+
+// the launch of multisite.hip (defined there): the draw as its own kernel
+int meanfield_sample_launch(const MfArgs& args, int nsites, int64_t P, uint64_t seed,
+                            const uint64_t* offset_dev, hipStream_t s);
+
+int chain_flush_draw() {
+  if (!g_draw.have) return PA_OK;
+  g_draw.have = false;
+  return meanfield_sample_launch(g_draw.args, g_draw.nsites, g_draw.P, g_draw.seed, g_draw.offset_dev,
+                                 g_chain.stream);
+}
+
+int chain_park_draw(pa_stream_t stream, const MfArgs& args, int nsites, int64_t P, uint64_t seed,
+                    const uint64_t* offset_dev) {
+  if (!g_chain.on || !g_draw_enabled || (hipStream_t)stream != g_chain.stream || g_chain.top >= 0) return 0;
+  int rc = chain_flush_draw();
+  if (rc != PA_OK) return rc;
+  g_draw.have = true;
+  g_draw.args = args;
+  g_draw.nsites = nsites;
+  g_draw.P = P;
+  g_draw.seed = seed;
+  g_draw.offset_dev = offset_dev;
+  return 1;
+}
+
+bool glm_take_pending_draw(pa_stream_t stream, const float* w, const float* b, int64_t P, int64_t D,
+                           GlmDraw* out) {
+  if (!g_draw.have || (hipStream_t)stream != g_chain.stream || g_draw.P != P) return false;
+  int kw = -1, kb = -1;
+  for (int k = 0; k < g_draw.nsites; ++k) {
+    const MfSiteDev& sd = g_draw.args.s[k];
+    if (sd.z == (const void*)w && sd.n == D) kw = k;
+    if (b != nullptr && sd.z == (const void*)b && sd.n == 1) kb = k;
+  }
+  if (kw < 0 || (b != nullptr && kb < 0)) return false;
+  const MfSiteDev& sw = g_draw.args.s[kw];
+  out->loc_w = (const float*)sw.loc; out->rho_w = (const float*)sw.rho;
+  out->z_w = (float*)sw.z; out->eps_w = (float*)sw.eps; out->scale_w = (float*)sw.scale;
+  out->lout_w = (float*)sw.loc_out; out->off_w = sw.offset;
+  out->have_b = kb >= 0;
+  if (kb >= 0) {
+    const MfSiteDev& sb = g_draw.args.s[kb];
+    out->loc_b = (const float*)sb.loc; out->rho_b = (const float*)sb.rho;
+    out->z_b = (float*)sb.z; out->eps_b = (float*)sb.eps; out->scale_b = (float*)sb.scale;
+    out->lout_b = (float*)sb.loc_out; out->off_b = sb.offset;
+  } else {
+    out->loc_b = out->rho_b = nullptr;
+    out->z_b = out->eps_b = out->scale_b = out->lout_b = nullptr;
+    out->off_b = 0;
+  }
+  out->seed = g_draw.seed;
+  out->offset_dev = g_draw.offset_dev;
+  // the sites the GLM kernel does not draw keep their own (smaller) launch
+  MfArgs rest;
+  rest.nsites = 0;
+  for (int k = 0; k < g_draw.nsites; ++k)
+    if (k != kw && k != kb) rest.s[rest.nsites++] = g_draw.args.s[k];
+  g_draw.have = false;
+  if (rest.nsites > 0)
+    (void)meanfield_sample_launch(rest, rest.nsites, g_draw.P, g_draw.seed, g_draw.offset_dev, g_chain.stream);
+  return true;
+}
+
 hipStream_t as_stream(pa_stream_t s) {
+  if (g_draw.have) (void)chain_flush_draw();
   if (g_chain.on && g_chain.top >= 0) (void)chain_launch();
   return (hipStream_t)s;
 }
@@ -658,12 +734,18 @@ int pa_chain_begin(pa_stream_t stream, void* sync_words, size_t sync_bytes) {
 
 int pa_chain_flush(void) {
   if (!pa::g_chain.on) return PA_OK;
+  int rc = pa::chain_flush_draw();
+  if (rc != PA_OK) return rc;
   return pa::chain_launch();
 }
 
 int pa_chain_end(int* launches, int* phases) {
   int rc = PA_OK;
-  if (pa::g_chain.on) rc = pa::chain_launch();
+  if (pa::g_chain.on) {
+    rc = pa::chain_flush_draw();
+    const int rc2 = pa::chain_launch();
+    if (rc == PA_OK) rc = rc2;
+  }
   pa::g_chain.on = false;
   if (launches) *launches = pa::g_chain.launches;
   if (phases) *phases = pa::g_chain.phases;
@@ -675,6 +757,7 @@ int pa_chain_tune(int fuse_tail) {
   pa::g_chain_fuse = (fuse_tail & 1) ? 1 : 0;
   pa::g_chain_fast_sites = (fuse_tail & 2) ? 0 : 1;
   pa::g_chain_jitter = (uint32_t)fuse_tail >> 8;         // race hunting: see chain_jitter()
+  pa::g_draw_enabled = (fuse_tail & 4) ? 0 : 1;          // bit 2: the guide draw stays its own launch
   return PA_OK;
 }
 

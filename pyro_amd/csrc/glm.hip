@@ -570,16 +570,17 @@ static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
   return pl;
 }
 
-template <int NB, int OCC, bool PRIV = false, bool LIN = false>
+template <int NB, int OCC, bool PRIV = false, bool LIN = false, bool DRAW = false>
 static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, const float* y,
                             const float* w, const float* b, int64_t N, int D, int P, float* part,
-                            const uint32_t* trailer, hipStream_t s, const double* moments = nullptr) {
-  auto k = glm_planes_f16_kernel<NB, OCC, false, PRIV, LIN>;
-  constexpr int lds = GlmHCfg<NB, PRIV>::LDS_BYTES;
+                            const uint32_t* trailer, hipStream_t s, const double* moments = nullptr,
+                            const GlmDraw& draw = GlmDraw{}) {
+  auto k = glm_planes_f16_kernel<NB, OCC, false, PRIV, LIN, DRAW>;
+  constexpr int lds = GlmHCfg<NB, PRIV>::LDS_BYTES + (DRAW ? 256 : 0);     // + the workgroup's softplus(rho)
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.npass), dim3(256), lds, s, img, y, w,
                      b, N, D, P, pl.nst, part, cu_count(), trailer, g_planes_stamps,
-                     GlmGroupArgs{nullptr, nullptr, 1}, gate_word(), moments);
+                     GlmGroupArgs{nullptr, nullptr, 1}, gate_word(), moments, draw);
   gate_aware_launch();
 }
 
@@ -612,7 +613,7 @@ static void glmh_launch_grouped(int nseg, int npass, const unsigned char* img, c
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3((unsigned)nseg, (unsigned)npass), dim3(256), lds, s, img, y_img, w, b, N,
                      D, P, nst_total, part, cu_count(), trailer, g_planes_stamps, grp, gate_word(),
-                     (const double*)nullptr);
+                     (const double*)nullptr, GlmDraw{});
   gate_aware_launch();
 }
 
@@ -1030,6 +1031,13 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   PA_REQUIRE(N < (int64_t(1) << 40) && P < (1 << 20), "glm_planes: shape too large");
   PA_REQUIRE(w && ll && gw && gb, "glm_planes: NULL parameter/output pointer");
   PA_REQUIRE(N == 0 || (planes && y), "glm_planes: NULL data pointer");
+  // a guide draw parked in front of this launch (chain.h): the default f16 kernel draws w and b itself
+  pa::GlmDraw draw;
+  bool drawn = false;
+  if (format == PA_GLM_PLANES_F16X2 && N > 0) {
+    const pa::GlmPlanesPlan p0 = pa::glmh_plan(N, P);
+    if (p0.nb == 3 && p0.bpc < 4) drawn = pa::glm_take_pending_draw(stream, w, b, P, D, &draw);
+  }
   hipStream_t s = pa::as_stream(stream);
   if (N == 0) {
     hipError_t e1 = hipMemsetAsync(ll, 0, (size_t)P * 4, s);
@@ -1077,8 +1085,12 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
     else if (pl.nb == 6) pa::glmh_launch_one<4, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.nb == 4) pa::glmh_launch_one<4, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.bpc >= 4) pa::glmh_launch_one<3, 4>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
+    else if (moments != nullptr && drawn)
+      pa::glmh_launch_one<3, 3, false, true, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, moments, draw);
     else if (moments != nullptr)
       pa::glmh_launch_one<3, 3, false, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, moments);
+    else if (drawn)
+      pa::glmh_launch_one<3, 3, false, false, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, nullptr, draw);
     else pa::glmh_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
   } else if (pl.nb == 3) {
     pa::glm_planes_launch_one<3, 3>(pl, img, y, w, b, N, (int)D, (int)P, part, fin, s);

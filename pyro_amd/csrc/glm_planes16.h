@@ -37,7 +37,9 @@
 //       piece is normal down to |g| = 2^-17; the gradient accumulator of column d holds
 //       2^(14 + kx[d]) gw[., d].
 #pragma once
+#include "chain.h"
 #include "glm_planes.h"
+#include "multisite_dev.h"
 
 namespace pa {
 
@@ -240,13 +242,18 @@ __device__ __forceinline__ f32x16v glmh_keep(const f16x8& a, const f16x8& b, con
 // once per (X, y)), is added by workgroup 0 of each pass in the epilogue instead of one fma per (row,
 // particle) element in the loop.  Only the log-likelihood takes this route: the gradient keeps
 // g = y - sigmoid(l) element by element (near the optimum g is small where sigmoid - 1/2 is not).
-template <int NB, int OCC, bool GROUPED = false, bool PRIV = false, bool LIN = false>
+// DRAW: the weights and the bias ARE the draws of a mean-field Normal guide (chain.h GlmDraw): the
+// prologue draws them itself -- z = loc + softplus(rho) eps with eps from the guide's Philox blocks, the
+// numbers pa_meanfield_normal_sample would have written -- and workgroup 0 of each pass stores z, eps,
+// scale and loc for the step's tail; `w` / `b` are not read.
+template <int NB, int OCC, bool GROUPED = false, bool PRIV = false, bool LIN = false, bool DRAW = false>
 __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
     const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
     int64_t nst, float* __restrict__ part, int prio_cus, const uint32_t* __restrict__ trailer,
     unsigned long long* __restrict__ tstamps, const GlmGroupArgs grp,
-    const int64_t* __restrict__ gate, const double* __restrict__ moments = nullptr) {
+    const int64_t* __restrict__ gate, const double* __restrict__ moments = nullptr,
+    const GlmDraw draw = GlmDraw{}) {
   if (gate != nullptr && *gate != 0) return;        // the step gate gave this replay up (pa_gate)
   using C = GlmHCfg<NB, PRIV>;
   constexpr int NRT = C::NRT, NPT = C::NPT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS,
@@ -303,18 +310,82 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const int p = pbase + pl;
     float v[8];
     float mw = 0.0f;
+    float wraw[8], braw = 0.0f;          // the weights / bias in model units
+    if constexpr (DRAW) {
+      // softplus(rho) once per workgroup (32 + 1 values through LDS) instead of 8 per thread: the
+      // draw sits on the critical path of every workgroup's start
+      float* sp_s = reinterpret_cast<float*>(smem + C::LDS_BYTES);          // 64 floats behind the rings
+      if (threadIdx.x < 32) sp_s[threadIdx.x] = (int)threadIdx.x < D ? softplus_t<float>(draw.rho_w[threadIdx.x]) : 0.0f;
+      else if (threadIdx.x == 32) sp_s[32] = draw.have_b ? softplus_t<float>(draw.rho_b[0]) : 0.0f;
+      __syncthreads();
+      const uint64_t obase = draw.offset_dev ? *draw.offset_dev : 0;
+      const bool store = blockIdx.x == 0 && p < P;
+      float nrm[8];
+      const int64_t i0 = (int64_t)p * D + 8 * s;
+      if ((D & 3) == 0 && p < P) {
+        // 8 consecutive elements = two whole Philox blocks (element i: lane i % 4 of block i / 4)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x4 blk = philox4x32_10(draw.seed, draw.off_w + obase + (uint64_t)(i0 >> 2) + q, 0);
+          box_muller_f32(u32_to_unit_f32(blk.x), u32_to_unit_f32(blk.y), nrm[4 * q], nrm[4 * q + 1]);
+          box_muller_f32(u32_to_unit_f32(blk.z), u32_to_unit_f32(blk.w), nrm[4 * q + 2], nrm[4 * q + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          nrm[j] = (p < P && 8 * s + j < D)
+                       ? philox_normal_f32(draw.seed, draw.off_w + obase, (uint64_t)(i0 + j)) : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = 8 * s + j;
+        wraw[j] = 0.0f;
+        if (p < P && d < D) {
+          const float sp = sp_s[d];
+          wraw[j] = __builtin_fmaf(sp, nrm[j], draw.loc_w[d]);
+          if (store) {
+            draw.eps_w[i0 + j] = nrm[j];
+            draw.z_w[i0 + j] = wraw[j];
+            if (p == 0) {
+              draw.scale_w[d] = sp;
+              draw.lout_w[d] = draw.loc_w[d];
+            }
+          }
+        }
+      }
+      if (draw.have_b && p < P) {
+        // (every thread of the row computes it: the four of them need b for the row's exponent)
+        const float eb_ = philox_normal_f32(draw.seed, draw.off_b + obase, (uint64_t)p);
+        const float spb = sp_s[32];
+        braw = __builtin_fmaf(spb, eb_, draw.loc_b[0]);
+        if (store && s == 0) {
+          draw.eps_b[p] = eb_;
+          draw.z_b[p] = braw;
+          if (p == 0) {
+            draw.scale_b[0] = spb;
+            draw.lout_b[0] = draw.loc_b[0];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = 8 * s + j;
+        wraw[j] = (p < P && d < D) ? w[(int64_t)p * w_stride + d] : 0.0f;
+      }
+      braw = (p < P && b != nullptr) ? b[p] : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int d = 8 * s + j;
       // log2(e) rides in W and b (one f32 rounding each), as in glm_planes.h; the column's exponent
       // comes off here (exact)
-      v[j] = (p < P && d < D)
-                 ? ldexpf(w[(int64_t)p * w_stride + d] * GLMP_LOG2E, -(int)trailer[GLMH_KX + d]) : 0.0f;
+      v[j] = (p < P && d < D) ? ldexpf(wraw[j] * GLMP_LOG2E, -(int)trailer[GLMH_KX + d]) : 0.0f;
       mw = __builtin_fmaxf(mw, __builtin_fabsf(v[j]));
     }
     mw = __builtin_fmaxf(mw, __shfl_xor(mw, 1));
     mw = __builtin_fmaxf(mw, __shfl_xor(mw, 2));
-    const float b2 = (p < P && b != nullptr) ? b[p] * GLMP_LOG2E : 0.0f;
+    const float b2 = braw * GLMP_LOG2E;
     // NaN / inf weights: fmaxf drops a NaN; the scaled pieces below carry it into the accumulator
     const uint32_t mwb = __builtin_bit_cast(uint32_t, mw), bb = __builtin_bit_cast(uint32_t, b2) & 0x7fffffffu;
     const int ew = (int)(mwb >> 23), eb = (int)(bb >> 23);
@@ -667,8 +738,11 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
       // workgroup 0 of the pass: + c . w_p + c0 b_p (natural-log units, float64) on the ll slots
       const int p = pbase + (qq >> 1) * 32 + j;
       if (blockIdx.x == 0 && (qq & 1) == 0 && p < P) {
-        double lin = b != nullptr ? moments[32] * (double)b[p] : 0.0;
-        for (int d = 0; d < D; ++d) lin = __builtin_fma(moments[d], (double)w[(int64_t)p * w_stride + d], lin);
+        // (DRAW: this workgroup wrote z_w / z_b itself in its prologue, many barriers ago)
+        const float* wq = DRAW ? draw.z_w : w;
+        const float* bq = DRAW ? (draw.have_b ? draw.z_b : nullptr) : b;
+        double lin = bq != nullptr ? moments[32] * (double)bq[p] : 0.0;
+        for (int d = 0; d < D; ++d) lin = __builtin_fma(moments[d], (double)wq[(int64_t)p * w_stride + d], lin);
         v += (float)lin;
       }
     }

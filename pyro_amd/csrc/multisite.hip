@@ -2,6 +2,45 @@
 #include "multisite_dev.h"
 #include "chain.h"
 
+namespace pa {
+
+// the guide draw as its own kernel (also what a parked draw falls back to, chain.hip)
+int meanfield_sample_launch_any(int dtype, const MfArgs& args, int nsites, int64_t P, uint64_t seed,
+                                const uint64_t* offset_dev, hipStream_t s) {
+  int64_t maxn = 0;
+  for (int k = 0; k < nsites; ++k)
+    if (args.s[k].n > maxn) maxn = args.s[k].n;
+  // small sites: one element per thread (latency); from 64 K elements on: one Philox block = 4 f32 /
+  // 2 f64 elements per thread and trip (a quarter / half of the generator work) -- the same numbers
+  const bool big = P * maxn >= (int64_t(1) << 16);
+  const int64_t per = !big ? 1 : (dtype == PA_F32 ? 4 : 2);
+  int64_t gx = ((P * maxn + per - 1) / per + 255) / 256;
+  if (gx < 1) gx = 1;
+  const int64_t cap = (int64_t)cu_count() * 4;
+  if (gx > cap) gx = cap;
+  const dim3 grid((unsigned)gx, (unsigned)nsites);
+  if (dtype == PA_F32 && big)
+    hipLaunchKernelGGL((meanfield_sample_block_kernel<float>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, gate_word());
+  else if (dtype == PA_F32)
+    hipLaunchKernelGGL((meanfield_sample_kernel<float>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, gate_word());
+  else if (big)
+    hipLaunchKernelGGL((meanfield_sample_block_kernel<double>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, gate_word());
+  else
+    hipLaunchKernelGGL((meanfield_sample_kernel<double>), grid, dim3(256), 0, s, args, P, seed,
+                       offset_dev, gate_word());
+  gate_aware_launch();
+  return check_launch("meanfield_sample_kernel");
+}
+int meanfield_sample_launch(const MfArgs& args, int nsites, int64_t P, uint64_t seed,
+                            const uint64_t* offset_dev, hipStream_t s) {
+  return meanfield_sample_launch_any(PA_F32, args, nsites, P, seed, offset_dev, s);
+}
+
+}  // namespace pa
+
 extern "C" {
 
 int pa_multi_log_prob_sum(int dtype, void* out_total, const pa_site_entry* entries, int n,
@@ -74,37 +113,17 @@ int pa_meanfield_normal_sample(int dtype, const pa_mf_site* sites, int nsites, i
   int rc = pa::mf_to_dev(sites, nsites, &args, "pa_meanfield_normal_sample");
   if (rc != PA_OK) return rc;
   if (nsites == 0) return PA_OK;
-  int64_t maxn = 0;
-  for (int k = 0; k < nsites; ++k) {
+  for (int k = 0; k < nsites; ++k)
     PA_REQUIRE(sites[k].n == 0 || (sites[k].loc && sites[k].rho && sites[k].z && sites[k].scale &&
                                    sites[k].loc_out && sites[k].eps),
                "pa_meanfield_normal_sample: site %d: NULL pointer", k);
-    if (sites[k].n > maxn) maxn = sites[k].n;
+  if (dtype == PA_F32) {
+    // inside a recorded step the draw waits for the launch that consumes it (chain.h: the plane-image
+    // GLM kernel draws its own weights)
+    rc = pa::chain_park_draw(stream, args, nsites, P, seed, offset_dev);
+    if (rc != 0) return rc < 0 ? rc : PA_OK;
   }
-  // small sites: one element per thread (latency); from 64 K elements on: one Philox block = 4 f32 /
-  // 2 f64 elements per thread and trip (a quarter / half of the generator work) -- the same numbers
-  const bool big = P * maxn >= (int64_t(1) << 16);
-  const int64_t per = !big ? 1 : (dtype == PA_F32 ? 4 : 2);
-  int64_t gx = ((P * maxn + per - 1) / per + 255) / 256;
-  if (gx < 1) gx = 1;
-  const int64_t cap = (int64_t)pa::cu_count() * 4;
-  if (gx > cap) gx = cap;
-  hipStream_t s = pa::as_stream(stream);
-  const dim3 grid((unsigned)gx, (unsigned)nsites);
-  if (dtype == PA_F32 && big)
-    hipLaunchKernelGGL((pa::meanfield_sample_block_kernel<float>), grid, dim3(256), 0, s, args, P, seed,
-                       offset_dev, pa::gate_word());
-  else if (dtype == PA_F32)
-    hipLaunchKernelGGL((pa::meanfield_sample_kernel<float>), grid, dim3(256), 0, s, args, P, seed,
-                       offset_dev, pa::gate_word());
-  else if (big)
-    hipLaunchKernelGGL((pa::meanfield_sample_block_kernel<double>), grid, dim3(256), 0, s, args, P, seed,
-                       offset_dev, pa::gate_word());
-  else
-    hipLaunchKernelGGL((pa::meanfield_sample_kernel<double>), grid, dim3(256), 0, s, args, P, seed,
-                       offset_dev, pa::gate_word());
-  pa::gate_aware_launch();
-  return pa::check_launch("meanfield_sample_kernel");
+  return pa::meanfield_sample_launch_any(dtype, args, nsites, P, seed, offset_dev, pa::as_stream(stream));
 }
 
 int pa_meanfield_normal_sample_bwd(int dtype, const pa_mf_site* sites, int nsites, int64_t P,

@@ -512,6 +512,9 @@ static int to_dev(const pa_site_entry* in, int n, MultiArgs* out, const char* wh
 }
 
 // ---- mean-field Normal guide -----------------------------------------------------------------
+// (one fma, spelled out: the GLM kernel that draws its own weights must produce the same bits)
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 struct MfSiteDev {
   const void *loc, *rho;
   void *z, *scale, *loc_out, *eps;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256) void meanfield_sample_kernel(const MfArgs args
     else e = philox_normal_f64(seed, off, (uint64_t)i);
     const T sp = softplus_t<T>(rho[c]);
     eps[i] = e;
-    z[i] = loc[c] + sp * e;
+    z[i] = t_fma(sp, e, loc[c]);
     if (i < s.n) {
       sc[c] = sp;
       lo[c] = loc[c];
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(256) void meanfield_sample_block_kernel(const MfArg
       if (i < total) {
         const T sp = softplus_t<T>(rho[c]);
         eps[i] = nrm[u];
-        z[i] = loc[c] + sp * nrm[u];
+        z[i] = t_fma(sp, nrm[u], loc[c]);
         if (i < s.n) {
           sc[c] = sp;
           lo[c] = loc[c];

@@ -139,12 +139,14 @@ def chain_debug_stamps(buf):
     _CHAIN["stamps"] = buf
 
 
-def chain_tune(fuse_tail=True, fast_sites=True, jitter_seed=0):
+def chain_tune(fuse_tail=True, fast_sites=True, jitter_seed=0, fuse_draw=True):
     """pa_chain_tune: allow (default) / forbid the per-site fused form of the chained tail, and
     within it the one-pass code for AutoNormal-shaped sites.  ``jitter_seed`` != 0: race hunting --
-    pseudo-random per-workgroup delays around every device-wide arrival / wait of the chain kernels."""
+    pseudo-random per-workgroup delays around every device-wide arrival / wait of the chain kernels.
+    ``fuse_draw``: inside a recording the mean-field guide draw is made by the plane-image GLM kernel
+    that consumes it (default) or stays its own launch."""
     check(_lib.load().pa_chain_tune((1 if fuse_tail else 0) | (0 if fast_sites else 2)
-                                    | ((int(jitter_seed) & 0x7fffff) << 8)))
+                                    | (0 if fuse_draw else 4) | ((int(jitter_seed) & 0x7fffff) << 8)))
 
 
 def chain_flush():

@@ -82,9 +82,10 @@ def test_chained_tail_is_bitwise_the_separate_launches(gpu, P):
 
 
 def test_captured_step_is_three_nodes_of_ours(gpu):
-    """SVI(hip_graph=True) on the config-2 model text: the capture holds the guide draw, the GLM
-    kernel and ONE chain launch; the two ``X.new_zeros`` of the model are served from hoisted
-    constants; the trajectory is bitwise the eager one."""
+    """SVI(hip_graph=True) on the config-2 model text: the capture holds the GLM kernel -- which makes
+    the guide's draw in its own prologue (round 4; until then the draw was a node of its own) -- and
+    ONE chain launch; the two ``X.new_zeros`` of the model are served from hoisted constants; the
+    trajectory is bitwise the eager one (whose draw IS a launch of its own)."""
     import pyro_amd as pyro
     from pyro_amd import examples
     from pyro_amd.infer import SVI, Trace_ELBO
@@ -237,7 +238,8 @@ def test_prearmed_steps_are_bitwise_the_ordinary_ones(gpu):
     l1, p1, svi = _gate_run(gpu, prearm=True)
     (entry,) = svi._graphs.values()
     g = entry.gate
-    assert g is not None and g.armable and (g.total, g.aware, g.torch_ops) == (4, 4, 0), \
+    # gate node, the GLM kernel (which draws the guide's sample itself), the chained tail
+    assert g is not None and g.armable and (g.total, g.aware, g.torch_ops) == (3, 3, 0), \
         (g.total, g.aware, g.torch_ops)
     assert entry.armed and entry.arm_backoff == 0
     assert g.next == 24 - 3 + 1                     # every replay ran exactly once
@@ -406,5 +408,51 @@ def test_captured_step_is_bitwise_stable_under_shuffled_arrivals(gpu):
             assert got[0] == ref[0], seed
             for k in ref[1]:
                 assert torch.equal(ref[1][k], got[1][k]), (seed, k)
+    finally:
+        kernels.chain_tune(fuse_tail=True)
+
+
+def test_guide_draw_made_by_the_glm_kernel_is_bitwise_the_separate_launch(gpu):
+    """Inside a recording pa_meanfield_normal_sample parks its launch; the plane-image GLM kernel whose
+    weights and bias are two of its sites' draws makes them in its prologue (same Philox blocks, same
+    softplus, one fma) and workgroup 0 stores z / eps / scale / loc for the tail.  Against the draw as
+    its own launch (chain_tune(fuse_draw=False)): identical losses and parameters, with and without a
+    bias site, for D a multiple of 4 (two Philox blocks per thread) and not (element by element)."""
+    import pyro_amd as pyro
+    from pyro_amd import distributions as dist, kernels
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    def run(D, with_bias, fuse_draw):
+        kernels.chain_tune(fuse_tail=True, fuse_draw=fuse_draw)
+        g = torch.Generator().manual_seed(D)
+        X = torch.randn((9000, D), generator=g).to(gpu)
+        yv = (torch.rand((9000,), generator=g) < 0.5).float().to(gpu)
+
+        def model(X, y):
+            w = pyro.sample("w", dist.Normal(X.new_zeros(D), 1.0).to_event(1))
+            extra = pyro.sample("extra", dist.Normal(X.new_zeros(3), 2.0).to_event(1))   # a site the kernel does not draw
+            logits = w @ X.t()
+            if with_bias:
+                logits = logits + pyro.sample("b", dist.Normal(X.new_zeros(()), 1.0)).unsqueeze(-1)
+            with pyro.plate("data", X.shape[0]):
+                pyro.sample("obs", dist.Bernoulli(logits=logits.squeeze(-2) if logits.dim() > 2 else logits), obs=y)
+            return extra
+
+        pyro.clear_param_store()
+        pyro.set_rng_seed(4)
+        pyro.enable_validation(False)
+        svi = SVI(model, AutoNormal(model, init_scale=0.1), pyro.optim.Adam({"lr": 0.03}),
+                  Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1),
+                  hip_graph=True, graph_warmup=3)
+        losses = [svi.step(X, yv) for _ in range(9)]
+        return losses, _params(pyro)
+
+    try:
+        for D, with_bias in ((32, True), (20, True), (13, True), (32, False)):
+            a, b = run(D, with_bias, False), run(D, with_bias, True)
+            assert a[0] == b[0], (D, with_bias, a[0], b[0])
+            for k in a[1]:
+                assert torch.equal(a[1][k], b[1][k]), (D, with_bias, k)
     finally:
         kernels.chain_tune(fuse_tail=True)

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
                        (unsigned long long*)nullptr, (const int64_t*)nullptr);
 #else
     hipLaunchKernelGGL(k, dim3(nblocks, 1), dim3(256), lds, 0, img, y, w, b, N, D, P, nst, part, 256, trailer,
-                       (unsigned long long*)nullptr, GlmGroupArgs{nullptr, nullptr, 1}, (const int64_t*)nullptr, (const double*)nullptr);
+                       (unsigned long long*)nullptr, GlmGroupArgs{nullptr, nullptr, 1}, (const int64_t*)nullptr, (const double*)nullptr, GlmDraw{});
 #endif
   };
   for (int i = 0; i < 5; ++i) launch();
