@@ -248,6 +248,19 @@ class SVI:
             return entry.read_loss()
         return self._gated_step(entry, args, kwargs)
 
+    def release(self):
+        """Drop every captured step (hipGraph executables, their private memory pools, pinned mailboxes
+        and gate words) now instead of when the cyclic collector gets to this object.  A process that
+        builds hundreds of SVI objects with captured steps (a test suite, a hyper-parameter sweep) should
+        call this, or ``gc.collect()``, between them: the GPU suite of this repository aborted inside
+        the HIP runtime after ~300 un-collected captures (tests/conftest.py collects per module)."""
+        for e in self._graphs.values():
+            if e.armed:
+                e.cancel()
+        self._armed_fast = None
+        self._graphs.clear()
+        self._const_rec.clear()
+
     def disarm(self):
         """Stop enqueuing replays ahead of time (prearm=True): cancels a waiting one; later steps of
         the existing captures run as ordinary replays through their (already released) gates."""

@@ -21,6 +21,24 @@ def gpu():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _release_captured_steps():
+    """Captured steps (hipGraph executables with their private memory pools, pinned mailboxes, gate
+    words) die with the SVI objects that own them, and those sit in reference cycles: collect them at
+    the end of every test module instead of whenever the cyclic collector gets to it -- the GPU suite
+    creates several hundred captures in one process."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:      # noqa: BLE001
+        pass
+
+
 @pytest.fixture
 def oracle_backend(monkeypatch):
     """Route pyro_amd.kernels to the numpy oracle (TEST-ONLY; see tests/oracle_backend.py)."""
