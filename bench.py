@@ -571,8 +571,8 @@ def main():
                 rd = bench_configs.config2_variant(dev, "normal", D=Dv, steps=30)
                 rd["workload"] = ("BASELINE configs[1] at D=%d (SURVEY 8d sweep): %s" % (
                     Dv, "plane-image kernel" if Dv <= 32 else
-                    ("bf16x3 kernel, X split on the fly (no plane image beyond D=32)" if Dv <= 64 else
-                     "exact-f32 MFMA kernel (no split-precision variant beyond D=64)")))
+                    "plane-image kernel with %d feature tiles of 32 columns (csrc/glm_planes16d.h; until "
+                    "round 4 D > 32 split X on the fly in two passes)" % (2 if Dv <= 64 else 4)))
                 others["config2_D%d" % Dv] = rd
             r2u = bench_configs.config2_variant(dev, "normal", lazy_matmul=False, steps=20)
             r2u["workload"] = ("BASELINE configs[1], the reference's model text with the lazy recognition "

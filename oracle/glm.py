@@ -120,7 +120,8 @@ def f16_image_exponent(X):
     glm_absmax_kernel's column maxima: the unsigned maximum of the magnitudes' bit patterns, NaN
     above inf)."""
     X = np.asarray(X, dtype=np.float32)
-    kx = np.zeros(32, dtype=np.int32)
+    # (images of more than 32 columns -- feature tiles, csrc/glm_planes16d.h -- carry 128 exponents)
+    kx = np.zeros(32 if X.ndim < 2 or X.shape[1] <= 32 else 128, dtype=np.int32)
     if X.size == 0:
         return kx
     bits = (np.ascontiguousarray(X).view(np.uint32) & np.uint32(0x7FFFFFFF)).max(axis=0)
@@ -141,24 +142,28 @@ def f16_split2(x):
 
 
 def glm_plane_image_f16(X, kx=None):
-    """(uint16 image [tiles, 2 planes, 1024], kx[32]) of an [N, D <= 32] f32 design matrix:
-    glm_plane_image's tile geometry with the two f16 pieces of X[:, d] * 2^kx[d]."""
+    """(uint16 image [tiles * DT, 2 planes, 1024], kx[32 or 128]) of an [N, D <= 128] f32 design matrix:
+    glm_plane_image's tile geometry with the two f16 pieces of X[:, d] * 2^kx[d], DT = 1 / 2 / 4 feature
+    tiles of 32 columns per 32-row tile."""
     X = np.asarray(X, dtype=np.float32)
     N, D = X.shape
-    assert D <= 32
+    assert D <= 128
+    DT = 1 if D <= 32 else (2 if D <= 64 else 4)        # feature tiles of 32 columns
     if kx is None:
         kx = f16_image_exponent(X)
     tiles = -(-max(N, 0) // 32)
     tiles = -(-tiles // 4) * 4
-    Xp = np.zeros((tiles * 32, 32), dtype=np.float32)
+    Xp = np.zeros((tiles * 32, 32 * DT), dtype=np.float32)
     Xp[:N, :D] = np.ldexp(X, np.asarray(kx)[None, :D]).astype(np.float32)
-    img = np.zeros((tiles, 2, 32, 4, 8), dtype=np.uint16)
+    # tile T's sub-tile dt (columns 32 dt .. 32 dt + 31) is image block T * DT + dt
+    img = np.zeros((tiles, DT, 2, 32, 4, 8), dtype=np.uint16)
     r = np.arange(32)
     for pl, piece in enumerate(f16_split2(Xp)):
-        bits = piece.view(np.uint16).reshape(tiles, 32, 4, 8)
-        for s in range(4):
-            img[:, pl, r, s ^ ((r >> 2) & 3), :] = bits[:, r, s, :]
-    return img.reshape(tiles, 2, 1024), kx
+        bits = piece.view(np.uint16).reshape(tiles, 32, DT, 4, 8)
+        for dt in range(DT):
+            for s in range(4):
+                img[:, dt, pl, r, s ^ ((r >> 2) & 3), :] = bits[:, r, dt, s, :]
+    return img.reshape(tiles * DT, 2, 1024), kx
 
 
 def glm_grouped_plane_image_f16(X, y, seg):

@@ -25,6 +25,7 @@
 #include "glm_planes.h"
 #include "glm_planes16.h"
 #include "glm_planes16w.h"
+#include "glm_planes16d.h"
 #include "glm_finalize.h"
 #include "chain.h"
 
@@ -584,6 +585,59 @@ static void glmh_launch_one(const GlmPlanesPlan& pl, const unsigned char* img, c
   gate_aware_launch();
 }
 
+// 32 < D <= 128 (glm_planes16d.h): kernel + finalize (a phase of the chained tail where the tail knows
+// the record shape, its own launch otherwise)
+template <int DT, int OCC>
+static int glmd_launch(const unsigned char* img, const float* y, const float* w, const float* b, int64_t N,
+                       int D, int P, float* part, const uint32_t* trailer, int bpc, int* nblocks_out,
+                       int64_t* nst_out, hipStream_t s) {
+  auto k = glm_planes_f16d_kernel<DT, 3, OCC>;
+  constexpr int lds = GlmDCfg<DT, 3>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int npass = (int)((P + 63) / 64);
+  const int64_t nst = ((N + 31) / 32 + 1) / 2;
+  int64_t cap = (int64_t)cu_count() * bpc / npass;
+  if (cap < 1) cap = 1;
+  const int nblocks = (int)(nst < cap ? (nst < 1 ? 1 : nst) : cap);
+  *nblocks_out = nblocks;
+  *nst_out = nst;
+  hipLaunchKernelGGL(k, dim3((unsigned)nblocks, (unsigned)npass), dim3(256), lds, s, img, y, w, b, N, D, P,
+                     nst, part, trailer, gate_word());
+  gate_aware_launch();
+  return check_launch("glm_planes_f16d_kernel");
+}
+
+static int glmd_run(const void* planes, const float* y, const float* w, const float* b, double scale,
+                    int64_t N, int D, int P, float* ll, float* gw, float* gb, float* part,
+                    pa_stream_t stream, hipStream_t s) {
+  const int DT = D <= 64 ? 2 : 4;
+  const unsigned char* img = (const unsigned char*)planes;
+  const uint32_t* trailer = (const uint32_t*)(img + glmh_tile_bytes(glm_planes_tiles(N)) * DT);
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_GLM, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
+  int nblocks = 1;
+  int64_t nst = 0;
+  // two workgroups per CU with two feature tiles (68 KiB of LDS each), one with four (132 KiB)
+  int rc = DT == 2 ? glmd_launch<2, 2>(img, y, w, b, N, D, P, part, trailer, 2, &nblocks, &nst, s)
+                   : glmd_launch<4, 1>(img, y, w, b, N, D, P, part, trailer, 1, &nblocks, &nst, s);
+  if (br) (void)hipEventRecord(ev1, s);
+  if (rc != PA_OK) return rc;
+  const int npass = (P + 63) / 64;
+  const double ll_offset = (double)(nst * 64 - N) * 0.6931471805599453;
+  rc = chain_record_fin(stream, DT, 2, part, nblocks, npass, D, P, scale, ll, gw, gb, ll_offset);
+  if (rc != 0) return rc < 0 ? rc : PA_OK;
+  const int64_t J = (int64_t)P * D + 2 * P;
+  const dim3 fgrid((unsigned)((J + FIN_OUT - 1) / FIN_OUT)), fblock(FIN_OUT * FIN_GROUPS);
+  if (DT == 2)
+    hipLaunchKernelGGL((glm_finalize_kernel<2, 2>), fgrid, fblock, 0, s, part, nblocks, npass, D, P, scale, ll,
+                       gw, gb, ll_offset);
+  else
+    hipLaunchKernelGGL((glm_finalize_kernel<4, 2>), fgrid, fblock, 0, s, part, nblocks, npass, D, P, scale, ll,
+                       gw, gb, ll_offset);
+  return check_launch("glm_finalize_kernel");
+}
+
 // one wave per 32-row tile and 64 particles (glm_planes16w.h): groups of four tiles (128 rows)
 template <int NB>
 static void glmw_launch(int bpc, const unsigned char* img, const float* y, const float* w, const float* b,
@@ -912,8 +966,14 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, cons
   return pa::check_launch("glm_grouped_finalize");
 }
 
+// feature tiles of the f16 image: 1 (D <= 32), 2 (<= 64), 4 (<= 128: csrc/glm_planes16d.h)
+static int glmd_dt(int64_t D) { return D <= 32 ? 1 : (D <= 64 ? 2 : 4); }
+
 size_t pa_glm_planes_bytes(int format, int64_t N, int64_t D) {
-  if (N < 0 || D < 1 || D > 32) return 0;
+  if (N < 0 || D < 1 || D > 128) return 0;
+  if (format == PA_GLM_PLANES_F16X2 && D > 32)
+    return (size_t)pa::glmh_tile_bytes(pa::glm_planes_tiles(N)) * glmd_dt(D) + pa::GLMD_TRAILER;
+  if (D > 32) return 0;
   if (format == PA_GLM_PLANES_F16X2)
     return (size_t)pa::glmh_tile_bytes(pa::glm_planes_tiles(N)) + pa::GLMH_TRAILER;
   if (format != PA_GLM_PLANES_BF16X3) return 0;
@@ -930,8 +990,8 @@ int pa_glm_pack_planes(int format, const float* X, int64_t N, int64_t D, void* p
   }
   PA_REQUIRE_FORMAT(format, "glm_pack_planes");
   PA_REQUIRE(N >= 0 && D >= 1, "glm_pack_planes: bad shape N=%lld D=%lld", (long long)N, (long long)D);
-  if (D > 32)
-    return pa::fail(PA_ERR_UNSUPPORTED, "glm_pack_planes: the plane image holds D <= 32 (got %lld)",
+  if (D > 128 || (D > 32 && format != PA_GLM_PLANES_F16X2))
+    return pa::fail(PA_ERR_UNSUPPORTED, "glm_pack_planes: the plane image holds D <= 32 (f16 format: D <= 128), got %lld",
                     (long long)D);
   PA_REQUIRE(N < (int64_t(1) << 40), "glm_pack_planes: shape too large");
   PA_REQUIRE(planes && planes_bytes >= pa_glm_planes_bytes(format, N, D),
@@ -939,6 +999,30 @@ int pa_glm_pack_planes(int format, const float* X, int64_t N, int64_t D, void* p
   PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_pack_planes: unaligned image");
   PA_REQUIRE(N == 0 || X, "glm_pack_planes: NULL data pointer");
   const int64_t nt = pa::glm_planes_tiles(N);
+  if (format == PA_GLM_PLANES_F16X2 && D > 32) {
+    // DT feature tiles per row tile, a 1-KiB trailer of column maxima / exponents (glm_planes16d.h)
+    hipStream_t s = pa::as_stream(stream);
+    const int DT = glmd_dt(D);
+    uint32_t* trailer = (uint32_t*)((unsigned char*)planes + pa::glmh_tile_bytes(nt) * DT);
+    if (hipMemsetAsync(trailer, 0, pa::GLMD_TRAILER, s) != hipSuccess)
+      return pa::fail(PA_ERR_LAUNCH, "glm_pack_planes: memset of the image trailer failed");
+    if (N > 0) {
+      int64_t grid = (N + 63) / 64;
+      const int64_t cap = (int64_t)pa::cu_count() * 8;
+      if (grid > cap) grid = cap;
+      hipLaunchKernelGGL(pa::glmd_absmax_kernel, dim3((unsigned)grid), dim3(256), 0, s, X, N, (int)D, trailer);
+      const int rc = pa::check_launch("glmd_absmax_kernel");
+      if (rc != PA_OK) return rc;
+    }
+    const unsigned nblk = (unsigned)((nt * DT * 128 + 255) / 256 + (nt == 0));
+    if (DT == 2)
+      hipLaunchKernelGGL(pa::glmd_pack_kernel<2>, dim3(nblk), dim3(256), 0, s, X, N, (int)D, nt,
+                         (unsigned char*)planes, trailer);
+    else
+      hipLaunchKernelGGL(pa::glmd_pack_kernel<4>, dim3(nblk), dim3(256), 0, s, X, N, (int)D, nt,
+                         (unsigned char*)planes, trailer);
+    return pa::check_launch("glmd_pack_kernel");
+  }
   if (format == PA_GLM_PLANES_F16X2) {
     hipStream_t s = pa::as_stream(stream);
     uint32_t* trailer = (uint32_t*)((unsigned char*)planes + pa::glmh_tile_bytes(nt));
@@ -978,7 +1062,15 @@ int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
 }
 
 size_t pa_glm_bernoulli_planes_workspace(int64_t N, int64_t D, int64_t P) {
-  if (N < 0 || D < 1 || D > 32 || P < 1) return 0;
+  if (N < 0 || D < 1 || D > 128 || P < 1) return 0;
+  if (D > 32) {
+    // glm_planes16d.h: one record of DT feature tiles x 2 particle tiles per workgroup and pass
+    const size_t npass = (size_t)((P + 63) / 64);
+    const size_t cap = (size_t)pa::cu_count() * 2;
+    const size_t nst = (size_t)(((N + 31) / 32 + 1) / 2);
+    const size_t nb = nst < cap ? (nst < 1 ? 1 : nst) : cap;
+    return nb * npass * (2 * (size_t)glmd_dt(D) * 1024 + 2 * 2 * 32) * sizeof(float);
+  }
   // (the same for both image formats: the record count is capped at four workgroups per CU)
   const pa::GlmPlanesPlan pl = pa::glm_planes_plan(N, P);
   // records of the deepest / widest tuning so that the knob never invalidates a workspace
@@ -1024,8 +1116,8 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
                                     pa_stream_t stream) {
   PA_REQUIRE(N >= 0 && D >= 1 && P >= 1, "glm_planes: bad shape N=%lld D=%lld P=%lld", (long long)N,
              (long long)D, (long long)P);
-  if (D > 32)
-    return pa::fail(PA_ERR_UNSUPPORTED, "glm_planes: the plane image holds D <= 32 (got %lld)",
+  if (D > 128 || (D > 32 && format != PA_GLM_PLANES_F16X2))
+    return pa::fail(PA_ERR_UNSUPPORTED, "glm_planes: the plane image holds D <= 32 (f16 format: D <= 128), got %lld",
                     (long long)D);
   PA_REQUIRE_FORMAT(format, "glm_planes");
   PA_REQUIRE(N < (int64_t(1) << 40) && P < (1 << 20), "glm_planes: shape too large");
@@ -1050,6 +1142,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   PA_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "glm_planes: unaligned image");
   PA_REQUIRE(workspace && workspace_bytes >= pa_glm_bernoulli_planes_workspace(N, D, P),
              "glm_planes: workspace too small");
+  if (D > 32) return pa::glmd_run(planes, y, w, b, scale, N, (int)D, (int)P, ll, gw, gb, (float*)workspace, stream, s);
   pa::GlmPlanesPlan pl =
       format == PA_GLM_PLANES_F16X2 ? pa::glmh_plan(N, P) : pa::glm_planes_plan(N, P);
   // the f16 image: tuning codes 9 / 10 run one wave per 32-row tile and 64 particles (glm_planes16w.h,

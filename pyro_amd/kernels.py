@@ -714,6 +714,12 @@ _planes_format = {"bf16x3": GLM_PLANES_BF16X3, "f16x2": GLM_PLANES_F16X2}[
     os.environ.get("PYRO_AMD_GLM_PLANES", "f16x2")]
 _planes_cache = {}          # id(X) -> [weakref, version, planes or None, sightings]
 _PLANES_MAX_D, _PLANES_MIN_P = 32, 33
+_PLANES_MAX_D_F16 = 128            # the f16 image has feature tiles (csrc/glm_planes16d.h): D <= 128
+
+
+def planes_max_d():
+    """Largest feature count the plane image of the current format holds."""
+    return _PLANES_MAX_D_F16 if _planes_format == GLM_PLANES_F16X2 else _PLANES_MAX_D
 
 
 def glm_set_planes_mode(mode):
@@ -847,7 +853,7 @@ def glm_label_moments_of(X, y):
     a capture without a cached entry, labels that change from call to call, switched off)."""
     if not LABEL_MOMENTS["on"] or _planes_format != GLM_PLANES_F16X2 or _planes_mode == GLM_PLANES_OFF:
         return None
-    if not (X.is_contiguous() and y.is_contiguous() and y.dtype == torch.float32):
+    if not (X.is_contiguous() and y.is_contiguous() and y.dtype == torch.float32) or X.shape[1] > 32:
         return None
     ent = _planes_entry_of(X)
     if ent[2] is None or _format_of(ent[2]) != GLM_PLANES_F16X2:
@@ -1033,7 +1039,7 @@ def glm_bernoulli_fwd_bwd(X, y, w, b, mask, scale):
     if mask is not None:
         assert mask.is_contiguous() and mask.shape == (N,) and mask.dtype in (torch.bool,
                                                                              torch.uint8)
-    if (mask is None and D <= _PLANES_MAX_D and P >= _PLANES_MIN_P and N > 0
+    if (mask is None and D <= planes_max_d() and P >= _PLANES_MIN_P and N > 0
             and _glm_variant == GLM_AUTO):
         planes = glm_planes_of(X)
         if planes is not None:

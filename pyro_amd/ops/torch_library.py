@@ -116,7 +116,7 @@ def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
         N, D = int(X.shape[0]), int(X.shape[1])
         P = int(w.shape[0])
         planes = moments = None
-        if (mask is None and D <= kernels._PLANES_MAX_D and P >= kernels._PLANES_MIN_P and N > 0
+        if (mask is None and D <= kernels.planes_max_d() and P >= kernels._PLANES_MIN_P and N > 0
                 and kernels._glm_variant == kernels.GLM_AUTO):
             planes = kernels.glm_planes_of(X)
             if planes is not None:

@@ -568,6 +568,52 @@ def test_glm_plane_image_bit_exact(gpu, planes_fmt, N, D):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("N,D", [(1, 33), (100, 64), (4099, 100), (1000, 128), (0, 70)])
+def test_glm_plane_image_with_feature_tiles_bit_exact(gpu, N, D):
+    """32 < D <= 128 (csrc/glm_planes16d.h): DT = 2 / 4 sub-tiles of 32 columns per row tile, 128 column
+    exponents in a 1-KiB trailer; bf16x3 images stop at 32 columns."""
+    k = _k()
+    rng = np.random.default_rng(7 * N + D)
+    X = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-6, 6, (N, 1)))
+         * np.exp(rng.uniform(-8, 8, (1, D)))).astype(np.float32)
+    img = k.glm_pack_planes(tt(X, gpu), fmt=k.GLM_PLANES_F16X2).cpu().numpy()
+    ref, kx = o_glm.glm_plane_image_f16(X)
+    assert np.array_equal(img[ref.size * 2:][:1024].view(np.int32)[128:256], kx)
+    assert np.array_equal(img[:ref.size * 2].view(np.uint16).reshape(ref.shape), ref)
+    with pytest.raises(Exception):
+        k.glm_pack_planes(tt(X, gpu), fmt=k.GLM_PLANES_BF16X3)
+
+
+@pytest.mark.parametrize("N,D,P", [(1, 33, 64), (63, 40, 33), (4099, 64, 64), (1000, 100, 70), (70000, 128, 64),
+                                   (5000, 65, 130)])
+@pytest.mark.parametrize("use_bias", [True, False])
+def test_glm_planes_with_feature_tiles(gpu, N, D, P, use_bias):
+    """The plane-image kernel for 32 < D <= 128 against the float64 oracle (the tolerances of the D <= 32
+    kernel) and against the kernel that splits X on the fly."""
+    k = _k()
+    rng = np.random.default_rng(N + D + P)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    w = (rng.standard_normal((P, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32) if use_bias else None
+    y = (rng.uniform(size=N) < 0.5).astype(np.float32)
+    tX, ty, tw = tt(X, gpu), tt(y, gpu), tt(w, gpu)
+    tb = tt(b, gpu) if use_bias else None
+    planes = k.glm_pack_planes(tX, fmt=k.GLM_PLANES_F16X2)
+    ll, gw, gb = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 3.0, N, D)
+    rll, rgw, rgb = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 3.0)
+    sc = max(1.0, float(np.abs(rll).max()))
+    np.testing.assert_allclose(ll.cpu().numpy(), rll, rtol=2e-5, atol=2e-5 * sc)
+    np.testing.assert_allclose(gb.cpu().numpy(), rgb, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
+    np.testing.assert_allclose(gw.cpu().numpy(), rgw, rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
+    k.glm_set_planes_mode(k.GLM_PLANES_OFF)
+    try:
+        l0, g0, b0 = k.glm_bernoulli_fwd_bwd(tX, ty, tw, tb, None, 3.0)
+    finally:
+        k.glm_set_planes_mode(k.GLM_PLANES_AUTO)
+    torch.testing.assert_close(ll, l0, rtol=1e-5, atol=1e-4 * sc)
+    torch.testing.assert_close(gw, g0, rtol=1e-5, atol=1e-4 * max(1.0, N ** 0.5))
+
+
 @pytest.mark.parametrize("scale", [1e-30, 3e-5, 1.0, 77.0, 1e20, 0.0])
 def test_glm_plane_image_f16_exponent(gpu, scale):
     """The f16 image's power-of-two scale follows max |X| over the whole f32 range (and is 0 for an
