@@ -403,7 +403,8 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, cons
  * (pyro/infer/svi.py:134-162 passes the same data tensor every step), so the split, the staging
  * registers and the LDS writes of the on-the-fly kernel leave the per-step work; the arithmetic and
  * the outputs are those of pa_glm_bernoulli_fwd_bwd variant 0 (no mask argument: masked plates take
- * the entry above).  D <= 32; any P (64 particles per pass over the image).
+ * the entry above).  D <= 32 (format F16X2: D <= 128, with 2 or 4 feature tiles of 32 columns per row tile and a
+ * 1-KiB trailer of 128 column maxima / exponents, csrc/glm_planes16d.h); any P (64 particles per pass over the image).
  * pa_glm_planes_tune(ring depth code 3..10, workgroups per CU; 0 = default) is a measurement knob.
  *
  * Two image formats (`format`, the same value when an image is sized, packed and used):
