@@ -157,6 +157,8 @@ __device__ __forceinline__ void chain_fin_any(const ChainArgs& a, int me, int nw
   if (a.fin_DT == 1 && a.fin_PT == 2) chain_fin<1, 2, SUB>(a, me, nw);
   else if (a.fin_DT == 1 && a.fin_PT == 1) chain_fin<1, 1, SUB>(a, me, nw);
   else if (a.fin_DT == 2 && a.fin_PT == 1) chain_fin<2, 1, SUB>(a, me, nw);
+  else if (a.fin_DT == 2 && a.fin_PT == 2) chain_fin<2, 2, SUB>(a, me, nw);      // plane image, D <= 64
+  else if (a.fin_DT == 4 && a.fin_PT == 2) chain_fin<4, 2, SUB>(a, me, nw);      // plane image, D <= 128
   else chain_fin<4, 1, SUB>(a, me, nw);
 }
 
@@ -574,7 +576,7 @@ static bool chain_open(pa_stream_t stream, int k, int* rc) {
 
 int chain_record_fin(pa_stream_t stream, int DT, int PT, const float* part, int nblocks, int npass,
                      int D, int P, double scale, float* ll, float* gw, float* gb, double ll_offset) {
-  const bool shape_ok = (DT == 1 && (PT == 1 || PT == 2)) || (PT == 1 && (DT == 2 || DT == 4));
+  const bool shape_ok = (PT == 1 || PT == 2) && (DT == 1 || DT == 2 || DT == 4);
   if (!g_chain.on || !shape_ok) return 0;
   int rc;
   if (!chain_open(stream, CH_FIN, &rc)) return rc;

@@ -1126,7 +1126,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   // a guide draw parked in front of this launch (chain.h): the default f16 kernel draws w and b itself
   pa::GlmDraw draw;
   bool drawn = false;
-  if (format == PA_GLM_PLANES_F16X2 && N > 0) {
+  if (format == PA_GLM_PLANES_F16X2 && N > 0 && D <= 32) {
     const pa::GlmPlanesPlan p0 = pa::glmh_plan(N, P);
     if (p0.nb == 3 && p0.bpc < 4) drawn = pa::glm_take_pending_draw(stream, w, b, P, D, &draw);
   }

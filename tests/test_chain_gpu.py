@@ -456,3 +456,32 @@ def test_guide_draw_made_by_the_glm_kernel_is_bitwise_the_separate_launch(gpu):
                 assert torch.equal(a[1][k], b[1][k]), (D, with_bias, k)
     finally:
         kernels.chain_tune(fuse_tail=True)
+
+
+@pytest.mark.parametrize("D", [64, 100])
+def test_captured_step_with_feature_tiles_is_bitwise_the_eager_one(gpu, D):
+    """32 < D <= 128: the plane image with feature tiles (csrc/glm_planes16d.h) inside a captured step --
+    its finalize is a phase of the chained tail (record shape DT x 2), the guide draw stays its own
+    launch (only the D <= 32 kernel draws its own weights)."""
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    out = []
+    for graph in (False, True):
+        X, y = examples.synthetic_logreg_data(20000, D, gpu, seed=3)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(5)
+        pyro.enable_validation(False)
+        guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+        svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
+                  Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1),
+                  hip_graph=graph, graph_warmup=3)
+        losses = [svi.step(X, y) for _ in range(9)]
+        if graph:
+            assert svi.hip_graph and len(svi._graphs) == 1 and svi.chain_stats == [(1, 4)], svi.chain_stats
+        out.append((losses, _params(pyro)))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
