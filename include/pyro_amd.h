@@ -116,6 +116,19 @@ int pa_publish_scalar(int dtype, const void* src, double* host_value, uint64_t* 
                       uint64_t* counter, uint64_t inc, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * A latent with support (lower, inf) under a mean-field Normal guide (AutoNormal.forward,
+ * pyro/infer/autoguide/guides.py:494-519: value = biject_to(support)(u), log-density of the Delta site =
+ * transform.inv.log_abs_det_jacobian(value, u) summed over the event dims):
+ *   value[r,c] = lower + exp(u[r,c]),   log_density[r] = - sum_c u[r,c]       (one launch)
+ *   g_u[r,c]   = g_value[r,c] exp(u[r,c]) - g_log_density[r]                  (one launch; NULL gradient = 0)
+ * u / value contiguous [rows, cols], cols = the product of the site's event dims.
+ * ---------------------------------------------------------------------------------- */
+int pa_exp_site_fwd(int dtype, const void* u, int64_t rows, int64_t cols, double lower, void* value,
+                    void* log_density, pa_stream_t stream);
+int pa_exp_site_bwd(int dtype, const void* value, const void* g_value, const void* g_log_density, int64_t rows,
+                    int64_t cols, double lower, void* g_u, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * The step gate: a captured SVI step enqueued BEFORE the host asks for it.
  * (pyro/infer/svi.py:134-162: step() returns the loss, so the reference's loop has the host between
  * every two steps; here the launch latency of step k+1 overlaps the execution of step k.)

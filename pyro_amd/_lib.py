@@ -85,6 +85,9 @@ _SIGNATURES = {
     "pa_philox_uniform": (c_int, [c_void_p, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "pa_counter_add": (c_int, [c_void_p, c_uint64, c_void_p]),
     "pa_publish_scalar": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "pa_exp_site_fwd": (c_int, [c_int, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
+    "pa_exp_site_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p,
+                                c_void_p]),
     "pa_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pa_gate_scope": (c_int, [c_void_p]),
     "pa_gate_stats": (c_int, [c_void_p, c_void_p]),

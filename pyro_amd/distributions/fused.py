@@ -382,6 +382,49 @@ def standard_gamma(concentration, shape):
     return _StandardGamma.apply(concentration, shape, seed, off, off_dev)
 
 
+@_dispatcher_op("exp_site")
+class _ExpSite(torch.autograd.Function):
+    """A latent with support (lower, inf) under a Normal guide: value = lower + exp(u) and the Delta
+    site's log-density -sum_event u from ONE launch, their gradient from ONE (pa_exp_site_fwd / _bwd;
+    reference: AutoNormal.forward, guides.py:494-519 -- eight torch operators and their duals)."""
+
+    @staticmethod
+    def forward(ctx, u, cols, lower):
+        value, ld = kernels.exp_site_fwd(u.detach().contiguous(), cols, lower)
+        ctx.cols, ctx.lower = cols, lower
+        ctx.set_materialize_grads(False)        # an unused output's gradient arrives as None, not zeros
+        ctx.save_for_backward(value)
+        ld = ld.reshape(u.shape[:u.dim() - ctx_event_rank(u, cols)])
+        return value, ld
+
+    @staticmethod
+    def backward(ctx, g_value, g_ld):
+        (value,) = ctx.saved_tensors
+        if g_value is None and g_ld is None:
+            return None, None, None
+        gv = None if g_value is None else g_value.contiguous()
+        gl = None if g_ld is None else g_ld.contiguous().reshape(-1)
+        return kernels.exp_site_bwd(value, gv, gl, ctx.cols, ctx.lower), None, None
+
+
+def ctx_event_rank(u, cols):
+    """Number of trailing dims of ``u`` whose product is ``cols``."""
+    k, n = 0, 1
+    while n < cols:
+        k += 1
+        n *= int(u.shape[-k])
+    assert n == cols, (tuple(u.shape), cols)
+    return k
+
+
+def exp_site(u, event_rank, lower=0.0):
+    """(value = lower + exp(u), log_density = -(u summed over its ``event_rank`` rightmost dims))."""
+    cols = 1
+    for d in u.shape[u.dim() - event_rank:] if event_rank else ():
+        cols *= int(d)
+    return _ExpSite.apply(u, cols, float(lower))
+
+
 @_dispatcher_op("meanfield_normal_sample")
 class _MeanFieldSample(torch.autograd.Function):
     """All mean-field Normal sites of a guide: per site  scale = softplus(rho),

@@ -44,6 +44,22 @@ def _transform_to_softplus_positive(constraint):
 _IDENTITY = biject_to(constraints.real)
 
 
+def _exp_lower(transform):
+    """The lower bound L when ``transform`` is u -> L + exp(u) with a host-side scalar L (what
+    ``biject_to`` gives for positive / greater_than / nonnegative supports), else None."""
+    from torch.distributions import transforms as T
+    while type(transform) is T.IndependentTransform:      # (.to_event(k) sites: the sum over the event
+        transform = transform.base_transform              # dims is the caller's, by the site's event_dim)
+    if type(transform) is T.ExpTransform:
+        return 0.0
+    if type(transform) is T.ComposeTransform and len(transform.parts) == 2:
+        e, a = transform.parts
+        if (type(e) is T.ExpTransform and type(a) is T.AffineTransform and a.event_dim == 0
+                and isinstance(a.loc, (int, float)) and isinstance(a.scale, (int, float)) and a.scale == 1):
+            return float(a.loc)
+    return None
+
+
 def _is_identity(transform):
     while isinstance(transform, torch.distributions.transforms.IndependentTransform):
         transform = transform.base_transform
@@ -257,6 +273,8 @@ class AutoNormal(AutoGuide):
     def forward(self, *args, **kwargs):
         if self.prototype_trace is None:
             self._setup_prototype(*args, **kwargs)
+        from ... import kernels
+        from ...distributions import fused
         plates = self._create_plates(*args, **kwargs)
         fused_fns = self._fused_draw()
         result = {}
@@ -274,13 +292,21 @@ class AutoNormal(AutoGuide):
                 unconstrained_latent = sample(
                     name + "_unconstrained", base_fn.to_event(self._event_dims[name]),
                     infer={"is_auxiliary": True})
-                value = transform(unconstrained_latent)
-                if poutine.get_mask() is False or _is_identity(transform):
-                    log_density = 0.0      # real support: the Jacobian term is identically zero
+                lower = _exp_lower(transform)
+                if (lower is not None and poutine.get_mask() is not False
+                        and type(unconstrained_latent) is torch.Tensor
+                        and kernels.on_device(unconstrained_latent)
+                        and unconstrained_latent.dtype in (torch.float32, torch.float64)):
+                    # support (lower, inf): value and the Jacobian term from one kernel
+                    value, log_density = fused.exp_site(unconstrained_latent, site["fn"].event_dim, lower)
                 else:
-                    log_density = transform.inv.log_abs_det_jacobian(value, unconstrained_latent)
-                    log_density = sum_rightmost(
-                        log_density, log_density.dim() - value.dim() + site["fn"].event_dim)
+                    value = transform(unconstrained_latent)
+                    if poutine.get_mask() is False or _is_identity(transform):
+                        log_density = 0.0      # real support: the Jacobian term is identically zero
+                    else:
+                        log_density = transform.inv.log_abs_det_jacobian(value, unconstrained_latent)
+                        log_density = sum_rightmost(
+                            log_density, log_density.dim() - value.dim() + site["fn"].event_dim)
                 delta_dist = dist.Delta(value, log_density=log_density,
                                         event_dim=site["fn"].event_dim)
                 result[name] = sample(name, delta_dist)

@@ -278,6 +278,29 @@ def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
                                         _ptr(counter), int(inc), _stream()))
 
 
+def exp_site_fwd(u, cols, lower=0.0):
+    """u contiguous with prod(trailing dims) == cols per row -> (value = lower + exp(u) [u.shape],
+    log_density = -sum over each row [rows]).  pa_exp_site_fwd."""
+    _require_gpu(u)
+    assert u.is_contiguous() and u.dtype in (torch.float32, torch.float64) and cols >= 1
+    rows = u.numel() // cols
+    value = torch.empty_like(u)
+    ld = torch.empty((rows,), dtype=u.dtype, device=u.device)
+    check(_lib.load().pa_exp_site_fwd(_dtype(u), _ptr(u), rows, cols, float(lower), _ptr(value), _ptr(ld), _stream()))
+    return value, ld
+
+
+def exp_site_bwd(value, g_value, g_ld, cols, lower=0.0):
+    """d u = g_value * exp(u) - g_ld (per row); either gradient may be None."""
+    _require_gpu(value, g_value, g_ld)
+    assert value.is_contiguous()
+    rows = value.numel() // cols
+    g_u = torch.empty_like(value)
+    check(_lib.load().pa_exp_site_bwd(_dtype(value), _ptr(value), _ptr(g_value), _ptr(g_ld), rows, cols,
+                                      float(lower), _ptr(g_u), _stream()))
+    return g_u
+
+
 class StepGate:
     """The device / pinned-host words of one captured step's gate (include/pyro_amd.h "the step gate"):
     a replay enqueued ahead of time waits in its first node until the host writes its number into

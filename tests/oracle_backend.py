@@ -483,7 +483,24 @@ def chain_matvec(M, x, transpose=False):
     return torch.as_tensor(np.ascontiguousarray(y), dtype=x.dtype)
 
 
-FUNCTIONS = ["philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
+def exp_site_fwd(u, cols, lower=0.0):
+    a = _np(u).astype(np.float64)
+    value = lower + np.exp(a)
+    ld = -a.reshape(-1, cols).sum(1)
+    return torch.as_tensor(value, dtype=u.dtype), torch.as_tensor(ld, dtype=u.dtype)
+
+
+def exp_site_bwd(value, g_value, g_ld, cols, lower=0.0):
+    v = _np(value).astype(np.float64)
+    g = np.zeros_like(v)
+    if g_value is not None:
+        g = g + _np(g_value).astype(np.float64) * (v - lower)
+    if g_ld is not None:
+        g = (g.reshape(-1, cols) - _np(g_ld).astype(np.float64).reshape(-1, 1)).reshape(v.shape)
+    return torch.as_tensor(g, dtype=value.dtype)
+
+
+FUNCTIONS = ["exp_site_fwd", "exp_site_bwd", "philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "grouped_rows_of", "glm_grouped_rows_servable", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",

@@ -148,3 +148,81 @@ def test_median_of_the_fitted_guide(auto_class):
         assert {"AutoGuideList.0.locs.x", "AutoGuideList.1.loc", "AutoGuideList.1.cov_factor"} <= names
     else:
         assert pyro.param("AutoLowRankMultivariateNormal.cov_factor").shape == (3, 2)
+
+
+@pytest.mark.parametrize("support", ["positive", "tensor_bound", "event"])
+def test_positive_support_site_takes_the_one_kernel_form_with_the_transform_s_numbers(monkeypatch, support):
+    """AutoNormal.forward on a site with support (lower, inf): value and Jacobian term come from
+    fused.exp_site (one kernel each way) and equal biject_to(support)'s transform + log|det J|
+    (reference: guides.py:494-519), gradients included."""
+    from pyro_amd import kernels
+    from pyro_amd.distributions import fused
+
+    def model():
+        with pyro.plate("particles", 5, dim=-2):
+            if support == "positive":
+                with pyro.plate("g", 4, dim=-1):
+                    pyro.sample("tau", dist.HalfNormal(torch.ones((), dtype=torch.float64)))
+            elif support == "tensor_bound":
+                with pyro.plate("g", 4, dim=-1):
+                    pyro.sample("tau", dist.Pareto(torch.full((), 1.5, dtype=torch.float64),
+                                                   torch.full((), 3.0, dtype=torch.float64)))
+            else:
+                pyro.sample("tau", dist.LogNormal(torch.zeros(3, dtype=torch.float64), 1.0).to_event(1))
+
+    def run(fast):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(0)
+        calls = []
+        if fast:
+            real = fused.exp_site
+            monkeypatch.setattr(fused, "exp_site", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        else:
+            monkeypatch.setattr(kernels, "on_device", lambda t: False)
+        guide = AutoNormal(model)
+        tr = poutine.trace(guide).get_trace()
+        tr.compute_log_prob()
+        site = tr.nodes["tau"]
+        u = tr.nodes["tau_unconstrained"]["value"]
+        loss = (site["value"] * site["value"].cos()).sum() + 1.7 * site["log_prob"].sum()
+        params = [pyro.get_param_store()._params[n] for n in sorted(pyro.get_param_store().keys())]
+        grads = torch.autograd.grad(loss, params)
+        return site["value"].detach(), site["log_prob"].detach(), [g.detach() for g in grads], calls, u.detach()
+
+    v1, l1, g1, calls, u1 = run(True)
+    # (a bound held in a tensor would cost a device read per step: that site keeps the transform)
+    assert calls == ([] if support == "tensor_bound" else [1])
+    v0, l0, g0, _, u0 = run(False)
+    torch.testing.assert_close(u1, u0, rtol=0, atol=0)
+    torch.testing.assert_close(v1, v0, rtol=1e-14, atol=0)
+    torch.testing.assert_close(l1, l0, rtol=1e-14, atol=1e-14)
+    assert l1.shape == l0.shape
+    for a, b in zip(g1, g0):
+        torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-14)
+
+
+def test_exp_site_with_a_host_side_lower_bound():
+    from torch.distributions import biject_to, constraints
+    from pyro_amd.distributions import fused
+    from pyro_amd.infer.autoguide.guides import _exp_lower
+    assert _exp_lower(biject_to(constraints.greater_than(1.5))) == 1.5
+    assert _exp_lower(biject_to(constraints.positive)) == 0.0
+    assert _exp_lower(biject_to(constraints.independent(constraints.nonnegative, 2))) == 0.0
+    assert _exp_lower(biject_to(constraints.unit_interval)) is None
+    assert _exp_lower(biject_to(constraints.greater_than(torch.tensor(1.5)))) is None
+    u = torch.randn(3, 2, 4, dtype=torch.float64, requires_grad=True)
+    t = biject_to(constraints.greater_than(1.5))
+    for ed in (0, 1, 2):
+        value, ld = fused.exp_site(u, ed, 1.5)
+        ref_v = t(u)
+        ref_ld = t.inv.log_abs_det_jacobian(ref_v, u)
+        ref_ld = ref_ld.sum(tuple(range(-ed, 0))) if ed else ref_ld
+        torch.testing.assert_close(value, ref_v, rtol=1e-14, atol=0)
+        torch.testing.assert_close(ld, ref_ld, rtol=1e-14, atol=1e-14)
+        w = torch.randn_like(ld)
+        g, = torch.autograd.grad((value.sin()).sum() + (w * ld).sum(), u, retain_graph=True)
+        rg, = torch.autograd.grad((ref_v.sin()).sum() + (w * ref_ld).sum(), u)
+        torch.testing.assert_close(g, rg, rtol=1e-12, atol=1e-14)
+        # one of the two outputs unused: its gradient arrives as None / zeros
+        g, = torch.autograd.grad(value.sum(), u)
+        torch.testing.assert_close(g, ref_v.detach() - 1.5, rtol=1e-14, atol=0)
