@@ -129,6 +129,20 @@ int pa_exp_site_bwd(int dtype, const void* value, const void* g_value, const voi
                     int64_t cols, double lower, void* g_u, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * The score of a mean-field Normal guide site whose value is the guide's own reparameterised draw
+ * z[p,c] = loc[c] + scale[c] eps[p,c]  (Trace_ELBO scores it with Normal.log_prob and differentiates through
+ * z, loc and scale: pyro/infer/trace_elbo.py:142-160).  With eps fixed the three paths sum to d/d loc = 0,
+ * d/d scale = -1/scale per element, so:
+ *   sum_b partial[b] = coef * sum_{p,c} log Normal(z[p,c]; loc[c], scale[c])   (pa_meanfield_score_blocks(P, n)
+ *                      partial sums, each reduced in double in a fixed order)
+ *   gscale[c]        = -coef * P / scale[c]     = the TOTAL derivative of that sum w.r.t. scale[c]
+ * z contiguous [P, n]; loc, scale, gscale [n].
+ * ---------------------------------------------------------------------------------- */
+int64_t pa_meanfield_score_blocks(int64_t P, int64_t n);
+int pa_meanfield_score(int dtype, const void* z, const void* loc, const void* scale, int64_t P, int64_t n,
+                       double coef, void* partial, void* gscale, pa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * The step gate: a captured SVI step enqueued BEFORE the host asks for it.
  * (pyro/infer/svi.py:134-162: step() returns the loss, so the reference's loop has the host between
  * every two steps; here the launch latency of step k+1 overlaps the execution of step k.)
@@ -211,6 +225,10 @@ int pa_dist_log_prob_grad_nd(int dist, int dtype, void* d_value, void* d_p0, voi
 size_t pa_sum_to_nd_workspace(int64_t A, int64_t R, int64_t B);
 int pa_sum_to_nd(int dtype, const void* in, void* out, int64_t A, int64_t R, int64_t B,
                  void* workspace, size_t workspace_bytes, pa_stream_t stream);
+/* Two tensors of one shape (the two parameter gradients of a site) reduced by the same launches; results
+ * bitwise those of two pa_sum_to_nd calls.  Workspace: twice pa_sum_to_nd_workspace(A, R, B). */
+int pa_sum_to_nd_pair(int dtype, const void* in0, void* out0, const void* in1, void* out1, int64_t A,
+                      int64_t R, int64_t B, void* workspace, size_t workspace_bytes, pa_stream_t stream);
 
 /* Reparameterised Normal draw fused with the affine map (torch: normal.py:83-86):
  *   eps[r,c] = Philox normal (as pa_philox_normal with i = r*cols + c),

@@ -88,6 +88,9 @@ _SIGNATURES = {
     "pa_exp_site_fwd": (c_int, [c_int, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
     "pa_exp_site_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p,
                                 c_void_p]),
+    "pa_meanfield_score_blocks": (c_int64, [c_int64, c_int64]),
+    "pa_meanfield_score": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p,
+                                   c_void_p, c_void_p]),
     "pa_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pa_gate_scope": (c_int, [c_void_p]),
     "pa_gate_stats": (c_int, [c_void_p, c_void_p]),
@@ -217,6 +220,8 @@ _SIGNATURES = {
     "pa_sum_to_nd_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_sum_to_nd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                              c_size_t, c_void_p]),
+    "pa_sum_to_nd_pair": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                  c_void_p, c_size_t, c_void_p]),
     "pa_mvn_tril_sample": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_uint64,
                                    c_uint64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pa_mvn_tril_sample_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

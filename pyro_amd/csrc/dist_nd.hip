@@ -113,16 +113,25 @@ __global__ __launch_bounds__(ND_THREADS) void log_prob_grad_nd_kernel(
 // in[A, R, B] contiguous -> partial[A, K, B] (K splits of R) or out[A, B] directly when K == 1.
 // Thread (tb, tr): TB = min(pow2 >= B, 256) threads along the contiguous B, TR = 256 / TB rows of
 // R in flight per workgroup; grid = (B tiles, K, A).
+// With a second tensor (in1 / out1, same shape: the two parameter gradients of one site) the grid's y
+// extent is 2 K and the upper half works on the second pair; its partials follow the first tensor's.
 template <typename T>
 __global__ __launch_bounds__(256) void sum_to_nd_kernel(const T* __restrict__ in,
                                                         double* __restrict__ partial,
                                                         T* __restrict__ out, uint32_t A,
                                                         uint32_t R, uint32_t B, uint32_t TB,
-                                                        uint32_t K) {
+                                                        uint32_t K, const T* __restrict__ in1 = nullptr,
+                                                        T* __restrict__ out1 = nullptr) {
   __shared__ double sm[256];
   const uint32_t TR = 256 / TB;
   const uint32_t tb = threadIdx.x % TB, tr = threadIdx.x / TB;
-  const uint32_t bcol = blockIdx.x * TB + tb, k = blockIdx.y, a = blockIdx.z;
+  const uint32_t second = blockIdx.y >= K;
+  if (second) {
+    in = in1;
+    out = out1;
+    partial += (int64_t)A * K * B;
+  }
+  const uint32_t bcol = blockIdx.x * TB + tb, k = blockIdx.y - (second ? K : 0), a = blockIdx.z;
   const uint32_t per = (R + K - 1) / K;
   const uint32_t r0 = k * per, r1 = r0 + per < R ? r0 + per : R;
   double acc = 0.0;
@@ -149,8 +158,13 @@ __global__ __launch_bounds__(256) void sum_to_nd_kernel(const T* __restrict__ in
 template <typename T>
 __global__ __launch_bounds__(256) void sum_to_nd_final_kernel(const double* __restrict__ partial,
                                                               T* __restrict__ out, uint32_t A,
-                                                              uint32_t B, uint32_t K) {
+                                                              uint32_t B, uint32_t K,
+                                                              T* __restrict__ out1 = nullptr) {
   const int64_t n = (int64_t)A * B;
+  if (blockIdx.y == 1) {
+    partial += n * K;
+    out = out1;
+  }
   for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
     const int64_t a = o / B, bcol = o - a * B;
     const double* base = partial + a * K * B + bcol;
@@ -322,47 +336,64 @@ size_t pa_sum_to_nd_workspace(int64_t A, int64_t R, int64_t B) {
   return K > 1 ? (size_t)(A * K * B) * sizeof(double) : 0;
 }
 
-int pa_sum_to_nd(int dtype, const void* in, void* out, int64_t A, int64_t R, int64_t B,
-                 void* workspace, size_t workspace_bytes, pa_stream_t stream) {
-  PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "sum_to_nd: bad dtype %d", dtype);
-  PA_REQUIRE(A >= 0 && R >= 0 && B >= 0, "sum_to_nd: negative size");
+static int sum_to_nd_run(const char* who, int dtype, const void* in, void* out, const void* in1, void* out1,
+                         int64_t A, int64_t R, int64_t B, void* workspace, size_t workspace_bytes,
+                         pa_stream_t stream) {
+  const int two = out1 != nullptr;
+  PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "%s: bad dtype %d", who, dtype);
+  PA_REQUIRE(A >= 0 && R >= 0 && B >= 0, "%s: negative size", who);
   PA_REQUIRE(A < 65536 && R < (int64_t(1) << 31) && B < (int64_t(1) << 31) &&
-                 A * B < (int64_t(1) << 40), "sum_to_nd: shape too large");
+                 A * B < (int64_t(1) << 40), "%s: shape too large", who);
   if (A == 0 || B == 0) return PA_OK;
-  PA_REQUIRE(out, "sum_to_nd: NULL output");
+  PA_REQUIRE(out, "%s: NULL output", who);
   hipStream_t s = pa::as_stream(stream);
   const size_t esz = dtype == PA_F32 ? 4 : 8;
   if (R == 0) {
-    if (hipMemsetAsync(out, 0, (size_t)(A * B) * esz, s) != hipSuccess)
-      return pa::fail(PA_ERR_LAUNCH, "sum_to_nd: memset failed");
+    if (hipMemsetAsync(out, 0, (size_t)(A * B) * esz, s) != hipSuccess ||
+        (two && hipMemsetAsync(out1, 0, (size_t)(A * B) * esz, s) != hipSuccess))
+      return pa::fail(PA_ERR_LAUNCH, "%s: memset failed", who);
     return PA_OK;
   }
-  PA_REQUIRE(in, "sum_to_nd: NULL input");
+  PA_REQUIRE(in && (!two || in1), "%s: NULL input", who);
   uint32_t TB, K, bt;
   sum_to_plan(A, R, B, &TB, &K, &bt);
-  PA_REQUIRE(K == 1 || (workspace && workspace_bytes >= pa_sum_to_nd_workspace(A, R, B)),
-             "sum_to_nd: workspace too small");
-  dim3 grid(bt, K, (unsigned)A);
+  PA_REQUIRE(K == 1 || (workspace && workspace_bytes >= (two ? 2 : 1) * pa_sum_to_nd_workspace(A, R, B)),
+             "%s: workspace too small", who);
+  dim3 grid(bt, K * (two ? 2 : 1), (unsigned)A);
   if (dtype == PA_F32)
     hipLaunchKernelGGL((pa::sum_to_nd_kernel<float>), grid, dim3(256), 0, s, (const float*)in,
                        (double*)workspace, (float*)out, (uint32_t)A, (uint32_t)R, (uint32_t)B, TB,
-                       K);
+                       K, (const float*)in1, (float*)out1);
   else
     hipLaunchKernelGGL((pa::sum_to_nd_kernel<double>), grid, dim3(256), 0, s, (const double*)in,
                        (double*)workspace, (double*)out, (uint32_t)A, (uint32_t)R, (uint32_t)B,
-                       TB, K);
+                       TB, K, (const double*)in1, (double*)out1);
   int rc = pa::check_launch("sum_to_nd_kernel");
   if (rc != PA_OK || K == 1) return rc;
   const int64_t n = A * B;
   int64_t fb = (n + 255) / 256;
   if (fb > 1024) fb = 1024;
+  dim3 fgrid((unsigned)fb, two ? 2 : 1);
   if (dtype == PA_F32)
-    hipLaunchKernelGGL((pa::sum_to_nd_final_kernel<float>), dim3((unsigned)fb), dim3(256), 0, s,
-                       (const double*)workspace, (float*)out, (uint32_t)A, (uint32_t)B, K);
+    hipLaunchKernelGGL((pa::sum_to_nd_final_kernel<float>), fgrid, dim3(256), 0, s,
+                       (const double*)workspace, (float*)out, (uint32_t)A, (uint32_t)B, K, (float*)out1);
   else
-    hipLaunchKernelGGL((pa::sum_to_nd_final_kernel<double>), dim3((unsigned)fb), dim3(256), 0, s,
-                       (const double*)workspace, (double*)out, (uint32_t)A, (uint32_t)B, K);
+    hipLaunchKernelGGL((pa::sum_to_nd_final_kernel<double>), fgrid, dim3(256), 0, s,
+                       (const double*)workspace, (double*)out, (uint32_t)A, (uint32_t)B, K, (double*)out1);
   return pa::check_launch("sum_to_nd_final_kernel");
+}
+
+int pa_sum_to_nd(int dtype, const void* in, void* out, int64_t A, int64_t R, int64_t B,
+                 void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  return sum_to_nd_run("sum_to_nd", dtype, in, out, nullptr, nullptr, A, R, B, workspace, workspace_bytes,
+                       stream);
+}
+
+int pa_sum_to_nd_pair(int dtype, const void* in0, void* out0, const void* in1, void* out1, int64_t A,
+                      int64_t R, int64_t B, void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  PA_REQUIRE(out1 != nullptr || A == 0 || B == 0, "sum_to_nd_pair: NULL second output");
+  return sum_to_nd_run("sum_to_nd_pair", dtype, in0, out0, in1, out1, A, R, B, workspace, workspace_bytes,
+                       stream);
 }
 
 }  // extern "C"

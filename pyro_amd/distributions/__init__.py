@@ -108,4 +108,8 @@ class Independent(torch.distributions.Independent, TorchDistributionMixin):
             mask = mask.reshape(mask.shape + (1,) * self.reinterpreted_batch_ndims)
         f = getattr(self.base_dist, "fused_site_entry", None)
         return None if f is None else f(value, scale, mask)
+
+    def fused_score_term(self, value, scale=1.0, mask=None):
+        f = getattr(self.base_dist, "fused_score_term", None) if mask is None else None
+        return None if f is None else f(value, scale, mask)
 from .hmm import DiscreteHMM  # noqa: E402,F401

@@ -337,6 +337,14 @@ class Delta(TorchDistribution):
             return 0.0      # exactly zero whatever the scale / mask: no kernel, no tensor
         return None
 
+    def fused_score_term(self, value, scale=1.0, mask=None):
+        """The site's own draw, unscaled and unmasked: its score IS ``log_density``, handed over
+        un-summed so that the ELBO's one batched reduction adds it up (no reduction of its own)."""
+        if value is self.v and not self._zero_density and mask is None \
+                and not isinstance(scale, torch.Tensor) and scale == 1.0 and isinstance(self.log_density, torch.Tensor) and self.log_density.numel() > 0:
+            return self.log_density
+        return None
+
     @property
     def mean(self):
         return self.v

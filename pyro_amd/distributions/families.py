@@ -93,6 +93,9 @@ class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMix
     # a draw made ahead of time for this very distribution object (fused.meanfield_sample draws all
     # sites of a mean-field guide in one launch); handed out by rsample() when the shape matches
     _presampled = None
+    # ... and what it was drawn from: (z [P, n] as the kernel wrote it, loc_out [n], scale [n], P).  A site
+    # whose value IS that draw is scored in closed form (fused_linear_term below).
+    _drawn = None
 
     def __init__(self, loc, scale, validate_args=None):
         loc, scale = _on_device(loc, scale)
@@ -105,6 +108,7 @@ class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMix
         new._validate_args = self._validate_args
         new._base_params = getattr(self, "_base_params", None) or (self.loc, self.scale)
         new._presampled = self._presampled
+        new._drawn = self._drawn
         if "has_rsample" in self.__dict__:      # has_rsample_() set on this instance
             new.has_rsample = self.__dict__["has_rsample"]
         return new
@@ -125,6 +129,23 @@ class Normal(_FusedElementwise, torch.distributions.Normal, TorchDistributionMix
     def sample(self, sample_shape=torch.Size()):
         with torch.no_grad():
             return self.rsample(sample_shape)
+
+    def fused_score_term(self, value, scale=1.0, mask=None):
+        """A guide site scored at its own reparameterised draw z = loc + scale * eps: a small vector of
+        partial sums of scale * sum log q(z) from ONE pass over z, whose backward is one multiply.  With
+        eps fixed the derivative through z cancels the eps terms of the direct ones (d/d loc = 0, d/d scale
+        = -1/scale), which is what autograd arrives at through Normal.log_prob's three paths (reference:
+        trace_elbo.py:142-160) up to rounding.  Offered after the many-small-sites launch has declined
+        the site (too large); None when the value is not this object's own draw."""
+        drawn = self._drawn
+        if drawn is None or value is not self._presampled or mask is not None \
+                or isinstance(scale, torch.Tensor):
+            return None
+        from .. import kernels
+        z, loc, sc, P = drawn
+        if not kernels.on_device(z):
+            return None
+        return fused.drawn_score(z, loc, sc, P, float(scale))
 
 
 class LogNormal(_FusedElementwise, torch.distributions.LogNormal, TorchDistributionMixin):

@@ -104,20 +104,14 @@ def _frame_lazy(operands, shape):
     return frame(operands, shape)
 
 
-def _sum_to(g, like):
-    """``g`` (the frame's shape) summed down to the shape of the broadcast operand ``like``: large
-    device tensors go through pa_sum_to_nd, one pass per run of adjacent broadcast dims."""
-    if g is None:
-        return None
-    if g.shape == like.shape:
-        return g
-    if g.numel() < _ND_MIN_ELEMS or not kernels.on_device(g) \
-            or g.dtype not in (torch.float32, torch.float64):
-        return g.sum_to_size(like.shape) if like.dim() > 0 or g.dim() > 0 else g
-    shape = list(g.shape)
-    lead = len(shape) - like.dim()
-    keep = [False] * lead + [ls == s for ls, s in zip(like.shape, shape[lead:])]   # False = reduce
-    x = g.contiguous()
+def _sum_plan(shape, like_shape):
+    """The pa_sum_to_nd passes [(A, R, B), ...] that bring a tensor of ``shape`` down to the broadcast
+    operand's ``like_shape`` (one pass per run of adjacent reduced dims), or None when a pass falls
+    outside the kernel's grid."""
+    shape = list(shape)
+    lead = len(shape) - len(like_shape)
+    keep = [False] * lead + [ls == s for ls, s in zip(like_shape, shape[lead:])]   # False = reduce
+    plan = []
     d = len(shape) - 1
     while d >= 0:
         if keep[d] or shape[d] == 1:
@@ -136,12 +130,50 @@ def _sum_to(g, like):
         for s_ in shape[hi + 1:]:
             B *= s_
         if A >= 65536:                      # outside the kernel's grid: let torch do this one
-            return g.sum_to_size(like.shape)
-        x = kernels.sum_to_nd(x, A, R, B)
+            return None
+        plan.append((A, R, B))
         for j in range(d, hi + 1):
             shape[j] = 1
         d -= 1
+    return plan
+
+
+def _sum_to_eligible(g):
+    return g.numel() >= _ND_MIN_ELEMS and kernels.on_device(g) and g.dtype in (torch.float32, torch.float64)
+
+
+def _sum_to(g, like):
+    """``g`` (the frame's shape) summed down to the shape of the broadcast operand ``like``: large
+    device tensors go through pa_sum_to_nd, one pass per run of adjacent broadcast dims."""
+    if g is None:
+        return None
+    if g.shape == like.shape:
+        return g
+    if not _sum_to_eligible(g):
+        return g.sum_to_size(like.shape) if like.dim() > 0 or g.dim() > 0 else g
+    plan = _sum_plan(g.shape, like.shape)
+    if plan is None:
+        return g.sum_to_size(like.shape)
+    x = g.contiguous()
+    for A, R, B in plan:
+        x = kernels.sum_to_nd(x, A, R, B)
     return x.reshape(like.shape)
+
+
+def _sum_to_pair(g0, like0, g1, like1):
+    """(_sum_to(g0, like0), _sum_to(g1, like1)); two gradients of one shape going down to one shape (a
+    site's two parameters broadcast alike) share their launches (pa_sum_to_nd_pair)."""
+    if (g0 is None or g1 is None or g0.shape != g1.shape or like0.shape != like1.shape
+            or g0.shape == like0.shape or g0.dtype != g1.dtype or not _sum_to_eligible(g0)
+            or not kernels.on_device(g1)):
+        return _sum_to(g0, like0), _sum_to(g1, like1)
+    plan = _sum_plan(g0.shape, like0.shape)
+    if plan is None:
+        return _sum_to(g0, like0), _sum_to(g1, like1)
+    x0, x1 = g0.contiguous(), g1.contiguous()
+    for A, R, B in plan:
+        x0, x1 = kernels.sum_to_nd_pair(x0, x1, A, R, B)
+    return x0.reshape(like0.shape), x1.reshape(like1.shape)
 
 
 def _nd_frame(operands, shape):
@@ -294,9 +326,13 @@ class _LogProbSum(torch.autograd.Function):
             rows, cols, (v2, a2, b2, m2) = frame([value, p0, p1, mask], shape)
             dv, da, db = kernels.dist_log_prob_grad(ctx.dist_id, g.reshape(1, 1), v2, a2, b2, m2,
                                                     ctx.scale, rows, cols, need)
-        outs = [None if d is None else _sum_to(d.reshape(shape), like)
-                for d, like in ((dv, value), (da, p0), (db, p1))]
-        return (None,) + tuple(outs) + (None, None)
+        dv = None if dv is None else _sum_to(dv.reshape(shape), value)
+        if da is not None and db is not None:
+            da, db = _sum_to_pair(da.reshape(shape), p0, db.reshape(shape), p1)
+        else:
+            da = None if da is None else _sum_to(da.reshape(shape), p0)
+            db = None if db is None else _sum_to(db.reshape(shape), p1)
+        return (None, dv, da, db, None, None)
 
 
 @_dispatcher_op("dirichlet_log_prob")
@@ -423,6 +459,29 @@ def exp_site(u, event_rank, lower=0.0):
     for d in u.shape[u.dim() - event_rank:] if event_rank else ():
         cols *= int(d)
     return _ExpSite.apply(u, cols, float(lower))
+
+
+@_dispatcher_op("drawn_score")
+class _DrawnScore(torch.autograd.Function):
+    """coef * sum log Normal(z; loc, scale) at the guide's own draw z = loc + scale * eps, as a vector of
+    partial sums (pa_meanfield_score); differentiable in ``scale`` only, with the TOTAL derivative
+    -coef * P / scale (the paths through z and loc are accounted for: they cancel the eps terms)."""
+
+    @staticmethod
+    def forward(ctx, scale, z, loc, P, coef):
+        partial, gscale = kernels.meanfield_score(z.detach(), loc.detach(), scale.detach(), P, coef)
+        ctx.save_for_backward(gscale)
+        return partial
+
+    @staticmethod
+    def backward(ctx, g):
+        (gscale,) = ctx.saved_tensors
+        # every partial sum has the same upstream coefficient (they are summed by the caller)
+        return gscale * g.reshape(-1)[0], None, None, None, None
+
+
+def drawn_score(z, loc, scale, P, coef):
+    return _DrawnScore.apply(scale, z, loc, P, coef)
 
 
 @_dispatcher_op("meanfield_normal_sample")

@@ -267,6 +267,7 @@ class AutoNormal(AutoGuide):
                 lead[len(lead) + batch_rank + d] = size
             fn = dist.Normal(loc_out.reshape(loc.shape), scale.reshape(loc.shape))
             fn._presampled = z.reshape(tuple(lead) + tuple(loc.shape))
+            fn._drawn = (z, loc_out, scale, P)
             out[name] = fn
         return out
 

@@ -301,6 +301,22 @@ def exp_site_bwd(value, g_value, g_ld, cols, lower=0.0):
     return g_u
 
 
+def meanfield_score(z, loc, scale, P, coef):
+    """(partial sums of coef * sum log Normal(z; loc, scale) [blocks], -coef * P / scale [n]) for a draw
+    z [P, n] of the guide's own (pa_meanfield_score)."""
+    _require_gpu(z, loc, scale)
+    n = loc.numel()
+    assert z.is_contiguous() and loc.is_contiguous() and scale.is_contiguous() and z.numel() == P * n
+    assert z.dtype == loc.dtype == scale.dtype
+    lib = _lib.load()
+    nb = lib.pa_meanfield_score_blocks(P, n)
+    partial = torch.empty((nb,), dtype=z.dtype, device=z.device)
+    gscale = torch.empty((n,), dtype=z.dtype, device=z.device)
+    check(lib.pa_meanfield_score(_dtype(z), _ptr(z), _ptr(loc), _ptr(scale), P, n, float(coef), _ptr(partial),
+                                 _ptr(gscale), _stream()))
+    return partial, gscale
+
+
 class StepGate:
     """The device / pinned-host words of one captured step's gate (include/pyro_amd.h "the step gate"):
     a replay enqueued ahead of time waits in its first node until the host writes its number into
@@ -454,6 +470,21 @@ def sum_to_nd(x, A, R, B):
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device) if nbytes else None
     check(lib.pa_sum_to_nd(_dtype(x), _ptr(x), _ptr(out), A, R, B, _ptr(ws), nbytes, _stream()))
     return out
+
+
+def sum_to_nd_pair(x0, x1, A, R, B):
+    """Two contiguous tensors viewed as [A, R, B] -> two [A, B] by the same launches (pa_sum_to_nd_pair)."""
+    _require_gpu(x0, x1)
+    assert x0.is_contiguous() and x1.is_contiguous() and x0.numel() == x1.numel() == A * R * B
+    assert x0.dtype == x1.dtype
+    lib = _lib.load()
+    out0 = torch.empty((A, B), dtype=x0.dtype, device=x0.device)
+    out1 = torch.empty_like(out0)
+    nbytes = 2 * lib.pa_sum_to_nd_workspace(A, R, B)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device) if nbytes else None
+    check(lib.pa_sum_to_nd_pair(_dtype(x0), _ptr(x0), _ptr(out0), _ptr(x1), _ptr(out1), A, R, B, _ptr(ws),
+                                nbytes, _stream()))
+    return out0, out1
 
 
 def normal_rsample(loc, scale, rows, cols, seed, offset, want_eps=True, offset_dev=None):

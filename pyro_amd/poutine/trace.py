@@ -203,7 +203,10 @@ class Trace:
                         raise self._site_error(name, site, e, "log_prob_sum") from e
                     if lin is not None and batch.add_linear_term(lin[0], lin[1], sign):
                         continue
-                batch_fn = getattr(fn, "fused_log_prob_batch", None) if plain else None
+                score_fn = getattr(fn, "fused_score_term", None) if plain else None
+                if score_fn is not None and torch.is_grad_enabled():
+                    term = score_fn(value, scale, mask)          # a guide site at its own draw
+                batch_fn = getattr(fn, "fused_log_prob_batch", None) if plain and term is None else None
                 if batch_fn is not None:
                     try:
                         term = batch_fn(value, scale, mask)      # e.g. per-particle sums ll[P]

@@ -121,6 +121,10 @@ def sum_to_nd(x, A, R, B):
     return torch.as_tensor(np.ascontiguousarray(_np(x).reshape(A, R, B).sum(1)), dtype=x.dtype)
 
 
+def sum_to_nd_pair(x0, x1, A, R, B):
+    return sum_to_nd(x0, A, R, B), sum_to_nd(x1, A, R, B)
+
+
 def _entry_np(e):
     rows, cols = e["rows"], e["cols"]
     v = _bc(e["value"], rows, cols).astype(np.float64)
@@ -483,6 +487,15 @@ def chain_matvec(M, x, transpose=False):
     return torch.as_tensor(np.ascontiguousarray(y), dtype=x.dtype)
 
 
+def meanfield_score(z, loc, scale, P, coef):
+    n = loc.numel()
+    zz = _np(z).astype(np.float64).reshape(P, n)
+    l, s = _np(loc).astype(np.float64).reshape(-1), _np(scale).astype(np.float64).reshape(-1)
+    lp = -np.log(s)[None, :] - 0.5 * ((zz - l[None, :]) / s[None, :]) ** 2 - 0.5 * np.log(2 * np.pi)
+    partial = torch.as_tensor(np.array([coef * lp.sum()]), dtype=z.dtype)
+    return partial, torch.as_tensor(-coef * P / s, dtype=z.dtype)
+
+
 def exp_site_fwd(u, cols, lower=0.0):
     a = _np(u).astype(np.float64)
     value = lower + np.exp(a)
@@ -500,7 +513,7 @@ def exp_site_bwd(value, g_value, g_ld, cols, lower=0.0):
     return torch.as_tensor(g, dtype=value.dtype)
 
 
-FUNCTIONS = ["exp_site_fwd", "exp_site_bwd", "philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
+FUNCTIONS = ["exp_site_fwd", "exp_site_bwd", "meanfield_score", "sum_to_nd_pair", "philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "grouped_rows_of", "glm_grouped_rows_servable", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",

@@ -226,3 +226,53 @@ def test_exp_site_with_a_host_side_lower_bound():
         # one of the two outputs unused: its gradient arrives as None / zeros
         g, = torch.autograd.grad(value.sum(), u)
         torch.testing.assert_close(g, ref_v.detach() - 1.5, rtol=1e-14, atol=0)
+
+
+def test_large_guide_site_scored_in_closed_form_matches_autograd_through_log_prob(monkeypatch):
+    """A mean-field site too large for the many-small-sites launch, scored at the guide's own draw:
+    Normal.fused_score_term hands over sum log q(z) with its TOTAL derivative (-1/scale per element, 0 for
+    loc) behind a single autograd node.  Loss and parameter gradients equal the ones autograd derives through
+    Normal.log_prob's three paths (reference: trace_elbo.py:142-160) to rounding."""
+    from pyro_amd import _lib
+    from pyro_amd.distributions.families import Normal
+
+    G, D, P = 50, 8, 16
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(300, D, dtype=torch.float64, generator=g)
+    y = (torch.rand(300, dtype=torch.float64, generator=g) < 0.5).double()
+    grp = torch.randint(0, G, (300,), generator=g)
+
+    def model():
+        tau = pyro.sample("tau", dist.HalfNormal(torch.ones(D, dtype=torch.float64)).to_event(1))
+        with pyro.plate("groups", G):
+            w = pyro.sample("w", dist.Normal(torch.zeros(D, dtype=torch.float64), tau).to_event(1))
+        with pyro.plate("data", 300):
+            pyro.sample("obs", dist.Bernoulli(logits=(w[..., grp, :] * X).sum(-1)), obs=y)
+
+    monkeypatch.setattr(_lib, "MULTI_MAX_ELEMS", 1000)       # w's draw: 16 x 400 elements, its scale: 400
+    real = Normal.fused_score_term
+
+    def run(closed_form):
+        calls = []
+
+        def spy(self, value, scale=1.0, mask=None):
+            out = real(self, value, scale, mask) if closed_form else None
+            if out is not None:
+                calls.append(tuple(value.shape))
+            return out
+
+        monkeypatch.setattr(Normal, "fused_score_term", spy)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(1)
+        guide = AutoNormal(model, init_scale=0.3)
+        elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+        loss = elbo.loss_and_grads(model, guide)
+        store = pyro.get_param_store()
+        return loss, {n: store._params[n].grad.clone() for n in sorted(store.keys())}, calls
+
+    loss1, g1, calls = run(True)
+    assert calls == [(P, G, D)]
+    loss0, g0, _ = run(False)
+    assert loss1 == pytest.approx(loss0, rel=1e-12)
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-9, atol=1e-11)

@@ -1347,6 +1347,41 @@ def test_sum_to_nd(gpu, dtype, A, R, B):
     torch.testing.assert_close(got.double(), ref, rtol=tol, atol=tol * np.sqrt(R) * 4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("A,R,B", [(64, 1000, 32), (1, 64, 32000), (3, 5, 7), (1, 300000, 3), (5, 1, 9)])
+def test_sum_to_nd_pair_is_bitwise_two_single_reductions(gpu, dtype, A, R, B):
+    """pa_sum_to_nd_pair: the two parameter gradients of one site through the same launches; each result
+    bitwise the one pa_sum_to_nd gives on its own (same partition, same summation order)."""
+    k = _k()
+    rng = np.random.default_rng(A * 7 + R + B)
+    x0 = torch.tensor(rng.standard_normal((A, R, B)), dtype=dtype, device=gpu)
+    x1 = torch.tensor(rng.standard_normal((A, R, B)) * 3 + 1, dtype=dtype, device=gpu)
+    o0, o1 = k.sum_to_nd_pair(x0, x1, A, R, B)
+    assert o0.shape == o1.shape == (A, B)
+    assert torch.equal(o0, k.sum_to_nd(x0, A, R, B)) and torch.equal(o1, k.sum_to_nd(x1, A, R, B))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("P,n", [(64, 32000), (1, 1), (3, 7), (512, 33), (5, 70001)])
+def test_meanfield_score_against_the_restatement(gpu, dtype, P, n):
+    """pa_meanfield_score: sum of the partial sums = coef * sum log Normal(z; loc, scale), gscale =
+    -coef P / scale.  float64 rtol 1e-12; float32 against the float64 restatement of the SAME float32
+    inputs rtol 2e-6 (the partial sums are rounded to float32 once each)."""
+    from tests import oracle_backend as ob
+    k = _k()
+    rng = np.random.default_rng(P + n)
+    loc = torch.tensor(rng.standard_normal(n), dtype=dtype, device=gpu)
+    scale = torch.tensor(rng.uniform(0.05, 2.0, n), dtype=dtype, device=gpu)
+    z = (loc + scale * torch.tensor(rng.standard_normal((P, n)), dtype=dtype, device=gpu)).contiguous()
+    partial, gscale = k.meanfield_score(z, loc, scale, P, -0.25)
+    again, _ = k.meanfield_score(z, loc, scale, P, -0.25)
+    assert torch.equal(partial, again)                   # deterministic
+    rp, rg = ob.meanfield_score(z.double().cpu(), loc.double().cpu(), scale.double().cpu(), P, -0.25)
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    assert float(partial.double().sum()) == pytest.approx(float(rp.sum()), rel=tol)
+    torch.testing.assert_close(gscale.double().cpu(), rg, rtol=tol, atol=0)
+
+
 @pytest.mark.parametrize("Wd,B,V,H", [(64, 3000, 1024, 100), (7, 65, 128, 128), (30, 32, 256, 1)])
 def test_bag_of_words_linear(gpu, Wd, B, V, H):
     """The first layer of examples/lda.py's amortised guide without the per-step histogram

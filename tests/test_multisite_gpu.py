@@ -386,3 +386,62 @@ def test_positive_site_through_the_guide_equals_the_transform_path():
     torch.testing.assert_close(l1, l0, rtol=2e-6, atol=2e-6)
     for a, b in zip(g1, g0):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_large_guide_site_closed_form_score_equals_autograd_through_log_prob(dtype, monkeypatch):
+    """Config 5's guide site w [64, 1000, 32] (too large for the many-small-sites launch) scored by
+    Normal.fused_score_term (pa_meanfield_score: value in one pass, total derivative -1/scale in closed
+    form) against the same Philox draw scored by Normal.log_prob + autograd (log_prob_sum / grad / sum_to
+    kernels).  float64: loss rel 1e-12, gradients rtol 1e-9 (the eps terms that cancel analytically cancel
+    to rounding in autograd); float32: loss rel 2e-6, gradients rtol 2e-4 of each gradient's max."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.distributions.families import Normal
+    from pyro_amd.infer import Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+    dev = torch.device("cuda:0")
+    G, D, P, N = 1000, 32, 64, 20000
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, D, dtype=dtype, generator=g).to(dev)
+    y = (torch.rand(N, generator=g) < 0.5).to(dtype).to(dev)
+    grp = torch.randint(0, G, (N,), generator=g).to(dev)
+
+    def model():
+        mu = pyro.sample("mu", dist.Normal(torch.zeros(D, dtype=dtype, device=dev), 1.0).to_event(1))
+        tau = pyro.sample("tau", dist.HalfNormal(torch.ones(D, dtype=dtype, device=dev)).to_event(1))
+        with pyro.plate("groups", G):
+            w = pyro.sample("w", dist.Normal(mu, tau).to_event(1))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=(w[..., grp, :] * X).sum(-1)), obs=y)
+
+    real = Normal.fused_score_term
+
+    def run(closed_form):
+        calls = []
+
+        def spy(self, value, scale=1.0, mask=None):
+            out = real(self, value, scale, mask) if closed_form else None
+            if out is not None:
+                calls.append(tuple(value.shape))
+            return out
+
+        monkeypatch.setattr(Normal, "fused_score_term", spy)
+        pyro.clear_param_store()
+        pyro.set_rng_seed(1)
+        guide = AutoNormal(model, init_scale=0.1)
+        elbo = Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1)
+        loss = elbo.loss_and_grads(model, guide)
+        store = pyro.get_param_store()
+        return loss, {n: store._params[n].grad.clone() for n in sorted(store.keys())}, calls
+
+    loss1, g1, calls = run(True)
+    assert calls == [(P, G, D)]
+    loss0, g0, _ = run(False)
+    f64 = dtype == torch.float64
+    assert loss1 == pytest.approx(loss0, rel=1e-12 if f64 else 2e-6)
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-9 if f64 else 2e-4,
+                                   atol=(1e-11 if f64 else 2e-4) * scale)
+    pyro.clear_param_store()
