@@ -400,12 +400,12 @@ static int glm_launch(const GlmPlan& pl, const float* X, const float* y, const f
 // gw[p, g, d] = scale * sum over the segments of group g; ll[p], gb[p] = scale * sum over ALL
 // segments.  fp64 accumulation in a fixed order.
 template <int DT, int PT>
-__global__ __launch_bounds__(256) void glm_grouped_finalize_gw_kernel(
-    const float* __restrict__ part, const int64_t* __restrict__ group_seg_off, int nseg, int D,
+__device__ __forceinline__ void glm_grouped_finalize_gw(
+    unsigned bid, const float* __restrict__ part, const int64_t* __restrict__ group_seg_off, int nseg, int D,
     int P, int G, double scale, float* __restrict__ gw) {
   constexpr int REC = glm_record_floats<DT, PT>();
   const int64_t J = (int64_t)P * G * D;
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = (int64_t)bid * 256 + threadIdx.x;
   if (j >= J) return;
   const int d = (int)(j % D);
   const int g = (int)((j / D) % G);
@@ -422,13 +422,13 @@ __global__ __launch_bounds__(256) void glm_grouped_finalize_gw_kernel(
 }
 
 template <int DT, int PT>
-__global__ __launch_bounds__(256) void glm_grouped_finalize_scalar_kernel(
-    const float* __restrict__ part, int nseg, int P, double scale, float* __restrict__ ll,
+__device__ __forceinline__ void glm_grouped_finalize_scalar(
+    unsigned bid, const float* __restrict__ part, int nseg, int P, double scale, float* __restrict__ ll,
     float* __restrict__ gb, double ll_offset) {
   constexpr int REC = glm_record_floats<DT, PT>();
   __shared__ double smem[16];
-  const int which = blockIdx.x >= (unsigned)P ? 1 : 0;       // 0: ll, 1: gb
-  const int p = blockIdx.x - which * P;
+  const int which = bid >= (unsigned)P ? 1 : 0;       // 0: ll, 1: gb
+  const int p = bid - which * P;
   const int pl = p % (32 * PT), pt = pl >> 5, i = pl & 31;
   const int slot = PT * DT * 1024 + (2 * pt + which) * 32 + i;
   const int pass = p / (32 * PT);
@@ -437,6 +437,28 @@ __global__ __launch_bounds__(256) void glm_grouped_finalize_scalar_kernel(
   for (int sgi = threadIdx.x; sgi < nseg; sgi += 256) acc += (double)base[(int64_t)sgi * REC];
   const double t = block_sum_f64(acc, smem);
   if (threadIdx.x == 0) (which ? gb : ll)[p] = (float)((t + (which ? 0.0 : ll_offset)) * scale);
+}
+
+// one launch: the first `gw_blocks` workgroups write gw, the next 2 P reduce ll and gb
+template <int DT, int PT>
+__global__ __launch_bounds__(256) void glm_grouped_finalize_kernel(
+    const float* __restrict__ part, const int64_t* __restrict__ group_seg_off, int nseg, int D, int P, int G,
+    double scale, float* __restrict__ gw, float* __restrict__ ll, float* __restrict__ gb, double ll_offset,
+    unsigned gw_blocks) {
+  if (blockIdx.x < gw_blocks)
+    glm_grouped_finalize_gw<DT, PT>(blockIdx.x, part, group_seg_off, nseg, D, P, G, scale, gw);
+  else
+    glm_grouped_finalize_scalar<DT, PT>(blockIdx.x - gw_blocks, part, nseg, P, scale, ll, gb, ll_offset);
+}
+
+template <int DT, int PT>
+static void glm_grouped_finalize_launch(const float* part, const int64_t* group_seg_off, int nseg, int D, int P,
+                                        int G, double scale, float* gw, float* ll, float* gb, double ll_offset,
+                                        hipStream_t s) {
+  const int64_t J = (int64_t)P * G * D;
+  const unsigned gw_blocks = (unsigned)((J + 255) / 256);
+  hipLaunchKernelGGL((glm_grouped_finalize_kernel<DT, PT>), dim3(gw_blocks + (unsigned)(2 * P)), dim3(256), 0, s,
+                     part, group_seg_off, nseg, D, P, G, scale, gw, ll, gb, ll_offset, gw_blocks);
 }
 
 template <int DT, int PT>
@@ -479,11 +501,7 @@ static int glm_grouped_launch(const float* X, const float* y, const float* w, co
   if (br) (void)hipEventRecord(ev1, s);
   int rc = check_launch("glm_bernoulli_kernel<grouped>");
   if (rc != PA_OK) return rc;
-  const int64_t J = (int64_t)P * G * D;
-  hipLaunchKernelGGL((glm_grouped_finalize_gw_kernel<DT, PT>), dim3((unsigned)((J + 255) / 256)),
-                     dim3(256), 0, s, part, group_seg_off, nseg, D, P, G, scale, gw);
-  hipLaunchKernelGGL((glm_grouped_finalize_scalar_kernel<DT, PT>), dim3((unsigned)(2 * P)),
-                     dim3(256), 0, s, part, nseg, P, scale, ll, gb, 0.0);
+  glm_grouped_finalize_launch<DT, PT>(part, group_seg_off, nseg, D, P, G, scale, gw, ll, gb, 0.0, s);
   return check_launch("glm_grouped_finalize");
 }
 
@@ -958,11 +976,8 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, cons
   // the padding rows of every segment's last super-tile added log2(2) = 1 each to the log2(1 + e)
   // sum of every particle: ln2 per row back in
   const double ll_offset = (double)(nst_total * 64 - N) * 0.6931471805599453;
-  const int64_t J = (int64_t)P * G * D;
-  hipLaunchKernelGGL((pa::glm_grouped_finalize_gw_kernel<1, 2>), dim3((unsigned)((J + 255) / 256)),
-                     dim3(256), 0, s, part, group_seg_off, (int)nseg, (int)D, (int)P, (int)G, scale, gw);
-  hipLaunchKernelGGL((pa::glm_grouped_finalize_scalar_kernel<1, 2>), dim3((unsigned)(2 * P)),
-                     dim3(256), 0, s, part, (int)nseg, (int)P, scale, ll, gb, ll_offset);
+  pa::glm_grouped_finalize_launch<1, 2>(part, group_seg_off, (int)nseg, (int)D, (int)P, (int)G, scale, gw, ll,
+                                        gb, ll_offset, s);
   return pa::check_launch("glm_grouped_finalize");
 }
 

@@ -141,7 +141,7 @@ int pa_meanfield_normal_sample_bwd(int dtype, const pa_mf_site* sites, int nsite
                "pa_meanfield_normal_sample_bwd: site %d: NULL pointer", k);
     if (sites[k].n > maxn) maxn = sites[k].n;
   }
-  int64_t gy = (maxn + 255) / 256;
+  int64_t gy = (maxn >= pa::MF_BWD_WIDE_N && P >= 16) ? (maxn + 63) / 64 : (maxn + 255) / 256;
   if (gy < 1) gy = 1;
   if (gy > 4096) gy = 4096;
   if (dtype == PA_F32) {

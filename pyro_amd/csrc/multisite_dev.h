@@ -599,6 +599,56 @@ __global__ __launch_bounds__(256) void meanfield_sample_block_kernel(const MfArg
   // advances with the element instead of a 64-bit modulo per element
   constexpr int PER = sizeof(T) == 4 ? 4 : 2;
   const int64_t nblk = (total + PER - 1) / PER;
+  // A site whose rows are whole blocks (n % PER == 0, 16-byte aligned outputs): thread -> (a block of PER
+  // columns, a stride of particles).  softplus(rho) of those columns is evaluated ONCE per thread, not once
+  // per element, and each block's draws leave as one 16-byte store per output.  Same blocks, same
+  // arithmetic: bitwise the loop below.
+  if (s.n % PER == 0 && P >= 2 &&
+      ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(eps)) & 15) == 0) {
+    typedef T vecT __attribute__((ext_vector_type(PER)));
+    const int64_t nq = s.n / PER, nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t npc = nthreads / nq;                 // particle strides that fit the grid
+    const int64_t want = P / 4 > 1 ? P / 4 : 1;  // ... but at least ~4 particles per thread
+    if (npc > want) npc = want;
+    const int64_t pc = npc > 0 ? tid / nq : 0, pstep = npc > 0 ? npc : 1;
+    if (npc > 0 && pc >= npc) return;
+    for (int64_t cq = npc > 0 ? tid % nq : tid; cq < nq; cq += npc > 0 ? nq : nthreads) {
+      T sp[PER], lc[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        sp[u] = softplus_t<T>(rho[cq * PER + u]);
+        lc[u] = loc[cq * PER + u];
+      }
+      if (pc == 0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          sc[cq * PER + u] = sp[u];
+          lo[cq * PER + u] = lc[u];
+        }
+      }
+      for (int64_t p = pc; p < P; p += pstep) {
+        const int64_t q = p * nq + cq;
+        const u32x4 blk = philox4x32_10(seed, off + (uint64_t)q, 0);
+        vecT e, zz;
+        if constexpr (sizeof(T) == 4) {
+          float a0, a1, a2, a3;
+          box_muller_f32(u32_to_unit_f32(blk.x), u32_to_unit_f32(blk.y), a0, a1);
+          box_muller_f32(u32_to_unit_f32(blk.z), u32_to_unit_f32(blk.w), a2, a3);
+          e[0] = a0; e[1] = a1; e[2] = a2; e[3] = a3;
+        } else {
+          double a0, a1;
+          box_muller_f64(u32x2_to_unit_f64(blk.x, blk.y), u32x2_to_unit_f64(blk.z, blk.w), a0, a1);
+          e[0] = a0; e[1] = a1;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) zz[u] = t_fma(sp[u], (T)e[u], lc[u]);
+        *reinterpret_cast<vecT*>(eps + q * PER) = e;
+        *reinterpret_cast<vecT*>(z + q * PER) = zz;
+      }
+    }
+    return;
+  }
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nblk;
        q += (int64_t)gridDim.x * blockDim.x) {
     const u32x4 blk = philox4x32_10(seed, off + (uint64_t)q, 0);
@@ -634,6 +684,7 @@ __global__ __launch_bounds__(256) void meanfield_sample_block_kernel(const MfArg
 
 // grid = (sites, column tiles): a column's sum over the P particles is independent of every other
 // column, so a large (plated) site spreads over many workgroups; small sites use tile 0 only
+constexpr uint32_t MF_BWD_WIDE_N = 4096;
 template <typename T>
 __device__ __forceinline__ void meanfield_sample_bwd_body(uint32_t kbase, uint32_t site, uint32_t tile,
                                                           uint32_t ntiles, int64_t P) {
@@ -648,7 +699,10 @@ __device__ __forceinline__ void meanfield_sample_bwd_body(uint32_t kbase, uint32
   T* dloc = (T*)s.d_loc;
   T* drho = (T*)s.d_rho;
   const uint32_t n = (uint32_t)s.n, t = threadIdx.x, PP = (uint32_t)P;
-  const uint32_t tk = n < 256 ? n : 256;
+  // a plated site of thousands of columns: 64-column tiles x 4 row groups instead of 256 x 1 -- four
+  // times the tiles to spread over the workgroups and a quarter of the dependent load batches per thread
+  // (the pass is a latency chain of P / (UN * ng) round trips, not bandwidth)
+  const uint32_t tk = n < 256 ? n : ((n >= MF_BWD_WIDE_N && PP >= 16) ? 64u : 256u);
   if (n == 0 || tile * tk >= n) return;
   const uint32_t ng = row_groups(tk), c0 = t % tk, g = t / tk;
   for (uint32_t cb = tile * tk; cb < n; cb += ntiles * tk) {

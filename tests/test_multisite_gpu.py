@@ -167,6 +167,33 @@ def test_meanfield_sample_and_backward(gpu, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("P", [64, 5])
+def test_meanfield_backward_of_a_plated_site(gpu, dtype, P):
+    """A site of thousands of columns next to small ones (config 5's w beside mu, tau, b): 64-column tiles
+    x 4 row groups when P >= 16, the 256-column form otherwise; column sums against the float64
+    restatement (float32 rtol 3e-5 of sums of P terms)."""
+    from pyro_amd import kernels as k
+
+    rng = np.random.default_rng(15)
+    sizes = [32, 1, 4999]
+    rhos = [torch.as_tensor(rng.uniform(-3, 25, n), dtype=dtype, device=gpu) for n in sizes]
+    epss = [torch.as_tensor(rng.standard_normal((P, n)), dtype=dtype, device=gpu) for n in sizes]
+    d_zs = [torch.as_tensor(rng.standard_normal((P, n)), dtype=dtype, device=gpu) for n in sizes]
+    d_scs = [torch.as_tensor(rng.standard_normal(n), dtype=dtype, device=gpu) for n in sizes]
+    d_los = [None, None, torch.as_tensor(rng.standard_normal(4999), dtype=dtype, device=gpu)]
+    d_locs, d_rhos = k.meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scs, d_los, P)
+    again = k.meanfield_normal_sample_bwd(rhos, epss, d_zs, d_scs, d_los, P)
+    for a, b in zip(d_locs + d_rhos, again[0] + again[1]):
+        assert torch.equal(a, b)
+    cpu = lambda xs: [None if x is None else x.double().cpu() for x in xs]   # noqa: E731
+    r_locs, r_rhos = ob.meanfield_normal_sample_bwd(cpu(rhos), cpu(epss), cpu(d_zs), cpu(d_scs),
+                                                    cpu(d_los), P)
+    rt = 3e-5 if dtype == torch.float32 else 1e-11
+    for a, b in zip(d_locs + d_rhos, r_locs + r_rhos):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=rt, atol=rt * 10)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_meanfield_sample_block_kernel_draws_the_same_numbers(gpu, dtype):
     """Launches whose largest site has >= 64 K elements take the kernel that draws one Philox block (4
     f32 / 2 f64 normals) per thread and trip instead of one element per thread: bit for bit the same
@@ -188,6 +215,42 @@ def test_meanfield_sample_block_kernel_draws_the_same_numbers(gpu, dtype):
     ref_eps = o_philox.normal(P * 1027, np_dt, 11, 30000).reshape(P, 1027)
     tol = 2e-6 if dtype == torch.float32 else 1e-13
     np.testing.assert_allclose(b[3][3].cpu().numpy(), ref_eps, rtol=tol, atol=10 * tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_meanfield_sample_whole_block_rows_draw_the_same_numbers(gpu, dtype):
+    """Sites whose rows are whole Philox blocks (n % 4 == 0 in f32, % 2 in f64) take the block kernel's
+    column-block form (softplus once per thread, 16-byte stores): bit for bit the per-element kernel's
+    outputs; and a site with more column blocks than the grid has threads against the oracle's stream."""
+    from pyro_amd import kernels as k
+
+    rng = np.random.default_rng(8)
+    P = 64
+    small, big = [32, 4, 1000], [32, 4, 1000, 1028]           # 64 x 1028 = 65 792 elements
+    locs = [torch.as_tensor(rng.standard_normal(n), dtype=dtype, device=gpu) for n in big]
+    rhos = [torch.as_tensor(rng.uniform(-3, 25, n), dtype=dtype, device=gpu) for n in big]
+    offsets = [10, 700, 900, 30000]
+    a = k.meanfield_normal_sample(locs[:3], rhos[:3], P, 11, offsets[:3])      # per-element kernel
+    b = k.meanfield_normal_sample(locs, rhos, P, 11, offsets)                  # block kernel
+    for group_a, group_b in zip(a, b):
+        for ta, tb in zip(group_a, group_b[:3]):
+            assert torch.equal(ta, tb)
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    ref_eps = o_philox.normal(P * 1028, np_dt, 11, 30000).reshape(P, 1028)
+    np.testing.assert_allclose(b[3][3].cpu().numpy(), ref_eps, rtol=tol, atol=10 * tol)
+    # more column blocks than threads in the grid (each thread walks several), 3 particles
+    n, P3 = 1_200_000, 3
+    loc = torch.as_tensor(rng.standard_normal(n), dtype=dtype, device=gpu)
+    rho = torch.as_tensor(rng.uniform(-3, 3, n), dtype=dtype, device=gpu)
+    zs, scales, louts, epss = k.meanfield_normal_sample([loc], [rho], P3, 5, [123])
+    ref = o_philox.normal(P3 * n, np_dt, 5, 123).reshape(P3, n)
+    np.testing.assert_allclose(epss[0].cpu().numpy(), ref, rtol=tol, atol=10 * tol)
+    sp = torch.nn.functional.softplus(rho.double())
+    torch.testing.assert_close(scales[0].double(), sp, rtol=tol * 4, atol=0)
+    assert torch.equal(louts[0], loc)
+    torch.testing.assert_close(zs[0].double(), loc.double() + scales[0].double() * epss[0].double(),
+                               rtol=tol * 4, atol=tol * 4)
 
 
 def _logreg_loss_and_grads(gpu, batched, fused_guide, monkeypatch):
