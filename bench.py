@@ -666,8 +666,9 @@ def main():
             out["validated"] = validated
         if unarmed is not None:
             out["without_prearm"] = unarmed
-        out["step_anatomy"] = {"graph_nodes": "meanfield_sample, glm_planes, chain_tail (GLM finalize "
-                                              "+ ELBO assembly + guide backward + Adam + loss hand-over)",
+        out["step_anatomy"] = {"graph_nodes": "step gate (when pre-armed), glm_planes (its prologue makes the "
+                                              "guide draw), chain_tail (GLM finalize + ELBO assembly + guide "
+                                              "backward + Adam + loss hand-over)",
                                "chain": getattr(svi, "chain_stats", None),
                                "chain_fused": getattr(svi, "chain_fused", None)}
         if nuts is not None:
