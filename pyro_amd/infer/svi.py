@@ -261,6 +261,16 @@ class SVI:
         self._graphs.clear()
         self._const_rec.clear()
 
+    def pause(self):
+        """The caller is about to wait for the device (``synchronize()``, a device-to-host read) or to
+        enqueue work of its own: a replay waiting behind its gate is given up NOW instead of after the
+        gate's patience.  Pre-arming stays on: the next ``step()`` launches its replay itself and arms the
+        one after it."""
+        self._armed_fast = None
+        for e in self._graphs.values():
+            if e.armed:
+                e.cancel()
+
     def disarm(self):
         """Stop enqueuing replays ahead of time (prearm=True): cancels a waiting one; later steps of
         the existing captures run as ordinary replays through their (already released) gates."""

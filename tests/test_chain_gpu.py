@@ -255,6 +255,32 @@ def test_prearmed_steps_are_bitwise_the_ordinary_ones(gpu):
     assert int(g.ack_np[0]) == g.next
 
 
+def test_pause_gives_the_waiting_replay_up_at_once_and_arming_goes_on(gpu):
+    """SVI.pause() before a synchronisation: the armed replay returns without its 40 us of patience
+    (nothing has changed), later steps arm again, and the trajectory is the un-armed one bit for bit."""
+    import time
+
+    waits = []
+
+    def pause_and_sync(i, svi, X, y):
+        if i in (6, 7, 13, 20):
+            svi.pause()
+            (entry,) = svi._graphs.values()
+            assert not entry.armed
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()
+            waits.append(time.perf_counter() - t0)
+
+    l0, p0, _ = _gate_run(gpu, prearm=False)
+    l1, p1, svi = _gate_run(gpu, prearm=True, between=pause_and_sync)
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    (entry,) = svi._graphs.values()
+    assert entry.gate.next == 24 - 3 + 1 and entry.armed and svi.prearm
+    assert len(waits) == 4 and max(waits) < 5e-3
+
+
 def test_gate_gives_a_replay_up_when_the_host_stays_away(gpu):
     """The host sleeps between steps (longer than the gate's 40 us): the armed replay has given
     itself up, the step runs the ordinary way, arming backs off -- same trajectory."""
