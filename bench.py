@@ -381,7 +381,10 @@ def main():
     # driver's --steps 20 that is ~1.7 ms of timing, so the block is repeated (a count fixed by the
     # arguments alone: every rank runs the same number of barriers) and the MEDIAN block is the
     # headline; every block's time is in the line (`blocks_ms_per_step`).
-    nblocks = max(1, min(25, -(-2000 // max(args.steps, 1))))
+    # (The first ~250 replays after a capture run 8-10 % slower than the rest -- DESIGN.md section 3, "the
+    #  step gate"; tools/short_block_ramp.py -- so the blocks cover ~8000 steps: the median then sits in the
+    #  state a real SVI run, thousands of steps long, spends its time in.)
+    nblocks = max(1, min(100, -(-8000 // max(args.steps, 1))))
     block_s = []
     for _ in range(nblocks):
         sync()
