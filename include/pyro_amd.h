@@ -165,6 +165,18 @@ int pa_meanfield_score(int dtype, const void* z, const void* loc, const void* sc
 int pa_gate(const int64_t* go, int64_t* gate, int64_t* ack, int64_t timeout_us, pa_stream_t stream);
 int pa_gate_scope(int64_t* gate);
 int pa_gate_stats(int64_t* launches, int64_t* aware);
+/* The LATE gate: the same node, placed in front of the step's chained tail instead of first.  What the step
+ * launches before it -- its forward pass: the plane-image GLM kernel with the guide draw in its prologue --
+ * runs as soon as the previous step's tail has finished, i.e. WHILE the host is still reading that step's
+ * loss and calling step() again; it reads parameters, Philox position and data in the state that step left
+ * and writes only scratch that every replay rewrites (records, the draw).  Everything that changes
+ * persistent state (gradients, Adam, Philox position, loss hand-over) sits behind the gate and is given up
+ * with it.  pa_gate_defer registers the gate at the start of a capture (instead of pa_gate + pa_gate_scope;
+ * the scope opens when the node is emitted, pa_gate_scope(NULL) closes it); pa_gate_defer_stats: launches
+ * made before the gate node, how many of them were NOT the plane-image GLM kernel (a capture is armable this
+ * way only if none), whether the node was emitted at all (a step without a chained tail has no place for it). */
+int pa_gate_defer(const int64_t* go, int64_t* gate, int64_t* ack, int64_t timeout_us);
+int pa_gate_defer_stats(int64_t* pre, int64_t* pre_other, int* emitted);
 
 /* ------------------------------------------------------------------------------------
  * Element-wise site kernels (SURVEY 8a rows a1,a3,a4,a5).

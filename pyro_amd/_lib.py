@@ -91,6 +91,8 @@ _SIGNATURES = {
     "pa_meanfield_score_blocks": (c_int64, [c_int64, c_int64]),
     "pa_meanfield_score": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p,
                                    c_void_p, c_void_p]),
+    "pa_gate_defer": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "pa_gate_defer_stats": (c_int, [c_void_p, c_void_p, c_void_p]),
     "pa_gate": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "pa_gate_scope": (c_int, [c_void_p]),
     "pa_gate_stats": (c_int, [c_void_p, c_void_p]),

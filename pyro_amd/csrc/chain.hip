@@ -529,6 +529,7 @@ static int chain_launch() {
       if (a.grid[p] > maxgrid) maxgrid = a.grid[p];
     }
   a.stamps = g_chain_stamps;
+  gate_emit_deferred(c.stream);       // a late gate goes in front of the step's first chained kernel
   a.gate = gate_word();
   a.jitter = g_chain_jitter;
   gate_aware_launch();

@@ -22,6 +22,8 @@ int cu_count();
 // launcher of such a kernel calls gate_aware_launch() once per launch it passes gate_word() to
 const int64_t* gate_word();
 void gate_aware_launch();
+// emits a gate registered with pa_gate_defer (no-op otherwise); called in front of the chained tail
+void gate_emit_deferred(hipStream_t s);
 // true (and the two events) if pa_profile_bracket_next(tag, ...) is pending on this thread
 bool take_bracket(int tag, hipEvent_t* start, hipEvent_t* stop);
 

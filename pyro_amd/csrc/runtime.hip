@@ -25,11 +25,29 @@ int fail(int code, const char* fmt, ...) {
 // the step gate: see include/pyro_amd.h.  (entry points are serialised by the host language)
 static int64_t* g_gate = nullptr;
 static int64_t g_gate_launches = 0, g_gate_aware = 0;
+// a LATE gate (pa_gate_defer): registered at the start of a capture, emitted in front of the step's chained
+// tail; what is launched before it runs unconditionally (the forward pass of a step enqueued ahead of time)
+struct GateDeferred {
+  bool pending = false, emitted = false;
+  const int64_t* go = nullptr;
+  int64_t* gate = nullptr;
+  int64_t* ack = nullptr;
+  unsigned long long ticks = 0;
+  int64_t pre = 0, pre_other = 0;        // launches before the gate node / of them not the plane-image GLM
+};
+static GateDeferred g_gate_late;
 const int64_t* gate_word() { return g_gate == nullptr ? nullptr : g_gate + 1; }
-void gate_aware_launch() { g_gate_aware += 1; }
+void gate_aware_launch() {
+  if (!g_gate_late.pending) g_gate_aware += 1;
+}
 
 int check_launch(const char* what) {
-  g_gate_launches += 1;
+  if (g_gate_late.pending) {
+    g_gate_late.pre += 1;
+    if (strncmp(what, "glm_planes_kernel", 17) != 0 || strchr(what, '<') != nullptr) g_gate_late.pre_other += 1;
+  } else {
+    g_gate_launches += 1;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(PA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
   return PA_OK;
@@ -83,9 +101,43 @@ __global__ void gate_kernel(const int64_t* go, int64_t* gate, int64_t* ack, unsi
   }
 }
 
+// called by the chained tail's launcher right before it emits its kernel
+void gate_emit_deferred(hipStream_t s) {
+  GateDeferred& d = g_gate_late;
+  if (!d.pending) return;
+  d.pending = false;
+  d.emitted = true;
+  g_gate = d.gate;                       // the scope opens here: everything from now on polls gate[1]
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(1), 0, s, d.go, d.gate, d.ack, d.ticks);
+  g_gate_aware += 1;
+  (void)check_launch("gate_kernel");
+}
+
 }  // namespace pa
 
 extern "C" {
+
+int pa_gate_defer(const int64_t* go, int64_t* gate, int64_t* ack, int64_t timeout_us) {
+  PA_REQUIRE(go && gate && ack, "pa_gate_defer: NULL pointer");
+  PA_REQUIRE(timeout_us > 0 && timeout_us <= 100000, "pa_gate_defer: timeout_us=%lld outside (0, 1e5]",
+             (long long)timeout_us);
+  pa::g_gate = nullptr;
+  pa::g_gate_launches = pa::g_gate_aware = 0;
+  pa::g_gate_late = pa::GateDeferred{};
+  pa::g_gate_late.pending = true;
+  pa::g_gate_late.go = go;
+  pa::g_gate_late.gate = gate;
+  pa::g_gate_late.ack = ack;
+  pa::g_gate_late.ticks = (unsigned long long)timeout_us * 100ull;
+  return PA_OK;
+}
+
+int pa_gate_defer_stats(int64_t* pre, int64_t* pre_other, int* emitted) {
+  if (pre) *pre = pa::g_gate_late.pre;
+  if (pre_other) *pre_other = pa::g_gate_late.pre_other;
+  if (emitted) *emitted = pa::g_gate_late.emitted ? 1 : 0;
+  return PA_OK;
+}
 
 int pa_gate(const int64_t* go, int64_t* gate, int64_t* ack, int64_t timeout_us, pa_stream_t stream) {
   PA_REQUIRE(go && gate && ack, "pa_gate: NULL pointer");
@@ -101,6 +153,7 @@ int pa_gate(const int64_t* go, int64_t* gate, int64_t* ack, int64_t timeout_us, 
 int pa_gate_scope(int64_t* gate) {
   pa::g_gate = gate;
   pa::g_gate_launches = pa::g_gate_aware = 0;
+  pa::g_gate_late.pending = false;       // (a deferred gate that was never emitted is dropped; its counts stay readable)
   return PA_OK;
 }
 

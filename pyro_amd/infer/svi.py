@@ -96,6 +96,7 @@ class _CapturedStep:
         seq, spins = self._seq_np, 0
         g = self.gate
         ack = g.ack_np if (g is not None and released_armed) else None
+        gave_up = False
         while int(seq[0]) == last:
             spins += 1
             if ack is not None and int(ack[0]) == g.next:
@@ -104,6 +105,7 @@ class _CapturedStep:
                 # for the NEXT step numbers itself by what has run, finds its number released and
                 # runs as this step; otherwise the step is launched the ordinary way
                 ack = None
+                gave_up = True
                 if self.armed:
                     self.armed = False
                 else:
@@ -115,6 +117,8 @@ class _CapturedStep:
                 if int(seq[0]) == last:
                     raise RuntimeError("pyro_amd: the captured step did not publish its loss")
         self._seq = int(seq[0])
+        if released_armed and not gave_up and self.arm_penalty > 1:
+            self.arm_penalty >>= 1          # an armed replay that ran: the back-off decays again
         if g is not None:
             g.next += 1
         return float(self._value_np[0])
@@ -122,7 +126,7 @@ class _CapturedStep:
 
 class SVI:
     def __init__(self, model, guide, optim, loss, loss_and_grads=None, num_samples=0, num_steps=0,
-                 hip_graph=False, graph_warmup=3, prearm=False, **kwargs):
+                 hip_graph=False, graph_warmup=3, prearm=False, speculate=True, **kwargs):
         if num_steps or num_samples:
             warnings.warn("num_steps / num_samples are ignored (TracePosterior is not part of "
                           "this backend)")
@@ -152,6 +156,13 @@ class SVI:
         # stays away longer than the gate's patience (40 us) finds the replay given up and the step
         # runs the ordinary way.  Only steps whose every node can be given up are armed.
         self.prearm = bool(prearm) and _os.environ.get("PYRO_AMD_PREARM", "1") != "0"
+        # speculate (with prearm): the gate sits in front of the step's chained tail instead of first, so
+        # the forward pass of the replay enqueued ahead (the plane-image GLM kernel, which also makes the
+        # guide draw) runs while the host is still reading the previous loss and calling step() again.
+        # It reads what that step left behind and writes scratch only; everything that changes persistent
+        # state waits behind the gate and is given up with it.  Same promise by the caller as prearm.
+        # Taken only when nothing but that kernel precedes the tail; otherwise the gate goes first.
+        self.speculate = bool(speculate) and _os.environ.get("PYRO_AMD_SPECULATE", "1") != "0"
         self._armed_fast = None     # (entry, argument objects, their key) of the armed replay
         if self.hip_graph and self._loss_device is None:
             raise ValueError("hip_graph=True needs an ELBO that provides loss_and_grads_device")
@@ -352,7 +363,10 @@ class SVI:
         forms = [False, True] if multi and not getattr(self, "_force_split", False) \
             and _os.environ.get("PYRO_AMD_GRAPH_COLLECTIVE", "1") != "0" else [None]
         for form in forms:
-            gated = self.prearm and not multi
+            # with prearm: first with the gate in front of the chained tail (the forward pass of a replay
+            # enqueued ahead runs while the host is between two calls), then with the gate as the first
+            # node, then without one
+            gated = ("late" if self.speculate else True) if (self.prearm and not multi) else False
             try:
                 entry = self._capture_once(key, args, kwargs, rec, force_split=form,
                                            quiet=form is False, with_gate=gated)
@@ -362,12 +376,14 @@ class SVI:
                 rec = None
                 entry = self._capture_once(key, args, kwargs, None, force_split=form,
                                            quiet=form is False, with_gate=gated)
-            if getattr(entry, "gate", None) is not None and not entry.gate.armable:
+            while getattr(entry, "gate", None) is not None and not entry.gate.armable:
                 # some node of this step would still run after the gate gave a replay up (a torch
-                # kernel, a launch of ours that does not poll the gate): capture it without one
+                # kernel, a launch of ours that does not poll the gate), or something other than the
+                # GLM kernel runs in front of a late gate: the next weaker form
+                gated = True if gated == "late" else False
                 self._graphs.pop(key, None)
                 entry = self._capture_once(key, args, kwargs, rec, force_split=form,
-                                           quiet=form is False, with_gate=False)
+                                           quiet=form is False, with_gate=gated)
             if entry is not None:
                 return entry
             if form is False:
@@ -416,7 +432,8 @@ class SVI:
         else:
             consts = None
         hoist = (lambda: consts) if consts is not None else contextlib.nullcontext
-        gate = kernels.StepGate(device) if (with_gate and chained and not split) else None
+        gate = kernels.StepGate(device, late=(with_gate == "late")) \
+            if (with_gate and chained and not split) else None
         gated = (lambda: gate) if gate is not None else contextlib.nullcontext
         try:
             with validation_enabled(False):   # validation ran in the eager warm-up steps

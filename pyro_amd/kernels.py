@@ -324,7 +324,7 @@ class StepGate:
     host loop needs to come back (3-8 us), short enough that a stream synchronisation right after a
     step -- which has to sit out the armed replay's patience -- costs little."""
 
-    def __init__(self, device, timeout_us=40):
+    def __init__(self, device, timeout_us=40, late=False):
         self.gate = torch.zeros((2,), dtype=torch.int64, device=device)     # {last step run, abort}
         self.go = torch.zeros((1,), dtype=torch.int64).pin_memory()
         self.ack = torch.zeros((1,), dtype=torch.int64).pin_memory()
@@ -333,14 +333,25 @@ class StepGate:
         self.next = 1                  # number of the next replay that will RUN
         self.total = self.aware = -1   # launches of the capture / gate-aware ones among them
         self.torch_ops = -1            # torch operators that launched something during the capture
+        # late = the gate node sits in front of the step's chained tail, not first: the forward pass of a
+        # replay enqueued ahead of time runs while the host is still between two step() calls
+        # (include/pyro_amd.h, pa_gate_defer)
+        self.late = bool(late)
+        self.pre = self.pre_other = -1  # launches before a late gate / of them not the plane-image GLM
+        self.emitted = not self.late
 
     def launch(self):
-        """The gate node (first node of the capture)."""
-        check(_lib.load().pa_gate(_ptr(self.go), _ptr(self.gate), _ptr(self.ack), self.timeout_us,
-                                  _stream()))
+        """The gate node: first node of the capture, or (late) registered now and emitted in front of
+        the chained tail."""
+        lib = _lib.load()
+        if self.late:
+            check(lib.pa_gate_defer(_ptr(self.go), _ptr(self.gate), _ptr(self.ack), self.timeout_us))
+        else:
+            check(lib.pa_gate(_ptr(self.go), _ptr(self.gate), _ptr(self.ack), self.timeout_us, _stream()))
 
     def __enter__(self):
-        check(_lib.load().pa_gate_scope(_ptr(self.gate)))
+        # (late: pa_gate_defer in launch() resets the counters; the scope opens when the node is emitted)
+        check(_lib.load().pa_gate_scope(None if self.late else _ptr(self.gate)))
         _CHAIN["torch_ops"] = 0
         return self
 
@@ -348,6 +359,10 @@ class StepGate:
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         lib = _lib.load()
         lib.pa_gate_stats(ctypes.byref(a), ctypes.byref(b))
+        if self.late:
+            p, q, e = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+            lib.pa_gate_defer_stats(ctypes.byref(p), ctypes.byref(q), ctypes.byref(e))
+            self.pre, self.pre_other, self.emitted = p.value, q.value, bool(e.value)
         lib.pa_gate_scope(None)
         self.total, self.aware = a.value, b.value
         self.torch_ops = _CHAIN.pop("torch_ops", -1)
@@ -355,8 +370,10 @@ class StepGate:
 
     @property
     def armable(self):
-        """Every node of the captured step returns at once when the gate gives a replay up."""
-        return self.total > 0 and self.total == self.aware and self.torch_ops == 0
+        """Every node of the captured step behind the gate returns at once when the gate gives a replay
+        up -- and (late gate) nothing but the plane-image GLM kernel runs in front of it."""
+        return (self.emitted and self.total > 0 and self.total == self.aware and self.torch_ops == 0
+                and (not self.late or self.pre_other == 0))
 
 
 def counter_add(counter, inc):

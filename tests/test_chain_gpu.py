@@ -208,20 +208,20 @@ def test_chain_can_be_switched_off(gpu, monkeypatch):
 
 
 # ---- the step gate: replays enqueued ahead of the host (SVI(prearm=True), pa_gate) ----------------
-def _gate_run(gpu, prearm, between=None, steps=24, seed=7, N=20000):
+def _gate_run(gpu, prearm, between=None, steps=24, seed=7, N=20000, speculate=True, D=32):
     import pyro_amd as pyro
     from pyro_amd import examples
     from pyro_amd.infer import SVI, Trace_ELBO
     from pyro_amd.infer.autoguide import AutoNormal
 
-    X, y = examples.synthetic_logreg_data(N, 32, gpu, seed=3)
+    X, y = examples.synthetic_logreg_data(N, D, gpu, seed=3)
     pyro.clear_param_store()
     pyro.set_rng_seed(seed)
     pyro.enable_validation(False)
     guide = AutoNormal(examples.logreg_model, init_scale=0.1)
     svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.02}),
               Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1),
-              hip_graph=True, graph_warmup=3, prearm=prearm)
+              hip_graph=True, graph_warmup=3, prearm=prearm, speculate=speculate)
     losses = []
     for i in range(steps):
         if between is not None:
@@ -231,16 +231,24 @@ def _gate_run(gpu, prearm, between=None, steps=24, seed=7, N=20000):
     return losses, _params(pyro), svi
 
 
-def test_prearmed_steps_are_bitwise_the_ordinary_ones(gpu):
-    """Every node of the config-2 step polls the gate: the capture is armable, from the second
-    replay on each step() finds its replay already enqueued, and the trajectory is bit-identical."""
+@pytest.mark.parametrize("speculate", [False, True], ids=["gate_first", "gate_before_tail"])
+def test_prearmed_steps_are_bitwise_the_ordinary_ones(gpu, speculate):
+    """Every node of the config-2 step behind the gate polls it: the capture is armable, from the second
+    replay on each step() finds its replay already enqueued, and the trajectory is bit-identical -- with
+    the gate as the first node, and with the gate in front of the chained tail (the GLM kernel of the
+    replay enqueued ahead then runs before the host has asked for the step)."""
     l0, p0, _ = _gate_run(gpu, prearm=False)
-    l1, p1, svi = _gate_run(gpu, prearm=True)
+    l1, p1, svi = _gate_run(gpu, prearm=True, speculate=speculate)
     (entry,) = svi._graphs.values()
     g = entry.gate
-    # gate node, the GLM kernel (which draws the guide's sample itself), the chained tail
-    assert g is not None and g.armable and (g.total, g.aware, g.torch_ops) == (3, 3, 0), \
-        (g.total, g.aware, g.torch_ops)
+    assert g is not None and g.armable and g.late == speculate and g.torch_ops == 0
+    if speculate:
+        # in front of the gate: the GLM kernel (which draws the guide's sample itself); behind: the gate
+        # node and the chained tail
+        assert (g.pre, g.pre_other, g.total, g.aware) == (1, 0, 2, 2), (g.pre, g.pre_other, g.total, g.aware)
+    else:
+        # gate node, the GLM kernel, the chained tail
+        assert (g.total, g.aware) == (3, 3), (g.total, g.aware)
     assert entry.armed and entry.arm_backoff == 0
     assert g.next == 24 - 3 + 1                     # every replay ran exactly once
     assert l0 == l1
@@ -255,7 +263,8 @@ def test_prearmed_steps_are_bitwise_the_ordinary_ones(gpu):
     assert int(g.ack_np[0]) == g.next
 
 
-def test_pause_gives_the_waiting_replay_up_at_once_and_arming_goes_on(gpu):
+@pytest.mark.parametrize("speculate", [False, True], ids=["gate_first", "gate_before_tail"])
+def test_pause_gives_the_waiting_replay_up_at_once_and_arming_goes_on(gpu, speculate):
     """SVI.pause() before a synchronisation: the armed replay returns without its 40 us of patience
     (nothing has changed), later steps arm again, and the trajectory is the un-armed one bit for bit."""
     import time
@@ -272,7 +281,7 @@ def test_pause_gives_the_waiting_replay_up_at_once_and_arming_goes_on(gpu):
             waits.append(time.perf_counter() - t0)
 
     l0, p0, _ = _gate_run(gpu, prearm=False)
-    l1, p1, svi = _gate_run(gpu, prearm=True, between=pause_and_sync)
+    l1, p1, svi = _gate_run(gpu, prearm=True, between=pause_and_sync, speculate=speculate)
     assert l0 == l1
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
@@ -281,7 +290,8 @@ def test_pause_gives_the_waiting_replay_up_at_once_and_arming_goes_on(gpu):
     assert len(waits) == 4 and max(waits) < 5e-3
 
 
-def test_gate_gives_a_replay_up_when_the_host_stays_away(gpu):
+@pytest.mark.parametrize("speculate", [False, True], ids=["gate_first", "gate_before_tail"])
+def test_gate_gives_a_replay_up_when_the_host_stays_away(gpu, speculate):
     """The host sleeps between steps (longer than the gate's 40 us): the armed replay has given
     itself up, the step runs the ordinary way, arming backs off -- same trajectory."""
     import time
@@ -291,7 +301,7 @@ def test_gate_gives_a_replay_up_when_the_host_stays_away(gpu):
             time.sleep(0.003)
 
     l0, p0, _ = _gate_run(gpu, prearm=False)
-    l1, p1, svi = _gate_run(gpu, prearm=True, between=nap)
+    l1, p1, svi = _gate_run(gpu, prearm=True, between=nap, speculate=speculate)
     assert l0 == l1
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
@@ -299,7 +309,8 @@ def test_gate_gives_a_replay_up_when_the_host_stays_away(gpu):
     assert entry.gate.next == 24 - 3 + 1
 
 
-def test_writes_between_steps_cancel_the_armed_replay(gpu):
+@pytest.mark.parametrize("speculate", [False, True], ids=["gate_first", "gate_before_tail"])
+def test_writes_between_steps_cancel_the_armed_replay(gpu, speculate):
     """In-place writes to an argument tensor or to a parameter between two steps are enqueued BEHIND
     the armed replay; step() notices the version counters and cancels it, so the step sees them."""
     import pyro_amd as pyro
@@ -314,7 +325,22 @@ def test_writes_between_steps_cancel_the_armed_replay(gpu):
             pyro.set_rng_seed(123)                        # the host-side stream position moved
 
     l0, p0, _ = _gate_run(gpu, prearm=False, between=meddle)
-    l1, p1, _ = _gate_run(gpu, prearm=True, between=meddle)
+    l1, p1, svi = _gate_run(gpu, prearm=True, between=meddle, speculate=speculate)
+    (entry,) = svi._graphs.values()
+    assert entry.gate is not None and entry.gate.late == speculate
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
+def test_a_step_with_more_than_the_glm_kernel_before_its_tail_keeps_the_gate_first(gpu):
+    """D = 64: the guide draw is a launch of its own in front of the feature-tile GLM kernel, so the gate
+    may not move behind them (a late gate lets only the plane-image GLM kernel run ahead): the capture
+    falls back to the gate as first node, or to none -- same trajectory either way."""
+    l0, p0, _ = _gate_run(gpu, prearm=False, D=64)
+    l1, p1, svi = _gate_run(gpu, prearm=True, speculate=True, D=64)
+    (entry,) = svi._graphs.values()
+    assert entry.gate is None or (entry.gate.armable and not entry.gate.late)
     assert l0 == l1
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
