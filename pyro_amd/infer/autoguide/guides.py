@@ -60,6 +60,14 @@ def _exp_lower(transform):
     return None
 
 
+def _checked_init_scale(value):
+    """The guides' ``init_scale`` argument: a positive python float (same message as the reference's
+    constructors, which its tests match on)."""
+    if isinstance(value, float) and value > 0:
+        return value
+    raise ValueError("Expected init_scale > 0. but got {}".format(value))
+
+
 def _is_identity(transform):
     while isinstance(transform, torch.distributions.transforms.IndependentTransform):
         transform = transform.base_transform
@@ -173,9 +181,7 @@ class AutoNormal(AutoGuide):
 
     def __init__(self, model, *, init_loc_fn=init_to_feasible, init_scale=0.1, create_plates=None):
         self.init_loc_fn = init_loc_fn
-        if not isinstance(init_scale, float) or not (init_scale > 0):
-            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
-        self._init_scale = init_scale
+        self._init_scale = _checked_init_scale(init_scale)
         super().__init__(model, create_plates=create_plates)
         self._event_dims = {}
         self._inits = {}
@@ -573,9 +579,7 @@ class AutoDiagonalNormal(AutoContinuous):
     scale_constraint = softplus_positive
 
     def __init__(self, model, init_loc_fn=init_to_median, init_scale=0.1):
-        if not isinstance(init_scale, float) or not (init_scale > 0):
-            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
-        self._init_scale = init_scale
+        self._init_scale = _checked_init_scale(init_scale)
         super().__init__(model, init_loc_fn=init_loc_fn)
 
     def _setup_prototype(self, *args, **kwargs):
@@ -605,9 +609,7 @@ class AutoMultivariateNormal(AutoContinuous):
     scale_tril_constraint = unit_lower_cholesky
 
     def __init__(self, model, init_loc_fn=init_to_median, init_scale=0.1):
-        if not isinstance(init_scale, float) or not (init_scale > 0):
-            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
-        self._init_scale = init_scale
+        self._init_scale = _checked_init_scale(init_scale)
         super().__init__(model, init_loc_fn=init_loc_fn)
 
     def _setup_prototype(self, *args, **kwargs):
@@ -663,11 +665,9 @@ class AutoLowRankMultivariateNormal(AutoContinuous):
     scale_constraint = softplus_positive
 
     def __init__(self, model, init_loc_fn=init_to_median, init_scale=0.1, rank=None):
-        if not isinstance(init_scale, float) or not (init_scale > 0):
-            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
-        if not (rank is None or isinstance(rank, int) and rank > 0):
+        self._init_scale = _checked_init_scale(init_scale)
+        if rank is not None and not (isinstance(rank, int) and rank > 0):
             raise ValueError("Expected rank > 0 but got {}".format(rank))
-        self._init_scale = init_scale
         self.rank = rank
         super().__init__(model, init_loc_fn=init_loc_fn)
 

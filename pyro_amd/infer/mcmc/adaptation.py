@@ -20,30 +20,28 @@ adapt_window = namedtuple("adapt_window", ["start", "end"])
 
 
 def build_adaptation_schedule(warmup_steps, start_buffer=75, end_buffer=50, initial_window=25):
-    """Stan's windowed schedule (reference: adaptation.py:65-103)."""
-    schedule = []
-    if warmup_steps < 20:
-        schedule.append(adapt_window(0, warmup_steps - 1))
-        return schedule
-    start_buffer_size, end_buffer_size, init_window_size = start_buffer, end_buffer, initial_window
-    if start_buffer + end_buffer + initial_window > warmup_steps:
-        start_buffer_size = int(0.15 * warmup_steps)
-        end_buffer_size = int(0.1 * warmup_steps)
-        init_window_size = warmup_steps - start_buffer_size - end_buffer_size
-    schedule.append(adapt_window(start=0, end=start_buffer_size - 1))
-    end_window_start = warmup_steps - end_buffer_size
-    next_window_size = init_window_size
-    next_window_start = start_buffer_size
-    while next_window_start < end_window_start:
-        cur_window_start, cur_window_size = next_window_start, next_window_size
-        if 3 * cur_window_size <= end_window_start - cur_window_start:
-            next_window_size = 2 * cur_window_size
+    """Stan's windowed warm-up (reference: adaptation.py:65-103): a fast window for the step size only,
+    slow windows for the mass matrix that double in length while at least three of the current length
+    still fit before the closing fast window (the last slow window takes whatever is left), and a closing
+    fast window.  Returns inclusive (start, end) pairs that tile 0 .. warmup_steps - 1."""
+    W = int(warmup_steps)
+    if W < 20:                                   # too short to split: one window
+        return [adapt_window(0, W - 1)]
+    head, tail, width = start_buffer, end_buffer, initial_window
+    if head + tail + width > W:                  # the defaults do not fit: 15 % / 75 % / 10 %
+        head, tail = int(0.15 * W), int(0.1 * W)
+        width = W - head - tail
+    slow_end = W - tail                          # first transition of the closing window
+    cuts = [0, head]                             # window boundaries (each the start of a window)
+    while cuts[-1] < slow_end:
+        left = slow_end - cuts[-1]
+        if 3 * width <= left:
+            cuts.append(cuts[-1] + width)
+            width *= 2
         else:
-            cur_window_size = end_window_start - cur_window_start
-        next_window_start = cur_window_start + cur_window_size
-        schedule.append(adapt_window(cur_window_start, next_window_start - 1))
-    schedule.append(adapt_window(end_window_start, warmup_steps - 1))
-    return schedule
+            cuts.append(slow_end)
+    cuts.append(W)
+    return [adapt_window(a, b - 1) for a, b in zip(cuts[:-1], cuts[1:])]
 
 
 class DiagMassMatrix:
@@ -377,29 +375,24 @@ class WarmupAdapter:
         already-incremented counter, hmc.py:424-431); z [C, D], accept_prob [C]."""
         if t >= self._warmup_steps or self._adaptation_disabled:
             return
-        window = self._adaptation_schedule[self._current_window]
-        num_windows = len(self._adaptation_schedule)
-        mass_matrix_adaptation_phase = self.adapt_mass_matrix and \
-            (0 < self._current_window < num_windows - 1)
+        w, last = self._current_window, len(self._adaptation_schedule) - 1
+        slow = self.adapt_mass_matrix and 0 < w < last       # a mass-matrix window (not the two fast ones)
         if self.adapt_step_size:
             # NaN acceptance probabilities (diverged chains) count as 0, as exp(-inf) does
             self._update_step_size(torch.nan_to_num(accept_prob, nan=0.0))
-        if mass_matrix_adaptation_phase:
+        if slow:
             mm = self.mass_matrix_adapter
-            self.mass_matrix_adapter.update(z_grad if getattr(mm, "uses_grad", False) else z)
-        if t == window.end:
-            if self._current_window == num_windows - 1:
-                self._current_window += 1
-                self._end_adaptation()
-                return
-            if self._current_window == 0:
-                self._current_window += 1
-                return
-            if mass_matrix_adaptation_phase:
-                self.mass_matrix_adapter.end_adaptation()
-                if self.adapt_step_size:
-                    self.reset_step_size_adaptation(z)
-            self._current_window += 1
+            mm.update(z_grad if getattr(mm, "uses_grad", False) else z)
+        if t != self._adaptation_schedule[w].end:
+            return
+        # ---- the window closes with this transition ----
+        self._current_window = w + 1
+        if w == last:
+            self._end_adaptation()               # averaged step size from here on
+        elif slow:
+            self.mass_matrix_adapter.end_adaptation()        # new metric: the step-size search restarts
+            if self.adapt_step_size:
+                self.reset_step_size_adaptation(z)
 
     # ---- bulk interface: the per-transition part of step() runs inside the persistent NUTS kernel
     # (pa_nuts_gaussian_run); the host only handles the window-end events -------------------------
