@@ -161,3 +161,49 @@ def test_captured_collective_falls_back_to_the_split_form(monkeypatch):
                         lambda *a, force_split=None, quiet=False, with_gate=False: "one-graph")
     assert svi._capture(("k",), (), {}) == "one-graph"
     pyro.clear_param_store()
+
+
+def test_prearmed_capture_tries_the_late_gate_then_the_first_node_gate_then_none(monkeypatch):
+    """SVI._capture with prearm: the step is captured with the gate in front of its chained tail; if that
+    capture is not armable (something other than the GLM kernel ran in front of the gate) with the gate as
+    first node; if that is not armable either (a torch kernel in the step) without a gate.  Control flow
+    only (the captures need a GPU: tests/test_chain_gpu.py)."""
+    import pyro_amd as pyro
+    from pyro_amd.infer import SVI, Trace_ELBO
+
+    class _Optim:
+        def __call__(self, params, *a, **k):
+            pass
+
+    class _Gate:
+        def __init__(self, armable):
+            self.armable = armable
+
+    class _Entry:
+        def __init__(self, gate):
+            self.gate = gate
+
+    def run(armable_by_form, speculate=True):
+        svi = SVI(lambda: None, lambda: None, _Optim(), Trace_ELBO(), hip_graph=True, prearm=True,
+                  speculate=speculate)
+        forms = []
+
+        def fake_capture_once(key, args, kwargs, rec, force_split=None, quiet=False, with_gate=False):
+            forms.append(with_gate)
+            e = _Entry(None if with_gate is False else _Gate(armable_by_form[with_gate]))
+            svi._graphs[key] = e
+            return e
+
+        monkeypatch.setattr(svi, "_capture_once", fake_capture_once)
+        entry = svi._capture(("k",), (), {})
+        return forms, entry
+
+    forms, entry = run({"late": True})
+    assert forms == ["late"] and entry.gate.armable
+    forms, entry = run({"late": False, True: True})
+    assert forms == ["late", True] and entry.gate.armable
+    forms, entry = run({"late": False, True: False})
+    assert forms == ["late", True, False] and entry.gate is None
+    forms, entry = run({True: False}, speculate=False)
+    assert forms == [True, False] and entry.gate is None
+    pyro.clear_param_store()
