@@ -121,7 +121,9 @@ int pa_publish_scalar(int dtype, const void* src, double* host_value, uint64_t* 
  * transform.inv.log_abs_det_jacobian(value, u) summed over the event dims):
  *   value[r,c] = lower + exp(u[r,c]),   log_density[r] = - sum_c u[r,c]       (one launch)
  *   g_u[r,c]   = g_value[r,c] exp(u[r,c]) - g_log_density[r]                  (one launch; NULL gradient = 0)
- * u / value contiguous [rows, cols], cols = the product of the site's event dims.
+ * u / value contiguous [rows, cols], cols = the product of the site's event dims.  log_density == NULL: the value
+ * alone (a PARAMETER under a positive / greater-than constraint: transform_to(constraint)(unconstrained),
+ * pyro/params/param_store.py:99-119 -- exp, mul, add and their duals per access otherwise).
  * ---------------------------------------------------------------------------------- */
 int pa_exp_site_fwd(int dtype, const void* u, int64_t rows, int64_t cols, double lower, void* value,
                     void* log_density, pa_stream_t stream);

@@ -39,6 +39,19 @@ __global__ __launch_bounds__(256) void exp_site_fwd_kernel(const T* __restrict__
   }
 }
 
+// the value alone (a parameter with a positive / greater-than constraint: no Jacobian term is asked for)
+template <typename T>
+__global__ __launch_bounds__(256) void exp_lower_kernel(const T* __restrict__ u, int64_t n, T lower,
+                                                        T* __restrict__ value) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const T x = u[i];
+    T e;
+    if constexpr (sizeof(T) == 4) e = expf(x);
+    else e = exp(x);
+    value[i] = lower + e;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void exp_site_bwd_kernel(const T* __restrict__ value, const T* __restrict__ g_value,
                                                            const T* __restrict__ g_ld, int64_t R, int64_t C,
@@ -132,11 +145,23 @@ int pa_exp_site_fwd(int dtype, const void* u, int64_t rows, int64_t cols, double
   PA_REQUIRE(dtype == PA_F32 || dtype == PA_F64, "exp_site_fwd: bad dtype %d", dtype);
   PA_REQUIRE(rows >= 0 && cols >= 1, "exp_site_fwd: bad shape %lld x %lld", (long long)rows, (long long)cols);
   if (rows == 0) return PA_OK;
-  PA_REQUIRE(u && value && log_density, "exp_site_fwd: NULL pointer");
-  int64_t grid = (rows + 3) / 4;
+  PA_REQUIRE(u && value, "exp_site_fwd: NULL pointer");
   const int64_t cap = (int64_t)pa::cu_count() * 8;
-  if (grid > cap) grid = cap;
   hipStream_t s = pa::as_stream(stream);
+  if (log_density == nullptr) {                  // the value only, element by element
+    const int64_t n = rows * cols;
+    int64_t g1 = (n + 255) / 256;
+    if (g1 > cap) g1 = cap;
+    if (dtype == PA_F32)
+      hipLaunchKernelGGL(pa::exp_lower_kernel<float>, dim3((unsigned)g1), dim3(256), 0, s, (const float*)u, n,
+                         (float)lower, (float*)value);
+    else
+      hipLaunchKernelGGL(pa::exp_lower_kernel<double>, dim3((unsigned)g1), dim3(256), 0, s, (const double*)u, n,
+                         lower, (double*)value);
+    return pa::check_launch("exp_lower_kernel");
+  }
+  int64_t grid = (rows + 3) / 4;
+  if (grid > cap) grid = cap;
   if (dtype == PA_F32)
     hipLaunchKernelGGL(pa::exp_site_fwd_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, (const float*)u,
                        rows, cols, (float)lower, (float*)value, (float*)log_density);

@@ -453,6 +453,46 @@ def ctx_event_rank(u, cols):
     return k
 
 
+@_dispatcher_op("exp_lower")
+class _ExpLower(torch.autograd.Function):
+    """lower + exp(u): a parameter read through a positive / greater-than constraint, one launch each way
+    (pa_exp_site_fwd without the Jacobian term / pa_exp_site_bwd)."""
+
+    @staticmethod
+    def forward(ctx, u, lower):
+        value, _ = kernels.exp_site_fwd(u.detach().contiguous(), 1, lower, want_ld=False)
+        ctx.lower = lower
+        ctx.save_for_backward(value)
+        return value
+
+    @staticmethod
+    def backward(ctx, g):
+        (value,) = ctx.saved_tensors
+        if torch.is_grad_enabled():                  # create_graph=True: stay differentiable
+            return g * (value - ctx.lower), None
+        return kernels.exp_site_bwd(value, g.contiguous(), None, 1, ctx.lower), None
+
+
+def exp_lower(u, lower=0.0):
+    return _ExpLower.apply(u, float(lower))
+
+
+def exp_lower_bound_of(transform):
+    """The lower bound L when ``transform`` is u -> L + exp(u) with a host-side scalar L (what ``biject_to`` /
+    ``transform_to`` give for positive / greater_than / nonnegative supports), else None."""
+    from torch.distributions import transforms as T
+    while type(transform) is T.IndependentTransform:      # (.to_event(k) sites: the sum over the event
+        transform = transform.base_transform              # dims is the caller's, by the site's event_dim)
+    if type(transform) is T.ExpTransform:
+        return 0.0
+    if type(transform) is T.ComposeTransform and len(transform.parts) == 2:
+        e, a = transform.parts
+        if (type(e) is T.ExpTransform and type(a) is T.AffineTransform and a.event_dim == 0
+                and isinstance(a.loc, (int, float)) and isinstance(a.scale, (int, float)) and a.scale == 1):
+            return float(a.loc)
+    return None
+
+
 def exp_site(u, event_rank, lower=0.0):
     """(value = lower + exp(u), log_density = -(u summed over its ``event_rank`` rightmost dims))."""
     cols = 1

@@ -45,19 +45,8 @@ _IDENTITY = biject_to(constraints.real)
 
 
 def _exp_lower(transform):
-    """The lower bound L when ``transform`` is u -> L + exp(u) with a host-side scalar L (what
-    ``biject_to`` gives for positive / greater_than / nonnegative supports), else None."""
-    from torch.distributions import transforms as T
-    while type(transform) is T.IndependentTransform:      # (.to_event(k) sites: the sum over the event
-        transform = transform.base_transform              # dims is the caller's, by the site's event_dim)
-    if type(transform) is T.ExpTransform:
-        return 0.0
-    if type(transform) is T.ComposeTransform and len(transform.parts) == 2:
-        e, a = transform.parts
-        if (type(e) is T.ExpTransform and type(a) is T.AffineTransform and a.event_dim == 0
-                and isinstance(a.loc, (int, float)) and isinstance(a.scale, (int, float)) and a.scale == 1):
-            return float(a.loc)
-    return None
+    from ...distributions import fused
+    return fused.exp_lower_bound_of(transform)
 
 
 def _checked_init_scale(value):

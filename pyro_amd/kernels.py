@@ -278,14 +278,14 @@ def publish_scalar(src, host_value, host_seq, counter=None, inc=0):
                                         _ptr(counter), int(inc), _stream()))
 
 
-def exp_site_fwd(u, cols, lower=0.0):
+def exp_site_fwd(u, cols, lower=0.0, want_ld=True):
     """u contiguous with prod(trailing dims) == cols per row -> (value = lower + exp(u) [u.shape],
-    log_density = -sum over each row [rows]).  pa_exp_site_fwd."""
+    log_density = -sum over each row [rows], or None without ``want_ld``).  pa_exp_site_fwd."""
     _require_gpu(u)
     assert u.is_contiguous() and u.dtype in (torch.float32, torch.float64) and cols >= 1
     rows = u.numel() // cols
     value = torch.empty_like(u)
-    ld = torch.empty((rows,), dtype=u.dtype, device=u.device)
+    ld = torch.empty((rows,), dtype=u.dtype, device=u.device) if want_ld else None
     check(_lib.load().pa_exp_site_fwd(_dtype(u), _ptr(u), rows, cols, float(lower), _ptr(value), _ptr(ld), _stream()))
     return value, ld
 

@@ -47,7 +47,18 @@ class ParamStoreDict:
     def __getitem__(self, name):
         unconstrained = self._params[name]
         constraint = self._constraints[name]
-        constrained = transform_to(constraint)(unconstrained)
+        constrained = None
+        if constraint is not constraints.real and unconstrained.dtype in (torch.float32, torch.float64):
+            from . import kernels
+            if kernels.on_device(unconstrained) and unconstrained.is_contiguous():
+                from .distributions import fused
+                lower = fused.exp_lower_bound_of(transform_to(constraint))
+                if lower is not None:
+                    # positive / greater_than: value = lower + exp(u) in one launch each way instead of
+                    # exp, mul, add and their duals per access
+                    constrained = fused.exp_lower(unconstrained, lower)
+        if constrained is None:
+            constrained = transform_to(constraint)(unconstrained)
         if constrained is unconstrained:
             constrained = unconstrained.view_as(unconstrained) if False else unconstrained
         try:

@@ -496,11 +496,11 @@ def meanfield_score(z, loc, scale, P, coef):
     return partial, torch.as_tensor(-coef * P / s, dtype=z.dtype)
 
 
-def exp_site_fwd(u, cols, lower=0.0):
+def exp_site_fwd(u, cols, lower=0.0, want_ld=True):
     a = _np(u).astype(np.float64)
     value = lower + np.exp(a)
     ld = -a.reshape(-1, cols).sum(1)
-    return torch.as_tensor(value, dtype=u.dtype), torch.as_tensor(ld, dtype=u.dtype)
+    return torch.as_tensor(value, dtype=u.dtype), (torch.as_tensor(ld, dtype=u.dtype) if want_ld else None)
 
 
 def exp_site_bwd(value, g_value, g_ld, cols, lower=0.0):

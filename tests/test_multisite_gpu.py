@@ -407,6 +407,29 @@ def test_exp_site_kernels_against_the_restatement(dtype, shape, ed):
         torch.testing.assert_close(got.double().cpu(), ref, rtol=rt * 4, atol=1e-13 if dtype == torch.float64 else 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_exp_constrained_parameter_on_the_device(dtype):
+    """pyro.param under greater_than(0.5) on the device: pa_exp_site_fwd without the Jacobian term and
+    pa_exp_site_bwd against transform_to(constraint) (float32 rtol 2e-6)."""
+    import pyro_amd as pyro
+    from torch.distributions import constraints as C, transform_to
+    dev = torch.device("cuda:0")
+    pyro.clear_param_store()
+    g = torch.Generator().manual_seed(1)
+    init = (torch.rand(8, 1024, generator=g, dtype=torch.float64) * 3 + 0.6).to(dtype).to(dev)
+    value = pyro.param("tw", init, constraint=C.greater_than(0.5))
+    assert value.grad_fn is not None and "ExpLower" in type(value.grad_fn).__name__
+    u = pyro.get_param_store()._params["tw"]
+    ref = transform_to(C.greater_than(0.5))(u)
+    rt = 1e-13 if dtype == torch.float64 else 2e-6
+    torch.testing.assert_close(value, ref, rtol=rt, atol=0)
+    w = torch.randn(8, 1024, generator=g, dtype=torch.float64).to(dtype).to(dev)
+    got, = torch.autograd.grad((w * value).sum(), u)
+    want, = torch.autograd.grad((w * ref).sum(), u)
+    torch.testing.assert_close(got, want, rtol=rt * 4, atol=0)
+    pyro.clear_param_store()
+
+
 def test_positive_site_through_the_guide_equals_the_transform_path():
     """AutoNormal on a HalfNormal site on the device: value, log-density and parameter gradients from
     exp_site_fwd / _bwd equal those of biject_to(support)'s transform chain (float32: rtol 2e-6 on the

@@ -110,3 +110,36 @@ def test_scopes_are_separate_stores_that_can_be_reentered(store):
             assert again is state
             _holds(store, spec)
         _holds(store, outer)
+
+
+@pytest.mark.parametrize("constraint,lower", [("positive", 0.0), ("greater_than", 0.5), ("unit_interval", None)])
+def test_exp_constrained_parameters_read_through_one_kernel_each_way(monkeypatch, constraint, lower):
+    """A parameter under a positive / greater-than constraint: the store hands out lower + exp(u) from
+    fused.exp_lower (pa_exp_site_fwd without the Jacobian term; reference: param_store.py:99-119 applies
+    transform_to(constraint) operator by operator) -- same value, same gradient, differentiable twice;
+    other constraints keep the transform."""
+    from torch.distributions import constraints as C, transform_to
+
+    from pyro_amd.distributions import fused
+    from tests import oracle_backend
+    oracle_backend.install(monkeypatch)
+    calls = []
+    real = fused.exp_lower
+    monkeypatch.setattr(fused, "exp_lower", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    con = {"positive": C.positive, "greater_than": C.greater_than(0.5), "unit_interval": C.unit_interval}[constraint]
+    pyro.clear_param_store()
+    init = torch.rand(3, 4, dtype=torch.float64) * 0.4 + 0.55
+    value = pyro.param("p", init, constraint=con)
+    assert calls == ([1] if lower is not None else [])
+    torch.testing.assert_close(value.detach(), init, rtol=1e-12, atol=0)
+    u = pyro.get_param_store()._params["p"]
+    ref = transform_to(con)(u)
+    w = torch.randn(3, 4, dtype=torch.float64)
+    g, = torch.autograd.grad((w * value * value).sum(), u, create_graph=True)
+    rg, = torch.autograd.grad((w * ref * ref).sum(), u, create_graph=True)
+    torch.testing.assert_close(g, rg, rtol=1e-12, atol=1e-14)
+    gg, = torch.autograd.grad(g.sum(), u)
+    rgg, = torch.autograd.grad(rg.sum(), u)
+    torch.testing.assert_close(gg, rgg, rtol=1e-12, atol=1e-14)
+    assert value.unconstrained() is u
+    pyro.clear_param_store()
