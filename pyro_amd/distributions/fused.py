@@ -430,7 +430,7 @@ class _ExpSite(torch.autograd.Function):
         ctx.cols, ctx.lower = cols, lower
         ctx.set_materialize_grads(False)        # an unused output's gradient arrives as None, not zeros
         ctx.save_for_backward(value)
-        ld = ld.reshape(u.shape[:u.dim() - ctx_event_rank(u, cols)])
+        ld = ld.reshape(u.shape[:u.dim() - _event_rank_of(u, cols)])
         return value, ld
 
     @staticmethod
@@ -443,8 +443,8 @@ class _ExpSite(torch.autograd.Function):
         return kernels.exp_site_bwd(value, gv, gl, ctx.cols, ctx.lower), None, None
 
 
-def ctx_event_rank(u, cols):
-    """Number of trailing dims of ``u`` whose product is ``cols``."""
+def _event_rank_of(u, cols):
+    """Number of trailing dims of ``u`` whose product is ``cols`` (the site's event dims)."""
     k, n = 0, 1
     while n < cols:
         k += 1
