@@ -292,6 +292,19 @@ def bench_nuts(dev, rank, world, args):
                         "frac": flops / (kern_total_ms * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS,
                         "streaming_model_TBps": stream_bytes / (kern_total_ms * 1e-3) / 1e12,
                         "traffic": None}}
+    # counter-measured HBM bytes of the NUTS kernels over one such run (tools/nuts_traffic.sh, committed
+    # under profiles/: counters cannot be collected from inside the run)
+    npath = latest_profile("nuts_traffic.json")
+    if npath is not None:
+        try:
+            nj = json.load(open(npath))
+            out["roofline"]["traffic"] = nj.get("hbm_bytes_total")
+            out["roofline"]["traffic_per_leapfrog_bytes"] = nj.get("hbm_bytes_per_leapfrog")
+            out["roofline"]["traffic_source"] = "profiles/%s: HBM bytes of every NUTS kernel launch of one " \
+                "MCMC.run of this workload (%s leapfrogs); %s" % (os.path.basename(npath), nj.get("leapfrogs"),
+                                                                nj.get("how", ""))
+        except Exception:
+            pass
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = nuts_cpu_baseline(D, min(args.cpu_budget_s, 8.0))
     return out
