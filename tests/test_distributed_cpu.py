@@ -207,3 +207,24 @@ def test_prearmed_capture_tries_the_late_gate_then_the_first_node_gate_then_none
     forms, entry = run({True: False}, speculate=False)
     assert forms == [True, False] and entry.gate is None
     pyro.clear_param_store()
+
+
+def test_step_gate_armable_truth_table():
+    """kernels.StepGate.armable: every launch behind the gate polls it, torch launched nothing, the node was
+    emitted, and -- for a late gate -- nothing but the plane-image GLM kernel ran in front of it."""
+    from types import SimpleNamespace as NS
+
+    from pyro_amd.kernels import StepGate
+
+    def armable(**kw):
+        base = dict(emitted=True, total=3, aware=3, torch_ops=0, late=False, pre=0, pre_other=0)
+        base.update(kw)
+        return StepGate.armable.fget(NS(**base))
+
+    assert armable()
+    assert not armable(aware=2)                       # a launch of ours that does not poll the gate
+    assert not armable(torch_ops=1)                   # a torch kernel in the step
+    assert not armable(total=0, aware=0)              # nothing captured
+    assert armable(late=True, total=2, aware=2, pre=1, pre_other=0)
+    assert not armable(late=True, total=2, aware=2, pre=2, pre_other=1)     # e.g. a separate guide-draw launch
+    assert not armable(late=True, emitted=False, total=0, aware=0, pre=3)   # no chained tail to carry the gate
