@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-by-kernel sequence of ONE graphed SVI.step of config 5 (developer tool)
+# kernel-by-kernel sequence of ONE graphed SVI.step of config 1 (eight schools; developer tool)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 OUT=gpurun_out/trace_cfg1; rm -rf $OUT; mkdir -p $OUT
