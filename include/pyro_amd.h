@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 4
+#define PA_ABI_VERSION 5
 
 enum { PA_OK = 0, PA_ERR_INVALID = -1, PA_ERR_UNSUPPORTED = -2, PA_ERR_LAUNCH = -3 };
 
@@ -626,6 +626,54 @@ int pa_nuts_tree_advance_tdev(int dtype, void* z, void* pe, void* grad, void* zq
                               int32_t* n_leapfrog, int32_t* depth, int32_t* diverging,
                               int32_t* accepted, int32_t* n_active, void* workspace,
                               size_t workspace_bytes, pa_stream_t stream);
+
+/* ASYNCHRONOUS CHAINS: a span of K transitions per chain without a host decision inside.
+ * Replaces, per chain and per transition, what the reference does on the host between two trees:
+ * HMC._after_transition / WarmupAdapter.step without its window-end branch
+ * (pyro/infer/mcmc/hmc.py:425-438, adaptation.py:166-185: DualAveraging.step on H = target -
+ * accept_prob, pyro/ops/dual_averaging.py:55-78; diagonal WelfordCovariance.update,
+ * pyro/ops/welford.py:27-38), the running mean of the acceptance probability, the
+ * leapfrog / depth / accept counters, the store of the draw (api.py:405-651 collects it) -- and
+ * then NUTS.sample's prologue for the chain's NEXT transition (nuts.py:367-434), in the launch that
+ * finished the tree.  No chain waits for the slowest tree of a transition; every potential
+ * evaluation serves C live cursors.  Philox keys are (transition, slot, chain): the chains are
+ * those of the lock-step protocol above, bit for bit.
+ *
+ *     ctl (device int64[8]) = {t0, K, mean_n0, welford_n0, flags, samples, div_flags, row0}
+ *     pa_nuts_tree_run_begin(...)       transition t0 of every chain begins; tc[c] = 0, *n_done = 0
+ *     do { (peq, gq) = U(zq), dU/dz(zq);  pa_nuts_tree_run_advance(...); } while (*n_done < C)
+ *
+ * ctl lives in device memory so that ONE captured hipGraph of rounds serves every span:
+ *   flags   PA_NUTS_RUN_ADAPT_STEP | PA_NUTS_RUN_WELFORD | PA_NUTS_RUN_COUNT_ACCEPTS;
+ *   samples device address of T[rows][C][D] (0 = do not store): transition t0 + k of chain c is
+ *           stored at row row0 + k; div_flags: device address of int8[rows][C] (0 = none), written
+ *           when COUNT_ACCEPTS is set;
+ *   mean_n0 / welford_n0: transitions already averaged into mean_accept / draws already in welford.
+ * da_state[C,5] = {x_avg, g_avg, t, prox_center, x_t}, welford[C,2,D] = {mean, m2}, mean_accept[C],
+ * counters[3,C] = {leapfrogs, tree depths, accepted}, step[C] (rewritten by the dual averaging),
+ * tc[C] int32 (transitions completed in the span).  The statistics outputs hold each chain's LAST
+ * finished transition.  done_flag (may be NULL): set to 1 by the last chain to complete its span --
+ * passed as a step gate's abort word (pa_gate_scope) it makes the gate-aware kernels of the rounds
+ * still queued return at once.  inv_mass is fixed during a span. */
+#define PA_NUTS_RUN_ADAPT_STEP 1
+#define PA_NUTS_RUN_WELFORD 2
+#define PA_NUTS_RUN_COUNT_ACCEPTS 4
+int pa_nuts_tree_run_begin(int dtype, const void* z, const void* pe, const void* grad, void* zq,
+                           void* rq, const void* inv_mass, int64_t im_stride_row, const void* step,
+                           int64_t C, int64_t D, int max_tree_depth, int use_multinomial,
+                           uint64_t seed, uint64_t chain_offset, const int64_t* ctl, int32_t* tc,
+                           int32_t* n_done, int64_t* done_flag, void* workspace,
+                           size_t workspace_bytes, pa_stream_t stream);
+int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq, void* rq,
+                             const void* gq, const void* peq, const void* inv_mass,
+                             int64_t im_stride_row, void* step, int64_t C, int64_t D,
+                             int max_tree_depth, int use_multinomial, uint64_t seed,
+                             uint64_t chain_offset, const int64_t* ctl, void* da_state,
+                             double target_accept, void* welford, void* mean_accept,
+                             int64_t* counters, int32_t* tc, int32_t* n_done, int64_t* done_flag,
+                             void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
+                             int32_t* diverging, int32_t* accepted, void* workspace,
+                             size_t workspace_bytes, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpyro_amd.so")
 
 PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_LAUNCH = 0, -1, -2, -3
 PA_F32, PA_F64 = 0, 1
-ABI_VERSION = 4      # PA_ABI_VERSION of include/pyro_amd.h
+ABI_VERSION = 5      # PA_ABI_VERSION of include/pyro_amd.h
 
 DIST_NORMAL = 0
 DIST_BERNOULLI_LOGITS = 1
@@ -186,6 +186,16 @@ _SIGNATURES = {
                                           c_int64, c_int, c_int, c_uint64, c_void_p, c_uint64,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_size_t, c_void_p]),
+    "pa_nuts_tree_run_begin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                       c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
+    "pa_nuts_tree_run_advance": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_int64, c_int, c_int, c_uint64, c_uint64, c_void_p,
+                                         c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     "pa_nuts_gaussian_find_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_uint64,
                                            c_double, c_double, c_double, c_void_p]),

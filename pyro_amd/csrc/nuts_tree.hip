@@ -149,28 +149,55 @@ __device__ __forceinline__ void kick_drift(Vec<T, NPL>& z, Vec<T, NPL>& r, const
   }
 }
 
-template <typename T, int NW, int NPL>
-__global__ __launch_bounds__(64 * NW) void nuts_tree_begin_kernel(
-    const T* __restrict__ z, const T* __restrict__ pe, const T* __restrict__ grad,
-    T* __restrict__ zq, T* __restrict__ rq, const T* __restrict__ inv_mass, int64_t im_stride,
-    const T* __restrict__ step, int64_t C, int D, int multinomial, uint64_t seed, uint64_t t,
-    uint64_t chain_offset, TreeWs<T> ws) {
-  __shared__ T red[2 * NW];
-  const int chain = blockIdx.x;
-  Chain<T, NW, NPL> c{(int)threadIdx.x, D, (int64_t)chain * D, red};
-  const int64_t CD = C * D;
-  const uint64_t ctr_base = t << 20, cid = chain_offset + (uint64_t)chain;
+// ---- asynchronous chains (pa_nuts_tree_run_*) ------------------------------------------------
+// A SPAN is K transitions per chain with fixed adaptation bookkeeping (no warm-up window ends
+// inside).  Within a span a chain that finishes its transition does the per-transition half of
+// the adaptation itself (dual averaging of its step size, Welford update of its mass estimate,
+// running acceptance mean, counters, sample store -- what HMC._after_transition /
+// WarmupAdapter.step do on the host between the reference's transitions, adaptation.py:166-185)
+// and BEGINS ITS NEXT TRANSITION in the same launch: no chain waits for the slowest tree of a
+// transition, every potential evaluation serves C live cursors, and the host only counts
+// finished chains.  The Philox keys are (transition index, slot, chain), so a chain draws the
+// same numbers as under the lock-step schedule: same chains, bit for bit.
+//
+// The span's parameters live in DEVICE memory (ctl, int64 words) so that one captured hipGraph
+// of rounds serves every span of a run.
+enum { RC_T0 = 0, RC_K = 1, RC_MEAN_N0 = 2, RC_WF_N0 = 3, RC_FLAGS = 4, RC_SAMPLES = 5,
+       RC_DIV = 6, RC_ROW0 = 7, RC_COUNT = 8 };
+enum { RF_ADAPT_STEP = 1, RF_WELFORD = 2, RF_COUNT_ACCEPTS = 4 };
 
-  Vec<T, NPL> zc = c.ld(z), gc = c.ld(grad), v, isq, ru0;
+template <typename T>
+struct TreeRun {
+  const int64_t* ctl;     // [RC_COUNT]
+  T* step;                // [C], rewritten by the dual averaging
+  T* da;                  // [C,5] {x_avg, g_avg, t, prox_center, x_t}      (nuts.hip RunArgs)
+  T* wf;                  // [C,2,D] {mean, m2}
+  T* mean_accept;         // [C]
+  int64_t* counters;      // [3,C] leapfrogs, depth, accepted
+  int32_t* tc;            // [C] transitions this chain has completed in the span
+  int32_t* n_done;        // chains that completed the span
+  int64_t* done_flag;     // set to 1 by the last chain to complete (a step gate's abort word), or NULL
+  double target_accept, da_t0, da_kappa, da_gamma;
+};
+
+// tree state of a chain at the start of transition t (nuts.py:367-434): momentum draw, energies,
+// both edges at the current state, first direction, first half leapfrog into (zq, rq)
+template <typename T, int NW, int NPL>
+__device__ __forceinline__ void tree_begin_chain(
+    const Chain<T, NW, NPL>& c, int chain, int64_t C, const Vec<T, NPL>& zc, const Vec<T, NPL>& gc,
+    T pe_c, const Vec<T, NPL>& v, T eps, int multinomial, uint64_t seed, uint64_t t, uint64_t cid,
+    const TreeWs<T>& ws, T* __restrict__ zq, T* __restrict__ rq) {
+  const int64_t CD = C * c.D;
+  const uint64_t ctr_base = t << 20;
+  Vec<T, NPL> isq, ru0;
 #pragma unroll
   for (int m = 0; m < NPL; ++m) {
     const int d = c.tid + m * c.NT;
-    v.x[m] = c.ok(m) ? inv_mass[(int64_t)chain * im_stride + d] : T(1);
     isq.x[m] = T(1) / Num<T>::sqrt_(v.x[m]);  // mass_matrix_sqrt (adaptation.py:270-282)
     ru0.x[m] = c.ok(m) ? philox_normal_t<T>(seed, ctr_base, (uint64_t)d, cid) : T(0);
   }
   Vec<T, NPL> r0 = vmul(ru0, isq);                              // scale(), adaptation.py:349-373
-  const T energy_current = T(0.5) * c.dot(ru0, ru0) + pe[chain];  // nuts.py:380
+  const T energy_current = T(0.5) * c.dot(ru0, ru0) + pe_c;     // nuts.py:380
   T log_slice;
   if (multinomial) {
     log_slice = -energy_current;
@@ -188,7 +215,6 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_begin_kernel(
   // first doubling: direction draw, cursor = edge, first half leapfrog
   const u32x4 bj = philox4x32_10(seed, ctr_base + 1025, cid);
   const int dir = uniform_from<T>(bj, 0) < T(0.5) ? 1 : -1;
-  const T eps = step[chain];
   Vec<T, NPL> zn = zc, rn = r0;
   kick_drift(zn, rn, gc, v, dir == 1 ? eps : -eps);
   c.st(zq, zn);
@@ -208,24 +234,60 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_begin_kernel(
   }
 }
 
+// t_ctl == nullptr: the lock-step protocol (transition index t); else the first transition of a
+// span (index ctl[RC_T0]) and the span's per-chain / global counters are reset
 template <typename T, int NW, int NPL>
+__global__ __launch_bounds__(64 * NW) void nuts_tree_begin_kernel(
+    const T* __restrict__ z, const T* __restrict__ pe, const T* __restrict__ grad,
+    T* __restrict__ zq, T* __restrict__ rq, const T* __restrict__ inv_mass, int64_t im_stride,
+    const T* __restrict__ step, int64_t C, int D, int multinomial, uint64_t seed, uint64_t t,
+    uint64_t chain_offset, TreeWs<T> ws, const int64_t* __restrict__ t_ctl,
+    int32_t* __restrict__ tc, int32_t* __restrict__ n_done, int64_t* __restrict__ done_flag) {
+  __shared__ T red[2 * NW];
+  const int chain = blockIdx.x;
+  Chain<T, NW, NPL> c{(int)threadIdx.x, D, (int64_t)chain * D, red};
+  if (t_ctl != nullptr) {
+    t = (uint64_t)t_ctl[RC_T0];
+    if (threadIdx.x == 0) {
+      tc[chain] = 0;
+      if (chain == 0) {
+        *n_done = 0;
+        if (done_flag != nullptr) *done_flag = 0;
+      }
+    }
+  }
+  Vec<T, NPL> zc = c.ld(z), gc = c.ld(grad), v;
+#pragma unroll
+  for (int m = 0; m < NPL; ++m)
+    v.x[m] = c.ok(m) ? inv_mass[(int64_t)chain * im_stride + c.tid + m * c.NT] : T(1);
+  tree_begin_chain<T, NW, NPL>(c, chain, C, zc, gc, pe[chain], v, step[chain], multinomial, seed, t,
+                               chain_offset + (uint64_t)chain, ws, zq, rq);
+}
+
+template <typename T, int NW, int NPL, bool RUN>
 __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     T* __restrict__ z_io, T* __restrict__ pe_io, T* __restrict__ grad_io, T* __restrict__ zq_io,
     T* __restrict__ rq_io, const T* __restrict__ gq_in, const T* __restrict__ peq_in,
-    const T* __restrict__ inv_mass, int64_t im_stride, const T* __restrict__ step, int64_t C,
+    const T* __restrict__ inv_mass, int64_t im_stride, const T* step, int64_t C,
     int D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
     const uint64_t* __restrict__ t_dev, uint64_t chain_offset,
     TreeWs<T> ws, T* __restrict__ accept_prob_out, int32_t* __restrict__ nleap_out,
     int32_t* __restrict__ depth_out, int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out,
-    int32_t* __restrict__ n_active) {
+    int32_t* __restrict__ n_active, TreeRun<T> run) {
   __shared__ T red[2 * NW];
   const int chain = blockIdx.x;
   if (ws.iscal[IS_ACTIVE * C + chain] == 0) return;  // block-uniform
   Chain<T, NW, NPL> c{(int)threadIdx.x, D, (int64_t)chain * D, red};
   const int64_t CD = C * D;
   // the transition index keys the Philox draws; a launch that is replayed from a hipGraph reads it
-  // from device memory (pa_nuts_tree_advance_tdev) instead of its (captured) argument
-  const uint64_t tt = t_dev != nullptr ? *t_dev : t;
+  // from device memory (pa_nuts_tree_advance_tdev) instead of its (captured) argument; a chain of
+  // a span is at its own transition ctl[RC_T0] + tc[chain]
+  int span_k = 0;
+  uint64_t tt = t_dev != nullptr ? *t_dev : t;
+  if constexpr (RUN) {
+    span_k = run.tc[chain];
+    tt = (uint64_t)run.ctl[RC_T0] + (uint64_t)span_k;
+  }
   const uint64_t ctr_base = tt << 20, cid = chain_offset + (uint64_t)chain;
 
   const int dir = ws.iscal[IS_DIR * C + chain];
@@ -270,6 +332,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
   T b_pe = pe_q;
   bool turning = false;
   bool finished = false;
+  bool moved = false;      // this round's doubling accepted its proposal: (b_prop, b_propg, b_pe)
   int diverged = 0;
   int accepted = ws.iscal[IS_ACCEPTED * C + chain];
 
@@ -333,6 +396,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
       const u32x4 bj = philox4x32_10(seed, ctr_base + 1025 + (uint64_t)j, cid);
       if (uniform_from<T>(bj, 1) < new_tree_prob) {  // nuts.py:482-492
         accepted = 1;
+        moved = true;
         c.st(z_io, b_prop);
         c.st(grad_io, b_propg);
         if (threadIdx.x == 0) pe_io[chain] = b_pe;
@@ -370,6 +434,84 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     }
   }
 
+  if constexpr (RUN) {
+    if (finished) {
+      // ---- the transition is over: bookkeeping of HMC._after_transition / WarmupAdapter.step ---
+      const int64_t flags = run.ctl[RC_FLAGS];
+      const int64_t K = run.ctl[RC_K];
+      const T ap_raw = sum_accept / (T)num_prop;            // nuts.py:510
+      T ap = ap_raw;
+      if (ap != ap) ap = T(0);   // NaN acceptance counts as 0 (as exp(-inf) would)
+      const Vec<T, NPL> zc = moved ? b_prop : c.ld(z_io);
+      const Vec<T, NPL> gc = moved ? b_propg : c.ld(grad_io);
+      const T pe_c = moved ? b_pe : pe_io[chain];
+      T eps_next = eps;
+      if (flags & RF_ADAPT_STEP) {  // DualAveraging.step (pyro/ops/dual_averaging.py:55-78), H = target - ap
+        T x_avg = run.da[chain * 5], g_avg = run.da[chain * 5 + 1], da_t = run.da[chain * 5 + 2];
+        const T prox = run.da[chain * 5 + 3];
+        const T g = (T)run.target_accept - ap;
+        da_t += T(1);
+        g_avg = (T(1) - T(1) / (da_t + (T)run.da_t0)) * g_avg + g / (da_t + (T)run.da_t0);
+        const T x_t = prox - Num<T>::sqrt_(da_t) / (T)run.da_gamma * g_avg;
+        const T weight = Num<T>::exp_(-(T)run.da_kappa * Num<T>::log_(da_t));
+        x_avg = (T(1) - weight) * x_avg + weight * x_t;
+        eps_next = Num<T>::exp_(x_t);
+        if constexpr (NW > 1) __syncthreads();    // every thread has read the record
+        if (threadIdx.x == 0) {
+          run.da[chain * 5] = x_avg; run.da[chain * 5 + 1] = g_avg; run.da[chain * 5 + 2] = da_t;
+          run.da[chain * 5 + 4] = x_t;
+          run.step[chain] = eps_next;
+        }
+      }
+      if (flags & RF_WELFORD) {  // WelfordCovariance.update, diagonal (pyro/ops/welford.py:27-38)
+        const T n = (T)(run.ctl[RC_WF_N0] + span_k + 1);
+        T* wrow = run.wf + (int64_t)chain * 2 * D;
+#pragma unroll
+        for (int m = 0; m < NPL; ++m) {
+          const int d = c.tid + m * c.NT;
+          if (c.ok(m)) {
+            T mean = wrow[d], m2 = wrow[D + d];
+            const T pre = zc.x[m] - mean;
+            mean = mean + pre / n;
+            m2 = m2 + pre * (zc.x[m] - mean);
+            wrow[d] = mean;
+            wrow[D + d] = m2;
+          }
+        }
+      }
+      T* samples = (T*)run.ctl[RC_SAMPLES];
+      if (samples != nullptr)
+        c.st(samples + (run.ctl[RC_ROW0] + span_k) * CD, zc);
+      if (threadIdx.x == 0) {
+        const T mean_ap = run.mean_accept[chain];
+        run.mean_accept[chain] = mean_ap + (ap - mean_ap) / (T)(run.ctl[RC_MEAN_N0] + span_k + 1);
+        run.counters[chain] += num_prop;
+        run.counters[C + chain] += tree_depth;
+        if (flags & RF_COUNT_ACCEPTS) {
+          run.counters[2 * C + chain] += accepted;
+          int8_t* div = (int8_t*)run.ctl[RC_DIV];
+          if (div != nullptr) div[(run.ctl[RC_ROW0] + span_k) * C + chain] = (int8_t)diverged;
+        }
+        accept_prob_out[chain] = ap_raw;
+        nleap_out[chain] = num_prop;
+        depth_out[chain] = tree_depth;
+        div_out[chain] = diverged;
+        acc_out[chain] = accepted;
+        run.tc[chain] = span_k + 1;
+      }
+      if ((int64_t)span_k + 1 < K) {
+        // the chain's next transition starts here (the scalars of the finished tree are dead)
+        tree_begin_chain<T, NW, NPL>(c, chain, C, zc, gc, pe_c, v, eps_next, multinomial, seed,
+                                     tt + 1, cid, ws, zq_io, rq_io);
+      } else if (threadIdx.x == 0) {
+        ws.iscal[IS_ACTIVE * C + chain] = 0;
+        ws.iscal[IS_DIVERGED * C + chain] = diverged;
+        const int32_t old = atomicAdd(run.n_done, 1);
+        if (old + 1 == (int32_t)C && run.done_flag != nullptr) *run.done_flag = 1;
+      }
+      return;
+    }
+  }
   if (threadIdx.x == 0) {
     ws.iscal[IS_DEPTH * C + chain] = tree_depth;
     ws.iscal[IS_NPROP * C + chain] = num_prop;
@@ -384,7 +526,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
       depth_out[chain] = tree_depth;
       div_out[chain] = diverged;
       acc_out[chain] = accepted;
-    } else {
+    } else if constexpr (!RUN) {
       atomicAdd(n_active, 1);
     }
   }
@@ -409,7 +551,9 @@ template <typename T>
 static int tree_begin(const void* z, const void* pe, const void* grad, void* zq, void* rq,
                       const void* inv_mass, int64_t im_stride, const void* step, int64_t C,
                       int64_t D, int max_depth, int multinomial, uint64_t seed, uint64_t t,
-                      uint64_t chain_offset, void* workspace, hipStream_t s) {
+                      uint64_t chain_offset, void* workspace, hipStream_t s,
+                      const int64_t* t_ctl = nullptr, int32_t* tc = nullptr,
+                      int32_t* n_done = nullptr, int64_t* done_flag = nullptr) {
   TreePlan pl;
   tree_plan(D, &pl);
   TreeWs<T> ws = tree_ws<T>(workspace, C, D, max_depth);
@@ -417,7 +561,7 @@ static int tree_begin(const void* z, const void* pe, const void* grad, void* zq,
   hipLaunchKernelGGL((nuts_tree_begin_kernel<TT, NW, NPL>), dim3((unsigned)C), dim3(64 * NW), 0, \
                      s, (const TT*)z, (const TT*)pe, (const TT*)grad, (TT*)zq, (TT*)rq,          \
                      (const TT*)inv_mass, im_stride, (const TT*)step, C, (int)D, multinomial,    \
-                     seed, t, chain_offset, ws)
+                     seed, t, chain_offset, ws, t_ctl, tc, n_done, done_flag)
   PA_TREE_DISPATCH(T, PA_CALL);
 #undef PA_CALL
   return check_launch("nuts_tree_begin_kernel");
@@ -439,15 +583,40 @@ static int tree_advance(void* z, void* pe, void* grad, void* zq, void* rq, const
   const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
 #define PA_CALL(TT, NW, NPL)                                                                      \
-  hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL>), dim3((unsigned)C), dim3(64 * NW), 0, \
-                     s, (TT*)z, (TT*)pe, (TT*)grad, (TT*)zq, (TT*)rq, (const TT*)gq,              \
-                     (const TT*)peq, (const TT*)inv_mass, im_stride, (const TT*)step, C, (int)D,  \
-                     max_depth, multinomial, seed, t, t_dev, chain_offset, ws, (TT*)accept_prob, nl, \
-                     dp, dv, ac, n_active)
+  hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL, false>), dim3((unsigned)C),            \
+                     dim3(64 * NW), 0, s, (TT*)z, (TT*)pe, (TT*)grad, (TT*)zq, (TT*)rq,           \
+                     (const TT*)gq, (const TT*)peq, (const TT*)inv_mass, im_stride,               \
+                     (const TT*)step, C, (int)D, max_depth, multinomial, seed, t, t_dev,          \
+                     chain_offset, ws, (TT*)accept_prob, nl, dp, dv, ac, n_active, TreeRun<TT>{})
   PA_TREE_DISPATCH(T, PA_CALL);
 #undef PA_CALL
   if (br) (void)hipEventRecord(ev1, s);
   return check_launch("nuts_tree_advance_kernel");
+}
+
+template <typename T>
+static int tree_run_advance(void* z, void* pe, void* grad, void* zq, void* rq, const void* gq,
+                            const void* peq, const void* inv_mass, int64_t im_stride, int64_t C,
+                            int64_t D, int max_depth, int multinomial, uint64_t seed,
+                            uint64_t chain_offset, TreeRun<T> run, void* accept_prob, int32_t* nl,
+                            int32_t* dp, int32_t* dv, int32_t* ac, void* workspace, hipStream_t s) {
+  TreePlan pl;
+  tree_plan(D, &pl);
+  TreeWs<T> ws = tree_ws<T>(workspace, C, D, max_depth);
+  hipEvent_t ev0, ev1;
+  const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
+  if (br) (void)hipEventRecord(ev0, s);
+#define PA_CALL(TT, NW, NPL)                                                                      \
+  hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL, true>), dim3((unsigned)C),             \
+                     dim3(64 * NW), 0, s, (TT*)z, (TT*)pe, (TT*)grad, (TT*)zq, (TT*)rq,           \
+                     (const TT*)gq, (const TT*)peq, (const TT*)inv_mass, im_stride,               \
+                     (const TT*)run.step, C, (int)D, max_depth, multinomial, seed, (uint64_t)0,   \
+                     (const uint64_t*)nullptr, chain_offset, ws, (TT*)accept_prob, nl, dp, dv, ac, \
+                     (int32_t*)nullptr, run)
+  PA_TREE_DISPATCH(T, PA_CALL);
+#undef PA_CALL
+  if (br) (void)hipEventRecord(ev1, s);
+  return check_launch("nuts_tree_run_advance_kernel");
 }
 
 }  // namespace pa
@@ -539,6 +708,63 @@ int pa_nuts_tree_advance_tdev(int dtype, void* z, void* pe, void* grad, void* zq
                                   D, max_tree_depth, use_multinomial, seed, 0, t_dev,
                                   chain_offset, accept_prob, n_leapfrog, depth, diverging,
                                   accepted, n_active, workspace, s);
+}
+
+int pa_nuts_tree_run_begin(int dtype, const void* z, const void* pe, const void* grad, void* zq,
+                           void* rq, const void* inv_mass, int64_t im_stride_row, const void* step,
+                           int64_t C, int64_t D, int max_tree_depth, int use_multinomial,
+                           uint64_t seed, uint64_t chain_offset, const int64_t* ctl, int32_t* tc,
+                           int32_t* n_done, int64_t* done_flag, void* workspace,
+                           size_t workspace_bytes, pa_stream_t stream) {
+  const uint64_t t = 0;
+  PA_TREE_COMMON_CHECKS("nuts_tree_run_begin")
+  PA_REQUIRE(z && pe && grad && zq && rq && inv_mass && step && ctl && tc && n_done,
+             "nuts_tree_run_begin: NULL pointer");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    return pa::tree_begin<float>(z, pe, grad, zq, rq, inv_mass, im_stride_row, step, C, D,
+                                 max_tree_depth, use_multinomial, seed, 0, chain_offset, workspace,
+                                 s, ctl, tc, n_done, done_flag);
+  return pa::tree_begin<double>(z, pe, grad, zq, rq, inv_mass, im_stride_row, step, C, D,
+                                max_tree_depth, use_multinomial, seed, 0, chain_offset, workspace,
+                                s, ctl, tc, n_done, done_flag);
+}
+
+int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq, void* rq,
+                             const void* gq, const void* peq, const void* inv_mass,
+                             int64_t im_stride_row, void* step, int64_t C, int64_t D,
+                             int max_tree_depth, int use_multinomial, uint64_t seed,
+                             uint64_t chain_offset, const int64_t* ctl, void* da_state,
+                             double target_accept, void* welford, void* mean_accept,
+                             int64_t* counters, int32_t* tc, int32_t* n_done, int64_t* done_flag,
+                             void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
+                             int32_t* diverging, int32_t* accepted, void* workspace,
+                             size_t workspace_bytes, pa_stream_t stream) {
+  const uint64_t t = 0;
+  PA_TREE_COMMON_CHECKS("nuts_tree_run_advance")
+  PA_REQUIRE(z && pe && grad && zq && rq && gq && peq && inv_mass && step && ctl && da_state &&
+                 welford && mean_accept && counters && tc && n_done && accept_prob && n_leapfrog &&
+                 depth && diverging && accepted,
+             "nuts_tree_run_advance: NULL pointer");
+  PA_REQUIRE(target_accept > 0.0 && target_accept < 1.0,
+             "nuts_tree_run_advance: target_accept=%g outside (0, 1)", target_accept);
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32) {
+    pa::TreeRun<float> run{ctl, (float*)step, (float*)da_state, (float*)welford,
+                           (float*)mean_accept, counters, tc, n_done, done_flag, target_accept,
+                           10.0, 0.75, 0.05};   // DualAveraging defaults (ops/dual_averaging.py)
+    return pa::tree_run_advance<float>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, C, D,
+                                       max_tree_depth, use_multinomial, seed, chain_offset, run,
+                                       accept_prob, n_leapfrog, depth, diverging, accepted,
+                                       workspace, s);
+  }
+  pa::TreeRun<double> run{ctl, (double*)step, (double*)da_state, (double*)welford,
+                          (double*)mean_accept, counters, tc, n_done, done_flag, target_accept,
+                          10.0, 0.75, 0.05};
+  return pa::tree_run_advance<double>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, C, D,
+                                      max_tree_depth, use_multinomial, seed, chain_offset, run,
+                                      accept_prob, n_leapfrog, depth, diverging, accepted,
+                                      workspace, s);
 }
 
 }  // extern "C"

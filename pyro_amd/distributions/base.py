@@ -193,6 +193,12 @@ def _of_base(name):
     return property(lambda self: getattr(self.base_dist, name))
 
 
+def _density_dtype(value):
+    """A log-density is floating point whatever the value's dtype (an integer-valued site switched off by
+    mask=False would otherwise hand an int64 zero to logsumexp / einsum)."""
+    return value.dtype if value.is_floating_point() else torch.get_default_dtype()
+
+
 class MaskedDistribution(TorchDistribution):
     """``base_dist.mask(m)``: the density counts only where ``m`` holds (what the reference's class of
     the same name provides, pyro/distributions/torch_distribution.py:302-396).  Here the mask is not an
@@ -227,7 +233,8 @@ class MaskedDistribution(TorchDistribution):
         """Zeros of the log-density's shape without evaluating the base distribution (a False mask is
         how models switch a site off on data that may lie outside its support)."""
         lead = value.shape[:value.dim() - self.event_dim]
-        return value.new_zeros(()).expand(broadcast_shape(self.base_dist.batch_shape, lead))
+        return value.new_zeros((), dtype=_density_dtype(value)).expand(
+            broadcast_shape(self.base_dist.batch_shape, lead))
 
     def expand(self, batch_shape, _instance=None):
         batch_shape = torch.Size(batch_shape)
@@ -271,7 +278,7 @@ class MaskedDistribution(TorchDistribution):
 
     def fused_log_prob_sum(self, value, scale=1.0, mask=None):
         if self._mask is False:
-            return value.new_zeros(())
+            return value.new_zeros((), dtype=_density_dtype(value))
         hit = self._fused("fused_log_prob_sum", value, scale, mask)
         return None if hit is None else hit[0](value, scale, hit[1])
 

@@ -425,32 +425,23 @@ class _ExpSite(torch.autograd.Function):
     reference: AutoNormal.forward, guides.py:494-519 -- eight torch operators and their duals)."""
 
     @staticmethod
-    def forward(ctx, u, cols, lower):
+    def forward(ctx, u, cols, lower, event_rank):
         value, ld = kernels.exp_site_fwd(u.detach().contiguous(), cols, lower)
         ctx.cols, ctx.lower = cols, lower
         ctx.set_materialize_grads(False)        # an unused output's gradient arrives as None, not zeros
         ctx.save_for_backward(value)
-        ld = ld.reshape(u.shape[:u.dim() - _event_rank_of(u, cols)])
+        # the site's event rank is the caller's knowledge: size-1 event dims cannot be told from ``cols``
+        ld = ld.reshape(u.shape[:u.dim() - event_rank])
         return value, ld
 
     @staticmethod
     def backward(ctx, g_value, g_ld):
         (value,) = ctx.saved_tensors
         if g_value is None and g_ld is None:
-            return None, None, None
+            return None, None, None, None
         gv = None if g_value is None else g_value.contiguous()
         gl = None if g_ld is None else g_ld.contiguous().reshape(-1)
-        return kernels.exp_site_bwd(value, gv, gl, ctx.cols, ctx.lower), None, None
-
-
-def _event_rank_of(u, cols):
-    """Number of trailing dims of ``u`` whose product is ``cols`` (the site's event dims)."""
-    k, n = 0, 1
-    while n < cols:
-        k += 1
-        n *= int(u.shape[-k])
-    assert n == cols, (tuple(u.shape), cols)
-    return k
+        return kernels.exp_site_bwd(value, gv, gl, ctx.cols, ctx.lower), None, None, None
 
 
 @_dispatcher_op("exp_lower")
@@ -498,7 +489,7 @@ def exp_site(u, event_rank, lower=0.0):
     cols = 1
     for d in u.shape[u.dim() - event_rank:] if event_rank else ():
         cols *= int(d)
-    return _ExpSite.apply(u, cols, float(lower))
+    return _ExpSite.apply(u, cols, float(lower), int(event_rank))
 
 
 @_dispatcher_op("drawn_score")

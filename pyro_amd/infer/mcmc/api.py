@@ -146,8 +146,7 @@ class MCMC:
             fast = isinstance(k, HMC) and not getattr(k, "_empty", False)
             S, C = self.num_samples, self._local_chains
             params = k.initial_params
-            bulk = fast and getattr(k, "_fused", False) and getattr(k, "use_persistent", False) \
-                and self.hook_fn is None
+            bulk = fast and bool(getattr(k, "bulk_ready", False)) and self.hook_fn is None
             per_chain_diag = None
 
             def hook(stage, i):

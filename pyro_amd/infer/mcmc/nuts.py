@@ -20,6 +20,12 @@ from ..autoguide.initialization import init_to_uniform
 from .hmc import HMC
 from .potentials import GaussianPotential
 
+# Rounds of the tree path (potential at the cursors + tree bookkeeping) are replayed from a captured
+# hipGraph: "auto" = whenever the chains live on the device (a capture that fails -- the potential
+# synchronises with the host, say -- falls back to eager rounds), True / False = always / never.
+# ``jit_compile=True`` asks for it whatever this says (and warns when the capture fails).
+CAPTURE_ROUNDS = "auto"
+
 
 class NUTS(HMC):
     def __init__(self, model=None, potential_fn=None, step_size=1, adapt_step_size=True,
@@ -40,12 +46,16 @@ class NUTS(HMC):
         self.sync_every = 4      # host polls of n_active in the generic tree loop
         self.use_fused_gaussian = True
         self.use_persistent = True   # many transitions per launch on the fused Gaussian path
+        self.use_async_chains = True # model / generic potentials: spans of transitions without lock step
+        self.rounds_per_replay = 16  # tree rounds in the captured graph of the asynchronous path
         self._launch_hook = None     # called before every fused launch (bench: event brackets)
 
     def release_graphs(self):
         super().release_graphs()
         self._round_graph = self._step_buf = self._mass_buf = None
         self._round_calls = 0
+        self._span_graph = self._span_keep = None
+        self._span_calls = 0
 
     def _prepare_paths(self):
         self._fused = (self.use_fused_gaussian and isinstance(self.potential_fn, GaussianPotential)
@@ -63,6 +73,9 @@ class NUTS(HMC):
         self._tree = None
         self._step_buf = self._mass_buf = self._round_graph = None     # jit_compile round graph
         self._round_calls, self._round_failed = 0, False
+        self._span_graph = self._span_keep = None                      # asynchronous spans
+        self._span_calls, self._span_failed, self._span_replays = 0, False, 0
+        self._da_buf = self._wf_buf = None
         self._tree_depth_sum = torch.zeros((), dtype=torch.int64, device=self._z.device)
         self._counters = torch.zeros((3, self.num_chains), dtype=torch.int64,
                                      device=self._z.device)
@@ -84,11 +97,24 @@ class NUTS(HMC):
         self._last_stats = out
         self._after_transition(out["accept_prob"], out["accepted"] != 0, out["diverging"] != 0)
 
+    @property
+    def bulk_ready(self):
+        """MCMC.run may drive this kernel through ``_transition_many`` (many transitions without a
+        host decision): the fused Gaussian launches, or asynchronous chains on the tree path --
+        diagonal mass only (a dense / arrowhead mass keeps its per-transition host step)."""
+        if getattr(self, "_empty", False) or self._z is None:
+            return False
+        if self._fused:
+            return bool(self.use_persistent)
+        return bool(self.use_async_chains) and not self._dense and self._layout.D <= 2048 \
+            and not getattr(self.mass_matrix_adapter, "uses_grad", False)
+
     def _transition_many(self, k, samples=None):
-        """Up to ``k`` transitions in ONE persistent launch (fused Gaussian path): returns how many
-        were done -- a launch never crosses a warm-up window end or the warm-up/sampling border.
-        The per-transition half of the adaptation (dual averaging, Welford) runs in the kernel."""
-        assert self._fused
+        """Up to ``k`` transitions per chain without a host decision inside: returns how many
+        were done -- a span never crosses a warm-up window end or the warm-up/sampling border.
+        The per-transition half of the adaptation (dual averaging, Welford) runs in the kernels."""
+        if not self._fused:
+            return self._span(k, samples)
         ad = self._adapter
         warm = self._t < self._warmup_steps
         da = wf = None
@@ -136,21 +162,154 @@ class NUTS(HMC):
     def num_leapfrog_steps(self):
         return int(self._n_leapfrog_total.item()) + int(self._counters[0].sum().item())
 
+    # ---- asynchronous chains on the tree path ------------------------------------------------
+    def _persistent_step_and_mass(self, step, inv_mass):
+        """The tree kernels of a captured round read step / inverse mass through pointers:
+        persistent buffers, refreshed in place when adaptation hands over new tensors."""
+        if getattr(self, "_step_buf", None) is None or self._step_buf.shape != step.shape \
+                or self._mass_buf.shape != inv_mass.shape:
+            self._step_buf, self._mass_buf = step.clone(), inv_mass.clone()
+            self._round_graph, self._round_calls = None, 0
+            self._span_graph, self._span_calls = None, 0
+            self._tree = None
+        else:
+            if step is not self._step_buf:
+                self._step_buf.copy_(step)
+            if inv_mass is not self._mass_buf:
+                self._mass_buf.copy_(inv_mass)
+        return self._step_buf, self._mass_buf
+
+    def _span(self, k, samples=None):
+        """``k`` transitions of every chain as ONE span of asynchronous rounds
+        (kernels.NutsTree.run_*): a chain that finishes a tree adapts, stores its draw and starts
+        its next tree in the same launch; the host replays a graph of rounds and counts finished
+        chains.  Same chains as ``_transition`` (the Philox keys do not know the schedule)."""
+        ad = self._adapter
+        warm = self._t < self._warmup_steps
+        T = kernels.NutsTree
+        flags, da, wf, wf_n0 = 0, None, None, 0
+        if warm:
+            span, adapting = ad.bulk_span(self._t)
+            k = min(k, span)
+            if adapting and ad.adapt_step_size:
+                da, flags = ad.da_state(), flags | T.RUN_ADAPT_STEP
+            if adapting and ad.in_mass_phase():
+                (wf, wf_n0), flags = ad.welford_state(), flags | T.RUN_WELFORD
+            mean_n0 = self._t
+        else:
+            mean_n0, flags = self._t - self._warmup_steps, flags | T.RUN_COUNT_ACCEPTS
+        C, D = self._z.shape
+        step, inv_mass = self._persistent_step_and_mass(ad.step_size.contiguous(),
+                                                       self._mm_eff.inverse_mass_matrix)
+        tree = self._tree
+        if tree is None:
+            tree = self._tree = kernels.NutsTree(self._z, self._pe, self._grad, inv_mass, step,
+                                                 self._max_tree_depth, self.use_multinomial_sampling,
+                                                 self._seed, self.chain_offset)
+        elif tree.inv_mass is not inv_mass or tree.step is not step:
+            tree.inv_mass, tree.step = inv_mass, step
+            tree.im_stride = tree.D if inv_mass.dim() == 2 else 0
+            self._span_graph = None
+        if self._da_buf is None:
+            self._da_buf = torch.zeros((C, 5), dtype=self._z.dtype, device=self._z.device)
+            self._wf_buf = torch.zeros((C, 2, D), dtype=self._z.dtype, device=self._z.device)
+        if da is not None:
+            self._da_buf.copy_(da)
+        if wf is not None:
+            self._wf_buf.copy_(wf)
+        div = None
+        if not warm:
+            div = torch.zeros((k, C), dtype=torch.int8, device=self._z.device)
+        if samples is not None:
+            samples = samples[:k]
+        tree.set_span(self._t, k, mean_n0=mean_n0, welford_n0=wf_n0, flags=flags, samples=samples,
+                      div_flags=div)
+        tree.run_begin()
+        self._run_rounds(tree)
+        self._last_stats = tree.stats()
+        self._t += k
+        if warm:
+            if da is not None:
+                ad.step_size = step.clone()
+                ad.load_da_state(self._da_buf.clone(), k)
+            if wf is not None:
+                ad.load_welford_state(self._wf_buf.clone(), k)
+            ad.finish_span(self._t, self._z)
+        else:
+            self._divergences.extend(div[i] for i in range(k))
+        return k
+
+    def _span_round(self, tree, potential):
+        pe, grad = potential(tree.zq)
+        tree.run_advance(pe.detach().contiguous(), grad.detach().contiguous(), self._da_buf,
+                         self._adapter.target_accept_prob, self._wf_buf, self._mean_accept_prob,
+                         self._counters)
+        return pe, grad
+
+    def _want_capture(self):
+        if self._span_failed or not self._z.is_cuda:
+            return False
+        if self._jit_compile:
+            return True
+        return CAPTURE_ROUNDS is True or CAPTURE_ROUNDS == "auto"
+
+    def _run_rounds(self, tree):
+        """Rounds until every chain has completed the span.  After a few eager rounds a block of
+        ``rounds_per_replay`` rounds is captured into ONE hipGraph (the span's parameters reach the
+        kernels through device memory, so the graph serves every later span too); the tree kernel
+        of the round that completes the span sets the abort word of a step gate, and the
+        gate-aware kernels of the rounds still queued behind it return at once."""
+        base = getattr(self._potential, "base", self._potential)
+        polls = 0
+        while True:
+            graph = self._span_graph
+            if graph is None and self._want_capture() and self._span_calls >= 4:
+                graph = self._capture_span(tree, base)
+            if graph is not None:
+                graph.replay()
+                self._span_replays += 1
+            else:
+                for _ in range(self.sync_every):
+                    self._span_round(tree, self._potential)
+                    self._span_calls += 1
+            polls += 1
+            if tree.span_done():
+                break
+            if polls > (1 << 22):
+                raise RuntimeError("pyro_amd: NUTS span did not complete")
+
+    def _capture_span(self, tree, base):
+        import os
+        import warnings
+        lib = kernels._lib.load()
+        try:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            keep = []
+            kernels.check(lib.pa_gate_scope(kernels._ptr(tree.gate)))
+            try:
+                with torch.cuda.graph(graph):
+                    for _ in range(self.rounds_per_replay):
+                        keep.append(self._span_round(tree, base))
+            finally:
+                lib.pa_gate_scope(None)
+            self._span_graph, self._span_keep = graph, keep
+            return graph
+        except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
+            if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
+                raise
+            if self._jit_compile:
+                warnings.warn("pyro_amd: hipGraph capture of the NUTS rounds failed ({}: {}); "
+                              "continuing with eager rounds".format(type(e).__name__, e))
+            self._span_failed = True
+            return None
+
     def _tree_transition(self, t, step, inv_mass):
         tree = self._tree
         replayable = bool(self._jit_compile)
-        if replayable:
-            # the tree kernels of a captured round read step / inverse mass through pointers:
-            # persistent buffers, refreshed in place when adaptation hands over new tensors
-            if getattr(self, "_step_buf", None) is None or self._step_buf.shape != step.shape \
-                    or self._mass_buf.shape != inv_mass.shape:
-                self._step_buf, self._mass_buf = step.clone(), inv_mass.clone()
-                self._round_graph, self._round_calls = None, 0
-                tree = self._tree = None
-            else:
-                self._step_buf.copy_(step)
-                self._mass_buf.copy_(inv_mass)
-            step, inv_mass = self._step_buf, self._mass_buf
+        if replayable or self._step_buf is not None:
+            step, inv_mass = self._persistent_step_and_mass(step, inv_mass)
+            tree = self._tree
         if tree is None or tree.inv_mass is not inv_mass or tree.step is not step:
             if tree is None:
                 tree = kernels.NutsTree(self._z, self._pe, self._grad, inv_mass, step,

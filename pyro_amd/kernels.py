@@ -940,9 +940,9 @@ def glm_label_moments_of(X, y):
         if capturing or cache.get("misses", 0) > 8:
             return None                       # (labels that keep changing: the kernel sums the term itself)
         import weakref
+        # (no eviction: a captured step holds the ADDRESS of the moments it was recorded with and SVI keeps
+        # that graph as long as it keeps (X, y); the miss budget above bounds the entries at nine of 264 bytes)
         cache["misses"] = cache.get("misses", 0) + 1
-        for k in [k for k in cache if k != "misses"][:-3]:
-            cache.pop(k, None)
         m = [weakref.ref(ybase), y._version, X._version, glm_label_moments(X, y),
              (y.storage_offset(), tuple(y.shape), tuple(y.stride()))]
         cache[key] = m
@@ -1556,6 +1556,70 @@ class NutsTree:
     def n_active(self):
         """Number of chains still building their tree (host synchronisation)."""
         return int(self._n_active.item())
+
+    # ---- asynchronous chains: spans of K transitions per chain (pa_nuts_tree_run_*) ------------
+    RUN_ADAPT_STEP, RUN_WELFORD, RUN_COUNT_ACCEPTS = 1, 2, 4
+
+    def run_buffers(self):
+        """Span control words and per-chain progress (allocated once: a captured graph of rounds
+        holds their addresses)."""
+        if getattr(self, "ctl", None) is None:
+            dev = self.z.device
+            self.ctl = torch.zeros((8,), dtype=torch.int64, device=dev)
+            self.tc = torch.zeros((self.C,), dtype=torch.int32, device=dev)
+            self.n_done = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.gate = torch.zeros((2,), dtype=torch.int64, device=dev)   # [1]: the abort word
+        return self.ctl
+
+    def set_span(self, t0, K, mean_n0=0, welford_n0=0, flags=0, samples=None, div_flags=None, row0=0):
+        """Transitions t0 .. t0+K-1 of every chain; ``samples`` [rows, C, D] / ``div_flags``
+        [rows, C] int8 receive transition t0 + k at row row0 + k."""
+        self.run_buffers()
+        if samples is not None:
+            _require_gpu(samples)
+            assert samples.is_contiguous() and samples.dtype == self.z.dtype
+            assert samples.shape[1:] == self.z.shape and samples.shape[0] >= row0 + K
+        if div_flags is not None:
+            _require_gpu(div_flags)
+            assert div_flags.is_contiguous() and div_flags.dtype == torch.int8
+            assert div_flags.shape[1] == self.C and div_flags.shape[0] >= row0 + K
+        self._span_keep = (samples, div_flags)
+        words = [int(t0), int(K), int(mean_n0), int(welford_n0), int(flags),
+                 0 if samples is None else samples.data_ptr(),
+                 0 if div_flags is None else div_flags.data_ptr(), int(row0)]
+        self.ctl.copy_(torch.tensor(words, dtype=torch.int64))
+
+    def run_begin(self):
+        check(_lib.load().pa_nuts_tree_run_begin(
+            self.dt, _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq),
+            _ptr(self.inv_mass), self.im_stride, _ptr(self.step), self.C, self.D,
+            self.max_tree_depth, self.multinomial, self.seed, self.chain_offset, _ptr(self.ctl),
+            _ptr(self.tc), _ptr(self.n_done), _ptr(self.gate[1:]), _ptr(self.ws), self.nbytes,
+            _stream()))
+
+    def run_advance(self, peq, gq, da_state, target_accept, welford, mean_accept, counters):
+        """One round of a span: every live chain consumes (peq, gq) at its cursor; a chain whose
+        tree finishes adapts, stores its draw and begins its next transition in the same launch."""
+        _require_gpu(peq, gq, da_state, welford, mean_accept, counters)
+        assert peq.is_contiguous() and gq.is_contiguous() and gq.dtype == self.z.dtype
+        assert peq.dtype == self.z.dtype and gq.shape == self.z.shape and peq.numel() == self.C
+        assert da_state.shape == (self.C, 5) and welford.shape == (self.C, 2, self.D)
+        assert da_state.dtype == welford.dtype == mean_accept.dtype == self.z.dtype
+        assert counters.shape == (3, self.C) and counters.dtype == torch.int64
+        for x in (da_state, welford, mean_accept, counters):
+            assert x.is_contiguous()
+        check(_lib.load().pa_nuts_tree_run_advance(
+            self.dt, _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq),
+            _ptr(gq), _ptr(peq), _ptr(self.inv_mass), self.im_stride, _ptr(self.step),
+            self.C, self.D, self.max_tree_depth, self.multinomial, self.seed, self.chain_offset,
+            _ptr(self.ctl), _ptr(da_state), float(target_accept), _ptr(welford), _ptr(mean_accept),
+            _ptr(counters), _ptr(self.tc), _ptr(self.n_done), _ptr(self.gate[1:]),
+            _ptr(self.accept_prob), _ptr(self.ints[0]), _ptr(self.ints[1]), _ptr(self.ints[2]),
+            _ptr(self.ints[3]), _ptr(self.ws), self.nbytes, _stream()))
+
+    def span_done(self):
+        """True when every chain has completed its span (host synchronisation)."""
+        return int(self.n_done.item()) >= self.C
 
     def stats(self):
         return {"accept_prob": self.accept_prob, "n_leapfrog": self.ints[0], "depth": self.ints[1],

@@ -369,6 +369,42 @@ def run_persistent_equals_stepwise(device, dtype, rtol, C=6, D=9, warmup=40, S=6
     assert abs(a[4]["mean tree depth"] - b[4]["mean tree depth"]) < 1e-12
 
 
+def run_async_equals_lockstep(device, dtype, rtol, C=6, D=9, warmup=40, S=6, multinomial=True, adapt=True):
+    """MCMC(NUTS(generic potential)) with step-size + mass adaptation: spans of ASYNCHRONOUS chains
+    (a chain that finishes a tree adapts and starts its next tree in the same launch, in-kernel dual
+    averaging / Welford) against the lock-step per-transition path with host adaptation.  The Philox
+    keys do not know the schedule => the same chains up to rounding of the adaptation math."""
+    Lam = torch.tensor(make_precision(D, 4), dtype=dtype, device=device)
+    z0 = torch.tensor(np.random.default_rng(1).standard_normal((C, D)) * 0.3, dtype=dtype,
+                      device=device)
+    outs = []
+    for async_chains in (False, True):
+        pyro.set_rng_seed(78)
+        kernel = NUTS(potential_fn=LogCoshPotential(Lam), max_tree_depth=5, step_size=1.0 if adapt else 0.15,
+                      use_multinomial_sampling=multinomial, adapt_step_size=adapt, adapt_mass_matrix=adapt)
+        kernel.use_async_chains = async_chains
+        mcmc = MCMC(kernel, num_samples=S, warmup_steps=warmup, num_chains=C,
+                    initial_params={"x": z0.clone()})
+        mcmc.run()
+        assert kernel.bulk_ready == async_chains
+        outs.append((mcmc.get_samples(group_by_chain=True)["x"].clone(),
+                     kernel.step_size.clone(), kernel.mass_matrix_adapter.inverse_mass_matrix.clone(),
+                     kernel.num_leapfrog_steps, mcmc.diagnostics(), kernel._mean_accept_prob.clone()))
+    a, b = outs
+    assert a[3] == b[3], (a[3], b[3])                       # identical trees
+    if not adapt:
+        # no host-side adaptation arithmetic to differ from the kernel's: the two schedules run the same
+        # kernels on the same numbers
+        rtol = 0.0
+    torch.testing.assert_close(a[1], b[1], rtol=rtol, atol=0)
+    torch.testing.assert_close(a[2], b[2], rtol=rtol, atol=0)
+    torch.testing.assert_close(a[0], b[0], rtol=rtol, atol=rtol)
+    torch.testing.assert_close(a[5], b[5], rtol=max(rtol, 1e-14), atol=max(rtol, 1e-14))
+    assert a[4]["acceptance rate"] == b[4]["acceptance rate"]
+    assert a[4]["divergences"] == b[4]["divergences"]
+    assert abs(a[4]["mean tree depth"] - b[4]["mean tree depth"]) < 1e-12
+
+
 # ---- discrete latents summed out of the potential (tests/golden/mcmc_enum.npz) -------------------
 def _enum_models(device, dtype, batch_safe):
     import pyro_amd as pyro

@@ -380,6 +380,42 @@ class NutsTree:
     def n_active(self):
         return self._o.n_active()
 
+    # asynchronous chains (kernels.NutsTree.run_*): the span oracle of oracle/nuts_tree.py
+    RUN_ADAPT_STEP, RUN_WELFORD, RUN_COUNT_ACCEPTS = 1, 2, 4
+    gate = None
+
+    def set_span(self, t0, K, mean_n0=0, welford_n0=0, flags=0, samples=None, div_flags=None, row0=0):
+        self._span = dict(t0=t0, K=K, mean_n0=mean_n0, welford_n0=welford_n0, flags=flags, row0=row0)
+        self._span_out = (samples, div_flags)
+
+    def run_begin(self):
+        np_dt = np.float32 if self.z.dtype == torch.float32 else np.float64
+        self._zn, self._pn, self._gn = _np(self.z).copy(), _np(self.pe).copy(), _np(self.grad).copy()
+        self._stepn = _np(self.step).copy()
+        self._o = o_tree.NutsTreeOracle(self._zn, self._pn, self._gn, _np(self.inv_mass),
+                                        self._stepn, *self._args, dtype=np_dt)
+        samples, div = self._span_out
+        self._sn = None if samples is None else _np(samples).copy()
+        self._dn = None if div is None else _np(div).copy()
+        self._o.run_begin(samples=self._sn, div_flags=self._dn, **self._span)
+        self._sync()
+
+    def run_advance(self, peq, gq, da_state, target_accept, welford, mean_accept, counters):
+        arrs = [_np(x).copy() for x in (da_state, welford, mean_accept, counters)]
+        self._o.run_advance(_np(peq), _np(gq), arrs[0], target_accept, arrs[1], arrs[2], arrs[3])
+        for t, a in zip((da_state, welford, mean_accept, counters), arrs):
+            t.copy_(torch.as_tensor(a))
+        self.step.copy_(torch.as_tensor(self._stepn))
+        samples, div = self._span_out
+        if samples is not None:
+            samples.copy_(torch.as_tensor(self._sn))
+        if div is not None:
+            div.copy_(torch.as_tensor(self._dn))
+        self._sync()
+
+    def span_done(self):
+        return self._o.span_done()
+
     def stats(self):
         ti = torch.as_tensor(self._o.ints)
         return {"accept_prob": torch.as_tensor(self._o.accept_prob, dtype=self.z.dtype),

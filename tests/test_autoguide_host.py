@@ -210,10 +210,13 @@ def test_exp_site_with_a_host_side_lower_bound():
     assert _exp_lower(biject_to(constraints.independent(constraints.nonnegative, 2))) == 0.0
     assert _exp_lower(biject_to(constraints.unit_interval)) is None
     assert _exp_lower(biject_to(constraints.greater_than(torch.tensor(1.5)))) is None
-    u = torch.randn(3, 2, 4, dtype=torch.float64, requires_grad=True)
     t = biject_to(constraints.greater_than(1.5))
-    for ed in (0, 1, 2):
+    # (size-1 event dims: the event rank cannot be recovered from the number of event elements)
+    for shape, ed in (((3, 2, 4), 0), ((3, 2, 4), 1), ((3, 2, 4), 2), ((3, 1), 1), ((3, 1, 5), 2), ((4, 1, 1), 2),
+                      ((1,), 1), ((2, 5, 1), 1)):
+        u = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
         value, ld = fused.exp_site(u, ed, 1.5)
+        assert ld.shape == u.shape[:u.dim() - ed]
         ref_v = t(u)
         ref_ld = t.inv.log_abs_det_jacobian(ref_v, u)
         ref_ld = ref_ld.sum(tuple(range(-ed, 0))) if ed else ref_ld

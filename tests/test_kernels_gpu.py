@@ -1634,3 +1634,14 @@ def test_glm_label_moments_follow_the_tensors(gpu):
     got = k.glm_bernoulli_fwd_bwd(X, y, w, None, None, 1.0)
     want = o_glm.glm_bernoulli_fwd_bwd(X.cpu().numpy(), y.cpu().numpy(), w.cpu().numpy(), None, None, 1.0)
     np.testing.assert_allclose(got[0].cpu().numpy(), want[0], rtol=2e-5)
+    # several label vectors over one X (one-vs-rest): the moments handed out for the first one stay the
+    # first one's -- a captured step has their ADDRESS baked in -- however many others follow
+    addr, keep = m.data_ptr(), []
+    for j in range(6):
+        yj = tt((rng.uniform(size=N) < 0.3 + 0.05 * j).astype(np.float32), gpu)
+        keep.append(yj)
+        mj = k.glm_label_moments_of(X, yj)
+        assert mj is not None and mj.data_ptr() != addr
+    again = k.glm_label_moments_of(X, y)
+    assert again is m and again.data_ptr() == addr
+    np.testing.assert_allclose(m.cpu().numpy(), -ref, rtol=1e-12, atol=1e-9)

@@ -185,6 +185,26 @@ def test_persistent_launch_path_equals_per_transition_path_f64(gpu):
     mc.run_persistent_equals_stepwise(gpu, torch.float64, 1e-6)
 
 
+@pytest.mark.parametrize("dtype,rtol,D", [(torch.float64, 1e-6, 9), (torch.float64, 1e-6, 200),
+                                           (torch.float64, 5e-5, 700)])
+def test_asynchronous_chains_equal_lock_step_chains(gpu, dtype, rtol, D):
+    """Spans of asynchronous chains (captured rounds, in-kernel adaptation) against the lock-step
+    per-transition path: every tree plan of the kernel (1 wave x 2 / x 8, 4 waves x 8).  The in-kernel
+    dual averaging uses device exp / log / sqrt: equal to the host recurrences to rounding, which 46
+    transitions of a 700-dimensional chain amplify to ~1e-5."""
+    mc.run_async_equals_lockstep(gpu, dtype, rtol, C=6, D=D, warmup=40, S=6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("D", [9, 200, 700])
+def test_asynchronous_chains_are_bitwise_the_lock_step_chains_without_adaptation(gpu, dtype, D):
+    mc.run_async_equals_lockstep(gpu, dtype, 0.0, C=7, D=D, warmup=5, S=25, adapt=False)
+
+
+def test_asynchronous_chains_slice_sampling(gpu):
+    mc.run_async_equals_lockstep(gpu, torch.float64, 1e-6, C=5, D=7, warmup=30, S=5, multinomial=False)
+
+
 @pytest.mark.parametrize("D", [5, 64, 100, 128])
 def test_multi_transition_launch_is_bitwise_sequence_of_single_launches(gpu, D):
     """K transitions in one launch == K launches of one transition (no adaptation), bit for bit,

@@ -204,6 +204,16 @@ def test_persistent_launch_path_equals_per_transition_path(_cpu_backend):
                                       warmup=30, S=4)
 
 
+@pytest.mark.parametrize("multinomial", [True, False])
+def test_asynchronous_chains_equal_lock_step_chains(_cpu_backend, multinomial):
+    mc.run_async_equals_lockstep(torch.device("cpu"), torch.float64, 1e-10, C=3, D=5, warmup=30, S=4,
+                                 multinomial=multinomial)
+
+
+def test_asynchronous_chains_without_adaptation_are_the_lock_step_chains_exactly(_cpu_backend):
+    mc.run_async_equals_lockstep(torch.device("cpu"), torch.float64, 0.0, C=3, D=5, warmup=3, S=8, adapt=False)
+
+
 def test_discrete_latents_are_summed_out_of_the_potential(_cpu_backend):
     mc.run_enum_potential_vs_reference(torch.device("cpu"))
 
