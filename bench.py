@@ -47,6 +47,7 @@ BINDING_BF16 = ("VALU issue next to the MFMA pipe: 332 VALU instructions per wav
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_F32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak (FMA = 2 flop)
+CPU_BASELINE_THREADS = 32      # the CPU legs run on this many host threads, every round
 
 
 def parse():
@@ -70,6 +71,12 @@ def parse():
     ap.add_argument("--nuts-dim", type=int, default=100)
     ap.add_argument("--nuts-warmup", type=int, default=200)
     ap.add_argument("--nuts-samples", type=int, default=200)
+    ap.add_argument("--no-model-nuts", action="store_true",
+                    help="skip NUTS on the logistic-regression MODEL (secondary_model_nuts)")
+    ap.add_argument("--model-nuts-chains", type=int, default=256, help="chains per GPU")
+    ap.add_argument("--model-nuts-warmup", type=int, default=100)
+    ap.add_argument("--model-nuts-samples", type=int, default=100)
+    ap.add_argument("--model-nuts-depth", type=int, default=10)
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--config5-sharded", action=argparse.BooleanOptionalAction, default=None,
                     help="also time BASELINE configs[4] with the PLATE sharded over the ranks (SURVEY "
@@ -133,32 +140,34 @@ def cpu_baseline(N, D, P, budget_s):
     y = (torch.rand((N,), generator=g) < torch.sigmoid(X @ w_true)).float()
     port = LogRegAutoNormalPort(X, y, P)
     ncpu = os.cpu_count() or 1
-    sweep = sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}) or [ncpu]
+    # a STATED thread count (the same every round, so that ratios compare across rounds): 32, the
+    # neighbourhood the sweeps of rounds 2-4 found best on this shape (16 and 32 within a few per cent,
+    # 128 slower); one probe of 16 beside it is reported, not used
+    cores = min(CPU_BASELINE_THREADS, ncpu)
     default_threads = torch.get_num_threads()
     probe = {}
     try:
-        for t in sweep:
+        for t in sorted({min(16, ncpu), cores}):
             torch.set_num_threads(t)
             port.step()
             t0 = time.perf_counter()
             port.step()
             probe[t] = time.perf_counter() - t0
-        best = min(probe, key=probe.get)
-        torch.set_num_threads(best)
+        torch.set_num_threads(cores)
         left = max(2.0, budget_s - 2.0 * sum(probe.values()))
-        n = max(3, min(40, int(left / max(probe[best], 1e-3))))
+        n = max(3, min(40, int(left / max(probe[cores], 1e-3))))
         t0 = time.perf_counter()
         for _ in range(n):
             port.step()
         dt = time.perf_counter() - t0
     finally:
         torch.set_num_threads(default_threads)
-    return {"value": n / dt, "unit": "ELBO-grad steps/s", "cores": best, "kind": "port",
-            "thread_sweep_steps_per_s": {str(t): 1.0 / v for t, v in probe.items()},
+    return {"value": n / dt, "unit": "ELBO-grad steps/s", "cores": cores, "kind": "port",
+            "probe_steps_per_s": {str(t): 1.0 / v for t, v in probe.items()},
             "host_cpus": ncpu,
             "sample": "%d full SVI steps (N=%d, D=%d, P=%d, fp32) of oracle/ref_port_torch.py "
-                      "(the reference's torch-CPU operators without its handler overhead) at the "
-                      "best of the swept thread counts" % (n, N, D, P)}
+                      "(the reference's torch-CPU operators without its handler overhead) on %d "
+                      "threads (fixed)" % (n, N, D, P, cores)}
 
 
 def _nuts_chain_on_host(D, budget_s, chain):
@@ -310,6 +319,174 @@ def bench_nuts(dev, rank, world, args):
     return out
 
 
+def _model_nuts_chain_on_host(N, D, budget_s, threads):
+    """One reference-style chain of NUTS on the logistic-regression MODEL on the host: the recursive
+    tree of pyro/infer/mcmc/nuts.py (oracle/nuts.py), the potential (-log joint of examples.logreg_model:
+    pyro/infer/mcmc/util.py:264-286) and its gradient by torch-CPU autograd on every leapfrog step, as
+    pyro/ops/integrator.py:68-94 does.  -> (leapfrogs, transitions, seconds)."""
+    import numpy as np
+    from oracle import nuts as o_nuts
+
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn((N, D), generator=g)
+    w_true = torch.randn((D,), generator=g)
+    y = (torch.rand((N,), generator=g) < torch.sigmoid(X @ w_true)).float()
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def pot_and_grad(z):
+        zt = torch.tensor(z, dtype=torch.float32, requires_grad=True)
+        b, w = zt[0], zt[1:]                       # flat layout: sites sorted by name
+        pe = bce(X @ w + b, y, reduction="sum") + 0.5 * (zt * zt).sum()
+        (gr,) = torch.autograd.grad(pe, zt)
+        return float(pe.detach()), gr.double().numpy()
+
+    z = np.zeros(D + 1)
+    pe, gr = pot_and_grad(z)
+    n, t0, t = 0, time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        out = o_nuts.nuts_transition(z, pe, gr, pot_and_grad, np.ones(D + 1), 0.02,
+                                     o_nuts.KeyedDraws(1, 0, t, np.float64), 10, True)
+        z, pe, gr = out["z"], out["pe"], out["grad"]
+        n += out["n_leapfrog"]
+        t += 1
+    return n, t, time.perf_counter() - t0
+
+
+def bench_model_nuts(dev, rank, world, args):
+    """NUTS on a MODEL potential (north_star: "the velocity-Verlet update with potential_fn grad"):
+    MCMC(NUTS(examples.logreg_model)) -- BASELINE configs[1]'s model text, through the handlers -- with
+    per-chain step-size and diagonal-mass adaptation, C vectorised chains per GPU, at N = 1e5 and 1e6.
+    Leapfrog steps/s = leapfrogs of all chains / wall time, for the whole MCMC.run (setup, capture and
+    warm-up included) and for its sampling phase alone."""
+    import torch.distributed as dist
+
+    import pyro_amd as pyro
+    from pyro_amd import _lib, examples, kernels
+    from pyro_amd.infer.mcmc import MCMC, NUTS
+
+    C, D = args.model_nuts_chains, args.features
+    W, S = args.model_nuts_warmup, args.model_nuts_samples
+
+    def run(X, y, warmup, samples, chains):
+        pyro.set_rng_seed(11 + rank)
+        kernel = NUTS(examples.logreg_model, max_tree_depth=args.model_nuts_depth)
+        mcmc = MCMC(kernel, num_samples=samples, warmup_steps=warmup, num_chains=chains,
+                    shard_chains=False)
+        marks = {}
+        end_warmup = kernel.end_warmup
+
+        def marked():
+            torch.cuda.synchronize()
+            marks.update(t=time.perf_counter(), n=kernel.num_leapfrog_steps,
+                         replays=getattr(kernel, "_span_replays", 0))
+            end_warmup()
+        kernel.end_warmup = marked
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mcmc.run(X, y)
+        n = kernel.num_leapfrog_steps
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        return kernel, mcmc, dict(wall=t1 - t0, n=n, t_sample=t1 - marks["t"], n_sample=n - marks["n"],
+                                  replays_sample=getattr(kernel, "_span_replays", 0) - marks["replays"])
+
+    out = {}
+    # (N, chains, warm-up, samples): the 1e6-row posterior is ~30x tighter than the prior's scale, so chains
+    # started at the reference's uniform(-2, 2) points spend a short warm-up travelling with deep trees --
+    # that run is a throughput measurement (its R-hat says so), the 1e5-row runs are converged ones
+    plan = [(100_000, C, 2 * W, 2 * S), (100_000, 4 * C, W, S), (1_000_000, C, max(W // 2, 10), max(S // 4, 5))]
+    X = y = None
+    for N, C, W, S in plan:
+        if X is None or X.shape[0] != N:
+            X, y = examples.synthetic_logreg_data(N, D, dev, seed=0)
+        run(X, y, 12, 4, C)                      # warm the allocator / code objects / the plane image of X
+        kernel, mcmc, r = run(X, y, W, S, C)
+        tot = torch.tensor([float(r["n"]), r["wall"], float(r["n_sample"]), r["t_sample"]], device=dev,
+                           dtype=torch.float64)
+        if world > 1:
+            mx = tot.clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            n_all, wall, ns_all, ts = float(tot[0]), float(mx[1]), float(tot[2]), float(mx[3])
+        else:
+            n_all, wall, ns_all, ts = (float(v) for v in tot)
+        if rank != 0:
+            continue
+        # the dominant kernel at P = C particles, HIP events on its launch stream, eager evaluations
+        # of the same potential at the chains' final positions
+        timer = kernels.KernelTimer(_lib.KERNEL_GLM)
+        with pyro.validation_enabled(False):
+            for _ in range(8):
+                timer.arm()
+                kernel._potential(kernel._z)
+        torch.cuda.synchronize()
+        kms = sorted(timer.times_ms())
+        kern_ms = kms[len(kms) // 2] if kms else float("nan")
+        rounds = r["replays_sample"] * kernel.rounds_per_replay
+        alg = N * (4 * D + 4)
+        diag = mcmc.diagnostics()
+        key = "N%d_C%d" % (N, C)
+        out[key] = {
+            "value": n_all / wall, "sampling_phase": ns_all / ts, "unit": "leapfrog steps/s summed over chains",
+            "wall_s": wall, "leapfrogs": n_all, "sampling_s": ts, "sampling_leapfrogs": ns_all,
+            "mean_tree_leaves": r["n"] / ((W + S) * C),
+            "rounds_sampling": rounds, "us_per_round": ts / max(rounds, 1) * 1e6,
+            "round_occupancy": r["n_sample"] / max(rounds * C, 1),
+            "graphed": bool(rounds),
+            "posterior_check": {"max_r_hat": float(max(d["r_hat"].max() for k, d in diag.items()
+                                                       if isinstance(d, dict) and "r_hat" in d)),
+                                "mean_accept_prob": float(kernel._mean_accept_prob.mean()),
+                                "mean_step_size": float(kernel.step_size.mean())},
+            "roofline": {"bound": "hbm", "kernel": "glm_planes_f16_kernel (P = %d chains: %d passes of 64 over "
+                                                   "the image)" % (C, -(-C // 64)),
+                         "kernel_ms": kern_ms, "kernel_ms_source": "HIP events around the kernel on its launch "
+                         "stream, median of %d eager evaluations of the potential" % len(kms),
+                         "algorithmic_bytes_per_round": alg, "achieved": alg / (kern_ms * 1e-3) / 1e9,
+                         "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                         "frac": alg / (kern_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                         "frac_of_round": alg / (ts / max(rounds, 1)) / 1e12 / PEAK_HBM_TBS,
+                         "note": "N(4D+4) bytes per round are shared by all chains; the kernel is bound by "
+                                 "VALU issue (14.6 instructions per (row, chain) element), so its time "
+                                 "grows with C at fixed bytes",
+                         "traffic": None}}
+        tp = latest_profile("nuts_model_traffic.json")
+        if tp is not None:
+            try:
+                tj = json.load(open(tp))
+                ent = tj.get(key)
+                if ent:
+                    out[key]["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
+                    out[key]["roofline"]["traffic_source"] = "profiles/%s" % os.path.basename(tp)
+            except Exception:
+                pass
+        out[key]["transitions"] = "%d warm-up + %d samples" % (W, S)
+        kernel.cleanup()
+    C, W, S = args.model_nuts_chains, args.model_nuts_warmup, args.model_nuts_samples
+    if rank != 0:
+        return None
+    res = {"metric": "leapfrog steps/sec (NUTS on a model potential)", "n_gpus": world, "scaling": "weak",
+           "dtype": "f32",
+           "config": {"workload": "MCMC(NUTS(model)), model = BASELINE configs[1]'s logistic regression (SURVEY "
+                                  "8(d) text, w @ X.t() recognised lazily), D=%d, %d / %d vectorised chains per GPU, "
+                                  "per-chain step-size + diagonal-mass adaptation, "
+                                  "max_tree_depth=%d; asynchronous chains (a chain that finishes a tree starts "
+                                  "its next one in the same launch), %d rounds per hipGraph replay"
+                                  % (D, C, 4 * C, args.model_nuts_depth, 16)},
+           "runs": out}
+    if world == 1 and not args.no_cpu_baseline:
+        n, t, dt = _model_nuts_chain_on_host(100_000, D, min(args.cpu_budget_s, 8.0),
+                                             min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
+        res["cpu_baseline"] = {"value": n / dt, "unit": "leapfrog steps/s", "kind": "port",
+                               "cores": min(CPU_BASELINE_THREADS, os.cpu_count() or 1),
+                               "sample": "%d NUTS transitions (%d leapfrogs) of ONE chain at N=1e5, D=%d: "
+                                         "oracle/nuts.py recursion + torch-CPU autograd of the model's log "
+                                         "joint per leapfrog, step 0.02, unit mass" % (t, n, D)}
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,7 +509,7 @@ def main():
         dev = torch.device("cpu")
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        args.no_nuts = args.no_others = args.no_cpu_baseline = args.no_graph = True
+        args.no_nuts = args.no_others = args.no_cpu_baseline = args.no_graph = args.no_model_nuts = True
 
     import pyro_amd as pyro
     from pyro_amd import _lib, examples, kernels
@@ -525,6 +702,14 @@ def main():
                                 "flat gradient all-reduce (mean)" % (n_loc * world, args.config5_groups, P)}
         pyro.clear_param_store()
     nuts = None if args.no_nuts else bench_nuts(dev, rank, world, args)
+    model_nuts = None
+    if not args.no_model_nuts:
+        try:
+            model_nuts = bench_model_nuts(dev, rank, world, args)
+        except Exception as e:  # noqa: BLE001  (a secondary measurement must not kill the headline)
+            if world > 1:
+                raise
+            model_nuts = {"error": "%s: %s" % (type(e).__name__, e)}
     others = None
     if world == 1 and not args.no_others:
         # BASELINE configs[3] and configs[4] (one GPU's share) -- reported, not the headline value
@@ -696,13 +881,16 @@ def main():
                                               "+ ELBO assembly + guide backward + Adam + loss hand-over)",
                                "chain": getattr(svi, "chain_stats", None),
                                "chain_fused": getattr(svi, "chain_fused", None)}
-        if nuts is not None:
-            out["secondary"] = nuts
         if sharded5 is not None:
             others = dict(others or {})
             others["config5_plate_sharded"] = sharded5
         if others:
             out["other_configs"] = others
+        # (the two NUTS blocks LAST: the driver keeps the tail of this line)
+        if nuts is not None:
+            out["secondary"] = nuts
+        if model_nuts is not None:
+            out["secondary_model_nuts"] = model_nuts
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
