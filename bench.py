@@ -230,6 +230,24 @@ def nuts_cpu_baseline(D, budget_s, procs=7):
     return out
 
 
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+class _NoKernelTimer:                      # (host run of the plumbing: nothing to bracket)
+    pairs = []
+
+    def arm(self):
+        pass
+
+    def times_ms(self):
+        return []
+
+    def mean_ms(self):
+        return float("nan")
+
+
 def bench_nuts(dev, rank, world, args):
     """BASELINE config 3: NUTS on a 100-dim correlated Gaussian, 1024 vectorised chains per GPU,
     200 warm-up (step size + diagonal mass adapted per chain) + 200 sampling transitions.
@@ -250,19 +268,19 @@ def bench_nuts(dev, rank, world, args):
                       target_accept_prob=0.8)
         mcmc = MCMC(kernel, num_samples=samples, warmup_steps=warmup, num_chains=C,
                     initial_params={"x": torch.zeros((C, D), device=dev)}, shard_chains=False)
-        timer = kernels.KernelTimer(_lib.KERNEL_NUTS)
+        timer = kernels.KernelTimer(_lib.KERNEL_NUTS) if dev.type == "cuda" else _NoKernelTimer()
         kernel._launch_hook = timer.arm      # brackets every persistent launch
         mcmc.run()
         return kernel, mcmc, timer
 
-    run(20, 5)                                   # warm the allocator / code objects
+    run(min(20, args.nuts_warmup), min(5, args.nuts_samples))    # warm the allocator / code objects
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync(dev)
     t0 = time.perf_counter()
     kernel, mcmc, timer = run(args.nuts_warmup, args.nuts_samples)
     nleap = kernel.num_leapfrog_steps
-    torch.cuda.synchronize()
+    _sync(dev)
     elapsed = time.perf_counter() - t0
     tot = torch.tensor([float(nleap), elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -377,18 +395,18 @@ def bench_model_nuts(dev, rank, world, args):
         end_warmup = kernel.end_warmup
 
         def marked():
-            torch.cuda.synchronize()
+            _sync(dev)
             marks.update(t=time.perf_counter(), n=kernel.num_leapfrog_steps,
                          replays=getattr(kernel, "_span_replays", 0))
             end_warmup()
         kernel.end_warmup = marked
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(dev)
         t0 = time.perf_counter()
         mcmc.run(X, y)
         n = kernel.num_leapfrog_steps
-        torch.cuda.synchronize()
+        _sync(dev)
         t1 = time.perf_counter()
         return kernel, mcmc, dict(wall=t1 - t0, n=n, t_sample=t1 - marks["t"], n_sample=n - marks["n"],
                                   replays_sample=getattr(kernel, "_span_replays", 0) - marks["replays"])
@@ -398,11 +416,13 @@ def bench_model_nuts(dev, rank, world, args):
     # started at the reference's uniform(-2, 2) points spend a short warm-up travelling with deep trees --
     # that run is a throughput measurement (its R-hat says so), the 1e5-row runs are converged ones
     plan = [(100_000, C, 2 * W, 2 * S), (100_000, 4 * C, W, S), (1_000_000, C, max(W // 2, 10), max(S // 4, 5))]
+    if dev.type != "cuda":                 # the plumbing test of tests/test_distributed_cpu.py
+        plan = [(args.plate, C, W, S)]
     X = y = None
     for N, C, W, S in plan:
         if X is None or X.shape[0] != N:
             X, y = examples.synthetic_logreg_data(N, D, dev, seed=0)
-        run(X, y, 12, 4, C)                      # warm the allocator / code objects / the plane image of X
+        run(X, y, min(12, W), min(4, S), C)      # warm the allocator / code objects / the plane image of X
         kernel, mcmc, r = run(X, y, W, S, C)
         tot = torch.tensor([float(r["n"]), r["wall"], float(r["n_sample"]), r["t_sample"]], device=dev,
                            dtype=torch.float64)
@@ -417,12 +437,12 @@ def bench_model_nuts(dev, rank, world, args):
             continue
         # the dominant kernel at P = C particles, HIP events on its launch stream, eager evaluations
         # of the same potential at the chains' final positions
-        timer = kernels.KernelTimer(_lib.KERNEL_GLM)
+        timer = kernels.KernelTimer(_lib.KERNEL_GLM) if dev.type == "cuda" else _NoKernelTimer()
         with pyro.validation_enabled(False):
-            for _ in range(8):
+            for _ in range(8 if dev.type == "cuda" else 1):
                 timer.arm()
                 kernel._potential(kernel._z)
-        torch.cuda.synchronize()
+        _sync(dev)
         kms = sorted(timer.times_ms())
         kern_ms = kms[len(kms) // 2] if kms else float("nan")
         rounds = r["replays_sample"] * kernel.rounds_per_replay
@@ -509,7 +529,10 @@ def main():
         dev = torch.device("cpu")
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        args.no_nuts = args.no_others = args.no_cpu_baseline = args.no_graph = args.no_model_nuts = True
+        args.no_others = args.no_cpu_baseline = args.no_graph = True
+        # PYRO_AMD_BENCH_CPU_NUTS=1 keeps the two NUTS blocks in the host run (chain sharding, the sums and
+        # maxima over ranks, rank > 0 returning nothing): small sizes from the command line
+        args.no_nuts = args.no_model_nuts = not os.environ.get("PYRO_AMD_BENCH_CPU_NUTS")
 
     import pyro_amd as pyro
     from pyro_amd import _lib, examples, kernels

@@ -57,9 +57,11 @@ def _digamma(x):
     return digamma(x)
 
 
-def implicit_grad(alpha, x):
+def implicit_grad(alpha, x, asymptotic=True):
     """d x / d alpha of the reparameterised standard-Gamma draw (implicit differentiation of the CDF):
-    the dual-number power series (x < alpha + 1) / modified-Lentz continued fraction of gamma.hip."""
+    the dual-number power series (x < alpha + 1) / modified-Lentz continued fraction of gamma.hip, and from
+    alpha = 1e4 on its Cornish-Fisher form (``asymptotic=False``: the series everywhere, for the test that
+    pins the one on the other)."""
     a_all = np.asarray(alpha, dtype=np.float64)
     x_all = np.asarray(x, dtype=np.float64)
     a_all, x_all = np.broadcast_arrays(a_all, x_all)
@@ -68,7 +70,25 @@ def implicit_grad(alpha, x):
         a, xv = float(a_all[idx]), float(x_all[idx])
         if not (xv > 0.0 and a > 0.0):
             continue
-        if a > 1e8:             # normal limit, see gamma.hip
+        if asymptotic and a >= 1e4 and abs(xv - a) <= 8.0 * np.sqrt(a):
+            # Cornish-Fisher form of the quantile at fixed standard-normal z (gamma.hip), statement for statement
+            s = np.sqrt(a)
+            z = (xv - a) / s
+            for _ in range(4):
+                z2 = z * z
+                f = a + s * z + (z2 - 1.0) / 3.0 + (z2 * z - 7.0 * z) / (36.0 * s) - \
+                    (3.0 * z2 * z2 + 7.0 * z2 - 16.0) / (810.0 * a) + \
+                    (9.0 * z2 * z2 * z + 256.0 * z2 * z - 433.0 * z) / (38880.0 * a * s) - xv
+                fp = s + 2.0 * z / 3.0 + (3.0 * z2 - 7.0) / (36.0 * s) - \
+                    (12.0 * z2 * z + 14.0 * z) / (810.0 * a) + \
+                    (45.0 * z2 * z2 + 768.0 * z2 - 433.0) / (38880.0 * a * s)
+                z -= f / fp
+            z2 = z * z
+            out[idx] = 1.0 + z / (2.0 * s) - (z2 * z - 7.0 * z) / (72.0 * a * s) + \
+                (3.0 * z2 * z2 + 7.0 * z2 - 16.0) / (810.0 * a * a) - \
+                1.5 * (9.0 * z2 * z2 * z + 256.0 * z2 * z - 433.0 * z) / (38880.0 * a * a * s)
+            continue
+        if a > 1e8:             # (a tail draw out there) normal limit, see gamma.hip
             out[idx] = 1.0 + (xv - a) / (2.0 * a)
             continue
         budget = 500 + int(16.0 * np.sqrt(a))      # ~ c sqrt(a) terms are needed near x ~ a

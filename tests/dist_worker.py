@@ -118,7 +118,7 @@ def data_sharded_worker(rank, world, port, out_path, bank, X, y, steps):
         dist.destroy_process_group()
 
 
-def bench_worker(rank, world, port, out_path, steps):
+def bench_worker(rank, world, port, out_path, steps, nuts=False):
     """bench.py itself, launched the way the driver launches it for N > 1 (RANK / WORLD_SIZE /
     MASTER_* in the environment), on host tensors over gloo with the kernels answered by the oracle:
     the rendezvous, the barrier-bracketed timed region, the max-over-ranks time and the ONE JSON line
@@ -128,6 +128,8 @@ def bench_worker(rank, world, port, out_path, steps):
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                        "PYRO_AMD_BENCH_DEVICE": "cpu"})
+    if nuts:
+        os.environ["PYRO_AMD_BENCH_CPU_NUTS"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
@@ -137,6 +139,10 @@ def bench_worker(rank, world, port, out_path, steps):
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", str(steps), "--warmup", "1",
                 "--plate", "512", "--features", "8", "--particles", "4",
                 "--config5-rows", "600", "--config5-groups", "5"]     # (--config5-sharded: on by default at N > 1)
+    if nuts:      # the driver's 8-GPU shares at toy sizes: 1024 chains / 8 -> 2 per rank, 512 particles / 8 -> 4
+        sys.argv += ["--chains", "2", "--nuts-dim", "5", "--nuts-warmup", "6", "--nuts-samples", "4",
+                     "--model-nuts-chains", "2", "--model-nuts-warmup", "5", "--model-nuts-samples", "3",
+                     "--model-nuts-depth", "3"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main()

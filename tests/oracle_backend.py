@@ -566,5 +566,8 @@ def install(monkeypatch):
     # the product refuses CPU tensors; lift that check for host-logic tests only
     monkeypatch.setattr(k, "_require_gpu", lambda *a: None)
     monkeypatch.setattr(k, "on_device", lambda t: True)     # the oracle stands in for the device
-    from pyro_amd.ops import lazy
+    from pyro_amd.ops import lazy, torch_library
     monkeypatch.setattr(lazy, "_on_device", lambda t: True)  # ... for the lazy recognition too
+    # the TORCH_LIBRARY ops launch HIP kernels from C++: host tensors take the autograd.Function route,
+    # whose kernels.* calls are the stand-ins above
+    monkeypatch.setattr(torch_library, "available", lambda: False)

@@ -112,6 +112,32 @@ def test_bench_torchrun_path_prints_one_line_with_two_ranks(tmp_path):
 
 
 
+@pytest.mark.timeout(900)
+def test_bench_with_eight_ranks_including_both_nuts_blocks(tmp_path):
+    """`bench.py --gpus 8 --steps 3` as the driver launches it on an 8-GPU node, on host tensors over gloo
+    with the oracle's kernels: eight ranks in the gradient all-reduce, config 5 sharded over them, the
+    chain-sharded NUTS blocks summed over ranks -- so that a first 8-GPU run does not trip on rank > 1
+    bookkeeping.  Rank 0 prints the one line; the others nothing."""
+    import json
+    outs = _run(dw.bench_worker, 8, (3, True), tmp_path, "bench8")
+    lines = [ln for ln in outs[0]["stdout"].splitlines() if ln.strip()]
+    assert len(lines) == 1, outs[0]["stdout"]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["steps"] == 3
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+    sh = rec["other_configs"]["config5_plate_sharded"]
+    assert sh["ranks"] == 8 and sh["rows_total"] == 600 and sh["steps_per_s"] > 0
+    nuts = rec["secondary"]
+    assert nuts["n_gpus"] == 8 and nuts["leapfrogs"] >= 8 * 2 * (6 + 4)      # >= one leapfrog per transition
+    mn = rec["secondary_model_nuts"]
+    assert "error" not in mn, mn
+    run = next(iter(mn["runs"].values()))
+    assert mn["n_gpus"] == 8 and run["leapfrogs"] >= 8 * 2 * (5 + 3) and run["value"] > 0
+    assert list(rec)[-2:] == ["secondary", "secondary_model_nuts"]            # (the driver keeps the line's tail)
+    for r in range(1, 8):
+        assert outs[r]["stdout"].strip() == ""
+
+
 def test_captured_collective_falls_back_to_the_split_form(monkeypatch):
     """SVI._capture with several ranks: the step is first captured as ONE graph holding the gradient
     all-reduce; when that capture fails the split form (graph 1 -> eager collective -> graph 2) is

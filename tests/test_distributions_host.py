@@ -144,3 +144,26 @@ def test_sum_plan_lists_one_pass_per_run_of_reduced_dims():
         for A, R, B in _sum_plan(g.shape, like):
             x = x.reshape(A, R, B).sum(1)
         torch.testing.assert_close(x.reshape(like), g.sum_to_size(like))
+
+
+def test_shape_and_scaling_helpers():
+    """distributions/util.py: block sums at either end of a tensor, the un-fused scale_and_mask (SURVEY 8a
+    row a5 for log-densities that come from torch's own classes), numpy-style broadcast of shape tuples."""
+    from pyro_amd.distributions import util as u
+    t = torch.arange(120.0).reshape(2, 3, 4, 5)
+    assert torch.equal(u.sum_rightmost(t, 2), t.sum((-1, -2))) and torch.equal(u.sum_leftmost(t, 2), t.sum((0, 1)))
+    assert torch.equal(u.sum_rightmost(t, -1), t.sum((1, 2, 3)))          # keep one leftmost dim
+    assert torch.equal(u.sum_leftmost(t, -1), t.sum((0, 1, 2)))           # keep one rightmost dim
+    assert u.sum_rightmost(t, 0) is t and u.sum_rightmost(t, 9).shape == () and u.sum_rightmost(2.5, 3) == 2.5
+    m = t.remainder(2) == 0
+    assert u.scale_and_mask(t, 1.0, None) is t and u.scale_and_mask(t, 1.0, True) is t
+    assert torch.equal(u.scale_and_mask(t, 3.0), 3.0 * t)
+    assert torch.equal(u.scale_and_mask(t, 3.0, m), torch.where(m, 3.0 * t, torch.zeros(())))
+    assert torch.equal(u.scale_and_mask(t, 1.0, m), torch.where(m, t, torch.zeros(())))
+    assert not u.scale_and_mask(t, 3.0, False).any() and u.scale_and_mask(0.0, 3.0, m) == 0.0
+    assert u.broadcast_shape((2, 1), (3,), ()) == (2, 3) and u.broadcast_shape() == ()
+    assert u.broadcast_shape((4, 1, 1), (2, 3)) == (4, 2, 3)
+    assert u.broadcast_shape((2, 3), (3,), strict=True) == (2, 3)
+    for a, b, strict in (((2,), (3,), False), ((2, 1), (2, 3), True), ((1,), (3,), True)):
+        with pytest.raises(ValueError, match="shape mismatch"):
+            u.broadcast_shape(a, b, strict=strict)
