@@ -6,7 +6,7 @@ RuntimeError is raised -- the product path never silently runs on the CPU.
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t,
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_uint32,
                     c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -196,6 +196,8 @@ _SIGNATURES = {
                                          c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pa_rtc_compile": (c_int, [c_char_p, c_char_p, c_void_p]),
+    "pa_rtc_launch": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_int, c_void_p]),
     "pa_nuts_gaussian_find_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_uint64,
                                            c_double, c_double, c_double, c_void_p]),

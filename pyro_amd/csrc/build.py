@@ -77,7 +77,8 @@ def build_library(force=False, verbose=False):
     objs = [o for o, _ in results]
     rebuilt = any(r for _, r in results)
     if rebuilt or force or not os.path.exists(LIB_PATH):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + \
+            ["-L/opt/rocm/lib", "-lhiprtc"]          # (csrc/rtc.hip: run-time compiled element-wise kernels)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (res.stdout, res.stderr))

@@ -281,18 +281,31 @@ class NUTS(HMC):
     def _capture_span(self, tree, base):
         import os
         import warnings
+        from ...ops import fuser
         lib = kernels._lib.load()
         try:
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            keep = []
-            kernels.check(lib.pa_gate_scope(kernels._ptr(tree.gate)))
-            try:
-                with torch.cuda.graph(graph):
-                    for _ in range(self.rounds_per_replay):
-                        keep.append(self._span_round(tree, base))
-            finally:
-                lib.pa_gate_scope(None)
+            # one eager round under the fuser: the element-wise kernels of a round (the glue between the
+            # model's fused sites and their autograd duals) are generated and compiled before the capture
+            with fuser.scope():
+                self._span_round(tree, base)
+            for attempt in (0, 1):
+                compiled = fuser.STATS["compiled"]
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                keep = []
+                kernels.check(lib.pa_gate_scope(kernels._ptr(tree.gate)))
+                try:
+                    with torch.cuda.graph(graph):
+                        for _ in range(self.rounds_per_replay):
+                            with fuser.scope():
+                                keep.append(self._span_round(tree, base))
+                    break
+                except Exception:  # noqa: BLE001
+                    # (a kernel generated during the capture loaded its module there: cached now, once more)
+                    if attempt == 1 or fuser.STATS["compiled"] == compiled:
+                        raise
+                finally:
+                    lib.pa_gate_scope(None)
             self._span_graph, self._span_keep = graph, keep
             return graph
         except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)

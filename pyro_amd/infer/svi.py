@@ -124,9 +124,42 @@ class _CapturedStep:
         return float(self._value_np[0])
 
 
+# ``SVI(model, guide, optim, loss)`` -- the reference's constructor, nothing else said -- captures its step
+# into a hipGraph by itself ("auto") when the step can be one: the ELBO assembles its loss on the device,
+# every tensor argument of step() lives on the GPU and there is at least one (a model that closes over
+# its data gives no argument whose identity says "same step again").  False: eager unless asked;
+# True: as if every SVI were built with hip_graph=True.  (pyro.settings alias: svi_capture_steps)
+CAPTURE_STEPS = "auto"
+
+
+def _FlatOptimOK(optim):
+    """An optimizer whose update a captured step may hold: the package's own (their step counters live on
+    the device); a wrapped torch optimizer keeps host-side state per call."""
+    return bool(getattr(optim, "zeroes_grads", False) or getattr(optim, "capturable", False))
+
+
+def _capturable_arguments(args, kwargs):
+    """Every tensor argument on the GPU, at least one of them, and nothing else but hashable constants."""
+    seen = False
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor):
+            if not a.is_cuda:
+                return False
+            seen = True
+        elif isinstance(a, (list, tuple)):
+            for t in a:
+                if isinstance(t, torch.Tensor):
+                    if not t.is_cuda:
+                        return False
+                    seen = True
+        elif not isinstance(a, (int, float, bool, str, type(None))):
+            return False
+    return seen
+
+
 class SVI:
     def __init__(self, model, guide, optim, loss, loss_and_grads=None, num_samples=0, num_steps=0,
-                 hip_graph=False, graph_warmup=3, prearm=False, speculate=True, **kwargs):
+                 hip_graph=None, graph_warmup=3, prearm=False, speculate=True, **kwargs):
         if num_steps or num_samples:
             warnings.warn("num_steps / num_samples are ignored (TracePosterior is not part of "
                           "this backend)")
@@ -146,6 +179,13 @@ class SVI:
 
                 loss_and_grads = _loss_and_grads
             self.loss, self.loss_and_grads = loss, loss_and_grads
+        # hip_graph=None (the default): decided at the first step() from its arguments, see CAPTURE_STEPS;
+        # a capture that fails leaves such an SVI eager without a warning (nobody asked for a graph)
+        self._auto_graph = hip_graph is None
+        if hip_graph is None:
+            want = CAPTURE_STEPS if _os.environ.get("PYRO_AMD_HIP_GRAPH", "1") != "0" else False
+            hip_graph = (want is True or want == "auto") and self._loss_device is not None \
+                and not prearm and _FlatOptimOK(optim)
         self.hip_graph = bool(hip_graph)
         # prearm: right after launching step k the replay of step k+1 is enqueued behind a gate node
         # and released by the next step() call with one store to pinned memory (the launch latency
@@ -201,6 +241,8 @@ class SVI:
         """One gradient step: loss_and_grads, optimizer update on every touched param, zero grads."""
         if not self.hip_graph:
             return self._eager_step(*args, **kwargs)
+        if self._auto_graph and not _capturable_arguments(args, kwargs):
+            return self._eager_step(*args, **kwargs)
         fast = self._armed_fast
         if fast is not None:
             # the step after an armed one, called with the very same argument objects: release the
@@ -221,7 +263,7 @@ class SVI:
                     for k in list(self._eager_seen)[:len(self._eager_seen) // 2]:
                         del self._eager_seen[k]
                         self._const_rec.pop(k, None)
-                    if not self._warned_keys:
+                    if not self._warned_keys and not self._auto_graph:
                         self._warned_keys = True
                         warnings.warn("pyro_amd: SVI(hip_graph=True) keeps seeing new argument "
                                       "signatures (fresh tensors or changing scalars every step); "
@@ -233,7 +275,10 @@ class SVI:
                     # and guide create, so that the captured step need not fill them again
                     from .constants import ConstantRecorder
                     rec = ConstantRecorder()
-                    with rec:
+                    from ..ops import fuser
+                    # (under the fuser too: the kernels the captured step will launch are generated and
+                    #  compiled here, before the capture starts)
+                    with fuser.scope(), rec:
                         out = self._eager_step(*args, **kwargs)
                     self._const_rec[key] = rec
                     return out
@@ -393,9 +438,12 @@ class SVI:
         return None
 
     def _capture_once(self, key, args, kwargs, const_rec, force_split=None, quiet=False,
-                      with_gate=False):
+                      with_gate=False, _retried=False):
         from .. import rng
+        from ..ops import fuser
         from ..primitives import validation_enabled
+
+        compiled_before = fuser.STATS["compiled"]
 
         device = None
         for a in list(args) + list(kwargs.values()):
@@ -442,7 +490,8 @@ class SVI:
                 multi = getattr(self.optim, "multi_rank", False)
                 mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
                 with torch.cuda.graph(graph, **mode):
-                    with gated(), cap, chain() as rec, hoist():
+                    # (the fuser outermost: it sees what the inner modes let through, last)
+                    with fuser.scope(), gated(), cap, chain() as rec, hoist():
                         if gate is not None:
                             gate.launch()          # first node: holds a replay enqueued ahead of time
                         with poutine.trace(param_only=True) as param_capture:
@@ -479,9 +528,14 @@ class SVI:
             from .constants import HoistedConstantWritten
             if isinstance(e, HoistedConstantWritten):
                 raise
+            if not _retried and fuser.STATS["compiled"] != compiled_before:
+                # a kernel the fuser generated DURING the capture loaded its module there, which a capture
+                # does not allow; it is cached now: the second attempt finds it
+                return self._capture_once(key, args, kwargs, const_rec, force_split=force_split, quiet=quiet,
+                                          with_gate=with_gate, _retried=True)
             if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):
                 raise
-            if quiet:
+            if quiet or self._auto_graph:
                 self.hip_graph = False
                 return None
             warnings.warn("pyro_amd: hipGraph capture of SVI.step failed ({}: {}); continuing "

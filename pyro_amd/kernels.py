@@ -41,9 +41,16 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# pyro_amd/ops/fuser.py defers eligible torch operators; a launch of ours is about to touch device memory,
+# so whatever is recorded has to be materialised first (the hook is set while a Fuser scope is open)
+_FUSER_HOOK = [None]
+
+
 def _ptr(t):
     if t is None:
         return None
+    if _FUSER_HOOK[0] is not None:
+        _FUSER_HOOK[0]()
     if _CHAIN["keep"] is not None:
         _CHAIN["keep"].append(t)       # a recorded launch reads / writes it at the flush
     return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,918 @@
+"""Fused element-wise kernels, generated at run time.
+
+What it replaces.  Between the fused sites of a step the reference -- and this package, wherever a model or
+guide is written in plain torch -- runs a long tail of small ATen operators: constraint transforms of
+parameters, ``probs -> logits``, a guide's normalisations, and the autograd duals of every one of them
+(pyro/infer/traceenum_elbo.py:112-214 over examples/lda.py:78-122: ~110 such operators per step, 65 of
+them on the autograd thread).  Inside a captured step each is a graph node that costs its dispatch
+(~3-5 us) whatever it computes.
+
+How.  ``Fuser`` is a ``TorchDispatchMode``: an eligible operator (element-wise arithmetic, comparisons,
+``where``, constant fills, copies / casts, small ``sum`` reductions; float32 / float64 / bool on the GPU) is
+NOT launched -- its output tensor is allocated and the operator recorded.  Recorded operators are
+materialised when something needs their memory: an operator the fuser does not know, a launch of the
+package's own kernels (``kernels._ptr``), the end of the scope.  At that point the recorded run is
+partitioned into kernels -- operators with the same output shape whose data flow is index-for-index go into
+ONE kernel, intermediates in registers; memory hazards (views, in-place writes, reductions) separate
+kernels -- and for each a HIP source is emitted, compiled for gfx950 (``pa_rtc_compile``: hiprtc, cached by
+source text) and launched on the current stream.  Arithmetic is the replaced operators' own: the same
+libm calls, no contraction of a*b+c, opmath in the output type.
+
+Scope.  Worth its host cost only where a step is recorded once and replayed: SVI's captured step and NUTS's
+captured rounds enter it (the last eager step before a capture runs under it too, so that every kernel is
+compiled before the capture starts).  ``pyro_amd.ops.fuser.ENABLED["on"] = False`` (or PYRO_AMD_FUSER=0)
+switches it off.
+"""
+import ctypes
+import math
+import os
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+ENABLED = {"on": os.environ.get("PYRO_AMD_FUSER", "1") != "0"}
+STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "flushes": 0}
+MAX_POINTERS = 64           # PA_RTC_MAX_POINTERS
+MAX_REDUCE = 1 << 14        # longest reduction taken (one wave per output element)
+MAX_DIMS = 6
+
+_ACTIVE = [None]
+aten = torch.ops.aten
+_CTYPE = {torch.float32: "float", torch.float64: "double", torch.bool: "bool"}
+
+
+def _dev(t):
+    """Does ``t`` live where the generated kernels run?  (tools/fuser_dry.py overrides this to walk the
+    recording / scheduling / code generation on a machine without a GPU.)"""
+    return t.is_cuda
+
+
+def active():
+    return _ACTIVE[0]
+
+
+def scope():
+    """A Fuser scope, or a null context when the facility is switched off."""
+    import contextlib
+    return Fuser() if ENABLED["on"] else contextlib.nullcontext()
+
+
+# ---------------------------------------------------------------------------------------------------
+# expression templates: {0}, {1}, {2} are operands already cast to the compute type T
+# ---------------------------------------------------------------------------------------------------
+_PRELUDE = r'''
+struct Ptrs { void* p[%d]; };
+#define DEV static __device__ __forceinline__
+DEV float exp_(float x) { return expf(x); }        DEV double exp_(double x) { return exp(x); }
+DEV float log_(float x) { return logf(x); }        DEV double log_(double x) { return log(x); }
+DEV float log1p_(float x) { return log1pf(x); }    DEV double log1p_(double x) { return log1p(x); }
+DEV float expm1_(float x) { return expm1f(x); }    DEV double expm1_(double x) { return expm1(x); }
+DEV float sqrt_(float x) { return sqrtf(x); }      DEV double sqrt_(double x) { return sqrt(x); }
+DEV float rsqrt_(float x) { return 1.0f / sqrtf(x); } DEV double rsqrt_(double x) { return 1.0 / sqrt(x); }
+DEV float tanh_(float x) { return tanhf(x); }      DEV double tanh_(double x) { return tanh(x); }
+DEV float abs_(float x) { return fabsf(x); }       DEV double abs_(double x) { return fabs(x); }
+DEV float lgamma_(float x) { return lgammaf(x); }  DEV double lgamma_(double x) { return lgamma(x); }
+DEV float erf_(float x) { return erff(x); }        DEV double erf_(double x) { return erf(x); }
+DEV float pow_(float x, float y) { return powf(x, y); } DEV double pow_(double x, double y) { return pow(x, y); }
+template <typename T> DEV T sigmoid_(T x) { return T(1) / (T(1) + exp_(-x)); }
+template <typename T> DEV T max_(T a, T b) { return a != a ? a : (b != b ? b : (a > b ? a : b)); }
+template <typename T> DEV T min_(T a, T b) { return a != a ? a : (b != b ? b : (a < b ? a : b)); }
+template <typename T> DEV T clamp_(T x, T lo, T hi) { return x != x ? x : (x < lo ? lo : (x > hi ? hi : x)); }
+template <typename T> DEV T clamp_lo_(T x, T lo) { return x != x ? x : (x < lo ? lo : x); }
+template <typename T> DEV T clamp_hi_(T x, T hi) { return x != x ? x : (x > hi ? hi : x); }
+template <typename T> DEV T sign_(T x) { return T((T(0) < x) - (x < T(0))); }
+template <typename T> DEV T relu_(T x) { return x != x ? x : (x > T(0) ? x : T(0)); }
+''' % MAX_POINTERS
+
+_UNARY = {
+    "neg": "(-{0})", "exp": "exp_({0})", "log": "log_({0})", "log1p": "log1p_({0})", "expm1": "expm1_({0})",
+    "sqrt": "sqrt_({0})", "rsqrt": "rsqrt_({0})", "reciprocal": "(T(1) / {0})", "sigmoid": "sigmoid_<T>({0})",
+    "tanh": "tanh_({0})", "abs": "abs_({0})", "lgamma": "lgamma_({0})", "erf": "erf_({0})",
+    "sign": "sign_<T>({0})", "relu": "relu_<T>({0})", "clone": "{0}", "_to_copy": "{0}", "alias_copy": "{0}",
+}
+_BINARY = {
+    "mul": "({0} * {1})", "div": "({0} / {1})", "maximum": "max_<T>({0}, {1})", "minimum": "min_<T>({0}, {1})",
+    "sigmoid_backward": "({0} * ((T(1) - {1}) * {1}))", "tanh_backward": "({0} * (T(1) - {1} * {1}))",
+}
+_COMPARE = {"gt": ">", "ge": ">=", "lt": "<", "le": "<=", "eq": "==", "ne": "!="}
+_LOGICAL = {"logical_and": "({0} && {1})", "logical_or": "({0} || {1})", "bitwise_and": "({0} && {1})",
+            "bitwise_or": "({0} || {1})", "logical_xor": "({0} != {1})"}
+
+
+def _lit(v, dtype):
+    """C literal of python scalar ``v`` in the compute type of ``dtype``, exact."""
+    if dtype == torch.bool:
+        return "true" if bool(v) else "false"
+    v = float(v)
+    f32 = dtype == torch.float32
+    if math.isnan(v):
+        return "__builtin_nanf(\"\")" if f32 else "__builtin_nan(\"\")"
+    if math.isinf(v):
+        s = "__builtin_inff()" if f32 else "__builtin_inf()"
+        return s if v > 0 else "(-%s)" % s
+    if f32:
+        v = float(torch.tensor(v, dtype=torch.float32))      # the value the operator itself would use
+        if math.isinf(v):
+            return "__builtin_inff()" if v > 0 else "(-__builtin_inff())"
+        return "(%sf)" % v.hex()
+    return "(%s)" % v.hex()
+
+
+def _contig_strides(shape):
+    st, acc = [], 1
+    for n in reversed(shape):
+        st.append(acc)
+        acc *= max(int(n), 1)
+    return tuple(reversed(st))
+
+
+def _span(t):
+    """(storage address, first byte, one past the last byte) a tensor may touch."""
+    base = t.untyped_storage().data_ptr()
+    lo = t.storage_offset()
+    hi = lo
+    for n, s in zip(t.shape, t.stride()):
+        if n == 0:
+            return base, 0, 0
+        if s < 0:                   # (flipped views: the whole storage)
+            return base, 0, t.untyped_storage().nbytes()
+        hi += (n - 1) * s
+    isz = t.element_size()
+    return base, lo * isz, (hi + 1) * isz
+
+
+def _overlap(a, b):
+    return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+
+
+def _view_key(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+
+
+class _Node:
+    __slots__ = ("op", "ins", "out", "shape", "dtype", "ctype", "expr", "kind", "kernel", "wspan", "rspans",
+                 "rviews", "red", "order", "fresh")
+
+
+class _Kernel:
+    __slots__ = ("kind", "shape", "nodes", "index", "npointers", "fixed")
+
+
+def _bcast(a, b):
+    """Broadcast of two shapes (right-aligned), or None."""
+    if len(a) < len(b):
+        a, b = b, a
+    out = list(a)
+    for k in range(1, len(b) + 1):
+        x, y = a[-k], b[-k]
+        if x == y or y == 1:
+            continue
+        if x == 1:
+            out[-k] = y
+        else:
+            return None
+    return tuple(out)
+
+
+class Unfusable(Exception):
+    pass
+
+
+class Fuser(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.pending = []
+        self.kernels = []
+        self.writer = {}            # view key -> pending node that last wrote exactly this view
+        self._busy = False
+        self._prev = None
+        self.log = []               # (op name, fused?) of this scope, for tests / attribution
+
+    # ---- scope ------------------------------------------------------------------------------------
+    def __enter__(self):
+        from .. import kernels
+        self._prev = (_ACTIVE[0], kernels._FUSER_HOOK[0])
+        _ACTIVE[0] = self
+        kernels._FUSER_HOOK[0] = self._before_launch
+        return super().__enter__()
+
+    def _before_launch(self):
+        if self.pending and not self._busy:
+            self.flush()
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                self.flush()
+            else:
+                for n in self.pending:
+                    n.kernel = n.ins = n.out = None
+                self.pending, self.kernels, self.writer = [], [], {}
+        finally:
+            from .. import kernels
+            _ACTIVE[0], kernels._FUSER_HOOK[0] = self._prev
+            super().__exit__(*exc)
+
+    # ---- dispatch ---------------------------------------------------------------------------------
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if self._busy:
+            return func(*args, **kwargs)
+        if _launches_nothing(func):
+            return func(*args, **kwargs)
+        if ENABLED["on"]:
+            try:
+                self._busy = True
+                out = self._record(func, args, kwargs)
+            except Unfusable:
+                out = NotImplemented
+            finally:
+                self._busy = False
+            if out is not NotImplemented:
+                STATS["recorded"] += 1
+                return out
+        self.flush()
+        return func(*args, **kwargs)
+
+    # ---- recording --------------------------------------------------------------------------------
+    def _tensor_ok(self, t):
+        return _dev(t) and t.dtype in _CTYPE and t.layout == torch.strided and t.dim() <= MAX_DIMS \
+            and not t.is_complex()
+
+    def _meta(self, func, args, kwargs):
+        def conv(x):
+            if isinstance(x, torch.Tensor):
+                if _dev(x):
+                    return torch.empty_strided(tuple(x.shape), tuple(x.stride()), dtype=x.dtype, device="meta")
+                if x.dim() == 0:
+                    return torch.empty((), dtype=x.dtype, device="meta")
+                raise Unfusable
+            if isinstance(x, (list, tuple)):
+                return type(x)(conv(v) for v in x)
+            if isinstance(x, torch.device):
+                return torch.device("meta")
+            return x
+        kw = {k: conv(v) for k, v in kwargs.items()}
+        if "device" in kw:
+            kw["device"] = torch.device("meta")
+        try:
+            return func(*conv(args), **kw)
+        except Unfusable:
+            raise
+        except Exception:       # noqa: BLE001  (no meta kernel, arguments the operator rejects, ...)
+            raise Unfusable
+
+    def _operand(self, x, cdtype):
+        """-> ("n", node) | ("t", tensor) | ("s", literal) for an input of a node computed in ``cdtype``."""
+        if isinstance(x, torch.Tensor):
+            if not _dev(x):
+                if x.dim() == 0:
+                    return ("s", _lit(x.item(), cdtype))
+                raise Unfusable
+            if not self._tensor_ok(x):
+                raise Unfusable
+            w = self.writer.get(_view_key(x))
+            if w is not None:
+                return ("n", w)
+            return ("t", x)
+        if isinstance(x, (bool, int, float)):
+            return ("s", _lit(x, cdtype))
+        raise Unfusable
+
+    def _record(self, func, args, kwargs):
+        name = func._schema.name.split("::")[1]
+        overload = func._overloadname
+        inplace = name.endswith("_") and not name.startswith("_")
+        base = name[:-1] if inplace else name
+        if kwargs.get("out") is not None:
+            raise Unfusable
+        handler = getattr(self, "_op_" + base, None)
+        if handler is None:
+            if base in _UNARY:
+                handler = self._op_unary
+            elif base in _BINARY or base in _COMPARE or base in _LOGICAL:
+                handler = self._op_binary
+            else:
+                raise Unfusable
+        return handler(func, base, overload, inplace, args, kwargs)
+
+    # -- node construction
+    def _new_node(self, op, expr, ins, meta_out, out=None, compute=None, red=None, fresh=None):
+        """``expr``: C expression over {0}.. in compute type T; ``out``: existing tensor (in-place) or None."""
+        if not isinstance(meta_out, torch.Tensor) or meta_out.dtype not in _CTYPE:
+            raise Unfusable
+        shape = tuple(meta_out.shape)
+        if len(shape) > MAX_DIMS:
+            raise Unfusable
+        n = _Node()
+        n.op, n.expr, n.ins, n.shape, n.dtype = op, expr, ins, shape, meta_out.dtype
+        n.ctype = _CTYPE[compute or meta_out.dtype]
+        n.red = red
+        n.kind = "red" if red is not None else "ew"
+        # fresh: the fuser allocates the output -- nobody has read or written it before
+        n.fresh = (out is None) if fresh is None else fresh
+        if out is None:
+            if not meta_out.is_contiguous():
+                raise Unfusable
+            dev = next(x[1].device for x in ins if x[0] == "t") if any(x[0] == "t" for x in ins) else \
+                next((x[1].out.device for x in ins if x[0] == "n"), None)
+            if dev is None:
+                raise Unfusable
+            out = torch.empty(shape, dtype=meta_out.dtype, device=dev)
+        elif tuple(out.shape) != shape or not self._tensor_ok(out):
+            raise Unfusable
+        n.out = out
+        n.wspan = _span(out)
+        # every tensor operand must expand to the node's ITERATION shape; a recorded value of another shape,
+        # a reduction's result, and the input of a reduction are read back from memory
+        it_shape = red["in_shape"] if red is not None else shape
+        norm = []
+        for x in ins:
+            if x[0] == "n" and (red is not None or x[1].kind != "ew" or _bcast(x[1].shape, it_shape) != it_shape):
+                x = ("t", x[1].out)
+            if x[0] != "s":
+                s = tuple(x[1].shape) if x[0] == "t" else x[1].shape
+                if len(s) > len(it_shape) or any(a != b and a != 1 for a, b in zip(reversed(s), reversed(it_shape))):
+                    raise Unfusable
+            norm.append(x)
+        n.ins = ins = norm
+        mem = [x[1] if x[0] == "t" else x[1].out for x in ins if x[0] != "s"]
+        n.rspans = [_span(t) for t in mem]
+        n.rviews = [_view_key(t) for t in mem]
+        self._schedule(n)
+        return out
+
+    def _schedule(self, n):
+        """Kernel of node ``n``.  Kernels run in index order; a node goes behind every recorded node it has a
+        memory hazard with -- into the SAME kernel when the hazard is index-for-index (element i of one is
+        element i of the other, so the thread that owns the element runs both in program order).  A kernel's
+        iteration domain is the broadcast of its nodes' shapes: a node of a smaller shape is evaluated by every
+        thread at its own broadcast index (its operands are loaded with stride 0 there) and stored by the threads
+        whose index in the expanded dims is 0.  An in-place target must not be expanded (other threads would
+        read the element while its owner writes it): such a node pins the domain to its own shape."""
+        jmin = 0
+        for m in self.pending:
+            conflict = _overlap(n.wspan, m.wspan) or any(_overlap(r, m.wspan) for r in n.rspans) \
+                or any(_overlap(n.wspan, r) for r in m.rspans)
+            if not conflict:
+                continue
+            same = n.kind == "ew" and m.kind == "ew" and self._index_for_index(n, m) and \
+                (n.shape == m.shape or (n.fresh and m.fresh and _bcast(n.shape, m.shape) is not None))
+            jmin = max(jmin, m.kernel.index + (0 if same else 1))
+        k = None
+        if n.kind == "ew":
+            for cand in reversed(self.kernels):
+                if cand.index < jmin:
+                    break
+                if cand.kind != "ew" or len(cand.nodes) >= 64 or \
+                        len(cand.npointers | self._pointer_keys(n)) > MAX_POINTERS:
+                    continue
+                dom = _bcast(cand.shape, n.shape)
+                if dom is None or len(dom) > MAX_DIMS:
+                    continue
+                if (cand.fixed and dom != cand.shape) or (not n.fresh and dom != n.shape):
+                    continue
+                # (a small run must not be blown up to a large domain for nothing, nor a large one re-run)
+                if dom != cand.shape and dom != n.shape:
+                    continue
+                k = cand
+                k.shape = dom
+                break
+        if k is None:
+            k = _Kernel()
+            k.kind, k.shape, k.nodes, k.index, k.npointers, k.fixed = n.kind, n.shape, [], len(self.kernels), set(), False
+            self.kernels.append(k)
+        if not n.fresh:
+            k.fixed = True
+        k.nodes.append(n)
+        k.npointers |= self._pointer_keys(n)
+        n.kernel = k
+        n.order = len(self.pending)
+        self.pending.append(n)
+        self.writer[_view_key(n.out)] = n
+        # a write that overlaps OTHER views of the same memory makes their recorded writers stale
+        for key, w in list(self.writer.items()):
+            if w is not n and _overlap(n.wspan, w.wspan) and key != _view_key(n.out):
+                del self.writer[key]
+
+    @staticmethod
+    def _pointer_keys(n):
+        """The tensors a kernel holding ``n`` needs pointers to (an upper bound: operands that are values of the
+        same kernel stay in registers)."""
+        keys = {id(n.out)}
+        for x in n.ins:
+            if x[0] == "t":
+                keys.add(id(x[1]))
+            elif x[0] == "n":
+                keys.add(id(x[1].out))
+        return keys
+
+    @staticmethod
+    def _index_for_index(n, m):
+        """Every overlap between the two nodes is through the SAME view (element i of one is element i of the
+        other), so thread i of one kernel may run both in program order."""
+        nk = _view_key(n.out)
+        mk = _view_key(m.out)
+        if _overlap(n.wspan, m.wspan) and nk != mk:
+            return False
+        for r, v in zip(n.rspans, n.rviews):
+            if _overlap(r, m.wspan) and v != mk:
+                return False
+        for r, v in zip(m.rspans, m.rviews):
+            if _overlap(n.wspan, r) and v != nk:
+                return False
+        return True
+
+    # -- operator handlers (each returns the output tensor or raises Unfusable)
+    def _op_unary(self, func, base, overload, inplace, args, kwargs):
+        if base == "_to_copy":
+            if any(k not in ("dtype", "layout", "device", "pin_memory", "non_blocking", "memory_format")
+                   for k in kwargs) or kwargs.get("device") not in (None, args[0].device) \
+                    or kwargs.get("memory_format") not in (None, torch.contiguous_format, torch.preserve_format):
+                raise Unfusable
+        elif base == "clone":
+            if kwargs.get("memory_format") not in (None, torch.contiguous_format, torch.preserve_format):
+                raise Unfusable
+        elif kwargs or len(args) != 1:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if base in ("clone", "_to_copy") and not meta.is_contiguous():
+            raise Unfusable
+        a = self._operand(args[0], meta.dtype)
+        return self._new_node(base, _UNARY[base], [a], meta, out=args[0] if inplace else None)
+
+    def _op_binary(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 2:
+            raise Unfusable                      # (div's rounding_mode, ...)
+        meta = self._meta(func, args, kwargs)
+        if base in _COMPARE or base in _LOGICAL:
+            ts = [x for x in args if isinstance(x, torch.Tensor)]
+            if not ts:
+                raise Unfusable
+            as_meta = [torch.empty(tuple(x.shape), dtype=x.dtype, device="meta")
+                       if isinstance(x, torch.Tensor) and _dev(x) else x for x in args]
+            cd = torch.result_type(*as_meta)
+            if base in _LOGICAL:
+                if any(t.dtype != torch.bool for t in ts) or len(ts) != 2:
+                    raise Unfusable
+                cd = torch.bool
+            if cd not in _CTYPE:
+                raise Unfusable
+            expr = "({0} %s {1})" % _COMPARE[base] if base in _COMPARE else _LOGICAL[base]
+            ins = [self._operand(args[0], cd), self._operand(args[1], cd)]
+            return self._new_node(base, expr, ins, meta, out=args[0] if inplace else None, compute=cd)
+        if meta.dtype == torch.bool:
+            raise Unfusable
+        ins = [self._operand(args[0], meta.dtype), self._operand(args[1], meta.dtype)]
+        return self._new_node(base, _BINARY[base], ins, meta, out=args[0] if inplace else None)
+
+    def _addsub(self, func, base, overload, inplace, args, kwargs, sign):
+        alpha = kwargs.get("alpha", args[2] if len(args) > 2 else 1)
+        if any(k != "alpha" for k in kwargs) or not isinstance(alpha, (int, float)) or isinstance(alpha, bool):
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if meta.dtype == torch.bool:
+            raise Unfusable
+        ins = [self._operand(args[0], meta.dtype), self._operand(args[1], meta.dtype)]
+        if alpha == 1:
+            expr = "({0} %s {1})" % sign
+        else:
+            expr = "({0} %s %s * {1})" % (sign, _lit(alpha, meta.dtype))
+        return self._new_node(base, expr, ins, meta, out=args[0] if inplace else None)
+
+    def _op_add(self, *a):
+        return self._addsub(*a, sign="+")
+
+    def _op_sub(self, *a):
+        return self._addsub(*a, sign="-")
+
+    def _op_rsub(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 2:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        ins = [self._operand(args[0], meta.dtype), self._operand(args[1], meta.dtype)]
+        return self._new_node(base, "({1} - {0})", ins, meta)
+
+    def _op_pow(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or overload != "Tensor_Scalar" or not isinstance(args[1], (int, float)):
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if meta.dtype == torch.bool:
+            raise Unfusable
+        e = float(args[1])
+        expr = {2.0: "({0} * {0})", 3.0: "({0} * {0} * {0})", 0.5: "sqrt_({0})", -0.5: "rsqrt_({0})",
+                -1.0: "(T(1) / {0})", -2.0: "(T(1) / ({0} * {0}))", 1.0: "{0}"}.get(e)
+        if expr is None:
+            expr = "pow_({0}, %s)" % _lit(e, meta.dtype)
+        return self._new_node(base, expr, [self._operand(args[0], meta.dtype)], meta,
+                              out=args[0] if inplace else None)
+
+    def _op_clamp(self, func, base, overload, inplace, args, kwargs):
+        lo = kwargs.get("min", args[1] if len(args) > 1 else None)
+        hi = kwargs.get("max", args[2] if len(args) > 2 else None)
+        if overload not in ("default", "") or any(isinstance(v, torch.Tensor) for v in (lo, hi)):
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if meta.dtype == torch.bool:
+            raise Unfusable
+        if lo is not None and hi is not None:
+            expr = "clamp_<T>({0}, %s, %s)" % (_lit(lo, meta.dtype), _lit(hi, meta.dtype))
+        elif lo is not None:
+            expr = "clamp_lo_<T>({0}, %s)" % _lit(lo, meta.dtype)
+        elif hi is not None:
+            expr = "clamp_hi_<T>({0}, %s)" % _lit(hi, meta.dtype)
+        else:
+            raise Unfusable
+        return self._new_node(base, expr, [self._operand(args[0], meta.dtype)], meta,
+                              out=args[0] if inplace else None)
+
+    def _op_clamp_min(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 2 or isinstance(args[1], torch.Tensor):
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        return self._new_node(base, "clamp_lo_<T>({0}, %s)" % _lit(args[1], meta.dtype),
+                              [self._operand(args[0], meta.dtype)], meta, out=args[0] if inplace else None)
+
+    def _op_clamp_max(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 2 or isinstance(args[1], torch.Tensor):
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        return self._new_node(base, "clamp_hi_<T>({0}, %s)" % _lit(args[1], meta.dtype),
+                              [self._operand(args[0], meta.dtype)], meta, out=args[0] if inplace else None)
+
+    def _op_where(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 3 or not isinstance(args[0], torch.Tensor) or args[0].dtype != torch.bool:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        ins = [self._operand(args[0], torch.bool), self._operand(args[1], meta.dtype),
+               self._operand(args[2], meta.dtype)]
+        return self._new_node(base, "({0} ? {1} : {2})", ins, meta)
+
+    def _op_logical_not(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 1 or args[0].dtype != torch.bool:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        return self._new_node(base, "(!{0})", [self._operand(args[0], torch.bool)], meta,
+                              out=args[0] if inplace else None)
+
+    def _op_isnan(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 1 or args[0].dtype == torch.bool:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        return self._new_node(base, "({0} != {0})", [self._operand(args[0], args[0].dtype)], meta,
+                              compute=args[0].dtype)
+
+    def _op_copy(self, func, base, overload, inplace, args, kwargs):
+        dst, src = args[0], args[1]
+        if not inplace or not isinstance(src, torch.Tensor) or not _dev(src) or not _dev(dst) \
+                or src.device != dst.device:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        return self._new_node(base, "{0}", [self._operand(src, meta.dtype)], meta, out=dst)
+
+    def _fill(self, value, meta, out=None, device=None):
+        if isinstance(value, torch.Tensor):
+            if value.dim() != 0:
+                raise Unfusable
+            ins = [self._operand(value, meta.dtype)]
+            if ins[0][0] == "s":
+                return self._const(ins[0][1], meta, out, device)
+            return self._new_node("fill", "{0}", ins, meta, out=out)
+        if not isinstance(value, (bool, int, float)):
+            raise Unfusable
+        return self._const(_lit(value, meta.dtype), meta, out, device)
+
+    def _const(self, literal, meta, out, device):
+        if meta.dtype not in _CTYPE or len(meta.shape) > MAX_DIMS:
+            raise Unfusable
+        fresh = out is None
+        if out is None:
+            if device is None or torch.device(device).type != "cuda" or not meta.is_contiguous():
+                raise Unfusable
+            out = torch.empty(tuple(meta.shape), dtype=meta.dtype, device=device)
+        return self._new_node("const", literal, [], meta, out=out, fresh=fresh)
+
+    def _op_fill(self, func, base, overload, inplace, args, kwargs):
+        if not inplace or kwargs or len(args) != 2:
+            raise Unfusable
+        return self._fill(args[1], self._meta(aten.alias.default, (args[0],), {}), out=args[0])
+
+    def _op_zero(self, func, base, overload, inplace, args, kwargs):
+        if not inplace:
+            raise Unfusable
+        return self._fill(0, self._meta(aten.alias.default, (args[0],), {}), out=args[0])
+
+    def _factory(self, func, args, kwargs, value):
+        dev = kwargs.get("device")
+        if dev is None or torch.device(dev).type != "cuda" or kwargs.get("layout") not in (None, torch.strided) \
+                or kwargs.get("pin_memory") or kwargs.get("memory_format") not in (None, torch.contiguous_format):
+            raise Unfusable
+        dev = torch.device(dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return self._fill(value, self._meta(func, args, kwargs), device=dev)
+
+    def _op_zeros(self, func, base, overload, inplace, args, kwargs):
+        return self._factory(func, args, kwargs, 0)
+
+    def _op_ones(self, func, base, overload, inplace, args, kwargs):
+        return self._factory(func, args, kwargs, 1)
+
+    def _op_full(self, func, base, overload, inplace, args, kwargs):
+        return self._factory(func, args, kwargs, args[1])
+
+    def _like(self, func, args, kwargs, value):
+        x = args[0]
+        if not _dev(x) or kwargs.get("device") not in (None, x.device) or \
+                kwargs.get("layout") not in (None, torch.strided) or kwargs.get("pin_memory") or \
+                kwargs.get("memory_format") not in (None, torch.contiguous_format, torch.preserve_format):
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if not meta.is_contiguous():
+            raise Unfusable
+        return self._fill(value, meta, device=x.device)
+
+    def _op_zeros_like(self, func, base, overload, inplace, args, kwargs):
+        return self._like(func, args, kwargs, 0)
+
+    def _op_ones_like(self, func, base, overload, inplace, args, kwargs):
+        return self._like(func, args, kwargs, 1)
+
+    def _op_full_like(self, func, base, overload, inplace, args, kwargs):
+        return self._like(func, args, kwargs, args[1])
+
+    def _op_new_zeros(self, func, base, overload, inplace, args, kwargs):
+        kw = dict(kwargs)
+        kw.setdefault("device", args[0].device)
+        return self._factory(func, args, kw, 0)
+
+    def _op_new_ones(self, func, base, overload, inplace, args, kwargs):
+        kw = dict(kwargs)
+        kw.setdefault("device", args[0].device)
+        return self._factory(func, args, kw, 1)
+
+    def _op_new_full(self, func, base, overload, inplace, args, kwargs):
+        kw = dict(kwargs)
+        kw.setdefault("device", args[0].device)
+        return self._factory(func, args, kw, args[2])
+
+    def _op_sum(self, func, base, overload, inplace, args, kwargs):
+        x = args[0]
+        if not isinstance(x, torch.Tensor) or not self._tensor_ok(x) or x.dtype == torch.bool:
+            raise Unfusable
+        dtype = kwargs.get("dtype", None)
+        if overload == "default":
+            dims, keep = tuple(range(x.dim())), False
+            if len(args) > 1:
+                dtype = args[1]
+        elif overload == "dim_IntList":
+            dims = args[1] if len(args) > 1 else kwargs.get("dim")
+            keep = args[2] if len(args) > 2 else kwargs.get("keepdim", False)
+            if len(args) > 3:
+                dtype = args[3]
+            dims = tuple(range(x.dim())) if dims is None or len(dims) == 0 else \
+                tuple(sorted(d % x.dim() for d in dims)) if x.dim() else ()
+        else:
+            raise Unfusable
+        if dtype not in (None, x.dtype) or x.dim() == 0 or x.numel() == 0:
+            raise Unfusable
+        rsize = 1
+        for d in dims:
+            rsize *= x.shape[d]
+        if rsize > MAX_REDUCE or rsize < 1:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        red = {"in_shape": tuple(x.shape), "dims": dims, "keep": bool(keep), "rsize": rsize}
+        return self._new_node("sum", "{0}", [self._operand(x, x.dtype)], meta, red=red)
+
+    # ---- materialisation ----------------------------------------------------------------------------
+    def flush(self):
+        if not self.pending:
+            return
+        kernels = self.kernels
+        self.pending, self.kernels, self.writer = [], [], {}
+        STATS["flushes"] += 1
+        prev, self._busy = self._busy, True
+        try:
+            for k in kernels:
+                if k.kind == "ew":
+                    _launch_elementwise(k)
+                else:
+                    _launch_reduce(k.nodes[0])
+        finally:
+            self._busy = prev
+            # nodes and kernels point at each other: take the cycle apart NOW -- the tensors they hold carry
+            # autograd graphs (a step's graph kept alive until the cyclic collector runs keeps its
+            # AccumulateGrad nodes, created on this stream, alive into a later capture on another stream)
+            for k in kernels:
+                for n in k.nodes:
+                    n.kernel = n.ins = n.out = None
+                k.nodes = None
+
+
+# ---------------------------------------------------------------------------------------------------
+# code generation
+# ---------------------------------------------------------------------------------------------------
+_CACHE = {}
+
+
+def _compiled(src):
+    fn = _CACHE.get(src)
+    if fn is None:
+        from .. import _lib
+        out = ctypes.c_void_p()
+        _lib.check(_lib.load().pa_rtc_compile(src.encode(), b"k", ctypes.byref(out)))
+        fn = _CACHE[src] = out
+        STATS["compiled"] += 1
+    return fn
+
+
+def _launch(src, grid, block, tensors):
+    from .. import _lib
+    fn = _compiled(src)
+    table = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().pa_rtc_launch(fn, grid, block, table, len(tensors), stream))
+    STATS["kernels"] += 1
+
+
+def _offset_expr(t_shape, t_strides, it_shape, used):
+    """Element offset of an operand of shape ``t_shape`` / ``t_strides`` at iteration index (i0 .. ik) of
+    ``it_shape`` (operand broadcast from the right); '' + marks which index variables are needed."""
+    nd = len(it_shape)
+    pad = nd - len(t_shape)
+    strides = [0] * pad + [0 if n == 1 else s for n, s in zip(t_shape, t_strides)]
+    strides = [0 if it_shape[d] == 1 else strides[d] for d in range(nd)]
+    if all(s == 0 for s in strides):
+        return "0"
+    if tuple(strides) == tuple(0 if it_shape[d] == 1 else s for d, s in enumerate(_contig_strides(it_shape))):
+        return "i"
+    terms = []
+    for d, s in enumerate(strides):
+        if s != 0:
+            used.add(d)
+            terms.append("i%d * %dL" % (d, s) if s != 1 else "i%d" % d)
+    return " + ".join(terms)
+
+
+def _index_decl(it_shape, used, var="i"):
+    """Declarations of the index variables in ``used`` from the linear index ``var``."""
+    if not used:
+        return ""
+    lines, rem = [], "r_"
+    lines.append("  long r_ = %s;" % var)
+    for d in range(len(it_shape) - 1, -1, -1):
+        n = it_shape[d]
+        if d in used:
+            lines.append("  const long i%d = %s %% %dL;" % (d, rem, n) if d > 0 else "  const long i0 = %s;" % rem)
+        if d > 0:
+            lines.append("  r_ /= %dL;" % n)
+    return "\n".join(lines) + "\n"
+
+
+def _gen_body(nodes, it_shape, ptrs, used, store_index="i"):
+    """Loads, node expressions and stores of an element-wise run; returns (loads+compute lines, store lines)."""
+    lines, stores = [], []
+    leaf_var = {}
+    val = {}
+
+    def pointer(t):
+        for j, p in enumerate(ptrs):
+            if p is t:
+                return j
+        ptrs.append(t)
+        return len(ptrs) - 1
+
+    def leaf(t):
+        key = _view_key(t)
+        v = leaf_var.get(key)
+        if v is None:
+            j = pointer(t)
+            v = leaf_var[key] = "l%d" % len(leaf_var)
+            off = _offset_expr(tuple(t.shape), tuple(t.stride()), it_shape, used)
+            lines.append("  const %s %s = ((const %s*)a.p[%d])[%s];" % (_CTYPE[t.dtype], v, _CTYPE[t.dtype], j, off))
+        return v
+
+    for q, n in enumerate(nodes):
+        T = n.ctype
+        ops = []
+        for x in n.ins:
+            if x[0] == "s":
+                ops.append(x[1])
+            elif x[0] == "n" and id(x[1]) in val:
+                ops.append("((%s)%s)" % (T, val[id(x[1])]))
+            else:
+                t = x[1].out if x[0] == "n" else x[1]
+                ops.append("((%s)%s)" % (T, leaf(t)))
+        expr = n.expr.format(*ops).replace("T(", "%s(" % T).replace("<T>", "<%s>" % T)
+        out_t = _CTYPE[n.dtype]
+        v = "v%d" % q
+        lines.append("  const %s %s = (%s)(%s);" % (out_t, v, out_t, expr))
+        val[id(n)] = v
+        # an in-place target read later through the same view must see this value, not the stale load
+        leaf_var[_view_key(n.out)] = v
+        j = pointer(n.out)
+        off = _offset_expr(tuple(n.out.shape), tuple(n.out.stride()), it_shape, used) \
+            if store_index == "i" else store_index
+        # a node smaller than the domain is stored once: by the threads at index 0 of the expanded dims
+        pad = len(it_shape) - len(n.shape)
+        expanded = [d for d in range(len(it_shape)) if it_shape[d] > 1 and (d < pad or n.shape[d - pad] == 1)]
+        used.update(expanded)
+        guard = "if (%s) " % " && ".join("i%d == 0" % d for d in expanded) if expanded else ""
+        stores.append("  %s((%s*)a.p[%d])[%s] = %s;" % (guard, out_t, j, off, v))
+    return lines, stores
+
+
+def _launch_elementwise(k):
+    shape = k.shape
+    numel = 1
+    for n in shape:
+        numel *= n
+    if numel == 0:
+        return
+    # later stores to the same view supersede earlier ones
+    last = {}
+    for n in k.nodes:
+        last[_view_key(n.out)] = n
+    ptrs, used = [], set()
+    lines, stores = _gen_body(k.nodes, shape, ptrs, used)
+    keep = {id(n) for n in last.values()}
+    stores = [s for n, s in zip(k.nodes, stores) if id(n) in keep]
+    src = _PRELUDE + "extern \"C\" __global__ __launch_bounds__(256) void k(Ptrs a) {\n" \
+        "  const long i = (long)blockIdx.x * 256L + threadIdx.x;\n  if (i >= %dL) return;\n" % numel + \
+        _index_decl(shape, used) + "\n".join(lines) + "\n" + "\n".join(stores) + "\n}\n"
+    _launch(src, (numel + 255) // 256, 256, ptrs)
+
+
+def _launch_reduce(n):
+    red = n.red
+    in_shape, dims, rsize = red["in_shape"], red["dims"], red["rsize"]
+    kept = [d for d in range(len(in_shape)) if d not in dims]
+    n_out = 1
+    for d in kept:
+        n_out *= in_shape[d]
+    x = n.ins[0]
+    t = x[1].out if x[0] == "n" else x[1]
+    T = n.ctype
+    acc = "double" if n.dtype == torch.float64 else "float"
+    st = t.stride()
+    # offset of (output index o, reduce index r): decompose both
+    def decomp(var, ds, prefix):
+        lines, rem = ["  long %s_ = %s;" % (prefix, var)], "%s_" % prefix
+        for q in range(len(ds) - 1, -1, -1):
+            d = ds[q]
+            if q > 0:
+                lines.append("  const long %s%d = %s %% %dL; %s /= %dL;" % (prefix, d, rem, in_shape[d], rem, in_shape[d]))
+            else:
+                lines.append("  const long %s%d = %s;" % (prefix, d, rem))
+        return lines
+    o_lines = decomp("o", kept, "o") if kept else []
+    o_off = " + ".join("o%d * %dL" % (d, st[d]) for d in kept if in_shape[d] > 1 and st[d] != 0) or "0"
+    r_off = " + ".join("q%d * %dL" % (d, st[d]) for d in dims if in_shape[d] > 1 and st[d] != 0) or "0"
+    r_lines = decomp("r", list(dims), "q")
+    ptrs = [t, n.out]
+    if rsize <= 32:        # one thread per output element
+        body = "  const long o = (long)blockIdx.x * 256L + threadIdx.x;\n  if (o >= %dL) return;\n" % n_out + \
+            "\n".join(o_lines) + "\n  const long base = %s;\n  %s s = 0;\n  for (long r = 0; r < %dL; ++r) {\n" % (o_off, acc, rsize) + \
+            "\n".join("  " + ln for ln in r_lines) + \
+            "\n    s += (%s)((const %s*)a.p[0])[base + %s];\n  }\n  ((%s*)a.p[1])[o] = (%s)s;\n" % (acc, T, r_off, T, T)
+        grid = (n_out + 255) // 256
+    else:                  # one wave per output element, lanes stride over the reduced range
+        body = "  const long o = (long)blockIdx.x * 4L + (threadIdx.x >> 6);\n  const int lane = threadIdx.x & 63;\n" \
+            "  if (o >= %dL) return;\n" % n_out + "\n".join(o_lines) + \
+            "\n  const long base = %s;\n  %s s = 0;\n  for (long r = lane; r < %dL; r += 64) {\n" % (o_off, acc, rsize) + \
+            "\n".join("  " + ln for ln in r_lines) + \
+            "\n    s += (%s)((const %s*)a.p[0])[base + %s];\n  }\n" % (acc, T, r_off) + \
+            "  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n" \
+            "  if (lane == 0) ((%s*)a.p[1])[o] = (%s)s;\n" % (T, T)
+        grid = (n_out + 3) // 4
+    src = _PRELUDE + "extern \"C\" __global__ __launch_bounds__(256) void k(Ptrs a) {\n" + body + "}\n"
+    _launch(src, grid, 256, ptrs)
+
+
+# ---------------------------------------------------------------------------------------------------
+_FREE = None
+
+
+def _launches_nothing(func):
+    global _FREE
+    if _FREE is None:
+        names = ("empty.memory_format", "empty_like.default", "empty_strided.default", "new_empty.default",
+                 "new_empty_strided.default", "detach.default", "alias.default", "lift_fresh.default",
+                 "_unsafe_view.default", "_reshape_alias.default", "sym_size.int", "sym_stride.int",
+                 "sym_numel.default", "is_same_size.default", "_has_compatible_shallow_copy_type.default",
+                 "result_type.Tensor", "result_type.Scalar", "is_nonzero.default_")
+        ops = set()
+        for nm in names:
+            pkt, ov = nm.split(".")
+            try:
+                ops.add(getattr(getattr(aten, pkt), ov))
+            except AttributeError:
+                pass
+        _FREE = ops
+    if func in _FREE:
+        return True
+    try:
+        return bool(func.is_view)
+    except AttributeError:
+        return False

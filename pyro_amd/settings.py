@@ -86,3 +86,13 @@ for _alias, _module, _name in (
         ("module_local_params", "pyro_amd.nn.module", "_MODULE_LOCAL_PARAMS")):
     register(_alias, _module, _name, _must_be_bool)
 del _alias, _module, _name
+
+
+def _auto_or_bool(value):
+    assert value in ("auto", True, False), value
+
+
+# what runs when nobody says: SVI(model, guide, optim, loss) captures its step / NUTS replays its rounds
+# from a hipGraph when the arguments live on the GPU ("auto"), always (True), or only when asked (False)
+register("svi_capture_steps", "pyro_amd.infer.svi", "CAPTURE_STEPS", _auto_or_bool)
+register("mcmc_capture_rounds", "pyro_amd.infer.mcmc.nuts", "CAPTURE_ROUNDS", _auto_or_bool)

@@ -205,7 +205,8 @@ def test_svi_converges_to_reference_posterior(gpu):
     pyro.clear_param_store()
     guide = pyro.infer.autoguide.AutoNormal(models.logreg_model_fused, init_scale=0.1)
     svi = pyro.infer.SVI(models.logreg_model_fused, guide, pyro.optim.Adam({"lr": 0.05}),
-                         pyro.infer.Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1))
+                         pyro.infer.Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
+                         hip_graph=False)        # (injected draws: host code of every step)
     guide._setup_prototype(Xt, yt)
     flat = [e for pair in bank for e in pair]
     orig = rng.normal
@@ -232,7 +233,7 @@ def test_hip_graph_step_equals_eager_step(gpu):
 
     X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=3)
     runs = []
-    for use_graph in (False, True, "split"):
+    for use_graph in (False, True, "split", "auto"):
         pyro.clear_param_store()
         pyro.set_rng_seed(7)
         pyro.enable_validation(False)
@@ -243,9 +244,13 @@ def test_hip_graph_step_equals_eager_step(gpu):
                 # the multi-GPU shape of the step on one GPU: [loss+backward] graph, eager
                 # (here: no-op) gradient all-reduce, [optimizer] graph
                 optim = pyro.optim.RcclOptimizer(optim)
-            svi = SVI(examples.logreg_model, guide, optim,
-                      Trace_ELBO(num_particles=16, vectorize_particles=True, max_plate_nesting=1),
-                      hip_graph=bool(use_graph), graph_warmup=3)
+            elbo = Trace_ELBO(num_particles=16, vectorize_particles=True, max_plate_nesting=1)
+            if use_graph == "auto":
+                # the reference's constructor and nothing else: device arguments => captured by itself
+                svi = SVI(examples.logreg_model, guide, optim, elbo)
+                assert svi._auto_graph
+            else:
+                svi = SVI(examples.logreg_model, guide, optim, elbo, hip_graph=bool(use_graph), graph_warmup=3)
             svi._force_split = use_graph == "split"
             losses = [svi.step(X, y) for _ in range(12)]
             if use_graph:
@@ -261,6 +266,65 @@ def test_hip_graph_step_equals_eager_step(gpu):
         for k in runs[0][1]:
             assert torch.equal(runs[0][1][k], other[1][k]), k
     assert runs[0][0][-1] < runs[0][0][0]
+
+
+def test_default_svi_captures_only_what_can_be_a_graph(gpu):
+    """SVI(model, guide, optim, loss) decides by itself: device tensors as arguments => captured step;
+    host tensors, no arguments at all (a model that closes over its data), a wrapped torch optimizer, a
+    capture that fails (the model synchronises with the host) => eager steps, silently; the
+    svi_capture_steps setting switches the decision off."""
+    import warnings
+
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(4096, 8, gpu, seed=1)
+    elbo = lambda: Trace_ELBO(num_particles=4, vectorize_particles=True, max_plate_nesting=1)  # noqa: E731
+
+    def build(model, optim=None, **kw):
+        pyro.clear_param_store()
+        pyro.set_rng_seed(1)
+        return SVI(model, AutoNormal(model, init_scale=0.1), optim or pyro.optim.Adam({"lr": 0.01}), elbo(), **kw)
+
+    pyro.enable_validation(False)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            svi = build(examples.logreg_model)
+            for _ in range(6):
+                svi.step(X, y)
+            assert svi.hip_graph and len(svi._graphs) == 1
+            closed = lambda: examples.logreg_model(X, y)  # noqa: E731
+            svi = build(closed)
+            for _ in range(6):
+                svi.step()
+            assert not svi._graphs
+
+            def syncing(X, y):
+                w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), 1.0).to_event(1))
+                float(w.sum())                      # a host read: not capturable
+                with pyro.plate("data", X.shape[0]):
+                    pyro.sample("obs", dist.Bernoulli(logits=X @ w), obs=y)
+            svi = build(syncing)
+            losses = [svi.step(X, y) for _ in range(6)]
+            assert not svi.hip_graph and not svi._graphs and all(np.isfinite(losses))
+            svi = build(examples.logreg_model, optim=pyro.optim.PyroOptim(torch.optim.Adam, {"lr": 0.01}))
+            for _ in range(5):
+                svi.step(X, y)
+            assert not svi.hip_graph
+            with pyro.settings.context(svi_capture_steps=False):
+                svi = build(examples.logreg_model)
+            for _ in range(5):
+                svi.step(X, y)
+            assert not svi.hip_graph and not svi._graphs
+            svi = build(examples.logreg_model, hip_graph=False)
+            assert not svi.hip_graph and not svi._auto_graph
+    finally:
+        pyro.enable_validation(True)
+        pyro.clear_param_store()
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -431,7 +495,8 @@ def test_north_star_acceptance_at_the_north_star_config(gpu):
         guide = pyro.infer.autoguide.AutoNormal(examples.logreg_model, init_scale=0.1)
         svi = pyro.infer.SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": lr}),
                              pyro.infer.Trace_ELBO(num_particles=P, vectorize_particles=True,
-                                                   max_plate_nesting=1))
+                                                   max_plate_nesting=1),
+                             hip_graph=False)    # (injected draws: host code of every step)
         guide._setup_prototype(Xt, yt)
         flat = [e for pair in bank for e in pair]
         orig = rng.normal

@@ -164,7 +164,7 @@ def config1(dev, steps=300, graph=True):
     pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
     svi = SVI(model, guide, pyro.optim.Adam({"lr": 0.01}), Trace_ELBO(), hip_graph=graph, graph_warmup=2)
     dt = timed(lambda: svi.step(y, sigma), steps, 10)
-    return {"steps_per_s": 1 / dt, "us_per_step": dt * 1e6,
+    return {"steps_per_s": 1 / dt, "us_per_step": dt * 1e6, "last_loss": svi.step(y, sigma),
             "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1)}
 
 
@@ -221,7 +221,7 @@ def config4(dev, docs=100_000, steps=10, batch_size=None):
     dt = timed(lambda: svi.step(data, args), steps, 6)
     pairs = (docs if batch_size is None else batch_size) * args.num_words_per_doc
     out = {"batch_size": batch_size, "steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "word_doc_pairs_per_s": pairs / dt,
-           "graphed": bool(svi.hip_graph and len(svi._graphs) == 1),
+           "graphed": bool(svi.hip_graph and len(svi._graphs) == 1), "last_loss": svi.step(data, args),
            "algorithmic_TBps": pairs * 8.5 / dt / 1e12}
     import os
     if batch_size is None and not os.environ.get("PA_NO_ROOFLINE"):
