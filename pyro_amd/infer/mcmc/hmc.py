@@ -272,7 +272,7 @@ class HMC(MCMCKernel):
         self._accept_cnt = torch.zeros((C,), dtype=torch.int64, device=z.device)
         self._mean_accept_prob = torch.zeros((C,), dtype=z.dtype, device=z.device)
         self._n_leapfrog_total = torch.zeros((), dtype=torch.int64, device=z.device)
-        self._seed = rng._STATE["seed"]
+        self._seed = rng.current_seed()
         self._prepare_paths()
         if self._adapter.adapt_step_size:
             self._adapter.reset_step_size_adaptation(z)
@@ -321,7 +321,7 @@ class HMC(MCMCKernel):
             key = (1 << 42) + 256 * self._find_step_calls       # disjoint from transition indices
             return kernels.nuts_gaussian_find_step(
                 z, pe.detach(), grad.detach(), self._Lambda, self.mass_matrix_adapter.inverse_mass_matrix, step,
-                self._seed if getattr(self, "_seed", None) is not None else rng._STATE["seed"],
+                self._seed if getattr(self, "_seed", None) is not None else rng.current_seed(),
                 key, self.chain_offset, self._min_stepsize, self._max_stepsize,
                 self._direction_threshold)
         if self._dense:

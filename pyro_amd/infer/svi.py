@@ -255,6 +255,13 @@ class SVI:
                 return self._gated_step(entry, args, kwargs, checked=True)
         key = (_arg_key(args), _arg_key(tuple(sorted(kwargs.items()))))
         entry = self._graphs.get(key)
+        if entry is not None and entry.cap.stale():
+            # torch.manual_seed since the capture: the recorded draws hold the old seed as a launch constant
+            if entry.armed:
+                entry.cancel()
+            self._armed_fast = None
+            del self._graphs[key]
+            entry = None
         if entry is None:
             n = self._eager_seen.get(key, 0)
             if n < self.graph_warmup:
@@ -353,6 +360,8 @@ class SVI:
 
     @staticmethod
     def _host_state_unchanged(state, offset):
+        from .. import rng
+        rng._follow_torch()                # (a re-seeded default generator restarts the stream: offset 0)
         refs, nparams, rng_state = state
         if rng_state["offset"] != offset or len(_PARAM_STORE._params) != nparams:
             return False

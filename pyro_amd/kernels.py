@@ -50,7 +50,7 @@ def _ptr(t):
     if t is None:
         return None
     if _FUSER_HOOK[0] is not None:
-        _FUSER_HOOK[0]()
+        _FUSER_HOOK[0](t)
     if _CHAIN["keep"] is not None:
         _CHAIN["keep"].append(t)       # a recorded launch reads / writes it at the flush
     return ctypes.c_void_p(t.data_ptr())
@@ -61,6 +61,8 @@ def _view(t, rows, cols):
     2-D strided view without materialising broadcasts."""
     if t is None:
         return NULL_VIEW
+    if _FUSER_HOOK[0] is not None:
+        _FUSER_HOOK[0](t)
     if _CHAIN["keep"] is not None:
         _CHAIN["keep"].append(t)
     assert t.dim() == 2

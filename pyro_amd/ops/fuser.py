@@ -26,12 +26,14 @@ switches it off.
 import ctypes
 import math
 import os
+import sys
 
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
 ENABLED = {"on": os.environ.get("PYRO_AMD_FUSER", "1") != "0"}
-STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "flushes": 0}
+STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "flushes": 0, "dead": 0}
+UNFUSED = {}                # operator name -> how often it was met and run as it is (attribution)
 MAX_POINTERS = 64           # PA_RTC_MAX_POINTERS
 MAX_REDUCE = 1 << 14        # longest reduction taken (one wave per output element)
 MAX_DIMS = 6
@@ -151,7 +153,26 @@ def _view_key(t):
 
 class _Node:
     __slots__ = ("op", "ins", "out", "shape", "dtype", "ctype", "expr", "kind", "kernel", "wspan", "rspans",
-                 "rviews", "red", "order", "fresh")
+                 "rviews", "red", "order", "fresh", "live")
+
+
+DEAD_STORES = {"eliminate": os.environ.get("PYRO_AMD_FUSER_DEAD_STORES", "1") != "0"}
+_BASELINE = []
+
+
+def _counts(n):
+    """(python references to the output tensor, owners of its TensorImpl, owners of its storage)."""
+    return (sys.getrefcount(n.out), n.out._use_count(),
+            torch._C._storage_Use_Count(n.out.untyped_storage()._cdata))
+
+
+def _baseline_counts():
+    """What _counts gives for an output nobody but its node refers to (measured, not assumed)."""
+    if not _BASELINE:
+        n = _Node()
+        n.out = torch.empty(4)
+        _BASELINE.append(_counts(n))
+    return _BASELINE[0]
 
 
 class _Kernel:
@@ -196,9 +217,10 @@ class Fuser(TorchDispatchMode):
         kernels._FUSER_HOOK[0] = self._before_launch
         return super().__enter__()
 
-    def _before_launch(self):
+    def _before_launch(self, t):
+        """kernels._ptr / _view: a launch of the package's own is about to read or write tensor ``t``."""
         if self.pending and not self._busy:
-            self.flush()
+            self.flush_for([t])
 
     def __exit__(self, *exc):
         try:
@@ -231,7 +253,11 @@ class Fuser(TorchDispatchMode):
             if out is not NotImplemented:
                 STATS["recorded"] += 1
                 return out
-        self.flush()
+            name = func._schema.name
+            UNFUSED[name] = UNFUSED.get(name, 0) + 1
+        # an operator run as it is: whatever recorded work shares memory with its arguments goes first (its
+        # result is a fresh tensor; recorded operators that touch none of its arguments are independent of it)
+        self.flush_for(_tensors_of(args) + _tensors_of(tuple(kwargs.values())))
         return func(*args, **kwargs)
 
     # ---- recording --------------------------------------------------------------------------------
@@ -308,6 +334,7 @@ class Fuser(TorchDispatchMode):
         n.op, n.expr, n.ins, n.shape, n.dtype = op, expr, ins, shape, meta_out.dtype
         n.ctype = _CTYPE[compute or meta_out.dtype]
         n.red = red
+        n.live = True
         n.kind = "red" if red is not None else "ew"
         # fresh: the fuser allocates the output -- nobody has read or written it before
         n.fresh = (out is None) if fresh is None else fresh
@@ -686,12 +713,66 @@ class Fuser(TorchDispatchMode):
         return self._new_node("sum", "{0}", [self._operand(x, x.dtype)], meta, red=red)
 
     # ---- materialisation ----------------------------------------------------------------------------
+    def flush_for(self, tensors):
+        """Materialise the recorded kernels that share memory with any of ``tensors`` -- and, kernels being
+        ordered, every kernel in front of the last such one.  The rest stays recorded."""
+        if not self.pending:
+            return
+        spans = [_span(t) for t in tensors if _dev(t)]
+        hit = -1
+        for n in self.pending:
+            if n.kernel.index > hit and any(_overlap(sp, n.wspan) or any(_overlap(sp, r) for r in n.rspans)
+                                            for sp in spans):
+                hit = n.kernel.index
+        if hit < 0:
+            return
+        if hit == len(self.kernels) - 1:
+            return self.flush()
+        head, tail = self.kernels[:hit + 1], self.kernels[hit + 1:]
+        done = {id(n) for k in head for n in k.nodes}
+        for k in tail:
+            k.index -= hit + 1
+            for n in k.nodes:      # a value of a materialised kernel is read back from memory from now on
+                n.ins = [("t", x[1].out) if x[0] == "n" and id(x[1]) in done else x for x in n.ins]
+        self.pending = [n for n in self.pending if id(n) not in done]
+        self.kernels = tail
+        self.writer = {key: w for key, w in self.writer.items() if id(w) not in done}
+        self._run(head)
+
     def flush(self):
         if not self.pending:
             return
         kernels = self.kernels
         self.pending, self.kernels, self.writer = [], [], {}
+        self._run(kernels)
+
+    def _mark_live(self, kernels):
+        """Which outputs must reach memory: anything the fuser did not allocate itself, anything somebody
+        outside still refers to (a python variable, a tensor saved for backward, a view of its storage), and
+        anything a recorded operator OUTSIDE the value's own kernel reads.  The rest lives and dies in
+        registers."""
+        base = _baseline_counts()
+        needed = set()
+        for n in self.pending:                          # (what stays recorded behind this flush)
+            for x in n.ins:
+                if x[0] == "n":
+                    needed.add(id(x[1]))
+        for k in kernels:
+            for n in k.nodes:
+                for x in n.ins:
+                    if x[0] == "n" and x[1].kernel is not k:
+                        needed.add(id(x[1]))
+        dead = 0
+        for k in kernels:
+            for n in k.nodes:
+                n.live = (not n.fresh) or n.kind != "ew" or id(n) in needed or _counts(n) != base
+                dead += not n.live
+        STATS["dead"] += dead
+
+    def _run(self, kernels):
         STATS["flushes"] += 1
+        if DEAD_STORES["eliminate"]:
+            self._mark_live(kernels)
         prev, self._busy = self._busy, True
         try:
             for k in kernels:
@@ -811,6 +892,9 @@ def _gen_body(nodes, it_shape, ptrs, used, store_index="i"):
         val[id(n)] = v
         # an in-place target read later through the same view must see this value, not the stale load
         leaf_var[_view_key(n.out)] = v
+        if not n.live:
+            stores.append("")
+            continue
         j = pointer(n.out)
         off = _offset_expr(tuple(n.out.shape), tuple(n.out.stride()), it_shape, used) \
             if store_index == "i" else store_index
@@ -830,13 +914,15 @@ def _launch_elementwise(k):
         numel *= n
     if numel == 0:
         return
+    if not any(n.live for n in k.nodes):
+        return
     # later stores to the same view supersede earlier ones
     last = {}
     for n in k.nodes:
         last[_view_key(n.out)] = n
     ptrs, used = [], set()
     lines, stores = _gen_body(k.nodes, shape, ptrs, used)
-    keep = {id(n) for n in last.values()}
+    keep = {id(n) for n in last.values() if n.live}
     stores = [s for n, s in zip(k.nodes, stores) if id(n) in keep]
     src = _PRELUDE + "extern \"C\" __global__ __launch_bounds__(256) void k(Ptrs a) {\n" \
         "  const long i = (long)blockIdx.x * 256L + threadIdx.x;\n  if (i >= %dL) return;\n" % numel + \
@@ -845,6 +931,8 @@ def _launch_elementwise(k):
 
 
 def _launch_reduce(n):
+    if not n.live:
+        return
     red = n.red
     in_shape, dims, rsize = red["in_shape"], red["dims"], red["rsize"]
     kept = [d for d in range(len(in_shape)) if d not in dims]
@@ -888,6 +976,16 @@ def _launch_reduce(n):
         grid = (n_out + 3) // 4
     src = _PRELUDE + "extern \"C\" __global__ __launch_bounds__(256) void k(Ptrs a) {\n" + body + "}\n"
     _launch(src, grid, 256, ptrs)
+
+
+def _tensors_of(xs):
+    out = []
+    for x in xs:
+        if isinstance(x, torch.Tensor):
+            out.append(x)
+        elif isinstance(x, (list, tuple)):
+            out.extend(_tensors_of(x))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ class _ReplaySafeDraws:
         cap = self.cap
         if cap is None:                       # host tensors (tests): the stream advances by itself
             return fn()
+        rng._follow_torch()                   # (torch.manual_seed since the last draw restarts the stream)
         state = rng._STATE
         start = state["offset"]
         cap.base[:1].fill_(start)             # what *base + relative offset resolves against

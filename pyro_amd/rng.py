@@ -1,10 +1,12 @@
 """Process-wide counter-based RNG state for the HIP kernels (Philox4x32-10).
 
-``set_rng_seed`` mirrors pyro.set_rng_seed (reference: pyro/util.py:37-45): it seeds torch,
-python and numpy *and* the Philox stream used by the fused kernels.  Every draw advances a
-host-side 64-bit block offset, so the sequence is reproducible and independent of launch
-geometry; ranks of a multi-GPU job de-correlate by seeding with ``seed + rank`` exactly as the
-reference de-correlates chains (pyro/infer/mcmc/api.py:107).
+The stream is OWNED by torch's default generator, as the reference's draws are (pyro/util.py:37-45 seeds
+torch / random / numpy and nothing else; every ``rsample`` then goes through torch's generator): the Philox
+seed is ``torch.initial_seed()`` and a call of ``torch.manual_seed`` -- by ``pyro.set_rng_seed`` or by the
+user directly -- restarts the stream at block 0.  ``torch.manual_seed(s)`` alone therefore reproduces a
+run.  Every draw advances a host-side 64-bit block offset, so the sequence is reproducible and
+independent of launch geometry; ranks of a multi-GPU job de-correlate by seeding with ``seed + rank``
+exactly as the reference de-correlates chains (pyro/infer/mcmc/api.py:107).
 """
 import random
 
@@ -13,7 +15,49 @@ import torch
 
 from . import kernels
 
-_STATE = {"seed": 0, "offset": 0}
+_MASK = 0xFFFFFFFFFFFFFFFF
+_STATE = {"seed": 0, "offset": 0, "torch_seed": None}
+_SEEDINGS = [0]          # calls of torch.manual_seed / torch.seed so far
+
+
+def _count_seedings():
+    """``torch.manual_seed(s)`` with the seed ALREADY set leaves nothing to read off the generator (its
+    initial seed is the same and its state only moves when somebody draws from it), yet it means "start
+    over": the two entry points are wrapped to count their calls.  The wrappers change nothing else."""
+    import functools
+
+    def counting(fn):
+        if getattr(fn, "_pyro_amd_counts", False):
+            return fn
+
+        @functools.wraps(fn)
+        def seeded(*args, **kwargs):
+            _SEEDINGS[0] += 1
+            return fn(*args, **kwargs)
+        seeded._pyro_amd_counts = True
+        return seeded
+
+    for name in ("manual_seed", "seed"):
+        wrapped = counting(getattr(torch.random, name))
+        setattr(torch.random, name, wrapped)
+        setattr(torch, name, wrapped)
+
+
+_count_seedings()
+
+
+def _follow_torch():
+    """The default generator was re-seeded since the last draw: the stream restarts under the new seed."""
+    ts = (torch.initial_seed(), _SEEDINGS[0])
+    if ts != _STATE["torch_seed"]:
+        _STATE["torch_seed"] = ts
+        _STATE["seed"] = int(ts[0]) & _MASK
+        _STATE["offset"] = 0
+
+
+def current_seed():
+    _follow_torch()
+    return _STATE["seed"]
 # While a hipGraph is being captured the block offset of a draw cannot be a launch constant (every
 # replay would repeat the same numbers): draws are addressed relative to a device-resident base
 # counter that the graph itself advances (pa_counter_add) -- see GraphCapture below.
@@ -24,8 +68,7 @@ def set_rng_seed(seed):
     torch.manual_seed(seed)
     random.seed(seed)
     np.random.seed(seed % (2 ** 32))
-    _STATE["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
-    _STATE["offset"] = 0
+    _follow_torch()
 
 
 def get_rng_state():
@@ -38,12 +81,14 @@ def set_rng_state(state):
     random.setstate(state["random"])
     np.random.set_state(state["numpy"])
     _STATE.update(state["philox"])
+    _STATE["torch_seed"] = (torch.initial_seed(), _SEEDINGS[0])   # the restored generator owns the stream again
 
 
 def reserve(n_elements, dtype):
     """Reserve Philox blocks for ``n_elements`` draws; returns (seed, offset, offset_dev) where
     ``offset_dev`` is None (eager) or the device base counter of the active graph capture."""
     per = 4 if dtype == torch.float32 else 2
+    _follow_torch()
     off = _STATE["offset"]
     _STATE["offset"] = off + (int(n_elements) + per - 1) // per
     cap = _CAPTURE["active"]
@@ -55,6 +100,7 @@ def reserve(n_elements, dtype):
 def reserve_blocks(n_blocks):
     """Reserve ``n_blocks`` whole Philox blocks (draws that key one block per element, such as the
     Gamma sampler's rejection loop); returns (seed, offset, offset_dev) like ``reserve``."""
+    _follow_torch()
     off = _STATE["offset"]
     _STATE["offset"] = off + int(n_blocks)
     cap = _CAPTURE["active"]
@@ -100,6 +146,8 @@ class GraphCapture:
 
     def __enter__(self):
         assert _CAPTURE["active"] is None, "nested RNG graph captures are not supported"
+        _follow_torch()
+        self.seed = _STATE["seed"]          # a launch constant of every draw recorded in here
         self.start = _STATE["offset"]
         _CAPTURE["active"] = self
         return self
@@ -123,6 +171,11 @@ class GraphCapture:
     def __exit__(self, *exc):
         _CAPTURE["active"] = None
         _STATE["offset"] = self.start      # capturing executes nothing: no draws were consumed
+
+    def stale(self):
+        """The default generator was re-seeded after the capture: its draws carry the old seed."""
+        _follow_torch()
+        return getattr(self, "seed", _STATE["seed"]) != _STATE["seed"]
 
     def before_replay(self):
         if self._base_value != _STATE["offset"]:

@@ -374,10 +374,15 @@ def run_async_equals_lockstep(device, dtype, rtol, C=6, D=9, warmup=40, S=6, mul
     (a chain that finishes a tree adapts and starts its next tree in the same launch, in-kernel dual
     averaging / Welford) against the lock-step per-transition path with host adaptation.  The Philox
     keys do not know the schedule => the same chains up to rounding of the adaptation math."""
+    from pyro_amd.ops import fuser
     Lam = torch.tensor(make_precision(D, 4), dtype=dtype, device=device)
     z0 = torch.tensor(np.random.default_rng(1).standard_normal((C, D)) * 0.3, dtype=dtype,
                       device=device)
     outs = []
+    # the two schedules are compared on the SAME potential kernels: the captured rounds of the asynchronous
+    # path would otherwise run the potential's element-wise glue as generated kernels (sums in another
+    # order), the eager lock-step rounds as ATen's
+    fused_glue, fuser.ENABLED["on"] = fuser.ENABLED["on"], False
     for async_chains in (False, True):
         pyro.set_rng_seed(78)
         kernel = NUTS(potential_fn=LogCoshPotential(Lam), max_tree_depth=5, step_size=1.0 if adapt else 0.15,
@@ -390,6 +395,7 @@ def run_async_equals_lockstep(device, dtype, rtol, C=6, D=9, warmup=40, S=6, mul
         outs.append((mcmc.get_samples(group_by_chain=True)["x"].clone(),
                      kernel.step_size.clone(), kernel.mass_matrix_adapter.inverse_mass_matrix.clone(),
                      kernel.num_leapfrog_steps, mcmc.diagnostics(), kernel._mean_accept_prob.clone()))
+    fuser.ENABLED["on"] = fused_glue
     a, b = outs
     assert a[3] == b[3], (a[3], b[3])                       # identical trees
     if not adapt:

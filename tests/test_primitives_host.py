@@ -78,3 +78,29 @@ def test_obs_mask_semantics():
                 pyro.sample("y", dist.Laplace(torch.zeros(4), 1.0), obs=data,
                             obs_mask=torch.tensor([True, False, True]))
         poutine.trace(bad).get_trace()
+
+
+def test_philox_stream_follows_torchs_default_generator(oracle_backend):
+    """torch.manual_seed alone restarts the kernels' stream (reference: every draw goes through torch's
+    generator, pyro/util.py:37-45 seeds nothing else); get / set_rng_state carry its position."""
+    import torch
+    import pyro_amd as pyro
+    from pyro_amd import rng
+    dev = torch.device("cpu")
+    torch.manual_seed(5)
+    a = rng.normal((6,), torch.float64, dev)
+    b = rng.normal((6,), torch.float64, dev)
+    assert rng.current_seed() == 5 and not torch.equal(a, b)
+    torch.manual_seed(5)
+    assert torch.equal(rng.normal((6,), torch.float64, dev), a)
+    state = pyro.util.get_rng_state()
+    c = rng.normal((6,), torch.float64, dev)
+    assert torch.equal(c, b)
+    torch.manual_seed(99)
+    assert not torch.equal(rng.normal((6,), torch.float64, dev), a)
+    pyro.util.set_rng_state(state)
+    assert rng.current_seed() == 5 and torch.equal(rng.normal((6,), torch.float64, dev), b)
+    pyro.set_rng_seed(5)
+    assert torch.equal(rng.normal((6,), torch.float64, dev), a)
+    pyro.set_rng_seed(5)                               # the seed already set: starts over all the same
+    assert torch.equal(rng.normal((6,), torch.float64, dev), a)

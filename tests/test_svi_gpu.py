@@ -305,9 +305,9 @@ def test_default_svi_captures_only_what_can_be_a_graph(gpu):
 
             def syncing(X, y):
                 w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), 1.0).to_event(1))
-                float(w.sum())                      # a host read: not capturable
+                float(w.detach().sum())             # a host read: not capturable
                 with pyro.plate("data", X.shape[0]):
-                    pyro.sample("obs", dist.Bernoulli(logits=X @ w), obs=y)
+                    pyro.sample("obs", dist.Bernoulli(logits=(w @ X.t()).squeeze(-2)), obs=y)
             svi = build(syncing)
             losses = [svi.step(X, y) for _ in range(6)]
             assert not svi.hip_graph and not svi._graphs and all(np.isfinite(losses))
@@ -538,3 +538,47 @@ def test_rccl_all_reduce_eager_and_captured_in_the_step_graph(gpu):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "RCCL one-rank OK" in out.stdout
     assert "two graphs + eager collective" in out.stdout and out.stdout.count("one graph") >= 2
+
+
+def test_torch_manual_seed_alone_reproduces_a_run(gpu):
+    """The Philox stream of the kernels is owned by torch's default generator (the reference's draws all go
+    through it, pyro/util.py:37-45): torch.manual_seed(s) -- without pyro.set_rng_seed -- restarts it, for
+    eager steps and for a captured step (whose draws hold the seed as a launch constant: re-captured)."""
+    import pyro_amd as pyro
+    from pyro_amd import examples, rng
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(4096, 8, gpu, seed=1)
+
+    def run(seed_fn, graph):
+        pyro.clear_param_store()
+        seed_fn()
+        guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+        svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.01}),
+                  Trace_ELBO(num_particles=4, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph)
+        a = [svi.step(X, y) for _ in range(7)]
+        # the same parameters, the stream restarted in the middle of the run
+        seed_fn()
+        b = [svi.step(X, y) for _ in range(3)]
+        seed_fn()
+        c = [svi.step(X, y) for _ in range(3)]
+        return a, b, c, svi
+
+    pyro.enable_validation(False)
+    try:
+        for graph in (False, True):
+            a1, b1, c1, _ = run(lambda: pyro.set_rng_seed(11), graph)
+            a2, b2, c2, svi = run(lambda: torch.manual_seed(11), graph)
+            assert a1 == a2 and b1 == b2 and c1 == c2
+            assert rng.current_seed() == 11
+            a3 = run(lambda: torch.manual_seed(12), graph)[0]
+            assert a3 != a1
+        torch.manual_seed(3)
+        u = rng.normal((8,), torch.float32, gpu)
+        v = rng.normal((8,), torch.float32, gpu)
+        torch.manual_seed(3)
+        assert torch.equal(rng.normal((8,), torch.float32, gpu), u) and not torch.equal(u, v)
+    finally:
+        pyro.enable_validation(True)
+        pyro.clear_param_store()
