@@ -551,16 +551,22 @@ def main():
     use_graph = not args.no_graph
     # the dominant kernel's own clock stamps (a launch argument: created before the capture)
     clock = kernels.GlmDeviceClock(dev) if on_gpu else None
-    # prearm: step k+1's replay is enqueued (behind a gate node) while step k executes, and released
-    # by the next step() call -- SVI.step per step, loss returned per step (pyro_amd/infer/svi.py)
-    # With the gate in front of the chained tail (SVI(speculate=True), the default with prearm) the GLM
-    # kernel of step k+1 runs while the host is still between the two calls.  Every timed block ends with
-    # SVI.pause(): the replay armed for the step after the block's last one is given up at once instead
-    # of being sat out by the closing synchronisation (its GLM kernel, already running, is waited for).
-    prearm = use_graph and world == 1 and not args.no_prearm
+    # The headline is the reference's constructor and nothing else: SVI(model, guide, optim, loss).  With
+    # device tensors as arguments such an SVI captures its step into a hipGraph by itself (after 3 eager
+    # steps) and enqueues the replay of step k+1 behind a gate node while step k executes; the replay is
+    # released by the next step() call when no tensor the captured step reads has changed meanwhile (version
+    # counters of everything it reads from outside itself), otherwise given up -- nothing is asked of the
+    # caller (pyro_amd/infer/svi.py).  Every timed block ends with SVI.pause(): the replay armed for the step
+    # after the block's last one is given up at once instead of being sat out by the closing synchronisation.
+    # --no-prearm / --no-graph switch the two mechanisms off (hip_graph=False is the reference's eager step).
+    kw = {}
+    if not use_graph:
+        kw["hip_graph"] = False
+    elif args.no_prearm:
+        kw["prearm"] = False
     svi = SVI(examples.logreg_model, guide, optim,
-              Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
-              hip_graph=use_graph, graph_warmup=2, prearm=prearm)
+              Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1), **kw)
+    prearm = bool(svi.prearm and svi.hip_graph and world == 1)
 
     class _NoTimer:                      # (host run: nothing to bracket)
         pairs = []
@@ -634,7 +640,7 @@ def main():
         tu = sorted(tus)[len(tus) // 2]
         unarmed = {"value": nu / tu, "ms_per_step": tu / nu * 1e3, "steps": nu, "blocks": len(tus),
                    "note": "the same capture after SVI.disarm(): the host launches each replay when "
-                           "step() is called (round 3's way)"}
+                           "step() is called (what SVI(..., prearm=False) runs)"}
     clock_ms = []
     if graphed and not graphed_events:
         # the kernel's duration inside the graph, from its own stamps on the device clock
@@ -846,11 +852,14 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Bayesian logistic regression, plate=%d, "
                                    "D=%d, Trace_ELBO num_particles=%d per GPU (vectorised), AutoNormal, "
                                    "Adam; the model text of SURVEY 8(d) verbatim (logits = w @ X.t() ...); "
-                                   "full SVI.step (%s)" % (N, D, P, ("one hipGraph replay per step" + (
-                                       ", SVI(prearm=True): the replay of step k+1 is enqueued while step k "
-                                       "executes; its GLM kernel (forward pass) runs ahead, a gate node in "
-                                       "front of its chained tail waits for the next step() call" if prearmed
-                                       else "")) if graphed else "eager launches"),
+                                   "full SVI.step of SVI(model, guide, optim, loss) -- the reference's "
+                                   "constructor, no other argument (%s)" % (N, D, P, (
+                                       "it captures its step by itself: one hipGraph replay per step" + (
+                                           ", the replay of step k+1 enqueued while step k executes (its GLM "
+                                           "kernel runs ahead, a gate node in front of its chained tail waits "
+                                           "for the next step() call and gives the replay up when anything the "
+                                           "step reads has changed)" if prearmed else "")) if graphed
+                                       else "eager launches"),
                        "parallelism": "particles sharded x%d, flat RCCL grad all-reduce" % world},
             # the plate scan is priced against HBM (algorithmic bytes = X and y once)
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,

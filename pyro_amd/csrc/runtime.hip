@@ -1,6 +1,7 @@
 // runtime.hip -- host-side plumbing of the C-ABI: error strings, device queries.
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace pa {
@@ -42,6 +43,8 @@ void gate_aware_launch() {
 }
 
 int check_launch(const char* what) {
+  static const bool trace = getenv("PYRO_AMD_TRACE_LAUNCHES") != nullptr;   // developer aid: every launch by name
+  if (trace) fprintf(stderr, "pyro_amd launch: %s%s\n", what, g_gate_late.pending ? "  (in front of a late gate)" : "");
   if (g_gate_late.pending) {
     g_gate_late.pre += 1;
     if (strncmp(what, "glm_planes_kernel", 17) != 0 || strchr(what, '<') != nullptr) g_gate_late.pre_other += 1;

@@ -13,6 +13,7 @@ import os as _os
 import warnings
 
 import torch
+import torch.utils._python_dispatch
 
 from .. import kernels, poutine
 from ..params import _PARAM_STORE
@@ -36,7 +37,50 @@ def _arg_key(x):
         return ("id", id(x))
 
 
+class _ReadSet(torch.utils._python_dispatch.TorchDispatchMode):
+    """Every tensor a step READS (or writes) that was not made inside the step: the arguments of the
+    operators torch dispatches and of the package's own launches (kernels._ptr) whose storage was not
+    allocated while this scope was open.  A replay enqueued ahead of the host (prearm) is only let run when
+    the version counters of all of them are what they were when it was enqueued -- not just those of
+    step()'s arguments and of the parameters: a model that closes over a tensor the user updates between
+    steps is noticed the same way."""
+
+    def __init__(self):
+        super().__init__()
+        self.internal = set()
+        self.external = {}
+
+    def note(self, t):
+        if t.is_cuda and t.untyped_storage().data_ptr() not in self.internal:
+            self.external[id(t)] = t
+
+    def __enter__(self):
+        kernels._PTR_HOOKS.append(self.note)
+        return super().__enter__()
+
+    def __exit__(self, *exc):
+        kernels._PTR_HOOKS.remove(self.note)
+        return super().__exit__(*exc)
+
+    def _walk(self, xs, fn):
+        for x in xs:
+            if isinstance(x, torch.Tensor):
+                fn(x)
+            elif isinstance(x, (list, tuple)):
+                self._walk(x, fn)
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        self._walk(args, self.note)
+        self._walk(tuple(kwargs.values()), self.note)
+        out = func(*args, **kwargs)
+        self._walk(out if isinstance(out, (list, tuple)) else (out,),
+                   lambda t: self.internal.add(t.untyped_storage().data_ptr()) if t.is_cuda else None)
+        return out
+
+
 class _CapturedStep:
+    reads = ()             # tensors the step reads that it did not make (see _ReadSet)
     gate = None            # kernels.StepGate when the step's first node is a gate (SVI(prearm=True))
     armed = False          # the NEXT replay is already enqueued behind its gate
     armed_state = None     # what the host looked like when it was enqueued
@@ -159,7 +203,7 @@ def _capturable_arguments(args, kwargs):
 
 class SVI:
     def __init__(self, model, guide, optim, loss, loss_and_grads=None, num_samples=0, num_steps=0,
-                 hip_graph=None, graph_warmup=3, prearm=False, speculate=True, **kwargs):
+                 hip_graph=None, graph_warmup=3, prearm=None, speculate=True, **kwargs):
         if num_steps or num_samples:
             warnings.warn("num_steps / num_samples are ignored (TracePosterior is not part of "
                           "this backend)")
@@ -185,16 +229,24 @@ class SVI:
         if hip_graph is None:
             want = CAPTURE_STEPS if _os.environ.get("PYRO_AMD_HIP_GRAPH", "1") != "0" else False
             hip_graph = (want is True or want == "auto") and self._loss_device is not None \
-                and not prearm and _FlatOptimOK(optim)
+                and _FlatOptimOK(optim)
         self.hip_graph = bool(hip_graph)
+        if prearm is None:
+            # a step that captures itself also enqueues its next replay ahead of the host when every node
+            # of it can be given up (below); an explicit hip_graph=True keeps the plain replay unless asked
+            prearm = self._auto_graph and self.hip_graph
         # prearm: right after launching step k the replay of step k+1 is enqueued behind a gate node
         # and released by the next step() call with one store to pinned memory (the launch latency
-        # of a step overlaps the execution of the one before).  A promise by the caller: between two
-        # step() calls with the same arguments nothing is enqueued on the device that the step must
-        # see or that must see the step -- in-place writes to the step's ARGUMENT tensors and to
-        # parameters are noticed (the armed replay is cancelled), other device work is not; a host that
-        # stays away longer than the gate's patience (40 us) finds the replay given up and the step
-        # runs the ordinary way.  Only steps whose every node can be given up are armed.
+        # of a step overlaps the execution of the one before).  Nothing is asked of the caller: the replay
+        # is only released when the host-visible state it depends on is what it was when the replay was
+        # enqueued -- the version counter of EVERY tensor the captured step reads that it did not make
+        # itself (arguments, parameters, optimizer state, tensors the model closes over: _ReadSet), the
+        # position and seed of the random stream, the set of parameters; otherwise it is given up and the
+        # step runs the ordinary way.  Work the caller enqueues between two steps waits behind the gate
+        # node for at most the gate's patience (40 us), after which the gate gives the replay up by
+        # itself; a host that stays away longer than that finds the same.  Only steps whose every node
+        # can be given up are armed.  (What no version counter sees -- memory written behind torch's back
+        # by a foreign kernel between two steps -- a step enqueued ahead does not see either.)
         self.prearm = bool(prearm) and _os.environ.get("PYRO_AMD_PREARM", "1") != "0"
         # speculate (with prearm): the gate sits in front of the step's chained tail instead of first, so
         # the forward pass of the replay enqueued ahead (the plane-image GLM kernel, which also makes the
@@ -344,11 +396,12 @@ class SVI:
                 e.cancel()
             e.arm_backoff = 1 << 60
 
-    def _host_state(self, args, kwargs):
+    def _host_state(self, args, kwargs, entry=None):
         """What an armed replay depends on besides the device's own state: (tensor, version) of every
-        argument tensor and parameter, and the host-side position of the Philox stream."""
+        argument tensor, every parameter and every other tensor the captured step reads from outside
+        itself, and the host-side position of the Philox stream."""
         from .. import rng
-        refs = []
+        refs = [(t, t._version) for t in entry.reads] if entry is not None else []
         for a in list(args) + [v for _, v in sorted(kwargs.items())]:
             if isinstance(a, torch.Tensor):
                 refs.append((a, a._version))
@@ -376,7 +429,7 @@ class SVI:
             entry.launch()
             entry.cap.after_replay()
             from .. import rng
-            entry.arm((self._host_state(args, kwargs), rng._STATE["offset"]))
+            entry.arm((self._host_state(args, kwargs, entry), rng._STATE["offset"]))
             return entry.read_loss(released_armed=True)
         if entry.armed:
             # the armed replay reads the device as the stream will have left it BEFORE anything the
@@ -399,7 +452,7 @@ class SVI:
         else:
             from .. import rng
             entry.armed_nargs = len(args)
-            entry.arm((self._host_state(args, kwargs), rng._STATE["offset"]))
+            entry.arm((self._host_state(args, kwargs, entry), rng._STATE["offset"]))
             self._armed_fast = (entry, args, _arg_key(args)) if not kwargs else None
         loss = entry.read_loss(released_armed=released)
         if released and entry.arm_backoff == 0:
@@ -431,6 +484,12 @@ class SVI:
                 entry = self._capture_once(key, args, kwargs, None, force_split=form,
                                            quiet=form is False, with_gate=gated)
             while getattr(entry, "gate", None) is not None and not entry.gate.armable:
+                if _os.environ.get("PYRO_AMD_DEBUG_GATE"):
+                    g = entry.gate
+                    print("pyro_amd: gate form %r not armable: launches %s gate-aware %s torch operators %s "
+                          "emitted %s in front of a late gate %s (not the GLM kernel: %s)"
+                          % (gated, g.total, g.aware, g.torch_ops, getattr(g, "emitted", None),
+                             getattr(g, "pre", None), getattr(g, "pre_other", None)), flush=True)
                 # some node of this step would still run after the gate gave a replay up (a torch
                 # kernel, a launch of ours that does not poll the gate), or something other than the
                 # GLM kernel runs in front of a late gate: the next weaker form
@@ -498,9 +557,11 @@ class SVI:
                 # only THIS thread's calls may invalidate the capture
                 multi = getattr(self.optim, "multi_rank", False)
                 mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
+                reads = _ReadSet()
                 with torch.cuda.graph(graph, **mode):
-                    # (the fuser outermost: it sees what the inner modes let through, last)
-                    with fuser.scope(), gated(), cap, chain() as rec, hoist():
+                    # (the fuser outermost: it sees what the inner modes let through, last; the read-set
+                    #  recorder innermost: it sees every operator first)
+                    with fuser.scope(), gated(), cap, chain() as rec, hoist(), reads:
                         if gate is not None:
                             gate.launch()          # first node: holds a replay enqueued ahead of time
                         with poutine.trace(param_only=True) as param_capture:
@@ -553,6 +614,7 @@ class SVI:
             return None
         entry = _CapturedStep(graph, cap, loss, graph2, between, mailbox)
         entry.gate = gate
+        entry.reads = tuple(reads.external.values())
         # the graph reads the hoisted constants on every replay: they live as long as the entry
         entry.constants = consts.tensors if consts is not None else []
         entry.constants_served = consts.served if consts is not None else 0

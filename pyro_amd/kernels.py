@@ -41,16 +41,17 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# pyro_amd/ops/fuser.py defers eligible torch operators; a launch of ours is about to touch device memory,
-# so whatever is recorded has to be materialised first (the hook is set while a Fuser scope is open)
-_FUSER_HOOK = [None]
+# Who wants to know that a launch of ours is about to touch tensor t: pyro_amd/ops/fuser.py (it defers
+# eligible torch operators; whatever is recorded and shares memory with t has to be materialised first),
+# SVI's capture (it notes every tensor a captured step reads that was not made inside the step)
+_PTR_HOOKS = []
 
 
 def _ptr(t):
     if t is None:
         return None
-    if _FUSER_HOOK[0] is not None:
-        _FUSER_HOOK[0](t)
+    for hook in _PTR_HOOKS:
+        hook(t)
     if _CHAIN["keep"] is not None:
         _CHAIN["keep"].append(t)       # a recorded launch reads / writes it at the flush
     return ctypes.c_void_p(t.data_ptr())
@@ -61,8 +62,8 @@ def _view(t, rows, cols):
     2-D strided view without materialising broadcasts."""
     if t is None:
         return NULL_VIEW
-    if _FUSER_HOOK[0] is not None:
-        _FUSER_HOOK[0](t)
+    for hook in _PTR_HOOKS:
+        hook(t)
     if _CHAIN["keep"] is not None:
         _CHAIN["keep"].append(t)
     assert t.dim() == 2

@@ -212,9 +212,9 @@ class Fuser(TorchDispatchMode):
     # ---- scope ------------------------------------------------------------------------------------
     def __enter__(self):
         from .. import kernels
-        self._prev = (_ACTIVE[0], kernels._FUSER_HOOK[0])
+        self._prev = _ACTIVE[0]
         _ACTIVE[0] = self
-        kernels._FUSER_HOOK[0] = self._before_launch
+        kernels._PTR_HOOKS.append(self._before_launch)
         return super().__enter__()
 
     def _before_launch(self, t):
@@ -232,7 +232,8 @@ class Fuser(TorchDispatchMode):
                 self.pending, self.kernels, self.writer = [], [], {}
         finally:
             from .. import kernels
-            _ACTIVE[0], kernels._FUSER_HOOK[0] = self._prev
+            _ACTIVE[0] = self._prev
+            kernels._PTR_HOOKS.remove(self._before_launch)
             super().__exit__(*exc)
 
     # ---- dispatch ---------------------------------------------------------------------------------

@@ -307,7 +307,9 @@ def test_default_svi_captures_only_what_can_be_a_graph(gpu):
                 w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), 1.0).to_event(1))
                 float(w.detach().sum())             # a host read: not capturable
                 with pyro.plate("data", X.shape[0]):
-                    pyro.sample("obs", dist.Bernoulli(logits=(w @ X.t()).squeeze(-2)), obs=y)
+                    logits = w @ X.t()
+                    pyro.sample("obs", dist.Bernoulli(logits=logits.squeeze(-2) if logits.dim() > 1 else logits),
+                                obs=y)
             svi = build(syncing)
             losses = [svi.step(X, y) for _ in range(6)]
             assert not svi.hip_graph and not svi._graphs and all(np.isfinite(losses))
@@ -582,3 +584,50 @@ def test_torch_manual_seed_alone_reproduces_a_run(gpu):
     finally:
         pyro.enable_validation(True)
         pyro.clear_param_store()
+
+
+def test_replay_enqueued_ahead_notices_tensors_the_model_closes_over(gpu):
+    """The default SVI enqueues its next replay ahead of the host.  It may only run if nothing it reads has
+    changed since: not just step()'s arguments and the parameters, every tensor the captured step reads from
+    outside itself -- here the prior scale the model closes over, rewritten in place between two steps.  The
+    losses equal the eager run's bit for bit, before and after the change."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=2)
+    prior_scale = torch.ones((), device=gpu)
+    zeros = torch.zeros(32, device=gpu)
+
+    def model(X, y):
+        w = pyro.sample("w", dist.Normal(zeros, prior_scale).to_event(1))
+        b = pyro.sample("b", dist.Normal(zeros[0], prior_scale))
+        with pyro.plate("data", X.shape[0]):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
+
+    runs = []
+    pyro.enable_validation(False)
+    try:
+        for graph in (False, None):
+            pyro.clear_param_store()
+            pyro.set_rng_seed(3)
+            prior_scale.fill_(1.0)
+            svi = SVI(model, AutoNormal(model, init_scale=0.1), pyro.optim.Adam({"lr": 0.02}),
+                      Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph)
+            losses = [svi.step(X, y) for _ in range(9)]
+            if graph is None:
+                entry = next(iter(svi._graphs.values()))
+                assert entry.gate is not None and entry.armed, "the default step is not pre-armed here"
+                assert any(t is prior_scale for t in entry.reads)
+            prior_scale.fill_(0.05)                 # (a tight prior: the loss jumps)
+            losses += [svi.step(X, y) for _ in range(5)]
+            runs.append((losses, {k: v.detach().clone() for k, v in pyro.get_param_store().items()}))
+    finally:
+        pyro.enable_validation(True)
+        pyro.clear_param_store()
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert abs(runs[0][0][9] - runs[0][0][8]) > 1.0
+    for k in runs[0][1]:      # (the chained tail rounds this model's prior gradient once differently: 1 ulp)
+        torch.testing.assert_close(runs[0][1][k], runs[1][1][k], rtol=1e-6, atol=1e-7)
