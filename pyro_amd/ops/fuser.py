@@ -36,6 +36,7 @@ STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "flushes": 0, "dead": 0}
 UNFUSED = {}                # operator name -> how often it was met and run as it is (attribution)
 MAX_POINTERS = 64           # PA_RTC_MAX_POINTERS
 MAX_REDUCE = 1 << 14        # longest reduction taken (one wave per output element)
+INLINE_REDUCE = 32          # up to here a reduction is a loop inside an element-wise kernel
 MAX_DIMS = 6
 
 _ACTIVE = [None]
@@ -153,7 +154,7 @@ def _view_key(t):
 
 class _Node:
     __slots__ = ("op", "ins", "out", "shape", "dtype", "ctype", "expr", "kind", "kernel", "wspan", "rspans",
-                 "rviews", "red", "order", "fresh", "live")
+                 "rviews", "red", "order", "fresh", "live", "inline")
 
 
 DEAD_STORES = {"eliminate": os.environ.get("PYRO_AMD_FUSER_DEAD_STORES", "1") != "0"}
@@ -324,7 +325,7 @@ class Fuser(TorchDispatchMode):
         return handler(func, base, overload, inplace, args, kwargs)
 
     # -- node construction
-    def _new_node(self, op, expr, ins, meta_out, out=None, compute=None, red=None, fresh=None):
+    def _new_node(self, op, expr, ins, meta_out, out=None, compute=None, red=None, fresh=None, inline=None):
         """``expr``: C expression over {0}.. in compute type T; ``out``: existing tensor (in-place) or None."""
         if not isinstance(meta_out, torch.Tensor) or meta_out.dtype not in _CTYPE:
             raise Unfusable
@@ -335,6 +336,7 @@ class Fuser(TorchDispatchMode):
         n.op, n.expr, n.ins, n.shape, n.dtype = op, expr, ins, shape, meta_out.dtype
         n.ctype = _CTYPE[compute or meta_out.dtype]
         n.red = red
+        n.inline = inline
         n.live = True
         n.kind = "red" if red is not None else "ew"
         # fresh: the fuser allocates the output -- nobody has read or written it before
@@ -356,9 +358,10 @@ class Fuser(TorchDispatchMode):
         it_shape = red["in_shape"] if red is not None else shape
         norm = []
         for x in ins:
-            if x[0] == "n" and (red is not None or x[1].kind != "ew" or _bcast(x[1].shape, it_shape) != it_shape):
+            if x[0] == "n" and (red is not None or inline is not None or x[1].kind != "ew"
+                                or _bcast(x[1].shape, it_shape) != it_shape):
                 x = ("t", x[1].out)
-            if x[0] != "s":
+            if x[0] != "s" and inline is None:
                 s = tuple(x[1].shape) if x[0] == "t" else x[1].shape
                 if len(s) > len(it_shape) or any(a != b and a != 1 for a, b in zip(reversed(s), reversed(it_shape))):
                     raise Unfusable
@@ -386,6 +389,11 @@ class Fuser(TorchDispatchMode):
                 continue
             same = n.kind == "ew" and m.kind == "ew" and self._index_for_index(n, m) and \
                 (n.shape == m.shape or (n.fresh and m.fresh and _bcast(n.shape, m.shape) is not None))
+            # an inline reduction reads a RANGE of its operand per thread, not its own element: what it reads
+            # must be in memory before its kernel starts, and must not be overwritten by that kernel
+            if same and ((n.inline is not None and any(_overlap(r, m.wspan) for r in n.rspans))
+                         or (m.inline is not None and any(_overlap(n.wspan, r) for r in m.rspans))):
+                same = False
             jmin = max(jmin, m.kernel.index + (0 if same else 1))
         k = None
         if n.kind == "ew":
@@ -711,6 +719,10 @@ class Fuser(TorchDispatchMode):
             raise Unfusable
         meta = self._meta(func, args, kwargs)
         red = {"in_shape": tuple(x.shape), "dims": dims, "keep": bool(keep), "rsize": rsize}
+        if rsize <= INLINE_REDUCE:
+            # a short reduction is an element-wise operator of its OUTPUT domain whose thread loops over the
+            # reduced range: it shares a kernel with what follows it (x.sum(-1) then neg, add, ...)
+            return self._new_node("sum", "{0}", [self._operand(x, x.dtype)], meta, inline=red)
         return self._new_node("sum", "{0}", [self._operand(x, x.dtype)], meta, red=red)
 
     # ---- materialisation ----------------------------------------------------------------------------
@@ -877,6 +889,21 @@ def _gen_body(nodes, it_shape, ptrs, used, store_index="i"):
 
     for q, n in enumerate(nodes):
         T = n.ctype
+        if n.inline is not None:
+            lines.extend(_inline_reduce(n, q, it_shape, used, pointer))
+            val[id(n)] = "v%d" % q
+            leaf_var[_view_key(n.out)] = "v%d" % q
+            if not n.live:
+                stores.append("")
+                continue
+            j = pointer(n.out)
+            off = _offset_expr(tuple(n.out.shape), tuple(n.out.stride()), it_shape, used)
+            pad = len(it_shape) - len(n.shape)
+            expanded = [d for d in range(len(it_shape)) if it_shape[d] > 1 and (d < pad or n.shape[d - pad] == 1)]
+            used.update(expanded)
+            guard = "if (%s) " % " && ".join("i%d == 0" % d for d in expanded) if expanded else ""
+            stores.append("  %s((%s*)a.p[%d])[%s] = v%d;" % (guard, _CTYPE[n.dtype], j, off, q))
+            continue
         ops = []
         for x in n.ins:
             if x[0] == "s":
@@ -906,6 +933,46 @@ def _gen_body(nodes, it_shape, ptrs, used, store_index="i"):
         guard = "if (%s) " % " && ".join("i%d == 0" % d for d in expanded) if expanded else ""
         stores.append("  %s((%s*)a.p[%d])[%s] = %s;" % (guard, out_t, j, off, v))
     return lines, stores
+
+
+def _inline_reduce(n, q, it_shape, used, pointer):
+    """v<q> = sum over the reduced dims of the node's (memory) operand at this thread's output index."""
+    red = n.inline
+    x = n.ins[0]
+    t = x[1].out if x[0] == "n" else x[1]
+    in_shape, dims, st = red["in_shape"], red["dims"], t.stride()
+    kept = [d for d in range(len(in_shape)) if d not in dims]
+    out_rank = len(n.shape)
+    pad = len(it_shape) - out_rank
+    terms = []
+    for j, d in enumerate(kept if not red["keep"] else range(len(in_shape))):
+        if red["keep"] and d in dims:
+            continue
+        # output dim j (keepdim: the same position d) sits at kernel dim j + pad
+        kd = (d if red["keep"] else j) + pad
+        if in_shape[d] > 1 and st[d] != 0:
+            used.add(kd)
+            terms.append("i%d * %dL" % (kd, st[d]))
+    base = " + ".join(terms) or "0"
+    acc = "double" if n.dtype == torch.float64 else "float"
+    T = n.ctype
+    j = pointer(t)
+    lines = ["  %s v%d;" % (_CTYPE[n.dtype], q), "  {", "    %s s_ = 0;" % acc,
+             "    const long b_ = %s;" % base, "    for (long r = 0; r < %dL; ++r) {" % red["rsize"],
+             "      long q_ = r;"]
+    ds = list(dims)
+    offs = []
+    for qi in range(len(ds) - 1, -1, -1):
+        d = ds[qi]
+        if qi > 0:
+            lines.append("      const long q%d = q_ %% %dL; q_ /= %dL;" % (d, in_shape[d], in_shape[d]))
+        else:
+            lines.append("      const long q%d = q_;" % d)
+        if in_shape[d] > 1 and st[d] != 0:
+            offs.append("q%d * %dL" % (d, st[d]))
+    lines += ["      s_ += (%s)((const %s*)a.p[%d])[b_ + %s];" % (acc, _CTYPE[t.dtype], j, " + ".join(offs) or "0"),
+              "    }", "    v%d = (%s)s_;" % (q, _CTYPE[n.dtype]), "  }"]
+    return lines
 
 
 def _launch_elementwise(k):

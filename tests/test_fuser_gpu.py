@@ -96,6 +96,35 @@ def test_views_and_in_place_writes_keep_their_order(gpu):
         torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-6)
 
 
+def test_short_reductions_inside_elementwise_kernels(gpu):
+    """A reduction over <= 32 elements is a loop of the thread that owns the output element, in one kernel
+    with what follows it -- but never in one kernel with the operator that PRODUCES what it sums (it reads
+    a range, not its own element) nor with one that overwrites it."""
+    from pyro_amd.ops import fuser
+
+    def run(x, w):
+        pe = -(x * w).sum(-1)                       # [C]: product, short row sum, neg
+        total = pe.sum()                            # reads ALL of pe
+        g = (pe - total / 6.0).unsqueeze(-1) * x    # back to [C, D]
+        col = g.sum(0, keepdim=True)                # short column sum, keepdim
+        x2 = x.clone()
+        s = x2.sum(-1, keepdim=True)
+        x2.sub_(s)                                  # overwrites what the row sum read
+        return pe, total, g, col, x2, (g / (col + 7.0)).sum((0, 1))
+
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(6, 8, generator=gen, dtype=torch.float64).to(gpu)
+    w = torch.randn(8, generator=gen, dtype=torch.float64).to(gpu)
+    ref = run(x, w)
+    before = dict(fuser.STATS)
+    with fuser.Fuser():
+        got = run(x, w)
+    torch.cuda.synchronize()
+    assert fuser.STATS["kernels"] - before["kernels"] <= 8
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=1e-13, atol=1e-13)
+
+
 def test_fused_kernels_inside_a_captured_graph_follow_their_inputs(gpu):
     from pyro_amd.ops import fuser
     x = torch.randn(64, 8, device=gpu)
