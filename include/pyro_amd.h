@@ -671,9 +671,21 @@ int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq,
                              uint64_t chain_offset, const int64_t* ctl, void* da_state,
                              double target_accept, void* welford, void* mean_accept,
                              int64_t* counters, int32_t* tc, int32_t* n_done, int64_t* done_flag,
+                             const int32_t* slot2chain, void* zq_slot, int64_t n_slots,
                              void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
                              int32_t* diverging, int32_t* accepted, void* workspace,
                              size_t workspace_bytes, pa_stream_t stream);
+/* COMPACTED rounds.  Late in a span few chains are still building trees (per-chain step sizes differ; the
+ * reference's chain processes simply finish at different times, api.py:239-351); evaluating the potential
+ * for all C cursors then serves mostly finished chains.  pa_nuts_tree_compact lists the chains still active
+ * (ascending; -1 pads) in slot2chain[n_slots] and gathers their cursors into zq_slot[n_slots, D];
+ * *n_placed = number of slots filled (the caller picks n_slots >= the number of active chains).  From then
+ * on the caller evaluates the potential at zq_slot and passes (slot2chain, zq_slot, n_slots) to
+ * pa_nuts_tree_run_advance: peq / gq are slot-indexed, the launch has one workgroup per slot, a chain writes
+ * its next cursor to its slot row too.  NULL / NULL: slot == chain, n_slots ignored (the full round). */
+int pa_nuts_tree_compact(int dtype, const void* zq, int64_t C, int64_t D, int max_tree_depth,
+                         int32_t* slot2chain, void* zq_slot, int64_t n_slots, int32_t* n_placed,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under

@@ -81,6 +81,18 @@ struct Chain {
     for (int m = 0; m < NPL; ++m)
       if (ok(m)) p[row + tid + m * NT] = v.x[m];
   }
+  // the same at another row of a [*, D] array (a SLOT of a compacted round, see TreeRun)
+  __device__ __forceinline__ Vec<T, NPL> ld_at(const T* p, int64_t r) const {
+    Vec<T, NPL> v;
+#pragma unroll
+    for (int m = 0; m < NPL; ++m) v.x[m] = ok(m) ? p[r + tid + m * NT] : T(0);
+    return v;
+  }
+  __device__ __forceinline__ void st_at(T* p, int64_t r, const Vec<T, NPL>& v) const {
+#pragma unroll
+    for (int m = 0; m < NPL; ++m)
+      if (ok(m)) p[r + tid + m * NT] = v.x[m];
+  }
   // block-wide sums of two per-thread values, identical in every thread, fixed order
   __device__ __forceinline__ void sum2(T& a, T& b) const {
     a = wave_sum(a);
@@ -178,6 +190,12 @@ struct TreeRun {
   int32_t* n_done;        // chains that completed the span
   int64_t* done_flag;     // set to 1 by the last chain to complete (a step gate's abort word), or NULL
   double target_accept, da_t0, da_kappa, da_gamma;
+  // COMPACTED rounds (late in a span few chains are still building trees): the potential is evaluated at
+  // n_slots < C cursor rows zq_slot[n_slots, D]; slot s belongs to chain slot2chain[s] (-1: empty).  The
+  // launch has one workgroup per slot, (peq, gq) are slot-indexed, the chain's next cursor is written to its
+  // slot row as well as to its own row.  NULL: slot == chain (the full round).
+  const int32_t* slot2chain;
+  T* zq_slot;
 };
 
 // tree state of a chain at the start of transition t (nuts.py:367-434): momentum draw, energies,
@@ -186,7 +204,8 @@ template <typename T, int NW, int NPL>
 __device__ __forceinline__ void tree_begin_chain(
     const Chain<T, NW, NPL>& c, int chain, int64_t C, const Vec<T, NPL>& zc, const Vec<T, NPL>& gc,
     T pe_c, const Vec<T, NPL>& v, T eps, int multinomial, uint64_t seed, uint64_t t, uint64_t cid,
-    const TreeWs<T>& ws, T* __restrict__ zq, T* __restrict__ rq) {
+    const TreeWs<T>& ws, T* __restrict__ zq, T* __restrict__ rq, T* __restrict__ zq_slot = nullptr,
+    int64_t slot_row = 0) {
   const int64_t CD = C * c.D;
   const uint64_t ctr_base = t << 20;
   Vec<T, NPL> isq, ru0;
@@ -219,6 +238,7 @@ __device__ __forceinline__ void tree_begin_chain(
   kick_drift(zn, rn, gc, v, dir == 1 ? eps : -eps);
   c.st(zq, zn);
   c.st(rq, rn);
+  if (zq_slot != nullptr) c.st_at(zq_slot, slot_row, zn);
   if (threadIdx.x == 0) {
     ws.fscal[FS_ENERGY * C + chain] = energy_current;
     ws.fscal[FS_LOGSLICE * C + chain] = log_slice;
@@ -275,9 +295,18 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     int32_t* __restrict__ depth_out, int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out,
     int32_t* __restrict__ n_active, TreeRun<T> run) {
   __shared__ T red[2 * NW];
-  const int chain = blockIdx.x;
+  const int slot = blockIdx.x;
+  int chain = slot;
+  if constexpr (RUN) {
+    if (run.slot2chain != nullptr) {
+      chain = run.slot2chain[slot];
+      if (chain < 0) return;                         // an empty slot of a compacted round
+    }
+  }
   if (ws.iscal[IS_ACTIVE * C + chain] == 0) return;  // block-uniform
   Chain<T, NW, NPL> c{(int)threadIdx.x, D, (int64_t)chain * D, red};
+  const int64_t slot_row = (int64_t)slot * D;
+  T* const zq_slot = RUN ? run.zq_slot : nullptr;
   const int64_t CD = C * D;
   // the transition index keys the Philox draws; a launch that is replayed from a hipGraph reads it
   // from device memory (pa_nuts_tree_advance_tdev) instead of its (captured) argument; a chain of
@@ -308,8 +337,8 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     v.x[m] = c.ok(m) ? inv_mass[(int64_t)chain * im_stride + c.tid + m * c.NT] : T(1);
     sq.x[m] = Num<T>::sqrt_(v.x[m]);  // mass_matrix_sqrt_inverse
   }
-  Vec<T, NPL> zq = c.ld(zq_io), rq = c.ld(rq_io), gq = c.ld(gq_in);
-  const T pe_q = peq_in[chain];
+  Vec<T, NPL> zq = c.ld(zq_io), rq = c.ld(rq_io), gq = c.ld_at(gq_in, slot_row);
+  const T pe_q = peq_in[slot];
 
   // ---- second half-kick (integrator.py:62-63) and the base tree (nuts.py:197-248) ----------
   {
@@ -385,6 +414,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
       kick_drift(zq, rq, gq, v, eps_d);
       c.st(zq_io, zq);
       c.st(rq_io, rq);
+      if (zq_slot != nullptr) c.st_at(zq_slot, slot_row, zq);
     } else {
       // ---- the doubling is complete (nuts.py:436-503) ---------------------------------------
       const int e_dir = dir == 1 ? 1 : 0;
@@ -425,6 +455,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
           kick_drift(zn, rn, gn, v, ndir == 1 ? eps : -eps);
           c.st(zq_io, zn);
           c.st(rq_io, rn);
+          if (zq_slot != nullptr) c.st_at(zq_slot, slot_row, zn);
           if (threadIdx.x == 0) {
             ws.iscal[IS_DIR * C + chain] = ndir;
             ws.iscal[IS_LEAF * C + chain] = 0;
@@ -502,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
       if ((int64_t)span_k + 1 < K) {
         // the chain's next transition starts here (the scalars of the finished tree are dead)
         tree_begin_chain<T, NW, NPL>(c, chain, C, zc, gc, pe_c, v, eps_next, multinomial, seed,
-                                     tt + 1, cid, ws, zq_io, rq_io);
+                                     tt + 1, cid, ws, zq_io, rq_io, zq_slot, slot_row);
       } else if (threadIdx.x == 0) {
         ws.iscal[IS_ACTIVE * C + chain] = 0;
         ws.iscal[IS_DIVERGED * C + chain] = diverged;
@@ -529,6 +560,45 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     } else if constexpr (!RUN) {
       atomicAdd(n_active, 1);
     }
+  }
+}
+
+// slots of a compacted round: the chains still building a tree, in ascending order, then -1; their cursor
+// rows gathered.  One workgroup (the map is a few thousand entries at most; this runs when the host switches
+// to a smaller round, a handful of times per span).
+template <typename T>
+__global__ __launch_bounds__(1024) void nuts_tree_compact_kernel(const int32_t* __restrict__ iscal, int64_t C,
+                                                               int D, const T* __restrict__ zq,
+                                                               int32_t* __restrict__ slot2chain,
+                                                               T* __restrict__ zq_slot, int n_slots,
+                                                               int32_t* __restrict__ n_placed) {
+  __shared__ int32_t counts[1024];
+  __shared__ int32_t total;
+  const int tid = threadIdx.x;
+  const int64_t per = (C + 1023) / 1024, lo = tid * per, hi = lo + per < C ? lo + per : C;
+  int32_t mine = 0;
+  for (int64_t ch = lo; ch < hi; ++ch) mine += iscal[IS_ACTIVE * C + ch] != 0;
+  counts[tid] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    int32_t run = 0;
+    for (int i = 0; i < 1024; ++i) { const int32_t v = counts[i]; counts[i] = run; run += v; }
+    total = run;
+    *n_placed = run < n_slots ? run : n_slots;
+  }
+  __syncthreads();
+  int32_t at = counts[tid];
+  for (int64_t ch = lo; ch < hi; ++ch)
+    if (iscal[IS_ACTIVE * C + ch] != 0) {
+      if (at < n_slots) slot2chain[at] = (int32_t)ch;
+      ++at;
+    }
+  for (int s = total + tid; s < n_slots; s += 1024) slot2chain[s] = -1;
+  __syncthreads();
+  const int filled = total < n_slots ? total : n_slots;
+  for (int64_t e = tid; e < (int64_t)filled * D; e += 1024) {
+    const int s = (int)(e / D), d = (int)(e % D);
+    zq_slot[e] = zq[(int64_t)slot2chain[s] * D + d];
   }
 }
 
@@ -598,8 +668,9 @@ template <typename T>
 static int tree_run_advance(void* z, void* pe, void* grad, void* zq, void* rq, const void* gq,
                             const void* peq, const void* inv_mass, int64_t im_stride, int64_t C,
                             int64_t D, int max_depth, int multinomial, uint64_t seed,
-                            uint64_t chain_offset, TreeRun<T> run, void* accept_prob, int32_t* nl,
-                            int32_t* dp, int32_t* dv, int32_t* ac, void* workspace, hipStream_t s) {
+                            uint64_t chain_offset, TreeRun<T> run, int64_t n_slots, void* accept_prob,
+                            int32_t* nl, int32_t* dp, int32_t* dv, int32_t* ac, void* workspace,
+                            hipStream_t s) {
   TreePlan pl;
   tree_plan(D, &pl);
   TreeWs<T> ws = tree_ws<T>(workspace, C, D, max_depth);
@@ -607,7 +678,7 @@ static int tree_run_advance(void* z, void* pe, void* grad, void* zq, void* rq, c
   const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
 #define PA_CALL(TT, NW, NPL)                                                                      \
-  hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL, true>), dim3((unsigned)C),             \
+  hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL, true>), dim3((unsigned)n_slots),       \
                      dim3(64 * NW), 0, s, (TT*)z, (TT*)pe, (TT*)grad, (TT*)zq, (TT*)rq,           \
                      (const TT*)gq, (const TT*)peq, (const TT*)inv_mass, im_stride,               \
                      (const TT*)run.step, C, (int)D, max_depth, multinomial, seed, (uint64_t)0,   \
@@ -737,11 +808,15 @@ int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq,
                              uint64_t chain_offset, const int64_t* ctl, void* da_state,
                              double target_accept, void* welford, void* mean_accept,
                              int64_t* counters, int32_t* tc, int32_t* n_done, int64_t* done_flag,
+                             const int32_t* slot2chain, void* zq_slot, int64_t n_slots,
                              void* accept_prob, int32_t* n_leapfrog, int32_t* depth,
                              int32_t* diverging, int32_t* accepted, void* workspace,
                              size_t workspace_bytes, pa_stream_t stream) {
   const uint64_t t = 0;
   PA_TREE_COMMON_CHECKS("nuts_tree_run_advance")
+  PA_REQUIRE((slot2chain == nullptr) == (zq_slot == nullptr), "nuts_tree_run_advance: slot2chain and zq_slot go together");
+  if (slot2chain == nullptr) n_slots = C;
+  PA_REQUIRE(n_slots >= 1 && n_slots <= C, "nuts_tree_run_advance: n_slots=%lld outside [1, C]", (long long)n_slots);
   PA_REQUIRE(z && pe && grad && zq && rq && gq && peq && inv_mass && step && ctl && da_state &&
                  welford && mean_accept && counters && tc && n_done && accept_prob && n_leapfrog &&
                  depth && diverging && accepted,
@@ -752,19 +827,41 @@ int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq,
   if (dtype == PA_F32) {
     pa::TreeRun<float> run{ctl, (float*)step, (float*)da_state, (float*)welford,
                            (float*)mean_accept, counters, tc, n_done, done_flag, target_accept,
-                           10.0, 0.75, 0.05};   // DualAveraging defaults (ops/dual_averaging.py)
+                           10.0, 0.75, 0.05,   // DualAveraging defaults (ops/dual_averaging.py)
+                           slot2chain, (float*)zq_slot};
     return pa::tree_run_advance<float>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, C, D,
-                                       max_tree_depth, use_multinomial, seed, chain_offset, run,
+                                       max_tree_depth, use_multinomial, seed, chain_offset, run, n_slots,
                                        accept_prob, n_leapfrog, depth, diverging, accepted,
                                        workspace, s);
   }
   pa::TreeRun<double> run{ctl, (double*)step, (double*)da_state, (double*)welford,
                           (double*)mean_accept, counters, tc, n_done, done_flag, target_accept,
-                          10.0, 0.75, 0.05};
+                          10.0, 0.75, 0.05, slot2chain, (double*)zq_slot};
   return pa::tree_run_advance<double>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, C, D,
-                                      max_tree_depth, use_multinomial, seed, chain_offset, run,
+                                      max_tree_depth, use_multinomial, seed, chain_offset, run, n_slots,
                                       accept_prob, n_leapfrog, depth, diverging, accepted,
                                       workspace, s);
+}
+
+int pa_nuts_tree_compact(int dtype, const void* zq, int64_t C, int64_t D, int max_tree_depth,
+                         int32_t* slot2chain, void* zq_slot, int64_t n_slots, int32_t* n_placed,
+                         void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  const uint64_t t = 0;
+  const int64_t im_stride_row = 0;
+  PA_TREE_COMMON_CHECKS("nuts_tree_compact")
+  PA_REQUIRE(zq && slot2chain && zq_slot && n_placed && n_slots >= 1 && n_slots <= C,
+             "nuts_tree_compact: bad arguments");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32) {
+    pa::TreeWs<float> ws = pa::tree_ws<float>(workspace, C, D, max_tree_depth);
+    hipLaunchKernelGGL((pa::nuts_tree_compact_kernel<float>), dim3(1), dim3(1024), 0, s, ws.iscal, C, (int)D,
+                       (const float*)zq, slot2chain, (float*)zq_slot, (int)n_slots, n_placed);
+  } else {
+    pa::TreeWs<double> ws = pa::tree_ws<double>(workspace, C, D, max_tree_depth);
+    hipLaunchKernelGGL((pa::nuts_tree_compact_kernel<double>), dim3(1), dim3(1024), 0, s, ws.iscal, C, (int)D,
+                       (const double*)zq, slot2chain, (double*)zq_slot, (int)n_slots, n_placed);
+  }
+  return pa::check_launch("nuts_tree_compact_kernel");
 }
 
 }  // extern "C"

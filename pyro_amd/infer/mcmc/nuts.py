@@ -48,6 +48,8 @@ class NUTS(HMC):
         self.use_persistent = True   # many transitions per launch on the fused Gaussian path
         self.use_async_chains = True # model / generic potentials: spans of transitions without lock step
         self.rounds_per_replay = 16  # tree rounds in the captured graph of the asynchronous path
+        self.compact_chains = True   # late in a span: rounds over the chains still active only
+        self.min_slots = 64          # smallest compacted round (the GLM kernels take 64 columns per pass)
         self._launch_hook = None     # called before every fused launch (bench: event brackets)
 
     def release_graphs(self):
@@ -55,6 +57,7 @@ class NUTS(HMC):
         self._round_graph = self._step_buf = self._mass_buf = None
         self._round_calls = 0
         self._span_graph = self._span_keep = None
+        self._span_graphs = {}
         self._span_calls = 0
 
     def _prepare_paths(self):
@@ -74,7 +77,10 @@ class NUTS(HMC):
         self._step_buf = self._mass_buf = self._round_graph = None     # jit_compile round graph
         self._round_calls, self._round_failed = 0, False
         self._span_graph = self._span_keep = None                      # asynchronous spans
+        self._span_graphs = {}                                         # rounds per replay size -> graph
         self._span_calls, self._span_failed, self._span_replays = 0, False, 0
+        self._span_rounds = 0                                          # slot-rounds evaluated (occupancy)
+        self._span_compactions = 0
         self._da_buf = self._wf_buf = None
         self._tree_depth_sum = torch.zeros((), dtype=torch.int64, device=self._z.device)
         self._counters = torch.zeros((3, self.num_chains), dtype=torch.int64,
@@ -170,7 +176,7 @@ class NUTS(HMC):
                 or self._mass_buf.shape != inv_mass.shape:
             self._step_buf, self._mass_buf = step.clone(), inv_mass.clone()
             self._round_graph, self._round_calls = None, 0
-            self._span_graph, self._span_calls = None, 0
+            self._span_graph, self._span_calls, self._span_graphs = None, 0, {}
             self._tree = None
         else:
             if step is not self._step_buf:
@@ -209,7 +215,7 @@ class NUTS(HMC):
         elif tree.inv_mass is not inv_mass or tree.step is not step:
             tree.inv_mass, tree.step = inv_mass, step
             tree.im_stride = tree.D if inv_mass.dim() == 2 else 0
-            self._span_graph = None
+            self._span_graph, self._span_graphs = None, {}
         if self._da_buf is None:
             self._da_buf = torch.zeros((C, 5), dtype=self._z.dtype, device=self._z.device)
             self._wf_buf = torch.zeros((C, 2, D), dtype=self._z.dtype, device=self._z.device)
@@ -239,11 +245,11 @@ class NUTS(HMC):
             self._divergences.extend(div[i] for i in range(k))
         return k
 
-    def _span_round(self, tree, potential):
-        pe, grad = potential(tree.zq)
+    def _span_round(self, tree, potential, slots=None):
+        pe, grad = potential(tree.zq if slots is None else slots[1])
         tree.run_advance(pe.detach().contiguous(), grad.detach().contiguous(), self._da_buf,
                          self._adapter.target_accept_prob, self._wf_buf, self._mean_accept_prob,
-                         self._counters)
+                         self._counters, slots=slots)
         return pe, grad
 
     def _want_capture(self):
@@ -253,32 +259,58 @@ class NUTS(HMC):
             return True
         return CAPTURE_ROUNDS is True or CAPTURE_ROUNDS == "auto"
 
+    def _slot_sizes(self):
+        """Round sizes a span may shrink to: C, C/2, C/4, ... down to ``min_slots``."""
+        C, sizes = self.num_chains, []
+        n = C
+        while self.compact_chains and n % 2 == 0 and n // 2 >= self.min_slots:
+            n //= 2
+            sizes.append(n)
+        return sizes
+
     def _run_rounds(self, tree):
         """Rounds until every chain has completed the span.  After a few eager rounds a block of
         ``rounds_per_replay`` rounds is captured into ONE hipGraph (the span's parameters reach the
         kernels through device memory, so the graph serves every later span too); the tree kernel
         of the round that completes the span sets the abort word of a step gate, and the
-        gate-aware kernels of the rounds still queued behind it return at once."""
+        gate-aware kernels of the rounds still queued behind it return at once.
+
+        Per-chain step sizes differ, so chains complete a span at different times; once at most half
+        of the round's slots hold a chain that is still building trees the round is COMPACTED: the
+        potential is evaluated at the cursors of the active chains only (kernels.NutsTree.compact; one
+        captured graph per round size C/2, C/4, ...)."""
         base = getattr(self._potential, "base", self._potential)
+        C = self.num_chains
+        sizes = self._slot_sizes()
+        cur, slots = C, None
         polls = 0
         while True:
-            graph = self._span_graph
+            graph = self._span_graphs.get(cur)
             if graph is None and self._want_capture() and self._span_calls >= 4:
-                graph = self._capture_span(tree, base)
+                graph = self._capture_span(tree, base, slots, cur)
             if graph is not None:
                 graph.replay()
                 self._span_replays += 1
+                self._span_rounds += self.rounds_per_replay * cur
             else:
                 for _ in range(self.sync_every):
-                    self._span_round(tree, self._potential)
+                    self._span_round(tree, self._potential, slots)
                     self._span_calls += 1
+                self._span_rounds += self.sync_every * cur
             polls += 1
-            if tree.span_done():
+            done = tree.chains_done()
+            if done >= C:
                 break
+            active = C - done
+            fit = [n for n in sizes if n >= active and n < cur]
+            if fit:
+                cur = min(fit)
+                slots = tree.compact(cur)
+                self._span_compactions += 1
             if polls > (1 << 22):
                 raise RuntimeError("pyro_amd: NUTS span did not complete")
 
-    def _capture_span(self, tree, base):
+    def _capture_span(self, tree, base, slots=None, size=None):
         import os
         import warnings
         from ...ops import fuser
@@ -287,7 +319,7 @@ class NUTS(HMC):
             # one eager round under the fuser: the element-wise kernels of a round (the glue between the
             # model's fused sites and their autograd duals) are generated and compiled before the capture
             with fuser.scope():
-                self._span_round(tree, base)
+                self._span_round(tree, base, slots)
             for attempt in (0, 1):
                 compiled = fuser.STATS["compiled"]
                 torch.cuda.synchronize()
@@ -298,7 +330,7 @@ class NUTS(HMC):
                     with torch.cuda.graph(graph):
                         for _ in range(self.rounds_per_replay):
                             with fuser.scope():
-                                keep.append(self._span_round(tree, base))
+                                keep.append(self._span_round(tree, base, slots))
                     break
                 except Exception:  # noqa: BLE001
                     # (a kernel generated during the capture loaded its module there: cached now, once more)
@@ -306,7 +338,9 @@ class NUTS(HMC):
                         raise
                 finally:
                     lib.pa_gate_scope(None)
-            self._span_graph, self._span_keep = graph, keep
+            self._span_graphs[size if size is not None else self.num_chains] = graph
+            self._span_graph = graph
+            self._span_keep = (getattr(self, "_span_keep", None) or []) + [keep]
             return graph
         except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
             if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):

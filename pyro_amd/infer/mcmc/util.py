@@ -217,7 +217,7 @@ class _PEMaker:
         self.model, self.args, self.kwargs = model, model_args, model_kwargs
         self.transforms = transforms
         self.mpn = max_plate_nesting
-        self.C = num_chains
+        self.C = self._rows = num_chains
         self.batch_ndims = batch_ndims   # site -> number of batch dims of its distribution
         self.enum = False                # the model has discrete latent sites to sum out
 
@@ -246,7 +246,7 @@ class _PEMaker:
 
     def _chain_sum(self, site):
         fn, value, scale, mask = site["fn"], site["value"], site["scale"], site["mask"]
-        C = self.C
+        C = self._rows
         if mask is False:
             return 0.0
         if mask is True:
@@ -283,7 +283,9 @@ class _PEMaker:
                 log_joint = log_joint - torch.sum(
                     t.log_abs_det_jacobian(constrained[name], params[name]))
             return -log_joint
-        C = self.C
+        # the number of chain rows of THIS evaluation: num_chains, or fewer in a compacted round of NUTS
+        # (the cursors of the chains still building trees only)
+        C = self._rows = int(next(iter(params.values())).shape[0]) if params else self.C
         constrained = {k: self.transforms[k].inv(v) for k, v in params.items()}
         cond = {k: self._chain_value(k, v) for k, v in constrained.items()}
 

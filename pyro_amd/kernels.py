@@ -1607,12 +1607,32 @@ class NutsTree:
             _ptr(self.tc), _ptr(self.n_done), _ptr(self.gate[1:]), _ptr(self.ws), self.nbytes,
             _stream()))
 
-    def run_advance(self, peq, gq, da_state, target_accept, welford, mean_accept, counters):
+    def compact(self, n_slots):
+        """Slots of a COMPACTED round: the chains still building a tree (ascending, -1 pads) and their
+        cursor rows.  Returns (slot2chain int32[n_slots], zq_slot [n_slots, D]) -- persistent per size (a
+        captured graph of rounds of that size holds their addresses) -- after refreshing them; the caller
+        makes sure n_slots >= the number of active chains (``n_placed()``)."""
+        bufs = getattr(self, "_slots", None)
+        if bufs is None:
+            bufs = self._slots = {}
+            self._n_placed = torch.zeros((1,), dtype=torch.int32, device=self.z.device)
+        if n_slots not in bufs:
+            bufs[n_slots] = (torch.full((n_slots,), -1, dtype=torch.int32, device=self.z.device),
+                             torch.zeros((n_slots, self.D), dtype=self.z.dtype, device=self.z.device))
+        s2c, zqs = bufs[n_slots]
+        check(_lib.load().pa_nuts_tree_compact(
+            self.dt, _ptr(self.zq), self.C, self.D, self.max_tree_depth, _ptr(s2c), _ptr(zqs), n_slots,
+            _ptr(self._n_placed), _ptr(self.ws), self.nbytes, _stream()))
+        return s2c, zqs
+
+    def run_advance(self, peq, gq, da_state, target_accept, welford, mean_accept, counters, slots=None):
         """One round of a span: every live chain consumes (peq, gq) at its cursor; a chain whose
-        tree finishes adapts, stores its draw and begins its next transition in the same launch."""
+        tree finishes adapts, stores its draw and begins its next transition in the same launch.
+        ``slots`` = (slot2chain, zq_slot) of ``compact``: a compacted round, (peq, gq) per slot."""
         _require_gpu(peq, gq, da_state, welford, mean_accept, counters)
+        n_slots = self.C if slots is None else slots[0].numel()
         assert peq.is_contiguous() and gq.is_contiguous() and gq.dtype == self.z.dtype
-        assert peq.dtype == self.z.dtype and gq.shape == self.z.shape and peq.numel() == self.C
+        assert peq.dtype == self.z.dtype and gq.shape == (n_slots, self.D) and peq.numel() == n_slots
         assert da_state.shape == (self.C, 5) and welford.shape == (self.C, 2, self.D)
         assert da_state.dtype == welford.dtype == mean_accept.dtype == self.z.dtype
         assert counters.shape == (3, self.C) and counters.dtype == torch.int64
@@ -1624,12 +1644,17 @@ class NutsTree:
             self.C, self.D, self.max_tree_depth, self.multinomial, self.seed, self.chain_offset,
             _ptr(self.ctl), _ptr(da_state), float(target_accept), _ptr(welford), _ptr(mean_accept),
             _ptr(counters), _ptr(self.tc), _ptr(self.n_done), _ptr(self.gate[1:]),
+            None if slots is None else _ptr(slots[0]), None if slots is None else _ptr(slots[1]), n_slots,
             _ptr(self.accept_prob), _ptr(self.ints[0]), _ptr(self.ints[1]), _ptr(self.ints[2]),
             _ptr(self.ints[3]), _ptr(self.ws), self.nbytes, _stream()))
 
+    def chains_done(self):
+        """How many chains have completed their span (host synchronisation)."""
+        return int(self.n_done.item())
+
     def span_done(self):
         """True when every chain has completed its span (host synchronisation)."""
-        return int(self.n_done.item()) >= self.C
+        return self.chains_done() >= self.C
 
     def stats(self):
         return {"accept_prob": self.accept_prob, "n_leapfrog": self.ints[0], "depth": self.ints[1],

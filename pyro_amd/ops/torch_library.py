@@ -83,8 +83,13 @@ def _register():
         _, gw, gb, _ws = output
         ctx.save_for_backward(gw, gb)
         ctx.has_b = inputs[3] is not None            # (.., .., w, b, ...) in both schemas
+        # only ll is differentiated: without this the engine hands over ZEROS for the other three outputs --
+        # the workspace among them, a fill of megabytes per backward pass (9 us of a NUTS round)
+        ctx.set_materialize_grads(False)
 
     def _grads(ctx, g_ll):
+        if g_ll is None:
+            return None, None
         gw, gb = ctx.saved_tensors
         dw, db = torch.ops.pyro_amd.glm_chain(g_ll, gw, gb)
         return (dw if ctx.needs_input_grad[2] else None,

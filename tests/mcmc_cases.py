@@ -369,7 +369,8 @@ def run_persistent_equals_stepwise(device, dtype, rtol, C=6, D=9, warmup=40, S=6
     assert abs(a[4]["mean tree depth"] - b[4]["mean tree depth"]) < 1e-12
 
 
-def run_async_equals_lockstep(device, dtype, rtol, C=6, D=9, warmup=40, S=6, multinomial=True, adapt=True):
+def run_async_equals_lockstep(device, dtype, rtol, C=6, D=9, warmup=40, S=6, multinomial=True, adapt=True,
+                              min_slots=None):
     """MCMC(NUTS(generic potential)) with step-size + mass adaptation: spans of ASYNCHRONOUS chains
     (a chain that finishes a tree adapts and starts its next tree in the same launch, in-kernel dual
     averaging / Welford) against the lock-step per-transition path with host adaptation.  The Philox
@@ -388,17 +389,22 @@ def run_async_equals_lockstep(device, dtype, rtol, C=6, D=9, warmup=40, S=6, mul
         kernel = NUTS(potential_fn=LogCoshPotential(Lam), max_tree_depth=5, step_size=1.0 if adapt else 0.15,
                       use_multinomial_sampling=multinomial, adapt_step_size=adapt, adapt_mass_matrix=adapt)
         kernel.use_async_chains = async_chains
+        kernel.compact_chains = min_slots is not None      # late in a span: rounds over the active chains only
+        if min_slots is not None:
+            kernel.min_slots, kernel.sync_every, kernel.rounds_per_replay = min_slots, 2, 4
         mcmc = MCMC(kernel, num_samples=S, warmup_steps=warmup, num_chains=C,
                     initial_params={"x": z0.clone()})
         mcmc.run()
         assert kernel.bulk_ready == async_chains
+        if async_chains and min_slots is not None:
+            assert kernel._span_compactions > 0, "no round was compacted"
         outs.append((mcmc.get_samples(group_by_chain=True)["x"].clone(),
                      kernel.step_size.clone(), kernel.mass_matrix_adapter.inverse_mass_matrix.clone(),
                      kernel.num_leapfrog_steps, mcmc.diagnostics(), kernel._mean_accept_prob.clone()))
     fuser.ENABLED["on"] = fused_glue
     a, b = outs
     assert a[3] == b[3], (a[3], b[3])                       # identical trees
-    if not adapt:
+    if not adapt and min_slots is None:
         # no host-side adaptation arithmetic to differ from the kernel's: the two schedules run the same
         # kernels on the same numbers
         rtol = 0.0

@@ -400,9 +400,27 @@ class NutsTree:
         self._o.run_begin(samples=self._sn, div_flags=self._dn, **self._span)
         self._sync()
 
-    def run_advance(self, peq, gq, da_state, target_accept, welford, mean_accept, counters):
+    def compact(self, n_slots):
+        """kernels.NutsTree.compact: the chains still building a tree (ascending, -1 pads), their cursors."""
+        active = [c for c in range(self.C) if self._o.chains[c].active]
+        assert len(active) <= n_slots
+        s2c = torch.full((n_slots,), -1, dtype=torch.int32)
+        s2c[:len(active)] = torch.tensor(active, dtype=torch.int32)
+        zqs = torch.zeros((n_slots, self.D), dtype=self.z.dtype)
+        zqs[:len(active)] = self.zq[active]
+        return s2c, zqs
+
+    def run_advance(self, peq, gq, da_state, target_accept, welford, mean_accept, counters, slots=None):
         arrs = [_np(x).copy() for x in (da_state, welford, mean_accept, counters)]
-        self._o.run_advance(_np(peq), _np(gq), arrs[0], target_accept, arrs[1], arrs[2], arrs[3])
+        if slots is not None:          # a compacted round: (peq, gq) per slot -> per chain
+            s2c = slots[0].tolist()
+            pf, gf = np.zeros(self.C, _np(peq).dtype), np.zeros((self.C, self.D), _np(gq).dtype)
+            for s_, c in enumerate(s2c):
+                if c >= 0:
+                    pf[c], gf[c] = _np(peq)[s_], _np(gq)[s_]
+            self._o.run_advance(pf, gf, arrs[0], target_accept, arrs[1], arrs[2], arrs[3])
+        else:
+            self._o.run_advance(_np(peq), _np(gq), arrs[0], target_accept, arrs[1], arrs[2], arrs[3])
         for t, a in zip((da_state, welford, mean_accept, counters), arrs):
             t.copy_(torch.as_tensor(a))
         self.step.copy_(torch.as_tensor(self._stepn))
@@ -412,6 +430,13 @@ class NutsTree:
         if div is not None:
             div.copy_(torch.as_tensor(self._dn))
         self._sync()
+        if slots is not None:          # a chain writes its next cursor to its slot row too
+            for s_, c in enumerate(slots[0].tolist()):
+                if c >= 0:
+                    slots[1][s_] = self.zq[c]
+
+    def chains_done(self):
+        return self._o.n_done
 
     def span_done(self):
         return self._o.span_done()

@@ -201,6 +201,14 @@ def test_asynchronous_chains_are_bitwise_the_lock_step_chains_without_adaptation
     mc.run_async_equals_lockstep(gpu, dtype, 0.0, C=7, D=D, warmup=5, S=25, adapt=False)
 
 
+@pytest.mark.parametrize("D", [9, 200])
+def test_compacted_rounds_leave_the_chains_unchanged(gpu, D):
+    """Rounds over the chains still active only (sizes C/2, C/4, captured per size): the lock-step chains to
+    rounding (a batched potential of another batch size may round its sums differently)."""
+    mc.run_async_equals_lockstep(gpu, torch.float64, 1e-6, C=16, D=D, warmup=40, S=8, min_slots=2)
+    mc.run_async_equals_lockstep(gpu, torch.float64, 1e-9, C=16, D=D, warmup=4, S=20, adapt=False, min_slots=4)
+
+
 def test_asynchronous_chains_slice_sampling(gpu):
     mc.run_async_equals_lockstep(gpu, torch.float64, 1e-6, C=5, D=7, warmup=30, S=5, multinomial=False)
 

@@ -210,6 +210,14 @@ def test_asynchronous_chains_equal_lock_step_chains(_cpu_backend, multinomial):
                                  multinomial=multinomial)
 
 
+def test_compacted_rounds_leave_the_chains_unchanged(_cpu_backend):
+    """Late in a span the potential is evaluated at the cursors of the chains still building trees only
+    (round sizes C/2, C/4): the same chains as the lock-step schedule."""
+    # (to rounding: the batched potential of another batch size rounds its matrix product differently)
+    mc.run_async_equals_lockstep(torch.device("cpu"), torch.float64, 1e-7, C=8, D=5, warmup=30, S=6,
+                                 min_slots=2)
+
+
 def test_asynchronous_chains_without_adaptation_are_the_lock_step_chains_exactly(_cpu_backend):
     mc.run_async_equals_lockstep(torch.device("cpu"), torch.float64, 0.0, C=3, D=5, warmup=3, S=8, adapt=False)
 

@@ -16,16 +16,17 @@ from pyro_amd.infer.mcmc import NUTS  # noqa: E402
 from tests import mcmc_cases as mc  # noqa: E402
 
 
-def run(X, y, C, warmup, samples, max_tree_depth=6, lockstep=False, jit=False, seed=1, model=None):
+def run(X, y, C, warmup, samples, max_tree_depth=6, lockstep=False, jit=False, seed=1, model=None, compact=True):
     """-> dict(leapfrog_per_s, leapfrogs, seconds, rounds, mean_depth, step_size) of the sampling phase."""
     with pyro.validation_enabled(False):        # (MCMC.run's default: disable_validation=True)
-        return _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model)
+        return _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model, compact)
 
 
-def _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model):
+def _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model, compact):
     pyro.set_rng_seed(seed)
     kernel = NUTS(model or mc.logreg_mcmc_model, max_tree_depth=max_tree_depth, jit_compile=jit)
     kernel.use_async_chains = not lockstep
+    kernel.compact_chains = compact
     kernel.num_chains = C
     kernel.setup(warmup, X, y)
     dev = X.device
@@ -61,6 +62,7 @@ def _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model):
                replays=getattr(kernel, "_span_replays", 0) - r0,
                rounds_per_replay=kernel.rounds_per_replay,
                step_size=float(kernel.step_size.mean()), graphed=getattr(kernel, "_span_graph", None) is not None,
+               compactions=getattr(kernel, "_span_compactions", 0),
                posterior_mean_w0=float(buf[:, :, 0].mean()))
     kernel.release_graphs()
     return out
@@ -74,6 +76,7 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--lockstep", action="store_true")
+    ap.add_argument("--no-compact", action="store_true")
     ap.add_argument("--both", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -83,7 +86,7 @@ if __name__ == "__main__":
     yc = (torch.rand((N,), generator=g) < torch.sigmoid(Xc @ torch.randn(D, generator=g) * 0.3)).float()
     X, y = Xc.to(dev), yc.to(dev)
     for lock in ((True, False) if a.both else (a.lockstep,)):
-        r = run(X, y, C, a.warmup, a.samples, a.depth, lockstep=lock)
+        r = run(X, y, C, a.warmup, a.samples, a.depth, lockstep=lock, compact=not a.no_compact)
         print("N=%d C=%d %s: sampling %.3f s, %d leapfrogs, %.0f leapfrog/s (%.0f rounds/s if every round served all "
               "chains); warm-up %.2f s; %s" % (N, C, "lock-step" if lock else "async spans", r["seconds"],
                                                r["leapfrogs"], r["leapfrog_per_s"], r["leapfrog_per_s"] / C,
