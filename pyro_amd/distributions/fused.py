@@ -360,13 +360,15 @@ class _DirichletLogProb(torch.autograd.Function):
 
 
 def dirichlet_log_prob(value, concentration):
-    return _DirichletLogProb.apply(value, concentration)
+    return _DirichletLogProb.invoke(value, concentration)
 
 
 @_dispatcher_op("normal_rsample")
 class _NormalRsample(torch.autograd.Function):
     """value = loc + scale * eps with eps from the Philox stream, ONE launch (pa_normal_rsample);
     backward: d loc = g, d scale = g * eps (torch: normal.py:83-86)."""
+    volatile_args = (3, 4)      # Philox seed / block offsets: new on every call (ops/torch_library.py)
+
 
     @staticmethod
     def forward(ctx, loc, scale, shape, seed, offset, offset_dev):
@@ -391,6 +393,8 @@ class _StandardGamma(torch.autograd.Function):
     produces d g / d concentration (pa_gamma_rsample: Marsaglia-Tsang + the implicit
     reparameterisation gradient); backward = one product and the un-broadcast.  torch:
     _standard_gamma / _standard_gamma_grad behind Gamma.rsample (gamma.py:80-88)."""
+    volatile_args = (2, 3)      # Philox seed / block offsets: new on every call (ops/torch_library.py)
+
 
     @staticmethod
     def forward(ctx, concentration, shape, seed, offset, offset_dev):
@@ -415,7 +419,7 @@ def standard_gamma(concentration, shape):
     from .. import rng
     shape = torch.Size(shape)
     seed, off, off_dev = rng.reserve_blocks(shape.numel())
-    return _StandardGamma.apply(concentration, shape, seed, off, off_dev)
+    return _StandardGamma.invoke(concentration, shape, seed, off, off_dev)
 
 
 @_dispatcher_op("exp_site")
@@ -465,7 +469,7 @@ class _ExpLower(torch.autograd.Function):
 
 
 def exp_lower(u, lower=0.0):
-    return _ExpLower.apply(u, float(lower))
+    return _ExpLower.invoke(u, float(lower))
 
 
 def exp_lower_bound_of(transform):
@@ -489,7 +493,7 @@ def exp_site(u, event_rank, lower=0.0):
     cols = 1
     for d in u.shape[u.dim() - event_rank:] if event_rank else ():
         cols *= int(d)
-    return _ExpSite.apply(u, cols, float(lower), int(event_rank))
+    return _ExpSite.invoke(u, cols, float(lower), int(event_rank))
 
 
 @_dispatcher_op("drawn_score")
@@ -512,7 +516,7 @@ class _DrawnScore(torch.autograd.Function):
 
 
 def drawn_score(z, loc, scale, P, coef):
-    return _DrawnScore.apply(scale, z, loc, P, coef)
+    return _DrawnScore.invoke(scale, z, loc, P, coef)
 
 
 @_dispatcher_op("meanfield_normal_sample")
@@ -522,6 +526,8 @@ class _MeanFieldSample(torch.autograd.Function):
     (pa_meanfield_normal_sample) and ONE backward (pa_meanfield_normal_sample_bwd).  Inputs are the
     unconstrained parameter leaves (loc_0, rho_0, loc_1, rho_1, ...); outputs per site
     (z [P, n], scale [n], loc_out [n])."""
+    volatile_args = (1, 2)      # Philox seed / block offsets: new on every call (ops/torch_library.py)
+
 
     @staticmethod
     def forward(ctx, P, seed, offsets, offset_dev, *params):
@@ -609,7 +615,7 @@ def meanfield_sample(locs, rhos, P):
     params = []
     for loc, rho in zip(locs, rhos):
         params += [loc, rho]
-    out = _MeanFieldSample.apply(P, seed, tuple(offsets), off_dev, *params)
+    out = _MeanFieldSample.invoke(P, seed, tuple(offsets), off_dev, *params)
     return [tuple(out[3 * i:3 * i + 3]) for i in range(len(locs))]
 
 
@@ -618,6 +624,8 @@ class _MvnTrilSample(torch.autograd.Function):
     """Full-covariance Normal guide draw: z [P, n] and log q(z) [P] from the unconstrained leaves
     (loc, rho, A) in ONE launch (pa_mvn_tril_sample), their gradients in ONE (.._bwd), added
     straight into the parameters' dense .grad buffers when those exist (see _MeanFieldSample)."""
+    volatile_args = (1, 2)      # Philox seed / block offsets: new on every call (ops/torch_library.py)
+
 
     @staticmethod
     def forward(ctx, P, seed, offset, offset_dev, eps, loc, rho, A):
@@ -654,9 +662,9 @@ def mvn_tril_sample(loc, rho, A, shape):
     P = torch.Size(shape).numel() // n
     if rng.normal is not rng._default_normal:
         eps = rng.normal(tuple(shape), loc.dtype, loc.device).reshape(P, n).contiguous()
-        return _MvnTrilSample.apply(P, 0, 0, None, eps, loc, rho, A)
+        return _MvnTrilSample.invoke(P, 0, 0, None, eps, loc, rho, A)
     seed, off, off_dev = rng.reserve(P * n, loc.dtype)
-    return _MvnTrilSample.apply(P, seed, off, off_dev, None, loc, rho, A)
+    return _MvnTrilSample.invoke(P, seed, off, off_dev, None, loc, rho, A)
 
 
 def normal_rsample(loc, scale, shape):
@@ -671,7 +679,7 @@ def normal_rsample(loc, scale, shape):
         return loc + eps * scale
     n = shape.numel()
     seed, off, off_dev = rng.reserve(n, loc.dtype)
-    return _NormalRsample.apply(loc, scale, shape, seed, off, off_dev)
+    return _NormalRsample.invoke(loc, scale, shape, seed, off, off_dev)
 
 
 # ---- many small sites in one launch ---------------------------------------------------------------
@@ -969,20 +977,20 @@ class SiteBatch:
                 meta.append((_lib.SITE_NONE, 1, None, 0.0, None))
                 tensors.append(t)
             extras.append((pos, gt, coef))
-        out = _MultiLogProbSum.apply(tuple(meta), tuple(extras), float(coef_all), *tensors)
+        out = _MultiLogProbSum.invoke(tuple(meta), tuple(extras), float(coef_all), *tensors)
         if self.const != 0.0:
             out = out + coef_all * self.const
         return out
 
 
 def log_prob(dist_id, value, p0, p1=None):
-    return _LogProb.apply(dist_id, value, p0, p1)
+    return _LogProb.invoke(dist_id, value, p0, p1)
 
 
 def log_prob_sum(dist_id, value, p0, p1=None, mask=None, scale=1.0):
     if mask is not None and mask.dtype != torch.bool:
         mask = mask.bool()
-    return _LogProbSum.apply(dist_id, value, p0, p1, mask, float(scale))
+    return _LogProbSum.invoke(dist_id, value, p0, p1, mask, float(scale))
 
 
 @_dispatcher_op("glm_bernoulli_ll")
@@ -1014,7 +1022,7 @@ def glm_bernoulli_ll(X, y, w, b=None, mask=None, scale=1.0):
         from ..ops import torch_library
         if torch_library.available():
             return torch_library.glm_bernoulli_ll(X, y, w, b, mask, scale)
-    return _GlmBernoulliSum.apply(X, y, w, b, mask, float(scale))
+    return _GlmBernoulliSum.invoke(X, y, w, b, mask, float(scale))
 
 
 @_dispatcher_op("glm_bernoulli_grouped_ll")
@@ -1038,4 +1046,4 @@ class _GlmBernoulliGroupedSum(torch.autograd.Function):
 
 
 def glm_bernoulli_grouped_ll(X, y, w, b, mask, scale, segs):
-    return _GlmBernoulliGroupedSum.apply(X, y, w, b, mask, float(scale), segs)
+    return _GlmBernoulliGroupedSum.invoke(X, y, w, b, mask, float(scale), segs)

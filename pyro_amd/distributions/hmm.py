@@ -99,7 +99,7 @@ class DiscreteHMM(TorchDistribution):
             pair = pair[0].contiguous() if pair.shape[0] == 1 else pair.contiguous()
         else:
             pair = trans.expand(batch + (T, K, K)).reshape(B, T, K, K).contiguous()
-        return _LogChain.apply(unary, pair).reshape(batch)
+        return _LogChain.invoke(unary, pair).reshape(batch)
 
     def sample(self, sample_shape=torch.Size()):
         raise NotImplementedError("DiscreteHMM.sample is not built in this backend (log_prob only)")

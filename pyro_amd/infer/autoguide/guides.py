@@ -505,7 +505,7 @@ class AutoContinuous(AutoGuide):
         sites = list(self.prototype_trace.iter_stochastic_nodes())
         sizes = tuple(_product(self._unconstrained_shapes[name]) for name, _ in sites)
         assert sum(sizes) == latent.size(-1)
-        parts = _SplitLatent.apply(latent, sizes) if latent.requires_grad else \
+        parts = _SplitLatent.invoke(latent, sizes) if latent.requires_grad else \
             torch.split(latent, sizes, dim=-1)
         for (name, site), part in zip(sites, parts):
             constrained_shape = site["value"].shape

@@ -208,7 +208,7 @@ def _try_fused_chain(terms, sum_ids):
     nb = len(batch)
     U = U.permute(tuple(range(2, 2 + nb)) + (0, 1)).reshape(B, T, K).contiguous()
     P = P.permute(tuple(range(3, 3 + nb)) + (0, 1, 2)).reshape(B, T - 1, K, K).contiguous()
-    return _LogChain.apply(U, P).reshape(tuple(batch))
+    return _LogChain.invoke(U, P).reshape(tuple(batch))
 
 
 FUSED_SUMPRODUCT = True       # eliminations go through pa_logsumexp_terms (one pass, no frame tensor)
@@ -272,7 +272,7 @@ def _sumproduct(terms, sum_ids):
                                                         + tuple(x.shape[m:])) for x in aligned]
             frame = tuple(torch.broadcast_shapes(*(x.shape for x in padded)))
             if len(frame) <= 6 and all(s > 0 for s in frame):
-                out = _LogSumExpTerms.apply(frame, drop[0], *padded)
+                out = _LogSumExpTerms.invoke(frame, drop[0], *padded)
                 return out, keep_ids
     total = None
     for x in aligned:
@@ -346,7 +346,7 @@ def _try_fused_lda(terms, sum_ids, contract_frames):
     log_theta = a.select(-2, 0).t().contiguous()           # [D, T]
     if lz.table.dtype != log_theta.dtype:
         return None
-    return _LdaFactor.apply(lz.index.contiguous(), log_theta, lz.table.contiguous())
+    return _LdaFactor.invoke(lz.index.contiguous(), log_theta, lz.table.contiguous())
 
 
 def _partition(terms, sum_ids):

@@ -71,6 +71,9 @@ class CompiledFunction:
         self.compiled = {}
         self.ignore_warnings = ignore_warnings
         self.jit_options = dict(jit_options or {})
+        # (the reference's own option, pyro/ops/jit.py:71-75: timing of the compilation, not torch.jit.trace's)
+        self._time_compilation = bool(self.jit_options.pop("time_compilation", False))
+        self.compile_time = None
         self.jit_options.setdefault("check_trace", False)
         self._param_names = None
         self._draws = {}

@@ -424,7 +424,7 @@ class DeferredCounts:
         images = kernels.bow_images_of(self.words, self.V)
         if images is None:
             return None
-        out = _BowLinear.apply(weight, bias, images[0], images[1], self.words.shape[1])
+        out = _BowLinear.invoke(weight, bias, images[0], images[1], self.words.shape[1])
         return out.as_subclass(TallActivation) if out.shape[0] >= TALL_MIN_ROWS else out
 
     @classmethod
@@ -473,7 +473,7 @@ class TallActivation(torch.Tensor):
             if (x.dim() == 2 and x.shape[0] >= TALL_MIN_ROWS and x.shape[1] <= 128 and x.is_cuda
                     and x.dtype == torch.float32 and type(weight) in (torch.Tensor, torch.nn.Parameter)
                     and weight.dim() == 2 and weight.shape[0] <= 128 and weight.dtype == torch.float32):
-                out = _TallLinear.apply(x.as_subclass(torch.Tensor), weight, bias)
+                out = _TallLinear.invoke(x.as_subclass(torch.Tensor), weight, bias)
                 return out.as_subclass(TallActivation)
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)

@@ -174,6 +174,10 @@ class routing:
     def __enter__(self):
         self._prev = ROUTE["on"]
         ROUTE["on"] = True
+        if _WHILE_COMPILING[0] is None:
+            import torch._dynamo           # (here, not at import: 0.9 s that only a compiling caller needs)
+            _WHILE_COMPILING[0] = torch._dynamo.assume_constant_result(
+                lambda name, hkey, n_words: _register(name, hkey, n_words))
         return self
 
     def __exit__(self, *exc):
@@ -193,6 +197,16 @@ class _Slot:
         self.i = i
 
 
+class _Vol:
+    """Where a VOLATILE integer argument sat (a Philox seed, a block offset: new values on every call).  Such
+    arguments are not part of a call signature -- the table of signatures would grow by one entry per draw --
+    they travel with the call as one int64 host tensor at the end of ``tensors``."""
+    __slots__ = ("i", "n")
+
+    def __init__(self, i, n):
+        self.i, self.n = i, n          # first word, number of words (None: a plain int)
+
+
 def _flatten(obj, tensors):
     if isinstance(obj, torch.Tensor):
         tensors.append(obj)
@@ -206,26 +220,37 @@ def _flatten(obj, tensors):
     return obj
 
 
-def _unflatten(obj, tensors):
+_U64 = (1 << 64) - 1
+
+
+def _unflatten(obj, tensors, words=None):
     if isinstance(obj, _Slot):
         return tensors[obj.i]
+    if isinstance(obj, _Vol):
+        if obj.n is None:
+            return words[obj.i] & _U64
+        return tuple(w & _U64 for w in words[obj.i:obj.i + obj.n])
     if isinstance(obj, tuple):
-        return tuple(_unflatten(o, tensors) for o in obj)
+        return tuple(_unflatten(o, tensors, words) for o in obj)
     if isinstance(obj, list):
-        return [_unflatten(o, tensors) for o in obj]
+        return [_unflatten(o, tensors, words) for o in obj]
     if isinstance(obj, dict):
-        return {k: _unflatten(v, tensors) for k, v in obj.items()}
+        return {k: _unflatten(v, tensors, words) for k, v in obj.items()}
     return obj
 
 
 def _hashable(obj, tensors):
+    if isinstance(obj, _Vol):
+        return ("V", obj.i, obj.n)
     if isinstance(obj, _Slot):
         t = tensors[obj.i]
         return ("T", tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device), t.requires_grad)
     if isinstance(obj, (tuple, list)):
-        return (type(obj).__name__,) + tuple(_hashable(o, tensors) for o in obj)
+        return ("tuple" if isinstance(obj, tuple) else "list",) + tuple(_hashable(o, tensors) for o in obj)
     if isinstance(obj, dict):
         return ("dict",) + tuple(sorted((k, _hashable(v, tensors)) for k, v in obj.items()))
+    if obj is None or isinstance(obj, (bool, int, float, str, torch.dtype, torch.Size)):
+        return obj                     # (spelled out: a compiler inlining this knows these, not ``hash``)
     try:
         hash(obj)
         return obj
@@ -263,32 +288,98 @@ class _CallSpec:
         self.bwd_none = None            # per tensor input: backward gave no gradient
         self.n_in = 0
         self.n_ret = 0
+        self.n_words = 0                # volatile integers riding in the call's last (host) tensor
 
 
-def _spec_of(name, fn_cls, args):
-    tensors = []
-    structure = _flatten(tuple(args), tensors)
-    try:
-        key = (name, _hashable(structure, tensors))
-        hash(key)
-    except TypeError:
-        key = None
-    sid = _SPEC_INDEX.get(key) if key is not None else None
+def _structure_from_key(hk, counter):
+    """The argument structure (tensor slots, volatile-integer slots, constants) back from its hashable form:
+    tensors were numbered in the order _flatten met them."""
+    if isinstance(hk, tuple) and hk:
+        tag = hk[0]
+        if tag == "T" and len(hk) == 6:
+            counter[0] += 1
+            return _Slot(counter[0] - 1)
+        if tag == "V" and len(hk) == 3:
+            return _Vol(hk[1], hk[2])
+        if tag == "tuple":
+            return tuple(_structure_from_key(o, counter) for o in hk[1:])
+        if tag == "list":
+            return [_structure_from_key(o, counter) for o in hk[1:]]
+        if tag == "dict":
+            return {k: _structure_from_key(v, counter) for k, v in hk[1:]}
+        if tag == "id":
+            raise TypeError("an argument that is neither a tensor nor a constant")
+    return hk
+
+
+def _tensor_entries(hk, out):
+    if isinstance(hk, tuple) and hk:
+        if hk[0] == "T" and len(hk) == 6:
+            out.append(hk)
+        elif hk[0] in ("tuple", "list"):
+            for o in hk[1:]:
+                _tensor_entries(o, out)
+        elif hk[0] == "dict":
+            for _, v in hk[1:]:
+                _tensor_entries(v, out)
+    return out
+
+
+def _register(name, hkey, n_words, structure=None):
+    """The table entry of call signature ``hkey`` of op ``name`` (made on first sight).  Everything the entry
+    holds follows from the hashable form, so that a compiler can have it made AT RECORDING TIME by a call it
+    treats as a constant (``_register_while_compiling``): a table append inside recorded code would only be
+    replayed after the recording, too late for the shape functions that run during it."""
+    key = (name, hkey)
+    sid = _SPEC_INDEX.get(key)
     if sid is None:
+        if structure is None:
+            structure = _structure_from_key(hkey, [0])
+        ents = _tensor_entries(hkey, [])
         top = tuple(a.i if isinstance(a, _Slot) else None for a in structure)
-        needs = tuple(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
-        sp = _CallSpec(name, fn_cls, structure, top, needs)
-        sp.n_in = len(tensors)
+        needs = tuple(isinstance(h, tuple) and len(h) == 6 and h[0] == "T" and bool(h[5]) for h in hkey[1:])
+        sp = _CallSpec(name, _OPS[name], structure, top, needs)
+        sp.n_in = len(ents)
+        sp.in_meta = [(tuple(h[1]), h[3]) for h in ents]       # the shape function of the backward op
+        sp.n_words = n_words
         _SPECS.append(sp)
         sid = len(_SPECS) - 1
-        if key is not None:
-            _SPEC_INDEX[key] = sid
+        _SPEC_INDEX[key] = sid
+    return sid
+
+
+_WHILE_COMPILING = [None]     # _register as a call dynamo evaluates at recording time (made by routing())
+
+
+def _spec_of(name, fn_cls, args, vol=()):
+    tensors = []
+    words = []
+    if vol:
+        args = list(args)
+        for i in vol:
+            v = args[i]
+            if isinstance(v, int):
+                args[i] = _Vol(len(words), None)
+                words.append(v)
+            elif isinstance(v, (tuple, list)) and all(isinstance(x, int) for x in v):
+                args[i] = _Vol(len(words), len(v))
+                words.extend(v)
+    structure = _flatten(tuple(args), tensors)
+    hkey = _hashable(structure, tensors)          # (hashable by construction: see _hashable)
+    if torch.compiler.is_compiling():
+        sid = _WHILE_COMPILING[0](name, hkey, len(words))
+    else:
+        sid = _register(name, hkey, len(words), structure)
+    if words:
+        tensors.append(torch.tensor([w - (1 << 64) if w >= (1 << 63) else w for w in words], dtype=torch.int64))
     return sid, tensors
 
 
 def _fwd_impl(tensors, spec):
     sp = _SPECS[spec]
-    args = _unflatten(sp.structure, list(tensors))
+    tensors = list(tensors)
+    words = tensors.pop().tolist() if sp.n_words else None
+    args = _unflatten(sp.structure, tensors, words)
     ctx = _Ctx(sp.needs)
     with torch.no_grad():
         out = sp.fn_cls.forward(ctx, *args)
@@ -324,8 +415,13 @@ def _fwd_impl(tensors, spec):
 def _fwd_fake(tensors, spec):
     sp = _SPECS[spec]
     if sp.out_meta is None:
-        raise RuntimeError("pyro_amd::%s: shapes are known once the call has run for real (trace / "
-                           "compile after one eager step)" % sp.name)
+        # the shapes of this call signature are not known yet: ONE real evaluation on zero-filled stand-ins
+        # of the arguments tells them (outside the fake mode; the kernels' shape rules live in C, there is
+        # no second statement of them to keep in step)
+        from torch._subclasses.fake_tensor import unset_fake_temporarily
+        with unset_fake_temporarily(), torch.no_grad():
+            real = [torch.zeros(tuple(t.shape), dtype=t.dtype, device=t.device) for t in tensors]
+            _fwd_impl(real, spec)
     proto = tensors[0]
     return [proto.new_empty(shape, dtype=dtype) for shape, dtype in sp.out_meta]
 
@@ -333,6 +429,8 @@ def _fwd_fake(tensors, spec):
 def _bwd_impl(tensors, spec):
     sp = _SPECS[spec]
     grads, saved = list(tensors[:sp.n_out]), list(tensors[sp.n_out:])
+    # (a saved None travelled as an empty tensor: back to None)
+    saved = [None if kind == "none" else t for (kind, _), t in zip(sp.saved_from, saved)]
     ctx = _Ctx(sp.needs)
     ctx.__dict__.update(sp.attrs)
     ctx.saved_tensors = tuple(saved)
@@ -351,8 +449,17 @@ def _bwd_impl(tensors, spec):
 
 def _bwd_fake(tensors, spec):
     sp = _SPECS[spec]
+    if sp.bwd_none is None:
+        # which inputs get a gradient, before any real backward has run: those the Function was told to
+        # differentiate (top-level tensor arguments that required a gradient)
+        none = [True] * sp.n_in
+        for pos, j in enumerate(sp.top_slots):
+            if j is not None and pos < len(sp.needs) and sp.needs[pos]:
+                none[j] = False
+        sp.bwd_none = none
     proto = tensors[0]
-    return [proto.new_empty((0,)) for _ in range(sp.n_in)]
+    return [proto.new_empty((0,)) if sp.bwd_none[j] else proto.new_empty(sp.in_meta[j][0], dtype=sp.in_meta[j][1])
+            for j in range(sp.n_in)]
 
 
 def _setup_context(ctx, inputs, output):
@@ -377,7 +484,8 @@ def _make_backward(name):
         # (a saved None cannot travel in a Tensor[]: an empty tensor stands for it)
         saved = [gs[0].new_empty((0,)) if is_none else next(it) for is_none in ctx.none_saved]
         res = getattr(torch.ops.pyro_amd, name + "_bwd")(gs + saved, ctx.spec)
-        return [None if sp.bwd_none[j] else res[j] for j in range(sp.n_in)], None
+        # (the host tensor of volatile integers at the end of the inputs has no gradient)
+        return [None if sp.bwd_none[j] else res[j] for j in range(sp.n_in)] + [None] * bool(sp.n_words), None
     return backward
 
 
@@ -399,16 +507,21 @@ def dispatcher_op(name):
                                         setup_context=_setup_context, lib=lib)
         _OPS[name] = fn_cls
         eager_apply = fn_cls.apply
+        vol = tuple(getattr(fn_cls, "volatile_args", ()))       # (read here: a compiler inlines ``apply`` below)
 
         def apply(*args):
             if not _routing_now() or not any(isinstance(a, torch.Tensor) for a in args):
                 return eager_apply(*args)
-            sid, tensors = _spec_of(name, fn_cls, args)
+            sid, tensors = _spec_of(name, fn_cls, args, vol)
             out = getattr(torch.ops.pyro_amd, name)(tensors, sid)
             sp = _SPECS[sid]
             return out[0] if sp.single else tuple(out[:sp.n_out])
 
         fn_cls.apply = staticmethod(apply)
+        # the package's call sites use ``invoke``: dynamo special-cases ``apply`` of an autograd.Function
+        # (it traces the Function's forward -- ctypes launches it cannot record) but inlines this plain
+        # function, which hands the call to the dispatcher op while a tracer / compiler records
+        fn_cls.invoke = staticmethod(apply)
         fn_cls.op_name = "pyro_amd::" + name
         return fn_cls
     return deco

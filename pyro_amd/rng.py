@@ -48,6 +48,8 @@ _count_seedings()
 
 def _follow_torch():
     """The default generator was re-seeded since the last draw: the stream restarts under the new seed."""
+    if torch.compiler.is_compiling():
+        return          # (dynamo is recording: the wrapper that owns the draws synchronised before the call)
     ts = (torch.initial_seed(), _SEEDINGS[0])
     if ts != _STATE["torch_seed"]:
         _STATE["torch_seed"] = ts

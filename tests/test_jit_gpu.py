@@ -110,3 +110,72 @@ def test_svi_with_a_traced_loss_follows_the_eager_trajectory(gpu):
     np.testing.assert_allclose(l_jit, l_eager, rtol=2e-6)
     for name in p_eager:
         np.testing.assert_allclose(p_jit[name], p_eager[name], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
+def test_torch_compile_of_the_config2_loss_over_the_registered_ops(gpu):
+    """torch.compile(fullgraph=True) of config 2's differentiable loss written against the registered
+    operators (the guide draw, the GLM site, the one-launch sums of the small sites): dynamo records them as
+    pyro_amd::* graph nodes, their shape functions answer without a prior eager call, AOT autograd
+    differentiates through the registered formulas; loss and gradients equal the eager evaluation with the
+    same draws.  (The Python effect handlers themselves are not dynamo's to trace; ``ops.jit.trace`` /
+    ``JitTrace_ELBO`` record the full loss by executing it, see the tests above.)"""
+    import pyro_amd as pyro
+    from pyro_amd import _lib, examples, rng
+    from pyro_amd.distributions import fused
+    from pyro_amd.ops import torch_library as tl
+
+    N, D, P = 4096, 32, 64
+    X, y = examples.synthetic_logreg_data(N, D, gpu, seed=5)
+    from pyro_amd import kernels
+    kernels.glm_bernoulli_fwd_bwd(X, y, torch.zeros(P, D, device=gpu), None, None, 1.0)   # (second sighting:
+    kernels.glm_bernoulli_fwd_bwd(X, y, torch.zeros(P, D, device=gpu), None, None, 1.0)   #  the plane image)
+    loc_w = torch.zeros(D, device=gpu, requires_grad=True)
+    rho_w = torch.full((D,), -2.0, device=gpu, requires_grad=True)
+    loc_b = torch.zeros(1, device=gpu, requires_grad=True)
+    rho_b = torch.full((1,), -2.0, device=gpu, requires_grad=True)
+    zero = torch.zeros((), device=gpu)
+    one = torch.ones((), device=gpu)
+    # the plane image of X and the label moments are facts about the DATA, looked up on the host (by tensor
+    # identity): taken outside the compiled function, they enter its graph as constants
+    planes, moments = kernels.glm_planes_of(X), kernels.glm_label_moments_of(X, y)
+    fmt = kernels._format_of(planes)
+    assert planes is not None and tl.available()
+
+    def loss_fn(loc_w, rho_w, loc_b, rho_b, X, y):
+        (zw, sw, lw), (zb, sb, lb) = fused.meanfield_sample([loc_w, loc_b], [rho_w, rho_b], P)
+        ll = torch.ops.pyro_amd.glm_bernoulli_planes(planes, y, zw, zb.reshape(P), 1.0, N, D, fmt, moments)[0]
+        prior = fused.log_prob_sum(_lib.DIST_NORMAL, zw, zero, one) + fused.log_prob_sum(_lib.DIST_NORMAL, zb, zero, one)
+        entropy = fused.log_prob_sum(_lib.DIST_NORMAL, zw, lw, sw) + fused.log_prob_sum(_lib.DIST_NORMAL, zb, lb, sb)
+        return -(ll.sum() + prior - entropy) / P
+
+    from pyro_amd.ops.jit import _ReplaySafeDraws
+    leaves = (loc_w, rho_w, loc_b, rho_b)
+    with tl.routing():
+        # the draws are addressed relative to a device word the wrapper sets before each call (what
+        # ops.jit.trace does for a traced loss): a compiled call draws what the eager code would draw then.
+        # One eager call first: it enters the call signatures in the table (a compiler replays such side
+        # effects only after it has finished recording)
+        draws = _ReplaySafeDraws(gpu)
+        pyro.set_rng_seed(21)
+        ref = draws.run(lambda: loss_fn(*leaves, X, y), first=True)
+        ref_g = torch.autograd.grad(ref, leaves)
+        pyro.set_rng_seed(22)
+        ref2 = draws.run(lambda: loss_fn(*leaves, X, y), first=False)
+        n_specs = len(tl._SPECS)
+        compiled = torch.compile(loss_fn, fullgraph=True, backend="aot_eager")
+        pyro.set_rng_seed(21)
+        got = draws.run(lambda: compiled(*leaves, X, y), first=False)
+        got_g = torch.autograd.grad(got, leaves)
+        pyro.set_rng_seed(22)
+        got2 = draws.run(lambda: compiled(*leaves, X, y), first=False)
+        torch.testing.assert_close(got2, ref2, rtol=1e-6, atol=1e-6)
+        assert abs(float(ref2) - float(ref)) > 1e-4
+        # the Philox seed / offsets are not part of a call signature: more draws, no more signatures
+        before = len(tl._SPECS)
+        for _ in range(3):
+            draws.run(lambda: loss_fn(*leaves, X, y), first=False)
+        assert len(tl._SPECS) == before == n_specs
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
+    for a, b in zip(got_g, ref_g):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    assert torch.isfinite(ref) and float(ref) > 0

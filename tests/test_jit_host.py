@@ -120,3 +120,47 @@ def test_svi_over_a_traced_loss_updates_the_parameters(monkeypatch, fused):
     np.testing.assert_allclose(l_jit, l_eager, rtol=1e-10)
     for name in p_eager:
         np.testing.assert_allclose(p_jit[name], p_eager[name], rtol=1e-9, atol=1e-12, err_msg=name)
+
+
+def test_a_registered_function_compiles_with_fullgraph_on_the_host():
+    """ops/torch_library.dispatcher_op under torch.compile(fullgraph=True, backend="aot_eager"): the call site's
+    ``invoke`` is inlined by dynamo and hands the call to the dispatcher op; the shape function answers for
+    a signature it has never run (one evaluation on zeros), the backward's shape function too; a volatile
+    integer argument (a Philox seed) is not part of the signature."""
+    import torch
+    from pyro_amd.ops import torch_library as tl
+
+    @tl.dispatcher_op("host_probe_scale")
+    class _Probe(torch.autograd.Function):
+        volatile_args = (1,)
+
+        @staticmethod
+        def forward(ctx, x, seed, k):
+            ctx.k = k
+            ctx.save_for_backward(x)
+            return x * k + (seed % 7), x.sum()
+
+        @staticmethod
+        def backward(ctx, g, gs):
+            (x,) = ctx.saved_tensors
+            return g * ctx.k + gs, None, None
+
+    def f(x, seed):
+        a, s = _Probe.invoke(x, seed, 3.0)
+        return (a * a).sum() + s
+
+    x = torch.randn(5, requires_grad=True)
+    with tl.routing():
+        n0 = len(tl._SPECS)
+        compiled = torch.compile(f, fullgraph=True, backend="aot_eager")
+        got = compiled(x, 12345678901234)                     # (no eager call before: nothing knows the shapes)
+        g_got, = torch.autograd.grad(got, x)
+        ref = f(x, 12345678901234)
+        g_ref, = torch.autograd.grad(ref, x)
+        assert len(tl._SPECS) == n0 + 1
+        f(x, 99)                                              # another seed: the same signature
+        f(x, (1 << 64) - 3)                                   # (unsigned 64-bit values survive the int64 tensor)
+        assert len(tl._SPECS) == n0 + 1
+    torch.testing.assert_close(got, ref)
+    torch.testing.assert_close(g_got, g_ref)
+    assert float(f(x, 8)) != float(f(x, 9))                   # eager apply, not routed: seed % 7 differs
