@@ -177,7 +177,7 @@ class routing:
         if _WHILE_COMPILING[0] is None:
             import torch._dynamo           # (here, not at import: 0.9 s that only a compiling caller needs)
             _WHILE_COMPILING[0] = torch._dynamo.assume_constant_result(
-                lambda name, hkey, n_words: _register(name, hkey, n_words))
+                lambda name, hkey, n_words: _register_signature(name, hkey, n_words))
         return self
 
     def __exit__(self, *exc):
@@ -325,7 +325,7 @@ def _tensor_entries(hk, out):
     return out
 
 
-def _register(name, hkey, n_words, structure=None):
+def _register_signature(name, hkey, n_words, structure=None):
     """The table entry of call signature ``hkey`` of op ``name`` (made on first sight).  Everything the entry
     holds follows from the hashable form, so that a compiler can have it made AT RECORDING TIME by a call it
     treats as a constant (``_register_while_compiling``): a table append inside recorded code would only be
@@ -348,7 +348,7 @@ def _register(name, hkey, n_words, structure=None):
     return sid
 
 
-_WHILE_COMPILING = [None]     # _register as a call dynamo evaluates at recording time (made by routing())
+_WHILE_COMPILING = [None]     # _register_signature as a call dynamo evaluates at recording time (made by routing())
 
 
 def _spec_of(name, fn_cls, args, vol=()):
@@ -369,7 +369,7 @@ def _spec_of(name, fn_cls, args, vol=()):
     if torch.compiler.is_compiling():
         sid = _WHILE_COMPILING[0](name, hkey, len(words))
     else:
-        sid = _register(name, hkey, len(words), structure)
+        sid = _register_signature(name, hkey, len(words), structure)
     if words:
         tensors.append(torch.tensor([w - (1 << 64) if w >= (1 << 63) else w for w in words], dtype=torch.int64))
     return sid, tensors
