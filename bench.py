@@ -88,17 +88,14 @@ def parse():
     return ap.parse_args()
 
 
+ROUND = 5       # profiles/r05_*: counter files of another round measured other kernels and are refused
+
+
 def latest_profile(suffix):
-    """profiles/rNN_<suffix> of the latest round that committed one (counters cannot be collected from
-    inside the run: the rocprofv3 passes of tools/prof.sh write them), or None."""
-    import re
-    pdir = os.path.join(ROOT, "profiles")
-    best = None
-    for f in os.listdir(pdir) if os.path.isdir(pdir) else []:
-        m = re.fullmatch(r"r(\d+)_" + re.escape(suffix), f)
-        if m and (best is None or int(m.group(1)) > best[0]):
-            best = (int(m.group(1)), os.path.join(pdir, f))
-    return best[1] if best else None
+    """profiles/r<ROUND>_<suffix> (counters cannot be collected from inside the run: the rocprofv3 passes
+    of tools/prof.sh write them), or None -- a file of an earlier round is NOT taken in its place."""
+    path = os.path.join(ROOT, "profiles", "r%02d_%s" % (ROUND, suffix))
+    return path if os.path.exists(path) else None
 
 
 def measured_hbm(dev):
@@ -397,7 +394,7 @@ def bench_model_nuts(dev, rank, world, args):
         def marked():
             _sync(dev)
             marks.update(t=time.perf_counter(), n=kernel.num_leapfrog_steps,
-                         replays=getattr(kernel, "_span_replays", 0))
+                         replays=getattr(kernel, "_span_replays", 0), slots=getattr(kernel, "_span_rounds", 0))
             end_warmup()
         kernel.end_warmup = marked
         if world > 1:
@@ -409,13 +406,15 @@ def bench_model_nuts(dev, rank, world, args):
         _sync(dev)
         t1 = time.perf_counter()
         return kernel, mcmc, dict(wall=t1 - t0, n=n, t_sample=t1 - marks["t"], n_sample=n - marks["n"],
-                                  replays_sample=getattr(kernel, "_span_replays", 0) - marks["replays"])
+                                  replays_sample=getattr(kernel, "_span_replays", 0) - marks["replays"],
+                                  slots_sample=getattr(kernel, "_span_rounds", 0) - marks["slots"],
+                                  compactions=getattr(kernel, "_span_compactions", 0))
 
     out = {}
     # (N, chains, warm-up, samples): the 1e6-row posterior is ~30x tighter than the prior's scale, so chains
     # started at the reference's uniform(-2, 2) points spend a short warm-up travelling with deep trees --
     # that run is a throughput measurement (its R-hat says so), the 1e5-row runs are converged ones
-    plan = [(100_000, C, 2 * W, 2 * S), (100_000, 4 * C, W, S), (1_000_000, C, max(W // 2, 10), max(S // 4, 5))]
+    plan = [(100_000, C, 5 * W, 10 * S), (100_000, 4 * C, 2 * W, 4 * S), (1_000_000, C, max(W // 2, 10), max(S // 4, 5))]
     if dev.type != "cuda":                 # the plumbing test of tests/test_distributed_cpu.py
         plan = [(args.plate, C, W, S)]
     X = y = None
@@ -454,7 +453,9 @@ def bench_model_nuts(dev, rank, world, args):
             "wall_s": wall, "leapfrogs": n_all, "sampling_s": ts, "sampling_leapfrogs": ns_all,
             "mean_tree_leaves": r["n"] / ((W + S) * C),
             "rounds_sampling": rounds, "us_per_round": ts / max(rounds, 1) * 1e6,
-            "round_occupancy": r["n_sample"] / max(rounds * C, 1),
+            # leapfrogs done per cursor row the potential was evaluated at (compacted rounds evaluate fewer rows)
+            "round_occupancy": r["n_sample"] / max(r["slots_sample"], 1),
+            "compactions": r["compactions"],
             "graphed": bool(rounds),
             "posterior_check": {"max_r_hat": float(max(d["r_hat"].max() for k, d in diag.items()
                                                        if isinstance(d, dict) and "r_hat" in d)),
@@ -831,11 +832,20 @@ def main():
         traffic = rocprof_ms = None
         traffic_src = None
         tpath = latest_profile("traffic.json")
+        if tpath is None:
+            traffic_src = "none: no profiles/r%02d_traffic.json committed this round (earlier rounds' files are refused)" % ROUND
         if tpath is not None:
             try:
                 tj = json.load(open(tpath))
-                traffic, rocprof_ms = tj.get("hbm_bytes_per_launch"), tj.get("kernel_ms_in_graph")
-                traffic_src = "profiles/%s (%s)" % (os.path.basename(tpath), tj.get("how", ""))
+                # ... and only for the kernel family that is running now
+                running = ("glm_planes_f16_kernel" if headline_f16 else "glm_planes_kernel") if headline_planes \
+                    else "glm_bernoulli_bf16_kernel"
+                if running in str(tj.get("kernel", "")):
+                    traffic, rocprof_ms = tj.get("hbm_bytes_per_launch"), tj.get("kernel_ms_in_graph")
+                    traffic_src = "profiles/%s (%s)" % (os.path.basename(tpath), tj.get("how", ""))
+                else:
+                    traffic_src = "refused: profiles/%s measured %s, this run launches %s" % (
+                        os.path.basename(tpath), str(tj.get("kernel"))[:60], running)
             except Exception:
                 traffic = None
         planes, f16 = headline_planes, headline_f16      # (noted right after the timed region)

@@ -12,11 +12,18 @@ from pyro_amd.infer import SVI, Trace_ELBO, TraceEnum_ELBO
 from pyro_amd.infer.autoguide import AutoMultivariateNormal, AutoNormal
 
 
+ROUND = 5       # profiles of THIS round only: a counter file of another round measured other kernels
+
+
 def _committed_traffic(cfg, kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC passes (tools/pmc_cfg.sh ->
-    profiles/r03_traffic_cfg<cfg>.json), or None: counters cannot be collected from inside the run."""
+    """HBM bytes per launch of ``kernel`` from the PMC passes committed THIS round (tools/pmc_cfg.sh ->
+    profiles/r%02d_traffic_cfg<cfg>.json), or None: counters cannot be collected from inside the run, and a
+    file of an earlier round is refused (its kernels were other kernels)."""
     import json
+    import os
     path = _traffic_path(cfg)
+    if not os.path.exists(path):
+        return None
     try:
         return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:  # noqa: BLE001
@@ -24,16 +31,17 @@ def _committed_traffic(cfg, kernel):
 
 
 def _traffic_path(cfg):
-    """The latest round's profiles/rNN_traffic_cfg<cfg>.json."""
     import os
-    import re
     pdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    best = None
-    for f in os.listdir(pdir):
-        m = re.fullmatch(r"r(\d+)_traffic_cfg%s\.json" % cfg, f)
-        if m and (best is None or int(m.group(1)) > best[0]):
-            best = (int(m.group(1)), os.path.join(pdir, f))
-    return best[1] if best else os.path.join(pdir, "r03_traffic_cfg%s.json" % cfg)
+    return os.path.join(pdir, "r%02d_traffic_cfg%s.json" % (ROUND, cfg))
+
+
+def _traffic_source(cfg):
+    import os
+    path = _traffic_path(cfg)
+    if os.path.exists(path):
+        return "profiles/%s (rocprofv3 --pmc, tools/pmc_cfg.sh)" % os.path.basename(path)
+    return "none: no profiles/%s committed this round (files of earlier rounds are refused)" % os.path.basename(path)
 
 
 def timed(fn, n, warm):
@@ -86,7 +94,7 @@ def config5(dev, N=10_000_000, D=32, G=1000, P=64, steps=20, graph=True, referen
                            "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9,
                            "peak": 8000.0, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
                            "traffic": _committed_traffic(5, "glm_planes_f16_kernel" if f16 else "glm_planes_kernel"),
-                           "traffic_source": "profiles/%s (rocprofv3 --pmc, tools/pmc_cfg.sh)" % __import__("os").path.basename(_traffic_path(5)),
+                           "traffic_source": _traffic_source(5),
                            "share_of_step": k_ms / (dt * 1e3)}
     return out
 
@@ -289,10 +297,26 @@ def _config4_roofline(data, args, predictor, dt):
             "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0,
             "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
             "traffic": _committed_traffic(4, "bow_linear_fwd_kernel"),
-            "traffic_source": "profiles/%s (rocprofv3 --pmc, tools/pmc_cfg.sh)" % __import__("os").path.basename(_traffic_path(4)),
+            "traffic_source": _traffic_source(4),
             "share_of_step": k_ms / (dt * 1e3),
-            "note": "a flat step: 153 launches, the largest kernel 7 % of it -- see step_composition",
+            # the WHOLE step against HBM: what one step must move at least -- the word ids once (int64), the
+            # two bag-of-words images (forward and backward pass of the guide's first layer), the guide's
+            # activations written and read back once per layer (forward + backward)
+            "whole_step": _config4_whole_step(data, args, predictor, imgs, dt),
+            "note": "a flat step: no kernel above a tenth of it -- see step_composition",
             "step_composition": _step_composition(4)}
+
+
+def _config4_whole_step(data, args, predictor, imgs, dt):
+    B = data.shape[1]
+    widths = [m.out_features for m in predictor.modules() if isinstance(m, torch.nn.Linear)]
+    act = sum(widths) * B * 4
+    alg = data.numel() * 8 + 2 * sum(int(i.numel()) * i.element_size() for i in imgs) + 4 * act
+    return {"algorithmic_bytes_per_step": alg, "achieved": alg / dt / 1e9, "unit": "GB/s", "peak": 8000.0,
+            "frac": alg / dt / 8e12,
+            "bytes": "word ids %d + bag-of-words images 2 x %d + activations 4 x %d" % (
+                data.numel() * 8, sum(int(i.numel()) * i.element_size() for i in imgs), act)}
+
 
 
 if __name__ == "__main__":

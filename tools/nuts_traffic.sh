@@ -1,11 +1,11 @@
 #!/bin/bash
 # HBM traffic of the NUTS kernels over one MCMC.run of bench.py's secondary workload (two PMC passes, as
-# tools/prof.sh): writes gpurun_out/r04_nuts_traffic.json
+# tools/prof.sh): writes gpurun_out/r05_nuts_traffic.json
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 OUT=gpurun_out/nuts_pmc; rm -rf $OUT; mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o b -- python bench.py --steps 5 --warmup 5 --no-others --no-cpu-baseline > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o b -- python bench.py --steps 5 --warmup 5 --no-others --no-model-nuts --no-cpu-baseline > $OUT/$C.log 2>&1
 done
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
@@ -32,6 +32,6 @@ if secondary:
     res["leapfrogs"] = secondary.get("leapfrogs")
     if secondary.get("leapfrogs"):
         res["hbm_bytes_per_leapfrog"] = res["hbm_bytes_total"] / secondary["leapfrogs"]
-json.dump(res, open("gpurun_out/r04_nuts_traffic.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r05_nuts_traffic.json", "w"), indent=1)
 print(json.dumps(res)[:1500])
 PY

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 OUT=gpurun_out/trace_step; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python bench.py --steps 40 --warmup 8 ${GRAPHFLAG:---no-graph} --no-nuts --no-others --no-cpu-baseline --plate ${1:-1000000} > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o t -- python bench.py --steps 40 --warmup 8 ${GRAPHFLAG:---no-graph} --no-nuts --no-model-nuts --no-others --no-cpu-baseline --plate ${1:-1000000} > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True)[0]
