@@ -685,7 +685,41 @@ int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq,
  * its next cursor to its slot row too.  NULL / NULL: slot == chain, n_slots ignored (the full round). */
 int pa_nuts_tree_compact(int dtype, const void* zq, int64_t C, int64_t D, int max_tree_depth,
                          int32_t* slot2chain, void* zq_slot, int64_t n_slots, int32_t* n_placed,
+                         int n_sites, const int32_t* site_off, const int32_t* site_len,
                          void* workspace, size_t workspace_bytes, pa_stream_t stream);
+/* A FLAT model's potential assembled inside the tree kernel.  When every latent site of the model is scored
+ * by one of the fused families at parameters that do not depend on other latents, and what remains are
+ * observed sites with their own fused kernels (the Bernoulli-logits GLM site over the latent weights / bias),
+ * the reference's potential (pyro/infer/mcmc/util.py:264-286: the conditioned model run under the handlers,
+ * trace.log_prob_sum, autograd backward -- ~25 operators per evaluation) is
+ *     U(u) = -( ll_ext[slot] + sum_sites sum_j [ log p_s(v_j; p0, p1) + log |dv_j/du_j| ] ),  v = T_s(u),
+ * T_s the identity (transform 0) or v = lower + exp(u) (transform 1: biject_to of a positive /
+ * greater-than support), and its gradient -( (d log p_s/dv + g_ext) dv/du + d log|dv/du|/du ).
+ * pa_nuts_tree_run_advance_direct is pa_nuts_tree_run_advance (float32) computing (peq, gq) that way:
+ * n_sites sites tile the flat coordinates [0, D) in ascending order (site_off / site_len); site k has family
+ * site_dist[k] (PA_DIST_NORMAL, _HALF_CAUCHY, _LOG_NORMAL, _EXPONENTIAL, _HALF_NORMAL, _GAMMA), parameters
+ * site_p0/p1[k] (device, element j at p[j * stride]; NULL: unused) and -- when an external kernel scored an
+ * observed site against it -- site_g_ext[k] = d ll_ext / d v [n_slots, len] (else NULL); ll_ext[n_slots] (or
+ * NULL).  The cursor handed to the external kernels, zq_pack, is SITE-MAJOR: site k's block [n_slots, len_k]
+ * starts at element n_slots * site_off[k] (the GLM kernel reads weights [P, D_w] and bias [P] in place);
+ * pa_nuts_tree_compact with the same (n_sites, site_off, site_len) fills it (slot2chain NULL and
+ * n_slots == C: the full round, identity map).  n_sites == 0 there: the row-major [n_slots, D] buffer of a
+ * potential that takes the flat state. */
+int pa_nuts_tree_run_advance_direct(void* z, void* pe, void* grad, void* zq, void* rq, const void* inv_mass,
+                                    int64_t im_stride_row, void* step, int64_t C, int64_t D,
+                                    int max_tree_depth, int use_multinomial, uint64_t seed,
+                                    uint64_t chain_offset, const int64_t* ctl, void* da_state,
+                                    double target_accept, void* welford, void* mean_accept,
+                                    int64_t* counters, int32_t* tc, int32_t* n_done, int64_t* done_flag,
+                                    const int32_t* slot2chain, void* zq_pack, int64_t n_slots,
+                                    int n_sites, const int32_t* site_off, const int32_t* site_len,
+                                    const int32_t* site_dist, const int32_t* site_transform,
+                                    const double* site_lower, const void* const* site_p0,
+                                    const int64_t* site_s0, const void* const* site_p1,
+                                    const int64_t* site_s1, const void* const* site_g_ext,
+                                    const void* ll_ext, void* accept_prob, int32_t* n_leapfrog,
+                                    int32_t* depth, int32_t* diverging, int32_t* accepted, void* workspace,
+                                    size_t workspace_bytes, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under

@@ -27,6 +27,7 @@
 // Randomness: the SAME keyed Philox contract as nuts.hip (so both kernels, and the recursive
 // oracle, draw identical numbers): counter_lo = t*2^20 + slot, counter_hi = global chain id.
 #include "nuts_common.h"
+#include "dist_fam.h"
 
 namespace pa {
 
@@ -63,6 +64,24 @@ static TreeWs<T> tree_ws(void* base, int64_t C, int64_t D, int max_depth) {
   return w;
 }
 
+// Where slot s, coordinate d of the cursor buffer handed to the potential lives.  n_sites == 0: row-major
+// [n_slots, D] (a potential that takes the flat state).  Otherwise SITE-MAJOR: the sites of the flat layout
+// (ascending offsets covering [0, D)) as contiguous blocks [n_slots, len_s] one after the other, so that a
+// kernel that takes one site as its operand (the GLM kernel: weights [P, D_w], bias [P]) reads it in place.
+constexpr int TREE_MAX_SITES = 8;
+struct SlotLayout {
+  int n_sites;
+  int off[TREE_MAX_SITES], len[TREE_MAX_SITES];
+};
+__device__ __forceinline__ int64_t slot_index(const SlotLayout& L, int64_t n_slots, int64_t slot, int D, int d) {
+  if (L.n_sites == 0) return slot * D + d;
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < TREE_MAX_SITES; ++k)
+    if (k < L.n_sites && d >= L.off[k]) s = k;
+  return n_slots * L.off[s] + slot * L.len[s] + (d - L.off[s]);
+}
+
 template <typename T, int NW, int NPL>
 struct Chain {
   static constexpr int NT = 64 * NW;
@@ -92,6 +111,13 @@ struct Chain {
 #pragma unroll
     for (int m = 0; m < NPL; ++m)
       if (ok(m)) p[r + tid + m * NT] = v.x[m];
+  }
+  // slot `slot` of a cursor buffer laid out by `L`
+  __device__ __forceinline__ void st_slot(T* p, const SlotLayout& L, int64_t n_slots, int64_t slot,
+                                          const Vec<T, NPL>& v) const {
+#pragma unroll
+    for (int m = 0; m < NPL; ++m)
+      if (ok(m)) p[slot_index(L, n_slots, slot, D, tid + m * NT)] = v.x[m];
   }
   // block-wide sums of two per-thread values, identical in every thread, fixed order
   __device__ __forceinline__ void sum2(T& a, T& b) const {
@@ -178,6 +204,26 @@ enum { RC_T0 = 0, RC_K = 1, RC_MEAN_N0 = 2, RC_WF_N0 = 3, RC_FLAGS = 4, RC_SAMPL
        RC_DIV = 6, RC_ROW0 = 7, RC_COUNT = 8 };
 enum { RF_ADAPT_STEP = 1, RF_WELFORD = 2, RF_COUNT_ACCEPTS = 4 };
 
+// The potential of a FLAT model assembled inside the tree kernel (pa_nuts_tree_run_advance_direct): every
+// latent site is scored by a fused family at parameters that do not depend on other latents (the reference
+// evaluates them site by site, pyro/infer/mcmc/util.py:264-286 -> trace.log_prob_sum), through the identity
+// or the exp transform of its support; one or more observed sites were evaluated outside (the GLM kernel)
+// and hand over their log-likelihood per slot and its gradient per site.
+//   U(z)  = -( ll_ext[slot] + sum_sites sum_j [ log p_s(v_j) + log|dv_j/du_j| ] ),   v = T_s(u)
+//   dU/du = -( (d log p_s/dv + g_ext) dv/du + d log|dv/du| / du )
+struct DirectSite {
+  int dist, transform;            // PA_DIST_*; 0: v = u, 1: v = lower + exp(u)
+  const void *p0, *p1;            // the family's parameters, element j of the site at p[j * stride]
+  int64_t s0, s1;
+  const void* g_ext;              // [n_slots, len]: d ll_ext / d v of this site, or NULL
+  double lower;
+};
+struct TreeDirect {
+  int n_sites;                    // 0: (peq, gq) come from the caller
+  const void* ll_ext;             // [n_slots] or NULL
+  DirectSite s[TREE_MAX_SITES];
+};
+
 template <typename T>
 struct TreeRun {
   const int64_t* ctl;     // [RC_COUNT]
@@ -196,6 +242,8 @@ struct TreeRun {
   // slot row as well as to its own row.  NULL: slot == chain (the full round).
   const int32_t* slot2chain;
   T* zq_slot;
+  SlotLayout lay;         // layout of zq_slot (row-major when lay.n_sites == 0)
+  int64_t n_slots;
 };
 
 // tree state of a chain at the start of transition t (nuts.py:367-434): momentum draw, energies,
@@ -205,7 +253,7 @@ __device__ __forceinline__ void tree_begin_chain(
     const Chain<T, NW, NPL>& c, int chain, int64_t C, const Vec<T, NPL>& zc, const Vec<T, NPL>& gc,
     T pe_c, const Vec<T, NPL>& v, T eps, int multinomial, uint64_t seed, uint64_t t, uint64_t cid,
     const TreeWs<T>& ws, T* __restrict__ zq, T* __restrict__ rq, T* __restrict__ zq_slot = nullptr,
-    int64_t slot_row = 0) {
+    int64_t slot = 0, const SlotLayout* lay = nullptr, int64_t n_slots = 0) {
   const int64_t CD = C * c.D;
   const uint64_t ctr_base = t << 20;
   Vec<T, NPL> isq, ru0;
@@ -238,7 +286,7 @@ __device__ __forceinline__ void tree_begin_chain(
   kick_drift(zn, rn, gc, v, dir == 1 ? eps : -eps);
   c.st(zq, zn);
   c.st(rq, rn);
-  if (zq_slot != nullptr) c.st_at(zq_slot, slot_row, zn);
+  if (zq_slot != nullptr) c.st_slot(zq_slot, *lay, n_slots, slot, zn);
   if (threadIdx.x == 0) {
     ws.fscal[FS_ENERGY * C + chain] = energy_current;
     ws.fscal[FS_LOGSLICE * C + chain] = log_slice;
@@ -284,7 +332,61 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_begin_kernel(
                                chain_offset + (uint64_t)chain, ws, zq, rq);
 }
 
-template <typename T, int NW, int NPL, bool RUN>
+template <int DIST, typename T>
+__device__ __forceinline__ T elem_site_lp(T v, T a, T b, T& dv, T& da, T& db) {
+  Fam<DIST, T>::grad(v, a, b, dv, da, db);
+  return Fam<DIST, T>::lp(v, a, b);
+}
+// the families a continuous latent site of a flat model can have (real or positive support)
+#define PA_TREE_FAMILY(DIST_ID, CALL)                                                      \
+  switch (DIST_ID) {                                                                       \
+    case PA_DIST_NORMAL: { constexpr int D_ = PA_DIST_NORMAL; CALL; } break;               \
+    case PA_DIST_HALF_CAUCHY: { constexpr int D_ = PA_DIST_HALF_CAUCHY; CALL; } break;     \
+    case PA_DIST_LOG_NORMAL: { constexpr int D_ = PA_DIST_LOG_NORMAL; CALL; } break;       \
+    case PA_DIST_EXPONENTIAL: { constexpr int D_ = PA_DIST_EXPONENTIAL; CALL; } break;     \
+    case PA_DIST_HALF_NORMAL: { constexpr int D_ = PA_DIST_HALF_NORMAL; CALL; } break;     \
+    case PA_DIST_GAMMA: { constexpr int D_ = PA_DIST_GAMMA; CALL; } break;                 \
+    default: break;                                                                        \
+  }
+
+// (pe, gradient) of the flat model at this thread's coordinates of the cursor, see TreeDirect
+template <typename T, int NW, int NPL>
+__device__ __forceinline__ void direct_potential(const Chain<T, NW, NPL>& c, const TreeDirect& dp,
+                                                 const SlotLayout& lay, int64_t slot, const Vec<T, NPL>& zq,
+                                                 Vec<T, NPL>& gq, T& pe_q) {
+  T lp_sum = T(0), zero = T(0);
+#pragma unroll
+  for (int m = 0; m < NPL; ++m) {
+    gq.x[m] = T(0);
+    const int d = c.tid + m * c.NT;
+    if (!c.ok(m)) continue;
+    int si = 0;
+#pragma unroll
+    for (int k = 1; k < TREE_MAX_SITES; ++k)
+      if (k < lay.n_sites && d >= lay.off[k]) si = k;
+    const DirectSite& st = dp.s[si];
+    const int j = d - lay.off[si];
+    const T u = zq.x[m];
+    const T a = st.p0 != nullptr ? ((const T*)st.p0)[j * st.s0] : T(0);
+    const T b = st.p1 != nullptr ? ((const T*)st.p1)[j * st.s1] : T(0);
+    T v = u, dvdu = T(1), ladj = T(0), dladj = T(0);
+    if (st.transform == 1) {                 // support (lower, inf): biject_to = exp then shift
+      dvdu = Num<T>::exp_(u);
+      v = (T)st.lower + dvdu;
+      ladj = u;
+      dladj = T(1);
+    }
+    T lp = T(0), dv = T(0), da, db;
+    PA_TREE_FAMILY(st.dist, (lp = elem_site_lp<D_, T>(v, a, b, dv, da, db)));
+    const T ge = st.g_ext != nullptr ? ((const T*)st.g_ext)[slot * lay.len[si] + j] : T(0);
+    gq.x[m] = -((dv + ge) * dvdu + dladj);
+    lp_sum += lp + ladj;
+  }
+  c.sum2(lp_sum, zero);
+  pe_q = -(dp.ll_ext != nullptr ? ((const T*)dp.ll_ext)[slot] : T(0)) - lp_sum;
+}
+
+template <typename T, int NW, int NPL, bool RUN, bool DIRECT = false>
 __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     T* __restrict__ z_io, T* __restrict__ pe_io, T* __restrict__ grad_io, T* __restrict__ zq_io,
     T* __restrict__ rq_io, const T* __restrict__ gq_in, const T* __restrict__ peq_in,
@@ -293,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     const uint64_t* __restrict__ t_dev, uint64_t chain_offset,
     TreeWs<T> ws, T* __restrict__ accept_prob_out, int32_t* __restrict__ nleap_out,
     int32_t* __restrict__ depth_out, int32_t* __restrict__ div_out, int32_t* __restrict__ acc_out,
-    int32_t* __restrict__ n_active, TreeRun<T> run) {
+    int32_t* __restrict__ n_active, TreeRun<T> run, TreeDirect direct = TreeDirect{}) {
   __shared__ T red[2 * NW];
   const int slot = blockIdx.x;
   int chain = slot;
@@ -337,8 +439,14 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     v.x[m] = c.ok(m) ? inv_mass[(int64_t)chain * im_stride + c.tid + m * c.NT] : T(1);
     sq.x[m] = Num<T>::sqrt_(v.x[m]);  // mass_matrix_sqrt_inverse
   }
-  Vec<T, NPL> zq = c.ld(zq_io), rq = c.ld(rq_io), gq = c.ld_at(gq_in, slot_row);
-  const T pe_q = peq_in[slot];
+  Vec<T, NPL> zq = c.ld(zq_io), rq = c.ld(rq_io), gq;
+  T pe_q;
+  if constexpr (DIRECT) {
+    direct_potential<T, NW, NPL>(c, direct, run.lay, slot, zq, gq, pe_q);
+  } else {
+    gq = c.ld_at(gq_in, slot_row);
+    pe_q = peq_in[slot];
+  }
 
   // ---- second half-kick (integrator.py:62-63) and the base tree (nuts.py:197-248) ----------
   {
@@ -414,7 +522,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
       kick_drift(zq, rq, gq, v, eps_d);
       c.st(zq_io, zq);
       c.st(rq_io, rq);
-      if (zq_slot != nullptr) c.st_at(zq_slot, slot_row, zq);
+      if (zq_slot != nullptr) c.st_slot(zq_slot, run.lay, run.n_slots, slot, zq);
     } else {
       // ---- the doubling is complete (nuts.py:436-503) ---------------------------------------
       const int e_dir = dir == 1 ? 1 : 0;
@@ -455,7 +563,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
           kick_drift(zn, rn, gn, v, ndir == 1 ? eps : -eps);
           c.st(zq_io, zn);
           c.st(rq_io, rn);
-          if (zq_slot != nullptr) c.st_at(zq_slot, slot_row, zn);
+          if (zq_slot != nullptr) c.st_slot(zq_slot, run.lay, run.n_slots, slot, zn);
           if (threadIdx.x == 0) {
             ws.iscal[IS_DIR * C + chain] = ndir;
             ws.iscal[IS_LEAF * C + chain] = 0;
@@ -533,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
       if ((int64_t)span_k + 1 < K) {
         // the chain's next transition starts here (the scalars of the finished tree are dead)
         tree_begin_chain<T, NW, NPL>(c, chain, C, zc, gc, pe_c, v, eps_next, multinomial, seed,
-                                     tt + 1, cid, ws, zq_io, rq_io, zq_slot, slot_row);
+                                     tt + 1, cid, ws, zq_io, rq_io, zq_slot, slot, &run.lay, run.n_slots);
       } else if (threadIdx.x == 0) {
         ws.iscal[IS_ACTIVE * C + chain] = 0;
         ws.iscal[IS_DIVERGED * C + chain] = diverged;
@@ -571,10 +679,20 @@ __global__ __launch_bounds__(1024) void nuts_tree_compact_kernel(const int32_t* 
                                                                int D, const T* __restrict__ zq,
                                                                int32_t* __restrict__ slot2chain,
                                                                T* __restrict__ zq_slot, int n_slots,
-                                                               int32_t* __restrict__ n_placed) {
+                                                               int32_t* __restrict__ n_placed, SlotLayout lay,
+                                                               int identity) {
   __shared__ int32_t counts[1024];
   __shared__ int32_t total;
   const int tid = threadIdx.x;
+  if (identity) {
+    // the FULL round in the layout `lay` (slot == chain, every chain placed): the cursor rows re-laid only
+    for (int64_t e = tid; e < C * D; e += 1024) {
+      const int64_t ch = e / D;
+      zq_slot[slot_index(lay, C, ch, D, (int)(e % D))] = zq[e];
+    }
+    if (tid == 0) *n_placed = (int32_t)C;
+    return;
+  }
   const int64_t per = (C + 1023) / 1024, lo = tid * per, hi = lo + per < C ? lo + per : C;
   int32_t mine = 0;
   for (int64_t ch = lo; ch < hi; ++ch) mine += iscal[IS_ACTIVE * C + ch] != 0;
@@ -598,7 +716,7 @@ __global__ __launch_bounds__(1024) void nuts_tree_compact_kernel(const int32_t* 
   const int filled = total < n_slots ? total : n_slots;
   for (int64_t e = tid; e < (int64_t)filled * D; e += 1024) {
     const int s = (int)(e / D), d = (int)(e % D);
-    zq_slot[e] = zq[(int64_t)slot2chain[s] * D + d];
+    zq_slot[slot_index(lay, n_slots, s, D, d)] = zq[(int64_t)slot2chain[s] * D + d];
   }
 }
 
@@ -670,13 +788,33 @@ static int tree_run_advance(void* z, void* pe, void* grad, void* zq, void* rq, c
                             int64_t D, int max_depth, int multinomial, uint64_t seed,
                             uint64_t chain_offset, TreeRun<T> run, int64_t n_slots, void* accept_prob,
                             int32_t* nl, int32_t* dp, int32_t* dv, int32_t* ac, void* workspace,
-                            hipStream_t s) {
+                            hipStream_t s, const TreeDirect* direct = nullptr) {
   TreePlan pl;
   tree_plan(D, &pl);
   TreeWs<T> ws = tree_ws<T>(workspace, C, D, max_depth);
   hipEvent_t ev0, ev1;
   const bool br = take_bracket(PA_KERNEL_NUTS, &ev0, &ev1);
   if (br) (void)hipEventRecord(ev0, s);
+  if (direct != nullptr) {
+    if constexpr (sizeof(T) == 4) {
+      // (float32, D <= 512: what the GLM kernels feed)
+#define PA_CALLD(NW, NPL)                                                                          \
+  hipLaunchKernelGGL((nuts_tree_advance_kernel<float, NW, NPL, true, true>), dim3((unsigned)n_slots), \
+                     dim3(64 * NW), 0, s, (float*)z, (float*)pe, (float*)grad, (float*)zq, (float*)rq, \
+                     (const float*)nullptr, (const float*)nullptr, (const float*)inv_mass, im_stride, \
+                     (const float*)run.step, C, (int)D, max_depth, multinomial, seed, (uint64_t)0,  \
+                     (const uint64_t*)nullptr, chain_offset, ws, (float*)accept_prob, nl, dp, dv, ac, \
+                     (int32_t*)nullptr, run, *direct)
+      if (pl.nw == 1 && pl.npl == 2) { PA_CALLD(1, 2); }
+      else if (pl.nw == 1 && pl.npl == 8) { PA_CALLD(1, 8); }
+      else return fail(PA_ERR_UNSUPPORTED, "nuts_tree_run_advance_direct: D > 512");
+#undef PA_CALLD
+      if (br) (void)hipEventRecord(ev1, s);
+      return check_launch("nuts_tree_run_advance_direct_kernel");
+    } else {
+      return fail(PA_ERR_UNSUPPORTED, "nuts_tree_run_advance_direct: float32 only");
+    }
+  }
 #define PA_CALL(TT, NW, NPL)                                                                      \
   hipLaunchKernelGGL((nuts_tree_advance_kernel<TT, NW, NPL, true>), dim3((unsigned)n_slots),       \
                      dim3(64 * NW), 0, s, (TT*)z, (TT*)pe, (TT*)grad, (TT*)zq, (TT*)rq,           \
@@ -828,7 +966,7 @@ int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq,
     pa::TreeRun<float> run{ctl, (float*)step, (float*)da_state, (float*)welford,
                            (float*)mean_accept, counters, tc, n_done, done_flag, target_accept,
                            10.0, 0.75, 0.05,   // DualAveraging defaults (ops/dual_averaging.py)
-                           slot2chain, (float*)zq_slot};
+                           slot2chain, (float*)zq_slot, pa::SlotLayout{}, n_slots};
     return pa::tree_run_advance<float>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, C, D,
                                        max_tree_depth, use_multinomial, seed, chain_offset, run, n_slots,
                                        accept_prob, n_leapfrog, depth, diverging, accepted,
@@ -836,32 +974,103 @@ int pa_nuts_tree_run_advance(int dtype, void* z, void* pe, void* grad, void* zq,
   }
   pa::TreeRun<double> run{ctl, (double*)step, (double*)da_state, (double*)welford,
                           (double*)mean_accept, counters, tc, n_done, done_flag, target_accept,
-                          10.0, 0.75, 0.05, slot2chain, (double*)zq_slot};
+                          10.0, 0.75, 0.05, slot2chain, (double*)zq_slot, pa::SlotLayout{}, n_slots};
   return pa::tree_run_advance<double>(z, pe, grad, zq, rq, gq, peq, inv_mass, im_stride_row, C, D,
                                       max_tree_depth, use_multinomial, seed, chain_offset, run, n_slots,
                                       accept_prob, n_leapfrog, depth, diverging, accepted,
                                       workspace, s);
 }
 
+static int tree_layout(int n_sites, const int32_t* site_off, const int32_t* site_len, int64_t D,
+                       pa::SlotLayout* lay) {
+  *lay = pa::SlotLayout{};
+  if (n_sites == 0) return PA_OK;
+  PA_REQUIRE(n_sites >= 1 && n_sites <= pa::TREE_MAX_SITES && site_off && site_len,
+             "nuts_tree: 1..%d sites", pa::TREE_MAX_SITES);
+  int64_t at = 0;
+  for (int k = 0; k < n_sites; ++k) {
+    PA_REQUIRE(site_off[k] == at && site_len[k] >= 1, "nuts_tree: sites must tile [0, D) in ascending order");
+    lay->off[k] = site_off[k];
+    lay->len[k] = site_len[k];
+    at += site_len[k];
+  }
+  PA_REQUIRE(at == D, "nuts_tree: the sites cover %lld of D = %lld coordinates", (long long)at, (long long)D);
+  lay->n_sites = n_sites;
+  return PA_OK;
+}
+
 int pa_nuts_tree_compact(int dtype, const void* zq, int64_t C, int64_t D, int max_tree_depth,
                          int32_t* slot2chain, void* zq_slot, int64_t n_slots, int32_t* n_placed,
+                         int n_sites, const int32_t* site_off, const int32_t* site_len,
                          void* workspace, size_t workspace_bytes, pa_stream_t stream) {
   const uint64_t t = 0;
   const int64_t im_stride_row = 0;
   PA_TREE_COMMON_CHECKS("nuts_tree_compact")
-  PA_REQUIRE(zq && slot2chain && zq_slot && n_placed && n_slots >= 1 && n_slots <= C,
-             "nuts_tree_compact: bad arguments");
+  PA_REQUIRE(zq && zq_slot && n_placed && n_slots >= 1 && n_slots <= C, "nuts_tree_compact: bad arguments");
+  PA_REQUIRE(slot2chain != nullptr || n_slots == C, "nuts_tree_compact: the identity map is the full round");
+  pa::SlotLayout lay;
+  const int rc = tree_layout(n_sites, site_off, site_len, D, &lay);
+  if (rc != PA_OK) return rc;
+  const int identity = slot2chain == nullptr;
   hipStream_t s = pa::as_stream(stream);
   if (dtype == PA_F32) {
     pa::TreeWs<float> ws = pa::tree_ws<float>(workspace, C, D, max_tree_depth);
     hipLaunchKernelGGL((pa::nuts_tree_compact_kernel<float>), dim3(1), dim3(1024), 0, s, ws.iscal, C, (int)D,
-                       (const float*)zq, slot2chain, (float*)zq_slot, (int)n_slots, n_placed);
+                       (const float*)zq, slot2chain, (float*)zq_slot, (int)n_slots, n_placed, lay, identity);
   } else {
     pa::TreeWs<double> ws = pa::tree_ws<double>(workspace, C, D, max_tree_depth);
     hipLaunchKernelGGL((pa::nuts_tree_compact_kernel<double>), dim3(1), dim3(1024), 0, s, ws.iscal, C, (int)D,
-                       (const double*)zq, slot2chain, (double*)zq_slot, (int)n_slots, n_placed);
+                       (const double*)zq, slot2chain, (double*)zq_slot, (int)n_slots, n_placed, lay, identity);
   }
   return pa::check_launch("nuts_tree_compact_kernel");
+}
+
+int pa_nuts_tree_run_advance_direct(void* z, void* pe, void* grad, void* zq, void* rq, const void* inv_mass,
+                                    int64_t im_stride_row, void* step, int64_t C, int64_t D,
+                                    int max_tree_depth, int use_multinomial, uint64_t seed,
+                                    uint64_t chain_offset, const int64_t* ctl, void* da_state,
+                                    double target_accept, void* welford, void* mean_accept,
+                                    int64_t* counters, int32_t* tc, int32_t* n_done, int64_t* done_flag,
+                                    const int32_t* slot2chain, void* zq_pack, int64_t n_slots,
+                                    int n_sites, const int32_t* site_off, const int32_t* site_len,
+                                    const int32_t* site_dist, const int32_t* site_transform,
+                                    const double* site_lower, const void* const* site_p0,
+                                    const int64_t* site_s0, const void* const* site_p1,
+                                    const int64_t* site_s1, const void* const* site_g_ext,
+                                    const void* ll_ext, void* accept_prob, int32_t* n_leapfrog,
+                                    int32_t* depth, int32_t* diverging, int32_t* accepted, void* workspace,
+                                    size_t workspace_bytes, pa_stream_t stream) {
+  const int dtype = PA_F32;
+  const uint64_t t = 0;
+  PA_TREE_COMMON_CHECKS("nuts_tree_run_advance_direct")
+  PA_REQUIRE(z && pe && grad && zq && rq && inv_mass && step && ctl && da_state && welford && mean_accept &&
+                 counters && tc && n_done && accept_prob && n_leapfrog && depth && diverging && accepted &&
+                 zq_pack && site_dist && site_transform && site_lower && site_p0 && site_s0 && site_p1 &&
+                 site_s1 && site_g_ext,
+             "nuts_tree_run_advance_direct: NULL pointer");
+  PA_REQUIRE(target_accept > 0.0 && target_accept < 1.0, "nuts_tree_run_advance_direct: target_accept");
+  if (slot2chain == nullptr) n_slots = C;
+  PA_REQUIRE(n_slots >= 1 && n_slots <= C, "nuts_tree_run_advance_direct: n_slots=%lld outside [1, C]",
+             (long long)n_slots);
+  PA_REQUIRE(n_sites >= 1, "nuts_tree_run_advance_direct: at least one site");
+  pa::SlotLayout lay;
+  const int rc = tree_layout(n_sites, site_off, site_len, D, &lay);
+  if (rc != PA_OK) return rc;
+  pa::TreeDirect dp{};
+  dp.n_sites = n_sites;
+  dp.ll_ext = ll_ext;
+  for (int k = 0; k < n_sites; ++k) {
+    PA_REQUIRE(site_transform[k] == 0 || site_transform[k] == 1, "nuts_tree_run_advance_direct: transform");
+    dp.s[k] = pa::DirectSite{site_dist[k], site_transform[k], site_p0[k], site_p1[k], site_s0[k], site_s1[k],
+                             site_g_ext[k], site_lower[k]};
+  }
+  pa::TreeRun<float> run{ctl, (float*)step, (float*)da_state, (float*)welford, (float*)mean_accept, counters,
+                         tc, n_done, done_flag, target_accept, 10.0, 0.75, 0.05, slot2chain, (float*)zq_pack,
+                         lay, n_slots};
+  return pa::tree_run_advance<float>(z, pe, grad, zq, rq, nullptr, nullptr, inv_mass, im_stride_row, C, D,
+                                     max_tree_depth, use_multinomial, seed, chain_offset, run, n_slots,
+                                     accept_prob, n_leapfrog, depth, diverging, accepted, workspace,
+                                     pa::as_stream(stream), &dp);
 }
 
 }  // extern "C"

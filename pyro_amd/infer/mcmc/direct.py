@@ -1,0 +1,185 @@
+"""The potential of a FLAT model evaluated without the handlers and without autograd.
+
+The reference evaluates the potential of every leapfrog step by running the conditioned model under its effect
+handlers, summing the sites' log-densities and differentiating the sum (pyro/infer/mcmc/util.py:264-286,
+pyro/ops/integrator.py:68-94).  For a model whose latent sites are scored by fused families at parameters that
+do not depend on other latents, and whose observed site is the Bernoulli-logits GLM over latent weights /
+bias -- Bayesian logistic regression, BASELINE configs[1]'s model under NUTS -- the whole evaluation is
+
+    GLM kernel (log-likelihood per chain + its gradient w.r.t. weights and bias, one pass over X)
+    -> its finalize
+    -> the tree kernel, which adds the latent sites' own log-densities / gradients itself
+       (pa_nuts_tree_run_advance_direct)
+
+three launches per round instead of ~25 operators.  ``recognise`` inspects ONE execution of the model (through
+the handlers, as the generic path runs it) and returns a ``DirectProgram`` or None; nothing is assumed that the
+inspection does not establish, and a model it does not cover keeps the generic potential.
+"""
+import ctypes
+
+import torch
+from torch.distributions import transforms as T
+
+from ... import _lib, kernels, poutine
+from ...primitives import plate
+
+_FAMILIES = (_lib.DIST_NORMAL, _lib.DIST_HALF_CAUCHY, _lib.DIST_LOG_NORMAL, _lib.DIST_EXPONENTIAL,
+             _lib.DIST_HALF_NORMAL, _lib.DIST_GAMMA)
+ENABLED = {"on": True}
+
+
+def _transform_kind(t):
+    """(kind, lower) of ``t`` = biject_to(support).inv: 0 identity, 1 v = lower + exp(u); None otherwise."""
+    from ...distributions import fused
+    if t is T.identity_transform or (type(t) is T.ComposeTransform and not t.parts):
+        return 0, 0.0
+    inv = getattr(t, "inv", None)
+    while type(inv) is T.IndependentTransform:
+        inv = inv.base_transform
+    if inv is T.identity_transform or (type(inv) is T.ComposeTransform and not inv.parts):
+        return 0, 0.0
+    lower = fused.exp_lower_bound_of(t.inv) if inv is not None else None
+    if lower is not None:
+        return 1, float(lower)
+    return None
+
+
+def _param_view(p, n):
+    """(tensor, stride) reading element j of a site of n elements at p[j * stride], or None."""
+    if p is None:
+        return None, 0
+    if not isinstance(p, torch.Tensor) or p.requires_grad or p.dtype != torch.float32 or not p.is_cuda:
+        return False
+    if p.numel() == 1:
+        return p.reshape(1).contiguous(), 0
+    if p.numel() == n:
+        return p.reshape(n).contiguous(), 1
+    return False
+
+
+class DirectProgram:
+    def __init__(self, layout, sites, glm):
+        self.layout, self.sites, self.glm = layout, sites, glm
+        n = len(sites)
+        self.n = n
+        self.off = (ctypes.c_int32 * n)(*[s["off"] for s in sites])
+        self.len = (ctypes.c_int32 * n)(*[s["len"] for s in sites])
+        self.dist = (ctypes.c_int32 * n)(*[s["dist"] for s in sites])
+        self.transform = (ctypes.c_int32 * n)(*[s["transform"] for s in sites])
+        self.lower = (ctypes.c_double * n)(*[s["lower"] for s in sites])
+        self.s0 = (ctypes.c_int64 * n)(*[s["s0"] for s in sites])
+        self.s1 = (ctypes.c_int64 * n)(*[s["s1"] for s in sites])
+        self.keep = [s["p0"] for s in sites] + [s["p1"] for s in sites]
+
+    def pointers(self, g_ext):
+        """(p0, p1, g_ext) pointer arrays of one launch; g_ext: site index -> tensor."""
+        n = self.n
+        p0 = (ctypes.c_void_p * n)(*[None if s["p0"] is None else kernels._ptr(s["p0"]).value for s in self.sites])
+        p1 = (ctypes.c_void_p * n)(*[None if s["p1"] is None else kernels._ptr(s["p1"]).value for s in self.sites])
+        ge = (ctypes.c_void_p * n)(*[None if g_ext.get(k) is None else kernels._ptr(g_ext[k]).value
+                                     for k in range(n)])
+        return p0, p1, ge
+
+    def glm_round(self, pack, n_slots):
+        """The observed site at the cursors of ``pack`` (site-major): (ll [n_slots], {site: d ll / d value})."""
+        g = self.glm
+        wk, bk = g["w_site"], g["b_site"]
+        sw = self.sites[wk]
+        w = pack[n_slots * sw["off"]: n_slots * (sw["off"] + sw["len"])].view(n_slots, sw["len"])
+        b = None
+        if bk is not None:
+            sb = self.sites[bk]
+            b = pack[n_slots * sb["off"]: n_slots * (sb["off"] + 1)]
+        ll, gw, gb = kernels.glm_bernoulli_fwd_bwd(g["X"], g["y"], w, b, None, 1.0)
+        ext = {wk: gw}
+        if bk is not None:
+            ext[bk] = gb
+        return ll, ext
+
+
+def recognise(pe_maker, layout, transforms, init_params, num_chains):
+    """A DirectProgram for the model behind ``pe_maker`` (infer/mcmc/util._PEMaker), or None."""
+    if not ENABLED["on"] or pe_maker.enum or num_chains < 2:
+        return None
+    try:
+        return _recognise(pe_maker, layout, transforms, init_params, num_chains)
+    except Exception:      # noqa: BLE001  (anything unexpected in the inspection: the generic potential stays)
+        return None
+
+
+def _recognise(pe_maker, layout, transforms, init_params, C):
+    first = next(iter(init_params.values()))
+    if not first.is_cuda or first.dtype != torch.float32 or len(layout.names) > 8 or layout.D > 512:
+        return None
+    # one execution as the generic potential makes it, the unconstrained values as leaves
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in init_params.items()}
+    constrained = {k: transforms[k].inv(v) for k, v in leaves.items()}
+    cond = {k: pe_maker._chain_value(k, v) for k, v in constrained.items()}
+
+    def chained(*a, **kw):
+        with plate("_num_chains", C, dim=-1 - pe_maker.mpn):
+            return pe_maker.model(*a, **kw)
+
+    trace = poutine.trace(poutine.condition(chained, cond)).get_trace(*pe_maker.args, **pe_maker.kwargs)
+    sites, glm, seen = [], None, set()
+    by_name = {}
+    for name, site in trace.nodes.items():
+        if site["type"] != "sample" or type(site["fn"]).__name__ == "_Subsample":
+            continue
+        if name == "_num_chains":
+            continue
+        fn, mask, scale = site["fn"], site["mask"], site["scale"]
+        if mask is not None and mask is not True:
+            return None
+        if isinstance(scale, torch.Tensor) or float(scale) != 1.0:
+            return None
+        if name in layout.slices:                                     # a latent site
+            if site["is_observed"] is False and name not in cond:
+                return None
+            entry = getattr(fn, "fused_site_entry", None)
+            entry = entry(site["value"], 1.0, None) if entry is not None else None
+            if entry is None or entry[0] not in _FAMILIES:
+                return None
+            a, b = layout.slices[name]
+            kind = _transform_kind(transforms[name])
+            if kind is None:
+                return None
+            p0 = _param_view(entry[2], b - a)
+            p1 = _param_view(entry[3], b - a)
+            if p0 is False or p1 is False:
+                return None
+            by_name[name] = dict(name=name, off=a, len=b - a, dist=int(entry[0]), transform=kind[0], lower=kind[1],
+                                 p0=p0[0], s0=p0[1], p1=p1[0], s1=p1[1])
+            seen.add(name)
+        else:                                                         # an observed site: the GLM, once
+            lz = getattr(fn, "lazy", None)
+            if glm is not None or lz is None or type(lz).__name__ != "LinearLogits" or not site["is_observed"]:
+                return None
+            X, y = lz.X, site["value"]
+            if not (X.is_cuda and X.dtype == torch.float32 and X.is_contiguous() and y.dim() == 1
+                    and y.shape[0] == X.shape[0] and X.shape[1] <= kernels.planes_max_d() and X.shape[0] > 0):
+                return None
+            glm = dict(X=X, y=y.to(torch.float32).contiguous(), w=lz.w, b=lz.b)
+    if glm is None or seen != set(layout.names):
+        return None
+    ordered = [by_name[n] for n in layout.names]                      # ascending offsets: the flat layout's order
+
+    def site_of(t):
+        """The latent site whose (identity-transformed) value ``t`` is a view of."""
+        if t is None:
+            return None
+        for k, s in enumerate(ordered):
+            v = cond[s["name"]]
+            if s["transform"] == 0 and t.numel() == v.numel() and \
+                    t.untyped_storage().data_ptr() == v.untyped_storage().data_ptr():
+                return k
+        return False
+
+    from ...ops.lazy import _plain
+    wk, bk = site_of(_plain(glm["w"])), site_of(_plain(glm["b"]) if glm["b"] is not None else None)
+    if wk is False or wk is None or bk is False:
+        return None
+    if ordered[wk]["len"] != glm["X"].shape[1] or (bk is not None and ordered[bk]["len"] != 1):
+        return None
+    glm.update(w_site=wk, b_site=bk)
+    return DirectProgram(layout, ordered, glm)
