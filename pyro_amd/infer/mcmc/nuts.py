@@ -48,6 +48,7 @@ class NUTS(HMC):
         self.use_persistent = True   # many transitions per launch on the fused Gaussian path
         self.use_async_chains = True # model / generic potentials: spans of transitions without lock step
         self.rounds_per_replay = 16  # tree rounds in the captured graph of the asynchronous path
+        self.use_direct_potential = True   # flat models: the potential without handlers / autograd (direct.py)
         self.compact_chains = True   # late in a span: rounds over the chains still active only
         self.min_slots = 64          # smallest compacted round (the GLM kernels take 64 columns per pass)
         self._launch_hook = None     # called before every fused launch (bench: event brackets)
@@ -82,6 +83,14 @@ class NUTS(HMC):
         self._span_rounds = 0                                          # slot-rounds evaluated (occupancy)
         self._span_compactions = 0
         self._da_buf = self._wf_buf = None
+        self._direct = None
+        if self.use_direct_potential and self.model is not None and not self._dense and self.num_chains > 1 \
+                and self._z.is_cuda:
+            from . import direct
+            maker = getattr(self.potential_fn, "__self__", None)       # the bound _PEMaker.potential_fn
+            if maker is not None:
+                self._direct = direct.recognise(maker, self._layout, self.transforms, self._initial_params,
+                                                self.num_chains)
         self._tree_depth_sum = torch.zeros((), dtype=torch.int64, device=self._z.device)
         self._counters = torch.zeros((3, self.num_chains), dtype=torch.int64,
                                      device=self._z.device)
@@ -246,6 +255,15 @@ class NUTS(HMC):
         return k
 
     def _span_round(self, tree, potential, slots=None):
+        prog = self._direct
+        if prog is not None:
+            # a flat model: the observed site's kernel at the (site-major) cursors, everything else inside
+            # the tree kernel -- three launches, no handlers, no autograd (infer/mcmc/direct.py)
+            n_slots = self.num_chains if slots[0] is None else slots[0].numel()
+            ll, ext = prog.glm_round(slots[1], n_slots)
+            tree.run_advance_direct(prog, ll, ext, self._da_buf, self._adapter.target_accept_prob,
+                                    self._wf_buf, self._mean_accept_prob, self._counters, slots)
+            return ll, ext
         pe, grad = potential(tree.zq if slots is None else slots[1])
         tree.run_advance(pe.detach().contiguous(), grad.detach().contiguous(), self._da_buf,
                          self._adapter.target_accept_prob, self._wf_buf, self._mean_accept_prob,
@@ -283,6 +301,8 @@ class NUTS(HMC):
         C = self.num_chains
         sizes = self._slot_sizes()
         cur, slots = C, None
+        if self._direct is not None:
+            slots = tree.compact(C, self._direct)      # the full round's cursors in the site-major layout
         polls = 0
         while True:
             graph = self._span_graphs.get(cur)
@@ -305,7 +325,7 @@ class NUTS(HMC):
             fit = [n for n in sizes if n >= active and n < cur]
             if fit:
                 cur = min(fit)
-                slots = tree.compact(cur)
+                slots = tree.compact(cur, self._direct)
                 self._span_compactions += 1
             if polls > (1 << 22):
                 raise RuntimeError("pyro_amd: NUTS span did not complete")

@@ -1607,23 +1607,53 @@ class NutsTree:
             _ptr(self.tc), _ptr(self.n_done), _ptr(self.gate[1:]), _ptr(self.ws), self.nbytes,
             _stream()))
 
-    def compact(self, n_slots):
+    def compact(self, n_slots, program=None):
         """Slots of a COMPACTED round: the chains still building a tree (ascending, -1 pads) and their
         cursor rows.  Returns (slot2chain int32[n_slots], zq_slot [n_slots, D]) -- persistent per size (a
         captured graph of rounds of that size holds their addresses) -- after refreshing them; the caller
-        makes sure n_slots >= the number of active chains (``n_placed()``)."""
+        makes sure n_slots >= the number of active chains.  With ``program`` (infer/mcmc/direct.py) the
+        cursor buffer is SITE-MAJOR (the sites' blocks [n_slots, len] one after the other) and
+        ``n_slots == C`` is the full round (slot2chain None: the identity)."""
         bufs = getattr(self, "_slots", None)
         if bufs is None:
             bufs = self._slots = {}
             self._n_placed = torch.zeros((1,), dtype=torch.int32, device=self.z.device)
-        if n_slots not in bufs:
-            bufs[n_slots] = (torch.full((n_slots,), -1, dtype=torch.int32, device=self.z.device),
-                             torch.zeros((n_slots, self.D), dtype=self.z.dtype, device=self.z.device))
-        s2c, zqs = bufs[n_slots]
+        key = (n_slots, program is not None)
+        if key not in bufs:
+            full = program is not None and n_slots == self.C
+            bufs[key] = (None if full else torch.full((n_slots,), -1, dtype=torch.int32, device=self.z.device),
+                         torch.zeros((n_slots * self.D,), dtype=self.z.dtype, device=self.z.device)
+                         if program is not None else
+                         torch.zeros((n_slots, self.D), dtype=self.z.dtype, device=self.z.device))
+        s2c, zqs = bufs[key]
         check(_lib.load().pa_nuts_tree_compact(
             self.dt, _ptr(self.zq), self.C, self.D, self.max_tree_depth, _ptr(s2c), _ptr(zqs), n_slots,
-            _ptr(self._n_placed), _ptr(self.ws), self.nbytes, _stream()))
+            _ptr(self._n_placed), 0 if program is None else program.n,
+            None if program is None else program.off, None if program is None else program.len,
+            _ptr(self.ws), self.nbytes, _stream()))
         return s2c, zqs
+
+    def run_advance_direct(self, program, ll_ext, g_ext, da_state, target_accept, welford, mean_accept,
+                           counters, slots):
+        """run_advance for a flat model (infer/mcmc/direct.DirectProgram): the latent sites' own
+        log-densities and gradients are computed by the tree kernel, ``ll_ext`` [n_slots] / ``g_ext``
+        {site: [n_slots, len]} come from the observed site's kernel; ``slots`` = compact(n, program)."""
+        s2c, pack = slots
+        n_slots = self.C if s2c is None else s2c.numel()
+        _require_gpu(ll_ext, pack, da_state, welford, mean_accept, counters)
+        assert self.z.dtype == torch.float32 and ll_ext.is_contiguous() and ll_ext.numel() == n_slots
+        for t in g_ext.values():
+            assert t.is_contiguous() and t.dtype == torch.float32
+        p0, p1, ge = program.pointers(g_ext)
+        check(_lib.load().pa_nuts_tree_run_advance_direct(
+            _ptr(self.z), _ptr(self.pe), _ptr(self.grad), _ptr(self.zq), _ptr(self.rq), _ptr(self.inv_mass),
+            self.im_stride, _ptr(self.step), self.C, self.D, self.max_tree_depth, self.multinomial, self.seed,
+            self.chain_offset, _ptr(self.ctl), _ptr(da_state), float(target_accept), _ptr(welford),
+            _ptr(mean_accept), _ptr(counters), _ptr(self.tc), _ptr(self.n_done), _ptr(self.gate[1:]),
+            _ptr(s2c), _ptr(pack), n_slots, program.n, program.off, program.len, program.dist,
+            program.transform, program.lower, p0, program.s0, p1, program.s1, ge, _ptr(ll_ext),
+            _ptr(self.accept_prob), _ptr(self.ints[0]), _ptr(self.ints[1]), _ptr(self.ints[2]),
+            _ptr(self.ints[3]), _ptr(self.ws), self.nbytes, _stream()))
 
     def run_advance(self, peq, gq, da_state, target_accept, welford, mean_accept, counters, slots=None):
         """One round of a span: every live chain consumes (peq, gq) at its cursor; a chain whose

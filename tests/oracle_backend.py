@@ -400,8 +400,9 @@ class NutsTree:
         self._o.run_begin(samples=self._sn, div_flags=self._dn, **self._span)
         self._sync()
 
-    def compact(self, n_slots):
+    def compact(self, n_slots, program=None):
         """kernels.NutsTree.compact: the chains still building a tree (ascending, -1 pads), their cursors."""
+        assert program is None          # (the direct potential is a device path: tests/test_mcmc_gpu.py)
         active = [c for c in range(self.C) if self._o.chains[c].active]
         assert len(active) <= n_slots
         s2c = torch.full((n_slots,), -1, dtype=torch.int32)

@@ -389,3 +389,97 @@ def test_device_step_size_search_matches_the_lock_step_search(gpu, dtype):
     med = {f: float(v.median()) for f, v in res.items()}
     assert abs(med[True] - med[False]) <= 1.0, med
     assert float((res[True] - med[True]).abs().max()) <= 3.0
+
+
+def _logreg_data(gpu, N=20000, D=32, seed=3):
+    from pyro_amd import examples
+    return examples.synthetic_logreg_data(N, D, gpu, seed=seed)
+
+
+def test_flat_models_are_recognised_and_others_are_not(gpu):
+    """infer/mcmc/direct.recognise: Bayesian logistic regression (with and without a bias, a HalfNormal-scaled
+    variant whose positive site goes through the exp transform) gets a direct program; a hierarchical prior
+    (a site's scale is another latent), a second observed site, a masked site do not."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd import examples
+    from pyro_amd.infer.mcmc import NUTS
+
+    X, y = _logreg_data(gpu)
+
+    def no_bias(X, y):
+        w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), 2.0).to_event(1))
+        with pyro.plate("data", X.shape[0]):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
+
+    def with_positive_site(X, y):
+        pyro.sample("tau", dist.HalfNormal(X.new_ones(())))          # a flat extra latent: exp transform
+        examples.logreg_model(X, y)
+
+    def hierarchical(X, y):
+        tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), tau).to_event(1))
+        with pyro.plate("data", X.shape[0]):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
+
+    def two_observed(X, y):
+        examples.logreg_model(X, y)
+        pyro.sample("extra", dist.Normal(X.new_zeros(()), 1.0), obs=X.new_ones(()))
+
+    expect = [(examples.logreg_model, 2), (no_bias, 1), (with_positive_site, 3), (hierarchical, None),
+              (two_observed, None)]
+    for model, n_sites in expect:
+        pyro.set_rng_seed(0)
+        k = NUTS(model, max_tree_depth=4)
+        k.num_chains = 64
+        with pyro.validation_enabled(False):
+            k.setup(4, X, y)
+        if n_sites is None:
+            assert k._direct is None, model.__name__
+        else:
+            assert k._direct is not None and k._direct.n == n_sites, model.__name__
+            assert k._direct.glm["w_site"] is not None
+        k.cleanup()
+
+
+@pytest.mark.parametrize("model_name", ["logreg", "positive_site"])
+def test_direct_potential_runs_the_chains_of_the_generic_potential(gpu, model_name):
+    """MCMC(NUTS(flat model)) with the potential assembled inside the tree kernel (GLM kernel + finalize +
+    tree kernel per round) against the same run through the handlers and autograd: the first transitions
+    chain for chain (float32 potentials rounded differently: rtol 5e-4, the same trees), the posterior means
+    of a longer run within Monte-Carlo error."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd import examples
+    from pyro_amd.infer.mcmc import MCMC, NUTS
+
+    X, y = _logreg_data(gpu, N=20000, D=32)
+
+    def positive_site(X, y):
+        pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        examples.logreg_model(X, y)
+
+    model = examples.logreg_model if model_name == "logreg" else positive_site
+
+    def run(direct, warmup, samples, adapt, C=64, depth=5):
+        pyro.set_rng_seed(5)
+        k = NUTS(model, max_tree_depth=depth, step_size=0.02, adapt_step_size=adapt, adapt_mass_matrix=adapt)
+        k.use_direct_potential = direct
+        k.compact_chains = False
+        m = MCMC(k, num_samples=samples, warmup_steps=warmup, num_chains=C)
+        m.run(X, y)
+        assert (k._direct is not None) == direct
+        s = m.get_samples(group_by_chain=True)
+        return s, k.num_leapfrog_steps
+
+    a, na = run(True, 0, 3, False)
+    b, nb = run(False, 0, 3, False)
+    assert na == nb, (na, nb)
+    for name in a:
+        torch.testing.assert_close(a[name], b[name], rtol=5e-4, atol=5e-5)
+    a, _ = run(True, 150, 150, True)
+    b, _ = run(False, 150, 150, True)
+    for name in a:
+        ma, mb = a[name].mean((0, 1)), b[name].mean((0, 1))
+        sd = b[name].std((0, 1)) + 1e-6
+        assert float(((ma - mb).abs() / sd).max()) < 0.2, name        # (64 x 150 draws: ~0.01 sd of MC error)
