@@ -16,17 +16,21 @@ from pyro_amd.infer.mcmc import NUTS  # noqa: E402
 from tests import mcmc_cases as mc  # noqa: E402
 
 
-def run(X, y, C, warmup, samples, max_tree_depth=6, lockstep=False, jit=False, seed=1, model=None, compact=True):
+def run(X, y, C, warmup, samples, max_tree_depth=6, lockstep=False, jit=False, seed=1, model=None, compact=True,
+        rounds=0, generic=False):
     """-> dict(leapfrog_per_s, leapfrogs, seconds, rounds, mean_depth, step_size) of the sampling phase."""
     with pyro.validation_enabled(False):        # (MCMC.run's default: disable_validation=True)
-        return _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model, compact)
+        return _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model, compact, rounds, generic)
 
 
-def _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model, compact):
+def _run(X, y, C, warmup, samples, max_tree_depth, lockstep, jit, seed, model, compact, rounds, generic):
     pyro.set_rng_seed(seed)
     kernel = NUTS(model or mc.logreg_mcmc_model, max_tree_depth=max_tree_depth, jit_compile=jit)
     kernel.use_async_chains = not lockstep
     kernel.compact_chains = compact
+    kernel.use_direct_potential = not generic
+    if rounds:
+        kernel.rounds_per_replay = rounds
     kernel.num_chains = C
     kernel.setup(warmup, X, y)
     dev = X.device
@@ -77,6 +81,8 @@ if __name__ == "__main__":
     ap.add_argument("--depth", type=int, default=6)
     ap.add_argument("--lockstep", action="store_true")
     ap.add_argument("--no-compact", action="store_true")
+    ap.add_argument("--rounds", type=int, default=0, help="tree rounds per graph replay (0: the kernel's default)")
+    ap.add_argument("--generic", action="store_true", help="the potential through the handlers and autograd")
     ap.add_argument("--both", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -86,7 +92,8 @@ if __name__ == "__main__":
     yc = (torch.rand((N,), generator=g) < torch.sigmoid(Xc @ torch.randn(D, generator=g) * 0.3)).float()
     X, y = Xc.to(dev), yc.to(dev)
     for lock in ((True, False) if a.both else (a.lockstep,)):
-        r = run(X, y, C, a.warmup, a.samples, a.depth, lockstep=lock, compact=not a.no_compact)
+        r = run(X, y, C, a.warmup, a.samples, a.depth, lockstep=lock, compact=not a.no_compact, rounds=a.rounds,
+                generic=a.generic)
         print("N=%d C=%d %s: sampling %.3f s, %d leapfrogs, %.0f leapfrog/s (%.0f rounds/s if every round served all "
               "chains); warm-up %.2f s; %s" % (N, C, "lock-step" if lock else "async spans", r["seconds"],
                                                r["leapfrogs"], r["leapfrog_per_s"], r["leapfrog_per_s"] / C,
