@@ -982,9 +982,9 @@ int pa_chain_debug_stamps(void* stamps32);
  * over examples/lda.py:78-122 dispatches ~110 of them per step).  The host emits one HIP source per run;
  * pa_rtc_compile builds it for gfx950 with hiprtc (-ffp-contract=off: a product and a sum stay two
  * roundings, as in the operators they replace) and returns the kernel `kernel_name` of it; the kernel's
- * single parameter is a struct of PA_RTC_MAX_POINTERS device pointers by value (shapes and strides are
+ * single parameter is a struct of at most PA_RTC_MAX_POINTERS device pointers by value (shapes and strides are
  * constants of the source).  pa_rtc_launch: grid x block threads on `stream`, pointers[0..n). */
-#define PA_RTC_MAX_POINTERS 64
+#define PA_RTC_MAX_POINTERS 384
 int pa_rtc_compile(const char* source, const char* kernel_name, void** function_out);
 int pa_rtc_launch(void* function, uint32_t grid, uint32_t block, const void* const* pointers,
                   int n_pointers, pa_stream_t stream);

@@ -62,9 +62,9 @@ int pa_rtc_launch(void* function, uint32_t grid, uint32_t block, const void* con
   PA_REQUIRE(function && grid > 0 && block > 0 && block <= 1024, "rtc_launch: bad launch geometry");
   PA_REQUIRE(n_pointers >= 0 && n_pointers <= PA_RTC_MAX_POINTERS && (pointers || n_pointers == 0),
              "rtc_launch: %d pointers (at most %d)", n_pointers, PA_RTC_MAX_POINTERS);
-  // the kernel's ONE parameter is a struct of PA_RTC_MAX_POINTERS pointers, by value.  While the stream is
+  // the kernel's ONE parameter is a struct of at most PA_RTC_MAX_POINTERS pointers, by value.  While the stream is
   // being captured the runtime reads the parameter block when the capture ENDS (a block on this stack frame
-  // crashed hipStreamEndCapture): such launches get a block that lives as long as the process (520 bytes per
+  // crashed hipStreamEndCapture): such launches get a block that lives as long as the process (3 KB per
   // captured launch)
   struct Block { const void* table[PA_RTC_MAX_POINTERS]; void* params[1]; };
   Block local{};

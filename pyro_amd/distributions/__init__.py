@@ -40,6 +40,9 @@ _wrap_all()
 
 
 # pyro-style overrides that matter for the enumeration path (reference: torch.py:124-149)
+_SUPPORTS = {}
+
+
 class Categorical(torch.distributions.Categorical, TorchDistributionMixin):
     def expand(self, batch_shape, _instance=None):
         """Expansion keeps the log-probability table a stride-0 VIEW of the un-expanded one.
@@ -62,8 +65,18 @@ class Categorical(torch.distributions.Categorical, TorchDistributionMixin):
         return new
 
     def enumerate_support(self, expand=True):
-        result = super().enumerate_support(expand=expand)
-        if not expand:
+        # (torch/distributions/categorical.py:149-156: arange(num_events) on a fresh leftmost dim; the arange
+        # itself is kept per (size, device) -- a step of a pyro.markov loop would launch one per time step)
+        n, dev = self._num_events, self._param.device
+        values = _SUPPORTS.get((n, dev))
+        if values is None:
+            values = torch.arange(n, dtype=torch.long, device=dev)
+            if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                _SUPPORTS[(n, dev)] = values
+        result = values.view((-1,) + (1,) * len(self._batch_shape))
+        if expand:
+            result = result.expand((-1,) + self._batch_shape)
+        else:
             result._pyro_categorical_support = id(self)
         return result
 

@@ -8,6 +8,7 @@ passed as stride-0 views and never materialised.
 import torch
 
 from .. import kernels
+from ..ops import fuser as _fuser
 from ..ops.torch_library import dispatcher_op as _dispatcher_op
 
 
@@ -154,6 +155,8 @@ def _sum_to(g, like):
     plan = _sum_plan(g.shape, like.shape)
     if plan is None:
         return g.sum_to_size(like.shape)
+    if _fuser.active() is not None and len(plan) == 1 and plan[0][1] <= _fuser.MAX_REDUCE:
+        return g.sum_to_size(like.shape)        # (a recorded reduction: no launch of its own, see ops/fuser.py)
     x = g.contiguous()
     for A, R, B in plan:
         x = kernels.sum_to_nd(x, A, R, B)
@@ -263,8 +266,11 @@ class _LogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dist_id, value, p0, p1):
         shape = torch.broadcast_shapes(value.shape, p0.shape, p1.shape if p1 is not None else ())
-        rows, cols, (v2, a2, b2) = frame([value, p0, p1], shape)
-        out = kernels.dist_log_prob(dist_id, v2, a2, b2, rows, cols).reshape(shape)
+        f = _fuser.active()
+        out = f.family_log_prob(dist_id, value, p0, p1, shape) if f is not None else None
+        if out is None:
+            rows, cols, (v2, a2, b2) = frame([value, p0, p1], shape)
+            out = kernels.dist_log_prob(dist_id, v2, a2, b2, rows, cols).reshape(shape)
         ctx.dist_id, ctx.shape = dist_id, shape
         ctx.save_for_backward(value, p0, p1)
         return out
@@ -277,9 +283,12 @@ class _LogProb(torch.autograd.Function):
                 p1 is not None and ctx.needs_input_grad[3])
         if torch.is_grad_enabled():                 # create_graph=True
             return (None,) + _differentiable_grads(ctx.dist_id, g, value, p0, p1, None, 1.0, need)
-        rows, cols, (g2, v2, a2, b2) = frame([g, value, p0, p1], shape)
-        dv, da, db = kernels.dist_log_prob_grad(ctx.dist_id, g2, v2, a2, b2, None, 1.0, rows, cols,
-                                                need)
+        f = _fuser.active()
+        got = f.family_grads(ctx.dist_id, g, value, p0, p1, shape, need) if f is not None else None
+        if got is None:
+            rows, cols, (g2, v2, a2, b2) = frame([g, value, p0, p1], shape)
+            got = kernels.dist_log_prob_grad(ctx.dist_id, g2, v2, a2, b2, None, 1.0, rows, cols, need)
+        dv, da, db = got
         outs = [None if d is None else _sum_to(d.reshape(shape), like)
                 for d, like in ((dv, value), (da, p0), (db, p1))]
         return (None,) + tuple(outs)

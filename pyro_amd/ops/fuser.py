@@ -26,6 +26,7 @@ switches it off.
 import ctypes
 import math
 import os
+import re
 import sys
 
 import torch
@@ -34,14 +35,20 @@ from torch.utils._python_dispatch import TorchDispatchMode
 ENABLED = {"on": os.environ.get("PYRO_AMD_FUSER", "1") != "0"}
 STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "flushes": 0, "dead": 0}
 UNFUSED = {}                # operator name -> how often it was met and run as it is (attribution)
-MAX_POINTERS = 64           # PA_RTC_MAX_POINTERS
+MAX_POINTERS = 384          # PA_RTC_MAX_POINTERS
 MAX_REDUCE = 1 << 14        # longest reduction taken (one wave per output element)
 INLINE_REDUCE = 32          # up to here a reduction is a loop inside an element-wise kernel
 MAX_DIMS = 6
+SMALL = 1 << 14             # up to here unconnected nodes of one shape and level share a kernel
+MAX_SCATTER = 64            # index_put(accumulate=True): most index entries a thread walks per element
+MERGE_LEVELS = {"on": os.environ.get("PYRO_AMD_FUSER_LEVELS", "1") != "0"}
+TRACE = {"on": False, "sites": {}, "kernels": []}     # tools/fuser_attribution.py: where the rest comes from
 
 _ACTIVE = [None]
 aten = torch.ops.aten
 _CTYPE = {torch.float32: "float", torch.float64: "double", torch.bool: "bool"}
+_ITYPE = {torch.int64: "long long", torch.int32: "int"}        # operands of comparisons only
+_CTYPE_ALL = {**_CTYPE, **_ITYPE}
 
 
 def _dev(t):
@@ -64,7 +71,6 @@ def scope():
 # expression templates: {0}, {1}, {2} are operands already cast to the compute type T
 # ---------------------------------------------------------------------------------------------------
 _PRELUDE = r'''
-struct Ptrs { void* p[%d]; };
 #define DEV static __device__ __forceinline__
 DEV float exp_(float x) { return expf(x); }        DEV double exp_(double x) { return exp(x); }
 DEV float log_(float x) { return logf(x); }        DEV double log_(double x) { return log(x); }
@@ -85,7 +91,29 @@ template <typename T> DEV T clamp_lo_(T x, T lo) { return x != x ? x : (x < lo ?
 template <typename T> DEV T clamp_hi_(T x, T hi) { return x != x ? x : (x > hi ? hi : x); }
 template <typename T> DEV T sign_(T x) { return T((T(0) < x) - (x < T(0))); }
 template <typename T> DEV T relu_(T x) { return x != x ? x : (x > T(0) ? x : T(0)); }
-''' % MAX_POINTERS
+'''
+
+_FAMILY = []
+
+
+def _family_prelude():
+    """The per-family arithmetic of the library's own site kernels (csrc/dist_fam.h), compiled into the
+    generated source: a family's log-density and its partial derivatives recorded as element-wise nodes are
+    the SAME expressions pa_dist_log_prob / pa_dist_log_prob_grad evaluate."""
+    if not _FAMILY:
+        from .. import _lib
+        here = os.path.dirname(os.path.abspath(__file__))
+        text = open(os.path.join(here, "..", "csrc", "dist_fam.h")).read()
+        text = text.replace('#include "common.h"', "").replace("#pragma once", "")
+        text = text.split("#define PA_DISPATCH_DIST")[0]
+        ids = "".join("#define PA_%s %d\n" % (k, v) for k, v in vars(_lib).items()
+                      if k.startswith("DIST_") and isinstance(v, int))
+        _FAMILY.append(ids + text + "\n}  // namespace pa\n")
+        _FAMILY[0] += ("template <int ID, int W, typename T> DEV T fam_g(T g, T v, T a, T b) {\n"
+                       "  T dv, da, db; pa::Fam<ID, T>::grad(v, a, b, dv, da, db);\n"
+                       "  return g * (W == 0 ? dv : (W == 1 ? da : db));\n}\n")
+    return _FAMILY[0]
+
 
 _UNARY = {
     "neg": "(-{0})", "exp": "exp_({0})", "log": "log_({0})", "log1p": "log1p_({0})", "expm1": "expm1_({0})",
@@ -106,6 +134,10 @@ def _lit(v, dtype):
     """C literal of python scalar ``v`` in the compute type of ``dtype``, exact."""
     if dtype == torch.bool:
         return "true" if bool(v) else "false"
+    if dtype in _ITYPE:
+        if float(v) != int(v):
+            raise Unfusable
+        return "(%dL)" % int(v)
     v = float(v)
     f32 = dtype == torch.float32
     if math.isnan(v):
@@ -121,12 +153,46 @@ def _lit(v, dtype):
     return "(%s)" % v.hex()
 
 
+_STRUCTURAL = (0.0, 1.0, -1.0, 2.0, 0.5)
+
+
+def _scalar(v, dtype):
+    """Operand for python scalar ``v`` of a node computed in ``dtype``: the constants every expression is full
+    of stay literals of the source; any other value travels in the launch's argument table -- bodies that
+    differ only in such a value (``t < lengths`` of time step t) then share one compiled function."""
+    if dtype == torch.bool or isinstance(v, bool):
+        return ("s", _lit(v, dtype))
+    f = float(v)
+    if math.isnan(f) or math.isinf(f) or f in _STRUCTURAL:
+        return ("s", _lit(v, dtype))
+    if dtype in _ITYPE:
+        if f != int(v):
+            raise Unfusable
+        return ("a", int(v) & 0xFFFFFFFFFFFFFFFF, "long")
+    if dtype == torch.float32:
+        f = float(torch.tensor(f, dtype=torch.float32))          # the value the operator itself would use
+        if math.isinf(f):
+            return ("s", _lit(v, dtype))
+    import struct
+    return ("a", struct.unpack("<Q", struct.pack("<d", f))[0], "double")
+
+
 def _contig_strides(shape):
     st, acc = [], 1
     for n in reversed(shape):
         st.append(acc)
         acc *= max(int(n), 1)
     return tuple(reversed(st))
+
+
+def _dense(shape, strides):
+    """Do the strides describe a permutation of a contiguous block (non-overlapping, no holes)?"""
+    acc = 1
+    for n, st in sorted(((n, st) for n, st in zip(shape, strides) if n != 1), key=lambda p: p[1]):
+        if st != acc:
+            return False
+        acc *= n
+    return True
 
 
 def _span(t):
@@ -177,7 +243,14 @@ def _baseline_counts():
 
 
 class _Kernel:
-    __slots__ = ("kind", "shape", "nodes", "index", "npointers", "fixed")
+    __slots__ = ("kind", "shape", "nodes", "index", "npointers", "fixed", "level")
+
+
+def _numel(shape):
+    out = 1
+    for n in shape:
+        out *= n
+    return out
 
 
 def _bcast(a, b):
@@ -206,6 +279,10 @@ class Fuser(TorchDispatchMode):
         self.pending = []
         self.kernels = []
         self.writer = {}            # view key -> pending node that last wrote exactly this view
+        self.touch = {}             # storage address -> pending nodes that read or write it (hazard search)
+        self.wkeys = {}             # storage address -> view keys in self.writer
+        self.small = {}             # (level, shape) -> latest kernel of small nodes there
+        self.created = 0
         self._busy = False
         self._prev = None
         self.log = []               # (op name, fused?) of this scope, for tests / attribution
@@ -230,7 +307,7 @@ class Fuser(TorchDispatchMode):
             else:
                 for n in self.pending:
                     n.kernel = n.ins = n.out = None
-                self.pending, self.kernels, self.writer = [], [], {}
+                self.pending, self.kernels, self.writer, self.touch, self.wkeys, self.small = [], [], {}, {}, {}, {}
         finally:
             from .. import kernels
             _ACTIVE[0] = self._prev
@@ -257,15 +334,17 @@ class Fuser(TorchDispatchMode):
                 return out
             name = func._schema.name
             UNFUSED[name] = UNFUSED.get(name, 0) + 1
+            if TRACE["on"]:
+                _trace_site(name, args)
         # an operator run as it is: whatever recorded work shares memory with its arguments goes first (its
         # result is a fresh tensor; recorded operators that touch none of its arguments are independent of it)
         self.flush_for(_tensors_of(args) + _tensors_of(tuple(kwargs.values())))
         return func(*args, **kwargs)
 
     # ---- recording --------------------------------------------------------------------------------
-    def _tensor_ok(self, t):
-        return _dev(t) and t.dtype in _CTYPE and t.layout == torch.strided and t.dim() <= MAX_DIMS \
-            and not t.is_complex()
+    def _tensor_ok(self, t, ints=False):
+        return _dev(t) and (t.dtype in _CTYPE or (ints and t.dtype in _ITYPE)) and t.layout == torch.strided \
+            and t.dim() <= MAX_DIMS
 
     def _meta(self, func, args, kwargs):
         def conv(x):
@@ -290,21 +369,21 @@ class Fuser(TorchDispatchMode):
         except Exception:       # noqa: BLE001  (no meta kernel, arguments the operator rejects, ...)
             raise Unfusable
 
-    def _operand(self, x, cdtype):
+    def _operand(self, x, cdtype, ints=False):
         """-> ("n", node) | ("t", tensor) | ("s", literal) for an input of a node computed in ``cdtype``."""
         if isinstance(x, torch.Tensor):
             if not _dev(x):
                 if x.dim() == 0:
-                    return ("s", _lit(x.item(), cdtype))
+                    return _scalar(x.item(), cdtype)
                 raise Unfusable
-            if not self._tensor_ok(x):
+            if not self._tensor_ok(x, ints):
                 raise Unfusable
             w = self.writer.get(_view_key(x))
             if w is not None:
                 return ("n", w)
             return ("t", x)
         if isinstance(x, (bool, int, float)):
-            return ("s", _lit(x, cdtype))
+            return _scalar(x, cdtype)
         raise Unfusable
 
     def _record(self, func, args, kwargs):
@@ -334,7 +413,7 @@ class Fuser(TorchDispatchMode):
             raise Unfusable
         n = _Node()
         n.op, n.expr, n.ins, n.shape, n.dtype = op, expr, ins, shape, meta_out.dtype
-        n.ctype = _CTYPE[compute or meta_out.dtype]
+        n.ctype = _CTYPE_ALL[compute or meta_out.dtype]
         n.red = red
         n.inline = inline
         n.live = True
@@ -342,13 +421,18 @@ class Fuser(TorchDispatchMode):
         # fresh: the fuser allocates the output -- nobody has read or written it before
         n.fresh = (out is None) if fresh is None else fresh
         if out is None:
-            if not meta_out.is_contiguous():
-                raise Unfusable
             dev = next(x[1].device for x in ins if x[0] == "t") if any(x[0] == "t" for x in ins) else \
                 next((x[1].out.device for x in ins if x[0] == "n"), None)
             if dev is None:
                 raise Unfusable
-            out = torch.empty(shape, dtype=meta_out.dtype, device=dev)
+            if meta_out.is_contiguous():
+                out = torch.empty(shape, dtype=meta_out.dtype, device=dev)
+            elif _dense(shape, meta_out.stride()):
+                # (the operator's own output layout: a permutation of a contiguous block -- operands that are
+                # transposed views give transposed results, and later operators expect exactly that)
+                out = torch.empty_strided(shape, tuple(meta_out.stride()), dtype=meta_out.dtype, device=dev)
+            else:
+                raise Unfusable
         elif tuple(out.shape) != shape or not self._tensor_ok(out):
             raise Unfusable
         n.out = out
@@ -361,63 +445,81 @@ class Fuser(TorchDispatchMode):
             if x[0] == "n" and (red is not None or inline is not None or x[1].kind != "ew"
                                 or _bcast(x[1].shape, it_shape) != it_shape):
                 x = ("t", x[1].out)
-            if x[0] != "s" and inline is None:
+            if x[0] in "tn" and inline is None:
                 s = tuple(x[1].shape) if x[0] == "t" else x[1].shape
                 if len(s) > len(it_shape) or any(a != b and a != 1 for a, b in zip(reversed(s), reversed(it_shape))):
                     raise Unfusable
             norm.append(x)
         n.ins = ins = norm
-        mem = [x[1] if x[0] == "t" else x[1].out for x in ins if x[0] != "s"]
+        mem = [x[1] if x[0] == "t" else x[1].out for x in ins if x[0] in "tn"]
         n.rspans = [_span(t) for t in mem]
         n.rviews = [_view_key(t) for t in mem]
         self._schedule(n)
         return out
 
     def _schedule(self, n):
-        """Kernel of node ``n``.  Kernels run in index order; a node goes behind every recorded node it has a
-        memory hazard with -- into the SAME kernel when the hazard is index-for-index (element i of one is
-        element i of the other, so the thread that owns the element runs both in program order).  A kernel's
-        iteration domain is the broadcast of its nodes' shapes: a node of a smaller shape is evaluated by every
-        thread at its own broadcast index (its operands are loaded with stride 0 there) and stored by the threads
-        whose index in the expanded dims is 0.  An in-place target must not be expanded (other threads would
-        read the element while its owner writes it): such a node pins the domain to its own shape."""
-        jmin = 0
-        for m in self.pending:
-            conflict = _overlap(n.wspan, m.wspan) or any(_overlap(r, m.wspan) for r in n.rspans) \
-                or any(_overlap(n.wspan, r) for r in m.rspans)
-            if not conflict:
-                continue
-            same = n.kind == "ew" and m.kind == "ew" and self._index_for_index(n, m) and \
-                (n.shape == m.shape or (n.fresh and m.fresh and _bcast(n.shape, m.shape) is not None))
-            # an inline reduction reads a RANGE of its operand per thread, not its own element: what it reads
-            # must be in memory before its kernel starts, and must not be overwritten by that kernel
-            if same and ((n.inline is not None and any(_overlap(r, m.wspan) for r in n.rspans))
-                         or (m.inline is not None and any(_overlap(n.wspan, r) for r in m.rspans))):
-                same = False
-            jmin = max(jmin, m.kernel.index + (0 if same else 1))
+        """Kernel of node ``n``.  Every kernel has a launch LEVEL; kernels of one level are mutually independent
+        (they become one launch, each its own body), every memory hazard points from a lower level to a higher
+        one -- or stays INSIDE a kernel when it is index-for-index (element i of one node is element i of the
+        other: the thread that owns the element runs both in program order).  A node therefore goes one level
+        above every recorded node it has a hazard with, except into the kernel of such a node when all its
+        hazards with that kernel are index-for-index.  A kernel's iteration domain is the broadcast of its
+        nodes' shapes: a node of a smaller shape is evaluated by every thread at its own broadcast index (its
+        operands are loaded with stride 0 there) and stored by the threads whose index in the expanded dims is
+        0.  An in-place target must not be expanded (other threads would read the element while its owner
+        writes it): such a node pins the domain to its own shape."""
+        seen, hazards = set(), []           # (kernel, index-for-index?)
+        for base in {n.wspan[0]} | {r[0] for r in n.rspans}:
+            for m in self.touch.get(base, ()):
+                if id(m) in seen:
+                    continue
+                seen.add(id(m))
+                conflict = _overlap(n.wspan, m.wspan) or any(_overlap(r, m.wspan) for r in n.rspans) \
+                    or any(_overlap(n.wspan, r) for r in m.rspans)
+                if not conflict:
+                    continue
+                same = n.kind == "ew" and m.kind == "ew" and self._index_for_index(n, m) and \
+                    (n.shape == m.shape or (n.fresh and m.fresh and _bcast(n.shape, m.shape) is not None))
+                # an inline reduction reads a RANGE of its operand per thread, not its own element: what it
+                # reads must be in memory before its kernel starts, and must not be overwritten by that kernel
+                if same and ((n.inline is not None and any(_overlap(r, m.wspan) for r in n.rspans))
+                             or (m.inline is not None and any(_overlap(n.wspan, r) for r in m.rspans))):
+                    same = False
+                hazards.append((m.kernel, same))
+        floor = max((h[0].level + 1 for h in hazards), default=0)
+
+        def fits(cand):
+            return self._fits([cand], n)
+
+        # A node joins a kernel where the data flow connects them (it reads a value of that kernel, or rewrites
+        # a view of it, index for index): independent runs stay separate bodies -- the levels put them side by
+        # side in one launch anyway, and bodies of the same text (the time steps of a pyro.markov loop) then
+        # share one compiled function.
         k = None
-        if n.kind == "ew":
-            for cand in reversed(self.kernels):
-                if cand.index < jmin:
-                    break
-                if cand.kind != "ew" or len(cand.nodes) >= 64 or \
-                        len(cand.npointers | self._pointer_keys(n)) > MAX_POINTERS:
-                    continue
-                dom = _bcast(cand.shape, n.shape)
-                if dom is None or len(dom) > MAX_DIMS:
-                    continue
-                if (cand.fixed and dom != cand.shape) or (not n.fresh and dom != n.shape):
-                    continue
-                # (a small run must not be blown up to a large domain for nothing, nor a large one re-run)
-                if dom != cand.shape and dom != n.shape:
-                    continue
-                k = cand
-                k.shape = dom
-                break
+        if n.kind == "ew" and hazards:
+            top = floor - 1
+            group = {id(h[0]): h[0] for h in hazards if h[0].level == top}
+            if all(h[1] for h in hazards if h[0].level == top):
+                # every hazard on the highest level is index-for-index: the node joins that kernel -- kernels,
+                # when it connects several (they are independent of each other so far: one level), which then
+                # become one
+                k = self._merged(list(group.values()), n)
+            if k is None and n.fresh and _numel(n.shape) <= SMALL:
+                # a SMALL node without such a kernel joins the latest kernel of its own shape on its level:
+                # the partial results of a sum over many uses of one parameter (autograd adds them one after
+                # the other) then accumulate inside one kernel instead of one launch per term
+                cand = self.small.get((floor, n.shape))
+                if cand is not None and cand.nodes is not None and not any(h[0] is cand for h in hazards) \
+                        and fits(cand) == n.shape:
+                    k = cand
         if k is None:
             k = _Kernel()
-            k.kind, k.shape, k.nodes, k.index, k.npointers, k.fixed = n.kind, n.shape, [], len(self.kernels), set(), False
+            k.kind, k.shape, k.nodes, k.index, k.npointers, k.fixed = n.kind, n.shape, [], self.created, set(), False
+            k.level = floor
+            self.created += 1
             self.kernels.append(k)
+            if n.kind == "ew" and _numel(n.shape) <= SMALL:
+                self.small[(floor, n.shape)] = k
         if not n.fresh:
             k.fixed = True
         k.nodes.append(n)
@@ -425,11 +527,76 @@ class Fuser(TorchDispatchMode):
         n.kernel = k
         n.order = len(self.pending)
         self.pending.append(n)
-        self.writer[_view_key(n.out)] = n
+        self._index(n)
         # a write that overlaps OTHER views of the same memory makes their recorded writers stale
-        for key, w in list(self.writer.items()):
-            if w is not n and _overlap(n.wspan, w.wspan) and key != _view_key(n.out):
+        key_n = _view_key(n.out)
+        keys = self.wkeys.setdefault(n.wspan[0], set())
+        for key in list(keys):
+            w = self.writer.get(key)
+            if w is None:
+                keys.discard(key)
+            elif w is not n and key != key_n and _overlap(n.wspan, w.wspan):
                 del self.writer[key]
+                keys.discard(key)
+        self.writer[key_n] = n
+        keys.add(key_n)
+
+    def _fits(self, cands, n):
+        """Iteration domain of kernels ``cands`` and node ``n`` as ONE kernel, or None."""
+        if any(c.kind != "ew" for c in cands) or sum(len(c.nodes) for c in cands) >= 64:
+            return None
+        keys = self._pointer_keys(n)
+        for c in cands:
+            keys = keys | c.npointers
+        if len(keys) > 48:
+            return None
+        dom = n.shape
+        for c in cands:
+            dom = _bcast(dom, c.shape)
+            if dom is None or len(dom) > MAX_DIMS:
+                return None
+        # (a small run must not be blown up to a larger domain than any of its parts, nor a large one re-run;
+        # an in-place target pins the domain to its own shape)
+        if dom != n.shape and all(dom != c.shape for c in cands):
+            return None
+        if any(c.fixed and dom != c.shape for c in cands) or (not n.fresh and dom != n.shape):
+            return None
+        return dom
+
+    def _merged(self, cands, n):
+        """The kernel ``n`` goes into: ``cands`` (one level, mutually independent) merged; None if they do not
+        fit one kernel."""
+        dom = self._fits(cands, n)
+        if dom is None:
+            return None
+        k = cands[0]
+        for other in cands[1:]:
+            for m in other.nodes:
+                m.kernel = k
+            k.nodes.extend(other.nodes)
+            k.npointers |= other.npointers
+            k.fixed = k.fixed or other.fixed
+            other.nodes = None
+            self.kernels.remove(other)
+            for key, v in list(self.small.items()):
+                if v is other:
+                    self.small[key] = k
+        if len(cands) > 1:
+            k.nodes.sort(key=lambda m: m.order)
+        k.shape = dom
+        return k
+
+    def _index(self, n):
+        for base in {n.wspan[0]} | {r[0] for r in n.rspans}:
+            self.touch.setdefault(base, []).append(n)
+
+    def _reindex(self):
+        """After a partial flush: the hazard index of what stays recorded."""
+        self.touch, self.wkeys = {}, {}
+        for n in self.pending:
+            self._index(n)
+        for key, w in self.writer.items():
+            self.wkeys.setdefault(w.wspan[0], set()).add(key)
 
     @staticmethod
     def _pointer_keys(n):
@@ -492,10 +659,11 @@ class Fuser(TorchDispatchMode):
                 if any(t.dtype != torch.bool for t in ts) or len(ts) != 2:
                     raise Unfusable
                 cd = torch.bool
-            if cd not in _CTYPE:
+            if cd not in _CTYPE and not (base in _COMPARE and cd in _ITYPE):
                 raise Unfusable
             expr = "({0} %s {1})" % _COMPARE[base] if base in _COMPARE else _LOGICAL[base]
-            ins = [self._operand(args[0], cd), self._operand(args[1], cd)]
+            ints = base in _COMPARE
+            ins = [self._operand(args[0], cd, ints), self._operand(args[1], cd, ints)]
             return self._new_node(base, expr, ins, meta, out=args[0] if inplace else None, compute=cd)
         if meta.dtype == torch.bool:
             raise Unfusable
@@ -723,7 +891,201 @@ class Fuser(TorchDispatchMode):
             # a short reduction is an element-wise operator of its OUTPUT domain whose thread loops over the
             # reduced range: it shares a kernel with what follows it (x.sum(-1) then neg, add, ...)
             return self._new_node("sum", "{0}", [self._operand(x, x.dtype)], meta, inline=red)
+        if not meta.is_contiguous():
+            raise Unfusable
         return self._new_node("sum", "{0}", [self._operand(x, x.dtype)], meta, red=red)
+
+    def _join(self, func, args, kwargs, stack):
+        """stack / cat: a copy of every input into its slice of a fresh tensor -- each copy joins the kernel
+        that computed the input (index for index), whose own store is then dead."""
+        tensors = args[0]
+        dim = kwargs.get("dim", args[1] if len(args) > 1 else 0)
+        if any(k != "dim" for k in kwargs) or not tensors or len(tensors) > 256:
+            raise Unfusable
+        t0 = tensors[0]
+        for t in tensors:
+            if not isinstance(t, torch.Tensor) or not self._tensor_ok(t) or t.dtype != t0.dtype or \
+                    t.device != t0.device or t.dim() != t0.dim() or t.numel() == 0:
+                raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if not meta.is_contiguous() or meta.dim() > MAX_DIMS:
+            raise Unfusable
+        dim = dim % meta.dim()
+        ops = [self._operand(t, t0.dtype) for t in tensors]
+        full = torch.empty(tuple(meta.shape), dtype=meta.dtype, device=t0.device)
+        at = 0
+        for t, x in zip(tensors, ops):
+            if stack:
+                dst = full.select(dim, at)
+                at += 1
+            else:
+                dst = full.narrow(dim, at, t.shape[dim])
+                at += t.shape[dim]
+            m = torch.empty_strided(tuple(dst.shape), tuple(dst.stride()), dtype=dst.dtype, device="meta")
+            self._new_node("copy", "{0}", [x], m, out=dst)
+        return full
+
+    def _op_stack(self, func, base, overload, inplace, args, kwargs):
+        return self._join(func, args, kwargs, True)
+
+    def _op_cat(self, func, base, overload, inplace, args, kwargs):
+        return self._join(func, args, kwargs, False)
+
+    def _op_dot(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or len(args) != 2:
+            raise Unfusable
+        x, y = args
+        if not (self._tensor_ok(x) and self._tensor_ok(y)) or x.dim() != 1 or x.shape != y.shape or \
+                x.dtype != y.dtype or x.dtype == torch.bool or not 1 <= x.shape[0] <= INLINE_REDUCE:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        return self._new_node("dot", "{0}", [self._operand(x, x.dtype), self._operand(y, x.dtype)], meta,
+                              inline={"kind": "dot", "rsize": x.shape[0]})
+
+    # -- the library's own element-wise families (distributions/fused.py asks while a scope is active)
+    def _family_operands(self, dt, tensors):
+        ins = []
+        for t in tensors:
+            if t is None:
+                ins.append(("s", _lit(0, dt)))
+                continue
+            if not isinstance(t, torch.Tensor) or (t.dtype != dt and t.dtype != torch.bool) or not _dev(t):
+                raise Unfusable
+            ins.append(self._operand(t, dt))
+        return ins
+
+    def family_log_prob(self, dist_id, value, p0, p1, shape):
+        """log-density of family ``dist_id`` as a recorded node (the expression of csrc/dist_fam.h), or None."""
+        if self._busy or not ENABLED["on"] or p0.dtype not in (torch.float32, torch.float64):
+            return None
+        self._busy = True
+        try:
+            dt = p0.dtype
+            ins = self._family_operands(dt, (value, p0, p1))
+            meta = torch.empty(tuple(shape), dtype=dt, device="meta")
+            out = self._new_node("fam_lp", "pa::Fam<%d, $T>::lp({0}, {1}, {2})" % dist_id, ins, meta)
+            STATS["recorded"] += 1
+            return out
+        except Unfusable:
+            return None
+        finally:
+            self._busy = False
+
+    def family_grads(self, dist_id, g, value, p0, p1, shape, need):
+        """(g * d lp / d value, g * d lp / d p0, g * d lp / d p1) on the broadcast ``shape`` (None where not
+        needed) as recorded nodes, or None."""
+        if self._busy or not ENABLED["on"] or p0.dtype not in (torch.float32, torch.float64):
+            return None
+        self._busy = True
+        try:
+            dt = p0.dtype
+            ins = self._family_operands(dt, (g, value, p0, p1))
+            meta = torch.empty(tuple(shape), dtype=dt, device="meta")
+            outs = []
+            for w, wanted in enumerate(need):
+                outs.append(self._new_node("fam_g%d" % w, "fam_g<%d, %d, $T>({0}, {1}, {2}, {3})" % (dist_id, w),
+                                           list(ins), meta) if wanted else None)
+                STATS["recorded"] += bool(wanted)
+            return tuple(outs)
+        except Unfusable:
+            return None
+        finally:
+            self._busy = False
+
+    def _op_scalar_tensor(self, func, base, overload, inplace, args, kwargs):
+        return self._factory(func, args, kwargs, args[0])
+
+    # -- operators that read a RANGE of their operands per output element (n.inline = {"kind": ...})
+    def _leading_index(self, indices):
+        """``indices`` of aten::index / index_put: ONE int64 tensor indexing dim 0 (the enumeration idiom
+        ``table[enumerated_values]``, pyro/infer/traceenum_elbo.py over examples/lda.py:66), or Unfusable."""
+        if not indices or indices[0] is None or any(x is not None for x in indices[1:]):
+            raise Unfusable
+        idx = indices[0]
+        if not isinstance(idx, torch.Tensor) or idx.dtype != torch.int64 or not _dev(idx) or \
+                idx.layout != torch.strided:
+            raise Unfusable
+        return idx
+
+    def _op_index(self, func, base, overload, inplace, args, kwargs):
+        if kwargs or overload != "Tensor" or len(args) != 2:
+            raise Unfusable
+        x = args[0]
+        idx = self._leading_index(args[1])
+        if not self._tensor_ok(x) or x.dim() < 1 or x.dtype == torch.bool or \
+                idx.dim() + x.dim() - 1 > MAX_DIMS or x.shape[0] == 0:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if tuple(meta.shape) != tuple(idx.shape) + tuple(x.shape[1:]):
+            raise Unfusable
+        return self._new_node("index", "{0}", [self._operand(x, x.dtype), ("t", idx)], meta,
+                              inline={"kind": "gather"})
+
+    def _scatter_add(self, func, inplace, args, kwargs):
+        x, indices, values = args[0], args[1], args[2]
+        accumulate = kwargs.get("accumulate", args[3] if len(args) > 3 else False)
+        if not accumulate or not isinstance(values, torch.Tensor):
+            raise Unfusable
+        idx = self._leading_index(indices)
+        K = idx.numel()
+        if not self._tensor_ok(x) or x.dim() < 1 or x.dtype == torch.bool or K < 1 or K > MAX_SCATTER or \
+                values.dtype != x.dtype or not self._tensor_ok(values) or idx.dim() + x.dim() - 1 > MAX_DIMS:
+            raise Unfusable
+        target = tuple(idx.shape) + tuple(x.shape[1:])
+        if values.dim() > len(target) or _bcast(tuple(values.shape), target) != target:
+            raise Unfusable
+        meta = torch.empty(tuple(x.shape), dtype=x.dtype, device="meta")
+        w = self.writer.get(_view_key(x))
+        ins = [self._operand(values, x.dtype), ("t", idx)]
+        if w is not None and w.op == "const" and w.shape == tuple(x.shape):
+            init = w.expr                       # zeros(...).index_put_(...): the fill never reaches memory
+        else:
+            init = None
+            ins.append(self._operand(x, x.dtype))
+        return self._new_node("index_put", "{0}", ins, meta, out=x if inplace else None,
+                              inline={"kind": "scatter_add", "init": init, "ishape": tuple(idx.shape),
+                                      "istride": tuple(idx.stride())})
+
+    def _op_index_put(self, func, base, overload, inplace, args, kwargs):
+        return self._scatter_add(func, inplace, args, kwargs)
+
+    def _op__index_put_impl_(self, func, base, overload, inplace, args, kwargs):
+        return self._scatter_add(func, True, args, kwargs)
+
+    def _softmax_like(self, func, args, kwargs, kind, n_mem):
+        if kwargs:
+            raise Unfusable
+        x = args[0]
+        for t in args[:n_mem]:
+            if not isinstance(t, torch.Tensor) or not self._tensor_ok(t) or t.dtype not in (torch.float32, torch.float64) \
+                    or tuple(t.shape) != tuple(x.shape) or t.dtype != x.dtype:
+                raise Unfusable
+        if x.dim() == 0 or x.numel() == 0:
+            raise Unfusable
+        dim = args[n_mem] % x.dim()
+        if n_mem == 1 and args[2]:                       # half_to_float
+            raise Unfusable
+        if n_mem == 2 and args[3] != x.dtype:            # input_dtype
+            raise Unfusable
+        if x.shape[dim] > INLINE_REDUCE:
+            raise Unfusable
+        meta = self._meta(func, args, kwargs)
+        if not meta.is_contiguous():
+            raise Unfusable
+        ins = [self._operand(t, x.dtype) for t in args[:n_mem]]
+        return self._new_node(kind, "{0}", ins, meta, inline={"kind": kind, "dim": dim, "rsize": x.shape[dim]})
+
+    def _op__softmax(self, func, base, overload, inplace, args, kwargs):
+        return self._softmax_like(func, args, kwargs, "softmax", 1)
+
+    def _op__log_softmax(self, func, base, overload, inplace, args, kwargs):
+        return self._softmax_like(func, args, kwargs, "log_softmax", 1)
+
+    def _op__softmax_backward_data(self, func, base, overload, inplace, args, kwargs):
+        return self._softmax_like(func, args, kwargs, "softmax_bwd", 2)
+
+    def _op__log_softmax_backward_data(self, func, base, overload, inplace, args, kwargs):
+        return self._softmax_like(func, args, kwargs, "log_softmax_bwd", 2)
 
     # ---- materialisation ----------------------------------------------------------------------------
     def flush_for(self, tensors):
@@ -731,32 +1093,36 @@ class Fuser(TorchDispatchMode):
         ordered, every kernel in front of the last such one.  The rest stays recorded."""
         if not self.pending:
             return
-        spans = [_span(t) for t in tensors if _dev(t)]
         hit = -1
-        for n in self.pending:
-            if n.kernel.index > hit and any(_overlap(sp, n.wspan) or any(_overlap(sp, r) for r in n.rspans)
-                                            for sp in spans):
-                hit = n.kernel.index
+        for t in tensors:
+            if not _dev(t):
+                continue
+            sp = _span(t)
+            for n in self.touch.get(sp[0], ()):
+                if n.kernel.level > hit and (_overlap(sp, n.wspan) or any(_overlap(sp, r) for r in n.rspans)):
+                    hit = n.kernel.level
         if hit < 0:
             return
-        if hit == len(self.kernels) - 1:
+        head = [k for k in self.kernels if k.level <= hit]
+        tail = [k for k in self.kernels if k.level > hit]
+        if not tail:
             return self.flush()
-        head, tail = self.kernels[:hit + 1], self.kernels[hit + 1:]
         done = {id(n) for k in head for n in k.nodes}
         for k in tail:
-            k.index -= hit + 1
             for n in k.nodes:      # a value of a materialised kernel is read back from memory from now on
                 n.ins = [("t", x[1].out) if x[0] == "n" and id(x[1]) in done else x for x in n.ins]
         self.pending = [n for n in self.pending if id(n) not in done]
         self.kernels = tail
         self.writer = {key: w for key, w in self.writer.items() if id(w) not in done}
+        self.small = {key: k for key, k in self.small.items() if k.level > hit}
+        self._reindex()
         self._run(head)
 
     def flush(self):
         if not self.pending:
             return
         kernels = self.kernels
-        self.pending, self.kernels, self.writer = [], [], {}
+        self.pending, self.kernels, self.writer, self.touch, self.wkeys, self.small = [], [], {}, {}, {}, {}
         self._run(kernels)
 
     def _mark_live(self, kernels):
@@ -788,11 +1154,8 @@ class Fuser(TorchDispatchMode):
             self._mark_live(kernels)
         prev, self._busy = self._busy, True
         try:
-            for k in kernels:
-                if k.kind == "ew":
-                    _launch_elementwise(k)
-                else:
-                    _launch_reduce(k.nodes[0])
+            for level in _levels(kernels):
+                _launch_level(level)
         finally:
             self._busy = prev
             # nodes and kernels point at each other: take the cycle apart NOW -- the tensors they hold carry
@@ -824,7 +1187,7 @@ def _compiled(src):
 def _launch(src, grid, block, tensors):
     from .. import _lib
     fn = _compiled(src)
-    table = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    table = (ctypes.c_void_p * len(tensors))(*[t[1] if isinstance(t, tuple) else t.data_ptr() for t in tensors])
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(_lib.load().pa_rtc_launch(fn, grid, block, table, len(tensors), stream))
     STATS["kernels"] += 1
@@ -884,13 +1247,13 @@ def _gen_body(nodes, it_shape, ptrs, used, store_index="i"):
             j = pointer(t)
             v = leaf_var[key] = "l%d" % len(leaf_var)
             off = _offset_expr(tuple(t.shape), tuple(t.stride()), it_shape, used)
-            lines.append("  const %s %s = ((const %s*)a.p[%d])[%s];" % (_CTYPE[t.dtype], v, _CTYPE[t.dtype], j, off))
+            lines.append("  const %s %s = ((const %s*)p%d)[%s];" % (_CTYPE_ALL[t.dtype], v, _CTYPE_ALL[t.dtype], j, off))
         return v
 
     for q, n in enumerate(nodes):
         T = n.ctype
         if n.inline is not None:
-            lines.extend(_inline_reduce(n, q, it_shape, used, pointer))
+            lines.extend(_INLINE[n.inline.get("kind", "sum")](n, q, it_shape, used, pointer))
             val[id(n)] = "v%d" % q
             leaf_var[_view_key(n.out)] = "v%d" % q
             if not n.live:
@@ -902,18 +1265,23 @@ def _gen_body(nodes, it_shape, ptrs, used, store_index="i"):
             expanded = [d for d in range(len(it_shape)) if it_shape[d] > 1 and (d < pad or n.shape[d - pad] == 1)]
             used.update(expanded)
             guard = "if (%s) " % " && ".join("i%d == 0" % d for d in expanded) if expanded else ""
-            stores.append("  %s((%s*)a.p[%d])[%s] = v%d;" % (guard, _CTYPE[n.dtype], j, off, q))
+            stores.append("  %s((%s*)p%d)[%s] = v%d;" % (guard, _CTYPE[n.dtype], j, off, q))
             continue
         ops = []
         for x in n.ins:
             if x[0] == "s":
                 ops.append(x[1])
+            elif x[0] == "a":
+                ptrs.append(("scalar", x[1]))
+                j = len(ptrs) - 1
+                ops.append("((%s)(long long)p%d)" % (T, j) if x[2] == "long" else
+                           "((%s)__builtin_bit_cast(double, p%d))" % (T, j))
             elif x[0] == "n" and id(x[1]) in val:
                 ops.append("((%s)%s)" % (T, val[id(x[1])]))
             else:
                 t = x[1].out if x[0] == "n" else x[1]
                 ops.append("((%s)%s)" % (T, leaf(t)))
-        expr = n.expr.format(*ops).replace("T(", "%s(" % T).replace("<T>", "<%s>" % T)
+        expr = n.expr.format(*ops).replace("T(", "%s(" % T).replace("<T>", "<%s>" % T).replace("$T", T)
         out_t = _CTYPE[n.dtype]
         v = "v%d" % q
         lines.append("  const %s %s = (%s)(%s);" % (out_t, v, out_t, expr))
@@ -931,7 +1299,7 @@ def _gen_body(nodes, it_shape, ptrs, used, store_index="i"):
         expanded = [d for d in range(len(it_shape)) if it_shape[d] > 1 and (d < pad or n.shape[d - pad] == 1)]
         used.update(expanded)
         guard = "if (%s) " % " && ".join("i%d == 0" % d for d in expanded) if expanded else ""
-        stores.append("  %s((%s*)a.p[%d])[%s] = %s;" % (guard, out_t, j, off, v))
+        stores.append("  %s((%s*)p%d)[%s] = %s;" % (guard, out_t, j, off, v))
     return lines, stores
 
 
@@ -970,49 +1338,276 @@ def _inline_reduce(n, q, it_shape, used, pointer):
             lines.append("      const long q%d = q_;" % d)
         if in_shape[d] > 1 and st[d] != 0:
             offs.append("q%d * %dL" % (d, st[d]))
-    lines += ["      s_ += (%s)((const %s*)a.p[%d])[b_ + %s];" % (acc, _CTYPE[t.dtype], j, " + ".join(offs) or "0"),
+    lines += ["      s_ += (%s)((const %s*)p%d)[b_ + %s];" % (acc, _CTYPE[t.dtype], j, " + ".join(offs) or "0"),
               "    }", "    v%d = (%s)s_;" % (q, _CTYPE[n.dtype]), "  }"]
     return lines
 
 
-def _launch_elementwise(k):
+def _mem(x):
+    return x[1].out if x[0] == "n" else x[1]
+
+
+def _dim_terms(shape, strides, first_kernel_dim, used, skip=()):
+    """sum_d i<first_kernel_dim + d> * strides[d] over the dims of ``shape`` that move (size > 1, stride != 0)."""
+    terms = []
+    for d, (n, st) in enumerate(zip(shape, strides)):
+        if d in skip or n <= 1 or st == 0:
+            continue
+        used.add(first_kernel_dim + d)
+        terms.append("i%d * %dL" % (first_kernel_dim + d, st))
+    return " + ".join(terms) or "0"
+
+
+def _inline_gather(n, q, it_shape, used, pointer):
+    """v<q> = table[index[i_lead...], i_rest...]   (aten::index with one leading int64 index)."""
+    table, idx = _mem(n.ins[0]), n.ins[1][1]
+    pad = len(it_shape) - len(n.shape)
+    ni = idx.dim()
+    ioff = _dim_terms(tuple(idx.shape), tuple(idx.stride()), pad, used)
+    roff = _dim_terms(tuple(table.shape[1:]), tuple(table.stride()[1:]), pad + ni, used)
+    T = _CTYPE[n.dtype]
+    return ["  %s v%d;" % (T, q), "  {",
+            "    long long x_ = ((const long long*)p%d)[%s];" % (pointer(idx), ioff),
+            "    if (x_ < 0) x_ += %dL;" % table.shape[0],
+            "    v%d = ((const %s*)p%d)[x_ * %dL + %s];" % (q, T, pointer(table), table.stride(0), roff), "  }"]
+
+
+def _inline_scatter_add(n, q, it_shape, used, pointer):
+    """v<q> = self[i] + sum over the index entries k (ascending) with index[k] == i0 of values[k, i_rest...]:
+    aten::index_put(accumulate=True) with one short leading index, without atomics or a sort -- the order of
+    the additions is the operator's own (entries of one row in ascending position)."""
+    info = n.inline
+    values, idx = _mem(n.ins[0]), n.ins[1][1]
+    pad = len(it_shape) - len(n.shape)
+    ishape, ni = info["ishape"], len(info["ishape"])
+    rest = tuple(n.shape[1:])
+    T = _CTYPE[n.dtype]
+    # values broadcast (right-aligned) to ishape + rest
+    vshape = (1,) * (ni + len(rest) - values.dim()) + tuple(values.shape)
+    vstride = (0,) * (ni + len(rest) - values.dim()) + tuple(values.stride())
+    voff_rest = _dim_terms(vshape[ni:], vstride[ni:], pad + 1, used)
+    used.add(pad)
+    lines = ["  %s v%d;" % (T, q), "  {"]
+    if info["init"] is not None:
+        lines.append("    %s s_ = %s;" % (T, info["init"]))
+    else:
+        x = _mem(n.ins[2])
+        xoff = _dim_terms(tuple(x.shape), tuple(x.stride()), pad, used)
+        lines.append("    %s s_ = ((const %s*)p%d)[%s];" % (T, T, pointer(x), xoff))
+    K = 1
+    for m in ishape:
+        K *= m
+    lines += ["    for (long k = 0; k < %dL; ++k) {" % K, "      long k_ = k;"]
+    io, vo = [], []
+    for d in range(ni - 1, -1, -1):
+        if d > 0:
+            lines.append("      const long k%d = k_ %% %dL; k_ /= %dL;" % (d, ishape[d], ishape[d]))
+        else:
+            lines.append("      const long k0 = k_;")
+        if ishape[d] > 1 and info["istride"][d] != 0:
+            io.append("k%d * %dL" % (d, info["istride"][d]))
+        if vshape[d] > 1 and vstride[d] != 0:
+            vo.append("k%d * %dL" % (d, vstride[d]))
+    lines += ["      long long x_ = ((const long long*)p%d)[%s];" % (pointer(idx), " + ".join(io) or "0"),
+              "      if (x_ < 0) x_ += %dL;" % n.shape[0],
+              "      if (x_ == i%d) s_ += ((const %s*)p%d)[%s + %s];" % (pad, T, pointer(values),
+                                                                             " + ".join(vo) or "0", voff_rest),
+              "    }", "    v%d = s_;" % q, "  }"]
+    return lines
+
+
+def _inline_softmax(n, q, it_shape, used, pointer):
+    """(log_)softmax / its backward along a short dim: every thread walks its own row."""
+    info = n.inline
+    kind, dim, L = info["kind"], info["dim"], info["rsize"]
+    pad = len(it_shape) - len(n.shape)
+    T = _CTYPE[n.dtype]
+    a0 = _mem(n.ins[0])
+    row0 = _dim_terms(tuple(a0.shape), tuple(a0.stride()), pad, used, skip=(dim,))
+    s0 = a0.stride(dim)
+    used.add(pad + dim)
+    p0 = "((const %s*)p%d)" % (T, pointer(a0))
+    lines = ["  %s v%d;" % (T, q), "  {", "    const long b0_ = %s;" % row0]
+    if kind in ("softmax", "log_softmax"):
+        lines += ["    %s m_ = %s[b0_];" % (T, p0),
+                  "    for (long r = 1; r < %dL; ++r) { const %s x_ = %s[b0_ + r * %dL]; m_ = x_ > m_ ? x_ : m_; }"
+                  % (L, T, p0, s0),
+                  "    %s s_ = 0;" % T,
+                  "    for (long r = 0; r < %dL; ++r) s_ += exp_(%s[b0_ + r * %dL] - m_);" % (L, p0, s0),
+                  "    const %s x_ = %s[b0_ + i%d * %dL];" % (T, p0, pad + dim, s0)]
+        if kind == "softmax":
+            lines.append("    v%d = exp_(x_ - m_) / s_;" % q)
+        else:
+            lines.append("    v%d = (x_ - m_) - log_(s_);" % q)
+    else:
+        a1 = _mem(n.ins[1])
+        row1 = _dim_terms(tuple(a1.shape), tuple(a1.stride()), pad, used, skip=(dim,))
+        s1 = a1.stride(dim)
+        p1 = "((const %s*)p%d)" % (T, pointer(a1))
+        lines += ["    const long b1_ = %s;" % row1, "    %s s_ = 0;" % T]
+        if kind == "softmax_bwd":       # (grad, output): (g_i - sum_r g_r y_r) * y_i
+            lines += ["    for (long r = 0; r < %dL; ++r) s_ += %s[b0_ + r * %dL] * %s[b1_ + r * %dL];"
+                      % (L, p0, s0, p1, s1),
+                      "    v%d = (%s[b0_ + i%d * %dL] - s_) * %s[b1_ + i%d * %dL];"
+                      % (q, p0, pad + dim, s0, p1, pad + dim, s1)]
+        else:                           # (grad, output = log p): g_i - exp(y_i) * sum_r g_r
+            lines += ["    for (long r = 0; r < %dL; ++r) s_ += %s[b0_ + r * %dL];" % (L, p0, s0),
+                      "    v%d = %s[b0_ + i%d * %dL] - exp_(%s[b1_ + i%d * %dL]) * s_;"
+                      % (q, p0, pad + dim, s0, p1, pad + dim, s1)]
+    lines.append("  }")
+    return lines
+
+
+def _inline_dot(n, q, it_shape, used, pointer):
+    a, b = _mem(n.ins[0]), _mem(n.ins[1])
+    T = _CTYPE[n.dtype]
+    return ["  %s v%d;" % (T, q), "  {", "    %s s_ = 0;" % T,
+            "    for (long r = 0; r < %dL; ++r) s_ += ((const %s*)p%d)[r * %dL] * ((const %s*)p%d)[r * %dL];"
+            % (n.inline["rsize"], T, pointer(a), a.stride(0), T, pointer(b), b.stride(0)),
+            "    v%d = s_;" % q, "  }"]
+
+
+_INLINE = {"dot": _inline_dot, "sum": _inline_reduce, "gather": _inline_gather, "scatter_add": _inline_scatter_add,
+           "softmax": _inline_softmax, "log_softmax": _inline_softmax, "softmax_bwd": _inline_softmax,
+           "log_softmax_bwd": _inline_softmax}
+
+
+def _levels(kernels):
+    """Kernels grouped by launch level (ascending); with the merge switched off every kernel is its own launch."""
+    ordered = sorted(kernels, key=lambda k: (k.level, k.index))
+    if not MERGE_LEVELS["on"]:
+        return [[k] for k in ordered]
+    out = []
+    for k in ordered:
+        if out and out[-1][0].level == k.level:
+            out[-1].append(k)
+        else:
+            out.append([k])
+    return out
+
+
+_LONG = re.compile(r"(?<!long )\blong\b(?! long)")
+_LSUFFIX = re.compile(r"\b(\d+)L\b")
+
+
+def _narrow(text, numel, ptrs):
+    """Index arithmetic in 32 bits when every index and element offset fits (a 64-bit division per element
+    and dim costs more than the operators it serves): ``long`` -> ``int`` (``long long``, the element type of
+    int64 operands, stays)."""
+    if numel >= 2 ** 31:
+        return text
+    for t in ptrs:
+        if isinstance(t, torch.Tensor):
+            sp = _span(t)
+            if (sp[2] - sp[1]) // t.element_size() >= 2 ** 31:
+                return text
+    return _LSUFFIX.sub(r"\1", _LONG.sub("int", text))
+
+
+def _body(k):
+    """(numel, pointers, function text with the name left open) of one element-wise kernel; None when it has
+    nothing to store."""
     shape = k.shape
     numel = 1
     for n in shape:
         numel *= n
-    if numel == 0:
-        return
-    if not any(n.live for n in k.nodes):
-        return
-    # later stores to the same view supersede earlier ones
-    last = {}
+    if numel == 0 or not any(n.live for n in k.nodes):
+        return None
+    last = {}                       # later stores to the same view supersede earlier ones
     for n in k.nodes:
         last[_view_key(n.out)] = n
-    ptrs, used = [], set()
+    used, ptrs = set(), []
     lines, stores = _gen_body(k.nodes, shape, ptrs, used)
     keep = {id(n) for n in last.values() if n.live}
     stores = [s for n, s in zip(k.nodes, stores) if id(n) in keep]
-    src = _PRELUDE + "extern \"C\" __global__ __launch_bounds__(256) void k(Ptrs a) {\n" \
-        "  const long i = (long)blockIdx.x * 256L + threadIdx.x;\n  if (i >= %dL) return;\n" % numel + \
+    if TRACE["on"]:
+        TRACE["kernels"].append((shape, [(n.op, n.shape, n.live) for n in k.nodes]))
+    text = "(const long i%s) {\n" % "".join(", void* p%d" % j for j in range(len(ptrs))) + \
         _index_decl(shape, used) + "\n".join(lines) + "\n" + "\n".join(stores) + "\n}\n"
-    _launch(src, (numel + 255) // 256, 256, ptrs)
+    return numel, ptrs, _narrow(text, numel, ptrs)
 
 
-def _launch_reduce(n):
+def _launch_level(ks):
+    """One launch for the element-wise kernels ``ks`` (mutually independent; more than one launch when the
+    pointer table would overflow).  Every kernel is a device function of (element index, its pointers) and
+    owns a contiguous range of workgroups -- the bodies run side by side, not one after the other -- and
+    kernels with the same text (the same operators over tensors of the same shapes and strides: the sites of
+    the time steps of a pyro.markov loop) share ONE function."""
+    group, table, count = [], [], 0
+
+    def go():
+        if not group:
+            return
+        # bodies of one text and size become ONE range of workgroups: the instance is the quotient of the
+        # workgroup index, its pointers are read from the table at a computed position
+        runs, order = {}, []
+        for numel, ptrs, text in group:
+            key = (text, numel)
+            if key not in runs:
+                runs[key] = []
+                order.append(key)
+            runs[key].append(ptrs)
+        funcs, calls, first, at = {}, [], 0, 0
+        for key in order:
+            text, numel = key
+            inst = runs[key]
+            f = funcs.setdefault(text, len(funcs))
+            nblk = (numel + 255) // 256
+            np_ = len(inst[0])
+            for ptrs in inst:
+                table.extend(ptrs)
+            if len(inst) == 1:
+                args = "".join(", a.p[%d]" % (at + j) for j in range(np_))
+                calls.append("  if (b < %dL) { const long i = (b - %dL) * 256L + threadIdx.x; if (i < %dL) f%d(i%s); "
+                             "return; }\n" % (first + nblk, first, numel, f, args))
+            else:
+                args = "".join(", a.p[%d + q * %d + %d]" % (at, np_, j) for j in range(np_))
+                calls.append("  if (b < %dL) { const int q = (int)((b - %dL) / %dL); const long i = ((b - %dL) %% %dL) * 256L "
+                             "+ threadIdx.x; if (i < %dL) f%d(i%s); return; }\n"
+                             % (first + nblk * len(inst), first, nblk, first, nblk, numel, f, args))
+            first += nblk * len(inst)
+            at += np_ * len(inst)
+        src = _PRELUDE + "struct Ptrs { void* p[%d]; };\n" % max(16, (at + 15) // 16 * 16)
+        if any("pa::Fam<" in text or "fam_g<" in text for text in funcs):
+            src += _family_prelude()
+        for text, f in funcs.items():
+            src += "static __device__ __forceinline__ void f%d%s" % (f, text)
+        src += "extern \"C\" __global__ __launch_bounds__(256) void k(Ptrs a) {\n  const long b = blockIdx.x;\n" + \
+            "".join(calls) + "}\n"
+        if TRACE["on"]:
+            TRACE["kernels"].append(("launch", len(group), len(funcs)))
+        _launch(src, first, 256, table)
+
+    for k in ks:
+        b = _body(k) if k.kind == "ew" else _reduce_body(k.nodes[0])
+        if b is None:
+            continue
+        if count + len(b[1]) > MAX_POINTERS and group:
+            go()
+            group, table, count = [], [], 0
+        group.append(b)
+        count += len(b[1])
+    go()
+
+
+def _reduce_body(n):
+    """(threads, pointers, function text) of a longer sum: one wave per output element, lanes stride over the
+    reduced range (element index i = 64 * output + lane)."""
     if not n.live:
-        return
+        return None
     red = n.red
     in_shape, dims, rsize = red["in_shape"], red["dims"], red["rsize"]
     kept = [d for d in range(len(in_shape)) if d not in dims]
     n_out = 1
     for d in kept:
         n_out *= in_shape[d]
-    x = n.ins[0]
-    t = x[1].out if x[0] == "n" else x[1]
+    if n_out == 0:
+        return None
+    t = _mem(n.ins[0])
     T = n.ctype
     acc = "double" if n.dtype == torch.float64 else "float"
     st = t.stride()
-    # offset of (output index o, reduce index r): decompose both
+
     def decomp(var, ds, prefix):
         lines, rem = ["  long %s_ = %s;" % (prefix, var)], "%s_" % prefix
         for q in range(len(ds) - 1, -1, -1):
@@ -1026,24 +1621,24 @@ def _launch_reduce(n):
     o_off = " + ".join("o%d * %dL" % (d, st[d]) for d in kept if in_shape[d] > 1 and st[d] != 0) or "0"
     r_off = " + ".join("q%d * %dL" % (d, st[d]) for d in dims if in_shape[d] > 1 and st[d] != 0) or "0"
     r_lines = decomp("r", list(dims), "q")
-    ptrs = [t, n.out]
-    if rsize <= 32:        # one thread per output element
-        body = "  const long o = (long)blockIdx.x * 256L + threadIdx.x;\n  if (o >= %dL) return;\n" % n_out + \
-            "\n".join(o_lines) + "\n  const long base = %s;\n  %s s = 0;\n  for (long r = 0; r < %dL; ++r) {\n" % (o_off, acc, rsize) + \
-            "\n".join("  " + ln for ln in r_lines) + \
-            "\n    s += (%s)((const %s*)a.p[0])[base + %s];\n  }\n  ((%s*)a.p[1])[o] = (%s)s;\n" % (acc, T, r_off, T, T)
-        grid = (n_out + 255) // 256
-    else:                  # one wave per output element, lanes stride over the reduced range
-        body = "  const long o = (long)blockIdx.x * 4L + (threadIdx.x >> 6);\n  const int lane = threadIdx.x & 63;\n" \
-            "  if (o >= %dL) return;\n" % n_out + "\n".join(o_lines) + \
-            "\n  const long base = %s;\n  %s s = 0;\n  for (long r = lane; r < %dL; r += 64) {\n" % (o_off, acc, rsize) + \
-            "\n".join("  " + ln for ln in r_lines) + \
-            "\n    s += (%s)((const %s*)a.p[0])[base + %s];\n  }\n" % (acc, T, r_off) + \
-            "  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n" \
-            "  if (lane == 0) ((%s*)a.p[1])[o] = (%s)s;\n" % (T, T)
-        grid = (n_out + 3) // 4
-    src = _PRELUDE + "extern \"C\" __global__ __launch_bounds__(256) void k(Ptrs a) {\n" + body + "}\n"
-    _launch(src, grid, 256, ptrs)
+    text = "(const long i, void* p0, void* p1) {\n  const long o = i >> 6;\n  const int lane = (int)(i & 63);\n" + \
+        "\n".join(o_lines) + "\n  const long base = %s;\n  %s s = 0;\n  for (long r = lane; r < %dL; r += 64) {\n" \
+        % (o_off, acc, rsize) + "\n".join("  " + ln for ln in r_lines) + \
+        "\n    s += (%s)((const %s*)p0)[base + %s];\n  }\n" % (acc, T, r_off) + \
+        "  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n" \
+        "  if (lane == 0) ((%s*)p1)[o] = (%s)s;\n}\n" % (T, T)
+    if TRACE["on"]:
+        TRACE["kernels"].append((tuple(in_shape), [("sum%d" % rsize, n.shape, True)]))
+    return n_out * 64, [t, n.out], _narrow(text, n_out * 64, [t, n.out])
+
+
+def _trace_site(name, args):
+    import traceback
+    frames = [f for f in traceback.extract_stack()[:-3] if "/torch/" not in f.filename
+              and "fuser.py" not in f.filename]
+    where = " < ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in frames[-4:][::-1])
+    shapes = [tuple(a.shape) for a in _tensors_of(args)][:3]
+    TRACE["sites"].setdefault(name, []).append((where, shapes))
 
 
 def _tensors_of(xs):

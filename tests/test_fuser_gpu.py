@@ -125,6 +125,101 @@ def test_short_reductions_inside_elementwise_kernels(gpu):
         torch.testing.assert_close(a, b, rtol=1e-13, atol=1e-13)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_enumeration_indexing_and_its_backward(gpu, dtype):
+    """``table[enumerated_values]`` (one leading int64 index) and the accumulate=True index_put that is its
+    dual -- duplicates, negative entries, values that broadcast -- element-wise only: bitwise gathers, sums in
+    the operator's own order."""
+    from pyro_amd.ops import fuser
+    g = torch.Generator().manual_seed(3)
+    t0 = torch.randn(5, 3, 4, dtype=dtype, generator=g).to(gpu)
+    idx = torch.tensor([[4], [0], [-1], [2], [0], [0]], device=gpu)               # [6, 1]: duplicates + negative
+    w0 = torch.randn(6, 1, 3, 4, dtype=dtype, generator=g).to(gpu)
+
+    def run():
+        table = t0.clone().requires_grad_(True)
+        out = table[idx] * 1.5
+        (out * w0).sum().backward()
+        base = torch.zeros(5, 4, dtype=dtype, device=gpu)
+        base.index_put_((torch.tensor([1, 1, 3], device=gpu),), torch.ones(4, dtype=dtype, device=gpu) * 0.25,
+                        accumulate=True)
+        fn = torch.index_put(t0[:, 0], (torch.tensor([[2, 2], [0, 4]], device=gpu),), w0[:4, 0, 0].reshape(2, 2, 4),
+                             accumulate=True)
+        return out.detach(), table.grad, base, fn
+
+    ref = run()
+    fuser.UNFUSED.clear()
+    before = dict(fuser.STATS)
+    with fuser.Fuser():
+        got = run()
+    torch.cuda.synchronize()
+    assert not any(k.startswith("aten::index") or k.startswith("aten::_index") for k in fuser.UNFUSED), fuser.UNFUSED
+    assert fuser.STATS["kernels"] - before["kernels"] <= 6
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+    tol = dict(rtol=2e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(got[1], ref[1], **tol)
+    torch.testing.assert_close(got[3], ref[3], **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("dim", [-1, 0, 1])
+def test_softmax_family_over_a_short_dim(gpu, dtype, dim):
+    from pyro_amd.ops import fuser
+    g = torch.Generator().manual_seed(4)
+    x0 = (torch.randn(9, 7, 8, dtype=dtype, generator=g) * 3).to(gpu)
+    w0 = torch.randn(9, 7, 8, dtype=dtype, generator=g).to(gpu)
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        y = x.transpose(0, 1)                                  # (strided operand)
+        a = torch.softmax(y, dim)
+        b = torch.log_softmax(x * 0.5, dim)
+        ((a.transpose(0, 1) * w0).sum() + (b * w0 * w0).sum()).backward()
+        return a.detach(), b.detach(), x.grad
+
+    ref = run()
+    fuser.UNFUSED.clear()
+    with fuser.Fuser():
+        got = run()
+    torch.cuda.synchronize()
+    assert not any("softmax" in k for k in fuser.UNFUSED), fuser.UNFUSED
+    tol = dict(rtol=3e-6, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-13, atol=1e-13)
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, **tol)
+
+
+def test_independent_kernels_share_a_launch(gpu):
+    """Kernels of different iteration domains without a hazard between them are ONE launch (guarded bodies);
+    dependent ones stay ordered.  Same numbers with the merge switched off."""
+    from pyro_amd.ops import fuser
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(n, generator=g).to(gpu) for n in (5, 300, 7000, 64)]
+
+    def run():
+        ys = [(x * 2.0 + 1.0).exp() for x in xs]              # four domains, independent
+        z = ys[1].sum() + ys[0].sum()                         # reductions: the next level
+        return ys + [z * xs[3]]
+
+    outs = {}
+    for on in (False, True):
+        fuser.MERGE_LEVELS["on"] = on
+        try:
+            before = fuser.STATS["kernels"]
+            with fuser.Fuser():
+                outs[on] = run()
+            torch.cuda.synchronize()
+            outs[on, "n"] = fuser.STATS["kernels"] - before
+        finally:
+            fuser.MERGE_LEVELS["on"] = True
+    assert outs[True, "n"] < outs[False, "n"] and outs[True, "n"] <= 4, (outs[True, "n"], outs[False, "n"])
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    ref = run()
+    for a, b in zip(outs[True][:4], ref[:4]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(outs[True][4], ref[4], rtol=1e-5, atol=1e-5)
+
+
 def test_fused_kernels_inside_a_captured_graph_follow_their_inputs(gpu):
     from pyro_amd.ops import fuser
     x = torch.randn(64, 8, device=gpu)
@@ -198,3 +293,100 @@ def test_captured_steps_launch_fewer_kernels(gpu):
         a, b = out[True][j], out[False][j]
         assert a["graphed"] and b["graphed"]
         np.testing.assert_allclose(a["last_loss"], b["last_loss"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_family_nodes_are_the_site_kernels_arithmetic(gpu, dtype):
+    """A family's log-density / partial derivatives recorded under a scope (csrc/dist_fam.h compiled into the
+    generated source) against pa_dist_log_prob / pa_dist_log_prob_grad: the same expressions (the library
+    contracts a*b+c into fused multiply-adds, the generated source does not: agreement to an ulp or two)."""
+    from pyro_amd import _lib as L
+    from pyro_amd.distributions import fused
+    from pyro_amd.ops import fuser
+    g = torch.Generator().manual_seed(7)
+    cases = [(L.DIST_NORMAL, torch.randn(6, 40, 9, generator=g), torch.randn(40, 1, generator=g),
+              torch.rand(9, generator=g) + 0.5),
+             (L.DIST_BERNOULLI_LOGITS, (torch.rand(6, 40, 9, generator=g) > 0.5).float(),
+              torch.randn(6, 1, 9, generator=g) * 3, None),
+             (L.DIST_GAMMA, torch.rand(6, 40, 9, generator=g) + 0.1, torch.rand(40, 9, generator=g) + 0.5,
+              torch.rand(1, generator=g) + 0.5),
+             (L.DIST_BETA, torch.rand(6, 40, 9, generator=g) * 0.9 + 0.05, torch.rand(9, generator=g) + 0.5,
+              torch.rand(40, 1, generator=g) + 0.5),
+             (L.DIST_HALF_CAUCHY, torch.rand(6, 40, 9, generator=g) * 4, torch.rand(9, generator=g) + 0.5, None)]
+    for dist_id, v, a, b in cases:
+        v, a = v.to(dtype).to(gpu), a.to(dtype).to(gpu)
+        b = None if b is None else b.to(dtype).to(gpu)
+
+        def run():
+            ps = [a.clone().requires_grad_(True)] + ([] if b is None else [b.clone().requires_grad_(True)])
+            lp = fused.log_prob(dist_id, v, ps[0], ps[1] if len(ps) > 1 else None)
+            (lp * 0.5).sum().backward()
+            return [lp.detach()] + [p.grad for p in ps]
+
+        ref = run()
+        before = fuser.STATS["recorded"]
+        with fuser.Fuser():
+            got = run()
+        torch.cuda.synchronize()
+        assert fuser.STATS["recorded"] - before >= 3
+        tight = dict(rtol=2e-6, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-14, atol=1e-14)
+        torch.testing.assert_close(got[0], ref[0], **tight)
+        tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
+        for x, y in zip(got[1:], ref[1:]):
+            torch.testing.assert_close(x, y, **tol)
+
+
+def test_joins_integer_comparisons_and_layouts(gpu):
+    """stack / cat as copies into slices (the producers' own stores are dropped), dot of short vectors,
+    comparisons of integer tensors with scalars that travel as launch arguments, transposed results."""
+    from pyro_amd.ops import fuser
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(7, 5, generator=g).to(gpu)
+    w = torch.randn(5, generator=g).to(gpu)
+    lengths = torch.randint(1, 9, (7,), generator=g).to(gpu)
+
+    def run():
+        parts = [torch.where((t < lengths).unsqueeze(-1), x * float(t + 3), x.new_zeros(())) for t in range(5)]
+        st = torch.stack(parts).permute(1, 0, 2).contiguous() + torch.cat(parts, -1).sum()
+        d = torch.dot(w, w * 2.0) + (x.t() / (x.t().abs() + 1.0)).sum()
+        tr = x.t() * 3.0 - x.t().exp()                      # (a transposed result, as the operators give it)
+        return st, d, tr, (lengths >= 4) | (lengths == 1)
+
+    ref = run()
+    fuser.UNFUSED.clear()
+    before = fuser.STATS["kernels"]
+    with fuser.Fuser():
+        got = run()
+    torch.cuda.synchronize()
+    assert not fuser.UNFUSED, fuser.UNFUSED
+    assert fuser.STATS["kernels"] - before <= 10
+    assert got[2].stride() == ref[2].stride() and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+    torch.testing.assert_close(got[0], ref[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-5, atol=1e-5)
+
+
+def test_markov_loop_is_batched_across_its_time_steps(gpu):
+    """examples/hmm.py model_1 (toy size) under pyro.markov: the sites of ALL time steps are recorded before
+    anything is launched -- the captured step holds a few dozen launches, not a few per time step -- and the
+    trajectory is the one of the step with the fuser switched off."""
+    import pyro_amd as pyro
+    from pyro_amd.ops import fuser
+    from tools import bench_configs as bc
+
+    out = {}
+    for on in (False, True):
+        fuser.ENABLED["on"] = on
+        try:
+            before = dict(fuser.STATS)
+            pyro.set_rng_seed(3)
+            out[on] = (bc.config_hmm(gpu, S=20, L=24, K=5, D=11, steps=4, graph=True),
+                       {k: fuser.STATS[k] - before[k] for k in fuser.STATS})
+        finally:
+            fuser.ENABLED["on"] = True
+    a, b = out[True][0], out[False][0]
+    assert a["graphed"] and b["graphed"]
+    np.testing.assert_allclose(a["loss_first"], b["loss_first"], rtol=2e-5)
+    np.testing.assert_allclose(a["loss_last"], b["loss_last"], rtol=2e-4)
+    d = out[True][1]
+    # two passes (the eager pre-pass and the capture) of 24 time steps: far fewer launches than time steps x sites
+    assert d["recorded"] > 24 * 40 and d["kernels"] <= 2 * 60, d

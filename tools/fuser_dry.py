@@ -69,15 +69,31 @@ def program(dtype):
     acc[2:4].zero_()
     acc[:, 1].fill_(3.0)
     b = (acc > 0) & (acc < 2.0) | torch.isnan(acc)
-    return loss, b.to(dtype).sum()
+    # the enumeration idiom table[values] and its backward, (log_)softmax over a short dim
+    table = torch.randn(4, 6, dtype=dtype, requires_grad=True)
+    idx = torch.arange(4).reshape(4, 1, 1)
+    sm = torch.softmax(table[idx] * 2.0, -1) + torch.log_softmax(table, 0)
+    (sm * sm).sum().backward()
+    lengths = torch.randint(1, 9, (7,))
+    parts = [torch.where((t < lengths).unsqueeze(-1), x.detach() * float(t), x.new_zeros(())) for t in range(5)]
+    st = torch.stack(parts).permute(1, 0, 2).contiguous() + torch.cat(parts, -1).sum()
+    d = torch.dot(w.detach(), w.detach() * 2.0) + (x.detach().t() / acc.t()).sum()
+    f = fuser.active()
+    v = torch.rand(7, 5, dtype=dtype) + 0.5
+    fam = [f.family_log_prob(k, v, w.detach().abs() + 0.5, x.detach().abs() + 0.5, (7, 5)) for k in range(10)]
+    assert all(t is not None for t in fam)
+    fam += list(f.family_grads(6, fam[0], v, w.detach().abs() + 0.5, x.detach().abs() + 0.5, (7, 5), (True, True, True)))
+    fam += list(f.family_grads(1, fam[1].sum(), v, w.detach(), None, (7, 5), (False, True, False)))
+    return loss, b.to(dtype).sum(), st, d, fam
 
 
 for dt in (torch.float32, torch.float64):
     before = dict(fuser.STATS)
     with fuser.Fuser() as f:
-        program(dt)
+        res = program(dt)
     print(dt, {k: fuser.STATS[k] - before[k] for k in fuser.STATS})
 print("kernels generated:", len(SOURCES), "distinct:", len(set(SOURCES)))
 if "-v" in sys.argv:
     for s in sorted(set(SOURCES), key=len)[-3:]:
         print(s[s.index("extern"):])
+print("not taken:", fuser.UNFUSED)

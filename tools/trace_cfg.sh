@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-by-kernel sequence of ONE graphed SVI.step of configs 4 / 5 (developer tool): bash tools/trace_cfg.sh 4|5
+# kernel-by-kernel sequence of ONE graphed SVI.step of configs 4 / 5 (developer tool): bash tools/trace_cfg.sh 4|5|h
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 C=${1:-4}; OUT=gpurun_out/trace_cfg$C; rm -rf $OUT; mkdir -p $OUT
@@ -8,7 +8,7 @@ import sys; sys.path.insert(0,'.')
 import torch
 from tools import bench_configs as b
 dev=torch.device('cuda:0')
-print({'4': lambda: b.config4(dev, steps=4), '5': lambda: b.config5(dev, steps=4)}['$C']())
+print({'4': lambda: b.config4(dev, steps=4), '5': lambda: b.config5(dev, steps=4), 'h': lambda: b.config_hmm(dev, steps=3, graph=True)}['$C']())
 " > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys, os
