@@ -58,6 +58,19 @@ class _FusedElementwise:
         if self._validate_args:
             self._validate_sample(value)
         p0, p1 = self._params()
+        base = getattr(self, "_base_params", None)
+        if base is not None and base[0] is not None and isinstance(value, torch.Tensor):
+            # the parameters as given BEFORE .expand() wherever the value carries the batch shape anyway: the
+            # kernels broadcast by stride, and a parameter derived lazily from an expanded one (logits from
+            # expanded probs) would be derived once per ELEMENT instead of once per table entry
+            full = torch.broadcast_shapes(value.shape, p0.shape, p1.shape if p1 is not None else ())
+            try:
+                small = torch.broadcast_shapes(value.shape, base[0].shape,
+                                               base[1].shape if base[1] is not None else ())
+            except RuntimeError:
+                small = None
+            if small == full:
+                p0, p1 = base
         return fused.log_prob(self._dist_id, value, p0, p1)
 
     def fused_log_prob_sum(self, value, scale=1.0, mask=None):

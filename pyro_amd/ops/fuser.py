@@ -41,6 +41,7 @@ INLINE_REDUCE = 32          # up to here a reduction is a loop inside an element
 MAX_DIMS = 6
 SMALL = 1 << 14             # up to here unconnected nodes of one shape and level share a kernel
 MAX_SCATTER = 64            # index_put(accumulate=True): most index entries a thread walks per element
+MAP_REDUCE = {"on": os.environ.get("PYRO_AMD_FUSER_MAP_REDUCE", "1") != "0"}
 MERGE_LEVELS = {"on": os.environ.get("PYRO_AMD_FUSER_LEVELS", "1") != "0"}
 TRACE = {"on": False, "sites": {}, "kernels": []}     # tools/fuser_attribution.py: where the rest comes from
 
@@ -220,7 +221,7 @@ def _view_key(t):
 
 class _Node:
     __slots__ = ("op", "ins", "out", "shape", "dtype", "ctype", "expr", "kind", "kernel", "wspan", "rspans",
-                 "rviews", "red", "order", "fresh", "live", "inline")
+                 "rviews", "red", "order", "fresh", "live", "inline", "src")
 
 
 DEAD_STORES = {"eliminate": os.environ.get("PYRO_AMD_FUSER_DEAD_STORES", "1") != "0"}
@@ -243,7 +244,7 @@ def _baseline_counts():
 
 
 class _Kernel:
-    __slots__ = ("kind", "shape", "nodes", "index", "npointers", "fixed", "level")
+    __slots__ = ("kind", "shape", "nodes", "index", "npointers", "fixed", "level", "absorbs", "absorbed")
 
 
 def _numel(shape):
@@ -415,6 +416,7 @@ class Fuser(TorchDispatchMode):
         n.op, n.expr, n.ins, n.shape, n.dtype = op, expr, ins, shape, meta_out.dtype
         n.ctype = _CTYPE_ALL[compute or meta_out.dtype]
         n.red = red
+        n.src = None
         n.inline = inline
         n.live = True
         n.kind = "red" if red is not None else "ew"
@@ -444,6 +446,8 @@ class Fuser(TorchDispatchMode):
         for x in ins:
             if x[0] == "n" and (red is not None or inline is not None or x[1].kind != "ew"
                                 or _bcast(x[1].shape, it_shape) != it_shape):
+                if red is not None and x[1].kind == "ew":
+                    n.src = x[1]            # (a longer sum may take its operand's kernel into its own loop)
                 x = ("t", x[1].out)
             if x[0] in "tn" and inline is None:
                 s = tuple(x[1].shape) if x[0] == "t" else x[1].shape
@@ -516,6 +520,7 @@ class Fuser(TorchDispatchMode):
             k = _Kernel()
             k.kind, k.shape, k.nodes, k.index, k.npointers, k.fixed = n.kind, n.shape, [], self.created, set(), False
             k.level = floor
+            k.absorbs = k.absorbed = None
             self.created += 1
             self.kernels.append(k)
             if n.kind == "ew" and _numel(n.shape) <= SMALL:
@@ -1150,6 +1155,8 @@ class Fuser(TorchDispatchMode):
 
     def _run(self, kernels):
         STATS["flushes"] += 1
+        if MAP_REDUCE["on"]:
+            _plan_map_reduce(kernels)
         if DEAD_STORES["eliminate"]:
             self._mark_live(kernels)
         prev, self._busy = self._busy, True
@@ -1163,8 +1170,9 @@ class Fuser(TorchDispatchMode):
             # AccumulateGrad nodes, created on this stream, alive into a later capture on another stream)
             for k in kernels:
                 for n in k.nodes:
-                    n.kernel = n.ins = n.out = None
+                    n.kernel = n.ins = n.out = n.src = None
                 k.nodes = None
+                k.absorbs = k.absorbed = None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1579,7 +1587,10 @@ def _launch_level(ks):
         _launch(src, first, 256, table)
 
     for k in ks:
-        b = _body(k) if k.kind == "ew" else _reduce_body(k.nodes[0])
+        if k.absorbed is not None:
+            continue                        # (runs inside the loop of the sum that reads it)
+        b = _body(k) if k.kind == "ew" else \
+            (_reduce_body(k.nodes[0]) if k.absorbs is None else _map_reduce_body(k.nodes[0], k.absorbs))
         if b is None:
             continue
         if count + len(b[1]) > MAX_POINTERS and group:
@@ -1588,6 +1599,114 @@ def _launch_level(ks):
         group.append(b)
         count += len(b[1])
     go()
+
+
+def _plan_map_reduce(kernels):
+    """A longer sum whose operand is the value of an element-wise kernel of the same batch, over exactly the
+    sum's input shape, takes that kernel into its own loop: the operand (a site's log-density over a plate
+    before the plate is summed out, a gradient before it is summed down to a broadcast parameter's shape) is
+    never written when nothing else reads it.  The pair runs on the element-wise kernel's level."""
+    batch = {id(k) for k in kernels}
+    for k in kernels:
+        if k.kind != "red":
+            continue
+        n = k.nodes[0]
+        m = n.src
+        if m is None or m.kernel is None or id(m.kernel) not in batch:
+            continue
+        M = m.kernel
+        if M.kind != "ew" or M.absorbed is not None or M.level >= k.level or \
+                tuple(m.shape) != tuple(M.shape) or len(M.npointers) > 40:
+            continue
+        # the sum may read the value through a view that only adds / drops size-1 dims
+        t = _mem_of(n)
+        squeeze = lambda sh: tuple(x for x in sh if x != 1)      # noqa: E731
+        if t is None or t.data_ptr() != m.out.data_ptr() or not t.is_contiguous() or \
+                not m.out.is_contiguous() or squeeze(t.shape) != squeeze(M.shape) or \
+                tuple(t.shape) != tuple(n.red["in_shape"]):
+            continue
+        # the reduced dims, as dims of the kernel's own domain
+        big = [d for d, x in enumerate(M.shape) if x != 1]
+        small = [d for d, x in enumerate(t.shape) if x != 1]
+        to_M = dict(zip(small, big))
+        n.red["dims_M"] = tuple(to_M[d] for d in n.red["dims"] if d in to_M)
+        k.absorbs, M.absorbed = M, k
+        k.level = M.level
+        n.ins = []                          # (the operand's tensor is no longer read: its store may be dead)
+
+
+def _group_width(rsize):
+    """Lanes that share one output element of a longer sum (a power of two: the groups tile a wave)."""
+    return 64 if rsize >= 256 else (32 if rsize >= 128 else (16 if rsize >= 48 else 8))
+
+
+def _mem_of(n):
+    x = n.ins[0] if n.ins else None
+    return None if x is None else (x[1].out if x[0] == "n" else x[1])
+
+
+def _map_reduce_body(n, M):
+    """(threads, pointers, function text) of sum node ``n`` with the element-wise kernel ``M`` evaluated inside
+    its loop: one wave per output element with the lanes striding over the reduced range when the operand's
+    innermost dim is reduced, one thread per output element looping over the range otherwise."""
+    red = n.red
+    in_shape, dims, rsize = tuple(M.shape), red["dims_M"], red["rsize"]
+    nd = len(in_shape)
+    kept = [d for d in range(nd) if d not in dims]
+    n_out = 1
+    for d in kept:
+        n_out *= in_shape[d]
+    if n_out == 0 or not n.live and not any(x.live for x in M.nodes):
+        return None
+    inner = max((d for d in range(nd) if in_shape[d] > 1), default=nd - 1)
+    by_wave = inner in dims or n_out < 1024
+    used, ptrs = set(), []
+    lines, stores = _gen_body(M.nodes, tuple(in_shape), ptrs, used)
+    last = {}
+    for x in M.nodes:
+        last[_view_key(x.out)] = x
+    keep = {id(x) for x in last.values() if x.live}
+    stores = [s_ for x, s_ in zip(M.nodes, stores) if id(x) in keep]
+    src = "v%d" % next(q for q, x in enumerate(M.nodes) if x is n.src)
+    T = n.ctype
+    acc = "double" if n.dtype == torch.float64 else "float"
+    ptrs.append(n.out)
+    po = len(ptrs) - 1
+
+    def decomp(var, ds, prefix, indent):
+        out, rem = [indent + "long %s_ = %s;" % (prefix, var)], "%s_" % prefix
+        for q in range(len(ds) - 1, -1, -1):
+            d = ds[q]
+            if q > 0:
+                out.append(indent + "const long i%d = %s %% %dL; %s /= %dL;" % (d, rem, in_shape[d], rem, in_shape[d]))
+            else:
+                out.append(indent + "const long i%d = %s;" % (d, rem))
+        return out
+    cst = _contig_strides(in_shape)
+    linear = " + ".join("i%d * %dL" % (d, cst[d]) for d in range(nd) if in_shape[d] > 1) or "0"
+    head = "(const long gi%s) {\n" % "".join(", void* p%d" % j for j in range(len(ptrs)))
+    W = _group_width(rsize)
+    if by_wave:
+        head += "  const long o = gi / %dL;\n  const int lane = (int)(gi & %d);\n" % (W, W - 1)
+        loop = "  for (long r = lane; r < %dL; r += %d) {\n" % (rsize, W)
+        threads = n_out * W
+    else:
+        head += "  const long o = gi;\n"
+        loop = "  _Pragma(\"unroll 4\")\n  for (long r = 0; r < %dL; ++r) {\n" % rsize
+        threads = n_out
+    text = head + "\n".join(decomp("o", kept, "o", "  ") if kept else []) + "\n  %s s = 0;\n" % acc + loop + \
+        "\n".join(decomp("r", list(dims), "q", "    ")) + "\n    const long i = %s;\n" % linear + \
+        "\n".join("  " + ln for ln in lines) + "\n" + "\n".join("  " + ln for ln in stores if ln) + \
+        "\n    s += (%s)%s;\n  }\n" % (acc, src)
+    if by_wave:
+        text += "  for (int m = %d; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n  if (lane == 0) " % (W // 2)
+    else:
+        text += "  "
+    text += "((%s*)p%d)[o] = (%s)s;\n}\n" % (T, po, T) if n.live else ";\n}\n"
+    if TRACE["on"]:
+        TRACE["kernels"].append((tuple(in_shape), [(x.op, x.shape, x.live) for x in M.nodes] +
+                                 [("sum%d%s" % (rsize, "w" if by_wave else "t"), n.shape, n.live)]))
+    return threads, ptrs, _narrow(text, max(threads, _numel(in_shape)), ptrs)
 
 
 def _reduce_body(n):
@@ -1621,15 +1740,17 @@ def _reduce_body(n):
     o_off = " + ".join("o%d * %dL" % (d, st[d]) for d in kept if in_shape[d] > 1 and st[d] != 0) or "0"
     r_off = " + ".join("q%d * %dL" % (d, st[d]) for d in dims if in_shape[d] > 1 and st[d] != 0) or "0"
     r_lines = decomp("r", list(dims), "q")
-    text = "(const long i, void* p0, void* p1) {\n  const long o = i >> 6;\n  const int lane = (int)(i & 63);\n" + \
-        "\n".join(o_lines) + "\n  const long base = %s;\n  %s s = 0;\n  for (long r = lane; r < %dL; r += 64) {\n" \
-        % (o_off, acc, rsize) + "\n".join("  " + ln for ln in r_lines) + \
+    W = _group_width(rsize)
+    text = "(const long i, void* p0, void* p1) {\n  const long o = i / %dL;\n  const int lane = (int)(i & %d);\n" \
+        % (W, W - 1) + \
+        "\n".join(o_lines) + "\n  const long base = %s;\n  %s s = 0;\n  for (long r = lane; r < %dL; r += %d) {\n" \
+        % (o_off, acc, rsize, W) + "\n".join("  " + ln for ln in r_lines) + \
         "\n    s += (%s)((const %s*)p0)[base + %s];\n  }\n" % (acc, T, r_off) + \
-        "  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n" \
+        "  for (int m = %d; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n" % (W // 2) + \
         "  if (lane == 0) ((%s*)p1)[o] = (%s)s;\n}\n" % (T, T)
     if TRACE["on"]:
         TRACE["kernels"].append((tuple(in_shape), [("sum%d" % rsize, n.shape, True)]))
-    return n_out * 64, [t, n.out], _narrow(text, n_out * 64, [t, n.out])
+    return n_out * W, [t, n.out], _narrow(text, n_out * W, [t, n.out])
 
 
 def _trace_site(name, args):

@@ -87,7 +87,9 @@ def test_hmm_under_markov_matches_reference(gpu, which, fused_chain, dtype, rtol
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("B,T,K,shared", [(1, 1, 1, False), (5, 2, 3, False), (7, 9, 16, True),
-                                          (3, 130, 64, False), (229, 129, 16, True)])
+                                          (3, 130, 64, False), (229, 129, 16, True), (229, 129, 16, False),
+                                          (4, 23, 5, False), (6, 8, 17, False), (3, 40, 24, True),
+                                          (2, 35, 32, False), (2, 9, 33, False)])
 def test_logchain_kernel(gpu, dtype, B, T, K, shared):
     """pa_logchain_fwd_bwd against the numpy forward-backward restatement and torch autograd of a
     plain log-space forward recursion; -inf potentials (forbidden transitions) included."""
