@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 5
+#define PA_ABI_VERSION 6
 
 enum { PA_OK = 0, PA_ERR_INVALID = -1, PA_ERR_UNSUPPORTED = -2, PA_ERR_LAUNCH = -3 };
 
@@ -886,6 +886,19 @@ int pa_bow_linear_fwd(const void* image_a, const float* W, const float* bias, in
                       pa_stream_t stream);
 int pa_bow_linear_bwd(const void* image_b, const float* d_out, int64_t B, int64_t V, int64_t H,
                       float* dW, void* workspace, size_t workspace_bytes, pa_stream_t stream);
+/* The same layer with the Sigmoid that follows it in examples/lda.py:84-87 (nn.Sequential(Linear, Sigmoid,
+ * ...): torch runs sigmoid / sigmoid_backward as two more passes over [B, H] in each direction).
+ * pa_bow_linear_fwd_act: sigmoid_out != 0 stores y = 1 / (1 + exp(-(bias + C W^T))).
+ * pa_bow_linear_bwd_act: y_mul != NULL (that y) makes d_out the gradient of the ACTIVATION: what is split
+ * and multiplied is d_out * (1 - y) * y (sigmoid_backward, never written); db_partial != NULL
+ * ([4 * Bp / 16][32] floats) receives the bias gradient's partial sums -- entry [(t * Bp/16 + k)][c] is
+ * the sum over documents 16 k .. 16 k + 15 for hidden unit 32 t + c -- which the caller sums over k. */
+int pa_bow_linear_fwd_act(const void* image_a, const float* W, const float* bias, int64_t B, int64_t V,
+                          int64_t H, int sigmoid_out, float* out, void* workspace,
+                          size_t workspace_bytes, pa_stream_t stream);
+int pa_bow_linear_bwd_act(const void* image_b, const float* d_out, const float* y_mul, int64_t B, int64_t V,
+                          int64_t H, float* dW, float* db_partial, void* workspace, size_t workspace_bytes,
+                          pa_stream_t stream);
 
 /* out[M, N] = A^T X for tall f32 operands A[B, M], X[B, N] (M, N <= 128, B large): the weight
  * gradient of a Linear layer over a large batch, dW = d_out^T input (examples/lda.py:76-92 with
@@ -913,6 +926,15 @@ int pa_tall_linear(const float* G, int64_t B, int64_t R, const float* W, int64_t
 size_t pa_tall_wgrad_workspace(int64_t B, int64_t R, int64_t K);
 int pa_tall_wgrad(const float* G, const float* X, int64_t B, int64_t R, int64_t K, float* dW, float* db,
                   void* workspace, size_t workspace_bytes, pa_stream_t stream);
+/* ... with the Sigmoid behind the layer fused (see pa_bow_linear_fwd_act): pa_tall_linear_act stores
+ * sigmoid(G Wm + bias) when sigmoid_out != 0 and reads its first operand as G * (1 - y) * y when
+ * y_mul[B, R] != NULL (the input gradient THROUGH the previous layer's Sigmoid); pa_tall_wgrad_act
+ * likewise takes G * (1 - y) * y for G (dW and db of a layer whose output went through a Sigmoid). */
+int pa_tall_linear_act(const float* G, int64_t B, int64_t R, const float* W, int64_t w_row_stride,
+                       int64_t w_col_stride, int64_t C, const float* bias, const float* y_mul,
+                       int sigmoid_out, float* Y, pa_stream_t stream);
+int pa_tall_wgrad_act(const float* G, const float* X, const float* y_mul, int64_t B, int64_t R, int64_t K,
+                      float* dW, float* db, void* workspace, size_t workspace_bytes, pa_stream_t stream);
 
 /* Reparameterised standard-Gamma draws out[i] ~ Gamma(alpha[i], 1) on the keyed Philox stream and,
  * when d_alpha != NULL, the implicit reparameterisation gradient d out[i] / d alpha[i].  Replaces

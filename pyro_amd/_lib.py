@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpyro_amd.so")
 
 PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_LAUNCH = 0, -1, -2, -3
 PA_F32, PA_F64 = 0, 1
-ABI_VERSION = 5      # PA_ABI_VERSION of include/pyro_amd.h
+ABI_VERSION = 6      # PA_ABI_VERSION of include/pyro_amd.h
 
 DIST_NORMAL = 0
 DIST_BERNOULLI_LOGITS = 1
@@ -124,6 +124,10 @@ _SIGNATURES = {
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
     "pa_tall_linear": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                c_void_p, c_void_p]),
+    "pa_tall_linear_act": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                   c_void_p, c_int, c_void_p, c_void_p]),
+    "pa_tall_wgrad_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
     "pa_tall_wgrad_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_tall_wgrad": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                               c_size_t, c_void_p]),
@@ -264,6 +268,10 @@ _SIGNATURES = {
                                   c_void_p, c_size_t, c_void_p]),
     "pa_bow_linear_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
+    "pa_bow_linear_fwd_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "pa_bow_linear_bwd_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     "pa_tsgemm_tn_workspace": (c_size_t, [c_int64, c_int64, c_int64]),
     "pa_tsgemm_tn": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
                              c_void_p]),

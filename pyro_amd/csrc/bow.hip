@@ -58,9 +58,15 @@ __global__ __launch_bounds__(256) void bow_split_w_kernel(const float* __restric
   planes[2 * nblk * 64 + idx] = c3;
 }
 
-// d[B, H] f32 -> planes[3][BOW_HT][Bp/16] blocks (A operand of the backward product); rows >= B are zero
-__global__ __launch_bounds__(256) void bow_split_d_kernel(const float* __restrict__ d, int64_t B, int64_t Bp,
-                                                          int H, uint4* __restrict__ planes) {
+// d[B, H] f32 -> planes[3][BOW_HT][Bp/16] blocks (A operand of the backward product); rows >= B are zero.
+// With `ymul` (the layer's sigmoid output y[B, H]) d is the gradient of the ACTIVATION and what is split is
+// d * (1 - y) * y (torch's sigmoid_backward, never written); `db_part` [BOW_HT * Bp/16][32] receives, per
+// operand block, the sums of its 16 rows for the block's 32 hidden units (the bias gradient's partial sums:
+// summed over the k-steps by the caller, in a fixed order).
+__global__ __launch_bounds__(256) void bow_split_d_kernel(const float* __restrict__ d,
+                                                          const float* __restrict__ ymul, int64_t B,
+                                                          int64_t Bp, int H, uint4* __restrict__ planes,
+                                                          float* __restrict__ db_part) {
   const int64_t nkt = Bp / 16, nblk = (int64_t)BOW_HT * nkt;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= nblk * 64) return;
@@ -73,6 +79,18 @@ __global__ __launch_bounds__(256) void bow_split_d_kernel(const float* __restric
   float v[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) v[q] = (j < H && b0 + q < B) ? d[(b0 + q) * H + j] : 0.0f;
+  if (ymul != nullptr) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float y = (j < H && b0 + q < B) ? ymul[(b0 + q) * H + j] : 0.0f;
+      v[q] = v[q] * (1.0f - y) * y;
+    }
+  }
+  if (db_part != nullptr) {               // (whole waves are inside nblk * 64: every lane takes part)
+    float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    sum += __shfl_xor(sum, 32, 64);
+    if (lane < 32) db_part[blk * 32 + lane] = sum;
+  }
   uint4 c1, c2, c3;
   split8(v, c1, c2, c3);
   planes[idx] = c1;
@@ -119,7 +137,7 @@ __device__ __forceinline__ void bow_wait(BowASet& a) {
 __global__ __launch_bounds__(256, 2) void bow_linear_fwd_kernel(const uint4* __restrict__ imgA,
                                                                 const uint4* __restrict__ wpl,
                                                                 const float* __restrict__ bias,
-                                                                int64_t B, int V, int H,
+                                                                int64_t B, int V, int H, int act,
                                                                 float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bow_smem[];
   const uint4* wsm = reinterpret_cast<const uint4*>(bow_smem);   // [buffer][k-step][tile][plane][lane]
@@ -210,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void bow_linear_fwd_kernel(const uint4* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t doc = (mt0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (doc < B) out[doc * H + j] = acc[m][n][r] + bj;
+          const float h = acc[m][n][r] + bj;
+          if (doc < B) out[doc * H + j] = act ? fast_sigmoid(h) : h;
         }
       }
     }
@@ -454,8 +473,10 @@ int pa_tsgemm_tn(const float* A, const float* X, int64_t B, int64_t M, int64_t N
   float* part = (float*)((char*)workspace + 2 * pbytes);
   const int64_t nchunks = (int64_t)pa::BOW_HT * (Bp / 16) * 64;
   const unsigned g = (unsigned)((nchunks + 255) / 256);
-  hipLaunchKernelGGL(pa::bow_split_d_kernel, dim3(g), dim3(256), 0, s, A, B, Bp, (int)M, apl);
-  hipLaunchKernelGGL(pa::bow_split_d_kernel, dim3(g), dim3(256), 0, s, X, B, Bp, (int)N, xpl);
+  hipLaunchKernelGGL(pa::bow_split_d_kernel, dim3(g), dim3(256), 0, s, A, (const float*)nullptr, B, Bp, (int)M,
+                     apl, (float*)nullptr);
+  hipLaunchKernelGGL(pa::bow_split_d_kernel, dim3(g), dim3(256), 0, s, X, (const float*)nullptr, B, Bp, (int)N,
+                     xpl, (float*)nullptr);
   const int ks = pa_ts_ksplit(Bp);
   hipLaunchKernelGGL(pa::tsgemm_tn_kernel, dim3((unsigned)ks), dim3(256), 0, s, (const uint4*)apl,
                      (const uint4*)xpl, Bp, ks, part);
@@ -467,6 +488,12 @@ int pa_tsgemm_tn(const float* A, const float* X, int64_t B, int64_t M, int64_t N
 int pa_bow_linear_fwd(const void* image_a, const float* W, const float* bias, int64_t B, int64_t V,
                       int64_t H, float* out, void* workspace, size_t workspace_bytes,
                       pa_stream_t stream) {
+  return pa_bow_linear_fwd_act(image_a, W, bias, B, V, H, 0, out, workspace, workspace_bytes, stream);
+}
+
+int pa_bow_linear_fwd_act(const void* image_a, const float* W, const float* bias, int64_t B, int64_t V,
+                          int64_t H, int sigmoid_out, float* out, void* workspace,
+                          size_t workspace_bytes, pa_stream_t stream) {
   PA_REQUIRE(B >= 0 && V >= 128 && V % 128 == 0 && H >= 1 && H <= 128,
              "bow_linear_fwd: needs V a multiple of 128 and H <= 128 (B=%lld V=%lld H=%lld)",
              (long long)B, (long long)V, (long long)H);
@@ -487,13 +514,20 @@ int pa_bow_linear_fwd(const void* image_a, const float* W, const float* bias, in
   (void)hipFuncSetAttribute((const void*)pa::bow_linear_fwd_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize, pa::BOW_FWD_LDS);
   hipLaunchKernelGGL(pa::bow_linear_fwd_kernel, dim3((unsigned)nwg), dim3(256), pa::BOW_FWD_LDS, s,
-                     (const uint4*)image_a, (const uint4*)wpl, bias, B, (int)V, (int)H, out);
+                     (const uint4*)image_a, (const uint4*)wpl, bias, B, (int)V, (int)H, sigmoid_out, out);
   if (br) (void)hipEventRecord(ev1, s);
   return pa::check_launch("bow_linear_fwd_kernel");
 }
 
 int pa_bow_linear_bwd(const void* image_b, const float* d_out, int64_t B, int64_t V, int64_t H,
                       float* dW, void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  return pa_bow_linear_bwd_act(image_b, d_out, nullptr, B, V, H, dW, nullptr, workspace, workspace_bytes,
+                               stream);
+}
+
+int pa_bow_linear_bwd_act(const void* image_b, const float* d_out, const float* y_mul, int64_t B, int64_t V,
+                          int64_t H, float* dW, float* db_partial, void* workspace, size_t workspace_bytes,
+                          pa_stream_t stream) {
   PA_REQUIRE(B >= 0 && V >= 128 && V % 128 == 0 && H >= 1 && H <= 128,
              "bow_linear_bwd: needs V a multiple of 128 and H <= 128 (B=%lld V=%lld H=%lld)",
              (long long)B, (long long)V, (long long)H);
@@ -512,7 +546,7 @@ int pa_bow_linear_bwd(const void* image_b, const float* d_out, int64_t B, int64_
   float* part = (float*)((char*)workspace + dbytes);
   const int64_t nchunks = (int64_t)pa::BOW_HT * (Bp / 16) * 64;
   hipLaunchKernelGGL(pa::bow_split_d_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, d_out,
-                     B, Bp, (int)H, dpl);
+                     y_mul, B, Bp, (int)H, dpl, db_partial);
   const int ks = pa::bow_ksplit(Bp, (int)V);
   const int64_t ks8 = (ks + 7) / 8 * 8;           // (workgroups with s >= ks return at once)
   hipLaunchKernelGGL(pa::bow_linear_bwd_kernel, dim3((unsigned)((V / 128) * ks8)), dim3(256), 0, s,

@@ -10,6 +10,13 @@
 
 namespace pa {
 
+// 1 / (1 + exp(-h)) on v_exp_f32 / v_rcp_f32 (1 ulp each; exp2 of a large argument is +inf and rcp(inf) = 0, so
+// both limits come out right): the activation in the epilogue of the Linear-layer kernels (tall.hip, bow.hip)
+__device__ __forceinline__ float fast_sigmoid(float h) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * h));
+}
+
+
 constexpr int WAVE = 64;
 
 // ---- host-side error plumbing ------------------------------------------------------------

@@ -59,7 +59,11 @@ __device__ __forceinline__ double gamma_draw(double a, uint64_t seed, uint64_t b
 }
 
 // d x / d a at (a, x), see the header
-__device__ __forceinline__ double gamma_implicit_grad(double a, double x) {
+// `tol`: where the series / continued fraction stop.  1e-17 / 1e-16 for fp64 tensors; a float32 tensor rounds
+// the result to 6e-8 anyway and stops at 1e-10 (both converge at least geometrically: a third fewer of the
+// serial fp64 iterations that bound this kernel -- one lane's longest chain is the launch's duration).
+__device__ __forceinline__ double gamma_implicit_grad(double a, double x, double tol_series = 1e-17,
+                                                      double tol_cf = 1e-16) {
   if (!(x > 0.0) || !(a > 0.0)) return 0.0;
   // Both evaluations below need ~ c sqrt(a) terms near x ~ a (the terms only start to fall once
   // n > x - a and then fall like exp(-n^2 / 2a)): the budget grows with sqrt(a) -- a fixed 500 was
@@ -103,7 +107,7 @@ __device__ __forceinline__ double gamma_implicit_grad(double a, double x) {
       t *= f;
       S += t;
       dS += dt;
-      if (fabs(t) < 1e-17 * fabs(S) && fabs(dt) < 1e-17 * fabs(dS)) break;
+      if (fabs(t) < tol_series * fabs(S) && fabs(dt) < tol_series * fabs(dS)) break;
     }
     return -x * (S * lx_psi + dS);
   }
@@ -128,7 +132,7 @@ __device__ __forceinline__ double gamma_implicit_grad(double a, double x) {
     const double del = d * c, ddel = dd * c + d * dc;
     dh = dh * del + h * ddel;
     h *= del;
-    if (fabs(del - 1.0) < 1e-16 && fabs(ddel) < 1e-16) break;
+    if (fabs(del - 1.0) < tol_cf && fabs(ddel) < tol_cf) break;
   }
   return x * (h * lx_psi + dh);
 }
@@ -148,7 +152,9 @@ __global__ __launch_bounds__(256) void gamma_rsample_kernel(T* __restrict__ out,
     const double lo = sizeof(T) == 4 ? 1.1754943508222875e-38 : 2.2250738585072014e-308;
     x = x > lo ? x : lo;
     out[i] = (T)x;
-    if (dalpha != nullptr) dalpha[i] = (T)gamma_implicit_grad(a, (double)(T)x);
+    if (dalpha != nullptr)
+      dalpha[i] = (T)gamma_implicit_grad(a, (double)(T)x, sizeof(T) == 4 ? 1e-10 : 1e-17,
+                                         sizeof(T) == 4 ? 1e-10 : 1e-16);
   }
 }
 
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(256) void gamma_grad_kernel(T* __restrict__ dalpha,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x)
     dalpha[i] = (T)gamma_implicit_grad((double)alpha.at(i / cols, i % cols),
-                                       (double)value.at(i / cols, i % cols));
+                                       (double)value.at(i / cols, i % cols), sizeof(T) == 4 ? 1e-10 : 1e-17,
+                                       sizeof(T) == 4 ? 1e-10 : 1e-16);
 }
 
 }  // namespace pa

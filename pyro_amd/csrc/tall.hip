@@ -21,6 +21,11 @@
 //                       fixed row the 32 lanes of a group read 32 consecutive floats -- and splits them
 //                       in registers; every wave accumulates its own [32, 128] tile over its share of
 //                       the rows, partial tiles are reduced in a fixed order (bitwise reproducible).
+// A Sigmoid behind the layer (examples/lda.py:84-87: every Linear of the predictor is followed by one) rides
+// along instead of taking two more passes over [B, C] in each direction: pa_tall_linear_act stores
+// sigmoid(G Wm + bias) from the accumulators, and in the backward the upstream gradient g of the ACTIVATION
+// enters both kernels as g * y * (1 - y) with y read next to g (`y_mul`): torch's sigmoid_backward, fused
+// into the operand loads of dx and dW / db.
 #include "common.h"
 #include "glm_bf16.h"
 
@@ -49,6 +54,7 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
                                                           const float* __restrict__ W, int64_t w_rs,
                                                           int64_t w_cs, int C,
                                                           const float* __restrict__ bias,
+                                                          const float* __restrict__ Ymul, int act,
                                                           float* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tall_smem[];
   uint4* wsm = reinterpret_cast<uint4*>(tall_smem);
@@ -93,20 +99,30 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
     const int64_t row = t * 32 + l31;
     const bool rok = row < B;
     const float* gr = G + (rok ? row : B - 1) * R;
+    const float* yr = Ymul != nullptr ? Ymul + (rok ? row : B - 1) * R : nullptr;
+    auto dsig = [](float g, float y) { return g * (1.0f - y) * y; };      // (sigmoid_backward's expression)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int r0 = 16 * ks + 8 * kg;
       if (vec4) {                                            // (wave-uniform) R % 4 == 0: two 16-byte granules
         const bool ok0 = r0 + 4 <= R, ok1 = r0 + 8 <= R;
-        const float4 a = *reinterpret_cast<const float4*>(gr + (ok0 ? r0 : 0));
-        const float4 b = *reinterpret_cast<const float4*>(gr + (ok1 ? r0 + 4 : 0));
+        float4 a = *reinterpret_cast<const float4*>(gr + (ok0 ? r0 : 0));
+        float4 b = *reinterpret_cast<const float4*>(gr + (ok1 ? r0 + 4 : 0));
+        if (yr != nullptr) {                                 // (wave-uniform)
+          const float4 ya = *reinterpret_cast<const float4*>(yr + (ok0 ? r0 : 0));
+          const float4 yb = *reinterpret_cast<const float4*>(yr + (ok1 ? r0 + 4 : 0));
+          a.x = dsig(a.x, ya.x); a.y = dsig(a.y, ya.y); a.z = dsig(a.z, ya.z); a.w = dsig(a.w, ya.w);
+          b.x = dsig(b.x, yb.x); b.y = dsig(b.y, yb.y); b.z = dsig(b.z, yb.z); b.w = dsig(b.w, yb.w);
+        }
         const bool k0 = rok && ok0, k1 = rok && ok1;
         v[ks][0] = k0 ? a.x : 0.0f; v[ks][1] = k0 ? a.y : 0.0f; v[ks][2] = k0 ? a.z : 0.0f; v[ks][3] = k0 ? a.w : 0.0f;
         v[ks][4] = k1 ? b.x : 0.0f; v[ks][5] = k1 ? b.y : 0.0f; v[ks][6] = k1 ? b.z : 0.0f; v[ks][7] = k1 ? b.w : 0.0f;
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float x = gr[r0 + q < R ? r0 + q : 0];
+          const int c = r0 + q < R ? r0 + q : 0;
+          float x = gr[c];
+          if (yr != nullptr) x = dsig(x, yr[c]);
           v[ks][q] = (rok && r0 + q < R) ? x : 0.0f;
         }
       }
@@ -156,14 +172,21 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
       if (c >= C) continue;
       const float bc = bias != nullptr ? bias[c] : 0.0f;
       float* yp = Y + (t * 32 + 4 * kg) * C + c;
+      // (act: sigmoid on the hardware exp2 / rcp -- 1 ulp each; the library expf and the IEEE division cost a
+      // wave that has nothing to overlap them with 19 us over the 1e5 x 100 layer, as much as the separate
+      // operator they replace)
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yp[((r & 3) + 8 * (r >> 2)) * C] = acc[ct][r] + bc;
+        for (int r = 0; r < 16; ++r) {
+          const float h = acc[ct][r] + bc;
+          yp[((r & 3) + 8 * (r >> 2)) * C] = act ? fast_sigmoid(h) : h;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t orow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-          if (orow < B) yp[((r & 3) + 8 * (r >> 2)) * C] = acc[ct][r] + bc;
+          const float h = acc[ct][r] + bc;
+          if (orow < B) yp[((r & 3) + 8 * (r >> 2)) * C] = act ? fast_sigmoid(h) : h;
         }
       }
     }
@@ -175,7 +198,8 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
 // rows; partial[gw][32][128] and partial_db[gw][32].
 template <int NCT>
 __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict__ G,
-                                                         const float* __restrict__ X, int64_t B, int R,
+                                                         const float* __restrict__ X,
+                                                         const float* __restrict__ Ymul, int64_t B, int R,
                                                          int K, int nrt, float* __restrict__ partial,
                                                          float* __restrict__ partial_db) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,6 +231,14 @@ __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict
         const float x = gp[(int64_t)q * R];
         o.ga[q] = r_ok ? x : 0.0f;
       }
+      if (Ymul != nullptr) {                              // (wave-uniform) g * ((1 - y) * y)
+        const float* yp = Ymul + b0 * R + rc;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float y = yp[(int64_t)q * R];
+          o.ga[q] = o.ga[q] * (1.0f - y) * y;
+        }
+      }
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         const int k = 32 * ct + l31;
@@ -219,7 +251,13 @@ __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict
       }
     } else {                                              // the last k-step (or one past the end: all zero)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o.ga[q] = (r_ok && b0 + q < B) ? G[(b0 + q) * R + r] : 0.0f;
+      for (int q = 0; q < 8; ++q) {
+        o.ga[q] = (r_ok && b0 + q < B) ? G[(b0 + q) * R + r] : 0.0f;
+        if (Ymul != nullptr && r_ok && b0 + q < B) {
+          const float y = Ymul[(b0 + q) * R + r];
+          o.ga[q] = o.ga[q] * (1.0f - y) * y;
+        }
+      }
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         const int k = 32 * ct + l31;
@@ -319,6 +357,12 @@ extern "C" {
 
 int pa_tall_linear(const float* G, int64_t B, int64_t R, const float* W, int64_t w_row_stride,
                    int64_t w_col_stride, int64_t C, const float* bias, float* Y, pa_stream_t stream) {
+  return pa_tall_linear_act(G, B, R, W, w_row_stride, w_col_stride, C, bias, nullptr, 0, Y, stream);
+}
+
+int pa_tall_linear_act(const float* G, int64_t B, int64_t R, const float* W, int64_t w_row_stride,
+                       int64_t w_col_stride, int64_t C, const float* bias, const float* y_mul,
+                       int sigmoid_out, float* Y, pa_stream_t stream) {
   PA_REQUIRE(B >= 0 && R >= 1 && R <= pa::TALL_MAX && C >= 1 && C <= pa::TALL_MAX,
              "tall_linear: needs 1 <= R, C <= 128 (B=%lld R=%lld C=%lld)", (long long)B, (long long)R,
              (long long)C);
@@ -337,7 +381,7 @@ int pa_tall_linear(const float* G, int64_t B, int64_t R, const float* W, int64_t
     const size_t l = (size_t)NKS_ * NCT_ * 3 * 1024;                                                   \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);     \
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), l, s, G, B, (int)R, W, w_row_stride,        \
-                       w_col_stride, (int)C, bias, Y);                                                 \
+                       w_col_stride, (int)C, bias, y_mul, sigmoid_out, Y);                             \
     return pa::check_launch("tall_linear_kernel");                                                     \
   }
   (void)lds;
@@ -357,6 +401,11 @@ size_t pa_tall_wgrad_workspace(int64_t B, int64_t R, int64_t K) {
 
 int pa_tall_wgrad(const float* G, const float* X, int64_t B, int64_t R, int64_t K, float* dW, float* db,
                   void* workspace, size_t workspace_bytes, pa_stream_t stream) {
+  return pa_tall_wgrad_act(G, X, nullptr, B, R, K, dW, db, workspace, workspace_bytes, stream);
+}
+
+int pa_tall_wgrad_act(const float* G, const float* X, const float* y_mul, int64_t B, int64_t R, int64_t K,
+                      float* dW, float* db, void* workspace, size_t workspace_bytes, pa_stream_t stream) {
   PA_REQUIRE(B >= 0 && R >= 1 && R <= pa::TALL_MAX && K >= 1 && K <= pa::TALL_MAX,
              "tall_wgrad: needs 1 <= R, K <= 128 (B=%lld R=%lld K=%lld)", (long long)B, (long long)R,
              (long long)K);
@@ -379,8 +428,8 @@ int pa_tall_wgrad(const float* G, const float* X, int64_t B, int64_t R, int64_t 
   const int nct = (int)((K + 31) / 32);
 #define PA_TALLW_CASE(NCT_)                                                                            \
   if (nct == NCT_)                                                                                     \
-    hipLaunchKernelGGL((pa::tall_wgrad_kernel<NCT_>), dim3((unsigned)grid), dim3(256), 0, s, G, X, B,  \
-                       (int)R, (int)K, nrt, part, part_db);
+    hipLaunchKernelGGL((pa::tall_wgrad_kernel<NCT_>), dim3((unsigned)grid), dim3(256), 0, s, G, X,     \
+                       y_mul, B, (int)R, (int)K, nrt, part, part_db);
   PA_TALLW_CASE(1)
   PA_TALLW_CASE(2)
   PA_TALLW_CASE(3)

@@ -155,7 +155,8 @@ def _sum_to(g, like):
     plan = _sum_plan(g.shape, like.shape)
     if plan is None:
         return g.sum_to_size(like.shape)
-    if _fuser.active() is not None and len(plan) == 1 and plan[0][1] <= _fuser.MAX_REDUCE:
+    if _fuser.active() is not None and len(plan) == 1 and \
+            (plan[0][1] <= _fuser.MAX_REDUCE or (g.is_contiguous() and plan[0][1] <= (1 << 26))):
         return g.sum_to_size(like.shape)        # (a recorded reduction: no launch of its own, see ops/fuser.py)
     x = g.contiguous()
     for A, R, B in plan:

@@ -1982,8 +1982,8 @@ def bow_revalidate():
             ent[1] = base._version
 
 
-def bow_linear_fwd(image_a, W, bias, B):
-    """out[B, H] = bias + counts @ W.T (pa_bow_linear_fwd); W [H, V] f32."""
+def bow_linear_fwd(image_a, W, bias, B, sigmoid=False):
+    """out[B, H] = bias + counts @ W.T, through a sigmoid when asked (pa_bow_linear_fwd_act); W [H, V] f32."""
     _require_gpu(image_a, W, bias)
     H, V = W.shape
     assert W.is_contiguous() and W.dtype == torch.float32 and (bias is None or bias.is_contiguous())
@@ -1993,43 +1993,54 @@ def bow_linear_fwd(image_a, W, bias, B):
         raise Unsupported("pyro_amd: bag-of-words layer does not cover B=%d V=%d H=%d" % (B, V, H))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=W.device)
     out = torch.empty((B, H), dtype=torch.float32, device=W.device)
-    check(lib.pa_bow_linear_fwd(_ptr(image_a), _ptr(W), _ptr(bias), B, V, H, _ptr(out), _ptr(ws), nbytes,
-                                _stream()))
+    check(lib.pa_bow_linear_fwd_act(_ptr(image_a), _ptr(W), _ptr(bias), B, V, H, int(bool(sigmoid)), _ptr(out),
+                                    _ptr(ws), nbytes, _stream()))
     return out
 
 
-def bow_linear_bwd(image_b, d_out, V):
-    """dW[H, V] = d_out.T @ counts (pa_bow_linear_bwd); d_out [B, H] f32."""
-    _require_gpu(image_b, d_out)
+def bow_linear_bwd(image_b, d_out, V, y_mul=None, want_bias=False):
+    """dW[H, V] = d.T @ counts with d = d_out [B, H] f32, or d = d_out * (1 - y_mul) * y_mul (the gradient
+    through the layer's sigmoid output ``y_mul``) -- pa_bow_linear_bwd_act.  ``want_bias``: returns
+    (dW, partial sums [4, ceil(B / 32) * 2, 32] of d over blocks of 16 documents: .sum(1) is the bias gradient
+    of hidden units 32 t + c)."""
+    _require_gpu(image_b, d_out, y_mul)
     B, H = d_out.shape
     d_out = d_out.contiguous()
+    assert y_mul is None or (y_mul.shape == d_out.shape and y_mul.is_contiguous() and y_mul.dtype == torch.float32)
     lib = _lib.load()
     nbytes = lib.pa_bow_workspace(B, V, H)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=d_out.device)
     dW = torch.empty((H, V), dtype=torch.float32, device=d_out.device)
-    check(lib.pa_bow_linear_bwd(_ptr(image_b), _ptr(d_out), B, V, H, _ptr(dW), _ptr(ws), nbytes, _stream()))
-    return dW
+    nkt = (B + 31) // 32 * 2
+    part = torch.empty((4, nkt, 32), dtype=torch.float32, device=d_out.device) if want_bias else None
+    check(lib.pa_bow_linear_bwd_act(_ptr(image_b), _ptr(d_out), _ptr(y_mul), B, V, H, _ptr(dW), _ptr(part),
+                                    _ptr(ws), nbytes, _stream()))
+    return (dW, part) if want_bias else dW
 
 
-def tall_linear(g, W, w_row_stride, w_col_stride, C, bias=None):
-    """g[B, R] @ Wm[R, C] (+ bias): pa_tall_linear; Wm[r][c] = W.flat[r * w_row_stride + c * w_col_stride]."""
-    _require_gpu(g, W, bias)
+def tall_linear(g, W, w_row_stride, w_col_stride, C, bias=None, y_mul=None, sigmoid=False):
+    """g[B, R] @ Wm[R, C] (+ bias): pa_tall_linear_act; Wm[r][c] = W.flat[r * w_row_stride + c * w_col_stride].
+    ``y_mul`` [B, R]: the first operand is g * (1 - y_mul) * y_mul; ``sigmoid``: the result goes through one."""
+    _require_gpu(g, W, bias, y_mul)
     B, R = g.shape
     assert g.dtype == torch.float32 == W.dtype and g.is_contiguous() and W.is_contiguous()
+    assert y_mul is None or (y_mul.shape == g.shape and y_mul.is_contiguous() and y_mul.dtype == torch.float32)
     if R > 128 or C > 128:
         raise Unsupported("pyro_amd: tall_linear covers at most 128 features (R=%d C=%d)" % (R, C))
     out = torch.empty((B, C), dtype=torch.float32, device=g.device)
-    check(_lib.load().pa_tall_linear(_ptr(g), B, R, _ptr(W), int(w_row_stride), int(w_col_stride), int(C),
-                                     _ptr(bias), _ptr(out), _stream()))
+    check(_lib.load().pa_tall_linear_act(_ptr(g), B, R, _ptr(W), int(w_row_stride), int(w_col_stride), int(C),
+                                         _ptr(bias), _ptr(y_mul), int(bool(sigmoid)), _ptr(out), _stream()))
     return out
 
 
-def tall_wgrad(g, x, want_bias=True):
-    """(g[B, R].T @ x[B, K], g.sum(0)) in one pass over the batch: pa_tall_wgrad."""
-    _require_gpu(g, x)
+def tall_wgrad(g, x, want_bias=True, y_mul=None):
+    """(d[B, R].T @ x[B, K], d.sum(0)) in one pass over the batch with d = g, or g * (1 - y_mul) * y_mul:
+    pa_tall_wgrad_act."""
+    _require_gpu(g, x, y_mul)
     B, R = g.shape
     K = x.shape[1]
     assert x.shape[0] == B and g.dtype == torch.float32 == x.dtype and g.is_contiguous() and x.is_contiguous()
+    assert y_mul is None or (y_mul.shape == g.shape and y_mul.is_contiguous() and y_mul.dtype == torch.float32)
     lib = _lib.load()
     nbytes = lib.pa_tall_wgrad_workspace(B, R, K)
     if nbytes == 0:
@@ -2037,7 +2048,8 @@ def tall_wgrad(g, x, want_bias=True):
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=g.device)
     dW = torch.empty((R, K), dtype=torch.float32, device=g.device)
     db = torch.empty((R,), dtype=torch.float32, device=g.device) if want_bias else None
-    check(lib.pa_tall_wgrad(_ptr(g), _ptr(x), B, R, K, _ptr(dW), _ptr(db), _ptr(ws), nbytes, _stream()))
+    check(lib.pa_tall_wgrad_act(_ptr(g), _ptr(x), _ptr(y_mul), B, R, K, _ptr(dW), _ptr(db), _ptr(ws), nbytes,
+                                _stream()))
     return dW, db
 
 

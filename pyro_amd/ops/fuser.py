@@ -2,21 +2,32 @@
 
 What it replaces.  Between the fused sites of a step the reference -- and this package, wherever a model or
 guide is written in plain torch -- runs a long tail of small ATen operators: constraint transforms of
-parameters, ``probs -> logits``, a guide's normalisations, and the autograd duals of every one of them
-(pyro/infer/traceenum_elbo.py:112-214 over examples/lda.py:78-122: ~110 such operators per step, 65 of
-them on the autograd thread).  Inside a captured step each is a graph node that costs its dispatch
-(~3-5 us) whatever it computes.
+parameters, ``probs -> logits``, a guide's normalisations, the indexing of a table by enumerated values, and
+the autograd duals of every one of them (pyro/infer/traceenum_elbo.py:112-214 over examples/lda.py:78-122:
+~110 such operators per step, 65 of them on the autograd thread; examples/hmm.py under pyro.markov: ~50 per
+TIME STEP).  Inside a captured step each is a graph node that costs its dispatch (~3-5 us) whatever it
+computes.
 
 How.  ``Fuser`` is a ``TorchDispatchMode``: an eligible operator (element-wise arithmetic, comparisons,
-``where``, constant fills, copies / casts, small ``sum`` reductions; float32 / float64 / bool on the GPU) is
-NOT launched -- its output tensor is allocated and the operator recorded.  Recorded operators are
-materialised when something needs their memory: an operator the fuser does not know, a launch of the
-package's own kernels (``kernels._ptr``), the end of the scope.  At that point the recorded run is
-partitioned into kernels -- operators with the same output shape whose data flow is index-for-index go into
-ONE kernel, intermediates in registers; memory hazards (views, in-place writes, reductions) separate
-kernels -- and for each a HIP source is emitted, compiled for gfx950 (``pa_rtc_compile``: hiprtc, cached by
-source text) and launched on the current stream.  Arithmetic is the replaced operators' own: the same
-libm calls, no contraction of a*b+c, opmath in the output type.
+``where``, constant fills, copies / casts, ``stack`` / ``cat``, sums, short dot products, (log_)softmax over a
+short dim, ``table[index]`` and its accumulate=True dual, and -- asked for by distributions/fused.py -- the
+log-density / gradient of the library's element-wise families; float32 / float64 / bool on the GPU) is NOT
+launched -- its output tensor is allocated and the operator recorded.  Recorded operators are materialised when
+something needs their memory: an operator the fuser does not know, a launch of the package's own kernels
+(``kernels._ptr``), the end of the scope.
+
+Scheduling.  A recorded operator joins the kernel it is connected to index-for-index (it reads a value of that
+kernel, or rewrites a view of it: intermediates stay in registers, stores nobody reads are dropped); every
+other memory hazard puts it one launch LEVEL above what it depends on.  Kernels of one level are mutually
+independent: they become ONE launch in which every kernel owns a range of workgroups -- kernels with the
+same source text (the same operators over tensors of the same shapes and strides: the sites of the time steps
+of a ``pyro.markov`` loop, which are all recorded before anything runs) share one compiled function and find
+their pointers and scalars at a computed position of the launch's argument table.  A longer sum whose operand
+is the value of an element-wise kernel runs that kernel inside its own loop (the operand is never written when
+nothing else reads it); sums beyond one lane group's reach are recorded in two stages.  For each launch a HIP
+source is emitted, compiled for gfx950 (``pa_rtc_compile``: hiprtc, cached by source text) and launched on the
+current stream.  Arithmetic is the replaced operators' own: the same libm calls, no contraction of a*b+c,
+opmath in the output type; the families' expressions are csrc/dist_fam.h itself.
 
 Scope.  Worth its host cost only where a step is recorded once and replayed: SVI's captured step and NUTS's
 captured rounds enter it (the last eager step before a capture runs under it too, so that every kernel is
@@ -36,7 +47,7 @@ ENABLED = {"on": os.environ.get("PYRO_AMD_FUSER", "1") != "0"}
 STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "flushes": 0, "dead": 0}
 UNFUSED = {}                # operator name -> how often it was met and run as it is (attribution)
 MAX_POINTERS = 384          # PA_RTC_MAX_POINTERS
-MAX_REDUCE = 1 << 14        # longest reduction taken (one wave per output element)
+MAX_REDUCE = 1 << 14        # longest reduction one lane group takes (longer ones: two recorded stages)
 INLINE_REDUCE = 32          # up to here a reduction is a loop inside an element-wise kernel
 MAX_DIMS = 6
 SMALL = 1 << 14             # up to here unconnected nodes of one shape and level share a kernel
@@ -888,7 +899,9 @@ class Fuser(TorchDispatchMode):
         rsize = 1
         for d in dims:
             rsize *= x.shape[d]
-        if rsize > MAX_REDUCE or rsize < 1:
+        if rsize > MAX_REDUCE:
+            return self._chunked_sum(func, args, kwargs, x, dims, rsize)
+        if rsize < 1:
             raise Unfusable
         meta = self._meta(func, args, kwargs)
         red = {"in_shape": tuple(x.shape), "dims": dims, "keep": bool(keep), "rsize": rsize}
@@ -1091,6 +1104,25 @@ class Fuser(TorchDispatchMode):
 
     def _op__log_softmax_backward_data(self, func, base, overload, inplace, args, kwargs):
         return self._softmax_like(func, args, kwargs, "log_softmax_bwd", 2)
+
+    def _chunked_sum(self, func, args, kwargs, x, dims, rsize):
+        """A sum longer than one lane group takes: two recorded sums over a view [.., S, C, ..] of the operand
+        (C elements per group, then the S partial sums) -- for a contiguous operand whose reduced dims are
+        adjacent."""
+        if not x.is_contiguous() or list(dims) != list(range(dims[0], dims[-1] + 1)) or rsize > (1 << 26):
+            raise Unfusable
+        c = max((q for q in range(1, 4097) if rsize % q == 0), default=1)
+        if c < 64 or rsize // c > MAX_REDUCE:
+            raise Unfusable
+        a = _numel(x.shape[:dims[0]])
+        b = _numel(x.shape[dims[-1] + 1:])
+        meta = self._meta(func, args, kwargs)
+        sum_dims = aten.sum.dim_IntList
+        xv = x.view(a, rsize // c, c, b)
+        part = self._op_sum(sum_dims, "sum", "dim_IntList", False, (xv, [2]), {})
+        out = self._op_sum(sum_dims, "sum", "dim_IntList", False, (part, [1]), {})
+        STATS["recorded"] += 1
+        return out.view(tuple(meta.shape))
 
     # ---- materialisation ----------------------------------------------------------------------------
     def flush_for(self, tensors):

@@ -424,7 +424,10 @@ class DeferredCounts:
         images = kernels.bow_images_of(self.words, self.V)
         if images is None:
             return None
-        out = _BowLinear.invoke(weight, bias, images[0], images[1], self.words.shape[1])
+        B = self.words.shape[1]
+        if B >= TALL_MIN_ROWS and FUSE_ACTIVATION["on"]:
+            return DeferredLinear("bow", (weight, bias, images[0], images[1], B), (B, weight.shape[0]), weight)
+        out = _BowLinear.invoke(weight, bias, images[0], images[1], B)
         return out.as_subclass(TallActivation) if out.shape[0] >= TALL_MIN_ROWS else out
 
     @classmethod
@@ -473,6 +476,9 @@ class TallActivation(torch.Tensor):
             if (x.dim() == 2 and x.shape[0] >= TALL_MIN_ROWS and x.shape[1] <= 128 and x.is_cuda
                     and x.dtype == torch.float32 and type(weight) in (torch.Tensor, torch.nn.Parameter)
                     and weight.dim() == 2 and weight.shape[0] <= 128 and weight.dtype == torch.float32):
+                if FUSE_ACTIVATION["on"]:
+                    return DeferredLinear("tall", (x.as_subclass(torch.Tensor), weight, bias),
+                                          (x.shape[0], weight.shape[0]), weight)
                 out = _TallLinear.invoke(x.as_subclass(torch.Tensor), weight, bias)
                 return out.as_subclass(TallActivation)
         with torch._C.DisableTorchFunctionSubclass():
@@ -482,6 +488,142 @@ class TallActivation(torch.Tensor):
                 and out.dim() == 2:
             return out.as_subclass(TallActivation)
         return out
+
+
+FUSE_ACTIVATION = {"on": True}
+
+
+class DeferredLinear:
+    """A Linear layer over a tall batch that has not been launched yet.  nn.Sequential(Linear, Sigmoid, ...)
+    (examples/lda.py:84-87) hands it to ``torch.sigmoid`` next: the layer then runs with the sigmoid in its
+    kernel's epilogue, and its backward takes the gradient THROUGH the sigmoid in the operand loads of dx /
+    dW / db (pa_tall_linear_act, pa_tall_wgrad_act, pa_bow_linear_*_act) -- torch's two extra passes over
+    [B, features] in each direction are gone.  ANY other use launches the plain layer and goes on with its
+    result (a TallActivation), exactly as before."""
+
+    def __init__(self, kind, args, shape, like):
+        self.kind, self.args = kind, args
+        self.shape = torch.Size(shape)
+        self.dtype, self.device = like.dtype, like.device
+        self._plain = None
+
+    ndim = 2
+
+    def dim(self):
+        return 2
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def materialize(self, sigmoid=False):
+        if sigmoid:
+            fn = _BowLinearSigmoid if self.kind == "bow" else _TallLinearSigmoid
+            return fn.invoke(*self.args).as_subclass(TallActivation)
+        if self._plain is None:
+            fn = _BowLinear if self.kind == "bow" else _TallLinear
+            self._plain = fn.invoke(*self.args).as_subclass(TallActivation)
+        return self._plain
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.sigmoid, torch.nn.functional.sigmoid, torch.Tensor.sigmoid) and len(args) == 1 \
+                and not kwargs and isinstance(args[0], DeferredLinear) and ENABLED["on"]:
+            return args[0].materialize(sigmoid=True)
+
+        def ev(x):
+            if isinstance(x, DeferredLinear):
+                return x.materialize()
+            if isinstance(x, (list, tuple)):
+                return type(x)(ev(v) for v in x)
+            return x
+        return func(*ev(args), **{k: ev(v) for k, v in kwargs.items()})
+
+    def sigmoid(self):
+        return self.materialize(sigmoid=True) if ENABLED["on"] else self.materialize().sigmoid()
+
+    def __getattr__(self, name):        # only reached for attributes not defined above
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def _binary(name):
+        def op(self, *other):
+            return getattr(self.materialize(), name)(*other)
+        op.__name__ = name
+        return op
+
+    for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__",
+               "__rtruediv__", "__neg__", "__getitem__", "__matmul__", "__rmatmul__", "__pow__", "__lt__",
+               "__gt__", "__le__", "__ge__", "__len__", "__iter__"):
+        locals()[_n] = _binary(_n)
+    del _n, _binary
+
+
+@_dispatcher_op("tall_linear_sigmoid")
+class _TallLinearSigmoid(torch.autograd.Function):
+    """sigmoid(F.linear(x, weight, bias)) over a tall batch: the sigmoid in pa_tall_linear_act's epilogue; the
+    backward never forms g * (1 - y) * y -- dx, dW and db read y next to g."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .. import kernels
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        n_out, n_in = w.shape
+        y = kernels.tall_linear(x, w, 1, n_in, n_out, None if bias is None else bias.detach().contiguous(),
+                                sigmoid=True)
+        ctx.save_for_backward(x, w, y)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import kernels
+        x, w, y = ctx.saved_tensors
+        g = g.contiguous()
+        n_out, n_in = w.shape
+        dx = kernels.tall_linear(g, w, n_in, 1, n_in, y_mul=y) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = kernels.tall_wgrad(g, x, want_bias=ctx.has_bias and ctx.needs_input_grad[2], y_mul=y)
+        return dx, dW, db
+
+
+@_dispatcher_op("bow_linear_sigmoid")
+class _BowLinearSigmoid(torch.autograd.Function):
+    """sigmoid(bias + counts @ W.T): see _BowLinear and _TallLinearSigmoid; the bias gradient comes from the
+    partial sums the operand-split pass of the backward leaves behind."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, image_a, image_b, B):
+        from .. import kernels
+        w = weight.detach().contiguous()
+        y = kernels.bow_linear_fwd(image_a, w, None if bias is None else bias.detach().contiguous(), B,
+                                   sigmoid=True)
+        ctx.save_for_backward(y)
+        ctx.image_b, ctx.V, ctx.H, ctx.has_bias = image_b, w.shape[1], w.shape[0], bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import kernels
+        y, = ctx.saved_tensors
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        if not ctx.needs_input_grad[0] and not want_b:
+            return None, None, None, None, None
+        out = kernels.bow_linear_bwd(ctx.image_b, g, ctx.V, y_mul=y, want_bias=want_b)
+        if not want_b:
+            return out, None, None, None, None
+        dW, part = out
+        # [4, nkt, 32] -> [4, 32] in two coalesced stages (a thread per (chunk, unit) walks its chunk with its
+        # neighbours on consecutive units; one long strided walk per unit is a cache line per element)
+        nkt = part.shape[1]
+        d = max((q for q in range(1, min(nkt, 256) + 1) if nkt % q == 0), default=1)
+        db = part.view(4, nkt // d, d, 32).sum(2).sum(1)
+        return dW, db.reshape(-1)[:ctx.H], None, None, None
 
 
 @_dispatcher_op("tall_linear")

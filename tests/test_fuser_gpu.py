@@ -390,3 +390,26 @@ def test_markov_loop_is_batched_across_its_time_steps(gpu):
     d = out[True][1]
     # two passes (the eager pre-pass and the capture) of 24 time steps: far fewer launches than time steps x sites
     assert d["recorded"] > 24 * 40 and d["kernels"] <= 2 * 60, d
+
+
+def test_long_sums_in_two_recorded_stages(gpu):
+    """Sums longer than a lane group takes (1e5 documents down to a scalar / to a parameter's shape): a view
+    [.., S, C, ..] of the contiguous operand, C elements per group, then the S partial sums -- recorded, so
+    that they share launches with their neighbours."""
+    from pyro_amd.ops import fuser
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(100000, 8, generator=g).to(gpu)
+    y = torch.randn(100000, generator=g).to(gpu)
+
+    def run():
+        return (x * 2.0).sum(0), y.sum(), y.exp().sum(), x.sum(), x.view(10, 10000, 8).sum(1)
+
+    ref = run()
+    fuser.UNFUSED.clear()
+    with fuser.Fuser():
+        got = run()
+    torch.cuda.synchronize()
+    assert not fuser.UNFUSED, fuser.UNFUSED
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-3)

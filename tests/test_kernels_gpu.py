@@ -1412,6 +1412,20 @@ def test_bag_of_words_linear(gpu, Wd, B, V, H):
     out0 = k.bow_linear_fwd(ia, tt(W, gpu), None, B)
     counts = torch.zeros(V, B, device=gpu).scatter_add(0, tw, torch.ones(tw.shape, device=gpu))
     torch.testing.assert_close(out0, counts.t() @ tt(W, gpu).t(), rtol=1e-5, atol=1e-5 * float(scale))
+    # the Sigmoid behind the layer, fused (pa_bow_linear_fwd_act / _bwd_act): y from the accumulators, the
+    # gradient through it d * (1 - y) * y in the operand-split pass, which also leaves the bias gradient's sums
+    y = k.bow_linear_fwd(ia, tt(W, gpu), tt(bias, gpu), B, sigmoid=True)
+    ry = 1.0 / (1.0 + np.exp(-ref.astype(np.float64)))
+    np.testing.assert_allclose(y.cpu().numpy(), ry, rtol=3e-6, atol=3e-6)
+    yn = y.cpu().numpy().astype(np.float64)
+    dh = d.astype(np.float64) * (1.0 - yn) * yn
+    dW2, part = k.bow_linear_bwd(ib, tt(d, gpu), V, y_mul=y, want_bias=True)
+    rdW2, _ = o_lda.bow_linear_grad(words, V, dh.astype(np.float32))
+    np.testing.assert_allclose(dW2.cpu().numpy(), rdW2, rtol=3e-6, atol=3e-6 * np.abs(rdW2).max())
+    db = part.sum(1).reshape(-1)[:H]
+    np.testing.assert_allclose(db.cpu().numpy(), dh.sum(0), rtol=0, atol=2e-6 * np.abs(dh).sum(0).max() + 1e-6)
+    dW3, part3 = k.bow_linear_bwd(ib, tt(d, gpu), V, y_mul=y, want_bias=True)
+    assert torch.equal(dW2, dW3) and torch.equal(part, part3)
 
 
 @pytest.mark.parametrize("B,n_in,n_out", [(20000, 100, 100), (5000, 100, 8), (4100, 8, 100), (33, 16, 32),
@@ -1443,6 +1457,19 @@ def test_tall_linear_layer(gpu, B, n_in, n_out):
     dW2, db2 = k.tall_wgrad(tg, tx)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
     assert k.tall_wgrad(tg, tx, want_bias=False)[1] is None
+    # the Sigmoid behind the layer, fused (pa_tall_linear_act / pa_tall_wgrad_act): y from the accumulators;
+    # dx / dW / db of the layer BEHIND a sigmoid output y read g * (1 - y) * y in their operand loads
+    y = k.tall_linear(tx, tW, 1, n_in, n_out, tb, sigmoid=True)
+    np.testing.assert_allclose(y.cpu().numpy(), 1.0 / (1.0 + np.exp(-ref.astype(np.float64))), rtol=3e-6, atol=3e-6)
+    yn = y.cpu().numpy().astype(np.float64)
+    gh = (g.astype(np.float64) * (1.0 - yn) * yn).astype(np.float32)
+    dxs = k.tall_linear(tg, tW, n_in, 1, n_in, y_mul=y)
+    dWs, dbs = k.tall_wgrad(tg, tx, y_mul=y)
+    sdx, sdW, sdb = o_lda.tall_linear_grads(x, W, gh)
+    np.testing.assert_allclose(dxs.cpu().numpy(), sdx, rtol=3e-6, atol=3e-6 * np.abs(sdx).max())
+    sscale = (np.abs(gh).astype(np.float64).T @ np.abs(x).astype(np.float64)).max()
+    np.testing.assert_allclose(dWs.cpu().numpy(), sdW, rtol=0, atol=2e-6 * sscale)
+    np.testing.assert_allclose(dbs.cpu().numpy(), sdb, rtol=0, atol=2e-6 * np.abs(gh).sum(0).max() + 1e-6)
 
 
 def test_tall_linear_autograd_route(gpu):
@@ -1463,6 +1490,57 @@ def test_tall_linear_autograd_route(gpu):
     out.square().sum().backward()
     for got, w in zip([x.grad, lin.weight.grad, lin.bias.grad], want):
         torch.testing.assert_close(got, w, rtol=1e-4, atol=1e-4 * float(w.abs().max()))
+
+
+def test_sigmoid_behind_a_tall_linear_layer_rides_in_its_kernels(gpu):
+    """nn.Sequential(Linear, Sigmoid, Linear, Sigmoid) over a tall batch (examples/lda.py:84-87): the layer is
+    deferred until its consumer is known -- torch.sigmoid gets the fused kernels (values and every gradient as
+    torch's own route gives them), anything else the plain layer, computed once."""
+    import torch.nn as nn
+    from pyro_amd.ops import lazy
+    torch.manual_seed(1)
+    B = 5000
+    x0 = torch.randn((B, 100), device=gpu)
+    net = nn.Sequential(nn.Linear(100, 100), nn.Sigmoid(), nn.Linear(100, 8), nn.Sigmoid()).to(gpu)
+
+    def run(tall):
+        for p in net.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = net(x.as_subclass(lazy.TallActivation) if tall else x)
+        (out.as_subclass(torch.Tensor) ** 2).sum().backward()
+        return [out.detach().as_subclass(torch.Tensor), x.grad] + [p.grad.clone() for p in net.parameters()]
+
+    want = run(False)
+    launched = []
+    k = _k()
+    real = k.tall_linear
+    k.tall_linear = lambda *a, **kw: (launched.append(kw.get("sigmoid", False) or kw.get("y_mul") is not None),
+                                      real(*a, **kw))[1]
+    try:
+        got = run(True)
+    finally:
+        k.tall_linear = real
+    assert launched and all(launched)                      # every launch carried the activation
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
+    # a deferred layer that meets anything but a sigmoid is the plain layer, launched once
+    lin = net[0]
+    d = lazy.TallActivation.__torch_function__(torch.nn.functional.linear, (),
+                                               (x0.as_subclass(lazy.TallActivation), lin.weight, lin.bias))
+    assert isinstance(d, lazy.DeferredLinear) and d.shape == (B, 100) and d.dim() == 2
+    r1, r2 = torch.tanh(d), d + 1.0
+    ref = torch.nn.functional.linear(x0, lin.weight, lin.bias)
+    torch.testing.assert_close(r1.as_subclass(torch.Tensor), torch.tanh(ref), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(r2.as_subclass(torch.Tensor), ref + 1.0, rtol=1e-4, atol=1e-5)
+    assert d._plain is not None
+    lazy.FUSE_ACTIVATION["on"] = False
+    try:
+        plain = run(True)
+    finally:
+        lazy.FUSE_ACTIVATION["on"] = True
+    for a, b in zip(plain, want):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
 
 
 def test_word_histogram_is_recognised_in_guide_text(gpu):
