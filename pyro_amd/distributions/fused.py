@@ -479,6 +479,8 @@ class _ExpLower(torch.autograd.Function):
 
 
 def exp_lower(u, lower=0.0):
+    if _recording(u):
+        return torch.exp(u) + float(lower) if lower else torch.exp(u)
     return _ExpLower.invoke(u, float(lower))
 
 
@@ -500,6 +502,9 @@ def exp_lower_bound_of(transform):
 
 def exp_site(u, event_rank, lower=0.0):
     """(value = lower + exp(u), log_density = -(u summed over its ``event_rank`` rightmost dims))."""
+    if _recording(u):
+        value = torch.exp(u) + float(lower) if lower else torch.exp(u)
+        return value, -(u.sum(tuple(range(u.dim() - event_rank, u.dim()))) if event_rank else u)
     cols = 1
     for d in u.shape[u.dim() - event_rank:] if event_rank else ():
         cols *= int(d)
@@ -997,9 +1002,25 @@ def log_prob(dist_id, value, p0, p1=None):
     return _LogProb.invoke(dist_id, value, p0, p1)
 
 
+_RECORD_MAX = 65536        # up to here a site scored under a recorder scope is recorded, not launched
+
+
+def _recording(*tensors):
+    """Is a recorder scope (ops/fuser.py) active and are these small device tensors?  Then the site's few
+    operators are written with torch operators -- the recorder turns them into nodes of its generated kernels,
+    next to whatever else runs on that level -- instead of taking a launch of their own each way."""
+    if _fuser.active() is None or not _fuser.ENABLED["on"]:
+        return False
+    return all(t is None or (isinstance(t, torch.Tensor) and t.is_cuda and t.numel() <= _RECORD_MAX
+                             and t.dtype in (torch.float32, torch.float64, torch.bool)) for t in tensors)
+
+
 def log_prob_sum(dist_id, value, p0, p1=None, mask=None, scale=1.0):
     if mask is not None and mask.dtype != torch.bool:
         mask = mask.bool()
+    if _recording(value, p0, p1, mask) and torch.is_floating_point(value):
+        from .util import scale_and_mask
+        return scale_and_mask(log_prob(dist_id, value, p0, p1), float(scale), mask).sum()
     return _LogProbSum.invoke(dist_id, value, p0, p1, mask, float(scale))
 
 

@@ -894,8 +894,11 @@ class Fuser(TorchDispatchMode):
                 tuple(sorted(d % x.dim() for d in dims)) if x.dim() else ()
         else:
             raise Unfusable
-        if dtype not in (None, x.dtype) or x.dim() == 0 or x.numel() == 0:
+        if dtype not in (None, x.dtype) or x.numel() == 0:
             raise Unfusable
+        if x.dim() == 0:                    # (the sum of a scalar: a copy)
+            return self._new_node("clone", "{0}", [self._operand(x, x.dtype)],
+                                  torch.empty((), dtype=x.dtype, device="meta"))
         rsize = 1
         for d in dims:
             rsize *= x.shape[d]
@@ -1069,6 +1072,23 @@ class Fuser(TorchDispatchMode):
 
     def _op__index_put_impl_(self, func, base, overload, inplace, args, kwargs):
         return self._scatter_add(func, True, args, kwargs)
+
+    def _op_select_backward(self, func, base, overload, inplace, args, kwargs):
+        """zeros(sizes) with ``grad`` in the slice ``index`` of dim ``dim`` (autograd's dual of x.select(dim,
+        index) / x[..., index]): one node over the full shape instead of a fill and a strided copy."""
+        if kwargs or len(args) != 4:
+            raise Unfusable
+        grad, sizes, dim, index = args
+        if not isinstance(grad, torch.Tensor) or not self._tensor_ok(grad) or grad.dtype == torch.bool or \
+                not all(isinstance(n, int) for n in sizes) or len(sizes) > MAX_DIMS or len(sizes) < 1:
+            raise Unfusable
+        dim = dim % len(sizes)
+        index = index % sizes[dim] if sizes[dim] else 0
+        if tuple(grad.shape) != tuple(sizes[:dim]) + tuple(sizes[dim + 1:]) or _numel(sizes) == 0:
+            raise Unfusable
+        meta = torch.empty(tuple(sizes), dtype=grad.dtype, device="meta")
+        return self._new_node("select_backward", "{0}", [self._operand(grad, grad.dtype)], meta,
+                              inline={"kind": "select_bwd", "dim": dim, "index": int(index)})
 
     def _softmax_like(self, func, args, kwargs, kind, n_mem):
         if kwargs:
@@ -1507,7 +1527,25 @@ def _inline_dot(n, q, it_shape, used, pointer):
             "    v%d = s_;" % q, "  }"]
 
 
-_INLINE = {"dot": _inline_dot, "sum": _inline_reduce, "gather": _inline_gather, "scatter_add": _inline_scatter_add,
+def _inline_select_bwd(n, q, it_shape, used, pointer):
+    g = _mem(n.ins[0])
+    dim, index = n.inline["dim"], n.inline["index"]
+    pad = len(it_shape) - len(n.shape)
+    T = _CTYPE[n.dtype]
+    terms = []
+    for d in range(len(n.shape)):           # node dim d -> grad dim d (before ``dim``) or d - 1 (after it)
+        if d == dim:
+            continue
+        gd = d if d < dim else d - 1
+        if g.shape[gd] > 1 and g.stride(gd) != 0:
+            used.add(pad + d)
+            terms.append("i%d * %dL" % (pad + d, g.stride(gd)))
+    used.add(pad + dim)
+    return ["  const %s v%d = i%d == %dL ? ((const %s*)p%d)[%s] : (%s)0;"
+            % (T, q, pad + dim, index, T, pointer(g), " + ".join(terms) or "0", T)]
+
+
+_INLINE = {"select_bwd": _inline_select_bwd, "dot": _inline_dot, "sum": _inline_reduce, "gather": _inline_gather, "scatter_add": _inline_scatter_add,
            "softmax": _inline_softmax, "log_softmax": _inline_softmax, "softmax_bwd": _inline_softmax,
            "log_softmax_bwd": _inline_softmax}
 

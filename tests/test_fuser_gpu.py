@@ -350,7 +350,9 @@ def test_joins_integer_comparisons_and_layouts(gpu):
         st = torch.stack(parts).permute(1, 0, 2).contiguous() + torch.cat(parts, -1).sum()
         d = torch.dot(w, w * 2.0) + (x.t() / (x.t().abs() + 1.0)).sum()
         tr = x.t() * 3.0 - x.t().exp()                      # (a transposed result, as the operators give it)
-        return st, d, tr, (lengths >= 4) | (lengths == 1)
+        sel = x.clone().requires_grad_(True)                # the duals of x[:, k] / x[k]: one node over the full shape
+        ((sel[:, 2] * 2.0).sum() + sel[1].exp().sum() + sel.sum().sum()).backward()
+        return st, d, tr, (lengths >= 4) | (lengths == 1), sel.grad
 
     ref = run()
     fuser.UNFUSED.clear()
@@ -359,10 +361,11 @@ def test_joins_integer_comparisons_and_layouts(gpu):
         got = run()
     torch.cuda.synchronize()
     assert not fuser.UNFUSED, fuser.UNFUSED
-    assert fuser.STATS["kernels"] - before <= 10
+    assert fuser.STATS["kernels"] - before <= 16
     assert got[2].stride() == ref[2].stride() and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
     torch.testing.assert_close(got[0], ref[0], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(got[1], ref[1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got[4], ref[4], rtol=1e-6, atol=1e-6)
 
 
 def test_markov_loop_is_batched_across_its_time_steps(gpu):

@@ -13,11 +13,12 @@ from pyro_amd.ops import fuser  # noqa: E402
 
 rtc = ctypes.CDLL("/opt/rocm/lib/libhiprtc.so")
 SOURCES = []
+_COMPILED = set()
 
 
 def compile_only(src, grid, block, tensors):
     SOURCES.append(src)
-    if src in fuser._CACHE:
+    if src in _COMPILED:
         return
     prog = ctypes.c_void_p()
     assert rtc.hiprtcCreateProgram(ctypes.byref(prog), src.encode(), b"k.hip", 0, None, None) == 0
@@ -30,13 +31,26 @@ def compile_only(src, grid, block, tensors):
         rtc.hiprtcGetProgramLog(prog, log)
         print(src)
         raise SystemExit(log.value.decode()[:3000])
-    fuser._CACHE[src] = True
+    _COMPILED.add(src)          # (its own record: fuser._CACHE holds kernel handles)
     fuser.STATS["compiled"] += 1
     assert len(tensors) <= fuser.MAX_POINTERS
 
 
-fuser._dev = lambda t: True
-fuser._launch = compile_only
+import contextlib
+
+
+@contextlib.contextmanager
+def dry():
+    """Host tensors stand in for device tensors, every generated source is compiled and nothing is launched."""
+    saved = (fuser._dev, fuser._launch, fuser.Fuser._factory, fuser.Fuser._const)
+    fuser._dev = lambda t: True
+    fuser._launch = compile_only
+    fuser.Fuser._factory = _factory_cuda
+    fuser.Fuser._const = _const
+    try:
+        yield
+    finally:
+        fuser._dev, fuser._launch, fuser.Fuser._factory, fuser.Fuser._const = saved
 
 
 def _factory_cuda(self, func, args, kwargs, value):       # (host tensors stand in: accept device=cpu)
@@ -48,10 +62,6 @@ def _const(self, literal, meta, out, device):
     if out is None:
         out = torch.empty(tuple(meta.shape), dtype=meta.dtype)
     return self._new_node("const", literal, [], meta, out=out, fresh=fresh)
-
-
-fuser.Fuser._factory = _factory_cuda
-fuser.Fuser._const = _const
 
 
 def program(dtype):
@@ -74,6 +84,8 @@ def program(dtype):
     idx = torch.arange(4).reshape(4, 1, 1)
     sm = torch.softmax(table[idx] * 2.0, -1) + torch.log_softmax(table, 0)
     (sm * sm).sum().backward()
+    sel = torch.randn(3, 7, 5, dtype=dtype, requires_grad=True)
+    ((sel[:, 2] * 2.0).sum() + sel[1].sum() + sel[..., 4].sum()).sum().backward()
     lengths = torch.randint(1, 9, (7,))
     parts = [torch.where((t < lengths).unsqueeze(-1), x.detach() * float(t), x.new_zeros(())) for t in range(5)]
     st = torch.stack(parts).permute(1, 0, 2).contiguous() + torch.cat(parts, -1).sum()
@@ -87,13 +99,17 @@ def program(dtype):
     return loss, b.to(dtype).sum(), st, d, fam
 
 
-for dt in (torch.float32, torch.float64):
-    before = dict(fuser.STATS)
-    with fuser.Fuser() as f:
-        res = program(dt)
-    print(dt, {k: fuser.STATS[k] - before[k] for k in fuser.STATS})
-print("kernels generated:", len(SOURCES), "distinct:", len(set(SOURCES)))
-if "-v" in sys.argv:
-    for s in sorted(set(SOURCES), key=len)[-3:]:
-        print(s[s.index("extern"):])
-print("not taken:", fuser.UNFUSED)
+def main():
+    with dry():
+        for dt in (torch.float32, torch.float64):
+            before = dict(fuser.STATS)
+            with fuser.Fuser():
+                res = program(dt)
+            del res
+            print(dt, {k: fuser.STATS[k] - before[k] for k in fuser.STATS})
+    print("kernels generated:", len(SOURCES), "distinct:", len(set(SOURCES)))
+    print("not taken:", fuser.UNFUSED)
+
+
+if __name__ == "__main__":
+    main()
