@@ -226,10 +226,12 @@ def group_rows(g, G):
     """(offsets int64 [G+1], rows int64 [N]): rows[offsets[k]:offsets[k+1]] = the n with g[n] == k in
     ascending n.  Restates what the reference's advanced index ``w[..., g, :]`` (SURVEY 8d config 5;
     torch: aten index, scored by pyro/poutine/trace_struct.py:264-278) implies for a kernel that
-    visits rows group by group: integer work, the kernel's output is compared bit for bit."""
+    visits rows group by group: integer work, the kernel's output is compared bit for bit.  Ids in [-G, 0)
+    count from the end, as the reference's index does; anything else is its IndexError."""
     g = np.asarray(g, dtype=np.int64)
+    g = np.where(g < 0, g + G, g)
     if g.size and (g.min() < 0 or g.max() >= G):
-        raise IndexError("group id outside [0, %d)" % G)
+        raise IndexError("group id outside [-%d, %d)" % (G, G))
     rows = np.argsort(g, kind="stable").astype(np.int64)
     offsets = np.concatenate([[0], np.cumsum(np.bincount(g, minlength=G))]).astype(np.int64)
     return offsets, rows

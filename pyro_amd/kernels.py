@@ -1225,11 +1225,13 @@ def glm_pack_planes_grouped(X, y, segs, out=None, fmt=None):
 def group_rows_build(g, G):
     """g: int64 [N] device, unsorted group ids -> (offsets int64 [G+1], rows int64 [N]) on the device:
     rows[offsets[k]:offsets[k+1]] = the n with g[n] == k, ascending (a stable counting sort;
-    bit-exact against oracle/glm.py::group_rows).  Raises IndexError for ids outside [0, G) as
-    torch's advanced indexing does, Unsupported beyond the kernel's limits."""
+    bit-exact against oracle/glm.py::group_rows).  Ids in [-G, 0) count from the end and anything outside
+    [-G, G) raises IndexError, as torch's advanced indexing does; Unsupported beyond the kernel's limits."""
     _require_gpu(g)
     assert g.dtype == torch.int64 and g.dim() == 1 and g.is_contiguous()
     N, G = g.shape[0], int(G)
+    if N:
+        g = torch.where(g < 0, g + G, g)       # (built once per id tensor: the partition is cached)
     lib = _lib.load()
     nbytes = lib.pa_group_rows_workspace(N, G)
     if nbytes == 0:
@@ -1242,7 +1244,7 @@ def group_rows_build(g, G):
                                   _stream()))
     nbad = int(bad.item())
     if nbad:
-        raise IndexError("pyro_amd: %d group ids are outside [0, %d)" % (nbad, G))
+        raise IndexError("pyro_amd: %d group ids are outside [-%d, %d)" % (nbad, G, G))
     return offsets, rows
 
 

@@ -46,7 +46,10 @@ def test_group_rows_rejects_ids_out_of_range_like_torch(gpu):
     with pytest.raises(IndexError):
         k.group_rows_build(g, 5)
     with pytest.raises(IndexError):
-        k.group_rows_build(torch.tensor([0, -1, 2], device=gpu), 5)
+        k.group_rows_build(torch.tensor([0, -6, 2], device=gpu), 5)
+    # ids in [-G, 0) count from the end, as w[..., g, :] reads them
+    off, rows = k.group_rows_build(torch.tensor([0, -1, 2, -5, 4], device=gpu), 5)
+    assert off.tolist() == [0, 2, 2, 3, 3, 5] and rows.tolist() == [0, 3, 2, 1, 4]
     with pytest.raises(k.Unsupported):
         k.group_rows_build(torch.zeros(10, dtype=torch.int64, device=gpu), 16385)
 

@@ -26,6 +26,10 @@ def test_oracle_group_rows_is_the_stable_sort():
             assert (g[seg] == k).all() and (np.diff(seg) > 0).all()       # ascending inside a group
     with pytest.raises(IndexError):
         o_glm.group_rows(np.array([0, 5]), 5)
+    with pytest.raises(IndexError):
+        o_glm.group_rows(np.array([0, -6]), 5)
+    off, rows = o_glm.group_rows(np.array([0, -1, 2, -5, 4]), 5)            # ids in [-G, 0) count from the end
+    assert off.tolist() == [0, 2, 2, 3, 3, 5] and rows.tolist() == [0, 3, 2, 1, 4]
 
 
 def test_group_gather_recognition_and_fallbacks():
