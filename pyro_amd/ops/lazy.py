@@ -554,10 +554,12 @@ class DeferredLinear:
         return op
 
     for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__",
-               "__rtruediv__", "__neg__", "__getitem__", "__matmul__", "__rmatmul__", "__pow__", "__lt__",
-               "__gt__", "__le__", "__ge__", "__len__", "__iter__"):
+               "__rtruediv__", "__floordiv__", "__rfloordiv__", "__mod__", "__rmod__", "__neg__", "__abs__",
+               "__getitem__", "__matmul__", "__rmatmul__", "__pow__", "__rpow__", "__lt__", "__gt__", "__le__",
+               "__ge__", "__eq__", "__ne__", "__len__", "__iter__", "__bool__", "__float__", "__int__"):
         locals()[_n] = _binary(_n)
     del _n, _binary
+    __hash__ = object.__hash__          # (``==`` is the tensor's: identity keeps the object usable as a key)
 
 
 @_dispatcher_op("tall_linear_sigmoid")

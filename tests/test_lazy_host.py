@@ -84,3 +84,21 @@ def test_bias_on_the_left_keeps_the_plated_glm_deferred():
     s = (w @ X.t()).squeeze(-2)
     for sb in (s + b, b + s):
         assert isinstance(sb, lazy.DeferredMatmul) and sb.as_linear_logits() is not None
+
+
+def test_deferred_linear_behaves_like_its_result_everywhere_but_under_a_sigmoid():
+    """ops/lazy.py::DeferredLinear (a tall Linear layer not launched yet): every use that is not a sigmoid
+    goes on with the plain layer's result, launched once -- operators, comparisons, torch functions, methods,
+    attributes (host stand-in for the launch; the fused route is a GPU test)."""
+    from pyro_amd.ops import lazy
+    d = lazy.DeferredLinear("tall", (), (3, 2), torch.zeros(1))
+    ref = torch.arange(6.0).reshape(3, 2)
+    d._plain = ref.clone()                       # (what materialize() would have launched)
+    assert d.shape == (3, 2) and d.dim() == 2 and d.size(1) == 2 and len(d) == 3 and d.dtype == torch.float32
+    assert torch.equal(d == ref, torch.ones(3, 2, dtype=torch.bool)) and hash(d) == hash(d)
+    for got, want in ((d + 1, ref + 1), (2 - d, 2 - ref), (d * d, ref * ref), (-d, -ref), (abs(-d), ref),
+                      (d / 2, ref / 2), (2 ** d, 2 ** ref), (d[1:], ref[1:]), (d @ ref.t(), ref @ ref.t()),
+                      (torch.tanh(d), torch.tanh(ref)), (torch.cat([d, d]), torch.cat([ref, ref])),
+                      (d.t(), ref.t()), (d.clamp(min=2.0), ref.clamp(min=2.0)), (d > 2, ref > 2)):
+        assert torch.equal(got, want)
+    assert float(d[0, 1]) == 1.0 and [row.tolist() for row in d] == ref.tolist()
