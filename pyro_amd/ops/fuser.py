@@ -232,7 +232,7 @@ def _view_key(t):
 
 class _Node:
     __slots__ = ("op", "ins", "out", "shape", "dtype", "ctype", "expr", "kind", "kernel", "wspan", "rspans",
-                 "rviews", "red", "order", "fresh", "live", "inline", "src")
+                 "rviews", "red", "order", "fresh", "live", "inline", "src", "replay")
 
 
 DEAD_STORES = {"eliminate": os.environ.get("PYRO_AMD_FUSER_DEAD_STORES", "1") != "0"}
@@ -252,6 +252,18 @@ def _baseline_counts():
         n.out = torch.empty(4)
         _BASELINE.append(_counts(n))
     return _BASELINE[0]
+
+
+class _Ref:
+    """A weak reference standing in for a recorded node's output tensor (see Fuser._weak)."""
+    __slots__ = ("ref",)
+
+    def __init__(self, tensor):
+        import weakref
+        self.ref = weakref.ref(tensor)
+
+
+REPLAY = {"on": False}      # keep every recorded operator on its node (tools/fuser_dry.py::replaying)
 
 
 class _Kernel:
@@ -295,8 +307,11 @@ class Fuser(TorchDispatchMode):
         self.wkeys = {}             # storage address -> view keys in self.writer
         self.small = {}             # (level, shape) -> latest kernel of small nodes there
         self.created = 0
+        self.recorded = 0
         self._busy = False
         self._prev = None
+        self._op = None             # (func, args, kwargs) being recorded: kept on its node for the host-side
+        #                             check of the schedule (tools/fuser_dry.py::replaying)
         self.log = []               # (op name, fused?) of this scope, for tests / attribution
 
     # ---- scope ------------------------------------------------------------------------------------
@@ -336,11 +351,13 @@ class Fuser(TorchDispatchMode):
         if ENABLED["on"]:
             try:
                 self._busy = True
+                self._op = (func, args, kwargs) if REPLAY["on"] else None
                 out = self._record(func, args, kwargs)
             except Unfusable:
                 out = NotImplemented
             finally:
                 self._busy = False
+                self._op = None
             if out is not NotImplemented:
                 STATS["recorded"] += 1
                 return out
@@ -415,6 +432,19 @@ class Fuser(TorchDispatchMode):
                 raise Unfusable
         return handler(func, base, overload, inplace, args, kwargs)
 
+    def _weak(self, op):
+        """(func, args, kwargs) with every tensor that IS a recorded node's output replaced by the node (the
+        check of the schedule must not keep outputs alive that the program itself has dropped)."""
+        def conv(x):
+            if isinstance(x, torch.Tensor):
+                w = self.writer.get(_view_key(x)) if _dev(x) else None
+                return _Ref(x) if w is not None and w.out is x else x
+            if isinstance(x, (list, tuple)):
+                return type(x)(conv(v) for v in x)
+            return x
+        func, args, kwargs = op
+        return func, conv(args), {k: conv(v) for k, v in kwargs.items()}
+
     # -- node construction
     def _new_node(self, op, expr, ins, meta_out, out=None, compute=None, red=None, fresh=None, inline=None):
         """``expr``: C expression over {0}.. in compute type T; ``out``: existing tensor (in-place) or None."""
@@ -428,6 +458,7 @@ class Fuser(TorchDispatchMode):
         n.ctype = _CTYPE_ALL[compute or meta_out.dtype]
         n.red = red
         n.src = None
+        n.replay = None if self._op is None else self._weak(self._op)
         n.inline = inline
         n.live = True
         n.kind = "red" if red is not None else "ew"
@@ -541,7 +572,8 @@ class Fuser(TorchDispatchMode):
         k.nodes.append(n)
         k.npointers |= self._pointer_keys(n)
         n.kernel = k
-        n.order = len(self.pending)
+        n.order = self.recorded            # (program order across partial flushes: merged kernels sort by it)
+        self.recorded += 1
         self.pending.append(n)
         self._index(n)
         # a write that overlaps OTHER views of the same memory makes their recorded writers stale
@@ -943,7 +975,11 @@ class Fuser(TorchDispatchMode):
                 dst = full.narrow(dim, at, t.shape[dim])
                 at += t.shape[dim]
             m = torch.empty_strided(tuple(dst.shape), tuple(dst.stride()), dtype=dst.dtype, device="meta")
+            keep = self._op
+            if keep is not None:
+                self._op = (aten.copy_.default, (dst, t), {})
             self._new_node("copy", "{0}", [x], m, out=dst)
+            self._op = keep
         return full
 
     def _op_stack(self, func, base, overload, inplace, args, kwargs):
@@ -1058,7 +1094,7 @@ class Fuser(TorchDispatchMode):
         meta = torch.empty(tuple(x.shape), dtype=x.dtype, device="meta")
         w = self.writer.get(_view_key(x))
         ins = [self._operand(values, x.dtype), ("t", idx)]
-        if w is not None and w.op == "const" and w.shape == tuple(x.shape):
+        if w is not None and w.op == "const" and w.shape == tuple(x.shape) and not REPLAY["on"]:
             init = w.expr                       # zeros(...).index_put_(...): the fill never reaches memory
         else:
             init = None
@@ -1139,8 +1175,14 @@ class Fuser(TorchDispatchMode):
         meta = self._meta(func, args, kwargs)
         sum_dims = aten.sum.dim_IntList
         xv = x.view(a, rsize // c, c, b)
+        keep = self._op
+        if keep is not None:
+            self._op = (sum_dims, (xv, [2]), {})
         part = self._op_sum(sum_dims, "sum", "dim_IntList", False, (xv, [2]), {})
+        if keep is not None:
+            self._op = (sum_dims, (part, [1]), {})
         out = self._op_sum(sum_dims, "sum", "dim_IntList", False, (part, [1]), {})
+        self._op = keep
         STATS["recorded"] += 1
         return out.view(tuple(meta.shape))
 
@@ -1222,7 +1264,7 @@ class Fuser(TorchDispatchMode):
             # AccumulateGrad nodes, created on this stream, alive into a later capture on another stream)
             for k in kernels:
                 for n in k.nodes:
-                    n.kernel = n.ins = n.out = n.src = None
+                    n.kernel = n.ins = n.out = n.src = n.replay = None
                 k.nodes = None
                 k.absorbs = k.absorbed = None
 

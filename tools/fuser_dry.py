@@ -53,6 +53,145 @@ def dry():
         fuser._dev, fuser._launch, fuser.Fuser._factory, fuser.Fuser._const = saved
 
 
+# ---- the schedule, checked on the host -----------------------------------------------------------------
+# ``replaying()``: instead of generating code, every recorded operator is kept on its node and RE-RUN (the ATen
+# operator itself, on the host tensors) when and where the schedule puts it -- level by level, kernel by kernel,
+# node by node; a store the recorder declares dead is poisoned with NaN after its kernel.  A program gives the
+# numbers of its eager run, bit for bit, exactly if the schedule respects every dependence of the program and
+# drops no store that something still reads: launch levels, kernel merges, partial flushes, sums that take their
+# operand's kernel along, dead-store elimination by reference counts.
+def _resolve(x):
+    if isinstance(x, fuser._Ref):
+        t = x.ref()
+        assert t is not None, "a recorded operand died before the operator that reads it ran"
+        return t.detach()
+    if isinstance(x, torch.Tensor):
+        return x.detach()               # (the same memory, no autograd history: operators re-run below autograd)
+    if isinstance(x, (list, tuple)):
+        return type(x)(_resolve(v) for v in x)
+    return x
+
+
+def _rerun(n):
+    assert n.replay is not None, "node %s carries no operator" % n.op
+    func, args, kwargs = n.replay
+    with torch.no_grad():
+        res = func(*_resolve(args), **{k: _resolve(v) for k, v in kwargs.items()})
+        out = n.out.detach()
+        if not (res.data_ptr() == out.data_ptr() and res.shape == out.shape and res.stride() == out.stride()):
+            out.copy_(res)
+
+
+def _replay_level(ks):
+    for k in ks:
+        if k.absorbed is not None:
+            continue
+        nodes = list(k.absorbs.nodes) + list(k.nodes) if k.kind == "red" and k.absorbs is not None else list(k.nodes)
+        for n in nodes:
+            _rerun(n)
+        for n in nodes:
+            if not n.live and n.out.is_floating_point():
+                with torch.no_grad():
+                    n.out.detach().fill_(float("nan"))
+
+
+@contextlib.contextmanager
+def replaying():
+    saved = (fuser._launch_level, fuser.REPLAY["on"])
+    fuser._launch_level = _replay_level
+    fuser.REPLAY["on"] = True
+    try:
+        with dry():
+            yield
+    finally:
+        fuser._launch_level, fuser.REPLAY["on"] = saved
+
+
+def random_program(seed, n_ops=60, grad=False):
+    """A list of steps over a pool of tensors: element-wise chains with broadcasting, in-place writes through
+    views, reductions short and long, where / comparisons, stack / cat, gathers and their accumulate duals,
+    softmax, operators the recorder does not know (partial flushes), dropped references (dead stores)."""
+    import random
+    rnd = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(4, 3), (3,), (4, 1), (2, 4, 3), (), (1, 3), (70, 3)]
+    pool0 = [torch.randn(sh, generator=g) for sh in shapes for _ in range(2)]
+    steps = []
+    unary = [torch.exp, torch.neg, torch.abs, torch.sigmoid, torch.tanh, lambda t: t * 0.5, lambda t: t + 1.5,
+             lambda t: t.clamp(min=-0.5, max=0.75), lambda t: t ** 2, lambda t: torch.log1p(t.abs()),
+             lambda t: t.clone(), lambda t: 1.0 - t, lambda t: torch.where(t > 0.1, t, t * 0.0 - 1.0)]
+    binary = [torch.add, torch.mul, torch.sub, lambda a, b: a / (b.abs() + 1.0), torch.maximum,
+              lambda a, b: torch.where(a > b, a, b * 2.0)]
+    for _ in range(n_ops):
+        steps.append((rnd.choice(["unary", "unary", "binary", "binary", "inplace", "view", "sum", "sum", "join",
+                                  "index", "softmax", "unknown", "drop", "scatter"]),
+                      rnd.random(), rnd.random(), rnd.random(), rnd.randrange(len(unary)), rnd.randrange(len(binary))))
+
+    def run():
+        pool = [t.clone().requires_grad_(grad) for t in pool0]
+        leaves = list(pool)
+
+        def pick(r, pred=lambda t: True):
+            c = [t for t in pool if pred(t)]
+            return c[int(r * len(c)) % len(c)] if c else None
+        for kind, r0, r1, r2, iu, ib in steps:
+            out = None
+            if kind == "unary":
+                out = unary[iu](pick(r0))
+            elif kind == "binary":
+                a = pick(r0)
+                b = pick(r1, lambda t: fuser._bcast(tuple(t.shape), tuple(a.shape)) is not None)
+                out = binary[ib](a, b)
+            elif kind == "inplace":
+                a = pick(r0, lambda t: t.dim() >= 1 and t.shape[0] > 1 and not t._is_view() or t.dim() == 0)
+                if a is not None and a.dim() >= 1 and not grad:
+                    tgt = a[1:] if r1 < 0.5 else a
+                    src = pick(r2, lambda t: fuser._bcast(tuple(t.shape), tuple(tgt.shape)) == tuple(tgt.shape))
+                    if r1 < 0.25:
+                        tgt.mul_(0.5)
+                    elif r1 < 0.5:
+                        tgt.zero_()
+                    elif src is not None and src.data_ptr() != tgt.data_ptr():
+                        tgt.add_(src, alpha=0.25)
+                    else:
+                        tgt.clamp_(min=-1.0)
+            elif kind == "view":
+                a = pick(r0, lambda t: t.dim() >= 2)
+                out = a.transpose(0, 1) if r1 < 0.4 else (a[0] if r1 < 0.7 else a.unsqueeze(0))
+            elif kind == "sum":
+                a = pick(r0, lambda t: t.dim() >= 1)
+                out = a.sum() if r1 < 0.3 else a.sum(int(r2 * a.dim()) % a.dim(), keepdim=r1 < 0.6)
+            elif kind == "join":
+                a = pick(r0, lambda t: t.dim() >= 1)
+                b = pick(r1, lambda t: t.shape == a.shape)
+                out = torch.stack([a, b * 2.0]) if r2 < 0.5 else torch.cat([a, b, a], -1)
+            elif kind == "index":
+                a = pick(r0, lambda t: t.dim() >= 2)
+                idx = torch.tensor([[a.shape[0] - 1], [0], [-1]])
+                out = a[idx] * 1.5
+            elif kind == "scatter":
+                a = pick(r0, lambda t: t.dim() == 2)
+                v = pick(r1, lambda t: t.shape == a.shape[1:])
+                if v is not None:
+                    out = torch.index_put(a, (torch.tensor([0, a.shape[0] - 1, 0]),), v, accumulate=True)
+            elif kind == "softmax":
+                a = pick(r0, lambda t: t.dim() >= 1 and t.shape[-1] <= 32)
+                out = torch.softmax(a, -1) if r1 < 0.5 else torch.log_softmax(a, 0)
+            elif kind == "unknown":
+                a = pick(r0, lambda t: t.dim() >= 1)
+                out = torch.cumsum(a, 0)                       # (not recorded: whatever it reads is flushed first)
+            elif kind == "drop" and len(pool) > 8:
+                del pool[int(r0 * len(pool)) % len(pool)]
+            if out is not None and out.numel() > 0:
+                pool.append(out)
+        if grad:        # the autograd duals run on the autograd thread, inside the same scope: recorded too
+            terms = [(t * (0.5 + 0.25 * j)).sum() for j, t in enumerate(pool[-12:]) if t.requires_grad]
+            torch.stack(terms).sum().backward()
+            return [t.detach() for t in pool] + [t.grad for t in leaves if t.grad is not None]
+        return pool
+    return run
+
+
 def _factory_cuda(self, func, args, kwargs, value):       # (host tensors stand in: accept device=cpu)
     return self._fill(value, self._meta(func, args, kwargs), device=torch.device("cpu"))
 
