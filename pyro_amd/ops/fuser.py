@@ -83,6 +83,10 @@ def scope():
 # expression templates: {0}, {1}, {2} are operands already cast to the compute type T
 # ---------------------------------------------------------------------------------------------------
 _PRELUDE = r'''
+#ifndef PA_GROUP_SUM      // the sum over the W lanes that share an output element, and who stores it
+#define PA_GROUP_SUM(s, W) for (int m_ = (W) / 2; m_ > 0; m_ >>= 1) s += __shfl_xor(s, m_, 64);
+#define PA_GROUP_LEADER(lane, W) ((lane) == 0)
+#endif
 #define DEV static __device__ __forceinline__
 DEV float exp_(float x) { return expf(x); }        DEV double exp_(double x) { return exp(x); }
 DEV float log_(float x) { return logf(x); }        DEV double log_(double x) { return log(x); }
@@ -1460,6 +1464,15 @@ def _dim_terms(shape, strides, first_kernel_dim, used, skip=()):
     return " + ".join(terms) or "0"
 
 
+def _own_index(n, d, pad, used):
+    """The index of node ``n``'s dim d inside a kernel whose domain may be wider: a dim the node has with size 1
+    is index 0 whatever the thread's own index on the domain's dim is (the node is evaluated by broadcast)."""
+    if n.shape[d] == 1:
+        return "0"
+    used.add(pad + d)
+    return "i%d" % (pad + d)
+
+
 def _inline_gather(n, q, it_shape, used, pointer):
     """v<q> = table[index[i_lead...], i_rest...]   (aten::index with one leading int64 index)."""
     table, idx = _mem(n.ins[0]), n.ins[1][1]
@@ -1488,7 +1501,7 @@ def _inline_scatter_add(n, q, it_shape, used, pointer):
     vshape = (1,) * (ni + len(rest) - values.dim()) + tuple(values.shape)
     vstride = (0,) * (ni + len(rest) - values.dim()) + tuple(values.stride())
     voff_rest = _dim_terms(vshape[ni:], vstride[ni:], pad + 1, used)
-    used.add(pad)
+    row = _own_index(n, 0, pad, used)
     lines = ["  %s v%d;" % (T, q), "  {"]
     if info["init"] is not None:
         lines.append("    %s s_ = %s;" % (T, info["init"]))
@@ -1512,7 +1525,7 @@ def _inline_scatter_add(n, q, it_shape, used, pointer):
             vo.append("k%d * %dL" % (d, vstride[d]))
     lines += ["      long long x_ = ((const long long*)p%d)[%s];" % (pointer(idx), " + ".join(io) or "0"),
               "      if (x_ < 0) x_ += %dL;" % n.shape[0],
-              "      if (x_ == i%d) s_ += ((const %s*)p%d)[%s + %s];" % (pad, T, pointer(values),
+              "      if (x_ == %s) s_ += ((const %s*)p%d)[%s + %s];" % (row, T, pointer(values),
                                                                              " + ".join(vo) or "0", voff_rest),
               "    }", "    v%d = s_;" % q, "  }"]
     return lines
@@ -1527,7 +1540,7 @@ def _inline_softmax(n, q, it_shape, used, pointer):
     a0 = _mem(n.ins[0])
     row0 = _dim_terms(tuple(a0.shape), tuple(a0.stride()), pad, used, skip=(dim,))
     s0 = a0.stride(dim)
-    used.add(pad + dim)
+    own = _own_index(n, dim, pad, used)
     p0 = "((const %s*)p%d)" % (T, pointer(a0))
     lines = ["  %s v%d;" % (T, q), "  {", "    const long b0_ = %s;" % row0]
     if kind in ("softmax", "log_softmax"):
@@ -1536,7 +1549,7 @@ def _inline_softmax(n, q, it_shape, used, pointer):
                   % (L, T, p0, s0),
                   "    %s s_ = 0;" % T,
                   "    for (long r = 0; r < %dL; ++r) s_ += exp_(%s[b0_ + r * %dL] - m_);" % (L, p0, s0),
-                  "    const %s x_ = %s[b0_ + i%d * %dL];" % (T, p0, pad + dim, s0)]
+                  "    const %s x_ = %s[b0_ + %s * %dL];" % (T, p0, own, s0)]
         if kind == "softmax":
             lines.append("    v%d = exp_(x_ - m_) / s_;" % q)
         else:
@@ -1550,12 +1563,12 @@ def _inline_softmax(n, q, it_shape, used, pointer):
         if kind == "softmax_bwd":       # (grad, output): (g_i - sum_r g_r y_r) * y_i
             lines += ["    for (long r = 0; r < %dL; ++r) s_ += %s[b0_ + r * %dL] * %s[b1_ + r * %dL];"
                       % (L, p0, s0, p1, s1),
-                      "    v%d = (%s[b0_ + i%d * %dL] - s_) * %s[b1_ + i%d * %dL];"
-                      % (q, p0, pad + dim, s0, p1, pad + dim, s1)]
+                      "    v%d = (%s[b0_ + %s * %dL] - s_) * %s[b1_ + %s * %dL];"
+                      % (q, p0, own, s0, p1, own, s1)]
         else:                           # (grad, output = log p): g_i - exp(y_i) * sum_r g_r
             lines += ["    for (long r = 0; r < %dL; ++r) s_ += %s[b0_ + r * %dL];" % (L, p0, s0),
-                      "    v%d = %s[b0_ + i%d * %dL] - exp_(%s[b1_ + i%d * %dL]) * s_;"
-                      % (q, p0, pad + dim, s0, p1, pad + dim, s1)]
+                      "    v%d = %s[b0_ + %s * %dL] - exp_(%s[b1_ + %s * %dL]) * s_;"
+                      % (q, p0, own, s0, p1, own, s1)]
     lines.append("  }")
     return lines
 
@@ -1582,9 +1595,9 @@ def _inline_select_bwd(n, q, it_shape, used, pointer):
         if g.shape[gd] > 1 and g.stride(gd) != 0:
             used.add(pad + d)
             terms.append("i%d * %dL" % (pad + d, g.stride(gd)))
-    used.add(pad + dim)
-    return ["  const %s v%d = i%d == %dL ? ((const %s*)p%d)[%s] : (%s)0;"
-            % (T, q, pad + dim, index, T, pointer(g), " + ".join(terms) or "0", T)]
+    own = _own_index(n, dim, pad, used)
+    return ["  const %s v%d = %s == %dL ? ((const %s*)p%d)[%s] : (%s)0;"
+            % (T, q, own, index, T, pointer(g), " + ".join(terms) or "0", T)]
 
 
 _INLINE = {"select_bwd": _inline_select_bwd, "dot": _inline_dot, "sum": _inline_reduce, "gather": _inline_gather, "scatter_add": _inline_scatter_add,
@@ -1811,7 +1824,7 @@ def _map_reduce_body(n, M):
         "\n".join("  " + ln for ln in lines) + "\n" + "\n".join("  " + ln for ln in stores if ln) + \
         "\n    s += (%s)%s;\n  }\n" % (acc, src)
     if by_wave:
-        text += "  for (int m = %d; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n  if (lane == 0) " % (W // 2)
+        text += "  PA_GROUP_SUM(s, %d)\n  if (PA_GROUP_LEADER(lane, %d)) " % (W, W)
     else:
         text += "  "
     text += "((%s*)p%d)[o] = (%s)s;\n}\n" % (T, po, T) if n.live else ";\n}\n"
@@ -1858,8 +1871,8 @@ def _reduce_body(n):
         "\n".join(o_lines) + "\n  const long base = %s;\n  %s s = 0;\n  for (long r = lane; r < %dL; r += %d) {\n" \
         % (o_off, acc, rsize, W) + "\n".join("  " + ln for ln in r_lines) + \
         "\n    s += (%s)((const %s*)p0)[base + %s];\n  }\n" % (acc, T, r_off) + \
-        "  for (int m = %d; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);\n" % (W // 2) + \
-        "  if (lane == 0) ((%s*)p1)[o] = (%s)s;\n}\n" % (T, T)
+        "  PA_GROUP_SUM(s, %d)\n" % W + \
+        "  if (PA_GROUP_LEADER(lane, %d)) ((%s*)p1)[o] = (%s)s;\n}\n" % (W, T, T)
     if TRACE["on"]:
         TRACE["kernels"].append((tuple(in_shape), [("sum%d" % rsize, n.shape, True)]))
     return n_out * W, [t, n.out], _narrow(text, n_out * W, [t, n.out])

@@ -77,3 +77,50 @@ def test_the_schedule_of_forward_and_autograd_duals(block):
         for a, b in zip(got, want):
             assert a.shape == b.shape and a.dtype == b.dtype, seed
             assert torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)), (seed, a, b)
+
+
+def _close(a, b, tol):
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(_close(x, y, tol) for x, y in zip(a, b))
+    if not isinstance(a, torch.Tensor):
+        return True
+    if a.dtype == torch.bool:
+        return torch.equal(a, b)
+    return a.shape == b.shape and torch.allclose(a, b, rtol=tol, atol=tol, equal_nan=True)
+
+
+@pytest.mark.skipif(os.system("g++ --version > /dev/null 2>&1") != 0, reason="needs g++")
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float64, 1e-11)])
+def test_generated_code_executed_on_the_host_gives_the_operators_numbers(dtype, tol):
+    """The generated HIP source ITSELF, compiled by g++ behind a page of shims and run on the host tensors
+    (tools/fuser_dry.py::hosting): the program of the compile test -- element-wise chains, broadcasting, views,
+    in-place writes, short and long sums, gathers / scatters, softmax, joins, transposed results, scalars in the
+    argument table, the element-wise families with csrc/dist_fam.h's expressions, and the autograd duals of all
+    of it -- against the eager run."""
+    from pyro_amd.ops import fuser
+    from tools import fuser_dry
+
+    torch.manual_seed(11)
+    want = fuser_dry.program(dtype)
+    torch.manual_seed(11)
+    before = dict(fuser.STATS)
+    with fuser_dry.hosting():
+        with fuser.Fuser():
+            got = fuser_dry.program(dtype)
+    assert fuser.STATS["kernels"] - before["kernels"] >= 4
+    assert _close(got, want, tol)
+
+
+@pytest.mark.skipif(os.system("g++ --version > /dev/null 2>&1") != 0, reason="needs g++")
+@pytest.mark.parametrize("grad", [False, True], ids=["forward", "with_duals"])
+def test_generated_code_of_random_programs_on_the_host(grad):
+    from pyro_amd.ops import fuser
+    from tools import fuser_dry
+
+    for seed in range(5000, 5006) if not grad else range(6000, 6004):
+        run = fuser_dry.random_program(seed, n_ops=60 if not grad else 45, grad=grad)
+        want = run()
+        with fuser_dry.hosting():
+            with fuser.Fuser():
+                got = run()
+        assert _close(got, want, 3e-5), seed

@@ -4,6 +4,7 @@ launched -- recorded outputs stay uninitialised, so nothing here checks numbers 
     python tools/fuser_dry.py
 """
 import ctypes
+import os
 import sys
 
 import torch
@@ -105,6 +106,83 @@ def replaying():
             yield
     finally:
         fuser._launch_level, fuser.REPLAY["on"] = saved
+
+
+# ---- the generated code, RUN on the host ---------------------------------------------------------------
+# ``hosting()``: the generated HIP source itself is compiled by g++ behind a page of shims (the kernel becomes a
+# function, blockIdx / threadIdx thread-local variables set by a serial launcher, the lane-group sum a small
+# buffer filled by the lanes in turn, the three amdgcn builtins of csrc/dist_fam.h their libm equivalents) and
+# executed on the host tensors: index arithmetic, broadcasting, strides, gathers / scatters, softmax, sums with
+# their operand's kernel inside, scalars in the argument table -- against the eager run, without a GPU.
+_HOST_SHIM = r"""
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __noinline__
+#define __launch_bounds__(x)
+struct PaDim3 { unsigned x, y, z; };
+static thread_local PaDim3 blockIdx, threadIdx;
+static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static thread_local double pa_group_buf_[64];
+#define PA_GROUP_SUM(s, W) { pa_group_buf_[lane] = (double)s; if (lane == (W) - 1) { double t_ = 0; \
+    for (int q_ = 0; q_ < (W); ++q_) t_ += pa_group_buf_[q_]; s = t_; } }
+#define PA_GROUP_LEADER(lane, W) ((lane) == (W) - 1)
+"""
+_HOST_LAUNCHER = r"""
+extern "C" void pa_host_launch(const void* const* table, int n, long grid) {
+  Ptrs a;
+  std::memset(&a, 0, sizeof a);
+  for (int j = 0; j < n; ++j) a.p[j] = const_cast<void*>(table[j]);
+  for (long b = 0; b < grid; ++b)
+    for (unsigned t = 0; t < 256; ++t) { blockIdx.x = (unsigned)b; threadIdx.x = t; k(a); }
+}
+"""
+_HOST_LIBS = {}
+
+
+def _host_launch(src, grid, block, tensors):
+    import hashlib
+    import subprocess
+    import tempfile
+    assert block == 256
+    SOURCES.append(src)
+    lib = _HOST_LIBS.get(src)
+    if lib is None:
+        d = tempfile.mkdtemp(prefix="pa_fuser_host_")
+        name = os.path.join(d, hashlib.sha1(src.encode()).hexdigest()[:16])
+        with open(name + ".cpp", "w") as fh:
+            fh.write(_HOST_SHIM + src + _HOST_LAUNCHER)
+        r = subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-w", "-ffp-contract=off",
+                            name + ".cpp", "-o", name + ".so"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host build of a generated kernel failed:\n" + r.stderr[:3000] + "\n" + src)
+        lib = _HOST_LIBS[src] = ctypes.CDLL(name + ".so")
+        lib.pa_host_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long]
+        fuser.STATS["compiled"] += 1
+    keep = [t for t in tensors if isinstance(t, torch.Tensor)]
+    table = (ctypes.c_void_p * len(tensors))(*[t[1] if isinstance(t, tuple) else t.data_ptr() for t in tensors])
+    lib.pa_host_launch(table, len(tensors), int(grid))
+    del keep
+    fuser.STATS["kernels"] += 1
+
+
+@contextlib.contextmanager
+def hosting():
+    saved = (fuser._dev, fuser._launch, fuser.Fuser._factory, fuser.Fuser._const)
+    fuser._dev = lambda t: True
+    fuser._launch = _host_launch
+    fuser.Fuser._factory = _factory_cuda
+    fuser.Fuser._const = _const
+    try:
+        yield
+    finally:
+        fuser._dev, fuser._launch, fuser.Fuser._factory, fuser.Fuser._const = saved
 
 
 def random_program(seed, n_ops=60, grad=False):
@@ -229,12 +307,23 @@ def program(dtype):
     parts = [torch.where((t < lengths).unsqueeze(-1), x.detach() * float(t), x.new_zeros(())) for t in range(5)]
     st = torch.stack(parts).permute(1, 0, 2).contiguous() + torch.cat(parts, -1).sum()
     d = torch.dot(w.detach(), w.detach() * 2.0) + (x.detach().t() / acc.t()).sum()
+    # the element-wise families: recorded with csrc/dist_fam.h's expressions under a scope, torch's own eagerly
+    from pyro_amd.distributions import fused
     f = fuser.active()
-    v = torch.rand(7, 5, dtype=dtype) + 0.5
-    fam = [f.family_log_prob(k, v, w.detach().abs() + 0.5, x.detach().abs() + 0.5, (7, 5)) for k in range(10)]
-    assert all(t is not None for t in fam)
-    fam += list(f.family_grads(6, fam[0], v, w.detach().abs() + 0.5, x.detach().abs() + 0.5, (7, 5), (True, True, True)))
-    fam += list(f.family_grads(1, fam[1].sum(), v, w.detach(), None, (7, 5), (False, True, False)))
+    v = torch.rand(7, 5, dtype=dtype) * 0.8 + 0.1
+    a0, b0 = w.detach().abs() + 0.5, x.detach().abs() + 0.5
+    if f is not None:
+        fam = [f.family_log_prob(k, v, a0, b0, (7, 5)) for k in range(10)]
+        assert all(t is not None for t in fam)
+        fam += list(f.family_grads(6, fam[0], v, a0, b0, (7, 5), (True, True, True)))
+        fam.append(f.family_grads(1, fam[1].sum(), v, w.detach(), None, (7, 5), (False, True, False))[1])
+    else:
+        fam = [fused._differentiable_log_prob(k, v, a0, b0) for k in range(10)]
+        leaves = [t.expand(7, 5).clone().requires_grad_(True) for t in (v, a0, b0)]
+        fam += list(torch.autograd.grad(fused._differentiable_log_prob(6, *leaves), leaves, fam[0]))
+        la = w.detach().expand(7, 5).clone().requires_grad_(True)
+        fam.append(torch.autograd.grad(fused._differentiable_log_prob(1, v, la, None), [la],
+                                       fam[1].sum() * torch.ones(7, 5, dtype=dtype))[0])
     return loss, b.to(dtype).sum(), st, d, fam
 
 
