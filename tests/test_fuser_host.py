@@ -27,7 +27,8 @@ def test_every_generated_source_compiles_for_gfx950():
     # one launch per level, not per operator; the families' expressions, gathers, softmax, joins and long sums in
     assert 4 <= len(fuser_dry.SOURCES) <= 40
     text = "\n".join(fuser_dry.SOURCES)
-    for needle in ("pa::Fam<", "fam_g<", "__shfl_xor", "long long x_", "__builtin_bit_cast(double"):
+    for needle in ("pa::Fam<", "fam_g<", "__shfl_xor", "long long x_", "__builtin_bit_cast(double", "_Pragma(\"unroll 4\")",
+                   "PA_GROUP_SUM(s, 64)"):
         assert needle in text, needle
     # only what the program draws / creates with operators outside the recorder's reach is left to ATen
     assert set(fuser.UNFUSED) <= {"aten::randn", "aten::rand", "aten::sgn", "aten::arange", "aten::randint"}, \

@@ -307,6 +307,12 @@ def program(dtype):
     parts = [torch.where((t < lengths).unsqueeze(-1), x.detach() * float(t), x.new_zeros(())) for t in range(5)]
     st = torch.stack(parts).permute(1, 0, 2).contiguous() + torch.cat(parts, -1).sum()
     d = torch.dot(w.detach(), w.detach() * 2.0) + (x.detach().t() / acc.t()).sum()
+    # sums that walk their range per thread (many outputs, innermost dim kept), that take their operand's
+    # kernel along, and that are longer than a lane group takes (two recorded stages)
+    big = torch.randn(40, 1100, dtype=dtype)
+    lng = torch.randn(20000, 2, dtype=dtype)
+    sums = [(big * 2.0).tanh().sum(0), big.sum(0), (big.t() + 1.0).sum(1), (lng * 0.5).sum(0), lng.abs().sum(),
+            lng.view(4, 5000, 2).sum(1), (big[:, :70] * big[:, 70:140]).sum(-1)]
     # the element-wise families: recorded with csrc/dist_fam.h's expressions under a scope, torch's own eagerly
     from pyro_amd.distributions import fused
     f = fuser.active()
@@ -324,7 +330,7 @@ def program(dtype):
         la = w.detach().expand(7, 5).clone().requires_grad_(True)
         fam.append(torch.autograd.grad(fused._differentiable_log_prob(1, v, la, None), [la],
                                        fam[1].sum() * torch.ones(7, 5, dtype=dtype))[0])
-    return loss, b.to(dtype).sum(), st, d, fam
+    return loss, b.to(dtype).sum(), st, d, fam, sums
 
 
 def main():
