@@ -17,7 +17,12 @@ from oracle import philox as o_philox
 
 
 def _np(t):
-    return None if t is None else t.detach().cpu().numpy()
+    if t is None:
+        return None
+    import pyro_amd.kernels as k
+    for hook in k._PTR_HOOKS:          # (a recorder scope: what the stand-in reads is materialised first)
+        hook(t)
+    return t.detach().cpu().numpy()
 
 
 def _bc(t, rows, cols):

@@ -125,3 +125,79 @@ def test_generated_code_of_random_programs_on_the_host(grad):
             with fuser.Fuser():
                 got = run()
         assert _close(got, want, 3e-5), seed
+
+
+def _flush_after_differentiation(monkeypatch):
+    """On the device a result reaches the host through a copy operator, which materialises what it reads; a host
+    tensor's .numpy() is no operator at all: materialise explicitly before a case reads its gradients."""
+    from pyro_amd.ops import fuser
+    grad, backward = torch.autograd.grad, torch.Tensor.backward
+
+    def grad_then_flush(*a, **kw):
+        out = grad(*a, **kw)
+        if fuser.active() is not None:
+            fuser.active().flush()
+        return out
+
+    def backward_then_flush(self, *a, **kw):
+        backward(self, *a, **kw)
+        if fuser.active() is not None:
+            fuser.active().flush()
+    monkeypatch.setattr(torch.autograd, "grad", grad_then_flush)
+    monkeypatch.setattr(torch.Tensor, "backward", backward_then_flush)
+
+
+@pytest.fixture
+def _cpu_backend(oracle_backend):
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+@pytest.mark.skipif(os.system("g++ --version > /dev/null 2>&1") != 0, reason="needs g++")
+@pytest.mark.parametrize("which", [1, 3])
+def test_hmm_under_markov_through_the_recorder_matches_the_reference(_cpu_backend, monkeypatch, which):
+    """examples/hmm.py model_1 / model_3 under pyro.markov with TraceEnum_ELBO, on the host: the package's
+    kernels answered by the oracle, every other operator of the time steps -- and of the backward pass --
+    recorded, batched level by level and EXECUTED from the generated code (tools/fuser_dry.py::hosting); loss
+    and gradients against the unmodified reference's (tests/golden/hmm.npz), as the plain host run's."""
+    import numpy as np
+    from pyro_amd.ops import fuser
+    from tests import enum_cases as ec
+    from tools import fuser_dry
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hmm.npz"), allow_pickle=False)
+    _flush_after_differentiation(monkeypatch)
+    before = dict(fuser.STATS)
+    with fuser_dry.hosting():
+        with fuser.Fuser():
+            ec.run_hmm(g, torch.device("cpu"), which, fused_chain=True)
+    d = {k: fuser.STATS[k] - before[k] for k in fuser.STATS}
+    assert d["recorded"] > 200 and d["kernels"] < d["recorded"] // 4, d
+
+
+@pytest.mark.skipif(os.system("g++ --version > /dev/null 2>&1") != 0, reason="needs g++")
+@pytest.mark.parametrize("case", ["lda_fused", "lda_generic", "gmm", "gmm_subsampled"])
+def test_enumerated_models_through_the_recorder_match_the_reference(_cpu_backend, monkeypatch, case):
+    """examples/lda.py (word topics summed out: the fused factor kernel answered by the oracle, or the generic
+    log-space contraction) and the Gaussian mixture with its assignments enumerated, TraceEnum_ELBO on the
+    host through the recorder with the generated code executed: loss and gradients of the unmodified reference
+    (tests/golden/enum.npz)."""
+    import numpy as np
+    from pyro_amd.ops import fuser
+    from tests import enum_cases as ec
+    from tools import fuser_dry
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "enum.npz"), allow_pickle=False)
+    _flush_after_differentiation(monkeypatch)
+    if case == "lda_generic":
+        import pyro_amd.ops.contract as c
+        monkeypatch.setattr(c, "_try_fused_lda", lambda *a: None)
+    before = dict(fuser.STATS)
+    with fuser_dry.hosting():
+        with fuser.Fuser():
+            if case.startswith("lda"):
+                ec.run_lda(g, torch.device("cpu"), monkeypatch, expect_fused=case == "lda_fused")
+            else:
+                ec.run_gmm(g, torch.device("cpu"), monkeypatch, case == "gmm_subsampled")
+    assert fuser.STATS["recorded"] - before["recorded"] > 20
