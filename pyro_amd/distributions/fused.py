@@ -1011,7 +1011,7 @@ def _recording(*tensors):
     next to whatever else runs on that level -- instead of taking a launch of their own each way."""
     if _fuser.active() is None or not _fuser.ENABLED["on"]:
         return False
-    return all(t is None or (isinstance(t, torch.Tensor) and t.is_cuda and t.numel() <= _RECORD_MAX
+    return all(t is None or (isinstance(t, torch.Tensor) and _fuser._dev(t) and t.numel() <= _RECORD_MAX
                              and t.dtype in (torch.float32, torch.float64, torch.bool)) for t in tensors)
 
 

@@ -145,6 +145,14 @@ def _flush_after_differentiation(monkeypatch):
             fuser.active().flush()
     monkeypatch.setattr(torch.autograd, "grad", grad_then_flush)
     monkeypatch.setattr(torch.Tensor, "backward", backward_then_flush)
+    import numpy as np
+    compare = np.testing.assert_allclose
+
+    def flush_then_compare(*a, **kw):
+        if fuser.active() is not None:
+            fuser.active().flush()
+        return compare(*a, **kw)
+    monkeypatch.setattr(np.testing, "assert_allclose", flush_then_compare)
 
 
 @pytest.fixture
@@ -201,3 +209,34 @@ def test_enumerated_models_through_the_recorder_match_the_reference(_cpu_backend
             else:
                 ec.run_gmm(g, torch.device("cpu"), monkeypatch, case == "gmm_subsampled")
     assert fuser.STATS["recorded"] - before["recorded"] > 20
+
+
+@pytest.mark.skipif(os.system("g++ --version > /dev/null 2>&1") != 0, reason="needs g++")
+@pytest.mark.parametrize("case", ["eight_schools", "logreg_f64", "logreg_fused", "scale_mask", "hier", "hier_fused"])
+def test_svi_models_through_the_recorder_match_the_reference(_cpu_backend, monkeypatch, case):
+    """Trace_ELBO on the host through the recorder (generated code executed, small sites and constrained
+    parameters recorded instead of launched): eight schools' loss, gradients and 30-step Adam trajectory, the
+    logistic regressions (materialised logits and the GLM site), scale / mask / subsampling, the hierarchical
+    model -- against the unmodified reference's golden vectors, at the plain host run's tolerances."""
+    import numpy as np
+    from pyro_amd.ops import fuser
+    from tests import models
+    from tools import fuser_dry
+
+    def load(name):
+        return np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"), allow_pickle=False)
+    _flush_after_differentiation(monkeypatch)
+    cpu = torch.device("cpu")
+    before = dict(fuser.STATS)
+    with fuser_dry.hosting():
+        with fuser.Fuser():
+            if case == "eight_schools":
+                models.run_eight_schools(load("eight_schools"), cpu, monkeypatch, rtol=1e-9)
+            elif case.startswith("logreg"):
+                models.run_logreg(load("logreg_f64"), cpu, monkeypatch, fused=case.endswith("fused"),
+                                  dtype=torch.float64, rtol=1e-9)
+            elif case == "scale_mask":
+                models.run_scale_mask(load("scale_mask"), cpu, monkeypatch, rtol=1e-9)
+            else:
+                models.run_hier(load("hier"), cpu, monkeypatch, fused=case.endswith("fused"), rtol=1e-9)
+    assert fuser.STATS["recorded"] - before["recorded"] > 10
