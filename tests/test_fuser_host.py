@@ -240,3 +240,27 @@ def test_svi_models_through_the_recorder_match_the_reference(_cpu_backend, monke
             else:
                 models.run_hier(load("hier"), cpu, monkeypatch, fused=case.endswith("fused"), rtol=1e-9)
     assert fuser.STATS["recorded"] - before["recorded"] > 10
+
+
+@pytest.mark.skipif(os.system("g++ --version > /dev/null 2>&1") != 0, reason="needs g++")
+@pytest.mark.skipif(not os.environ.get("PYRO_AMD_SLOW_TESTS"),
+                    reason="~40 s each (a g++ build per distinct generated kernel): PYRO_AMD_SLOW_TESTS=1 runs them")
+@pytest.mark.parametrize("case", ["enum_potential", "constrained_potentials"])
+def test_model_potentials_through_the_recorder_match_the_reference(_cpu_backend, monkeypatch, case):
+    """The potential of a model as HMC / NUTS evaluate it (the conditioned model under the handlers, the transforms'
+    Jacobians, autograd), through the recorder on the host: discrete latents summed out of the potential, and
+    constrained supports (positive, unit interval, simplex, ...) -- values and gradients against the unmodified
+    reference's (tests/golden/mcmc_*.npz), as the plain host run's."""
+    from pyro_amd.ops import fuser
+    from tests import mcmc_cases as mc
+    from tools import fuser_dry
+
+    _flush_after_differentiation(monkeypatch)
+    before = dict(fuser.STATS)
+    with fuser_dry.hosting():
+        with fuser.Fuser():
+            if case == "enum_potential":
+                mc.run_enum_potential_vs_reference(torch.device("cpu"))
+            else:
+                mc.run_constrained_potentials_vs_reference(torch.device("cpu"))
+    assert fuser.STATS["recorded"] - before["recorded"] > 10
