@@ -416,7 +416,7 @@ class DeferredCounts:
         """F.linear(self, weight, bias) on the kernels, or None when they do not cover the call."""
         from .. import kernels
         if not (ENABLED["on"] and self.transposed and self.dtype == torch.float32
-                and isinstance(weight, torch.Tensor) and weight.dim() == 2 and weight.is_cuda
+                and isinstance(weight, torch.Tensor) and weight.dim() == 2 and _on_device(weight)
                 and weight.dtype == torch.float32 and weight.shape[1] == self.V
                 and weight.shape[0] <= 128 and self.V % 128 == 0
                 and (bias is None or (isinstance(bias, torch.Tensor) and bias.dtype == torch.float32))):
@@ -473,7 +473,7 @@ class TallActivation(torch.Tensor):
             x = args[0]
             weight = args[1] if len(args) > 1 else kwargs.get("weight")
             bias = args[2] if len(args) > 2 else kwargs.get("bias")
-            if (x.dim() == 2 and x.shape[0] >= TALL_MIN_ROWS and x.shape[1] <= 128 and x.is_cuda
+            if (x.dim() == 2 and x.shape[0] >= TALL_MIN_ROWS and x.shape[1] <= 128 and _on_device(x)
                     and x.dtype == torch.float32 and type(weight) in (torch.Tensor, torch.nn.Parameter)
                     and weight.dim() == 2 and weight.shape[0] <= 128 and weight.dtype == torch.float32):
                 if FUSE_ACTIVATION["on"]:
@@ -688,7 +688,7 @@ class _HistogramWatcher(torch.overrides.TorchFunctionMode):
 
     def _note(self, t, value):
         import weakref
-        if type(t) is torch.Tensor and t.is_cuda:
+        if type(t) is torch.Tensor and _on_device(t):
             self._fresh[id(t)] = (weakref.ref(t), value)
 
     def _is_fresh(self, t, value):
@@ -706,7 +706,7 @@ class _HistogramWatcher(torch.overrides.TorchFunctionMode):
             if len(full) == 4:
                 base, dim, index, src = full
                 if (ENABLED["on"] and isinstance(dim, int) and dim == 0 and type(index) is torch.Tensor
-                        and index.dtype == torch.int64 and index.dim() == 2 and index.is_cuda
+                        and index.dtype == torch.int64 and index.dim() == 2 and _on_device(index)
                         and type(base) is torch.Tensor and base.dim() == 2
                         and base.shape[1] == index.shape[1] and base.is_floating_point()
                         and type(src) is torch.Tensor and src.shape == index.shape

@@ -580,7 +580,70 @@ def exp_site_bwd(value, g_value, g_ld, cols, lower=0.0):
     return torch.as_tensor(g, dtype=value.dtype)
 
 
-FUNCTIONS = ["exp_site_fwd", "exp_site_bwd", "meanfield_score", "sum_to_nd_pair", "philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
+# ---- the Linear layers of an amortised guide over word histograms (csrc/bow.hip, csrc/tall.hip) -------
+# The "images" of the stand-in are the word matrix itself; everything else restates the entry points'
+# contracts in float64 numpy (oracle/lda.py holds the layout-exact restatements the GPU tests compare with).
+def bow_images_of(words, V):
+    return (words, words)
+
+
+def _counts(words, V):
+    w = _np(words)
+    c = np.zeros((w.shape[1], V))
+    for b in range(w.shape[1]):
+        c[b] = np.bincount(w[:, b], minlength=V)
+    return c
+
+
+def _sig(h):
+    return 1.0 / (1.0 + np.exp(-h))
+
+
+def bow_linear_fwd(image_a, W, bias, B, sigmoid=False):
+    Wn = _np(W).astype(np.float64)
+    h = _counts(image_a, Wn.shape[1]) @ Wn.T + (0.0 if bias is None else _np(bias).astype(np.float64))
+    return torch.as_tensor(_sig(h) if sigmoid else h, dtype=W.dtype, device=W.device)
+
+
+def bow_linear_bwd(image_b, d_out, V, y_mul=None, want_bias=False):
+    d = _np(d_out).astype(np.float64)
+    if y_mul is not None:
+        y = _np(y_mul).astype(np.float64)
+        d = d * (1.0 - y) * y
+    dW = torch.as_tensor(d.T @ _counts(image_b, V), dtype=d_out.dtype, device=d_out.device)
+    if not want_bias:
+        return dW
+    B, H = d.shape
+    nkt = (B + 31) // 32 * 2
+    dp = np.zeros((nkt * 16, 128))
+    dp[:B, :H] = d
+    part = dp.reshape(nkt, 16, 4, 32).sum(1).transpose(1, 0, 2)          # [4, nkt, 32]
+    return dW, torch.as_tensor(np.ascontiguousarray(part), dtype=d_out.dtype, device=d_out.device)
+
+
+def tall_linear(g, W, w_row_stride, w_col_stride, C, bias=None, y_mul=None, sigmoid=False):
+    gn = _np(g).astype(np.float64)
+    if y_mul is not None:
+        y = _np(y_mul).astype(np.float64)
+        gn = gn * (1.0 - y) * y
+    R = gn.shape[1]
+    flat = _np(W).astype(np.float64).reshape(-1)
+    Wm = flat[(np.arange(R)[:, None] * w_row_stride + np.arange(C)[None, :] * w_col_stride)]
+    h = gn @ Wm + (0.0 if bias is None else _np(bias).astype(np.float64))
+    return torch.as_tensor(_sig(h) if sigmoid else h, dtype=g.dtype, device=g.device)
+
+
+def tall_wgrad(g, x, want_bias=True, y_mul=None):
+    gn = _np(g).astype(np.float64)
+    if y_mul is not None:
+        y = _np(y_mul).astype(np.float64)
+        gn = gn * (1.0 - y) * y
+    dW = torch.as_tensor(gn.T @ _np(x).astype(np.float64), dtype=g.dtype, device=g.device)
+    db = torch.as_tensor(gn.sum(0), dtype=g.dtype, device=g.device) if want_bias else None
+    return dW, db
+
+
+FUNCTIONS = ["bow_images_of", "bow_linear_fwd", "bow_linear_bwd", "tall_linear", "tall_wgrad", "exp_site_fwd", "exp_site_bwd", "meanfield_score", "sum_to_nd_pair", "philox_normal", "philox_uniform", "dist_log_prob", "dist_log_prob_sum",
              "dist_log_prob_grad", "glm_bernoulli_fwd_bwd", "leapfrog_kick_drift", "leapfrog_kick",
              "nuts_gaussian_transition", "nuts_gaussian_run", "lda_factor_fwd_bwd", "adam_step", "NutsTree", "GroupSegments",
              "glm_bernoulli_grouped_fwd_bwd", "grouped_rows_of", "glm_grouped_rows_servable", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",

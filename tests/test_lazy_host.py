@@ -102,3 +102,52 @@ def test_deferred_linear_behaves_like_its_result_everywhere_but_under_a_sigmoid(
                       (d.t(), ref.t()), (d.clamp(min=2.0), ref.clamp(min=2.0)), (d > 2, ref > 2)):
         assert torch.equal(got, want)
     assert float(d[0, 1]) == 1.0 and [row.tolist() for row in d] == ref.tolist()
+
+
+def test_amortised_guide_layers_take_the_fused_routes(oracle_backend, monkeypatch):
+    """examples/lda.py's guide text (histogram by scatter_add, then nn.Sequential(Linear, Sigmoid, Linear,
+    Sigmoid, Linear, Sigmoid, Softmax)) on the host with the kernels answered by the oracle: from the second
+    sighting of the corpus the first layer is the bag-of-words route, every layer is deferred until its Sigmoid
+    arrives and launched WITH it (forward: sigmoid_out, backward: the gradient through it in the operand loads,
+    the first layer's bias gradient from its partial sums); values and all parameter gradients equal the dense
+    torch route."""
+    import torch.nn as nn
+    from pyro_amd import kernels as k
+    from pyro_amd.ops import lazy
+    monkeypatch.setattr(lazy, "TALL_MIN_ROWS", 16)
+    gen = torch.Generator().manual_seed(0)
+    V, B, Wd = 256, 70, 12
+    data = torch.randint(0, V, (Wd, B), generator=gen)
+    torch.manual_seed(0)
+    predictor = nn.Sequential(nn.Linear(V, 20), nn.Sigmoid(), nn.Linear(20, 9), nn.Sigmoid(), nn.Linear(9, 4),
+                              nn.Sigmoid(), nn.Softmax(dim=-1))
+
+    def guide_body():
+        counts = torch.zeros(V, B).scatter_add(0, data, torch.ones(data.shape))
+        return predictor(counts.transpose(0, 1))
+
+    log = []
+    for name in ("bow_linear_fwd", "bow_linear_bwd", "tall_linear", "tall_wgrad"):
+        real = getattr(k, name)
+        monkeypatch.setattr(k, name, lambda *a, _r=real, _n=name, **kw: (log.append((_n, kw.get("sigmoid", False),
+                                                                                  kw.get("y_mul") is not None)), _r(*a, **kw))[1])
+    outs, grads = [], []
+    for rep in range(3):
+        for p in predictor.parameters():
+            p.grad = None
+        monkeypatch.setitem(lazy.ENABLED, "on", rep > 0)          # (the first run: torch's dense route)
+        with lazy.watch_histograms():
+            y = guide_body()
+        (y * torch.arange(4.0)).sum().backward()
+        outs.append(y.detach().clone())
+        grads.append([p.grad.clone() for p in predictor.parameters()])
+    for o, gr in zip(outs[1:], grads[1:]):
+        torch.testing.assert_close(torch.as_tensor(o), torch.as_tensor(outs[0]), rtol=1e-5, atol=1e-6)
+        for a, b in zip(gr, grads[0]):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-9)
+    names = [n for n, _, _ in log]
+    assert names.count("bow_linear_fwd") == 2 and names.count("bow_linear_bwd") == 2 and \
+        names.count("tall_linear") == 2 * (2 + 2) and names.count("tall_wgrad") == 2 * 2
+    assert all(sig for n, sig, _ in log if n in ("bow_linear_fwd",))                      # launched with the Sigmoid
+    assert all(sig or ym for n, sig, ym in log if n == "tall_linear")
+    assert all(ym for n, _, ym in log if n in ("tall_wgrad", "bow_linear_bwd"))
