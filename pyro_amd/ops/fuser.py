@@ -32,7 +32,15 @@ opmath in the output type; the families' expressions are csrc/dist_fam.h itself.
 Scope.  Worth its host cost only where a step is recorded once and replayed: SVI's captured step and NUTS's
 captured rounds enter it (the last eager step before a capture runs under it too, so that every kernel is
 compiled before the capture starts).  ``pyro_amd.ops.fuser.ENABLED["on"] = False`` (or PYRO_AMD_FUSER=0)
-switches it off.
+switches it off; ``MERGE_LEVELS`` (PYRO_AMD_FUSER_LEVELS=0: one launch per kernel), ``MAP_REDUCE``
+(PYRO_AMD_FUSER_MAP_REDUCE=0: sums read their operand from memory) and ``DEAD_STORES``
+(PYRO_AMD_FUSER_DEAD_STORES=0) switch single stages off for A/B measurements.
+
+Checked three ways (DESIGN.md section 4): against the replaced operators on the GPU (tests/test_fuser_gpu.py);
+the schedule by re-running every recorded operator where it was put, on the host, bit for bit against the
+eager run (``REPLAY`` + tools/fuser_dry.py::replaying); and the generated source itself compiled by g++ behind
+shims and executed on the host (tools/fuser_dry.py::hosting) -- random programs, and the reference's golden
+losses / gradients of its SVI, enumeration and Markov models end to end (tests/test_fuser_host.py).
 """
 import ctypes
 import math
