@@ -119,7 +119,7 @@ def test_generated_code_of_random_programs_on_the_host(grad):
     from tools import fuser_dry
 
     for seed in range(5000, 5006) if not grad else range(6000, 6004):
-        run = fuser_dry.random_program(seed, n_ops=60 if not grad else 45, grad=grad)
+        run = fuser_dry.random_program(seed, n_ops=60 if not grad else 45, grad=grad, long_sums=True)
         want = run()
         with fuser_dry.hosting():
             with fuser.Fuser():

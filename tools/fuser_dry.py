@@ -185,14 +185,16 @@ def hosting():
         fuser._dev, fuser._launch, fuser.Fuser._factory, fuser.Fuser._const = saved
 
 
-def random_program(seed, n_ops=60, grad=False):
+def random_program(seed, n_ops=60, grad=False, long_sums=False):
     """A list of steps over a pool of tensors: element-wise chains with broadcasting, in-place writes through
     views, reductions short and long, where / comparisons, stack / cat, gathers and their accumulate duals,
     softmax, operators the recorder does not know (partial flushes), dropped references (dead stores)."""
     import random
     rnd = random.Random(seed)
     g = torch.Generator().manual_seed(seed)
-    shapes = [(4, 3), (3,), (4, 1), (2, 4, 3), (), (1, 3), (70, 3)]
+    shapes = [(4, 3), (3,), (4, 1), (2, 4, 3), (), (1, 3), (70, 3), (5, 33), (5, 32), (2, 1, 2, 1, 3, 2)]
+    if long_sums and seed % 3 == 0:
+        shapes.append((17000,))                 # (a sum beyond one lane group's reach: two recorded stages)
     pool0 = [torch.randn(sh, generator=g) for sh in shapes for _ in range(2)]
     steps = []
     unary = [torch.exp, torch.neg, torch.abs, torch.sigmoid, torch.tanh, lambda t: t * 0.5, lambda t: t + 1.5,
@@ -202,7 +204,8 @@ def random_program(seed, n_ops=60, grad=False):
               lambda a, b: torch.where(a > b, a, b * 2.0)]
     for _ in range(n_ops):
         steps.append((rnd.choice(["unary", "unary", "binary", "binary", "inplace", "view", "sum", "sum", "join",
-                                  "index", "softmax", "unknown", "drop", "scatter"]),
+                                  "index", "softmax", "unknown", "drop", "scatter", "cast", "logic", "fills",
+                                  "expand", "copyview", "pow", "dot", "intcmp"]),
                       rnd.random(), rnd.random(), rnd.random(), rnd.randrange(len(unary)), rnd.randrange(len(binary))))
 
     def run():
@@ -249,7 +252,7 @@ def random_program(seed, n_ops=60, grad=False):
                 out = a[idx] * 1.5
             elif kind == "scatter":
                 a = pick(r0, lambda t: t.dim() == 2)
-                v = pick(r1, lambda t: t.shape == a.shape[1:])
+                v = pick(r1, lambda t: t.shape == a.shape[1:] and t.dtype == a.dtype)
                 if v is not None:
                     out = torch.index_put(a, (torch.tensor([0, a.shape[0] - 1, 0]),), v, accumulate=True)
             elif kind == "softmax":
@@ -258,12 +261,48 @@ def random_program(seed, n_ops=60, grad=False):
             elif kind == "unknown":
                 a = pick(r0, lambda t: t.dim() >= 1)
                 out = torch.cumsum(a, 0)                       # (not recorded: whatever it reads is flushed first)
+            elif kind == "cast":
+                a = pick(r0)
+                out = a.double().float() * 1.5 if r1 < 0.3 else ((a > 0.2).to(a.dtype) + a if r1 < 0.6 else
+                                                                 a.double() + 0.25)
+            elif kind == "logic":
+                a = pick(r0)
+                b = pick(r1, lambda t: t.shape == a.shape)
+                m = ((a > 0.1) & (b < 0.5)) | (a != a) | ~(b >= -1.0)
+                out = torch.where(m, a, b * 2.0) if r2 < 0.7 else m.to(a.dtype)
+            elif kind == "fills":
+                a = pick(r0)
+                out = torch.zeros_like(a) + a if r1 < 0.3 else (torch.full_like(a, 2.5) * a if r1 < 0.6 else
+                                                                a.new_ones(tuple(a.shape)) - a)
+            elif kind == "expand":
+                a = pick(r0, lambda t: 1 <= t.dim() <= 4)
+                e = a.unsqueeze(0).expand(3, *a.shape)
+                out = e * 2.0 if r1 < 0.5 else (e + 1.0).sum(0)
+            elif kind == "copyview":
+                a = pick(r0, lambda t: t.dim() >= 2 and t.shape[-1] >= 2)
+                if a is not None and not grad:
+                    dst = a.clone()
+                    dst[..., 0].copy_(dst[..., 1] * 2.0)
+                    dst[..., 1].fill_(0.5)
+                    out = dst
+            elif kind == "pow":
+                a = pick(r0)
+                out = (a.abs() + 0.1) ** 1.5 if r1 < 0.3 else (a ** 3 if r1 < 0.6 else (a.abs() + 0.5) ** -1.0)
+            elif kind == "dot":
+                a = pick(r0, lambda t: t.dim() == 1 and t.shape[0] <= 32)
+                b = pick(r1, lambda t: t.shape == a.shape and t.dtype == a.dtype) if a is not None else None
+                if b is not None:
+                    out = torch.dot(a, b * 0.5)
+            elif kind == "intcmp":
+                a = pick(r0, lambda t: t.dim() >= 1)
+                ids = torch.arange(a.shape[-1])
+                out = torch.where((ids < int(r1 * a.shape[-1]) + 1) & (ids >= 0), a, a * 0.0 + 3.0)
             elif kind == "drop" and len(pool) > 8:
                 del pool[int(r0 * len(pool)) % len(pool)]
             if out is not None and out.numel() > 0:
                 pool.append(out)
         if grad:        # the autograd duals run on the autograd thread, inside the same scope: recorded too
-            terms = [(t * (0.5 + 0.25 * j)).sum() for j, t in enumerate(pool[-12:]) if t.requires_grad]
+            terms = [(t * (0.5 + 0.25 * j)).sum().float() for j, t in enumerate(pool[-12:]) if t.requires_grad]
             torch.stack(terms).sum().backward()
             return [t.detach() for t in pool] + [t.grad for t in leaves if t.grad is not None]
         return pool
