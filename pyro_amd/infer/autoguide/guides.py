@@ -734,30 +734,30 @@ class AutoGuideList(AutoGuide):
         self._parts.append(part)
 
     def add(self, part):
+        """Old spelling of ``append`` (kept, with the reference's deprecation notice)."""
         import warnings
-        warnings.warn("The method `.add` has been deprecated in favor of `.append`.", DeprecationWarning)
+        warnings.warn("The method `.add` has been deprecated in favor of `.append`.", DeprecationWarning,
+                      stacklevel=2)
         self.append(part)
+
+    def _collect(self, ask):
+        """One dict out of every part's answer, in the order the parts were appended."""
+        merged = {}
+        for part in self._parts:
+            merged.update(ask(part))
+        return merged
 
     def forward(self, *args, **kwargs):
         if self.prototype_trace is None:
             self._setup_prototype(*args, **kwargs)
-        self._create_plates(*args, **kwargs)
-        result = {}
-        for part in self._parts:
-            result.update(part(*args, **kwargs))
-        return result
+        self._create_plates(*args, **kwargs)               # once per call: the parts share them
+        return self._collect(lambda part: part(*args, **kwargs))
 
     def median(self, *args, **kwargs):
-        result = {}
-        for part in self._parts:
-            result.update(part.median(*args, **kwargs))
-        return result
+        return self._collect(lambda part: part.median(*args, **kwargs))
 
     def quantiles(self, quantiles, *args, **kwargs):
-        result = {}
-        for part in self._parts:
-            result.update(part.quantiles(quantiles, *args, **kwargs))
-        return result
+        return self._collect(lambda part: part.quantiles(quantiles, *args, **kwargs))
 
 
 class AutoDelta(AutoGuide):
