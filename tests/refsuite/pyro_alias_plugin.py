@@ -68,7 +68,9 @@ def _module_paths():
     import types
     import torch
     from pyro_amd.distributions import base
-    from pyro_amd.poutine import handlers, trace
+    import importlib
+    from pyro_amd.poutine import handlers
+    trace = importlib.import_module("pyro_amd.poutine.trace")      # (the package exports a FUNCTION of that name)
     H = handlers
     table = {
         "poutine.block_messenger": {"BlockMessenger": H.BlockMessenger},
