@@ -144,18 +144,28 @@ extern "C" void pa_host_launch(const void* const* table, int n, long grid) {
 }
 """
 _HOST_LIBS = {}
+_HOST_DIR = []
+
+
+def _host_dir():
+    """One scratch directory per process for the host builds, removed at exit."""
+    if not _HOST_DIR:
+        import atexit
+        import shutil
+        import tempfile
+        _HOST_DIR.append(tempfile.mkdtemp(prefix="pa_fuser_host_"))
+        atexit.register(shutil.rmtree, _HOST_DIR[0], ignore_errors=True)
+    return _HOST_DIR[0]
 
 
 def _host_launch(src, grid, block, tensors):
     import hashlib
     import subprocess
-    import tempfile
     assert block == 256
     SOURCES.append(src)
     lib = _HOST_LIBS.get(src)
     if lib is None:
-        d = tempfile.mkdtemp(prefix="pa_fuser_host_")
-        name = os.path.join(d, hashlib.sha1(src.encode()).hexdigest()[:16])
+        name = os.path.join(_host_dir(), hashlib.sha1(src.encode()).hexdigest()[:16])
         with open(name + ".cpp", "w") as fh:
             fh.write(_HOST_SHIM + src + _HOST_LAUNCHER)
         r = subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-w", "-ffp-contract=off",
