@@ -370,12 +370,15 @@ def program(dtype):
     if f is not None:
         fam = [f.family_log_prob(k, v, a0, b0, (7, 5)) for k in range(10)]
         assert all(t is not None for t in fam)
-        fam += list(f.family_grads(6, fam[0], v, a0, b0, (7, 5), (True, True, True)))
+        for k in range(10):
+            fam += list(f.family_grads(k, fam[0], v, a0, b0, (7, 5), (True, True, True)))
         fam.append(f.family_grads(1, fam[1].sum(), v, w.detach(), None, (7, 5), (False, True, False))[1])
     else:
         fam = [fused._differentiable_log_prob(k, v, a0, b0) for k in range(10)]
-        leaves = [t.expand(7, 5).clone().requires_grad_(True) for t in (v, a0, b0)]
-        fam += list(torch.autograd.grad(fused._differentiable_log_prob(6, *leaves), leaves, fam[0]))
+        for k in range(10):
+            leaves = [t.expand(7, 5).clone().requires_grad_(True) for t in (v, a0, b0)]
+            got = torch.autograd.grad(fused._differentiable_log_prob(k, *leaves), leaves, fam[0], allow_unused=True)
+            fam += [torch.zeros(7, 5, dtype=dtype) if t is None else t for t in got]      # (one-parameter families)
         la = w.detach().expand(7, 5).clone().requires_grad_(True)
         fam.append(torch.autograd.grad(fused._differentiable_log_prob(1, v, la, None), [la],
                                        fam[1].sum() * torch.ones(7, 5, dtype=dtype))[0])
