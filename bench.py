@@ -62,8 +62,13 @@ def parse():
     ap.add_argument("--no-nuts", action="store_true", help="skip the secondary NUTS measurement")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the one-GPU measurements of BASELINE configs 4 (LDA) and 5 (hierarchical)")
-    ap.add_argument("--no-prearm", action="store_true",
-                    help="headline without SVI(prearm=True): every replay launched by its own step() call")
+    ap.add_argument("--full", action="store_true",
+                    help="also time the variants of configs[1] (guides, D sweep, image formats, ...), the LDA "
+                         "mini-batch sizes, eight schools and the HMM example: they go into bench_full.json, "
+                         "never into the printed line")
+    ap.add_argument("--prearm", action="store_true",
+                    help="headline with SVI(prearm=True) (opt-in: the caller promises to enqueue nothing between "
+                         "two steps); by default it is measured beside the headline as `with_prearm`")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager SVI.step (Python handlers + one launch per kernel) instead of the "
                          "captured hipGraph step")
@@ -88,7 +93,7 @@ def parse():
     return ap.parse_args()
 
 
-ROUND = 5       # profiles/r05_*: counter files of another round measured other kernels and are refused
+ROUND = 6       # profiles/r05_*: counter files of another round measured other kernels and are refused
 
 
 def latest_profile(suffix):
@@ -484,6 +489,10 @@ def bench_model_nuts(dev, rank, world, args):
             except Exception:
                 pass
         out[key]["transitions"] = "%d warm-up + %d samples" % (W, S)
+        # a run whose chains have not mixed is a throughput measurement of unconverged chains: said so, and
+        # its roofline block is not a claim about a working sampler
+        out[key]["converged"] = bool(out[key]["posterior_check"]["max_r_hat"] < 1.05)
+        out[key]["roofline"]["claimed"] = out[key]["converged"]
         kernel.cleanup()
     C, W, S = args.model_nuts_chains, args.model_nuts_warmup, args.model_nuts_samples
     if rank != 0:
@@ -506,6 +515,122 @@ def bench_model_nuts(dev, rank, world, args):
                                          "oracle/nuts.py recursion + torch-CPU autograd of the model's log "
                                          "joint per leapfrog, step 0.02, unit mass" % (t, n, D)}
     return res
+
+
+def _r(v, sig=6):
+    """A float at `sig` significant digits (the printed line is a record, not a dump)."""
+    if isinstance(v, float) and v == v and abs(v) != float("inf"):
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def _pick(d, *keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def _file_only(src):
+    """profiles/<file> of a "profiles/<file> (how ...)" source string."""
+    return src.split(" ")[0] if isinstance(src, str) else src
+
+
+def reference_cpu_record():
+    """The UNMODIFIED reference's SVI.step on configs[1], timed in the build container where /root/reference
+    exists (tools/time_reference_cpu.py) and committed as a fixture: profiles/r<ROUND>_reference_cpu.json."""
+    path = latest_profile("reference_cpu.json")
+    if path is None:
+        return None
+    try:
+        j = json.load(open(path))
+        return {"value": _r(j["validation_off"]["steps_per_s"]),
+                "validated": _r(j["validation_on"]["steps_per_s"]), "cores": j["cores"],
+                "kind": "reference", "where": "build container", "source": "profiles/" + os.path.basename(path)}
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def compact(out):
+    """The ONE line the driver parses: numbers and short names only, < 4 KB whatever was measured.  The full
+    record (every block time, every note, every variant) goes to bench_full.json."""
+    line = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                 "scaling", "vs_baseline", "dtype", "data", "rccl_ranks")
+    line["config"] = out["config"]
+    rf = out["roofline"]
+    line["roofline"] = _pick(rf, "bound", "kernel", "kernel_ms", "kernel_ms_eager", "kernel_ms_rocprof", "achieved",
+                             "peak", "unit", "frac", "frac_rocprof", "traffic", "algorithmic_bytes_per_launch")
+    line["roofline"]["traffic_source"] = _file_only(rf.get("traffic_source"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind")
+        line["cpu_baseline"]["sample"] = "%s SVI steps of the torch-CPU port, same N/D/P" % cb.get("sample", "?").split(" ")[0]
+        if cb.get("reference"):
+            line["cpu_baseline"]["reference"] = cb["reference"]
+    for k in ("with_prearm", "without_prearm", "validated"):
+        if out.get(k):
+            line[k] = _pick(out[k], "value", "ms_per_step")
+    oc = out.get("other_configs") or {}
+    others = {}
+    keep = ("config4_lda", "config5_hierarchical_logreg", "config5_plate_sharded", "config2_loss_and_grads_only",
+            "config2_bf16x3_exact_split", "error")
+    for k, v in oc.items():
+        if k not in keep:                      # (the variants of --full: bench_full.json only)
+            continue
+        if not isinstance(v, dict):
+            others[k] = str(v)[:120]
+            continue
+        e = _pick(v, "steps_per_s", "ms_per_step", "ranks", "rows_total")
+        r = v.get("roofline")
+        if isinstance(r, dict):
+            e.update(_pick(r, "kernel_ms", "frac"))
+            e["kernel"] = str(r.get("kernel", ""))[:40]
+        others[k] = e
+    if others:
+        line["other_configs"] = others
+    sec = out.get("secondary")
+    if sec:
+        e = _pick(sec, "metric", "value", "unit", "n_gpus", "leapfrogs", "wall_s", "dtype")
+        e["roofline"] = _pick(sec.get("roofline", {}), "kernel", "kernel_ms_total", "achieved", "peak", "unit", "frac")
+        e["max_r_hat"] = _r(sec.get("posterior_check", {}).get("max_r_hat"))
+        if sec.get("cpu_baseline"):
+            e["cpu_baseline"] = _pick(sec["cpu_baseline"], "value", "cores", "kind")
+        line["secondary"] = e
+    mn = out.get("secondary_model_nuts")
+    if mn:
+        e = _pick(mn, "metric", "n_gpus", "dtype", "error")
+        runs = {}
+        for k, v in (mn.get("runs") or {}).items():
+            rr = _pick(v, "value", "sampling_phase", "leapfrogs", "us_per_round", "round_occupancy", "converged")
+            rr["max_r_hat"] = _r(v.get("posterior_check", {}).get("max_r_hat"))
+            rr["roofline"] = _pick(v.get("roofline", {}), "kernel_ms", "frac", "frac_of_round", "traffic",
+                                   "algorithmic_bytes_per_round", "claimed")
+            runs[k] = rr
+        e["runs"] = runs
+        if mn.get("cpu_baseline"):
+            e["cpu_baseline"] = _pick(mn["cpu_baseline"], "value", "cores", "kind")
+        line["secondary_model_nuts"] = e
+    line["full_record"] = "bench_full.json"
+    return line
+
+
+def emit(out):
+    """Write the full record to bench_full.json (repo root, and gpurun_out/ when that exists so that it comes
+    back from the GPU box) and print the compact line -- the only thing this script writes to stdout."""
+    full = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as fh:
+                    fh.write(full + "\n")
+            except OSError:
+                pass
+    line = json.dumps(compact(out), separators=(",", ":"))
+    if len(line) >= 4096:                      # never again a line the driver cannot keep whole
+        c = compact(out)
+        for k in ("other_configs", "validated", "without_prearm", "with_prearm"):
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) < 4096:
+                break
+    print(line, flush=True)
 
 
 def main():
@@ -554,19 +679,20 @@ def main():
     clock = kernels.GlmDeviceClock(dev) if on_gpu else None
     # The headline is the reference's constructor and nothing else: SVI(model, guide, optim, loss).  With
     # device tensors as arguments such an SVI captures its step into a hipGraph by itself (after 3 eager
-    # steps) and enqueues the replay of step k+1 behind a gate node while step k executes; the replay is
-    # released by the next step() call when no tensor the captured step reads has changed meanwhile (version
-    # counters of everything it reads from outside itself), otherwise given up -- nothing is asked of the
-    # caller (pyro_amd/infer/svi.py).  Every timed block ends with SVI.pause(): the replay armed for the step
-    # after the block's last one is given up at once instead of being sat out by the closing synchronisation.
-    # --no-prearm / --no-graph switch the two mechanisms off (hip_graph=False is the reference's eager step).
+    # steps, with a one-time warning naming what a captured step freezes); every step() launches its own
+    # replay.  SVI(prearm=True) -- opt-in, the caller promises to enqueue nothing between two steps that
+    # reads what a step writes -- is measured beside it (`with_prearm`); --prearm makes it the headline,
+    # --no-graph is the reference's eager step.
     kw = {}
     if not use_graph:
         kw["hip_graph"] = False
-    elif args.no_prearm:
-        kw["prearm"] = False
-    svi = SVI(examples.logreg_model, guide, optim,
-              Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1), **kw)
+    elif args.prearm:
+        kw["prearm"] = True
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        svi = SVI(examples.logreg_model, guide, optim,
+                  Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1), **kw)
     prearm = bool(svi.prearm and svi.hip_graph and world == 1)
 
     class _NoTimer:                      # (host run: nothing to bracket)
@@ -656,6 +782,32 @@ def main():
             timer.arm()
             svi._eager_step(X, y)
         torch.cuda.synchronize()
+    armed = None
+    if world == 1 and graphed and not prearmed and on_gpu:
+        # the opt-in variant beside the headline: SVI(prearm=True) on the same guide / optimizer
+        svi_p = SVI(examples.logreg_model, guide, optim,
+                    Trace_ELBO(num_particles=P, vectorize_particles=True, max_plate_nesting=1),
+                    hip_graph=True, graph_warmup=2, prearm=True)
+        for _ in range(8):
+            svi_p.step(X, y)
+        na = min(args.steps, 300)
+        tas = []
+        for _ in range(max(1, min(25, nblocks))):
+            sync()
+            ta = time.perf_counter()
+            for _ in range(na):
+                svi_p.step(X, y)
+            svi_p.pause()
+            sync()
+            tas.append(time.perf_counter() - ta)
+        ta = sorted(tas)[len(tas) // 2]
+        ent = next(iter(svi_p._graphs.values()), None)
+        armed = {"value": na / ta, "ms_per_step": ta / na * 1e3, "steps": na, "blocks": len(tas),
+                 "gated": bool(ent is not None and ent.gate is not None),
+                 "note": "SVI(..., prearm=True): the replay of step k+1 enqueued behind a gate while step k "
+                         "executes (opt-in: the caller enqueues nothing between steps that reads what a step "
+                         "writes)"}
+        svi_p.release()
     validated = None
     if world == 1 and graphed:
         # the same measurement with validation switched on (it runs in the eager steps before the
@@ -760,39 +912,40 @@ def main():
                               "(no atomics), the guide's first layer on the bag-of-words image, its inner "
                               "layers on the tall-batch kernels; graphed SVI.step")
             others["config4_lda"] = r4
-            for bs in (32, 4096):      # the mini-batch variants SURVEY 8(d) lists
-                rb = bench_configs.config4(dev, steps=30, batch_size=bs)
-                rb["workload"] = ("examples/lda.py with batch_size=%d of 1e5 documents per step (a fresh "
-                                  "sub-sampled word matrix every step: LDS-atomic factor kernel), "
-                                  "graphed SVI.step" % bs)
-                others["config4_lda_batch%d" % bs] = rb
-            r1 = bench_configs.config1(dev)
-            r1["workload"] = ("BASELINE configs[0]: eight schools, Trace_ELBO, 1 particle, Adam; graphed "
-                              "SVI.step (the reference's own CPU-runnable case: ~58 steps/s there)")
-            others["config1_eight_schools"] = r1
-            rh = bench_configs.config_hmm(dev, steps=10, graph=True)
-            rh["workload"] = ("examples/hmm.py model_1 at its JSB-chorales size (229 sequences x 129 "
-                              "steps, 16 hidden states, 88 tones), TraceEnum_ELBO under pyro.markov, "
-                              "chain summed out by pa_logchain_fwd_bwd, graphed SVI.step")
-            others["hmm_example"] = rh
-            rv = bench_configs.config_hmm_vectorised(dev)
-            rv["workload"] = ("the same HMM likelihood with time vectorised in one DiscreteHMM site "
-                              "(examples/hmm.py model_7's construction): one pa_logchain_fwd_bwd launch "
-                              "for all sequences, graphed SVI.step")
-            others["hmm_example_vectorised"] = rv
-            r2m = bench_configs.config2_variant(dev, "mvn")
-            r2m["workload"] = ("BASELINE configs[1] with AutoMultivariateNormal (the second guide "
-                               "SURVEY 8d names), 64 particles, graphed SVI.step")
-            others["config2_automultivariatenormal"] = r2m
-            r2p = bench_configs.config2_variant(dev, "normal", P=1)
-            r2p["workload"] = ("BASELINE configs[1] at the reference's default num_particles=1: "
-                               "few-particle vector-ALU GLM kernel (HBM-bound), graphed SVI.step")
-            others["config2_one_particle"] = r2p
-            r2e = bench_configs.config2_variant(dev, "normal", model=examples.logreg_model_explicit)
-            r2e["workload"] = ("BASELINE configs[1] with the logits spelled as dist.linear_logits(X, w, b) "
-                               "and hoisted prior constants instead of the reference's model text "
-                               "(same kernels, two fill launches fewer)")
-            others["config2_explicit_linear_logits"] = r2e
+            if args.full:
+                for bs in (32, 4096):      # the mini-batch variants SURVEY 8(d) lists
+                    rb = bench_configs.config4(dev, steps=30, batch_size=bs)
+                    rb["workload"] = ("examples/lda.py with batch_size=%d of 1e5 documents per step (a fresh "
+                                      "sub-sampled word matrix every step: LDS-atomic factor kernel), "
+                                      "graphed SVI.step" % bs)
+                    others["config4_lda_batch%d" % bs] = rb
+                r1 = bench_configs.config1(dev)
+                r1["workload"] = ("BASELINE configs[0]: eight schools, Trace_ELBO, 1 particle, Adam; graphed "
+                                  "SVI.step (the reference's own CPU-runnable case: ~58 steps/s there)")
+                others["config1_eight_schools"] = r1
+                rh = bench_configs.config_hmm(dev, steps=10, graph=True)
+                rh["workload"] = ("examples/hmm.py model_1 at its JSB-chorales size (229 sequences x 129 "
+                                  "steps, 16 hidden states, 88 tones), TraceEnum_ELBO under pyro.markov, "
+                                  "chain summed out by pa_logchain_fwd_bwd, graphed SVI.step")
+                others["hmm_example"] = rh
+                rv = bench_configs.config_hmm_vectorised(dev)
+                rv["workload"] = ("the same HMM likelihood with time vectorised in one DiscreteHMM site "
+                                  "(examples/hmm.py model_7's construction): one pa_logchain_fwd_bwd launch "
+                                  "for all sequences, graphed SVI.step")
+                others["hmm_example_vectorised"] = rv
+                r2m = bench_configs.config2_variant(dev, "mvn")
+                r2m["workload"] = ("BASELINE configs[1] with AutoMultivariateNormal (the second guide "
+                                   "SURVEY 8d names), 64 particles, graphed SVI.step")
+                others["config2_automultivariatenormal"] = r2m
+                r2p = bench_configs.config2_variant(dev, "normal", P=1)
+                r2p["workload"] = ("BASELINE configs[1] at the reference's default num_particles=1: "
+                                   "few-particle vector-ALU GLM kernel (HBM-bound), graphed SVI.step")
+                others["config2_one_particle"] = r2p
+                r2e = bench_configs.config2_variant(dev, "normal", model=examples.logreg_model_explicit)
+                r2e["workload"] = ("BASELINE configs[1] with the logits spelled as dist.linear_logits(X, w, b) "
+                                   "and hoisted prior constants instead of the reference's model text "
+                                   "(same kernels, two fill launches fewer)")
+                others["config2_explicit_linear_logits"] = r2e
             # "loss_and_grads only" beside the full step, the D sweep, and the
             # exact three-plane bf16 image beside the default two-plane f16 one on every run
             r2g = bench_configs.config2_variant(dev, "normal", no_update=True)
@@ -805,18 +958,19 @@ def main():
                                "split exactly, 6 piece products): the headline's arithmetic without the "
                                "2^-22 representation error of the two-plane f16 image")
             others["config2_bf16x3_exact_split"] = r2x
-            for Dv in (8, 64, 128):
-                rd = bench_configs.config2_variant(dev, "normal", D=Dv, steps=30)
-                rd["workload"] = ("BASELINE configs[1] at D=%d (SURVEY 8d sweep): %s" % (
-                    Dv, "plane-image kernel" if Dv <= 32 else
-                    "plane-image kernel with %d feature tiles of 32 columns (csrc/glm_planes16d.h; until "
-                    "round 4 D > 32 split X on the fly in two passes)" % (2 if Dv <= 64 else 4)))
-                others["config2_D%d" % Dv] = rd
-            r2u = bench_configs.config2_variant(dev, "normal", lazy_matmul=False, steps=20)
-            r2u["workload"] = ("BASELINE configs[1], the reference's model text with the lazy recognition "
-                               "of w @ X.t() switched OFF: [P, N] logits materialised by rocBLAS, "
-                               "log-prob / gradient by the fused site kernels, rocBLAS for dw")
-            others["config2_materialised_logits"] = r2u
+            if args.full:
+                for Dv in (8, 64, 128):
+                    rd = bench_configs.config2_variant(dev, "normal", D=Dv, steps=30)
+                    rd["workload"] = ("BASELINE configs[1] at D=%d (SURVEY 8d sweep): %s" % (
+                        Dv, "plane-image kernel" if Dv <= 32 else
+                        "plane-image kernel with %d feature tiles of 32 columns (csrc/glm_planes16d.h; until "
+                        "round 4 D > 32 split X on the fly in two passes)" % (2 if Dv <= 64 else 4)))
+                    others["config2_D%d" % Dv] = rd
+                r2u = bench_configs.config2_variant(dev, "normal", lazy_matmul=False, steps=20)
+                r2u["workload"] = ("BASELINE configs[1], the reference's model text with the lazy recognition "
+                                   "of w @ X.t() switched OFF: [P, N] logits materialised by rocBLAS, "
+                                   "log-prob / gradient by the fused site kernels, rocBLAS for dw")
+                others["config2_materialised_logits"] = r2u
         except Exception as e:  # noqa: BLE001  (secondary measurements must not kill the headline)
             others["error"] = "%s: %s" % (type(e).__name__, e)
         pyro.clear_param_store()
@@ -859,17 +1013,11 @@ def main():
                        "(each block = exactly `steps` steps between barrier + synchronize, max over ranks)",
                        "blocks_ms_per_step": [round(b / args.steps * 1e3, 5) for b in block_s]},
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Bayesian logistic regression, plate=%d, "
-                                   "D=%d, Trace_ELBO num_particles=%d per GPU (vectorised), AutoNormal, "
-                                   "Adam; the model text of SURVEY 8(d) verbatim (logits = w @ X.t() ...); "
-                                   "full SVI.step of SVI(model, guide, optim, loss) -- the reference's "
-                                   "constructor, no other argument (%s)" % (N, D, P, (
-                                       "it captures its step by itself: one hipGraph replay per step" + (
-                                           ", the replay of step k+1 enqueued while step k executes (its GLM "
-                                           "kernel runs ahead, a gate node in front of its chained tail waits "
-                                           "for the next step() call and gives the replay up when anything the "
-                                           "step reads has changed)" if prearmed else "")) if graphed
-                                       else "eager launches"),
+            "config": {"workload": "BASELINE configs[1]: Bayesian logistic regression, plate=%d, D=%d, Trace_ELBO "
+                                   "num_particles=%d per GPU (vectorised), AutoNormal, Adam; full SVI.step of "
+                                   "SVI(model, guide, optim, loss), %s" % (N, D, P, (
+                                       ("one hipGraph replay per step" + (", prearm=True" if prearmed else ""))
+                                       if graphed else "eager launches")),
                        "parallelism": "particles sharded x%d, flat RCCL grad all-reduce" % world},
             # the plate scan is priced against HBM (algorithmic bytes = X and y once)
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
@@ -913,10 +1061,15 @@ def main():
                 out["roofline"]["measured_hbm"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, P, args.cpu_budget_s)
+            ref = reference_cpu_record()
+            if ref is not None:
+                out["cpu_baseline"]["reference"] = ref
         if validated is not None:
             out["validated"] = validated
         if unarmed is not None:
             out["without_prearm"] = unarmed
+        if armed is not None:
+            out["with_prearm"] = armed
         out["step_anatomy"] = {"graph_nodes": "glm_planes (its prologue makes the guide draw), step gate (when "
                                               "pre-armed: in front of the tail, so a replay enqueued ahead runs "
                                               "its forward pass before the host asks), chain_tail (GLM finalize "
@@ -933,7 +1086,7 @@ def main():
             out["secondary"] = nuts
         if model_nuts is not None:
             out["secondary_model_nuts"] = model_nuts
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

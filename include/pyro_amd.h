@@ -720,6 +720,18 @@ int pa_nuts_tree_run_advance_direct(void* z, void* pe, void* grad, void* zq, voi
                                     const void* ll_ext, void* accept_prob, int32_t* n_leapfrog,
                                     int32_t* depth, int32_t* diverging, int32_t* accepted, void* workspace,
                                     size_t workspace_bytes, pa_stream_t stream);
+/* The same potential on its own: (U, dU/du) of the flat model at n_slots cursors of a site-major zq_pack
+ * (float32, D <= 512; arguments as above), pe_out[n_slots], grad_out[n_slots, D] row-major.  Replaces one
+ * evaluation of the reference's potential_fn + autograd at given unconstrained points
+ * (pyro/infer/mcmc/util.py:264-286, pyro/ops/integrator.py:68-94); the tree kernel runs this arithmetic in
+ * registers, this entry writes it out (initial state of a chain, step-size search, parity tests against
+ * the reference's potential_fn values). */
+int pa_nuts_direct_potential(const void* zq_pack, int64_t n_slots, int64_t D, int n_sites,
+                             const int32_t* site_off, const int32_t* site_len, const int32_t* site_dist,
+                             const int32_t* site_transform, const double* site_lower,
+                             const void* const* site_p0, const int64_t* site_s0, const void* const* site_p1,
+                             const int64_t* site_s1, const void* const* site_g_ext, const void* ll_ext,
+                             void* pe_out, void* grad_out, pa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under

@@ -212,6 +212,9 @@ _SIGNATURES = {
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_size_t, c_void_p]),
+    "pa_nuts_direct_potential": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "pa_rtc_compile": (c_int, [c_char_p, c_char_p, c_void_p]),
     "pa_rtc_launch": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_int, c_void_p]),
     "pa_nuts_gaussian_find_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -386,6 +386,25 @@ __device__ __forceinline__ void direct_potential(const Chain<T, NW, NPL>& c, con
   pe_q = -(dp.ll_ext != nullptr ? ((const T*)dp.ll_ext)[slot] : T(0)) - lp_sum;
 }
 
+// the same arithmetic on its own (pa_nuts_direct_potential): (U, dU/du) at n_slots cursors of a site-major pack,
+// one workgroup per slot -- what the tree kernel computes in registers for its kick, written out
+template <int NW, int NPL>
+__global__ __launch_bounds__(64 * NW) void nuts_direct_potential_kernel(
+    const float* __restrict__ zq_pack, int64_t n_slots, int D, SlotLayout lay, TreeDirect direct,
+    float* __restrict__ pe_out, float* __restrict__ grad_out) {
+  __shared__ float red[2 * NW];
+  const int64_t slot = blockIdx.x;
+  Chain<float, NW, NPL> c{(int)threadIdx.x, D, slot * D, red};
+  Vec<float, NPL> zq, gq;
+#pragma unroll
+  for (int m = 0; m < NPL; ++m)
+    zq.x[m] = c.ok(m) ? zq_pack[slot_index(lay, n_slots, slot, D, c.tid + m * c.NT)] : 0.0f;
+  float pe_q;
+  direct_potential<float, NW, NPL>(c, direct, lay, slot, zq, gq, pe_q);
+  c.st(grad_out, gq);
+  if (c.tid == 0) pe_out[slot] = pe_q;
+}
+
 template <typename T, int NW, int NPL, bool RUN, bool DIRECT = false>
 __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
     T* __restrict__ z_io, T* __restrict__ pe_io, T* __restrict__ grad_io, T* __restrict__ zq_io,
@@ -1071,6 +1090,40 @@ int pa_nuts_tree_run_advance_direct(void* z, void* pe, void* grad, void* zq, voi
                                      max_tree_depth, use_multinomial, seed, chain_offset, run, n_slots,
                                      accept_prob, n_leapfrog, depth, diverging, accepted, workspace,
                                      pa::as_stream(stream), &dp);
+}
+
+int pa_nuts_direct_potential(const void* zq_pack, int64_t n_slots, int64_t D, int n_sites,
+                             const int32_t* site_off, const int32_t* site_len, const int32_t* site_dist,
+                             const int32_t* site_transform, const double* site_lower,
+                             const void* const* site_p0, const int64_t* site_s0, const void* const* site_p1,
+                             const int64_t* site_s1, const void* const* site_g_ext, const void* ll_ext,
+                             void* pe_out, void* grad_out, pa_stream_t stream) {
+  PA_REQUIRE(zq_pack && pe_out && grad_out && site_off && site_len && site_dist && site_transform &&
+                 site_lower && site_p0 && site_s0 && site_p1 && site_s1 && site_g_ext,
+             "nuts_direct_potential: NULL pointer");
+  PA_REQUIRE(n_slots >= 0 && n_slots < (1ll << 31), "nuts_direct_potential: n_slots=%lld", (long long)n_slots);
+  PA_REQUIRE(D >= 1 && D <= 512, "nuts_direct_potential: D=%lld outside [1, 512]", (long long)D);
+  PA_REQUIRE(n_sites >= 1, "nuts_direct_potential: at least one site");
+  if (n_slots == 0) return PA_OK;
+  pa::SlotLayout lay;
+  const int rc = tree_layout(n_sites, site_off, site_len, D, &lay);
+  if (rc != PA_OK) return rc;
+  pa::TreeDirect dp{};
+  dp.n_sites = n_sites;
+  dp.ll_ext = ll_ext;
+  for (int k = 0; k < n_sites; ++k) {
+    PA_REQUIRE(site_transform[k] == 0 || site_transform[k] == 1, "nuts_direct_potential: transform");
+    dp.s[k] = pa::DirectSite{site_dist[k], site_transform[k], site_p0[k], site_p1[k], site_s0[k], site_s1[k],
+                             site_g_ext[k], site_lower[k]};
+  }
+  hipStream_t s = pa::as_stream(stream);
+  if (D <= 128)
+    hipLaunchKernelGGL((pa::nuts_direct_potential_kernel<1, 2>), dim3((unsigned)n_slots), dim3(64), 0, s,
+                       (const float*)zq_pack, n_slots, (int)D, lay, dp, (float*)pe_out, (float*)grad_out);
+  else
+    hipLaunchKernelGGL((pa::nuts_direct_potential_kernel<1, 8>), dim3((unsigned)n_slots), dim3(64), 0, s,
+                       (const float*)zq_pack, n_slots, (int)D, lay, dp, (float*)pe_out, (float*)grad_out);
+  return pa::check_launch("nuts_direct_potential_kernel");
 }
 
 }  // extern "C"

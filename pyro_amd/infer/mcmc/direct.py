@@ -97,6 +97,26 @@ class DirectProgram:
         return ll, ext
 
 
+    def pack(self, z):
+        """Row-major unconstrained points z [n, D] -> the site-major pack the round's kernels read."""
+        n = z.shape[0]
+        return torch.cat([z[:, s["off"]: s["off"] + s["len"]].reshape(-1) for s in self.sites]).contiguous(), n
+
+    def potential(self, z):
+        """(U [n], dU/du [n, D]) at unconstrained points z [n, D]: the observed site's kernel, then
+        pa_nuts_direct_potential -- the arithmetic the tree kernel runs in registers, written out."""
+        pack, n = self.pack(z.detach().to(torch.float32))
+        ll, ext = self.glm_round(pack, n)
+        p0, p1, ge = self.pointers(ext)
+        pe = torch.empty((n,), dtype=torch.float32, device=z.device)
+        grad = torch.empty((n, self.layout.D), dtype=torch.float32, device=z.device)
+        kernels.check(_lib.load().pa_nuts_direct_potential(
+            kernels._ptr(pack), n, self.layout.D, self.n, self.off, self.len, self.dist, self.transform,
+            self.lower, p0, self.s0, p1, self.s1, ge, kernels._ptr(ll), kernels._ptr(pe), kernels._ptr(grad),
+            kernels._stream()))
+        return pe, grad
+
+
 def recognise(pe_maker, layout, transforms, init_params, num_chains):
     """A DirectProgram for the model behind ``pe_maker`` (infer/mcmc/util._PEMaker), or None."""
     if not ENABLED["on"] or pe_maker.enum or num_chains < 2:

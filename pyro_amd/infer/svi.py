@@ -201,6 +201,110 @@ def _capturable_arguments(args, kwargs):
     return seen
 
 
+class CapturedStepWarning(UserWarning):
+    """Emitted once per process when an SVI built WITHOUT hip_graph=... captures its step by itself."""
+
+
+_CAPTURE_NOTE = (
+    "pyro_amd: SVI captured its step into a hipGraph after {n} eager steps (device tensors as arguments, a "
+    "device-side ELBO and a flat optimizer: nobody asked, so this is said once).  A captured step does not "
+    "re-run the Python of the model and guide: what they read from the host at capture time is frozen into "
+    "the graph.  Guarded -- the capture is dropped and re-made when it changes: step() arguments, Python "
+    "scalars / flags the model or guide reach through closures, globals, functools.partial or attributes "
+    "(an annealing factor `self.beta`, nn.Module.training), the seed, the set of parameters "
+    "(pyro.clear_param_store()).  NOT guarded: Python control flow on device values, host-side randomness "
+    "(random / numpy / CPU torch generators), state mutated through containers (lists, dicts, numpy "
+    "arrays).  Models that need those: SVI(..., hip_graph=False), PYRO_AMD_HIP_GRAPH=0 or "
+    "pyro.settings.set(svi_capture_steps=False).")
+_WARNED_CAPTURE = [False]
+_SCALAR_TYPES = (bool, int, float, str, type(None))
+_MISSING = object()
+
+
+def _host_scalar_watch(*fns, depth=3):
+    """Every Python scalar (bool / int / float / str / None) a callable can read from outside its arguments
+    without the version counter of any tensor moving: closure cells, the globals its code names, the
+    arguments of a functools.partial, the attributes of the object a bound method / callable object belongs
+    to and -- for torch.nn.Module trees -- of every sub-module (`training` among them).  Returns
+    ([(mapping, key, value)], [(cell, value)]): live references, compared by SVI.step before every replay
+    (the reference re-runs the model each step, pyro/infer/svi.py:134-162, so it sees such changes)."""
+    import functools
+    import types
+    maps, cells, seen = [], [], set()
+
+    def scan_mapping(d, keys=None):
+        for k in (list(d) if keys is None else keys):
+            v = d.get(k, _MISSING)
+            if isinstance(v, _SCALAR_TYPES) and isinstance(k, str) and not k.startswith("__"):
+                maps.append((d, k, v))
+
+    def scan_object(o, level):
+        if id(o) in seen:
+            return
+        seen.add(id(o))
+        if isinstance(o, torch.nn.Module):
+            for m in o.modules():
+                if id(m) not in seen or m is o:
+                    seen.add(id(m))
+                    scan_mapping(vars(m))
+        elif hasattr(o, "__dict__") and not isinstance(o, (type, types.ModuleType)):
+            scan_mapping(vars(o))
+        if level > 0 and hasattr(o, "__dict__") and not isinstance(o, (type, types.ModuleType)):
+            for v in list(vars(o).values()):
+                if callable(v) and not isinstance(v, (type, torch.Tensor)):
+                    scan(v, level - 1)
+
+    def scan(fn, level):
+        if fn is None or id(fn) in seen or level < 0:
+            return
+        if isinstance(fn, functools.partial):
+            seen.add(id(fn))
+            scan(fn.func, level)
+            for a in list(fn.args) + list((fn.keywords or {}).values()):
+                if callable(a) or hasattr(a, "__dict__"):
+                    scan(a, level - 1)
+            return
+        if isinstance(fn, types.MethodType):
+            scan_object(fn.__self__, level - 1)
+            fn = fn.__func__
+        if isinstance(fn, types.FunctionType):
+            seen.add(id(fn))
+            code = fn.__code__
+            scan_mapping(fn.__globals__, [n for n in code.co_names if n in fn.__globals__])
+            for c in fn.__closure__ or ():
+                try:
+                    v = c.cell_contents
+                except ValueError:
+                    continue
+                if isinstance(v, _SCALAR_TYPES):
+                    cells.append((c, v))
+                elif isinstance(v, torch.Tensor):
+                    continue
+                elif callable(v) or hasattr(v, "__dict__"):
+                    scan(v, level - 1)
+            return
+        if isinstance(fn, (torch.Tensor, type, types.ModuleType, types.BuiltinFunctionType)):
+            return
+        scan_object(fn, level - 1)              # a callable object (autoguide, nn.Module, class instance)
+
+    for f in fns:
+        scan(f, depth)
+    return maps, cells
+
+
+def _host_scalars_changed(watch):
+    maps, cells = watch
+    for d, k, v in maps:
+        w = d.get(k, _MISSING)
+        if w is not v and w != v:
+            return k
+    for c, v in cells:
+        w = c.cell_contents
+        if w is not v and w != v:
+            return "<closure>"
+    return None
+
+
 class SVI:
     def __init__(self, model, guide, optim, loss, loss_and_grads=None, num_samples=0, num_steps=0,
                  hip_graph=None, graph_warmup=3, prearm=None, speculate=True, **kwargs):
@@ -231,22 +335,22 @@ class SVI:
             hip_graph = (want is True or want == "auto") and self._loss_device is not None \
                 and _FlatOptimOK(optim)
         self.hip_graph = bool(hip_graph)
+        # prearm (OPT-IN, default off): right after launching step k the replay of step k+1 is enqueued
+        # behind a gate node and released by the next step() call with one store to pinned memory (the
+        # launch latency of a step overlaps the execution of the one before).  THE CALLER'S PROMISE: between
+        # two step() calls nothing is enqueued on the step's stream that READS what a step writes
+        # (parameters, optimizer state) -- a `pyro.param("w").detach().clone()`, an EMA update or a
+        # device-side metric enqueued after step k returns would sit BEHIND step k+1's replay on the stream
+        # and see the parameters after step k+1.  (Call SVI.pause() before such work: it gives the waiting
+        # replay up at once.)  What the package can check itself it does: the replay is only released when
+        # the version counter of every tensor the captured step reads that it did not make itself
+        # (arguments, parameters, optimizer state, tensors the model closes over: _ReadSet), the position
+        # and seed of the random stream and the set of parameters are what they were when it was enqueued;
+        # otherwise it is given up and the step runs the ordinary way.  A read-only use of a parameter
+        # moves no version counter -- hence the promise, and hence opt-in.  Only steps whose every node can
+        # be given up are armed; the gate gives a replay up by itself after 40 us without a release.
         if prearm is None:
-            # a step that captures itself also enqueues its next replay ahead of the host when every node
-            # of it can be given up (below); an explicit hip_graph=True keeps the plain replay unless asked
-            prearm = self._auto_graph and self.hip_graph
-        # prearm: right after launching step k the replay of step k+1 is enqueued behind a gate node
-        # and released by the next step() call with one store to pinned memory (the launch latency
-        # of a step overlaps the execution of the one before).  Nothing is asked of the caller: the replay
-        # is only released when the host-visible state it depends on is what it was when the replay was
-        # enqueued -- the version counter of EVERY tensor the captured step reads that it did not make
-        # itself (arguments, parameters, optimizer state, tensors the model closes over: _ReadSet), the
-        # position and seed of the random stream, the set of parameters; otherwise it is given up and the
-        # step runs the ordinary way.  Work the caller enqueues between two steps waits behind the gate
-        # node for at most the gate's patience (40 us), after which the gate gives the replay up by
-        # itself; a host that stays away longer than that finds the same.  Only steps whose every node
-        # can be given up are armed.  (What no version counter sees -- memory written behind torch's back
-        # by a foreign kernel between two steps -- a step enqueued ahead does not see either.)
+            prearm = False
         self.prearm = bool(prearm) and _os.environ.get("PYRO_AMD_PREARM", "1") != "0"
         # speculate (with prearm): the gate sits in front of the step's chained tail instead of first, so
         # the forward pass of the replay enqueued ahead (the plane-image GLM kernel, which also makes the
@@ -267,6 +371,12 @@ class SVI:
         self.max_graphs = int(kwargs.pop("max_graphs", 8))
         self._warned_keys = False
         self._const_rec = {}       # signature -> ConstantRecorder of its last eager step
+        # host state a captured step froze (see _CAPTURE_NOTE): Python scalars the model / guide can reach,
+        # the parameter store's generation
+        self._watch = None
+        self._watch_first = None   # the same scalars after the FIRST eager step of a signature
+        self._store_generation = None
+        self._self_mutating = False
 
     def evaluate_loss(self, *args, **kwargs):
         with torch.no_grad():
@@ -295,6 +405,14 @@ class SVI:
             return self._eager_step(*args, **kwargs)
         if self._auto_graph and not _capturable_arguments(args, kwargs):
             return self._eager_step(*args, **kwargs)
+        if self._graphs:
+            changed = _host_scalars_changed(self._watch) if self._watch is not None else None
+            if changed is not None or _PARAM_STORE.generation != self._store_generation:
+                # something the captured steps froze has changed on the host (an annealing factor, a
+                # train()/eval() flag, pyro.clear_param_store()): drop them; this step and the next
+                # graph_warmup - 1 run eagerly (as the reference's every step does), then it is captured anew
+                self.release()
+                self._eager_seen.clear()
         fast = self._armed_fast
         if fast is not None:
             # the step after an armed one, called with the very same argument objects: release the
@@ -329,6 +447,7 @@ class SVI:
                                       "such steps run eagerly. Pass the same tensors (update them "
                                       "in place) to reach the captured step.")
                 self._eager_seen[key] = n + 1
+                first = n == 0 and not self._graphs
                 if n == self.graph_warmup - 1 and _os.environ.get("PYRO_AMD_HOIST", "1") != "0":
                     # the last eager step before the capture: note the constant tensors the model
                     # and guide create, so that the captured step need not fill them again
@@ -340,11 +459,33 @@ class SVI:
                     with fuser.scope(), rec:
                         out = self._eager_step(*args, **kwargs)
                     self._const_rec[key] = rec
-                    return out
-                return self._eager_step(*args, **kwargs)
+                else:
+                    out = self._eager_step(*args, **kwargs)
+                if first and self.graph_warmup > 1:
+                    # (what the model and guide can read from the host, after their first run: compared at
+                    #  capture time -- a scalar that moves while they run cannot be frozen)
+                    self._watch_first = _host_scalar_watch(self.model, self.guide)
+                return out
+            if self._watch_first is not None and not self._graphs:
+                moved = _host_scalars_changed(self._watch_first)
+                self._watch_first = None
+                if moved is not None:
+                    # the model / guide change a host scalar of their own on every call (a step counter,
+                    # an annealing schedule advanced inside the model): a replay would not
+                    self._self_mutating = True
+                    if self._auto_graph:
+                        self.hip_graph = False
+                        return self._eager_step(*args, **kwargs)
+                    warnings.warn("pyro_amd: SVI(hip_graph=True): the model or guide changed the host-side "
+                                  "value %r while it ran; the captured step freezes it" % (moved,))
             entry = self._capture(key, args, kwargs)
             if entry is None:                      # capture failed: stay eager
                 return self._eager_step(*args, **kwargs)
+            self._watch = _host_scalar_watch(self.model, self.guide)
+            self._store_generation = _PARAM_STORE.generation
+            if self._auto_graph and not _WARNED_CAPTURE[0]:
+                _WARNED_CAPTURE[0] = True
+                warnings.warn(_CAPTURE_NOTE.format(n=self.graph_warmup), CapturedStepWarning, stacklevel=2)
             self._eager_seen.pop(key, None)
             while len(self._graphs) > self.max_graphs:     # evict the least recently used capture
                 del self._graphs[next(iter(self._graphs))]

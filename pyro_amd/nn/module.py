@@ -233,6 +233,7 @@ class PyroModule(torch.nn.Module, metaclass=_PyroModuleMeta):
             _PARAM_STORE._params[full] = leaf
             _PARAM_STORE._param_to_name[leaf] = full
             _PARAM_STORE._constraints[full] = constraint
+            _PARAM_STORE.generation += 1
         return primitives.param(full, event_dim=event_dim)
 
     def _pyro_read_sample(self, name):

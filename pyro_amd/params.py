@@ -12,9 +12,14 @@ class ParamStoreDict:
         self._params = {}        # name -> unconstrained leaf tensor
         self._param_to_name = {}  # unconstrained leaf -> name
         self._constraints = {}
+        # bumped whenever the SET of leaf tensors changes (a parameter created, replaced, deleted, the store
+        # cleared, a scope entered or left): a captured SVI step holds the leaves it was captured with by
+        # address, so it is dropped when this moves (infer/svi.py)
+        self.generation = 0
 
     def clear(self):
         self._params, self._param_to_name, self._constraints = {}, {}, {}
+        self.generation += 1
 
     def items(self):
         for name in self._params:
@@ -43,6 +48,7 @@ class ParamStoreDict:
         unconstrained = self._params.pop(name)
         self._param_to_name.pop(unconstrained)
         self._constraints.pop(name)
+        self.generation += 1
 
     def __getitem__(self, name):
         unconstrained = self._params[name]
@@ -83,6 +89,7 @@ class ParamStoreDict:
         self._params[name] = unconstrained
         self._param_to_name[unconstrained] = name
         self._constraints[name] = constraint
+        self.generation += 1
 
     def setdefault(self, name, init_constrained_value, constraint=constraints.real):
         if name not in self._params:
@@ -124,6 +131,7 @@ class ParamStoreDict:
             self._params[name] = u
             self._param_to_name[u] = name
             self._constraints[name] = constraint
+        self.generation += 1
 
     def scope(self, state=None):
         """Context manager for several parameter stores in one process (param_store.py:337-372):
@@ -155,6 +163,7 @@ class ParamStoreDict:
             self._params[name] = u
             self._param_to_name[u] = name
             self._constraints[name] = snap["constraints"][name]
+        self.generation += 1
 
     def save(self, filename):
         torch.save(self.get_state(), filename)

@@ -1371,6 +1371,59 @@ def g_mcmc_potential():
 
 
 # ---------------------------------------------------------------------------------------------
+# FLAT models under MCMC: the reference's potential_fn (pyro/infer/mcmc/util.py:264-286, built by
+# initialize_model :370-482) and its autograd gradient (pyro/ops/integrator.py:68-94) at fixed unconstrained
+# points -- what pa_nuts_tree_run_advance_direct / pa_nuts_direct_potential assemble themselves (GLM kernel +
+# the latent sites' six fused families through the identity / exp transforms).
+# ---------------------------------------------------------------------------------------------
+def g_mcmc_direct_potential():
+    torch.set_default_dtype(torch.float64)
+    from pyro.infer.mcmc.util import initialize_model
+    gen = torch.Generator().manual_seed(11)
+    N, D = 300, 8
+    X = torch.randn(N, D, generator=gen)
+    w_true = torch.randn(D, generator=gen)
+    y = (torch.rand(N, generator=gen) < torch.sigmoid(X @ w_true + 0.3)).double()
+
+    def logreg(X, y):
+        w = pyro.sample("w", dist.Normal(X.new_zeros(D), 1.0).to_event(1))
+        b = pyro.sample("b", dist.Normal(X.new_zeros(()), 1.0))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=X @ w + b), obs=y)
+
+    def positive_site(X, y):
+        pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        logreg(X, y)
+
+    def all_families(X, y):
+        # every family the direct program scores, vector- and scalar-valued, tensor and broadcast parameters
+        pyro.sample("a_hc", dist.HalfCauchy(X.new_full((3,), 0.7)).to_event(1))
+        pyro.sample("c_ln", dist.LogNormal(X.new_tensor([0.2, -0.4]), X.new_tensor([0.5, 1.5])).to_event(1))
+        pyro.sample("d_ex", dist.Exponential(X.new_tensor(1.3)))
+        pyro.sample("e_hn", dist.HalfNormal(X.new_tensor([0.8, 2.0])).to_event(1))
+        pyro.sample("f_ga", dist.Gamma(X.new_tensor([2.5, 0.6]), X.new_tensor([1.5, 0.9])).to_event(1))
+        w = pyro.sample("w", dist.Normal(X.new_full((D,), 0.1), X.new_full((D,), 2.0)).to_event(1))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=X @ w), obs=y)
+
+    flat = {"X": X.numpy(), "y": y.numpy()}
+    for tag, model in (("logreg", logreg), ("positive_site", positive_site), ("all_families", all_families)):
+        pyro.set_rng_seed(0)
+        init, potential_fn, transforms, _ = initialize_model(model, (X, y))
+        flat[tag + "/sites"] = np.array(sorted(init), dtype="U16")
+        for k in range(5):
+            z = {n: (torch.randn(v.shape, generator=gen) * (0.25 if n == "w" else 0.7)).requires_grad_(True)
+                 for n, v in sorted(init.items())}
+            pe = potential_fn(z)
+            grads = torch.autograd.grad(pe, list(z.values()))
+            flat["%s/pe%d" % (tag, k)] = pe.item()
+            for (n, v), g_ in zip(z.items(), grads):
+                flat["%s/z%d/%s" % (tag, k, n)] = v.detach().numpy()
+                flat["%s/g%d/%s" % (tag, k, n)] = g_.numpy()
+    save("mcmc_direct_potential", **flat)
+
+
+# ---------------------------------------------------------------------------------------------
 # posterior marginals of model-enumerated sites (traceenum_elbo.py:224-251, 473-493): a global
 # Bernoulli and a plated Categorical sharing a Normal likelihood
 # ---------------------------------------------------------------------------------------------
@@ -1433,7 +1486,7 @@ def g_gamma_grad():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dists", "eight_schools", "logreg", "scale_mask", "integrator", "nuts",
-                             "adaptation", "enum", "hier", "hier_unsorted", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "marginals", "expfam", "tracegraph_prov", "arrowhead", "gamma_grad"]
+                             "adaptation", "enum", "hier", "hier_unsorted", "meanfield", "autocont", "hmm", "discrete_hmm", "tracegraph", "guide_enum", "mcmc_enum", "mcmc_potential", "mcmc_direct_potential", "marginals", "expfam", "tracegraph_prov", "arrowhead", "gamma_grad"]
     for w in which:
         globals()["g_" + w]()
 

@@ -92,9 +92,11 @@ class LogCoshPotential:
 
 
 def run_nuts_chains_vs_oracle(device, D, C, kind, multinomial, n_trans, fused, rtol=1e-8,
-                              max_tree_depth=6, dtype=torch.float64):
+                              max_tree_depth=6, dtype=torch.float64, async_chains=None, min_slots=None):
     """NUTS kernel (no adaptation) driven through MCMC, chain-for-chain against the recursive
-    restatement of the reference with the same keyed draws."""
+    restatement of the reference with the same keyed draws.  ``async_chains`` True / False pins the
+    schedule (spans of asynchronous chains: pa_nuts_tree_run_begin/_advance, captured rounds; or the
+    lock-step per-transition path) and asserts it ran; ``min_slots`` switches compacted rounds on."""
     Lam = make_precision(D, 11)
     g = np.random.default_rng(5)
     z0 = g.standard_normal((C, D)) * 0.4
@@ -106,6 +108,11 @@ def run_nuts_chains_vs_oracle(device, D, C, kind, multinomial, n_trans, fused, r
     kernel = NUTS(potential_fn=pot, step_size=1.0, adapt_step_size=False, adapt_mass_matrix=False,
                   use_multinomial_sampling=multinomial, max_tree_depth=max_tree_depth)
     kernel.use_fused_gaussian = fused
+    if async_chains is not None:
+        kernel.use_async_chains = async_chains
+        kernel.compact_chains = min_slots is not None
+        if min_slots is not None:
+            kernel.min_slots, kernel.sync_every, kernel.rounds_per_replay = min_slots, 2, 4
     mcmc = MCMC(kernel, num_samples=n_trans, warmup_steps=0, num_chains=C,
                 initial_params={"x": torch.tensor(z0, dtype=dtype, device=device)})
     # fixed per-chain step sizes / masses: set after setup through a hook on the first call
@@ -118,6 +125,13 @@ def run_nuts_chains_vs_oracle(device, D, C, kind, multinomial, n_trans, fused, r
                                                                      device=device)
     kernel.setup = setup
     mcmc.run()
+    if async_chains is not None:
+        assert kernel.bulk_ready == async_chains
+        assert (kernel._span_rounds > 0) == async_chains, "the asynchronous schedule did not run"
+        if async_chains and device.type == "cuda" and n_trans >= 8:
+            assert kernel._span_replays > 0, "no round of the span was a captured graph"
+        if async_chains and min_slots is not None:
+            assert kernel._span_compactions > 0, "no round was compacted"
     samples = mcmc.get_samples(group_by_chain=True)["x"].cpu().numpy()   # [C, S, D]
     assert samples.shape == (C, n_trans, D)
     pg = _np_potentials(kind, Lam)

@@ -102,8 +102,10 @@ def test_bench_torchrun_path_prints_one_line_with_two_ranks(tmp_path):
     outs = _run(dw.bench_worker, 2, (3,), tmp_path, "bench2")
     lines = [ln for ln in outs[0]["stdout"].splitlines() if ln.strip()]
     assert len(lines) == 1, outs[0]["stdout"]
+    assert len(lines[0]) < 4096                   # (the driver keeps a bounded tail of stdout)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 3
+    assert {"value", "ms_per_step", "roofline", "config", "dtype", "unit"} <= set(rec)
     assert rec["metric"].startswith("ELBO-grad steps/sec") and rec["value"] > 0
     assert rec["scaling"] == "weak" and rec["higher_is_better"] is True
     assert outs[1]["stdout"].strip() == ""
@@ -122,6 +124,7 @@ def test_bench_with_eight_ranks_including_both_nuts_blocks(tmp_path):
     outs = _run(dw.bench_worker, 8, (3, True), tmp_path, "bench8")
     lines = [ln for ln in outs[0]["stdout"].splitlines() if ln.strip()]
     assert len(lines) == 1, outs[0]["stdout"]
+    assert len(lines[0]) < 4096
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["steps"] == 3
     assert rec["value"] > 0 and rec["scaling"] == "weak"
@@ -133,7 +136,7 @@ def test_bench_with_eight_ranks_including_both_nuts_blocks(tmp_path):
     assert "error" not in mn, mn
     run = next(iter(mn["runs"].values()))
     assert mn["n_gpus"] == 8 and run["leapfrogs"] >= 8 * 2 * (5 + 3) and run["value"] > 0
-    assert list(rec)[-2:] == ["secondary", "secondary_model_nuts"]            # (the driver keeps the line's tail)
+    assert rec["full_record"] == "bench_full.json"
     for r in range(1, 8):
         assert outs[r]["stdout"].strip() == ""
 

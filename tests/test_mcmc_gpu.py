@@ -35,6 +35,22 @@ def test_nuts_chain_for_chain_f64(gpu, D, C, kind, multinomial, fused):
     mc.run_nuts_chains_vs_oracle(gpu, D, C, kind, multinomial, 3, fused=fused, rtol=1e-8)
 
 
+@pytest.mark.parametrize("D,C,multinomial,min_slots", [(33, 6, True, None), (130, 5, True, None),
+                                                        (20, 6, False, None), (33, 16, True, 2)])
+def test_asynchronous_chains_chain_for_chain_against_the_recursive_oracle(gpu, D, C, multinomial, min_slots):
+    """the ASYNCHRONOUS schedule (pa_nuts_tree_run_begin / _advance, a chain that
+    finishes a tree starts its next one in the same launch; rounds replayed from a captured hipGraph; with
+    min_slots also pa_nuts_tree_compact) against oracle/nuts.py -- the recursive restatement of
+    pyro/infer/mcmc/nuts.py:184-522, itself pinned on the unmodified reference's NUTS.sample -- directly,
+    float64, every chain, every one of 12 transitions, per-chain step sizes and masses; the lock-step
+    schedule beside it against the same oracle."""
+    mc.run_nuts_chains_vs_oracle(gpu, D, C, "logcosh", multinomial, 12, fused=False, rtol=1e-8,
+                                 async_chains=True, min_slots=min_slots)
+    if min_slots is None:
+        mc.run_nuts_chains_vs_oracle(gpu, D, C, "logcosh", multinomial, 4, fused=False, rtol=1e-8,
+                                     async_chains=False)
+
+
 def test_tree_kernel_equals_fused_kernel_f32(gpu):
     """Same keyed draws => the generic tree kernel (torch matmul potential) and the fused
     Gaussian kernel walk the same trees in float32 for the first transition."""
@@ -483,3 +499,66 @@ def test_direct_potential_runs_the_chains_of_the_generic_potential(gpu, model_na
         ma, mb = a[name].mean((0, 1)), b[name].mean((0, 1))
         sd = b[name].std((0, 1)) + 1e-6
         assert float(((ma - mb).abs() / sd).max()) < 0.2, name        # (64 x 150 draws: ~0.01 sd of MC error)
+
+
+@pytest.mark.parametrize("tag", ["logreg", "positive_site", "all_families"])
+def test_direct_potential_against_the_references_potential_fn(gpu, tag):
+    """the arithmetic pa_nuts_tree_run_advance_direct runs in registers -- the latent
+    sites' log-densities through the identity / exp transform with its Jacobian, added to the GLM kernel's
+    log-likelihood and gradient -- written out by pa_nuts_direct_potential and compared with the UNMODIFIED
+    reference's potential_fn + autograd at fixed unconstrained points (tests/golden/mcmc_direct_potential.npz:
+    pyro/infer/mcmc/util.py:264-286, 370-482), all six families.  float32 kernels against float64 values:
+    1e-4 of the potential, 1e-4 of the largest gradient entry."""
+    import numpy as np
+
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    from pyro_amd.infer.mcmc import NUTS
+
+    g = mc.load("mcmc_direct_potential")
+    X = torch.tensor(g["X"], dtype=torch.float32, device=gpu)
+    y = torch.tensor(g["y"], dtype=torch.float32, device=gpu)
+    N, D = X.shape
+
+    def logreg(X, y):
+        w = pyro.sample("w", dist.Normal(X.new_zeros(D), 1.0).to_event(1))
+        b = pyro.sample("b", dist.Normal(X.new_zeros(()), 1.0))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
+
+    def positive_site(X, y):
+        pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        logreg(X, y)
+
+    def all_families(X, y):
+        pyro.sample("a_hc", dist.HalfCauchy(X.new_full((3,), 0.7)).to_event(1))
+        pyro.sample("c_ln", dist.LogNormal(X.new_tensor([0.2, -0.4]), X.new_tensor([0.5, 1.5])).to_event(1))
+        pyro.sample("d_ex", dist.Exponential(X.new_tensor(1.3)))
+        pyro.sample("e_hn", dist.HalfNormal(X.new_tensor([0.8, 2.0])).to_event(1))
+        pyro.sample("f_ga", dist.Gamma(X.new_tensor([2.5, 0.6]), X.new_tensor([1.5, 0.9])).to_event(1))
+        w = pyro.sample("w", dist.Normal(X.new_full((D,), 0.1), X.new_full((D,), 2.0)).to_event(1))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
+
+    model = dict(logreg=logreg, positive_site=positive_site, all_families=all_families)[tag]
+    names = [str(n) for n in g[tag + "/sites"]]
+    pyro.set_rng_seed(0)
+    k = NUTS(model, max_tree_depth=4)
+    k.num_chains = 5
+    with pyro.validation_enabled(False):
+        k.setup(2, X, y)
+    prog = k._direct
+    assert prog is not None and [s["name"] for s in prog.sites] == names, "the model was not recognised"
+    z = np.stack([np.concatenate([np.atleast_1d(g["%s/z%d/%s" % (tag, i, n)]) for n in names]) for i in range(5)])
+    want_g = np.stack([np.concatenate([np.atleast_1d(g["%s/g%d/%s" % (tag, i, n)]) for n in names])
+                       for i in range(5)])
+    want_pe = np.array([g["%s/pe%d" % (tag, i)] for i in range(5)])
+    pe, grad = prog.potential(torch.tensor(z, dtype=torch.float32, device=gpu))
+    np.testing.assert_allclose(pe.cpu().numpy(), want_pe, rtol=1e-4)
+    scale = np.abs(want_g).max(axis=1, keepdims=True)
+    np.testing.assert_allclose(grad.cpu().numpy() / scale, want_g / scale, rtol=0, atol=1e-4)
+    # ... and the generic potential (handlers + autograd) of the same kernel object agrees with both
+    pe_g, grad_g = k._potential(torch.tensor(z, dtype=torch.float32, device=gpu))
+    np.testing.assert_allclose(pe_g.detach().cpu().numpy(), want_pe, rtol=1e-4)
+    np.testing.assert_allclose(grad_g.detach().cpu().numpy() / scale, want_g / scale, rtol=0, atol=1e-4)
+    k.cleanup()

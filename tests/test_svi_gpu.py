@@ -291,8 +291,10 @@ def test_default_svi_captures_only_what_can_be_a_graph(gpu):
 
     pyro.enable_validation(False)
     try:
+        from pyro_amd.infer.svi import CapturedStepWarning
         with warnings.catch_warnings():
             warnings.simplefilter("error")
+            warnings.simplefilter("ignore", CapturedStepWarning)    # (said once per process: its own test below)
             svi = build(examples.logreg_model)
             for _ in range(6):
                 svi.step(X, y)
@@ -587,7 +589,7 @@ def test_torch_manual_seed_alone_reproduces_a_run(gpu):
 
 
 def test_replay_enqueued_ahead_notices_tensors_the_model_closes_over(gpu):
-    """The default SVI enqueues its next replay ahead of the host.  It may only run if nothing it reads has
+    """SVI(prearm=True) enqueues its next replay ahead of the host.  It may only run if nothing it reads has
     changed since: not just step()'s arguments and the parameters, every tensor the captured step reads from
     outside itself -- here the prior scale the model closes over, rewritten in place between two steps.  The
     losses equal the eager run's bit for bit, before and after the change."""
@@ -615,11 +617,12 @@ def test_replay_enqueued_ahead_notices_tensors_the_model_closes_over(gpu):
             pyro.set_rng_seed(3)
             prior_scale.fill_(1.0)
             svi = SVI(model, AutoNormal(model, init_scale=0.1), pyro.optim.Adam({"lr": 0.02}),
-                      Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph)
+                      Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph,
+                      prearm=graph is None)
             losses = [svi.step(X, y) for _ in range(9)]
             if graph is None:
                 entry = next(iter(svi._graphs.values()))
-                assert entry.gate is not None and entry.armed, "the default step is not pre-armed here"
+                assert entry.gate is not None and entry.armed, "the step is not pre-armed here"
                 assert any(t is prior_scale for t in entry.reads)
             prior_scale.fill_(0.05)                 # (a tight prior: the loss jumps)
             losses += [svi.step(X, y) for _ in range(5)]
@@ -631,3 +634,161 @@ def test_replay_enqueued_ahead_notices_tensors_the_model_closes_over(gpu):
     assert abs(runs[0][0][9] - runs[0][0][8]) > 1.0
     for k in runs[0][1]:      # (the chained tail rounds this model's prior gradient once differently: 1 ulp)
         torch.testing.assert_close(runs[0][1][k], runs[1][1][k], rtol=1e-6, atol=1e-7)
+
+
+# ---- what a captured step freezes on the host -------------------------------------------------
+def _guard_run(gpu, graph, between=None, steps=14, model=None, seed=5, **kw):
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    model = model or examples.logreg_model
+    X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=2)
+    pyro.clear_param_store()
+    pyro.set_rng_seed(seed)
+    svi = SVI(model, AutoNormal(model, init_scale=0.1), pyro.optim.Adam({"lr": 0.02}),
+              Trace_ELBO(num_particles=16, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph, **kw)
+    losses, seen = [], []
+    for k in range(steps):
+        losses.append(svi.step(X, y))
+        if between is not None:
+            seen.append(between(k, svi))
+    return losses, seen, svi
+
+
+def test_default_svi_is_not_prearmed_and_reads_between_steps_see_the_step_just_made(gpu):
+    """the bare constructor must not enqueue step k+1 ahead of the caller.  A parameter
+    cloned between two steps (asynchronously, on the step's stream) is the parameter after step k -- the
+    eager run's, bit for bit; and no captured step of the default SVI has a gate."""
+    import pyro_amd as pyro
+    pyro.enable_validation(False)
+    try:
+        def snap(k, svi):
+            return pyro.param("AutoNormal.locs.w").detach().clone()       # enqueued, not synchronised
+        l0, s0, _ = _guard_run(gpu, False, snap)
+        l1, s1, svi = _guard_run(gpu, None, snap)
+        assert svi._graphs and not svi.prearm
+        assert all(e.gate is None and not e.armed for e in svi._graphs.values())
+        assert l0 == l1
+        for a, b in zip(s0, s1):
+            assert torch.equal(a, b)
+    finally:
+        pyro.enable_validation(True)
+
+
+def test_captured_step_is_remade_when_a_host_scalar_of_the_model_changes(gpu):
+    """a model that reads `self.beta` -- a Python float the training loop updates every
+    few steps (KL annealing) -- trains with the CURRENT value: the capture is dropped when the scalar
+    moves, a few eager steps follow, then it is captured anew.  Losses equal the eager run's bit for bit."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+
+    class Annealed:
+        def __init__(self):
+            self.beta = 1.0
+
+        def __call__(self, X, y):
+            w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), 1.0).to_event(1))
+            b = pyro.sample("b", dist.Normal(X.new_zeros(()), 1.0))
+            with pyro.plate("data", X.shape[0]), pyro.poutine.scale(scale=self.beta):
+                pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
+
+    pyro.enable_validation(False)
+    try:
+        runs = []
+        for graph in (False, None):
+            m = Annealed()
+            captured = []
+
+            def anneal(k, svi, m=m, captured=captured):
+                captured.append(len(svi._graphs))
+                if k == 7:
+                    m.beta = 0.25
+            losses, _, svi = _guard_run(gpu, graph, anneal, steps=16, model=m)
+            runs.append(losses)
+            if graph is None:
+                # captured before the change, dropped by it, captured again after the eager warm-up
+                assert captured[6] == 1 and captured[8] == 0 and captured[-1] == 1, captured
+        assert runs[0] == runs[1], runs
+        assert abs(runs[0][8] - runs[0][7]) > 100.0      # (the likelihood's weight changed: the loss jumps)
+    finally:
+        pyro.enable_validation(True)
+
+
+def test_model_that_mutates_its_own_host_state_is_never_captured(gpu):
+    """A scalar that moves while the model RUNS (a step counter driving a schedule) cannot be frozen: the
+    bare constructor stays eager, silently, and follows the eager trajectory trivially."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+
+    class Counting:
+        calls = 0
+
+        def __init__(self):
+            self.calls = 0
+
+        def __call__(self, X, y):
+            self.calls += 1
+            w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), 1.0).to_event(1))
+            with pyro.plate("data", X.shape[0]), pyro.poutine.scale(scale=min(1.0, self.calls / 8.0)):
+                pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, None)), obs=y)
+
+    pyro.enable_validation(False)
+    try:
+        l0, _, _ = _guard_run(gpu, False, model=Counting(), steps=10)
+        l1, _, svi = _guard_run(gpu, None, model=Counting(), steps=10)
+        assert not svi._graphs and not svi.hip_graph and svi._self_mutating
+        assert l0 == l1
+    finally:
+        pyro.enable_validation(True)
+
+
+def test_captured_step_is_dropped_when_the_param_store_is_cleared(gpu):
+    """pyro.clear_param_store() followed by re-initialisation on the SAME SVI object: the captured step holds
+    the old leaves by address; the store's generation moved, so it is dropped and the new parameters train
+    (equal to a fresh eager run from the same seed)."""
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=2)
+    pyro.enable_validation(False)
+    try:
+        def run(graph, restart):
+            pyro.clear_param_store()
+            pyro.set_rng_seed(5)
+            guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+            optim = pyro.optim.Adam({"lr": 0.02})
+            svi = SVI(examples.logreg_model, guide, optim,
+                      Trace_ELBO(num_particles=16, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph)
+            out = [svi.step(X, y) for _ in range(8)]
+            if restart:
+                pyro.clear_param_store()
+                pyro.set_rng_seed(5)
+                guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+                svi.guide, svi.optim = guide, pyro.optim.Adam({"lr": 0.02})
+                out = [svi.step(X, y) for _ in range(8)]
+            return out, {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
+        l0, p0 = run(False, False)
+        l1, p1 = run(None, True)
+        assert l0 == l1
+        for k in p0:
+            assert torch.equal(p0[k], p1[k]), k
+    finally:
+        pyro.enable_validation(True)
+
+
+def test_self_capturing_svi_says_so_once(gpu):
+    import warnings
+
+    from pyro_amd.infer import svi as svi_mod
+    svi_mod._WARNED_CAPTURE[0] = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _guard_run(gpu, None, steps=6)
+        _guard_run(gpu, None, steps=6)
+        _guard_run(gpu, True, steps=6)
+    said = [x for x in w if issubclass(x.category, svi_mod.CapturedStepWarning)]
+    assert len(said) == 1 and "hip_graph=False" in str(said[0].message)

@@ -1,0 +1,96 @@
+"""What a captured SVI step freezes on the host, and the guards around it: pre-arming is
+opt-in, the Python scalars a model / guide can reach are watched, the parameter store has a generation.
+The reference re-runs the model on every step (pyro/infer/svi.py:134-162), so it needs none of this; a
+backend that replays a graph has to notice what the reference would have seen."""
+import functools
+
+import torch
+
+import pyro_amd as pyro
+from pyro_amd.infer import SVI, Trace_ELBO
+from pyro_amd.infer import svi as svi_mod
+
+
+def test_prearm_is_opt_in():
+    class _Optim:
+        zeroes_grads = True
+
+        def __call__(self, params, *a, **k):
+            pass
+    for kw, want in (({}, False), ({"hip_graph": True}, False), ({"prearm": True, "hip_graph": True}, True)):
+        s = SVI(lambda: None, lambda: None, _Optim(), Trace_ELBO(), **kw)
+        assert s.prearm is want, kw
+
+
+BETA = 0.5
+
+
+def test_watch_sees_closures_globals_partials_attributes_and_module_flags():
+    scale = 2.0
+
+    def closure_model(x):
+        return x * scale * BETA
+
+    class Obj:
+        def __init__(self):
+            self.beta, self.name, self.t = 1.0, "a", torch.zeros(1)
+
+        def __call__(self, x):
+            return x * self.beta
+
+    net = torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.Dropout(0.5))
+
+    class WithNet:
+        def __init__(self):
+            self.net = net
+
+        def model(self, x):
+            return self.net(x)
+
+    o, w = Obj(), WithNet()
+    part = functools.partial(closure_model)
+    watch = svi_mod._host_scalar_watch(part, o, w.model, net)
+    names = {k for _, k, _ in watch[0]}
+    assert {"BETA", "beta", "name", "training"} <= names and len(watch[1]) == 1
+    assert svi_mod._host_scalars_changed(watch) is None
+    o.beta = 0.25
+    assert svi_mod._host_scalars_changed(watch) == "beta"
+    o.beta = 1.0
+    assert svi_mod._host_scalars_changed(watch) is None
+    net.eval()
+    assert svi_mod._host_scalars_changed(watch) == "training"
+    net.train()
+    global BETA
+    BETA = 0.75
+    assert svi_mod._host_scalars_changed(watch) == "BETA"
+    BETA = 0.5
+    scale = 3.0                          # noqa: F841  (the closure cell of closure_model)
+    assert svi_mod._host_scalars_changed(watch) == "<closure>"
+
+
+def test_watch_of_the_bench_model_is_small():
+    from pyro_amd import examples
+    from pyro_amd.infer.autoguide import AutoNormal
+    guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+    maps, cells = svi_mod._host_scalar_watch(examples.logreg_model, guide)
+    assert len(maps) + len(cells) < 64          # (compared before every replay)
+
+
+def test_param_store_generation_moves_with_the_set_of_leaves():
+    pyro.clear_param_store()
+    store = pyro.get_param_store()
+    g0 = store.generation
+    pyro.param("a", torch.zeros(2))
+    g1 = store.generation
+    assert g1 > g0
+    pyro.param("a")                       # a read creates nothing
+    pyro.param("a", torch.ones(2))        # nor does an init for an existing name
+    assert store.generation == g1
+    with store.scope():
+        assert store.generation > g1
+    g2 = store.generation
+    del store["a"]
+    assert store.generation > g2
+    g3 = store.generation
+    pyro.clear_param_store()
+    assert store.generation > g3
