@@ -416,10 +416,12 @@ def bench_model_nuts(dev, rank, world, args):
                                   compactions=getattr(kernel, "_span_compactions", 0))
 
     out = {}
-    # (N, chains, warm-up, samples): the 1e6-row posterior is ~30x tighter than the prior's scale, so chains
-    # started at the reference's uniform(-2, 2) points spend a short warm-up travelling with deep trees --
-    # that run is a throughput measurement (its R-hat says so), the 1e5-row runs are converged ones
-    plan = [(100_000, C, 5 * W, 10 * S), (100_000, 4 * C, 2 * W, 4 * S), (1_000_000, C, max(W // 2, 10), max(S // 4, 5))]
+    # (N, chains, warm-up, samples).  The 1e6-row posterior is ~30x tighter than the prior's scale: chains started
+    # at the reference's uniform(-2, 2) points travel for ~100 transitions with deep trees before the step size
+    # and the diagonal mass have adapted (tools/nuts_model_converge.py: 150 warm-up transitions -> R-hat 1.07,
+    # 300 -> 1.045, and the sampling phase then runs ~7 leaves per transition at 0.94 round occupancy); round 5
+    # timed 50 + 25 transitions of chains that had not arrived (R-hat 8.4, occupancy 0.28)
+    plan = [(100_000, C, 5 * W, 10 * S), (100_000, 4 * C, 2 * W, 4 * S), (1_000_000, C, 3 * W, 2 * S)]
     if dev.type != "cuda":                 # the plumbing test of tests/test_distributed_cpu.py
         plan = [(args.plate, C, W, S)]
     X = y = None
@@ -530,7 +532,7 @@ def _pick(d, *keys):
 
 def _file_only(src):
     """profiles/<file> of a "profiles/<file> (how ...)" source string."""
-    return src.split(" ")[0] if isinstance(src, str) else src
+    return src.split(" ")[0].rstrip(":") if isinstance(src, str) else src
 
 
 def reference_cpu_record():
