@@ -57,6 +57,16 @@ __device__ __forceinline__ void glm_finalize_body(
         for (int u = 0; u < 24; ++u) acc += (double)v[u];
       }
     }
+    {
+      // (a thread's 16 records of the 512-workgroup default launch: one round trip, not two)
+      float v[16];
+      for (; blk + 15 * FIN_GROUPS < nblocks; blk += 16 * FIN_GROUPS) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = base[(int64_t)(blk + u * FIN_GROUPS) * REC];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (double)v[u];
+      }
+    }
     float v[8];
     for (; blk + 7 * FIN_GROUPS < nblocks; blk += 8 * FIN_GROUPS) {   // 8 loads in flight
 #pragma unroll

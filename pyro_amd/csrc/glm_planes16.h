@@ -294,9 +294,25 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
                          (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + (wave * PW) * 1024);
 #pragma unroll
     for (int k = 0; k < PW; ++k) dma16(src + k * 1024, dst + k * 1024);
-    int64_t row = (stc * NRT + rt) * 32 + l31;
-    if constexpr (!GROUPED) row = row < N ? row : N - 1;
-    dma4(y + row, lds_base + C::OFS_Y + (bi * 4 + wave) * 256);
+    if constexpr (PRIV) {
+      int64_t row = (stc * NRT + rt) * 32 + l31;
+      if constexpr (!GROUPED) row = row < N ? row : N - 1;
+      dma4(y + row, lds_base + C::OFS_Y + (bi * 4 + wave) * 256);
+    } else if (wave == 0) {
+      // the super-tile's 64 observations are ONE piece (64 lanes x 4 B) issued by wave 0 for the workgroup
+      // (every wave used to fetch its own 32: four LDS-DMA issues per super-tile instead of one; an LDS-DMA
+      // instruction costs ~60-90 cycles of issue beside the compute stream)
+      int64_t row = stc * (NRT * 32) + lane;
+      if constexpr (!GROUPED) row = row < N ? row : N - 1;
+      dma4(y + row, lds_base + C::OFS_Y + bi * 1024);
+    }
+  };
+  // this wave's LDS-DMA instructions per tile (wave-uniform)
+  const int my_ndma = (PRIV || wave == 0) ? C::NDMA : C::NDMA - 1;
+  auto wait_tiles_in_flight = [&](auto kconst) {
+    constexpr int K = decltype(kconst)::value;
+    if (my_ndma == C::NDMA) wait_vmcnt<K * C::NDMA>();
+    else wait_vmcnt<K * (C::NDMA - 1)>();
   };
 
 #pragma unroll
@@ -455,12 +471,20 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 
   // the wave's 32 observations of ring slot b become 2^14 (y - 1/2) in place (0 past the end)
   auto prep_rows = [&](int b_, int64_t st_) -> bool {
-    float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + (b_ * 4 + wave) * 256);
     const int64_t rows_left = n_rows - ((st_ - row_st0) * NRT + rt) * 32;        // scalar
     const bool okr = (int64_t)l31 < rows_left;
     // (GROUPED: the image already holds the transformed observations)
-    if constexpr (!GROUPED)
-      if (lane < 32) ys_[lane] = okr ? __builtin_fmaf(ys_[lane], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
+    if constexpr (!GROUPED) {
+      if constexpr (PRIV) {
+        float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + (b_ * 4 + wave) * 256);
+        if (lane < 32) ys_[lane] = okr ? __builtin_fmaf(ys_[lane], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
+      } else if (wave == 0) {
+        // the shared slot, all 64 rows of the super-tile (the other waves read it behind the tile's barrier)
+        float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + b_ * 1024);
+        const int64_t left64 = n_rows - (st_ - row_st0) * (NRT * 32);
+        ys_[lane] = (int64_t)lane < left64 ? __builtin_fmaf(ys_[lane], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
+      }
+    }
     return okr;
   };
   auto gemm1_aux = [&](bool okr) -> f32x16v {
@@ -584,7 +608,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   //      and GEMM2 of tile it ---------------------------------------------------------------------
   f32x16v acc_cur = {};
   if (my_count > 0) {
-    wait_vmcnt<(NB - 2) * C::NDMA>();
+    wait_tiles_in_flight(std::integral_constant<int, NB - 2>{});
     if constexpr (!PRIV) __builtin_amdgcn_s_barrier();
     const bool ok0 = prep_rows(0, st);
     acc_cur = gemm1_aux(ok0);
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     }
     if ((it & 7) == 7) renorm();
     int bn = bi + 1 == NB ? 0 : bi + 1;
-    wait_vmcnt<(NB - 3) * C::NDMA>();
+    wait_tiles_in_flight(std::integral_constant<int, NB - 3>{});
     if constexpr (!PRIV) __builtin_amdgcn_s_barrier();
     {
       int bf = bi + (NB - 1);
@@ -633,7 +657,8 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     }
     const unsigned char* Xc = smem + C::OFS_RING + (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + rt * GLMH_TILE);
     const unsigned char* Xn = smem + C::OFS_RING + (PRIV ? (wave * NB + bn) * GLMH_TILE : bn * ST_BYTES + rt * GLMH_TILE);
-    const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y + (bi * 4 + wave) * 256);
+    const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y +
+                                                      (PRIV ? (bi * 4 + wave) * 256 : bi * 1024 + rt * 128));
     const uint32_t tr_a = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_a;
     const uint32_t tr_b = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_b;
 
