@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 6
+#define PA_ABI_VERSION 7
 
 enum { PA_OK = 0, PA_ERR_INVALID = -1, PA_ERR_UNSUPPORTED = -2, PA_ERR_LAUNCH = -3 };
 
@@ -1020,6 +1020,21 @@ int pa_chain_debug_stamps(void* stamps32);
  * constants of the source).  pa_rtc_launch: grid x block threads on `stream`, pointers[0..n). */
 #define PA_RTC_MAX_POINTERS 384
 int pa_rtc_compile(const char* source, const char* kernel_name, void** function_out);
+/* The same with a PERSISTENT cache: `cache_file` (or NULL) names the code object of this source -- the caller
+ * derives the name from a digest of the source, the compiler's version (pa_rtc_version) and the options.  An
+ * existing file is loaded with hipModuleLoadData and hiprtc is not called (*compiled_out = 0); otherwise the
+ * source is compiled (*compiled_out = 1) and the code object written there (private name + rename).  A second
+ * process warms up a step without a single hiprtc call. */
+int pa_rtc_compile_cached(const char* source, const char* kernel_name, const char* cache_file,
+                          void** function_out, int* compiled_out);
+int pa_rtc_version(int* hiprtc_major, int* hiprtc_minor, int* runtime_version);
+/* Launches made while their stream is being captured keep a parameter block alive for the captured graph.
+ * pa_rtc_blocks_begin opens a scope on the calling thread that OWNS the blocks of such launches until
+ * pa_rtc_blocks_end (*n_blocks_out: how many it holds); pa_rtc_blocks_free releases them -- call it when the
+ * captured graph is destroyed.  Without a scope a block lives as long as the process. */
+void* pa_rtc_blocks_begin(void);
+int pa_rtc_blocks_end(void* scope, int64_t* n_blocks_out);
+int pa_rtc_blocks_free(void* scope);
 int pa_rtc_launch(void* function, uint32_t grid, uint32_t block, const void* const* pointers,
                   int n_pointers, pa_stream_t stream);
 

@@ -17,8 +17,10 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <algorithm>
 #include <optional>
 #include <tuple>
+#include <vector>
 
 #include "pyro_amd.h"
 
@@ -154,6 +156,313 @@ void adam_step(at::Tensor param, at::Tensor grad, at::Tensor exp_avg, at::Tensor
         "adam_step");
 }
 
+
+// ---- typed ops for the rest of a step (round 6): the operations a Pyro maintainer would bind first, with real
+//      argument lists -- loadable from C++ / TorchScript, readable in a traced graph.  (Python keeps a generic
+//      (Tensor[] tensors, int spec) trampoline for the remaining autograd Functions: ops/torch_library.py.)
+
+int dtype_of(const at::Tensor& t, const char* who) {
+  TORCH_CHECK(t.is_cuda() && (t.scalar_type() == at::kFloat || t.scalar_type() == at::kDouble), "pyro_amd::", who,
+              ": float32 / float64 tensors on the GPU");
+  return t.scalar_type() == at::kFloat ? PA_F32 : PA_F64;
+}
+
+// an operand of a site as a strided [rows, cols] view of the value's frame: a scalar, the full frame (contiguous),
+// one row [cols] / [1, cols] or one column [rows, 1] -- ExpandedDistribution's stride-0 views
+// (pyro/distributions/torch_distribution.py:483-488) without materialising them
+pa_view2d view2d(const std::optional<at::Tensor>& t, int64_t rows, int64_t cols, at::ScalarType st, const char* who) {
+  pa_view2d v{nullptr, 0, 0};
+  if (!t.has_value() || !t->defined()) return v;
+  TORCH_CHECK(t->is_cuda() && t->scalar_type() == st, "pyro_amd::", who, ": operand dtype / device");
+  v.ptr = t->data_ptr();
+  const int64_t n = t->numel();
+  if (n == 1) return v;
+  TORCH_CHECK(t->is_contiguous(), "pyro_amd::", who, ": operands must be contiguous");
+  if (n == rows * cols) { v.stride_row = cols; v.stride_col = 1; }
+  else if (n == cols && (t->dim() <= 1 || t->size(-1) == cols)) { v.stride_col = 1; }
+  else if (n == rows) { v.stride_row = 1; }
+  else TORCH_CHECK(false, "pyro_amd::", who, ": operand of ", n, " elements does not broadcast to [", rows, ", ", cols, "]");
+  return v;
+}
+
+void frame_of(const at::Tensor& value, int64_t* rows, int64_t* cols) {
+  *cols = value.dim() == 0 ? 1 : value.size(-1);
+  *rows = *cols > 0 ? value.numel() / *cols : 0;
+}
+
+// site["fn"].log_prob(value) -> scale_and_mask -> sum over the last dim (+ the grand total):
+// pyro/poutine/trace_struct.py:264-278, pyro/distributions/util.py:311-328
+std::tuple<at::Tensor, at::Tensor> dist_log_prob_sum(int64_t dist, const at::Tensor& value,
+                                                     const std::optional<at::Tensor>& p0,
+                                                     const std::optional<at::Tensor>& p1,
+                                                     const std::optional<at::Tensor>& mask, double scale) {
+  const int dt = dtype_of(value, "dist_log_prob_sum");
+  TORCH_CHECK(value.is_contiguous(), "pyro_amd::dist_log_prob_sum: contiguous value");
+  int64_t rows, cols;
+  frame_of(value, &rows, &cols);
+  const auto st = value.scalar_type();
+  std::optional<at::Tensor> val = value;
+  const size_t ws_bytes = pa_dist_log_prob_sum_workspace(rows, cols);
+  at::Tensor ws = at::empty({(int64_t)(ws_bytes < 16 ? 16 : ws_bytes)}, value.options().dtype(at::kByte));
+  at::Tensor rowsum = at::empty({rows}, value.options()), total = at::empty({}, value.options());
+  pa_view2d m{nullptr, 0, 0};
+  if (mask.has_value() && mask->defined()) {
+    TORCH_CHECK(mask->scalar_type() == at::kBool || mask->scalar_type() == at::kByte, "pyro_amd::dist_log_prob_sum: bool mask");
+    m = view2d(mask, rows, cols, mask->scalar_type(), "dist_log_prob_sum");
+  }
+  check(pa_dist_log_prob_sum((int)dist, dt, rowsum.data_ptr(), total.data_ptr(),
+                             view2d(val, rows, cols, st, "dist_log_prob_sum"),
+                             view2d(p0, rows, cols, st, "dist_log_prob_sum"),
+                             view2d(p1, rows, cols, st, "dist_log_prob_sum"), m, scale, rows, cols, ws.data_ptr(),
+                             ws_bytes, current_stream()),
+        "dist_log_prob_sum");
+  return {rowsum, total};
+}
+
+// the ELBO assembly of Trace_ELBO in one launch: sum_i coef[i] * sum(log_prob_i) (pyro/infer/trace_elbo.py:
+// 82-112, trace_struct.py:248-288); entries beyond PA_MULTI_MAX_ENTRIES are chained with accumulate = 1
+at::Tensor multi_log_prob_sum(at::IntArrayRef dist, at::TensorList value, const c10::List<std::optional<at::Tensor>>& p0,
+                              const c10::List<std::optional<at::Tensor>>& p1, at::ArrayRef<double> coef,
+                              double coef_all) {
+  const size_t n = value.size();
+  TORCH_CHECK(n >= 1 && dist.size() == n && p0.size() == n && p1.size() == n && coef.size() == n,
+              "pyro_amd::multi_log_prob_sum: one dist / p0 / p1 / coef per value");
+  const int dt = dtype_of(value[0], "multi_log_prob_sum");
+  at::Tensor total = at::zeros({}, value[0].options());
+  std::vector<pa_site_entry> e(n);
+  for (size_t i = 0; i < n; ++i) {
+    TORCH_CHECK(value[i].scalar_type() == value[0].scalar_type() && value[i].is_contiguous(),
+                "pyro_amd::multi_log_prob_sum: values of one dtype, contiguous");
+    pa_site_entry& s = e[i];
+    s = pa_site_entry{};
+    s.dist = (int32_t)dist[i];
+    frame_of(value[i], &s.rows, &s.cols);
+    TORCH_CHECK(s.rows * s.cols <= PA_MULTI_MAX_ELEMS, "pyro_amd::multi_log_prob_sum: a site of more than ",
+                PA_MULTI_MAX_ELEMS, " elements goes through dist_log_prob_sum");
+    const auto st = value[i].scalar_type();
+    std::optional<at::Tensor> v = value[i], a = p0.get(i), b = p1.get(i);
+    s.value = view2d(v, s.rows, s.cols, st, "multi_log_prob_sum");
+    s.p0 = view2d(a, s.rows, s.cols, st, "multi_log_prob_sum");
+    s.p1 = view2d(b, s.rows, s.cols, st, "multi_log_prob_sum");
+    s.mask = pa_view2d{nullptr, 0, 0};
+    s.coef = coef[i];
+    s.chain_next = -1;
+  }
+  for (size_t at_ = 0; at_ < n; at_ += PA_MULTI_MAX_ENTRIES) {
+    const int k = (int)std::min<size_t>(PA_MULTI_MAX_ENTRIES, n - at_);
+    check(pa_multi_log_prob_sum(dt, total.data_ptr(), e.data() + at_, k, coef_all, at_ == 0 ? 0 : 1, current_stream()),
+          "multi_log_prob_sum");
+  }
+  return total;
+}
+
+// AutoNormal's draw of every latent site in one launch (pyro/infer/autoguide/guides.py:415-603):
+// z_s = loc_s + softplus(rho_s) eps_s, eps from the keyed Philox stream at offsets[s] (+ *offset_dev)
+std::tuple<std::vector<at::Tensor>, std::vector<at::Tensor>, std::vector<at::Tensor>> meanfield_normal_sample(
+    at::TensorList loc, at::TensorList rho, int64_t P, int64_t seed, at::IntArrayRef offsets,
+    const std::optional<at::Tensor>& offset_dev) {
+  const size_t n = loc.size();
+  TORCH_CHECK(n >= 1 && n <= PA_MF_MAX_SITES && rho.size() == n && offsets.size() == n && P >= 1,
+              "pyro_amd::meanfield_normal_sample: 1..", PA_MF_MAX_SITES, " sites, one rho / offset per loc");
+  const int dt = dtype_of(loc[0], "meanfield_normal_sample");
+  std::vector<at::Tensor> z(n), scale(n), eps(n), loc_out(n);
+  std::vector<pa_mf_site> s(n);
+  for (size_t i = 0; i < n; ++i) {
+    TORCH_CHECK(loc[i].scalar_type() == loc[0].scalar_type() && rho[i].scalar_type() == loc[0].scalar_type() &&
+                    loc[i].is_contiguous() && rho[i].is_contiguous() && rho[i].numel() == loc[i].numel(),
+                "pyro_amd::meanfield_normal_sample: loc / rho of one dtype and size per site");
+    const int64_t m = loc[i].numel();
+    z[i] = at::empty({P, m}, loc[i].options());
+    eps[i] = at::empty({P, m}, loc[i].options());
+    scale[i] = at::empty({m}, loc[i].options());
+    loc_out[i] = at::empty({m}, loc[i].options());
+    s[i] = pa_mf_site{};
+    s[i].loc = loc[i].data_ptr(); s[i].rho = rho[i].data_ptr();
+    s[i].z = z[i].data_ptr(); s[i].scale = scale[i].data_ptr(); s[i].loc_out = loc_out[i].data_ptr();
+    s[i].eps = eps[i].data_ptr();
+    s[i].n = m; s[i].offset = (uint64_t)offsets[i];
+  }
+  const uint64_t* od = nullptr;
+  if (offset_dev.has_value() && offset_dev->defined()) {
+    TORCH_CHECK(offset_dev->is_cuda() && offset_dev->scalar_type() == at::kLong, "pyro_amd::meanfield_normal_sample: offset_dev int64");
+    od = (const uint64_t*)offset_dev->data_ptr();
+  }
+  check(pa_meanfield_normal_sample(dt, s.data(), (int)n, P, (uint64_t)seed, od, current_stream()), "meanfield_normal_sample");
+  return {z, scale, eps};
+}
+
+// the positive-support transform of a parameter / site in one launch: value = lower + exp(u), log|dv/du| = u
+// (torch.distributions.constraint_registry biject_to(positive / greater_than); pyro/params/param_store.py:138-199)
+std::tuple<at::Tensor, at::Tensor> exp_site(const at::Tensor& u, double lower) {
+  const int dt = dtype_of(u, "exp_site");
+  TORCH_CHECK(u.is_contiguous(), "pyro_amd::exp_site: contiguous u");
+  int64_t rows, cols;
+  frame_of(u, &rows, &cols);
+  at::Tensor value = at::empty_like(u), ld = at::empty({rows}, u.options());
+  check(pa_exp_site_fwd(dt, u.data_ptr(), rows, cols, lower, value.data_ptr(), ld.data_ptr(), current_stream()), "exp_site");
+  return {value, ld};
+}
+
+at::Tensor exp_site_bwd(const at::Tensor& value, const std::optional<at::Tensor>& g_value,
+                        const std::optional<at::Tensor>& g_log_density, double lower) {
+  const int dt = dtype_of(value, "exp_site_bwd");
+  int64_t rows, cols;
+  frame_of(value, &rows, &cols);
+  at::Tensor g_u = at::empty_like(value);
+  check(pa_exp_site_bwd(dt, value.data_ptr(), g_value.has_value() && g_value->defined() ? g_value->data_ptr() : nullptr,
+                        g_log_density.has_value() && g_log_density->defined() ? g_log_density->data_ptr() : nullptr,
+                        rows, cols, lower, g_u.data_ptr(), current_stream()),
+        "exp_site_bwd");
+  return g_u;
+}
+
+// AutoMultivariateNormal's draw: z = loc + (softplus(rho) (*) tril(A)) eps and log q(z), all particles
+// (pyro/infer/autoguide/guides.py:820-905)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> mvn_tril_sample(const at::Tensor& loc, const at::Tensor& rho,
+                                                               const at::Tensor& A, int64_t P, int64_t seed,
+                                                               int64_t offset, const std::optional<at::Tensor>& offset_dev) {
+  const int dt = dtype_of(loc, "mvn_tril_sample");
+  const int64_t n = loc.numel();
+  TORCH_CHECK(rho.numel() == n && A.numel() == n * n && loc.is_contiguous() && rho.is_contiguous() && A.is_contiguous() &&
+                  rho.scalar_type() == loc.scalar_type() && A.scalar_type() == loc.scalar_type() && P >= 1,
+              "pyro_amd::mvn_tril_sample: loc[n], rho[n], A[n, n] of one dtype");
+  at::Tensor eps = at::empty({P, n}, loc.options()), z = at::empty({P, n}, loc.options()), logq = at::empty({P}, loc.options());
+  const uint64_t* od = nullptr;
+  if (offset_dev.has_value() && offset_dev->defined()) od = (const uint64_t*)offset_dev->data_ptr();
+  check(pa_mvn_tril_sample(dt, loc.data_ptr(), rho.data_ptr(), A.data_ptr(), n, P, (uint64_t)seed, (uint64_t)offset, od,
+                           0, eps.data_ptr(), z.data_ptr(), logq.data_ptr(), current_stream()),
+        "mvn_tril_sample");
+  return {eps, z, logq};
+}
+
+// one elimination step of the plated sum-product: out = logsumexp over frame dim rdim of the sum of the terms,
+// each term EXPANDED (stride 0) to the frame `sizes` (pyro/ops/contract.py:79-160, pyro/ops/einsum/torch_log.py:14-55)
+at::Tensor logsumexp_terms(at::TensorList terms, at::IntArrayRef sizes, int64_t rdim) {
+  const int nd = (int)sizes.size(), nt = (int)terms.size();
+  TORCH_CHECK(nt >= 1 && nt <= PA_LSE_MAX_TERMS && nd >= 1 && nd <= PA_LSE_MAX_DIMS && rdim >= 0 && rdim < nd,
+              "pyro_amd::logsumexp_terms: 1..", PA_LSE_MAX_TERMS, " terms over a frame of 1..", PA_LSE_MAX_DIMS, " dims");
+  const int dt = dtype_of(terms[0], "logsumexp_terms");
+  pa_lse_term t[PA_LSE_MAX_TERMS];
+  std::vector<at::Tensor> keep;
+  for (int k = 0; k < nt; ++k) {
+    at::Tensor e = terms[k].expand(sizes);          // (a view: stride 0 where the term does not depend on a dim)
+    TORCH_CHECK(e.scalar_type() == terms[0].scalar_type() && e.is_cuda(), "pyro_amd::logsumexp_terms: one dtype");
+    t[k].ptr = e.data_ptr();
+    for (int d = 0; d < PA_LSE_MAX_DIMS; ++d) t[k].strides[d] = d < nd ? (sizes[d] == 1 ? 0 : e.stride(d)) : 0;
+    keep.push_back(e);
+  }
+  std::vector<int64_t> kept;
+  for (int d = 0; d < nd; ++d) if (d != rdim) kept.push_back(sizes[d]);
+  at::Tensor out = at::empty(kept, terms[0].options());
+  check(pa_logsumexp_terms(dt, out.data_ptr(), nt, t, nd, sizes.data(), (int)rdim, current_stream()), "logsumexp_terms");
+  return out;
+}
+
+// a chain of T enumerated variables with K states summed out for every batch element: log Z and its gradient
+// (the unary / pairwise posteriors) in one launch (pyro/ops/contract.py:79-160 applied T times under pyro.markov;
+// pyro/distributions/hmm.py:_sequential_logmatmulexp)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> logchain(const at::Tensor& unary, const at::Tensor& pairwise) {
+  const int dt = dtype_of(unary, "logchain");
+  TORCH_CHECK(unary.dim() == 3 && unary.is_contiguous() && pairwise.is_contiguous() && pairwise.scalar_type() == unary.scalar_type(),
+              "pyro_amd::logchain: unary [B, T, K] contiguous, pairwise [B | 1, T - 1 | 1, K, K] contiguous");
+  const int64_t B = unary.size(0), T = unary.size(1), K = unary.size(2);
+  TORCH_CHECK(pairwise.dim() == 4 && pairwise.size(2) == K && pairwise.size(3) == K &&
+                  (pairwise.size(0) == B || pairwise.size(0) == 1) && (pairwise.size(1) == T - 1 || pairwise.size(1) == 1),
+              "pyro_amd::logchain: pairwise [B | 1, T - 1 | 1, K, K]");
+  const int64_t sb = pairwise.size(0) == 1 ? 0 : pairwise.stride(0), ss = pairwise.size(1) == 1 ? 0 : pairwise.stride(1);
+  const size_t ws_bytes = pa_logchain_workspace(dt, B, T, K);
+  at::Tensor ws = at::empty({(int64_t)(ws_bytes < 16 ? 16 : ws_bytes)}, unary.options().dtype(at::kByte));
+  at::Tensor log_z = at::empty({B}, unary.options()), gu = at::empty_like(unary),
+             gp = at::zeros({B, T > 1 ? T - 1 : 0, K, K}, unary.options());
+  check(pa_logchain_fwd_bwd(dt, unary.data_ptr(), pairwise.data_ptr(), sb, ss, B, T, K, log_z.data_ptr(), gu.data_ptr(),
+                            gp.data_ptr(), ws.data_ptr(), ws_bytes, current_stream()),
+        "logchain");
+  return {log_z, gu, gp};
+}
+
+// the enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under TraceEnum_ELBO with its
+// gradient, word-major half through the corpus index (pa_lda_build_index): pyro/infer/traceenum_elbo.py:112-214
+std::tuple<at::Tensor, at::Tensor, at::Tensor> lda_factor_indexed(const at::Tensor& words, const at::Tensor& index,
+                                                                  const at::Tensor& log_theta, const at::Tensor& log_phi) {
+  const int dt = dtype_of(log_theta, "lda_factor_indexed");
+  TORCH_CHECK(words.is_cuda() && words.scalar_type() == at::kLong && words.dim() == 2 && words.is_contiguous() &&
+                  index.is_cuda() && index.scalar_type() == at::kByte && log_theta.dim() == 2 && log_phi.dim() == 2 &&
+                  log_theta.is_contiguous() && log_phi.is_contiguous() && log_phi.scalar_type() == log_theta.scalar_type(),
+              "pyro_amd::lda_factor_indexed: words int64 [Wd, B], index uint8, log_theta [B, T], log_phi [T, V]");
+  const int64_t Wd = words.size(0), B = words.size(1), T = log_theta.size(1), V = log_phi.size(1);
+  TORCH_CHECK(log_theta.size(0) == B && log_phi.size(0) == T, "pyro_amd::lda_factor_indexed: shapes");
+  const size_t ws_bytes = pa_lda_factor_indexed_workspace(dt, Wd, B, T, V);
+  at::Tensor ws = at::empty({(int64_t)(ws_bytes < 16 ? 16 : ws_bytes)}, log_theta.options().dtype(at::kByte));
+  at::Tensor out_doc = at::empty({B}, log_theta.options()), g_theta = at::empty_like(log_theta), g_phi = at::empty_like(log_phi);
+  check(pa_lda_factor_indexed_fwd_bwd(dt, words.data_ptr<int64_t>(), index.data_ptr(), (size_t)index.numel(),
+                                      log_theta.data_ptr(), log_phi.data_ptr(), Wd, B, T, V, out_doc.data_ptr(),
+                                      g_theta.data_ptr(), g_phi.data_ptr(), ws.data_ptr(), ws_bytes, current_stream()),
+        "lda_factor_indexed");
+  return {out_doc, g_theta, g_phi};
+}
+
+// F.linear over a tall batch with the Sigmoid behind it (and the gradient through the previous one) fused:
+// Y = act(G' W^T + bias), G' = G (1 - y_mul) y_mul when y_mul is given (examples/lda.py:76-92's predictor)
+at::Tensor tall_linear_act(const at::Tensor& G, const at::Tensor& weight, const std::optional<at::Tensor>& bias,
+                           const std::optional<at::Tensor>& y_mul, bool sigmoid_out, bool transpose_weight) {
+  require_f32_gpu(G, "G");
+  TORCH_CHECK(G.dim() == 2 && weight.dim() == 2 && weight.is_cuda() && weight.scalar_type() == at::kFloat,
+              "pyro_amd::tall_linear_act: G [B, R], weight 2-D float32");
+  const int64_t B = G.size(0), R = G.size(1);
+  // transpose_weight = true: F.linear's forward, Wm = weight^T (weight [C, R]); false: autograd's dx, Wm = weight [R, C]
+  const int64_t C = transpose_weight ? weight.size(0) : weight.size(1);
+  TORCH_CHECK((transpose_weight ? weight.size(1) : weight.size(0)) == R, "pyro_amd::tall_linear_act: weight does not match G");
+  const int64_t rs = transpose_weight ? weight.stride(1) : weight.stride(0), cs = transpose_weight ? weight.stride(0) : weight.stride(1);
+  if (y_mul.has_value() && y_mul->defined()) {
+    require_f32_gpu(*y_mul, "y_mul");
+    TORCH_CHECK(y_mul->numel() == B * R, "pyro_amd::tall_linear_act: y_mul [B, R]");
+  }
+  if (bias.has_value() && bias->defined()) {
+    require_f32_gpu(*bias, "bias");
+    TORCH_CHECK(bias->numel() == C, "pyro_amd::tall_linear_act: bias [C]");
+  }
+  at::Tensor Y = at::empty({B, C}, G.options());
+  check(pa_tall_linear_act(G.data_ptr<float>(), B, R, weight.data_ptr<float>(), rs, cs, C, f32_ptr(bias), f32_ptr(y_mul),
+                           sigmoid_out ? 1 : 0, Y.data_ptr<float>(), current_stream()),
+        "tall_linear_act");
+  return Y;
+}
+
+// one round of a span of asynchronous NUTS chains: every live chain consumes (peq, gq) at its cursor; a chain
+// whose tree finishes adapts, stores its draw and begins its next transition in the same launch
+// (pyro/infer/mcmc/nuts.py:184-522, adaptation.py:166-185); every state tensor is updated in place
+void nuts_tree_run_advance(at::Tensor z, at::Tensor pe, at::Tensor grad, at::Tensor zq, at::Tensor rq, const at::Tensor& gq,
+                           const at::Tensor& peq, const at::Tensor& inv_mass, at::Tensor step, int64_t max_tree_depth,
+                           bool use_multinomial, int64_t seed, int64_t chain_offset, const at::Tensor& ctl,
+                           at::Tensor da_state, double target_accept, at::Tensor welford, at::Tensor mean_accept,
+                           at::Tensor counters, at::Tensor tc, at::Tensor n_done, const std::optional<at::Tensor>& done_flag,
+                           const std::optional<at::Tensor>& slot2chain, const std::optional<at::Tensor>& zq_slot,
+                           at::Tensor accept_prob, at::Tensor stats, at::Tensor workspace) {
+  const int dt = dtype_of(z, "nuts_tree_run_advance");
+  TORCH_CHECK(z.dim() == 2 && z.is_contiguous(), "pyro_amd::nuts_tree_run_advance: z [C, D] contiguous");
+  const int64_t C = z.size(0), D = z.size(1);
+  TORCH_CHECK(stats.scalar_type() == at::kInt && stats.dim() == 2 && stats.size(0) == 4 && stats.size(1) == C && stats.is_contiguous(),
+              "pyro_amd::nuts_tree_run_advance: stats int32 [4, C] {n_leapfrog, depth, diverging, accepted}");
+  TORCH_CHECK(ctl.scalar_type() == at::kLong && counters.scalar_type() == at::kLong && tc.scalar_type() == at::kInt &&
+                  n_done.scalar_type() == at::kInt && workspace.scalar_type() == at::kByte,
+              "pyro_amd::nuts_tree_run_advance: ctl / counters int64, tc / n_done int32, workspace uint8");
+  const bool compact = slot2chain.has_value() && slot2chain->defined();
+  const int64_t n_slots = compact ? slot2chain->numel() : C;
+  int32_t* st = stats.data_ptr<int32_t>();
+  check(pa_nuts_tree_run_advance(
+            dt, z.data_ptr(), pe.data_ptr(), grad.data_ptr(), zq.data_ptr(), rq.data_ptr(), gq.data_ptr(), peq.data_ptr(),
+            inv_mass.data_ptr(), inv_mass.dim() == 2 ? D : 0, step.data_ptr(), C, D, (int)max_tree_depth,
+            use_multinomial ? 1 : 0, (uint64_t)seed, (uint64_t)chain_offset, ctl.data_ptr<int64_t>(), da_state.data_ptr(),
+            target_accept, welford.data_ptr(), mean_accept.data_ptr(), counters.data_ptr<int64_t>(), tc.data_ptr<int32_t>(),
+            n_done.data_ptr<int32_t>(),
+            done_flag.has_value() && done_flag->defined() ? done_flag->data_ptr<int64_t>() : nullptr,
+            compact ? slot2chain->data_ptr<int32_t>() : nullptr,
+            compact && zq_slot.has_value() && zq_slot->defined() ? zq_slot->data_ptr() : nullptr, n_slots,
+            accept_prob.data_ptr(), st, st + C, st + 2 * C, st + 3 * C, workspace.data_ptr(), (size_t)workspace.numel(),
+            current_stream()),
+        "nuts_tree_run_advance");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(pyro_amd, m) {
@@ -166,6 +475,28 @@ TORCH_LIBRARY(pyro_amd, m) {
         "Tensor(e!) step, float lr, float beta1, float beta2, float eps, float weight_decay, float clip_norm, "
         "float lrd, bool clipped, bool zero_grad) -> ()");
   m.def("glm_chain(Tensor g, Tensor gw, Tensor gb) -> (Tensor, Tensor)");
+  // typed schemas of the next ten (round 6)
+  m.def("dist_log_prob_sum(int dist, Tensor value, Tensor? p0, Tensor? p1, Tensor? mask, float scale) -> "
+        "(Tensor rowsum, Tensor total)");
+  m.def("multi_log_prob_sum(int[] dist, Tensor[] value, Tensor?[] p0, Tensor?[] p1, float[] coef, float coef_all) "
+        "-> Tensor");
+  m.def("meanfield_normal_sample(Tensor[] loc, Tensor[] rho, int P, int seed, int[] offsets, Tensor? offset_dev) -> "
+        "(Tensor[] z, Tensor[] scale, Tensor[] eps)");
+  m.def("exp_site(Tensor u, float lower) -> (Tensor value, Tensor log_density)");
+  m.def("exp_site_bwd(Tensor value, Tensor? g_value, Tensor? g_log_density, float lower) -> Tensor");
+  m.def("mvn_tril_sample(Tensor loc, Tensor rho, Tensor A, int P, int seed, int offset, Tensor? offset_dev) -> "
+        "(Tensor eps, Tensor z, Tensor logq)");
+  m.def("logsumexp_terms(Tensor[] terms, int[] sizes, int rdim) -> Tensor");
+  m.def("logchain(Tensor unary, Tensor pairwise) -> (Tensor log_z, Tensor grad_unary, Tensor grad_pairwise)");
+  m.def("lda_factor_indexed(Tensor words, Tensor index, Tensor log_theta, Tensor log_phi) -> "
+        "(Tensor out_doc, Tensor g_theta, Tensor g_phi)");
+  m.def("tall_linear_act(Tensor G, Tensor weight, Tensor? bias, Tensor? y_mul, bool sigmoid_out, "
+        "bool transpose_weight) -> Tensor");
+  m.def("nuts_tree_run_advance(Tensor(a!) z, Tensor(b!) pe, Tensor(c!) grad, Tensor(d!) zq, Tensor(e!) rq, Tensor gq, "
+        "Tensor peq, Tensor inv_mass, Tensor(f!) step, int max_tree_depth, bool use_multinomial, int seed, "
+        "int chain_offset, Tensor ctl, Tensor(g!) da_state, float target_accept, Tensor(h!) welford, "
+        "Tensor(i!) mean_accept, Tensor(j!) counters, Tensor(k!) tc, Tensor(l!) n_done, Tensor(m!)? done_flag, "
+        "Tensor? slot2chain, Tensor(n!)? zq_slot, Tensor(o!) accept_prob, Tensor(p!) stats, Tensor(q!) workspace) -> ()");
 }
 
 // HIP tensors carry the CUDA dispatch key in a ROCm build of torch
@@ -175,4 +506,15 @@ TORCH_LIBRARY_IMPL(pyro_amd, CUDA, m) {
   m.impl("glm_bernoulli", &glm_bernoulli);
   m.impl("glm_chain", &glm_chain);
   m.impl("adam_step", &adam_step);
+  m.impl("dist_log_prob_sum", &dist_log_prob_sum);
+  m.impl("multi_log_prob_sum", &multi_log_prob_sum);
+  m.impl("meanfield_normal_sample", &meanfield_normal_sample);
+  m.impl("exp_site", &exp_site);
+  m.impl("exp_site_bwd", &exp_site_bwd);
+  m.impl("mvn_tril_sample", &mvn_tril_sample);
+  m.impl("logsumexp_terms", &logsumexp_terms);
+  m.impl("logchain", &logchain);
+  m.impl("lda_factor_indexed", &lda_factor_indexed);
+  m.impl("tall_linear_act", &tall_linear_act);
+  m.impl("nuts_tree_run_advance", &nuts_tree_run_advance);
 }

@@ -341,26 +341,28 @@ class NUTS(HMC):
             with fuser.scope():
                 self._span_round(tree, base, slots)
             for attempt in (0, 1):
-                compiled = fuser.STATS["compiled"]
+                compiled = fuser.STATS["loaded"]
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 keep = []
                 kernels.check(lib.pa_gate_scope(kernels._ptr(tree.gate)))
+                blocks = fuser.RtcBlocks()
                 try:
-                    with torch.cuda.graph(graph):
+                    with blocks, torch.cuda.graph(graph):
                         for _ in range(self.rounds_per_replay):
                             with fuser.scope():
                                 keep.append(self._span_round(tree, base, slots))
                     break
                 except Exception:  # noqa: BLE001
                     # (a kernel generated during the capture loaded its module there: cached now, once more)
-                    if attempt == 1 or fuser.STATS["compiled"] == compiled:
+                    blocks.free()
+                    if attempt == 1 or fuser.STATS["loaded"] == compiled:
                         raise
                 finally:
                     lib.pa_gate_scope(None)
             self._span_graphs[size if size is not None else self.num_chains] = graph
             self._span_graph = graph
-            self._span_keep = (getattr(self, "_span_keep", None) or []) + [keep]
+            self._span_keep = (getattr(self, "_span_keep", None) or []) + [keep, blocks]
             return graph
         except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
             if os.environ.get("PYRO_AMD_DEBUG_GRAPH"):

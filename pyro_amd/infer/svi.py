@@ -80,6 +80,7 @@ class _ReadSet(torch.utils._python_dispatch.TorchDispatchMode):
 
 
 class _CapturedStep:
+    rtc_blocks = None
     reads = ()             # tensors the step reads that it did not make (see _ReadSet)
     gate = None            # kernels.StepGate when the step's first node is a gate (SVI(prearm=True))
     armed = False          # the NEXT replay is already enqueued behind its gate
@@ -652,7 +653,7 @@ class SVI:
         from ..ops import fuser
         from ..primitives import validation_enabled
 
-        compiled_before = fuser.STATS["compiled"]
+        compiled_before = fuser.STATS["loaded"]
 
         device = None
         for a in list(args) + list(kwargs.values()):
@@ -699,7 +700,9 @@ class SVI:
                 multi = getattr(self.optim, "multi_rank", False)
                 mode = {"capture_error_mode": "thread_local"} if (split or multi) else {}
                 reads = _ReadSet()
-                with torch.cuda.graph(graph, **mode):
+                # (parameter blocks of generated-kernel launches: owned by this capture, freed with it)
+                blocks = fuser.RtcBlocks()
+                with blocks, torch.cuda.graph(graph, **mode):
                     # (the fuser outermost: it sees what the inner modes let through, last; the read-set
                     #  recorder innermost: it sees every operator first)
                     with fuser.scope(), gated(), cap, chain() as rec, hoist(), reads:
@@ -728,7 +731,8 @@ class SVI:
                     optim = self.optim
                     optim.reduce_gradients(params)
                     graph2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph2, pool=graph.pool(), **mode):
+                    blocks2 = fuser.RtcBlocks()
+                    with blocks2, torch.cuda.graph(graph2, pool=graph.pool(), **mode):
                         with chain():
                             optim.apply(params)
                             if not getattr(optim, "zeroes_grads", False):
@@ -737,9 +741,12 @@ class SVI:
         except Exception as e:  # noqa: BLE001  (anything that synchronises inside the capture)
             import os
             from .constants import HoistedConstantWritten
+            for b_ in (locals().get("blocks"), locals().get("blocks2")):
+                if b_ is not None:
+                    b_.free()
             if isinstance(e, HoistedConstantWritten):
                 raise
-            if not _retried and fuser.STATS["compiled"] != compiled_before:
+            if not _retried and fuser.STATS["loaded"] != compiled_before:
                 # a kernel the fuser generated DURING the capture loaded its module there, which a capture
                 # does not allow; it is cached now: the second attempt finds it
                 return self._capture_once(key, args, kwargs, const_rec, force_split=force_split, quiet=quiet,
@@ -754,6 +761,7 @@ class SVI:
             self.hip_graph = False
             return None
         entry = _CapturedStep(graph, cap, loss, graph2, between, mailbox)
+        entry.rtc_blocks = (blocks, blocks2 if split else None)     # (die with the entry: RtcBlocks.__del__)
         entry.gate = gate
         entry.reads = tuple(reads.external.values())
         # the graph reads the hoisted constants on every replay: they live as long as the entry

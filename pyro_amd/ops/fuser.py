@@ -52,7 +52,9 @@ import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
 ENABLED = {"on": os.environ.get("PYRO_AMD_FUSER", "1") != "0"}
-STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "flushes": 0, "dead": 0}
+# compiled: hiprtc runs in this process; from_disk: code objects taken from the persistent cache; loaded: modules
+# loaded into this process either way (a capture that meets a load is retried: svi.py, mcmc/nuts.py)
+STATS = {"recorded": 0, "kernels": 0, "compiled": 0, "from_disk": 0, "loaded": 0, "flushes": 0, "dead": 0}
 UNFUSED = {}                # operator name -> how often it was met and run as it is (attribution)
 MAX_POINTERS = 384          # PA_RTC_MAX_POINTERS
 MAX_REDUCE = 1 << 14        # longest reduction one lane group takes (longer ones: two recorded stages)
@@ -1285,17 +1287,97 @@ class Fuser(TorchDispatchMode):
 # code generation
 # ---------------------------------------------------------------------------------------------------
 _CACHE = {}
+# the options pa_rtc_compile_cached passes to hiprtc (csrc/rtc.hip): part of the persistent cache's key
+RTC_OPTIONS = ("--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17")
+_RTC_VERSION = [None]
+
+
+def rtc_cache_dir():
+    """Where compiled kernels persist between processes: $PYRO_AMD_RTC_CACHE (``0`` / ``off`` / empty: no
+    persistent cache), default ~/.cache/pyro_amd/rtc.  None when switched off or not creatable."""
+    d = os.environ.get("PYRO_AMD_RTC_CACHE")
+    if d is not None and d.strip().lower() in ("", "0", "off", "none"):
+        return None
+    d = d or os.path.join(os.path.expanduser("~"), ".cache", "pyro_amd", "rtc")
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        return None
+    return d
+
+
+def rtc_cache_key(src, version, options=RTC_OPTIONS, kernel="k"):
+    """sha256 over everything the code object depends on: the source text, the compiler (hiprtc major.minor +
+    HIP runtime version), its options (they name the architecture) and the kernel's name."""
+    import hashlib
+    h = hashlib.sha256()
+    for part in ("pyro_amd-rtc-1", "hiprtc %d.%d runtime %d" % tuple(version), " ".join(options), kernel, src):
+        b = part.encode()
+        h.update(len(b).to_bytes(8, "little"))
+        h.update(b)
+    return h.hexdigest()
+
+
+def _rtc_version():
+    if _RTC_VERSION[0] is None:
+        from .. import _lib
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().pa_rtc_version(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        _RTC_VERSION[0] = (a.value, b.value, c.value)
+    return _RTC_VERSION[0]
 
 
 def _compiled(src):
     fn = _CACHE.get(src)
     if fn is None:
         from .. import _lib
-        out = ctypes.c_void_p()
-        _lib.check(_lib.load().pa_rtc_compile(src.encode(), b"k", ctypes.byref(out)))
+        out, compiled = ctypes.c_void_p(), ctypes.c_int(1)
+        d = rtc_cache_dir()
+        path = None if d is None else os.path.join(d, rtc_cache_key(src, _rtc_version()) + ".hsaco").encode()
+        _lib.check(_lib.load().pa_rtc_compile_cached(src.encode(), b"k", path, ctypes.byref(out),
+                                                     ctypes.byref(compiled)))
         fn = _CACHE[src] = out
-        STATS["compiled"] += 1
+        STATS["loaded"] += 1
+        STATS["compiled"] += 1 if compiled.value else 0
+        STATS["from_disk"] += 0 if compiled.value else 1
     return fn
+
+
+class RtcBlocks:
+    """The parameter blocks of generated-kernel launches made while a stream is captured (csrc/rtc.hip keeps
+    one per launch for the captured graph): opened around a capture, owned by whoever owns the graph, freed
+    with it -- re-captures (a re-seeded generator, an evicted signature, every NUTS span size) no longer
+    grow the process."""
+
+    def __init__(self):
+        self._scope = None
+        self.count = 0
+
+    def __enter__(self):
+        from .. import _lib
+        if torch.cuda.is_available():
+            self._scope = _lib.load().pa_rtc_blocks_begin()
+        return self
+
+    def __exit__(self, *exc):
+        if self._scope is not None:
+            from .. import _lib
+            n = ctypes.c_int64()
+            _lib.check(_lib.load().pa_rtc_blocks_end(ctypes.c_void_p(self._scope), ctypes.byref(n)))
+            self.count = n.value
+        return False
+
+    def free(self):
+        if self._scope is not None:
+            from .. import _lib
+            scope, self._scope = self._scope, None
+            _lib.load().pa_rtc_blocks_free(ctypes.c_void_p(scope))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def _launch(src, grid, block, tensors):

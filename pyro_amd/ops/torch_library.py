@@ -79,6 +79,60 @@ def _register():
           clipped, zero_grad):
         return None
 
+    # ---- shape functions of the typed ops (csrc/torch_ops.cpp, round 6) --------------------------------------
+    def _frame(value):
+        cols = value.shape[-1] if value.dim() else 1
+        return (value.numel() // cols if cols else 0), cols
+
+    @lib.register_fake("pyro_amd::dist_log_prob_sum")
+    def _(dist, value, p0, p1, mask, scale):
+        return value.new_empty((_frame(value)[0],)), value.new_empty(())
+
+    @lib.register_fake("pyro_amd::multi_log_prob_sum")
+    def _(dist, value, p0, p1, coef, coef_all):
+        return value[0].new_empty(())
+
+    @lib.register_fake("pyro_amd::meanfield_normal_sample")
+    def _(loc, rho, P, seed, offsets, offset_dev):
+        z = [t.new_empty((P, t.numel())) for t in loc]
+        return z, [t.new_empty((t.numel(),)) for t in loc], [t.new_empty((P, t.numel())) for t in loc]
+
+    @lib.register_fake("pyro_amd::exp_site")
+    def _(u, lower):
+        return torch.empty_like(u), u.new_empty((_frame(u)[0],))
+
+    @lib.register_fake("pyro_amd::exp_site_bwd")
+    def _(value, g_value, g_log_density, lower):
+        return torch.empty_like(value)
+
+    @lib.register_fake("pyro_amd::mvn_tril_sample")
+    def _(loc, rho, A, P, seed, offset, offset_dev):
+        n = loc.numel()
+        return loc.new_empty((P, n)), loc.new_empty((P, n)), loc.new_empty((P,))
+
+    @lib.register_fake("pyro_amd::logsumexp_terms")
+    def _(terms, sizes, rdim):
+        return terms[0].new_empty([n for d, n in enumerate(sizes) if d != rdim])
+
+    @lib.register_fake("pyro_amd::logchain")
+    def _(unary, pairwise):
+        B, T, K = unary.shape
+        return unary.new_empty((B,)), torch.empty_like(unary), unary.new_empty((B, max(T - 1, 0), K, K))
+
+    @lib.register_fake("pyro_amd::lda_factor_indexed")
+    def _(words, index, log_theta, log_phi):
+        return log_theta.new_empty((words.shape[1],)), torch.empty_like(log_theta), torch.empty_like(log_phi)
+
+    @lib.register_fake("pyro_amd::tall_linear_act")
+    def _(G, weight, bias, y_mul, sigmoid_out, transpose_weight):
+        return G.new_empty((G.shape[0], weight.shape[0] if transpose_weight else weight.shape[1]))
+
+    @lib.register_fake("pyro_amd::nuts_tree_run_advance")
+    def _(z, pe, grad, zq, rq, gq, peq, inv_mass, step, max_tree_depth, use_multinomial, seed, chain_offset, ctl,
+          da_state, target_accept, welford, mean_accept, counters, tc, n_done, done_flag, slot2chain, zq_slot,
+          accept_prob, stats, workspace):
+        return None
+
     def setup(ctx, inputs, output):
         _, gw, gb, _ws = output
         ctx.save_for_backward(gw, gb)
@@ -489,7 +543,7 @@ def _make_backward(name):
     return backward
 
 
-def dispatcher_op(name):
+def dispatcher_op(fn_name):
     """Class decorator for a ``torch.autograd.Function``: registers ``pyro_amd::<name>`` and
     ``pyro_amd::<name>_bwd`` (see the module docstring) and makes ``apply`` go through them while a
     tracer is recording."""
@@ -497,6 +551,9 @@ def dispatcher_op(name):
         if _frag["lib"] is None:
             _frag["lib"] = torch.library.Library("pyro_amd", "FRAGMENT")
         lib = _frag["lib"]
+        # the trampoline's op is pyro_amd::fn_<name> (_OPS / the spec table keep the Function's own name); the
+        # plain name belongs to the TYPED op of csrc/torch_ops.cpp where one exists
+        name = "fn_" + fn_name
         lib.define("%s(Tensor[] tensors, int spec) -> Tensor[]" % name)
         lib.define("%s_bwd(Tensor[] tensors, int spec) -> Tensor[]" % name)
         lib.impl(name, _fwd_impl, "CompositeExplicitAutograd")
@@ -505,14 +562,14 @@ def dispatcher_op(name):
         torch.library.register_fake("pyro_amd::" + name + "_bwd", _bwd_fake, lib=lib)
         torch.library.register_autograd("pyro_amd::" + name, _make_backward(name),
                                         setup_context=_setup_context, lib=lib)
-        _OPS[name] = fn_cls
+        _OPS[fn_name] = fn_cls
         eager_apply = fn_cls.apply
         vol = tuple(getattr(fn_cls, "volatile_args", ()))       # (read here: a compiler inlines ``apply`` below)
 
         def apply(*args):
             if not _routing_now() or not any(isinstance(a, torch.Tensor) for a in args):
                 return eager_apply(*args)
-            sid, tensors = _spec_of(name, fn_cls, args, vol)
+            sid, tensors = _spec_of(fn_name, fn_cls, args, vol)
             out = getattr(torch.ops.pyro_amd, name)(tensors, sid)
             sp = _SPECS[sid]
             return out[0] if sp.single else tuple(out[:sp.n_out])
@@ -529,8 +586,14 @@ def dispatcher_op(name):
 
 def registered_ops():
     """Names of the dispatcher ops of this module (C++ ones once the shim is loaded)."""
-    names = ["pyro_amd::" + n for n in _OPS] + ["pyro_amd::" + n + "_bwd" for n in _OPS]
+    names = ["pyro_amd::fn_" + n for n in _OPS] + ["pyro_amd::fn_" + n + "_bwd" for n in _OPS]
     if available():
         names += ["pyro_amd::" + n for n in ("glm_pack_planes", "glm_bernoulli_planes", "glm_bernoulli",
-                                             "glm_chain", "adam_step")]
+                                             "glm_chain", "adam_step") + TYPED_OPS]
     return sorted(names)
+
+
+# the typed C++ ops of csrc/torch_ops.cpp beside the GLM site's (round 6): real argument lists, loadable from C++
+TYPED_OPS = ("dist_log_prob_sum", "multi_log_prob_sum", "meanfield_normal_sample", "exp_site", "exp_site_bwd",
+             "mvn_tril_sample", "logsumexp_terms", "logchain", "lda_factor_indexed", "tall_linear_act",
+             "nuts_tree_run_advance")

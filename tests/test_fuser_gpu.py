@@ -416,3 +416,66 @@ def test_long_sums_in_two_recorded_stages(gpu):
     for a, b in zip(got, ref):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-3)
+
+
+_CACHE_PROBE = r"""
+import json, sys
+import torch
+sys.path.insert(0, %r)
+import pyro_amd as pyro
+from pyro_amd.ops import fuser
+from tools import bench_configs
+dev = torch.device("cuda", 0)
+r = bench_configs.config1(dev, steps=5)          # eight schools: 34 operators per step -> generated kernels
+print("STATS " + json.dumps({"stats": fuser.STATS, "loss": r["last_loss"], "graphed": r["graphed"]}))
+"""
+
+
+def test_second_process_compiles_nothing(gpu, tmp_path):
+    """Persistent cache of generated kernels (~/.cache/pyro_amd/rtc/<sha256>.hsaco, here a temporary
+    directory): the first process compiles every kernel of a captured eight-schools step with hiprtc and
+    writes the code objects; a second process loads them (hipModuleLoadData) and runs the same step --
+    same loss, captured -- without a single hiprtc call."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYRO_AMD_RTC_CACHE=str(tmp_path / "rtc"))
+    outs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, "-c", _CACHE_PROBE % root], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("STATS ")][-1]
+        outs.append(json.loads(line[6:]))
+    first, second = outs
+    files = [f for f in os.listdir(tmp_path / "rtc") if f.endswith(".hsaco")]
+    assert first["stats"]["compiled"] >= 2 and first["stats"]["from_disk"] == 0
+    assert len(files) == first["stats"]["compiled"] and not [f for f in os.listdir(tmp_path / "rtc") if ".tmp." in f]
+    assert second["stats"]["compiled"] == 0, second
+    assert second["stats"]["from_disk"] == second["stats"]["loaded"] == first["stats"]["loaded"]
+    assert second["graphed"] and first["graphed"] and second["loss"] == first["loss"]
+
+
+def test_capture_parameter_blocks_are_freed_with_the_capture(gpu):
+    """a generated-kernel launch made during a capture keeps a ~3 KB parameter block for the
+    graph; the blocks belong to the captured step and go when it goes (SVI.release, eviction, re-capture)."""
+    import gc
+
+    from pyro_amd.ops import fuser
+    from tools import bench_configs
+    freed = []
+    orig = fuser.RtcBlocks.free
+
+    def counting_free(self):
+        if self._scope is not None:
+            freed.append(self.count)
+        orig(self)
+    fuser.RtcBlocks.free = counting_free
+    try:
+        bench_configs.config1(gpu, steps=3)
+        gc.collect()
+    finally:
+        fuser.RtcBlocks.free = orig
+    assert freed and max(freed) >= 2, freed

@@ -264,3 +264,34 @@ def test_model_potentials_through_the_recorder_match_the_reference(_cpu_backend,
             else:
                 mc.run_constrained_potentials_vs_reference(torch.device("cpu"))
     assert fuser.STATS["recorded"] - before["recorded"] > 10
+
+
+def test_persistent_cache_key_covers_source_compiler_and_options(tmp_path, monkeypatch):
+    """The name of a cached code object is a digest of everything the
+    object depends on: the generated source, the compiler's version (hiprtc major.minor + HIP runtime), the
+    options (which name the architecture) and the kernel's name; where it lives follows PYRO_AMD_RTC_CACHE."""
+    from pyro_amd.ops import fuser
+    src = 'extern "C" __global__ void k(T t) { }'
+    v = (7, 2, 70253)
+    k0 = fuser.rtc_cache_key(src, v)
+    assert len(k0) == 64 and k0 == fuser.rtc_cache_key(src, v)
+    others = {fuser.rtc_cache_key(src + " ", v), fuser.rtc_cache_key(src, (7, 3, 70253)),
+              fuser.rtc_cache_key(src, (7, 2, 70254)),
+              fuser.rtc_cache_key(src, v, options=("--offload-arch=gfx942",) + fuser.RTC_OPTIONS[1:]),
+              fuser.rtc_cache_key(src, v, kernel="k2")}
+    assert len(others) == 5 and k0 not in others
+    # length-prefixed fields: moving a character between two of them changes the digest
+    assert fuser.rtc_cache_key("ab", v, kernel="c") != fuser.rtc_cache_key("a", v, kernel="bc")
+    assert fuser.RTC_OPTIONS[0] == "--offload-arch=gfx950"
+    # ... and the options in the key are the ones the native side compiles with
+    import os
+    rtc = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "pyro_amd", "csrc", "rtc.hip")).read()
+    assert ", ".join('"%s"' % o for o in fuser.RTC_OPTIONS) in rtc
+    monkeypatch.setenv("PYRO_AMD_RTC_CACHE", str(tmp_path / "c"))
+    assert fuser.rtc_cache_dir() == str(tmp_path / "c") and (tmp_path / "c").is_dir()
+    for off in ("0", "off", ""):
+        monkeypatch.setenv("PYRO_AMD_RTC_CACHE", off)
+        assert fuser.rtc_cache_dir() is None
+    monkeypatch.delenv("PYRO_AMD_RTC_CACHE")
+    monkeypatch.setenv("HOME", str(tmp_path))
+    assert fuser.rtc_cache_dir() == str(tmp_path / ".cache" / "pyro_amd" / "rtc")

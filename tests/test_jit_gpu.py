@@ -28,8 +28,8 @@ def _clean():
 def test_traced_config2_loss_replays_with_the_reference_numbers(gpu, monkeypatch, fused):
     g = np.load(os.path.join(G, "logreg_f32.npz"))
     # (the guide draw is not the fused one here: the recorded noise of the fixture is fed through
-    # rng.normal; test_traced_draws_continue_the_philox_stream covers pyro_amd::meanfield_normal_sample)
-    ops = ("pyro_amd::glm_bernoulli", "pyro_amd::multi_log_prob_sum") if fused else ()
+    # rng.normal; test_traced_draws_continue_the_philox_stream covers pyro_amd::fn_meanfield_normal_sample)
+    ops = ("pyro_amd::glm_bernoulli", "pyro_amd::fn_multi_log_prob_sum") if fused else ()
     graph = models.run_logreg_jit(g, gpu, monkeypatch, fused=fused, dtype=torch.float32, rtol=2e-4,
                                   expect_ops=ops)
     recorded = {ln.split("= ")[1].split("(")[0] for ln in graph.split("\n") if "= pyro_amd::" in ln}
@@ -63,8 +63,8 @@ def test_traced_draws_continue_the_philox_stream(gpu):
             (compiled,) = [c for c, _, _ in elbo._jit_cache.values()]
             (traced,) = compiled.compiled.values()
             graph = str(traced.graph)
-            for op in ("pyro_amd::meanfield_normal_sample", "pyro_amd::glm_bernoulli",
-                       "pyro_amd::multi_log_prob_sum"):
+            for op in ("pyro_amd::fn_meanfield_normal_sample", "pyro_amd::glm_bernoulli",
+                       "pyro_amd::fn_multi_log_prob_sum"):
                 assert op in graph, (op, graph)
         return out
 

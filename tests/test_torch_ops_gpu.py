@@ -187,3 +187,195 @@ def test_op_workspace_stays_alive_while_its_finalize_phase_is_pending(gpu):
     assert torch.equal(ll, ref)
     (gw, gb) = torch.autograd.grad(ll.sum(), [w, b])
     assert torch.equal(gw, rw) and torch.equal(gb, rb)
+
+
+# ---- the typed C++ ops of round 6 (csrc/torch_ops.cpp): each against a plain torch float64 statement of the
+#      operation it names (tolerances: f32 kernels 2e-5 relative unless said otherwise) -------------------------------
+def _ops():
+    from pyro_amd.ops import torch_library
+    assert torch_library.available()
+    return torch.ops.pyro_amd
+
+
+def test_typed_dist_and_multi_log_prob_sum(gpu):
+    ops = _ops()
+    g = torch.Generator(device=gpu).manual_seed(0)
+    v = torch.randn((6, 50), device=gpu, generator=g)
+    loc = torch.randn((50,), device=gpu, generator=g)
+    scale = torch.rand((1,), device=gpu, generator=g) + 0.5
+    mask = torch.rand((6, 50), device=gpu, generator=g) < 0.7
+    rs, tot = ops.dist_log_prob_sum(0, v, loc, scale, mask, 2.5)
+    want = (torch.distributions.Normal(loc.double(), scale.double()).log_prob(v.double()) * 2.5 * mask).sum(-1)
+    torch.testing.assert_close(rs.double(), want, rtol=2e-5, atol=1e-4)
+    torch.testing.assert_close(tot.double(), want.sum(), rtol=2e-5, atol=1e-4)
+    # the ELBO assembly: three sites, one total (Normal, HalfCauchy = 2, Exponential = 4: include/pyro_amd.h PA_DIST_*)
+    hc = torch.rand((4, 3), device=gpu, generator=g) + 0.1
+    ex = torch.rand((7,), device=gpu, generator=g) + 0.1
+    s_hc, r_ex = torch.tensor([0.7], device=gpu), torch.tensor([1.3], device=gpu)
+    total = ops.multi_log_prob_sum([0, 2, 4], [v, hc, ex], [loc, s_hc, r_ex], [scale, None, None], [1.0, -1.0, 0.5], 2.0)
+    want = 2.0 * (torch.distributions.Normal(loc.double(), scale.double()).log_prob(v.double()).sum()
+                  - torch.distributions.HalfCauchy(s_hc.double()).log_prob(hc.double()).sum()
+                  + 0.5 * torch.distributions.Exponential(r_ex.double()).log_prob(ex.double()).sum())
+    torch.testing.assert_close(total.double(), want, rtol=2e-5, atol=1e-4)
+
+
+def test_typed_meanfield_and_mvn_draws(gpu):
+    """The guide draws: z = loc + softplus(rho) eps with eps the keyed Philox numbers -- the SAME numbers the
+    package's own path (kernels.philox_normal at the same seed / offset) hands out; AutoMultivariateNormal's z and
+    log q against torch.distributions.MultivariateNormal at the kernel's own eps."""
+    from pyro_amd import kernels
+    ops = _ops()
+    P, seed = 16, 1234
+    loc = [torch.linspace(-1, 1, 5, device=gpu), torch.tensor([0.3], device=gpu)]
+    rho = [torch.linspace(-2, 0.5, 5, device=gpu), torch.tensor([-1.0], device=gpu)]
+    z, scale, eps = ops.meanfield_normal_sample(loc, rho, P, seed, [0, 64], None)
+    for i, off in enumerate((0, 64)):
+        n = loc[i].numel()
+        assert z[i].shape == (P, n) and eps[i].shape == (P, n)
+        torch.testing.assert_close(scale[i], torch.nn.functional.softplus(rho[i]), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(z[i], loc[i] + scale[i] * eps[i], rtol=1e-6, atol=1e-7)
+        want = kernels.philox_normal((P, n), torch.float32, gpu, seed, off)
+        assert torch.equal(eps[i], want)
+    z2, _, _ = ops.meanfield_normal_sample(loc, rho, P, seed, [0, 64], None)
+    assert torch.equal(z[0], z2[0])
+    n = 6
+    g = torch.Generator(device=gpu).manual_seed(1)
+    mloc, mrho = torch.randn((n,), device=gpu, generator=g), torch.randn((n,), device=gpu, generator=g) * 0.3
+    A = torch.randn((n, n), device=gpu, generator=g) * 0.4
+    e, zz, logq = ops.mvn_tril_sample(mloc, mrho, A, P, seed, 128, None)
+    L = (torch.nn.functional.softplus(mrho)[:, None] * (torch.tril(A, -1) + torch.eye(n, device=gpu))).double()
+    torch.testing.assert_close(zz.double(), mloc.double() + e.double() @ L.T, rtol=1e-5, atol=1e-5)
+    mvn = torch.distributions.MultivariateNormal(mloc.double(), scale_tril=L)
+    torch.testing.assert_close(logq.double(), mvn.log_prob(zz.double()), rtol=1e-5, atol=1e-4)
+
+
+def test_typed_exp_site_and_its_backward(gpu):
+    ops = _ops()
+    u = torch.linspace(-3, 2, 24, device=gpu).reshape(4, 6).contiguous()
+    value, ld = ops.exp_site(u, 0.5)
+    torch.testing.assert_close(value, 0.5 + u.exp(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ld, u.sum(-1), rtol=1e-6, atol=1e-6)
+    gv, gl = torch.randn_like(value), torch.randn((4,), device=gpu)
+    gu = ops.exp_site_bwd(value, gv, gl, 0.5)
+    torch.testing.assert_close(gu, gv * u.exp() + gl[:, None], rtol=1e-5, atol=1e-6)
+
+
+def test_typed_logsumexp_terms_and_logchain(gpu):
+    ops = _ops()
+    g = torch.Generator(device=gpu).manual_seed(2)
+    a = torch.randn((5, 1, 7), device=gpu, generator=g)
+    b = torch.randn((1, 4, 7), device=gpu, generator=g)
+    c = torch.randn((5, 4, 1), device=gpu, generator=g)
+    out = ops.logsumexp_terms([a, b, c], [5, 4, 7], 2)
+    torch.testing.assert_close(out.double(), torch.logsumexp((a + b + c).double(), -1), rtol=1e-5, atol=1e-5)
+    out0 = ops.logsumexp_terms([a, b], [5, 4, 7], 0)
+    torch.testing.assert_close(out0.double(), torch.logsumexp((a + b).double(), 0), rtol=1e-5, atol=1e-5)
+    # a chain of T variables with K states: log Z by the forward recursion, its gradient by autograd
+    B, T, K = 9, 6, 4
+    un = torch.randn((B, T, K), device=gpu, generator=g)
+    pw = torch.randn((1, T - 1, K, K), device=gpu, generator=g)
+    log_z, gu, gp = ops.logchain(un, pw)
+    und, pwd = un.double().requires_grad_(True), pw.double().requires_grad_(True)
+    alpha = und[:, 0]
+    for t in range(1, T):
+        alpha = torch.logsumexp(alpha[:, :, None] + pwd[0, t - 1][None], 1) + und[:, t]
+    want = torch.logsumexp(alpha, -1)
+    torch.testing.assert_close(log_z.double(), want.detach(), rtol=1e-5, atol=1e-5)
+    want.sum().backward()
+    torch.testing.assert_close(gu.double(), und.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gp.double().sum(0, keepdim=True), pwd.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_typed_lda_factor_and_tall_linear(gpu):
+    from pyro_amd import kernels
+    ops = _ops()
+    g = torch.Generator(device=gpu).manual_seed(3)
+    Wd, B, T, V = 12, 40, 8, 64
+    words = torch.randint(0, V, (Wd, B), device=gpu, generator=g)
+    lt = torch.log_softmax(torch.randn((B, T), device=gpu, generator=g), -1)
+    lp = torch.log_softmax(torch.randn((T, V), device=gpu, generator=g), -1)
+    index = kernels.lda_build_index(words, V)
+    assert index is not None
+    out_doc, g_theta, g_phi = ops.lda_factor_indexed(words, index.view(torch.uint8).reshape(-1), lt, lp)
+    ltd, lpd = lt.double().requires_grad_(True), lp.double().requires_grad_(True)
+    # out[d] = sum_w logsumexp_t(log_theta[d, t] + log_phi[t, words[w, d]])
+    terms = ltd[None, :, :] + lpd.t()[words]              # [Wd, B, T]
+    want = torch.logsumexp(terms, -1).sum(0)
+    torch.testing.assert_close(out_doc.double(), want.detach(), rtol=1e-5, atol=1e-4)
+    want.sum().backward()
+    torch.testing.assert_close(g_theta.double(), ltd.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(g_phi.double(), lpd.grad, rtol=1e-4, atol=1e-4)
+    # F.linear + Sigmoid over a tall batch, and the input gradient through the previous Sigmoid
+    Bt, R, C = 5000, 24, 40
+    G = torch.randn((Bt, R), device=gpu, generator=g)
+    W = torch.randn((C, R), device=gpu, generator=g) * 0.3
+    bias = torch.randn((C,), device=gpu, generator=g)
+    Y = ops.tall_linear_act(G, W, bias, None, True, True)
+    want = torch.sigmoid(G.double() @ W.double().t() + bias.double())
+    torch.testing.assert_close(Y.double(), want, rtol=2e-5, atol=2e-6)
+    ymul = torch.rand((Bt, C), device=gpu, generator=g)
+    Gy = torch.randn((Bt, C), device=gpu, generator=g)
+    dX = ops.tall_linear_act(Gy, W, None, ymul, False, False)          # dx = (g (1 - y) y) W
+    want = (Gy.double() * (1 - ymul.double()) * ymul.double()) @ W.double()
+    torch.testing.assert_close(dX.double(), want, rtol=2e-5, atol=2e-5)
+
+
+def test_typed_nuts_round_is_the_ctypes_round(gpu):
+    """pyro_amd::nuts_tree_run_advance on a copy of a span's state == kernels.NutsTree.run_advance (ctypes) on the
+    original, bit for bit, three rounds of a Gaussian potential."""
+    import copy
+
+    from pyro_amd import kernels
+    ops = _ops()
+    C, D = 8, 5
+    g = torch.Generator(device=gpu).manual_seed(4)
+
+    def fresh():
+        gg = torch.Generator(device=gpu).manual_seed(4)
+        z = torch.randn((C, D), device=gpu, generator=gg) * 0.3
+        pe, grad = 0.5 * (z * z).sum(-1), z.clone()
+        step = torch.full((C,), 0.2, device=gpu)
+        tree = kernels.NutsTree(z, pe, grad, torch.ones((D,), device=gpu), step, 5, True, 7, 0)
+        st = dict(da=torch.zeros((C, 5), device=gpu), wf=torch.zeros((C, 2, D), device=gpu),
+                  mean=torch.zeros((C,), device=gpu), counters=torch.zeros((3, C), dtype=torch.int64, device=gpu))
+        tree.set_span(0, 3, flags=kernels.NutsTree.RUN_COUNT_ACCEPTS)
+        tree.run_begin()
+        return tree, st
+    ta, sa = fresh()
+    tb, sb = fresh()
+    for _ in range(3):
+        for tree, st, typed in ((ta, sa, False), (tb, sb, True)):
+            peq, gq = 0.5 * (tree.zq * tree.zq).sum(-1), tree.zq.clone()
+            if typed:
+                ops.nuts_tree_run_advance(tree.z, tree.pe, tree.grad, tree.zq, tree.rq, gq, peq, tree.inv_mass, tree.step,
+                                          tree.max_tree_depth, True, tree.seed, tree.chain_offset, tree.ctl, st["da"], 0.8,
+                                          st["wf"], st["mean"], st["counters"], tree.tc, tree.n_done, None, None, None,
+                                          tree.accept_prob, tree.ints, tree.ws)
+            else:
+                tree.run_advance(peq, gq, st["da"], 0.8, st["wf"], st["mean"], st["counters"])
+    for name in ("z", "pe", "grad", "zq", "rq", "accept_prob", "ints", "tc"):
+        assert torch.equal(getattr(ta, name), getattr(tb, name)), name
+    assert torch.equal(sa["counters"], sb["counters"]) and int(sa["counters"][0].sum()) > 0
+
+
+def test_torch_compile_over_the_typed_ops(gpu):
+    """torch.compile(fullgraph=True) of a function made of typed ops: they are graph nodes with shape functions
+    (no graph break, no Python call-back), and the compiled function returns the eager numbers."""
+    ops = _ops()
+    g = torch.Generator(device=gpu).manual_seed(5)
+    u = torch.randn((3, 8), device=gpu, generator=g)
+    a = torch.randn((6, 1, 5), device=gpu, generator=g)
+    b = torch.randn((1, 4, 5), device=gpu, generator=g)
+    un = torch.randn((7, 5, 3), device=gpu, generator=g)
+    pw = torch.randn((1, 4, 3, 3), device=gpu, generator=g)
+
+    def f(u, a, b, un, pw):
+        value, ld = ops.exp_site(u, 0.0)
+        rs, tot = ops.dist_log_prob_sum(4, value, torch.ones((1,), device=u.device), None, None, 1.0)
+        lse = ops.logsumexp_terms([a, b], [6, 4, 5], 2)
+        log_z, _, _ = ops.logchain(un, pw)
+        return tot + ld.sum() + lse.sum() + log_z.sum()
+
+    want = f(u, a, b, un, pw)
+    got = torch.compile(f, fullgraph=True, backend="aot_eager")(u, a, b, un, pw)
+    torch.testing.assert_close(got, want, rtol=0, atol=0)

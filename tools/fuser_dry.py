@@ -34,6 +34,7 @@ def compile_only(src, grid, block, tensors):
         raise SystemExit(log.value.decode()[:3000])
     _COMPILED.add(src)          # (its own record: fuser._CACHE holds kernel handles)
     fuser.STATS["compiled"] += 1
+    fuser.STATS["loaded"] += 1
     assert len(tensors) <= fuser.MAX_POINTERS
 
 
@@ -175,6 +176,7 @@ def _host_launch(src, grid, block, tensors):
         lib = _HOST_LIBS[src] = ctypes.CDLL(name + ".so")
         lib.pa_host_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_long]
         fuser.STATS["compiled"] += 1
+    fuser.STATS["loaded"] += 1
     keep = [t for t in tensors if isinstance(t, torch.Tensor)]
     table = (ctypes.c_void_p * len(tensors))(*[t[1] if isinstance(t, tuple) else t.data_ptr() for t in tensors])
     lib.pa_host_launch(table, len(tensors), int(grid))
