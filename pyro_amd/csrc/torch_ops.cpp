@@ -291,8 +291,8 @@ std::tuple<std::vector<at::Tensor>, std::vector<at::Tensor>, std::vector<at::Ten
   return {z, scale, eps};
 }
 
-// the positive-support transform of a parameter / site in one launch: value = lower + exp(u), log|dv/du| = u
-// (torch.distributions.constraint_registry biject_to(positive / greater_than); pyro/params/param_store.py:138-199)
+// a positive-support latent under AutoNormal in one launch: value = lower + exp(u) and the Delta site's
+// log-density -sum_c u (pyro/infer/autoguide/guides.py:494-519; biject_to(positive / greater_than))
 std::tuple<at::Tensor, at::Tensor> exp_site(const at::Tensor& u, double lower) {
   const int dt = dtype_of(u, "exp_site");
   TORCH_CHECK(u.is_contiguous(), "pyro_amd::exp_site: contiguous u");

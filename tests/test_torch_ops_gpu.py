@@ -254,10 +254,10 @@ def test_typed_exp_site_and_its_backward(gpu):
     u = torch.linspace(-3, 2, 24, device=gpu).reshape(4, 6).contiguous()
     value, ld = ops.exp_site(u, 0.5)
     torch.testing.assert_close(value, 0.5 + u.exp(), rtol=1e-6, atol=1e-7)
-    torch.testing.assert_close(ld, u.sum(-1), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ld, -u.sum(-1), rtol=1e-6, atol=1e-6)      # the Delta site's density: -log|dv/du|
     gv, gl = torch.randn_like(value), torch.randn((4,), device=gpu)
     gu = ops.exp_site_bwd(value, gv, gl, 0.5)
-    torch.testing.assert_close(gu, gv * u.exp() + gl[:, None], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gu, gv * u.exp() - gl[:, None], rtol=1e-5, atol=1e-6)
 
 
 def test_typed_logsumexp_terms_and_logchain(gpu):
@@ -322,7 +322,7 @@ def test_typed_lda_factor_and_tall_linear(gpu):
 
 def test_typed_nuts_round_is_the_ctypes_round(gpu):
     """pyro_amd::nuts_tree_run_advance on a copy of a span's state == kernels.NutsTree.run_advance (ctypes) on the
-    original, bit for bit, three rounds of a Gaussian potential."""
+    original, bit for bit, forty rounds of a Gaussian potential (chains finish trees and start their next ones)."""
     import copy
 
     from pyro_amd import kernels
@@ -343,7 +343,7 @@ def test_typed_nuts_round_is_the_ctypes_round(gpu):
         return tree, st
     ta, sa = fresh()
     tb, sb = fresh()
-    for _ in range(3):
+    for _ in range(40):
         for tree, st, typed in ((ta, sa, False), (tb, sb, True)):
             peq, gq = 0.5 * (tree.zq * tree.zq).sum(-1), tree.zq.clone()
             if typed:
