@@ -650,11 +650,20 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     int bn = bi + 1 == NB ? 0 : bi + 1;
     wait_tiles_in_flight(std::integral_constant<int, NB - 3>{});
     if constexpr (!PRIV) __builtin_amdgcn_s_barrier();
-    {
+    // the LDS-DMA of tile it + NB - 1 goes into the slot the barrier above has just freed.  Issued by every
+    // wave at once right behind the barrier, the ~100 issue cycles of each piece (MI355X_MICROARCH.md: an LDS-DMA
+    // piece costs 60-185 cycles of issue inside a busy phase) fall on all waves of the SIMD at the same moment;
+    // PA_GLMH_DMA_STAGGER moves it into the element-wise stream of half (1) or all (2) of the waves
+    auto issue_next = [&]() {
       int bf = bi + (NB - 1);
       bf = bf >= NB ? bf - NB : bf;
       issue(st + (NB - 1) * grid, bf);
-    }
+    };
+#ifndef PA_GLMH_DMA_STAGGER
+#define PA_GLMH_DMA_STAGGER 0
+#endif
+    const bool dma_late = PA_GLMH_DMA_STAGGER == 2 || (PA_GLMH_DMA_STAGGER == 1 && (wave & 1) != 0);
+    if (!dma_late) issue_next();
     const unsigned char* Xc = smem + C::OFS_RING + (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + rt * GLMH_TILE);
     const unsigned char* Xn = smem + C::OFS_RING + (PRIV ? (wave * NB + bn) * GLMH_TILE : bn * ST_BYTES + rt * GLMH_TILE);
     const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y +
@@ -679,6 +688,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
       elem2(acc_cur[2 * t], acc_cur[2 * t + 1], yv[2 * t], yv[2 * t + 1], t & 1, g[2 * t], g[2 * t + 1]);
     }
     load_a(Xn, 1, xa);
+    if (dma_late) issue_next();
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       acc_nxt = GLMH_MFMA1(xa[TA[t]], wa1[TB[t]], acc_nxt);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel of NUTS on the logistic-regression MODEL (the plane-image GLM kernel at
-# P = chains), two PMC passes as tools/prof.sh: writes gpurun_out/r05_nuts_model_traffic.json
+# P = chains), two PMC passes as tools/prof.sh: writes gpurun_out/${TAG:-r06}_nuts_model_traffic.json
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 OUT=gpurun_out/nuts_model_pmc; rm -rf $OUT; mkdir -p $OUT
@@ -31,7 +31,7 @@ for N in (100000, 1000000):
 res["how"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/bench_nuts_model.py (full rounds, no "
               "compaction), median over the kernel's launches; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 "
               "correction of MI355X_MICROARCH.md); tools/nuts_model_traffic.sh")
-json.dump(res, open("gpurun_out/r05_nuts_model_traffic.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/%s_nuts_model_traffic.json" % os.environ.get("TAG", "r06"), "w"), indent=1)
 print(json.dumps(res)[:1200])
 for f in glob.glob(out + "/**/*.db", recursive=True): os.remove(f)
 for f in glob.glob(out + "/**/*kernel_trace.csv", recursive=True): os.remove(f)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the NUTS kernels over one MCMC.run of bench.py's secondary workload (two PMC passes, as
-# tools/prof.sh): writes gpurun_out/r05_nuts_traffic.json
+# tools/prof.sh): writes gpurun_out/${TAG:-r06}_nuts_traffic.json
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
 OUT=gpurun_out/nuts_pmc; rm -rf $OUT; mkdir -p $OUT
@@ -32,6 +32,6 @@ if secondary:
     res["leapfrogs"] = secondary.get("leapfrogs")
     if secondary.get("leapfrogs"):
         res["hbm_bytes_per_leapfrog"] = res["hbm_bytes_total"] / secondary["leapfrogs"]
-json.dump(res, open("gpurun_out/r05_nuts_traffic.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/%s_nuts_traffic.json" % os.environ.get("TAG", "r06"), "w"), indent=1)
 print(json.dumps(res)[:1500])
 PY
