@@ -237,6 +237,23 @@ __device__ __forceinline__ f32x16v glmh_keep(const f16x8& a, const f16x8& b, con
 #define GLMH_MFMA2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
 
+// PA_GLMH_SCHED (experiment): a scheduling barrier behind each MFMA + element-wise group pins the source's
+// interleave (hipcc's machine scheduler otherwise gathers dependent MFMAs into back-to-back runs)
+#ifndef PA_GLMH_SCHED
+#define PA_GLMH_SCHED 0
+#endif
+// PA_GLMH_DEFER (experiment): the three GEMM2 MFMAs of a tile's SECOND K half, which have no element-wise work left
+// beside them, run beside the first element-wise groups of the NEXT tile instead (their operands wait in 16
+// registers; same accumulation order: bit-identical)
+#ifndef PA_GLMH_DEFER
+#define PA_GLMH_DEFER 0
+#endif
+#if PA_GLMH_SCHED
+#define GLMH_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GLMH_SB() do { } while (0)
+#endif
+
 // LIN: the label-linear part of the log-likelihood, sum_n (y_n - 1/2) l[n,p] = c . w_p + c0 b_p with the
 // data moments c[d] = sum_n (y_n - 1/2) x[n,d], c0 = sum_n (y_n - 1/2) (pa_glm_label_moments: float64,
 // once per (X, y)), is added by workgroup 0 of each pass in the epilogue instead of one fma per (row,
@@ -627,6 +644,9 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   // -- the loop below calls it with the two accumulators swapped every other tile, so that the
   // hand-over costs no register copies
   int64_t it = 0;
+#if PA_GLMH_DEFER
+  f16x8 pend_ga[2] = {}, pend_xb[2] = {};       // (zeros the first time: those MFMAs add nothing)
+#endif
   auto tile = [&](const f32x16v& acc_cur, f32x16v& acc_nxt) {
 #if defined(PA_GLMH_ABL_NOPRIO)
     if constexpr (false) {
@@ -650,20 +670,14 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     int bn = bi + 1 == NB ? 0 : bi + 1;
     wait_tiles_in_flight(std::integral_constant<int, NB - 3>{});
     if constexpr (!PRIV) __builtin_amdgcn_s_barrier();
-    // the LDS-DMA of tile it + NB - 1 goes into the slot the barrier above has just freed.  Issued by every
-    // wave at once right behind the barrier, the ~100 issue cycles of each piece (MI355X_MICROARCH.md: an LDS-DMA
-    // piece costs 60-185 cycles of issue inside a busy phase) fall on all waves of the SIMD at the same moment;
-    // PA_GLMH_DMA_STAGGER moves it into the element-wise stream of half (1) or all (2) of the waves
-    auto issue_next = [&]() {
+    {
+      // (issued right behind the barrier by every wave.  Moving the issue into the element-wise stream of half
+      //  or all of the waves -- so that the ~100 issue cycles of a piece do not fall on every wave of a SIMD at
+      //  once -- was measured at 76 / 79 us against 54: profiles/r06_glm16_cycle_budget.txt)
       int bf = bi + (NB - 1);
       bf = bf >= NB ? bf - NB : bf;
       issue(st + (NB - 1) * grid, bf);
-    };
-#ifndef PA_GLMH_DMA_STAGGER
-#define PA_GLMH_DMA_STAGGER 0
-#endif
-    const bool dma_late = PA_GLMH_DMA_STAGGER == 2 || (PA_GLMH_DMA_STAGGER == 1 && (wave & 1) != 0);
-    if (!dma_late) issue_next();
+    }
     const unsigned char* Xc = smem + C::OFS_RING + (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + rt * GLMH_TILE);
     const unsigned char* Xn = smem + C::OFS_RING + (PRIV ? (wave * NB + bn) * GLMH_TILE : bn * ST_BYTES + rt * GLMH_TILE);
     const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y +
@@ -685,10 +699,13 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       acc_nxt = GLMH_MFMA1(xa[TA[t]], wa0[TB[t]], acc_nxt);
+#if PA_GLMH_DEFER
+      gwacc = GLMH_MFMA2(pend_ga[TA[t]], pend_xb[TB[t]], gwacc);      // GEMM2(it - 1, K half 1)
+#endif
       elem2(acc_cur[2 * t], acc_cur[2 * t + 1], yv[2 * t], yv[2 * t + 1], t & 1, g[2 * t], g[2 * t + 1]);
+      GLMH_SB();
     }
     load_a(Xn, 1, xa);
-    if (dma_late) issue_next();
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       acc_nxt = GLMH_MFMA1(xa[TA[t]], wa1[TB[t]], acc_nxt);
@@ -698,6 +715,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
         split_pair_f16(g[4 * (t - 1)], g[4 * (t - 1) + 1], g1[2 * (t - 1)], g2[2 * (t - 1)]);
         split_pair_f16(g[4 * (t - 1) + 2], g[4 * (t - 1) + 3], g1[2 * (t - 1) + 1], g2[2 * (t - 1) + 1]);
       }
+      GLMH_SB();
     }
     tr_wait(xlo, xhi, xb);
     // -- GEMM2(it, K half 0)  ||  element-wise(it, K half 1)
@@ -714,6 +732,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
         for (int qp = q0; qp < q1; ++qp)
           elem2(acc_cur[8 + 2 * qp], acc_cur[9 + 2 * qp], yv[2 * qp], yv[2 * qp + 1], qp & 1, g[2 * qp],
                 g[2 * qp + 1]);
+        GLMH_SB();
       }
     }
     uint32_t h1[4], h2[4];
@@ -723,9 +742,14 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     // -- GEMM2(it, K half 1)
     {
       const f16x8 ga[2] = {as_f16x8(h1[0], h1[1], h1[2], h1[3]), as_f16x8(h2[0], h2[1], h2[2], h2[3])};
+#if PA_GLMH_DEFER
+      pend_ga[0] = ga[0]; pend_ga[1] = ga[1];
+      pend_xb[0] = xb[0]; pend_xb[1] = xb[1];
+#else
 #pragma unroll
       for (int t = 0; t < 3; ++t)
         gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
+#endif
     }
     st += grid;
     bi = bn;
@@ -745,6 +769,10 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     }
     if (it < my_count) tile(acc_cur, acc_alt);
   }
+#if PA_GLMH_DEFER
+#pragma unroll
+  for (int t = 0; t < 3; ++t) gwacc = GLMH_MFMA2(pend_ga[TA[t]], pend_xb[TB[t]], gwacc);
+#endif
   wait_vmcnt<0>();
   __builtin_amdgcn_s_setprio(0);
   renorm();
