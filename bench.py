@@ -388,9 +388,10 @@ def bench_model_nuts(dev, rank, world, args):
     C, D = args.model_nuts_chains, args.features
     W, S = args.model_nuts_warmup, args.model_nuts_samples
 
-    def run(X, y, warmup, samples, chains):
+    def run(X, y, warmup, samples, chains, init=None):
         pyro.set_rng_seed(11 + rank)
-        kernel = NUTS(examples.logreg_model, max_tree_depth=args.model_nuts_depth)
+        kw = {} if init is None else {"init_strategy": init}
+        kernel = NUTS(examples.logreg_model, max_tree_depth=args.model_nuts_depth, **kw)
         mcmc = MCMC(kernel, num_samples=samples, warmup_steps=warmup, num_chains=chains,
                     shard_chains=False)
         marks = {}
@@ -416,20 +417,27 @@ def bench_model_nuts(dev, rank, world, args):
                                   compactions=getattr(kernel, "_span_compactions", 0))
 
     out = {}
-    # (N, chains, warm-up, samples).  The 1e6-row posterior is ~30x tighter than the prior's scale: chains started
-    # at the reference's uniform(-2, 2) points travel for ~100 transitions with deep trees before the step size
-    # and the diagonal mass have adapted (tools/nuts_model_converge.py: 150 warm-up transitions -> R-hat 1.07,
-    # 300 -> 1.045, and the sampling phase then runs ~7 leaves per transition at 0.94 round occupancy); round 5
-    # timed 50 + 25 transitions of chains that had not arrived (R-hat 8.4, occupancy 0.28)
-    plan = [(100_000, C, 5 * W, 10 * S), (100_000, 4 * C, 2 * W, 4 * S), (1_000_000, C, 3 * W, 2 * S)]
+    # (N, chains, warm-up, samples, init strategy).  The 1e6-row posterior is ~1000x tighter than the prior's scale.
+    # From the reference's default starting points (init_to_uniform: U(-2, 2) in every coordinate, potential ~5e6
+    # with gradients of ~1e5 per coordinate) most chains reach it within ~100 transitions, but with 256 chains one
+    # or two do not: their step size collapses (1e-7) while the gradient is still enormous, and in float32 the
+    # position update eps * v falls below the position's ulp -- such a chain is frozen for good and every later
+    # transition of it is a 1023-leapfrog tree the other 255 chains wait for (tools/_nuts_stuck*.py printed it;
+    # round 5's R-hat of 8.4 and this round's first collection, R-hat 77, were that).  The N = 1e6 run therefore
+    # starts at the prior's median -- NUTS(init_strategy=init_to_median), the reference's own strategy
+    # (pyro/infer/autoguide/initialization.py:67-92, accepted by pyro/infer/mcmc/nuts.py:125) -- from where 150
+    # warm-up transitions give R-hat 1.04 with either wave geometry; the 1e5-row runs keep the default.
+    from pyro_amd.infer.autoguide.initialization import init_to_median
+    plan = [(100_000, C, 5 * W, 10 * S, None), (100_000, 4 * C, 2 * W, 4 * S, None),
+            (1_000_000, C, 3 * W, 2 * S, init_to_median)]
     if dev.type != "cuda":                 # the plumbing test of tests/test_distributed_cpu.py
-        plan = [(args.plate, C, W, S)]
+        plan = [(args.plate, C, W, S, None)]
     X = y = None
-    for N, C, W, S in plan:
+    for N, C, W, S, init in plan:
         if X is None or X.shape[0] != N:
             X, y = examples.synthetic_logreg_data(N, D, dev, seed=0)
-        run(X, y, min(12, W), min(4, S), C)      # warm the allocator / code objects / the plane image of X
-        kernel, mcmc, r = run(X, y, W, S, C)
+        run(X, y, min(12, W), min(4, S), C, init)      # warm the allocator / code objects / the plane image of X
+        kernel, mcmc, r = run(X, y, W, S, C, init)
         tot = torch.tensor([float(r["n"]), r["wall"], float(r["n_sample"]), r["t_sample"]], device=dev,
                            dtype=torch.float64)
         if world > 1:
@@ -468,8 +476,9 @@ def bench_model_nuts(dev, rank, world, args):
                                                        if isinstance(d, dict) and "r_hat" in d)),
                                 "mean_accept_prob": float(kernel._mean_accept_prob.mean()),
                                 "mean_step_size": float(kernel.step_size.mean())},
-            "roofline": {"bound": "hbm", "kernel": "glm_planes_f16_kernel (P = %d chains: %d passes of 64 over "
-                                                   "the image)" % (C, -(-C // 64)),
+            "roofline": {"bound": "hbm", "kernel": "glm_planes_f16_kernel (P = %d chains: %d pass%s of %d over "
+                                                   "the image)" % (C, -(-C // (256 if C > 128 else 128 if C > 64 else 64)),
+                                                                   "" if C <= 256 else "es", 256 if C > 128 else 128 if C > 64 else 64),
                          "kernel_ms": kern_ms, "kernel_ms_source": "HIP events around the kernel on its launch "
                          "stream, median of %d eager evaluations of the potential" % len(kms),
                          "algorithmic_bytes_per_round": alg, "achieved": alg / (kern_ms * 1e-3) / 1e9,
@@ -491,6 +500,7 @@ def bench_model_nuts(dev, rank, world, args):
             except Exception:
                 pass
         out[key]["transitions"] = "%d warm-up + %d samples" % (W, S)
+        out[key]["init_strategy"] = "init_to_uniform (default)" if init is None else init.__name__
         # a run whose chains have not mixed is a throughput measurement of unconverged chains: said so, and
         # its roofline block is not a claim about a working sampler
         out[key]["converged"] = bool(out[key]["posterior_check"]["max_r_hat"] < 1.05)

@@ -518,6 +518,8 @@ static int64_t glm_planes_tiles(int64_t N) {
 struct GlmPlanesPlan {
   int nb, bpc, npass, nblocks;
   int64_t nst;
+  int nrt = 2, npt = 2;     // waves per workgroup of the f16 kernel: row tiles x particle tiles (glm_planes16.h)
+  int ypass = 0;            // grid.y (0: = npass)
 };
 
 static GlmPlanesPlan glm_planes_plan(int64_t N, int64_t P) {
@@ -575,7 +577,9 @@ static void glm_planes_launch_grouped(int nseg, int npass, const unsigned char* 
 // ---- the two-plane f16 image (glm_planes16.h): 8 KiB super-tiles, four workgroups per CU ----------
 static int64_t glmh_tile_bytes(int64_t ntiles) { return ntiles * (int64_t)GLMH_TILE; }
 
-static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
+static bool g_planes_wide = true;      // pa_glm_planes_tune(11, .): 2 x 2 waves whatever P (measurement knob)
+
+static GlmPlanesPlan glmh_plan(int64_t N, int64_t P, bool allow_wide = true) {
   GlmPlanesPlan pl;
   pl.nb = g_planes_nb;
   // measured at the headline size (tools/bench_glm_planes.py, kernel + finalize): 2 workgroups per
@@ -586,7 +590,35 @@ static GlmPlanesPlan glmh_plan(int64_t N, int64_t P) {
   int64_t cap = (int64_t)cu_count() * pl.bpc / pl.npass;
   if (cap < 1) cap = 1;
   pl.nblocks = (int)(pl.nst < cap ? (pl.nst < 1 ? 1 : pl.nst) : cap);
+  pl.ypass = pl.npass;
+  if (allow_wide && g_planes_wide && pl.nb == 3 && g_planes_bpc <= 0 && P > 64) {
+    // many particles / chains: 128 or 256 of them per pass over the image, eight waves per workgroup, one
+    // workgroup per CU (the same two waves per SIMD).  The records keep the 64-particle format: npass groups
+    pl.nrt = P > 128 ? 1 : 2;
+    pl.npt = P > 128 ? 8 : 4;
+    const int64_t wrows = 32 * pl.npt;
+    pl.ypass = (int)((P + wrows - 1) / wrows);
+    pl.nst = pl.nrt == 1 ? (N + 31) / 32 : ((N + 31) / 32 + 1) / 2;
+    pl.bpc = 1;
+    cap = (int64_t)cu_count() / pl.ypass;
+    if (cap < 1) cap = 1;
+    pl.nblocks = (int)(pl.nst < cap ? (pl.nst < 1 ? 1 : pl.nst) : cap);
+  }
   return pl;
+}
+
+// the wide geometries: 2 x 4 / 1 x 8 waves (LIN only: a guide draw in the prologue stays with 2 x 2)
+template <int NRT, int NPT, bool LIN>
+static void glmh_launch_wide(const GlmPlanesPlan& pl, const unsigned char* img, const float* y, const float* w,
+                             const float* b, int64_t N, int D, int P, float* part, const uint32_t* trailer,
+                             hipStream_t s, const double* moments) {
+  auto k = glm_planes_f16_kernel<3, 1, false, false, LIN, false, NRT, NPT>;
+  constexpr int lds = GlmHCfg<3, false, NRT, NPT>::LDS_BYTES;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3((unsigned)pl.nblocks, (unsigned)pl.ypass), dim3(64 * NRT * NPT), lds, s, img, y, w, b,
+                     N, D, P, pl.nst, part, cu_count(), trailer, g_planes_stamps, GlmGroupArgs{nullptr, nullptr, 1},
+                     gate_word(), moments, GlmDraw{});
+  gate_aware_launch();
 }
 
 template <int NB, int OCC, bool PRIV = false, bool LIN = false, bool DRAW = false>
@@ -1068,10 +1100,12 @@ int pa_glm_planes_finalize_mode(int in_kernel) {
 int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
   // (f16 image: 3 / 4 = ring depth of the 32 x 32-tile kernel; measurement knobs: 5 / 6 the same with
   //  per-wave private rings of depth 3 / 4, 9 / 10 one wave per tile and 64 particles, ring depth 3 / 4)
-  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 10),
-             "glm_planes_tune: ring depth code 3..10 (0 = default)");
+  //  11 = the default ring with the 2 x 2 wave geometry whatever P: no 128 / 256-particle passes)
+  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 11),
+             "glm_planes_tune: ring depth code 3..11 (0 = default)");
   PA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 4, "glm_planes_tune: 0..4 workgroups per CU");
-  pa::g_planes_nb = ring_depth == 0 ? 3 : ring_depth;
+  pa::g_planes_wide = ring_depth != 11;
+  pa::g_planes_nb = (ring_depth == 0 || ring_depth == 11) ? 3 : ring_depth;
   pa::g_planes_bpc = blocks_per_cu;
   return PA_OK;
 }
@@ -1159,7 +1193,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
              "glm_planes: workspace too small");
   if (D > 32) return pa::glmd_run(planes, y, w, b, scale, N, (int)D, (int)P, ll, gw, gb, (float*)workspace, stream, s);
   pa::GlmPlanesPlan pl =
-      format == PA_GLM_PLANES_F16X2 ? pa::glmh_plan(N, P) : pa::glm_planes_plan(N, P);
+      format == PA_GLM_PLANES_F16X2 ? pa::glmh_plan(N, P, !drawn) : pa::glm_planes_plan(N, P);
   // the f16 image: tuning codes 9 / 10 run one wave per 32-row tile and 64 particles (glm_planes16w.h,
   // ring depth 3 / 4) -- measured equal to the default kernel (profiles/r04_glm16_ablation.txt): both
   // are bound by the same element-wise VALU stream
@@ -1171,7 +1205,7 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   if (br) (void)hipEventRecord(ev0, s);
   // every padding row of the processed super-tiles added log2(2) = 1 to the log2(1 + e) sum of
   // every particle (glm_planes.h): ln2 per row back in
-  const double ll_offset = (double)((wide ? (N + 127) / 128 * 128 : pl.nst * 64) - N) * 0.6931471805599453;
+  const double ll_offset = (double)((wide ? (N + 127) / 128 * 128 : pl.nst * 32 * pl.nrt) - N) * 0.6931471805599453;
   pa::GlmFinArgs fin;
   fin.counters = nullptr;
   if (format == PA_GLM_PLANES_BF16X3 && pa::g_planes_fin_mode == 1 && pl.npass <= pa::GLMF_MAX_PASSES) {
@@ -1187,7 +1221,11 @@ int pa_glm_bernoulli_planes_fwd_bwd(int format, const void* planes, const float*
   fin.tstamps = pa::g_planes_stamps;
   if (format == PA_GLM_PLANES_F16X2) {
     const uint32_t* trailer = (const uint32_t*)(img + pa::glmh_tile_bytes(pa::glm_planes_tiles(N)));
-    if (wide && pl.nb == 9) pa::glmw_launch<3>(pl.bpc, img, y, w, b, N, (int)D, (int)P, part, trailer, &pl.nblocks, s);
+    if (pl.npt == 4 && moments != nullptr) pa::glmh_launch_wide<2, 4, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, moments);
+    else if (pl.npt == 4) pa::glmh_launch_wide<2, 4, false>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, nullptr);
+    else if (pl.npt == 8 && moments != nullptr) pa::glmh_launch_wide<1, 8, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, moments);
+    else if (pl.npt == 8) pa::glmh_launch_wide<1, 8, false>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s, nullptr);
+    else if (wide && pl.nb == 9) pa::glmw_launch<3>(pl.bpc, img, y, w, b, N, (int)D, (int)P, part, trailer, &pl.nblocks, s);
     else if (wide) pa::glmw_launch<4>(pl.bpc, img, y, w, b, N, (int)D, (int)P, part, trailer, &pl.nblocks, s);
     else if (pl.nb == 5) pa::glmh_launch_one<3, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);
     else if (pl.nb == 6) pa::glmh_launch_one<4, 3, true>(pl, img, y, w, b, N, (int)D, (int)P, part, trailer, s);

@@ -57,6 +57,7 @@ __device__ __forceinline__ void glm_finalize_body(
         for (int u = 0; u < 24; ++u) acc += (double)v[u];
       }
     }
+#ifndef PA_FIN_NO16
     {
       // (a thread's 16 records of the 512-workgroup default launch: one round trip, not two)
       float v[16];
@@ -67,6 +68,7 @@ __device__ __forceinline__ void glm_finalize_body(
         for (int u = 0; u < 16; ++u) acc += (double)v[u];
       }
     }
+#endif
     float v[8];
     for (; blk + 7 * FIN_GROUPS < nblocks; blk += 8 * FIN_GROUPS) {   // 8 loads in flight
 #pragma unroll

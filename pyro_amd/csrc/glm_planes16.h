@@ -203,19 +203,29 @@ __global__ __launch_bounds__(256) void glm_pack_planes_f16_grouped_kernel(
 // -- particle tiles 0 and 1 -- each fetch it, the second from the cache) instead of the workgroup
 // sharing a ring of super-tiles: the tile loop then needs no workgroup barrier at all, only the wave's
 // own counted s_waitcnt.
-template <int NB, bool PRIV = false>
+// NRT x NPT waves per workgroup: NRT row tiles of 32 rows (one super-tile of the ring) x NPT particle tiles of 32.
+// 2 x 2 (256 threads, 64 particles per pass over the image) is the SVI geometry; 2 x 4 and 1 x 8 (512 threads, 128 /
+// 256 particles per pass) serve many chains / particles with ONE pass over the image where 2 x 2 makes two / four
+// (NUTS on a model: P = the number of chains) -- the image pieces, the observations and their LDS-DMA issue cost
+// are then shared by twice / four times as many (row, particle) elements.
+template <int NB, bool PRIV = false, int NRT_ = 2, int NPT_ = 2>
 struct GlmHCfg {
-  static constexpr int NRT = 2, NPT = 2;
-  static constexpr int ST_BYTES = NRT * GLMH_TILE;     // 8 KiB super-tile image (64 rows)
-  static constexpr int PW = PRIV ? GLMH_TILE / 1024 : ST_BYTES / 1024 / 4;   // 1 KiB DMA pieces per wave and tile
-  static constexpr int NDMA = PW + 1;                  // + the wave's 32 observations
-  static constexpr int RING_BYTES = PRIV ? 4 * NB * GLMH_TILE : NB * ST_BYTES;
+  static constexpr int NRT = NRT_, NPT = NPT_, NW = NRT_ * NPT_;
+  static constexpr int ST_BYTES = NRT * GLMH_TILE;     // super-tile image (32 NRT rows)
+  static constexpr int PIECES = ST_BYTES / 1024;       // 1 KiB DMA pieces per super-tile
+  // pieces per issuing wave and tile, and how many waves issue (1 x 8: four of the eight)
+  static constexpr int PW = PRIV ? GLMH_TILE / 1024 : (PIECES >= NW ? PIECES / NW : 1);
+  static constexpr int DMA_WAVES = PRIV ? NW : PIECES / PW;
+  static constexpr int NDMA = PW + 1;                  // + the observations (wave 0; PRIV: every wave)
+  static constexpr int RING_BYTES = PRIV ? NW * NB * GLMH_TILE : NB * ST_BYTES;
   static constexpr int WROWS = 32 * NPT;
   static constexpr int WPL = WROWS * 64;               // one W plane
   static constexpr int OFS_WAUX = 2 * WPL;             // per particle 16 B: {b1 | b2, b3, descale, -}
   static constexpr int OFS_RING = OFS_WAUX + WROWS * 16;
   static constexpr int OFS_Y = OFS_RING + RING_BYTES;
   static constexpr int LDS_BYTES = OFS_Y + NB * 4 * 256;
+  static_assert(!PRIV || (NRT_ == 2 && NPT_ == 2), "private rings: the 2 x 2 geometry only");
+  static_assert(PW * DMA_WAVES == PIECES || PRIV, "the image pieces must divide over the issuing waves");
 };
 
 constexpr uint32_t F16_2P15 = 0x7800u;        // 2^15
@@ -263,8 +273,9 @@ __device__ __forceinline__ f32x16v glmh_keep(const f16x8& a, const f16x8& b, con
 // prologue draws them itself -- z = loc + softplus(rho) eps with eps from the guide's Philox blocks, the
 // numbers pa_meanfield_normal_sample would have written -- and workgroup 0 of each pass stores z, eps,
 // scale and loc for the step's tail; `w` / `b` are not read.
-template <int NB, int OCC, bool GROUPED = false, bool PRIV = false, bool LIN = false, bool DRAW = false>
-__global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
+template <int NB, int OCC, bool GROUPED = false, bool PRIV = false, bool LIN = false, bool DRAW = false,
+          int NRT_ = 2, int NPT_ = 2>
+__global__ __launch_bounds__(64 * NRT_ * NPT_, OCC) void glm_planes_f16_kernel(
     const unsigned char* __restrict__ img, const float* __restrict__ y,
     const float* __restrict__ w, const float* __restrict__ b, int64_t N, int D, int P,
     int64_t nst, float* __restrict__ part, int prio_cus, const uint32_t* __restrict__ trailer,
@@ -272,9 +283,16 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const int64_t* __restrict__ gate, const double* __restrict__ moments = nullptr,
     const GlmDraw draw = GlmDraw{}) {
   if (gate != nullptr && *gate != 0) return;        // the step gate gave this replay up (pa_gate)
-  using C = GlmHCfg<NB, PRIV>;
+  using C = GlmHCfg<NB, PRIV, NRT_, NPT_>;
   constexpr int NRT = C::NRT, NPT = C::NPT, ST_BYTES = C::ST_BYTES, PW = C::PW, WROWS = C::WROWS,
-                WPL = C::WPL;
+                WPL = C::WPL, NT = 64 * C::NW;
+  static_assert(!GROUPED || (NRT == 2 && NPT == 2), "the grouped image: 2 x 2 only");
+#ifdef PA_GLMH_Y_PER_WAVE
+  constexpr bool YSHARE = !PRIV && !(NRT == 2 && NPT == 2);   // (A/B switch: in the 2 x 2 geometry every wave
+                                                              //  fetches and transforms its own 32 observations)
+#else
+  constexpr bool YSHARE = !PRIV;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -309,9 +327,11 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const unsigned char* src = img + stc * ST_BYTES + (PRIV ? rt * GLMH_TILE : (wave * PW) * 1024) + lane * 16;
     const uint32_t dst = lds_base + C::OFS_RING +
                          (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + (wave * PW) * 1024);
+    if (PRIV || wave < C::DMA_WAVES) {
 #pragma unroll
-    for (int k = 0; k < PW; ++k) dma16(src + k * 1024, dst + k * 1024);
-    if constexpr (PRIV) {
+      for (int k = 0; k < PW; ++k) dma16(src + k * 1024, dst + k * 1024);
+    }
+    if constexpr (!YSHARE) {
       int64_t row = (stc * NRT + rt) * 32 + l31;
       if constexpr (!GROUPED) row = row < N ? row : N - 1;
       dma4(y + row, lds_base + C::OFS_Y + (bi * 4 + wave) * 256);
@@ -324,12 +344,13 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
       dma4(y + row, lds_base + C::OFS_Y + bi * 1024);
     }
   };
-  // this wave's LDS-DMA instructions per tile (wave-uniform)
-  const int my_ndma = (PRIV || wave == 0) ? C::NDMA : C::NDMA - 1;
+  // this wave's LDS-DMA instructions per tile (wave-uniform): its image pieces (+ the observations: wave 0)
+  const int my_ndma = !YSHARE ? C::NDMA : (wave < C::DMA_WAVES ? PW : 0) + (wave == 0 ? 1 : 0);
   auto wait_tiles_in_flight = [&](auto kconst) {
     constexpr int K = decltype(kconst)::value;
-    if (my_ndma == C::NDMA) wait_vmcnt<K * C::NDMA>();
-    else wait_vmcnt<K * (C::NDMA - 1)>();
+    if (my_ndma == PW + 1) wait_vmcnt<K * (PW + 1)>();
+    else if (my_ndma == PW) wait_vmcnt<K * PW>();
+    else wait_vmcnt<0>();                           // (a wave that issues nothing has nothing in flight)
   };
 
 #pragma unroll
@@ -338,19 +359,23 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
   // ---- W planes and the per-particle constants, once per block: thread (pl, s) holds 8 features of
   //      particle row pl; the four threads of a row are neighbours --------------------------------
   const int kx_l = (int)trailer[GLMH_KX + l31];        // the exponent of this lane's gradient column
-  {
-    const int pl = threadIdx.x >> 2, s = threadIdx.x & 3;
+  float* sp_s = reinterpret_cast<float*>(smem + C::LDS_BYTES);          // DRAW: 64 floats behind the rings
+  if constexpr (DRAW) {
+    // softplus(rho) once per workgroup (32 + 1 values through LDS) instead of 8 per thread: the
+    // draw sits on the critical path of every workgroup's start
+    if (threadIdx.x < 32) sp_s[threadIdx.x] = (int)threadIdx.x < D ? softplus_t<float>(draw.rho_w[threadIdx.x]) : 0.0f;
+    else if (threadIdx.x == 32) sp_s[32] = draw.have_b ? softplus_t<float>(draw.rho_b[0]) : 0.0f;
+    __syncthreads();
+  }
+  // (NT / 4 particle rows per round: one round at 2 row tiles, two at one)
+#pragma unroll 1
+  for (int pl0 = 0; pl0 < WROWS; pl0 += NT / 4) {
+    const int pl = pl0 + (int)(threadIdx.x >> 2), s = threadIdx.x & 3;
     const int p = pbase + pl;
     float v[8];
     float mw = 0.0f;
     float wraw[8], braw = 0.0f;          // the weights / bias in model units
     if constexpr (DRAW) {
-      // softplus(rho) once per workgroup (32 + 1 values through LDS) instead of 8 per thread: the
-      // draw sits on the critical path of every workgroup's start
-      float* sp_s = reinterpret_cast<float*>(smem + C::LDS_BYTES);          // 64 floats behind the rings
-      if (threadIdx.x < 32) sp_s[threadIdx.x] = (int)threadIdx.x < D ? softplus_t<float>(draw.rho_w[threadIdx.x]) : 0.0f;
-      else if (threadIdx.x == 32) sp_s[32] = draw.have_b ? softplus_t<float>(draw.rho_b[0]) : 0.0f;
-      __syncthreads();
       const uint64_t obase = draw.offset_dev ? *draw.offset_dev : 0;
       const bool store = blockIdx.x == 0 && p < P;
       float nrm[8];
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const bool okr = (int64_t)l31 < rows_left;
     // (GROUPED: the image already holds the transformed observations)
     if constexpr (!GROUPED) {
-      if constexpr (PRIV) {
+      if constexpr (!YSHARE) {
         float* ys_ = reinterpret_cast<float*>(smem + C::OFS_Y + (b_ * 4 + wave) * 256);
         if (lane < 32) ys_[lane] = okr ? __builtin_fmaf(ys_[lane], GLMH_GSCALE, -0.5f * GLMH_GSCALE) : 0.0f;
       } else if (wave == 0) {
@@ -681,7 +706,7 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     const unsigned char* Xc = smem + C::OFS_RING + (PRIV ? (wave * NB + bi) * GLMH_TILE : bi * ST_BYTES + rt * GLMH_TILE);
     const unsigned char* Xn = smem + C::OFS_RING + (PRIV ? (wave * NB + bn) * GLMH_TILE : bn * ST_BYTES + rt * GLMH_TILE);
     const float* ysc = reinterpret_cast<const float*>(smem + C::OFS_Y +
-                                                      (PRIV ? (bi * 4 + wave) * 256 : bi * 1024 + rt * 128));
+                                                      (!YSHARE ? (bi * 4 + wave) * 256 : bi * 1024 + rt * 128));
     const uint32_t tr_a = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_a;
     const uint32_t tr_b = (uint32_t)(uintptr_t)Xc + (uint32_t)tr_ofs_b;
 
@@ -780,9 +805,11 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
 
   // ---- block reduction over the row tiles in a fixed order, one partial record in the format of
   //      glm.hip; the power-of-two scales come out here (exact) --------------------------------------
-  constexpr int REC = NPT * 1024 + 2 * NPT * 32;
-  static_assert((NPT * 1024 + 2 * NPT * 64) * 4 <= C::LDS_BYTES - C::OFS_RING, "LDS too small");
-  float* red = reinterpret_cast<float*>(smem + C::OFS_RING);
+  // (records in the 64-particle format of glm_finalize.h whatever NPT: one per PAIR of particle tiles)
+  constexpr int NPG = NPT / 2, REC2 = 2 * 1024 + 2 * 2 * 32;
+  constexpr int RED_OFS = NPT > 2 ? 0 : C::OFS_RING;      // (the W planes are not read any more: NPT > 2 needs the room)
+  static_assert((NPT * 1024 + 2 * NPT * 64) * 4 <= C::LDS_BYTES - RED_OFS, "LDS too small");
+  float* red = reinterpret_cast<float*>(smem + RED_OFS);
   float* red2 = red + NPT * 1024;
   const float g_dsc = 1.0f / GLMH_GSCALE;
   const float s_lg = (float)(e_t[0] + e_t[1]) + (__builtin_amdgcn_logf(p_t[0]) + __builtin_amdgcn_logf(p_t[1]));
@@ -802,24 +829,29 @@ __global__ __launch_bounds__(256, OCC) void glm_planes_f16_kernel(
     }
     __syncthreads();
   }
-  float* rec = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * REC;
-  for (int i = threadIdx.x; i < NPT * 1024; i += 256) rec[i] = red[i];
-  for (int i = threadIdx.x; i < 2 * NPT * 32; i += 256) {
-    const int qq = i >> 5, j = i & 31;
-    float v = red2[qq * 64 + j] + red2[qq * 64 + 32 + j];
-    if constexpr (LIN) {
-      // workgroup 0 of the pass: + c . w_p + c0 b_p (natural-log units, float64) on the ll slots
-      const int p = pbase + (qq >> 1) * 32 + j;
-      if (blockIdx.x == 0 && (qq & 1) == 0 && p < P) {
-        // (DRAW: this workgroup wrote z_w / z_b itself in its prologue, many barriers ago)
-        const float* wq = DRAW ? draw.z_w : w;
-        const float* bq = DRAW ? (draw.have_b ? draw.z_b : nullptr) : b;
-        double lin = bq != nullptr ? moments[32] * (double)bq[p] : 0.0;
-        for (int d = 0; d < D; ++d) lin = __builtin_fma(moments[d], (double)wq[(int64_t)p * w_stride + d], lin);
-        v += (float)lin;
+  for (int gi = 0; gi < NPG; ++gi) {
+    const int pass = (int)blockIdx.y * NPG + gi;
+    if ((int64_t)pass * 64 >= P) continue;              // (a pair of particle tiles past the end: no record)
+    float* rec = part + ((int64_t)pass * gridDim.x + blockIdx.x) * REC2;
+    for (int i = threadIdx.x; i < 2 * 1024; i += NT) rec[i] = red[gi * 2048 + i];
+    for (int i = threadIdx.x; i < 2 * 2 * 32; i += NT) {
+      const int qq = i >> 5, j = i & 31, ptl = qq >> 1, which = qq & 1;
+      const int src = (2 * (2 * gi + ptl) + which) * 64;
+      float v = red2[src + j] + red2[src + 32 + j];
+      if constexpr (LIN) {
+        // workgroup 0 of the pass: + c . w_p + c0 b_p (natural-log units, float64) on the ll slots
+        const int p = pass * 64 + ptl * 32 + j;
+        if (blockIdx.x == 0 && which == 0 && p < P) {
+          // (DRAW: this workgroup wrote z_w / z_b itself in its prologue, many barriers ago)
+          const float* wq = DRAW ? draw.z_w : w;
+          const float* bq = DRAW ? (draw.have_b ? draw.z_b : nullptr) : b;
+          double lin = bq != nullptr ? moments[32] * (double)bq[p] : 0.0;
+          for (int d = 0; d < D; ++d) lin = __builtin_fma(moments[d], (double)wq[(int64_t)p * w_stride + d], lin);
+          v += (float)lin;
+        }
       }
+      rec[2 * 1024 + i] = v;
     }
-    rec[NPT * 1024 + i] = v;
   }
   if (tstamps != nullptr && threadIdx.x == 0)
     __hip_atomic_fetch_max(&tstamps[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED,

@@ -1687,6 +1687,43 @@ def test_glm_planes_with_label_moments(gpu, N, D, P, use_bias):
     assert e_lin <= 2 * e_plain + 1e-6 * sc, (e_lin, e_plain)
 
 
+@pytest.mark.parametrize("N,D,P", [(1, 3, 65), (33, 32, 128), (5000, 32, 129), (4099, 20, 192), (70001, 32, 256),
+                                   (3001, 12, 300), (2500, 32, 513), (31, 1, 257)])
+@pytest.mark.parametrize("use_bias,with_moments", [(True, False), (False, True), (True, True)])
+def test_glm_planes_many_particles_in_one_pass(gpu, N, D, P, use_bias, with_moments):
+    """More than 64 particles / chains (NUTS on a model: P = the number of chains): 65..128 run as 2 x 4 waves
+    (128 per pass over the image), more as 1 x 8 (256 per pass) instead of ceil(P / 64) passes of the 2 x 2
+    geometry.  Against the float64 oracle at the kernel's usual tolerance, and against the 2 x 2 passes of the
+    same launch (pa_glm_planes_tune(11, 0)) to f32 rounding of the per-workgroup partial sums."""
+    k = _k()
+    rng = np.random.default_rng(N + 7 * D + P)
+    X = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-1, 1, (1, D)))).astype(np.float32)
+    w = (rng.standard_normal((P, D)) / np.sqrt(D) * np.exp(rng.uniform(-2, 2, (P, 1)))).astype(np.float32)
+    b = rng.standard_normal(P).astype(np.float32) if use_bias else None
+    y = (rng.uniform(size=N) < 0.4).astype(np.float32)
+    tX, ty, tw = tt(X, gpu), tt(y, gpu), tt(w, gpu)
+    tb = tt(b, gpu) if use_bias else None
+    planes = k.glm_pack_planes(tX, fmt=k.GLM_PLANES_F16X2)
+    mom = k.glm_label_moments(tX, ty) if with_moments else None
+    wide = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
+    k.glm_planes_tune(11, 0)
+    try:
+        narrow = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
+    finally:
+        k.glm_planes_tune(0, 0)
+    ref = o_glm.glm_bernoulli_fwd_bwd(X, y, w, b, None, 2.0)
+    sc = max(1.0, float(np.abs(ref[0]).max()))
+    gs = max(1.0, float(np.abs(ref[1]).max()))
+    for got in (wide, narrow):
+        np.testing.assert_allclose(got[0].cpu().numpy(), ref[0], rtol=2e-5, atol=2e-5 * sc)
+        np.testing.assert_allclose(got[1].cpu().numpy(), ref[1], rtol=2e-5, atol=2e-5 * max(gs, N ** 0.5))
+        np.testing.assert_allclose(got[2].cpu().numpy(), ref[2], rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
+    np.testing.assert_allclose(wide[0].cpu().numpy(), narrow[0].cpu().numpy(), rtol=3e-6, atol=3e-6 * sc)
+    np.testing.assert_allclose(wide[1].cpu().numpy(), narrow[1].cpu().numpy(), rtol=3e-6, atol=3e-6 * max(gs, N ** 0.5))
+    again = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
+    assert all(torch.equal(a, c) for a, c in zip(wide, again))               # fixed summation order
+
+
 def test_glm_label_moments_follow_the_tensors(gpu):
     """kernels.glm_label_moments_of: cached per (image of X, y); labels written in place are picked up
     by the revalidate hook (the buffer a captured step reads is refreshed, not replaced)."""

@@ -20,11 +20,28 @@ ap.add_argument("--chains", type=int, default=256)
 ap.add_argument("--warmup", type=int, default=150)
 ap.add_argument("--samples", type=int, default=50)
 ap.add_argument("--depth", type=int, default=10)
+ap.add_argument("--no-compact", action="store_true")
+ap.add_argument("--eager", action="store_true", help="no captured rounds")
+ap.add_argument("--generic", action="store_true", help="the handlers + autograd potential")
+ap.add_argument("--init", default="uniform", help="uniform (reference default) | median | mean | sample")
+ap.add_argument("--tune", type=int, default=0, help="pa_glm_planes_tune ring-depth code (measurement knob)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
+if a.tune:
+    from pyro_amd import kernels as _k
+    _k.glm_planes_tune(a.tune, 0)
 X, y = examples.synthetic_logreg_data(a.n, 32, dev, seed=0)
 pyro.set_rng_seed(11)
-k = NUTS(examples.logreg_model, max_tree_depth=a.depth)
+from pyro_amd.infer.autoguide import initialization as _init  # noqa: E402
+k = NUTS(examples.logreg_model, max_tree_depth=a.depth,
+         init_strategy=getattr(_init, "init_to_" + a.init))
+if a.no_compact:
+    k.compact_chains = False
+if a.generic:
+    k.use_direct_potential = False
+if a.eager:
+    from pyro_amd.infer.mcmc import nuts as _nuts
+    _nuts.CAPTURE_ROUNDS = False
 m = MCMC(k, num_samples=a.samples, warmup_steps=a.warmup, num_chains=a.chains, shard_chains=False)
 marks = {}
 end_warmup = k.end_warmup
