@@ -422,7 +422,7 @@ def bench_model_nuts(dev, rank, world, args):
     # with gradients of ~1e5 per coordinate) most chains reach it within ~100 transitions, but with 256 chains one
     # or two do not: their step size collapses (1e-7) while the gradient is still enormous, and in float32 the
     # position update eps * v falls below the position's ulp -- such a chain is frozen for good and every later
-    # transition of it is a 1023-leapfrog tree the other 255 chains wait for (tools/_nuts_stuck*.py printed it;
+    # transition of it is a 1023-leapfrog tree the other 255 chains wait for (tools/nuts_stuck_chain.py and nuts_stuck_chain_history.py print it;
     # round 5's R-hat of 8.4 and this round's first collection, R-hat 77, were that).  The N = 1e6 run therefore
     # starts at the prior's median -- NUTS(init_strategy=init_to_median), the reference's own strategy
     # (pyro/infer/autoguide/initialization.py:67-92, accepted by pyro/infer/mcmc/nuts.py:125) -- from where 150

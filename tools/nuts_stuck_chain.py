@@ -1,3 +1,7 @@
+"""Developer probe: NUTS on BASELINE configs[1]'s model at N = 1e6 from the reference's default starting points
+(init_to_uniform) -- finds the chain whose step size collapsed, prints its distance from the other chains, its
+step / acceptance / mass, and the float32 potential against float64 at its position and at 1e-6 perturbations
+(the position update eps * v is below the position's ulp there: the chain is frozen).  python tools/nuts_stuck_chain.py"""
 import sys, torch
 sys.path.insert(0, ".")
 import pyro_amd as pyro

@@ -1,3 +1,5 @@
+"""Developer probe: the warm-up history (distance from the final median, step size, potential) of the chain that
+freezes in tools/nuts_stuck_chain.py, transition by transition (hook_fn: lock-step transitions)."""
 import sys, torch
 sys.path.insert(0, ".")
 import pyro_amd as pyro
