@@ -16,6 +16,7 @@ from collections import OrderedDict
 import torch
 
 from ... import kernels
+from ...util import capture_scope
 from ..autoguide.initialization import init_to_uniform
 from .hmc import HMC
 from .potentials import GaussianPotential
@@ -348,7 +349,7 @@ class NUTS(HMC):
                 kernels.check(lib.pa_gate_scope(kernels._ptr(tree.gate)))
                 blocks = fuser.RtcBlocks()
                 try:
-                    with blocks, torch.cuda.graph(graph):
+                    with capture_scope(), blocks, torch.cuda.graph(graph):
                         for _ in range(self.rounds_per_replay):
                             with fuser.scope():
                                 keep.append(self._span_round(tree, base, slots))
@@ -420,7 +421,7 @@ class NUTS(HMC):
                 try:
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    with capture_scope(), torch.cuda.graph(graph):
                         pe, grad = base(tree.zq)
                         tree.advance_replayable(pe.detach().contiguous(), grad.detach().contiguous())
                     self._round_graph = graph

@@ -22,6 +22,7 @@ from ... import poutine
 from ...distributions.util import scale_and_mask
 from ...ops.integrator import potential_grad
 from ...primitives import plate
+from ...util import capture_scope
 from ..autoguide.initialization import InitMessenger, init_to_uniform
 
 
@@ -126,7 +127,7 @@ class GraphedPotential:
         self.z_static = z_flat.detach().clone()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with capture_scope(), torch.cuda.graph(graph):
             pe, grad = self.base(self.z_static)
             pe, grad = pe.detach().contiguous(), grad.detach().contiguous()
         self.graph, self.pe_static, self.grad_static = graph, pe, grad

@@ -17,7 +17,7 @@ import torch.utils._python_dispatch
 
 from .. import kernels, poutine
 from ..params import _PARAM_STORE
-from ..util import torch_isnan, zero_grads
+from ..util import capture_scope, torch_isnan, zero_grads
 from .elbo import ELBO
 
 
@@ -702,7 +702,7 @@ class SVI:
                 reads = _ReadSet()
                 # (parameter blocks of generated-kernel launches: owned by this capture, freed with it)
                 blocks = fuser.RtcBlocks()
-                with blocks, torch.cuda.graph(graph, **mode):
+                with capture_scope(), blocks, torch.cuda.graph(graph, **mode):
                     # (the fuser outermost: it sees what the inner modes let through, last; the read-set
                     #  recorder innermost: it sees every operator first)
                     with fuser.scope(), gated(), cap, chain() as rec, hoist(), reads:
@@ -732,7 +732,7 @@ class SVI:
                     optim.reduce_gradients(params)
                     graph2 = torch.cuda.CUDAGraph()
                     blocks2 = fuser.RtcBlocks()
-                    with blocks2, torch.cuda.graph(graph2, pool=graph.pool(), **mode):
+                    with capture_scope(), blocks2, torch.cuda.graph(graph2, pool=graph.pool(), **mode):
                         with chain():
                             optim.apply(params)
                             if not getattr(optim, "zeroes_grads", False):

@@ -1371,6 +1371,8 @@ class RtcBlocks:
         if self._scope is not None:
             from .. import _lib
             scope, self._scope = self._scope, None
+            if os.environ.get("PYRO_AMD_RTC_KEEP_BLOCKS"):        # (debugging: the pre-ABI-7 behaviour)
+                return
             _lib.load().pa_rtc_blocks_free(ctypes.c_void_p(scope))
 
     def __del__(self):

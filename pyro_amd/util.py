@@ -86,6 +86,28 @@ def zero_grads(tensors):
                 p.grad.zero_()     # works for gradients that are views of a flat buffer too
 
 
+class capture_scope:
+    """Around a hipGraph capture: the cyclic collector must not run inside it.  Captured steps of earlier SVI / NUTS
+    objects sit in reference cycles; when the collector gets to them in the middle of ANOTHER capture their
+    hipGraph executables and private memory pools are destroyed under the open capture and the HIP runtime aborts
+    (seen as "Fatal Python error: Aborted ... Garbage-collecting" in the GPU suite, depending on where the
+    collector's thresholds fall).  So: collect BEFORE the capture starts -- garbage graphs die outside it -- and
+    keep the collector off until it has ended."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self._was:
+            import gc
+            gc.enable()
+        return False
+
+
 def scalar_like(prototype, fill_value):
     return torch.tensor(fill_value, dtype=prototype.dtype, device=prototype.device)
 
