@@ -506,6 +506,7 @@ class DeferredLinear:
         self.shape = torch.Size(shape)
         self.dtype, self.device = like.dtype, like.device
         self._plain = None
+        self._sigmoid = None
 
     ndim = 2
 
@@ -517,8 +518,10 @@ class DeferredLinear:
 
     def materialize(self, sigmoid=False):
         if sigmoid:
-            fn = _BowLinearSigmoid if self.kind == "bow" else _TallLinearSigmoid
-            return fn.invoke(*self.args).as_subclass(TallActivation)
+            if self._sigmoid is None:          # (a second torch.sigmoid of the same object: the same launch's result)
+                fn = _BowLinearSigmoid if self.kind == "bow" else _TallLinearSigmoid
+                self._sigmoid = fn.invoke(*self.args).as_subclass(TallActivation)
+            return self._sigmoid
         if self._plain is None:
             fn = _BowLinear if self.kind == "bow" else _TallLinear
             self._plain = fn.invoke(*self.args).as_subclass(TallActivation)
@@ -556,7 +559,12 @@ class DeferredLinear:
     for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__",
                "__rtruediv__", "__floordiv__", "__rfloordiv__", "__mod__", "__rmod__", "__neg__", "__abs__",
                "__getitem__", "__matmul__", "__rmatmul__", "__pow__", "__rpow__", "__lt__", "__gt__", "__le__",
-               "__ge__", "__eq__", "__ne__", "__len__", "__iter__", "__bool__", "__float__", "__int__"):
+               "__ge__", "__eq__", "__ne__", "__len__", "__iter__", "__bool__", "__float__", "__int__",
+               # (the operators a tensor has and the proxy lacked; in-place forms act on the
+               #  materialised layer output, which the proxy keeps handing out afterwards)
+               "__invert__", "__and__", "__rand__", "__or__", "__ror__", "__xor__", "__rxor__", "__setitem__",
+               "__contains__", "__iadd__", "__isub__", "__imul__", "__itruediv__", "__pos__", "__lshift__",
+               "__rshift__", "__index__", "__array__", "__repr__", "__format__"):
         locals()[_n] = _binary(_n)
     del _n, _binary
     __hash__ = object.__hash__          # (``==`` is the tensor's: identity keeps the object usable as a key)

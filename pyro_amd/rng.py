@@ -4,7 +4,10 @@ The stream is OWNED by torch's default generator, as the reference's draws are (
 torch / random / numpy and nothing else; every ``rsample`` then goes through torch's generator): the Philox
 seed is ``torch.initial_seed()`` and a call of ``torch.manual_seed`` -- by ``pyro.set_rng_seed`` or by the
 user directly -- restarts the stream at block 0.  ``torch.manual_seed(s)`` alone therefore reproduces a
-run.  Every draw advances a host-side 64-bit block offset, so the sequence is reproducible and
+run; ``torch.get_rng_state`` / ``torch.set_rng_state`` / ``torch.random.fork_rng`` rewind it with the generator
+(see _follow_state_calls; a ``manual_seed`` bound by ``from torch import manual_seed`` BEFORE this package was
+imported bypasses the counter: re-seeding with the seed already set is then not noticed -- ``pyro.set_rng_seed``
+is the route that never depends on that).  Every draw advances a host-side 64-bit block offset, so the sequence is reproducible and
 independent of launch geometry; ranks of a multi-GPU job de-correlate by seeding with ``seed + rank``
 exactly as the reference de-correlates chains (pyro/infer/mcmc/api.py:107).
 """
@@ -44,6 +47,67 @@ def _count_seedings():
 
 
 _count_seedings()
+
+# torch.get_rng_state() / torch.set_rng_state() / torch.random.fork_rng() snapshot and restore the default
+# generator; the reference's draws come out of that generator, so restoring it replays them
+# (pyro/util.py:48-63 get_rng_state / set_rng_state are built on it).  The Philox position lives on the host
+# beside the generator, not in its state bytes: the two module-level functions are wrapped (fork_rng calls them)
+# so that a snapshot REMEMBERS the position and a restore of that snapshot rewinds it -- matched by the identity
+# of the returned state tensor, else by its bytes (a state made by another process, or two snapshots with
+# identical generator bytes taken at different Philox positions and then copied, cannot be told apart:
+# pyro.get_rng_state / pyro.set_rng_state carry the position explicitly and are the exact route).
+_SNAPSHOTS = {}          # id(state tensor) or bytes digest -> (weakref or None, Philox state)
+_SNAPSHOT_LIMIT = 256
+
+
+def _snapshot_key(t):
+    import hashlib
+    return hashlib.blake2b(t.numpy().tobytes(), digest_size=16).digest()
+
+
+def _follow_state_calls():
+    import functools
+    import weakref
+    if getattr(torch.random.get_rng_state, "_pyro_amd_follows", False):
+        return
+    get0, set0 = torch.random.get_rng_state, torch.random.set_rng_state
+
+    @functools.wraps(get0)
+    def get_rng_state(*args, **kwargs):
+        st = get0(*args, **kwargs)
+        try:
+            _follow_torch()
+            snap = dict(_STATE)
+            if len(_SNAPSHOTS) >= _SNAPSHOT_LIMIT:
+                for k in list(_SNAPSHOTS)[:_SNAPSHOT_LIMIT // 2]:
+                    del _SNAPSHOTS[k]
+            _SNAPSHOTS[id(st)] = (weakref.ref(st), snap)
+            _SNAPSHOTS[_snapshot_key(st)] = (None, snap)
+        except Exception:      # noqa: BLE001  (never in the way of torch's own function)
+            pass
+        return st
+
+    @functools.wraps(set0)
+    def set_rng_state(new_state, *args, **kwargs):
+        out = set0(new_state, *args, **kwargs)
+        try:
+            ent = _SNAPSHOTS.get(id(new_state))
+            if ent is None or ent[0] is None or ent[0]() is not new_state:
+                ent = _SNAPSHOTS.get(_snapshot_key(new_state))
+            if ent is not None:
+                _STATE.update(ent[1])
+                _STATE["torch_seed"] = (torch.initial_seed(), _SEEDINGS[0])
+        except Exception:      # noqa: BLE001
+            pass
+        return out
+
+    get_rng_state._pyro_amd_follows = True
+    for name, fn in (("get_rng_state", get_rng_state), ("set_rng_state", set_rng_state)):
+        setattr(torch.random, name, fn)
+        setattr(torch, name, fn)
+
+
+_follow_state_calls()
 
 
 def _follow_torch():

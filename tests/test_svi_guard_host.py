@@ -94,3 +94,36 @@ def test_param_store_generation_moves_with_the_set_of_leaves():
     g3 = store.generation
     pyro.clear_param_store()
     assert store.generation > g3
+
+
+def test_torch_rng_state_restores_rewind_the_philox_stream():
+    """the kernels' Philox position follows the default generator not only through
+    torch.manual_seed but through torch.get_rng_state / set_rng_state and torch.random.fork_rng as well --
+    restoring the generator replays the draws, as it does in the reference (pyro/util.py:48-63)."""
+    from pyro_amd import rng
+    pyro.set_rng_seed(5)
+    rng.reserve(1000, torch.float32)
+    at = rng._STATE["offset"]
+    state = torch.get_rng_state()
+    rng.reserve(4000, torch.float32)
+    assert rng._STATE["offset"] == at + 1000
+    torch.set_rng_state(state)                              # the same tensor object: matched by identity
+    assert rng._STATE["offset"] == at and rng.current_seed() == 5
+    with torch.random.fork_rng(devices=[]):
+        rng.reserve(999, torch.float32)
+        torch.rand(3)
+    assert rng._STATE["offset"] == at
+    copy = torch.get_rng_state().clone()                    # a copy: matched by its bytes
+    rng.reserve(8, torch.float32)
+    torch.set_rng_state(copy)
+    assert rng._STATE["offset"] == at
+    # a state this process never handed out re-seeds the generator: the stream restarts under its seed
+    torch.set_rng_state(torch.Generator().manual_seed(99).get_state())
+    assert rng.current_seed() == 99 and rng._STATE["offset"] == 0
+    # pyro's own pair carries the position explicitly
+    pyro.set_rng_seed(7)
+    rng.reserve(64, torch.float32)
+    full = pyro.util.get_rng_state()
+    rng.reserve(64, torch.float32)
+    pyro.util.set_rng_state(full)
+    assert rng._STATE["offset"] == 16 and rng.current_seed() == 7
