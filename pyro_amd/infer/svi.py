@@ -37,6 +37,12 @@ def _arg_key(x):
         return ("id", id(x))
 
 
+def _fast_geometry(args):
+    """Per positional argument: (data_ptr, shape, stride) of a tensor, None otherwise -- what the fast path of
+    SVI.step compares (with the arguments' identity) instead of building the signature key again."""
+    return tuple((a.data_ptr(), a.shape, a.stride()) if isinstance(a, torch.Tensor) else None for a in args)
+
+
 class _ReadSet(torch.utils._python_dispatch.TorchDispatchMode):
     """Every tensor a step READS (or writes) that was not made inside the step: the arguments of the
     operators torch dispatches and of the package's own launches (kernels._ptr) whose storage was not
@@ -80,6 +86,7 @@ class _ReadSet(torch.utils._python_dispatch.TorchDispatchMode):
 
 
 class _CapturedStep:
+    alive = True           # False once the entry left SVI._graphs (evicted, stale, released)
     rtc_blocks = None
     reads = ()             # tensors the step reads that it did not make (see _ReadSet)
     gate = None            # kernels.StepGate when the step's first node is a gate (SVI(prearm=True))
@@ -361,6 +368,7 @@ class SVI:
         # Taken only when nothing but that kernel precedes the tail; otherwise the gate goes first.
         self.speculate = bool(speculate) and _os.environ.get("PYRO_AMD_SPECULATE", "1") != "0"
         self._armed_fast = None     # (entry, argument objects, their key) of the armed replay
+        self._last_fast = None      # (argument objects, their geometry, entry) of the last un-gated replay
         if self.hip_graph and self._loss_device is None:
             raise ValueError("hip_graph=True needs an ELBO that provides loss_and_grads_device")
         self.graph_warmup = int(graph_warmup)
@@ -414,6 +422,31 @@ class SVI:
                 # graph_warmup - 1 run eagerly (as the reference's every step does), then it is captured anew
                 self.release()
                 self._eager_seen.clear()
+        last = self._last_fast
+        if last is not None and not kwargs and len(args) == len(last[0]):
+            # the same argument OBJECTS as the last replay, still where and what they were: straight to the
+            # replay (the signature key -- nested tuples of every tensor's geometry -- is what the rest of
+            # this function's ~6 us of Python is spent on)
+            entry = last[2]
+            same = entry.alive
+            if same:
+                for a, b, g in zip(args, last[0], last[1]):
+                    if a is not b or (g is not None and (a.data_ptr() != g[0] or a.shape != g[1]
+                                                         or a.stride() != g[2])):
+                        same = False
+                        break
+            if same and not entry.cap.stale():
+                kernels.glm_planes_revalidate()     # data the graph reads through a cached image
+                kernels.lda_index_revalidate()
+                kernels.bow_revalidate()
+                entry.cap.before_replay()
+                entry.graph.replay()
+                if entry.graph2 is not None:
+                    entry.between()
+                    entry.graph2.replay()
+                entry.cap.after_replay()
+                return entry.read_loss()
+            self._last_fast = None
         fast = self._armed_fast
         if fast is not None:
             # the step after an armed one, called with the very same argument objects: release the
@@ -431,7 +464,7 @@ class SVI:
             if entry.armed:
                 entry.cancel()
             self._armed_fast = None
-            del self._graphs[key]
+            self._drop(key)
             entry = None
         if entry is None:
             n = self._eager_seen.get(key, 0)
@@ -489,7 +522,7 @@ class SVI:
                 warnings.warn(_CAPTURE_NOTE.format(n=self.graph_warmup), CapturedStepWarning, stacklevel=2)
             self._eager_seen.pop(key, None)
             while len(self._graphs) > self.max_graphs:     # evict the least recently used capture
-                del self._graphs[next(iter(self._graphs))]
+                self._drop(next(iter(self._graphs)))
         else:
             self._graphs[key] = self._graphs.pop(key)      # most recently used last
         if entry.gate is None:
@@ -502,8 +535,16 @@ class SVI:
                 entry.between()            # eager RCCL all-reduce of the flat gradient
                 entry.graph2.replay()
             entry.cap.after_replay()
+            if not kwargs:
+                self._last_fast = (args, _fast_geometry(args), entry)
             return entry.read_loss()
         return self._gated_step(entry, args, kwargs)
+
+    def _drop(self, key):
+        e = self._graphs.pop(key, None)
+        if e is not None:
+            e.alive = False
+        return e
 
     def release(self):
         """Drop every captured step (hipGraph executables, their private memory pools, pinned mailboxes
@@ -514,7 +555,8 @@ class SVI:
         for e in self._graphs.values():
             if e.armed:
                 e.cancel()
-        self._armed_fast = None
+            e.alive = False
+        self._armed_fast = self._last_fast = None
         self._graphs.clear()
         self._const_rec.clear()
 
@@ -636,7 +678,7 @@ class SVI:
                 # kernel, a launch of ours that does not poll the gate), or something other than the
                 # GLM kernel runs in front of a late gate: the next weaker form
                 gated = True if gated == "late" else False
-                self._graphs.pop(key, None)
+                self._drop(key)
                 entry = self._capture_once(key, args, kwargs, rec, force_split=form,
                                            quiet=form is False, with_gate=gated)
             if entry is not None:

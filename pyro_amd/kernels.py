@@ -1043,6 +1043,8 @@ def glm_planes_revalidate():
             ent[1] = base._version
         if len(ent[5]) > 0 and _label_moments_stale(ent):
             _label_moments_refresh(ent)           # (the captured step reads the moments, not y)
+    if not len(_grouped_with_image):              # (a WeakSet: iterating an empty one still costs a microsecond)
+        return
     for segs in list(_grouped_with_image):
         ent = segs._planes
         if ent is None or ent[4] is None:
