@@ -86,6 +86,7 @@ class _ReadSet(torch.utils._python_dispatch.TorchDispatchMode):
 
 
 class _CapturedStep:
+    eager_params = None    # parameters of a step whose optimizer update runs eagerly behind the replay
     alive = True           # False once the entry left SVI._graphs (evicted, stale, released)
     rtc_blocks = None
     reads = ()             # tensors the step reads that it did not make (see _ReadSet)
@@ -214,8 +215,9 @@ class CapturedStepWarning(UserWarning):
 
 
 _CAPTURE_NOTE = (
-    "pyro_amd: SVI captured its step into a hipGraph after {n} eager steps (device tensors as arguments, a "
-    "device-side ELBO and a flat optimizer: nobody asked, so this is said once).  A captured step does not "
+    "pyro_amd: SVI captured its step into a hipGraph after {n} eager steps (device tensors as arguments and a "
+    "device-side ELBO; with an optimizer other than this package's flat ones the update runs eagerly behind "
+    "the replay: nobody asked, so this is said once).  A captured step does not "
     "re-run the Python of the model and guide: what they read from the host at capture time is frozen into "
     "the graph.  Guarded -- the capture is dropped and re-made when it changes: step() arguments, Python "
     "scalars / flags the model or guide reach through closures, globals, functools.partial or attributes "
@@ -338,10 +340,15 @@ class SVI:
         # hip_graph=None (the default): decided at the first step() from its arguments, see CAPTURE_STEPS;
         # a capture that fails leaves such an SVI eager without a warning (nobody asked for a graph)
         self._auto_graph = hip_graph is None
+        # an optimizer whose update cannot sit in a graph (a wrapped torch optimizer keeps host-side state per
+        # call; a plain callable): the step's LOSS AND GRADIENTS are captured, the update and the gradient
+        # zeroing run eagerly behind every replay -- the reference's step order (pyro/infer/svi.py:144-156)
+        # with its first half as one graph launch
+        self._eager_update = not _FlatOptimOK(optim)
         if hip_graph is None:
             want = CAPTURE_STEPS if _os.environ.get("PYRO_AMD_HIP_GRAPH", "1") != "0" else False
             hip_graph = (want is True or want == "auto") and self._loss_device is not None \
-                and _FlatOptimOK(optim)
+                and callable(optim)
         self.hip_graph = bool(hip_graph)
         # prearm (OPT-IN, default off): right after launching step k the replay of step k+1 is enqueued
         # behind a gate node and released by the next step() call with one store to pinned memory (the
@@ -403,7 +410,9 @@ class SVI:
         params = self._params_of(param_capture)
         self.optim(params)
         if not getattr(self.optim, "zeroes_grads", False):
-            zero_grads(params)
+            grads = [p.grad for p in params if p.grad is not None]
+            if grads:
+                torch._foreach_zero_(grads)           # one launch for all of them, in place (zero_grads' contract)
         if isinstance(loss, tuple):
             return type(loss)(map(lambda x: x.item() if isinstance(x, torch.Tensor) else x, loss))
         return loss.item() if isinstance(loss, torch.Tensor) else loss
@@ -445,6 +454,8 @@ class SVI:
                     entry.between()
                     entry.graph2.replay()
                 entry.cap.after_replay()
+                if entry.eager_params is not None:
+                    self._update_eagerly(entry.eager_params)
                 return entry.read_loss()
             self._last_fast = None
         fast = self._armed_fast
@@ -535,10 +546,22 @@ class SVI:
                 entry.between()            # eager RCCL all-reduce of the flat gradient
                 entry.graph2.replay()
             entry.cap.after_replay()
+            if entry.eager_params is not None:
+                self._update_eagerly(entry.eager_params)
             if not kwargs:
                 self._last_fast = (args, _fast_geometry(args), entry)
             return entry.read_loss()
         return self._gated_step(entry, args, kwargs)
+
+    def _update_eagerly(self, params):
+        """The second half of the reference's step (pyro/infer/svi.py:153-156) behind a captured first half:
+        the optimizer's own launches and the gradient zeroing, enqueued while the host has not read the loss
+        yet (the replay's last node published it; these kernels queue behind it)."""
+        self.optim(params)
+        if not getattr(self.optim, "zeroes_grads", False):
+            grads = [p.grad for p in params if p.grad is not None]
+            if grads:
+                torch._foreach_zero_(grads)           # one launch for all of them, in place (zero_grads' contract)
 
     def _drop(self, key):
         e = self._graphs.pop(key, None)
@@ -657,7 +680,8 @@ class SVI:
             # with prearm: first with the gate in front of the chained tail (the forward pass of a replay
             # enqueued ahead runs while the host is between two calls), then with the gate as the first
             # node, then without one
-            gated = ("late" if self.speculate else True) if (self.prearm and not multi) else False
+            gated = ("late" if self.speculate else True) if (self.prearm and not multi
+                                                             and not self._eager_update) else False
             try:
                 entry = self._capture_once(key, args, kwargs, rec, force_split=form,
                                            quiet=form is False, with_gate=gated)
@@ -760,7 +784,7 @@ class SVI:
                             # loss to the host: the step ends in it
                             self.optim(params, publish=cap.finish_args((loss,) + mailbox))
                         else:
-                            if not split:
+                            if not split and not self._eager_update:
                                 self.optim(params)
                                 if not getattr(self.optim, "zeroes_grads", False):
                                     zero_grads(params)
@@ -803,6 +827,10 @@ class SVI:
             self.hip_graph = False
             return None
         entry = _CapturedStep(graph, cap, loss, graph2, between, mailbox)
+        if self._eager_update and not split:
+            # (the gradients the captured backward writes are the .grad tensors of these leaves: the eager
+            #  update reads them, zero_grads clears them in place -- their addresses are part of the graph)
+            entry.eager_params = list(params)
         entry.rtc_blocks = (blocks, blocks2 if split else None)     # (die with the entry: RtcBlocks.__del__)
         entry.gate = gate
         entry.reads = tuple(reads.external.values())

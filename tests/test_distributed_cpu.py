@@ -201,6 +201,8 @@ def test_prearmed_capture_tries_the_late_gate_then_the_first_node_gate_then_none
     from pyro_amd.infer import SVI, Trace_ELBO
 
     class _Optim:
+        zeroes_grads = True            # (a flat optimizer: its update sits in the graph; others update eagerly, un-gated)
+
         def __call__(self, params, *a, **k):
             pass
 

@@ -315,10 +315,13 @@ def test_default_svi_captures_only_what_can_be_a_graph(gpu):
             svi = build(syncing)
             losses = [svi.step(X, y) for _ in range(6)]
             assert not svi.hip_graph and not svi._graphs and all(np.isfinite(losses))
+            # a wrapped torch optimizer: the loss and the gradients are captured, the update runs eagerly behind
+            # every replay (test_torch_optimizer_behind_a_captured_loss_follows_the_eager_trajectory)
             svi = build(examples.logreg_model, optim=pyro.optim.PyroOptim(torch.optim.Adam, {"lr": 0.01}))
             for _ in range(5):
                 svi.step(X, y)
-            assert not svi.hip_graph
+            assert svi.hip_graph and len(svi._graphs) == 1 and svi._eager_update
+            assert next(iter(svi._graphs.values())).eager_params is not None
             with pyro.settings.context(svi_capture_steps=False):
                 svi = build(examples.logreg_model)
             for _ in range(5):
@@ -792,3 +795,60 @@ def test_self_capturing_svi_says_so_once(gpu):
         _guard_run(gpu, True, steps=6)
     said = [x for x in w if issubclass(x.category, svi_mod.CapturedStepWarning)]
     assert len(said) == 1 and "hip_graph=False" in str(said[0].message)
+
+
+@pytest.mark.parametrize("which", ["sgd_momentum", "torch_adam", "rmsprop", "callable"])
+def test_torch_optimizer_behind_a_captured_loss_follows_the_eager_trajectory(gpu, which):
+    """An optimizer whose update cannot sit in a graph -- `PyroOptim(torch.optim.X)`: host-side state per call; a
+    plain callable -- no longer sends the whole step back to the handlers: the step's loss and gradients are ONE
+    graph replay (the reference's `loss_and_grads`, pyro/infer/svi.py:144-150), the update and the gradient
+    zeroing (:153-156) run eagerly behind it.  Losses equal the eager run's bit for bit, parameters to a gradient's last bit."""
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(20000, 32, gpu, seed=4)
+    seen = []
+
+    def make():
+        if which == "sgd_momentum":
+            return pyro.optim.PyroOptim(torch.optim.SGD, {"lr": 1e-5, "momentum": 0.9})
+        if which == "torch_adam":
+            return pyro.optim.PyroOptim(torch.optim.Adam, {"lr": 0.02})
+        if which == "rmsprop":
+            return pyro.optim.RMSprop({"lr": 0.01})
+
+        def plain(params, *a, **k):                    # a user's own update: p -= 1e-6 g
+            with torch.no_grad():
+                for p in sorted(params, key=lambda t: t.numel()):
+                    seen.append(float(p.grad.abs().sum()))
+                    p.add_(p.grad, alpha=-1e-6)
+        return plain
+
+    pyro.enable_validation(False)
+    try:
+        runs = []
+        for graph in (False, None):
+            pyro.clear_param_store()
+            pyro.set_rng_seed(9)
+            del seen[:]
+            svi = SVI(examples.logreg_model, AutoNormal(examples.logreg_model, init_scale=0.1), make(),
+                      Trace_ELBO(num_particles=16, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph)
+            losses = [svi.step(X, y) for _ in range(12)]
+            if graph is None:
+                assert svi.hip_graph and len(svi._graphs) == 1 and svi._eager_update
+            # gradients are zero between steps, as after the reference's zero_grads (pyro/infer/util.py:85-91)
+            for name, p in pyro.get_param_store().named_parameters():
+                assert p.grad is None or float(p.grad.abs().sum()) == 0.0, name
+            runs.append((losses, {k: v.detach().clone() for k, v in pyro.get_param_store().items()}, list(seen)))
+        assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+        for k in runs[0][1]:      # (the chained tail rounds the prior's gradient once differently: 1 ulp of a gradient)
+            torch.testing.assert_close(runs[0][1][k], runs[1][1][k], rtol=1e-6, atol=1e-7)
+        assert len(runs[0][2]) == len(runs[1][2])
+        for a, b in zip(sorted(runs[0][2]), sorted(runs[1][2])):
+            assert abs(a - b) <= 1e-5 * max(abs(a), 1.0)
+        assert runs[0][0][-1] < runs[0][0][0] or which in ("sgd_momentum", "callable")
+    finally:
+        pyro.enable_validation(True)
+        pyro.clear_param_store()
