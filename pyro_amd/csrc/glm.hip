@@ -578,6 +578,7 @@ static void glm_planes_launch_grouped(int nseg, int npass, const unsigned char* 
 static int64_t glmh_tile_bytes(int64_t ntiles) { return ntiles * (int64_t)GLMH_TILE; }
 
 static bool g_planes_wide = true;      // pa_glm_planes_tune(11, .): 2 x 2 waves whatever P (measurement knob)
+static int g_planes_wide_max = 8;      // pa_glm_planes_tune(12, .): at most 2 x 4 waves (128 particles per pass)
 
 static GlmPlanesPlan glmh_plan(int64_t N, int64_t P, bool allow_wide = true) {
   GlmPlanesPlan pl;
@@ -594,8 +595,9 @@ static GlmPlanesPlan glmh_plan(int64_t N, int64_t P, bool allow_wide = true) {
   if (allow_wide && g_planes_wide && pl.nb == 3 && g_planes_bpc <= 0 && P > 64) {
     // many particles / chains: 128 or 256 of them per pass over the image, eight waves per workgroup, one
     // workgroup per CU (the same two waves per SIMD).  The records keep the 64-particle format: npass groups
-    pl.nrt = P > 128 ? 1 : 2;
-    pl.npt = P > 128 ? 8 : 4;
+    const bool eight = P > 128 && g_planes_wide_max >= 8;
+    pl.nrt = eight ? 1 : 2;
+    pl.npt = eight ? 8 : 4;
     const int64_t wrows = 32 * pl.npt;
     pl.ypass = (int)((P + wrows - 1) / wrows);
     pl.nst = pl.nrt == 1 ? (N + 31) / 32 : ((N + 31) / 32 + 1) / 2;
@@ -1101,11 +1103,13 @@ int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
   // (f16 image: 3 / 4 = ring depth of the 32 x 32-tile kernel; measurement knobs: 5 / 6 the same with
   //  per-wave private rings of depth 3 / 4, 9 / 10 one wave per tile and 64 particles, ring depth 3 / 4)
   //  11 = the default ring with the 2 x 2 wave geometry whatever P: no 128 / 256-particle passes)
-  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 11),
-             "glm_planes_tune: ring depth code 3..11 (0 = default)");
+  //  12 = at most 128 particles per pass: 2 x 4 waves for every P > 64)
+  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 12),
+             "glm_planes_tune: ring depth code 3..12 (0 = default)");
   PA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 4, "glm_planes_tune: 0..4 workgroups per CU");
   pa::g_planes_wide = ring_depth != 11;
-  pa::g_planes_nb = (ring_depth == 0 || ring_depth == 11) ? 3 : ring_depth;
+  pa::g_planes_wide_max = ring_depth == 12 ? 4 : 8;
+  pa::g_planes_nb = (ring_depth == 0 || ring_depth >= 11) ? 3 : ring_depth;
   pa::g_planes_bpc = blocks_per_cu;
   return PA_OK;
 }

@@ -25,7 +25,7 @@ for _ in range(4):
 torch.cuda.synchronize()
 SKIP = ("aten::view", "aten::expand", "aten::reshape", "aten::_unsafe_view", "aten::t", "aten::transpose",
         "aten::unsqueeze", "aten::squeeze", "aten::detach", "aten::alias", "aten::as_strided", "aten::permute",
-        "aten::select", "aten::slice", "aten::empty", "aten::empty_like", "aten::empty_strided", "aten::_to_copy")
+        "aten::select", "aten::slice", "aten::empty", "aten::empty_like", "aten::empty_strided")
 
 
 class Count(TorchDispatchMode):
