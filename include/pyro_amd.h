@@ -450,8 +450,9 @@ int pa_glm_bernoulli_grouped_planes_fwd_bwd(int format, const void* planes, cons
  * the outputs are those of pa_glm_bernoulli_fwd_bwd variant 0 (no mask argument: masked plates take
  * the entry above).  D <= 32 (format F16X2: D <= 128, with 2 or 4 feature tiles of 32 columns per row tile and a
  * 1-KiB trailer of 128 column maxima / exponents, csrc/glm_planes16d.h); any P (64 particles per pass over the image).
- * pa_glm_planes_tune(ring depth code 3..11, workgroups per CU; 0 = default) is a measurement knob (11: the 2 x 2 wave
- * geometry whatever P -- by default 65..128 particles run 128 and more run 256 per pass over the image).
+ * pa_glm_planes_tune(ring depth code 3..13, workgroups per CU; 0 = default) is a measurement knob (11: the 2 x 2 wave
+ * geometry whatever P -- by default, from ~48 row tiles per workgroup on (N >= 393 k on 256 CUs), 65..128 particles run
+ * 128 and more run 256 per pass over the image; 12: at most 128 per pass, at every N; 13: the default's choice at every N).
  *
  * Two image formats (`format`, the same value when an image is sized, packed and used):
  *   PA_GLM_PLANES_BF16X3  three bf16 planes, x = x1 + x2 + x3 EXACTLY; six piece products per

@@ -579,6 +579,7 @@ static int64_t glmh_tile_bytes(int64_t ntiles) { return ntiles * (int64_t)GLMH_T
 
 static bool g_planes_wide = true;      // pa_glm_planes_tune(11, .): 2 x 2 waves whatever P (measurement knob)
 static int g_planes_wide_max = 8;      // pa_glm_planes_tune(12, .): at most 2 x 4 waves (128 particles per pass)
+static bool g_planes_wide_force = false;   // pa_glm_planes_tune(13, .): the wide geometries at every N (tests)
 
 static GlmPlanesPlan glmh_plan(int64_t N, int64_t P, bool allow_wide = true) {
   GlmPlanesPlan pl;
@@ -592,7 +593,14 @@ static GlmPlanesPlan glmh_plan(int64_t N, int64_t P, bool allow_wide = true) {
   if (cap < 1) cap = 1;
   pl.nblocks = (int)(pl.nst < cap ? (pl.nst < 1 ? 1 : pl.nst) : cap);
   pl.ypass = pl.npass;
-  if (allow_wide && g_planes_wide && pl.nb == 3 && g_planes_bpc <= 0 && P > 64) {
+  // Measured (tools/bench_glm_particles.py, kernel + finalize, us): at N = 1e5 the 2 x 2 passes win (P = 256: 31.9
+  // against 34.2 / 46.3 for 2 x 4 / 1 x 8: with ~12 tiles per workgroup the wider workgroup's prologue -- W planes
+  // of 128 / 256 particles -- and its 8-wave barrier are not amortised); at N = 1e6 the wide geometries are equal
+  // or better (P = 256: 174 / 168 / 174, P = 1024: 658 / 620 / 616) and read the image once (1.10 x the
+  // algorithmic bytes at P = 256 instead of 2.1 x).  So: wide only from ~48 tiles per workgroup on.
+  const bool enough_tiles = (N + 31) / 32 >= (int64_t)48 * cu_count();
+  if (allow_wide && g_planes_wide && pl.nb == 3 && g_planes_bpc <= 0 && P > 64 &&
+      (enough_tiles || g_planes_wide_force)) {
     // many particles / chains: 128 or 256 of them per pass over the image, eight waves per workgroup, one
     // workgroup per CU (the same two waves per SIMD).  The records keep the 64-particle format: npass groups
     const bool eight = P > 128 && g_planes_wide_max >= 8;
@@ -1103,12 +1111,14 @@ int pa_glm_planes_tune(int ring_depth, int blocks_per_cu) {
   // (f16 image: 3 / 4 = ring depth of the 32 x 32-tile kernel; measurement knobs: 5 / 6 the same with
   //  per-wave private rings of depth 3 / 4, 9 / 10 one wave per tile and 64 particles, ring depth 3 / 4)
   //  11 = the default ring with the 2 x 2 wave geometry whatever P: no 128 / 256-particle passes)
-  //  12 = at most 128 particles per pass: 2 x 4 waves for every P > 64)
-  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 12),
-             "glm_planes_tune: ring depth code 3..12 (0 = default)");
+  //  12 = at most 128 particles per pass: 2 x 4 waves for every P > 64; 13 = the wide geometries at every N -- by
+  //  default only from ~48 32-row tiles per workgroup on, N >= 393 k on 256 CUs)
+  PA_REQUIRE(ring_depth == 0 || (ring_depth >= 3 && ring_depth <= 13),
+             "glm_planes_tune: ring depth code 3..13 (0 = default)");
   PA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 4, "glm_planes_tune: 0..4 workgroups per CU");
   pa::g_planes_wide = ring_depth != 11;
   pa::g_planes_wide_max = ring_depth == 12 ? 4 : 8;
+  pa::g_planes_wide_force = ring_depth == 12 || ring_depth == 13;
   pa::g_planes_nb = (ring_depth == 0 || ring_depth >= 11) ? 3 : ring_depth;
   pa::g_planes_bpc = blocks_per_cu;
   return PA_OK;

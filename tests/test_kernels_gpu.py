@@ -1688,7 +1688,7 @@ def test_glm_planes_with_label_moments(gpu, N, D, P, use_bias):
 
 
 @pytest.mark.parametrize("N,D,P", [(1, 3, 65), (33, 32, 128), (5000, 32, 129), (4099, 20, 192), (70001, 32, 256),
-                                   (3001, 12, 300), (2500, 32, 513), (31, 1, 257)])
+                                   (3001, 12, 300), (2500, 32, 513), (31, 1, 257), (400000, 32, 200)])
 @pytest.mark.parametrize("use_bias,with_moments", [(True, False), (False, True), (True, True)])
 def test_glm_planes_many_particles_in_one_pass(gpu, N, D, P, use_bias, with_moments):
     """More than 64 particles / chains (NUTS on a model: P = the number of chains): 65..128 run as 2 x 4 waves
@@ -1705,7 +1705,12 @@ def test_glm_planes_many_particles_in_one_pass(gpu, N, D, P, use_bias, with_mome
     tb = tt(b, gpu) if use_bias else None
     planes = k.glm_pack_planes(tX, fmt=k.GLM_PLANES_F16X2)
     mom = k.glm_label_moments(tX, ty) if with_moments else None
-    wide = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
+    k.glm_planes_tune(13, 0)             # (the wide geometries at every N: by default only from N ~ 4e5 on)
+    try:
+        wide = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
+        again = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
+    finally:
+        k.glm_planes_tune(0, 0)
     k.glm_planes_tune(11, 0)
     try:
         narrow = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
@@ -1720,8 +1725,10 @@ def test_glm_planes_many_particles_in_one_pass(gpu, N, D, P, use_bias, with_mome
         np.testing.assert_allclose(got[2].cpu().numpy(), ref[2], rtol=2e-5, atol=2e-5 * max(1.0, N ** 0.5))
     np.testing.assert_allclose(wide[0].cpu().numpy(), narrow[0].cpu().numpy(), rtol=3e-6, atol=3e-6 * sc)
     np.testing.assert_allclose(wide[1].cpu().numpy(), narrow[1].cpu().numpy(), rtol=3e-6, atol=3e-6 * max(gs, N ** 0.5))
-    again = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
     assert all(torch.equal(a, c) for a, c in zip(wide, again))               # fixed summation order
+    if N >= 48 * 256 * 32:               # (>= 48 row tiles per workgroup on 256 CUs: the default's own choice)
+        default = k.glm_bernoulli_planes_fwd_bwd(planes, ty, tw, tb, 2.0, N, D, moments=mom)
+        assert all(torch.equal(a, c) for a, c in zip(wide, default))
 
 
 def test_glm_label_moments_follow_the_tensors(gpu):
