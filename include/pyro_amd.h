@@ -706,7 +706,12 @@ int pa_nuts_tree_compact(int dtype, const void* zq, int64_t C, int64_t D, int ma
  * starts at element n_slots * site_off[k] (the GLM kernel reads weights [P, D_w] and bias [P] in place);
  * pa_nuts_tree_compact with the same (n_sites, site_off, site_len) fills it (slot2chain NULL and
  * n_slots == C: the full round, identity map).  n_sites == 0 there: the row-major [n_slots, D] buffer of a
- * potential that takes the flat state. */
+ * potential that takes the flat state.
+ * HIERARCHICAL priors (ABI 7): a parameter of site k may be the constrained VALUE of another latent site q of the
+ * same chain (w ~ Normal(mu, tau) with mu / tau latent): site_p0[k] == NULL with site_s0[k] = -(q + 1) (likewise
+ * p1 / s1); element j of site k takes element j % site_len[q] of site q (a parent broadcast over leading plate
+ * dims; site_len[k] must be a multiple of site_len[q]); d log p_k / d parameter is added to q's gradient inside
+ * the kernel, in a fixed order.  D <= 512 as for the direct form in general. */
 int pa_nuts_tree_run_advance_direct(void* z, void* pe, void* grad, void* zq, void* rq, const void* inv_mass,
                                     int64_t im_stride_row, void* step, int64_t C, int64_t D,
                                     int max_tree_depth, int use_multinomial, uint64_t seed,

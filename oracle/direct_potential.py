@@ -24,9 +24,12 @@ from . import dists, glm
 
 def direct_potential(sites, z, X=None, y=None, w_site=None, b_site=None):
     """sites: list of dicts {name, dist (oracle.dists id), transform (0 identity / 1 lower + exp), lower,
-    p0, p1} in the flat layout's order; z: {name: unconstrained value}.  -> (U, {name: dU/du})."""
+    p0, p1} in the flat layout's order; z: {name: unconstrained value}.  -> (U, {name: dU/du}).
+    A HIERARCHICAL prior: ``par0`` / ``par1`` = the name of the latent site whose constrained value is the
+    parameter (w ~ Normal(mu, tau)); flat element j of the site takes element j % len(parent) of the parent
+    (a parent broadcast over leading plate dims) and d log p / d parameter flows back to it."""
     v, dvdu, lp, dlp = {}, {}, 0.0, {}
-    for s in sites:
+    for s in sites:                                           # every site's constrained value first
         u = np.asarray(z[s["name"]], dtype=np.float64)
         if s["transform"] == 1:
             e = np.exp(u)
@@ -34,10 +37,26 @@ def direct_potential(sites, z, X=None, y=None, w_site=None, b_site=None):
             lp += u.sum()                                     # log |dv/du| = u
         else:
             v[s["name"]], dvdu[s["name"]] = u, np.ones_like(u)
-        a = 0.0 if s.get("p0") is None else np.asarray(s["p0"], dtype=np.float64)
-        b = 0.0 if s.get("p1") is None else np.asarray(s["p1"], dtype=np.float64)
-        lp += np.sum(dists.LOG_PROB[s["dist"]](v[s["name"]], a, b))
-        dlp[s["name"]] = np.broadcast_to(dists.log_prob_grad(s["dist"], v[s["name"]], a, b)[0], u.shape).copy()
+        dlp[s["name"]] = np.zeros_like(u)
+    for s in sites:
+        val = v[s["name"]]
+        params, pars = [], []
+        for key, pk in (("p0", "par0"), ("p1", "par1")):
+            if s.get(pk) is not None:
+                pv = v[s[pk]].reshape(-1)
+                params.append(np.resize(pv, val.size).reshape(val.shape))       # element j <- parent[j % len]
+                pars.append(s[pk])
+            else:
+                params.append(0.0 if s.get(key) is None else np.asarray(s[key], dtype=np.float64))
+                pars.append(None)
+        a, b = params
+        lp += np.sum(dists.LOG_PROB[s["dist"]](val, a, b))
+        g = dists.log_prob_grad(s["dist"], val, a, b)
+        dlp[s["name"]] = dlp[s["name"]] + np.broadcast_to(g[0], val.shape)
+        for t, par in enumerate(pars):
+            if par is not None:
+                gp = np.broadcast_to(g[1 + t], val.shape).reshape(-1, v[par].size).sum(0)
+                dlp[par] = dlp[par] + gp.reshape(v[par].shape)
     if X is not None:
         w = v[w_site].reshape(1, -1)
         b = None if b_site is None else np.asarray(v[b_site]).reshape(1)
@@ -69,4 +88,13 @@ def golden_models(D):
             dict(name="f_ga", dist=6, transform=1, lower=0.0, p0=np.array([2.5, 0.6]), p1=np.array([1.5, 0.9])),
             dict(name="w", dist=0, transform=0, lower=0.0, p0=np.full(D, 0.1), p1=np.full(D, 2.0))],
             w_site="w", b_site=None),
+        "hier_scale": dict(sites=[
+            dict(name="tau", dist=5, transform=1, lower=0.0, p0=1.0, p1=None),
+            dict(name="w", dist=0, transform=0, lower=0.0, p0=np.zeros(D), par1="tau")], w_site="w", b_site=None),
+        "hier_loc_scale": dict(sites=[
+            normal_b,
+            dict(name="mu", dist=0, transform=0, lower=0.0, p0=np.zeros(D), p1=1.0),
+            dict(name="tau", dist=5, transform=1, lower=0.0, p0=np.ones(D), p1=None),
+            dict(name="theta", dist=0, transform=0, lower=0.0, par0="mu", par1="tau"),
+            dict(name="w", dist=0, transform=0, lower=0.0, par0="mu", par1="tau")], w_site="w", b_site="b"),
     }

@@ -211,10 +211,15 @@ enum { RF_ADAPT_STEP = 1, RF_WELFORD = 2, RF_COUNT_ACCEPTS = 4 };
 // and hand over their log-likelihood per slot and its gradient per site.
 //   U(z)  = -( ll_ext[slot] + sum_sites sum_j [ log p_s(v_j) + log|dv_j/du_j| ] ),   v = T_s(u)
 //   dU/du = -( (d log p_s/dv + g_ext) dv/du + d log|dv/du| / du )
+// A HIERARCHICAL prior: a parameter of site s may be the (constrained) VALUE of another latent site q of the same
+// chain -- w ~ Normal(mu, tau) with mu, tau latent (pyro/infer/mcmc/util.py:264-286 scores it through the handlers
+// and autograd carries d log p_s / d parameter back to q).  Encoded without a new argument: p == NULL and stride
+// s = -(q + 1); element j of s reads element j % len_q of q (a parent broadcast over leading plate dims).  The
+// gradient d log p_s[j] / d parameter is added to q's coordinates through LDS, in a fixed order.
 struct DirectSite {
   int dist, transform;            // PA_DIST_*; 0: v = u, 1: v = lower + exp(u)
   const void *p0, *p1;            // the family's parameters, element j of the site at p[j * stride]
-  int64_t s0, s1;
+  int64_t s0, s1;                 // (p == NULL, s < 0: the value of site -s - 1, see above)
   const void* g_ext;              // [n_slots, len]: d ll_ext / d v of this site, or NULL
   double lower;
 };
@@ -349,15 +354,30 @@ __device__ __forceinline__ T elem_site_lp(T v, T a, T b, T& dv, T& da, T& db) {
     default: break;                                                                        \
   }
 
-// (pe, gradient) of the flat model at this thread's coordinates of the cursor, see TreeDirect
-template <typename T, int NW, int NPL>
+// (pe, gradient) of the flat model at this thread's coordinates of the cursor, see TreeDirect.  `ucoord(d)` = the
+// unconstrained value of coordinate d of THIS chain's cursor (any coordinate: parents are read through it);
+// par_lds = 2 x TREE_DIRECT_MAXD values of LDS (used only when some site has a parent-valued parameter).
+constexpr int TREE_DIRECT_MAXD = 512;
+template <typename T, int NW, int NPL, typename UCoord>
 __device__ __forceinline__ void direct_potential(const Chain<T, NW, NPL>& c, const TreeDirect& dp,
                                                  const SlotLayout& lay, int64_t slot, const Vec<T, NPL>& zq,
-                                                 Vec<T, NPL>& gq, T& pe_q) {
+                                                 Vec<T, NPL>& gq, T& pe_q, UCoord ucoord, T* par_lds) {
   T lp_sum = T(0), zero = T(0);
+  bool any_parent = false;
+#pragma unroll
+  for (int k = 0; k < TREE_MAX_SITES; ++k)
+    if (k < lay.n_sites && ((dp.s[k].p0 == nullptr && dp.s[k].s0 < 0) || (dp.s[k].p1 == nullptr && dp.s[k].s1 < 0)))
+      any_parent = true;
+  // the constrained value of element i of site q of this chain
+  auto parent_value = [&](int q, int i) -> T {
+    const T u = ucoord(lay.off[q] + i);
+    return dp.s[q].transform == 1 ? (T)dp.s[q].lower + Num<T>::exp_(u) : u;
+  };
+  T dvdu_own[NPL];
 #pragma unroll
   for (int m = 0; m < NPL; ++m) {
     gq.x[m] = T(0);
+    dvdu_own[m] = T(1);
     const int d = c.tid + m * c.NT;
     if (!c.ok(m)) continue;
     int si = 0;
@@ -367,8 +387,10 @@ __device__ __forceinline__ void direct_potential(const Chain<T, NW, NPL>& c, con
     const DirectSite& st = dp.s[si];
     const int j = d - lay.off[si];
     const T u = zq.x[m];
-    const T a = st.p0 != nullptr ? ((const T*)st.p0)[j * st.s0] : T(0);
-    const T b = st.p1 != nullptr ? ((const T*)st.p1)[j * st.s1] : T(0);
+    const int q0 = (st.p0 == nullptr && st.s0 < 0) ? (int)(-st.s0 - 1) : -1;
+    const int q1 = (st.p1 == nullptr && st.s1 < 0) ? (int)(-st.s1 - 1) : -1;
+    const T a = q0 >= 0 ? parent_value(q0, j % lay.len[q0]) : (st.p0 != nullptr ? ((const T*)st.p0)[j * st.s0] : T(0));
+    const T b = q1 >= 0 ? parent_value(q1, j % lay.len[q1]) : (st.p1 != nullptr ? ((const T*)st.p1)[j * st.s1] : T(0));
     T v = u, dvdu = T(1), ladj = T(0), dladj = T(0);
     if (st.transform == 1) {                 // support (lower, inf): biject_to = exp then shift
       dvdu = Num<T>::exp_(u);
@@ -376,11 +398,44 @@ __device__ __forceinline__ void direct_potential(const Chain<T, NW, NPL>& c, con
       ladj = u;
       dladj = T(1);
     }
-    T lp = T(0), dv = T(0), da, db;
+    dvdu_own[m] = dvdu;
+    T lp = T(0), dv = T(0), da = T(0), db = T(0);
     PA_TREE_FAMILY(st.dist, (lp = elem_site_lp<D_, T>(v, a, b, dv, da, db)));
     const T ge = st.g_ext != nullptr ? ((const T*)st.g_ext)[slot * lay.len[si] + j] : T(0);
     gq.x[m] = -((dv + ge) * dvdu + dladj);
     lp_sum += lp + ladj;
+    if (any_parent) {
+      par_lds[d] = da;
+      par_lds[TREE_DIRECT_MAXD + d] = db;
+    }
+  }
+  if (any_parent) {
+    // d U / d v_q[i] = - sum over the sites s that take q as a parameter, over their elements j = i (mod len_q),
+    // of d log p_s[j] / d that parameter -- summed in increasing (s, j): the same bits on every run
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NPL; ++m) {
+      const int d = c.tid + m * c.NT;
+      if (!c.ok(m)) continue;
+      int q = 0;
+#pragma unroll
+      for (int k = 1; k < TREE_MAX_SITES; ++k)
+        if (k < lay.n_sites && d >= lay.off[k]) q = k;
+      const int i = d - lay.off[q], lq = lay.len[q];
+      T acc = T(0);
+      for (int k = 0; k < lay.n_sites; ++k) {
+        const DirectSite& st = dp.s[k];
+        const bool t0 = st.p0 == nullptr && st.s0 == -(int64_t)(q + 1);
+        const bool t1 = st.p1 == nullptr && st.s1 == -(int64_t)(q + 1);
+        if (!t0 && !t1) continue;
+        for (int j = i; j < lay.len[k]; j += lq) {
+          if (t0) acc += par_lds[lay.off[k] + j];
+          if (t1) acc += par_lds[TREE_DIRECT_MAXD + lay.off[k] + j];
+        }
+      }
+      gq.x[m] -= acc * dvdu_own[m];
+    }
+    __syncthreads();
   }
   c.sum2(lp_sum, zero);
   pe_q = -(dp.ll_ext != nullptr ? ((const T*)dp.ll_ext)[slot] : T(0)) - lp_sum;
@@ -400,7 +455,9 @@ __global__ __launch_bounds__(64 * NW) void nuts_direct_potential_kernel(
   for (int m = 0; m < NPL; ++m)
     zq.x[m] = c.ok(m) ? zq_pack[slot_index(lay, n_slots, slot, D, c.tid + m * c.NT)] : 0.0f;
   float pe_q;
-  direct_potential<float, NW, NPL>(c, direct, lay, slot, zq, gq, pe_q);
+  __shared__ float par_lds[2 * TREE_DIRECT_MAXD];
+  auto ucoord = [&](int d) -> float { return zq_pack[slot_index(lay, n_slots, slot, D, d)]; };
+  direct_potential<float, NW, NPL>(c, direct, lay, slot, zq, gq, pe_q, ucoord, par_lds);
   c.st(grad_out, gq);
   if (c.tid == 0) pe_out[slot] = pe_q;
 }
@@ -461,7 +518,11 @@ __global__ __launch_bounds__(64 * NW) void nuts_tree_advance_kernel(
   Vec<T, NPL> zq = c.ld(zq_io), rq = c.ld(rq_io), gq;
   T pe_q;
   if constexpr (DIRECT) {
-    direct_potential<T, NW, NPL>(c, direct, run.lay, slot, zq, gq, pe_q);
+    // (the chain's cursor row in the row-major [C, D] buffer: a parent-valued parameter reads other coordinates)
+    __shared__ T par_lds[2 * TREE_DIRECT_MAXD];
+    const T* zq_row = zq_io + c.row;
+    auto ucoord = [&](int d) -> T { return zq_row[d]; };
+    direct_potential<T, NW, NPL>(c, direct, run.lay, slot, zq, gq, pe_q, ucoord, par_lds);
   } else {
     gq = c.ld_at(gq_in, slot_row);
     pe_q = peq_in[slot];
@@ -1044,6 +1105,28 @@ int pa_nuts_tree_compact(int dtype, const void* zq, int64_t C, int64_t D, int ma
   return pa::check_launch("nuts_tree_compact_kernel");
 }
 
+// parent-valued parameters of the direct potential (DirectSite): p == NULL with stride -(q + 1)
+static int tree_check_parents(const char* who, int n_sites, const int32_t* site_len, const void* const* site_p0,
+                              const int64_t* site_s0, const void* const* site_p1, const int64_t* site_s1, int64_t D) {
+  for (int k = 0; k < n_sites; ++k) {
+    const void* const pp[2] = {site_p0[k], site_p1[k]};
+    const int64_t ss[2] = {site_s0[k], site_s1[k]};
+    for (int t = 0; t < 2; ++t) {
+      if (pp[t] != nullptr) {
+        PA_REQUIRE(ss[t] >= 0, "%s: negative stride of a parameter tensor", who);
+        continue;
+      }
+      if (ss[t] >= 0) continue;                               // unused parameter
+      const int64_t q = -ss[t] - 1;
+      PA_REQUIRE(q >= 0 && q < n_sites && q != k, "%s: site %d takes its parameter from site %lld", who, k, (long long)q);
+      PA_REQUIRE(site_len[k] % site_len[q] == 0, "%s: site %d (%d elements) is not a whole number of copies of its "
+                 "parent site %lld (%d elements)", who, k, site_len[k], (long long)q, site_len[q]);
+      PA_REQUIRE(D <= pa::TREE_DIRECT_MAXD, "%s: parent-valued parameters need D <= %d", who, pa::TREE_DIRECT_MAXD);
+    }
+  }
+  return PA_OK;
+}
+
 int pa_nuts_tree_run_advance_direct(void* z, void* pe, void* grad, void* zq, void* rq, const void* inv_mass,
                                     int64_t im_stride_row, void* step, int64_t C, int64_t D,
                                     int max_tree_depth, int use_multinomial, uint64_t seed,
@@ -1073,7 +1156,9 @@ int pa_nuts_tree_run_advance_direct(void* z, void* pe, void* grad, void* zq, voi
              (long long)n_slots);
   PA_REQUIRE(n_sites >= 1, "nuts_tree_run_advance_direct: at least one site");
   pa::SlotLayout lay;
-  const int rc = tree_layout(n_sites, site_off, site_len, D, &lay);
+  int rc = tree_layout(n_sites, site_off, site_len, D, &lay);
+  if (rc != PA_OK) return rc;
+  rc = tree_check_parents("nuts_tree_run_advance_direct", n_sites, site_len, site_p0, site_s0, site_p1, site_s1, D);
   if (rc != PA_OK) return rc;
   pa::TreeDirect dp{};
   dp.n_sites = n_sites;
@@ -1106,7 +1191,9 @@ int pa_nuts_direct_potential(const void* zq_pack, int64_t n_slots, int64_t D, in
   PA_REQUIRE(n_sites >= 1, "nuts_direct_potential: at least one site");
   if (n_slots == 0) return PA_OK;
   pa::SlotLayout lay;
-  const int rc = tree_layout(n_sites, site_off, site_len, D, &lay);
+  int rc = tree_layout(n_sites, site_off, site_len, D, &lay);
+  if (rc != PA_OK) return rc;
+  rc = tree_check_parents("nuts_direct_potential", n_sites, site_len, site_p0, site_s0, site_p1, site_s1, D);
   if (rc != PA_OK) return rc;
   pa::TreeDirect dp{};
   dp.n_sites = n_sites;

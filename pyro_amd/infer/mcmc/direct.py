@@ -3,8 +3,9 @@
 The reference evaluates the potential of every leapfrog step by running the conditioned model under its effect
 handlers, summing the sites' log-densities and differentiating the sum (pyro/infer/mcmc/util.py:264-286,
 pyro/ops/integrator.py:68-94).  For a model whose latent sites are scored by fused families at parameters that
-do not depend on other latents, and whose observed site is the Bernoulli-logits GLM over latent weights /
-bias -- Bayesian logistic regression, BASELINE configs[1]'s model under NUTS -- the whole evaluation is
+do not depend on other latents -- or ARE the value of another latent site (a hierarchical prior: w ~
+Normal(mu, tau) with mu / tau latent; round 6) -- and whose observed site is the Bernoulli-logits GLM over latent
+weights / bias -- Bayesian logistic regression, BASELINE configs[1]'s model under NUTS -- the whole evaluation is
 
     GLM kernel (log-likelihood per chain + its gradient w.r.t. weights and bias, one pass over X)
     -> its finalize
@@ -44,8 +45,9 @@ def _transform_kind(t):
     return None
 
 
-def _param_view(p, n):
-    """(tensor, stride) reading element j of a site of n elements at p[j * stride], or None."""
+def _param_view(p, n, shape=None):
+    """(tensor, stride) reading element j of a site of n elements at p[j * stride]; (None, 0) for an absent
+    parameter; False for one this form cannot hold.  ``shape``: the site's chain-batched value shape."""
     if p is None:
         return None, 0
     if not isinstance(p, torch.Tensor) or p.requires_grad or p.dtype != torch.float32 or not p.is_cuda:
@@ -54,7 +56,37 @@ def _param_view(p, n):
         return p.reshape(1).contiguous(), 0
     if p.numel() == n:
         return p.reshape(n).contiguous(), 1
+    if shape is not None and p.dim() == len(shape) and tuple(p.shape) == tuple(shape) and p.stride(0) == 0:
+        # broadcast against a chain-valued sibling parameter (Normal(zeros(D), tau)): the same n values for every chain
+        return p[0].reshape(n).contiguous(), 1
     return False
+
+
+def _parent_of(p, value, cond, C, n):
+    """The latent site whose chain value the parameter tensor ``p`` IS: a pure view of it (same storage, no
+    arithmetic in between) that, broadcast against the site's value [C, ..., event], reads element j % len_q of
+    chain c's parent for flat element j of chain c.  -> name or None."""
+    if not isinstance(p, torch.Tensor) or not p.is_cuda or p.dtype != torch.float32:
+        return None
+    try:
+        pe = p.expand(value.shape)
+    except RuntimeError:
+        return None
+    for qname, qv in cond.items():
+        if qv is value or p.untyped_storage().data_ptr() != qv.untyped_storage().data_ptr():
+            continue
+        numel = qv.untyped_storage().nbytes() // 4
+        if numel > (1 << 22) or qv.numel() % C != 0:
+            return None
+        lq = qv.numel() // C
+        if n % lq != 0:
+            return None
+        base = torch.arange(numel)
+        got = base.as_strided(tuple(pe.shape), tuple(pe.stride()), pe.storage_offset()).reshape(C, n)
+        par = base.as_strided(tuple(qv.shape), tuple(qv.stride()), qv.storage_offset()).reshape(C, lq)
+        want = par[:, torch.arange(n) % lq]
+        return qname if torch.equal(got, want) else None
+    return None
 
 
 class DirectProgram:
@@ -67,8 +99,9 @@ class DirectProgram:
         self.dist = (ctypes.c_int32 * n)(*[s["dist"] for s in sites])
         self.transform = (ctypes.c_int32 * n)(*[s["transform"] for s in sites])
         self.lower = (ctypes.c_double * n)(*[s["lower"] for s in sites])
-        self.s0 = (ctypes.c_int64 * n)(*[s["s0"] for s in sites])
-        self.s1 = (ctypes.c_int64 * n)(*[s["s1"] for s in sites])
+        # (a parent-valued parameter: no tensor, stride -(parent site + 1): include/pyro_amd.h)
+        self.s0 = (ctypes.c_int64 * n)(*[s["s0"] if s.get("par0") is None else -(s["par0"] + 1) for s in sites])
+        self.s1 = (ctypes.c_int64 * n)(*[s["s1"] if s.get("par1") is None else -(s["par1"] + 1) for s in sites])
         self.keep = [s["p0"] for s in sites] + [s["p1"] for s in sites]
 
     def pointers(self, g_ext):
@@ -164,12 +197,21 @@ def _recognise(pe_maker, layout, transforms, init_params, C):
             kind = _transform_kind(transforms[name])
             if kind is None:
                 return None
-            p0 = _param_view(entry[2], b - a)
-            p1 = _param_view(entry[3], b - a)
+            p0 = _param_view(entry[2], b - a, site["value"].shape)
+            p1 = _param_view(entry[3], b - a, site["value"].shape)
+            par = [None, None]
             if p0 is False or p1 is False:
-                return None
+                # a hierarchical prior: the parameter is the value of another latent site (pa_nuts_*_direct take
+                # it as a parent-valued parameter: the tree kernel reads it from the chain's own cursor)
+                for t, (view, raw) in enumerate(((p0, entry[2]), (p1, entry[3]))):
+                    if view is False:
+                        par[t] = _parent_of(raw, site["value"], cond, C, b - a)
+                        if par[t] is None:
+                            return None
+                p0 = (None, 0) if p0 is False else p0
+                p1 = (None, 0) if p1 is False else p1
             by_name[name] = dict(name=name, off=a, len=b - a, dist=int(entry[0]), transform=kind[0], lower=kind[1],
-                                 p0=p0[0], s0=p0[1], p1=p1[0], s1=p1[1])
+                                 p0=p0[0], s0=p0[1], p1=p1[0], s1=p1[1], par0=par[0], par1=par[1])
             seen.add(name)
         else:                                                         # an observed site: the GLM, once
             lz = getattr(fn, "lazy", None)
@@ -183,6 +225,14 @@ def _recognise(pe_maker, layout, transforms, init_params, C):
     if glm is None or seen != set(layout.names):
         return None
     ordered = [by_name[n] for n in layout.names]                      # ascending offsets: the flat layout's order
+    index_of = {s_["name"]: k for k, s_ in enumerate(ordered)}
+    for s_ in ordered:                                                # parents by site index; whole copies only
+        for key in ("par0", "par1"):
+            if s_[key] is not None:
+                q = index_of[s_[key]]
+                if ordered[q]["len"] == 0 or s_["len"] % ordered[q]["len"] != 0:
+                    return None
+                s_[key] = q
 
     def site_of(t):
         """The latent site whose (identity-transformed) value ``t`` is a view of."""

@@ -1406,8 +1406,28 @@ def g_mcmc_direct_potential():
         with pyro.plate("data", N):
             pyro.sample("obs", dist.Bernoulli(logits=X @ w), obs=y)
 
+    def hier_scale(X, y):
+        # a HIERARCHICAL prior: the scale of w is another latent (direct.py encodes it as a parent-valued parameter)
+        tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        w = pyro.sample("w", dist.Normal(X.new_zeros(D), tau.unsqueeze(-1)).to_event(1))   # (broadcast-safe text)
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=X @ w), obs=y)
+
+    def hier_loc_scale(X, y):
+        # BASELINE configs[4]'s prior structure at a size the tree kernel's direct form holds: vector parents
+        # mu[D], tau[D]; a plated block theta[3, D] and the regression weights w[D] both drawn around them
+        mu = pyro.sample("mu", dist.Normal(X.new_zeros(D), 1.0).to_event(1))
+        tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(D)).to_event(1))
+        b = pyro.sample("b", dist.Normal(X.new_zeros(()), 1.0))
+        with pyro.plate("groups", 3):
+            pyro.sample("theta", dist.Normal(mu, tau).to_event(1))
+        w = pyro.sample("w", dist.Normal(mu, tau).to_event(1))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=X @ w + b), obs=y)
+
     flat = {"X": X.numpy(), "y": y.numpy()}
-    for tag, model in (("logreg", logreg), ("positive_site", positive_site), ("all_families", all_families)):
+    for tag, model in (("logreg", logreg), ("positive_site", positive_site), ("all_families", all_families),
+                       ("hier_scale", hier_scale), ("hier_loc_scale", hier_loc_scale)):
         pyro.set_rng_seed(0)
         init, potential_fn, transforms, _ = initialize_model(model, (X, y))
         flat[tag + "/sites"] = np.array(sorted(init), dtype="U16")

@@ -414,8 +414,8 @@ def _logreg_data(gpu, N=20000, D=32, seed=3):
 
 def test_flat_models_are_recognised_and_others_are_not(gpu):
     """infer/mcmc/direct.recognise: Bayesian logistic regression (with and without a bias, a HalfNormal-scaled
-    variant whose positive site goes through the exp transform) gets a direct program; a hierarchical prior
-    (a site's scale is another latent), a second observed site, a masked site do not."""
+    variant whose positive site goes through the exp transform, a hierarchical prior whose scale IS another
+    latent's value) gets a direct program; a parameter COMPUTED from another latent, a second observed site do not."""
     import pyro_amd as pyro
     import pyro_amd.distributions as dist
     from pyro_amd import examples
@@ -434,7 +434,13 @@ def test_flat_models_are_recognised_and_others_are_not(gpu):
 
     def hierarchical(X, y):
         tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
-        w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), tau).to_event(1))
+        w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), tau.unsqueeze(-1)).to_event(1))
+        with pyro.plate("data", X.shape[0]):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
+
+    def computed_parameter(X, y):
+        tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        w = pyro.sample("w", dist.Normal(X.new_zeros(X.shape[1]), 2.0 * tau.unsqueeze(-1)).to_event(1))
         with pyro.plate("data", X.shape[0]):
             pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
 
@@ -442,8 +448,8 @@ def test_flat_models_are_recognised_and_others_are_not(gpu):
         examples.logreg_model(X, y)
         pyro.sample("extra", dist.Normal(X.new_zeros(()), 1.0), obs=X.new_ones(()))
 
-    expect = [(examples.logreg_model, 2), (no_bias, 1), (with_positive_site, 3), (hierarchical, None),
-              (two_observed, None)]
+    expect = [(examples.logreg_model, 2), (no_bias, 1), (with_positive_site, 3), (hierarchical, 2),
+              (computed_parameter, None), (two_observed, None)]
     for model, n_sites in expect:
         pyro.set_rng_seed(0)
         k = NUTS(model, max_tree_depth=4)
@@ -458,7 +464,7 @@ def test_flat_models_are_recognised_and_others_are_not(gpu):
         k.cleanup()
 
 
-@pytest.mark.parametrize("model_name", ["logreg", "positive_site"])
+@pytest.mark.parametrize("model_name", ["logreg", "positive_site", "hierarchical"])
 def test_direct_potential_runs_the_chains_of_the_generic_potential(gpu, model_name):
     """MCMC(NUTS(flat model)) with the potential assembled inside the tree kernel (GLM kernel + finalize +
     tree kernel per round) against the same run through the handlers and autograd: the first transitions
@@ -475,7 +481,14 @@ def test_direct_potential_runs_the_chains_of_the_generic_potential(gpu, model_na
         pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
         examples.logreg_model(X, y)
 
-    model = examples.logreg_model if model_name == "logreg" else positive_site
+    def hierarchical(X, y):
+        mu = pyro.sample("mu", dist.Normal(X.new_zeros(X.shape[1]), 1.0).to_event(1))
+        tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        w = pyro.sample("w", dist.Normal(mu, tau.unsqueeze(-1)).to_event(1))
+        with pyro.plate("data", X.shape[0]):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
+
+    model = dict(logreg=examples.logreg_model, positive_site=positive_site, hierarchical=hierarchical)[model_name]
 
     def run(direct, warmup, samples, adapt, C=64, depth=5):
         pyro.set_rng_seed(5)
@@ -501,13 +514,14 @@ def test_direct_potential_runs_the_chains_of_the_generic_potential(gpu, model_na
         assert float(((ma - mb).abs() / sd).max()) < 0.2, name        # (64 x 150 draws: ~0.01 sd of MC error)
 
 
-@pytest.mark.parametrize("tag", ["logreg", "positive_site", "all_families"])
+@pytest.mark.parametrize("tag", ["logreg", "positive_site", "all_families", "hier_scale", "hier_loc_scale"])
 def test_direct_potential_against_the_references_potential_fn(gpu, tag):
     """the arithmetic pa_nuts_tree_run_advance_direct runs in registers -- the latent
     sites' log-densities through the identity / exp transform with its Jacobian, added to the GLM kernel's
     log-likelihood and gradient -- written out by pa_nuts_direct_potential and compared with the UNMODIFIED
     reference's potential_fn + autograd at fixed unconstrained points (tests/golden/mcmc_direct_potential.npz:
-    pyro/infer/mcmc/util.py:264-286, 370-482), all six families.  float32 kernels against float64 values:
+    pyro/infer/mcmc/util.py:264-286, 370-482), all six families, and the hierarchical forms (a site's loc / scale
+    is another latent site's value: the parent's gradient collects d log p / d parameter).  float32 kernels against float64 values:
     1e-4 of the potential, 1e-4 of the largest gradient entry."""
     import numpy as np
 
@@ -540,7 +554,24 @@ def test_direct_potential_against_the_references_potential_fn(gpu, tag):
         with pyro.plate("data", N):
             pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
 
-    model = dict(logreg=logreg, positive_site=positive_site, all_families=all_families)[tag]
+    def hier_scale(X, y):
+        tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(())))
+        w = pyro.sample("w", dist.Normal(X.new_zeros(D), tau.unsqueeze(-1)).to_event(1))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w)), obs=y)
+
+    def hier_loc_scale(X, y):
+        mu = pyro.sample("mu", dist.Normal(X.new_zeros(D), 1.0).to_event(1))
+        tau = pyro.sample("tau", dist.HalfNormal(X.new_ones(D)).to_event(1))
+        b = pyro.sample("b", dist.Normal(X.new_zeros(()), 1.0))
+        with pyro.plate("groups", 3):
+            pyro.sample("theta", dist.Normal(mu, tau).to_event(1))
+        w = pyro.sample("w", dist.Normal(mu, tau).to_event(1))
+        with pyro.plate("data", N):
+            pyro.sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
+
+    model = dict(logreg=logreg, positive_site=positive_site, all_families=all_families, hier_scale=hier_scale,
+                 hier_loc_scale=hier_loc_scale)[tag]
     names = [str(n) for n in g[tag + "/sites"]]
     pyro.set_rng_seed(0)
     k = NUTS(model, max_tree_depth=4)
@@ -549,8 +580,8 @@ def test_direct_potential_against_the_references_potential_fn(gpu, tag):
         k.setup(2, X, y)
     prog = k._direct
     assert prog is not None and [s["name"] for s in prog.sites] == names, "the model was not recognised"
-    z = np.stack([np.concatenate([np.atleast_1d(g["%s/z%d/%s" % (tag, i, n)]) for n in names]) for i in range(5)])
-    want_g = np.stack([np.concatenate([np.atleast_1d(g["%s/g%d/%s" % (tag, i, n)]) for n in names])
+    z = np.stack([np.concatenate([np.reshape(g["%s/z%d/%s" % (tag, i, n)], -1) for n in names]) for i in range(5)])
+    want_g = np.stack([np.concatenate([np.reshape(g["%s/g%d/%s" % (tag, i, n)], -1) for n in names])
                        for i in range(5)])
     want_pe = np.array([g["%s/pe%d" % (tag, i)] for i in range(5)])
     pe, grad = prog.potential(torch.tensor(z, dtype=torch.float32, device=gpu))
