@@ -388,10 +388,10 @@ def bench_model_nuts(dev, rank, world, args):
     C, D = args.model_nuts_chains, args.features
     W, S = args.model_nuts_warmup, args.model_nuts_samples
 
-    def run(X, y, warmup, samples, chains, init=None):
+    def run(X, y, warmup, samples, chains, init=None, model=None):
         pyro.set_rng_seed(11 + rank)
         kw = {} if init is None else {"init_strategy": init}
-        kernel = NUTS(examples.logreg_model, max_tree_depth=args.model_nuts_depth, **kw)
+        kernel = NUTS(model or examples.logreg_model, max_tree_depth=args.model_nuts_depth, **kw)
         mcmc = MCMC(kernel, num_samples=samples, warmup_steps=warmup, num_chains=chains,
                     shard_chains=False)
         marks = {}
@@ -428,16 +428,20 @@ def bench_model_nuts(dev, rank, world, args):
     # (pyro/infer/autoguide/initialization.py:67-92, accepted by pyro/infer/mcmc/nuts.py:125) -- from where 150
     # warm-up transitions give R-hat 1.04 with either wave geometry; the 1e5-row runs keep the default.
     from pyro_amd.infer.autoguide.initialization import init_to_median
-    plan = [(100_000, C, 5 * W, 10 * S, None), (100_000, 4 * C, 2 * W, 4 * S, None),
-            (1_000_000, C, 3 * W, 2 * S, init_to_median)]
+    # the last run: config 5's prior structure (mu, tau -> w: a site's loc and scale ARE other latent sites), which
+    # the direct potential holds since round 6 -- 3 launches per round as for the flat model (VERDICT r05 item 7;
+    # config 5's own G = 1000 groups are 32 065 coordinates per chain: beyond the tree kernel's per-chain form)
+    plan = [(100_000, C, 5 * W, 10 * S, None, None), (100_000, 4 * C, 2 * W, 4 * S, None, None),
+            (1_000_000, C, 3 * W, 2 * S, init_to_median, None),
+            (100_000, C, 5 * W, 10 * S, None, examples.hier_prior_logreg_model)]
     if dev.type != "cuda":                 # the plumbing test of tests/test_distributed_cpu.py
-        plan = [(args.plate, C, W, S, None)]
+        plan = [(args.plate, C, W, S, None, None)]
     X = y = None
-    for N, C, W, S, init in plan:
+    for N, C, W, S, init, model in plan:
         if X is None or X.shape[0] != N:
             X, y = examples.synthetic_logreg_data(N, D, dev, seed=0)
-        run(X, y, min(12, W), min(4, S), C, init)      # warm the allocator / code objects / the plane image of X
-        kernel, mcmc, r = run(X, y, W, S, C, init)
+        run(X, y, min(12, W), min(4, S), C, init, model)   # warm the allocator / code objects / the plane image of X
+        kernel, mcmc, r = run(X, y, W, S, C, init, model)
         tot = torch.tensor([float(r["n"]), r["wall"], float(r["n_sample"]), r["t_sample"]], device=dev,
                            dtype=torch.float64)
         if world > 1:
@@ -462,8 +466,10 @@ def bench_model_nuts(dev, rank, world, args):
         rounds = r["replays_sample"] * kernel.rounds_per_replay
         alg = N * (4 * D + 4)
         diag = mcmc.diagnostics()
-        key = "N%d_C%d" % (N, C)
+        key = "N%d_C%d" % (N, C) + ("" if model is None else "_hier_prior")
+        direct = getattr(kernel, "_direct", None)
         out[key] = {
+            "direct_potential": direct is not None, "latent_sites": None if direct is None else int(direct.n),
             "value": n_all / wall, "sampling_phase": ns_all / ts, "unit": "leapfrog steps/s summed over chains",
             "wall_s": wall, "leapfrogs": n_all, "sampling_s": ts, "sampling_leapfrogs": ns_all,
             "mean_tree_leaves": r["n"] / ((W + S) * C),
@@ -610,7 +616,8 @@ def compact(out):
         e = _pick(mn, "metric", "n_gpus", "dtype", "error")
         runs = {}
         for k, v in (mn.get("runs") or {}).items():
-            rr = _pick(v, "value", "sampling_phase", "leapfrogs", "us_per_round", "round_occupancy", "converged")
+            rr = _pick(v, "value", "sampling_phase", "leapfrogs", "us_per_round", "round_occupancy", "converged",
+                       "direct_potential")
             rr["max_r_hat"] = _r(v.get("posterior_check", {}).get("max_r_hat"))
             rr["roofline"] = _pick(v.get("roofline", {}), "kernel_ms", "frac", "frac_of_round", "traffic",
                                    "algorithmic_bytes_per_round", "claimed")

@@ -163,6 +163,19 @@ def hier_logreg_model(X, y, segments, plate_scale=1.0):
         sample("obs", dist.Bernoulli(logits=dist.grouped_linear_logits(X, w, b, segments)), obs=y)
 
 
+def hier_prior_logreg_model(X, y):
+    """BASELINE config 5's prior structure over ONE group: mu ~ N(0,1)^D, tau ~ HalfNormal(1)^D, w ~ N(mu, tau),
+    obs_n ~ Bernoulli(logits = x_n . w + b).  The smallest model whose site parameters are other latent sites'
+    values: under NUTS the direct potential holds it (infer/mcmc/direct.py, parent-valued parameters)."""
+    N, D = X.shape
+    mu = sample("mu", dist.Normal(X.new_zeros(D), 1.0).to_event(1))
+    tau = sample("tau", dist.HalfNormal(X.new_ones(D)).to_event(1))
+    b = sample("b", dist.Normal(X.new_zeros(()), 1.0))
+    w = sample("w", dist.Normal(mu, tau).to_event(1))
+    with plate("data", N):
+        sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
+
+
 def hier_logreg_model_reference(X, y, g, G, plate_scale=1.0):
     """SURVEY 8(d) config 5 exactly as the reference would write it: g = int64 [N] group ids in ANY
     order, logit_n = x_n . w_{g_n} + b through an advanced-index gather.  Nothing here names the
