@@ -29,6 +29,8 @@
 #include "common.h"
 #include "glm_bf16.h"
 
+#include <cstdlib>
+
 namespace pa {
 
 constexpr int TALL_MAX = 128;
@@ -49,37 +51,81 @@ constexpr int TALL_TB[6] = {0, 1, 2, 0, 1, 0};
 // ---- Y = G Wm + bias ---------------------------------------------------------------------------
 // LDS: Wm planes [k-step][column tile][plane] blocks of 64 lanes x 16 B (lane = column (l & 31) of the
 // tile, k group l >> 5: Wm[16 ks + 8 kg .. + 7][column]); NKS k-steps x NCT column tiles.
-template <int NKS, int NCT>
-__global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restrict__ G, int64_t B, int R,
+// NW waves per workgroup share the planes.  NW = 4 (round 3): one wave per SIMD, the next tile's loads travel
+// under this tile's MFMAs -- nothing else hides a latency, and the phases of a tile add up (50 us for 8 us of
+// matrix work at 100 -> 100 over 1e5 rows).  NW = 16 (round 6): four waves per SIMD, ONE tile each in a single
+// round of the grid; a wave keeps three k-steps of loads in flight and the other three waves of its SIMD fill
+// its waits (128 registers per wave: no second tile in registers).
+template <int NKS, int NCT, int NW>
+__global__ __launch_bounds__(64 * NW) void tall_linear_kernel(const float* __restrict__ G, int64_t B, int R,
                                                           const float* __restrict__ W, int64_t w_rs,
                                                           int64_t w_cs, int C,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ Ymul, int act,
-                                                          float* __restrict__ Y) {
+                                                          float* __restrict__ Y, int stage) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tall_smem[];
   uint4* wsm = reinterpret_cast<uint4*>(tall_smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, kg = lane >> 5;
   // the planes, once per workgroup: all of a wave's loads are requested before the first split
-  {
-    constexpr int NBLK = (NKS * NCT + 3) / 4;
-    float wv[NBLK][8];
-#pragma unroll
-    for (int i = 0; i < NBLK; ++i) {
-      const int blk = wave + 4 * i;
+  if (stage) {                                               // (workgroup-uniform)
+    // a contiguous weight (either orientation) travels ONCE, in 16-byte granules in memory order, into a staging
+    // area behind the planes; the lanes then pick their operand-order values out of LDS.  (Lane = column of Wm:
+    // for the forward's Wm = weight^T every lane of a load sits on its own cache line -- 9 us of the launch.)
+    float* stg = reinterpret_cast<float*>(tall_smem + NKS * NCT * 3 * 1024);
+    const int n4 = (R * C) >> 2;
+    for (int i = (int)threadIdx.x; i < n4; i += 64 * NW)
+      reinterpret_cast<float4*>(stg)[i] = reinterpret_cast<const float4*>(W)[i];
+    __syncthreads();
+    const int rs = (int)w_rs, cs = (int)w_cs;
+    for (int blk = wave; blk < NKS * NCT; blk += NW) {
       const int ks = blk / NCT, ct = blk % NCT;
       const int c = 32 * ct + l31;
-      const float* wp = W + (int64_t)(c < C ? c : C - 1) * w_cs;
+      float wv[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int r = 16 * ks + 8 * kg + q;
-        const float x = wp[(int64_t)(r < R ? r : R - 1) * w_rs];
-        wv[i][q] = (blk < NKS * NCT && r < R && c < C) ? x : 0.0f;
+        const float x = stg[(c < C ? c : C - 1) * cs + (r < R ? r : R - 1) * rs];
+        wv[q] = (r < R && c < C) ? x : 0.0f;
+      }
+      bf16x8 c1, c2, c3;
+      tall_split8(wv, c1, c2, c3);
+      wsm[(blk * 3 + 0) * 64 + lane] = __builtin_bit_cast(uint4, c1);
+      wsm[(blk * 3 + 1) * 64 + lane] = __builtin_bit_cast(uint4, c2);
+      wsm[(blk * 3 + 2) * 64 + lane] = __builtin_bit_cast(uint4, c3);
+    }
+  } else {
+    constexpr int NBLK = (NKS * NCT + NW - 1) / NW;
+    float wv[NBLK][8];
+    // (the forward's Wm = weight^T: a lane's 8 values are consecutive in memory -- two 16-byte loads instead of
+    //  eight gathers that touch 64 cache lines each: 224 of those per workgroup were ~7 us of the CU's texture path)
+    const bool wvec = w_rs == 1 && (w_cs & 3) == 0 && (R & 3) == 0 && ((uintptr_t)W & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+      const int blk = wave + NW * i;
+      const int ks = blk / NCT, ct = blk % NCT;
+      const int c = 32 * ct + l31;
+      const float* wp = W + (int64_t)(c < C ? c : C - 1) * w_cs;
+      if (wvec) {                                            // (wave-uniform)
+        const int r0 = 16 * ks + 8 * kg;                     // (R % 4 == 0: a granule is inside or outside)
+        const bool in = blk < NKS * NCT && c < C;
+        const bool ok0 = in && r0 + 4 <= R, ok1 = in && r0 + 8 <= R;
+        const float4 a = *reinterpret_cast<const float4*>(wp + (r0 + 4 <= R ? r0 : 0));
+        const float4 b = *reinterpret_cast<const float4*>(wp + (r0 + 8 <= R ? r0 + 4 : 0));
+        wv[i][0] = ok0 ? a.x : 0.0f; wv[i][1] = ok0 ? a.y : 0.0f; wv[i][2] = ok0 ? a.z : 0.0f; wv[i][3] = ok0 ? a.w : 0.0f;
+        wv[i][4] = ok1 ? b.x : 0.0f; wv[i][5] = ok1 ? b.y : 0.0f; wv[i][6] = ok1 ? b.z : 0.0f; wv[i][7] = ok1 ? b.w : 0.0f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = 16 * ks + 8 * kg + q;
+          const float x = wp[(int64_t)(r < R ? r : R - 1) * w_rs];
+          wv[i][q] = (blk < NKS * NCT && r < R && c < C) ? x : 0.0f;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) {
-      const int blk = wave + 4 * i;
+      const int blk = wave + NW * i;
       if (blk >= NKS * NCT) break;
       bf16x8 c1, c2, c3;
       tall_split8(wv[i], c1, c2, c3);
@@ -91,8 +137,35 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
   __syncthreads();
   const int64_t ntiles = (B + 31) / 32;
   const bool vec4 = (R & 3) == 0;                       // 16-byte row loads
-  // this lane's 8 floats of every k-step of tile t (rows past the end: zeros)
-  auto load_tile = [&](int64_t t, float (&v)[NKS][8]) {
+  // this lane's 8 floats of k-step ks of tile t (rows past the end: zeros)
+  // NW > 4: buffer loads -- ONE 32-bit offset per lane and tile, the k-step in the instruction's immediate, rows
+  // past the end of the batch answered with zeros by the bounds check of the descriptor.  (With 64-bit clamped
+  // addresses per granule the compiler keeps 4 NKS pointers live across the tile loop: 58 spilled registers at 128.)
+  const int buf_bytes = NW > 4 ? (int)(B * R * 4) : 0;
+  __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, buf_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t y_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ymul != nullptr ? Ymul : G), 0, buf_bytes, 0x00020000);
+  auto load_step = [&](int64_t t, int ks, float (&v)[8]) {
+    auto dsig = [](float g, float y) { return g * (1.0f - y) * y; };      // (sigmoid_backward's expression)
+    const int r0 = 16 * ks + 8 * kg;
+    if constexpr (NW > 4) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const int row_off = ((int)(t * 32 + l31) * R + 8 * kg) * 4;         // (B R < 2^29: the launcher's condition)
+      const bool ok0 = r0 + 4 <= R, ok1 = r0 + 8 <= R;                     // (R % 4 == 0: a granule is in or out)
+      f4 a = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, row_off + 64 * ks, 0, 0));
+      f4 b = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, row_off + 64 * ks + 16, 0, 0));
+      if (Ymul != nullptr) {                                 // (wave-uniform)
+        const f4 ya = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, row_off + 64 * ks, 0, 0));
+        const f4 yb = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, row_off + 64 * ks + 16, 0, 0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = dsig(a[q], ya[q]); b[q] = dsig(b[q], yb[q]); }
+      }
+      // (a granule past the end of the ROW belongs to the next row: zeroed here; past the end of the batch
+      //  the loads returned zeros)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] = ok0 ? a[q] : 0.0f; v[4 + q] = ok1 ? b[q] : 0.0f; }
+      return;
+    }
     // Every load is unconditional, from a clamped address, and a select zeroes what is out of range:
     // a predicated load compiles to a branch with its own s_waitcnt, and a tile has up to 56 of them
     // (measured: 110 waits per tile, 62 us for 11 us of MFMA work).
@@ -100,47 +173,53 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
     const bool rok = row < B;
     const float* gr = G + (rok ? row : B - 1) * R;
     const float* yr = Ymul != nullptr ? Ymul + (rok ? row : B - 1) * R : nullptr;
-    auto dsig = [](float g, float y) { return g * (1.0f - y) * y; };      // (sigmoid_backward's expression)
+    if (vec4) {                                              // (wave-uniform) R % 4 == 0: two 16-byte granules
+      const bool ok0 = r0 + 4 <= R, ok1 = r0 + 8 <= R;
+      float4 a = *reinterpret_cast<const float4*>(gr + (ok0 ? r0 : 0));
+      float4 b = *reinterpret_cast<const float4*>(gr + (ok1 ? r0 + 4 : 0));
+      if (yr != nullptr) {                                   // (wave-uniform)
+        const float4 ya = *reinterpret_cast<const float4*>(yr + (ok0 ? r0 : 0));
+        const float4 yb = *reinterpret_cast<const float4*>(yr + (ok1 ? r0 + 4 : 0));
+        a.x = dsig(a.x, ya.x); a.y = dsig(a.y, ya.y); a.z = dsig(a.z, ya.z); a.w = dsig(a.w, ya.w);
+        b.x = dsig(b.x, yb.x); b.y = dsig(b.y, yb.y); b.z = dsig(b.z, yb.z); b.w = dsig(b.w, yb.w);
+      }
+      const bool k0 = rok && ok0, k1 = rok && ok1;
+      v[0] = k0 ? a.x : 0.0f; v[1] = k0 ? a.y : 0.0f; v[2] = k0 ? a.z : 0.0f; v[3] = k0 ? a.w : 0.0f;
+      v[4] = k1 ? b.x : 0.0f; v[5] = k1 ? b.y : 0.0f; v[6] = k1 ? b.z : 0.0f; v[7] = k1 ? b.w : 0.0f;
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int r0 = 16 * ks + 8 * kg;
-      if (vec4) {                                            // (wave-uniform) R % 4 == 0: two 16-byte granules
-        const bool ok0 = r0 + 4 <= R, ok1 = r0 + 8 <= R;
-        float4 a = *reinterpret_cast<const float4*>(gr + (ok0 ? r0 : 0));
-        float4 b = *reinterpret_cast<const float4*>(gr + (ok1 ? r0 + 4 : 0));
-        if (yr != nullptr) {                                 // (wave-uniform)
-          const float4 ya = *reinterpret_cast<const float4*>(yr + (ok0 ? r0 : 0));
-          const float4 yb = *reinterpret_cast<const float4*>(yr + (ok1 ? r0 + 4 : 0));
-          a.x = dsig(a.x, ya.x); a.y = dsig(a.y, ya.y); a.z = dsig(a.z, ya.z); a.w = dsig(a.w, ya.w);
-          b.x = dsig(b.x, yb.x); b.y = dsig(b.y, yb.y); b.z = dsig(b.z, yb.z); b.w = dsig(b.w, yb.w);
-        }
-        const bool k0 = rok && ok0, k1 = rok && ok1;
-        v[ks][0] = k0 ? a.x : 0.0f; v[ks][1] = k0 ? a.y : 0.0f; v[ks][2] = k0 ? a.z : 0.0f; v[ks][3] = k0 ? a.w : 0.0f;
-        v[ks][4] = k1 ? b.x : 0.0f; v[ks][5] = k1 ? b.y : 0.0f; v[ks][6] = k1 ? b.z : 0.0f; v[ks][7] = k1 ? b.w : 0.0f;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int c = r0 + q < R ? r0 + q : 0;
-          float x = gr[c];
-          if (yr != nullptr) x = dsig(x, yr[c]);
-          v[ks][q] = (rok && r0 + q < R) ? x : 0.0f;
-        }
+      for (int q = 0; q < 8; ++q) {
+        const int c = r0 + q < R ? r0 + q : 0;
+        float x = gr[c];
+        if (yr != nullptr) x = dsig(x, yr[c]);
+        v[q] = (rok && r0 + q < R) ? x : 0.0f;
       }
     }
   };
-  const int64_t t_step = (int64_t)gridDim.x * 4;
-  float vn[NKS][8];
-  {
-    const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
+  auto load_tile = [&](int64_t t, float (&v)[NKS][8]) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) load_step(t, ks, v[ks]);
+  };
+  const int64_t t_step = (int64_t)gridDim.x * NW;
+  constexpr bool AHEAD = NW <= 4;                            // the next tile in registers (one wave per SIMD)
+  constexpr int WIN = 2;                                     // otherwise: k-steps of loads in flight
+  float vn[AHEAD ? NKS : 1][8];
+  if constexpr (AHEAD) {
+    const int64_t t0 = (int64_t)blockIdx.x * NW + wave;
     if (t0 < ntiles) load_tile(t0, vn);
   }
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += t_step) {
+  for (int64_t t = (int64_t)blockIdx.x * NW + wave; t < ntiles; t += t_step) {
     float v[NKS][8];
+    if constexpr (AHEAD) {
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
+      for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[ks][q] = vn[ks][q];
-    if (t + t_step < ntiles) load_tile(t + t_step, vn);      // the next tile travels under this one's MFMAs
+        for (int q = 0; q < 8; ++q) v[ks][q] = vn[ks][q];
+      if (t + t_step < ntiles) load_tile(t + t_step, vn);    // the next tile travels under this one's MFMAs
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < (WIN < NKS ? WIN : NKS); ++ks) load_step(t, ks, v[ks]);
+    }
     f32x16t acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -148,6 +227,9 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
       for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
+      if constexpr (!AHEAD) {
+        if (ks + WIN < NKS) load_step(t, ks + WIN, v[ks + WIN]);
+      }
       bf16x8 a[3];
       tall_split8(v[ks], a[0], a[1], a[2]);
 #pragma unroll
@@ -196,15 +278,17 @@ __global__ __launch_bounds__(256) void tall_linear_kernel(const float* __restric
 // ---- dW = G^T X, db = sum G --------------------------------------------------------------------
 // Wave `gw` (global index) owns row tile gw % nrt of dW and every (nwaves / nrt)-th k-step of 16 batch
 // rows; partial[gw][32][128] and partial_db[gw][32].
-template <int NCT>
-__global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict__ G,
+// NW = 8 (round 6): two waves per SIMD -- one wave's loads / splits under the other's MFMAs -- and the waves w,
+// w + 4 of a workgroup (same row tile) add their tiles through LDS, so the number of partial tiles stays 4 per CU.
+template <int NCT, int NW>
+__global__ __launch_bounds__(64 * NW) void tall_wgrad_kernel(const float* __restrict__ G,
                                                          const float* __restrict__ X,
                                                          const float* __restrict__ Ymul, int64_t B, int R,
                                                          int K, int nrt, float* __restrict__ partial,
                                                          float* __restrict__ partial_db) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, kg = lane >> 5;
-  const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
+  const int64_t gw = (int64_t)blockIdx.x * NW + wave, nwaves = (int64_t)gridDim.x * NW;
   const int rt = (int)(gw % nrt);
   const int64_t share = gw / nrt, nshares = nwaves / nrt;            // (nwaves is a multiple of nrt)
   const int64_t nks = (B + 15) / 16;
@@ -296,7 +380,28 @@ __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict
     if (ks < nks) mma(o0);
     if (ks + nshares < nks) mma(o1);
   }
-  float* dst = partial + gw * (32 * TALL_MAX);
+  dbs += __shfl_xor(dbs, 32);
+  if constexpr (NW == 8) {
+    // waves 4..7 hand their tile to waves 0..3 (same row tile: 4 % nrt == 0), which add it to their own
+    extern __shared__ __attribute__((aligned(16))) unsigned char tallw_smem[];
+    float* xch = reinterpret_cast<float*>(tallw_smem) + (wave & 3) * (NCT * 16 + 1) * 64;
+    if (wave >= 4) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xch[(ct * 16 + i) * 64 + lane] = acc[ct][i];
+      xch[NCT * 16 * 64 + lane] = dbs;
+    }
+    __syncthreads();
+    if (wave >= 4) return;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ct][i] += xch[(ct * 16 + i) * 64 + lane];
+    dbs += xch[NCT * 16 * 64 + lane];
+  }
+  const int64_t gp = (int64_t)blockIdx.x * 4 + wave;        // (gp % nrt == rt)
+  float* dst = partial + gp * (32 * TALL_MAX);
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -304,8 +409,7 @@ __global__ __launch_bounds__(256) void tall_wgrad_kernel(const float* __restrict
       const int m = (i & 3) + 8 * (i >> 2) + 4 * kg;
       dst[m * TALL_MAX + 32 * ct + l31] = acc[ct][i];
     }
-  dbs += __shfl_xor(dbs, 32);
-  if (kg == 0) partial_db[gw * 32 + l31] = dbs;
+  if (kg == 0) partial_db[gp * 32 + l31] = dbs;
 }
 
 // dW[r][k] = the sum over the waves that own r's tile: 8 outputs x 32 groups per workgroup, thread (j, g)
@@ -343,11 +447,21 @@ __global__ __launch_bounds__(256) void tall_wgrad_reduce_kernel(const float* __r
   }
 }
 
-static int tall_wgrad_grid(int64_t B) {
-  // one workgroup per CU (a wave per SIMD; each keeps three k-steps in flight); never more waves than k-steps
+// waves per workgroup of tall_linear_kernel: 0 = by size; PA_TALL_WAVES=4 | 16 pins it (measurements)
+static int tall_waves() {
+  static const int v = [] {
+    const char* e = getenv("PA_TALL_WAVES");
+    const int n = e ? atoi(e) : 0;
+    return (n == 4 || n == 16) ? n : 0;
+  }();
+  return v;
+}
+
+static int tall_wgrad_grid(int64_t B, int nw) {
+  // one workgroup per CU (nw / 4 waves per SIMD; each keeps three k-steps in flight); never more waves than k-steps
   int64_t g = (int64_t)cu_count();
   const int64_t nks = (B + 15) / 16;
-  if (g * 4 > nks) g = (nks + 3) / 4;
+  if (g * nw > nks) g = (nks + nw - 1) / nw;
   return (int)(g < 1 ? 1 : g);
 }
 
@@ -370,26 +484,42 @@ int pa_tall_linear_act(const float* G, int64_t B, int64_t R, const float* W, int
   PA_REQUIRE(G && W && Y, "tall_linear: NULL pointer");
   const int nks = (int)((R + 15) / 16), nct = (int)((C + 31) / 32);
   const int64_t ntiles = (B + 31) / 32;
-  int64_t grid = (ntiles + 3) / 4;
-  const int64_t cap = (int64_t)pa::cu_count() * (nks * nct > 16 ? 1 : 2);
+  // sixteen waves per workgroup (four per SIMD, one tile each) once there is a tile for every wave of a
+  // quarter of the chip; below that the four-wave form (fewer, longer-lived waves: the planes' prologue is
+  // per workgroup)
+  int nw = pa::tall_waves() != 0 ? pa::tall_waves() : (ntiles >= (int64_t)pa::cu_count() * 4 ? 16 : 4);
+  // (the sixteen-wave form reads rows in 16-byte granules through 32-bit buffer offsets)
+  if ((R & 3) != 0 || B * R >= (1ll << 29) || ((uintptr_t)G & 15) != 0 || (y_mul && ((uintptr_t)y_mul & 15) != 0)) nw = 4;
+  int64_t grid = (ntiles + nw - 1) / nw;
+  const int64_t cap = (int64_t)pa::cu_count() * (nw == 16 || nks * nct > 16 ? 1 : 2);
   if (grid > cap) grid = cap;
-  const size_t lds = (size_t)nks * nct * 3 * 1024;
+  // a contiguous weight is staged through LDS in memory order (sixteen-wave form, when it fits behind the planes)
+  const bool contiguous = (w_row_stride == 1 && w_col_stride == R) || (w_col_stride == 1 && w_row_stride == C);
+  const size_t stage_bytes = ((size_t)R * C * 4 + 15) & ~(size_t)15;
   hipStream_t s = pa::as_stream(stream);
-#define PA_TALL_CASE(NKS_, NCT_)                                                                       \
-  if (nks <= NKS_ && nct <= NCT_) {                                                                    \
-    auto k = pa::tall_linear_kernel<NKS_, NCT_>;                                                       \
-    const size_t l = (size_t)NKS_ * NCT_ * 3 * 1024;                                                   \
+#define PA_TALL_LAUNCH(NKS_, NCT_, NW_)                                                                \
+  {                                                                                                    \
+    auto k = pa::tall_linear_kernel<NKS_, NCT_, NW_>;                                                  \
+    size_t l = (size_t)NKS_ * NCT_ * 3 * 1024;                                                         \
+    const int stage = NW_ == 16 && contiguous && ((R * C) & 3) == 0 && ((uintptr_t)W & 15) == 0 &&     \
+                      l + stage_bytes <= (size_t)156 * 1024;                                           \
+    if (stage) l += stage_bytes;                                                                       \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);     \
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), l, s, G, B, (int)R, W, w_row_stride,        \
-                       w_col_stride, (int)C, bias, y_mul, sigmoid_out, Y);                             \
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * NW_), l, s, G, B, (int)R, W, w_row_stride,   \
+                       w_col_stride, (int)C, bias, y_mul, sigmoid_out, Y, stage);                      \
     return pa::check_launch("tall_linear_kernel");                                                     \
   }
-  (void)lds;
+#define PA_TALL_CASE(NKS_, NCT_)                                                                       \
+  if (nks <= NKS_ && nct <= NCT_) {                                                                    \
+    if (nw == 16) PA_TALL_LAUNCH(NKS_, NCT_, 16)                                                       \
+    PA_TALL_LAUNCH(NKS_, NCT_, 4)                                                                      \
+  }
   PA_TALL_CASE(1, 4)
   PA_TALL_CASE(8, 1)
   PA_TALL_CASE(7, 4)
   PA_TALL_CASE(8, 4)
 #undef PA_TALL_CASE
+#undef PA_TALL_LAUNCH
   return pa::fail(PA_ERR_UNSUPPORTED, "tall_linear: no kernel for R=%lld C=%lld", (long long)R, (long long)C);
 }
 
@@ -421,15 +551,28 @@ int pa_tall_wgrad_act(const float* G, const float* X, const float* y_mul, int64_
   PA_REQUIRE(workspace_bytes >= pa_tall_wgrad_workspace(B, R, K), "tall_wgrad: workspace too small");
   int nrt = (int)((R + 31) / 32);
   if (nrt == 3) nrt = 4;                               // (a wave's tile index is gw % nrt, 4 waves per workgroup)
-  const int grid = pa::tall_wgrad_grid(B);
-  const int64_t nwaves = (int64_t)grid * 4;
+  // eight waves per workgroup (two per SIMD) once every wave has k-steps for its three register sets
+  const int64_t nks16 = (B + 15) / 16;
+  const int tw = pa::tall_waves();
+  const int nw = tw == 4 ? 4 : tw == 16 ? 8 : (nks16 * nrt >= (int64_t)pa::cu_count() * 8 * 6 ? 8 : 4);
+  const int grid = pa::tall_wgrad_grid(B, nw);
+  const int64_t nwaves = (int64_t)grid * 4;            // partial tiles (the eight-wave form adds pairs in LDS)
   float* part = (float*)workspace;
   float* part_db = part + nwaves * (32 * pa::TALL_MAX);
   const int nct = (int)((K + 31) / 32);
 #define PA_TALLW_CASE(NCT_)                                                                            \
-  if (nct == NCT_)                                                                                     \
-    hipLaunchKernelGGL((pa::tall_wgrad_kernel<NCT_>), dim3((unsigned)grid), dim3(256), 0, s, G, X,     \
-                       y_mul, B, (int)R, (int)K, nrt, part, part_db);
+  if (nct == NCT_) {                                                                                   \
+    if (nw == 8) {                                                                                     \
+      auto k = pa::tall_wgrad_kernel<NCT_, 8>;                                                         \
+      const size_t l = (size_t)4 * (NCT_ * 16 + 1) * 64 * sizeof(float);                               \
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);   \
+      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), l, s, G, X, y_mul, B, (int)R, (int)K,     \
+                         nrt, part, part_db);                                                          \
+    } else {                                                                                           \
+      hipLaunchKernelGGL((pa::tall_wgrad_kernel<NCT_, 4>), dim3((unsigned)grid), dim3(256), 0, s, G,   \
+                         X, y_mul, B, (int)R, (int)K, nrt, part, part_db);                             \
+    }                                                                                                  \
+  }
   PA_TALLW_CASE(1)
   PA_TALLW_CASE(2)
   PA_TALLW_CASE(3)

@@ -164,14 +164,15 @@ def hier_logreg_model(X, y, segments, plate_scale=1.0):
 
 
 def hier_prior_logreg_model(X, y):
-    """BASELINE config 5's prior structure over ONE group: mu ~ N(0,1)^D, tau ~ HalfNormal(1)^D, w ~ N(mu, tau),
-    obs_n ~ Bernoulli(logits = x_n . w + b).  The smallest model whose site parameters are other latent sites'
-    values: under NUTS the direct potential holds it (infer/mcmc/direct.py, parent-valued parameters)."""
+    """Logistic regression with a LEARNED prior scale: tau ~ HalfNormal(1), w ~ N(0, tau)^D, b ~ N(0, 1),
+    obs_n ~ Bernoulli(logits = x_n . w + b).  The smallest well-identified model whose site parameter is another
+    latent site's value (BASELINE config 5's w_g ~ N(mu, tau) has the same structure over G groups): under NUTS
+    the direct potential holds it (infer/mcmc/direct.py, parent-valued parameters).  ``tau.unsqueeze(-1)``: the
+    broadcast-safe text vectorised chains / particles need (a scalar site against an event dimension)."""
     N, D = X.shape
-    mu = sample("mu", dist.Normal(X.new_zeros(D), 1.0).to_event(1))
-    tau = sample("tau", dist.HalfNormal(X.new_ones(D)).to_event(1))
+    tau = sample("tau", dist.HalfNormal(X.new_ones(())))
     b = sample("b", dist.Normal(X.new_zeros(()), 1.0))
-    w = sample("w", dist.Normal(mu, tau).to_event(1))
+    w = sample("w", dist.Normal(X.new_zeros(D), tau.unsqueeze(-1)).to_event(1))
     with plate("data", N):
         sample("obs", dist.Bernoulli(logits=dist.linear_logits(X, w, b)), obs=y)
 

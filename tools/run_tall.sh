@@ -1,8 +1,11 @@
 #!/bin/bash
 # developer tool: tests and timings of the tall-batch Linear kernels (csrc/tall.hip) and config 4
+#   PA_TALL_WAVES=4|16 pins the waves per workgroup of tall_linear_kernel (default: by size)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 timeout -s KILL 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k 'tall or bow or histogram or bag' 2>&1 | tail -6
-timeout -s KILL 120 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -8
+for NWV in 4 0; do
+echo "PA_TALL_WAVES=$NWV"
+PA_TALL_WAVES=$NWV timeout -s KILL 120 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -8
 import sys; sys.path.insert(0, '.')
 import torch
 from pyro_amd import kernels as k
@@ -24,7 +27,7 @@ for name, fn in (('fwd 100->100', lambda: k.tall_linear(x, W, 1, 100, 100, b)),
     e.record(); torch.cuda.synchronize()
     print('  %-14s %.1f us' % (name, s.elapsed_time(e) * 100), flush=True)
 PY
-timeout -s KILL 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -3
+PA_TALL_WAVES=$NWV timeout -s KILL 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -3
 import sys; sys.path.insert(0, '.')
 import torch
 from tools import bench_configs as b
@@ -32,3 +35,4 @@ dev = torch.device('cuda:0')
 r = b.config4(dev, steps=10)
 print('config4:', {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != 'roofline'})
 PY
+done
