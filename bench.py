@@ -571,7 +571,7 @@ def compact(out):
     """The ONE line the driver parses: numbers and short names only, < 4 KB whatever was measured.  The full
     record (every block time, every note, every variant) goes to bench_full.json."""
     line = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                 "scaling", "vs_baseline", "dtype", "data", "rccl_ranks")
+                 "scaling", "vs_baseline", "dtype", "data", "rccl_ranks", "replay")
     line["config"] = out["config"]
     rf = out["roofline"]
     line["roofline"] = _pick(rf, "bound", "kernel", "kernel_ms", "kernel_ms_eager", "kernel_ms_rocprof", "achieved",
@@ -617,7 +617,7 @@ def compact(out):
         e = _pick(mn, "metric", "n_gpus", "dtype", "error")
         runs = {}
         for k, v in (mn.get("runs") or {}).items():
-            rr = _pick(v, "value", "sampling_phase", "us_per_round", "round_occupancy", "converged",
+            rr = _pick(v, "value", "sampling_phase", "leapfrogs", "us_per_round", "round_occupancy", "converged",
                        "direct_potential")
             rr["max_r_hat"] = _r(v.get("posterior_check", {}).get("max_r_hat"))
             rr["roofline"] = _pick(v.get("roofline", {}), "kernel_ms", "frac", "traffic", "claimed")
@@ -724,10 +724,12 @@ def main():
             return float("nan")
 
     timer = kernels.KernelTimer(_lib.KERNEL_GLM) if on_gpu else _NoTimer()
-    # untimed warm-up; with hip_graph the step is captured here (after 2 eager steps) and the
-    # bracket armed for the capturing step becomes two event-record nodes of the graph
+    # untimed warm-up; with hip_graph the step is captured here (after 3 eager steps).  The event bracket is NOT
+    # armed then: armed for the capturing step it became two event-record nodes of the graph, which do not time
+    # the node on ROCm 7.2 (below) -- the headline graph is the two kernel nodes and nothing else
     for _ in range(max(args.warmup, 4 if use_graph else 0)):
-        timer.arm()
+        if not use_graph:
+            timer.arm()
         svi.step(X, y)
     graphed = use_graph and svi.hip_graph and len(svi._graphs) == 1
     kern_ms_list = []
@@ -1095,6 +1097,11 @@ def main():
                                               "+ ELBO assembly + guide backward + Adam + loss hand-over)",
                                "chain": getattr(svi, "chain_stats", None),
                                "chain_fused": getattr(svi, "chain_fused", None)}
+        ent = next(iter(svi._graphs.values()), None) if graphed else None
+        # how a step is enqueued: its kernels one by one (csrc/replay.hip: a graph that is a chain of <= 4 kernel
+        # nodes) or one hipGraphLaunch
+        out["replay"] = ("eager" if ent is None else "hipGraphLaunch" if ent.direct is None
+                         else "%d kernel launches" % ent.direct.n_nodes)
         if sharded5 is not None:
             others = dict(others or {})
             others["config5_plate_sharded"] = sharded5

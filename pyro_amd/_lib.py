@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpyro_amd.so")
 
 PA_OK, PA_ERR_INVALID, PA_ERR_UNSUPPORTED, PA_ERR_LAUNCH = 0, -1, -2, -3
 PA_F32, PA_F64 = 0, 1
-ABI_VERSION = 7      # PA_ABI_VERSION of include/pyro_amd.h
+ABI_VERSION = 8      # PA_ABI_VERSION of include/pyro_amd.h
 
 DIST_NORMAL = 0
 DIST_BERNOULLI_LOGITS = 1
@@ -221,6 +221,9 @@ _SIGNATURES = {
     "pa_rtc_blocks_begin": (c_void_p, []),
     "pa_rtc_blocks_end": (c_int, [c_void_p, c_void_p]),
     "pa_rtc_blocks_free": (c_int, [c_void_p]),
+    "pa_graph_direct_plan": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int)]),
+    "pa_graph_direct_launch": (c_int, [c_void_p, c_void_p]),
+    "pa_graph_direct_free": (c_int, [c_void_p]),
     "pa_rtc_launch": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_int, c_void_p]),
     "pa_nuts_gaussian_find_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_uint64,

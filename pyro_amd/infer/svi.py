@@ -90,6 +90,7 @@ class _CapturedStep:
     alive = True           # False once the entry left SVI._graphs (evicted, stale, released)
     rtc_blocks = None
     reads = ()             # tensors the step reads that it did not make (see _ReadSet)
+    direct = None          # kernels.DirectReplay when the graph is a short chain of kernels (launched as such)
     gate = None            # kernels.StepGate when the step's first node is a gate (SVI(prearm=True))
     armed = False          # the NEXT replay is already enqueued behind its gate
     armed_state = None     # what the host looked like when it was enqueued
@@ -107,24 +108,33 @@ class _CapturedStep:
             self._value_np, self._seq_np = mailbox[0].numpy(), mailbox[1].numpy()
             self._seq = int(self._seq_np[0])
 
+    def replay(self):
+        """Enqueue the captured step: one hipGraphLaunch, or -- opt-in, kernels.DIRECT_REPLAY -- its two or three
+        kernels one by one (measured slower for a step that waits for its loss, closer together when queued ahead)."""
+        d = self.direct
+        if d is not None:
+            d.launch()
+        else:
+            self.graph.replay()
+
     # ---- the step gate (kernels.StepGate): replays enqueued ahead of the host ------------------
     def launch(self):
         """Run the step now: release the replay waiting in its gate, or enqueue one that passes."""
         g = self.gate
         if g is None:
-            self.graph.replay()
+            self.replay()
             return False
         g.go_np[0] = g.next
         if self.armed:
             self.armed = False
             return True                 # (it may have given itself up meanwhile: read_loss checks)
-        self.graph.replay()
+        self.replay()
         return False
 
     def arm(self, state):
         """Enqueue the NEXT step behind its gate (call right after launch(): the host's launch
         latency then overlaps the device's execution of the current step)."""
-        self.graph.replay()
+        self.replay()
         self.armed, self.armed_state = True, state
 
     def cancel(self):
@@ -162,7 +172,7 @@ class _CapturedStep:
                 if self.armed:
                     self.armed = False
                 else:
-                    self.graph.replay()
+                    self.replay()
                 self.arm_backoff = self.arm_penalty
                 self.arm_penalty = min(self.arm_penalty * 2, 1024)
             if spins > 5_000_000:           # ~seconds: something is wrong, fall back to a real sync
@@ -449,7 +459,7 @@ class SVI:
                 kernels.lda_index_revalidate()
                 kernels.bow_revalidate()
                 entry.cap.before_replay()
-                entry.graph.replay()
+                entry.replay()
                 if entry.graph2 is not None:
                     entry.between()
                     entry.graph2.replay()
@@ -541,7 +551,7 @@ class SVI:
             kernels.lda_index_revalidate()
             kernels.bow_revalidate()
             entry.cap.before_replay()
-            entry.graph.replay()
+            entry.replay()
             if entry.graph2 is not None:
                 entry.between()            # eager RCCL all-reduce of the flat gradient
                 entry.graph2.replay()
@@ -731,7 +741,7 @@ class SVI:
         cap = rng.GraphCapture(device)
         mailbox = (torch.zeros(1, dtype=torch.float64).pin_memory(),
                    torch.zeros(1, dtype=torch.int64).pin_memory())
-        graph = torch.cuda.CUDAGraph()
+        graph = kernels.new_graph()
         graph2 = between = None
         split = hasattr(self.optim, "reduce_gradients") and \
             (getattr(self.optim, "multi_rank", False) or getattr(self, "_force_split", False))
@@ -827,6 +837,15 @@ class SVI:
             self.hip_graph = False
             return None
         entry = _CapturedStep(graph, cap, loss, graph2, between, mailbox)
+        if not split:
+            entry.direct = kernels.graph_direct_plan(graph)
+        if entry.direct is None and hasattr(graph, "instantiate"):
+            for g_ in (graph, graph2):          # (kept hipGraph_t: the executable is made here, not in a timed step)
+                if g_ is not None:
+                    try:
+                        g_.instantiate()
+                    except RuntimeError:
+                        pass
         if self._eager_update and not split:
             # (the gradients the captured backward writes are the .grad tensors of these leaves: the eager
             #  update reads them, zero_grads clears them in place -- their addresses are part of the graph)

@@ -41,6 +41,70 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class DirectReplay:
+    """A captured hipGraph that is one short chain of kernel nodes, replayed as plain kernel launches
+    (csrc/replay.hip).  Opt-in (DIRECT_REPLAY below: measured slower than hipGraphLaunch for a step that waits
+    for its loss, faster when replays are queued ahead).  Holds the graph (the plan points into its nodes'
+    argument blocks)."""
+
+    def __init__(self, handle, graph, n_nodes):
+        self._handle = ctypes.c_void_p(handle)
+        self.graph, self.n_nodes = graph, n_nodes
+        self._launch = _lib.load().pa_graph_direct_launch
+
+    def launch(self):
+        rc = self._launch(self._handle, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            check(rc)
+
+    def free(self):
+        h, self._handle = self._handle, None
+        if h is not None:
+            _lib.load().pa_graph_direct_free(h)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+# Measured on the config-2 step (two kernel nodes; tools/graph_launch_host_cost.py, ROCm 7.2): both forms cost the
+# host ~10 us per enqueue.  UN-ARMED (step() launches its replay and waits for the loss) the pre-encoded graph
+# reaches the device sooner: 72.2 us per step against 75.7 as two launches -- so "on" is opt-in
+# (PYRO_AMD_DIRECT_REPLAY=1 / DIRECT_REPLAY["on"] = True).  When replays are enqueued AHEAD of the host the device's
+# cadence is what counts and plain launches follow each other more closely than graph launches (62.5 against
+# 66.5 us per step with the queue kept full).
+DIRECT_REPLAY = {"on": os.environ.get("PYRO_AMD_DIRECT_REPLAY", "0") == "1", "max_nodes": 4}
+
+
+def new_graph():
+    """A torch CUDAGraph that keeps its hipGraph_t after the capture (so that graph_direct_plan can read its
+    nodes) when direct replay is switched on and this torch can do that; a plain one otherwise."""
+    if DIRECT_REPLAY["on"]:
+        try:
+            return torch.cuda.CUDAGraph(keep_graph=True)
+        except TypeError:      # (an older torch: no keep_graph)
+            pass
+    return torch.cuda.CUDAGraph()
+
+
+def graph_direct_plan(graph):
+    """DirectReplay for a captured torch CUDAGraph made by new_graph(), or None (more than
+    DIRECT_REPLAY["max_nodes"] nodes, a node that is not a kernel, a fork, a module-launched kernel, or a torch
+    that cannot hand out the hipGraph_t): the caller then replays the graph the ordinary way."""
+    if not DIRECT_REPLAY["on"] or not hasattr(graph, "raw_cuda_graph"):
+        return None
+    try:
+        raw = graph.raw_cuda_graph()
+    except RuntimeError:       # (keep_graph was not set)
+        return None
+    plan, n = ctypes.c_void_p(), ctypes.c_int()
+    check(_lib.load().pa_graph_direct_plan(ctypes.c_void_p(raw), DIRECT_REPLAY["max_nodes"], ctypes.byref(plan),
+                                           ctypes.byref(n)))
+    return DirectReplay(plan.value, graph, n.value) if plan.value else None
+
+
 # Who wants to know that a launch of ours is about to touch tensor t: pyro_amd/ops/fuser.py (it defers
 # eligible torch operators; whatever is recorded and shares memory with t has to be materialised first),
 # SVI's capture (it notes every tensor a captured step reads that was not made inside the step)

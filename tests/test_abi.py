@@ -30,7 +30,7 @@ def test_header_vs_binding_vs_library():
     exported = sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\b", out)))
     assert exported == declared
     lib = _lib.load()
-    assert lib.pa_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.pa_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_no_torch_types_in_abi():

@@ -3,6 +3,7 @@ the golden vectors of the unmodified reference.  Tolerances: float64 element-wis
 kernels 1e-9; float32 (including the fused f32-MFMA GLM kernel) vs the reference's own float32
 run 2e-4 on the loss and 2e-3 (relative to the largest gradient entry) on gradients."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -852,3 +853,84 @@ def test_torch_optimizer_behind_a_captured_loss_follows_the_eager_trajectory(gpu
     finally:
         pyro.enable_validation(True)
         pyro.clear_param_store()
+
+
+def test_short_captured_step_is_replayed_as_its_kernels(gpu):
+    """csrc/replay.hip (opt-in: kernels.DIRECT_REPLAY): the captured config-2 step is a chain of two kernel nodes;
+    switched on, it is launched as those two kernels (pa_graph_direct_launch) instead of through hipGraphLaunch.
+    Same device work: the losses and the parameters of 15 steps equal, bit for bit, those of the run that
+    replays the graph."""
+    import pyro_amd as pyro
+    from pyro_amd import examples, kernels
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(50_000, 32, gpu, seed=0)
+
+    def run(direct):
+        prev = kernels.DIRECT_REPLAY["on"]
+        kernels.DIRECT_REPLAY["on"] = direct
+        try:
+            pyro.clear_param_store(); pyro.set_rng_seed(3)
+            guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+            svi = SVI(examples.logreg_model, guide, pyro.optim.Adam({"lr": 0.01}),
+                      Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                losses = [svi.step(X, y) for _ in range(15)]
+            entries = list(svi._graphs.values())
+            assert len(entries) == 1
+            plan = entries[0].direct
+            params = {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
+            svi.release()
+            return losses, params, plan
+        finally:
+            kernels.DIRECT_REPLAY["on"] = prev
+
+    run(False)        # (the first step of a process on new data builds the plane image of X: a different launch)
+    la, pa_, plan = run(True)
+    assert plan is not None and plan.n_nodes == 2, "the headline step is expected to be two kernel nodes"
+    lb, pb, none = run(False)
+    assert none is None
+    assert la == lb
+    for k in pa_:
+        assert torch.equal(pa_[k], pb[k]), k
+
+
+def test_direct_replay_plan_only_for_short_kernel_chains(gpu):
+    """pa_graph_direct_plan: a chain of three kernels gets a plan whose launch does what graph.replay() does; a
+    graph of more nodes than DIRECT_REPLAY["max_nodes"], and one holding a memset node, get none."""
+    from pyro_amd import kernels
+
+    prev = kernels.DIRECT_REPLAY["on"]
+    kernels.DIRECT_REPLAY["on"] = True
+
+    def capture(n_ops, memset=False):
+        x = torch.zeros(1024, device=gpu)
+        g = kernels.new_graph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            if memset:
+                x.zero_()
+            for _ in range(n_ops):
+                x.add_(1.0)
+        return g, x
+
+    g, x = capture(3)
+    plan = kernels.graph_direct_plan(g)
+    assert plan is not None and plan.n_nodes == 3
+    plan.launch(); plan.launch()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(x[0]) == 9.0 and float(x[-1]) == 9.0
+    g2, _ = capture(kernels.DIRECT_REPLAY["max_nodes"] + 2)
+    assert kernels.graph_direct_plan(g2) is None
+    g3, x3 = capture(1, memset=True)
+    p3 = kernels.graph_direct_plan(g3)
+    if p3 is not None:                       # (a runtime that captures zero_() as a kernel: still a chain)
+        p3.launch()
+    else:
+        g3.replay()
+    torch.cuda.synchronize()
+    kernels.DIRECT_REPLAY["on"] = prev
+    assert float(x3[0]) == 1.0
