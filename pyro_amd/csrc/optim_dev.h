@@ -70,6 +70,10 @@ template <typename T>
 __device__ __forceinline__ void adam_update(T gi, T& pi, T& mi, T& vi, const AdamStep& st, double b1,
                                             double b2, double eps, double wd, double clip,
                                             int clipped) {
+  // lr == 0 without weight decay: the no-op optimizer (pyro_amd.optim.NoUpdate -- a step that computes the loss
+  // and the gradients, hands the loss over and zeroes the gradients): parameter AND moments stay as they are
+  // (0 * m / denom would also turn an overflowed moment into a NaN parameter)
+  if (st.lr_t == 0.0 && wd == 0.0) return;
   if (clipped && clip > 0.0) {  // element-wise clamp, clipped_adam.py:69
     gi = gi > (T)clip ? (T)clip : (gi < (T)(-clip) ? (T)(-clip) : gi);
   }

@@ -1,4 +1,4 @@
-from .optim import (SGD, Adam, AdamW, ClippedAdam, PyroLRScheduler, PyroOptim, RMSprop,  # noqa: F401
+from .optim import (SGD, Adam, AdamW, ClippedAdam, NoUpdate, PyroLRScheduler, PyroOptim, RMSprop,  # noqa: F401
                     TorchAdam, _torch_wrappers)
 
 for _name, _factory in _torch_wrappers().items():

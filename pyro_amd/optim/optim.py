@@ -398,6 +398,21 @@ class Adam(_FlatAdam):
         return super().__new__(cls)
 
 
+class NoUpdate(_FlatAdam):
+    """The optimizer that does nothing -- ``SVI(model, guide, NoUpdate(), loss).step()`` is the reference's step
+    (pyro/infer/svi.py:134-162) without its middle line: the loss and the gradients are computed, the loss is
+    handed to the host, the gradients are zeroed; parameters (and the moments this object never uses) stay
+    bit for bit.  It keeps the flat buffers of the package's Adam, so a captured step ends in the same fused
+    tail kernel as the full step (the tail's update arithmetic returns at once for a zero learning rate): what
+    a step costs WITHOUT the update, on the same launches -- bench.py's `config2_loss_and_grads_only`.  To read
+    gradients use ``loss.loss_and_grads`` (they accumulate in ``.grad`` as the reference's do)."""
+
+    def __init__(self, optim_args=None, clip_args=None):
+        if optim_args or clip_args:
+            raise ValueError("NoUpdate takes no arguments")
+        super().__init__({"lr": 0.0})
+
+
 class ClippedAdam(_FlatAdam):
     """pyro.optim.ClippedAdam semantics (element-wise gradient clamp + lr decay)."""
 

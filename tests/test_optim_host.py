@@ -251,3 +251,17 @@ def test_per_parameter_arguments_receive_module_style_names():
     assert torch.allclose(pyro.param("free"), torch.full((3,), -0.1))
     optim.SGD(two_args)(leaves)
     assert seen2 == {("free", "free"), ("net", "weight"), ("net", "bias")}
+
+
+def test_no_update_optimizer_is_a_flat_optimizer_with_a_zero_rate():
+    """pyro_amd.optim.NoUpdate: the flat buffers of the package's Adam (so that a captured step keeps its fused
+    tail) with lr = 0 -- the device code returns before touching parameter or moments; no arguments."""
+    import pytest
+
+    import pyro_amd as pyro
+    from pyro_amd.infer.svi import _FlatOptimOK
+
+    o = pyro.optim.NoUpdate()
+    assert o.lr == 0.0 and o.weight_decay == 0.0 and o.zeroes_grads and _FlatOptimOK(o)
+    with pytest.raises(ValueError):
+        pyro.optim.NoUpdate({"lr": 0.1})

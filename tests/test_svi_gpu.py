@@ -934,3 +934,43 @@ def test_direct_replay_plan_only_for_short_kernel_chains(gpu):
     torch.cuda.synchronize()
     kernels.DIRECT_REPLAY["on"] = prev
     assert float(x3[0]) == 1.0
+
+
+def test_no_update_optimizer_leaves_parameters_and_zeroes_gradients(gpu):
+    """pyro_amd.optim.NoUpdate: SVI.step computes the loss and the gradients, hands the loss over, zeroes the
+    gradients; the parameters stay bit for bit -- eagerly and as a captured step (which ends in the fused tail of
+    the full step: two graph nodes), and both give the losses of the full step's FIRST evaluation sequence with
+    frozen parameters (the same draws: the Philox stream advances as in any step)."""
+    import pyro_amd as pyro
+    from pyro_amd import examples
+    from pyro_amd.infer import SVI, Trace_ELBO
+    from pyro_amd.infer.autoguide import AutoNormal
+
+    X, y = examples.synthetic_logreg_data(20_000, 32, gpu, seed=0)
+
+    def run(graph):
+        pyro.clear_param_store(); pyro.set_rng_seed(7)
+        guide = AutoNormal(examples.logreg_model, init_scale=0.1)
+        svi = SVI(examples.logreg_model, guide, pyro.optim.NoUpdate(),
+                  Trace_ELBO(num_particles=64, vectorize_particles=True, max_plate_nesting=1), hip_graph=graph)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            first = svi.step(X, y)
+            before = {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
+            losses = [first] + [svi.step(X, y) for _ in range(9)]
+        after = {k: v.detach().clone() for k, v in pyro.get_param_store().items()}
+        grads = [p.grad for p in pyro.get_param_store()._params.values() if p.grad is not None]
+        captured = len(svi._graphs)
+        svi.release()
+        return losses, before, after, grads, captured
+
+    le, be, ae, ge, ce = run(False)
+    lg, bg, ag, gg, cg = run(True)
+    assert ce == 0 and cg == 1
+    for before, after in ((be, ae), (bg, ag)):
+        for k in before:
+            assert torch.equal(before[k], after[k]), k
+    for g in ge + gg:
+        assert float(g.abs().max()) == 0.0
+    assert len(set(le)) > 1                      # new draws every step
+    np.testing.assert_allclose(lg, le, rtol=2e-6)
