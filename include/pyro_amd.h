@@ -1045,6 +1045,20 @@ int pa_rtc_blocks_free(void* scope);
 int pa_rtc_launch(void* function, uint32_t grid, uint32_t block, const void* const* pointers,
                   int n_pointers, pa_stream_t stream);
 
+/* ---- csrc/mixture.hip: an observed site under an enumerated assignment, forward and backward in one pass ----
+ * Replaces, for the leaf of a plated mixture under TraceEnum_ELBO (pyro/infer/traceenum_elbo.py:112-214): the
+ * observed site's [K, N] log_prob (pyro/poutine/trace_struct.py:248-288), the sum-product's add + logsumexp over the
+ * enumerated variable and the plate sum (pyro/ops/contract.py:79-160), and the autograd duals of all three.
+ *   S = sum_n log sum_k exp(a[k] + log p(x[n] | p0[k * p0_stride], p1[k * p1_stride]))     (family `dist`, K <= 64)
+ * out[0] = S, out[1 + k] = dS/da_k, out[1 + K + k] = dS/dp0_k, out[1 + 2 K + k] = dS/dp1_k (doubles, device memory,
+ * 1 + 3 K of them; the parameter gradients are per k -- a parameter shared by all k (stride 0) takes their sum).
+ * x, a, p0, p1 are `dtype` (PA_F32 / PA_F64); p1 = NULL for one-parameter families.  Families: Normal, LogNormal,
+ * Exponential, Bernoulli(logits), Poisson, Gamma.  Workspace: pa_mixture_workspace(K) bytes.  Bit-reproducible. */
+size_t pa_mixture_workspace(int K);
+int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, const void* a, const void* p0,
+                       int64_t p0_stride, const void* p1, int64_t p1_stride, void* workspace,
+                       size_t workspace_bytes, double* out, pa_stream_t stream);
+
 /* ---- csrc/replay.hip: a captured step that is a short chain of kernels, launched as kernels ----------------
  * Replaces nothing of the reference's (its SVI.step, pyro/infer/svi.py:134-162, re-runs the model): it is the
  * replay path of this package's captured step, opt-in on the host side: measured on config 2 a step that waits for

@@ -1,0 +1,225 @@
+// mixture.hip -- the marginal likelihood of an observed site under an enumerated assignment, in one pass.
+//
+// Reference path replaced: TraceEnum_ELBO on a plated mixture (pyro/infer/traceenum_elbo.py:112-214): the observed
+// site's log_prob against every value of the enumerated variable -- a [K, N] tensor -- is materialised
+// (pyro/poutine/trace_struct.py:248-288), added to the assignment's log-probabilities, reduced by logsumexp over K
+// (pyro/ops/contract.py:79-160 -> torch_log.einsum) and summed over the plate; autograd keeps the [K, N] frame and
+// walks it twice more.  Round 3 fused the adds + logsumexp (logsumexp.hip) but still read a materialised [K, N]
+// likelihood (64 MB at N = 1e6, K = 16, written once and read twice).
+//
+// Here:   S = sum_n log sum_k exp(a_k + log p(x_n | p0_k, p1_k))
+// with the responsibilities r_nk never leaving registers, and in the same pass
+//         dS/da_k = sum_n r_nk,   dS/dp0_k = sum_n r_nk d log p / d p0,   dS/dp1_k likewise
+// -- the whole forward AND backward of the leaf: x is read once (4 MB), nothing of size K N exists.
+// Lane layout: KP = K rounded up to a power of two (<= 64) lanes hold one row's K terms; 64 / KP rows per wave
+// and iteration; the logsumexp of a row is KP-lane shuffles, the gradient sums live in the lane that owns k.
+// Reduction: lanes -> waves -> workgroup partials in double, added in a fixed order by a second small launch
+// (bit-reproducible).
+#include "common.h"
+#include "dist_fam.h"
+
+namespace pa {
+
+constexpr int MIX_THREADS = 256;
+constexpr int MIX_MAXK = 64;
+
+template <typename T> __device__ __forceinline__ T mix_max(T a, T b) { return a > b ? a : b; }
+
+// The value of lane (l ^ o) for o < 16 without the LDS crossbar: after quad_perm [1,0,3,2] and [2,3,0,1] every lane
+// of a quad has combined the quad's four values; row_half_mirror exchanges the two quads of 8 lanes, row_mirror the
+// two halves of 16 -- an all-reduce over 2 / 4 / 8 / 16 lanes in 1..4 DPP moves (ds_bpermute: an LDS instruction
+// and its wait each).  64-bit values travel as two halves.
+template <int CTRL> __device__ __forceinline__ float mix_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ double mix_dpp(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// all-reduce over the KP lanes (a power of two, aligned) that hold one row's terms
+template <int KP, typename T, typename Op> __device__ __forceinline__ T mix_allreduce(T v, Op op) {
+  if constexpr (KP >= 2) v = op(v, mix_dpp<0xB1>(v));
+  if constexpr (KP >= 4) v = op(v, mix_dpp<0x4E>(v));
+  if constexpr (KP >= 8) v = op(v, mix_dpp<0x141>(v));
+  if constexpr (KP >= 16) v = op(v, mix_dpp<0x140>(v));
+  if constexpr (KP >= 32) v = op(v, __shfl_xor(v, 16, 64));
+  if constexpr (KP >= 64) v = op(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+template <int DIST, typename T, int KP>
+__global__ __launch_bounds__(MIX_THREADS) void mixture_kernel(const T* __restrict__ x, int64_t N, int K,
+                                                              const T* __restrict__ a,
+                                                              const T* __restrict__ p0, int64_t s0,
+                                                              const T* __restrict__ p1, int64_t s1,
+                                                              double* __restrict__ partial) {
+  constexpr int RPW = 64 / KP;                     // rows per wave and iteration
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane & (KP - 1), slot = lane / KP;
+  const bool kok = k < K;
+  const T ninf = -t_inf<T>();
+  const T ak = kok ? a[k] : ninf;
+  const T p0k = p0[kok ? (int64_t)k * s0 : 0];
+  const T p1k = p1 != nullptr ? p1[kok ? (int64_t)k * s1 : 0] : T(0);
+  // (a lane sees N / (waves RPW) rows: tens to a few thousand -- sums in T per lane, in double across lanes)
+  T acc_s = T(0), acc_a = T(0), acc_0 = T(0), acc_1 = T(0);
+  const int64_t step = (int64_t)gridDim.x * (MIX_THREADS / 64) * RPW;
+  for (int64_t base = ((int64_t)blockIdx.x * (MIX_THREADS / 64) + wave) * RPW; base < N; base += step) {
+    const int64_t row = base + slot;
+    const bool valid = row < N;
+    const T xv = x[valid ? row : N - 1];
+    T t = kok ? ak + Fam<DIST, T>::lp(xv, p0k, p1k) : ninf;
+    const T m = mix_allreduce<KP>(t, [](T p, T q) { return mix_max(p, q); });
+    // (a row whose every term is -inf: its logsumexp is -inf and it has no responsibilities)
+    const bool dead = !(m > ninf);
+    const T e = (dead || !kok) ? T(0) : t_exp(t - m);
+    const T ssum = mix_allreduce<KP>(e, [](T p, T q) { return p + q; });
+    // (ssum >= 1 for a live row: the hardware log / reciprocal of the float path are 1 ulp there)
+    const T lse = dead ? ninf : m + pos_log(dead ? T(1) : ssum);
+    const T r = (dead || !valid) ? T(0) : e * pos_rcp(dead ? T(1) : ssum);
+    T dv, da, db;
+    Fam<DIST, T>::grad(xv, p0k, p1k, dv, da, db);
+    acc_s += (valid && k == 0) ? lse : T(0);
+    acc_a += r;
+    acc_0 += r > T(0) ? r * da : T(0);
+    acc_1 += r > T(0) ? r * db : T(0);
+  }
+  // lanes of the same k (the wave's RPW row slots), in double
+  double ds = (double)acc_s, dsa = (double)acc_a, ds0 = (double)acc_0, ds1 = (double)acc_1;
+#pragma unroll
+  for (int o = KP; o < 64; o <<= 1) {
+    ds += __shfl_xor(ds, o, 64);
+    dsa += __shfl_xor(dsa, o, 64);
+    ds0 += __shfl_xor(ds0, o, 64);
+    ds1 += __shfl_xor(ds1, o, 64);
+  }
+  __shared__ double red[MIX_THREADS / 64][4][MIX_MAXK];
+  if (lane < KP) {
+    red[wave][0][lane] = ds;
+    red[wave][1][lane] = dsa;
+    red[wave][2][lane] = ds0;
+    red[wave][3][lane] = ds1;
+  }
+  __syncthreads();
+  // partial[block][0] = sum of the rows' logsumexp; [1 + q * KP + k], q = 0..2: the three gradient sums
+  const int J = 1 + 3 * KP;
+  for (int j = threadIdx.x; j < J; j += MIX_THREADS) {
+    const int q = j == 0 ? 0 : 1 + (j - 1) / KP, kk = j == 0 ? 0 : (j - 1) % KP;
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < MIX_THREADS / 64; ++w) v += red[w][q][kk];
+    partial[(int64_t)blockIdx.x * J + j] = v;
+  }
+}
+
+// out[0] = S, out[1 + k] = dS/da_k, out[1 + K + k] = dS/dp0_k, out[1 + 2 K + k] = dS/dp1_k: the workgroups'
+// partials added in index order (16 segments per output in parallel, the segments in order)
+__global__ __launch_bounds__(1024) void mixture_finalize_kernel(const double* __restrict__ partial, int nblocks,
+                                                                int K, int KP, double* __restrict__ out) {
+  __shared__ double seg[16][64];
+  const int jj = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int J = 1 + 3 * KP;
+  const int j = blockIdx.x * 64 + jj;
+  double v = 0.0;
+  if (j < J) {
+    const int per = (nblocks + 15) / 16;
+    const int b0 = sg * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    // (eight loads in flight: the loop is a chain of L2 round trips otherwise -- 38 us for 2048 partials)
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = partial[(int64_t)(b + u) * J + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += q[u];
+    }
+    for (; b < b1; ++b) v += partial[(int64_t)b * J + j];
+  }
+  seg[sg][jj] = v;
+  __syncthreads();
+  if (sg == 0 && j < J) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += seg[q][jj];
+    if (j == 0) {
+      out[0] = t;
+    } else {
+      const int q = (j - 1) / KP, kk = (j - 1) % KP;
+      if (kk < K) out[1 + q * K + kk] = t;
+    }
+  }
+}
+
+static int mixture_grid(int64_t N, int KP) {
+  const int64_t rows_per_block = (int64_t)(MIX_THREADS / 64) * (64 / KP);
+  int64_t g = (N + rows_per_block * 8 - 1) / (rows_per_block * 8);       // >= 8 iterations per wave
+  const int64_t cap = (int64_t)cu_count() * 2;       // two waves per SIMD; few partials for the second launch
+  if (g > cap) g = cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <int DIST, typename T>
+static int mixture_launch(const T* x, int64_t N, int K, const T* a, const T* p0, int64_t s0, const T* p1,
+                          int64_t s1, double* partial, double* out, hipStream_t s) {
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  const int grid = mixture_grid(N, KP);
+#define PA_MIX_CASE(KP_)                                                                               \
+  if (KP == KP_)                                                                                       \
+    hipLaunchKernelGGL((mixture_kernel<DIST, T, KP_>), dim3((unsigned)grid), dim3(MIX_THREADS), 0, s,  \
+                       x, N, K, a, p0, s0, p1, s1, partial);
+  PA_MIX_CASE(1) PA_MIX_CASE(2) PA_MIX_CASE(4) PA_MIX_CASE(8) PA_MIX_CASE(16) PA_MIX_CASE(32) PA_MIX_CASE(64)
+#undef PA_MIX_CASE
+  const int J = 1 + 3 * KP;
+  hipLaunchKernelGGL(mixture_finalize_kernel, dim3((unsigned)((J + 63) / 64)), dim3(1024), 0, s, partial, grid,
+                     K, KP, out);
+  return check_launch("mixture_kernel");
+}
+
+template <typename T>
+static int mixture_t(int dist, const T* x, int64_t N, int K, const T* a, const T* p0, int64_t s0, const T* p1,
+                     int64_t s1, double* partial, double* out, hipStream_t s) {
+  switch (dist) {
+    case PA_DIST_NORMAL: return mixture_launch<PA_DIST_NORMAL, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
+    case PA_DIST_LOG_NORMAL: return mixture_launch<PA_DIST_LOG_NORMAL, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
+    case PA_DIST_EXPONENTIAL: return mixture_launch<PA_DIST_EXPONENTIAL, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
+    case PA_DIST_BERNOULLI_LOGITS:
+      return mixture_launch<PA_DIST_BERNOULLI_LOGITS, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
+    case PA_DIST_POISSON: return mixture_launch<PA_DIST_POISSON, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
+    case PA_DIST_GAMMA: return mixture_launch<PA_DIST_GAMMA, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
+    default: return fail(PA_ERR_UNSUPPORTED, "mixture_fwd_bwd: distribution id %d not implemented", dist);
+  }
+}
+
+}  // namespace pa
+
+extern "C" {
+
+size_t pa_mixture_workspace(int K) {
+  if (K < 1 || K > pa::MIX_MAXK) return 0;
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  return (size_t)pa::cu_count() * 8 * (1 + 3 * KP) * sizeof(double);
+}
+
+int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, const void* a, const void* p0,
+                       int64_t p0_stride, const void* p1, int64_t p1_stride, void* workspace,
+                       size_t workspace_bytes, double* out, pa_stream_t stream) {
+  PA_REQUIRE(K >= 1 && K <= pa::MIX_MAXK, "mixture_fwd_bwd: K=%d outside [1, %d]", K, pa::MIX_MAXK);
+  PA_REQUIRE(N >= 1 && x && a && p0 && out && workspace, "mixture_fwd_bwd: NULL pointer or N < 1");
+  PA_REQUIRE(p0_stride >= 0 && p1_stride >= 0, "mixture_fwd_bwd: negative parameter stride");
+  PA_REQUIRE(workspace_bytes >= pa_mixture_workspace(K), "mixture_fwd_bwd: workspace too small");
+  PA_REQUIRE(pa::dist_nparams(dist) == 1 || p1 != nullptr, "mixture_fwd_bwd: the family takes two parameters");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    return pa::mixture_t<float>(dist, (const float*)x, N, K, (const float*)a, (const float*)p0, p0_stride,
+                                (const float*)p1, p1_stride, (double*)workspace, out, s);
+  if (dtype == PA_F64)
+    return pa::mixture_t<double>(dist, (const double*)x, N, K, (const double*)a, (const double*)p0, p0_stride,
+                                 (const double*)p1, p1_stride, (double*)workspace, out, s);
+  return pa::fail(PA_ERR_UNSUPPORTED, "mixture_fwd_bwd: dtype %d", dtype);
+}
+
+}  // extern "C"

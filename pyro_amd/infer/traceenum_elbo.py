@@ -29,7 +29,7 @@ import torch
 
 from ..distributions.fused import grad_sink as _grad_sink
 
-from .. import poutine
+from .. import kernels, poutine
 from ..distributions.util import scale_and_mask
 from ..ops.contract import LazyGather, Term, _eliminate, align, contract_tensor_tree, pack
 from ..poutine.util import prune_subsample_sites
@@ -115,6 +115,56 @@ def _lazy_gather(site, first_enum_dim):
         idx = (0,) * nz[0] + (slice(None),) + (0,) * (len(lead) - nz[0] - 1) + (0, 0, slice(None))
         table = logits[idx].reshape(T, V)  # [T, V] view of the un-expanded log-probabilities
     return site["infer"]["_dim_to_id"][edim], LazyGather(table, value)
+
+
+def _lazy_family(site, first_enum_dim):
+    """An observed element-wise site under ONE plate (dim -1) whose parameters were indexed by ONE enumerated
+    value -- ``Normal(locs[z], scale)`` with float data [N]: keep the [K, N] factor as (family, data, parameters
+    per k) for the mixture leaf kernel (ops/contract.py::_try_fused_mixture).  -> (enum id, LazyFamily) or None."""
+    from ..ops import contract
+    fn, value = site["fn"], site["value"]
+    if not contract.FUSED_MIXTURE or not site["is_observed"] or site["mask"] is not None:
+        return None
+    if not isinstance(value, torch.Tensor) or value.dim() != 1 or value.requires_grad \
+            or value.dtype not in (torch.float32, torch.float64) or not kernels.on_device(value):
+        return None
+    if [f.dim for f in site["cond_indep_stack"] if f.vectorized] != [-1]:
+        return None
+    entry = getattr(fn, "fused_site_entry", None)
+    bs = tuple(getattr(fn, "batch_shape", ()))
+    if entry is None or tuple(getattr(fn, "event_shape", ())) != () or len(bs) < 2 \
+            or bs[-1] not in (1, value.shape[0]):
+        return None
+    nz = [i for i, s_ in enumerate(bs[:-1]) if s_ > 1]
+    if len(nz) != 1:
+        return None
+    edim = nz[0] - len(bs)
+    if edim > first_enum_dim or edim not in site["infer"].get("_dim_to_id", {}):
+        return None
+    K = bs[nz[0]]
+    ent = entry(value, 1.0, None)
+    if ent is None or ent[0] not in kernels.MIXTURE_FAMILIES or K > kernels.MIXTURE_MAX_K:
+        return None
+    params = []
+    for p in (ent[2], ent[3]):
+        if p is None:
+            params.append(None)
+            continue
+        if not isinstance(p, torch.Tensor) or p.dtype != value.dtype or not kernels.on_device(p):
+            return None
+        shp = (1,) * (len(bs) - p.dim()) + tuple(p.shape)
+        if len(shp) != len(bs) or shp[-1] != 1 or any(s_ != 1 for i, s_ in enumerate(shp[:-1]) if i != nz[0]) \
+                or shp[nz[0]] not in (1, K):
+            return None                       # a parameter that varies along the plate: the generic path
+        params.append(p)
+    if params[0] is None:
+        return None
+
+    def packed():
+        lp = fn.log_prob(value, *site["args"], **site["kwargs"])
+        return _packed(site, lp, first_enum_dim).tensor
+
+    return site["infer"]["_dim_to_id"][edim], contract.LazyFamily(ent[0], value, params[0], params[1], packed)
 
 
 class TraceEnum_ELBO(ELBO):
@@ -324,6 +374,13 @@ class TraceEnum_ELBO(ELBO):
                 continue
             lazy = _lazy_gather(site, first_enum_dim) if enum_ids else None
             if lazy is not None and lazy[0] in enum_ids:
+                factors.setdefault(_ordinal(site), []).append(
+                    Term(None, (lazy[0],), _ordinal(site), lazy=lazy[1]))
+                scales.append(site["scale"])
+                continue
+            lazy = _lazy_family(site, first_enum_dim) if enum_ids else None
+            if lazy is not None and lazy[0] in enum_ids:
+                # a plated mixture's likelihood: never materialised when the leaf pattern matches
                 factors.setdefault(_ordinal(site), []).append(
                     Term(None, (lazy[0],), _ordinal(site), lazy=lazy[1]))
                 scales.append(site["scale"])

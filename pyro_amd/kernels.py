@@ -1948,6 +1948,30 @@ def lda_index_revalidate():
             ent[1] = base._version
 
 
+MIXTURE_FAMILIES = (_lib.DIST_NORMAL, _lib.DIST_LOG_NORMAL, _lib.DIST_EXPONENTIAL, _lib.DIST_BERNOULLI_LOGITS,
+                    _lib.DIST_POISSON, _lib.DIST_GAMMA)
+MIXTURE_MAX_K = 64
+
+
+def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1):
+    """sum_n logsumexp_k(a[k] + log p(x[n] | p0[k * s0], p1[k * s1])) and its gradients from ONE pass over x
+    (pa_mixture_fwd_bwd): x [N]; a [K]; p0 / p1 flat with stride 1 (per component) or 0 (shared); p1 None for
+    one-parameter families.  -> float64 [1 + 3 K] on the device: S, dS/da, dS/dp0 (per k), dS/dp1 (per k)."""
+    _require_gpu(x, a, p0, p1)
+    K, N = a.numel(), x.numel()
+    assert x.is_contiguous() and a.is_contiguous() and p0.is_contiguous() and (p1 is None or p1.is_contiguous())
+    assert a.dtype == x.dtype and p0.dtype == x.dtype and (p1 is None or p1.dtype == x.dtype)
+    lib = _lib.load()
+    nbytes = lib.pa_mixture_workspace(K)
+    if nbytes == 0:
+        raise Unsupported("pyro_amd: mixture_fwd_bwd needs 1 <= K <= %d (K=%d)" % (MIXTURE_MAX_K, K))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    out = torch.empty((1 + 3 * K,), dtype=torch.float64, device=x.device)
+    check(lib.pa_mixture_fwd_bwd(_dtype(x), int(dist_id), _ptr(x), N, K, _ptr(a), _ptr(p0), int(s0), _ptr(p1),
+                                 int(s1), _ptr(ws), ws.numel(), _ptr(out), _stream()))
+    return out
+
+
 def lda_factor_fwd_bwd(words, log_theta, log_phi, index=None):
     """words int64 [Wd,B]; log_theta [B,T]; log_phi [T,V] -> (out_doc[B], g_theta[B,T], g_phi[T,V]).
     ``index``: an image from lda_build_index (default: the cached one of ``words``, if any)."""

@@ -97,6 +97,95 @@ class LazyGather:
         return self.table[:, self.index]                   # [T, W, D]: packed, two plates
 
 
+class LazyFamily:
+    """log-factor f[k, n] = log p(x[n] | p0[k], p1[k]) of an OBSERVED element-wise site whose parameters were
+    indexed by an enumerated value (``Normal(locs[z], scale)`` under ``plate(n)``: a plated mixture's likelihood),
+    kept un-materialised: the leaf kernel evaluates it in registers (csrc/mixture.hip).  ``packed``: a callable
+    that makes the packed [K, N] tensor the generic elimination needs when the pattern does not match."""
+
+    def __init__(self, dist_id, value, p0, p1, packed):
+        self.dist_id, self.value, self.p0, self.p1, self._packed = dist_id, value, p0, p1, packed
+
+    def materialize(self):
+        return self._packed()
+
+
+FUSED_MIXTURE = True          # the mixture leaf goes through pa_mixture_fwd_bwd
+
+
+@_dispatcher_op("mixture_factor")
+class _MixtureFactor(torch.autograd.Function):
+    """sum_n logsumexp_k(a[k] + log p(x[n] | p0[k], p1[k])) with its gradient from the same pass
+    (pa_mixture_fwd_bwd): nothing of size K N is written."""
+
+    @staticmethod
+    def forward(ctx, dist_id, s0, s1, x, a, p0, p1):
+        out = kernels.mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1)
+        K = a.numel()
+        g = out[1:].to(a.dtype)
+        ctx.shared = (s0 == 0, s1 == 0)
+        ctx.save_for_backward(g[:K], g[K:2 * K], g[2 * K:])
+        return out[0].to(a.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        da, d0, d1 = ctx.saved_tensors
+        if ctx.shared[0]:
+            d0 = d0.sum().reshape(1)
+        if ctx.shared[1]:
+            d1 = d1.sum().reshape(1)
+        return None, None, None, None, g * da, g * d0, (g * d1 if ctx.needs_input_grad[6] else None)
+
+
+def _try_fused_mixture(terms, sum_ids, contract_frames):
+    """The mixture leaf: one enumerated name k, ONE lazy observed-family term over (k, n), every other term a
+    function of k alone (constant along the plate), and the plate n is contracted here.  Returns a 0-dim tensor
+    or None when the pattern does not match."""
+    if not FUSED_MIXTURE or len(sum_ids) != 1 or len(terms) < 1:
+        return None
+    lazy = [t for t in terms if t.tensor is None and isinstance(t.lazy, LazyFamily)]
+    dense = [t for t in terms if t.tensor is not None]
+    if len(lazy) != 1 or len(lazy) + len(dense) != len(terms):
+        return None
+    (kid,) = sum_ids
+    lz = lazy[0].lazy
+    if lazy[0].ids != (kid,) or {f.dim for f in contract_frames} != {-1} \
+            or {f.dim for f in lazy[0].ordinal} != {-1}:
+        return None
+    x = lz.value
+    K = None
+    a = None
+    for t in dense:
+        if t.ids != (kid,) or not isinstance(t.tensor, torch.Tensor) or t.tensor.dtype != x.dtype \
+                or not kernels.on_device(t.tensor):
+            return None
+        k_t = t.tensor.shape[0]
+        if t.tensor.numel() != k_t or (K is not None and k_t != K):
+            return None                     # depends on the plate too (per-row weights): generic path
+        K = k_t
+        a = t.tensor.reshape(K) if a is None else a + t.tensor.reshape(K)
+    if K is None:                            # no assignment probabilities here (they sit higher up the tree)
+        K = max(lz.p0.numel(), 1 if lz.p1 is None else lz.p1.numel())
+        a = x.new_zeros(K)
+    if K > kernels.MIXTURE_MAX_K or K < 1:
+        return None
+
+    def flat(p):
+        if p is None:
+            return None, 0
+        if p.numel() == K and K > 1:
+            return p.reshape(K).contiguous(), 1
+        if p.numel() == 1:
+            return p.reshape(1), 0
+        return False, 0
+
+    p0, s0 = flat(lz.p0)
+    p1, s1 = flat(lz.p1)
+    if p0 is False or p1 is False or p0 is None:
+        return None
+    return _MixtureFactor.invoke(int(lz.dist_id), s0, s1, x.contiguous(), a.contiguous(), p0, p1)
+
+
 @_dispatcher_op("lda_factor")
 class _LdaFactor(torch.autograd.Function):
     """sum_{d,w} logsumexp_t(log_theta[d,t] + log_phi[t, words[w,d]]) and its gradient from ONE
@@ -410,6 +499,8 @@ def _contract_component(tensor_tree, sum_ids, reduce_all=False):
             # logsumexp AND both plate sums
             fuse_frames = leaf if (reduce_all and parent == leaf) else contract_frames
             fused = _try_fused_lda(terms, ids, fuse_frames)
+            if fused is None:
+                fused = _try_fused_mixture(terms, ids, fuse_frames)
             chain = _try_fused_chain(terms, ids) if fused is None and FUSED_CHAIN else None
             if fused is not None:
                 tensor, new_ids = fused, []

@@ -65,8 +65,14 @@ def run_lda(g, device, monkeypatch=None, rtol=1e-9, dtype=torch.float64, expect_
                                float(g["lda/loss"]), rtol=rtol)
 
 
-def run_gmm(g, device, monkeypatch, sub, rtol=1e-9, dtype=torch.float64):
-    from pyro_amd import rng
+def run_gmm(g, device, monkeypatch, sub, rtol=1e-9, dtype=torch.float64, expect_fused=None):
+    from pyro_amd import kernels, rng
+    calls = []
+    if expect_fused is not None:
+        import pyro_amd.ops.contract as c
+        monkeypatch.setattr(c, "FUSED_MIXTURE", bool(expect_fused))
+        real = kernels.mixture_fwd_bwd
+        monkeypatch.setattr(kernels, "mixture_fwd_bwd", lambda *a: calls.append(1) or real(*a))
     K = g["gmm/locs0"].shape[0]
     x = _t(g["gmm/x"], device, dtype)
     N = x.shape[0]
@@ -100,6 +106,8 @@ def run_gmm(g, device, monkeypatch, sub, rtol=1e-9, dtype=torch.float64):
     loss = TraceEnum_ELBO(max_plate_nesting=1).loss_and_grads(model, guide, *args)
     np.testing.assert_allclose(loss, float(g[tag + "/loss"]), rtol=rtol)
     assert_grads(store_grads(), g, tag + "/grad", rtol)
+    if expect_fused is not None:
+        assert len(calls) == (1 if expect_fused else 0), "mixture leaf: %d kernel calls" % len(calls)
 
 
 def lda_brute_force_loss(g):

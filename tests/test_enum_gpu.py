@@ -27,9 +27,12 @@ def test_lda_matches_reference(gpu, monkeypatch, fused):
     ec.run_lda(load("enum"), gpu, monkeypatch, rtol=1e-9, expect_fused=fused)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("sub", [False, True])
-def test_gmm_matches_reference(gpu, monkeypatch, sub):
-    ec.run_gmm(load("enum"), gpu, monkeypatch, sub, rtol=1e-9)
+def test_gmm_matches_reference(gpu, monkeypatch, sub, fused):
+    """The unmodified reference's TraceEnum_ELBO loss and gradients of a plated Gaussian mixture (whole plate and
+    subsampled): through the mixture leaf kernel (csrc/mixture.hip) and through the generic contraction."""
+    ec.run_gmm(load("enum"), gpu, monkeypatch, sub, rtol=1e-9, expect_fused=fused)
 
 
 def _lda_loss_and_grads(args, data, fused, monkeypatch, seed=0):
@@ -235,3 +238,101 @@ def test_lda_minibatch_graphed_steps_draw_the_eager_subsamples(gpu):
             assert len(svi._graphs) == 1
     assert len(set(seqs[0])) == 9                       # nine different subsamples
     np.testing.assert_allclose(seqs[0], seqs[1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dist_id,name", [(0, "Normal"), (3, "LogNormal"), (4, "Exponential"), (1, "Bernoulli"),
+                                           (8, "Poisson"), (6, "Gamma")])
+@pytest.mark.parametrize("dtype,K,N", [(torch.float64, 5, 1237), (torch.float32, 16, 100_003), (torch.float64, 64, 777),
+                                       (torch.float32, 1, 5000), (torch.float64, 3, 1)])
+def test_mixture_kernel_against_the_oracle(gpu, dist_id, name, dtype, K, N):
+    """pa_mixture_fwd_bwd (csrc/mixture.hip) against oracle/mixture.py: S and the three gradient sums for every
+    family it scores, K not a power of two / 1 / 64, ragged N, one component switched off (a = -inf), a shared
+    second parameter (stride 0).  float64: 1e-11; float32 kernels against float64 values: 2e-5 of S, 2e-4 of the
+    largest gradient entry."""
+    from oracle import mixture
+    from pyro_amd import kernels
+
+    rng = np.random.default_rng(11 * dist_id + K)
+    a = np.log(rng.dirichlet(np.ones(K)))
+    if K > 2:
+        a[1] = -np.inf
+    if name in ("Normal", "LogNormal"):
+        p0, p1 = rng.standard_normal(K), rng.uniform(0.5, 2.0, 1)
+        x = rng.standard_normal(N) * 2 if name == "Normal" else np.exp(rng.standard_normal(N))
+    elif name == "Exponential":
+        p0, p1, x = rng.uniform(0.3, 3.0, K), None, rng.exponential(1.0, N)
+    elif name == "Bernoulli":
+        p0, p1, x = rng.standard_normal(K) * 2, None, (rng.uniform(size=N) < 0.4).astype(np.float64)
+    elif name == "Poisson":
+        p0, p1, x = rng.uniform(0.5, 6.0, K), None, rng.poisson(3.0, N).astype(np.float64)
+    else:
+        p0, p1, x = rng.uniform(0.5, 4.0, K), rng.uniform(0.5, 2.0, K), rng.gamma(2.0, 1.0, N)
+    to = lambda v: None if v is None else torch.tensor(v, dtype=dtype, device=gpu)  # noqa: E731
+    tx, ta, t0, t1 = to(x), to(a), to(p0), to(p1)
+    # (the oracle sees the values the kernel sees)
+    back = lambda t: None if t is None else t.double().cpu().numpy()  # noqa: E731
+    S, da, d0, d1 = mixture.mixture_fwd_bwd(dist_id, back(tx), back(ta), back(t0), back(t1))
+    s1 = 0 if (t1 is None or t1.numel() == 1) else 1
+    out = kernels.mixture_fwd_bwd(dist_id, tx, ta, t0, 1 if K > 1 else 0, t1, s1).cpu().numpy()
+    again = kernels.mixture_fwd_bwd(dist_id, tx, ta, t0, 1 if K > 1 else 0, t1, s1).cpu().numpy()
+    assert np.array_equal(out, again)                     # bit-reproducible
+    tol_s, tol_g = (1e-11, 1e-10) if dtype == torch.float64 else (2e-5, 2e-4)
+    np.testing.assert_allclose(out[0], S, rtol=tol_s)
+    for got, want in ((out[1:1 + K], da), (out[1 + K:1 + 2 * K], d0), (out[1 + 2 * K:], d1)):
+        if t1 is None and want is d1:
+            continue
+        scale = max(np.abs(want).max(), 1e-30)
+        np.testing.assert_allclose(got / scale, want / scale, rtol=0, atol=tol_g)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_mixture_leaf_is_fused_and_equals_the_generic_contraction(gpu, monkeypatch, dtype):
+    """TraceEnum_ELBO on a plated Gaussian mixture (the text of tests/golden/make_golden.py's gmm_model at
+    N = 20 000, K = 7): the likelihood is recognised lazily (infer/traceenum_elbo.py::_lazy_family), the leaf runs
+    pa_mixture_fwd_bwd -- no [K, N] tensor -- and loss and gradients equal the generic contraction's (which
+    tests/test_enum_gpu.py::test_gmm_matches_reference pins on the reference)."""
+    import pyro_amd.distributions as dist
+    import pyro_amd.ops.contract as c
+    from pyro_amd import kernels
+    from torch.distributions import constraints
+
+    K, N = 7, 20_000
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(N, generator=g, dtype=torch.float64) + 3.0 * torch.randint(0, K, (N,), generator=g)).to(gpu, dtype)
+    locs0 = 3.0 * torch.arange(K, dtype=dtype, device=gpu) + 0.1
+
+    def model(x):
+        w = pyro.sample("w", dist.Dirichlet(torch.ones(K, dtype=dtype, device=gpu)))
+        with pyro.plate("comp", K):
+            locs = pyro.sample("locs", dist.Normal(torch.zeros((), dtype=dtype, device=gpu), 10.0))
+        with pyro.plate("data", N):
+            z = pyro.sample("z", dist.Categorical(w), infer={"enumerate": "parallel"})
+            pyro.sample("x", dist.Normal(locs[z], 0.7), obs=x)
+
+    def guide(x):
+        ql = pyro.param("ql", locs0.clone())
+        qs = pyro.param("qs", torch.tensor(0.3, dtype=dtype, device=gpu), constraint=constraints.positive)
+        qw = pyro.param("qw", torch.full((K,), 1.0 / K, dtype=dtype, device=gpu), constraint=constraints.simplex)
+        pyro.sample("w", dist.Delta(qw, event_dim=1))
+        with pyro.plate("comp", K):
+            pyro.sample("locs", dist.Normal(ql, qs))
+
+    calls = []
+    real = kernels.mixture_fwd_bwd
+    monkeypatch.setattr(kernels, "mixture_fwd_bwd", lambda *a: calls.append(1) or real(*a))
+
+    def run(fused):
+        monkeypatch.setattr(c, "FUSED_MIXTURE", fused)
+        pyro.clear_param_store(); pyro.set_rng_seed(1)
+        loss = TraceEnum_ELBO(max_plate_nesting=1).loss_and_grads(model, guide, x)
+        return loss, {n: p.grad.detach().clone() for n, p in pyro.get_param_store().named_parameters()}
+
+    la, ga = run(True)
+    assert len(calls) == 1, "the mixture leaf was not recognised"
+    lb, gb = run(False)
+    assert len(calls) == 1
+    rtol = 1e-10 if dtype == torch.float64 else 2e-5
+    assert abs(la - lb) <= rtol * abs(lb), (la, lb)
+    for n in gb:
+        scale = float(gb[n].abs().max()) + 1e-30
+        assert float((ga[n] - gb[n]).abs().max()) <= (1e-9 if dtype == torch.float64 else 2e-4) * scale, n

@@ -36,8 +36,10 @@ def guide(data):
         pyro.sample("loc", dist.Normal(lq, 0.5))
 
 
-for fused in (True, False):
-    contract.FUSED_SUMPRODUCT = fused
+for leaf, fused in ((True, True), (False, True), (False, False)):
+    # leaf: the mixture leaf kernel (csrc/mixture.hip: no [K, N] tensor at all); fused: the elimination through
+    # pa_logsumexp_terms over a materialised [K, N] likelihood (round 3); neither: adds + torch.logsumexp
+    contract.FUSED_MIXTURE, contract.FUSED_SUMPRODUCT = leaf, fused
     for graph in (False, True):
         pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
         svi = SVI(model, guide, pyro.optim.Adam({"lr": 0.01}), TraceEnum_ELBO(max_plate_nesting=1),
@@ -47,5 +49,19 @@ for fused in (True, False):
         for _ in range(30):
             l = svi.step(data)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
-        print("fused_sumproduct", fused, "graph", graph, "ms/step %.3f" % (dt * 1e3), "loss %.1f" % losses[-1])
-contract.FUSED_SUMPRODUCT = True
+        print("mixture_leaf", leaf, "fused_sumproduct", fused, "graph", graph, "ms/step %.3f" % (dt * 1e3),
+              "loss %.1f" % losses[-1], flush=True)
+        svi.release()
+contract.FUSED_MIXTURE = contract.FUSED_SUMPRODUCT = True
+# the leaf kernel alone
+from pyro_amd import _lib, kernels
+a = torch.log(torch.full((K,), 1.0 / K, device=dev))
+p0 = 3.0 * torch.arange(K, device=dev, dtype=torch.float32)
+p1 = torch.ones(1, device=dev)
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+kernels.mixture_fwd_bwd(_lib.DIST_NORMAL, data, a, p0, 1, p1, 0)
+s.record()
+for _ in range(20):
+    kernels.mixture_fwd_bwd(_lib.DIST_NORMAL, data, a, p0, 1, p1, 0)
+e.record(); torch.cuda.synchronize()
+print("pa_mixture_fwd_bwd alone (kernel + finalize + workspace): %.1f us for N=%d K=%d" % (s.elapsed_time(e) * 50, N, K))
