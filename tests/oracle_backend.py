@@ -459,6 +459,12 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
     return torch.as_tensor(out, dtype=dt), torch.as_tensor(gt, dtype=dt), torch.as_tensor(gp, dtype=dt)
 
 
+def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1):
+    from oracle import mixture as o_mix
+    S, da, d0, d1 = o_mix.mixture_fwd_bwd(int(dist_id), _np(x), _np(a), _np(p0), None if p1 is None else _np(p1))
+    return torch.as_tensor(np.concatenate([[S], da, d0, d1]), dtype=torch.float64)
+
+
 def logsumexp_terms(terms, frame, rdim):
     from oracle import logsumexp as o_lse
     out, _ = o_lse.logsumexp_terms([_np(t) for t in terms], tuple(frame), rdim)
@@ -649,7 +655,7 @@ FUNCTIONS = ["bow_images_of", "bow_linear_fwd", "bow_linear_bwd", "tall_linear",
              "glm_bernoulli_grouped_fwd_bwd", "grouped_rows_of", "glm_grouped_rows_servable", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
              "mvn_tril_sample_bwd", "logchain_fwd_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd",
-             "logsumexp_terms", "logsumexp_terms_grad", "gamma_rsample"]
+             "logsumexp_terms", "logsumexp_terms_grad", "gamma_rsample", "mixture_fwd_bwd"]
 
 
 def install(monkeypatch):
