@@ -588,7 +588,7 @@ def compact(out):
             line[k] = _pick(out[k], "value", "ms_per_step")
     oc = out.get("other_configs") or {}
     others = {}
-    keep = ("config4_lda", "config5_hierarchical_logreg", "config5_plate_sharded", "config2_loss_and_grads_only",
+    keep = ("config4_lda", "gmm_enumerated", "config5_hierarchical_logreg", "config5_plate_sharded", "config2_loss_and_grads_only",
             "config2_bf16x3_exact_split", "error")
     for k, v in oc.items():
         if k not in keep:                      # (the variants of --full: bench_full.json only)
@@ -933,7 +933,15 @@ def main():
                               "(no atomics), the guide's first layer on the bag-of-words image, its inner "
                               "layers on the tall-batch kernels; graphed SVI.step")
             others["config4_lda"] = r4
+            rg = bench_configs.config_gmm(dev)
+            rg["workload"] = ("a plated Gaussian mixture under TraceEnum_ELBO, N=1e6 data, K=16 components, the "
+                              "assignment enumerated: likelihood against every component + logsumexp + plate sum "
+                              "+ all gradients in one pass over the data (csrc/mixture.hip); graphed SVI.step")
+            others["gmm_enumerated"] = rg
             if args.full:
+                rg0 = bench_configs.config_gmm(dev, leaf=False)
+                rg0["workload"] = "the same mixture with its [K, N] likelihood materialised (round 3's elimination)"
+                others["gmm_enumerated_materialised"] = rg0
                 for bs in (32, 4096):      # the mini-batch variants SURVEY 8(d) lists
                     rb = bench_configs.config4(dev, steps=30, batch_size=bs)
                     rb["workload"] = ("examples/lda.py with batch_size=%d of 1e5 documents per step (a fresh "

@@ -212,6 +212,49 @@ def config_hmm(dev, S=229, L=129, K=16, D=88, steps=5, fused=True, graph=False):
             "fused_chain": fused, "graphed": bool(graph and svi.hip_graph and len(svi._graphs) == 1)}
 
 
+def config_gmm(dev, N=1_000_000, K=16, steps=200, leaf=True):
+    """A plated Gaussian mixture with the assignment enumerated (TraceEnum_ELBO's other plated pattern beside
+    LDA): z_n ~ Categorical(w) summed out, x_n ~ Normal(loc[z_n], 1).  leaf=True: the likelihood never exists as a
+    [K, N] tensor (csrc/mixture.hip); False: materialised once and eliminated by pa_logsumexp_terms (round 3)."""
+    import pyro_amd.distributions as dist
+    import pyro_amd.ops.contract as contract
+    from pyro_amd.infer import config_enumerate
+    from torch.distributions import constraints
+    g = torch.Generator().manual_seed(0)
+    data = (torch.randn(N, generator=g) + 3 * torch.randint(0, K, (N,), generator=g).float()).to(dev)
+
+    @config_enumerate
+    def model(data):
+        w = pyro.sample("w", dist.Dirichlet(torch.ones(K, device=dev)))
+        with pyro.plate("k", K):
+            loc = pyro.sample("loc", dist.Normal(torch.zeros((), device=dev), 20.0))
+        with pyro.plate("n", N):
+            z = pyro.sample("z", dist.Categorical(w))
+            pyro.sample("x", dist.Normal(loc[z], 1.0), obs=data)
+
+    def guide(data):
+        wq = pyro.param("wq", torch.ones(K, device=dev), constraint=constraints.positive)
+        lq = pyro.param("lq", 3.0 * torch.arange(K, device=dev, dtype=torch.float32))
+        pyro.sample("w", dist.Dirichlet(wq))
+        with pyro.plate("k", K):
+            pyro.sample("loc", dist.Normal(lq, 0.5))
+
+    pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
+    prev = contract.FUSED_MIXTURE
+    contract.FUSED_MIXTURE = bool(leaf)
+    try:
+        svi = SVI(model, guide, pyro.optim.Adam({"lr": 0.01}), TraceEnum_ELBO(max_plate_nesting=1),
+                  hip_graph=True, graph_warmup=3)
+        dt = timed(lambda: svi.step(data), steps, 20)
+        graphed = bool(svi.hip_graph and len(svi._graphs) == 1)
+        last = svi.step(data)
+        svi.release()
+    finally:
+        contract.FUSED_MIXTURE = prev
+    return {"steps_per_s": 1 / dt, "ms_per_step": dt * 1e3, "graphed": graphed, "last_loss": last,
+            "mixture_leaf_kernel": bool(leaf), "rows_per_s": N / dt}
+
+
 def config4(dev, docs=100_000, steps=10, batch_size=None):
     """batch_size=None: every document in every step (BASELINE configs[3] as quoted); 32 / 4096: the
     mini-batch variants SURVEY 8(d) lists (examples/lda.py's own default is 32): the sub-sampled
