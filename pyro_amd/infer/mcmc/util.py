@@ -145,7 +145,8 @@ def enum_log_joint(trace, nplates, C=None):
     """log of the joint density of ``trace`` with every enumerated site summed out: one value per
     chain (``C`` given; the chain plate is the outermost of the ``nplates`` plate dims) or a scalar.
     As in the reference every factor enters scaled and masked (trace_struct.py:248-288)."""
-    from ...ops.contract import contract_tensor_tree, pack
+    from ...ops.contract import Term, contract_tensor_tree, pack
+    from ..traceenum_elbo import _lazy_family
 
     terms, enum_ids = [], set()
     for name, site in trace.nodes.items():
@@ -154,6 +155,14 @@ def enum_log_joint(trace, nplates, C=None):
         mask = site["mask"]
         if mask is False:
             continue
+        if C is None and site["is_observed"] and not isinstance(site["scale"], torch.Tensor) \
+                and float(site["scale"]) == 1.0:
+            # a plated mixture's likelihood (one chain): kept lazy for the leaf kernel (csrc/mixture.hip)
+            lazy = _lazy_family(site, -1 - nplates)
+            if lazy is not None:
+                ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
+                terms.append(Term(None, (lazy[0],), ordinal, lazy=lazy[1]))
+                continue
         lp = scale_and_mask(site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"]),
                             site["scale"], None if mask is True else mask)
         ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
@@ -175,7 +184,7 @@ def enum_log_joint(trace, nplates, C=None):
         if term.dims & enum_ids:
             factors.setdefault(term.ordinal, []).append(term)
         else:
-            total = total + reduce(term.tensor)
+            total = total + reduce(term.dense())
     if factors:
         for out in contract_tensor_tree(factors, enum_ids).values():
             for term in out:

@@ -514,6 +514,15 @@ def run_enum_potential_vs_reference(device, dtype=torch.float64, rtol=1e-9):
                         np.testing.assert_allclose(gr[k].cpu().numpy(), ref, rtol=rtol * 100,
                                                    atol=rtol * 100 * float(np.abs(ref).max() + 1e-300))
             else:
+                from pyro_amd import kernels
+                calls, real = [], kernels.mixture_fwd_bwd
+                kernels.mixture_fwd_bwd = lambda *a: calls.append(1) or real(*a)
+                try:
+                    pot({n: v for n, v in point(0).items()})
+                finally:
+                    kernels.mixture_fwd_bwd = real
+                # (one chain of the Gaussian mixture: the likelihood goes through the mixture leaf kernel)
+                assert len(calls) == (1 if tag == "gmm" else 0), (tag, len(calls))
                 for k in range(3):
                     z = {n: v.requires_grad_(True) for n, v in point(k).items()}
                     pe = pot(z)
