@@ -146,7 +146,7 @@ def enum_log_joint(trace, nplates, C=None):
     chain (``C`` given; the chain plate is the outermost of the ``nplates`` plate dims) or a scalar.
     As in the reference every factor enters scaled and masked (trace_struct.py:248-288)."""
     from ...ops.contract import Term, contract_tensor_tree, pack
-    from ..traceenum_elbo import _lazy_family
+    from ..traceenum_elbo import _enum_log_prob, _lazy_family
 
     terms, enum_ids = [], set()
     for name, site in trace.nodes.items():
@@ -163,8 +163,14 @@ def enum_log_joint(trace, nplates, C=None):
                 ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
                 terms.append(Term(None, (lazy[0],), ordinal, lazy=lazy[1]))
                 continue
-        lp = scale_and_mask(site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"]),
-                            site["scale"], None if mask is True else mask)
+        if C is None and site["infer"].get("_enumerate_dim") is not None and (mask is None or mask is True) \
+                and not isinstance(site["scale"], torch.Tensor) and float(site["scale"]) == 1.0:
+            # an enumerated site at its own support (one chain): the un-expanded table, constant along the plate
+            # (the plate product multiplies it by the plate's size), not a gather out of its plate-expanded copy
+            lp = _enum_log_prob(site)
+        else:
+            lp = scale_and_mask(site["fn"].log_prob(site["value"], *site["args"], **site["kwargs"]),
+                                site["scale"], None if mask is True else mask)
         ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
         terms.append(pack(lp, site["infer"].get("_dim_to_id", {}), nplates, ordinal))
         edim = site["infer"].get("_enumerate_dim")
@@ -186,7 +192,8 @@ def enum_log_joint(trace, nplates, C=None):
         else:
             total = total + reduce(term.dense())
     if factors:
-        for out in contract_tensor_tree(factors, enum_ids).values():
+        # (one chain: every factor is summed completely below, so a leaf kernel may cover its plates too)
+        for out in contract_tensor_tree(factors, enum_ids, reduce_all=C is None).values():
             for term in out:
                 total = total + reduce(term.tensor)
     return total

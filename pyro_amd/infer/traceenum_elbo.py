@@ -123,7 +123,7 @@ def _lazy_family(site, first_enum_dim):
     per k) for the mixture leaf kernel (ops/contract.py::_try_fused_mixture).  -> (enum id, LazyFamily) or None."""
     from ..ops import contract
     fn, value = site["fn"], site["value"]
-    if not contract.FUSED_MIXTURE or not site["is_observed"] or site["mask"] is not None:
+    if not contract.FUSED_MIXTURE or not site["is_observed"] or not (site["mask"] is None or site["mask"] is True):
         return None
     if not isinstance(value, torch.Tensor) or value.dim() != 1 or value.requires_grad \
             or value.dtype not in (torch.float32, torch.float64) or not kernels.on_device(value):
