@@ -132,6 +132,23 @@ __device__ __forceinline__ void split_pair_f16(float a, float b, uint32_t& p1, u
   asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p1), "v"(b));
   p2 = r;
 }
+// The gradient operand g = sigmoid(l) - y of GEMM2.  PA_GLMH_ABL_G1 (tools/probes/glm_planes16_probe.hip ONLY: a
+// timing ablation of the precision contract, never built into the library): ONE f16 piece of g -- 2^-11 relative per
+// element instead of 2^-22 -- drops the 2 x v_fma_mix per pair and the (g lo, X hi) product of every K half.
+__device__ __forceinline__ void split_pair_g(float a, float b, uint32_t& p1, uint32_t& p2) {
+#ifdef PA_GLMH_ABL_G1
+  const f32x2v v = {a, b};
+  p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2v));
+  p2 = 0u;
+#else
+  split_pair_f16(a, b, p1, p2);
+#endif
+}
+#ifdef PA_GLMH_ABL_G1
+#define GLMH_G_PIECE(t) (TA[t] == 0)
+#else
+#define GLMH_G_PIECE(t) true
+#endif
 __device__ __forceinline__ float f16_lo(uint32_t p) {
   return (float)__builtin_bit_cast(f16x2v, p)[0];
 }
@@ -737,8 +754,8 @@ __global__ __launch_bounds__(64 * NRT_ * NPT_, OCC) void glm_planes_f16_kernel(
       if (t == 0) {
         elem2(acc_cur[6], acc_cur[7], yv[6], yv[7], 1, g[6], g[7]);
       } else {
-        split_pair_f16(g[4 * (t - 1)], g[4 * (t - 1) + 1], g1[2 * (t - 1)], g2[2 * (t - 1)]);
-        split_pair_f16(g[4 * (t - 1) + 2], g[4 * (t - 1) + 3], g1[2 * (t - 1) + 1], g2[2 * (t - 1) + 1]);
+        split_pair_g(g[4 * (t - 1)], g[4 * (t - 1) + 1], g1[2 * (t - 1)], g2[2 * (t - 1)]);
+        split_pair_g(g[4 * (t - 1) + 2], g[4 * (t - 1) + 3], g1[2 * (t - 1) + 1], g2[2 * (t - 1) + 1]);
       }
       GLMH_SB();
     }
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(64 * NRT_ * NPT_, OCC) void glm_planes_f16_kernel(
       load_y(ysc, 1, yv);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
+        if (GLMH_G_PIECE(t)) gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
         // (pairs 0, 1 | 2 | 3 of the K half beside the three MFMAs)
         const int q0 = t == 0 ? 0 : t + 1, q1 = t == 0 ? 2 : t + 2;
 #pragma unroll
@@ -762,7 +779,7 @@ __global__ __launch_bounds__(64 * NRT_ * NPT_, OCC) void glm_planes_f16_kernel(
     }
     uint32_t h1[4], h2[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split_pair_f16(g[2 * j], g[2 * j + 1], h1[j], h2[j]);
+    for (int j = 0; j < 4; ++j) split_pair_g(g[2 * j], g[2 * j + 1], h1[j], h2[j]);
     tr_wait(xlo, xhi, xb);
     // -- GEMM2(it, K half 1)
     {
@@ -773,7 +790,7 @@ __global__ __launch_bounds__(64 * NRT_ * NPT_, OCC) void glm_planes_f16_kernel(
 #else
 #pragma unroll
       for (int t = 0; t < 3; ++t)
-        gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
+        if (GLMH_G_PIECE(t)) gwacc = GLMH_MFMA2(ga[TA[t]], xb[TB[t]], gwacc);
 #endif
     }
     st += grid;
