@@ -1049,14 +1049,18 @@ int pa_rtc_launch(void* function, uint32_t grid, uint32_t block, const void* con
  * Replaces, for the leaf of a plated mixture under TraceEnum_ELBO (pyro/infer/traceenum_elbo.py:112-214): the
  * observed site's [K, N] log_prob (pyro/poutine/trace_struct.py:248-288), the sum-product's add + logsumexp over the
  * enumerated variable and the plate sum (pyro/ops/contract.py:79-160), and the autograd duals of all three.
- *   S = sum_n log sum_k exp(a[k] + log p(x[n] | p0[k * p0_stride], p1[k * p1_stride]))     (family `dist`, K <= 64)
- * out[0] = S, out[1 + k] = dS/da_k, out[1 + K + k] = dS/dp0_k, out[1 + 2 K + k] = dS/dp1_k (doubles, device memory,
- * 1 + 3 K of them; the parameter gradients are per k -- a parameter shared by all k (stride 0) takes their sum).
- * x, a, p0, p1 are `dtype` (PA_F32 / PA_F64); p1 = NULL for one-parameter families.  Families: Normal, LogNormal,
- * Exponential, Bernoulli(logits), Poisson, Gamma.  Workspace: pa_mixture_workspace(K) bytes.  Bit-reproducible. */
-size_t pa_mixture_workspace(int K);
-int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, const void* a, const void* p0,
-                       int64_t p0_stride, const void* p1, int64_t p1_stride, void* workspace,
+ *   S[b] = sum_n log sum_k exp(a[b][k] + log p(x[n] | p0[b][k], p1[b][k]))       (family `dist`, K <= 64, b < B)
+ * for B parameter sets over the SAME data (B = 1: one model evaluation; B = the vectorised chains of HMC / NUTS or
+ * the vectorised particles of an ELBO).  a[b][k] = a[b * a_batch_stride + k]; p0[b][k] = p0[b * p0_batch_stride +
+ * k * p0_stride] (stride 0: shared by the components / by the sets), p1 likewise or NULL for one-parameter families.
+ * out[b * (1 + 3 K) + ...]: [0] = S, [1 + k] = dS/da_k, [1 + K + k] = dS/dp0_k, [1 + 2 K + k] = dS/dp1_k (doubles in
+ * device memory; parameter gradients per (b, k) -- a shared parameter takes their sum).  x, a, p0, p1 are `dtype`
+ * (PA_F32 / PA_F64).  Families: Normal, LogNormal, Exponential, Bernoulli(logits), Poisson, Gamma.  Workspace:
+ * pa_mixture_workspace(K, B) bytes.  Bit-reproducible. */
+size_t pa_mixture_workspace(int K, int64_t B);
+int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, int64_t B, const void* a,
+                       int64_t a_batch_stride, const void* p0, int64_t p0_stride, int64_t p0_batch_stride,
+                       const void* p1, int64_t p1_stride, int64_t p1_batch_stride, void* workspace,
                        size_t workspace_bytes, double* out, pa_stream_t stream);
 
 /* ---- csrc/replay.hip: a captured step that is a short chain of kernels, launched as kernels ----------------

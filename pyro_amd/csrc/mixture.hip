@@ -54,7 +54,13 @@ __global__ __launch_bounds__(MIX_THREADS) void mixture_kernel(const T* __restric
                                                               const T* __restrict__ a,
                                                               const T* __restrict__ p0, int64_t s0,
                                                               const T* __restrict__ p1, int64_t s1,
+                                                              int64_t a_bs, int64_t p0_bs, int64_t p1_bs,
                                                               double* __restrict__ partial) {
+  // blockIdx.y: one of B parameter sets over the SAME data (vectorised chains / particles: a chain's weights and
+  // component parameters against the shared observations)
+  a += (int64_t)blockIdx.y * a_bs;
+  p0 += (int64_t)blockIdx.y * p0_bs;
+  if (p1 != nullptr) p1 += (int64_t)blockIdx.y * p1_bs;
   constexpr int RPW = 64 / KP;                     // rows per wave and iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane & (KP - 1), slot = lane / KP;
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(MIX_THREADS) void mixture_kernel(const T* __restric
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < MIX_THREADS / 64; ++w) v += red[w][q][kk];
-    partial[(int64_t)blockIdx.x * J + j] = v;
+    partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * J + j] = v;
   }
 }
 
@@ -136,6 +142,8 @@ __global__ __launch_bounds__(1024) void mixture_finalize_kernel(const double* __
   const int jj = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int J = 1 + 3 * KP;
   const int j = blockIdx.x * 64 + jj;
+  partial += (int64_t)blockIdx.y * nblocks * J;
+  out += (int64_t)blockIdx.y * (1 + 3 * K);
   double v = 0.0;
   if (j < J) {
     const int per = (nblocks + 15) / 16;
@@ -166,73 +174,85 @@ __global__ __launch_bounds__(1024) void mixture_finalize_kernel(const double* __
   }
 }
 
-static int mixture_grid(int64_t N, int KP) {
+static int mixture_grid(int64_t N, int KP, int64_t B) {
   const int64_t rows_per_block = (int64_t)(MIX_THREADS / 64) * (64 / KP);
   int64_t g = (N + rows_per_block * 8 - 1) / (rows_per_block * 8);       // >= 8 iterations per wave
-  const int64_t cap = (int64_t)cu_count() * 4;       // four waves per SIMD; 1024 partials for the second launch
+  // four waves per SIMD over all parameter sets; 1024 partials for the second launch
+  int64_t cap = ((int64_t)cu_count() * 4 + B - 1) / B;
+  if (cap < 1) cap = 1;
   if (g > cap) g = cap;
   return (int)(g < 1 ? 1 : g);
 }
 
 template <int DIST, typename T>
-static int mixture_launch(const T* x, int64_t N, int K, const T* a, const T* p0, int64_t s0, const T* p1,
-                          int64_t s1, double* partial, double* out, hipStream_t s) {
+static int mixture_launch(const T* x, int64_t N, int K, int64_t B, const T* a, const T* p0, int64_t s0,
+                          const T* p1, int64_t s1, int64_t a_bs, int64_t p0_bs, int64_t p1_bs, double* partial,
+                          double* out, hipStream_t s) {
   int KP = 1;
   while (KP < K) KP <<= 1;
-  const int grid = mixture_grid(N, KP);
+  const int grid = mixture_grid(N, KP, B);
 #define PA_MIX_CASE(KP_)                                                                               \
   if (KP == KP_)                                                                                       \
-    hipLaunchKernelGGL((mixture_kernel<DIST, T, KP_>), dim3((unsigned)grid), dim3(MIX_THREADS), 0, s,  \
-                       x, N, K, a, p0, s0, p1, s1, partial);
+    hipLaunchKernelGGL((mixture_kernel<DIST, T, KP_>), dim3((unsigned)grid, (unsigned)B),              \
+                       dim3(MIX_THREADS), 0, s, x, N, K, a, p0, s0, p1, s1, a_bs, p0_bs, p1_bs, partial);
   PA_MIX_CASE(1) PA_MIX_CASE(2) PA_MIX_CASE(4) PA_MIX_CASE(8) PA_MIX_CASE(16) PA_MIX_CASE(32) PA_MIX_CASE(64)
 #undef PA_MIX_CASE
   const int J = 1 + 3 * KP;
-  hipLaunchKernelGGL(mixture_finalize_kernel, dim3((unsigned)((J + 63) / 64)), dim3(1024), 0, s, partial, grid,
-                     K, KP, out);
+  hipLaunchKernelGGL(mixture_finalize_kernel, dim3((unsigned)((J + 63) / 64), (unsigned)B), dim3(1024), 0, s,
+                     partial, grid, K, KP, out);
   return check_launch("mixture_kernel");
 }
 
 template <typename T>
-static int mixture_t(int dist, const T* x, int64_t N, int K, const T* a, const T* p0, int64_t s0, const T* p1,
-                     int64_t s1, double* partial, double* out, hipStream_t s) {
+static int mixture_t(int dist, const T* x, int64_t N, int K, int64_t B, const T* a, const T* p0, int64_t s0,
+                     const T* p1, int64_t s1, int64_t a_bs, int64_t p0_bs, int64_t p1_bs, double* partial,
+                     double* out, hipStream_t s) {
+#define PA_MIX_FAM(ID)                                                                                 \
+  case ID: return mixture_launch<ID, T>(x, N, K, B, a, p0, s0, p1, s1, a_bs, p0_bs, p1_bs, partial, out, s);
   switch (dist) {
-    case PA_DIST_NORMAL: return mixture_launch<PA_DIST_NORMAL, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
-    case PA_DIST_LOG_NORMAL: return mixture_launch<PA_DIST_LOG_NORMAL, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
-    case PA_DIST_EXPONENTIAL: return mixture_launch<PA_DIST_EXPONENTIAL, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
-    case PA_DIST_BERNOULLI_LOGITS:
-      return mixture_launch<PA_DIST_BERNOULLI_LOGITS, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
-    case PA_DIST_POISSON: return mixture_launch<PA_DIST_POISSON, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
-    case PA_DIST_GAMMA: return mixture_launch<PA_DIST_GAMMA, T>(x, N, K, a, p0, s0, p1, s1, partial, out, s);
+    PA_MIX_FAM(PA_DIST_NORMAL)
+    PA_MIX_FAM(PA_DIST_LOG_NORMAL)
+    PA_MIX_FAM(PA_DIST_EXPONENTIAL)
+    PA_MIX_FAM(PA_DIST_BERNOULLI_LOGITS)
+    PA_MIX_FAM(PA_DIST_POISSON)
+    PA_MIX_FAM(PA_DIST_GAMMA)
     default: return fail(PA_ERR_UNSUPPORTED, "mixture_fwd_bwd: distribution id %d not implemented", dist);
   }
+#undef PA_MIX_FAM
 }
 
 }  // namespace pa
 
 extern "C" {
 
-size_t pa_mixture_workspace(int K) {
-  if (K < 1 || K > pa::MIX_MAXK) return 0;
+size_t pa_mixture_workspace(int K, int64_t B) {
+  if (K < 1 || K > pa::MIX_MAXK || B < 1) return 0;
   int KP = 1;
   while (KP < K) KP <<= 1;
-  return (size_t)pa::cu_count() * 8 * (1 + 3 * KP) * sizeof(double);
+  // (at most cu_count * 4 + B workgroups over all parameter sets)
+  return ((size_t)pa::cu_count() * 4 + (size_t)B) * (1 + 3 * KP) * sizeof(double);
 }
 
-int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, const void* a, const void* p0,
-                       int64_t p0_stride, const void* p1, int64_t p1_stride, void* workspace,
+int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, int64_t B, const void* a,
+                       int64_t a_batch_stride, const void* p0, int64_t p0_stride, int64_t p0_batch_stride,
+                       const void* p1, int64_t p1_stride, int64_t p1_batch_stride, void* workspace,
                        size_t workspace_bytes, double* out, pa_stream_t stream) {
   PA_REQUIRE(K >= 1 && K <= pa::MIX_MAXK, "mixture_fwd_bwd: K=%d outside [1, %d]", K, pa::MIX_MAXK);
+  PA_REQUIRE(B >= 1 && B <= 65535, "mixture_fwd_bwd: B=%lld outside [1, 65535]", (long long)B);
   PA_REQUIRE(N >= 1 && x && a && p0 && out && workspace, "mixture_fwd_bwd: NULL pointer or N < 1");
-  PA_REQUIRE(p0_stride >= 0 && p1_stride >= 0, "mixture_fwd_bwd: negative parameter stride");
-  PA_REQUIRE(workspace_bytes >= pa_mixture_workspace(K), "mixture_fwd_bwd: workspace too small");
+  PA_REQUIRE(p0_stride >= 0 && p1_stride >= 0 && a_batch_stride >= 0 && p0_batch_stride >= 0 &&
+                 p1_batch_stride >= 0, "mixture_fwd_bwd: negative stride");
+  PA_REQUIRE(workspace_bytes >= pa_mixture_workspace(K, B), "mixture_fwd_bwd: workspace too small");
   PA_REQUIRE(pa::dist_nparams(dist) == 1 || p1 != nullptr, "mixture_fwd_bwd: the family takes two parameters");
   hipStream_t s = pa::as_stream(stream);
   if (dtype == PA_F32)
-    return pa::mixture_t<float>(dist, (const float*)x, N, K, (const float*)a, (const float*)p0, p0_stride,
-                                (const float*)p1, p1_stride, (double*)workspace, out, s);
+    return pa::mixture_t<float>(dist, (const float*)x, N, K, B, (const float*)a, (const float*)p0, p0_stride,
+                                (const float*)p1, p1_stride, a_batch_stride, p0_batch_stride, p1_batch_stride,
+                                (double*)workspace, out, s);
   if (dtype == PA_F64)
-    return pa::mixture_t<double>(dist, (const double*)x, N, K, (const double*)a, (const double*)p0, p0_stride,
-                                 (const double*)p1, p1_stride, (double*)workspace, out, s);
+    return pa::mixture_t<double>(dist, (const double*)x, N, K, B, (const double*)a, (const double*)p0, p0_stride,
+                                 (const double*)p1, p1_stride, a_batch_stride, p0_batch_stride, p1_batch_stride,
+                                 (double*)workspace, out, s);
   return pa::fail(PA_ERR_UNSUPPORTED, "mixture_fwd_bwd: dtype %d", dtype);
 }
 

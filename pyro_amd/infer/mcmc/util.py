@@ -155,17 +155,18 @@ def enum_log_joint(trace, nplates, C=None):
         mask = site["mask"]
         if mask is False:
             continue
-        if C is None and site["is_observed"] and not isinstance(site["scale"], torch.Tensor) \
+        if site["is_observed"] and not isinstance(site["scale"], torch.Tensor) \
                 and float(site["scale"]) == 1.0:
-            # a plated mixture's likelihood (one chain): kept lazy for the leaf kernel (csrc/mixture.hip)
+            # a plated mixture's likelihood: kept lazy for the leaf kernel (csrc/mixture.hip; with vectorised
+            # chains the chain plate is the kernel's batch of parameter sets over the shared data)
             lazy = _lazy_family(site, -1 - nplates)
             if lazy is not None:
                 ordinal = frozenset(f for f in site["cond_indep_stack"] if f.vectorized)
                 terms.append(Term(None, (lazy[0],), ordinal, lazy=lazy[1]))
                 continue
-        if C is None and site["infer"].get("_enumerate_dim") is not None and (mask is None or mask is True) \
+        if site["infer"].get("_enumerate_dim") is not None and (mask is None or mask is True) \
                 and not isinstance(site["scale"], torch.Tensor) and float(site["scale"]) == 1.0:
-            # an enumerated site at its own support (one chain): the un-expanded table, constant along the plate
+            # an enumerated site at its own support: the un-expanded table, constant along the data plate
             # (the plate product multiplies it by the plate's size), not a gather out of its plate-expanded copy
             lp = _enum_log_prob(site)
         else:
@@ -192,8 +193,9 @@ def enum_log_joint(trace, nplates, C=None):
         else:
             total = total + reduce(term.dense())
     if factors:
-        # (one chain: every factor is summed completely below, so a leaf kernel may cover its plates too)
-        for out in contract_tensor_tree(factors, enum_ids, reduce_all=C is None).values():
+        # (every factor is summed over all its plates but the chain plate below: a leaf kernel may cover them)
+        for out in contract_tensor_tree(factors, enum_ids, reduce_all=True,
+                                        keep_dims=() if C is None else (-nplates,)).values():
             for term in out:
                 total = total + reduce(term.tensor)
     return total

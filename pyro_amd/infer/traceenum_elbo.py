@@ -118,9 +118,10 @@ def _lazy_gather(site, first_enum_dim):
 
 
 def _lazy_family(site, first_enum_dim):
-    """An observed element-wise site under ONE plate (dim -1) whose parameters were indexed by ONE enumerated
-    value -- ``Normal(locs[z], scale)`` with float data [N]: keep the [K, N] factor as (family, data, parameters
-    per k) for the mixture leaf kernel (ops/contract.py::_try_fused_mixture).  -> (enum id, LazyFamily) or None."""
+    """An observed element-wise site under the data plate (dim -1) -- and at most one outer plate (vectorised
+    chains / particles) -- whose parameters were indexed by ONE enumerated value: ``Normal(locs[z], scale)`` with
+    float data [N].  Keep the [K, (B,) N] factor as (family, data, parameters per k and b) for the mixture leaf
+    kernel (ops/contract.py::_try_fused_mixture).  -> (enum id, LazyFamily) or None."""
     from ..ops import contract
     fn, value = site["fn"], site["value"]
     if not contract.FUSED_MIXTURE or not site["is_observed"] or not (site["mask"] is None or site["mask"] is True):
@@ -128,20 +129,28 @@ def _lazy_family(site, first_enum_dim):
     if not isinstance(value, torch.Tensor) or value.dim() != 1 or value.requires_grad \
             or value.dtype not in (torch.float32, torch.float64) or not kernels.on_device(value):
         return None
-    if [f.dim for f in site["cond_indep_stack"] if f.vectorized] != [-1]:
+    plate_dims = sorted(f.dim for f in site["cond_indep_stack"] if f.vectorized)
+    if not plate_dims or plate_dims[-1] != -1 or len(plate_dims) > 2:
         return None
     entry = getattr(fn, "fused_site_entry", None)
     bs = tuple(getattr(fn, "batch_shape", ()))
     if entry is None or tuple(getattr(fn, "event_shape", ())) != () or len(bs) < 2 \
             or bs[-1] not in (1, value.shape[0]):
         return None
-    nz = [i for i, s_ in enumerate(bs[:-1]) if s_ > 1]
-    if len(nz) != 1:
+    nb = len(bs)
+    batch_dim = plate_dims[0] if len(plate_dims) == 2 else None
+    if batch_dim is not None and -batch_dim > nb:
+        batch_dim = None                      # the outer plate does not reach this site's parameters
+    nz = [i for i, s_ in enumerate(bs[:-1]) if s_ > 1 and i - nb != batch_dim]
+    if len(nz) != 1 or (batch_dim is not None and nz[0] - nb > batch_dim):
         return None
-    edim = nz[0] - len(bs)
+    edim = nz[0] - nb
     if edim > first_enum_dim or edim not in site["infer"].get("_dim_to_id", {}):
         return None
     K = bs[nz[0]]
+    B = 1 if batch_dim is None else bs[batch_dim]
+    if batch_dim is not None and B == 1:
+        batch_dim = None
     ent = entry(value, 1.0, None)
     if ent is None or ent[0] not in kernels.MIXTURE_FAMILIES or K > kernels.MIXTURE_MAX_K:
         return None
@@ -152,11 +161,17 @@ def _lazy_family(site, first_enum_dim):
             continue
         if not isinstance(p, torch.Tensor) or p.dtype != value.dtype or not kernels.on_device(p):
             return None
-        shp = (1,) * (len(bs) - p.dim()) + tuple(p.shape)
-        if len(shp) != len(bs) or shp[-1] != 1 or any(s_ != 1 for i, s_ in enumerate(shp[:-1]) if i != nz[0]) \
-                or shp[nz[0]] not in (1, K):
-            return None                       # a parameter that varies along the plate: the generic path
-        params.append(p)
+        if p.dim() > nb:
+            return None
+        shp = (1,) * (nb - p.dim()) + tuple(p.shape)
+        for i, s_ in enumerate(shp):
+            d = i - nb
+            ok = s_ == 1 or (d == edim and s_ == K) or (batch_dim is not None and d == batch_dim and s_ == B)
+            if not ok:
+                return None                   # a parameter that varies along the data plate: the generic path
+        Kp = shp[nz[0]]
+        Bp = 1 if batch_dim is None else shp[batch_dim]
+        params.append(p.reshape(Kp, Bp))      # (the enumeration dim lies left of the plate dim)
     if params[0] is None:
         return None
 
@@ -164,7 +179,8 @@ def _lazy_family(site, first_enum_dim):
         lp = fn.log_prob(value, *site["args"], **site["kwargs"])
         return _packed(site, lp, first_enum_dim).tensor
 
-    return site["infer"]["_dim_to_id"][edim], contract.LazyFamily(ent[0], value, params[0], params[1], packed)
+    return site["infer"]["_dim_to_id"][edim], contract.LazyFamily(ent[0], value, K, params[0], params[1], packed,
+                                                                  batch_dim, B)
 
 
 class TraceEnum_ELBO(ELBO):

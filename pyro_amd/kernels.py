@@ -1953,22 +1953,25 @@ MIXTURE_FAMILIES = (_lib.DIST_NORMAL, _lib.DIST_LOG_NORMAL, _lib.DIST_EXPONENTIA
 MIXTURE_MAX_K = 64
 
 
-def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1):
-    """sum_n logsumexp_k(a[k] + log p(x[n] | p0[k * s0], p1[k * s1])) and its gradients from ONE pass over x
-    (pa_mixture_fwd_bwd): x [N]; a [K]; p0 / p1 flat with stride 1 (per component) or 0 (shared); p1 None for
-    one-parameter families.  -> float64 [1 + 3 K] on the device: S, dS/da, dS/dp0 (per k), dS/dp1 (per k)."""
+def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1, p0_bs=0, p1_bs=0):
+    """sum_n logsumexp_k(a[b, k] + log p(x[n] | p0[b, k], p1[b, k])) and its gradients from ONE pass over x per
+    parameter set (pa_mixture_fwd_bwd): x [N]; a [K] or [B, K]; p0 / p1 flat, addressed b * bs + k * s (stride 0:
+    shared); p1 None for one-parameter families.  -> float64 [1 + 3 K] (a [K]) or [B, 1 + 3 K] on the device:
+    S, dS/da, dS/dp0 (per k), dS/dp1 (per k)."""
     _require_gpu(x, a, p0, p1)
-    K, N = a.numel(), x.numel()
+    batched = a.dim() == 2
+    B, K, N = (a.shape[0] if batched else 1), a.shape[-1], x.numel()
     assert x.is_contiguous() and a.is_contiguous() and p0.is_contiguous() and (p1 is None or p1.is_contiguous())
     assert a.dtype == x.dtype and p0.dtype == x.dtype and (p1 is None or p1.dtype == x.dtype)
     lib = _lib.load()
-    nbytes = lib.pa_mixture_workspace(K)
+    nbytes = lib.pa_mixture_workspace(K, B)
     if nbytes == 0:
         raise Unsupported("pyro_amd: mixture_fwd_bwd needs 1 <= K <= %d (K=%d)" % (MIXTURE_MAX_K, K))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-    out = torch.empty((1 + 3 * K,), dtype=torch.float64, device=x.device)
-    check(lib.pa_mixture_fwd_bwd(_dtype(x), int(dist_id), _ptr(x), N, K, _ptr(a), _ptr(p0), int(s0), _ptr(p1),
-                                 int(s1), _ptr(ws), ws.numel(), _ptr(out), _stream()))
+    out = torch.empty((B, 1 + 3 * K) if batched else (1 + 3 * K,), dtype=torch.float64, device=x.device)
+    check(lib.pa_mixture_fwd_bwd(_dtype(x), int(dist_id), _ptr(x), N, K, B, _ptr(a), K, _ptr(p0), int(s0),
+                                 int(p0_bs), _ptr(p1), int(s1), int(p1_bs), _ptr(ws), ws.numel(), _ptr(out),
+                                 _stream()))
     return out
 
 

@@ -98,13 +98,17 @@ class LazyGather:
 
 
 class LazyFamily:
-    """log-factor f[k, n] = log p(x[n] | p0[k], p1[k]) of an OBSERVED element-wise site whose parameters were
-    indexed by an enumerated value (``Normal(locs[z], scale)`` under ``plate(n)``: a plated mixture's likelihood),
-    kept un-materialised: the leaf kernel evaluates it in registers (csrc/mixture.hip).  ``packed``: a callable
-    that makes the packed [K, N] tensor the generic elimination needs when the pattern does not match."""
+    """log-factor f[k, (b), n] = log p(x[n] | p0[k, b], p1[k, b]) of an OBSERVED element-wise site whose parameters
+    were indexed by an enumerated value (``Normal(locs[z], scale)`` under ``plate(n)``: a plated mixture's
+    likelihood), kept un-materialised: the leaf kernel evaluates it in registers (csrc/mixture.hip).  ``b``: an
+    optional outer plate the parameters vary over (vectorised chains / particles).  ``p0`` / ``p1``: [K or 1,
+    B or 1] views of the parameters; ``batch_dim``: the outer plate's tensor dim (negative) or None, ``B`` its size.
+    ``packed``: a callable that makes the packed tensor the generic elimination needs when the pattern does not
+    match."""
 
-    def __init__(self, dist_id, value, p0, p1, packed):
-        self.dist_id, self.value, self.p0, self.p1, self._packed = dist_id, value, p0, p1, packed
+    def __init__(self, dist_id, value, K, p0, p1, packed, batch_dim=None, B=1):
+        self.dist_id, self.value, self.K, self.p0, self.p1, self._packed = dist_id, value, K, p0, p1, packed
+        self.batch_dim, self.B = batch_dim, B
 
     def materialize(self):
         return self._packed()
@@ -115,32 +119,42 @@ FUSED_MIXTURE = True          # the mixture leaf goes through pa_mixture_fwd_bwd
 
 @_dispatcher_op("mixture_factor")
 class _MixtureFactor(torch.autograd.Function):
-    """sum_n logsumexp_k(a[k] + log p(x[n] | p0[k], p1[k])) with its gradient from the same pass
-    (pa_mixture_fwd_bwd): nothing of size K N is written."""
+    """S[b] = sum_n logsumexp_k(a[b, k] + log p(x[n] | p0[b, k], p1[b, k])) with its gradient from the same pass
+    (pa_mixture_fwd_bwd): nothing of size K N is written.  a: [B, K]; p0 / p1: flat, addressed b * bs + k * s."""
 
     @staticmethod
-    def forward(ctx, dist_id, s0, s1, x, a, p0, p1):
-        out = kernels.mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1)
-        K = a.numel()
-        g = out[1:].to(a.dtype)
-        ctx.shared = (s0 == 0, s1 == 0)
-        ctx.save_for_backward(g[:K], g[K:2 * K], g[2 * K:])
-        return out[0].to(a.dtype)
+    def forward(ctx, dist_id, s0, s1, bs0, bs1, x, a, p0, p1):
+        out = kernels.mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1, bs0, bs1)      # [B, 1 + 3 K]
+        K = a.shape[-1]
+        g = out[:, 1:].to(a.dtype)
+        ctx.strides = (s0, s1, bs0, bs1)
+        ctx.save_for_backward(g[:, :K], g[:, K:2 * K], g[:, 2 * K:])
+        return out[:, 0].to(a.dtype)
 
     @staticmethod
     def backward(ctx, g):
         da, d0, d1 = ctx.saved_tensors
-        if ctx.shared[0]:
-            d0 = d0.sum().reshape(1)
-        if ctx.shared[1]:
-            d1 = d1.sum().reshape(1)
-        return None, None, None, None, g * da, g * d0, (g * d1 if ctx.needs_input_grad[6] else None)
+        s0, s1, bs0, bs1 = ctx.strides
+        g = g.reshape(-1, 1)
+
+        def param_grad(d, s_, bs):
+            d = g * d                                   # [B, K]
+            if s_ == 0:
+                d = d.sum(1, keepdim=True)
+            if bs == 0:
+                d = d.sum(0, keepdim=True)
+            return d.reshape(-1)
+
+        return (None, None, None, None, None, None, g * da, param_grad(d0, s0, bs0),
+                param_grad(d1, s1, bs1) if ctx.needs_input_grad[8] else None)
 
 
 def _try_fused_mixture(terms, sum_ids, contract_frames):
-    """The mixture leaf: one enumerated name k, ONE lazy observed-family term over (k, n), every other term a
-    function of k alone (constant along the plate), and the plate n is contracted here.  Returns a 0-dim tensor
-    or None when the pattern does not match."""
+    """The mixture leaf: one enumerated name k, ONE lazy observed-family term over (k, [b,] n), every other term a
+    function of k (and b) alone -- constant along the data plate --, and the data plate n (dim -1) is contracted
+    here; an outer plate b the parameters vary over (vectorised chains / particles) stays, or is summed too when the
+    caller contracts it here as well.  Returns a tensor (0-dim, or the plate block with n summed) or None when the
+    pattern does not match."""
     if not FUSED_MIXTURE or len(sum_ids) != 1 or len(terms) < 1:
         return None
     lazy = [t for t in terms if t.tensor is None and isinstance(t.lazy, LazyFamily)]
@@ -149,41 +163,54 @@ def _try_fused_mixture(terms, sum_ids, contract_frames):
         return None
     (kid,) = sum_ids
     lz = lazy[0].lazy
-    if lazy[0].ids != (kid,) or {f.dim for f in contract_frames} != {-1} \
-            or {f.dim for f in lazy[0].ordinal} != {-1}:
+    plates = {f.dim for f in lazy[0].ordinal}
+    frames = {f.dim for f in contract_frames}
+    want = {-1} if lz.batch_dim is None else {-1, lz.batch_dim}
+    if lazy[0].ids != (kid,) or plates != want or -1 not in frames or not frames <= plates:
         return None
-    x = lz.value
-    K = None
+    x, K, B = lz.value, lz.K, lz.B
+    if K > kernels.MIXTURE_MAX_K or K < 1 or B > 65535:
+        return None
+    nplates = None
     a = None
     for t in dense:
         if t.ids != (kid,) or not isinstance(t.tensor, torch.Tensor) or t.tensor.dtype != x.dtype \
-                or not kernels.on_device(t.tensor):
+                or not kernels.on_device(t.tensor) or t.tensor.shape[0] != K:
             return None
-        k_t = t.tensor.shape[0]
-        if t.tensor.numel() != k_t or (K is not None and k_t != K):
-            return None                     # depends on the plate too (per-row weights): generic path
-        K = k_t
-        a = t.tensor.reshape(K) if a is None else a + t.tensor.reshape(K)
-    if K is None:                            # no assignment probabilities here (they sit higher up the tree)
-        K = max(lz.p0.numel(), 1 if lz.p1 is None else lz.p1.numel())
-        a = x.new_zeros(K)
-    if K > kernels.MIXTURE_MAX_K or K < 1:
-        return None
+        blk = tuple(t.tensor.shape[1:])                # the plate block, right-aligned
+        if nplates is None:
+            nplates = len(blk)
+        big = [i - len(blk) for i, s_ in enumerate(blk) if s_ > 1]
+        if big and (big != [lz.batch_dim] or blk[lz.batch_dim] != B):
+            return None                                # varies along the data plate (per-row weights) or elsewhere
+        tk = t.tensor.reshape(K, -1).t()               # [B or 1, K]
+        a = tk if a is None else a + tk
+    if a is None:                                      # no assignment probabilities here
+        a = x.new_zeros((1, K))
+    a = a.expand(B, K).contiguous()
 
     def flat(p):
+        # [Kp, Bp] view -> (flat tensor addressed b * bs + k * s, s, bs)
         if p is None:
-            return None, 0
-        if p.numel() == K and K > 1:
-            return p.reshape(K).contiguous(), 1
-        if p.numel() == 1:
-            return p.reshape(1), 0
-        return False, 0
+            return None, 0, 0
+        Kp, Bp = p.shape
+        if Kp not in (1, K) or Bp not in (1, B):
+            return False, 0, 0
+        q = p.t().contiguous().reshape(-1)             # [Bp, Kp] row-major
+        return q, (1 if Kp == K and K > 1 else 0), (Kp if Bp == B and B > 1 else 0)
 
-    p0, s0 = flat(lz.p0)
-    p1, s1 = flat(lz.p1)
+    p0, s0, bs0 = flat(lz.p0)
+    p1, s1, bs1 = flat(lz.p1)
     if p0 is False or p1 is False or p0 is None:
         return None
-    return _MixtureFactor.invoke(int(lz.dist_id), s0, s1, x.contiguous(), a.contiguous(), p0, p1)
+    S = _MixtureFactor.invoke(int(lz.dist_id), s0, s1, bs0, bs1, x.contiguous(), a, p0, p1)       # [B]
+    if lz.batch_dim is None or lz.batch_dim in frames:
+        return S.sum()                                 # every plate contracted here
+    if nplates is None:
+        nplates = -lz.batch_dim
+    shape = [1] * nplates
+    shape[lz.batch_dim] = B
+    return S.reshape(shape)
 
 
 @_dispatcher_op("lda_factor")
@@ -466,7 +493,7 @@ def _partition(terms, sum_ids):
     return components
 
 
-def _contract_component(tensor_tree, sum_ids, reduce_all=False):
+def _contract_component(tensor_tree, sum_ids, reduce_all=False, keep_dims=()):
     """Contract all ``sum_ids`` out of one connected component by message passing from the
     deepest plate context to the root (reference: contract.py:87-165 with target_dims = {})."""
     id_to_ordinal = {}
@@ -497,7 +524,9 @@ def _contract_component(tensor_tree, sum_ids, reduce_all=False):
             # at the root of the component the caller may ask for the plates to be reduced too
             # (the ELBO sums every contracted factor completely): lets the fused kernel cover
             # logsumexp AND both plate sums
-            fuse_frames = leaf if (reduce_all and parent == leaf) else contract_frames
+            # (keep_dims: plate dims the caller does NOT sum -- the chain plate of a vectorised potential)
+            fuse_frames = frozenset(f for f in leaf if f.dim not in keep_dims) \
+                if (reduce_all and parent == leaf) else contract_frames
             fused = _try_fused_lda(terms, ids, fuse_frames)
             if fused is None:
                 fused = _try_fused_mixture(terms, ids, fuse_frames)
@@ -516,10 +545,11 @@ def _contract_component(tensor_tree, sum_ids, reduce_all=False):
     return ordinal, Term(tensor, ids, ordinal)
 
 
-def contract_tensor_tree(tensor_tree, sum_ids, reduce_all=False):
+def contract_tensor_tree(tensor_tree, sum_ids, reduce_all=False, keep_dims=()):
     """{ordinal: [Term]} -> {ordinal: [Term]} with every name of ``sum_ids`` summed out; plate dims
     are contracted only as far as the message passing requires (reference: contract.py:168-210).
-    With ``reduce_all`` a factor may come back already summed over its remaining plates."""
+    With ``reduce_all`` a factor may come back already summed over its remaining plates -- except those at the
+    tensor dims ``keep_dims``."""
     assert isinstance(tensor_tree, OrderedDict)
     all_terms = [t for terms in tensor_tree.values() for t in terms]
     contracted = OrderedDict()
@@ -527,6 +557,6 @@ def contract_tensor_tree(tensor_tree, sum_ids, reduce_all=False):
         component = OrderedDict()
         for t in terms:
             component.setdefault(t.ordinal, []).append(t)
-        ordinal, term = _contract_component(component, ids, reduce_all)
+        ordinal, term = _contract_component(component, ids, reduce_all, keep_dims)
         contracted.setdefault(ordinal, []).append(term)
     return contracted

@@ -504,7 +504,17 @@ def run_enum_potential_vs_reference(device, dtype=torch.float64, rtol=1e-9):
             if batch_safe:
                 z = {n: torch.stack([point(k)[n] for k in range(3)]).requires_grad_(True)
                      for n in names}
-                pe = pot(z)
+                from pyro_amd import kernels
+                calls, real = [], kernels.mixture_fwd_bwd
+                kernels.mixture_fwd_bwd = lambda *a: calls.append(tuple(a[2].shape)) or real(*a)
+                try:
+                    pe = pot(z)
+                finally:
+                    kernels.mixture_fwd_bwd = real
+                # (three chains of the Gaussian mixture: ONE launch of the mixture leaf kernel, the chains its batch
+                #  of parameter sets -- where the kernels serve the data's device)
+                if tag == "gmm" and kernels.on_device(data):
+                    assert calls == [(3, 3)], calls
                 assert pe.shape == (3,)
                 grads = torch.autograd.grad(pe.sum(), [z[n] for n in names])
                 for k in range(3):

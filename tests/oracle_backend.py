@@ -459,10 +459,23 @@ def lda_factor_fwd_bwd(words, log_theta, log_phi):
     return torch.as_tensor(out, dtype=dt), torch.as_tensor(gt, dtype=dt), torch.as_tensor(gp, dtype=dt)
 
 
-def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1):
+def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1, p0_bs=0, p1_bs=0):
     from oracle import mixture as o_mix
-    S, da, d0, d1 = o_mix.mixture_fwd_bwd(int(dist_id), _np(x), _np(a), _np(p0), None if p1 is None else _np(p1))
-    return torch.as_tensor(np.concatenate([[S], da, d0, d1]), dtype=torch.float64)
+    an = _np(a)
+    K = an.shape[-1]
+
+    def of(p, s_, bs, b):
+        if p is None:
+            return None
+        flat = _np(p).reshape(-1)
+        return np.array([flat[b * bs + k * s_] for k in range(K)])
+
+    rows = []
+    for b in range(an.shape[0] if an.ndim == 2 else 1):
+        S, da, d0, d1 = o_mix.mixture_fwd_bwd(int(dist_id), _np(x), an[b] if an.ndim == 2 else an,
+                                              of(p0, s0, p0_bs, b), of(p1, s1, p1_bs, b))
+        rows.append(np.concatenate([[S], da, d0, d1]))
+    return torch.as_tensor(np.stack(rows) if an.ndim == 2 else rows[0], dtype=torch.float64)
 
 
 def logsumexp_terms(terms, frame, rdim):
