@@ -380,6 +380,38 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> logchain(const at::Tensor& unary,
   return {log_z, gu, gp};
 }
 
+// the leaf of a plated mixture under TraceEnum_ELBO / the enumerated potential of HMC and NUTS: the observed site's
+// log_prob against every value of the enumerated assignment (pyro/poutine/trace_struct.py:248-288), logsumexp over it
+// (pyro/ops/contract.py:79-160) and the plate sum, forward and backward in one pass over the data, for B parameter
+// sets (vectorised particles / chains).  a [B, K]; p0, p1 [B | 1, K | 1]; -> float64 [B, 1 + 3 K]:
+// S, dS/da, dS/dp0, dS/dp1 per (b, k) (a shared parameter takes their sum)
+at::Tensor mixture_fwd_bwd(int64_t dist, const at::Tensor& x, const at::Tensor& a, const at::Tensor& p0,
+                           const std::optional<at::Tensor>& p1) {
+  const int dt = dtype_of(x, "mixture_fwd_bwd");
+  TORCH_CHECK(x.dim() == 1 && x.is_contiguous() && a.dim() == 2 && a.is_contiguous() && a.scalar_type() == x.scalar_type(),
+              "pyro_amd::mixture_fwd_bwd: x [N] contiguous, a [B, K] contiguous, one dtype");
+  const int64_t N = x.size(0), B = a.size(0), K = a.size(1);
+  auto strides = [&](const at::Tensor& p, int64_t& sk, int64_t& sb) {
+    TORCH_CHECK(p.dim() == 2 && p.is_contiguous() && p.scalar_type() == x.scalar_type() &&
+                    (p.size(0) == B || p.size(0) == 1) && (p.size(1) == K || p.size(1) == 1),
+                "pyro_amd::mixture_fwd_bwd: parameters [B | 1, K | 1] contiguous");
+    sk = p.size(1) == 1 ? 0 : 1;
+    sb = p.size(0) == 1 ? 0 : p.size(1);
+  };
+  int64_t s0 = 0, b0 = 0, s1 = 0, b1 = 0;
+  strides(p0, s0, b0);
+  if (p1.has_value()) strides(*p1, s1, b1);
+  const size_t ws_bytes = pa_mixture_workspace((int)K, B);
+  TORCH_CHECK(ws_bytes > 0, "pyro_amd::mixture_fwd_bwd: K = ", K, " outside [1, 64]");
+  at::Tensor ws = at::empty({(int64_t)ws_bytes}, x.options().dtype(at::kByte));
+  at::Tensor out = at::empty({B, 1 + 3 * K}, x.options().dtype(at::kDouble));
+  check(pa_mixture_fwd_bwd(dt, (int)dist, x.data_ptr(), N, (int)K, B, a.data_ptr(), K, p0.data_ptr(), s0, b0,
+                           p1.has_value() ? p1->data_ptr() : nullptr, s1, b1, ws.data_ptr(), ws_bytes,
+                           (double*)out.data_ptr(), current_stream()),
+        "mixture_fwd_bwd");
+  return out;
+}
+
 // the enumerated Categorical-Categorical mixture factor of examples/lda.py:53-71 under TraceEnum_ELBO with its
 // gradient, word-major half through the corpus index (pa_lda_build_index): pyro/infer/traceenum_elbo.py:112-214
 std::tuple<at::Tensor, at::Tensor, at::Tensor> lda_factor_indexed(const at::Tensor& words, const at::Tensor& index,
@@ -488,6 +520,7 @@ TORCH_LIBRARY(pyro_amd, m) {
         "(Tensor eps, Tensor z, Tensor logq)");
   m.def("logsumexp_terms(Tensor[] terms, int[] sizes, int rdim) -> Tensor");
   m.def("logchain(Tensor unary, Tensor pairwise) -> (Tensor log_z, Tensor grad_unary, Tensor grad_pairwise)");
+  m.def("mixture_fwd_bwd(int dist, Tensor x, Tensor a, Tensor p0, Tensor? p1) -> Tensor");
   m.def("lda_factor_indexed(Tensor words, Tensor index, Tensor log_theta, Tensor log_phi) -> "
         "(Tensor out_doc, Tensor g_theta, Tensor g_phi)");
   m.def("tall_linear_act(Tensor G, Tensor weight, Tensor? bias, Tensor? y_mul, bool sigmoid_out, "
@@ -514,6 +547,7 @@ TORCH_LIBRARY_IMPL(pyro_amd, CUDA, m) {
   m.impl("mvn_tril_sample", &mvn_tril_sample);
   m.impl("logsumexp_terms", &logsumexp_terms);
   m.impl("logchain", &logchain);
+  m.impl("mixture_fwd_bwd", &mixture_fwd_bwd);
   m.impl("lda_factor_indexed", &lda_factor_indexed);
   m.impl("tall_linear_act", &tall_linear_act);
   m.impl("nuts_tree_run_advance", &nuts_tree_run_advance);

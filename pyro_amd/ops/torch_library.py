@@ -119,6 +119,10 @@ def _register():
         B, T, K = unary.shape
         return unary.new_empty((B,)), torch.empty_like(unary), unary.new_empty((B, max(T - 1, 0), K, K))
 
+    @lib.register_fake("pyro_amd::mixture_fwd_bwd")
+    def _(dist, x, a, p0, p1):
+        return x.new_empty((a.shape[0], 1 + 3 * a.shape[1]), dtype=torch.float64)
+
     @lib.register_fake("pyro_amd::lda_factor_indexed")
     def _(words, index, log_theta, log_phi):
         return log_theta.new_empty((words.shape[1],)), torch.empty_like(log_theta), torch.empty_like(log_phi)
@@ -595,5 +599,5 @@ def registered_ops():
 
 # the typed C++ ops of csrc/torch_ops.cpp beside the GLM site's (round 6): real argument lists, loadable from C++
 TYPED_OPS = ("dist_log_prob_sum", "multi_log_prob_sum", "meanfield_normal_sample", "exp_site", "exp_site_bwd",
-             "mvn_tril_sample", "logsumexp_terms", "logchain", "lda_factor_indexed", "tall_linear_act",
+             "mvn_tril_sample", "logsumexp_terms", "logchain", "mixture_fwd_bwd", "lda_factor_indexed", "tall_linear_act",
              "nuts_tree_run_advance")

@@ -114,6 +114,7 @@ def test_torch_library_shim_loads_and_registers_the_schemas():
                            "(Tensor eps, Tensor z, Tensor logq)",
         "logsumexp_terms": "(Tensor[] terms, int[] sizes, int rdim) -> Tensor",
         "logchain": "(Tensor unary, Tensor pairwise) -> (Tensor log_z, Tensor grad_unary, Tensor grad_pairwise)",
+        "mixture_fwd_bwd": "(int dist, Tensor x, Tensor a, Tensor p0, Tensor? p1) -> Tensor",
         "lda_factor_indexed": "(Tensor words, Tensor index, Tensor log_theta, Tensor log_phi) -> "
                               "(Tensor out_doc, Tensor g_theta, Tensor g_phi)",
         "tall_linear_act": "(Tensor G, Tensor weight, Tensor? bias, Tensor? y_mul, bool sigmoid_out, "
@@ -133,5 +134,7 @@ def test_torch_library_shim_loads_and_registers_the_schemas():
     assert [t.shape for t in z] == [(8, 4), (8, 1)] and sc[0].shape == (4,) and eps[1].shape == (8, 1)
     assert torch.ops.pyro_amd.logsumexp_terms([m(3, 1, 4), m(1, 5, 4)], [3, 5, 4], 2).shape == (3, 5)
     assert torch.ops.pyro_amd.tall_linear_act(m(100, 16), m(24, 16), m(24), None, True, True).shape == (100, 24)
+    mx = torch.ops.pyro_amd.mixture_fwd_bwd(0, m(1000), m(4, 5), m(4, 5), m(1, 1))
+    assert mx.shape == (4, 16) and mx.dtype == torch.float64
     rs, tot = torch.ops.pyro_amd.dist_log_prob_sum(0, m(6, 9), m(9), m(1), None, 1.0)
     assert rs.shape == (6,) and tot.shape == ()

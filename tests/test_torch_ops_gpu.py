@@ -379,3 +379,30 @@ def test_torch_compile_over_the_typed_ops(gpu):
     want = f(u, a, b, un, pw)
     got = torch.compile(f, fullgraph=True, backend="aot_eager")(u, a, b, un, pw)
     torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
+def test_typed_mixture_fwd_bwd(gpu):
+    """pyro_amd::mixture_fwd_bwd(int dist, Tensor x, Tensor a, Tensor p0, Tensor? p1) -> Tensor: the leaf of a plated
+    mixture for B parameter sets, against its float64 torch statement (the [K, N] log-prob frame, logsumexp, plate
+    sum, autograd) -- the operators of the reference's route."""
+    ops = _ops()
+    g = torch.Generator(device=gpu).manual_seed(4)
+    B, K, N = 3, 5, 4001
+    x = torch.randn((N,), device=gpu, generator=g) * 2
+    a = torch.log_softmax(torch.randn((B, K), device=gpu, generator=g), -1)
+    p0 = torch.randn((B, K), device=gpu, generator=g)
+    p1 = torch.rand((1, K), device=gpu, generator=g) + 0.5
+    out = ops.mixture_fwd_bwd(0, x, a, p0, p1)
+    assert out.shape == (B, 1 + 3 * K) and out.dtype == torch.float64
+    ad, p0d = a.double().requires_grad_(True), p0.double().requires_grad_(True)
+    p1d = p1.double().expand(B, K).clone().requires_grad_(True)
+    lp = torch.distributions.Normal(p0d[:, :, None], p1d[:, :, None]).log_prob(x.double())
+    S = torch.logsumexp(ad[:, :, None] + lp, 1).sum(-1)
+    torch.testing.assert_close(out[:, 0], S.detach(), rtol=2e-5, atol=1e-3)
+    S.sum().backward()
+    for got, want in ((out[:, 1:1 + K], ad.grad), (out[:, 1 + K:1 + 2 * K], p0d.grad), (out[:, 1 + 2 * K:], p1d.grad)):
+        torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4 * float(want.abs().max()))
+    # ... and it composes under torch.compile(fullgraph=True)
+    f = torch.compile(lambda x, a, p0, p1: ops.mixture_fwd_bwd(0, x, a, p0, p1)[:, 0].sum(), fullgraph=True,
+                      backend="aot_eager")
+    torch.testing.assert_close(f(x, a, p0, p1), out[:, 0].sum())
