@@ -412,36 +412,56 @@ __global__ __launch_bounds__(64 * NW) void tall_wgrad_kernel(const float* __rest
   if (kg == 0) partial_db[gp * 32 + l31] = dbs;
 }
 
-// dW[r][k] = the sum over the waves that own r's tile: 8 outputs x 32 groups per workgroup, thread (j, g)
-// sums the parts g, g + 32, ... in fp64 and the 32 group sums are added in order (fixed order, whole
+// dW[r][k] = the sum over the waves that own r's tile: JW outputs x 256 / JW groups per workgroup, thread (j, g)
+// sums the parts g, g + NG, ... in fp64 and the NG group sums are added in order (fixed order, whole
 // chip); the outputs past R K are db
+template <int JW>
 __global__ __launch_bounds__(256) void tall_wgrad_reduce_kernel(const float* __restrict__ partial,
                                                                 const float* __restrict__ partial_db,
                                                                 int64_t nwaves, int nrt, int R, int K,
                                                                 float* __restrict__ dW,
                                                                 float* __restrict__ db) {
-  __shared__ double sm[32][8];
-  const int jj = threadIdx.x & 7, g = threadIdx.x >> 3;
-  const int idx = blockIdx.x * 8 + jj;
+  // 64 consecutive outputs per workgroup (a wave reads 256 contiguous bytes of every partial tile), four groups
+  // of partial tiles side by side, eight loads in flight per thread: until round 6 eight outputs x 32 groups with
+  // one load per iteration -- a chain of L2 round trips over 32-byte pieces (9-12 us for 16 MB of partial tiles)
+  // (JW = 16 for few outputs -- an 8 x 100 gradient is 13 workgroups of 64: 16 x 16 keeps the chip busier)
+  constexpr int NG = 256 / JW;
+  __shared__ double sm[NG][JW];
+  const int jj = threadIdx.x % JW, g = threadIdx.x / JW;
+  const int idx = blockIdx.x * JW + jj;
   const int nout = R * K + (db != nullptr ? R : 0);
   const int64_t nparts = nwaves / nrt;
   double acc = 0.0;
+  const float* src = nullptr;
+  int64_t stride = 0;
   if (idx < R * K) {
     const int r = idx / K, k = idx - r * K;
     const int rt = r >> 5, m = r & 31;
-    for (int64_t p = g; p < nparts; p += 32)
-      acc += (double)partial[(rt + nrt * p) * (32 * TALL_MAX) + m * TALL_MAX + k];
+    src = partial + (int64_t)rt * (32 * TALL_MAX) + m * TALL_MAX + k;
+    stride = (int64_t)nrt * (32 * TALL_MAX);
   } else if (idx < nout) {
     const int r = idx - R * K;
     const int rt = r >> 5, m = r & 31;
-    for (int64_t p = g; p < nparts; p += 32) acc += (double)partial_db[(rt + nrt * p) * 32 + m];
+    src = partial_db + (int64_t)rt * 32 + m;
+    stride = (int64_t)nrt * 32;
+  }
+  if (src != nullptr) {
+    int64_t p = g;
+    for (; p + 7 * NG < nparts; p += 8 * NG) {
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = src[(p + NG * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)q[u];
+    }
+    for (; p < nparts; p += NG) acc += (double)src[p * stride];
   }
   sm[g][jj] = acc;
   __syncthreads();
   if (g == 0 && idx < nout) {
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) t += sm[q][jj];
+    for (int q = 0; q < NG; ++q) t += sm[q][jj];
     if (idx < R * K) dW[idx] = (float)t;
     else db[idx - R * K] = (float)t;
   }
@@ -579,8 +599,12 @@ int pa_tall_wgrad_act(const float* G, const float* X, const float* y_mul, int64_
   PA_TALLW_CASE(4)
 #undef PA_TALLW_CASE
   const int64_t n = R * K + R;
-  hipLaunchKernelGGL(pa::tall_wgrad_reduce_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, s, part,
-                     part_db, nwaves, nrt, (int)R, (int)K, dW, db);
+  if (n >= 4096)
+    hipLaunchKernelGGL(pa::tall_wgrad_reduce_kernel<64>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part,
+                       part_db, nwaves, nrt, (int)R, (int)K, dW, db);
+  else
+    hipLaunchKernelGGL(pa::tall_wgrad_reduce_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part,
+                       part_db, nwaves, nrt, (int)R, (int)K, dW, db);
   return pa::check_launch("tall_wgrad");
 }
 

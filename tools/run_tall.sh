@@ -3,7 +3,7 @@
 #   PA_TALL_WAVES=4|16 pins the waves per workgroup of tall_linear_kernel (default: by size)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 timeout -s KILL 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k 'tall or bow or histogram or bag' 2>&1 | tail -6
-for NWV in 4 0; do
+for NWV in 0; do
 echo "PA_TALL_WAVES=$NWV"
 PA_TALL_WAVES=$NWV timeout -s KILL 120 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -8
 import sys; sys.path.insert(0, '.')
