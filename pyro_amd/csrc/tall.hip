@@ -574,7 +574,7 @@ int pa_tall_wgrad_act(const float* G, const float* X, const float* y_mul, int64_
   // eight waves per workgroup (two per SIMD) once every wave has k-steps for its three register sets
   const int64_t nks16 = (B + 15) / 16;
   const int tw = pa::tall_waves();
-  const int nw = tw == 4 ? 4 : tw == 16 ? 8 : (nks16 * nrt >= (int64_t)pa::cu_count() * 8 * 6 ? 8 : 4);
+  const int nw = tw == 4 ? 4 : tw == 16 ? 8 : (nks16 * nrt >= (int64_t)pa::cu_count() * 8 * 3 ? 8 : 4);
   const int grid = pa::tall_wgrad_grid(B, nw);
   const int64_t nwaves = (int64_t)grid * 4;            // partial tiles (the eight-wave form adds pairs in LDS)
   float* part = (float*)workspace;
