@@ -180,9 +180,11 @@ def test_gamma_function_family_classes(gpu, fam, dist_id, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("rows,K,shared", [(1000, 8, True), (1000, 8, False), (8, 1024, False),
-                                           (3, 70, True), (1, 2, False), (40000, 5, True)])
+                                           (3, 70, True), (1, 2, False), (40000, 5, True), (5, 300, True),
+                                           (2, 5000, False), (2000, 300, False)])
 def test_dirichlet_log_prob_and_grad(gpu, dtype, rows, K, shared):
-    """pa_dirichlet_log_prob / _grad (thread-per-row for K <= 32, wave-per-row above) against the
+    """pa_dirichlet_log_prob / _grad (thread-per-row for K <= 32, wave-per-row above, a 1024-thread workgroup
+    per row for few rows of K >= 256) against the
     oracle, with a concentration vector shared by all rows read through row stride 0."""
     k = _k()
     rng = np.random.default_rng(rows + K)
