@@ -1181,9 +1181,15 @@ class Fuser(TorchDispatchMode):
         adjacent."""
         if not x.is_contiguous() or list(dims) != list(range(dims[0], dims[-1] + 1)) or rsize > (1 << 26):
             raise Unfusable
-        c = max((q for q in range(1, 4097) if rsize % q == 0), default=1)
-        if c < 64 or rsize // c > MAX_REDUCE:
+        # C: a lane group walks its C elements 64 at a time, one group per partial sum.  The LARGEST divisor up to
+        # 4096 (until round 6) made a sum over 1e5 documents 25 groups of 4000 -- 25 waves on the whole chip, 62
+        # dependent iterations each: 17-20 us per launch in config 4's step, three times.  The smallest divisor
+        # from 256 up (1e5: 400 -> 250 groups of 7 iterations, then one group over the 250 partial sums).
+        divisors = [q for q in range(64, 4097) if rsize % q == 0 and rsize // q <= MAX_REDUCE]
+        if not divisors:
             raise Unfusable
+        wide = [q for q in divisors if q >= 256]
+        c = wide[0] if wide else divisors[-1]
         a = _numel(x.shape[:dims[0]])
         b = _numel(x.shape[dims[-1] + 1:])
         meta = self._meta(func, args, kwargs)
