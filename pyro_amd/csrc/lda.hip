@@ -254,7 +254,7 @@ static int lda_launch(const int64_t* words, const T* log_theta, const T* log_phi
 //            lda_vocab_kernel                 (word-major: lane = pair of the word's list, gathers
 //                                              the document's log_theta row, posterior, register
 //                                              accumulation, fixed-order reduction)
-//            lda_vocab_finalize_kernel        (sums a word's segments in order)
+//            lda_vocab_finalize_kernel        (sums a word's segments: a wave per word, fixed tree)
 // Everything is summed in a fixed order: g_phi is bitwise reproducible (the atomic path is not).
 //
 // Index image (int32 words; header first):
@@ -477,19 +477,34 @@ __global__ __launch_bounds__(256) void lda_vocab_kernel(const int* __restrict__ 
   }
 }
 
+// One WAVE per word: lane = (task slot, topic) with TP = Tn rounded up to a power of two topics and 64 / TP slots; a
+// slot adds every (64 / TP)-th segment of the word (the wave reads 64 consecutive values of `part` per step, four
+// steps in flight), the slots are added in a fixed tree.  (Until round 6 a thread per (topic, word) walked the
+// word's segments one by one: the most frequent word's ~200 dependent loads set the launch's 39 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void lda_vocab_finalize_kernel(const int* __restrict__ img,
                                                                  LdaIndexLayout L,
                                                                  const T* __restrict__ part,
-                                                                 int Tn, int V,
+                                                                 int Tn, int TP, int V,
                                                                  T* __restrict__ g_phi) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)Tn * V) return;
-  const int tt = (int)(i / V), v = (int)(i % V);
+  const int v = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (v >= V) return;
+  const int lane = threadIdx.x & 63;
+  const int tt = lane & (TP - 1), slot = lane / TP, nslots = 64 / TP;
   const int t0 = img[L.first_task + v], t1 = img[L.first_task + v + 1];
+  const bool tok = tt < Tn;
   double acc = 0.0;
-  for (int t = t0; t < t1; ++t) acc += (double)part[(int64_t)t * Tn + tt];
-  g_phi[i] = (T)acc;
+  int t = t0 + slot;
+  for (; t + 3 * nslots < t1; t += 4 * nslots) {
+    T q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = tok ? part[(int64_t)(t + u * nslots) * Tn + tt] : T(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += (double)q[u];
+  }
+  for (; t < t1; t += nslots) acc += tok ? (double)part[(int64_t)t * Tn + tt] : 0.0;
+  for (int o = TP; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+  if (slot == 0 && tok) g_phi[(int64_t)tt * V + v] = (T)acc;
 }
 
 // waves per workgroup of the document-major half (its LDS: one V x T table + the reduction area)
@@ -535,9 +550,10 @@ static int lda_indexed_launch_nw(const int64_t* words, const int* img, const Lda
   if (br) (void)hipEventRecord(ev1, s);
   rc = check_launch("lda_vocab_kernel");
   if (rc != PA_OK) return rc;
-  const int64_t n = (int64_t)Tn * V;
-  hipLaunchKernelGGL((lda_vocab_finalize_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256),
-                     0, s, img, L, part, Tn, V, g_phi);
+  int TP = 1;
+  while (TP < Tn) TP <<= 1;
+  hipLaunchKernelGGL((lda_vocab_finalize_kernel<T>), dim3((unsigned)((V + 3) / 4)), dim3(256),
+                     0, s, img, L, part, Tn, TP, V, g_phi);
   return check_launch("lda_vocab_finalize_kernel");
 }
 
