@@ -1063,6 +1063,23 @@ int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, int
                        const void* p1, int64_t p1_stride, int64_t p1_batch_stride, void* workspace,
                        size_t workspace_bytes, double* out, pa_stream_t stream);
 
+/* The same leaf for EVENT-SHAPED observations: a diagonal Normal over D <= 8 features
+ * (`Normal(locs[z], scale).to_event(1)` under the data plate: the multi-dimensional Gaussian mixture) --
+ *   S[b] = sum_n log sum_k exp(a[b][k] + sum_d log N(x[n][d] | loc[b][k][d], scale[b][k][d])),
+ * the sum over the features inside the logsumexp (pyro/distributions/torch.py Independent.log_prob ->
+ * torch/distributions/independent.py:96-98).  x [N, D] row-major; loc[b][k][d] = loc[b * loc_batch_stride +
+ * k * loc_stride_k + d * loc_stride_d], scale likewise (stride 0: shared).  The output is PADDED: with
+ * J = pa_mixture_diag_normal_layout(K, D, &KP, &DD) doubles per set, out[b * J + ...]: [0] = S, [1 + k] = dS/da_k,
+ * [1 + KP + k * DD + d] = dS/dloc_kd, [1 + KP + KP * DD + k * DD + d] = dS/dscale_kd (entries past K / D are zero).
+ * Workspace: pa_mixture_diag_normal_workspace(K, D, B) bytes.  Bit-reproducible. */
+int pa_mixture_diag_normal_layout(int K, int D, int* kp_out, int* dd_out);
+size_t pa_mixture_diag_normal_workspace(int K, int D, int64_t B);
+int pa_mixture_diag_normal_fwd_bwd(int dtype, const void* x, int64_t N, int D, int K, int64_t B, const void* a,
+                                   int64_t a_batch_stride, const void* loc, int64_t loc_stride_k,
+                                   int64_t loc_stride_d, int64_t loc_batch_stride, const void* scale,
+                                   int64_t scale_stride_k, int64_t scale_stride_d, int64_t scale_batch_stride,
+                                   void* workspace, size_t workspace_bytes, double* out_padded, pa_stream_t stream);
+
 /* ---- csrc/replay.hip: a captured step that is a short chain of kernels, launched as kernels ----------------
  * Replaces nothing of the reference's (its SVI.step, pyro/infer/svi.py:134-162, re-runs the model): it is the
  * replay path of this package's captured step, opt-in on the host side: measured on config 2 a step that waits for

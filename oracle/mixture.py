@@ -47,3 +47,27 @@ def mixture_fwd_bwd(dist_id, x, a, p0, p1=None):
         d0 = np.where(r > 0, r * g0, 0.0).sum(axis=0)
         d1 = np.where(r > 0, r * g1, 0.0).sum(axis=0)
     return S, da, d0, d1
+
+
+def mixture_diag_normal_fwd_bwd(x, a, loc, scale):
+    """The same leaf for event-shaped observations (Normal(loc[z], scale).to_event(1): Independent.log_prob sums the
+    features, torch/distributions/independent.py:96-98, INSIDE the logsumexp): x [N, D]; a [K]; loc, scale [K, D].
+    -> (S, dS/da [K], dS/dloc [K, D], dS/dscale [K, D])."""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    K = a.shape[0]
+    D = x.shape[1]
+    loc = np.broadcast_to(np.asarray(loc, dtype=np.float64), (K, D))
+    scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), (K, D))
+    z = (x[:, None, :] - loc[None]) / scale[None]                                     # [N, K, D]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = a[None, :] + (-0.5 * z * z - np.log(scale)[None] - 0.5 * np.log(2 * np.pi)).sum(-1)
+        m = t.max(axis=1, keepdims=True)
+        dead = ~np.isfinite(m[:, 0])
+        e = np.where(dead[:, None], 0.0, np.exp(t - np.where(dead[:, None], 0.0, m)))
+        ssum = e.sum(axis=1, keepdims=True)
+        lse = np.where(dead, -np.inf, m[:, 0] + np.log(np.where(dead[:, None], 1.0, ssum))[:, 0])
+        r = np.where(dead[:, None], 0.0, e / np.where(dead[:, None], 1.0, ssum))       # [N, K]
+    dl = (r[:, :, None] * z / scale[None]).sum(0)
+    dc = (r[:, :, None] * (z * z - 1.0) / scale[None]).sum(0)
+    return lse.sum(), r.sum(0), dl, dc

@@ -225,6 +225,11 @@ _SIGNATURES = {
     "pa_mixture_fwd_bwd": (c_int, [c_int, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_void_p,
                                    c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p,
                                    c_void_p]),
+    "pa_mixture_diag_normal_layout": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "pa_mixture_diag_normal_workspace": (c_size_t, [c_int, c_int, c_int64]),
+    "pa_mixture_diag_normal_fwd_bwd": (c_int, [c_int, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_int64,
+                                               c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                               c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pa_graph_direct_plan": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int)]),
     "pa_graph_direct_launch": (c_int, [c_void_p, c_void_p]),
     "pa_graph_direct_free": (c_int, [c_void_p]),

@@ -174,6 +174,170 @@ __global__ __launch_bounds__(1024) void mixture_finalize_kernel(const double* __
   }
 }
 
+// ---- event-shaped observations: a diagonal Normal over D features (Normal(loc[z], scale).to_event(1)) -------------
+//   S[b] = sum_n log sum_k exp(a[b][k] + sum_d log N(x[n][d] | loc[b][k][d], scale[b][k][d]))
+// The sum over d sits INSIDE the logsumexp, so the features of a row stay with the lane that holds (row, k): DD = D
+// rounded up to 2 / 4 / 8 loc and 1 / scale values and the same number of gradient sums per lane.  Every WAVE writes
+// its own partial (no LDS stage: 2 + 2 DD doubles per lane would be 70 KB); the second launch adds them in order.
+// Partial / padded output layout per set: [0] = S, [1 + k] = dS/da_k, [1 + KP + k * DD + d] = dS/dloc_kd,
+// [1 + KP + KP * DD + k * DD + d] = dS/dscale_kd.
+template <typename T, int KP, int DD>
+__global__ __launch_bounds__(MIX_THREADS) void mixture_diag_kernel(const T* __restrict__ x, int64_t N, int D, int K,
+                                                                   const T* __restrict__ a, int64_t a_bs,
+                                                                   const T* __restrict__ loc, int64_t l_sk,
+                                                                   int64_t l_sd, int64_t l_bs,
+                                                                   const T* __restrict__ scl, int64_t s_sk,
+                                                                   int64_t s_sd, int64_t s_bs,
+                                                                   double* __restrict__ partial) {
+  a += (int64_t)blockIdx.y * a_bs;
+  loc += (int64_t)blockIdx.y * l_bs;
+  scl += (int64_t)blockIdx.y * s_bs;
+  constexpr int RPW = 64 / KP;
+  constexpr int JP = 1 + KP + 2 * KP * DD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane & (KP - 1), slot = lane / KP;
+  const bool kok = k < K;
+  const T ninf = -t_inf<T>();
+  T mu[DD], inv[DD];
+  T ck = kok ? a[k] : ninf;                         // a_k - sum_d log scale_d - D / 2 log 2 pi
+#pragma unroll
+  for (int d = 0; d < DD; ++d) {
+    const bool dok = d < D;
+    mu[d] = loc[(kok ? (int64_t)k * l_sk : 0) + (dok ? (int64_t)d * l_sd : 0)];
+    const T sg = scl[(kok ? (int64_t)k * s_sk : 0) + (dok ? (int64_t)d * s_sd : 0)];
+    inv[d] = dok ? pos_rcp(sg) : T(0);
+    if (dok && kok) ck -= pos_log(sg) + Consts<T>::half_log_2pi;
+  }
+  T acc_s = T(0), acc_a = T(0), acc_l[DD], acc_c[DD];
+#pragma unroll
+  for (int d = 0; d < DD; ++d) acc_l[d] = acc_c[d] = T(0);
+  const int64_t nwaves = (int64_t)gridDim.x * (MIX_THREADS / 64);
+  const int64_t step = nwaves * RPW;
+  for (int64_t base = ((int64_t)blockIdx.x * (MIX_THREADS / 64) + wave) * RPW; base < N; base += step) {
+    const int64_t row = base + slot;
+    const bool valid = row < N;
+    const T* xr = x + (valid ? row : N - 1) * D;
+    T z[DD];
+    T q = T(0);
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+      const T xv = xr[d < D ? d : 0];
+      z[d] = (xv - mu[d]) * inv[d];                 // (inv = 0 past D)
+      q += z[d] * z[d];
+    }
+    const T t = kok ? ck - T(0.5) * q : ninf;
+    const T m = mix_allreduce<KP>(t, [](T p, T r_) { return mix_max(p, r_); });
+    const bool dead = !(m > ninf);
+    const T e = (dead || !kok) ? T(0) : t_exp(t - m);
+    const T ssum = mix_allreduce<KP>(e, [](T p, T r_) { return p + r_; });
+    const T lse = dead ? ninf : m + pos_log(dead ? T(1) : ssum);
+    const T r = (dead || !valid) ? T(0) : e * pos_rcp(dead ? T(1) : ssum);
+    acc_s += (valid && k == 0) ? lse : T(0);
+    acc_a += r;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+      const T w = r * inv[d];
+      acc_l[d] += w * z[d];                         // r (x - loc) / scale^2
+      acc_c[d] += w * (z[d] * z[d] - T(1));         // r ((x - loc)^2 / scale^2 - 1) / scale
+    }
+  }
+  const int64_t gw = (int64_t)blockIdx.x * (MIX_THREADS / 64) + wave;
+  double* out = partial + ((int64_t)blockIdx.y * nwaves + gw) * JP;
+  auto over_slots = [&](T v) {
+    double dv = (double)v;
+#pragma unroll
+    for (int o = KP; o < 64; o <<= 1) dv += __shfl_xor(dv, o, 64);
+    return dv;
+  };
+  const double ds = over_slots(acc_s), da = over_slots(acc_a);
+  if (lane == 0) out[0] = ds;
+  if (lane < KP) out[1 + lane] = da;
+#pragma unroll
+  for (int d = 0; d < DD; ++d) {
+    const double dl = over_slots(acc_l[d]), dc = over_slots(acc_c[d]);
+    if (lane < KP) {
+      out[1 + KP + lane * DD + d] = dl;
+      out[1 + KP + KP * DD + lane * DD + d] = dc;
+    }
+  }
+}
+
+// out[b][j] = the waves' partials added in index order (16 segments per output in parallel, eight loads in flight)
+__global__ __launch_bounds__(1024) void mixture_sum_partials_kernel(const double* __restrict__ partial, int nparts,
+                                                                    int J, double* __restrict__ out) {
+  __shared__ double seg[16][64];
+  const int jj = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jj;
+  partial += (int64_t)blockIdx.y * nparts * J;
+  out += (int64_t)blockIdx.y * J;
+  double v = 0.0;
+  if (j < J) {
+    const int per = (nparts + 15) / 16;
+    const int b0 = sg * per, b1 = b0 + per < nparts ? b0 + per : nparts;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = partial[(int64_t)(b + u) * J + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += q[u];
+    }
+    for (; b < b1; ++b) v += partial[(int64_t)b * J + j];
+  }
+  seg[sg][jj] = v;
+  __syncthreads();
+  if (sg == 0 && j < J) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += seg[q][jj];
+    out[j] = t;
+  }
+}
+
+static int mixture_diag_blocks(int64_t N, int KP, int64_t B) {
+  const int64_t rows_per_block = (int64_t)(MIX_THREADS / 64) * (64 / KP);
+  int64_t g = (N + rows_per_block * 8 - 1) / (rows_per_block * 8);
+  int64_t cap = ((int64_t)cu_count() * 2 + B - 1) / B;      // (every wave writes a partial: fewer, longer waves)
+  if (cap < 1) cap = 1;
+  if (g > cap) g = cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <typename T, int KP>
+static int mixture_diag_launch(const T* x, int64_t N, int D, int K, int64_t B, const T* a, int64_t a_bs,
+                               const T* loc, int64_t l_sk, int64_t l_sd, int64_t l_bs, const T* scl, int64_t s_sk,
+                               int64_t s_sd, int64_t s_bs, double* partial, double* out, hipStream_t s) {
+  const int DD = D <= 2 ? 2 : D <= 4 ? 4 : 8;
+  const int grid = mixture_diag_blocks(N, KP, B);
+  const int nparts = grid * (MIX_THREADS / 64);
+  const int JP = 1 + KP + 2 * KP * DD;
+#define PA_MIXD_CASE(DD_)                                                                              \
+  if (DD == DD_)                                                                                       \
+    hipLaunchKernelGGL((mixture_diag_kernel<T, KP, DD_>), dim3((unsigned)grid, (unsigned)B),           \
+                       dim3(MIX_THREADS), 0, s, x, N, D, K, a, a_bs, loc, l_sk, l_sd, l_bs, scl, s_sk, \
+                       s_sd, s_bs, partial);
+  PA_MIXD_CASE(2) PA_MIXD_CASE(4) PA_MIXD_CASE(8)
+#undef PA_MIXD_CASE
+  hipLaunchKernelGGL(mixture_sum_partials_kernel, dim3((unsigned)((JP + 63) / 64), (unsigned)B), dim3(1024), 0, s,
+                     partial, nparts, JP, out);
+  return check_launch("mixture_diag_kernel");
+}
+
+template <typename T>
+static int mixture_diag_t(const T* x, int64_t N, int D, int K, int64_t B, const T* a, int64_t a_bs, const T* loc,
+                          int64_t l_sk, int64_t l_sd, int64_t l_bs, const T* scl, int64_t s_sk, int64_t s_sd,
+                          int64_t s_bs, double* partial, double* out, hipStream_t s) {
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+#define PA_MIXD_K(KP_)                                                                                 \
+  if (KP == KP_)                                                                                       \
+    return mixture_diag_launch<T, KP_>(x, N, D, K, B, a, a_bs, loc, l_sk, l_sd, l_bs, scl, s_sk, s_sd, s_bs,     \
+                                       partial, out, s);
+  PA_MIXD_K(1) PA_MIXD_K(2) PA_MIXD_K(4) PA_MIXD_K(8) PA_MIXD_K(16) PA_MIXD_K(32) PA_MIXD_K(64)
+#undef PA_MIXD_K
+  return fail(PA_ERR_UNSUPPORTED, "mixture_diag_normal_fwd_bwd: K=%d", K);
+}
+
 static int mixture_grid(int64_t N, int KP, int64_t B) {
   const int64_t rows_per_block = (int64_t)(MIX_THREADS / 64) * (64 / KP);
   int64_t g = (N + rows_per_block * 8 - 1) / (rows_per_block * 8);       // >= 8 iterations per wave
@@ -231,6 +395,49 @@ size_t pa_mixture_workspace(int K, int64_t B) {
   while (KP < K) KP <<= 1;
   // (at most cu_count * 4 + B workgroups over all parameter sets)
   return ((size_t)pa::cu_count() * 4 + (size_t)B) * (1 + 3 * KP) * sizeof(double);
+}
+
+static int mixture_diag_padded(int K, int D, int* kp, int* dd) {
+  int KP = 1;
+  while (KP < K) KP <<= 1;
+  const int DD = D <= 2 ? 2 : D <= 4 ? 4 : 8;
+  if (kp) *kp = KP;
+  if (dd) *dd = DD;
+  return 1 + KP + 2 * KP * DD;
+}
+
+int pa_mixture_diag_normal_layout(int K, int D, int* kp_out, int* dd_out) {
+  if (K < 1 || K > pa::MIX_MAXK || D < 1 || D > 8) return 0;
+  return mixture_diag_padded(K, D, kp_out, dd_out);
+}
+
+size_t pa_mixture_diag_normal_workspace(int K, int D, int64_t B) {
+  if (K < 1 || K > pa::MIX_MAXK || D < 1 || D > 8 || B < 1) return 0;
+  const int JP = mixture_diag_padded(K, D, nullptr, nullptr);
+  return ((size_t)pa::cu_count() * 2 + (size_t)B) * (pa::MIX_THREADS / 64) * (size_t)JP * sizeof(double);
+}
+
+int pa_mixture_diag_normal_fwd_bwd(int dtype, const void* x, int64_t N, int D, int K, int64_t B, const void* a,
+                                   int64_t a_batch_stride, const void* loc, int64_t loc_stride_k,
+                                   int64_t loc_stride_d, int64_t loc_batch_stride, const void* scale,
+                                   int64_t scale_stride_k, int64_t scale_stride_d, int64_t scale_batch_stride,
+                                   void* workspace, size_t workspace_bytes, double* out_padded, pa_stream_t stream) {
+  PA_REQUIRE(K >= 1 && K <= pa::MIX_MAXK && D >= 1 && D <= 8, "mixture_diag_normal_fwd_bwd: K=%d (<= %d), D=%d (<= 8)",
+             K, pa::MIX_MAXK, D);
+  PA_REQUIRE(B >= 1 && B <= 65535, "mixture_diag_normal_fwd_bwd: B=%lld outside [1, 65535]", (long long)B);
+  PA_REQUIRE(N >= 1 && x && a && loc && scale && out_padded && workspace, "mixture_diag_normal_fwd_bwd: NULL pointer or N < 1");
+  PA_REQUIRE(workspace_bytes >= pa_mixture_diag_normal_workspace(K, D, B), "mixture_diag_normal_fwd_bwd: workspace too small");
+  hipStream_t s = pa::as_stream(stream);
+  if (dtype == PA_F32)
+    return pa::mixture_diag_t<float>((const float*)x, N, D, K, B, (const float*)a, a_batch_stride, (const float*)loc,
+                                     loc_stride_k, loc_stride_d, loc_batch_stride, (const float*)scale, scale_stride_k,
+                                     scale_stride_d, scale_batch_stride, (double*)workspace, out_padded, s);
+  if (dtype == PA_F64)
+    return pa::mixture_diag_t<double>((const double*)x, N, D, K, B, (const double*)a, a_batch_stride,
+                                      (const double*)loc, loc_stride_k, loc_stride_d, loc_batch_stride,
+                                      (const double*)scale, scale_stride_k, scale_stride_d, scale_batch_stride,
+                                      (double*)workspace, out_padded, s);
+  return pa::fail(PA_ERR_UNSUPPORTED, "mixture_diag_normal_fwd_bwd: dtype %d", dtype);
 }
 
 int pa_mixture_fwd_bwd(int dtype, int dist, const void* x, int64_t N, int K, int64_t B, const void* a,

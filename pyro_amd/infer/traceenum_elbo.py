@@ -126,16 +126,19 @@ def _lazy_family(site, first_enum_dim):
     fn, value = site["fn"], site["value"]
     if not contract.FUSED_MIXTURE or not site["is_observed"] or not (site["mask"] is None or site["mask"] is True):
         return None
-    if not isinstance(value, torch.Tensor) or value.dim() != 1 or value.requires_grad \
+    ev = tuple(getattr(fn, "event_shape", ()))
+    if not isinstance(value, torch.Tensor) or value.dim() != 1 + len(ev) or value.requires_grad \
             or value.dtype not in (torch.float32, torch.float64) or not kernels.on_device(value):
         return None
+    if len(ev) > 1 or (len(ev) == 1 and (ev[0] > kernels.MIXTURE_MAX_D or value.shape[1] != ev[0])):
+        return None
+    D = ev[0] if ev else None                 # a diagonal family over D features (to_event(1)) or scalar data
     plate_dims = sorted(f.dim for f in site["cond_indep_stack"] if f.vectorized)
     if not plate_dims or plate_dims[-1] != -1 or len(plate_dims) > 2:
         return None
     entry = getattr(fn, "fused_site_entry", None)
     bs = tuple(getattr(fn, "batch_shape", ()))
-    if entry is None or tuple(getattr(fn, "event_shape", ())) != () or len(bs) < 2 \
-            or bs[-1] not in (1, value.shape[0]):
+    if entry is None or len(bs) < 2 or bs[-1] not in (1, value.shape[0]):
         return None
     nb = len(bs)
     batch_dim = plate_dims[0] if len(plate_dims) == 2 else None
@@ -154,6 +157,8 @@ def _lazy_family(site, first_enum_dim):
     ent = entry(value, 1.0, None)
     if ent is None or ent[0] not in kernels.MIXTURE_FAMILIES or K > kernels.MIXTURE_MAX_K:
         return None
+    if D is not None and ent[0] != kernels._lib.DIST_NORMAL:
+        return None                           # (the event-shaped leaf scores the diagonal Normal only)
     params = []
     for p in (ent[2], ent[3]):
         if p is None:
@@ -161,9 +166,15 @@ def _lazy_family(site, first_enum_dim):
             continue
         if not isinstance(p, torch.Tensor) or p.dtype != value.dtype or not kernels.on_device(p):
             return None
-        if p.dim() > nb:
+        ne = 0 if D is None else 1            # trailing event dims of the parameter
+        if p.dim() > nb + ne:
             return None
-        shp = (1,) * (nb - p.dim()) + tuple(p.shape)
+        shp = (1,) * (nb + ne - p.dim()) + tuple(p.shape)
+        Dp = 1
+        if ne:
+            Dp, shp = shp[-1], shp[:-1]
+            if Dp not in (1, D):
+                return None
         for i, s_ in enumerate(shp):
             d = i - nb
             ok = s_ == 1 or (d == edim and s_ == K) or (batch_dim is not None and d == batch_dim and s_ == B)
@@ -171,7 +182,8 @@ def _lazy_family(site, first_enum_dim):
                 return None                   # a parameter that varies along the data plate: the generic path
         Kp = shp[nz[0]]
         Bp = 1 if batch_dim is None else shp[batch_dim]
-        params.append(p.reshape(Kp, Bp))      # (the enumeration dim lies left of the plate dim)
+        # (the enumeration dim lies left of the plate dim, the event dim right of both)
+        params.append(p.reshape(Kp, Bp) if D is None else p.reshape(Kp, Bp, Dp))
     if params[0] is None:
         return None
 
@@ -179,8 +191,10 @@ def _lazy_family(site, first_enum_dim):
         lp = fn.log_prob(value, *site["args"], **site["kwargs"])
         return _packed(site, lp, first_enum_dim).tensor
 
+    if D is not None and params[1] is None:
+        return None
     return site["infer"]["_dim_to_id"][edim], contract.LazyFamily(ent[0], value, K, params[0], params[1], packed,
-                                                                  batch_dim, B)
+                                                                  batch_dim, B, D)
 
 
 class TraceEnum_ELBO(ELBO):

@@ -1975,6 +1975,45 @@ def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1, p0_bs=0, p1_bs=0):
     return out
 
 
+MIXTURE_MAX_D = 8
+
+
+def mixture_diag_normal_fwd_bwd(x, a, loc, scale):
+    """The mixture leaf for a diagonal Normal over D <= 8 features (pa_mixture_diag_normal_fwd_bwd): x [N, D];
+    a [B, K]; loc, scale [B | 1, K | 1, D | 1] (contiguous).  -> (S [B], dS/da [B, K], dS/dloc [B, K, D],
+    dS/dscale [B, K, D]) in float64 on the device, per (b, k, d): a shared parameter takes the sum."""
+    _require_gpu(x, a, loc, scale)
+    N, D = x.shape
+    B, K = a.shape
+    assert x.is_contiguous() and a.is_contiguous() and loc.is_contiguous() and scale.is_contiguous()
+    assert loc.dim() == 3 and scale.dim() == 3 and a.dtype == x.dtype == loc.dtype == scale.dtype
+    lib = _lib.load()
+    kp, dd = ctypes.c_int(), ctypes.c_int()
+    J = lib.pa_mixture_diag_normal_layout(K, D, ctypes.byref(kp), ctypes.byref(dd))
+    nbytes = lib.pa_mixture_diag_normal_workspace(K, D, B)
+    if J == 0 or nbytes == 0:
+        raise Unsupported("pyro_amd: mixture_diag_normal_fwd_bwd needs K <= %d, D <= %d (K=%d, D=%d)" % (
+            MIXTURE_MAX_K, MIXTURE_MAX_D, K, D))
+    KP, DD = kp.value, dd.value
+
+    def strides(p):
+        Bp, Kp, Dp = p.shape
+        assert Bp in (1, B) and Kp in (1, K) and Dp in (1, D), (tuple(p.shape), (B, K, D))
+        return (Dp if Kp > 1 else 0), (1 if Dp > 1 else 0), (Kp * Dp if Bp > 1 else 0)
+
+    lk, ld, lb = strides(loc)
+    sk, sd, sb = strides(scale)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    out = torch.empty((B, J), dtype=torch.float64, device=x.device)
+    check(lib.pa_mixture_diag_normal_fwd_bwd(_dtype(x), _ptr(x), N, D, K, B, _ptr(a), K, _ptr(loc), lk, ld, lb,
+                                             _ptr(scale), sk, sd, sb, _ptr(ws), ws.numel(), _ptr(out), _stream()))
+    S = out[:, 0]
+    da = out[:, 1:1 + K]
+    dl = out[:, 1 + KP:1 + KP + KP * DD].reshape(B, KP, DD)[:, :K, :D]
+    dc = out[:, 1 + KP + KP * DD:].reshape(B, KP, DD)[:, :K, :D]
+    return S, da, dl, dc
+
+
 def lda_factor_fwd_bwd(words, log_theta, log_phi, index=None):
     """words int64 [Wd,B]; log_theta [B,T]; log_phi [T,V] -> (out_doc[B], g_theta[B,T], g_phi[T,V]).
     ``index``: an image from lda_build_index (default: the cached one of ``words``, if any)."""

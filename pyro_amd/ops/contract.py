@@ -106,9 +106,12 @@ class LazyFamily:
     ``packed``: a callable that makes the packed tensor the generic elimination needs when the pattern does not
     match."""
 
-    def __init__(self, dist_id, value, K, p0, p1, packed, batch_dim=None, B=1):
+    def __init__(self, dist_id, value, K, p0, p1, packed, batch_dim=None, B=1, D=None):
         self.dist_id, self.value, self.K, self.p0, self.p1, self._packed = dist_id, value, K, p0, p1, packed
         self.batch_dim, self.B = batch_dim, B
+        # D: the event size of a diagonal Normal over features (value [N, D], p0 / p1 [K | 1, B | 1, D | 1]); None:
+        # scalar observations (p0 / p1 [K | 1, B | 1])
+        self.D = D
 
     def materialize(self):
         return self._packed()
@@ -147,6 +150,34 @@ class _MixtureFactor(torch.autograd.Function):
 
         return (None, None, None, None, None, None, g * da, param_grad(d0, s0, bs0),
                 param_grad(d1, s1, bs1) if ctx.needs_input_grad[8] else None)
+
+
+@_dispatcher_op("mixture_diag_factor")
+class _MixtureDiagFactor(torch.autograd.Function):
+    """The mixture leaf for a diagonal Normal over D features (pa_mixture_diag_normal_fwd_bwd): a [B, K];
+    loc / scale [B | 1, K | 1, D | 1]."""
+
+    @staticmethod
+    def forward(ctx, x, a, loc, scale):
+        S, da, dl, dc = kernels.mixture_diag_normal_fwd_bwd(x, a, loc, scale)
+        dt = a.dtype
+        ctx.shapes = (tuple(loc.shape), tuple(scale.shape))
+        ctx.save_for_backward(da.to(dt), dl.to(dt), dc.to(dt))
+        return S.to(dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        da, dl, dc = ctx.saved_tensors
+        g1, g2 = g.reshape(-1, 1), g.reshape(-1, 1, 1)
+
+        def to_shape(d, shape):
+            d = g2 * d                                  # [B, K, D]
+            for ax in range(3):
+                if shape[ax] == 1 and d.shape[ax] != 1:
+                    d = d.sum(ax, keepdim=True)
+            return d
+
+        return None, g1 * da, to_shape(dl, ctx.shapes[0]), to_shape(dc, ctx.shapes[1])
 
 
 def _try_fused_mixture(terms, sum_ids, contract_frames):
@@ -199,11 +230,17 @@ def _try_fused_mixture(terms, sum_ids, contract_frames):
         q = p.t().contiguous().reshape(-1)             # [Bp, Kp] row-major
         return q, (1 if Kp == K and K > 1 else 0), (Kp if Bp == B and B > 1 else 0)
 
-    p0, s0, bs0 = flat(lz.p0)
-    p1, s1, bs1 = flat(lz.p1)
-    if p0 is False or p1 is False or p0 is None:
-        return None
-    S = _MixtureFactor.invoke(int(lz.dist_id), s0, s1, bs0, bs1, x.contiguous(), a, p0, p1)       # [B]
+    if lz.D is not None:                               # a diagonal Normal over features: value [N, D]
+        if lz.p1 is None:
+            return None
+        S = _MixtureDiagFactor.invoke(x.contiguous(), a, lz.p0.transpose(0, 1).contiguous(),
+                                      lz.p1.transpose(0, 1).contiguous())                          # [B]
+    else:
+        p0, s0, bs0 = flat(lz.p0)
+        p1, s1, bs1 = flat(lz.p1)
+        if p0 is False or p1 is False or p0 is None:
+            return None
+        S = _MixtureFactor.invoke(int(lz.dist_id), s0, s1, bs0, bs1, x.contiguous(), a, p0, p1)   # [B]
     if lz.batch_dim is None or lz.batch_dim in frames:
         return S.sum()                                 # every plate contracted here
     if nplates is None:

@@ -478,6 +478,18 @@ def mixture_fwd_bwd(dist_id, x, a, p0, s0, p1, s1, p0_bs=0, p1_bs=0):
     return torch.as_tensor(np.stack(rows) if an.ndim == 2 else rows[0], dtype=torch.float64)
 
 
+def mixture_diag_normal_fwd_bwd(x, a, loc, scale):
+    from oracle import mixture as o_mix
+    an = _np(a)
+    B, K = an.shape
+    D = x.shape[1]
+    ln = np.broadcast_to(_np(loc), (B, K, D))
+    sn = np.broadcast_to(_np(scale), (B, K, D))
+    rows = [o_mix.mixture_diag_normal_fwd_bwd(_np(x), an[b], ln[b], sn[b]) for b in range(B)]
+    f = lambda i: torch.as_tensor(np.stack([np.asarray(r[i]) for r in rows]), dtype=torch.float64)  # noqa: E731
+    return f(0), f(1), f(2), f(3)
+
+
 def logsumexp_terms(terms, frame, rdim):
     from oracle import logsumexp as o_lse
     out, _ = o_lse.logsumexp_terms([_np(t) for t in terms], tuple(frame), rdim)
@@ -668,7 +680,8 @@ FUNCTIONS = ["bow_images_of", "bow_linear_fwd", "bow_linear_bwd", "tall_linear",
              "glm_bernoulli_grouped_fwd_bwd", "grouped_rows_of", "glm_grouped_rows_servable", "multi_log_prob_sum", "multi_log_prob_grad", "multi_log_prob_sum_grad",
              "meanfield_normal_sample", "meanfield_normal_sample_bwd", "glm_chain", "chain_matvec", "mvn_tril_sample",
              "mvn_tril_sample_bwd", "logchain_fwd_bwd", "dist_log_prob_sum_nd", "dist_log_prob_grad_nd", "sum_to_nd",
-             "logsumexp_terms", "logsumexp_terms_grad", "gamma_rsample", "mixture_fwd_bwd"]
+             "logsumexp_terms", "logsumexp_terms_grad", "gamma_rsample", "mixture_fwd_bwd",
+             "mixture_diag_normal_fwd_bwd"]
 
 
 def install(monkeypatch):
