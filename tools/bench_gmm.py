@@ -65,3 +65,43 @@ for _ in range(20):
     kernels.mixture_fwd_bwd(_lib.DIST_NORMAL, data, a, p0, 1, p1, 0)
 e.record(); torch.cuda.synchronize()
 print("pa_mixture_fwd_bwd alone (kernel + finalize + workspace): %.1f us for N=%d K=%d" % (s.elapsed_time(e) * 50, N, K))
+
+# ---- the multi-dimensional mixture: Normal(loc[z], 1).to_event(1) over D features ------------------------------
+D = 4
+datad = (torch.randn(N, D, generator=g) + 3 * torch.randn(K, D, generator=g)[torch.randint(0, K, (N,), generator=g)]).to(dev)
+
+
+@config_enumerate
+def modeld(data):
+    w = pyro.sample("w", dist.Dirichlet(torch.ones(K, device=dev)))
+    with pyro.plate("k", K):
+        loc = pyro.sample("loc", dist.Normal(torch.zeros(D, device=dev), 20.0).to_event(1))
+    with pyro.plate("n", N):
+        z = pyro.sample("z", dist.Categorical(w))
+        pyro.sample("x", dist.Normal(loc[z], 1.0).to_event(1), obs=data)
+
+
+lq0 = (3.0 * torch.randn(K, D, generator=g)).to(dev)
+
+
+def guided(data):
+    wq = pyro.param("wq", torch.ones(K, device=dev), constraint=constraints.positive)
+    lq = pyro.param("lqd", lq0)
+    pyro.sample("w", dist.Dirichlet(wq))
+    with pyro.plate("k", K):
+        pyro.sample("loc", dist.Normal(lq, 0.5).to_event(1))
+
+
+for leaf in (True, False):
+    contract.FUSED_MIXTURE = leaf
+    pyro.clear_param_store(); pyro.set_rng_seed(0); pyro.enable_validation(False)
+    svi = SVI(modeld, guided, pyro.optim.Adam({"lr": 0.01}), TraceEnum_ELBO(max_plate_nesting=1), hip_graph=True,
+              graph_warmup=3)
+    losses = [svi.step(datad) for _ in range(8)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(30):
+        svi.step(datad)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
+    print("D=%d mixture_leaf" % D, leaf, "graph True ms/step %.3f" % (dt * 1e3), "loss %.1f" % losses[-1], flush=True)
+    svi.release()
+contract.FUSED_MIXTURE = True
