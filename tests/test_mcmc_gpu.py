@@ -593,3 +593,49 @@ def test_direct_potential_against_the_references_potential_fn(gpu, tag):
     np.testing.assert_allclose(pe_g.detach().cpu().numpy(), want_pe, rtol=1e-4)
     np.testing.assert_allclose(grad_g.detach().cpu().numpy() / scale, want_g / scale, rtol=0, atol=1e-4)
     k.cleanup()
+
+
+def test_enumerated_multidimensional_mixture_potential_through_the_leaf_kernel(gpu, monkeypatch):
+    """The potential HMC / NUTS differentiate for a 3-dimensional Gaussian mixture with the assignments enumerated
+    (`Normal(means[a], 1).to_event(1)`), five vectorised chains: ONE launch of pa_mixture_diag_normal_fwd_bwd with
+    the chains as its batch of parameter sets; potential and gradient equal the generic contraction's (float64)."""
+    import pyro_amd as pyro
+    import pyro_amd.distributions as dist
+    import pyro_amd.ops.contract as c
+    from pyro_amd import kernels
+    from pyro_amd.infer.mcmc import initialize_model
+    from pyro_amd.ops.indexing import Vindex
+
+    dtype = torch.float64
+    K, N, D, C = 3, 500, 3, 5
+    g = torch.Generator().manual_seed(4)
+    data = (torch.randn(N, D, generator=g, dtype=dtype) + 3.0 * torch.randint(0, K, (N, 1), generator=g)).to(gpu)
+
+    def model(data):
+        phi = pyro.sample("phi", dist.Dirichlet(torch.ones(K, dtype=dtype, device=gpu)))
+        with pyro.plate("num_clusters", K):
+            means = pyro.sample("means", dist.Normal(torch.zeros(D, dtype=dtype, device=gpu), 5.0).to_event(1))
+        with pyro.plate("data", N):
+            a = pyro.sample("assignments", dist.Categorical(phi))
+            pyro.sample("obs", dist.Normal(Vindex(means.unsqueeze(-3))[..., a, :], 1.0).to_event(1), obs=data)
+
+    calls = []
+    real = kernels.mixture_diag_normal_fwd_bwd
+    monkeypatch.setattr(kernels, "mixture_diag_normal_fwd_bwd", lambda *a: calls.append(tuple(a[1].shape)) or real(*a))
+
+    def run(fused):
+        monkeypatch.setattr(c, "FUSED_MIXTURE", fused)
+        pyro.set_rng_seed(0)
+        init, pot, _, _ = initialize_model(model, (data,), max_plate_nesting=1, num_chains=C)
+        z = {n: v.detach().clone().requires_grad_(True) for n, v in sorted(init.items())}
+        pe = pot(z)
+        return pe.detach(), [t.detach() for t in torch.autograd.grad(pe.sum(), list(z.values()))]
+
+    pa_, ga = run(True)
+    assert (C, K) in calls, calls
+    n_calls = len(calls)
+    pb, gb = run(False)
+    assert len(calls) == n_calls
+    torch.testing.assert_close(pa_, pb, rtol=1e-11, atol=0)
+    for x, y in zip(ga, gb):
+        torch.testing.assert_close(x, y, rtol=1e-9, atol=1e-9 * float(y.abs().max()))
